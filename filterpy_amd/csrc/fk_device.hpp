@@ -1,0 +1,153 @@
+// fk_device.hpp -- record addressing, padded register loads/stores and host-side
+// launch helpers shared by the gfx950 kernels of libfilterhip.
+//
+// Record addressing (see include/filterhip.h):
+//   AOS  a[i][e]   element e of track i at  i*E + e     (NumPy C order)
+//   SOA  a[e][i]   element e of track i at  e*N + i     (lane-coalesced)
+// A kernel instantiated for <NX,NZ> also serves any runtime n <= NX, m <= NZ by
+// padding in registers (P,F with identity, Q,H with zeros, R with identity,
+// vectors with zeros): the padded block never couples to the real block and
+// every extra FMA term is an exact zero, so results are bit-identical to the
+// unpadded arithmetic.  EXACT instantiations (n == NX, m == NZ) drop the guards.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "fk_math.hpp"
+
+namespace fk {
+
+constexpr int LAYOUT_AOS = 0;
+constexpr int LAYOUT_SOA = 1;
+constexpr int BLOCK = 256;   // 4 wavefronts of 64 tracks
+
+// Position of a lane inside the record arrays.  All record traffic goes through
+// raw buffer loads/stores: per (array, time step) ONE wave-uniform 128-bit descriptor
+// (SGPRs; base = record block advanced to the workgroup) plus ONE 32-bit per-lane byte
+// offset; the element index goes into the instruction's immediate offset (AOS) or the
+// scalar soffset e*N*8 (SOA).  (Written as 64-bit per-lane pointer arithmetic instead,
+// hipcc hoists one loop-invariant 64-bit VGPR pointer per output element out of the
+// time loop -- 80+ VGPRs at dim_x=4 -- and spills.)
+// Limit that follows: one step's record block must stay below 4 GiB (N*E*8 < 2^32);
+// the host launcher checks it.
+struct Lane {
+    long blk0;      // first track of this workgroup (uniform)
+    unsigned tid;   // lane's track offset inside the workgroup
+    long N;         // tracks (uniform)
+};
+
+using rsrc_t = __amdgpu_buffer_rsrc_t;
+
+__device__ __forceinline__ rsrc_t make_rsrc(const void *p)
+{
+    // raw buffer (stride 0), no clipping: tail lanes exit before touching memory
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), /*stride*/ 0, /*num_records*/ -1, 0x00020000);
+}
+
+using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
+
+// Per-lane view of one record block `blk` ([N][E] AOS / [E][N] SOA) for the lane's workgroup.
+template <int LAYOUT>
+struct RecView {
+    rsrc_t rs;
+    unsigned voff;        // per-lane byte offset
+    unsigned estride;     // SOA: N*8 (bytes between consecutive elements), uniform
+    __device__ __forceinline__ RecView(const double *blk, const Lane &ln, int E)
+    {
+        if (LAYOUT == LAYOUT_AOS) {
+            rs = make_rsrc(blk + ln.blk0 * (long)E);
+            voff = ln.tid * (unsigned)E * 8u;
+            estride = 0;
+        } else {
+            rs = make_rsrc(blk + ln.blk0);
+            voff = ln.tid * 8u;
+            estride = (unsigned)ln.N * 8u;
+        }
+    }
+    __device__ __forceinline__ double load(int e) const
+    {
+        const u32x2 v = (LAYOUT == LAYOUT_AOS)
+            ? __builtin_amdgcn_raw_buffer_load_b64(rs, voff + (unsigned)e * 8u, 0, 0)
+            : __builtin_amdgcn_raw_buffer_load_b64(rs, voff, (unsigned)e * estride, 0);
+        return __builtin_bit_cast(double, v);
+    }
+    __device__ __forceinline__ void store(int e, double x) const
+    {
+        const u32x2 v = __builtin_bit_cast(u32x2, x);
+        if (LAYOUT == LAYOUT_AOS) __builtin_amdgcn_raw_buffer_store_b64(v, rs, voff + (unsigned)e * 8u, 0, 0);
+        else __builtin_amdgcn_raw_buffer_store_b64(v, rs, voff, (unsigned)e * estride, 0);
+    }
+};
+
+// Load an r x c matrix record of the lane's track (C order, row stride c) into a ROWS x COLS
+// register tile, padding with diag_pad on the diagonal and 0 elsewhere.
+template <int ROWS, int COLS, int LAYOUT, bool EXACT>
+__device__ __forceinline__ void load_rec(double (&M)[ROWS * COLS], const double *__restrict__ blk,
+                                         const Lane &ln, int r, int c, double diag_pad)
+{
+    const int E = EXACT ? ROWS * COLS : r * c;
+    const RecView<LAYOUT> v(blk, ln, E);
+    FK_UNROLL for (int a = 0; a < ROWS; ++a) {
+        FK_UNROLL for (int b = 0; b < COLS; ++b) {
+            if (EXACT || (a < r && b < c))
+                M[a * COLS + b] = v.load(EXACT ? a * COLS + b : a * c + b);
+            else
+                M[a * COLS + b] = (a == b) ? diag_pad : 0.0;
+        }
+    }
+}
+
+template <int ROWS, int COLS, int LAYOUT, bool EXACT>
+__device__ __forceinline__ void store_rec(const double (&M)[ROWS * COLS], double *__restrict__ blk,
+                                          const Lane &ln, int r, int c)
+{
+    const int E = EXACT ? ROWS * COLS : r * c;
+    const RecView<LAYOUT> v(blk, ln, E);
+    FK_UNROLL for (int a = 0; a < ROWS; ++a) {
+        FK_UNROLL for (int b = 0; b < COLS; ++b) {
+            if (EXACT || (a < r && b < c))
+                v.store(EXACT ? a * COLS + b : a * c + b, M[a * COLS + b]);
+        }
+    }
+}
+
+// Model shared by all tracks, staged in LDS (padded to NX/NZ) and broadcast-read one row
+// at a time (all lanes read the same address: conflict-free, one ds_read_b128 per 2 doubles).
+// Layout in LDS: F[NX*NX] | Q[NX*NX] | H[NZ*NX] | R[NZ*NZ].
+template <int NX, int NZ>
+struct LdsModel {
+    static constexpr int OFF_F = 0, OFF_Q = NX * NX, OFF_H = 2 * NX * NX, OFF_R = 2 * NX * NX + NZ * NX;
+    static constexpr int SIZE = OFF_R + NZ * NZ;
+    const double *s;
+    __device__ __forceinline__ void rowF(int i, double (&r)[NX]) const { FK_UNROLL for (int j = 0; j < NX; ++j) r[j] = s[OFF_F + i * NX + j]; }
+    __device__ __forceinline__ void rowQ(int i, double (&r)[NX]) const { FK_UNROLL for (int j = 0; j < NX; ++j) r[j] = s[OFF_Q + i * NX + j]; }
+    __device__ __forceinline__ void rowH(int i, double (&r)[NX]) const { FK_UNROLL for (int j = 0; j < NX; ++j) r[j] = s[OFF_H + i * NX + j]; }
+    __device__ __forceinline__ void rowR(int i, double (&r)[NZ]) const { FK_UNROLL for (int j = 0; j < NZ; ++j) r[j] = s[OFF_R + i * NZ + j]; }
+};
+
+// Cooperative fill of one padded ROWS x COLS matrix in LDS from an r x c matrix in global
+// memory (src may be NULL: pure padding).  Caller synchronises.
+template <int ROWS, int COLS>
+__device__ __forceinline__ void lds_fill(double *dst, const double *__restrict__ src, int r, int c,
+                                         double diag_pad, unsigned tid)
+{
+    for (unsigned k = tid; k < (unsigned)(ROWS * COLS); k += BLOCK) {
+        const int a = (int)k / COLS, b = (int)k % COLS;
+        dst[k] = (src != nullptr && a < r && b < c) ? src[a * c + b] : ((a == b) ? diag_pad : 0.0);
+    }
+}
+
+template <int LEN>
+__device__ __forceinline__ bool all_finite(const double (&v)[LEN])
+{
+    bool ok = true;
+    FK_UNROLL for (int k = 0; k < LEN; ++k) ok = ok && (fabs(v[k]) <= 1.79769313486231570815e+308);
+    return ok;
+}
+
+// ---- host side ------------------------------------------------------------
+void set_last_error(const char *msg);
+int check_launch(const char *what);   // hipGetLastError -> FK_ERR_LAUNCH + message
+
+}  // namespace fk

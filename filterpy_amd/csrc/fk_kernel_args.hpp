@@ -1,0 +1,41 @@
+// fk_kernel_args.hpp -- by-value argument blocks of the gfx950 kernels (kernarg segment).
+#pragma once
+#include <stdint.h>
+
+namespace fk {
+
+struct KfArgs {
+    const double *F, *Q, *H, *R, *B, *u, *z;
+    const uint8_t *mask;
+    double *x, *P, *means, *covs, *means_p, *covs_p;
+    double *y_out, *K_out, *S_out, *SI_out;   // single-step update() extras (T == 1)
+    int32_t *status;
+    long N, T;
+    int n, m, nu;
+    int model_t;        // 1: model records advance with the time step
+    int update_first;
+    int do_predict, do_update;
+    double alpha_sq;
+};
+
+struct RtsArgs {
+    const double *F, *Q, *Xs, *Ps;
+    double *xs, *Ps_out, *K, *Pp;
+    int32_t *status;
+    long N, T;
+    int n;
+    int model_t;
+    int conv_off;       // 1: class method uses model[k+1]; 0: module function uses model[k]
+};
+
+struct UkfArgs {
+    const double *F, *H, *Q, *R, *Wm, *Wc, *z;
+    const uint8_t *mask;
+    double *x, *P, *means, *covs;
+    int32_t *status;
+    long N, T;
+    int n, m;
+    double scale;
+};
+
+}  // namespace fk

@@ -1,0 +1,190 @@
+// kf_dispatch.cpp -- C-ABI entry points of the linear Kalman filter path and the
+// (dim_x, dim_z) -> kernel instantiation dispatch.
+//
+// fk_kf_batch_filter_f64 <- KalmanFilter.batch_filter  (filterpy/kalman/kalman_filter.py:826-993)
+// fk_kf_predict_f64      <- KalmanFilter.predict       (:437-482)
+// fk_kf_update_f64       <- KalmanFilter.update        (:485-561)
+// fk_kf_rts_f64          <- KalmanFilter.rts_smoother  (:995-1074), module rts_smoother (:1792-1858)
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+
+#include "../../include/filterhip.h"
+#include "fk_device.hpp"
+#include "fk_kernel_args.hpp"
+
+namespace fk {
+
+#define FK_KF_INST(NX, NZ, EX) int launch_kf_##NX##_##NZ##_##EX(const KfArgs &, int, bool, hipStream_t);
+#include "fk_dims.def"
+#undef FK_KF_INST
+#define FK_RTS_INST(NX, EX) int launch_rts_##NX##_##EX(const RtsArgs &, int, bool, hipStream_t);
+#include "fk_dims_rts.def"
+#undef FK_RTS_INST
+
+struct KfEntry {
+    int nx, nz, exact;
+    int (*fn)(const KfArgs &, int, bool, hipStream_t);
+};
+static const KfEntry kf_table[] = {
+#define FK_KF_INST(NX, NZ, EX) {NX, NZ, EX, launch_kf_##NX##_##NZ##_##EX},
+#include "fk_dims.def"
+#undef FK_KF_INST
+};
+
+struct RtsEntry {
+    int nx, exact;
+    int (*fn)(const RtsArgs &, int, bool, hipStream_t);
+};
+static const RtsEntry rts_table[] = {
+#define FK_RTS_INST(NX, EX) {NX, EX, launch_rts_##NX##_##EX},
+#include "fk_dims_rts.def"
+#undef FK_RTS_INST
+};
+
+// cheapest instantiation that can serve (n, m): exact match first, else the padded
+// instantiation with the smallest NX^3 + NX^2*NZ cost.
+static const KfEntry *pick_kf(int n, int m)
+{
+    const KfEntry *best = nullptr;
+    long best_cost = 0;
+    for (const KfEntry &e : kf_table) {
+        if (e.exact) {
+            if (e.nx == n && e.nz == m) return &e;
+            continue;
+        }
+        if (e.nx < n || e.nz < m) continue;
+        const long cost = (long)e.nx * e.nx * e.nx + (long)e.nx * e.nx * e.nz;
+        if (!best || cost < best_cost) {
+            best = &e;
+            best_cost = cost;
+        }
+    }
+    return best;
+}
+
+static const RtsEntry *pick_rts(int n)
+{
+    const RtsEntry *best = nullptr;
+    for (const RtsEntry &e : rts_table) {
+        if (e.exact) {
+            if (e.nx == n) return &e;
+            continue;
+        }
+        if (e.nx < n) continue;
+        if (!best || e.nx < best->nx) best = &e;
+    }
+    return best;
+}
+
+static int fail(int code, const char *msg)
+{
+    set_last_error(msg);
+    return code;
+}
+
+static int check_desc(const fk_kf_desc *d)
+{
+    if (!d) return fail(FK_ERR_BAD_ARG, "desc is NULL");
+    if (d->n < 1 || d->m < 1 || d->nu < 0) return fail(FK_ERR_BAD_ARG, "dim_x, dim_z must be >= 1, dim_u >= 0");
+    if (d->N < 0 || d->T < 0) return fail(FK_ERR_BAD_ARG, "N and T must be >= 0");
+    if (d->layout != FK_LAYOUT_AOS && d->layout != FK_LAYOUT_SOA) return fail(FK_ERR_BAD_ARG, "bad layout");
+    if (d->model_mode < 0 || d->model_mode > 3) return fail(FK_ERR_BAD_ARG, "bad model_mode");
+    // one step's record block is addressed with 32-bit byte offsets (fk_device.hpp)
+    const long E = (long)d->n * (d->n > d->m ? d->n : d->m);
+    if ((double)d->N * (double)E * 8.0 >= 4294967296.0)
+        return fail(FK_ERR_UNSUPPORTED, "N * dim^2 * 8 bytes must stay below 4 GiB per launch: split the batch");
+    return FK_OK;
+}
+
+static int run_kf(const fk_kf_desc *d, KfArgs &a, void *stream)
+{
+    if (d->N == 0 || a.T == 0) return FK_OK;
+    const KfEntry *e = pick_kf(d->n, d->m);
+    if (!e) return fail(FK_ERR_UNSUPPORTED, "dim_x/dim_z outside the compiled range (dim_x <= 16, dim_z <= 8)");
+    a.N = d->N;
+    a.n = d->n;
+    a.m = d->m;
+    a.nu = d->nu;
+    a.model_t = (d->model_mode == FK_MODEL_PER_TRACK_STEP || d->model_mode == FK_MODEL_PER_STEP) ? 1 : 0;
+    a.update_first = d->update_first;
+    a.alpha_sq = d->alpha_sq;
+    const bool uniform = (d->model_mode == FK_MODEL_SHARED || d->model_mode == FK_MODEL_PER_STEP);
+    return e->fn(a, d->layout, uniform, (hipStream_t)stream);
+}
+
+}  // namespace fk
+
+using namespace fk;
+
+extern "C" {
+
+int fk_kf_batch_filter_f64(const fk_kf_desc *desc, const double *F, const double *Q, const double *H,
+                           const double *R, const double *B, const double *u, const double *z,
+                           const uint8_t *mask, double *x, double *P, double *means, double *covs,
+                           double *means_p, double *covs_p, int32_t *status, void *stream)
+{
+    if (int rc = check_desc(desc)) return rc;
+    if (!F || !Q || !H || !R || !z || !x || !P) return fail(FK_ERR_BAD_ARG, "F,Q,H,R,z,x,P must not be NULL");
+    if (desc->nu > 0 && (!B || !u)) return fail(FK_ERR_BAD_ARG, "dim_u > 0 needs B and u");
+    KfArgs a{};
+    a.F = F; a.Q = Q; a.H = H; a.R = R; a.B = B; a.u = u; a.z = z; a.mask = mask;
+    a.x = x; a.P = P; a.means = means; a.covs = covs; a.means_p = means_p; a.covs_p = covs_p;
+    a.status = status;
+    a.T = desc->T;
+    a.do_predict = 1;
+    a.do_update = 1;
+    return run_kf(desc, a, stream);
+}
+
+int fk_kf_predict_f64(const fk_kf_desc *desc, const double *F, const double *Q, const double *B,
+                      const double *u, double *x, double *P, int32_t *status, void *stream)
+{
+    if (int rc = check_desc(desc)) return rc;
+    if (!F || !Q || !x || !P) return fail(FK_ERR_BAD_ARG, "F,Q,x,P must not be NULL");
+    if (desc->nu > 0 && (!B || !u)) return fail(FK_ERR_BAD_ARG, "dim_u > 0 needs B and u");
+    KfArgs a{};
+    a.F = F; a.Q = Q; a.B = B; a.u = u; a.x = x; a.P = P; a.status = status;
+    a.T = 1;
+    a.do_predict = 1;
+    a.do_update = 0;
+    return run_kf(desc, a, stream);
+}
+
+int fk_kf_update_f64(const fk_kf_desc *desc, const double *H, const double *R, const double *z,
+                     const uint8_t *mask, double *x, double *P, double *y, double *K, double *S,
+                     double *SI, int32_t *status, void *stream)
+{
+    if (int rc = check_desc(desc)) return rc;
+    if (!H || !R || !z || !x || !P) return fail(FK_ERR_BAD_ARG, "H,R,z,x,P must not be NULL");
+    KfArgs a{};
+    a.H = H; a.R = R; a.z = z; a.mask = mask; a.x = x; a.P = P;
+    a.y_out = y; a.K_out = K; a.S_out = S; a.SI_out = SI; a.status = status;
+    a.T = 1;
+    a.do_predict = 0;
+    a.do_update = 1;
+    fk_kf_desc d = *desc;
+    d.nu = 0;
+    return run_kf(&d, a, stream);
+}
+
+int fk_kf_rts_f64(const fk_kf_desc *desc, const double *F, const double *Q, const double *Xs,
+                  const double *Ps, double *xs, double *Ps_out, double *K, double *Pp,
+                  int32_t index_convention, int32_t *status, void *stream)
+{
+    if (int rc = check_desc(desc)) return rc;
+    if (!F || !Q || !Xs || !Ps || !xs || !Ps_out) return fail(FK_ERR_BAD_ARG, "F,Q,Xs,Ps,xs,Ps_out must not be NULL");
+    if (index_convention != 0 && index_convention != 1) return fail(FK_ERR_BAD_ARG, "index_convention must be 0 or 1");
+    if (desc->N == 0 || desc->T == 0) return FK_OK;
+    const RtsEntry *e = pick_rts(desc->n);
+    if (!e) return fail(FK_ERR_UNSUPPORTED, "dim_x outside the compiled range (<= 16)");
+    RtsArgs a{};
+    a.F = F; a.Q = Q; a.Xs = Xs; a.Ps = Ps; a.xs = xs; a.Ps_out = Ps_out; a.K = K; a.Pp = Pp;
+    a.status = status;
+    a.N = desc->N; a.T = desc->T; a.n = desc->n;
+    a.model_t = (desc->model_mode == FK_MODEL_PER_TRACK_STEP || desc->model_mode == FK_MODEL_PER_STEP) ? 1 : 0;
+    a.conv_off = index_convention == 0 ? 1 : 0;
+    const bool uniform = (desc->model_mode == FK_MODEL_SHARED || desc->model_mode == FK_MODEL_PER_STEP);
+    return e->fn(a, desc->layout, uniform, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,118 @@
+// rts_kernels.hip -- Rauch-Tung-Striebel smoother kernels for gfx950 (MI355X).
+//
+// One track per lane, the backward time loop inside the kernel; the smoothed
+// (x, P) of step k+1 stays in VGPRs for step k.  Per step the kernel reads the
+// filtered (x_k, P_k) and writes the smoothed x, P, the gain K and the predicted
+// covariance Pp: 8*(2n + 4n^2) algorithmic bytes per track-step.
+//
+// Replaces the backward loop of KalmanFilter.rts_smoother
+// (filterpy/kalman/kalman_filter.py:1066-1072; F[k+1], Q[k+1]) and of the module
+// function rts_smoother (:1851-1856; F[k], Q[k]) -- selected by conv_off.
+#include "fk_device.hpp"
+#include "fk_kernel_args.hpp"
+
+#ifndef FK_NX
+#error "compile with -DFK_NX=<dim_x> -DFK_EXACT=<0|1>"
+#endif
+
+namespace fk {
+
+constexpr int rts_min_waves(int nx) { return nx <= 2 ? 4 : nx <= 4 ? 2 : 1; }
+
+template <int NX, bool EXACT, int LAYOUT, bool UNIFORM>
+__global__ void __launch_bounds__(BLOCK, rts_min_waves(NX))
+rts_kernel(const RtsArgs a, const double *__restrict__ pF, const double *__restrict__ pQ,
+           const double *__restrict__ pXs, const double *__restrict__ pPs)
+{
+    using SharedModel = LdsModel<NX, 1>;
+    using TrackModel = RegModel<NX, 1>;
+    __shared__ double s_model[UNIFORM ? SharedModel::SIZE : 1];
+
+    const long N = a.N, T = a.T;
+    const long blk0 = (long)blockIdx.x * BLOCK;
+    const Lane ln{blk0, threadIdx.x, N};
+    const bool live = blk0 + ln.tid < N;
+    const Lane lr{blk0, live ? ln.tid : 0u, N};
+    const int n = EXACT ? NX : a.n;
+    const long xs_blk = N * n, ps_blk = N * (long)n * n;
+
+    // k = T-1: smoothed == filtered; K = 0; Pp = Ps   (kalman_filter.py:1063-1065)
+    double xn[NX], Pn[NX * NX];
+    load_rec<NX, 1, LAYOUT, EXACT>(xn, pXs + (T - 1) * xs_blk, lr, n, 1, 0.0);
+    load_rec<NX, NX, LAYOUT, EXACT>(Pn, pPs + (T - 1) * ps_blk, lr, n, n, 1.0);
+    if (live) {
+        store_rec<NX, 1, LAYOUT, EXACT>(xn, a.xs + (T - 1) * xs_blk, ln, n, 1);
+        store_rec<NX, NX, LAYOUT, EXACT>(Pn, a.Ps_out + (T - 1) * ps_blk, ln, n, n);
+        if (a.Pp) store_rec<NX, NX, LAYOUT, EXACT>(Pn, a.Pp + (T - 1) * ps_blk, ln, n, n);
+        if (a.K) {
+            double Z[NX * NX];
+            FK_UNROLL for (int i = 0; i < NX * NX; ++i) Z[i] = 0.0;
+            store_rec<NX, NX, LAYOUT, EXACT>(Z, a.K + (T - 1) * ps_blk, ln, n, n);
+        }
+    }
+
+    TrackModel tm;
+    const SharedModel sm{s_model};
+    int st = 0;
+    bool first = true;
+
+    for (long k = T - 2; k >= 0; --k) {
+        if (first || a.model_t) {
+            const long mt = a.model_t ? k + a.conv_off : 0;
+            if (UNIFORM) {
+                if (!first) __syncthreads();
+                lds_fill<NX, NX>(s_model + SharedModel::OFF_F, pF + mt * n * n, n, n, 1.0, ln.tid);
+                lds_fill<NX, NX>(s_model + SharedModel::OFF_Q, pQ + mt * n * n, n, n, 0.0, ln.tid);
+                __syncthreads();
+            } else {
+                load_rec<NX, NX, LAYOUT, EXACT>(tm.F, pF + mt * ps_blk, lr, n, n, 1.0);
+                load_rec<NX, NX, LAYOUT, EXACT>(tm.Q, pQ + mt * ps_blk, lr, n, n, 0.0);
+            }
+            first = false;
+        }
+        double x[NX], P[NX * NX], K[NX * NX], Pp[NX * NX];
+        load_rec<NX, 1, LAYOUT, EXACT>(x, pXs + k * xs_blk, lr, n, 1, 0.0);
+        load_rec<NX, NX, LAYOUT, EXACT>(P, pPs + k * ps_blk, lr, n, n, 1.0);
+        if (UNIFORM) st |= rts_step<NX>(x, P, xn, Pn, sm, K, Pp);
+        else st |= rts_step<NX>(x, P, xn, Pn, tm, K, Pp);
+        if (live) {
+            store_rec<NX, 1, LAYOUT, EXACT>(x, a.xs + k * xs_blk, ln, n, 1);
+            store_rec<NX, NX, LAYOUT, EXACT>(P, a.Ps_out + k * ps_blk, ln, n, n);
+            if (a.K) store_rec<NX, NX, LAYOUT, EXACT>(K, a.K + k * ps_blk, ln, n, n);
+            if (a.Pp) store_rec<NX, NX, LAYOUT, EXACT>(Pp, a.Pp + k * ps_blk, ln, n, n);
+        }
+        FK_UNROLL for (int i = 0; i < NX; ++i) xn[i] = x[i];
+        FK_UNROLL for (int i = 0; i < NX * NX; ++i) Pn[i] = P[i];
+    }
+    if (live && a.status) {
+        if (!all_finite<NX>(xn) || !all_finite<NX * NX>(Pn)) st |= ST_NONFINITE;
+        a.status[ln.blk0 + ln.tid] = st;
+    }
+}
+
+template <int NX, bool EXACT>
+static int launch(const RtsArgs &a, int layout, bool uniform, hipStream_t stream)
+{
+    const dim3 grid((unsigned)((a.N + BLOCK - 1) / BLOCK)), block(BLOCK);
+#define FK_GO(LAY, UNI) \
+    hipLaunchKernelGGL((rts_kernel<NX, EXACT, LAY, UNI>), grid, block, 0, stream, a, a.F, a.Q, a.Xs, a.Ps)
+    if (layout == LAYOUT_SOA) {
+        if (uniform) FK_GO(LAYOUT_SOA, true);
+        else FK_GO(LAYOUT_SOA, false);
+    } else {
+        if (uniform) FK_GO(LAYOUT_AOS, true);
+        else FK_GO(LAYOUT_AOS, false);
+    }
+#undef FK_GO
+    return check_launch("rts_kernel");
+}
+
+#define FK_CAT_(a, b, c) a##b##_##c
+#define FK_CAT(a, b, c) FK_CAT_(a, b, c)
+
+int FK_CAT(launch_rts_, FK_NX, FK_EXACT)(const RtsArgs &a, int layout, bool uniform, hipStream_t stream)
+{
+    return launch<FK_NX, (FK_EXACT != 0)>(a, layout, uniform, stream);
+}
+
+}  // namespace fk

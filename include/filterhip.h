@@ -1,0 +1,232 @@
+/* filterhip.h -- C ABI of libfilterhip.so, the MI355X (gfx950) batched-filter engine.
+ *
+ * This is the drop-in boundary for ONE hot path of rlabbe/filterpy (v1.4.5):
+ * many independent small filters stepped in lock-step.  The reference has no
+ * FFI of its own (it is pure Python); each entry point below names the
+ * reference function (file:line under /root/reference) whose arithmetic it
+ * replaces.  INTEGRATION.md shows the ctypes binding a filterpy maintainer
+ * would add.
+ *
+ * Conventions (all entry points):
+ *   - extern "C", plain pointers and sizes, no C++/torch types;
+ *   - every data pointer is a DEVICE pointer owned by the caller (HBM resident);
+ *     the library never allocates, frees or copies user-visible memory;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); calls
+ *     only enqueue work, they do not synchronise;
+ *   - return value: FK_OK (0) or a negative FK_ERR_* for argument / launch
+ *     errors.  Per-track numerical trouble is reported in the caller's
+ *     `status[N]` array (bit flags FK_STATUS_*), never by faulting;
+ *   - all arithmetic is IEEE fp64 ("f64" suffix).
+ *
+ * Array layouts.  `layout` selects how per-track records are laid out:
+ *   FK_LAYOUT_AOS (0): NumPy C order, track-major records:  a[t][i][e]
+ *                      (e.g. covariances[T][N][n][n]) -- what np.asarray() of the
+ *                      reference's return values would look like with a track axis;
+ *   FK_LAYOUT_SOA (1): track-minor (coalesced) records:      a[t][e][i]
+ * with t = time step, i = track, e = element index in C order (row*cols+col).
+ *
+ * Model matrices F,Q (n x n), H (m x n), R (m x m), B (n x nu) follow
+ * `model_mode`:
+ *   FK_MODEL_SHARED           (0): one matrix for every track and step   M[e]
+ *   FK_MODEL_PER_TRACK        (1): one per track                          AOS M[i][e] / SOA M[e][i]
+ *   FK_MODEL_PER_TRACK_STEP   (2): one per track and step (Fs/Qs/Hs/Rs lists,
+ *                                  kalman_filter.py:941-952)              AOS M[t][i][e] / SOA M[t][e][i]
+ *   FK_MODEL_PER_STEP         (3): one per step shared by all tracks     M[t][e]
+ */
+#ifndef FILTERHIP_H
+#define FILTERHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FK_ABI_VERSION 1
+
+enum {
+    FK_OK = 0,
+    FK_ERR_BAD_ARG = -1,      /* NULL where data is required, negative sizes, ... */
+    FK_ERR_UNSUPPORTED = -2,  /* dims outside the compiled range (dim_x <= 16, dim_z <= 8) */
+    FK_ERR_LAUNCH = -3,       /* HIP reported a launch / runtime error */
+    FK_ERR_WORKSPACE = -4     /* workspace too small: see the *_workspace_bytes query */
+};
+
+enum { FK_LAYOUT_AOS = 0, FK_LAYOUT_SOA = 1 };
+
+enum {
+    FK_MODEL_SHARED = 0,
+    FK_MODEL_PER_TRACK = 1,
+    FK_MODEL_PER_TRACK_STEP = 2,
+    FK_MODEL_PER_STEP = 3
+};
+
+/* bits of status[i] */
+enum {
+    FK_STATUS_NOT_PD = 1,      /* S (or Pp / P for RTS / sigma points) not positive definite:
+                                  the reference would raise numpy.linalg.LinAlgError or return junk */
+    FK_STATUS_NONFINITE = 2,   /* NaN/Inf in the track's state after the call */
+    FK_STATUS_OVERRUN = 4      /* resample: a position >= cumsum[-1] (reference: IndexError,
+                                  resampling.py:109,145); the index is clamped to Np-1 */
+};
+
+/* ------------------------------------------------------------------ */
+/* Linear Kalman filter                                               */
+/* ------------------------------------------------------------------ */
+typedef struct fk_kf_desc {
+    int32_t n;            /* dim_x  (1..16) */
+    int32_t m;            /* dim_z  (1..8, <= n not required) */
+    int32_t nu;           /* dim_u  (0 = no control input) */
+    int32_t model_mode;   /* FK_MODEL_* for F,Q,H,R,B */
+    int64_t N;            /* tracks */
+    int64_t T;            /* time steps */
+    int32_t layout;       /* FK_LAYOUT_* for z,u,mask-free records, x,P, outputs, per-track models */
+    int32_t update_first; /* kalman_filter.py:966-978: update then predict */
+    double  alpha_sq;     /* fading memory alpha^2 (kalman_filter.py:478), 1.0 = off */
+} fk_kf_desc;
+
+/* KalmanFilter.batch_filter (filterpy/kalman/kalman_filter.py:826-993; module twin :1664-1788)
+ * for N independent filters: T x { predict (:472-478) ; update (:533-556, Joseph form) },
+ * state kept in registers across the whole time loop.
+ *
+ *   F,Q,H,R : models per desc->model_mode.          B,u : control (NULL when nu == 0);
+ *             u is a record array u[T][N][nu] in `layout`.
+ *   z       : measurements, record array [T][N][m] in `layout`.
+ *   mask    : uint8 [T][N] (always t-major, track-minor), 0 = missing measurement
+ *             (the reference's `None`, kalman_filter.py:515-520: update skipped); NULL = none missing.
+ *   x, P    : in: initial state [N][n] / [N][n][n] (in `layout`: AOS x[i][e], SOA x[e][i]);
+ *             out: final state.
+ *   means, covs     : posterior per step, records [T][N][n] / [T][N][n*n]; may be NULL (not stored).
+ *   means_p, covs_p : prior per step; may be NULL.
+ *   status  : int32 [N] (OR-ed FK_STATUS_* bits); may be NULL.
+ *
+ * S^-1 is applied by an in-lane LDL^T (square-root-free Cholesky) solve, not an
+ * explicit inverse; S must be symmetric positive definite (status bit otherwise).
+ */
+int fk_kf_batch_filter_f64(const fk_kf_desc *desc,
+                           const double *F, const double *Q, const double *H, const double *R,
+                           const double *B, const double *u,
+                           const double *z, const uint8_t *mask,
+                           double *x, double *P,
+                           double *means, double *covs, double *means_p, double *covs_p,
+                           int32_t *status, void *stream);
+
+/* KalmanFilter.predict (kalman_filter.py:437-482; module twin :1571-1621) on a resident batch:
+ * one step, x/P updated in place.  desc->T is ignored (treated as 1). */
+int fk_kf_predict_f64(const fk_kf_desc *desc, const double *F, const double *Q,
+                      const double *B, const double *u, double *x, double *P,
+                      int32_t *status, void *stream);
+
+/* KalmanFilter.update (kalman_filter.py:485-561; module twin :1401-1508) on a resident batch.
+ * Optional extra outputs (NULL = skip), records per track in `layout`:
+ *   y [N][m], K [N][n*m], S [N][m*m], SI [N][m*m]  (attributes kalman_filter.py:533-544). */
+int fk_kf_update_f64(const fk_kf_desc *desc, const double *H, const double *R,
+                     const double *z, const uint8_t *mask, double *x, double *P,
+                     double *y, double *K, double *S, double *SI,
+                     int32_t *status, void *stream);
+
+/* KalmanFilter.rts_smoother (kalman_filter.py:995-1074) / module rts_smoother (:1792-1858).
+ *   Xs [T][N][n], Ps [T][N][n*n] : filter output (read only)
+ *   xs, Ps_out, K, Pp            : smoothed means / covariances / gains / predicted covariances,
+ *                                  same shapes ([T][N][n*n] for K, Pp); K[T-1] = 0, Pp[T-1] = Ps[T-1].
+ *   index_convention 0: class method, uses F[k+1],Q[k+1] (:1067);  1: module function, F[k],Q[k] (:1851).
+ *   F,Q per desc->model_mode (only PER_STEP / PER_TRACK_STEP make the convention visible).
+ * Pp must be SPD (LDL^T solve); status bit otherwise. */
+int fk_kf_rts_f64(const fk_kf_desc *desc, const double *F, const double *Q,
+                  const double *Xs, const double *Ps,
+                  double *xs, double *Ps_out, double *K, double *Pp,
+                  int32_t index_convention, int32_t *status, void *stream);
+
+/* ------------------------------------------------------------------ */
+/* Unscented transform path                                           */
+/* ------------------------------------------------------------------ */
+
+/* MerweScaledSigmaPoints.sigma_points (filterpy/kalman/sigma_points.py:124-177) and
+ * JulierSigmaPoints.sigma_points (:289-357): U = chol_upper(scale * P);
+ * sigma_0 = x, sigma_{k+1} = x + U[k], sigma_{n+k+1} = x - U[k].
+ *   scale = lambda + n (Merwe) or n + kappa (Julier), computed by the caller.
+ *   x [N][n], P [N][n*n] -> sigmas [N][(2n+1)*n] (record = the (2n+1, n) C-order array). */
+int fk_ut_sigma_points_f64(int32_t n, int64_t N, int32_t layout, double scale,
+                           const double *x, const double *P, double *sigmas,
+                           int32_t *status, void *stream);
+
+/* unscented_transform (filterpy/kalman/unscented_transform.py:99-128), default mean/residual:
+ *   x = Wm . sigmas ; y = sigmas - x ; P = y' diag(Wc) y (+ noise_cov).
+ *   sigmas [N][k*n] records; Wm, Wc [k] shared (device); noise_cov [n*n] shared or NULL.
+ *   -> x_out [N][n], P_out [N][n*n]. */
+int fk_ut_transform_f64(int32_t n, int32_t k, int64_t N, int32_t layout,
+                        const double *sigmas, const double *Wm, const double *Wc,
+                        const double *noise_cov, double *x_out, double *P_out, void *stream);
+
+/* UnscentedKalmanFilter.cross_variance (filterpy/kalman/UKF.py:493-504), default residuals:
+ *   Pxz = sum_i Wc[i] (sigmas_f[i]-x)(sigmas_h[i]-z)'.
+ *   sigmas_f [N][k*n], sigmas_h [N][k*m], x [N][n], z [N][m] -> Pxz [N][n*m]. */
+int fk_ut_cross_variance_f64(int32_t n, int32_t m, int32_t k, int64_t N, int32_t layout,
+                             const double *x, const double *z,
+                             const double *sigmas_f, const double *sigmas_h,
+                             const double *Wc, double *Pxz, void *stream);
+
+typedef struct fk_ukf_desc {
+    int32_t n, m;         /* dim_x (1..8), dim_z (1..4) */
+    int64_t N, T;
+    int32_t layout;
+    int32_t reserved;
+    double  scale;        /* lambda + n */
+} fk_ukf_desc;
+
+/* UnscentedKalmanFilter.batch_filter (UKF.py:524-632) with LINEAR fx(x,dt)=F x, hx(x)=H x,
+ * fused per track: T x { predict (UKF.py:400-411: sigma points, F sigma, UT+Q, regenerate
+ * sigma points) ; update (UKF.py:462-481: H sigma, UT+R, cross variance, K = Pxz S^-1,
+ * x += K y, P -= K S K') }.
+ *   F [n*n], H [m*n], Q [n*n], R [m*m], Wm, Wc [2n+1] : shared device arrays.
+ *   z [T][N][m], mask [T][N] or NULL; x [N][n], P [N][n*n] in/out;
+ *   means [T][N][n], covs [T][N][n*n] posterior per step (NULL = not stored). */
+int fk_ukf_linear_batch_f64(const fk_ukf_desc *desc,
+                            const double *F, const double *H, const double *Q, const double *R,
+                            const double *Wm, const double *Wc,
+                            const double *z, const uint8_t *mask,
+                            double *x, double *P, double *means, double *covs,
+                            int32_t *status, void *stream);
+
+/* ------------------------------------------------------------------ */
+/* Particle-filter resampling                                         */
+/* ------------------------------------------------------------------ */
+
+/* systematic_resample (filterpy/monte_carlo/resampling.py:117-150) for Fn independent
+ * filters of Np particles:  pos_i = fl(fl(u_f + i)/Np); cs = cumsum(w_f) reproduced
+ * bit-for-bit as a sequential fp64 add chain; idx_i = #{ j : cs_j <= pos_i }.
+ *   w   [Fn][Np] weights;  u [Fn] one uniform per filter (drawn by the host from numpy.random);
+ *   idx [Fn][Np] int32 (np.zeros(N,'i'), resampling.py:141);  status [Fn] or NULL.
+ *   ws / ws_bytes : scratch from fk_resample_workspace_bytes(Fn, Np). */
+int fk_resample_systematic_f64(int64_t Fn, int64_t Np, const double *w, const double *u,
+                               int32_t *idx, int32_t *status,
+                               void *ws, size_t ws_bytes, void *stream);
+
+/* stratified_resample (resampling.py:80-114): pos_i = fl(fl(u_{f,i} + i)/Np), u [Fn][Np]. */
+int fk_resample_stratified_f64(int64_t Fn, int64_t Np, const double *w, const double *u,
+                               int32_t *idx, int32_t *status,
+                               void *ws, size_t ws_bytes, void *stream);
+
+/* multinomial_resample (resampling.py:153-176) and the random tail of residual_resample
+ * (:72-76):  cs = cumsum(w_f) sequential, cs[-1] = 1.0, idx_i = searchsorted(cs, u_{f,i}) (side
+ * 'left'), for Nu draws per filter.   u [Fn][Nu] -> idx [Fn][Nu] int64 (np.intp, as the
+ * reference returns). */
+int fk_resample_multinomial_f64(int64_t Fn, int64_t Np, int64_t Nu, const double *w, const double *u,
+                                int64_t *idx, void *ws, size_t ws_bytes, void *stream);
+
+size_t fk_resample_workspace_bytes(int64_t Fn, int64_t Np);
+
+/* ------------------------------------------------------------------ */
+/* Utilities                                                          */
+/* ------------------------------------------------------------------ */
+int fk_abi_version(void);
+/* name of the gfx target the kernels were compiled for ("gfx950") */
+const char *fk_build_arch(void);
+/* last HIP error string seen by this library on the calling thread ("" if none) */
+const char *fk_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FILTERHIP_H */
