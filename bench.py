@@ -1,0 +1,233 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark: track-steps/sec (predict+update) at dim_x=4, dim_z=2.
+
+Workload = BASELINE.json configs[1]: 1e6 independent dim_x=4 dim_z=2 constant-velocity
+tracks x 100 steps, fp64, shared F/H/Q/R, one fk_kf_batch_filter_f64 launch per "step"
+(= one full batch_filter pass: T predict+update per track, all four outputs of
+KalmanFilter.batch_filter written: means, covariances, means_p, covariances_p).
+Inputs (z, x0, P0) are resident in HBM before the timed region.
+
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1: launched by torch.distributed.run, one rank per GPU; tracks shard across ranks
+(weak scaling: every rank filters its own 1e6 tracks, no data-path collective), then one
+RCCL all-gather of the summary state (final x of every track) per step.
+
+Prints ONE JSON line (rank 0) with `roofline` (HBM) and, at N=1, `cpu_baseline`
+(the NumPy oracle = the reference's algorithm, timed on this host's cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X spec (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
+
+
+# ---------------------------------------------------------------- workload --
+def c2_model():
+    """dt=1 constant velocity in 2-D; H picks the two positions."""
+    F1 = np.array([[1., 1.], [0., 1.]])
+    F = np.kron(np.eye(2), F1)
+    H = np.array([[1., 0., 0., 0.], [0., 0., 1., 0.]])
+    q = np.array([[.25, .5], [.5, 1.]]) * 0.01          # Q_discrete_white_noise(2, 1., 0.01)
+    Q = np.kron(np.eye(2), q)
+    R = 4.0 * np.eye(2)
+    return F, Q, H, R
+
+
+def c2_inputs(N, T, seed=1):
+    """Host (NumPy) inputs for N tracks: x0 = 0, P0 = 100 I, z = H x_true + 2 randn."""
+    F, _, H, _ = c2_model()
+    rs = np.random.RandomState(seed)
+    xt = rs.randn(N, 4) * np.array([10., 1., 10., 1.])
+    zs = np.empty((T, N, 2))
+    for t in range(T):
+        xt = xt @ F.T
+        zs[t] = xt @ H.T + 2.0 * rs.randn(N, 2)
+    return np.zeros((N, 4)), np.tile(100.0 * np.eye(4), (N, 1, 1)), zs
+
+
+def c2_inputs_device(N, T, layout, seed, device):
+    """Same distribution generated on the GPU (1.6 GB of z at N=1e6: too slow to draw on the host).
+    Returns device records x0, P0, z in `layout`."""
+    import torch
+    from filterpy_amd import _engine as E
+    F, _, H, _ = c2_model()
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    Fd, Hd = E.dev(F), E.dev(H)
+    xt = torch.randn(N, 4, generator=g, device=device, dtype=torch.float64) * torch.tensor(
+        [10., 1., 10., 1.], device=device, dtype=torch.float64)
+    z = E.alloc_records((T,), N, 2, layout)
+    for t in range(T):
+        xt = xt @ Fd.T
+        zt = xt @ Hd.T + 2.0 * torch.randn(N, 2, generator=g, device=device, dtype=torch.float64)
+        z[t] = zt if layout == "aos" else zt.T
+    x0 = torch.zeros((N, 4) if layout == "aos" else (4, N), dtype=torch.float64, device=device)
+    P0 = (100.0 * torch.eye(4, dtype=torch.float64, device=device)).reshape(1, 16).repeat(N, 1)
+    P0 = P0.contiguous() if layout == "aos" else P0.T.contiguous()
+    return x0, P0, z
+
+
+# ------------------------------------------------------------ CPU baseline --
+def _cpu_worker(args):
+    seed, ntracks, T = args
+    from oracle import kf_oracle
+    F, Q, H, R = c2_model()
+    x0, P0, zs = c2_inputs(ntracks, T, seed=seed)
+    t0 = time.perf_counter()
+    for i in range(ntracks):
+        kf_oracle.kf_batch_filter(x0[i], P0[i], list(zs[:, i]), F, Q, H, R)
+    return time.perf_counter() - t0
+
+
+def cpu_baseline(T, tracks_per_core):
+    """The NumPy oracle (= the reference's per-epoch NumPy loop, oracle/kf_oracle.py) on every
+    host core, one process per core, on a bounded sample of the same workload."""
+    import multiprocessing as mp
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    os.environ.setdefault("OMP_NUM_THREADS", "1")
+    os.environ.setdefault("OPENBLAS_NUM_THREADS", "1")
+    ctx = mp.get_context("spawn")
+    t0 = time.perf_counter()
+    with ctx.Pool(cores) as pool:
+        pool.map(_cpu_worker, [(1000 + c, tracks_per_core, T) for c in range(cores)])
+    wall = time.perf_counter() - t0
+    # include only the filtering time as seen by the slowest worker + pool overhead: use wall
+    steps = cores * tracks_per_core * T
+    return {"value": steps / wall, "unit": "track-steps/s", "cores": cores, "kind": "port",
+            "sample": f"{cores} procs x {tracks_per_core} tracks x {T} steps of the C2 workload "
+                      f"(NumPy oracle of KalmanFilter.batch_filter), {wall:.1f} s wall"}
+
+
+# -------------------------------------------------------------------- main --
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--tracks", type=int, default=1_000_000, help="tracks per GPU")
+    ap.add_argument("--T", type=int, default=100)
+    ap.add_argument("--layout", default=os.environ.get("FK_BENCH_LAYOUT", "soa"), choices=["soa", "aos"])
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--cpu-tracks-per-core", type=int, default=2500)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from filterpy_amd import _engine as E
+    from oracle import kf_oracle
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    N, T, layout, n, m = args.tracks, args.T, args.layout, 4, 2
+    F, Q, H, R = c2_model()
+    dF, dQ, dH, dR = (E.dev(M, device) for M in (F, Q, H, R))
+    x0, P0, z = c2_inputs_device(N, T, layout, seed=1234 + rank, device=device)
+    x, P = x0.clone(), P0.clone()
+    means = E.alloc_records((T,), N, n, layout, device)
+    covs = E.alloc_records((T,), N, n * n, layout, device)
+    means_p = E.alloc_records((T,), N, n, layout, device)
+    covs_p = E.alloc_records((T,), N, n * n, layout, device)
+    status = torch.zeros(N, dtype=torch.int32, device=device)
+    gathered = torch.empty((world,) + tuple(x.shape), dtype=torch.float64, device=device) if world > 1 else None
+    desc = dict(n=n, m=m, nu=0, model_mode=0, N=N, T=T, layout=E.LAYOUTS[layout], update_first=0, alpha_sq=1.0)
+
+    def step(ev=None):
+        x.copy_(x0)
+        P.copy_(P0)
+        if ev:
+            ev[0].record()
+        E.kf_batch_filter(desc, dF, dQ, dH, dR, z, x, P, means=means, covs=covs, means_p=means_p,
+                          covs_p=covs_p, status=status)
+        if ev:
+            ev[1].record()
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, x)       # summary state over RCCL/xGMI
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+              for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(events[k])
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax)
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in events])) if events else float("nan")
+    assert int(status.abs().max()) == 0, "kernel flagged tracks"
+
+    # parity on the timed buffers: a sample of tracks against the oracle (not timed)
+    sample = [0, 1, 255, 256, N // 2, N - 1]
+    idx = torch.tensor(sample, device=device)
+    if layout == "aos":
+        zs_h = z[:, idx].cpu().numpy()
+        got = [means[:, idx].cpu().numpy(), covs[:, idx].cpu().numpy().reshape(T, -1, n, n),
+               means_p[:, idx].cpu().numpy(), covs_p[:, idx].cpu().numpy().reshape(T, -1, n, n)]
+    else:
+        zs_h = z[:, :, idx].cpu().numpy().transpose(0, 2, 1)
+        tr = lambda a: a[:, :, idx].cpu().numpy().transpose(0, 2, 1)
+        got = [tr(means), tr(covs).reshape(T, -1, n, n), tr(means_p), tr(covs_p).reshape(T, -1, n, n)]
+    ref = kf_oracle.kf_batch_filter_tracks(np.zeros((len(sample), n)), np.tile(100.0 * np.eye(n), (len(sample), 1, 1)),
+                                           zs_h, F, Q, H, R, tracks=range(len(sample)))
+    worst = 0.0
+    for g_, r_ in zip(got, ref):
+        g2, r2 = g_.reshape(T * len(sample), -1), r_.reshape(T * len(sample), -1)
+        worst = max(worst, float(np.max(np.max(np.abs(g2 - r2), axis=1) / np.max(np.abs(r2), axis=1))))
+    assert worst < 1e-10, f"parity vs oracle failed: {worst}"
+
+    if rank == 0:
+        units = float(N) * T * world * args.steps
+        alg_bytes = 8.0 * (m + 2 * n + 2 * n * n) * N * T + 2 * 8.0 * (n + n * n) * N   # per launch
+        achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+        out = {
+            "metric": "track-steps/sec (predict+update) at dim_x=4 dim_z=2",
+            "value": units / elapsed, "unit": "track-steps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[1]: {N} independent dim_x=4 dim_z=2 tracks x {T} steps per GPU, "
+                                   "fp64, shared F/H/Q/R, KalmanFilter.batch_filter (all 4 outputs stored)",
+                       "tracks_per_gpu": N, "T": T, "layout": layout,
+                       "parallelism": f"tracks sharded over {world} GPU(s)" + (", RCCL all-gather of final x per step" if world > 1 else "")},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "fk::kf_kernel<4,2,exact," + layout + ",shared>", "kernel_ms": kernel_ms,
+                         "algorithmic_bytes_per_launch": alg_bytes},
+            "parity_max_rel_vs_oracle": worst,
+        }
+        if world == 1 and not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(T, args.cpu_tracks_per_core)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,81 @@
+"""ctypes binding of libfilterhip.so (include/filterhip.h) -- the only way Python reaches the
+HIP kernels.  There is no fallback: if the shared library is missing or a call fails this
+module raises.
+
+Device memory, streams and torch.distributed come from PyTorch-ROCm (plumbing); torch is
+imported BEFORE the library is loaded so that both resolve the same libamdhip64.so.7 and
+device pointers / streams are interchangeable.
+"""
+import ctypes
+import os
+
+import torch  # noqa: F401  (must precede CDLL: shares the HIP runtime)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfilterhip.so")
+
+FK_OK = 0
+FK_LAYOUT_AOS, FK_LAYOUT_SOA = 0, 1
+FK_MODEL_SHARED, FK_MODEL_PER_TRACK, FK_MODEL_PER_TRACK_STEP, FK_MODEL_PER_STEP = 0, 1, 2, 3
+FK_STATUS_NOT_PD, FK_STATUS_NONFINITE, FK_STATUS_OVERRUN = 1, 2, 4
+
+c_i32, c_i64, c_f64, c_vp, c_sz = ctypes.c_int32, ctypes.c_int64, ctypes.c_double, ctypes.c_void_p, ctypes.c_size_t
+
+
+class fk_kf_desc(ctypes.Structure):
+    _fields_ = [("n", c_i32), ("m", c_i32), ("nu", c_i32), ("model_mode", c_i32),
+                ("N", c_i64), ("T", c_i64), ("layout", c_i32), ("update_first", c_i32),
+                ("alpha_sq", c_f64)]
+
+
+class fk_ukf_desc(ctypes.Structure):
+    _fields_ = [("n", c_i32), ("m", c_i32), ("N", c_i64), ("T", c_i64), ("layout", c_i32),
+                ("reserved", c_i32), ("scale", c_f64)]
+
+
+class FilterHipError(RuntimeError):
+    pass
+
+
+# every symbol include/filterhip.h declares, with its signature
+SIGNATURES = {
+    "fk_kf_batch_filter_f64": (ctypes.c_int, [ctypes.POINTER(fk_kf_desc)] + [c_vp] * 16),
+    "fk_kf_predict_f64": (ctypes.c_int, [ctypes.POINTER(fk_kf_desc)] + [c_vp] * 8),
+    "fk_kf_update_f64": (ctypes.c_int, [ctypes.POINTER(fk_kf_desc)] + [c_vp] * 12),
+    "fk_kf_rts_f64": (ctypes.c_int, [ctypes.POINTER(fk_kf_desc)] + [c_vp] * 8 + [c_i32, c_vp, c_vp]),
+    "fk_ut_sigma_points_f64": (ctypes.c_int, [c_i32, c_i64, c_i32, c_f64, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "fk_ut_transform_f64": (ctypes.c_int, [c_i32, c_i32, c_i64, c_i32] + [c_vp] * 7),
+    "fk_ut_cross_variance_f64": (ctypes.c_int, [c_i32, c_i32, c_i32, c_i64, c_i32] + [c_vp] * 7),
+    "fk_ukf_linear_batch_f64": (ctypes.c_int, [ctypes.POINTER(fk_ukf_desc)] + [c_vp] * 14),
+    "fk_resample_systematic_f64": (ctypes.c_int, [c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "fk_resample_stratified_f64": (ctypes.c_int, [c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "fk_resample_multinomial_f64": (ctypes.c_int, [c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "fk_resample_workspace_bytes": (c_sz, [c_i64, c_i64]),
+    "fk_abi_version": (ctypes.c_int, []),
+    "fk_build_arch": (ctypes.c_char_p, []),
+    "fk_last_error": (ctypes.c_char_p, []),
+}
+
+_lib = None
+
+
+def lib():
+    """Load libfilterhip.so (once).  Raises FilterHipError if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise FilterHipError(
+                f"{LIB_PATH} not found: build it with `make -C filterpy_amd/csrc` "
+                "(or __graft_entry__.build()). filterpy_amd has no CPU fallback.")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)     # AttributeError if the library lacks a declared symbol
+            fn.restype, fn.argtypes = res, args
+        _lib = handle
+    return _lib
+
+
+def check(rc, what):
+    if rc != FK_OK:
+        msg = lib().fk_last_error().decode(errors="replace")
+        raise FilterHipError(f"{what} failed with code {rc}: {msg}")

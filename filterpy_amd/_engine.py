@@ -1,0 +1,171 @@
+"""Thin Python layer over the C ABI: device buffers (torch tensors as plain HBM allocations),
+argument marshalling and status handling.  All arithmetic happens in libfilterhip.so.
+
+Record layouts (see include/filterhip.h): 'aos' = NumPy C order [..][N][E], 'soa' =
+lane-coalesced [..][E][N].  Every function here takes/returns torch CUDA tensors of dtype
+float64 already in the requested layout; `to_records`/`from_records` convert NumPy arrays.
+"""
+import numpy as np
+import torch
+
+from . import _abi
+from ._abi import (FK_LAYOUT_AOS, FK_LAYOUT_SOA, FK_MODEL_SHARED, FK_MODEL_PER_TRACK,
+                   FK_MODEL_PER_TRACK_STEP, FK_MODEL_PER_STEP, fk_kf_desc, fk_ukf_desc)
+
+LAYOUTS = {"aos": FK_LAYOUT_AOS, "soa": FK_LAYOUT_SOA}
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise _abi.FilterHipError("filterpy_amd needs an AMD GPU (torch.cuda.is_available() is False); "
+                                  "there is no CPU path")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def dev(a, device=None):
+    """NumPy/torch -> contiguous float64 tensor on the current GPU."""
+    device = device or require_gpu()
+    if isinstance(a, torch.Tensor):
+        return a.to(device=device, dtype=torch.float64).contiguous()
+    return torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64), device=device)
+
+
+def to_records(a, layout, lead):
+    """Host array shaped lead + (N,) + rec  ->  device tensor in `layout`.
+
+    `lead` = number of leading (time) axes (0 or 1).  For 'soa' the track axis is moved
+    behind the flattened record axis."""
+    t = dev(a)
+    if layout == "aos":
+        return t
+    shp = t.shape
+    N = shp[lead]
+    t = t.reshape(*shp[:lead], N, -1)
+    return t.transpose(-1, -2).contiguous()
+
+
+def from_records(t, layout, lead, rec_shape):
+    """Device tensor in `layout` -> host NumPy array lead + (N,) + rec_shape (zero-copy view of
+    the downloaded buffer for 'soa': a transposed view, as the API docs describe)."""
+    h = t.cpu().numpy()
+    if layout == "aos":
+        return h.reshape(*h.shape[:lead], -1, *rec_shape) if rec_shape else h
+    # [lead][E][N] -> [lead][N][E]
+    h = np.swapaxes(h.reshape(*h.shape[:lead], -1, h.shape[-1]), -1, -2)
+    return h.reshape(*h.shape[:lead + 1], *rec_shape)
+
+
+def alloc_records(lead_shape, N, E, layout, device=None):
+    device = device or require_gpu()
+    shape = (*lead_shape, N, E) if layout == "aos" else (*lead_shape, E, N)
+    return torch.empty(shape, dtype=torch.float64, device=device)
+
+
+def raise_on_status(status, what):
+    """Map per-track status bits to the exception the reference would raise."""
+    if status is None:
+        return
+    bad = status.nonzero()
+    if bad.numel() == 0:
+        return
+    first = int(bad[0])
+    bits = int(status[first])
+    if bits & _abi.FK_STATUS_NOT_PD:
+        raise np.linalg.LinAlgError(
+            f"{what}: matrix not positive definite / singular for {bad.numel()} track(s), first = {first}")
+    if bits & _abi.FK_STATUS_NONFINITE:
+        raise FloatingPointError(f"{what}: non-finite state for {bad.numel()} track(s), first = {first}")
+
+
+def kf_batch_filter(desc_kw, F, Q, H, R, z, x, P, *, B=None, u=None, mask=None,
+                    means=None, covs=None, means_p=None, covs_p=None, status=None):
+    """fk_kf_batch_filter_f64.  desc_kw: n, m, nu, model_mode, N, T, layout, update_first, alpha_sq."""
+    d = fk_kf_desc(**desc_kw)
+    rc = _abi.lib().fk_kf_batch_filter_f64(d, _ptr(F), _ptr(Q), _ptr(H), _ptr(R), _ptr(B), _ptr(u),
+                                           _ptr(z), _ptr(mask), _ptr(x), _ptr(P), _ptr(means), _ptr(covs),
+                                           _ptr(means_p), _ptr(covs_p), _ptr(status), _stream())
+    _abi.check(rc, "fk_kf_batch_filter_f64")
+
+
+def kf_predict(desc_kw, F, Q, x, P, *, B=None, u=None, status=None):
+    d = fk_kf_desc(**desc_kw)
+    rc = _abi.lib().fk_kf_predict_f64(d, _ptr(F), _ptr(Q), _ptr(B), _ptr(u), _ptr(x), _ptr(P),
+                                      _ptr(status), _stream())
+    _abi.check(rc, "fk_kf_predict_f64")
+
+
+def kf_update(desc_kw, H, R, z, x, P, *, mask=None, y=None, K=None, S=None, SI=None, status=None):
+    d = fk_kf_desc(**desc_kw)
+    rc = _abi.lib().fk_kf_update_f64(d, _ptr(H), _ptr(R), _ptr(z), _ptr(mask), _ptr(x), _ptr(P),
+                                     _ptr(y), _ptr(K), _ptr(S), _ptr(SI), _ptr(status), _stream())
+    _abi.check(rc, "fk_kf_update_f64")
+
+
+def kf_rts(desc_kw, F, Q, Xs, Ps, xs, Ps_out, K, Pp, *, convention=0, status=None):
+    d = fk_kf_desc(**desc_kw)
+    rc = _abi.lib().fk_kf_rts_f64(d, _ptr(F), _ptr(Q), _ptr(Xs), _ptr(Ps), _ptr(xs), _ptr(Ps_out),
+                                  _ptr(K), _ptr(Pp), int(convention), _ptr(status), _stream())
+    _abi.check(rc, "fk_kf_rts_f64")
+
+
+def ut_sigma_points(n, N, layout, scale, x, P, sigmas, status=None):
+    rc = _abi.lib().fk_ut_sigma_points_f64(n, N, LAYOUTS[layout], float(scale), _ptr(x), _ptr(P),
+                                           _ptr(sigmas), _ptr(status), _stream())
+    _abi.check(rc, "fk_ut_sigma_points_f64")
+
+
+def ut_transform(n, k, N, layout, sigmas, Wm, Wc, noise, x_out, P_out):
+    rc = _abi.lib().fk_ut_transform_f64(n, k, N, LAYOUTS[layout], _ptr(sigmas), _ptr(Wm), _ptr(Wc),
+                                        _ptr(noise), _ptr(x_out), _ptr(P_out), _stream())
+    _abi.check(rc, "fk_ut_transform_f64")
+
+
+def ut_cross_variance(n, m, k, N, layout, x, z, sigmas_f, sigmas_h, Wc, Pxz):
+    rc = _abi.lib().fk_ut_cross_variance_f64(n, m, k, N, LAYOUTS[layout], _ptr(x), _ptr(z), _ptr(sigmas_f),
+                                             _ptr(sigmas_h), _ptr(Wc), _ptr(Pxz), _stream())
+    _abi.check(rc, "fk_ut_cross_variance_f64")
+
+
+def ukf_linear_batch(n, m, N, T, layout, scale, F, H, Q, R, Wm, Wc, z, x, P, *, mask=None,
+                     means=None, covs=None, status=None):
+    d = fk_ukf_desc(n=n, m=m, N=N, T=T, layout=LAYOUTS[layout], reserved=0, scale=float(scale))
+    rc = _abi.lib().fk_ukf_linear_batch_f64(d, _ptr(F), _ptr(H), _ptr(Q), _ptr(R), _ptr(Wm), _ptr(Wc),
+                                            _ptr(z), _ptr(mask), _ptr(x), _ptr(P), _ptr(means), _ptr(covs),
+                                            _ptr(status), _stream())
+    _abi.check(rc, "fk_ukf_linear_batch_f64")
+
+
+def resample_workspace_bytes(Fn, Np):
+    return int(_abi.lib().fk_resample_workspace_bytes(Fn, Np))
+
+
+def _resample(fn_name, Fn, Np, w, u, idx, status):
+    nbytes = resample_workspace_bytes(Fn, Np)
+    ws = torch.empty(max(nbytes, 8), dtype=torch.uint8, device=w.device)
+    rc = getattr(_abi.lib(), fn_name)(Fn, Np, _ptr(w), _ptr(u), _ptr(idx), _ptr(status), _ptr(ws), nbytes,
+                                      _stream())
+    _abi.check(rc, fn_name)
+
+
+def resample_systematic(Fn, Np, w, u, idx, status=None):
+    _resample("fk_resample_systematic_f64", Fn, Np, w, u, idx, status)
+
+
+def resample_stratified(Fn, Np, w, u, idx, status=None):
+    _resample("fk_resample_stratified_f64", Fn, Np, w, u, idx, status)
+
+
+def resample_multinomial(Fn, Np, Nu, w, u, idx):
+    nbytes = resample_workspace_bytes(Fn, Np)
+    ws = torch.empty(max(nbytes, 8), dtype=torch.uint8, device=w.device)
+    rc = _abi.lib().fk_resample_multinomial_f64(Fn, Np, Nu, _ptr(w), _ptr(u), _ptr(idx), _ptr(ws), nbytes,
+                                                _stream())
+    _abi.check(rc, "fk_resample_multinomial_f64")

@@ -1,0 +1,158 @@
+// hostcheck.cpp -- TEST-ONLY harness: compiles the per-track arithmetic of the HIP kernels
+// (filterpy_amd/csrc/fk_math.hpp, the same templates the gfx950 kernels instantiate) for the
+// HOST with g++, so the build container (no GPU) can check the arithmetic against the oracle
+// and the goldens before any GPU time is spent.  It is never loaded by filterpy_amd/ and is not
+// part of libfilterhip.so: the product has no CPU path.
+#include <stdint.h>
+#include <string.h>
+
+#include "../../filterpy_amd/csrc/fk_math.hpp"
+
+using namespace fk;
+
+// pad an r x c matrix into ROWS x COLS (diag_pad on the padded diagonal)
+template <int ROWS, int COLS>
+static void pad(double (&M)[ROWS * COLS], const double *src, int r, int c, double diag_pad)
+{
+    for (int a = 0; a < ROWS; ++a)
+        for (int b = 0; b < COLS; ++b)
+            M[a * COLS + b] = (a < r && b < c) ? src[a * c + b] : (a == b ? diag_pad : 0.0);
+}
+template <int ROWS, int COLS>
+static void unpad(const double (&M)[ROWS * COLS], double *dst, int r, int c)
+{
+    for (int a = 0; a < r; ++a)
+        for (int b = 0; b < c; ++b) dst[a * c + b] = M[a * COLS + b];
+}
+
+// One track, T steps, shared model; mirrors kf_kernel's control flow.
+template <int NX, int NZ>
+static int kf_batch(int n, int m, long T, const double *F, const double *Q, const double *H, const double *R,
+                    const double *z, const uint8_t *mask, double *x0, double *P0, double *means, double *covs,
+                    double *means_p, double *covs_p, double alpha_sq, int update_first)
+{
+    RegModel<NX, NZ> M;
+    pad<NX, NX>(M.F, F, n, n, 1.0);
+    pad<NX, NX>(M.Q, Q, n, n, 0.0);
+    pad<NZ, NX>(M.H, H, m, n, 0.0);
+    pad<NZ, NZ>(M.R, R, m, m, 1.0);
+    double x[NX], P[NX * NX];
+    pad<NX, 1>(x, x0, n, 1, 0.0);
+    pad<NX, NX>(P, P0, n, n, 1.0);
+    int st = 0;
+    for (long t = 0; t < T; ++t) {
+        double zz[NZ];
+        pad<NZ, 1>(zz, z + t * m, m, 1, 0.0);
+        const bool has_z = !mask || mask[t];
+        for (int phase = 0; phase < 2; ++phase) {
+            const bool is_predict = (phase == 0) != (update_first != 0);
+            if (is_predict) {
+                kf_predict<NX>(x, P, M, alpha_sq);
+                unpad<NX, 1>(x, means_p + t * n, n, 1);
+                unpad<NX, NX>(P, covs_p + t * n * n, n, n);
+            } else {
+                if (has_z) {
+                    double K[NX * NZ], y[NZ], S[NZ * NZ], Lf[NZ * NZ], dinv[NZ];
+                    st |= kf_update<NX, NZ>(x, P, zz, M, K, y, S, Lf, dinv);
+                }
+                unpad<NX, 1>(x, means + t * n, n, 1);
+                unpad<NX, NX>(P, covs + t * n * n, n, n);
+            }
+        }
+    }
+    unpad<NX, 1>(x, x0, n, 1);
+    unpad<NX, NX>(P, P0, n, n);
+    return st;
+}
+
+template <int NX>
+static int rts(int n, long T, const double *F, const double *Q, const double *Xs, const double *Ps, double *xs,
+               double *Pso, double *Ko, double *Ppo)
+{
+    RegModel<NX, 1> M;
+    pad<NX, NX>(M.F, F, n, n, 1.0);
+    pad<NX, NX>(M.Q, Q, n, n, 0.0);
+    double xn[NX], Pn[NX * NX];
+    pad<NX, 1>(xn, Xs + (T - 1) * n, n, 1, 0.0);
+    pad<NX, NX>(Pn, Ps + (T - 1) * n * n, n, n, 1.0);
+    unpad<NX, 1>(xn, xs + (T - 1) * n, n, 1);
+    unpad<NX, NX>(Pn, Pso + (T - 1) * n * n, n, n);
+    unpad<NX, NX>(Pn, Ppo + (T - 1) * n * n, n, n);
+    memset(Ko + (T - 1) * n * n, 0, sizeof(double) * n * n);
+    int st = 0;
+    for (long k = T - 2; k >= 0; --k) {
+        double x[NX], P[NX * NX], K[NX * NX], Pp[NX * NX];
+        pad<NX, 1>(x, Xs + k * n, n, 1, 0.0);
+        pad<NX, NX>(P, Ps + k * n * n, n, n, 1.0);
+        st |= rts_step<NX>(x, P, xn, Pn, M, K, Pp);
+        unpad<NX, 1>(x, xs + k * n, n, 1);
+        unpad<NX, NX>(P, Pso + k * n * n, n, n);
+        unpad<NX, NX>(K, Ko + k * n * n, n, n);
+        unpad<NX, NX>(Pp, Ppo + k * n * n, n, n);
+        for (int i = 0; i < NX; ++i) xn[i] = x[i];
+        for (int i = 0; i < NX * NX; ++i) Pn[i] = P[i];
+    }
+    return st;
+}
+
+template <int NX>
+static int sigma(int n, double scale, const double *x0, const double *P0, double *sig)
+{
+    double x[NX], P[NX * NX], L[NX * NX];
+    pad<NX, 1>(x, x0, n, 1, 0.0);
+    pad<NX, NX>(P, P0, n, n, 1.0 / scale);
+    const bool pd = chol_lower<NX>(P, scale, L);
+    for (int c = 0; c < n; ++c) sig[c] = x[c];
+    for (int k = 0; k < n; ++k)
+        for (int c = 0; c < n; ++c) {
+            sig[(k + 1) * n + c] = x[c] - (-L[c * NX + k]);
+            sig[(n + k + 1) * n + c] = x[c] - L[c * NX + k];
+        }
+    return pd ? 0 : ST_NOT_PD;
+}
+
+#define BY_DIMS(n, m, CALL)                                   \
+    if ((n) == 1 && (m) == 1) return CALL(1, 1);              \
+    if ((n) == 2 && (m) == 1) return CALL(2, 1);              \
+    if ((n) == 4 && (m) == 2) return CALL(4, 2);              \
+    if ((n) == 6 && (m) == 3) return CALL(6, 3);              \
+    if ((n) == 9 && (m) == 3) return CALL(9, 3);              \
+    if ((n) <= 2 && (m) <= 2) return CALL(2, 2);              \
+    if ((n) <= 4 && (m) <= 4) return CALL(4, 4);              \
+    if ((n) <= 6 && (m) <= 6) return CALL(6, 6);              \
+    if ((n) <= 8 && (m) <= 4) return CALL(8, 4);              \
+    return CALL(16, 8);
+
+extern "C" {
+
+int hc_kf_batch(int n, int m, long T, const double *F, const double *Q, const double *H, const double *R,
+                const double *z, const uint8_t *mask, double *x0, double *P0, double *means, double *covs,
+                double *means_p, double *covs_p, double alpha_sq, int update_first)
+{
+#define CALL(NX, NZ) kf_batch<NX, NZ>(n, m, T, F, Q, H, R, z, mask, x0, P0, means, covs, means_p, covs_p, alpha_sq, update_first)
+    BY_DIMS(n, m, CALL)
+#undef CALL
+}
+
+int hc_rts(int n, long T, const double *F, const double *Q, const double *Xs, const double *Ps, double *xs,
+           double *Pso, double *Ko, double *Ppo)
+{
+    if (n == 1) return rts<1>(n, T, F, Q, Xs, Ps, xs, Pso, Ko, Ppo);
+    if (n == 2) return rts<2>(n, T, F, Q, Xs, Ps, xs, Pso, Ko, Ppo);
+    if (n <= 3) return rts<3>(n, T, F, Q, Xs, Ps, xs, Pso, Ko, Ppo);
+    if (n == 4) return rts<4>(n, T, F, Q, Xs, Ps, xs, Pso, Ko, Ppo);
+    if (n == 6) return rts<6>(n, T, F, Q, Xs, Ps, xs, Pso, Ko, Ppo);
+    if (n <= 8) return rts<8>(n, T, F, Q, Xs, Ps, xs, Pso, Ko, Ppo);
+    if (n == 9) return rts<9>(n, T, F, Q, Xs, Ps, xs, Pso, Ko, Ppo);
+    return rts<16>(n, T, F, Q, Xs, Ps, xs, Pso, Ko, Ppo);
+}
+
+int hc_sigma(int n, double scale, const double *x, const double *P, double *sig)
+{
+    if (n <= 2) return sigma<2>(n, scale, x, P, sig);
+    if (n <= 4) return sigma<4>(n, scale, x, P, sig);
+    if (n <= 6) return sigma<6>(n, scale, x, P, sig);
+    if (n <= 8) return sigma<8>(n, scale, x, P, sig);
+    return sigma<16>(n, scale, x, P, sig);
+}
+}

@@ -1,0 +1,158 @@
+"""-m gpu parity tests: the HIP Kalman kernels, called through the C ABI, against the goldens
+frozen from the live reference and against the NumPy oracle on seeded random banks."""
+import numpy as np
+import pytest
+
+from conftest import golden, rel_err_rows
+from oracle import kf_oracle
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-10      # BASELINE.json north_star: x/P within 1e-10 rel fp64 (normwise per matrix)
+DIMS = [tuple(d) for d in golden("kf_dims")["dims"]]
+NTRK = 300       # two workgroups, the second partially filled
+
+
+def _per_track(a):
+    """(T,N,...) -> worst normwise error helper expects leading axis = samples"""
+    return a.reshape((-1,) + a.shape[2:])
+
+
+@pytest.mark.parametrize("layout", ["soa", "aos"])
+@pytest.mark.parametrize("n,m", DIMS)
+def test_batch_filter_goldens(n, m, layout):
+    from gpu_util import run_kf_batch, tile_tracks
+    g = golden("kf_dims")
+    p = f"n{n}m{m}_"
+    for variant in ("plain", "uf", "alpha", "miss", "ctrl"):
+        kw = {}
+        if variant == "uf":
+            kw["update_first"] = True
+        if variant == "alpha":
+            kw["alpha_sq"] = 1.02 ** 2
+        if variant == "miss":
+            kw["mask"] = tile_tracks(g[p + "mask"], NTRK, 1)
+        if variant == "ctrl":
+            kw["B"] = g[p + "B"]
+            kw["us"] = tile_tracks(g[p + "us"], NTRK, 1)
+        mu, cov, mup, covp, xf, Pf, st = run_kf_batch(
+            tile_tracks(g[p + "x0"], NTRK), tile_tracks(g[p + "P0"], NTRK), tile_tracks(g[p + "zs"], NTRK, 1),
+            g[p + "F"], g[p + "Q"], g[p + "H"], g[p + "R"], layout=layout, **kw)
+        for got, key in ((mu, "mu"), (cov, "cov"), (mup, "mup"), (covp, "covp")):
+            ref = g[p + variant + "_" + key]
+            for trk in (0, 63, 64, 255, 256, NTRK - 1):
+                assert rel_err_rows(got[:, trk], ref) < TOL, (variant, key, trk)
+            # every track saw the same inputs -> identical bits
+            assert np.array_equal(got, np.broadcast_to(got[:, :1], got.shape)), (variant, key)
+        if variant != "miss":
+            assert rel_err_rows(xf[:1], g[p + variant + "_xfinal"].reshape(1, -1)) < TOL
+            assert rel_err_rows(Pf[:1], g[p + variant + "_Pfinal"][None]) < TOL
+
+
+@pytest.mark.parametrize("layout", ["soa", "aos"])
+@pytest.mark.parametrize("n,m", [(2, 1), (4, 2), (6, 3), (9, 3)])
+def test_batch_filter_per_step_models(n, m, layout):
+    """Fs/Qs/Hs/Rs lists (kalman_filter.py:941-952): PER_STEP (shared) and PER_TRACK_STEP."""
+    from gpu_util import run_kf_batch, tile_tracks
+    from filterpy_amd._abi import FK_MODEL_PER_STEP, FK_MODEL_PER_TRACK_STEP
+    g = golden("kf_models")
+    p = f"n{n}m{m}_"
+    N = 130
+    x0, P0, zs = tile_tracks(g[p + "x0"], N), tile_tracks(g[p + "P0"], N), tile_tracks(g[p + "zs"], N, 1)
+    for mode in (FK_MODEL_PER_STEP, FK_MODEL_PER_TRACK_STEP):
+        mods = [g[p + k] for k in ("Fs", "Qs", "Hs", "Rs")]
+        if mode == FK_MODEL_PER_TRACK_STEP:
+            mods = [tile_tracks(M, N, 1) for M in mods]
+        mu, cov, mup, covp, *_ = run_kf_batch(x0, P0, zs, *mods, layout=layout, mode=mode)
+        for got, key in ((mu, "mu"), (cov, "cov"), (mup, "mup"), (covp, "covp")):
+            for trk in (0, 64, N - 1):
+                assert rel_err_rows(got[:, trk], g[p + key]) < TOL, (mode, key, trk)
+
+
+@pytest.mark.parametrize("layout", ["soa", "aos"])
+@pytest.mark.parametrize("n,m", [(2, 1), (4, 2), (3, 2), (6, 3)])
+def test_batch_filter_random_bank_vs_oracle(n, m, layout):
+    """Every track different (x0, P0, z, and per-track models) against the NumPy oracle."""
+    from gpu_util import run_kf_batch
+    from filterpy_amd._abi import FK_MODEL_PER_TRACK, FK_MODEL_SHARED
+    rs = np.random.RandomState(100 * n + m)
+    N, T = 777, 25
+
+    def spd(k, s):
+        A = rs.randn(N, k, k)
+        return s * (A @ A.transpose(0, 2, 1) / k + 0.5 * np.eye(k))
+    x0, P0 = rs.randn(N, n), spd(n, 5.0)
+    zs = rs.randn(T, N, m) * 3
+    F = np.eye(n) + 0.1 * rs.randn(N, n, n)
+    Q, H, R = spd(n, 0.1), rs.randn(N, m, n), spd(m, 0.5)
+    mask = rs.rand(T, N) > 0.2
+    sample = [0, 1, 63, 64, 255, 256, 511, 512, N - 1]
+    for mode in (FK_MODEL_SHARED, FK_MODEL_PER_TRACK):
+        mods = (F, Q, H, R) if mode == FK_MODEL_PER_TRACK else (F[0], Q[0], H[0], R[0])
+        got = run_kf_batch(x0, P0, zs, *mods, layout=layout, mode=mode, mask=mask)
+        ref = kf_oracle.kf_batch_filter_tracks(x0, P0, zs, *mods, tracks=sample,
+                                               model_mode=1 if mode == FK_MODEL_PER_TRACK else 0, mask=mask)
+        for k in range(4):
+            assert rel_err_rows(_per_track(got[k][:, sample]), _per_track(ref[k])) < TOL, (mode, k)
+
+
+@pytest.mark.parametrize("layout", ["soa", "aos"])
+@pytest.mark.parametrize("n,m", DIMS)
+def test_rts_goldens(n, m, layout):
+    from gpu_util import run_rts, tile_tracks
+    g = golden("kf_dims")
+    p = f"n{n}m{m}_"
+    N = 100
+    Xs, Ps = tile_tracks(g[p + "plain_mu"], N, 1), tile_tracks(g[p + "plain_cov"], N, 1)
+    out = run_rts(Xs, Ps, g[p + "F"], g[p + "Q"], layout=layout)
+    for got, key in zip(out, ("rts_x", "rts_P", "rts_K", "rts_Pp")):
+        for trk in (0, 64, N - 1):
+            assert rel_err_rows(got[:, trk], g[p + key]) < 1e-9, (key, trk)
+
+
+@pytest.mark.parametrize("n,m", [(2, 1), (4, 2), (9, 3)])
+def test_rts_index_conventions(n, m):
+    """class method uses F[k+1],Q[k+1] (kalman_filter.py:1067); module function F[k],Q[k] (:1851)."""
+    from gpu_util import run_rts, tile_tracks
+    from filterpy_amd._abi import FK_MODEL_PER_STEP
+    g = golden("kf_models")
+    p = f"n{n}m{m}_"
+    N = 70
+    for conv, src, pre in ((0, "", "rts_"), (1, "mod_", "rtsm_")):
+        Xs, Ps = tile_tracks(g[p + src + "mu"], N, 1), tile_tracks(g[p + src + "cov"], N, 1)
+        out = run_rts(Xs, Ps, g[p + "Fs"], g[p + "Qs"], mode=FK_MODEL_PER_STEP, convention=conv)
+        for got, key in zip(out, ("x", "P", "K", "Pp")):
+            assert rel_err_rows(got[:, 5], g[p + pre + key]) < 1e-9, (conv, key)
+
+
+def test_status_flags_non_pd():
+    """S not positive definite -> status bit instead of a fault (the reference raises LinAlgError)."""
+    from gpu_util import run_kf_batch
+    N, T = 70, 3
+    x0, P0 = np.zeros((N, 2)), np.tile(np.eye(2), (N, 1, 1))
+    P0[7] = -np.eye(2)           # makes S = H P H' + R negative for track 7
+    zs = np.ones((T, N, 1))
+    out = run_kf_batch(x0, P0, zs, np.eye(2), np.zeros((2, 2)), np.array([[1., 0.]]), np.array([[0.5]]),
+                       check_status=False)
+    st = out[-1]
+    assert st[7] & 1 == 0        # 1x1 S = -0.5 is invertible: NOT flagged (numpy.linalg.inv works too)
+    P0[7] = np.zeros((2, 2))
+    out = run_kf_batch(x0, P0, zs, np.eye(2), np.zeros((2, 2)), np.array([[1., 0.]]), np.array([[0.0]]),
+                       check_status=False)
+    st = out[-1]
+    assert st[7] != 0 and not st[np.arange(N) != 7].any()
+
+
+def test_c2_shape_sample_vs_oracle():
+    """BASELINE config 2 model at reduced N: constant-velocity 2-D, 100 steps, sample vs oracle."""
+    from gpu_util import run_kf_batch
+    from bench import c2_model, c2_inputs
+    N, T = 70001, 100
+    F, Q, H, R = c2_model()
+    x0, P0, zs = c2_inputs(N, T, seed=1)
+    for layout in ("soa", "aos"):
+        got = run_kf_batch(x0, P0, zs, F, Q, H, R, layout=layout)
+        sample = [0, 1, 255, 256, 4095, 4096, 65535, 65536, N - 1]
+        ref = kf_oracle.kf_batch_filter_tracks(x0, P0, zs, F, Q, H, R, tracks=sample)
+        for k in range(4):
+            assert rel_err_rows(_per_track(got[k][:, sample]), _per_track(ref[k])) < TOL, (layout, k)

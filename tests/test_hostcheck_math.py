@@ -1,0 +1,99 @@
+"""The per-track arithmetic of the HIP kernels (filterpy_amd/csrc/fk_math.hpp), compiled for the
+host by the test-only harness tests/hostcheck, against the goldens generated from the live
+reference.  Runs in the GPU-less build container; the same templates are instantiated by the
+gfx950 kernels (tests/test_gpu_*.py check those on the GPU box)."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, golden, rel_err_rows
+
+TOL = 1e-10   # BASELINE.json: x/P within 1e-10 rel fp64
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = ctypes.CDLL(os.path.join(ROOT, "tests", "hostcheck", "libhostcheck.so"))
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p) if a is not None else None
+
+
+def hc_batch(x0, P0, zs, F, Q, H, R, mask=None, alpha_sq=1.0, update_first=False):
+    n, m = F.shape[0], H.shape[0]
+    T = zs.shape[0]
+    c = np.ascontiguousarray
+    x, P = c(x0, dtype=float).copy(), c(P0, dtype=float).copy()
+    mu, cov = np.zeros((T, n)), np.zeros((T, n, n))
+    mup, covp = np.zeros((T, n)), np.zeros((T, n, n))
+    mk = None if mask is None else c(mask, dtype=np.uint8)
+    st = lib().hc_kf_batch(n, m, ctypes.c_long(T), _p(c(F)), _p(c(Q)), _p(c(H)), _p(c(R)), _p(c(zs)), _p(mk),
+                           _p(x), _p(P), _p(mu), _p(cov), _p(mup), _p(covp),
+                           ctypes.c_double(alpha_sq), int(update_first))
+    return mu, cov, mup, covp, x, P, st
+
+
+def hc_rts(Xs, Ps, F, Q):
+    T, n = Xs.shape
+    c = np.ascontiguousarray
+    xs, Pso, K, Pp = np.zeros((T, n)), np.zeros((T, n, n)), np.zeros((T, n, n)), np.zeros((T, n, n))
+    st = lib().hc_rts(n, ctypes.c_long(T), _p(c(F)), _p(c(Q)), _p(c(Xs)), _p(c(Ps)), _p(xs), _p(Pso), _p(K), _p(Pp))
+    return xs, Pso, K, Pp, st
+
+
+DIMS = [tuple(d) for d in golden("kf_dims")["dims"]]
+
+
+@pytest.mark.parametrize("n,m", DIMS)
+@pytest.mark.parametrize("variant", ["plain", "uf", "alpha", "miss"])
+def test_kf_batch_vs_golden(n, m, variant):
+    g = golden("kf_dims")
+    p = f"n{n}m{m}_"
+    kw = {}
+    if variant == "uf":
+        kw["update_first"] = True
+    if variant == "alpha":
+        kw["alpha_sq"] = 1.02 ** 2
+    if variant == "miss":
+        kw["mask"] = g[p + "mask"]
+    mu, cov, mup, covp, xf, Pf, st = hc_batch(g[p + "x0"], g[p + "P0"], g[p + "zs"], g[p + "F"], g[p + "Q"],
+                                              g[p + "H"], g[p + "R"], **kw)
+    assert st == 0
+    for got, key in ((mu, "mu"), (cov, "cov"), (mup, "mup"), (covp, "covp")):
+        assert rel_err_rows(got, g[p + variant + "_" + key]) < TOL, key
+
+
+@pytest.mark.parametrize("n,m", DIMS)
+def test_rts_vs_golden(n, m):
+    g = golden("kf_dims")
+    p = f"n{n}m{m}_"
+    xs, Ps, K, Pp, st = hc_rts(g[p + "plain_mu"], g[p + "plain_cov"], g[p + "F"], g[p + "Q"])
+    assert st == 0
+    for got, key in ((xs, "rts_x"), (Ps, "rts_P"), (K, "rts_K"), (Pp, "rts_Pp")):
+        assert rel_err_rows(got, g[p + key]) < 1e-9, key   # n x n solve: cond(Pp) enters
+
+
+def test_c1_vs_golden():
+    g = golden("kf_c1")
+    mu, cov, mup, covp, *_ = hc_batch(np.zeros(2), g["P0"], g["zs"].reshape(-1, 1), g["F"], g["Q"], g["H"], g["R"])
+    for got, key in ((mu, "mu"), (cov, "cov"), (mup, "mup"), (covp, "covp")):
+        assert rel_err_rows(got, g["1d_" + key]) < TOL
+
+
+def test_sigma_points_vs_golden():
+    g = golden("ukf_merwe")
+    for ci, (n, m, alpha, beta, kappa) in enumerate(g["cases"]):
+        n = int(n)
+        lam = alpha ** 2 * (n + kappa) - n
+        sig = np.zeros((2 * n + 1, n))
+        x0, P0 = np.ascontiguousarray(g[f"c{ci}_x0"]), np.ascontiguousarray(g[f"c{ci}_P0"])
+        st = lib().hc_sigma(n, ctypes.c_double(lam + n), _p(x0), _p(P0), _p(sig))
+        assert st == 0
+        assert rel_err_rows(sig, g[f"c{ci}_sigmas"]) < 1e-12
