@@ -11,6 +11,7 @@ struct KfArgs {
     double *y_out, *K_out, *S_out, *SI_out;   // single-step update() extras (T == 1)
     int32_t *status;
     long N, T;
+    long i0, cnt;       // this launch handles tracks [i0, i0+cnt); N stays the array stride
     int n, m, nu;
     int model_t;        // 1: model records advance with the time step
     int update_first;

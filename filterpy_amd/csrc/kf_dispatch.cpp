@@ -7,6 +7,7 @@
 // fk_kf_rts_f64          <- KalmanFilter.rts_smoother  (:995-1074), module rts_smoother (:1792-1858)
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "../../include/filterhip.h"
 #include "fk_device.hpp"
@@ -17,6 +18,9 @@ namespace fk {
 #define FK_KF_INST(NX, NZ, EX) int launch_kf_##NX##_##NZ##_##EX(const KfArgs &, int, bool, hipStream_t);
 #include "fk_dims.def"
 #undef FK_KF_INST
+#define FK_FAST_INST(NX, NZ, V, W) int launch_kf_fast_##NX##_##NZ##_v##V(const KfArgs &, int, bool, hipStream_t);
+#include "fk_dims_fast.def"
+#undef FK_FAST_INST
 #define FK_RTS_INST(NX, EX) int launch_rts_##NX##_##EX(const RtsArgs &, int, bool, hipStream_t);
 #include "fk_dims_rts.def"
 #undef FK_RTS_INST
@@ -30,6 +34,30 @@ static const KfEntry kf_table[] = {
 #include "fk_dims.def"
 #undef FK_KF_INST
 };
+
+struct FastEntry {
+    int nx, nz, variant;
+    int (*fn)(const KfArgs &, int, bool, hipStream_t);
+};
+static const FastEntry fast_table[] = {
+#define FK_FAST_INST(NX, NZ, V, W) {NX, NZ, V, launch_kf_fast_##NX##_##NZ##_v##V},
+#include "fk_dims_fast.def"
+#undef FK_FAST_INST
+};
+
+static const FastEntry *pick_fast(int n, int m)
+{
+    // FK_FAST_VARIANT selects a tuning variant (A/B measurements); default 0
+    const char *ev = getenv("FK_FAST_VARIANT");
+    const int want = ev ? atoi(ev) : 0;
+    const FastEntry *dflt = nullptr;
+    for (const FastEntry &e : fast_table) {
+        if (e.nx != n || e.nz != m) continue;
+        if (e.variant == want) return &e;
+        if (e.variant == 0) dflt = &e;
+    }
+    return dflt;
+}
 
 struct RtsEntry {
     int nx, exact;
@@ -109,6 +137,26 @@ static int run_kf(const fk_kf_desc *d, KfArgs &a, void *stream)
     a.update_first = d->update_first;
     a.alpha_sq = d->alpha_sq;
     const bool uniform = (d->model_mode == FK_MODEL_SHARED || d->model_mode == FK_MODEL_PER_STEP);
+    a.i0 = 0;
+    a.cnt = d->N;
+    // Specialised kernel (kf_fast.hip) for the common batch_filter call: one shared constant
+    // model, predict->update, no control input, all four outputs stored or none.  It runs on whole
+    // workgroups; the < BLOCK-track remainder goes through the generic kernel.
+    const bool all_out = a.means && a.covs && a.means_p && a.covs_p;
+    const bool no_out = !a.means && !a.covs && !a.means_p && !a.covs_p;
+    if (d->model_mode == FK_MODEL_SHARED && d->nu == 0 && !d->update_first && a.do_predict && a.do_update &&
+        (all_out || no_out) && !a.y_out && !a.K_out && !a.S_out && !a.SI_out && !getenv("FK_NO_FAST")) {
+        if (const FastEntry *f = pick_fast(d->n, d->m)) {
+            const long full = (d->N / BLOCK) * BLOCK;
+            if (full > 0) {
+                a.cnt = full;
+                if (int rc = f->fn(a, d->layout, all_out, (hipStream_t)stream)) return rc;
+            }
+            if (full == d->N) return FK_OK;
+            a.i0 = full;
+            a.cnt = d->N - full;
+        }
+    }
     return e->fn(a, d->layout, uniform, (hipStream_t)stream);
 }
 

@@ -38,12 +38,12 @@ kf_kernel(const KfArgs a,
     __shared__ double s_model[UNIFORM ? SharedModel::SIZE : 1];
 
     const long N = a.N;
-    const long blk0 = (long)blockIdx.x * BLOCK;
+    const long blk0 = a.i0 + (long)blockIdx.x * BLOCK;
     const Lane ln{blk0, threadIdx.x, N};
     // Lanes past N stay in the kernel (the shared-model refill uses workgroup barriers)
     // but never touch memory: they are redirected to the workgroup's first track for loads
     // and predicated off for stores.
-    const bool live = blk0 + ln.tid < N;
+    const bool live = blk0 + ln.tid < a.i0 + a.cnt;
     const Lane lr{blk0, live ? ln.tid : 0u, N};
     const int n = EXACT ? NX : a.n;
     const int m = EXACT ? NZ : a.m;
@@ -153,7 +153,7 @@ kf_kernel(const KfArgs a,
 template <int NX, int NZ, bool EXACT>
 static int launch(const KfArgs &a, int layout, bool uniform, hipStream_t stream)
 {
-    const dim3 grid((unsigned)((a.N + BLOCK - 1) / BLOCK)), block(BLOCK);
+    const dim3 grid((unsigned)((a.cnt + BLOCK - 1) / BLOCK)), block(BLOCK);
 #define FK_GO(LAY, UNI)                                                                             \
     hipLaunchKernelGGL((kf_kernel<NX, NZ, EXACT, LAY, UNI>), grid, block, 0, stream, a, a.F, a.Q, \
                        a.H, a.R, a.B, a.u, a.z, a.mask)

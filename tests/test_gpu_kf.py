@@ -137,7 +137,7 @@ def test_status_flags_non_pd():
     st = out[-1]
     assert st[7] & 1 == 0        # 1x1 S = -0.5 is invertible: NOT flagged (numpy.linalg.inv works too)
     P0[7] = np.zeros((2, 2))
-    out = run_kf_batch(x0, P0, zs, np.eye(2), np.zeros((2, 2)), np.array([[1., 0.]]), np.array([[0.0]]),
+    out = run_kf_batch(x0, P0, zs[:1], np.eye(2), np.zeros((2, 2)), np.array([[1., 0.]]), np.array([[0.0]]),
                        check_status=False)
     st = out[-1]
     assert st[7] != 0 and not st[np.arange(N) != 7].any()
