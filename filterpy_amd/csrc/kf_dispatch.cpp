@@ -140,22 +140,12 @@ static int run_kf(const fk_kf_desc *d, KfArgs &a, void *stream)
     a.i0 = 0;
     a.cnt = d->N;
     // Specialised kernel (kf_fast.hip) for the common batch_filter call: one shared constant
-    // model, predict->update, no control input, all four outputs stored or none.  It runs on whole
-    // workgroups; the < BLOCK-track remainder goes through the generic kernel.
+    // model, predict->update, no control input, all four outputs stored or none.
     const bool all_out = a.means && a.covs && a.means_p && a.covs_p;
     const bool no_out = !a.means && !a.covs && !a.means_p && !a.covs_p;
     if (d->model_mode == FK_MODEL_SHARED && d->nu == 0 && !d->update_first && a.do_predict && a.do_update &&
         (all_out || no_out) && !a.y_out && !a.K_out && !a.S_out && !a.SI_out && !getenv("FK_NO_FAST")) {
-        if (const FastEntry *f = pick_fast(d->n, d->m)) {
-            const long full = (d->N / BLOCK) * BLOCK;
-            if (full > 0) {
-                a.cnt = full;
-                if (int rc = f->fn(a, d->layout, all_out, (hipStream_t)stream)) return rc;
-            }
-            if (full == d->N) return FK_OK;
-            a.i0 = full;
-            a.cnt = d->N - full;
-        }
+        if (const FastEntry *f = pick_fast(d->n, d->m)) return f->fn(a, d->layout, all_out, (hipStream_t)stream);
     }
     return e->fn(a, d->layout, uniform, (hipStream_t)stream);
 }

@@ -49,14 +49,16 @@ __device__ __forceinline__ void wave_lds_fence()
 }
 
 // Wave-cooperative store of one LEN-double record per lane into an AOS block:
-// lane l owns the record of track (wave_first_track + l); `rs` is the descriptor of the
-// workgroup's slab, `wave_off` the byte offset of the wave's first record in it.
+// lane l owns the record of track (block_first + wave_row0 + l); `rs` is the descriptor of the
+// workgroup's slab.  Rows past `last_row` (the block's last valid track; only in the tail
+// workgroup, where those lanes carry a duplicate of that track) are redirected onto it:
+// the same bytes are written twice instead of predicating the store.
 // The tile is written row-per-lane (row stride LEN|1 doubles: conflict-free ds_write_b64) and read
 // back in memory order, two consecutive doubles per lane per pass -> buffer_store_dwordx4,
 // 1 KiB contiguous per instruction.
 template <int LEN>
-__device__ __forceinline__ void wave_store_aos(const double (&v)[LEN], rsrc_t rs, unsigned wave_off,
-                                               double *tile, unsigned lane, unsigned nvalid)
+__device__ __forceinline__ void wave_store_aos(const double (&v)[LEN], rsrc_t rs, unsigned wave_row0,
+                                               double *tile, unsigned lane, unsigned last_row)
 {
     constexpr int LENP = LEN | 1;
     FK_UNROLL for (int e = 0; e < LEN; ++e) tile[lane * LENP + e] = v[e];
@@ -67,29 +69,28 @@ __device__ __forceinline__ void wave_store_aos(const double (&v)[LEN], rsrc_t rs
             const unsigned q = it * 128u + lane * 2u;
             const unsigned row = q / LEN, col = q % LEN;
             const double a = tile[row * LENP + col], b = tile[row * LENP + col + 1];
-            if (row < nvalid) {
-                const u32x2 ua = __builtin_bit_cast(u32x2, a), ub = __builtin_bit_cast(u32x2, b);
-                const u32x4 w = {ua.x, ua.y, ub.x, ub.y};
-                __builtin_amdgcn_raw_buffer_store_b128(w, rs, wave_off + q * 8u, 0, 0);
-            }
+            const unsigned grow = min(wave_row0 + row, last_row);
+            const u32x2 ua = __builtin_bit_cast(u32x2, a), ub = __builtin_bit_cast(u32x2, b);
+            const u32x4 w = {ua.x, ua.y, ub.x, ub.y};
+            __builtin_amdgcn_raw_buffer_store_b128(w, rs, (grow * LEN + col) * 8u, 0, 0);
         }
     } else {
         FK_UNROLL for (int it = 0; it < LEN; ++it) {
             const unsigned q = it * 64u + lane;
             const unsigned row = q / LEN, col = q % LEN;
             const double a = tile[row * LENP + col];
-            if (row < nvalid)
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, a), rs, wave_off + q * 8u, 0, 0);
+            const unsigned grow = min(wave_row0 + row, last_row);
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, a), rs, (grow * LEN + col) * 8u, 0, 0);
         }
     }
     wave_lds_fence();
 }
 
 // OUTS: true = all four outputs (means, covs, means_p, covs_p) are stored every step; false =
-// none (only the final state).  The kernel is launched on whole workgroups only (the host sends
-// the < 256-track remainder to the generic kernel), so no store is ever predicated: the number of
-// stores between a measurement load and its use is a compile-time constant and the wait for it is
-// a counted vmcnt that never drains the store queue.
+// none (only the final state).  No store is ever predicated: in the tail workgroup the lanes past
+// the last track recompute that track and write the same bytes again.  The number of stores
+// between a measurement load and its use is therefore a compile-time constant and the wait for
+// it is a counted vmcnt that never drains the store queue.
 template <int NX, int NZ, int LAYOUT, bool HAS_MASK, bool OUTS>
 __global__ void __launch_bounds__(BLOCK, fast_min_waves(NX))
 kf_fast_kernel(const KfArgs a, const double *__restrict__ pF, const double *__restrict__ pQ,
@@ -106,10 +107,11 @@ kf_fast_kernel(const KfArgs a, const double *__restrict__ pF, const double *__re
     const long N = a.N, T = a.T;
     const long blk0 = a.i0 + (long)blockIdx.x * BLOCK;
     const unsigned tid = threadIdx.x;
-    const Lane ln{blk0, tid, N};
+    const long left = a.i0 + a.cnt - blk0;                       // >= 1
+    const unsigned last_row = (unsigned)(left < BLOCK ? left : BLOCK) - 1u;
+    const Lane ln{blk0, min(threadIdx.x, last_row), N};          // tail lanes duplicate the last track
     const Lane lr = ln;
     const unsigned lane = tid & 63u, wave = tid >> 6;
-    const unsigned nvalid = 64;
     double *tile = s_mem + SharedModel::SIZE + wave * TILE;
 
     lds_fill<NX, NX>(s_mem + SharedModel::OFF_F, pF, NX, NX, 1.0, tid);
@@ -147,8 +149,8 @@ kf_fast_kernel(const KfArgs a, const double *__restrict__ pF, const double *__re
             store_rec<NX, 1, LAYOUT, true>(x, a.means_p + t * N * NX, ln, NX, 1);
             store_rec<NX, NX, LAYOUT, true>(P, a.covs_p + t * N * NX * NX, ln, NX, NX);
         } else {
-            wave_store_aos<NX>(x, make_rsrc(a.means_p + (t * N + blk0) * NX), wave * 64u * NX * 8u, tile, lane, nvalid);
-            wave_store_aos<NX * NX>(P, make_rsrc(a.covs_p + (t * N + blk0) * NX * NX), wave * 64u * NX * NX * 8u, tile, lane, nvalid);
+            wave_store_aos<NX>(x, make_rsrc(a.means_p + (t * N + blk0) * NX), wave * 64u, tile, lane, last_row);
+            wave_store_aos<NX * NX>(P, make_rsrc(a.covs_p + (t * N + blk0) * NX * NX), wave * 64u, tile, lane, last_row);
         }
         if (hc) {
             double K[NX * NZ], y[NZ], S[NZ * NZ], Lf[NZ * NZ], dinv[NZ];
@@ -159,8 +161,8 @@ kf_fast_kernel(const KfArgs a, const double *__restrict__ pF, const double *__re
             store_rec<NX, 1, LAYOUT, true>(x, a.means + t * N * NX, ln, NX, 1);
             store_rec<NX, NX, LAYOUT, true>(P, a.covs + t * N * NX * NX, ln, NX, NX);
         } else {
-            wave_store_aos<NX>(x, make_rsrc(a.means + (t * N + blk0) * NX), wave * 64u * NX * 8u, tile, lane, nvalid);
-            wave_store_aos<NX * NX>(P, make_rsrc(a.covs + (t * N + blk0) * NX * NX), wave * 64u * NX * NX * 8u, tile, lane, nvalid);
+            wave_store_aos<NX>(x, make_rsrc(a.means + (t * N + blk0) * NX), wave * 64u, tile, lane, last_row);
+            wave_store_aos<NX * NX>(P, make_rsrc(a.covs + (t * N + blk0) * NX * NX), wave * 64u, tile, lane, last_row);
         }
         FK_UNROLL for (int i = 0; i < NZ; ++i) zc[i] = zn[i];
         hc = hn;
@@ -170,7 +172,7 @@ kf_fast_kernel(const KfArgs a, const double *__restrict__ pF, const double *__re
     store_rec<NX, NX, LAYOUT, true>(P, a.P, ln, NX, NX);
     if (a.status) {
         if (!all_finite<NX>(x) || !all_finite<NX * NX>(P)) st |= ST_NONFINITE;
-        a.status[blk0 + tid] = st;
+        a.status[blk0 + ln.tid] = st;
     }
 }
 
@@ -179,11 +181,11 @@ kf_fast_kernel(const KfArgs a, const double *__restrict__ pF, const double *__re
 }  // namespace (variant)
 using namespace FK_CAT(fastv_, FK_NX, FK_NZ, FK_VARIANT);
 
-// Handles tracks [a.i0, a.i0 + a.cnt) with a.cnt a multiple of BLOCK.  outs: all four outputs
+// Handles tracks [a.i0, a.i0 + a.cnt).  outs: all four outputs
 // non-NULL (true) or all NULL (false).
 int FK_CAT(launch_kf_fast_, FK_NX, FK_NZ, FK_VARIANT)(const KfArgs &a, int layout, bool outs, hipStream_t stream)
 {
-    const dim3 grid((unsigned)(a.cnt / BLOCK)), block(BLOCK);
+    const dim3 grid((unsigned)((a.cnt + BLOCK - 1) / BLOCK)), block(BLOCK);
 #define FK_GO(LAY, MSK, OUT)                                                                               \
     hipLaunchKernelGGL((kf_fast_kernel<FK_NX, FK_NZ, LAY, MSK, OUT>), grid, block, 0, stream, a, a.F, a.Q, \
                        a.H, a.R, a.z, a.mask)
