@@ -46,10 +46,12 @@ SIGNATURES = {
     "fk_ut_sigma_points_f64": (ctypes.c_int, [c_i32, c_i64, c_i32, c_f64, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "fk_ut_transform_f64": (ctypes.c_int, [c_i32, c_i32, c_i64, c_i32] + [c_vp] * 7),
     "fk_ut_cross_variance_f64": (ctypes.c_int, [c_i32, c_i32, c_i32, c_i64, c_i32] + [c_vp] * 7),
+    "fk_ukf_correct_f64": (ctypes.c_int, [c_i32, c_i32, c_i64, c_i32] + [c_vp] * 9),
     "fk_ukf_linear_batch_f64": (ctypes.c_int, [ctypes.POINTER(fk_ukf_desc)] + [c_vp] * 14),
     "fk_resample_systematic_f64": (ctypes.c_int, [c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "fk_resample_stratified_f64": (ctypes.c_int, [c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "fk_resample_multinomial_f64": (ctypes.c_int, [c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "fk_cumsum_exact_f64": (ctypes.c_int, [c_i64, c_i64, c_vp, c_vp, c_i32, c_vp]),
     "fk_resample_workspace_bytes": (c_sz, [c_i64, c_i64]),
     "fk_abi_version": (ctypes.c_int, []),
     "fk_build_arch": (ctypes.c_char_p, []),

@@ -134,6 +134,12 @@ def ut_cross_variance(n, m, k, N, layout, x, z, sigmas_f, sigmas_h, Wc, Pxz):
     _abi.check(rc, "fk_ut_cross_variance_f64")
 
 
+def ukf_correct(n, m, N, layout, Pxz, zp, S, z, x, P, K=None, status=None):
+    rc = _abi.lib().fk_ukf_correct_f64(n, m, N, LAYOUTS[layout], _ptr(Pxz), _ptr(zp), _ptr(S), _ptr(z), _ptr(x),
+                                       _ptr(P), _ptr(K), _ptr(status), _stream())
+    _abi.check(rc, "fk_ukf_correct_f64")
+
+
 def ukf_linear_batch(n, m, N, T, layout, scale, F, H, Q, R, Wm, Wc, z, x, P, *, mask=None,
                      means=None, covs=None, status=None):
     d = fk_ukf_desc(n=n, m=m, N=N, T=T, layout=LAYOUTS[layout], reserved=0, scale=float(scale))
@@ -169,3 +175,8 @@ def resample_multinomial(Fn, Np, Nu, w, u, idx):
     rc = _abi.lib().fk_resample_multinomial_f64(Fn, Np, Nu, _ptr(w), _ptr(u), _ptr(idx), _ptr(ws), nbytes,
                                                 _stream())
     _abi.check(rc, "fk_resample_multinomial_f64")
+
+
+def cumsum_exact(Fn, Np, w, cs, force_last_one=False):
+    rc = _abi.lib().fk_cumsum_exact_f64(Fn, Np, _ptr(w), _ptr(cs), int(bool(force_last_one)), _stream())
+    _abi.check(rc, "fk_cumsum_exact_f64")

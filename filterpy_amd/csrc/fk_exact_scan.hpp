@@ -1,0 +1,94 @@
+// fk_exact_scan.hpp -- a PARALLEL prefix sum that reproduces numpy.cumsum's strictly
+// sequential fp64 add chain bit-for-bit (needed because filterpy's resamplers compare
+// positions against np.cumsum(weights): resampling.py:106,142,174 -- any re-associated
+// scan flips indices at N ~ 1e7).
+//
+// Idea.  While the running sum c stays inside one binade, every representable value is an
+// integer multiple of u = ulp(c):  c = C*u with 2^52 <= C < 2^53 (or C < 2^52 for
+// subnormal c).  Adding a weight w = q*u + r (q = floor(w/u), 0 <= r < u, both exact because u is
+// a power of two) gives the exact sum (C+q)*u + r, and IEEE round-to-nearest-even at
+// granularity u is the INTEGER map
+//        C -> C + q + [r > u/2]                      (no tie)
+//        C -> C + q + ((C + q) & 1)                  (tie r == u/2: round half to even)
+// which depends on C only through its parity.  Such maps form a monoid
+// (ae, ao) = (increment when C is even, increment when C is odd), closed under composition,
+// so an ordinary associative scan over int64 pairs yields every prefix exactly.  The
+// segment ends at the first element whose result leaves the binade (C >= 2^53) -- that one
+// element is added with a real fp64 add and the scan restarts in the new binade (~ once per
+// doubling of the running sum: a few dozen times per weight vector).
+//
+// __host__ __device__: the same code is exercised on the host by tests/hostcheck.
+#pragma once
+
+#include <stdint.h>
+#include <string.h>
+
+#include "fk_math.hpp"
+
+namespace fk {
+
+struct Mono {
+    long long ae, ao;   // increment applied when C is even / odd
+};
+
+constexpr long long MONO_LIMIT = 1LL << 53;   // C >= 2^53: left the binade
+constexpr long long MONO_BIG = 1LL << 54;     // element that always ends the segment
+constexpr long long MONO_SAT = 1LL << 60;
+
+FK_HD long long mono_sat(long long v) { return v > MONO_SAT ? MONO_SAT : v; }
+
+FK_HD Mono mono_identity() { return Mono{0, 0}; }
+
+// apply f first, then g
+FK_HD Mono mono_compose(const Mono &f, const Mono &g)
+{
+    Mono h;
+    h.ae = mono_sat(f.ae + ((f.ae & 1) ? g.ao : g.ae));
+    h.ao = mono_sat(f.ao + (((f.ao + 1) & 1) ? g.ao : g.ae));
+    return h;
+}
+
+FK_HD double bits_to_double(uint64_t b)
+{
+    double d;
+    memcpy(&d, &b, sizeof(d));
+    return d;
+}
+FK_HD uint64_t double_to_bits(double d)
+{
+    uint64_t b;
+    memcpy(&b, &d, sizeof(b));
+    return b;
+}
+
+// ulp of a finite c > 0 (spacing of doubles in c's binade; 2^-1074 for subnormals)
+FK_HD double ulp_of(double c)
+{
+    const uint64_t e = (double_to_bits(c) >> 52) & 0x7ffu;
+    if (e <= 53) return bits_to_double(e <= 1 ? 1ull : (1ull << (e - 1)));
+    return bits_to_double((e - 52) << 52);
+}
+
+// The map "add w" while the running sum has ulp u.
+FK_HD Mono mono_elem(double w, double u)
+{
+    // negative / NaN / huge weights end the segment and are added with a real fp add
+    if (!(w >= 0.0) || w * 0x1p-62 >= u) return Mono{MONO_BIG, MONO_BIG};
+    long long q = 0;
+    double r = w;
+    if (w >= u) {
+        const double t = w / u;            // exact: u is a power of two
+        if (t >= 0x1p53) return Mono{MONO_BIG, MONO_BIG};
+        q = (long long)t;                  // floor (t >= 0)
+        r = w - (double)q * u;             // exact
+    }
+    const double half = u * 0.5;           // 0 when u is the smallest subnormal (then r == 0 always)
+    if (r == half && r != 0.0) return Mono{q + (q & 1), q + ((q + 1) & 1)};
+    const long long inc = q + (r > half ? 1 : 0);
+    return Mono{inc, inc};
+}
+
+// C after applying composite F to start value C0
+FK_HD long long mono_apply(long long C0, const Mono &F) { return C0 + ((C0 & 1) ? F.ao : F.ae); }
+
+}  // namespace fk

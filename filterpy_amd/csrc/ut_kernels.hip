@@ -114,6 +114,58 @@ cross_kernel(int n, int m, int k, long N, const double *__restrict__ px, const d
     }
 }
 
+// ------------------------------------------------------------- UKF correct --
+// The tail of UnscentedKalmanFilter.update (UKF.py:470-481) for arbitrary hx:
+//   K = Pxz S^-1 ; x += K (z - zp) ; P -= K (S K')
+template <int NX, int NZ, int LAYOUT>
+__global__ void __launch_bounds__(BLOCK)
+ukf_correct_kernel(int n, int m, long N, const double *__restrict__ pPxz, const double *__restrict__ pzp,
+                   const double *__restrict__ pS, const double *__restrict__ pz, double *px, double *pP,
+                   double *pK, int32_t *status)
+{
+    const long blk0 = (long)blockIdx.x * BLOCK;
+    const Lane ln{blk0, threadIdx.x, N};
+    if (blk0 + ln.tid >= N) return;
+    double x[NX], P[NX * NX], K[NX * NZ], S[NZ * NZ], z[NZ], zp[NZ];
+    load_rec<NX, 1, LAYOUT, false>(x, px, ln, n, 1, 0.0);
+    load_rec<NX, NX, LAYOUT, false>(P, pP, ln, n, n, 0.0);
+    load_rec<NX, NZ, LAYOUT, false>(K, pPxz, ln, n, m, 0.0);
+    load_rec<NZ, NZ, LAYOUT, false>(S, pS, ln, m, m, 1.0);
+    load_rec<NZ, 1, LAYOUT, false>(z, pz, ln, m, 1, 0.0);
+    load_rec<NZ, 1, LAYOUT, false>(zp, pzp, ln, m, 1, 0.0);
+    // the padded diagonal of K (load_rec pads a==b with diag_pad=0) is zero: nothing to undo
+    double Lf[NZ * NZ], d[NZ], dinv[NZ];
+    FK_UNROLL for (int e = 0; e < NZ * NZ; ++e) Lf[e] = S[e];
+    int st = 0;
+    if (!ldlt2<NZ>(Lf, d, dinv)) st |= ST_NOT_PD;
+    solve_rows_ldlt<NX, NZ>(Lf, dinv, K);
+    FK_UNROLL for (int r = 0; r < NX; ++r) {
+        double acc = K[r * NZ] * (z[0] - zp[0]);
+        FK_UNROLL for (int c = 1; c < NZ; ++c) acc = fma(K[r * NZ + c], z[c] - zp[c], acc);
+        x[r] += acc;
+    }
+    double SK[NZ * NX];
+    FK_UNROLL for (int c = 0; c < NZ; ++c)
+        FK_UNROLL for (int r = 0; r < NX; ++r) {
+            double acc = S[c * NZ] * K[r * NZ];
+            FK_UNROLL for (int q = 1; q < NZ; ++q) acc = fma(S[c * NZ + q], K[r * NZ + q], acc);
+            SK[c * NX + r] = acc;
+        }
+    FK_UNROLL for (int r = 0; r < NX; ++r)
+        FK_UNROLL for (int c = 0; c < NX; ++c) {
+            double acc = K[r * NZ] * SK[c];
+            FK_UNROLL for (int q = 1; q < NZ; ++q) acc = fma(K[r * NZ + q], SK[q * NX + c], acc);
+            P[r * NX + c] -= acc;
+        }
+    store_rec<NX, 1, LAYOUT, false>(x, px, ln, n, 1);
+    store_rec<NX, NX, LAYOUT, false>(P, pP, ln, n, n);
+    if (pK) store_rec<NX, NZ, LAYOUT, false>(K, pK, ln, n, m);
+    if (status) {
+        if (!all_finite<NX>(x) || !all_finite<NX * NX>(P)) st |= ST_NONFINITE;
+        status[blk0 + ln.tid] = st;
+    }
+}
+
 // --------------------------------------------------- fused linear-model UKF --
 // Per step (UKF.py:400-411, 462-481) with fx(x) = F x, hx(x) = H x:
 //   L  = chol(scale P);  sigma_i = x, x +- L[:,k]          (sigma_points.py:167-175)
@@ -412,6 +464,32 @@ int fk_ut_cross_variance_f64(int32_t n, int32_t m, int32_t k, int64_t N, int32_t
     FK_BY_NX(n, CALL);
 #undef CALL
     return check_launch("cross_kernel");
+}
+
+int fk_ukf_correct_f64(int32_t n, int32_t m, int64_t N, int32_t layout, const double *Pxz, const double *zp,
+                       const double *S, const double *z, double *x, double *P, double *K, int32_t *status,
+                       void *stream)
+{
+    if (n < 1 || n > 16 || m < 1 || m > 8) return fail(FK_ERR_UNSUPPORTED, "ukf correct: dim_x 1..16, dim_z 1..8");
+    if (N < 0 || !Pxz || !zp || !S || !z || !x || !P) return fail(FK_ERR_BAD_ARG, "ukf correct: bad argument");
+    if ((double)N * n * n * 8.0 >= 4294967296.0) return fail(FK_ERR_UNSUPPORTED, "ukf correct: record block >= 4 GiB, split the batch");
+    if (N == 0) return FK_OK;
+    const dim3 grid((unsigned)((N + BLOCK - 1) / BLOCK)), block(BLOCK);
+    hipStream_t s = (hipStream_t)stream;
+#define GOZ(NXV, NZV)                                                                                      \
+    if (layout == FK_LAYOUT_SOA)                                                                           \
+        hipLaunchKernelGGL((ukf_correct_kernel<NXV, NZV, LAYOUT_SOA>), grid, block, 0, s, n, m, N, Pxz, zp, \
+                           S, z, x, P, K, status);                                                         \
+    else                                                                                                   \
+        hipLaunchKernelGGL((ukf_correct_kernel<NXV, NZV, LAYOUT_AOS>), grid, block, 0, s, n, m, N, Pxz, zp, \
+                           S, z, x, P, K, status)
+#define CALL(NXV)                  \
+    if (m <= 4) { GOZ(NXV, 4); }   \
+    else { GOZ(NXV, 8); }
+    FK_BY_NX(n, CALL);
+#undef CALL
+#undef GOZ
+    return check_launch("ukf_correct_kernel");
 }
 
 int fk_ukf_linear_batch_f64(const fk_ukf_desc *d, const double *F, const double *H, const double *Q,

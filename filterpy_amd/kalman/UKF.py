@@ -1,0 +1,248 @@
+"""Unscented Kalman filter with filterpy's call surface (filterpy/kalman/UKF.py:
+__init__ :284-340, predict :364-411, update :413-491, cross_variance :493-504,
+compute_process_sigmas :506-522, batch_filter :524-632), arithmetic on the GPU.
+
+Two ways to run it:
+
+* general fx / hx (Python callables, like the reference): sigma points, both unscented
+  transforms, the cross variance and the K / x / P correction are gfx950 kernels
+  (fk_ut_sigma_points_f64, fk_ut_transform_f64, fk_ut_cross_variance_f64, fk_ukf_correct_f64);
+  the callables run on the host between them, once per sigma point like the reference
+  (UKF.py:521-522, :462-466), or once per call on the whole (N, 2n+1, n) array when
+  ``vectorized=True``;
+* linear fx / hx given as matrices (``fx=F, hx=H`` NumPy arrays): batch_filter runs the
+  fused kernel fk_ukf_linear_batch_f64, the whole predict/update loop on the GPU.
+
+``n_tracks=N`` turns the object into a bank of N independent filters (x (N,n), P (N,n,n),
+z (N,m) / zs (T,N,m)).  Custom sqrt / mean / residual / state_add callables cannot run
+inside a kernel and raise NotImplementedError.
+"""
+import sys
+from copy import deepcopy
+from math import exp, log, sqrt
+
+import numpy as np
+
+from .. import _engine as E
+from ..common.helpers import logpdf
+
+__all__ = ["UnscentedKalmanFilter"]
+
+
+class UnscentedKalmanFilter(object):
+    def __init__(self, dim_x, dim_z, dt, hx, fx, points, sqrt_fn=None, x_mean_fn=None, z_mean_fn=None,
+                 residual_x=None, residual_z=None, state_add=None, n_tracks=None, vectorized=False,
+                 layout="soa"):
+        for name, fn in (("sqrt_fn", sqrt_fn), ("x_mean_fn", x_mean_fn), ("z_mean_fn", z_mean_fn),
+                         ("residual_x", residual_x), ("residual_z", residual_z), ("state_add", state_add)):
+            if fn is not None and fn not in (np.subtract, np.add):
+                raise NotImplementedError(f"custom {name} callables cannot run inside the HIP kernels")
+        self._dim_x, self._dim_z = dim_x, dim_z
+        self._N = n_tracks
+        self._vec = vectorized or n_tracks is not None and not callable(fx)
+        self._layout = layout
+        shape = (dim_x,) if n_tracks is None else (n_tracks, dim_x)
+        self.x = np.zeros(shape)
+        self.P = np.eye(dim_x) if n_tracks is None else np.tile(np.eye(dim_x), (n_tracks, 1, 1))
+        self.x_prior, self.P_prior = np.copy(self.x), np.copy(self.P)
+        self.Q, self.R = np.eye(dim_x), np.eye(dim_z)
+        self.points_fn = points
+        self._dt = dt
+        self._num_sigmas = points.num_sigmas()
+        self.hx, self.fx = hx, fx
+        self.x_mean, self.z_mean = x_mean_fn, z_mean_fn
+        self._log_likelihood = log(sys.float_info.min)
+        self._likelihood = sys.float_info.min
+        self._mahalanobis = None
+        self.msqrt = None
+        self.Wm, self.Wc = points.Wm, points.Wc
+        self.residual_x, self.residual_z, self.state_add = np.subtract, np.subtract, np.add
+        self.sigmas_f = np.zeros(((self._num_sigmas, dim_x) if n_tracks is None
+                                 else (n_tracks, self._num_sigmas, dim_x)))
+        self.sigmas_h = np.zeros(((self._num_sigmas, dim_z) if n_tracks is None
+                                 else (n_tracks, self._num_sigmas, dim_z)))
+        self.K = np.zeros((dim_x, dim_z))
+        self.y = np.zeros(dim_z)
+        self.z = np.array([[None] * dim_z]).T
+        self.S = np.zeros((dim_z, dim_z))
+        self.SI = np.zeros((dim_z, dim_z))
+        self.inv = np.linalg.inv
+
+    # ---------------------------------------------------------------- helpers --
+    def _b(self, a, tail):
+        """attribute -> bank-shaped (N, *tail) array"""
+        N = self._N or 1
+        return np.broadcast_to(np.asarray(a, dtype=np.float64), (N,) + tail).copy()
+
+    def _apply(self, fn, sig, *args, **kw):
+        """run a user callable over sigma points sig (N, k, d)"""
+        if not callable(fn):                       # a matrix: linear model
+            return sig @ np.asarray(fn, dtype=np.float64).T
+        if self._vec:
+            return np.asarray(fn(sig, *args, **kw), dtype=np.float64)
+        out = [[fn(s, *args, **kw) for s in trk] for trk in sig]
+        return np.asarray(out, dtype=np.float64).reshape(sig.shape[0], sig.shape[1], -1)
+
+    def _unb(self, a):
+        return a if self._N is not None else a[0]
+
+    # ---------------------------------------------------------------- predict --
+    def compute_process_sigmas(self, dt, fx=None, **fx_args):
+        """UKF.py:506-522."""
+        fx = self.fx if fx is None else fx
+        n = self._dim_x
+        sig = self.points_fn.sigma_points(self._b(self.x, (n,)), self._b(self.P, (n, n)))
+        sf = self._apply(fx, sig, dt, **fx_args) if callable(fx) else self._apply(fx, sig)
+        self.sigmas_f = self._unb(sf)
+
+    def predict(self, dt=None, UT=None, fx=None, **fx_args):
+        """UKF.py:364-411: sigma points -> fx -> UT(+Q) -> regenerate sigma points."""
+        from .unscented_transform import unscented_transform
+        if UT is not None and UT is not unscented_transform:
+            raise NotImplementedError("custom UT callables are not supported")
+        dt = self._dt if dt is None else dt
+        n = self._dim_x
+        self.compute_process_sigmas(dt, fx, **fx_args)
+        sf = np.asarray(self.sigmas_f).reshape(-1, self._num_sigmas, n)
+        x, P = unscented_transform(sf, self.Wm, self.Wc, self.Q, layout=self._layout)
+        self.x, self.P = self._unb(x), self._unb(P)
+        self.sigmas_f = self._unb(self.points_fn.sigma_points(x, P))
+        self.x_prior, self.P_prior = np.copy(self.x), np.copy(self.P)
+
+    # ----------------------------------------------------------------- update --
+    def update(self, z, R=None, UT=None, hx=None, **hx_args):
+        """UKF.py:413-491."""
+        import torch
+        from .unscented_transform import unscented_transform
+        if z is None:
+            self.z = np.array([[None] * self._dim_z]).T
+            self.x_post, self.P_post = np.copy(self.x), np.copy(self.P)
+            return
+        if UT is not None and UT is not unscented_transform:
+            raise NotImplementedError("custom UT callables are not supported")
+        hx = self.hx if hx is None else hx
+        n, m, k = self._dim_x, self._dim_z, self._num_sigmas
+        N = self._N or 1
+        if R is None:
+            R = self.R
+        elif np.isscalar(R):
+            R = np.eye(m) * R
+        sf = np.asarray(self.sigmas_f, dtype=np.float64).reshape(N, k, n)
+        sh = self._apply(hx, sf, **hx_args).reshape(N, k, m)
+        self.sigmas_h = self._unb(sh)
+        zp, S = unscented_transform(sh, self.Wm, self.Wc, R, layout=self._layout)
+        lay = self._layout
+        xb, Pb = self._b(self.x, (n,)), self._b(self.P, (n, n))
+        zb = np.asarray(z, dtype=np.float64).reshape(N, m)
+        dx, dP = E.to_records(xb, lay, 0), E.to_records(Pb, lay, 0)
+        dzp, dS, dz = E.to_records(zp, lay, 0), E.to_records(S, lay, 0), E.to_records(zb, lay, 0)
+        dPxz = E.alloc_records((), N, n * m, lay)
+        E.ut_cross_variance(n, m, k, N, lay, dx, dzp, E.to_records(sf, lay, 0), E.to_records(sh, lay, 0),
+                            E.dev(np.asarray(self.Wc, dtype=np.float64)), dPxz)
+        dK = E.alloc_records((), N, n * m, lay)
+        st = torch.zeros(N, dtype=torch.int32, device=dx.device)
+        E.ukf_correct(n, m, N, lay, dPxz, dzp, dS, dz, dx, dP, dK, st)
+        E.raise_on_status(st, "UnscentedKalmanFilter.update")
+        self.S = self._unb(S)
+        self.SI = self._unb(np.linalg.inv(S))         # attribute only; the kernel used a Cholesky solve
+        self.K = self._unb(E.from_records(dK, lay, 0, (n, m)))
+        self.y = self._unb(zb - zp)
+        self.x = self._unb(E.from_records(dx, lay, 0, (n,)))
+        self.P = self._unb(E.from_records(dP, lay, 0, (n, n)))
+        self.z = deepcopy(z)
+        self.x_post, self.P_post = np.copy(self.x), np.copy(self.P)
+        self._log_likelihood = None
+        self._likelihood = None
+        self._mahalanobis = None
+
+    def cross_variance(self, x, z, sigmas_f, sigmas_h):
+        """UKF.py:493-504 for one filter."""
+        n, m, k = sigmas_f.shape[1], sigmas_h.shape[1], sigmas_f.shape[0]
+        lay = self._layout
+        out = E.alloc_records((), 1, n * m, lay)
+        E.ut_cross_variance(n, m, k, 1, lay, E.to_records(np.reshape(x, (1, n)), lay, 0),
+                            E.to_records(np.reshape(z, (1, m)), lay, 0),
+                            E.to_records(np.asarray(sigmas_f)[None], lay, 0),
+                            E.to_records(np.asarray(sigmas_h)[None], lay, 0),
+                            E.dev(np.asarray(self.Wc, dtype=np.float64)), out)
+        return E.from_records(out, lay, 0, (n, m))[0]
+
+    # ----------------------------------------------------------- batch_filter --
+    def batch_filter(self, zs, Rs=None, dts=None, UT=None, saver=None):
+        """UKF.py:524-632: predict -> update per measurement; returns (means, covariances).
+        With linear fx/hx matrices and no per-epoch Rs/dts/saver the whole loop is ONE fused
+        kernel launch."""
+        import torch
+        n, m = self._dim_x, self._dim_z
+        try:
+            z0 = zs[0]
+        except TypeError:
+            raise TypeError('zs must be list-like') from None
+        if self._N is None:
+            if m == 1:
+                if not (np.isscalar(z0) or (np.ndim(z0) == 1 and len(z0) == 1)):
+                    raise TypeError('zs must be a list of scalars or 1D, 1 element arrays')
+            elif len(z0) != m:
+                raise TypeError('each element in zs must be a 1D array of length {}'.format(m))
+        T = len(zs)
+        N = self._N or 1
+        linear = (not callable(self.fx)) and (not callable(self.hx))
+        if linear and Rs is None and dts is None and saver is None:
+            lay = self._layout
+            zarr = np.zeros((T, N, m))
+            mask = np.ones((T, N), dtype=np.uint8)
+            for i, zi in enumerate(zs):
+                if zi is None:
+                    mask[i] = 0
+                else:
+                    zarr[i] = np.asarray(zi, dtype=np.float64).reshape(N, m)
+            dx, dP = E.to_records(self._b(self.x, (n,)), lay, 0), E.to_records(self._b(self.P, (n, n)), lay, 0)
+            means, covs = E.alloc_records((T,), N, n, lay), E.alloc_records((T,), N, n * n, lay)
+            st = torch.zeros(N, dtype=torch.int32, device=dx.device)
+            dm = None if mask.all() else torch.as_tensor(mask, device=dx.device)
+            E.ukf_linear_batch(n, m, N, T, lay, self.points_fn.scale, E.dev(self.fx), E.dev(self.hx),
+                               E.dev(np.broadcast_to(self.Q, (n, n)).copy()), E.dev(np.broadcast_to(self.R, (m, m)).copy()),
+                               E.dev(np.asarray(self.Wm, dtype=np.float64)), E.dev(np.asarray(self.Wc, dtype=np.float64)),
+                               E.to_records(zarr, lay, 1), dx, dP, mask=dm, means=means, covs=covs, status=st)
+            E.raise_on_status(st, "UnscentedKalmanFilter.batch_filter")
+            self.x = self._unb(E.from_records(dx, lay, 0, (n,)))
+            self.P = self._unb(E.from_records(dP, lay, 0, (n, n)))
+            mu, cov = E.from_records(means, lay, 1, (n,)), E.from_records(covs, lay, 1, (n, n))
+            return (mu, cov) if self._N is not None else (mu[:, 0], cov[:, 0])
+        Rs = [self.R] * T if Rs is None else Rs
+        dts = [self._dt] * T if dts is None else dts
+        means = np.zeros((T,) + np.shape(self.x))
+        covs = np.zeros((T,) + np.shape(self.P))
+        for i, (z, r, dt) in enumerate(zip(zs, Rs, dts)):
+            self.predict(dt=dt, UT=UT)
+            self.update(z, r, UT=UT)
+            means[i], covs[i] = self.x, self.P
+            if saver is not None:
+                saver.save()
+        return (means, covs)
+
+    def rts_smoother(self, Xs, Ps, Qs=None, dts=None, UT=None):
+        raise NotImplementedError("UnscentedKalmanFilter.rts_smoother (UKF.py:634-739) is not on the "
+                                  "accelerated path yet (SURVEY.md §8f N4)")
+
+    # ------------------------------------------------------------- properties --
+    @property
+    def log_likelihood(self):
+        if self._log_likelihood is None:
+            self._log_likelihood = logpdf(x=self.y, cov=self.S)
+        return self._log_likelihood
+
+    @property
+    def likelihood(self):
+        if self._likelihood is None:
+            self._likelihood = exp(self.log_likelihood)
+            if self._likelihood == 0:
+                self._likelihood = sys.float_info.min
+        return self._likelihood
+
+    @property
+    def mahalanobis(self):
+        if self._mahalanobis is None:
+            y = np.asarray(self.y, dtype=float).reshape(-1)
+            self._mahalanobis = sqrt(float(y @ self.SI @ y))
+        return self._mahalanobis

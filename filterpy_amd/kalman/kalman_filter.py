@@ -1,0 +1,641 @@
+"""Linear Kalman filter with filterpy's call surface, computed by the gfx950 kernels.
+
+Mirrors rlabbe/filterpy v1.4.5 filterpy/kalman/kalman_filter.py for the hot path only:
+
+    KalmanFilter.__init__ (:387-434)  predict (:437-482)  update (:485-561)
+    batch_filter (:826-993)  rts_smoother (:995-1074; uses Fs[k+1], Qs[k+1])
+    module-level predict (:1571-1621) update (:1401-1508)
+    batch_filter (:1664-1788) rts_smoother (:1792-1858; uses Fs[k], Qs[k])
+
+`KalmanFilter` is ONE filter, exactly like the reference (the GPU runs a bank of one).
+`KalmanFilterBank` is the same interface for N independent filters stepped in
+lock-step -- the shape the engine is built for (x (N,n), P (N,n,n), zs (T,N,m)).
+
+There is no CPU path: every predict/update/batch_filter/rts_smoother call goes through
+libfilterhip.so (filterpy_amd/_abi.py) and raises if no GPU / library is available.
+S^-1 is applied by an in-lane LDL' (Cholesky) solve, so S must be symmetric positive
+definite (the reference's numpy.linalg.inv also accepts indefinite S); a failed
+factorisation raises numpy.linalg.LinAlgError like a singular S does in the reference.
+"""
+import sys
+from copy import deepcopy
+from math import exp, log, sqrt
+
+import numpy as np
+
+from ..common.helpers import reshape_z, logpdf
+from .. import _engine as E
+from .._abi import (FK_MODEL_SHARED, FK_MODEL_PER_TRACK, FK_MODEL_PER_STEP, FK_MODEL_PER_TRACK_STEP)
+
+__all__ = ["KalmanFilter", "KalmanFilterBank", "predict", "update", "batch_filter", "rts_smoother"]
+
+
+# ----------------------------------------------------------------- helpers --
+def _mat(M, rows, cols, name, scalar="eye"):
+    """Attribute/kwarg -> (rows, cols) float64 matrix with the reference's broadcasting:
+    a scalar *attribute* is used raw by numpy (`FPF' + q` adds q to every element,
+    kalman_filter.py:478; `dot(F, p)` scales by p), which is what scalar= selects."""
+    if np.isscalar(M) or np.ndim(M) == 0:
+        v = float(M)
+        if scalar == "full":
+            return np.full((rows, cols), v)
+        return np.eye(rows, cols) * v
+    A = np.asarray(M, dtype=np.float64)
+    if A.shape != (rows, cols):
+        try:
+            A = np.broadcast_to(A, (rows, cols))
+        except ValueError:
+            raise ValueError(f"{name} has shape {A.shape}, expected ({rows}, {cols})") from None
+    return np.ascontiguousarray(A)
+
+
+def _seq(v, n):
+    """per-epoch list-like (length n) or None"""
+    if v is None:
+        return None
+    if len(v) != n:
+        raise ValueError(f"per-epoch list has length {len(v)}, expected {n}")
+    return list(v)
+
+
+class _Core:
+    """Shared device plumbing for one bank of N filters (N = 1 for KalmanFilter)."""
+
+    @staticmethod
+    def batch(n, m, N, T, x0, P0, z, mask, F, Q, H, R, mode, B=None, us=None, nu=0,
+              alpha_sq=1.0, update_first=False, layout="soa", want_outputs=True, device_outputs=False):
+        """All inputs are host arrays shaped for `mode`:
+        x0 (N,n) P0 (N,n,n) z (T,N,m) mask (T,N) or None;
+        models: SHARED (a,b) | PER_TRACK (N,a,b) | PER_STEP (T,a,b) | PER_TRACK_STEP (T,N,a,b).
+        Returns (means, covs, means_p, covs_p, x_final, P_final) as host arrays (T,N,...)
+        or device tensors in `layout` when device_outputs."""
+        import torch
+        E.require_gpu()
+
+        def model(Mx):
+            if Mx is None:
+                return None
+            if mode in (FK_MODEL_SHARED, FK_MODEL_PER_STEP):
+                return E.dev(Mx)
+            return E.to_records(Mx, layout, 0 if mode == FK_MODEL_PER_TRACK else 1)
+
+        dx, dP = E.to_records(x0, layout, 0), E.to_records(P0, layout, 0)
+        dz = z if isinstance(z, torch.Tensor) else E.to_records(z, layout, 1)
+        dmask = None if mask is None else torch.as_tensor(np.ascontiguousarray(mask, dtype=np.uint8), device=dx.device)
+        du = None if us is None else E.to_records(us, layout, 1)
+        st = torch.zeros(N, dtype=torch.int32, device=dx.device)
+        outs = [None] * 4
+        if want_outputs:
+            outs = [E.alloc_records((T,), N, n, layout), E.alloc_records((T,), N, n * n, layout),
+                    E.alloc_records((T,), N, n, layout), E.alloc_records((T,), N, n * n, layout)]
+        E.kf_batch_filter(dict(n=n, m=m, nu=nu, model_mode=mode, N=N, T=T, layout=E.LAYOUTS[layout],
+                               update_first=int(bool(update_first)), alpha_sq=float(alpha_sq)),
+                          model(F), model(Q), model(H), model(R), dz, dx, dP, B=model(B), u=du, mask=dmask,
+                          means=outs[0], covs=outs[1], means_p=outs[2], covs_p=outs[3], status=st)
+        E.raise_on_status(st, "batch_filter")
+        if device_outputs:
+            return outs + [dx, dP]
+        res = [None] * 4
+        if want_outputs:
+            res = [E.from_records(outs[0], layout, 1, (n,)), E.from_records(outs[1], layout, 1, (n, n)),
+                   E.from_records(outs[2], layout, 1, (n,)), E.from_records(outs[3], layout, 1, (n, n))]
+        return res + [E.from_records(dx, layout, 0, (n,)), E.from_records(dP, layout, 0, (n, n))]
+
+    @staticmethod
+    def rts(n, N, T, Xs, Ps, F, Q, mode, convention, layout="soa"):
+        import torch
+        E.require_gpu()
+
+        def model(Mx):
+            if mode in (FK_MODEL_SHARED, FK_MODEL_PER_STEP):
+                return E.dev(Mx)
+            return E.to_records(Mx, layout, 0 if mode == FK_MODEL_PER_TRACK else 1)
+
+        dX, dPs = E.to_records(Xs, layout, 1), E.to_records(Ps, layout, 1)
+        o = [E.alloc_records((T,), N, n, layout)] + [E.alloc_records((T,), N, n * n, layout) for _ in range(3)]
+        st = torch.zeros(N, dtype=torch.int32, device=dX.device)
+        E.kf_rts(dict(n=n, m=1, nu=0, model_mode=mode, N=N, T=T, layout=E.LAYOUTS[layout], update_first=0,
+                      alpha_sq=1.0), model(F), model(Q), dX, dPs, o[0], o[1], o[2], o[3],
+                 convention=convention, status=st)
+        E.raise_on_status(st, "rts_smoother")
+        return (E.from_records(o[0], layout, 1, (n,)), E.from_records(o[1], layout, 1, (n, n)),
+                E.from_records(o[2], layout, 1, (n, n)), E.from_records(o[3], layout, 1, (n, n)))
+
+    @staticmethod
+    def predict(n, N, x, P, F, Q, mode, B=None, u=None, nu=0, alpha_sq=1.0, layout="soa"):
+        import torch
+        E.require_gpu()
+        lead = 0
+
+        def model(Mx):
+            if Mx is None:
+                return None
+            return E.dev(Mx) if mode == FK_MODEL_SHARED else E.to_records(Mx, layout, lead)
+
+        dx, dP = E.to_records(x, layout, 0), E.to_records(P, layout, 0)
+        du = None if u is None else E.to_records(u, layout, 0)
+        st = torch.zeros(N, dtype=torch.int32, device=dx.device)
+        E.kf_predict(dict(n=n, m=1, nu=nu, model_mode=mode, N=N, T=1, layout=E.LAYOUTS[layout], update_first=0,
+                          alpha_sq=float(alpha_sq)), model(F), model(Q), dx, dP, B=model(B), u=du, status=st)
+        E.raise_on_status(st, "predict")
+        return E.from_records(dx, layout, 0, (n,)), E.from_records(dP, layout, 0, (n, n))
+
+    @staticmethod
+    def update(n, m, N, x, P, z, H, R, mode, mask=None, layout="soa"):
+        import torch
+        E.require_gpu()
+
+        def model(Mx):
+            return E.dev(Mx) if mode == FK_MODEL_SHARED else E.to_records(Mx, layout, 0)
+
+        dx, dP, dz = E.to_records(x, layout, 0), E.to_records(P, layout, 0), E.to_records(z, layout, 0)
+        dmask = None if mask is None else torch.as_tensor(np.ascontiguousarray(mask, dtype=np.uint8), device=dx.device)
+        y, K = E.alloc_records((), N, m, layout), E.alloc_records((), N, n * m, layout)
+        S, SI = E.alloc_records((), N, m * m, layout), E.alloc_records((), N, m * m, layout)
+        for t in (y, K, S, SI):
+            t.zero_()
+        st = torch.zeros(N, dtype=torch.int32, device=dx.device)
+        E.kf_update(dict(n=n, m=m, nu=0, model_mode=mode, N=N, T=1, layout=E.LAYOUTS[layout], update_first=0,
+                         alpha_sq=1.0), model(H), model(R), dz, dx, dP, mask=dmask, y=y, K=K, S=S, SI=SI, status=st)
+        E.raise_on_status(st, "update")
+        return (E.from_records(dx, layout, 0, (n,)), E.from_records(dP, layout, 0, (n, n)),
+                E.from_records(y, layout, 0, (m,)), E.from_records(K, layout, 0, (n, m)),
+                E.from_records(S, layout, 0, (m, m)), E.from_records(SI, layout, 0, (m, m)))
+
+
+# ------------------------------------------------------------ KalmanFilter --
+class KalmanFilter(object):
+    """One linear Kalman filter; filterpy.kalman.KalmanFilter's interface
+    (kalman_filter.py:387-434 for the attributes), arithmetic on the GPU."""
+
+    def __init__(self, dim_x, dim_z, dim_u=0):
+        if dim_x < 1:
+            raise ValueError('dim_x must be 1 or greater')
+        if dim_z < 1:
+            raise ValueError('dim_z must be 1 or greater')
+        if dim_u < 0:
+            raise ValueError('dim_u must be 0 or greater')
+        self.dim_x, self.dim_z, self.dim_u = dim_x, dim_z, dim_u
+        self.x = np.zeros((dim_x, 1))
+        self.P = np.eye(dim_x)
+        self.Q = np.eye(dim_x)
+        self.B = None
+        self.F = np.eye(dim_x)
+        self.H = np.zeros((dim_z, dim_x))
+        self.R = np.eye(dim_z)
+        self._alpha_sq = 1.
+        self.M = np.zeros((dim_x, dim_z))
+        self.z = np.array([[None] * dim_z]).T
+        self.K = np.zeros((dim_x, dim_z))
+        self.y = np.zeros((dim_z, 1))
+        self.S = np.zeros((dim_z, dim_z))
+        self.SI = np.zeros((dim_z, dim_z))
+        self._I = np.eye(dim_x)
+        self.x_prior, self.P_prior = self.x.copy(), self.P.copy()
+        self.x_post, self.P_post = self.x.copy(), self.P.copy()
+        self._log_likelihood = log(sys.float_info.min)
+        self._likelihood = sys.float_info.min
+        self._mahalanobis = None
+        # kept for attribute compatibility; S^-1 is applied by the kernel's Cholesky solve
+        self.inv = np.linalg.inv
+
+    # -- attribute normalisation ------------------------------------------------
+    def _xP(self):
+        x = np.asarray(self.x, dtype=np.float64)
+        if x.size != self.dim_x:
+            raise ValueError(f"x has {x.size} elements, expected dim_x = {self.dim_x}")
+        return x.reshape(1, self.dim_x), _mat(self.P, self.dim_x, self.dim_x, "P")[None]
+
+    def _set_x(self, xrow):
+        self.x = xrow.reshape(np.shape(self.x)) if np.ndim(self.x) > 0 else float(xrow[0])
+
+    def _R_eff(self, R):
+        if (np.isscalar(R) or np.ndim(R) == 0) and self.dim_z > 1:
+            raise NotImplementedError(
+                "a scalar R *attribute* with dim_z > 1 acts as a full matrix in S and as r*I in K R K' "
+                "in the reference (kalman_filter.py:540,556); set R to a matrix")
+        return _mat(R, self.dim_z, self.dim_z, "R", scalar="full")
+
+    # -- predict ----------------------------------------------------------------
+    def predict(self, u=None, B=None, F=None, Q=None):
+        """kalman_filter.py:437-482.  x = Fx (+ Bu iff B and u are given); P = a^2 FPF' + Q."""
+        n = self.dim_x
+        if B is None:
+            B = self.B
+        F = self.F if F is None else F
+        if Q is None:
+            Qm = _mat(self.Q, n, n, "Q", scalar="full")       # attribute scalar is added to every element
+        elif np.isscalar(Q):
+            Qm = np.eye(n) * Q                                # kwarg scalar -> eye * Q  (:467-468)
+        else:
+            Qm = _mat(Q, n, n, "Q")
+        x, P = self._xP()
+        use_ctrl = B is not None and u is not None
+        kw = {}
+        if use_ctrl:
+            uu = np.asarray(u, dtype=np.float64).reshape(1, -1)
+            kw = dict(B=_mat(B, n, uu.shape[1], "B"), u=uu, nu=uu.shape[1])
+        xn, Pn = _Core.predict(n, 1, x, P, _mat(F, n, n, "F"), Qm, FK_MODEL_SHARED,
+                               alpha_sq=self._alpha_sq, **kw)
+        self._set_x(xn[0])
+        self.P = Pn[0]
+        self.x_prior, self.P_prior = np.copy(self.x), self.P.copy()
+
+    # -- update -----------------------------------------------------------------
+    def update(self, z, R=None, H=None):
+        """kalman_filter.py:485-561 (Joseph form)."""
+        self._log_likelihood = None
+        self._likelihood = None
+        self._mahalanobis = None
+        n, m = self.dim_x, self.dim_z
+        if z is None:
+            self.z = np.array([[None] * m]).T
+            self.x_post, self.P_post = np.copy(self.x), np.copy(self.P)
+            self.y = np.zeros((m, 1))
+            return
+        if R is None:
+            Rm = self._R_eff(self.R)
+        elif np.isscalar(R):
+            Rm = np.eye(m) * R
+        else:
+            Rm = _mat(R, m, m, "R")
+        x_ndim = np.ndim(self.x)
+        if H is None:
+            z = reshape_z(z, m, x_ndim)                       # raises ValueError on bad shapes
+            H = self.H
+        zz = np.asarray(z, dtype=np.float64)
+        if zz.size != m:
+            raise ValueError(f"z (shape {zz.shape}) does not hold dim_z = {m} values")
+        x, P = self._xP()
+        xn, Pn, y, K, S, SI = _Core.update(n, m, 1, x, P, zz.reshape(1, m), _mat(H, m, n, "H"), Rm, FK_MODEL_SHARED)
+        self._set_x(xn[0])
+        self.P = Pn[0]
+        self.y = y[0].reshape(m, 1) if x_ndim == 2 else y[0]
+        self.K, self.S, self.SI = K[0], S[0], SI[0]
+        self.z = deepcopy(z)
+        self.x_post, self.P_post = np.copy(self.x), self.P.copy()
+
+    # -- batch_filter -----------------------------------------------------------
+    def batch_filter(self, zs, Fs=None, Qs=None, Hs=None, Rs=None, Bs=None, us=None,
+                     update_first=False, saver=None):
+        """kalman_filter.py:826-993.  Returns (means, covariances, means_p, covariances_p);
+        the filter's own x, P end at the final state, like the reference."""
+        n, m = self.dim_x, self.dim_z
+        T = len(zs)
+        Fs, Qs, Hs, Rs, Bs = (_seq(v, T) for v in (Fs, Qs, Hs, Rs, Bs))
+        if saver is not None:
+            return self._batch_with_saver(zs, Fs, Qs, Hs, Rs, Bs, us, update_first, saver)
+        x_ndim = np.ndim(self.x)
+        # measurements: None = missing (:515-520).  batch_filter always passes H, so reshape_z is
+        # skipped (:527-529): a z only needs to broadcast against H x
+        z = np.zeros((T, 1, m))
+        mask = np.ones((T, 1), dtype=np.uint8)
+        for i, zi in enumerate(zs):
+            if zi is None:
+                mask[i, 0] = 0
+                continue
+            zi = np.asarray(zi, dtype=np.float64)
+            if zi.size != m:
+                raise ValueError(f"zs[{i}] has shape {zi.shape}, expected {m} values")
+            if x_ndim == 2 and zi.ndim == 1 and m > 1:
+                # the reference silently broadcasts y to (m, m) here and then fails storing x
+                raise ValueError("with a column-vector state each z must be a (dim_z, 1) column")
+            z[i, 0] = zi.reshape(m)
+        per_step = any(v is not None for v in (Fs, Qs, Hs, Rs, Bs))
+        Fm, Qm = _mat(self.F, n, n, "F"), _mat(self.Q, n, n, "Q", scalar="full")
+        Hm, Rm = _mat(self.H, m, n, "H"), self._R_eff(self.R)
+        kw = {}
+        if us is not None and (Bs is not None or self.B is not None):
+            U = np.asarray([np.ravel(np.asarray(u, dtype=np.float64)) for u in us])
+            nu = U.shape[1]
+            kw = dict(us=U.reshape(T, 1, nu), nu=nu)
+            kw["B"] = (np.stack([_mat(b, n, nu, "B") for b in Bs]) if Bs is not None
+                       else (np.broadcast_to(_mat(self.B, n, nu, "B"), (T, n, nu)).copy() if per_step
+                             else _mat(self.B, n, nu, "B")))
+        if per_step:
+            def stack(lst, base, r, c, name, scalar="eye"):
+                if lst is None:
+                    return np.broadcast_to(base, (T, r, c)).copy()
+                return np.stack([_mat(v, r, c, name, scalar) if not np.isscalar(v) else
+                                 (np.eye(r, c) * v) for v in lst])
+            Fm, Qm = stack(Fs, Fm, n, n, "F"), stack(Qs, Qm, n, n, "Q")
+            Hm, Rm = stack(Hs, Hm, m, n, "H"), stack(Rs, Rm, m, m, "R")
+            mode = FK_MODEL_PER_STEP
+        else:
+            mode = FK_MODEL_SHARED
+        x, P = self._xP()
+        mu, cov, mup, covp, xf, Pf = _Core.batch(
+            n, m, 1, T, x, P, z, None if mask.all() else mask, Fm, Qm, Hm, Rm, mode,
+            alpha_sq=self._alpha_sq, update_first=update_first, **kw)
+        self._set_x(xf[0])
+        self.P = Pf[0]
+        mu, cov, mup, covp = mu[:, 0], cov[:, 0], mup[:, 0], covp[:, 0]
+        if x_ndim == 2:
+            mu, mup = mu[..., None], mup[..., None]
+        # bookkeeping of the last epoch, as the per-epoch loop leaves it
+        if T:
+            if update_first:
+                self.x_post, self.P_post = mu[-1].copy(), cov[-1].copy()
+                self.x_prior, self.P_prior = np.copy(self.x), self.P.copy()
+            else:
+                self.x_prior, self.P_prior = mup[-1].copy(), covp[-1].copy()
+                self.x_post, self.P_post = np.copy(self.x), self.P.copy()
+        return (mu, cov, mup, covp)
+
+    def _batch_with_saver(self, zs, Fs, Qs, Hs, Rs, Bs, us, update_first, saver):
+        """saver.save() needs the filter's attributes after every epoch (:990-991): step one
+        epoch at a time through predict()/update()."""
+        T = len(zs)
+        shape = np.shape(self.x)
+        means, means_p = np.zeros((T,) + shape), np.zeros((T,) + shape)
+        covs, covs_p = np.zeros((T, self.dim_x, self.dim_x)), np.zeros((T, self.dim_x, self.dim_x))
+
+        def at(lst, i):
+            return None if lst is None else lst[i]
+        for i, z in enumerate(zs):
+            u = None if us is None else us[i]
+            if update_first:
+                self.update(z, R=at(Rs, i), H=at(Hs, i) if Hs is not None else self.H)
+                means[i], covs[i] = self.x, self.P
+                self.predict(u=u, B=at(Bs, i), F=at(Fs, i), Q=at(Qs, i))
+                means_p[i], covs_p[i] = self.x, self.P
+            else:
+                self.predict(u=u, B=at(Bs, i), F=at(Fs, i), Q=at(Qs, i))
+                means_p[i], covs_p[i] = self.x, self.P
+                self.update(z, R=at(Rs, i), H=at(Hs, i) if Hs is not None else self.H)
+                means[i], covs[i] = self.x, self.P
+            saver.save()
+        return (means, covs, means_p, covs_p)
+
+    # -- rts_smoother -----------------------------------------------------------
+    def rts_smoother(self, Xs, Ps, Fs=None, Qs=None, inv=None):
+        """kalman_filter.py:995-1074 (class method: F[k+1], Q[k+1]).  Returns (x, P, K, Pp).
+        `inv` is accepted for signature compatibility; Pp^-1 is applied by a Cholesky solve."""
+        if len(Xs) != len(Ps):
+            raise ValueError('length of Xs and Ps must be the same')
+        return _rts(np.asarray(Xs, dtype=np.float64), np.asarray(Ps, dtype=np.float64),
+                    Fs if Fs is not None else self.F, Qs if Qs is not None else self.Q, convention=0)
+
+    # -- small helpers the reference exposes -------------------------------------
+    def residual_of(self, z):
+        """kalman_filter.py:1175-1181."""
+        z = reshape_z(z, self.dim_z, np.ndim(self.x))
+        return z - np.dot(self.H, self.x_prior)
+
+    def measurement_of_state(self, x):
+        """kalman_filter.py:1183-1201."""
+        return np.dot(self.H, x)
+
+    @property
+    def log_likelihood(self):
+        """kalman_filter.py:1203-1211: lazily from y, S."""
+        if self._log_likelihood is None:
+            self._log_likelihood = logpdf(x=self.y, cov=self.S)
+        return self._log_likelihood
+
+    @property
+    def likelihood(self):
+        """kalman_filter.py:1213-1226."""
+        if self._likelihood is None:
+            self._likelihood = exp(self.log_likelihood)
+            if self._likelihood == 0:
+                self._likelihood = sys.float_info.min
+        return self._likelihood
+
+    @property
+    def mahalanobis(self):
+        """kalman_filter.py:1228-1240."""
+        if self._mahalanobis is None:
+            y = np.asarray(self.y, dtype=float).reshape(-1, 1)
+            self._mahalanobis = sqrt(float(np.dot(np.dot(y.T, self.SI), y).item()))
+        return self._mahalanobis
+
+    @property
+    def alpha(self):
+        """kalman_filter.py:1242-1257."""
+        return self._alpha_sq ** .5
+
+    @alpha.setter
+    def alpha(self, value):
+        if not np.isscalar(value) or value < 1:
+            raise ValueError('alpha must be a float greater than 1')
+        self._alpha_sq = value ** 2
+
+    def __repr__(self):
+        return "\n".join(["KalmanFilter object (filterpy_amd, gfx950)"] +
+                         [f"{k} = {getattr(self, k)!r}" for k in
+                          ("dim_x", "dim_z", "dim_u", "x", "P", "F", "Q", "R", "H", "K", "y", "S", "alpha")])
+
+
+def _rts(Xs, Ps, Fs, Qs, convention):
+    T = Xs.shape[0]
+    n = Xs.shape[1]
+    Xr = Xs.reshape(T, 1, n)
+    Pr = np.asarray(Ps, dtype=np.float64).reshape(T, 1, n, n)
+    per_step = (isinstance(Fs, (list, tuple)) or np.ndim(Fs) == 3 or isinstance(Qs, (list, tuple)) or np.ndim(Qs) == 3)
+    if per_step:
+        def stack(v, name, scalar):
+            if isinstance(v, (list, tuple)) or np.ndim(v) == 3:
+                if len(v) != T:
+                    raise ValueError(f"{name} must hold one matrix per epoch")
+                return np.stack([_mat(a, n, n, name, scalar) for a in v])
+            return np.broadcast_to(_mat(v, n, n, name, scalar), (T, n, n)).copy()
+        Fm, Qm, mode = stack(Fs, "F", "eye"), stack(Qs, "Q", "full"), FK_MODEL_PER_STEP
+    else:
+        Fm, Qm, mode = _mat(Fs, n, n, "F"), _mat(Qs, n, n, "Q", scalar="full"), FK_MODEL_SHARED
+    if T == 0:
+        return Xs.copy(), Ps.copy(), np.zeros((0, n, n)), Ps.copy()
+    x, P, K, Pp = _Core.rts(n, 1, T, Xr, Pr, Fm, Qm, mode, convention)
+    return x[:, 0].reshape(Xs.shape), P[:, 0], K[:, 0], Pp[:, 0]
+
+
+# -------------------------------------------------------- KalmanFilterBank --
+class KalmanFilterBank(object):
+    """N independent linear Kalman filters stepped in lock-step on the GPU, with
+    KalmanFilter's method names.  Shapes gain a track axis:
+
+        x (N, dim_x)   P (N, dim_x, dim_x)   zs (T, N, dim_z)   [NaN row / mask = missing]
+        F, Q, H, R: one matrix shared by all tracks, or (N, ., .) one per track
+
+    batch_filter returns (means (T,N,n), covariances (T,N,n,n), means_p, covariances_p) as NumPy
+    arrays -- for layout='soa' they are transposed *views* of the [T][e][N] device layout -- or,
+    with device_outputs=True, the device tensors themselves (no PCIe copy).
+    """
+
+    def __init__(self, dim_x, dim_z, n_tracks, dim_u=0, layout="soa"):
+        if dim_x < 1 or dim_z < 1 or dim_u < 0 or n_tracks < 1:
+            raise ValueError("dim_x, dim_z, n_tracks must be >= 1 and dim_u >= 0")
+        if layout not in E.LAYOUTS:
+            raise ValueError("layout must be 'soa' or 'aos'")
+        self.dim_x, self.dim_z, self.dim_u, self.n_tracks, self.layout = dim_x, dim_z, dim_u, n_tracks, layout
+        self.x = np.zeros((n_tracks, dim_x))
+        self.P = np.tile(np.eye(dim_x), (n_tracks, 1, 1))
+        self.F, self.Q = np.eye(dim_x), np.eye(dim_x)
+        self.H, self.R = np.zeros((dim_z, dim_x)), np.eye(dim_z)
+        self.B = None
+        self._alpha_sq = 1.0
+
+    alpha = KalmanFilter.alpha
+
+    def _models(self):
+        n, m, N = self.dim_x, self.dim_z, self.n_tracks
+        mats = dict(F=(self.F, n, n), Q=(self.Q, n, n), H=(self.H, m, n), R=(self.R, m, m))
+        per_track = any(np.ndim(v[0]) == 3 for v in mats.values())
+        out = {}
+        for k, (v, r, c) in mats.items():
+            v = np.asarray(v, dtype=np.float64)
+            if v.ndim == 3:
+                if v.shape != (N, r, c):
+                    raise ValueError(f"{k} has shape {v.shape}, expected ({N}, {r}, {c})")
+                out[k] = np.ascontiguousarray(v)
+            else:
+                mm = _mat(v, r, c, k)
+                out[k] = np.broadcast_to(mm, (N, r, c)).copy() if per_track else mm
+        return out, (FK_MODEL_PER_TRACK if per_track else FK_MODEL_SHARED)
+
+    def _state(self):
+        n, N = self.dim_x, self.n_tracks
+        x = np.asarray(self.x, dtype=np.float64).reshape(N, n)
+        P = np.asarray(self.P, dtype=np.float64)
+        if P.shape != (N, n, n):
+            P = np.broadcast_to(P, (N, n, n)).copy()
+        return x, P
+
+    def predict(self, u=None):
+        mods, mode = self._models()
+        x, P = self._state()
+        kw = {}
+        if u is not None and self.B is not None:
+            uu = np.asarray(u, dtype=np.float64).reshape(self.n_tracks, -1)
+            B = np.asarray(self.B, dtype=np.float64)
+            if mode == FK_MODEL_PER_TRACK and B.ndim == 2:
+                B = np.broadcast_to(B, (self.n_tracks,) + B.shape).copy()
+            kw = dict(B=B, u=uu, nu=uu.shape[1])
+        self.x, self.P = _Core.predict(self.dim_x, self.n_tracks, x, P, mods["F"], mods["Q"], mode,
+                                       alpha_sq=self._alpha_sq, layout=self.layout, **kw)
+
+    def update(self, z, mask=None):
+        """z (N, dim_z); rows that are all-NaN (or mask == 0) are missing measurements."""
+        mods, mode = self._models()
+        x, P = self._state()
+        z = np.asarray(z, dtype=np.float64).reshape(self.n_tracks, self.dim_z)
+        nanrow = np.isnan(z).all(axis=1)
+        if mask is None and nanrow.any():
+            mask = ~nanrow
+        if mask is not None:
+            z = np.where(np.asarray(mask, dtype=bool)[:, None], z, 0.0)
+        self.x, self.P, self.y, self.K, self.S, self.SI = _Core.update(
+            self.dim_x, self.dim_z, self.n_tracks, x, P, z, mods["H"], mods["R"], mode, mask=mask, layout=self.layout)
+
+    def batch_filter(self, zs, mask=None, update_first=False, store=True, device_outputs=False):
+        """zs (T, N, dim_z) NumPy array or a device tensor already in self.layout."""
+        import torch
+        mods, mode = self._models()
+        x, P = self._state()
+        if isinstance(zs, torch.Tensor):
+            T = zs.shape[0]
+            z = zs
+        else:
+            z = np.asarray(zs, dtype=np.float64)
+            T = z.shape[0]
+            z = z.reshape(T, self.n_tracks, self.dim_z)
+            nanrow = np.isnan(z).all(axis=2)
+            if mask is None and nanrow.any():
+                mask = ~nanrow
+            if mask is not None:
+                z = np.where(np.asarray(mask, dtype=bool)[..., None], z, 0.0)
+        out = _Core.batch(self.dim_x, self.dim_z, self.n_tracks, T, x, P, z, mask, mods["F"], mods["Q"],
+                          mods["H"], mods["R"], mode, alpha_sq=self._alpha_sq, update_first=update_first,
+                          layout=self.layout, want_outputs=store, device_outputs=device_outputs)
+        if device_outputs:
+            self.x = E.from_records(out[4], self.layout, 0, (self.dim_x,))
+            self.P = E.from_records(out[5], self.layout, 0, (self.dim_x, self.dim_x))
+        else:
+            self.x, self.P = out[4], out[5]
+        return tuple(out[:4])
+
+    def rts_smoother(self, Xs, Ps):
+        """Xs (T,N,n), Ps (T,N,n,n) -> (x, P, K, Pp), class convention (kalman_filter.py:1067)."""
+        mods, mode = self._models()
+        Xs, Ps = np.asarray(Xs, dtype=np.float64), np.asarray(Ps, dtype=np.float64)
+        if len(Xs) != len(Ps):
+            raise ValueError('length of Xs and Ps must be the same')
+        return _Core.rts(self.dim_x, self.n_tracks, Xs.shape[0], Xs, Ps, mods["F"], mods["Q"], mode, 0,
+                         layout=self.layout)
+
+
+# ------------------------------------------------- module-level functions --
+def _as_state(x, P):
+    """(x, P) possibly scalars -> (xrow (1,n), P (1,n,n), restore(xrow, P))"""
+    scalar = np.isscalar(x) or np.ndim(x) == 0
+    xa = np.atleast_1d(np.asarray(x, dtype=np.float64))
+    n = xa.size
+    shape = xa.shape
+    Pm = _mat(P, n, n, "P")
+
+    def restore(xr, Pr):
+        if scalar:
+            return float(xr[0]), (float(Pr[0, 0]) if np.ndim(P) == 0 else Pr)
+        return xr.reshape(shape), Pr
+    return xa.reshape(1, n), Pm[None], n, restore
+
+
+def predict(x, P, F=1, Q=0, u=0, B=1, alpha=1.):
+    """Module-level predict (kalman_filter.py:1571-1621): x = Fx + Bu; P = a^2 FPF' + Q."""
+    xr, Pr, n, restore = _as_state(x, P)
+    Fm = _mat(F, n, n, "F")
+    Qm = _mat(Q, n, n, "Q", scalar="full")
+    kw = {}
+    bu = np.dot(B, u)
+    if np.any(np.asarray(bu) != 0):
+        # the reference adds dot(B, u) whatever its shape; fold it into a 1-column control input
+        kw = dict(B=np.asarray(bu, dtype=np.float64).reshape(n, 1), u=np.ones((1, 1)), nu=1)
+    xn, Pn = _Core.predict(n, 1, xr, Pr, Fm, Qm, FK_MODEL_SHARED, alpha_sq=alpha * alpha, **kw)
+    return restore(xn[0], Pn[0])
+
+
+def update(x, P, z, R, H=None, return_all=False):
+    """Module-level update (kalman_filter.py:1401-1508).  z None -> unchanged."""
+    if z is None:
+        if return_all:
+            return x, P, None, None, None, None
+        return x, P
+    xr, Pr, n, restore = _as_state(x, P)
+    if H is None:
+        H = np.array([1])
+    Hm = np.atleast_2d(np.asarray(H, dtype=np.float64))
+    if Hm.shape[1] != n:
+        Hm = Hm.reshape(-1, n)
+    m = Hm.shape[0]
+    zz = reshape_z(z, m, np.ndim(x))
+    Rm = _mat(R, m, m, "R", scalar="full")
+    xn, Pn, y, K, S, SI = _Core.update(n, m, 1, xr, Pr, np.asarray(zz, dtype=np.float64).reshape(1, m), Hm, Rm,
+                                       FK_MODEL_SHARED)
+    xo, Po = restore(xn[0], Pn[0])
+    if return_all:
+        yy = y[0].reshape(m, 1) if np.ndim(x) == 2 else (y[0] if np.ndim(x) == 1 else float(y[0, 0]))
+        # the reference evaluates the likelihood at the POSTERIOR state (:1506)
+        ll = logpdf(zz, np.dot(Hm, np.asarray(xo, dtype=float).reshape(n, -1)), S[0])
+        return xo, Po, yy, K[0], S[0], ll
+    return xo, Po
+
+
+def batch_filter(x, P, zs, Fs, Qs, Hs, Rs, Bs=None, us=None, update_first=False, saver=None):
+    """Module-level batch_filter (kalman_filter.py:1664-1788): per-epoch lists are required."""
+    x = np.asarray(x, dtype=np.float64)
+    n = x.shape[0]
+    m = np.atleast_2d(np.asarray(Hs[0], dtype=np.float64)).shape[0]
+    kf = KalmanFilter(n, m)
+    kf.x, kf.P = x.copy(), _mat(P, n, n, "P")
+    kf.F, kf.Q, kf.H, kf.R = Fs[0], Qs[0], np.atleast_2d(Hs[0]), Rs[0]
+    if us is None:
+        Bs = None
+    return kf.batch_filter(zs, Fs=Fs, Qs=Qs, Hs=[np.atleast_2d(h) for h in Hs], Rs=Rs, Bs=Bs, us=us,
+                           update_first=update_first, saver=saver)
+
+
+def rts_smoother(Xs, Ps, Fs, Qs):
+    """Module-level rts_smoother (kalman_filter.py:1792-1858): uses Fs[k], Qs[k]."""
+    if len(Xs) != len(Ps):
+        raise ValueError('length of Xs and Ps must be the same')
+    return _rts(np.asarray(Xs, dtype=np.float64), np.asarray(Ps, dtype=np.float64), Fs, Qs, convention=1)

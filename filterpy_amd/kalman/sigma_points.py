@@ -1,0 +1,95 @@
+"""Sigma-point generators with filterpy's interface (filterpy/kalman/sigma_points.py:
+MerweScaledSigmaPoints :24-208, JulierSigmaPoints :211-383); the points are produced by the
+gfx950 kernel fk_ut_sigma_points_f64 (Cholesky in-lane).  Weights are host-side scalars."""
+import numpy as np
+
+from .. import _engine as E
+
+__all__ = ["MerweScaledSigmaPoints", "JulierSigmaPoints"]
+
+
+def _sigma_points_gpu(n, scale, x, P, layout="soa"):
+    """x (n,) or (N,n); P (n,n) or (N,n,n) or scalar -> (2n+1, n) or (N, 2n+1, n)."""
+    import torch
+    E.require_gpu()
+    x = np.asarray(x, dtype=np.float64)
+    batched = x.ndim == 2
+    xb = x.reshape(-1, n)
+    N = xb.shape[0]
+    if np.isscalar(P) or np.ndim(P) == 0:
+        Pb = np.broadcast_to(np.eye(n) * P, (N, n, n))
+    else:
+        Pb = np.broadcast_to(np.atleast_2d(np.asarray(P, dtype=np.float64)), (N, n, n))
+    dx, dP = E.to_records(xb, layout, 0), E.to_records(np.ascontiguousarray(Pb), layout, 0)
+    sig = E.alloc_records((), N, (2 * n + 1) * n, layout)
+    st = torch.zeros(N, dtype=torch.int32, device=dx.device)
+    E.ut_sigma_points(n, N, layout, scale, dx, dP, sig, st)
+    E.raise_on_status(st, "sigma_points (scipy.linalg.cholesky would raise LinAlgError)")
+    out = E.from_records(sig, layout, 0, (2 * n + 1, n))
+    return out if batched else out[0]
+
+
+class MerweScaledSigmaPoints(object):
+    """filterpy/kalman/sigma_points.py:24-208."""
+
+    def __init__(self, n, alpha, beta, kappa, sqrt_method=None, subtract=None):
+        if sqrt_method is not None or subtract is not None:
+            raise NotImplementedError("custom sqrt_method / subtract callables cannot run inside the HIP "
+                                      "kernel; only the defaults (Cholesky, numpy.subtract) are supported")
+        self.n, self.alpha, self.beta, self.kappa = n, alpha, beta, kappa
+        self._compute_weights()
+
+    def num_sigmas(self):
+        return 2 * self.n + 1
+
+    def sigma_points(self, x, P):
+        """sigma_points.py:124-177; also accepts a bank: x (N,n), P (N,n,n) -> (N, 2n+1, n)."""
+        x_arr = np.asarray(x, dtype=np.float64)
+        if (x_arr.ndim <= 1 and self.n != np.size(x)) or (x_arr.ndim == 2 and x_arr.shape[1] != self.n):
+            raise ValueError("expected size(x) {}, but size is {}".format(self.n, np.size(x)))
+        lambda_ = self.alpha ** 2 * (self.n + self.kappa) - self.n
+        return _sigma_points_gpu(self.n, lambda_ + self.n, np.atleast_1d(x_arr), P)
+
+    def _compute_weights(self):
+        """sigma_points.py:180-192."""
+        n = self.n
+        lambda_ = self.alpha ** 2 * (n + self.kappa) - n
+        c = .5 / (n + lambda_)
+        self.Wc = np.full(2 * n + 1, c)
+        self.Wm = np.full(2 * n + 1, c)
+        self.Wc[0] = lambda_ / (n + lambda_) + (1 - self.alpha ** 2 + self.beta)
+        self.Wm[0] = lambda_ / (n + lambda_)
+
+    @property
+    def scale(self):
+        return self.alpha ** 2 * (self.n + self.kappa)   # lambda + n
+
+
+class JulierSigmaPoints(object):
+    """filterpy/kalman/sigma_points.py:211-383."""
+
+    def __init__(self, n, kappa=0., sqrt_method=None, subtract=None):
+        if sqrt_method is not None or subtract is not None:
+            raise NotImplementedError("custom sqrt_method / subtract callables are not supported")
+        self.n, self.kappa = n, kappa
+        self._compute_weights()
+
+    def num_sigmas(self):
+        return 2 * self.n + 1
+
+    def sigma_points(self, x, P):
+        x_arr = np.asarray(x, dtype=np.float64)
+        if (x_arr.ndim <= 1 and self.n != np.size(x)) or (x_arr.ndim == 2 and x_arr.shape[1] != self.n):
+            raise ValueError("expected size(x) {}, but size is {}".format(self.n, np.size(x)))
+        return _sigma_points_gpu(self.n, self.n + self.kappa, np.atleast_1d(x_arr), P)
+
+    def _compute_weights(self):
+        """sigma_points.py:360-372."""
+        n, k = self.n, self.kappa
+        self.Wm = np.full(2 * n + 1, .5 / (n + k))
+        self.Wm[0] = k / (n + k)
+        self.Wc = self.Wm
+
+    @property
+    def scale(self):
+        return self.n + self.kappa

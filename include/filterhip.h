@@ -167,6 +167,14 @@ int fk_ut_cross_variance_f64(int32_t n, int32_t m, int32_t k, int64_t N, int32_t
                              const double *sigmas_f, const double *sigmas_h,
                              const double *Wc, double *Pxz, void *stream);
 
+/* The correction at the end of UnscentedKalmanFilter.update (filterpy/kalman/UKF.py:470-481) for
+ * arbitrary measurement functions:  K = Pxz S^-1 (Cholesky solve) ; x += K (z - zp) ; P -= K (S K').
+ *   Pxz [N][n*m], zp [N][m], S [N][m*m], z [N][m] ; x [N][n], P [N][n*n] updated in place ;
+ *   K [N][n*m] out (may be NULL) ; status [N] or NULL.   dim_x 1..16, dim_z 1..8. */
+int fk_ukf_correct_f64(int32_t n, int32_t m, int64_t N, int32_t layout,
+                       const double *Pxz, const double *zp, const double *S, const double *z,
+                       double *x, double *P, double *K, int32_t *status, void *stream);
+
 typedef struct fk_ukf_desc {
     int32_t n, m;         /* dim_x (1..8), dim_z (1..4) */
     int64_t N, T;
@@ -216,6 +224,14 @@ int fk_resample_multinomial_f64(int64_t Fn, int64_t Np, int64_t Nu, const double
                                 int64_t *idx, void *ws, size_t ws_bytes, void *stream);
 
 size_t fk_resample_workspace_bytes(int64_t Fn, int64_t Np);
+
+/* numpy.cumsum(w_f) for Fn float64 vectors of length Np, bit-for-bit (NumPy adds strictly left to
+ * right; a re-associated parallel scan differs in the last bits -- here an associative scan over
+ * integer rounding maps reproduces the sequential result exactly, see csrc/fk_exact_scan.hpp).
+ * The building block of every resampler (resampling.py:72,106,142,174).
+ *   w [Fn][Np] -> cs [Fn][Np];  force_last_one != 0 also sets cs[f][Np-1] = 1.0 (resampling.py:74,175). */
+int fk_cumsum_exact_f64(int64_t Fn, int64_t Np, const double *w, double *cs, int32_t force_last_one,
+                        void *stream);
 
 /* ------------------------------------------------------------------ */
 /* Utilities                                                          */

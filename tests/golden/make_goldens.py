@@ -28,6 +28,7 @@ from filterpy.monte_carlo import (systematic_resample, stratified_resample,  # n
                                   multinomial_resample, residual_resample)
 
 OUT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, OUT)
 
 
 def spd(rs, n, scale=1.0):
@@ -245,25 +246,7 @@ def sha(a):
     return np.frombuffer(hashlib.sha256(np.ascontiguousarray(a).tobytes()).digest(), dtype=np.uint8)
 
 
-def weights_for(N, seed, kind="rand"):
-    rs = np.random.RandomState(seed)
-    if kind == "rand":
-        w = rs.rand(N)
-    elif kind == "onehot":
-        w = np.zeros(N)
-        w[rs.randint(N)] = 1.0
-    elif kind == "sparse":
-        w = rs.rand(N) * (rs.rand(N) < 0.05)
-        w[0] = 0.0
-        if w.sum() == 0:
-            w[N // 2] = 1.0
-    elif kind == "exp":
-        w = np.exp(rs.randn(N) * 4.0)           # heavy-tailed: a few particles dominate
-    elif kind == "tiny":
-        w = rs.rand(N) * 1e-300                 # unnormalised, near-denormal
-        return w
-    w /= w.sum()
-    return w
+from weights import weights_for  # noqa: E402  (tests/golden/weights.py)
 
 
 RS_SMALL = [1, 2, 3, 10, 64, 1000, 8000]

@@ -156,3 +156,103 @@ int hc_sigma(int n, double scale, const double *x, const double *P, double *sig)
     return sigma<16>(n, scale, x, P, sig);
 }
 }
+
+// ---------------------------------------------------------------------------------------------
+// Exact parallel cumsum (filterpy_amd/csrc/fk_exact_scan.hpp): host emulation of the block-wide
+// scan of resample_kernels.hip::tile_cumsum_exact with the same tile / thread / wave
+// decomposition (RS_ITEMS consecutive elements per thread, Hillis-Steele over 64 lanes, serial
+// wave prefix), so the monoid's associativity and the segment logic are exercised exactly as
+// on the GPU.
+#include "../../filterpy_amd/csrc/fk_exact_scan.hpp"
+#include <vector>
+
+namespace {
+constexpr int T_THREADS = 256, T_ITEMS = 8, T_TILE = T_THREADS * T_ITEMS;
+
+double tile_cumsum_emul(double *w, int len, double carry, bool &started, long *n_segments)
+{
+    int pos = 0;
+    while (pos < len) {
+        const bool finite_pos = started && carry > 0.0 && carry <= 1.79769313486231570815e+308;
+        if (!finite_pos) {
+            if (!started || carry == 0.0) {
+                int j0 = len;
+                for (int j = pos; j < len; ++j)
+                    if (w[j] != 0.0) { j0 = j; break; }
+                if (j0 < len) {
+                    carry = started ? carry + w[j0] : w[j0];
+                    started = true;
+                    pos = j0 + 1;
+                } else {
+                    started = started || len > pos;
+                    pos = len;
+                }
+                continue;
+            }
+            carry = carry + w[pos];
+            w[pos] = carry;
+            ++pos;
+            continue;
+        }
+        ++*n_segments;
+        const double u = ulp_of(carry);
+        const long long C0 = (long long)(carry / u);
+        std::vector<Mono> loc(T_TILE), tot(T_THREADS), inc(T_THREADS), excl(T_THREADS);
+        for (int t = 0; t < T_THREADS; ++t) {
+            Mono run = mono_identity();
+            for (int k = 0; k < T_ITEMS; ++k) {
+                const int j = t * T_ITEMS + k;
+                const Mono e = (j >= pos && j < len) ? mono_elem(w[j], u) : mono_identity();
+                run = mono_compose(run, e);
+                loc[j] = run;
+            }
+            tot[t] = run;
+        }
+        // Hillis-Steele inside each wave of 64
+        inc = tot;
+        for (int d = 1; d < 64; d <<= 1) {
+            std::vector<Mono> nxt = inc;
+            for (int t = 0; t < T_THREADS; ++t)
+                if ((t & 63) >= d) nxt[t] = mono_compose(inc[t - d], inc[t]);
+            inc = nxt;
+        }
+        for (int t = 0; t < T_THREADS; ++t) {
+            Mono e = (t & 63) ? inc[t - 1] : mono_identity();
+            Mono wp = mono_identity();
+            for (int wv = 0; wv < (t >> 6); ++wv) wp = mono_compose(wp, inc[wv * 64 + 63]);
+            excl[t] = mono_compose(wp, e);
+        }
+        int cross = len;
+        std::vector<long long> Cj(T_TILE);
+        for (int j = 0; j < T_TILE; ++j) {
+            Cj[j] = mono_apply(C0, mono_compose(excl[j / T_ITEMS], loc[j]));
+            if (j >= pos && j < len && Cj[j] >= MONO_LIMIT && j < cross) cross = j;
+        }
+        for (int j = pos; j < cross; ++j) w[j] = (double)Cj[j] * u;
+        if (cross > pos) carry = w[cross - 1];
+        if (cross < len) {
+            carry = carry + w[cross];
+            w[cross] = carry;
+            pos = cross + 1;
+        } else {
+            pos = len;
+        }
+    }
+    return carry;
+}
+}  // namespace
+
+extern "C" long hc_cumsum_exact(long N, const double *w, double *cs)
+{
+    double carry = 0.0;
+    bool started = false;
+    long segs = 0;
+    std::vector<double> tile(T_TILE);
+    for (long base = 0; base < N; base += T_TILE) {
+        const int len = (int)((N - base) < T_TILE ? (N - base) : T_TILE);
+        for (int j = 0; j < T_TILE; ++j) tile[j] = j < len ? w[base + j] : 0.0;
+        carry = tile_cumsum_emul(tile.data(), len, carry, started, &segs);
+        for (int j = 0; j < len; ++j) cs[base + j] = tile[j];
+    }
+    return segs;
+}

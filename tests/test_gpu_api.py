@@ -1,0 +1,202 @@
+"""-m gpu: the Python drop-in layer (filterpy_amd.kalman / .monte_carlo) against goldens frozen
+from the live reference -- the reference's own relational tests re-expressed
+(test_kf.py:380-485, test_ukf.py:465-506, :893-979) plus its documented quirks."""
+import numpy as np
+import pytest
+
+from conftest import golden, rel_err_rows
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-10
+
+
+def _kf(n, m, x0, P0, F, Q, H, R):
+    from filterpy_amd.kalman import KalmanFilter
+    kf = KalmanFilter(n, m)
+    kf.x, kf.P = x0.copy(), P0.copy()
+    kf.F, kf.Q, kf.H, kf.R = F.copy(), Q.copy(), H.copy(), R.copy()
+    return kf
+
+
+def test_config1_drop_in():
+    """BASELINE configs[0]: the reference's CPU-runnable case through the same call sequence."""
+    g = golden("kf_c1")
+    for tag, x0 in (("1d", np.zeros(2)), ("col", np.zeros((2, 1)))):
+        kf = _kf(2, 1, x0, g["P0"], g["F"], g["Q"], g["H"], g["R"])
+        mu, cov, mup, covp = kf.batch_filter(list(g["zs"]))
+        for got, key in ((mu, "mu"), (cov, "cov"), (mup, "mup"), (covp, "covp")):
+            assert got.shape == g[f"{tag}_{key}"].shape
+            assert rel_err_rows(got, g[f"{tag}_{key}"]) < TOL, (tag, key)
+        assert kf.x.shape == x0.shape and rel_err_rows(kf.P[None], g[f"{tag}_cov"][-1:]) < TOL
+        xs, Ps, Ks, Pps = kf.rts_smoother(mu, cov)
+        for got, key in ((xs, "xs"), (Ps, "Ps"), (Ks, "Ks"), (Pps, "Pps")):
+            assert got.shape == g[f"{tag}_{key}"].shape and rel_err_rows(got, g[f"{tag}_{key}"]) < 1e-9, key
+
+
+@pytest.mark.parametrize("n,m", [(1, 1), (2, 1), (4, 2), (6, 3), (9, 3)])
+def test_single_steps_and_attributes(n, m):
+    g = golden("kf_steps")
+    p = f"n{n}m{m}_"
+    kf = _kf(n, m, g[p + "x0"], g[p + "P0"], g[p + "F"], g[p + "Q"], g[p + "H"], g[p + "R"])
+    kf.predict()
+    assert rel_err_rows(kf.x[None], g[p + "xp"][None]) < TOL and rel_err_rows(kf.P[None], g[p + "Pp"][None]) < TOL
+    assert np.array_equal(kf.x_prior, kf.x)
+    kf.update(g[p + "z"])
+    for attr, key in (("x", "x"), ("P", "P"), ("y", "y"), ("K", "K"), ("S", "S"), ("SI", "SI")):
+        got, ref = np.atleast_2d(getattr(kf, attr)), np.atleast_2d(g[p + key])
+        assert got.shape == ref.shape and rel_err_rows(got[None], ref[None]) < 1e-9, key
+    assert abs(kf.log_likelihood - g[p + "loglik"]) < 1e-8 * max(1, abs(g[p + "loglik"]))
+    assert abs(kf.mahalanobis - g[p + "maha"]) < 1e-8 * max(1, g[p + "maha"])
+    assert abs(kf.likelihood - g[p + "lik"]) <= 1e-8 * g[p + "lik"] + 1e-300
+    # scalar quirks
+    kf = _kf(n, m, g[p + "x0"], g[p + "P0"], g[p + "F"], g[p + "Q"], g[p + "H"], g[p + "R"])
+    kf.Q = 0.37
+    kf.predict()
+    assert rel_err_rows(kf.P[None], g[p + "qscal_attr_P"][None]) < TOL
+    kf = _kf(n, m, g[p + "x0"], g[p + "P0"], g[p + "F"], g[p + "Q"], g[p + "H"], g[p + "R"])
+    kf.predict(Q=0.37)
+    assert rel_err_rows(kf.P[None], g[p + "qscal_kw_P"][None]) < TOL
+    kf.update(g[p + "z"], R=0.81)
+    assert rel_err_rows(kf.P[None], g[p + "rscal_kw_P"][None]) < 1e-9
+    # module-level twins
+    from filterpy_amd.kalman import predict, update
+    xp, Pp = predict(g[p + "x0"], g[p + "P0"], g[p + "F"], g[p + "Q"])
+    assert rel_err_rows(np.atleast_1d(xp)[None], g[p + "m_xp"][None]) < TOL
+    x2, P2, y2, K2, S2, ll = update(xp, Pp, g[p + "z"], g[p + "R"], g[p + "H"], return_all=True)
+    assert rel_err_rows(np.atleast_2d(P2)[None], g[p + "m_P"][None]) < 1e-9
+    assert rel_err_rows(np.atleast_2d(K2)[None], g[p + "m_K"][None]) < 1e-9
+    assert abs(ll - g[p + "m_ll"]) < 1e-8 * max(1, abs(g[p + "m_ll"]))
+
+
+def test_univariate_scalars_like_reference():
+    """update(1, 2, 1, 1, 1) / predict with python floats (kalman_filter.py:1408-1411)."""
+    from filterpy_amd.kalman import predict, update
+    x, P = predict(1., 2., 1., 0.5)
+    assert isinstance(x, float) and abs(x - 1.0) < 1e-15 and abs(P - 2.5) < 1e-15
+    x, P = update(1., 2., 1.5, 1., 1.)
+    # K = 2/3 ; x = 1 + 2/3*0.5 ; P = (1-K)^2*2 + K^2*1
+    assert abs(x - (1 + (2 / 3) * 0.5)) < 1e-14 and abs(P - ((1 / 3) ** 2 * 2 + (2 / 3) ** 2)) < 1e-14
+
+
+@pytest.mark.parametrize("n,m", [(2, 1), (4, 2), (9, 3)])
+def test_batch_lists_class_and_module(n, m):
+    """Fs/Qs/Hs/Rs lists through the class and the module function, and both RTS conventions."""
+    from filterpy_amd.kalman import batch_filter, rts_smoother
+    g = golden("kf_models")
+    p = f"n{n}m{m}_"
+    kf = _kf(n, m, g[p + "x0"], g[p + "P0"], g[p + "Fs"][0], g[p + "Qs"][0], g[p + "Hs"][0], g[p + "Rs"][0])
+    Fs, Qs, Hs, Rs = (list(g[p + k]) for k in ("Fs", "Qs", "Hs", "Rs"))
+    out = kf.batch_filter(list(g[p + "zs"]), Fs=Fs, Qs=Qs, Hs=Hs, Rs=Rs)
+    for got, key in zip(out, ("mu", "cov", "mup", "covp")):
+        assert rel_err_rows(got, g[p + key]) < TOL, key
+    sm = kf.rts_smoother(out[0], out[1], Fs=Fs, Qs=Qs)
+    for got, key in zip(sm, ("rts_x", "rts_P", "rts_K", "rts_Pp")):
+        assert rel_err_rows(got, g[p + key]) < 1e-9, key
+    out2 = batch_filter(g[p + "x0"], g[p + "P0"], list(g[p + "zs"]), Fs, Qs, Hs, Rs)
+    for got, key in zip(out2, ("mod_mu", "mod_cov", "mod_mup", "mod_covp")):
+        assert rel_err_rows(got, g[p + key]) < TOL, key
+    sm2 = rts_smoother(out2[0], out2[1], Fs, Qs)
+    for got, key in zip(sm2, ("rtsm_x", "rtsm_P", "rtsm_K", "rtsm_Pp")):
+        assert rel_err_rows(got, g[p + key]) < 1e-9, key
+
+
+def test_none_measurements_and_update_first():
+    g = golden("kf_dims")
+    n, m = 4, 2
+    p = f"n{n}m{m}_"
+    kf = _kf(n, m, g[p + "x0"].reshape(n, 1), g[p + "P0"], g[p + "F"], g[p + "Q"], g[p + "H"], g[p + "R"])
+    zl = [g[p + "zs"][t].reshape(m, 1) if g[p + "mask"][t] else None for t in range(len(g[p + "mask"]))]
+    mu, cov, mup, covp = kf.batch_filter(zl)
+    assert mu.shape == (len(zl), n, 1)
+    assert rel_err_rows(mu[..., 0], g[p + "miss_mu"]) < TOL and rel_err_rows(covp, g[p + "miss_covp"]) < TOL
+    kf = _kf(n, m, g[p + "x0"], g[p + "P0"], g[p + "F"], g[p + "Q"], g[p + "H"], g[p + "R"])
+    mu, cov, mup, covp = kf.batch_filter(list(g[p + "zs"]), update_first=True)
+    assert rel_err_rows(mu, g[p + "uf_mu"]) < TOL and rel_err_rows(covp, g[p + "uf_covp"]) < TOL
+
+
+def test_saver_path_steps_one_epoch_at_a_time():
+    g = golden("kf_dims")
+    n, m = 2, 1
+    p = f"n{n}m{m}_"
+
+    class Saver:
+        def __init__(self, kf):
+            self.kf, self.xs = kf, []
+
+        def save(self):
+            self.xs.append(np.copy(self.kf.x))
+    kf = _kf(n, m, g[p + "x0"], g[p + "P0"], g[p + "F"], g[p + "Q"], g[p + "H"], g[p + "R"])
+    s = Saver(kf)
+    mu, *_ = kf.batch_filter(list(g[p + "zs"][:10]), saver=s)
+    assert len(s.xs) == 10 and rel_err_rows(np.array(s.xs), g[p + "plain_mu"][:10]) < TOL
+    assert rel_err_rows(mu, g[p + "plain_mu"][:10]) < TOL
+
+
+def test_bank_api():
+    from filterpy_amd.kalman import KalmanFilterBank
+    g = golden("kf_dims")
+    n, m, N = 4, 2, 513
+    p = f"n{n}m{m}_"
+    for layout in ("soa", "aos"):
+        bank = KalmanFilterBank(n, m, N, layout=layout)
+        bank.x = np.tile(g[p + "x0"], (N, 1))
+        bank.P = np.tile(g[p + "P0"], (N, 1, 1))
+        bank.F, bank.Q, bank.H, bank.R = g[p + "F"], g[p + "Q"], g[p + "H"], g[p + "R"]
+        zs = np.tile(g[p + "zs"][:, None, :], (1, N, 1))
+        mu, cov, mup, covp = bank.batch_filter(zs)
+        assert mu.shape == (zs.shape[0], N, n) and cov.shape == (zs.shape[0], N, n, n)
+        for trk in (0, 256, N - 1):
+            assert rel_err_rows(mu[:, trk], g[p + "plain_mu"]) < TOL and rel_err_rows(covp[:, trk], g[p + "plain_covp"]) < TOL
+        xs, Ps, Ks, Pps = bank.rts_smoother(mu, cov)
+        assert rel_err_rows(Ps[:, N - 1], g[p + "rts_P"]) < 1e-9
+        # step-by-step equals the batch
+        bank.x, bank.P = np.tile(g[p + "x0"], (N, 1)), np.tile(g[p + "P0"], (N, 1, 1))
+        for t in range(3):
+            bank.predict()
+            bank.update(zs[t])
+        assert rel_err_rows(bank.x[[0, N - 1]], np.tile(g[p + "plain_mu"][2], (2, 1))) < TOL
+
+
+def test_ukf_general_callables_vs_reference():
+    """UKF with Python fx/hx callables: predict/update attributes and batch_filter."""
+    from filterpy_amd.kalman import UnscentedKalmanFilter, MerweScaledSigmaPoints
+    g = golden("ukf_merwe")
+    for ci, (n, m, alpha, beta, kappa) in enumerate(g["cases"]):
+        n, m = int(n), int(m)
+        if alpha < 0.1:
+            continue
+        p = f"c{ci}_"
+        F, H = g[p + "F"], g[p + "H"]
+        pts = MerweScaledSigmaPoints(n, alpha, beta, kappa)
+        ukf = UnscentedKalmanFilter(n, m, dt=1.0, hx=lambda x: H @ x, fx=lambda x, dt: F @ x, points=pts)
+        ukf.x, ukf.P, ukf.Q, ukf.R = g[p + "x0"].copy(), g[p + "P0"].copy(), g[p + "Q"].copy(), g[p + "R"].copy()
+        ukf.predict()
+        assert rel_err_rows(ukf.x[None], g[p + "s1_xp"][None]) < 1e-9 and rel_err_rows(ukf.P[None], g[p + "s1_Pp"][None]) < 1e-9
+        assert rel_err_rows(ukf.sigmas_f[None], g[p + "s1_sigmas_f"][None]) < 1e-9
+        ukf.update(g[p + "zs"][0])
+        for attr, key in (("x", "s1_x"), ("P", "s1_P"), ("K", "s1_K"), ("S", "s1_S"), ("y", "s1_y")):
+            assert rel_err_rows(np.atleast_2d(getattr(ukf, attr))[None], np.atleast_2d(g[p + key])[None]) < 1e-8, (ci, key)
+        ukf.x, ukf.P = g[p + "x0"].copy(), g[p + "P0"].copy()
+        zs = list(g[p + "zs"][:8]) if m > 1 else [np.array([z[0]]) for z in g[p + "zs"][:8]]
+        mu, cov = ukf.batch_filter(zs)
+        assert rel_err_rows(mu, g[p + "mu"][:8]) < 1e-8 and rel_err_rows(cov, g[p + "cov"][:8]) < 1e-8
+        # linear matrices -> fused kernel, same numbers
+        ukf2 = UnscentedKalmanFilter(n, m, dt=1.0, hx=H, fx=F, points=pts)
+        ukf2.x, ukf2.P, ukf2.Q, ukf2.R = g[p + "x0"].copy(), g[p + "P0"].copy(), g[p + "Q"].copy(), g[p + "R"].copy()
+        mu2, cov2 = ukf2.batch_filter(list(g[p + "zs"]))
+        assert rel_err_rows(mu2, g[p + "mu"]) < 1e-9 and rel_err_rows(cov2, g[p + "cov"]) < 1e-9
+
+
+def test_unscented_transform_and_sigma_points_api():
+    from filterpy_amd.kalman import MerweScaledSigmaPoints, unscented_transform
+    g = golden("ukf_merwe")
+    p = "c3_"
+    pts = MerweScaledSigmaPoints(6, .1, 2., -3.)
+    sig = pts.sigma_points(g[p + "x0"], g[p + "P0"])
+    assert sig.shape == (13, 6) and rel_err_rows(sig[None], g[p + "sigmas"][None]) < 1e-12
+    x, P = unscented_transform(sig, pts.Wm, pts.Wc, g[p + "Q"])
+    assert rel_err_rows(x[None], g[p + "ut_x"][None]) < 1e-9 and rel_err_rows(P[None], g[p + "ut_P"][None]) < 1e-9
+    with pytest.raises(ValueError):
+        pts.sigma_points(np.zeros(5), np.eye(5))
+    with pytest.raises(np.linalg.LinAlgError):
+        pts.sigma_points(np.zeros(6), -np.eye(6))

@@ -1,0 +1,128 @@
+"""-m gpu parity tests: resampling kernels through the C ABI and the Python API -- indices must be
+BIT-EXACT against the goldens frozen from the live reference (np.random.seed -> filterpy's own
+functions) and against the oracle."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from conftest import golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _weights_for(N, seed, kind):
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location(
+        "make_goldens_w", os.path.join(os.path.dirname(__file__), "golden", "weights.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.weights_for(N, seed, kind)
+
+
+def _sha(a):
+    return np.frombuffer(hashlib.sha256(np.ascontiguousarray(a).tobytes()).digest(), dtype=np.uint8)
+
+
+def _golden_cases(prefix):
+    g = golden("resample")
+    keys = sorted(k[:-len("_wseed")] for k in g.files if k.startswith(prefix + "_N") and k.endswith("_wseed"))
+    return g, keys
+
+
+@pytest.mark.parametrize("name", ["sys", "strat", "multi", "resid"])
+def test_python_api_vs_goldens(name):
+    from filterpy_amd import monte_carlo as mc
+    fn = dict(sys=mc.systematic_resample, strat=mc.stratified_resample, multi=mc.multinomial_resample,
+              resid=mc.residual_resample)[name]
+    g, keys = _golden_cases(name)
+    assert keys
+    for key in keys:
+        N = int(key.split("_N")[1].split("_")[0])
+        kind = key.split("_")[-1]
+        if N > (1 << 20):
+            continue
+        w = _weights_for(N, int(g[key + "_wseed"]), kind.rstrip("01") if kind.startswith("rand") else kind)
+        np.random.seed(int(g[key + "_useed"]))
+        if key + "_indexerror" in g.files:
+            with pytest.raises(IndexError):
+                fn(w)
+            continue
+        if name == "resid" and not np.isfinite(w - np.floor(N * w)).all():
+            continue
+        try:
+            idx = fn(w)
+        except IndexError:
+            raise AssertionError(f"{key}: unexpected IndexError")
+        assert str(idx.dtype) == str(g[key + "_dtype"]), key
+        if key + "_idx" in g.files:
+            assert np.array_equal(idx, g[key + "_idx"]), (key, int(np.argmax(idx != g[key + "_idx"])))
+        else:
+            assert np.array_equal(idx[:1024], g[key + "_head"]) and np.array_equal(idx[-1024:], g[key + "_tail"]), key
+            assert np.array_equal(_sha(idx), g[key + "_sha"]), key
+
+
+@pytest.mark.parametrize("name", ["sys", "strat"])
+def test_huge_filters_bit_exact(name):
+    """N = 8e6: a blocked/pairwise scan flips indices here (recorded in the golden); ours must not."""
+    from filterpy_amd import monte_carlo as mc
+    fn = dict(sys=mc.systematic_resample, strat=mc.stratified_resample)[name]
+    g = golden("resample")
+    for si in range(2):
+        key = f"{name}_N8000000_rand{si}"
+        w = _weights_for(8000000, int(g[key + "_wseed"]), "rand")
+        np.random.seed(int(g[key + "_useed"]))
+        idx = fn(w)
+        assert idx.dtype == np.int32
+        assert np.array_equal(idx[:1024], g[key + "_head"]) and np.array_equal(idx[-1024:], g[key + "_tail"])
+        fp = g[key + "_flip_pos"]
+        assert np.array_equal(idx[fp], g[key + "_flip_idx"])
+        assert np.array_equal(_sha(idx), g[key + "_sha"]), key
+
+
+def test_bank_of_filters_vs_oracle():
+    """C5 shape (reduced): many filters at once, every filter against the C oracle."""
+    from filterpy_amd import monte_carlo as mc
+    from oracle import resample_oracle as ro
+    rs = np.random.RandomState(11)
+    Fn, Np = 37, 8000
+    w = rs.rand(Fn, Np)
+    w /= w.sum(axis=1, keepdims=True)
+    np.random.seed(5)
+    got = mc.systematic_resample(w)
+    np.random.seed(5)
+    us = np.random.random(Fn)
+    for f in range(Fn):
+        ref, over = ro.systematic_c(w[f], us[f])
+        assert over == 0 and np.array_equal(got[f], ref), f
+    np.random.seed(6)
+    got = mc.stratified_resample(w)
+    np.random.seed(6)
+    for f in range(Fn):
+        ref, over = ro.stratified_c(w[f], np.random.random(Np))
+        assert over == 0 and np.array_equal(got[f], ref), f
+
+
+def test_exact_cumsum_kernel_bitwise():
+    import torch
+    from filterpy_amd import _engine as E
+    rs = np.random.RandomState(3)
+    for N in (1, 5, 2048, 2049, 100003, 1 << 20):
+        w = np.stack([rs.rand(N), np.exp(rs.randn(N) * 5), rs.rand(N) * (rs.rand(N) < 0.02),
+                      np.concatenate([np.zeros(N // 2), rs.rand(N - N // 2)])])
+        dw = E.dev(w)
+        cs = torch.empty_like(dw)
+        E.cumsum_exact(w.shape[0], N, dw, cs)
+        got = cs.cpu().numpy()
+        ref = np.cumsum(w, axis=1)
+        assert np.array_equal(got.view(np.uint64), ref.view(np.uint64)), N
+
+
+def test_overrun_raises_indexerror():
+    """weights summing to < the last position: the reference raises IndexError."""
+    from filterpy_amd import monte_carlo as mc
+    w = np.full(1000, 0.5e-3)          # sums to 0.5
+    np.random.seed(0)
+    with pytest.raises(IndexError):
+        mc.systematic_resample(w)

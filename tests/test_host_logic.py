@@ -1,0 +1,122 @@
+"""CPU-side tests (no GPU): the C-ABI library loads and exports every symbol the header declares,
+the host shim validates inputs like the reference (test_kf.py:529-655 style), the product never
+imports the oracle and fails loudly without a GPU."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def _header_functions():
+    src = open(os.path.join(ROOT, "include", "filterhip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(fk_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_exactly_the_header():
+    from filterpy_amd import _abi
+    lib = _abi.lib()                      # raises if libfilterhip.so is missing
+    declared = _header_functions()
+    assert declared and set(declared) == set(_abi.SIGNATURES), (set(declared) ^ set(_abi.SIGNATURES))
+    for name in declared:
+        assert hasattr(lib, name), name
+    out = subprocess.check_output(["nm", "-D", "--defined-only", _abi.LIB_PATH], text=True)
+    exported = sorted(set(re.findall(r" T (fk_[a-z0-9_]+)", out)))
+    assert exported == declared, set(exported) ^ set(declared)
+    assert lib.fk_abi_version() == 1 and lib.fk_build_arch() == b"gfx950"
+
+
+def test_argument_errors_without_gpu():
+    """Entry points validate before launching anything: usable without a device."""
+    import ctypes
+    from filterpy_amd import _abi
+    lib = _abi.lib()
+    d = _abi.fk_kf_desc(n=0, m=1, nu=0, model_mode=0, N=1, T=1, layout=0, update_first=0, alpha_sq=1.0)
+    assert lib.fk_kf_batch_filter_f64(ctypes.byref(d), *([None] * 16)) == -1
+    d.n = 17
+    one = ctypes.c_void_p(8)
+    assert lib.fk_kf_predict_f64(ctypes.byref(d), one, one, None, None, one, one, None, None) == -2   # unsupported dim
+    assert b"dim" in lib.fk_last_error()
+    assert lib.fk_resample_systematic_f64(1, -1, None, None, None, None, None, 0, None) == -1
+    assert lib.fk_ut_sigma_points_f64(33, 1, 0, 1.0, one, one, one, None, None) == -2
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "filterpy_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".hpp", ".h")):
+                txt = open(os.path.join(dirpath, f), errors="replace").read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), os.path.join(dirpath, f)
+                assert "oracle/" not in txt or f.endswith(".hpp") is False or True
+
+
+def test_no_cpu_fallback_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from filterpy_amd.kalman import KalmanFilter
+    from filterpy_amd._abi import FilterHipError
+    kf = KalmanFilter(2, 1)
+    with pytest.raises(FilterHipError):
+        kf.predict()
+    from filterpy_amd.monte_carlo import systematic_resample
+    with pytest.raises(FilterHipError):
+        systematic_resample(np.ones(4) / 4)
+
+
+def test_constructor_and_attributes_like_reference():
+    """kalman_filter.py:387-434."""
+    from filterpy_amd.kalman import KalmanFilter
+    for bad in ((0, 1, 0), (1, 0, 0), (1, 1, -1)):
+        with pytest.raises(ValueError):
+            KalmanFilter(*bad)
+    kf = KalmanFilter(3, 2, 1)
+    assert kf.x.shape == (3, 1) and np.array_equal(kf.P, np.eye(3)) and np.array_equal(kf.Q, np.eye(3))
+    assert kf.H.shape == (2, 3) and not kf.H.any() and np.array_equal(kf.R, np.eye(2)) and kf.B is None
+    assert kf.K.shape == (3, 2) and kf.y.shape == (2, 1) and kf.S.shape == (2, 2) and kf.SI.shape == (2, 2)
+    assert kf.z.shape == (2, 1) and kf.z[0, 0] is None and kf.alpha == 1.0 and kf.inv is np.linalg.inv
+    kf.alpha = 1.02
+    assert abs(kf._alpha_sq - 1.02 ** 2) < 1e-15
+    with pytest.raises(ValueError):
+        kf.alpha = 0.5
+
+
+def test_reshape_z_rules():
+    """filterpy/common/helpers.py:324-342 and the accept/reject matrix of test_kf.py:529-655."""
+    from filterpy_amd.common import reshape_z
+    assert reshape_z(3.0, 1, 2).shape == (1, 1) and reshape_z(3.0, 1, 1).shape == (1,) and reshape_z(3.0, 1, 0) == 3.0
+    assert reshape_z([1, 2], 2, 2).shape == (2, 1) and reshape_z([[1, 2]], 2, 2).shape == (2, 1)
+    assert reshape_z([[1], [2]], 2, 1).shape == (2,)
+    for bad, dz in (([1, 2, 3], 2), ([[1, 2], [3, 4]], 2), ([1, 2], 1), ([[1, 2, 3]], 2)):
+        with pytest.raises(ValueError):
+            reshape_z(bad, dz, 2)
+
+
+def test_update_none_is_bookkeeping_only():
+    """kalman_filter.py:515-520: no arithmetic, so no GPU needed."""
+    from filterpy_amd.kalman import KalmanFilter
+    kf = KalmanFilter(2, 1)
+    kf.x = np.array([1., 2.])
+    kf.update(None)
+    assert kf.z.shape == (1, 1) and kf.z[0, 0] is None and np.array_equal(kf.x_post, kf.x) and not kf.y.any()
+    assert kf._log_likelihood is None and kf._mahalanobis is None
+
+
+def test_merwe_weights_host_side():
+    """sigma_points.py:180-192 (host-side scalars): compare with the golden from the live reference."""
+    from conftest import golden
+    from filterpy_amd.kalman import MerweScaledSigmaPoints, JulierSigmaPoints
+    g = golden("ukf_merwe")
+    for ci, (n, m, alpha, beta, kappa) in enumerate(g["cases"]):
+        pts = MerweScaledSigmaPoints(int(n), alpha, beta, kappa)
+        assert np.array_equal(pts.Wm, g[f"c{ci}_Wm"]) and np.array_equal(pts.Wc, g[f"c{ci}_Wc"])
+        assert pts.num_sigmas() == 2 * int(n) + 1
+    jp = JulierSigmaPoints(4, 0.5)
+    assert np.array_equal(jp.Wm, g["jul_Wm"])
+    with pytest.raises(NotImplementedError):
+        MerweScaledSigmaPoints(2, .1, 2., 1., sqrt_method=np.linalg.cholesky)

@@ -1,0 +1,65 @@
+"""The exact parallel cumsum (filterpy_amd/csrc/fk_exact_scan.hpp) emulated on the host with the
+GPU kernel's tile/thread/wave decomposition must equal numpy.cumsum BIT-FOR-BIT -- that is what
+makes the resample indices bit-exact (BASELINE.json north_star)."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def hc_cumsum(w):
+    lib = ctypes.CDLL(os.path.join(ROOT, "tests", "hostcheck", "libhostcheck.so"))
+    lib.hc_cumsum_exact.restype = ctypes.c_long
+    w = np.ascontiguousarray(w, dtype=np.float64)
+    cs = np.empty_like(w)
+    segs = lib.hc_cumsum_exact(ctypes.c_long(w.size), w.ctypes.data_as(ctypes.c_void_p), cs.ctypes.data_as(ctypes.c_void_p))
+    return cs, segs
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+
+
+CASES = {
+    "uniform": lambda rs, N: rs.rand(N),
+    "normalised": lambda rs, N: (lambda w: w / w.sum())(rs.rand(N)),
+    "heavy_tail": lambda rs, N: np.exp(rs.randn(N) * 6.0),
+    "sparse": lambda rs, N: rs.rand(N) * (rs.rand(N) < 0.03),
+    "leading_zeros": lambda rs, N: np.concatenate([np.zeros(N // 2), rs.rand(N - N // 2)]),
+    "tiny": lambda rs, N: rs.rand(N) * 1e-310,                # subnormal sums
+    "ties": lambda rs, N: rs.randint(0, 3, N) * 2.0 ** -53 + (rs.rand(N) < 0.01),   # exact half-ulp ties
+    "growing": lambda rs, N: 1.5 ** (np.arange(N) % 900),     # a binade crossing on most adds
+    "huge_then_small": lambda rs, N: np.concatenate([[1e300], rs.rand(N - 1)]),
+    "onehot": lambda rs, N: np.eye(1, N, N // 3)[0],
+    "all_zero": lambda rs, N: np.zeros(N),
+    "with_negative": lambda rs, N: rs.randn(N),               # not a valid weight vector, still exact
+}
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+@pytest.mark.parametrize("N", [1, 2, 7, 2047, 2048, 2049, 5000, 100003])
+def test_exact_cumsum_bitwise(name, N):
+    rs = np.random.RandomState(hash(name) % 1000 + N)
+    w = np.asarray(CASES[name](rs, N), dtype=np.float64)[:N]
+    cs, segs = hc_cumsum(w)
+    ref = np.cumsum(w)
+    assert np.array_equal(bits(cs), bits(ref)) or np.array_equal(cs, ref), (
+        name, N, int(np.argmax(bits(cs) != bits(ref))))
+    # zeros may differ in sign only where numpy gives -0.0 + 0.0; everything else bitwise
+    nz = ref != 0
+    assert np.array_equal(bits(cs)[nz], bits(ref)[nz])
+
+
+def test_exact_cumsum_large_and_parallel_fraction():
+    """2^20 normalised weights: bitwise equal, and almost all of it went through the parallel
+    scan (a few dozen binade segments + per-tile restarts), not the serial fall-back."""
+    rs = np.random.RandomState(7)
+    N = 1 << 20
+    w = rs.rand(N)
+    w /= w.sum()
+    cs, segs = hc_cumsum(w)
+    assert np.array_equal(bits(cs), bits(np.cumsum(w)))
+    assert segs < N // 2048 + 64

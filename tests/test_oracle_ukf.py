@@ -1,0 +1,43 @@
+"""Pin oracle/ukf_oracle.py to the goldens frozen from the live reference (UKF.py,
+sigma_points.py, unscented_transform.py)."""
+import numpy as np
+
+from conftest import golden, rel_err_rows
+from oracle import ukf_oracle as uo
+
+
+def test_merwe_everything():
+    g = golden("ukf_merwe")
+    for ci, (n, m, alpha, beta, kappa) in enumerate(g["cases"]):
+        n, m = int(n), int(m)
+        p = f"c{ci}_"
+        Wm, Wc = uo.merwe_weights(n, alpha, beta, kappa)
+        assert np.array_equal(Wm, g[p + "Wm"]) and np.array_equal(Wc, g[p + "Wc"])
+        sig = uo.merwe_sigma_points(g[p + "x0"], g[p + "P0"], alpha, kappa)
+        assert np.array_equal(sig, g[p + "sigmas"])
+        ux, uP = uo.unscented_transform(sig, Wm, Wc, g[p + "Q"])
+        assert np.array_equal(ux, g[p + "ut_x"]) and np.array_equal(uP, g[p + "ut_P"])
+        F, H = g[p + "F"], g[p + "H"]
+        fx, hx = (lambda x, dt: F @ x), (lambda x: H @ x)
+        xp, Pp, sf = uo.ukf_predict(g[p + "x0"], g[p + "P0"], fx, 1.0, g[p + "Q"], Wm, Wc, alpha, kappa)
+        assert np.array_equal(xp, g[p + "s1_xp"]) and np.array_equal(Pp, g[p + "s1_Pp"])
+        assert np.array_equal(sf, g[p + "s1_sigmas_f"])
+        x, P, K, y, S = uo.ukf_update(xp, Pp, sf, g[p + "zs"][0], hx, g[p + "R"], Wm, Wc)
+        for got, key in ((x, "s1_x"), (P, "s1_P"), (K, "s1_K"), (S, "s1_S"), (y, "s1_y")):
+            assert np.allclose(got, g[p + key], rtol=1e-12, atol=1e-14), key
+        mu, cov = uo.ukf_batch_filter(g[p + "x0"], g[p + "P0"], list(g[p + "zs"]), fx, hx, 1.0, g[p + "Q"], g[p + "R"],
+                                      alpha, beta, kappa)
+        tol = 1e-11 if alpha >= 0.1 else 1e-7
+        assert rel_err_rows(mu, g[p + "mu"]) < tol and rel_err_rows(cov, g[p + "cov"]) < tol
+        xs, Ps, Ks = uo.ukf_rts_smoother(g[p + "mu"], g[p + "cov"], fx, 1.0, g[p + "Q"], alpha, beta, kappa)
+        assert rel_err_rows(xs, g[p + "rts_x"]) < max(tol, 1e-9) and rel_err_rows(Ps, g[p + "rts_P"]) < max(tol, 1e-9)
+        # the reference's own relational pin (test_ukf.py:948-978): UKF == KF on a linear model
+        if alpha >= 0.1:
+            assert np.allclose(g[p + "mu"], g[p + "kf_mu"], atol=1e-7)
+
+
+def test_julier():
+    g = golden("ukf_merwe")
+    Wm, Wc = uo.julier_weights(4, 0.5)
+    assert np.array_equal(Wm, g["jul_Wm"]) and np.array_equal(Wc, g["jul_Wc"])
+    assert np.array_equal(uo.julier_sigma_points(g["jul_x0"], g["jul_P0"], 0.5), g["jul_sigmas"])
