@@ -116,6 +116,17 @@ def cpu_baseline(T, budget_s=10.0, max_procs=64):
                       f"{wall:.1f} s wall"}
 
 
+def pmc_traffic(layout):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary of this
+    same command (profiles/pmc_traffic.json: FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE,
+    separate passes).  None if no summary is committed for this layout."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
+            return json.load(fh)[layout]["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 # -------------------------------------------------------------------- main --
 def main():
     ap = argparse.ArgumentParser()
@@ -132,18 +143,16 @@ def main():
     import torch
     import torch.distributed as dist
     from filterpy_amd import _engine as E
+    from filterpy_amd import parallel
     from oracle import kf_oracle
 
-    rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    rank, world = parallel.init_from_env(backend="nccl", device=device)
 
     N, T, layout, n, m = args.tracks, args.T, args.layout, 4, 2
     F, Q, H, R = c2_model()
@@ -168,12 +177,9 @@ def main():
         if ev:
             ev[1].record()
         if world > 1:
-            dist.all_gather_into_tensor(gathered, x)       # summary state over RCCL/xGMI
+            parallel.allgather_summary(x, gathered)        # summary state over RCCL/xGMI
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+    barrier = parallel.barrier
 
     for _ in range(args.warmup):
         step()
@@ -185,10 +191,7 @@ def main():
         step(events[k])
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax)
+    elapsed = parallel.max_over_ranks(elapsed, device)
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in events])) if events else float("nan")
     assert int(status.abs().max()) == 0, "kernel flagged tracks"
 
@@ -225,7 +228,7 @@ def main():
                        "tracks_per_gpu": N, "T": T, "layout": layout,
                        "parallelism": f"tracks sharded over {world} GPU(s)" + (", RCCL all-gather of final x per step" if world > 1 else "")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(layout),
                          "kernel": "fk::kf_fast_kernel<4,2," + layout + ",nomask,outs> (variant " + os.environ.get("FK_FAST_VARIANT", "0") + ")", "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_launch": alg_bytes},
             "parity_max_rel_vs_oracle": worst,

@@ -1,0 +1,58 @@
+"""Multi-GPU plumbing: one process per GPU (torch.distributed; backend "nccl" is RCCL over xGMI
+on ROCm, "gloo" on CPU for tests).  Tracks / particle filters are independent, so the data path
+has NO collective: units are sharded in contiguous blocks and the only exchange is an all-gather
+of summary state (final x per track, posterior means per filter) after the time loop."""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(n_units, rank, world):
+    """Contiguous block [lo, hi) of `n_units` owned by `rank` (sizes differ by at most one)."""
+    base, rem = divmod(int(n_units), int(world))
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def init_from_env(backend=None, device=None):
+    """Initialise the default process group from RANK / WORLD_SIZE / MASTER_* (torchrun sets them).
+    Returns (rank, world).  A single process needs no group."""
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+        kw = {"device_id": device} if (backend == "nccl" and device is not None) else {}
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    return rank, world
+
+
+def allgather_summary(local, out=None):
+    """All-gather equally-shaped per-rank summary tensors -> tensor (world, *local.shape)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return local.unsqueeze(0) if out is None else out.copy_(local.unsqueeze(0))
+    world = dist.get_world_size()
+    if out is None:
+        out = torch.empty((world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
+    if dist.get_backend() == "nccl":
+        dist.all_gather_into_tensor(out, local.contiguous())
+    else:
+        dist.all_gather(list(out.unbind(0)), local.contiguous())
+    return out
+
+
+def max_over_ranks(value, device=None):
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device or "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t)
+
+
+def barrier():
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
