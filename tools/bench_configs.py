@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""Secondary measurements for BASELINE.json configs[2..4] on ONE MI355X (bench.py is configs[1]):
+
+  C3  1e5 tracks dim_x=9 dim_z=3 (CV-3D, dt=0.1) batch_filter + rts_smoother backward pass
+  C4  UKF dim_x=6 dim_z=3, 1e5 tracks: sigma_points / unscented_transform standalone, fused linear UKF
+  C5  systematic_resample: 1e3 filters x 8e3 particles (one GPU's view), plus a few 8e6-particle filters
+
+Each line: kernel, units/s, achieved algorithmic GB/s and fraction of the 8 TB/s HBM peak,
+plus a parity figure against the oracle on a sample.  Writes JSON lines to stdout.
+"""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+PEAK = 8000.0
+
+
+def timeit(fn, warm=2, reps=5):
+    import torch
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for a, b in evs:
+        a.record()
+        fn()
+        b.record()
+    torch.cuda.synchronize()
+    return float(np.median([a.elapsed_time(b) for a, b in evs]))
+
+
+def emit(name, units, unit_name, ms, bytes_per_unit, **extra):
+    gbs = units * bytes_per_unit / (ms * 1e-3) / 1e9
+    print(json.dumps(dict(kernel=name, units=units, unit=unit_name, ms=ms, units_per_s=units / (ms * 1e-3),
+                          alg_bytes_per_unit=bytes_per_unit, achieved_GBs=gbs, frac_of_8TBs=gbs / PEAK, **extra)),
+          flush=True)
+
+
+def cv3d_model(dt=0.1):
+    F2 = np.array([[1, dt, dt * dt / 2], [0, 1, dt], [0, 0, 1.]])
+    F = np.kron(np.eye(3), F2)
+    H = np.zeros((3, 9))
+    H[0, 0] = H[1, 3] = H[2, 6] = 1.0
+    q = np.array([[dt ** 4 / 4, dt ** 3 / 2, dt ** 2 / 2], [dt ** 3 / 2, dt ** 2, dt], [dt ** 2 / 2, dt, 1.]]) * 0.01
+    return F, np.kron(np.eye(3), q), H, 0.25 * np.eye(3)
+
+
+def rel(a, b):
+    a, b = a.reshape(a.shape[0], -1), b.reshape(b.shape[0], -1)
+    s = np.max(np.abs(b), axis=1)
+    s[s == 0] = 1
+    return float(np.max(np.max(np.abs(a - b), axis=1) / s))
+
+
+def config3(layout, N, T):
+    import torch
+    from filterpy_amd import _engine as E
+    from oracle import kf_oracle
+    n, m = 9, 3
+    F, Q, H, R = cv3d_model()
+    dev = torch.device("cuda")
+    g = torch.Generator(device=dev)
+    g.manual_seed(3)
+    z = torch.randn((T, N, m) if layout == "aos" else (T, m, N), generator=g, device=dev, dtype=torch.float64)
+    x0 = torch.zeros((N, n) if layout == "aos" else (n, N), dtype=torch.float64, device=dev)
+    P0 = (10.0 * torch.eye(n, dtype=torch.float64, device=dev)).reshape(1, n * n).repeat(N, 1)
+    P0 = P0.contiguous() if layout == "aos" else P0.T.contiguous()
+    x, P = x0.clone(), P0.clone()
+    outs = [E.alloc_records((T,), N, n, layout), E.alloc_records((T,), N, n * n, layout),
+            E.alloc_records((T,), N, n, layout), E.alloc_records((T,), N, n * n, layout)]
+    st = torch.zeros(N, dtype=torch.int32, device=dev)
+    dF, dQ, dH, dR = (E.dev(M) for M in (F, Q, H, R))
+    desc = dict(n=n, m=m, nu=0, model_mode=0, N=N, T=T, layout=E.LAYOUTS[layout], update_first=0, alpha_sq=1.0)
+
+    def fwd():
+        x.copy_(x0)
+        P.copy_(P0)
+        E.kf_batch_filter(desc, dF, dQ, dH, dR, z, x, P, means=outs[0], covs=outs[1], means_p=outs[2], covs_p=outs[3], status=st)
+    ms = timeit(fwd)
+    assert not st.any()
+    sample = [0, 255, 256, N - 1]
+    zs_h = (z[:, sample] if layout == "aos" else z[:, :, sample].permute(0, 2, 1)).cpu().numpy()
+    ref = kf_oracle.kf_batch_filter_tracks(np.zeros((4, n)), np.tile(10 * np.eye(n), (4, 1, 1)), zs_h, F, Q, H, R, tracks=range(4))
+    mu = E.from_records(outs[0], layout, 1, (n,))[:, sample]
+    cov = E.from_records(outs[1], layout, 1, (n, n))[:, sample]
+    par = max(rel(mu.reshape(-1, n), ref[0].reshape(-1, n)), rel(cov.reshape(-1, n * n), ref[1].reshape(-1, n * n)))
+    emit(f"C3 kf batch_filter (9,3) {layout}", N * T, "track-steps", ms, 8 * (m + 2 * n + 2 * n * n), parity_max_rel=par)
+
+    so = [E.alloc_records((T,), N, n, layout)] + [E.alloc_records((T,), N, n * n, layout) for _ in range(3)]
+
+    def bwd():
+        E.kf_rts(desc, dF, dQ, outs[0], outs[1], so[0], so[1], so[2], so[3], convention=0, status=st)
+    ms = timeit(bwd)
+    assert not st.any()
+    sm = kf_oracle.rts_smoother_tracks(ref[0], ref[1], F, Q, tracks=range(4))
+    Ps = E.from_records(so[1], layout, 1, (n, n))[:, sample]
+    par = rel(Ps.reshape(-1, n * n), sm[1].reshape(-1, n * n))
+    emit(f"C3 rts_smoother n=9 {layout}", N * T, "track-steps", ms, 8 * (2 * n + 4 * n * n), parity_max_rel=par)
+
+
+def config4(layout, N, T):
+    import torch
+    from filterpy_amd import _engine as E
+    from oracle import ukf_oracle
+    n, m, k = 6, 3, 13
+    alpha, beta, kappa = .1, 2., -3.
+    lam = alpha ** 2 * (n + kappa) - n
+    Wm, Wc = ukf_oracle.merwe_weights(n, alpha, beta, kappa)
+    dt = 0.1
+    F = np.eye(n)
+    for i in range(3):
+        F[i, i + 3] = dt
+    H = np.zeros((m, n))
+    H[0, 0] = H[1, 1] = H[2, 2] = 1.0
+    Q, R = 0.01 * np.eye(n), 0.5 * np.eye(m)
+    dev = torch.device("cuda")
+    g = torch.Generator(device=dev)
+    g.manual_seed(4)
+    for NN in (N, 10 * N, 50 * N):          # 50N = 5e6 tracks: the (2n+1)n record slab stays below the 4 GiB addressing limit
+        x = torch.randn((NN, n) if layout == "aos" else (n, NN), generator=g, device=dev, dtype=torch.float64)
+        P = (10.0 * torch.eye(n, dtype=torch.float64, device=dev)).reshape(1, n * n).repeat(NN, 1)
+        P = P.contiguous() if layout == "aos" else P.T.contiguous()
+        sig = E.alloc_records((), NN, k * n, layout)
+        xo, Po = E.alloc_records((), NN, n, layout), E.alloc_records((), NN, n * n, layout)
+        dWm, dWc, dQ = E.dev(Wm), E.dev(Wc), E.dev(Q)
+        ms = timeit(lambda: E.ut_sigma_points(n, NN, layout, lam + n, x, P, sig))
+        emit(f"C4 sigma_points n=6 N={NN} {layout}", NN, "tracks", ms, 8 * (n + n * n + k * n))
+        ms = timeit(lambda: E.ut_transform(n, k, NN, layout, sig, dWm, dWc, dQ, xo, Po))
+        emit(f"C4 unscented_transform n=6 N={NN} {layout}", NN, "tracks", ms, 8 * (k * n + n + n * n))
+    # fused linear UKF over T steps
+    z = torch.randn((T, N, m) if layout == "aos" else (T, m, N), generator=g, device=dev, dtype=torch.float64)
+    x0 = torch.randn((N, n) if layout == "aos" else (n, N), generator=g, device=dev, dtype=torch.float64)
+    P0 = (10.0 * torch.eye(n, dtype=torch.float64, device=dev)).reshape(1, n * n).repeat(N, 1)
+    P0 = P0.contiguous() if layout == "aos" else P0.T.contiguous()
+    x, P = x0.clone(), P0.clone()
+    means, covs = E.alloc_records((T,), N, n, layout), E.alloc_records((T,), N, n * n, layout)
+    st = torch.zeros(N, dtype=torch.int32, device=dev)
+    dd = [E.dev(M) for M in (F, H, Q, R, Wm, Wc)]
+
+    def run():
+        x.copy_(x0)
+        P.copy_(P0)
+        E.ukf_linear_batch(n, m, N, T, layout, lam + n, *dd, z, x, P, means=means, covs=covs, status=st)
+    ms = timeit(run)
+    assert not st.any()
+    trk = 7
+    zs_h = (z[:, trk] if layout == "aos" else z[:, :, trk]).cpu().numpy()
+    x0h = (x0[trk] if layout == "aos" else x0[:, trk]).cpu().numpy()
+    mu_ref, cov_ref = ukf_oracle.ukf_batch_filter(x0h, 10 * np.eye(n), list(zs_h), lambda s, d: F @ s, lambda s: H @ s,
+                                                  dt, Q, R, alpha, beta, kappa)
+    mu = E.from_records(means, layout, 1, (n,))[:, trk]
+    cov = E.from_records(covs, layout, 1, (n, n))[:, trk]
+    par = max(rel(mu, mu_ref), rel(cov.reshape(T, -1), cov_ref.reshape(T, -1)))
+    emit(f"C4 fused linear UKF (6,3) {layout}", N * T, "track-steps", ms, 8 * (m + n + n * n), parity_max_rel=par)
+
+
+def config5():
+    import torch
+    from filterpy_amd import _engine as E
+    from oracle import resample_oracle as ro
+    dev = torch.device("cuda")
+    for Fn, Np in ((1000, 8000), (125, 8000), (8, 8_000_000), (1, 8_000_000)):
+        rs = np.random.RandomState(5)
+        w = rs.rand(min(Fn, 8), Np)
+        w /= w.sum(axis=1, keepdims=True)
+        wd = E.dev(np.tile(w, (Fn // w.shape[0] + 1, 1))[:Fn])
+        u = E.dev(rs.rand(Fn))
+        idx = torch.empty((Fn, Np), dtype=torch.int32, device=dev)
+        st = torch.zeros(Fn, dtype=torch.int32, device=dev)
+        ms = timeit(lambda: E.resample_systematic(Fn, Np, wd, u, idx, st), warm=1, reps=3)
+        assert not st.any()
+        ref = ro.systematic_np(w[0], float(u[0]))
+        exact = bool(np.array_equal(idx[0].cpu().numpy(), ref))
+        emit(f"C5 systematic_resample {Fn} filters x {Np} particles", Fn * Np, "particles", ms, 12, bit_exact=exact)
+        if Np <= 8000:
+            us = E.dev(rs.rand(Fn, Np))
+            ms = timeit(lambda: E.resample_stratified(Fn, Np, wd, us, idx, st), warm=1, reps=3)
+            emit(f"C5 stratified_resample {Fn} filters x {Np} particles", Fn * Np, "particles", ms, 20)
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--configs", default="3,4,5")
+    ap.add_argument("--layouts", default="soa,aos")
+    ap.add_argument("--N", type=int, default=100_000)
+    ap.add_argument("--T", type=int, default=100)
+    a = ap.parse_args()
+    for lay in a.layouts.split(","):
+        if "3" in a.configs:
+            config3(lay, a.N, a.T)
+        if "4" in a.configs:
+            config4(lay, a.N, a.T)
+    if "5" in a.configs:
+        config5()
