@@ -53,6 +53,7 @@ SIGNATURES = {
     "fk_resample_multinomial_f64": (ctypes.c_int, [c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "fk_cumsum_exact_f64": (ctypes.c_int, [c_i64, c_i64, c_vp, c_vp, c_i32, c_vp]),
     "fk_resample_workspace_bytes": (c_sz, [c_i64, c_i64]),
+    "fk_multinomial_workspace_bytes": (c_sz, [c_i64, c_i64]),
     "fk_abi_version": (ctypes.c_int, []),
     "fk_build_arch": (ctypes.c_char_p, []),
     "fk_last_error": (ctypes.c_char_p, []),

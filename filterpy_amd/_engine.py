@@ -170,7 +170,7 @@ def resample_stratified(Fn, Np, w, u, idx, status=None):
 
 
 def resample_multinomial(Fn, Np, Nu, w, u, idx):
-    nbytes = resample_workspace_bytes(Fn, Np)
+    nbytes = int(_abi.lib().fk_multinomial_workspace_bytes(Fn, Np))
     ws = torch.empty(max(nbytes, 8), dtype=torch.uint8, device=w.device)
     rc = _abi.lib().fk_resample_multinomial_f64(Fn, Np, Nu, _ptr(w), _ptr(u), _ptr(idx), _ptr(ws), nbytes,
                                                 _stream())

@@ -69,18 +69,35 @@ FK_HD double ulp_of(double c)
     return bits_to_double((e - 52) << 52);
 }
 
-// The map "add w" while the running sum has ulp u.
-FK_HD Mono mono_elem(double w, double u)
+// log2 of ulp_of(c): the ulp is 2^ulp_exp(c), -1074 <= ulp_exp <= 971
+FK_HD int ulp_exp(double c)
+{
+    const int e = (int)((double_to_bits(c) >> 52) & 0x7ffu);
+    return (e <= 1 ? 1 : e) - 1075;
+}
+
+// x * 2^k, exact when the result is representable (one v_ldexp_f64 on the GPU)
+FK_HD double scale2(double x, int k)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_ldexp(x, k);
+#else
+    return ldexp(x, k);
+#endif
+}
+
+// The map "add w" while the running sum has ulp u = 2^eu.
+FK_HD Mono mono_elem(double w, double u, int eu)
 {
     // negative / NaN / huge weights end the segment and are added with a real fp add
-    if (!(w >= 0.0) || w * 0x1p-62 >= u) return Mono{MONO_BIG, MONO_BIG};
+    if (!(w >= 0.0) || !(w < 0x1p1000)) return Mono{MONO_BIG, MONO_BIG};
     long long q = 0;
     double r = w;
     if (w >= u) {
-        const double t = w / u;            // exact: u is a power of two
-        if (t >= 0x1p53) return Mono{MONO_BIG, MONO_BIG};
+        const double t = scale2(w, -eu);   // w / u, exact: u is a power of two and t >= 1
+        if (!(t < 0x1p53)) return Mono{MONO_BIG, MONO_BIG};
         q = (long long)t;                  // floor (t >= 0)
-        r = w - (double)q * u;             // exact
+        r = w - scale2((double)q, eu);     // exact
     }
     const double half = u * 0.5;           // 0 when u is the smallest subnormal (then r == 0 always)
     if (r == half && r != 0.0) return Mono{q + (q & 1), q + ((q + 1) & 1)};

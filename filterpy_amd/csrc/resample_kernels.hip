@@ -17,6 +17,8 @@
 // Algorithmic HBM traffic: 8 B read + 4 B written per particle (+ 8 B per particle for the
 // stratified uniforms).  This translation unit is compiled with -ffp-contract=off: positions
 // and sums must be single IEEE operations.
+#include <stdlib.h>
+
 #include "../../include/filterhip.h"
 #include "fk_device.hpp"
 #include "fk_exact_scan.hpp"
@@ -26,6 +28,7 @@ namespace fk {
 constexpr int RS_THREADS = 256;
 constexpr int RS_ITEMS = 8;
 constexpr int RS_TILE = RS_THREADS * RS_ITEMS;   // 2048 weights per tile
+constexpr int RS_PRELUDE = 128;                  // first non-zero-sum elements of a vector: sequential adds
 
 struct ScanShared {
     double w[RS_TILE];          // weights of the tile, then (in place) their cumulative sums
@@ -46,7 +49,7 @@ __device__ __forceinline__ Mono shfl_up_mono(const Mono &m, int delta)
 // In-place exact inclusive prefix sum of sh.w[0..len) continuing from the running sum `carry`
 // (`started` = false means no element has been summed yet: cs[0] = w[0], like numpy.cumsum).
 // All RS_THREADS threads participate.  Returns the running sum after the tile.
-__device__ double tile_cumsum_exact(ScanShared &sh, int len, double carry, bool &started)
+__device__ double tile_cumsum_exact(ScanShared &sh, int len, double carry, bool &started, int &prelude)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int pos = 0;
@@ -87,14 +90,35 @@ __device__ double tile_cumsum_exact(ScanShared &sh, int len, double carry, bool 
             continue;
         }
 
+        // --- start of a vector: the running sum doubles after 1, 2, 4, ... elements, so nearly every
+        // add crosses a binade; a short plain sequential chain is cheaper than one scan per crossing
+        if (prelude > 0) {
+            const int stop = (pos + prelude < len) ? pos + prelude : len;
+            __syncthreads();
+            if (tid == 0) {
+                double c = carry;
+                for (int j = pos; j < stop; ++j) {
+                    c = c + sh.w[j];
+                    sh.w[j] = c;
+                }
+                sh.carry = c;
+            }
+            __syncthreads();
+            carry = sh.carry;
+            prelude -= stop - pos;
+            pos = stop;
+            continue;
+        }
+
         // --- one binade: parallel exact scan over [pos, len) ---------------------------------
         const double u = ulp_of(carry);
-        const long long C0 = (long long)(carry / u);
+        const int eu = ulp_exp(carry);
+        const long long C0 = (long long)scale2(carry, -eu);
         Mono loc[RS_ITEMS];
         Mono run = mono_identity();
         FK_UNROLL for (int k = 0; k < RS_ITEMS; ++k) {
             const int j = tid * RS_ITEMS + k;
-            const Mono e = (j >= pos && j < len) ? mono_elem(sh.w[j], u) : mono_identity();
+            const Mono e = (j >= pos && j < len) ? mono_elem(sh.w[j], u, eu) : mono_identity();
             run = mono_compose(run, e);
             loc[k] = run;
         }
@@ -180,12 +204,13 @@ resample_kernel(long Np, const double *__restrict__ w, const double *__restrict_
 
     double carry = 0.0;
     bool started = false;
+    int prelude = RS_PRELUDE;
     long out_lo = 0;     // output slots [0, out_lo) are done
     for (long base = 0; base < Np; base += RS_TILE) {
         const int len = (int)((Np - base) < RS_TILE ? (Np - base) : RS_TILE);
         for (int j = tid; j < RS_TILE; j += RS_THREADS) sh.w[j] = j < len ? wf[base + j] : 0.0;
         __syncthreads();
-        carry = tile_cumsum_exact(sh, len, carry, started);
+        carry = tile_cumsum_exact(sh, len, carry, started, prelude);
         // slots covered by this tile: pos_i < cs_last  (cs is non-decreasing for weights >= 0)
         const long out_hi = count_below<STRATIFIED>(carry, out_lo, Np, dNp, u_sys, u_str);
         for (long i = out_lo + tid; i < out_hi; i += RS_THREADS) {
@@ -218,11 +243,12 @@ cumsum_kernel(long Np, const double *__restrict__ w, double *__restrict__ cs, in
     const int tid = threadIdx.x;
     double carry = 0.0;
     bool started = false;
+    int prelude = RS_PRELUDE;
     for (long base = 0; base < Np; base += RS_TILE) {
         const int len = (int)((Np - base) < RS_TILE ? (Np - base) : RS_TILE);
         for (int j = tid; j < RS_TILE; j += RS_THREADS) sh.w[j] = j < len ? wf[base + j] : 0.0;
         __syncthreads();
-        carry = tile_cumsum_exact(sh, len, carry, started);
+        carry = tile_cumsum_exact(sh, len, carry, started, prelude);
         for (int j = tid; j < len; j += RS_THREADS) cf[base + j] = sh.w[j];
         __syncthreads();
     }
@@ -249,6 +275,195 @@ searchsorted_left_kernel(long Np, long Nu, const double *__restrict__ cs, const 
     idx[f * Nu + i] = lo;
 }
 
+// =================================================================================================
+// Chunk-parallel path for long weight vectors (Np >= RS_PAR_MIN): the sequential dependency of the
+// exact cumulative sum is reduced to one O(1) step per 2048-element chunk.
+//   P1 chunk_sum_kernel     : plain fp64 sum of every chunk (any order) + a "bad weight" flag
+//   P2 chunk_plan_kernel    : per filter, approximate running sum at every chunk start -> the binade
+//                             the exact running sum MUST be in for the whole chunk (error-bounded), or
+//                             "dirty" when the chunk may cross a binade / sits at the vector start
+//   P3 chunk_compose_kernel : clean chunks: the chunk's composite rounding map (Mono) in that binade
+//   P4 chain_kernel         : per filter, walk the chunks: clean -> c_out = map(c_in) after VERIFYING
+//                             the binade and that no crossing happened; dirty or unverified -> the exact
+//                             tile algorithm.  Stores the exact carry-in (+ scan state) of every chunk.
+//   P5 resample_chunk_kernel: every chunk independently: exact tile cumsum from its carry-in, output
+//                             range from the implicit positions, binary search, coalesced int32 stores.
+// Correctness never rests on the approximation of P1/P2 -- it only decides how much of P4 runs as O(1)
+// steps; every shortcut is verified against the exact carry.
+constexpr long RS_PAR_MIN = 16L * RS_TILE;
+
+struct ChunkPlan {          // one per (filter, chunk), in the caller's workspace
+    double approx_sum;      // P1
+    double cin;             // P4: exact running sum entering the chunk
+    Mono F;                 // P3: composite map of the chunk (clean chunks)
+    int eu;                 // P2: ulp exponent of the binade, RS_DIRTY when not clean
+    int bad;                // P1: chunk holds a negative / NaN / Inf weight
+    int started;            // P4: scan state entering the chunk
+    int prelude;            // P4
+};
+constexpr int RS_DIRTY = -100000;
+
+__global__ void __launch_bounds__(RS_THREADS)
+chunk_sum_kernel(long Np, long nch, const double *__restrict__ w, ChunkPlan *__restrict__ plan)
+{
+    __shared__ double red[RS_THREADS / 64];
+    __shared__ int badf;
+    const long f = blockIdx.y, k = blockIdx.x;
+    const long base = k * RS_TILE;
+    const int len = (int)((Np - base) < RS_TILE ? (Np - base) : RS_TILE);
+    const int tid = threadIdx.x;
+    if (tid == 0) badf = 0;
+    __syncthreads();
+    double acc = 0.0;
+    int bad = 0;
+    for (int j = tid; j < len; j += RS_THREADS) {
+        const double v = w[f * Np + base + j];
+        bad |= !(v >= 0.0 && v < 0x1p1000);
+        acc += v;
+    }
+    FK_UNROLL for (int d = 32; d > 0; d >>= 1) acc += __shfl_down(acc, d, 64);
+    if ((tid & 63) == 0) red[tid >> 6] = acc;
+    if (bad) atomicOr(&badf, 1);
+    __syncthreads();
+    if (tid == 0) {
+        ChunkPlan &p = plan[f * nch + k];
+        p.approx_sum = (red[0] + red[1]) + (red[2] + red[3]);
+        p.bad = badf;
+    }
+}
+
+// (the plan is small: a single thread per filter walks it)
+__global__ void __launch_bounds__(64)
+chunk_plan_kernel(long Fn, long Np, long nch, ChunkPlan *__restrict__ plan)
+{
+    const long f = (long)blockIdx.x * 64 + threadIdx.x;
+    if (f >= Fn) return;
+    // |approx prefix - exact sequential prefix| <= delta * prefix for non-negative weights
+    const double delta = 8.0 * (double)(Np + 4096) * 0x1p-53;
+    double A = 0.0;
+    bool poisoned = false;
+    for (long k = 0; k < nch; ++k) {
+        ChunkPlan &p = plan[f * nch + k];
+        const double S = p.approx_sum;
+        poisoned = poisoned || p.bad != 0 || !(S >= 0.0) || !(A + S < 0x1p1000);
+        int eu = RS_DIRTY;
+        if (!poisoned && k > 0) {
+            const double lo = A * (1.0 - delta), hi = (A + S) * (1.0 + delta);
+            if (lo > 0x1p-900 && ulp_exp(lo) == ulp_exp(hi)) eu = ulp_exp(lo);
+        }
+        p.eu = eu;
+        A += S;
+    }
+}
+
+__global__ void __launch_bounds__(RS_THREADS)
+chunk_compose_kernel(long Np, long nch, const double *__restrict__ w, ChunkPlan *__restrict__ plan)
+{
+    __shared__ Mono wave_tot[RS_THREADS / 64];
+    const long f = blockIdx.y, k = blockIdx.x;
+    ChunkPlan &p = plan[f * nch + k];
+    const int eu = p.eu;
+    if (eu == RS_DIRTY) return;            // uniform
+    const long base = k * RS_TILE;
+    const int len = (int)((Np - base) < RS_TILE ? (Np - base) : RS_TILE);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const double u = scale2(1.0, eu);
+    Mono run = mono_identity();
+    FK_UNROLL for (int q = 0; q < RS_ITEMS; ++q) {
+        const int j = tid * RS_ITEMS + q;
+        if (j < len) run = mono_compose(run, mono_elem(w[f * Np + base + j], u, eu));
+    }
+    FK_UNROLL for (int d = 1; d < 64; d <<= 1) {
+        const Mono up = shfl_up_mono(run, d);
+        if (lane >= d) run = mono_compose(up, run);
+    }
+    if (lane == 63) wave_tot[wave] = run;
+    __syncthreads();
+    if (tid == 0) {
+        Mono t = wave_tot[0];
+        for (int wv = 1; wv < RS_THREADS / 64; ++wv) t = mono_compose(t, wave_tot[wv]);
+        p.F = t;
+    }
+}
+
+__global__ void __launch_bounds__(RS_THREADS)
+chain_kernel(long Np, long nch, const double *__restrict__ w, ChunkPlan *__restrict__ plan)
+{
+    __shared__ ScanShared sh;
+    const long f = blockIdx.x;
+    const int tid = threadIdx.x;
+    double carry = 0.0;
+    bool started = false;
+    int prelude = RS_PRELUDE;
+    for (long k = 0; k < nch; ++k) {
+        ChunkPlan &p = plan[f * nch + k];
+        if (tid == 0) {
+            p.cin = carry;
+            p.started = started ? 1 : 0;
+            p.prelude = prelude;
+        }
+        const int eu = p.eu;                       // uniform
+        bool shortcut = false;
+        if (eu != RS_DIRTY && started && prelude == 0 && carry > 0.0 && ulp_exp(carry) == eu) {
+            const long long C0 = (long long)scale2(carry, -eu);
+            const long long C1 = mono_apply(C0, p.F);
+            if (C1 < MONO_LIMIT) {                 // stayed inside the binade: the map is exact
+                carry = scale2((double)C1, eu);
+                shortcut = true;
+            }
+        }
+        if (!shortcut) {
+            const long base = k * RS_TILE;
+            const int len = (int)((Np - base) < RS_TILE ? (Np - base) : RS_TILE);
+            __syncthreads();
+            for (int j = tid; j < RS_TILE; j += RS_THREADS) sh.w[j] = j < len ? w[f * Np + base + j] : 0.0;
+            __syncthreads();
+            carry = tile_cumsum_exact(sh, len, carry, started, prelude);
+        }
+    }
+}
+
+template <bool STRATIFIED>
+__global__ void __launch_bounds__(RS_THREADS)
+resample_chunk_kernel(long Np, long nch, const double *__restrict__ w, const double *__restrict__ u,
+                      const ChunkPlan *__restrict__ plan, int32_t *__restrict__ idx, int32_t *__restrict__ status)
+{
+    __shared__ ScanShared sh;
+    const long f = blockIdx.y, k = blockIdx.x;
+    const ChunkPlan &p = plan[f * nch + k];
+    const double *wf = w + f * Np;
+    int32_t *of = idx + f * Np;
+    const double u_sys = STRATIFIED ? 0.0 : u[f];
+    const double *u_str = STRATIFIED ? u + f * Np : nullptr;
+    const double dNp = (double)Np;
+    const int tid = threadIdx.x;
+    const long base = k * RS_TILE;
+    const int len = (int)((Np - base) < RS_TILE ? (Np - base) : RS_TILE);
+    for (int j = tid; j < RS_TILE; j += RS_THREADS) sh.w[j] = j < len ? wf[base + j] : 0.0;
+    __syncthreads();
+    double carry = p.cin;
+    bool started = p.started != 0;
+    int prelude = p.prelude;
+    // slots below the previous chunk's last cumulative sum belong to earlier chunks
+    const long out_lo = (k == 0) ? 0 : count_below<STRATIFIED>(carry, 0, Np, dNp, u_sys, u_str);
+    carry = tile_cumsum_exact(sh, len, carry, started, prelude);
+    const long out_hi = count_below<STRATIFIED>(carry, out_lo, Np, dNp, u_sys, u_str);
+    for (long i = out_lo + tid; i < out_hi; i += RS_THREADS) {
+        const double ps = position<STRATIFIED>(i, dNp, u_sys, u_str);
+        int lo = 0, hi = len;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (sh.w[mid] <= ps) lo = mid + 1;
+            else hi = mid;
+        }
+        of[i] = (int32_t)(base + lo);
+    }
+    if (k == nch - 1) {
+        for (long i = out_hi + tid; i < Np; i += RS_THREADS) of[i] = (int32_t)(Np - 1);
+        if (tid == 0 && status) status[f] = out_hi < Np ? ST_OVERRUN : 0;
+    }
+}
+
 static int fail(int code, const char *msg)
 {
     set_last_error(msg);
@@ -263,35 +478,60 @@ extern "C" {
 
 size_t fk_resample_workspace_bytes(int64_t Fn, int64_t Np)
 {
-    // only multinomial needs scratch: the cumulative sums, Fn * Np doubles
+    // systematic / stratified on long vectors: one ChunkPlan per 2048 weights
+    if (Fn <= 0 || Np <= 0) return 0;
+    const size_t nch = (size_t)((Np + RS_TILE - 1) / RS_TILE);
+    return (size_t)Fn * nch * sizeof(ChunkPlan);
+}
+
+size_t fk_multinomial_workspace_bytes(int64_t Fn, int64_t Np)
+{
+    // the cumulative sums: Fn * Np doubles
     return (Fn > 0 && Np > 0) ? (size_t)Fn * (size_t)Np * sizeof(double) : 0;
 }
 
 static int resample_common(bool stratified, int64_t Fn, int64_t Np, const double *w, const double *u,
-                           int32_t *idx, int32_t *status, void *stream)
+                           int32_t *idx, int32_t *status, void *ws, size_t ws_bytes, void *stream)
 {
     if (Fn < 0 || Np < 0) return fail(FK_ERR_BAD_ARG, "resample: negative size");
     if (Np >= 2147483647LL) return fail(FK_ERR_UNSUPPORTED, "resample: Np must fit int32 (the reference returns int32 indices)");
     if (Fn == 0 || Np == 0) return FK_OK;
     if (!w || !u || !idx) return fail(FK_ERR_BAD_ARG, "resample: w, u, idx must not be NULL");
+    hipStream_t s = (hipStream_t)stream;
+    const long nch = (long)((Np + RS_TILE - 1) / RS_TILE);
+    const size_t plan_bytes = (size_t)Fn * (size_t)nch * sizeof(ChunkPlan);
+    if (Np >= RS_PAR_MIN && ws && ws_bytes >= plan_bytes && nch <= 65535 * 32L && Fn <= 65535 && !getenv("FK_RESAMPLE_SERIAL")) {
+        // chunk-parallel path: the caller's workspace holds the plan
+        ChunkPlan *plan = (ChunkPlan *)ws;
+        const dim3 gch((unsigned)nch, (unsigned)Fn), block(RS_THREADS);
+        hipLaunchKernelGGL(chunk_sum_kernel, gch, block, 0, s, (long)Np, nch, w, plan);
+        hipLaunchKernelGGL(chunk_plan_kernel, dim3((unsigned)((Fn + 63) / 64)), dim3(64), 0, s, (long)Fn, (long)Np, nch, plan);
+        hipLaunchKernelGGL(chunk_compose_kernel, gch, block, 0, s, (long)Np, nch, w, plan);
+        hipLaunchKernelGGL(chain_kernel, dim3((unsigned)Fn), block, 0, s, (long)Np, nch, w, plan);
+        if (stratified)
+            hipLaunchKernelGGL((resample_chunk_kernel<true>), gch, block, 0, s, (long)Np, nch, w, u, plan, idx, status);
+        else
+            hipLaunchKernelGGL((resample_chunk_kernel<false>), gch, block, 0, s, (long)Np, nch, w, u, plan, idx, status);
+        return check_launch("resample_chunk_kernel");
+    }
     const dim3 grid((unsigned)Fn), block(RS_THREADS);
     if (stratified)
-        hipLaunchKernelGGL((resample_kernel<true>), grid, block, 0, (hipStream_t)stream, (long)Np, w, u, idx, status);
+        hipLaunchKernelGGL((resample_kernel<true>), grid, block, 0, s, (long)Np, w, u, idx, status);
     else
-        hipLaunchKernelGGL((resample_kernel<false>), grid, block, 0, (hipStream_t)stream, (long)Np, w, u, idx, status);
+        hipLaunchKernelGGL((resample_kernel<false>), grid, block, 0, s, (long)Np, w, u, idx, status);
     return check_launch("resample_kernel");
 }
 
 int fk_resample_systematic_f64(int64_t Fn, int64_t Np, const double *w, const double *u, int32_t *idx,
-                               int32_t *status, void *, size_t, void *stream)
+                               int32_t *status, void *ws, size_t ws_bytes, void *stream)
 {
-    return resample_common(false, Fn, Np, w, u, idx, status, stream);
+    return resample_common(false, Fn, Np, w, u, idx, status, ws, ws_bytes, stream);
 }
 
 int fk_resample_stratified_f64(int64_t Fn, int64_t Np, const double *w, const double *u, int32_t *idx,
-                               int32_t *status, void *, size_t, void *stream)
+                               int32_t *status, void *ws, size_t ws_bytes, void *stream)
 {
-    return resample_common(true, Fn, Np, w, u, idx, status, stream);
+    return resample_common(true, Fn, Np, w, u, idx, status, ws, ws_bytes, stream);
 }
 
 int fk_cumsum_exact_f64(int64_t Fn, int64_t Np, const double *w, double *cs, int32_t force_last_one, void *stream)
@@ -310,7 +550,7 @@ int fk_resample_multinomial_f64(int64_t Fn, int64_t Np, int64_t Nu, const double
     if (Fn < 0 || Np < 0 || Nu < 0) return fail(FK_ERR_BAD_ARG, "multinomial: negative size");
     if (Fn == 0 || Np == 0 || Nu == 0) return FK_OK;
     if (!w || !u || !idx) return fail(FK_ERR_BAD_ARG, "multinomial: w, u, idx must not be NULL");
-    if (!ws || ws_bytes < fk_resample_workspace_bytes(Fn, Np)) return fail(FK_ERR_WORKSPACE, "multinomial: workspace too small");
+    if (!ws || ws_bytes < fk_multinomial_workspace_bytes(Fn, Np)) return fail(FK_ERR_WORKSPACE, "multinomial: workspace too small");
     double *cs = (double *)ws;
     if (int rc = fk_cumsum_exact_f64(Fn, Np, w, cs, 1, stream)) return rc;
     const dim3 grid((unsigned)((Nu + RS_THREADS - 1) / RS_THREADS), (unsigned)Fn), block(RS_THREADS);

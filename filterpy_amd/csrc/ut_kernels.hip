@@ -48,6 +48,50 @@ sigma_kernel(int n, long N, double scale, const double *__restrict__ px, const d
     if (status) status[blk0 + ln.tid] = pd ? 0 : ST_NOT_PD;
 }
 
+// Register-resident variant for the standard point sets (k == 2n+1, n == NX <= 6): every sigma
+// point is read from HBM exactly once (the generic kernel below re-reads them for the second pass).
+template <int NX, int LAYOUT>
+__global__ void __launch_bounds__(BLOCK, (NX <= 4 ? 4 : 1))
+ut_reg_kernel(long N, const double *__restrict__ sig, const double *__restrict__ Wm,
+              const double *__restrict__ Wc, const double *__restrict__ noise, double *xo, double *Po)
+{
+    constexpr int K = 2 * NX + 1;
+    const long blk0 = (long)blockIdx.x * BLOCK;
+    const Lane ln{blk0, threadIdx.x, N};
+    if (blk0 + ln.tid >= N) return;
+    double s[K * NX];
+    load_rec<K, NX, LAYOUT, true>(s, sig, ln, K, NX, 0.0);
+    double x[NX];
+    FK_UNROLL for (int c = 0; c < NX; ++c) {
+        double acc = Wm[0] * s[c];
+        FK_UNROLL for (int i = 1; i < K; ++i) acc = fma(Wm[i], s[i * NX + c], acc);
+        x[c] = acc;
+    }
+    FK_UNROLL for (int i = 0; i < K; ++i)
+        FK_UNROLL for (int c = 0; c < NX; ++c) s[i * NX + c] -= x[c];
+    store_rec<NX, 1, LAYOUT, true>(x, xo, ln, NX, 1);
+    // P = sum_i y_i (Wc_i y_i)': accumulate the upper triangle point by point (P is symmetric by
+    // construction: the same two factors commute), mirror on store
+    double U[NX * (NX + 1) / 2];
+    FK_UNROLL for (int i = 0; i < K; ++i) {
+        double wy[NX];
+        FK_UNROLL for (int c = 0; c < NX; ++c) wy[c] = Wc[i] * s[i * NX + c];
+        int t = 0;
+        FK_UNROLL for (int a = 0; a < NX; ++a)
+            FK_UNROLL for (int b2 = a; b2 < NX; ++b2, ++t)
+                U[t] = (i == 0) ? s[a] * wy[b2] : fma(s[i * NX + a], wy[b2], U[t]);
+        FK_STAGE();
+    }
+    const RecView<LAYOUT> pv(Po, ln, NX * NX);
+    int t = 0;
+    FK_UNROLL for (int a = 0; a < NX; ++a)
+        FK_UNROLL for (int b2 = a; b2 < NX; ++b2, ++t) {
+            const double v = noise ? U[t] + noise[a * NX + b2] : U[t];
+            pv.store(a * NX + b2, v);
+            if (b2 != a) pv.store(b2 * NX + a, noise ? U[t] + noise[b2 * NX + a] : U[t]);
+        }
+}
+
 // ------------------------------------------------------ unscented transform --
 template <int NX, int LAYOUT>
 __global__ void __launch_bounds__(BLOCK)
@@ -433,6 +477,20 @@ int fk_ut_transform_f64(int32_t n, int32_t k, int64_t N, int32_t layout, const d
     if ((double)N * k * n * 8.0 >= 4294967296.0) return fail(FK_ERR_UNSUPPORTED, "unscented transform: record block >= 4 GiB, split the batch");
     if (N == 0) return FK_OK;
     const dim3 grid((unsigned)((N + BLOCK - 1) / BLOCK)), block(BLOCK);
+    if (k == 2 * n + 1 && (n == 2 || n == 4 || n == 6)) {
+#define REG(NXV)                                                                                          \
+    if (layout == FK_LAYOUT_SOA)                                                                          \
+        hipLaunchKernelGGL((ut_reg_kernel<NXV, LAYOUT_SOA>), grid, block, 0, (hipStream_t)stream, (long)N, \
+                           sigmas, Wm, Wc, noise_cov, x_out, P_out);                                      \
+    else                                                                                                  \
+        hipLaunchKernelGGL((ut_reg_kernel<NXV, LAYOUT_AOS>), grid, block, 0, (hipStream_t)stream, (long)N, \
+                           sigmas, Wm, Wc, noise_cov, x_out, P_out)
+        if (n == 2) { REG(2); }
+        else if (n == 4) { REG(4); }
+        else { REG(6); }
+#undef REG
+        return check_launch("ut_reg_kernel");
+    }
 #define CALL(NXV)                                                                                   \
     if (layout == FK_LAYOUT_SOA)                                                                    \
         hipLaunchKernelGGL((ut_kernel<NXV, LAYOUT_SOA>), grid, block, 0, (hipStream_t)stream, n, k, \

@@ -206,7 +206,9 @@ int fk_ukf_linear_batch_f64(const fk_ukf_desc *desc,
  * bit-for-bit as a sequential fp64 add chain; idx_i = #{ j : cs_j <= pos_i }.
  *   w   [Fn][Np] weights;  u [Fn] one uniform per filter (drawn by the host from numpy.random);
  *   idx [Fn][Np] int32 (np.zeros(N,'i'), resampling.py:141);  status [Fn] or NULL.
- *   ws / ws_bytes : scratch from fk_resample_workspace_bytes(Fn, Np). */
+ *   ws / ws_bytes : scratch from fk_resample_workspace_bytes(Fn, Np); with it, weight vectors of
+ *                   >= 32768 particles are processed chunk-parallel (many workgroups per filter);
+ *                   NULL / too small = one workgroup per filter. */
 int fk_resample_systematic_f64(int64_t Fn, int64_t Np, const double *w, const double *u,
                                int32_t *idx, int32_t *status,
                                void *ws, size_t ws_bytes, void *stream);
@@ -223,7 +225,8 @@ int fk_resample_stratified_f64(int64_t Fn, int64_t Np, const double *w, const do
 int fk_resample_multinomial_f64(int64_t Fn, int64_t Np, int64_t Nu, const double *w, const double *u,
                                 int64_t *idx, void *ws, size_t ws_bytes, void *stream);
 
-size_t fk_resample_workspace_bytes(int64_t Fn, int64_t Np);
+size_t fk_resample_workspace_bytes(int64_t Fn, int64_t Np);     /* systematic / stratified */
+size_t fk_multinomial_workspace_bytes(int64_t Fn, int64_t Np);  /* multinomial: Fn*Np doubles */
 
 /* numpy.cumsum(w_f) for Fn float64 vectors of length Np, bit-for-bit (NumPy adds strictly left to
  * right; a re-associated parallel scan differs in the last bits -- here an associative scan over

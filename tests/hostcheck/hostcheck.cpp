@@ -169,7 +169,7 @@ int hc_sigma(int n, double scale, const double *x, const double *P, double *sig)
 namespace {
 constexpr int T_THREADS = 256, T_ITEMS = 8, T_TILE = T_THREADS * T_ITEMS;
 
-double tile_cumsum_emul(double *w, int len, double carry, bool &started, long *n_segments)
+double tile_cumsum_emul(double *w, int len, double carry, bool &started, long *n_segments, int &prelude)
 {
     int pos = 0;
     while (pos < len) {
@@ -194,15 +194,27 @@ double tile_cumsum_emul(double *w, int len, double carry, bool &started, long *n
             ++pos;
             continue;
         }
+        if (prelude > 0) {
+            const int stop = (pos + prelude < len) ? pos + prelude : len;
+            for (int j = pos; j < stop; ++j) {
+                carry = carry + w[j];
+                w[j] = carry;
+            }
+            prelude -= stop - pos;
+            pos = stop;
+            continue;
+        }
         ++*n_segments;
         const double u = ulp_of(carry);
-        const long long C0 = (long long)(carry / u);
+        const int eu = ulp_exp(carry);
+        if (scale2(1.0, eu) != u) return carry / 0.0 * 0.0;   // self-check: poisons the result
+        const long long C0 = (long long)scale2(carry, -eu);
         std::vector<Mono> loc(T_TILE), tot(T_THREADS), inc(T_THREADS), excl(T_THREADS);
         for (int t = 0; t < T_THREADS; ++t) {
             Mono run = mono_identity();
             for (int k = 0; k < T_ITEMS; ++k) {
                 const int j = t * T_ITEMS + k;
-                const Mono e = (j >= pos && j < len) ? mono_elem(w[j], u) : mono_identity();
+                const Mono e = (j >= pos && j < len) ? mono_elem(w[j], u, eu) : mono_identity();
                 run = mono_compose(run, e);
                 loc[j] = run;
             }
@@ -247,12 +259,100 @@ extern "C" long hc_cumsum_exact(long N, const double *w, double *cs)
     double carry = 0.0;
     bool started = false;
     long segs = 0;
+    int prelude = 128;
     std::vector<double> tile(T_TILE);
     for (long base = 0; base < N; base += T_TILE) {
         const int len = (int)((N - base) < T_TILE ? (N - base) : T_TILE);
         for (int j = 0; j < T_TILE; ++j) tile[j] = j < len ? w[base + j] : 0.0;
-        carry = tile_cumsum_emul(tile.data(), len, carry, started, &segs);
+        carry = tile_cumsum_emul(tile.data(), len, carry, started, &segs, prelude);
         for (int j = 0; j < len; ++j) cs[base + j] = tile[j];
     }
     return segs;
+}
+
+// Host emulation of the chunk-parallel plan/chain (resample_kernels.hip P1-P4): chunk sums in a
+// different association order, error-bounded binade guess, composite map per clean chunk, verified
+// O(1) chain step -- the resulting carry-in of every chunk must equal the sequential one.
+extern "C" long hc_cumsum_chunked(long N, const double *w, double *cs, long *n_shortcuts)
+{
+    const long nch = (N + T_TILE - 1) / T_TILE;
+    std::vector<double> S(nch), cin(nch);
+    std::vector<int> eu(nch, -100000), bad(nch, 0), st_started(nch), st_prelude(nch);
+    std::vector<Mono> F(nch);
+    for (long k = 0; k < nch; ++k) {
+        const long base = k * T_TILE;
+        const int len = (int)((N - base) < T_TILE ? (N - base) : T_TILE);
+        double part[4] = {0, 0, 0, 0};
+        for (int j = 0; j < len; ++j) {
+            part[j & 3] += w[base + j];
+            if (!(w[base + j] >= 0.0 && w[base + j] < 0x1p1000)) bad[k] = 1;
+        }
+        S[k] = (part[0] + part[1]) + (part[2] + part[3]);
+    }
+    const double delta = 8.0 * (double)(N + 4096) * 0x1p-53;
+    double A = 0.0;
+    bool poisoned = false;
+    for (long k = 0; k < nch; ++k) {
+        poisoned = poisoned || bad[k] || !(S[k] >= 0.0) || !(A + S[k] < 0x1p1000);
+        if (!poisoned && k > 0) {
+            const double lo = A * (1.0 - delta), hi = (A + S[k]) * (1.0 + delta);
+            if (lo > 0x1p-900 && ulp_exp(lo) == ulp_exp(hi)) eu[k] = ulp_exp(lo);
+        }
+        A += S[k];
+    }
+    for (long k = 0; k < nch; ++k) {
+        if (eu[k] == -100000) continue;
+        const long base = k * T_TILE;
+        const int len = (int)((N - base) < T_TILE ? (N - base) : T_TILE);
+        const double u = scale2(1.0, eu[k]);
+        // tree-ish order: per-thread runs of 8, then sequential over threads
+        Mono tot = mono_identity();
+        for (int t = 0; t < T_THREADS; ++t) {
+            Mono run = mono_identity();
+            for (int q = 0; q < T_ITEMS; ++q) {
+                const int j = t * T_ITEMS + q;
+                if (j < len) run = mono_compose(run, mono_elem(w[base + j], u, eu[k]));
+            }
+            tot = mono_compose(tot, run);
+        }
+        F[k] = tot;
+    }
+    double carry = 0.0;
+    bool started = false;
+    int prelude = 128;
+    long segs = 0;
+    std::vector<double> tile(T_TILE);
+    *n_shortcuts = 0;
+    for (long k = 0; k < nch; ++k) {
+        cin[k] = carry;
+        st_started[k] = started;
+        st_prelude[k] = prelude;
+        bool shortcut = false;
+        if (eu[k] != -100000 && started && prelude == 0 && carry > 0.0 && ulp_exp(carry) == eu[k]) {
+            const long long C0 = (long long)scale2(carry, -eu[k]);
+            const long long C1 = mono_apply(C0, F[k]);
+            if (C1 < MONO_LIMIT) {
+                carry = scale2((double)C1, eu[k]);
+                shortcut = true;
+                ++*n_shortcuts;
+            }
+        }
+        if (!shortcut) {
+            const long base = k * T_TILE;
+            const int len = (int)((N - base) < T_TILE ? (N - base) : T_TILE);
+            for (int j = 0; j < T_TILE; ++j) tile[j] = j < len ? w[base + j] : 0.0;
+            carry = tile_cumsum_emul(tile.data(), len, carry, started, &segs, prelude);
+        }
+    }
+    // P5: every chunk independently from its recorded carry-in
+    for (long k = 0; k < nch; ++k) {
+        const long base = k * T_TILE;
+        const int len = (int)((N - base) < T_TILE ? (N - base) : T_TILE);
+        for (int j = 0; j < T_TILE; ++j) tile[j] = j < len ? w[base + j] : 0.0;
+        bool stt = st_started[k] != 0;
+        int pre = st_prelude[k];
+        tile_cumsum_emul(tile.data(), len, cin[k], stt, &segs, pre);
+        for (int j = 0; j < len; ++j) cs[base + j] = tile[j];
+    }
+    return nch;
 }

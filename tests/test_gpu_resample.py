@@ -126,3 +126,38 @@ def test_overrun_raises_indexerror():
     np.random.seed(0)
     with pytest.raises(IndexError):
         mc.systematic_resample(w)
+
+
+def test_chunk_parallel_path_equals_serial_path(monkeypatch):
+    """Long vectors take the chunk-parallel path (many workgroups per filter); it must give the same
+    indices as the one-workgroup-per-filter path and as the oracle, incl. hard inputs."""
+    import torch
+    from filterpy_amd import _engine as E
+    from oracle import resample_oracle as ro
+    rs = np.random.RandomState(21)
+    Np = 300007
+    ws = np.stack([rs.rand(Np), np.exp(rs.randn(Np) * 5), rs.rand(Np) * (rs.rand(Np) < 0.02),
+                   np.concatenate([np.zeros(Np // 3), rs.rand(Np - Np // 3)]), np.eye(1, Np, 777)[0] + 1e-12])
+    ws /= ws.sum(axis=1, keepdims=True)
+    Fn = ws.shape[0]
+    u = rs.rand(Fn)
+    us = rs.rand(Fn, Np)
+    dw, du, dus = E.dev(ws), E.dev(u), E.dev(us)
+    out = {}
+    for mode in ("parallel", "serial"):
+        if mode == "serial":
+            monkeypatch.setenv("FK_RESAMPLE_SERIAL", "1")
+        idx = torch.empty((Fn, Np), dtype=torch.int32, device=dw.device)
+        st = torch.zeros(Fn, dtype=torch.int32, device=dw.device)
+        E.resample_systematic(Fn, Np, dw, du, idx, st)
+        a = idx.cpu().numpy().copy()
+        E.resample_stratified(Fn, Np, dw, dus, idx, st)
+        out[mode] = (a, idx.cpu().numpy().copy(), st.cpu().numpy().copy())
+    assert np.array_equal(out["parallel"][0], out["serial"][0]) and np.array_equal(out["parallel"][1], out["serial"][1])
+    for f in range(Fn):
+        ref, over = ro.systematic_c(ws[f], u[f])
+        if over == 0:
+            assert np.array_equal(out["parallel"][0][f], ref), f
+        ref, over = ro.stratified_c(ws[f], us[f])
+        if over == 0:
+            assert np.array_equal(out["parallel"][1][f], ref), f

@@ -63,3 +63,24 @@ def test_exact_cumsum_large_and_parallel_fraction():
     cs, segs = hc_cumsum(w)
     assert np.array_equal(bits(cs), bits(np.cumsum(w)))
     assert segs < N // 2048 + 64
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+@pytest.mark.parametrize("N", [2049, 40000, 300007])
+def test_chunk_parallel_plan_bitwise(name, N):
+    """The chunk-parallel plan/chain (approximate binade guess + verified O(1) chain steps) must give
+    the same bits as the sequential sum for every kind of input, including the ones it cannot
+    shortcut (negatives, zeros, subnormals)."""
+    lib = ctypes.CDLL(os.path.join(ROOT, "tests", "hostcheck", "libhostcheck.so"))
+    lib.hc_cumsum_chunked.restype = ctypes.c_long
+    rs = np.random.RandomState(hash(name) % 1000 + N)
+    w = np.ascontiguousarray(np.asarray(CASES[name](rs, N), dtype=np.float64)[:N])
+    cs = np.empty_like(w)
+    nshort = ctypes.c_long(0)
+    nch = lib.hc_cumsum_chunked(ctypes.c_long(N), w.ctypes.data_as(ctypes.c_void_p), cs.ctypes.data_as(ctypes.c_void_p),
+                                ctypes.byref(nshort))
+    ref = np.cumsum(w)
+    nz = ref != 0
+    assert np.array_equal(cs, ref) and np.array_equal(bits(cs)[nz], bits(ref)[nz]), (name, N)
+    if name in ("uniform", "normalised") and N >= 300000:
+        assert nshort.value > 0.8 * nch        # almost every chunk took the O(1) step
