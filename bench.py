@@ -135,7 +135,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--tracks", type=int, default=1_000_000, help="tracks per GPU")
     ap.add_argument("--T", type=int, default=100)
-    ap.add_argument("--layout", default=os.environ.get("FK_BENCH_LAYOUT", "soa"), choices=["soa", "aos"])
+    ap.add_argument("--layout", default=os.environ.get("FK_BENCH_LAYOUT", "aos"), choices=["soa", "aos"],
+                    help="record layout of z and the outputs: aos = NumPy C order [T][N][n][n] (default), soa = [T][n*n][N]")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     args = ap.parse_args()

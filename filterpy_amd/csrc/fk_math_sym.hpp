@@ -1,0 +1,150 @@
+// fk_math_sym.hpp -- Kalman predict/update on a PACKED SYMMETRIC covariance.
+//
+// Same equations as fk_math.hpp (filterpy/kalman/kalman_filter.py:472-478, 533-556) but P lives
+// in registers as its upper triangle U (n(n+1)/2 doubles instead of n^2) and no n x n temporary
+// is ever materialised: every product is formed one row at a time.  This is what lets the
+// per-lane state of dim_x = 9 fit the register file without spilling and dim_x = 4 run at
+// 3-4 waves per SIMD.  Only valid for symmetric P, Q, R (covariances): the fast kernel reads the
+// upper triangle of P0 only; kf_kernels.hip keeps the fully general arithmetic.
+//
+// Update, with PHT = P H', S = H PHT + R, K = PHT S^-1 as in the reference:
+//   (I-KH) P          = P - K PHT'                        =: T1   (row i: U(i,:) - K_i PHT')
+//   T1 (I-KH)'        = T1 - (T1 H') K'                           (G_i = T1_i H', m values)
+//   Joseph:  P+ = T1 (I-KH)' + K R K' = T1 + ((K R)_i - G_i) K'   (upper triangle only)
+// i.e. the reference's (I-KH) P (I-KH)' + K R K' with the identity-minus-product factors applied
+// implicitly; rounding differences vs the factored form are O(eps |P|), the same size as the
+// reference's own.
+#pragma once
+
+#include "fk_math.hpp"
+
+namespace fk {
+
+// packed index of element (i, j) of a symmetric NX x NX matrix stored by rows of its upper triangle
+template <int NX>
+FK_HD constexpr int sym_idx(int i, int j)
+{
+    return (i <= j) ? (i * NX - i * (i - 1) / 2 + (j - i)) : (j * NX - j * (j - 1) / 2 + (i - j));
+}
+
+template <int NX>
+constexpr int SYM_LEN = NX * (NX + 1) / 2;
+
+template <int NX, class Model>
+FK_HD void kf_predict_sym(double (&x)[NX], double (&U)[NX * (NX + 1) / 2], const Model &M, double alpha_sq)
+{
+    double xn[NX];
+    double Un[NX * (NX + 1) / 2];
+    FK_UNROLL for (int i = 0; i < NX; ++i) {
+        double f[NX];
+        M.rowF(i, f);
+        xn[i] = dot<NX>(f, x);
+        // row i of F P
+        double fp[NX];
+        FK_UNROLL for (int j = 0; j < NX; ++j) {
+            double acc = f[0] * U[sym_idx<NX>(0, j)];
+            FK_UNROLL for (int k = 1; k < NX; ++k) acc = fma(f[k], U[sym_idx<NX>(k, j)], acc);
+            fp[j] = acc;
+        }
+        // (F P F')(i, j >= i) = fp . F_j
+        Un[sym_idx<NX>(i, i)] = dot<NX>(fp, f);
+        FK_UNROLL for (int j = i + 1; j < NX; ++j) {
+            double g[NX];
+            M.rowF(j, g);
+            Un[sym_idx<NX>(i, j)] = dot<NX>(fp, g);
+        }
+        FK_STAGE();
+    }
+    FK_UNROLL for (int i = 0; i < NX; ++i) x[i] = xn[i];
+    FK_UNROLL for (int i = 0; i < NX; ++i) {
+        double q[NX];
+        M.rowQ(i, q);
+        FK_UNROLL for (int j = i; j < NX; ++j) U[sym_idx<NX>(i, j)] = fma(alpha_sq, Un[sym_idx<NX>(i, j)], q[j]);
+    }
+    FK_STAGE();
+}
+
+// Returns status bits.  K, y, S (full m x m) and the factorisation are outputs like kf_update.
+template <int NX, int NZ, class Model>
+FK_HD int kf_update_sym(double (&x)[NX], double (&U)[NX * (NX + 1) / 2], const double (&z)[NZ], const Model &M,
+                        double (&K)[NX * NZ], double (&y)[NZ], double (&S)[NZ * NZ],
+                        double (&Lf)[NZ * NZ], double (&dinv)[NZ])
+{
+    int st = 0;
+    double PHT[NX * NZ];
+    FK_UNROLL for (int r = 0; r < NZ; ++r) {
+        double h[NX];
+        M.rowH(r, h);
+        y[r] = z[r] - dot<NX>(h, x);
+        FK_UNROLL for (int i = 0; i < NX; ++i) {
+            double acc = U[sym_idx<NX>(i, 0)] * h[0];
+            FK_UNROLL for (int k = 1; k < NX; ++k) acc = fma(U[sym_idx<NX>(i, k)], h[k], acc);
+            PHT[i * NZ + r] = acc;
+        }
+    }
+    FK_STAGE();
+    FK_UNROLL for (int r = 0; r < NZ; ++r) {
+        double h[NX], rr[NZ];
+        M.rowH(r, h);
+        M.rowR(r, rr);
+        FK_UNROLL for (int c = 0; c < NZ; ++c) {
+            double acc = h[0] * PHT[c];
+            FK_UNROLL for (int k = 1; k < NX; ++k) acc = fma(h[k], PHT[k * NZ + c], acc);
+            S[r * NZ + c] = acc + rr[c];
+        }
+    }
+    FK_STAGE();
+    FK_UNROLL for (int i = 0; i < NX * NZ; ++i) K[i] = PHT[i];
+    if constexpr (NZ == 1) {
+        const double si = 1.0 / S[0];
+        if (!(S[0] != 0.0)) st |= ST_NOT_PD;
+        dinv[0] = si;
+        Lf[0] = S[0];
+        FK_UNROLL for (int i = 0; i < NX; ++i) K[i] = PHT[i] * si;
+    } else {
+        double d[NZ];
+        FK_UNROLL for (int i = 0; i < NZ * NZ; ++i) Lf[i] = S[i];
+        if (!ldlt2<NZ>(Lf, d, dinv)) st |= ST_NOT_PD;
+        solve_rows_ldlt<NX, NZ>(Lf, dinv, K);
+    }
+    FK_STAGE();
+    FK_UNROLL for (int i = 0; i < NX; ++i) {
+        double acc = x[i];
+        FK_UNROLL for (int k = 0; k < NZ; ++k) acc = fma(K[i * NZ + k], y[k], acc);
+        x[i] = acc;
+    }
+    // Joseph form, one row of the result at a time
+    double Un[NX * (NX + 1) / 2];
+    FK_UNROLL for (int i = 0; i < NX; ++i) {
+        // T1_i = row i of (I - K H) P = U(i,:) - K_i PHT'
+        double t1[NX];
+        FK_UNROLL for (int k = 0; k < NX; ++k) {
+            double acc = U[sym_idx<NX>(i, k)];
+            FK_UNROLL for (int r = 0; r < NZ; ++r) acc = fma(-K[i * NZ + r], PHT[k * NZ + r], acc);
+            t1[k] = acc;
+        }
+        // D_i = (K R)_i - T1_i H'
+        double D[NZ];
+        FK_UNROLL for (int c = 0; c < NZ; ++c) D[c] = 0.0;
+        FK_UNROLL for (int r = 0; r < NZ; ++r) {
+            double rr[NZ];
+            M.rowR(r, rr);
+            FK_UNROLL for (int c = 0; c < NZ; ++c) D[c] = (r == 0) ? K[i * NZ] * rr[c] : fma(K[i * NZ + r], rr[c], D[c]);
+        }
+        FK_UNROLL for (int r = 0; r < NZ; ++r) {
+            double h[NX];
+            M.rowH(r, h);
+            D[r] -= dot<NX>(t1, h);
+        }
+        FK_UNROLL for (int j = i; j < NX; ++j) {
+            double acc = t1[j];
+            FK_UNROLL for (int r = 0; r < NZ; ++r) acc = fma(D[r], K[j * NZ + r], acc);
+            Un[sym_idx<NX>(i, j)] = acc;
+        }
+        FK_STAGE();
+    }
+    FK_UNROLL for (int e = 0; e < NX * (NX + 1) / 2; ++e) U[e] = Un[e];
+    return st;
+}
+
+}  // namespace fk

@@ -18,7 +18,7 @@ namespace fk {
 #define FK_KF_INST(NX, NZ, EX) int launch_kf_##NX##_##NZ##_##EX(const KfArgs &, int, bool, hipStream_t);
 #include "fk_dims.def"
 #undef FK_KF_INST
-#define FK_FAST_INST(NX, NZ, V, W) int launch_kf_fast_##NX##_##NZ##_v##V(const KfArgs &, int, bool, hipStream_t);
+#define FK_FAST_INST(NX, NZ, V, W, S) int launch_kf_fast_##NX##_##NZ##_v##V(const KfArgs &, int, bool, hipStream_t);
 #include "fk_dims_fast.def"
 #undef FK_FAST_INST
 #define FK_RTS_INST(NX, EX) int launch_rts_##NX##_##EX(const RtsArgs &, int, bool, hipStream_t);
@@ -40,7 +40,7 @@ struct FastEntry {
     int (*fn)(const KfArgs &, int, bool, hipStream_t);
 };
 static const FastEntry fast_table[] = {
-#define FK_FAST_INST(NX, NZ, V, W) {NX, NZ, V, launch_kf_fast_##NX##_##NZ##_v##V},
+#define FK_FAST_INST(NX, NZ, V, W, S) {NX, NZ, V, launch_kf_fast_##NX##_##NZ##_v##V},
 #include "fk_dims_fast.def"
 #undef FK_FAST_INST
 };

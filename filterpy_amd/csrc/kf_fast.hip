@@ -15,12 +15,18 @@
 // HBM-bound: 8*(m + 2n + 2n^2) algorithmic bytes per track-step (336 B at n=4, m=2).
 #include "fk_device.hpp"
 #include "fk_kernel_args.hpp"
+#include "fk_math_sym.hpp"
 
 #ifndef FK_NX
 #error "compile with -DFK_NX=<dim_x> -DFK_NZ=<dim_z> -DFK_VARIANT=<v> -DFK_FAST_WAVES=<w>"
 #endif
 #ifndef FK_FAST_WAVES
 #define FK_FAST_WAVES 0
+#endif
+// FK_FAST_SYM=1: covariance kept as a packed upper triangle (fk_math_sym.hpp) -- fewer registers
+// and flops; reads only the upper triangle of P0 and writes a mirrored P.
+#ifndef FK_FAST_SYM
+#define FK_FAST_SYM 0
 #endif
 
 #ifndef FK_VARIANT
@@ -91,7 +97,16 @@ __device__ __forceinline__ void wave_store_aos(const double (&v)[LEN], rsrc_t rs
 // the last track recompute that track and write the same bytes again.  The number of stores
 // between a measurement load and its use is therefore a compile-time constant and the wait for
 // it is a counted vmcnt that never drains the store queue.
-template <int NX, int NZ, int LAYOUT, bool HAS_MASK, bool OUTS>
+// expand the covariance state (full or packed upper triangle) to a row-major NX x NX array;
+// pure register renaming after optimisation
+template <int NX, bool SYM, int PLEN>
+__device__ __forceinline__ void cov_full(const double (&P)[PLEN], double (&M)[NX * NX])
+{
+    FK_UNROLL for (int a = 0; a < NX; ++a)
+        FK_UNROLL for (int b = 0; b < NX; ++b) M[a * NX + b] = SYM ? P[sym_idx<NX>(a, b)] : P[a * NX + b];
+}
+
+template <int NX, int NZ, int LAYOUT, bool HAS_MASK, bool OUTS, bool SYM>
 __global__ void __launch_bounds__(BLOCK, fast_min_waves(NX))
 kf_fast_kernel(const KfArgs a, const double *__restrict__ pF, const double *__restrict__ pQ,
                const double *__restrict__ pH, const double *__restrict__ pR,
@@ -121,9 +136,15 @@ kf_fast_kernel(const KfArgs a, const double *__restrict__ pF, const double *__re
     __syncthreads();
     const SharedModel sm{s_mem};
 
-    double x[NX], P[NX * NX];
+    constexpr int PLEN = SYM ? NX * (NX + 1) / 2 : NX * NX;
+    double x[NX], P[PLEN];      // SYM: P is the packed upper triangle
     load_rec<NX, 1, LAYOUT, true>(x, a.x, lr, NX, 1, 0.0);
-    load_rec<NX, NX, LAYOUT, true>(P, a.P, lr, NX, NX, 1.0);
+    {
+        const RecView<LAYOUT> pv(a.P, lr, NX * NX);
+        FK_UNROLL for (int i = 0; i < NX; ++i)
+            FK_UNROLL for (int j = (SYM ? i : 0); j < NX; ++j)
+                P[SYM ? sym_idx<NX>(i, j) : i * NX + j] = pv.load(i * NX + j);
+    }
 
     // measurement pipeline: z[t+1] is requested at the top of step t
     double zc[NZ], zn[NZ];
@@ -133,7 +154,7 @@ kf_fast_kernel(const KfArgs a, const double *__restrict__ pF, const double *__re
     // Land every prologue load before the loop: a load still pending at the loop header would
     // make the compiler wait vmcnt(0) inside the loop on every iteration (draining the stores).
     FK_UNROLL for (int i = 0; i < NX; ++i) asm volatile("" ::"v"(x[i]));
-    FK_UNROLL for (int i = 0; i < NX * NX; ++i) asm volatile("" ::"v"(P[i]));
+    FK_UNROLL for (int i = 0; i < PLEN; ++i) asm volatile("" ::"v"(P[i]));
     FK_UNROLL for (int i = 0; i < NZ; ++i) asm volatile("" ::"v"(zc[i]));
     FK_UNROLL for (int i = 0; i < NZ; ++i) zn[i] = zc[i];
 
@@ -143,35 +164,42 @@ kf_fast_kernel(const KfArgs a, const double *__restrict__ pF, const double *__re
             load_rec<NZ, 1, LAYOUT, true>(zn, pz + (t + 1) * N * NZ, lr, NZ, 1, 0.0);
             if (HAS_MASK) hn = pmask[(t + 1) * N + lr.blk0 + lr.tid] != 0;
         }
-        kf_predict<NX>(x, P, sm, a.alpha_sq);
+        if constexpr (SYM) kf_predict_sym<NX>(x, P, sm, a.alpha_sq);
+        else kf_predict<NX>(x, P, sm, a.alpha_sq);
+        double Pf[NX * NX];
+        cov_full<NX, SYM, PLEN>(P, Pf);
         if (!OUTS) {
         } else if (!COOP) {
             store_rec<NX, 1, LAYOUT, true>(x, a.means_p + t * N * NX, ln, NX, 1);
-            store_rec<NX, NX, LAYOUT, true>(P, a.covs_p + t * N * NX * NX, ln, NX, NX);
+            store_rec<NX, NX, LAYOUT, true>(Pf, a.covs_p + t * N * NX * NX, ln, NX, NX);
         } else {
             wave_store_aos<NX>(x, make_rsrc(a.means_p + (t * N + blk0) * NX), wave * 64u, tile, lane, last_row);
-            wave_store_aos<NX * NX>(P, make_rsrc(a.covs_p + (t * N + blk0) * NX * NX), wave * 64u, tile, lane, last_row);
+            wave_store_aos<NX * NX>(Pf, make_rsrc(a.covs_p + (t * N + blk0) * NX * NX), wave * 64u, tile, lane, last_row);
         }
         if (hc) {
             double K[NX * NZ], y[NZ], S[NZ * NZ], Lf[NZ * NZ], dinv[NZ];
-            st |= kf_update<NX, NZ>(x, P, zc, sm, K, y, S, Lf, dinv);
+            if constexpr (SYM) st |= kf_update_sym<NX, NZ>(x, P, zc, sm, K, y, S, Lf, dinv);
+            else st |= kf_update<NX, NZ>(x, P, zc, sm, K, y, S, Lf, dinv);
         }
+        cov_full<NX, SYM, PLEN>(P, Pf);
         if (!OUTS) {
         } else if (!COOP) {
             store_rec<NX, 1, LAYOUT, true>(x, a.means + t * N * NX, ln, NX, 1);
-            store_rec<NX, NX, LAYOUT, true>(P, a.covs + t * N * NX * NX, ln, NX, NX);
+            store_rec<NX, NX, LAYOUT, true>(Pf, a.covs + t * N * NX * NX, ln, NX, NX);
         } else {
             wave_store_aos<NX>(x, make_rsrc(a.means + (t * N + blk0) * NX), wave * 64u, tile, lane, last_row);
-            wave_store_aos<NX * NX>(P, make_rsrc(a.covs + (t * N + blk0) * NX * NX), wave * 64u, tile, lane, last_row);
+            wave_store_aos<NX * NX>(Pf, make_rsrc(a.covs + (t * N + blk0) * NX * NX), wave * 64u, tile, lane, last_row);
         }
         FK_UNROLL for (int i = 0; i < NZ; ++i) zc[i] = zn[i];
         hc = hn;
     }
 
     store_rec<NX, 1, LAYOUT, true>(x, a.x, ln, NX, 1);
-    store_rec<NX, NX, LAYOUT, true>(P, a.P, ln, NX, NX);
+    double Pl[NX * NX];
+    cov_full<NX, SYM, PLEN>(P, Pl);
+    store_rec<NX, NX, LAYOUT, true>(Pl, a.P, ln, NX, NX);
     if (a.status) {
-        if (!all_finite<NX>(x) || !all_finite<NX * NX>(P)) st |= ST_NONFINITE;
+        if (!all_finite<NX>(x) || !all_finite<PLEN>(P)) st |= ST_NONFINITE;
         a.status[blk0 + ln.tid] = st;
     }
 }
@@ -187,7 +215,7 @@ int FK_CAT(launch_kf_fast_, FK_NX, FK_NZ, FK_VARIANT)(const KfArgs &a, int layou
 {
     const dim3 grid((unsigned)((a.cnt + BLOCK - 1) / BLOCK)), block(BLOCK);
 #define FK_GO(LAY, MSK, OUT)                                                                               \
-    hipLaunchKernelGGL((kf_fast_kernel<FK_NX, FK_NZ, LAY, MSK, OUT>), grid, block, 0, stream, a, a.F, a.Q, \
+    hipLaunchKernelGGL((kf_fast_kernel<FK_NX, FK_NZ, LAY, MSK, OUT, (FK_FAST_SYM != 0)>), grid, block, 0, stream, a, a.F, a.Q, \
                        a.H, a.R, a.z, a.mask)
 #define FK_GO2(LAY)                          \
     do {                                     \

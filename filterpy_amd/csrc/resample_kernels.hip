@@ -332,22 +332,43 @@ chunk_sum_kernel(long Np, long nch, const double *__restrict__ w, ChunkPlan *__r
     }
 }
 
-// (the plan is small: a single thread per filter walks it)
-__global__ void __launch_bounds__(64)
-chunk_plan_kernel(long Fn, long Np, long nch, ChunkPlan *__restrict__ plan)
+// one workgroup per filter: every thread owns a contiguous slice of the chunks; slice totals are
+// scanned across the workgroup, then each thread walks its slice (the prefix is only approximate
+// anyway, so its association order is free)
+__global__ void __launch_bounds__(RS_THREADS)
+chunk_plan_kernel(long Np, long nch, ChunkPlan *__restrict__ plan)
 {
-    const long f = (long)blockIdx.x * 64 + threadIdx.x;
-    if (f >= Fn) return;
+    __shared__ double tot[RS_THREADS];
+    __shared__ int badpos[RS_THREADS];
+    const long f = blockIdx.x;
+    const int tid = threadIdx.x;
+    const long per = (nch + RS_THREADS - 1) / RS_THREADS;
+    const long k0 = tid * per, k1 = (k0 + per < nch) ? k0 + per : nch;
+    double acc = 0.0;
+    long firstbad = nch;
+    for (long k = k0; k < k1; ++k) {
+        const ChunkPlan &p = plan[f * nch + k];
+        const double S = p.approx_sum;
+        if ((p.bad != 0 || !(S >= 0.0) || !(S < 0x1p1000)) && firstbad == nch) firstbad = k;
+        acc += S;
+    }
+    tot[tid] = acc;
+    badpos[tid] = (int)(firstbad < nch ? firstbad : nch);
+    __syncthreads();
+    // serial exclusive prefix over 256 slice totals by every thread up to its own slot (cheap, LDS)
+    double A = 0.0;
+    long poison_from = nch;
+    for (int t = 0; t < RS_THREADS; ++t) {
+        if (t < tid) A += tot[t];
+        if (badpos[t] < poison_from) poison_from = badpos[t];
+    }
     // |approx prefix - exact sequential prefix| <= delta * prefix for non-negative weights
     const double delta = 8.0 * (double)(Np + 4096) * 0x1p-53;
-    double A = 0.0;
-    bool poisoned = false;
-    for (long k = 0; k < nch; ++k) {
+    for (long k = k0; k < k1; ++k) {
         ChunkPlan &p = plan[f * nch + k];
         const double S = p.approx_sum;
-        poisoned = poisoned || p.bad != 0 || !(S >= 0.0) || !(A + S < 0x1p1000);
         int eu = RS_DIRTY;
-        if (!poisoned && k > 0) {
+        if (k < poison_from && k > 0 && A + S < 0x1p1000) {
             const double lo = A * (1.0 - delta), hi = (A + S) * (1.0 + delta);
             if (lo > 0x1p-900 && ulp_exp(lo) == ulp_exp(hi)) eu = ulp_exp(lo);
         }
@@ -386,39 +407,92 @@ chunk_compose_kernel(long Np, long nch, const double *__restrict__ w, ChunkPlan 
     }
 }
 
+constexpr int RS_CHAIN_BATCH = 1024;   // chunks staged in LDS per batch of the chain walk
+
 __global__ void __launch_bounds__(RS_THREADS)
 chain_kernel(long Np, long nch, const double *__restrict__ w, ChunkPlan *__restrict__ plan)
 {
     __shared__ ScanShared sh;
+    // the plan of a batch of chunks, staged in LDS so the sequential walk never waits on HBM
+    __shared__ Mono b_F[RS_CHAIN_BATCH];
+    __shared__ double b_cin[RS_CHAIN_BATCH];
+    __shared__ long long b_C[RS_CHAIN_BATCH];
+    __shared__ int b_eu[RS_CHAIN_BATCH], b_started[RS_CHAIN_BATCH], b_prelude[RS_CHAIN_BATCH], b_isint[RS_CHAIN_BATCH];
     const long f = blockIdx.x;
     const int tid = threadIdx.x;
     double carry = 0.0;
     bool started = false;
     int prelude = RS_PRELUDE;
-    for (long k = 0; k < nch; ++k) {
-        ChunkPlan &p = plan[f * nch + k];
-        if (tid == 0) {
-            p.cin = carry;
-            p.started = started ? 1 : 0;
-            p.prelude = prelude;
+    // integer mode: while consecutive chunks stay in one binade the running sum is carried as the
+    // integer C (sum = C * 2^ceu) and a chunk costs a handful of integer instructions
+    bool int_mode = false;
+    long long C = 0;
+    int ceu = 0;
+    for (long k0 = 0; k0 < nch; k0 += RS_CHAIN_BATCH) {
+        const int nb = (int)((nch - k0) < RS_CHAIN_BATCH ? (nch - k0) : RS_CHAIN_BATCH);
+        __syncthreads();
+        for (int q = tid; q < nb; q += RS_THREADS) {
+            const ChunkPlan &p = plan[f * nch + k0 + q];
+            b_eu[q] = p.eu;
+            b_F[q] = p.F;
         }
-        const int eu = p.eu;                       // uniform
-        bool shortcut = false;
-        if (eu != RS_DIRTY && started && prelude == 0 && carry > 0.0 && ulp_exp(carry) == eu) {
-            const long long C0 = (long long)scale2(carry, -eu);
-            const long long C1 = mono_apply(C0, p.F);
-            if (C1 < MONO_LIMIT) {                 // stayed inside the binade: the map is exact
-                carry = scale2((double)C1, eu);
-                shortcut = true;
+        __syncthreads();
+        for (int q = 0; q < nb; ++q) {                 // every thread walks the same (uniform) chain
+            const int eu = b_eu[q];
+            if (eu != RS_DIRTY && started && prelude == 0) {
+                if (!int_mode || ceu != eu) {
+                    // (re-)enter integer mode if the exact running sum really sits in the planned binade
+                    if (int_mode) carry = scale2((double)C, ceu);
+                    int_mode = carry > 0.0 && ulp_exp(carry) == eu;
+                    if (int_mode) {
+                        C = (long long)scale2(carry, -eu);
+                        ceu = eu;
+                    }
+                }
+                if (int_mode) {
+                    // one chunk = one integer step: C -> C + (C odd ? ao : ae); exact while C stays < 2^53
+                    const long long C1 = mono_apply(C, b_F[q]);
+                    if (C1 < MONO_LIMIT) {
+                        if (tid == 0) {
+                            b_C[q] = C;
+                            b_started[q] = 1;
+                            b_prelude[q] = eu;          // integer-mode record: prelude slot carries eu
+                            b_isint[q] = 1;
+                        }
+                        C = C1;
+                        continue;
+                    }
+                }
             }
-        }
-        if (!shortcut) {
-            const long base = k * RS_TILE;
+            if (int_mode) {
+                carry = scale2((double)C, ceu);
+                int_mode = false;
+            }
+            if (tid == 0) {
+                b_cin[q] = carry;
+                b_started[q] = started ? 1 : 0;
+                b_prelude[q] = prelude;
+                b_isint[q] = 0;
+            }
+            const long base = (k0 + q) * RS_TILE;
             const int len = (int)((Np - base) < RS_TILE ? (Np - base) : RS_TILE);
             __syncthreads();
             for (int j = tid; j < RS_TILE; j += RS_THREADS) sh.w[j] = j < len ? w[f * Np + base + j] : 0.0;
             __syncthreads();
             carry = tile_cumsum_exact(sh, len, carry, started, prelude);
+        }
+        __syncthreads();
+        for (int q = tid; q < nb; q += RS_THREADS) {
+            ChunkPlan &p = plan[f * nch + k0 + q];
+            if (b_isint[q]) {                           // convert the integer-mode records in parallel
+                p.cin = scale2((double)b_C[q], b_prelude[q]);
+                p.started = 1;
+                p.prelude = 0;
+            } else {
+                p.cin = b_cin[q];
+                p.started = b_started[q];
+                p.prelude = b_prelude[q];
+            }
         }
     }
 }
@@ -505,7 +579,7 @@ static int resample_common(bool stratified, int64_t Fn, int64_t Np, const double
         ChunkPlan *plan = (ChunkPlan *)ws;
         const dim3 gch((unsigned)nch, (unsigned)Fn), block(RS_THREADS);
         hipLaunchKernelGGL(chunk_sum_kernel, gch, block, 0, s, (long)Np, nch, w, plan);
-        hipLaunchKernelGGL(chunk_plan_kernel, dim3((unsigned)((Fn + 63) / 64)), dim3(64), 0, s, (long)Fn, (long)Np, nch, plan);
+        hipLaunchKernelGGL(chunk_plan_kernel, dim3((unsigned)Fn), block, 0, s, (long)Np, nch, plan);
         hipLaunchKernelGGL(chunk_compose_kernel, gch, block, 0, s, (long)Np, nch, w, plan);
         hipLaunchKernelGGL(chain_kernel, dim3((unsigned)Fn), block, 0, s, (long)Np, nch, w, plan);
         if (stratified)

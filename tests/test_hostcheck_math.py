@@ -97,3 +97,42 @@ def test_sigma_points_vs_golden():
         st = lib().hc_sigma(n, ctypes.c_double(lam + n), _p(x0), _p(P0), _p(sig))
         assert st == 0
         assert rel_err_rows(sig, g[f"c{ci}_sigmas"]) < 1e-12
+
+
+def hc_batch_sym(x0, P0, zs, F, Q, H, R, mask=None, alpha_sq=1.0):
+    n, m = F.shape[0], H.shape[0]
+    T = zs.shape[0]
+    c = np.ascontiguousarray
+    x, P = c(x0, dtype=float).copy(), c(P0, dtype=float).copy()
+    mu, cov = np.zeros((T, n)), np.zeros((T, n, n))
+    mup, covp = np.zeros((T, n)), np.zeros((T, n, n))
+    mk = None if mask is None else c(mask, dtype=np.uint8)
+    st = lib().hc_kf_batch_sym(n, m, ctypes.c_long(T), _p(c(F)), _p(c(Q)), _p(c(H)), _p(c(R)), _p(c(zs)), _p(mk),
+                               _p(x), _p(P), _p(mu), _p(cov), _p(mup), _p(covp), ctypes.c_double(alpha_sq))
+    return mu, cov, mup, covp, x, P, st
+
+
+@pytest.mark.parametrize("n,m", [(1, 1), (2, 1), (4, 2), (6, 3), (9, 3)])
+@pytest.mark.parametrize("variant", ["plain", "alpha", "miss"])
+def test_kf_packed_symmetric_vs_golden(n, m, variant):
+    """fk_math_sym.hpp (packed symmetric P, row-streamed Joseph form) -- the arithmetic of the fast
+    kernel -- against the live-reference goldens."""
+    g = golden("kf_dims")
+    p = f"n{n}m{m}_"
+    kw = {}
+    if variant == "alpha":
+        kw["alpha_sq"] = 1.02 ** 2
+    if variant == "miss":
+        kw["mask"] = g[p + "mask"]
+    mu, cov, mup, covp, xf, Pf, st = hc_batch_sym(g[p + "x0"], g[p + "P0"], g[p + "zs"], g[p + "F"], g[p + "Q"],
+                                                  g[p + "H"], g[p + "R"], **kw)
+    assert st == 0
+    for got, key in ((mu, "mu"), (cov, "cov"), (mup, "mup"), (covp, "covp")):
+        assert rel_err_rows(got, g[p + variant + "_" + key]) < TOL, key
+
+
+def test_packed_symmetric_c1_1000_steps():
+    g = golden("kf_c1")
+    mu, cov, mup, covp, *_ = hc_batch_sym(np.zeros(2), g["P0"], g["zs"].reshape(-1, 1), g["F"], g["Q"], g["H"], g["R"])
+    for got, key in ((mu, "mu"), (cov, "cov"), (mup, "mup"), (covp, "covp")):
+        assert rel_err_rows(got, g["1d_" + key]) < TOL
