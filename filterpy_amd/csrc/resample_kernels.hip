@@ -46,6 +46,28 @@ __device__ __forceinline__ Mono shfl_up_mono(const Mono &m, int delta)
     return r;
 }
 
+// Block-wide scan of Mono elements laid out ITEMS-per-thread (thread t owns elements
+// t*ITEMS .. t*ITEMS+ITEMS-1).  In: loc[k] = the thread's running composites (inclusive within
+// the thread).  Out: excl = composite of everything before the thread's first element.
+// `wave_tot` is LDS scratch (RS_THREADS/64 entries); contains one __syncthreads().
+template <int ITEMS>
+__device__ __forceinline__ Mono block_mono_excl(const Mono (&loc)[ITEMS], Mono *wave_tot)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    Mono inc = loc[ITEMS - 1];
+    FK_UNROLL for (int d = 1; d < 64; d <<= 1) {
+        const Mono up = shfl_up_mono(inc, d);
+        if (lane >= d) inc = mono_compose(up, inc);
+    }
+    if (lane == 63) wave_tot[wave] = inc;
+    __syncthreads();
+    Mono excl = shfl_up_mono(inc, 1);
+    if (lane == 0) excl = mono_identity();
+    Mono wprefix = mono_identity();
+    for (int wv = 0; wv < wave; ++wv) wprefix = mono_compose(wprefix, wave_tot[wv]);
+    return mono_compose(wprefix, excl);
+}
+
 // In-place exact inclusive prefix sum of sh.w[0..len) continuing from the running sum `carry`
 // (`started` = false means no element has been summed yet: cs[0] = w[0], like numpy.cumsum).
 // All RS_THREADS threads participate.  Returns the running sum after the tile.
@@ -122,20 +144,8 @@ __device__ double tile_cumsum_exact(ScanShared &sh, int len, double carry, bool 
             run = mono_compose(run, e);
             loc[k] = run;
         }
-        // wave-level inclusive scan of the thread totals
-        Mono inc = run;
-        FK_UNROLL for (int d = 1; d < 64; d <<= 1) {
-            const Mono up = shfl_up_mono(inc, d);
-            if (lane >= d) inc = mono_compose(up, inc);
-        }
         if (tid == 0) sh.first_cross = RS_TILE;
-        if (lane == 63) sh.wave_tot[wave] = inc;
-        __syncthreads();
-        Mono excl = shfl_up_mono(inc, 1);
-        if (lane == 0) excl = mono_identity();
-        Mono wprefix = mono_identity();
-        for (int wv = 0; wv < wave; ++wv) wprefix = mono_compose(wprefix, sh.wave_tot[wv]);
-        excl = mono_compose(wprefix, excl);
+        const Mono excl = block_mono_excl<RS_ITEMS>(loc, sh.wave_tot);
         // element results, crossing detection
         long long Cj[RS_ITEMS];
         int my_cross = RS_TILE;
@@ -416,18 +426,12 @@ chain_kernel(long Np, long nch, const double *__restrict__ w, ChunkPlan *__restr
     // the plan of a batch of chunks, staged in LDS so the sequential walk never waits on HBM
     __shared__ Mono b_F[RS_CHAIN_BATCH];
     __shared__ double b_cin[RS_CHAIN_BATCH];
-    __shared__ long long b_C[RS_CHAIN_BATCH];
-    __shared__ int b_eu[RS_CHAIN_BATCH], b_started[RS_CHAIN_BATCH], b_prelude[RS_CHAIN_BATCH], b_isint[RS_CHAIN_BATCH];
+    __shared__ int b_eu[RS_CHAIN_BATCH], b_started[RS_CHAIN_BATCH], b_prelude[RS_CHAIN_BATCH];
     const long f = blockIdx.x;
     const int tid = threadIdx.x;
     double carry = 0.0;
     bool started = false;
     int prelude = RS_PRELUDE;
-    // integer mode: while consecutive chunks stay in one binade the running sum is carried as the
-    // integer C (sum = C * 2^ceu) and a chunk costs a handful of integer instructions
-    bool int_mode = false;
-    long long C = 0;
-    int ceu = 0;
     for (long k0 = 0; k0 < nch; k0 += RS_CHAIN_BATCH) {
         const int nb = (int)((nch - k0) < RS_CHAIN_BATCH ? (nch - k0) : RS_CHAIN_BATCH);
         __syncthreads();
@@ -437,42 +441,59 @@ chain_kernel(long Np, long nch, const double *__restrict__ w, ChunkPlan *__restr
             b_F[q] = p.F;
         }
         __syncthreads();
-        for (int q = 0; q < nb; ++q) {                 // every thread walks the same (uniform) chain
+        int q = 0;
+        while (q < nb) {                               // uniform
             const int eu = b_eu[q];
-            if (eu != RS_DIRTY && started && prelude == 0) {
-                if (!int_mode || ceu != eu) {
-                    // (re-)enter integer mode if the exact running sum really sits in the planned binade
-                    if (int_mode) carry = scale2((double)C, ceu);
-                    int_mode = carry > 0.0 && ulp_exp(carry) == eu;
-                    if (int_mode) {
-                        C = (long long)scale2(carry, -eu);
-                        ceu = eu;
-                    }
+            if (eu != RS_DIRTY && started && prelude == 0 && carry > 0.0 && ulp_exp(carry) == eu) {
+                // A run of chunks planned for this binade: one integer step per chunk,
+                // C -> C + (C odd ? ao : ae), exact while C stays < 2^53 -- evaluated for the whole
+                // rest of the batch at once by a scan over the chunks' composite maps.  Chunks of
+                // another binade / dirty chunks are poisoned so that they end the run.
+                const long long C0 = (long long)scale2(carry, -eu);
+                constexpr int CI = RS_CHAIN_BATCH / RS_THREADS;
+                Mono loc[CI];
+                Mono run = mono_identity();
+                FK_UNROLL for (int k = 0; k < CI; ++k) {
+                    const int j = tid * CI + k;
+                    Mono e = mono_identity();
+                    if (j >= q && j < nb) e = (b_eu[j] == eu) ? b_F[j] : Mono{MONO_BIG, MONO_BIG};
+                    run = mono_compose(run, e);
+                    loc[k] = run;
                 }
-                if (int_mode) {
-                    // one chunk = one integer step: C -> C + (C odd ? ao : ae); exact while C stays < 2^53
-                    const long long C1 = mono_apply(C, b_F[q]);
-                    if (C1 < MONO_LIMIT) {
-                        if (tid == 0) {
-                            b_C[q] = C;
-                            b_started[q] = 1;
-                            b_prelude[q] = eu;          // integer-mode record: prelude slot carries eu
-                            b_isint[q] = 1;
-                        }
-                        C = C1;
-                        continue;
-                    }
+                if (tid == 0) sh.first_cross = RS_CHAIN_BATCH;
+                const Mono excl = block_mono_excl<CI>(loc, sh.wave_tot);
+                long long Cin[CI];
+                int my_bad = RS_CHAIN_BATCH;
+                FK_UNROLL for (int k = 0; k < CI; ++k) {
+                    const int j = tid * CI + k;
+                    Cin[k] = mono_apply(C0, k == 0 ? excl : mono_compose(excl, loc[k - 1]));
+                    const long long Cout = mono_apply(C0, mono_compose(excl, loc[k]));
+                    if (j >= q && j < nb && Cout >= MONO_LIMIT && my_bad == RS_CHAIN_BATCH) my_bad = j;
                 }
-            }
-            if (int_mode) {
-                carry = scale2((double)C, ceu);
-                int_mode = false;
+                if (my_bad < RS_CHAIN_BATCH) atomicMin(&sh.first_cross, my_bad);
+                __syncthreads();
+                const int stop = sh.first_cross < nb ? sh.first_cross : nb;   // first chunk NOT covered by the run
+                FK_UNROLL for (int k = 0; k < CI; ++k) {
+                    const int j = tid * CI + k;
+                    if (j >= q && j < stop) {
+                        b_cin[j] = scale2((double)Cin[k], eu);
+                        b_started[j] = 1;
+                        b_prelude[j] = 0;
+                    }
+                    if (j == stop - 1 && stop > q) sh.carry = scale2((double)mono_apply(C0, mono_compose(excl, loc[k])), eu);
+                }
+                __syncthreads();
+                if (stop > q) {
+                    carry = sh.carry;
+                    q = stop;
+                    continue;
+                }
+                // the very first chunk of the run leaves the binade: general path below
             }
             if (tid == 0) {
                 b_cin[q] = carry;
                 b_started[q] = started ? 1 : 0;
                 b_prelude[q] = prelude;
-                b_isint[q] = 0;
             }
             const long base = (k0 + q) * RS_TILE;
             const int len = (int)((Np - base) < RS_TILE ? (Np - base) : RS_TILE);
@@ -480,19 +501,14 @@ chain_kernel(long Np, long nch, const double *__restrict__ w, ChunkPlan *__restr
             for (int j = tid; j < RS_TILE; j += RS_THREADS) sh.w[j] = j < len ? w[f * Np + base + j] : 0.0;
             __syncthreads();
             carry = tile_cumsum_exact(sh, len, carry, started, prelude);
+            ++q;
         }
         __syncthreads();
         for (int q = tid; q < nb; q += RS_THREADS) {
             ChunkPlan &p = plan[f * nch + k0 + q];
-            if (b_isint[q]) {                           // convert the integer-mode records in parallel
-                p.cin = scale2((double)b_C[q], b_prelude[q]);
-                p.started = 1;
-                p.prelude = 0;
-            } else {
-                p.cin = b_cin[q];
-                p.started = b_started[q];
-                p.prelude = b_prelude[q];
-            }
+            p.cin = b_cin[q];
+            p.started = b_started[q];
+            p.prelude = b_prelude[q];
         }
     }
 }
