@@ -63,6 +63,10 @@ struct RecView {
             rs = make_rsrc(blk + ln.blk0);
             voff = ln.tid * 8u;
             estride = (unsigned)ln.N * 8u;
+            // Opaque to the optimiser: otherwise every e*estride (one SGPR per record element, 100+
+            // at dim_x = 9) is hoisted out of the time loop and the scalar file spills; recomputing
+            // the product is one s_mul_i32 next to each store.
+            asm volatile("" : "+s"(estride));
         }
     }
     __device__ __forceinline__ double load(int e) const
@@ -120,10 +124,15 @@ struct LdsModel {
     static constexpr int OFF_F = 0, OFF_Q = NX * NX, OFF_H = 2 * NX * NX, OFF_R = 2 * NX * NX + NZ * NX;
     static constexpr int SIZE = OFF_R + NZ * NZ;
     const double *s;
-    __device__ __forceinline__ void rowF(int i, double (&r)[NX]) const { FK_UNROLL for (int j = 0; j < NX; ++j) r[j] = s[OFF_F + i * NX + j]; }
-    __device__ __forceinline__ void rowQ(int i, double (&r)[NX]) const { FK_UNROLL for (int j = 0; j < NX; ++j) r[j] = s[OFF_Q + i * NX + j]; }
-    __device__ __forceinline__ void rowH(int i, double (&r)[NX]) const { FK_UNROLL for (int j = 0; j < NX; ++j) r[j] = s[OFF_H + i * NX + j]; }
-    __device__ __forceinline__ void rowR(int i, double (&r)[NZ]) const { FK_UNROLL for (int j = 0; j < NZ; ++j) r[j] = s[OFF_R + i * NZ + j]; }
+    template <int LEN>
+    __device__ __forceinline__ void row(int off, double (&r)[LEN]) const
+    {
+        FK_UNROLL for (int j = 0; j < LEN; ++j) r[j] = s[off + j];
+    }
+    __device__ __forceinline__ void rowF(int i, double (&r)[NX]) const { row<NX>(OFF_F + i * NX, r); }
+    __device__ __forceinline__ void rowQ(int i, double (&r)[NX]) const { row<NX>(OFF_Q + i * NX, r); }
+    __device__ __forceinline__ void rowH(int i, double (&r)[NX]) const { row<NX>(OFF_H + i * NX, r); }
+    __device__ __forceinline__ void rowR(int i, double (&r)[NZ]) const { row<NZ>(OFF_R + i * NZ, r); }
 };
 
 // Cooperative fill of one padded ROWS x COLS matrix in LDS from an r x c matrix in global

@@ -16,6 +16,7 @@ struct KfArgs {
     int model_t;        // 1: model records advance with the time step
     int update_first;
     int do_predict, do_update;
+    int xcd_swizzle;    // kf_fast: give each XCD (blockIdx % 8) one contiguous range of tracks
     double alpha_sq;
 };
 

@@ -28,6 +28,10 @@
 #ifndef FK_FAST_SYM
 #define FK_FAST_SYM 0
 #endif
+// FK_FAST_ZDEPTH: steps of measurement prefetch (0 = default: 2 for AOS with small records, else 1)
+#ifndef FK_FAST_ZDEPTH
+#define FK_FAST_ZDEPTH 0
+#endif
 
 #ifndef FK_VARIANT
 #define FK_VARIANT 0
@@ -38,8 +42,16 @@
 namespace fk {
 namespace FK_CAT(fastv_, FK_NX, FK_NZ, FK_VARIANT) {
 
-constexpr int fast_min_waves(int nx)
+// Occupancy target per SIMD.  The AOS kernels carry the transpose addressing on top of the filter
+// state: at dim_x = 4 they need ~190 VGPRs, so they run at 2 waves per SIMD (and make up for it with a
+// two-step-deep store pipeline, ZDEPTH) instead of spilling at 3.
+#ifndef FK_FAST_WAVES_AOS
+#define FK_FAST_WAVES_AOS 0
+#endif
+constexpr int fast_min_waves(int nx, int layout)
 {
+    if (layout == LAYOUT_AOS && FK_FAST_WAVES_AOS) return FK_FAST_WAVES_AOS;
+    if (layout == LAYOUT_AOS && nx > 2 && nx <= 4) return 2;
     return FK_FAST_WAVES ? FK_FAST_WAVES : (nx <= 2 ? 8 : nx <= 4 ? 3 : nx <= 6 ? 2 : 1);
 }
 
@@ -55,48 +67,56 @@ __device__ __forceinline__ void wave_lds_fence()
 }
 
 // Wave-cooperative store of one LEN-double record per lane into an AOS block:
-// lane l owns the record of track (block_first + wave_row0 + l); `rs` is the descriptor of the
-// workgroup's slab.  Rows past `last_row` (the block's last valid track; only in the tail
-// workgroup, where those lanes carry a duplicate of that track) are redirected onto it:
-// the same bytes are written twice instead of predicating the store.
+// lane l owns the record of track (block_first + wave_row0 + l); `slab` is the workgroup's slab
+// of the output array.  The descriptor is sized to the block's valid rows, so in the tail workgroup
+// the hardware range check drops the stores of rows past the last track (AOS offsets are
+// voffset + immediate: no scalar offset takes part in the check) -- no store is predicated.
 // The tile is written row-per-lane (row stride LEN|1 doubles: conflict-free ds_write_b64) and read
 // back in memory order, two consecutive doubles per lane per pass -> buffer_store_dwordx4,
-// 1 KiB contiguous per instruction.
+// 1 KiB contiguous per instruction.  When LEN divides 128 every pass uses the same lane-dependent
+// base addresses plus compile-time immediates (2 VGPRs of addressing for the whole record).
 template <int LEN>
-__device__ __forceinline__ void wave_store_aos(const double (&v)[LEN], rsrc_t rs, unsigned wave_row0,
+__device__ __forceinline__ void wave_store_aos(const double (&v)[LEN], const double *slab, unsigned wave_row0,
                                                double *tile, unsigned lane, unsigned last_row)
 {
     constexpr int LENP = LEN | 1;
+    const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(slab), 0,
+                                                        (int)((last_row + 1u) * (unsigned)LEN * 8u), 0x00020000);
     FK_UNROLL for (int e = 0; e < LEN; ++e) tile[lane * LENP + e] = v[e];
     wave_lds_fence();
-    if constexpr (LEN % 2 == 0) {
+    if constexpr (LEN % 2 == 0 && 128 % LEN == 0) {
         constexpr int PASSES = LEN / 2;          // 64*LEN doubles, 128 per pass
+        constexpr int RPP = 128 / LEN;           // rows per pass
+        const unsigned r0 = (lane * 2u) / LEN, col = (lane * 2u) % LEN;
+        const double *tb = tile + r0 * LENP + col;
+        const unsigned gb = ((wave_row0 + r0) * LEN + col) * 8u;
+        FK_UNROLL for (int it = 0; it < PASSES; ++it) {
+            const double a = tb[it * RPP * LENP], b = tb[it * RPP * LENP + 1];
+            const u32x2 ua = __builtin_bit_cast(u32x2, a), ub = __builtin_bit_cast(u32x2, b);
+            const u32x4 w = {ua.x, ua.y, ub.x, ub.y};
+            __builtin_amdgcn_raw_buffer_store_b128(w, rs, gb + (unsigned)(it * RPP * LEN * 8), 0, 0);
+        }
+    } else if constexpr (LEN % 2 == 0) {
+        constexpr int PASSES = LEN / 2;
         FK_UNROLL for (int it = 0; it < PASSES; ++it) {
             const unsigned q = it * 128u + lane * 2u;
             const unsigned row = q / LEN, col = q % LEN;
             const double a = tile[row * LENP + col], b = tile[row * LENP + col + 1];
-            const unsigned grow = min(wave_row0 + row, last_row);
             const u32x2 ua = __builtin_bit_cast(u32x2, a), ub = __builtin_bit_cast(u32x2, b);
             const u32x4 w = {ua.x, ua.y, ub.x, ub.y};
-            __builtin_amdgcn_raw_buffer_store_b128(w, rs, (grow * LEN + col) * 8u, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(w, rs, ((wave_row0 + row) * LEN + col) * 8u, 0, 0);
         }
     } else {
         FK_UNROLL for (int it = 0; it < LEN; ++it) {
             const unsigned q = it * 64u + lane;
             const unsigned row = q / LEN, col = q % LEN;
             const double a = tile[row * LENP + col];
-            const unsigned grow = min(wave_row0 + row, last_row);
-            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, a), rs, (grow * LEN + col) * 8u, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, a), rs, ((wave_row0 + row) * LEN + col) * 8u, 0, 0);
         }
     }
     wave_lds_fence();
 }
 
-// OUTS: true = all four outputs (means, covs, means_p, covs_p) are stored every step; false =
-// none (only the final state).  No store is ever predicated: in the tail workgroup the lanes past
-// the last track recompute that track and write the same bytes again.  The number of stores
-// between a measurement load and its use is therefore a compile-time constant and the wait for
-// it is a counted vmcnt that never drains the store queue.
 // expand the covariance state (full or packed upper triangle) to a row-major NX x NX array;
 // pure register renaming after optimisation
 template <int NX, bool SYM, int PLEN>
@@ -107,7 +127,7 @@ __device__ __forceinline__ void cov_full(const double (&P)[PLEN], double (&M)[NX
 }
 
 template <int NX, int NZ, int LAYOUT, bool HAS_MASK, bool OUTS, bool SYM>
-__global__ void __launch_bounds__(BLOCK, fast_min_waves(NX))
+__global__ void __launch_bounds__(BLOCK, fast_min_waves(NX, LAYOUT))
 kf_fast_kernel(const KfArgs a, const double *__restrict__ pF, const double *__restrict__ pQ,
                const double *__restrict__ pH, const double *__restrict__ pR,
                const double *__restrict__ pz, const uint8_t *__restrict__ pmask)
@@ -120,7 +140,15 @@ kf_fast_kernel(const KfArgs a, const double *__restrict__ pF, const double *__re
     __shared__ double s_mem[SharedModel::SIZE + (BLOCK / 64) * TILE + 1];
 
     const long N = a.N, T = a.T;
-    const long blk0 = a.i0 + (long)blockIdx.x * BLOCK;
+    // Workgroup -> track-block mapping.  Workgroups are dispatched round-robin over the 8 XCDs
+    // (block b on XCD b % 8, MI355X_MICROARCH.md); with xcd_swizzle each XCD works on ONE contiguous
+    // eighth of the tracks, so the lines (and translations) it touches per step are contiguous too.
+    unsigned bid = blockIdx.x;
+    if (a.xcd_swizzle) {
+        const unsigned nb = gridDim.x, per = nb / 8u, rem = nb % 8u, xcd = bid % 8u;
+        bid = xcd * per + (xcd < rem ? xcd : rem) + bid / 8u;
+    }
+    const long blk0 = a.i0 + (long)bid * BLOCK;
     const unsigned tid = threadIdx.x;
     const long left = a.i0 + a.cnt - blk0;                       // >= 1
     const unsigned last_row = (unsigned)(left < BLOCK ? left : BLOCK) - 1u;
@@ -146,24 +174,33 @@ kf_fast_kernel(const KfArgs a, const double *__restrict__ pF, const double *__re
                 P[SYM ? sym_idx<NX>(i, j) : i * NX + j] = pv.load(i * NX + j);
     }
 
-    // measurement pipeline: z[t+1] is requested at the top of step t
-    double zc[NZ], zn[NZ];
-    bool hc = true, hn = true;
-    load_rec<NZ, 1, LAYOUT, true>(zc, pz, lr, NZ, 1, 0.0);
-    if (HAS_MASK) hc = pmask[lr.blk0 + lr.tid] != 0;
+    // Measurement pipeline: z[t + ZDEPTH] is requested at the top of step t and consumed ZDEPTH steps
+    // later; the time loop is unrolled by three with statically rotating buffers so that a pending
+    // load is never copied (a copy would wait for it).  The wait for a measurement only needs the
+    // stores issued BEFORE its load to have drained, so a wave may have ZDEPTH steps of stores in
+    // flight: ZDEPTH = 2 for AOS (20 x 1 KiB stores per step), 1 for SOA (40 x 512 B per step; the
+    // vmcnt counter tops out at 63 outstanding operations).
+    constexpr int ZDEPTH = (FK_FAST_ZDEPTH > 0) ? FK_FAST_ZDEPTH : ((LAYOUT == LAYOUT_AOS && NX * NX + NX <= 24) ? 2 : 1);
+    double zb[3][NZ];
+    bool hb[3] = {true, true, true};
+    auto load_z = [&](long tt, double (&zd)[NZ], bool &hd) {
+        const long tq = tt < T ? tt : T - 1;          // clamp: always issue the same number of loads
+        load_rec<NZ, 1, LAYOUT, true>(zd, pz + tq * N * NZ, lr, NZ, 1, 0.0);
+        if (HAS_MASK) hd = pmask[tq * N + lr.blk0 + lr.tid] != 0;
+    };
+    load_z(0, zb[0], hb[0]);
+    if (ZDEPTH == 2) load_z(1, zb[1], hb[1]);
     // Land every prologue load before the loop: a load still pending at the loop header would
     // make the compiler wait vmcnt(0) inside the loop on every iteration (draining the stores).
     FK_UNROLL for (int i = 0; i < NX; ++i) asm volatile("" ::"v"(x[i]));
     FK_UNROLL for (int i = 0; i < PLEN; ++i) asm volatile("" ::"v"(P[i]));
-    FK_UNROLL for (int i = 0; i < NZ; ++i) asm volatile("" ::"v"(zc[i]));
-    FK_UNROLL for (int i = 0; i < NZ; ++i) zn[i] = zc[i];
+    FK_UNROLL for (int i = 0; i < NZ; ++i) asm volatile("" ::"v"(zb[0][i]));
+    if (ZDEPTH == 2) { FK_UNROLL for (int i = 0; i < NZ; ++i) asm volatile("" ::"v"(zb[1][i])); }
 
     int st = 0;
-    for (long t = 0; t < T; ++t) {
-        if (t + 1 < T) {
-            load_rec<NZ, 1, LAYOUT, true>(zn, pz + (t + 1) * N * NZ, lr, NZ, 1, 0.0);
-            if (HAS_MASK) hn = pmask[(t + 1) * N + lr.blk0 + lr.tid] != 0;
-        }
+    // one time step: consumes (zu, hu), requests the measurement of step t + ZDEPTH into (zl, hl)
+    auto step = [&](long t, const double (&zu)[NZ], bool hu, double (&zl)[NZ], bool &hl) {
+        load_z(t + ZDEPTH, zl, hl);
         if constexpr (SYM) kf_predict_sym<NX>(x, P, sm, a.alpha_sq);
         else kf_predict<NX>(x, P, sm, a.alpha_sq);
         double Pf[NX * NX];
@@ -173,13 +210,13 @@ kf_fast_kernel(const KfArgs a, const double *__restrict__ pF, const double *__re
             store_rec<NX, 1, LAYOUT, true>(x, a.means_p + t * N * NX, ln, NX, 1);
             store_rec<NX, NX, LAYOUT, true>(Pf, a.covs_p + t * N * NX * NX, ln, NX, NX);
         } else {
-            wave_store_aos<NX>(x, make_rsrc(a.means_p + (t * N + blk0) * NX), wave * 64u, tile, lane, last_row);
-            wave_store_aos<NX * NX>(Pf, make_rsrc(a.covs_p + (t * N + blk0) * NX * NX), wave * 64u, tile, lane, last_row);
+            wave_store_aos<NX>(x, a.means_p + (t * N + blk0) * NX, wave * 64u, tile, lane, last_row);
+            wave_store_aos<NX * NX>(Pf, a.covs_p + (t * N + blk0) * NX * NX, wave * 64u, tile, lane, last_row);
         }
-        if (hc) {
+        if (hu) {
             double K[NX * NZ], y[NZ], S[NZ * NZ], Lf[NZ * NZ], dinv[NZ];
-            if constexpr (SYM) st |= kf_update_sym<NX, NZ>(x, P, zc, sm, K, y, S, Lf, dinv);
-            else st |= kf_update<NX, NZ>(x, P, zc, sm, K, y, S, Lf, dinv);
+            if constexpr (SYM) st |= kf_update_sym<NX, NZ>(x, P, zu, sm, K, y, S, Lf, dinv);
+            else st |= kf_update<NX, NZ>(x, P, zu, sm, K, y, S, Lf, dinv);
         }
         cov_full<NX, SYM, PLEN>(P, Pf);
         if (!OUTS) {
@@ -187,11 +224,15 @@ kf_fast_kernel(const KfArgs a, const double *__restrict__ pF, const double *__re
             store_rec<NX, 1, LAYOUT, true>(x, a.means + t * N * NX, ln, NX, 1);
             store_rec<NX, NX, LAYOUT, true>(Pf, a.covs + t * N * NX * NX, ln, NX, NX);
         } else {
-            wave_store_aos<NX>(x, make_rsrc(a.means + (t * N + blk0) * NX), wave * 64u, tile, lane, last_row);
-            wave_store_aos<NX * NX>(Pf, make_rsrc(a.covs + (t * N + blk0) * NX * NX), wave * 64u, tile, lane, last_row);
+            wave_store_aos<NX>(x, a.means + (t * N + blk0) * NX, wave * 64u, tile, lane, last_row);
+            wave_store_aos<NX * NX>(Pf, a.covs + (t * N + blk0) * NX * NX, wave * 64u, tile, lane, last_row);
         }
-        FK_UNROLL for (int i = 0; i < NZ; ++i) zc[i] = zn[i];
-        hc = hn;
+    };
+    // buffer roles rotate statically: step t uses zb[t % 3] and loads into zb[(t + ZDEPTH) % 3]
+    for (long t = 0; t < T; t += 3) {
+        step(t, zb[0], hb[0], zb[ZDEPTH % 3], hb[ZDEPTH % 3]);
+        if (t + 1 < T) step(t + 1, zb[1], hb[1], zb[(1 + ZDEPTH) % 3], hb[(1 + ZDEPTH) % 3]);
+        if (t + 2 < T) step(t + 2, zb[2], hb[2], zb[(2 + ZDEPTH) % 3], hb[(2 + ZDEPTH) % 3]);
     }
 
     store_rec<NX, 1, LAYOUT, true>(x, a.x, ln, NX, 1);

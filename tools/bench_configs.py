@@ -103,6 +103,46 @@ def config3(layout, N, T):
     emit(f"C3 rts_smoother n=9 {layout}", N * T, "track-steps", ms, 8 * (2 * n + 4 * n * n), parity_max_rel=par)
 
 
+def config_kf(layout, n, m, N, T):
+    """plain batch_filter at other (dim_x, dim_z): random stable model, shared"""
+    import torch
+    from filterpy_amd import _engine as E
+    from oracle import kf_oracle
+    rs = np.random.RandomState(n * 10 + m)
+    F = np.eye(n) + 0.05 * rs.randn(n, n)
+    A = rs.randn(n, n)
+    Q = 0.1 * (A @ A.T / n + 0.5 * np.eye(n))
+    H = rs.randn(m, n)
+    B = rs.randn(m, m)
+    R = 0.5 * (B @ B.T / m + 0.5 * np.eye(m))
+    dev = torch.device("cuda")
+    g = torch.Generator(device=dev)
+    g.manual_seed(6)
+    z = torch.randn((T, N, m) if layout == "aos" else (T, m, N), generator=g, device=dev, dtype=torch.float64)
+    x0 = torch.zeros((N, n) if layout == "aos" else (n, N), dtype=torch.float64, device=dev)
+    P0 = (10.0 * torch.eye(n, dtype=torch.float64, device=dev)).reshape(1, n * n).repeat(N, 1)
+    P0 = P0.contiguous() if layout == "aos" else P0.T.contiguous()
+    x, P = x0.clone(), P0.clone()
+    outs = [E.alloc_records((T,), N, n, layout), E.alloc_records((T,), N, n * n, layout),
+            E.alloc_records((T,), N, n, layout), E.alloc_records((T,), N, n * n, layout)]
+    st = torch.zeros(N, dtype=torch.int32, device=dev)
+    dF, dQ, dH, dR = (E.dev(M) for M in (F, Q, H, R))
+    desc = dict(n=n, m=m, nu=0, model_mode=0, N=N, T=T, layout=E.LAYOUTS[layout], update_first=0, alpha_sq=1.0)
+
+    def fwd():
+        x.copy_(x0)
+        P.copy_(P0)
+        E.kf_batch_filter(desc, dF, dQ, dH, dR, z, x, P, means=outs[0], covs=outs[1], means_p=outs[2], covs_p=outs[3], status=st)
+    ms = timeit(fwd)
+    assert not st.any()
+    sample = [0, 255, 256, N - 1]
+    zs_h = (z[:, sample] if layout == "aos" else z[:, :, sample].permute(0, 2, 1)).cpu().numpy()
+    ref = kf_oracle.kf_batch_filter_tracks(np.zeros((4, n)), np.tile(10 * np.eye(n), (4, 1, 1)), zs_h, F, Q, H, R, tracks=range(4))
+    cov = E.from_records(outs[1], layout, 1, (n, n))[:, sample]
+    par = rel(cov.reshape(-1, n * n), ref[1].reshape(-1, n * n))
+    emit(f"KF batch_filter ({n},{m}) N={N} {layout}", N * T, "track-steps", ms, 8 * (m + 2 * n + 2 * n * n), parity_max_rel=par)
+
+
 def config4(layout, N, T):
     import torch
     from filterpy_amd import _engine as E
@@ -195,5 +235,8 @@ if __name__ == "__main__":
             config3(lay, a.N, a.T)
         if "4" in a.configs:
             config4(lay, a.N, a.T)
+        if "6" in a.configs:
+            config_kf(lay, 6, 3, 300_000, a.T)
+            config_kf(lay, 2, 1, 2_000_000, a.T)
     if "5" in a.configs:
         config5()
