@@ -147,4 +147,131 @@ FK_HD int kf_update_sym(double (&x)[NX], double (&U)[NX * (NX + 1) / 2], const d
     return st;
 }
 
+// ------------------------------------------------------------------------------------ RTS --
+// In-place L D L' of a packed symmetric matrix (upper-triangle storage A(i,j), i <= j, read as the
+// lower triangle A(j,i)).  On return A(i,j), i < j, holds L(j,i) and A(j,j) is untouched garbage-free:
+// d[j], dinv[j] carry the pivots.  Returns true iff SPD.
+template <int N>
+FK_HD bool ldlt_packed(double (&A)[N * (N + 1) / 2], double (&d)[N], double (&dinv)[N])
+{
+    bool pd = true;
+    FK_UNROLL for (int j = 0; j < N; ++j) {
+        double dj = A[sym_idx<N>(j, j)];
+        FK_UNROLL for (int k = 0; k < N; ++k)
+            if (k < j) {
+                const double l = A[sym_idx<N>(j, k)];
+                dj = fma(-l * l, d[k], dj);
+            }
+        pd = pd && (dj > 0.0);
+        d[j] = dj;
+        const double di = 1.0 / dj;
+        dinv[j] = di;
+        FK_UNROLL for (int i = 0; i < N; ++i)
+            if (i > j) {
+                double t = A[sym_idx<N>(i, j)];
+                FK_UNROLL for (int k = 0; k < N; ++k)
+                    if (k < j) t = fma(-(A[sym_idx<N>(i, k)] * d[k]), A[sym_idx<N>(j, k)], t);
+                A[sym_idx<N>(i, j)] = t * di;
+            }
+    }
+    return pd;
+}
+
+// solve x S = b for one row (S = L D L' from ldlt_packed), in place
+template <int N>
+FK_HD void solve_row_packed(const double (&Lp)[N * (N + 1) / 2], const double (&dinv)[N], double (&b)[N])
+{
+    FK_UNROLL for (int i = 1; i < N; ++i) {
+        double t = b[i];
+        FK_UNROLL for (int k = 0; k < N; ++k)
+            if (k < i) t = fma(-Lp[sym_idx<N>(i, k)], b[k], t);
+        b[i] = t;
+    }
+    FK_UNROLL for (int i = 0; i < N; ++i) b[i] *= dinv[i];
+    FK_UNROLL for (int i = N - 2; i >= 0; --i) {
+        double t = b[i];
+        FK_UNROLL for (int k = 0; k < N; ++k)
+            if (k > i) t = fma(-Lp[sym_idx<N>(k, i)], b[k], t);
+        b[i] = t;
+    }
+}
+
+// One backward RTS step on packed symmetric covariances (kalman_filter.py:1067-1072):
+//   Pp = F P F' + Q ; K = (P F') Pp^-1 ; x += K (xn - F x) ; P += K (Pn - Pp) K'
+// U: filtered P_k in, smoothed P_k out.  Un: smoothed P_{k+1} in, DESTROYED (holds Pn - Pp).
+// K: full n x n gain (row-major).  The packed predicted covariance Pp is handed to `pp_sink` the
+// moment it is complete and its registers are then reused for the factorisation (at dim_x = 9 the
+// live set would otherwise exceed the 512-register file).
+template <int NX, class Model, class PpSink>
+FK_HD int rts_step_sym(double (&x)[NX], double (&U)[NX * (NX + 1) / 2], const double (&xn)[NX],
+                       double (&Un)[NX * (NX + 1) / 2], const Model &M, double (&K)[NX * NX],
+                       PpSink &&pp_sink)
+{
+    double Pp[NX * (NX + 1) / 2];
+    int st = 0;
+    double dx[NX];
+    // K0 = P F' = (F P)' : row i of F P is column i of K0
+    FK_UNROLL for (int i = 0; i < NX; ++i) {
+        double f[NX];
+        M.rowF(i, f);
+        dx[i] = xn[i] - dot<NX>(f, x);
+        FK_UNROLL for (int j = 0; j < NX; ++j) {
+            double acc = f[0] * U[sym_idx<NX>(0, j)];
+            FK_UNROLL for (int k = 1; k < NX; ++k) acc = fma(f[k], U[sym_idx<NX>(k, j)], acc);
+            K[j * NX + i] = acc;
+        }
+        FK_STAGE();
+    }
+    // Pp(i, j >= i) = (F P)_i . F_j + Q(i,j) ;  (F P)_i = column i of K0
+    FK_UNROLL for (int j = 0; j < NX; ++j) {
+        double f[NX], q[NX];
+        M.rowF(j, f);
+        M.rowQ(j, q);
+        FK_UNROLL for (int i = 0; i < NX; ++i)
+            if (i <= j) {
+                double acc = K[i] * f[0];
+                FK_UNROLL for (int k = 1; k < NX; ++k) acc = fma(K[k * NX + i], f[k], acc);
+                Pp[sym_idx<NX>(i, j)] = acc + q[i];
+            }
+        FK_STAGE();
+    }
+    pp_sink(Pp);
+    // D = Pn - Pp (in place in Un), then factor Pp in place
+    FK_UNROLL for (int e = 0; e < NX * (NX + 1) / 2; ++e) Un[e] -= Pp[e];
+    double (&Lp)[NX * (NX + 1) / 2] = Pp;
+    double d[NX], dinv[NX];
+    if (!ldlt_packed<NX>(Lp, d, dinv)) st |= ST_NOT_PD;
+    FK_STAGE();
+    // K rows: solve, then the state update
+    FK_UNROLL for (int r = 0; r < NX; ++r) {
+        double b[NX];
+        FK_UNROLL for (int c = 0; c < NX; ++c) b[c] = K[r * NX + c];
+        solve_row_packed<NX>(Lp, dinv, b);
+        double acc = x[r];
+        FK_UNROLL for (int c = 0; c < NX; ++c) {
+            K[r * NX + c] = b[c];
+            acc = fma(b[c], dx[c], acc);
+        }
+        x[r] = acc;
+        FK_STAGE();
+    }
+    // P += (K D) K', upper triangle
+    FK_UNROLL for (int i = 0; i < NX; ++i) {
+        double kd[NX];
+        FK_UNROLL for (int b2 = 0; b2 < NX; ++b2) {
+            double acc = K[i * NX] * Un[sym_idx<NX>(0, b2)];
+            FK_UNROLL for (int a2 = 1; a2 < NX; ++a2) acc = fma(K[i * NX + a2], Un[sym_idx<NX>(a2, b2)], acc);
+            kd[b2] = acc;
+        }
+        FK_UNROLL for (int j = 0; j < NX; ++j)
+            if (j >= i) {
+                double acc = U[sym_idx<NX>(i, j)];
+                FK_UNROLL for (int k = 0; k < NX; ++k) acc = fma(kd[k], K[j * NX + k], acc);
+                U[sym_idx<NX>(i, j)] = acc;
+            }
+        FK_STAGE();
+    }
+    return st;
+}
+
 }  // namespace fk

@@ -228,11 +228,23 @@ kf_fast_kernel(const KfArgs a, const double *__restrict__ pF, const double *__re
             wave_store_aos<NX * NX>(Pf, a.covs + (t * N + blk0) * NX * NX, wave * 64u, tile, lane, last_row);
         }
     };
-    // buffer roles rotate statically: step t uses zb[t % 3] and loads into zb[(t + ZDEPTH) % 3]
-    for (long t = 0; t < T; t += 3) {
-        step(t, zb[0], hb[0], zb[ZDEPTH % 3], hb[ZDEPTH % 3]);
-        if (t + 1 < T) step(t + 1, zb[1], hb[1], zb[(1 + ZDEPTH) % 3], hb[(1 + ZDEPTH) % 3]);
-        if (t + 2 < T) step(t + 2, zb[2], hb[2], zb[(2 + ZDEPTH) % 3], hb[(2 + ZDEPTH) % 3]);
+    if constexpr (NX <= 6) {
+        // buffer roles rotate statically: step t uses zb[t % 3] and loads into zb[(t + ZDEPTH) % 3]
+        for (long t = 0; t < T; t += 3) {
+            step(t, zb[0], hb[0], zb[ZDEPTH % 3], hb[ZDEPTH % 3]);
+            if (t + 1 < T) step(t + 1, zb[1], hb[1], zb[(1 + ZDEPTH) % 3], hb[(1 + ZDEPTH) % 3]);
+            if (t + 2 < T) step(t + 2, zb[2], hb[2], zb[(2 + ZDEPTH) % 3], hb[(2 + ZDEPTH) % 3]);
+        }
+    } else {
+        // large dim_x: one step body is already several thousand instructions -- unrolling it three
+        // times overflows the instruction cache (measured 3x slower at dim_x = 9); depth-1 pipeline
+        // with a register copy of the prefetched measurement instead
+        static_assert(NX <= 6 || ZDEPTH == 1, "the rolled loop implements ZDEPTH == 1");
+        for (long t = 0; t < T; ++t) {
+            step(t, zb[0], hb[0], zb[1], hb[1]);
+            FK_UNROLL for (int i = 0; i < NZ; ++i) zb[0][i] = zb[1][i];
+            hb[0] = hb[1];
+        }
     }
 
     store_rec<NX, 1, LAYOUT, true>(x, a.x, ln, NX, 1);

@@ -10,14 +10,42 @@
 // function rts_smoother (:1851-1856; F[k], Q[k]) -- selected by conv_off.
 #include "fk_device.hpp"
 #include "fk_kernel_args.hpp"
+#include "fk_math_sym.hpp"
 
 #ifndef FK_NX
 #error "compile with -DFK_NX=<dim_x> -DFK_EXACT=<0|1>"
+#endif
+// Exact-dimension instantiations keep every covariance as a packed upper triangle and stream the
+// products row by row (fk_math_sym.hpp: no n x n temporary besides the gain K itself); the padded
+// instantiations use the general full-matrix arithmetic of fk_math.hpp.
+#ifndef FK_RTS_SYM
+#define FK_RTS_SYM FK_EXACT
 #endif
 
 namespace fk {
 
 constexpr int rts_min_waves(int nx) { return nx <= 2 ? 4 : nx <= 4 ? 2 : 1; }
+
+// covariance state (full or packed upper triangle) <-> row-major NX x NX
+template <int NX, bool SYM, int PL>
+__device__ __forceinline__ void cov_expand(const double (&P)[PL], double (&M)[NX * NX])
+{
+    FK_UNROLL for (int a = 0; a < NX; ++a)
+        FK_UNROLL for (int b = 0; b < NX; ++b) M[a * NX + b] = SYM ? P[sym_idx<NX>(a, b)] : P[a * NX + b];
+}
+
+template <int NX, bool SYM, int PL, int LAYOUT, bool EXACT>
+__device__ __forceinline__ void cov_load(double (&P)[PL], const double *blk, const Lane &ln, int n)
+{
+    if constexpr (SYM) {
+        const RecView<LAYOUT> pv(blk, ln, NX * NX);
+        FK_UNROLL for (int i = 0; i < NX; ++i)
+            FK_UNROLL for (int j = 0; j < NX; ++j)
+                if (j >= i) P[sym_idx<NX>(i, j)] = pv.load(i * NX + j);
+    } else {
+        load_rec<NX, NX, LAYOUT, EXACT>(P, blk, ln, n, n, 1.0);
+    }
+}
 
 template <int NX, bool EXACT, int LAYOUT, bool UNIFORM>
 __global__ void __launch_bounds__(BLOCK, rts_min_waves(NX))
@@ -37,13 +65,17 @@ rts_kernel(const RtsArgs a, const double *__restrict__ pF, const double *__restr
     const long xs_blk = N * n, ps_blk = N * (long)n * n;
 
     // k = T-1: smoothed == filtered; K = 0; Pp = Ps   (kalman_filter.py:1063-1065)
-    double xn[NX], Pn[NX * NX];
+    constexpr bool SYM = (FK_RTS_SYM != 0) && EXACT;
+    constexpr int PL = SYM ? NX * (NX + 1) / 2 : NX * NX;
+    double xn[NX], Pn[PL];
     load_rec<NX, 1, LAYOUT, EXACT>(xn, pXs + (T - 1) * xs_blk, lr, n, 1, 0.0);
-    load_rec<NX, NX, LAYOUT, EXACT>(Pn, pPs + (T - 1) * ps_blk, lr, n, n, 1.0);
+    cov_load<NX, SYM, PL, LAYOUT, EXACT>(Pn, pPs + (T - 1) * ps_blk, lr, n);
     if (live) {
+        double Pf[NX * NX];
+        cov_expand<NX, SYM, PL>(Pn, Pf);
         store_rec<NX, 1, LAYOUT, EXACT>(xn, a.xs + (T - 1) * xs_blk, ln, n, 1);
-        store_rec<NX, NX, LAYOUT, EXACT>(Pn, a.Ps_out + (T - 1) * ps_blk, ln, n, n);
-        if (a.Pp) store_rec<NX, NX, LAYOUT, EXACT>(Pn, a.Pp + (T - 1) * ps_blk, ln, n, n);
+        store_rec<NX, NX, LAYOUT, EXACT>(Pf, a.Ps_out + (T - 1) * ps_blk, ln, n, n);
+        if (a.Pp) store_rec<NX, NX, LAYOUT, EXACT>(Pf, a.Pp + (T - 1) * ps_blk, ln, n, n);
         if (a.K) {
             double Z[NX * NX];
             FK_UNROLL for (int i = 0; i < NX * NX; ++i) Z[i] = 0.0;
@@ -70,22 +102,38 @@ rts_kernel(const RtsArgs a, const double *__restrict__ pF, const double *__restr
             }
             first = false;
         }
-        double x[NX], P[NX * NX], K[NX * NX], Pp[NX * NX];
+        double x[NX], P[PL], K[NX * NX];
         load_rec<NX, 1, LAYOUT, EXACT>(x, pXs + k * xs_blk, lr, n, 1, 0.0);
-        load_rec<NX, NX, LAYOUT, EXACT>(P, pPs + k * ps_blk, lr, n, n, 1.0);
-        if (UNIFORM) st |= rts_step<NX>(x, P, xn, Pn, sm, K, Pp);
-        else st |= rts_step<NX>(x, P, xn, Pn, tm, K, Pp);
+        cov_load<NX, SYM, PL, LAYOUT, EXACT>(P, pPs + k * ps_blk, lr, n);
+        if constexpr (SYM) {
+            // Pp is streamed out the moment it is complete (its registers are reused by the solve)
+            auto pp_sink = [&](const double (&Ppk)[PL]) {
+                if (live && a.Pp) {
+                    double Pf[NX * NX];
+                    cov_expand<NX, SYM, PL>(Ppk, Pf);
+                    store_rec<NX, NX, LAYOUT, EXACT>(Pf, a.Pp + k * ps_blk, ln, n, n);
+                }
+            };
+            if (UNIFORM) st |= rts_step_sym<NX>(x, P, xn, Pn, sm, K, pp_sink);
+            else st |= rts_step_sym<NX>(x, P, xn, Pn, tm, K, pp_sink);
+        } else {
+            double Pp[PL];
+            if (UNIFORM) st |= rts_step<NX>(x, P, xn, Pn, sm, K, Pp);
+            else st |= rts_step<NX>(x, P, xn, Pn, tm, K, Pp);
+            if (live && a.Pp) store_rec<NX, NX, LAYOUT, EXACT>(Pp, a.Pp + k * ps_blk, ln, n, n);
+        }
         if (live) {
             store_rec<NX, 1, LAYOUT, EXACT>(x, a.xs + k * xs_blk, ln, n, 1);
-            store_rec<NX, NX, LAYOUT, EXACT>(P, a.Ps_out + k * ps_blk, ln, n, n);
             if (a.K) store_rec<NX, NX, LAYOUT, EXACT>(K, a.K + k * ps_blk, ln, n, n);
-            if (a.Pp) store_rec<NX, NX, LAYOUT, EXACT>(Pp, a.Pp + k * ps_blk, ln, n, n);
+            double Pf[NX * NX];
+            cov_expand<NX, SYM, PL>(P, Pf);
+            store_rec<NX, NX, LAYOUT, EXACT>(Pf, a.Ps_out + k * ps_blk, ln, n, n);
         }
         FK_UNROLL for (int i = 0; i < NX; ++i) xn[i] = x[i];
-        FK_UNROLL for (int i = 0; i < NX * NX; ++i) Pn[i] = P[i];
+        FK_UNROLL for (int i = 0; i < PL; ++i) Pn[i] = P[i];
     }
     if (live && a.status) {
-        if (!all_finite<NX>(xn) || !all_finite<NX * NX>(Pn)) st |= ST_NONFINITE;
+        if (!all_finite<NX>(xn) || !all_finite<PL>(Pn)) st |= ST_NONFINITE;
         a.status[ln.blk0 + ln.tid] = st;
     }
 }

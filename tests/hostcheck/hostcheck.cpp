@@ -162,6 +162,58 @@ extern "C" int hc_kf_batch_sym(int n, int m, long T, const double *F, const doub
     return -1;
 }
 
+template <int NX>
+static int rts_sym(long T, const double *F, const double *Q, const double *Xs, const double *Ps, double *xs,
+                   double *Pso, double *Ko, double *Ppo)
+{
+    constexpr int PL = NX * (NX + 1) / 2;
+    RegModel<NX, 1> M;
+    pad<NX, NX>(M.F, F, NX, NX, 1.0);
+    pad<NX, NX>(M.Q, Q, NX, NX, 0.0);
+    double xn[NX], Un[PL];
+    auto pack = [](const double *src, double (&dst)[PL]) {
+        for (int i = 0; i < NX; ++i)
+            for (int j = i; j < NX; ++j) dst[sym_idx<NX>(i, j)] = src[i * NX + j];
+    };
+    auto unpack = [](const double (&src)[PL], double *dst) {
+        for (int i = 0; i < NX; ++i)
+            for (int j = 0; j < NX; ++j) dst[i * NX + j] = src[sym_idx<NX>(i, j)];
+    };
+    for (int i = 0; i < NX; ++i) xn[i] = Xs[(T - 1) * NX + i];
+    pack(Ps + (T - 1) * NX * NX, Un);
+    for (int i = 0; i < NX; ++i) xs[(T - 1) * NX + i] = xn[i];
+    unpack(Un, Pso + (T - 1) * NX * NX);
+    unpack(Un, Ppo + (T - 1) * NX * NX);
+    memset(Ko + (T - 1) * NX * NX, 0, sizeof(double) * NX * NX);
+    int st = 0;
+    for (long k = T - 2; k >= 0; --k) {
+        double x[NX], U[PL], K[NX * NX], Pp[PL];
+        for (int i = 0; i < NX; ++i) x[i] = Xs[k * NX + i];
+        pack(Ps + k * NX * NX, U);
+        st |= rts_step_sym<NX>(x, U, xn, Un, M, K, [&](const double (&Ppk)[PL]) {
+            for (int e = 0; e < PL; ++e) Pp[e] = Ppk[e];
+        });
+        for (int i = 0; i < NX; ++i) xs[k * NX + i] = x[i];
+        unpack(U, Pso + k * NX * NX);
+        unpack(Pp, Ppo + k * NX * NX);
+        for (int i = 0; i < NX * NX; ++i) Ko[k * NX * NX + i] = K[i];
+        for (int i = 0; i < NX; ++i) xn[i] = x[i];
+        for (int i = 0; i < PL; ++i) Un[i] = U[i];
+    }
+    return st;
+}
+
+extern "C" int hc_rts_sym(int n, long T, const double *F, const double *Q, const double *Xs, const double *Ps,
+                          double *xs, double *Pso, double *Ko, double *Ppo)
+{
+    if (n == 1) return rts_sym<1>(T, F, Q, Xs, Ps, xs, Pso, Ko, Ppo);
+    if (n == 2) return rts_sym<2>(T, F, Q, Xs, Ps, xs, Pso, Ko, Ppo);
+    if (n == 4) return rts_sym<4>(T, F, Q, Xs, Ps, xs, Pso, Ko, Ppo);
+    if (n == 6) return rts_sym<6>(T, F, Q, Xs, Ps, xs, Pso, Ko, Ppo);
+    if (n == 9) return rts_sym<9>(T, F, Q, Xs, Ps, xs, Pso, Ko, Ppo);
+    return -1;
+}
+
 #define BY_DIMS(n, m, CALL)                                   \
     if ((n) == 1 && (m) == 1) return CALL(1, 1);              \
     if ((n) == 2 && (m) == 1) return CALL(2, 1);              \

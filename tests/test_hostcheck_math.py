@@ -136,3 +136,19 @@ def test_packed_symmetric_c1_1000_steps():
     mu, cov, mup, covp, *_ = hc_batch_sym(np.zeros(2), g["P0"], g["zs"].reshape(-1, 1), g["F"], g["Q"], g["H"], g["R"])
     for got, key in ((mu, "mu"), (cov, "cov"), (mup, "mup"), (covp, "covp")):
         assert rel_err_rows(got, g["1d_" + key]) < TOL
+
+
+@pytest.mark.parametrize("n,m", [(1, 1), (2, 1), (4, 2), (6, 3), (9, 3)])
+def test_rts_packed_symmetric_vs_golden(n, m):
+    """rts_step_sym (packed symmetric, row-streamed) -- the arithmetic of the exact-dim RTS kernels."""
+    g = golden("kf_dims")
+    p = f"n{n}m{m}_"
+    Xs, Ps = g[p + "plain_mu"], g[p + "plain_cov"]
+    T = Xs.shape[0]
+    c = np.ascontiguousarray
+    xs, Pso, K, Pp = np.zeros((T, n)), np.zeros((T, n, n)), np.zeros((T, n, n)), np.zeros((T, n, n))
+    st = lib().hc_rts_sym(n, ctypes.c_long(T), _p(c(g[p + "F"])), _p(c(g[p + "Q"])), _p(c(Xs)), _p(c(Ps)),
+                          _p(xs), _p(Pso), _p(K), _p(Pp))
+    assert st == 0
+    for got, key in ((xs, "rts_x"), (Pso, "rts_P"), (K, "rts_K"), (Pp, "rts_Pp")):
+        assert rel_err_rows(got, g[p + key]) < 1e-9, key

@@ -141,6 +141,13 @@ def config_kf(layout, n, m, N, T):
     cov = E.from_records(outs[1], layout, 1, (n, n))[:, sample]
     par = rel(cov.reshape(-1, n * n), ref[1].reshape(-1, n * n))
     emit(f"KF batch_filter ({n},{m}) N={N} {layout}", N * T, "track-steps", ms, 8 * (m + 2 * n + 2 * n * n), parity_max_rel=par)
+    so = [E.alloc_records((T,), N, n, layout)] + [E.alloc_records((T,), N, n * n, layout) for _ in range(3)]
+    ms = timeit(lambda: E.kf_rts(desc, dF, dQ, outs[0], outs[1], so[0], so[1], so[2], so[3], convention=0, status=st))
+    assert not st.any()
+    sm = kf_oracle.rts_smoother_tracks(ref[0], ref[1], F, Q, tracks=range(4))
+    Ps = E.from_records(so[1], layout, 1, (n, n))[:, sample]
+    emit(f"RTS smoother n={n} N={N} {layout}", N * T, "track-steps", ms, 8 * (2 * n + 4 * n * n),
+         parity_max_rel=rel(Ps.reshape(-1, n * n), sm[1].reshape(-1, n * n)))
 
 
 def config4(layout, N, T):
@@ -237,6 +244,7 @@ if __name__ == "__main__":
             config4(lay, a.N, a.T)
         if "6" in a.configs:
             config_kf(lay, 6, 3, 300_000, a.T)
+            config_kf(lay, 4, 2, 500_000, a.T)
             config_kf(lay, 2, 1, 2_000_000, a.T)
     if "5" in a.configs:
         config5()
