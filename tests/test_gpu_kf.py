@@ -156,3 +156,28 @@ def test_c2_shape_sample_vs_oracle():
         ref = kf_oracle.kf_batch_filter_tracks(x0, P0, zs, F, Q, H, R, tracks=sample)
         for k in range(4):
             assert rel_err_rows(_per_track(got[k][:, sample]), _per_track(ref[k])) < TOL, (layout, k)
+
+
+@pytest.mark.parametrize("n,m,variants", [(4, 2, (0, 1, 2, 3, 4)), (6, 3, (0, 1)), (9, 3, (0, 1))])
+@pytest.mark.parametrize("layout", ["soa", "aos"])
+def test_fast_kernel_tuning_variants(n, m, variants, layout, monkeypatch):
+    """Every compiled tuning variant of the shared-model kernel (occupancy / packed-symmetric /
+    prefetch depth, csrc/fk_dims_fast.def), the XCD-contiguous block mapping and the generic kernel
+    (FK_NO_FAST) must give the same results as the goldens."""
+    from gpu_util import run_kf_batch, tile_tracks
+    g = golden("kf_dims")
+    p = f"n{n}m{m}_"
+    N = 777
+    args = (tile_tracks(g[p + "x0"], N), tile_tracks(g[p + "P0"], N), tile_tracks(g[p + "zs"], N, 1),
+            g[p + "F"], g[p + "Q"], g[p + "H"], g[p + "R"])
+    mask = tile_tracks(g[p + "mask"], N, 1)
+    settings = [{"FK_FAST_VARIANT": str(v)} for v in variants] + [{"FK_FAST_XCD": "1"}, {"FK_NO_FAST": "1"}]
+    for env in settings:
+        with monkeypatch.context() as mp:
+            for k, v in env.items():
+                mp.setenv(k, v)
+            for kw, tag in (({}, "plain"), ({"mask": mask}, "miss")):
+                mu, cov, mup, covp, *_ = run_kf_batch(*args, layout=layout, **kw)
+                for got, key in ((mu, "mu"), (cov, "cov"), (mup, "mup"), (covp, "covp")):
+                    for trk in (0, 255, 256, N - 1):
+                        assert rel_err_rows(got[:, trk], g[p + tag + "_" + key]) < TOL, (env, tag, key, trk)

@@ -150,6 +150,47 @@ def config_kf(layout, n, m, N, T):
          parity_max_rel=rel(Ps.reshape(-1, n * n), sm[1].reshape(-1, n * n)))
 
 
+def config_generic(layout, N, T):
+    """The generic kernel (kf_kernels.hip) on the C2 model: per-track models, per-step models,
+    control input, update_first -- the calls the specialised kernel does not take."""
+    import torch
+    from filterpy_amd import _engine as E
+    sys.path.insert(0, ROOT)
+    from bench import c2_model, c2_inputs_device
+    n, m = 4, 2
+    F, Q, H, R = c2_model()
+    dev = torch.device("cuda")
+    x0, P0, z = c2_inputs_device(N, T, layout, 7, dev)
+    x, P = x0.clone(), P0.clone()
+    outs = [E.alloc_records((T,), N, n, layout), E.alloc_records((T,), N, n * n, layout),
+            E.alloc_records((T,), N, n, layout), E.alloc_records((T,), N, n * n, layout)]
+    st = torch.zeros(N, dtype=torch.int32, device=dev)
+
+    def rep(M, lead):
+        t = torch.as_tensor(M, dtype=torch.float64, device=dev)
+        t = t.reshape(1, -1).repeat(N, 1) if lead == 0 else t.reshape(1, 1, -1).repeat(T, N, 1)
+        if layout == "soa":
+            t = t.transpose(-1, -2).contiguous()
+        return t
+    cases = {
+        "shared, update_first": (0, [E.dev(M) for M in (F, Q, H, R)], dict(update_first=1), 0),
+        "per-track models": (1, [rep(M, 0) for M in (F, Q, H, R)], {}, 8 * (2 * n * n + m * n + m * m) / T),
+        "per-step shared models": (3, [E.dev(np.tile(M, (T, 1, 1))) for M in (F, Q, H, R)], {}, 0),
+        "per-track-per-step models": (2, [rep(M, 1) for M in (F, Q, H, R)], {}, 8 * (2 * n * n + m * n + m * m)),
+    }
+    for name, (mode, mods, kw, extra) in cases.items():
+        desc = dict(n=n, m=m, nu=0, model_mode=mode, N=N, T=T, layout=E.LAYOUTS[layout], update_first=0, alpha_sq=1.0)
+        desc.update(kw)
+
+        def run():
+            x.copy_(x0)
+            P.copy_(P0)
+            E.kf_batch_filter(desc, *mods, z, x, P, means=outs[0], covs=outs[1], means_p=outs[2], covs_p=outs[3], status=st)
+        ms = timeit(run, warm=1, reps=3)
+        assert not st.any()
+        emit(f"generic kf_kernel (4,2) {name} N={N} {layout}", N * T, "track-steps", ms, 8 * (m + 2 * n + 2 * n * n) + extra)
+
+
 def config4(layout, N, T):
     import torch
     from filterpy_amd import _engine as E
@@ -242,6 +283,8 @@ if __name__ == "__main__":
             config3(lay, a.N, a.T)
         if "4" in a.configs:
             config4(lay, a.N, a.T)
+        if "7" in a.configs:
+            config_generic(lay, 200_000, a.T)
         if "6" in a.configs:
             config_kf(lay, 6, 3, 300_000, a.T)
             config_kf(lay, 4, 2, 500_000, a.T)
