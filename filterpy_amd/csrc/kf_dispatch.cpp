@@ -18,7 +18,7 @@ namespace fk {
 #define FK_KF_INST(NX, NZ, EX) int launch_kf_##NX##_##NZ##_##EX(const KfArgs &, int, bool, hipStream_t);
 #include "fk_dims.def"
 #undef FK_KF_INST
-#define FK_FAST_INST(NX, NZ, V, W, S, WA, ZD) int launch_kf_fast_##NX##_##NZ##_v##V(const KfArgs &, int, bool, hipStream_t);
+#define FK_FAST_INST(NX, NZ, V, W, S, WA, ZD) int launch_kf_fast_##NX##_##NZ##_v##V(const KfArgs &, int, bool, int, hipStream_t);
 #include "fk_dims_fast.def"
 #undef FK_FAST_INST
 #define FK_RTS_INST(NX, EX) int launch_rts_##NX##_##EX(const RtsArgs &, int, bool, hipStream_t);
@@ -37,7 +37,7 @@ static const KfEntry kf_table[] = {
 
 struct FastEntry {
     int nx, nz, variant;
-    int (*fn)(const KfArgs &, int, bool, hipStream_t);
+    int (*fn)(const KfArgs &, int, bool, int, hipStream_t);
 };
 static const FastEntry fast_table[] = {
 #define FK_FAST_INST(NX, NZ, V, W, S, WA, ZD) {NX, NZ, V, launch_kf_fast_##NX##_##NZ##_v##V},
@@ -139,16 +139,17 @@ static int run_kf(const fk_kf_desc *d, KfArgs &a, void *stream)
     const bool uniform = (d->model_mode == FK_MODEL_SHARED || d->model_mode == FK_MODEL_PER_STEP);
     a.i0 = 0;
     a.cnt = d->N;
-    // Specialised kernel (kf_fast.hip) for the common batch_filter call: one shared constant
-    // model, predict->update, no control input, all four outputs stored or none.
+    // Specialised kernel (kf_fast.hip) for the common batch_filter call: predict->update, no control
+    // input, all four outputs stored or none (every model mode at dim_x <= 6, shared constant model above).
     const bool all_out = a.means && a.covs && a.means_p && a.covs_p;
     const bool no_out = !a.means && !a.covs && !a.means_p && !a.covs_p;
-    if (d->model_mode == FK_MODEL_SHARED && d->nu == 0 && !d->update_first && a.do_predict && a.do_update &&
+    if (d->nu == 0 && !d->update_first && a.do_predict && a.do_update &&
         (all_out || no_out) && !a.y_out && !a.K_out && !a.S_out && !a.SI_out && !getenv("FK_NO_FAST")) {
         if (const FastEntry *f = pick_fast(d->n, d->m)) {
             const char *ev = getenv("FK_FAST_XCD");
             a.xcd_swizzle = ev ? atoi(ev) : 0;
-            return f->fn(a, d->layout, all_out, (hipStream_t)stream);
+            const int rc = f->fn(a, d->layout, all_out, d->model_mode, (hipStream_t)stream);
+            if (rc <= 0) return rc;        // 1 = this instantiation does not carry the model mode
         }
     }
     return e->fn(a, d->layout, uniform, (hipStream_t)stream);

@@ -126,8 +126,12 @@ __device__ __forceinline__ void cov_full(const double (&P)[PLEN], double (&M)[NX
         FK_UNROLL for (int b = 0; b < NX; ++b) M[a * NX + b] = SYM ? P[sym_idx<NX>(a, b)] : P[a * NX + b];
 }
 
-template <int NX, int NZ, int LAYOUT, bool HAS_MASK, bool OUTS, bool SYM>
-__global__ void __launch_bounds__(BLOCK, fast_min_waves(NX, LAYOUT))
+// MMODE (= FK_MODEL_* of include/filterhip.h): 0 one shared constant model (LDS), 1 one model per
+// track (registers, loaded once: coalesced in SOA), 2 one model per track and step (registers,
+// reloaded every step), 3 one model per step shared by all tracks (LDS, double-buffered, fetched a
+// step ahead by the first SIZE threads).
+template <int NX, int NZ, int LAYOUT, bool HAS_MASK, bool OUTS, bool SYM, int MMODE>
+__global__ void __launch_bounds__(BLOCK, fast_min_waves(NX, LAYOUT) > 1 && (MMODE == 1 || MMODE == 2) ? fast_min_waves(NX, LAYOUT) - 1 : fast_min_waves(NX, LAYOUT))
 kf_fast_kernel(const KfArgs a, const double *__restrict__ pF, const double *__restrict__ pQ,
                const double *__restrict__ pH, const double *__restrict__ pR,
                const double *__restrict__ pz, const uint8_t *__restrict__ pmask)
@@ -137,7 +141,8 @@ kf_fast_kernel(const KfArgs a, const double *__restrict__ pF, const double *__re
     // records fall back to per-lane stores (TODO: chunked tiles)
     constexpr bool COOP = (LAYOUT == LAYOUT_AOS) && (NX * NX <= 36);
     constexpr int TILE = COOP ? 64 * ((NX * NX) | 1) : 0;   // doubles per wave
-    __shared__ double s_mem[SharedModel::SIZE + (BLOCK / 64) * TILE + 1];
+    constexpr int MSIZE = SharedModel::SIZE * (MMODE == 3 ? 2 : 1);   // per-step models: double buffer
+    __shared__ double s_mem[MSIZE + (BLOCK / 64) * TILE + 1];
 
     const long N = a.N, T = a.T;
     // Workgroup -> track-block mapping.  Workgroups are dispatched round-robin over the 8 XCDs
@@ -155,14 +160,43 @@ kf_fast_kernel(const KfArgs a, const double *__restrict__ pF, const double *__re
     const Lane ln{blk0, min(threadIdx.x, last_row), N};          // tail lanes duplicate the last track
     const Lane lr = ln;
     const unsigned lane = tid & 63u, wave = tid >> 6;
-    double *tile = s_mem + SharedModel::SIZE + wave * TILE;
+    double *tile = s_mem + MSIZE + wave * TILE;
 
-    lds_fill<NX, NX>(s_mem + SharedModel::OFF_F, pF, NX, NX, 1.0, tid);
-    lds_fill<NX, NX>(s_mem + SharedModel::OFF_Q, pQ, NX, NX, 0.0, tid);
-    lds_fill<NZ, NX>(s_mem + SharedModel::OFF_H, pH, NZ, NX, 0.0, tid);
-    lds_fill<NZ, NZ>(s_mem + SharedModel::OFF_R, pR, NZ, NZ, 1.0, tid);
-    __syncthreads();
-    const SharedModel sm{s_mem};
+    RegModel<NX, NZ> tm;                       // per-track models (MMODE 1, 2)
+    constexpr long FSZ = NX * NX, HSZ = NZ * NX, RSZ = NZ * NZ;
+    // element `tid` of the concatenated shared model [F | Q | H | R] of step tt (MMODE 3)
+    auto shared_elem = [&](long tt) -> double {
+        const int k = (int)tid;
+        if (k < SharedModel::OFF_Q) return pF[tt * FSZ + k];
+        if (k < SharedModel::OFF_H) return pQ[tt * FSZ + (k - SharedModel::OFF_Q)];
+        if (k < SharedModel::OFF_R) return pH[tt * HSZ + (k - SharedModel::OFF_H)];
+        if (k < SharedModel::SIZE) return pR[tt * RSZ + (k - SharedModel::OFF_R)];
+        return 0.0;
+    };
+    auto load_track_model = [&](long tt) {
+        load_rec<NX, NX, LAYOUT, true>(tm.F, pF + tt * N * FSZ, lr, NX, NX, 1.0);
+        load_rec<NX, NX, LAYOUT, true>(tm.Q, pQ + tt * N * FSZ, lr, NX, NX, 0.0);
+        load_rec<NZ, NX, LAYOUT, true>(tm.H, pH + tt * N * HSZ, lr, NZ, NX, 0.0);
+        load_rec<NZ, NZ, LAYOUT, true>(tm.R, pR + tt * N * RSZ, lr, NZ, NZ, 1.0);
+    };
+    double mnext = 0.0;                        // MMODE 3: this thread's element of the NEXT step's model
+    if constexpr (MMODE == 0 || MMODE == 3) {
+        lds_fill<NX, NX>(s_mem + SharedModel::OFF_F, pF, NX, NX, 1.0, tid);
+        lds_fill<NX, NX>(s_mem + SharedModel::OFF_Q, pQ, NX, NX, 0.0, tid);
+        lds_fill<NZ, NX>(s_mem + SharedModel::OFF_H, pH, NZ, NX, 0.0, tid);
+        lds_fill<NZ, NZ>(s_mem + SharedModel::OFF_R, pR, NZ, NZ, 1.0, tid);
+        if constexpr (MMODE == 3) {
+            mnext = shared_elem(T > 1 ? 1 : 0);     // model[1]
+            asm volatile("" ::"v"(mnext));
+        }
+        __syncthreads();
+    } else {
+        load_track_model(0);
+        FK_UNROLL for (int i = 0; i < NX * NX; ++i) { asm volatile("" ::"v"(tm.F[i])); asm volatile("" ::"v"(tm.Q[i])); }
+        FK_UNROLL for (int i = 0; i < NZ * NX; ++i) asm volatile("" ::"v"(tm.H[i]));
+        FK_UNROLL for (int i = 0; i < NZ * NZ; ++i) asm volatile("" ::"v"(tm.R[i]));
+    }
+    SharedModel sm{s_mem};
 
     constexpr int PLEN = SYM ? NX * (NX + 1) / 2 : NX * NX;
     double x[NX], P[PLEN];      // SYM: P is the packed upper triangle
@@ -201,8 +235,20 @@ kf_fast_kernel(const KfArgs a, const double *__restrict__ pF, const double *__re
     // one time step: consumes (zu, hu), requests the measurement of step t + ZDEPTH into (zl, hl)
     auto step = [&](long t, const double (&zu)[NZ], bool hu, double (&zl)[NZ], bool &hl) {
         load_z(t + ZDEPTH, zl, hl);
-        if constexpr (SYM) kf_predict_sym<NX>(x, P, sm, a.alpha_sq);
-        else kf_predict<NX>(x, P, sm, a.alpha_sq);
+        if constexpr (MMODE == 2) {
+            if (t > 0) load_track_model(t);            // this step's per-track model
+        }
+        // MMODE 3: mnext holds this thread's element of model[t+1]; keep it for the hand-over at the end
+        // of the step and request model[t+2] (consumed one step later: a counted wait)
+        const double mpub = mnext;
+        if constexpr (MMODE == 3) mnext = shared_elem(t + 2 < T ? t + 2 : T - 1);
+        if constexpr (MMODE == 1 || MMODE == 2) {
+            if constexpr (SYM) kf_predict_sym<NX>(x, P, tm, a.alpha_sq);
+            else kf_predict<NX>(x, P, tm, a.alpha_sq);
+        } else {
+            if constexpr (SYM) kf_predict_sym<NX>(x, P, sm, a.alpha_sq);
+            else kf_predict<NX>(x, P, sm, a.alpha_sq);
+        }
         double Pf[NX * NX];
         cov_full<NX, SYM, PLEN>(P, Pf);
         if (!OUTS) {
@@ -215,8 +261,13 @@ kf_fast_kernel(const KfArgs a, const double *__restrict__ pF, const double *__re
         }
         if (hu) {
             double K[NX * NZ], y[NZ], S[NZ * NZ], Lf[NZ * NZ], dinv[NZ];
-            if constexpr (SYM) st |= kf_update_sym<NX, NZ>(x, P, zu, sm, K, y, S, Lf, dinv);
-            else st |= kf_update<NX, NZ>(x, P, zu, sm, K, y, S, Lf, dinv);
+            if constexpr (MMODE == 1 || MMODE == 2) {
+                if constexpr (SYM) st |= kf_update_sym<NX, NZ>(x, P, zu, tm, K, y, S, Lf, dinv);
+                else st |= kf_update<NX, NZ>(x, P, zu, tm, K, y, S, Lf, dinv);
+            } else {
+                if constexpr (SYM) st |= kf_update_sym<NX, NZ>(x, P, zu, sm, K, y, S, Lf, dinv);
+                else st |= kf_update<NX, NZ>(x, P, zu, sm, K, y, S, Lf, dinv);
+            }
         }
         cov_full<NX, SYM, PLEN>(P, Pf);
         if (!OUTS) {
@@ -226,6 +277,14 @@ kf_fast_kernel(const KfArgs a, const double *__restrict__ pF, const double *__re
         } else {
             wave_store_aos<NX>(x, a.means + (t * N + blk0) * NX, wave * 64u, tile, lane, last_row);
             wave_store_aos<NX * NX>(Pf, a.covs + (t * N + blk0) * NX * NX, wave * 64u, tile, lane, last_row);
+        }
+        if constexpr (MMODE == 3) {
+            // publish model[t+1] into the other LDS buffer: nobody reads that buffer during step t, and
+            // one barrier makes it visible for step t+1
+            double *nb = s_mem + ((t + 1) & 1) * SharedModel::SIZE;
+            if (tid < (unsigned)SharedModel::SIZE) nb[tid] = mpub;
+            __syncthreads();
+            sm.s = nb;
         }
     };
     if constexpr (NX <= 6) {
@@ -262,27 +321,43 @@ kf_fast_kernel(const KfArgs a, const double *__restrict__ pF, const double *__re
 }  // namespace (variant)
 using namespace FK_CAT(fastv_, FK_NX, FK_NZ, FK_VARIANT);
 
-// Handles tracks [a.i0, a.i0 + a.cnt).  outs: all four outputs
-// non-NULL (true) or all NULL (false).
-int FK_CAT(launch_kf_fast_, FK_NX, FK_NZ, FK_VARIANT)(const KfArgs &a, int layout, bool outs, hipStream_t stream)
+// Handles tracks [a.i0, a.i0 + a.cnt).  outs: all four outputs non-NULL (true) or all NULL (false).
+// mmode: FK_MODEL_* of the descriptor.  Returns 1 if this instantiation does not carry that model
+// mode (only variant 0 at dim_x <= 6 compiles the per-track / per-step modes): the caller then falls
+// back to the generic kernel.
+#define FK_FAST_ALL_MODES (FK_VARIANT == 0 && FK_NX <= 6)
+int FK_CAT(launch_kf_fast_, FK_NX, FK_NZ, FK_VARIANT)(const KfArgs &a, int layout, bool outs, int mmode, hipStream_t stream)
 {
+    if (mmode != 0 && !FK_FAST_ALL_MODES) return 1;
     const dim3 grid((unsigned)((a.cnt + BLOCK - 1) / BLOCK)), block(BLOCK);
-#define FK_GO(LAY, MSK, OUT)                                                                               \
-    hipLaunchKernelGGL((kf_fast_kernel<FK_NX, FK_NZ, LAY, MSK, OUT, (FK_FAST_SYM != 0)>), grid, block, 0, stream, a, a.F, a.Q, \
-                       a.H, a.R, a.z, a.mask)
-#define FK_GO2(LAY)                          \
-    do {                                     \
-        if (a.mask) {                        \
-            if (outs) FK_GO(LAY, true, true); \
-            else FK_GO(LAY, true, false);    \
-        } else {                             \
-            if (outs) FK_GO(LAY, false, true); \
-            else FK_GO(LAY, false, false);   \
-        }                                    \
+#define FK_GO(LAY, MSK, OUT, MM)                                                                          \
+    hipLaunchKernelGGL((kf_fast_kernel<FK_NX, FK_NZ, LAY, MSK, OUT, (FK_FAST_SYM != 0), MM>), grid, block, 0, \
+                       stream, a, a.F, a.Q, a.H, a.R, a.z, a.mask)
+#define FK_GO3(LAY, MM)                          \
+    do {                                         \
+        if (a.mask) {                            \
+            if (outs) FK_GO(LAY, true, true, MM); \
+            else FK_GO(LAY, true, false, MM);    \
+        } else {                                 \
+            if (outs) FK_GO(LAY, false, true, MM); \
+            else FK_GO(LAY, false, false, MM);   \
+        }                                        \
     } while (0)
+#if FK_FAST_ALL_MODES
+#define FK_GO2(LAY)                      \
+    do {                                 \
+        if (mmode == 0) FK_GO3(LAY, 0);  \
+        else if (mmode == 1) FK_GO3(LAY, 1); \
+        else if (mmode == 2) FK_GO3(LAY, 2); \
+        else FK_GO3(LAY, 3);             \
+    } while (0)
+#else
+#define FK_GO2(LAY) FK_GO3(LAY, 0)
+#endif
     if (layout == LAYOUT_SOA) FK_GO2(LAYOUT_SOA);
     else FK_GO2(LAYOUT_AOS);
 #undef FK_GO2
+#undef FK_GO3
 #undef FK_GO
     return check_launch("kf_fast_kernel");
 }

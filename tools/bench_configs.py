@@ -188,7 +188,7 @@ def config_generic(layout, N, T):
             E.kf_batch_filter(desc, *mods, z, x, P, means=outs[0], covs=outs[1], means_p=outs[2], covs_p=outs[3], status=st)
         ms = timeit(run, warm=1, reps=3)
         assert not st.any()
-        emit(f"generic kf_kernel (4,2) {name} N={N} {layout}", N * T, "track-steps", ms, 8 * (m + 2 * n + 2 * n * n) + extra)
+        emit(f"KF (4,2) {name} N={N} {layout}", N * T, "track-steps", ms, 8 * (m + 2 * n + 2 * n * n) + extra)
 
 
 def config4(layout, N, T):
