@@ -274,4 +274,37 @@ FK_HD int rts_step_sym(double (&x)[NX], double (&U)[NX * (NX + 1) / 2], const do
     return st;
 }
 
+// Cholesky factor of scale * P for a packed symmetric P: L (lower, L L' = scale P) packed with the
+// same index map (L(i,j), i >= j, lives at sym_idx(j,i)).  U(k,j) = L(j,k) are the rows that
+// scipy.linalg.cholesky (upper) returns (sigma_points.py:167-168).  Returns true iff SPD.
+template <int NX>
+FK_HD bool chol_packed(const double (&P)[NX * (NX + 1) / 2], double scale, double (&L)[NX * (NX + 1) / 2])
+{
+    bool pd = true;
+    FK_UNROLL for (int j = 0; j < NX; ++j) {
+        double d = scale * P[sym_idx<NX>(j, j)];
+        FK_UNROLL for (int k = 0; k < NX; ++k)
+            if (k < j) d = fma(-L[sym_idx<NX>(j, k)], L[sym_idx<NX>(j, k)], d);
+        pd = pd && (d > 0.0);
+        const double ljj = sqrt(d);
+        L[sym_idx<NX>(j, j)] = ljj;
+        const double inv = 1.0 / ljj;
+        FK_UNROLL for (int i = 0; i < NX; ++i)
+            if (i > j) {
+                double t = scale * P[sym_idx<NX>(j, i)];
+                FK_UNROLL for (int k = 0; k < NX; ++k)
+                    if (k < j) t = fma(-L[sym_idx<NX>(i, k)], L[sym_idx<NX>(j, k)], t);
+                L[sym_idx<NX>(i, j)] = t * inv;
+            }
+    }
+    return pd;
+}
+
+// component c of column k of L (0 above the diagonal)
+template <int NX>
+FK_HD double lcol(const double (&L)[NX * (NX + 1) / 2], int c, int k)
+{
+    return c >= k ? L[sym_idx<NX>(c, k)] : 0.0;
+}
+
 }  // namespace fk

@@ -1,0 +1,294 @@
+// ukf_kernels.hip -- fused linear-model unscented Kalman filter for gfx950 (MI355X).
+//
+//   fk_ukf_linear_batch_f64 <- UnscentedKalmanFilter.batch_filter (filterpy/kalman/UKF.py:524-632) with
+//                              fx(x, dt) = F x, hx(x) = H x: the whole predict (UKF.py:400-411) / update
+//                              (:462-481) loop stays in registers over the time steps.
+// (Split from ut_kernels.hip so the two translation units compile in parallel.)
+#include "../../include/filterhip.h"
+#include "fk_device.hpp"
+#include "fk_kernel_args.hpp"
+#include "fk_math_sym.hpp"
+
+namespace fk {
+
+// --------------------------------------------------- fused linear-model UKF --
+// Per step (UKF.py:400-411, 462-481) with fx(x) = F x, hx(x) = H x:
+//   L  = chol(scale P);  sigma_i = x, x +- L[:,k]          (sigma_points.py:167-175)
+//   sf_i = F sigma_i ;  (x,P) = UT(sf, Wm, Wc, Q)
+//   L  = chol(scale P);  sf_i = sigma_i(x,P)  (regenerated, UKF.py:407)
+//   sh_i = H sf_i ; (zp,S) = UT(sh, Wm, Wc, R) ; Pxz = sum Wc_i (sf_i-x)(sh_i-zp)'
+//   K = Pxz S^-1 ; x += K (z-zp) ; P -= K (S K')
+// The covariance and both Cholesky factors are packed triangles, and the propagated sigma points are
+// never all materialised: the predict makes two sweeps over the 2n+1 points (mean, then covariance),
+// regenerating each point x +- L[:,k] and pushing it through F on the fly -- ~70 live doubles at
+// n = 6 instead of ~260 (the first version spilled 196 registers at one wave per SIMD).
+template <int NX, int NZ, int LAYOUT>
+__global__ void __launch_bounds__(BLOCK, (NX <= 2 ? 4 : NX <= 4 ? 2 : 1))
+ukf_linear_kernel(const UkfArgs a, const double *__restrict__ pF, const double *__restrict__ pH,
+                  const double *__restrict__ pQ, const double *__restrict__ pR,
+                  const double *__restrict__ pWm, const double *__restrict__ pWc,
+                  const double *__restrict__ pz, const uint8_t *__restrict__ pmask)
+{
+    constexpr int KS = 2 * NX + 1;
+    constexpr int PL = NX * (NX + 1) / 2;
+    using SharedModel = LdsModel<NX, NZ>;
+    __shared__ double s_model[SharedModel::SIZE + 2 * KS];
+    const long N = a.N;
+    const long blk0 = (long)blockIdx.x * BLOCK;
+    const Lane ln{blk0, threadIdx.x, N};
+    const bool live = blk0 + ln.tid < N;
+    const Lane lr{blk0, live ? ln.tid : 0u, N};
+    const int n = a.n, m = a.m;
+    const int ks = 2 * n + 1;
+
+    lds_fill<NX, NX>(s_model + SharedModel::OFF_F, pF, n, n, 1.0, ln.tid);
+    lds_fill<NX, NX>(s_model + SharedModel::OFF_Q, pQ, n, n, 1.0, ln.tid);   // padded block of P stays I
+    lds_fill<NZ, NX>(s_model + SharedModel::OFF_H, pH, m, n, 0.0, ln.tid);
+    lds_fill<NZ, NZ>(s_model + SharedModel::OFF_R, pR, m, m, 1.0, ln.tid);
+    // weights, re-indexed from the runtime point set (0, 1..n, n+1..2n) to the padded one
+    // (0, 1..NX, NX+1..2NX); padded points get weight 0
+    for (unsigned q = ln.tid; q < (unsigned)(2 * KS); q += BLOCK) {
+        const int which = q / KS, i = q % KS;
+        int src = -1;
+        if (i == 0) src = 0;
+        else if (i <= NX) { if (i <= n) src = i; }
+        else { if (i - NX <= n) src = n + (i - NX); }
+        const double *W = which ? pWc : pWm;
+        s_model[SharedModel::SIZE + q] = (src >= 0 && src < ks) ? W[src] : 0.0;
+    }
+    __syncthreads();
+    const SharedModel sm{s_model};
+    const double *sWm = s_model + SharedModel::SIZE, *sWc = sWm + KS;
+
+    double x[NX], P[PL];
+    load_rec<NX, 1, LAYOUT, false>(x, a.x, lr, n, 1, 0.0);
+    {
+        const RecView<LAYOUT> pv(a.P, lr, n * n);
+        FK_UNROLL for (int i = 0; i < NX; ++i)
+            FK_UNROLL for (int j = 0; j < NX; ++j)
+                if (j >= i) P[sym_idx<NX>(i, j)] = (i < n && j < n) ? pv.load(i * n + j) : (i == j ? 1.0 : 0.0);
+    }
+    int st = 0;
+
+    for (long t = 0; t < a.T; ++t) {
+        double z[NZ];
+        bool has_z = true;
+        if (pmask) has_z = pmask[t * N + lr.blk0 + lr.tid] != 0;
+        load_rec<NZ, 1, LAYOUT, false>(z, pz + t * N * m, lr, m, 1, 0.0);
+
+        // ---------------- predict (UKF.py:400-411)
+        double L[PL];
+        if (!chol_packed<NX>(P, a.scale, L)) st |= ST_NOT_PD;
+        // sweep 1: x- = sum_i Wm_i F sigma_i, one output component (row of F) at a time, points in
+        // index order 0, x + L[:,k] (k = 0..n-1), x - L[:,k]
+        double xm[NX];
+        FK_UNROLL for (int r = 0; r < NX; ++r) {
+            double f[NX];
+            sm.rowF(r, f);
+            double acc = sWm[0] * dot<NX>(f, x);
+            FK_UNROLL for (int k = 0; k < NX; ++k) {
+                double v = f[0] * (x[0] - (-lcol<NX>(L, 0, k)));
+                FK_UNROLL for (int c = 1; c < NX; ++c) v = fma(f[c], x[c] - (-lcol<NX>(L, c, k)), v);
+                acc = fma(sWm[1 + k], v, acc);
+            }
+            FK_UNROLL for (int k = 0; k < NX; ++k) {
+                double v = f[0] * (x[0] - lcol<NX>(L, 0, k));
+                FK_UNROLL for (int c = 1; c < NX; ++c) v = fma(f[c], x[c] - lcol<NX>(L, c, k), v);
+                acc = fma(sWm[1 + NX + k], v, acc);
+            }
+            xm[r] = acc;
+            FK_STAGE();
+        }
+        // sweep 2: P- = sum_i Wc_i y_i y_i' + Q, y_i = F sigma_i - x-   (upper triangle).
+        // The points are recomputed from copies the optimiser cannot relate to sweep 1 (otherwise it
+        // common-subexpression-eliminates the recomputation by keeping all (2n+1) n values alive).
+        double Pn[PL];
+        FK_UNROLL for (int c = 0; c < NX; ++c) asm volatile("" : "+v"(x[c]));
+        FK_UNROLL for (int e = 0; e < PL; ++e) asm volatile("" : "+v"(L[e]));
+        FK_UNROLL for (int i = 0; i < KS; ++i) {
+            double y[NX], wy[NX];
+            FK_UNROLL for (int r = 0; r < NX; ++r) {
+                double f[NX];
+                sm.rowF(r, f);
+                double v;
+                if (i == 0) {
+                    v = dot<NX>(f, x);
+                } else if (i <= NX) {
+                    v = f[0] * (x[0] - (-lcol<NX>(L, 0, i - 1)));
+                    FK_UNROLL for (int c = 1; c < NX; ++c) v = fma(f[c], x[c] - (-lcol<NX>(L, c, i - 1)), v);
+                } else {
+                    v = f[0] * (x[0] - lcol<NX>(L, 0, i - 1 - NX));
+                    FK_UNROLL for (int c = 1; c < NX; ++c) v = fma(f[c], x[c] - lcol<NX>(L, c, i - 1 - NX), v);
+                }
+                y[r] = v - xm[r];
+            }
+            FK_UNROLL for (int r = 0; r < NX; ++r) wy[r] = sWc[i] * y[r];
+            FK_UNROLL for (int a2 = 0; a2 < NX; ++a2)
+                FK_UNROLL for (int b = 0; b < NX; ++b)
+                    if (b >= a2)
+                        Pn[sym_idx<NX>(a2, b)] = (i == 0) ? y[a2] * wy[b] : fma(y[a2], wy[b], Pn[sym_idx<NX>(a2, b)]);
+            FK_STAGE();
+        }
+        FK_UNROLL for (int r = 0; r < NX; ++r) {
+            double q[NX];
+            sm.rowQ(r, q);
+            FK_UNROLL for (int b = 0; b < NX; ++b)
+                if (b >= r) P[sym_idx<NX>(r, b)] = Pn[sym_idx<NX>(r, b)] + q[b];
+            x[r] = xm[r];
+        }
+
+        // ---------------- update (UKF.py:462-481), sigma points regenerated from the prior (:407)
+        if (has_z) {
+            if (!chol_packed<NX>(P, a.scale, L)) st |= ST_NOT_PD;
+            double h0[NZ], hp[NZ * NX], hm[NZ * NX];
+            FK_UNROLL for (int r = 0; r < NZ; ++r) {
+                double h[NX];
+                sm.rowH(r, h);
+                h0[r] = dot<NX>(h, x);
+                FK_UNROLL for (int k = 0; k < NX; ++k) {
+                    double vp = h[0] * (x[0] - (-lcol<NX>(L, 0, k))), vm = h[0] * (x[0] - lcol<NX>(L, 0, k));
+                    FK_UNROLL for (int c = 1; c < NX; ++c) {
+                        vp = fma(h[c], x[c] - (-lcol<NX>(L, c, k)), vp);
+                        vm = fma(h[c], x[c] - lcol<NX>(L, c, k), vm);
+                    }
+                    hp[r * NX + k] = vp;
+                    hm[r * NX + k] = vm;
+                }
+                FK_STAGE();
+            }
+            double zp[NZ];
+            FK_UNROLL for (int r = 0; r < NZ; ++r) {
+                double acc = sWm[0] * h0[r];
+                FK_UNROLL for (int k = 0; k < NX; ++k) acc = fma(sWm[1 + k], hp[r * NX + k], acc);
+                FK_UNROLL for (int k = 0; k < NX; ++k) acc = fma(sWm[1 + NX + k], hm[r * NX + k], acc);
+                zp[r] = acc;
+            }
+            FK_UNROLL for (int r = 0; r < NZ; ++r) {
+                h0[r] -= zp[r];
+                FK_UNROLL for (int k = 0; k < NX; ++k) {
+                    hp[r * NX + k] -= zp[r];
+                    hm[r * NX + k] -= zp[r];
+                }
+            }
+            double S[NZ * NZ];
+            FK_UNROLL for (int r = 0; r < NZ; ++r) {
+                double rr[NZ];
+                sm.rowR(r, rr);
+                FK_UNROLL for (int c = 0; c < NZ; ++c) {
+                    double acc = h0[r] * (sWc[0] * h0[c]);
+                    FK_UNROLL for (int k = 0; k < NX; ++k) acc = fma(hp[r * NX + k], sWc[1 + k] * hp[c * NX + k], acc);
+                    FK_UNROLL for (int k = 0; k < NX; ++k) acc = fma(hm[r * NX + k], sWc[1 + NX + k] * hm[c * NX + k], acc);
+                    S[r * NZ + c] = acc + rr[c];
+                }
+            }
+            // Pxz = sum Wc_i (sf_i - x)(sh_i - zp)' ; sf_0 - x = 0, sf_{k+1} - x = (x + l_k) - x
+            double K[NX * NZ];
+            FK_UNROLL for (int r = 0; r < NX; ++r) {
+                FK_UNROLL for (int c = 0; c < NZ; ++c) {
+                    double acc = sWc[0] * (((x[r]) - x[r]) * h0[c]);
+                    FK_UNROLL for (int k = 0; k < NX; ++k) {
+                        const double dp = (x[r] - (-lcol<NX>(L, r, k))) - x[r];
+                        acc += sWc[1 + k] * (dp * hp[c * NX + k]);
+                    }
+                    FK_UNROLL for (int k = 0; k < NX; ++k) {
+                        const double dm = (x[r] - lcol<NX>(L, r, k)) - x[r];
+                        acc += sWc[1 + NX + k] * (dm * hm[c * NX + k]);
+                    }
+                    K[r * NZ + c] = acc;
+                }
+                FK_STAGE();
+            }
+            // K = Pxz S^-1
+            double Lf[NZ * NZ], d[NZ], dinv[NZ];
+            FK_UNROLL for (int e = 0; e < NZ * NZ; ++e) Lf[e] = S[e];
+            if (!ldlt2<NZ>(Lf, d, dinv)) st |= ST_NOT_PD;
+            solve_rows_ldlt<NX, NZ>(Lf, dinv, K);
+            // x += K (z - zp)
+            FK_UNROLL for (int r = 0; r < NX; ++r) {
+                double acc = K[r * NZ] * (z[0] - zp[0]);
+                FK_UNROLL for (int c = 1; c < NZ; ++c) acc = fma(K[r * NZ + c], z[c] - zp[c], acc);
+                x[r] += acc;
+            }
+            // P -= K (S K'), upper triangle
+            FK_UNROLL for (int c2 = 0; c2 < NX; ++c2) {
+                double sk[NZ];                 // column c2 of S K'
+                FK_UNROLL for (int q = 0; q < NZ; ++q) {
+                    double acc = S[q * NZ] * K[c2 * NZ];
+                    FK_UNROLL for (int w = 1; w < NZ; ++w) acc = fma(S[q * NZ + w], K[c2 * NZ + w], acc);
+                    sk[q] = acc;
+                }
+                FK_UNROLL for (int r = 0; r < NX; ++r)
+                    if (r <= c2) {
+                        double acc = K[r * NZ] * sk[0];
+                        FK_UNROLL for (int q = 1; q < NZ; ++q) acc = fma(K[r * NZ + q], sk[q], acc);
+                        P[sym_idx<NX>(r, c2)] -= acc;
+                    }
+            }
+        }
+        if (live) {
+            if (a.means) store_rec<NX, 1, LAYOUT, false>(x, a.means + t * N * n, ln, n, 1);
+            if (a.covs) {
+                double Pf[NX * NX];
+                FK_UNROLL for (int i = 0; i < NX; ++i)
+                    FK_UNROLL for (int j = 0; j < NX; ++j) Pf[i * NX + j] = P[sym_idx<NX>(i, j)];
+                store_rec<NX, NX, LAYOUT, false>(Pf, a.covs + t * N * n * n, ln, n, n);
+            }
+        }
+    }
+    if (live) {
+        store_rec<NX, 1, LAYOUT, false>(x, a.x, ln, n, 1);
+        double Pf[NX * NX];
+        FK_UNROLL for (int i = 0; i < NX; ++i)
+            FK_UNROLL for (int j = 0; j < NX; ++j) Pf[i * NX + j] = P[sym_idx<NX>(i, j)];
+        store_rec<NX, NX, LAYOUT, false>(Pf, a.P, ln, n, n);
+        if (a.status) {
+            if (!all_finite<NX>(x) || !all_finite<PL>(P)) st |= ST_NONFINITE;
+            a.status[ln.blk0 + ln.tid] = st;
+        }
+    }
+}
+
+static int fail(int code, const char *msg)
+{
+    set_last_error(msg);
+    return code;
+}
+
+}  // namespace fk
+
+using namespace fk;
+
+extern "C" {
+
+int fk_ukf_linear_batch_f64(const fk_ukf_desc *d, const double *F, const double *H, const double *Q,
+                            const double *R, const double *Wm, const double *Wc, const double *z,
+                            const uint8_t *mask, double *x, double *P, double *means, double *covs,
+                            int32_t *status, void *stream)
+{
+    if (!d) return fail(FK_ERR_BAD_ARG, "desc is NULL");
+    if (d->n < 1 || d->n > 6 || d->m < 1 || d->m > 3) return fail(FK_ERR_UNSUPPORTED, "fused linear UKF: dim_x 1..6, dim_z 1..3");
+    if (d->N < 0 || d->T < 0 || !F || !H || !Q || !R || !Wm || !Wc || !z || !x || !P)
+        return fail(FK_ERR_BAD_ARG, "fused linear UKF: bad argument");
+    if ((double)d->N * d->n * d->n * 8.0 >= 4294967296.0) return fail(FK_ERR_UNSUPPORTED, "fused linear UKF: record block >= 4 GiB, split the batch");
+    if (d->N == 0 || d->T == 0) return FK_OK;
+    UkfArgs a{};
+    a.F = F; a.H = H; a.Q = Q; a.R = R; a.Wm = Wm; a.Wc = Wc; a.z = z; a.mask = mask;
+    a.x = x; a.P = P; a.means = means; a.covs = covs; a.status = status;
+    a.N = d->N; a.T = d->T; a.n = d->n; a.m = d->m; a.scale = d->scale;
+    const dim3 grid((unsigned)((a.N + BLOCK - 1) / BLOCK)), block(BLOCK);
+    hipStream_t s = (hipStream_t)stream;
+#define GO(NXV, NZV)                                                                                    \
+    if (d->layout == FK_LAYOUT_SOA)                                                                     \
+        hipLaunchKernelGGL((ukf_linear_kernel<NXV, NZV, LAYOUT_SOA>), grid, block, 0, s, a, F, H, Q, R, \
+                           Wm, Wc, z, mask);                                                            \
+    else                                                                                                \
+        hipLaunchKernelGGL((ukf_linear_kernel<NXV, NZV, LAYOUT_AOS>), grid, block, 0, s, a, F, H, Q, R, \
+                           Wm, Wc, z, mask)
+    if (d->n <= 2 && d->m <= 2) { GO(2, 2); }
+    else if (d->n <= 4 && d->m <= 2) { GO(4, 2); }
+    else { GO(6, 3); }
+#undef GO
+    return check_launch("ukf_linear_kernel");
+}
+
+}  // extern "C"

@@ -6,14 +6,13 @@
 //                               JulierSigmaPoints.sigma_points      (sigma_points.py:289-357)
 //   fk_ut_transform_f64      <- unscented_transform (unscented_transform.py:99-128)
 //   fk_ut_cross_variance_f64 <- UnscentedKalmanFilter.cross_variance (UKF.py:493-504)
-// and the fused linear-model filter keeps the whole predict/update of UKF.py:364-481 in
-// registers over the time loop:
-//   fk_ukf_linear_batch_f64  <- UnscentedKalmanFilter.batch_filter (UKF.py:524-632), fx = F x, hx = H x.
+// (the fused linear-model filter lives in ukf_kernels.hip)
 // Algorithmic bytes: sigma points 8(n + n^2 + (2n+1)n), UT 8((2n+1)n + n + n^2) per track;
 // fused step 8(m + n + n^2) per track-step.
 #include "../../include/filterhip.h"
 #include "fk_device.hpp"
 #include "fk_kernel_args.hpp"
+#include "fk_math_sym.hpp"
 
 namespace fk {
 
@@ -210,222 +209,6 @@ ukf_correct_kernel(int n, int m, long N, const double *__restrict__ pPxz, const 
     }
 }
 
-// --------------------------------------------------- fused linear-model UKF --
-// Per step (UKF.py:400-411, 462-481) with fx(x) = F x, hx(x) = H x:
-//   L  = chol(scale P);  sigma_i = x, x +- L[:,k]          (sigma_points.py:167-175)
-//   sf_i = F sigma_i ;  (x,P) = UT(sf, Wm, Wc, Q)
-//   L  = chol(scale P);  sf_i = sigma_i(x,P)  (regenerated, UKF.py:407)
-//   sh_i = H sf_i ; (zp,S) = UT(sh, Wm, Wc, R) ; Pxz = sum Wc_i (sf_i-x)(sh_i-zp)'
-//   K = Pxz S^-1 ; x += K (z-zp) ; P -= K (S K')
-template <int NX, int NZ, int LAYOUT>
-__global__ void __launch_bounds__(BLOCK, (NX <= 4 ? 2 : 1))
-ukf_linear_kernel(const UkfArgs a, const double *__restrict__ pF, const double *__restrict__ pH,
-                  const double *__restrict__ pQ, const double *__restrict__ pR,
-                  const double *__restrict__ pWm, const double *__restrict__ pWc,
-                  const double *__restrict__ pz, const uint8_t *__restrict__ pmask)
-{
-    constexpr int KS = 2 * NX + 1;
-    using SharedModel = LdsModel<NX, NZ>;
-    __shared__ double s_model[SharedModel::SIZE + 2 * KS];
-    const long N = a.N;
-    const long blk0 = (long)blockIdx.x * BLOCK;
-    const Lane ln{blk0, threadIdx.x, N};
-    const bool live = blk0 + ln.tid < N;
-    const Lane lr{blk0, live ? ln.tid : 0u, N};
-    const int n = a.n, m = a.m;
-    const int ks = 2 * n + 1;
-
-    lds_fill<NX, NX>(s_model + SharedModel::OFF_F, pF, n, n, 1.0, ln.tid);
-    lds_fill<NX, NX>(s_model + SharedModel::OFF_Q, pQ, n, n, 1.0, ln.tid);   // padded block of P stays I
-    lds_fill<NZ, NX>(s_model + SharedModel::OFF_H, pH, m, n, 0.0, ln.tid);
-    lds_fill<NZ, NZ>(s_model + SharedModel::OFF_R, pR, m, m, 1.0, ln.tid);
-    // weights, re-indexed from the runtime point set (0, 1..n, n+1..2n) to the padded one
-    // (0, 1..NX, NX+1..2NX); padded points get weight 0
-    for (unsigned q = ln.tid; q < (unsigned)(2 * KS); q += BLOCK) {
-        const int which = q / KS, i = q % KS;
-        int src = -1;
-        if (i == 0) src = 0;
-        else if (i <= NX) { if (i <= n) src = i; }
-        else { if (i - NX <= n) src = n + (i - NX); }
-        const double *W = which ? pWc : pWm;
-        s_model[SharedModel::SIZE + q] = (src >= 0 && src < ks) ? W[src] : 0.0;
-    }
-    __syncthreads();
-    const SharedModel sm{s_model};
-    const double *sWm = s_model + SharedModel::SIZE, *sWc = sWm + KS;
-
-    double x[NX], P[NX * NX];
-    load_rec<NX, 1, LAYOUT, false>(x, a.x, lr, n, 1, 0.0);
-    load_rec<NX, NX, LAYOUT, false>(P, a.P, lr, n, n, 1.0);
-    int st = 0;
-
-    for (long t = 0; t < a.T; ++t) {
-        double z[NZ];
-        bool has_z = true;
-        if (pmask) has_z = pmask[t * N + lr.blk0 + lr.tid] != 0;
-        load_rec<NZ, 1, LAYOUT, false>(z, pz + t * N * m, lr, m, 1, 0.0);
-
-        // ---- predict
-        double L[NX * NX];
-        if (!chol_lower<NX>(P, a.scale, L)) st |= ST_NOT_PD;
-        // sf_i = F sigma_i: F x and F L[:,k]
-        double Fx[NX], FL[NX * NX];   // FL[r][k] = sum_c F[r][c] L[c][k]
-        FK_UNROLL for (int r = 0; r < NX; ++r) {
-            double f[NX];
-            sm.rowF(r, f);
-            Fx[r] = dot<NX>(f, x);
-            FK_UNROLL for (int k = 0; k < NX; ++k) {
-                // propagate the actual points (x + L[:,k]) like the reference does: F (x + l) is
-                // not bitwise F x + F l, so form the point first
-                double accp = 0.0, accm = 0.0;
-                FK_UNROLL for (int c = 0; c < NX; ++c) {
-                    const double sp = x[c] - (-L[c * NX + k]), smn = x[c] - L[c * NX + k];
-                    accp = (c == 0) ? f[0] * sp : fma(f[c], sp, accp);
-                    accm = (c == 0) ? f[0] * smn : fma(f[c], smn, accm);
-                }
-                FL[r * NX + k] = accp;       // component r of F sigma_{k+1}
-                P[r * NX + k] = accm;        // reuse P as scratch: component r of F sigma_{NX+k+1}
-            }
-            FK_STAGE();
-        }
-        // mean: x = sum Wm_i sf_i (index order 0, 1..NX, NX+1..2NX)
-        double xm[NX];
-        FK_UNROLL for (int r = 0; r < NX; ++r) {
-            double acc = sWm[0] * Fx[r];
-            FK_UNROLL for (int k = 0; k < NX; ++k) acc = fma(sWm[1 + k], FL[r * NX + k], acc);
-            FK_UNROLL for (int k = 0; k < NX; ++k) acc = fma(sWm[1 + NX + k], P[r * NX + k], acc);
-            xm[r] = acc;
-        }
-        // covariance: Pn = sum Wc_i y_i y_i' + Q
-        double Pn[NX * NX];
-        {
-            double y0[NX];
-            FK_UNROLL for (int r = 0; r < NX; ++r) y0[r] = Fx[r] - xm[r];
-            FK_UNROLL for (int r = 0; r < NX; ++r) {
-                FK_UNROLL for (int k = 0; k < NX; ++k) {
-                    FL[r * NX + k] -= xm[r];
-                    P[r * NX + k] -= xm[r];
-                }
-            }
-            FK_UNROLL for (int a2 = 0; a2 < NX; ++a2) {
-                double q[NX];
-                sm.rowQ(a2, q);
-                FK_UNROLL for (int b = 0; b < NX; ++b) {
-                    double acc = y0[a2] * (sWc[0] * y0[b]);
-                    FK_UNROLL for (int k = 0; k < NX; ++k) acc = fma(FL[a2 * NX + k], sWc[1 + k] * FL[b * NX + k], acc);
-                    FK_UNROLL for (int k = 0; k < NX; ++k) acc = fma(P[a2 * NX + k], sWc[1 + NX + k] * P[b * NX + k], acc);
-                    Pn[a2 * NX + b] = acc + q[b];
-                }
-                FK_STAGE();
-            }
-        }
-        FK_UNROLL for (int r = 0; r < NX; ++r) x[r] = xm[r];
-        FK_UNROLL for (int e = 0; e < NX * NX; ++e) P[e] = Pn[e];
-
-        // ---- update
-        if (has_z) {
-            if (!chol_lower<NX>(P, a.scale, L)) st |= ST_NOT_PD;
-            // sh_i = H sf_i with sf_i regenerated from the prior
-            double h0[NZ], hp[NZ * NX], hm[NZ * NX];
-            FK_UNROLL for (int r = 0; r < NZ; ++r) {
-                double h[NX];
-                sm.rowH(r, h);
-                h0[r] = dot<NX>(h, x);
-                FK_UNROLL for (int k = 0; k < NX; ++k) {
-                    double accp = 0.0, accm = 0.0;
-                    FK_UNROLL for (int c = 0; c < NX; ++c) {
-                        const double sp = x[c] - (-L[c * NX + k]), smn = x[c] - L[c * NX + k];
-                        accp = (c == 0) ? h[0] * sp : fma(h[c], sp, accp);
-                        accm = (c == 0) ? h[0] * smn : fma(h[c], smn, accm);
-                    }
-                    hp[r * NX + k] = accp;
-                    hm[r * NX + k] = accm;
-                }
-                FK_STAGE();
-            }
-            double zp[NZ];
-            FK_UNROLL for (int r = 0; r < NZ; ++r) {
-                double acc = sWm[0] * h0[r];
-                FK_UNROLL for (int k = 0; k < NX; ++k) acc = fma(sWm[1 + k], hp[r * NX + k], acc);
-                FK_UNROLL for (int k = 0; k < NX; ++k) acc = fma(sWm[1 + NX + k], hm[r * NX + k], acc);
-                zp[r] = acc;
-            }
-            FK_UNROLL for (int r = 0; r < NZ; ++r) {
-                h0[r] -= zp[r];
-                FK_UNROLL for (int k = 0; k < NX; ++k) {
-                    hp[r * NX + k] -= zp[r];
-                    hm[r * NX + k] -= zp[r];
-                }
-            }
-            double S[NZ * NZ];
-            FK_UNROLL for (int r = 0; r < NZ; ++r) {
-                double rr[NZ];
-                sm.rowR(r, rr);
-                FK_UNROLL for (int c = 0; c < NZ; ++c) {
-                    double acc = h0[r] * (sWc[0] * h0[c]);
-                    FK_UNROLL for (int k = 0; k < NX; ++k) acc = fma(hp[r * NX + k], sWc[1 + k] * hp[c * NX + k], acc);
-                    FK_UNROLL for (int k = 0; k < NX; ++k) acc = fma(hm[r * NX + k], sWc[1 + NX + k] * hm[c * NX + k], acc);
-                    S[r * NZ + c] = acc + rr[c];
-                }
-            }
-            // Pxz = sum Wc_i (sf_i - x)(sh_i - zp)' ; sf_0 - x = 0, sf_{k+1} - x = (x + l_k) - x
-            double K[NX * NZ];
-            FK_UNROLL for (int r = 0; r < NX; ++r) {
-                FK_UNROLL for (int c = 0; c < NZ; ++c) {
-                    double acc = sWc[0] * (((x[r]) - x[r]) * h0[c]);
-                    FK_UNROLL for (int k = 0; k < NX; ++k) {
-                        const double dp = (x[r] - (-L[r * NX + k])) - x[r];
-                        acc += sWc[1 + k] * (dp * hp[c * NX + k]);
-                    }
-                    FK_UNROLL for (int k = 0; k < NX; ++k) {
-                        const double dm = (x[r] - L[r * NX + k]) - x[r];
-                        acc += sWc[1 + NX + k] * (dm * hm[c * NX + k]);
-                    }
-                    K[r * NZ + c] = acc;
-                }
-                FK_STAGE();
-            }
-            // K = Pxz S^-1
-            double Lf[NZ * NZ], d[NZ], dinv[NZ];
-            FK_UNROLL for (int e = 0; e < NZ * NZ; ++e) Lf[e] = S[e];
-            if (!ldlt2<NZ>(Lf, d, dinv)) st |= ST_NOT_PD;
-            solve_rows_ldlt<NX, NZ>(Lf, dinv, K);
-            // x += K (z - zp)
-            FK_UNROLL for (int r = 0; r < NX; ++r) {
-                double acc = 0.0;
-                FK_UNROLL for (int c = 0; c < NZ; ++c) acc = (c == 0) ? K[r * NZ] * (z[0] - zp[0]) : fma(K[r * NZ + c], z[c] - zp[c], acc);
-                x[r] += acc;
-            }
-            // P -= K (S K')
-            double SK[NZ * NX];
-            FK_UNROLL for (int c = 0; c < NZ; ++c)
-                FK_UNROLL for (int r = 0; r < NX; ++r) {
-                    double acc = S[c * NZ] * K[r * NZ];
-                    FK_UNROLL for (int q = 1; q < NZ; ++q) acc = fma(S[c * NZ + q], K[r * NZ + q], acc);
-                    SK[c * NX + r] = acc;
-                }
-            FK_UNROLL for (int r = 0; r < NX; ++r)
-                FK_UNROLL for (int c = 0; c < NX; ++c) {
-                    double acc = K[r * NZ] * SK[c];
-                    FK_UNROLL for (int q = 1; q < NZ; ++q) acc = fma(K[r * NZ + q], SK[q * NX + c], acc);
-                    P[r * NX + c] -= acc;
-                }
-        }
-        if (live) {
-            if (a.means) store_rec<NX, 1, LAYOUT, false>(x, a.means + t * N * n, ln, n, 1);
-            if (a.covs) store_rec<NX, NX, LAYOUT, false>(P, a.covs + t * N * n * n, ln, n, n);
-        }
-    }
-    if (live) {
-        store_rec<NX, 1, LAYOUT, false>(x, a.x, ln, n, 1);
-        store_rec<NX, NX, LAYOUT, false>(P, a.P, ln, n, n);
-        if (a.status) {
-            if (!all_finite<NX>(x) || !all_finite<NX * NX>(P)) st |= ST_NONFINITE;
-            a.status[ln.blk0 + ln.tid] = st;
-        }
-    }
-}
-
 static int fail(int code, const char *msg)
 {
     set_last_error(msg);
@@ -548,38 +331,6 @@ int fk_ukf_correct_f64(int32_t n, int32_t m, int64_t N, int32_t layout, const do
 #undef CALL
 #undef GOZ
     return check_launch("ukf_correct_kernel");
-}
-
-int fk_ukf_linear_batch_f64(const fk_ukf_desc *d, const double *F, const double *H, const double *Q,
-                            const double *R, const double *Wm, const double *Wc, const double *z,
-                            const uint8_t *mask, double *x, double *P, double *means, double *covs,
-                            int32_t *status, void *stream)
-{
-    if (!d) return fail(FK_ERR_BAD_ARG, "desc is NULL");
-    if (d->n < 1 || d->n > 8 || d->m < 1 || d->m > 4) return fail(FK_ERR_UNSUPPORTED, "fused linear UKF: dim_x 1..8, dim_z 1..4");
-    if (d->N < 0 || d->T < 0 || !F || !H || !Q || !R || !Wm || !Wc || !z || !x || !P)
-        return fail(FK_ERR_BAD_ARG, "fused linear UKF: bad argument");
-    if ((double)d->N * d->n * d->n * 8.0 >= 4294967296.0) return fail(FK_ERR_UNSUPPORTED, "fused linear UKF: record block >= 4 GiB, split the batch");
-    if (d->N == 0 || d->T == 0) return FK_OK;
-    UkfArgs a{};
-    a.F = F; a.H = H; a.Q = Q; a.R = R; a.Wm = Wm; a.Wc = Wc; a.z = z; a.mask = mask;
-    a.x = x; a.P = P; a.means = means; a.covs = covs; a.status = status;
-    a.N = d->N; a.T = d->T; a.n = d->n; a.m = d->m; a.scale = d->scale;
-    const dim3 grid((unsigned)((a.N + BLOCK - 1) / BLOCK)), block(BLOCK);
-    hipStream_t s = (hipStream_t)stream;
-#define GO(NXV, NZV)                                                                                    \
-    if (d->layout == FK_LAYOUT_SOA)                                                                     \
-        hipLaunchKernelGGL((ukf_linear_kernel<NXV, NZV, LAYOUT_SOA>), grid, block, 0, s, a, F, H, Q, R, \
-                           Wm, Wc, z, mask);                                                            \
-    else                                                                                                \
-        hipLaunchKernelGGL((ukf_linear_kernel<NXV, NZV, LAYOUT_AOS>), grid, block, 0, s, a, F, H, Q, R, \
-                           Wm, Wc, z, mask)
-    if (d->n <= 2 && d->m <= 2) { GO(2, 2); }
-    else if (d->n <= 4 && d->m <= 2) { GO(4, 2); }
-    else if (d->n <= 6 && d->m <= 3) { GO(6, 3); }
-    else { GO(8, 4); }
-#undef GO
-    return check_launch("ukf_linear_kernel");
 }
 
 }  // extern "C"

@@ -176,7 +176,7 @@ int fk_ukf_correct_f64(int32_t n, int32_t m, int64_t N, int32_t layout,
                        double *x, double *P, double *K, int32_t *status, void *stream);
 
 typedef struct fk_ukf_desc {
-    int32_t n, m;         /* dim_x (1..8), dim_z (1..4) */
+    int32_t n, m;         /* dim_x (1..6), dim_z (1..3) */
     int64_t N, T;
     int32_t layout;
     int32_t reserved;
