@@ -153,16 +153,6 @@ def rts_smoother(Xs, Ps, F, Q, convention="class", inv=np.linalg.inv):
 # helpers looping the single-filter oracle over a batch of tracks
 # --------------------------------------------------------------------------
 
-def _track_model(M, i):
-    """shared (a,b) | per-track (N,a,b) | per-step (T,a,b) | per-track-per-step (T,N,a,b)"""
-    M = np.asarray(M)
-    if M.ndim == 2:
-        return M
-    if M.ndim == 4:
-        return M[:, i]
-    raise ValueError("ambiguous 3-D model; pass mode explicitly")
-
-
 def kf_batch_filter_tracks(x0, P0, zs, F, Q, H, R, tracks, model_mode=0, B=None, us=None,
                            alpha_sq=1.0, update_first=False, mask=None):
     """Run kf_batch_filter for each track index in ``tracks``.

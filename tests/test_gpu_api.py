@@ -200,3 +200,35 @@ def test_unscented_transform_and_sigma_points_api():
         pts.sigma_points(np.zeros(5), np.eye(5))
     with pytest.raises(np.linalg.LinAlgError):
         pts.sigma_points(np.zeros(6), -np.eye(6))
+
+
+def test_bank_per_track_models_and_device_outputs():
+    """KalmanFilterBank with one F/Q/H/R per track (the north star's 'coalesced loads of F/H/Q/R')
+    against the oracle, and the device_outputs path (no PCIe copy of the histories)."""
+    import torch
+    from filterpy_amd.kalman import KalmanFilterBank
+    from oracle import kf_oracle
+    rs = np.random.RandomState(9)
+    n, m, N, T = 4, 2, 600, 20
+
+    def spd(k, s):
+        A = rs.randn(N, k, k)
+        return s * (A @ A.transpose(0, 2, 1) / k + 0.5 * np.eye(k))
+    F = np.eye(n) + 0.1 * rs.randn(N, n, n)
+    Q, H, R = spd(n, 0.1), rs.randn(N, m, n), spd(m, 0.5)
+    x0, P0, zs = rs.randn(N, n), spd(n, 3.0), rs.randn(T, N, m)
+    for layout in ("soa", "aos"):
+        bank = KalmanFilterBank(n, m, N, layout=layout)
+        bank.x, bank.P, bank.F, bank.Q, bank.H, bank.R = x0.copy(), P0.copy(), F, Q, H, R
+        mu, cov, mup, covp = bank.batch_filter(zs)
+        sample = [0, 255, 256, N - 1]
+        ref = kf_oracle.kf_batch_filter_tracks(x0, P0, zs, F, Q, H, R, tracks=sample, model_mode=1)
+        for got, r in zip((mu, cov, mup, covp), ref):
+            assert rel_err_rows(got[:, sample].reshape((-1,) + got.shape[2:]), r.reshape((-1,) + r.shape[2:])) < TOL
+        bank.x, bank.P = x0.copy(), P0.copy()
+        outs = bank.batch_filter(zs, device_outputs=True)
+        assert all(isinstance(o, torch.Tensor) and o.is_cuda for o in outs)
+        want = (T, N, n * n) if layout == "aos" else (T, n * n, N)
+        assert tuple(outs[1].shape) == want
+        got = outs[1].cpu().numpy() if layout == "aos" else outs[1].cpu().numpy().transpose(0, 2, 1)
+        assert rel_err_rows(got[:, 0], cov[:, 0].reshape(T, -1)) < 1e-15
