@@ -119,9 +119,17 @@ __device__ double tile_cumsum_exact(ScanShared &sh, int len, double carry, bool 
             __syncthreads();
             if (tid == 0) {
                 double c = carry;
-                for (int j = pos; j < stop; ++j) {
-                    c = c + sh.w[j];
-                    sh.w[j] = c;
+                // blocks of 16: the LDS reads of a block are independent (issued back to back), only the
+                // adds are a dependent chain; padding with +0.0 leaves the sum unchanged
+                for (int j = pos; j < stop; j += 16) {
+                    double v[16];
+                    FK_UNROLL for (int k = 0; k < 16; ++k) v[k] = (j + k < stop) ? sh.w[j + k] : 0.0;
+                    FK_UNROLL for (int k = 0; k < 16; ++k) {
+                        c = c + v[k];
+                        v[k] = c;
+                    }
+                    FK_UNROLL for (int k = 0; k < 16; ++k)
+                        if (j + k < stop) sh.w[j + k] = v[k];
                 }
                 sh.carry = c;
             }
