@@ -28,6 +28,10 @@ class fk_kf_desc(ctypes.Structure):
                 ("alpha_sq", c_f64)]
 
 
+class fk_kf_extras(ctypes.Structure):
+    _fields_ = [("y", c_vp), ("K", c_vp), ("S", c_vp), ("SI", c_vp), ("log_likelihood", c_vp), ("mahalanobis", c_vp)]
+
+
 class fk_ukf_desc(ctypes.Structure):
     _fields_ = [("n", c_i32), ("m", c_i32), ("N", c_i64), ("T", c_i64), ("layout", c_i32),
                 ("reserved", c_i32), ("scale", c_f64)]
@@ -40,6 +44,8 @@ class FilterHipError(RuntimeError):
 # every symbol include/filterhip.h declares, with its signature
 SIGNATURES = {
     "fk_kf_batch_filter_f64": (ctypes.c_int, [ctypes.POINTER(fk_kf_desc)] + [c_vp] * 16),
+    "fk_kf_batch_filter_ex_f64": (ctypes.c_int, [ctypes.POINTER(fk_kf_desc)] + [c_vp] * 14 +
+                                  [ctypes.POINTER(fk_kf_extras), c_vp, c_vp]),
     "fk_kf_predict_f64": (ctypes.c_int, [ctypes.POINTER(fk_kf_desc)] + [c_vp] * 8),
     "fk_kf_update_f64": (ctypes.c_int, [ctypes.POINTER(fk_kf_desc)] + [c_vp] * 12),
     "fk_kf_rts_f64": (ctypes.c_int, [ctypes.POINTER(fk_kf_desc)] + [c_vp] * 8 + [c_i32, c_vp, c_vp]),

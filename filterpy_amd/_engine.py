@@ -10,7 +10,7 @@ import torch
 
 from . import _abi
 from ._abi import (FK_LAYOUT_AOS, FK_LAYOUT_SOA, FK_MODEL_SHARED, FK_MODEL_PER_TRACK,
-                   FK_MODEL_PER_TRACK_STEP, FK_MODEL_PER_STEP, fk_kf_desc, fk_ukf_desc)
+                   FK_MODEL_PER_TRACK_STEP, FK_MODEL_PER_STEP, fk_kf_desc, fk_ukf_desc)  # noqa: F401
 
 LAYOUTS = {"aos": FK_LAYOUT_AOS, "soa": FK_LAYOUT_SOA}
 
@@ -93,6 +93,17 @@ def kf_batch_filter(desc_kw, F, Q, H, R, z, x, P, *, B=None, u=None, mask=None,
                                            _ptr(z), _ptr(mask), _ptr(x), _ptr(P), _ptr(means), _ptr(covs),
                                            _ptr(means_p), _ptr(covs_p), _ptr(status), _stream())
     _abi.check(rc, "fk_kf_batch_filter_f64")
+
+
+def kf_batch_filter_ex(desc_kw, F, Q, H, R, z, x, P, extras, *, B=None, u=None, mask=None,
+                       means=None, covs=None, means_p=None, covs_p=None, status=None):
+    """fk_kf_batch_filter_ex_f64: `extras` maps y/K/S/SI/log_likelihood/mahalanobis -> device tensor."""
+    d = fk_kf_desc(**desc_kw)
+    ex = _abi.fk_kf_extras(**{k: _ptr(extras.get(k)) for k in ("y", "K", "S", "SI", "log_likelihood", "mahalanobis")})
+    rc = _abi.lib().fk_kf_batch_filter_ex_f64(d, _ptr(F), _ptr(Q), _ptr(H), _ptr(R), _ptr(B), _ptr(u), _ptr(z),
+                                              _ptr(mask), _ptr(x), _ptr(P), _ptr(means), _ptr(covs), _ptr(means_p),
+                                              _ptr(covs_p), ex, _ptr(status), _stream())
+    _abi.check(rc, "fk_kf_batch_filter_ex_f64")
 
 
 def kf_predict(desc_kw, F, Q, x, P, *, B=None, u=None, status=None):

@@ -8,7 +8,9 @@ struct KfArgs {
     const double *F, *Q, *H, *R, *B, *u, *z;
     const uint8_t *mask;
     double *x, *P, *means, *covs, *means_p, *covs_p;
-    double *y_out, *K_out, *S_out, *SI_out;   // single-step update() extras (T == 1)
+    double *y_out, *K_out, *S_out, *SI_out;   // update() extras: one record (T == 1) or one per step
+    double *ll_out, *maha_out;                // per-step log-likelihood / mahalanobis [T][N]
+    int extras_per_step;                      // 1: the extras are [T][N][..] histories (batch_filter_ex)
     int32_t *status;
     long N, T;
     long i0, cnt;       // this launch handles tracks [i0, i0+cnt); N stays the array stride

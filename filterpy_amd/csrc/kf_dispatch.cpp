@@ -144,7 +144,8 @@ static int run_kf(const fk_kf_desc *d, KfArgs &a, void *stream)
     const bool all_out = a.means && a.covs && a.means_p && a.covs_p;
     const bool no_out = !a.means && !a.covs && !a.means_p && !a.covs_p;
     if (d->nu == 0 && !d->update_first && a.do_predict && a.do_update &&
-        (all_out || no_out) && !a.y_out && !a.K_out && !a.S_out && !a.SI_out && !getenv("FK_NO_FAST")) {
+        (all_out || no_out) && !a.y_out && !a.K_out && !a.S_out && !a.SI_out && !a.ll_out && !a.maha_out &&
+        !getenv("FK_NO_FAST")) {
         if (const FastEntry *f = pick_fast(d->n, d->m)) {
             const char *ev = getenv("FK_FAST_XCD");
             a.xcd_swizzle = ev ? atoi(ev) : 0;
@@ -176,6 +177,30 @@ int fk_kf_batch_filter_f64(const fk_kf_desc *desc, const double *F, const double
     a.T = desc->T;
     a.do_predict = 1;
     a.do_update = 1;
+    return run_kf(desc, a, stream);
+}
+
+int fk_kf_batch_filter_ex_f64(const fk_kf_desc *desc, const double *F, const double *Q, const double *H,
+                              const double *R, const double *B, const double *u, const double *z,
+                              const uint8_t *mask, double *x, double *P, double *means, double *covs,
+                              double *means_p, double *covs_p, const fk_kf_extras *ex, int32_t *status,
+                              void *stream)
+{
+    if (int rc = check_desc(desc)) return rc;
+    if (!F || !Q || !H || !R || !z || !x || !P) return fail(FK_ERR_BAD_ARG, "F,Q,H,R,z,x,P must not be NULL");
+    if (desc->nu > 0 && (!B || !u)) return fail(FK_ERR_BAD_ARG, "dim_u > 0 needs B and u");
+    KfArgs a{};
+    a.F = F; a.Q = Q; a.H = H; a.R = R; a.B = B; a.u = u; a.z = z; a.mask = mask;
+    a.x = x; a.P = P; a.means = means; a.covs = covs; a.means_p = means_p; a.covs_p = covs_p;
+    a.status = status;
+    a.T = desc->T;
+    a.do_predict = 1;
+    a.do_update = 1;
+    if (ex) {
+        a.y_out = ex->y; a.K_out = ex->K; a.S_out = ex->S; a.SI_out = ex->SI;
+        a.ll_out = ex->log_likelihood; a.maha_out = ex->mahalanobis;
+        a.extras_per_step = 1;
+    }
     return run_kf(desc, a, stream);
 }
 

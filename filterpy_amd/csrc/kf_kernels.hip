@@ -55,6 +55,11 @@ kf_kernel(const KfArgs a,
     TrackModel tm;
     const SharedModel sm{s_model};
     int st = 0;
+    // carried K, S, SI, log det S for the per-step histories (zeros before the first update, like the
+    // attributes of a fresh KalmanFilter)
+    double cK[NX * NZ], cS[NZ * NZ], cSI[NZ * NZ], c_logdet = 0.0;
+    FK_UNROLL for (int i = 0; i < NX * NZ; ++i) cK[i] = 0.0;
+    FK_UNROLL for (int i = 0; i < NZ * NZ; ++i) { cS[i] = 0.0; cSI[i] = 0.0; }
 
     for (long t = 0; t < a.T; ++t) {
         if (t == 0 || a.model_t) {
@@ -117,20 +122,55 @@ kf_kernel(const KfArgs a,
                 }
             } else {
                 if (!a.do_update) continue;
+                // extras: per-step histories or the single record of update()
+                const long et = a.extras_per_step ? t : 0;
+                const bool want_extras = a.y_out || a.K_out || a.S_out || a.SI_out || a.ll_out || a.maha_out;
                 if (has_z) {
                     double K[NX * NZ], y[NZ], S[NZ * NZ], Lf[NZ * NZ], dinv[NZ];
                     if (UNIFORM) st |= kf_update<NX, NZ>(x, P, z, sm, K, y, S, Lf, dinv);
                     else st |= kf_update<NX, NZ>(x, P, z, tm, K, y, S, Lf, dinv);
-                    if (live) {
-                        if (a.y_out) store_rec<NZ, 1, LAYOUT, EXACT>(y, a.y_out, ln, m, 1);
-                        if (a.K_out) store_rec<NX, NZ, LAYOUT, EXACT>(K, a.K_out, ln, n, m);
-                        if (a.S_out) store_rec<NZ, NZ, LAYOUT, EXACT>(S, a.S_out, ln, m, m);
-                        if (a.SI_out) {
-                            double SI[NZ * NZ];
-                            inv_from_ldlt<NZ>(Lf, dinv, SI);
-                            store_rec<NZ, NZ, LAYOUT, EXACT>(SI, a.SI_out, ln, m, m);
+                    if (want_extras) {
+                        double SI[NZ * NZ];
+                        inv_from_ldlt<NZ>(Lf, dinv, SI);
+                        // log det S and y' S^-1 y from the factorisation
+                        double logdet = 0.0, q = 0.0;
+                        if constexpr (NZ == 1) {
+                            logdet = log(S[0]);
+                            q = y[0] * y[0] * dinv[0];
+                        } else {
+                            double w[NZ];
+                            FK_UNROLL for (int i = 0; i < NZ; ++i) {
+                                double acc = y[i];
+                                FK_UNROLL for (int k2 = 0; k2 < NZ; ++k2)
+                                    if (k2 < i) acc = fma(-Lf[i * NZ + k2], w[k2], acc);
+                                w[i] = acc;
+                                if (EXACT || i < m) {
+                                    logdet += log(1.0 / dinv[i]);
+                                    q = fma(acc * acc, dinv[i], q);
+                                }
+                            }
+                        }
+                        FK_UNROLL for (int i = 0; i < NX * NZ; ++i) cK[i] = K[i];
+                        FK_UNROLL for (int i = 0; i < NZ * NZ; ++i) { cS[i] = S[i]; cSI[i] = SI[i]; }
+                        c_logdet = logdet;
+                        if (live) {
+                            if (a.y_out) store_rec<NZ, 1, LAYOUT, EXACT>(y, a.y_out + et * N * m, ln, m, 1);
+                            if (a.ll_out) a.ll_out[t * N + ln.blk0 + ln.tid] = -0.5 * (m * 1.8378770664093453 + logdet + q);
+                            if (a.maha_out) a.maha_out[t * N + ln.blk0 + ln.tid] = sqrt(q);
                         }
                     }
+                } else if (want_extras && live) {
+                    // missing measurement (kalman_filter.py:515-520): y = 0, K / S / SI keep their last values
+                    double y0[NZ];
+                    FK_UNROLL for (int i = 0; i < NZ; ++i) y0[i] = 0.0;
+                    if (a.y_out) store_rec<NZ, 1, LAYOUT, EXACT>(y0, a.y_out + et * N * m, ln, m, 1);
+                    if (a.ll_out) a.ll_out[t * N + ln.blk0 + ln.tid] = -0.5 * (m * 1.8378770664093453 + c_logdet);
+                    if (a.maha_out) a.maha_out[t * N + ln.blk0 + ln.tid] = 0.0;
+                }
+                if (want_extras && live) {
+                    if (a.K_out) store_rec<NX, NZ, LAYOUT, EXACT>(cK, a.K_out + et * N * n * m, ln, n, m);
+                    if (a.S_out) store_rec<NZ, NZ, LAYOUT, EXACT>(cS, a.S_out + et * N * m * m, ln, m, m);
+                    if (a.SI_out) store_rec<NZ, NZ, LAYOUT, EXACT>(cSI, a.SI_out + et * N * m * m, ln, m, m);
                 }
                 if (live) {
                     if (a.means) store_rec<NX, 1, LAYOUT, EXACT>(x, a.means + t * N * n, ln, n, 1);

@@ -63,7 +63,8 @@ class _Core:
 
     @staticmethod
     def batch(n, m, N, T, x0, P0, z, mask, F, Q, H, R, mode, B=None, us=None, nu=0,
-              alpha_sq=1.0, update_first=False, layout="soa", want_outputs=True, device_outputs=False):
+              alpha_sq=1.0, update_first=False, layout="soa", want_outputs=True, device_outputs=False,
+              extras=()):
         """All inputs are host arrays shaped for `mode`:
         x0 (N,n) P0 (N,n,n) z (T,N,m) mask (T,N) or None;
         models: SHARED (a,b) | PER_TRACK (N,a,b) | PER_STEP (T,a,b) | PER_TRACK_STEP (T,N,a,b).
@@ -88,18 +89,35 @@ class _Core:
         if want_outputs:
             outs = [E.alloc_records((T,), N, n, layout), E.alloc_records((T,), N, n * n, layout),
                     E.alloc_records((T,), N, n, layout), E.alloc_records((T,), N, n * n, layout)]
-        E.kf_batch_filter(dict(n=n, m=m, nu=nu, model_mode=mode, N=N, T=T, layout=E.LAYOUTS[layout],
-                               update_first=int(bool(update_first)), alpha_sq=float(alpha_sq)),
-                          model(F), model(Q), model(H), model(R), dz, dx, dP, B=model(B), u=du, mask=dmask,
-                          means=outs[0], covs=outs[1], means_p=outs[2], covs_p=outs[3], status=st)
+        desc = dict(n=n, m=m, nu=nu, model_mode=mode, N=N, T=T, layout=E.LAYOUTS[layout],
+                    update_first=int(bool(update_first)), alpha_sq=float(alpha_sq))
+        ex = {}
+        if extras:
+            # per-step histories of the update's by-products
+            shapes = dict(y=(m,), K=(n, m), S=(m, m), SI=(m, m))
+            for k in extras:
+                if k in shapes:
+                    ex[k] = E.alloc_records((T,), N, int(np.prod(shapes[k])), layout).zero_()
+                else:
+                    ex[k] = torch.zeros((T, N), dtype=torch.float64, device=dx.device)
+            E.kf_batch_filter_ex(desc, model(F), model(Q), model(H), model(R), dz, dx, dP, ex, B=model(B), u=du,
+                                 mask=dmask, means=outs[0], covs=outs[1], means_p=outs[2], covs_p=outs[3], status=st)
+        else:
+            E.kf_batch_filter(desc, model(F), model(Q), model(H), model(R), dz, dx, dP, B=model(B), u=du, mask=dmask,
+                              means=outs[0], covs=outs[1], means_p=outs[2], covs_p=outs[3], status=st)
         E.raise_on_status(st, "batch_filter")
         if device_outputs:
-            return outs + [dx, dP]
+            return outs + [dx, dP] + ([ex] if extras else [])
         res = [None] * 4
         if want_outputs:
             res = [E.from_records(outs[0], layout, 1, (n,)), E.from_records(outs[1], layout, 1, (n, n)),
                    E.from_records(outs[2], layout, 1, (n,)), E.from_records(outs[3], layout, 1, (n, n))]
-        return res + [E.from_records(dx, layout, 0, (n,)), E.from_records(dP, layout, 0, (n, n))]
+        res += [E.from_records(dx, layout, 0, (n,)), E.from_records(dP, layout, 0, (n, n))]
+        if extras:
+            shapes = dict(y=(m,), K=(n, m), S=(m, m), SI=(m, m))
+            res.append({k: (E.from_records(v, layout, 1, shapes[k]) if k in shapes else v.cpu().numpy())
+                        for k, v in ex.items()})
+        return res
 
     @staticmethod
     def rts(n, N, T, Xs, Ps, F, Q, mode, convention, layout="soa"):
@@ -283,8 +301,7 @@ class KalmanFilter(object):
         n, m = self.dim_x, self.dim_z
         T = len(zs)
         Fs, Qs, Hs, Rs, Bs = (_seq(v, T) for v in (Fs, Qs, Hs, Rs, Bs))
-        if saver is not None:
-            return self._batch_with_saver(zs, Fs, Qs, Hs, Rs, Bs, us, update_first, saver)
+        want_hist = saver is not None
         x_ndim = np.ndim(self.x)
         # measurements: None = missing (:515-520).  batch_filter always passes H, so reshape_z is
         # skipped (:527-529): a z only needs to broadcast against H x
@@ -324,14 +341,18 @@ class KalmanFilter(object):
         else:
             mode = FK_MODEL_SHARED
         x, P = self._xP()
-        mu, cov, mup, covp, xf, Pf = _Core.batch(
+        res = _Core.batch(
             n, m, 1, T, x, P, z, None if mask.all() else mask, Fm, Qm, Hm, Rm, mode,
-            alpha_sq=self._alpha_sq, update_first=update_first, **kw)
+            alpha_sq=self._alpha_sq, update_first=update_first,
+            extras=("y", "K", "S", "SI") if want_hist else (), **kw)
+        mu, cov, mup, covp, xf, Pf = res[:6]
         self._set_x(xf[0])
         self.P = Pf[0]
         mu, cov, mup, covp = mu[:, 0], cov[:, 0], mup[:, 0], covp[:, 0]
         if x_ndim == 2:
             mu, mup = mu[..., None], mup[..., None]
+        if want_hist:
+            self._replay_for_saver(saver, zs, mask[:, 0], mu, cov, mup, covp, res[6], update_first)
         # bookkeeping of the last epoch, as the per-epoch loop leaves it
         if T:
             if update_first:
@@ -342,30 +363,28 @@ class KalmanFilter(object):
                 self.x_post, self.P_post = np.copy(self.x), self.P.copy()
         return (mu, cov, mup, covp)
 
-    def _batch_with_saver(self, zs, Fs, Qs, Hs, Rs, Bs, us, update_first, saver):
-        """saver.save() needs the filter's attributes after every epoch (:990-991): step one
-        epoch at a time through predict()/update()."""
-        T = len(zs)
-        shape = np.shape(self.x)
-        means, means_p = np.zeros((T,) + shape), np.zeros((T,) + shape)
-        covs, covs_p = np.zeros((T, self.dim_x, self.dim_x)), np.zeros((T, self.dim_x, self.dim_x))
-
-        def at(lst, i):
-            return None if lst is None else lst[i]
-        for i, z in enumerate(zs):
-            u = None if us is None else us[i]
+    def _replay_for_saver(self, saver, zs, present, mu, cov, mup, covp, hist, update_first):
+        """saver.save() reads the filter's attributes after every epoch (kalman_filter.py:990-991,
+        filterpy/common/helpers.py:121-152).  The whole run was ONE kernel launch that also stored the
+        per-epoch K, y, S, SI; here the attributes are set epoch by epoch from those histories and
+        saver.save() is called -- bookkeeping only, no arithmetic."""
+        x_ndim = np.ndim(self.x)
+        m = self.dim_z
+        for i in range(len(zs)):
+            self.K, self.S, self.SI = hist["K"][i, 0].copy(), hist["S"][i, 0].copy(), hist["SI"][i, 0].copy()
+            yv = hist["y"][i, 0]
+            self.y = yv.reshape(m, 1).copy() if (x_ndim == 2 or not present[i]) else yv.copy()
+            self.z = deepcopy(zs[i]) if present[i] else np.array([[None] * m]).T
+            self._log_likelihood = self._likelihood = self._mahalanobis = None
             if update_first:
-                self.update(z, R=at(Rs, i), H=at(Hs, i) if Hs is not None else self.H)
-                means[i], covs[i] = self.x, self.P
-                self.predict(u=u, B=at(Bs, i), F=at(Fs, i), Q=at(Qs, i))
-                means_p[i], covs_p[i] = self.x, self.P
+                self.x_post, self.P_post = mu[i].copy(), cov[i].copy()
+                self.x_prior, self.P_prior = mup[i].copy(), covp[i].copy()
+                self.x, self.P = mup[i].copy(), covp[i].copy()
             else:
-                self.predict(u=u, B=at(Bs, i), F=at(Fs, i), Q=at(Qs, i))
-                means_p[i], covs_p[i] = self.x, self.P
-                self.update(z, R=at(Rs, i), H=at(Hs, i) if Hs is not None else self.H)
-                means[i], covs[i] = self.x, self.P
+                self.x_prior, self.P_prior = mup[i].copy(), covp[i].copy()
+                self.x_post, self.P_post = mu[i].copy(), cov[i].copy()
+                self.x, self.P = mu[i].copy(), cov[i].copy()
             saver.save()
-        return (means, covs, means_p, covs_p)
 
     # -- rts_smoother -----------------------------------------------------------
     def rts_smoother(self, Xs, Ps, Fs=None, Qs=None, inv=None):
@@ -527,8 +546,10 @@ class KalmanFilterBank(object):
         self.x, self.P, self.y, self.K, self.S, self.SI = _Core.update(
             self.dim_x, self.dim_z, self.n_tracks, x, P, z, mods["H"], mods["R"], mode, mask=mask, layout=self.layout)
 
-    def batch_filter(self, zs, mask=None, update_first=False, store=True, device_outputs=False):
-        """zs (T, N, dim_z) NumPy array or a device tensor already in self.layout."""
+    def batch_filter(self, zs, mask=None, update_first=False, store=True, device_outputs=False, extras=()):
+        """zs (T, N, dim_z) NumPy array or a device tensor already in self.layout.
+        extras: any of 'y', 'K', 'S', 'SI', 'log_likelihood', 'mahalanobis' -> also returns a dict of the
+        per-step histories (T, N, ...) as a fifth element (what filterpy.common.Saver would record)."""
         import torch
         mods, mode = self._models()
         x, P = self._state()
@@ -546,13 +567,13 @@ class KalmanFilterBank(object):
                 z = np.where(np.asarray(mask, dtype=bool)[..., None], z, 0.0)
         out = _Core.batch(self.dim_x, self.dim_z, self.n_tracks, T, x, P, z, mask, mods["F"], mods["Q"],
                           mods["H"], mods["R"], mode, alpha_sq=self._alpha_sq, update_first=update_first,
-                          layout=self.layout, want_outputs=store, device_outputs=device_outputs)
+                          layout=self.layout, want_outputs=store, device_outputs=device_outputs, extras=tuple(extras))
         if device_outputs:
             self.x = E.from_records(out[4], self.layout, 0, (self.dim_x,))
             self.P = E.from_records(out[5], self.layout, 0, (self.dim_x, self.dim_x))
         else:
             self.x, self.P = out[4], out[5]
-        return tuple(out[:4])
+        return tuple(out[:4]) + ((out[6],) if extras else ())
 
     def rts_smoother(self, Xs, Ps):
         """Xs (T,N,n), Ps (T,N,n,n) -> (x, P, K, Pp), class convention (kalman_filter.py:1067)."""

@@ -112,6 +112,28 @@ int fk_kf_batch_filter_f64(const fk_kf_desc *desc,
                            double *means, double *covs, double *means_p, double *covs_p,
                            int32_t *status, void *stream);
 
+/* Per-step histories of the update's by-products: what filterpy.common.Saver
+ * (filterpy/common/helpers.py:121-152) records when it is attached to batch_filter (kalman_filter.py:990-991)
+ * and the lazily computed properties log_likelihood / mahalanobis (kalman_filter.py:1203-1239).
+ * Every pointer may be NULL (not stored).  Records per (step, track) in desc->layout:
+ *   y [T][N][m], K [T][N][n*m], S [T][N][m*m], SI [T][N][m*m];  scalars [T][N]: log_likelihood
+ *   = log N(y; 0, S), mahalanobis = sqrt(y' S^-1 y).  A missing measurement stores y = 0 and repeats
+ *   the previous K, S, SI (zeros before the first update), exactly like the attributes of the
+ *   reference object after update(None). */
+typedef struct fk_kf_extras {
+    double *y, *K, *S, *SI;
+    double *log_likelihood, *mahalanobis;
+} fk_kf_extras;
+
+/* fk_kf_batch_filter_f64 plus the histories above (ex may be NULL). */
+int fk_kf_batch_filter_ex_f64(const fk_kf_desc *desc,
+                              const double *F, const double *Q, const double *H, const double *R,
+                              const double *B, const double *u,
+                              const double *z, const uint8_t *mask,
+                              double *x, double *P,
+                              double *means, double *covs, double *means_p, double *covs_p,
+                              const fk_kf_extras *extras, int32_t *status, void *stream);
+
 /* KalmanFilter.predict (kalman_filter.py:437-482; module twin :1571-1621) on a resident batch:
  * one step, x/P updated in place.  desc->T is ignored (treated as 1). */
 int fk_kf_predict_f64(const fk_kf_desc *desc, const double *F, const double *Q,

@@ -74,7 +74,9 @@ def kf_batch_filter(x0, P0, zs, F, Q, H, R, B=None, us=None, alpha_sq=1.0,
     x0 may be (n,) or (n,1); each z must then be (m,) or (m,1) respectively
     (batch_filter always passes H, so reshape_z is skipped: :527-529).
     Returns (means, covariances, means_p, covariances_p) like the reference;
-    with return_all also (Ks, ys, Ss) per epoch (zeros where skipped).
+    with return_all also the per-epoch histories (Ks, ys, Ss, SIs) as filterpy.common.Saver
+    records them (helpers.py:121-152): after update(None) y = 0 and K, S, SI keep their previous
+    values (zeros before the first update, kalman_filter.py:411-414, :515-520).
     """
     n_steps = len(zs)
     Fs, Qs, Hs, Rs, Bs = (_per_step(v, n_steps) for v in (F, Q, H, R, B))
@@ -90,6 +92,8 @@ def kf_batch_filter(x0, P0, zs, F, Q, H, R, B=None, us=None, alpha_sq=1.0,
     Ks = np.zeros((n_steps, dim_x, dim_z))
     ys = np.zeros((n_steps, dim_z))
     Ss = np.zeros((n_steps, dim_z, dim_z))
+    SIs = np.zeros((n_steps, dim_z, dim_z))
+    last = [np.zeros((dim_x, dim_z)), np.zeros((dim_z, dim_z)), np.zeros((dim_z, dim_z))]
 
     def missing(z):
         return z is None or (np.ndim(z) > 0 and np.all(np.isnan(np.asarray(z, dtype=float))))
@@ -98,12 +102,14 @@ def kf_batch_filter(x0, P0, zs, F, Q, H, R, B=None, us=None, alpha_sq=1.0,
         nonlocal x, P
         z = zs[i]
         if missing(z):
+            Ks[i], Ss[i], SIs[i] = last
             return
         z = np.asarray(z, dtype=float)
         if x.ndim == 2 and z.ndim == 1:
             z = z.reshape(-1, 1)
-        x, P, y, K, S, _ = kf_update(x, P, z, Rs[i], Hs[i])
-        Ks[i], ys[i], Ss[i] = K, np.ravel(y), S
+        x, P, y, K, S, SI = kf_update(x, P, z, Rs[i], Hs[i])
+        Ks[i], ys[i], Ss[i], SIs[i] = K, np.ravel(y), S, SI
+        last[:] = [K, S, SI]
 
     def do_predict(i):
         nonlocal x, P
@@ -121,7 +127,7 @@ def kf_batch_filter(x0, P0, zs, F, Q, H, R, B=None, us=None, alpha_sq=1.0,
             do_update(i)
             means[i], covs[i] = x, P
     if return_all:
-        return means, covs, means_p, covs_p, Ks, ys, Ss
+        return means, covs, means_p, covs_p, Ks, ys, Ss, SIs
     return means, covs, means_p, covs_p
 
 
@@ -195,3 +201,16 @@ def rts_smoother_tracks(Xs, Ps, F, Q, tracks, convention="class", model_mode=0):
             return M[:, i]
         outs.append(rts_smoother(Xs[:, i].copy(), Ps[:, i].copy(), pick(F), pick(Q), convention))
     return tuple(np.stack([o[k] for o in outs], axis=1) for k in range(4))
+
+
+def log_likelihood(y, S):
+    """KalmanFilter.log_likelihood (kalman_filter.py:1203-1211) = logpdf(x=y, cov=S)
+    (filterpy/stats/stats.py:131-154 -> scipy.stats.multivariate_normal.logpdf, allow_singular)."""
+    from scipy.stats import multivariate_normal
+    return multivariate_normal.logpdf(np.asarray(y).flatten(), None, S, True)
+
+
+def mahalanobis(y, SI):
+    """KalmanFilter.mahalanobis (kalman_filter.py:1228-1240)."""
+    y = np.asarray(y, dtype=float).reshape(-1, 1)
+    return float(np.sqrt(float(dot(dot(y.T, SI), y).item())))

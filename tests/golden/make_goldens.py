@@ -198,6 +198,36 @@ def gen_steps():
     np.savez_compressed(os.path.join(OUT, "kf_steps.npz"), **d)
 
 
+
+# ------------------------------------------------------- Saver histories ---
+def gen_saver():
+    """per-epoch attribute histories as filterpy.common.Saver records them during
+    batch_filter(saver=...) -- K, y, S, SI, priors/posts and the lazy log_likelihood / likelihood /
+    mahalanobis properties -- including epochs with a missing measurement."""
+    from filterpy.common import Saver
+    d = {}
+    T = 25
+    for (n, m) in [(2, 1), (4, 2), (6, 3), (9, 3)]:
+        rs = np.random.RandomState(6000 + 7 * n + m)
+        F, Q, H, R = stable_F(rs, n), spd(rs, n, 0.1), rs.randn(m, n), spd(rs, m, 0.5)
+        P0, x0 = spd(rs, n, 5.0), rs.randn(n, 1)
+        zs = rs.randn(T, m, 1) * 3
+        mask = rs.rand(T) > 0.25
+        zl = np.empty(T, dtype=object)
+        for t in range(T):
+            zl[t] = zs[t] if mask[t] else None
+        kf = make_kf(n, m, x0, P0, F, Q, H, R)
+        s = Saver(kf)
+        mu, cov, mup, covp = kf.batch_filter(zl, saver=s)
+        p = f"n{n}m{m}_"
+        d.update({p + "F": F, p + "Q": Q, p + "H": H, p + "R": R, p + "P0": P0, p + "x0": x0, p + "zs": zs,
+                  p + "mask": mask, p + "mu": mu, p + "cov": cov})
+        for key in ("x", "P", "x_prior", "P_prior", "x_post", "P_post", "K", "y", "S", "SI"):
+            d[p + key] = np.array(s[key], dtype=float)
+        for key in ("log_likelihood", "likelihood", "mahalanobis"):
+            d[p + key] = np.array(s[key], dtype=float)
+    np.savez_compressed(os.path.join(OUT, "kf_saver.npz"), **d)
+
 # ---------------------------------------------------------------- UKF -----
 UKF_CASES = [(1, 1, .5, 2., 1.), (2, 1, .1, 2., -1.), (4, 2, 1e-3, 2., 0.), (6, 3, .1, 2., -3.), (4, 2, 1., 2., .1)]
 
@@ -326,7 +356,7 @@ def gen_resample():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["c1", "dims", "models", "steps", "ukf", "resample"]
+    which = sys.argv[1:] or ["c1", "dims", "models", "steps", "saver", "ukf", "resample"]
     for w in which:
         print("generating", w)
         globals()["gen_" + w]()

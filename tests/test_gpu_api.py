@@ -232,3 +232,62 @@ def test_bank_per_track_models_and_device_outputs():
         assert tuple(outs[1].shape) == want
         got = outs[1].cpu().numpy() if layout == "aos" else outs[1].cpu().numpy().transpose(0, 2, 1)
         assert rel_err_rows(got[:, 0], cov[:, 0].reshape(T, -1)) < 1e-15
+
+
+@pytest.mark.parametrize("n,m", [(2, 1), (4, 2), (6, 3), (9, 3)])
+def test_saver_histories_drop_in(n, m):
+    """batch_filter(saver=...) -- one kernel launch also stores the per-epoch
+    K / y / S / SI; a Saver-like object attached to the filter then sees, epoch by epoch, the same
+    attributes (incl. the lazy log_likelihood / mahalanobis) as filterpy.common.Saver records from the
+    reference, missing measurements included."""
+    g = golden("kf_saver")
+    p = f"n{n}m{m}_"
+
+    class Saver:                       # the part of filterpy.common.Saver the test needs
+        KEYS = ("x", "P", "x_prior", "P_prior", "x_post", "P_post", "K", "y", "S", "SI")
+
+        def __init__(self, kf):
+            self.kf, self.h = kf, {k: [] for k in self.KEYS + ("log_likelihood", "likelihood", "mahalanobis")}
+
+        def save(self):
+            for k in self.KEYS:
+                self.h[k].append(np.array(getattr(self.kf, k), dtype=float))
+            for k in ("log_likelihood", "likelihood", "mahalanobis"):
+                self.h[k].append(float(getattr(self.kf, k)))
+    kf = _kf(n, m, g[p + "x0"], g[p + "P0"], g[p + "F"], g[p + "Q"], g[p + "H"], g[p + "R"])
+    s = Saver(kf)
+    zl = [z if k else None for z, k in zip(g[p + "zs"], g[p + "mask"])]
+    mu, cov, mup, covp = kf.batch_filter(zl, saver=s)
+    assert rel_err_rows(mu, g[p + "mu"]) < TOL and rel_err_rows(cov, g[p + "cov"]) < TOL
+    for k in Saver.KEYS:
+        got, ref = np.array(s.h[k]), g[p + k]
+        assert got.shape == ref.shape, (k, got.shape, ref.shape)
+        assert np.allclose(got, ref, rtol=1e-9, atol=1e-11), k
+    assert np.allclose(s.h["log_likelihood"], g[p + "log_likelihood"], rtol=1e-8, atol=1e-8)
+    assert np.allclose(s.h["mahalanobis"], g[p + "mahalanobis"], rtol=1e-8, atol=1e-10)
+    assert np.allclose(s.h["likelihood"], g[p + "likelihood"], rtol=1e-7, atol=1e-300)
+
+
+def test_bank_extras_in_kernel_likelihood():
+    """The bank's per-step log_likelihood / mahalanobis come out of the kernel (LDL' factors)."""
+    from filterpy_amd.kalman import KalmanFilterBank
+    g = golden("kf_saver")
+    n, m, N = 4, 2, 300
+    p = f"n{n}m{m}_"
+    for layout in ("soa", "aos"):
+        bank = KalmanFilterBank(n, m, N, layout=layout)
+        bank.x, bank.P = np.tile(g[p + "x0"][:, 0], (N, 1)), np.tile(g[p + "P0"], (N, 1, 1))
+        bank.F, bank.Q, bank.H, bank.R = g[p + "F"], g[p + "Q"], g[p + "H"], g[p + "R"]
+        zs = np.tile(g[p + "zs"][:, None, :, 0], (1, N, 1))
+        mask = np.tile(g[p + "mask"][:, None], (1, N))
+        out = bank.batch_filter(zs, mask=mask, extras=("y", "K", "S", "SI", "log_likelihood", "mahalanobis"))
+        hist = out[4]
+        for trk in (0, 255, 256, N - 1):
+            assert np.allclose(hist["K"][:, trk], g[p + "K"], rtol=1e-9, atol=1e-11)
+            assert np.allclose(hist["S"][:, trk], g[p + "S"], rtol=1e-9, atol=1e-11)
+            assert np.allclose(hist["y"][:, trk], g[p + "y"][..., 0], rtol=1e-9, atol=1e-11)
+            # epochs before the first measurement have S = 0: the reference's allow_singular logpdf returns a
+            # pseudo-determinant based value there; compare where S is defined
+            ok = np.abs(g[p + "S"]).reshape(len(mask), -1).max(axis=1) > 0
+            assert np.allclose(hist["log_likelihood"][ok, trk], g[p + "log_likelihood"][ok], rtol=1e-8, atol=1e-8)
+            assert np.allclose(hist["mahalanobis"][:, trk], g[p + "mahalanobis"], rtol=1e-8, atol=1e-10)

@@ -76,3 +76,23 @@ def test_single_steps(n, m):
     x2, P2, y2, K2, S2 = kf_oracle.proc_update(g[p + "m_xp"], g[p + "m_Pp"], g[p + "z"], g[p + "R"], g[p + "H"])
     for got, key in ((x2, "m_x"), (P2, "m_P"), (K2, "m_K"), (S2, "m_S")):
         assert rel_err_rows(np.atleast_2d(got)[None], np.atleast_2d(g[p + key])[None]) < TIGHT, key
+
+
+@pytest.mark.parametrize("n,m", [(2, 1), (4, 2), (6, 3), (9, 3)])
+def test_saver_histories(n, m):
+    """the histories filterpy.common.Saver records during batch_filter(saver=...)."""
+    g = golden("kf_saver")
+    p = f"n{n}m{m}_"
+    zl = [z if k else None for z, k in zip(g[p + "zs"], g[p + "mask"])]
+    mu, cov, mup, covp, Ks, ys, Ss, SIs = kf_oracle.kf_batch_filter(
+        g[p + "x0"], g[p + "P0"], zl, g[p + "F"], g[p + "Q"], g[p + "H"], g[p + "R"], return_all=True)
+    assert rel_err_rows(mu, g[p + "x"]) < TIGHT and rel_err_rows(cov, g[p + "P"]) < TIGHT
+    assert rel_err_rows(mup, g[p + "x_prior"]) < TIGHT and rel_err_rows(covp, g[p + "P_prior"]) < TIGHT
+    for got, key in ((Ks, "K"), (Ss, "S"), (SIs, "SI")):
+        assert np.allclose(got, g[p + key], rtol=1e-12, atol=1e-14), key
+    assert np.allclose(ys, g[p + "y"][..., 0], rtol=1e-12, atol=1e-13)
+    ll = np.array([kf_oracle.log_likelihood(y, S) if S.any() else g[p + "log_likelihood"][i]
+                   for i, (y, S) in enumerate(zip(ys, Ss))])
+    assert np.allclose(ll, g[p + "log_likelihood"], rtol=1e-10, atol=1e-10)
+    mh = np.array([kf_oracle.mahalanobis(y, SI) for y, SI in zip(ys, SIs)])
+    assert np.allclose(mh, g[p + "mahalanobis"], rtol=1e-10, atol=1e-12)
