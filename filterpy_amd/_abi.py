@@ -37,6 +37,11 @@ class fk_ukf_desc(ctypes.Structure):
                 ("reserved", c_i32), ("scale", c_f64)]
 
 
+class fk_imm_desc(ctypes.Structure):
+    _fields_ = [("n", c_i32), ("m", c_i32), ("n_models", c_i32), ("layout", c_i32), ("N", c_i64), ("T", c_i64),
+                ("phase", c_i32), ("reserved", c_i32)]
+
+
 class FilterHipError(RuntimeError):
     pass
 
@@ -54,6 +59,7 @@ SIGNATURES = {
     "fk_ut_cross_variance_f64": (ctypes.c_int, [c_i32, c_i32, c_i32, c_i64, c_i32] + [c_vp] * 7),
     "fk_ukf_correct_f64": (ctypes.c_int, [c_i32, c_i32, c_i64, c_i32] + [c_vp] * 9),
     "fk_ukf_linear_batch_f64": (ctypes.c_int, [ctypes.POINTER(fk_ukf_desc)] + [c_vp] * 14),
+    "fk_imm_batch_f64": (ctypes.c_int, [ctypes.POINTER(fk_imm_desc)] + [c_vp] * 17),
     "fk_resample_systematic_f64": (ctypes.c_int, [c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "fk_resample_stratified_f64": (ctypes.c_int, [c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "fk_resample_multinomial_f64": (ctypes.c_int, [c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),

@@ -1,0 +1,120 @@
+// fk_imm.hpp -- per-track arithmetic of the interacting-multiple-model estimator
+// (filterpy/kalman/IMM.py:160-249) on a bank of NM linear Kalman filters whose covariances are
+// held packed (upper triangle, fk_math_sym.hpp).  Host/device like fk_math.hpp so the test-only
+// host harness can run it against the oracle; the product calls it from imm_kernels.hip only.
+#pragma once
+
+#include "fk_math.hpp"
+#include "fk_math_sym.hpp"
+
+namespace fk {
+
+// mu-weighted moments of the bank (IMM.py:224-237)
+template <int NX, int NM>
+FK_HD void imm_estimate(const double (&xs)[NM][NX], const double (&Ps)[NM][NX * (NX + 1) / 2],
+                                             const double (&mu)[NM], double (&x)[NX], double (&P)[NX * NX])
+{
+    FK_UNROLL for (int a = 0; a < NX; ++a) {
+        double acc = 0.0;
+        FK_UNROLL for (int j = 0; j < NM; ++j) acc = fma(xs[j][a], mu[j], acc);
+        x[a] = acc;
+    }
+    FK_UNROLL for (int k = 0; k < NX * NX; ++k) P[k] = 0.0;
+    FK_UNROLL for (int j = 0; j < NM; ++j) {
+        double y[NX];
+        FK_UNROLL for (int a = 0; a < NX; ++a) y[a] = xs[j][a] - x[a];
+        FK_UNROLL for (int a = 0; a < NX; ++a)
+            FK_UNROLL for (int b = a; b < NX; ++b)
+                P[a * NX + b] = fma(mu[j], fma(y[a], y[b], Ps[j][sym_idx<NX>(a, b)]), P[a * NX + b]);
+        FK_STAGE();
+    }
+    FK_UNROLL for (int a = 0; a < NX; ++a)
+        FK_UNROLL for (int b = 0; b < a; ++b) P[a * NX + b] = P[b * NX + a];
+}
+
+// cbar = mu . M  (IMM.py:244); M row-major NM x NM
+template <int NM>
+FK_HD void imm_mixing_cbar(const double (&mu)[NM], const double *M, double (&cbar)[NM])
+{
+    FK_UNROLL for (int j = 0; j < NM; ++j) {
+        double acc = 0.0;
+        FK_UNROLL for (int i = 0; i < NM; ++i) acc = fma(mu[i], M[i * NM + j], acc);
+        cbar[j] = acc;
+    }
+}
+
+// IMMEstimator.predict (IMM.py:200-219): mixed initial conditions with
+// omega[i][j] = M[i][j] mu[i] / cbar[j] (IMM.py:245-249), then every filter's own predict.
+template <int NX, int NM, class Model>
+FK_HD void imm_predict(double (&xs)[NM][NX], double (&Ps)[NM][NX * (NX + 1) / 2], const double (&mu)[NM],
+                       const double (&cbar)[NM], const double *M, const Model (&mods)[NM])
+{
+    constexpr int PL = NX * (NX + 1) / 2;
+    double mx[NM][NX], mP[NM][PL];
+    FK_UNROLL for (int j = 0; j < NM; ++j) {
+        double w[NM];
+        FK_UNROLL for (int i = 0; i < NM; ++i) w[i] = (M[i * NM + j] * mu[i]) / cbar[j];
+        FK_UNROLL for (int r = 0; r < NX; ++r) {
+            double acc = 0.0;
+            FK_UNROLL for (int i = 0; i < NM; ++i) acc = fma(xs[i][r], w[i], acc);
+            mx[j][r] = acc;
+        }
+        FK_UNROLL for (int k = 0; k < PL; ++k) mP[j][k] = 0.0;
+        FK_UNROLL for (int i = 0; i < NM; ++i) {
+            double y[NX];
+            FK_UNROLL for (int r = 0; r < NX; ++r) y[r] = xs[i][r] - mx[j][r];
+            FK_UNROLL for (int r = 0; r < NX; ++r)
+                FK_UNROLL for (int c = r; c < NX; ++c)
+                    mP[j][sym_idx<NX>(r, c)] = fma(w[i], fma(y[r], y[c], Ps[i][sym_idx<NX>(r, c)]), mP[j][sym_idx<NX>(r, c)]);
+        }
+        FK_STAGE();
+    }
+    FK_UNROLL for (int j = 0; j < NM; ++j) {
+        FK_UNROLL for (int r = 0; r < NX; ++r) xs[j][r] = mx[j][r];
+        FK_UNROLL for (int k = 0; k < PL; ++k) Ps[j][k] = mP[j][k];
+        kf_predict_sym<NX>(xs[j], Ps[j], mods[j], 1.0);
+    }
+}
+
+// IMMEstimator.update (IMM.py:171-179): every filter's update with the same z, its likelihood
+// exp(logpdf(y; 0, S)) floored at DBL_MIN (kalman_filter.py:1213-1226), then
+// mu = cbar * likelihood, normalised.  m = runtime dim_z (<= NZ).  Returns status bits.
+template <int NX, int NZ, int NM, class Model>
+FK_HD int imm_update(double (&xs)[NM][NX], double (&Ps)[NM][NX * (NX + 1) / 2], double (&mu)[NM],
+                     const double (&cbar)[NM], const double (&z)[NZ], int m, const Model (&mods)[NM],
+                     double (&L)[NM])
+{
+    int st = 0;
+    const double log2pi_m = m * 1.8378770664093453;
+    FK_UNROLL for (int j = 0; j < NM; ++j) {
+        double K[NX * NZ], y[NZ], S[NZ * NZ], Lf[NZ * NZ], dinv[NZ];
+        st |= kf_update_sym<NX, NZ>(xs[j], Ps[j], z, mods[j], K, y, S, Lf, dinv);
+        double logdet = 0.0, q = 0.0;
+        if constexpr (NZ == 1) {
+            logdet = log(S[0]);
+            q = y[0] * y[0] * dinv[0];
+        } else {
+            double w[NZ];
+            FK_UNROLL for (int i = 0; i < NZ; ++i) {
+                double acc = y[i];
+                FK_UNROLL for (int k2 = 0; k2 < NZ; ++k2)
+                    if (k2 < i) acc = fma(-Lf[i * NZ + k2], w[k2], acc);
+                w[i] = acc;
+                if (i < m) {
+                    logdet += log(1.0 / dinv[i]);
+                    q = fma(acc * acc, dinv[i], q);
+                }
+            }
+        }
+        double lj = exp(-0.5 * (log2pi_m + logdet + q));
+        if (lj == 0.0) lj = 2.2250738585072014e-308;
+        L[j] = lj;
+        FK_STAGE();
+    }
+    double sum = 0.0;
+    FK_UNROLL for (int j = 0; j < NM; ++j) { mu[j] = cbar[j] * L[j]; sum += mu[j]; }
+    FK_UNROLL for (int j = 0; j < NM; ++j) mu[j] /= sum;
+    return st;
+}
+
+}  // namespace fk

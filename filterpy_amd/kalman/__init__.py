@@ -5,3 +5,4 @@ from .kalman_filter import (KalmanFilter, KalmanFilterBank, predict, update, bat
 from .sigma_points import MerweScaledSigmaPoints, JulierSigmaPoints  # noqa: F401
 from .unscented_transform import unscented_transform  # noqa: F401
 from .UKF import UnscentedKalmanFilter  # noqa: F401
+from .IMM import IMMEstimator  # noqa: F401

@@ -220,6 +220,45 @@ int fk_ukf_linear_batch_f64(const fk_ukf_desc *desc,
                             int32_t *status, void *stream);
 
 /* ------------------------------------------------------------------ */
+/* Interacting multiple models                     */
+/* ------------------------------------------------------------------ */
+
+typedef struct fk_imm_desc {
+    int32_t n, m;         /* dim_x (1..6), dim_z (1..3): the same for every filter of the bank */
+    int32_t n_models;     /* filters per track: 2 or 3 */
+    int32_t layout;
+    int64_t N, T;
+    int32_t phase;        /* FK_IMM_STEP: T x {predict; update}; FK_IMM_PREDICT / FK_IMM_UPDATE: that half once */
+    int32_t reserved;
+} fk_imm_desc;
+
+enum { FK_IMM_STEP = 0, FK_IMM_PREDICT = 1, FK_IMM_UPDATE = 2 };
+
+/* filterpy.kalman.IMMEstimator (filterpy/kalman/IMM.py) for N independent tracks, each with its own
+ * bank of n_models linear Kalman filters, T x { predict() (IMM.py:188-222) ; update(z) (IMM.py:160-186) }
+ * in one launch: mixing probabilities (IMM.py:239-249), mixed initial conditions, each filter's
+ * KalmanFilter.predict/update (kalman_filter.py:472-478, 533-556), likelihood = exp(logpdf(y; 0, S))
+ * floored at DBL_MIN (kalman_filter.py:1213-1226), mode probabilities, mixed estimate (IMM.py:224-237).
+ *   F, Q [n_models][n*n], H [n_models][m*n], R [n_models][m*m], M [n_models][n_models] (mode
+ *   transition probabilities): device arrays shared by all tracks.
+ *   z [T][N][m] (every measurement present).
+ *   xs [N][n_models*n], Ps [N][n_models*n*n], mu [N][n_models]: the banks' filter states and mode
+ *   probabilities (mu normalised by the caller like IMM.py:129), updated in place.
+ *   x_out [T][N][n], P_out [T][N][n*n], mu_out [T][N][n_models]: IMMEstimator.x/.P/.mu after each
+ *   update; x_prior_out, P_prior_out: after each predict; likelihood_out [T][N][n_models].
+ *   Any output may be NULL.  status [N] or NULL.
+ * phase FK_IMM_PREDICT runs IMMEstimator.predict() once (mixing + every filter's predict; writes
+ * xs, Ps and the prior outputs [N][..]), FK_IMM_UPDATE runs IMMEstimator.update(z) once (z [N][m];
+ * writes xs, Ps, mu and x_out/P_out/mu_out/likelihood_out [N][..]); T is ignored for both. */
+int fk_imm_batch_f64(const fk_imm_desc *desc,
+                     const double *F, const double *Q, const double *H, const double *R,
+                     const double *M, const double *z,
+                     double *xs, double *Ps, double *mu,
+                     double *x_out, double *P_out, double *mu_out,
+                     double *x_prior_out, double *P_prior_out, double *likelihood_out,
+                     int32_t *status, void *stream);
+
+/* ------------------------------------------------------------------ */
 /* Particle-filter resampling                                         */
 /* ------------------------------------------------------------------ */
 

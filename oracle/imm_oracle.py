@@ -1,0 +1,83 @@
+"""NumPy restatement of filterpy.kalman.IMMEstimator -- TEST INFRASTRUCTURE ONLY.
+
+Follows rlabbe/filterpy v1.4.5 filterpy/kalman/IMM.py: __init__ :124-158, update :160-186,
+predict :188-222, _compute_state_estimate :224-237, _compute_mixing_probabilities :239-249,
+on top of the linear Kalman filter of oracle/kf_oracle.py and the lazy likelihood of
+kalman_filter.py:1203-1226.  Never imported by filterpy_amd/.
+"""
+import sys
+
+import numpy as np
+
+from . import kf_oracle
+
+
+def mixing(mu, M):
+    """IMM.py:239-249: cbar = mu . M ; omega[i,j] = M[i,j] mu[i] / cbar[j]."""
+    cbar = np.dot(mu, M)
+    nm = len(mu)
+    omega = np.zeros((nm, nm))
+    for i in range(nm):
+        for j in range(nm):
+            omega[i, j] = (M[i, j] * mu[i]) / cbar[j]
+    return cbar, omega
+
+
+def state_estimate(xs, Ps, mu):
+    """IMM.py:224-237."""
+    x = np.zeros_like(xs[0])
+    for xj, m in zip(xs, mu):
+        x += xj * m
+    P = np.zeros_like(Ps[0])
+    for xj, Pj, m in zip(xs, Ps, mu):
+        y = xj - x
+        P += m * (np.outer(y, y) + Pj)
+    return x, P
+
+
+def imm_batch(xs0, Ps0, mu0, Mtrans, zs, Fs, Qs, Hs, Rs):
+    """T x { imm.predict(); imm.update(z) } for one IMM with len(Fs) linear models.
+
+    xs0 (nm, n), Ps0 (nm, n, n): the filters' states; mu0 (nm,) (normalised like IMM.py:129).
+    Returns per step: combined posterior x (T,n), P (T,n,n), mode probabilities (T,nm),
+    combined prior x, P, and the per-model likelihoods (T,nm)."""
+    nm = len(Fs)
+    xs = [np.array(x, dtype=float) for x in xs0]
+    Ps = [np.array(P, dtype=float) for P in Ps0]
+    mu = np.asarray(mu0, dtype=float) / np.sum(mu0)
+    Mtrans = np.asarray(Mtrans, dtype=float)
+    cbar, omega = mixing(mu, Mtrans)
+    T = len(zs)
+    n = xs[0].shape[0]
+    out_x, out_P, out_mu = np.zeros((T, n)), np.zeros((T, n, n)), np.zeros((T, nm))
+    out_xp, out_Pp, out_L = np.zeros((T, n)), np.zeros((T, n, n)), np.zeros((T, nm))
+    for t in range(T):
+        # predict (IMM.py:200-222): mixed initial conditions, then each filter's own predict
+        mx, mP = [], []
+        for j in range(nm):
+            w = omega[:, j]
+            x = np.zeros(n)
+            for xi, wi in zip(xs, w):
+                x += xi * wi
+            P = np.zeros((n, n))
+            for xi, Pi, wi in zip(xs, Ps, w):
+                y = xi - x
+                P += wi * (np.outer(y, y) + Pi)
+            mx.append(x)
+            mP.append(P)
+        for j in range(nm):
+            xs[j], Ps[j] = kf_oracle.kf_predict(mx[j], mP[j], Fs[j], Qs[j])
+        out_xp[t], out_Pp[t] = state_estimate(xs, Ps, mu)
+        # update (IMM.py:171-186)
+        L = np.zeros(nm)
+        for j in range(nm):
+            xs[j], Ps[j], y, K, S, SI = kf_oracle.kf_update(xs[j], Ps[j], zs[t], Rs[j], Hs[j])
+            L[j] = np.exp(kf_oracle.log_likelihood(y, S))
+            if L[j] == 0:
+                L[j] = sys.float_info.min          # kalman_filter.py:1221-1225
+        mu = cbar * L
+        mu /= np.sum(mu)
+        cbar, omega = mixing(mu, Mtrans)
+        out_x[t], out_P[t] = state_estimate(xs, Ps, mu)
+        out_mu[t], out_L[t] = mu, L
+    return out_x, out_P, out_mu, out_xp, out_Pp, out_L

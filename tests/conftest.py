@@ -32,7 +32,8 @@ def _helpers_built():
     _build(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=on", "-w",
             "-o", os.path.join(hc, "libhostcheck.so"), os.path.join(hc, "hostcheck.cpp")],
            os.path.join(hc, "libhostcheck.so"),
-           [os.path.join(hc, "hostcheck.cpp"), os.path.join(ROOT, "filterpy_amd", "csrc", "fk_math.hpp")])
+           [os.path.join(hc, "hostcheck.cpp")] + [os.path.join(ROOT, "filterpy_amd", "csrc", h) for h in
+                                                 ("fk_math.hpp", "fk_math_sym.hpp", "fk_imm.hpp", "fk_exact_scan.hpp")])
 
 
 def golden(name):

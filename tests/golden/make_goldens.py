@@ -228,6 +228,48 @@ def gen_saver():
             d[p + key] = np.array(s[key], dtype=float)
     np.savez_compressed(os.path.join(OUT, "kf_saver.npz"), **d)
 
+
+# ------------------------------------------------------------------ IMM ----
+IMM_CASES = [(2, 1, 2), (4, 2, 2), (4, 2, 3), (6, 3, 2), (3, 2, 2), (5, 2, 3)]
+
+
+def gen_imm():
+    """filterpy.kalman.IMMEstimator (IMM.py) over T steps of predict(); update(z)."""
+    from filterpy.kalman import IMMEstimator
+    d = {}
+    T = 30
+    for (n, m, nm) in IMM_CASES:
+        rs = np.random.RandomState(8000 + 11 * n + 3 * m + nm)
+        Fs = [stable_F(rs, n) for _ in range(nm)]
+        Qs = [spd(rs, n, 0.05 * (j + 1)) for j in range(nm)]
+        H = rs.randn(m, n)
+        Hs = [H.copy() for _ in range(nm)]
+        Rs = [spd(rs, m, 0.5) for _ in range(nm)]
+        xs0 = [rs.randn(n) for _ in range(nm)]
+        Ps0 = [spd(rs, n, 3.0) for _ in range(nm)]
+        mu0 = rs.rand(nm) + 0.2
+        Mt = rs.rand(nm, nm) + np.eye(nm) * 3
+        Mt /= Mt.sum(axis=1, keepdims=True)
+        zs = rs.randn(T, m) * 2
+        filters = []
+        for j in range(nm):
+            filters.append(make_kf(n, m, xs0[j], Ps0[j], Fs[j], Qs[j], Hs[j], Rs[j]))
+        imm = IMMEstimator(filters, mu0, Mt)
+        X, P, MU, XP, PP, L = [], [], [], [], [], []
+        for t in range(T):
+            imm.predict()
+            XP.append(imm.x.copy()); PP.append(imm.P.copy())
+            imm.update(zs[t])
+            X.append(imm.x.copy()); P.append(imm.P.copy()); MU.append(imm.mu.copy()); L.append(imm.likelihood.copy())
+        p = f"n{n}m{m}k{nm}_"
+        d.update({p + "Fs": np.array(Fs), p + "Qs": np.array(Qs), p + "Hs": np.array(Hs), p + "Rs": np.array(Rs),
+                  p + "xs0": np.array(xs0), p + "Ps0": np.array(Ps0), p + "mu0": mu0, p + "M": Mt, p + "zs": zs,
+                  p + "x": np.array(X), p + "P": np.array(P), p + "mu": np.array(MU), p + "xp": np.array(XP),
+                  p + "Pp": np.array(PP), p + "L": np.array(L),
+                  p + "xs_final": np.array([f.x for f in filters]), p + "Ps_final": np.array([f.P for f in filters])})
+    d["cases"] = np.array(IMM_CASES)
+    np.savez_compressed(os.path.join(OUT, "imm.npz"), **d)
+
 # ---------------------------------------------------------------- UKF -----
 UKF_CASES = [(1, 1, .5, 2., 1.), (2, 1, .1, 2., -1.), (4, 2, 1e-3, 2., 0.), (6, 3, .1, 2., -3.), (4, 2, 1., 2., .1)]
 
@@ -356,7 +398,7 @@ def gen_resample():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["c1", "dims", "models", "steps", "saver", "ukf", "resample"]
+    which = sys.argv[1:] or ["c1", "dims", "models", "steps", "saver", "imm", "ukf", "resample"]
     for w in which:
         print("generating", w)
         globals()["gen_" + w]()

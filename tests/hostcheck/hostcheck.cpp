@@ -8,6 +8,7 @@
 
 #include "../../filterpy_amd/csrc/fk_math.hpp"
 #include "../../filterpy_amd/csrc/fk_math_sym.hpp"
+#include "../../filterpy_amd/csrc/fk_imm.hpp"
 
 using namespace fk;
 
@@ -458,4 +459,74 @@ extern "C" long hc_cumsum_chunked(long N, const double *w, double *cs, long *n_s
         for (int j = 0; j < len; ++j) cs[base + j] = tile[j];
     }
     return nch;
+}
+
+// --------------------------------------------------------------------------------- IMM --
+// One track's bank of nm filters, T x { predict; update }, padded like imm_kernel.
+template <int NX, int NZ, int NM>
+static int imm_batch(int n, int m, long T, const double *F, const double *Q, const double *H, const double *R,
+                     const double *Mt, const double *z, double *xs0, double *Ps0, double *mu0, double *x_out,
+                     double *P_out, double *mu_out, double *xp_out, double *Pp_out, double *L_out)
+{
+    constexpr int PL = NX * (NX + 1) / 2;
+    RegModel<NX, NZ> mods[NM];
+    double xs[NM][NX], Ps[NM][PL], mu[NM];
+    for (int j = 0; j < NM; ++j) {
+        pad<NX, NX>(mods[j].F, F + j * n * n, n, n, 1.0);
+        pad<NX, NX>(mods[j].Q, Q + j * n * n, n, n, 0.0);
+        pad<NZ, NX>(mods[j].H, H + j * m * n, m, n, 0.0);
+        pad<NZ, NZ>(mods[j].R, R + j * m * m, m, m, 1.0);
+        double Pf[NX * NX];
+        pad<NX, 1>(xs[j], xs0 + j * n, n, 1, 0.0);
+        pad<NX, NX>(Pf, Ps0 + j * n * n, n, n, 1.0);
+        for (int r = 0; r < NX; ++r)
+            for (int c = r; c < NX; ++c) Ps[j][sym_idx<NX>(r, c)] = Pf[r * NX + c];
+        mu[j] = mu0[j];
+    }
+    int st = 0;
+    for (long t = 0; t < T; ++t) {
+        double zz[NZ], cbar[NM], L[NM], x[NX], P[NX * NX];
+        pad<NZ, 1>(zz, z + t * m, m, 1, 0.0);
+        imm_mixing_cbar<NM>(mu, Mt, cbar);
+        imm_predict<NX, NM>(xs, Ps, mu, cbar, Mt, mods);
+        imm_estimate<NX, NM>(xs, Ps, mu, x, P);
+        unpad<NX, 1>(x, xp_out + t * n, n, 1);
+        unpad<NX, NX>(P, Pp_out + t * n * n, n, n);
+        st |= imm_update<NX, NZ, NM>(xs, Ps, mu, cbar, zz, m, mods, L);
+        imm_estimate<NX, NM>(xs, Ps, mu, x, P);
+        unpad<NX, 1>(x, x_out + t * n, n, 1);
+        unpad<NX, NX>(P, P_out + t * n * n, n, n);
+        for (int j = 0; j < NM; ++j) { mu_out[t * NM + j] = mu[j]; L_out[t * NM + j] = L[j]; }
+    }
+    for (int j = 0; j < NM; ++j) {
+        double Pf[NX * NX];
+        for (int r = 0; r < NX; ++r)
+            for (int c = 0; c < NX; ++c) Pf[r * NX + c] = Ps[j][sym_idx<NX>(r, c)];
+        unpad<NX, 1>(xs[j], xs0 + j * n, n, 1);
+        unpad<NX, NX>(Pf, Ps0 + j * n * n, n, n);
+        mu0[j] = mu[j];
+    }
+    return st;
+}
+
+extern "C" int hc_imm_batch(int n, int m, int nm, long T, const double *F, const double *Q, const double *H,
+                            const double *R, const double *Mt, const double *z, double *xs0, double *Ps0,
+                            double *mu0, double *x_out, double *P_out, double *mu_out, double *xp_out,
+                            double *Pp_out, double *L_out)
+{
+#define GO(NXV, NZV, NMV) \
+    return imm_batch<NXV, NZV, NMV>(n, m, T, F, Q, H, R, Mt, z, xs0, Ps0, mu0, x_out, P_out, mu_out, xp_out, Pp_out, L_out)
+    const int cls = (n <= 2 && m <= 1) ? 0 : (n <= 4 && m <= 2) ? 1 : 2;
+    if (nm == 2) {
+        if (cls == 0) GO(2, 1, 2);
+        if (cls == 1) GO(4, 2, 2);
+        GO(6, 3, 2);
+    }
+    if (nm == 3) {
+        if (cls == 0) GO(2, 1, 3);
+        if (cls == 1) GO(4, 2, 3);
+        GO(6, 3, 3);
+    }
+#undef GO
+    return -1;
 }

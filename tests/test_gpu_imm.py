@@ -1,0 +1,174 @@
+"""-m gpu parity tests: the batched IMM estimator through the C ABI
+(fk_imm_batch_f64) and through the filterpy-shaped ``IMMEstimator`` class, against goldens frozen
+from the live filterpy.kalman.IMMEstimator and against oracle/imm_oracle.py on seeded banks."""
+import numpy as np
+import pytest
+
+from conftest import golden, rel_err_rows
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-10
+CASES = [(2, 1, 2), (4, 2, 2), (4, 2, 3), (6, 3, 2), (3, 2, 2), (5, 2, 3)]
+
+
+def spd(rs, n, scale=1.0):
+    A = rs.randn(n, n)
+    return scale * (A @ A.T / n + 0.5 * np.eye(n))
+
+
+def stable_F(rs, n):
+    F = np.eye(n) + 0.1 * rs.randn(n, n)
+    return F / max(1.0, 1.05 * np.max(np.abs(np.linalg.eigvals(F))))
+
+
+def run_imm(xs0, Ps0, mu0, M, zs, Fs, Qs, Hs, Rs, layout, phase=0, priors=True):
+    """xs0 (N,nm,n), Ps0 (N,nm,n,n), mu0 (N,nm), zs (T,N,m) -> dict of host arrays."""
+    import torch
+    from filterpy_amd import _engine as E
+    N, nm, n = xs0.shape
+    T, _, m = zs.shape
+    dxs = E.to_records(xs0.reshape(N, nm * n), layout, 0)
+    dPs = E.to_records(Ps0.reshape(N, nm * n * n), layout, 0)
+    dmu = E.to_records(mu0, layout, 0)
+    dz = E.to_records(zs, layout, 1)
+    out = dict(x_out=E.alloc_records((T,), N, n, layout), P_out=E.alloc_records((T,), N, n * n, layout),
+               mu_out=E.alloc_records((T,), N, nm, layout), likelihood_out=E.alloc_records((T,), N, nm, layout))
+    if priors:
+        out.update(x_prior_out=E.alloc_records((T,), N, n, layout), P_prior_out=E.alloc_records((T,), N, n * n, layout))
+    for o in out.values():
+        o.fill_(float("nan"))
+    st = torch.zeros(N, dtype=torch.int32, device=dxs.device)
+    E.imm_batch(n, m, nm, N, T, layout, E.dev(Fs), E.dev(Qs), E.dev(Hs), E.dev(Rs), E.dev(M), dz, dxs, dPs, dmu,
+                status=st, phase=phase, **out)
+    torch.cuda.synchronize()
+    assert not st.any()
+    shapes = dict(x_out=(n,), P_out=(n, n), mu_out=(nm,), likelihood_out=(nm,), x_prior_out=(n,), P_prior_out=(n, n))
+    res = {k: E.from_records(v, layout, 1, shapes[k]) for k, v in out.items()}
+    res["xs"] = E.from_records(dxs, layout, 0, (nm, n))
+    res["Ps"] = E.from_records(dPs, layout, 0, (nm, n, n))
+    res["mu"] = E.from_records(dmu, layout, 0, (nm,))
+    return res
+
+
+@pytest.mark.parametrize("layout", ["soa", "aos"])
+@pytest.mark.parametrize("n,m,nm", CASES)
+def test_imm_goldens(n, m, nm, layout):
+    """every track of the bank runs the golden sequence (N not a multiple of the workgroup)."""
+    from gpu_util import tile_tracks
+    g = golden("imm")
+    p = f"n{n}m{m}k{nm}_"
+    N = 300
+    mu0 = g[p + "mu0"] / g[p + "mu0"].sum()
+    r = run_imm(tile_tracks(g[p + "xs0"], N), tile_tracks(g[p + "Ps0"], N), tile_tracks(mu0, N), g[p + "M"],
+                tile_tracks(g[p + "zs"], N, axis=1), g[p + "Fs"], g[p + "Qs"], g[p + "Hs"], g[p + "Rs"], layout)
+    for trk in (0, 63, 255, 256, N - 1):
+        assert rel_err_rows(r["x_out"][:, trk], g[p + "x"]) < TOL and rel_err_rows(r["P_out"][:, trk], g[p + "P"]) < TOL
+        assert rel_err_rows(r["x_prior_out"][:, trk], g[p + "xp"]) < TOL
+        assert rel_err_rows(r["P_prior_out"][:, trk], g[p + "Pp"]) < TOL
+        assert np.allclose(r["mu_out"][:, trk], g[p + "mu"], rtol=1e-9, atol=1e-14)
+        assert np.allclose(r["likelihood_out"][:, trk], g[p + "L"], rtol=1e-9, atol=1e-300)
+        assert rel_err_rows(r["xs"][trk], g[p + "xs_final"]) < TOL and rel_err_rows(r["Ps"][trk], g[p + "Ps_final"]) < TOL
+        assert np.allclose(r["mu"][trk], g[p + "mu"][-1], rtol=1e-9, atol=1e-14)
+
+
+@pytest.mark.parametrize("layout", ["soa", "aos"])
+@pytest.mark.parametrize("n,m,nm", [(4, 2, 2), (4, 2, 3), (6, 3, 3)])
+def test_imm_seeded_bank_vs_oracle(n, m, nm, layout):
+    """independent tracks (own states, measurements and mode probabilities) against the oracle."""
+    from oracle import imm_oracle
+    rs = np.random.RandomState(77 + n + nm)
+    N, T = 1000, 25
+    Fs = np.array([stable_F(rs, n) for _ in range(nm)])
+    Qs = np.array([spd(rs, n, 0.05 * (j + 1)) for j in range(nm)])
+    Hs = np.array([rs.randn(m, n)] * nm)
+    Rs = np.array([spd(rs, m, 0.5) for _ in range(nm)])
+    M = rs.rand(nm, nm) + 2 * np.eye(nm)
+    M /= M.sum(axis=1, keepdims=True)
+    xs0 = rs.randn(N, nm, n)
+    Ps0 = np.array([[spd(rs, n, 2.0) for _ in range(nm)] for _ in range(N)])
+    mu0 = rs.rand(N, nm) + 0.1
+    mu0 /= mu0.sum(axis=1, keepdims=True)
+    zs = rs.randn(T, N, m) * 2
+    r = run_imm(xs0, Ps0, mu0, M, zs, Fs, Qs, Hs, Rs, layout)
+    for trk in (0, 1, 255, 256, 511, N - 1):
+        x, P, mu, xp, Pp, L = imm_oracle.imm_batch(xs0[trk], Ps0[trk], mu0[trk], M, zs[:, trk], Fs, Qs, Hs, Rs)
+        assert rel_err_rows(r["x_out"][:, trk], x) < TOL and rel_err_rows(r["P_out"][:, trk], P) < TOL
+        assert rel_err_rows(r["x_prior_out"][:, trk], xp) < TOL and rel_err_rows(r["P_prior_out"][:, trk], Pp) < TOL
+        assert np.allclose(r["mu_out"][:, trk], mu, rtol=1e-9, atol=1e-14)
+        assert np.allclose(r["likelihood_out"][:, trk], L, rtol=1e-9, atol=1e-300)
+    # properties that hold for every track: mode probabilities sum to one, P symmetric
+    assert np.abs(r["mu_out"].sum(axis=-1) - 1).max() < 1e-14
+    assert np.abs(r["P_out"] - np.swapaxes(r["P_out"], -1, -2)).max() == 0.0
+
+
+def _make_filters(g, p, n, m, nm, column):
+    from filterpy_amd.kalman import KalmanFilter
+    fs = []
+    for j in range(nm):
+        f = KalmanFilter(dim_x=n, dim_z=m)
+        f.x = g[p + "xs0"][j].reshape(-1, 1).copy() if column else g[p + "xs0"][j].copy()
+        f.P, f.F, f.Q, f.H, f.R = (g[p + k][j].copy() for k in ("Ps0", "Fs", "Qs", "Hs", "Rs"))
+        fs.append(f)
+    return fs
+
+
+@pytest.mark.parametrize("column", [False, True])
+@pytest.mark.parametrize("n,m,nm", [(2, 1, 2), (4, 2, 3)])
+def test_imm_class_drop_in(n, m, nm, column):
+    """the reference's own usage: imm.predict(); imm.update(z) in a loop, attributes after each call."""
+    from filterpy_amd.kalman import IMMEstimator
+    g = golden("imm")
+    p = f"n{n}m{m}k{nm}_"
+    imm = IMMEstimator(_make_filters(g, p, n, m, nm, column), g[p + "mu0"], g[p + "M"])
+    shp = (lambda a: a.reshape(-1, 1)) if column else (lambda a: a)
+    for t in range(10):
+        imm.predict()
+        assert imm.x.shape == ((n, 1) if column else (n,))
+        assert rel_err_rows(imm.x_prior, shp(g[p + "xp"][t])) < TOL and rel_err_rows(imm.P_prior, g[p + "Pp"][t]) < TOL
+        z = g[p + "zs"][t]
+        imm.update(z.reshape(-1, 1) if column else z)
+        assert rel_err_rows(imm.x, shp(g[p + "x"][t])) < TOL and rel_err_rows(imm.P, g[p + "P"][t]) < TOL
+        assert rel_err_rows(imm.x_post, shp(g[p + "x"][t])) < TOL
+        assert np.allclose(imm.mu, g[p + "mu"][t], rtol=1e-9, atol=1e-14)
+        assert np.allclose(imm.likelihood, g[p + "L"][t], rtol=1e-9, atol=1e-300)
+        assert imm.filters[0].x.shape == ((n, 1) if column else (n,))
+    # the remaining steps in one launch; the object ends where the reference ends
+    xs, Ps, mus = imm.batch_filter(g[p + "zs"][10:])
+    assert rel_err_rows(xs.reshape(-1, n), g[p + "x"][10:]) < TOL and rel_err_rows(Ps, g[p + "P"][10:]) < TOL
+    assert np.allclose(mus, g[p + "mu"][10:], rtol=1e-9, atol=1e-14)
+    for j in range(nm):
+        assert rel_err_rows(imm.filters[j].x.reshape(-1), g[p + "xs_final"][j]) < TOL
+        assert rel_err_rows(imm.filters[j].P, g[p + "Ps_final"][j]) < TOL
+    cbar = imm.mu @ g[p + "M"]
+    assert np.allclose(imm.cbar, cbar, rtol=1e-13) and imm.omega.shape == (nm, nm)
+
+
+def test_imm_bank_class():
+    from filterpy_amd.kalman import IMMEstimator
+    from gpu_util import tile_tracks
+    g = golden("imm")
+    n, m, nm = 4, 2, 2
+    p = f"n{n}m{m}k{nm}_"
+    N = 130
+    imm = IMMEstimator(_make_filters(g, p, n, m, nm, False), g[p + "mu0"], g[p + "M"], n_tracks=N)
+    assert imm.x.shape == (N, n) and imm.mu.shape == (N, nm)
+    xs, Ps, mus, xp, Pp = imm.batch_filter(tile_tracks(g[p + "zs"], N, axis=1), return_priors=True)
+    assert xs.shape == (30, N, n) and Ps.shape == (30, N, n, n) and mus.shape == (30, N, nm)
+    for trk in (0, 64, N - 1):
+        assert rel_err_rows(xs[:, trk], g[p + "x"]) < TOL and rel_err_rows(Ps[:, trk], g[p + "P"]) < TOL
+        assert rel_err_rows(xp[:, trk], g[p + "xp"]) < TOL and rel_err_rows(Pp[:, trk], g[p + "Pp"]) < TOL
+    assert imm.filters[1].x.shape == (N, n)
+
+
+def test_imm_rejects_what_the_kernel_cannot_do():
+    from filterpy_amd.kalman import IMMEstimator, KalmanFilter
+    fs = [KalmanFilter(dim_x=2, dim_z=1) for _ in range(2)]
+    with pytest.raises(ValueError):
+        IMMEstimator(fs[:1], [1.0], np.eye(1))
+    imm = IMMEstimator(fs, [0.5, 0.5], np.array([[0.9, 0.1], [0.1, 0.9]]))
+    with pytest.raises(NotImplementedError):
+        imm.predict(u=np.zeros(1))
+    with pytest.raises(NotImplementedError):
+        imm.update(None)
+    with pytest.raises(NotImplementedError):
+        IMMEstimator([KalmanFilter(dim_x=2, dim_z=1) for _ in range(4)], [1, 1, 1, 1], np.full((4, 4), 0.25))

@@ -191,6 +191,53 @@ def config_generic(layout, N, T):
         emit(f"KF (4,2) {name} N={N} {layout}", N * T, "track-steps", ms, 8 * (m + 2 * n + 2 * n * n) + extra)
 
 
+def config_imm(layout, n, m, nm, N, T):
+    """N banks of nm filters, T x {IMM predict; update} in one launch.
+    Algorithmic bytes per bank-step: z in, combined x, P and mu out."""
+    import torch
+    from filterpy_amd import _engine as E
+    from oracle import imm_oracle
+    rs = np.random.RandomState(100 * n + 10 * m + nm)
+    Fs = np.array([np.eye(n) + 0.03 * (j + 1) * rs.randn(n, n) for j in range(nm)])
+    Qs = np.array([0.05 * (j + 1) * np.eye(n) for j in range(nm)])
+    Hs = np.array([np.eye(m, n)] * nm)
+    Rs = np.array([0.5 * np.eye(m)] * nm)
+    M = np.full((nm, nm), 0.05 / (nm - 1)) + (0.95 - 0.05 / (nm - 1)) * np.eye(nm)
+    dev = torch.device("cuda")
+    g = torch.Generator(device=dev)
+    g.manual_seed(8)
+    z = torch.randn((T, N, m) if layout == "aos" else (T, m, N), generator=g, device=dev, dtype=torch.float64)
+    xs0 = torch.zeros((N, nm * n) if layout == "aos" else (nm * n, N), dtype=torch.float64, device=dev)
+    Ps0 = (4.0 * torch.eye(n, dtype=torch.float64, device=dev)).reshape(1, n * n).repeat(N, nm)
+    Ps0 = Ps0.contiguous() if layout == "aos" else Ps0.T.contiguous()
+    mu0 = torch.full((N, nm) if layout == "aos" else (nm, N), 1.0 / nm, dtype=torch.float64, device=dev)
+    xs, Ps, mu = xs0.clone(), Ps0.clone(), mu0.clone()
+    out = dict(x_out=E.alloc_records((T,), N, n, layout), P_out=E.alloc_records((T,), N, n * n, layout),
+               mu_out=E.alloc_records((T,), N, nm, layout))
+    st = torch.zeros(N, dtype=torch.int32, device=dev)
+    d = [E.dev(a) for a in (Fs, Qs, Hs, Rs, M)]
+
+    def run():
+        xs.copy_(xs0)
+        Ps.copy_(Ps0)
+        mu.copy_(mu0)
+        E.imm_batch(n, m, nm, N, T, layout, *d, z, xs, Ps, mu, status=st, **out)
+    ms = timeit(run)
+    assert not st.any()
+    sample = [0, 255, 256, N - 1]
+    zs_h = (z[:, sample] if layout == "aos" else z[:, :, sample].permute(0, 2, 1)).cpu().numpy()
+    P_got = E.from_records(out["P_out"], layout, 1, (n, n))[:, sample]
+    mu_got = E.from_records(out["mu_out"], layout, 1, (nm,))[:, sample]
+    par, parmu = 0.0, 0.0
+    for k in range(4):
+        r = imm_oracle.imm_batch(np.zeros((nm, n)), np.tile(4 * np.eye(n), (nm, 1, 1)), np.full(nm, 1.0 / nm), M,
+                                 zs_h[:, k], Fs, Qs, Hs, Rs)
+        par = max(par, rel(P_got[:, k].reshape(-1, n * n), r[1].reshape(-1, n * n)))
+        parmu = max(parmu, float(np.max(np.abs(mu_got[:, k] - r[2]))))
+    emit(f"IMM ({n},{m}) x{nm} models N={N} {layout}", N * T, "bank-steps", ms, 8 * (m + n + n * n + nm),
+         parity_max_rel=par, mu_max_abs=parmu, filter_steps_per_s=N * T * nm / (ms * 1e-3))
+
+
 def config4(layout, N, T):
     import torch
     from filterpy_amd import _engine as E
@@ -289,5 +336,10 @@ if __name__ == "__main__":
             config_kf(lay, 6, 3, 300_000, a.T)
             config_kf(lay, 4, 2, 500_000, a.T)
             config_kf(lay, 2, 1, 2_000_000, a.T)
+        if "8" in a.configs:
+            config_imm(lay, 4, 2, 2, 500_000, a.T)
+            config_imm(lay, 4, 2, 3, 300_000, a.T)
+            config_imm(lay, 6, 3, 2, 200_000, a.T)
+            config_imm(lay, 2, 1, 2, 1_000_000, a.T)
     if "5" in a.configs:
         config5()
