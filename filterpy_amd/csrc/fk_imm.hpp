@@ -49,29 +49,36 @@ template <int NX, int NM, class Model>
 FK_HD void imm_predict(double (&xs)[NM][NX], double (&Ps)[NM][NX * (NX + 1) / 2], const double (&mu)[NM],
                        const double (&cbar)[NM], const double *M, const Model (&mods)[NM])
 {
-    constexpr int PL = NX * (NX + 1) / 2;
-    double mx[NM][NX], mP[NM][PL];
+    // Mixed covariances are formed ELEMENT BY ELEMENT, in place: element (r,c) of every mixed P_j
+    // needs only element (r,c) of the old P_i and the spreads y_ij = x_i - x0_j, so the bank is never
+    // held twice (same operations and order per element as the reference's loop over filters).
+    double w[NM][NM], mx[NM][NX], y[NM][NM][NX];
     FK_UNROLL for (int j = 0; j < NM; ++j) {
-        double w[NM];
-        FK_UNROLL for (int i = 0; i < NM; ++i) w[i] = (M[i * NM + j] * mu[i]) / cbar[j];
+        FK_UNROLL for (int i = 0; i < NM; ++i) w[i][j] = (M[i * NM + j] * mu[i]) / cbar[j];
         FK_UNROLL for (int r = 0; r < NX; ++r) {
             double acc = 0.0;
-            FK_UNROLL for (int i = 0; i < NM; ++i) acc = fma(xs[i][r], w[i], acc);
+            FK_UNROLL for (int i = 0; i < NM; ++i) acc = fma(xs[i][r], w[i][j], acc);
             mx[j][r] = acc;
         }
-        FK_UNROLL for (int k = 0; k < PL; ++k) mP[j][k] = 0.0;
-        FK_UNROLL for (int i = 0; i < NM; ++i) {
-            double y[NX];
-            FK_UNROLL for (int r = 0; r < NX; ++r) y[r] = xs[i][r] - mx[j][r];
-            FK_UNROLL for (int r = 0; r < NX; ++r)
-                FK_UNROLL for (int c = r; c < NX; ++c)
-                    mP[j][sym_idx<NX>(r, c)] = fma(w[i], fma(y[r], y[c], Ps[i][sym_idx<NX>(r, c)]), mP[j][sym_idx<NX>(r, c)]);
+    }
+    FK_UNROLL for (int j = 0; j < NM; ++j)
+        FK_UNROLL for (int i = 0; i < NM; ++i)
+            FK_UNROLL for (int r = 0; r < NX; ++r) y[i][j][r] = xs[i][r] - mx[j][r];
+    FK_STAGE();
+    FK_UNROLL for (int r = 0; r < NX; ++r) {
+        FK_UNROLL for (int c = r; c < NX; ++c) {
+            double acc[NM];
+            FK_UNROLL for (int j = 0; j < NM; ++j) {
+                acc[j] = 0.0;
+                FK_UNROLL for (int i = 0; i < NM; ++i)
+                    acc[j] = fma(w[i][j], fma(y[i][j][r], y[i][j][c], Ps[i][sym_idx<NX>(r, c)]), acc[j]);
+            }
+            FK_UNROLL for (int j = 0; j < NM; ++j) Ps[j][sym_idx<NX>(r, c)] = acc[j];
         }
         FK_STAGE();
     }
     FK_UNROLL for (int j = 0; j < NM; ++j) {
         FK_UNROLL for (int r = 0; r < NX; ++r) xs[j][r] = mx[j][r];
-        FK_UNROLL for (int k = 0; k < PL; ++k) Ps[j][k] = mP[j][k];
         kf_predict_sym<NX>(xs[j], Ps[j], mods[j], 1.0);
     }
 }

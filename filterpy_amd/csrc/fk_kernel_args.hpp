@@ -42,4 +42,14 @@ struct UkfArgs {
     double scale;
 };
 
+struct ImmArgs {
+    const double *F, *Q, *H, *R, *Mt, *z;
+    double *xs, *Ps, *mu;
+    double *x_out, *P_out, *mu_out, *xp_out, *Pp_out, *L_out;
+    int32_t *status;
+    long N, T;
+    int n, m;
+    int phase;
+};
+
 }  // namespace fk

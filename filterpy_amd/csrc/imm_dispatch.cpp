@@ -1,0 +1,63 @@
+// imm_dispatch.cpp -- C ABI entry of the batched IMM estimator: argument checks and the choice of
+// the (dim_x, dim_z, n_models) instantiation of imm_kernels.hip.
+#include <hip/hip_runtime.h>
+
+#include "fk_device.hpp"
+#include "fk_kernel_args.hpp"
+#include "../../include/filterhip.h"
+
+using namespace fk;
+
+#define FK_IMM_INST(NX, NZ, NM, W) void launch_imm_##NX##_##NZ##_##NM(const ImmArgs &, int, int, hipStream_t);
+#include "fk_dims_imm.def"
+#undef FK_IMM_INST
+
+static int fail(int code, const char *msg)
+{
+    set_last_error(msg);
+    return code;
+}
+
+extern "C" int fk_imm_batch_f64(const fk_imm_desc *d, const double *F, const double *Q, const double *H,
+                                const double *R, const double *M, const double *z, double *xs, double *Ps,
+                                double *mu, double *x_out, double *P_out, double *mu_out, double *x_prior_out,
+                                double *P_prior_out, double *likelihood_out, int32_t *status, void *stream)
+{
+    if (!d) return fail(FK_ERR_BAD_ARG, "desc is NULL");
+    if (d->n < 1 || d->n > 6 || d->m < 1 || d->m > 3 || d->n_models < 2 || d->n_models > 3)
+        return fail(FK_ERR_UNSUPPORTED, "IMM: dim_x 1..6, dim_z 1..3, 2..3 models");
+    if (d->layout != FK_LAYOUT_AOS && d->layout != FK_LAYOUT_SOA) return fail(FK_ERR_BAD_ARG, "IMM: bad layout");
+    if (d->phase < FK_IMM_STEP || d->phase > FK_IMM_UPDATE) return fail(FK_ERR_BAD_ARG, "IMM: bad phase");
+    const bool needs_z = (d->phase == FK_IMM_STEP && d->T > 0) || d->phase == FK_IMM_UPDATE;
+    if (d->N < 0 || d->T < 0 || !F || !Q || !H || !R || !M || !xs || !Ps || !mu || (needs_z && !z))
+        return fail(FK_ERR_BAD_ARG, "IMM: bad argument");
+    if ((double)d->N * d->n_models * d->n * d->n * 8.0 >= 4294967296.0)
+        return fail(FK_ERR_UNSUPPORTED, "IMM: record block >= 4 GiB, split the batch");
+    if (d->N == 0) return FK_OK;
+    ImmArgs a{};
+    a.F = F; a.Q = Q; a.H = H; a.R = R; a.Mt = M;
+    a.z = z ? z : xs;   // predict-only: the measurement is read but never used
+    a.xs = xs; a.Ps = Ps; a.mu = mu;
+    a.x_out = x_out; a.P_out = P_out; a.mu_out = mu_out; a.xp_out = x_prior_out; a.Pp_out = P_prior_out;
+    a.L_out = likelihood_out; a.status = status; a.N = d->N; a.T = d->phase == FK_IMM_STEP ? d->T : 1;
+    a.n = d->n; a.m = d->m; a.phase = d->phase;
+    // which compiled output set (if any) the given pointers form; the single-phase calls use the
+    // run-time-tested kernel (one step, launch-bound anyway)
+    const int post = (x_out && P_out && mu_out) ? 1 : ((x_out || P_out || mu_out) ? -1 : 0);
+    const int prior = (x_prior_out && P_prior_out) ? 2 : ((x_prior_out || P_prior_out) ? -1 : 0);
+    int mask = (post < 0 || prior < 0) ? -1 : (post | prior | (likelihood_out ? 4 : 0));
+    if (mask != 0 && mask != 1 && mask != 7) mask = -1;
+    if (d->phase != FK_IMM_STEP) mask = -1;
+    hipStream_t s = (hipStream_t)stream;
+    const int cls = (d->n <= 2 && d->m <= 1) ? 0 : (d->n <= 4 && d->m <= 2) ? 1 : 2;
+    if (d->n_models == 2) {
+        if (cls == 0) launch_imm_2_1_2(a, d->layout, mask, s);
+        else if (cls == 1) launch_imm_4_2_2(a, d->layout, mask, s);
+        else launch_imm_6_3_2(a, d->layout, mask, s);
+    } else {
+        if (cls == 0) launch_imm_2_1_3(a, d->layout, mask, s);
+        else if (cls == 1) launch_imm_4_2_3(a, d->layout, mask, s);
+        else launch_imm_6_3_3(a, d->layout, mask, s);
+    }
+    return check_launch("imm_kernel");
+}

@@ -21,25 +21,23 @@
 #include "fk_kernel_args.hpp"
 #include "../../include/filterhip.h"
 
+#ifndef FK_NX
+#error "compile with -DFK_NX= -DFK_NZ= -DFK_NM= -DFK_IMM_WAVES= (see Makefile, fk_dims_imm.def)"
+#endif
+
 namespace fk {
 
-struct ImmArgs {
-    const double *F, *Q, *H, *R, *Mt, *z;
-    double *xs, *Ps, *mu;
-    double *x_out, *P_out, *mu_out, *xp_out, *Pp_out, *L_out;
-    int32_t *status;
-    long N, T;
-    int n, m;
-    int phase;
-};
 
-template <int NX, int NZ, int NM, int LAYOUT>
-__global__ void __launch_bounds__(BLOCK, 1)
+// OUTS: which per-step outputs this instantiation writes -- bit 0: x_out, P_out, mu_out; bit 1: the
+// prior estimate; bit 2: likelihoods -- unconditionally (a store under a run-time pointer test costs
+// the whole kernel its register allocation); OUTS < 0: tested at run time (any subset).
+template <int NX, int NZ, int NM, int LAYOUT, bool EXACT, int OUTS>
+__global__ void __launch_bounds__(BLOCK, (EXACT && OUTS >= 0) ? FK_IMM_WAVES : 1)
 imm_kernel(const ImmArgs a)
 {
     using LM = LdsModel<NX, NZ>;
     __shared__ double smem[NM * LM::SIZE + NM * NM];
-    const int n = a.n, m = a.m;
+    const int n = EXACT ? NX : a.n, m = EXACT ? NZ : a.m;   // EXACT: no padding guards, no branches
     const long N = a.N;
     FK_UNROLL for (int j = 0; j < NM; ++j) {
         double *s = smem + j * LM::SIZE;
@@ -77,33 +75,33 @@ imm_kernel(const ImmArgs a)
         double z[NZ];
         {
             const RecView<LAYOUT> vz(a.z + t * N * m, ln, m);
-            FK_UNROLL for (int r = 0; r < NZ; ++r) z[r] = (r < m && a.phase != FK_IMM_PREDICT) ? vz.load(r) : 0.0;
+            FK_UNROLL for (int r = 0; r < NZ; ++r) z[r] = (r < m) ? vz.load(r) : 0.0;
         }
         double cbar[NM];
         imm_mixing_cbar<NM>(mu, sM, cbar);
         if (a.phase != FK_IMM_UPDATE) {
         imm_predict<NX, NM>(xs, Ps, mu, cbar, sM, mods);
-        if (a.xp_out || a.Pp_out) {
+        if (OUTS < 0 ? (a.xp_out || a.Pp_out) : (OUTS & 2) != 0) {
             double x[NX], P[NX * NX];
             imm_estimate<NX, NM>(xs, Ps, mu, x, P);
-            if (a.xp_out) store_rec<NX, 1, LAYOUT, false>(x, a.xp_out + t * N * n, ln, n, 1);
-            if (a.Pp_out) store_rec<NX, NX, LAYOUT, false>(P, a.Pp_out + t * N * n * n, ln, n, n);
+            if (OUTS >= 0 || a.xp_out) store_rec<NX, 1, LAYOUT, EXACT>(x, a.xp_out + t * N * n, ln, n, 1);
+            if (OUTS >= 0 || a.Pp_out) store_rec<NX, NX, LAYOUT, EXACT>(P, a.Pp_out + t * N * n * n, ln, n, n);
         }
         }
         if (a.phase == FK_IMM_PREDICT) break;
         double L[NM];
         st |= imm_update<NX, NZ, NM>(xs, Ps, mu, cbar, z, m, mods, L);
-        {
+        if (OUTS < 0 ? (a.x_out || a.P_out) : (OUTS & 1) != 0) {
             double x[NX], P[NX * NX];
             imm_estimate<NX, NM>(xs, Ps, mu, x, P);
-            if (a.x_out) store_rec<NX, 1, LAYOUT, false>(x, a.x_out + t * N * n, ln, n, 1);
-            if (a.P_out) store_rec<NX, NX, LAYOUT, false>(P, a.P_out + t * N * n * n, ln, n, n);
+            if (OUTS >= 0 || a.x_out) store_rec<NX, 1, LAYOUT, EXACT>(x, a.x_out + t * N * n, ln, n, 1);
+            if (OUTS >= 0 || a.P_out) store_rec<NX, NX, LAYOUT, EXACT>(P, a.P_out + t * N * n * n, ln, n, n);
         }
-        if (a.mu_out) {
+        if (OUTS < 0 ? a.mu_out != nullptr : (OUTS & 1) != 0) {
             const RecView<LAYOUT> v(a.mu_out + t * N * NM, ln, NM);
             FK_UNROLL for (int j = 0; j < NM; ++j) v.store(j, mu[j]);
         }
-        if (a.L_out) {
+        if (OUTS < 0 ? a.L_out != nullptr : (OUTS & 4) != 0) {
             const RecView<LAYOUT> v(a.L_out + t * N * NM, ln, NM);
             FK_UNROLL for (int j = 0; j < NM; ++j) v.store(j, L[j]);
         }
@@ -124,55 +122,27 @@ imm_kernel(const ImmArgs a)
     }
 }
 
-static int fail(int code, const char *msg)
-{
-    set_last_error(msg);
-    return code;
-}
-
-template <int NX, int NZ, int NM>
-static void launch(const ImmArgs &a, int layout, hipStream_t s)
-{
-    const dim3 grid((unsigned)((a.N + BLOCK - 1) / BLOCK)), block(BLOCK);
-    if (layout == FK_LAYOUT_SOA) hipLaunchKernelGGL((imm_kernel<NX, NZ, NM, LAYOUT_SOA>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((imm_kernel<NX, NZ, NM, LAYOUT_AOS>), grid, block, 0, s, a);
-}
-
 }  // namespace fk
 
 using namespace fk;
 
-extern "C" int fk_imm_batch_f64(const fk_imm_desc *d, const double *F, const double *Q, const double *H,
-                                const double *R, const double *M, const double *z, double *xs, double *Ps,
-                                double *mu, double *x_out, double *P_out, double *mu_out, double *x_prior_out,
-                                double *P_prior_out, double *likelihood_out, int32_t *status, void *stream)
+template <int LAYOUT>
+static void launch_layout(const ImmArgs &a, int mask, hipStream_t s)
 {
-    if (!d) return fail(FK_ERR_BAD_ARG, "desc is NULL");
-    if (d->n < 1 || d->n > 6 || d->m < 1 || d->m > 3 || d->n_models < 2 || d->n_models > 3)
-        return fail(FK_ERR_UNSUPPORTED, "IMM: dim_x 1..6, dim_z 1..3, 2..3 models");
-    if (d->layout != FK_LAYOUT_AOS && d->layout != FK_LAYOUT_SOA) return fail(FK_ERR_BAD_ARG, "IMM: bad layout");
-    if (d->phase < FK_IMM_STEP || d->phase > FK_IMM_UPDATE) return fail(FK_ERR_BAD_ARG, "IMM: bad phase");
-    const bool needs_z = (d->phase == FK_IMM_STEP && d->T > 0) || d->phase == FK_IMM_UPDATE;
-    if (d->N < 0 || d->T < 0 || !F || !Q || !H || !R || !M || !xs || !Ps || !mu || (needs_z && !z))
-        return fail(FK_ERR_BAD_ARG, "IMM: bad argument");
-    if ((double)d->N * d->n_models * d->n * d->n * 8.0 >= 4294967296.0)
-        return fail(FK_ERR_UNSUPPORTED, "IMM: record block >= 4 GiB, split the batch");
-    if (d->N == 0) return FK_OK;
-    ImmArgs a{};
-    a.F = F; a.Q = Q; a.H = H; a.R = R; a.Mt = M; a.z = z; a.xs = xs; a.Ps = Ps; a.mu = mu;
-    a.x_out = x_out; a.P_out = P_out; a.mu_out = mu_out; a.xp_out = x_prior_out; a.Pp_out = P_prior_out;
-    a.L_out = likelihood_out; a.status = status; a.N = d->N; a.T = d->phase == FK_IMM_STEP ? d->T : 1;
-    a.n = d->n; a.m = d->m; a.phase = d->phase;
-    hipStream_t s = (hipStream_t)stream;
-    const int cls = (d->n <= 2 && d->m <= 1) ? 0 : (d->n <= 4 && d->m <= 2) ? 1 : 2;
-    if (d->n_models == 2) {
-        if (cls == 0) launch<2, 1, 2>(a, d->layout, s);
-        else if (cls == 1) launch<4, 2, 2>(a, d->layout, s);
-        else launch<6, 3, 2>(a, d->layout, s);
-    } else {
-        if (cls == 0) launch<2, 1, 3>(a, d->layout, s);
-        else if (cls == 1) launch<4, 2, 3>(a, d->layout, s);
-        else launch<6, 3, 3>(a, d->layout, s);
-    }
-    return check_launch("imm_kernel");
+    constexpr int NX = FK_NX, NZ = FK_NZ, NM = FK_NM;
+    const dim3 grid((unsigned)((a.N + BLOCK - 1) / BLOCK)), block(BLOCK);
+    const bool exact = a.n == NX && a.m == NZ;
+    if (exact && mask == 0) hipLaunchKernelGGL((imm_kernel<NX, NZ, NM, LAYOUT, true, 0>), grid, block, 0, s, a);
+    else if (exact && mask == 1) hipLaunchKernelGGL((imm_kernel<NX, NZ, NM, LAYOUT, true, 1>), grid, block, 0, s, a);
+    else if (exact && mask == 7) hipLaunchKernelGGL((imm_kernel<NX, NZ, NM, LAYOUT, true, 7>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((imm_kernel<NX, NZ, NM, LAYOUT, false, -1>), grid, block, 0, s, a);
+}
+
+#define FK_CAT_(a, b, c, d) a##b##_##c##_##d
+#define FK_CAT(a, b, c, d) FK_CAT_(a, b, c, d)
+// launch_imm_<NX>_<NZ>_<NM>: mask = OUTS bits when the outputs form one of the compiled sets, else -1
+void FK_CAT(launch_imm_, FK_NX, FK_NZ, FK_NM)(const ImmArgs &a, int layout, int mask, hipStream_t s)
+{
+    if (layout == FK_LAYOUT_SOA) launch_layout<LAYOUT_SOA>(a, mask, s);
+    else launch_layout<LAYOUT_AOS>(a, mask, s);
 }
