@@ -39,7 +39,7 @@ class fk_ukf_desc(ctypes.Structure):
 
 class fk_imm_desc(ctypes.Structure):
     _fields_ = [("n", c_i32), ("m", c_i32), ("n_models", c_i32), ("layout", c_i32), ("N", c_i64), ("T", c_i64),
-                ("phase", c_i32), ("reserved", c_i32)]
+                ("phase", c_i32), ("flags", c_i32)]
 
 
 class FilterHipError(RuntimeError):

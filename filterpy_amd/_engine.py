@@ -161,9 +161,9 @@ def ukf_linear_batch(n, m, N, T, layout, scale, F, H, Q, R, Wm, Wc, z, x, P, *, 
 
 
 def imm_batch(n, m, n_models, N, T, layout, F, Q, H, R, M, z, xs, Ps, mu, *, x_out=None, P_out=None,
-              mu_out=None, x_prior_out=None, P_prior_out=None, likelihood_out=None, status=None, phase=0):
+              mu_out=None, x_prior_out=None, P_prior_out=None, likelihood_out=None, status=None, phase=0, mmae=False):
     """fk_imm_batch_f64: T x { IMMEstimator.predict(); IMMEstimator.update(z) } for N banks."""
-    d = _abi.fk_imm_desc(n=n, m=m, n_models=n_models, layout=LAYOUTS[layout], N=N, T=T, phase=phase, reserved=0)
+    d = _abi.fk_imm_desc(n=n, m=m, n_models=n_models, layout=LAYOUTS[layout], N=N, T=T, phase=phase, flags=1 if mmae else 0)
     rc = _abi.lib().fk_imm_batch_f64(d, _ptr(F), _ptr(Q), _ptr(H), _ptr(R), _ptr(M), _ptr(z), _ptr(xs), _ptr(Ps),
                                      _ptr(mu), _ptr(x_out), _ptr(P_out), _ptr(mu_out), _ptr(x_prior_out),
                                      _ptr(P_prior_out), _ptr(likelihood_out), _ptr(status), _stream())

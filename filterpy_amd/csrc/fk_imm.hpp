@@ -32,6 +32,30 @@ FK_HD void imm_estimate(const double (&xs)[NM][NX], const double (&Ps)[NM][NX * 
         FK_UNROLL for (int b = 0; b < a; ++b) P[a * NX + b] = P[b * NX + a];
 }
 
+// MMAEFilterBank's estimate (mmae.py:191-207): x as above; the covariance loop zips the components
+// of x with the filters, i.e. filter k is centred on the SCALAR x[k] and only the first
+// min(dim_x, n_models) filters contribute -- reproduced as the reference computes it.  n = runtime dim_x.
+template <int NX, int NM>
+FK_HD void mmae_estimate(const double (&xs)[NM][NX], const double (&Ps)[NM][NX * (NX + 1) / 2],
+                         const double (&p)[NM], int n, double (&x)[NX], double (&P)[NX * NX])
+{
+    FK_UNROLL for (int a = 0; a < NX; ++a) {
+        double acc = 0.0;
+        FK_UNROLL for (int j = 0; j < NM; ++j) acc = fma(xs[j][a], p[j], acc);
+        x[a] = acc;
+    }
+    FK_UNROLL for (int k = 0; k < NX * NX; ++k) P[k] = 0.0;
+    FK_UNROLL for (int k = 0; k < NM; ++k) {
+        if (k < NX && k < n) {
+            double y[NX];
+            FK_UNROLL for (int a = 0; a < NX; ++a) y[a] = xs[k][a] - x[k];
+            FK_UNROLL for (int a = 0; a < NX; ++a)
+                FK_UNROLL for (int b = 0; b < NX; ++b)
+                    P[a * NX + b] = fma(p[k], fma(y[a], y[b], Ps[k][sym_idx<NX>(a, b)]), P[a * NX + b]);
+        }
+    }
+}
+
 // cbar = mu . M  (IMM.py:244); M row-major NM x NM
 template <int NM>
 FK_HD void imm_mixing_cbar(const double (&mu)[NM], const double *M, double (&cbar)[NM])

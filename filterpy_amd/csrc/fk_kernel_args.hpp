@@ -50,6 +50,7 @@ struct ImmArgs {
     long N, T;
     int n, m;
     int phase;
+    int mmae;
 };
 
 }  // namespace fk

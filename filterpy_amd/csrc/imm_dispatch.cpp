@@ -29,7 +29,7 @@ extern "C" int fk_imm_batch_f64(const fk_imm_desc *d, const double *F, const dou
     if (d->layout != FK_LAYOUT_AOS && d->layout != FK_LAYOUT_SOA) return fail(FK_ERR_BAD_ARG, "IMM: bad layout");
     if (d->phase < FK_IMM_STEP || d->phase > FK_IMM_UPDATE) return fail(FK_ERR_BAD_ARG, "IMM: bad phase");
     const bool needs_z = (d->phase == FK_IMM_STEP && d->T > 0) || d->phase == FK_IMM_UPDATE;
-    if (d->N < 0 || d->T < 0 || !F || !Q || !H || !R || !M || !xs || !Ps || !mu || (needs_z && !z))
+    if (d->N < 0 || d->T < 0 || !F || !Q || !H || !R || (!M && !(d->flags & FK_IMM_FLAG_MMAE)) || !xs || !Ps || !mu || (needs_z && !z))
         return fail(FK_ERR_BAD_ARG, "IMM: bad argument");
     if ((double)d->N * d->n_models * d->n * d->n * 8.0 >= 4294967296.0)
         return fail(FK_ERR_UNSUPPORTED, "IMM: record block >= 4 GiB, split the batch");
@@ -40,14 +40,15 @@ extern "C" int fk_imm_batch_f64(const fk_imm_desc *d, const double *F, const dou
     a.xs = xs; a.Ps = Ps; a.mu = mu;
     a.x_out = x_out; a.P_out = P_out; a.mu_out = mu_out; a.xp_out = x_prior_out; a.Pp_out = P_prior_out;
     a.L_out = likelihood_out; a.status = status; a.N = d->N; a.T = d->phase == FK_IMM_STEP ? d->T : 1;
-    a.n = d->n; a.m = d->m; a.phase = d->phase;
+    a.n = d->n; a.m = d->m; a.phase = d->phase; a.mmae = (d->flags & FK_IMM_FLAG_MMAE) ? 1 : 0;
+    if (a.mmae && (x_prior_out || P_prior_out)) return fail(FK_ERR_BAD_ARG, "MMAE: prior outputs are not defined");
     // which compiled output set (if any) the given pointers form; the single-phase calls use the
     // run-time-tested kernel (one step, launch-bound anyway)
     const int post = (x_out && P_out && mu_out) ? 1 : ((x_out || P_out || mu_out) ? -1 : 0);
     const int prior = (x_prior_out && P_prior_out) ? 2 : ((x_prior_out || P_prior_out) ? -1 : 0);
     int mask = (post < 0 || prior < 0) ? -1 : (post | prior | (likelihood_out ? 4 : 0));
     if (mask != 0 && mask != 1 && mask != 7) mask = -1;
-    if (d->phase != FK_IMM_STEP) mask = -1;
+    if (d->phase != FK_IMM_STEP || a.mmae) mask = -1;   // the general kernel also carries the MMAE arithmetic
     hipStream_t s = (hipStream_t)stream;
     const int cls = (d->n <= 2 && d->m <= 1) ? 0 : (d->n <= 4 && d->m <= 2) ? 1 : 2;
     if (d->n_models == 2) {

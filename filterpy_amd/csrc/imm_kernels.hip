@@ -46,7 +46,7 @@ imm_kernel(const ImmArgs a)
         lds_fill<NZ, NX>(s + LM::OFF_H, a.H + (long)j * m * n, m, n, 0.0, threadIdx.x);
         lds_fill<NZ, NZ>(s + LM::OFF_R, a.R + (long)j * m * m, m, m, 1.0, threadIdx.x);
     }
-    if (threadIdx.x < NM * NM) smem[NM * LM::SIZE + threadIdx.x] = a.Mt[threadIdx.x];
+    if (threadIdx.x < NM * NM) smem[NM * LM::SIZE + threadIdx.x] = a.Mt ? a.Mt[threadIdx.x] : 0.0;
     __syncthreads();
     const double *sM = smem + NM * LM::SIZE;
 
@@ -77,10 +77,20 @@ imm_kernel(const ImmArgs a)
             const RecView<LAYOUT> vz(a.z + t * N * m, ln, m);
             FK_UNROLL for (int r = 0; r < NZ; ++r) z[r] = (r < m) ? vz.load(r) : 0.0;
         }
+        constexpr bool GENERAL = !(EXACT && OUTS >= 0);     // only the general kernel carries MMAE
+        const bool mmae = GENERAL && a.mmae;
         double cbar[NM];
-        imm_mixing_cbar<NM>(mu, sM, cbar);
+        if (mmae) {
+            FK_UNROLL for (int j = 0; j < NM; ++j) cbar[j] = mu[j];      // p_i *= likelihood_i (mmae.py:186-187)
+        } else {
+            imm_mixing_cbar<NM>(mu, sM, cbar);
+        }
         if (a.phase != FK_IMM_UPDATE) {
-        imm_predict<NX, NM>(xs, Ps, mu, cbar, sM, mods);
+        if (mmae) {
+            FK_UNROLL for (int j = 0; j < NM; ++j) kf_predict_sym<NX>(xs[j], Ps[j], mods[j], 1.0);   // mmae.py:153-154
+        } else {
+            imm_predict<NX, NM>(xs, Ps, mu, cbar, sM, mods);
+        }
         if (OUTS < 0 ? (a.xp_out || a.Pp_out) : (OUTS & 2) != 0) {
             double x[NX], P[NX * NX];
             imm_estimate<NX, NM>(xs, Ps, mu, x, P);
@@ -93,7 +103,8 @@ imm_kernel(const ImmArgs a)
         st |= imm_update<NX, NZ, NM>(xs, Ps, mu, cbar, z, m, mods, L);
         if (OUTS < 0 ? (a.x_out || a.P_out) : (OUTS & 1) != 0) {
             double x[NX], P[NX * NX];
-            imm_estimate<NX, NM>(xs, Ps, mu, x, P);
+            if (mmae) mmae_estimate<NX, NM>(xs, Ps, mu, n, x, P);
+            else imm_estimate<NX, NM>(xs, Ps, mu, x, P);
             if (OUTS >= 0 || a.x_out) store_rec<NX, 1, LAYOUT, EXACT>(x, a.x_out + t * N * n, ln, n, 1);
             if (OUTS >= 0 || a.P_out) store_rec<NX, NX, LAYOUT, EXACT>(P, a.P_out + t * N * n * n, ln, n, n);
         }

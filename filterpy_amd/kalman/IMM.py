@@ -36,8 +36,24 @@ class IMMEstimator(object):
         for f in filters:
             if x_shape != np.shape(f.x):
                 raise ValueError('All filters must have the same state dimension')
+        self._init_bank(filters, n_tracks, layout)
+        mu = np.asarray(mu, dtype=np.float64)
+        self.mu = mu / np.sum(mu, axis=-1, keepdims=True)          # IMM.py:129
+        if n_tracks is not None:
+            self.mu = np.broadcast_to(self.mu, (n_tracks, self.N)).copy()
+        self.M = np.asarray(M, dtype=np.float64)
+        self.likelihood = np.zeros(self.N if n_tracks is None else (n_tracks, self.N))
+        self._compute_mixing_probabilities()
+        x, P = self._estimate_host()
+        self._set_estimate(x, P)
+        self.x_prior, self.P_prior = self.x.copy(), self.P.copy()
+        self.x_post, self.P_post = self.x.copy(), self.P.copy()
+
+    def _init_bank(self, filters, n_tracks, layout):
+        """dimensions and the host copy of the bank state (shared with MMAEFilterBank)"""
         self.filters = filters
         self.N = len(filters)
+        self.M = None
         if self.N > 3:
             raise NotImplementedError("the IMM kernel is built for 2 or 3 filters per bank")
         self._nt = n_tracks
@@ -53,23 +69,11 @@ class IMMEstimator(object):
         if n > 6 or m > 3:
             raise NotImplementedError("the IMM kernel is built for dim_x <= 6 and dim_z <= 3")
 
-        mu = np.asarray(mu, dtype=np.float64)
-        self.mu = mu / np.sum(mu, axis=-1, keepdims=True)          # IMM.py:129
-        if n_tracks is not None:
-            self.mu = np.broadcast_to(self.mu, (nt, self.N)).copy()
-        self.M = np.asarray(M, dtype=np.float64)
-
         # bank state on the host, (nt, n_models, ...)
         self._xs = np.stack([np.broadcast_to(np.asarray(f.x, dtype=np.float64).reshape(-1, n), (nt, n))
                              for f in filters], axis=1).copy()
         self._Ps = np.stack([np.broadcast_to(np.asarray(f.P, dtype=np.float64), (nt, n, n))
                              for f in filters], axis=1).copy()
-        self.likelihood = np.zeros(self.N if n_tracks is None else (nt, self.N))
-        self._compute_mixing_probabilities()
-        x, P = self._estimate_host()
-        self._set_estimate(x, P)
-        self.x_prior, self.P_prior = self.x.copy(), self.P.copy()
-        self.x_post, self.P_post = self.x.copy(), self.P.copy()
 
     # ----------------------------------------------------------------- host bookkeeping --
     def _compute_mixing_probabilities(self):
@@ -100,13 +104,18 @@ class IMMEstimator(object):
         self.x = self._shape_x(x)
         self.P = P if self._nt is not None else P[0]
 
-    def _models(self):
+    def _models(self, R=None, H=None):
+        """stacked device models; R / H override every filter's own for this launch
+        (MMAEFilterBank.update(z, R, H), mmae.py:160-186; a scalar R means R * I, kalman_filter.py:525)"""
         n, m = self._n, self._m
         F = np.stack([np.asarray(f.F, dtype=np.float64).reshape(n, n) for f in self.filters])
         Q = np.stack([np.asarray(f.Q, dtype=np.float64).reshape(n, n) for f in self.filters])
-        H = np.stack([np.asarray(f.H, dtype=np.float64).reshape(m, n) for f in self.filters])
-        R = np.stack([np.asarray(f.R, dtype=np.float64).reshape(m, m) for f in self.filters])
-        return [E.dev(np.ascontiguousarray(a)) for a in (F, Q, H, R, self.M)]
+        Hs = np.stack([np.asarray(f.H if H is None else H, dtype=np.float64).reshape(m, n) for f in self.filters])
+        if R is not None and np.isscalar(R):
+            R = np.eye(m) * R
+        Rs = np.stack([np.asarray(f.R if R is None else R, dtype=np.float64).reshape(m, m) for f in self.filters])
+        out = [E.dev(np.ascontiguousarray(a)) for a in (F, Q, Hs, Rs)]
+        return out + [None if self.M is None else E.dev(np.ascontiguousarray(self.M))]
 
     def _pull_from_filters(self):
         """The reference reads f.x / f.P at every call, so user edits between calls must count."""
@@ -123,10 +132,10 @@ class IMMEstimator(object):
             else:
                 f.x, f.P = self._xs[:, j].copy(), self._Ps[:, j].copy()
 
-    def _launch(self, phase, zs, T, want_prior, want_post):
+    def _launch(self, phase, zs, T, want_prior, want_post, mmae=False, R=None, H=None):
         nt, n, m, nm, lay = self._nt or 1, self._n, self._m, self.N, self._layout
         self._pull_from_filters()
-        F, Q, H, R, M = self._models()
+        F, Q, H, R, M = self._models(R, H)
         xs = E.to_records(self._xs.reshape(nt, nm * n), lay, 0)
         Ps = E.to_records(self._Ps.reshape(nt, nm * n * n), lay, 0)
         mu = E.to_records(self.mu.reshape(nt, nm), lay, 0)
@@ -138,7 +147,7 @@ class IMMEstimator(object):
         if want_prior:
             out.update(x_prior_out=E.alloc_records((T,), nt, n, lay), P_prior_out=E.alloc_records((T,), nt, n * n, lay))
         status = torch.zeros(nt, dtype=torch.int32, device=xs.device)
-        E.imm_batch(n, m, nm, nt, T, lay, F, Q, H, R, M, z, xs, Ps, mu, status=status, phase=phase, **out)
+        E.imm_batch(n, m, nm, nt, T, lay, F, Q, H, R, M, z, xs, Ps, mu, status=status, phase=phase, mmae=mmae, **out)
         E.raise_on_status(status, "IMMEstimator")
         self._xs = E.from_records(xs, lay, 0, (nm, n)).copy()
         self._Ps = E.from_records(Ps, lay, 0, (nm, n, n)).copy()

@@ -6,3 +6,4 @@ from .sigma_points import MerweScaledSigmaPoints, JulierSigmaPoints  # noqa: F40
 from .unscented_transform import unscented_transform  # noqa: F401
 from .UKF import UnscentedKalmanFilter  # noqa: F401
 from .IMM import IMMEstimator  # noqa: F401
+from .mmae import MMAEFilterBank  # noqa: F401

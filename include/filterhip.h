@@ -229,10 +229,11 @@ typedef struct fk_imm_desc {
     int32_t layout;
     int64_t N, T;
     int32_t phase;        /* FK_IMM_STEP: T x {predict; update}; FK_IMM_PREDICT / FK_IMM_UPDATE: that half once */
-    int32_t reserved;
+    int32_t flags;        /* FK_IMM_FLAG_MMAE: MMAEFilterBank arithmetic (below) */
 } fk_imm_desc;
 
 enum { FK_IMM_STEP = 0, FK_IMM_PREDICT = 1, FK_IMM_UPDATE = 2 };
+enum { FK_IMM_FLAG_MMAE = 1 };
 
 /* filterpy.kalman.IMMEstimator (filterpy/kalman/IMM.py) for N independent tracks, each with its own
  * bank of n_models linear Kalman filters, T x { predict() (IMM.py:188-222) ; update(z) (IMM.py:160-186) }
@@ -249,7 +250,14 @@ enum { FK_IMM_STEP = 0, FK_IMM_PREDICT = 1, FK_IMM_UPDATE = 2 };
  *   Any output may be NULL.  status [N] or NULL.
  * phase FK_IMM_PREDICT runs IMMEstimator.predict() once (mixing + every filter's predict; writes
  * xs, Ps and the prior outputs [N][..]), FK_IMM_UPDATE runs IMMEstimator.update(z) once (z [N][m];
- * writes xs, Ps, mu and x_out/P_out/mu_out/likelihood_out [N][..]); T is ignored for both. */
+ * writes xs, Ps, mu and x_out/P_out/mu_out/likelihood_out [N][..]); T is ignored for both.
+ *
+ * flags & FK_IMM_FLAG_MMAE: filterpy.kalman.MMAEFilterBank (filterpy/kalman/mmae.py:140-212) on the
+ * same records: no mixing (every filter predicts from its own state, mmae.py:153-154; M is unused and
+ * may be NULL), p_i *= likelihood_i then normalised (mmae.py:185-189; mu holds p), x = sum p_i x_i and
+ * the covariance exactly as mmae.py:205-207 computes it (the loop zips the COMPONENTS of x with the
+ * filters: P = sum over k < min(dim_x, n_models) of p_k (outer(x_k - x[k]) + P_k), reproduced as is).
+ * The prior outputs are not defined for MMAE (the reference's x_prior is a copy of the last x). */
 int fk_imm_batch_f64(const fk_imm_desc *desc,
                      const double *F, const double *Q, const double *H, const double *R,
                      const double *M, const double *z,

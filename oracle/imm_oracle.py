@@ -81,3 +81,37 @@ def imm_batch(xs0, Ps0, mu0, Mtrans, zs, Fs, Qs, Hs, Rs):
         out_x[t], out_P[t] = state_estimate(xs, Ps, mu)
         out_mu[t], out_L[t] = mu, L
     return out_x, out_P, out_mu, out_xp, out_Pp, out_L
+
+
+def mmae_batch(xs0, Ps0, p0, zs, Fs, Qs, Hs, Rs):
+    """T x { bank.predict(); bank.update(z) } of filterpy.kalman.MMAEFilterBank (mmae.py:140-212).
+
+    No mixing; p_i *= likelihood_i, normalised with Python's sum (mmae.py:185-189); x = sum p_i x_i;
+    the covariance loop zips the components of x with the filters (mmae.py:205-207) and is restated
+    as written.  Returns per step x (T,n), P (T,n,n), p (T,nm), likelihoods (T,nm)."""
+    nm = len(Fs)
+    xs = [np.array(x, dtype=float) for x in xs0]
+    Ps = [np.array(P, dtype=float) for P in Ps0]
+    p = np.array(p0, dtype=float)
+    T, n = len(zs), xs[0].shape[0]
+    out_x, out_P, out_p, out_L = np.zeros((T, n)), np.zeros((T, n, n)), np.zeros((T, nm)), np.zeros((T, nm))
+    for t in range(T):
+        for j in range(nm):
+            xs[j], Ps[j] = kf_oracle.kf_predict(xs[j], Ps[j], Fs[j], Qs[j])
+        L = np.zeros(nm)
+        for j in range(nm):
+            xs[j], Ps[j], y, K, S, SI = kf_oracle.kf_update(xs[j], Ps[j], zs[t], Rs[j], Hs[j])
+            L[j] = np.exp(kf_oracle.log_likelihood(y, S))
+            if L[j] == 0:
+                L[j] = sys.float_info.min
+            p[j] *= L[j]
+        p /= sum(p)
+        x = np.zeros(n)
+        for xj, pj in zip(xs, p):
+            x += np.dot(xj, pj)
+        P = np.zeros((n, n))
+        for xk, xj, Pj, pj in zip(x, xs, Ps, p):
+            y = xj - xk
+            P += pj * (np.outer(y, y) + Pj)
+        out_x[t], out_P[t], out_p[t], out_L[t] = x, P, p, L
+    return out_x, out_P, out_p, out_L

@@ -270,6 +270,41 @@ def gen_imm():
     d["cases"] = np.array(IMM_CASES)
     np.savez_compressed(os.path.join(OUT, "imm.npz"), **d)
 
+
+def gen_mmae():
+    """filterpy.kalman.MMAEFilterBank (mmae.py) over T steps of predict(); update(z)."""
+    from filterpy.kalman import MMAEFilterBank
+    d = {}
+    T = 30
+    cases = [(2, 1, 2), (4, 2, 2), (4, 2, 3), (6, 3, 3), (3, 2, 2), (2, 1, 3)]
+    for (n, m, nm) in cases:
+        rs = np.random.RandomState(9000 + 11 * n + 3 * m + nm)
+        Fs = [stable_F(rs, n) for _ in range(nm)]
+        Qs = [spd(rs, n, 0.05 * (j + 1)) for j in range(nm)]
+        H = rs.randn(m, n)
+        Hs = [H.copy() for _ in range(nm)]
+        Rs = [spd(rs, m, 0.5) for _ in range(nm)]
+        xs0 = [rs.randn(n) for _ in range(nm)]
+        Ps0 = [spd(rs, n, 3.0) for _ in range(nm)]
+        p0 = rs.rand(nm) + 0.2
+        p0 /= p0.sum()
+        zs = rs.randn(T, m) * 2
+        filters = [make_kf(n, m, xs0[j], Ps0[j], Fs[j], Qs[j], Hs[j], Rs[j]) for j in range(nm)]
+        bank = MMAEFilterBank(filters, p0.copy(), dim_x=n)
+        X, P, PR, L = [], [], [], []
+        for t in range(T):
+            bank.predict()
+            bank.update(zs[t])
+            X.append(bank.x.copy()); P.append(bank.P.copy()); PR.append(bank.p.copy())
+            L.append(np.array([f.likelihood for f in filters]))
+        q = f"n{n}m{m}k{nm}_"
+        d.update({q + "Fs": np.array(Fs), q + "Qs": np.array(Qs), q + "Hs": np.array(Hs), q + "Rs": np.array(Rs),
+                  q + "xs0": np.array(xs0), q + "Ps0": np.array(Ps0), q + "p0": p0, q + "zs": zs,
+                  q + "x": np.array(X), q + "P": np.array(P), q + "p": np.array(PR), q + "L": np.array(L),
+                  q + "xs_final": np.array([f.x for f in filters]), q + "Ps_final": np.array([f.P for f in filters])})
+    d["cases"] = np.array(cases)
+    np.savez_compressed(os.path.join(OUT, "mmae.npz"), **d)
+
 # ---------------------------------------------------------------- UKF -----
 UKF_CASES = [(1, 1, .5, 2., 1.), (2, 1, .1, 2., -1.), (4, 2, 1e-3, 2., 0.), (6, 3, .1, 2., -3.), (4, 2, 1., 2., .1)]
 
@@ -398,7 +433,7 @@ def gen_resample():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["c1", "dims", "models", "steps", "saver", "imm", "ukf", "resample"]
+    which = sys.argv[1:] or ["c1", "dims", "models", "steps", "saver", "imm", "mmae", "ukf", "resample"]
     for w in which:
         print("generating", w)
         globals()["gen_" + w]()

@@ -466,7 +466,7 @@ extern "C" long hc_cumsum_chunked(long N, const double *w, double *cs, long *n_s
 template <int NX, int NZ, int NM>
 static int imm_batch(int n, int m, long T, const double *F, const double *Q, const double *H, const double *R,
                      const double *Mt, const double *z, double *xs0, double *Ps0, double *mu0, double *x_out,
-                     double *P_out, double *mu_out, double *xp_out, double *Pp_out, double *L_out)
+                     double *P_out, double *mu_out, double *xp_out, double *Pp_out, double *L_out, int mmae)
 {
     constexpr int PL = NX * (NX + 1) / 2;
     RegModel<NX, NZ> mods[NM];
@@ -487,13 +487,19 @@ static int imm_batch(int n, int m, long T, const double *F, const double *Q, con
     for (long t = 0; t < T; ++t) {
         double zz[NZ], cbar[NM], L[NM], x[NX], P[NX * NX];
         pad<NZ, 1>(zz, z + t * m, m, 1, 0.0);
-        imm_mixing_cbar<NM>(mu, Mt, cbar);
-        imm_predict<NX, NM>(xs, Ps, mu, cbar, Mt, mods);
-        imm_estimate<NX, NM>(xs, Ps, mu, x, P);
-        unpad<NX, 1>(x, xp_out + t * n, n, 1);
-        unpad<NX, NX>(P, Pp_out + t * n * n, n, n);
+        if (mmae) {   // mirrors imm_kernel's MMAE branch
+            for (int j = 0; j < NM; ++j) cbar[j] = mu[j];
+            for (int j = 0; j < NM; ++j) kf_predict_sym<NX>(xs[j], Ps[j], mods[j], 1.0);
+        } else {
+            imm_mixing_cbar<NM>(mu, Mt, cbar);
+            imm_predict<NX, NM>(xs, Ps, mu, cbar, Mt, mods);
+            imm_estimate<NX, NM>(xs, Ps, mu, x, P);
+            unpad<NX, 1>(x, xp_out + t * n, n, 1);
+            unpad<NX, NX>(P, Pp_out + t * n * n, n, n);
+        }
         st |= imm_update<NX, NZ, NM>(xs, Ps, mu, cbar, zz, m, mods, L);
-        imm_estimate<NX, NM>(xs, Ps, mu, x, P);
+        if (mmae) mmae_estimate<NX, NM>(xs, Ps, mu, n, x, P);
+        else imm_estimate<NX, NM>(xs, Ps, mu, x, P);
         unpad<NX, 1>(x, x_out + t * n, n, 1);
         unpad<NX, NX>(P, P_out + t * n * n, n, n);
         for (int j = 0; j < NM; ++j) { mu_out[t * NM + j] = mu[j]; L_out[t * NM + j] = L[j]; }
@@ -512,10 +518,10 @@ static int imm_batch(int n, int m, long T, const double *F, const double *Q, con
 extern "C" int hc_imm_batch(int n, int m, int nm, long T, const double *F, const double *Q, const double *H,
                             const double *R, const double *Mt, const double *z, double *xs0, double *Ps0,
                             double *mu0, double *x_out, double *P_out, double *mu_out, double *xp_out,
-                            double *Pp_out, double *L_out)
+                            double *Pp_out, double *L_out, int mmae)
 {
 #define GO(NXV, NZV, NMV) \
-    return imm_batch<NXV, NZV, NMV>(n, m, T, F, Q, H, R, Mt, z, xs0, Ps0, mu0, x_out, P_out, mu_out, xp_out, Pp_out, L_out)
+    return imm_batch<NXV, NZV, NMV>(n, m, T, F, Q, H, R, Mt, z, xs0, Ps0, mu0, x_out, P_out, mu_out, xp_out, Pp_out, L_out, mmae)
     const int cls = (n <= 2 && m <= 1) ? 0 : (n <= 4 && m <= 2) ? 1 : 2;
     if (nm == 2) {
         if (cls == 0) GO(2, 1, 2);

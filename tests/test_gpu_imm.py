@@ -172,3 +172,93 @@ def test_imm_rejects_what_the_kernel_cannot_do():
         imm.update(None)
     with pytest.raises(NotImplementedError):
         IMMEstimator([KalmanFilter(dim_x=2, dim_z=1) for _ in range(4)], [1, 1, 1, 1], np.full((4, 4), 0.25))
+
+
+# ------------------------------------------------------------------------------- MMAE ----
+MMAE_CASES = [(2, 1, 2), (4, 2, 2), (4, 2, 3), (6, 3, 3), (3, 2, 2), (2, 1, 3)]
+
+
+@pytest.mark.parametrize("layout", ["soa", "aos"])
+@pytest.mark.parametrize("n,m,nm", MMAE_CASES)
+def test_mmae_goldens_c_abi(n, m, nm, layout):
+    """FK_IMM_FLAG_MMAE through the C ABI against goldens from the live MMAEFilterBank."""
+    import torch
+    from filterpy_amd import _engine as E
+    from gpu_util import tile_tracks
+    g = golden("mmae")
+    p = f"n{n}m{m}k{nm}_"
+    N, T = 200, 30
+    dxs = E.to_records(tile_tracks(g[p + "xs0"], N).reshape(N, nm * n), layout, 0)
+    dPs = E.to_records(tile_tracks(g[p + "Ps0"], N).reshape(N, nm * n * n), layout, 0)
+    dp = E.to_records(tile_tracks(g[p + "p0"], N), layout, 0)
+    dz = E.to_records(tile_tracks(g[p + "zs"], N, axis=1), layout, 1)
+    out = dict(x_out=E.alloc_records((T,), N, n, layout), P_out=E.alloc_records((T,), N, n * n, layout),
+               mu_out=E.alloc_records((T,), N, nm, layout), likelihood_out=E.alloc_records((T,), N, nm, layout))
+    st = torch.zeros(N, dtype=torch.int32, device=dxs.device)
+    E.imm_batch(n, m, nm, N, T, layout, E.dev(g[p + "Fs"]), E.dev(g[p + "Qs"]), E.dev(g[p + "Hs"]), E.dev(g[p + "Rs"]),
+                None, dz, dxs, dPs, dp, status=st, mmae=True, **out)
+    torch.cuda.synchronize()
+    assert not st.any()
+    x = E.from_records(out["x_out"], layout, 1, (n,))
+    P = E.from_records(out["P_out"], layout, 1, (n, n))
+    pr = E.from_records(out["mu_out"], layout, 1, (nm,))
+    L = E.from_records(out["likelihood_out"], layout, 1, (nm,))
+    xs = E.from_records(dxs, layout, 0, (nm, n))
+    for trk in (0, 64, N - 1):
+        assert rel_err_rows(x[:, trk], g[p + "x"]) < TOL and rel_err_rows(P[:, trk], g[p + "P"]) < TOL
+        assert np.allclose(pr[:, trk], g[p + "p"], rtol=1e-9, atol=1e-14)
+        assert np.allclose(L[:, trk], g[p + "L"], rtol=1e-9, atol=1e-300)
+        assert rel_err_rows(xs[trk], g[p + "xs_final"]) < TOL
+
+
+@pytest.mark.parametrize("column", [False, True])
+@pytest.mark.parametrize("n,m,nm", [(2, 1, 3), (4, 2, 2)])
+def test_mmae_class_drop_in(n, m, nm, column):
+    from filterpy_amd.kalman import MMAEFilterBank
+    g = golden("mmae")
+    p = f"n{n}m{m}k{nm}_"
+    q = {k[len(p):]: g[k] for k in g.files if k.startswith(p)}
+    gg = {p + k: v for k, v in q.items()}
+    gg[p + "mu0"] = q["p0"]
+    fs = _make_filters(gg, p, n, m, nm, column)
+    bank = MMAEFilterBank(fs, q["p0"].copy(), dim_x=n)
+    shp = (lambda a: a.reshape(-1, 1)) if column else (lambda a: a)
+    for t in range(12):
+        bank.predict()
+        z = q["zs"][t]
+        bank.update(z.reshape(-1, 1) if column else z)
+        assert bank.x.shape == ((n, 1) if column else (n,))
+        assert rel_err_rows(bank.x, shp(q["x"][t])) < TOL and rel_err_rows(bank.P, q["P"][t]) < TOL
+        assert np.allclose(bank.p, q["p"][t], rtol=1e-9, atol=1e-14)
+    assert rel_err_rows(bank.x_prior, shp(q["x"][10])) < TOL        # prior = the estimate before the last predict
+    xs, Ps, ps = bank.batch_filter(q["zs"][12:])
+    assert rel_err_rows(xs.reshape(-1, n), q["x"][12:]) < TOL and rel_err_rows(Ps, q["P"][12:]) < TOL
+    assert np.allclose(ps, q["p"][12:], rtol=1e-9, atol=1e-14)
+    for j in range(nm):
+        assert rel_err_rows(bank.filters[j].x.reshape(-1), q["xs_final"][j]) < TOL
+
+
+def test_mmae_update_overrides_and_bank():
+    """update(z, R=, H=) overrides every filter's R / H for that call (mmae.py:160-186); n_tracks banks."""
+    from filterpy_amd.kalman import MMAEFilterBank
+    from oracle import kf_oracle
+    g = golden("mmae")
+    n, m, nm = 4, 2, 2
+    p = f"n{n}m{m}k{nm}_"
+    gg = {k: g[k] for k in g.files if k.startswith(p)}
+    gg[p + "mu0"] = g[p + "p0"]
+    fs = _make_filters(gg, p, n, m, nm, False)
+    bank = MMAEFilterBank(fs, g[p + "p0"].copy(), dim_x=n)
+    R2, H2 = 2.0 * np.eye(m), g[p + "Hs"][0] * 0.5
+    z = g[p + "zs"][0]
+    bank.update(z, R=R2, H=H2)
+    for j in range(nm):
+        x, P, *_ = kf_oracle.kf_update(g[p + "xs0"][j], g[p + "Ps0"][j], z, R2, H2)
+        assert rel_err_rows(bank.filters[j].x, x) < TOL and rel_err_rows(bank.filters[j].P, P) < TOL
+    N = 70
+    fs = _make_filters(gg, p, n, m, nm, False)
+    bank = MMAEFilterBank(fs, g[p + "p0"].copy(), dim_x=n, n_tracks=N)
+    from gpu_util import tile_tracks
+    xs, Ps, ps = bank.batch_filter(tile_tracks(g[p + "zs"], N, axis=1))
+    assert xs.shape == (30, N, n) and ps.shape == (30, N, nm)
+    assert rel_err_rows(xs[:, N - 1], g[p + "x"]) < TOL and rel_err_rows(Ps[:, 3], g[p + "P"]) < TOL

@@ -21,17 +21,18 @@ def _p(a):
     return a.ctypes.data_as(ctypes.c_void_p)
 
 
-def hc_imm(g, p, n, m, nm, T=None):
+def hc_imm(g, p, n, m, nm, T=None, mmae=False):
     c = lambda a: np.ascontiguousarray(a, dtype=np.float64)  # noqa: E731
     zs = c(g[p + "zs"]) if T is None else c(g[p + "zs"][:T])
     T = zs.shape[0]
     xs, Ps = c(g[p + "xs0"]).copy(), c(g[p + "Ps0"]).copy()
-    mu = c(g[p + "mu0"] / g[p + "mu0"].sum())
+    mu = c(g[p + "p0"]).copy() if mmae else c(g[p + "mu0"] / g[p + "mu0"].sum())
+    M = c(np.eye(nm)) if mmae else c(g[p + "M"])
     x, P, MU = np.zeros((T, n)), np.zeros((T, n, n)), np.zeros((T, nm))
     xp, Pp, L = np.zeros((T, n)), np.zeros((T, n, n)), np.zeros((T, nm))
     st = lib().hc_imm_batch(n, m, nm, ctypes.c_long(T), _p(c(g[p + "Fs"])), _p(c(g[p + "Qs"])), _p(c(g[p + "Hs"])),
-                            _p(c(g[p + "Rs"])), _p(c(g[p + "M"])), _p(zs), _p(xs), _p(Ps), _p(mu), _p(x), _p(P),
-                            _p(MU), _p(xp), _p(Pp), _p(L))
+                            _p(c(g[p + "Rs"])), _p(M), _p(zs), _p(xs), _p(Ps), _p(mu), _p(x), _p(P),
+                            _p(MU), _p(xp), _p(Pp), _p(L), int(mmae))
     return st, x, P, MU, xp, Pp, L, xs, Ps, mu
 
 
@@ -47,3 +48,17 @@ def test_imm_math_vs_golden(n, m, nm):
     assert np.allclose(L, g[p + "L"], rtol=1e-9, atol=1e-300)
     assert rel_err_rows(xs, g[p + "xs_final"]) < TOL and rel_err_rows(Ps, g[p + "Ps_final"]) < TOL
     assert np.allclose(mu, g[p + "mu"][-1], rtol=1e-9, atol=1e-14)
+
+
+@pytest.mark.parametrize("n,m,nm", [(2, 1, 2), (4, 2, 2), (4, 2, 3), (6, 3, 3), (3, 2, 2), (2, 1, 3)])
+def test_mmae_math_vs_golden(n, m, nm):
+    """the MMAE branch (no mixing, p *= likelihood, mmae.py's own covariance loop) against goldens
+    frozen from the live filterpy.kalman.MMAEFilterBank."""
+    g = golden("mmae")
+    p = f"n{n}m{m}k{nm}_"
+    st, x, P, PR, _, _, L, xs, Ps, pf = hc_imm(g, p, n, m, nm, mmae=True)
+    assert st == 0
+    assert rel_err_rows(x, g[p + "x"]) < TOL and rel_err_rows(P, g[p + "P"]) < TOL
+    assert np.allclose(PR, g[p + "p"], rtol=1e-9, atol=1e-14)
+    assert np.allclose(L, g[p + "L"], rtol=1e-9, atol=1e-300)
+    assert rel_err_rows(xs, g[p + "xs_final"]) < TOL and rel_err_rows(Ps, g[p + "Ps_final"]) < TOL

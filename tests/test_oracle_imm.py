@@ -16,3 +16,14 @@ def test_imm_vs_golden(n, m, nm):
     assert rel_err_rows(xp, g[p + "xp"]) < 1e-12 and rel_err_rows(Pp, g[p + "Pp"]) < 1e-12
     assert np.allclose(mu, g[p + "mu"], rtol=1e-11, atol=1e-15)
     assert np.allclose(L, g[p + "L"], rtol=1e-11, atol=1e-300)
+
+
+@pytest.mark.parametrize("n,m,nm", [(2, 1, 2), (4, 2, 2), (4, 2, 3), (6, 3, 3), (3, 2, 2), (2, 1, 3)])
+def test_mmae_vs_golden(n, m, nm):
+    g = golden("mmae")
+    p = f"n{n}m{m}k{nm}_"
+    x, P, pr, L = imm_oracle.mmae_batch(g[p + "xs0"], g[p + "Ps0"], g[p + "p0"], g[p + "zs"],
+                                        g[p + "Fs"], g[p + "Qs"], g[p + "Hs"], g[p + "Rs"])
+    assert rel_err_rows(x, g[p + "x"]) < 1e-12 and rel_err_rows(P, g[p + "P"]) < 1e-12
+    assert np.allclose(pr, g[p + "p"], rtol=1e-11, atol=1e-15)
+    assert np.allclose(L, g[p + "L"], rtol=1e-11, atol=1e-300)
