@@ -160,6 +160,27 @@ def ukf_linear_batch(n, m, N, T, layout, scale, F, H, Q, R, Wm, Wc, z, x, P, *, 
     _abi.check(rc, "fk_ukf_linear_batch_f64")
 
 
+def kf_steadystate(desc_kw, F, H, K, z, x, *, B=None, u=None, mask=None, means=None, means_p=None, y=None):
+    """fk_kf_steadystate_f64 (F None: update only; z None: predict only)."""
+    d = fk_kf_desc(**desc_kw)
+    rc = _abi.lib().fk_kf_steadystate_f64(d, _ptr(F), _ptr(H), _ptr(K), _ptr(B), _ptr(u), _ptr(z), _ptr(mask),
+                                          _ptr(x), _ptr(means), _ptr(means_p), _ptr(y), _stream())
+    _abi.check(rc, "fk_kf_steadystate_f64")
+
+
+def kf_update_correlated(desc_kw, H, R, M, z, x, P, *, mask=None, y=None, K=None, S=None, SI=None, status=None):
+    d = fk_kf_desc(**desc_kw)
+    rc = _abi.lib().fk_kf_update_correlated_f64(d, _ptr(H), _ptr(R), _ptr(M), _ptr(z), _ptr(mask), _ptr(x), _ptr(P),
+                                                _ptr(y), _ptr(K), _ptr(S), _ptr(SI), _ptr(status), _stream())
+    _abi.check(rc, "fk_kf_update_correlated_f64")
+
+
+def ukf_rts_correct(n, N, layout, Pxb, xb, Pb, xn, Pn, x, P, K=None, status=None):
+    rc = _abi.lib().fk_ukf_rts_correct_f64(n, N, LAYOUTS[layout], _ptr(Pxb), _ptr(xb), _ptr(Pb), _ptr(xn), _ptr(Pn),
+                                           _ptr(x), _ptr(P), _ptr(K), _ptr(status), _stream())
+    _abi.check(rc, "fk_ukf_rts_correct_f64")
+
+
 def imm_batch(n, m, n_models, N, T, layout, F, Q, H, R, M, z, xs, Ps, mu, *, x_out=None, P_out=None,
               mu_out=None, x_prior_out=None, P_prior_out=None, likelihood_out=None, status=None, phase=0, mmae=False):
     """fk_imm_batch_f64: T x { IMMEstimator.predict(); IMMEstimator.update(z) } for N banks."""

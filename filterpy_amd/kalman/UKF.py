@@ -15,7 +15,8 @@ Two ways to run it:
 
 ``n_tracks=N`` turns the object into a bank of N independent filters (x (N,n), P (N,n,n),
 z (N,m) / zs (T,N,m)).  Custom sqrt / mean / residual / state_add callables cannot run
-inside a kernel and raise NotImplementedError.
+inside a kernel and raise NotImplementedError.  ``rts_smoother`` (UKF.py:634-739) runs its
+backward loop on the host like the reference, every step's arithmetic on the GPU.
 """
 import sys
 from copy import deepcopy
@@ -222,8 +223,51 @@ class UnscentedKalmanFilter(object):
         return (means, covs)
 
     def rts_smoother(self, Xs, Ps, Qs=None, dts=None, UT=None):
-        raise NotImplementedError("UnscentedKalmanFilter.rts_smoother (UKF.py:634-739) is not on the "
-                                  "accelerated path yet (SURVEY.md §8f N4)")
+        """UKF.py:634-739: backward pass over the filter output.  Per step k (from the end): sigma
+        points of (xs[k], ps[k]) -> fx -> UT (+ self.Q: the reference passes self.Q, its Qs argument
+        is never read, UKF.py:717-719) -> cross variance of the sigma points around Xs[k] and their
+        images around xb -> fk_ukf_rts_correct_f64 (K = Pxb inv(Pb); x += K (x[k+1] - xb);
+        P += K (P[k+1] - Pb) K').  Xs (T, n) / Ps (T, n, n), or (T, N, n) / (T, N, n, n) for a bank.
+        Returns (xs, Ps, Ks)."""
+        import torch
+        from .unscented_transform import unscented_transform
+        if UT is not None and UT is not unscented_transform:
+            raise NotImplementedError("custom UT callables are not supported")
+        if len(Xs) != len(Ps):
+            raise ValueError('Xs and Ps must have the same length')
+        n, k = self._dim_x, self._num_sigmas
+        N = self._N or 1
+        Xs = np.asarray(Xs, dtype=np.float64)
+        T = Xs.shape[0]
+        if dts is None:
+            dts = [self._dt] * T
+        elif np.isscalar(dts):
+            dts = [dts] * T
+        lay = self._layout
+        X = Xs.reshape(T, N, n)
+        xs, ps = X.copy(), np.asarray(Ps, dtype=np.float64).reshape(T, N, n, n).copy()
+        Ks = np.zeros((T, N, n, n))
+        dWc = E.dev(np.asarray(self.Wc, dtype=np.float64))
+        for j in reversed(range(T - 1)):
+            sig = self.points_fn.sigma_points(xs[j], ps[j]).reshape(N, k, n)
+            sf = (self._apply(self.fx, sig, dts[j]) if callable(self.fx) else self._apply(self.fx, sig)).reshape(N, k, n)
+            xb, Pb = unscented_transform(sf, self.Wm, self.Wc, self.Q, layout=lay)
+            dxb, dPb = E.to_records(xb.reshape(N, n), lay, 0), E.to_records(Pb.reshape(N, n, n), lay, 0)
+            dPxb = E.alloc_records((), N, n * n, lay)
+            E.ut_cross_variance(n, n, k, N, lay, E.to_records(X[j], lay, 0), dxb, E.to_records(sig, lay, 0),
+                                E.to_records(sf, lay, 0), dWc, dPxb)
+            dx, dP = E.to_records(xs[j], lay, 0), E.to_records(ps[j], lay, 0)
+            dK = E.alloc_records((), N, n * n, lay)
+            st = torch.zeros(N, dtype=torch.int32, device=dx.device)
+            E.ukf_rts_correct(n, N, lay, dPxb, dxb, dPb, E.to_records(xs[j + 1], lay, 0),
+                              E.to_records(ps[j + 1], lay, 0), dx, dP, dK, st)
+            E.raise_on_status(st, "UnscentedKalmanFilter.rts_smoother")
+            xs[j] = E.from_records(dx, lay, 0, (n,))
+            ps[j] = E.from_records(dP, lay, 0, (n, n))
+            Ks[j] = E.from_records(dK, lay, 0, (n, n))
+        if self._N is None:
+            return xs[:, 0].reshape(Xs.shape), ps[:, 0], Ks[:, 0]
+        return xs, ps, Ks
 
     # ------------------------------------------------------------- properties --
     @property

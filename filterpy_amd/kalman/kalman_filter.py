@@ -181,6 +181,50 @@ class _Core:
                 E.from_records(S, layout, 0, (m, m)), E.from_records(SI, layout, 0, (m, m)))
 
 
+
+    @staticmethod
+    def steadystate(n, m, N, T, x, F, H, K, z, mask=None, B=None, us=None, nu=0, k_per_track=False, layout="soa"):
+        """fk_kf_steadystate_f64.  F None: update only; z None: predict only.
+        Returns x_final (N,n), means (T,N,n) | None, means_p (T,N,n) | None, y (T,N,m) | None."""
+        import torch
+        E.require_gpu()
+        dx = E.to_records(x, layout, 0)
+        dz = None if z is None else E.to_records(z, layout, 1)
+        dmask = None if mask is None else torch.as_tensor(np.ascontiguousarray(mask, dtype=np.uint8), device=dx.device)
+        dK = None if K is None else (E.to_records(K.reshape(N, n * m), layout, 0) if k_per_track else E.dev(K))
+        du = None if us is None else E.to_records(us, layout, 1)
+        means = None if z is None else E.alloc_records((T,), N, n, layout)
+        means_p = None if F is None else E.alloc_records((T,), N, n, layout)
+        y = None if z is None else E.alloc_records((T,), N, m, layout)
+        E.kf_steadystate(dict(n=n, m=m, nu=nu, model_mode=FK_MODEL_PER_TRACK if k_per_track else FK_MODEL_SHARED,
+                              N=N, T=T, layout=E.LAYOUTS[layout], update_first=0, alpha_sq=1.0),
+                         None if F is None else E.dev(F), None if H is None else E.dev(H), dK, z=dz, x=dx,
+                         B=None if B is None else E.dev(B), u=du, mask=dmask, means=means, means_p=means_p, y=y)
+        back = lambda t, rec: None if t is None else E.from_records(t, layout, 1, rec)  # noqa: E731
+        return E.from_records(dx, layout, 0, (n,)), back(means, (n,)), back(means_p, (n,)), back(y, (m,))
+
+    @staticmethod
+    def update_correlated(n, m, N, x, P, z, H, R, M, mask=None, m_per_track=False, layout="soa"):
+        """fk_kf_update_correlated_f64 -> x, P, y, K, S, SI host arrays."""
+        import torch
+        E.require_gpu()
+        dx, dP, dz = E.to_records(x, layout, 0), E.to_records(P, layout, 0), E.to_records(z, layout, 0)
+        dmask = None if mask is None else torch.as_tensor(np.ascontiguousarray(mask, dtype=np.uint8), device=dx.device)
+        dM = E.to_records(M.reshape(N, n * m), layout, 0) if m_per_track else E.dev(M)
+        y, K = E.alloc_records((), N, m, layout), E.alloc_records((), N, n * m, layout)
+        S, SI = E.alloc_records((), N, m * m, layout), E.alloc_records((), N, m * m, layout)
+        for t in (y, K, S, SI):
+            t.zero_()
+        st = torch.zeros(N, dtype=torch.int32, device=dx.device)
+        E.kf_update_correlated(dict(n=n, m=m, nu=0, model_mode=FK_MODEL_PER_TRACK if m_per_track else FK_MODEL_SHARED,
+                                    N=N, T=1, layout=E.LAYOUTS[layout], update_first=0, alpha_sq=1.0),
+                               E.dev(H), E.dev(R), dM, dz, dx, dP, mask=dmask, y=y, K=K, S=S, SI=SI, status=st)
+        E.raise_on_status(st, "update_correlated")
+        return (E.from_records(dx, layout, 0, (n,)), E.from_records(dP, layout, 0, (n, n)),
+                E.from_records(y, layout, 0, (m,)), E.from_records(K, layout, 0, (n, m)),
+                E.from_records(S, layout, 0, (m, m)), E.from_records(SI, layout, 0, (m, m)))
+
+
 # ------------------------------------------------------------ KalmanFilter --
 class KalmanFilter(object):
     """One linear Kalman filter; filterpy.kalman.KalmanFilter's interface
@@ -291,6 +335,106 @@ class KalmanFilter(object):
         self.y = y[0].reshape(m, 1) if x_ndim == 2 else y[0]
         self.K, self.S, self.SI = K[0], S[0], SI[0]
         self.z = deepcopy(z)
+        self.x_post, self.P_post = np.copy(self.x), self.P.copy()
+
+    # -- steady state, correlated noise, sequential ---------------
+    def predict_steadystate(self, u=0, B=None):
+        """kalman_filter.py:563-593: x = Fx (+ Bu iff B is set); P is left unchanged."""
+        n = self.dim_x
+        if B is None:
+            B = self.B
+        x, _ = self._xP()
+        kw = {}
+        if B is not None:
+            nu = np.shape(np.atleast_2d(B))[1] if np.ndim(B) else 1
+            uu = np.broadcast_to(np.asarray(u, dtype=np.float64).reshape(-1), (nu,)).reshape(1, 1, nu).copy()
+            kw = dict(B=_mat(B, n, nu, "B"), us=uu, nu=nu)
+        xn, _, _, _ = _Core.steadystate(n, self.dim_z, 1, 1, x, _mat(self.F, n, n, "F"), None, None, None, **kw)
+        self._set_x(xn[0])
+        self.x_prior, self.P_prior = np.copy(self.x), np.copy(self.P)
+
+    def update_steadystate(self, z):
+        """kalman_filter.py:595-668: y = z - Hx ; x += K y with the stored gain; P, K, S untouched."""
+        self._log_likelihood = None
+        self._likelihood = None
+        self._mahalanobis = None
+        n, m = self.dim_x, self.dim_z
+        if z is None:
+            self.z = np.array([[None] * m]).T
+            self.x_post, self.P_post = np.copy(self.x), np.copy(self.P)
+            self.y = np.zeros((m, 1))
+            return
+        x_ndim = np.ndim(self.x)
+        z = reshape_z(z, m, x_ndim)
+        x, _ = self._xP()
+        xn, _, _, y = _Core.steadystate(n, m, 1, 1, x, None, _mat(self.H, m, n, "H"), _mat(self.K, n, m, "K"),
+                                        np.asarray(z, dtype=np.float64).reshape(1, 1, m))
+        self._set_x(xn[0])
+        self.y = y[0, 0].reshape(m, 1) if x_ndim == 2 else y[0, 0]
+        self.z = deepcopy(z)
+        self.x_post, self.P_post = np.copy(self.x), np.copy(self.P)
+
+    def update_correlated(self, z, R=None, H=None):
+        """kalman_filter.py:670-752: update with process and measurement noise correlated through self.M."""
+        self._log_likelihood = None
+        self._likelihood = None
+        self._mahalanobis = None
+        n, m = self.dim_x, self.dim_z
+        if z is None:
+            self.z = np.array([[None] * m]).T
+            self.x_post, self.P_post = np.copy(self.x), np.copy(self.P)
+            self.y = np.zeros((m, 1))
+            return
+        if R is None:
+            Rm = self._R_eff(self.R)
+        elif np.isscalar(R):
+            Rm = np.eye(m) * R
+        else:
+            Rm = _mat(R, m, m, "R")
+        x_ndim = np.ndim(self.x)
+        if H is None:
+            z = reshape_z(z, m, x_ndim)
+            H = self.H
+        zz = np.asarray(z, dtype=np.float64)
+        if zz.size != m:
+            raise ValueError(f"z (shape {zz.shape}) does not hold dim_z = {m} values")
+        x, P = self._xP()
+        xn, Pn, y, K, S, SI = _Core.update_correlated(n, m, 1, x, P, zz.reshape(1, m), _mat(H, m, n, "H"), Rm,
+                                                      _mat(self.M, n, m, "M"))
+        self._set_x(xn[0])
+        self.P = Pn[0]
+        self.y = y[0].reshape(m, 1) if x_ndim == 2 else y[0]
+        self.K, self.S, self.SI = K[0], S[0], SI[0]
+        self.z = deepcopy(z)
+        self.x_post, self.P_post = np.copy(self.x), self.P.copy()
+
+    def update_sequential(self, start, z_i, R_i=None, H_i=None):
+        """kalman_filter.py:754-824: the ordinary (Joseph-form) update restricted to the measurement
+        components start:start+len(z_i) -- the same kernel as update() on the sliced H, R."""
+        n = self.dim_x
+        length = 1 if np.isscalar(z_i) else len(z_i)
+        z_i = np.reshape(np.asarray(z_i, dtype=np.float64), [length, 1])
+        stop = start + length
+        if R_i is None:
+            R_i = _mat(self.R, self.dim_z, self.dim_z, "R")[start:stop, start:stop]
+        elif np.isscalar(R_i):
+            R_i = np.eye(length) * R_i
+        if H_i is None:
+            H_i = np.asarray(self.H, dtype=np.float64)[start:stop]
+        H_i = np.reshape(np.asarray(H_i, dtype=np.float64), [length, n])
+        x, P = self._xP()
+        xn, Pn, y, K, S, SI = _Core.update(n, length, 1, x, P, z_i.reshape(1, length), H_i,
+                                           _mat(R_i, length, length, "R_i"), FK_MODEL_SHARED)
+        if np.shape(self.y) != (self.dim_z, 1):
+            self.y = np.zeros((self.dim_z, 1))
+        self.y[start:stop] = y[0].reshape(length, 1)
+        self.K = np.array(self.K, dtype=np.float64)
+        self.K[:, start:stop] = K[0]
+        self._set_x(xn[0])
+        self.P = Pn[0]
+        if np.shape(self.z) != (self.dim_z, 1):
+            self.z = np.array([[None] * self.dim_z]).T
+        self.z[start:stop] = z_i
         self.x_post, self.P_post = np.copy(self.x), self.P.copy()
 
     # -- batch_filter -----------------------------------------------------------
@@ -492,6 +636,8 @@ class KalmanFilterBank(object):
         self.F, self.Q = np.eye(dim_x), np.eye(dim_x)
         self.H, self.R = np.zeros((dim_z, dim_x)), np.eye(dim_z)
         self.B = None
+        self.K = np.zeros((dim_x, dim_z))
+        self.M = np.zeros((dim_x, dim_z))
         self._alpha_sq = 1.0
 
     alpha = KalmanFilter.alpha
@@ -574,6 +720,88 @@ class KalmanFilterBank(object):
         else:
             self.x, self.P = out[4], out[5]
         return tuple(out[:4]) + ((out[6],) if extras else ())
+
+    # -- SURVEY §8f N4 on the bank ---------------------------------------------------
+    def _gain(self):
+        K = np.asarray(self.K, dtype=np.float64)
+        per_track = K.ndim == 3
+        if per_track and K.shape != (self.n_tracks, self.dim_x, self.dim_z):
+            raise ValueError(f"K has shape {K.shape}, expected ({self.n_tracks}, {self.dim_x}, {self.dim_z})")
+        return (np.ascontiguousarray(K) if per_track else _mat(K, self.dim_x, self.dim_z, "K")), per_track
+
+    def _shared(self, name, r, c):
+        v = np.asarray(getattr(self, name), dtype=np.float64)
+        if v.ndim == 3:
+            raise NotImplementedError(f"per-track {name} is not supported by the steady-state / correlated kernels")
+        return _mat(v, r, c, name)
+
+    def steadystate_filter(self, zs, mask=None, us=None):
+        """T x { predict_steadystate(); update_steadystate(zs[t]) } (kalman_filter.py:563-668) in one
+        launch with the fixed gain self.K ((n, m) shared or (N, n, m) per track).  zs (T, N, dim_z).
+        Returns (means (T,N,n), means_p (T,N,n), residuals (T,N,m)); P is untouched."""
+        n, m, N = self.dim_x, self.dim_z, self.n_tracks
+        z = np.asarray(zs, dtype=np.float64)
+        T = z.shape[0]
+        z = z.reshape(T, N, m)
+        nanrow = np.isnan(z).all(axis=2)
+        if mask is None and nanrow.any():
+            mask = ~nanrow
+        if mask is not None:
+            z = np.where(np.asarray(mask, dtype=bool)[..., None], z, 0.0)
+        K, per_track = self._gain()
+        x, _ = self._state()
+        kw = {}
+        if us is not None and self.B is not None:
+            uu = np.asarray(us, dtype=np.float64).reshape(T, N, -1)
+            kw = dict(B=_mat(self.B, n, uu.shape[2], "B"), us=uu, nu=uu.shape[2])
+        self.x, means, means_p, y = _Core.steadystate(n, m, N, T, x, self._shared("F", n, n), self._shared("H", m, n),
+                                                      K, z, mask=mask, k_per_track=per_track, layout=self.layout, **kw)
+        return means, means_p, y
+
+    def predict_steadystate(self, u=None):
+        n, N = self.dim_x, self.n_tracks
+        x, _ = self._state()
+        kw = {}
+        if u is not None and self.B is not None:
+            uu = np.asarray(u, dtype=np.float64).reshape(1, N, -1)
+            kw = dict(B=_mat(self.B, n, uu.shape[2], "B"), us=uu, nu=uu.shape[2])
+        self.x = _Core.steadystate(n, self.dim_z, N, 1, x, self._shared("F", n, n), None, None, None,
+                                   layout=self.layout, **kw)[0]
+
+    def update_steadystate(self, z, mask=None):
+        n, m, N = self.dim_x, self.dim_z, self.n_tracks
+        K, per_track = self._gain()
+        x, _ = self._state()
+        z = np.asarray(z, dtype=np.float64).reshape(1, N, m)
+        self.x, _, _, y = _Core.steadystate(n, m, N, 1, x, None, self._shared("H", m, n), K, z,
+                                            mask=None if mask is None else np.asarray(mask).reshape(1, N),
+                                            k_per_track=per_track, layout=self.layout)
+        self.y = y[0]
+
+    def update_correlated(self, z, mask=None):
+        """kalman_filter.py:670-752 for every track; self.M is (n, m) shared or (N, n, m)."""
+        n, m, N = self.dim_x, self.dim_z, self.n_tracks
+        M = np.asarray(self.M, dtype=np.float64)
+        per_track = M.ndim == 3
+        x, P = self._state()
+        z = np.asarray(z, dtype=np.float64).reshape(N, m)
+        self.x, self.P, self.y, self.K, self.S, self.SI = _Core.update_correlated(
+            n, m, N, x, P, z, self._shared("H", m, n), self._shared("R", m, m),
+            np.ascontiguousarray(M) if per_track else _mat(M, n, m, "M"), mask=mask, m_per_track=per_track,
+            layout=self.layout)
+
+    def update_sequential(self, start, z_i):
+        """kalman_filter.py:754-824 for every track: z_i (N, length) are measurement components
+        start:start+length; H and R are sliced accordingly."""
+        n, N = self.dim_x, self.n_tracks
+        z_i = np.asarray(z_i, dtype=np.float64).reshape(N, -1)
+        length = z_i.shape[1]
+        stop = start + length
+        H = self._shared("H", self.dim_z, n)[start:stop]
+        R = self._shared("R", self.dim_z, self.dim_z)[start:stop, start:stop]
+        x, P = self._state()
+        self.x, self.P, y, K, _, _ = _Core.update(n, length, N, x, P, z_i, H, R, FK_MODEL_SHARED, layout=self.layout)
+        return y, K
 
     def rts_smoother(self, Xs, Ps):
         """Xs (T,N,n), Ps (T,N,n,n) -> (x, P, K, Pp), class convention (kalman_filter.py:1067)."""

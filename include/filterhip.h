@@ -220,6 +220,53 @@ int fk_ukf_linear_batch_f64(const fk_ukf_desc *desc,
                             int32_t *status, void *stream);
 
 /* ------------------------------------------------------------------ */
+/* API variants of the linear filter               */
+/* ------------------------------------------------------------------ */
+
+/* KalmanFilter.predict_steadystate (filterpy/kalman/kalman_filter.py:563-593) and
+ * update_steadystate (:595-668) for N tracks: only x moves, the gain K is fixed.
+ * T x { x = F x (+ B u) ; means_p[t] = x ; y = z - H x ; x += K y ; means[t] = x }.
+ *   desc: n (1..9), m (1..4), nu (0..4), N, T, layout; model_mode FK_MODEL_SHARED: K [n*m] shared,
+ *   FK_MODEL_PER_TRACK: K [N][n*m] records (every track its own converged gain).
+ *   F [n*n], H [m*n], B [n*nu]: shared.  F == NULL: no predict (update_steadystate alone);
+ *   z == NULL: no update (predict_steadystate alone).  u [T][N][nu], z [T][N][m], mask [T][N] or NULL
+ *   (0 = z is None: x unchanged, y = 0, kalman_filter.py:647-652).
+ *   x [N][n] in/out; means, means_p [T][N][n], y_out [T][N][m]: optional outputs. */
+int fk_kf_steadystate_f64(const fk_kf_desc *desc,
+                          const double *F, const double *H, const double *K,
+                          const double *B, const double *u,
+                          const double *z, const uint8_t *mask,
+                          double *x, double *means, double *means_p, double *y_out,
+                          void *stream);
+
+/* KalmanFilter.update_correlated (kalman_filter.py:670-752): process and measurement noise correlated
+ * through M (dim_x x dim_z):  y = z - H x ; S = H P H' + H M + M' H' + R ; K = (P H' + M) S^-1 ;
+ * x += K y ; P -= K (H P + M').   One update of N tracks.
+ *   desc: n (1..9), m (1..4), N, layout; model_mode FK_MODEL_SHARED: M [n*m] shared,
+ *   FK_MODEL_PER_TRACK: M [N][n*m].  H [m*n], R [m*m]: shared.  z [N][m], mask [N] or NULL.
+ *   x [N][n], P [N][n*n] in/out; y [N][m], K [N][n*m], S, SI [N][m*m]: optional outputs; status [N] or NULL. */
+int fk_kf_update_correlated_f64(const fk_kf_desc *desc,
+                                const double *H, const double *R, const double *M,
+                                const double *z, const uint8_t *mask,
+                                double *x, double *P,
+                                double *y, double *K, double *S, double *SI,
+                                int32_t *status, void *stream);
+
+/* The gain / correction of one backward step of UnscentedKalmanFilter.rts_smoother
+ * (filterpy/kalman/UKF.py:726-733):  K = Pxb inv(Pb) ; x += K (xn - xb) ; P += K (Pn - Pb) K'.
+ *   Pxb [N][n*n] (cross variance of the sigma points around Xs[k] and their images around xb),
+ *   xb [N][n], Pb [N][n*n] (unscented transform of the propagated sigma points + Q),
+ *   xn [N][n], Pn [N][n*n] (smoothed step k+1); x [N][n], P [N][n*n]: filtered step k in, smoothed out;
+ *   K [N][n*n] out (may be NULL); status [N] or NULL.  dim_x 1..9.
+ * The sigma points, their transform and the cross variance are fk_ut_sigma_points_f64,
+ * fk_ut_transform_f64 and fk_ut_cross_variance_f64. */
+int fk_ukf_rts_correct_f64(int32_t n, int64_t N, int32_t layout,
+                           const double *Pxb, const double *xb, const double *Pb,
+                           const double *xn, const double *Pn,
+                           double *x, double *P, double *K,
+                           int32_t *status, void *stream);
+
+/* ------------------------------------------------------------------ */
 /* Interacting multiple models                     */
 /* ------------------------------------------------------------------ */
 

@@ -214,3 +214,62 @@ def mahalanobis(y, SI):
     """KalmanFilter.mahalanobis (kalman_filter.py:1228-1240)."""
     y = np.asarray(y, dtype=float).reshape(-1, 1)
     return float(np.sqrt(float(dot(dot(y.T, SI), y).item())))
+
+
+# --------------------------------------------------------------------------
+# API variants (SURVEY §8f N4)
+# --------------------------------------------------------------------------
+
+def steadystate_filter(x0, zs, F, H, K, B=None, us=None):
+    """T x { predict_steadystate (kalman_filter.py:582-589) ; update_steadystate (:654-660) }:
+    x = F x (+ B u) ; y = z - H x ; x = x + K y.  z None: x unchanged, y = 0 (:647-652).
+    Returns means (T,n), means_p (T,n), ys (T,m)."""
+    x = np.array(x0, dtype=float)
+    T = len(zs)
+    m = np.asarray(H).shape[0]
+    means, means_p, ys = np.zeros((T,) + x.shape), np.zeros((T,) + x.shape), np.zeros((T, m))
+    for t in range(T):
+        if B is not None:
+            x = dot(F, x) + dot(B, us[t])
+        else:
+            x = dot(F, x)
+        means_p[t] = x
+        if zs[t] is not None:
+            y = zs[t] - dot(H, x)
+            x = x + dot(K, y)
+            ys[t] = y
+        means[t] = x
+    return means, means_p, ys
+
+
+def update_correlated(x, P, z, R, H, M, inv=np.linalg.inv):
+    """KalmanFilter.update_correlated (kalman_filter.py:727-748)."""
+    y = z - dot(H, x)
+    PHT = dot(P, H.T)
+    S = dot(H, PHT) + dot(H, M) + dot(M.T, H.T) + R
+    SI = inv(S)
+    K = dot(PHT + M, SI)
+    x = x + dot(K, y)
+    P = P - dot(K, dot(H, P) + M.T)
+    return x, P, y, K, S, SI
+
+
+def update_sequential(x, P, start, z_i, R, H):
+    """KalmanFilter.update_sequential (kalman_filter.py:778-824) with R_i, H_i taken from R, H.
+    x is a column vector (n,1) like the reference requires (z_i is reshaped to (length,1))."""
+    length = 1 if np.isscalar(z_i) else len(z_i)
+    z_i = np.reshape(z_i, [length, 1])
+    stop = start + length
+    R_i = R[start:stop, start:stop]
+    H_i = np.reshape(H[start:stop], [length, x.shape[0]])
+    y_i = z_i - dot(H_i, x)
+    PHT = dot(P, H_i.T)
+    S_i = dot(H_i, PHT) + R_i
+    if length == 1:
+        K_i = PHT * (1.0 / S_i)
+    else:
+        K_i = dot(PHT, np.linalg.inv(S_i))
+    I_KH = np.eye(x.shape[0]) - dot(K_i, H_i)
+    x = x + dot(K_i, y_i)
+    P = dot(dot(I_KH, P), I_KH.T) + dot(dot(K_i, R_i), K_i.T)
+    return x, P, y_i, K_i

@@ -229,6 +229,81 @@ def gen_saver():
     np.savez_compressed(os.path.join(OUT, "kf_saver.npz"), **d)
 
 
+
+# ------------------------------------------------------- KF API variants ----
+def gen_variants():
+    """predict_steadystate/update_steadystate, update_correlated, update_sequential
+    of the live filterpy.kalman.KalmanFilter."""
+    d = {}
+    T = 25
+    cases = [(2, 1), (4, 2), (6, 3), (9, 3), (3, 2)]
+    for (n, m) in cases:
+        rs = np.random.RandomState(9500 + 7 * n + m)
+        F, H = stable_F(rs, n), rs.randn(m, n)
+        Q, R, P0, x0 = spd(rs, n, 0.05), spd(rs, m, 0.5), spd(rs, n, 3.0), rs.randn(n)
+        zs = rs.randn(T, m) * 2
+        q = f"n{n}m{m}_"
+        d.update({q + "F": F, q + "H": H, q + "Q": Q, q + "R": R, q + "P0": P0, q + "x0": x0, q + "zs": zs})
+        # --- steady state: converge a gain with the ordinary filter, then run with it fixed
+        kf = make_kf(n, m, x0, P0, F, Q, H, R)
+        for t in range(60):
+            kf.predict()
+            kf.update(zs[t % T])
+        K, Pss = kf.K.copy(), kf.P.copy()
+        B = rs.randn(n, 2)
+        us = rs.randn(T, 2)
+        for tag, ctrl in (("ss_", False), ("ssu_", True)):
+            kf = make_kf(n, m, x0, P0, F, Q, H, R)
+            kf.K, kf.P = K.copy(), Pss.copy()
+            if ctrl:
+                kf.B = B.copy()
+            X, XP, Y = [], [], []
+            for t in range(T):
+                if ctrl:
+                    kf.predict_steadystate(u=us[t])
+                else:
+                    kf.predict_steadystate()
+                XP.append(kf.x.copy())
+                if t == 7:
+                    kf.update_steadystate(None)
+                else:
+                    kf.update_steadystate(zs[t])
+                X.append(kf.x.copy()); Y.append(np.ravel(kf.y).copy())
+            d.update({q + tag + "x": np.array(X), q + tag + "xp": np.array(XP), q + tag + "y": np.array(Y)})
+            assert np.array_equal(kf.P, Pss)
+        d.update({q + "K": K, q + "Pss": Pss, q + "B": B, q + "us": us})
+        # --- correlated noise: three consecutive updates with a non-zero M
+        M = 0.1 * rs.randn(n, m)
+        kf = make_kf(n, m, x0, P0, F, Q, H, R)
+        kf.M = M.copy()
+        cx, cP, cK, cS, cy = [], [], [], [], []
+        for t in range(3):
+            kf.predict()
+            if t == 2:
+                kf.update_correlated(zs[t], R=2.0 * R, H=0.5 * H)
+            else:
+                kf.update_correlated(zs[t])
+            cx.append(kf.x.copy()); cP.append(kf.P.copy()); cK.append(kf.K.copy()); cS.append(kf.S.copy())
+            cy.append(np.ravel(kf.y).copy())
+        d.update({q + "M": M, q + "corr_x": np.array(cx), q + "corr_P": np.array(cP), q + "corr_K": np.array(cK),
+                  q + "corr_S": np.array(cS), q + "corr_y": np.array(cy)})
+        # --- sequential: the components of one z one at a time (column-vector state, as the reference needs)
+        kf = make_kf(n, m, x0.reshape(-1, 1), P0, F, Q, H, R)
+        kf.predict()
+        sx, sP = [], []
+        for i in range(m):
+            kf.update_sequential(i, zs[0][i])
+            sx.append(kf.x.copy().ravel()); sP.append(kf.P.copy())
+        d.update({q + "seq_x": np.array(sx), q + "seq_P": np.array(sP), q + "seq_K": kf.K.copy(),
+                  q + "seq_y": np.ravel(kf.y).copy()})
+        if m >= 2:    # a 2-component block
+            kf = make_kf(n, m, x0.reshape(-1, 1), P0, F, Q, H, R)
+            kf.predict()
+            kf.update_sequential(m - 2, zs[0][m - 2:])
+            d.update({q + "seqb_x": kf.x.copy().ravel(), q + "seqb_P": kf.P.copy()})
+    d["cases"] = np.array(cases)
+    np.savez_compressed(os.path.join(OUT, "kf_variants.npz"), **d)
+
 # ------------------------------------------------------------------ IMM ----
 IMM_CASES = [(2, 1, 2), (4, 2, 2), (4, 2, 3), (6, 3, 2), (3, 2, 2), (5, 2, 3)]
 
@@ -433,7 +508,7 @@ def gen_resample():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["c1", "dims", "models", "steps", "saver", "imm", "mmae", "ukf", "resample"]
+    which = sys.argv[1:] or ["c1", "dims", "models", "steps", "saver", "variants", "imm", "mmae", "ukf", "resample"]
     for w in which:
         print("generating", w)
         globals()["gen_" + w]()

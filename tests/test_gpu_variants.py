@@ -1,0 +1,199 @@
+"""-m gpu parity tests for the N4 API variants: steady-state filter, update_correlated,
+update_sequential (kf_variants.hip / fk_kf_update_f64) and UnscentedKalmanFilter.rts_smoother
+(fk_ukf_rts_correct_f64), through the filterpy-shaped classes and the bank, against goldens frozen
+from the live reference and against the oracle on seeded banks."""
+import numpy as np
+import pytest
+
+from conftest import golden, rel_err_rows
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-10
+CASES = [(2, 1), (4, 2), (6, 3), (9, 3), (3, 2)]
+
+
+def _kf(g, q, n, m, column=False):
+    from filterpy_amd.kalman import KalmanFilter
+    kf = KalmanFilter(dim_x=n, dim_z=m)
+    kf.x = g[q + "x0"].reshape(-1, 1).copy() if column else g[q + "x0"].copy()
+    kf.P, kf.F, kf.Q, kf.H, kf.R = (g[q + k].copy() for k in ("P0", "F", "Q", "H", "R"))
+    return kf
+
+
+@pytest.mark.parametrize("n,m", CASES)
+def test_steadystate_class_drop_in(n, m):
+    g = golden("kf_variants")
+    q = f"n{n}m{m}_"
+    for tag, ctrl in (("ss_", False), ("ssu_", True)):
+        kf = _kf(g, q, n, m)
+        kf.K, kf.P = g[q + "K"].copy(), g[q + "Pss"].copy()
+        if ctrl:
+            kf.B = g[q + "B"].copy()
+        for t in range(12):
+            kf.predict_steadystate(u=g[q + "us"][t]) if ctrl else kf.predict_steadystate()
+            assert rel_err_rows(kf.x, g[q + tag + "xp"][t]) < TOL and rel_err_rows(kf.x_prior, g[q + tag + "xp"][t]) < TOL
+            kf.update_steadystate(None if t == 7 else g[q + "zs"][t])
+            assert rel_err_rows(kf.x, g[q + tag + "x"][t]) < TOL
+            assert np.allclose(np.ravel(kf.y), g[q + tag + "y"][t], rtol=1e-9, atol=1e-12)
+        assert np.array_equal(kf.P, g[q + "Pss"]) and np.array_equal(kf.K, g[q + "K"])
+
+
+@pytest.mark.parametrize("layout", ["soa", "aos"])
+@pytest.mark.parametrize("n,m", CASES)
+def test_steadystate_bank(n, m, layout):
+    """T steps in one launch: golden track replicated; shared and per-track gains; missing z."""
+    from filterpy_amd.kalman import KalmanFilterBank
+    from gpu_util import tile_tracks
+    from oracle import kf_oracle
+    g = golden("kf_variants")
+    q = f"n{n}m{m}_"
+    N, T = 300, 25
+    bank = KalmanFilterBank(n, m, N, layout=layout)
+    bank.x, bank.F, bank.H, bank.K = tile_tracks(g[q + "x0"], N), g[q + "F"], g[q + "H"], g[q + "K"]
+    zs = tile_tracks(g[q + "zs"], N, axis=1)
+    mask = np.ones((T, N), dtype=bool)
+    mask[7] = False
+    means, means_p, y = bank.steadystate_filter(zs, mask=mask)
+    for trk in (0, 255, 256, N - 1):
+        assert rel_err_rows(means[:, trk], g[q + "ss_x"]) < TOL and rel_err_rows(means_p[:, trk], g[q + "ss_xp"]) < TOL
+        assert np.allclose(y[:, trk], g[q + "ss_y"], rtol=1e-9, atol=1e-12)
+    assert rel_err_rows(bank.x[5], g[q + "ss_x"][-1]) < TOL
+    # per-track gains and states, control input, against the oracle
+    rs = np.random.RandomState(n + m)
+    bank = KalmanFilterBank(n, m, N, dim_u=2, layout=layout)
+    x0 = rs.randn(N, n)
+    Ks = g[q + "K"][None] * (1 + 0.1 * rs.rand(N, 1, 1))
+    zs, us = rs.randn(T, N, m), rs.randn(T, N, 2)
+    bank.x, bank.F, bank.H, bank.K, bank.B = x0.copy(), g[q + "F"], g[q + "H"], Ks, g[q + "B"]
+    means, means_p, y = bank.steadystate_filter(zs, us=us)
+    for trk in (0, 100, N - 1):
+        rx, rxp, ry = kf_oracle.steadystate_filter(x0[trk], list(zs[:, trk]), g[q + "F"], g[q + "H"], Ks[trk],
+                                                   B=g[q + "B"], us=us[:, trk])
+        assert rel_err_rows(means[:, trk], rx) < TOL and rel_err_rows(means_p[:, trk], rxp) < TOL
+        assert np.allclose(y[:, trk], ry, rtol=1e-9, atol=1e-12)
+    # the single-step methods of the bank
+    bank.x = x0.copy()
+    bank.predict_steadystate(u=us[0])
+    bank.update_steadystate(zs[0])
+    assert rel_err_rows(bank.x, means[0]) < 1e-14
+
+
+@pytest.mark.parametrize("column", [False, True])
+@pytest.mark.parametrize("n,m", CASES)
+def test_update_correlated_class_drop_in(n, m, column):
+    g = golden("kf_variants")
+    q = f"n{n}m{m}_"
+    kf = _kf(g, q, n, m, column)
+    kf.M = g[q + "M"].copy()
+    for t in range(3):
+        kf.predict()
+        z = g[q + "zs"][t].reshape(-1, 1) if column else g[q + "zs"][t]
+        if t == 2:
+            kf.update_correlated(z, R=2.0 * g[q + "R"], H=0.5 * g[q + "H"])
+        else:
+            kf.update_correlated(z)
+        assert rel_err_rows(np.ravel(kf.x), g[q + "corr_x"][t]) < TOL and rel_err_rows(kf.P, g[q + "corr_P"][t]) < TOL
+        assert rel_err_rows(kf.K, g[q + "corr_K"][t]) < TOL and rel_err_rows(kf.S, g[q + "corr_S"][t]) < TOL
+        assert np.allclose(np.ravel(kf.y), g[q + "corr_y"][t], rtol=1e-9, atol=1e-12)
+        assert rel_err_rows(kf.SI, np.linalg.inv(g[q + "corr_S"][t])) < 1e-8
+    kf.update_correlated(None)
+    assert np.all(kf.y == 0)
+
+
+@pytest.mark.parametrize("layout", ["soa", "aos"])
+@pytest.mark.parametrize("n,m", [(4, 2), (9, 3), (3, 2)])
+def test_update_correlated_bank_vs_oracle(n, m, layout):
+    from filterpy_amd.kalman import KalmanFilterBank
+    from oracle import kf_oracle
+    g = golden("kf_variants")
+    q = f"n{n}m{m}_"
+    rs = np.random.RandomState(5 * n + m)
+    N = 500
+    x0 = rs.randn(N, n)
+    A = rs.randn(N, n, n)
+    P0 = A @ np.swapaxes(A, 1, 2) / n + 0.5 * np.eye(n)
+    z = rs.randn(N, m)
+    for per_track in (False, True):
+        M = 0.1 * rs.randn(N, n, m) if per_track else g[q + "M"]
+        bank = KalmanFilterBank(n, m, N, layout=layout)
+        bank.x, bank.P, bank.H, bank.R, bank.M = x0.copy(), P0.copy(), g[q + "H"], g[q + "R"], M
+        mask = np.ones(N, dtype=bool)
+        mask[3] = False
+        bank.update_correlated(z, mask=mask)
+        for trk in (0, 255, 256, N - 1):
+            x, P, y, K, S, SI = kf_oracle.update_correlated(x0[trk], P0[trk], z[trk], g[q + "R"], g[q + "H"],
+                                                            M[trk] if per_track else M)
+            assert rel_err_rows(bank.x[trk], x) < TOL and rel_err_rows(bank.P[trk], P) < TOL
+            assert rel_err_rows(bank.K[trk], K) < TOL and rel_err_rows(bank.S[trk], S) < TOL
+        assert np.array_equal(bank.x[3], x0[3]) and np.array_equal(bank.P[3], P0[3])
+
+
+@pytest.mark.parametrize("n,m", CASES)
+def test_update_sequential_class_and_bank(n, m):
+    from filterpy_amd.kalman import KalmanFilterBank
+    from gpu_util import tile_tracks
+    g = golden("kf_variants")
+    q = f"n{n}m{m}_"
+    kf = _kf(g, q, n, m, column=True)
+    kf.predict()
+    xp, Pp = kf.x.copy(), kf.P.copy()
+    for i in range(m):
+        kf.update_sequential(i, g[q + "zs"][0][i])
+        assert rel_err_rows(np.ravel(kf.x), g[q + "seq_x"][i]) < TOL and rel_err_rows(kf.P, g[q + "seq_P"][i]) < TOL
+    assert rel_err_rows(kf.K, g[q + "seq_K"]) < TOL
+    assert np.allclose(np.ravel(kf.y), g[q + "seq_y"], rtol=1e-9, atol=1e-12)
+    if m >= 2:
+        kf.x, kf.P = xp.copy(), Pp.copy()
+        kf.update_sequential(m - 2, g[q + "zs"][0][m - 2:])
+        assert rel_err_rows(np.ravel(kf.x), g[q + "seqb_x"]) < TOL and rel_err_rows(kf.P, g[q + "seqb_P"]) < TOL
+    N = 70
+    bank = KalmanFilterBank(n, m, N)
+    bank.x, bank.P = tile_tracks(xp.ravel(), N), tile_tracks(Pp, N)
+    bank.H, bank.R = g[q + "H"], g[q + "R"]
+    for i in range(m):
+        bank.update_sequential(i, np.full((N, 1), g[q + "zs"][0][i]))
+    assert rel_err_rows(bank.x[N - 1], g[q + "seq_x"][-1]) < TOL and rel_err_rows(bank.P[1], g[q + "seq_P"][-1]) < TOL
+
+
+def _ukf_cases():
+    g = golden("ukf_merwe")
+    return [(ci, int(c[0]), int(c[1]), float(c[2]), float(c[3]), float(c[4])) for ci, c in enumerate(g["cases"])]
+
+
+@pytest.mark.parametrize("linear_matrices", [False, True])
+def test_ukf_rts_smoother_goldens(linear_matrices):
+    """UnscentedKalmanFilter.rts_smoother on the reference's own filter output (goldens from the
+    live reference: ukf.rts_smoother(mu, cov))."""
+    from filterpy_amd.kalman import UnscentedKalmanFilter, MerweScaledSigmaPoints
+    g = golden("ukf_merwe")
+    for ci, n, m, alpha, beta, kappa in _ukf_cases():
+        if n > 9:
+            continue
+        p = f"c{ci}_"
+        F, H = g[p + "F"], g[p + "H"]
+        pts = MerweScaledSigmaPoints(n, alpha, beta, kappa)
+        if linear_matrices:
+            ukf = UnscentedKalmanFilter(n, m, dt=1.0, hx=H, fx=F, points=pts)
+        else:
+            ukf = UnscentedKalmanFilter(n, m, dt=1.0, hx=lambda x: H @ x, fx=lambda x, dt: F @ x, points=pts)
+        ukf.Q, ukf.R = g[p + "Q"].copy(), g[p + "R"].copy()
+        xs, Ps, Ks = ukf.rts_smoother(g[p + "mu"], g[p + "cov"])
+        assert xs.shape == g[p + "rts_x"].shape and Ks.shape == g[p + "rts_K"].shape
+        assert rel_err_rows(xs, g[p + "rts_x"]) < 1e-9, ci
+        assert rel_err_rows(Ps, g[p + "rts_P"]) < 1e-9, ci
+        assert rel_err_rows(Ks[:-1], g[p + "rts_K"][:-1]) < 1e-8, ci
+
+
+def test_ukf_rts_smoother_bank():
+    from filterpy_amd.kalman import UnscentedKalmanFilter, MerweScaledSigmaPoints
+    from gpu_util import tile_tracks
+    g = golden("ukf_merwe")
+    ci, n, m, alpha, beta, kappa = _ukf_cases()[1]
+    p = f"c{ci}_"
+    N = 40
+    ukf = UnscentedKalmanFilter(n, m, dt=1.0, hx=g[p + "H"], fx=g[p + "F"],
+                                points=MerweScaledSigmaPoints(n, alpha, beta, kappa), n_tracks=N)
+    ukf.Q, ukf.R = g[p + "Q"].copy(), g[p + "R"].copy()
+    xs, Ps, Ks = ukf.rts_smoother(tile_tracks(g[p + "mu"], N, axis=1), tile_tracks(g[p + "cov"], N, axis=1))
+    assert xs.shape == (30, N, n)
+    assert rel_err_rows(xs[:, N - 1], g[p + "rts_x"]) < 1e-9 and rel_err_rows(Ps[:, 0], g[p + "rts_P"]) < 1e-9

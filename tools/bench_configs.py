@@ -238,6 +238,37 @@ def config_imm(layout, n, m, nm, N, T):
          parity_max_rel=par, mu_max_abs=parmu, filter_steps_per_s=N * T * nm / (ms * 1e-3))
 
 
+def config_steady(layout, n, m, N, T):
+    """steady-state filter (fixed gain), T x {x = Fx; y = z - Hx; x += Ky} in one launch.
+    Algorithmic bytes per track-step: z in, prior and posterior x out."""
+    import torch
+    from filterpy_amd import _engine as E
+    from oracle import kf_oracle
+    rs = np.random.RandomState(n + m)
+    F = np.eye(n) + 0.05 * rs.randn(n, n)
+    H = np.eye(m, n)
+    K = 0.3 * rs.rand(n, m)
+    dev = torch.device("cuda")
+    g = torch.Generator(device=dev)
+    g.manual_seed(9)
+    z = torch.randn((T, N, m) if layout == "aos" else (T, m, N), generator=g, device=dev, dtype=torch.float64)
+    x0 = torch.zeros((N, n) if layout == "aos" else (n, N), dtype=torch.float64, device=dev)
+    x = x0.clone()
+    means, means_p = E.alloc_records((T,), N, n, layout), E.alloc_records((T,), N, n, layout)
+    desc = dict(n=n, m=m, nu=0, model_mode=0, N=N, T=T, layout=E.LAYOUTS[layout], update_first=0, alpha_sq=1.0)
+    d = [E.dev(a) for a in (F, H, K)]
+
+    def run():
+        x.copy_(x0)
+        E.kf_steadystate(desc, *d, z, x, means=means, means_p=means_p)
+    ms = timeit(run)
+    sample = [0, 255, N - 1]
+    zs_h = (z[:, sample] if layout == "aos" else z[:, :, sample].permute(0, 2, 1)).cpu().numpy()
+    got = E.from_records(means, layout, 1, (n,))[:, sample]
+    par = max(rel(got[:, k], kf_oracle.steadystate_filter(np.zeros(n), list(zs_h[:, k]), F, H, K)[0]) for k in range(3))
+    emit(f"steady-state KF ({n},{m}) N={N} {layout}", N * T, "track-steps", ms, 8 * (m + 2 * n), parity_max_rel=par)
+
+
 def config4(layout, N, T):
     import torch
     from filterpy_amd import _engine as E
@@ -336,6 +367,9 @@ if __name__ == "__main__":
             config_kf(lay, 6, 3, 300_000, a.T)
             config_kf(lay, 4, 2, 500_000, a.T)
             config_kf(lay, 2, 1, 2_000_000, a.T)
+        if "9" in a.configs:
+            config_steady(lay, 4, 2, 4_000_000, a.T)
+            config_steady(lay, 9, 3, 1_000_000, a.T)
         if "8" in a.configs:
             config_imm(lay, 4, 2, 2, 500_000, a.T)
             config_imm(lay, 4, 2, 3, 300_000, a.T)
