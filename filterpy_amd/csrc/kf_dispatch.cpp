@@ -25,6 +25,8 @@ namespace fk {
 #include "fk_dims_rts.def"
 #undef FK_RTS_INST
 
+int launch_kf_ml_9_3(const KfArgs &, int, bool, int, hipStream_t);   // kf_ml.hip: three lanes per track
+
 struct KfEntry {
     int nx, nz, exact;
     int (*fn)(const KfArgs &, int, bool, hipStream_t);
@@ -146,6 +148,10 @@ static int run_kf(const fk_kf_desc *d, KfArgs &a, void *stream)
     if (d->nu == 0 && !d->update_first && a.do_predict && a.do_update &&
         (all_out || no_out) && !a.y_out && !a.K_out && !a.S_out && !a.SI_out && !a.ll_out && !a.maha_out &&
         !getenv("FK_NO_FAST")) {
+        if (d->n == 9 && d->m == 3 && !getenv("FK_NO_ML")) {
+            const int rc = launch_kf_ml_9_3(a, d->layout, all_out, d->model_mode, (hipStream_t)stream);
+            if (rc <= 0) return rc;        // 1 = not a call the multi-lane kernel serves
+        }
         if (const FastEntry *f = pick_fast(d->n, d->m)) {
             const char *ev = getenv("FK_FAST_XCD");
             a.xcd_swizzle = ev ? atoi(ev) : 0;

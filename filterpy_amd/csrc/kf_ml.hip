@@ -1,0 +1,341 @@
+// kf_ml.hip -- batch_filter for dim_x = 9 with THREE LANES PER TRACK (gfx950).
+//
+// One lane per track stops scaling at dim_x = 9: P alone is 81 doubles = 162 VGPRs, the step's
+// temporaries push the kernel to one wave per SIMD with AGPR spills, and BASELINE config 3's 1e5
+// tracks are only 1563 waves for 1024 SIMDs.  Here a QUAD of lanes owns a track: lanes 0..2 hold
+// three rows of P each (27 doubles), lane 3 mirrors lane 2 (same loads, same stores: no lane is
+// ever predicated).  Every matrix product is arranged so that each output element is produced
+// whole by the lane that owns its row, in the reference's k = 0..n-1 order; the rows a lane does
+// not own arrive by quad-permute DPP moves (v_mov_b32 quad_perm:[s,s,s,s], two per double, no LDS):
+//
+//   predict  T = P F' (rows local) ; P' = a2 (F T) + Q : row k of T is broadcast, lane accumulates
+//            F[i][k] T[k][:] into its rows i       (kalman_filter.py:472-478; F P F' = F (P F') with
+//            P's symmetry, cf. fk_math_sym.hpp)
+//   update   PHT = P H' rows local, broadcast -> S, its L D L' and y replicated in every lane ;
+//            K rows local ; H P by a three-way sum across the quad ; T1 = P - K (H P) ;
+//            D = K R - T1 H' ; P+ = T1 + D K' with K's rows broadcast
+//            (Joseph form, kalman_filter.py:533-556, with the I - K H factors applied implicitly like
+//            fk_math_sym.hpp does, but without assuming P symmetric)
+//   x (9 doubles) is replicated in all lanes.
+//
+// Per lane and step: ~1250 FMAs and ~190 exchanged doubles, ~90 live doubles (one lane per track:
+// ~3700 FMAs, > 250 live doubles).  A wave carries 16 tracks, so config 3 becomes 6250 waves.
+// Layout: SOA only (element-major: a quad's three active lanes write three 128-byte segments per
+// store); exact dims (9, 3), shared constant model, predict -> update, no control input, no mask,
+// all four outputs or none.  Everything else stays on kf_fast / kf_kernel.
+#include <stdlib.h>
+
+#include "fk_device.hpp"
+#include "fk_kernel_args.hpp"
+#include "../../include/filterhip.h"
+
+#ifndef FK_ML_WAVES
+#define FK_ML_WAVES 2
+#endif
+
+namespace fk {
+
+template <int SRC>
+__device__ __forceinline__ double quad_bcast(double v)
+{
+    constexpr int ctrl = SRC * 0x55;   // quad_perm:[SRC,SRC,SRC,SRC]
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_mov_dpp(lo, ctrl, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_mov_dpp(hi, ctrl, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+
+// value of the lane selected by an arbitrary quad permutation (CTRL = quad_perm encoding)
+template <int CTRL>
+__device__ __forceinline__ double quad_rot(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+
+// raw buffer access with a per-lane byte offset and a wave-uniform element offset
+struct MlView {
+    rsrc_t rs;
+    unsigned voff, estride;
+    __device__ __forceinline__ MlView(const double *blk, unsigned lane_off, unsigned es) : rs(make_rsrc(blk)), voff(lane_off), estride(es)
+    {
+        // re-laundered per view (i.e. per time step): otherwise every e * estride is loop-invariant,
+        // gets hoisted out of the time loop (60 SGPRs) and the scalar file spills into VGPRs
+        asm volatile("" : "+s"(estride));
+    }
+    __device__ __forceinline__ double load(int e) const
+    {
+        return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, voff, (unsigned)e * estride, 0));
+    }
+    __device__ __forceinline__ void store(int e, double x) const
+    {
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, x), rs, voff, (unsigned)e * estride, 0);
+    }
+};
+
+template <int R, int NZ, bool OUTS, int WAVES, int VAR>
+__global__ void __launch_bounds__(BLOCK, WAVES)
+kf_ml_kernel(const KfArgs a)
+{
+    constexpr int NX = 3 * R;
+    using LM = LdsModel<NX, NZ>;
+    __shared__ double smem[LM::SIZE];
+    lds_fill<NX, NX>(smem + LM::OFF_F, a.F, NX, NX, 1.0, threadIdx.x);
+    lds_fill<NX, NX>(smem + LM::OFF_Q, a.Q, NX, NX, 0.0, threadIdx.x);
+    lds_fill<NZ, NX>(smem + LM::OFF_H, a.H, NZ, NX, 0.0, threadIdx.x);
+    lds_fill<NZ, NZ>(smem + LM::OFF_R, a.R, NZ, NZ, 1.0, threadIdx.x);
+    __syncthreads();
+    const double *sF = smem + LM::OFF_F, *sQ = smem + LM::OFF_Q, *sH = smem + LM::OFF_H, *sR = smem + LM::OFF_R;
+
+    const long N = a.N;
+    const unsigned L = threadIdx.x & 3u;
+    const unsigned Lc = L < 3u ? L : 2u;                       // lane 3 mirrors lane 2
+    long trk = (long)blockIdx.x * (BLOCK / 4) + (threadIdx.x >> 2);
+    if (trk >= N) trk = N - 1;                                 // tail quads recompute the last track
+    unsigned estride = (unsigned)N * 8u;
+    asm volatile("" : "+s"(estride));
+    const unsigned t8 = (unsigned)trk * 8u;
+    const unsigned off_rows = t8 + Lc * (unsigned)(R * NX) * estride;   // element (Lc*R + r)*NX + c
+    const double *myF = sF + Lc * (R * NX);                     // this lane's rows of F and Q
+    const double *myQ = sQ + Lc * (R * NX);
+
+    // VAR & 1: H (27 doubles, replicated) lives in VGPRs instead of being re-read from LDS per use
+    double Hreg[(VAR & 1) ? NZ * NX : 1];
+    if constexpr ((VAR & 1) != 0) {
+        FK_UNROLL for (int e = 0; e < NZ * NX; ++e) Hreg[e] = sH[e];
+    }
+#define HX(e) (((VAR & 1) != 0) ? Hreg[(e)] : sH[(e)])
+    double P[R][NX], x[NX];
+    {
+        const MlView vP(a.P, off_rows, estride), vx(a.x, t8, estride);
+        FK_UNROLL for (int r = 0; r < R; ++r)
+            FK_UNROLL for (int c = 0; c < NX; ++c) P[r][c] = vP.load(r * NX + c);
+        FK_UNROLL for (int k = 0; k < NX; ++k) x[k] = vx.load(k);
+        // land the prologue loads here: left pending, the loop header's s_waitcnt (which must cover this
+        // path too) makes every iteration wait for the previous step's stores
+        FK_UNROLL for (int r = 0; r < R; ++r)
+            FK_UNROLL for (int c = 0; c < NX; ++c) asm volatile("" ::"v"(P[r][c]));
+        FK_UNROLL for (int k = 0; k < NX; ++k) asm volatile("" ::"v"(x[k]));
+    }
+    int st = 0;
+    // z is fetched one step ahead: vmcnt retires in order, so waiting for a load also waits for every
+    // store issued before it; with a whole step between a load and its use, the wait is behind stores
+    // that had a full step to drain (the counter saturates at 63 anyway).
+    double zn[NZ];
+    {
+        const MlView vz(a.z, t8, estride);
+        FK_UNROLL for (int c = 0; c < NZ; ++c) zn[c] = vz.load(c);
+        FK_UNROLL for (int c = 0; c < NZ; ++c) asm volatile("" ::"v"(zn[c]));     // landed, like x and P above
+    }
+    _Pragma("nounroll") for (long t = 0; t < a.T; ++t) {
+        double z[NZ];
+        FK_UNROLL for (int c = 0; c < NZ; ++c) z[c] = zn[c];
+        {
+            long tn = t + 1 < a.T ? t + 1 : t;
+            asm volatile("" : "+s"(tn));      // opaque: keeps the compiler from re-deriving this load one iteration later
+            const MlView vz(a.z + tn * N * NZ, t8, estride);
+            FK_UNROLL for (int c = 0; c < NZ; ++c) zn[c] = vz.load(c);
+        }
+        // ---------------------------------------------------------------- predict --
+        {
+            double xn[NX];
+            FK_UNROLL for (int i = 0; i < NX; ++i) {
+                double acc = sF[i * NX] * x[0];
+                FK_UNROLL for (int k = 1; k < NX; ++k) acc = fma(sF[i * NX + k], x[k], acc);
+                xn[i] = acc;
+                FK_STAGE();                  // one row of F in flight at a time
+            }
+            FK_UNROLL for (int i = 0; i < NX; ++i) x[i] = xn[i];
+        }
+        if (OUTS) {
+            const MlView vx(a.means_p + t * N * NX, t8, estride);
+            FK_UNROLL for (int k = 0; k < NX; ++k) vx.store(k, x[k]);     // replicated: the quad writes the same bytes
+        }
+        FK_STAGE();
+        {
+            // The posterior covariance of step t-1 is still in P: its 27 stores are spread over the nine
+            // iterations below (and the prior's over the PHT stage), so that a wave's store traffic is
+            // issued evenly through its arithmetic instead of in two bursts per step that every wave of
+            // the chip fires at the same moment.
+            const MlView vPost(a.covs + (t > 0 ? t - 1 : 0) * N * NX * NX, off_rows, estride);
+            double T[R][NX];                 // T = P F' : T[r][i] = sum_k P[r][k] F[i][k]
+            FK_UNROLL for (int i = 0; i < NX; ++i) {
+                FK_UNROLL for (int r = 0; r < R; ++r) {
+                    double acc = P[r][0] * sF[i * NX];
+                    FK_UNROLL for (int k = 1; k < NX; ++k) acc = fma(P[r][k], sF[i * NX + k], acc);
+                    T[r][i] = acc;
+                }
+                if (OUTS) {
+                    // (at t == 0 this writes the initial P into covs[0], overwritten by step 0's own result later)
+                    FK_UNROLL for (int e = 0; e < R; ++e) vPost.store((i / R) * NX + (i % R) * R + e, P[i / R][(i % R) * R + e]);
+                }
+                FK_STAGE();
+            }
+            // P' = F T : row i (own) = sum_k F[i][k] T[k][:]
+            FK_UNROLL for (int k = 0; k < NX; ++k) {
+                double Tk[NX];
+                FK_UNROLL for (int j = 0; j < NX; ++j) {
+                    const double v = T[k % R][j];
+                    Tk[j] = (k / R == 0) ? quad_bcast<0>(v) : (k / R == 1) ? quad_bcast<1>(v) : quad_bcast<2>(v);
+                }
+                FK_UNROLL for (int r = 0; r < R; ++r) {
+                    const double f = myF[r * NX + k];
+                    FK_UNROLL for (int j = 0; j < NX; ++j) P[r][j] = (k == 0) ? f * Tk[j] : fma(f, Tk[j], P[r][j]);
+                }
+                FK_STAGE();
+            }
+            FK_UNROLL for (int r = 0; r < R; ++r)
+                FK_UNROLL for (int j = 0; j < NX; ++j) P[r][j] = fma(a.alpha_sq, P[r][j], myQ[r * NX + j]);
+        }
+        FK_STAGE();
+        // ----------------------------------------------------------------- update --
+        // Joseph form with the identity-minus-product factors applied implicitly (cf. fk_math_sym.hpp),
+        // WITHOUT assuming P symmetric -- P is held by rows and its two triangles round differently;
+        // replacing H P by (P H')' turns the contraction of that rounding asymmetry into an
+        // amplification, 1e-16 -> 1e-8 in 40 steps of an unstable model:
+        //   T1 = (I-KH) P = P - K (H P) ;  G = T1 H' ;  P+ = T1 (I-KH)' + K R K' = T1 + (K R - G) K'
+        // PHT = P H', G and every row of T1 / P+ are lane-local; H P needs columns of P, i.e. one
+        // three-way sum across the quad (27 values); PHT (for S) and K's rows are gathered.
+        double y[NZ], K[R][NZ];
+        {
+            FK_UNROLL for (int c = 0; c < NZ; ++c) {
+                double acc = HX(c * NX) * x[0];
+                FK_UNROLL for (int k = 1; k < NX; ++k) acc = fma(HX(c * NX + k), x[k], acc);
+                y[c] = z[c] - acc;
+            }
+            const MlView vPri(a.covs_p + t * N * NX * NX, off_rows, estride);
+            double PHT[R][NZ], S[NZ * NZ];
+            FK_UNROLL for (int r = 0; r < R; ++r) {
+                FK_UNROLL for (int c = 0; c < NZ; ++c) {
+                    double acc = P[r][0] * HX(c * NX);
+                    FK_UNROLL for (int k = 1; k < NX; ++k) acc = fma(P[r][k], HX(c * NX + k), acc);
+                    PHT[r][c] = acc;
+                }
+                if (OUTS) {
+                    FK_UNROLL for (int c = 0; c < NX; ++c) vPri.store(r * NX + c, P[r][c]);
+                }
+                FK_STAGE();
+            }
+            // S = H PHT + R, replicated in every lane: PHT's row k comes from its owner
+            FK_UNROLL for (int k = 0; k < NX; ++k) {
+                double pk[NZ];
+                FK_UNROLL for (int c = 0; c < NZ; ++c) {
+                    const double v = PHT[k % R][c];
+                    pk[c] = (k / R == 0) ? quad_bcast<0>(v) : (k / R == 1) ? quad_bcast<1>(v) : quad_bcast<2>(v);
+                }
+                FK_UNROLL for (int r = 0; r < NZ; ++r)
+                    FK_UNROLL for (int c = 0; c < NZ; ++c)
+                        S[r * NZ + c] = (k == 0) ? HX(r * NX) * pk[c] : fma(HX(r * NX + k), pk[c], S[r * NZ + c]);
+            }
+            FK_UNROLL for (int e = 0; e < NZ * NZ; ++e) S[e] += sR[e];
+            FK_STAGE();
+            double Lf[NZ * NZ], d[NZ], dinv[NZ], Kr[R * NZ];
+            FK_UNROLL for (int e = 0; e < NZ * NZ; ++e) Lf[e] = S[e];
+            if (!ldlt2<NZ>(Lf, d, dinv)) st |= ST_NOT_PD;
+            FK_UNROLL for (int r = 0; r < R; ++r)
+                FK_UNROLL for (int c = 0; c < NZ; ++c) Kr[r * NZ + c] = PHT[r][c];
+            solve_rows_ldlt<R, NZ>(Lf, dinv, Kr);
+            FK_UNROLL for (int r = 0; r < R; ++r)
+                FK_UNROLL for (int c = 0; c < NZ; ++c) K[r][c] = Kr[r * NZ + c];
+        }
+        FK_STAGE();
+        {
+            // H P: this lane's rows contribute sum_r H[c][row0 + r] P[r][:]; the quad adds the three parts
+            const double *myH = sH + Lc * R;
+            double HP[NZ][NX];
+            FK_UNROLL for (int c = 0; c < NZ; ++c) {
+                FK_UNROLL for (int j = 0; j < NX; ++j) {
+                    double acc = myH[c * NX] * P[0][j];
+                    FK_UNROLL for (int r = 1; r < R; ++r) acc = fma(myH[c * NX + r], P[r][j], acc);
+                    HP[c][j] = acc;
+                }
+                FK_UNROLL for (int j = 0; j < NX; ++j) HP[c][j] = (HP[c][j] + quad_rot<0x09>(HP[c][j])) + quad_rot<0x52>(HP[c][j]);
+                FK_STAGE();
+            }
+            // T1 = P - K (H P) (own rows, in place)
+            FK_UNROLL for (int r = 0; r < R; ++r) {
+                FK_UNROLL for (int j = 0; j < NX; ++j) {
+                    double acc = P[r][j];
+                    FK_UNROLL for (int c = 0; c < NZ; ++c) acc = fma(-K[r][c], HP[c][j], acc);
+                    P[r][j] = acc;
+                }
+                FK_STAGE();
+            }
+            // D = K R - T1 H' (own rows)
+            double D[R][NZ];
+            FK_UNROLL for (int r = 0; r < R; ++r)
+                FK_UNROLL for (int c = 0; c < NZ; ++c) {
+                    double kr = K[r][0] * sR[c];
+                    FK_UNROLL for (int q = 1; q < NZ; ++q) kr = fma(K[r][q], sR[q * NZ + c], kr);
+                    double g = P[r][0] * HX(c * NX);
+                    FK_UNROLL for (int k = 1; k < NX; ++k) g = fma(P[r][k], HX(c * NX + k), g);
+                    D[r][c] = kr - g;
+                }
+            FK_STAGE();
+            // P+ = T1 + D K' : column j needs K's row j from its owner; the same row updates x[j]
+            FK_UNROLL for (int j = 0; j < NX; ++j) {
+                double Kj[NZ];
+                FK_UNROLL for (int c = 0; c < NZ; ++c) {
+                    const double v = K[j % R][c];
+                    Kj[c] = (j / R == 0) ? quad_bcast<0>(v) : (j / R == 1) ? quad_bcast<1>(v) : quad_bcast<2>(v);
+                }
+                double xa = x[j];
+                FK_UNROLL for (int c = 0; c < NZ; ++c) xa = fma(Kj[c], y[c], xa);
+                x[j] = xa;
+                FK_UNROLL for (int r = 0; r < R; ++r) {
+                    double acc = P[r][j];
+                    FK_UNROLL for (int c = 0; c < NZ; ++c) acc = fma(D[r][c], Kj[c], acc);
+                    P[r][j] = acc;
+                }
+            }
+        }
+        if (OUTS) {
+            const MlView vx(a.means + t * N * NX, t8, estride);
+            FK_UNROLL for (int k = 0; k < NX; ++k) vx.store(k, x[k]);
+        }
+    }
+    if (OUTS && a.T > 0) {      // the last step's posterior covariance (the others were stored one step late)
+        const MlView vP(a.covs + (a.T - 1) * N * NX * NX, off_rows, estride);
+        FK_UNROLL for (int r = 0; r < R; ++r)
+            FK_UNROLL for (int c = 0; c < NX; ++c) vP.store(r * NX + c, P[r][c]);
+    }
+    {
+        const MlView vx(a.x, t8, estride), vP(a.P, off_rows, estride);
+        bool fin = all_finite<NX>(x);
+        FK_UNROLL for (int k = 0; k < NX; ++k) vx.store(k, x[k]);
+        FK_UNROLL for (int r = 0; r < R; ++r) {
+            FK_UNROLL for (int c = 0; c < NX; ++c) {
+                vP.store(r * NX + c, P[r][c]);
+                fin = fin && (fabs(P[r][c]) <= 1.79769313486231570815e+308);
+            }
+        }
+        if (a.status) {
+            int s = st | (fin ? 0 : ST_NONFINITE);
+            s |= __builtin_amdgcn_mov_dpp(s, 0x55 * 1, 0xf, 0xf, true) | __builtin_amdgcn_mov_dpp(s, 0x55 * 2, 0xf, 0xf, true);
+            if (L == 0) a.status[trk] = s;       // duplicate tail quads write the same value
+        }
+    }
+}
+
+// returns 1 when this call is not one the multi-lane kernel serves
+int launch_kf_ml_9_3(const KfArgs &a, int layout, bool outs, int model_mode, hipStream_t s)
+{
+    if (layout != FK_LAYOUT_SOA || model_mode != FK_MODEL_SHARED || a.n != 9 || a.m != 3 || a.mask) return 1;
+    const dim3 grid((unsigned)((a.N + BLOCK / 4 - 1) / (BLOCK / 4))), block(BLOCK);
+    // FK_ML_WAVES = 1 | 2 | 3: occupancy target of the instantiation (A/B measurements); default 2
+    // FK_ML_VAR=0: H re-read from LDS at every use instead of held in VGPRs (A/B measurements)
+    const char *vv = getenv("FK_ML_VAR");
+    const int var = vv ? atoi(vv) : 1;
+#define GO(V)                                                                                             \
+    if (outs) hipLaunchKernelGGL((kf_ml_kernel<3, 3, true, FK_ML_WAVES, V>), grid, block, 0, s, a);      \
+    else hipLaunchKernelGGL((kf_ml_kernel<3, 3, false, FK_ML_WAVES, V>), grid, block, 0, s, a)
+    if (var == 0) { GO(0); } else { GO(1); }
+#undef GO
+    return check_launch("kf_ml_kernel");
+}
+
+#undef HX
+
+}  // namespace fk

@@ -171,7 +171,9 @@ def test_fast_kernel_tuning_variants(n, m, variants, layout, monkeypatch):
     args = (tile_tracks(g[p + "x0"], N), tile_tracks(g[p + "P0"], N), tile_tracks(g[p + "zs"], N, 1),
             g[p + "F"], g[p + "Q"], g[p + "H"], g[p + "R"])
     mask = tile_tracks(g[p + "mask"], N, 1)
-    settings = [{"FK_FAST_VARIANT": str(v)} for v in variants] + [{"FK_FAST_XCD": "1"}, {"FK_NO_FAST": "1"}]
+    # FK_NO_ML: keep the one-lane-per-track variants of (9,3) covered now that kf_ml.hip takes that call
+    settings = ([{"FK_FAST_VARIANT": str(v), "FK_NO_ML": "1"} for v in variants] +
+                [{}, {"FK_ML_VAR": "0"}, {"FK_FAST_XCD": "1", "FK_NO_ML": "1"}, {"FK_NO_FAST": "1"}])
     for env in settings:
         with monkeypatch.context() as mp:
             for k, v in env.items():
@@ -181,3 +183,29 @@ def test_fast_kernel_tuning_variants(n, m, variants, layout, monkeypatch):
                 for got, key in ((mu, "mu"), (cov, "cov"), (mup, "mup"), (covp, "covp")):
                     for trk in (0, 255, 256, N - 1):
                         assert rel_err_rows(got[:, trk], g[p + tag + "_" + key]) < TOL, (env, tag, key, trk)
+
+
+@pytest.mark.parametrize("outputs", [True, False])
+def test_multilane_9_3_vs_oracle(outputs):
+    """kf_ml.hip (three lanes per track, quad-permute row exchange): every track its own state and
+    measurements, N not a multiple of the 64 tracks per workgroup, alpha != 1."""
+    from gpu_util import run_kf_batch
+    n, m = 9, 3
+    rs = np.random.RandomState(93)
+    N, T = 1000, 40
+    A = rs.randn(N, n, n)
+    x0, P0 = rs.randn(N, n), 4.0 * (A @ A.transpose(0, 2, 1) / n + 0.5 * np.eye(n))
+    zs = rs.randn(T, N, m) * 3
+    F = np.eye(n) + 0.1 * rs.randn(n, n)
+    B = rs.randn(n, n)
+    Q = 0.1 * (B @ B.T / n + 0.5 * np.eye(n))
+    H = rs.randn(m, n)
+    C = rs.randn(m, m)
+    R = 0.5 * (C @ C.T / m + 0.5 * np.eye(m))
+    got = run_kf_batch(x0, P0, zs, F, Q, H, R, layout="soa", alpha_sq=1.02 ** 2, outputs=outputs)
+    sample = [0, 1, 15, 16, 63, 64, 255, 256, 959, 960, N - 1]
+    ref = kf_oracle.kf_batch_filter_tracks(x0, P0, zs, F, Q, H, R, tracks=sample, alpha_sq=1.02 ** 2)
+    if outputs:
+        for k in range(4):
+            assert rel_err_rows(_per_track(got[k][:, sample]), _per_track(ref[k])) < TOL, k
+    assert rel_err_rows(got[4][sample], ref[0][-1]) < TOL and rel_err_rows(got[5][sample], ref[1][-1]) < TOL

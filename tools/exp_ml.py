@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""A/B timing of the (9,3) kernels on one GPU: multi-lane (FK_ML_VAR=1|0: H in VGPRs or LDS) vs one lane per track
+(FK_NO_ML=1), with and without the four per-step outputs.  SOA, shared model, N tracks x T steps."""
+import json
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    import torch
+    from filterpy_amd import _engine as E
+    from tools.bench_configs import cv3d_model, timeit
+    N, T, n, m = int(os.environ.get("ML_N", 100000)), 100, 9, 3
+    F, Q, H, R = cv3d_model()
+    dev = torch.device("cuda")
+    g = torch.Generator(device=dev)
+    g.manual_seed(3)
+    z = torch.randn((T, m, N), generator=g, device=dev, dtype=torch.float64)
+    x0 = torch.zeros((n, N), dtype=torch.float64, device=dev)
+    P0 = (10.0 * torch.eye(n, dtype=torch.float64, device=dev)).reshape(1, n * n).repeat(N, 1).T.contiguous()
+    x, P = x0.clone(), P0.clone()
+    outs = [E.alloc_records((T,), N, n, "soa"), E.alloc_records((T,), N, n * n, "soa"),
+            E.alloc_records((T,), N, n, "soa"), E.alloc_records((T,), N, n * n, "soa")]
+    st = torch.zeros(N, dtype=torch.int32, device=dev)
+    d = [E.dev(a) for a in (F, Q, H, R)]
+    desc = dict(n=n, m=m, nu=0, model_mode=0, N=N, T=T, layout=E.LAYOUTS["soa"], update_first=0, alpha_sq=1.0)
+    for env in ({"FK_ML_VAR": "1"}, {"FK_ML_VAR": "0"}, {"FK_NO_ML": "1"}):
+        for k in ("FK_ML_WAVES", "FK_NO_ML", "FK_ML_SKEW", "FK_ML_VAR"):
+            os.environ.pop(k, None)
+        os.environ.update(env)
+        for with_out in (True, False):
+            o = outs if with_out else [None] * 4
+
+            def run():
+                x.copy_(x0)
+                P.copy_(P0)
+                E.kf_batch_filter(desc, *d, z, x, P, means=o[0], covs=o[1], means_p=o[2], covs_p=o[3], status=st)
+            ms = timeit(run, warm=2, reps=5)
+            print(json.dumps(dict(env=env, outputs=with_out, N=N, ms=ms, track_steps_per_s=N * T / ms * 1e3,
+                                  frac=N * T * 1464 / (ms * 1e-3) / 8e12 if with_out else None)), flush=True)
+
+
+if __name__ == "__main__":
+    main()
