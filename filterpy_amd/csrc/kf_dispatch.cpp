@@ -26,6 +26,7 @@ namespace fk {
 #undef FK_RTS_INST
 
 int launch_kf_ml_9_3(const KfArgs &, int, bool, int, hipStream_t);   // kf_ml.hip: three lanes per track
+int launch_rts_ml_9(const RtsArgs &, int, bool, hipStream_t);
 
 struct KfEntry {
     int nx, nz, exact;
@@ -258,6 +259,10 @@ int fk_kf_rts_f64(const fk_kf_desc *desc, const double *F, const double *Q, cons
     a.model_t = (desc->model_mode == FK_MODEL_PER_TRACK_STEP || desc->model_mode == FK_MODEL_PER_STEP) ? 1 : 0;
     a.conv_off = index_convention == 0 ? 1 : 0;
     const bool uniform = (desc->model_mode == FK_MODEL_SHARED || desc->model_mode == FK_MODEL_PER_STEP);
+    if (desc->n == 9 && !getenv("FK_NO_ML")) {
+        const int rc = launch_rts_ml_9(a, desc->layout, uniform, (hipStream_t)stream);
+        if (rc <= 0) return rc;            // 1 = not a call the multi-lane smoother serves
+    }
     return e->fn(a, desc->layout, uniform, (hipStream_t)stream);
 }
 

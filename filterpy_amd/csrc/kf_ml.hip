@@ -26,6 +26,7 @@
 #include <stdlib.h>
 
 #include "fk_device.hpp"
+#include "fk_math_sym.hpp"
 #include "fk_kernel_args.hpp"
 #include "../../include/filterhip.h"
 
@@ -58,8 +59,11 @@ __device__ __forceinline__ double quad_rot(double v)
 // raw buffer access with a per-lane byte offset and a wave-uniform element offset
 struct MlView {
     rsrc_t rs;
-    unsigned voff, estride;
-    __device__ __forceinline__ MlView(const double *blk, unsigned lane_off, unsigned es) : rs(make_rsrc(blk)), voff(lane_off), estride(es)
+    unsigned voff, voff2, estride;
+    // lane_off: this lane's byte offset for 8-byte accesses; pair_off: for the 16-byte pair accesses
+    // (even quads: lane_off; odd quads: one track back and one element plane up)
+    __device__ __forceinline__ MlView(const double *blk, unsigned lane_off, unsigned es, unsigned pair_off = 0)
+        : rs(make_rsrc(blk)), voff(lane_off), voff2(pair_off), estride(es)
     {
         // re-laundered per view (i.e. per time step): otherwise every e * estride is loop-invariant,
         // gets hoisted out of the time loop (60 SGPRs) and the scalar file spills into VGPRs
@@ -73,9 +77,87 @@ struct MlView {
     {
         __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, x), rs, voff, (unsigned)e * estride, 0);
     }
+    // Two elements per lane as ONE 16-byte store.  In the element-major layout the 16 bytes next to a
+    // lane's value belong to the next track, i.e. to the next quad: even quads write element e of tracks
+    // (q, q+1), odd quads element e+1 of tracks (q-1, q), each taking the partner's value over a row
+    // shift by 4 lanes with a bank mask (DPP banks are the quads).  A wave may have 63 vector-memory
+    // operations in flight whatever their size; with 8-byte stores that, not HBM, bounded this kernel
+    // (~4 TB/s; the same bytes in half as many stores: +25 %).
+    //   a = element e, b = element e + 1 of this lane's track.
+    __device__ __forceinline__ void store_pair(int e, double a, double b) const
+    {
+        using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+        const int ax = __double2loint(a), ay = __double2hiint(a), bx = __double2loint(b), by = __double2hiint(b);
+        u32x4 v;
+        v.x = (unsigned)__builtin_amdgcn_update_dpp(ax, bx, 0x114, 0xf, 0xa, false);   // odd quads: b of quad - 1 (row_shr:4)
+        v.y = (unsigned)__builtin_amdgcn_update_dpp(ay, by, 0x114, 0xf, 0xa, false);
+        v.z = (unsigned)__builtin_amdgcn_update_dpp(bx, ax, 0x104, 0xf, 0x5, false);   // even quads: a of quad + 1 (row_shl:4)
+        v.w = (unsigned)__builtin_amdgcn_update_dpp(by, ay, 0x104, 0xf, 0x5, false);
+        __builtin_amdgcn_raw_buffer_store_b128(v, rs, voff2, (unsigned)e * estride, 0);
+    }
+    // the mirror image for loads: one 16-byte load per lane, then the quads swap halves
+    __device__ __forceinline__ void load_pair(int e, double &a, double &b) const
+    {
+        using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff2, (unsigned)e * estride, 0);
+        // even quad holds [a(q), a(q+1)], odd quad [b(q-1), b(q)]
+        const int ax = __builtin_amdgcn_update_dpp((int)v.x, (int)v.z, 0x114, 0xf, 0xa, false);   // odd: a(q) = even's high half
+        const int ay = __builtin_amdgcn_update_dpp((int)v.y, (int)v.w, 0x114, 0xf, 0xa, false);
+        const int bx = __builtin_amdgcn_update_dpp((int)v.z, (int)v.x, 0x104, 0xf, 0x5, false);   // even: b(q) = odd's low half
+        const int by = __builtin_amdgcn_update_dpp((int)v.w, (int)v.y, 0x104, 0xf, 0x5, false);
+        a = __hiloint2double(ay, ax);
+        b = __hiloint2double(by, bx);
+    }
 };
 
-template <int R, int NZ, bool OUTS, int WAVES, int VAR>
+// a lane's R x NX rows (R*NX consecutive elements) as pairs + one odd element
+template <int R, int NX, bool PAIRS>
+__device__ __forceinline__ void store_rows(const MlView &v, const double (&M)[R][NX])
+{
+    if constexpr (PAIRS) {
+        FK_UNROLL for (int f = 0; f + 1 < R * NX; f += 2) v.store_pair(f, M[f / NX][f % NX], M[(f + 1) / NX][(f + 1) % NX]);
+        if ((R * NX) % 2) v.store(R * NX - 1, M[R - 1][NX - 1]);
+    } else {
+        FK_UNROLL for (int r = 0; r < R; ++r)
+            FK_UNROLL for (int c = 0; c < NX; ++c) v.store(r * NX + c, M[r][c]);
+    }
+}
+
+template <int R, int NX, bool PAIRS>
+__device__ __forceinline__ void load_rows(const MlView &v, double (&M)[R][NX])
+{
+    if constexpr (PAIRS) {
+        FK_UNROLL for (int f = 0; f + 1 < R * NX; f += 2) v.load_pair(f, M[f / NX][f % NX], M[(f + 1) / NX][(f + 1) % NX]);
+        if ((R * NX) % 2) M[R - 1][NX - 1] = v.load(R * NX - 1);
+    } else {
+        FK_UNROLL for (int r = 0; r < R; ++r)
+            FK_UNROLL for (int c = 0; c < NX; ++c) M[r][c] = v.load(r * NX + c);
+    }
+}
+
+template <int NX, bool PAIRS>
+__device__ __forceinline__ void load_x(const MlView &v, double (&x)[NX])
+{
+    if constexpr (PAIRS) {
+        FK_UNROLL for (int k = 0; k + 1 < NX; k += 2) v.load_pair(k, x[k], x[k + 1]);
+        if (NX % 2) x[NX - 1] = v.load(NX - 1);
+    } else {
+        FK_UNROLL for (int k = 0; k < NX; ++k) x[k] = v.load(k);
+    }
+}
+
+template <int NX, bool PAIRS>
+__device__ __forceinline__ void store_x(const MlView &v, const double (&x)[NX])
+{
+    if constexpr (PAIRS) {
+        FK_UNROLL for (int k = 0; k + 1 < NX; k += 2) v.store_pair(k, x[k], x[k + 1]);
+        if (NX % 2) v.store(NX - 1, x[NX - 1]);
+    } else {
+        FK_UNROLL for (int k = 0; k < NX; ++k) v.store(k, x[k]);
+    }
+}
+
+template <int R, int NZ, bool OUTS, int WAVES, int VAR, bool PAIRS>
 __global__ void __launch_bounds__(BLOCK, WAVES)
 kf_ml_kernel(const KfArgs a)
 {
@@ -93,11 +175,14 @@ kf_ml_kernel(const KfArgs a)
     const unsigned L = threadIdx.x & 3u;
     const unsigned Lc = L < 3u ? L : 2u;                       // lane 3 mirrors lane 2
     long trk = (long)blockIdx.x * (BLOCK / 4) + (threadIdx.x >> 2);
-    if (trk >= N) trk = N - 1;                                 // tail quads recompute the last track
+    const unsigned odd = (threadIdx.x >> 2) & 1u;              // odd quad of its pair (workgroups start on even tracks)
+    if (trk >= N) trk = PAIRS ? N - 2 + odd : N - 1;           // tail quads recompute the last track (pair)
     unsigned estride = (unsigned)N * 8u;
     asm volatile("" : "+s"(estride));
     const unsigned t8 = (unsigned)trk * 8u;
     const unsigned off_rows = t8 + Lc * (unsigned)(R * NX) * estride;   // element (Lc*R + r)*NX + c
+    const unsigned pair_rows = odd ? off_rows - 8u + estride : off_rows;
+    const unsigned pair_x = odd ? t8 - 8u + estride : t8;
     const double *myF = sF + Lc * (R * NX);                     // this lane's rows of F and Q
     const double *myQ = sQ + Lc * (R * NX);
 
@@ -150,8 +235,8 @@ kf_ml_kernel(const KfArgs a)
             FK_UNROLL for (int i = 0; i < NX; ++i) x[i] = xn[i];
         }
         if (OUTS) {
-            const MlView vx(a.means_p + t * N * NX, t8, estride);
-            FK_UNROLL for (int k = 0; k < NX; ++k) vx.store(k, x[k]);     // replicated: the quad writes the same bytes
+            const MlView vx(a.means_p + t * N * NX, t8, estride, pair_x);
+            store_x<NX, PAIRS>(vx, x);      // replicated: the quad writes the same bytes
         }
         FK_STAGE();
         {
@@ -159,7 +244,7 @@ kf_ml_kernel(const KfArgs a)
             // iterations below (and the prior's over the PHT stage), so that a wave's store traffic is
             // issued evenly through its arithmetic instead of in two bursts per step that every wave of
             // the chip fires at the same moment.
-            const MlView vPost(a.covs + (t > 0 ? t - 1 : 0) * N * NX * NX, off_rows, estride);
+            const MlView vPost(a.covs + (t > 0 ? t - 1 : 0) * N * NX * NX, off_rows, estride, pair_rows);
             double T[R][NX];                 // T = P F' : T[r][i] = sum_k P[r][k] F[i][k]
             FK_UNROLL for (int i = 0; i < NX; ++i) {
                 FK_UNROLL for (int r = 0; r < R; ++r) {
@@ -169,7 +254,20 @@ kf_ml_kernel(const KfArgs a)
                 }
                 if (OUTS) {
                     // (at t == 0 this writes the initial P into covs[0], overwritten by step 0's own result later)
-                    FK_UNROLL for (int e = 0; e < R; ++e) vPost.store((i / R) * NX + (i % R) * R + e, P[i / R][(i % R) * R + e]);
+                    if constexpr (PAIRS) {
+                        // the lane's 27 elements as 13 pairs + 1: iterations 0,2,4,6 send 3 pairs, 8 sends 1 pair + the last
+                        if (i % 2 == 0 && i < NX - 1) {
+                            FK_UNROLL for (int e = 0; e < 2 * R; e += 2) {
+                                const int f0 = i * R + e, f1 = f0 + 1;
+                                vPost.store_pair(f0, P[f0 / NX][f0 % NX], P[f1 / NX][f1 % NX]);
+                            }
+                        } else if (i == NX - 1) {
+                            vPost.store_pair(i * R, P[R - 1][NX - 3], P[R - 1][NX - 2]);
+                            vPost.store(R * NX - 1, P[R - 1][NX - 1]);
+                        }
+                    } else {
+                        FK_UNROLL for (int e = 0; e < R; ++e) vPost.store((i / R) * NX + (i % R) * R + e, P[i / R][(i % R) * R + e]);
+                    }
                 }
                 FK_STAGE();
             }
@@ -205,7 +303,7 @@ kf_ml_kernel(const KfArgs a)
                 FK_UNROLL for (int k = 1; k < NX; ++k) acc = fma(HX(c * NX + k), x[k], acc);
                 y[c] = z[c] - acc;
             }
-            const MlView vPri(a.covs_p + t * N * NX * NX, off_rows, estride);
+            const MlView vPri(a.covs_p + t * N * NX * NX, off_rows, estride, pair_rows);
             double PHT[R][NZ], S[NZ * NZ];
             FK_UNROLL for (int r = 0; r < R; ++r) {
                 FK_UNROLL for (int c = 0; c < NZ; ++c) {
@@ -214,7 +312,14 @@ kf_ml_kernel(const KfArgs a)
                     PHT[r][c] = acc;
                 }
                 if (OUTS) {
-                    FK_UNROLL for (int c = 0; c < NX; ++c) vPri.store(r * NX + c, P[r][c]);
+                    if constexpr (PAIRS) {
+                        // 27 elements = 13 pairs + 1, pairs may straddle rows: row r sends the pairs that END in it
+                        FK_UNROLL for (int f0 = 0; f0 + 1 < R * NX; f0 += 2)
+                            if ((f0 + 1) / NX == r) vPri.store_pair(f0, P[f0 / NX][f0 % NX], P[(f0 + 1) / NX][(f0 + 1) % NX]);
+                        if (r == R - 1) vPri.store(R * NX - 1, P[R - 1][NX - 1]);
+                    } else {
+                        FK_UNROLL for (int c = 0; c < NX; ++c) vPri.store(r * NX + c, P[r][c]);
+                    }
                 }
                 FK_STAGE();
             }
@@ -292,8 +397,8 @@ kf_ml_kernel(const KfArgs a)
             }
         }
         if (OUTS) {
-            const MlView vx(a.means + t * N * NX, t8, estride);
-            FK_UNROLL for (int k = 0; k < NX; ++k) vx.store(k, x[k]);
+            const MlView vx(a.means + t * N * NX, t8, estride, pair_x);
+            store_x<NX, PAIRS>(vx, x);
         }
     }
     if (OUTS && a.T > 0) {      // the last step's posterior covariance (the others were stored one step late)
@@ -319,6 +424,225 @@ kf_ml_kernel(const KfArgs a)
     }
 }
 
+// row k of a rows-per-lane matrix, delivered to every lane of the quad by its owner
+#define FK_ROW_FROM_OWNER(dst, M, k, LEN)                                                                     \
+    FK_UNROLL for (int j_ = 0; j_ < (LEN); ++j_) {                                                            \
+        const double v_ = M[(k) % R][j_];                                                                     \
+        dst[j_] = ((k) / R == 0) ? quad_bcast<0>(v_) : ((k) / R == 1) ? quad_bcast<1>(v_) : quad_bcast<2>(v_); \
+    }
+
+// rts_smoother for dim_x = 9 on the same three-lanes-per-track layout (kalman_filter.py:1066-1072):
+//   Pp = F P F' + Q ;  K = (P F') Pp^-1 ;  x += K (xn - F x) ;  P += K (Pn - Pp) K'
+// T = P F' and every row of Pp, K, E = K (Pn - Pp) and P live in the lane that owns the row; rows of
+// T, of Pn - Pp and of K are broadcast by their owners; the 9 x 9 factorisation of Pp is done by
+// every lane on a gathered packed copy (45 doubles) and each lane back-substitutes its own three
+// rows of K.  The filtered P is read twice (second time from L2) instead of being held across the
+// factorisation.  Shared constant F, Q; SOA; K and Pp outputs both present.
+template <int R, int WAVES, bool PAIRS>
+__global__ void __launch_bounds__(BLOCK, WAVES)
+rts_ml_kernel(const RtsArgs a)
+{
+    constexpr int NX = 3 * R, PL = NX * (NX + 1) / 2;
+    __shared__ double smem[2 * NX * NX];
+    // x and xn - F x are parked here ([element][lane]: conflict-free) across the E = K D stage: spilled
+    // to scratch instead, their reloads would be vector-memory operations that retire in order behind
+    // the step's stores (s_waitcnt vmcnt(0)); LDS traffic has its own counter.
+    __shared__ double park[R * NX + NX][BLOCK];   // rows 0..26: D = Pn - Pp across the factorisation (the register peak), then x | dx; rows 27..35: x from the top of the step
+    lds_fill<NX, NX>(smem, a.F, NX, NX, 1.0, threadIdx.x);
+    lds_fill<NX, NX>(smem + NX * NX, a.Q, NX, NX, 0.0, threadIdx.x);
+    __syncthreads();
+    const double *sF = smem, *sQ = smem + NX * NX;
+
+    const long N = a.N, T = a.T;
+    const unsigned L = threadIdx.x & 3u;
+    const unsigned Lc = L < 3u ? L : 2u;
+    long trk = (long)blockIdx.x * (BLOCK / 4) + (threadIdx.x >> 2);
+    const unsigned odd = (threadIdx.x >> 2) & 1u;
+    if (trk >= N) trk = PAIRS ? N - 2 + odd : N - 1;
+    const unsigned estride = (unsigned)N * 8u;
+    const unsigned t8 = (unsigned)trk * 8u;
+    const unsigned off_rows = t8 + Lc * (unsigned)(R * NX) * estride;
+    const unsigned pair_rows = odd ? off_rows - 8u + estride : off_rows;
+    const unsigned pair_x = odd ? t8 - 8u + estride : t8;
+    const double *myF = sF + Lc * (R * NX), *myQ = sQ + Lc * (R * NX);
+    const long xs_blk = N * NX, ps_blk = N * (long)NX * NX;
+
+    // k = T-1: smoothed == filtered; K = 0; Pp = Ps   (kalman_filter.py:1063-1065)
+    double xn[NX], Pn[R][NX];
+    {
+        const MlView vx(a.Xs + (T - 1) * xs_blk, t8, estride), vP(a.Ps + (T - 1) * ps_blk, off_rows, estride);
+        FK_UNROLL for (int k = 0; k < NX; ++k) xn[k] = vx.load(k);
+        FK_UNROLL for (int r = 0; r < R; ++r)
+            FK_UNROLL for (int c = 0; c < NX; ++c) Pn[r][c] = vP.load(r * NX + c);
+        const MlView ox(a.xs + (T - 1) * xs_blk, t8, estride), oP(a.Ps_out + (T - 1) * ps_blk, off_rows, estride);
+        const MlView oK(a.K + (T - 1) * ps_blk, off_rows, estride), oPp(a.Pp + (T - 1) * ps_blk, off_rows, estride);
+        FK_UNROLL for (int k = 0; k < NX; ++k) ox.store(k, xn[k]);
+        FK_UNROLL for (int r = 0; r < R; ++r)
+            FK_UNROLL for (int c = 0; c < NX; ++c) {
+                oP.store(r * NX + c, Pn[r][c]);
+                oPp.store(r * NX + c, Pn[r][c]);
+                oK.store(r * NX + c, 0.0);
+            }
+    }
+    int st = 0;
+
+    // The filtered P, x of step k are fetched at the END of step k+1, before that step's last stores
+    // are issued: vmcnt retires in order, so a load issued behind 36 stores is only usable once they
+    // have all been acknowledged -- a pipeline drain per step otherwise.
+    double Pnx[R][NX], xnx[NX];
+    {
+        const long k0 = T >= 2 ? T - 2 : 0;
+        const MlView vx(a.Xs + k0 * xs_blk, t8, estride, pair_x), vP(a.Ps + k0 * ps_blk, off_rows, estride, pair_rows);
+        load_rows<R, NX, PAIRS>(vP, Pnx);
+        load_x<NX, PAIRS>(vx, xnx);
+        FK_UNROLL for (int r = 0; r < R; ++r)
+            FK_UNROLL for (int c = 0; c < NX; ++c) asm volatile("" ::"v"(Pnx[r][c]));
+        FK_UNROLL for (int i = 0; i < NX; ++i) asm volatile("" ::"v"(xnx[i]));
+    }
+    _Pragma("nounroll") for (long k = T - 2; k >= 0; --k) {
+        const MlView vP(a.Ps + k * ps_blk, off_rows, estride, pair_rows);
+        double Tm[R][NX];
+        FK_UNROLL for (int i = 0; i < NX; ++i) park[R * NX + i][threadIdx.x] = xnx[i];
+        {
+            double P[R][NX];
+            FK_UNROLL for (int r = 0; r < R; ++r)
+                FK_UNROLL for (int c = 0; c < NX; ++c) P[r][c] = Pnx[r][c];
+            // T = P F'
+            FK_UNROLL for (int i = 0; i < NX; ++i) {
+                FK_UNROLL for (int r = 0; r < R; ++r) {
+                    double acc = P[r][0] * sF[i * NX];
+                    FK_UNROLL for (int q = 1; q < NX; ++q) acc = fma(P[r][q], sF[i * NX + q], acc);
+                    Tm[r][i] = acc;
+                }
+                FK_STAGE();
+            }
+        }
+        // Pp = F T + Q (own rows)
+        double Pp[R][NX];
+        FK_UNROLL for (int q = 0; q < NX; ++q) {
+            double Tq[NX];
+            FK_ROW_FROM_OWNER(Tq, Tm, q, NX);
+            FK_UNROLL for (int r = 0; r < R; ++r) {
+                const double f = myF[r * NX + q];
+                FK_UNROLL for (int j = 0; j < NX; ++j) Pp[r][j] = (q == 0) ? f * Tq[j] : fma(f, Tq[j], Pp[r][j]);
+            }
+            FK_STAGE();
+        }
+        {
+            const MlView oPp(a.Pp + k * ps_blk, off_rows, estride, pair_rows);
+            FK_UNROLL for (int r = 0; r < R; ++r)
+                FK_UNROLL for (int j = 0; j < NX; ++j) Pp[r][j] += myQ[r * NX + j];
+            store_rows<R, NX, PAIRS>(oPp, Pp);
+        }
+        FK_STAGE();
+        // K = T Pp^-1: every lane factors a gathered packed copy of Pp and solves its own rows
+        {
+            double Pf[PL], d[NX], dinv[NX];
+            // D = Pn - Pp (own rows) goes to LDS first: Pn is dead from here, Pp's rows after the gather
+            FK_UNROLL for (int r = 0; r < R; ++r)
+                FK_UNROLL for (int j = 0; j < NX; ++j) park[r * NX + j][threadIdx.x] = Pn[r][j] - Pp[r][j];
+            FK_STAGE();
+            FK_UNROLL for (int i = 0; i < NX; ++i)
+                FK_UNROLL for (int j = i; j < NX; ++j) {
+                    const double v = Pp[i % R][j];
+                    Pf[sym_idx<NX>(i, j)] = (i / R == 0) ? quad_bcast<0>(v) : (i / R == 1) ? quad_bcast<1>(v) : quad_bcast<2>(v);
+                }
+            FK_STAGE();
+            if (!ldlt_packed<NX>(Pf, d, dinv)) st |= ST_NOT_PD;
+            FK_STAGE();
+            FK_UNROLL for (int r = 0; r < R; ++r) {
+                solve_row_packed<NX>(Pf, dinv, Tm[r]);      // Tm's rows become K's rows
+                FK_STAGE();
+            }
+        }
+        FK_UNROLL for (int r = 0; r < R; ++r)
+            FK_UNROLL for (int j = 0; j < NX; ++j) Pn[r][j] = park[r * NX + j][threadIdx.x];
+        FK_STAGE();
+        {
+            const MlView oK(a.K + k * ps_blk, off_rows, estride, pair_rows);
+            store_rows<R, NX, PAIRS>(oK, Tm);
+        }
+        // x += K (xn - F x), replicated: K's rows come from their owners.  (x is only fetched now: nine
+        // doubles less across the factorisation, which is where this kernel's register peak is.)
+        {
+            double x[NX], dx[NX];
+            FK_UNROLL for (int i = 0; i < NX; ++i) x[i] = park[R * NX + i][threadIdx.x];
+            FK_UNROLL for (int i = 0; i < NX; ++i) {
+                double acc = sF[i * NX] * x[0];
+                FK_UNROLL for (int q = 1; q < NX; ++q) acc = fma(sF[i * NX + q], x[q], acc);
+                dx[i] = xn[i] - acc;
+                FK_STAGE();
+            }
+            FK_UNROLL for (int i = 0; i < NX; ++i) {
+                park[i][threadIdx.x] = x[i];
+                park[NX + i][threadIdx.x] = dx[i];
+            }
+            FK_STAGE();
+            // E = K D (own rows): rows of D broadcast
+            double E[R][NX];
+            FK_UNROLL for (int q = 0; q < NX; ++q) {
+                double Dq[NX];
+                FK_ROW_FROM_OWNER(Dq, Pn, q, NX);
+                FK_UNROLL for (int r = 0; r < R; ++r) {
+                    const double kq = Tm[r][q];
+                    FK_UNROLL for (int j = 0; j < NX; ++j) E[r][j] = (q == 0) ? kq * Dq[j] : fma(kq, Dq[j], E[r][j]);
+                }
+                FK_STAGE();
+            }
+            // P (filtered, second read) += E K' : column j needs K's row j; the same row updates x[j]
+            load_rows<R, NX, PAIRS>(vP, Pn);
+            double dxr[NX];
+            FK_UNROLL for (int i = 0; i < NX; ++i) dxr[i] = park[NX + i][threadIdx.x];
+            FK_UNROLL for (int j = 0; j < NX; ++j) {
+                double Kj[NX];
+                FK_ROW_FROM_OWNER(Kj, Tm, j, NX);
+                double xa = park[j][threadIdx.x];
+                FK_UNROLL for (int q = 0; q < NX; ++q) xa = fma(Kj[q], dxr[q], xa);
+                xn[j] = xa;
+                FK_UNROLL for (int r = 0; r < R; ++r) {
+                    double acc = Pn[r][j];
+                    FK_UNROLL for (int q = 0; q < NX; ++q) acc = fma(E[r][q], Kj[q], acc);
+                    Pn[r][j] = acc;
+                }
+                FK_STAGE();
+            }
+        }
+        {
+            long kn = k > 0 ? k - 1 : 0;
+            asm volatile("" : "+s"(kn));
+            const MlView nx(a.Xs + kn * xs_blk, t8, estride, pair_x), nP(a.Ps + kn * ps_blk, off_rows, estride, pair_rows);
+            load_rows<R, NX, PAIRS>(nP, Pnx);
+            load_x<NX, PAIRS>(nx, xnx);
+        }
+        FK_STAGE();
+        {
+            const MlView ox(a.xs + k * xs_blk, t8, estride, pair_x), oP(a.Ps_out + k * ps_blk, off_rows, estride, pair_rows);
+            store_x<NX, PAIRS>(ox, xn);
+            store_rows<R, NX, PAIRS>(oP, Pn);
+        }
+    }
+    if (a.status) {
+        bool fin = all_finite<NX>(xn);
+        FK_UNROLL for (int r = 0; r < R; ++r)
+            FK_UNROLL for (int c = 0; c < NX; ++c) fin = fin && (fabs(Pn[r][c]) <= 1.79769313486231570815e+308);
+        int s = st | (fin ? 0 : ST_NONFINITE);
+        s |= __builtin_amdgcn_mov_dpp(s, 0x55 * 1, 0xf, 0xf, true) | __builtin_amdgcn_mov_dpp(s, 0x55 * 2, 0xf, 0xf, true);
+        if (L == 0) a.status[trk] = s;
+    }
+}
+
+// returns 1 when this call is not one the multi-lane smoother serves
+int launch_rts_ml_9(const RtsArgs &a, int layout, bool uniform, hipStream_t s)
+{
+    if (layout != FK_LAYOUT_SOA || !uniform || a.model_t || a.n != 9 || !a.K || !a.Pp || a.T < 2) return 1;
+    const dim3 grid((unsigned)((a.N + BLOCK / 4 - 1) / (BLOCK / 4))), block(BLOCK);
+    const char *pv = getenv("FK_ML_PAIRS");
+    const bool pairs = (a.N % 2 == 0) && a.N >= 2 && !(pv && atoi(pv) == 0);
+    if (pairs) hipLaunchKernelGGL((rts_ml_kernel<3, FK_ML_WAVES, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((rts_ml_kernel<3, FK_ML_WAVES, false>), grid, block, 0, s, a);
+    return check_launch("rts_ml_kernel");
+}
+
 // returns 1 when this call is not one the multi-lane kernel serves
 int launch_kf_ml_9_3(const KfArgs &a, int layout, bool outs, int model_mode, hipStream_t s)
 {
@@ -328,9 +652,13 @@ int launch_kf_ml_9_3(const KfArgs &a, int layout, bool outs, int model_mode, hip
     // FK_ML_VAR=0: H re-read from LDS at every use instead of held in VGPRs (A/B measurements)
     const char *vv = getenv("FK_ML_VAR");
     const int var = vv ? atoi(vv) : 1;
-#define GO(V)                                                                                             \
-    if (outs) hipLaunchKernelGGL((kf_ml_kernel<3, 3, true, FK_ML_WAVES, V>), grid, block, 0, s, a);      \
-    else hipLaunchKernelGGL((kf_ml_kernel<3, 3, false, FK_ML_WAVES, V>), grid, block, 0, s, a)
+    // 16-byte pair stores need the track count even (a pair never straddles a plane); FK_ML_PAIRS=0 turns them off
+    const char *pv = getenv("FK_ML_PAIRS");
+    const bool pairs = (a.N % 2 == 0) && a.N >= 2 && !(pv && atoi(pv) == 0);
+#define GO(V)                                                                                                       \
+    if (outs && pairs) hipLaunchKernelGGL((kf_ml_kernel<3, 3, true, FK_ML_WAVES, V, true>), grid, block, 0, s, a);   \
+    else if (outs) hipLaunchKernelGGL((kf_ml_kernel<3, 3, true, FK_ML_WAVES, V, false>), grid, block, 0, s, a);     \
+    else hipLaunchKernelGGL((kf_ml_kernel<3, 3, false, FK_ML_WAVES, V, false>), grid, block, 0, s, a)
     if (var == 0) { GO(0); } else { GO(1); }
 #undef GO
     return check_launch("kf_ml_kernel");

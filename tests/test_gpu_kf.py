@@ -209,3 +209,24 @@ def test_multilane_9_3_vs_oracle(outputs):
         for k in range(4):
             assert rel_err_rows(_per_track(got[k][:, sample]), _per_track(ref[k])) < TOL, k
     assert rel_err_rows(got[4][sample], ref[0][-1]) < TOL and rel_err_rows(got[5][sample], ref[1][-1]) < TOL
+
+
+@pytest.mark.parametrize("N", [1000, 777])
+def test_multilane_rts_9_vs_oracle(N):
+    """rts_ml_kernel (three lanes per track; N even: 16-byte pair loads/stores, N odd: 8-byte path):
+    every track its own filter output, both index conventions."""
+    from gpu_util import run_rts
+    n = 9
+    rs = np.random.RandomState(99)
+    T = 30
+    A = rs.randn(T, N, n, n)
+    Xs, Ps = rs.randn(T, N, n), A @ A.transpose(0, 1, 3, 2) / n + 0.5 * np.eye(n)
+    F = np.eye(n) + 0.1 * rs.randn(n, n)
+    B = rs.randn(n, n)
+    Q = 0.1 * (B @ B.T / n + 0.5 * np.eye(n))
+    sample = [0, 1, 15, 16, 63, 64, 255, 256, N - 2, N - 1]
+    for conv, name in ((0, "class"), (1, "module")):
+        got = run_rts(Xs, Ps, F, Q, layout="soa", convention=conv)
+        ref = kf_oracle.rts_smoother_tracks(Xs, Ps, F, Q, tracks=sample, convention=name)
+        for k in range(4):
+            assert rel_err_rows(_per_track(got[k][:, sample]), _per_track(ref[k])) < 1e-9, (name, k)

@@ -28,8 +28,8 @@ def main():
     st = torch.zeros(N, dtype=torch.int32, device=dev)
     d = [E.dev(a) for a in (F, Q, H, R)]
     desc = dict(n=n, m=m, nu=0, model_mode=0, N=N, T=T, layout=E.LAYOUTS["soa"], update_first=0, alpha_sq=1.0)
-    for env in ({"FK_ML_VAR": "1"}, {"FK_ML_VAR": "0"}, {"FK_NO_ML": "1"}):
-        for k in ("FK_ML_WAVES", "FK_NO_ML", "FK_ML_SKEW", "FK_ML_VAR"):
+    for env in ({}, {"FK_ML_PAIRS": "0"}):
+        for k in ("FK_ML_WAVES", "FK_NO_ML", "FK_ML_PAIRS", "FK_ML_VAR"):
             os.environ.pop(k, None)
         os.environ.update(env)
         for with_out in (True, False):
@@ -44,5 +44,34 @@ def main():
                                   frac=N * T * 1464 / (ms * 1e-3) / 8e12 if with_out else None)), flush=True)
 
 
+def rts():
+    import torch
+    from filterpy_amd import _engine as E
+    from tools.bench_configs import cv3d_model, timeit
+    N, T, n = int(os.environ.get("ML_N", 100000)), 100, 9
+    F, Q, H, R = cv3d_model()
+    dev = torch.device("cuda")
+    g = torch.Generator(device=dev)
+    g.manual_seed(4)
+    Xs = torch.randn((T, n, N), generator=g, device=dev, dtype=torch.float64)
+    A = torch.randn((n, n), generator=g, device=dev, dtype=torch.float64)
+    P1 = (A @ A.T / n + torch.eye(n, device=dev, dtype=torch.float64)).reshape(1, n * n, 1)
+    Ps = P1.repeat(T, 1, N).contiguous()
+    o = [E.alloc_records((T,), N, n, "soa")] + [E.alloc_records((T,), N, n * n, "soa") for _ in range(3)]
+    st = torch.zeros(N, dtype=torch.int32, device=dev)
+    desc = dict(n=n, m=1, nu=0, model_mode=0, N=N, T=T, layout=E.LAYOUTS["soa"], update_first=0, alpha_sq=1.0)
+    dF, dQ = E.dev(F), E.dev(Q)
+    for env in ({}, {"FK_ML_PAIRS": "0"}, {"FK_NO_ML": "1"}):
+        for k in ("FK_ML_WAVES", "FK_NO_ML", "FK_ML_VAR", "FK_ML_PAIRS"):
+            os.environ.pop(k, None)
+        os.environ.update(env)
+        ms = timeit(lambda: E.kf_rts(desc, dF, dQ, Xs, Ps, o[0], o[1], o[2], o[3], convention=0, status=st), warm=2, reps=5)
+        print(json.dumps(dict(kernel="rts n=9", env=env, N=N, ms=ms, track_steps_per_s=N * T / ms * 1e3,
+                              frac=N * T * 2736 / (ms * 1e-3) / 8e12)), flush=True)
+
+
 if __name__ == "__main__":
-    main()
+    if os.environ.get("ML_WHAT", "kf") == "rts":
+        rts()
+    else:
+        main()
