@@ -130,7 +130,8 @@ __device__ __forceinline__ void cov_full(const double (&P)[PLEN], double (&M)[NX
 // track (registers, loaded once: coalesced in SOA), 2 one model per track and step (registers,
 // reloaded every step), 3 one model per step shared by all tracks (LDS, double-buffered, fetched a
 // step ahead by the first SIZE threads).
-template <int NX, int NZ, int LAYOUT, bool HAS_MASK, bool OUTS, bool SYM, int MMODE>
+// UF: update_first (kalman_filter.py:966-978): every step is update(z) -> store posterior -> predict -> store prior
+template <int NX, int NZ, int LAYOUT, bool HAS_MASK, bool OUTS, bool SYM, int MMODE, bool UF>
 __global__ void __launch_bounds__(BLOCK, fast_min_waves(NX, LAYOUT) > 1 && (MMODE == 1 || MMODE == 2) ? fast_min_waves(NX, LAYOUT) - 1 : fast_min_waves(NX, LAYOUT))
 kf_fast_kernel(const KfArgs a, const double *__restrict__ pF, const double *__restrict__ pQ,
                const double *__restrict__ pH, const double *__restrict__ pR,
@@ -242,41 +243,52 @@ kf_fast_kernel(const KfArgs a, const double *__restrict__ pF, const double *__re
         // of the step and request model[t+2] (consumed one step later: a counted wait)
         const double mpub = mnext;
         if constexpr (MMODE == 3) mnext = shared_elem(t + 2 < T ? t + 2 : T - 1);
-        if constexpr (MMODE == 1 || MMODE == 2) {
-            if constexpr (SYM) kf_predict_sym<NX>(x, P, tm, a.alpha_sq);
-            else kf_predict<NX>(x, P, tm, a.alpha_sq);
-        } else {
-            if constexpr (SYM) kf_predict_sym<NX>(x, P, sm, a.alpha_sq);
-            else kf_predict<NX>(x, P, sm, a.alpha_sq);
-        }
         double Pf[NX * NX];
-        cov_full<NX, SYM, PLEN>(P, Pf);
-        if (!OUTS) {
-        } else if (!COOP) {
-            store_rec<NX, 1, LAYOUT, true>(x, a.means_p + t * N * NX, ln, NX, 1);
-            store_rec<NX, NX, LAYOUT, true>(Pf, a.covs_p + t * N * NX * NX, ln, NX, NX);
-        } else {
-            wave_store_aos<NX>(x, a.means_p + (t * N + blk0) * NX, wave * 64u, tile, lane, last_row);
-            wave_store_aos<NX * NX>(Pf, a.covs_p + (t * N + blk0) * NX * NX, wave * 64u, tile, lane, last_row);
-        }
-        if (hu) {
-            double K[NX * NZ], y[NZ], S[NZ * NZ], Lf[NZ * NZ], dinv[NZ];
+        auto do_predict = [&]() {
             if constexpr (MMODE == 1 || MMODE == 2) {
-                if constexpr (SYM) st |= kf_update_sym<NX, NZ>(x, P, zu, tm, K, y, S, Lf, dinv);
-                else st |= kf_update<NX, NZ>(x, P, zu, tm, K, y, S, Lf, dinv);
+                if constexpr (SYM) kf_predict_sym<NX>(x, P, tm, a.alpha_sq);
+                else kf_predict<NX>(x, P, tm, a.alpha_sq);
             } else {
-                if constexpr (SYM) st |= kf_update_sym<NX, NZ>(x, P, zu, sm, K, y, S, Lf, dinv);
-                else st |= kf_update<NX, NZ>(x, P, zu, sm, K, y, S, Lf, dinv);
+                if constexpr (SYM) kf_predict_sym<NX>(x, P, sm, a.alpha_sq);
+                else kf_predict<NX>(x, P, sm, a.alpha_sq);
             }
-        }
-        cov_full<NX, SYM, PLEN>(P, Pf);
-        if (!OUTS) {
-        } else if (!COOP) {
-            store_rec<NX, 1, LAYOUT, true>(x, a.means + t * N * NX, ln, NX, 1);
-            store_rec<NX, NX, LAYOUT, true>(Pf, a.covs + t * N * NX * NX, ln, NX, NX);
+            cov_full<NX, SYM, PLEN>(P, Pf);
+            if (!OUTS) {
+            } else if (!COOP) {
+                store_rec<NX, 1, LAYOUT, true>(x, a.means_p + t * N * NX, ln, NX, 1);
+                store_rec<NX, NX, LAYOUT, true>(Pf, a.covs_p + t * N * NX * NX, ln, NX, NX);
+            } else {
+                wave_store_aos<NX>(x, a.means_p + (t * N + blk0) * NX, wave * 64u, tile, lane, last_row);
+                wave_store_aos<NX * NX>(Pf, a.covs_p + (t * N + blk0) * NX * NX, wave * 64u, tile, lane, last_row);
+            }
+        };
+        auto do_update = [&]() {
+            if (hu) {
+                double K[NX * NZ], y[NZ], S[NZ * NZ], Lf[NZ * NZ], dinv[NZ];
+                if constexpr (MMODE == 1 || MMODE == 2) {
+                    if constexpr (SYM) st |= kf_update_sym<NX, NZ>(x, P, zu, tm, K, y, S, Lf, dinv);
+                    else st |= kf_update<NX, NZ>(x, P, zu, tm, K, y, S, Lf, dinv);
+                } else {
+                    if constexpr (SYM) st |= kf_update_sym<NX, NZ>(x, P, zu, sm, K, y, S, Lf, dinv);
+                    else st |= kf_update<NX, NZ>(x, P, zu, sm, K, y, S, Lf, dinv);
+                }
+            }
+            cov_full<NX, SYM, PLEN>(P, Pf);
+            if (!OUTS) {
+            } else if (!COOP) {
+                store_rec<NX, 1, LAYOUT, true>(x, a.means + t * N * NX, ln, NX, 1);
+                store_rec<NX, NX, LAYOUT, true>(Pf, a.covs + t * N * NX * NX, ln, NX, NX);
+            } else {
+                wave_store_aos<NX>(x, a.means + (t * N + blk0) * NX, wave * 64u, tile, lane, last_row);
+                wave_store_aos<NX * NX>(Pf, a.covs + (t * N + blk0) * NX * NX, wave * 64u, tile, lane, last_row);
+            }
+        };
+        if constexpr (UF) {
+            do_update();
+            do_predict();
         } else {
-            wave_store_aos<NX>(x, a.means + (t * N + blk0) * NX, wave * 64u, tile, lane, last_row);
-            wave_store_aos<NX * NX>(Pf, a.covs + (t * N + blk0) * NX * NX, wave * 64u, tile, lane, last_row);
+            do_predict();
+            do_update();
         }
         if constexpr (MMODE == 3) {
             // publish model[t+1] into the other LDS buffer: nobody reads that buffer during step t, and
@@ -329,9 +341,13 @@ using namespace FK_CAT(fastv_, FK_NX, FK_NZ, FK_VARIANT);
 int FK_CAT(launch_kf_fast_, FK_NX, FK_NZ, FK_VARIANT)(const KfArgs &a, int layout, bool outs, int mmode, hipStream_t stream)
 {
     if (mmode != 0 && !FK_FAST_ALL_MODES) return 1;
+    if (a.update_first && !(FK_FAST_ALL_MODES && mmode == 0)) return 1;   // update_first: shared model, variant 0, dim_x <= 6
     const dim3 grid((unsigned)((a.cnt + BLOCK - 1) / BLOCK)), block(BLOCK);
 #define FK_GO(LAY, MSK, OUT, MM)                                                                          \
-    hipLaunchKernelGGL((kf_fast_kernel<FK_NX, FK_NZ, LAY, MSK, OUT, (FK_FAST_SYM != 0), MM>), grid, block, 0, \
+    hipLaunchKernelGGL((kf_fast_kernel<FK_NX, FK_NZ, LAY, MSK, OUT, (FK_FAST_SYM != 0), MM, false>), grid, block, 0, \
+                       stream, a, a.F, a.Q, a.H, a.R, a.z, a.mask)
+#define FK_GOUF(LAY, MSK, OUT)                                                                                \
+    hipLaunchKernelGGL((kf_fast_kernel<FK_NX, FK_NZ, LAY, MSK, OUT, (FK_FAST_SYM != 0), 0, true>), grid, block, 0, \
                        stream, a, a.F, a.Q, a.H, a.R, a.z, a.mask)
 #define FK_GO3(LAY, MM)                          \
     do {                                         \
@@ -354,9 +370,28 @@ int FK_CAT(launch_kf_fast_, FK_NX, FK_NZ, FK_VARIANT)(const KfArgs &a, int layou
 #else
 #define FK_GO2(LAY) FK_GO3(LAY, 0)
 #endif
+#if FK_FAST_ALL_MODES
+#define FK_GOUF2(LAY)                              \
+    do {                                           \
+        if (a.mask) {                              \
+            if (outs) FK_GOUF(LAY, true, true);    \
+            else FK_GOUF(LAY, true, false);        \
+        } else {                                   \
+            if (outs) FK_GOUF(LAY, false, true);   \
+            else FK_GOUF(LAY, false, false);       \
+        }                                          \
+    } while (0)
+    if (a.update_first) {
+        if (layout == LAYOUT_SOA) FK_GOUF2(LAYOUT_SOA);
+        else FK_GOUF2(LAYOUT_AOS);
+        return check_launch("kf_fast_kernel");
+    }
+#undef FK_GOUF2
+#endif
     if (layout == LAYOUT_SOA) FK_GO2(LAYOUT_SOA);
     else FK_GO2(LAYOUT_AOS);
 #undef FK_GO2
+#undef FK_GOUF
 #undef FK_GO3
 #undef FK_GO
     return check_launch("kf_fast_kernel");

@@ -157,7 +157,7 @@ __device__ __forceinline__ void store_x(const MlView &v, const double (&x)[NX])
     }
 }
 
-template <int R, int NZ, bool OUTS, int WAVES, int VAR, bool PAIRS>
+template <int R, int NZ, bool OUTS, int WAVES, int VAR, bool PAIRS, bool MASK>
 __global__ void __launch_bounds__(BLOCK, WAVES)
 kf_ml_kernel(const KfArgs a)
 {
@@ -208,20 +208,28 @@ kf_ml_kernel(const KfArgs a)
     // z is fetched one step ahead: vmcnt retires in order, so waiting for a load also waits for every
     // store issued before it; with a whole step between a load and its use, the wait is behind stores
     // that had a full step to drain (the counter saturates at 63 anyway).
+    // MASK: a missing measurement (mask byte 0; kalman_filter.py:515-520) leaves x, P at the prior.  No
+    // branch: the step runs with z = 0 and K = 0, which makes T1 = P, P+ = P + D 0' = P and
+    // x + 0 y = x exactly (every product with the zero gain is an exact zero).
     double zn[NZ];
+    unsigned hn = 1u;
     {
         const MlView vz(a.z, t8, estride);
         FK_UNROLL for (int c = 0; c < NZ; ++c) zn[c] = vz.load(c);
+        if constexpr (MASK) hn = a.mask[trk];
         FK_UNROLL for (int c = 0; c < NZ; ++c) asm volatile("" ::"v"(zn[c]));     // landed, like x and P above
+        if constexpr (MASK) asm volatile("" ::"v"(hn));
     }
     _Pragma("nounroll") for (long t = 0; t < a.T; ++t) {
         double z[NZ];
-        FK_UNROLL for (int c = 0; c < NZ; ++c) z[c] = zn[c];
+        const bool has_z = !MASK || hn != 0u;
+        FK_UNROLL for (int c = 0; c < NZ; ++c) z[c] = has_z ? zn[c] : 0.0;
         {
             long tn = t + 1 < a.T ? t + 1 : t;
             asm volatile("" : "+s"(tn));      // opaque: keeps the compiler from re-deriving this load one iteration later
             const MlView vz(a.z + tn * N * NZ, t8, estride);
             FK_UNROLL for (int c = 0; c < NZ; ++c) zn[c] = vz.load(c);
+            if constexpr (MASK) hn = a.mask[tn * N + trk];
         }
         // ---------------------------------------------------------------- predict --
         {
@@ -338,12 +346,12 @@ kf_ml_kernel(const KfArgs a)
             FK_STAGE();
             double Lf[NZ * NZ], d[NZ], dinv[NZ], Kr[R * NZ];
             FK_UNROLL for (int e = 0; e < NZ * NZ; ++e) Lf[e] = S[e];
-            if (!ldlt2<NZ>(Lf, d, dinv)) st |= ST_NOT_PD;
+            if (!ldlt2<NZ>(Lf, d, dinv) && has_z) st |= ST_NOT_PD;
             FK_UNROLL for (int r = 0; r < R; ++r)
                 FK_UNROLL for (int c = 0; c < NZ; ++c) Kr[r * NZ + c] = PHT[r][c];
             solve_rows_ldlt<R, NZ>(Lf, dinv, Kr);
             FK_UNROLL for (int r = 0; r < R; ++r)
-                FK_UNROLL for (int c = 0; c < NZ; ++c) K[r][c] = Kr[r * NZ + c];
+                FK_UNROLL for (int c = 0; c < NZ; ++c) K[r][c] = has_z ? Kr[r * NZ + c] : 0.0;
         }
         FK_STAGE();
         {
@@ -646,20 +654,17 @@ int launch_rts_ml_9(const RtsArgs &a, int layout, bool uniform, hipStream_t s)
 // returns 1 when this call is not one the multi-lane kernel serves
 int launch_kf_ml_9_3(const KfArgs &a, int layout, bool outs, int model_mode, hipStream_t s)
 {
-    if (layout != FK_LAYOUT_SOA || model_mode != FK_MODEL_SHARED || a.n != 9 || a.m != 3 || a.mask) return 1;
+    if (layout != FK_LAYOUT_SOA || model_mode != FK_MODEL_SHARED || a.n != 9 || a.m != 3) return 1;
     const dim3 grid((unsigned)((a.N + BLOCK / 4 - 1) / (BLOCK / 4))), block(BLOCK);
     // FK_ML_WAVES = 1 | 2 | 3: occupancy target of the instantiation (A/B measurements); default 2
-    // FK_ML_VAR=0: H re-read from LDS at every use instead of held in VGPRs (A/B measurements)
-    const char *vv = getenv("FK_ML_VAR");
-    const int var = vv ? atoi(vv) : 1;
     // 16-byte pair stores need the track count even (a pair never straddles a plane); FK_ML_PAIRS=0 turns them off
     const char *pv = getenv("FK_ML_PAIRS");
     const bool pairs = (a.N % 2 == 0) && a.N >= 2 && !(pv && atoi(pv) == 0);
-#define GO(V)                                                                                                       \
-    if (outs && pairs) hipLaunchKernelGGL((kf_ml_kernel<3, 3, true, FK_ML_WAVES, V, true>), grid, block, 0, s, a);   \
-    else if (outs) hipLaunchKernelGGL((kf_ml_kernel<3, 3, true, FK_ML_WAVES, V, false>), grid, block, 0, s, a);     \
-    else hipLaunchKernelGGL((kf_ml_kernel<3, 3, false, FK_ML_WAVES, V, false>), grid, block, 0, s, a)
-    if (var == 0) { GO(0); } else { GO(1); }
+#define GO(M)                                                                                                         \
+    if (outs && pairs) hipLaunchKernelGGL((kf_ml_kernel<3, 3, true, FK_ML_WAVES, 1, true, M>), grid, block, 0, s, a);   \
+    else if (outs) hipLaunchKernelGGL((kf_ml_kernel<3, 3, true, FK_ML_WAVES, 1, false, M>), grid, block, 0, s, a);     \
+    else hipLaunchKernelGGL((kf_ml_kernel<3, 3, false, FK_ML_WAVES, 1, false, M>), grid, block, 0, s, a)
+    if (a.mask) { GO(true); } else { GO(false); }
 #undef GO
     return check_launch("kf_ml_kernel");
 }

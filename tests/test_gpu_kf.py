@@ -173,7 +173,7 @@ def test_fast_kernel_tuning_variants(n, m, variants, layout, monkeypatch):
     mask = tile_tracks(g[p + "mask"], N, 1)
     # FK_NO_ML: keep the one-lane-per-track variants of (9,3) covered now that kf_ml.hip takes that call
     settings = ([{"FK_FAST_VARIANT": str(v), "FK_NO_ML": "1"} for v in variants] +
-                [{}, {"FK_ML_VAR": "0"}, {"FK_FAST_XCD": "1", "FK_NO_ML": "1"}, {"FK_NO_FAST": "1"}])
+                [{}, {"FK_ML_PAIRS": "0"}, {"FK_FAST_XCD": "1", "FK_NO_ML": "1"}, {"FK_NO_FAST": "1"}])
     for env in settings:
         with monkeypatch.context() as mp:
             for k, v in env.items():
@@ -185,8 +185,9 @@ def test_fast_kernel_tuning_variants(n, m, variants, layout, monkeypatch):
                         assert rel_err_rows(got[:, trk], g[p + tag + "_" + key]) < TOL, (env, tag, key, trk)
 
 
+@pytest.mark.parametrize("masked", [False, True])
 @pytest.mark.parametrize("outputs", [True, False])
-def test_multilane_9_3_vs_oracle(outputs):
+def test_multilane_9_3_vs_oracle(outputs, masked):
     """kf_ml.hip (three lanes per track, quad-permute row exchange): every track its own state and
     measurements, N not a multiple of the 64 tracks per workgroup, alpha != 1."""
     from gpu_util import run_kf_batch
@@ -202,9 +203,12 @@ def test_multilane_9_3_vs_oracle(outputs):
     H = rs.randn(m, n)
     C = rs.randn(m, m)
     R = 0.5 * (C @ C.T / m + 0.5 * np.eye(m))
-    got = run_kf_batch(x0, P0, zs, F, Q, H, R, layout="soa", alpha_sq=1.02 ** 2, outputs=outputs)
+    mask = (rs.rand(T, N) > 0.25) if masked else None
+    if masked:
+        zs[~mask] = np.nan              # the kernel must not look at a masked measurement
+    got = run_kf_batch(x0, P0, zs, F, Q, H, R, layout="soa", alpha_sq=1.02 ** 2, outputs=outputs, mask=mask)
     sample = [0, 1, 15, 16, 63, 64, 255, 256, 959, 960, N - 1]
-    ref = kf_oracle.kf_batch_filter_tracks(x0, P0, zs, F, Q, H, R, tracks=sample, alpha_sq=1.02 ** 2)
+    ref = kf_oracle.kf_batch_filter_tracks(x0, P0, zs, F, Q, H, R, tracks=sample, alpha_sq=1.02 ** 2, mask=mask)
     if outputs:
         for k in range(4):
             assert rel_err_rows(_per_track(got[k][:, sample]), _per_track(ref[k])) < TOL, k
