@@ -105,6 +105,25 @@ FK_HD Mono mono_elem(double w, double u, int eu)
     return Mono{inc, inc};
 }
 
+// The same map in the common case, as ONE number: when the remainder is not an exact half ulp the
+// map is "C -> C + inc" whatever C's parity, and inc (an integer < 2^53) is held exactly by a double.
+// Composition is then a plain fp64 add -- exact while the sum stays below 2^53, and a sum that
+// reaches 2^53 stays >= 2^53 after rounding, which is all the crossing test needs.  A tile without
+// any tie (ties need the bits of w below u to be exactly 100...0: ~2^-23 per element for random
+// weights) is scanned with doubles; a tile with one falls back to the Mono scan.
+//   returns inc (2^54 for an element that must end the segment); tie = exact half-ulp remainder
+FK_HD double fast_inc(double w, int eu, bool &tie)
+{
+    tie = false;
+    if (!(w >= 0.0) || !(w < 0x1p1000)) return 0x1p54;
+    const double t = scale2(w, -eu);       // w / u; an underflow only happens far below 1/2
+    if (!(t < 0x1p53)) return 0x1p54;
+    const double q = floor(t);
+    const double r = t - q;                // exact, in [0, 1)
+    tie = (r == 0.5);
+    return q + (r > 0.5 ? 1.0 : 0.0);
+}
+
 // C after applying composite F to start value C0
 FK_HD long long mono_apply(long long C0, const Mono &F) { return C0 + ((C0 & 1) ? F.ao : F.ae); }
 

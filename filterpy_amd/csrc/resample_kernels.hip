@@ -33,6 +33,7 @@ constexpr int RS_PRELUDE = 128;                  // first non-zero-sum elements 
 struct ScanShared {
     double w[RS_TILE];          // weights of the tile, then (in place) their cumulative sums
     Mono wave_tot[RS_THREADS / 64];
+    double wave_sum[RS_THREADS / 64];
     double carry;               // exact running sum entering the next segment
     int first_cross;            // first tile index whose add leaves the binade (RS_TILE = none)
     int first_nonzero;
@@ -143,6 +144,64 @@ __device__ double tile_cumsum_exact(ScanShared &sh, int len, double carry, bool 
         // --- one binade: parallel exact scan over [pos, len) ---------------------------------
         const double u = ulp_of(carry);
         const int eu = ulp_exp(carry);
+        // fast path (fk_exact_scan.hpp, fast_inc): no half-ulp tie in the segment -> integer increments
+        // held in doubles, the scan is a plain fp64 prefix sum
+        {
+            const double C0d = scale2(carry, -eu);
+            double incl[RS_ITEMS];
+            double runs = 0.0;
+            bool tie = false;
+            FK_UNROLL for (int k = 0; k < RS_ITEMS; ++k) {
+                const int j = tid * RS_ITEMS + k;
+                bool tk = false;
+                const double e = (j >= pos && j < len) ? fast_inc(sh.w[j], eu, tk) : 0.0;
+                tie = tie || tk;
+                runs += e;
+                incl[k] = runs;
+            }
+            if (tid == 0) sh.first_cross = RS_TILE;
+            const int any_tie = __syncthreads_or(tie ? 1 : 0);
+            if (!any_tie) {
+                double inc = runs;
+                FK_UNROLL for (int d = 1; d < 64; d <<= 1) {
+                    const double up = __shfl_up(inc, d, 64);
+                    if (lane >= d) inc += up;
+                }
+                if (lane == 63) sh.wave_sum[wave] = inc;
+                __syncthreads();
+                double excl = __shfl_up(inc, 1, 64);
+                if (lane == 0) excl = 0.0;
+                FK_UNROLL for (int wv = 0; wv < RS_THREADS / 64; ++wv)
+                    if (wv < wave) excl += sh.wave_sum[wv];
+                double Cd[RS_ITEMS];
+                int my_cross = RS_TILE;
+                FK_UNROLL for (int k = 0; k < RS_ITEMS; ++k) {
+                    const int j = tid * RS_ITEMS + k;
+                    Cd[k] = C0d + (excl + incl[k]);
+                    if (j >= pos && j < len && !(Cd[k] < 0x1p53) && my_cross == RS_TILE) my_cross = j;
+                }
+                if (my_cross < RS_TILE) atomicMin(&sh.first_cross, my_cross);
+                __syncthreads();
+                const int cross = sh.first_cross < len ? sh.first_cross : len;   // first element NOT covered
+                FK_UNROLL for (int k = 0; k < RS_ITEMS; ++k) {
+                    const int j = tid * RS_ITEMS + k;
+                    if (j >= pos && j < cross) sh.w[j] = Cd[k] * u;               // exact
+                }
+                __syncthreads();
+                if (cross > pos) carry = sh.w[cross - 1];
+                if (cross < len) {
+                    carry = carry + sh.w[cross];      // the add that leaves the binade: a real IEEE add
+                    __syncthreads();
+                    if (tid == 0) sh.w[cross] = carry;
+                    __syncthreads();
+                    pos = cross + 1;
+                } else {
+                    pos = len;
+                }
+                continue;
+            }
+        }
+        // general path: Mono scan (handles exact ties)
         const long long C0 = (long long)scale2(carry, -eu);
         Mono loc[RS_ITEMS];
         Mono run = mono_identity();
@@ -407,10 +466,41 @@ chunk_compose_kernel(long Np, long nch, const double *__restrict__ w, ChunkPlan 
     const int len = (int)((Np - base) < RS_TILE ? (Np - base) : RS_TILE);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const double u = scale2(1.0, eu);
+    double wv[RS_ITEMS];
+    FK_UNROLL for (int q = 0; q < RS_ITEMS; ++q) {
+        const int j = tid * RS_ITEMS + q;
+        wv[q] = j < len ? w[f * Np + base + j] : 0.0;
+    }
+    // fast path: no half-ulp tie in the chunk -> its composite map is "add S", S a plain fp64 sum of
+    // integer increments (fast_inc); an S that reaches 2^53 is inexact but still >= 2^53, which the
+    // chain kernel treats as a binade crossing and redoes exactly
+    {
+        __shared__ double wsum[RS_THREADS / 64];
+        double S = 0.0;
+        bool tie = false;
+        FK_UNROLL for (int q = 0; q < RS_ITEMS; ++q) {
+            bool tk = false;
+            S += (tid * RS_ITEMS + q < len) ? fast_inc(wv[q], eu, tk) : 0.0;
+            tie = tie || tk;
+        }
+        const int any_tie = __syncthreads_or(tie ? 1 : 0);
+        if (!any_tie) {
+            FK_UNROLL for (int d = 32; d > 0; d >>= 1) S += __shfl_down(S, d, 64);
+            if (lane == 0) wsum[wave] = S;
+            __syncthreads();
+            if (tid == 0) {
+                double t = wsum[0];
+                for (int k2 = 1; k2 < RS_THREADS / 64; ++k2) t += wsum[k2];
+                const long long Sl = t >= 0x1p60 ? MONO_SAT : (long long)t;
+                p.F = Mono{Sl, Sl};
+            }
+            return;
+        }
+    }
     Mono run = mono_identity();
     FK_UNROLL for (int q = 0; q < RS_ITEMS; ++q) {
         const int j = tid * RS_ITEMS + q;
-        if (j < len) run = mono_compose(run, mono_elem(w[f * Np + base + j], u, eu));
+        if (j < len) run = mono_compose(run, mono_elem(wv[q], u, eu));
     }
     FK_UNROLL for (int d = 1; d < 64; d <<= 1) {
         const Mono up = shfl_up_mono(run, d);

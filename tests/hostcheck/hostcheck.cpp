@@ -312,6 +312,49 @@ double tile_cumsum_emul(double *w, int len, double carry, bool &started, long *n
         const double u = ulp_of(carry);
         const int eu = ulp_exp(carry);
         if (scale2(1.0, eu) != u) return carry / 0.0 * 0.0;   // self-check: poisons the result
+        // fast path of the kernel (fast_inc, fk_exact_scan.hpp): no half-ulp tie in [pos, len) -> the
+        // increments are summed as doubles, thread by thread and then across threads in a different
+        // association order than the Mono scan (all exact below 2^53)
+        {
+            const double C0d = scale2(carry, -eu);
+            std::vector<double> incl(T_TILE), run_t(T_THREADS);
+            bool any_tie = false;
+            for (int t = 0; t < T_THREADS; ++t) {
+                double run = 0.0;
+                for (int k = 0; k < T_ITEMS; ++k) {
+                    const int j = t * T_ITEMS + k;
+                    bool tk = false;
+                    const double e = (j >= pos && j < len) ? fast_inc(w[j], eu, tk) : 0.0;
+                    any_tie = any_tie || tk;
+                    run += e;
+                    incl[j] = run;
+                }
+                run_t[t] = run;
+            }
+            if (!any_tie) {
+                int cross = len;
+                std::vector<double> Cd(T_TILE);
+                double excl = 0.0;
+                for (int t = 0; t < T_THREADS; ++t) {
+                    for (int k = 0; k < T_ITEMS; ++k) {
+                        const int j = t * T_ITEMS + k;
+                        Cd[j] = C0d + (excl + incl[j]);
+                        if (j >= pos && j < len && !(Cd[j] < 0x1p53) && j < cross) cross = j;
+                    }
+                    excl += run_t[t];
+                }
+                for (int j = pos; j < cross; ++j) w[j] = Cd[j] * u;
+                if (cross > pos) carry = w[cross - 1];
+                if (cross < len) {
+                    carry = carry + w[cross];
+                    w[cross] = carry;
+                    pos = cross + 1;
+                } else {
+                    pos = len;
+                }
+                continue;
+            }
+        }
         const long long C0 = (long long)scale2(carry, -eu);
         std::vector<Mono> loc(T_TILE), tot(T_THREADS), inc(T_THREADS), excl(T_THREADS);
         for (int t = 0; t < T_THREADS; ++t) {

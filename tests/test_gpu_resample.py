@@ -119,6 +119,36 @@ def test_exact_cumsum_kernel_bitwise():
         assert np.array_equal(got.view(np.uint64), ref.view(np.uint64)), N
 
 
+HARD = {
+    "ties": lambda rs, N: rs.randint(0, 3, N) * 2.0 ** -53 + (rs.rand(N) < 0.01),       # exact half-ulp ties
+    "ties_everywhere": lambda rs, N: np.full(N, 2.0 ** -12 + 2.0 ** -54),               # every add is a tie in [1/2, 1)
+    "rare_tie": lambda rs, N: np.where(np.arange(N) % 5000 == 4999, 2.0 ** -54, 0.0) + rs.randint(1, 1000, N) * 2.0 ** -40,
+    "tiny": lambda rs, N: rs.rand(N) * 1e-310,                                          # subnormal sums
+    "growing": lambda rs, N: 1.5 ** (np.arange(N) % 900),                               # a binade crossing on most adds
+    "huge_then_small": lambda rs, N: np.concatenate([[1e300], rs.rand(N - 1)]),
+    "onehot": lambda rs, N: np.eye(1, N, N // 3)[0],
+    "with_negative": lambda rs, N: rs.randn(N),                                         # not valid weights, still exact
+    "heavy_tail": lambda rs, N: np.exp(rs.randn(N) * 6.0),
+}
+
+
+@pytest.mark.parametrize("name", sorted(HARD))
+def test_exact_cumsum_kernel_hard_cases(name):
+    """the tie-free double-increment fast path and its fall-back to the Mono scan, bit for bit against
+    numpy.cumsum (the same hard inputs as tests/test_hostcheck_exact_scan.py)"""
+    import torch
+    from filterpy_amd import _engine as E
+    for N in (7, 2048, 2049, 5000, 100003, 300007):
+        rs = np.random.RandomState(len(name) * 31 + N)
+        w = np.asarray(HARD[name](rs, N), dtype=np.float64)[None, :N]
+        dw = E.dev(w)
+        cs = torch.empty_like(dw)
+        E.cumsum_exact(1, N, dw, cs)
+        got, ref = cs.cpu().numpy(), np.cumsum(w, axis=1)
+        nz = ref != 0                       # zeros may differ in sign only (-0.0 + 0.0)
+        assert np.array_equal(got.view(np.uint64)[nz], ref.view(np.uint64)[nz]) and np.array_equal(got == 0, ref == 0), (name, N)
+
+
 def test_overrun_raises_indexerror():
     """weights summing to < the last position: the reference raises IndexError."""
     from filterpy_amd import monte_carlo as mc

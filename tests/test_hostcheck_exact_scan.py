@@ -31,6 +31,8 @@ CASES = {
     "leading_zeros": lambda rs, N: np.concatenate([np.zeros(N // 2), rs.rand(N - N // 2)]),
     "tiny": lambda rs, N: rs.rand(N) * 1e-310,                # subnormal sums
     "ties": lambda rs, N: rs.randint(0, 3, N) * 2.0 ** -53 + (rs.rand(N) < 0.01),   # exact half-ulp ties
+    "ties_everywhere": lambda rs, N: np.full(N, 2.0 ** -12 + 2.0 ** -54),           # every add in [1/2, 1) is a tie
+    "rare_tie": lambda rs, N: np.where(np.arange(N) % 5000 == 4999, 2.0 ** -54, 0.0) + rs.randint(1, 1000, N) * 2.0 ** -40,
     "growing": lambda rs, N: 1.5 ** (np.arange(N) % 900),     # a binade crossing on most adds
     "huge_then_small": lambda rs, N: np.concatenate([[1e300], rs.rand(N - 1)]),
     "onehot": lambda rs, N: np.eye(1, N, N // 3)[0],
