@@ -157,7 +157,7 @@ __device__ __forceinline__ void store_x(const MlView &v, const double (&x)[NX])
     }
 }
 
-template <int R, int NZ, bool OUTS, int WAVES, int VAR, bool PAIRS, bool MASK>
+template <int R, int NZ, bool OUTS, int WAVES, bool PAIRS, bool MASK>
 __global__ void __launch_bounds__(BLOCK, WAVES)
 kf_ml_kernel(const KfArgs a)
 {
@@ -186,12 +186,11 @@ kf_ml_kernel(const KfArgs a)
     const double *myF = sF + Lc * (R * NX);                     // this lane's rows of F and Q
     const double *myQ = sQ + Lc * (R * NX);
 
-    // VAR & 1: H (27 doubles, replicated) lives in VGPRs instead of being re-read from LDS per use
-    double Hreg[(VAR & 1) ? NZ * NX : 1];
-    if constexpr ((VAR & 1) != 0) {
-        FK_UNROLL for (int e = 0; e < NZ * NX; ++e) Hreg[e] = sH[e];
-    }
-#define HX(e) (((VAR & 1) != 0) ? Hreg[(e)] : sH[(e)])
+    // H (27 doubles, replicated) lives in VGPRs instead of being re-read from LDS at each of its five uses
+    // per step (measured: 2 % faster than LDS reads, no occupancy change)
+    double Hreg[NZ * NX];
+    FK_UNROLL for (int e = 0; e < NZ * NX; ++e) Hreg[e] = sH[e];
+#define HX(e) Hreg[(e)]
     double P[R][NX], x[NX];
     {
         const MlView vP(a.P, off_rows, estride), vx(a.x, t8, estride);
@@ -661,9 +660,9 @@ int launch_kf_ml_9_3(const KfArgs &a, int layout, bool outs, int model_mode, hip
     const char *pv = getenv("FK_ML_PAIRS");
     const bool pairs = (a.N % 2 == 0) && a.N >= 2 && !(pv && atoi(pv) == 0);
 #define GO(M)                                                                                                         \
-    if (outs && pairs) hipLaunchKernelGGL((kf_ml_kernel<3, 3, true, FK_ML_WAVES, 1, true, M>), grid, block, 0, s, a);   \
-    else if (outs) hipLaunchKernelGGL((kf_ml_kernel<3, 3, true, FK_ML_WAVES, 1, false, M>), grid, block, 0, s, a);     \
-    else hipLaunchKernelGGL((kf_ml_kernel<3, 3, false, FK_ML_WAVES, 1, false, M>), grid, block, 0, s, a)
+    if (outs && pairs) hipLaunchKernelGGL((kf_ml_kernel<3, 3, true, FK_ML_WAVES, true, M>), grid, block, 0, s, a);   \
+    else if (outs) hipLaunchKernelGGL((kf_ml_kernel<3, 3, true, FK_ML_WAVES, false, M>), grid, block, 0, s, a);     \
+    else hipLaunchKernelGGL((kf_ml_kernel<3, 3, false, FK_ML_WAVES, false, M>), grid, block, 0, s, a)
     if (a.mask) { GO(true); } else { GO(false); }
 #undef GO
     return check_launch("kf_ml_kernel");

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""A/B timing of the (9,3) kernels on one GPU: multi-lane (FK_ML_VAR=1|0: H in VGPRs or LDS) vs one lane per track
+"""A/B timing of the (9,3) kernels on one GPU: three lanes per track (FK_ML_PAIRS=1|0: 16- or 8-byte accesses) vs one lane per track
 (FK_NO_ML=1), with and without the four per-step outputs.  SOA, shared model, N tracks x T steps."""
 import json
 import os
@@ -28,7 +28,7 @@ def main():
     st = torch.zeros(N, dtype=torch.int32, device=dev)
     d = [E.dev(a) for a in (F, Q, H, R)]
     desc = dict(n=n, m=m, nu=0, model_mode=0, N=N, T=T, layout=E.LAYOUTS["soa"], update_first=0, alpha_sq=1.0)
-    for env in ({}, {"FK_ML_PAIRS": "0"}):
+    for env in ({}, {"FK_ML_PAIRS": "0"}, {"FK_NO_ML": "1"}):
         for k in ("FK_ML_WAVES", "FK_NO_ML", "FK_ML_PAIRS", "FK_ML_VAR"):
             os.environ.pop(k, None)
         os.environ.update(env)
