@@ -234,3 +234,29 @@ def test_multilane_rts_9_vs_oracle(N):
         ref = kf_oracle.rts_smoother_tracks(Xs, Ps, F, Q, tracks=sample, convention=name)
         for k in range(4):
             assert rel_err_rows(_per_track(got[k][:, sample]), _per_track(ref[k])) < 1e-9, (name, k)
+
+
+@pytest.mark.parametrize("N", [1, 2, 3, 16, 17, 64, 65, 66, 130])
+def test_multilane_small_shapes(N):
+    """tiny and ragged banks through the three-lane kernels (pair path for even N, tail quads, T = 1..3)."""
+    from gpu_util import run_kf_batch, run_rts
+    n, m = 9, 3
+    rs = np.random.RandomState(500 + N)
+    F = np.eye(n) + 0.05 * rs.randn(n, n)
+    B = rs.randn(n, n)
+    Q = 0.1 * (B @ B.T / n + 0.5 * np.eye(n))
+    H = rs.randn(m, n)
+    R = 0.5 * np.eye(m)
+    for T in (1, 2, 3):
+        A = rs.randn(N, n, n)
+        x0, P0 = rs.randn(N, n), A @ A.transpose(0, 2, 1) / n + 0.5 * np.eye(n)
+        zs = rs.randn(T, N, m)
+        got = run_kf_batch(x0, P0, zs, F, Q, H, R, layout="soa")
+        ref = kf_oracle.kf_batch_filter_tracks(x0, P0, zs, F, Q, H, R, tracks=range(N))
+        for k in range(4):
+            assert rel_err_rows(_per_track(got[k]), _per_track(ref[k])) < TOL, (T, k)
+        assert rel_err_rows(got[4], ref[0][-1]) < TOL and rel_err_rows(got[5], ref[1][-1]) < TOL
+        sm = run_rts(ref[0], ref[1], F, Q, layout="soa")
+        rr = kf_oracle.rts_smoother_tracks(ref[0], ref[1], F, Q, tracks=range(N))
+        for k in range(4):
+            assert rel_err_rows(_per_track(sm[k]), _per_track(rr[k])) < 1e-9, (T, "rts", k)
