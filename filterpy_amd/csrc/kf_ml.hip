@@ -20,8 +20,8 @@
 //
 // Per lane and step: ~1250 FMAs and ~190 exchanged doubles, ~90 live doubles (one lane per track:
 // ~3700 FMAs, > 250 live doubles).  A wave carries 16 tracks, so config 3 becomes 6250 waves.
-// Layout: SOA only (element-major: a quad's three active lanes write three 128-byte segments per
-// store); exact dims (9, 3), shared constant model, predict -> update, no control input, no mask,
+// Layouts: SOA (element-major: 16-byte pair stores, see MlView::store_pair) and AOS (NumPy order: output
+// sets staged through a wave-private LDS tile, ml_store_aos); exact dims (9, 3), shared constant model, predict -> update, no control input, no mask,
 // all four outputs or none.  Everything else stays on kf_fast / kf_kernel.
 #include <stdlib.h>
 
@@ -95,6 +95,21 @@ struct MlView {
         v.w = (unsigned)__builtin_amdgcn_update_dpp(by, ay, 0x104, 0xf, 0x5, false);
         __builtin_amdgcn_raw_buffer_store_b128(v, rs, voff2, (unsigned)e * estride, 0);
     }
+    // AOS: elements e and e + 1 of a track are adjacent in memory -- one 16-byte access, no exchange
+    __device__ __forceinline__ void store2(int e, double a, double b) const
+    {
+        using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+        const u32x2 lo = __builtin_bit_cast(u32x2, a), hi = __builtin_bit_cast(u32x2, b);
+        const u32x4 v = {lo.x, lo.y, hi.x, hi.y};
+        __builtin_amdgcn_raw_buffer_store_b128(v, rs, voff, (unsigned)e * estride, 0);
+    }
+    __device__ __forceinline__ void load2(int e, double &a, double &b) const
+    {
+        using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, (unsigned)e * estride, 0);
+        a = __hiloint2double((int)v.y, (int)v.x);
+        b = __hiloint2double((int)v.w, (int)v.z);
+    }
     // the mirror image for loads: one 16-byte load per lane, then the quads swap halves
     __device__ __forceinline__ void load_pair(int e, double &a, double &b) const
     {
@@ -111,11 +126,16 @@ struct MlView {
 };
 
 // a lane's R x NX rows (R*NX consecutive elements) as pairs + one odd element
-template <int R, int NX, bool PAIRS>
+// MODE: 0 = 8-byte accesses; 1 = 16-byte pairs over the quad exchange (SOA, even N); 2 = 16-byte
+// contiguous element pairs (AOS)
+template <int R, int NX, int MODE>
 __device__ __forceinline__ void store_rows(const MlView &v, const double (&M)[R][NX])
 {
-    if constexpr (PAIRS) {
-        FK_UNROLL for (int f = 0; f + 1 < R * NX; f += 2) v.store_pair(f, M[f / NX][f % NX], M[(f + 1) / NX][(f + 1) % NX]);
+    if constexpr (MODE != 0) {
+        FK_UNROLL for (int f = 0; f + 1 < R * NX; f += 2) {
+            if constexpr (MODE == 1) v.store_pair(f, M[f / NX][f % NX], M[(f + 1) / NX][(f + 1) % NX]);
+            else v.store2(f, M[f / NX][f % NX], M[(f + 1) / NX][(f + 1) % NX]);
+        }
         if ((R * NX) % 2) v.store(R * NX - 1, M[R - 1][NX - 1]);
     } else {
         FK_UNROLL for (int r = 0; r < R; ++r)
@@ -123,11 +143,14 @@ __device__ __forceinline__ void store_rows(const MlView &v, const double (&M)[R]
     }
 }
 
-template <int R, int NX, bool PAIRS>
+template <int R, int NX, int MODE>
 __device__ __forceinline__ void load_rows(const MlView &v, double (&M)[R][NX])
 {
-    if constexpr (PAIRS) {
-        FK_UNROLL for (int f = 0; f + 1 < R * NX; f += 2) v.load_pair(f, M[f / NX][f % NX], M[(f + 1) / NX][(f + 1) % NX]);
+    if constexpr (MODE != 0) {
+        FK_UNROLL for (int f = 0; f + 1 < R * NX; f += 2) {
+            if constexpr (MODE == 1) v.load_pair(f, M[f / NX][f % NX], M[(f + 1) / NX][(f + 1) % NX]);
+            else v.load2(f, M[f / NX][f % NX], M[(f + 1) / NX][(f + 1) % NX]);
+        }
         if ((R * NX) % 2) M[R - 1][NX - 1] = v.load(R * NX - 1);
     } else {
         FK_UNROLL for (int r = 0; r < R; ++r)
@@ -135,35 +158,88 @@ __device__ __forceinline__ void load_rows(const MlView &v, double (&M)[R][NX])
     }
 }
 
-template <int NX, bool PAIRS>
+template <int NX, int MODE>
 __device__ __forceinline__ void load_x(const MlView &v, double (&x)[NX])
 {
-    if constexpr (PAIRS) {
-        FK_UNROLL for (int k = 0; k + 1 < NX; k += 2) v.load_pair(k, x[k], x[k + 1]);
+    if constexpr (MODE != 0) {
+        FK_UNROLL for (int k = 0; k + 1 < NX; k += 2) {
+            if constexpr (MODE == 1) v.load_pair(k, x[k], x[k + 1]);
+            else v.load2(k, x[k], x[k + 1]);
+        }
         if (NX % 2) x[NX - 1] = v.load(NX - 1);
     } else {
         FK_UNROLL for (int k = 0; k < NX; ++k) x[k] = v.load(k);
     }
 }
 
-template <int NX, bool PAIRS>
+template <int NX, int MODE>
 __device__ __forceinline__ void store_x(const MlView &v, const double (&x)[NX])
 {
-    if constexpr (PAIRS) {
-        FK_UNROLL for (int k = 0; k + 1 < NX; k += 2) v.store_pair(k, x[k], x[k + 1]);
+    if constexpr (MODE != 0) {
+        FK_UNROLL for (int k = 0; k + 1 < NX; k += 2) {
+            if constexpr (MODE == 1) v.store_pair(k, x[k], x[k + 1]);
+            else v.store2(k, x[k], x[k + 1]);
+        }
         if (NX % 2) v.store(NX - 1, x[NX - 1]);
     } else {
         FK_UNROLL for (int k = 0; k < NX; ++k) v.store(k, x[k]);
     }
 }
 
-template <int R, int NZ, bool OUTS, int WAVES, bool PAIRS, bool MASK>
+__device__ __forceinline__ void ml_wave_fence()
+{
+    // LDS operations of one wave execute in order; this only keeps the compiler from moving the tile
+    // writes and the transposed reads across each other
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// AOS ([track][element], NumPy order) output of one (x, P) set: a wave's 16 tracks are one contiguous
+// slab of 16 * E doubles; the quads write their rows into a wave-private LDS tile laid out like the
+// slab, then the 64 lanes copy consecutive 16-byte units (1 KiB per store instruction).  The buffer
+// descriptor is sized to the wave's valid tracks: the hardware range check drops the tail.
+template <int R, int NX>
+__device__ __forceinline__ void ml_store_aos(const double (&x)[NX], const double (&P)[R][NX], double *xdst, double *Pdst,
+                                             double *tile, unsigned lane, unsigned Lc, unsigned valid)
+{
+    constexpr int EP = NX * NX, UP = 16 * EP / 2, UX = 16 * NX / 2;      // 16-byte units per wave
+    using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+    const unsigned q = lane >> 2;
+    double *tx = tile, *tP = tile + 16 * NX;
+    ml_wave_fence();
+    FK_UNROLL for (int k = 0; k < NX; ++k) tx[q * NX + k] = x[k];                         // the quad writes the same value
+    FK_UNROLL for (int r = 0; r < R; ++r)
+        FK_UNROLL for (int c = 0; c < NX; ++c) tP[q * EP + Lc * (R * NX) + r * NX + c] = P[r][c];
+    ml_wave_fence();
+    const rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(xdst, 0, (int)(valid * (unsigned)NX * 8u), 0x00020000);
+    const rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc(Pdst, 0, (int)(valid * (unsigned)EP * 8u), 0x00020000);
+    FK_UNROLL for (int it = 0; it * 64 < UX; ++it) {
+        const unsigned unit = it * 64u + lane;
+        if (unit < (unsigned)UX) {
+            const u32x4 v = *reinterpret_cast<const u32x4 *>(tx + 2 * unit);
+            __builtin_amdgcn_raw_buffer_store_b128(v, rx, unit * 16u, 0, 0);
+        }
+    }
+    FK_UNROLL for (int it = 0; it * 64 < UP; ++it) {
+        const unsigned unit = it * 64u + lane;
+        if (it * 64 + 63 < UP || unit < (unsigned)UP) {
+            const u32x4 v = *reinterpret_cast<const u32x4 *>(tP + 2 * unit);
+            __builtin_amdgcn_raw_buffer_store_b128(v, rP, unit * 16u, 0, 0);
+        }
+    }
+}
+
+template <int R, int NZ, bool OUTS, int WAVES, bool PAIRS, bool MASK, int LAYOUT>
 __global__ void __launch_bounds__(BLOCK, WAVES)
 kf_ml_kernel(const KfArgs a)
 {
     constexpr int NX = 3 * R;
     using LM = LdsModel<NX, NZ>;
-    __shared__ double smem[LM::SIZE];
+    constexpr bool AOS = LAYOUT == LAYOUT_AOS;
+    constexpr int TILE = 16 * NX + 16 * NX * NX;                 // AOS: one (x, P) output set of a wave
+    __shared__ double smem[LM::SIZE + (AOS && OUTS ? (BLOCK / 64) * TILE : 0)];
+    double *tile = smem + LM::SIZE + (threadIdx.x >> 6) * TILE;
     lds_fill<NX, NX>(smem + LM::OFF_F, a.F, NX, NX, 1.0, threadIdx.x);
     lds_fill<NX, NX>(smem + LM::OFF_Q, a.Q, NX, NX, 0.0, threadIdx.x);
     lds_fill<NZ, NX>(smem + LM::OFF_H, a.H, NZ, NX, 0.0, threadIdx.x);
@@ -177,20 +253,31 @@ kf_ml_kernel(const KfArgs a)
     long trk = (long)blockIdx.x * (BLOCK / 4) + (threadIdx.x >> 2);
     const unsigned odd = (threadIdx.x >> 2) & 1u;              // odd quad of its pair (workgroups start on even tracks)
     if (trk >= N) trk = PAIRS ? N - 2 + odd : N - 1;           // tail quads recompute the last track (pair)
-    unsigned estride = (unsigned)N * 8u;
+    // element e of this lane's track sits at  lane offset + e * estride:  SOA: track*8 + e*N*8 ;
+    // AOS: track*E*8 + e*8 (E = elements per record of the array: the offsets below are per array)
+    unsigned estride = AOS ? 8u : (unsigned)N * 8u;
     asm volatile("" : "+s"(estride));
-    const unsigned t8 = (unsigned)trk * 8u;
-    const unsigned off_rows = t8 + Lc * (unsigned)(R * NX) * estride;   // element (Lc*R + r)*NX + c
+    const unsigned t8 = (unsigned)trk * (AOS ? (unsigned)NX * 8u : 8u);                       // x-like arrays
+    const unsigned tz8 = (unsigned)trk * (AOS ? (unsigned)NZ * 8u : 8u);                      // z
+    const unsigned off_rows = (AOS ? (unsigned)trk * (unsigned)(NX * NX) * 8u : (unsigned)trk * 8u)
+                              + Lc * (unsigned)(R * NX) * estride;                            // element (Lc*R + r)*NX + c
     const unsigned pair_rows = odd ? off_rows - 8u + estride : off_rows;
     const unsigned pair_x = odd ? t8 - 8u + estride : t8;
+    // AOS output slabs: first track of this wave and how many of its 16 tracks exist
+    const long w0 = (long)blockIdx.x * (BLOCK / 4) + (long)(threadIdx.x >> 6) * 16;
+    const unsigned valid = (unsigned)(N - w0 >= 16 ? 16 : (N - w0 > 0 ? N - w0 : 0));
+    const unsigned lane = threadIdx.x & 63u;
     const double *myF = sF + Lc * (R * NX);                     // this lane's rows of F and Q
     const double *myQ = sQ + Lc * (R * NX);
 
     // H (27 doubles, replicated) lives in VGPRs instead of being re-read from LDS at each of its five uses
     // per step (measured: 2 % faster than LDS reads, no occupancy change)
-    double Hreg[NZ * NX];
-    FK_UNROLL for (int e = 0; e < NZ * NX; ++e) Hreg[e] = sH[e];
-#define HX(e) Hreg[(e)]
+    // (not in the AOS instantiation: its LDS staging needs the registers, H is read from LDS there)
+    double Hreg[AOS ? 1 : NZ * NX];
+    if constexpr (!AOS) {
+        FK_UNROLL for (int e = 0; e < NZ * NX; ++e) Hreg[e] = sH[e];
+    }
+#define HX(e) (AOS ? sH[(e)] : Hreg[AOS ? 0 : (e)])
     double P[R][NX], x[NX];
     {
         const MlView vP(a.P, off_rows, estride), vx(a.x, t8, estride);
@@ -213,7 +300,7 @@ kf_ml_kernel(const KfArgs a)
     double zn[NZ];
     unsigned hn = 1u;
     {
-        const MlView vz(a.z, t8, estride);
+        const MlView vz(a.z, tz8, estride);
         FK_UNROLL for (int c = 0; c < NZ; ++c) zn[c] = vz.load(c);
         if constexpr (MASK) hn = a.mask[trk];
         FK_UNROLL for (int c = 0; c < NZ; ++c) asm volatile("" ::"v"(zn[c]));     // landed, like x and P above
@@ -226,7 +313,7 @@ kf_ml_kernel(const KfArgs a)
         {
             long tn = t + 1 < a.T ? t + 1 : t;
             asm volatile("" : "+s"(tn));      // opaque: keeps the compiler from re-deriving this load one iteration later
-            const MlView vz(a.z + tn * N * NZ, t8, estride);
+            const MlView vz(a.z + tn * N * NZ, tz8, estride);
             FK_UNROLL for (int c = 0; c < NZ; ++c) zn[c] = vz.load(c);
             if constexpr (MASK) hn = a.mask[tn * N + trk];
         }
@@ -241,9 +328,9 @@ kf_ml_kernel(const KfArgs a)
             }
             FK_UNROLL for (int i = 0; i < NX; ++i) x[i] = xn[i];
         }
-        if (OUTS) {
+        if (OUTS && !AOS) {
             const MlView vx(a.means_p + t * N * NX, t8, estride, pair_x);
-            store_x<NX, PAIRS>(vx, x);      // replicated: the quad writes the same bytes
+            store_x<NX, PAIRS ? 1 : 0>(vx, x);      // replicated: the quad writes the same bytes
         }
         FK_STAGE();
         {
@@ -259,7 +346,7 @@ kf_ml_kernel(const KfArgs a)
                     FK_UNROLL for (int k = 1; k < NX; ++k) acc = fma(P[r][k], sF[i * NX + k], acc);
                     T[r][i] = acc;
                 }
-                if (OUTS) {
+                if (OUTS && !AOS) {
                     // (at t == 0 this writes the initial P into covs[0], overwritten by step 0's own result later)
                     if constexpr (PAIRS) {
                         // the lane's 27 elements as 13 pairs + 1: iterations 0,2,4,6 send 3 pairs, 8 sends 1 pair + the last
@@ -294,6 +381,8 @@ kf_ml_kernel(const KfArgs a)
             FK_UNROLL for (int r = 0; r < R; ++r)
                 FK_UNROLL for (int j = 0; j < NX; ++j) P[r][j] = fma(a.alpha_sq, P[r][j], myQ[r * NX + j]);
         }
+        if constexpr (OUTS && AOS)
+            ml_store_aos<R, NX>(x, P, a.means_p + (t * N + w0) * NX, a.covs_p + (t * N + w0) * NX * NX, tile, lane, Lc, valid);
         FK_STAGE();
         // ----------------------------------------------------------------- update --
         // Joseph form with the identity-minus-product factors applied implicitly (cf. fk_math_sym.hpp),
@@ -318,7 +407,7 @@ kf_ml_kernel(const KfArgs a)
                     FK_UNROLL for (int k = 1; k < NX; ++k) acc = fma(P[r][k], HX(c * NX + k), acc);
                     PHT[r][c] = acc;
                 }
-                if (OUTS) {
+                if (OUTS && !AOS) {
                     if constexpr (PAIRS) {
                         // 27 elements = 13 pairs + 1, pairs may straddle rows: row r sends the pairs that END in it
                         FK_UNROLL for (int f0 = 0; f0 + 1 < R * NX; f0 += 2)
@@ -403,12 +492,14 @@ kf_ml_kernel(const KfArgs a)
                 }
             }
         }
-        if (OUTS) {
+        if (OUTS && !AOS) {
             const MlView vx(a.means + t * N * NX, t8, estride, pair_x);
-            store_x<NX, PAIRS>(vx, x);
+            store_x<NX, PAIRS ? 1 : 0>(vx, x);
         }
+        if constexpr (OUTS && AOS)
+            ml_store_aos<R, NX>(x, P, a.means + (t * N + w0) * NX, a.covs + (t * N + w0) * NX * NX, tile, lane, Lc, valid);
     }
-    if (OUTS && a.T > 0) {      // the last step's posterior covariance (the others were stored one step late)
+    if (OUTS && !AOS && a.T > 0) {      // the last step's posterior covariance (the others were stored one step late)
         const MlView vP(a.covs + (a.T - 1) * N * NX * NX, off_rows, estride);
         FK_UNROLL for (int r = 0; r < R; ++r)
             FK_UNROLL for (int c = 0; c < NX; ++c) vP.store(r * NX + c, P[r][c]);
@@ -445,7 +536,7 @@ kf_ml_kernel(const KfArgs a)
 // every lane on a gathered packed copy (45 doubles) and each lane back-substitutes its own three
 // rows of K.  The filtered P is read twice (second time from L2) instead of being held across the
 // factorisation.  Shared constant F, Q; SOA; K and Pp outputs both present.
-template <int R, int WAVES, bool PAIRS>
+template <int R, int WAVES, int MODE>
 __global__ void __launch_bounds__(BLOCK, WAVES)
 rts_ml_kernel(const RtsArgs a)
 {
@@ -465,10 +556,12 @@ rts_ml_kernel(const RtsArgs a)
     const unsigned Lc = L < 3u ? L : 2u;
     long trk = (long)blockIdx.x * (BLOCK / 4) + (threadIdx.x >> 2);
     const unsigned odd = (threadIdx.x >> 2) & 1u;
-    if (trk >= N) trk = PAIRS ? N - 2 + odd : N - 1;
-    const unsigned estride = (unsigned)N * 8u;
-    const unsigned t8 = (unsigned)trk * 8u;
-    const unsigned off_rows = t8 + Lc * (unsigned)(R * NX) * estride;
+    if (trk >= N) trk = MODE == 1 ? N - 2 + odd : N - 1;
+    // SOA: element e of a track at track*8 + e*N*8 ; AOS (MODE 2): track*E*8 + e*8
+    constexpr bool AOS = MODE == 2;
+    const unsigned estride = AOS ? 8u : (unsigned)N * 8u;
+    const unsigned t8 = (unsigned)trk * (AOS ? (unsigned)NX * 8u : 8u);
+    const unsigned off_rows = (AOS ? (unsigned)trk * (unsigned)(NX * NX) * 8u : (unsigned)trk * 8u) + Lc * (unsigned)(R * NX) * estride;
     const unsigned pair_rows = odd ? off_rows - 8u + estride : off_rows;
     const unsigned pair_x = odd ? t8 - 8u + estride : t8;
     const double *myF = sF + Lc * (R * NX), *myQ = sQ + Lc * (R * NX);
@@ -500,8 +593,8 @@ rts_ml_kernel(const RtsArgs a)
     {
         const long k0 = T >= 2 ? T - 2 : 0;
         const MlView vx(a.Xs + k0 * xs_blk, t8, estride, pair_x), vP(a.Ps + k0 * ps_blk, off_rows, estride, pair_rows);
-        load_rows<R, NX, PAIRS>(vP, Pnx);
-        load_x<NX, PAIRS>(vx, xnx);
+        load_rows<R, NX, MODE>(vP, Pnx);
+        load_x<NX, MODE>(vx, xnx);
         FK_UNROLL for (int r = 0; r < R; ++r)
             FK_UNROLL for (int c = 0; c < NX; ++c) asm volatile("" ::"v"(Pnx[r][c]));
         FK_UNROLL for (int i = 0; i < NX; ++i) asm volatile("" ::"v"(xnx[i]));
@@ -539,7 +632,7 @@ rts_ml_kernel(const RtsArgs a)
             const MlView oPp(a.Pp + k * ps_blk, off_rows, estride, pair_rows);
             FK_UNROLL for (int r = 0; r < R; ++r)
                 FK_UNROLL for (int j = 0; j < NX; ++j) Pp[r][j] += myQ[r * NX + j];
-            store_rows<R, NX, PAIRS>(oPp, Pp);
+            store_rows<R, NX, MODE>(oPp, Pp);
         }
         FK_STAGE();
         // K = T Pp^-1: every lane factors a gathered packed copy of Pp and solves its own rows
@@ -567,7 +660,7 @@ rts_ml_kernel(const RtsArgs a)
         FK_STAGE();
         {
             const MlView oK(a.K + k * ps_blk, off_rows, estride, pair_rows);
-            store_rows<R, NX, PAIRS>(oK, Tm);
+            store_rows<R, NX, MODE>(oK, Tm);
         }
         // x += K (xn - F x), replicated: K's rows come from their owners.  (x is only fetched now: nine
         // doubles less across the factorisation, which is where this kernel's register peak is.)
@@ -597,7 +690,7 @@ rts_ml_kernel(const RtsArgs a)
                 FK_STAGE();
             }
             // P (filtered, second read) += E K' : column j needs K's row j; the same row updates x[j]
-            load_rows<R, NX, PAIRS>(vP, Pn);
+            load_rows<R, NX, MODE>(vP, Pn);
             double dxr[NX];
             FK_UNROLL for (int i = 0; i < NX; ++i) dxr[i] = park[NX + i][threadIdx.x];
             FK_UNROLL for (int j = 0; j < NX; ++j) {
@@ -618,14 +711,14 @@ rts_ml_kernel(const RtsArgs a)
             long kn = k > 0 ? k - 1 : 0;
             asm volatile("" : "+s"(kn));
             const MlView nx(a.Xs + kn * xs_blk, t8, estride, pair_x), nP(a.Ps + kn * ps_blk, off_rows, estride, pair_rows);
-            load_rows<R, NX, PAIRS>(nP, Pnx);
-            load_x<NX, PAIRS>(nx, xnx);
+            load_rows<R, NX, MODE>(nP, Pnx);
+            load_x<NX, MODE>(nx, xnx);
         }
         FK_STAGE();
         {
             const MlView ox(a.xs + k * xs_blk, t8, estride, pair_x), oP(a.Ps_out + k * ps_blk, off_rows, estride, pair_rows);
-            store_x<NX, PAIRS>(ox, xn);
-            store_rows<R, NX, PAIRS>(oP, Pn);
+            store_x<NX, MODE>(ox, xn);
+            store_rows<R, NX, MODE>(oP, Pn);
         }
     }
     if (a.status) {
@@ -641,29 +734,36 @@ rts_ml_kernel(const RtsArgs a)
 // returns 1 when this call is not one the multi-lane smoother serves
 int launch_rts_ml_9(const RtsArgs &a, int layout, bool uniform, hipStream_t s)
 {
-    if (layout != FK_LAYOUT_SOA || !uniform || a.model_t || a.n != 9 || !a.K || !a.Pp || a.T < 2) return 1;
+    if (!uniform || a.model_t || a.n != 9 || !a.K || !a.Pp || a.T < 2) return 1;
+    if (layout == FK_LAYOUT_AOS && (double)a.N * 81.0 * 8.0 >= 4294967296.0) return 1;
     const dim3 grid((unsigned)((a.N + BLOCK / 4 - 1) / (BLOCK / 4))), block(BLOCK);
     const char *pv = getenv("FK_ML_PAIRS");
     const bool pairs = (a.N % 2 == 0) && a.N >= 2 && !(pv && atoi(pv) == 0);
-    if (pairs) hipLaunchKernelGGL((rts_ml_kernel<3, FK_ML_WAVES, true>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((rts_ml_kernel<3, FK_ML_WAVES, false>), grid, block, 0, s, a);
+    if (layout == FK_LAYOUT_AOS) hipLaunchKernelGGL((rts_ml_kernel<3, FK_ML_WAVES, 2>), grid, block, 0, s, a);
+    else if (pairs) hipLaunchKernelGGL((rts_ml_kernel<3, FK_ML_WAVES, 1>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((rts_ml_kernel<3, FK_ML_WAVES, 0>), grid, block, 0, s, a);
     return check_launch("rts_ml_kernel");
 }
 
 // returns 1 when this call is not one the multi-lane kernel serves
 int launch_kf_ml_9_3(const KfArgs &a, int layout, bool outs, int model_mode, hipStream_t s)
 {
-    if (layout != FK_LAYOUT_SOA || model_mode != FK_MODEL_SHARED || a.n != 9 || a.m != 3) return 1;
+    if (model_mode != FK_MODEL_SHARED || a.n != 9 || a.m != 3) return 1;
+    if (layout == FK_LAYOUT_AOS && (double)a.N * 81.0 * 8.0 >= 4294967296.0) return 1;      // 32-bit record offsets
     const dim3 grid((unsigned)((a.N + BLOCK / 4 - 1) / (BLOCK / 4))), block(BLOCK);
-    // FK_ML_WAVES = 1 | 2 | 3: occupancy target of the instantiation (A/B measurements); default 2
-    // 16-byte pair stores need the track count even (a pair never straddles a plane); FK_ML_PAIRS=0 turns them off
+    // 16-byte pair stores (SOA) need the track count even (a pair never straddles a plane); FK_ML_PAIRS=0 turns them off
     const char *pv = getenv("FK_ML_PAIRS");
     const bool pairs = (a.N % 2 == 0) && a.N >= 2 && !(pv && atoi(pv) == 0);
-#define GO(M)                                                                                                         \
-    if (outs && pairs) hipLaunchKernelGGL((kf_ml_kernel<3, 3, true, FK_ML_WAVES, true, M>), grid, block, 0, s, a);   \
-    else if (outs) hipLaunchKernelGGL((kf_ml_kernel<3, 3, true, FK_ML_WAVES, false, M>), grid, block, 0, s, a);     \
-    else hipLaunchKernelGGL((kf_ml_kernel<3, 3, false, FK_ML_WAVES, false, M>), grid, block, 0, s, a)
-    if (a.mask) { GO(true); } else { GO(false); }
+#define GO(M, LAY)                                                                                                          \
+    if (outs && pairs && LAY == LAYOUT_SOA)                                                                                 \
+        hipLaunchKernelGGL((kf_ml_kernel<3, 3, true, FK_ML_WAVES, true, M, LAYOUT_SOA>), grid, block, 0, s, a);             \
+    else if (outs) hipLaunchKernelGGL((kf_ml_kernel<3, 3, true, FK_ML_WAVES, false, M, LAY>), grid, block, 0, s, a);        \
+    else hipLaunchKernelGGL((kf_ml_kernel<3, 3, false, FK_ML_WAVES, false, M, LAY>), grid, block, 0, s, a)
+    if (layout == FK_LAYOUT_SOA) {
+        if (a.mask) { GO(true, LAYOUT_SOA); } else { GO(false, LAYOUT_SOA); }
+    } else {
+        if (a.mask) { GO(true, LAYOUT_AOS); } else { GO(false, LAYOUT_AOS); }
+    }
 #undef GO
     return check_launch("kf_ml_kernel");
 }
