@@ -146,10 +146,10 @@ static int run_kf(const fk_kf_desc *d, KfArgs &a, void *stream)
     // input, all four outputs stored or none (every model mode at dim_x <= 6, shared constant model above).
     const bool all_out = a.means && a.covs && a.means_p && a.covs_p;
     const bool no_out = !a.means && !a.covs && !a.means_p && !a.covs_p;
-    if (d->nu == 0 && a.do_predict && a.do_update &&
+    if (a.do_predict && a.do_update &&
         (all_out || no_out) && !a.y_out && !a.K_out && !a.S_out && !a.SI_out && !a.ll_out && !a.maha_out &&
         !getenv("FK_NO_FAST")) {
-        if (d->n == 9 && d->m == 3 && !d->update_first && !getenv("FK_NO_ML")) {
+        if (d->n == 9 && d->m == 3 && !d->update_first && d->nu == 0 && !getenv("FK_NO_ML")) {
             const int rc = launch_kf_ml_9_3(a, d->layout, all_out, d->model_mode, (hipStream_t)stream);
             if (rc <= 0) return rc;        // 1 = not a call the multi-lane kernel serves
         }

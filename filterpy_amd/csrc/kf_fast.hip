@@ -131,7 +131,8 @@ __device__ __forceinline__ void cov_full(const double (&P)[PLEN], double (&M)[NX
 // reloaded every step), 3 one model per step shared by all tracks (LDS, double-buffered, fetched a
 // step ahead by the first SIZE threads).
 // UF: update_first (kalman_filter.py:966-978): every step is update(z) -> store posterior -> predict -> store prior
-template <int NX, int NZ, int LAYOUT, bool HAS_MASK, bool OUTS, bool SYM, int MMODE, bool UF>
+// CTRL: control input x = F x + B u (kalman_filter.py:472-475) with one shared B (dim_u <= 4); u[t] travels with z[t]
+template <int NX, int NZ, int LAYOUT, bool HAS_MASK, bool OUTS, bool SYM, int MMODE, bool UF, bool CTRL>
 __global__ void __launch_bounds__(BLOCK, fast_min_waves(NX, LAYOUT) > 1 && (MMODE == 1 || MMODE == 2) ? fast_min_waves(NX, LAYOUT) - 1 : fast_min_waves(NX, LAYOUT))
 kf_fast_kernel(const KfArgs a, const double *__restrict__ pF, const double *__restrict__ pQ,
                const double *__restrict__ pH, const double *__restrict__ pR,
@@ -144,6 +145,10 @@ kf_fast_kernel(const KfArgs a, const double *__restrict__ pF, const double *__re
     constexpr int TILE = COOP ? 64 * ((NX * NX) | 1) : 0;   // doubles per wave
     constexpr int MSIZE = SharedModel::SIZE * (MMODE == 3 ? 2 : 1);   // per-step models: double buffer
     __shared__ double s_mem[MSIZE + (BLOCK / 64) * TILE + 1];
+    constexpr int NUC = 4;                                   // padded dim_u
+    constexpr int ZW = NZ + (CTRL ? NUC : 0);                // a measurement buffer carries [z | u]
+    __shared__ double s_B[CTRL ? NX * NUC : 1];
+    if constexpr (CTRL) lds_fill<NX, NUC>(s_B, a.B, NX, a.nu, 0.0, threadIdx.x);   // synchronised with the model fill below
 
     const long N = a.N, T = a.T;
     // Workgroup -> track-block mapping.  Workgroups are dispatched round-robin over the 8 XCDs
@@ -216,11 +221,18 @@ kf_fast_kernel(const KfArgs a, const double *__restrict__ pF, const double *__re
     // flight: ZDEPTH = 2 for AOS (20 x 1 KiB stores per step), 1 for SOA (40 x 512 B per step; the
     // vmcnt counter tops out at 63 outstanding operations).
     constexpr int ZDEPTH = (FK_FAST_ZDEPTH > 0) ? FK_FAST_ZDEPTH : ((LAYOUT == LAYOUT_AOS && NX * NX + NX <= 24) ? 2 : 1);
-    double zb[3][NZ];
+    double zb[3][ZW];
     bool hb[3] = {true, true, true};
-    auto load_z = [&](long tt, double (&zd)[NZ], bool &hd) {
+    auto load_z = [&](long tt, double (&zd)[ZW], bool &hd) {
         const long tq = tt < T ? tt : T - 1;          // clamp: always issue the same number of loads
-        load_rec<NZ, 1, LAYOUT, true>(zd, pz + tq * N * NZ, lr, NZ, 1, 0.0);
+        {
+            const RecView<LAYOUT> zv(pz + tq * N * NZ, lr, NZ);
+            FK_UNROLL for (int c = 0; c < NZ; ++c) zd[c] = zv.load(c);
+        }
+        if constexpr (CTRL) {
+            const RecView<LAYOUT> uv(a.u + tq * N * a.nu, lr, a.nu);
+            FK_UNROLL for (int c = 0; c < NUC; ++c) zd[NZ + c] = uv.load(c < a.nu ? c : a.nu - 1);   // clamped: no branch
+        }
         if (HAS_MASK) hd = pmask[tq * N + lr.blk0 + lr.tid] != 0;
     };
     load_z(0, zb[0], hb[0]);
@@ -229,12 +241,12 @@ kf_fast_kernel(const KfArgs a, const double *__restrict__ pF, const double *__re
     // make the compiler wait vmcnt(0) inside the loop on every iteration (draining the stores).
     FK_UNROLL for (int i = 0; i < NX; ++i) asm volatile("" ::"v"(x[i]));
     FK_UNROLL for (int i = 0; i < PLEN; ++i) asm volatile("" ::"v"(P[i]));
-    FK_UNROLL for (int i = 0; i < NZ; ++i) asm volatile("" ::"v"(zb[0][i]));
-    if (ZDEPTH == 2) { FK_UNROLL for (int i = 0; i < NZ; ++i) asm volatile("" ::"v"(zb[1][i])); }
+    FK_UNROLL for (int i = 0; i < ZW; ++i) asm volatile("" ::"v"(zb[0][i]));
+    if (ZDEPTH == 2) { FK_UNROLL for (int i = 0; i < ZW; ++i) asm volatile("" ::"v"(zb[1][i])); }
 
     int st = 0;
     // one time step: consumes (zu, hu), requests the measurement of step t + ZDEPTH into (zl, hl)
-    auto step = [&](long t, const double (&zu)[NZ], bool hu, double (&zl)[NZ], bool &hl) {
+    auto step = [&](long t, const double (&zu)[ZW], bool hu, double (&zl)[ZW], bool &hl) {
         load_z(t + ZDEPTH, zl, hl);
         if constexpr (MMODE == 2) {
             if (t > 0) load_track_model(t);            // this step's per-track model
@@ -252,6 +264,14 @@ kf_fast_kernel(const KfArgs a, const double *__restrict__ pF, const double *__re
                 if constexpr (SYM) kf_predict_sym<NX>(x, P, sm, a.alpha_sq);
                 else kf_predict<NX>(x, P, sm, a.alpha_sq);
             }
+            if constexpr (CTRL) {
+                // x = (F x) + (B u): the product first, like dot(F, x) + dot(B, u)
+                FK_UNROLL for (int i = 0; i < NX; ++i) {
+                    double bu = s_B[i * NUC] * zu[NZ];
+                    FK_UNROLL for (int k = 1; k < NUC; ++k) bu = fma(s_B[i * NUC + k], (k < a.nu ? zu[NZ + k] : 0.0), bu);
+                    x[i] += bu;
+                }
+            }
             cov_full<NX, SYM, PLEN>(P, Pf);
             if (!OUTS) {
             } else if (!COOP) {
@@ -264,13 +284,15 @@ kf_fast_kernel(const KfArgs a, const double *__restrict__ pF, const double *__re
         };
         auto do_update = [&]() {
             if (hu) {
+                double zq[NZ];
+                FK_UNROLL for (int c = 0; c < NZ; ++c) zq[c] = zu[c];
                 double K[NX * NZ], y[NZ], S[NZ * NZ], Lf[NZ * NZ], dinv[NZ];
                 if constexpr (MMODE == 1 || MMODE == 2) {
-                    if constexpr (SYM) st |= kf_update_sym<NX, NZ>(x, P, zu, tm, K, y, S, Lf, dinv);
-                    else st |= kf_update<NX, NZ>(x, P, zu, tm, K, y, S, Lf, dinv);
+                    if constexpr (SYM) st |= kf_update_sym<NX, NZ>(x, P, zq, tm, K, y, S, Lf, dinv);
+                    else st |= kf_update<NX, NZ>(x, P, zq, tm, K, y, S, Lf, dinv);
                 } else {
-                    if constexpr (SYM) st |= kf_update_sym<NX, NZ>(x, P, zu, sm, K, y, S, Lf, dinv);
-                    else st |= kf_update<NX, NZ>(x, P, zu, sm, K, y, S, Lf, dinv);
+                    if constexpr (SYM) st |= kf_update_sym<NX, NZ>(x, P, zq, sm, K, y, S, Lf, dinv);
+                    else st |= kf_update<NX, NZ>(x, P, zq, sm, K, y, S, Lf, dinv);
                 }
             }
             cov_full<NX, SYM, PLEN>(P, Pf);
@@ -313,7 +335,7 @@ kf_fast_kernel(const KfArgs a, const double *__restrict__ pF, const double *__re
         static_assert(NX <= 6 || ZDEPTH == 1, "the rolled loop implements ZDEPTH == 1");
         for (long t = 0; t < T; ++t) {
             step(t, zb[0], hb[0], zb[1], hb[1]);
-            FK_UNROLL for (int i = 0; i < NZ; ++i) zb[0][i] = zb[1][i];
+            FK_UNROLL for (int i = 0; i < ZW; ++i) zb[0][i] = zb[1][i];
             hb[0] = hb[1];
         }
     }
@@ -342,12 +364,13 @@ int FK_CAT(launch_kf_fast_, FK_NX, FK_NZ, FK_VARIANT)(const KfArgs &a, int layou
 {
     if (mmode != 0 && !FK_FAST_ALL_MODES) return 1;
     if (a.update_first && !(FK_FAST_ALL_MODES && mmode == 0)) return 1;   // update_first: shared model, variant 0, dim_x <= 6
+    if (a.nu > 0 && !(FK_FAST_ALL_MODES && mmode == 0 && !a.update_first && a.nu <= 4)) return 1;   // control input: same, dim_u <= 4
     const dim3 grid((unsigned)((a.cnt + BLOCK - 1) / BLOCK)), block(BLOCK);
 #define FK_GO(LAY, MSK, OUT, MM)                                                                          \
-    hipLaunchKernelGGL((kf_fast_kernel<FK_NX, FK_NZ, LAY, MSK, OUT, (FK_FAST_SYM != 0), MM, false>), grid, block, 0, \
+    hipLaunchKernelGGL((kf_fast_kernel<FK_NX, FK_NZ, LAY, MSK, OUT, (FK_FAST_SYM != 0), MM, false, false>), grid, block, 0, \
                        stream, a, a.F, a.Q, a.H, a.R, a.z, a.mask)
 #define FK_GOUF(LAY, MSK, OUT)                                                                                \
-    hipLaunchKernelGGL((kf_fast_kernel<FK_NX, FK_NZ, LAY, MSK, OUT, (FK_FAST_SYM != 0), 0, true>), grid, block, 0, \
+    hipLaunchKernelGGL((kf_fast_kernel<FK_NX, FK_NZ, LAY, MSK, OUT, (FK_FAST_SYM != 0), 0, true, false>), grid, block, 0, \
                        stream, a, a.F, a.Q, a.H, a.R, a.z, a.mask)
 #define FK_GO3(LAY, MM)                          \
     do {                                         \
@@ -387,6 +410,26 @@ int FK_CAT(launch_kf_fast_, FK_NX, FK_NZ, FK_VARIANT)(const KfArgs &a, int layou
         return check_launch("kf_fast_kernel");
     }
 #undef FK_GOUF2
+#define FK_GOC(LAY, MSK, OUT)                                                                                     \
+    hipLaunchKernelGGL((kf_fast_kernel<FK_NX, FK_NZ, LAY, MSK, OUT, (FK_FAST_SYM != 0), 0, false, true>), grid, block, 0, \
+                       stream, a, a.F, a.Q, a.H, a.R, a.z, a.mask)
+#define FK_GOC2(LAY)                              \
+    do {                                          \
+        if (a.mask) {                             \
+            if (outs) FK_GOC(LAY, true, true);    \
+            else FK_GOC(LAY, true, false);        \
+        } else {                                  \
+            if (outs) FK_GOC(LAY, false, true);   \
+            else FK_GOC(LAY, false, false);       \
+        }                                         \
+    } while (0)
+    if (a.nu > 0) {
+        if (layout == LAYOUT_SOA) FK_GOC2(LAYOUT_SOA);
+        else FK_GOC2(LAYOUT_AOS);
+        return check_launch("kf_fast_kernel");
+    }
+#undef FK_GOC2
+#undef FK_GOC
 #endif
     if (layout == LAYOUT_SOA) FK_GO2(LAYOUT_SOA);
     else FK_GO2(LAYOUT_AOS);

@@ -174,6 +174,7 @@ def config_generic(layout, N, T):
         return t
     cases = {
         "shared, update_first": (0, [E.dev(M) for M in (F, Q, H, R)], dict(update_first=1), 0),
+        "shared, control input dim_u=2": (0, [E.dev(M) for M in (F, Q, H, R)], dict(nu=2), 16),
         "per-track models": (1, [rep(M, 0) for M in (F, Q, H, R)], {}, 8 * (2 * n * n + m * n + m * m) / T),
         "per-step shared models": (3, [E.dev(np.tile(M, (T, 1, 1))) for M in (F, Q, H, R)], {}, 0),
         "per-track-per-step models": (2, [rep(M, 1) for M in (F, Q, H, R)], {}, 8 * (2 * n * n + m * n + m * m)),
@@ -182,10 +183,17 @@ def config_generic(layout, N, T):
         desc = dict(n=n, m=m, nu=0, model_mode=mode, N=N, T=T, layout=E.LAYOUTS[layout], update_first=0, alpha_sq=1.0)
         desc.update(kw)
 
+        ctrl = {}
+        if desc["nu"]:
+            g2 = torch.Generator(device=dev)
+            g2.manual_seed(11)
+            ctrl = dict(B=E.dev(np.array([[0.5, 0.0], [1.0, 0.0], [0.0, 0.5], [0.0, 1.0]])),
+                        u=torch.randn((T, N, 2) if layout == "aos" else (T, 2, N), generator=g2, device=dev, dtype=torch.float64))
+
         def run():
             x.copy_(x0)
             P.copy_(P0)
-            E.kf_batch_filter(desc, *mods, z, x, P, means=outs[0], covs=outs[1], means_p=outs[2], covs_p=outs[3], status=st)
+            E.kf_batch_filter(desc, *mods, z, x, P, means=outs[0], covs=outs[1], means_p=outs[2], covs_p=outs[3], status=st, **ctrl)
         ms = timeit(run, warm=1, reps=3)
         assert not st.any()
         emit(f"KF (4,2) {name} N={N} {layout}", N * T, "track-steps", ms, 8 * (m + 2 * n + 2 * n * n) + extra)
