@@ -82,6 +82,22 @@ struct RecView {
         if (LAYOUT == LAYOUT_AOS) __builtin_amdgcn_raw_buffer_store_b64(v, rs, voff + (unsigned)e * 8u, 0, 0);
         else __builtin_amdgcn_raw_buffer_store_b64(v, rs, voff, (unsigned)e * estride, 0);
     }
+    // AOS only: elements e and e + 1 of a record are adjacent in memory -> one 16-byte access.  A wave
+    // may have 63 vector-memory operations in flight whatever their size, so on the lane-strided AOS
+    // paths twice the bytes per operation is close to twice the bandwidth.
+    using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+    __device__ __forceinline__ void load2(int e, double &a, double &b) const
+    {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + (unsigned)e * 8u, 0, 0);
+        a = __builtin_bit_cast(double, u32x2{v.x, v.y});
+        b = __builtin_bit_cast(double, u32x2{v.z, v.w});
+    }
+    __device__ __forceinline__ void store2(int e, double a, double b) const
+    {
+        const u32x2 lo = __builtin_bit_cast(u32x2, a), hi = __builtin_bit_cast(u32x2, b);
+        const u32x4 v = {lo.x, lo.y, hi.x, hi.y};
+        __builtin_amdgcn_raw_buffer_store_b128(v, rs, voff + (unsigned)e * 8u, 0, 0);
+    }
 };
 
 // Load an r x c matrix record of the lane's track (C order, row stride c) into a ROWS x COLS
@@ -92,6 +108,11 @@ __device__ __forceinline__ void load_rec(double (&M)[ROWS * COLS], const double 
 {
     const int E = EXACT ? ROWS * COLS : r * c;
     const RecView<LAYOUT> v(blk, ln, E);
+    if constexpr (EXACT && LAYOUT == LAYOUT_AOS && ROWS * COLS >= 2) {
+        FK_UNROLL for (int e = 0; e + 1 < ROWS * COLS; e += 2) v.load2(e, M[e], M[e + 1]);
+        if ((ROWS * COLS) % 2) M[ROWS * COLS - 1] = v.load(ROWS * COLS - 1);
+        return;
+    }
     FK_UNROLL for (int a = 0; a < ROWS; ++a) {
         FK_UNROLL for (int b = 0; b < COLS; ++b) {
             if (EXACT || (a < r && b < c))
@@ -108,6 +129,11 @@ __device__ __forceinline__ void store_rec(const double (&M)[ROWS * COLS], double
 {
     const int E = EXACT ? ROWS * COLS : r * c;
     const RecView<LAYOUT> v(blk, ln, E);
+    if constexpr (EXACT && LAYOUT == LAYOUT_AOS && ROWS * COLS >= 2) {
+        FK_UNROLL for (int e = 0; e + 1 < ROWS * COLS; e += 2) v.store2(e, M[e], M[e + 1]);
+        if ((ROWS * COLS) % 2) v.store(ROWS * COLS - 1, M[ROWS * COLS - 1]);
+        return;
+    }
     FK_UNROLL for (int a = 0; a < ROWS; ++a) {
         FK_UNROLL for (int b = 0; b < COLS; ++b) {
             if (EXACT || (a < r && b < c))
