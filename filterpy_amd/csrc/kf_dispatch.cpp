@@ -57,7 +57,7 @@ static const FastEntry *pick_fast(int n, int m)
     for (const FastEntry &e : fast_table) {
         if (e.nx != n || e.nz != m) continue;
         if (e.variant == want) return &e;
-        if (e.variant == 0) dflt = &e;
+        if (!dflt || e.variant < dflt->variant) dflt = &e;     // variant 0 if compiled, else the lean one
     }
     return dflt;
 }

@@ -260,3 +260,54 @@ def test_multilane_small_shapes(N):
         rr = kf_oracle.rts_smoother_tracks(ref[0], ref[1], F, Q, tracks=range(N))
         for k in range(4):
             assert rel_err_rows(_per_track(sm[k]), _per_track(rr[k])) < 1e-9, (T, "rts", k)
+
+
+@pytest.mark.parametrize("layout", ["soa", "aos"])
+@pytest.mark.parametrize("n,m", [(n, m) for n in range(1, 10) for m in range(1, min(n, 4) + 1)
+                                 if (n, m) not in ((1, 1), (2, 1), (4, 2), (6, 3), (9, 3))])
+def test_lean_fast_instantiations_vs_oracle(n, m, layout, monkeypatch):
+    """the dims that only have the lean specialised instantiation (shared model, optional mask): against
+    the oracle, and identical to what the generic kernel gives within the parity bar"""
+    from gpu_util import run_kf_batch
+    rs = np.random.RandomState(10 * n + m)
+    N, T = 500, 30
+    A = rs.randn(N, n, n)
+    x0, P0 = rs.randn(N, n), 3.0 * (A @ A.transpose(0, 2, 1) / n + 0.5 * np.eye(n))
+    zs = rs.randn(T, N, m) * 2
+    F = np.eye(n) + 0.05 * rs.randn(n, n)
+    F /= max(1.0, 1.05 * np.max(np.abs(np.linalg.eigvals(F))))     # stable, like the goldens' models
+    B = rs.randn(n, n)
+    Q = 0.1 * (B @ B.T / n + 0.5 * np.eye(n))
+    H = rs.randn(m, n)
+    C = rs.randn(m, m)
+    R = 0.5 * (C @ C.T / m + 0.5 * np.eye(m))
+    mask = rs.rand(T, N) > 0.2
+    sample = [0, 1, 63, 64, 255, 256, N - 1]
+    for kw in ({}, {"mask": mask}):
+        got = run_kf_batch(x0, P0, zs, F, Q, H, R, layout=layout, **kw)
+        ref = kf_oracle.kf_batch_filter_tracks(x0, P0, zs, F, Q, H, R, tracks=sample, **kw)
+        for k in range(4):
+            assert rel_err_rows(_per_track(got[k][:, sample]), _per_track(ref[k])) < TOL, (kw.keys(), k)
+    with monkeypatch.context() as mp:
+        mp.setenv("FK_NO_FAST", "1")
+        gen = run_kf_batch(x0, P0, zs, F, Q, H, R, layout=layout)
+    plain = run_kf_batch(x0, P0, zs, F, Q, H, R, layout=layout)
+    assert rel_err_rows(_per_track(plain[1][:, sample]), _per_track(gen[1][:, sample])) < TOL
+
+
+@pytest.mark.parametrize("layout", ["soa", "aos"])
+@pytest.mark.parametrize("n", [3, 5, 7, 8])
+def test_rts_more_exact_dims_vs_oracle(n, layout):
+    from gpu_util import run_rts
+    rs = np.random.RandomState(70 + n)
+    N, T = 300, 20
+    A = rs.randn(T, N, n, n)
+    Xs, Ps = rs.randn(T, N, n), A @ A.transpose(0, 1, 3, 2) / n + 0.5 * np.eye(n)
+    F = np.eye(n) + 0.1 * rs.randn(n, n)
+    B = rs.randn(n, n)
+    Q = 0.1 * (B @ B.T / n + 0.5 * np.eye(n))
+    sample = [0, 63, 64, 255, 256, N - 1]
+    got = run_rts(Xs, Ps, F, Q, layout=layout)
+    ref = kf_oracle.rts_smoother_tracks(Xs, Ps, F, Q, tracks=sample)
+    for k in range(4):
+        assert rel_err_rows(_per_track(got[k][:, sample]), _per_track(ref[k])) < 1e-9, k

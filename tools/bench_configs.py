@@ -371,6 +371,12 @@ if __name__ == "__main__":
             config4(lay, a.N, a.T)
         if "7" in a.configs:
             config_generic(lay, 200_000, a.T)
+        if "a" in a.configs:      # dims served by the lean specialised instantiations
+            config_kf(lay, 3, 1, 2_000_000, a.T)
+            config_kf(lay, 5, 2, 500_000, a.T)
+            config_kf(lay, 6, 2, 400_000, a.T)
+            config_kf(lay, 7, 4, 200_000, a.T)
+            config_kf(lay, 8, 4, 200_000, a.T)
         if "6" in a.configs:
             config_kf(lay, 6, 3, 300_000, a.T)
             config_kf(lay, 4, 2, 500_000, a.T)
