@@ -10,7 +10,7 @@ cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_stats -- python $R/bench.py --steps 5 --warmup 1 --no-cpu > $R/gpurun_out/prof_stats.log 2>&1; echo "stats rc=$?"
 timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/prof_fetch -- python $R/bench.py --steps 3 --warmup 1 --no-cpu > $R/gpurun_out/prof_fetch.log 2>&1; echo "fetch rc=$?"
 timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/prof_write -- python $R/bench.py --steps 3 --warmup 1 --no-cpu > $R/gpurun_out/prof_write.log 2>&1; echo "write rc=$?"
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_cfg -- python $R/tools/bench_configs.py --configs 3456789 --layouts soa > $R/gpurun_out/prof_cfg.log 2>&1; echo "cfg rc=$?"
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_cfg -- python $R/tools/bench_configs.py --configs 3456789a --layouts soa > $R/gpurun_out/prof_cfg.log 2>&1; echo "cfg rc=$?"
 cd $R
 for f in $(find gpurun_out/prof_stats -name "*kernel_stats.csv"); do cut -c1-160 $f | head -4; done
 python tools/pmc_summary.py gpurun_out/prof_fetch gpurun_out/prof_write 2>&1 | tail -6
