@@ -139,9 +139,10 @@ kf_fast_kernel(const KfArgs a, const double *__restrict__ pF, const double *__re
                const double *__restrict__ pz, const uint8_t *__restrict__ pmask)
 {
     using SharedModel = LdsModel<NX, NZ>;
-    // AOS records go through the LDS transpose while a wave tile fits (dim_x <= 6); larger
-    // records fall back to per-lane stores (TODO: chunked tiles)
-    constexpr bool COOP = (LAYOUT == LAYOUT_AOS) && (NX * NX <= 36);
+    // AOS records go through the LDS transpose while the wave tiles fit: dim_x <= 6 at any occupancy,
+    // dim_x <= 8 for the one-wave-per-SIMD instantiations (4 tiles of 64 x 65 doubles = 133 KB);
+    // dim_x = 9 falls back to per-lane 16-byte stores (the three-lane kernel takes the common call)
+    constexpr bool COOP = (LAYOUT == LAYOUT_AOS) && (NX * NX <= 36 || (NX <= 8 && fast_min_waves(NX, LAYOUT) == 1));
     constexpr int TILE = COOP ? 64 * ((NX * NX) | 1) : 0;   // doubles per wave
     constexpr int MSIZE = SharedModel::SIZE * (MMODE == 3 ? 2 : 1);   // per-step models: double buffer
     __shared__ double s_mem[MSIZE + (BLOCK / 64) * TILE + 1];
