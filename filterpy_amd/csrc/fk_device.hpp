@@ -181,6 +181,68 @@ __device__ __forceinline__ bool all_finite(const double (&v)[LEN])
     return ok;
 }
 
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+
+__device__ __forceinline__ void wave_lds_fence()
+{
+    // LDS operations of one wave execute in order; this only stops the compiler from
+    // reordering the tile writes and the transposed reads around each other.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Wave-cooperative store of one LEN-double record per lane into an AOS block:
+// lane l owns the record of track (block_first + wave_row0 + l); `slab` is the workgroup's slab
+// of the output array.  The descriptor is sized to the block's valid rows, so in the tail workgroup
+// the hardware range check drops the stores of rows past the last track (AOS offsets are
+// voffset + immediate: no scalar offset takes part in the check) -- no store is predicated.
+// The tile is written row-per-lane (row stride LEN|1 doubles: conflict-free ds_write_b64) and read
+// back in memory order, two consecutive doubles per lane per pass -> buffer_store_dwordx4,
+// 1 KiB contiguous per instruction.  When LEN divides 128 every pass uses the same lane-dependent
+// base addresses plus compile-time immediates (2 VGPRs of addressing for the whole record).
+template <int LEN>
+__device__ __forceinline__ void wave_store_aos(const double (&v)[LEN], const double *slab, unsigned wave_row0,
+                                               double *tile, unsigned lane, unsigned last_row)
+{
+    constexpr int LENP = LEN | 1;
+    const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(slab), 0,
+                                                        (int)((last_row + 1u) * (unsigned)LEN * 8u), 0x00020000);
+    FK_UNROLL for (int e = 0; e < LEN; ++e) tile[lane * LENP + e] = v[e];
+    wave_lds_fence();
+    if constexpr (LEN % 2 == 0 && 128 % LEN == 0) {
+        constexpr int PASSES = LEN / 2;          // 64*LEN doubles, 128 per pass
+        constexpr int RPP = 128 / LEN;           // rows per pass
+        const unsigned r0 = (lane * 2u) / LEN, col = (lane * 2u) % LEN;
+        const double *tb = tile + r0 * LENP + col;
+        const unsigned gb = ((wave_row0 + r0) * LEN + col) * 8u;
+        FK_UNROLL for (int it = 0; it < PASSES; ++it) {
+            const double a = tb[it * RPP * LENP], b = tb[it * RPP * LENP + 1];
+            const u32x2 ua = __builtin_bit_cast(u32x2, a), ub = __builtin_bit_cast(u32x2, b);
+            const u32x4 w = {ua.x, ua.y, ub.x, ub.y};
+            __builtin_amdgcn_raw_buffer_store_b128(w, rs, gb + (unsigned)(it * RPP * LEN * 8), 0, 0);
+        }
+    } else if constexpr (LEN % 2 == 0) {
+        constexpr int PASSES = LEN / 2;
+        FK_UNROLL for (int it = 0; it < PASSES; ++it) {
+            const unsigned q = it * 128u + lane * 2u;
+            const unsigned row = q / LEN, col = q % LEN;
+            const double a = tile[row * LENP + col], b = tile[row * LENP + col + 1];
+            const u32x2 ua = __builtin_bit_cast(u32x2, a), ub = __builtin_bit_cast(u32x2, b);
+            const u32x4 w = {ua.x, ua.y, ub.x, ub.y};
+            __builtin_amdgcn_raw_buffer_store_b128(w, rs, ((wave_row0 + row) * LEN + col) * 8u, 0, 0);
+        }
+    } else {
+        FK_UNROLL for (int it = 0; it < LEN; ++it) {
+            const unsigned q = it * 64u + lane;
+            const unsigned row = q / LEN, col = q % LEN;
+            const double a = tile[row * LENP + col];
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, a), rs, ((wave_row0 + row) * LEN + col) * 8u, 0, 0);
+        }
+    }
+    wave_lds_fence();
+}
+
 // ---- host side ------------------------------------------------------------
 void set_last_error(const char *msg);
 int check_launch(const char *what);   // hipGetLastError -> FK_ERR_LAUNCH + message

@@ -66,10 +66,10 @@ kf_kernel(const KfArgs a,
             const long mt = a.model_t ? t : 0;
             if (UNIFORM) {
                 if (t != 0) __syncthreads();   // everyone done reading the previous step's model
-                lds_fill<NX, NX>(s_model + SharedModel::OFF_F, a.do_predict ? pF + mt * n * n : nullptr, n, n, 1.0, ln.tid);
-                lds_fill<NX, NX>(s_model + SharedModel::OFF_Q, a.do_predict ? pQ + mt * n * n : nullptr, n, n, 0.0, ln.tid);
-                lds_fill<NZ, NX>(s_model + SharedModel::OFF_H, a.do_update ? pH + mt * m * n : nullptr, m, n, 0.0, ln.tid);
-                lds_fill<NZ, NZ>(s_model + SharedModel::OFF_R, a.do_update ? pR + mt * m * m : nullptr, m, m, 1.0, ln.tid);
+                lds_fill<NX, NX>(s_model + SharedModel::OFF_F, a.do_predict ? pF + mt * n * n : nullptr, n, n, 1.0, threadIdx.x);
+                lds_fill<NX, NX>(s_model + SharedModel::OFF_Q, a.do_predict ? pQ + mt * n * n : nullptr, n, n, 0.0, threadIdx.x);
+                lds_fill<NZ, NX>(s_model + SharedModel::OFF_H, a.do_update ? pH + mt * m * n : nullptr, m, n, 0.0, threadIdx.x);
+                lds_fill<NZ, NZ>(s_model + SharedModel::OFF_R, a.do_update ? pR + mt * m * m : nullptr, m, m, 1.0, threadIdx.x);
                 __syncthreads();
             } else {
                 if (a.do_predict) {

@@ -55,12 +55,30 @@ rts_kernel(const RtsArgs a, const double *__restrict__ pF, const double *__restr
     using SharedModel = LdsModel<NX, 1>;
     using TrackModel = RegModel<NX, 1>;
     __shared__ double s_model[UNIFORM ? SharedModel::SIZE : 1];
+    // AOS (NumPy order) outputs of the exact instantiations up to dim_x = 8 go through a wave-private LDS
+    // tile and leave as 1 KiB stores (wave_store_aos, fk_device.hpp); tail lanes then duplicate the last
+    // track and the buffer descriptor clips what they would write
+    constexpr bool COOP = (LAYOUT == LAYOUT_AOS) && EXACT && NX <= 8;
+    constexpr int TILE = COOP ? 64 * ((NX * NX) | 1) : 0;
+    __shared__ double s_tile[COOP ? (BLOCK / 64) * TILE : 1];
+    double *tile = s_tile + (threadIdx.x >> 6) * TILE;
+    const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
 
     const long N = a.N, T = a.T;
     const long blk0 = (long)blockIdx.x * BLOCK;
-    const Lane ln{blk0, threadIdx.x, N};
-    const bool live = blk0 + ln.tid < N;
+    const unsigned last_row = (unsigned)(N - blk0 < BLOCK ? N - blk0 : BLOCK) - 1u;
+    const Lane ln{blk0, COOP ? min(threadIdx.x, last_row) : threadIdx.x, N};
+    const bool live = COOP || blk0 + ln.tid < N;
     const Lane lr{blk0, live ? ln.tid : 0u, N};
+    // one record array of the step: x-like (LEN = NX) or covariance-like (LEN = NX * NX)
+    auto put_x = [&](const double (&v)[NX], double *dst, long k) {
+        if constexpr (COOP) wave_store_aos<NX>(v, dst + (k * N + blk0) * NX, wave * 64u, tile, lane, last_row);
+        else store_rec<NX, 1, LAYOUT, EXACT>(v, dst + k * N * (EXACT ? NX : a.n), ln, EXACT ? NX : a.n, 1);
+    };
+    auto put_P = [&](const double (&v)[NX * NX], double *dst, long k) {
+        if constexpr (COOP) wave_store_aos<NX * NX>(v, dst + (k * N + blk0) * NX * NX, wave * 64u, tile, lane, last_row);
+        else store_rec<NX, NX, LAYOUT, EXACT>(v, dst + k * N * (long)(EXACT ? NX : a.n) * (EXACT ? NX : a.n), ln, EXACT ? NX : a.n, EXACT ? NX : a.n);
+    };
     const int n = EXACT ? NX : a.n;
     const long xs_blk = N * n, ps_blk = N * (long)n * n;
 
@@ -73,13 +91,13 @@ rts_kernel(const RtsArgs a, const double *__restrict__ pF, const double *__restr
     if (live) {
         double Pf[NX * NX];
         cov_expand<NX, SYM, PL>(Pn, Pf);
-        store_rec<NX, 1, LAYOUT, EXACT>(xn, a.xs + (T - 1) * xs_blk, ln, n, 1);
-        store_rec<NX, NX, LAYOUT, EXACT>(Pf, a.Ps_out + (T - 1) * ps_blk, ln, n, n);
-        if (a.Pp) store_rec<NX, NX, LAYOUT, EXACT>(Pf, a.Pp + (T - 1) * ps_blk, ln, n, n);
+        put_x(xn, a.xs, T - 1);
+        put_P(Pf, a.Ps_out, T - 1);
+        if (a.Pp) put_P(Pf, a.Pp, T - 1);
         if (a.K) {
             double Z[NX * NX];
             FK_UNROLL for (int i = 0; i < NX * NX; ++i) Z[i] = 0.0;
-            store_rec<NX, NX, LAYOUT, EXACT>(Z, a.K + (T - 1) * ps_blk, ln, n, n);
+            put_P(Z, a.K, T - 1);
         }
     }
 
@@ -93,8 +111,8 @@ rts_kernel(const RtsArgs a, const double *__restrict__ pF, const double *__restr
             const long mt = a.model_t ? k + a.conv_off : 0;
             if (UNIFORM) {
                 if (!first) __syncthreads();
-                lds_fill<NX, NX>(s_model + SharedModel::OFF_F, pF + mt * n * n, n, n, 1.0, ln.tid);
-                lds_fill<NX, NX>(s_model + SharedModel::OFF_Q, pQ + mt * n * n, n, n, 0.0, ln.tid);
+                lds_fill<NX, NX>(s_model + SharedModel::OFF_F, pF + mt * n * n, n, n, 1.0, threadIdx.x);
+                lds_fill<NX, NX>(s_model + SharedModel::OFF_Q, pQ + mt * n * n, n, n, 0.0, threadIdx.x);
                 __syncthreads();
             } else {
                 load_rec<NX, NX, LAYOUT, EXACT>(tm.F, pF + mt * ps_blk, lr, n, n, 1.0);
@@ -111,7 +129,7 @@ rts_kernel(const RtsArgs a, const double *__restrict__ pF, const double *__restr
                 if (live && a.Pp) {
                     double Pf[NX * NX];
                     cov_expand<NX, SYM, PL>(Ppk, Pf);
-                    store_rec<NX, NX, LAYOUT, EXACT>(Pf, a.Pp + k * ps_blk, ln, n, n);
+                    put_P(Pf, a.Pp, k);
                 }
             };
             if (UNIFORM) st |= rts_step_sym<NX>(x, P, xn, Pn, sm, K, pp_sink);
@@ -120,14 +138,14 @@ rts_kernel(const RtsArgs a, const double *__restrict__ pF, const double *__restr
             double Pp[PL];
             if (UNIFORM) st |= rts_step<NX>(x, P, xn, Pn, sm, K, Pp);
             else st |= rts_step<NX>(x, P, xn, Pn, tm, K, Pp);
-            if (live && a.Pp) store_rec<NX, NX, LAYOUT, EXACT>(Pp, a.Pp + k * ps_blk, ln, n, n);
+            if (live && a.Pp) put_P(Pp, a.Pp, k);
         }
         if (live) {
-            store_rec<NX, 1, LAYOUT, EXACT>(x, a.xs + k * xs_blk, ln, n, 1);
-            if (a.K) store_rec<NX, NX, LAYOUT, EXACT>(K, a.K + k * ps_blk, ln, n, n);
+            put_x(x, a.xs, k);
+            if (a.K) put_P(K, a.K, k);
             double Pf[NX * NX];
             cov_expand<NX, SYM, PL>(P, Pf);
-            store_rec<NX, NX, LAYOUT, EXACT>(Pf, a.Ps_out + k * ps_blk, ln, n, n);
+            put_P(Pf, a.Ps_out, k);
         }
         FK_UNROLL for (int i = 0; i < NX; ++i) xn[i] = x[i];
         FK_UNROLL for (int i = 0; i < PL; ++i) Pn[i] = P[i];

@@ -41,10 +41,10 @@ ukf_linear_kernel(const UkfArgs a, const double *__restrict__ pF, const double *
     const int n = a.n, m = a.m;
     const int ks = 2 * n + 1;
 
-    lds_fill<NX, NX>(s_model + SharedModel::OFF_F, pF, n, n, 1.0, ln.tid);
-    lds_fill<NX, NX>(s_model + SharedModel::OFF_Q, pQ, n, n, 1.0, ln.tid);   // padded block of P stays I
-    lds_fill<NZ, NX>(s_model + SharedModel::OFF_H, pH, m, n, 0.0, ln.tid);
-    lds_fill<NZ, NZ>(s_model + SharedModel::OFF_R, pR, m, m, 1.0, ln.tid);
+    lds_fill<NX, NX>(s_model + SharedModel::OFF_F, pF, n, n, 1.0, threadIdx.x);
+    lds_fill<NX, NX>(s_model + SharedModel::OFF_Q, pQ, n, n, 1.0, threadIdx.x);   // padded block of P stays I
+    lds_fill<NZ, NX>(s_model + SharedModel::OFF_H, pH, m, n, 0.0, threadIdx.x);
+    lds_fill<NZ, NZ>(s_model + SharedModel::OFF_R, pR, m, m, 1.0, threadIdx.x);
     // weights, re-indexed from the runtime point set (0, 1..n, n+1..2n) to the padded one
     // (0, 1..NX, NX+1..2NX); padded points get weight 0
     for (unsigned q = ln.tid; q < (unsigned)(2 * KS); q += BLOCK) {
