@@ -311,3 +311,31 @@ def test_rts_more_exact_dims_vs_oracle(n, layout):
     ref = kf_oracle.rts_smoother_tracks(Xs, Ps, F, Q, tracks=sample)
     for k in range(4):
         assert rel_err_rows(_per_track(got[k][:, sample]), _per_track(ref[k])) < 1e-9, k
+
+
+@pytest.mark.parametrize("layout", ["soa", "aos"])
+@pytest.mark.parametrize("n,m", [(2, 1), (3, 1), (4, 2), (5, 3), (6, 3), (7, 4), (8, 4)])
+def test_tail_shapes_kf_and_rts(n, m, layout):
+    """banks smaller than a wave / with a partial first wave in the tail workgroup (the cooperative AOS
+    paths clamp tail lanes and clip their stores; the model fill must not depend on the clamped index)"""
+    from gpu_util import run_kf_batch, run_rts
+    rs = np.random.RandomState(900 + 10 * n + m)
+    F = np.eye(n) + 0.05 * rs.randn(n, n)
+    F /= max(1.0, 1.05 * np.max(np.abs(np.linalg.eigvals(F))))
+    B = rs.randn(n, n)
+    Q = 0.1 * (B @ B.T / n + 0.5 * np.eye(n))
+    H = rs.randn(m, n)
+    R = 0.5 * np.eye(m)
+    T = 4
+    for N in (1, 44, 257, 300):
+        A = rs.randn(N, n, n)
+        x0, P0 = rs.randn(N, n), A @ A.transpose(0, 2, 1) / n + 0.5 * np.eye(n)
+        zs = rs.randn(T, N, m)
+        got = run_kf_batch(x0, P0, zs, F, Q, H, R, layout=layout)
+        ref = kf_oracle.kf_batch_filter_tracks(x0, P0, zs, F, Q, H, R, tracks=range(N))
+        for k in range(4):
+            assert rel_err_rows(_per_track(got[k]), _per_track(ref[k])) < TOL, (N, k)
+        sm = run_rts(ref[0], ref[1], F, Q, layout=layout)
+        rr = kf_oracle.rts_smoother_tracks(ref[0], ref[1], F, Q, tracks=range(N))
+        for k in range(4):
+            assert rel_err_rows(_per_track(sm[k]), _per_track(rr[k])) < 1e-9, (N, "rts", k)
