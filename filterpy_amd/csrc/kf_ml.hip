@@ -1,4 +1,4 @@
-// kf_ml.hip -- batch_filter for dim_x = 9 with THREE LANES PER TRACK (gfx950).
+// kf_ml.hip -- batch_filter and rts_smoother for dim_x = 9 with THREE LANES PER TRACK (gfx950).
 //
 // One lane per track stops scaling at dim_x = 9: P alone is 81 doubles = 162 VGPRs, the step's
 // temporaries push the kernel to one wave per SIMD with AGPR spills, and BASELINE config 3's 1e5
@@ -9,8 +9,7 @@
 // not own arrive by quad-permute DPP moves (v_mov_b32 quad_perm:[s,s,s,s], two per double, no LDS):
 //
 //   predict  T = P F' (rows local) ; P' = a2 (F T) + Q : row k of T is broadcast, lane accumulates
-//            F[i][k] T[k][:] into its rows i       (kalman_filter.py:472-478; F P F' = F (P F') with
-//            P's symmetry, cf. fk_math_sym.hpp)
+//            F[i][k] T[k][:] into its rows i       (kalman_filter.py:472-478, associated as F (P F'))
 //   update   PHT = P H' rows local, broadcast -> S, its L D L' and y replicated in every lane ;
 //            K rows local ; H P by a three-way sum across the quad ; T1 = P - K (H P) ;
 //            D = K R - T1 H' ; P+ = T1 + D K' with K's rows broadcast
@@ -21,8 +20,10 @@
 // Per lane and step: ~1250 FMAs and ~190 exchanged doubles, ~90 live doubles (one lane per track:
 // ~3700 FMAs, > 250 live doubles).  A wave carries 16 tracks, so config 3 becomes 6250 waves.
 // Layouts: SOA (element-major: 16-byte pair stores, see MlView::store_pair) and AOS (NumPy order: output
-// sets staged through a wave-private LDS tile, ml_store_aos); exact dims (9, 3), shared constant model, predict -> update, no control input, no mask,
-// all four outputs or none.  Everything else stays on kf_fast / kf_kernel.
+// sets staged through a wave-private LDS tile, ml_store_aos); exact dims (9, 3), shared constant
+// model, predict -> update, no control input, optional mask (no branch: see MASK below), all four
+// outputs or none.  Everything else stays on kf_fast / kf_kernel.  The smoother (rts_ml_kernel) is at
+// the end of the file.
 #include <stdlib.h>
 
 #include "fk_device.hpp"
