@@ -337,6 +337,29 @@ class KalmanFilter(object):
         self.z = deepcopy(z)
         self.x_post, self.P_post = np.copy(self.x), self.P.copy()
 
+    # -- get_prediction / get_update: the same kernels on a copy of the state ---------
+    def get_prediction(self, u=None, B=None, F=None, Q=None):
+        """kalman_filter.py:1076-1117: predict() without modifying the object; returns (x, P)."""
+        keep = (np.copy(self.x), np.copy(self.P), np.copy(self.x_prior), np.copy(self.P_prior))
+        try:
+            self.predict(u=u, B=B, F=F, Q=Q)
+            return np.copy(self.x), np.copy(self.P)
+        finally:
+            self.x, self.P, self.x_prior, self.P_prior = keep
+
+    def get_update(self, z=None):
+        """kalman_filter.py:1119-1173: update(z) without altering the filter; returns (x, P)."""
+        if z is None:
+            return self.x, self.P
+        names = ("x", "P", "y", "K", "S", "SI", "z", "x_post", "P_post", "_log_likelihood", "_likelihood", "_mahalanobis")
+        keep = {k: deepcopy(getattr(self, k)) for k in names}
+        try:
+            self.update(z)
+            return np.copy(self.x), np.copy(self.P)
+        finally:
+            for k, v in keep.items():
+                setattr(self, k, v)
+
     # -- steady state, correlated noise, sequential (SURVEY §8f N4) ---------------
     def predict_steadystate(self, u=0, B=None):
         """kalman_filter.py:563-593: x = Fx (+ Bu iff B is set); P is left unchanged."""

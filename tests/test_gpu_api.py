@@ -38,9 +38,17 @@ def test_single_steps_and_attributes(n, m):
     g = golden("kf_steps")
     p = f"n{n}m{m}_"
     kf = _kf(n, m, g[p + "x0"], g[p + "P0"], g[p + "F"], g[p + "Q"], g[p + "H"], g[p + "R"])
+    # get_prediction / get_update (kalman_filter.py:1076-1173) return the result and leave the filter alone
+    xg, Pg = kf.get_prediction()
+    assert rel_err_rows(xg[None], g[p + "xp"][None]) < TOL and rel_err_rows(Pg[None], g[p + "Pp"][None]) < TOL
+    assert np.array_equal(kf.x, g[p + "x0"]) and np.array_equal(kf.P, g[p + "P0"])
     kf.predict()
     assert rel_err_rows(kf.x[None], g[p + "xp"][None]) < TOL and rel_err_rows(kf.P[None], g[p + "Pp"][None]) < TOL
     assert np.array_equal(kf.x_prior, kf.x)
+    xu, Pu = kf.get_update(g[p + "z"])
+    assert rel_err_rows(np.atleast_1d(xu)[None], np.atleast_1d(g[p + "x"])[None]) < 1e-9 and rel_err_rows(Pu[None], g[p + "P"][None]) < 1e-9
+    assert np.array_equal(kf.x, kf.x_prior) and np.all(kf.K == 0)
+    assert kf.get_update(None)[0] is kf.x
     kf.update(g[p + "z"])
     for attr, key in (("x", "x"), ("P", "P"), ("y", "y"), ("K", "K"), ("S", "S"), ("SI", "SI")):
         got, ref = np.atleast_2d(getattr(kf, attr)), np.atleast_2d(g[p + key])
