@@ -302,6 +302,7 @@ using namespace FK_CAT(fastv_, FK_NX, FK_NZ, FK_VARIANT);
 int FK_CAT(launch_kf_fast_, FK_NX, FK_NZ, FK_VARIANT)(const KfArgs &a, int layout, bool outs, int mmode, hipStream_t stream)
 {
     if (mmode != 0 && !FK_FAST_ALL_MODES) return 1;
+    if (!outs && FK_VARIANT != 0) return 1;
     if (a.update_first && !(FK_FAST_ALL_MODES && mmode == 0)) return 1;   // update_first: shared model, variant 0, dim_x <= 6
     if (a.nu > 0 && !(FK_FAST_ALL_MODES && mmode == 0 && !a.update_first && a.nu <= 4)) return 1;   // control input: same, dim_u <= 4
     const dim3 grid((unsigned)((a.cnt + BLOCK - 1) / BLOCK)), block(BLOCK);
@@ -311,6 +312,7 @@ int FK_CAT(launch_kf_fast_, FK_NX, FK_NZ, FK_VARIANT)(const KfArgs &a, int layou
 #define FK_GOUF(LAY, MSK, OUT)                                                                                \
     hipLaunchKernelGGL((kf_fast_kernel<FK_NX, FK_NZ, LAY, MSK, OUT, (FK_FAST_SYM != 0), 0, true, false>), grid, block, 0, \
                        stream, a, a.F, a.Q, a.H, a.R, a.z, a.mask)
+#if FK_VARIANT == 0
 #define FK_GO3(LAY, MM)                          \
     do {                                         \
         if (a.mask) {                            \
@@ -321,6 +323,13 @@ int FK_CAT(launch_kf_fast_, FK_NX, FK_NZ, FK_VARIANT)(const KfArgs &a, int layou
             else FK_GO(LAY, false, false, MM);   \
         }                                        \
     } while (0)
+#else       // lean / tuning variants: only the four-outputs kernels (a final-state-only call runs variant 0 or the generic kernel)
+#define FK_GO3(LAY, MM)                          \
+    do {                                         \
+        if (a.mask) FK_GO(LAY, true, true, MM);  \
+        else FK_GO(LAY, false, true, MM);        \
+    } while (0)
+#endif
 #if FK_FAST_ALL_MODES
 #define FK_GO2(LAY)                      \
     do {                                 \

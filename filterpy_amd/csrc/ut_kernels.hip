@@ -14,6 +14,12 @@
 #include "fk_kernel_args.hpp"
 #include "fk_math_sym.hpp"
 
+// FK_UT_PART: the Makefile compiles this file twice (1: sigma points + transform, 2: cross variance +
+// correction) so that the two halves build in parallel; kernels unused by a half are never instantiated.
+#ifndef FK_UT_PART
+#define FK_UT_PART 0
+#endif
+
 namespace fk {
 
 // ------------------------------------------------------------ sigma points --
@@ -231,6 +237,7 @@ using namespace fk;
 
 extern "C" {
 
+#if FK_UT_PART != 2
 int fk_ut_sigma_points_f64(int32_t n, int64_t N, int32_t layout, double scale, const double *x,
                            const double *P, double *sigmas, int32_t *status, void *stream)
 {
@@ -286,6 +293,8 @@ int fk_ut_transform_f64(int32_t n, int32_t k, int64_t N, int32_t layout, const d
     return check_launch("ut_kernel");
 }
 
+#endif   // FK_UT_PART
+#if FK_UT_PART != 1
 int fk_ut_cross_variance_f64(int32_t n, int32_t m, int32_t k, int64_t N, int32_t layout,
                              const double *x, const double *z, const double *sigmas_f,
                              const double *sigmas_h, const double *Wc, double *Pxz, void *stream)
@@ -333,4 +342,5 @@ int fk_ukf_correct_f64(int32_t n, int32_t m, int64_t N, int32_t layout, const do
     return check_launch("ukf_correct_kernel");
 }
 
+#endif   // FK_UT_PART
 }  // extern "C"

@@ -158,7 +158,7 @@ def test_c2_shape_sample_vs_oracle():
             assert rel_err_rows(_per_track(got[k][:, sample]), _per_track(ref[k])) < TOL, (layout, k)
 
 
-@pytest.mark.parametrize("n,m,variants", [(4, 2, (0, 1, 2, 3, 4)), (6, 3, (0, 1)), (9, 3, (0, 1))])
+@pytest.mark.parametrize("n,m,variants", [(4, 2, (0, 1)), (6, 3, (0, 1)), (9, 3, (0,))])
 @pytest.mark.parametrize("layout", ["soa", "aos"])
 def test_fast_kernel_tuning_variants(n, m, variants, layout, monkeypatch):
     """Every compiled tuning variant of the shared-model kernel (occupancy / packed-symmetric /
