@@ -35,7 +35,10 @@ def dev(a, device=None):
     device = device or require_gpu()
     if isinstance(a, torch.Tensor):
         return a.to(device=device, dtype=torch.float64).contiguous()
-    return torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64), device=device)
+    h = np.ascontiguousarray(a, dtype=np.float64)
+    if not h.flags.writeable:          # e.g. a broadcast view: torch refuses to wrap read-only memory silently
+        h = h.copy()
+    return torch.as_tensor(h, device=device)
 
 
 def to_records(a, layout, lead):
