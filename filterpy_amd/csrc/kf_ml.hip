@@ -523,6 +523,35 @@ kf_ml_kernel(const KfArgs a)
     }
 }
 
+// AOS output of one R x NX row block per lane (the wave's 16 x NX*NX slab) staged through the wave's own
+// columns of the smoother's parking buffer: element i of the slab lives at park[i / 64][64 * wave + i % 64].
+// Only used at points of the step where the rows it touches (0 .. 16*NX*NX/64) hold nothing live.
+template <int R, int NX, int PARK_COLS>
+__device__ __forceinline__ void ml_store_rows_aos_park(const double (&M)[R][NX], double *dst, double (*park)[PARK_COLS],
+                                                       unsigned lane, unsigned wave, unsigned Lc, unsigned valid)
+{
+    constexpr int EP = NX * NX, UP = 16 * EP / 2;
+    using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+    const unsigned q = lane >> 2, c0 = 64u * wave;
+    ml_wave_fence();
+    FK_UNROLL for (int r = 0; r < R; ++r)
+        FK_UNROLL for (int c = 0; c < NX; ++c) {
+            const unsigned i = q * EP + Lc * (R * NX) + r * NX + c;
+            park[i >> 6][c0 + (i & 63u)] = M[r][c];
+        }
+    ml_wave_fence();
+    const rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc(dst, 0, (int)(valid * (unsigned)EP * 8u), 0x00020000);
+    FK_UNROLL for (int it = 0; it * 64 < UP; ++it) {
+        const unsigned unit = it * 64u + lane;
+        if (it * 64 + 63 < UP || unit < (unsigned)UP) {
+            const unsigned i = 2u * unit;
+            const u32x4 v = *reinterpret_cast<const u32x4 *>(&park[i >> 6][c0 + (i & 63u)]);
+            __builtin_amdgcn_raw_buffer_store_b128(v, rP, unit * 16u, 0, 0);
+        }
+    }
+    ml_wave_fence();
+}
+
 // row k of a rows-per-lane matrix, delivered to every lane of the quad by its owner
 #define FK_ROW_FROM_OWNER(dst, M, k, LEN)                                                                     \
     FK_UNROLL for (int j_ = 0; j_ < (LEN); ++j_) {                                                            \
@@ -566,6 +595,11 @@ rts_ml_kernel(const RtsArgs a)
     const unsigned pair_rows = odd ? off_rows - 8u + estride : off_rows;
     const unsigned pair_x = odd ? t8 - 8u + estride : t8;
     const double *myF = sF + Lc * (R * NX), *myQ = sQ + Lc * (R * NX);
+    // AOS: covariance-like outputs leave through the parking buffer as 1 KiB stores (first track of this
+    // wave, how many of its 16 tracks exist)
+    const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const long w0 = (long)blockIdx.x * (BLOCK / 4) + (long)wave * 16;
+    const unsigned valid = (unsigned)(N - w0 >= 16 ? 16 : (N - w0 > 0 ? N - w0 : 0));
     const long xs_blk = N * NX, ps_blk = N * (long)NX * NX;
 
     // k = T-1: smoothed == filtered; K = 0; Pp = Ps   (kalman_filter.py:1063-1065)
@@ -633,7 +667,8 @@ rts_ml_kernel(const RtsArgs a)
             const MlView oPp(a.Pp + k * ps_blk, off_rows, estride, pair_rows);
             FK_UNROLL for (int r = 0; r < R; ++r)
                 FK_UNROLL for (int j = 0; j < NX; ++j) Pp[r][j] += myQ[r * NX + j];
-            store_rows<R, NX, MODE>(oPp, Pp);
+            if constexpr (AOS) ml_store_rows_aos_park<R, NX, BLOCK>(Pp, a.Pp + (k * N + w0) * NX * NX, park, lane, wave, Lc, valid);
+            else store_rows<R, NX, MODE>(oPp, Pp);
         }
         FK_STAGE();
         // K = T Pp^-1: every lane factors a gathered packed copy of Pp and solves its own rows
@@ -661,7 +696,8 @@ rts_ml_kernel(const RtsArgs a)
         FK_STAGE();
         {
             const MlView oK(a.K + k * ps_blk, off_rows, estride, pair_rows);
-            store_rows<R, NX, MODE>(oK, Tm);
+            if constexpr (AOS) ml_store_rows_aos_park<R, NX, BLOCK>(Tm, a.K + (k * N + w0) * NX * NX, park, lane, wave, Lc, valid);
+            else store_rows<R, NX, MODE>(oK, Tm);
         }
         // x += K (xn - F x), replicated: K's rows come from their owners.  (x is only fetched now: nine
         // doubles less across the factorisation, which is where this kernel's register peak is.)
@@ -719,7 +755,8 @@ rts_ml_kernel(const RtsArgs a)
         {
             const MlView ox(a.xs + k * xs_blk, t8, estride, pair_x), oP(a.Ps_out + k * ps_blk, off_rows, estride, pair_rows);
             store_x<NX, MODE>(ox, xn);
-            store_rows<R, NX, MODE>(oP, Pn);
+            if constexpr (AOS) ml_store_rows_aos_park<R, NX, BLOCK>(Pn, a.Ps_out + (k * N + w0) * NX * NX, park, lane, wave, Lc, valid);
+            else store_rows<R, NX, MODE>(oP, Pn);
         }
     }
     if (a.status) {
