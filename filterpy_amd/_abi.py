@@ -66,6 +66,7 @@ SIGNATURES = {
     "fk_resample_systematic_f64": (ctypes.c_int, [c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "fk_resample_stratified_f64": (ctypes.c_int, [c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "fk_resample_multinomial_f64": (ctypes.c_int, [c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "fk_resample_gather_mean_f64": (ctypes.c_int, [c_i64, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp]),
     "fk_cumsum_exact_f64": (ctypes.c_int, [c_i64, c_i64, c_vp, c_vp, c_i32, c_vp]),
     "fk_resample_workspace_bytes": (c_sz, [c_i64, c_i64]),
     "fk_multinomial_workspace_bytes": (c_sz, [c_i64, c_i64]),

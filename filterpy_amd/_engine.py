@@ -222,6 +222,12 @@ def resample_multinomial(Fn, Np, Nu, w, u, idx):
     _abi.check(rc, "fk_resample_multinomial_f64")
 
 
+def resample_gather_mean(Fn, Np, d, particles, idx, mean):
+    """fk_resample_gather_mean_f64: mean[f] = particles[f][idx[f]].mean(axis=0) without the resampled copy."""
+    rc = _abi.lib().fk_resample_gather_mean_f64(Fn, Np, d, _ptr(particles), _ptr(idx), _ptr(mean), _stream())
+    _abi.check(rc, "fk_resample_gather_mean_f64")
+
+
 def cumsum_exact(Fn, Np, w, cs, force_last_one=False):
     rc = _abi.lib().fk_cumsum_exact_f64(Fn, Np, _ptr(w), _ptr(cs), int(bool(force_last_one)), _stream())
     _abi.check(rc, "fk_cumsum_exact_f64")

@@ -652,6 +652,44 @@ resample_chunk_kernel(long Np, long nch, const double *__restrict__ w, const dou
     }
 }
 
+
+// Posterior mean of the resampled set: mean[f][k] = (1/Np) sum_i particles[f][idx[f][i]][k].  Not a filterpy
+// function -- it is the "resample from index" + mean every caller of the resamplers writes
+// (particles[:] = particles[indexes]; docs/monte_carlo/resampling.rst), fused so that the resampled copy is
+// never materialised; BASELINE configs[4] all-gathers these means.  Partial sums meet in fp64 atomic adds:
+// the result is the mean up to summation-order rounding (not bit-reproducible run to run).
+constexpr int GM_CHUNK = 16384;
+template <int D>
+__global__ void __launch_bounds__(RS_THREADS)
+gather_mean_kernel(long Np, const double *__restrict__ particles, const int32_t *__restrict__ idx, double *__restrict__ mean,
+                   int d)
+{
+    __shared__ double red[RS_THREADS / 64][D];
+    const long f = blockIdx.y;
+    const long i0 = (long)blockIdx.x * GM_CHUNK;
+    const long i1 = (i0 + GM_CHUNK < Np) ? i0 + GM_CHUNK : Np;
+    const double *pf = particles + f * Np * d;
+    const int32_t *xf = idx + f * Np;
+    double acc[D];
+    FK_UNROLL for (int k = 0; k < D; ++k) acc[k] = 0.0;
+    for (long i = i0 + threadIdx.x; i < i1; i += RS_THREADS) {
+        const double *src = pf + (long)xf[i] * d;
+        FK_UNROLL for (int k = 0; k < D; ++k)
+            if (k < d) acc[k] += src[k];
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    FK_UNROLL for (int k = 0; k < D; ++k) {
+        FK_UNROLL for (int s = 32; s > 0; s >>= 1) acc[k] += __shfl_down(acc[k], s, 64);
+        if (lane == 0) red[wave][k] = acc[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < (unsigned)d) {
+        double t = 0.0;
+        for (int w = 0; w < RS_THREADS / 64; ++w) t += red[w][threadIdx.x];
+        atomicAdd(&mean[f * d + threadIdx.x], t / (double)Np);
+    }
+}
+
 static int fail(int code, const char *msg)
 {
     set_last_error(msg);
@@ -744,6 +782,22 @@ int fk_resample_multinomial_f64(int64_t Fn, int64_t Np, int64_t Nu, const double
     const dim3 grid((unsigned)((Nu + RS_THREADS - 1) / RS_THREADS), (unsigned)Fn), block(RS_THREADS);
     hipLaunchKernelGGL(searchsorted_left_kernel, grid, block, 0, (hipStream_t)stream, (long)Np, (long)Nu, cs, u, idx);
     return check_launch("searchsorted_left_kernel");
+}
+
+int fk_resample_gather_mean_f64(int64_t Fn, int64_t Np, int32_t d, const double *particles, const int32_t *idx,
+                                double *mean, void *stream)
+{
+    if (Fn < 0 || Np < 0 || d < 1 || d > 8) return fail(FK_ERR_BAD_ARG, "gather_mean: Fn, Np >= 0 and 1 <= d <= 8");
+    if (Fn == 0) return FK_OK;
+    if (!mean || (Np > 0 && (!particles || !idx))) return fail(FK_ERR_BAD_ARG, "gather_mean: NULL argument");
+    if (Fn > 65535) return fail(FK_ERR_UNSUPPORTED, "gather_mean: at most 65535 filters per call");
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(mean, 0, (size_t)Fn * d * sizeof(double), s) != hipSuccess) return fail(FK_ERR_LAUNCH, "gather_mean: memset failed");
+    if (Np == 0) return FK_OK;
+    const dim3 grid((unsigned)((Np + GM_CHUNK - 1) / GM_CHUNK), (unsigned)Fn), block(RS_THREADS);
+    if (d <= 4) hipLaunchKernelGGL((gather_mean_kernel<4>), grid, block, 0, s, (long)Np, particles, idx, mean, (int)d);
+    else hipLaunchKernelGGL((gather_mean_kernel<8>), grid, block, 0, s, (long)Np, particles, idx, mean, (int)d);
+    return check_launch("gather_mean_kernel");
 }
 
 }  // extern "C"

@@ -344,6 +344,16 @@ int fk_resample_multinomial_f64(int64_t Fn, int64_t Np, int64_t Nu, const double
 size_t fk_resample_workspace_bytes(int64_t Fn, int64_t Np);     /* systematic / stratified */
 size_t fk_multinomial_workspace_bytes(int64_t Fn, int64_t Np);  /* multinomial: Fn*Np doubles */
 
+/* Posterior mean of a resampled particle set, mean[f][k] = (1/Np) sum_i particles[f][idx[f][i]][k], without
+ * materialising the resampled copy.  NOT a filterpy function: it is the "resample from index" step every
+ * caller of the resamplers writes (particles[:] = particles[indexes], docs/monte_carlo/resampling.rst) fused
+ * with the mean that BASELINE configs[4] all-gathers across GPUs.
+ *   particles [Fn][Np][d] (d = 1..8), idx [Fn][Np] (output of fk_resample_*), mean [Fn][d] out.
+ * Partial sums meet in fp64 atomic adds: the mean is exact up to summation-order rounding. */
+int fk_resample_gather_mean_f64(int64_t Fn, int64_t Np, int32_t d,
+                                const double *particles, const int32_t *idx,
+                                double *mean, void *stream);
+
 /* numpy.cumsum(w_f) for Fn float64 vectors of length Np, bit-for-bit (NumPy adds strictly left to
  * right; a re-associated parallel scan differs in the last bits -- here an associative scan over
  * integer rounding maps reproduces the sequential result exactly, see csrc/fk_exact_scan.hpp).

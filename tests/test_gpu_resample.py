@@ -191,3 +191,25 @@ def test_chunk_parallel_path_equals_serial_path(monkeypatch):
         ref, over = ro.stratified_c(ws[f], us[f])
         if over == 0:
             assert np.array_equal(out["parallel"][1][f], ref), f
+
+
+def test_gather_mean_vs_numpy():
+    """fk_resample_gather_mean_f64 (the fused "resample from index" + mean of BASELINE configs[4]):
+    against numpy on the indices the resampler produced, ragged sizes, d = 1..8."""
+    import torch
+    from filterpy_amd import _engine as E
+    rs = np.random.RandomState(12)
+    for Fn, Np, d in ((1, 1, 1), (3, 1000, 4), (5, 16385, 3), (2, 70001, 8), (4, 8000, 6)):
+        w = rs.rand(Fn, Np)
+        w /= w.sum(axis=1, keepdims=True)
+        u = rs.rand(Fn)
+        parts = rs.randn(Fn, Np, d)
+        dw, du, dp = E.dev(w), E.dev(u), E.dev(parts)
+        idx = torch.empty((Fn, Np), dtype=torch.int32, device=dw.device)
+        st = torch.zeros(Fn, dtype=torch.int32, device=dw.device)
+        E.resample_systematic(Fn, Np, dw, du, idx, st)
+        mean = torch.full((Fn, d), float("nan"), dtype=torch.float64, device=dw.device)
+        E.resample_gather_mean(Fn, Np, d, dp, idx, mean)
+        ih = idx.cpu().numpy()
+        ref = np.stack([parts[f][ih[f]].mean(axis=0) for f in range(Fn)])
+        assert np.allclose(mean.cpu().numpy(), ref, rtol=1e-11, atol=1e-13), (Fn, Np, d)

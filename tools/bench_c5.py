@@ -8,8 +8,8 @@ of one node, RCCL all-gather of the posterior means over xGMI.
 
 Filters are independent: rank r resamples filters [lo_r, hi_r) with no data-path collective; the
 only exchange is one all-gather of the (filters, dim) posterior means per step (the caller-side
-"resample from index" of docs/monte_carlo/resampling.rst is a gather + mean, done here with torch as
-harness code and reported apart from the resampling kernel).  Prints one JSON line (rank 0).
+"resample from index" of docs/monte_carlo/resampling.rst is a gather + mean: fk_resample_gather_mean_f64,
+reported apart from the resampling kernel).  Prints one JSON line (rank 0).
 """
 import argparse
 import json
@@ -66,12 +66,8 @@ def main():
         E.resample_systematic(Fn, Np, w, u, idx, st)
         if e:
             e[1].record()
-        # posterior mean of the resampled set (harness, not a filterpy function)
-        if Fn * Np * d <= 64_000_000:
-            torch.mean(torch.gather(particles, 1, idx.long().unsqueeze(-1).expand(-1, -1, d)), dim=1, out=means)
-        else:
-            for f in range(Fn):
-                means[f] = particles[f].index_select(0, idx[f].long()).mean(dim=0)
+        # posterior mean of the resampled set: gather + mean fused (fk_resample_gather_mean_f64)
+        E.resample_gather_mean(Fn, Np, d, particles, idx, means)
         if e:
             e[2].record()
         parallel.allgather_summary(means, gathered)
@@ -89,6 +85,8 @@ def main():
     ref = ro.systematic_np(w[0].cpu().numpy(), float(u[0]))
     exact = bool(np.array_equal(idx[0].cpu().numpy(), ref))
     assert exact, "resample indices differ from the oracle"
+    m_ref = particles[0].index_select(0, idx[0].long()).mean(dim=0)
+    assert torch.allclose(means[0], m_ref, rtol=1e-11, atol=1e-13), "posterior mean differs from the gathered mean"
     if rank == 0:
         rs_ms = float(np.median([e[0].elapsed_time(e[1]) for e in ev]))
         gm_ms = float(np.median([e[1].elapsed_time(e[2]) for e in ev]))
@@ -98,7 +96,7 @@ def main():
             "n_gpus": world, "steps": a.steps, "ms_per_step": 1e3 * elapsed / a.steps,
             "config": {"workload": f"BASELINE configs[4]: {per * world} filters x {Np} particles, {per} filters per GPU, "
                                    f"all-gather of ({per * world}, {d}) posterior means per step"},
-            "resample_kernel_ms": rs_ms, "gather_mean_harness_ms": gm_ms,
+            "resample_kernel_ms": rs_ms, "gather_mean_kernel_ms": gm_ms,
             "resample_GBs_algorithmic": 12.0 * per * Np / (rs_ms * 1e-3) / 1e9, "bit_exact_vs_oracle": exact}), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()
