@@ -264,6 +264,32 @@ __device__ long count_below(double c, long lo, long Np, double dNp, double u_sys
     return k;
 }
 
+// idx = #{ j < len : cs[j] <= p }  (upper bound) in the LDS tile.  The positions are evenly spaced and the
+// tile's cumulative sums rise from c_lo (carry into the tile) to c_hi, so an interpolated guess usually
+// lands within a few elements: two probes bracket a 16-element window, the binary search then needs four
+// steps instead of eleven dependent LDS reads.  Any bracketing is valid -- the result is the same index.
+__device__ __forceinline__ int tile_upper_bound(const double *cs, int len, double p, double c_lo, double inv_span)
+{
+    int lo = 0, hi = len;
+    const double gf = (p - c_lo) * inv_span;            // may be NaN / huge for degenerate tiles: clamped below
+    int g = gf > 0.0 ? (gf < (double)len ? (int)gf : len - 1) : 0;
+    const int a = g > 8 ? g - 8 : 0, b = g + 8 < len ? g + 8 : len;
+    if (a > 0) {
+        if (cs[a - 1] <= p) lo = a;
+        else hi = a - 1;
+    }
+    if (b < len && hi == len) {      // (not after the first probe already cut the range below a)
+        if (cs[b] <= p) lo = b + 1;
+        else hi = b;
+    }
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (cs[mid] <= p) lo = mid + 1;
+        else hi = mid;
+    }
+    return lo;
+}
+
 // systematic / stratified: one workgroup per filter
 template <bool STRATIFIED>
 __global__ void __launch_bounds__(RS_THREADS)
@@ -287,19 +313,15 @@ resample_kernel(long Np, const double *__restrict__ w, const double *__restrict_
         const int len = (int)((Np - base) < RS_TILE ? (Np - base) : RS_TILE);
         for (int j = tid; j < RS_TILE; j += RS_THREADS) sh.w[j] = j < len ? wf[base + j] : 0.0;
         __syncthreads();
+        const double c_in = carry;
         carry = tile_cumsum_exact(sh, len, carry, started, prelude);
         // slots covered by this tile: pos_i < cs_last  (cs is non-decreasing for weights >= 0)
         const long out_hi = count_below<STRATIFIED>(carry, out_lo, Np, dNp, u_sys, u_str);
+        const double inv_span = (double)len / (carry - c_in);
         for (long i = out_lo + tid; i < out_hi; i += RS_THREADS) {
             const double p = position<STRATIFIED>(i, dNp, u_sys, u_str);
             // idx = #{ j : cs_j <= p }  (upper bound; the two-pointer merge of resampling.py:143-149)
-            int lo = 0, hi = len;
-            while (lo < hi) {
-                const int mid = (lo + hi) >> 1;
-                if (sh.w[mid] <= p) lo = mid + 1;
-                else hi = mid;
-            }
-            of[i] = (int32_t)(base + lo);
+            of[i] = (int32_t)(base + tile_upper_bound(sh.w, len, p, c_in, inv_span));
         }
         out_lo = out_hi;
         __syncthreads();
@@ -634,17 +656,13 @@ resample_chunk_kernel(long Np, long nch, const double *__restrict__ w, const dou
     int prelude = p.prelude;
     // slots below the previous chunk's last cumulative sum belong to earlier chunks
     const long out_lo = (k == 0) ? 0 : count_below<STRATIFIED>(carry, 0, Np, dNp, u_sys, u_str);
+    const double c_in = carry;
     carry = tile_cumsum_exact(sh, len, carry, started, prelude);
     const long out_hi = count_below<STRATIFIED>(carry, out_lo, Np, dNp, u_sys, u_str);
+    const double inv_span = (double)len / (carry - c_in);
     for (long i = out_lo + tid; i < out_hi; i += RS_THREADS) {
         const double ps = position<STRATIFIED>(i, dNp, u_sys, u_str);
-        int lo = 0, hi = len;
-        while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            if (sh.w[mid] <= ps) lo = mid + 1;
-            else hi = mid;
-        }
-        of[i] = (int32_t)(base + lo);
+        of[i] = (int32_t)(base + tile_upper_bound(sh.w, len, ps, c_in, inv_span));
     }
     if (k == nch - 1) {
         for (long i = out_hi + tid; i < Np; i += RS_THREADS) of[i] = (int32_t)(Np - 1);
