@@ -124,6 +124,43 @@ FK_HD double fast_inc(double w, int eu, bool &tie)
     return q + (r > 0.5 ? 1.0 : 0.0);
 }
 
+// idx = #{ j < len : cs[j] <= p }  (upper bound of p in the tile's cumulative sums; the two-pointer merge
+// of resampling.py:103-112 / 143-149 visits exactly this index).  The output positions are evenly spaced
+// and the sums rise from c_lo (carry into the tile) to c_lo + len / inv_span, so an interpolated guess
+// usually lands within a few elements: two probes confirm a 16-element window, five select-only
+// power-of-two steps (8, 4, 2, 1, 1) count the elements <= p inside it.  A window the probes reject (skewed
+// weights) falls back to the binary search of the side they left.  Every route returns the same index
+// for non-decreasing cs; inv_span may be NaN / Inf for a degenerate tile (the guess is clamped).
+//   The tile is GUARDED so that no read needs a bounds test: cs[-1] = -inf and cs[len .. len+TILE_GUARD) = +inf.
+constexpr int TILE_GUARD = 16;
+FK_HD int tile_upper_bound(const double *cs, int len, double p, double c_lo, double inv_span)
+{
+    const double gf = (p - c_lo) * inv_span;
+    const int g = gf > 0.0 ? (gf < (double)len ? (int)gf : len - 1) : 0;
+    const int a = g > 8 ? g - 8 : 0;
+    const double *w = cs + a;
+    const bool ok_lo = w[-1] <= p, ok_hi = !(w[16] <= p);
+    if (!(ok_lo & ok_hi)) {
+        int lo = 0, hi = len;
+        if (!ok_lo) hi = a - 1;                          // cs[a-1] > p  (a >= 1: the low guard never rejects)
+        else lo = a + 17 < len ? a + 17 : len;           // cs[a+16] <= p
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (cs[mid] <= p) lo = mid + 1;
+            else hi = mid;
+        }
+        return lo;
+    }
+    // count of elements <= p in [a, a+16): everything from a+16 on is > p, so no step can overshoot
+    int r = 0;
+    r += (w[r + 7] <= p) ? 8 : 0;
+    r += (w[r + 3] <= p) ? 4 : 0;
+    r += (w[r + 1] <= p) ? 2 : 0;
+    r += (w[r] <= p) ? 1 : 0;
+    r += (w[r] <= p) ? 1 : 0;
+    return a + r;
+}
+
 // C after applying composite F to start value C0
 FK_HD long long mono_apply(long long C0, const Mono &F) { return C0 + ((C0 & 1) ? F.ao : F.ae); }
 

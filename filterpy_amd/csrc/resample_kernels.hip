@@ -31,13 +31,26 @@ constexpr int RS_TILE = RS_THREADS * RS_ITEMS;   // 2048 weights per tile
 constexpr int RS_PRELUDE = 128;                  // first non-zero-sum elements of a vector: sequential adds
 
 struct ScanShared {
-    double w[RS_TILE];          // weights of the tile, then (in place) their cumulative sums
+    // weights of the tile, then (in place) their cumulative sums, between the guards tile_upper_bound reads
+    // without a bounds test: w()[-1] = -inf, w()[len ..] = +inf (load_tile)
+    double tile[2 + RS_TILE + TILE_GUARD];
+    __device__ __forceinline__ double *w() { return tile + 2; }
     Mono wave_tot[RS_THREADS / 64];
     double wave_sum[RS_THREADS / 64];
     double carry;               // exact running sum entering the next segment
     int first_cross;            // first tile index whose add leaves the binade (RS_TILE = none)
     int first_nonzero;
 };
+
+// weights of one tile -> LDS.  Slots past `len` and the guards hold +inf / -inf: the scan never reads them
+// (every read there is bounded by len), the output search relies on them.
+__device__ __forceinline__ void load_tile(ScanShared &sh, const double *__restrict__ src, int len)
+{
+    const int tid = threadIdx.x;
+    for (int j = tid; j < RS_TILE; j += RS_THREADS) sh.w()[j] = j < len ? src[j] : __builtin_inf();
+    if (tid < TILE_GUARD) sh.w()[RS_TILE + tid] = __builtin_inf();
+    if (tid == 0) sh.w()[-1] = -__builtin_inf();
+}
 
 __device__ __forceinline__ Mono shfl_up_mono(const Mono &m, int delta)
 {
@@ -69,7 +82,7 @@ __device__ __forceinline__ Mono block_mono_excl(const Mono (&loc)[ITEMS], Mono *
     return mono_compose(wprefix, excl);
 }
 
-// In-place exact inclusive prefix sum of sh.w[0..len) continuing from the running sum `carry`
+// In-place exact inclusive prefix sum of sh.w()[0..len) continuing from the running sum `carry`
 // (`started` = false means no element has been summed yet: cs[0] = w[0], like numpy.cumsum).
 // All RS_THREADS threads participate.  Returns the running sum after the tile.
 __device__ double tile_cumsum_exact(ScanShared &sh, int len, double carry, bool &started, int &prelude)
@@ -86,7 +99,7 @@ __device__ double tile_cumsum_exact(ScanShared &sh, int len, double carry, bool 
                 __syncthreads();
                 int mine = len;
                 for (int j = pos + tid; j < len; j += RS_THREADS)
-                    if (sh.w[j] != 0.0) { mine = j; break; }
+                    if (sh.w()[j] != 0.0) { mine = j; break; }
                 if (mine < len) atomicMin(&sh.first_nonzero, mine);
                 __syncthreads();
                 const int j0 = sh.first_nonzero;
@@ -94,9 +107,9 @@ __device__ double tile_cumsum_exact(ScanShared &sh, int len, double carry, bool 
                 // elements pos..j0-1 are zero weights: their cumulative sum is +0.0 (0+0, or w itself)
                 if (j0 < len) {
                     // 0 + w = w exactly (also for negative / NaN w)
-                    carry = started ? carry + sh.w[j0] : sh.w[j0];
+                    carry = started ? carry + sh.w()[j0] : sh.w()[j0];
                     started = true;
-                    pos = j0 + 1;      // sh.w[j0] already holds its own cumulative sum
+                    pos = j0 + 1;      // sh.w()[j0] already holds its own cumulative sum
                 } else {
                     started = started || len > pos;
                     if (started && !(carry == 0.0)) carry = 0.0;
@@ -105,9 +118,9 @@ __device__ double tile_cumsum_exact(ScanShared &sh, int len, double carry, bool 
                 continue;
             }
             // negative, NaN or infinite running sum: plain sequential adds
-            carry = carry + sh.w[pos];
+            carry = carry + sh.w()[pos];
             __syncthreads();
-            if (tid == 0) sh.w[pos] = carry;
+            if (tid == 0) sh.w()[pos] = carry;
             __syncthreads();
             ++pos;
             continue;
@@ -124,13 +137,13 @@ __device__ double tile_cumsum_exact(ScanShared &sh, int len, double carry, bool 
                 // adds are a dependent chain; padding with +0.0 leaves the sum unchanged
                 for (int j = pos; j < stop; j += 16) {
                     double v[16];
-                    FK_UNROLL for (int k = 0; k < 16; ++k) v[k] = (j + k < stop) ? sh.w[j + k] : 0.0;
+                    FK_UNROLL for (int k = 0; k < 16; ++k) v[k] = (j + k < stop) ? sh.w()[j + k] : 0.0;
                     FK_UNROLL for (int k = 0; k < 16; ++k) {
                         c = c + v[k];
                         v[k] = c;
                     }
                     FK_UNROLL for (int k = 0; k < 16; ++k)
-                        if (j + k < stop) sh.w[j + k] = v[k];
+                        if (j + k < stop) sh.w()[j + k] = v[k];
                 }
                 sh.carry = c;
             }
@@ -154,7 +167,7 @@ __device__ double tile_cumsum_exact(ScanShared &sh, int len, double carry, bool 
             FK_UNROLL for (int k = 0; k < RS_ITEMS; ++k) {
                 const int j = tid * RS_ITEMS + k;
                 bool tk = false;
-                const double e = (j >= pos && j < len) ? fast_inc(sh.w[j], eu, tk) : 0.0;
+                const double e = (j >= pos && j < len) ? fast_inc(sh.w()[j], eu, tk) : 0.0;
                 tie = tie || tk;
                 runs += e;
                 incl[k] = runs;
@@ -185,14 +198,14 @@ __device__ double tile_cumsum_exact(ScanShared &sh, int len, double carry, bool 
                 const int cross = sh.first_cross < len ? sh.first_cross : len;   // first element NOT covered
                 FK_UNROLL for (int k = 0; k < RS_ITEMS; ++k) {
                     const int j = tid * RS_ITEMS + k;
-                    if (j >= pos && j < cross) sh.w[j] = Cd[k] * u;               // exact
+                    if (j >= pos && j < cross) sh.w()[j] = Cd[k] * u;               // exact
                 }
                 __syncthreads();
-                if (cross > pos) carry = sh.w[cross - 1];
+                if (cross > pos) carry = sh.w()[cross - 1];
                 if (cross < len) {
-                    carry = carry + sh.w[cross];      // the add that leaves the binade: a real IEEE add
+                    carry = carry + sh.w()[cross];      // the add that leaves the binade: a real IEEE add
                     __syncthreads();
-                    if (tid == 0) sh.w[cross] = carry;
+                    if (tid == 0) sh.w()[cross] = carry;
                     __syncthreads();
                     pos = cross + 1;
                 } else {
@@ -207,7 +220,7 @@ __device__ double tile_cumsum_exact(ScanShared &sh, int len, double carry, bool 
         Mono run = mono_identity();
         FK_UNROLL for (int k = 0; k < RS_ITEMS; ++k) {
             const int j = tid * RS_ITEMS + k;
-            const Mono e = (j >= pos && j < len) ? mono_elem(sh.w[j], u, eu) : mono_identity();
+            const Mono e = (j >= pos && j < len) ? mono_elem(sh.w()[j], u, eu) : mono_identity();
             run = mono_compose(run, e);
             loc[k] = run;
         }
@@ -226,15 +239,15 @@ __device__ double tile_cumsum_exact(ScanShared &sh, int len, double carry, bool 
         const int cross = sh.first_cross < len ? sh.first_cross : len;   // first element NOT covered
         FK_UNROLL for (int k = 0; k < RS_ITEMS; ++k) {
             const int j = tid * RS_ITEMS + k;
-            if (j >= pos && j < cross) sh.w[j] = (double)Cj[k] * u;       // exact
+            if (j >= pos && j < cross) sh.w()[j] = (double)Cj[k] * u;       // exact
         }
         __syncthreads();
-        if (cross > pos) carry = sh.w[cross - 1];
+        if (cross > pos) carry = sh.w()[cross - 1];
         if (cross < len) {
             // the add that leaves the binade: a real IEEE add
-            carry = carry + sh.w[cross];
+            carry = carry + sh.w()[cross];
             __syncthreads();
-            if (tid == 0) sh.w[cross] = carry;
+            if (tid == 0) sh.w()[cross] = carry;
             __syncthreads();
             pos = cross + 1;
         } else {
@@ -245,49 +258,26 @@ __device__ double tile_cumsum_exact(ScanShared &sh, int len, double carry, bool 
     return carry;
 }
 
+// Np < 2^31 (checked by the entry point: the indices are int32), so slot numbers are ints and
+// (double)i is one conversion instead of the four of an int64
 template <bool STRATIFIED>
-__device__ __forceinline__ double position(long i, double dNp, double u_sys, const double *__restrict__ u_str)
+__device__ __forceinline__ double position(int i, double dNp, double u_sys, const double *__restrict__ u_str)
 {
     const double ui = STRATIFIED ? u_str[i] : u_sys;
     return (ui + (double)i) / dNp;      // fl(fl(u + i) / Np): resampling.py:103,139
 }
 
 // number of output slots whose position is < c  (= first i with pos_i >= c), searched upward
-// from `lo` around the estimate c*Np - u
+// from `lo` around the estimate c*Np - u.  The estimate is off by a slot or two at most: the loops
+// stay rolled (an unrolled-by-four body runs four divisions where one is needed).
 template <bool STRATIFIED>
-__device__ long count_below(double c, long lo, long Np, double dNp, double u_sys, const double *__restrict__ u_str)
+__device__ int count_below(double c, int lo, int Np, double dNp, double u_sys, const double *__restrict__ u_str)
 {
-    double est = c * dNp - (STRATIFIED ? 0.5 : u_sys);
-    long k = est <= (double)lo ? lo : (est >= (double)Np ? Np : (long)est);
-    while (k > lo && !(position<STRATIFIED>(k - 1, dNp, u_sys, u_str) < c)) --k;
-    while (k < Np && position<STRATIFIED>(k, dNp, u_sys, u_str) < c) ++k;
+    const double est = c * dNp - (STRATIFIED ? 0.5 : u_sys);
+    int k = est <= (double)lo ? lo : (est >= (double)Np ? Np : (int)est);
+    _Pragma("nounroll") while (k > lo && !(position<STRATIFIED>(k - 1, dNp, u_sys, u_str) < c)) --k;
+    _Pragma("nounroll") while (k < Np && position<STRATIFIED>(k, dNp, u_sys, u_str) < c) ++k;
     return k;
-}
-
-// idx = #{ j < len : cs[j] <= p }  (upper bound) in the LDS tile.  The positions are evenly spaced and the
-// tile's cumulative sums rise from c_lo (carry into the tile) to c_hi, so an interpolated guess usually
-// lands within a few elements: two probes bracket a 16-element window, the binary search then needs four
-// steps instead of eleven dependent LDS reads.  Any bracketing is valid -- the result is the same index.
-__device__ __forceinline__ int tile_upper_bound(const double *cs, int len, double p, double c_lo, double inv_span)
-{
-    int lo = 0, hi = len;
-    const double gf = (p - c_lo) * inv_span;            // may be NaN / huge for degenerate tiles: clamped below
-    int g = gf > 0.0 ? (gf < (double)len ? (int)gf : len - 1) : 0;
-    const int a = g > 8 ? g - 8 : 0, b = g + 8 < len ? g + 8 : len;
-    if (a > 0) {
-        if (cs[a - 1] <= p) lo = a;
-        else hi = a - 1;
-    }
-    if (b < len && hi == len) {      // (not after the first probe already cut the range below a)
-        if (cs[b] <= p) lo = b + 1;
-        else hi = b;
-    }
-    while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (cs[mid] <= p) lo = mid + 1;
-        else hi = mid;
-    }
-    return lo;
 }
 
 // systematic / stratified: one workgroup per filter
@@ -308,27 +298,27 @@ resample_kernel(long Np, const double *__restrict__ w, const double *__restrict_
     double carry = 0.0;
     bool started = false;
     int prelude = RS_PRELUDE;
-    long out_lo = 0;     // output slots [0, out_lo) are done
+    int out_lo = 0;      // output slots [0, out_lo) are done
     for (long base = 0; base < Np; base += RS_TILE) {
         const int len = (int)((Np - base) < RS_TILE ? (Np - base) : RS_TILE);
-        for (int j = tid; j < RS_TILE; j += RS_THREADS) sh.w[j] = j < len ? wf[base + j] : 0.0;
+        load_tile(sh, wf + base, len);
         __syncthreads();
         const double c_in = carry;
         carry = tile_cumsum_exact(sh, len, carry, started, prelude);
         // slots covered by this tile: pos_i < cs_last  (cs is non-decreasing for weights >= 0)
-        const long out_hi = count_below<STRATIFIED>(carry, out_lo, Np, dNp, u_sys, u_str);
+        const int out_hi = count_below<STRATIFIED>(carry, out_lo, (int)Np, dNp, u_sys, u_str);
         const double inv_span = (double)len / (carry - c_in);
-        for (long i = out_lo + tid; i < out_hi; i += RS_THREADS) {
+        for (int i = out_lo + tid; i < out_hi; i += RS_THREADS) {
             const double p = position<STRATIFIED>(i, dNp, u_sys, u_str);
             // idx = #{ j : cs_j <= p }  (upper bound; the two-pointer merge of resampling.py:143-149)
-            of[i] = (int32_t)(base + tile_upper_bound(sh.w, len, p, c_in, inv_span));
+            of[i] = (int32_t)(base + tile_upper_bound(sh.w(), len, p, c_in, inv_span));
         }
         out_lo = out_hi;
         __syncthreads();
     }
     // positions >= cumsum[-1]: the reference raises IndexError (resampling.py:109,145)
-    for (long i = out_lo + tid; i < Np; i += RS_THREADS) of[i] = (int32_t)(Np - 1);
-    if (tid == 0 && status) status[f] = out_lo < Np ? ST_OVERRUN : 0;
+    for (int i = out_lo + tid; i < (int)Np; i += RS_THREADS) of[i] = (int32_t)(Np - 1);
+    if (tid == 0 && status) status[f] = out_lo < (int)Np ? ST_OVERRUN : 0;
 }
 
 // exact cumulative sums to HBM (multinomial needs random access to them)
@@ -345,10 +335,10 @@ cumsum_kernel(long Np, const double *__restrict__ w, double *__restrict__ cs, in
     int prelude = RS_PRELUDE;
     for (long base = 0; base < Np; base += RS_TILE) {
         const int len = (int)((Np - base) < RS_TILE ? (Np - base) : RS_TILE);
-        for (int j = tid; j < RS_TILE; j += RS_THREADS) sh.w[j] = j < len ? wf[base + j] : 0.0;
+        load_tile(sh, wf + base, len);
         __syncthreads();
         carry = tile_cumsum_exact(sh, len, carry, started, prelude);
-        for (int j = tid; j < len; j += RS_THREADS) cf[base + j] = sh.w[j];
+        for (int j = tid; j < len; j += RS_THREADS) cf[base + j] = sh.w()[j];
         __syncthreads();
     }
     // cumulative_sum[-1] = 1.  (resampling.py:74,175)
@@ -618,7 +608,7 @@ chain_kernel(long Np, long nch, const double *__restrict__ w, ChunkPlan *__restr
             const long base = (k0 + q) * RS_TILE;
             const int len = (int)((Np - base) < RS_TILE ? (Np - base) : RS_TILE);
             __syncthreads();
-            for (int j = tid; j < RS_TILE; j += RS_THREADS) sh.w[j] = j < len ? w[f * Np + base + j] : 0.0;
+            load_tile(sh, w + f * Np + base, len);
             __syncthreads();
             carry = tile_cumsum_exact(sh, len, carry, started, prelude);
             ++q;
@@ -649,24 +639,24 @@ resample_chunk_kernel(long Np, long nch, const double *__restrict__ w, const dou
     const int tid = threadIdx.x;
     const long base = k * RS_TILE;
     const int len = (int)((Np - base) < RS_TILE ? (Np - base) : RS_TILE);
-    for (int j = tid; j < RS_TILE; j += RS_THREADS) sh.w[j] = j < len ? wf[base + j] : 0.0;
+    load_tile(sh, wf + base, len);
     __syncthreads();
     double carry = p.cin;
     bool started = p.started != 0;
     int prelude = p.prelude;
     // slots below the previous chunk's last cumulative sum belong to earlier chunks
-    const long out_lo = (k == 0) ? 0 : count_below<STRATIFIED>(carry, 0, Np, dNp, u_sys, u_str);
+    const int out_lo = (k == 0) ? 0 : count_below<STRATIFIED>(carry, 0, (int)Np, dNp, u_sys, u_str);
     const double c_in = carry;
     carry = tile_cumsum_exact(sh, len, carry, started, prelude);
-    const long out_hi = count_below<STRATIFIED>(carry, out_lo, Np, dNp, u_sys, u_str);
+    const int out_hi = count_below<STRATIFIED>(carry, out_lo, (int)Np, dNp, u_sys, u_str);
     const double inv_span = (double)len / (carry - c_in);
-    for (long i = out_lo + tid; i < out_hi; i += RS_THREADS) {
+    for (int i = out_lo + tid; i < out_hi; i += RS_THREADS) {
         const double ps = position<STRATIFIED>(i, dNp, u_sys, u_str);
-        of[i] = (int32_t)(base + tile_upper_bound(sh.w, len, ps, c_in, inv_span));
+        of[i] = (int32_t)(base + tile_upper_bound(sh.w(), len, ps, c_in, inv_span));
     }
     if (k == nch - 1) {
-        for (long i = out_hi + tid; i < Np; i += RS_THREADS) of[i] = (int32_t)(Np - 1);
-        if (tid == 0 && status) status[f] = out_hi < Np ? ST_OVERRUN : 0;
+        for (int i = out_hi + tid; i < (int)Np; i += RS_THREADS) of[i] = (int32_t)(Np - 1);
+        if (tid == 0 && status) status[f] = out_hi < (int)Np ? ST_OVERRUN : 0;
     }
 }
 

@@ -268,6 +268,7 @@ int hc_sigma(int n, double scale, const double *x, const double *P, double *sig)
 // wave prefix), so the monoid's associativity and the segment logic are exercised exactly as
 // on the GPU.
 #include "../../filterpy_amd/csrc/fk_exact_scan.hpp"
+#include <limits>
 #include <vector>
 
 namespace {
@@ -415,6 +416,18 @@ extern "C" long hc_cumsum_exact(long N, const double *w, double *cs)
         for (int j = 0; j < len; ++j) cs[base + j] = tile[j];
     }
     return segs;
+}
+
+// The output loop of resample_kernel / resample_chunk_kernel on one tile: the tile's cumulative sums
+// (cs, from carry-in c_in), the slot positions ps, and fk::tile_upper_bound exactly as the kernels call it.
+extern "C" void hc_tile_search(int len, const double *cs, double c_in, long n_pos, const double *ps, int *out)
+{
+    const double inf = std::numeric_limits<double>::infinity();
+    std::vector<double> g(1 + len + fk::TILE_GUARD, inf);      // guarded like ScanShared::tile
+    g[0] = -inf;
+    std::copy(cs, cs + len, g.begin() + 1);
+    const double inv_span = (double)len / (cs[len - 1] - c_in);
+    for (long i = 0; i < n_pos; ++i) out[i] = fk::tile_upper_bound(g.data() + 1, len, ps[i], c_in, inv_span);
 }
 
 // Host emulation of the chunk-parallel plan/chain (resample_kernels.hip P1-P4): chunk sums in a

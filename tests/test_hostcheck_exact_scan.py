@@ -86,3 +86,46 @@ def test_chunk_parallel_plan_bitwise(name, N):
     assert np.array_equal(cs, ref) and np.array_equal(bits(cs)[nz], bits(ref)[nz]), (name, N)
     if name in ("uniform", "normalised") and N >= 300000:
         assert nshort.value > 0.8 * nch        # almost every chunk took the O(1) step
+
+
+def _tile_search(cs, c_in, ps):
+    lib = ctypes.CDLL(os.path.join(ROOT, "tests", "hostcheck", "libhostcheck.so"))
+    cs = np.ascontiguousarray(cs, dtype=np.float64)
+    ps = np.ascontiguousarray(ps, dtype=np.float64)
+    out = np.empty(ps.size, dtype=np.int32)
+    lib.hc_tile_search(ctypes.c_int(cs.size), cs.ctypes.data_as(ctypes.c_void_p), ctypes.c_double(c_in),
+                       ctypes.c_long(ps.size), ps.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p))
+    return out
+
+
+TILE_CASES = {
+    "uniform": lambda r, n: r.random(n),
+    "skewed": lambda r, n: r.random(n) ** 12,                       # the interpolated window misses often
+    "one_heavy": lambda r, n: np.where(np.arange(n) == n // 3, 1e3, r.random(n)),
+    "zeros": lambda r, n: np.where(r.random(n) < 0.7, 0.0, r.random(n)),   # runs of equal sums
+    "all_zero": lambda r, n: np.zeros(n),                           # span 0: inv_span = inf / NaN guess
+    "steps": lambda r, n: np.where(np.arange(n) % 17 == 0, 1.0, 0.0),
+    "tiny": lambda r, n: r.random(n) * 1e-300,
+}
+
+
+@pytest.mark.parametrize("name", sorted(TILE_CASES))
+@pytest.mark.parametrize("n", [1, 2, 7, 16, 17, 33, 1000, 2048])
+def test_tile_upper_bound_equals_searchsorted(name, n):
+    """fk::tile_upper_bound (interpolated window + branch-free steps, or the fallback search) must return
+    #{j : cs[j] <= p} for every p -- inside the tile, on the sums themselves, below and above the tile."""
+    r = np.random.default_rng(n * 131 + len(name))
+    c_in = float(r.random() * 3)
+    cs = c_in + np.cumsum(TILE_CASES[name](r, n))
+    lo, hi = c_in, cs[-1]
+    span = hi - lo if hi > lo else 1.0
+    ps = np.concatenate([
+        lo + span * r.random(4000),                       # inside
+        cs, np.nextafter(cs, -np.inf), np.nextafter(cs, np.inf),       # on and next to every sum
+        [lo, np.nextafter(lo, -np.inf), lo - span, hi + span, 0.0],
+        np.linspace(lo, hi, 513),                         # evenly spaced, like systematic positions
+    ])
+    want = np.searchsorted(cs, ps, side="right").astype(np.int32)
+    got = _tile_search(cs, c_in, ps)
+    bad = np.nonzero(want != got)[0]
+    assert bad.size == 0, (name, n, ps[bad[:5]], want[bad[:5]], got[bad[:5]])
