@@ -44,12 +44,35 @@ struct ScanShared {
 
 // weights of one tile -> LDS.  Slots past `len` and the guards hold +inf / -inf: the scan never reads them
 // (every read there is bounded by len), the output search relies on them.
-__device__ __forceinline__ void load_tile(ScanShared &sh, const double *__restrict__ src, int len)
+__device__ __forceinline__ void fetch_tile(double (&v)[RS_ITEMS], const double *__restrict__ src, int len)
 {
     const int tid = threadIdx.x;
-    for (int j = tid; j < RS_TILE; j += RS_THREADS) sh.w()[j] = j < len ? src[j] : __builtin_inf();
+    // all RS_ITEMS loads are issued back to back: a load under a per-element bounds branch is followed by
+    // its own vmcnt(0), i.e. RS_ITEMS serial HBM round trips per tile
+    if (len == RS_TILE) {                                         // uniform
+        FK_UNROLL for (int k = 0; k < RS_ITEMS; ++k) v[k] = src[tid + k * RS_THREADS];
+    } else {
+        FK_UNROLL for (int k = 0; k < RS_ITEMS; ++k) {
+            const int j = tid + k * RS_THREADS;
+            const double t = src[j < len ? j : 0];                // len >= 1: always a valid address
+            v[k] = j < len ? t : __builtin_inf();
+        }
+    }
+}
+
+__device__ __forceinline__ void stage_tile(ScanShared &sh, const double (&v)[RS_ITEMS])
+{
+    const int tid = threadIdx.x;
+    FK_UNROLL for (int k = 0; k < RS_ITEMS; ++k) sh.w()[tid + k * RS_THREADS] = v[k];
     if (tid < TILE_GUARD) sh.w()[RS_TILE + tid] = __builtin_inf();
     if (tid == 0) sh.w()[-1] = -__builtin_inf();
+}
+
+__device__ __forceinline__ void load_tile(ScanShared &sh, const double *__restrict__ src, int len)
+{
+    double v[RS_ITEMS];
+    fetch_tile(v, src, len);
+    stage_tile(sh, v);
 }
 
 __device__ __forceinline__ Mono shfl_up_mono(const Mono &m, int delta)
@@ -299,10 +322,15 @@ resample_kernel(long Np, const double *__restrict__ w, const double *__restrict_
     bool started = false;
     int prelude = RS_PRELUDE;
     int out_lo = 0;      // output slots [0, out_lo) are done
+    // the next tile's weights are fetched while this tile is scanned and searched
+    double v[RS_ITEMS];
+    fetch_tile(v, wf, (int)(Np < RS_TILE ? Np : RS_TILE));
     for (long base = 0; base < Np; base += RS_TILE) {
         const int len = (int)((Np - base) < RS_TILE ? (Np - base) : RS_TILE);
-        load_tile(sh, wf + base, len);
+        stage_tile(sh, v);
         __syncthreads();
+        const long nbase = base + RS_TILE;
+        if (nbase < Np) fetch_tile(v, wf + nbase, (int)((Np - nbase) < RS_TILE ? (Np - nbase) : RS_TILE));
         const double c_in = carry;
         carry = tile_cumsum_exact(sh, len, carry, started, prelude);
         // slots covered by this tile: pos_i < cs_last  (cs is non-decreasing for weights >= 0)
@@ -623,6 +651,23 @@ chain_kernel(long Np, long nch, const double *__restrict__ w, ChunkPlan *__restr
     }
 }
 
+// Build-time instrumentation (tools/rs_phase.py builds a separate library with -DFK_RS_PHASE_CLOCKS; the
+// shipped library has none of it): wave 0 of every workgroup of resample_chunk_kernel adds the s_memtime
+// ticks of each phase to fk_rs_phase[], fk_debug_rs_phases() reads and clears them.
+#ifdef FK_RS_PHASE_CLOCKS
+__device__ unsigned long long fk_rs_phase[8];
+#define RS_CLOCK(slot)                                                              \
+    do {                                                                            \
+        const long long t_now = __builtin_readcyclecounter();                       \
+        if (threadIdx.x == 0) atomicAdd(&fk_rs_phase[slot], (unsigned long long)(t_now - t_prev)); \
+        t_prev = t_now;                                                             \
+    } while (0)
+#define RS_CLOCK_START() long long t_prev = __builtin_readcyclecounter()
+#else
+#define RS_CLOCK(slot) do { } while (0)
+#define RS_CLOCK_START() do { } while (0)
+#endif
+
 template <bool STRATIFIED>
 __global__ void __launch_bounds__(RS_THREADS)
 resample_chunk_kernel(long Np, long nch, const double *__restrict__ w, const double *__restrict__ u,
@@ -639,21 +684,33 @@ resample_chunk_kernel(long Np, long nch, const double *__restrict__ w, const dou
     const int tid = threadIdx.x;
     const long base = k * RS_TILE;
     const int len = (int)((Np - base) < RS_TILE ? (Np - base) : RS_TILE);
-    load_tile(sh, wf + base, len);
-    __syncthreads();
+    RS_CLOCK_START();
+    double v[RS_ITEMS];
+    fetch_tile(v, wf + base, len);
+    RS_CLOCK(5);                    // loads issued
+    // Waiting for the tile is the largest single share of this kernel (tools/rs_phase.py: 44 %), so everything
+    // that does not need it runs first: the plan entry and the first output slot.
     double carry = p.cin;
     bool started = p.started != 0;
     int prelude = p.prelude;
     // slots below the previous chunk's last cumulative sum belong to earlier chunks
     const int out_lo = (k == 0) ? 0 : count_below<STRATIFIED>(carry, 0, (int)Np, dNp, u_sys, u_str);
+    RS_CLOCK(1);
+    stage_tile(sh, v);
+    RS_CLOCK(6);                    // loads landed, LDS written
+    __syncthreads();
+    RS_CLOCK(0);                    // the other waves arrived
     const double c_in = carry;
     carry = tile_cumsum_exact(sh, len, carry, started, prelude);
+    RS_CLOCK(2);
     const int out_hi = count_below<STRATIFIED>(carry, out_lo, (int)Np, dNp, u_sys, u_str);
+    RS_CLOCK(3);
     const double inv_span = (double)len / (carry - c_in);
     for (int i = out_lo + tid; i < out_hi; i += RS_THREADS) {
         const double ps = position<STRATIFIED>(i, dNp, u_sys, u_str);
         of[i] = (int32_t)(base + tile_upper_bound(sh.w(), len, ps, c_in, inv_span));
     }
+    RS_CLOCK(4);
     if (k == nch - 1) {
         for (int i = out_hi + tid; i < (int)Np; i += RS_THREADS) of[i] = (int32_t)(Np - 1);
         if (tid == 0 && status) status[f] = out_hi < (int)Np ? ST_OVERRUN : 0;
@@ -755,6 +812,15 @@ static int resample_common(bool stratified, int64_t Fn, int64_t Np, const double
         hipLaunchKernelGGL((resample_kernel<false>), grid, block, 0, s, (long)Np, w, u, idx, status);
     return check_launch("resample_kernel");
 }
+
+#ifdef FK_RS_PHASE_CLOCKS
+extern "C" int fk_debug_rs_phases(unsigned long long *out)     // only in the instrumented build (tools/rs_phase.py)
+{
+    const unsigned long long zero[8] = {0};
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(fk_rs_phase), sizeof(zero)) != hipSuccess) return FK_ERR_LAUNCH;
+    return hipMemcpyToSymbol(HIP_SYMBOL(fk_rs_phase), zero, sizeof(zero)) == hipSuccess ? FK_OK : FK_ERR_LAUNCH;
+}
+#endif
 
 int fk_resample_systematic_f64(int64_t Fn, int64_t Np, const double *w, const double *u, int32_t *idx,
                                int32_t *status, void *ws, size_t ws_bytes, void *stream)
