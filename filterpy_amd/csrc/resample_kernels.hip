@@ -417,6 +417,7 @@ struct ChunkPlan {          // one per (filter, chunk), in the caller's workspac
     int bad;                // P1: chunk holds a negative / NaN / Inf weight
     int started;            // P4: scan state entering the chunk
     int prelude;            // P4
+    int todo;               // P5: the lean output kernel could not finish this chunk -> the general one does
 };
 constexpr int RS_DIRTY = -100000;
 
@@ -668,40 +669,97 @@ __device__ unsigned long long fk_rs_phase[8];
 #define RS_CLOCK_START() do { } while (0)
 #endif
 
+// P5, lean route: the chunk as ONE tie-free binade segment (the fast path of tile_cumsum_exact with pos = 0 and
+// no crossing -- the same operations in the same order, so the same bits), which is what nearly every chunk
+// of a long vector is.  Half of a workgroup's life in this phase is the wait for its tile
+// (tools/rs_phase.py), so what matters is how many workgroups a CU holds: without the int64 Mono scan, the
+// serial fall-backs and the prelude this kernel needs about half the registers of the general one.  Anything
+// it cannot prove (scan not started, prelude pending, running sum not a positive finite number, a half-ulp
+// tie, a sum that leaves the binade, a negative / non-finite weight) is left untouched and flagged in
+// plan.todo for resample_chunk_kernel.
+struct LeanShared {
+    double tile[2 + RS_TILE + TILE_GUARD];      // guarded like ScanShared::tile
+    double wave_sum[RS_THREADS / 64];
+    __device__ __forceinline__ double *w() { return tile + 2; }
+};
+
 template <bool STRATIFIED>
 __global__ void __launch_bounds__(RS_THREADS)
-resample_chunk_kernel(long Np, long nch, const double *__restrict__ w, const double *__restrict__ u,
-                      const ChunkPlan *__restrict__ plan, int32_t *__restrict__ idx, int32_t *__restrict__ status)
+resample_chunk_lean_kernel(long Np, long nch, const double *__restrict__ w, const double *__restrict__ u,
+                           ChunkPlan *__restrict__ plan, int32_t *__restrict__ idx, int32_t *__restrict__ status)
 {
-    __shared__ ScanShared sh;
+    __shared__ LeanShared sh;
     const long f = blockIdx.y, k = blockIdx.x;
-    const ChunkPlan &p = plan[f * nch + k];
+    ChunkPlan &p = plan[f * nch + k];
     const double *wf = w + f * Np;
     int32_t *of = idx + f * Np;
     const double u_sys = STRATIFIED ? 0.0 : u[f];
     const double *u_str = STRATIFIED ? u + f * Np : nullptr;
     const double dNp = (double)Np;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long base = k * RS_TILE;
     const int len = (int)((Np - base) < RS_TILE ? (Np - base) : RS_TILE);
     RS_CLOCK_START();
+    const double c_in = p.cin;
+    const bool can = p.started != 0 && p.prelude == 0 && c_in > 0.0 && c_in <= 1.79769313486231570815e+308 && k > 0;
+    if (!can) {                                                       // uniform
+        if (tid == 0) p.todo = 1;
+        return;
+    }
     double v[RS_ITEMS];
     fetch_tile(v, wf + base, len);
     RS_CLOCK(5);                    // loads issued
-    // Waiting for the tile is the largest single share of this kernel (tools/rs_phase.py: 44 %), so everything
-    // that does not need it runs first: the plan entry and the first output slot.
-    double carry = p.cin;
-    bool started = p.started != 0;
-    int prelude = p.prelude;
-    // slots below the previous chunk's last cumulative sum belong to earlier chunks
-    const int out_lo = (k == 0) ? 0 : count_below<STRATIFIED>(carry, 0, (int)Np, dNp, u_sys, u_str);
+    // everything that does not need the tile runs while it is in flight: the binade of the running sum and
+    // the first output slot (slots below the previous chunk's last cumulative sum belong to earlier chunks)
+    const double ulp = ulp_of(c_in);
+    const int eu = ulp_exp(c_in);
+    const double C0d = scale2(c_in, -eu);
+    const int out_lo = count_below<STRATIFIED>(c_in, 0, (int)Np, dNp, u_sys, u_str);
     RS_CLOCK(1);
-    stage_tile(sh, v);
+    FK_UNROLL for (int q = 0; q < RS_ITEMS; ++q) sh.w()[tid + q * RS_THREADS] = v[q];
+    if (tid < TILE_GUARD) sh.w()[RS_TILE + tid] = __builtin_inf();
+    if (tid == 0) sh.w()[-1] = -__builtin_inf();
     RS_CLOCK(6);                    // loads landed, LDS written
     __syncthreads();
     RS_CLOCK(0);                    // the other waves arrived
-    const double c_in = carry;
-    carry = tile_cumsum_exact(sh, len, carry, started, prelude);
+    // tie-free exact scan (fk_exact_scan.hpp, fast_inc): thread t owns elements t*RS_ITEMS ..
+    double incl[RS_ITEMS];
+    double runs = 0.0;
+    bool odd = false;               // a tie, or (below) a sum that reaches 2^53
+    FK_UNROLL for (int q = 0; q < RS_ITEMS; ++q) {
+        const int j = tid * RS_ITEMS + q;
+        bool tk = false;
+        const double e = j < len ? fast_inc(sh.w()[j], eu, tk) : 0.0;
+        odd = odd || tk;
+        runs += e;
+        incl[q] = runs;
+    }
+    double inc = runs;
+    FK_UNROLL for (int d = 1; d < 64; d <<= 1) {
+        const double up = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += up;
+    }
+    if (lane == 63) sh.wave_sum[wave] = inc;
+    __syncthreads();
+    double excl = __shfl_up(inc, 1, 64);
+    if (lane == 0) excl = 0.0;
+    FK_UNROLL for (int wv = 0; wv < RS_THREADS / 64; ++wv)
+        if (wv < wave) excl += sh.wave_sum[wv];
+    FK_UNROLL for (int q = 0; q < RS_ITEMS; ++q) {
+        const int j = tid * RS_ITEMS + q;
+        incl[q] = C0d + (excl + incl[q]);
+        odd = odd || (j < len && !(incl[q] < 0x1p53));
+    }
+    if (__syncthreads_or(odd ? 1 : 0)) {                              // uniform
+        if (tid == 0) p.todo = 1;
+        return;
+    }
+    FK_UNROLL for (int q = 0; q < RS_ITEMS; ++q) {
+        const int j = tid * RS_ITEMS + q;
+        if (j < len) sh.w()[j] = incl[q] * ulp;                       // exact
+    }
+    __syncthreads();
+    const double carry = sh.w()[len - 1];
     RS_CLOCK(2);
     const int out_hi = count_below<STRATIFIED>(carry, out_lo, (int)Np, dNp, u_sys, u_str);
     RS_CLOCK(3);
@@ -711,6 +769,47 @@ resample_chunk_kernel(long Np, long nch, const double *__restrict__ w, const dou
         of[i] = (int32_t)(base + tile_upper_bound(sh.w(), len, ps, c_in, inv_span));
     }
     RS_CLOCK(4);
+    if (k == nch - 1) {
+        for (int i = out_hi + tid; i < (int)Np; i += RS_THREADS) of[i] = (int32_t)(Np - 1);
+        if (tid == 0 && status) status[f] = out_hi < (int)Np ? ST_OVERRUN : 0;
+    }
+    if (tid == 0) p.todo = 0;
+}
+
+// P5, general route: the chunks the lean kernel flagged (first chunk of a filter, binade crossings, ties,
+// invalid weights), every case of tile_cumsum_exact
+template <bool STRATIFIED>
+__global__ void __launch_bounds__(RS_THREADS)
+resample_chunk_kernel(long Np, long nch, const double *__restrict__ w, const double *__restrict__ u,
+                      const ChunkPlan *__restrict__ plan, int32_t *__restrict__ idx, int32_t *__restrict__ status)
+{
+    __shared__ ScanShared sh;
+    const long f = blockIdx.y, k = blockIdx.x;
+    const ChunkPlan &p = plan[f * nch + k];
+    if (p.todo == 0) return;                                          // uniform
+    const double *wf = w + f * Np;
+    int32_t *of = idx + f * Np;
+    const double u_sys = STRATIFIED ? 0.0 : u[f];
+    const double *u_str = STRATIFIED ? u + f * Np : nullptr;
+    const double dNp = (double)Np;
+    const int tid = threadIdx.x;
+    const long base = k * RS_TILE;
+    const int len = (int)((Np - base) < RS_TILE ? (Np - base) : RS_TILE);
+    load_tile(sh, wf + base, len);
+    __syncthreads();
+    double carry = p.cin;
+    bool started = p.started != 0;
+    int prelude = p.prelude;
+    // slots below the previous chunk's last cumulative sum belong to earlier chunks
+    const int out_lo = (k == 0) ? 0 : count_below<STRATIFIED>(carry, 0, (int)Np, dNp, u_sys, u_str);
+    const double c_in = carry;
+    carry = tile_cumsum_exact(sh, len, carry, started, prelude);
+    const int out_hi = count_below<STRATIFIED>(carry, out_lo, (int)Np, dNp, u_sys, u_str);
+    const double inv_span = (double)len / (carry - c_in);
+    for (int i = out_lo + tid; i < out_hi; i += RS_THREADS) {
+        const double ps = position<STRATIFIED>(i, dNp, u_sys, u_str);
+        of[i] = (int32_t)(base + tile_upper_bound(sh.w(), len, ps, c_in, inv_span));
+    }
     if (k == nch - 1) {
         for (int i = out_hi + tid; i < (int)Np; i += RS_THREADS) of[i] = (int32_t)(Np - 1);
         if (tid == 0 && status) status[f] = out_hi < (int)Np ? ST_OVERRUN : 0;
@@ -799,10 +898,13 @@ static int resample_common(bool stratified, int64_t Fn, int64_t Np, const double
         hipLaunchKernelGGL(chunk_plan_kernel, dim3((unsigned)Fn), block, 0, s, (long)Np, nch, plan);
         hipLaunchKernelGGL(chunk_compose_kernel, gch, block, 0, s, (long)Np, nch, w, plan);
         hipLaunchKernelGGL(chain_kernel, dim3((unsigned)Fn), block, 0, s, (long)Np, nch, w, plan);
-        if (stratified)
+        if (stratified) {
+            hipLaunchKernelGGL((resample_chunk_lean_kernel<true>), gch, block, 0, s, (long)Np, nch, w, u, plan, idx, status);
             hipLaunchKernelGGL((resample_chunk_kernel<true>), gch, block, 0, s, (long)Np, nch, w, u, plan, idx, status);
-        else
+        } else {
+            hipLaunchKernelGGL((resample_chunk_lean_kernel<false>), gch, block, 0, s, (long)Np, nch, w, u, plan, idx, status);
             hipLaunchKernelGGL((resample_chunk_kernel<false>), gch, block, 0, s, (long)Np, nch, w, u, plan, idx, status);
+        }
         return check_launch("resample_chunk_kernel");
     }
     const dim3 grid((unsigned)Fn), block(RS_THREADS);
