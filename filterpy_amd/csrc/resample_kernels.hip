@@ -18,6 +18,7 @@
 // stratified uniforms).  This translation unit is compiled with -ffp-contract=off: positions
 // and sums must be single IEEE operations.
 #include <stdlib.h>
+#include <string.h>
 
 #include "../../include/filterhip.h"
 #include "fk_device.hpp"
@@ -656,24 +657,37 @@ chain_kernel(long Np, long nch, const double *__restrict__ w, ChunkPlan *__restr
 // shipped library has none of it): wave 0 of every workgroup of resample_chunk_kernel adds the s_memtime
 // ticks of each phase to fk_rs_phase[], fk_debug_rs_phases() reads and clears them.
 #ifdef FK_RS_PHASE_CLOCKS
-__device__ unsigned long long fk_rs_phase[8];
-#define RS_CLOCK(slot)                                                              \
-    do {                                                                            \
-        const long long t_now = __builtin_readcyclecounter();                       \
-        if (threadIdx.x == 0) atomicAdd(&fk_rs_phase[slot], (unsigned long long)(t_now - t_prev)); \
-        t_prev = t_now;                                                             \
+constexpr int RS_PHASE_BUCKETS = 4096;
+__device__ unsigned long long fk_rs_phase[8][RS_PHASE_BUCKETS];
+// ticks are kept in registers and reach memory once, after the last phase (an atomic per phase would sit in
+// the same in-order vmcnt queue as the tile loads and be measured as "waiting for the tile"), spread over
+// RS_PHASE_BUCKETS addresses per slot (half a million workgroups adding to ONE address serialize in L2 and slow
+// the very kernel being measured)
+#define RS_CLOCK_START()                                \
+    long long t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};      \
+    long long t_prev = __builtin_readcyclecounter()
+#define RS_CLOCK(slot)                                              \
+    do {                                                            \
+        const long long t_now = __builtin_readcyclecounter();       \
+        t_acc[slot] += t_now - t_prev;                              \
+        t_prev = t_now;                                             \
     } while (0)
-#define RS_CLOCK_START() long long t_prev = __builtin_readcyclecounter()
+#define RS_CLOCK_FLUSH()                                                                           \
+    do {                                                                                           \
+        if (threadIdx.x == 0)                                                                      \
+            for (int q_ = 0; q_ < 8; ++q_)                                                         \
+                atomicAdd(&fk_rs_phase[q_][(blockIdx.x + 977u * blockIdx.y) % RS_PHASE_BUCKETS], (unsigned long long)t_acc[q_]); \
+    } while (0)
 #else
 #define RS_CLOCK(slot) do { } while (0)
 #define RS_CLOCK_START() do { } while (0)
+#define RS_CLOCK_FLUSH() do { } while (0)
 #endif
 
 // P5, lean route: the chunk as ONE tie-free binade segment (the fast path of tile_cumsum_exact with pos = 0 and
 // no crossing -- the same operations in the same order, so the same bits), which is what nearly every chunk
-// of a long vector is.  Half of a workgroup's life in this phase is the wait for its tile
-// (tools/rs_phase.py), so what matters is how many workgroups a CU holds: without the int64 Mono scan, the
-// serial fall-backs and the prelude this kernel needs about half the registers of the general one.  Anything
+// of a long vector is.  Without the int64 Mono scan, the serial fall-backs and the prelude this kernel needs
+// 64 VGPRs where the general one needs 94: eight workgroups per CU instead of five.  Anything
 // it cannot prove (scan not started, prelude pending, running sum not a positive finite number, a half-ulp
 // tie, a sum that leaves the binade, a negative / non-finite weight) is left untouched and flagged in
 // plan.todo for resample_chunk_kernel.
@@ -700,15 +714,17 @@ resample_chunk_lean_kernel(long Np, long nch, const double *__restrict__ w, cons
     const long base = k * RS_TILE;
     const int len = (int)((Np - base) < RS_TILE ? (Np - base) : RS_TILE);
     RS_CLOCK_START();
+    // the tile's address does not depend on the plan entry: its loads go out before that entry is waited for
+    // (a chunk that turns out not to be ours costs one unused fetch)
+    double v[RS_ITEMS];
+    fetch_tile(v, wf + base, len);
+    RS_CLOCK(5);                    // loads issued
     const double c_in = p.cin;
     const bool can = p.started != 0 && p.prelude == 0 && c_in > 0.0 && c_in <= 1.79769313486231570815e+308 && k > 0;
     if (!can) {                                                       // uniform
         if (tid == 0) p.todo = 1;
         return;
     }
-    double v[RS_ITEMS];
-    fetch_tile(v, wf + base, len);
-    RS_CLOCK(5);                    // loads issued
     // everything that does not need the tile runs while it is in flight: the binade of the running sum and
     // the first output slot (slots below the previous chunk's last cumulative sum belong to earlier chunks)
     const double ulp = ulp_of(c_in);
@@ -774,6 +790,7 @@ resample_chunk_lean_kernel(long Np, long nch, const double *__restrict__ w, cons
         if (tid == 0 && status) status[f] = out_hi < (int)Np ? ST_OVERRUN : 0;
     }
     if (tid == 0) p.todo = 0;
+    RS_CLOCK_FLUSH();
 }
 
 // P5, general route: the chunks the lean kernel flagged (first chunk of a filter, binade crossings, ties,
@@ -918,9 +935,14 @@ static int resample_common(bool stratified, int64_t Fn, int64_t Np, const double
 #ifdef FK_RS_PHASE_CLOCKS
 extern "C" int fk_debug_rs_phases(unsigned long long *out)     // only in the instrumented build (tools/rs_phase.py)
 {
-    const unsigned long long zero[8] = {0};
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(fk_rs_phase), sizeof(zero)) != hipSuccess) return FK_ERR_LAUNCH;
-    return hipMemcpyToSymbol(HIP_SYMBOL(fk_rs_phase), zero, sizeof(zero)) == hipSuccess ? FK_OK : FK_ERR_LAUNCH;
+    static unsigned long long host[8][RS_PHASE_BUCKETS];
+    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(fk_rs_phase), sizeof(host)) != hipSuccess) return FK_ERR_LAUNCH;
+    for (int q = 0; q < 8; ++q) {
+        out[q] = 0;
+        for (int b = 0; b < RS_PHASE_BUCKETS; ++b) out[q] += host[q][b];
+    }
+    memset(host, 0, sizeof(host));
+    return hipMemcpyToSymbol(HIP_SYMBOL(fk_rs_phase), host, sizeof(host)) == hipSuccess ? FK_OK : FK_ERR_LAUNCH;
 }
 #endif
 

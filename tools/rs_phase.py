@@ -1,4 +1,4 @@
-"""Where does resample_chunk_kernel spend its time?  Builds an INSTRUMENTED copy of the resampling unit
+"""Where does resample_chunk_lean_kernel spend its time?  Builds an INSTRUMENTED copy of the resampling unit
 (-DFK_RS_PHASE_CLOCKS -> filterpy_amd/csrc/build/librs_phase.so; the shipped libfilterhip.so carries none
 of it), runs systematic resampling and prints the share of wave-0 clock ticks per phase:
 
