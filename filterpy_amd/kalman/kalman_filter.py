@@ -27,7 +27,8 @@ from ..common.helpers import reshape_z, logpdf
 from .. import _engine as E
 from .._abi import (FK_MODEL_SHARED, FK_MODEL_PER_TRACK, FK_MODEL_PER_STEP, FK_MODEL_PER_TRACK_STEP)
 
-__all__ = ["KalmanFilter", "KalmanFilterBank", "predict", "update", "batch_filter", "rts_smoother"]
+__all__ = ["KalmanFilter", "KalmanFilterBank", "predict", "update", "batch_filter", "rts_smoother",
+           "predict_steadystate", "update_steadystate"]
 
 
 # ----------------------------------------------------------------- helpers --
@@ -596,6 +597,52 @@ class KalmanFilter(object):
             self._mahalanobis = sqrt(float(np.dot(np.dot(y.T, self.SI), y).item()))
         return self._mahalanobis
 
+    def log_likelihood_of(self, z):
+        """kalman_filter.py:1252-1260: log-density of ``z`` under N(Hx, S) with the S of the last update
+        (host arithmetic on the kernel's outputs, like the reference's own lazily evaluated likelihoods)."""
+        if z is None:
+            return log(sys.float_info.min)
+        return logpdf(z, np.dot(self.H, self.x), self.S)
+
+    def test_matrix_dimensions(self, z=None, H=None, R=None, F=None, Q=None):
+        """kalman_filter.py:1299-1398: assert that x, P, Q, F, H, R (the arguments override the attributes)
+        and a measurement ``z`` have shapes the filter equations accept.  Raises AssertionError with the
+        offending shape; returns None."""
+        H = self.H if H is None else H
+        R = self.R if R is None else R
+        F = self.F if F is None else F
+        Q = self.Q if Q is None else Q
+        x, P, n = self.x, self.P, self.dim_x
+
+        def need(ok, what, want, got):
+            assert ok, "Shape of {} must be {}, but is {}".format(what, want, got)
+
+        assert x.ndim in (1, 2), "x must have one or two dimensions, but has {}".format(x.ndim)
+        need(x.shape == ((n,) if x.ndim == 1 else (n, 1)), "x", (n, 1), x.shape)
+        need(P.shape == (n, n), "P", (n, n), P.shape)
+        need(np.shape(Q) == (n, n), "Q", (n, n), np.shape(Q))
+        need(np.shape(F) == (n, n), "F", (n, n), np.shape(F))
+        need(np.ndim(H) == 2 and np.shape(H)[1] == P.shape[0], "H", ("dim_z", P.shape[0]), np.shape(H))
+        mz = np.shape(H)[0]
+        r_shape = np.shape(R)
+        if mz == 1:      # a 1x1 innovation covariance: scalar, 1-element vector or 1x1 matrix
+            assert r_shape in ((), (1,), (1, 1)), "R must be scalar or one element array, but is shaped {}".format(r_shape)
+        else:
+            need(r_shape == (mz, mz), "R", (mz, mz), r_shape)
+
+        # z must be subtractable from Hx, whose shape follows x's (vector or column)
+        z_shape = np.shape(z) if z is not None else (self.dim_z, 1)
+        hx_shape = np.shape(np.dot(H, x))
+        msg = "shape of z should be {}, not {} for the given H".format(hx_shape, z_shape)
+        if z_shape == ():
+            assert len(hx_shape) == 1 or hx_shape == (1, 1), msg
+        elif hx_shape == (1,):
+            assert z_shape[0] == 1, msg
+        else:
+            assert z_shape == hx_shape or (len(z_shape) == 1 and hx_shape == (z_shape[0], 1)), msg
+        if len(hx_shape) > 1 and hx_shape != (1, 1):
+            assert hx_shape == z_shape, msg
+
     @property
     def alpha(self):
         """kalman_filter.py:1242-1257."""
@@ -890,6 +937,40 @@ def update(x, P, z, R, H=None, return_all=False):
         ll = logpdf(zz, np.dot(Hm, np.asarray(xo, dtype=float).reshape(n, -1)), S[0])
         return xo, Po, yy, K[0], S[0], ll
     return xo, Po
+
+
+def update_steadystate(x, z, K, H=None):
+    """Module-level steady-state update (kalman_filter.py:1511-1568): x + K (z - Hx) with a given gain, no
+    covariance anywhere.  z None -> x unchanged.  Runs fk_kf_steadystate_f64 on one track."""
+    if z is None:
+        return x
+    scalar = np.isscalar(x) or np.ndim(x) == 0
+    xa = np.atleast_1d(np.asarray(x, dtype=np.float64))
+    n = xa.size
+    Hm = np.atleast_2d(np.asarray(1.0 if H is None else H, dtype=np.float64))
+    if Hm.shape[1] != n:
+        Hm = Hm.reshape(-1, n)
+    m = Hm.shape[0]
+    zz = np.asarray(reshape_z(z, m, np.ndim(x)), dtype=np.float64).reshape(1, 1, m)
+    # a scalar gain scales the residual (dot(K, y) = K * y); a scalar for a 1 x m gain multiplies every entry
+    Km = np.eye(n) * float(K) if (np.ndim(K) == 0 and n == m) else _mat(K, n, m, "K", scalar="full")
+    xn, _, _, _ = _Core.steadystate(n, m, 1, 1, xa.reshape(1, n), None, Hm, Km, zz)
+    return float(xn[0, 0]) if scalar else xn[0].reshape(xa.shape)
+
+
+def predict_steadystate(x, F=1, u=0, B=1):
+    """Module-level steady-state predict (kalman_filter.py:1624-1660): Fx + Bu, no covariance.
+    Runs fk_kf_steadystate_f64 on one track."""
+    scalar = np.isscalar(x) or np.ndim(x) == 0
+    xa = np.atleast_1d(np.asarray(x, dtype=np.float64))
+    n = xa.size
+    kw = {}
+    bu = np.dot(B, u)
+    if np.any(np.asarray(bu) != 0):
+        # the reference adds dot(B, u) whatever its shape; fold it into a 1-column control input
+        kw = dict(B=np.asarray(bu, dtype=np.float64).reshape(n, 1), us=np.ones((1, 1, 1)), nu=1)
+    xn, _, _, _ = _Core.steadystate(n, 1, 1, 1, xa.reshape(1, n), _mat(F, n, n, "F"), None, None, None, **kw)
+    return float(xn[0, 0]) if scalar else xn[0].reshape(xa.shape)
 
 
 def batch_filter(x, P, zs, Fs, Qs, Hs, Rs, Bs=None, us=None, update_first=False, saver=None):
