@@ -25,7 +25,7 @@ import numpy as np
 
 from ..common.helpers import reshape_z, logpdf
 from .. import _engine as E
-from .._abi import (FK_MODEL_SHARED, FK_MODEL_PER_TRACK, FK_MODEL_PER_STEP, FK_MODEL_PER_TRACK_STEP)
+from .._abi import FK_MODEL_SHARED, FK_MODEL_PER_TRACK, FK_MODEL_PER_STEP
 
 __all__ = ["KalmanFilter", "KalmanFilterBank", "predict", "update", "batch_filter", "rts_smoother",
            "predict_steadystate", "update_steadystate"]

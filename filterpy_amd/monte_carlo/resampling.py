@@ -14,7 +14,6 @@ import numpy as np
 from numpy.random import random
 
 from .. import _engine as E
-from .. import _abi
 
 __all__ = ["residual_resample", "stratified_resample", "systematic_resample", "multinomial_resample"]
 
