@@ -326,11 +326,27 @@ class KalmanFilter(object):
         if H is None:
             z = reshape_z(z, m, x_ndim)                       # raises ValueError on bad shapes
             H = self.H
-        zz = np.asarray(z, dtype=np.float64)
-        if zz.size != m:
-            raise ValueError(f"z (shape {zz.shape}) does not hold dim_z = {m} values")
+            zz = np.asarray(z, dtype=np.float64)
+            if zz.size != m:
+                raise ValueError(f"z (shape {zz.shape}) does not hold dim_z = {m} values")
+        else:
+            # with an explicit H the reference skips reshape_z (kalman_filter.py:530-533) and numpy broadcasts
+            # z against Hx: a scalar feeds every measurement, a z shaped like Hx is used as it is.  A z that
+            # would broadcast the residual beyond Hx's shape turns the reference's STATE into a matrix (or
+            # fails in a later dot); here that is a ValueError.
+            zraw = np.asarray(z, dtype=np.float64)
+            hx_shape = (m,) if x_ndim == 1 else (m, 1)
+            try:
+                y_shape = np.broadcast_shapes(zraw.shape, hx_shape)
+            except ValueError:
+                raise ValueError(f"z (shape {zraw.shape}) does not broadcast against Hx (shape {hx_shape})") from None
+            if y_shape != hx_shape:
+                raise ValueError(f"z (shape {zraw.shape}) would broadcast the residual to {y_shape}, "
+                                 f"Hx has shape {hx_shape}")
+            zz = np.broadcast_to(zraw, hx_shape)
         x, P = self._xP()
-        xn, Pn, y, K, S, SI = _Core.update(n, m, 1, x, P, zz.reshape(1, m), _mat(H, m, n, "H"), Rm, FK_MODEL_SHARED)
+        xn, Pn, y, K, S, SI = _Core.update(n, m, 1, x, P, np.ascontiguousarray(zz).reshape(1, m), _mat(H, m, n, "H"),
+                                           Rm, FK_MODEL_SHARED)
         self._set_x(xn[0])
         self.P = Pn[0]
         self.y = y[0].reshape(m, 1) if x_ndim == 2 else y[0]
