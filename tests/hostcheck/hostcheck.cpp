@@ -418,6 +418,60 @@ extern "C" long hc_cumsum_exact(long N, const double *w, double *cs)
     return segs;
 }
 
+// One tile from a given scan state through (a) the general algorithm (tile_cumsum_exact) and (b) the lean
+// output kernel's route (resample_chunk_lean_kernel: one tie-free binade segment with the kernel's wave-scan
+// association order, or "todo").  Returns the lean route's todo flag; cs_general / cs_lean get the sums.
+extern "C" int hc_tile_lean_vs_general(int len, const double *w, double cin, int started_in, int prelude_in,
+                                       int first_chunk, double *cs_general, double *cs_lean)
+{
+    {
+        std::vector<double> tile(T_TILE, 0.0);
+        std::copy(w, w + len, tile.begin());
+        bool started = started_in != 0;
+        int prelude = prelude_in;
+        long segs = 0;
+        tile_cumsum_emul(tile.data(), len, cin, started, &segs, prelude);
+        std::copy(tile.begin(), tile.begin() + len, cs_general);
+    }
+    const bool can = started_in != 0 && prelude_in == 0 && cin > 0.0 && cin <= 1.79769313486231570815e+308 && !first_chunk;
+    if (!can) return 1;
+    const double ulp = ulp_of(cin);
+    const int eu = ulp_exp(cin);
+    const double C0d = scale2(cin, -eu);
+    std::vector<double> incl(T_TILE), inc(T_THREADS);
+    bool odd = false;
+    for (int t = 0; t < T_THREADS; ++t) {
+        double runs = 0.0;
+        for (int q = 0; q < T_ITEMS; ++q) {
+            const int j = t * T_ITEMS + q;
+            bool tk = false;
+            const double e = j < len ? fast_inc(w[j], eu, tk) : 0.0;
+            odd = odd || tk;
+            runs += e;
+            incl[j] = runs;
+        }
+        inc[t] = runs;
+    }
+    for (int d = 1; d < 64; d <<= 1) {                 // the kernel's Hillis-Steele wave scan
+        std::vector<double> nxt = inc;
+        for (int t = 0; t < T_THREADS; ++t)
+            if ((t & 63) >= d) nxt[t] = inc[t] + inc[t - d];
+        inc = nxt;
+    }
+    for (int t = 0; t < T_THREADS; ++t) {
+        double excl = (t & 63) ? inc[t - 1] : 0.0;
+        for (int wv = 0; wv < (t >> 6); ++wv) excl += inc[wv * 64 + 63];
+        for (int q = 0; q < T_ITEMS; ++q) {
+            const int j = t * T_ITEMS + q;
+            incl[j] = C0d + (excl + incl[j]);
+            odd = odd || (j < len && !(incl[j] < 0x1p53));
+        }
+    }
+    if (odd) return 1;
+    for (int j = 0; j < len; ++j) cs_lean[j] = incl[j] * ulp;
+    return 0;
+}
+
 // The output loop of resample_kernel / resample_chunk_kernel on one tile: the tile's cumulative sums
 // (cs, from carry-in c_in), the slot positions ps, and fk::tile_upper_bound exactly as the kernels call it.
 extern "C" void hc_tile_search(int len, const double *cs, double c_in, long n_pos, const double *ps, int *out)

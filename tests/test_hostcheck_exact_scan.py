@@ -129,3 +129,60 @@ def test_tile_upper_bound_equals_searchsorted(name, n):
     got = _tile_search(cs, c_in, ps)
     bad = np.nonzero(want != got)[0]
     assert bad.size == 0, (name, n, ps[bad[:5]], want[bad[:5]], got[bad[:5]])
+
+
+def _lean_vs_general(w, cin, started=1, prelude=0, first_chunk=0):
+    lib = ctypes.CDLL(os.path.join(ROOT, "tests", "hostcheck", "libhostcheck.so"))
+    w = np.ascontiguousarray(w, dtype=np.float64)
+    g, l = np.empty_like(w), np.full_like(w, np.nan)
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+    todo = lib.hc_tile_lean_vs_general(ctypes.c_int(w.size), p(w), ctypes.c_double(cin), ctypes.c_int(started),
+                                       ctypes.c_int(prelude), ctypes.c_int(first_chunk), p(g), p(l))
+    return todo, g, l
+
+
+@pytest.mark.parametrize("n", [2048, 2047, 1000, 1])
+def test_lean_output_route_is_the_general_one_or_declines(n):
+    """resample_chunk_lean_kernel either reproduces tile_cumsum_exact bit for bit or flags the chunk for the
+    general kernel -- and it must decline exactly the chunks it cannot prove: state not started, prelude
+    pending, first chunk, a half-ulp tie, a sum leaving the binade, an invalid weight."""
+    r = np.random.default_rng(n)
+    accepted = 0
+    for trial in range(60):
+        w = r.random(n) / 8e6
+        cin = float(r.random() * 0.9 + 0.05)                   # somewhere inside a binade, or crossing it
+        todo, g, l = _lean_vs_general(w, cin)
+        ref = cin + 0.0
+        want = np.empty(n)
+        for j in range(n):                                     # plain sequential fp64 adds = numpy.cumsum
+            ref = ref + w[j]
+            want[j] = ref
+        assert np.array_equal(bits(g), bits(want))
+        crosses = np.frexp(want[-1])[1] != np.frexp(cin)[1]
+        if todo == 0:
+            accepted += 1
+            assert not crosses
+            assert np.array_equal(bits(l), bits(want))
+        else:
+            assert crosses or _has_tie(w, cin)
+    assert accepted > 30
+    w = r.random(n) / 8e6
+    assert _lean_vs_general(w, 0.3, started=0)[0] == 1
+    assert _lean_vs_general(w, 0.3, prelude=5)[0] == 1
+    assert _lean_vs_general(w, 0.3, first_chunk=1)[0] == 1
+    assert _lean_vs_general(w, 0.0)[0] == 1
+    assert _lean_vs_general(w, np.inf)[0] == 1
+    for badv in (-1e-9, np.nan, np.inf):
+        wb = w.copy()
+        wb[n // 2] = badv
+        assert _lean_vs_general(wb, 0.3)[0] == 1
+    # an exact half-ulp tie: ulp(0.3) = 2^-54, so 1.5 ulp has a remainder of exactly half an ulp
+    wt = w.copy()
+    wt[n // 3] = 1.5 * 2.0 ** -54
+    assert _lean_vs_general(wt, 0.3)[0] == 1
+
+
+def _has_tie(w, cin):
+    u = np.spacing(cin)
+    t = w / u
+    return bool(np.any(t - np.floor(t) == 0.5))
