@@ -1,1 +1,1 @@
-from .helpers import reshape_z, logpdf  # noqa: F401
+from .helpers import reshape_z, logpdf, Saver  # noqa: F401
