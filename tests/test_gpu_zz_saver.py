@@ -1,0 +1,30 @@
+"""batch_filter(saver=filterpy_amd.common.Saver(kf)) through the real kernel: the histories the package's Saver
+collects equal the ones filterpy.common.Saver recorded from the reference (tests/golden/kf_saver.npz).
+(tests/test_host_saver_batch.py is the same comparison with the launch replaced by the oracle, on the CPU.)"""
+import numpy as np
+import pytest
+
+from conftest import golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("n,m", [(2, 1), (4, 2)])
+def test_package_saver_histories(n, m):
+    from filterpy_amd.common import Saver
+    from filterpy_amd.kalman import KalmanFilter
+    g = golden("kf_saver")
+    p = f"n{n}m{m}_"
+    kf = KalmanFilter(n, m)
+    kf.x, kf.P = g[p + "x0"].copy(), g[p + "P0"].copy()
+    kf.F, kf.Q, kf.H, kf.R = g[p + "F"].copy(), g[p + "Q"].copy(), g[p + "H"].copy(), g[p + "R"].copy()
+    s = Saver(kf, skip_private=True)
+    zl = [z if k else None for z, k in zip(g[p + "zs"], g[p + "mask"])]
+    kf.batch_filter(zl, saver=s)
+    assert len(s) == len(zl)
+    for k in ("x", "P", "x_prior", "P_prior", "x_post", "P_post", "K", "y", "S", "SI"):
+        got, ref = np.array(s[k], dtype=float), g[p + k]
+        assert got.shape == ref.shape, (k, got.shape, ref.shape)
+        assert np.allclose(got, ref, rtol=1e-9, atol=1e-11), k
+    assert np.allclose(np.array(s["log_likelihood"], dtype=float), g[p + "log_likelihood"], rtol=1e-8, atol=1e-8)
+    assert np.allclose(np.array(s["mahalanobis"], dtype=float), g[p + "mahalanobis"], rtol=1e-8, atol=1e-10)
