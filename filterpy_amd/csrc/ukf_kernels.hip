@@ -22,6 +22,270 @@ namespace fk {
 // never all materialised: the predict makes two sweeps over the 2n+1 points (mean, then covariance),
 // regenerating each point x +- L[:,k] and pushing it through F on the fly -- ~70 live doubles at
 // n = 6 instead of ~260 (the first version spilled 196 registers at one wave per SIMD).
+// Two builds of the kernel.  The default is the one every GPU parity test of round 1 ran against.  -DFK_UKF_V2
+// (tools/exp_ukf2.py builds it into a separate build/libfk_exp_ukf.so) is the same arithmetic -- every sum
+// accumulates over the sigma points in the same index order -- reorganised for registers, written at the end of
+// round 1 when no GPU time was left, so NOT validated on a GPU yet:
+//   * the mean sweeps run point by point like the covariance sweeps (row by row, the compiler kept all
+//     (2n+1) n sigma-point values alive across the rows);
+//   * the measurement update is two sweeps (zp, then S and Pxz) instead of holding all H sigma_i;
+//   * every unrolled point re-reads its model rows through an LDS offset the optimiser cannot see through
+//     (otherwise the broadcast reads of all points are hoisted and held);
+//   => (6,3): 223 (SOA) / 256 (AOS) VGPRs, no scratch, two waves per SIMD, against 512 VGPRs + 44 spilled
+//      registers at one wave per SIMD.
+#ifdef FK_UKF_V2
+template <int NX, int NZ, int LAYOUT>
+__global__ void __launch_bounds__(BLOCK, (NX <= 2 ? 4 : 2))
+ukf_linear_kernel(const UkfArgs a, const double *__restrict__ pF, const double *__restrict__ pH,
+                  const double *__restrict__ pQ, const double *__restrict__ pR,
+                  const double *__restrict__ pWm, const double *__restrict__ pWc,
+                  const double *__restrict__ pz, const uint8_t *__restrict__ pmask)
+{
+    constexpr int KS = 2 * NX + 1;
+    constexpr int PL = NX * (NX + 1) / 2;
+    using SharedModel = LdsModel<NX, NZ>;
+    __shared__ double s_model[SharedModel::SIZE + 2 * KS];
+    const long N = a.N;
+    const long blk0 = (long)blockIdx.x * BLOCK;
+    const Lane ln{blk0, threadIdx.x, N};
+    const bool live = blk0 + ln.tid < N;
+    const Lane lr{blk0, live ? ln.tid : 0u, N};
+    const int n = a.n, m = a.m;
+    const int ks = 2 * n + 1;
+
+    lds_fill<NX, NX>(s_model + SharedModel::OFF_F, pF, n, n, 1.0, threadIdx.x);
+    lds_fill<NX, NX>(s_model + SharedModel::OFF_Q, pQ, n, n, 1.0, threadIdx.x);   // padded block of P stays I
+    lds_fill<NZ, NX>(s_model + SharedModel::OFF_H, pH, m, n, 0.0, threadIdx.x);
+    lds_fill<NZ, NZ>(s_model + SharedModel::OFF_R, pR, m, m, 1.0, threadIdx.x);
+    // weights, re-indexed from the runtime point set (0, 1..n, n+1..2n) to the padded one
+    // (0, 1..NX, NX+1..2NX); padded points get weight 0
+    for (unsigned q = ln.tid; q < (unsigned)(2 * KS); q += BLOCK) {
+        const int which = q / KS, i = q % KS;
+        int src = -1;
+        if (i == 0) src = 0;
+        else if (i <= NX) { if (i <= n) src = i; }
+        else { if (i - NX <= n) src = n + (i - NX); }
+        const double *W = which ? pWc : pWm;
+        s_model[SharedModel::SIZE + q] = (src >= 0 && src < ks) ? W[src] : 0.0;
+    }
+    __syncthreads();
+    const SharedModel sm{s_model};
+    const double *sWm = s_model + SharedModel::SIZE, *sWc = sWm + KS;
+    // a view of the LDS model the optimiser cannot relate to the previous one: keeps it from hoisting the
+    // broadcast row reads of all 2n+1 unrolled points to the top (they are cheap to repeat, dear to hold)
+    auto fresh = [&]() { int off = 0; asm volatile("" : "+v"(off)); return s_model + off; };   // (an offset, not the pointer: keeps the LDS address space)
+
+    double x[NX], P[PL];
+    load_rec<NX, 1, LAYOUT, false>(x, a.x, lr, n, 1, 0.0);
+    {
+        const RecView<LAYOUT> pv(a.P, lr, n * n);
+        FK_UNROLL for (int i = 0; i < NX; ++i)
+            FK_UNROLL for (int j = 0; j < NX; ++j)
+                if (j >= i) P[sym_idx<NX>(i, j)] = (i < n && j < n) ? pv.load(i * n + j) : (i == j ? 1.0 : 0.0);
+    }
+    int st = 0;
+
+    for (long t = 0; t < a.T; ++t) {
+        double z[NZ];
+        bool has_z = true;
+        if (pmask) has_z = pmask[t * N + lr.blk0 + lr.tid] != 0;
+        load_rec<NZ, 1, LAYOUT, false>(z, pz + t * N * m, lr, m, 1, 0.0);
+
+        // ---------------- predict (UKF.py:400-411)
+        double L[PL];
+        if (!chol_packed<NX>(P, a.scale, L)) st |= ST_NOT_PD;
+        // sweep 1: x- = sum_i Wm_i F sigma_i, one output component (row of F) at a time, points in
+        // index order 0, x + L[:,k] (k = 0..n-1), x - L[:,k]
+        double xm[NX];
+        FK_UNROLL for (int i = 0; i < KS; ++i) {
+            const double *mb = fresh();
+            const SharedModel sm{mb};
+            const double *sWm = mb + SharedModel::SIZE, *sWc = sWm + KS;
+            (void)sWm; (void)sWc;
+            FK_UNROLL for (int r = 0; r < NX; ++r) {
+                double f[NX];
+                sm.rowF(r, f);
+                double v;
+                if (i == 0) {
+                    v = dot<NX>(f, x);
+                } else if (i <= NX) {
+                    v = f[0] * (x[0] - (-lcol<NX>(L, 0, i - 1)));
+                    FK_UNROLL for (int c = 1; c < NX; ++c) v = fma(f[c], x[c] - (-lcol<NX>(L, c, i - 1)), v);
+                } else {
+                    v = f[0] * (x[0] - lcol<NX>(L, 0, i - 1 - NX));
+                    FK_UNROLL for (int c = 1; c < NX; ++c) v = fma(f[c], x[c] - lcol<NX>(L, c, i - 1 - NX), v);
+                }
+                xm[r] = (i == 0) ? sWm[0] * v : fma(sWm[i], v, xm[r]);
+            }
+            FK_STAGE();
+        }
+        // sweep 2: P- = sum_i Wc_i y_i y_i' + Q, y_i = F sigma_i - x-   (upper triangle).
+        // The points are recomputed from copies the optimiser cannot relate to sweep 1 (otherwise it
+        // common-subexpression-eliminates the recomputation by keeping all (2n+1) n values alive).
+        double Pn[PL];
+        FK_UNROLL for (int c = 0; c < NX; ++c) asm volatile("" : "+v"(x[c]));
+        FK_UNROLL for (int e = 0; e < PL; ++e) asm volatile("" : "+v"(L[e]));
+        FK_UNROLL for (int i = 0; i < KS; ++i) {
+            const double *mb = fresh();
+            const SharedModel sm{mb};
+            const double *sWm = mb + SharedModel::SIZE, *sWc = sWm + KS;
+            (void)sWm; (void)sWc;
+            double y[NX], wy[NX];
+            FK_UNROLL for (int r = 0; r < NX; ++r) {
+                double f[NX];
+                sm.rowF(r, f);
+                double v;
+                if (i == 0) {
+                    v = dot<NX>(f, x);
+                } else if (i <= NX) {
+                    v = f[0] * (x[0] - (-lcol<NX>(L, 0, i - 1)));
+                    FK_UNROLL for (int c = 1; c < NX; ++c) v = fma(f[c], x[c] - (-lcol<NX>(L, c, i - 1)), v);
+                } else {
+                    v = f[0] * (x[0] - lcol<NX>(L, 0, i - 1 - NX));
+                    FK_UNROLL for (int c = 1; c < NX; ++c) v = fma(f[c], x[c] - lcol<NX>(L, c, i - 1 - NX), v);
+                }
+                y[r] = v - xm[r];
+            }
+            FK_UNROLL for (int r = 0; r < NX; ++r) wy[r] = sWc[i] * y[r];
+            FK_UNROLL for (int a2 = 0; a2 < NX; ++a2)
+                FK_UNROLL for (int b = 0; b < NX; ++b)
+                    if (b >= a2)
+                        Pn[sym_idx<NX>(a2, b)] = (i == 0) ? y[a2] * wy[b] : fma(y[a2], wy[b], Pn[sym_idx<NX>(a2, b)]);
+            FK_STAGE();
+        }
+        FK_UNROLL for (int r = 0; r < NX; ++r) {
+            double q[NX];
+            sm.rowQ(r, q);
+            FK_UNROLL for (int b = 0; b < NX; ++b)
+                if (b >= r) P[sym_idx<NX>(r, b)] = Pn[sym_idx<NX>(r, b)] + q[b];
+            x[r] = xm[r];
+        }
+
+        // ---------------- update (UKF.py:462-481), sigma points regenerated from the prior (:407)
+        if (has_z) {
+            if (!chol_packed<NX>(P, a.scale, L)) st |= ST_NOT_PD;
+            // sweep 1: zp = sum_i Wm_i H sigma_i, point by point (index order 0, +k, -k)
+            double zp[NZ];
+            FK_UNROLL for (int i = 0; i < KS; ++i) {
+            const double *mb = fresh();
+            const SharedModel sm{mb};
+            const double *sWm = mb + SharedModel::SIZE, *sWc = sWm + KS;
+            (void)sWm; (void)sWc;
+                FK_UNROLL for (int r = 0; r < NZ; ++r) {
+                    double h[NX];
+                    sm.rowH(r, h);
+                    double v;
+                    if (i == 0) {
+                        v = dot<NX>(h, x);
+                    } else if (i <= NX) {
+                        v = h[0] * (x[0] - (-lcol<NX>(L, 0, i - 1)));
+                        FK_UNROLL for (int c = 1; c < NX; ++c) v = fma(h[c], x[c] - (-lcol<NX>(L, c, i - 1)), v);
+                    } else {
+                        v = h[0] * (x[0] - lcol<NX>(L, 0, i - 1 - NX));
+                        FK_UNROLL for (int c = 1; c < NX; ++c) v = fma(h[c], x[c] - lcol<NX>(L, c, i - 1 - NX), v);
+                    }
+                    zp[r] = (i == 0) ? sWm[0] * v : fma(sWm[i], v, zp[r]);
+                }
+                FK_STAGE();
+            }
+            // sweep 2: S = sum Wc_i d_i d_i' + R,  Pxz = sum Wc_i (sf_i - x) d_i',  d_i = H sigma_i - zp
+            double S[NZ * NZ], K[NX * NZ];
+            FK_UNROLL for (int c = 0; c < NX; ++c) asm volatile("" : "+v"(x[c]));
+            FK_UNROLL for (int e = 0; e < PL; ++e) asm volatile("" : "+v"(L[e]));
+            FK_UNROLL for (int i = 0; i < KS; ++i) {
+            const double *mb = fresh();
+            const SharedModel sm{mb};
+            const double *sWm = mb + SharedModel::SIZE, *sWc = sWm + KS;
+            (void)sWm; (void)sWc;
+                double d[NZ], wd[NZ];
+                FK_UNROLL for (int r = 0; r < NZ; ++r) {
+                    double h[NX];
+                    sm.rowH(r, h);
+                    double v;
+                    if (i == 0) {
+                        v = dot<NX>(h, x);
+                    } else if (i <= NX) {
+                        v = h[0] * (x[0] - (-lcol<NX>(L, 0, i - 1)));
+                        FK_UNROLL for (int c = 1; c < NX; ++c) v = fma(h[c], x[c] - (-lcol<NX>(L, c, i - 1)), v);
+                    } else {
+                        v = h[0] * (x[0] - lcol<NX>(L, 0, i - 1 - NX));
+                        FK_UNROLL for (int c = 1; c < NX; ++c) v = fma(h[c], x[c] - lcol<NX>(L, c, i - 1 - NX), v);
+                    }
+                    d[r] = v - zp[r];
+                }
+                FK_UNROLL for (int r = 0; r < NZ; ++r) wd[r] = sWc[i] * d[r];
+                FK_UNROLL for (int r = 0; r < NZ; ++r)
+                    FK_UNROLL for (int c = 0; c < NZ; ++c)
+                        S[r * NZ + c] = (i == 0) ? d[r] * wd[c] : fma(d[r], wd[c], S[r * NZ + c]);
+                FK_UNROLL for (int r = 0; r < NX; ++r) {
+                    double dx;
+                    if (i == 0) dx = x[r] - x[r];
+                    else if (i <= NX) dx = (x[r] - (-lcol<NX>(L, r, i - 1))) - x[r];
+                    else dx = (x[r] - lcol<NX>(L, r, i - 1 - NX)) - x[r];
+                    FK_UNROLL for (int c = 0; c < NZ; ++c) {
+                        const double term = sWc[i] * (dx * d[c]);
+                        K[r * NZ + c] = (i == 0) ? term : K[r * NZ + c] + term;
+                    }
+                }
+                FK_STAGE();
+            }
+            FK_UNROLL for (int r = 0; r < NZ; ++r) {
+                double rr[NZ];
+                sm.rowR(r, rr);
+                FK_UNROLL for (int c = 0; c < NZ; ++c) S[r * NZ + c] += rr[c];
+            }
+            // K = Pxz S^-1
+            double Lf[NZ * NZ], d[NZ], dinv[NZ];
+            FK_UNROLL for (int e = 0; e < NZ * NZ; ++e) Lf[e] = S[e];
+            if (!ldlt2<NZ>(Lf, d, dinv)) st |= ST_NOT_PD;
+            solve_rows_ldlt<NX, NZ>(Lf, dinv, K);
+            // x += K (z - zp)
+            FK_UNROLL for (int r = 0; r < NX; ++r) {
+                double acc = K[r * NZ] * (z[0] - zp[0]);
+                FK_UNROLL for (int c = 1; c < NZ; ++c) acc = fma(K[r * NZ + c], z[c] - zp[c], acc);
+                x[r] += acc;
+            }
+            // P -= K (S K'), upper triangle
+            FK_UNROLL for (int c2 = 0; c2 < NX; ++c2) {
+                double sk[NZ];                 // column c2 of S K'
+                FK_UNROLL for (int q = 0; q < NZ; ++q) {
+                    double acc = S[q * NZ] * K[c2 * NZ];
+                    FK_UNROLL for (int w = 1; w < NZ; ++w) acc = fma(S[q * NZ + w], K[c2 * NZ + w], acc);
+                    sk[q] = acc;
+                }
+                FK_UNROLL for (int q = 0; q < NZ; ++q) asm volatile("" : "+v"(sk[q]));
+                FK_UNROLL for (int r = 0; r < NX; ++r)
+                    if (r <= c2) {
+                        double acc = K[r * NZ] * sk[0];
+                        FK_UNROLL for (int q = 1; q < NZ; ++q) acc = fma(K[r * NZ + q], sk[q], acc);
+                        P[sym_idx<NX>(r, c2)] -= acc;
+                    }
+                FK_STAGE();
+            }
+        }
+        if (live) {
+            if (a.means) store_rec<NX, 1, LAYOUT, false>(x, a.means + t * N * n, ln, n, 1);
+            if (a.covs) {
+                double Pf[NX * NX];
+                FK_UNROLL for (int i = 0; i < NX; ++i)
+                    FK_UNROLL for (int j = 0; j < NX; ++j) Pf[i * NX + j] = P[sym_idx<NX>(i, j)];
+                store_rec<NX, NX, LAYOUT, false>(Pf, a.covs + t * N * n * n, ln, n, n);
+            }
+        }
+    }
+    if (live) {
+        store_rec<NX, 1, LAYOUT, false>(x, a.x, ln, n, 1);
+        double Pf[NX * NX];
+        FK_UNROLL for (int i = 0; i < NX; ++i)
+            FK_UNROLL for (int j = 0; j < NX; ++j) Pf[i * NX + j] = P[sym_idx<NX>(i, j)];
+        store_rec<NX, NX, LAYOUT, false>(Pf, a.P, ln, n, n);
+        if (a.status) {
+            if (!all_finite<NX>(x) || !all_finite<PL>(P)) st |= ST_NONFINITE;
+            a.status[ln.blk0 + ln.tid] = st;
+        }
+    }
+}
+#else
 template <int NX, int NZ, int LAYOUT>
 __global__ void __launch_bounds__(BLOCK, (NX <= 2 ? 4 : NX <= 4 ? 2 : 1))
 ukf_linear_kernel(const UkfArgs a, const double *__restrict__ pF, const double *__restrict__ pH,
@@ -247,6 +511,7 @@ ukf_linear_kernel(const UkfArgs a, const double *__restrict__ pF, const double *
         }
     }
 }
+#endif
 
 static int fail(int code, const char *msg)
 {
