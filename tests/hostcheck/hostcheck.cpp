@@ -484,6 +484,29 @@ extern "C" void hc_tile_search(int len, const double *cs, double c_in, long n_po
     for (long i = 0; i < n_pos; ++i) out[i] = fk::tile_upper_bound(g.data() + 1, len, ps[i], c_in, inv_span);
 }
 
+// Output loop of the experimental lean kernel (csrc/experimental/resample_lean2.hip): groups of 8 consecutive
+// (non-decreasing) positions, the first by fk::tile_upper_bound, the others by walking on from the previous index
+// over the guarded tile.
+extern "C" void hc_tile_search_walk(int len, const double *cs, double c_in, long n_pos, const double *ps, int *out)
+{
+    const double inf = std::numeric_limits<double>::infinity();
+    std::vector<double> g(1 + len + fk::TILE_GUARD, inf);
+    g[0] = -inf;
+    std::copy(cs, cs + len, g.begin() + 1);
+    const double *w = g.data() + 1;
+    const double inv_span = (double)len / (cs[len - 1] - c_in);
+    for (long i0 = 0; i0 < n_pos; i0 += 8) {
+        int r = 0;
+        for (long e = 0; e < 8 && i0 + e < n_pos; ++e) {
+            const double p = ps[i0 + e];
+            if (e == 0) r = fk::tile_upper_bound(w, len, p, c_in, inv_span);
+            else
+                while (w[r] <= p) ++r;
+            out[i0 + e] = r;
+        }
+    }
+}
+
 // Host emulation of the chunk-parallel plan/chain (resample_kernels.hip P1-P4): chunk sums in a
 // different association order, error-bounded binade guess, composite map per clean chunk, verified
 // O(1) chain step -- the resulting carry-in of every chunk must equal the sequential one.

@@ -186,3 +186,29 @@ def _has_tie(w, cin):
     u = np.spacing(cin)
     t = w / u
     return bool(np.any(t - np.floor(t) == 0.5))
+
+
+@pytest.mark.parametrize("name", sorted(TILE_CASES))
+@pytest.mark.parametrize("n", [1, 9, 100, 2048])
+def test_search_then_walk_equals_searchsorted(name, n):
+    """The output scheme of the experimental lean kernel (one search per 8 consecutive slots, then walks over the
+    guarded tile) returns #{j : cs[j] <= p} for every non-decreasing run of positions, also when many slots
+    fall on one element or many elements lie between two slots."""
+    r = np.random.default_rng(n * 7 + len(name))
+    c_in = float(r.random() * 3)
+    cs = c_in + np.cumsum(TILE_CASES[name](r, n))
+    lo, hi = c_in, cs[-1]
+    span = hi - lo if hi > lo else 1.0
+    for ps in (np.sort(lo + span * r.random(4001)),                     # random, sorted
+               np.linspace(lo, hi, 1237),                                # evenly spaced like systematic positions
+               np.sort(np.concatenate([cs, cs, np.nextafter(cs, -np.inf)])),   # on the sums themselves, repeated
+               np.linspace(lo - span, hi + span, 77)):                   # starting below, ending above the tile
+        lib = ctypes.CDLL(os.path.join(ROOT, "tests", "hostcheck", "libhostcheck.so"))
+        ps = np.ascontiguousarray(ps, dtype=np.float64)
+        csc = np.ascontiguousarray(cs, dtype=np.float64)
+        out = np.empty(ps.size, dtype=np.int32)
+        lib.hc_tile_search_walk(ctypes.c_int(csc.size), csc.ctypes.data_as(ctypes.c_void_p), ctypes.c_double(c_in),
+                                ctypes.c_long(ps.size), ps.ctypes.data_as(ctypes.c_void_p),
+                                out.ctypes.data_as(ctypes.c_void_p))
+        want = np.searchsorted(cs, ps, side="right").astype(np.int32)
+        assert np.array_equal(out, want), (name, n)
