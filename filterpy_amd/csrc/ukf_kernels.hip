@@ -8,6 +8,7 @@
 #include "fk_device.hpp"
 #include "fk_kernel_args.hpp"
 #include "fk_math_sym.hpp"
+#include "fk_ukf.hpp"
 
 namespace fk {
 
@@ -69,11 +70,16 @@ ukf_linear_kernel(const UkfArgs a, const double *__restrict__ pF, const double *
         s_model[SharedModel::SIZE + q] = (src >= 0 && src < ks) ? W[src] : 0.0;
     }
     __syncthreads();
-    const SharedModel sm{s_model};
-    const double *sWm = s_model + SharedModel::SIZE, *sWc = sWm + KS;
     // a view of the LDS model the optimiser cannot relate to the previous one: keeps it from hoisting the
     // broadcast row reads of all 2n+1 unrolled points to the top (they are cheap to repeat, dear to hold)
-    auto fresh = [&]() { int off = 0; asm volatile("" : "+v"(off)); return s_model + off; };   // (an offset, not the pointer: keeps the LDS address space)
+    // (an offset is made opaque, not the pointer: that keeps the LDS address space)
+    struct View { SharedModel sm; const double *Wm, *Wc; };
+    auto fresh = [&]() {
+        int off = 0;
+        asm volatile("" : "+v"(off));
+        const double *mb = s_model + off;
+        return View{SharedModel{mb}, mb + SharedModel::SIZE, mb + SharedModel::SIZE + KS};
+    };
 
     double x[NX], P[PL];
     load_rec<NX, 1, LAYOUT, false>(x, a.x, lr, n, 1, 0.0);
@@ -91,178 +97,7 @@ ukf_linear_kernel(const UkfArgs a, const double *__restrict__ pF, const double *
         if (pmask) has_z = pmask[t * N + lr.blk0 + lr.tid] != 0;
         load_rec<NZ, 1, LAYOUT, false>(z, pz + t * N * m, lr, m, 1, 0.0);
 
-        // ---------------- predict (UKF.py:400-411)
-        double L[PL];
-        if (!chol_packed<NX>(P, a.scale, L)) st |= ST_NOT_PD;
-        // sweep 1: x- = sum_i Wm_i F sigma_i, one output component (row of F) at a time, points in
-        // index order 0, x + L[:,k] (k = 0..n-1), x - L[:,k]
-        double xm[NX];
-        FK_UNROLL for (int i = 0; i < KS; ++i) {
-            const double *mb = fresh();
-            const SharedModel sm{mb};
-            const double *sWm = mb + SharedModel::SIZE, *sWc = sWm + KS;
-            (void)sWm; (void)sWc;
-            FK_UNROLL for (int r = 0; r < NX; ++r) {
-                double f[NX];
-                sm.rowF(r, f);
-                double v;
-                if (i == 0) {
-                    v = dot<NX>(f, x);
-                } else if (i <= NX) {
-                    v = f[0] * (x[0] - (-lcol<NX>(L, 0, i - 1)));
-                    FK_UNROLL for (int c = 1; c < NX; ++c) v = fma(f[c], x[c] - (-lcol<NX>(L, c, i - 1)), v);
-                } else {
-                    v = f[0] * (x[0] - lcol<NX>(L, 0, i - 1 - NX));
-                    FK_UNROLL for (int c = 1; c < NX; ++c) v = fma(f[c], x[c] - lcol<NX>(L, c, i - 1 - NX), v);
-                }
-                xm[r] = (i == 0) ? sWm[0] * v : fma(sWm[i], v, xm[r]);
-            }
-            FK_STAGE();
-        }
-        // sweep 2: P- = sum_i Wc_i y_i y_i' + Q, y_i = F sigma_i - x-   (upper triangle).
-        // The points are recomputed from copies the optimiser cannot relate to sweep 1 (otherwise it
-        // common-subexpression-eliminates the recomputation by keeping all (2n+1) n values alive).
-        double Pn[PL];
-        FK_UNROLL for (int c = 0; c < NX; ++c) asm volatile("" : "+v"(x[c]));
-        FK_UNROLL for (int e = 0; e < PL; ++e) asm volatile("" : "+v"(L[e]));
-        FK_UNROLL for (int i = 0; i < KS; ++i) {
-            const double *mb = fresh();
-            const SharedModel sm{mb};
-            const double *sWm = mb + SharedModel::SIZE, *sWc = sWm + KS;
-            (void)sWm; (void)sWc;
-            double y[NX], wy[NX];
-            FK_UNROLL for (int r = 0; r < NX; ++r) {
-                double f[NX];
-                sm.rowF(r, f);
-                double v;
-                if (i == 0) {
-                    v = dot<NX>(f, x);
-                } else if (i <= NX) {
-                    v = f[0] * (x[0] - (-lcol<NX>(L, 0, i - 1)));
-                    FK_UNROLL for (int c = 1; c < NX; ++c) v = fma(f[c], x[c] - (-lcol<NX>(L, c, i - 1)), v);
-                } else {
-                    v = f[0] * (x[0] - lcol<NX>(L, 0, i - 1 - NX));
-                    FK_UNROLL for (int c = 1; c < NX; ++c) v = fma(f[c], x[c] - lcol<NX>(L, c, i - 1 - NX), v);
-                }
-                y[r] = v - xm[r];
-            }
-            FK_UNROLL for (int r = 0; r < NX; ++r) wy[r] = sWc[i] * y[r];
-            FK_UNROLL for (int a2 = 0; a2 < NX; ++a2)
-                FK_UNROLL for (int b = 0; b < NX; ++b)
-                    if (b >= a2)
-                        Pn[sym_idx<NX>(a2, b)] = (i == 0) ? y[a2] * wy[b] : fma(y[a2], wy[b], Pn[sym_idx<NX>(a2, b)]);
-            FK_STAGE();
-        }
-        FK_UNROLL for (int r = 0; r < NX; ++r) {
-            double q[NX];
-            sm.rowQ(r, q);
-            FK_UNROLL for (int b = 0; b < NX; ++b)
-                if (b >= r) P[sym_idx<NX>(r, b)] = Pn[sym_idx<NX>(r, b)] + q[b];
-            x[r] = xm[r];
-        }
-
-        // ---------------- update (UKF.py:462-481), sigma points regenerated from the prior (:407)
-        if (has_z) {
-            if (!chol_packed<NX>(P, a.scale, L)) st |= ST_NOT_PD;
-            // sweep 1: zp = sum_i Wm_i H sigma_i, point by point (index order 0, +k, -k)
-            double zp[NZ];
-            FK_UNROLL for (int i = 0; i < KS; ++i) {
-            const double *mb = fresh();
-            const SharedModel sm{mb};
-            const double *sWm = mb + SharedModel::SIZE, *sWc = sWm + KS;
-            (void)sWm; (void)sWc;
-                FK_UNROLL for (int r = 0; r < NZ; ++r) {
-                    double h[NX];
-                    sm.rowH(r, h);
-                    double v;
-                    if (i == 0) {
-                        v = dot<NX>(h, x);
-                    } else if (i <= NX) {
-                        v = h[0] * (x[0] - (-lcol<NX>(L, 0, i - 1)));
-                        FK_UNROLL for (int c = 1; c < NX; ++c) v = fma(h[c], x[c] - (-lcol<NX>(L, c, i - 1)), v);
-                    } else {
-                        v = h[0] * (x[0] - lcol<NX>(L, 0, i - 1 - NX));
-                        FK_UNROLL for (int c = 1; c < NX; ++c) v = fma(h[c], x[c] - lcol<NX>(L, c, i - 1 - NX), v);
-                    }
-                    zp[r] = (i == 0) ? sWm[0] * v : fma(sWm[i], v, zp[r]);
-                }
-                FK_STAGE();
-            }
-            // sweep 2: S = sum Wc_i d_i d_i' + R,  Pxz = sum Wc_i (sf_i - x) d_i',  d_i = H sigma_i - zp
-            double S[NZ * NZ], K[NX * NZ];
-            FK_UNROLL for (int c = 0; c < NX; ++c) asm volatile("" : "+v"(x[c]));
-            FK_UNROLL for (int e = 0; e < PL; ++e) asm volatile("" : "+v"(L[e]));
-            FK_UNROLL for (int i = 0; i < KS; ++i) {
-            const double *mb = fresh();
-            const SharedModel sm{mb};
-            const double *sWm = mb + SharedModel::SIZE, *sWc = sWm + KS;
-            (void)sWm; (void)sWc;
-                double d[NZ], wd[NZ];
-                FK_UNROLL for (int r = 0; r < NZ; ++r) {
-                    double h[NX];
-                    sm.rowH(r, h);
-                    double v;
-                    if (i == 0) {
-                        v = dot<NX>(h, x);
-                    } else if (i <= NX) {
-                        v = h[0] * (x[0] - (-lcol<NX>(L, 0, i - 1)));
-                        FK_UNROLL for (int c = 1; c < NX; ++c) v = fma(h[c], x[c] - (-lcol<NX>(L, c, i - 1)), v);
-                    } else {
-                        v = h[0] * (x[0] - lcol<NX>(L, 0, i - 1 - NX));
-                        FK_UNROLL for (int c = 1; c < NX; ++c) v = fma(h[c], x[c] - lcol<NX>(L, c, i - 1 - NX), v);
-                    }
-                    d[r] = v - zp[r];
-                }
-                FK_UNROLL for (int r = 0; r < NZ; ++r) wd[r] = sWc[i] * d[r];
-                FK_UNROLL for (int r = 0; r < NZ; ++r)
-                    FK_UNROLL for (int c = 0; c < NZ; ++c)
-                        S[r * NZ + c] = (i == 0) ? d[r] * wd[c] : fma(d[r], wd[c], S[r * NZ + c]);
-                FK_UNROLL for (int r = 0; r < NX; ++r) {
-                    double dx;
-                    if (i == 0) dx = x[r] - x[r];
-                    else if (i <= NX) dx = (x[r] - (-lcol<NX>(L, r, i - 1))) - x[r];
-                    else dx = (x[r] - lcol<NX>(L, r, i - 1 - NX)) - x[r];
-                    FK_UNROLL for (int c = 0; c < NZ; ++c) {
-                        const double term = sWc[i] * (dx * d[c]);
-                        K[r * NZ + c] = (i == 0) ? term : K[r * NZ + c] + term;
-                    }
-                }
-                FK_STAGE();
-            }
-            FK_UNROLL for (int r = 0; r < NZ; ++r) {
-                double rr[NZ];
-                sm.rowR(r, rr);
-                FK_UNROLL for (int c = 0; c < NZ; ++c) S[r * NZ + c] += rr[c];
-            }
-            // K = Pxz S^-1
-            double Lf[NZ * NZ], d[NZ], dinv[NZ];
-            FK_UNROLL for (int e = 0; e < NZ * NZ; ++e) Lf[e] = S[e];
-            if (!ldlt2<NZ>(Lf, d, dinv)) st |= ST_NOT_PD;
-            solve_rows_ldlt<NX, NZ>(Lf, dinv, K);
-            // x += K (z - zp)
-            FK_UNROLL for (int r = 0; r < NX; ++r) {
-                double acc = K[r * NZ] * (z[0] - zp[0]);
-                FK_UNROLL for (int c = 1; c < NZ; ++c) acc = fma(K[r * NZ + c], z[c] - zp[c], acc);
-                x[r] += acc;
-            }
-            // P -= K (S K'), upper triangle
-            FK_UNROLL for (int c2 = 0; c2 < NX; ++c2) {
-                double sk[NZ];                 // column c2 of S K'
-                FK_UNROLL for (int q = 0; q < NZ; ++q) {
-                    double acc = S[q * NZ] * K[c2 * NZ];
-                    FK_UNROLL for (int w = 1; w < NZ; ++w) acc = fma(S[q * NZ + w], K[c2 * NZ + w], acc);
-                    sk[q] = acc;
-                }
-                FK_UNROLL for (int q = 0; q < NZ; ++q) asm volatile("" : "+v"(sk[q]));
-                FK_UNROLL for (int r = 0; r < NX; ++r)
-                    if (r <= c2) {
-                        double acc = K[r * NZ] * sk[0];
-                        FK_UNROLL for (int q = 1; q < NZ; ++q) acc = fma(K[r * NZ + q], sk[q], acc);
-                        P[sym_idx<NX>(r, c2)] -= acc;
-                    }
-                FK_STAGE();
-            }
-        }
+        st |= ukf_linear_step_v2<NX, NZ>(x, P, z, has_z, a.scale, fresh);
         if (live) {
             if (a.means) store_rec<NX, 1, LAYOUT, false>(x, a.means + t * N * n, ln, n, 1);
             if (a.covs) {

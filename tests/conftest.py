@@ -33,7 +33,7 @@ def _helpers_built():
             "-o", os.path.join(hc, "libhostcheck.so"), os.path.join(hc, "hostcheck.cpp")],
            os.path.join(hc, "libhostcheck.so"),
            [os.path.join(hc, "hostcheck.cpp")] + [os.path.join(ROOT, "filterpy_amd", "csrc", h) for h in
-                                                 ("fk_math.hpp", "fk_math_sym.hpp", "fk_imm.hpp", "fk_exact_scan.hpp")])
+                                                 ("fk_math.hpp", "fk_math_sym.hpp", "fk_imm.hpp", "fk_exact_scan.hpp", "fk_ukf.hpp")])
 
 
 def golden(name):

@@ -669,3 +669,65 @@ extern "C" int hc_imm_batch(int n, int m, int nm, long T, const double *F, const
 #undef GO
     return -1;
 }
+
+
+// ---------------------------------------------------------------------------------------------------------
+// The register-lean organisation of the fused linear UKF step (filterpy_amd/csrc/fk_ukf.hpp, "V2" of
+// ukf_kernels.hip) on the host: T x { predict; update } for one track with exact dims, so that its arithmetic
+// can be held against the oracle without a GPU.
+#include "../../filterpy_amd/csrc/fk_ukf.hpp"
+
+namespace {
+template <int NX, int NZ>
+int ukf_v2_batch(long T, const double *F, const double *H, const double *Q, const double *R, const double *Wm,
+                 const double *Wc, double scale, const double *zs, const unsigned char *mask, double *x0,
+                 double *P0, double *means, double *covs)
+{
+    constexpr int PL = NX * (NX + 1) / 2, KS = 2 * NX + 1;
+    struct View {
+        fk::RegModel<NX, NZ> sm;
+        const double *Wm, *Wc;
+    };
+    View v;
+    std::copy(F, F + NX * NX, v.sm.F);
+    std::copy(Q, Q + NX * NX, v.sm.Q);
+    std::copy(H, H + NZ * NX, v.sm.H);
+    std::copy(R, R + NZ * NZ, v.sm.R);
+    double wm[KS], wc[KS];
+    std::copy(Wm, Wm + KS, wm);
+    std::copy(Wc, Wc + KS, wc);
+    v.Wm = wm;
+    v.Wc = wc;
+    auto fresh = [&]() -> const View & { return v; };
+    double x[NX], P[PL];
+    for (int i = 0; i < NX; ++i) {
+        x[i] = x0[i];
+        for (int j = i; j < NX; ++j) P[fk::sym_idx<NX>(i, j)] = P0[i * NX + j];
+    }
+    int st = 0;
+    for (long t = 0; t < T; ++t) {
+        double z[NZ];
+        for (int r = 0; r < NZ; ++r) z[r] = zs[t * NZ + r];
+        st |= fk::ukf_linear_step_v2<NX, NZ>(x, P, z, mask ? mask[t] != 0 : true, scale, fresh);
+        for (int i = 0; i < NX; ++i) {
+            means[t * NX + i] = x[i];
+            for (int j = 0; j < NX; ++j) covs[(t * NX + i) * NX + j] = P[fk::sym_idx<NX>(i, j)];
+        }
+    }
+    for (int i = 0; i < NX; ++i) {
+        x0[i] = x[i];
+        for (int j = 0; j < NX; ++j) P0[i * NX + j] = P[fk::sym_idx<NX>(i, j)];
+    }
+    return st;
+}
+}  // namespace
+
+extern "C" int hc_ukf_linear_v2(int n, int m, long T, const double *F, const double *H, const double *Q, const double *R,
+                                const double *Wm, const double *Wc, double scale, const double *zs,
+                                const unsigned char *mask, double *x0, double *P0, double *means, double *covs)
+{
+    if (n == 2 && m == 2) return ukf_v2_batch<2, 2>(T, F, H, Q, R, Wm, Wc, scale, zs, mask, x0, P0, means, covs);
+    if (n == 4 && m == 2) return ukf_v2_batch<4, 2>(T, F, H, Q, R, Wm, Wc, scale, zs, mask, x0, P0, means, covs);
+    if (n == 6 && m == 3) return ukf_v2_batch<6, 3>(T, F, H, Q, R, Wm, Wc, scale, zs, mask, x0, P0, means, covs);
+    return -1;
+}

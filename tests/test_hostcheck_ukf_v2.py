@@ -1,0 +1,78 @@
+"""The register-lean organisation of the fused linear UKF step (filterpy_amd/csrc/fk_ukf.hpp; the -DFK_UKF_V2 build
+of ukf_kernels.hip, not the default yet) compiled for the host and held against the oracle's UKF
+(oracle/ukf_oracle.py, pinned to the reference by tests/test_oracle_ukf.py) with fx = F x, hx = H x."""
+import ctypes
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+sys.path.insert(0, ROOT)
+from oracle import ukf_oracle  # noqa: E402
+
+
+def _v2(n, m, F, H, Q, R, Wm, Wc, scale, zs, mask, x0, P0):
+    lib = ctypes.CDLL(os.path.join(ROOT, "tests", "hostcheck", "libhostcheck.so"))
+    T = zs.shape[0]
+    c = lambda a: np.ascontiguousarray(a, dtype=np.float64)  # noqa: E731
+    F, H, Q, R, Wm, Wc, zs = map(c, (F, H, Q, R, Wm, Wc, zs))
+    x, P = c(x0).copy(), c(P0).copy()
+    means, covs = np.empty((T, n)), np.empty((T, n, n))
+    mk = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+    p = lambda a: None if a is None else a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+    st = lib.hc_ukf_linear_v2(ctypes.c_int(n), ctypes.c_int(m), ctypes.c_long(T), p(F), p(H), p(Q), p(R), p(Wm), p(Wc),
+                              ctypes.c_double(scale), p(zs), p(mk), p(x), p(P), p(means), p(covs))
+    assert st == 0, st
+    return means, covs, x, P
+
+
+@pytest.mark.parametrize("n,m", [(2, 2), (4, 2), (6, 3)])
+@pytest.mark.parametrize("abk", [(.1, 2., None), (1e-3, 2., 0.), (1., 2., .1)])
+def test_ukf_v2_step_matches_the_oracle(n, m, abk):
+    alpha, beta, kappa = abk
+    kappa = 3. - n if kappa is None else kappa
+    r = np.random.default_rng(n * 10 + m)
+    T = 40
+    F = np.eye(n) + 0.05 * np.triu(r.standard_normal((n, n)), 1)
+    H = np.eye(m, n) + 0.1 * r.standard_normal((m, n))
+    A = r.standard_normal((n, n))
+    Q = 0.01 * np.eye(n) + 0.002 * A @ A.T
+    B = r.standard_normal((m, m))
+    R = 0.5 * np.eye(m) + 0.05 * B @ B.T
+    x0 = r.standard_normal(n)
+    P0 = 10.0 * np.eye(n)
+    zs = r.standard_normal((T, m))
+    lam = alpha ** 2 * (n + kappa) - n
+    Wm, Wc = ukf_oracle.merwe_weights(n, alpha, beta, kappa)
+    mu_ref, cov_ref = ukf_oracle.ukf_batch_filter(x0, P0, list(zs), lambda s, d: F @ s, lambda s: H @ s, 0.1, Q, R,
+                                                  alpha, beta, kappa)
+    mu, cov, xf, Pf = _v2(n, m, F, H, Q, R, Wm, Wc, lam + n, zs, None, x0, P0)
+    rel = lambda a, b: np.max(np.abs(a - b)) / np.max(np.abs(b))  # noqa: E731
+    # Merwe's cancelling weights (Wm0 ~ -1e6 at alpha = 1e-3) amplify rounding: the package's UKF bar is 1e-9
+    tol = 1e-9 if alpha > 1e-2 else 1e-6
+    assert rel(mu, mu_ref) < tol and rel(cov, cov_ref) < tol
+    assert np.allclose(xf, mu[-1]) and np.allclose(Pf, cov[-1])
+    assert np.allclose(cov, np.swapaxes(cov, 1, 2))
+
+
+def test_ukf_v2_missing_measurements_skip_the_update():
+    n, m, T = 4, 2, 12
+    r = np.random.default_rng(5)
+    F = np.eye(n) + 0.05 * np.triu(r.standard_normal((n, n)), 1)
+    H = np.eye(m, n)
+    Q, R = 0.01 * np.eye(n), 0.5 * np.eye(m)
+    x0, P0 = r.standard_normal(n), 10.0 * np.eye(n)
+    zs = r.standard_normal((T, m))
+    mask = (np.arange(T) % 3 != 1).astype(np.uint8)
+    alpha, beta, kappa = .1, 2., -1.
+    lam = alpha ** 2 * (n + kappa) - n
+    Wm, Wc = ukf_oracle.merwe_weights(n, alpha, beta, kappa)
+    zl = [z if k else None for z, k in zip(zs, mask)]
+    mu_ref, cov_ref = ukf_oracle.ukf_batch_filter(x0, P0, zl, lambda s, d: F @ s, lambda s: H @ s, 0.1, Q, R,
+                                                  alpha, beta, kappa)
+    mu, cov, _, _ = _v2(n, m, F, H, Q, R, Wm, Wc, lam + n, zs, mask, x0, P0)
+    assert np.max(np.abs(mu - mu_ref)) / np.max(np.abs(mu_ref)) < 1e-9
+    assert np.max(np.abs(cov - cov_ref)) / np.max(np.abs(cov_ref)) < 1e-9
