@@ -40,75 +40,73 @@ class Saver(object):
 
     def __init__(self, kf, save_current=False, skip_private=False, skip_callable=False, ignore=()):
         import inspect
-        from collections import defaultdict
-        self._kf = kf
-        self._DL = defaultdict(list)
-        self._skip_private = skip_private
-        self._skip_callable = skip_callable
-        self._ignore = ignore
-        self._len = 0
-        # (name, property object) pairs like the reference keeps them: callers index [0]
-        self.properties = [(name, prop) for name, prop in
-                           inspect.getmembers(type(kf), lambda member: isinstance(member, property))
-                           if name not in ignore]
+        self._watched = kf
+        self._hist = {}                      # name -> list of per-epoch values, in first-seen order
+        self._epochs = 0
+        self._drop_private, self._drop_callable, self._ignored = skip_private, skip_callable, tuple(ignore)
+        # (name, property object) pairs, the form callers of the reference index with [0]
+        self.properties = [pair for pair in inspect.getmembers(type(kf), lambda member: isinstance(member, property))
+                           if pair[0] not in self._ignored]
         if save_current:
             self.save()
 
-    def _wanted(self, name, value):
-        if self._skip_private and name.startswith("_"):
-            return False
-        if self._skip_callable and callable(value):
-            return False
-        return name not in self._ignore
+    def _keep(self, name, value):
+        return not ((self._drop_private and name.startswith("_")) or (self._drop_callable and callable(value))
+                    or name in self._ignored)
+
+    def _publish(self):
+        """the histories are also attributes of the saver (lists until to_array())"""
+        self.__dict__.update(self._hist)
 
     def save(self):
         import copy
-        kf = self._kf
-        for name, _ in self.properties:                     # properties first: their lists lead the key order
-            self._DL[name].append(getattr(kf, name))
-        for name, value in copy.deepcopy(kf.__dict__).items():
-            if self._wanted(name, value):
-                self._DL[name].append(value)
-        self.__dict__.update(self._DL)
-        self._len += 1
+        snapshot = [(name, getattr(self._watched, name)) for name, _ in self.properties]   # properties lead the key order
+        snapshot += [(name, value) for name, value in copy.deepcopy(self._watched.__dict__).items()
+                     if self._keep(name, value)]
+        for name, value in snapshot:
+            self._hist.setdefault(name, []).append(value)
+        self._publish()
+        self._epochs += 1
 
     def __getitem__(self, key):
-        return self._DL[key]
+        return self._hist.setdefault(key, [])           # an unknown key reads as an empty history
 
     def __setitem__(self, key, newvalue):
-        self._DL[key] = newvalue
-        self.__dict__.update(self._DL)
+        self._hist[key] = newvalue
+        self._publish()
 
     def __len__(self):
-        return self._len
+        return self._epochs
 
     @property
     def keys(self):
-        return list(self._DL.keys())
+        return list(self._hist)
 
     def to_array(self, flatten=False):
         """Every history becomes one ndarray (the lists stay available through ``[]``).  Raises ValueError,
         leaving the attributes as lists, if some attribute changed shape between epochs."""
-        for key in self.keys:
+        arrays = {}
+        for name, values in self._hist.items():
             try:
-                self.__dict__[key] = np.array(self._DL[key])
+                arrays[name] = np.array(values)
             except Exception:
-                self.__dict__.update(self._DL)
-                raise ValueError("could not convert {} into np.array".format(key)) from None
+                self._publish()
+                raise ValueError("could not convert {} into np.array".format(name)) from None
+        self.__dict__.update(arrays)
         if flatten:
             self.flatten()
 
     def flatten(self):
         """(T, n, 1) histories of column vectors become (T, n) -- and (T,) when n = 1.  Histories that are not
         at least 3-D arrays are left alone, like in the reference (a (T, 1) history stays (T, 1)).  One way."""
-        for key in self.keys:
-            arr = self.__dict__[key]
+        for name in self._hist:
+            arr = self.__dict__[name]
             if not isinstance(arr, np.ndarray) or arr.ndim < 3 or arr.shape[2] != 1:
                 continue
             if arr.size != arr.shape[0] * arr.shape[1]:       # (T, n, 1, k...): not a column-vector history
                 continue
             arr = arr.reshape(arr.shape[0], arr.shape[1])
-            self.__dict__[key] = arr.ravel() if arr.shape[1] == 1 else arr
+            self.__dict__[name] = arr.ravel() if arr.shape[1] == 1 else arr
 
     def __repr__(self):
         return "<Saver object at {}\n  Keys: {}>".format(hex(id(self)), " ".join(self.keys))
