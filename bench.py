@@ -9,9 +9,12 @@ Inputs (z, x0, P0) are resident in HBM before the timed region.
 
     python bench.py --gpus N --steps K --warmup W
 
-N > 1: launched by torch.distributed.run, one rank per GPU; tracks shard across ranks
-(weak scaling: every rank filters its own 1e6 tracks, no data-path collective), then one
-RCCL all-gather of the summary state (final x of every track) per step.
+N > 1: one rank per GPU under torch.distributed.run -- either the caller launches it that way
+(RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment) or, when `python bench.py --gpus N`
+is started bare, this file re-executes itself under torch.distributed.run with N ranks (and exits
+with an error if the node has fewer than N GPUs).  Tracks shard across ranks (weak scaling: every
+rank filters its own 1e6 tracks, no data-path collective), then one RCCL all-gather of the summary
+state (final x of every track) per step.
 
 Prints ONE JSON line (rank 0) with `roofline` (HBM) and, at N=1, `cpu_baseline`
 (the NumPy oracle = the reference's algorithm, timed on this host's cores).
@@ -94,13 +97,13 @@ def _cpu_worker(args):
     return done, time.perf_counter() - t0
 
 
-def cpu_baseline(T, budget_s=10.0, max_procs=64):
+def cpu_baseline(T, budget_s=10.0, max_procs=None):
     """The NumPy oracle (= the reference's per-epoch NumPy loop, oracle/kf_oracle.py) on the host
-    cores, one single-threaded process per core (capped at `max_procs`), each filtering tracks
+    cores, one single-threaded process per core (all of them unless `max_procs` caps it), each filtering tracks
     of the same C2 workload for `budget_s` seconds; value = total track-steps / wall."""
     import multiprocessing as mp
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    cores = max(1, min(avail, max_procs))
+    cores = max(1, min(avail, max_procs) if max_procs else avail)      # every host core this process may use
     for v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
         os.environ[v] = "1"
     ctx = mp.get_context("spawn")
@@ -127,6 +130,74 @@ def pmc_traffic(layout):
         return None
 
 
+def parity_rel_err(got, ref):
+    """Worst normwise relative error over (step, track) records: max|got - ref| / max|ref| per vector / matrix
+    (tests/conftest.py::rel_err_rows).  A record whose reference is exactly zero (means_p at t = 0 with
+    x0 = 0) is measured absolutely; any NaN / Inf in `got` makes the result non-finite, which fails."""
+    g2 = np.asarray(got, dtype=float).reshape(got.shape[0] * got.shape[1], -1)
+    r2 = np.asarray(ref, dtype=float).reshape(g2.shape)
+    scale = np.max(np.abs(r2), axis=1)
+    scale[scale == 0] = 1.0
+    d = np.max(np.abs(g2 - r2), axis=1) / scale
+    return float("nan") if not np.all(np.isfinite(g2)) else float(np.max(d))
+
+
+def gpu_clocks():
+    """sclk / mclk / power of GPU 0 from rocm-smi (recorded next to the measurement: boxes of the pool differ)."""
+    import subprocess
+    try:
+        txt = subprocess.run(["rocm-smi", "-d", "0", "--showclocks", "--showpower", "--json"], capture_output=True,
+                             text=True, timeout=30).stdout
+        card = next(iter(json.loads(txt).values()))
+        keep = {k: v for k, v in card.items() if any(t in k.lower() for t in ("sclk", "mclk", "fclk", "power"))}
+        return keep or None
+    except Exception as e:                     # the measurement does not depend on it
+        return {"error": repr(e)}
+
+
+def selftest_cpu(args):
+    """--selftest-cpu: the N-rank control flow of this file (env -> process group -> contiguous shards -> per-step
+    all-gather of the summary state -> barrier + max-over-ranks timing -> ONE JSON line on rank 0) on the gloo
+    backend with CPU tensors.  The kernel launch is replaced by a stub that writes a known function of the
+    global track index, so the gathered state can be checked; nothing here is a measurement."""
+    import torch
+    import torch.distributed as dist
+    from filterpy_amd import parallel
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world_env:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world_env}: launch one rank per GPU")
+    rank, world = parallel.init_from_env(backend="gloo")
+    N, n = min(args.tracks, 1000), 4
+    x = torch.empty(N, n, dtype=torch.float64)
+    gathered = torch.empty((world, N, n), dtype=torch.float64) if world > 1 else None
+
+    def step():
+        x.copy_((torch.arange(N * n, dtype=torch.float64).reshape(N, n) + rank * N * n) * 0.5)   # stub "kernel"
+        if world > 1:
+            parallel.allgather_summary(x, gathered)
+
+    for _ in range(args.warmup):
+        step()
+    parallel.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    parallel.barrier()
+    elapsed = parallel.max_over_ranks(time.perf_counter() - t0)
+    ok = True
+    if world > 1:
+        want = torch.arange(world * N * n, dtype=torch.float64).reshape(world, N, n) * 0.5
+        ok = bool(torch.equal(gathered, want))
+    if rank == 0:
+        print(json.dumps({"metric": "selftest", "value": None, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": 1e3 * elapsed / max(1, args.steps), "data": "selftest-stub", "gather_ok": ok,
+                          "scaling": "weak"}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+    if not ok:
+        raise SystemExit("selftest: gathered summary state is wrong")
+
+
 # -------------------------------------------------------------------- main --
 def main():
     ap = argparse.ArgumentParser()
@@ -139,18 +210,35 @@ def main():
                     help="record layout of z and the outputs: aos = NumPy C order [T][N][n][n] (default), soa = [T][n*n][N]")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--cpu-procs", type=int, default=0, help="cap the CPU baseline's process count (0 = every host core)")
+    ap.add_argument("--parity-tracks", type=int, default=1024,
+                    help="parity sample: the first K tracks + K random tracks of the timed buffers against the oracle")
+    ap.add_argument("--selftest-cpu", action="store_true",
+                    help="TEST ONLY (tests/test_parallel_gloo.py): drive the launch / shard / all-gather / timing path with the "
+                         "gloo backend on CPU tensors and a stub in place of the kernel launch; the line it prints is marked "
+                         "\"data\": \"selftest-stub\" and carries no measurement")
     args = ap.parse_args()
+
+    from filterpy_amd import parallel
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: become `torch.distributed.run` with one rank per GPU
+        parallel.relaunch_under_torchrun(args.gpus, [os.path.abspath(__file__)] + sys.argv[1:],
+                                         require_devices=not args.selftest_cpu)
+    if args.selftest_cpu:
+        return selftest_cpu(args)
 
     import torch
     import torch.distributed as dist
     from filterpy_amd import _engine as E
-    from filterpy_amd import parallel
     from oracle import kf_oracle
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU")
+    if not torch.cuda.is_available() or torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"rank {local_rank}: no GPU {local_rank} visible ({torch.cuda.device_count()} device(s)); "
+                         "bench.py has no CPU path")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     rank, world = parallel.init_from_env(backend="nccl", device=device)
@@ -196,9 +284,12 @@ def main():
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in events])) if events else float("nan")
     assert int(status.abs().max()) == 0, "kernel flagged tracks"
 
-    # parity on the timed buffers: a sample of tracks against the oracle (not timed)
-    sample = [0, 1, 255, 256, N // 2, N - 1]
-    idx = torch.tensor(sample, device=device)
+    # parity on the timed buffers (not timed): the first K tracks + K random tracks, all T steps, all four
+    # outputs, against the oracle (K = 1024); normwise per vector / matrix, NaN fails
+    K = max(1, min(args.parity_tracks, N // 2))
+    rs = np.random.RandomState(99 + rank)
+    sample = np.concatenate([np.arange(K), K + np.sort(rs.choice(N - K, size=K, replace=False))])
+    idx = torch.as_tensor(sample, device=device)
     if layout == "aos":
         zs_h = z[:, idx].cpu().numpy()
         got = [means[:, idx].cpu().numpy(), covs[:, idx].cpu().numpy().reshape(T, -1, n, n),
@@ -209,11 +300,8 @@ def main():
         got = [tr(means), tr(covs).reshape(T, -1, n, n), tr(means_p), tr(covs_p).reshape(T, -1, n, n)]
     ref = kf_oracle.kf_batch_filter_tracks(np.zeros((len(sample), n)), np.tile(100.0 * np.eye(n), (len(sample), 1, 1)),
                                            zs_h, F, Q, H, R, tracks=range(len(sample)))
-    worst = 0.0
-    for g_, r_ in zip(got, ref):
-        g2, r2 = g_.reshape(T * len(sample), -1), r_.reshape(T * len(sample), -1)
-        worst = max(worst, float(np.max(np.max(np.abs(g2 - r2), axis=1) / np.max(np.abs(r2), axis=1))))
-    assert worst < 1e-10, f"parity vs oracle failed: {worst}"
+    worst = max(parity_rel_err(g_, r_) for g_, r_ in zip(got, ref))
+    assert np.isfinite(worst) and worst < 1e-10, f"parity vs oracle failed: {worst}"
 
     if rank == 0:
         units = float(N) * T * world * args.steps
@@ -232,10 +320,11 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(layout),
                          "kernel": "fk::kf_fast_kernel<4,2," + layout + ",nomask,outs> (variant " + os.environ.get("FK_FAST_VARIANT", "0") + ")", "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_launch": alg_bytes},
-            "parity_max_rel_vs_oracle": worst,
+            "parity_max_rel_vs_oracle": worst, "parity_tracks": int(len(sample)),
+            "gpu_clocks": gpu_clocks(),
         }
         if world == 1 and not args.no_cpu:
-            out["cpu_baseline"] = cpu_baseline(T, args.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(T, args.cpu_seconds, args.cpu_procs or None)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

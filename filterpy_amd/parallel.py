@@ -15,6 +15,31 @@ def shard_bounds(n_units, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def relaunch_under_torchrun(n_ranks, argv, require_devices=True):
+    """`script --gpus N` started WITHOUT a launcher: replace this process by
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... script argv`, one rank per GPU of this
+    node (rendezvous on 127.0.0.1, a free port).  Fails loudly when the node has fewer than N GPUs.  Never returns."""
+    import sys
+    if require_devices:
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < n_ranks:
+            raise SystemExit(f"--gpus {n_ranks} requested but only {have} GPU(s) are visible on this node")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={int(n_ranks)}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port())] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL across processes needs it on this driver
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os.execvpe(sys.executable, cmd, env)
+
+
 def init_from_env(backend=None, device=None):
     """Initialise the default process group from RANK / WORLD_SIZE / MASTER_* (torchrun sets them).
     Returns (rank, world).  A single process needs no group."""

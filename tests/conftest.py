@@ -40,12 +40,28 @@ def golden(name):
     return np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
 
 
+def _log_err(err):
+    """FK_PARITY_LOG=<file>: every measured parity error is appended with the asserting test line, so one
+    GPU run shows the margin of every assertion (profiles/rNN/parity_errors.jsonl)."""
+    path = os.environ.get("FK_PARITY_LOG")
+    if not path:
+        return
+    import inspect
+    import json
+    fr = inspect.stack()[2]
+    with open(path, "a") as fh:
+        fh.write(json.dumps({"test": os.environ.get("PYTEST_CURRENT_TEST", "").split(" ")[0],
+                             "at": f"{os.path.basename(fr.filename)}:{fr.lineno}", "err": err}) + "\n")
+
+
 def rel_err(a, b):
     """normwise relative error per array: max|a-b| / max(|b|)  (SURVEY §7 hard part 4)."""
     a, b = np.asarray(a, dtype=float), np.asarray(b, dtype=float)
     assert a.shape == b.shape, (a.shape, b.shape)
     scale = np.max(np.abs(b)) if b.size else 1.0
-    return float(np.max(np.abs(a - b)) / (scale if scale > 0 else 1.0)) if b.size else 0.0
+    err = float(np.max(np.abs(a - b)) / (scale if scale > 0 else 1.0)) if b.size else 0.0
+    _log_err(err)
+    return err
 
 
 def rel_err_rows(a, b):
@@ -55,4 +71,17 @@ def rel_err_rows(a, b):
     a2, b2 = a.reshape(a.shape[0], -1), b.reshape(b.shape[0], -1)
     scale = np.max(np.abs(b2), axis=1)
     scale[scale == 0] = 1.0
-    return float(np.max(np.max(np.abs(a2 - b2), axis=1) / scale))
+    err = float(np.max(np.max(np.abs(a2 - b2), axis=1) / scale))
+    _log_err(err)
+    return err
+
+
+def ukf_tol(ci, key):
+    """Parity bar of UKF golden case `ci`, output `key` (mu, cov, rts_x, rts_P, rts_K): the stated 1e-10, unless
+    the REFERENCE's own outputs move by more than a quarter of that under one-ulp input perturbations
+    (tests/golden/ukf_conditioning.json, written by make_conditioning.py from the live reference) -- then
+    4 x that spread.  Only the alpha = 1e-3 case (Wm[0] ~ -1e6) is affected: mu / rts_x 2.3e-9 in the reference."""
+    import json
+    with open(os.path.join(GOLDEN, "ukf_conditioning.json")) as fh:
+        spread = json.load(fh)[f"c{ci}"]["spread"][key]
+    return max(1e-10, 4.0 * spread)

@@ -4,7 +4,7 @@ from the live reference -- the reference's own relational tests re-expressed
 import numpy as np
 import pytest
 
-from conftest import golden, rel_err_rows
+from conftest import golden, rel_err_rows, ukf_tol
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-10
@@ -30,7 +30,7 @@ def test_config1_drop_in():
         assert kf.x.shape == x0.shape and rel_err_rows(kf.P[None], g[f"{tag}_cov"][-1:]) < TOL
         xs, Ps, Ks, Pps = kf.rts_smoother(mu, cov)
         for got, key in ((xs, "xs"), (Ps, "Ps"), (Ks, "Ks"), (Pps, "Pps")):
-            assert got.shape == g[f"{tag}_{key}"].shape and rel_err_rows(got, g[f"{tag}_{key}"]) < 1e-9, key
+            assert got.shape == g[f"{tag}_{key}"].shape and rel_err_rows(got, g[f"{tag}_{key}"]) < 1e-10, key
 
 
 @pytest.mark.parametrize("n,m", [(1, 1), (2, 1), (4, 2), (6, 3), (9, 3)])
@@ -46,16 +46,16 @@ def test_single_steps_and_attributes(n, m):
     assert rel_err_rows(kf.x[None], g[p + "xp"][None]) < TOL and rel_err_rows(kf.P[None], g[p + "Pp"][None]) < TOL
     assert np.array_equal(kf.x_prior, kf.x)
     xu, Pu = kf.get_update(g[p + "z"])
-    assert rel_err_rows(np.atleast_1d(xu)[None], np.atleast_1d(g[p + "x"])[None]) < 1e-9 and rel_err_rows(Pu[None], g[p + "P"][None]) < 1e-9
+    assert rel_err_rows(np.atleast_1d(xu)[None], np.atleast_1d(g[p + "x"])[None]) < 1e-10 and rel_err_rows(Pu[None], g[p + "P"][None]) < 1e-10
     assert np.array_equal(kf.x, kf.x_prior) and np.all(kf.K == 0)
     assert kf.get_update(None)[0] is kf.x
     kf.update(g[p + "z"])
     for attr, key in (("x", "x"), ("P", "P"), ("y", "y"), ("K", "K"), ("S", "S"), ("SI", "SI")):
         got, ref = np.atleast_2d(getattr(kf, attr)), np.atleast_2d(g[p + key])
-        assert got.shape == ref.shape and rel_err_rows(got[None], ref[None]) < 1e-9, key
-    assert abs(kf.log_likelihood - g[p + "loglik"]) < 1e-8 * max(1, abs(g[p + "loglik"]))
-    assert abs(kf.mahalanobis - g[p + "maha"]) < 1e-8 * max(1, g[p + "maha"])
-    assert abs(kf.likelihood - g[p + "lik"]) <= 1e-8 * g[p + "lik"] + 1e-300
+        assert got.shape == ref.shape and rel_err_rows(got[None], ref[None]) < 1e-10, key
+    assert abs(kf.log_likelihood - g[p + "loglik"]) < 1e-10 * max(1, abs(g[p + "loglik"]))
+    assert abs(kf.mahalanobis - g[p + "maha"]) < 1e-10 * max(1, g[p + "maha"])
+    assert abs(kf.likelihood - g[p + "lik"]) <= 1e-10 * g[p + "lik"] + 1e-300
     # scalar quirks
     kf = _kf(n, m, g[p + "x0"], g[p + "P0"], g[p + "F"], g[p + "Q"], g[p + "H"], g[p + "R"])
     kf.Q = 0.37
@@ -65,15 +65,15 @@ def test_single_steps_and_attributes(n, m):
     kf.predict(Q=0.37)
     assert rel_err_rows(kf.P[None], g[p + "qscal_kw_P"][None]) < TOL
     kf.update(g[p + "z"], R=0.81)
-    assert rel_err_rows(kf.P[None], g[p + "rscal_kw_P"][None]) < 1e-9
+    assert rel_err_rows(kf.P[None], g[p + "rscal_kw_P"][None]) < 1e-10
     # module-level twins
     from filterpy_amd.kalman import predict, update
     xp, Pp = predict(g[p + "x0"], g[p + "P0"], g[p + "F"], g[p + "Q"])
     assert rel_err_rows(np.atleast_1d(xp)[None], g[p + "m_xp"][None]) < TOL
     x2, P2, y2, K2, S2, ll = update(xp, Pp, g[p + "z"], g[p + "R"], g[p + "H"], return_all=True)
-    assert rel_err_rows(np.atleast_2d(P2)[None], g[p + "m_P"][None]) < 1e-9
-    assert rel_err_rows(np.atleast_2d(K2)[None], g[p + "m_K"][None]) < 1e-9
-    assert abs(ll - g[p + "m_ll"]) < 1e-8 * max(1, abs(g[p + "m_ll"]))
+    assert rel_err_rows(np.atleast_2d(P2)[None], g[p + "m_P"][None]) < 1e-10
+    assert rel_err_rows(np.atleast_2d(K2)[None], g[p + "m_K"][None]) < 1e-10
+    assert abs(ll - g[p + "m_ll"]) < 1e-10 * max(1, abs(g[p + "m_ll"]))
 
 
 def test_univariate_scalars_like_reference():
@@ -99,13 +99,13 @@ def test_batch_lists_class_and_module(n, m):
         assert rel_err_rows(got, g[p + key]) < TOL, key
     sm = kf.rts_smoother(out[0], out[1], Fs=Fs, Qs=Qs)
     for got, key in zip(sm, ("rts_x", "rts_P", "rts_K", "rts_Pp")):
-        assert rel_err_rows(got, g[p + key]) < 1e-9, key
+        assert rel_err_rows(got, g[p + key]) < 1e-10, key
     out2 = batch_filter(g[p + "x0"], g[p + "P0"], list(g[p + "zs"]), Fs, Qs, Hs, Rs)
     for got, key in zip(out2, ("mod_mu", "mod_cov", "mod_mup", "mod_covp")):
         assert rel_err_rows(got, g[p + key]) < TOL, key
     sm2 = rts_smoother(out2[0], out2[1], Fs, Qs)
     for got, key in zip(sm2, ("rtsm_x", "rtsm_P", "rtsm_K", "rtsm_Pp")):
-        assert rel_err_rows(got, g[p + key]) < 1e-9, key
+        assert rel_err_rows(got, g[p + key]) < 1e-10, key
 
 
 def test_none_measurements_and_update_first():
@@ -156,7 +156,7 @@ def test_bank_api():
         for trk in (0, 256, N - 1):
             assert rel_err_rows(mu[:, trk], g[p + "plain_mu"]) < TOL and rel_err_rows(covp[:, trk], g[p + "plain_covp"]) < TOL
         xs, Ps, Ks, Pps = bank.rts_smoother(mu, cov)
-        assert rel_err_rows(Ps[:, N - 1], g[p + "rts_P"]) < 1e-9
+        assert rel_err_rows(Ps[:, N - 1], g[p + "rts_P"]) < 1e-10
         # step-by-step equals the batch
         bank.x, bank.P = np.tile(g[p + "x0"], (N, 1)), np.tile(g[p + "P0"], (N, 1, 1))
         for t in range(3):
@@ -171,28 +171,27 @@ def test_ukf_general_callables_vs_reference():
     g = golden("ukf_merwe")
     for ci, (n, m, alpha, beta, kappa) in enumerate(g["cases"]):
         n, m = int(n), int(m)
-        if alpha < 0.1:
-            continue
+        tmu, tcov = ukf_tol(ci, "mu"), ukf_tol(ci, "cov")      # 1e-10 except alpha = 1e-3 (reference spread 2.3e-9)
         p = f"c{ci}_"
         F, H = g[p + "F"], g[p + "H"]
         pts = MerweScaledSigmaPoints(n, alpha, beta, kappa)
         ukf = UnscentedKalmanFilter(n, m, dt=1.0, hx=lambda x: H @ x, fx=lambda x, dt: F @ x, points=pts)
         ukf.x, ukf.P, ukf.Q, ukf.R = g[p + "x0"].copy(), g[p + "P0"].copy(), g[p + "Q"].copy(), g[p + "R"].copy()
         ukf.predict()
-        assert rel_err_rows(ukf.x[None], g[p + "s1_xp"][None]) < 1e-9 and rel_err_rows(ukf.P[None], g[p + "s1_Pp"][None]) < 1e-9
-        assert rel_err_rows(ukf.sigmas_f[None], g[p + "s1_sigmas_f"][None]) < 1e-9
+        assert rel_err_rows(ukf.x[None], g[p + "s1_xp"][None]) < tmu and rel_err_rows(ukf.P[None], g[p + "s1_Pp"][None]) < tcov
+        assert rel_err_rows(ukf.sigmas_f[None], g[p + "s1_sigmas_f"][None]) < 1e-10
         ukf.update(g[p + "zs"][0])
         for attr, key in (("x", "s1_x"), ("P", "s1_P"), ("K", "s1_K"), ("S", "s1_S"), ("y", "s1_y")):
-            assert rel_err_rows(np.atleast_2d(getattr(ukf, attr))[None], np.atleast_2d(g[p + key])[None]) < 1e-8, (ci, key)
+            assert rel_err_rows(np.atleast_2d(getattr(ukf, attr))[None], np.atleast_2d(g[p + key])[None]) < (tmu if attr in "xyK" else tcov), (ci, key)
         ukf.x, ukf.P = g[p + "x0"].copy(), g[p + "P0"].copy()
         zs = list(g[p + "zs"][:8]) if m > 1 else [np.array([z[0]]) for z in g[p + "zs"][:8]]
         mu, cov = ukf.batch_filter(zs)
-        assert rel_err_rows(mu, g[p + "mu"][:8]) < 1e-8 and rel_err_rows(cov, g[p + "cov"][:8]) < 1e-8
+        assert rel_err_rows(mu, g[p + "mu"][:8]) < tmu and rel_err_rows(cov, g[p + "cov"][:8]) < tcov
         # linear matrices -> fused kernel, same numbers
         ukf2 = UnscentedKalmanFilter(n, m, dt=1.0, hx=H, fx=F, points=pts)
         ukf2.x, ukf2.P, ukf2.Q, ukf2.R = g[p + "x0"].copy(), g[p + "P0"].copy(), g[p + "Q"].copy(), g[p + "R"].copy()
         mu2, cov2 = ukf2.batch_filter(list(g[p + "zs"]))
-        assert rel_err_rows(mu2, g[p + "mu"]) < 1e-9 and rel_err_rows(cov2, g[p + "cov"]) < 1e-9
+        assert rel_err_rows(mu2, g[p + "mu"]) < tmu and rel_err_rows(cov2, g[p + "cov"]) < tcov
 
 
 def test_unscented_transform_and_sigma_points_api():
@@ -203,7 +202,7 @@ def test_unscented_transform_and_sigma_points_api():
     sig = pts.sigma_points(g[p + "x0"], g[p + "P0"])
     assert sig.shape == (13, 6) and rel_err_rows(sig[None], g[p + "sigmas"][None]) < 1e-12
     x, P = unscented_transform(sig, pts.Wm, pts.Wc, g[p + "Q"])
-    assert rel_err_rows(x[None], g[p + "ut_x"][None]) < 1e-9 and rel_err_rows(P[None], g[p + "ut_P"][None]) < 1e-9
+    assert rel_err_rows(x[None], g[p + "ut_x"][None]) < 1e-10 and rel_err_rows(P[None], g[p + "ut_P"][None]) < 1e-10
     with pytest.raises(ValueError):
         pts.sigma_points(np.zeros(5), np.eye(5))
     with pytest.raises(np.linalg.LinAlgError):
@@ -270,10 +269,10 @@ def test_saver_histories_drop_in(n, m):
     for k in Saver.KEYS:
         got, ref = np.array(s.h[k]), g[p + k]
         assert got.shape == ref.shape, (k, got.shape, ref.shape)
-        assert np.allclose(got, ref, rtol=1e-9, atol=1e-11), k
-    assert np.allclose(s.h["log_likelihood"], g[p + "log_likelihood"], rtol=1e-8, atol=1e-8)
-    assert np.allclose(s.h["mahalanobis"], g[p + "mahalanobis"], rtol=1e-8, atol=1e-10)
-    assert np.allclose(s.h["likelihood"], g[p + "likelihood"], rtol=1e-7, atol=1e-300)
+        assert np.allclose(got, ref, rtol=1e-10, atol=1e-11), k
+    assert np.allclose(s.h["log_likelihood"], g[p + "log_likelihood"], rtol=1e-10, atol=1e-10)
+    assert np.allclose(s.h["mahalanobis"], g[p + "mahalanobis"], rtol=1e-10, atol=1e-10)
+    assert np.allclose(s.h["likelihood"], g[p + "likelihood"], rtol=1e-10, atol=1e-300)
 
 
 def test_bank_extras_in_kernel_likelihood():
@@ -291,11 +290,11 @@ def test_bank_extras_in_kernel_likelihood():
         out = bank.batch_filter(zs, mask=mask, extras=("y", "K", "S", "SI", "log_likelihood", "mahalanobis"))
         hist = out[4]
         for trk in (0, 255, 256, N - 1):
-            assert np.allclose(hist["K"][:, trk], g[p + "K"], rtol=1e-9, atol=1e-11)
-            assert np.allclose(hist["S"][:, trk], g[p + "S"], rtol=1e-9, atol=1e-11)
-            assert np.allclose(hist["y"][:, trk], g[p + "y"][..., 0], rtol=1e-9, atol=1e-11)
+            assert np.allclose(hist["K"][:, trk], g[p + "K"], rtol=1e-10, atol=1e-11)
+            assert np.allclose(hist["S"][:, trk], g[p + "S"], rtol=1e-10, atol=1e-11)
+            assert np.allclose(hist["y"][:, trk], g[p + "y"][..., 0], rtol=1e-10, atol=1e-11)
             # epochs before the first measurement have S = 0: the reference's allow_singular logpdf returns a
             # pseudo-determinant based value there; compare where S is defined
             ok = np.abs(g[p + "S"]).reshape(len(mask), -1).max(axis=1) > 0
-            assert np.allclose(hist["log_likelihood"][ok, trk], g[p + "log_likelihood"][ok], rtol=1e-8, atol=1e-8)
-            assert np.allclose(hist["mahalanobis"][:, trk], g[p + "mahalanobis"], rtol=1e-8, atol=1e-10)
+            assert np.allclose(hist["log_likelihood"][ok, trk], g[p + "log_likelihood"][ok], rtol=1e-10, atol=1e-10)
+            assert np.allclose(hist["mahalanobis"][:, trk], g[p + "mahalanobis"], rtol=1e-10, atol=1e-10)

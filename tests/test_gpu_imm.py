@@ -65,10 +65,10 @@ def test_imm_goldens(n, m, nm, layout):
         assert rel_err_rows(r["x_out"][:, trk], g[p + "x"]) < TOL and rel_err_rows(r["P_out"][:, trk], g[p + "P"]) < TOL
         assert rel_err_rows(r["x_prior_out"][:, trk], g[p + "xp"]) < TOL
         assert rel_err_rows(r["P_prior_out"][:, trk], g[p + "Pp"]) < TOL
-        assert np.allclose(r["mu_out"][:, trk], g[p + "mu"], rtol=1e-9, atol=1e-14)
-        assert np.allclose(r["likelihood_out"][:, trk], g[p + "L"], rtol=1e-9, atol=1e-300)
+        assert np.allclose(r["mu_out"][:, trk], g[p + "mu"], rtol=1e-10, atol=1e-14)
+        assert np.allclose(r["likelihood_out"][:, trk], g[p + "L"], rtol=1e-10, atol=1e-300)
         assert rel_err_rows(r["xs"][trk], g[p + "xs_final"]) < TOL and rel_err_rows(r["Ps"][trk], g[p + "Ps_final"]) < TOL
-        assert np.allclose(r["mu"][trk], g[p + "mu"][-1], rtol=1e-9, atol=1e-14)
+        assert np.allclose(r["mu"][trk], g[p + "mu"][-1], rtol=1e-10, atol=1e-14)
 
 
 @pytest.mark.parametrize("layout", ["soa", "aos"])
@@ -94,8 +94,8 @@ def test_imm_seeded_bank_vs_oracle(n, m, nm, layout):
         x, P, mu, xp, Pp, L = imm_oracle.imm_batch(xs0[trk], Ps0[trk], mu0[trk], M, zs[:, trk], Fs, Qs, Hs, Rs)
         assert rel_err_rows(r["x_out"][:, trk], x) < TOL and rel_err_rows(r["P_out"][:, trk], P) < TOL
         assert rel_err_rows(r["x_prior_out"][:, trk], xp) < TOL and rel_err_rows(r["P_prior_out"][:, trk], Pp) < TOL
-        assert np.allclose(r["mu_out"][:, trk], mu, rtol=1e-9, atol=1e-14)
-        assert np.allclose(r["likelihood_out"][:, trk], L, rtol=1e-9, atol=1e-300)
+        assert np.allclose(r["mu_out"][:, trk], mu, rtol=1e-10, atol=1e-14)
+        assert np.allclose(r["likelihood_out"][:, trk], L, rtol=1e-10, atol=1e-300)
     # properties that hold for every track: mode probabilities sum to one, P symmetric
     assert np.abs(r["mu_out"].sum(axis=-1) - 1).max() < 1e-14
     assert np.abs(r["P_out"] - np.swapaxes(r["P_out"], -1, -2)).max() == 0.0
@@ -129,13 +129,13 @@ def test_imm_class_drop_in(n, m, nm, column):
         imm.update(z.reshape(-1, 1) if column else z)
         assert rel_err_rows(imm.x, shp(g[p + "x"][t])) < TOL and rel_err_rows(imm.P, g[p + "P"][t]) < TOL
         assert rel_err_rows(imm.x_post, shp(g[p + "x"][t])) < TOL
-        assert np.allclose(imm.mu, g[p + "mu"][t], rtol=1e-9, atol=1e-14)
-        assert np.allclose(imm.likelihood, g[p + "L"][t], rtol=1e-9, atol=1e-300)
+        assert np.allclose(imm.mu, g[p + "mu"][t], rtol=1e-10, atol=1e-14)
+        assert np.allclose(imm.likelihood, g[p + "L"][t], rtol=1e-10, atol=1e-300)
         assert imm.filters[0].x.shape == ((n, 1) if column else (n,))
     # the remaining steps in one launch; the object ends where the reference ends
     xs, Ps, mus = imm.batch_filter(g[p + "zs"][10:])
     assert rel_err_rows(xs.reshape(-1, n), g[p + "x"][10:]) < TOL and rel_err_rows(Ps, g[p + "P"][10:]) < TOL
-    assert np.allclose(mus, g[p + "mu"][10:], rtol=1e-9, atol=1e-14)
+    assert np.allclose(mus, g[p + "mu"][10:], rtol=1e-10, atol=1e-14)
     for j in range(nm):
         assert rel_err_rows(imm.filters[j].x.reshape(-1), g[p + "xs_final"][j]) < TOL
         assert rel_err_rows(imm.filters[j].P, g[p + "Ps_final"][j]) < TOL
@@ -206,8 +206,8 @@ def test_mmae_goldens_c_abi(n, m, nm, layout):
     xs = E.from_records(dxs, layout, 0, (nm, n))
     for trk in (0, 64, N - 1):
         assert rel_err_rows(x[:, trk], g[p + "x"]) < TOL and rel_err_rows(P[:, trk], g[p + "P"]) < TOL
-        assert np.allclose(pr[:, trk], g[p + "p"], rtol=1e-9, atol=1e-14)
-        assert np.allclose(L[:, trk], g[p + "L"], rtol=1e-9, atol=1e-300)
+        assert np.allclose(pr[:, trk], g[p + "p"], rtol=1e-10, atol=1e-14)
+        assert np.allclose(L[:, trk], g[p + "L"], rtol=1e-10, atol=1e-300)
         assert rel_err_rows(xs[trk], g[p + "xs_final"]) < TOL
 
 
@@ -229,11 +229,11 @@ def test_mmae_class_drop_in(n, m, nm, column):
         bank.update(z.reshape(-1, 1) if column else z)
         assert bank.x.shape == ((n, 1) if column else (n,))
         assert rel_err_rows(bank.x, shp(q["x"][t])) < TOL and rel_err_rows(bank.P, q["P"][t]) < TOL
-        assert np.allclose(bank.p, q["p"][t], rtol=1e-9, atol=1e-14)
+        assert np.allclose(bank.p, q["p"][t], rtol=1e-10, atol=1e-14)
     assert rel_err_rows(bank.x_prior, shp(q["x"][10])) < TOL        # prior = the estimate before the last predict
     xs, Ps, ps = bank.batch_filter(q["zs"][12:])
     assert rel_err_rows(xs.reshape(-1, n), q["x"][12:]) < TOL and rel_err_rows(Ps, q["P"][12:]) < TOL
-    assert np.allclose(ps, q["p"][12:], rtol=1e-9, atol=1e-14)
+    assert np.allclose(ps, q["p"][12:], rtol=1e-10, atol=1e-14)
     for j in range(nm):
         assert rel_err_rows(bank.filters[j].x.reshape(-1), q["xs_final"][j]) < TOL
 

@@ -107,7 +107,7 @@ def test_rts_goldens(n, m, layout):
     out = run_rts(Xs, Ps, g[p + "F"], g[p + "Q"], layout=layout)
     for got, key in zip(out, ("rts_x", "rts_P", "rts_K", "rts_Pp")):
         for trk in (0, 64, N - 1):
-            assert rel_err_rows(got[:, trk], g[p + key]) < 1e-9, (key, trk)
+            assert rel_err_rows(got[:, trk], g[p + key]) < 1e-10, (key, trk)
 
 
 @pytest.mark.parametrize("n,m", [(2, 1), (4, 2), (9, 3)])
@@ -122,7 +122,7 @@ def test_rts_index_conventions(n, m):
         Xs, Ps = tile_tracks(g[p + src + "mu"], N, 1), tile_tracks(g[p + src + "cov"], N, 1)
         out = run_rts(Xs, Ps, g[p + "Fs"], g[p + "Qs"], mode=FK_MODEL_PER_STEP, convention=conv)
         for got, key in zip(out, ("x", "P", "K", "Pp")):
-            assert rel_err_rows(got[:, 5], g[p + pre + key]) < 1e-9, (conv, key)
+            assert rel_err_rows(got[:, 5], g[p + pre + key]) < 1e-10, (conv, key)
 
 
 def test_status_flags_non_pd():
@@ -233,7 +233,7 @@ def test_multilane_rts_9_vs_oracle(N):
         got = run_rts(Xs, Ps, F, Q, layout="soa", convention=conv)
         ref = kf_oracle.rts_smoother_tracks(Xs, Ps, F, Q, tracks=sample, convention=name)
         for k in range(4):
-            assert rel_err_rows(_per_track(got[k][:, sample]), _per_track(ref[k])) < 1e-9, (name, k)
+            assert rel_err_rows(_per_track(got[k][:, sample]), _per_track(ref[k])) < 1e-10, (name, k)
 
 
 @pytest.mark.parametrize("N", [1, 2, 3, 16, 17, 64, 65, 66, 130])
@@ -259,7 +259,7 @@ def test_multilane_small_shapes(N):
         sm = run_rts(ref[0], ref[1], F, Q, layout="soa")
         rr = kf_oracle.rts_smoother_tracks(ref[0], ref[1], F, Q, tracks=range(N))
         for k in range(4):
-            assert rel_err_rows(_per_track(sm[k]), _per_track(rr[k])) < 1e-9, (T, "rts", k)
+            assert rel_err_rows(_per_track(sm[k]), _per_track(rr[k])) < 1e-10, (T, "rts", k)
 
 
 @pytest.mark.parametrize("layout", ["soa", "aos"])
@@ -310,7 +310,7 @@ def test_rts_more_exact_dims_vs_oracle(n, layout):
     got = run_rts(Xs, Ps, F, Q, layout=layout)
     ref = kf_oracle.rts_smoother_tracks(Xs, Ps, F, Q, tracks=sample)
     for k in range(4):
-        assert rel_err_rows(_per_track(got[k][:, sample]), _per_track(ref[k])) < 1e-9, k
+        assert rel_err_rows(_per_track(got[k][:, sample]), _per_track(ref[k])) < 1e-10, k
 
 
 @pytest.mark.parametrize("layout", ["soa", "aos"])
@@ -338,4 +338,4 @@ def test_tail_shapes_kf_and_rts(n, m, layout):
         sm = run_rts(ref[0], ref[1], F, Q, layout=layout)
         rr = kf_oracle.rts_smoother_tracks(ref[0], ref[1], F, Q, tracks=range(N))
         for k in range(4):
-            assert rel_err_rows(_per_track(sm[k]), _per_track(rr[k])) < 1e-9, (N, "rts", k)
+            assert rel_err_rows(_per_track(sm[k]), _per_track(rr[k])) < 1e-10, (N, "rts", k)

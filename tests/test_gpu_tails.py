@@ -44,7 +44,7 @@ def test_imm_tails(n, m, nm, layout):
         for trk in range(N):
             x, P, mu, xp, Pp, L = imm_oracle.imm_batch(xs0[trk], Ps0[trk], mu0[trk], M, zs[:, trk], Fs, Qs, Hs, Rs)
             assert rel_err_rows(r["x_out"][:, trk], x) < TOL and rel_err_rows(r["P_out"][:, trk], P) < TOL, (N, trk)
-            assert np.allclose(r["mu_out"][:, trk], mu, rtol=1e-9, atol=1e-14), (N, trk)
+            assert np.allclose(r["mu_out"][:, trk], mu, rtol=1e-10, atol=1e-14), (N, trk)
 
 
 @pytest.mark.parametrize("layout", ["soa", "aos"])
@@ -99,4 +99,4 @@ def test_ukf_building_blocks_tails(n, m, layout):
         for trk in range(min(N, 70)):
             rmu, rcov = ukf_oracle.ukf_batch_filter(x0[trk], P0[trk], zs[:, trk], lambda x, dt: F @ x, lambda x: H @ x,
                                                     1.0, Q, R, alpha, beta, kappa)
-            assert rel_err_rows(mu[:, trk], rmu) < 1e-9 and rel_err_rows(cov[:, trk], rcov) < 1e-9, (N, trk)
+            assert rel_err_rows(mu[:, trk], rmu) < 1e-10 and rel_err_rows(cov[:, trk], rcov) < 1e-10, (N, trk)

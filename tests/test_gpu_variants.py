@@ -5,7 +5,7 @@ from the live reference and against the oracle on seeded banks."""
 import numpy as np
 import pytest
 
-from conftest import golden, rel_err_rows
+from conftest import golden, rel_err_rows, ukf_tol
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-10
@@ -34,7 +34,7 @@ def test_steadystate_class_drop_in(n, m):
             assert rel_err_rows(kf.x, g[q + tag + "xp"][t]) < TOL and rel_err_rows(kf.x_prior, g[q + tag + "xp"][t]) < TOL
             kf.update_steadystate(None if t == 7 else g[q + "zs"][t])
             assert rel_err_rows(kf.x, g[q + tag + "x"][t]) < TOL
-            assert np.allclose(np.ravel(kf.y), g[q + tag + "y"][t], rtol=1e-9, atol=1e-12)
+            assert np.allclose(np.ravel(kf.y), g[q + tag + "y"][t], rtol=1e-10, atol=1e-12)
         assert np.array_equal(kf.P, g[q + "Pss"]) and np.array_equal(kf.K, g[q + "K"])
 
 
@@ -56,7 +56,7 @@ def test_steadystate_bank(n, m, layout):
     means, means_p, y = bank.steadystate_filter(zs, mask=mask)
     for trk in (0, 255, 256, N - 1):
         assert rel_err_rows(means[:, trk], g[q + "ss_x"]) < TOL and rel_err_rows(means_p[:, trk], g[q + "ss_xp"]) < TOL
-        assert np.allclose(y[:, trk], g[q + "ss_y"], rtol=1e-9, atol=1e-12)
+        assert np.allclose(y[:, trk], g[q + "ss_y"], rtol=1e-10, atol=1e-12)
     assert rel_err_rows(bank.x[5], g[q + "ss_x"][-1]) < TOL
     # per-track gains and states, control input, against the oracle
     rs = np.random.RandomState(n + m)
@@ -70,7 +70,7 @@ def test_steadystate_bank(n, m, layout):
         rx, rxp, ry = kf_oracle.steadystate_filter(x0[trk], list(zs[:, trk]), g[q + "F"], g[q + "H"], Ks[trk],
                                                    B=g[q + "B"], us=us[:, trk])
         assert rel_err_rows(means[:, trk], rx) < TOL and rel_err_rows(means_p[:, trk], rxp) < TOL
-        assert np.allclose(y[:, trk], ry, rtol=1e-9, atol=1e-12)
+        assert np.allclose(y[:, trk], ry, rtol=1e-10, atol=1e-12)
     # the single-step methods of the bank
     bank.x = x0.copy()
     bank.predict_steadystate(u=us[0])
@@ -94,8 +94,8 @@ def test_update_correlated_class_drop_in(n, m, column):
             kf.update_correlated(z)
         assert rel_err_rows(np.ravel(kf.x), g[q + "corr_x"][t]) < TOL and rel_err_rows(kf.P, g[q + "corr_P"][t]) < TOL
         assert rel_err_rows(kf.K, g[q + "corr_K"][t]) < TOL and rel_err_rows(kf.S, g[q + "corr_S"][t]) < TOL
-        assert np.allclose(np.ravel(kf.y), g[q + "corr_y"][t], rtol=1e-9, atol=1e-12)
-        assert rel_err_rows(kf.SI, np.linalg.inv(g[q + "corr_S"][t])) < 1e-8
+        assert np.allclose(np.ravel(kf.y), g[q + "corr_y"][t], rtol=1e-10, atol=1e-12)
+        assert rel_err_rows(kf.SI, np.linalg.inv(g[q + "corr_S"][t])) < 1e-10
     kf.update_correlated(None)
     assert np.all(kf.y == 0)
 
@@ -141,7 +141,7 @@ def test_update_sequential_class_and_bank(n, m):
         kf.update_sequential(i, g[q + "zs"][0][i])
         assert rel_err_rows(np.ravel(kf.x), g[q + "seq_x"][i]) < TOL and rel_err_rows(kf.P, g[q + "seq_P"][i]) < TOL
     assert rel_err_rows(kf.K, g[q + "seq_K"]) < TOL
-    assert np.allclose(np.ravel(kf.y), g[q + "seq_y"], rtol=1e-9, atol=1e-12)
+    assert np.allclose(np.ravel(kf.y), g[q + "seq_y"], rtol=1e-10, atol=1e-12)
     if m >= 2:
         kf.x, kf.P = xp.copy(), Pp.copy()
         kf.update_sequential(m - 2, g[q + "zs"][0][m - 2:])
@@ -179,9 +179,10 @@ def test_ukf_rts_smoother_goldens(linear_matrices):
         ukf.Q, ukf.R = g[p + "Q"].copy(), g[p + "R"].copy()
         xs, Ps, Ks = ukf.rts_smoother(g[p + "mu"], g[p + "cov"])
         assert xs.shape == g[p + "rts_x"].shape and Ks.shape == g[p + "rts_K"].shape
-        assert rel_err_rows(xs, g[p + "rts_x"]) < 1e-9, ci
-        assert rel_err_rows(Ps, g[p + "rts_P"]) < 1e-9, ci
-        assert rel_err_rows(Ks[:-1], g[p + "rts_K"][:-1]) < 1e-8, ci
+        # 1e-10 unless the reference's own output moves more under one-ulp input perturbations (conftest.ukf_tol)
+        assert rel_err_rows(xs, g[p + "rts_x"]) < ukf_tol(ci, "rts_x"), ci
+        assert rel_err_rows(Ps, g[p + "rts_P"]) < ukf_tol(ci, "rts_P"), ci
+        assert rel_err_rows(Ks[:-1], g[p + "rts_K"][:-1]) < ukf_tol(ci, "rts_K"), ci
 
 
 def test_ukf_rts_smoother_bank():
@@ -196,4 +197,4 @@ def test_ukf_rts_smoother_bank():
     ukf.Q, ukf.R = g[p + "Q"].copy(), g[p + "R"].copy()
     xs, Ps, Ks = ukf.rts_smoother(tile_tracks(g[p + "mu"], N, axis=1), tile_tracks(g[p + "cov"], N, axis=1))
     assert xs.shape == (30, N, n)
-    assert rel_err_rows(xs[:, N - 1], g[p + "rts_x"]) < 1e-9 and rel_err_rows(Ps[:, 0], g[p + "rts_P"]) < 1e-9
+    assert rel_err_rows(xs[:, N - 1], g[p + "rts_x"]) < 1e-10 and rel_err_rows(Ps[:, 0], g[p + "rts_P"]) < 1e-10

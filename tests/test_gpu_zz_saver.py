@@ -25,6 +25,6 @@ def test_package_saver_histories(n, m):
     for k in ("x", "P", "x_prior", "P_prior", "x_post", "P_post", "K", "y", "S", "SI"):
         got, ref = np.array(s[k], dtype=float), g[p + k]
         assert got.shape == ref.shape, (k, got.shape, ref.shape)
-        assert np.allclose(got, ref, rtol=1e-9, atol=1e-11), k
-    assert np.allclose(np.array(s["log_likelihood"], dtype=float), g[p + "log_likelihood"], rtol=1e-8, atol=1e-8)
-    assert np.allclose(np.array(s["mahalanobis"], dtype=float), g[p + "mahalanobis"], rtol=1e-8, atol=1e-10)
+        assert np.allclose(got, ref, rtol=1e-10, atol=1e-11), k
+    assert np.allclose(np.array(s["log_likelihood"], dtype=float), g[p + "log_likelihood"], rtol=1e-10, atol=1e-10)
+    assert np.allclose(np.array(s["mahalanobis"], dtype=float), g[p + "mahalanobis"], rtol=1e-10, atol=1e-10)

@@ -62,3 +62,49 @@ def test_single_process_needs_no_group():
     t = torch.ones(3, 2)
     assert parallel.allgather_summary(t).shape == (1, 3, 2)
     assert parallel.max_over_ranks(3.5) == 3.5
+
+
+# ---- the command the driver runs: `python bench.py --gpus N` must use N ranks -----------------------------
+def _run_bench(*argv, env_extra=None, timeout=300):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, *argv], cwd=root, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def _json_line(out):
+    import json
+    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out
+    return json.loads(lines[0])
+
+
+def test_bench_self_spawns_one_rank_per_gpu():
+    """bare `python bench.py --gpus 2` re-executes itself under torch.distributed.run with 2 ranks (gloo + a stub
+    kernel here: --selftest-cpu), shards, all-gathers the summary state and prints ONE line with n_gpus = 2."""
+    r = _run_bench("bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--selftest-cpu")
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = _json_line(r.stdout)
+    assert line["n_gpus"] == 2 and line["gather_ok"] is True and line["steps"] == 3 and line["data"] == "selftest-stub"
+
+
+def test_bench_under_the_drivers_torchrun_command():
+    """the driver's own launch line: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N"""
+    r = _run_bench("-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                   "--master-port", str(_free_port()), "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1",
+                   "--selftest-cpu")
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert _json_line(r.stdout)["n_gpus"] == 2
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    """no silent 1-GPU run: asking for more GPUs than the node has is an error (this container has none)."""
+    r = _run_bench("bench.py", "--gpus", "8", "--steps", "1", "--warmup", "0", "--no-cpu")
+    assert r.returncode != 0 and "GPU(s) are visible" in (r.stderr + r.stdout)
+
+
+def test_bench_rejects_world_size_mismatch():
+    r = _run_bench("bench.py", "--gpus", "4", "--selftest-cpu", env_extra={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "WORLD_SIZE=2" in (r.stderr + r.stdout)

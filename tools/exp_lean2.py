@@ -15,11 +15,11 @@ import sys
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, ROOT)
 CSRC = os.path.join(ROOT, "filterpy_amd", "csrc")
-LIB = os.path.join(CSRC, "build", "libfk_exp.so")
+LIB = os.path.join(CSRC, "exp_build", "libfk_exp.so")
 
 
 def build():
-    os.makedirs(os.path.join(CSRC, "build"), exist_ok=True)
+    os.makedirs(os.path.join(CSRC, "exp_build"), exist_ok=True)
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
                            "-ffp-contract=off", "-o", LIB, os.path.join(CSRC, "experimental", "resample_lean2.hip"),
                            "-x", "hip", os.path.join(CSRC, "fk_host.cpp")], cwd=CSRC)

@@ -18,11 +18,11 @@ import numpy as np
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, ROOT)
 CSRC = os.path.join(ROOT, "filterpy_amd", "csrc")
-LIB = os.path.join(CSRC, "build", "libfk_exp_ukf.so")
+LIB = os.path.join(CSRC, "exp_build", "libfk_exp_ukf.so")
 
 
 def build():
-    os.makedirs(os.path.join(CSRC, "build"), exist_ok=True)
+    os.makedirs(os.path.join(CSRC, "exp_build"), exist_ok=True)
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
                            "-DFK_UKF_V2", "-o", LIB, os.path.join(CSRC, "ukf_kernels.hip"), "-x", "hip",
                            os.path.join(CSRC, "fk_host.cpp")], cwd=CSRC)
