@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libfilterhip.so")
 FK_OK = 0
 FK_LAYOUT_AOS, FK_LAYOUT_SOA = 0, 1
 FK_MODEL_SHARED, FK_MODEL_PER_TRACK, FK_MODEL_PER_TRACK_STEP, FK_MODEL_PER_STEP = 0, 1, 2, 3
-FK_STATUS_NOT_PD, FK_STATUS_NONFINITE, FK_STATUS_OVERRUN = 1, 2, 4
+FK_STATUS_NOT_PD, FK_STATUS_NONFINITE, FK_STATUS_OVERRUN, FK_STATUS_INTERNAL = 1, 2, 4, 8
 
 c_i32, c_i64, c_f64, c_vp, c_sz = ctypes.c_int32, ctypes.c_int64, ctypes.c_double, ctypes.c_void_p, ctypes.c_size_t
 

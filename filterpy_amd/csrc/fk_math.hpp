@@ -47,7 +47,7 @@
 
 namespace fk {
 
-enum : int { ST_NOT_PD = 1, ST_NONFINITE = 2, ST_OVERRUN = 4 };
+enum : int { ST_NOT_PD = 1, ST_NONFINITE = 2, ST_OVERRUN = 4, ST_INTERNAL = 8 };
 
 // C[R x C] = A[R x K] * B[K x C]
 template <int R, int K, int C>

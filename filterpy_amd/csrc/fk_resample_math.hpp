@@ -69,4 +69,33 @@ FK_HD int n_boundary(double c, int Np, double Nd, double halfNd, double u_sys, c
     return n;
 }
 
+// The same n(c), decided by the estimate alone whenever that is safe.  With e = N c - u (systematic) the answer is
+// ceil(e) unless e sits within eps of an integer; every rounding that separates the computed e from the exact
+// comparison pos_i >= c is bounded in slot units for Np < 2^31: the product and the difference 2^-22 each, the two
+// roundings inside pos_i together N * 2^-52 <= 2^-21 -- 2^-20 in total, and eps = 2^-18.  Stratified: with
+// f = floor(N c), slot f - 1 is below c, slot f + 1 is not, and slot f is decided by u_f against frac(N c) when
+// they are farther apart than eps.  About one weight in 10^5 takes the exact tests above.
+constexpr double N_BOUNDARY_EPS = 0x1p-18;
+
+template <bool STRATIFIED>
+FK_HD int n_boundary_fast(double c, int Np, double Nd, double halfNd, double u_sys, const double *u_str)
+{
+    if (!(c > 0.0)) return 0;
+    const double e = c * Nd - (STRATIFIED ? 0.0 : u_sys);
+    // every position is below c, with a margin of one slot (stratified: fl(u + Np - 1) may round up to Np, so
+    // N c in [Np, Np + 1) still goes through the exact tests)
+    if (e >= (double)Np + (STRATIFIED ? 1.0 : 0.0)) return Np;
+    const double fl = floor(e), fr = e - fl;            // fr exact
+    bool sure = fr > N_BOUNDARY_EPS && fr < 1.0 - N_BOUNDARY_EPS && fl < (double)Np;
+    int n = (int)fl + 1;                                // systematic: ceil(e)  (e > -1: n >= 0)
+    if (STRATIFIED) {
+        const double uf = u_str[fl < (double)Np ? (int)fl : 0];   // e > 0 here (c > 0, u = 0)
+        const double gap = uf - fr;
+        sure = sure && (gap > N_BOUNDARY_EPS || gap < -N_BOUNDARY_EPS);
+        n = (int)fl + (gap > 0.0 ? 0 : 1);
+    }
+    if (!sure) n = n_boundary<STRATIFIED>(c, Np, Nd, halfNd, u_sys, u_str);
+    return n;
+}
+
 }  // namespace fk

@@ -23,6 +23,7 @@
 #include "../../include/filterhip.h"
 #include "fk_device.hpp"
 #include "fk_exact_scan.hpp"
+#include "resample_onepass.hpp"
 
 namespace fk {
 
@@ -885,10 +886,12 @@ extern "C" {
 
 size_t fk_resample_workspace_bytes(int64_t Fn, int64_t Np)
 {
-    // systematic / stratified on long vectors: one ChunkPlan per 2048 weights
+    // systematic / stratified: the hand-off records of the one-pass path (resample_onepass.hip); the multi-pass
+    // path kept for comparison (FK_RESAMPLE_PATH=chunk) needs one ChunkPlan per 2048 weights
     if (Fn <= 0 || Np <= 0) return 0;
     const size_t nch = (size_t)((Np + RS_TILE - 1) / RS_TILE);
-    return (size_t)Fn * nch * sizeof(ChunkPlan);
+    const size_t a = (size_t)Fn * nch * sizeof(ChunkPlan), b = onepass_workspace_bytes(Fn, Np);
+    return a > b ? a : b;
 }
 
 size_t fk_multinomial_workspace_bytes(int64_t Fn, int64_t Np)
@@ -907,7 +910,19 @@ static int resample_common(bool stratified, int64_t Fn, int64_t Np, const double
     hipStream_t s = (hipStream_t)stream;
     const long nch = (long)((Np + RS_TILE - 1) / RS_TILE);
     const size_t plan_bytes = (size_t)Fn * (size_t)nch * sizeof(ChunkPlan);
-    if (Np >= RS_PAR_MIN && ws && ws_bytes >= plan_bytes && nch <= 65535 * 32L && Fn <= 65535 && !getenv("FK_RESAMPLE_SERIAL")) {
+    // Long vectors (Np >= RS_PAR_MIN) take the one-pass path (resample_onepass.hip); short ones are a handful of
+    // dependent tiles whatever is done and stay with one workgroup per filter (resample_kernel above).
+    // FK_RESAMPLE_PATH overrides: onepass (any length) | chunk (the multi-pass path of round 1) | serial
+    const char *path = getenv("FK_RESAMPLE_PATH");
+    const bool want_onepass = path ? !strcmp(path, "onepass") : Np >= RS_PAR_MIN;
+    const bool want_chunk = path && !strcmp(path, "chunk");
+    if (want_onepass && ws && ws_bytes >= onepass_workspace_bytes(Fn, Np) && !getenv("FK_RESAMPLE_SERIAL")) {
+        const int rc = onepass_launch(stratified, Fn, Np, w, u, idx, status, ws, ws_bytes, s);
+        if (rc == FK_ERR_UNSUPPORTED) return fail(rc, "resample: too many chunks for one launch");
+        if (rc != FK_OK && rc != FK_ERR_LAUNCH) return fail(rc, "resample: one-pass launch failed");
+        return rc;
+    }
+    if (want_chunk && Np >= RS_PAR_MIN && ws && ws_bytes >= plan_bytes && nch <= 65535 * 32L && Fn <= 65535 && !getenv("FK_RESAMPLE_SERIAL")) {
         // chunk-parallel path: the caller's workspace holds the plan
         ChunkPlan *plan = (ChunkPlan *)ws;
         const dim3 gch((unsigned)nch, (unsigned)Fn), block(RS_THREADS);
@@ -929,7 +944,8 @@ static int resample_common(bool stratified, int64_t Fn, int64_t Np, const double
         hipLaunchKernelGGL((resample_kernel<true>), grid, block, 0, s, (long)Np, w, u, idx, status);
     else
         hipLaunchKernelGGL((resample_kernel<false>), grid, block, 0, s, (long)Np, w, u, idx, status);
-    return check_launch("resample_kernel");
+    if (int rc = check_launch("resample_kernel")) return rc;
+    return literal_fixup_launch(stratified, Fn, Np, w, u, idx, status, s);
 }
 
 #ifdef FK_RS_PHASE_CLOCKS

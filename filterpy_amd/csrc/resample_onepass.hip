@@ -1,0 +1,928 @@
+// resample_onepass.hip -- systematic / stratified resampling in ONE pass over the weights (gfx950).
+//
+//   fk_resample_systematic_f64  <- systematic_resample (filterpy/monte_carlo/resampling.py:117-150)
+//   fk_resample_stratified_f64  <- stratified_resample (:80-114)
+//
+// The reference compares the positions against numpy.cumsum(weights), a strictly sequential fp64 add chain, and
+// the indices must match it bit for bit.  This kernel reads every weight from HBM exactly once (8 B) and writes
+// every index once (4 B): the algorithmic traffic.  One workgroup owns one chunk of 2048 weights of one filter;
+// the sequential dependency between chunks is carried by TWO chained "decoupled look-back" hand-offs:
+//
+//   stage 1 (approximate): plain fp64 chunk sums, summed in any order, tell every chunk -- with a rigorous error
+//            bound -- which binade the exact running sum is in while it crosses the chunk;
+//   stage 2 (exact): inside one binade every add of the sequential chain is the integer map C -> C + inc
+//            (fk_exact_scan.hpp, fast_inc), so a chunk whose binade is known publishes the integer sum of its
+//            increments BEFORE its own carry-in is known, and the exact carry of a run of such chunks is an
+//            integer sum -- associative.  Chunks that cross a binade, hold a half-ulp tie or start a vector
+//            resolve their carry-out from the exact carry-in with the general segmented scan below and publish
+//            it; nobody ever trusts the approximation: every shortcut is re-verified against the exact carry.
+//
+// All hand-off words are single 8-byte granules {state, payload} moved with relaxed agent-scope atomics (the
+// data IS the flag: no fences, no L2 write-backs; MI355X guide, Guideline 16 form R2).  Workgroups take their
+// chunk from an atomic ticket, so a chunk only ever waits for chunks taken earlier; spins are bounded and set an
+// abort word instead of hanging.
+//
+// Output side: slot i receives #{ j : cs_j <= pos_i }.  Seen from the weights, weight j owns the slots
+// [n(cs_{j-1}), n(cs_j)), n(c) = #{ i : pos_i < c } (fk_resample_math.hpp: exact, division-free).  Each weight
+// drops its index at the head of its run in an LDS window; an inclusive max-scan fills the runs; the window
+// leaves as 16-byte coalesced stores.  No per-output search, no division.
+//
+// This unit is compiled with -ffp-contract=off: positions and sums must be single IEEE operations.
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../include/filterhip.h"
+#include "fk_device.hpp"
+#include "fk_exact_scan.hpp"
+#include "fk_resample_math.hpp"
+#include "resample_onepass.hpp"
+
+namespace fk {
+
+using u64 = unsigned long long;
+
+constexpr int OP_THREADS = 256;
+constexpr int OP_ITEMS = 8;
+constexpr int OP_TILE = OP_THREADS * OP_ITEMS;             // 2048 weights per chunk
+constexpr int OP_WIN = 12 * OP_THREADS;                     // 3072 output slots per window, 12 consecutive per thread
+constexpr int OP_REGIONS = 32;                             // ticket heads, each in a cache line of its own: ONE word takes
+                                                           // ~88 atomics per microsecond, and so do eight words in one line
+                                                           // (measured: 488k tickets -> 6.1 ms whatever the kernel did)
+constexpr int OP_SERIAL_RUN = 256;                         // elements per sequential run of the general scan
+constexpr int OP_MAX_TIES = 8;                             // more half-ulp ties than this in a chunk: sequential
+constexpr unsigned OP_SPIN_LIMIT = 1u << 22;
+#ifndef FK_OP_LOOKBACK
+#define FK_OP_LOOKBACK 64      // predecessors polled per look-back step (lanes of wave 0 that load a hand-off word)
+#endif
+#ifndef FK_OP_SLEEP
+#define FK_OP_SLEEP 2          // s_sleep argument between two polls
+#endif
+constexpr int OP_LB = FK_OP_LOOKBACK;
+
+// per-chunk hand-off record (zeroed by the launcher before every call)
+struct OpDesc {
+    u64 approx;     // stage 1: bits of a double; low 2 bits = state (0 empty, 1 chunk sum, 2 inclusive prefix)
+    u64 exact;      // stage 2: state:2 | eu9:9 | C:53   (1 = increment sum of the chunk, 2 = carry-out = C * 2^eu,
+                    //          3 = carry-out only in `raw`)
+    u64 raw;        // bits of the exact carry-out
+    u64 raw_chk;    // ~raw: the pair is valid when raw_chk == ~raw
+};
+
+struct OpHead {
+    unsigned next;      // next ticket of the region
+    unsigned pad[31];   // 128 bytes apart
+};
+struct OpCtl {      // head of the workspace (zeroed with it)
+    OpHead head[OP_REGIONS];
+    unsigned abort;
+    unsigned pad[31];
+};
+
+constexpr u64 ST_MASK = 3;
+constexpr double OP_SANE_LO = 0x1p-900, OP_SANE_HI = 0x1p900;
+constexpr u64 OP_NAN_BITS = 0x7ff8000000000000ull;
+
+__device__ __forceinline__ u64 ld_agent(const u64 *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_agent(u64 *p, u64 v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ int pad8(int j) { return j + (j >> 3); }   // one spare slot per eight: the
+                                                                     // thread-owns-8-consecutive reads are conflict-free
+
+// ---- wave primitives (DPP: no LDS traffic) ---------------------------------------------------------------
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_add(double acc)
+{
+    const int lo = __double2loint(acc), hi = __double2hiint(acc);
+    const int slo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, false);   // no source / masked row: +0.0
+    const int shi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, false);
+    return acc + __hiloint2double(shi, slo);
+}
+// inclusive prefix sum over the 64 lanes (values whose partial sums are exact, or whose order is free)
+__device__ __forceinline__ double wave_incl_sum(double v)
+{
+    v = dpp_add<0x111, 0xf>(v);   // row_shr:1
+    v = dpp_add<0x112, 0xf>(v);   // row_shr:2
+    v = dpp_add<0x114, 0xf>(v);   // row_shr:4
+    v = dpp_add<0x118, 0xf>(v);   // row_shr:8 -> inclusive within rows of 16
+    v = dpp_add<0x142, 0xa>(v);   // row_bcast:15 into rows 1, 3
+    v = dpp_add<0x143, 0xc>(v);   // row_bcast:31 into rows 2, 3
+    return v;
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_max(int acc)
+{
+    const int s = __builtin_amdgcn_update_dpp(acc, acc, CTRL, ROW_MASK, 0xf, false);   // no source: itself
+    return s > acc ? s : acc;
+}
+__device__ __forceinline__ int wave_incl_max(int v)
+{
+    v = dpp_max<0x111, 0xf>(v);
+    v = dpp_max<0x112, 0xf>(v);
+    v = dpp_max<0x114, 0xf>(v);
+    v = dpp_max<0x118, 0xf>(v);
+    v = dpp_max<0x142, 0xa>(v);
+    v = dpp_max<0x143, 0xc>(v);
+    return v;
+}
+__device__ __forceinline__ double lane_bcast(double v, int src)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src), __builtin_amdgcn_readlane(__double2loint(v), src));
+}
+__device__ __forceinline__ u64 lane_bcast_u64(u64 v, int src)
+{
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, src);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), src);
+    return ((u64)hi << 32) | lo;
+}
+
+struct OpShared {
+    double tile[OP_TILE + OP_TILE / 8];   // weights (padded), later their cumulative sums; then aliased by the window
+    int nlast[OP_THREADS];                // slot boundary after each thread's last element
+    double wsum[OP_THREADS / 64];         // per-wave partials (stage-1 sum, increment sums)
+    int wmax[OP_THREADS / 64];
+    double bc_d[2];                       // broadcast slots written by wave 0 / thread 0
+    int bc_i[6];
+    __device__ __forceinline__ int *win() { return reinterpret_cast<int *>(tile); }
+};
+static_assert(sizeof(OpShared) <= 20480, "eight workgroups per CU need <= 20 KiB of LDS each");
+
+// ---- hand-off words --------------------------------------------------------------------------------------
+__device__ __forceinline__ u64 pack_approx(double v, u64 state) { return (double_to_bits(v) & ~ST_MASK) | state; }
+__device__ __forceinline__ double unpack_approx(u64 w) { return bits_to_double(w & ~ST_MASK); }
+__device__ __forceinline__ u64 pack_exact(u64 state, int eu, double C) { return state | ((u64)(eu & 511) << 2) | ((u64)C << 11); }
+__device__ __forceinline__ int exact_eu9(u64 w) { return (int)((w >> 2) & 511); }
+__device__ __forceinline__ double exact_C(u64 w) { return (double)(w >> 11); }
+
+__device__ __forceinline__ bool spin_fail(unsigned &spins, unsigned *abort_word)
+{
+    __builtin_amdgcn_s_sleep(FK_OP_SLEEP);
+    ++spins;
+    if ((spins & 63u) == 0u) {
+        if (spins > OP_SPIN_LIMIT) __hip_atomic_store(abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return true;
+    }
+    return false;
+}
+
+// stage 1, wave 0 only: approximate running sum entering chunk k (k >= 1) = sum of the predecessors' chunk sums
+// down to the nearest published inclusive prefix.  NaN = poison (a bad weight upstream) or abort.
+__device__ double lookback_approx(const OpDesc *d, int k, int lane, unsigned *abort_word)
+{
+    double A = 0.0;
+    unsigned spins = 0;
+    for (int j = k - 1;; j -= OP_LB) {
+        const int jj = j - lane;
+        u64 word, incl;
+        for (;;) {
+            // before the vector: inclusive prefix 0; lanes beyond the window: a chunk sum of 0 (never waited for)
+            word = lane >= OP_LB ? (u64)1 : (jj >= 0 ? ld_agent(&d[jj].approx) : (u64)2);
+            incl = __ballot((word & ST_MASK) == 2);
+            const u64 empty = __ballot((word & ST_MASK) == 0);
+            const u64 need = incl ? ((incl & (0 - incl)) << 1) - 1 : ~(u64)0;   // lanes up to the nearest inclusive one
+            if ((empty & need) == 0) break;
+            if (spin_fail(spins, abort_word)) return __builtin_nan("");
+        }
+        const int L = incl ? __builtin_ctzll(incl) : 63;
+        const double v = lane <= L ? unpack_approx(word) : 0.0;
+        A += lane_bcast(wave_incl_sum(v), 63);
+        if (incl) return A;
+    }
+}
+
+// exact carry-out pair of chunk jj (valid once its stage-2 word says state >= 2)
+__device__ double read_raw(const OpDesc *d, int jj, unsigned *abort_word)
+{
+    unsigned spins = 0;
+    for (;;) {
+        const u64 r = ld_agent(&d[jj].raw), c = ld_agent(&d[jj].raw_chk);
+        if (c == ~r) return bits_to_double(r);
+        if (spin_fail(spins, abort_word)) return __builtin_nan("");
+    }
+}
+
+// stage 2, wave 0 only: EXACT running sum entering chunk k (k >= 1).  A chunk that knows its binade (`clean`,
+// ulp exponent eu) may add up the increment sums of predecessors in the same binade down to the nearest
+// published carry-out; anything else waits for the carry-out of chunk k-1.  `ok` = false on abort.
+__device__ double lookback_exact(const OpDesc *d, int k, bool clean, int eu, int lane, unsigned *abort_word, bool &ok)
+{
+    ok = true;
+    double acc = 0.0;            // integer sum of increments, in units of 2^eu
+    unsigned spins = 0;
+    const int my9 = eu & 511;
+    for (int j = k - 1;; j -= OP_LB) {
+        const int jj = j - lane;
+        u64 word, term;
+        for (;;) {
+            // before the vector: carry-out 0 (state 3: value in `raw`, handled below without a load); lanes beyond
+            // the window: an increment sum of 0
+            word = lane >= OP_LB ? (u64)1 : (jj >= 0 ? ld_agent(&d[jj].exact) : (u64)3);
+            const u64 st = word & ST_MASK;
+            const bool is_term = st >= 2;
+            const bool compat = (clean || lane >= OP_LB) && st == 1 && (exact_eu9(word) == my9 || (word >> 11) == 0);
+            term = __ballot(is_term);
+            const u64 blocked = __ballot(!(is_term || compat));
+            const u64 below = term ? (term & (0 - term)) - 1 : ~(u64)0;   // lanes nearer than the nearest carry-out
+            if ((blocked & below) == 0) break;
+            if (spin_fail(spins, abort_word)) { ok = false; return 0.0; }
+        }
+        const int L = term ? __builtin_ctzll(term) : 64;
+        acc += lane_bcast(wave_incl_sum(lane < L ? exact_C(word) : 0.0), 63);
+        if (!term) continue;
+        const u64 tw = lane_bcast_u64(word, L);
+        const int tj = j - L;
+        if (L == 0 && j == k - 1) {                    // the carry-out of chunk k-1 itself
+            if ((tw & ST_MASK) == 2 && clean && exact_eu9(tw) == my9) return scale2(exact_C(tw), eu);
+            return tj >= 0 ? read_raw(d, tj, abort_word) : 0.0;
+        }
+        // a farther carry-out plus the increment sums in between: valid only inside my binade
+        double Ct = -1.0;
+        if ((tw & ST_MASK) == 2 && exact_eu9(tw) == my9) Ct = exact_C(tw);
+        else if (tj >= 0) {
+            const double c = read_raw(d, tj, abort_word);
+            if (c > OP_SANE_LO && c < OP_SANE_HI && ulp_exp(c) == eu) Ct = scale2(c, -eu);
+        }
+        if (Ct >= 0x1p52 && Ct + acc < 0x1p53) return scale2(Ct + acc, eu);
+        // inconsistent with what stage 1 promised (never observed; kept so that nothing rests on it): wait for k-1
+        unsigned spins2 = 0;
+        for (;;) {
+            const u64 w1 = ld_agent(&d[k - 1].exact);
+            if ((w1 & ST_MASK) >= 2) return read_raw(d, k - 1, abort_word);
+            if (spin_fail(spins2, abort_word)) { ok = false; return 0.0; }
+        }
+    }
+}
+
+// publish the exact carry-out of a chunk (one lane)
+__device__ __forceinline__ void publish_carry(OpDesc *dk, double c)
+{
+    const u64 r = (c == c) ? double_to_bits(c) : OP_NAN_BITS;
+    st_agent(&dk->raw, r);
+    st_agent(&dk->raw_chk, ~r);
+    if (c > OP_SANE_LO && c < OP_SANE_HI) {
+        const int eu = ulp_exp(c);
+        st_agent(&dk->exact, pack_exact(2, eu, scale2(c, -eu)));
+    } else {
+        st_agent(&dk->exact, (u64)3);
+    }
+}
+
+// plain sequential adds of elements [pos, stop) by ONE thread (the start of a vector, odd values, tie-ridden chunks);
+// the result goes to sh.bc_d[0].  Kept out of line: inlined, its loop costs the whole kernel 20 registers.
+__device__ __attribute__((noinline)) void serial_run(OpShared &sh, int pos, int stop, double carry)
+{
+    double c = carry;
+    _Pragma("nounroll") for (int j = pos; j < stop; j += 4) {              // 4 independent LDS reads, then the add chain
+        double v0 = sh.tile[pad8(j + 0)];
+        double v1 = sh.tile[pad8(j + 1 < OP_TILE ? j + 1 : j)];
+        double v2 = sh.tile[pad8(j + 2 < OP_TILE ? j + 2 : j)];
+        double v3 = sh.tile[pad8(j + 3 < OP_TILE ? j + 3 : j)];
+        v0 = c + v0;
+        v1 = v0 + v1;
+        v2 = v1 + v2;
+        v3 = v2 + v3;
+        sh.tile[pad8(j + 0)] = v0;
+        c = v0;
+        if (j + 1 < stop) { sh.tile[pad8(j + 1)] = v1; c = v1; }
+        if (j + 2 < stop) { sh.tile[pad8(j + 2)] = v2; c = v2; }
+        if (j + 3 < stop) { sh.tile[pad8(j + 3)] = v3; c = v3; }
+    }
+    sh.bc_d[0] = c;
+}
+
+// ---- the general exact scan of one chunk (binade crossings, ties, vector start, odd values) ---------------
+// In: weights in sh.tile (padded), exact carry-in.  Out: cumulative sums in sh.tile, returns the carry-out.
+// Rounds: inside the binade of the running sum the adds are integer increments -> one block scan; the round
+// ends at the first element that would leave the binade or that holds a half-ulp tie -- that single element is
+// added with a real IEEE add and the next round starts behind it.  A running sum that is not a positive normal
+// number (start of a vector, garbage) is advanced by plain sequential adds.
+__device__ double general_cumsum(OpShared &sh, int len, double carry)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int pos = 0;
+    bool force_serial = false;
+    while (pos < len) {                                                   // uniform
+        if (force_serial || !(carry > OP_SANE_LO && carry < OP_SANE_HI)) {
+            const int stop = force_serial ? len : (pos + OP_SERIAL_RUN < len ? pos + OP_SERIAL_RUN : len);
+            __syncthreads();
+            if (tid == 0) serial_run(sh, pos, stop, carry);
+            __syncthreads();
+            carry = sh.bc_d[0];
+            pos = stop;
+            continue;
+        }
+        // one binade: integer increments (a half-ulp tie or a weight this binade cannot take counts 2^54 and so
+        // ends the round like a crossing), block scan, first stop element
+        const int eu = ulp_exp(carry);
+        const double ulp = ulp_of(carry);
+        const double C0 = scale2(carry, -eu);
+        double E[OP_ITEMS];
+        double run = 0.0;
+        int nties = 0;
+        FK_UNROLL for (int q = 0; q < OP_ITEMS; ++q) {
+            const int j = tid * OP_ITEMS + q;
+            bool tk = false;
+            const double e = fast_inc(sh.tile[pad8(j)], eu, tk);          // (slots >= len hold +0.0)
+            nties += (tk && j >= pos && j < len) ? 1 : 0;
+            run += (j >= pos && j < len) ? (tk ? 0x1p54 : e) : 0.0;
+            E[q] = run;
+            FK_STAGE();                                                    // one element at a time: short live ranges
+        }
+        const double winc = wave_incl_sum(run);
+        if (tid == 0) sh.bc_i[0] = OP_TILE;
+        if (lane == 63) sh.wsum[wave] = winc;
+        const int tie_threads = __syncthreads_count(nties > 0 ? 1 : 0);
+        if (tie_threads > OP_MAX_TIES) {                                  // tie-ridden chunk: sequential
+            force_serial = true;
+            continue;
+        }
+        // running C before this thread's elements.  NOT winc - run: a 2^54 marker among the own elements would
+        // absorb the low bits of the lanes before it
+        const double before = __shfl_up(winc, 1, 64);
+        double acc = C0 + (lane == 0 ? 0.0 : before);
+        FK_UNROLL for (int wv = 0; wv < OP_THREADS / 64; ++wv)
+            if (wv < wave) acc += sh.wsum[wv];
+        // (exact below 2^53; a sum that reaches 2^53 stays >= 2^53, which is all the stop test needs)
+        int my_stop = OP_TILE;
+        FK_UNROLL for (int q = OP_ITEMS - 1; q >= 0; --q) {
+            const int j = tid * OP_ITEMS + q;
+            E[q] += acc;
+            if (j >= pos && j < len && !(E[q] < 0x1p53)) my_stop = j;     // descending: the first one wins
+        }
+        if (my_stop < OP_TILE) atomicMin(&sh.bc_i[0], my_stop);
+        __syncthreads();
+        const int first_stop = __builtin_amdgcn_readfirstlane(sh.bc_i[0]);
+        const int stop = first_stop < len ? first_stop : len;             // first element NOT covered by this round
+        const double w_stop = stop < len ? sh.tile[pad8(stop)] : 0.0;     // still the weight: read before the writes
+        FK_UNROLL for (int q = 0; q < OP_ITEMS; ++q) {
+            const int j = tid * OP_ITEMS + q;
+            if (j >= pos && j < stop) sh.tile[pad8(j)] = E[q] * ulp;      // exact: no tie, no crossing before `stop`
+        }
+        __syncthreads();
+        if (stop > pos) carry = sh.tile[pad8(stop - 1)];
+        if (stop < len) {
+            carry = carry + w_stop;                                       // the real IEEE add
+            if (tid == 0) sh.tile[pad8(stop)] = carry;
+            pos = stop + 1;
+        } else {
+            pos = len;
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    return carry;
+}
+
+// Build-time instrumentation (tools/op_phase.py builds a separate library with -DFK_OP_CLOCKS; the shipped library
+// has none of it): thread 0 of every workgroup adds the shader-clock ticks of each phase, and the polls its wave
+// spent in the two look-backs, to fk_op_phase[]; fk_debug_op_phases() reads and clears them.
+#ifdef FK_OP_CLOCKS
+constexpr int OP_PHASE_SLOTS = 16, OP_PHASE_BUCKETS = 1024;
+__device__ unsigned long long fk_op_phase[OP_PHASE_SLOTS][OP_PHASE_BUCKETS];
+__device__ double *g_dbg_cs;     // [Fn][Np] dump of the cumulative sums / boundaries the kernel worked with (or null)
+__device__ int *g_dbg_n;
+// (accumulators live in LDS, touched by thread 0 only: sixteen 64-bit counters in registers would spill)
+#define OP_CLOCK_START() __shared__ long long t_acc[OP_PHASE_SLOTS]; long long t_prev = clock64(); \
+    if (threadIdx.x == 0) for (int q_ = 0; q_ < OP_PHASE_SLOTS; ++q_) t_acc[q_] = 0
+#define OP_CLOCK(slot) do { if (threadIdx.x == 0) { const long long t_now = clock64(); t_acc[slot] += t_now - t_prev; t_prev = t_now; } } while (0)
+#define OP_COUNT(slot, n) do { if (threadIdx.x == 0) t_acc[slot] += (n); } while (0)
+#define OP_CLOCK_FLUSH() do { if (threadIdx.x == 0) for (int q_ = 0; q_ < OP_PHASE_SLOTS; ++q_) \
+        if (t_acc[q_]) atomicAdd(&fk_op_phase[q_][blockIdx.x % OP_PHASE_BUCKETS], (unsigned long long)t_acc[q_]); } while (0)
+#else
+#define OP_CLOCK_START() do { } while (0)
+#define OP_CLOCK(slot) do { } while (0)
+#define OP_COUNT(slot, n) do { } while (0)
+#define OP_CLOCK_FLUSH() do { } while (0)
+#endif
+
+// ---- the kernel -------------------------------------------------------------------------------------------
+struct OpArgs {
+    long Np, nch;
+    int Fn, nregions;
+    const double *w, *u;
+    int32_t *idx, *status;
+    OpCtl *ctl;
+    OpDesc *desc;
+    int *bad;           // [Fn]: filter holds a weight the fast path does not take -> resample_literal_kernel
+    double delta;       // relative error bound of the stage-1 prefix
+};
+
+#ifndef FK_OP_WAVES
+#define FK_OP_WAVES 5          // workgroups per CU the register allocation aims at (<= 96 VGPRs, no scratch)
+#endif
+using i32x4 = __attribute__((ext_vector_type(4))) int;
+using f64x2 = __attribute__((ext_vector_type(2))) double;
+
+__device__ __forceinline__ void init_window(int *win, int tid)
+{
+    FK_UNROLL for (int g = 0; g < 3; ++g) *reinterpret_cast<i32x4 *>(&win[12 * tid + 4 * g]) = i32x4{-1, -1, -1, -1};
+}
+
+template <bool STRATIFIED>
+__global__ void __launch_bounds__(OP_THREADS, FK_OP_WAVES)
+resample_onepass_kernel(const OpArgs a)
+{
+    __shared__ OpShared sh;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long Np = a.Np, nch = a.nch;
+    OP_CLOCK_START();
+
+    // ---- ticket: chunk (f, k).  Filters are split into contiguous regions, one head each; a workgroup starts at
+    // its home region (blockIdx % regions ~ its XCD) and moves on when that one is exhausted.  Inside a region the
+    // tickets run chunk-major (chunk k of every filter of the region before chunk k + 1 of any): the resident
+    // workgroups then advance all the region's filters together, and a chunk that has to resolve its carry with the
+    // general scan (a binade crossing: ~20 per 8e6-particle vector) holds up its own filter's chain only.
+    if (tid == 0) {
+        const int R = a.nregions;
+        int f = -1, k = 0;
+        for (int s = 0; s < R; ++s) {
+            const int r = (int)((blockIdx.x + (unsigned)s) % (unsigned)R);
+            const long f_lo = (long)a.Fn * r / R, f_hi = (long)a.Fn * (r + 1) / R;
+            const unsigned long cnt = (unsigned long)(f_hi - f_lo) * (unsigned long)nch;
+            const unsigned t = __hip_atomic_fetch_add(&a.ctl->head[r].next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (t < cnt) {
+                const unsigned nf = (unsigned)(f_hi - f_lo);
+                f = (int)(f_lo + t % nf);
+                k = (int)(t / nf);
+                break;
+            }
+        }
+        sh.bc_i[1] = f;
+        sh.bc_i[2] = k;
+    }
+    int *win = sh.win();
+    init_window(win, tid);                 // the output window (it shares its LDS with the general scan's tile)
+    __syncthreads();
+    const int f = __builtin_amdgcn_readfirstlane(sh.bc_i[1]);
+    const int k = __builtin_amdgcn_readfirstlane(sh.bc_i[2]);
+    if (f < 0) return;                                                     // cannot happen: one workgroup per chunk
+    OP_CLOCK(0);                                                           // ticket
+
+    const double *wf = a.w + (long)f * Np;
+    int32_t *of = a.idx + (long)f * Np;
+    const double u_sys = STRATIFIED ? 0.0 : a.u[f];
+    const double *u_str = STRATIFIED ? a.u + (long)f * Np : nullptr;
+    const double Nd = (double)Np, halfNd = 0.5 * Nd;
+    OpDesc *d = a.desc + (long)f * nch;
+    unsigned *abort_word = &a.ctl->abort;
+    const long base = (long)k * OP_TILE;
+    const int len = (int)((Np - base) < OP_TILE ? (Np - base) : OP_TILE);
+
+    // ---- weights: every thread reads its eight CONSECUTIVE weights straight from HBM (a wave covers 4 KiB with four
+    // 16-byte loads per lane: every byte of every line is used, nothing is staged or transposed through LDS) ----
+    double w8[OP_ITEMS];
+    {
+        const double *src = wf + base + tid * OP_ITEMS;
+        if (len == OP_TILE && (((uintptr_t)(wf + base)) & 15) == 0) {                          // uniform
+            FK_UNROLL for (int q = 0; q < OP_ITEMS; q += 2) {
+                const f64x2 t = *reinterpret_cast<const f64x2 *>(src + q);
+                w8[q] = t.x;
+                w8[q + 1] = t.y;
+            }
+        } else if (len == OP_TILE) {
+            FK_UNROLL for (int q = 0; q < OP_ITEMS; ++q) w8[q] = src[q];
+        } else {
+            FK_UNROLL for (int q = 0; q < OP_ITEMS; ++q) {
+                const int j = tid * OP_ITEMS + q;
+                const double t = wf[base + (j < len ? j : 0)];
+                w8[q] = j < len ? t : 0.0;
+            }
+        }
+    }
+    double s = 0.0, mn = 0.0;
+    FK_UNROLL for (int q = 0; q < OP_ITEMS; ++q) {
+        s += w8[q];
+        mn = w8[q] < mn ? w8[q] : mn;                                      // a negative weight (NaN / Inf show in the sum)
+    }
+    s = lane_bcast(wave_incl_sum(s), 63);
+    if (lane == 0) sh.wsum[wave] = s;
+    const int any_neg = __syncthreads_or(mn < 0.0 ? 1 : 0);                                  // (A)
+    double S = (sh.wsum[0] + sh.wsum[1]) + (sh.wsum[2] + sh.wsum[3]);
+    const bool any_bad = any_neg || !(S < 0x1p1000);                       // negative, NaN, Inf or absurdly large
+    if (any_bad) S = __builtin_nan("");
+    OP_CLOCK(1);                                                           // weights landed
+
+    // ---- stage 1: approximate carry-in --------------------------------------------------------------------
+    if (wave == 0) {
+        double A = 0.0;
+        if (k > 0) {
+            if (lane == 0) st_agent(&d[k].approx, pack_approx(S, 1));
+            A = lookback_approx(d, k, lane, abort_word);
+        }
+        if (lane == 0) {
+            st_agent(&d[k].approx, pack_approx(A + S, 2));
+            sh.bc_d[0] = A;
+        }
+    }
+    __syncthreads();                                                                          // (B)
+    const double A = sh.bc_d[0];
+    OP_CLOCK(2);                                                           // stage 1
+
+    // ---- what stage 1 tells this chunk --------------------------------------------------------------------
+    const bool poison = !(A >= 0.0 && S >= 0.0 && A + S < 0x1p1000);
+    if (poison) {                                                          // uniform
+        // a weight this path does not take (negative, NaN, huge) here or upstream: the whole filter is redone by
+        // resample_literal_kernel; successors only need to learn that quickly
+        if (tid == 0) {
+            publish_carry(&d[k], __builtin_nan(""));
+            if (any_bad) __hip_atomic_store(&a.bad[f], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (a.status && __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                atomicOr(&a.status[f], ST_INTERNAL);
+        }
+        return;
+    }
+    // A == 0 means EXACTLY: every weight before this chunk is +0.0 (they are all >= 0), so the carry-in is 0 and
+    // needs no stage 2; with S == 0 as well the chunk is empty-handed: carry-out 0, no slots
+    const bool at_start = (k == 0) || (A == 0.0);
+    bool clean = false;
+    int eu = 0;
+    {
+        const double lo = A * (1.0 - a.delta), hi = (A + S) * (1.0 + a.delta);
+        if (lo > OP_SANE_LO && hi < OP_SANE_HI && ulp_exp(lo) == ulp_exp(hi)) {
+            clean = true;
+            eu = ulp_exp(lo);
+        }
+    }
+    // increments in the promised binade (fk_exact_scan.hpp, fast_inc): inc = floor(w / ulp + 1/2) unless the
+    // remainder is exactly half an ulp -- such a chunk, and one whose sums reach 2^53 (which is also where t + 1/2
+    // stops being exact, and then the test fires by itself), leaves this path.  E[q] = inclusive sums of the thread.
+    double E[OP_ITEMS];
+    double excl = 0.0, I = 0.0;
+    bool fast = false;
+    if (clean) {                                                           // uniform
+        bool tie = false;
+        double run = 0.0;
+        FK_UNROLL for (int q = 0; q < OP_ITEMS; ++q) {
+            const double x = scale2(w8[q], -eu) + 0.5;
+            const double i = floor(x);
+            tie = tie || (i == x);
+            run += i;
+            E[q] = run;
+        }
+        const double winc = wave_incl_sum(run);
+        if (lane == 63) sh.wsum[wave] = winc;
+        const int any_tie = __syncthreads_or(tie ? 1 : 0);                                    // (C)
+        excl = winc - run;                                                 // exact: everything is an integer < 2^53 ...
+        FK_UNROLL for (int wv = 0; wv < OP_THREADS / 64; ++wv) {
+            if (wv < wave) excl += sh.wsum[wv];
+            I += sh.wsum[wv];
+        }
+        fast = !any_tie && I < 0x1p53;                                     // ... or this says so
+    } else {
+        FK_UNROLL for (int q = 0; q < OP_ITEMS; ++q) E[q] = 0.0;
+    }
+    OP_CLOCK(3);                                                           // increments
+
+    // ---- stage 2: exact carry-in ---------------------------------------------------------------------------
+    if (wave == 0) {
+        double c_in = 0.0;
+        bool ok = true;
+        if (!at_start) {
+            if (fast && lane == 0) st_agent(&d[k].exact, pack_exact(1, eu, I));
+            c_in = lookback_exact(d, k, fast, eu, lane, abort_word, ok);
+        }
+        // carry-out of a chunk that stayed inside its binade: known right now, successors need not wait for the scan
+        int quick = 0;
+        if (ok && fast && c_in > OP_SANE_LO && c_in < OP_SANE_HI && ulp_exp(c_in) == eu) {
+            const double Cout = scale2(c_in, -eu) + I;
+            if (Cout < 0x1p53) {
+                quick = 1;
+                if (lane == 0) publish_carry(&d[k], scale2(Cout, eu));
+            }
+        }
+        if (ok && at_start && S == 0.0) {
+            quick = 2;                                                     // still nothing but zeros
+            if (lane == 0) publish_carry(&d[k], 0.0);
+        }
+        // first slot of this chunk: everything below n(carry-in) belongs to earlier chunks
+        const int out_lo = at_start ? 0 : n_boundary_fast<STRATIFIED>(c_in, (int)Np, Nd, halfNd, u_sys, u_str);
+        if (lane == 0) {
+            sh.bc_d[1] = c_in;
+            sh.bc_i[3] = ok ? quick : -1;
+            sh.bc_i[4] = out_lo;
+        }
+    }
+    __syncthreads();                                                                          // (D)
+    const double c_in = sh.bc_d[1];
+    const int quick = __builtin_amdgcn_readfirstlane(sh.bc_i[3]);
+    const int u_lo = __builtin_amdgcn_readfirstlane(sh.bc_i[4]);
+    OP_CLOCK(4);                                                           // stage 2
+    OP_COUNT(8 + (quick < 0 ? 3 : quick), 1);                              // 8: general, 9: quick, 10: zeros
+    if (quick < 0) {                                                       // abort: a predecessor never published
+        if (tid == 0 && a.status) atomicOr(&a.status[f], ST_INTERNAL);
+        return;
+    }
+
+    // ---- slot boundaries: weight j owns the slots [n_{j-1}, n_j), n_j = n(cs_j)  (fk_resample_math.hpp) -----------
+    int nb[OP_ITEMS];
+    bool win_ready = true;
+    if (quick == 1) {                                                      // uniform
+        // cs_j = (C0 + E_j) ulp exactly, so N cs_j - u = fma(E_j, N ulp, C0 N ulp - u): ONE fma per weight gives the
+        // estimate whose ceiling is n_j whenever it is not within eps of an integer (n_boundary_fast's argument:
+        // here two roundings of 2^-22 slots each, the same budget); the rare rest takes the exact tests on cs_j.
+        const double ulp = scale2(1.0, eu), C0 = scale2(c_in, -eu), Nu = scale2(Nd, eu);
+        const double K = __builtin_fma(C0, Nu, STRATIFIED ? 0.0 : -u_sys);
+        unsigned unsure = 0;
+        FK_UNROLL for (int q = 0; q < OP_ITEMS; ++q) {
+            const double Et = excl + E[q];                                 // exact
+            const double e = __builtin_fma(Et, Nu, K);
+            const double fl = floor(e), fr = e - fl;
+            bool sure = fr > N_BOUNDARY_EPS && fr < 1.0 - N_BOUNDARY_EPS && e < Nd;
+            int n = (int)fl + 1;
+            if (STRATIFIED) {
+                const double uf = u_str[e < Nd ? (int)fl : 0];             // e >= 0 here
+                const double gap = uf - fr;
+                sure = sure && (gap > N_BOUNDARY_EPS || gap < -N_BOUNDARY_EPS);
+                n = (int)fl + (gap > 0.0 ? 0 : 1);
+            }
+            unsure |= sure ? 0u : (1u << q);
+            nb[q] = n;
+        }
+        if (unsure) {                                                      // about one weight in 10^5: the exact tests
+            // ONE inlined copy in a rolled loop; E[q] / nb[q] are picked and put back with selects (registers
+            // cannot be indexed)
+            _Pragma("nounroll") for (int q = 0; q < OP_ITEMS; ++q) {
+                if (!(unsure & (1u << q))) continue;
+                double Eq = E[0];
+                FK_UNROLL for (int r = 1; r < OP_ITEMS; ++r) Eq = (q == r) ? E[r] : Eq;
+                const int n = n_boundary<STRATIFIED>((C0 + (excl + Eq)) * ulp, (int)Np, Nd, halfNd, u_sys, u_str);
+                FK_UNROLL for (int r = 0; r < OP_ITEMS; ++r) nb[r] = (q == r) ? n : nb[r];
+            }
+        }
+#ifdef FK_OP_CLOCKS
+        FK_UNROLL for (int q = 0; q < OP_ITEMS; ++q) {
+            if (g_dbg_cs && tid * OP_ITEMS + q < len) {
+                g_dbg_cs[(long)f * Np + base + tid * OP_ITEMS + q] = (C0 + (excl + E[q])) * ulp;
+                g_dbg_n[(long)f * Np + base + tid * OP_ITEMS + q] = nb[q];
+            }
+        }
+#endif
+        OP_CLOCK(5);
+    } else if (quick == 2) {
+        FK_UNROLL for (int q = 0; q < OP_ITEMS; ++q) nb[q] = 0;
+        OP_CLOCK(5);
+    } else {
+        // general scan: the weights once more (L2), now into the padded LDS tile the scan works in
+        FK_UNROLL for (int q = 0; q < OP_ITEMS; ++q) {
+            const int j = tid * OP_ITEMS + q;
+            sh.tile[pad8(j)] = j < len ? wf[base + j] : 0.0;
+        }
+        __syncthreads();
+        const double c_out = general_cumsum(sh, len, c_in);
+        if (tid == 0) publish_carry(&d[k], c_out);
+        OP_CLOCK(5);                                                       // general scan
+        // (each thread reads back only its own slots, behind general_cumsum's final barrier; n_j goes into the low
+        // half of cs_j's slot so that this loop stays rolled)
+        int *nslot = reinterpret_cast<int *>(&sh.tile[pad8(tid * OP_ITEMS)]);
+        _Pragma("nounroll") for (int q = 0; q < OP_ITEMS; ++q) {
+            const int j = tid * OP_ITEMS + q;
+            const double c = j < len ? sh.tile[pad8(j)] : c_out;
+            const int n = n_boundary_fast<STRATIFIED>(c, (int)Np, Nd, halfNd, u_sys, u_str);
+            nslot[2 * q] = n;
+#ifdef FK_OP_CLOCKS
+            if (g_dbg_cs && j < len) {
+                g_dbg_cs[(long)f * Np + base + j] = c;
+                g_dbg_n[(long)f * Np + base + j] = n;
+            }
+#endif
+        }
+        FK_UNROLL for (int q = 0; q < OP_ITEMS; ++q) nb[q] = nslot[2 * q];
+        win_ready = false;                                                 // the tile overwrote the window
+    }
+    sh.nlast[tid] = nb[OP_ITEMS - 1];
+    __syncthreads();                                                                          // (E)
+    int nprev = tid == 0 ? u_lo : sh.nlast[tid - 1];
+    const int u_hi = __builtin_amdgcn_readfirstlane(sh.nlast[OP_THREADS - 1]);
+    // heads: the slot where each non-empty run starts (boundaries are non-decreasing for valid input)
+    int head[OP_ITEMS];
+    FK_UNROLL for (int q = 0; q < OP_ITEMS; ++q) {
+        head[q] = nb[q] > nprev ? nprev : -1;
+        nprev = nb[q] > nprev ? nb[q] : nprev;
+    }
+    OP_CLOCK(6);                                                           // boundaries
+
+    // ---- emission: windows of OP_WIN slots; heads -> inclusive max-scan -> coalesced 16-byte stores --------------
+    // (slot numbers fit an int: Np < 2^31; everything about a window is wave-uniform and lives in SGPRs)
+    const int mis = (int)(((uintptr_t)of >> 2) & 3);
+    int seed = -1;
+    for (int wb = u_lo - ((mis + u_lo) & 3); u_hi > u_lo && wb < u_hi; wb += OP_WIN) {        // uniform
+        if (!win_ready) {
+            __syncthreads();                                               // everybody is done with the tile / the last window
+            init_window(win, tid);
+            __syncthreads();
+        }
+        win_ready = false;
+        int have = 0;
+        FK_UNROLL for (int q = 0; q < OP_ITEMS; ++q) {
+            const unsigned h = (unsigned)(head[q] - wb);                   // a head below wb wraps to a huge number
+            if (head[q] >= 0 && h < (unsigned)OP_WIN) {
+                win[h] = (int)base + tid * OP_ITEMS + q;
+                have = 1;
+            }
+        }
+        const int any_head = __syncthreads_or(have);                                          // (G)
+        const int lim = u_hi - wb;                                         // slots [max(first, 0), lim) are ours
+        const int first = u_lo - wb;
+        int32_t *ow = of + wb;                                             // uniform; 16-byte aligned
+        const int s0 = 12 * tid;
+        int x[12];
+        if (any_head) {                                                    // uniform
+            FK_UNROLL for (int g = 0; g < 3; ++g) {
+                const i32x4 t = *reinterpret_cast<const i32x4 *>(&win[s0 + 4 * g]);
+                x[4 * g + 0] = t.x;
+                x[4 * g + 1] = t.y;
+                x[4 * g + 2] = t.z;
+                x[4 * g + 3] = t.w;
+            }
+            FK_UNROLL for (int e = 1; e < 12; ++e) x[e] = x[e] > x[e - 1] ? x[e] : x[e - 1];
+            const int wincl = wave_incl_max(x[11]);
+            if (lane == 63) sh.wmax[wave] = wincl;
+            __syncthreads();
+            const int up = __shfl_up(wincl, 1, 64);
+            int pre = (lane == 0 || up < seed) ? seed : up;               // everything before this thread, this wave
+            FK_UNROLL for (int wv = 0; wv < OP_THREADS / 64; ++wv) {
+                const int t = sh.wmax[wv];
+                if (wv < wave) pre = pre > t ? pre : t;
+                seed = seed > t ? seed : t;                                // every thread: running max after this window
+            }
+            FK_UNROLL for (int e = 0; e < 12; ++e) x[e] = x[e] > pre ? x[e] : pre;
+        } else {
+            // the whole window lies inside one run (a weight owning more than OP_WIN slots): constant fill
+            FK_UNROLL for (int e = 0; e < 12; ++e) x[e] = seed;
+        }
+        if (s0 < lim) {
+            FK_UNROLL for (int g = 0; g < 3; ++g) {
+                const int sg = s0 + 4 * g;
+                if (sg >= first && sg + 3 < lim) *reinterpret_cast<i32x4 *>(&ow[sg]) = i32x4{x[4 * g], x[4 * g + 1], x[4 * g + 2], x[4 * g + 3]};
+                else {
+                    FK_UNROLL for (int e = 0; e < 4; ++e)
+                        if (sg + e >= first && sg + e < lim) ow[sg + e] = x[4 * g + e];
+                }
+            }
+        }
+    }
+    OP_CLOCK(7);                                                           // emission
+    OP_COUNT(11, 1);
+    OP_CLOCK_FLUSH();
+
+    // ---- end of the vector: positions >= cumsum[-1] (the reference raises IndexError, resampling.py:109,145) --
+    if (k == nch - 1) {
+        for (long i = (long)u_hi + tid; i < Np; i += OP_THREADS) of[i] = (int32_t)(Np - 1);
+        if (tid == 0 && a.status && u_hi < (int)Np) atomicOr(&a.status[f], ST_OVERRUN);
+    }
+}
+
+// ---- filters the one-pass kernel declined (a negative / NaN / huge weight): the reference's loop, literally -----
+// cumulative_sum = np.cumsum(weights); i, j = 0, 0; while i < N: positions[i] < cumulative_sum[j] ? indexes[i] = j,
+// i += 1 : j += 1   (resampling.py:106-112 / 142-149; j == N is the IndexError).  One thread: such input is
+// garbage, but the answer is still the reference's.
+template <bool STRATIFIED>
+__global__ void __launch_bounds__(64)
+resample_literal_kernel(const OpArgs a)
+{
+    const int f = blockIdx.x;
+    const long Np = a.Np;
+    if (a.bad) {
+        if (!a.bad[f]) return;
+    } else {
+        // no verdict from the one-pass kernel (short vectors take resample_kernel): look for a weight that path is
+        // not defined on -- negative, NaN, Inf or absurdly large
+        int bad = 0;
+        for (long j = threadIdx.x; j < Np; j += 64) {
+            const double v = a.w[(long)f * Np + j];
+            bad |= !(v >= 0.0 && v < 0x1p1000);
+        }
+        if (!__syncthreads_or(bad)) return;
+    }
+    if (threadIdx.x != 0) return;
+    const double *wf = a.w + (long)f * Np;
+    int32_t *of = a.idx + (long)f * Np;
+    const double Nd = (double)Np;
+    long i = 0, j = 0;
+    double c = wf[0];
+    while (i < Np) {
+        const double ui = STRATIFIED ? a.u[(long)f * Np + i] : a.u[f];
+        const double p = (ui + (double)i) / Nd;
+        if (p < c) {
+            of[i] = (int32_t)j;
+            ++i;
+        } else {
+            ++j;
+            if (j == Np) break;
+            c = c + wf[j];
+        }
+    }
+    int st = 0;
+    for (; i < Np; ++i) {
+        of[i] = (int32_t)(Np - 1);
+        st = ST_OVERRUN;
+    }
+    if (a.status) a.status[f] = st;
+}
+
+#ifdef FK_OP_CLOCKS
+__global__ void debug_n_boundary_kernel(int K, const double *c, int Np, double u, int *out, double *aux)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= K) return;
+    const double Nd = (double)Np;
+    out[i] = n_boundary<false>(c[i], Np, Nd, 0.5 * Nd, u, nullptr);
+    const double e = c[i] * Nd - u;
+    const int b = e > 0.0 ? (int)e : 0;
+    aux[4 * i + 0] = e;
+    aux[4 * i + 1] = pos_ge(u + (double)b, c[i], Nd, 0.5 * Nd) ? 1.0 : 0.0;
+    aux[4 * i + 2] = __builtin_fma(Nd, c[i], -(u + (double)b));
+    aux[4 * i + 3] = (c[i] - bits_to_double(double_to_bits(c[i]) - 1)) * (0.5 * Nd);
+}
+}  // namespace fk
+extern "C" int fk_debug_n_boundary(int K, const double *c, int Np, double u, int *out, double *aux)
+{
+    hipLaunchKernelGGL(fk::debug_n_boundary_kernel, dim3((K + 63) / 64), dim3(64), 0, 0, K, c, Np, u, out, aux);
+    return hipDeviceSynchronize() == hipSuccess ? 0 : -1;
+}
+extern "C" int fk_debug_set_dump(double *cs, int *n)
+{
+    if (hipMemcpyToSymbol(HIP_SYMBOL(fk::g_dbg_cs), &cs, sizeof(cs)) != hipSuccess) return -1;
+    return hipMemcpyToSymbol(HIP_SYMBOL(fk::g_dbg_n), &n, sizeof(n)) == hipSuccess ? 0 : -1;
+}
+extern "C" int fk_debug_op_phases(unsigned long long *out)     // only in the instrumented build (tools/op_phase.py)
+{
+    using namespace fk;
+    static unsigned long long host[OP_PHASE_SLOTS][OP_PHASE_BUCKETS];
+    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(fk_op_phase), sizeof(host)) != hipSuccess) return FK_ERR_LAUNCH;
+    for (int q = 0; q < OP_PHASE_SLOTS; ++q) {
+        out[q] = 0;
+        for (int b = 0; b < OP_PHASE_BUCKETS; ++b) out[q] += host[q][b];
+    }
+    memset(host, 0, sizeof(host));
+    return hipMemcpyToSymbol(HIP_SYMBOL(fk_op_phase), host, sizeof(host)) == hipSuccess ? FK_OK : FK_ERR_LAUNCH;
+}
+namespace fk {
+#endif
+
+static size_t op_align(size_t v) { return (v + 255) & ~(size_t)255; }
+
+// short vectors (resample_kernel): redo the filters that hold a weight that kernel is not defined on, literally
+int literal_fixup_launch(bool stratified, int64_t Fn, int64_t Np, const double *w, const double *u, int32_t *idx,
+                         int32_t *status, hipStream_t s)
+{
+    OpArgs a = {};
+    a.Np = (long)Np;
+    a.Fn = (int)Fn;
+    a.w = w;
+    a.u = u;
+    a.idx = idx;
+    a.status = status;
+    a.bad = nullptr;
+    if (stratified) hipLaunchKernelGGL((resample_literal_kernel<true>), dim3((unsigned)Fn), dim3(64), 0, s, a);
+    else hipLaunchKernelGGL((resample_literal_kernel<false>), dim3((unsigned)Fn), dim3(64), 0, s, a);
+    return check_launch("resample_literal_kernel");
+}
+
+size_t onepass_workspace_bytes(int64_t Fn, int64_t Np)
+{
+    if (Fn <= 0 || Np <= 0) return 0;
+    const size_t nch = (size_t)((Np + OP_TILE - 1) / OP_TILE);
+    return op_align(sizeof(OpCtl)) + op_align((size_t)Fn * nch * sizeof(OpDesc)) + op_align((size_t)Fn * sizeof(int));
+}
+
+int onepass_launch(bool stratified, int64_t Fn, int64_t Np, const double *w, const double *u, int32_t *idx,
+                   int32_t *status, void *ws, size_t ws_bytes, hipStream_t s)
+{
+    const long nch = (long)((Np + OP_TILE - 1) / OP_TILE);
+    const size_t need = onepass_workspace_bytes(Fn, Np);
+    if (!ws || ws_bytes < need) return FK_ERR_WORKSPACE;
+    const unsigned long total = (unsigned long)Fn * (unsigned long)nch;
+    if (total >= 0x7fffffffUL || Fn > 0x7fffffffL / 2) return FK_ERR_UNSUPPORTED;
+    char *p = (char *)ws;
+    OpArgs a;
+    a.Np = (long)Np;
+    a.nch = nch;
+    a.Fn = (int)Fn;
+    a.nregions = Fn < OP_REGIONS ? (int)Fn : OP_REGIONS;
+    a.w = w;
+    a.u = u;
+    a.idx = idx;
+    a.status = status;
+    a.ctl = (OpCtl *)p;
+    a.desc = (OpDesc *)(p + op_align(sizeof(OpCtl)));
+    a.bad = (int *)(p + op_align(sizeof(OpCtl)) + op_align((size_t)Fn * nch * sizeof(OpDesc)));
+    a.delta = (8.0 * (double)(Np + 4096) + 16.0 * (double)nch) * 0x1p-53;
+    if (hipMemsetAsync(ws, 0, need, s) != hipSuccess) return FK_ERR_LAUNCH;
+    if (status && hipMemsetAsync(status, 0, (size_t)Fn * sizeof(int32_t), s) != hipSuccess) return FK_ERR_LAUNCH;
+    if (stratified) {
+        hipLaunchKernelGGL((resample_onepass_kernel<true>), dim3((unsigned)total), dim3(OP_THREADS), 0, s, a);
+        hipLaunchKernelGGL((resample_literal_kernel<true>), dim3((unsigned)Fn), dim3(64), 0, s, a);
+    } else {
+        hipLaunchKernelGGL((resample_onepass_kernel<false>), dim3((unsigned)total), dim3(OP_THREADS), 0, s, a);
+        hipLaunchKernelGGL((resample_literal_kernel<false>), dim3((unsigned)Fn), dim3(64), 0, s, a);
+    }
+    return check_launch("resample_onepass_kernel");
+}
+
+}  // namespace fk

@@ -1,0 +1,23 @@
+// resample_onepass.hpp -- entry of the one-pass resampling path (resample_onepass.hip), called by the C-ABI
+// functions in resample_kernels.hip.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace fk {
+
+size_t onepass_workspace_bytes(int64_t Fn, int64_t Np);
+
+// systematic (u [Fn]) / stratified (u [Fn][Np]) resampling of Fn weight vectors of Np weights; `ws` must hold
+// onepass_workspace_bytes(Fn, Np) bytes (it is zeroed here, on `s`).  Returns FK_OK / FK_ERR_*.
+int onepass_launch(bool stratified, int64_t Fn, int64_t Np, const double *w, const double *u, int32_t *idx,
+                   int32_t *status, void *ws, size_t ws_bytes, hipStream_t s);
+
+// after resample_kernel (short vectors): filters holding a negative / NaN / huge weight are redone by the reference's
+// merge loop, literally (one thread each)
+int literal_fixup_launch(bool stratified, int64_t Fn, int64_t Np, const double *w, const double *u, int32_t *idx,
+                         int32_t *status, hipStream_t s);
+
+}  // namespace fk

@@ -32,6 +32,9 @@ def _prep(weights):
 
 
 def _finish(idx, status, batched, name):
+    from .. import _abi
+    if bool((status & _abi.FK_STATUS_INTERNAL).any()):
+        raise _abi.FilterHipError(f"{name}: an in-launch hand-off of the resampling kernel timed out")
     bad = status.nonzero()
     if bad.numel():
         # a position >= cumulative_sum[-1]: the reference's merge loop runs off the end
@@ -90,6 +93,8 @@ def residual_resample(weights):
     num_copies = torch.floor(N * wd)                              # :61
     counts = num_copies.to(torch.int64)
     k = int(counts.sum())
+    if k > N:        # the reference's fill loop writes indexes[k] past the end (resampling.py:63-66)
+        raise IndexError(f"index {N} is out of bounds for axis 0 with size {N}")
     idx = torch.zeros(N, dtype=torch.int32, device=wd.device)
     if k:
         idx[:k] = torch.repeat_interleave(torch.arange(N, device=wd.device, dtype=torch.int32), counts)[:N]

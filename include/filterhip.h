@@ -67,8 +67,10 @@ enum {
     FK_STATUS_NOT_PD = 1,      /* S (or Pp / P for RTS / sigma points) not positive definite:
                                   the reference would raise numpy.linalg.LinAlgError or return junk */
     FK_STATUS_NONFINITE = 2,   /* NaN/Inf in the track's state after the call */
-    FK_STATUS_OVERRUN = 4      /* resample: a position >= cumsum[-1] (reference: IndexError,
+    FK_STATUS_OVERRUN = 4,     /* resample: a position >= cumsum[-1] (reference: IndexError,
                                   resampling.py:109,145); the index is clamped to Np-1 */
+    FK_STATUS_INTERNAL = 8     /* resample: an in-launch hand-off timed out (never expected; the indices of this
+                                  filter are not valid) */
 };
 
 /* ------------------------------------------------------------------ */

@@ -193,6 +193,111 @@ def test_chunk_parallel_path_equals_serial_path(monkeypatch):
             assert np.array_equal(out["parallel"][1][f], ref), f
 
 
+# ---- the one-pass path (resample_onepass.hip) ---------------------------------------------------------------------
+_FAMILIES = ("uniform", "heavy_tail", "zeros", "leading_zeros", "one_heavy", "ties", "sum_half", "unnormalised",
+             "all_zero_filter", "negative", "nan")
+
+
+def _family(kind, Fn, Np, rs):
+    """weight families that drive every route of the kernel: the quick route, binade crossings and half-ulp ties
+    (general scan), runs of zero weights, one weight owning many windows of slots, positions past cumsum[-1]
+    (IndexError), and garbage (negative / NaN: the reference's loop, literally)."""
+    w = rs.rand(Fn, Np)
+    if kind == "heavy_tail":
+        w = w ** 12
+    elif kind == "zeros":
+        w = np.where(rs.rand(Fn, Np) < 0.7, 0.0, w)
+    elif kind == "leading_zeros":
+        w[:, : (Np * 3) // 10] = 0.0
+    elif kind == "one_heavy":
+        w[:, Np // 3] = 1e4
+    elif kind == "ties":
+        w = np.floor(w * 2 ** 20) * 2.0 ** -40
+    w = w / w.sum(axis=1, keepdims=True)
+    if kind == "sum_half":
+        w = w * 0.5
+    elif kind == "unnormalised":
+        w = w * 1e6
+    elif kind == "all_zero_filter":
+        w[0] = 0.0
+    elif kind == "negative":
+        w[-1, Np // 2] = -0.25 / Np
+        w[0, 0] = -1e-9
+    elif kind == "nan":
+        w[-1, Np // 5] = np.nan
+    return np.ascontiguousarray(w)
+
+
+def _check_against_merge_loop(Fn, Np, kinds, filters, monkeypatch, force):
+    import torch
+    from filterpy_amd import _engine as E
+    from oracle import resample_oracle as ro
+    if force:
+        monkeypatch.setenv("FK_RESAMPLE_PATH", "onepass")
+    for strat in (0, 1):
+        for kind in kinds:
+            rs = np.random.RandomState(hash((Np, kind, strat)) % (2 ** 31))
+            w = _family(kind, Fn, Np, rs)
+            u = rs.rand(Fn, Np) if strat else rs.rand(Fn)
+            dw, du = E.dev(w), E.dev(u)
+            idx = torch.full((Fn, Np), -7, dtype=torch.int32, device=dw.device)
+            st = torch.zeros(Fn, dtype=torch.int32, device=dw.device)
+            (E.resample_stratified if strat else E.resample_systematic)(Fn, Np, dw, du, idx, st)
+            got, sth = idx.cpu().numpy(), st.cpu().numpy()
+            for f in filters:
+                ref, over = (ro.stratified_c if strat else ro.systematic_c)(w[f], u[f])
+                ok = ref < Np                      # the slots the reference fills before it raises IndexError
+                assert np.array_equal(got[f][ok], ref[ok]), (Np, kind, strat, f, int(np.argmax(got[f][ok] != ref[ok])))
+                assert bool(sth[f] & 4) == (over > 0) and not (sth[f] & 8), (Np, kind, strat, f, int(sth[f]))
+
+
+@pytest.mark.parametrize("Np", [1, 2, 100, 2049, 65536])
+def test_onepass_every_route_small(Np, monkeypatch):
+    """FK_RESAMPLE_PATH=onepass forces short vectors through the one-pass kernel: every weight family, every filter,
+    against the reference's merge loop (C restatement), systematic and stratified."""
+    kinds = [k for k in _FAMILIES if not (k in ("negative", "nan") and Np < 8)]
+    _check_against_merge_loop(5, Np, kinds, range(5), monkeypatch, force=True)
+
+
+def test_onepass_every_route_long(monkeypatch):
+    """default dispatch on a long ragged vector (not a multiple of the chunk, odd address alignment per filter)"""
+    _check_against_merge_loop(6, 1000003, _FAMILIES, (0, 3, 5), monkeypatch, force=False)
+
+
+def test_short_vectors_with_garbage_weights_follow_the_reference_loop(monkeypatch):
+    """default dispatch, short vectors (one workgroup per filter): filters with a negative / NaN weight are redone
+    by the literal merge loop"""
+    _check_against_merge_loop(4, 8000, ("uniform", "negative", "nan", "sum_half"), range(4), monkeypatch, force=False)
+
+
+def test_c5_multi_filter_8e6_particles():
+    """BASELINE configs[4] read as 8e6 particles PER filter: several such filters in one call (one GPU's share is
+    125), indices bit-exact against the merge loop on the first, a middle and the last filter, plus the fused
+    posterior mean (the summary state the ranks all-gather) against numpy on those filters."""
+    import torch
+    from filterpy_amd import _engine as E
+    from oracle import resample_oracle as ro
+    Fn, Np, d = 6, 8_000_000, 4
+    dev = torch.device("cuda")
+    g = torch.Generator(device=dev)
+    g.manual_seed(3)
+    w = torch.rand((Fn, Np), generator=g, device=dev, dtype=torch.float64)
+    w /= w.sum(dim=1, keepdim=True)
+    u = E.dev(np.random.RandomState(5).rand(Fn))
+    particles = torch.randn((Fn, Np, d), generator=g, device=dev, dtype=torch.float64)
+    idx = torch.empty((Fn, Np), dtype=torch.int32, device=dev)
+    st = torch.zeros(Fn, dtype=torch.int32, device=dev)
+    mean = torch.empty((Fn, d), dtype=torch.float64, device=dev)
+    E.resample_systematic(Fn, Np, w, u, idx, st)
+    E.resample_gather_mean(Fn, Np, d, particles, idx, mean)
+    assert not st.any()
+    for f in (0, 3, Fn - 1):
+        ref, over = ro.systematic_c(w[f].cpu().numpy(), float(u[f]))
+        assert over == 0 and np.array_equal(idx[f].cpu().numpy(), ref), f
+        want = particles[f].cpu().numpy()[ref].mean(axis=0)
+        assert np.allclose(mean[f].cpu().numpy(), want, rtol=1e-11, atol=1e-13), f
+
+
 def test_gather_mean_vs_numpy():
     """fk_resample_gather_mean_f64 (the fused "resample from index" + mean of BASELINE configs[4]):
     against numpy on the indices the resampler produced, ragged sizes, d = 1..8."""

@@ -1,0 +1,89 @@
+"""Where does resample_onepass_kernel spend its time?  Builds an INSTRUMENTED copy of the resampling units
+(-DFK_OP_CLOCKS -> filterpy_amd/csrc/exp_build/libop_phase.so; the shipped libfilterhip.so carries none of it), runs
+systematic resampling and prints thread 0's shader-clock ticks per phase and workgroup:
+
+    python tools/op_phase.py --build            # here (hipcc cross-compiles)
+    python tools/op_phase.py --run [--shapes 125x8000000,1000x8000]      # on the GPU box
+"""
+import argparse
+import ctypes
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+CSRC = os.path.join(ROOT, "filterpy_amd", "csrc")
+LIB = os.path.join(CSRC, "exp_build", "libop_phase%s.so")
+PHASES = ["ticket", "load+stage", "stage1", "increments", "stage2", "general_scan", "boundaries", "emission"]
+COUNTS = {8: "general", 9: "quick", 10: "zeros", 11: "workgroups"}
+
+
+def build(extra, tag):
+    os.makedirs(os.path.join(CSRC, "exp_build"), exist_ok=True)
+    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+           "-fno-gpu-rdc", "-DFK_OP_CLOCKS"] + extra + ["-o", LIB % tag, os.path.join(CSRC, "resample_onepass.hip"),
+           os.path.join(CSRC, "resample_kernels.hip"), "-x", "hip", os.path.join(CSRC, "fk_host.cpp")]
+    subprocess.check_call(cmd, cwd=CSRC)
+    print("built", LIB % tag)
+
+
+def run(shapes, iters, strat, tag):
+    import torch
+    lib = ctypes.CDLL(LIB % tag)
+    dev = torch.device("cuda")
+    for shape in shapes.split(","):
+        Fn, Np = (int(v) for v in shape.split("x"))
+        g = torch.Generator(device=dev)
+        g.manual_seed(1)
+        w = torch.rand((Fn, Np), generator=g, device=dev, dtype=torch.float64)
+        w /= w.sum(dim=1, keepdim=True)
+        u = torch.rand((Fn, Np) if strat else (Fn,), generator=g, device=dev, dtype=torch.float64)
+        idx = torch.empty((Fn, Np), dtype=torch.int32, device=dev)
+        lib.fk_resample_workspace_bytes.restype = ctypes.c_size_t
+        nb = lib.fk_resample_workspace_bytes(ctypes.c_int64(Fn), ctypes.c_int64(Np))
+        ws = torch.empty(max(nb, 8), dtype=torch.uint8, device=dev)
+        p = ctypes.c_void_p
+        fn = lib.fk_resample_stratified_f64 if strat else lib.fk_resample_systematic_f64
+
+        def go():
+            rc = fn(ctypes.c_int64(Fn), ctypes.c_int64(Np), p(w.data_ptr()), p(u.data_ptr()),
+                    p(idx.data_ptr()), p(0), p(ws.data_ptr()), ctypes.c_size_t(nb), p(0))
+            assert rc == 0, rc
+        out = (ctypes.c_ulonglong * 16)()
+        go()
+        torch.cuda.synchronize()
+        lib.fk_debug_op_phases(out)          # clear
+        t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0.record()
+        for _ in range(iters):
+            go()
+        t1.record()
+        torch.cuda.synchronize()
+        assert lib.fk_debug_op_phases(out) == 0
+        v = [int(x) for x in out]
+        nwg = float(v[11]) or 1.0
+        tot = float(sum(v[:8])) or 1.0
+        print(json.dumps({"tag": tag, "shape": shape, "stratified": strat, "ms_per_call": round(t0.elapsed_time(t1) / iters, 4),
+                          "ticks_per_workgroup": {k: round(t / nwg, 1) for k, t in zip(PHASES, v[:8])},
+                          "share": {k: round(t / tot, 3) for k, t in zip(PHASES, v[:8])},
+                          "total_ticks_per_workgroup": round(tot / nwg, 1),
+                          "counts_per_call": {n: v[s] / iters for s, n in COUNTS.items()}}), flush=True)
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--build", action="store_true")
+    ap.add_argument("--run", action="store_true")
+    ap.add_argument("--shapes", default="125x8000000,1000x8000,8x8000000")
+    ap.add_argument("--iters", type=int, default=3)
+    ap.add_argument("--stratified", type=int, default=0)
+    ap.add_argument("--define", action="append", default=[])
+    ap.add_argument("--tag", default="")
+    a = ap.parse_args()
+    if a.build:
+        build(["-D" + d for d in a.define], a.tag)
+    if a.run:
+        run(a.shapes, a.iters, a.stratified, a.tag)
+    if not (a.build or a.run):
+        ap.print_help()
