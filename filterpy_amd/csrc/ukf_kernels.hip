@@ -23,10 +23,10 @@ namespace fk {
 // never all materialised: the predict makes two sweeps over the 2n+1 points (mean, then covariance),
 // regenerating each point x +- L[:,k] and pushing it through F on the fly -- ~70 live doubles at
 // n = 6 instead of ~260 (the first version spilled 196 registers at one wave per SIMD).
-// Two builds of the kernel.  The default is the one every GPU parity test of round 1 ran against.  -DFK_UKF_V2
-// (tools/exp_ukf2.py builds it into a separate build/libfk_exp_ukf.so) is the same arithmetic -- every sum
-// accumulates over the sigma points in the same index order -- reorganised for registers, written at the end of
-// round 1 when no GPU time was left, so NOT validated on a GPU yet:
+// Two organisations of the kernel.  ukf_linear_kernel is the straightforward one; ukf_linear_kernel_v2 is the same
+// arithmetic -- every sum accumulates over the sigma points in the same index order -- reorganised for registers
+// (step arithmetic in fk_ukf.hpp, held against the oracle on the host; on the GPU it agrees with the first to 2e-13
+// and with the oracle to 1e-13, profiles/r02/exp_ukf2.log):
 //   * the mean sweeps run point by point like the covariance sweeps (row by row, the compiler kept all
 //     (2n+1) n sigma-point values alive across the rows);
 //   * the measurement update is two sweeps (zp, then S and Pxz) instead of holding all H sigma_i;
@@ -34,10 +34,9 @@ namespace fk {
 //     (otherwise the broadcast reads of all points are hoisted and held);
 //   => (6,3): 223 (SOA) / 256 (AOS) VGPRs, no scratch, two waves per SIMD, against 512 VGPRs + 44 spilled
 //      registers at one wave per SIMD.
-#ifdef FK_UKF_V2
 template <int NX, int NZ, int LAYOUT>
 __global__ void __launch_bounds__(BLOCK, (NX <= 2 ? 4 : 2))
-ukf_linear_kernel(const UkfArgs a, const double *__restrict__ pF, const double *__restrict__ pH,
+ukf_linear_kernel_v2(const UkfArgs a, const double *__restrict__ pF, const double *__restrict__ pH,
                   const double *__restrict__ pQ, const double *__restrict__ pR,
                   const double *__restrict__ pWm, const double *__restrict__ pWc,
                   const double *__restrict__ pz, const uint8_t *__restrict__ pmask)
@@ -120,7 +119,6 @@ ukf_linear_kernel(const UkfArgs a, const double *__restrict__ pF, const double *
         }
     }
 }
-#else
 template <int NX, int NZ, int LAYOUT>
 __global__ void __launch_bounds__(BLOCK, (NX <= 2 ? 4 : NX <= 4 ? 2 : 1))
 ukf_linear_kernel(const UkfArgs a, const double *__restrict__ pF, const double *__restrict__ pH,
@@ -346,7 +344,6 @@ ukf_linear_kernel(const UkfArgs a, const double *__restrict__ pF, const double *
         }
     }
 }
-#endif
 
 static int fail(int code, const char *msg)
 {
@@ -384,9 +381,14 @@ int fk_ukf_linear_batch_f64(const fk_ukf_desc *d, const double *F, const double 
     else                                                                                                \
         hipLaunchKernelGGL((ukf_linear_kernel<NXV, NZV, LAYOUT_AOS>), grid, block, 0, s, a, F, H, Q, R, \
                            Wm, Wc, z, mask)
+    // the register-lean organisation wins where the straightforward one runs at one wave per SIMD ((6,3): 3.08 ->
+    // 2.68 ms SOA, 4.22 -> 2.90 ms AOS at 1e5 x 100; profiles/r02/exp_ukf2.log) and loses below it
     if (d->n <= 2 && d->m <= 2) { GO(2, 2); }
     else if (d->n <= 4 && d->m <= 2) { GO(4, 2); }
-    else { GO(6, 3); }
+    else if (d->layout == FK_LAYOUT_SOA)
+        hipLaunchKernelGGL((ukf_linear_kernel_v2<6, 3, LAYOUT_SOA>), grid, block, 0, s, a, F, H, Q, R, Wm, Wc, z, mask);
+    else
+        hipLaunchKernelGGL((ukf_linear_kernel_v2<6, 3, LAYOUT_AOS>), grid, block, 0, s, a, F, H, Q, R, Wm, Wc, z, mask);
 #undef GO
     return check_launch("ukf_linear_kernel");
 }

@@ -418,59 +418,6 @@ extern "C" long hc_cumsum_exact(long N, const double *w, double *cs)
     return segs;
 }
 
-// One tile from a given scan state through (a) the general algorithm (tile_cumsum_exact) and (b) the lean
-// output kernel's route (resample_chunk_lean_kernel: one tie-free binade segment with the kernel's wave-scan
-// association order, or "todo").  Returns the lean route's todo flag; cs_general / cs_lean get the sums.
-extern "C" int hc_tile_lean_vs_general(int len, const double *w, double cin, int started_in, int prelude_in,
-                                       int first_chunk, double *cs_general, double *cs_lean)
-{
-    {
-        std::vector<double> tile(T_TILE, 0.0);
-        std::copy(w, w + len, tile.begin());
-        bool started = started_in != 0;
-        int prelude = prelude_in;
-        long segs = 0;
-        tile_cumsum_emul(tile.data(), len, cin, started, &segs, prelude);
-        std::copy(tile.begin(), tile.begin() + len, cs_general);
-    }
-    const bool can = started_in != 0 && prelude_in == 0 && cin > 0.0 && cin <= 1.79769313486231570815e+308 && !first_chunk;
-    if (!can) return 1;
-    const double ulp = ulp_of(cin);
-    const int eu = ulp_exp(cin);
-    const double C0d = scale2(cin, -eu);
-    std::vector<double> incl(T_TILE), inc(T_THREADS);
-    bool odd = false;
-    for (int t = 0; t < T_THREADS; ++t) {
-        double runs = 0.0;
-        for (int q = 0; q < T_ITEMS; ++q) {
-            const int j = t * T_ITEMS + q;
-            bool tk = false;
-            const double e = j < len ? fast_inc(w[j], eu, tk) : 0.0;
-            odd = odd || tk;
-            runs += e;
-            incl[j] = runs;
-        }
-        inc[t] = runs;
-    }
-    for (int d = 1; d < 64; d <<= 1) {                 // the kernel's Hillis-Steele wave scan
-        std::vector<double> nxt = inc;
-        for (int t = 0; t < T_THREADS; ++t)
-            if ((t & 63) >= d) nxt[t] = inc[t] + inc[t - d];
-        inc = nxt;
-    }
-    for (int t = 0; t < T_THREADS; ++t) {
-        double excl = (t & 63) ? inc[t - 1] : 0.0;
-        for (int wv = 0; wv < (t >> 6); ++wv) excl += inc[wv * 64 + 63];
-        for (int q = 0; q < T_ITEMS; ++q) {
-            const int j = t * T_ITEMS + q;
-            incl[j] = C0d + (excl + incl[j]);
-            odd = odd || (j < len && !(incl[j] < 0x1p53));
-        }
-    }
-    if (odd) return 1;
-    for (int j = 0; j < len; ++j) cs_lean[j] = incl[j] * ulp;
-    return 0;
-}
 
 // The output loop of resample_kernel / resample_chunk_kernel on one tile: the tile's cumulative sums
 // (cs, from carry-in c_in), the slot positions ps, and fk::tile_upper_bound exactly as the kernels call it.
@@ -484,115 +431,7 @@ extern "C" void hc_tile_search(int len, const double *cs, double c_in, long n_po
     for (long i = 0; i < n_pos; ++i) out[i] = fk::tile_upper_bound(g.data() + 1, len, ps[i], c_in, inv_span);
 }
 
-// Output loop of the experimental lean kernel (csrc/experimental/resample_lean2.hip): groups of 8 consecutive
-// (non-decreasing) positions, the first by fk::tile_upper_bound, the others by walking on from the previous index
-// over the guarded tile.
-extern "C" void hc_tile_search_walk(int len, const double *cs, double c_in, long n_pos, const double *ps, int *out)
-{
-    const double inf = std::numeric_limits<double>::infinity();
-    std::vector<double> g(1 + len + fk::TILE_GUARD, inf);
-    g[0] = -inf;
-    std::copy(cs, cs + len, g.begin() + 1);
-    const double *w = g.data() + 1;
-    const double inv_span = (double)len / (cs[len - 1] - c_in);
-    for (long i0 = 0; i0 < n_pos; i0 += 8) {
-        int r = 0;
-        for (long e = 0; e < 8 && i0 + e < n_pos; ++e) {
-            const double p = ps[i0 + e];
-            if (e == 0) r = fk::tile_upper_bound(w, len, p, c_in, inv_span);
-            else
-                while (w[r] <= p) ++r;
-            out[i0 + e] = r;
-        }
-    }
-}
 
-// Host emulation of the chunk-parallel plan/chain (resample_kernels.hip P1-P4): chunk sums in a
-// different association order, error-bounded binade guess, composite map per clean chunk, verified
-// O(1) chain step -- the resulting carry-in of every chunk must equal the sequential one.
-extern "C" long hc_cumsum_chunked(long N, const double *w, double *cs, long *n_shortcuts)
-{
-    const long nch = (N + T_TILE - 1) / T_TILE;
-    std::vector<double> S(nch), cin(nch);
-    std::vector<int> eu(nch, -100000), bad(nch, 0), st_started(nch), st_prelude(nch);
-    std::vector<Mono> F(nch);
-    for (long k = 0; k < nch; ++k) {
-        const long base = k * T_TILE;
-        const int len = (int)((N - base) < T_TILE ? (N - base) : T_TILE);
-        double part[4] = {0, 0, 0, 0};
-        for (int j = 0; j < len; ++j) {
-            part[j & 3] += w[base + j];
-            if (!(w[base + j] >= 0.0 && w[base + j] < 0x1p1000)) bad[k] = 1;
-        }
-        S[k] = (part[0] + part[1]) + (part[2] + part[3]);
-    }
-    const double delta = 8.0 * (double)(N + 4096) * 0x1p-53;
-    double A = 0.0;
-    bool poisoned = false;
-    for (long k = 0; k < nch; ++k) {
-        poisoned = poisoned || bad[k] || !(S[k] >= 0.0) || !(A + S[k] < 0x1p1000);
-        if (!poisoned && k > 0) {
-            const double lo = A * (1.0 - delta), hi = (A + S[k]) * (1.0 + delta);
-            if (lo > 0x1p-900 && ulp_exp(lo) == ulp_exp(hi)) eu[k] = ulp_exp(lo);
-        }
-        A += S[k];
-    }
-    for (long k = 0; k < nch; ++k) {
-        if (eu[k] == -100000) continue;
-        const long base = k * T_TILE;
-        const int len = (int)((N - base) < T_TILE ? (N - base) : T_TILE);
-        const double u = scale2(1.0, eu[k]);
-        // tree-ish order: per-thread runs of 8, then sequential over threads
-        Mono tot = mono_identity();
-        for (int t = 0; t < T_THREADS; ++t) {
-            Mono run = mono_identity();
-            for (int q = 0; q < T_ITEMS; ++q) {
-                const int j = t * T_ITEMS + q;
-                if (j < len) run = mono_compose(run, mono_elem(w[base + j], u, eu[k]));
-            }
-            tot = mono_compose(tot, run);
-        }
-        F[k] = tot;
-    }
-    double carry = 0.0;
-    bool started = false;
-    int prelude = 128;
-    long segs = 0;
-    std::vector<double> tile(T_TILE);
-    *n_shortcuts = 0;
-    for (long k = 0; k < nch; ++k) {
-        cin[k] = carry;
-        st_started[k] = started;
-        st_prelude[k] = prelude;
-        bool shortcut = false;
-        if (eu[k] != -100000 && started && prelude == 0 && carry > 0.0 && ulp_exp(carry) == eu[k]) {
-            const long long C0 = (long long)scale2(carry, -eu[k]);
-            const long long C1 = mono_apply(C0, F[k]);
-            if (C1 < MONO_LIMIT) {
-                carry = scale2((double)C1, eu[k]);
-                shortcut = true;
-                ++*n_shortcuts;
-            }
-        }
-        if (!shortcut) {
-            const long base = k * T_TILE;
-            const int len = (int)((N - base) < T_TILE ? (N - base) : T_TILE);
-            for (int j = 0; j < T_TILE; ++j) tile[j] = j < len ? w[base + j] : 0.0;
-            carry = tile_cumsum_emul(tile.data(), len, carry, started, &segs, prelude);
-        }
-    }
-    // P5: every chunk independently from its recorded carry-in
-    for (long k = 0; k < nch; ++k) {
-        const long base = k * T_TILE;
-        const int len = (int)((N - base) < T_TILE ? (N - base) : T_TILE);
-        for (int j = 0; j < T_TILE; ++j) tile[j] = j < len ? w[base + j] : 0.0;
-        bool stt = st_started[k] != 0;
-        int pre = st_prelude[k];
-        tile_cumsum_emul(tile.data(), len, cin[k], stt, &segs, pre);
-        for (int j = 0; j < len; ++j) cs[base + j] = tile[j];
-    }
-    return nch;
-}
 
 // --------------------------------------------------------------------------------- IMM --
 // One track's bank of nm filters, T x { predict; update }, padded like imm_kernel.

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """The one-pass resampling path (filterpy_amd/csrc/resample_onepass.hip) against the C oracle (the reference's merge
-loop, literally) and against the multi-pass path of round 1, bit for bit, on weight families that exercise every
+loop, literally) and against the one-workgroup-per-filter path (resample_kernel), bit for bit, on weight families that exercise every
 route of the kernel; then both paths are timed.  GPU box only.
 
     python tools/exp_onepass.py [--shapes 125x8000000,1000x8000,...] [--iters 10] [--quick]
@@ -63,7 +63,13 @@ def main():
     ok_all = True
 
     def run(path, strat, Fn, Np, w, u, idx, st):
-        os.environ["FK_RESAMPLE_PATH"] = path
+        # "onepass": every length through resample_onepass.hip; "serial": one workgroup per filter (resample_kernel)
+        os.environ.pop("FK_RESAMPLE_PATH", None)
+        os.environ.pop("FK_RESAMPLE_SERIAL", None)
+        if path == "onepass":
+            os.environ["FK_RESAMPLE_PATH"] = "onepass"
+        else:
+            os.environ["FK_RESAMPLE_SERIAL"] = "1"
         (E.resample_stratified if strat else E.resample_systematic)(Fn, Np, w, u, idx, st)
 
     for shape in a.shapes.split(","):
@@ -94,15 +100,15 @@ def main():
                         rec.setdefault("mismatch", []).append(
                             {"filter": f, "first_diff": int(np.flatnonzero(got[valid] != ref[valid])[0]) if (got[valid] != ref[valid]).any() else -1,
                              "n_diff": int((got[valid] != ref[valid]).sum()), "status": int(st[f]), "overrun": int(overrun)})
-                # the multi-pass path on everything (valid inputs only: it is not defined on garbage)
+                # the per-filter path on everything (valid inputs only)
                 if kind not in ("negative", "nan"):
                     old = torch.full((Fn, Np), -9, dtype=torch.int32, device=dev)
                     st2 = torch.zeros(Fn, dtype=torch.int32, device=dev)
-                    run("chunk", strat, Fn, Np, w, u, old, st2)
+                    run("serial", strat, Fn, Np, w, u, old, st2)
                     torch.cuda.synchronize()
                     okf = (st == 0) & (st2 == 0)
                     same_all = bool(torch.equal(new[okf], old[okf])) and bool(torch.equal(st != 0, st2 != 0))
-                    rec["equals_multipass"] = same_all
+                    rec["equals_serial_path"] = same_all
                     good &= same_all
                 rec["ok"] = good
                 ok_all &= good
@@ -118,7 +124,7 @@ def main():
             idx = torch.empty((Fn, Np), dtype=torch.int32, device=dev)
             st = torch.zeros(Fn, dtype=torch.int32, device=dev)
             rec = {"time_shape": shape, "stratified": strat}
-            for path in ("onepass", "chunk"):
+            for path in ("onepass", "serial"):
                 run(path, strat, Fn, Np, w, u, idx, st)
                 t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 t0.record()
