@@ -533,6 +533,31 @@ class KalmanFilter(object):
         self._set_x(xf[0])
         self.P = Pf[0]
         mu, cov, mup, covp = mu[:, 0], cov[:, 0], mup[:, 0], covp[:, 0]
+        if T and not want_hist:
+            # K, y, S, SI, z and the lazy likelihoods as the reference's per-epoch loop leaves them
+            # (kalman_filter.py:511-561): z and y belong to the last epoch, K / S / SI to the last epoch that had a
+            # measurement (update(None) leaves them alone) -- one single-step update launch on the state that
+            # update started from reproduces them
+            present = mask[:, 0].astype(bool)
+            self.z = deepcopy(zs[T - 1]) if present[T - 1] else np.array([[None] * m]).T
+            yv = None
+            meas = np.flatnonzero(present)
+            if meas.size:
+                i = int(meas[-1])
+                if update_first:
+                    px, pP = (x, P) if i == 0 else (mup[i - 1][None], covp[i - 1][None])
+                else:
+                    px, pP = mup[i][None], covp[i][None]
+                Hi, Ri = (Hm[i], Rm[i]) if per_step else (Hm, Rm)
+                _, _, yv, Ki, Si, SIi = _Core.update(n, m, 1, np.ascontiguousarray(px), np.ascontiguousarray(pP),
+                                                     z[i], Hi, Ri, FK_MODEL_SHARED)
+                self.K, self.S, self.SI = Ki[0], Si[0], SIi[0]
+                yv = yv[0]
+            if present[T - 1]:
+                self.y = yv.reshape(m, 1).copy() if x_ndim == 2 else yv.copy()
+            else:
+                self.y = np.zeros((m, 1))
+            self._log_likelihood = self._likelihood = self._mahalanobis = None
         if x_ndim == 2:
             mu, mup = mu[..., None], mup[..., None]
         if want_hist:

@@ -54,3 +54,43 @@ def test_batch_filter_fills_the_package_saver(monkeypatch, n, m):
     assert np.allclose(np.array(s["likelihood"], dtype=float), g[p + "likelihood"], rtol=1e-8, atol=1e-300)
     s.to_array()
     assert s.x.shape == g[p + "x"].shape and s.P.shape == g[p + "P"].shape
+
+
+def _fake_update(n, m, N, x, P, z, H, R, mode, mask=None, layout="soa"):
+    assert N == 1 and mode == kfm.FK_MODEL_SHARED and mask is None
+    xn, Pn, y, K, S, SI = kf_oracle.kf_update(x[0], P[0], np.asarray(z).reshape(m), R, H)
+    return xn[None], Pn[None], y[None], K[None], S[None], SI[None]
+
+
+@pytest.mark.parametrize("n,m", [(2, 1), (4, 2), (6, 3)])
+@pytest.mark.parametrize("drop_tail", [0, 1, 3])
+def test_attributes_after_batch_filter_without_saver(monkeypatch, n, m, drop_tail):
+    """without a saver the reference's per-epoch loop still leaves K, y, S, SI, z at the last
+    epoch and clears the cached likelihoods (kalman_filter.py:511-561, :940-993); the histories recorded by
+    filterpy.common.Saver from the live reference (kf_saver.npz) give the expected last values."""
+    monkeypatch.setattr(kfm._Core, "batch", staticmethod(_fake_batch))
+    monkeypatch.setattr(kfm._Core, "update", staticmethod(_fake_update))
+    g = golden("kf_saver")
+    p = f"n{n}m{m}_"
+    kf = kfm.KalmanFilter(dim_x=n, dim_z=m)
+    kf.x, kf.P = g[p + "x0"].copy(), g[p + "P0"].copy()
+    kf.F, kf.Q, kf.H, kf.R = g[p + "F"], g[p + "Q"], g[p + "H"], g[p + "R"]
+    zl = [zz if k else None for zz, k in zip(g[p + "zs"], g[p + "mask"])]
+    T = len(zl) - drop_tail
+    # cut the run so that it ends on a measured epoch (drop_tail = 0 may or may not) or on a missing one
+    while drop_tail == 3 and T > 1 and zl[T - 1] is not None:
+        T -= 1
+    zl = zl[:T]
+    kf._log_likelihood = kf._likelihood = kf._mahalanobis = 123.0   # stale cache from "before the call"
+    kf.batch_filter(zl)
+    for k in ("K", "S", "SI", "y"):
+        got, ref = np.asarray(getattr(kf, k), dtype=float), g[p + k][T - 1]
+        assert got.shape == ref.shape, (k, got.shape, ref.shape)
+        assert np.allclose(got, ref, rtol=1e-10, atol=1e-12), (k, T)
+    if zl[-1] is None:
+        assert kf.z.shape == (m, 1) and all(v is None for v in kf.z.ravel())
+    else:
+        assert np.array_equal(np.asarray(kf.z, dtype=float), np.asarray(zl[-1], dtype=float))
+    assert kf._log_likelihood is None and kf._likelihood is None and kf._mahalanobis is None
+    assert np.allclose(kf.log_likelihood, g[p + "log_likelihood"][T - 1], rtol=1e-9, atol=1e-9)
+    assert np.allclose(kf.mahalanobis, g[p + "mahalanobis"][T - 1], rtol=1e-9, atol=1e-11)
