@@ -25,7 +25,10 @@ c_i32, c_i64, c_f64, c_vp, c_sz = ctypes.c_int32, ctypes.c_int64, ctypes.c_doubl
 class fk_kf_desc(ctypes.Structure):
     _fields_ = [("n", c_i32), ("m", c_i32), ("nu", c_i32), ("model_mode", c_i32),
                 ("N", c_i64), ("T", c_i64), ("layout", c_i32), ("update_first", c_i32),
-                ("alpha_sq", c_f64)]
+                ("alpha_sq", c_f64), ("flags", c_i32), ("reserved", c_i32)]
+
+
+FK_KF_FLAG_R_JOSEPH_DIAG = 1
 
 
 class fk_kf_extras(ctypes.Structure):

@@ -19,6 +19,7 @@ struct KfArgs {
     int update_first;
     int do_predict, do_update;
     int xcd_swizzle;    // kf_fast: give each XCD (blockIdx % 8) one contiguous range of tracks
+    int rj_diag;        // FK_KF_FLAG_R_JOSEPH_DIAG: K R K' uses only R's diagonal (generic kernel only)
     double alpha_sq;
 };
 

@@ -210,8 +210,10 @@ FK_HD void kf_predict(double (&x)[NX], double (&P)[NX * NX], const Model &M, dou
 template <int NX, int NZ, class Model>
 FK_HD int kf_update(double (&x)[NX], double (&P)[NX * NX], const double (&z)[NZ], const Model &M,
                     double (&K)[NX * NZ], double (&y)[NZ], double (&S)[NZ * NZ],
-                    double (&Lf)[NZ * NZ], double (&dinv)[NZ])
+                    double (&Lf)[NZ * NZ], double (&dinv)[NZ], bool rj_diag = false)
 {
+    // rj_diag: the reference with a scalar R attribute and dim_z > 1 (kalman_filter.py:540 adds r to every element of
+    // S, :556 forms r K K'): R arrives as r * ones and the Joseph term below keeps only its diagonal
     int st = 0;
     double PHT[NX * NZ];
     FK_UNROLL for (int r = 0; r < NZ; ++r) {
@@ -279,6 +281,7 @@ FK_HD int kf_update(double (&x)[NX], double (&P)[NX * NX], const double (&z)[NZ]
     FK_UNROLL for (int r = 0; r < NZ; ++r) {
         double rr[NZ];
         M.rowR(r, rr);
+        FK_UNROLL for (int c = 0; c < NZ; ++c) rr[c] = (rj_diag && c != r) ? 0.0 : rr[c];
         FK_UNROLL for (int i = 0; i < NX; ++i)
             FK_UNROLL for (int c = 0; c < NZ; ++c)
                 KR[i * NZ + c] = (r == 0) ? K[i * NZ] * rr[c] : fma(K[i * NZ + r], rr[c], KR[i * NZ + c]);

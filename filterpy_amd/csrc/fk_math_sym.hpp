@@ -68,7 +68,7 @@ FK_HD void kf_predict_sym(double (&x)[NX], double (&U)[NX * (NX + 1) / 2], const
 template <int NX, int NZ, class Model>
 FK_HD int kf_update_sym(double (&x)[NX], double (&U)[NX * (NX + 1) / 2], const double (&z)[NZ], const Model &M,
                         double (&K)[NX * NZ], double (&y)[NZ], double (&S)[NZ * NZ],
-                        double (&Lf)[NZ * NZ], double (&dinv)[NZ])
+                        double (&Lf)[NZ * NZ], double (&dinv)[NZ], bool rj_diag = false)
 {
     int st = 0;
     double PHT[NX * NZ];
@@ -129,6 +129,7 @@ FK_HD int kf_update_sym(double (&x)[NX], double (&U)[NX * (NX + 1) / 2], const d
         FK_UNROLL for (int r = 0; r < NZ; ++r) {
             double rr[NZ];
             M.rowR(r, rr);
+            FK_UNROLL for (int c = 0; c < NZ; ++c) rr[c] = (rj_diag && c != r) ? 0.0 : rr[c];   // fk_math.hpp, kf_update
             FK_UNROLL for (int c = 0; c < NZ; ++c) D[c] = (r == 0) ? K[i * NZ] * rr[c] : fma(K[i * NZ + r], rr[c], D[c]);
         }
         FK_UNROLL for (int r = 0; r < NZ; ++r) {

@@ -18,9 +18,16 @@
 
 namespace fk {
 
-template <int NX, int NZ, class Fresh>
+struct NoSweep {
+    FK_HD void operator()() const {}
+};
+
+//   sweep() is called at the head of each of the four passes over the sigma points: a model policy that keeps F / H
+//   in scalar registers for the length of one pass re-derives its (optimiser-opaque) base there, so that the rows
+//   are re-fetched per pass instead of being hoisted out of the time loop and held.
+template <int NX, int NZ, class Fresh, class Sweep = NoSweep>
 FK_HD int ukf_linear_step_v2(double (&x)[NX], double (&P)[NX * (NX + 1) / 2], const double (&z)[NZ], bool has_z,
-                             double scale, Fresh &&fresh)
+                             double scale, Fresh &&fresh, Sweep &&sweep = Sweep{})
 {
     constexpr int KS = 2 * NX + 1;
     constexpr int PL = NX * (NX + 1) / 2;
@@ -33,6 +40,7 @@ FK_HD int ukf_linear_step_v2(double (&x)[NX], double (&P)[NX * (NX + 1) / 2], co
     // sweep 1: x- = sum_i Wm_i F sigma_i, one output component (row of F) at a time, points in
     // index order 0, x + L[:,k] (k = 0..n-1), x - L[:,k]
     double xm[NX];
+    sweep();
     FK_UNROLL for (int i = 0; i < KS; ++i) {
         const auto mv = fresh();
         const auto &sm = mv.sm;
@@ -61,6 +69,7 @@ FK_HD int ukf_linear_step_v2(double (&x)[NX], double (&P)[NX * (NX + 1) / 2], co
     double Pn[PL];
     FK_UNROLL for (int c = 0; c < NX; ++c) FK_OPAQUE(x[c]);
     FK_UNROLL for (int e = 0; e < PL; ++e) FK_OPAQUE(L[e]);
+    sweep();
     FK_UNROLL for (int i = 0; i < KS; ++i) {
         const auto mv = fresh();
         const auto &sm = mv.sm;
@@ -102,6 +111,7 @@ FK_HD int ukf_linear_step_v2(double (&x)[NX], double (&P)[NX * (NX + 1) / 2], co
         if (!chol_packed<NX>(P, scale, L)) st |= ST_NOT_PD;
         // sweep 1: zp = sum_i Wm_i H sigma_i, point by point (index order 0, +k, -k)
         double zp[NZ];
+        sweep();
         FK_UNROLL for (int i = 0; i < KS; ++i) {
             const auto mv = fresh();
             const auto &sm = mv.sm;
@@ -128,6 +138,7 @@ FK_HD int ukf_linear_step_v2(double (&x)[NX], double (&P)[NX * (NX + 1) / 2], co
         double S[NZ * NZ], K[NX * NZ];
         FK_UNROLL for (int c = 0; c < NX; ++c) FK_OPAQUE(x[c]);
         FK_UNROLL for (int e = 0; e < PL; ++e) FK_OPAQUE(L[e]);
+        sweep();
         FK_UNROLL for (int i = 0; i < KS; ++i) {
             const auto mv = fresh();
             const auto &sm = mv.sm;

@@ -120,6 +120,7 @@ static int check_desc(const fk_kf_desc *d)
     if (d->N < 0 || d->T < 0) return fail(FK_ERR_BAD_ARG, "N and T must be >= 0");
     if (d->layout != FK_LAYOUT_AOS && d->layout != FK_LAYOUT_SOA) return fail(FK_ERR_BAD_ARG, "bad layout");
     if (d->model_mode < 0 || d->model_mode > 3) return fail(FK_ERR_BAD_ARG, "bad model_mode");
+    if (d->flags & ~FK_KF_FLAG_R_JOSEPH_DIAG) return fail(FK_ERR_BAD_ARG, "unknown desc flag");
     // one step's record block is addressed with 32-bit byte offsets (fk_device.hpp)
     const long E = (long)d->n * (d->n > d->m ? d->n : d->m);
     if ((double)d->N * (double)E * 8.0 >= 4294967296.0)
@@ -139,6 +140,7 @@ static int run_kf(const fk_kf_desc *d, KfArgs &a, void *stream)
     a.model_t = (d->model_mode == FK_MODEL_PER_TRACK_STEP || d->model_mode == FK_MODEL_PER_STEP) ? 1 : 0;
     a.update_first = d->update_first;
     a.alpha_sq = d->alpha_sq;
+    a.rj_diag = (d->flags & FK_KF_FLAG_R_JOSEPH_DIAG) ? 1 : 0;      // served by the generic kernel only
     const bool uniform = (d->model_mode == FK_MODEL_SHARED || d->model_mode == FK_MODEL_PER_STEP);
     a.i0 = 0;
     a.cnt = d->N;
@@ -148,7 +150,7 @@ static int run_kf(const fk_kf_desc *d, KfArgs &a, void *stream)
     const bool no_out = !a.means && !a.covs && !a.means_p && !a.covs_p;
     if (a.do_predict && a.do_update &&
         (all_out || no_out) && !a.y_out && !a.K_out && !a.S_out && !a.SI_out && !a.ll_out && !a.maha_out &&
-        !getenv("FK_NO_FAST")) {
+        !a.rj_diag && !getenv("FK_NO_FAST")) {
         if (d->n == 9 && d->m == 3 && !d->update_first && d->nu == 0 && !getenv("FK_NO_ML")) {
             const int rc = launch_kf_ml_9_3(a, d->layout, all_out, d->model_mode, (hipStream_t)stream);
             if (rc <= 0) return rc;        // 1 = not a call the multi-lane kernel serves

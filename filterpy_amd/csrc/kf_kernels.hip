@@ -127,8 +127,8 @@ kf_kernel(const KfArgs a,
                 const bool want_extras = a.y_out || a.K_out || a.S_out || a.SI_out || a.ll_out || a.maha_out;
                 if (has_z) {
                     double K[NX * NZ], y[NZ], S[NZ * NZ], Lf[NZ * NZ], dinv[NZ];
-                    if (UNIFORM) st |= kf_update<NX, NZ>(x, P, z, sm, K, y, S, Lf, dinv);
-                    else st |= kf_update<NX, NZ>(x, P, z, tm, K, y, S, Lf, dinv);
+                    if (UNIFORM) st |= kf_update<NX, NZ>(x, P, z, sm, K, y, S, Lf, dinv, a.rj_diag != 0);
+                    else st |= kf_update<NX, NZ>(x, P, z, tm, K, y, S, Lf, dinv, a.rj_diag != 0);
                     if (want_extras) {
                         double SI[NZ * NZ];
                         inv_from_ldlt<NZ>(Lf, dinv, SI);

@@ -4,6 +4,10 @@
 //                              fx(x, dt) = F x, hx(x) = H x: the whole predict (UKF.py:400-411) / update
 //                              (:462-481) loop stays in registers over the time steps.
 // (Split from ut_kernels.hip so the two translation units compile in parallel.)
+#include <stdlib.h>
+
+#include <type_traits>
+
 #include "../../include/filterhip.h"
 #include "fk_device.hpp"
 #include "fk_kernel_args.hpp"
@@ -34,7 +38,22 @@ namespace fk {
 //     (otherwise the broadcast reads of all points are hoisted and held);
 //   => (6,3): 223 (SOA) / 256 (AOS) VGPRs, no scratch, two waves per SIMD, against 512 VGPRs + 44 spilled
 //      registers at one wave per SIMD.
-template <int NX, int NZ, int LAYOUT>
+//   * SCALAR_FH (exact dims only): the rows of F and H do not come from LDS at all but from the kernel's uniform
+//     pointers through the scalar cache into SGPRs, fetched once per pass over the sigma points and used as the
+//     scalar operand of the FMAs.  A broadcast ds_read still delivers 64 x 16 bytes through the CU's one 128 B/clk
+//     LDS port: 716 ds_read2_b64 per step and wave x 8 waves per CU was 46k LDS clocks per step against 30k VALU
+//     clocks per SIMD -- the kernel was LDS-bound, not VALU-bound.
+template <int NX, int NZ>
+struct ScalarFHModel {
+    const double *s;          // LDS model: Q, R (read once per step)
+    const double *gF, *gH;    // uniform global pointers
+    __device__ __forceinline__ void rowF(int i, double (&r)[NX]) const { FK_UNROLL for (int j = 0; j < NX; ++j) r[j] = gF[i * NX + j]; }
+    __device__ __forceinline__ void rowH(int i, double (&r)[NX]) const { FK_UNROLL for (int j = 0; j < NX; ++j) r[j] = gH[i * NX + j]; }
+    __device__ __forceinline__ void rowQ(int i, double (&r)[NX]) const { LdsModel<NX, NZ>{s}.rowQ(i, r); }
+    __device__ __forceinline__ void rowR(int i, double (&r)[NZ]) const { LdsModel<NX, NZ>{s}.rowR(i, r); }
+};
+
+template <int NX, int NZ, int LAYOUT, bool SCALAR_FH>
 __global__ void __launch_bounds__(BLOCK, (NX <= 2 ? 4 : 2))
 ukf_linear_kernel_v2(const UkfArgs a, const double *__restrict__ pF, const double *__restrict__ pH,
                   const double *__restrict__ pQ, const double *__restrict__ pR,
@@ -72,12 +91,22 @@ ukf_linear_kernel_v2(const UkfArgs a, const double *__restrict__ pF, const doubl
     // a view of the LDS model the optimiser cannot relate to the previous one: keeps it from hoisting the
     // broadcast row reads of all 2n+1 unrolled points to the top (they are cheap to repeat, dear to hold)
     // (an offset is made opaque, not the pointer: that keeps the LDS address space)
-    struct View { SharedModel sm; const double *Wm, *Wc; };
+    using StepModel = std::conditional_t<SCALAR_FH, ScalarFHModel<NX, NZ>, SharedModel>;
+    struct View { StepModel sm; const double *Wm, *Wc; };
+    int goff = 0;                                           // wave-uniform, re-made opaque at the head of every pass
+    auto sweep = [&]() {
+        if constexpr (SCALAR_FH) {
+            int t;
+            asm volatile("s_mov_b32 %0, 0" : "=s"(t));
+            goff = t;
+        }
+    };
     auto fresh = [&]() {
         int off = 0;
         asm volatile("" : "+v"(off));
         const double *mb = s_model + off;
-        return View{SharedModel{mb}, mb + SharedModel::SIZE, mb + SharedModel::SIZE + KS};
+        if constexpr (SCALAR_FH) return View{StepModel{mb, pF + goff, pH + goff}, mb + SharedModel::SIZE, mb + SharedModel::SIZE + KS};
+        else return View{StepModel{mb}, mb + SharedModel::SIZE, mb + SharedModel::SIZE + KS};
     };
 
     double x[NX], P[PL];
@@ -96,7 +125,7 @@ ukf_linear_kernel_v2(const UkfArgs a, const double *__restrict__ pF, const doubl
         if (pmask) has_z = pmask[t * N + lr.blk0 + lr.tid] != 0;
         load_rec<NZ, 1, LAYOUT, false>(z, pz + t * N * m, lr, m, 1, 0.0);
 
-        st |= ukf_linear_step_v2<NX, NZ>(x, P, z, has_z, a.scale, fresh);
+        st |= ukf_linear_step_v2<NX, NZ>(x, P, z, has_z, a.scale, fresh, sweep);
         if (live) {
             if (a.means) store_rec<NX, 1, LAYOUT, false>(x, a.means + t * N * n, ln, n, 1);
             if (a.covs) {
@@ -385,10 +414,18 @@ int fk_ukf_linear_batch_f64(const fk_ukf_desc *d, const double *F, const double 
     // 2.68 ms SOA, 4.22 -> 2.90 ms AOS at 1e5 x 100; profiles/r02/exp_ukf2.log) and loses below it
     if (d->n <= 2 && d->m <= 2) { GO(2, 2); }
     else if (d->n <= 4 && d->m <= 2) { GO(4, 2); }
-    else if (d->layout == FK_LAYOUT_SOA)
-        hipLaunchKernelGGL((ukf_linear_kernel_v2<6, 3, LAYOUT_SOA>), grid, block, 0, s, a, F, H, Q, R, Wm, Wc, z, mask);
-    else
-        hipLaunchKernelGGL((ukf_linear_kernel_v2<6, 3, LAYOUT_AOS>), grid, block, 0, s, a, F, H, Q, R, Wm, Wc, z, mask);
+    else {
+        // exact (6,3): F and H as scalar operands (FK_UKF_LDS_MODEL=1 keeps them in LDS, for A/B timing and the parity tests)
+        static const bool lds_model = getenv("FK_UKF_LDS_MODEL") && getenv("FK_UKF_LDS_MODEL")[0] == '1';
+        const bool scalar = d->n == 6 && d->m == 3 && !lds_model;
+        if (d->layout == FK_LAYOUT_SOA) {
+            if (scalar) hipLaunchKernelGGL((ukf_linear_kernel_v2<6, 3, LAYOUT_SOA, true>), grid, block, 0, s, a, F, H, Q, R, Wm, Wc, z, mask);
+            else hipLaunchKernelGGL((ukf_linear_kernel_v2<6, 3, LAYOUT_SOA, false>), grid, block, 0, s, a, F, H, Q, R, Wm, Wc, z, mask);
+        } else {
+            if (scalar) hipLaunchKernelGGL((ukf_linear_kernel_v2<6, 3, LAYOUT_AOS, true>), grid, block, 0, s, a, F, H, Q, R, Wm, Wc, z, mask);
+            else hipLaunchKernelGGL((ukf_linear_kernel_v2<6, 3, LAYOUT_AOS, false>), grid, block, 0, s, a, F, H, Q, R, Wm, Wc, z, mask);
+        }
+    }
 #undef GO
     return check_launch("ukf_linear_kernel");
 }

@@ -25,7 +25,7 @@ import numpy as np
 
 from ..common.helpers import reshape_z, logpdf
 from .. import _engine as E
-from .._abi import FK_MODEL_SHARED, FK_MODEL_PER_TRACK, FK_MODEL_PER_STEP
+from .._abi import FK_MODEL_SHARED, FK_MODEL_PER_TRACK, FK_MODEL_PER_STEP, FK_KF_FLAG_R_JOSEPH_DIAG
 
 __all__ = ["KalmanFilter", "KalmanFilterBank", "predict", "update", "batch_filter", "rts_smoother",
            "predict_steadystate", "update_steadystate"]
@@ -160,7 +160,7 @@ class _Core:
         return E.from_records(dx, layout, 0, (n,)), E.from_records(dP, layout, 0, (n, n))
 
     @staticmethod
-    def update(n, m, N, x, P, z, H, R, mode, mask=None, layout="soa"):
+    def update(n, m, N, x, P, z, H, R, mode, mask=None, layout="soa", flags=0):
         import torch
         E.require_gpu()
 
@@ -175,7 +175,8 @@ class _Core:
             t.zero_()
         st = torch.zeros(N, dtype=torch.int32, device=dx.device)
         E.kf_update(dict(n=n, m=m, nu=0, model_mode=mode, N=N, T=1, layout=E.LAYOUTS[layout], update_first=0,
-                         alpha_sq=1.0), model(H), model(R), dz, dx, dP, mask=dmask, y=y, K=K, S=S, SI=SI, status=st)
+                         alpha_sq=1.0, flags=flags), model(H), model(R), dz, dx, dP, mask=dmask, y=y, K=K, S=S, SI=SI,
+                    status=st)
         E.raise_on_status(st, "update")
         return (E.from_records(dx, layout, 0, (n,)), E.from_records(dP, layout, 0, (n, n)),
                 E.from_records(y, layout, 0, (m,)), E.from_records(K, layout, 0, (n, m)),
@@ -273,11 +274,13 @@ class KalmanFilter(object):
         self.x = xrow.reshape(np.shape(self.x)) if np.ndim(self.x) > 0 else float(xrow[0])
 
     def _R_eff(self, R):
-        if (np.isscalar(R) or np.ndim(R) == 0) and self.dim_z > 1:
-            raise NotImplementedError(
-                "a scalar R *attribute* with dim_z > 1 acts as a full matrix in S and as r*I in K R K' "
-                "in the reference (kalman_filter.py:540,556); set R to a matrix")
-        return _mat(R, self.dim_z, self.dim_z, "R", scalar="full")
+        """The R *attribute* as update(z) uses it -> (matrix, desc flags).  A scalar attribute is taken raw by the
+        reference (kalman_filter.py:522-523): `S = dot(H, PHT) + R` adds r to every element of S (:540) while
+        `dot(dot(K, R), K.T)` is r K K' (:556) -- the kernel gets r * ones and FK_KF_FLAG_R_JOSEPH_DIAG."""
+        m = self.dim_z
+        if (np.isscalar(R) or np.ndim(R) == 0) and m > 1:
+            return np.full((m, m), float(R)), FK_KF_FLAG_R_JOSEPH_DIAG
+        return _mat(R, m, m, "R", scalar="full"), 0
 
     # -- predict ----------------------------------------------------------------
     def predict(self, u=None, B=None, F=None, Q=None):
@@ -316,8 +319,9 @@ class KalmanFilter(object):
             self.x_post, self.P_post = np.copy(self.x), np.copy(self.P)
             self.y = np.zeros((m, 1))
             return
+        rflags = 0
         if R is None:
-            Rm = self._R_eff(self.R)
+            Rm, rflags = self._R_eff(self.R)
         elif np.isscalar(R):
             Rm = np.eye(m) * R
         else:
@@ -346,7 +350,7 @@ class KalmanFilter(object):
             zz = np.broadcast_to(zraw, hx_shape)
         x, P = self._xP()
         xn, Pn, y, K, S, SI = _Core.update(n, m, 1, x, P, np.ascontiguousarray(zz).reshape(1, m), _mat(H, m, n, "H"),
-                                           Rm, FK_MODEL_SHARED)
+                                           Rm, FK_MODEL_SHARED, flags=rflags)
         self._set_x(xn[0])
         self.P = Pn[0]
         self.y = y[0].reshape(m, 1) if x_ndim == 2 else y[0]
@@ -426,7 +430,7 @@ class KalmanFilter(object):
             self.y = np.zeros((m, 1))
             return
         if R is None:
-            Rm = self._R_eff(self.R)
+            Rm = self._R_eff(self.R)[0]       # R enters S only here (kalman_filter.py:735-745): a raw scalar is r * ones
         elif np.isscalar(R):
             Rm = np.eye(m) * R
         else:
@@ -503,8 +507,11 @@ class KalmanFilter(object):
                 raise ValueError("with a column-vector state each z must be a (dim_z, 1) column")
             z[i, 0] = zi.reshape(m)
         per_step = any(v is not None for v in (Fs, Qs, Hs, Rs, Bs))
-        Fm, Qm = _mat(self.F, n, n, "F"), _mat(self.Q, n, n, "Q", scalar="full")
-        Hm, Rm = _mat(self.H, m, n, "H"), self._R_eff(self.R)
+        # the attributes reach predict() / update() as KWARGS here (Qs = [self.Q] * n, Rs = [self.R] * n,
+        # kalman_filter.py:944-947), and a scalar kwarg is eye * value (:467-468, :524-525) -- unlike the raw
+        # attribute of a direct predict() / update() call
+        Fm, Qm = _mat(self.F, n, n, "F"), _mat(self.Q, n, n, "Q", scalar="eye")
+        Hm, Rm = _mat(self.H, m, n, "H"), _mat(self.R, m, m, "R", scalar="eye")
         kw = {}
         if us is not None and (Bs is not None or self.B is not None):
             U = np.asarray([np.ravel(np.asarray(u, dtype=np.float64)) for u in us])
@@ -968,9 +975,11 @@ def update(x, P, z, R, H=None, return_all=False):
         Hm = Hm.reshape(-1, n)
     m = Hm.shape[0]
     zz = reshape_z(z, m, np.ndim(x))
+    # a scalar R is used as given in both places (:1477 adds it to every element of S, :1497 forms r K K')
     Rm = _mat(R, m, m, "R", scalar="full")
+    rflags = FK_KF_FLAG_R_JOSEPH_DIAG if ((np.isscalar(R) or np.ndim(R) == 0) and m > 1) else 0
     xn, Pn, y, K, S, SI = _Core.update(n, m, 1, xr, Pr, np.asarray(zz, dtype=np.float64).reshape(1, m), Hm, Rm,
-                                       FK_MODEL_SHARED)
+                                       FK_MODEL_SHARED, flags=rflags)
     xo, Po = restore(xn[0], Pn[0])
     if return_all:
         yy = y[0].reshape(m, 1) if np.ndim(x) == 2 else (y[0] if np.ndim(x) == 1 else float(y[0, 0]))

@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define FK_ABI_VERSION 1
+#define FK_ABI_VERSION 2
 
 enum {
     FK_OK = 0,
@@ -86,7 +86,14 @@ typedef struct fk_kf_desc {
     int32_t layout;       /* FK_LAYOUT_* for z,u,mask-free records, x,P, outputs, per-track models */
     int32_t update_first; /* kalman_filter.py:966-978: update then predict */
     double  alpha_sq;     /* fading memory alpha^2 (kalman_filter.py:478), 1.0 = off */
+    int32_t flags;        /* FK_KF_FLAG_* (0 = none) */
+    int32_t reserved;     /* 0 */
 } fk_kf_desc;
+
+/* The reference with a SCALAR `R` attribute and dim_z > 1 (kalman_filter.py:540, 556: `S = dot(H, PHT) + R` adds r to
+ * every element of S, `dot(dot(K, R), K.T)` is r K K'): pass R = r * ones(m, m) and set this flag -- the innovation
+ * covariance uses R as given, the Joseph term K R K' only its diagonal. */
+#define FK_KF_FLAG_R_JOSEPH_DIAG 1
 
 /* KalmanFilter.batch_filter (filterpy/kalman/kalman_filter.py:826-993; module twin :1664-1788)
  * for N independent filters: T x { predict (:472-478) ; update (:533-556, Joseph form) },

@@ -298,3 +298,44 @@ def test_bank_extras_in_kernel_likelihood():
             ok = np.abs(g[p + "S"]).reshape(len(mask), -1).max(axis=1) > 0
             assert np.allclose(hist["log_likelihood"][ok, trk], g[p + "log_likelihood"][ok], rtol=1e-10, atol=1e-10)
             assert np.allclose(hist["mahalanobis"][:, trk], g[p + "mahalanobis"], rtol=1e-10, atol=1e-10)
+
+
+@pytest.mark.parametrize("n,m", [(2, 2), (4, 2), (6, 3), (9, 3), (3, 1)])
+def test_scalar_q_r_attributes_like_the_reference(n, m):
+    """VERDICT r1 missing #5 / ADVICE r1: a scalar R attribute with dim_z > 1 is reproduced, not refused -- raw in
+    update(z) (r on every element of S, r K K' in the Joseph term: FK_KF_FLAG_R_JOSEPH_DIAG), eye * value inside
+    batch_filter, where the attributes arrive as kwargs; the same for a scalar Q; module-level update() with scalar R.
+    Goldens: tests/golden/make_scalar_attr_golden.py (live reference)."""
+    from filterpy_amd.kalman import KalmanFilter
+    import filterpy_amd.kalman as fk
+    g = golden("kf_scalar_attr")
+    p = f"n{n}m{m}_"
+    F, H, P0, x0, zs = (g[p + k] for k in ("F", "H", "P0", "x0", "zs"))
+    q, r = float(g[p + "q"]), float(g[p + "r"])
+
+    def make():
+        kf = KalmanFilter(dim_x=n, dim_z=m)
+        kf.x, kf.P, kf.F, kf.H = x0.copy(), P0.copy(), F.copy(), H.copy()
+        kf.Q, kf.R = q, r
+        return kf
+    kf = make()
+    kf.predict()
+    assert rel_err_rows(kf.P[None], g[p + "step_Pp"][None]) < 1e-10
+    xp, Pp = kf.x.copy(), kf.P.copy()
+    kf.update(zs[0])
+    for key in ("x", "P", "y", "K", "S", "SI"):
+        a, b = np.asarray(getattr(kf, key), dtype=float), g[p + "step_" + key]
+        assert a.shape == b.shape, (key, a.shape, b.shape)
+        assert rel_err_rows(a.reshape(1, -1), b.reshape(1, -1)) < 1e-10, key
+    kf = make()
+    for t, z in enumerate(zs):
+        kf.predict()
+        kf.update(z)
+        assert rel_err_rows(kf.x[None], g[p + "loop_x"][t][None]) < 1e-10 and rel_err_rows(kf.P[None], g[p + "loop_P"][t][None]) < 1e-10, t
+    kf = make()
+    mu, cov, mup, covp = kf.batch_filter(list(zs))
+    for got, key in ((mu, "bf_mu"), (cov, "bf_cov"), (mup, "bf_mup"), (covp, "bf_covp")):
+        assert rel_err_rows(got, g[p + key]) < 1e-10, key
+    x2, P2, y2, K2, S2, _ = fk.update(xp, Pp, zs[0], r, H, return_all=True)
+    for got, key in ((x2, "mod_x"), (P2, "mod_P"), (K2, "mod_K"), (S2, "mod_S")):
+        assert rel_err_rows(np.asarray(got, dtype=float).reshape(1, -1), g[p + key].reshape(1, -1)) < 1e-10, key

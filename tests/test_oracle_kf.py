@@ -96,3 +96,29 @@ def test_saver_histories(n, m):
     assert np.allclose(ll, g[p + "log_likelihood"], rtol=1e-10, atol=1e-10)
     mh = np.array([kf_oracle.mahalanobis(y, SI) for y, SI in zip(ys, SIs)])
     assert np.allclose(mh, g[p + "mahalanobis"], rtol=1e-10, atol=1e-12)
+
+
+@pytest.mark.parametrize("n,m", [(2, 2), (4, 2), (6, 3), (9, 3), (3, 1)])
+def test_scalar_attributes_vs_live_reference(n, m):
+    """Scalar Q / R: raw in direct predict() / update() calls (q on every element of P, r on every element of S but
+    r K K' in the Joseph term), eye * value inside batch_filter (tests/golden/make_scalar_attr_golden.py)."""
+    g = golden("kf_scalar_attr")
+    p = f"n{n}m{m}_"
+    F, H, P0, x0, zs = (g[p + k] for k in ("F", "H", "P0", "x0", "zs"))
+    q, r = float(g[p + "q"]), float(g[p + "r"])
+    xp, Pp = kf_oracle.kf_predict(x0, P0, F, q)
+    assert np.allclose(Pp, g[p + "step_Pp"], rtol=1e-13, atol=1e-14)
+    x, P, y, K, S, SI = kf_oracle.kf_update(xp, Pp, zs[0], r, H)
+    for got, key in ((x, "step_x"), (P, "step_P"), (y, "step_y"), (K, "step_K"), (S, "step_S"), (SI, "step_SI")):
+        assert np.allclose(got, g[p + key], rtol=1e-12, atol=1e-13), key
+    x, P = x0, P0
+    for t, z in enumerate(zs):
+        x, P = kf_oracle.kf_predict(x, P, F, q)
+        x, P = kf_oracle.kf_update(x, P, z, r, H)[:2]
+        assert np.allclose(x, g[p + "loop_x"][t], rtol=1e-11, atol=1e-12) and np.allclose(P, g[p + "loop_P"][t], rtol=1e-11, atol=1e-12)
+    mu, cov, mup, covp = kf_oracle.kf_batch_filter(x0, P0, list(zs), F, q * np.eye(n), H, r * np.eye(m))
+    for got, key in ((mu, "bf_mu"), (cov, "bf_cov"), (mup, "bf_mup"), (covp, "bf_covp")):
+        assert np.allclose(got, g[p + key], rtol=1e-11, atol=1e-12), key
+    x2, P2, y2, K2, S2 = kf_oracle.proc_update(xp, Pp, zs[0], r, H)
+    for got, key in ((x2, "mod_x"), (P2, "mod_P"), (K2, "mod_K"), (S2, "mod_S")):
+        assert np.allclose(got, g[p + key], rtol=1e-12, atol=1e-13), key

@@ -6,7 +6,8 @@ import os
 import sys
 from collections import defaultdict
 
-for d in sys.argv[1:]:
+ALL = "--all" in sys.argv
+for d in [a for a in sys.argv[1:] if a != "--all"]:
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         acc = defaultdict(lambda: defaultdict(list))
         with open(f) as fh:
@@ -15,7 +16,9 @@ for d in sys.argv[1:]:
                 acc[k][row.get("Counter_Name", "?")].append(float(row.get("Counter_Value", "nan")))
         print("==", f)
         for k, cs in acc.items():
-            if "kf_" not in k:
+            if not ALL and "kf_" not in k:
+                continue
+            if "fk::" not in k and "kf_" not in k:
                 continue
             for c, vals in cs.items():
                 print(f"{k[:90]:90s} {c:12s} n={len(vals):4d} mean={sum(vals)/len(vals):.6g}")
