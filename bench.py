@@ -106,12 +106,20 @@ def cpu_baseline(T, budget_s=10.0, max_procs=None):
     cores = max(1, min(avail, max_procs) if max_procs else avail)      # every host core this process may use
     for v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
         os.environ[v] = "1"
+    # the workers are CPU-only: under `rocprofv3 -- python bench.py` they must not inherit the profiler (hundreds of
+    # processes each attaching the tool -- and, in a --pmc pass, the counters -- stalled the r02 evidence run)
+    scrubbed = {k: os.environ.pop(k) for k in list(os.environ)
+                if k.startswith(("ROCP", "ROCPROF", "HSA_TOOLS", "ROCTRACER")) or
+                (k == "LD_PRELOAD" and "rocprof" in os.environ[k])}
     ctx = mp.get_context("spawn")
-    with ctx.Pool(cores) as pool:
-        pool.map(_cpu_worker, [(c, 0.05, T) for c in range(cores)])          # start-up / import warm-up
-        t0 = time.perf_counter()
-        res = pool.map(_cpu_worker, [(1000 + c, budget_s, T) for c in range(cores)])
-        wall = time.perf_counter() - t0
+    try:
+        with ctx.Pool(cores) as pool:
+            pool.map(_cpu_worker, [(c, 0.05, T) for c in range(cores)])          # start-up / import warm-up
+            t0 = time.perf_counter()
+            res = pool.map(_cpu_worker, [(1000 + c, budget_s, T) for c in range(cores)])
+            wall = time.perf_counter() - t0
+    finally:
+        os.environ.update(scrubbed)
     tracks = sum(r[0] for r in res)
     return {"value": tracks * T / wall, "unit": "track-steps/s", "cores": cores, "kind": "port",
             "sample": f"{cores} single-threaded procs (host has {avail} cpus) x {budget_s:.0f} s of the C2 workload: "

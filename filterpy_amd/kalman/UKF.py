@@ -11,7 +11,13 @@ Two ways to run it:
   (UKF.py:521-522, :462-466), or once per call on the whole (N, 2n+1, n) array when
   ``vectorized=True``;
 * linear fx / hx given as matrices (``fx=F, hx=H`` NumPy arrays): batch_filter runs the
-  fused kernel fk_ukf_linear_batch_f64, the whole predict/update loop on the GPU.
+  fused kernel fk_ukf_linear_batch_f64, the whole predict/update loop on the GPU;
+* ``device_callables=True`` (banks only): fx / hx are vectorised callables on GPU tensors --
+  ``fx(sigmas (N, 2n+1, n), dt, **args) -> (N, 2n+1, n)``, ``hx(sigmas (N, 2n+1, n), **args) -> (N, 2n+1, m)``,
+  torch tensors in, torch tensors out -- and the whole split path stays in HBM: sigma_kernel -> fx -> ut_kernel ->
+  sigma_kernel -> hx -> ut_kernel -> cross_kernel -> ukf_correct_kernel, no host copy between them
+  (UKF.py:506-522, :462-481); batch_filter / rts_smoother keep state, histories and sigma points as device
+  records for all T steps and download (or hand over, ``device_outputs=True``) only the results.
 
 ``n_tracks=N`` turns the object into a bank of N independent filters (x (N,n), P (N,n,n),
 z (N,m) / zs (T,N,m)).  Custom sqrt / mean / residual / state_add callables cannot run
@@ -33,13 +39,16 @@ __all__ = ["UnscentedKalmanFilter"]
 class UnscentedKalmanFilter(object):
     def __init__(self, dim_x, dim_z, dt, hx, fx, points, sqrt_fn=None, x_mean_fn=None, z_mean_fn=None,
                  residual_x=None, residual_z=None, state_add=None, n_tracks=None, vectorized=False,
-                 layout="soa"):
+                 layout="soa", device_callables=False):
         for name, fn in (("sqrt_fn", sqrt_fn), ("x_mean_fn", x_mean_fn), ("z_mean_fn", z_mean_fn),
                          ("residual_x", residual_x), ("residual_z", residual_z), ("state_add", state_add)):
             if fn is not None and fn not in (np.subtract, np.add):
                 raise NotImplementedError(f"custom {name} callables cannot run inside the HIP kernels")
+        if device_callables and n_tracks is None:
+            raise ValueError("device_callables=True needs a bank: pass n_tracks=N (use N = 1 for one filter)")
         self._dim_x, self._dim_z = dim_x, dim_z
         self._N = n_tracks
+        self._devcall = bool(device_callables)
         self._vec = vectorized or n_tracks is not None and not callable(fx)
         self._layout = layout
         shape = (dim_x,) if n_tracks is None else (n_tracks, dim_x)
@@ -86,6 +95,95 @@ class UnscentedKalmanFilter(object):
 
     def _unb(self, a):
         return a if self._N is not None else a[0]
+
+    # ------------------------------------------------- device-resident split path --
+    def _rec_view(self, rec, k, d):
+        """device records of N (k x d) blocks -> torch view (N, k, d), no copy"""
+        N = self._N
+        if self._layout == "aos":
+            return rec.view(N, k, d)
+        return rec.view(k, d, N).permute(2, 0, 1)
+
+    def _to_rec(self, t, k, d):
+        """torch tensor (N, k, d) as the callable returned it -> device records in the bank's layout"""
+        import torch
+        N = self._N
+        if not isinstance(t, torch.Tensor) or not t.is_cuda or t.dtype != torch.float64 or tuple(t.shape) != (N, k, d):
+            raise TypeError(f"device callables must return a float64 CUDA tensor shaped {(N, k, d)}")
+        if self._layout == "aos":
+            return t.contiguous().view(N, k * d)
+        return t.permute(1, 2, 0).contiguous().view(k * d, N)
+
+    def _dev_consts(self):
+        n, m = self._dim_x, self._dim_z
+        return dict(Wm=E.dev(np.asarray(self.Wm, dtype=np.float64)), Wc=E.dev(np.asarray(self.Wc, dtype=np.float64)),
+                    Q=E.dev(np.broadcast_to(np.asarray(self.Q, dtype=np.float64), (n, n)).copy()),
+                    R=E.dev(np.broadcast_to(np.asarray(self.R, dtype=np.float64), (m, m)).copy()))
+
+    def _dev_predict(self, dx, dP, c, dt, st, fx=None, **fx_args):
+        """UKF.py:400-411 on device records; returns the regenerated sigma points (records)."""
+        n, k, N, lay = self._dim_x, self._num_sigmas, self._N, self._layout
+        fx = self.fx if fx is None else fx
+        sig = E.alloc_records((), N, k * n, lay)
+        E.ut_sigma_points(n, N, lay, self.points_fn.scale, dx, dP, sig, st)
+        if callable(fx):
+            sf = self._to_rec(fx(self._rec_view(sig, k, n), dt, **fx_args), k, n)
+        else:
+            import torch
+            sf = self._to_rec(torch.matmul(self._rec_view(sig, k, n), E.dev(np.asarray(fx, dtype=np.float64)).T), k, n)
+        E.ut_transform(n, k, N, lay, sf, c["Wm"], c["Wc"], c["Q"], dx, dP)
+        E.ut_sigma_points(n, N, lay, self.points_fn.scale, dx, dP, sig, st)      # UKF.py:407
+        return sig
+
+    def _dev_update(self, dx, dP, sig, dz, c, st, dK=None, hx=None, R=None, **hx_args):
+        """UKF.py:462-481 on device records (sig = the sigma points the predict left behind)."""
+        n, m, k, N, lay = self._dim_x, self._dim_z, self._num_sigmas, self._N, self._layout
+        hx = self.hx if hx is None else hx
+        if callable(hx):
+            sh = self._to_rec(hx(self._rec_view(sig, k, n), **hx_args), k, m)
+        else:
+            import torch
+            sh = self._to_rec(torch.matmul(self._rec_view(sig, k, n), E.dev(np.asarray(hx, dtype=np.float64)).T), k, m)
+        zp, S = E.alloc_records((), N, m, lay), E.alloc_records((), N, m * m, lay)
+        E.ut_transform(m, k, N, lay, sh, c["Wm"], c["Wc"], c["R"] if R is None else R, zp, S)
+        Pxz = E.alloc_records((), N, n * m, lay)
+        E.ut_cross_variance(n, m, k, N, lay, dx, zp, sig, sh, c["Wc"], Pxz)
+        E.ukf_correct(n, m, N, lay, Pxz, zp, S, dz, dx, dP, dK, st)
+        return sh, zp, S
+
+    def _dev_batch_filter(self, zs, Rs, dts, device_outputs):
+        import torch
+        n, m, N, lay = self._dim_x, self._dim_z, self._N, self._layout
+        T = len(zs)
+        c = self._dev_consts()
+        dx, dP = E.to_records(self._b(self.x, (n,)), lay, 0), E.to_records(self._b(self.P, (n, n)), lay, 0)
+        if isinstance(zs, torch.Tensor):           # already device records [T][N][m] (aos) / [T][m][N] (soa)
+            dzs, present = zs, [True] * T
+        else:
+            present = [z is not None for z in zs]
+            zarr = np.zeros((T, N, m))
+            for i, z in enumerate(zs):
+                if z is not None:
+                    zarr[i] = np.asarray(z, dtype=np.float64).reshape(N, m)
+            dzs = E.to_records(zarr, lay, 1)
+        means, covs = E.alloc_records((T,), N, n, lay), E.alloc_records((T,), N, n * n, lay)
+        st = torch.zeros(N, dtype=torch.int32, device=dx.device)
+        for t in range(T):
+            dt = self._dt if dts is None else dts[t]
+            sig = self._dev_predict(dx, dP, c, dt, st)
+            if present[t]:
+                Rt = None
+                if Rs is not None:
+                    r = Rs[t]
+                    Rt = E.dev(np.eye(m) * r if np.isscalar(r) else np.broadcast_to(np.asarray(r, dtype=np.float64), (m, m)).copy())
+                self._dev_update(dx, dP, sig, dzs[t], c, st, R=Rt)
+            means[t].copy_(dx)
+            covs[t].copy_(dP)
+        E.raise_on_status(st, "UnscentedKalmanFilter.batch_filter")
+        self.x, self.P = E.from_records(dx, lay, 0, (n,)), E.from_records(dP, lay, 0, (n, n))
+        if device_outputs:
+            return means, covs
+        return E.from_records(means, lay, 1, (n,)), E.from_records(covs, lay, 1, (n, n))
 
     # ---------------------------------------------------------------- predict --
     def compute_process_sigmas(self, dt, fx=None, **fx_args):
@@ -169,12 +267,17 @@ class UnscentedKalmanFilter(object):
         return E.from_records(out, lay, 0, (n, m))[0]
 
     # ----------------------------------------------------------- batch_filter --
-    def batch_filter(self, zs, Rs=None, dts=None, UT=None, saver=None):
+    def batch_filter(self, zs, Rs=None, dts=None, UT=None, saver=None, device_outputs=False):
         """UKF.py:524-632: predict -> update per measurement; returns (means, covariances).
         With linear fx/hx matrices and no per-epoch Rs/dts/saver the whole loop is ONE fused
         kernel launch."""
         import torch
+        from .unscented_transform import unscented_transform
         n, m = self._dim_x, self._dim_z
+        if self._devcall and saver is None:
+            if UT is not None and UT is not unscented_transform:
+                raise NotImplementedError("custom UT callables are not supported")
+            return self._dev_batch_filter(zs, Rs, dts, device_outputs)
         try:
             z0 = zs[0]
         except TypeError:
@@ -222,7 +325,45 @@ class UnscentedKalmanFilter(object):
                 saver.save()
         return (means, covs)
 
-    def rts_smoother(self, Xs, Ps, Qs=None, dts=None, UT=None):
+    def _dev_rts_smoother(self, Xs, Ps, dts, device_outputs):
+        """The backward pass with everything resident: Xs / Ps are uploaded once (or arrive as device records
+        [T][N][..]), every step is sigma_kernel -> fx -> ut_kernel -> cross_kernel -> ukf_rts_kernel on device
+        records, and only the results come back."""
+        import torch
+        n, k, N, lay = self._dim_x, self._num_sigmas, self._N, self._layout
+        c = self._dev_consts()
+        if isinstance(Xs, torch.Tensor):
+            dXs, dPs = Xs, Ps
+            T = int(Xs.shape[0])
+        else:
+            Xs = np.asarray(Xs, dtype=np.float64)
+            T = Xs.shape[0]
+            dXs = E.to_records(Xs.reshape(T, N, n), lay, 1)
+            dPs = E.to_records(np.asarray(Ps, dtype=np.float64).reshape(T, N, n, n), lay, 1)
+        if dts is None:
+            dts = [self._dt] * T
+        elif np.isscalar(dts):
+            dts = [dts] * T
+        xs, ps = dXs.clone(), dPs.clone()
+        Ks = torch.zeros_like(ps)
+        sig = E.alloc_records((), N, k * n, lay)
+        xb, Pb, Pxb = E.alloc_records((), N, n, lay), E.alloc_records((), N, n * n, lay), E.alloc_records((), N, n * n, lay)
+        st = torch.zeros(N, dtype=torch.int32, device=xs.device)
+        for j in reversed(range(T - 1)):
+            E.ut_sigma_points(n, N, lay, self.points_fn.scale, xs[j], ps[j], sig, st)
+            if callable(self.fx):
+                sf = self._to_rec(self.fx(self._rec_view(sig, k, n), dts[j]), k, n)
+            else:
+                sf = self._to_rec(torch.matmul(self._rec_view(sig, k, n), E.dev(np.asarray(self.fx, dtype=np.float64)).T), k, n)
+            E.ut_transform(n, k, N, lay, sf, c["Wm"], c["Wc"], c["Q"], xb, Pb)
+            E.ut_cross_variance(n, n, k, N, lay, dXs[j], xb, sig, sf, c["Wc"], Pxb)
+            E.ukf_rts_correct(n, N, lay, Pxb, xb, Pb, xs[j + 1], ps[j + 1], xs[j], ps[j], Ks[j], st)
+        E.raise_on_status(st, "UnscentedKalmanFilter.rts_smoother")
+        if device_outputs:
+            return xs, ps, Ks
+        return E.from_records(xs, lay, 1, (n,)), E.from_records(ps, lay, 1, (n, n)), E.from_records(Ks, lay, 1, (n, n))
+
+    def rts_smoother(self, Xs, Ps, Qs=None, dts=None, UT=None, device_outputs=False):
         """UKF.py:634-739: backward pass over the filter output.  Per step k (from the end): sigma
         points of (xs[k], ps[k]) -> fx -> UT (+ self.Q: the reference passes self.Q, its Qs argument
         is never read, UKF.py:717-719) -> cross variance of the sigma points around Xs[k] and their
@@ -235,6 +376,8 @@ class UnscentedKalmanFilter(object):
             raise NotImplementedError("custom UT callables are not supported")
         if len(Xs) != len(Ps):
             raise ValueError('Xs and Ps must have the same length')
+        if self._devcall:
+            return self._dev_rts_smoother(Xs, Ps, dts, device_outputs)
         n, k = self._dim_x, self._num_sigmas
         N = self._N or 1
         Xs = np.asarray(Xs, dtype=np.float64)

@@ -179,7 +179,7 @@ def test_ukf_general_callables_vs_reference():
         ukf.x, ukf.P, ukf.Q, ukf.R = g[p + "x0"].copy(), g[p + "P0"].copy(), g[p + "Q"].copy(), g[p + "R"].copy()
         ukf.predict()
         assert rel_err_rows(ukf.x[None], g[p + "s1_xp"][None]) < tmu and rel_err_rows(ukf.P[None], g[p + "s1_Pp"][None]) < tcov
-        assert rel_err_rows(ukf.sigmas_f[None], g[p + "s1_sigmas_f"][None]) < 1e-10
+        assert rel_err_rows(ukf.sigmas_f[None], g[p + "s1_sigmas_f"][None]) < tmu, ci      # regenerated from x, P: inherits their bar
         ukf.update(g[p + "zs"][0])
         for attr, key in (("x", "s1_x"), ("P", "s1_P"), ("K", "s1_K"), ("S", "s1_S"), ("y", "s1_y")):
             assert rel_err_rows(np.atleast_2d(getattr(ukf, attr))[None], np.atleast_2d(g[p + key])[None]) < (tmu if attr in "xyK" else tcov), (ci, key)
