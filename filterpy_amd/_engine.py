@@ -163,6 +163,14 @@ def ukf_linear_batch(n, m, N, T, layout, scale, F, H, Q, R, Wm, Wc, z, x, P, *, 
     _abi.check(rc, "fk_ukf_linear_batch_f64")
 
 
+def ukf_linear_rts(n, N, T, layout, scale, F, Q, Wm, Wc, Xs, Ps, xs, Ps_out, K=None, status=None):
+    """fk_ukf_linear_rts_f64: the UKF smoother's whole backward pass for a linear fx, one launch."""
+    d = fk_ukf_desc(n=n, m=1, N=N, T=T, layout=LAYOUTS[layout], reserved=0, scale=float(scale))
+    rc = _abi.lib().fk_ukf_linear_rts_f64(d, _ptr(F), _ptr(Q), _ptr(Wm), _ptr(Wc), _ptr(Xs), _ptr(Ps), _ptr(xs),
+                                          _ptr(Ps_out), _ptr(K), _ptr(status), _stream())
+    _abi.check(rc, "fk_ukf_linear_rts_f64")
+
+
 def kf_steadystate(desc_kw, F, H, K, z, x, *, B=None, u=None, mask=None, means=None, means_p=None, y=None):
     """fk_kf_steadystate_f64 (F None: update only; z None: predict only)."""
     d = fk_kf_desc(**desc_kw)

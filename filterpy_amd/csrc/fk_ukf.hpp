@@ -213,4 +213,149 @@ FK_HD int ukf_linear_step_v2(double (&x)[NX], double (&P)[NX * (NX + 1) / 2], co
     return st;
 }
 
+// One backward step of UnscentedKalmanFilter.rts_smoother with fx(x, dt) = F x (UKF.py:714-737), fused:
+//   sigmas = sigma_points(xs[k], ps[k]) ; sigmas_f = F sigmas ; (xb, Pb) = UT(sigmas_f, Wm, Wc, Q)
+//   Pxb = sum_i Wc_i (sigmas_i - Xs[k]) (sigmas_f_i - xb)' ; K = Pxb inv(Pb)
+//   xs[k] += K (xs[k+1] - xb) ; ps[k] += K (ps[k+1] - Pb) K'
+// x / P (packed upper triangle): the filter output of step k in (xs[k] = Xs[k] until this step touches it), the
+// smoothed step k out; xn / Pn: the smoothed step k+1.  K: full n x n gain out.  The sums run over the sigma points
+// in the reference's index order, the sigma points and their images are regenerated point by point exactly like
+// ukf_linear_step_v2's sweeps.  inv(Pb) is applied by an L D L' solve (like every other gain here).
+// Two halves, so that the caller may keep xn / Pn out of the registers during the first:
+//   ukf_linear_rts_gain    (x, P) -> xb, Pb (packed), K            (the two sweeps and the solve)
+//   ukf_linear_rts_correct x, P updated in place from xn, Pn, xb, Pb, K   (Pb is destroyed)
+template <int NX, class Fresh, class Sweep = NoSweep>
+FK_HD int ukf_linear_rts_gain(double (&x)[NX], const double (&P)[NX * (NX + 1) / 2], double scale, double (&xb)[NX],
+                              double (&Pb)[NX * (NX + 1) / 2], double (&K)[NX * NX], Fresh &&fresh,
+                              Sweep &&sweep = Sweep{})
+{
+    constexpr int KS = 2 * NX + 1;
+    constexpr int PL = NX * (NX + 1) / 2;
+    int st = 0;
+    double L[PL];
+    if (!chol_packed<NX>(P, scale, L)) st |= ST_NOT_PD;
+    // sweep 1: xb = sum_i Wm_i F sigma_i
+    sweep();
+    FK_UNROLL for (int i = 0; i < KS; ++i) {
+        const auto mv = fresh();
+        const auto &sm = mv.sm;
+        const double *sWm = mv.Wm;
+        FK_UNROLL for (int r = 0; r < NX; ++r) {
+            double f[NX];
+            sm.rowF(r, f);
+            double v;
+            if (i == 0) {
+                v = dot<NX>(f, x);
+            } else if (i <= NX) {
+                v = f[0] * (x[0] - (-lcol<NX>(L, 0, i - 1)));
+                FK_UNROLL for (int c = 1; c < NX; ++c) v = fma(f[c], x[c] - (-lcol<NX>(L, c, i - 1)), v);
+            } else {
+                v = f[0] * (x[0] - lcol<NX>(L, 0, i - 1 - NX));
+                FK_UNROLL for (int c = 1; c < NX; ++c) v = fma(f[c], x[c] - lcol<NX>(L, c, i - 1 - NX), v);
+            }
+            xb[r] = (i == 0) ? sWm[0] * v : fma(sWm[i], v, xb[r]);
+        }
+        FK_STAGE();
+    }
+    // sweep 2: Pb = sum Wc_i y_i y_i' (+ Q), Pxb = sum Wc_i z_i y_i', y_i = F sigma_i - xb, z_i = sigma_i - x
+    FK_UNROLL for (int c = 0; c < NX; ++c) FK_OPAQUE(x[c]);
+    FK_UNROLL for (int e = 0; e < PL; ++e) FK_OPAQUE(L[e]);
+    sweep();
+    FK_UNROLL for (int i = 0; i < KS; ++i) {
+        const auto mv = fresh();
+        const auto &sm = mv.sm;
+        const double *sWc = mv.Wc;
+        double y[NX], wy[NX];
+        FK_UNROLL for (int r = 0; r < NX; ++r) {
+            double f[NX];
+            sm.rowF(r, f);
+            double v;
+            if (i == 0) {
+                v = dot<NX>(f, x);
+            } else if (i <= NX) {
+                v = f[0] * (x[0] - (-lcol<NX>(L, 0, i - 1)));
+                FK_UNROLL for (int c = 1; c < NX; ++c) v = fma(f[c], x[c] - (-lcol<NX>(L, c, i - 1)), v);
+            } else {
+                v = f[0] * (x[0] - lcol<NX>(L, 0, i - 1 - NX));
+                FK_UNROLL for (int c = 1; c < NX; ++c) v = fma(f[c], x[c] - lcol<NX>(L, c, i - 1 - NX), v);
+            }
+            y[r] = v - xb[r];
+        }
+        FK_UNROLL for (int r = 0; r < NX; ++r) wy[r] = sWc[i] * y[r];
+        FK_UNROLL for (int a2 = 0; a2 < NX; ++a2)
+            FK_UNROLL for (int b = 0; b < NX; ++b)
+                if (b >= a2)
+                    Pb[sym_idx<NX>(a2, b)] = (i == 0) ? y[a2] * wy[b] : fma(y[a2], wy[b], Pb[sym_idx<NX>(a2, b)]);
+        FK_UNROLL for (int r = 0; r < NX; ++r) {
+            double z;
+            if (i == 0) z = x[r] - x[r];
+            else if (i <= NX) z = (x[r] - (-lcol<NX>(L, r, i - 1))) - x[r];
+            else z = (x[r] - lcol<NX>(L, r, i - 1 - NX)) - x[r];
+            FK_UNROLL for (int c = 0; c < NX; ++c) {
+                const double term = sWc[i] * (z * y[c]);
+                K[r * NX + c] = (i == 0) ? term : K[r * NX + c] + term;
+            }
+        }
+        FK_STAGE();
+    }
+    {
+        const auto mv = fresh();
+        FK_UNROLL for (int r = 0; r < NX; ++r) {
+            double q[NX];
+            mv.sm.rowQ(r, q);
+            FK_UNROLL for (int b = 0; b < NX; ++b)
+                if (b >= r) Pb[sym_idx<NX>(r, b)] += q[b];
+        }
+    }
+    // K = Pxb inv(Pb)
+    {
+        double Lp[PL], d[NX], dinv[NX];
+        FK_UNROLL for (int e = 0; e < PL; ++e) Lp[e] = Pb[e];
+        if (!ldlt_packed<NX>(Lp, d, dinv)) st |= ST_NOT_PD;
+        FK_UNROLL for (int r = 0; r < NX; ++r) {
+            double row[NX];
+            FK_UNROLL for (int c = 0; c < NX; ++c) row[c] = K[r * NX + c];
+            solve_row_packed<NX>(Lp, dinv, row);
+            FK_UNROLL for (int c = 0; c < NX; ++c) K[r * NX + c] = row[c];
+        }
+    }
+    FK_STAGE();
+    return st;
+}
+
+template <int NX>
+FK_HD void ukf_linear_rts_correct(double (&x)[NX], double (&P)[NX * (NX + 1) / 2], const double (&xn)[NX],
+                                  const double (&Pn)[NX * (NX + 1) / 2], const double (&xb)[NX],
+                                  double (&Pb)[NX * (NX + 1) / 2], const double (&K)[NX * NX])
+{
+    constexpr int PL = NX * (NX + 1) / 2;
+    // x += K (xn - xb)
+    {
+        double dx[NX];
+        FK_UNROLL for (int c = 0; c < NX; ++c) dx[c] = xn[c] - xb[c];
+        FK_UNROLL for (int r = 0; r < NX; ++r) {
+            double acc = K[r * NX] * dx[0];
+            FK_UNROLL for (int c = 1; c < NX; ++c) acc = fma(K[r * NX + c], dx[c], acc);
+            x[r] += acc;
+        }
+    }
+    // P += (K (Pn - Pb)) K', upper triangle, one row of K (Pn - Pb) at a time
+    FK_UNROLL for (int e = 0; e < PL; ++e) Pb[e] = Pn[e] - Pb[e];            // D
+    FK_UNROLL for (int i = 0; i < NX; ++i) {
+        double t1[NX];
+        FK_UNROLL for (int c = 0; c < NX; ++c) {
+            double acc = K[i * NX] * Pb[sym_idx<NX>(0, c)];
+            FK_UNROLL for (int k = 1; k < NX; ++k) acc = fma(K[i * NX + k], Pb[sym_idx<NX>(k, c)], acc);
+            t1[c] = acc;
+        }
+        FK_UNROLL for (int j = 0; j < NX; ++j)
+            if (j >= i) {
+                double acc = t1[0] * K[j * NX];
+                FK_UNROLL for (int k = 1; k < NX; ++k) acc = fma(t1[k], K[j * NX + k], acc);
+                P[sym_idx<NX>(i, j)] += acc;
+            }
+        FK_STAGE();
+    }
+}
+
 }  // namespace fk

@@ -86,22 +86,6 @@ __device__ __forceinline__ u64 ld_agent(const u64 *p)
 {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// A poll of a hand-off word.  The first FK_OP_SC0_POLLS polls of a wait are `sc0` loads: they bypass the CU's L1 and
-// are served by the XCD's L2, which is where a producer on the SAME XCD left the word (its agent-scope store writes
-// through the L2 it passes).  A producer on another XCD is not seen that way (the L2s are not coherent with each
-// other: MI355X guide, correctness boundaries) -- the word then reads as an OLDER state, which every consumer
-// tolerates (states only move forward), and the later polls are agent-scope loads that see everything.  So the
-// co-location of a filter's chunks on one XCD (the ticket regions follow the XCC id) buys latency, never correctness.
-#ifndef FK_OP_SC0_POLLS
-#define FK_OP_SC0_POLLS 0
-#endif
-__device__ __forceinline__ u64 ld_poll(const u64 *p, unsigned spins)
-{
-#if FK_OP_SC0_POLLS > 0
-    if (spins < (unsigned)FK_OP_SC0_POLLS) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#endif
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
 __device__ __forceinline__ void st_agent(u64 *p, u64 v)
 {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -197,7 +181,7 @@ __device__ double lookback_approx(const OpDesc *d, int k, int lane, unsigned *ab
         u64 word, incl;
         for (;;) {
             // before the vector: inclusive prefix 0; lanes beyond the window: a chunk sum of 0 (never waited for)
-            word = lane >= OP_LB ? (u64)1 : (jj >= 0 ? ld_poll(&d[jj].approx, spins) : (u64)2);
+            word = lane >= OP_LB ? (u64)1 : (jj >= 0 ? ld_agent(&d[jj].approx) : (u64)2);
             incl = __ballot((word & ST_MASK) == 2);
             const u64 empty = __ballot((word & ST_MASK) == 0);
             const u64 need = incl ? ((incl & (0 - incl)) << 1) - 1 : ~(u64)0;   // lanes up to the nearest inclusive one
@@ -216,7 +200,7 @@ __device__ double read_raw(const OpDesc *d, int jj, unsigned *abort_word)
 {
     unsigned spins = 0;
     for (;;) {
-        const u64 r = ld_poll(&d[jj].raw, spins), c = ld_poll(&d[jj].raw_chk, spins);
+        const u64 r = ld_agent(&d[jj].raw), c = ld_agent(&d[jj].raw_chk);
         if (c == ~r) return bits_to_double(r);
         if (spin_fail(spins, abort_word)) return __builtin_nan("");
     }
@@ -237,7 +221,7 @@ __device__ double lookback_exact(const OpDesc *d, int k, bool clean, int eu, int
         for (;;) {
             // before the vector: carry-out 0 (state 3: value in `raw`, handled below without a load); lanes beyond
             // the window: an increment sum of 0
-            word = lane >= OP_LB ? (u64)1 : (jj >= 0 ? ld_poll(&d[jj].exact, spins) : (u64)3);
+            word = lane >= OP_LB ? (u64)1 : (jj >= 0 ? ld_agent(&d[jj].exact) : (u64)3);
             const u64 st = word & ST_MASK;
             const bool is_term = st >= 2;
             const bool compat = (clean || lane >= OP_LB) && st == 1 && (exact_eu9(word) == my9 || (word >> 11) == 0);
@@ -444,67 +428,40 @@ __global__ void __launch_bounds__(OP_THREADS, FK_OP_WAVES)
 resample_onepass_kernel(const OpArgs a)
 {
     __shared__ OpShared sh;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long Np = a.Np, nch = a.nch;
     OP_CLOCK_START();
 
-    // ---- tickets: chunk (f, k).  Filters are split into contiguous regions, one head each; a workgroup starts at
-    // its home region (the XCC it runs on, so that a filter's chunks meet in one L2) and moves on when that one is
-    // exhausted.  Inside a region the tickets run chunk-major (chunk k of every filter of the region before chunk k + 1
-    // of any): the resident workgroups then advance all the region's filters together, and a chunk that has to resolve
-    // its carry with the general scan (a binade crossing: ~20 per 8e6-particle vector) holds up its own filter's chain
-    // only.
-    // The grid is PERSISTENT: a workgroup keeps taking tickets until none is left, and the atomic for its NEXT ticket is
-    // issued right before the loads of the current chunk's weights, so its round trip (~1.5 us under load) hides behind
-    // theirs.  Progress: a chunk waits only for chunks whose tickets were handed out earlier, every workgroup works its
-    // tickets off in the order it took them, so the unfinished chunk with the oldest ticket is always being worked on.
-    const int R = a.nregions;
-    unsigned home;
-    {
-        unsigned xcc;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        home = ((xcc & 7u) + 8u * ((blockIdx.x >> 3) & 3u)) % (unsigned)R;
-    }
-    int t_step = 0;                 // thread 0: regions tried so far
-    unsigned t_pend = 0;            // thread 0: the ticket last drawn from region (home + t_step) % R
-    if (threadIdx.x == 0)
-        t_pend = __hip_atomic_fetch_add(&a.ctl->head[home].next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    int *win = sh.win();
-  for (;;) {
-    // (the thread index is re-made opaque every round: otherwise everything derived from it -- a dozen offsets and
-    // masks -- is hoisted out of the loop and held in registers across it)
-    int tid_opaque = threadIdx.x;
-    asm volatile("" : "+v"(tid_opaque));
-    const int tid = tid_opaque, lane = tid & 63, wave = tid >> 6;
+    // ---- ticket: chunk (f, k).  Filters are split into contiguous regions, one head each; a workgroup starts at
+    // its home region (blockIdx % regions ~ its XCD) and moves on when that one is exhausted.  Inside a region the
+    // tickets run chunk-major (chunk k of every filter of the region before chunk k + 1 of any): the resident
+    // workgroups then advance all the region's filters together, and a chunk that has to resolve its carry with the
+    // general scan (a binade crossing: ~20 per 8e6-particle vector) holds up its own filter's chain only.
     if (tid == 0) {
+        const int R = a.nregions;
         int f = -1, k = 0;
-        for (; t_step < R; ) {
-            const int r = (int)((home + (unsigned)t_step) % (unsigned)R);
+        for (int s = 0; s < R; ++s) {
+            const int r = (int)((blockIdx.x + (unsigned)s) % (unsigned)R);
             const long f_lo = (long)a.Fn * r / R, f_hi = (long)a.Fn * (r + 1) / R;
             const unsigned long cnt = (unsigned long)(f_hi - f_lo) * (unsigned long)nch;
-            if (t_pend < cnt) {
+            const unsigned t = __hip_atomic_fetch_add(&a.ctl->head[r].next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (t < cnt) {
                 const unsigned nf = (unsigned)(f_hi - f_lo);
-                f = (int)(f_lo + t_pend % nf);
-                k = (int)(t_pend / nf);
+                f = (int)(f_lo + t % nf);
+                k = (int)(t / nf);
                 break;
             }
-            if (++t_step < R)
-                t_pend = __hip_atomic_fetch_add(&a.ctl->head[(home + (unsigned)t_step) % (unsigned)R].next, 1u,
-                                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         sh.bc_i[1] = f;
         sh.bc_i[2] = k;
-        // the next one (its answer is looked at one chunk later)
-        if (f >= 0)
-            t_pend = __hip_atomic_fetch_add(&a.ctl->head[(home + (unsigned)t_step) % (unsigned)R].next, 1u,
-                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    int *win = sh.win();
     init_window(win, tid);                 // the output window (it shares its LDS with the general scan's tile)
     __syncthreads();
     const int f = __builtin_amdgcn_readfirstlane(sh.bc_i[1]);
     const int k = __builtin_amdgcn_readfirstlane(sh.bc_i[2]);
-    if (f < 0) break;                                                      // no ticket left
+    if (f < 0) return;                                                     // cannot happen: one workgroup per chunk
     OP_CLOCK(0);                                                           // ticket
-  do {
 
     const double *wf = a.w + (long)f * Np;
     int32_t *of = a.idx + (long)f * Np;
@@ -577,7 +534,7 @@ resample_onepass_kernel(const OpArgs a)
             if (a.status && __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
                 atomicOr(&a.status[f], ST_INTERNAL);
         }
-        break;
+        return;
     }
     // A == 0 means EXACTLY: every weight before this chunk is +0.0 (they are all >= 0), so the carry-in is 0 and
     // needs no stage 2; with S == 0 as well the chunk is empty-handed: carry-out 0, no slots
@@ -658,7 +615,7 @@ resample_onepass_kernel(const OpArgs a)
     OP_COUNT(8 + (quick < 0 ? 3 : quick), 1);                              // 8: general, 9: quick, 10: zeros
     if (quick < 0) {                                                       // abort: a predecessor never published
         if (tid == 0 && a.status) atomicOr(&a.status[f], ST_INTERNAL);
-        break;
+        return;
     }
 
     // ---- slot boundaries: weight j owns the slots [n_{j-1}, n_j), n_j = n(cs_j)  (fk_resample_math.hpp) -----------
@@ -811,16 +768,13 @@ resample_onepass_kernel(const OpArgs a)
     }
     OP_CLOCK(7);                                                           // emission
     OP_COUNT(11, 1);
+    OP_CLOCK_FLUSH();
 
     // ---- end of the vector: positions >= cumsum[-1] (the reference raises IndexError, resampling.py:109,145) --
     if (k == nch - 1) {
         for (long i = (long)u_hi + tid; i < Np; i += OP_THREADS) of[i] = (int32_t)(Np - 1);
         if (tid == 0 && a.status && u_hi < (int)Np) atomicOr(&a.status[f], ST_OVERRUN);
     }
-  } while (0);
-    __syncthreads();                       // the LDS slots of this chunk are free for the next one
-  }
-    OP_CLOCK_FLUSH();
 }
 
 // ---- filters the one-pass kernel declined (a negative / NaN / huge weight): the reference's loop, literally -----
@@ -961,21 +915,11 @@ int onepass_launch(bool stratified, int64_t Fn, int64_t Np, const double *w, con
     a.delta = (8.0 * (double)(Np + 4096) + 16.0 * (double)nch) * 0x1p-53;
     if (hipMemsetAsync(ws, 0, need, s) != hipSuccess) return FK_ERR_LAUNCH;
     if (status && hipMemsetAsync(status, 0, (size_t)Fn * sizeof(int32_t), s) != hipSuccess) return FK_ERR_LAUNCH;
-    // persistent grid: as many workgroups as the chip holds (a few more do no harm: they find the tickets gone)
-    static int n_cu = 0;
-    if (!n_cu) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return FK_ERR_LAUNCH;
-        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
-    const unsigned long resident = (unsigned long)n_cu * 8UL;
-    const unsigned grid = (unsigned)(total < resident ? total : resident);
     if (stratified) {
-        hipLaunchKernelGGL((resample_onepass_kernel<true>), dim3(grid), dim3(OP_THREADS), 0, s, a);
+        hipLaunchKernelGGL((resample_onepass_kernel<true>), dim3((unsigned)total), dim3(OP_THREADS), 0, s, a);
         hipLaunchKernelGGL((resample_literal_kernel<true>), dim3((unsigned)Fn), dim3(64), 0, s, a);
     } else {
-        hipLaunchKernelGGL((resample_onepass_kernel<false>), dim3(grid), dim3(OP_THREADS), 0, s, a);
+        hipLaunchKernelGGL((resample_onepass_kernel<false>), dim3((unsigned)total), dim3(OP_THREADS), 0, s, a);
         hipLaunchKernelGGL((resample_literal_kernel<false>), dim3((unsigned)Fn), dim3(64), 0, s, a);
     }
     return check_launch("resample_onepass_kernel");

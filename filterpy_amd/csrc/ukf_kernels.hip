@@ -374,6 +374,120 @@ ukf_linear_kernel(const UkfArgs a, const double *__restrict__ pF, const double *
     }
 }
 
+// ------------------------------------------------ fused linear-model UKF smoother --
+//   fk_ukf_linear_rts_f64 <- UnscentedKalmanFilter.rts_smoother (filterpy/kalman/UKF.py:634-739) with fx(x, dt) = F x:
+// the whole backward loop in one launch, one track per lane, the smoothed step k+1 carried in registers
+// (fk_ukf.hpp, ukf_linear_rts_step).  Reads Xs[k], Ps[k]; writes xs[k], ps[k], Ks[k]: 8 (2n + 3n^2) bytes per
+// track-step (1008 at n = 6).  Before: four kernel launches and nine host<->device copies per step.
+struct UkfRtsArgs {
+    const double *Xs, *Ps;
+    double *xs, *ps, *Ks;
+    int32_t *status;
+    long N, T;
+    int n;
+    double scale;
+};
+
+// (at dim_x = 6 the gain's second sweep accumulates Pb and the full n x n Pxb side by side next to L, x and xb: ~115
+// live doubles -- one wave per SIMD there; two spilled 90-220 registers)
+template <int NX, int LAYOUT, bool SCALAR_F>
+__global__ void __launch_bounds__(BLOCK, (NX <= 2 ? 4 : NX <= 4 ? 2 : 1))
+ukf_linear_rts_kernel(const UkfRtsArgs a, const double *__restrict__ pF, const double *__restrict__ pQ,
+                      const double *__restrict__ pWm, const double *__restrict__ pWc)
+{
+    constexpr int KS = 2 * NX + 1;
+    constexpr int PL = NX * (NX + 1) / 2;
+    using SharedModel = LdsModel<NX, 1>;
+    __shared__ double s_model[SharedModel::SIZE + 2 * KS];
+    const long N = a.N;
+    const long blk0 = (long)blockIdx.x * BLOCK;
+    const Lane ln{blk0, threadIdx.x, N};
+    const bool live = blk0 + ln.tid < N;
+    const Lane lr{blk0, live ? ln.tid : 0u, N};
+    const int n = a.n;
+    const int ks = 2 * n + 1;
+    lds_fill<NX, NX>(s_model + SharedModel::OFF_F, pF, n, n, 1.0, threadIdx.x);
+    lds_fill<NX, NX>(s_model + SharedModel::OFF_Q, pQ, n, n, 1.0, threadIdx.x);
+    for (unsigned q = ln.tid; q < (unsigned)(2 * KS); q += BLOCK) {           // weights re-indexed to the padded point set
+        const int which = q / KS, i = q % KS;
+        int src = -1;
+        if (i == 0) src = 0;
+        else if (i <= NX) { if (i <= n) src = i; }
+        else { if (i - NX <= n) src = n + (i - NX); }
+        const double *W = which ? pWc : pWm;
+        s_model[SharedModel::SIZE + q] = (src >= 0 && src < ks) ? W[src] : 0.0;
+    }
+    __syncthreads();
+    using StepModel = std::conditional_t<SCALAR_F, ScalarFHModel<NX, 1>, SharedModel>;
+    struct View { StepModel sm; const double *Wm, *Wc; };
+    int goff = 0;
+    auto sweep = [&]() {
+        if constexpr (SCALAR_F) {
+            int t;
+            asm volatile("s_mov_b32 %0, 0" : "=s"(t));
+            goff = t;
+        }
+    };
+    auto fresh = [&]() {
+        int off = 0;
+        asm volatile("" : "+v"(off));
+        const double *mb = s_model + off;
+        if constexpr (SCALAR_F) return View{StepModel{mb, pF + goff, pF + goff}, mb + SharedModel::SIZE, mb + SharedModel::SIZE + KS};
+        else return View{StepModel{mb}, mb + SharedModel::SIZE, mb + SharedModel::SIZE + KS};
+    };
+    auto load_state = [&](long t, double (&x)[NX], double (&P)[PL]) {
+        load_rec<NX, 1, LAYOUT, false>(x, a.Xs + t * N * n, lr, n, 1, 0.0);
+        const RecView<LAYOUT> pv(a.Ps + t * N * n * n, lr, n * n);
+        FK_UNROLL for (int i = 0; i < NX; ++i)
+            FK_UNROLL for (int j = 0; j < NX; ++j)
+                if (j >= i) P[sym_idx<NX>(i, j)] = (i < n && j < n) ? pv.load(i * n + j) : (i == j ? 1.0 : 0.0);
+    };
+    auto store_state = [&](long t, const double (&x)[NX], const double (&P)[PL]) {
+        store_rec<NX, 1, LAYOUT, false>(x, a.xs + t * N * n, ln, n, 1);
+        double Pf[NX * NX];
+        FK_UNROLL for (int i = 0; i < NX; ++i)
+            FK_UNROLL for (int j = 0; j < NX; ++j) Pf[i * NX + j] = P[sym_idx<NX>(i, j)];
+        store_rec<NX, NX, LAYOUT, false>(Pf, a.ps + t * N * n * n, ln, n, n);
+    };
+
+    double xn[NX], Pn[PL];
+    load_state(a.T - 1, xn, Pn);
+    if (live) {
+        // the last step is the filter's own output, copied as it is (both triangles: xs, ps = Xs.copy(), Ps.copy())
+        store_rec<NX, 1, LAYOUT, false>(xn, a.xs + (a.T - 1) * N * n, ln, n, 1);
+        {
+            double Pf[NX * NX];
+            load_rec<NX, NX, LAYOUT, false>(Pf, a.Ps + (a.T - 1) * N * n * n, lr, n, n, 0.0);
+            store_rec<NX, NX, LAYOUT, false>(Pf, a.ps + (a.T - 1) * N * n * n, ln, n, n);
+        }
+        if (a.Ks) {
+            double Z[NX * NX];
+            FK_UNROLL for (int e = 0; e < NX * NX; ++e) Z[e] = 0.0;
+            store_rec<NX, NX, LAYOUT, false>(Z, a.Ks + (a.T - 1) * N * n * n, ln, n, n);
+        }
+    }
+    int st = 0;
+    for (long t = a.T - 2; t >= 0; --t) {
+        double x[NX], P[PL], K[NX * NX];
+        load_state(t, x, P);
+        {
+            double xb[NX], Pb[PL];
+            st |= ukf_linear_rts_gain<NX>(x, P, a.scale, xb, Pb, K, fresh, sweep);
+            ukf_linear_rts_correct<NX>(x, P, xn, Pn, xb, Pb, K);
+            FK_UNROLL for (int c = 0; c < NX; ++c) xn[c] = x[c];
+            FK_UNROLL for (int e = 0; e < PL; ++e) Pn[e] = P[e];
+        }
+        if (live) {
+            store_state(t, x, P);
+            if (a.Ks) store_rec<NX, NX, LAYOUT, false>(K, a.Ks + t * N * n * n, ln, n, n);
+        }
+    }
+    if (live && a.status) {
+        if (!all_finite<NX>(xn) || !all_finite<PL>(Pn)) st |= ST_NONFINITE;
+        a.status[ln.blk0 + ln.tid] = st;
+    }
+}
+
 static int fail(int code, const char *msg)
 {
     set_last_error(msg);
@@ -428,6 +542,35 @@ int fk_ukf_linear_batch_f64(const fk_ukf_desc *d, const double *F, const double 
     }
 #undef GO
     return check_launch("ukf_linear_kernel");
+}
+
+int fk_ukf_linear_rts_f64(const fk_ukf_desc *d, const double *F, const double *Q, const double *Wm, const double *Wc,
+                          const double *Xs, const double *Ps, double *xs, double *Ps_out, double *K, int32_t *status,
+                          void *stream)
+{
+    if (!d) return fail(FK_ERR_BAD_ARG, "desc is NULL");
+    if (d->n < 1 || d->n > 6) return fail(FK_ERR_UNSUPPORTED, "fused linear UKF smoother: dim_x 1..6");
+    if (d->N < 0 || d->T < 0 || !F || !Q || !Wm || !Wc || !Xs || !Ps || !xs || !Ps_out)
+        return fail(FK_ERR_BAD_ARG, "fused linear UKF smoother: bad argument");
+    if ((double)d->N * d->n * d->n * 8.0 >= 4294967296.0) return fail(FK_ERR_UNSUPPORTED, "fused linear UKF smoother: record block >= 4 GiB, split the batch");
+    if (d->N == 0 || d->T == 0) return FK_OK;
+    UkfRtsArgs a{};
+    a.Xs = Xs; a.Ps = Ps; a.xs = xs; a.ps = Ps_out; a.Ks = K; a.status = status;
+    a.N = d->N; a.T = d->T; a.n = d->n; a.scale = d->scale;
+    const dim3 grid((unsigned)((a.N + BLOCK - 1) / BLOCK)), block(BLOCK);
+    hipStream_t s = (hipStream_t)stream;
+    const bool soa = d->layout == FK_LAYOUT_SOA;
+#define GO(NXV, SC)                                                                                              \
+    do {                                                                                                         \
+        if (soa) hipLaunchKernelGGL((ukf_linear_rts_kernel<NXV, LAYOUT_SOA, SC>), grid, block, 0, s, a, F, Q, Wm, Wc); \
+        else hipLaunchKernelGGL((ukf_linear_rts_kernel<NXV, LAYOUT_AOS, SC>), grid, block, 0, s, a, F, Q, Wm, Wc);     \
+    } while (0)
+    if (d->n <= 2) GO(2, false);
+    else if (d->n <= 4) GO(4, false);
+    else if (d->n == 6) GO(6, true);
+    else GO(6, false);
+#undef GO
+    return check_launch("ukf_linear_rts_kernel");
 }
 
 }  // extern "C"

@@ -378,6 +378,24 @@ class UnscentedKalmanFilter(object):
             raise ValueError('Xs and Ps must have the same length')
         if self._devcall:
             return self._dev_rts_smoother(Xs, Ps, dts, device_outputs)
+        if not callable(self.fx) and dts is None and self._dim_x <= 6 and not isinstance(Xs, torch.Tensor):
+            # linear fx given as a matrix: the whole backward loop is ONE fused launch (fk_ukf_linear_rts_f64)
+            n, N, lay = self._dim_x, self._N or 1, self._layout
+            Xa = np.asarray(Xs, dtype=np.float64)
+            T = Xa.shape[0]
+            dX = E.to_records(Xa.reshape(T, N, n), lay, 1)
+            dP = E.to_records(np.asarray(Ps, dtype=np.float64).reshape(T, N, n, n), lay, 1)
+            oxs, ops, oK = E.alloc_records((T,), N, n, lay), E.alloc_records((T,), N, n * n, lay), E.alloc_records((T,), N, n * n, lay)
+            st = torch.zeros(N, dtype=torch.int32, device=dX.device)
+            E.ukf_linear_rts(n, N, T, lay, self.points_fn.scale, E.dev(np.asarray(self.fx, dtype=np.float64)),
+                             E.dev(np.broadcast_to(np.asarray(self.Q, dtype=np.float64), (n, n)).copy()),
+                             E.dev(np.asarray(self.Wm, dtype=np.float64)), E.dev(np.asarray(self.Wc, dtype=np.float64)),
+                             dX, dP, oxs, ops, oK, st)
+            E.raise_on_status(st, "UnscentedKalmanFilter.rts_smoother")
+            xs, ps, Ks = E.from_records(oxs, lay, 1, (n,)), E.from_records(ops, lay, 1, (n, n)), E.from_records(oK, lay, 1, (n, n))
+            if self._N is None:
+                return xs[:, 0].reshape(Xa.shape), ps[:, 0], Ks[:, 0]
+            return xs, ps, Ks
         n, k = self._dim_x, self._num_sigmas
         N = self._N or 1
         Xs = np.asarray(Xs, dtype=np.float64)

@@ -62,7 +62,11 @@ class MerweScaledSigmaPoints(object):
 
     @property
     def scale(self):
-        return self.alpha ** 2 * (self.n + self.kappa)   # lambda + n
+        """lambda + n exactly as sigma_points() forms it (sigma_points.py:165-168): lambda_ is rounded first (it
+        cancels against n: six digits at alpha = 1e-3), and the weights divide by the same rounded sum
+        (:184-185) -- spread^2 * Wc stays exactly 1/2 only if this is the same floating-point number."""
+        lambda_ = self.alpha ** 2 * (self.n + self.kappa) - self.n
+        return lambda_ + self.n
 
 
 class JulierSigmaPoints(object):

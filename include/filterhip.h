@@ -228,6 +228,17 @@ int fk_ukf_linear_batch_f64(const fk_ukf_desc *desc,
                             double *x, double *P, double *means, double *covs,
                             int32_t *status, void *stream);
 
+/* UnscentedKalmanFilter.rts_smoother (filterpy/kalman/UKF.py:634-739) with LINEAR fx(x, dt) = F x, fused per track:
+ * the whole backward loop in one launch (per step: sigma points of (xs[k], ps[k]) -> F sigma -> unscented transform
+ * + Q -> cross variance around Xs[k] / xb -> K = Pxb inv(Pb) -> xs[k] += K (xs[k+1] - xb), ps[k] += K (ps[k+1] - Pb) K').
+ * desc: n (1..6), N, T, layout, scale = lambda + n (m is ignored).
+ *   F [n*n], Q [n*n] (the filter's Q: the reference never reads its Qs argument, UKF.py:717-722), Wm, Wc [2n+1];
+ *   Xs [T][N][n], Ps [T][N][n*n]: the filter output; xs, Ps_out likewise: the smoothed output; K [T][N][n*n] or NULL
+ *   (K of the last step is zero, like the reference's); status [N] or NULL. */
+int fk_ukf_linear_rts_f64(const fk_ukf_desc *desc, const double *F, const double *Q, const double *Wm, const double *Wc,
+                          const double *Xs, const double *Ps, double *xs, double *Ps_out, double *K, int32_t *status,
+                          void *stream);
+
 /* ------------------------------------------------------------------ */
 /* API variants of the linear filter               */
 /* ------------------------------------------------------------------ */

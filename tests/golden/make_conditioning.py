@@ -10,6 +10,12 @@ so the stated 1e-10 bar is kept wherever the reference itself is that well condi
 appears only with this file as its justification (MerweScaledSigmaPoints with alpha = 1e-3: Wm[0] ~ -1e6,
 every unscented transform cancels six digits -- in the reference too).
 
+A second family of K runs keeps the inputs bit-identical and changes only the ORDER in which the reference's own
+unscented_transform sums the sigma points (filterpy/kalman/unscented_transform.py:104 `np.dot(Wm, sigmas)`, :117-118
+`np.dot(y.T, np.dot(np.diag(Wc), y))`: the rows of `sigmas` and the entries of Wm / Wc are permuted together before the
+call, which is the same sum in exact arithmetic and what another BLAS build would be free to do).  `spread` holds the
+larger of the two, `spread_inputs` / `spread_order` each of them.
+
     PYTHONPATH=/root/reference MPLBACKEND=Agg python tests/golden/make_conditioning.py
 writes tests/golden/ukf_conditioning.json
 """
@@ -41,34 +47,51 @@ def rel_rows(a, b):
     return float(np.max(np.max(np.abs(a2 - b2), axis=1) / sc))
 
 
-def run(n, m, pts, x0, P0, zs, F, H, Q, R):
+def run(n, m, pts, x0, P0, zs, F, H, Q, R, order_rs=None):
+    from filterpy.kalman import unscented_transform
+    UT = None
+    if order_rs is not None:
+        def UT(sigmas, Wm, Wc, noise_cov=None, mean_fn=None, residual_fn=None):
+            perm = order_rs.permutation(len(Wm))
+            return unscented_transform(sigmas[perm], Wm[perm], Wc[perm], noise_cov, mean_fn, residual_fn)
     ukf = UnscentedKalmanFilter(n, m, dt=1.0, hx=lambda x: H @ x, fx=lambda x, dt: F @ x, points=pts)
     ukf.x, ukf.P, ukf.Q, ukf.R = x0.copy(), P0.copy(), Q.copy(), R.copy()
-    mu, cov = ukf.batch_filter(list(zs) if m > 1 else [np.array([z[0]]) for z in zs])
-    xs, Ps, Ks = ukf.rts_smoother(mu, cov)
-    return dict(mu=mu, cov=cov, rts_x=xs, rts_P=Ps, rts_K=Ks[:-1])
+    mu, cov = ukf.batch_filter(list(zs) if m > 1 else [np.array([z[0]]) for z in zs], UT=UT)
+    xs, Ps, Ks = ukf.rts_smoother(mu, cov, UT=UT)
+    # the first predict alone (the single-step goldens s1_xp / s1_Pp of ukf_merwe.npz)
+    ukf.x, ukf.P = x0.copy(), P0.copy()
+    ukf.predict(UT=UT)
+    return dict(mu=mu, cov=cov, rts_x=xs, rts_P=Ps, rts_K=Ks[:-1], s1_xp=ukf.x.copy()[None], s1_Pp=ukf.P.copy()[None])
 
 
 def main():
     g = np.load(os.path.join(HERE, "ukf_merwe.npz"))
-    out = {"_doc": "max over %d one-ulp input perturbations of the normwise relative change (per step vector / matrix) "
-                   "of the reference's own outputs; see make_conditioning.py" % K}
+    out = {"_doc": "max over %d one-ulp input perturbations, and over %d re-orderings of the sigma-point sums inside the "
+                   "reference's own unscented_transform, of the normwise relative change (per step vector / matrix) of the "
+                   "reference's outputs; see make_conditioning.py" % (K, K)}
     for ci, c in enumerate(g["cases"]):
         n, m, alpha, beta, kappa = int(c[0]), int(c[1]), float(c[2]), float(c[3]), float(c[4])
         p = f"c{ci}_"
         pts = MerweScaledSigmaPoints(n, alpha, beta, kappa)
         base = run(n, m, pts, g[p + "x0"], g[p + "P0"], g[p + "zs"], g[p + "F"], g[p + "H"], g[p + "Q"], g[p + "R"])
         assert np.array_equal(base["mu"], g[p + "mu"]) and np.array_equal(base["rts_P"], g[p + "rts_P"])
-        spread = {k: 0.0 for k in base}
+        sp_in, sp_ord = {k: 0.0 for k in base}, {k: 0.0 for k in base}
         rs = np.random.RandomState(9000 + ci)
         for _ in range(K):
             r = run(n, m, pts, ulp_perturb(rs, g[p + "x0"]), ulp_perturb(rs, g[p + "P0"], True),
                     ulp_perturb(rs, g[p + "zs"]), ulp_perturb(rs, g[p + "F"]), ulp_perturb(rs, g[p + "H"]),
                     ulp_perturb(rs, g[p + "Q"], True), ulp_perturb(rs, g[p + "R"], True))
             for k in base:
-                spread[k] = max(spread[k], rel_rows(r[k], base[k]))
-        out[f"c{ci}"] = dict(n=n, m=m, alpha=alpha, beta=beta, kappa=kappa, Wm0=float(pts.Wm[0]), spread=spread)
-        print(ci, n, m, alpha, {k: f"{v:.1e}" for k, v in spread.items()})
+                sp_in[k] = max(sp_in[k], rel_rows(r[k], base[k]))
+        ors = np.random.RandomState(9500 + ci)
+        for _ in range(K):
+            r = run(n, m, pts, g[p + "x0"], g[p + "P0"], g[p + "zs"], g[p + "F"], g[p + "H"], g[p + "Q"], g[p + "R"], order_rs=ors)
+            for k in base:
+                sp_ord[k] = max(sp_ord[k], rel_rows(r[k], base[k]))
+        spread = {k: max(sp_in[k], sp_ord[k]) for k in base}
+        out[f"c{ci}"] = dict(n=n, m=m, alpha=alpha, beta=beta, kappa=kappa, Wm0=float(pts.Wm[0]), spread=spread,
+                             spread_inputs=sp_in, spread_order=sp_ord)
+        print(ci, n, m, alpha, "inputs", {k: f"{v:.1e}" for k, v in sp_in.items()}, "order", {k: f"{v:.1e}" for k, v in sp_ord.items()})
     with open(os.path.join(HERE, "ukf_conditioning.json"), "w") as fh:
         json.dump(out, fh, indent=1)
 

@@ -561,6 +561,67 @@ int ukf_v2_batch(long T, const double *F, const double *H, const double *Q, cons
 }
 }  // namespace
 
+namespace {
+// the fused linear-model UKF smoother's step (fk_ukf.hpp: ukf_linear_rts_gain / _correct) over a whole backward pass
+template <int NX>
+int ukf_rts_batch(long T, const double *F, const double *Q, const double *Wm, const double *Wc, double scale,
+                  const double *Xs, const double *Ps, double *xs, double *ps, double *Ks)
+{
+    constexpr int PL = NX * (NX + 1) / 2, KS = 2 * NX + 1;
+    struct View {
+        fk::RegModel<NX, 1> sm;
+        const double *Wm, *Wc;
+    };
+    View v;
+    std::copy(F, F + NX * NX, v.sm.F);
+    std::copy(Q, Q + NX * NX, v.sm.Q);
+    double wm[KS], wc[KS];
+    std::copy(Wm, Wm + KS, wm);
+    std::copy(Wc, Wc + KS, wc);
+    v.Wm = wm;
+    v.Wc = wc;
+    auto fresh = [&]() -> const View & { return v; };
+    auto load = [&](long t, double (&x)[NX], double (&P)[PL]) {
+        for (int i = 0; i < NX; ++i) {
+            x[i] = Xs[t * NX + i];
+            for (int j = i; j < NX; ++j) P[fk::sym_idx<NX>(i, j)] = Ps[(t * NX + i) * NX + j];
+        }
+    };
+    auto store = [&](long t, const double (&x)[NX], const double (&P)[PL]) {
+        for (int i = 0; i < NX; ++i) {
+            xs[t * NX + i] = x[i];
+            for (int j = 0; j < NX; ++j) ps[(t * NX + i) * NX + j] = P[fk::sym_idx<NX>(i, j)];
+        }
+    };
+    double xn[NX], Pn[PL];
+    load(T - 1, xn, Pn);
+    for (int i = 0; i < NX; ++i) xs[(T - 1) * NX + i] = Xs[(T - 1) * NX + i];
+    for (int e = 0; e < NX * NX; ++e) ps[(T - 1) * NX * NX + e] = Ps[(T - 1) * NX * NX + e];     // copied as it is
+    for (int e = 0; e < NX * NX; ++e) Ks[(T - 1) * NX * NX + e] = 0.0;
+    int st = 0;
+    for (long t = T - 2; t >= 0; --t) {
+        double x[NX], P[PL], K[NX * NX], xb[NX], Pb[PL];
+        load(t, x, P);
+        st |= fk::ukf_linear_rts_gain<NX>(x, P, scale, xb, Pb, K, fresh);
+        fk::ukf_linear_rts_correct<NX>(x, P, xn, Pn, xb, Pb, K);
+        store(t, x, P);
+        for (int e = 0; e < NX * NX; ++e) Ks[t * NX * NX + e] = K[e];
+        for (int i = 0; i < NX; ++i) xn[i] = x[i];
+        for (int e = 0; e < PL; ++e) Pn[e] = P[e];
+    }
+    return st;
+}
+}  // namespace
+
+extern "C" int hc_ukf_linear_rts(int n, long T, const double *F, const double *Q, const double *Wm, const double *Wc,
+                                 double scale, const double *Xs, const double *Ps, double *xs, double *ps, double *Ks)
+{
+    if (n == 2) return ukf_rts_batch<2>(T, F, Q, Wm, Wc, scale, Xs, Ps, xs, ps, Ks);
+    if (n == 4) return ukf_rts_batch<4>(T, F, Q, Wm, Wc, scale, Xs, Ps, xs, ps, Ks);
+    if (n == 6) return ukf_rts_batch<6>(T, F, Q, Wm, Wc, scale, Xs, Ps, xs, ps, Ks);
+    return -1;
+}
+
 extern "C" int hc_ukf_linear_v2(int n, int m, long T, const double *F, const double *H, const double *Q, const double *R,
                                 const double *Wm, const double *Wc, double scale, const double *zs,
                                 const unsigned char *mask, double *x0, double *P0, double *means, double *covs)

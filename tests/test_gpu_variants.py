@@ -198,3 +198,28 @@ def test_ukf_rts_smoother_bank():
     xs, Ps, Ks = ukf.rts_smoother(tile_tracks(g[p + "mu"], N, axis=1), tile_tracks(g[p + "cov"], N, axis=1))
     assert xs.shape == (30, N, n)
     assert rel_err_rows(xs[:, N - 1], g[p + "rts_x"]) < 1e-10 and rel_err_rows(Ps[:, 0], g[p + "rts_P"]) < 1e-10
+
+
+@pytest.mark.parametrize("layout", ["soa", "aos"])
+def test_fused_linear_ukf_smoother_bank_goldens(layout):
+    """fk_ukf_linear_rts_f64 (one launch for the whole backward pass, UKF.py:714-739 with fx = F x) on banks in both
+    layouts, full and partial workgroups, against the live reference's rts_smoother on its own filter output."""
+    from filterpy_amd.kalman import UnscentedKalmanFilter, MerweScaledSigmaPoints
+    from gpu_util import tile_tracks
+    g = golden("ukf_merwe")
+    for ci, n, m, alpha, beta, kappa in _ukf_cases():
+        if n > 6:
+            continue
+        p = f"c{ci}_"
+        for N in (1, 70, 300):
+            ukf = UnscentedKalmanFilter(n, m, dt=1.0, hx=g[p + "H"], fx=g[p + "F"],
+                                        points=MerweScaledSigmaPoints(n, alpha, beta, kappa), n_tracks=N, layout=layout)
+            ukf.Q, ukf.R = g[p + "Q"].copy(), g[p + "R"].copy()
+            xs, Ps, Ks = ukf.rts_smoother(tile_tracks(g[p + "mu"], N, axis=1), tile_tracks(g[p + "cov"], N, axis=1))
+            T = g[p + "mu"].shape[0]
+            assert xs.shape == (T, N, n) and Ps.shape == (T, N, n, n) and Ks.shape == (T, N, n, n)
+            for trk in sorted({0, N // 2, N - 1}):
+                assert rel_err_rows(xs[:, trk], g[p + "rts_x"]) < ukf_tol(ci, "rts_x"), (ci, N, trk)
+                assert rel_err_rows(Ps[:, trk], g[p + "rts_P"]) < ukf_tol(ci, "rts_P"), (ci, N, trk)
+                assert rel_err_rows(Ks[:-1, trk], g[p + "rts_K"][:-1]) < ukf_tol(ci, "rts_K"), (ci, N, trk)
+            assert np.array_equal(Ps[-1, 0], g[p + "cov"][-1]) and not Ks[-1].any()

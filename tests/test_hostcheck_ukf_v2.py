@@ -76,3 +76,42 @@ def test_ukf_v2_missing_measurements_skip_the_update():
     mu, cov, _, _ = _v2(n, m, F, H, Q, R, Wm, Wc, lam + n, zs, mask, x0, P0)
     assert np.max(np.abs(mu - mu_ref)) / np.max(np.abs(mu_ref)) < 1e-9
     assert np.max(np.abs(cov - cov_ref)) / np.max(np.abs(cov_ref)) < 1e-9
+
+
+def _rts(n, F, Q, Wm, Wc, scale, Xs, Ps):
+    lib = ctypes.CDLL(os.path.join(ROOT, "tests", "hostcheck", "libhostcheck.so"))
+    T = Xs.shape[0]
+    c = lambda a: np.ascontiguousarray(a, dtype=np.float64)  # noqa: E731
+    F, Q, Wm, Wc, Xs, Ps = map(c, (F, Q, Wm, Wc, Xs, Ps))
+    xs, ps, Ks = np.empty((T, n)), np.empty((T, n, n)), np.empty((T, n, n))
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+    st = lib.hc_ukf_linear_rts(ctypes.c_int(n), ctypes.c_long(T), p(F), p(Q), p(Wm), p(Wc), ctypes.c_double(scale),
+                               p(Xs), p(Ps), p(xs), p(ps), p(Ks))
+    assert st == 0, st
+    return xs, ps, Ks
+
+
+@pytest.mark.parametrize("n,m", [(2, 2), (4, 2), (6, 3)])
+@pytest.mark.parametrize("abk", [(.1, 2., None), (1., 2., .1)])
+def test_fused_ukf_smoother_step_matches_the_oracle(n, m, abk):
+    """fk_ukf.hpp ukf_linear_rts_gain / _correct (the arithmetic of fk_ukf_linear_rts_f64) on the host against the
+    oracle's UKF.rts_smoother (UKF.py:714-739; oracle pinned to the live reference by tests/test_oracle_ukf.py)."""
+    alpha, beta, kappa = abk
+    kappa = 3. - n if kappa is None else kappa
+    r = np.random.default_rng(n * 10 + m + 1)
+    T = 30
+    F = np.eye(n) + 0.05 * np.triu(r.standard_normal((n, n)), 1)
+    H = np.eye(m, n) + 0.1 * r.standard_normal((m, n))
+    A = r.standard_normal((n, n))
+    Q = 0.01 * np.eye(n) + 0.002 * A @ A.T
+    R = 0.5 * np.eye(m)
+    x0, P0 = r.standard_normal(n), 10.0 * np.eye(n)
+    zs = r.standard_normal((T, m))
+    lam = alpha ** 2 * (n + kappa) - n
+    Wm, Wc = ukf_oracle.merwe_weights(n, alpha, beta, kappa)
+    mu, cov = ukf_oracle.ukf_batch_filter(x0, P0, list(zs), lambda s, d: F @ s, lambda s: H @ s, 0.1, Q, R, alpha, beta, kappa)
+    xr, Pr, Kr = ukf_oracle.ukf_rts_smoother(mu, cov, lambda s, d: F @ s, 0.1, Q, alpha, beta, kappa)
+    xs, ps, Ks = _rts(n, F, Q, Wm, Wc, lam + n, mu, cov)
+    rel = lambda a, b: float(np.max(np.max(np.abs(a - b).reshape(len(a), -1), axis=1) / np.max(np.abs(b).reshape(len(b), -1), axis=1)))  # noqa: E731
+    assert rel(xs, xr) < 1e-10 and rel(ps, Pr) < 1e-10 and rel(Ks[:-1], Kr[:-1]) < 1e-10
+    assert np.array_equal(xs[-1], mu[-1]) and np.array_equal(ps[-1], cov[-1]) and not Ks[-1].any()
