@@ -177,8 +177,8 @@ class UnscentedKalmanFilter(object):
                     r = Rs[t]
                     Rt = E.dev(np.eye(m) * r if np.isscalar(r) else np.broadcast_to(np.asarray(r, dtype=np.float64), (m, m)).copy())
                 self._dev_update(dx, dP, sig, dzs[t], c, st, R=Rt)
-            means[t].copy_(dx)
-            covs[t].copy_(dP)
+            means[t].copy_(dx.reshape(means[t].shape))      # (aos records keep the host array's trailing shape)
+            covs[t].copy_(dP.reshape(covs[t].shape))
         E.raise_on_status(st, "UnscentedKalmanFilter.batch_filter")
         self.x, self.P = E.from_records(dx, lay, 0, (n,)), E.from_records(dP, lay, 0, (n, n))
         if device_outputs:
