@@ -64,7 +64,13 @@ __device__ __forceinline__ double quad_rot(double v)
 // with the NEXT value -- the low half of one covariance element per pair, 3e-7 relative, on every fourth track of
 // every workgroup that was not the first on its CU (round 2, tests/test_gpu_baseline_configs.py found it at
 // N = 1e5; tools/dbg_r02.py pinned the dword).  Two wait states after every such store.
-__device__ __forceinline__ void store_data_hazard() { asm volatile("s_nop 1"); }
+// (the asm takes the four data dwords as inputs and clobbers memory: the registers stay live up to it and it cannot
+// move above the store -- a bare `s_nop` was scheduled BEFORE the store it was meant to follow)
+using hz_u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+__device__ __forceinline__ void store_data_hazard(const hz_u32x4 &v)
+{
+    asm volatile("s_nop 1" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w) : "memory");
+}
 
 // raw buffer access with a per-lane byte offset and a wave-uniform element offset
 struct MlView {
@@ -104,7 +110,7 @@ struct MlView {
         v.z = (unsigned)__builtin_amdgcn_update_dpp(bx, ax, 0x104, 0xf, 0x5, false);   // even quads: a of quad + 1 (row_shl:4)
         v.w = (unsigned)__builtin_amdgcn_update_dpp(by, ay, 0x104, 0xf, 0x5, false);
         __builtin_amdgcn_raw_buffer_store_b128(v, rs, voff2, (unsigned)e * estride, 0);
-        store_data_hazard();
+        store_data_hazard(v);
     }
     // AOS: elements e and e + 1 of a track are adjacent in memory -- one 16-byte access, no exchange
     __device__ __forceinline__ void store2(int e, double a, double b) const
@@ -113,7 +119,7 @@ struct MlView {
         const u32x2 lo = __builtin_bit_cast(u32x2, a), hi = __builtin_bit_cast(u32x2, b);
         const u32x4 v = {lo.x, lo.y, hi.x, hi.y};
         __builtin_amdgcn_raw_buffer_store_b128(v, rs, voff, (unsigned)e * estride, 0);
-        store_data_hazard();
+        store_data_hazard(v);
     }
     __device__ __forceinline__ void load2(int e, double &a, double &b) const
     {

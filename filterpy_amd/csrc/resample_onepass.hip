@@ -130,6 +130,39 @@ __device__ __forceinline__ int wave_incl_max(int v)
     v = dpp_max<0x143, 0xc>(v);
     return v;
 }
+// inclusive prefix sums over the 64 lanes of 64-bit (wrapping) and 32-bit integers
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ u64 dpp_add_u64(u64 acc)
+{
+    const int slo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)acc, CTRL, ROW_MASK, 0xf, false);
+    const int shi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(acc >> 32), CTRL, ROW_MASK, 0xf, false);
+    return acc + (((u64)(unsigned)shi << 32) | (u64)(unsigned)slo);
+}
+__device__ __forceinline__ u64 wave_incl_sum_u64(u64 v)
+{
+    v = dpp_add_u64<0x111, 0xf>(v);
+    v = dpp_add_u64<0x112, 0xf>(v);
+    v = dpp_add_u64<0x114, 0xf>(v);
+    v = dpp_add_u64<0x118, 0xf>(v);
+    v = dpp_add_u64<0x142, 0xa>(v);
+    v = dpp_add_u64<0x143, 0xc>(v);
+    return v;
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_add_i32(int acc)
+{
+    return acc + __builtin_amdgcn_update_dpp(0, acc, CTRL, ROW_MASK, 0xf, false);
+}
+__device__ __forceinline__ int wave_incl_sum_i32(int v)
+{
+    v = dpp_add_i32<0x111, 0xf>(v);
+    v = dpp_add_i32<0x112, 0xf>(v);
+    v = dpp_add_i32<0x114, 0xf>(v);
+    v = dpp_add_i32<0x118, 0xf>(v);
+    v = dpp_add_i32<0x142, 0xa>(v);
+    v = dpp_add_i32<0x143, 0xc>(v);
+    return v;
+}
 __device__ __forceinline__ double lane_bcast(double v, int src)
 {
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src), __builtin_amdgcn_readlane(__double2loint(v), src));
@@ -141,6 +174,27 @@ __device__ __forceinline__ u64 lane_bcast_u64(u64 v, int src)
     return ((u64)hi << 32) | lo;
 }
 
+// scratch of segmented_cumsum (below): the elements of a chunk that cannot be taken as integer increments (`dirty`:
+// a binade crossing, the first weight of a vector, a half-ulp tie, an ambiguous prediction) cut it into SEGMENTS of
+// clean elements
+constexpr int SEG_DMAX = 64;              // dirty elements a chunk may hold before the scan declines
+constexpr int SEG_NONE = 0x7fffffff;      // a segment without a non-zero clean element claims no binade
+struct SegShared {
+    double wtot[OP_THREADS / 64];         // per-wave partial sums (approximate prefix)
+    u64 ptot[OP_THREADS / 64];            // per-wave increment sums
+    int dtot[OP_THREADS / 64];            // per-wave dirty counts
+    int d_pos[SEG_DMAX];                  // dirty element r: its position,
+    double d_w[SEG_DMAX];                 //   its weight,
+    u64 d_ps[SEG_DMAX];                   //   the increment prefix up to it,
+    double d_cs[SEG_DMAX];                //   and (from the chain) the running sum after its real add
+    int seg_e[SEG_DMAX + 1];              // segment r (the clean elements before dirty element r): claimed ulp exponent,
+    double seg_C0[SEG_DMAX + 1];          //   running sum at its start in ulps,
+    u64 seg_ps0[SEG_DMAX + 1];            //   increment prefix at its start,
+    double seg_c[SEG_DMAX + 1];           //   running sum at its start (what a segment of zeros keeps)
+    double carry_out;
+    int fail;
+};
+
 struct OpShared {
     double tile[OP_TILE + OP_TILE / 8];   // weights (padded), later their cumulative sums; then aliased by the window
     int nlast[OP_THREADS];                // slot boundary after each thread's last element
@@ -148,9 +202,10 @@ struct OpShared {
     int wmax[OP_THREADS / 64];
     double bc_d[2];                       // broadcast slots written by wave 0 / thread 0
     int bc_i[6];
+    SegShared seg;
     __device__ __forceinline__ int *win() { return reinterpret_cast<int *>(tile); }
 };
-static_assert(sizeof(OpShared) <= 20480, "eight workgroups per CU need <= 20 KiB of LDS each");
+static_assert(sizeof(OpShared) <= 24576, "six workgroups per CU need <= 24 KiB of LDS each (the kernel runs five)");
 
 // ---- hand-off words --------------------------------------------------------------------------------------
 __device__ __forceinline__ u64 pack_approx(double v, u64 state) { return (double_to_bits(v) & ~ST_MASK) | state; }
@@ -376,6 +431,193 @@ __device__ double general_cumsum(OpShared &sh, int len, double carry)
     }
     __syncthreads();
     return carry;
+}
+
+// ---- the exact scan of one chunk in ONE round (binade crossings, vector start, rare ties) ---------------------------
+// general_cumsum above spends one block scan and four barriers per binade the running sum passes through; the start
+// of a vector passes through a dozen (the sum doubles every time the element count does), which made the first chunk
+// of every vector cost ~45k clocks and a short vector -- four dependent tiles -- mostly that.  Here the binades are
+// PREDICTED for all elements at once and the prediction is then verified, so nothing rests on it:
+//   1. plain fp64 prefix sums (any order, all terms >= 0) bound the exact running sum before and after every add to
+//      a factor (1 +- delta); an element whose two bounds lie in one binade e is CLEAN: its add is the integer map
+//      C -> C + inc_e(w) (fk_exact_scan.hpp, fast_inc), a zero weight is clean in any binade (inc = 0); everything
+//      else -- the crossings themselves, the first weight of a vector (running sum 0), half-ulp ties, ambiguous
+//      bounds -- is DIRTY and will be added with a real IEEE add;
+//   2. one wrapping 64-bit prefix sum of the increments and one of the dirty flags: the dirty elements (a few dozen
+//      at most, else the scan declines) cut the chunk into segments of clean elements that share one binade;
+//   3. wave 0 walks the segments in order, O(1) per segment: the exact running sum entering a segment must have the
+//      claimed ulp and, with the segment's whole increment sum added, stay below 2^53 -- then every prefix inside did
+//      -- else the scan declines; a dirty element is one real add;
+//   4. every element reads its segment's start and scales its increment prefix: cs_j = (C0 + (PS_j - PS0)) 2^e.
+// Declining (returns false; the tile still holds the weights) hands the chunk to general_cumsum.
+// In: weights in sh.tile (padded; slots >= len hold +0.0, no negative / NaN weight), exact carry-in.
+// Out: cumulative sums in sh.tile, *c_out = carry-out.
+__device__ __forceinline__ bool segmented_cumsum(OpShared &sh, int len, double carry, double *c_out)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    SegShared &sg = sh.seg;
+    // bound on the relative distance between the plain prefix sums and the sequential fp64 sums: both are within
+    // (OP_TILE + 1) rounding errors of the real sum of non-negative terms, 2 * 2049 * 2^-53 < 2^-41; 2^-38 is safe
+    constexpr double DELTA = 0x1p-38;
+    if (tid <= SEG_DMAX) sg.seg_e[tid] = SEG_NONE;
+    if (tid == 0) sg.fail = 0;
+    // (registers: the weights and one exponent per element are kept; the increments are recomputed from them at each
+    // of their three uses -- two instructions -- instead of being held)
+    double w[OP_ITEMS];
+    double run = 0.0;
+    FK_UNROLL for (int q = 0; q < OP_ITEMS; ++q) {
+        w[q] = sh.tile[pad8(tid * OP_ITEMS + q)];
+        run += w[q];
+    }
+    const double winc = wave_incl_sum(run);
+    if (lane == 63) sg.wtot[wave] = winc;
+    __syncthreads();                                                                          // (1)
+    double excl = __shfl_up(winc, 1, 64);
+    if (lane == 0) excl = 0.0;
+    FK_UNROLL for (int wv = 0; wv < OP_THREADS / 64; ++wv)
+        if (wv < wave) excl += sg.wtot[wv];
+    // classification + increments
+    unsigned dirty = 0, claims = 0;       // bit q: element q is dirty / claims a binade (clean and non-zero)
+    int eq[OP_ITEMS];
+    int dl = 0;
+    u64 psum = 0;
+    double prev = carry + excl, arun = 0.0;
+    auto inc_of = [&](int q) -> u64 {     // increment of a claiming element in its claimed binade
+        return (u64)floor(scale2(w[q], -eq[q]) + 0.5);
+    };
+    FK_UNROLL for (int q = 0; q < OP_ITEMS; ++q) {
+        const int j = tid * OP_ITEMS + q;
+        arun += w[q];
+        const double cur = carry + (excl + arun);
+        const double lo = prev * (1.0 - DELTA), hi = cur * (1.0 + DELTA);
+        const bool known = lo > OP_SANE_LO && hi < OP_SANE_HI && ulp_exp(lo) == ulp_exp(hi);
+        const int e = ulp_exp(lo);
+        const double x = scale2(w[q], -e) + 0.5;
+        const double i = floor(x);
+        const bool zero = w[q] == 0.0;
+        const bool ok = known && i != x && i < 0x1p53;        // no half-ulp tie; (i < 2^53 always holds: w <= hi)
+        const bool in = j < len;
+        if (in && !zero && ok) claims |= 1u << q;
+        if (in && !zero && !ok) dirty |= 1u << q;
+        eq[q] = e;
+        psum += (in && !zero && ok) ? (u64)i : (u64)0;
+        prev = cur;
+    }
+    dl = __builtin_popcount(dirty);
+    const int dincl = wave_incl_sum_i32(dl);
+    const u64 pincl = wave_incl_sum_u64(psum);
+    if (lane == 63) {
+        sg.dtot[wave] = dincl;
+        sg.ptot[wave] = pincl;
+    }
+    __syncthreads();                                                                          // (2)
+    int dbase = dincl - dl, D = 0;
+    u64 pbase = pincl - psum, ptotal = 0;
+    FK_UNROLL for (int wv = 0; wv < OP_THREADS / 64; ++wv) {
+        if (wv < wave) {
+            dbase += sg.dtot[wv];
+            pbase += sg.ptot[wv];
+        }
+        D += sg.dtot[wv];
+        ptotal += sg.ptot[wv];
+    }
+    if (D > SEG_DMAX) return false;                                        // uniform
+    // the dirty list and the segments' claims (all claimants of a segment write the same value -- checked below)
+    {
+        int r = dbase;
+        u64 ps = pbase;
+        FK_UNROLL for (int q = 0; q < OP_ITEMS; ++q) {
+            if (claims & (1u << q)) {
+                sg.seg_e[r] = eq[q];
+                ps += inc_of(q);
+            }
+            if (dirty & (1u << q)) {
+                sg.d_pos[r] = tid * OP_ITEMS + q;
+                sg.d_w[r] = w[q];
+                sg.d_ps[r] = ps;
+                ++r;
+            }
+        }
+    }
+    __syncthreads();                                                                          // (3)
+    {
+        int r = dbase, bad = 0;
+        FK_UNROLL for (int q = 0; q < OP_ITEMS; ++q) {
+            if ((claims & (1u << q)) && sg.seg_e[r] != eq[q]) bad = 1;    // two binades claimed inside one segment
+            if (dirty & (1u << q)) ++r;
+        }
+        if (bad) sg.fail = 1;
+    }
+    // ---- the chain over the segments (wave 0; lane r holds segment r and dirty element r) -------------------------
+    if (wave == 0) {
+        const u64 my_end = lane < D ? sg.d_ps[lane < SEG_DMAX ? lane : 0] : ptotal;
+        const int my_e = lane <= D ? sg.seg_e[lane] : SEG_NONE;
+        const double my_w = lane < D ? sg.d_w[lane < SEG_DMAX ? lane : 0] : 0.0;
+        double c = carry;
+        u64 psprev = 0;
+        int fail = 0;
+        double r_C0 = 0.0, r_c = 0.0, r_dcs = 0.0;
+        u64 r_ps0 = 0;
+        for (int r = 0; r <= D; ++r) {                                     // uniform
+            const u64 pe = lane_bcast_u64(my_end, r);
+            const int e = __builtin_amdgcn_readlane(my_e, r);
+            const double wr = lane_bcast(my_w, r);
+            const u64 I = pe - psprev;
+            double C0 = 0.0, c_after = c;
+            if (e != SEG_NONE) {
+                C0 = scale2(c, -e);
+                const double Cend = C0 + (double)I;
+                const bool ok = c > OP_SANE_LO && c < OP_SANE_HI && ulp_exp(c) == e && I < (1ull << 53) && Cend < 0x1p53;
+                fail |= ok ? 0 : 1;
+                c_after = scale2(Cend, e);
+            } else {
+                fail |= I != 0 ? 1 : 0;
+            }
+            if (lane == r) {
+                r_C0 = C0;
+                r_ps0 = psprev;
+                r_c = c;
+            }
+            c = c_after;
+            if (r < D) {
+                c = c + wr;                                                // the real IEEE add
+                if (lane == r) r_dcs = c;
+                psprev = pe;
+            }
+        }
+        if (lane <= D) {
+            sg.seg_C0[lane] = r_C0;
+            sg.seg_ps0[lane] = r_ps0;
+            sg.seg_c[lane] = r_c;
+            if (lane < D) sg.d_cs[lane] = r_dcs;
+        }
+        if (lane == 0) {
+            sg.carry_out = c;
+            if (fail) sg.fail = 1;
+        }
+    }
+    __syncthreads();                                                                          // (4)
+    if (sg.fail) return false;                                             // uniform; the tile is untouched
+    {
+        int r = dbase;
+        u64 ps = pbase;
+        FK_UNROLL for (int q = 0; q < OP_ITEMS; ++q) {
+            const int j = tid * OP_ITEMS + q;
+            if (claims & (1u << q)) ps += inc_of(q);
+            double cs;
+            if (dirty & (1u << q)) {
+                cs = sg.d_cs[r];
+                ++r;
+            } else {
+                const int e = sg.seg_e[r];
+                cs = e == SEG_NONE ? sg.seg_c[r] : scale2(sg.seg_C0[r] + (double)(ps - sg.seg_ps0[r]), e);
+            }
+            if (j < len) sh.tile[pad8(j)] = cs;
+        }
+    }
+    __syncthreads();                                                                          // (5)
+    *c_out = sg.carry_out;
+    return true;
 }
 
 // Build-time instrumentation (tools/op_phase.py builds a separate library with -DFK_OP_CLOCKS; the shipped library

@@ -105,6 +105,6 @@ def ukf_c2():
 
 if __name__ == "__main__":
     c3(100_000, 30, "soa")
-    c3(16384, 30, "soa")
-    c3(16448, 30, "soa")
-    c3(32768, 30, "soa")
+    c3(100_000, 100, "aos")
+    c3(400_000, 20, "soa")
+
