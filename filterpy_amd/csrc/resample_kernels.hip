@@ -471,11 +471,18 @@ static int resample_common(bool stratified, int64_t Fn, int64_t Np, const double
     // dependent tiles whatever is done and stay with one workgroup per filter (resample_kernel above).
     // FK_RESAMPLE_PATH=onepass sends every length through the one-pass kernel, FK_RESAMPLE_SERIAL=1 none (tests).
     const char *path = getenv("FK_RESAMPLE_PATH");
-    const bool want_onepass = (path && !strcmp(path, "onepass")) || Np >= RS_PAR_MIN;
+    const bool want_onepass = (path && !strcmp(path, "onepass")) || (Np >= RS_PAR_MIN && !(path && !strcmp(path, "local")));
     if (want_onepass && ws && ws_bytes >= onepass_workspace_bytes(Fn, Np) && !getenv("FK_RESAMPLE_SERIAL")) {
         const int rc = onepass_launch(stratified, Fn, Np, w, u, idx, status, ws, ws_bytes, s);
         if (rc == FK_ERR_UNSUPPORTED) return fail(rc, "resample: too many chunks for one launch");
         if (rc != FK_OK && rc != FK_ERR_LAUNCH) return fail(rc, "resample: one-pass launch failed");
+        return rc;
+    }
+    // short vectors: one workgroup per filter, the carry local (resample_onepass.hip, resample_local_kernel);
+    // FK_RESAMPLE_PATH=local sends every length there, FK_RESAMPLE_SERIAL=1 keeps the tile-by-tile kernel below (tests)
+    if (!getenv("FK_RESAMPLE_SERIAL")) {
+        const int rc = local_launch(stratified, Fn, Np, w, u, idx, status, s);
+        if (rc == FK_ERR_UNSUPPORTED) return fail(rc, "resample: too many filters for one launch");
         return rc;
     }
     const dim3 grid((unsigned)Fn), block(RS_THREADS);

@@ -188,11 +188,14 @@ struct SegShared {
     u64 d_ps[SEG_DMAX];                   //   the increment prefix up to it,
     double d_cs[SEG_DMAX];                //   and (from the chain) the running sum after its real add
     int seg_e[SEG_DMAX + 1];              // segment r (the clean elements before dirty element r): claimed ulp exponent,
-    double seg_C0[SEG_DMAX + 1];          //   running sum at its start in ulps,
     u64 seg_ps0[SEG_DMAX + 1];            //   increment prefix at its start,
     double seg_c[SEG_DMAX + 1];           //   running sum at its start (what a segment of zeros keeps)
     double carry_out;
     int fail;
+#ifdef FK_OP_CLOCKS
+    long long dbg_t[5];                   // thread 0's clock after each barrier of segmented_cumsum (tools/op_phase.py)
+    int dbg_D;
+#endif
 };
 
 struct OpShared {
@@ -445,10 +448,10 @@ __device__ double general_cumsum(OpShared &sh, int len, double carry)
 //      bounds -- is DIRTY and will be added with a real IEEE add;
 //   2. one wrapping 64-bit prefix sum of the increments and one of the dirty flags: the dirty elements (a few dozen
 //      at most, else the scan declines) cut the chunk into segments of clean elements that share one binade;
-//   3. wave 0 walks the segments in order, O(1) per segment: the exact running sum entering a segment must have the
-//      claimed ulp and, with the segment's whole increment sum added, stay below 2^53 -- then every prefix inside did
-//      -- else the scan declines; a dirty element is one real add;
-//   4. every element reads its segment's start and scales its increment prefix: cs_j = (C0 + (PS_j - PS0)) 2^e.
+//   3. wave 0 walks the segments in order, two dependent adds per segment: the exact running sum entering a segment
+//      must have the claimed ulp and, with the segment's whole increment sum added, stay in that binade -- then every
+//      prefix inside did -- else the scan declines; a dirty element is one real add;
+//   4. every element reads its segment's start and adds its scaled increment prefix: cs_j = c_start + (PS_j - PS0) 2^e.
 // Declining (returns false; the tile still holds the weights) hands the chunk to general_cumsum.
 // In: weights in sh.tile (padded; slots >= len hold +0.0, no negative / NaN weight), exact carry-in.
 // Out: cumulative sums in sh.tile, *c_out = carry-out.
@@ -472,6 +475,9 @@ __device__ __forceinline__ bool segmented_cumsum(OpShared &sh, int len, double c
     const double winc = wave_incl_sum(run);
     if (lane == 63) sg.wtot[wave] = winc;
     __syncthreads();                                                                          // (1)
+#ifdef FK_OP_CLOCKS
+    if (tid == 0) sg.dbg_t[0] = clock64();
+#endif
     double excl = __shfl_up(winc, 1, 64);
     if (lane == 0) excl = 0.0;
     FK_UNROLL for (int wv = 0; wv < OP_THREADS / 64; ++wv)
@@ -511,6 +517,9 @@ __device__ __forceinline__ bool segmented_cumsum(OpShared &sh, int len, double c
         sg.ptot[wave] = pincl;
     }
     __syncthreads();                                                                          // (2)
+#ifdef FK_OP_CLOCKS
+    if (tid == 0) sg.dbg_t[1] = clock64();
+#endif
     int dbase = dincl - dl, D = 0;
     u64 pbase = pincl - psum, ptotal = 0;
     FK_UNROLL for (int wv = 0; wv < OP_THREADS / 64; ++wv) {
@@ -540,6 +549,9 @@ __device__ __forceinline__ bool segmented_cumsum(OpShared &sh, int len, double c
         }
     }
     __syncthreads();                                                                          // (3)
+#ifdef FK_OP_CLOCKS
+    if (tid == 0) { sg.dbg_t[2] = clock64(); sg.dbg_D = D; }
+#endif
     {
         int r = dbase, bad = 0;
         FK_UNROLL for (int q = 0; q < OP_ITEMS; ++q) {
@@ -549,54 +561,49 @@ __device__ __forceinline__ bool segmented_cumsum(OpShared &sh, int len, double c
         if (bad) sg.fail = 1;
     }
     // ---- the chain over the segments (wave 0; lane r holds segment r and dirty element r) -------------------------
+    // Everything that does not depend on the running sum is prepared by the lanes in parallel -- the segment's whole
+    // increment sum as a double in units of ONE (I 2^e: exact, a power-of-two scaling) and the exponent field its
+    // running sum must show -- so that the serial part is two dependent fp64 adds per segment:
+    //   c + I 2^e  is exact when C0 + I < 2^53 (the sum is representable), and when it is not the rounded result is
+    //   >= 2^(e+53), the next binade (rounding is monotone, the bound is representable): the exponent field of the
+    //   result tells; the exponent field of c before the add is the claim itself.
     if (wave == 0) {
         const u64 my_end = lane < D ? sg.d_ps[lane < SEG_DMAX ? lane : 0] : ptotal;
+        const u64 my_start = (lane >= 1 && lane <= D) ? sg.d_ps[lane - 1] : 0;
         const int my_e = lane <= D ? sg.seg_e[lane] : SEG_NONE;
         const double my_w = lane < D ? sg.d_w[lane < SEG_DMAX ? lane : 0] : 0.0;
-        double c = carry;
-        u64 psprev = 0;
-        int fail = 0;
-        double r_C0 = 0.0, r_c = 0.0, r_dcs = 0.0;
-        u64 r_ps0 = 0;
+        const u64 I = my_end - my_start;                                   // (wrapping; < 2^53 for a segment that passes)
+        const bool claim = my_e != SEG_NONE;
+        int fail = (lane <= D && ((claim && !(I < (1ull << 53))) || (!claim && I != 0))) ? 1 : 0;
+        const double my_add = claim ? scale2((double)I, my_e) : 0.0;      // I 2^e
+        const int my_xf = claim ? my_e + 1075 : -1;                        // biased exponent of a sum with ulp 2^e (-1: any)
+        double c = carry, r_c = 0.0, r_dcs = 0.0;
         for (int r = 0; r <= D; ++r) {                                     // uniform
-            const u64 pe = lane_bcast_u64(my_end, r);
-            const int e = __builtin_amdgcn_readlane(my_e, r);
+            const double add = lane_bcast(my_add, r);
             const double wr = lane_bcast(my_w, r);
-            const u64 I = pe - psprev;
-            double C0 = 0.0, c_after = c;
-            if (e != SEG_NONE) {
-                C0 = scale2(c, -e);
-                const double Cend = C0 + (double)I;
-                const bool ok = c > OP_SANE_LO && c < OP_SANE_HI && ulp_exp(c) == e && I < (1ull << 53) && Cend < 0x1p53;
-                fail |= ok ? 0 : 1;
-                c_after = scale2(Cend, e);
-            } else {
-                fail |= I != 0 ? 1 : 0;
-            }
-            if (lane == r) {
-                r_C0 = C0;
-                r_ps0 = psprev;
-                r_c = c;
-            }
-            c = c_after;
+            const int xf = __builtin_amdgcn_readlane(my_xf, r);
+            const int x0 = (int)((double_to_bits(c) >> 52) & 0x7ffu);
+            if (lane == r) r_c = c;
+            c = c + add;                                                   // exact, or out of the binade (see above)
+            const int x1 = (int)((double_to_bits(c) >> 52) & 0x7ffu);
+            fail |= (xf >= 0 && (x0 != xf || x1 != xf || xf <= 1075 - 900 || xf >= 1075 + 900 - 52)) ? 1 : 0;
             if (r < D) {
-                c = c + wr;                                                // the real IEEE add
+                c = c + wr;                                                // the real IEEE add of the dirty element
                 if (lane == r) r_dcs = c;
-                psprev = pe;
             }
         }
         if (lane <= D) {
-            sg.seg_C0[lane] = r_C0;
-            sg.seg_ps0[lane] = r_ps0;
             sg.seg_c[lane] = r_c;
+            sg.seg_ps0[lane] = my_start;
             if (lane < D) sg.d_cs[lane] = r_dcs;
         }
-        if (lane == 0) {
-            sg.carry_out = c;
-            if (fail) sg.fail = 1;
-        }
+        if (__builtin_amdgcn_ballot_w64(fail != 0) != 0 && lane == 0) sg.fail = 1;
+        if (lane == 0) sg.carry_out = c;
     }
     __syncthreads();                                                                          // (4)
+#ifdef FK_OP_CLOCKS
+    if (tid == 0) sg.dbg_t[3] = clock64();
+#endif
     if (sg.fail) return false;                                             // uniform; the tile is untouched
     {
         int r = dbase;
@@ -609,13 +616,17 @@ __device__ __forceinline__ bool segmented_cumsum(OpShared &sh, int len, double c
                 cs = sg.d_cs[r];
                 ++r;
             } else {
+                // (C0 + dPS) 2^e = c_start + dPS 2^e: exact for the same reason as in the chain
                 const int e = sg.seg_e[r];
-                cs = e == SEG_NONE ? sg.seg_c[r] : scale2(sg.seg_C0[r] + (double)(ps - sg.seg_ps0[r]), e);
+                cs = e == SEG_NONE ? sg.seg_c[r] : sg.seg_c[r] + scale2((double)(ps - sg.seg_ps0[r]), e);
             }
             if (j < len) sh.tile[pad8(j)] = cs;
         }
     }
     __syncthreads();                                                                          // (5)
+#ifdef FK_OP_CLOCKS
+    if (tid == 0) sg.dbg_t[4] = clock64();
+#endif
     *c_out = sg.carry_out;
     return true;
 }
@@ -1019,6 +1030,333 @@ resample_onepass_kernel(const OpArgs a)
     }
 }
 
+// ---- short vectors: one workgroup per filter, its chunks in sequence, the carry in a register ------------------------
+// (Np < RS_PAR_MIN.  No tickets, no look-back, no workspace: the exact carry-in of a chunk is the carry-out of the one
+// before, so its binade is KNOWN and most chunks take the integer-increment path straight away; the chunks that cross
+// a binade, the start of the vector and tie-holders take segmented_cumsum, and only what that declines the round-by-
+// round general_cumsum.  Before: one
+// workgroup per filter walking 2048-weight tiles with an int64 Mono scan per binade and one binary search per output
+// slot, 140 us for 1000 x 8000.)
+template <bool STRATIFIED>
+struct ChunkCtx {
+    long Np;
+    double Nd, halfNd, u_sys;
+    const double *u_str;
+};
+
+// slot boundaries of a chunk that stayed inside the binade of its carry-in: cs_j = (C0 + excl + E_j) 2^eu
+template <bool STRATIFIED>
+__device__ __forceinline__ void quick_boundaries(const double (&E)[OP_ITEMS], double excl, double c_in, int eu,
+                                                 const ChunkCtx<STRATIFIED> &cx, int (&nb)[OP_ITEMS])
+{
+    const double ulp = scale2(1.0, eu), C0 = scale2(c_in, -eu), Nu = scale2(cx.Nd, eu);
+    const double K = __builtin_fma(C0, Nu, STRATIFIED ? 0.0 : -cx.u_sys);
+    unsigned unsure = 0;
+    FK_UNROLL for (int q = 0; q < OP_ITEMS; ++q) {
+        const double Et = excl + E[q];                                     // exact
+        const double e = __builtin_fma(Et, Nu, K);
+        const double fl = floor(e), fr = e - fl;
+        bool sure = fr > N_BOUNDARY_EPS && fr < 1.0 - N_BOUNDARY_EPS && e < cx.Nd;
+        int n = (int)fl + 1;
+        if (STRATIFIED) {
+            const double uf = cx.u_str[e < cx.Nd ? (int)fl : 0];           // e >= 0 here
+            const double gap = uf - fr;
+            sure = sure && (gap > N_BOUNDARY_EPS || gap < -N_BOUNDARY_EPS);
+            n = (int)fl + (gap > 0.0 ? 0 : 1);
+        }
+        unsure |= sure ? 0u : (1u << q);
+        nb[q] = n;
+    }
+    if (unsure) {                                                          // about one weight in 10^5: the exact tests
+        _Pragma("nounroll") for (int q = 0; q < OP_ITEMS; ++q) {
+            if (!(unsure & (1u << q))) continue;
+            double Eq = E[0];
+            FK_UNROLL for (int r = 1; r < OP_ITEMS; ++r) Eq = (q == r) ? E[r] : Eq;
+            const int n = n_boundary<STRATIFIED>((C0 + (excl + Eq)) * ulp, (int)cx.Np, cx.Nd, cx.halfNd, cx.u_sys, cx.u_str);
+            FK_UNROLL for (int r = 0; r < OP_ITEMS; ++r) nb[r] = (q == r) ? n : nb[r];
+        }
+    }
+}
+
+// slot boundaries from the cumulative sums a scan left in the tile (slots >= len take the carry-out: no slots)
+template <bool STRATIFIED>
+__device__ __forceinline__ void tile_boundaries(OpShared &sh, int len, double c_out, const ChunkCtx<STRATIFIED> &cx, int tid,
+                                                int (&nb)[OP_ITEMS])
+{
+    int *nslot = reinterpret_cast<int *>(&sh.tile[pad8(tid * OP_ITEMS)]);
+    _Pragma("nounroll") for (int q = 0; q < OP_ITEMS; ++q) {
+        const int j = tid * OP_ITEMS + q;
+        const double c = j < len ? sh.tile[pad8(j)] : c_out;
+        nslot[2 * q] = n_boundary_fast<STRATIFIED>(c, (int)cx.Np, cx.Nd, cx.halfNd, cx.u_sys, cx.u_str);
+    }
+    FK_UNROLL for (int q = 0; q < OP_ITEMS; ++q) nb[q] = nslot[2 * q];
+}
+
+// heads -> windows -> coalesced stores (the emission of resample_onepass_kernel); returns the chunk's last boundary
+__device__ __forceinline__ int emit_slots(OpShared &sh, int *win, const int (&nb)[OP_ITEMS], int u_lo, long base,
+                                          int32_t *of, int tid, bool win_ready)
+{
+    const int lane = tid & 63, wave = tid >> 6;
+    sh.nlast[tid] = nb[OP_ITEMS - 1];
+    __syncthreads();
+    int nprev = tid == 0 ? u_lo : sh.nlast[tid - 1];
+    const int u_hi = __builtin_amdgcn_readfirstlane(sh.nlast[OP_THREADS - 1]);
+    int head[OP_ITEMS];
+    FK_UNROLL for (int q = 0; q < OP_ITEMS; ++q) {
+        head[q] = nb[q] > nprev ? nprev : -1;
+        nprev = nb[q] > nprev ? nb[q] : nprev;
+    }
+    const int mis = (int)(((uintptr_t)of >> 2) & 3);
+    int seed = -1;
+    for (int wb = u_lo - ((mis + u_lo) & 3); u_hi > u_lo && wb < u_hi; wb += OP_WIN) {        // uniform
+        if (!win_ready) {
+            __syncthreads();
+            init_window(win, tid);
+            __syncthreads();
+        }
+        win_ready = false;
+        int have = 0;
+        FK_UNROLL for (int q = 0; q < OP_ITEMS; ++q) {
+            const unsigned h = (unsigned)(head[q] - wb);
+            if (head[q] >= 0 && h < (unsigned)OP_WIN) {
+                win[h] = (int)base + tid * OP_ITEMS + q;
+                have = 1;
+            }
+        }
+        const int any_head = __syncthreads_or(have);
+        const int lim = u_hi - wb;
+        const int first = u_lo - wb;
+        int32_t *ow = of + wb;
+        const int s0 = 12 * tid;
+        int x[12];
+        if (any_head) {                                                    // uniform
+            FK_UNROLL for (int g = 0; g < 3; ++g) {
+                const i32x4 t = *reinterpret_cast<const i32x4 *>(&win[s0 + 4 * g]);
+                x[4 * g + 0] = t.x;
+                x[4 * g + 1] = t.y;
+                x[4 * g + 2] = t.z;
+                x[4 * g + 3] = t.w;
+            }
+            FK_UNROLL for (int e = 1; e < 12; ++e) x[e] = x[e] > x[e - 1] ? x[e] : x[e - 1];
+            const int wincl = wave_incl_max(x[11]);
+            if (lane == 63) sh.wmax[wave] = wincl;
+            __syncthreads();
+            const int up = __shfl_up(wincl, 1, 64);
+            int pre = (lane == 0 || up < seed) ? seed : up;
+            FK_UNROLL for (int wv = 0; wv < OP_THREADS / 64; ++wv) {
+                const int t = sh.wmax[wv];
+                if (wv < wave) pre = pre > t ? pre : t;
+                seed = seed > t ? seed : t;
+            }
+            FK_UNROLL for (int e = 0; e < 12; ++e) x[e] = x[e] > pre ? x[e] : pre;
+        } else {
+            FK_UNROLL for (int e = 0; e < 12; ++e) x[e] = seed;
+        }
+        if (s0 < lim) {
+            FK_UNROLL for (int g = 0; g < 3; ++g) {
+                const int s4 = s0 + 4 * g;
+                if (s4 >= first && s4 + 3 < lim) *reinterpret_cast<i32x4 *>(&ow[s4]) = i32x4{x[4 * g], x[4 * g + 1], x[4 * g + 2], x[4 * g + 3]};
+                else {
+                    FK_UNROLL for (int e = 0; e < 4; ++e)
+                        if (s4 + e >= first && s4 + e < lim) ow[s4 + e] = x[4 * g + e];
+                }
+            }
+        }
+    }
+    return u_hi;
+}
+
+__device__ __forceinline__ void load_chunk(double (&w8)[OP_ITEMS], const double *wf, long base, long Np, int tid)
+{
+    const int len = (int)((Np - base) < OP_TILE ? (Np - base) : OP_TILE);
+    const double *src = wf + base + tid * OP_ITEMS;
+    if (len == OP_TILE && (((uintptr_t)(wf + base)) & 15) == 0) {                              // uniform
+        FK_UNROLL for (int q = 0; q < OP_ITEMS; q += 2) {
+            const f64x2 t = *reinterpret_cast<const f64x2 *>(src + q);
+            w8[q] = t.x;
+            w8[q + 1] = t.y;
+        }
+    } else if (len == OP_TILE) {
+        FK_UNROLL for (int q = 0; q < OP_ITEMS; ++q) w8[q] = src[q];
+    } else {
+        FK_UNROLL for (int q = 0; q < OP_ITEMS; ++q) {
+            const int j = tid * OP_ITEMS + q;
+            const double t = wf[base + (j < len ? j : 0)];
+            w8[q] = j < len ? t : 0.0;
+        }
+    }
+}
+
+// the reference's merge loop, literally, by one thread (a filter holding a negative / NaN / huge weight)
+template <bool STRATIFIED>
+__device__ __forceinline__ int literal_merge(const double *wf, const double *u, long Np, int32_t *of)
+{
+    const double Nd = (double)Np;
+    long i = 0, j = 0;
+    double c = wf[0];
+    while (i < Np) {
+        const double ui = STRATIFIED ? u[i] : u[0];
+        const double p = (ui + (double)i) / Nd;
+        if (p < c) {
+            of[i] = (int32_t)j;
+            ++i;
+        } else {
+            ++j;
+            if (j == Np) break;
+            c = c + wf[j];
+        }
+    }
+    int st = 0;
+    for (; i < Np; ++i) {
+        of[i] = (int32_t)(Np - 1);
+        st = ST_OVERRUN;
+    }
+    return st;
+}
+
+// WAVES = workgroups per CU the registers are budgeted for.  Looped, the chunk body wants ~165 VGPRs: three per CU run
+// without a spill and are the faster ones while the chip is not full (125 x 8000: 39 vs 46 us); four per CU spill ~30
+// registers but hold 1024 filters at once -- one round instead of two for BASELINE configs[4]'s 1000 x 8000 (68 vs
+// 80 us; profiles/r02/resample_local_variants.log).  The launcher picks by the filter count.
+#ifndef FK_LOCAL_PREFETCH
+#define FK_LOCAL_PREFETCH 0    // 1: the next chunk's weights are requested before the current chunk is worked on (measured: no gain)
+#endif
+template <bool STRATIFIED, int WAVES>
+__global__ void __launch_bounds__(OP_THREADS, WAVES)
+resample_local_kernel(const OpArgs a)
+{
+    __shared__ OpShared sh;
+    const long Np = a.Np, nch = a.nch;
+    const int f = blockIdx.x;
+    const double *wf = a.w + (long)f * Np;
+    int32_t *of = a.idx + (long)f * Np;
+    ChunkCtx<STRATIFIED> cx;
+    cx.Np = Np;
+    cx.Nd = (double)Np;
+    cx.halfNd = 0.5 * cx.Nd;
+    cx.u_sys = STRATIFIED ? 0.0 : a.u[f];
+    cx.u_str = STRATIFIED ? a.u + (long)f * Np : nullptr;
+    int *win = sh.win();
+    double carry = 0.0;
+    int u_lo = 0;
+    bool bad = false;
+    OP_CLOCK_START();
+#if FK_LOCAL_PREFETCH
+    double wn[OP_ITEMS];
+    load_chunk(wn, wf, 0, Np, (int)threadIdx.x);
+#endif
+    for (long k = 0; k < nch; ++k) {                                       // uniform
+        // (the thread index is re-made opaque every round: otherwise everything derived from it -- a dozen offsets and
+        // masks -- is hoisted out of the loop and held in registers across it)
+        int tid_opaque = threadIdx.x;
+        asm volatile("" : "+v"(tid_opaque));
+        const int tid = tid_opaque, lane = tid & 63, wave = tid >> 6;
+        const long base = k * OP_TILE;
+        const int len = (int)((Np - base) < OP_TILE ? (Np - base) : OP_TILE);
+        double w8[OP_ITEMS];
+#if FK_LOCAL_PREFETCH
+        FK_UNROLL for (int q = 0; q < OP_ITEMS; ++q) w8[q] = wn[q];
+        if (k + 1 < nch) load_chunk(wn, wf, base + OP_TILE, Np, tid);
+#else
+        load_chunk(w8, wf, base, Np, tid);
+#endif
+
+        init_window(win, tid);
+        double s = 0.0, mn = 0.0;
+        FK_UNROLL for (int q = 0; q < OP_ITEMS; ++q) {
+            s += w8[q];
+            mn = w8[q] < mn ? w8[q] : mn;
+        }
+        s = lane_bcast(wave_incl_sum(s), 63);
+        if (lane == 0) sh.seg.wtot[wave] = s;
+        const int any_neg = __syncthreads_or(mn < 0.0 ? 1 : 0);
+        OP_CLOCK(1);                                                       // weights landed, chunk sum
+        const double S = (sh.seg.wtot[0] + sh.seg.wtot[1]) + (sh.seg.wtot[2] + sh.seg.wtot[3]);
+        if (any_neg || !(S < 0x1p1000)) {                                  // negative, NaN, Inf or absurdly large
+            bad = true;
+            break;
+        }
+        int nb[OP_ITEMS];
+        bool win_ready = true;
+        double c_out = carry;
+        if (carry == 0.0 && S == 0.0) {
+            // nothing but zeros so far (carry == 0 means exactly that: the weights are >= 0): no slots
+            FK_UNROLL for (int q = 0; q < OP_ITEMS; ++q) nb[q] = 0;
+        } else {
+            bool fast = false;
+            double E[OP_ITEMS], excl = 0.0, I = 0.0;
+            int eu = 0;
+            if (carry > OP_SANE_LO && carry < OP_SANE_HI) {                // uniform
+                eu = ulp_exp(carry);
+                bool tie = false;
+                double run = 0.0;
+                FK_UNROLL for (int q = 0; q < OP_ITEMS; ++q) {
+                    const double x = scale2(w8[q], -eu) + 0.5;
+                    const double i = floor(x);
+                    tie = tie || (i == x);
+                    run += i;
+                    E[q] = run;
+                }
+                const double winc = wave_incl_sum(run);
+                if (lane == 63) sh.wsum[wave] = winc;
+                const int any_tie = __syncthreads_or(tie ? 1 : 0);
+                excl = winc - run;
+                FK_UNROLL for (int wv = 0; wv < OP_THREADS / 64; ++wv) {
+                    if (wv < wave) excl += sh.wsum[wv];
+                    I += sh.wsum[wv];
+                }
+                fast = !any_tie && I < 0x1p53 && scale2(carry, -eu) + I < 0x1p53;
+            }
+            OP_CLOCK(3);                                                   // increments
+            if (fast) {                                                    // uniform
+                quick_boundaries<STRATIFIED>(E, excl, carry, eu, cx, nb);
+                c_out = scale2(scale2(carry, -eu) + I, eu);
+                OP_CLOCK(5);                                               // quick boundaries
+                OP_COUNT(9, 1);
+            } else {
+                __syncthreads();                                           // (the window shares the tile's LDS)
+                FK_UNROLL for (int q = 0; q < OP_ITEMS; ++q) sh.tile[pad8(tid * OP_ITEMS + q)] = w8[q];   // slots >= len: +0.0
+                __syncthreads();
+                if (!segmented_cumsum(sh, len, carry, &c_out)) {
+                    c_out = general_cumsum(sh, len, carry);
+                    OP_COUNT(10, 1);
+                }
+                OP_CLOCK(4);                                               // exact scan of the chunk
+#ifdef FK_OP_CLOCKS
+                if (tid == 0) {
+                    t_acc[12] += sh.seg.dbg_t[1] - sh.seg.dbg_t[0];        // classification + scans
+                    t_acc[13] += sh.seg.dbg_t[2] - sh.seg.dbg_t[1];        // lists
+                    t_acc[14] += sh.seg.dbg_t[3] - sh.seg.dbg_t[2];        // claims check + chain
+                    t_acc[15] += sh.seg.dbg_t[4] - sh.seg.dbg_t[3];        // cumulative sums into the tile
+                    t_acc[0] += sh.seg.dbg_D;                              // (slot 0 is unused here: dirty elements)
+                }
+#endif
+                tile_boundaries<STRATIFIED>(sh, len, c_out, cx, tid, nb);
+                win_ready = false;
+                OP_CLOCK(2);                                               // boundaries from the tile
+                OP_COUNT(8, 1);
+            }
+        }
+        u_lo = emit_slots(sh, win, nb, u_lo, base, of, tid, win_ready);
+        carry = c_out;
+        __syncthreads();                                                   // the LDS slots are free for the next chunk
+        OP_CLOCK(7);                                                       // emission
+        OP_COUNT(11, 1);
+    }
+    OP_CLOCK_FLUSH();
+    const int tid = threadIdx.x;
+    if (bad) {                                                             // uniform
+        if (tid == 0) {
+            const int st = literal_merge<STRATIFIED>(wf, STRATIFIED ? cx.u_str : a.u + f, Np, of);
+            if (a.status) a.status[f] = st;
+        }
+        return;
+    }
+    // ---- end of the vector: positions >= cumsum[-1] (the reference raises IndexError, resampling.py:109,145) --
+    for (long i = (long)u_lo + tid; i < Np; i += OP_THREADS) of[i] = (int32_t)(Np - 1);
+    if (tid == 0 && a.status) a.status[f] = u_lo < (int)Np ? ST_OVERRUN : 0;
+}
+
 // ---- filters the one-pass kernel declined (a negative / NaN / huge weight): the reference's loop, literally -----
 // cumulative_sum = np.cumsum(weights); i, j = 0, 0; while i < N: positions[i] < cumulative_sum[j] ? indexes[i] = j,
 // i += 1 : j += 1   (resampling.py:106-112 / 142-149; j == N is the IndexError).  One thread: such input is
@@ -1124,6 +1462,38 @@ int literal_fixup_launch(bool stratified, int64_t Fn, int64_t Np, const double *
     if (stratified) hipLaunchKernelGGL((resample_literal_kernel<true>), dim3((unsigned)Fn), dim3(64), 0, s, a);
     else hipLaunchKernelGGL((resample_literal_kernel<false>), dim3((unsigned)Fn), dim3(64), 0, s, a);
     return check_launch("resample_literal_kernel");
+}
+
+int local_launch(bool stratified, int64_t Fn, int64_t Np, const double *w, const double *u, int32_t *idx,
+                 int32_t *status, hipStream_t s)
+{
+    if (Fn > 0x7fffffffL) return FK_ERR_UNSUPPORTED;
+    OpArgs a = {};
+    a.Np = (long)Np;
+    a.nch = (long)((Np + OP_TILE - 1) / OP_TILE);
+    a.Fn = (int)Fn;
+    a.w = w;
+    a.u = u;
+    a.idx = idx;
+    a.status = status;
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+                   ? prop.multiProcessorCount : 256;
+    }
+    const char *ev = getenv("FK_LOCAL_WAVES");
+    const bool four = ev ? atoi(ev) == 4 : Fn > 3L * n_cu;                 // more filters than three per CU hold at once
+    const dim3 grid((unsigned)Fn), block(OP_THREADS);
+    if (stratified) {
+        if (four) hipLaunchKernelGGL((resample_local_kernel<true, 4>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((resample_local_kernel<true, 3>), grid, block, 0, s, a);
+    } else {
+        if (four) hipLaunchKernelGGL((resample_local_kernel<false, 4>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((resample_local_kernel<false, 3>), grid, block, 0, s, a);
+    }
+    return check_launch("resample_local_kernel");
 }
 
 size_t onepass_workspace_bytes(int64_t Fn, int64_t Np)

@@ -15,6 +15,11 @@ size_t onepass_workspace_bytes(int64_t Fn, int64_t Np);
 int onepass_launch(bool stratified, int64_t Fn, int64_t Np, const double *w, const double *u, int32_t *idx,
                    int32_t *status, void *ws, size_t ws_bytes, hipStream_t s);
 
+// short vectors (Np below the one-pass threshold): one workgroup per filter, chunks in sequence, no workspace; writes
+// status[f] itself (0 / ST_OVERRUN) and redoes garbage-weight filters with the reference's literal loop
+int local_launch(bool stratified, int64_t Fn, int64_t Np, const double *w, const double *u, int32_t *idx,
+                 int32_t *status, hipStream_t s);
+
 // after resample_kernel (short vectors): filters holding a negative / NaN / huge weight are redone by the reference's
 // merge loop, literally (one thread each)
 int literal_fixup_launch(bool stratified, int64_t Fn, int64_t Np, const double *w, const double *u, int32_t *idx,

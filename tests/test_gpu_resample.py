@@ -271,6 +271,24 @@ def test_short_vectors_with_garbage_weights_follow_the_reference_loop(monkeypatc
     _check_against_merge_loop(4, 8000, ("uniform", "negative", "nan", "sum_half"), range(4), monkeypatch, force=False)
 
 
+@pytest.mark.parametrize("Np", [1, 2, 7, 100, 2047, 2048, 2049, 8000, 8192, 20000, 32767])
+def test_local_kernel_every_route(Np, monkeypatch):
+    """default dispatch below the one-pass threshold = resample_local_kernel (one workgroup per filter, chunks in
+    sequence, segmented exact scan at the vector start / binade crossings, literal loop for garbage): every weight
+    family, every filter, against the reference's merge loop (C restatement), systematic and stratified."""
+    kinds = [k for k in _FAMILIES if not (k in ("negative", "nan") and Np < 8)]
+    _check_against_merge_loop(5, Np, kinds, range(5), monkeypatch, force=False)
+
+
+def test_local_kernel_on_a_long_vector_and_many_filters(monkeypatch):
+    """FK_RESAMPLE_PATH=local forces a long ragged vector through the same kernel (hundreds of chunks per workgroup, a
+    crossing every few); and the C5 shape's filter count in one launch (more workgroups than the chip holds at once)"""
+    monkeypatch.setenv("FK_RESAMPLE_PATH", "local")
+    _check_against_merge_loop(3, 300007, ("uniform", "heavy_tail", "zeros", "ties", "one_heavy"), range(3), monkeypatch, force=False)
+    monkeypatch.delenv("FK_RESAMPLE_PATH")
+    _check_against_merge_loop(1000, 8000, ("uniform", "heavy_tail"), (0, 1, 511, 767, 768, 999), monkeypatch, force=False)
+
+
 def test_c5_multi_filter_8e6_particles():
     """BASELINE configs[4] read as 8e6 particles PER filter: several such filters in one call (one GPU's share is
     125), indices bit-exact against the merge loop on the first, a middle and the last filter, plus the fused

@@ -69,9 +69,10 @@ class Lib:
         assert rc == 0, (self.name, rc)
 
 
-def run(shapes, time_shapes, iters):
+def run(shapes, time_shapes, iters, path):
     import torch
-    os.environ["FK_RESAMPLE_PATH"] = "onepass"
+    if path:
+        os.environ["FK_RESAMPLE_PATH"] = path
     libs = [Lib(p) for p in sorted(glob.glob(os.path.join(OUT, "librsv_*.so")))]
     base = [l for l in libs if l.name.startswith("base")] or libs[:1]
     libs = base + [l for l in libs if l not in base]
@@ -138,8 +139,9 @@ if __name__ == "__main__":
     ap.add_argument("--shapes", default="3x65536,64x8000,5x2049,16x8000000")
     ap.add_argument("--time-shapes", default="125x8000000,1000x8000")
     ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--path", default="onepass", help="FK_RESAMPLE_PATH for the run ('' = default dispatch)")
     a = ap.parse_args()
     if a.build is not None:
         build(a.build)
     if a.run:
-        sys.exit(run(a.shapes, a.time_shapes, a.iters))
+        sys.exit(run(a.shapes, a.time_shapes, a.iters, a.path))

@@ -15,7 +15,7 @@ import sys
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 CSRC = os.path.join(ROOT, "filterpy_amd", "csrc")
 LIB = os.path.join(CSRC, "exp_build", "libop_phase%s.so")
-PHASES = ["ticket", "load+stage", "stage1", "increments", "stage2", "general_scan", "boundaries", "emission"]
+PHASES = ["ticket", "load+stage", "stage1 | tile boundaries", "increments", "stage2 | exact scan", "general_scan | quick boundaries", "boundaries", "emission"]
 COUNTS = {8: "general", 9: "quick", 10: "zeros", 11: "workgroups"}
 
 
@@ -63,12 +63,15 @@ def run(shapes, iters, strat, tag):
         assert lib.fk_debug_op_phases(out) == 0
         v = [int(x) for x in out]
         nwg = float(v[11]) or 1.0
-        tot = float(sum(v[:8])) or 1.0
+        tot = float(sum(v[1:8])) or 1.0
         print(json.dumps({"tag": tag, "shape": shape, "stratified": strat, "ms_per_call": round(t0.elapsed_time(t1) / iters, 4),
                           "ticks_per_workgroup": {k: round(t / nwg, 1) for k, t in zip(PHASES, v[:8])},
                           "share": {k: round(t / tot, 3) for k, t in zip(PHASES, v[:8])},
                           "total_ticks_per_workgroup": round(tot / nwg, 1),
-                          "counts_per_call": {n: v[s] / iters for s, n in COUNTS.items()}}), flush=True)
+                          "counts_per_call": {n: v[s] / iters for s, n in COUNTS.items()},
+                          "segmented_scan_ticks_per_general_chunk": {n: round(v[s] / max(v[8], 1), 1) for s, n in
+                                                                     ((12, "classify+scans"), (13, "lists"), (14, "check+chain"), (15, "sums"))},
+                          "dirty_per_general_chunk": round(v[0] / max(v[8], 1), 2)}), flush=True)
 
 
 if __name__ == "__main__":
