@@ -279,13 +279,19 @@ kf_fast_kernel(const KfArgs a, const double *__restrict__ pF, const double *__re
         }
     }
 
-    store_rec<NX, 1, LAYOUT, true>(x, a.x, ln, NX, 1);
-    double Pl[NX * NX];
-    cov_full<NX, SYM, PLEN>(P, Pl);
-    store_rec<NX, NX, LAYOUT, true>(Pl, a.P, ln, NX, NX);
-    if (a.status) {
-        if (!all_finite<NX>(x) || !all_finite<PLEN>(P)) st |= ST_NONFINITE;
-        a.status[blk0 + ln.tid] = st;
+    // The final state goes back IN PLACE (a.x, a.P are inputs too), so only the owner of a track may write it: a tail
+    // lane that duplicates the last track and loaded its x0 / P0 late would otherwise find the final state there and
+    // filter it a second time.  These stores are outside the time loop: predication costs nothing here (the
+    // per-step output stores stay unpredicated -- they only ever rewrite the same values).
+    if (tid <= last_row) {
+        store_rec<NX, 1, LAYOUT, true>(x, a.x, ln, NX, 1);
+        double Pl[NX * NX];
+        cov_full<NX, SYM, PLEN>(P, Pl);
+        store_rec<NX, NX, LAYOUT, true>(Pl, a.P, ln, NX, NX);
+        if (a.status) {
+            if (!all_finite<NX>(x) || !all_finite<PLEN>(P)) st |= ST_NONFINITE;
+            a.status[blk0 + ln.tid] = st;
+        }
     }
 }
 

@@ -270,6 +270,7 @@ kf_ml_kernel(const KfArgs a)
     const unsigned Lc = L < 3u ? L : 2u;                       // lane 3 mirrors lane 2
     long trk = (long)blockIdx.x * (BLOCK / 4) + (threadIdx.x >> 2);
     const unsigned odd = (threadIdx.x >> 2) & 1u;              // odd quad of its pair (workgroups start on even tracks)
+    const bool owner = trk < N;                                // tail quads only duplicate: they never write the final state
     if (trk >= N) trk = PAIRS ? N - 2 + odd : N - 1;           // tail quads recompute the last track (pair)
     // element e of this lane's track sits at  lane offset + e * estride:  SOA: track*8 + e*N*8 ;
     // AOS: track*E*8 + e*8 (E = elements per record of the array: the offsets below are per array)
@@ -522,7 +523,9 @@ kf_ml_kernel(const KfArgs a)
         FK_UNROLL for (int r = 0; r < R; ++r)
             FK_UNROLL for (int c = 0; c < NX; ++c) vP.store(r * NX + c, P[r][c]);
     }
-    {
+    // (the final state goes back in place: only a track's own quad writes it -- a duplicating tail quad that loaded
+    // x0 / P0 late must not find the final state there; these stores are outside the time loop)
+    if (owner) {
         const MlView vx(a.x, t8, estride), vP(a.P, off_rows, estride);
         bool fin = all_finite<NX>(x);
         FK_UNROLL for (int k = 0; k < NX; ++k) vx.store(k, x[k]);
