@@ -193,13 +193,14 @@ def ukf_rts_correct(n, N, layout, Pxb, xb, Pb, xn, Pn, x, P, K=None, status=None
 
 
 def imm_batch(n, m, n_models, N, T, layout, F, Q, H, R, M, z, xs, Ps, mu, *, x_out=None, P_out=None,
-              mu_out=None, x_prior_out=None, P_prior_out=None, likelihood_out=None, status=None, phase=0, mmae=False):
-    """fk_imm_batch_f64: T x { IMMEstimator.predict(); IMMEstimator.update(z) } for N banks."""
+              mu_out=None, x_prior_out=None, P_prior_out=None, likelihood_out=None, status=None, phase=0, mmae=False,
+              zmask=None, ll0=None):
+    """fk_imm_batch_masked_f64: T x { IMMEstimator.predict(); IMMEstimator.update(z or None) } for N banks."""
     d = _abi.fk_imm_desc(n=n, m=m, n_models=n_models, layout=LAYOUTS[layout], N=N, T=T, phase=phase, flags=1 if mmae else 0)
-    rc = _abi.lib().fk_imm_batch_f64(d, _ptr(F), _ptr(Q), _ptr(H), _ptr(R), _ptr(M), _ptr(z), _ptr(xs), _ptr(Ps),
-                                     _ptr(mu), _ptr(x_out), _ptr(P_out), _ptr(mu_out), _ptr(x_prior_out),
-                                     _ptr(P_prior_out), _ptr(likelihood_out), _ptr(status), _stream())
-    _abi.check(rc, "fk_imm_batch_f64")
+    rc = _abi.lib().fk_imm_batch_masked_f64(d, _ptr(F), _ptr(Q), _ptr(H), _ptr(R), _ptr(M), _ptr(z), _ptr(zmask), _ptr(ll0),
+                                            _ptr(xs), _ptr(Ps), _ptr(mu), _ptr(x_out), _ptr(P_out), _ptr(mu_out),
+                                            _ptr(x_prior_out), _ptr(P_prior_out), _ptr(likelihood_out), _ptr(status), _stream())
+    _abi.check(rc, "fk_imm_batch_masked_f64")
 
 
 def resample_workspace_bytes(Fn, Np):

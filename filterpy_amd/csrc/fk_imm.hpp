@@ -113,8 +113,10 @@ FK_HD void imm_predict(double (&xs)[NM][NX], double (&Ps)[NM][NX * (NX + 1) / 2]
 template <int NX, int NZ, int NM, class Model>
 FK_HD int imm_update(double (&xs)[NM][NX], double (&Ps)[NM][NX * (NX + 1) / 2], double (&mu)[NM],
                      const double (&cbar)[NM], const double (&z)[NZ], int m, const Model (&mods)[NM],
-                     double (&L)[NM])
+                     double (&L)[NM], double *ll0 = nullptr)
 {
+    // ll0 (optional, NM entries): -(m ln 2 pi + ln |S_j|) / 2, the log-density of a ZERO residual under this update's
+    // S_j -- what a later update(None) turns into that filter's likelihood (kalman_filter.py:511-520, :1203-1226)
     int st = 0;
     const double log2pi_m = m * 1.8378770664093453;
     FK_UNROLL for (int j = 0; j < NM; ++j) {
@@ -140,6 +142,7 @@ FK_HD int imm_update(double (&xs)[NM][NX], double (&Ps)[NM][NX * (NX + 1) / 2], 
         double lj = exp(-0.5 * (log2pi_m + logdet + q));
         if (lj == 0.0) lj = 2.2250738585072014e-308;
         L[j] = lj;
+        if (ll0) ll0[j] = -0.5 * (log2pi_m + logdet);
         FK_STAGE();
     }
     double sum = 0.0;

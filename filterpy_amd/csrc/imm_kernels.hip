@@ -70,6 +70,16 @@ imm_kernel(const ImmArgs a)
     int st = 0;
     LM mods[NM];
     FK_UNROLL for (int j = 0; j < NM; ++j) mods[j].s = smem + j * LM::SIZE;
+    // missing measurements (general kernel only): the log-density of a zero residual under each filter's last S
+    constexpr bool MASKED = !(EXACT && OUTS >= 0);
+    double ll0[NM];
+    // before any update S = 0: the reference's density of y = 0 under it evaluates to 0 and is floored at DBL_MIN
+    // (kalman_filter.py:1221-1225; frozen in tests/golden/imm_missing.npz, first step)
+    FK_UNROLL for (int j = 0; j < NM; ++j) ll0[j] = -__builtin_inf();
+    if (MASKED && a.ll0) {
+        const RecView<LAYOUT> vl(a.ll0, ln, NM);
+        FK_UNROLL for (int j = 0; j < NM; ++j) ll0[j] = vl.load(j);
+    }
 
     for (long t = 0; t < a.T; ++t) {
         double z[NZ];
@@ -100,7 +110,24 @@ imm_kernel(const ImmArgs a)
         }
         if (a.phase == FK_IMM_PREDICT) break;
         double L[NM];
-        st |= imm_update<NX, NZ, NM>(xs, Ps, mu, cbar, z, m, mods, L);
+        bool has_z = true;
+        if (MASKED && a.mask) has_z = a.mask[t * N + ln.blk0 + ln.tid] != 0;
+        if (has_z) {
+            st |= imm_update<NX, NZ, NM>(xs, Ps, mu, cbar, z, m, mods, L, MASKED ? ll0 : nullptr);
+        } else {
+            // IMMEstimator.update(None) / MMAEFilterBank.update(None): the filters keep x, P; each likelihood is the
+            // density of a zero residual under the S of that filter's last real update (IMM.py:171-179 reads
+            // f.likelihood after f.update(None): kalman_filter.py:511-520 set y = 0 and cleared the cache)
+            double sum = 0.0;
+            FK_UNROLL for (int j = 0; j < NM; ++j) {
+                double lj = exp(ll0[j]);
+                if (lj == 0.0) lj = 2.2250738585072014e-308;
+                L[j] = lj;
+                mu[j] = cbar[j] * lj;
+                sum += mu[j];
+            }
+            FK_UNROLL for (int j = 0; j < NM; ++j) mu[j] /= sum;
+        }
         if (OUTS < 0 ? (a.x_out || a.P_out) : (OUTS & 1) != 0) {
             double x[NX], P[NX * NX];
             if (mmae) mmae_estimate<NX, NM>(xs, Ps, mu, n, x, P);
@@ -128,6 +155,10 @@ imm_kernel(const ImmArgs a)
                 FK_UNROLL for (int c = 0; c < NX; ++c)
                     if (r < n && c < n) vP.store((j * n + r) * n + c, Ps[j][sym_idx<NX>(r, c)]);
             }
+        }
+        if (MASKED && a.ll0) {
+            const RecView<LAYOUT> vl(a.ll0, ln, NM);
+            FK_UNROLL for (int j = 0; j < NM; ++j) vl.store(j, ll0[j]);
         }
         if (a.status) a.status[ln.blk0 + ln.tid] = st | (fin ? 0 : ST_NONFINITE);
     }

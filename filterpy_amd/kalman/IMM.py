@@ -28,6 +28,22 @@ __all__ = ["IMMEstimator"]
 _PHASE_STEP, _PHASE_PREDICT, _PHASE_UPDATE = 0, 1, 2
 
 
+def _split_missing(zs, nt, m):
+    """zs: array (T, [nt,] m) or a list whose entries may be None (a missing measurement for the whole bank, like
+    the reference's update(None)) -> (array (T, nt, m) with zeros at the gaps, present (T, nt) or None)."""
+    if isinstance(zs, np.ndarray) and zs.dtype != object:
+        return np.asarray(zs, dtype=np.float64), None
+    T = len(zs)
+    out = np.zeros((T, nt, m))
+    present = np.ones((T, nt), dtype=bool)
+    for t, z in enumerate(zs):
+        if z is None:
+            present[t] = False
+        else:
+            out[t] = np.asarray(z, dtype=np.float64).reshape(nt, m)
+    return out, (None if present.all() else present)
+
+
 class IMMEstimator(object):
     def __init__(self, filters, mu, M, n_tracks=None, layout="soa"):
         if len(filters) < 2:
@@ -69,6 +85,10 @@ class IMMEstimator(object):
         if n > 6 or m > 3:
             raise NotImplementedError("the IMM kernel is built for dim_x <= 6 and dim_z <= 3")
 
+        # log-density of a zero residual under each filter's last real update's S (-inf before any: with S = 0 the
+        # reference's density is 0, floored at float_info.min) -- what update(None) turns into the filter's likelihood;
+        # kept across launches
+        self._ll0 = np.full((nt, self.N), -np.inf)
         # bank state on the host, (nt, n_models, ...)
         self._xs = np.stack([np.broadcast_to(np.asarray(f.x, dtype=np.float64).reshape(-1, n), (nt, n))
                              for f in filters], axis=1).copy()
@@ -132,7 +152,19 @@ class IMMEstimator(object):
             else:
                 f.x, f.P = self._xs[:, j].copy(), self._Ps[:, j].copy()
 
-    def _launch(self, phase, zs, T, want_prior, want_post, mmae=False, R=None, H=None):
+    def _launch(self, phase, zs, T, want_prior, want_post, mmae=False, R=None, H=None, present=None):
+        """One launch (`present`: (T, nt) booleans, False = that measurement is None; None = all there).  A long run
+        without missing measurements goes through the fast instantiations except for its LAST step, which the
+        general kernel runs so that the zero-residual log-densities (self._ll0) stay current for a later update(None)."""
+        nt, nm = self._nt or 1, self.N
+        if phase == _PHASE_STEP and present is None and not mmae and T >= 2:
+            zs = np.ascontiguousarray(zs, dtype=np.float64).reshape(T, nt, self._m)
+            a = self._launch1(phase, zs[:-1], T - 1, want_prior, want_post, mmae, R, H, None, track_ll0=False)
+            b = self._launch1(phase, zs[-1:], 1, want_prior, want_post, mmae, R, H, None, track_ll0=True)
+            return {k: np.concatenate([a[k], b[k]], axis=0) for k in a}
+        return self._launch1(phase, zs, T, want_prior, want_post, mmae, R, H, present, track_ll0=phase != _PHASE_PREDICT)
+
+    def _launch1(self, phase, zs, T, want_prior, want_post, mmae, R, H, present, track_ll0):
         nt, n, m, nm, lay = self._nt or 1, self._n, self._m, self.N, self._layout
         self._pull_from_filters()
         F, Q, H, R, M = self._models(R, H)
@@ -147,8 +179,14 @@ class IMMEstimator(object):
         if want_prior:
             out.update(x_prior_out=E.alloc_records((T,), nt, n, lay), P_prior_out=E.alloc_records((T,), nt, n * n, lay))
         status = torch.zeros(nt, dtype=torch.int32, device=xs.device)
-        E.imm_batch(n, m, nm, nt, T, lay, F, Q, H, R, M, z, xs, Ps, mu, status=status, phase=phase, mmae=mmae, **out)
+        zmask = None if present is None else torch.as_tensor(np.ascontiguousarray(present, dtype=np.uint8).reshape(T, nt),
+                                                              device=xs.device)
+        ll0 = E.to_records(self._ll0.reshape(nt, nm), lay, 0) if track_ll0 else None
+        E.imm_batch(n, m, nm, nt, T, lay, F, Q, H, R, M, z, xs, Ps, mu, status=status, phase=phase, mmae=mmae,
+                    zmask=zmask, ll0=ll0, **out)
         E.raise_on_status(status, "IMMEstimator")
+        if ll0 is not None:
+            self._ll0 = E.from_records(ll0, lay, 0, (nm,)).copy()
         self._xs = E.from_records(xs, lay, 0, (nm, n)).copy()
         self._Ps = E.from_records(Ps, lay, 0, (nm, n, n)).copy()
         mu_h = E.from_records(mu, lay, 0, (nm,)).copy()
@@ -168,9 +206,13 @@ class IMMEstimator(object):
 
     def update(self, z):
         """IMM.py:160-186: every filter's update, likelihoods, mode probabilities, posterior estimate."""
+        nt = self._nt or 1
         if z is None:
-            raise NotImplementedError("missing measurements are not supported by the IMM kernel")
-        o = self._launch(_PHASE_UPDATE, np.asarray(z, dtype=np.float64), 1, False, True)
+            # every filter's update(None) keeps x, P; the likelihoods are those of a zero residual under each filter's
+            # last S, and the mode probabilities are re-weighted with them (IMM.py:171-186 as the reference runs it)
+            o = self._launch(_PHASE_UPDATE, np.zeros((1, nt, self._m)), 1, False, True, present=np.zeros((1, nt), dtype=bool))
+        else:
+            o = self._launch(_PHASE_UPDATE, np.asarray(z, dtype=np.float64), 1, False, True)
         L = o["likelihood_out"][0]
         self.likelihood = L if self._nt is not None else L[0]
         self._compute_mixing_probabilities()
@@ -184,11 +226,11 @@ class IMMEstimator(object):
         and the mode probabilities after every update, shaped (T, ...) like ``x``, ``P``, ``mu``;
         with ``return_priors`` also the estimates after every predict.  The object ends in the
         state the reference reaches after the same sequence of calls."""
-        zs = np.asarray(zs, dtype=np.float64)
+        zs, present = _split_missing(zs, self._nt or 1, self._m)
         T = zs.shape[0]
         if T == 0:
             raise ValueError("zs is empty")
-        o = self._launch(_PHASE_STEP, zs, T, True, True)
+        o = self._launch(_PHASE_STEP, zs, T, True, True, present=present)
         L = o["likelihood_out"][-1]
         self.likelihood = L if self._nt is not None else L[0]
         self._compute_mixing_probabilities()

@@ -39,10 +39,10 @@ class MMAEFilterBank(object):
         self.x_prior, self.P_prior = self.x.copy(), self.P.copy()
         self.x_post, self.P_post = self.x.copy(), self.P.copy()
 
-    def _run(self, phase, zs, T, want_post, R=None, H=None):
+    def _run(self, phase, zs, T, want_post, R=None, H=None, present=None):
         e = self._eng
         e.mu = self.p
-        o = e._launch(phase, zs, T, False, want_post, mmae=True, R=R, H=H)
+        o = e._launch(phase, zs, T, False, want_post, mmae=True, R=R, H=H, present=present)
         self.p = e.mu
         return o
 
@@ -55,11 +55,15 @@ class MMAEFilterBank(object):
 
     def update(self, z, R=None, H=None):
         """mmae.py:160-212."""
-        if z is None:
-            raise NotImplementedError("missing measurements are not supported by the IMM/MMAE kernel")
         if H is None:
             H = self.H
-        o = self._run(2, np.asarray(z, dtype=np.float64), 1, True, R=R, H=H)
+        if z is None:
+            # mmae.py:184-187 with z = None: the filters keep x, P, p_i *= the density of a zero residual under
+            # filter i's last S (kalman_filter.py:511-520, :1203-1226)
+            nt = self._eng._nt or 1
+            o = self._run(2, np.zeros((1, nt, self._eng._m)), 1, True, R=R, H=H, present=np.zeros((1, nt), dtype=bool))
+        else:
+            o = self._run(2, np.asarray(z, dtype=np.float64), 1, True, R=R, H=H)
         e = self._eng
         e._set_estimate(o["x_out"][0], o["P_out"][0])
         self.x, self.P = e.x, e.P
@@ -69,11 +73,13 @@ class MMAEFilterBank(object):
     def batch_filter(self, zs):
         """T x { predict(); update(zs[t]) } in one launch (no reference counterpart).  Returns
         (xs, Ps, ps): estimate and model probabilities after every update."""
-        zs = np.asarray(zs, dtype=np.float64)
+        from .IMM import _split_missing
+        last_z = zs[-1] if len(zs) else None
+        zs, present = _split_missing(zs, self._eng._nt or 1, self._eng._m)
         T = zs.shape[0]
         if T == 0:
             raise ValueError("zs is empty")
-        o = self._run(0, zs, T, True, H=self.H)
+        o = self._run(0, zs, T, True, H=self.H, present=present)
         e = self._eng
         if T > 1:
             e._set_estimate(o["x_out"][-2], o["P_out"][-2])
@@ -82,7 +88,7 @@ class MMAEFilterBank(object):
             self.x_prior, self.P_prior = self.x.copy(), self.P.copy()
         e._set_estimate(o["x_out"][-1], o["P_out"][-1])
         self.x, self.P = e.x, e.P
-        self.z = deepcopy(zs[-1])
+        self.z = deepcopy(last_z)
         self.x_post, self.P_post = self.x.copy(), self.P.copy()
         if e._nt is not None:
             return o["x_out"], o["P_out"], o["mu_out"]

@@ -325,6 +325,23 @@ enum { FK_IMM_FLAG_MMAE = 1 };
  * the covariance exactly as mmae.py:205-207 computes it (the loop zips the COMPONENTS of x with the
  * filters: P = sum over k < min(dim_x, n_models) of p_k (outer(x_k - x[k]) + P_k), reproduced as is).
  * The prior outputs are not defined for MMAE (the reference's x_prior is a copy of the last x). */
+/* fk_imm_batch_f64 with MISSING measurements (IMMEstimator.update(None) / MMAEFilterBank.update(None): IMM.py:171-186,
+ * mmae.py:160-212 on top of kalman_filter.py:511-520, :1203-1226).
+ *   zmask [T][N] (t-major), 0 = the measurement of that track and step is None: the filters keep x and P, the
+ *         likelihood of each is the density of a ZERO residual under the S of ITS last real update, and the mode
+ *         probabilities are re-weighted with those numbers, mixed and re-estimated -- like the reference; NULL = none.
+ *   ll0   [N][n_models] in/out record, or NULL: -(m ln 2 pi + ln |S_j|) / 2 of each filter's last real update,
+ *         -inf for a filter that has not seen one (S = 0: the reference's density evaluates to 0 and is floored at
+ *         DBL_MIN like every likelihood).  Keeps the bookkeeping across launches (the call-by-call API); NULL starts
+ *         every filter at -inf and drops the result. */
+int fk_imm_batch_masked_f64(const fk_imm_desc *desc,
+                            const double *F, const double *Q, const double *H, const double *R, const double *M,
+                            const double *z, const uint8_t *zmask, double *ll0,
+                            double *xs, double *Ps, double *mu,
+                            double *x_out, double *P_out, double *mu_out,
+                            double *x_prior_out, double *P_prior_out, double *likelihood_out,
+                            int32_t *status, void *stream);
+
 int fk_imm_batch_f64(const fk_imm_desc *desc,
                      const double *F, const double *Q, const double *H, const double *R,
                      const double *M, const double *z,

@@ -51,6 +51,8 @@ def imm_batch(xs0, Ps0, mu0, Mtrans, zs, Fs, Qs, Hs, Rs):
     n = xs[0].shape[0]
     out_x, out_P, out_mu = np.zeros((T, n)), np.zeros((T, n, n)), np.zeros((T, nm))
     out_xp, out_Pp, out_L = np.zeros((T, n)), np.zeros((T, n, n)), np.zeros((T, nm))
+    m = np.asarray(Hs[0]).shape[0]
+    S_last = [np.zeros((m, m)) for _ in range(nm)]      # KalmanFilter.S before any update (kalman_filter.py:423): density 0 -> floored
     for t in range(T):
         # predict (IMM.py:200-222): mixed initial conditions, then each filter's own predict
         mx, mP = [], []
@@ -71,7 +73,13 @@ def imm_batch(xs0, Ps0, mu0, Mtrans, zs, Fs, Qs, Hs, Rs):
         # update (IMM.py:171-186)
         L = np.zeros(nm)
         for j in range(nm):
-            xs[j], Ps[j], y, K, S, SI = kf_oracle.kf_update(xs[j], Ps[j], zs[t], Rs[j], Hs[j])
+            if zs[t] is None:
+                # update(None) (kalman_filter.py:511-520): x, P untouched, y = 0, the cached likelihood cleared -- it is
+                # then re-evaluated for the zero residual under the S of the last real update (:1203-1226)
+                y, S = np.zeros(m), S_last[j]
+            else:
+                xs[j], Ps[j], y, K, S, SI = kf_oracle.kf_update(xs[j], Ps[j], zs[t], Rs[j], Hs[j])
+                S_last[j] = S
             L[j] = np.exp(kf_oracle.log_likelihood(y, S))
             if L[j] == 0:
                 L[j] = sys.float_info.min          # kalman_filter.py:1221-1225
@@ -95,12 +103,18 @@ def mmae_batch(xs0, Ps0, p0, zs, Fs, Qs, Hs, Rs):
     p = np.array(p0, dtype=float)
     T, n = len(zs), xs[0].shape[0]
     out_x, out_P, out_p, out_L = np.zeros((T, n)), np.zeros((T, n, n)), np.zeros((T, nm)), np.zeros((T, nm))
+    m = np.asarray(Hs[0]).shape[0]
+    S_last = [np.zeros((m, m)) for _ in range(nm)]
     for t in range(T):
         for j in range(nm):
             xs[j], Ps[j] = kf_oracle.kf_predict(xs[j], Ps[j], Fs[j], Qs[j])
         L = np.zeros(nm)
         for j in range(nm):
-            xs[j], Ps[j], y, K, S, SI = kf_oracle.kf_update(xs[j], Ps[j], zs[t], Rs[j], Hs[j])
+            if zs[t] is None:          # as in imm_batch: zero residual under the last real update's S
+                y, S = np.zeros(m), S_last[j]
+            else:
+                xs[j], Ps[j], y, K, S, SI = kf_oracle.kf_update(xs[j], Ps[j], zs[t], Rs[j], Hs[j])
+                S_last[j] = S
             L[j] = np.exp(kf_oracle.log_likelihood(y, S))
             if L[j] == 0:
                 L[j] = sys.float_info.min

@@ -169,8 +169,6 @@ def test_imm_rejects_what_the_kernel_cannot_do():
     with pytest.raises(NotImplementedError):
         imm.predict(u=np.zeros(1))
     with pytest.raises(NotImplementedError):
-        imm.update(None)
-    with pytest.raises(NotImplementedError):
         IMMEstimator([KalmanFilter(dim_x=2, dim_z=1) for _ in range(4)], [1, 1, 1, 1], np.full((4, 4), 0.25))
 
 
@@ -262,3 +260,80 @@ def test_mmae_update_overrides_and_bank():
     xs, Ps, ps = bank.batch_filter(tile_tracks(g[p + "zs"], N, axis=1))
     assert xs.shape == (30, N, n) and ps.shape == (30, N, nm)
     assert rel_err_rows(xs[:, N - 1], g[p + "x"]) < TOL and rel_err_rows(Ps[:, 3], g[p + "P"]) < TOL
+
+
+def _missing_bank(kind, p, g, nm, n, m, n_tracks, layout):
+    from filterpy_amd.kalman import IMMEstimator, KalmanFilter, MMAEFilterBank
+    fs = []
+    for j in range(nm):
+        f = KalmanFilter(dim_x=n, dim_z=m)
+        f.x = g[p + "xs0"][j].copy() if n_tracks is None else np.tile(g[p + "xs0"][j], (n_tracks, 1))
+        f.P = g[p + "Ps0"][j].copy() if n_tracks is None else np.tile(g[p + "Ps0"][j], (n_tracks, 1, 1))
+        f.F, f.Q, f.H, f.R = g[p + "Fs"][j].copy(), g[p + "Qs"][j].copy(), g[p + "H"].copy(), g[p + "Rs"][j].copy()
+        fs.append(f)
+    kw = {} if n_tracks is None else dict(n_tracks=n_tracks, layout=layout)
+    if kind == "imm":
+        return IMMEstimator(fs, g[p + "mu0"], g[p + "M"], **kw)
+    return MMAEFilterBank(fs, list(g[p + "mu0"] / g[p + "mu0"].sum()), dim_x=n, H=g[p + "H"], **kw)
+
+
+@pytest.mark.parametrize("kind", ["imm", "mmae"])
+def test_missing_measurements_call_by_call(kind):
+    """predict(); update(z or None) like the reference's loop: update(None) keeps the filters' x, P and re-weights the
+    modes with the density of a zero residual under each filter's last S (goldens: live reference,
+    tests/golden/make_imm_missing_golden.py; the first measurement is missing too)."""
+    g = golden("imm_missing")
+    miss = set(int(t) for t in g["missing"])
+    for n, m, nm in g["cases"]:
+        n, m, nm = int(n), int(m), int(nm)
+        p = f"n{n}m{m}k{nm}_"
+        q = p + kind + "_"
+        est = _missing_bank(kind, p, g, nm, n, m, None, "soa")
+        for t, z in enumerate(g[p + "zs"]):
+            est.predict()
+            est.update(None if t in miss else z)
+            mu = est.mu if kind == "imm" else est.p
+            assert rel_err_rows(np.asarray(est.x, dtype=float).reshape(1, n), g[q + "x"][t][None]) < TOL, (kind, n, m, nm, t)
+            assert rel_err_rows(np.asarray(est.P, dtype=float)[None], g[q + "P"][t][None]) < TOL, (kind, n, m, nm, t)
+            assert np.allclose(mu, g[q + "mu"][t], rtol=1e-10, atol=1e-14), (kind, n, m, nm, t)
+            if kind == "imm":
+                assert np.allclose(est.likelihood, g[q + "L"][t], rtol=1e-10, atol=1e-300), (n, m, nm, t)
+        for j in range(nm):
+            assert rel_err_rows(np.asarray(est.filters[j].x, dtype=float).reshape(1, n), g[q + "xs_final"][j].reshape(1, n)) < TOL
+            assert rel_err_rows(np.asarray(est.filters[j].P, dtype=float)[None], g[q + "Ps_final"][j][None]) < TOL
+
+
+@pytest.mark.parametrize("layout", ["soa", "aos"])
+@pytest.mark.parametrize("kind", ["imm", "mmae"])
+def test_missing_measurements_one_launch_bank(kind, layout):
+    """the same sequences as ONE launch over a bank (batch_filter with None entries -> zmask), and a run without gaps
+    followed by update(None): the zero-residual densities must have been kept current by the gap-free run"""
+    g = golden("imm_missing")
+    miss = set(int(t) for t in g["missing"])
+    N = 70
+    for n, m, nm in g["cases"]:
+        n, m, nm = int(n), int(m), int(nm)
+        p = f"n{n}m{m}k{nm}_"
+        q = p + kind + "_"
+        est = _missing_bank(kind, p, g, nm, n, m, N, layout)
+        zl = [None if t in miss else np.tile(z, (N, 1)) for t, z in enumerate(g[p + "zs"])]
+        xs, Ps, mus = est.batch_filter(zl)
+        for trk in (0, 63, 64, N - 1):
+            assert rel_err_rows(xs[:, trk], g[q + "x"]) < TOL and rel_err_rows(Ps[:, trk], g[q + "P"]) < TOL, (kind, n, m, nm)
+            assert np.allclose(mus[:, trk], g[q + "mu"], rtol=1e-10, atol=1e-14)
+    # gap-free batch, then a gap: equals the call-by-call sequence
+    n, m, nm = (int(v) for v in g["cases"][1])
+    p = f"n{n}m{m}k{nm}_"
+    a = _missing_bank(kind, p, g, nm, n, m, N, layout)
+    b = _missing_bank(kind, p, g, nm, n, m, N, layout)
+    zs = np.tile(g[p + "zs"][:6, None, :], (1, N, 1))
+    a.batch_filter(zs)
+    a.predict()
+    a.update(None)
+    for z in zs:
+        b.predict()
+        b.update(z)
+    b.predict()
+    b.update(None)
+    ma, mb = (a.mu, b.mu) if kind == "imm" else (a.p, b.p)
+    assert np.allclose(ma, mb, rtol=1e-10, atol=1e-14) and rel_err_rows(np.asarray(a.x), np.asarray(b.x)) < TOL

@@ -27,3 +27,25 @@ def test_mmae_vs_golden(n, m, nm):
     assert rel_err_rows(x, g[p + "x"]) < 1e-12 and rel_err_rows(P, g[p + "P"]) < 1e-12
     assert np.allclose(pr, g[p + "p"], rtol=1e-11, atol=1e-15)
     assert np.allclose(L, g[p + "L"], rtol=1e-11, atol=1e-300)
+
+
+@pytest.mark.parametrize("kind", ["imm", "mmae"])
+def test_missing_measurements_vs_live_reference(kind):
+    """update(None): the filters keep x, P; their likelihood is the density of a zero residual under the S of their last
+    real update (1 before any) and the mode probabilities are re-weighted with it (tests/golden/make_imm_missing_golden.py)."""
+    g = golden("imm_missing")
+    miss = set(int(t) for t in g["missing"])
+    for n, m, nm in g["cases"]:
+        p = f"n{n}m{m}k{nm}_"
+        zs = [None if t in miss else z for t, z in enumerate(g[p + "zs"])]
+        Hs = [g[p + "H"]] * int(nm)
+        q = p + kind + "_"
+        if kind == "imm":
+            x, P, mu, xp, Pp, L = imm_oracle.imm_batch(g[p + "xs0"], g[p + "Ps0"], g[p + "mu0"], g[p + "M"], zs,
+                                                      g[p + "Fs"], g[p + "Qs"], Hs, g[p + "Rs"])
+            assert np.allclose(L, g[q + "L"], rtol=1e-10, atol=1e-300)
+        else:
+            mu0 = g[p + "mu0"] / g[p + "mu0"].sum()
+            x, P, mu, L = imm_oracle.mmae_batch(g[p + "xs0"], g[p + "Ps0"], mu0, zs, g[p + "Fs"], g[p + "Qs"], Hs, g[p + "Rs"])
+        assert np.allclose(x, g[q + "x"], rtol=1e-11, atol=1e-12) and np.allclose(P, g[q + "P"], rtol=1e-11, atol=1e-12)
+        assert np.allclose(mu, g[q + "mu"], rtol=1e-11, atol=1e-13)
