@@ -67,7 +67,7 @@ SIGNATURES = {
     "fk_kf_update_correlated_f64": (ctypes.c_int, [ctypes.POINTER(fk_kf_desc)] + [c_vp] * 13),
     "fk_ukf_rts_correct_f64": (ctypes.c_int, [c_i32, c_i64, c_i32] + [c_vp] * 10),
     "fk_imm_batch_f64": (ctypes.c_int, [ctypes.POINTER(fk_imm_desc)] + [c_vp] * 17),
-    "fk_imm_batch_masked_f64": (ctypes.c_int, [ctypes.POINTER(fk_imm_desc)] + [c_vp] * 19),
+    "fk_imm_batch_ex_f64": (ctypes.c_int, [ctypes.POINTER(fk_imm_desc)] + [c_vp] * 8 + [ctypes.c_int32] + [c_vp] * 13),
     "fk_resample_systematic_f64": (ctypes.c_int, [c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "fk_resample_stratified_f64": (ctypes.c_int, [c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "fk_resample_multinomial_f64": (ctypes.c_int, [c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),

@@ -51,7 +51,8 @@ def to_records(a, layout, lead):
         return t
     shp = t.shape
     N = shp[lead]
-    t = t.reshape(*shp[:lead], N, -1)
+    rec = int(np.prod(shp[lead + 1:])) if len(shp) > lead + 1 else 1      # (explicit: -1 is ambiguous for N = 0)
+    t = t.reshape(*shp[:lead], N, rec)
     return t.transpose(-1, -2).contiguous()
 
 
@@ -59,10 +60,11 @@ def from_records(t, layout, lead, rec_shape):
     """Device tensor in `layout` -> host NumPy array lead + (N,) + rec_shape (zero-copy view of
     the downloaded buffer for 'soa': a transposed view, as the API docs describe)."""
     h = t.cpu().numpy()
+    rec = int(np.prod(rec_shape)) if rec_shape else 1                      # (explicit sizes: -1 is ambiguous for empty banks)
     if layout == "aos":
-        return h.reshape(*h.shape[:lead], -1, *rec_shape) if rec_shape else h
+        return h.reshape(*h.shape[:lead + 1], *rec_shape) if rec_shape else h
     # [lead][E][N] -> [lead][N][E]
-    h = np.swapaxes(h.reshape(*h.shape[:lead], -1, h.shape[-1]), -1, -2)
+    h = np.swapaxes(h.reshape(*h.shape[:lead], rec, h.shape[-1]), -1, -2)
     return h.reshape(*h.shape[:lead + 1], *rec_shape)
 
 
@@ -194,13 +196,14 @@ def ukf_rts_correct(n, N, layout, Pxb, xb, Pb, xn, Pn, x, P, K=None, status=None
 
 def imm_batch(n, m, n_models, N, T, layout, F, Q, H, R, M, z, xs, Ps, mu, *, x_out=None, P_out=None,
               mu_out=None, x_prior_out=None, P_prior_out=None, likelihood_out=None, status=None, phase=0, mmae=False,
-              zmask=None, ll0=None):
-    """fk_imm_batch_masked_f64: T x { IMMEstimator.predict(); IMMEstimator.update(z or None) } for N banks."""
+              zmask=None, ll0=None, nu=0, B=None, u=None):
+    """fk_imm_batch_ex_f64: T x { IMMEstimator.predict(); IMMEstimator.update(z or None) } for N banks."""
     d = _abi.fk_imm_desc(n=n, m=m, n_models=n_models, layout=LAYOUTS[layout], N=N, T=T, phase=phase, flags=1 if mmae else 0)
-    rc = _abi.lib().fk_imm_batch_masked_f64(d, _ptr(F), _ptr(Q), _ptr(H), _ptr(R), _ptr(M), _ptr(z), _ptr(zmask), _ptr(ll0),
+    rc = _abi.lib().fk_imm_batch_ex_f64(d, _ptr(F), _ptr(Q), _ptr(H), _ptr(R), _ptr(M), _ptr(z), _ptr(zmask), _ptr(ll0),
+                                            int(nu), _ptr(B), _ptr(u),
                                             _ptr(xs), _ptr(Ps), _ptr(mu), _ptr(x_out), _ptr(P_out), _ptr(mu_out),
                                             _ptr(x_prior_out), _ptr(P_prior_out), _ptr(likelihood_out), _ptr(status), _stream())
-    _abi.check(rc, "fk_imm_batch_masked_f64")
+    _abi.check(rc, "fk_imm_batch_ex_f64")
 
 
 def resample_workspace_bytes(Fn, Np):

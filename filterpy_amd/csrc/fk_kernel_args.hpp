@@ -47,6 +47,8 @@ struct ImmArgs {
     const double *F, *Q, *H, *R, *Mt, *z;
     double *xs, *Ps, *mu;
     double *x_out, *P_out, *mu_out, *xp_out, *Pp_out, *L_out;
+    const double *B, *u;     // control input (general kernel only): B [n_models][n*nu], u [T][N][nu]
+    int nu;
     const uint8_t *mask;     // [T][N], 0 = update(None); NULL = every measurement present (general kernel only)
     double *ll0;             // [N][n_models] in/out: log-density of a zero residual under each filter's last S (or NULL)
     int32_t *status;

@@ -23,13 +23,14 @@ extern "C" int fk_imm_batch_f64(const fk_imm_desc *d, const double *F, const dou
                                 double *mu, double *x_out, double *P_out, double *mu_out, double *x_prior_out,
                                 double *P_prior_out, double *likelihood_out, int32_t *status, void *stream)
 {
-    return fk_imm_batch_masked_f64(d, F, Q, H, R, M, z, nullptr, nullptr, xs, Ps, mu, x_out, P_out, mu_out, x_prior_out,
+    return fk_imm_batch_ex_f64(d, F, Q, H, R, M, z, nullptr, nullptr, 0, nullptr, nullptr, xs, Ps, mu, x_out, P_out, mu_out, x_prior_out,
                                    P_prior_out, likelihood_out, status, stream);
 }
 
-extern "C" int fk_imm_batch_masked_f64(const fk_imm_desc *d, const double *F, const double *Q, const double *H,
+extern "C" int fk_imm_batch_ex_f64(const fk_imm_desc *d, const double *F, const double *Q, const double *H,
                                        const double *R, const double *M, const double *z, const uint8_t *zmask,
-                                       double *ll0, double *xs, double *Ps, double *mu, double *x_out, double *P_out,
+                                       double *ll0, int32_t nu, const double *B, const double *u, double *xs, double *Ps,
+                                       double *mu, double *x_out, double *P_out,
                                        double *mu_out, double *x_prior_out, double *P_prior_out, double *likelihood_out,
                                        int32_t *status, void *stream)
 {
@@ -52,6 +53,8 @@ extern "C" int fk_imm_batch_masked_f64(const fk_imm_desc *d, const double *F, co
     a.L_out = likelihood_out; a.status = status; a.N = d->N; a.T = d->phase == FK_IMM_STEP ? d->T : 1;
     a.n = d->n; a.m = d->m; a.phase = d->phase; a.mmae = (d->flags & FK_IMM_FLAG_MMAE) ? 1 : 0;
     a.mask = zmask; a.ll0 = ll0;
+    if (nu < 0 || nu > 4 || (nu > 0 && (!B || !u))) return fail(FK_ERR_BAD_ARG, "IMM: control input needs 1 <= dim_u <= 4, B and u");
+    a.nu = nu; a.B = B; a.u = u;
     if (a.mmae && (x_prior_out || P_prior_out)) return fail(FK_ERR_BAD_ARG, "MMAE: prior outputs are not defined");
     // which compiled output set (if any) the given pointers form; the single-phase calls use the
     // run-time-tested kernel (one step, launch-bound anyway)
@@ -60,7 +63,7 @@ extern "C" int fk_imm_batch_masked_f64(const fk_imm_desc *d, const double *F, co
     int mask = (post < 0 || prior < 0) ? -1 : (post | prior | (likelihood_out ? 4 : 0));
     if (mask != 0 && mask != 1 && mask != 7) mask = -1;
     if (d->phase != FK_IMM_STEP || a.mmae) mask = -1;   // the general kernel also carries the MMAE arithmetic
-    if (zmask || ll0) mask = -1;                         // ... and the missing-measurement bookkeeping
+    if (zmask || ll0 || nu > 0) mask = -1;               // ... the missing-measurement bookkeeping and the control input
     hipStream_t s = (hipStream_t)stream;
     const int cls = (d->n <= 2 && d->m <= 1) ? 0 : (d->n <= 4 && d->m <= 2) ? 1 : 2;
     if (d->n_models == 2) {

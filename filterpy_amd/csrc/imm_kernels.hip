@@ -101,6 +101,21 @@ imm_kernel(const ImmArgs a)
         } else {
             imm_predict<NX, NM>(xs, Ps, mu, cbar, sM, mods);
         }
+        if (MASKED && a.nu > 0) {
+            // every filter's predict(u): x = F x + B u (kalman_filter.py:472-475), B u formed on its own like dot(B, u)
+            const RecView<LAYOUT> vu(a.u + t * N * a.nu, ln, a.nu);
+            double uu[4];
+            FK_UNROLL for (int c = 0; c < 4; ++c) uu[c] = c < a.nu ? vu.load(c) : 0.0;
+            FK_UNROLL for (int j = 0; j < NM; ++j)
+                FK_UNROLL for (int r = 0; r < NX; ++r) {
+                    if (r < n) {
+                        double bu = a.B[(j * n + r) * a.nu] * uu[0];
+                        FK_UNROLL for (int c = 1; c < 4; ++c)
+                            if (c < a.nu) bu = fma(a.B[(j * n + r) * a.nu + c], uu[c], bu);
+                        xs[j][r] += bu;
+                    }
+                }
+        }
         if (OUTS < 0 ? (a.xp_out || a.Pp_out) : (OUTS & 2) != 0) {
             double x[NX], P[NX * NX];
             imm_estimate<NX, NM>(xs, Ps, mu, x, P);

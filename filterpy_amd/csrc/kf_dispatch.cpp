@@ -177,6 +177,7 @@ int fk_kf_batch_filter_f64(const fk_kf_desc *desc, const double *F, const double
                            double *means_p, double *covs_p, int32_t *status, void *stream)
 {
     if (int rc = check_desc(desc)) return rc;
+    if (desc->N == 0 || desc->T == 0) return FK_OK;                 // an empty bank / an empty run: nothing to read, nothing to touch
     if (!F || !Q || !H || !R || !z || !x || !P) return fail(FK_ERR_BAD_ARG, "F,Q,H,R,z,x,P must not be NULL");
     if (desc->nu > 0 && (!B || !u)) return fail(FK_ERR_BAD_ARG, "dim_u > 0 needs B and u");
     KfArgs a{};
@@ -196,6 +197,7 @@ int fk_kf_batch_filter_ex_f64(const fk_kf_desc *desc, const double *F, const dou
                               void *stream)
 {
     if (int rc = check_desc(desc)) return rc;
+    if (desc->N == 0 || desc->T == 0) return FK_OK;                 // an empty bank / an empty run: nothing to read, nothing to touch
     if (!F || !Q || !H || !R || !z || !x || !P) return fail(FK_ERR_BAD_ARG, "F,Q,H,R,z,x,P must not be NULL");
     if (desc->nu > 0 && (!B || !u)) return fail(FK_ERR_BAD_ARG, "dim_u > 0 needs B and u");
     KfArgs a{};
@@ -217,6 +219,7 @@ int fk_kf_predict_f64(const fk_kf_desc *desc, const double *F, const double *Q, 
                       const double *u, double *x, double *P, int32_t *status, void *stream)
 {
     if (int rc = check_desc(desc)) return rc;
+    if (desc->N == 0) return FK_OK;                 // an empty bank / an empty run: nothing to read, nothing to touch
     if (!F || !Q || !x || !P) return fail(FK_ERR_BAD_ARG, "F,Q,x,P must not be NULL");
     if (desc->nu > 0 && (!B || !u)) return fail(FK_ERR_BAD_ARG, "dim_u > 0 needs B and u");
     KfArgs a{};
@@ -232,6 +235,7 @@ int fk_kf_update_f64(const fk_kf_desc *desc, const double *H, const double *R, c
                      double *SI, int32_t *status, void *stream)
 {
     if (int rc = check_desc(desc)) return rc;
+    if (desc->N == 0) return FK_OK;                 // an empty bank / an empty run: nothing to read, nothing to touch
     if (!H || !R || !z || !x || !P) return fail(FK_ERR_BAD_ARG, "H,R,z,x,P must not be NULL");
     KfArgs a{};
     a.H = H; a.R = R; a.z = z; a.mask = mask; a.x = x; a.P = P;
@@ -249,6 +253,7 @@ int fk_kf_rts_f64(const fk_kf_desc *desc, const double *F, const double *Q, cons
                   int32_t index_convention, int32_t *status, void *stream)
 {
     if (int rc = check_desc(desc)) return rc;
+    if (desc->N == 0 || desc->T == 0) return FK_OK;                 // an empty bank / an empty run: nothing to read, nothing to touch
     if (!F || !Q || !Xs || !Ps || !xs || !Ps_out) return fail(FK_ERR_BAD_ARG, "F,Q,Xs,Ps,xs,Ps_out must not be NULL");
     if (index_convention != 0 && index_convention != 1) return fail(FK_ERR_BAD_ARG, "index_convention must be 0 or 1");
     if (desc->N == 0 || desc->T == 0) return FK_OK;

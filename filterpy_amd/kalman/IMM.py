@@ -152,19 +152,19 @@ class IMMEstimator(object):
             else:
                 f.x, f.P = self._xs[:, j].copy(), self._Ps[:, j].copy()
 
-    def _launch(self, phase, zs, T, want_prior, want_post, mmae=False, R=None, H=None, present=None):
+    def _launch(self, phase, zs, T, want_prior, want_post, mmae=False, R=None, H=None, present=None, us=None):
         """One launch (`present`: (T, nt) booleans, False = that measurement is None; None = all there).  A long run
         without missing measurements goes through the fast instantiations except for its LAST step, which the
         general kernel runs so that the zero-residual log-densities (self._ll0) stay current for a later update(None)."""
         nt, nm = self._nt or 1, self.N
-        if phase == _PHASE_STEP and present is None and not mmae and T >= 2:
+        if phase == _PHASE_STEP and present is None and not mmae and us is None and T >= 2:
             zs = np.ascontiguousarray(zs, dtype=np.float64).reshape(T, nt, self._m)
             a = self._launch1(phase, zs[:-1], T - 1, want_prior, want_post, mmae, R, H, None, track_ll0=False)
             b = self._launch1(phase, zs[-1:], 1, want_prior, want_post, mmae, R, H, None, track_ll0=True)
             return {k: np.concatenate([a[k], b[k]], axis=0) for k in a}
-        return self._launch1(phase, zs, T, want_prior, want_post, mmae, R, H, present, track_ll0=phase != _PHASE_PREDICT)
+        return self._launch1(phase, zs, T, want_prior, want_post, mmae, R, H, present, track_ll0=phase != _PHASE_PREDICT, us=us)
 
-    def _launch1(self, phase, zs, T, want_prior, want_post, mmae, R, H, present, track_ll0):
+    def _launch1(self, phase, zs, T, want_prior, want_post, mmae, R, H, present, track_ll0, us=None):
         nt, n, m, nm, lay = self._nt or 1, self._n, self._m, self.N, self._layout
         self._pull_from_filters()
         F, Q, H, R, M = self._models(R, H)
@@ -182,8 +182,18 @@ class IMMEstimator(object):
         zmask = None if present is None else torch.as_tensor(np.ascontiguousarray(present, dtype=np.uint8).reshape(T, nt),
                                                               device=xs.device)
         ll0 = E.to_records(self._ll0.reshape(nt, nm), lay, 0) if track_ll0 else None
+        ctrl = {}
+        if us is not None:
+            # predict(u): every filter's own B (kalman_filter.py:472-475; a filter without B ignores u like the reference)
+            U = np.ascontiguousarray(us, dtype=np.float64).reshape(T, nt, -1)
+            nu = U.shape[2]
+            if nu > 4:
+                raise NotImplementedError("the IMM kernel takes dim_u <= 4")
+            Bs = np.stack([np.zeros((n, nu)) if getattr(f, "B", None) is None else
+                           np.asarray(f.B, dtype=np.float64).reshape(n, nu) for f in self.filters])
+            ctrl = dict(nu=nu, B=E.dev(Bs), u=E.to_records(U, lay, 1))
         E.imm_batch(n, m, nm, nt, T, lay, F, Q, H, R, M, z, xs, Ps, mu, status=status, phase=phase, mmae=mmae,
-                    zmask=zmask, ll0=ll0, **out)
+                    zmask=zmask, ll0=ll0, **ctrl, **out)
         E.raise_on_status(status, "IMMEstimator")
         if ll0 is not None:
             self._ll0 = E.from_records(ll0, lay, 0, (nm,)).copy()
@@ -198,9 +208,8 @@ class IMMEstimator(object):
     # ---------------------------------------------------------------------- reference API --
     def predict(self, u=None):
         """IMM.py:188-222: mixed initial conditions, every filter's predict, prior estimate."""
-        if u is not None:
-            raise NotImplementedError("control input is not supported by the IMM kernel")
-        o = self._launch(_PHASE_PREDICT, None, 1, True, False)
+        us = None if u is None else np.asarray(u, dtype=np.float64).reshape(1, self._nt or 1, -1)
+        o = self._launch(_PHASE_PREDICT, None, 1, True, False, us=us)
         self._set_estimate(o["x_prior_out"][0], o["P_prior_out"][0])
         self.x_prior, self.P_prior = self.x.copy(), self.P.copy()
 
@@ -219,7 +228,7 @@ class IMMEstimator(object):
         self._set_estimate(o["x_out"][0], o["P_out"][0])
         self.x_post, self.P_post = self.x.copy(), self.P.copy()
 
-    def batch_filter(self, zs, return_priors=False):
+    def batch_filter(self, zs, return_priors=False, us=None):
         """T x { predict(); update(zs[t]) } in one launch.
 
         zs: (T, m) for a single IMM, (T, N, m) for a bank.  Returns (xs, Ps, mus): the estimate
@@ -230,7 +239,7 @@ class IMMEstimator(object):
         T = zs.shape[0]
         if T == 0:
             raise ValueError("zs is empty")
-        o = self._launch(_PHASE_STEP, zs, T, True, True, present=present)
+        o = self._launch(_PHASE_STEP, zs, T, True, True, present=present, us=us)
         L = o["likelihood_out"][-1]
         self.likelihood = L if self._nt is not None else L[0]
         self._compute_mixing_probabilities()

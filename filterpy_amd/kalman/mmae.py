@@ -39,18 +39,19 @@ class MMAEFilterBank(object):
         self.x_prior, self.P_prior = self.x.copy(), self.P.copy()
         self.x_post, self.P_post = self.x.copy(), self.P.copy()
 
-    def _run(self, phase, zs, T, want_post, R=None, H=None, present=None):
+    def _run(self, phase, zs, T, want_post, R=None, H=None, present=None, us=None):
         e = self._eng
         e.mu = self.p
-        o = e._launch(phase, zs, T, False, want_post, mmae=True, R=R, H=H, present=present)
+        o = e._launch(phase, zs, T, False, want_post, mmae=True, R=R, H=H, present=present, us=us)
         self.p = e.mu
         return o
 
     def predict(self, u=0):
         """mmae.py:140-158: every filter predicts; the prior is a copy of the last estimate."""
+        us = None
         if np.any(np.asarray(u) != 0):
-            raise NotImplementedError("control input is not supported by the IMM/MMAE kernel")
-        self._run(1, None, 1, False)
+            us = np.asarray(u, dtype=np.float64).reshape(1, self._eng._nt or 1, -1)
+        self._run(1, None, 1, False, us=us)
         self.x_prior, self.P_prior = self.x.copy(), self.P.copy()
 
     def update(self, z, R=None, H=None):

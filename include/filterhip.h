@@ -333,10 +333,15 @@ enum { FK_IMM_FLAG_MMAE = 1 };
  *   ll0   [N][n_models] in/out record, or NULL: -(m ln 2 pi + ln |S_j|) / 2 of each filter's last real update,
  *         -inf for a filter that has not seen one (S = 0: the reference's density evaluates to 0 and is floored at
  *         DBL_MIN like every likelihood).  Keeps the bookkeeping across launches (the call-by-call API); NULL starts
- *         every filter at -inf and drops the result. */
-int fk_imm_batch_masked_f64(const fk_imm_desc *desc,
+ *         every filter at -inf and drops the result.
+ * ... and with a CONTROL input (IMMEstimator.predict(u) / MMAEFilterBank.predict(u) hand u to every filter's predict,
+ * kalman_filter.py:472-475: x = F x + B u):
+ *   nu    dim_u (0 = none); B [n_models][n*nu]: every filter's own B; u [T][N][nu] record array in `layout`
+ *         ([N][nu] for a single phase). */
+int fk_imm_batch_ex_f64(const fk_imm_desc *desc,
                             const double *F, const double *Q, const double *H, const double *R, const double *M,
                             const double *z, const uint8_t *zmask, double *ll0,
+                            int32_t nu, const double *B, const double *u,
                             double *xs, double *Ps, double *mu,
                             double *x_out, double *P_out, double *mu_out,
                             double *x_prior_out, double *P_prior_out, double *likelihood_out,

@@ -35,7 +35,7 @@ def state_estimate(xs, Ps, mu):
     return x, P
 
 
-def imm_batch(xs0, Ps0, mu0, Mtrans, zs, Fs, Qs, Hs, Rs):
+def imm_batch(xs0, Ps0, mu0, Mtrans, zs, Fs, Qs, Hs, Rs, Bs=None, us=None):
     """T x { imm.predict(); imm.update(z) } for one IMM with len(Fs) linear models.
 
     xs0 (nm, n), Ps0 (nm, n, n): the filters' states; mu0 (nm,) (normalised like IMM.py:129).
@@ -68,7 +68,9 @@ def imm_batch(xs0, Ps0, mu0, Mtrans, zs, Fs, Qs, Hs, Rs):
             mx.append(x)
             mP.append(P)
         for j in range(nm):
-            xs[j], Ps[j] = kf_oracle.kf_predict(mx[j], mP[j], Fs[j], Qs[j])
+            # f.predict(u) (IMM.py:214-216): x = F x + B u with the filter's own B (kalman_filter.py:472-475)
+            xs[j], Ps[j] = kf_oracle.kf_predict(mx[j], mP[j], Fs[j], Qs[j], None if Bs is None else Bs[j],
+                                                None if us is None else us[t])
         out_xp[t], out_Pp[t] = state_estimate(xs, Ps, mu)
         # update (IMM.py:171-186)
         L = np.zeros(nm)
@@ -91,7 +93,7 @@ def imm_batch(xs0, Ps0, mu0, Mtrans, zs, Fs, Qs, Hs, Rs):
     return out_x, out_P, out_mu, out_xp, out_Pp, out_L
 
 
-def mmae_batch(xs0, Ps0, p0, zs, Fs, Qs, Hs, Rs):
+def mmae_batch(xs0, Ps0, p0, zs, Fs, Qs, Hs, Rs, Bs=None, us=None):
     """T x { bank.predict(); bank.update(z) } of filterpy.kalman.MMAEFilterBank (mmae.py:140-212).
 
     No mixing; p_i *= likelihood_i, normalised with Python's sum (mmae.py:185-189); x = sum p_i x_i;
@@ -107,7 +109,8 @@ def mmae_batch(xs0, Ps0, p0, zs, Fs, Qs, Hs, Rs):
     S_last = [np.zeros((m, m)) for _ in range(nm)]
     for t in range(T):
         for j in range(nm):
-            xs[j], Ps[j] = kf_oracle.kf_predict(xs[j], Ps[j], Fs[j], Qs[j])
+            xs[j], Ps[j] = kf_oracle.kf_predict(xs[j], Ps[j], Fs[j], Qs[j], None if Bs is None else Bs[j],
+                                                None if us is None else us[t])
         L = np.zeros(nm)
         for j in range(nm):
             if zs[t] is None:          # as in imm_batch: zero residual under the last real update's S

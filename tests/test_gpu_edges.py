@@ -1,0 +1,82 @@
+"""Edge cases at the C ABI and the Python surface: empty inputs, the largest compiled dims, sizes the ABI refuses."""
+import numpy as np
+import pytest
+
+from conftest import rel_err_rows
+from oracle import kf_oracle
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-10
+
+
+def _spd(rs, n, scale=1.0):
+    A = rs.randn(n, n)
+    return scale * (A @ A.T / n + 0.5 * np.eye(n))
+
+
+def test_empty_inputs_are_no_ops():
+    """N = 0 tracks, T = 0 steps, 0 filters, 0 particles: FK_OK, nothing touched, empty results with the right shapes."""
+    import torch
+    from filterpy_amd import _engine as E
+    from filterpy_amd.kalman import KalmanFilter
+    from filterpy_amd.monte_carlo import systematic_resample, stratified_resample
+    from gpu_util import run_kf_batch, run_rts
+    n, m = 4, 2
+    F, Q, H, R = np.eye(n), 0.1 * np.eye(n), np.eye(m, n), np.eye(m)
+    for layout in ("soa", "aos"):
+        out = run_kf_batch(np.zeros((0, n)), np.zeros((0, n, n)), np.zeros((5, 0, m)), F, Q, H, R, layout=layout)
+        assert out[0].shape == (5, 0, n) and out[1].shape == (5, 0, n, n) and out[4].shape == (0, n)
+        x0, P0 = np.ones((3, n)), np.tile(np.eye(n), (3, 1, 1))
+        out = run_kf_batch(x0, P0, np.zeros((0, 3, m)), F, Q, H, R, layout=layout)
+        assert out[0].shape == (0, 3, n) and np.array_equal(out[4], x0) and np.array_equal(out[5], P0)      # T = 0: state untouched
+        xs, Ps, K, Pp = run_rts(np.zeros((4, 0, n)), np.zeros((4, 0, n, n)), F, Q, layout=layout)
+        assert xs.shape == (4, 0, n)
+    kf = KalmanFilter(n, m)
+    mu, cov, mup, covp = kf.batch_filter([])
+    assert mu.shape[0] == 0 and cov.shape[0] == 0 and np.array_equal(kf.x, np.zeros((n, 1)))
+    dev = torch.device("cuda")
+    w = torch.zeros((0, 8), dtype=torch.float64, device=dev)
+    E.resample_systematic(0, 8, w, torch.zeros(0, dtype=torch.float64, device=dev), torch.zeros((0, 8), dtype=torch.int32, device=dev))
+    E.resample_systematic(3, 0, torch.zeros((3, 0), dtype=torch.float64, device=dev), torch.zeros(3, dtype=torch.float64, device=dev),
+                          torch.zeros((3, 0), dtype=torch.int32, device=dev))
+    assert systematic_resample(np.array([1.0])).tolist() == [0] and stratified_resample(np.array([1.0])).tolist() == [0]
+
+
+@pytest.mark.parametrize("layout", ["soa", "aos"])
+@pytest.mark.parametrize("n,m", [(16, 8), (13, 7), (10, 4)])
+def test_largest_compiled_dims_vs_oracle(n, m, layout):
+    """dim_x <= 16, dim_z <= 8 is what the ABI promises (padded / rolled instantiations above 9 / 4): forward + smoother."""
+    from gpu_util import run_kf_batch, run_rts
+    rs = np.random.RandomState(100 * n + m)
+    N, T = 70, 12
+    F = np.eye(n) + 0.05 * rs.randn(n, n)
+    F /= max(1.0, 1.05 * np.max(np.abs(np.linalg.eigvals(F))))
+    Q, H, R = _spd(rs, n, 0.05), rs.randn(m, n), _spd(rs, m, 0.5)
+    x0, P0 = rs.randn(N, n), np.stack([_spd(rs, n, 3.0) for _ in range(N)])
+    zs = rs.randn(T, N, m)
+    got = run_kf_batch(x0, P0, zs, F, Q, H, R, layout=layout)
+    sample = [0, 63, 64, N - 1]
+    ref = kf_oracle.kf_batch_filter_tracks(x0, P0, zs, F, Q, H, R, tracks=sample)
+    for k in range(4):
+        a, b = got[k][:, sample], ref[k]
+        assert rel_err_rows(a.reshape(T * len(sample), -1), b.reshape(T * len(sample), -1)) < TOL, (n, m, k)
+    sm = run_rts(got[0], got[1], F, Q, layout=layout)
+    rsm = kf_oracle.rts_smoother_tracks(got[0], got[1], F, Q, tracks=sample)
+    for k in range(2):
+        assert rel_err_rows(sm[k][:, sample].reshape(T * len(sample), -1), rsm[k].reshape(T * len(sample), -1)) < TOL, (n, m, "rts", k)
+
+
+def test_sizes_the_abi_refuses():
+    """dim_x = 17 / dim_z = 9 (outside the compiled range) and a step slab >= 4 GiB come back as error codes with a message,
+    never as a fault."""
+    import torch
+    from filterpy_amd import _abi, _engine as E
+    dev = torch.device("cuda")
+    t = torch.zeros(8, dtype=torch.float64, device=dev)
+    for n, m, N in ((17, 2, 4), (4, 9, 4), (4, 2, 40_000_000)):
+        with pytest.raises(_abi.FilterHipError):
+            E.kf_batch_filter(dict(n=n, m=m, nu=0, model_mode=0, N=N, T=1, layout=0, update_first=0, alpha_sq=1.0),
+                              t, t, t, t, t, t, t)
+    with pytest.raises(_abi.FilterHipError):
+        E.kf_batch_filter(dict(n=4, m=2, nu=0, model_mode=0, N=4, T=1, layout=0, update_first=0, alpha_sq=1.0, flags=64),
+                          t, t, t, t, t, t, t)

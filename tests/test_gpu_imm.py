@@ -167,8 +167,6 @@ def test_imm_rejects_what_the_kernel_cannot_do():
         IMMEstimator(fs[:1], [1.0], np.eye(1))
     imm = IMMEstimator(fs, [0.5, 0.5], np.array([[0.9, 0.1], [0.1, 0.9]]))
     with pytest.raises(NotImplementedError):
-        imm.predict(u=np.zeros(1))
-    with pytest.raises(NotImplementedError):
         IMMEstimator([KalmanFilter(dim_x=2, dim_z=1) for _ in range(4)], [1, 1, 1, 1], np.full((4, 4), 0.25))
 
 
@@ -337,3 +335,46 @@ def test_missing_measurements_one_launch_bank(kind, layout):
     b.update(None)
     ma, mb = (a.mu, b.mu) if kind == "imm" else (a.p, b.p)
     assert np.allclose(ma, mb, rtol=1e-10, atol=1e-14) and rel_err_rows(np.asarray(a.x), np.asarray(b.x)) < TOL
+
+
+@pytest.mark.parametrize("layout", ["soa", "aos"])
+@pytest.mark.parametrize("kind", ["imm", "mmae"])
+def test_control_input(kind, layout):
+    """IMMEstimator.predict(u) / MMAEFilterBank.predict(u): every filter's x = F x + B u with its own B -- call by call
+    on one estimator and as one launch over a bank (goldens: live reference, tests/golden/make_imm_control_golden.py)."""
+    from filterpy_amd.kalman import IMMEstimator, KalmanFilter, MMAEFilterBank
+    g = golden("imm_control")
+    N = 70
+    for n, m, nm, nu in g["cases"]:
+        n, m, nm, nu = int(n), int(m), int(nm), int(nu)
+        p = f"n{n}m{m}k{nm}_"
+        q = p + kind + "_"
+
+        def make(n_tracks):
+            fs = []
+            for j in range(nm):
+                f = KalmanFilter(dim_x=n, dim_z=m, dim_u=nu)
+                f.x = g[p + "xs0"][j].copy() if n_tracks is None else np.tile(g[p + "xs0"][j], (n_tracks, 1))
+                f.P = g[p + "Ps0"][j].copy() if n_tracks is None else np.tile(g[p + "Ps0"][j], (n_tracks, 1, 1))
+                f.F, f.Q, f.H, f.R, f.B = (g[p + "Fs"][j].copy(), g[p + "Qs"][j].copy(), g[p + "H"].copy(),
+                                           g[p + "Rs"][j].copy(), g[p + "Bs"][j].copy())
+                fs.append(f)
+            kw = {} if n_tracks is None else dict(n_tracks=n_tracks, layout=layout)
+            if kind == "imm":
+                return IMMEstimator(fs, g[p + "mu0"], g[p + "M"], **kw)
+            return MMAEFilterBank(fs, list(g[p + "mu0"] / g[p + "mu0"].sum()), dim_x=n, H=g[p + "H"], **kw)
+        est = make(None)
+        for t, (z, u) in enumerate(zip(g[p + "zs"], g[p + "us"])):
+            est.predict(u)
+            est.update(z)
+            mu = est.mu if kind == "imm" else est.p
+            assert rel_err_rows(np.asarray(est.x, dtype=float).reshape(1, n), g[q + "x"][t][None]) < TOL, (kind, n, t)
+            assert rel_err_rows(np.asarray(est.P, dtype=float)[None], g[q + "P"][t][None]) < TOL, (kind, n, t)
+            assert np.allclose(mu, g[q + "mu"][t], rtol=1e-10, atol=1e-14)
+        if kind == "imm":
+            bank = make(N)
+            T = len(g[p + "zs"])
+            xs, Ps, mus = bank.batch_filter(np.tile(g[p + "zs"][:, None], (1, N, 1)), us=np.tile(g[p + "us"][:, None], (1, N, 1)))
+            for trk in (0, 64, N - 1):
+                assert rel_err_rows(xs[:, trk], g[q + "x"]) < TOL and rel_err_rows(Ps[:, trk], g[q + "P"]) < TOL
+                assert np.allclose(mus[:, trk], g[q + "mu"], rtol=1e-10, atol=1e-14)

@@ -49,3 +49,22 @@ def test_missing_measurements_vs_live_reference(kind):
             x, P, mu, L = imm_oracle.mmae_batch(g[p + "xs0"], g[p + "Ps0"], mu0, zs, g[p + "Fs"], g[p + "Qs"], Hs, g[p + "Rs"])
         assert np.allclose(x, g[q + "x"], rtol=1e-11, atol=1e-12) and np.allclose(P, g[q + "P"], rtol=1e-11, atol=1e-12)
         assert np.allclose(mu, g[q + "mu"], rtol=1e-11, atol=1e-13)
+
+
+@pytest.mark.parametrize("kind", ["imm", "mmae"])
+def test_control_input_vs_live_reference(kind):
+    """predict(u): x = F x + B u in every filter with its own B (tests/golden/make_imm_control_golden.py)."""
+    g = golden("imm_control")
+    for n, m, nm, nu in g["cases"]:
+        p = f"n{n}m{m}k{nm}_"
+        Hs = [g[p + "H"]] * int(nm)
+        q = p + kind + "_"
+        if kind == "imm":
+            x, P, mu = imm_oracle.imm_batch(g[p + "xs0"], g[p + "Ps0"], g[p + "mu0"], g[p + "M"], list(g[p + "zs"]),
+                                            g[p + "Fs"], g[p + "Qs"], Hs, g[p + "Rs"], Bs=g[p + "Bs"], us=g[p + "us"])[:3]
+        else:
+            mu0 = g[p + "mu0"] / g[p + "mu0"].sum()
+            x, P, mu = imm_oracle.mmae_batch(g[p + "xs0"], g[p + "Ps0"], mu0, list(g[p + "zs"]), g[p + "Fs"], g[p + "Qs"], Hs,
+                                             g[p + "Rs"], Bs=g[p + "Bs"], us=g[p + "us"])[:3]
+        assert np.allclose(x, g[q + "x"], rtol=1e-11, atol=1e-12) and np.allclose(P, g[q + "P"], rtol=1e-11, atol=1e-12)
+        assert np.allclose(mu, g[q + "mu"], rtol=1e-11, atol=1e-13)
