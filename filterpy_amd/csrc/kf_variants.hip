@@ -26,7 +26,9 @@ struct SteadyArgs {
 };
 
 // F (NX x NX), H (NZ x NX) and the shared K (NX x NZ) sit in LDS; a per-track K in registers.
-template <int NX, int NZ, int LAYOUT>
+// EXACT (n == NX, m == NZ): the x / z / y records move without per-element guards -- in NumPy order (AOS) as 16-byte
+// pairs, half as many memory operations (steady-state AOS measured 0.24-0.38 of HBM with the guarded 8-byte accesses).
+template <int NX, int NZ, int LAYOUT, bool EXACT>
 __global__ void __launch_bounds__(BLOCK)
 steady_kernel(const SteadyArgs a)
 {
@@ -42,7 +44,7 @@ steady_kernel(const SteadyArgs a)
     const Lane ln{(long)blockIdx.x * BLOCK, threadIdx.x, N};
     if (ln.blk0 + ln.tid >= N) return;
     double x[NX], K[NX * NZ];
-    load_rec<NX, 1, LAYOUT, false>(x, a.x, ln, n, 1, 0.0);
+    load_rec<NX, 1, LAYOUT, EXACT>(x, a.x, ln, n, 1, 0.0);
     if (a.k_per_track) {
         load_rec<NX, NZ, LAYOUT, false>(K, a.K, ln, n, m, 0.0);
     } else {
@@ -67,11 +69,11 @@ steady_kernel(const SteadyArgs a)
                 FK_UNROLL for (int i = 0; i < NX; ++i) xn[i] += Bu[i];
             }
             FK_UNROLL for (int i = 0; i < NX; ++i) x[i] = xn[i];
-            if (a.means_p) store_rec<NX, 1, LAYOUT, false>(x, a.means_p + t * N * n, ln, n, 1);
+            if (a.means_p) store_rec<NX, 1, LAYOUT, EXACT>(x, a.means_p + t * N * n, ln, n, 1);
         }
         if (a.z) {      // update_steadystate: y = z - H x ; x += K y
             double z[NZ], y[NZ];
-            load_rec<NZ, 1, LAYOUT, false>(z, a.z + t * N * m, ln, m, 1, 0.0);
+            load_rec<NZ, 1, LAYOUT, EXACT>(z, a.z + t * N * m, ln, m, 1, 0.0);
             const bool has_z = !a.mask || a.mask[t * N + ln.blk0 + ln.tid];
             FK_UNROLL for (int r = 0; r < NZ; ++r) {
                 double acc = sH[r * NX] * x[0];
@@ -85,11 +87,11 @@ steady_kernel(const SteadyArgs a)
                     x[i] += acc;
                 }
             }
-            if (a.y_out) store_rec<NZ, 1, LAYOUT, false>(y, a.y_out + t * N * m, ln, m, 1);
-            if (a.means) store_rec<NX, 1, LAYOUT, false>(x, a.means + t * N * n, ln, n, 1);
+            if (a.y_out) store_rec<NZ, 1, LAYOUT, EXACT>(y, a.y_out + t * N * m, ln, m, 1);
+            if (a.means) store_rec<NX, 1, LAYOUT, EXACT>(x, a.means + t * N * n, ln, n, 1);
         }
     }
-    store_rec<NX, 1, LAYOUT, false>(x, a.x, ln, n, 1);
+    store_rec<NX, 1, LAYOUT, EXACT>(x, a.x, ln, n, 1);
 }
 
 // update_correlated (kalman_filter.py:727-748), in the reference's association order:
@@ -282,9 +284,16 @@ int fk_kf_steadystate_f64(const fk_kf_desc *d, const double *F, const double *H,
     const dim3 grid((unsigned)((a.N + BLOCK - 1) / BLOCK)), block(BLOCK);
     hipStream_t s = (hipStream_t)stream;
 #define CALL(NXV, NZV)                                                                                      \
-    if (d->layout == FK_LAYOUT_SOA) hipLaunchKernelGGL((steady_kernel<NXV, NZV, LAYOUT_SOA>), grid, block, 0, s, a); \
-    else hipLaunchKernelGGL((steady_kernel<NXV, NZV, LAYOUT_AOS>), grid, block, 0, s, a)
-    FK_BY_DIMS(d->n, d->m, CALL);
+    if (d->n == NXV && d->m == NZV) {                                                                                    \
+        if (d->layout == FK_LAYOUT_SOA) hipLaunchKernelGGL((steady_kernel<NXV, NZV, LAYOUT_SOA, true>), grid, block, 0, s, a); \
+        else hipLaunchKernelGGL((steady_kernel<NXV, NZV, LAYOUT_AOS, true>), grid, block, 0, s, a);                       \
+    } else if (d->layout == FK_LAYOUT_SOA) hipLaunchKernelGGL((steady_kernel<NXV, NZV, LAYOUT_SOA, false>), grid, block, 0, s, a); \
+    else hipLaunchKernelGGL((steady_kernel<NXV, NZV, LAYOUT_AOS, false>), grid, block, 0, s, a)
+    // exact instantiations for the shapes of BASELINE / the benches, the padded size classes for everything else
+    if (d->n == 2 && d->m == 1) { CALL(2, 1); }
+    else if (d->n == 6 && d->m == 3) { CALL(6, 3); }
+    else if (d->n == 9 && d->m == 3) { CALL(9, 3); }
+    else FK_BY_DIMS(d->n, d->m, CALL);
 #undef CALL
     return check_launch("steady_kernel");
 }
