@@ -108,3 +108,11 @@ def test_bench_refuses_more_ranks_than_gpus():
 def test_bench_rejects_world_size_mismatch():
     r = _run_bench("bench.py", "--gpus", "4", "--selftest-cpu", env_extra={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
     assert r.returncode != 0 and "WORLD_SIZE=2" in (r.stderr + r.stdout)
+
+
+def test_bench_c5_uses_the_same_launcher():
+    """tools/bench_c5.py --gpus N: same rule as bench.py (self-spawn; never a silent 1-GPU run; WORLD_SIZE must agree)."""
+    r = _run_bench("tools/bench_c5.py", "--gpus", "8")
+    assert r.returncode != 0 and "GPU(s) are visible" in (r.stderr + r.stdout)
+    r = _run_bench("tools/bench_c5.py", "--gpus", "4", env_extra={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "WORLD_SIZE=2" in (r.stderr + r.stdout)

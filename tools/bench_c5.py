@@ -30,12 +30,18 @@ def main():
     ap.add_argument("--dim", type=int, default=4)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--gpus", type=int, default=0, help="ranks (one per GPU); without a launcher the script re-executes "
+                    "itself under torch.distributed.run like bench.py does")
     a = ap.parse_args()
 
+    from filterpy_amd import parallel
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        parallel.relaunch_under_torchrun(a.gpus, [os.path.abspath(__file__)] + sys.argv[1:])
     import torch
     from filterpy_amd import _engine as E
-    from filterpy_amd import parallel
     from oracle import resample_oracle as ro
+    if a.gpus and a.gpus != int(os.environ.get("WORLD_SIZE", "1")):
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={os.environ.get('WORLD_SIZE', '1')}: launch one rank per GPU")
 
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)
