@@ -209,7 +209,8 @@ ukf_rts_kernel(int n, long N, const double *__restrict__ pPxb, const double *__r
         double xn[NX], xb[NX];
         load_rec<NX, 1, LAYOUT, false>(x, px, ln, n, 1, 0.0);
         load_rec<NX, 1, LAYOUT, false>(xn, pxn, ln, n, 1, 0.0);
-        load_rec<NX, 1, LAYOUT, false>(xb, pxb, ln, n, 1, 0.0);
+        if (pxb) load_rec<NX, 1, LAYOUT, false>(xb, pxb, ln, n, 1, 0.0);   // nullptr: xn IS residual_x(xs[k+1], xb) (UKF.py:731)
+        else { FK_UNROLL for (int i = 0; i < NX; ++i) xb[i] = 0.0; }
         FK_UNROLL for (int i = 0; i < NX; ++i) dx[i] = xn[i] - xb[i];
     }
     FK_UNROLL for (int i = 0; i < NX; ++i) {
@@ -331,7 +332,7 @@ int fk_ukf_rts_correct_f64(int32_t n, int64_t N, int32_t layout, const double *P
 {
     if (n < 1 || n > 9) return fail(FK_ERR_UNSUPPORTED, "ukf rts: dim_x 1..9");
     if (layout != FK_LAYOUT_AOS && layout != FK_LAYOUT_SOA) return fail(FK_ERR_BAD_ARG, "ukf rts: bad layout");
-    if (N < 0 || !Pxb || !xb || !Pb || !xn || !Pn || !x || !P) return fail(FK_ERR_BAD_ARG, "ukf rts: bad argument");
+    if (N < 0 || !Pxb || !Pb || !xn || !Pn || !x || !P) return fail(FK_ERR_BAD_ARG, "ukf rts: bad argument");
     if ((double)N * n * n * 8.0 >= 4294967296.0) return fail(FK_ERR_UNSUPPORTED, "ukf rts: record block >= 4 GiB");
     if (N == 0) return FK_OK;
     const dim3 grid((unsigned)((N + BLOCK - 1) / BLOCK)), block(BLOCK);

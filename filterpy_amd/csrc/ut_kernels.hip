@@ -159,10 +159,13 @@ cross_kernel(int n, int m, int k, long N, const double *__restrict__ px, const d
     const Lane ln{blk0, threadIdx.x, N};
     if (blk0 + ln.tid >= N) return;
     const RecView<LAYOUT> fv(sf, ln, k * n), hv(sh, ln, k * m), zv(pz, ln, m), ov(Pxz, ln, n * m);
+    // px / pz == nullptr: the caller already applied its own residual_x / residual_z (UKF.py:500-501 with custom
+    // callables), sf / sh hold dx / dz; v - 0.0 is v exactly
     double x[NX];
-    load_rec<NX, 1, LAYOUT, false>(x, px, ln, n, 1, 0.0);
+    if (px) load_rec<NX, 1, LAYOUT, false>(x, px, ln, n, 1, 0.0);
+    else { FK_UNROLL for (int a = 0; a < NX; ++a) x[a] = 0.0; }
     for (int c = 0; c < m; ++c) {
-        const double zc = zv.load(c);
+        const double zc = pz ? zv.load(c) : 0.0;
         double acc[NX];
         FK_UNROLL for (int a = 0; a < NX; ++a) acc[a] = 0.0;
         for (int i = 0; i < k; ++i) {
@@ -195,7 +198,8 @@ ukf_correct_kernel(int n, int m, long N, const double *__restrict__ pPxz, const 
     load_rec<NX, NZ, LAYOUT, false>(K, pPxz, ln, n, m, 0.0);
     load_rec<NZ, NZ, LAYOUT, false>(S, pS, ln, m, m, 1.0);
     load_rec<NZ, 1, LAYOUT, false>(z, pz, ln, m, 1, 0.0);
-    load_rec<NZ, 1, LAYOUT, false>(zp, pzp, ln, m, 1, 0.0);
+    if (pzp) load_rec<NZ, 1, LAYOUT, false>(zp, pzp, ln, m, 1, 0.0);      // nullptr: z IS residual_z(z, zp) (UKF.py:474)
+    else { FK_UNROLL for (int c = 0; c < NZ; ++c) zp[c] = 0.0; }
     // the padded diagonal of K (load_rec pads a==b with diag_pad=0) is zero: nothing to undo
     double Lf[NZ * NZ], d[NZ], dinv[NZ];
     FK_UNROLL for (int e = 0; e < NZ * NZ; ++e) Lf[e] = S[e];
@@ -317,7 +321,7 @@ int fk_ut_cross_variance_f64(int32_t n, int32_t m, int32_t k, int64_t N, int32_t
                              const double *sigmas_h, const double *Wc, double *Pxz, void *stream)
 {
     if (n < 1 || n > 16 || m < 1 || k < 1) return fail(FK_ERR_UNSUPPORTED, "cross variance: dim_x must be 1..16");
-    if (N < 0 || !x || !z || !sigmas_f || !sigmas_h || !Wc || !Pxz) return fail(FK_ERR_BAD_ARG, "cross variance: bad argument");
+    if (N < 0 || !sigmas_f || !sigmas_h || !Wc || !Pxz) return fail(FK_ERR_BAD_ARG, "cross variance: bad argument");
     if ((double)N * k * (n > m ? n : m) * 8.0 >= 4294967296.0) return fail(FK_ERR_UNSUPPORTED, "cross variance: record block >= 4 GiB, split the batch");
     if (N == 0) return FK_OK;
     const dim3 grid((unsigned)((N + BLOCK - 1) / BLOCK)), block(BLOCK);
@@ -338,7 +342,7 @@ int fk_ukf_correct_f64(int32_t n, int32_t m, int64_t N, int32_t layout, const do
                        void *stream)
 {
     if (n < 1 || n > 16 || m < 1 || m > 8) return fail(FK_ERR_UNSUPPORTED, "ukf correct: dim_x 1..16, dim_z 1..8");
-    if (N < 0 || !Pxz || !zp || !S || !z || !x || !P) return fail(FK_ERR_BAD_ARG, "ukf correct: bad argument");
+    if (N < 0 || !Pxz || !S || !z || !x || !P) return fail(FK_ERR_BAD_ARG, "ukf correct: bad argument");
     if ((double)N * n * n * 8.0 >= 4294967296.0) return fail(FK_ERR_UNSUPPORTED, "ukf correct: record block >= 4 GiB, split the batch");
     if (N == 0) return FK_OK;
     const dim3 grid((unsigned)((N + BLOCK - 1) / BLOCK)), block(BLOCK);

@@ -20,9 +20,21 @@ Two ways to run it:
   records for all T steps and download (or hand over, ``device_outputs=True``) only the results.
 
 ``n_tracks=N`` turns the object into a bank of N independent filters (x (N,n), P (N,n,n),
-z (N,m) / zs (T,N,m)).  Custom sqrt / mean / residual / state_add callables cannot run
-inside a kernel and raise NotImplementedError.  ``rts_smoother`` (UKF.py:634-739) runs its
-backward loop on the host like the reference, every step's arithmetic on the GPU.
+z (N,m) / zs (T,N,m)).  ``rts_smoother`` (UKF.py:634-739) runs its backward loop on the host like
+the reference, every step's arithmetic on the GPU.
+
+Constructor hooks (UKF.py:284-340: x_mean_fn, z_mean_fn, residual_x, residual_z, state_add; sigma_points.py:99-116:
+sqrt_method, subtract) are user code like fx / hx and run where fx / hx run, between the kernels: the filter forms the
+means / residuals with them and hands the RESIDUALS to the kernels (fk_ut_cross_variance_f64 with x = z = NULL sums
+Wc[i] outer(dx_i, dz_i) in the reference loop's order -- UKF.py:500-503, unscented_transform.py:120-123;
+fk_ukf_correct_f64 with zp = NULL takes y = residual_z(z, zp); state_add receives K y).  Calling convention per mode:
+  default            exactly the reference's: mean(sigmas (k, d), Wm) -> (d,); residual(a (d,), b (d,)) -> (d,);
+                     state_add(x, dx); sqrt(A (n, n)) -> (n, n); subtract(x (n,), u (n,)) -- once per track / point;
+  vectorized=True    once per call on NumPy arrays: mean(sigmas (N, k, d), Wm) -> (N, d); residual(a (N, k, d), b (N, 1, d))
+                     and residual(a (N, d), b (N, d)); state_add(x (N, n), dx (N, n)); sqrt(A (N, n, n)); subtract(x (N, 1, n),
+                     U (N, n, n));
+  device_callables   the same shapes on float64 CUDA tensors; nothing leaves HBM.
+sqrt_fn is stored as ``msqrt`` and, like in the reference (UKF.py:318-321), never used by the filter itself.
 """
 import sys
 from copy import deepcopy
@@ -40,10 +52,6 @@ class UnscentedKalmanFilter(object):
     def __init__(self, dim_x, dim_z, dt, hx, fx, points, sqrt_fn=None, x_mean_fn=None, z_mean_fn=None,
                  residual_x=None, residual_z=None, state_add=None, n_tracks=None, vectorized=False,
                  layout="soa", device_callables=False):
-        for name, fn in (("sqrt_fn", sqrt_fn), ("x_mean_fn", x_mean_fn), ("z_mean_fn", z_mean_fn),
-                         ("residual_x", residual_x), ("residual_z", residual_z), ("state_add", state_add)):
-            if fn is not None and fn not in (np.subtract, np.add):
-                raise NotImplementedError(f"custom {name} callables cannot run inside the HIP kernels")
         if device_callables and n_tracks is None:
             raise ValueError("device_callables=True needs a bank: pass n_tracks=N (use N = 1 for one filter)")
         self._dim_x, self._dim_z = dim_x, dim_z
@@ -61,12 +69,15 @@ class UnscentedKalmanFilter(object):
         self._num_sigmas = points.num_sigmas()
         self.hx, self.fx = hx, fx
         self.x_mean, self.z_mean = x_mean_fn, z_mean_fn
+        self._mode = "torch" if device_callables else ("vec" if vectorized else "loop")
         self._log_likelihood = log(sys.float_info.min)
         self._likelihood = sys.float_info.min
         self._mahalanobis = None
-        self.msqrt = None
+        self.msqrt = sqrt_fn                  # kept, never used: UKF.py:318-321
         self.Wm, self.Wc = points.Wm, points.Wc
-        self.residual_x, self.residual_z, self.state_add = np.subtract, np.subtract, np.add
+        self.residual_x = np.subtract if residual_x is None else residual_x
+        self.residual_z = np.subtract if residual_z is None else residual_z
+        self.state_add = np.add if state_add is None else state_add
         self.sigmas_f = np.zeros(((self._num_sigmas, dim_x) if n_tracks is None
                                  else (n_tracks, self._num_sigmas, dim_x)))
         self.sigmas_h = np.zeros(((self._num_sigmas, dim_z) if n_tracks is None
@@ -97,22 +108,89 @@ class UnscentedKalmanFilter(object):
         return a if self._N is not None else a[0]
 
     # ------------------------------------------------- device-resident split path --
+    @property
+    def _hooked(self):
+        """any constructor hook that is not the reference's default (attributes may be reassigned after construction)"""
+        pf = self.points_fn
+        return (self.x_mean is not None or self.z_mean is not None or self.residual_x is not np.subtract
+                or self.residual_z is not np.subtract or self.state_add is not np.add
+                or getattr(pf, "_sqrt", None) is not None or getattr(pf, "_subtract", None) is not None)
+
+    @property
+    def _resident(self):
+        return self._devcall or self._hooked
+
     def _rec_view(self, rec, k, d):
         """device records of N (k x d) blocks -> torch view (N, k, d), no copy"""
-        N = self._N
+        N = self._N or 1
         if self._layout == "aos":
             return rec.view(N, k, d)
         return rec.view(k, d, N).permute(2, 0, 1)
 
+    def _vec_view(self, rec, d):
+        return self._rec_view(rec, 1, d)[:, 0, :]
+
     def _to_rec(self, t, k, d):
         """torch tensor (N, k, d) as the callable returned it -> device records in the bank's layout"""
         import torch
-        N = self._N
-        if not isinstance(t, torch.Tensor) or not t.is_cuda or t.dtype != torch.float64 or tuple(t.shape) != (N, k, d):
+        N = self._N or 1
+        if (not isinstance(t, torch.Tensor) or t.device.type != E.require_gpu().type or t.dtype != torch.float64
+                or tuple(t.shape) != (N, k, d)):
             raise TypeError(f"device callables must return a float64 CUDA tensor shaped {(N, k, d)}")
         if self._layout == "aos":
             return t.contiguous().view(N, k * d)
         return t.permute(1, 2, 0).contiguous().view(k * d, N)
+
+    @staticmethod
+    def _tt(a, like):
+        import torch
+        return torch.as_tensor(np.array(a, dtype=np.float64, order="C"), device=like.device)
+
+    def _user(self, fn, sig, *args, **kw):
+        """fx / hx on a (N, k, d) device tensor, in the mode's calling convention"""
+        import torch
+        if not callable(fn):                                   # a matrix: linear model
+            return torch.matmul(sig, E.dev(np.asarray(fn, dtype=np.float64)).T)
+        if self._mode == "torch":
+            return fn(sig, *args, **kw)
+        return self._tt(self._apply(fn, sig.cpu().numpy(), *args, **kw), sig)
+
+    def _pair(self, fn, default, a, b):
+        """residual_x / residual_z / state_add / subtract: a (N, [k,] d), b (N, d) device tensors -> like a"""
+        bb = b.unsqueeze(1) if a.dim() == 3 else b
+        if fn is default:
+            return a - bb if default is not np.add else a + bb
+        if self._mode == "torch":
+            return fn(a, bb)
+        an, bn = a.cpu().numpy(), bb.cpu().numpy()
+        if self._mode == "vec":
+            return self._tt(np.broadcast_to(fn(an, bn), an.shape), a)
+        out = np.empty(an.shape)
+        if an.ndim == 3:
+            for i in range(an.shape[0]):
+                for j in range(an.shape[1]):
+                    out[i, j] = fn(an[i, j].copy(), bn[i, 0].copy())
+        else:
+            for i in range(an.shape[0]):
+                out[i] = fn(an[i].copy(), bn[i].copy())
+        return self._tt(out, a)
+
+    def _mean(self, fn, sig):
+        """x_mean_fn / z_mean_fn on (N, k, d) -> (N, d)"""
+        if self._mode == "torch":
+            return fn(sig, E.dev(np.asarray(self.Wm, dtype=np.float64)))
+        sn = sig.cpu().numpy()
+        if self._mode == "vec":
+            return self._tt(fn(sn, self.Wm), sig)
+        return self._tt(np.array([fn(sn[i].copy(), self.Wm) for i in range(sn.shape[0])]), sig)
+
+    def _sqrt(self, fn, A):
+        if self._mode == "torch":
+            return fn(A)
+        An = A.cpu().numpy()
+        if self._mode == "vec":
+            return self._tt(fn(An), A)
+        return self._tt(np.array([fn(An[i].copy()) for i in range(An.shape[0])]), A)
 
     def _dev_consts(self):
         n, m = self._dim_x, self._dim_z
@@ -120,40 +198,139 @@ class UnscentedKalmanFilter(object):
                     Q=E.dev(np.broadcast_to(np.asarray(self.Q, dtype=np.float64), (n, n)).copy()),
                     R=E.dev(np.broadcast_to(np.asarray(self.R, dtype=np.float64), (m, m)).copy()))
 
+    def _dev_sigmas(self, dx, dP, sig, st):
+        """points_fn.sigma_points on device records.  Custom sqrt_method / subtract (sigma_points.py:106-116, :168-175):
+        U = sqrt(scale P) by the caller's function -- or, with only `subtract` custom, read off the kernel's points of a
+        zero mean (0 + u = u exactly) -- then sigma_{k+1} = subtract(x, -U[k]), sigma_{n+k+1} = subtract(x, U[k])."""
+        import torch
+        n, k, N, lay = self._dim_x, self._num_sigmas, self._N or 1, self._layout
+        pf = self.points_fn
+        sq, sb = getattr(pf, "_sqrt", None), getattr(pf, "_subtract", None)
+        if sq is None and sb is None:
+            E.ut_sigma_points(n, N, lay, pf.scale, dx, dP, sig, st)
+            return
+        x = self._vec_view(dx, n)
+        if sq is None:
+            E.ut_sigma_points(n, N, lay, pf.scale, torch.zeros_like(dx), dP, sig, st)
+            U = self._rec_view(sig, k, n)[:, 1:n + 1, :].clone()
+        else:
+            U = self._sqrt(sq, pf.scale * self._rec_view(dP, n, n))
+        sub = np.subtract if sb is None else sb
+        pts = torch.cat([x.unsqueeze(1), self._sub_from(sub, x, -U), self._sub_from(sub, x, U)], 1)
+        sig.copy_(self._to_rec(pts, k, n).reshape(sig.shape))
+
+    def _sub_from(self, fn, x, U):
+        """subtract(x, U[k]) for every row k: x (N, n), U (N, n, n) -> (N, n, n)"""
+        xx = x.unsqueeze(1)
+        if fn is np.subtract:
+            return xx - U
+        if self._mode == "torch":
+            return fn(xx, U)
+        xn, Un = xx.cpu().numpy(), U.cpu().numpy()
+        if self._mode == "vec":
+            return self._tt(np.broadcast_to(fn(xn, Un), Un.shape), U)
+        out = np.empty(Un.shape)
+        for i in range(Un.shape[0]):
+            for j in range(Un.shape[1]):
+                out[i, j] = fn(xn[i, 0].copy(), Un[i, j].copy())
+        return self._tt(out, U)
+
+    def _dev_ut(self, s_rec, k, d, Wm, Wc, noise, mean_fn, res_fn, x_out, P_out):
+        """unscented_transform (unscented_transform.py:101-126) on device records; with a custom mean / residual the
+        residuals are formed by the callables and summed by the cross kernel in the reference loop's order."""
+        N, lay = self._N or 1, self._layout
+        if mean_fn is None and res_fn is np.subtract:
+            E.ut_transform(d, k, N, lay, s_rec, Wm, Wc, noise, x_out, P_out)
+            return
+        s = self._rec_view(s_rec, k, d)
+        if mean_fn is None:
+            E.ut_transform(d, k, N, lay, s_rec, Wm, Wc, None, x_out, P_out)      # x = Wm . sigmas; P rewritten below
+        else:
+            x_out.copy_(self._to_rec(self._mean(mean_fn, s).unsqueeze(1), 1, d).reshape(x_out.shape))
+        y = self._to_rec(self._pair(res_fn, np.subtract, s, self._vec_view(x_out, d)), k, d)
+        E.ut_cross_variance(d, d, k, N, lay, None, None, y, y, Wc, P_out)
+        if noise is not None:
+            self._rec_view(P_out, d, d).add_(noise.view(d, d))
+
     def _dev_predict(self, dx, dP, c, dt, st, fx=None, **fx_args):
         """UKF.py:400-411 on device records; returns the regenerated sigma points (records)."""
-        n, k, N, lay = self._dim_x, self._num_sigmas, self._N, self._layout
+        n, k, N, lay = self._dim_x, self._num_sigmas, self._N or 1, self._layout
         fx = self.fx if fx is None else fx
         sig = E.alloc_records((), N, k * n, lay)
-        E.ut_sigma_points(n, N, lay, self.points_fn.scale, dx, dP, sig, st)
-        if callable(fx):
-            sf = self._to_rec(fx(self._rec_view(sig, k, n), dt, **fx_args), k, n)
-        else:
-            import torch
-            sf = self._to_rec(torch.matmul(self._rec_view(sig, k, n), E.dev(np.asarray(fx, dtype=np.float64)).T), k, n)
-        E.ut_transform(n, k, N, lay, sf, c["Wm"], c["Wc"], c["Q"], dx, dP)
-        E.ut_sigma_points(n, N, lay, self.points_fn.scale, dx, dP, sig, st)      # UKF.py:407
+        self._dev_sigmas(dx, dP, sig, st)
+        sv = self._rec_view(sig, k, n)
+        sf = self._to_rec(self._user(fx, sv, dt, **fx_args) if callable(fx) else self._user(fx, sv), k, n)
+        self._dev_ut(sf, k, n, c["Wm"], c["Wc"], c["Q"], self.x_mean, self.residual_x, dx, dP)
+        self._dev_sigmas(dx, dP, sig, st)                                         # UKF.py:407
         return sig
 
     def _dev_update(self, dx, dP, sig, dz, c, st, dK=None, hx=None, R=None, **hx_args):
         """UKF.py:462-481 on device records (sig = the sigma points the predict left behind)."""
-        n, m, k, N, lay = self._dim_x, self._dim_z, self._num_sigmas, self._N, self._layout
+        import torch
+        n, m, k, N, lay = self._dim_x, self._dim_z, self._num_sigmas, self._N or 1, self._layout
         hx = self.hx if hx is None else hx
-        if callable(hx):
-            sh = self._to_rec(hx(self._rec_view(sig, k, n), **hx_args), k, m)
-        else:
-            import torch
-            sh = self._to_rec(torch.matmul(self._rec_view(sig, k, n), E.dev(np.asarray(hx, dtype=np.float64)).T), k, m)
+        sh = self._to_rec(self._user(hx, self._rec_view(sig, k, n), **hx_args), k, m)
         zp, S = E.alloc_records((), N, m, lay), E.alloc_records((), N, m * m, lay)
-        E.ut_transform(m, k, N, lay, sh, c["Wm"], c["Wc"], c["R"] if R is None else R, zp, S)
+        self._dev_ut(sh, k, m, c["Wm"], c["Wc"], c["R"] if R is None else R, self.z_mean, self.residual_z, zp, S)
         Pxz = E.alloc_records((), N, n * m, lay)
-        E.ut_cross_variance(n, m, k, N, lay, dx, zp, sig, sh, c["Wc"], Pxz)
-        E.ukf_correct(n, m, N, lay, Pxz, zp, S, dz, dx, dP, dK, st)
+        rx, rz = self.residual_x, self.residual_z
+        if rx is np.subtract and rz is np.subtract:
+            E.ut_cross_variance(n, m, k, N, lay, dx, zp, sig, sh, c["Wc"], Pxz)
+        else:
+            ex = self._to_rec(self._pair(rx, np.subtract, self._rec_view(sig, k, n), self._vec_view(dx, n)), k, n)
+            ez = self._to_rec(self._pair(rz, np.subtract, self._rec_view(sh, k, m), self._vec_view(zp, m)), k, m)
+            E.ut_cross_variance(n, m, k, N, lay, None, None, ex, ez, c["Wc"], Pxz)
+        zin, zpin = dz, zp
+        if rz is not np.subtract:                                                 # y = residual_z(z, zp)  (UKF.py:474)
+            y = self._pair(rz, np.subtract, self._vec_view(dz, m), self._vec_view(zp, m))
+            zin, zpin = self._to_rec(y.unsqueeze(1), 1, m).reshape(dz.shape), None
+        if self.state_add is np.add:
+            E.ukf_correct(n, m, N, lay, Pxz, zpin, S, zin, dx, dP, dK, st)
+        else:                                                                     # x = state_add(x, K y)  (UKF.py:477)
+            x_old = self._vec_view(dx, n).clone()
+            Ky = torch.zeros_like(dx)
+            E.ukf_correct(n, m, N, lay, Pxz, zpin, S, zin, Ky, dP, dK, st)
+            xn = self._pair(self.state_add, np.add, x_old, self._vec_view(Ky, n))
+            dx.copy_(self._to_rec(xn.unsqueeze(1), 1, n).reshape(dx.shape))
         return sh, zp, S
+
+    def _res_predict(self, dt, fx, **fx_args):
+        """predict() with state resident for the step (device callables and / or hooks)"""
+        import torch
+        n, k, N, lay = self._dim_x, self._num_sigmas, self._N or 1, self._layout
+        dx, dP = E.to_records(self._b(self.x, (n,)), lay, 0), E.to_records(self._b(self.P, (n, n)), lay, 0)
+        st = torch.zeros(N, dtype=torch.int32, device=dx.device)
+        self._sig_dev = self._dev_predict(dx, dP, self._dev_consts(), dt, st, fx, **fx_args)
+        E.raise_on_status(st, "UnscentedKalmanFilter.predict")
+        self.x, self.P = self._unb(E.from_records(dx, lay, 0, (n,))), self._unb(E.from_records(dP, lay, 0, (n, n)))
+        self.sigmas_f = self._unb(E.from_records(self._sig_dev, lay, 0, (k, n)))
+        self.x_prior, self.P_prior = np.copy(self.x), np.copy(self.P)
+
+    def _res_update(self, z, R, hx, **hx_args):
+        import torch
+        n, m, k, N, lay = self._dim_x, self._dim_z, self._num_sigmas, self._N or 1, self._layout
+        dx, dP = E.to_records(self._b(self.x, (n,)), lay, 0), E.to_records(self._b(self.P, (n, n)), lay, 0)
+        sig = E.to_records(np.asarray(self.sigmas_f, dtype=np.float64).reshape(N, k, n), lay, 0)
+        zb = np.asarray(z, dtype=np.float64).reshape(N, m)
+        dz, dK = E.to_records(zb, lay, 0), E.alloc_records((), N, n * m, lay)
+        st = torch.zeros(N, dtype=torch.int32, device=dx.device)
+        c = self._dev_consts()
+        Rd = None if R is None else E.dev(np.eye(m) * R if np.isscalar(R) else np.broadcast_to(np.asarray(R, dtype=np.float64), (m, m)).copy())
+        sh, zp, S = self._dev_update(dx, dP, sig, dz, c, st, dK=dK, hx=hx, R=Rd, **hx_args)
+        E.raise_on_status(st, "UnscentedKalmanFilter.update")
+        zpn, Sn = E.from_records(zp, lay, 0, (m,)), E.from_records(S, lay, 0, (m, m))
+        self.sigmas_h = self._unb(E.from_records(sh, lay, 0, (k, m)))
+        self.S, self.SI = self._unb(Sn), self._unb(np.linalg.inv(Sn))
+        self.K = self._unb(E.from_records(dK, lay, 0, (n, m)))
+        if self.residual_z is np.subtract:
+            self.y = self._unb(zb - zpn)
+        else:
+            self.y = self._unb(self._pair(self.residual_z, np.subtract, self._vec_view(dz, m), self._vec_view(zp, m)).cpu().numpy())
+        self.x, self.P = self._unb(E.from_records(dx, lay, 0, (n,))), self._unb(E.from_records(dP, lay, 0, (n, n)))
 
     def _dev_batch_filter(self, zs, Rs, dts, device_outputs):
         import torch
-        n, m, N, lay = self._dim_x, self._dim_z, self._N, self._layout
+        n, m, N, lay = self._dim_x, self._dim_z, self._N or 1, self._layout
         T = len(zs)
         c = self._dev_consts()
         dx, dP = E.to_records(self._b(self.x, (n,)), lay, 0), E.to_records(self._b(self.P, (n, n)), lay, 0)
@@ -180,16 +357,29 @@ class UnscentedKalmanFilter(object):
             means[t].copy_(dx.reshape(means[t].shape))      # (aos records keep the host array's trailing shape)
             covs[t].copy_(dP.reshape(covs[t].shape))
         E.raise_on_status(st, "UnscentedKalmanFilter.batch_filter")
-        self.x, self.P = E.from_records(dx, lay, 0, (n,)), E.from_records(dP, lay, 0, (n, n))
+        self.x, self.P = self._unb(E.from_records(dx, lay, 0, (n,))), self._unb(E.from_records(dP, lay, 0, (n, n)))
         if device_outputs:
             return means, covs
-        return E.from_records(means, lay, 1, (n,)), E.from_records(covs, lay, 1, (n, n))
+        mu, cov = E.from_records(means, lay, 1, (n,)), E.from_records(covs, lay, 1, (n, n))
+        return (mu, cov) if self._N is not None else (mu[:, 0], cov[:, 0])
 
     # ---------------------------------------------------------------- predict --
     def compute_process_sigmas(self, dt, fx=None, **fx_args):
         """UKF.py:506-522."""
         fx = self.fx if fx is None else fx
         n = self._dim_x
+        if self._resident:
+            import torch
+            k, N, lay = self._num_sigmas, self._N or 1, self._layout
+            dx, dP = E.to_records(self._b(self.x, (n,)), lay, 0), E.to_records(self._b(self.P, (n, n)), lay, 0)
+            st = torch.zeros(N, dtype=torch.int32, device=dx.device)
+            sig = E.alloc_records((), N, k * n, lay)
+            self._dev_sigmas(dx, dP, sig, st)
+            E.raise_on_status(st, "UnscentedKalmanFilter.compute_process_sigmas")
+            sv = self._rec_view(sig, k, n)
+            sf = self._to_rec(self._user(fx, sv, dt, **fx_args) if callable(fx) else self._user(fx, sv), k, n)
+            self.sigmas_f = self._unb(E.from_records(sf, lay, 0, (k, n)))
+            return
         sig = self.points_fn.sigma_points(self._b(self.x, (n,)), self._b(self.P, (n, n)))
         sf = self._apply(fx, sig, dt, **fx_args) if callable(fx) else self._apply(fx, sig)
         self.sigmas_f = self._unb(sf)
@@ -201,6 +391,8 @@ class UnscentedKalmanFilter(object):
             raise NotImplementedError("custom UT callables are not supported")
         dt = self._dt if dt is None else dt
         n = self._dim_x
+        if self._resident:
+            return self._res_predict(dt, fx, **fx_args)
         self.compute_process_sigmas(dt, fx, **fx_args)
         sf = np.asarray(self.sigmas_f).reshape(-1, self._num_sigmas, n)
         x, P = unscented_transform(sf, self.Wm, self.Wc, self.Q, layout=self._layout)
@@ -222,6 +414,12 @@ class UnscentedKalmanFilter(object):
         hx = self.hx if hx is None else hx
         n, m, k = self._dim_x, self._dim_z, self._num_sigmas
         N = self._N or 1
+        if self._resident:
+            self._res_update(z, R, hx, **hx_args)
+            self.z = deepcopy(z)
+            self.x_post, self.P_post = np.copy(self.x), np.copy(self.P)
+            self._log_likelihood = self._likelihood = self._mahalanobis = None
+            return
         if R is None:
             R = self.R
         elif np.isscalar(R):
@@ -259,6 +457,14 @@ class UnscentedKalmanFilter(object):
         n, m, k = sigmas_f.shape[1], sigmas_h.shape[1], sigmas_f.shape[0]
         lay = self._layout
         out = E.alloc_records((), 1, n * m, lay)
+        if self.residual_x is not np.subtract or self.residual_z is not np.subtract:
+            if self._mode != "loop":
+                raise ValueError("cross_variance() is the reference's one-filter call: hooks in the per-vector convention")
+            ex = np.array([self.residual_x(np.array(s, dtype=np.float64), np.array(x, dtype=np.float64)) for s in sigmas_f])
+            ez = np.array([self.residual_z(np.array(s, dtype=np.float64), np.array(z, dtype=np.float64)) for s in sigmas_h])
+            E.ut_cross_variance(n, m, k, 1, lay, None, None, E.to_records(ex[None], lay, 0), E.to_records(ez[None], lay, 0),
+                                E.dev(np.asarray(self.Wc, dtype=np.float64)), out)
+            return E.from_records(out, lay, 0, (n, m))[0]
         E.ut_cross_variance(n, m, k, 1, lay, E.to_records(np.reshape(x, (1, n)), lay, 0),
                             E.to_records(np.reshape(z, (1, m)), lay, 0),
                             E.to_records(np.asarray(sigmas_f)[None], lay, 0),
@@ -274,7 +480,7 @@ class UnscentedKalmanFilter(object):
         import torch
         from .unscented_transform import unscented_transform
         n, m = self._dim_x, self._dim_z
-        if self._devcall and saver is None:
+        if self._resident and saver is None:
             if UT is not None and UT is not unscented_transform:
                 raise NotImplementedError("custom UT callables are not supported")
             return self._dev_batch_filter(zs, Rs, dts, device_outputs)
@@ -330,14 +536,16 @@ class UnscentedKalmanFilter(object):
         [T][N][..]), every step is sigma_kernel -> fx -> ut_kernel -> cross_kernel -> ukf_rts_kernel on device
         records, and only the results come back."""
         import torch
-        n, k, N, lay = self._dim_x, self._num_sigmas, self._N, self._layout
+        n, k, N, lay = self._dim_x, self._num_sigmas, self._N or 1, self._layout
         c = self._dev_consts()
+        single_shape = None
         if isinstance(Xs, torch.Tensor):
             dXs, dPs = Xs, Ps
             T = int(Xs.shape[0])
         else:
             Xs = np.asarray(Xs, dtype=np.float64)
             T = Xs.shape[0]
+            single_shape = Xs.shape if self._N is None else None
             dXs = E.to_records(Xs.reshape(T, N, n), lay, 1)
             dPs = E.to_records(np.asarray(Ps, dtype=np.float64).reshape(T, N, n, n), lay, 1)
         if dts is None:
@@ -349,19 +557,29 @@ class UnscentedKalmanFilter(object):
         sig = E.alloc_records((), N, k * n, lay)
         xb, Pb, Pxb = E.alloc_records((), N, n, lay), E.alloc_records((), N, n * n, lay), E.alloc_records((), N, n * n, lay)
         st = torch.zeros(N, dtype=torch.int32, device=xs.device)
+        rx = self.residual_x
         for j in reversed(range(T - 1)):
-            E.ut_sigma_points(n, N, lay, self.points_fn.scale, xs[j], ps[j], sig, st)
-            if callable(self.fx):
-                sf = self._to_rec(self.fx(self._rec_view(sig, k, n), dts[j]), k, n)
-            else:
-                sf = self._to_rec(torch.matmul(self._rec_view(sig, k, n), E.dev(np.asarray(self.fx, dtype=np.float64)).T), k, n)
-            E.ut_transform(n, k, N, lay, sf, c["Wm"], c["Wc"], c["Q"], xb, Pb)
-            E.ut_cross_variance(n, n, k, N, lay, dXs[j], xb, sig, sf, c["Wc"], Pxb)
-            E.ukf_rts_correct(n, N, lay, Pxb, xb, Pb, xs[j + 1], ps[j + 1], xs[j], ps[j], Ks[j], st)
+            self._dev_sigmas(xs[j], ps[j], sig, st)
+            sv = self._rec_view(sig, k, n)
+            sf = self._to_rec(self._user(self.fx, sv, dts[j]) if callable(self.fx) else self._user(self.fx, sv), k, n)
+            self._dev_ut(sf, k, n, c["Wm"], c["Wc"], c["Q"], self.x_mean, rx, xb, Pb)
+            if rx is np.subtract:
+                E.ut_cross_variance(n, n, k, N, lay, dXs[j], xb, sig, sf, c["Wc"], Pxb)
+                E.ukf_rts_correct(n, N, lay, Pxb, xb, Pb, xs[j + 1], ps[j + 1], xs[j], ps[j], Ks[j], st)
+            else:                        # UKF.py:722-731 with a custom residual_x: z around Xs[k], y around xb, x[k+1] - xb
+                ez = self._to_rec(self._pair(rx, np.subtract, sv, self._vec_view(dXs[j], n)), k, n)
+                ey = self._to_rec(self._pair(rx, np.subtract, self._rec_view(sf, k, n), self._vec_view(xb, n)), k, n)
+                E.ut_cross_variance(n, n, k, N, lay, None, None, ez, ey, c["Wc"], Pxb)
+                dn = self._pair(rx, np.subtract, self._vec_view(xs[j + 1], n), self._vec_view(xb, n))
+                E.ukf_rts_correct(n, N, lay, Pxb, None, Pb, self._to_rec(dn.unsqueeze(1), 1, n).reshape(xb.shape), ps[j + 1],
+                                  xs[j], ps[j], Ks[j], st)
         E.raise_on_status(st, "UnscentedKalmanFilter.rts_smoother")
         if device_outputs:
             return xs, ps, Ks
-        return E.from_records(xs, lay, 1, (n,)), E.from_records(ps, lay, 1, (n, n)), E.from_records(Ks, lay, 1, (n, n))
+        out = E.from_records(xs, lay, 1, (n,)), E.from_records(ps, lay, 1, (n, n)), E.from_records(Ks, lay, 1, (n, n))
+        if single_shape is not None:
+            return out[0][:, 0].reshape(single_shape), out[1][:, 0], out[2][:, 0]
+        return out
 
     def rts_smoother(self, Xs, Ps, Qs=None, dts=None, UT=None, device_outputs=False):
         """UKF.py:634-739: backward pass over the filter output.  Per step k (from the end): sigma
@@ -376,7 +594,7 @@ class UnscentedKalmanFilter(object):
             raise NotImplementedError("custom UT callables are not supported")
         if len(Xs) != len(Ps):
             raise ValueError('Xs and Ps must have the same length')
-        if self._devcall:
+        if self._resident:
             return self._dev_rts_smoother(Xs, Ps, dts, device_outputs)
         if not callable(self.fx) and dts is None and self._dim_x <= 6 and not isinstance(Xs, torch.Tensor):
             # linear fx given as a matrix: the whole backward loop is ONE fused launch (fk_ukf_linear_rts_f64)

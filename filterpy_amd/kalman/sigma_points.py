@@ -29,13 +29,53 @@ def _sigma_points_gpu(n, scale, x, P, layout="soa"):
     return out if batched else out[0]
 
 
-class MerweScaledSigmaPoints(object):
+def _sigma_points_hooked(n, scale, x, P, sqrt, subtract):
+    """sigma_points.py:165-175 / :343-355 with the constructor's sqrt_method / subtract, per filter like the reference:
+    U = sqrt(scale P) -- the caller's function, or (only `subtract` custom) the rows the kernel adds to a zero mean --
+    then sigma_0 = x, sigma_{k+1} = subtract(x, -U[k]), sigma_{n+k+1} = subtract(x, U[k]).
+    (Whole-bank conventions for these callables live with the filter: UnscentedKalmanFilter(vectorized= / device_callables=).)"""
+    x = np.asarray(x, dtype=np.float64)
+    batched = x.ndim == 2
+    xb = x.reshape(-1, n)
+    N = xb.shape[0]
+    if np.isscalar(P) or np.ndim(P) == 0:
+        Pb = np.broadcast_to(np.eye(n) * P, (N, n, n))
+    else:
+        Pb = np.broadcast_to(np.atleast_2d(np.asarray(P, dtype=np.float64)), (N, n, n))
+    if sqrt is None:
+        U = _sigma_points_gpu(n, scale, np.zeros((N, n)), Pb)[:, 1:n + 1, :]
+    else:
+        U = np.array([sqrt(scale * Pb[i]) for i in range(N)], dtype=np.float64)
+    sub = np.subtract if subtract is None else subtract
+    out = np.zeros((N, 2 * n + 1, n))
+    for i in range(N):
+        out[i, 0] = xb[i]
+        for k in range(n):
+            out[i, k + 1] = sub(xb[i].copy(), -U[i, k])
+            out[i, n + k + 1] = sub(xb[i].copy(), U[i, k].copy())
+    return out if batched else out[0]
+
+
+class _Hooks(object):
+    """sqrt_method / subtract of the reference constructors (sigma_points.py:106-116, :271-281)"""
+
+    def _set_hooks(self, sqrt_method, subtract):
+        self._sqrt = sqrt_method            # None = upper Cholesky factor inside the kernel (scipy.linalg.cholesky's convention)
+        self._subtract = None if subtract is np.subtract else subtract
+        self.sqrt = sqrt_method
+        self.subtract = np.subtract if subtract is None else subtract
+
+    def _points(self, scale, x_arr, P):
+        if self._sqrt is None and self._subtract is None:
+            return _sigma_points_gpu(self.n, scale, np.atleast_1d(x_arr), P)
+        return _sigma_points_hooked(self.n, scale, np.atleast_1d(x_arr), P, self._sqrt, self._subtract)
+
+
+class MerweScaledSigmaPoints(_Hooks):
     """filterpy/kalman/sigma_points.py:24-208."""
 
     def __init__(self, n, alpha, beta, kappa, sqrt_method=None, subtract=None):
-        if sqrt_method is not None or subtract is not None:
-            raise NotImplementedError("custom sqrt_method / subtract callables cannot run inside the HIP "
-                                      "kernel; only the defaults (Cholesky, numpy.subtract) are supported")
+        self._set_hooks(sqrt_method, subtract)
         self.n, self.alpha, self.beta, self.kappa = n, alpha, beta, kappa
         self._compute_weights()
 
@@ -48,7 +88,7 @@ class MerweScaledSigmaPoints(object):
         if (x_arr.ndim <= 1 and self.n != np.size(x)) or (x_arr.ndim == 2 and x_arr.shape[1] != self.n):
             raise ValueError("expected size(x) {}, but size is {}".format(self.n, np.size(x)))
         lambda_ = self.alpha ** 2 * (self.n + self.kappa) - self.n
-        return _sigma_points_gpu(self.n, lambda_ + self.n, np.atleast_1d(x_arr), P)
+        return self._points(lambda_ + self.n, x_arr, P)
 
     def _compute_weights(self):
         """sigma_points.py:180-192."""
@@ -69,12 +109,11 @@ class MerweScaledSigmaPoints(object):
         return lambda_ + self.n
 
 
-class JulierSigmaPoints(object):
+class JulierSigmaPoints(_Hooks):
     """filterpy/kalman/sigma_points.py:211-383."""
 
     def __init__(self, n, kappa=0., sqrt_method=None, subtract=None):
-        if sqrt_method is not None or subtract is not None:
-            raise NotImplementedError("custom sqrt_method / subtract callables are not supported")
+        self._set_hooks(sqrt_method, subtract)
         self.n, self.kappa = n, kappa
         self._compute_weights()
 
@@ -85,7 +124,7 @@ class JulierSigmaPoints(object):
         x_arr = np.asarray(x, dtype=np.float64)
         if (x_arr.ndim <= 1 and self.n != np.size(x)) or (x_arr.ndim == 2 and x_arr.shape[1] != self.n):
             raise ValueError("expected size(x) {}, but size is {}".format(self.n, np.size(x)))
-        return _sigma_points_gpu(self.n, self.n + self.kappa, np.atleast_1d(x_arr), P)
+        return self._points(self.n + self.kappa, x_arr, P)
 
     def _compute_weights(self):
         """sigma_points.py:360-372."""

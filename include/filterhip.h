@@ -192,7 +192,10 @@ int fk_ut_transform_f64(int32_t n, int32_t k, int64_t N, int32_t layout,
 
 /* UnscentedKalmanFilter.cross_variance (filterpy/kalman/UKF.py:493-504), default residuals:
  *   Pxz = sum_i Wc[i] (sigmas_f[i]-x)(sigmas_h[i]-z)'.
- *   sigmas_f [N][k*n], sigmas_h [N][k*m], x [N][n], z [N][m] -> Pxz [N][n*m]. */
+ *   sigmas_f [N][k*n], sigmas_h [N][k*m], x [N][n], z [N][m] -> Pxz [N][n*m].
+ * Custom residual_x / residual_z callables (UKF.py:500-501; unscented_transform.py:120-123 is the same sum with
+ * sigmas_f = sigmas_h = the residuals): the caller applies them and passes x = NULL and / or z = NULL -- that
+ * operand then already holds dx (dz) and nothing is subtracted; the accumulation order is the reference loop's. */
 int fk_ut_cross_variance_f64(int32_t n, int32_t m, int32_t k, int64_t N, int32_t layout,
                              const double *x, const double *z,
                              const double *sigmas_f, const double *sigmas_h,
@@ -201,7 +204,9 @@ int fk_ut_cross_variance_f64(int32_t n, int32_t m, int32_t k, int64_t N, int32_t
 /* The correction at the end of UnscentedKalmanFilter.update (filterpy/kalman/UKF.py:470-481) for
  * arbitrary measurement functions:  K = Pxz S^-1 (Cholesky solve) ; x += K (z - zp) ; P -= K (S K').
  *   Pxz [N][n*m], zp [N][m], S [N][m*m], z [N][m] ; x [N][n], P [N][n*n] updated in place ;
- *   K [N][n*m] out (may be NULL) ; status [N] or NULL.   dim_x 1..16, dim_z 1..8. */
+ *   K [N][n*m] out (may be NULL) ; status [N] or NULL.   dim_x 1..16, dim_z 1..8.
+ * zp = NULL: z already holds y = residual_z(z, zp) (UKF.py:474 with a custom callable).  For a custom state_add
+ * (UKF.py:477) pass x = 0 and read back K y. */
 int fk_ukf_correct_f64(int32_t n, int32_t m, int64_t N, int32_t layout,
                        const double *Pxz, const double *zp, const double *S, const double *z,
                        double *x, double *P, double *K, int32_t *status, void *stream);
@@ -278,6 +283,7 @@ int fk_kf_update_correlated_f64(const fk_kf_desc *desc,
  *   xb [N][n], Pb [N][n*n] (unscented transform of the propagated sigma points + Q),
  *   xn [N][n], Pn [N][n*n] (smoothed step k+1); x [N][n], P [N][n*n]: filtered step k in, smoothed out;
  *   K [N][n*n] out (may be NULL); status [N] or NULL.  dim_x 1..9.
+ * xb = NULL: xn already holds residual_x(xs[k+1], xb) (UKF.py:731 with a custom callable).
  * The sigma points, their transform and the cross variance are fk_ut_sigma_points_f64,
  * fk_ut_transform_f64 and fk_ut_cross_variance_f64. */
 int fk_ukf_rts_correct_f64(int32_t n, int64_t N, int32_t layout,

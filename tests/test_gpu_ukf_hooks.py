@@ -1,0 +1,118 @@
+"""UKF constructor hooks on the GPU (UKF.py:284-340, sigma_points.py:99-116, unscented_transform.py:105-123): the
+residual-input modes of fk_ut_cross_variance_f64 / fk_ukf_correct_f64 / fk_ukf_rts_correct_f64 and the whole hooked
+filter + smoother in the three calling conventions, against the numbers frozen from the live reference
+(tests/golden/ukf_hooks.npz, a heading tracked across the +-pi wrap) at the stated 1e-10."""
+import numpy as np
+import pytest
+
+import ukf_hook_model as hm
+from conftest import golden, rel_err_rows
+from oracle import ukf_oracle as uo
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-10
+
+
+@pytest.mark.parametrize("layout", ["soa", "aos"])
+@pytest.mark.parametrize("mode", ["loop", "vec", "torch"])
+def test_hooked_bank_matches_the_reference(mode, layout):
+    g = golden("ukf_hooks")
+    T, N = g["zs"].shape[:2]
+    kf = hm.make_filter(g, mode, layout, N)
+    kf.x, kf.P = g["x0"].copy(), g["P0"].copy()
+    mu, cov = kf.batch_filter([g["zs"][t] for t in range(T)])
+    keep = [i for i in range(N) if i != 1]                   # track 1 of the golden skips one measurement
+    assert rel_err_rows(mu[:, keep].reshape(-1, 3), g["mu"][:, keep].reshape(-1, 3)) < TOL
+    assert rel_err_rows(cov[:, keep].reshape(-1, 9), g["cov"][:, keep].reshape(-1, 9)) < TOL
+    xs, Ps, Ks = kf.rts_smoother(g["mu"], g["cov"])
+    assert rel_err_rows(xs.reshape(-1, 3), g["rts_x"].reshape(-1, 3)) < TOL
+    assert rel_err_rows(Ps.reshape(-1, 9), g["rts_P"].reshape(-1, 9)) < TOL
+    assert rel_err_rows(Ks[:-1].reshape(-1, 9), g["rts_K"][:-1].reshape(-1, 9)) < TOL
+
+
+def test_single_filter_step_api_with_hooks_and_missing_measurement():
+    from filterpy_amd.kalman import MerweScaledSigmaPoints, UnscentedKalmanFilter
+    g = golden("ukf_hooks")
+    T, i = g["zs"].shape[0], 1
+    pts = MerweScaledSigmaPoints(3, float(g["alpha"]), float(g["beta"]), float(g["kappa"]), sqrt_method=hm.sqrt_lower_t,
+                                 subtract=hm.sigma_subtract)
+    kf = UnscentedKalmanFilter(3, 2, float(g["dt"]), hm.hx, hm.fx, pts, x_mean_fn=hm.x_mean, z_mean_fn=hm.z_mean,
+                               residual_x=hm.residual_x, residual_z=hm.residual_z, state_add=hm.state_add)
+    kf.x, kf.P, kf.Q, kf.R = g["x0"][i].copy(), g["P0"][i].copy(), g["Q"], g["R"]
+    for t in range(T):
+        kf.predict()
+        kf.update(None if t == 4 else g["zs"][t, i])
+        assert rel_err_rows(kf.x[None], g["mu"][t, i][None]) < TOL
+        assert rel_err_rows(kf.P.reshape(1, -1), g["cov"][t, i].reshape(1, -1)) < TOL
+    assert np.isfinite(kf.log_likelihood) and kf.mahalanobis >= 0
+    xs, Ps, Ks = kf.rts_smoother(g["mu"][:, i], g["cov"][:, i])
+    assert rel_err_rows(xs, g["rts_x"][:, i]) < TOL and rel_err_rows(Ps.reshape(T, -1), g["rts_P"][:, i].reshape(T, -1)) < TOL
+
+
+def test_standalone_calls_and_partial_hooks():
+    from filterpy_amd.kalman import MerweScaledSigmaPoints, unscented_transform
+    g = golden("ukf_hooks")
+    alpha, beta, kappa, dt = float(g["alpha"]), float(g["beta"]), float(g["kappa"]), float(g["dt"])
+    pts = MerweScaledSigmaPoints(3, alpha, beta, kappa, subtract=hm.sigma_subtract)     # U from the Cholesky kernel
+    assert rel_err_rows(pts.sigma_points(g["x0"][0], g["P0"][0]), g["sigmas0"]) < 1e-13
+    pts2 = MerweScaledSigmaPoints(3, alpha, beta, kappa, sqrt_method=hm.sqrt_lower_t)   # caller's sqrt, plain subtraction
+    assert rel_err_rows(pts2.sigma_points(g["x0"], g["P0"])[2],
+                        uo.merwe_sigma_points(g["x0"][2], g["P0"][2], alpha, kappa, hm.sqrt_lower_t)) < 1e-15
+    sf = np.array([hm.fx(s, dt) for s in g["sigmas0"]])
+    x, P = unscented_transform(sf, g["Wm"], g["Wc"], g["Q"], hm.x_mean, hm.residual_x)
+    assert np.array_equal(x, g["ut_x"]) and rel_err_rows(P.reshape(1, -1), g["ut_P"].reshape(1, -1)) < 1e-14
+    x, P = unscented_transform(sf, g["Wm"], g["Wc"], g["Q"], hm.x_mean, None)
+    assert rel_err_rows(P.reshape(1, -1), g["ut_meanonly_P"].reshape(1, -1)) < 1e-13
+    x, P = unscented_transform(sf, g["Wm"], g["Wc"], g["Q"], None, hm.residual_x)       # kernel mean, caller's residual
+    xr, Pr = uo.unscented_transform(sf, g["Wm"], g["Wc"], g["Q"], None, hm.residual_x)
+    assert rel_err_rows(x[None], xr[None]) < 1e-14 and rel_err_rows(P.reshape(1, -1), Pr.reshape(1, -1)) < 1e-13
+
+
+@pytest.mark.parametrize("layout", ["soa", "aos"])
+@pytest.mark.parametrize("n,m", [(3, 2), (6, 3), (9, 4), (13, 5)])
+def test_residual_modes_of_the_entry_points(n, m, layout):
+    """x = z = NULL (cross variance), zp = NULL (correct), xb = NULL (rts): identical to the default mode fed the same
+    numbers as explicit differences -- bit for bit, since v - 0.0 is v"""
+    import torch
+    from filterpy_amd import _engine as E
+    N, k = 777, 2 * n + 1
+    rs = np.random.RandomState(n * 31 + m)
+    sf, sh = rs.randn(N, k, n), rs.randn(N, k, m)
+    x, z = rs.randn(N, n), rs.randn(N, m)
+    Wc = E.dev(rs.rand(k) - 0.3)
+    a, b = E.alloc_records((), N, n * m, layout), E.alloc_records((), N, n * m, layout)
+    R = lambda arr: E.to_records(arr, layout, 0)          # noqa: E731
+    E.ut_cross_variance(n, m, k, N, layout, R(x), R(z), R(sf), R(sh), Wc, a)
+    E.ut_cross_variance(n, m, k, N, layout, None, None, R(sf - x[:, None]), R(sh - z[:, None]), Wc, b)
+    assert torch.equal(a, b)
+    ref = np.array([uo.cross_variance(x[i], z[i], sf[i], sh[i], Wc.cpu().numpy()) for i in range(0, N, 97)])
+    assert rel_err_rows(E.from_records(a, layout, 0, (n, m))[::97].reshape(len(ref), -1), ref.reshape(len(ref), -1)) < 1e-13
+    if m <= 8:
+        A = rs.randn(N, m, m)
+        S = A @ A.transpose(0, 2, 1) + m * np.eye(m)
+        B = rs.randn(N, n, n)
+        P0 = B @ B.transpose(0, 2, 1) + n * np.eye(n)
+        zp = rs.randn(N, m)
+        outs = []
+        for resid in (False, True):
+            dx, dP, dK = R(x), R(P0), E.alloc_records((), N, n * m, layout)
+            st = torch.zeros(N, dtype=torch.int32, device=dx.device)
+            E.ukf_correct(n, m, N, layout, a, None if resid else R(zp), R(S), R(z - zp) if resid else R(z), dx, dP, dK, st)
+            assert not st.any()
+            outs.append((dx, dP, dK))
+        for u, v in zip(*outs):
+            assert torch.equal(u, v)
+    if n <= 9:
+        Bm = rs.randn(N, n, n)
+        Pb = Bm @ Bm.transpose(0, 2, 1) + n * np.eye(n)
+        Pn, Pxb, xb, xn = Pb + 0.1 * np.eye(n), rs.randn(N, n, n), rs.randn(N, n), rs.randn(N, n)
+        outs = []
+        for resid in (False, True):
+            dx, dP, dK = R(x), R(Pb * 0.9), E.alloc_records((), N, n * n, layout)
+            st = torch.zeros(N, dtype=torch.int32, device=dx.device)
+            E.ukf_rts_correct(n, N, layout, R(Pxb), None if resid else R(xb), R(Pb), R(xn - xb) if resid else R(xn), R(Pn),
+                              dx, dP, dK, st)
+            assert not st.any()
+            outs.append((dx, dP, dK))
+        for u, v in zip(*outs):
+            assert torch.equal(u, v)

@@ -118,5 +118,6 @@ def test_merwe_weights_host_side():
         assert pts.num_sigmas() == 2 * int(n) + 1
     jp = JulierSigmaPoints(4, 0.5)
     assert np.array_equal(jp.Wm, g["jul_Wm"])
-    with pytest.raises(NotImplementedError):
-        MerweScaledSigmaPoints(2, .1, 2., 1., sqrt_method=np.linalg.cholesky)
+    # constructor hooks are kept like the reference keeps them (sigma_points.py:106-116)
+    hp = MerweScaledSigmaPoints(2, .1, 2., 1., sqrt_method=np.linalg.cholesky)
+    assert hp.sqrt is np.linalg.cholesky and hp.subtract is np.subtract and pts.subtract is np.subtract

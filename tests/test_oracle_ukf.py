@@ -41,3 +41,34 @@ def test_julier():
     Wm, Wc = uo.julier_weights(4, 0.5)
     assert np.array_equal(Wm, g["jul_Wm"]) and np.array_equal(Wc, g["jul_Wc"])
     assert np.array_equal(uo.julier_sigma_points(g["jul_x0"], g["jul_P0"], 0.5), g["jul_sigmas"])
+
+
+def test_constructor_hooks_against_the_live_reference():
+    """every hook set (tests/ukf_hook_model.py; frozen by tests/golden/make_ukf_hooks_golden.py): the oracle's hooked
+    sigma points / UT are bit-identical, its filter and smoother agree to rounding over 25 steps across the +-pi wrap"""
+    import ukf_hook_model as hm
+    g = golden("ukf_hooks")
+    hk = uo.hooks(**hm.HOOKS)
+    alpha, beta, kappa, dt = float(g["alpha"]), float(g["beta"]), float(g["kappa"]), float(g["dt"])
+    Wm, Wc = uo.merwe_weights(3, alpha, beta, kappa)
+    assert np.array_equal(Wm, g["Wm"]) and np.array_equal(Wc, g["Wc"])
+    sig = uo.merwe_sigma_points(g["x0"][0], g["P0"][0], alpha, kappa, hk["sqrt"], hk["subtract"])
+    assert np.array_equal(sig, g["sigmas0"])
+    sf = np.array([hm.fx(s, dt) for s in sig])
+    ux, uP = uo.unscented_transform(sf, Wm, Wc, g["Q"], hm.x_mean, hm.residual_x)
+    assert np.array_equal(ux, g["ut_x"]) and np.array_equal(uP, g["ut_P"])
+    ux, uP = uo.unscented_transform(sf, Wm, Wc, g["Q"], hm.x_mean, None)
+    assert np.array_equal(ux, g["ut_meanonly_x"]) and np.array_equal(uP, g["ut_meanonly_P"])
+    T, N = g["zs"].shape[:2]
+    for i in range(N):
+        zs = [g["zs"][t, i] for t in range(T)]
+        if i == 1:
+            zs[4] = None
+        mu, cov = uo.ukf_batch_filter(g["x0"][i], g["P0"][i], zs, hm.fx, hm.hx, dt, g["Q"], g["R"], alpha, beta, kappa, hk)
+        assert rel_err_rows(mu, g["mu"][:, i]) < 1e-12 and rel_err_rows(cov.reshape(T, -1), g["cov"][:, i].reshape(T, -1)) < 1e-12
+        xs, Ps, Ks = uo.ukf_rts_smoother(g["mu"][:, i], g["cov"][:, i], hm.fx, dt, g["Q"], alpha, beta, kappa, hk=hk)
+        assert rel_err_rows(xs, g["rts_x"][:, i]) < 1e-12
+        assert rel_err_rows(Ps.reshape(T, -1), g["rts_P"][:, i].reshape(T, -1)) < 1e-12
+        assert rel_err_rows(Ks.reshape(T, -1)[:-1], g["rts_K"][:, i].reshape(T, -1)[:-1]) < 1e-12
+    # the headings really cross the wrap (the hooks are exercised, not idle)
+    assert (np.abs(np.diff(g["mu"][:, :, 2], axis=0)) > 3.0).any()
