@@ -151,7 +151,7 @@ static int run_kf(const fk_kf_desc *d, KfArgs &a, void *stream)
     if (a.do_predict && a.do_update &&
         (all_out || no_out) && !a.y_out && !a.K_out && !a.S_out && !a.SI_out && !a.ll_out && !a.maha_out &&
         !a.rj_diag && !getenv("FK_NO_FAST")) {
-        if (d->n == 9 && d->m == 3 && !d->update_first && d->nu == 0 && !getenv("FK_NO_ML")) {
+        if (d->n == 9 && d->m == 3 && !getenv("FK_NO_ML")) {
             const int rc = launch_kf_ml_9_3(a, d->layout, all_out, d->model_mode, (hipStream_t)stream);
             if (rc <= 0) return rc;        // 1 = not a call the multi-lane kernel serves
         }

@@ -20,10 +20,13 @@
 // Per lane and step: ~1250 FMAs and ~190 exchanged doubles, ~90 live doubles (one lane per track:
 // ~3700 FMAs, > 250 live doubles).  A wave carries 16 tracks, so config 3 becomes 6250 waves.
 // Layouts: SOA (element-major: 16-byte pair stores, see MlView::store_pair) and AOS (NumPy order: output
-// sets staged through a wave-private LDS tile, ml_store_aos); exact dims (9, 3), shared constant
-// model, predict -> update, no control input, optional mask (no branch: see MASK below), all four
-// outputs or none.  Everything else stays on kf_fast / kf_kernel.  The smoother (rts_ml_kernel) is at
-// the end of the file.
+// sets staged through a wave-private LDS tile, ml_store_aos); exact dims (9, 3), optional mask (no
+// branch: see MASK below), all four outputs or none.  The base instantiations serve the plain call (one
+// constant model, predict -> update, no control input); the VAR instantiations (FK_ML_PART=2 of the build)
+// add what KalmanFilter.batch_filter's other arguments ask for (kalman_filter.py:941-991): one model PER STEP
+// shared by the bank (Fs / Qs / Hs / Rs lists: double-buffered in LDS, fetched a step ahead), a control input
+// x = F x + B u (u[t] travels with z[t]) and update_first (UF: update -> predict inside a step).  Per-track
+// models stay on kf_fast / kf_kernel.  The smoother (rts_ml_kernel) is at the end of the file.
 #include <stdlib.h>
 
 #include "fk_device.hpp"
@@ -33,6 +36,11 @@
 
 #ifndef FK_ML_WAVES
 #define FK_ML_WAVES 2
+#endif
+// the build compiles this file twice (parallel): FK_ML_PART=1 the plain-call kernels + the smoother, FK_ML_PART=2
+// the VAR instantiations; 0 = everything in one unit
+#ifndef FK_ML_PART
+#define FK_ML_PART 0
 #endif
 
 namespace fk {
@@ -248,7 +256,9 @@ __device__ __forceinline__ void ml_store_aos(const double (&x)[NX], const double
     }
 }
 
-template <int R, int NZ, bool OUTS, int WAVES, bool PAIRS, bool MASK, int LAYOUT>
+// VAR: per-step shared models (a.model_t), control input (a.nu > 0), mask by pointer -- all wave-uniform run-time
+// switches of ONE extra instantiation family; UF (update_first) reorders the step and is compile-time.
+template <int R, int NZ, bool OUTS, int WAVES, bool PAIRS, bool MASK, int LAYOUT, bool VAR = false, bool UF = false>
 __global__ void __launch_bounds__(BLOCK, WAVES)
 kf_ml_kernel(const KfArgs a)
 {
@@ -256,12 +266,43 @@ kf_ml_kernel(const KfArgs a)
     using LM = LdsModel<NX, NZ>;
     constexpr bool AOS = LAYOUT == LAYOUT_AOS;
     constexpr int TILE = 16 * NX + 16 * NX * NX;                 // AOS: one (x, P) output set of a wave
-    __shared__ double smem[LM::SIZE + (AOS && OUTS ? (BLOCK / 64) * TILE : 0)];
-    double *tile = smem + LM::SIZE + (threadIdx.x >> 6) * TILE;
+    constexpr int NUC = 4;                                       // padded dim_u (VAR)
+    constexpr int MLEN = LM::SIZE + NX * NUC;                    // VAR: [F | Q | H | R | B padded to NX x NUC]
+    constexpr int MSTR = MLEN + 2;                               // ... + the pad slot idle threads publish into
+    constexpr int MSZ = VAR ? 2 * MSTR : LM::SIZE;               // VAR: two model buffers (this step's, the next one's)
+    static_assert(!VAR || MLEN <= BLOCK, "one thread per model element");
+    static_assert(!UF || VAR, "update_first is a VAR instantiation");
+    __shared__ double smem[MSZ + (AOS && OUTS ? (BLOCK / 64) * TILE : 0)];
+    double *tile = smem + MSZ + (threadIdx.x >> 6) * TILE;
+    const double *sB = smem + LM::SIZE;
     lds_fill<NX, NX>(smem + LM::OFF_F, a.F, NX, NX, 1.0, threadIdx.x);
     lds_fill<NX, NX>(smem + LM::OFF_Q, a.Q, NX, NX, 0.0, threadIdx.x);
     lds_fill<NZ, NX>(smem + LM::OFF_H, a.H, NZ, NX, 0.0, threadIdx.x);
     lds_fill<NZ, NZ>(smem + LM::OFF_R, a.R, NZ, NZ, 1.0, threadIdx.x);
+    if constexpr (VAR) lds_fill<NX, NUC>(smem + LM::SIZE, a.nu > 0 ? a.B : nullptr, NX, a.nu, 0.0, threadIdx.x);
+    // element `tid` of the concatenated model [F | Q | H | R | B] of step tt (VAR; B [tt][NX][nu] goes with the model
+    // mode like the others; no control input: a valid dummy address, the value selected to 0)
+    const double *B_or_dummy = VAR && a.nu > 0 ? a.B : a.F;
+    auto model_elem = [&](long tt) -> double {
+        const int k = (int)threadIdx.x;
+        if (k < LM::OFF_Q) return a.F[tt * (NX * NX) + k];
+        if (k < LM::OFF_H) return a.Q[tt * (NX * NX) + (k - LM::OFF_Q)];
+        if (k < LM::OFF_R) return a.H[tt * (NZ * NX) + (k - LM::OFF_H)];
+        if (k < LM::SIZE) return a.R[tt * (NZ * NZ) + (k - LM::OFF_R)];
+        const int i = (k - LM::SIZE) / NUC, j = (k - LM::SIZE) % NUC;
+        const bool live = k < MLEN && j < a.nu;
+        const double v = B_or_dummy[live ? tt * (long)(NX * a.nu) + i * a.nu + j : 0];
+        return live ? v : 0.0;
+    };
+    // The run-time switches of the VAR family are BRANCH-FREE (a branch inside the time loop splits its one basic
+    // block and the register allocation falls apart: +100 spilled doubles per lane measured): without per-step
+    // models the hand-over republishes model[0] every step, without a control input B is zero-filled and u is
+    // selected to 0, without a mask the byte is read from a valid dummy address and selected to 1.
+    double mnext = 0.0;                        // this thread's element of the NEXT step's model
+    if constexpr (VAR) {
+        mnext = model_elem(a.model_t && a.T > 1 ? 1 : 0);
+        asm volatile("" ::"v"(mnext));
+    }
     __syncthreads();
     const double *sF = smem + LM::OFF_F, *sQ = smem + LM::OFF_Q, *sH = smem + LM::OFF_H, *sR = smem + LM::OFF_R;
 
@@ -288,15 +329,23 @@ kf_ml_kernel(const KfArgs a)
     const unsigned lane = threadIdx.x & 63u;
     const double *myF = sF + Lc * (R * NX);                     // this lane's rows of F and Q
     const double *myQ = sQ + Lc * (R * NX);
+    const unsigned nu = VAR ? (unsigned)a.nu : 0u;
+    const unsigned nu_idx = nu ? nu - 1u : 0u;
+    const unsigned tu8 = (unsigned)trk * (AOS ? nu * 8u : 8u);                                // u
+    // (dummies: valid addresses whose contents are never used -- z is at least as large as a mask / one u element per track)
+    const uint8_t *mask_or_dummy = VAR && a.mask ? a.mask : reinterpret_cast<const uint8_t *>(a.z);
+    const double *u_or_dummy = VAR && nu ? a.u : a.z;
 
     // H (27 doubles, replicated) lives in VGPRs instead of being re-read from LDS at each of its five uses
     // per step (measured: 2 % faster than LDS reads, no occupancy change)
     // (not in the AOS instantiation: its LDS staging needs the registers, H is read from LDS there)
-    double Hreg[AOS ? 1 : NZ * NX];
-    if constexpr (!AOS) {
+    // (nor in the VAR instantiations: H may change every step)
+    constexpr bool HLDS = AOS || VAR;
+    double Hreg[HLDS ? 1 : NZ * NX];
+    if constexpr (!HLDS) {
         FK_UNROLL for (int e = 0; e < NZ * NX; ++e) Hreg[e] = sH[e];
     }
-#define HX(e) (AOS ? sH[(e)] : Hreg[AOS ? 0 : (e)])
+#define HX(e) (HLDS ? sH[(e)] : Hreg[HLDS ? 0 : (e)])
     double P[R][NX], x[NX];
     {
         const MlView vP(a.P, off_rows, estride), vx(a.x, t8, estride);
@@ -317,92 +366,60 @@ kf_ml_kernel(const KfArgs a)
     // branch: the step runs with z = 0 and K = 0, which makes T1 = P, P+ = P + D 0' = P and
     // x + 0 y = x exactly (every product with the zero gain is an exact zero).
     double zn[NZ];
+    double un[VAR ? NUC : 1];
     unsigned hn = 1u;
     {
         const MlView vz(a.z, tz8, estride);
         FK_UNROLL for (int c = 0; c < NZ; ++c) zn[c] = vz.load(c);
-        if constexpr (MASK) hn = a.mask[trk];
+        if constexpr (VAR) {
+            const unsigned hb = mask_or_dummy[trk];
+            hn = a.mask ? hb : 1u;
+            const MlView vu(u_or_dummy, tu8, estride);
+            FK_UNROLL for (int c = 0; c < NUC; ++c) {
+                const double v = vu.load((unsigned)c < nu ? c : (int)nu_idx);   // clamped element index: no branch
+                un[c] = nu ? v : 0.0;
+            }
+            FK_UNROLL for (int c = 0; c < NUC; ++c) asm volatile("" ::"v"(un[c]));
+        } else if constexpr (MASK) hn = a.mask[trk];
         FK_UNROLL for (int c = 0; c < NZ; ++c) asm volatile("" ::"v"(zn[c]));     // landed, like x and P above
         if constexpr (MASK) asm volatile("" ::"v"(hn));
     }
     _Pragma("nounroll") for (long t = 0; t < a.T; ++t) {
         double z[NZ];
+        double u[VAR ? NUC : 1];
         const bool has_z = !MASK || hn != 0u;
         FK_UNROLL for (int c = 0; c < NZ; ++c) z[c] = has_z ? zn[c] : 0.0;
+        if constexpr (VAR) {
+            FK_UNROLL for (int c = 0; c < NUC; ++c) u[c] = un[c];
+        }
         {
             long tn = t + 1 < a.T ? t + 1 : t;
             asm volatile("" : "+s"(tn));      // opaque: keeps the compiler from re-deriving this load one iteration later
             const MlView vz(a.z + tn * N * NZ, tz8, estride);
             FK_UNROLL for (int c = 0; c < NZ; ++c) zn[c] = vz.load(c);
-            if constexpr (MASK) hn = a.mask[tn * N + trk];
+            if constexpr (VAR) {
+                const unsigned hb = mask_or_dummy[tn * N + trk];
+                hn = a.mask ? hb : 1u;
+                const MlView vu(u_or_dummy + tn * N * (long)nu, tu8, estride);
+                FK_UNROLL for (int c = 0; c < NUC; ++c) {
+                    const double v = vu.load((unsigned)c < nu ? c : (int)nu_idx);
+                    un[c] = nu ? v : 0.0;
+                }
+            } else if constexpr (MASK) hn = a.mask[tn * N + trk];
         }
-        // ---------------------------------------------------------------- predict --
+        // VAR, per-step models: mnext holds this thread's element of model[t+1]; keep it for the hand-over at the
+        // end of the step and request model[t+2] (consumed one step later: a counted wait)
+        const double mpub = mnext;
+        if constexpr (VAR) {
+            long t2 = a.model_t ? (t + 2 < a.T ? t + 2 : a.T - 1) : 0;
+            asm volatile("" : "+s"(t2));
+            mnext = model_elem(t2);
+        }
+        // the two halves of a step, in the order update_first asks for (kalman_filter.py:966-991)
+        if constexpr (!UF) {
+#include "kf_ml_predict.inc"
+        }
         {
-            double xn[NX];
-            FK_UNROLL for (int i = 0; i < NX; ++i) {
-                double acc = sF[i * NX] * x[0];
-                FK_UNROLL for (int k = 1; k < NX; ++k) acc = fma(sF[i * NX + k], x[k], acc);
-                xn[i] = acc;
-                FK_STAGE();                  // one row of F in flight at a time
-            }
-            FK_UNROLL for (int i = 0; i < NX; ++i) x[i] = xn[i];
-        }
-        if (OUTS && !AOS) {
-            const MlView vx(a.means_p + t * N * NX, t8, estride, pair_x);
-            store_x<NX, PAIRS ? 1 : 0>(vx, x);      // replicated: the quad writes the same bytes
-        }
-        FK_STAGE();
-        {
-            // The posterior covariance of step t-1 is still in P: its 27 stores are spread over the nine
-            // iterations below (and the prior's over the PHT stage), so that a wave's store traffic is
-            // issued evenly through its arithmetic instead of in two bursts per step that every wave of
-            // the chip fires at the same moment.
-            const MlView vPost(a.covs + (t > 0 ? t - 1 : 0) * N * NX * NX, off_rows, estride, pair_rows);
-            double T[R][NX];                 // T = P F' : T[r][i] = sum_k P[r][k] F[i][k]
-            FK_UNROLL for (int i = 0; i < NX; ++i) {
-                FK_UNROLL for (int r = 0; r < R; ++r) {
-                    double acc = P[r][0] * sF[i * NX];
-                    FK_UNROLL for (int k = 1; k < NX; ++k) acc = fma(P[r][k], sF[i * NX + k], acc);
-                    T[r][i] = acc;
-                }
-                if (OUTS && !AOS) {
-                    // (at t == 0 this writes the initial P into covs[0], overwritten by step 0's own result later)
-                    if constexpr (PAIRS) {
-                        // the lane's 27 elements as 13 pairs + 1: iterations 0,2,4,6 send 3 pairs, 8 sends 1 pair + the last
-                        if (i % 2 == 0 && i < NX - 1) {
-                            FK_UNROLL for (int e = 0; e < 2 * R; e += 2) {
-                                const int f0 = i * R + e, f1 = f0 + 1;
-                                vPost.store_pair(f0, P[f0 / NX][f0 % NX], P[f1 / NX][f1 % NX]);
-                            }
-                        } else if (i == NX - 1) {
-                            vPost.store_pair(i * R, P[R - 1][NX - 3], P[R - 1][NX - 2]);
-                            vPost.store(R * NX - 1, P[R - 1][NX - 1]);
-                        }
-                    } else {
-                        FK_UNROLL for (int e = 0; e < R; ++e) vPost.store((i / R) * NX + (i % R) * R + e, P[i / R][(i % R) * R + e]);
-                    }
-                }
-                FK_STAGE();
-            }
-            // P' = F T : row i (own) = sum_k F[i][k] T[k][:]
-            FK_UNROLL for (int k = 0; k < NX; ++k) {
-                double Tk[NX];
-                FK_UNROLL for (int j = 0; j < NX; ++j) {
-                    const double v = T[k % R][j];
-                    Tk[j] = (k / R == 0) ? quad_bcast<0>(v) : (k / R == 1) ? quad_bcast<1>(v) : quad_bcast<2>(v);
-                }
-                FK_UNROLL for (int r = 0; r < R; ++r) {
-                    const double f = myF[r * NX + k];
-                    FK_UNROLL for (int j = 0; j < NX; ++j) P[r][j] = (k == 0) ? f * Tk[j] : fma(f, Tk[j], P[r][j]);
-                }
-                FK_STAGE();
-            }
-            FK_UNROLL for (int r = 0; r < R; ++r)
-                FK_UNROLL for (int j = 0; j < NX; ++j) P[r][j] = fma(a.alpha_sq, P[r][j], myQ[r * NX + j]);
-        }
-        if constexpr (OUTS && AOS)
-            ml_store_aos<R, NX>(x, P, a.means_p + (t * N + w0) * NX, a.covs_p + (t * N + w0) * NX * NX, tile, lane, Lc, valid);
-        FK_STAGE();
         // ----------------------------------------------------------------- update --
         // Joseph form with the identity-minus-product factors applied implicitly (cf. fk_math_sym.hpp),
         // WITHOUT assuming P symmetric -- P is held by rows and its two triangles round differently;
@@ -418,7 +435,9 @@ kf_ml_kernel(const KfArgs a)
                 FK_UNROLL for (int k = 1; k < NX; ++k) acc = fma(HX(c * NX + k), x[k], acc);
                 y[c] = z[c] - acc;
             }
-            const MlView vPri(a.covs_p + t * N * NX * NX, off_rows, estride, pair_rows);
+            // (update_first: P is the prior the PREVIOUS step's predict left; at t == 0 the initial P lands in covs_p[0]
+            // and is overwritten one step later)
+            const MlView vPri(a.covs_p + (UF ? (t > 0 ? t - 1 : 0) : t) * N * NX * NX, off_rows, estride, pair_rows);
             double PHT[R][NZ], S[NZ * NZ];
             FK_UNROLL for (int r = 0; r < R; ++r) {
                 FK_UNROLL for (int c = 0; c < NZ; ++c) {
@@ -517,9 +536,27 @@ kf_ml_kernel(const KfArgs a)
         }
         if constexpr (OUTS && AOS)
             ml_store_aos<R, NX>(x, P, a.means + (t * N + w0) * NX, a.covs + (t * N + w0) * NX * NX, tile, lane, Lc, valid);
+        }      // update half
+        if constexpr (UF) {
+#include "kf_ml_predict.inc"
+        }
+        if constexpr (VAR) {
+            // publish model[t+1] into the other LDS buffer: nobody reads that buffer during step t, and one
+            // barrier makes it visible for step t+1 (every thread of the workgroup runs all T steps)
+            double *nb = smem + ((t + 1) & 1) * MSTR;
+            nb[threadIdx.x < (unsigned)MLEN ? threadIdx.x : (unsigned)MLEN] = mpub;   // threads past the model: one pad slot
+            __syncthreads();
+            sF = nb + LM::OFF_F;
+            sQ = nb + LM::OFF_Q;
+            sH = nb + LM::OFF_H;
+            sR = nb + LM::OFF_R;
+            sB = nb + LM::SIZE;
+            myF = sF + Lc * (R * NX);
+            myQ = sQ + Lc * (R * NX);
+        }
     }
-    if (OUTS && !AOS && a.T > 0) {      // the last step's posterior covariance (the others were stored one step late)
-        const MlView vP(a.covs + (a.T - 1) * N * NX * NX, off_rows, estride);
+    if (OUTS && !AOS && a.T > 0) {      // the last step's posterior (update_first: prior) covariance -- the others were stored one step late
+        const MlView vP((UF ? a.covs_p : a.covs) + (a.T - 1) * N * NX * NX, off_rows, estride);
         FK_UNROLL for (int r = 0; r < R; ++r)
             FK_UNROLL for (int c = 0; c < NX; ++c) vP.store(r * NX + c, P[r][c]);
     }
@@ -543,6 +580,7 @@ kf_ml_kernel(const KfArgs a)
     }
 }
 
+#if FK_ML_PART != 2
 // AOS output of one R x NX row block per lane (the wave's 16 x NX*NX slab) staged through the wave's own
 // columns of the smoother's parking buffer: element i of the slab lives at park[i / 64][64 * wave + i % 64].
 // Only used at points of the step where the rows it touches (0 .. 16*NX*NX/64) hold nothing live.
@@ -803,11 +841,19 @@ int launch_rts_ml_9(const RtsArgs &a, int layout, bool uniform, hipStream_t s)
     return check_launch("rts_ml_kernel");
 }
 
+int launch_kf_ml_9_3_var(const KfArgs &a, int layout, hipStream_t s);
+
 // returns 1 when this call is not one the multi-lane kernel serves
 int launch_kf_ml_9_3(const KfArgs &a, int layout, bool outs, int model_mode, hipStream_t s)
 {
-    if (model_mode != FK_MODEL_SHARED || a.n != 9 || a.m != 3) return 1;
+    if ((model_mode != FK_MODEL_SHARED && model_mode != FK_MODEL_PER_STEP) || a.n != 9 || a.m != 3) return 1;
     if (layout == FK_LAYOUT_AOS && (double)a.N * 81.0 * 8.0 >= 4294967296.0) return 1;      // 32-bit record offsets
+    if (model_mode == FK_MODEL_PER_STEP || a.nu > 0 || a.update_first) {
+        // the VAR family: all four outputs, dim_u <= 4 (FK_ML_VAR=0 sends these calls back to kf_fast / kf_kernel)
+        const char *vv = getenv("FK_ML_VAR");
+        if (!outs || a.nu > 4 || (vv && atoi(vv) == 0)) return 1;
+        return launch_kf_ml_9_3_var(a, layout, s);
+    }
     const dim3 grid((unsigned)((a.N + BLOCK / 4 - 1) / (BLOCK / 4))), block(BLOCK);
     // 16-byte pair stores (SOA) need the track count even (a pair never straddles a plane); FK_ML_PAIRS=0 turns them off
     const char *pv = getenv("FK_ML_PAIRS");
@@ -825,6 +871,25 @@ int launch_kf_ml_9_3(const KfArgs &a, int layout, bool outs, int model_mode, hip
 #undef GO
     return check_launch("kf_ml_kernel");
 }
+#endif   // FK_ML_PART != 2
+
+#if FK_ML_PART != 1
+int launch_kf_ml_9_3_var(const KfArgs &a, int layout, hipStream_t s)
+{
+    const dim3 grid((unsigned)((a.N + BLOCK / 4 - 1) / (BLOCK / 4))), block(BLOCK);
+    const char *pv = getenv("FK_ML_PAIRS");
+    const bool pairs = (a.N % 2 == 0) && a.N >= 2 && !(pv && atoi(pv) == 0);
+#define GOV(UFV)                                                                                                            \
+    if (layout == FK_LAYOUT_AOS)                                                                                            \
+        hipLaunchKernelGGL((kf_ml_kernel<3, 3, true, FK_ML_WAVES, false, true, LAYOUT_AOS, true, UFV>), grid, block, 0, s, a); \
+    else if (pairs)                                                                                                         \
+        hipLaunchKernelGGL((kf_ml_kernel<3, 3, true, FK_ML_WAVES, true, true, LAYOUT_SOA, true, UFV>), grid, block, 0, s, a);  \
+    else hipLaunchKernelGGL((kf_ml_kernel<3, 3, true, FK_ML_WAVES, false, true, LAYOUT_SOA, true, UFV>), grid, block, 0, s, a)
+    if (a.update_first) { GOV(true); } else { GOV(false); }
+#undef GOV
+    return check_launch("kf_ml_kernel<var>");
+}
+#endif   // FK_ML_PART != 1
 
 #undef HX
 

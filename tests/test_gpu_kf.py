@@ -339,3 +339,84 @@ def test_tail_shapes_kf_and_rts(n, m, layout):
         rr = kf_oracle.rts_smoother_tracks(ref[0], ref[1], F, Q, tracks=range(N))
         for k in range(4):
             assert rel_err_rows(_per_track(sm[k]), _per_track(rr[k])) < 1e-10, (N, "rts", k)
+
+
+@pytest.mark.parametrize("layout", ["soa", "aos"])
+@pytest.mark.parametrize("N", [1000, 777])
+def test_multilane_9_3_variants_vs_oracle(N, layout, monkeypatch):
+    """The VAR family of kf_ml.hip (per-step shared models in double-buffered LDS, control input with a per-step B,
+    update_first, mask -- run-time switches of one instantiation, every combination): every track its own state,
+    measurements and controls; N even (16-byte pair stores) and odd; against the oracle at 1e-10, and against the
+    one-lane kernels (FK_ML_VAR=0 sends the same call there)."""
+    from gpu_util import run_kf_batch
+    from filterpy_amd._abi import FK_MODEL_PER_STEP, FK_MODEL_SHARED
+    n, m, nu = 9, 3, 2
+    rs = np.random.RandomState(1000 + N)
+    T = 12
+    A = rs.randn(N, n, n)
+    x0, P0 = rs.randn(N, n), 4.0 * (A @ A.transpose(0, 2, 1) / n + 0.5 * np.eye(n))
+    zs = rs.randn(T, N, m) * 3
+    us = rs.randn(T, N, nu)
+
+    def spd(k, s, cnt):
+        G = rs.randn(cnt, k, k)
+        return s * (G @ G.transpose(0, 2, 1) / k + 0.5 * np.eye(k))
+    Fs = np.eye(n) + 0.1 * rs.randn(T, n, n)
+    Qs, Hs, Rs = spd(n, 0.1, T), rs.randn(T, m, n), spd(m, 0.5, T)
+    Bs = rs.randn(T, n, nu)
+    mask = rs.rand(T, N) > 0.25
+    sample = [0, 1, 15, 16, 63, 64, 255, 256, N - 2, N - 1]
+    for per_step in (False, True):
+        for ctrl in (False, True):
+            for uf in (False, True):
+                for masked in (False, True):
+                    if not (per_step or ctrl or uf):
+                        continue                                    # the plain call: test_multilane_9_3_vs_oracle
+                    mods = (Fs, Qs, Hs, Rs) if per_step else (Fs[0], Qs[0], Hs[0], Rs[0])
+                    B = None if not ctrl else (Bs if per_step else Bs[0])
+                    z = zs.copy()
+                    if masked:
+                        z[~mask] = np.nan                           # a masked measurement must not be looked at
+                    kw = dict(mode=FK_MODEL_PER_STEP if per_step else FK_MODEL_SHARED, B=B, us=us if ctrl else None,
+                              update_first=uf, mask=mask if masked else None, alpha_sq=1.01 ** 2)
+                    got = run_kf_batch(x0, P0, z, *mods, layout=layout, **kw)
+                    ref = kf_oracle.kf_batch_filter_tracks(x0, P0, z, *mods, tracks=sample, B=B, us=us if ctrl else None,
+                                                           update_first=uf, mask=mask if masked else None, alpha_sq=1.01 ** 2)
+                    tag = (per_step, ctrl, uf, masked)
+                    for k in range(4):
+                        assert np.isfinite(got[k]).all(), (tag, k)
+                        assert rel_err_rows(_per_track(got[k][:, sample]), _per_track(ref[k])) < TOL, (tag, k)
+                    last = ref[2] if uf else ref[0]                  # update_first leaves the PRIOR as the state
+                    lastP = ref[3] if uf else ref[1]
+                    assert rel_err_rows(got[4][sample], last[-1]) < TOL and rel_err_rows(got[5][sample], lastP[-1]) < TOL, tag
+    # the same call through the one-lane kernels agrees to the tolerance too (the dispatch switch itself)
+    monkeypatch.setenv("FK_ML_VAR", "0")
+    one = run_kf_batch(x0, P0, zs, Fs, Qs, Hs, Rs, layout=layout, mode=FK_MODEL_PER_STEP, B=Bs, us=us, update_first=True)
+    monkeypatch.delenv("FK_ML_VAR")
+    ml = run_kf_batch(x0, P0, zs, Fs, Qs, Hs, Rs, layout=layout, mode=FK_MODEL_PER_STEP, B=Bs, us=us, update_first=True)
+    for k in range(4):
+        assert rel_err_rows(_per_track(ml[k]), _per_track(one[k])) < TOL, k
+
+
+@pytest.mark.parametrize("N,T", [(1, 1), (2, 1), (3, 2), (17, 3), (66, 2)])
+def test_multilane_variants_small_shapes(N, T):
+    """tiny / ragged banks and T = 1..3 through the VAR family (tail quads, deferred covariance stores at the edges)"""
+    from gpu_util import run_kf_batch
+    from filterpy_amd._abi import FK_MODEL_PER_STEP
+    n, m, nu = 9, 3, 1
+    rs = np.random.RandomState(7000 + 10 * N + T)
+    A = rs.randn(N, n, n)
+    x0, P0 = rs.randn(N, n), A @ A.transpose(0, 2, 1) / n + 0.5 * np.eye(n)
+    zs, us = rs.randn(T, N, m), rs.randn(T, N, nu)
+    Fs = np.eye(n) + 0.05 * rs.randn(T, n, n)
+    G = rs.randn(T, n, n)
+    Qs = 0.1 * (G @ G.transpose(0, 2, 1) / n + 0.5 * np.eye(n))
+    Hs, Rs, Bs = rs.randn(T, m, n), np.tile(0.5 * np.eye(m), (T, 1, 1)), rs.randn(T, n, nu)
+    for layout in ("soa", "aos"):
+        for uf in (False, True):
+            got = run_kf_batch(x0, P0, zs, Fs, Qs, Hs, Rs, layout=layout, mode=FK_MODEL_PER_STEP, B=Bs, us=us, update_first=uf)
+            ref = kf_oracle.kf_batch_filter_tracks(x0, P0, zs, Fs, Qs, Hs, Rs, tracks=range(N), B=Bs, us=us, update_first=uf)
+            for k in range(4):
+                assert rel_err_rows(_per_track(got[k]), _per_track(ref[k])) < TOL, (layout, uf, k)
+            last, lastP = (ref[2], ref[3]) if uf else (ref[0], ref[1])
+            assert rel_err_rows(got[4], last[-1]) < TOL and rel_err_rows(got[5], lastP[-1]) < TOL

@@ -69,8 +69,60 @@ def rts():
                               frac=N * T * 2736 / (ms * 1e-3) / 8e12)), flush=True)
 
 
+def variants():
+    """batch_filter's other arguments at (9, 3): per-step model lists, control input, update_first -- the VAR family
+    of kf_ml.hip against the one-lane kernels the same calls ran on before (FK_ML_VAR=0)."""
+    import numpy as np
+    import torch
+    from filterpy_amd import _engine as E
+    from tools.bench_configs import cv3d_model, timeit
+    N, T, n, m, nu = int(os.environ.get("ML_N", 100000)), 100, 9, 3, 2
+    F, Q, H, R = cv3d_model()
+    dev = torch.device("cuda")
+    g = torch.Generator(device=dev)
+    g.manual_seed(3)
+    rs = np.random.RandomState(5)
+    Bm = 0.01 * rs.randn(n, nu)
+    for layout in ("soa", "aos"):
+        zshape = (T, m, N) if layout == "soa" else (T, N, m)
+        ushape = (T, nu, N) if layout == "soa" else (T, N, nu)
+        z = torch.randn(zshape, generator=g, device=dev, dtype=torch.float64)
+        u = torch.randn(ushape, generator=g, device=dev, dtype=torch.float64)
+        x0 = E.to_records(np.zeros((N, n)), layout, 0)
+        P0 = E.to_records(np.tile(10.0 * np.eye(n), (N, 1, 1)), layout, 0)
+        x, P = x0.clone(), P0.clone()
+        outs = [E.alloc_records((T,), N, n, layout), E.alloc_records((T,), N, n * n, layout),
+                E.alloc_records((T,), N, n, layout), E.alloc_records((T,), N, n * n, layout)]
+        st = torch.zeros(N, dtype=torch.int32, device=dev)
+        shared = [E.dev(a) for a in (F, Q, H, R)]
+        stepped = [E.dev(np.tile(a, (T, 1, 1))) for a in (F, Q, H, R)]
+        for name, per_step, ctrl, uf in (("per_step", 1, 0, 0), ("control", 0, 1, 0), ("update_first", 0, 0, 1),
+                                         ("per_step+control+update_first", 1, 1, 1)):
+            desc = dict(n=n, m=m, nu=nu if ctrl else 0, model_mode=3 if per_step else 0, N=N, T=T, layout=E.LAYOUTS[layout],
+                        update_first=uf, alpha_sq=1.0)
+            d = stepped if per_step else shared
+            B = None if not ctrl else E.dev(np.tile(Bm, (T, 1, 1)) if per_step else Bm)
+            for env in ({}, {"FK_ML_VAR": "0"}):
+                os.environ.pop("FK_ML_VAR", None)
+                os.environ.update(env)
+
+                def run():
+                    x.copy_(x0)
+                    P.copy_(P0)
+                    E.kf_batch_filter(desc, *d, z, x, P, B=B, u=u if ctrl else None, means=outs[0], covs=outs[1],
+                                      means_p=outs[2], covs_p=outs[3], status=st)
+                ms = timeit(run, warm=2, reps=5)
+                assert not st.any()
+                by = 1464 + (8 * nu if ctrl else 0)
+                print(json.dumps(dict(call=name, layout=layout, kernel="one lane per track" if env else "kf_ml VAR", N=N, ms=ms,
+                                      track_steps_per_s=N * T / ms * 1e3, frac=N * T * by / (ms * 1e-3) / 8e12)), flush=True)
+    os.environ.pop("FK_ML_VAR", None)
+
+
 if __name__ == "__main__":
-    if os.environ.get("ML_WHAT", "kf") == "rts":
+    if os.environ.get("ML_WHAT", "kf") == "var":
+        variants()
+    elif os.environ.get("ML_WHAT", "kf") == "rts":
         rts()
     else:
         main()
