@@ -25,6 +25,10 @@ namespace fk {
 #include "fk_dims_rts.def"
 #undef FK_RTS_INST
 
+#define FK_MLG_INST(NX, NZ) int launch_kf_mlg_##NX##_##NZ(const KfArgs &, int, bool, int, hipStream_t);
+#include "fk_dims_mlg.def"
+#undef FK_MLG_INST
+
 int launch_kf_ml_9_3(const KfArgs &, int, bool, int, hipStream_t);   // kf_ml.hip: three lanes per track
 int launch_rts_ml_9(const RtsArgs &, int, bool, hipStream_t);
 
@@ -46,6 +50,13 @@ static const FastEntry fast_table[] = {
 #define FK_FAST_INST(NX, NZ, V, W, S, WA, ZD) {NX, NZ, V, launch_kf_fast_##NX##_##NZ##_v##V},
 #include "fk_dims_fast.def"
 #undef FK_FAST_INST
+};
+
+// kf_mlg.hip: four lanes per track, dim_x = 10..16
+static const FastEntry mlg_table[] = {
+#define FK_MLG_INST(NX, NZ) {NX, NZ, 0, launch_kf_mlg_##NX##_##NZ},
+#include "fk_dims_mlg.def"
+#undef FK_MLG_INST
 };
 
 static const FastEntry *pick_fast(int n, int m)
@@ -154,6 +165,13 @@ static int run_kf(const fk_kf_desc *d, KfArgs &a, void *stream)
         if (d->n == 9 && d->m == 3 && !getenv("FK_NO_ML")) {
             const int rc = launch_kf_ml_9_3(a, d->layout, all_out, d->model_mode, (hipStream_t)stream);
             if (rc <= 0) return rc;        // 1 = not a call the multi-lane kernel serves
+        }
+        if (d->n >= 10 && !getenv("FK_NO_MLG")) {
+            for (const FastEntry &g : mlg_table) {
+                if (g.nx != d->n || g.nz != d->m) continue;
+                const int rc = g.fn(a, d->layout, all_out, d->model_mode, (hipStream_t)stream);
+                if (rc <= 0) return rc;    // 1 = not a call the four-lane kernel serves
+            }
         }
         if (const FastEntry *f = pick_fast(d->n, d->m)) {
             const char *ev = getenv("FK_FAST_XCD");

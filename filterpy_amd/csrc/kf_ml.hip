@@ -32,6 +32,7 @@
 #include "fk_device.hpp"
 #include "fk_math_sym.hpp"
 #include "fk_kernel_args.hpp"
+#include "fk_ml.hpp"
 #include "../../include/filterhip.h"
 
 #ifndef FK_ML_WAVES
@@ -44,112 +45,6 @@
 #endif
 
 namespace fk {
-
-template <int SRC>
-__device__ __forceinline__ double quad_bcast(double v)
-{
-    constexpr int ctrl = SRC * 0x55;   // quad_perm:[SRC,SRC,SRC,SRC]
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_mov_dpp(lo, ctrl, 0xf, 0xf, true);
-    hi = __builtin_amdgcn_mov_dpp(hi, ctrl, 0xf, 0xf, true);
-    return __hiloint2double(hi, lo);
-}
-
-// value of the lane selected by an arbitrary quad permutation (CTRL = quad_perm encoding)
-template <int CTRL>
-__device__ __forceinline__ double quad_rot(double v)
-{
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xf, 0xf, true);
-    hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xf, 0xf, true);
-    return __hiloint2double(hi, lo);
-}
-
-// A buffer store of more than 8 bytes reads its data registers over several cycles; the VALU must not overwrite
-// them in the next cycle.  hipcc keeps that distance itself -- except when the store's soffset is an SGPR, which the
-// GCN3 manual exempts and LLVM's hazard recogniser therefore skips.  gfx950 does not honour the exemption: with the
-// very next instruction a v_mov into dword 0 of the data (the next pair's DPP exchange), that dword reached memory
-// with the NEXT value -- the low half of one covariance element per pair, 3e-7 relative, on every fourth track of
-// every workgroup that was not the first on its CU (round 2, tests/test_gpu_baseline_configs.py found it at
-// N = 1e5; tools/dbg_r02.py pinned the dword).  Two wait states after every such store.
-// (the asm takes the four data dwords as inputs and clobbers memory: the registers stay live up to it and it cannot
-// move above the store -- a bare `s_nop` was scheduled BEFORE the store it was meant to follow)
-using hz_u32x4 = __attribute__((ext_vector_type(4))) unsigned;
-__device__ __forceinline__ void store_data_hazard(const hz_u32x4 &v)
-{
-    asm volatile("s_nop 1" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w) : "memory");
-}
-
-// raw buffer access with a per-lane byte offset and a wave-uniform element offset
-struct MlView {
-    rsrc_t rs;
-    unsigned voff, voff2, estride;
-    // lane_off: this lane's byte offset for 8-byte accesses; pair_off: for the 16-byte pair accesses
-    // (even quads: lane_off; odd quads: one track back and one element plane up)
-    __device__ __forceinline__ MlView(const double *blk, unsigned lane_off, unsigned es, unsigned pair_off = 0)
-        : rs(make_rsrc(blk)), voff(lane_off), voff2(pair_off), estride(es)
-    {
-        // re-laundered per view (i.e. per time step): otherwise every e * estride is loop-invariant,
-        // gets hoisted out of the time loop (60 SGPRs) and the scalar file spills into VGPRs
-        asm volatile("" : "+s"(estride));
-    }
-    __device__ __forceinline__ double load(int e) const
-    {
-        return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, voff, (unsigned)e * estride, 0));
-    }
-    __device__ __forceinline__ void store(int e, double x) const
-    {
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, x), rs, voff, (unsigned)e * estride, 0);
-    }
-    // Two elements per lane as ONE 16-byte store.  In the element-major layout the 16 bytes next to a
-    // lane's value belong to the next track, i.e. to the next quad: even quads write element e of tracks
-    // (q, q+1), odd quads element e+1 of tracks (q-1, q), each taking the partner's value over a row
-    // shift by 4 lanes with a bank mask (DPP banks are the quads).  A wave may have 63 vector-memory
-    // operations in flight whatever their size; with 8-byte stores that, not HBM, bounded this kernel
-    // (~4 TB/s; the same bytes in half as many stores: +25 %).
-    //   a = element e, b = element e + 1 of this lane's track.
-    __device__ __forceinline__ void store_pair(int e, double a, double b) const
-    {
-        using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
-        const int ax = __double2loint(a), ay = __double2hiint(a), bx = __double2loint(b), by = __double2hiint(b);
-        u32x4 v;
-        v.x = (unsigned)__builtin_amdgcn_update_dpp(ax, bx, 0x114, 0xf, 0xa, false);   // odd quads: b of quad - 1 (row_shr:4)
-        v.y = (unsigned)__builtin_amdgcn_update_dpp(ay, by, 0x114, 0xf, 0xa, false);
-        v.z = (unsigned)__builtin_amdgcn_update_dpp(bx, ax, 0x104, 0xf, 0x5, false);   // even quads: a of quad + 1 (row_shl:4)
-        v.w = (unsigned)__builtin_amdgcn_update_dpp(by, ay, 0x104, 0xf, 0x5, false);
-        __builtin_amdgcn_raw_buffer_store_b128(v, rs, voff2, (unsigned)e * estride, 0);
-        store_data_hazard(v);
-    }
-    // AOS: elements e and e + 1 of a track are adjacent in memory -- one 16-byte access, no exchange
-    __device__ __forceinline__ void store2(int e, double a, double b) const
-    {
-        using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
-        const u32x2 lo = __builtin_bit_cast(u32x2, a), hi = __builtin_bit_cast(u32x2, b);
-        const u32x4 v = {lo.x, lo.y, hi.x, hi.y};
-        __builtin_amdgcn_raw_buffer_store_b128(v, rs, voff, (unsigned)e * estride, 0);
-        store_data_hazard(v);
-    }
-    __device__ __forceinline__ void load2(int e, double &a, double &b) const
-    {
-        using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
-        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, (unsigned)e * estride, 0);
-        a = __hiloint2double((int)v.y, (int)v.x);
-        b = __hiloint2double((int)v.w, (int)v.z);
-    }
-    // the mirror image for loads: one 16-byte load per lane, then the quads swap halves
-    __device__ __forceinline__ void load_pair(int e, double &a, double &b) const
-    {
-        using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
-        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff2, (unsigned)e * estride, 0);
-        // even quad holds [a(q), a(q+1)], odd quad [b(q-1), b(q)]
-        const int ax = __builtin_amdgcn_update_dpp((int)v.x, (int)v.z, 0x114, 0xf, 0xa, false);   // odd: a(q) = even's high half
-        const int ay = __builtin_amdgcn_update_dpp((int)v.y, (int)v.w, 0x114, 0xf, 0xa, false);
-        const int bx = __builtin_amdgcn_update_dpp((int)v.z, (int)v.x, 0x104, 0xf, 0x5, false);   // even: b(q) = odd's low half
-        const int by = __builtin_amdgcn_update_dpp((int)v.w, (int)v.y, 0x104, 0xf, 0x5, false);
-        a = __hiloint2double(ay, ax);
-        b = __hiloint2double(by, bx);
-    }
-};
 
 // a lane's R x NX rows (R*NX consecutive elements) as pairs + one odd element
 // MODE: 0 = 8-byte accesses; 1 = 16-byte pairs over the quad exchange (SOA, even N); 2 = 16-byte
@@ -210,15 +105,6 @@ __device__ __forceinline__ void store_x(const MlView &v, const double (&x)[NX])
     } else {
         FK_UNROLL for (int k = 0; k < NX; ++k) v.store(k, x[k]);
     }
-}
-
-__device__ __forceinline__ void ml_wave_fence()
-{
-    // LDS operations of one wave execute in order; this only keeps the compiler from moving the tile
-    // writes and the transposed reads across each other
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 // AOS ([track][element], NumPy order) output of one (x, P) set: a wave's 16 tracks are one contiguous

@@ -1,0 +1,356 @@
+// kf_mlg.hip -- KalmanFilter.batch_filter for dim_x = 10..16 (dim_z = 1..4) with FOUR LANES PER TRACK (gfx950).
+//
+// One lane per track ends at dim_x = 9: P alone is 2 n^2 VGPRs.  Above that the library used to run the padded /
+// rolled one-lane instantiations (scratch-resident arrays, guards around every access inside the time loop): 0.02-0.06
+// of the HBM peak.  Here the scheme of kf_ml.hip (dim_x = 9 on three lanes) is generalised: a QUAD of lanes owns a
+// track, lane L holds rows L*R .. L*R+R-1 of P (R = ceil(n/4)); rows past n-1 -- the tail of lane 3 for n = 10, 11,
+// 13, 14, 15 -- are CLAMPED to row n-1: the lane recomputes and rewrites that row (same values, same addresses), so no
+// lane is ever predicated, and it enters the one cross-lane SUM of the step (H P) with coefficient zero.  x, y, S
+// and its L D L' are replicated in the quad; rows travel by quad-permute DPP moves; every product keeps the
+// reference's k = 0..n-1 order (filterpy/kalman/kalman_filter.py:472-478 predict, :533-556 Joseph-form update,
+// :980-991 the batch loop):
+//
+//   predict  T = P F' (rows local) ; P' = a2 (F T) + Q : row k of T is broadcast by its owner
+//   update   PHT = P H' rows local, broadcast -> S (+R), L D L', y replicated ; K rows local ;
+//            H P = butterfly sum of the lanes' partial products ; T1 = P - K (H P) ; D = K R - T1 H' ;
+//            P+ = T1 + D K' with K's rows broadcast (the same row updates x)
+//
+// Exact dims (one instantiation per (dim_x, dim_z)), one constant model shared by the bank, predict -> update, all
+// four outputs, optional mask (branch-free, see kf_ml.hip), SOA and AOS (outputs staged through a wave-private LDS tile
+// and written as 1 KiB stores).  One wave per SIMD: at dim_x = 16 a lane holds P (64 doubles) and T (64) at once.
+// Everything else at these sizes stays on the padded kernels.
+#include <stdlib.h>
+
+#include "fk_device.hpp"
+#include "fk_math_sym.hpp"
+#include "fk_kernel_args.hpp"
+#include "fk_ml.hpp"
+#include "../../include/filterhip.h"
+
+#ifndef FK_NX
+#error "compile with -DFK_NX=<dim_x> -DFK_NZ=<dim_z>"
+#endif
+
+#define FK_MLG_CAT_(a, b, c) a##b##_##c
+#define FK_MLG_CAT(a, b, c) FK_MLG_CAT_(a, b, c)
+
+namespace fk {
+namespace FK_MLG_CAT(mlg_, FK_NX, FK_NZ) {
+
+// value v of row K's owner (lane K / R of the quad); K is a compile-time constant wherever this is used
+template <int OWNER>
+__device__ __forceinline__ double from_owner(double v)
+{
+    static_assert(OWNER >= 0 && OWNER < 4, "four lanes per track");
+    return quad_bcast<OWNER>(v);
+}
+#define FK_OWNER_ROW(dst, M, k, LEN)                                              \
+    FK_UNROLL for (int j_ = 0; j_ < (LEN); ++j_) {                                \
+        const double v_ = M[(k) % R][j_];                                         \
+        dst[j_] = ((k) / R == 0) ? from_owner<0>(v_) : ((k) / R == 1) ? from_owner<1>(v_) \
+                : ((k) / R == 2) ? from_owner<2>(v_) : from_owner<3>(v_);         \
+    }
+
+// sum over the four lanes of a quad, the same bits in every lane: (a0 + a1) + (a2 + a3) in lanes 0, 1 and
+// (a2 + a3) + (a0 + a1) in lanes 2, 3 (fp addition commutes)
+__device__ __forceinline__ double quad_sum(double v)
+{
+    v += quad_rot<0xB1>(v);      // quad_perm:[1,0,3,2]
+    v += quad_rot<0x4E>(v);      // quad_perm:[2,3,0,1]
+    return v;
+}
+
+// AOS ([track][element], NumPy order) output of one (x, P) set: a wave's 16 tracks are one contiguous slab; the quads
+// write their rows into a wave-private LDS tile laid out like the slab, then the 64 lanes copy consecutive 16-byte
+// units (1 KiB per store instruction).  The descriptor is sized to the wave's valid tracks: the range check drops the tail.
+template <int R, int NX>
+__device__ __forceinline__ void mlg_store_aos(const double (&x)[NX], const double (&P)[R][NX], const unsigned (&row)[R],
+                                              double *xdst, double *Pdst, double *tile, unsigned lane, unsigned valid)
+{
+    constexpr int EP = NX * NX, UP = 16 * EP / 2, UX = 16 * NX / 2;      // 16-byte units per wave
+    using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+    const unsigned q = lane >> 2;
+    double *tx = tile, *tP = tile + 16 * NX;
+    ml_wave_fence();
+    FK_UNROLL for (int k = 0; k < NX; ++k) tx[q * NX + k] = x[k];                         // the quad writes the same value
+    FK_UNROLL for (int r = 0; r < R; ++r)
+        FK_UNROLL for (int c = 0; c < NX; ++c) tP[q * EP + row[r] * NX + c] = P[r][c];
+    ml_wave_fence();
+    const rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(xdst, 0, (int)(valid * (unsigned)NX * 8u), 0x00020000);
+    const rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc(Pdst, 0, (int)(valid * (unsigned)EP * 8u), 0x00020000);
+    FK_UNROLL for (int it = 0; it * 64 < UX; ++it) {
+        const unsigned unit = it * 64u + lane;
+        if (it * 64 + 63 < UX || unit < (unsigned)UX) {
+            const u32x4 v = *reinterpret_cast<const u32x4 *>(tx + 2 * unit);
+            __builtin_amdgcn_raw_buffer_store_b128(v, rx, unit * 16u, 0, 0);
+        }
+    }
+    _Pragma("unroll 4") for (int it = 0; it * 64 < UP; ++it) {
+        const unsigned unit = it * 64u + lane;
+        if (it * 64 + 63 < UP || unit < (unsigned)UP) {
+            const u32x4 v = *reinterpret_cast<const u32x4 *>(tP + 2 * unit);
+            __builtin_amdgcn_raw_buffer_store_b128(v, rP, unit * 16u, 0, 0);
+        }
+    }
+}
+
+template <int NX, int NZ, int LAYOUT>
+__global__ void __launch_bounds__(BLOCK, 1)
+kf_mlg_kernel(const KfArgs a)
+{
+    constexpr int R = (NX + 3) / 4;
+    using LM = LdsModel<NX, NZ>;
+    constexpr bool AOS = LAYOUT == LAYOUT_AOS;
+    constexpr int TILE = 16 * NX + 16 * NX * NX;                 // AOS: one (x, P) output set of a wave
+    __shared__ double smem[LM::SIZE + (AOS ? (BLOCK / 64) * TILE : 0)];
+    double *tile = smem + LM::SIZE + (threadIdx.x >> 6) * TILE;
+    lds_fill<NX, NX>(smem + LM::OFF_F, a.F, NX, NX, 1.0, threadIdx.x);
+    lds_fill<NX, NX>(smem + LM::OFF_Q, a.Q, NX, NX, 0.0, threadIdx.x);
+    lds_fill<NZ, NX>(smem + LM::OFF_H, a.H, NZ, NX, 0.0, threadIdx.x);
+    lds_fill<NZ, NZ>(smem + LM::OFF_R, a.R, NZ, NZ, 1.0, threadIdx.x);
+    __syncthreads();
+    const double *sF = smem + LM::OFF_F, *sQ = smem + LM::OFF_Q, *sH = smem + LM::OFF_H, *sR = smem + LM::OFF_R;
+
+    const long N = a.N;
+    const unsigned L = threadIdx.x & 3u;
+    long trk = (long)blockIdx.x * (BLOCK / 4) + (threadIdx.x >> 2);
+    const bool owner = trk < N;                                // tail quads only duplicate: they never write the final state
+    if (trk >= N) trk = N - 1;
+    unsigned row[R];                                           // the rows this lane holds (clamped: see the header)
+    double live[R];                                            // 1.0 for a row of its own, 0.0 for a clamped duplicate
+    FK_UNROLL for (int r = 0; r < R; ++r) {
+        const unsigned g = L * (unsigned)R + (unsigned)r;
+        row[r] = g < (unsigned)NX ? g : (unsigned)NX - 1u;
+        live[r] = g < (unsigned)NX ? 1.0 : 0.0;
+    }
+    // element e of this lane's track sits at  lane offset + e * estride:  SOA: track*8 + e*N*8 ; AOS: track*E*8 + e*8
+    unsigned estride = AOS ? 8u : (unsigned)N * 8u;
+    asm volatile("" : "+s"(estride));
+    const unsigned t8 = (unsigned)trk * (AOS ? (unsigned)NX * 8u : 8u);                       // x-like arrays
+    const unsigned tz8 = (unsigned)trk * (AOS ? (unsigned)NZ * 8u : 8u);                      // z
+    unsigned off_row[R];                                                                      // element row[r] * NX of a covariance record
+    FK_UNROLL for (int r = 0; r < R; ++r)
+        off_row[r] = (AOS ? (unsigned)trk * (unsigned)(NX * NX) * 8u : (unsigned)trk * 8u) + row[r] * (unsigned)NX * estride;
+    const long w0 = (long)blockIdx.x * (BLOCK / 4) + (long)(threadIdx.x >> 6) * 16;
+    const unsigned valid = (unsigned)(N - w0 >= 16 ? 16 : (N - w0 > 0 ? N - w0 : 0));
+    const unsigned lane = threadIdx.x & 63u;
+    const uint8_t *mask_or_dummy = a.mask ? a.mask : reinterpret_cast<const uint8_t *>(a.z);
+
+    double P[R][NX], x[NX];
+    {
+        const MlView vx(a.x, t8, estride);
+        FK_UNROLL for (int r = 0; r < R; ++r) {
+            const MlView vP(a.P, off_row[r], estride);
+            FK_UNROLL for (int c = 0; c < NX; ++c) P[r][c] = vP.load(c);
+        }
+        FK_UNROLL for (int k = 0; k < NX; ++k) x[k] = vx.load(k);
+        FK_UNROLL for (int r = 0; r < R; ++r)
+            FK_UNROLL for (int c = 0; c < NX; ++c) asm volatile("" ::"v"(P[r][c]));     // landed before the loop (kf_ml.hip)
+        FK_UNROLL for (int k = 0; k < NX; ++k) asm volatile("" ::"v"(x[k]));
+    }
+    int st = 0;
+    double zn[NZ];
+    unsigned hn = 1u;
+    {
+        const MlView vz(a.z, tz8, estride);
+        FK_UNROLL for (int c = 0; c < NZ; ++c) zn[c] = vz.load(c);
+        const unsigned hb = mask_or_dummy[trk];
+        hn = a.mask ? hb : 1u;
+        FK_UNROLL for (int c = 0; c < NZ; ++c) asm volatile("" ::"v"(zn[c]));
+        asm volatile("" ::"v"(hn));
+    }
+    _Pragma("nounroll") for (long t = 0; t < a.T; ++t) {
+        double z[NZ];
+        const bool has_z = hn != 0u;
+        FK_UNROLL for (int c = 0; c < NZ; ++c) z[c] = has_z ? zn[c] : 0.0;
+        {
+            long tn = t + 1 < a.T ? t + 1 : t;
+            asm volatile("" : "+s"(tn));
+            const MlView vz(a.z + tn * N * NZ, tz8, estride);
+            FK_UNROLL for (int c = 0; c < NZ; ++c) zn[c] = vz.load(c);
+            const unsigned hb = mask_or_dummy[tn * N + trk];
+            hn = a.mask ? hb : 1u;
+        }
+        // ---------------------------------------------------------------- predict --
+        {
+            double xn[NX];
+            FK_UNROLL for (int i = 0; i < NX; ++i) {
+                double acc = sF[i * NX] * x[0];
+                FK_UNROLL for (int k = 1; k < NX; ++k) acc = fma(sF[i * NX + k], x[k], acc);
+                xn[i] = acc;
+                FK_STAGE();
+            }
+            FK_UNROLL for (int i = 0; i < NX; ++i) x[i] = xn[i];
+        }
+        if constexpr (!AOS) {
+            const MlView vx(a.means_p + t * N * NX, t8, estride);
+            FK_UNROLL for (int k = 0; k < NX; ++k) vx.store(k, x[k]);      // replicated: the quad writes the same bytes
+        }
+        FK_STAGE();
+        {
+            double T[R][NX];                 // T = P F' : T[r][i] = sum_k P[r][k] F[i][k]
+            FK_UNROLL for (int i = 0; i < NX; ++i) {
+                FK_UNROLL for (int r = 0; r < R; ++r) {
+                    double acc = P[r][0] * sF[i * NX];
+                    FK_UNROLL for (int k = 1; k < NX; ++k) acc = fma(P[r][k], sF[i * NX + k], acc);
+                    T[r][i] = acc;
+                }
+                FK_STAGE();
+            }
+            // P' = F T : row i (own) = sum_k F[i][k] T[k][:]
+            FK_UNROLL for (int k = 0; k < NX; ++k) {
+                double Tk[NX];
+                FK_OWNER_ROW(Tk, T, k, NX);
+                FK_UNROLL for (int r = 0; r < R; ++r) {
+                    const double f = sF[row[r] * NX + k];
+                    FK_UNROLL for (int j = 0; j < NX; ++j) P[r][j] = (k == 0) ? f * Tk[j] : fma(f, Tk[j], P[r][j]);
+                }
+                FK_STAGE();
+            }
+            FK_UNROLL for (int r = 0; r < R; ++r)
+                FK_UNROLL for (int j = 0; j < NX; ++j) P[r][j] = fma(a.alpha_sq, P[r][j], sQ[row[r] * NX + j]);
+        }
+        if constexpr (AOS) {
+            mlg_store_aos<R, NX>(x, P, row, a.means_p + (t * N + w0) * NX, a.covs_p + (t * N + w0) * NX * NX, tile, lane, valid);
+        } else {
+            FK_UNROLL for (int r = 0; r < R; ++r) {
+                const MlView vP(a.covs_p + t * N * NX * NX, off_row[r], estride);
+                FK_UNROLL for (int c = 0; c < NX; ++c) vP.store(c, P[r][c]);
+            }
+        }
+        FK_STAGE();
+        // ----------------------------------------------------------------- update --
+        // Joseph form with the identity-minus-product factors applied implicitly, WITHOUT assuming P symmetric
+        // (kf_ml.hip explains why H P is not replaced by (P H')'):
+        //   T1 = (I-KH) P = P - K (H P) ;  G = T1 H' ;  P+ = T1 (I-KH)' + K R K' = T1 + (K R - G) K'
+        double y[NZ], K[R][NZ];
+        {
+            FK_UNROLL for (int c = 0; c < NZ; ++c) {
+                double acc = sH[c * NX] * x[0];
+                FK_UNROLL for (int k = 1; k < NX; ++k) acc = fma(sH[c * NX + k], x[k], acc);
+                y[c] = z[c] - acc;
+            }
+            double PHT[R][NZ], S[NZ * NZ];
+            FK_UNROLL for (int r = 0; r < R; ++r) {
+                FK_UNROLL for (int c = 0; c < NZ; ++c) {
+                    double acc = P[r][0] * sH[c * NX];
+                    FK_UNROLL for (int k = 1; k < NX; ++k) acc = fma(P[r][k], sH[c * NX + k], acc);
+                    PHT[r][c] = acc;
+                }
+                FK_STAGE();
+            }
+            // S = H PHT + R, replicated in every lane: PHT's row k comes from its owner
+            FK_UNROLL for (int k = 0; k < NX; ++k) {
+                double pk[NZ];
+                FK_OWNER_ROW(pk, PHT, k, NZ);
+                FK_UNROLL for (int r = 0; r < NZ; ++r)
+                    FK_UNROLL for (int c = 0; c < NZ; ++c)
+                        S[r * NZ + c] = (k == 0) ? sH[r * NX] * pk[c] : fma(sH[r * NX + k], pk[c], S[r * NZ + c]);
+            }
+            FK_UNROLL for (int e = 0; e < NZ * NZ; ++e) S[e] += sR[e];
+            FK_STAGE();
+            double Lf[NZ * NZ], d[NZ], dinv[NZ], Kr[R * NZ];
+            FK_UNROLL for (int e = 0; e < NZ * NZ; ++e) Lf[e] = S[e];
+            if (!ldlt2<NZ>(Lf, d, dinv) && has_z) st |= ST_NOT_PD;
+            FK_UNROLL for (int r = 0; r < R; ++r)
+                FK_UNROLL for (int c = 0; c < NZ; ++c) Kr[r * NZ + c] = PHT[r][c];
+            solve_rows_ldlt<R, NZ>(Lf, dinv, Kr);
+            FK_UNROLL for (int r = 0; r < R; ++r)
+                FK_UNROLL for (int c = 0; c < NZ; ++c) K[r][c] = has_z ? Kr[r * NZ + c] : 0.0;
+        }
+        FK_STAGE();
+        {
+            // H P: this lane's OWN rows contribute sum_r H[c][row r] P[r][:] (a clamped duplicate: coefficient 0);
+            // the quad adds the four parts
+            double HP[NZ][NX];
+            FK_UNROLL for (int c = 0; c < NZ; ++c) {
+                double hc[R];
+                FK_UNROLL for (int r = 0; r < R; ++r) hc[r] = live[r] * sH[c * NX + row[r]];
+                FK_UNROLL for (int j = 0; j < NX; ++j) {
+                    double acc = hc[0] * P[0][j];
+                    FK_UNROLL for (int r = 1; r < R; ++r) acc = fma(hc[r], P[r][j], acc);
+                    HP[c][j] = quad_sum(acc);
+                }
+                FK_STAGE();
+            }
+            // T1 = P - K (H P) (own rows, in place)
+            FK_UNROLL for (int r = 0; r < R; ++r) {
+                FK_UNROLL for (int j = 0; j < NX; ++j) {
+                    double acc = P[r][j];
+                    FK_UNROLL for (int c = 0; c < NZ; ++c) acc = fma(-K[r][c], HP[c][j], acc);
+                    P[r][j] = acc;
+                }
+                FK_STAGE();
+            }
+            // D = K R - T1 H' (own rows)
+            double D[R][NZ];
+            FK_UNROLL for (int r = 0; r < R; ++r)
+                FK_UNROLL for (int c = 0; c < NZ; ++c) {
+                    double kr = K[r][0] * sR[c];
+                    FK_UNROLL for (int q = 1; q < NZ; ++q) kr = fma(K[r][q], sR[q * NZ + c], kr);
+                    double g = P[r][0] * sH[c * NX];
+                    FK_UNROLL for (int k = 1; k < NX; ++k) g = fma(P[r][k], sH[c * NX + k], g);
+                    D[r][c] = kr - g;
+                }
+            FK_STAGE();
+            // P+ = T1 + D K' : column j needs K's row j from its owner; the same row updates x[j]
+            FK_UNROLL for (int j = 0; j < NX; ++j) {
+                double Kj[NZ];
+                FK_OWNER_ROW(Kj, K, j, NZ);
+                double xa = x[j];
+                FK_UNROLL for (int c = 0; c < NZ; ++c) xa = fma(Kj[c], y[c], xa);
+                x[j] = xa;
+                FK_UNROLL for (int r = 0; r < R; ++r) {
+                    double acc = P[r][j];
+                    FK_UNROLL for (int c = 0; c < NZ; ++c) acc = fma(D[r][c], Kj[c], acc);
+                    P[r][j] = acc;
+                }
+            }
+        }
+        if constexpr (AOS) {
+            mlg_store_aos<R, NX>(x, P, row, a.means + (t * N + w0) * NX, a.covs + (t * N + w0) * NX * NX, tile, lane, valid);
+        } else {
+            const MlView vx(a.means + t * N * NX, t8, estride);
+            FK_UNROLL for (int k = 0; k < NX; ++k) vx.store(k, x[k]);
+            FK_UNROLL for (int r = 0; r < R; ++r) {
+                const MlView vP(a.covs + t * N * NX * NX, off_row[r], estride);
+                FK_UNROLL for (int c = 0; c < NX; ++c) vP.store(c, P[r][c]);
+            }
+        }
+    }
+    // the final state goes back in place: only a track's own quad writes it (a duplicating tail quad that loaded
+    // x0 / P0 late must not find the final state there)
+    if (owner) {
+        const MlView vx(a.x, t8, estride);
+        bool fin = all_finite<NX>(x);
+        FK_UNROLL for (int k = 0; k < NX; ++k) vx.store(k, x[k]);
+        FK_UNROLL for (int r = 0; r < R; ++r) {
+            const MlView vP(a.P, off_row[r], estride);
+            FK_UNROLL for (int c = 0; c < NX; ++c) {
+                vP.store(c, P[r][c]);
+                fin = fin && (fabs(P[r][c]) <= 1.79769313486231570815e+308);
+            }
+        }
+        if (a.status) {
+            int s = st | (fin ? 0 : ST_NONFINITE);
+            s |= __builtin_amdgcn_mov_dpp(s, 0xB1, 0xf, 0xf, true);
+            s |= __builtin_amdgcn_mov_dpp(s, 0x4E, 0xf, 0xf, true);
+            if (L == 0) a.status[trk] = s;
+        }
+    }
+}
+
+}  // namespace (instantiation)
+
+// returns 1 when this call is not one the four-lane kernel serves
+int FK_MLG_CAT(launch_kf_mlg_, FK_NX, FK_NZ)(const KfArgs &a, int layout, bool outs, int model_mode, hipStream_t s)
+{
+    using namespace FK_MLG_CAT(mlg_, FK_NX, FK_NZ);
+    if (model_mode != FK_MODEL_SHARED || a.n != FK_NX || a.m != FK_NZ || !outs || a.nu > 0 || a.update_first) return 1;
+    const dim3 grid((unsigned)((a.N + BLOCK / 4 - 1) / (BLOCK / 4))), block(BLOCK);
+    if (layout == FK_LAYOUT_AOS) hipLaunchKernelGGL((kf_mlg_kernel<FK_NX, FK_NZ, LAYOUT_AOS>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((kf_mlg_kernel<FK_NX, FK_NZ, LAYOUT_SOA>), grid, block, 0, s, a);
+    return check_launch("kf_mlg_kernel");
+}
+
+}  // namespace fk

@@ -420,3 +420,64 @@ def test_multilane_variants_small_shapes(N, T):
                 assert rel_err_rows(_per_track(got[k]), _per_track(ref[k])) < TOL, (layout, uf, k)
             last, lastP = (ref[2], ref[3]) if uf else (ref[0], ref[1])
             assert rel_err_rows(got[4], last[-1]) < TOL and rel_err_rows(got[5], lastP[-1]) < TOL
+
+
+@pytest.mark.parametrize("layout", ["soa", "aos"])
+@pytest.mark.parametrize("n,m", [(10, 1), (10, 4), (11, 2), (12, 3), (13, 1), (13, 4), (14, 2), (15, 3), (16, 1), (16, 4)])
+def test_four_lane_kernel_dims_10_to_16_vs_oracle(n, m, layout, monkeypatch):
+    """kf_mlg.hip (four lanes per track; the rows past n-1 of lane 3 clamped to row n-1, entering the quad's H P sum
+    with coefficient 0): every track its own state and measurements, N not a multiple of the 64 tracks of a workgroup,
+    alpha != 1, a mask with NaN behind it -- against the oracle, and against the padded one-lane kernel the same call
+    ran on before (FK_NO_MLG=1)."""
+    from gpu_util import run_kf_batch
+    rs = np.random.RandomState(100 * n + m)
+    N, T = 333, 12
+    A = rs.randn(N, n, n)
+    x0, P0 = rs.randn(N, n), 4.0 * (A @ A.transpose(0, 2, 1) / n + 0.5 * np.eye(n))
+    zs = rs.randn(T, N, m) * 3
+    F = np.eye(n) + 0.1 * rs.randn(n, n)
+    B = rs.randn(n, n)
+    Q = 0.1 * (B @ B.T / n + 0.5 * np.eye(n))
+    H = rs.randn(m, n)
+    C = rs.randn(m, m)
+    R = 0.5 * (C @ C.T / m + 0.5 * np.eye(m))
+    sample = [0, 1, 15, 16, 63, 64, 255, 256, N - 2, N - 1]
+    for masked in (False, True):
+        mask = (rs.rand(T, N) > 0.25) if masked else None
+        z = zs.copy()
+        if masked:
+            z[~mask] = np.nan
+        got = run_kf_batch(x0, P0, z, F, Q, H, R, layout=layout, alpha_sq=1.02 ** 2, mask=mask)
+        ref = kf_oracle.kf_batch_filter_tracks(x0, P0, z, F, Q, H, R, tracks=sample, alpha_sq=1.02 ** 2, mask=mask)
+        for k in range(4):
+            assert np.isfinite(got[k]).all(), (masked, k)
+            assert rel_err_rows(_per_track(got[k][:, sample]), _per_track(ref[k])) < TOL, (masked, k)
+        assert rel_err_rows(got[4][sample], ref[0][-1]) < TOL and rel_err_rows(got[5][sample], ref[1][-1]) < TOL
+    monkeypatch.setenv("FK_NO_MLG", "1")
+    old = run_kf_batch(x0, P0, zs, F, Q, H, R, layout=layout, alpha_sq=1.02 ** 2)
+    monkeypatch.delenv("FK_NO_MLG")
+    new = run_kf_batch(x0, P0, zs, F, Q, H, R, layout=layout, alpha_sq=1.02 ** 2)
+    for k in range(6):
+        assert rel_err_rows(new[k].reshape(-1, new[k].shape[-1]), old[k].reshape(-1, old[k].shape[-1])) < TOL, k
+
+
+@pytest.mark.parametrize("N", [1, 2, 3, 17, 64, 65])
+def test_four_lane_kernel_small_shapes(N):
+    """tiny / ragged banks, T = 1..3, both layouts (tail quads duplicate the last track; the AOS slab of a partly filled wave)"""
+    from gpu_util import run_kf_batch
+    n, m = 11, 2
+    rs = np.random.RandomState(900 + N)
+    F = np.eye(n) + 0.05 * rs.randn(n, n)
+    B = rs.randn(n, n)
+    Q = 0.1 * (B @ B.T / n + 0.5 * np.eye(n))
+    H, R = rs.randn(m, n), 0.5 * np.eye(m)
+    for T in (1, 2, 3):
+        A = rs.randn(N, n, n)
+        x0, P0 = rs.randn(N, n), A @ A.transpose(0, 2, 1) / n + 0.5 * np.eye(n)
+        zs = rs.randn(T, N, m)
+        ref = kf_oracle.kf_batch_filter_tracks(x0, P0, zs, F, Q, H, R, tracks=range(N))
+        for layout in ("soa", "aos"):
+            got = run_kf_batch(x0, P0, zs, F, Q, H, R, layout=layout)
+            for k in range(4):
+                assert rel_err_rows(_per_track(got[k]), _per_track(ref[k])) < TOL, (T, layout, k)
+            assert rel_err_rows(got[4], ref[0][-1]) < TOL and rel_err_rows(got[5], ref[1][-1]) < TOL
