@@ -26,8 +26,11 @@ namespace fk {
 #undef FK_RTS_INST
 
 #define FK_MLG_INST(NX, NZ) int launch_kf_mlg_##NX##_##NZ(const KfArgs &, int, bool, int, hipStream_t);
+#define FK_RMLG_INST(NX) int launch_rts_mlg_##NX(const RtsArgs &, int, bool, hipStream_t);
+#define FK_RMLX_INST(NX) int launch_rts_mlx_##NX(const RtsArgs &, int, bool, hipStream_t);
 #include "fk_dims_mlg.def"
 #undef FK_MLG_INST
+#undef FK_RMLG_INST
 
 int launch_kf_ml_9_3(const KfArgs &, int, bool, int, hipStream_t);   // kf_ml.hip: three lanes per track
 int launch_rts_ml_9(const RtsArgs &, int, bool, hipStream_t);
@@ -52,11 +55,26 @@ static const FastEntry fast_table[] = {
 #undef FK_FAST_INST
 };
 
-// kf_mlg.hip: four lanes per track, dim_x = 10..16
+struct RtsEntry_ {
+    int nx, exact;
+    int (*fn)(const RtsArgs &, int, bool, hipStream_t);
+};
+// kf_mlg.hip / rts_mlg.hip: four lanes per track, dim_x = 10..16
 static const FastEntry mlg_table[] = {
 #define FK_MLG_INST(NX, NZ) {NX, NZ, 0, launch_kf_mlg_##NX##_##NZ},
 #include "fk_dims_mlg.def"
 #undef FK_MLG_INST
+};
+
+static const RtsEntry_ rmlg_table[] = {
+#define FK_RMLG_INST(NX) {NX, 1, launch_rts_mlg_##NX},
+#include "fk_dims_mlg.def"
+#undef FK_RMLG_INST
+};
+
+static const RtsEntry_ rmlx_table[] = {
+#define FK_RMLX_INST(NX) {NX, 1, launch_rts_mlx_##NX},
+#include "fk_dims_mlg.def"
 };
 
 static const FastEntry *pick_fast(int n, int m)
@@ -287,6 +305,24 @@ int fk_kf_rts_f64(const fk_kf_desc *desc, const double *F, const double *Q, cons
     if (desc->n == 9 && !getenv("FK_NO_ML")) {
         const int rc = launch_rts_ml_9(a, desc->layout, uniform, (hipStream_t)stream);
         if (rc <= 0) return rc;            // 1 = not a call the multi-lane smoother serves
+    }
+    if (desc->n >= 10 && !getenv("FK_NO_MLG")) {
+        // eight lanes per track + LDS exchange where the four-lane kernel's unrolled step outgrows the instruction
+        // cache (dim_x >= 15); FK_RTS_LANES=8 / 4 forces one organisation (A/B measurements)
+        const char *lv = getenv("FK_RTS_LANES");
+        const int lanes = lv ? atoi(lv) : (desc->n >= 15 ? 8 : 4);
+        if (lanes == 8) {
+            for (const RtsEntry_ &g : rmlx_table) {
+                if (g.nx != desc->n) continue;
+                const int rc = g.fn(a, desc->layout, uniform, (hipStream_t)stream);
+                if (rc <= 0) return rc;
+            }
+        }
+        for (const RtsEntry_ &g : rmlg_table) {
+            if (g.nx != desc->n) continue;
+            const int rc = g.fn(a, desc->layout, uniform, (hipStream_t)stream);
+            if (rc <= 0) return rc;
+        }
     }
     return e->fn(a, desc->layout, uniform, (hipStream_t)stream);
 }

@@ -481,3 +481,75 @@ def test_four_lane_kernel_small_shapes(N):
             for k in range(4):
                 assert rel_err_rows(_per_track(got[k]), _per_track(ref[k])) < TOL, (T, layout, k)
             assert rel_err_rows(got[4], ref[0][-1]) < TOL and rel_err_rows(got[5], ref[1][-1]) < TOL
+
+
+@pytest.mark.parametrize("layout", ["soa", "aos"])
+@pytest.mark.parametrize("n", [10, 11, 12, 13, 14, 15, 16])
+def test_four_lane_smoother_dims_10_to_16_vs_oracle(n, layout, monkeypatch):
+    """rts_mlg.hip: every track its own filter output, both index conventions, N ragged; against the oracle and against
+    the padded one-lane smoother (FK_NO_MLG=1)."""
+    from gpu_util import run_rts
+    rs = np.random.RandomState(1600 + n)
+    N, T = 333, 9
+    A = rs.randn(T, N, n, n)
+    Xs, Ps = rs.randn(T, N, n), A @ A.transpose(0, 1, 3, 2) / n + 0.5 * np.eye(n)
+    F = np.eye(n) + 0.1 * rs.randn(n, n)
+    B = rs.randn(n, n)
+    Q = 0.1 * (B @ B.T / n + 0.5 * np.eye(n))
+    sample = [0, 1, 15, 16, 63, 64, 255, 256, N - 2, N - 1]
+    for conv, name in ((0, "class"), (1, "module")):
+        got = run_rts(Xs, Ps, F, Q, layout=layout, convention=conv)
+        ref = kf_oracle.rts_smoother_tracks(Xs, Ps, F, Q, tracks=sample, convention=name)
+        for k in range(4):
+            assert np.isfinite(got[k]).all(), (name, k)
+            assert rel_err_rows(_per_track(got[k][:, sample]), _per_track(ref[k])) < TOL, (name, k)
+    monkeypatch.setenv("FK_NO_MLG", "1")
+    old = run_rts(Xs, Ps, F, Q, layout=layout)
+    monkeypatch.delenv("FK_NO_MLG")
+    new = run_rts(Xs, Ps, F, Q, layout=layout)
+    for k in range(4):
+        assert rel_err_rows(_per_track(new[k]), _per_track(old[k])) < TOL, k
+
+
+@pytest.mark.parametrize("lanes", ["4", "8"])
+@pytest.mark.parametrize("layout", ["soa", "aos"])
+@pytest.mark.parametrize("n", [13, 14, 15, 16])
+def test_smoother_both_organisations_dims_13_to_16(n, layout, lanes, monkeypatch):
+    """dims 13..16 through BOTH smoothers (FK_RTS_LANES): four lanes + DPP (rts_mlg.hip) and eight lanes + LDS exchange
+    (rts_mlx.hip); every track its own data, ragged N (a partly filled group / wave / workgroup), against the oracle."""
+    from gpu_util import run_rts
+    monkeypatch.setenv("FK_RTS_LANES", lanes)
+    rs = np.random.RandomState(2600 + n)
+    N, T = 203, 7
+    A = rs.randn(T, N, n, n)
+    Xs, Ps = rs.randn(T, N, n), A @ A.transpose(0, 1, 3, 2) / n + 0.5 * np.eye(n)
+    F = np.eye(n) + 0.1 * rs.randn(n, n)
+    B = rs.randn(n, n)
+    Q = 0.1 * (B @ B.T / n + 0.5 * np.eye(n))
+    sample = [0, 1, 7, 8, 31, 32, 63, 64, N - 2, N - 1]
+    got = run_rts(Xs, Ps, F, Q, layout=layout)
+    ref = kf_oracle.rts_smoother_tracks(Xs, Ps, F, Q, tracks=sample)
+    for k in range(4):
+        assert np.isfinite(got[k]).all(), k
+        assert rel_err_rows(_per_track(got[k][:, sample]), _per_track(ref[k])) < TOL, k
+    for (Ns, Ts) in ((1, 2), (9, 3), (33, 2)):
+        ref = kf_oracle.rts_smoother_tracks(Xs[:Ts, :Ns], Ps[:Ts, :Ns], F, Q, tracks=range(Ns))
+        got = run_rts(np.ascontiguousarray(Xs[:Ts, :Ns]), np.ascontiguousarray(Ps[:Ts, :Ns]), F, Q, layout=layout)
+        for k in range(4):
+            assert rel_err_rows(_per_track(got[k]), _per_track(ref[k])) < TOL, (Ns, Ts, k)
+
+
+@pytest.mark.parametrize("N,T", [(1, 2), (2, 3), (17, 2), (65, 4)])
+def test_four_lane_smoother_small_shapes(N, T):
+    from gpu_util import run_rts
+    n = 13
+    rs = np.random.RandomState(40 + N)
+    A = rs.randn(T, N, n, n)
+    Xs, Ps = rs.randn(T, N, n), A @ A.transpose(0, 1, 3, 2) / n + 0.5 * np.eye(n)
+    F = np.eye(n) + 0.05 * rs.randn(n, n)
+    Q = 0.05 * np.eye(n)
+    ref = kf_oracle.rts_smoother_tracks(Xs, Ps, F, Q, tracks=range(N))
+    for layout in ("soa", "aos"):
+        got = run_rts(Xs, Ps, F, Q, layout=layout)
+        for k in range(4):
+            assert rel_err_rows(_per_track(got[k]), _per_track(ref[k])) < TOL, (layout, k)
