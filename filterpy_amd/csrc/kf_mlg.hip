@@ -15,10 +15,11 @@
 //            H P = butterfly sum of the lanes' partial products ; T1 = P - K (H P) ; D = K R - T1 H' ;
 //            P+ = T1 + D K' with K's rows broadcast (the same row updates x)
 //
-// Exact dims (one instantiation per (dim_x, dim_z)), one constant model shared by the bank, predict -> update, all
-// four outputs, optional mask (branch-free, see kf_ml.hip), SOA and AOS (outputs staged through a wave-private LDS tile
-// and written as 1 KiB stores).  One wave per SIMD: at dim_x = 16 a lane holds P (64 doubles) and T (64) at once.
-// Everything else at these sizes stays on the padded kernels.
+// Exact dims (one instantiation per (dim_x, dim_z)), all four outputs, optional mask (branch-free, see kf_ml.hip), SOA
+// and AOS (outputs staged through a wave-private LDS tile and written as 1 KiB stores); the plain call (one constant
+// model, predict -> update) and, as VAR instantiations, per-step model lists, a control input and update_first.  One
+// wave per SIMD: at dim_x = 16 a lane holds P (64 doubles) and T (64) at once.  Per-track models, the update's
+// by-products and dim_z > 4 at these sizes stay on the padded kernels.
 #include <stdlib.h>
 
 #include "fk_device.hpp"
@@ -94,7 +95,11 @@ __device__ __forceinline__ void mlg_store_aos(const double (&x)[NX], const doubl
     }
 }
 
-template <int NX, int NZ, int LAYOUT>
+// VAR: batch_filter's other arguments (kalman_filter.py:941-991) exactly as kf_ml.hip's VAR family serves them at (9, 3):
+// one model per step shared by the bank ([F | Q | H | R | B] double-buffered in LDS, fetched a step ahead), a control
+// input x = F x + B u (u[t] travels with z[t]), both as BRANCH-FREE run-time switches; UF (update_first) swaps the
+// halves of the step at compile time (the predict half is kf_mlg_predict.inc, included before or after the update half).
+template <int NX, int NZ, int LAYOUT, bool VAR = false, bool UF = false>
 __global__ void __launch_bounds__(BLOCK, 1)
 kf_mlg_kernel(const KfArgs a)
 {
@@ -102,14 +107,42 @@ kf_mlg_kernel(const KfArgs a)
     using LM = LdsModel<NX, NZ>;
     constexpr bool AOS = LAYOUT == LAYOUT_AOS;
     constexpr int TILE = 16 * NX + 16 * NX * NX;                 // AOS: one (x, P) output set of a wave
-    __shared__ double smem[LM::SIZE + (AOS ? (BLOCK / 64) * TILE : 0)];
-    double *tile = smem + LM::SIZE + (threadIdx.x >> 6) * TILE;
+    constexpr int NUC = 4;                                       // padded dim_u (VAR)
+    constexpr int MLEN = LM::SIZE + NX * NUC;                    // VAR: [F | Q | H | R | B padded to NX x NUC]
+    constexpr int MSTR = (MLEN + 2) & ~1;                        // ... + the pad slot idle fetch slots publish into
+    constexpr int MPT = (MLEN + BLOCK - 1) / BLOCK;              // model elements a thread fetches per step
+    constexpr int MSZ = VAR ? 2 * MSTR : LM::SIZE;
+    static_assert(!UF || VAR, "update_first is a VAR instantiation");
+    __shared__ double smem[MSZ + (AOS ? (BLOCK / 64) * TILE : 0)];
+    double *tile = smem + MSZ + (threadIdx.x >> 6) * TILE;
     lds_fill<NX, NX>(smem + LM::OFF_F, a.F, NX, NX, 1.0, threadIdx.x);
     lds_fill<NX, NX>(smem + LM::OFF_Q, a.Q, NX, NX, 0.0, threadIdx.x);
     lds_fill<NZ, NX>(smem + LM::OFF_H, a.H, NZ, NX, 0.0, threadIdx.x);
     lds_fill<NZ, NZ>(smem + LM::OFF_R, a.R, NZ, NZ, 1.0, threadIdx.x);
+    if constexpr (VAR) lds_fill<NX, NUC>(smem + LM::SIZE, a.nu > 0 ? a.B : nullptr, NX, a.nu, 0.0, threadIdx.x);
+    // element k of the concatenated model of step tt (B goes with the model mode like the others; no control input:
+    // a valid dummy address, the value selected to 0)
+    const double *B_or_dummy = VAR && a.nu > 0 ? a.B : a.F;
+    auto model_elem = [&](long tt, int k) -> double {
+        if (k < LM::OFF_Q) return a.F[tt * (NX * NX) + k];
+        if (k < LM::OFF_H) return a.Q[tt * (NX * NX) + (k - LM::OFF_Q)];
+        if (k < LM::OFF_R) return a.H[tt * (NZ * NX) + (k - LM::OFF_H)];
+        if (k < LM::SIZE) return a.R[tt * (NZ * NZ) + (k - LM::OFF_R)];
+        const int i = (k - LM::SIZE) / NUC, j = (k - LM::SIZE) % NUC;
+        const bool live = k < MLEN && j < a.nu;
+        const double v = B_or_dummy[live ? tt * (long)(NX * a.nu) + i * a.nu + j : 0];
+        return live ? v : 0.0;
+    };
+    double mnext[VAR ? MPT : 1];               // this thread's elements of the NEXT step's model
+    if constexpr (VAR) {
+        FK_UNROLL for (int e = 0; e < MPT; ++e) {
+            mnext[e] = model_elem(a.model_t && a.T > 1 ? 1 : 0, (int)threadIdx.x + e * BLOCK);
+            asm volatile("" ::"v"(mnext[e]));
+        }
+    }
     __syncthreads();
     const double *sF = smem + LM::OFF_F, *sQ = smem + LM::OFF_Q, *sH = smem + LM::OFF_H, *sR = smem + LM::OFF_R;
+    const double *sB = smem + LM::SIZE;
 
     const long N = a.N;
     const unsigned L = threadIdx.x & 3u;
@@ -135,6 +168,10 @@ kf_mlg_kernel(const KfArgs a)
     const unsigned valid = (unsigned)(N - w0 >= 16 ? 16 : (N - w0 > 0 ? N - w0 : 0));
     const unsigned lane = threadIdx.x & 63u;
     const uint8_t *mask_or_dummy = a.mask ? a.mask : reinterpret_cast<const uint8_t *>(a.z);
+    const unsigned nu = VAR ? (unsigned)a.nu : 0u;
+    const unsigned nu_idx = nu ? nu - 1u : 0u;
+    const unsigned tu8 = (unsigned)trk * (AOS ? nu * 8u : 8u);                                // u
+    const double *u_or_dummy = VAR && nu ? a.u : a.z;
 
     double P[R][NX], x[NX];
     {
@@ -150,19 +187,32 @@ kf_mlg_kernel(const KfArgs a)
     }
     int st = 0;
     double zn[NZ];
+    double un[VAR ? NUC : 1];
     unsigned hn = 1u;
     {
         const MlView vz(a.z, tz8, estride);
         FK_UNROLL for (int c = 0; c < NZ; ++c) zn[c] = vz.load(c);
         const unsigned hb = mask_or_dummy[trk];
         hn = a.mask ? hb : 1u;
+        if constexpr (VAR) {
+            const MlView vu(u_or_dummy, tu8, estride);
+            FK_UNROLL for (int c = 0; c < NUC; ++c) {
+                const double v = vu.load((unsigned)c < nu ? c : (int)nu_idx);   // clamped element index: no branch
+                un[c] = nu ? v : 0.0;
+            }
+            FK_UNROLL for (int c = 0; c < NUC; ++c) asm volatile("" ::"v"(un[c]));
+        }
         FK_UNROLL for (int c = 0; c < NZ; ++c) asm volatile("" ::"v"(zn[c]));
         asm volatile("" ::"v"(hn));
     }
     _Pragma("nounroll") for (long t = 0; t < a.T; ++t) {
         double z[NZ];
+        double u[VAR ? NUC : 1];
         const bool has_z = hn != 0u;
         FK_UNROLL for (int c = 0; c < NZ; ++c) z[c] = has_z ? zn[c] : 0.0;
+        if constexpr (VAR) {
+            FK_UNROLL for (int c = 0; c < NUC; ++c) u[c] = un[c];
+        }
         {
             long tn = t + 1 < a.T ? t + 1 : t;
             asm volatile("" : "+s"(tn));
@@ -170,55 +220,29 @@ kf_mlg_kernel(const KfArgs a)
             FK_UNROLL for (int c = 0; c < NZ; ++c) zn[c] = vz.load(c);
             const unsigned hb = mask_or_dummy[tn * N + trk];
             hn = a.mask ? hb : 1u;
-        }
-        // ---------------------------------------------------------------- predict --
-        {
-            double xn[NX];
-            FK_UNROLL for (int i = 0; i < NX; ++i) {
-                double acc = sF[i * NX] * x[0];
-                FK_UNROLL for (int k = 1; k < NX; ++k) acc = fma(sF[i * NX + k], x[k], acc);
-                xn[i] = acc;
-                FK_STAGE();
-            }
-            FK_UNROLL for (int i = 0; i < NX; ++i) x[i] = xn[i];
-        }
-        if constexpr (!AOS) {
-            const MlView vx(a.means_p + t * N * NX, t8, estride);
-            FK_UNROLL for (int k = 0; k < NX; ++k) vx.store(k, x[k]);      // replicated: the quad writes the same bytes
-        }
-        FK_STAGE();
-        {
-            double T[R][NX];                 // T = P F' : T[r][i] = sum_k P[r][k] F[i][k]
-            FK_UNROLL for (int i = 0; i < NX; ++i) {
-                FK_UNROLL for (int r = 0; r < R; ++r) {
-                    double acc = P[r][0] * sF[i * NX];
-                    FK_UNROLL for (int k = 1; k < NX; ++k) acc = fma(P[r][k], sF[i * NX + k], acc);
-                    T[r][i] = acc;
+            if constexpr (VAR) {
+                const MlView vu(u_or_dummy + tn * N * (long)nu, tu8, estride);
+                FK_UNROLL for (int c = 0; c < NUC; ++c) {
+                    const double v = vu.load((unsigned)c < nu ? c : (int)nu_idx);
+                    un[c] = nu ? v : 0.0;
                 }
-                FK_STAGE();
-            }
-            // P' = F T : row i (own) = sum_k F[i][k] T[k][:]
-            FK_UNROLL for (int k = 0; k < NX; ++k) {
-                double Tk[NX];
-                FK_OWNER_ROW(Tk, T, k, NX);
-                FK_UNROLL for (int r = 0; r < R; ++r) {
-                    const double f = sF[row[r] * NX + k];
-                    FK_UNROLL for (int j = 0; j < NX; ++j) P[r][j] = (k == 0) ? f * Tk[j] : fma(f, Tk[j], P[r][j]);
-                }
-                FK_STAGE();
-            }
-            FK_UNROLL for (int r = 0; r < R; ++r)
-                FK_UNROLL for (int j = 0; j < NX; ++j) P[r][j] = fma(a.alpha_sq, P[r][j], sQ[row[r] * NX + j]);
-        }
-        if constexpr (AOS) {
-            mlg_store_aos<R, NX>(x, P, row, a.means_p + (t * N + w0) * NX, a.covs_p + (t * N + w0) * NX * NX, tile, lane, valid);
-        } else {
-            FK_UNROLL for (int r = 0; r < R; ++r) {
-                const MlView vP(a.covs_p + t * N * NX * NX, off_row[r], estride);
-                FK_UNROLL for (int c = 0; c < NX; ++c) vP.store(c, P[r][c]);
             }
         }
-        FK_STAGE();
+        // VAR: mnext holds this thread's elements of model[t+1]; keep them for the hand-over at the end of the step and
+        // request model[t+2] (consumed one step later: a counted wait)
+        double mpub[VAR ? MPT : 1];
+        if constexpr (VAR) {
+            long t2 = a.model_t ? (t + 2 < a.T ? t + 2 : a.T - 1) : 0;
+            asm volatile("" : "+s"(t2));
+            FK_UNROLL for (int e = 0; e < MPT; ++e) {
+                mpub[e] = mnext[e];
+                mnext[e] = model_elem(t2, (int)threadIdx.x + e * BLOCK);
+            }
+        }
+        if constexpr (!UF) {
+#include "kf_mlg_predict.inc"
+        }
+        {
         // ----------------------------------------------------------------- update --
         // Joseph form with the identity-minus-product factors applied implicitly, WITHOUT assuming P symmetric
         // (kf_ml.hip explains why H P is not replaced by (P H')'):
@@ -317,6 +341,25 @@ kf_mlg_kernel(const KfArgs a)
                 FK_UNROLL for (int c = 0; c < NX; ++c) vP.store(c, P[r][c]);
             }
         }
+        }      // update half
+        if constexpr (UF) {
+#include "kf_mlg_predict.inc"
+        }
+        if constexpr (VAR) {
+            // publish model[t+1] into the other LDS buffer: nobody reads that buffer during step t, and one barrier makes
+            // it visible for step t+1 (every thread of the workgroup runs all T steps)
+            double *nb = smem + ((t + 1) & 1) * MSTR;
+            FK_UNROLL for (int e = 0; e < MPT; ++e) {
+                const unsigned k = threadIdx.x + (unsigned)e * BLOCK;
+                nb[k < (unsigned)MLEN ? k : (unsigned)MLEN] = mpub[e];       // slots past the model: one pad slot
+            }
+            __syncthreads();
+            sF = nb + LM::OFF_F;
+            sQ = nb + LM::OFF_Q;
+            sH = nb + LM::OFF_H;
+            sR = nb + LM::OFF_R;
+            sB = nb + LM::SIZE;
+        }
     }
     // the final state goes back in place: only a track's own quad writes it (a duplicating tail quad that loaded
     // x0 / P0 late must not find the final state there)
@@ -346,8 +389,19 @@ kf_mlg_kernel(const KfArgs a)
 int FK_MLG_CAT(launch_kf_mlg_, FK_NX, FK_NZ)(const KfArgs &a, int layout, bool outs, int model_mode, hipStream_t s)
 {
     using namespace FK_MLG_CAT(mlg_, FK_NX, FK_NZ);
-    if (model_mode != FK_MODEL_SHARED || a.n != FK_NX || a.m != FK_NZ || !outs || a.nu > 0 || a.update_first) return 1;
+    if ((model_mode != FK_MODEL_SHARED && model_mode != FK_MODEL_PER_STEP) || a.n != FK_NX || a.m != FK_NZ || !outs) return 1;
     const dim3 grid((unsigned)((a.N + BLOCK / 4 - 1) / (BLOCK / 4))), block(BLOCK);
+    if (model_mode == FK_MODEL_PER_STEP || a.nu > 0 || a.update_first) {
+        // the VAR instantiations (FK_ML_VAR=0 sends these calls back to the padded kernel)
+        const char *vv = getenv("FK_ML_VAR");
+        if (a.nu > 4 || (vv && atoi(vv) == 0)) return 1;
+#define GOV(UFV)                                                                                                    \
+    if (layout == FK_LAYOUT_AOS) hipLaunchKernelGGL((kf_mlg_kernel<FK_NX, FK_NZ, LAYOUT_AOS, true, UFV>), grid, block, 0, s, a); \
+    else hipLaunchKernelGGL((kf_mlg_kernel<FK_NX, FK_NZ, LAYOUT_SOA, true, UFV>), grid, block, 0, s, a)
+        if (a.update_first) { GOV(true); } else { GOV(false); }
+#undef GOV
+        return check_launch("kf_mlg_kernel<var>");
+    }
     if (layout == FK_LAYOUT_AOS) hipLaunchKernelGGL((kf_mlg_kernel<FK_NX, FK_NZ, LAYOUT_AOS>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((kf_mlg_kernel<FK_NX, FK_NZ, LAYOUT_SOA>), grid, block, 0, s, a);
     return check_launch("kf_mlg_kernel");

@@ -553,3 +553,46 @@ def test_four_lane_smoother_small_shapes(N, T):
         got = run_rts(Xs, Ps, F, Q, layout=layout)
         for k in range(4):
             assert rel_err_rows(_per_track(got[k]), _per_track(ref[k])) < TOL, (layout, k)
+
+
+@pytest.mark.parametrize("layout", ["soa", "aos"])
+@pytest.mark.parametrize("n,m", [(10, 2), (13, 4), (16, 3)])
+def test_four_lane_kernel_variants_vs_oracle(n, m, layout):
+    """kf_mlg.hip's VAR instantiations (per-step model lists incl. B, control input, update_first, mask: every
+    combination) at dims above 9 -- calls that ran on the padded one-lane kernel before."""
+    from gpu_util import run_kf_batch
+    from filterpy_amd._abi import FK_MODEL_PER_STEP, FK_MODEL_SHARED
+    nu = 3
+    rs = np.random.RandomState(5000 + 10 * n + m)
+    N, T = 203, 7
+    A = rs.randn(N, n, n)
+    x0, P0 = rs.randn(N, n), 4.0 * (A @ A.transpose(0, 2, 1) / n + 0.5 * np.eye(n))
+    zs, us = rs.randn(T, N, m) * 3, rs.randn(T, N, nu)
+
+    def spd(k, s, cnt):
+        G = rs.randn(cnt, k, k)
+        return s * (G @ G.transpose(0, 2, 1) / k + 0.5 * np.eye(k))
+    Fs = np.eye(n) + 0.1 * rs.randn(T, n, n)
+    Qs, Hs, Rs, Bs = spd(n, 0.1, T), rs.randn(T, m, n), spd(m, 0.5, T), rs.randn(T, n, nu)
+    mask = rs.rand(T, N) > 0.25
+    sample = [0, 1, 15, 16, 63, 64, 127, 128, N - 2, N - 1]
+    for per_step in (False, True):
+        for ctrl in (False, True):
+            for uf in (False, True):
+                for masked in (False, True):
+                    if not (per_step or ctrl or uf):
+                        continue
+                    mods = (Fs, Qs, Hs, Rs) if per_step else (Fs[0], Qs[0], Hs[0], Rs[0])
+                    B = None if not ctrl else (Bs if per_step else Bs[0])
+                    z = zs.copy()
+                    if masked:
+                        z[~mask] = np.nan
+                    kw = dict(B=B, us=us if ctrl else None, update_first=uf, mask=mask if masked else None, alpha_sq=1.01 ** 2)
+                    got = run_kf_batch(x0, P0, z, *mods, layout=layout, mode=FK_MODEL_PER_STEP if per_step else FK_MODEL_SHARED, **kw)
+                    ref = kf_oracle.kf_batch_filter_tracks(x0, P0, z, *mods, tracks=sample, **kw)
+                    tag = (per_step, ctrl, uf, masked)
+                    for k in range(4):
+                        assert np.isfinite(got[k]).all(), (tag, k)
+                        assert rel_err_rows(_per_track(got[k][:, sample]), _per_track(ref[k])) < TOL, (tag, k)
+                    last, lastP = (ref[2], ref[3]) if uf else (ref[0], ref[1])
+                    assert rel_err_rows(got[4][sample], last[-1]) < TOL and rel_err_rows(got[5][sample], lastP[-1]) < TOL, tag
