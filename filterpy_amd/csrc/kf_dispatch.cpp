@@ -180,11 +180,12 @@ static int run_kf(const fk_kf_desc *d, KfArgs &a, void *stream)
     if (a.do_predict && a.do_update &&
         (all_out || no_out) && !a.y_out && !a.K_out && !a.S_out && !a.SI_out && !a.ll_out && !a.maha_out &&
         !a.rj_diag && !getenv("FK_NO_FAST")) {
-        if (d->n == 9 && d->m == 3 && !getenv("FK_NO_ML")) {
+        const char *g9 = getenv("FK_ML9");          // "g": dim_x = 9 on the four-lane kernels (A/B against kf_ml / rts_ml)
+        if (d->n == 9 && d->m == 3 && !getenv("FK_NO_ML") && !(g9 && g9[0] == 'g')) {
             const int rc = launch_kf_ml_9_3(a, d->layout, all_out, d->model_mode, (hipStream_t)stream);
             if (rc <= 0) return rc;        // 1 = not a call the multi-lane kernel serves
         }
-        if (d->n >= 10 && !getenv("FK_NO_MLG")) {
+        if ((d->n >= 10 || (g9 && g9[0] == 'g')) && !getenv("FK_NO_MLG")) {
             for (const FastEntry &g : mlg_table) {
                 if (g.nx != d->n || g.nz != d->m) continue;
                 const int rc = g.fn(a, d->layout, all_out, d->model_mode, (hipStream_t)stream);
@@ -302,15 +303,20 @@ int fk_kf_rts_f64(const fk_kf_desc *desc, const double *F, const double *Q, cons
     a.model_t = (desc->model_mode == FK_MODEL_PER_TRACK_STEP || desc->model_mode == FK_MODEL_PER_STEP) ? 1 : 0;
     a.conv_off = index_convention == 0 ? 1 : 0;
     const bool uniform = (desc->model_mode == FK_MODEL_SHARED || desc->model_mode == FK_MODEL_PER_STEP);
-    if (desc->n == 9 && !getenv("FK_NO_ML")) {
+    // dim_x = 9: the three-lane smoother (rts_ml_kernel) in the element-major layout, the four-lane one (rts_mlg_kernel<9>)
+    // in NumPy order -- its row blocks leave through an LDS slab as 1 KiB stores: 0.51 of HBM against 0.35 for
+    // rts_ml's 16-byte-per-lane AOS path (profiles/r02/c3_ml_vs_mlg.jsonl).  FK_ML9=m / g forces one family.
+    const char *g9 = getenv("FK_ML9");
+    const bool rts9_generic = g9 ? g9[0] == 'g' : desc->layout == FK_LAYOUT_AOS;
+    if (desc->n == 9 && !getenv("FK_NO_ML") && !rts9_generic) {
         const int rc = launch_rts_ml_9(a, desc->layout, uniform, (hipStream_t)stream);
         if (rc <= 0) return rc;            // 1 = not a call the multi-lane smoother serves
     }
-    if (desc->n >= 10 && !getenv("FK_NO_MLG")) {
+    if ((desc->n >= 10 || (desc->n == 9 && rts9_generic)) && !getenv("FK_NO_MLG")) {
         // eight lanes per track + LDS exchange where the four-lane kernel's unrolled step outgrows the instruction
         // cache (dim_x >= 15); FK_RTS_LANES=8 / 4 forces one organisation (A/B measurements)
         const char *lv = getenv("FK_RTS_LANES");
-        const int lanes = lv ? atoi(lv) : (desc->n >= 15 ? 8 : 4);
+        const int lanes = lv ? atoi(lv) : ((desc->n >= 15 || (desc->n == 14 && desc->layout == FK_LAYOUT_AOS)) ? 8 : 4);   // (n = 14 AOS: 76 KB of code)
         if (lanes == 8) {
             for (const RtsEntry_ &g : rmlx_table) {
                 if (g.nx != desc->n) continue;

@@ -113,7 +113,11 @@ kf_mlg_kernel(const KfArgs a)
     constexpr int MPT = (MLEN + BLOCK - 1) / BLOCK;              // model elements a thread fetches per step
     constexpr int MSZ = VAR ? 2 * MSTR : LM::SIZE;
     static_assert(!UF || VAR, "update_first is a VAR instantiation");
-    __shared__ double smem[MSZ + (AOS ? (BLOCK / 64) * TILE : 0)];
+    // SOA covariances leave through an LDS slab as 16-byte units (ml_store_rows_soa_slab) up to dim_x = 12: measured
+    // 0.37 -> 0.48 of HBM at (10,2), 0.34 -> 0.35 at (12,3), but 0.39 -> 0.32 at (14,4) -- the larger kernels are bound by
+    // their arithmetic and code size, not by store slots (profiles/r02/dims_10_16.jsonl vs dims_10_16_slab.jsonl)
+    constexpr bool SOA_SLAB = !AOS && NX <= 12;
+    __shared__ double smem[MSZ + (AOS || SOA_SLAB ? (BLOCK / 64) * TILE : 0)];
     double *tile = smem + MSZ + (threadIdx.x >> 6) * TILE;
     lds_fill<NX, NX>(smem + LM::OFF_F, a.F, NX, NX, 1.0, threadIdx.x);
     lds_fill<NX, NX>(smem + LM::OFF_Q, a.Q, NX, NX, 0.0, threadIdx.x);
@@ -336,9 +340,13 @@ kf_mlg_kernel(const KfArgs a)
         } else {
             const MlView vx(a.means + t * N * NX, t8, estride);
             FK_UNROLL for (int k = 0; k < NX; ++k) vx.store(k, x[k]);
-            FK_UNROLL for (int r = 0; r < R; ++r) {
-                const MlView vP(a.covs + t * N * NX * NX, off_row[r], estride);
-                FK_UNROLL for (int c = 0; c < NX; ++c) vP.store(c, P[r][c]);
+            if constexpr (SOA_SLAB) {
+                ml_store_rows_soa_slab<R, NX, 16>(P, row, a.covs + t * N * NX * NX, N, w0, tile, lane, lane >> 2, valid);
+            } else {
+                FK_UNROLL for (int r = 0; r < R; ++r) {
+                    const MlView vP(a.covs + t * N * NX * NX, off_row[r], estride);
+                    FK_UNROLL for (int c = 0; c < NX; ++c) vP.store(c, P[r][c]);
+                }
             }
         }
         }      // update half

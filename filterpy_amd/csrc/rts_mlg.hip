@@ -65,6 +65,7 @@ rts_mlg_kernel(const RtsArgs a)
 {
     constexpr int R = (NX + 3) / 4;
     constexpr bool AOS = LAYOUT == LAYOUT_AOS;
+    constexpr bool SOA_SLAB = !AOS && NX <= 12;      // SOA row blocks through the slab too (16-byte units): n = 10: 0.36 -> 0.45 of HBM, n = 14: 0.32 -> 0.30
     // One wave-private LDS region, used in turn as the AOS staging slab (16 x NX*NX doubles) and as the PARK of a
     // row block ([element][lane], conflict-free, R*NX x 64 doubles): the smoothed P of step k+1 waits there between
     // iterations and D = Pn - Pp across the factorisation.
@@ -115,6 +116,8 @@ rts_mlg_kernel(const RtsArgs a)
 #define FK_STORE_ROWS(base, step, M)                                                   \
     if constexpr (AOS) {                                                               \
         store_rows_aos<R, NX>(M, row, (base) + ((step) * N + w0) * NX * NX, tile, lane, valid); \
+    } else if constexpr (SOA_SLAB) {                                                   \
+        ml_store_rows_soa_slab<R, NX, 16>(M, row, (base) + (step) * ps_blk, N, w0, tile, lane, lane >> 2, valid); \
     } else {                                                                           \
         FK_UNROLL for (int r_ = 0; r_ < R; ++r_) {                                     \
             const MlView v_((base) + (step) * ps_blk, off_row[r_], estride);           \
@@ -186,7 +189,7 @@ rts_mlg_kernel(const RtsArgs a)
             }
             FK_UNROLL for (int r = 0; r < R; ++r)
                 FK_UNROLL for (int j = 0; j < NX; ++j) Pp[r][j] += sQ[row[r] * NX + j];
-            if constexpr (AOS) {
+            if constexpr (AOS || SOA_SLAB) {
                 // the staging slab is the park: lift the parked Pn out, ship Pp, put D = Pn - Pp back
                 double Pn[R][NX];
                 FK_UNROLL for (int r = 0; r < R; ++r)

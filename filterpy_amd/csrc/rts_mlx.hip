@@ -106,10 +106,7 @@ rts_mlx_kernel(const RtsArgs a)
     if constexpr (AOS) {                                                               \
         store_rows_aos<R, NX>(M, row, (base) + ((step) * N + w0) * NX * NX, tile, lane, valid); \
     } else {                                                                           \
-        FK_UNROLL for (int r_ = 0; r_ < R; ++r_) {                                     \
-            const MlView v_((base) + (step) * ps_blk, off_row[r_], estride);           \
-            FK_UNROLL for (int c_ = 0; c_ < NX; ++c_) v_.store(c_, M[r_][c_]);         \
-        }                                                                              \
+        ml_store_rows_soa_slab<R, NX, TPW>(M, row, (base) + (step) * ps_blk, N, w0, tile, lane, lane / LPT, valid); \
     }
 #define FK_PUT(mine, M)                                                                \
     ml_wave_fence();                                                                   \

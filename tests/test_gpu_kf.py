@@ -215,11 +215,14 @@ def test_multilane_9_3_vs_oracle(outputs, masked):
     assert rel_err_rows(got[4][sample], ref[0][-1]) < TOL and rel_err_rows(got[5][sample], ref[1][-1]) < TOL
 
 
+@pytest.mark.parametrize("family,layout", [("m", "soa"), ("m", "aos"), ("g", "soa"), ("g", "aos")])
 @pytest.mark.parametrize("N", [1000, 777])
-def test_multilane_rts_9_vs_oracle(N):
-    """rts_ml_kernel (three lanes per track; N even: 16-byte pair loads/stores, N odd: 8-byte path):
-    every track its own filter output, both index conventions."""
+def test_multilane_rts_9_vs_oracle(N, family, layout, monkeypatch):
+    """dim_x = 9 through both smoother families in both layouts (FK_ML9; the default takes rts_ml for SOA, rts_mlg<9> for
+    AOS): rts_ml_kernel (three lanes per track; N even: 16-byte pair loads/stores, N odd: 8-byte path) and the
+    four-lane rts_mlg_kernel; every track its own filter output, both index conventions."""
     from gpu_util import run_rts
+    monkeypatch.setenv("FK_ML9", family)
     n = 9
     rs = np.random.RandomState(99)
     T = 30
@@ -230,7 +233,7 @@ def test_multilane_rts_9_vs_oracle(N):
     Q = 0.1 * (B @ B.T / n + 0.5 * np.eye(n))
     sample = [0, 1, 15, 16, 63, 64, 255, 256, N - 2, N - 1]
     for conv, name in ((0, "class"), (1, "module")):
-        got = run_rts(Xs, Ps, F, Q, layout="soa", convention=conv)
+        got = run_rts(Xs, Ps, F, Q, layout=layout, convention=conv)
         ref = kf_oracle.rts_smoother_tracks(Xs, Ps, F, Q, tracks=sample, convention=name)
         for k in range(4):
             assert rel_err_rows(_per_track(got[k][:, sample]), _per_track(ref[k])) < 1e-10, (name, k)
