@@ -70,6 +70,7 @@ class UnscentedKalmanFilter(object):
         self.hx, self.fx = hx, fx
         self.x_mean, self.z_mean = x_mean_fn, z_mean_fn
         self._mode = "torch" if device_callables else ("vec" if vectorized else "loop")
+        self._ut_fn = None
         self._log_likelihood = log(sys.float_info.min)
         self._likelihood = sys.float_info.min
         self._mahalanobis = None
@@ -118,7 +119,22 @@ class UnscentedKalmanFilter(object):
 
     @property
     def _resident(self):
-        return self._devcall or self._hooked
+        return self._devcall or self._hooked or self._ut_fn is not None
+
+    def _with_ut(self, UT):
+        """context: a caller-supplied UT function (UKF.py:395-396, :447-448, :712-713) for the duration of one call"""
+        from contextlib import contextmanager
+        from .unscented_transform import unscented_transform
+
+        @contextmanager
+        def cm():
+            old = self._ut_fn
+            self._ut_fn = None if (UT is None or UT is unscented_transform) else UT
+            try:
+                yield
+            finally:
+                self._ut_fn = old
+        return cm()
 
     def _rec_view(self, rec, k, d):
         """device records of N (k x d) blocks -> torch view (N, k, d), no copy"""
@@ -239,6 +255,26 @@ class UnscentedKalmanFilter(object):
         """unscented_transform (unscented_transform.py:101-126) on device records; with a custom mean / residual the
         residuals are formed by the callables and summed by the cross kernel in the reference loop's order."""
         N, lay = self._N or 1, self._layout
+        if self._ut_fn is not None:
+            # the caller's own transform: UT(sigmas, Wm, Wc, noise_cov, mean_fn, residual_fn) -> (x, P), called like the
+            # hooks are -- per filter on NumPy arrays, once on the NumPy bank (vectorized), or once on CUDA tensors
+            s = self._rec_view(s_rec, k, d)
+            mf = None if mean_fn is None else mean_fn
+            rf = None if res_fn is np.subtract else res_fn
+            if self._mode == "torch":
+                xo, Po = self._ut_fn(s, Wm, Wc, None if noise is None else noise.view(d, d), mf, rf)
+            else:
+                sn = s.cpu().numpy()
+                nz = None if noise is None else noise.cpu().numpy().reshape(d, d)
+                if self._mode == "vec":
+                    xo, Po = self._ut_fn(sn, self.Wm, self.Wc, nz, mf, rf)
+                else:
+                    outs = [self._ut_fn(sn[i].copy(), self.Wm, self.Wc, nz, mf, rf) for i in range(N)]
+                    xo, Po = np.array([o[0] for o in outs]), np.array([o[1] for o in outs])
+                xo, Po = self._tt(np.reshape(xo, (N, d)), s), self._tt(np.reshape(Po, (N, d, d)), s)
+            x_out.copy_(self._to_rec(xo.reshape(N, 1, d), 1, d).reshape(x_out.shape))
+            P_out.copy_(self._to_rec(Po.reshape(N, d, d), d, d).reshape(P_out.shape))
+            return
         if mean_fn is None and res_fn is np.subtract:
             E.ut_transform(d, k, N, lay, s_rec, Wm, Wc, noise, x_out, P_out)
             return
@@ -387,12 +423,11 @@ class UnscentedKalmanFilter(object):
     def predict(self, dt=None, UT=None, fx=None, **fx_args):
         """UKF.py:364-411: sigma points -> fx -> UT(+Q) -> regenerate sigma points."""
         from .unscented_transform import unscented_transform
-        if UT is not None and UT is not unscented_transform:
-            raise NotImplementedError("custom UT callables are not supported")
         dt = self._dt if dt is None else dt
         n = self._dim_x
-        if self._resident:
-            return self._res_predict(dt, fx, **fx_args)
+        with self._with_ut(UT):
+            if self._resident:
+                return self._res_predict(dt, fx, **fx_args)
         self.compute_process_sigmas(dt, fx, **fx_args)
         sf = np.asarray(self.sigmas_f).reshape(-1, self._num_sigmas, n)
         x, P = unscented_transform(sf, self.Wm, self.Wc, self.Q, layout=self._layout)
@@ -409,13 +444,14 @@ class UnscentedKalmanFilter(object):
             self.z = np.array([[None] * self._dim_z]).T
             self.x_post, self.P_post = np.copy(self.x), np.copy(self.P)
             return
-        if UT is not None and UT is not unscented_transform:
-            raise NotImplementedError("custom UT callables are not supported")
         hx = self.hx if hx is None else hx
         n, m, k = self._dim_x, self._dim_z, self._num_sigmas
         N = self._N or 1
-        if self._resident:
-            self._res_update(z, R, hx, **hx_args)
+        with self._with_ut(UT):
+            resident = self._resident
+            if resident:
+                self._res_update(z, R, hx, **hx_args)
+        if resident:
             self.z = deepcopy(z)
             self.x_post, self.P_post = np.copy(self.x), np.copy(self.P)
             self._log_likelihood = self._likelihood = self._mahalanobis = None
@@ -480,10 +516,9 @@ class UnscentedKalmanFilter(object):
         import torch
         from .unscented_transform import unscented_transform
         n, m = self._dim_x, self._dim_z
-        if self._resident and saver is None:
-            if UT is not None and UT is not unscented_transform:
-                raise NotImplementedError("custom UT callables are not supported")
-            return self._dev_batch_filter(zs, Rs, dts, device_outputs)
+        with self._with_ut(UT):
+            if self._resident and saver is None:
+                return self._dev_batch_filter(zs, Rs, dts, device_outputs)
         try:
             z0 = zs[0]
         except TypeError:
@@ -590,12 +625,11 @@ class UnscentedKalmanFilter(object):
         Returns (xs, Ps, Ks)."""
         import torch
         from .unscented_transform import unscented_transform
-        if UT is not None and UT is not unscented_transform:
-            raise NotImplementedError("custom UT callables are not supported")
         if len(Xs) != len(Ps):
             raise ValueError('Xs and Ps must have the same length')
-        if self._resident:
-            return self._dev_rts_smoother(Xs, Ps, dts, device_outputs)
+        with self._with_ut(UT):
+            if self._resident:
+                return self._dev_rts_smoother(Xs, Ps, dts, device_outputs)
         if not callable(self.fx) and dts is None and self._dim_x <= 6 and not isinstance(Xs, torch.Tensor):
             # linear fx given as a matrix: the whole backward loop is ONE fused launch (fk_ukf_linear_rts_f64)
             n, N, lay = self._dim_x, self._N or 1, self._layout
