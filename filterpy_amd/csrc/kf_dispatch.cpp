@@ -185,6 +185,8 @@ static int run_kf(const fk_kf_desc *d, KfArgs &a, void *stream)
             const int rc = launch_kf_ml_9_3(a, d->layout, all_out, d->model_mode, (hipStream_t)stream);
             if (rc <= 0) return rc;        // 1 = not a call the multi-lane kernel serves
         }
+        // (dim_x = 7, 8 were tried on the four-lane kernel too: 0.30 against kf_fast's 0.50 -- two rows per lane leave
+        // the replicated S / x work dominant; profiles/r02/dims_7_8_ml_vs_fast.txt)
         if ((d->n >= 10 || (g9 && g9[0] == 'g')) && !getenv("FK_NO_MLG")) {
             for (const FastEntry &g : mlg_table) {
                 if (g.nx != d->n || g.nz != d->m) continue;
@@ -312,7 +314,10 @@ int fk_kf_rts_f64(const fk_kf_desc *desc, const double *F, const double *Q, cons
         const int rc = launch_rts_ml_9(a, desc->layout, uniform, (hipStream_t)stream);
         if (rc <= 0) return rc;            // 1 = not a call the multi-lane smoother serves
     }
-    if ((desc->n >= 10 || (desc->n == 9 && rts9_generic)) && !getenv("FK_NO_MLG")) {
+    // dim_x = 8 in NumPy order: the one-lane smoother's per-lane 16-byte accesses reach 0.34, the four-lane kernel's
+    // slab 0.51 (element-major: 0.63 vs 0.58, stays); FK_ML9=m keeps the one-lane kernel
+    const bool rts8_generic = desc->n == 8 && desc->layout == FK_LAYOUT_AOS && !(g9 && g9[0] == 'm');
+    if ((desc->n >= 10 || (desc->n == 9 && rts9_generic) || rts8_generic) && !getenv("FK_NO_MLG")) {
         // eight lanes per track + LDS exchange where the four-lane kernel's unrolled step outgrows the instruction
         // cache (dim_x >= 15); FK_RTS_LANES=8 / 4 forces one organisation (A/B measurements)
         const char *lv = getenv("FK_RTS_LANES");

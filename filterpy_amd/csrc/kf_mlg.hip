@@ -100,7 +100,7 @@ __device__ __forceinline__ void mlg_store_aos(const double (&x)[NX], const doubl
 // input x = F x + B u (u[t] travels with z[t]), both as BRANCH-FREE run-time switches; UF (update_first) swaps the
 // halves of the step at compile time (the predict half is kf_mlg_predict.inc, included before or after the update half).
 template <int NX, int NZ, int LAYOUT, bool VAR = false, bool UF = false>
-__global__ void __launch_bounds__(BLOCK, (NX <= 9 ? 2 : 1))
+__global__ void __launch_bounds__(BLOCK, (NX <= 8 ? 3 : NX <= 9 ? 2 : 1))
 kf_mlg_kernel(const KfArgs a)
 {
     constexpr int R = (NX + 3) / 4;

@@ -60,7 +60,7 @@ __device__ __forceinline__ void store_rows_aos(const double (&M)[R][NX], const u
 }
 
 template <int NX, int LAYOUT>
-__global__ void __launch_bounds__(BLOCK, 1)
+__global__ void __launch_bounds__(BLOCK, (NX <= 8 ? 3 : NX <= 9 ? 2 : 1))
 rts_mlg_kernel(const RtsArgs a)
 {
     constexpr int R = (NX + 3) / 4;

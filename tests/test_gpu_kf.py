@@ -185,12 +185,15 @@ def test_fast_kernel_tuning_variants(n, m, variants, layout, monkeypatch):
                         assert rel_err_rows(got[:, trk], g[p + tag + "_" + key]) < TOL, (env, tag, key, trk)
 
 
+@pytest.mark.parametrize("family", ["m", "g"])
 @pytest.mark.parametrize("masked", [False, True])
 @pytest.mark.parametrize("outputs", [True, False])
-def test_multilane_9_3_vs_oracle(outputs, masked):
-    """kf_ml.hip (three lanes per track, quad-permute row exchange): every track its own state and
-    measurements, N not a multiple of the 64 tracks per workgroup, alpha != 1."""
+def test_multilane_9_3_vs_oracle(outputs, masked, family, monkeypatch):
+    """kf_ml.hip (three lanes per track, quad-permute row exchange; FK_ML9=m) and the generic four-lane kernel
+    instantiated at (9, 3) (FK_ML9=g): every track its own state and measurements, N not a multiple of the 64 tracks
+    per workgroup, alpha != 1."""
     from gpu_util import run_kf_batch
+    monkeypatch.setenv("FK_ML9", family)
     n, m = 9, 3
     rs = np.random.RandomState(93)
     N, T = 1000, 40
@@ -206,13 +209,14 @@ def test_multilane_9_3_vs_oracle(outputs, masked):
     mask = (rs.rand(T, N) > 0.25) if masked else None
     if masked:
         zs[~mask] = np.nan              # the kernel must not look at a masked measurement
-    got = run_kf_batch(x0, P0, zs, F, Q, H, R, layout="soa", alpha_sq=1.02 ** 2, outputs=outputs, mask=mask)
     sample = [0, 1, 15, 16, 63, 64, 255, 256, 959, 960, N - 1]
     ref = kf_oracle.kf_batch_filter_tracks(x0, P0, zs, F, Q, H, R, tracks=sample, alpha_sq=1.02 ** 2, mask=mask)
-    if outputs:
-        for k in range(4):
-            assert rel_err_rows(_per_track(got[k][:, sample]), _per_track(ref[k])) < TOL, k
-    assert rel_err_rows(got[4][sample], ref[0][-1]) < TOL and rel_err_rows(got[5][sample], ref[1][-1]) < TOL
+    for layout in ("soa", "aos"):
+        got = run_kf_batch(x0, P0, zs, F, Q, H, R, layout=layout, alpha_sq=1.02 ** 2, outputs=outputs, mask=mask)
+        if outputs:
+            for k in range(4):
+                assert rel_err_rows(_per_track(got[k][:, sample]), _per_track(ref[k])) < TOL, (layout, k)
+        assert rel_err_rows(got[4][sample], ref[0][-1]) < TOL and rel_err_rows(got[5][sample], ref[1][-1]) < TOL
 
 
 @pytest.mark.parametrize("family,layout", [("m", "soa"), ("m", "aos"), ("g", "soa"), ("g", "aos")])
@@ -540,6 +544,27 @@ def test_smoother_both_organisations_dims_13_to_16(n, layout, lanes, monkeypatch
         got = run_rts(np.ascontiguousarray(Xs[:Ts, :Ns]), np.ascontiguousarray(Ps[:Ts, :Ns]), F, Q, layout=layout)
         for k in range(4):
             assert rel_err_rows(_per_track(got[k]), _per_track(ref[k])) < TOL, (Ns, Ts, k)
+
+
+@pytest.mark.parametrize("family", ["m", ""])
+def test_smoother_dim_8_numpy_order_both_kernels(family, monkeypatch):
+    """n = 8 in NumPy order runs rts_mlg<8> by default and the one-lane rts_kernel with FK_ML9=m: both against the oracle"""
+    from gpu_util import run_rts
+    if family:
+        monkeypatch.setenv("FK_ML9", family)
+    n = 8
+    rs = np.random.RandomState(808)
+    N, T = 333, 9
+    A = rs.randn(T, N, n, n)
+    Xs, Ps = rs.randn(T, N, n), A @ A.transpose(0, 1, 3, 2) / n + 0.5 * np.eye(n)
+    F = np.eye(n) + 0.1 * rs.randn(n, n)
+    Q = 0.05 * np.eye(n)
+    sample = [0, 1, 15, 16, 63, 64, 255, 256, N - 2, N - 1]
+    for conv, name in ((0, "class"), (1, "module")):
+        got = run_rts(Xs, Ps, F, Q, layout="aos", convention=conv)
+        ref = kf_oracle.rts_smoother_tracks(Xs, Ps, F, Q, tracks=sample, convention=name)
+        for k in range(4):
+            assert rel_err_rows(_per_track(got[k][:, sample]), _per_track(ref[k])) < TOL, (name, k)
 
 
 @pytest.mark.parametrize("N,T", [(1, 2), (2, 3), (17, 2), (65, 4)])
