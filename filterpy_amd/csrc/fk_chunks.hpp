@@ -1,0 +1,114 @@
+// fk_chunks.hpp -- tail filling for the several-lanes-per-track kernels (host side).
+//
+// Their step is bound by arithmetic and latency, every wave runs the same T steps, so a bank of W waves on S wave slots
+// takes ceil(W / S) rounds: BASELINE config 3 (1e5 tracks = 6250 waves on 2048 slots) pays 4 rounds for 3.05 rounds of
+// work.  A chunked call cuts the bank into G track groups (multiples of 64 tracks) and the T steps into H time chunks and
+// launches the pieces on G streams -- group g's chunks in order on stream g, the state handed from chunk to chunk through
+// memory (kernel boundaries of one stream: no protocol), different groups concurrently: while one group's piece tails
+// off, the other groups' pieces fill the slots, and what is left at the very end is the tail of a piece 1/H as long.
+// Group g's chunk boundaries are shifted by g / G of a chunk, else all groups would tail off at the same moments.
+// Same arithmetic per track: results are bit-identical to the single launch (tests/test_gpu_kf.py).  The helper streams
+// fork from and join the caller's stream with events; they and the events are created once.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+// default decomposition of a chunked call (launch_kf_ml_chunked): track groups x time chunks
+#ifndef FK_ML_CHUNK_G
+#define FK_ML_CHUNK_G 3
+#endif
+#ifndef FK_ML_CHUNK_H
+#define FK_ML_CHUNK_H 4
+#endif
+#ifndef FK_ML_CHUNK_STAGGER
+#define FK_ML_CHUNK_STAGGER 1
+#endif
+
+namespace fk {
+
+struct MlStreams {
+    static constexpr int MAXG = 4;
+    hipStream_t st[MAXG] = {};
+    hipEvent_t fork = nullptr, done[MAXG] = {};
+    bool ok = false;
+    MlStreams()
+    {
+        ok = hipEventCreateWithFlags(&fork, hipEventDisableTiming) == hipSuccess;
+        for (int g = 1; g < MAXG && ok; ++g)
+            ok = hipStreamCreateWithFlags(&st[g], hipStreamNonBlocking) == hipSuccess &&
+                 hipEventCreateWithFlags(&done[g], hipEventDisableTiming) == hipSuccess;
+    }
+};
+
+inline MlStreams *ml_streams()
+{
+    static MlStreams ms;
+    return &ms;
+}
+
+// G x H decomposition of a call over `waves` waves and T steps ("G,H" from FK_ML_CHUNKS, else the default where the
+// last round would be less than 40 % full); false: one launch
+inline bool ml_chunk_policy(long waves, long T, int &G, int &H, long slots = 2048)
+{
+    G = H = 1;
+    if (const char *cv = getenv("FK_ML_CHUNKS")) {
+        if (sscanf(cv, "%d,%d", &G, &H) != 2) G = H = 1;
+    } else if (waves > 2 * slots && T >= 16) {
+        const long rem = waves % slots;
+        if (rem != 0 && rem * 10 < slots * 4) { G = FK_ML_CHUNK_G; H = FK_ML_CHUNK_H; }
+    }
+    if (G > MlStreams::MAXG) G = MlStreams::MAXG;
+    if (H > T) H = (int)T;
+    return G >= 1 && H >= 1 && !(G == 1 && H == 1);
+}
+
+
+// The smoother runs backwards: group g's chunks go from the last time window to the first on stream g; a chunk's window
+// [k0, k1] shares its top step k1 with the chunk before it (which smoothed it): RtsArgs::cont.  `one(args, stream)`
+// launches one piece.  (RtsArgs is a template parameter only to keep this header free of the kernel headers.)
+template <class Args, class One>
+int rts_chunked_call(const Args &a, int n, long slots, One &&one, hipStream_t s)
+{
+    int G, H;
+    const long steps = a.T - 1;                                   // backward steps T-2 .. 0
+    if (!ml_chunk_policy((a.N + 15) / 16, steps, G, H, slots) || a.N < 64L * G) return one(a, s);
+    MlStreams &ms = *ml_streams();
+    if (!ms.ok || hipEventRecord(ms.fork, s) != hipSuccess) return one(a, s);
+    const long blocks = (a.N + 63) / 64, per = (blocks + G - 1) / G * 64, nn = (long)n * n;
+    int rc = 0;
+    for (int g = 0; g < G && rc == 0; ++g) {
+        const long g0 = (long)g * per, gcnt = (g0 + per <= a.N) ? per : (a.N - g0);
+        if (gcnt <= 0) break;
+        hipStream_t sg = g == 0 ? s : ms.st[g];
+        if (g > 0 && hipStreamWaitEvent(sg, ms.fork, 0) != hipSuccess) return -1;
+        const long shift = (FK_ML_CHUNK_STAGGER && !getenv("FK_ML_NO_STAGGER")) ? (steps * g) / ((long)H * G) : 0;
+        bool first = true;
+        for (int h = H; h >= 0 && rc == 0; --h) {                 // windows of backward steps [k0, k1), last first
+            long k0 = steps * h / H - shift, k1 = steps * (h + 1) / H - shift;
+            if (k0 < 0) k0 = 0;
+            if (h == H) k1 = steps;
+            if (k1 > steps) k1 = steps;
+            if (k1 <= k0) continue;
+            Args b = a;
+            b.i0 = g0;
+            b.cnt = gcnt;
+            b.T = k1 - k0 + 1;                                     // steps k0 .. k1 of the arrays; k1 is the window's "T-1"
+            b.cont = first ? 0 : 1;
+            b.status_or = first ? a.status_or : 1;
+            b.Xs = a.Xs + k0 * a.N * n;
+            b.Ps = a.Ps + k0 * a.N * nn;
+            b.xs = a.xs + k0 * a.N * n;
+            b.Ps_out = a.Ps_out + k0 * a.N * nn;
+            b.K = a.K + k0 * a.N * nn;
+            b.Pp = a.Pp + k0 * a.N * nn;
+            rc = one(b, sg);
+            first = false;
+        }
+        if (g > 0 && rc == 0 && (hipEventRecord(ms.done[g], sg) != hipSuccess || hipStreamWaitEvent(s, ms.done[g], 0) != hipSuccess))
+            rc = -1;
+    }
+    return rc;
+}
+
+}  // namespace fk

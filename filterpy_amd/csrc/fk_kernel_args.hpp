@@ -20,6 +20,7 @@ struct KfArgs {
     int do_predict, do_update;
     int xcd_swizzle;    // kf_fast: give each XCD (blockIdx % 8) one contiguous range of tracks
     int rj_diag;        // FK_KF_FLAG_R_JOSEPH_DIAG: K R K' uses only R's diagonal (generic kernel only)
+    int status_or;      // kf_ml: OR the status bits into status[] instead of storing them (later time chunks of one call)
     double alpha_sq;
 };
 
@@ -31,6 +32,11 @@ struct RtsArgs {
     int n;
     int model_t;
     int conv_off;       // 1: class method uses model[k+1]; 0: module function uses model[k]
+    // rts_ml (chunked calls, kf_ml.hip): this launch handles tracks [i0, i0 + cnt) (cnt == 0: all N); cont: the last step
+    // of this launch's window is ALREADY smoothed in xs / Ps_out (written by the chunk after it in time) -- read it
+    // from there and leave it alone; status_or: OR the status bits into status[]
+    long i0, cnt;
+    int cont, status_or;
 };
 
 struct UkfArgs {

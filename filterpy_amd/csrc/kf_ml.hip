@@ -27,12 +27,14 @@
 // shared by the bank (Fs / Qs / Hs / Rs lists: double-buffered in LDS, fetched a step ahead), a control input
 // x = F x + B u (u[t] travels with z[t]) and update_first (UF: update -> predict inside a step).  Per-track
 // models stay on kf_fast / kf_kernel.  The smoother (rts_ml_kernel) is at the end of the file.
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "fk_device.hpp"
 #include "fk_math_sym.hpp"
 #include "fk_kernel_args.hpp"
 #include "fk_ml.hpp"
+#include "fk_chunks.hpp"
 #include "../../include/filterhip.h"
 
 #ifndef FK_ML_WAVES
@@ -195,10 +197,13 @@ kf_ml_kernel(const KfArgs a)
     const long N = a.N;
     const unsigned L = threadIdx.x & 3u;
     const unsigned Lc = L < 3u ? L : 2u;                       // lane 3 mirrors lane 2
-    long trk = (long)blockIdx.x * (BLOCK / 4) + (threadIdx.x >> 2);
+    // this launch handles tracks [i0, iend) of the bank (N stays the array stride): the whole bank, or one track group
+    // of a chunked call (launch_kf_ml_9_3: groups start on multiples of 64 tracks)
+    const long iend = a.i0 + a.cnt;
+    long trk = a.i0 + (long)blockIdx.x * (BLOCK / 4) + (threadIdx.x >> 2);
     const unsigned odd = (threadIdx.x >> 2) & 1u;              // odd quad of its pair (workgroups start on even tracks)
-    const bool owner = trk < N;                                // tail quads only duplicate: they never write the final state
-    if (trk >= N) trk = PAIRS ? N - 2 + odd : N - 1;           // tail quads recompute the last track (pair)
+    const bool owner = trk < iend;                             // tail quads only duplicate: they never write the final state
+    if (trk >= iend) trk = PAIRS ? iend - 2 + odd : iend - 1;  // tail quads recompute the last track (pair)
     // element e of this lane's track sits at  lane offset + e * estride:  SOA: track*8 + e*N*8 ;
     // AOS: track*E*8 + e*8 (E = elements per record of the array: the offsets below are per array)
     unsigned estride = AOS ? 8u : (unsigned)N * 8u;
@@ -210,8 +215,8 @@ kf_ml_kernel(const KfArgs a)
     const unsigned pair_rows = odd ? off_rows - 8u + estride : off_rows;
     const unsigned pair_x = odd ? t8 - 8u + estride : t8;
     // AOS output slabs: first track of this wave and how many of its 16 tracks exist
-    const long w0 = (long)blockIdx.x * (BLOCK / 4) + (long)(threadIdx.x >> 6) * 16;
-    const unsigned valid = (unsigned)(N - w0 >= 16 ? 16 : (N - w0 > 0 ? N - w0 : 0));
+    const long w0 = a.i0 + (long)blockIdx.x * (BLOCK / 4) + (long)(threadIdx.x >> 6) * 16;
+    const unsigned valid = (unsigned)(iend - w0 >= 16 ? 16 : (iend - w0 > 0 ? iend - w0 : 0));
     const unsigned lane = threadIdx.x & 63u;
     const double *myF = sF + Lc * (R * NX);                     // this lane's rows of F and Q
     const double *myQ = sQ + Lc * (R * NX);
@@ -461,7 +466,7 @@ kf_ml_kernel(const KfArgs a)
         if (a.status) {
             int s = st | (fin ? 0 : ST_NONFINITE);
             s |= __builtin_amdgcn_mov_dpp(s, 0x55 * 1, 0xf, 0xf, true) | __builtin_amdgcn_mov_dpp(s, 0x55 * 2, 0xf, 0xf, true);
-            if (L == 0) a.status[trk] = s;       // duplicate tail quads write the same value
+            if (L == 0) a.status[trk] = a.status_or ? (a.status[trk] | s) : s;
         }
     }
 }
@@ -528,9 +533,10 @@ rts_ml_kernel(const RtsArgs a)
     const long N = a.N, T = a.T;
     const unsigned L = threadIdx.x & 3u;
     const unsigned Lc = L < 3u ? L : 2u;
-    long trk = (long)blockIdx.x * (BLOCK / 4) + (threadIdx.x >> 2);
+    const long i0 = a.cnt ? a.i0 : 0, iend = a.cnt ? a.i0 + a.cnt : N;     // this launch's track group (chunked calls)
+    long trk = i0 + (long)blockIdx.x * (BLOCK / 4) + (threadIdx.x >> 2);
     const unsigned odd = (threadIdx.x >> 2) & 1u;
-    if (trk >= N) trk = MODE == 1 ? N - 2 + odd : N - 1;
+    if (trk >= iend) trk = MODE == 1 ? iend - 2 + odd : iend - 1;
     // SOA: element e of a track at track*8 + e*N*8 ; AOS (MODE 2): track*E*8 + e*8
     constexpr bool AOS = MODE == 2;
     const unsigned estride = AOS ? 8u : (unsigned)N * 8u;
@@ -542,13 +548,19 @@ rts_ml_kernel(const RtsArgs a)
     // AOS: covariance-like outputs leave through the parking buffer as 1 KiB stores (first track of this
     // wave, how many of its 16 tracks exist)
     const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const long w0 = (long)blockIdx.x * (BLOCK / 4) + (long)wave * 16;
-    const unsigned valid = (unsigned)(N - w0 >= 16 ? 16 : (N - w0 > 0 ? N - w0 : 0));
+    const long w0 = i0 + (long)blockIdx.x * (BLOCK / 4) + (long)wave * 16;
+    const unsigned valid = (unsigned)(iend - w0 >= 16 ? 16 : (iend - w0 > 0 ? iend - w0 : 0));
     const long xs_blk = N * NX, ps_blk = N * (long)NX * NX;
 
     // k = T-1: smoothed == filtered; K = 0; Pp = Ps   (kalman_filter.py:1063-1065)
     double xn[NX], Pn[R][NX];
-    {
+    if (a.cont) {
+        // a later chunk of the call: step T-1 of this window was smoothed by the chunk that ran before (after it in time)
+        const MlView vx(a.xs + (T - 1) * xs_blk, t8, estride), vP(a.Ps_out + (T - 1) * ps_blk, off_rows, estride);
+        FK_UNROLL for (int k = 0; k < NX; ++k) xn[k] = vx.load(k);
+        FK_UNROLL for (int r = 0; r < R; ++r)
+            FK_UNROLL for (int c = 0; c < NX; ++c) Pn[r][c] = vP.load(r * NX + c);
+    } else {
         const MlView vx(a.Xs + (T - 1) * xs_blk, t8, estride), vP(a.Ps + (T - 1) * ps_blk, off_rows, estride);
         FK_UNROLL for (int k = 0; k < NX; ++k) xn[k] = vx.load(k);
         FK_UNROLL for (int r = 0; r < R; ++r)
@@ -709,25 +721,35 @@ rts_ml_kernel(const RtsArgs a)
             FK_UNROLL for (int c = 0; c < NX; ++c) fin = fin && (fabs(Pn[r][c]) <= 1.79769313486231570815e+308);
         int s = st | (fin ? 0 : ST_NONFINITE);
         s |= __builtin_amdgcn_mov_dpp(s, 0x55 * 1, 0xf, 0xf, true) | __builtin_amdgcn_mov_dpp(s, 0x55 * 2, 0xf, 0xf, true);
-        if (L == 0) a.status[trk] = s;
+        if (L == 0) a.status[trk] = a.status_or ? (a.status[trk] | s) : s;
     }
 }
 
-// returns 1 when this call is not one the multi-lane smoother serves
-int launch_rts_ml_9(const RtsArgs &a, int layout, bool uniform, hipStream_t s)
+static int launch_rts_ml_one(const RtsArgs &a, int layout, hipStream_t s)
 {
-    if (!uniform || a.model_t || a.n != 9 || !a.K || !a.Pp || a.T < 2) return 1;
-    if (layout == FK_LAYOUT_AOS && (double)a.N * 81.0 * 8.0 >= 4294967296.0) return 1;
-    const dim3 grid((unsigned)((a.N + BLOCK / 4 - 1) / (BLOCK / 4))), block(BLOCK);
+    const long cnt = a.cnt ? a.cnt : a.N;
+    const dim3 grid((unsigned)((cnt + BLOCK / 4 - 1) / (BLOCK / 4))), block(BLOCK);
     const char *pv = getenv("FK_ML_PAIRS");
-    const bool pairs = (a.N % 2 == 0) && a.N >= 2 && !(pv && atoi(pv) == 0);
+    const bool pairs = (a.N % 2 == 0) && (cnt % 2 == 0) && cnt >= 2 && !(pv && atoi(pv) == 0);
     if (layout == FK_LAYOUT_AOS) hipLaunchKernelGGL((rts_ml_kernel<3, FK_ML_WAVES, 2>), grid, block, 0, s, a);
     else if (pairs) hipLaunchKernelGGL((rts_ml_kernel<3, FK_ML_WAVES, 1>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((rts_ml_kernel<3, FK_ML_WAVES, 0>), grid, block, 0, s, a);
     return check_launch("rts_ml_kernel");
 }
 
+static int launch_rts_ml_chunked(const RtsArgs &a, int layout, hipStream_t s);
+
+// returns 1 when this call is not one the multi-lane smoother serves
+int launch_rts_ml_9(const RtsArgs &a, int layout, bool uniform, hipStream_t s)
+{
+    if (!uniform || a.model_t || a.n != 9 || !a.K || !a.Pp || a.T < 2) return 1;
+    if (layout == FK_LAYOUT_AOS && (double)a.N * 81.0 * 8.0 >= 4294967296.0) return 1;
+    return launch_rts_ml_chunked(a, layout, s);
+}
+
 int launch_kf_ml_9_3_var(const KfArgs &a, int layout, hipStream_t s);
+static int launch_kf_ml_one(const KfArgs &a, int layout, bool outs, hipStream_t s);
+static int launch_kf_ml_chunked(const KfArgs &a, int layout, bool outs, hipStream_t s);
 
 // returns 1 when this call is not one the multi-lane kernel serves
 int launch_kf_ml_9_3(const KfArgs &a, int layout, bool outs, int model_mode, hipStream_t s)
@@ -740,10 +762,16 @@ int launch_kf_ml_9_3(const KfArgs &a, int layout, bool outs, int model_mode, hip
         if (!outs || a.nu > 4 || (vv && atoi(vv) == 0)) return 1;
         return launch_kf_ml_9_3_var(a, layout, s);
     }
-    const dim3 grid((unsigned)((a.N + BLOCK / 4 - 1) / (BLOCK / 4))), block(BLOCK);
+    return launch_kf_ml_chunked(a, layout, outs, s);
+}
+
+// one launch over tracks [a.i0, a.i0 + a.cnt), a.T steps from the pointers in `a`
+static int launch_kf_ml_one(const KfArgs &a, int layout, bool outs, hipStream_t s)
+{
+    const dim3 grid((unsigned)((a.cnt + BLOCK / 4 - 1) / (BLOCK / 4))), block(BLOCK);
     // 16-byte pair stores (SOA) need the track count even (a pair never straddles a plane); FK_ML_PAIRS=0 turns them off
     const char *pv = getenv("FK_ML_PAIRS");
-    const bool pairs = (a.N % 2 == 0) && a.N >= 2 && !(pv && atoi(pv) == 0);
+    const bool pairs = (a.N % 2 == 0) && (a.cnt % 2 == 0) && a.cnt >= 2 && !(pv && atoi(pv) == 0);
 #define GO(M, LAY)                                                                                                          \
     if (outs && pairs && LAY == LAYOUT_SOA)                                                                                 \
         hipLaunchKernelGGL((kf_ml_kernel<3, 3, true, FK_ML_WAVES, true, M, LAYOUT_SOA>), grid, block, 0, s, a);             \
@@ -756,6 +784,65 @@ int launch_kf_ml_9_3(const KfArgs &a, int layout, bool outs, int model_mode, hip
     }
 #undef GO
     return check_launch("kf_ml_kernel");
+}
+
+// Tail filling.  The step is bound by arithmetic and latency, every wave runs the same T steps, so a bank of W waves on S
+// wave slots takes ceil(W / S) rounds: BASELINE config 3 (1e5 tracks = 6250 waves on 2048 slots) pays 4 rounds for 3.05
+// rounds of work.  A chunked call cuts the bank into G track groups (multiples of 64 tracks) and the T steps into H time
+// chunks and launches the G x H pieces on G streams -- group g's chunks in order on stream g, the state handed from chunk
+// to chunk through x / P in place (kernel boundaries of one stream: no protocol), different groups concurrently: while one
+// group's piece tails off, the other groups' pieces fill the slots, and what is left at the very end is the tail of a
+// piece 1/H as long.  Same arithmetic per track: results are bit-identical to the single launch.  The helper streams
+// fork from and join the caller's stream with events (capturable); they and the events are created once.
+static int launch_rts_ml_chunked(const RtsArgs &a, int layout, hipStream_t s)
+{
+    return rts_chunked_call(a, 9, 2048, [layout](const RtsArgs &b, hipStream_t sb) { return launch_rts_ml_one(b, layout, sb); }, s);
+}
+
+static int launch_kf_ml_chunked(const KfArgs &a, int layout, bool outs, hipStream_t s)
+{
+    // policy: FK_ML_CHUNKS="G,H" forces a decomposition ("1,1" = one launch); default: only where a round would be
+    // mostly idle -- more than two rounds of work whose last round is less than 40 % full
+    int G, H;
+    if (!outs || !ml_chunk_policy((a.cnt + 15) / 16, a.T, G, H) || a.cnt < 64L * G) return launch_kf_ml_one(a, layout, outs, s);
+    MlStreams &ms = *ml_streams();
+    if (!ms.ok) return launch_kf_ml_one(a, layout, outs, s);
+    // track groups: multiples of 64 tracks (a workgroup), the last one takes the remainder
+    const long blocks = (a.cnt + 63) / 64, per = (blocks + G - 1) / G * 64;
+    if (hipEventRecord(ms.fork, s) != hipSuccess) return launch_kf_ml_one(a, layout, outs, s);
+    int rc = 0;
+    for (int g = 0; g < G && rc == 0; ++g) {
+        const long g0 = a.i0 + (long)g * per;
+        const long gcnt = (g0 + per <= a.i0 + a.cnt) ? per : (a.i0 + a.cnt - g0);
+        if (gcnt <= 0) break;
+        hipStream_t sg = g == 0 ? s : ms.st[g];
+        if (g > 0 && hipStreamWaitEvent(sg, ms.fork, 0) != hipSuccess) { rc = FK_ERR_LAUNCH; break; }
+        // group g's chunk boundaries are shifted by g / G of a chunk (one more, shorter, first chunk): groups whose
+        // pieces all ended at the same moments would tail off together and leave nothing to fill with
+        const long shift = (FK_ML_CHUNK_STAGGER && !getenv("FK_ML_NO_STAGGER")) ? (a.T * g) / ((long)H * G) : 0;
+        for (int h = 0; h <= H && rc == 0; ++h) {
+            long t0 = a.T * h / H - shift, t1 = a.T * (h + 1) / H - shift;
+            if (t0 < 0) t0 = 0;
+            if (h == H) t1 = a.T;
+            if (t1 > a.T) t1 = a.T;
+            if (t1 <= t0) continue;
+            KfArgs b = a;
+            b.i0 = g0;
+            b.cnt = gcnt;
+            b.T = t1 - t0;
+            b.status_or = t0 > 0 ? 1 : a.status_or;
+            b.z = a.z + t0 * a.N * 3;
+            if (a.mask) b.mask = a.mask + t0 * a.N;
+            b.means = a.means + t0 * a.N * 9;
+            b.means_p = a.means_p + t0 * a.N * 9;
+            b.covs = a.covs + t0 * a.N * 81;
+            b.covs_p = a.covs_p + t0 * a.N * 81;
+            rc = launch_kf_ml_one(b, layout, outs, sg);
+        }
+        if (g > 0 && rc == 0 && (hipEventRecord(ms.done[g], sg) != hipSuccess || hipStreamWaitEvent(s, ms.done[g], 0) != hipSuccess))
+            rc = FK_ERR_LAUNCH;
+    }
+    return rc;
 }
 #endif   // FK_ML_PART != 2
 

@@ -17,6 +17,7 @@
 #include "fk_math_sym.hpp"
 #include "fk_kernel_args.hpp"
 #include "fk_ml.hpp"
+#include "fk_chunks.hpp"
 #include "../../include/filterhip.h"
 
 #ifndef FK_NX
@@ -81,8 +82,9 @@ rts_mlg_kernel(const RtsArgs a)
 
     const long N = a.N, T = a.T;
     const unsigned L = threadIdx.x & 3u;
-    long trk = (long)blockIdx.x * (BLOCK / 4) + (threadIdx.x >> 2);
-    if (trk >= N) trk = N - 1;                                 // tail quads recompute the last track
+    const long i0 = a.cnt ? a.i0 : 0, iend = a.cnt ? a.i0 + a.cnt : N;     // this launch's track group (chunked calls, fk_chunks.hpp)
+    long trk = i0 + (long)blockIdx.x * (BLOCK / 4) + (threadIdx.x >> 2);
+    if (trk >= iend) trk = iend - 1;                           // tail quads recompute the last track
     unsigned estride = AOS ? 8u : (unsigned)N * 8u;
     asm volatile("" : "+s"(estride));
     const unsigned t8 = (unsigned)trk * (AOS ? (unsigned)NX * 8u : 8u);
@@ -103,8 +105,8 @@ rts_mlg_kernel(const RtsArgs a)
         }                                                                                                  \
     }
     const unsigned lane = threadIdx.x & 63u;
-    const long w0 = (long)blockIdx.x * (BLOCK / 4) + (long)(threadIdx.x >> 6) * 16;
-    const unsigned valid = (unsigned)(N - w0 >= 16 ? 16 : (N - w0 > 0 ? N - w0 : 0));
+    const long w0 = i0 + (long)blockIdx.x * (BLOCK / 4) + (long)(threadIdx.x >> 6) * 16;
+    const unsigned valid = (unsigned)(iend - w0 >= 16 ? 16 : (iend - w0 > 0 ? iend - w0 : 0));
     const long xs_blk = N * NX, ps_blk = N * (long)NX * NX;
     double *park = tile + lane;                                // element e of this lane: park[e * 64]
 
@@ -131,7 +133,16 @@ rts_mlg_kernel(const RtsArgs a)
     ml_wave_fence();
 
     // k = T-1: smoothed == filtered; K = 0; Pp = Ps   (kalman_filter.py:1063-1065)
-    {
+    if (a.cont) {
+        // a later chunk of the call: step T-1 of this window was smoothed by the chunk that ran before (after it in time)
+        FK_ROWS_HERE();
+        double xn[NX], Pn[R][NX];
+        const MlView vx(a.xs + (T - 1) * xs_blk, t8, estride);
+        FK_UNROLL for (int k = 0; k < NX; ++k) xn[k] = vx.load(k);
+        FK_LOAD_ROWS(a.Ps_out + (T - 1) * ps_blk, Pn);
+        FK_PARK(Pn);
+        FK_UNROLL for (int k = 0; k < NX; ++k) xpark[k] = xn[k];
+    } else {
         FK_ROWS_HERE();
         double xn[NX], Pn[R][NX];
         const MlView vx(a.Xs + (T - 1) * xs_blk, t8, estride);
@@ -341,7 +352,7 @@ rts_mlg_kernel(const RtsArgs a)
         int s = st | (fin ? 0 : ST_NONFINITE);
         s |= __builtin_amdgcn_mov_dpp(s, 0xB1, 0xf, 0xf, true);
         s |= __builtin_amdgcn_mov_dpp(s, 0x4E, 0xf, 0xf, true);
-        if (L == 0) a.status[trk] = s;
+        if (L == 0) a.status[trk] = a.status_or ? (a.status[trk] | s) : s;
     }
 #undef FK_ROWS_HERE
 #undef FK_ISYNC
@@ -357,10 +368,15 @@ int FK_RMLG_CAT(launch_rts_mlg_, FK_NX)(const RtsArgs &a, int layout, bool unifo
 {
     using namespace FK_RMLG_CAT(rmlg_, FK_NX);
     if (!uniform || a.model_t || a.n != FK_NX || !a.K || !a.Pp || a.T < 2) return 1;
-    const dim3 grid((unsigned)((a.N + BLOCK / 4 - 1) / (BLOCK / 4))), block(BLOCK);
-    if (layout == FK_LAYOUT_AOS) hipLaunchKernelGGL((rts_mlg_kernel<FK_NX, LAYOUT_AOS>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((rts_mlg_kernel<FK_NX, LAYOUT_SOA>), grid, block, 0, s, a);
-    return check_launch("rts_mlg_kernel");
+    auto one = [layout](const RtsArgs &b, hipStream_t sb) -> int {
+        const long cnt = b.cnt ? b.cnt : b.N;
+        const dim3 grid((unsigned)((cnt + BLOCK / 4 - 1) / (BLOCK / 4))), block(BLOCK);
+        if (layout == FK_LAYOUT_AOS) hipLaunchKernelGGL((rts_mlg_kernel<FK_NX, LAYOUT_AOS>), grid, block, 0, sb, b);
+        else hipLaunchKernelGGL((rts_mlg_kernel<FK_NX, LAYOUT_SOA>), grid, block, 0, sb, b);
+        return check_launch("rts_mlg_kernel");
+    };
+    // tail filling (fk_chunks.hpp): slots = one wave per SIMD above dim 9, two at 9, three below
+    return rts_chunked_call(a, FK_NX, FK_NX <= 8 ? 3072 : FK_NX <= 9 ? 2048 : 1024, one, s);
 }
 
 }  // namespace fk

@@ -624,3 +624,61 @@ def test_four_lane_kernel_variants_vs_oracle(n, m, layout):
                         assert rel_err_rows(_per_track(got[k][:, sample]), _per_track(ref[k])) < TOL, (tag, k)
                     last, lastP = (ref[2], ref[3]) if uf else (ref[0], ref[1])
                     assert rel_err_rows(got[4][sample], last[-1]) < TOL and rel_err_rows(got[5][sample], lastP[-1]) < TOL, tag
+
+
+@pytest.mark.parametrize("layout", ["soa", "aos"])
+@pytest.mark.parametrize("N", [1000, 777, 130])
+def test_multilane_chunked_call_is_bit_identical(N, layout, monkeypatch):
+    """launch_kf_ml_chunked: G track groups x H time chunks on G streams (tail filling) must give the single launch's
+    bits -- outputs, final state and status -- for every decomposition, with a mask, ragged N, AOS slabs"""
+    from gpu_util import run_kf_batch
+    n, m = 9, 3
+    rs = np.random.RandomState(4242 + N)
+    T = 23
+    A = rs.randn(N, n, n)
+    x0, P0 = rs.randn(N, n), 4.0 * (A @ A.transpose(0, 2, 1) / n + 0.5 * np.eye(n))
+    zs = rs.randn(T, N, m) * 3
+    F = np.eye(n) + 0.1 * rs.randn(n, n)
+    B = rs.randn(n, n)
+    Q = 0.1 * (B @ B.T / n + 0.5 * np.eye(n))
+    H = rs.randn(m, n)
+    R = 0.5 * np.eye(m)
+    mask = rs.rand(T, N) > 0.2
+    P0[5] = -np.eye(n)                     # one track whose S is not positive definite: the status bit must survive the chunks
+    monkeypatch.setenv("FK_ML_CHUNKS", "1,1")
+    one = run_kf_batch(x0, P0, zs, F, Q, H, R, layout=layout, mask=mask, check_status=False)
+    assert one[6][5] != 0 and not one[6][[0, 1, 6]].any()
+    for spec in ("2,5", "4,3", "3,23", "2,1", "1,4"):
+        monkeypatch.setenv("FK_ML_CHUNKS", spec)
+        got = run_kf_batch(x0, P0, zs, F, Q, H, R, layout=layout, mask=mask, check_status=False)
+        for k in range(7):
+            assert np.array_equal(got[k], one[k], equal_nan=True), (spec, k)
+    ref = kf_oracle.kf_batch_filter_tracks(x0, P0, zs, F, Q, H, R, tracks=[0, 64, N - 1], mask=mask)
+    for k in range(4):
+        assert rel_err_rows(_per_track(one[k][:, [0, 64, N - 1]]), _per_track(ref[k])) < TOL, k
+
+
+@pytest.mark.parametrize("family,n", [("m", 9), ("g", 9), ("g", 12)])
+@pytest.mark.parametrize("layout", ["soa", "aos"])
+@pytest.mark.parametrize("N", [1000, 777, 130])
+def test_multilane_chunked_smoother_is_bit_identical(N, layout, family, n, monkeypatch):
+    """rts_chunked_call (backward time windows that share their top step, G track groups on G streams) against the single
+    launch: every output bit, both layouts, ragged N; rts_ml (FK_ML9=m) and the four-lane rts_mlg at n = 9 and 12"""
+    from gpu_util import run_rts
+    monkeypatch.setenv("FK_ML9", family)
+    rs = np.random.RandomState(777 + N)
+    T = 19
+    A = rs.randn(T, N, n, n)
+    Xs, Ps = rs.randn(T, N, n), A @ A.transpose(0, 1, 3, 2) / n + 0.5 * np.eye(n)
+    F = np.eye(n) + 0.1 * rs.randn(n, n)
+    Q = 0.05 * np.eye(n)
+    monkeypatch.setenv("FK_ML_CHUNKS", "1,1")
+    one = run_rts(Xs, Ps, F, Q, layout=layout)
+    for spec in ("2,4", "3,3", "4,18", "1,5", "2,1"):
+        monkeypatch.setenv("FK_ML_CHUNKS", spec)
+        got = run_rts(Xs, Ps, F, Q, layout=layout)
+        for k in range(4):
+            assert np.array_equal(got[k], one[k]), (spec, k)
+    ref = kf_oracle.rts_smoother_tracks(Xs, Ps, F, Q, tracks=[0, 64, N - 1])
+    for k in range(4):
+        assert rel_err_rows(_per_track(one[k][:, [0, 64, N - 1]]), _per_track(ref[k])) < TOL, k

@@ -119,8 +119,45 @@ def variants():
     os.environ.pop("FK_ML_VAR", None)
 
 
+def chunks():
+    """tail filling (launch_kf_ml_chunked): sweep FK_ML_CHUNKS = "G,H" at (9,3), SOA and AOS, four outputs"""
+    import numpy as np
+    import torch
+    from filterpy_amd import _engine as E
+    from tools.bench_configs import cv3d_model, timeit
+    N, T, n, m = int(os.environ.get("ML_N", 100000)), 100, 9, 3
+    F, Q, H, R = cv3d_model()
+    dev = torch.device("cuda")
+    g = torch.Generator(device=dev)
+    g.manual_seed(3)
+    for layout in ("soa", "aos"):
+        z = torch.randn((T, m, N) if layout == "soa" else (T, N, m), generator=g, device=dev, dtype=torch.float64)
+        x0 = E.to_records(np.zeros((N, n)), layout, 0)
+        P0 = E.to_records(np.tile(10.0 * np.eye(n), (N, 1, 1)), layout, 0)
+        x, P = x0.clone(), P0.clone()
+        outs = [E.alloc_records((T,), N, n, layout), E.alloc_records((T,), N, n * n, layout),
+                E.alloc_records((T,), N, n, layout), E.alloc_records((T,), N, n * n, layout)]
+        st = torch.zeros(N, dtype=torch.int32, device=dev)
+        d = [E.dev(a) for a in (F, Q, H, R)]
+        desc = dict(n=n, m=m, nu=0, model_mode=0, N=N, T=T, layout=E.LAYOUTS[layout], update_first=0, alpha_sq=1.0)
+        for spec in os.environ.get("ML_SPECS", "1,1;2,2;2,4;2,5;2,10;3,5;4,4;4,10;default").split(";"):
+            os.environ.pop("FK_ML_CHUNKS", None)
+            if spec != "default":
+                os.environ["FK_ML_CHUNKS"] = spec
+
+            def run():
+                x.copy_(x0)
+                P.copy_(P0)
+                E.kf_batch_filter(desc, *d, z, x, P, means=outs[0], covs=outs[1], means_p=outs[2], covs_p=outs[3], status=st)
+            ms = timeit(run, warm=2, reps=5)
+            print(json.dumps(dict(chunks=spec, layout=layout, N=N, ms=ms, frac=N * T * 1464 / (ms * 1e-3) / 8e12)), flush=True)
+    os.environ.pop("FK_ML_CHUNKS", None)
+
+
 if __name__ == "__main__":
-    if os.environ.get("ML_WHAT", "kf") == "var":
+    if os.environ.get("ML_WHAT", "kf") == "chunks":
+        chunks()
+    elif os.environ.get("ML_WHAT", "kf") == "var":
         variants()
     elif os.environ.get("ML_WHAT", "kf") == "rts":
         rts()
