@@ -14,6 +14,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <mutex>
+
 // default decomposition of a chunked call (launch_kf_ml_chunked): track groups x time chunks
 #ifndef FK_ML_CHUNK_G
 #define FK_ML_CHUNK_G 3
@@ -32,6 +34,7 @@ struct MlStreams {
     hipStream_t st[MAXG] = {};
     hipEvent_t fork = nullptr, done[MAXG] = {};
     bool ok = false;
+    std::mutex mu;      // one chunked call enqueues at a time: a stream wait binds to the event's LATEST record
     MlStreams()
     {
         ok = hipEventCreateWithFlags(&fork, hipEventDisableTiming) == hipSuccess;
@@ -64,6 +67,53 @@ inline bool ml_chunk_policy(long waves, long T, int &G, int &H, long slots = 204
 }
 
 
+// Forward filter: `one(args, stream)` launches one piece (tracks [i0, i0 + cnt), T steps from the pointers in args); the
+// state is handed from chunk to chunk through x / P in place.  (KfArgs as a template parameter only keeps this header
+// free of the kernel headers.)  FK_ML_CHUNKS="G,H" forces a decomposition; default: ml_chunk_policy.
+template <class Args, class One>
+int kf_chunked_call(const Args &a, int n, int m, long slots, One &&one, hipStream_t s)
+{
+    int G, H;
+    if (!ml_chunk_policy((a.cnt + 15) / 16, a.T, G, H, slots) || a.cnt < 64L * G) return one(a, s);
+    MlStreams &ms = *ml_streams();
+    if (!ms.ok) return one(a, s);
+    std::lock_guard<std::mutex> lock(ms.mu);
+    if (hipEventRecord(ms.fork, s) != hipSuccess) return one(a, s);
+    // track groups: multiples of 64 tracks (a workgroup), the last one takes the remainder
+    const long blocks = (a.cnt + 63) / 64, per = (blocks + G - 1) / G * 64, nn = (long)n * n;
+    int rc = 0;
+    for (int g = 0; g < G && rc == 0; ++g) {
+        const long g0 = a.i0 + (long)g * per;
+        const long gcnt = (g0 + per <= a.i0 + a.cnt) ? per : (a.i0 + a.cnt - g0);
+        if (gcnt <= 0) break;
+        hipStream_t sg = g == 0 ? s : ms.st[g];
+        if (g > 0 && hipStreamWaitEvent(sg, ms.fork, 0) != hipSuccess) return -1;
+        const long shift = (FK_ML_CHUNK_STAGGER && !getenv("FK_ML_NO_STAGGER")) ? (a.T * g) / ((long)H * G) : 0;
+        for (int h = 0; h <= H && rc == 0; ++h) {
+            long t0 = a.T * h / H - shift, t1 = a.T * (h + 1) / H - shift;
+            if (t0 < 0) t0 = 0;
+            if (h == H) t1 = a.T;
+            if (t1 > a.T) t1 = a.T;
+            if (t1 <= t0) continue;
+            Args b = a;
+            b.i0 = g0;
+            b.cnt = gcnt;
+            b.T = t1 - t0;
+            b.status_or = t0 > 0 ? 1 : a.status_or;
+            b.z = a.z + t0 * a.N * m;
+            if (a.mask) b.mask = a.mask + t0 * a.N;
+            b.means = a.means + t0 * a.N * n;
+            b.means_p = a.means_p + t0 * a.N * n;
+            b.covs = a.covs + t0 * a.N * nn;
+            b.covs_p = a.covs_p + t0 * a.N * nn;
+            rc = one(b, sg);
+        }
+        if (g > 0 && rc == 0 && (hipEventRecord(ms.done[g], sg) != hipSuccess || hipStreamWaitEvent(s, ms.done[g], 0) != hipSuccess))
+            rc = -1;
+    }
+    return rc;
+}
+
 // The smoother runs backwards: group g's chunks go from the last time window to the first on stream g; a chunk's window
 // [k0, k1] shares its top step k1 with the chunk before it (which smoothed it): RtsArgs::cont.  `one(args, stream)`
 // launches one piece.  (RtsArgs is a template parameter only to keep this header free of the kernel headers.)
@@ -74,7 +124,9 @@ int rts_chunked_call(const Args &a, int n, long slots, One &&one, hipStream_t s)
     const long steps = a.T - 1;                                   // backward steps T-2 .. 0
     if (!ml_chunk_policy((a.N + 15) / 16, steps, G, H, slots) || a.N < 64L * G) return one(a, s);
     MlStreams &ms = *ml_streams();
-    if (!ms.ok || hipEventRecord(ms.fork, s) != hipSuccess) return one(a, s);
+    if (!ms.ok) return one(a, s);
+    std::lock_guard<std::mutex> lock(ms.mu);
+    if (hipEventRecord(ms.fork, s) != hipSuccess) return one(a, s);
     const long blocks = (a.N + 63) / 64, per = (blocks + G - 1) / G * 64, nn = (long)n * n;
     int rc = 0;
     for (int g = 0; g < G && rc == 0; ++g) {

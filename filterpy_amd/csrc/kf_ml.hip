@@ -801,48 +801,8 @@ static int launch_rts_ml_chunked(const RtsArgs &a, int layout, hipStream_t s)
 
 static int launch_kf_ml_chunked(const KfArgs &a, int layout, bool outs, hipStream_t s)
 {
-    // policy: FK_ML_CHUNKS="G,H" forces a decomposition ("1,1" = one launch); default: only where a round would be
-    // mostly idle -- more than two rounds of work whose last round is less than 40 % full
-    int G, H;
-    if (!outs || !ml_chunk_policy((a.cnt + 15) / 16, a.T, G, H) || a.cnt < 64L * G) return launch_kf_ml_one(a, layout, outs, s);
-    MlStreams &ms = *ml_streams();
-    if (!ms.ok) return launch_kf_ml_one(a, layout, outs, s);
-    // track groups: multiples of 64 tracks (a workgroup), the last one takes the remainder
-    const long blocks = (a.cnt + 63) / 64, per = (blocks + G - 1) / G * 64;
-    if (hipEventRecord(ms.fork, s) != hipSuccess) return launch_kf_ml_one(a, layout, outs, s);
-    int rc = 0;
-    for (int g = 0; g < G && rc == 0; ++g) {
-        const long g0 = a.i0 + (long)g * per;
-        const long gcnt = (g0 + per <= a.i0 + a.cnt) ? per : (a.i0 + a.cnt - g0);
-        if (gcnt <= 0) break;
-        hipStream_t sg = g == 0 ? s : ms.st[g];
-        if (g > 0 && hipStreamWaitEvent(sg, ms.fork, 0) != hipSuccess) { rc = FK_ERR_LAUNCH; break; }
-        // group g's chunk boundaries are shifted by g / G of a chunk (one more, shorter, first chunk): groups whose
-        // pieces all ended at the same moments would tail off together and leave nothing to fill with
-        const long shift = (FK_ML_CHUNK_STAGGER && !getenv("FK_ML_NO_STAGGER")) ? (a.T * g) / ((long)H * G) : 0;
-        for (int h = 0; h <= H && rc == 0; ++h) {
-            long t0 = a.T * h / H - shift, t1 = a.T * (h + 1) / H - shift;
-            if (t0 < 0) t0 = 0;
-            if (h == H) t1 = a.T;
-            if (t1 > a.T) t1 = a.T;
-            if (t1 <= t0) continue;
-            KfArgs b = a;
-            b.i0 = g0;
-            b.cnt = gcnt;
-            b.T = t1 - t0;
-            b.status_or = t0 > 0 ? 1 : a.status_or;
-            b.z = a.z + t0 * a.N * 3;
-            if (a.mask) b.mask = a.mask + t0 * a.N;
-            b.means = a.means + t0 * a.N * 9;
-            b.means_p = a.means_p + t0 * a.N * 9;
-            b.covs = a.covs + t0 * a.N * 81;
-            b.covs_p = a.covs_p + t0 * a.N * 81;
-            rc = launch_kf_ml_one(b, layout, outs, sg);
-        }
-        if (g > 0 && rc == 0 && (hipEventRecord(ms.done[g], sg) != hipSuccess || hipStreamWaitEvent(s, ms.done[g], 0) != hipSuccess))
-            rc = FK_ERR_LAUNCH;
-    }
-    return rc;
+    if (!outs) return launch_kf_ml_one(a, layout, outs, s);
+    return kf_chunked_call(a, 9, 3, 2048, [layout, outs](const KfArgs &b, hipStream_t sb) { return launch_kf_ml_one(b, layout, outs, sb); }, s);
 }
 #endif   // FK_ML_PART != 2
 

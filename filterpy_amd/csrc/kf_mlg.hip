@@ -26,6 +26,7 @@
 #include "fk_math_sym.hpp"
 #include "fk_kernel_args.hpp"
 #include "fk_ml.hpp"
+#include "fk_chunks.hpp"
 #include "../../include/filterhip.h"
 
 #ifndef FK_NX
@@ -150,9 +151,10 @@ kf_mlg_kernel(const KfArgs a)
 
     const long N = a.N;
     const unsigned L = threadIdx.x & 3u;
-    long trk = (long)blockIdx.x * (BLOCK / 4) + (threadIdx.x >> 2);
-    const bool owner = trk < N;                                // tail quads only duplicate: they never write the final state
-    if (trk >= N) trk = N - 1;
+    const long iend = a.i0 + a.cnt;                            // this launch's track group (chunked calls, fk_chunks.hpp)
+    long trk = a.i0 + (long)blockIdx.x * (BLOCK / 4) + (threadIdx.x >> 2);
+    const bool owner = trk < iend;                             // tail quads only duplicate: they never write the final state
+    if (trk >= iend) trk = iend - 1;
     unsigned row[R];                                           // the rows this lane holds (clamped: see the header)
     double live[R];                                            // 1.0 for a row of its own, 0.0 for a clamped duplicate
     FK_UNROLL for (int r = 0; r < R; ++r) {
@@ -168,8 +170,8 @@ kf_mlg_kernel(const KfArgs a)
     unsigned off_row[R];                                                                      // element row[r] * NX of a covariance record
     FK_UNROLL for (int r = 0; r < R; ++r)
         off_row[r] = (AOS ? (unsigned)trk * (unsigned)(NX * NX) * 8u : (unsigned)trk * 8u) + row[r] * (unsigned)NX * estride;
-    const long w0 = (long)blockIdx.x * (BLOCK / 4) + (long)(threadIdx.x >> 6) * 16;
-    const unsigned valid = (unsigned)(N - w0 >= 16 ? 16 : (N - w0 > 0 ? N - w0 : 0));
+    const long w0 = a.i0 + (long)blockIdx.x * (BLOCK / 4) + (long)(threadIdx.x >> 6) * 16;
+    const unsigned valid = (unsigned)(iend - w0 >= 16 ? 16 : (iend - w0 > 0 ? iend - w0 : 0));
     const unsigned lane = threadIdx.x & 63u;
     const uint8_t *mask_or_dummy = a.mask ? a.mask : reinterpret_cast<const uint8_t *>(a.z);
     const unsigned nu = VAR ? (unsigned)a.nu : 0u;
@@ -386,7 +388,7 @@ kf_mlg_kernel(const KfArgs a)
             int s = st | (fin ? 0 : ST_NONFINITE);
             s |= __builtin_amdgcn_mov_dpp(s, 0xB1, 0xf, 0xf, true);
             s |= __builtin_amdgcn_mov_dpp(s, 0x4E, 0xf, 0xf, true);
-            if (L == 0) a.status[trk] = s;
+            if (L == 0) a.status[trk] = a.status_or ? (a.status[trk] | s) : s;
         }
     }
 }
@@ -398,7 +400,7 @@ int FK_MLG_CAT(launch_kf_mlg_, FK_NX, FK_NZ)(const KfArgs &a, int layout, bool o
 {
     using namespace FK_MLG_CAT(mlg_, FK_NX, FK_NZ);
     if ((model_mode != FK_MODEL_SHARED && model_mode != FK_MODEL_PER_STEP) || a.n != FK_NX || a.m != FK_NZ || !outs) return 1;
-    const dim3 grid((unsigned)((a.N + BLOCK / 4 - 1) / (BLOCK / 4))), block(BLOCK);
+    const dim3 grid((unsigned)((a.cnt + BLOCK / 4 - 1) / (BLOCK / 4))), block(BLOCK);
     if (model_mode == FK_MODEL_PER_STEP || a.nu > 0 || a.update_first) {
         // the VAR instantiations (FK_ML_VAR=0 sends these calls back to the padded kernel)
         const char *vv = getenv("FK_ML_VAR");
@@ -410,9 +412,14 @@ int FK_MLG_CAT(launch_kf_mlg_, FK_NX, FK_NZ)(const KfArgs &a, int layout, bool o
 #undef GOV
         return check_launch("kf_mlg_kernel<var>");
     }
-    if (layout == FK_LAYOUT_AOS) hipLaunchKernelGGL((kf_mlg_kernel<FK_NX, FK_NZ, LAYOUT_AOS>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((kf_mlg_kernel<FK_NX, FK_NZ, LAYOUT_SOA>), grid, block, 0, s, a);
-    return check_launch("kf_mlg_kernel");
+    // the plain call, with tail filling where the last round of waves would be mostly idle (fk_chunks.hpp)
+    auto one = [layout](const KfArgs &b, hipStream_t sb) -> int {
+        const dim3 gb((unsigned)((b.cnt + BLOCK / 4 - 1) / (BLOCK / 4))), bb(BLOCK);
+        if (layout == FK_LAYOUT_AOS) hipLaunchKernelGGL((kf_mlg_kernel<FK_NX, FK_NZ, LAYOUT_AOS>), gb, bb, 0, sb, b);
+        else hipLaunchKernelGGL((kf_mlg_kernel<FK_NX, FK_NZ, LAYOUT_SOA>), gb, bb, 0, sb, b);
+        return check_launch("kf_mlg_kernel");
+    };
+    return kf_chunked_call(a, FK_NX, FK_NZ, FK_NX <= 8 ? 3072 : FK_NX <= 9 ? 2048 : 1024, one, s);
 }
 
 }  // namespace fk

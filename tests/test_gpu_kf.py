@@ -626,13 +626,14 @@ def test_four_lane_kernel_variants_vs_oracle(n, m, layout):
                     assert rel_err_rows(got[4][sample], last[-1]) < TOL and rel_err_rows(got[5][sample], lastP[-1]) < TOL, tag
 
 
+@pytest.mark.parametrize("n,m", [(9, 3), (12, 2)])
 @pytest.mark.parametrize("layout", ["soa", "aos"])
 @pytest.mark.parametrize("N", [1000, 777, 130])
-def test_multilane_chunked_call_is_bit_identical(N, layout, monkeypatch):
-    """launch_kf_ml_chunked: G track groups x H time chunks on G streams (tail filling) must give the single launch's
-    bits -- outputs, final state and status -- for every decomposition, with a mask, ragged N, AOS slabs"""
+def test_multilane_chunked_call_is_bit_identical(N, layout, n, m, monkeypatch):
+    """kf_chunked_call: G track groups x H time chunks on G streams (tail filling) must give the single launch's
+    bits -- outputs, final state and status -- for every decomposition, with a mask, ragged N, AOS slabs; kf_ml (9,3)
+    and the four-lane kf_mlg (12,2)"""
     from gpu_util import run_kf_batch
-    n, m = 9, 3
     rs = np.random.RandomState(4242 + N)
     T = 23
     A = rs.randn(N, n, n)
@@ -644,6 +645,7 @@ def test_multilane_chunked_call_is_bit_identical(N, layout, monkeypatch):
     H = rs.randn(m, n)
     R = 0.5 * np.eye(m)
     mask = rs.rand(T, N) > 0.2
+    mask[0, 5] = True
     P0[5] = -np.eye(n)                     # one track whose S is not positive definite: the status bit must survive the chunks
     monkeypatch.setenv("FK_ML_CHUNKS", "1,1")
     one = run_kf_batch(x0, P0, zs, F, Q, H, R, layout=layout, mask=mask, check_status=False)
