@@ -71,16 +71,16 @@ inline bool ml_chunk_policy(long waves, long T, int &G, int &H, long slots = 204
 // state is handed from chunk to chunk through x / P in place.  (KfArgs as a template parameter only keeps this header
 // free of the kernel headers.)  FK_ML_CHUNKS="G,H" forces a decomposition; default: ml_chunk_policy.
 template <class Args, class One>
-int kf_chunked_call(const Args &a, int n, int m, long slots, One &&one, hipStream_t s)
+int kf_chunked_call(const Args &a, int n, int m, long slots, One &&one, hipStream_t s, int tracks_per_wave = 16, long group_quantum = 64)
 {
     int G, H;
-    if (!ml_chunk_policy((a.cnt + 15) / 16, a.T, G, H, slots) || a.cnt < 64L * G) return one(a, s);
+    if (!ml_chunk_policy((a.cnt + tracks_per_wave - 1) / tracks_per_wave, a.T, G, H, slots) || a.cnt < group_quantum * G) return one(a, s);
     MlStreams &ms = *ml_streams();
     if (!ms.ok) return one(a, s);
     std::lock_guard<std::mutex> lock(ms.mu);
     if (hipEventRecord(ms.fork, s) != hipSuccess) return one(a, s);
-    // track groups: multiples of 64 tracks (a workgroup), the last one takes the remainder
-    const long blocks = (a.cnt + 63) / 64, per = (blocks + G - 1) / G * 64, nn = (long)n * n;
+    // track groups: multiples of a workgroup's tracks, the last one takes the remainder
+    const long blocks = (a.cnt + group_quantum - 1) / group_quantum, per = (blocks + G - 1) / G * group_quantum, nn = (long)n * n;
     int rc = 0;
     for (int g = 0; g < G && rc == 0; ++g) {
         const long g0 = a.i0 + (long)g * per;

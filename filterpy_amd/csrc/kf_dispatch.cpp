@@ -12,6 +12,7 @@
 #include "../../include/filterhip.h"
 #include "fk_device.hpp"
 #include "fk_kernel_args.hpp"
+#include "fk_chunks.hpp"
 
 namespace fk {
 
@@ -197,7 +198,18 @@ static int run_kf(const fk_kf_desc *d, KfArgs &a, void *stream)
         if (const FastEntry *f = pick_fast(d->n, d->m)) {
             const char *ev = getenv("FK_FAST_XCD");
             a.xcd_swizzle = ev ? atoi(ev) : 0;
-            const int rc = f->fn(a, d->layout, all_out, d->model_mode, (hipStream_t)stream);
+            int rc;
+            if (d->n >= 7 && all_out && d->model_mode == FK_MODEL_SHARED && d->nu == 0 && !d->update_first) {
+                // the one-wave-per-SIMD instantiations (dim_x 7..9) are bound by arithmetic, not HBM: tail filling
+                // (fk_chunks.hpp) where the last round of waves would be mostly idle -- e.g. 2e5 tracks = 3125 waves
+                // of 64 on 1024 slots
+                const int layout = d->layout, mm = d->model_mode;
+                rc = kf_chunked_call(a, d->n, d->m, 1024,
+                                     [f, layout, mm](const KfArgs &b, hipStream_t sb) { return f->fn(b, layout, true, mm, sb); },
+                                     (hipStream_t)stream, 64, 256);
+            } else {
+                rc = f->fn(a, d->layout, all_out, d->model_mode, (hipStream_t)stream);
+            }
             if (rc <= 0) return rc;        // 1 = this instantiation does not carry the model mode
         }
     }

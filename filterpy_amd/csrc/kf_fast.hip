@@ -290,7 +290,7 @@ kf_fast_kernel(const KfArgs a, const double *__restrict__ pF, const double *__re
         store_rec<NX, NX, LAYOUT, true>(Pl, a.P, ln, NX, NX);
         if (a.status) {
             if (!all_finite<NX>(x) || !all_finite<PLEN>(P)) st |= ST_NONFINITE;
-            a.status[blk0 + ln.tid] = st;
+            a.status[blk0 + ln.tid] = a.status_or ? (a.status[blk0 + ln.tid] | st) : st;
         }
     }
 }

@@ -684,3 +684,36 @@ def test_multilane_chunked_smoother_is_bit_identical(N, layout, family, n, monke
     ref = kf_oracle.rts_smoother_tracks(Xs, Ps, F, Q, tracks=[0, 64, N - 1])
     for k in range(4):
         assert rel_err_rows(_per_track(one[k][:, [0, 64, N - 1]]), _per_track(ref[k])) < TOL, k
+
+
+@pytest.mark.parametrize("layout", ["soa", "aos"])
+@pytest.mark.parametrize("n,m", [(7, 4), (8, 3), (9, 2)])
+def test_one_lane_chunked_call_is_bit_identical(n, m, layout, monkeypatch):
+    """the one-wave-per-SIMD kf_fast instantiations (dim_x 7..9) under tail filling (kf_chunked_call in run_kf): every
+    decomposition gives the single launch's bits, incl. the packed-triangle variants whose P goes through memory
+    between chunks, a mask and the status word"""
+    from gpu_util import run_kf_batch
+    rs = np.random.RandomState(90 * n + m)
+    N, T = 777, 17
+    A = rs.randn(N, n, n)
+    x0, P0 = rs.randn(N, n), 4.0 * (A @ A.transpose(0, 2, 1) / n + 0.5 * np.eye(n))
+    zs = rs.randn(T, N, m) * 3
+    F = np.eye(n) + 0.1 * rs.randn(n, n)
+    B = rs.randn(n, n)
+    Q = 0.1 * (B @ B.T / n + 0.5 * np.eye(n))
+    H = rs.randn(m, n)
+    R = 0.5 * np.eye(m)
+    mask = rs.rand(T, N) > 0.2
+    mask[0, 5] = True
+    P0[5] = -np.eye(n)
+    monkeypatch.setenv("FK_ML_CHUNKS", "1,1")
+    one = run_kf_batch(x0, P0, zs, F, Q, H, R, layout=layout, mask=mask, check_status=False)
+    assert one[6][5] != 0 and not one[6][[0, 1, 6]].any()
+    for spec in ("2,4", "3,3", "3,17"):
+        monkeypatch.setenv("FK_ML_CHUNKS", spec)
+        got = run_kf_batch(x0, P0, zs, F, Q, H, R, layout=layout, mask=mask, check_status=False)
+        for k in range(7):
+            assert np.array_equal(got[k], one[k], equal_nan=True), (spec, k)
+    ref = kf_oracle.kf_batch_filter_tracks(x0, P0, zs, F, Q, H, R, tracks=[0, 64, N - 1], mask=mask)
+    for k in range(4):
+        assert rel_err_rows(_per_track(one[k][:, [0, 64, N - 1]]), _per_track(ref[k])) < TOL, k
