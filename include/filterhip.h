@@ -110,6 +110,10 @@ typedef struct fk_kf_desc {
  *   means_p, covs_p : prior per step; may be NULL.
  *   status  : int32 [N] (OR-ed FK_STATUS_* bits); may be NULL.
  *
+ * The call is asynchronous on `stream` and ordered like one kernel on it; at dim_x >= 7 it may fan out over up to three
+ * helper streams of the library that fork from and join back into `stream` with events (same results bit for bit;
+ * INTEGRATION.md, "Streams").
+ *
  * S^-1 is applied by an in-lane LDL^T (square-root-free Cholesky) solve, not an
  * explicit inverse; S must be symmetric positive definite (status bit otherwise).
  */
