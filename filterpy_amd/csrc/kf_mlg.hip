@@ -1,8 +1,8 @@
 // kf_mlg.hip -- KalmanFilter.batch_filter for dim_x = 10..16 (dim_z = 1..4) with FOUR LANES PER TRACK (gfx950).
 //
 // One lane per track ends at dim_x = 9: P alone is 2 n^2 VGPRs.  Above that the library used to run the padded /
-// rolled one-lane instantiations (scratch-resident arrays, guards around every access inside the time loop): 0.02-0.06
-// of the HBM peak.  Here the scheme of kf_ml.hip (dim_x = 9 on three lanes) is generalised: a QUAD of lanes owns a
+// rolled one-lane instantiations (scratch-resident arrays, guards around every access inside the time loop): 0.002-0.004
+// of the HBM peak (profiles/r02/dims_10_16.jsonl).  Here the scheme of kf_ml.hip (dim_x = 9 on three lanes) is generalised: a QUAD of lanes owns a
 // track, lane L holds rows L*R .. L*R+R-1 of P (R = ceil(n/4)); rows past n-1 -- the tail of lane 3 for n = 10, 11,
 // 13, 14, 15 -- are CLAMPED to row n-1: the lane recomputes and rewrites that row (same values, same addresses), so no
 // lane is ever predicated, and it enters the one cross-lane SUM of the step (H P) with coefficient zero.  x, y, S

@@ -1,4 +1,4 @@
-// rts_mlg.hip -- KalmanFilter.rts_smoother for dim_x = 10..16 with FOUR LANES PER TRACK (gfx950); the backward
+// rts_mlg.hip -- KalmanFilter.rts_smoother for dim_x = 10..16 (and 8, 9 in NumPy order) with FOUR LANES PER TRACK (gfx950); the backward
 // companion of kf_mlg.hip, same row ownership (lane L: rows L*R .. L*R+R-1, R = ceil(n/4), rows past n-1 clamped to
 // row n-1 and recomputed -- nothing is predicated; the smoother has no cross-lane sum, so the duplicates need no
 // special care).  Per step k = T-2 .. 0 (filterpy/kalman/kalman_filter.py:1066-1072):
