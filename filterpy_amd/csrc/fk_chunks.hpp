@@ -106,6 +106,14 @@ int kf_chunked_call(const Args &a, int n, int m, long slots, One &&one, hipStrea
             b.means_p = a.means_p + t0 * a.N * n;
             b.covs = a.covs + t0 * a.N * nn;
             b.covs_p = a.covs_p + t0 * a.N * nn;
+            if (a.model_t) {                                   // one model per step, shared by the bank (VAR instantiations)
+                b.F = a.F + t0 * nn;
+                b.Q = a.Q + t0 * nn;
+                b.H = a.H + t0 * (long)m * n;
+                b.R = a.R + t0 * (long)m * m;
+                if (a.nu > 0) b.B = a.B + t0 * (long)n * a.nu;
+            }
+            if (a.nu > 0) b.u = a.u + t0 * a.N * a.nu;
             rc = one(b, sg);
         }
         if (g > 0 && rc == 0 && (hipEventRecord(ms.done[g], sg) != hipSuccess || hipStreamWaitEvent(s, ms.done[g], 0) != hipSuccess))

@@ -760,7 +760,7 @@ int launch_kf_ml_9_3(const KfArgs &a, int layout, bool outs, int model_mode, hip
         // the VAR family: all four outputs, dim_u <= 4 (FK_ML_VAR=0 sends these calls back to kf_fast / kf_kernel)
         const char *vv = getenv("FK_ML_VAR");
         if (!outs || a.nu > 4 || (vv && atoi(vv) == 0)) return 1;
-        return launch_kf_ml_9_3_var(a, layout, s);
+        return kf_chunked_call(a, 9, 3, 2048, [layout](const KfArgs &b, hipStream_t sb) { return launch_kf_ml_9_3_var(b, layout, sb); }, s);
     }
     return launch_kf_ml_chunked(a, layout, outs, s);
 }
@@ -809,9 +809,9 @@ static int launch_kf_ml_chunked(const KfArgs &a, int layout, bool outs, hipStrea
 #if FK_ML_PART != 1
 int launch_kf_ml_9_3_var(const KfArgs &a, int layout, hipStream_t s)
 {
-    const dim3 grid((unsigned)((a.N + BLOCK / 4 - 1) / (BLOCK / 4))), block(BLOCK);
+    const dim3 grid((unsigned)((a.cnt + BLOCK / 4 - 1) / (BLOCK / 4))), block(BLOCK);
     const char *pv = getenv("FK_ML_PAIRS");
-    const bool pairs = (a.N % 2 == 0) && a.N >= 2 && !(pv && atoi(pv) == 0);
+    const bool pairs = (a.N % 2 == 0) && (a.cnt % 2 == 0) && a.cnt >= 2 && !(pv && atoi(pv) == 0);
 #define GOV(UFV)                                                                                                            \
     if (layout == FK_LAYOUT_AOS)                                                                                            \
         hipLaunchKernelGGL((kf_ml_kernel<3, 3, true, FK_ML_WAVES, false, true, LAYOUT_AOS, true, UFV>), grid, block, 0, s, a); \

@@ -400,17 +400,20 @@ int FK_MLG_CAT(launch_kf_mlg_, FK_NX, FK_NZ)(const KfArgs &a, int layout, bool o
 {
     using namespace FK_MLG_CAT(mlg_, FK_NX, FK_NZ);
     if ((model_mode != FK_MODEL_SHARED && model_mode != FK_MODEL_PER_STEP) || a.n != FK_NX || a.m != FK_NZ || !outs) return 1;
-    const dim3 grid((unsigned)((a.cnt + BLOCK / 4 - 1) / (BLOCK / 4))), block(BLOCK);
     if (model_mode == FK_MODEL_PER_STEP || a.nu > 0 || a.update_first) {
         // the VAR instantiations (FK_ML_VAR=0 sends these calls back to the padded kernel)
         const char *vv = getenv("FK_ML_VAR");
         if (a.nu > 4 || (vv && atoi(vv) == 0)) return 1;
+        auto onev = [layout](const KfArgs &b, hipStream_t sb) -> int {
+            const dim3 gb((unsigned)((b.cnt + BLOCK / 4 - 1) / (BLOCK / 4))), bb(BLOCK);
 #define GOV(UFV)                                                                                                    \
-    if (layout == FK_LAYOUT_AOS) hipLaunchKernelGGL((kf_mlg_kernel<FK_NX, FK_NZ, LAYOUT_AOS, true, UFV>), grid, block, 0, s, a); \
-    else hipLaunchKernelGGL((kf_mlg_kernel<FK_NX, FK_NZ, LAYOUT_SOA, true, UFV>), grid, block, 0, s, a)
-        if (a.update_first) { GOV(true); } else { GOV(false); }
+    if (layout == FK_LAYOUT_AOS) hipLaunchKernelGGL((kf_mlg_kernel<FK_NX, FK_NZ, LAYOUT_AOS, true, UFV>), gb, bb, 0, sb, b); \
+    else hipLaunchKernelGGL((kf_mlg_kernel<FK_NX, FK_NZ, LAYOUT_SOA, true, UFV>), gb, bb, 0, sb, b)
+            if (b.update_first) { GOV(true); } else { GOV(false); }
 #undef GOV
-        return check_launch("kf_mlg_kernel<var>");
+            return check_launch("kf_mlg_kernel<var>");
+        };
+        return kf_chunked_call(a, FK_NX, FK_NZ, FK_NX <= 8 ? 3072 : FK_NX <= 9 ? 2048 : 1024, onev, s);
     }
     // the plain call, with tail filling where the last round of waves would be mostly idle (fk_chunks.hpp)
     auto one = [layout](const KfArgs &b, hipStream_t sb) -> int {

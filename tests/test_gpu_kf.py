@@ -717,3 +717,37 @@ def test_one_lane_chunked_call_is_bit_identical(n, m, layout, monkeypatch):
     ref = kf_oracle.kf_batch_filter_tracks(x0, P0, zs, F, Q, H, R, tracks=[0, 64, N - 1], mask=mask)
     for k in range(4):
         assert rel_err_rows(_per_track(one[k][:, [0, 64, N - 1]]), _per_track(ref[k])) < TOL, k
+
+
+@pytest.mark.parametrize("layout", ["soa", "aos"])
+@pytest.mark.parametrize("n,m", [(9, 3), (11, 2)])
+def test_variant_calls_chunked_are_bit_identical(n, m, layout, monkeypatch):
+    """per-step model lists (incl. B), control input, update_first and a mask under tail filling: the model / control
+    pointers advance with the time chunks; every decomposition must reproduce the single launch bit for bit"""
+    from gpu_util import run_kf_batch
+    from filterpy_amd._abi import FK_MODEL_PER_STEP, FK_MODEL_SHARED
+    nu = 2
+    rs = np.random.RandomState(31 * n + m)
+    N, T = 333, 13
+    A = rs.randn(N, n, n)
+    x0, P0 = rs.randn(N, n), 4.0 * (A @ A.transpose(0, 2, 1) / n + 0.5 * np.eye(n))
+    zs, us = rs.randn(T, N, m) * 3, rs.randn(T, N, nu)
+
+    def spd(k, s, cnt):
+        G = rs.randn(cnt, k, k)
+        return s * (G @ G.transpose(0, 2, 1) / k + 0.5 * np.eye(k))
+    Fs = np.eye(n) + 0.1 * rs.randn(T, n, n)
+    Qs, Hs, Rs, Bs = spd(n, 0.1, T), rs.randn(T, m, n), spd(m, 0.5, T), rs.randn(T, n, nu)
+    mask = rs.rand(T, N) > 0.25
+    for per_step, ctrl, uf in ((True, True, True), (True, False, False), (False, True, False), (False, False, True)):
+        mods = (Fs, Qs, Hs, Rs) if per_step else (Fs[0], Qs[0], Hs[0], Rs[0])
+        B = None if not ctrl else (Bs if per_step else Bs[0])
+        kw = dict(layout=layout, mode=FK_MODEL_PER_STEP if per_step else FK_MODEL_SHARED, B=B, us=us if ctrl else None,
+                  update_first=uf, mask=mask)
+        monkeypatch.setenv("FK_ML_CHUNKS", "1,1")
+        one = run_kf_batch(x0, P0, zs, *mods, **kw)
+        for spec in ("2,3", "3,13"):
+            monkeypatch.setenv("FK_ML_CHUNKS", spec)
+            got = run_kf_batch(x0, P0, zs, *mods, **kw)
+            for k in range(7):
+                assert np.array_equal(got[k], one[k]), (per_step, ctrl, uf, spec, k)
