@@ -78,6 +78,7 @@ SIGNATURES = {
     "fk_abi_version": (ctypes.c_int, []),
     "fk_build_arch": (ctypes.c_char_p, []),
     "fk_last_error": (ctypes.c_char_p, []),
+    "fk_chunk_plan": (ctypes.c_int, [c_i64, c_i64, c_i32, c_i64, c_i32, c_vp, c_vp, c_vp]),
 }
 
 _lib = None

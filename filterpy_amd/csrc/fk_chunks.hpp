@@ -62,10 +62,25 @@ inline bool ml_chunk_policy(long waves, long T, int &G, int &H, long slots = 204
         if (rem != 0 && rem * 10 < slots * 4) { G = FK_ML_CHUNK_G; H = FK_ML_CHUNK_H; }
     }
     if (G > MlStreams::MAXG) G = MlStreams::MAXG;
+    if (H > 64) H = 64;
     if (H > T) H = (int)T;
     return G >= 1 && H >= 1 && !(G == 1 && H == 1);
 }
 
+
+// Window h (0..H; there is one more window than chunks because of the stagger) of track group g over L steps: [w0, w1).
+// Group g's boundaries are shifted down by g / G of a chunk; false: empty window.  The H + 1 windows of a group tile
+// [0, L) in order (tests/test_host_logic.py checks this through fk_chunk_plan for every L <= 128, G <= 4, H <= L).
+inline bool chunk_window(long L, int G, int H, int g, int h, long &w0, long &w1)
+{
+    const long shift = (FK_ML_CHUNK_STAGGER && !getenv("FK_ML_NO_STAGGER")) ? (L * g) / ((long)H * G) : 0;
+    w0 = L * h / H - shift;
+    w1 = L * (h + 1) / H - shift;
+    if (w0 < 0) w0 = 0;
+    if (h == H) w1 = L;
+    if (w1 > L) w1 = L;
+    return w1 > w0;
+}
 
 // Forward filter: `one(args, stream)` launches one piece (tracks [i0, i0 + cnt), T steps from the pointers in args); the
 // state is handed from chunk to chunk through x / P in place.  (KfArgs as a template parameter only keeps this header
@@ -88,13 +103,9 @@ int kf_chunked_call(const Args &a, int n, int m, long slots, One &&one, hipStrea
         if (gcnt <= 0) break;
         hipStream_t sg = g == 0 ? s : ms.st[g];
         if (g > 0 && hipStreamWaitEvent(sg, ms.fork, 0) != hipSuccess) return -1;
-        const long shift = (FK_ML_CHUNK_STAGGER && !getenv("FK_ML_NO_STAGGER")) ? (a.T * g) / ((long)H * G) : 0;
         for (int h = 0; h <= H && rc == 0; ++h) {
-            long t0 = a.T * h / H - shift, t1 = a.T * (h + 1) / H - shift;
-            if (t0 < 0) t0 = 0;
-            if (h == H) t1 = a.T;
-            if (t1 > a.T) t1 = a.T;
-            if (t1 <= t0) continue;
+            long t0, t1;
+            if (!chunk_window(a.T, G, H, g, h, t0, t1)) continue;
             Args b = a;
             b.i0 = g0;
             b.cnt = gcnt;
@@ -142,14 +153,10 @@ int rts_chunked_call(const Args &a, int n, long slots, One &&one, hipStream_t s)
         if (gcnt <= 0) break;
         hipStream_t sg = g == 0 ? s : ms.st[g];
         if (g > 0 && hipStreamWaitEvent(sg, ms.fork, 0) != hipSuccess) return -1;
-        const long shift = (FK_ML_CHUNK_STAGGER && !getenv("FK_ML_NO_STAGGER")) ? (steps * g) / ((long)H * G) : 0;
         bool first = true;
         for (int h = H; h >= 0 && rc == 0; --h) {                 // windows of backward steps [k0, k1), last first
-            long k0 = steps * h / H - shift, k1 = steps * (h + 1) / H - shift;
-            if (k0 < 0) k0 = 0;
-            if (h == H) k1 = steps;
-            if (k1 > steps) k1 = steps;
-            if (k1 <= k0) continue;
+            long k0, k1;
+            if (!chunk_window(steps, G, H, g, h, k0, k1)) continue;
             Args b = a;
             b.i0 = g0;
             b.cnt = gcnt;

@@ -5,6 +5,7 @@
 
 #include "../../include/filterhip.h"
 #include "fk_device.hpp"
+#include "fk_chunks.hpp"
 
 namespace fk {
 
@@ -33,5 +34,31 @@ extern "C" {
 int fk_abi_version(void) { return FK_ABI_VERSION; }
 const char *fk_build_arch(void) { return "gfx950"; }
 const char *fk_last_error(void) { return fk::g_err; }
+
+// what a chunked call would do (fk_chunks.hpp): host arithmetic only, no GPU work
+int fk_chunk_plan(int64_t n_tracks, int64_t n_steps, int32_t tracks_per_wave, int64_t wave_slots, int32_t group,
+                  int64_t *windows, int32_t *n_groups, int32_t *n_chunks)
+{
+    if (n_tracks < 0 || n_steps < 1 || tracks_per_wave < 1 || wave_slots < 1 || !windows) return -1;
+    int G = 1, H = 1;
+    const bool chunked = fk::ml_chunk_policy((n_tracks + tracks_per_wave - 1) / tracks_per_wave, n_steps, G, H, wave_slots);
+    if (!chunked) G = H = 1;
+    if (n_groups) *n_groups = G;
+    if (n_chunks) *n_chunks = H;
+    if (group < 0 || group >= G) return -1;
+    int nw = 0;
+    for (int h = 0; h <= H; ++h) {
+        long w0, w1;
+        if (!chunked) {
+            if (h > 0) break;
+            w0 = 0;
+            w1 = n_steps;
+        } else if (!fk::chunk_window(n_steps, G, H, group, h, w0, w1)) continue;
+        windows[2 * nw] = w0;
+        windows[2 * nw + 1] = w1;
+        ++nw;
+    }
+    return nw;
+}
 
 }  // extern "C"

@@ -422,6 +422,13 @@ int fk_abi_version(void);
 const char *fk_build_arch(void);
 /* last HIP error string seen by this library on the calling thread ("" if none) */
 const char *fk_last_error(void);
+/* How a call would be cut for tail filling (INTEGRATION.md "Streams", csrc/fk_chunks.hpp) -- host arithmetic only:
+ * n_tracks tracks at tracks_per_wave per wave on wave_slots resident waves, n_steps time steps (the smoother: T - 1
+ * backward steps).  Writes the time windows [w0, w1) of track group `group` into windows[2 * i], windows[2 * i + 1]
+ * (room for 2 * 65 values), the group and chunk counts into n_groups / n_chunks (1, 1: one launch); returns the number
+ * of windows, -1 on a bad argument.  FK_ML_CHUNKS="G,H" in the environment overrides the policy. */
+int fk_chunk_plan(int64_t n_tracks, int64_t n_steps, int32_t tracks_per_wave, int64_t wave_slots, int32_t group,
+                  int64_t *windows, int32_t *n_groups, int32_t *n_chunks);
 
 #ifdef __cplusplus
 }

@@ -121,3 +121,39 @@ def test_merwe_weights_host_side():
     # constructor hooks are kept like the reference keeps them (sigma_points.py:106-116)
     hp = MerweScaledSigmaPoints(2, .1, 2., 1., sqrt_method=np.linalg.cholesky)
     assert hp.sqrt is np.linalg.cholesky and hp.subtract is np.subtract and pts.subtract is np.subtract
+
+
+def test_chunk_plan_windows_tile_the_time_axis(monkeypatch):
+    """fk_chunk_plan (csrc/fk_chunks.hpp through the C ABI, host arithmetic only): for every forced decomposition the
+    H + 1 staggered windows of every track group tile [0, L) in order; the default policy only cuts calls whose last
+    round of waves would be mostly idle."""
+    import ctypes
+    from filterpy_amd import _abi
+    lib = _abi.lib()
+    win = (ctypes.c_int64 * 130)()
+    G, H = ctypes.c_int32(), ctypes.c_int32()
+
+    def plan(N, L, tpw, slots, g):
+        n = lib.fk_chunk_plan(N, L, tpw, slots, g, ctypes.addressof(win), ctypes.addressof(G), ctypes.addressof(H))
+        return n, [(win[2 * i], win[2 * i + 1]) for i in range(max(n, 0))]
+    for L in list(range(1, 40)) + [64, 99, 100, 128]:
+        for g_req in (1, 2, 3, 4):
+            for h_req in {1, 2, 3, 5, min(L, 17), min(L, 64)}:
+                monkeypatch.setenv("FK_ML_CHUNKS", f"{g_req},{h_req}")
+                for g in range(g_req):
+                    n, w = plan(100000, L, 16, 2048, g)
+                    if g_req == 1 and h_req == 1:
+                        assert (n, w) == (1, [(0, L)])
+                        continue
+                    assert G.value == g_req and H.value == min(h_req, L) and 1 <= n <= H.value + 1, (L, g_req, h_req, g)
+                    assert w[0][0] == 0 and w[-1][1] == L and all(a[1] == b[0] and a[0] < a[1] for a, b in zip(w, w[1:] + [(L, L + 1)]))
+                assert plan(100000, L, 16, 2048, g_req)[0] == -1          # no such group
+    monkeypatch.delenv("FK_ML_CHUNKS")
+    # default policy: config 3 (6250 waves on 2048 slots: 3.05 rounds) is cut, 4e5 tracks (12.2 rounds: 20 % tail) too,
+    # but not a bank that fills its last round, nor a short run, nor one that fits two rounds
+    assert plan(100000, 100, 16, 2048, 0)[0] > 1 and (G.value, H.value) == (3, 4)
+    assert plan(98304, 100, 16, 2048, 0) == (1, [(0, 100)])
+    assert plan(100000 + 16 * 1024, 100, 16, 2048, 0) == (1, [(0, 100)])      # last round more than 40 % full
+    assert plan(100000, 8, 16, 2048, 0) == (1, [(0, 8)])
+    assert plan(60000, 100, 16, 2048, 0) == (1, [(0, 100)])
+    assert plan(200000, 100, 64, 1024, 0)[0] > 1                               # kf_fast (8,4): 3125 waves of 64 on 1024 slots
