@@ -751,3 +751,27 @@ def test_variant_calls_chunked_are_bit_identical(n, m, layout, monkeypatch):
             got = run_kf_batch(x0, P0, zs, *mods, **kw)
             for k in range(7):
                 assert np.array_equal(got[k], one[k]), (per_step, ctrl, uf, spec, k)
+
+
+@pytest.mark.parametrize("layout", ["soa", "aos"])
+@pytest.mark.parametrize("n,m,nu", [(9, 3, 2), (12, 2, 3), (16, 4, 1)])
+def test_every_batch_filter_argument_at_once_vs_live_reference(n, m, nu, layout):
+    """the golden frozen from the LIVE reference with Fs / Qs / Hs / Rs / Bs lists, us, update_first and missing
+    measurements in one call (tests/golden/make_kf_combo_golden.py), through the VAR instantiations of kf_ml / kf_mlg,
+    and its rts_smoother with constant models through the several-lanes smoothers"""
+    from gpu_util import run_kf_batch, tile_tracks
+    from filterpy_amd._abi import FK_MODEL_PER_STEP
+    g = golden("kf_combo")
+    p = f"n{n}m{m}_"
+    N = 130
+    zs = g[p + "zs"]
+    mask = ~np.isnan(zs).all(axis=1)
+    T = len(zs)
+    for uf, q in ((False, p + "pu_"), (True, p + "uf_")):
+        got = run_kf_batch(tile_tracks(g[p + "x0"], N), tile_tracks(g[p + "P0"], N), tile_tracks(zs, N, 1),
+                           g[p + "Fs"], g[p + "Qs"], g[p + "Hs"], g[p + "Rs"], layout=layout, mode=FK_MODEL_PER_STEP,
+                           B=g[p + "Bs"], us=tile_tracks(g[p + "us"], N, 1), update_first=uf, mask=tile_tracks(mask, N, 1))
+        for k, key in enumerate(("mu", "cov", "mup", "covp")):
+            for trk in (0, 63, 64, N - 1):
+                assert rel_err_rows(got[k][:, trk].reshape(T, -1), g[q + key].reshape(T, -1)) < TOL, (uf, key, trk)
+        assert rel_err_rows(got[4][:1], g[q + "xfinal"][None]) < TOL and rel_err_rows(got[5][:1].reshape(1, -1), g[q + "Pfinal"].reshape(1, -1)) < TOL

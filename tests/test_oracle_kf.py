@@ -122,3 +122,21 @@ def test_scalar_attributes_vs_live_reference(n, m):
     x2, P2, y2, K2, S2 = kf_oracle.proc_update(xp, Pp, zs[0], r, H)
     for got, key in ((x2, "mod_x"), (P2, "mod_P"), (K2, "mod_K"), (S2, "mod_S")):
         assert np.allclose(got, g[p + key], rtol=1e-12, atol=1e-13), key
+
+
+@pytest.mark.parametrize("n,m,nu", [(9, 3, 2), (12, 2, 3), (16, 4, 1)])
+def test_every_batch_filter_argument_at_once_vs_live_reference(n, m, nu):
+    """Fs / Qs / Hs / Rs / Bs lists + us + update_first + missing measurements in ONE call, and rts_smoother with
+    Fs / Qs lists, at the sizes of the several-lanes-per-track kernels (tests/golden/make_kf_combo_golden.py): the oracle
+    the GPU tests of the VAR instantiations compare against is the reference here too."""
+    g = golden("kf_combo")
+    p = f"n{n}m{m}_"
+    zs = [None if np.isnan(z).all() else z for z in g[p + "zs"]]
+    for uf, q in ((False, p + "pu_"), (True, p + "uf_")):
+        out = kf_oracle.kf_batch_filter(g[p + "x0"], g[p + "P0"], zs, g[p + "Fs"], g[p + "Qs"], g[p + "Hs"], g[p + "Rs"],
+                                        B=g[p + "Bs"], us=list(g[p + "us"]), update_first=uf)
+        for got, key in zip(out, ("mu", "cov", "mup", "covp")):
+            assert rel_err_rows(got.reshape(len(zs), -1), g[q + key].reshape(len(zs), -1)) < 1e-12, (uf, key)
+    sm = kf_oracle.rts_smoother(g[p + "pu_mu"], g[p + "pu_cov"], g[p + "Fs"], g[p + "Qs"], "class")
+    for got, key in zip(sm, ("x", "P", "K", "Pp")):
+        assert rel_err_rows(got.reshape(len(zs), -1), g[p + "rts_" + key].reshape(len(zs), -1)) < 1e-11, key
