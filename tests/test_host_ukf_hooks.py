@@ -119,3 +119,35 @@ def test_caller_supplied_ut_function(monkeypatch):
     assert len(calls) == n0 + 1 and kf2._ut_fn is None
     kf2.predict()
     assert len(calls) == n0 + 1
+
+
+@pytest.mark.parametrize("layout", ["soa", "aos"])
+def test_step_api_in_device_mode_equals_batch(monkeypatch, layout):
+    """device_callables=True: predict() / update() one call at a time (state up and down per call) give what batch_filter
+    gives with everything resident; update(None) skips; a per-call R and hx override reach the kernels"""
+    fake_ut_engine.install(monkeypatch)
+    g = golden("ukf_hooks")
+    T, N = g["zs"].shape[:2]
+    kf = hm.make_filter(g, "torch", layout, N)
+    kf.x, kf.P = g["x0"].copy(), g["P0"].copy()
+    for t in range(T):
+        kf.predict()
+        assert kf.x.shape == (N, 3) and kf.sigmas_f.shape == (N, 7, 3)
+        kf.update(g["zs"][t])
+        keep = [i for i in range(N) if i != 1]
+        assert rel_err_rows(kf.x[keep], g["mu"][t, keep]) < 1e-10
+        assert rel_err_rows(kf.P[keep].reshape(len(keep), -1), g["cov"][t, keep].reshape(len(keep), -1)) < 1e-10
+        assert kf.K.shape == (N, 3, 2) and kf.S.shape == (N, 2, 2) and kf.y.shape == (N, 2)
+    x_before = kf.x.copy()
+    kf.update(None)
+    assert np.array_equal(kf.x, x_before) and kf.z.shape == (2, 1)
+    # per-call overrides: a different R changes the gain, a different hx the innovation
+    kf.predict()
+    k0 = None
+    for R in (g["R"], 10.0 * g["R"]):
+        kf2 = hm.make_filter(g, "torch", layout, N)
+        kf2.x, kf2.P = kf.x.copy(), kf.P.copy()
+        kf2.sigmas_f = kf.sigmas_f.copy()
+        kf2.update(g["zs"][0], R=R)
+        k0 = kf2.K if k0 is None else k0
+    assert not np.allclose(k0, kf2.K)
