@@ -24,7 +24,8 @@ def main():
         Xs = torch.randn((T, n, N) if layout == "soa" else (T, N, n), generator=g, device=dev, dtype=torch.float64)
         A = rs.randn(n, n)
         P1 = A @ A.T / n + np.eye(n)
-        Ps = E.to_records(np.tile(P1, (T, 8, 1, 1)), layout, 1).repeat((1, 1, N // 8) if layout == "soa" else (1, N // 8, 1)).contiguous()
+        Ps = E.to_records(np.tile(P1, (T, 8, 1, 1)), layout, 1)
+        Ps = (Ps.repeat(1, 1, N // 8) if layout == "soa" else Ps.reshape(T, 8, n * n).repeat(1, N // 8, 1)).contiguous()
         Nn = Ps.shape[-1] if layout == "soa" else Ps.shape[1]
         Xs = Xs[..., :Nn].contiguous() if layout == "soa" else Xs[:, :Nn].contiguous()
         o = [E.alloc_records((T,), Nn, n, layout)] + [E.alloc_records((T,), Nn, n * n, layout) for _ in range(3)]
