@@ -157,3 +157,13 @@ def test_chunk_plan_windows_tile_the_time_axis(monkeypatch):
     assert plan(100000, 8, 16, 2048, 0) == (1, [(0, 8)])
     assert plan(60000, 100, 16, 2048, 0) == (1, [(0, 100)])
     assert plan(200000, 100, 64, 1024, 0)[0] > 1                               # kf_fast (8,4): 3125 waves of 64 on 1024 slots
+
+
+def test_design_table_is_the_committed_evidence():
+    """DESIGN.md section 5's per-kernel table is generated from profiles/r02/configs_all.jsonl (tools/make_design_table.py):
+    the document cannot drift from the measurement files"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "make_design_table.py"), "--check"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
