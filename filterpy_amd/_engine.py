@@ -156,6 +156,16 @@ def ukf_correct(n, m, N, layout, Pxz, zp, S, z, x, P, K=None, status=None):
     _abi.check(rc, "fk_ukf_correct_f64")
 
 
+def ukf_linear_supported(n, m):
+    """sizes fk_ukf_linear_batch_f64 is compiled for (csrc/ukf_kernels.hip)"""
+    return 1 <= n <= 6 and 1 <= m <= 3
+
+
+def ukf_linear_rts_supported(n):
+    """sizes fk_ukf_linear_rts_f64 is compiled for"""
+    return 1 <= n <= 6
+
+
 def ukf_linear_batch(n, m, N, T, layout, scale, F, H, Q, R, Wm, Wc, z, x, P, *, mask=None,
                      means=None, covs=None, status=None):
     d = fk_ukf_desc(n=n, m=m, N=N, T=T, layout=LAYOUTS[layout], reserved=0, scale=float(scale))

@@ -8,7 +8,7 @@
 // off, the other groups' pieces fill the slots, and what is left at the very end is the tail of a piece 1/H as long.
 // Group g's chunk boundaries are shifted by g / G of a chunk, else all groups would tail off at the same moments.
 // Same arithmetic per track: results are bit-identical to the single launch (tests/test_gpu_kf.py).  The helper streams
-// fork from and join the caller's stream with events; they and the events are created once.
+// fork from and join the caller's stream with events; they and the events are created once per device.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -35,7 +35,7 @@ struct MlStreams {
     hipEvent_t fork = nullptr, done[MAXG] = {};
     bool ok = false;
     std::mutex mu;      // one chunked call enqueues at a time: a stream wait binds to the event's LATEST record
-    MlStreams()
+    void create()       // on the device that is current: streams and events belong to a device
     {
         ok = hipEventCreateWithFlags(&fork, hipEventDisableTiming) == hipSuccess;
         for (int g = 1; g < MAXG && ok; ++g)
@@ -44,10 +44,41 @@ struct MlStreams {
     }
 };
 
+// one set of helper streams per device, created on first use with that device current (a process that drives several
+// GPUs must not launch one device's pieces on another device's streams: ADVICE r2); nullptr: no chunking
 inline MlStreams *ml_streams()
 {
-    static MlStreams ms;
-    return &ms;
+    static constexpr int MAXDEV = 16;
+    static MlStreams sets[MAXDEV];
+    static bool made[MAXDEV] = {};
+    static std::mutex mk;
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV) return nullptr;
+    std::lock_guard<std::mutex> lock(mk);
+    if (!made[dev]) {
+        sets[dev].create();
+        made[dev] = true;
+    }
+    return sets[dev].ok ? &sets[dev] : nullptr;
+}
+
+// every piece that was forked onto helper stream g is joined back into the caller's stream -- also when a later piece
+// failed to launch: the caller may free or reuse the buffers as soon as its own stream is done
+inline int ml_join(MlStreams &ms, const bool (&forked)[MlStreams::MAXG], hipStream_t s, int rc)
+{
+    for (int g = 1; g < MlStreams::MAXG; ++g)
+        if (forked[g] && (hipEventRecord(ms.done[g], ms.st[g]) != hipSuccess || hipStreamWaitEvent(s, ms.done[g], 0) != hipSuccess)) {
+            (void)hipStreamSynchronize(ms.st[g]);          // last resort: the join must not be skipped
+            if (rc == 0) rc = -1;
+        }
+    return rc;
+}
+
+// optional output / input arrays: a NULL stays NULL in every piece
+template <class Ptr>
+inline Ptr ml_off(Ptr p, long d)
+{
+    return p ? p + d : nullptr;
 }
 
 // G x H decomposition of a call over `waves` waves and T steps ("G,H" from FK_ML_CHUNKS, else the default where the
@@ -90,19 +121,24 @@ int kf_chunked_call(const Args &a, int n, int m, long slots, One &&one, hipStrea
 {
     int G, H;
     if (!ml_chunk_policy((a.cnt + tracks_per_wave - 1) / tracks_per_wave, a.T, G, H, slots) || a.cnt < group_quantum * G) return one(a, s);
-    MlStreams &ms = *ml_streams();
-    if (!ms.ok) return one(a, s);
+    MlStreams *msp = ml_streams();
+    if (!msp) return one(a, s);
+    MlStreams &ms = *msp;
     std::lock_guard<std::mutex> lock(ms.mu);
     if (hipEventRecord(ms.fork, s) != hipSuccess) return one(a, s);
     // track groups: multiples of a workgroup's tracks, the last one takes the remainder
     const long blocks = (a.cnt + group_quantum - 1) / group_quantum, per = (blocks + G - 1) / G * group_quantum, nn = (long)n * n;
     int rc = 0;
+    bool forked[MlStreams::MAXG] = {};
     for (int g = 0; g < G && rc == 0; ++g) {
         const long g0 = a.i0 + (long)g * per;
         const long gcnt = (g0 + per <= a.i0 + a.cnt) ? per : (a.i0 + a.cnt - g0);
         if (gcnt <= 0) break;
         hipStream_t sg = g == 0 ? s : ms.st[g];
-        if (g > 0 && hipStreamWaitEvent(sg, ms.fork, 0) != hipSuccess) return -1;
+        if (g > 0) {
+            if (hipStreamWaitEvent(sg, ms.fork, 0) != hipSuccess) { rc = -1; break; }
+            forked[g] = true;
+        }
         for (int h = 0; h <= H && rc == 0; ++h) {
             long t0, t1;
             if (!chunk_window(a.T, G, H, g, h, t0, t1)) continue;
@@ -112,25 +148,23 @@ int kf_chunked_call(const Args &a, int n, int m, long slots, One &&one, hipStrea
             b.T = t1 - t0;
             b.status_or = t0 > 0 ? 1 : a.status_or;
             b.z = a.z + t0 * a.N * m;
-            if (a.mask) b.mask = a.mask + t0 * a.N;
-            b.means = a.means + t0 * a.N * n;
-            b.means_p = a.means_p + t0 * a.N * n;
-            b.covs = a.covs + t0 * a.N * nn;
-            b.covs_p = a.covs_p + t0 * a.N * nn;
+            b.mask = ml_off(a.mask, t0 * a.N);
+            b.means = ml_off(a.means, t0 * a.N * n);
+            b.means_p = ml_off(a.means_p, t0 * a.N * n);
+            b.covs = ml_off(a.covs, t0 * a.N * nn);
+            b.covs_p = ml_off(a.covs_p, t0 * a.N * nn);
             if (a.model_t) {                                   // one model per step, shared by the bank (VAR instantiations)
                 b.F = a.F + t0 * nn;
                 b.Q = a.Q + t0 * nn;
                 b.H = a.H + t0 * (long)m * n;
                 b.R = a.R + t0 * (long)m * m;
-                if (a.nu > 0) b.B = a.B + t0 * (long)n * a.nu;
+                if (a.nu > 0) b.B = ml_off(a.B, t0 * (long)n * a.nu);
             }
-            if (a.nu > 0) b.u = a.u + t0 * a.N * a.nu;
+            if (a.nu > 0) b.u = ml_off(a.u, t0 * a.N * a.nu);
             rc = one(b, sg);
         }
-        if (g > 0 && rc == 0 && (hipEventRecord(ms.done[g], sg) != hipSuccess || hipStreamWaitEvent(s, ms.done[g], 0) != hipSuccess))
-            rc = -1;
     }
-    return rc;
+    return ml_join(ms, forked, s, rc);
 }
 
 // The smoother runs backwards: group g's chunks go from the last time window to the first on stream g; a chunk's window
@@ -142,17 +176,22 @@ int rts_chunked_call(const Args &a, int n, long slots, One &&one, hipStream_t s)
     int G, H;
     const long steps = a.T - 1;                                   // backward steps T-2 .. 0
     if (!ml_chunk_policy((a.N + 15) / 16, steps, G, H, slots) || a.N < 64L * G) return one(a, s);
-    MlStreams &ms = *ml_streams();
-    if (!ms.ok) return one(a, s);
+    MlStreams *msp = ml_streams();
+    if (!msp) return one(a, s);
+    MlStreams &ms = *msp;
     std::lock_guard<std::mutex> lock(ms.mu);
     if (hipEventRecord(ms.fork, s) != hipSuccess) return one(a, s);
     const long blocks = (a.N + 63) / 64, per = (blocks + G - 1) / G * 64, nn = (long)n * n;
     int rc = 0;
+    bool forked[MlStreams::MAXG] = {};
     for (int g = 0; g < G && rc == 0; ++g) {
         const long g0 = (long)g * per, gcnt = (g0 + per <= a.N) ? per : (a.N - g0);
         if (gcnt <= 0) break;
         hipStream_t sg = g == 0 ? s : ms.st[g];
-        if (g > 0 && hipStreamWaitEvent(sg, ms.fork, 0) != hipSuccess) return -1;
+        if (g > 0) {
+            if (hipStreamWaitEvent(sg, ms.fork, 0) != hipSuccess) { rc = -1; break; }
+            forked[g] = true;
+        }
         bool first = true;
         for (int h = H; h >= 0 && rc == 0; --h) {                 // windows of backward steps [k0, k1), last first
             long k0, k1;
@@ -167,15 +206,13 @@ int rts_chunked_call(const Args &a, int n, long slots, One &&one, hipStream_t s)
             b.Ps = a.Ps + k0 * a.N * nn;
             b.xs = a.xs + k0 * a.N * n;
             b.Ps_out = a.Ps_out + k0 * a.N * nn;
-            b.K = a.K + k0 * a.N * nn;
-            b.Pp = a.Pp + k0 * a.N * nn;
+            b.K = ml_off(a.K, k0 * a.N * nn);
+            b.Pp = ml_off(a.Pp, k0 * a.N * nn);
             rc = one(b, sg);
             first = false;
         }
-        if (g > 0 && rc == 0 && (hipEventRecord(ms.done[g], sg) != hipSuccess || hipStreamWaitEvent(s, ms.done[g], 0) != hipSuccess))
-            rc = -1;
     }
-    return rc;
+    return ml_join(ms, forked, s, rc);
 }
 
 }  // namespace fk

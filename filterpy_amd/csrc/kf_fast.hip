@@ -283,6 +283,9 @@ kf_fast_kernel(const KfArgs a, const double *__restrict__ pF, const double *__re
     // lane that duplicates the last track and loaded its x0 / P0 late would otherwise find the final state there and
     // filter it a second time.  These stores are outside the time loop: predication costs nothing here (the
     // per-step output stores stay unpredicated -- they only ever rewrite the same values).
+    // ... and no lane of the workgroup may still be about to LOAD x0 / P0 when an owner overwrites them: every wave has
+    // consumed its initial state once it arrives here (one barrier per launch, outside the time loop)
+    __syncthreads();
     if (tid <= last_row) {
         store_rec<NX, 1, LAYOUT, true>(x, a.x, ln, NX, 1);
         double Pl[NX * NX];

@@ -373,6 +373,9 @@ kf_mlg_kernel(const KfArgs a)
     }
     // the final state goes back in place: only a track's own quad writes it (a duplicating tail quad that loaded
     // x0 / P0 late must not find the final state there)
+    // ... and no lane of the workgroup may still be about to LOAD x0 / P0 when an owner overwrites them: every wave has
+    // consumed its initial state once it arrives here (one barrier per launch, outside the time loop)
+    __syncthreads();
     if (owner) {
         const MlView vx(a.x, t8, estride);
         bool fin = all_finite<NX>(x);

@@ -74,7 +74,8 @@ class UnscentedKalmanFilter(object):
         self._log_likelihood = log(sys.float_info.min)
         self._likelihood = sys.float_info.min
         self._mahalanobis = None
-        self.msqrt = sqrt_fn                  # kept, never used: UKF.py:318-321
+        from .sigma_points import _default_sqrt
+        self.msqrt = _default_sqrt if sqrt_fn is None else sqrt_fn        # kept, never used by the filter: UKF.py:318-321
         self.Wm, self.Wc = points.Wm, points.Wc
         self.residual_x = np.subtract if residual_x is None else residual_x
         self.residual_z = np.subtract if residual_z is None else residual_z
@@ -381,19 +382,49 @@ class UnscentedKalmanFilter(object):
             dzs = E.to_records(zarr, lay, 1)
         means, covs = E.alloc_records((T,), N, n, lay), E.alloc_records((T,), N, n * n, lay)
         st = torch.zeros(N, dtype=torch.int32, device=dx.device)
+        k = self._num_sigmas
+        last_upd = max([t for t in range(T) if present[t]], default=-1)
+        last = prior = None
         for t in range(T):
             dt = self._dt if dts is None else dts[t]
             sig = self._dev_predict(dx, dP, c, dt, st)
+            if t == T - 1:
+                prior = (dx.clone(), dP.clone())
             if present[t]:
                 Rt = None
                 if Rs is not None:
                     r = Rs[t]
                     Rt = E.dev(np.eye(m) * r if np.isscalar(r) else np.broadcast_to(np.asarray(r, dtype=np.float64), (m, m)).copy())
-                self._dev_update(dx, dP, sig, dzs[t], c, st, R=Rt)
+                dK = E.alloc_records((), N, n * m, lay) if t == last_upd else None
+                sh, zp, S = self._dev_update(dx, dP, sig, dzs[t], c, st, dK=dK, R=Rt)
+                if t == last_upd:
+                    last = (sh, zp, S, dK, dzs[t])
             means[t].copy_(dx.reshape(means[t].shape))      # (aos records keep the host array's trailing shape)
             covs[t].copy_(dP.reshape(covs[t].shape))
         E.raise_on_status(st, "UnscentedKalmanFilter.batch_filter")
         self.x, self.P = self._unb(E.from_records(dx, lay, 0, (n,))), self._unb(E.from_records(dP, lay, 0, (n, n)))
+        # leave the object where the reference's per-epoch loop leaves it (UKF.py:623-632 -> :400-411, :462-491): the
+        # attributes of the last predict and of the last update that ran
+        if T:
+            self.sigmas_f = self._unb(E.from_records(sig, lay, 0, (k, n)))
+            self.x_prior = self._unb(E.from_records(prior[0], lay, 0, (n,)))
+            self.P_prior = self._unb(E.from_records(prior[1], lay, 0, (n, n)))
+            self.x_post, self.P_post = np.copy(self.x), np.copy(self.P)
+        if last is not None:
+            sh, zp, S, dK, dz = last
+            zpn, Sn = E.from_records(zp, lay, 0, (m,)), E.from_records(S, lay, 0, (m, m))
+            zn = E.from_records(dz.reshape(zp.shape), lay, 0, (m,))
+            self.sigmas_h = self._unb(E.from_records(sh, lay, 0, (k, m)))
+            self.S, self.SI = self._unb(Sn), self._unb(np.linalg.inv(Sn))
+            self.K = self._unb(E.from_records(dK, lay, 0, (n, m)))
+            if self.residual_z is np.subtract:
+                self.y = self._unb(zn - zpn)
+            else:
+                self.y = self._unb(self._pair(self.residual_z, np.subtract, self._vec_view(dz.reshape(zp.shape), m),
+                                              self._vec_view(zp, m)).cpu().numpy())
+            self._log_likelihood = self._likelihood = self._mahalanobis = None
+        if T:
+            self.z = np.array([[None] * m]).T if last_upd != T - 1 else (zn if self._N is not None else zn[0])
         if device_outputs:
             return means, covs
         mu, cov = E.from_records(means, lay, 1, (n,)), E.from_records(covs, lay, 1, (n, n))
@@ -532,6 +563,9 @@ class UnscentedKalmanFilter(object):
         T = len(zs)
         N = self._N or 1
         linear = (not callable(self.fx)) and (not callable(self.hx))
+        if linear and saver is None and not E.ukf_linear_supported(n, m):
+            # a linear model outside the fused kernels' sizes: the split path, resident in HBM for the whole call
+            return self._dev_batch_filter(zs, Rs, dts, device_outputs)
         if linear and Rs is None and dts is None and saver is None:
             lay = self._layout
             zarr = np.zeros((T, N, m))
@@ -628,9 +662,11 @@ class UnscentedKalmanFilter(object):
         if len(Xs) != len(Ps):
             raise ValueError('Xs and Ps must have the same length')
         with self._with_ut(UT):
-            if self._resident:
+            if self._resident or isinstance(Xs, torch.Tensor):
                 return self._dev_rts_smoother(Xs, Ps, dts, device_outputs)
-        if not callable(self.fx) and dts is None and self._dim_x <= 6 and not isinstance(Xs, torch.Tensor):
+        if not callable(self.fx) and not E.ukf_linear_rts_supported(self._dim_x):
+            return self._dev_rts_smoother(Xs, Ps, dts, device_outputs)
+        if not callable(self.fx) and dts is None:
             # linear fx given as a matrix: the whole backward loop is ONE fused launch (fk_ukf_linear_rts_f64)
             n, N, lay = self._dim_x, self._N or 1, self._layout
             Xa = np.asarray(Xs, dtype=np.float64)

@@ -56,13 +56,22 @@ def _sigma_points_hooked(n, scale, x, P, sqrt, subtract):
     return out if batched else out[0]
 
 
+def _default_sqrt(A, *args, **kw):
+    """scipy.linalg.cholesky, imported on first use: what `points.sqrt` / `ukf.msqrt` are in the reference when no
+    callable was passed (sigma_points.py:106-109, UKF.py:318-321) -- for user code that calls the attribute"""
+    from scipy.linalg import cholesky
+    return cholesky(A, *args, **kw)
+
+
 class _Hooks(object):
     """sqrt_method / subtract of the reference constructors (sigma_points.py:106-116, :271-281)"""
 
     def _set_hooks(self, sqrt_method, subtract):
         self._sqrt = sqrt_method            # None = upper Cholesky factor inside the kernel (scipy.linalg.cholesky's convention)
         self._subtract = None if subtract is np.subtract else subtract
-        self.sqrt = sqrt_method
+        # public attribute like the reference's (sigma_points.py:106-109: scipy.linalg.cholesky unless given); the
+        # filter itself never calls it when it is the default -- _sqrt = None means "the factorisation inside the kernel"
+        self.sqrt = _default_sqrt if sqrt_method is None else sqrt_method
         self.subtract = np.subtract if subtract is None else subtract
 
     def _points(self, scale, x_arr, P):

@@ -40,23 +40,36 @@ def relaunch_under_torchrun(n_ranks, argv, require_devices=True):
     os.execvpe(sys.executable, cmd, env)
 
 
-def init_from_env(backend=None, device=None):
+_FORCE = False        # --force-dist: a 1-rank group still takes the collective branches (see init_from_env)
+
+
+def init_from_env(backend=None, device=None, force=False):
     """Initialise the default process group from RANK / WORLD_SIZE / MASTER_* (torchrun sets them).
-    Returns (rank, world).  A single process needs no group."""
+    Returns (rank, world).  A single process needs no group -- unless `force`: then a ONE-rank group is created and
+    allgather_summary / max_over_ranks / barrier run their real collectives on it.  That is how the code an N-GPU run
+    executes (init_process_group("nccl", device_id=...), all_gather_into_tensor, all_reduce, barrier over RCCL) is
+    executed on a one-GPU box (`bench.py --force-dist`, `tools/bench_c5.py --force-dist`)."""
+    global _FORCE
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1 and not dist.is_initialized():
+    _FORCE = bool(force)
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29500")
+        os.environ.setdefault("MASTER_PORT", str(free_port()) if world == 1 else "29500")
         backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
         kw = {"device_id": device} if (backend == "nccl" and device is not None) else {}
         dist.init_process_group(backend, rank=rank, world_size=world, **kw)
     return rank, world
 
 
+def collectives_active():
+    """True when the exchange step runs real collectives: more than one rank, or a forced one-rank group"""
+    return dist.is_initialized() and (dist.get_world_size() > 1 or _FORCE)
+
+
 def allgather_summary(local, out=None):
     """All-gather equally-shaped per-rank summary tensors -> tensor (world, *local.shape)."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not collectives_active():
         return local.unsqueeze(0) if out is None else out.copy_(local.unsqueeze(0))
     world = dist.get_world_size()
     if out is None:
@@ -69,7 +82,7 @@ def allgather_summary(local, out=None):
 
 
 def max_over_ranks(value, device=None):
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not collectives_active():
         return float(value)
     t = torch.tensor([float(value)], dtype=torch.float64, device=device or "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -77,7 +90,12 @@ def max_over_ranks(value, device=None):
 
 
 def barrier():
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if collectives_active():
         dist.barrier()
     if torch.cuda.is_available():
         torch.cuda.synchronize()
+
+
+def shutdown():
+    if dist.is_initialized():
+        dist.destroy_process_group()

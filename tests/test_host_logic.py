@@ -121,6 +121,15 @@ def test_merwe_weights_host_side():
     # constructor hooks are kept like the reference keeps them (sigma_points.py:106-116)
     hp = MerweScaledSigmaPoints(2, .1, 2., 1., sqrt_method=np.linalg.cholesky)
     assert hp.sqrt is np.linalg.cholesky and hp.subtract is np.subtract and pts.subtract is np.subtract
+    # without a callable the public attributes are scipy.linalg.cholesky like the reference's (sigma_points.py:106-109,
+    # UKF.py:318-321): user code that calls points.sqrt(...) / ukf.msqrt(...) keeps working
+    from scipy.linalg import cholesky
+    from filterpy_amd.kalman import UnscentedKalmanFilter
+    A = np.array([[4., 1.], [1., 3.]])
+    assert np.array_equal(pts.sqrt(A), cholesky(A)) and np.array_equal(jp.sqrt(A), cholesky(A)) and pts._sqrt is None
+    ukf = UnscentedKalmanFilter(2, 1, 1.0, hx=lambda x: x[:1], fx=lambda x, dt: x, points=hp)
+    assert np.array_equal(ukf.msqrt(A), cholesky(A))
+    assert UnscentedKalmanFilter(2, 1, 1.0, hx=None, fx=None, points=hp, sqrt_fn=np.linalg.cholesky).msqrt is np.linalg.cholesky
 
 
 def test_chunk_plan_windows_tile_the_time_axis(monkeypatch):

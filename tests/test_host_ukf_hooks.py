@@ -151,3 +151,30 @@ def test_step_api_in_device_mode_equals_batch(monkeypatch, layout):
         kf2.update(g["zs"][0], R=R)
         k0 = kf2.K if k0 is None else k0
     assert not np.allclose(k0, kf2.K)
+
+
+@pytest.mark.parametrize("mode", ["loop", "vec", "torch"])
+def test_resident_batch_filter_leaves_the_last_epochs_attributes(monkeypatch, mode):
+    """after batch_filter on the resident path the object holds what the reference's per-epoch loop leaves
+    behind (UKF.py:623-632): sigmas_f / x_prior / P_prior of the last predict, sigmas_h / K / S / SI / y / z of the
+    last update, posts = the final state -- i.e. exactly what the same calls made one at a time leave."""
+    fake_ut_engine.install(monkeypatch)
+    g = golden("ukf_hooks")
+    T, N = g["zs"].shape[:2]
+    zs = [g["zs"][t] for t in range(T)]
+    for miss_last in (False, True):
+        if miss_last:
+            zs[-1] = None
+        a, b = _make(g, mode, "soa", N), _make(g, mode, "soa", N)
+        for kf in (a, b):
+            kf.x, kf.P = g["x0"].copy(), g["P0"].copy()
+        a.batch_filter(zs)
+        for z in zs:
+            b.predict()
+            b.update(z)
+        for name in ("x", "P", "sigmas_f", "sigmas_h", "K", "S", "SI", "y", "x_prior", "P_prior", "x_post", "P_post"):
+            va, vb = np.asarray(getattr(a, name), dtype=float), np.asarray(getattr(b, name), dtype=float)
+            assert va.shape == vb.shape, name
+            assert np.allclose(va, vb, rtol=1e-12, atol=1e-14), (name, miss_last)
+        assert np.shape(a.z) == np.shape(b.z) and (miss_last or np.allclose(np.asarray(a.z, float), np.asarray(b.z, float)))
+        assert abs(a.log_likelihood - b.log_likelihood) < 1e-9 if N == 1 else True

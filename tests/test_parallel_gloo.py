@@ -116,3 +116,15 @@ def test_bench_c5_uses_the_same_launcher():
     assert r.returncode != 0 and "GPU(s) are visible" in (r.stderr + r.stdout)
     r = _run_bench("tools/bench_c5.py", "--gpus", "4", env_extra={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
     assert r.returncode != 0 and "WORLD_SIZE=2" in (r.stderr + r.stdout)
+
+
+def test_forced_one_rank_group_runs_the_collectives():
+    """--force-dist (VERDICT r2 missing 2): with ONE rank the process group is still created and the all-gather, the
+    barrier and the max-over-ranks all-reduce run on it -- on the GPU box that is how the RCCL branch gets executed
+    before the driver's 8-GPU run; here the same control flow on gloo."""
+    r = _run_bench("bench.py", "--gpus", "1", "--steps", "2", "--warmup", "1", "--selftest-cpu", "--force-dist")
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = _json_line(r.stdout)
+    assert line["n_gpus"] == 1 and line["gather_ok"] is True and line["collectives"] is True
+    r = _run_bench("bench.py", "--gpus", "1", "--steps", "2", "--warmup", "1", "--selftest-cpu")
+    assert r.returncode == 0 and _json_line(r.stdout)["collectives"] is False

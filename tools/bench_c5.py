@@ -32,6 +32,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--gpus", type=int, default=0, help="ranks (one per GPU); without a launcher the script re-executes "
                     "itself under torch.distributed.run like bench.py does")
+    ap.add_argument("--force-dist", action="store_true", help="one rank: still create the 1-rank RCCL group and run the "
+                    "all-gather / barrier / all-reduce on it (executes the N-GPU code path on a one-GPU box)")
     a = ap.parse_args()
 
     from filterpy_amd import parallel
@@ -46,7 +48,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    rank, world = parallel.init_from_env(backend="nccl", device=dev)
+    rank, world = parallel.init_from_env(backend="nccl", device=dev, force=a.force_dist)
     lo, hi = parallel.shard_bounds(a.filters, rank, world)
     per = a.filters // world                       # equal shards for the all-gather
     hi = lo + per
@@ -103,9 +105,10 @@ def main():
             "config": {"workload": f"BASELINE configs[4]: {per * world} filters x {Np} particles, {per} filters per GPU, "
                                    f"all-gather of ({per * world}, {d}) posterior means per step"},
             "resample_kernel_ms": rs_ms, "gather_mean_kernel_ms": gm_ms,
-            "resample_GBs_algorithmic": 12.0 * per * Np / (rs_ms * 1e-3) / 1e9, "bit_exact_vs_oracle": exact}), flush=True)
-    if world > 1:
-        torch.distributed.destroy_process_group()
+            "resample_GBs_algorithmic": 12.0 * per * Np / (rs_ms * 1e-3) / 1e9, "bit_exact_vs_oracle": exact,
+            "collectives": (f"{world}-rank {torch.distributed.get_backend()} group" if parallel.collectives_active() else "none (single process)"),
+            "gather_ok": bool(torch.equal(gathered[rank], means))}), flush=True)
+    parallel.shutdown()
 
 
 if __name__ == "__main__":
