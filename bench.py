@@ -123,7 +123,14 @@ def cpu_baseline(zs_host, budget_s=12.0, max_procs=None):
     import multiprocessing as mp
     avail, quota = cpu_quota()
     top = max(1, min(avail, max_procs) if max_procs else avail)
-    counts = sorted({c for c in (16, 32, 64, 128, 256, top) if c <= top}) or [top]
+    qn = None                                           # cpus the cgroup quota allows ("max 100000" = no quota)
+    try:
+        a_, b_ = (quota or "").split()[:2]
+        qn = max(1, int(a_) // int(b_)) if a_ != "max" else None
+    except (ValueError, ZeroDivisionError):
+        pass
+    cand = {8, 16, 32, 64, 128, 256, top} | ({qn, 2 * qn} if qn else set())
+    counts = sorted({c for c in cand if c <= top}) or [top]
     counts = [c for c in counts if c * CPU_TRACKS_PER_PROC <= zs_host.shape[1]] or [max(1, zs_host.shape[1] // CPU_TRACKS_PER_PROC)]
     per = max(1.0, budget_s / len(counts))
     T = zs_host.shape[0]
@@ -226,6 +233,15 @@ def gpu_clocks():
             with open("/sys/kernel/mm/transparent_hugepage/enabled") as fh:
                 keep["thp"] = fh.read().strip()
         except OSError:
+            pass
+        try:                                   # WHICH physical GPU this is: the boxes of the pool are not equally fast
+            import re
+            st = subprocess.run(["amd-smi", "static", "-g", "0"], capture_output=True, text=True, timeout=30).stdout
+            for key in ("ASIC_SERIAL", "OAM_ID", "VERSION"):
+                mm = re.search(r"^\s*" + key + r":\s*(\S+)", st, re.M)
+                if mm:
+                    keep[key.lower()] = mm.group(1)
+        except Exception:
             pass
         return keep or None
     except Exception as e:                     # the measurement does not depend on it

@@ -252,6 +252,31 @@ static int fail(int code, const char *msg)
 
 }  // namespace fk
 
+// dim_x 10 .. 16 of fk_ukf_rts_correct_f64: the same kernel on the padded classes 12 and 16, compiled in a unit of its own
+// (ukf_rts_big.hip) with rolled loops (FK_ROLLED: the n x n arrays live in scratch) -- slow, but the general-fx UKF smoother
+// needs them (UnscentedKalmanFilter.rts_smoother at dim_x > 9 was an FK_ERR_UNSUPPORTED until round 3)
+namespace fk {
+int ukf_rts_big_launch(int n, long N, int layout, const double *Pxb, const double *xb, const double *Pb, const double *xn,
+                       const double *Pn, double *x, double *P, double *K, int32_t *status, hipStream_t s);
+}
+#ifdef FK_VARIANTS_BIG
+namespace fk {
+int ukf_rts_big_launch(int n, long N, int layout, const double *Pxb, const double *xb, const double *Pb, const double *xn,
+                       const double *Pn, double *x, double *P, double *K, int32_t *status, hipStream_t s)
+{
+    const dim3 grid((unsigned)((N + BLOCK - 1) / BLOCK)), block(BLOCK);
+#define CALL(NXV)                                                                                                 \
+    if (layout == FK_LAYOUT_SOA)                                                                                  \
+        hipLaunchKernelGGL((ukf_rts_kernel<NXV, LAYOUT_SOA>), grid, block, 0, s, n, N, Pxb, xb, Pb, xn, Pn, x, P, K, status); \
+    else                                                                                                          \
+        hipLaunchKernelGGL((ukf_rts_kernel<NXV, LAYOUT_AOS>), grid, block, 0, s, n, N, Pxb, xb, Pb, xn, Pn, x, P, K, status)
+    if (n <= 12) { CALL(12); }
+    else { CALL(16); }
+#undef CALL
+    return check_launch("ukf_rts_kernel");
+}
+}  // namespace fk
+#else
 using namespace fk;
 
 #define FK_BY_DIMS(n, m, CALL)                              \
@@ -330,13 +355,14 @@ int fk_ukf_rts_correct_f64(int32_t n, int64_t N, int32_t layout, const double *P
                            const double *Pb, const double *xn, const double *Pn, double *x, double *P, double *K,
                            int32_t *status, void *stream)
 {
-    if (n < 1 || n > 9) return fail(FK_ERR_UNSUPPORTED, "ukf rts: dim_x 1..9");
+    if (n < 1 || n > 16) return fail(FK_ERR_UNSUPPORTED, "ukf rts: dim_x 1..16");
     if (layout != FK_LAYOUT_AOS && layout != FK_LAYOUT_SOA) return fail(FK_ERR_BAD_ARG, "ukf rts: bad layout");
     if (N < 0 || !Pxb || !Pb || !xn || !Pn || !x || !P) return fail(FK_ERR_BAD_ARG, "ukf rts: bad argument");
     if ((double)N * n * n * 8.0 >= 4294967296.0) return fail(FK_ERR_UNSUPPORTED, "ukf rts: record block >= 4 GiB");
     if (N == 0) return FK_OK;
     const dim3 grid((unsigned)((N + BLOCK - 1) / BLOCK)), block(BLOCK);
     hipStream_t s = (hipStream_t)stream;
+    if (n > 9) return ukf_rts_big_launch(n, (long)N, layout, Pxb, xb, Pb, xn, Pn, x, P, K, status, s);
 #define CALL(NXV, NZV)                                                                                       \
     if (layout == FK_LAYOUT_SOA)                                                                             \
         hipLaunchKernelGGL((ukf_rts_kernel<NXV, LAYOUT_SOA>), grid, block, 0, s, n, (long)N, Pxb, xb, Pb, xn, \
@@ -350,3 +376,4 @@ int fk_ukf_rts_correct_f64(int32_t n, int64_t N, int32_t layout, const double *P
 }
 
 }  // extern "C"
+#endif   // FK_VARIANTS_BIG

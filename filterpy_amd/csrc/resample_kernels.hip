@@ -467,10 +467,19 @@ static int resample_common(bool stratified, int64_t Fn, int64_t Np, const double
     if (Fn == 0 || Np == 0) return FK_OK;
     if (!w || !u || !idx) return fail(FK_ERR_BAD_ARG, "resample: w, u, idx must not be NULL");
     hipStream_t s = (hipStream_t)stream;
-    // Long vectors (Np >= RS_PAR_MIN) take the one-pass path (resample_onepass.hip); short ones are a handful of
-    // dependent tiles whatever is done and stay with one workgroup per filter (resample_kernel above).
-    // FK_RESAMPLE_PATH=onepass sends every length through the one-pass kernel, FK_RESAMPLE_SERIAL=1 none (tests).
+    // Three kernels by vector length: up to 8192 weights one workgroup takes the WHOLE vector in one round
+    // (resample_whole.hip); from RS_PAR_MIN on the one-pass path (resample_onepass.hip: many workgroups per filter);
+    // in between one workgroup per filter walks 2048-weight chunks in sequence (resample_local_kernel).
+    // FK_RESAMPLE_PATH=whole|local|onepass forces a kernel where it applies, FK_RESAMPLE_SERIAL=1 the round-1
+    // tile-by-tile kernel (the tests' independent cross-check).
     const char *path = getenv("FK_RESAMPLE_PATH");
+    const bool serial = getenv("FK_RESAMPLE_SERIAL") != nullptr;
+    const bool forced_other = path && (!strcmp(path, "onepass") || !strcmp(path, "local"));
+    if (!serial && !forced_other && whole_supported(Np)) {
+        const int rc = whole_launch(stratified, Fn, Np, w, u, idx, status, s);
+        if (rc == FK_ERR_UNSUPPORTED) return fail(rc, "resample: too many filters for one launch");
+        return rc;
+    }
     const bool want_onepass = (path && !strcmp(path, "onepass")) || (Np >= RS_PAR_MIN && !(path && !strcmp(path, "local")));
     if (want_onepass && ws && ws_bytes >= onepass_workspace_bytes(Fn, Np) && !getenv("FK_RESAMPLE_SERIAL")) {
         const int rc = onepass_launch(stratified, Fn, Np, w, u, idx, status, ws, ws_bytes, s);

@@ -20,6 +20,12 @@ int onepass_launch(bool stratified, int64_t Fn, int64_t Np, const double *w, con
 int local_launch(bool stratified, int64_t Fn, int64_t Np, const double *w, const double *u, int32_t *idx,
                  int32_t *status, hipStream_t s);
 
+// Np <= 8192 (resample_whole.hip): one workgroup takes the filter's whole vector in one round, no workspace; writes
+// status[f] itself and hands vectors it cannot take to the reference's literal loop
+bool whole_supported(int64_t Np);
+int whole_launch(bool stratified, int64_t Fn, int64_t Np, const double *w, const double *u, int32_t *idx,
+                 int32_t *status, hipStream_t s);
+
 // after resample_kernel (short vectors): filters holding a negative / NaN / huge weight are redone by the reference's
 // merge loop, literally (one thread each)
 int literal_fixup_launch(bool stratified, int64_t Fn, int64_t Np, const double *w, const double *u, int32_t *idx,

@@ -1,0 +1,302 @@
+// resample_whole.hip -- systematic / stratified resampling of SHORT weight vectors (gfx950): one workgroup takes a
+// filter's WHOLE vector (Np <= 8 weights x 1024 threads) and does it in one round.
+//
+//   fk_resample_systematic_f64  <- systematic_resample (filterpy/monte_carlo/resampling.py:117-150)
+//   fk_resample_stratified_f64  <- stratified_resample (:80-114)
+//
+// Round 2's short-vector kernel (resample_local_kernel) walked a vector's 2048-weight chunks in sequence -- four
+// dependent chunk rounds for BASELINE configs[4]'s 8000 particles, each with its own exact scan, ~75k dependent clocks
+// per filter, 39 us for 125 filters.  Here the exact scan sees the whole vector at once (fk_resample_whole.hpp: bounds
+// from plain prefix sums -> clean / dirty elements -> segments -> a chain of two adds per segment -> cs_j), the weights
+// never leave the registers (8 B read per particle, once), every weight computes its slot boundary n(cs_j) straight
+// from its cumulative sum (fk_resample_math.hpp: no division, no search), and ONE window of Np slots in LDS turns the
+// boundaries into indices: run heads -> inclusive max-scan -> 16-byte coalesced stores (4 B written per particle).
+// Seven workgroup barriers per filter in all.  A vector the round cannot take -- a negative / NaN / huge weight, more
+// than WH_DMAX dirty elements (half-ulp ties by the hundred, running sums below 2^-900), a failed binade check -- is
+// handed to the reference's merge loop, run literally by one thread: slow, but still the reference's answer.
+//
+// This unit is compiled with -ffp-contract=off: positions and sums must be single IEEE operations.
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../include/filterhip.h"
+#include "fk_device.hpp"
+#include "fk_exact_scan.hpp"
+#include "fk_resample_math.hpp"
+#include "fk_resample_whole.hpp"
+#include "resample_dev.hpp"
+#include "resample_onepass.hpp"
+
+namespace fk {
+
+struct WholeArgs {
+    int Np;
+    const double *w, *u;
+    int32_t *idx, *status;
+};
+
+template <int NT>
+struct WholeShared {
+    static constexpr int NW = NT / 64, CAP = NT * WH_ITEMS;
+    int win[CAP];                          // slot window: the index of the weight whose run starts there, else -1
+    int nlast[NT];                         // slot boundary after each thread's last element
+    double wtot[NW];                       // per-wave partials: plain sums,
+    u64 ptot[NW];                          //   increment sums,
+    int dtot[NW];                          //   dirty counts,
+    int wmax[NW];                          //   running maxima of the window
+    int d_pos[WH_DMAX];                    // dirty element r: its position, weight, increment prefix up to it
+    double d_w[WH_DMAX];
+    u64 d_ps[WH_DMAX];
+    double d_cs[WH_DMAX];                  //   and (from the chain) the running sum after its real add
+    int seg_e[WH_DMAX + 1];                // segment r: claimed ulp exponent, increment prefix and running sum at its start
+    u64 seg_ps0[WH_DMAX + 1];
+    double seg_c[WH_DMAX + 1];
+    double carry_out;
+    int fail;
+    int lit_status;
+};
+
+// EU = waves per SIMD the register allocation must allow: a 1024-thread workgroup is four waves per SIMD, so EU = 8 (at
+// most 64 VGPRs) lets a CU hold two filters at once, EU = 4 one
+template <bool STRATIFIED, int NT, int EU>
+__global__ void __launch_bounds__(NT, EU)
+resample_whole_kernel(const WholeArgs a)
+{
+    using Sh = WholeShared<NT>;
+    constexpr int NW = Sh::NW, CAP = Sh::CAP;
+    __shared__ Sh sh;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int Np = a.Np;
+    const int f = blockIdx.x;
+    const double *wf = a.w + (long)f * Np;
+    int32_t *of = a.idx + (long)f * Np;
+    const double u_sys = STRATIFIED ? 0.0 : a.u[f];
+    const double *u_str = STRATIFIED ? a.u + (long)f * Np : nullptr;
+    const double Nd = (double)Np, halfNd = 0.5 * Nd;
+    const int j0 = tid * WH_ITEMS;
+
+    // ---- weights: eight consecutive ones per thread, straight from HBM into registers (padding: +0.0) ----
+    double w[WH_ITEMS];
+    if ((((uintptr_t)wf) & 15) == 0 && j0 + WH_ITEMS <= Np) {
+        const double *src = wf + j0;
+        FK_UNROLL for (int q = 0; q < WH_ITEMS; q += 2) {
+            const f64x2 t = *reinterpret_cast<const f64x2 *>(src + q);
+            w[q] = t.x;
+            w[q + 1] = t.y;
+        }
+    } else {
+        FK_UNROLL for (int q = 0; q < WH_ITEMS; ++q) {
+            const int j = j0 + q;
+            const double t = wf[j < Np ? j : 0];                           // Np >= 1: always a valid address
+            w[q] = j < Np ? t : 0.0;
+        }
+    }
+    // the slot window and the segment claims are reset while the loads are in flight
+    FK_UNROLL for (int g = 0; g < WH_ITEMS / 4; ++g) *reinterpret_cast<i32x4 *>(&sh.win[j0 + 4 * g]) = i32x4{-1, -1, -1, -1};
+    for (int r = tid; r <= WH_DMAX; r += NT) sh.seg_e[r] = WH_NONE;
+    if (tid == 0) sh.fail = 0;
+
+    double run = 0.0, mn = 0.0;
+    FK_UNROLL for (int q = 0; q < WH_ITEMS; ++q) {
+        run += w[q];
+        mn = w[q] < mn ? w[q] : mn;                                        // a negative weight (NaN / Inf show in the sum)
+    }
+    const double winc = wave_incl_sum(run);
+    if (lane == 63) sh.wtot[wave] = winc;
+    const int any_neg = __syncthreads_or(mn < 0.0 ? 1 : 0);                                   // (1)
+    double before = __shfl_up(winc, 1, 64);
+    if (lane == 0) before = 0.0;
+    double S = 0.0;
+    FK_UNROLL for (int wv = 0; wv < NW; ++wv) {
+        const double t = sh.wtot[wv];
+        if (wv < wave) before += t;
+        S += t;
+    }
+    bool literal = any_neg || !(S < 0x1p1000);                             // negative, NaN, Inf or absurdly large: uniform
+
+    int D = 0;
+    WhThread th;
+    int dbase = 0;
+    u64 pbase = 0, ptotal = 0;
+    if (!literal) {
+        // ---- clean / dirty, increments; their prefix sums over the workgroup --------------------------------
+        wh_classify(w, before, j0, Np, th);
+        const int dincl = wave_incl_sum_i32(th.ndirty);
+        const u64 pincl = wave_incl_sum_u64(th.psum);
+        if (lane == 63) {
+            sh.dtot[wave] = dincl;
+            sh.ptot[wave] = pincl;
+        }
+        __syncthreads();                                                                      // (2)
+        dbase = dincl - th.ndirty;
+        pbase = pincl - th.psum;
+        FK_UNROLL for (int wv = 0; wv < NW; ++wv) {
+            const int dt = sh.dtot[wv];
+            const u64 pt = sh.ptot[wv];
+            if (wv < wave) {
+                dbase += dt;
+                pbase += pt;
+            }
+            D += dt;
+            ptotal += pt;
+        }
+        literal = D > WH_DMAX;                                             // uniform
+    }
+    if (!literal) {
+        wh_lists(w, th, j0, dbase, pbase, sh.seg_e, sh.d_pos, sh.d_w, sh.d_ps);
+        __syncthreads();                                                                      // (3)
+        if (wh_claims_bad(th, dbase, sh.seg_e)) sh.fail = 1;
+        // ---- the chain over the segments (wave 0; lane l holds segment b0 + l and dirty element b0 + l): what does
+        // not depend on the running sum is prepared by the lanes in parallel, the serial part is two dependent fp64
+        // adds per segment (fk_resample_whole.hpp, wh_chain_segment) --------------------------------------------------
+        if (wave == 0) {
+            double c = 0.0;
+            int fail = 0;
+            for (int b0 = 0; b0 <= D; b0 += 64) {                          // uniform
+                const int me = b0 + lane;
+                WhSeg sg;
+                sg.add = 0.0;
+                sg.xf = -1;
+                sg.bad = false;
+                sg.ps0 = 0;
+                if (me <= D) sg = wh_segment(me, D, ptotal, sh.seg_e, sh.d_ps);
+                const double my_w = me < D ? sh.d_w[me < WH_DMAX ? me : 0] : 0.0;
+                fail |= sg.bad ? 1 : 0;
+                double r_c = 0.0, r_dcs = 0.0;
+                const int cnt = D + 1 - b0 < 64 ? D + 1 - b0 : 64;
+                for (int r = 0; r < cnt; ++r) {                            // uniform
+                    const double add = lane_bcast(sg.add, r);
+                    const double wr = lane_bcast(my_w, r);
+                    const int xf = __builtin_amdgcn_readlane(sg.xf, r);
+                    if (lane == r) r_c = c;
+                    bool fl = false;
+                    c = wh_chain_segment(c, add, xf, fl);
+                    fail |= fl ? 1 : 0;
+                    if (b0 + r < D) {
+                        c = c + wr;                                        // the real IEEE add of the dirty element
+                        if (lane == r) r_dcs = c;
+                    }
+                }
+                if (me <= D) {
+                    sh.seg_c[me] = r_c;
+                    sh.seg_ps0[me] = sg.ps0;
+                    if (me < D) sh.d_cs[me] = r_dcs;
+                }
+            }
+            if (__builtin_amdgcn_ballot_w64(fail != 0) != 0 && lane == 0) sh.fail = 1;
+            if (lane == 0) sh.carry_out = c;
+        }
+        __syncthreads();                                                                      // (4)
+        literal = sh.fail != 0;                                            // uniform
+    }
+    if (literal) {
+        // the reference's loop, literally (resampling.py:106-112 / :142-149), one thread
+        if (tid == 0) {
+            const int st = literal_merge<STRATIFIED>(wf, STRATIFIED ? u_str : a.u + f, (long)Np, of);
+            if (a.status) a.status[f] = st;
+        }
+        return;
+    }
+
+    // ---- cumulative sums -> slot boundaries: weight j owns the slots [n_{j-1}, n_j), n_j = n(cs_j) ------------------
+    int nb[WH_ITEMS];
+    {
+        double cs[WH_ITEMS];
+        wh_cumsums(w, th, j0, Np, dbase, pbase, sh.seg_e, sh.seg_c, sh.seg_ps0, sh.d_cs, sh.carry_out, cs);
+        FK_UNROLL for (int q = 0; q < WH_ITEMS; ++q) {
+            nb[q] = n_boundary_fast<STRATIFIED>(cs[q], Np, Nd, halfNd, u_sys, u_str);
+            FK_STAGE();
+        }
+    }
+    sh.nlast[tid] = nb[WH_ITEMS - 1];
+    __syncthreads();                                                                          // (5)
+    int nprev = tid == 0 ? 0 : sh.nlast[tid - 1];
+    const int u_hi = __builtin_amdgcn_readfirstlane(sh.nlast[NT - 1]);     // = n(carry-out): slots [0, u_hi) get an index
+    // window position p = slot + sft: with sft = (address of slot 0 in ints) mod 4 a thread's two quads are 16-byte
+    // aligned stores.  A vector that would not fit the window shifted (Np > CAP - 3 at an odd address) goes unshifted
+    // and leaves as 4-byte stores.
+    const int mis = (int)(((uintptr_t)of >> 2) & 3);
+    const int sft = Np + mis <= CAP ? mis : 0;
+    const bool vec_ok = sft == mis;
+    FK_UNROLL for (int q = 0; q < WH_ITEMS; ++q) {
+        if (nb[q] > nprev) {
+            sh.win[nprev + sft] = j0 + q;                                  // (nprev < nb[q] <= Np: inside the window)
+            nprev = nb[q];
+        }
+    }
+    __syncthreads();                                                                          // (6)
+    int x[WH_ITEMS];
+    FK_UNROLL for (int g = 0; g < WH_ITEMS / 4; ++g) {
+        const i32x4 t = *reinterpret_cast<const i32x4 *>(&sh.win[j0 + 4 * g]);
+        x[4 * g + 0] = t.x;
+        x[4 * g + 1] = t.y;
+        x[4 * g + 2] = t.z;
+        x[4 * g + 3] = t.w;
+    }
+    FK_UNROLL for (int e = 1; e < WH_ITEMS; ++e) x[e] = x[e] > x[e - 1] ? x[e] : x[e - 1];
+    const int wincl = wave_incl_max(x[WH_ITEMS - 1]);
+    if (lane == 63) sh.wmax[wave] = wincl;
+    __syncthreads();                                                                          // (7)
+    int pre = __shfl_up(wincl, 1, 64);
+    if (lane == 0) pre = -1;
+    FK_UNROLL for (int wv = 0; wv < NW; ++wv) {
+        const int t = sh.wmax[wv];
+        if (wv < wave) pre = pre > t ? pre : t;
+    }
+    const int last = Np - 1;
+    FK_UNROLL for (int g = 0; g < WH_ITEMS / 4; ++g) {
+        int v[4];
+        FK_UNROLL for (int e = 0; e < 4; ++e) {
+            const int s = j0 + 4 * g + e - sft;                            // the slot of this window position
+            const int m = x[4 * g + e] > pre ? x[4 * g + e] : pre;
+            v[e] = s < u_hi ? m : last;                                    // positions >= cumsum[-1]: resampling.py:109,145
+        }
+        const int s0 = j0 + 4 * g - sft;
+        if (vec_ok && s0 >= 0 && s0 + 3 < Np) *reinterpret_cast<i32x4 *>(&of[s0]) = i32x4{v[0], v[1], v[2], v[3]};
+        else {
+            FK_UNROLL for (int e = 0; e < 4; ++e)
+                if (s0 + e >= 0 && s0 + e < Np) of[s0 + e] = v[e];
+        }
+    }
+    if (tid == 0 && a.status) a.status[f] = u_hi < Np ? ST_OVERRUN : 0;
+}
+
+// Np <= 8192: one workgroup of 256 / 512 / 1024 threads per filter (8 weights per thread)
+bool whole_supported(int64_t Np) { return Np >= 1 && Np <= 1024 * WH_ITEMS; }
+
+int whole_launch(bool stratified, int64_t Fn, int64_t Np, const double *w, const double *u, int32_t *idx,
+                 int32_t *status, hipStream_t s)
+{
+    if (Fn > 0x7fffffffL || !whole_supported(Np)) return FK_ERR_UNSUPPORTED;
+    WholeArgs a;
+    a.Np = (int)Np;
+    a.w = w;
+    a.u = u;
+    a.idx = idx;
+    a.status = status;
+    const dim3 grid((unsigned)Fn);
+#define GO(NTV, EUV)                                                                                             \
+    do {                                                                                                         \
+        if (stratified) hipLaunchKernelGGL((resample_whole_kernel<true, NTV, EUV>), grid, dim3(NTV), 0, s, a);   \
+        else hipLaunchKernelGGL((resample_whole_kernel<false, NTV, EUV>), grid, dim3(NTV), 0, s, a);             \
+    } while (0)
+    // FK_WHOLE_EU=4|8 picks the 1024-thread instantiation (A/B timing); default: two filters per CU once there are more
+    // filters than CUs
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+                   ? prop.multiProcessorCount : 256;
+    }
+    const char *ev = getenv("FK_WHOLE_EU");
+    const bool two = ev ? atoi(ev) == 8 : Fn > n_cu;
+    if (Np <= 256 * WH_ITEMS) GO(256, 4);
+    else if (Np <= 512 * WH_ITEMS) GO(512, 4);
+    else if (two) GO(1024, 8);
+    else GO(1024, 4);
+#undef GO
+    return check_launch("resample_whole_kernel");
+}
+
+}  // namespace fk

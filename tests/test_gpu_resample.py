@@ -214,6 +214,12 @@ def _family(kind, Fn, Np, rs):
         w[:, Np // 3] = 1e4
     elif kind == "ties":
         w = np.floor(w * 2 ** 20) * 2.0 ** -40
+    elif kind == "dyadic":                 # an exact half-ulp tie at every add once the running sum is in [0.5, 1)
+        w = np.full((Fn, Np), 3 * 2.0 ** -54)
+        w[:, 0] = 0.75
+        return np.ascontiguousarray(w)
+    elif kind == "tiny":                   # running sums below 2^-900
+        return np.ascontiguousarray(w * 1e-300)
     w = w / w.sum(axis=1, keepdims=True)
     if kind == "sum_half":
         w = w * 0.5
@@ -273,11 +279,35 @@ def test_short_vectors_with_garbage_weights_follow_the_reference_loop(monkeypatc
 
 @pytest.mark.parametrize("Np", [1, 2, 7, 100, 2047, 2048, 2049, 8000, 8192, 20000, 32767])
 def test_local_kernel_every_route(Np, monkeypatch):
-    """default dispatch below the one-pass threshold = resample_local_kernel (one workgroup per filter, chunks in
-    sequence, segmented exact scan at the vector start / binade crossings, literal loop for garbage): every weight
-    family, every filter, against the reference's merge loop (C restatement), systematic and stratified."""
+    """resample_local_kernel (one workgroup per filter, chunks in sequence, segmented exact scan at the vector start /
+    binade crossings, literal loop for garbage) -- the default between 8193 and 32767 weights, forced below: every
+    weight family, every filter, against the reference's merge loop (C restatement), systematic and stratified."""
     kinds = [k for k in _FAMILIES if not (k in ("negative", "nan") and Np < 8)]
+    monkeypatch.setenv("FK_RESAMPLE_PATH", "local")
     _check_against_merge_loop(5, Np, kinds, range(5), monkeypatch, force=False)
+
+
+@pytest.mark.parametrize("eu", ["4", "8"])
+@pytest.mark.parametrize("Np", [1, 2, 3, 7, 100, 2047, 2048, 2049, 4095, 4096, 4097, 8000, 8189, 8190, 8191, 8192])
+def test_whole_vector_kernel_every_route(Np, eu, monkeypatch):
+    """resample_whole_kernel (round 3; the default up to 8192 weights: one workgroup takes the whole vector in one
+    round): every weight family -- plus vectors the round declines (exact half-ulp ties by the hundred, running sums
+    below 2^-900) and must hand to the literal loop --, every filter of a 5-filter call (odd Np: every filter at another
+    16-byte phase, so the shifted window, the unshifted 4-byte-store fallback at Np > 8189 and the scalar weight loads
+    all run), systematic and stratified, both register budgets of the 1024-thread instantiation, against the
+    reference's merge loop (C restatement)."""
+    if eu == "8" and Np <= 4096:
+        pytest.skip("one instantiation below 4097 weights")
+    monkeypatch.setenv("FK_WHOLE_EU", eu)
+    kinds = [k for k in _FAMILIES + ("dyadic", "tiny") if not (k in ("negative", "nan") and Np < 8)]
+    _check_against_merge_loop(5, Np, kinds, range(5), monkeypatch, force=False)
+
+
+def test_whole_vector_kernel_many_filters(monkeypatch):
+    """the C5 shape: 1000 x 8000 and 125 x 8000 in one launch each (more workgroups than CUs; two filters per CU),
+    sampled filters bit-exact"""
+    _check_against_merge_loop(1000, 8000, ("uniform", "heavy_tail"), (0, 1, 255, 256, 511, 767, 768, 999), monkeypatch, force=False)
+    _check_against_merge_loop(125, 8000, ("uniform", "zeros"), (0, 1, 63, 124), monkeypatch, force=False)
 
 
 def test_local_kernel_on_a_long_vector_and_many_filters(monkeypatch):
@@ -285,7 +315,6 @@ def test_local_kernel_on_a_long_vector_and_many_filters(monkeypatch):
     crossing every few); and the C5 shape's filter count in one launch (more workgroups than the chip holds at once)"""
     monkeypatch.setenv("FK_RESAMPLE_PATH", "local")
     _check_against_merge_loop(3, 300007, ("uniform", "heavy_tail", "zeros", "ties", "one_heavy"), range(3), monkeypatch, force=False)
-    monkeypatch.delenv("FK_RESAMPLE_PATH")
     _check_against_merge_loop(1000, 8000, ("uniform", "heavy_tail"), (0, 1, 511, 767, 768, 999), monkeypatch, force=False)
 
 

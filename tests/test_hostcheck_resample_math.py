@@ -16,7 +16,7 @@ HC = os.path.join(ROOT, "tests", "hostcheck")
 @pytest.fixture(scope="module")
 def lib():
     so, src = os.path.join(HC, "libhostcheck_rs.so"), os.path.join(HC, "hostcheck_rs.cpp")
-    deps = [src] + [os.path.join(ROOT, "filterpy_amd", "csrc", h) for h in ("fk_resample_math.hpp", "fk_exact_scan.hpp", "fk_math.hpp")]
+    deps = [src] + [os.path.join(ROOT, "filterpy_amd", "csrc", h) for h in ("fk_resample_math.hpp", "fk_resample_whole.hpp", "fk_exact_scan.hpp", "fk_math.hpp")]
     if not os.path.exists(so) or any(os.path.getmtime(so) < os.path.getmtime(d) for d in deps):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-w", "-o", so, src])
     return ctypes.CDLL(so)
@@ -72,3 +72,84 @@ def test_stratified_boundaries_equal_the_division(lib, Np):
         ref = np.searchsorted(pos, c, side="left")
         assert np.array_equal(_call(lib, "hc_n_boundary_strat", Np, us, c), ref)
         assert np.array_equal(_call(lib, "hc_n_boundary_fast_strat", Np, us, c), ref)
+
+
+# ---- resample_whole_kernel's arithmetic (filterpy_amd/csrc/fk_resample_whole.hpp), emulated thread by thread ----------
+def _whole(lib, NT, w, strat, u):
+    Np = len(w)
+    w = np.ascontiguousarray(w, dtype=np.float64)
+    u = np.ascontiguousarray(np.atleast_1d(u), dtype=np.float64)
+    cs, idx, info = np.full(Np, np.nan), np.full(Np, -7, dtype=np.int32), np.zeros(3, dtype=np.int32)
+    vp = ctypes.c_void_p
+    rc = lib.hc_whole_resample(ctypes.c_int(NT), ctypes.c_int(Np), w.ctypes.data_as(vp), ctypes.c_int(int(strat)),
+                               u.ctypes.data_as(vp), cs.ctypes.data_as(vp), idx.ctypes.data_as(vp), info.ctypes.data_as(vp))
+    assert rc == 0
+    return cs, idx, info
+
+
+def _whole_family(kind, Np, rs):
+    w = rs.rand(Np)
+    if kind == "heavy_tail":
+        w = w ** 12
+    elif kind == "zeros":
+        w = np.where(rs.rand(Np) < 0.7, 0.0, w)
+    elif kind == "leading_zeros":
+        w[: (Np * 3) // 10] = 0.0
+    elif kind == "one_heavy":
+        w[Np // 3] = 1e4
+    elif kind == "ties":
+        w = np.floor(w * 2 ** 20) * 2.0 ** -40
+    elif kind == "dyadic":                      # exact half-ulp ties by the hundred: the round must decline, not err
+        w = np.full(Np, 3 * 2.0 ** -54)
+        w[0] = 0.75
+    elif kind == "tiny":
+        w = w * 1e-300
+    if kind not in ("dyadic", "tiny"):
+        w = w / w.sum()
+    if kind == "sum_half":
+        w = w * 0.5
+    elif kind == "unnormalised":
+        w = w * 1e6
+    return w
+
+
+@pytest.mark.parametrize("Np", [1, 2, 7, 100, 2047, 2048, 4096, 8000, 8189, 8192])
+def test_whole_vector_round_equals_cumsum_and_merge_loop(lib, Np):
+    """the one-round exact scan of resample_whole_kernel (classification -> lists -> chain -> cumulative sums ->
+    boundaries), emulated on the host with the kernel's own per-thread functions: cumulative sums bitwise equal to
+    numpy.cumsum, indices equal to the reference's merge loop (resampling.py:106-112, :142-149), for every weight family"""
+    from oracle import resample_oracle as ro
+    NT = 256 if Np <= 2048 else (512 if Np <= 4096 else 1024)
+    declined = 0
+    for kind in ("uniform", "heavy_tail", "zeros", "leading_zeros", "one_heavy", "ties", "sum_half", "unnormalised", "dyadic", "tiny"):
+        for seed in range(3):
+            rs = np.random.RandomState(1000 * Np + seed)
+            w = _whole_family(kind, Np, rs)
+            if not np.all(np.isfinite(w)):          # 0 / 0: the kernel hands NaN weights to the literal loop before this round
+                continue
+            for strat in (0, 1):
+                u = rs.rand(Np) if strat else rs.rand()
+                cs, idx, info = _whole(lib, NT, w, strat, u)
+                if info[1]:
+                    declined += 1
+                    assert kind in ("dyadic", "tiny") and Np > 256, (kind, Np)      # running sums below 2^-900: all dirty
+                    continue
+                assert np.array_equal(cs, np.cumsum(w)), (kind, Np, seed)
+                ref, over = (ro.stratified_c if strat else ro.systematic_c)(w, u)
+                ok = ref < Np
+                assert np.array_equal(idx[ok], ref[ok]), (kind, Np, seed, strat)
+                assert (info[2] < Np) == (over > 0)
+                assert info[0] <= 64 or kind in ("ties", "dyadic", "tiny"), (kind, info[0])
+    assert declined == 0 or Np > 256
+
+
+def test_whole_vector_round_dirty_counts(lib):
+    """how many dirty elements random normalised weights produce at Np = 8000 (the kernel's chain length): the first
+    non-zero weight, ~13 binade crossings, a handful of half-ulp ties"""
+    rs = np.random.RandomState(5)
+    Ds = []
+    for _ in range(40):
+        w = rs.rand(8000)
+        w /= w.sum()
+        Ds.append(int(_whole(lib, 1024, w, 0, rs.rand())[2][0]))
+    assert 10 <= min(Ds) and max(Ds) <= 40, (min(Ds), max(Ds))
