@@ -8,7 +8,7 @@
 //      factor (1 +- WH_DELTA); an element whose two bounds lie in one binade e is CLEAN -- its add is the integer map
 //      C -> C + inc_e(w) on the running sum in units of 2^e (fk_exact_scan.hpp) --, a zero weight is clean in any
 //      binade; everything else -- the binade crossings themselves, the first non-zero weight (running sum 0), half-ulp
-//      ties, ambiguous bounds -- is DIRTY and is added with a real IEEE add;
+//      ties, ambiguous bounds, a weight of half the running sum or more -- is DIRTY and is added with a real IEEE add;
 //   2. one wrapping 64-bit prefix sum of the increments and one of the dirty flags: the dirty elements (a few dozen for
 //      random weights; more than WH_DMAX and the kernel runs the reference's loop literally) cut the vector into
 //      SEGMENTS of clean elements that share one binade;
@@ -16,16 +16,21 @@
 //      show the claimed binade and, with the segment's whole increment sum added, still show it -- then every prefix
 //      inside did; a dirty element is one real add.  Nothing rests on the prediction: a segment that fails the check
 //      fails the whole round (-> literal loop);
-//   4. every element reads its segment's start and adds its scaled increment prefix: cs_j = c_start + (PS_j - PS0) 2^e.
+//   4. every element reads its segment's start and adds its scaled increment prefix: cs_j = c_start + (PS_j - PS0) 2^e;
+//      its slot boundary n(cs_j) (fk_resample_math.hpp) follows from ONE fma on the increment prefix where the thread's
+//      elements all lie in one segment that claims a binade, from cs_j itself elsewhere.
 //
 // This is resample_onepass.hip's segmented_cumsum (round 2) re-cut so that (a) the weights stay in registers -- no LDS
-// tile --, (b) the per-thread pieces are plain functions of the thread's eight elements, shared by the kernel and by the
-// host emulation tests/hostcheck drives against numpy.cumsum and the merge loop before any GPU time is spent.
+// tile --, (b) a thread whose eight elements share a binade (nearly all do: a vector of 8000 weights crosses ~13) never
+// runs the per-element machinery -- the first cut did, and measured 41k clocks per filter, all VALU issue --, (c) the
+// per-thread pieces are plain functions shared by the kernel and by the host emulation that tests/hostcheck drives
+// against numpy.cumsum and the merge loop before any GPU time is spent.
 #pragma once
 
 #include <stdint.h>
 
 #include "fk_exact_scan.hpp"
+#include "fk_resample_math.hpp"
 
 namespace fk {
 
@@ -39,62 +44,101 @@ constexpr double WH_SANE_LO = 0x1p-900, WH_SANE_HI = 0x1p900;
 
 typedef unsigned long long wh_u64;
 
-struct WhThread {
-    unsigned dirty, claims;               // bit q: element q is dirty / claims a binade (clean and non-zero)
-    int eq[WH_ITEMS];                     // ulp exponent of the binade the element's add happens in (if it claims)
-    wh_u64 psum;                          // sum of the claiming elements' increments (wrapping)
-    int ndirty;
-};
-
-// increment of a claiming element in its claimed binade: floor(w / 2^e + 1/2) (no tie: checked by wh_classify)
-FK_HD wh_u64 wh_inc(double w, int e)
+// integer-valued double in [0, 2^64) <-> wh_u64, exactly, without the library's range handling: two 32-bit halves
+FK_HD wh_u64 wh_to_u64(double v)
 {
-    return (wh_u64)floor(scale2(w, -e) + 0.5);
+    const double hi = floor(v * 0x1p-32);
+    const double lo = v - hi * 0x1p32;                 // exact: [0, 2^32)
+    return ((wh_u64)(unsigned)hi << 32) | (wh_u64)(unsigned)lo;
+}
+FK_HD double wh_to_f64(wh_u64 v)                       // exact for v < 2^53
+{
+    return (double)(unsigned)(v >> 32) * 0x1p32 + (double)(unsigned)v;
 }
 
-// step 1 for one thread: `before` = plain sum of every weight before the thread's first element, j0 = index of that
-// element, len = length of the vector (elements >= len are padding: weight +0.0)
-FK_HD void wh_classify(const double (&w)[WH_ITEMS], double before, int j0, int len, WhThread &t)
+struct WhThread {
+    unsigned dirty, claims;               // bit q: element q is dirty / claims a binade (clean and non-zero)
+    int eq[WH_ITEMS];                     // ulp exponent of the binade the element's add happens in (where it claims)
+    double inc[WH_ITEMS];                 // its increment there, floor(w / 2^e + 1/2) < 2^52 (0 where it does not claim)
+    wh_u64 psum;                          // sum of the thread's increments (wrapping)
+    int ndirty;
+    bool uniform;                         // all claims in ONE binade eq[0] and no dirty element: the one-fma boundary path
+};
+
+// one element against the bounds [lo, hi] on the running sum before / after its add
+FK_HD void wh_classify_element(double w, double lo, double hi, bool in, int q, WhThread &t)
+{
+    const bool known = lo > WH_SANE_LO && hi < WH_SANE_HI && ulp_exp(lo) == ulp_exp(hi);
+    const int e = ulp_exp(lo);
+    const double x = scale2(w, -e) + 0.5;
+    const double i = floor(x);
+    const bool zero = w == 0.0;
+    // no half-ulp tie, and an increment below 2^52 (a valid one always is: C >= 2^52 and C + inc < 2^53)
+    const bool ok = known && i != x && i < 0x1p52;
+    const bool claim = in && !zero && ok;
+    if (claim) t.claims |= 1u << q;
+    if (in && !zero && !ok) t.dirty |= 1u << q;
+    t.eq[q] = e;
+    t.inc[q] = claim ? i : 0.0;
+}
+
+// step 1 for one thread: `before` = plain sum of every weight before the thread's first element, `tsum` = plain sum of
+// its own, j0 = index of its first element, len = length of the vector (elements >= len are padding: weight +0.0)
+FK_HD void wh_classify(const double (&w)[WH_ITEMS], double before, double tsum, int j0, int len, WhThread &t)
 {
     t.dirty = t.claims = 0;
-    t.psum = 0;
-    double prev = before, arun = 0.0;
-    FK_UNROLL for (int q = 0; q < WH_ITEMS; ++q) {
-        arun += w[q];
-        const double cur = before + arun;
-        const double lo = prev * (1.0 - WH_DELTA), hi = cur * (1.0 + WH_DELTA);
-        const bool known = lo > WH_SANE_LO && hi < WH_SANE_HI && ulp_exp(lo) == ulp_exp(hi);
-        const int e = ulp_exp(lo);
-        const double x = scale2(w[q], -e) + 0.5;
-        const double i = floor(x);
-        const bool zero = w[q] == 0.0;
-        const bool ok = known && i != x && i < 0x1p53;         // no half-ulp tie; (i < 2^53 always holds: w <= hi)
-        const bool in = j0 + q < len;
-        if (in && !zero && ok) t.claims |= 1u << q;
-        if (in && !zero && !ok) t.dirty |= 1u << q;
-        t.eq[q] = e;
-        t.psum += (in && !zero && ok) ? (wh_u64)i : (wh_u64)0;
-        prev = cur;
+    const double tlo = before * (1.0 - WH_DELTA), thi = (before + tsum) * (1.0 + WH_DELTA);
+    const bool one = tlo > WH_SANE_LO && thi < WH_SANE_HI && ulp_exp(tlo) == ulp_exp(thi);
+    if (one) {
+        // the running sum stays in ONE binade across all eight adds: the bounds of every element lie inside [tlo, thi]
+        const int e = ulp_exp(tlo);
+        FK_UNROLL for (int q = 0; q < WH_ITEMS; ++q) {
+            const double x = scale2(w[q], -e) + 0.5;
+            const double i = floor(x);
+            const bool zero = w[q] == 0.0;
+            const bool ok = i != x && i < 0x1p52;
+            const bool in = j0 + q < len;
+            const bool claim = in && !zero && ok;
+            if (claim) t.claims |= 1u << q;
+            if (in && !zero && !ok) t.dirty |= 1u << q;
+            t.eq[q] = e;
+            t.inc[q] = claim ? i : 0.0;
+        }
+    } else {
+        double prev = before, arun = 0.0;
+        FK_UNROLL for (int q = 0; q < WH_ITEMS; ++q) {
+            arun += w[q];
+            const double cur = before + arun;
+            wh_classify_element(w[q], prev * (1.0 - WH_DELTA), cur * (1.0 + WH_DELTA), j0 + q < len, q, t);
+            prev = cur;
+        }
     }
     t.ndirty = 0;
-    FK_UNROLL for (int q = 0; q < WH_ITEMS; ++q) t.ndirty += (t.dirty >> q) & 1u;
+    t.psum = 0;
+    FK_UNROLL for (int q = 0; q < WH_ITEMS; ++q) {
+        t.ndirty += (t.dirty >> q) & 1u;
+        t.psum += wh_to_u64(t.inc[q]);
+    }
+    t.uniform = one && t.dirty == 0 && j0 + WH_ITEMS <= len;          // (a thread with padding takes the general form)
 }
 
 // step 2 for one thread: dbase / pbase = dirty elements / increment sum before the thread.  Writes the thread's dirty
 // elements into the lists and its claims into the segments (all claimants of a segment write the same value: checked
 // by wh_claims_bad after a barrier).
-FK_HD void wh_lists(const double (&w)[WH_ITEMS], const WhThread &t, int j0, int dbase, wh_u64 pbase, int *seg_e, int *d_pos,
-                    double *d_w, wh_u64 *d_ps)
+FK_HD void wh_lists(const double (&w)[WH_ITEMS], const WhThread &t, int dbase, wh_u64 pbase, int *seg_e, double *d_w, wh_u64 *d_ps)
 {
+    if (t.uniform) {
+        if (t.claims) seg_e[dbase] = t.eq[0];
+        return;
+    }
     int r = dbase;
     wh_u64 ps = pbase;
     FK_UNROLL for (int q = 0; q < WH_ITEMS; ++q) {
         if (t.claims & (1u << q)) {
             seg_e[r] = t.eq[q];
-            ps += wh_inc(w[q], t.eq[q]);
+            ps += wh_to_u64(t.inc[q]);
         }
         if (t.dirty & (1u << q)) {
-            d_pos[r] = j0 + q;
             d_w[r] = w[q];
             d_ps[r] = ps;
             ++r;
@@ -104,6 +148,7 @@ FK_HD void wh_lists(const double (&w)[WH_ITEMS], const WhThread &t, int j0, int 
 
 FK_HD bool wh_claims_bad(const WhThread &t, int dbase, const int *seg_e)
 {
+    if (t.uniform) return t.claims != 0 && seg_e[dbase] != t.eq[0];
     int r = dbase;
     bool bad = false;
     FK_UNROLL for (int q = 0; q < WH_ITEMS; ++q) {
@@ -127,11 +172,11 @@ FK_HD WhSeg wh_segment(int r, int D, wh_u64 ptotal, const int *seg_e, const wh_u
     const wh_u64 end = r < D ? d_ps[r] : ptotal;
     const wh_u64 start = r >= 1 ? d_ps[r - 1] : 0;
     const int e = seg_e[r];
-    const wh_u64 I = end - start;                                          // (wrapping; < 2^53 for a segment that passes)
+    const wh_u64 I = end - start;                                          // (wrapping; < 2^52 for a segment that passes)
     const bool claim = e != WH_NONE;
     WhSeg s;
     s.bad = (claim && !(I < (1ull << 53))) || (!claim && I != 0);
-    s.add = claim ? scale2((double)I, e) : 0.0;
+    s.add = claim ? scale2(wh_to_f64(I), e) : 0.0;
     s.xf = claim ? e + 1075 : -1;
     s.ps0 = start;
     return s;
@@ -172,22 +217,116 @@ FK_HD bool wh_chain_serial(int D, wh_u64 ptotal, const int *seg_e, const wh_u64 
     return !fail;
 }
 
-// step 4 for one thread: the cumulative sums of its elements (elements >= len: the carry-out, i.e. no slots)
-FK_HD void wh_cumsums(const double (&w)[WH_ITEMS], const WhThread &t, int j0, int len, int dbase, wh_u64 pbase, const int *seg_e,
-                      const double *seg_c, const wh_u64 *seg_ps0, const double *d_cs, double carry_out, double (&cs)[WH_ITEMS])
+// geometry of the positions, shared by every boundary of one vector
+template <bool STRATIFIED>
+struct WhPos {
+    int Np;
+    double Nd, halfNd, u_sys;
+    const double *u_str;
+};
+
+// The rare paths below run as ONE rolled copy instead of eight inlined ones.  Registers cannot be indexed -- and a chain
+// of selects on the loop counter is turned into an indexed scratch access by the optimiser, which moves the whole array
+// to scratch memory for the hot path too -- so the arrays are ROTATED: every trip works on element 0 and shifts.
+template <class T>
+FK_HD T wh_rotate(T (&a)[WH_ITEMS], T last)
 {
+    const T first = a[0];
+    FK_UNROLL for (int r = 0; r + 1 < WH_ITEMS; ++r) a[r] = a[r + 1];
+    a[WH_ITEMS - 1] = last;
+    return first;
+}
+
+// step 4 for one thread: the slot boundaries n(cs_j) of its elements (elements >= len: the carry-out, i.e. no slots)
+template <bool STRATIFIED>
+FK_HD void wh_boundaries(const WhThread &t, int j0, int len, int dbase, wh_u64 pbase, const int *seg_e, const double *seg_c,
+                         const wh_u64 *seg_ps0, const double *d_cs, double carry_out, const WhPos<STRATIFIED> &px,
+                         int (&nb)[WH_ITEMS])
+{
+    const int e0 = seg_e[dbase];
+    if (t.uniform && e0 != WH_NONE) {
+        // all eight elements lie in segment `dbase`, which claims binade e0: cs_j = (C0 + Et_j) 2^e0 exactly with
+        // C0 = c_start / 2^e0 and Et_j the increment prefix since the segment's start, so N cs_j - u = fma(Et_j, N 2^e0,
+        // C0 N 2^e0 - u): ONE fma per weight gives the estimate whose ceiling is n_j whenever it is not within eps of
+        // an integer (n_boundary_fast's argument: two roundings of 2^-22 slots each, the same budget); the rare rest
+        // takes the exact tests on cs_j.  (Round 2's quick_boundaries, per thread instead of per chunk.)
+        const double C0 = scale2(seg_c[dbase], -e0), Nu = scale2(px.Nd, e0);
+        const double K = fma(C0, Nu, STRATIFIED ? 0.0 : -px.u_sys);
+        const double E0 = wh_to_f64(pbase - seg_ps0[dbase]);
+        double Et = E0;
+        unsigned unsure = 0;
+        FK_UNROLL for (int q = 0; q < WH_ITEMS; ++q) {
+            Et += t.inc[q];                                                // exact: C0 + Et < 2^53 (the chain checked it)
+            const double est = fma(Et, Nu, K);
+            const double fl = floor(est), fr = est - fl;
+            bool sure = fr > N_BOUNDARY_EPS && fr < 1.0 - N_BOUNDARY_EPS && est < px.Nd;
+            int n = (int)fl + 1;
+            if (STRATIFIED) {
+                const double uf = px.u_str[est < px.Nd ? (int)fl : 0];     // est >= 0 here
+                const double gap = uf - fr;
+                sure = sure && (gap > N_BOUNDARY_EPS || gap < -N_BOUNDARY_EPS);
+                n = (int)fl + (gap > 0.0 ? 0 : 1);
+            }
+            unsure |= sure ? 0u : (1u << q);
+            nb[q] = n;
+        }
+        if (unsure) {                                                      // about one weight in 10^5: the exact tests
+            double incr[WH_ITEMS];
+            FK_UNROLL for (int q = 0; q < WH_ITEMS; ++q) incr[q] = t.inc[q];
+            double Eq = E0;
+            _Pragma("nounroll") for (int q = 0; q < WH_ITEMS; ++q) {
+                Eq += wh_rotate(incr, 0.0);
+                int n = nb[0];
+                if (unsure & 1u) n = n_boundary<STRATIFIED>(scale2(C0 + Eq, e0), px.Np, px.Nd, px.halfNd, px.u_sys, px.u_str);
+                unsure >>= 1;
+                wh_rotate(nb, n);
+            }
+        }
+        return;
+    }
+    // the general form, one rolled copy: a thread that holds a dirty element or padding, or whose segment claims nothing
     int r = dbase;
     wh_u64 ps = pbase;
+    double incr[WH_ITEMS];
     FK_UNROLL for (int q = 0; q < WH_ITEMS; ++q) {
-        if (t.claims & (1u << q)) ps += wh_inc(w[q], t.eq[q]);
+        incr[q] = t.inc[q];
+        nb[q] = 0;
+    }
+    unsigned claims = t.claims, dirty = t.dirty;
+    _Pragma("nounroll") for (int q = 0; q < WH_ITEMS; ++q) {
+        const double inc0 = wh_rotate(incr, 0.0);
+        if (claims & 1u) ps += wh_to_u64(inc0);
         double c;
-        if (t.dirty & (1u << q)) {
+        if (dirty & 1u) {
             c = d_cs[r];
             ++r;
         } else {
             // (C0 + dPS) 2^e = c_start + dPS 2^e: exact for the same reason as in the chain
             const int e = seg_e[r];
-            c = e == WH_NONE ? seg_c[r] : seg_c[r] + scale2((double)(ps - seg_ps0[r]), e);
+            c = e == WH_NONE ? seg_c[r] : seg_c[r] + scale2(wh_to_f64(ps - seg_ps0[r]), e);
+        }
+        claims >>= 1;
+        dirty >>= 1;
+        if (j0 + q >= len) c = carry_out;                                  // padding: the vector's last boundary, no slots
+        wh_rotate(nb, n_boundary_fast<STRATIFIED>(c, px.Np, px.Nd, px.halfNd, px.u_sys, px.u_str));
+    }
+}
+
+// the cumulative sums themselves (tests only: the kernel goes straight to the boundaries)
+FK_HD void wh_cumsums(const WhThread &t, int j0, int len, int dbase, wh_u64 pbase, const int *seg_e, const double *seg_c,
+                      const wh_u64 *seg_ps0, const double *d_cs, double carry_out, double (&cs)[WH_ITEMS])
+{
+    int r = dbase;
+    wh_u64 ps = pbase;
+    for (int q = 0; q < WH_ITEMS; ++q) {
+        if (t.claims & (1u << q)) ps += wh_to_u64(t.inc[q]);
+        double c;
+        if (t.dirty & (1u << q)) {
+            c = d_cs[r];
+            ++r;
+        } else {
+            const int e = seg_e[r];
+            c = e == WH_NONE ? seg_c[r] : seg_c[r] + scale2(wh_to_f64(ps - seg_ps0[r]), e);
         }
         cs[q] = j0 + q < len ? c : carry_out;
     }

@@ -593,7 +593,11 @@ __device__ __forceinline__ void init_window(int *win, int tid)
     FK_UNROLL for (int g = 0; g < 3; ++g) *reinterpret_cast<i32x4 *>(&win[12 * tid + 4 * g]) = i32x4{-1, -1, -1, -1};
 }
 
-template <bool STRATIFIED>
+// TICKET = false (FK_OP_STATIC=1, experiment): chunk (f, k) is a function of blockIdx alone -- chunk-major over the filters --
+// instead of an atomic ticket.  A chunk only waits for chunks with a smaller blockIdx; that is deadlock-free as long as the
+// dispatcher starts workgroups in blockIdx order per XCD (it does, but nothing guarantees it: the bounded spins + abort word
+// stay, and the default keeps the tickets).
+template <bool STRATIFIED, bool TICKET = true>
 __global__ void __launch_bounds__(OP_THREADS, FK_OP_WAVES)
 resample_onepass_kernel(const OpArgs a)
 {
@@ -607,9 +611,12 @@ resample_onepass_kernel(const OpArgs a)
     // tickets run chunk-major (chunk k of every filter of the region before chunk k + 1 of any): the resident
     // workgroups then advance all the region's filters together, and a chunk that has to resolve its carry with the
     // general scan (a binade crossing: ~20 per 8e6-particle vector) holds up its own filter's chain only.
+    int *win = sh.win();
+    int f, k;
+    if constexpr (TICKET) {
     if (tid == 0) {
         const int R = a.nregions;
-        int f = -1, k = 0;
+        int tf = -1, tk = 0;
         for (int s = 0; s < R; ++s) {
             const int r = (int)((blockIdx.x + (unsigned)s) % (unsigned)R);
             const long f_lo = (long)a.Fn * r / R, f_hi = (long)a.Fn * (r + 1) / R;
@@ -617,19 +624,23 @@ resample_onepass_kernel(const OpArgs a)
             const unsigned t = __hip_atomic_fetch_add(&a.ctl->head[r].next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (t < cnt) {
                 const unsigned nf = (unsigned)(f_hi - f_lo);
-                f = (int)(f_lo + t % nf);
-                k = (int)(t / nf);
+                tf = (int)(f_lo + t % nf);
+                tk = (int)(t / nf);
                 break;
             }
         }
-        sh.bc_i[1] = f;
-        sh.bc_i[2] = k;
+        sh.bc_i[1] = tf;
+        sh.bc_i[2] = tk;
     }
-    int *win = sh.win();
     init_window(win, tid);                 // the output window (it shares its LDS with the general scan's tile)
     __syncthreads();
-    const int f = __builtin_amdgcn_readfirstlane(sh.bc_i[1]);
-    const int k = __builtin_amdgcn_readfirstlane(sh.bc_i[2]);
+    f = __builtin_amdgcn_readfirstlane(sh.bc_i[1]);
+    k = __builtin_amdgcn_readfirstlane(sh.bc_i[2]);
+    } else {
+        f = (int)(blockIdx.x % (unsigned)a.Fn);
+        k = (int)(blockIdx.x / (unsigned)a.Fn);
+        init_window(win, tid);             // (first read far behind barrier (A))
+    }
     if (f < 0) return;                                                     // cannot happen: one workgroup per chunk
     OP_CLOCK(0);                                                           // ticket
 
@@ -1417,11 +1428,15 @@ int onepass_launch(bool stratified, int64_t Fn, int64_t Np, const double *w, con
     a.delta = (8.0 * (double)(Np + 4096) + 16.0 * (double)nch) * 0x1p-53;
     if (hipMemsetAsync(ws, 0, need, s) != hipSuccess) return FK_ERR_LAUNCH;
     if (status && hipMemsetAsync(status, 0, (size_t)Fn * sizeof(int32_t), s) != hipSuccess) return FK_ERR_LAUNCH;
+    const char *sv = getenv("FK_OP_STATIC");
+    const bool stat = sv && sv[0] == '1';
     if (stratified) {
-        hipLaunchKernelGGL((resample_onepass_kernel<true>), dim3((unsigned)total), dim3(OP_THREADS), 0, s, a);
+        if (stat) hipLaunchKernelGGL((resample_onepass_kernel<true, false>), dim3((unsigned)total), dim3(OP_THREADS), 0, s, a);
+        else hipLaunchKernelGGL((resample_onepass_kernel<true>), dim3((unsigned)total), dim3(OP_THREADS), 0, s, a);
         hipLaunchKernelGGL((resample_literal_kernel<true>), dim3((unsigned)Fn), dim3(64), 0, s, a);
     } else {
-        hipLaunchKernelGGL((resample_onepass_kernel<false>), dim3((unsigned)total), dim3(OP_THREADS), 0, s, a);
+        if (stat) hipLaunchKernelGGL((resample_onepass_kernel<false, false>), dim3((unsigned)total), dim3(OP_THREADS), 0, s, a);
+        else hipLaunchKernelGGL((resample_onepass_kernel<false>), dim3((unsigned)total), dim3(OP_THREADS), 0, s, a);
         hipLaunchKernelGGL((resample_literal_kernel<false>), dim3((unsigned)Fn), dim3(64), 0, s, a);
     }
     return check_launch("resample_onepass_kernel");

@@ -11,7 +11,8 @@
 // never leave the registers (8 B read per particle, once), every weight computes its slot boundary n(cs_j) straight
 // from its cumulative sum (fk_resample_math.hpp: no division, no search), and ONE window of Np slots in LDS turns the
 // boundaries into indices: run heads -> inclusive max-scan -> 16-byte coalesced stores (4 B written per particle).
-// Seven workgroup barriers per filter in all.  A vector the round cannot take -- a negative / NaN / huge weight, more
+// Seven workgroup barriers per filter in all; a thread whose eight weights share a binade (nearly all do) spends ~40 VALU
+// instructions per weight from load to store.  A vector the round cannot take -- a negative / NaN / huge weight, more
 // than WH_DMAX dirty elements (half-ulp ties by the hundred, running sums below 2^-900), a failed binade check -- is
 // handed to the reference's merge loop, run literally by one thread: slow, but still the reference's answer.
 //
@@ -44,8 +45,7 @@ struct WholeShared {
     u64 ptot[NW];                          //   increment sums,
     int dtot[NW];                          //   dirty counts,
     int wmax[NW];                          //   running maxima of the window
-    int d_pos[WH_DMAX];                    // dirty element r: its position, weight, increment prefix up to it
-    double d_w[WH_DMAX];
+    double d_w[WH_DMAX];                   // dirty element r: its weight, the increment prefix up to it
     u64 d_ps[WH_DMAX];
     double d_cs[WH_DMAX];                  //   and (from the chain) the running sum after its real add
     int seg_e[WH_DMAX + 1];                // segment r: claimed ulp exponent, increment prefix and running sum at its start
@@ -120,7 +120,7 @@ resample_whole_kernel(const WholeArgs a)
     u64 pbase = 0, ptotal = 0;
     if (!literal) {
         // ---- clean / dirty, increments; their prefix sums over the workgroup --------------------------------
-        wh_classify(w, before, j0, Np, th);
+        wh_classify(w, before, run, j0, Np, th);
         const int dincl = wave_incl_sum_i32(th.ndirty);
         const u64 pincl = wave_incl_sum_u64(th.psum);
         if (lane == 63) {
@@ -143,7 +143,7 @@ resample_whole_kernel(const WholeArgs a)
         literal = D > WH_DMAX;                                             // uniform
     }
     if (!literal) {
-        wh_lists(w, th, j0, dbase, pbase, sh.seg_e, sh.d_pos, sh.d_w, sh.d_ps);
+        wh_lists(w, th, dbase, pbase, sh.seg_e, sh.d_w, sh.d_ps);
         __syncthreads();                                                                      // (3)
         if (wh_claims_bad(th, dbase, sh.seg_e)) sh.fail = 1;
         // ---- the chain over the segments (wave 0; lane l holds segment b0 + l and dirty element b0 + l): what does
@@ -201,12 +201,13 @@ resample_whole_kernel(const WholeArgs a)
     // ---- cumulative sums -> slot boundaries: weight j owns the slots [n_{j-1}, n_j), n_j = n(cs_j) ------------------
     int nb[WH_ITEMS];
     {
-        double cs[WH_ITEMS];
-        wh_cumsums(w, th, j0, Np, dbase, pbase, sh.seg_e, sh.seg_c, sh.seg_ps0, sh.d_cs, sh.carry_out, cs);
-        FK_UNROLL for (int q = 0; q < WH_ITEMS; ++q) {
-            nb[q] = n_boundary_fast<STRATIFIED>(cs[q], Np, Nd, halfNd, u_sys, u_str);
-            FK_STAGE();
-        }
+        WhPos<STRATIFIED> px;
+        px.Np = Np;
+        px.Nd = Nd;
+        px.halfNd = halfNd;
+        px.u_sys = u_sys;
+        px.u_str = u_str;
+        wh_boundaries<STRATIFIED>(th, j0, Np, dbase, pbase, sh.seg_e, sh.seg_c, sh.seg_ps0, sh.d_cs, sh.carry_out, px, nb);
     }
     sh.nlast[tid] = nb[WH_ITEMS - 1];
     __syncthreads();                                                                          // (5)

@@ -39,12 +39,16 @@ void hc_n_boundary_fast_strat(int Np, const double *u, long K, const double *c, 
 // single comparison: fl(a / N) >= c
 int hc_pos_ge(double a, double c, double Nd) { return fk::pos_ge(a, c, Nd, 0.5 * Nd) ? 1 : 0; }
 
+}  // extern "C"
+
 
 // resample_whole_kernel's arithmetic, thread by thread in the kernel's phase order (NT threads x 8 consecutive weights,
 // the per-thread pieces are the kernel's own functions, fk_resample_whole.hpp; the chain runs in its serial form and the
 // emission is a plain fill): cumulative sums, slot boundaries, indices.  info[0] = dirty elements, info[1] = 1 when the
-// round declined (the kernel then runs the reference's loop literally), info[2] = last boundary (slots filled).
-int hc_whole_resample(int NT, int Np, const double *wts, int stratified, const double *u, double *cs_out, int *idx_out, int *info)
+// round declined (the kernel then runs the reference's loop literally), info[2] = last boundary (slots filled),
+// info[3] = threads on the one-fma boundary path.
+template <bool STRATIFIED>
+static int whole_resample(int NT, int Np, const double *wts, const double *u, double *cs_out, int *idx_out, int *info)
 {
     using namespace fk;
     if (Np > NT * WH_ITEMS) return -1;
@@ -77,43 +81,52 @@ int hc_whole_resample(int NT, int Np, const double *wts, int stratified, const d
     std::vector<wh_u64> pbase(NT);
     int D = 0;
     wh_u64 ptotal = 0;
+    info[3] = 0;
     for (int t = 0; t < NT; ++t) {
         double w8[WH_ITEMS];
         for (int q = 0; q < WH_ITEMS; ++q) w8[q] = w[t * WH_ITEMS + q];
-        wh_classify(w8, before[t], t * WH_ITEMS, Np, th[t]);
+        wh_classify(w8, before[t], tsum[t], t * WH_ITEMS, Np, th[t]);
         dbase[t] = D;
         pbase[t] = ptotal;
         D += th[t].ndirty;
         ptotal += th[t].psum;
+        info[3] += th[t].uniform ? 1 : 0;
     }
     info[0] = D;
     info[1] = 0;
     info[2] = 0;
     if (D > WH_DMAX) { info[1] = 1; return 0; }
-    std::vector<int> seg_e(WH_DMAX + 1, WH_NONE), d_pos(WH_DMAX);
+    std::vector<int> seg_e(WH_DMAX + 1, WH_NONE);
     std::vector<double> d_w(WH_DMAX), d_cs(WH_DMAX), seg_c(WH_DMAX + 1);
     std::vector<wh_u64> d_ps(WH_DMAX), seg_ps0(WH_DMAX + 1);
     for (int t = 0; t < NT; ++t) {
         double w8[WH_ITEMS];
         for (int q = 0; q < WH_ITEMS; ++q) w8[q] = w[t * WH_ITEMS + q];
-        wh_lists(w8, th[t], t * WH_ITEMS, dbase[t], pbase[t], seg_e.data(), d_pos.data(), d_w.data(), d_ps.data());
+        wh_lists(w8, th[t], dbase[t], pbase[t], seg_e.data(), d_w.data(), d_ps.data());
     }
     bool bad = false;
     for (int t = 0; t < NT; ++t) bad = bad || wh_claims_bad(th[t], dbase[t], seg_e.data());
     double carry_out = 0.0;
     const bool ok = wh_chain_serial(D, ptotal, seg_e.data(), d_ps.data(), d_w.data(), seg_c.data(), seg_ps0.data(), d_cs.data(), &carry_out);
     if (bad || !ok) { info[1] = 1; return 0; }
-    const double Nd = (double)Np, h = 0.5 * Nd;
-    const double u_sys = stratified ? 0.0 : u[0];
+    WhPos<STRATIFIED> px;
+    px.Np = Np;
+    px.Nd = (double)Np;
+    px.halfNd = 0.5 * px.Nd;
+    px.u_sys = STRATIFIED ? 0.0 : u[0];
+    px.u_str = STRATIFIED ? u : nullptr;
     std::vector<int> nb((size_t)NT * WH_ITEMS);
     for (int t = 0; t < NT; ++t) {
         double w8[WH_ITEMS], cs[WH_ITEMS];
+        int n8[WH_ITEMS];
         for (int q = 0; q < WH_ITEMS; ++q) w8[q] = w[t * WH_ITEMS + q];
-        wh_cumsums(w8, th[t], t * WH_ITEMS, Np, dbase[t], pbase[t], seg_e.data(), seg_c.data(), seg_ps0.data(), d_cs.data(), carry_out, cs);
+        wh_cumsums(th[t], t * WH_ITEMS, Np, dbase[t], pbase[t], seg_e.data(), seg_c.data(), seg_ps0.data(), d_cs.data(), carry_out, cs);
+        wh_boundaries<STRATIFIED>(th[t], t * WH_ITEMS, Np, dbase[t], pbase[t], seg_e.data(), seg_c.data(), seg_ps0.data(),
+                                  d_cs.data(), carry_out, px, n8);
         for (int q = 0; q < WH_ITEMS; ++q) {
             const int j = t * WH_ITEMS + q;
             if (j < Np) cs_out[j] = cs[q];
-            nb[j] = stratified ? n_boundary_fast<true>(cs[q], Np, Nd, h, 0.0, u) : n_boundary_fast<false>(cs[q], Np, Nd, h, u_sys, nullptr);
+            nb[j] = n8[q];
         }
     }
     // weight j owns the slots [n_{j-1}, n_j)
@@ -127,4 +140,7 @@ int hc_whole_resample(int NT, int Np, const double *wts, int stratified, const d
     return 0;
 }
 
-}  // extern "C"
+extern "C" int hc_whole_resample(int NT, int Np, const double *wts, int stratified, const double *u, double *cs_out, int *idx_out, int *info)
+{
+    return stratified ? whole_resample<true>(NT, Np, wts, u, cs_out, idx_out, info) : whole_resample<false>(NT, Np, wts, u, cs_out, idx_out, info);
+}

@@ -79,7 +79,7 @@ def _whole(lib, NT, w, strat, u):
     Np = len(w)
     w = np.ascontiguousarray(w, dtype=np.float64)
     u = np.ascontiguousarray(np.atleast_1d(u), dtype=np.float64)
-    cs, idx, info = np.full(Np, np.nan), np.full(Np, -7, dtype=np.int32), np.zeros(3, dtype=np.int32)
+    cs, idx, info = np.full(Np, np.nan), np.full(Np, -7, dtype=np.int32), np.zeros(4, dtype=np.int32)
     vp = ctypes.c_void_p
     rc = lib.hc_whole_resample(ctypes.c_int(NT), ctypes.c_int(Np), w.ctypes.data_as(vp), ctypes.c_int(int(strat)),
                                u.ctypes.data_as(vp), cs.ctypes.data_as(vp), idx.ctypes.data_as(vp), info.ctypes.data_as(vp))
@@ -153,3 +153,28 @@ def test_whole_vector_round_dirty_counts(lib):
         w /= w.sum()
         Ds.append(int(_whole(lib, 1024, w, 0, rs.rand())[2][0]))
     assert 10 <= min(Ds) and max(Ds) <= 40, (min(Ds), max(Ds))
+    # nearly every thread takes the one-fma boundary path (the kernel's cost rests on it)
+    w = rs.rand(8000)
+    assert _whole(lib, 1024, w / w.sum(), 0, 0.3)[2][3] >= 975
+
+
+def test_whole_vector_one_fma_boundaries_on_many_vectors(lib):
+    """2.4e6 weights through the one-fma boundary path (about one in 1e5 lands within eps of an integer and takes the exact
+    tests): indices equal the merge loop's for every vector, systematic and stratified, incl. u at the ends of [0, 1)"""
+    from oracle import resample_oracle as ro
+    rs = np.random.RandomState(77)
+    for k in range(150):
+        Np = int(rs.choice([8000, 8192, 5000, 3000]))
+        NT = 256 if Np <= 2048 else (512 if Np <= 4096 else 1024)
+        w = rs.rand(Np) ** rs.choice([1, 1, 3])
+        w /= w.sum()
+        if k % 7 == 0:
+            w *= 4.0 / 3.0                                   # cumsum[-1] > 1: every slot filled, boundaries up to Np
+        for strat in (0, 1):
+            u = rs.rand(Np) if strat else [rs.rand(), 0.0, np.nextafter(1.0, 0)][k % 3]
+            cs, idx, info = _whole(lib, NT, w, strat, u)
+            assert not info[1]
+            ref, over = (ro.stratified_c if strat else ro.systematic_c)(w, u)
+            ok = ref < Np
+            assert np.array_equal(idx[ok], ref[ok]), (k, Np, strat)
+            assert (info[2] < Np) == (over > 0)
