@@ -62,7 +62,8 @@ struct WhThread {
     double inc[WH_ITEMS];                 // its increment there, floor(w / 2^e + 1/2) < 2^52 (0 where it does not claim)
     wh_u64 psum;                          // sum of the thread's increments (wrapping)
     int ndirty;
-    bool uniform;                         // all claims in ONE binade eq[0] and no dirty element: the one-fma boundary path
+    bool uniform;                         // all claims in ONE binade eq[0] and no dirty element
+    bool overflow;                        // increment sum not below 2^53: the round declines
 };
 
 // one element against the bounds [lo, hi] on the running sum before / after its add
@@ -82,17 +83,16 @@ FK_HD void wh_classify_element(double w, double lo, double hi, bool in, int q, W
     t.inc[q] = claim ? i : 0.0;
 }
 
-// step 1 for one thread: `before` = plain sum of every weight before the thread's first element, `tsum` = plain sum of
-// its own, j0 = index of its first element, len = length of the vector (elements >= len are padding: weight +0.0)
-FK_HD void wh_classify(const double (&w)[WH_ITEMS], double before, double tsum, int j0, int len, WhThread &t)
+// elements [Q0, Q0 + 4) of a thread: `before` = plain sum of every weight before element Q0, `hsum` = plain sum of the four
+template <int Q0>
+FK_HD bool wh_classify_half(const double (&w)[WH_ITEMS], double before, double hsum, int j0, int len, WhThread &t)
 {
-    t.dirty = t.claims = 0;
-    const double tlo = before * (1.0 - WH_DELTA), thi = (before + tsum) * (1.0 + WH_DELTA);
+    const double tlo = before * (1.0 - WH_DELTA), thi = (before + hsum) * (1.0 + WH_DELTA);
     const bool one = tlo > WH_SANE_LO && thi < WH_SANE_HI && ulp_exp(tlo) == ulp_exp(thi);
     if (one) {
-        // the running sum stays in ONE binade across all eight adds: the bounds of every element lie inside [tlo, thi]
+        // the running sum stays in ONE binade across the four adds: the bounds of every element lie inside [tlo, thi]
         const int e = ulp_exp(tlo);
-        FK_UNROLL for (int q = 0; q < WH_ITEMS; ++q) {
+        FK_UNROLL for (int q = Q0; q < Q0 + 4; ++q) {
             const double x = scale2(w[q], -e) + 0.5;
             const double i = floor(x);
             const bool zero = w[q] == 0.0;
@@ -106,20 +106,54 @@ FK_HD void wh_classify(const double (&w)[WH_ITEMS], double before, double tsum, 
         }
     } else {
         double prev = before, arun = 0.0;
-        FK_UNROLL for (int q = 0; q < WH_ITEMS; ++q) {
+        FK_UNROLL for (int q = Q0; q < Q0 + 4; ++q) {
             arun += w[q];
             const double cur = before + arun;
             wh_classify_element(w[q], prev * (1.0 - WH_DELTA), cur * (1.0 + WH_DELTA), j0 + q < len, q, t);
             prev = cur;
         }
     }
-    t.ndirty = 0;
+    return one;
+}
+
+// step 1 for one thread: `before` = plain sum of every weight before the thread's first element, j0 = index of that
+// element, len = length of the vector (elements >= len are padding: weight +0.0).  The per-element bounds are only
+// formed in the HALF of the thread that holds a crossing (or the vector's start): the waves that hold one set the pace
+// of the phase (it ends in a barrier).
+FK_HD void wh_classify(const double (&w)[WH_ITEMS], double before, int j0, int len, WhThread &t)
+{
+    t.dirty = t.claims = 0;
+    const double h0 = (w[0] + w[1]) + (w[2] + w[3]), h1 = (w[4] + w[5]) + (w[6] + w[7]);
+    const bool one0 = wh_classify_half<0>(w, before, h0, j0, len, t);
+    const bool one1 = wh_classify_half<4>(w, before + h0, h1, j0, len, t);
+    t.uniform = one0 && one1 && t.eq[0] == t.eq[4] && t.dirty == 0;
+    // the thread's increment sum (wrapping 64-bit), segment by segment: the increments of ONE segment are integers
+    // below 2^52 whose double sum is exact below 2^53 -- and a sum that is not stays >= 2^53 after rounding (monotone),
+    // which no valid segment holds: `overflow` fails the round.  Segments end at the thread's dirty elements; the
+    // increments of different segments (other binades) do not add up to anything bounded and meet as integers.
+    t.overflow = false;
     t.psum = 0;
-    FK_UNROLL for (int q = 0; q < WH_ITEMS; ++q) {
-        t.ndirty += (t.dirty >> q) & 1u;
-        t.psum += wh_to_u64(t.inc[q]);
+    double acc = 0.0;
+    if (t.dirty == 0) {
+        FK_UNROLL for (int q = 0; q < WH_ITEMS; ++q) acc += t.inc[q];
+    } else {
+        FK_UNROLL for (int q = 0; q < WH_ITEMS; ++q) {
+            if (t.dirty & (1u << q)) {
+                t.overflow = t.overflow || !(acc < 0x1p53);
+                t.psum += wh_to_u64(acc < 0x1p53 ? acc : 0.0);
+                acc = 0.0;
+            }
+            acc += t.inc[q];
+        }
     }
-    t.uniform = one && t.dirty == 0 && j0 + WH_ITEMS <= len;          // (a thread with padding takes the general form)
+    t.overflow = t.overflow || !(acc < 0x1p53);
+    t.psum += wh_to_u64(acc < 0x1p53 ? acc : 0.0);
+#if defined(__HIP_DEVICE_COMPILE__)
+    t.ndirty = __builtin_popcount(t.dirty);
+#else
+    t.ndirty = 0;
+    for (int q = 0; q < WH_ITEMS; ++q) t.ndirty += (t.dirty >> q) & 1u;
+#endif
 }
 
 // step 2 for one thread: dbase / pbase = dirty elements / increment sum before the thread.  Writes the thread's dirty
@@ -133,12 +167,15 @@ FK_HD void wh_lists(const double (&w)[WH_ITEMS], const WhThread &t, int dbase, w
     }
     int r = dbase;
     wh_u64 ps = pbase;
+    double acc = 0.0;                                                      // (as in wh_classify: one conversion per segment)
     FK_UNROLL for (int q = 0; q < WH_ITEMS; ++q) {
         if (t.claims & (1u << q)) {
             seg_e[r] = t.eq[q];
-            ps += wh_to_u64(t.inc[q]);
+            acc += t.inc[q];
         }
         if (t.dirty & (1u << q)) {
+            ps += wh_to_u64(acc < 0x1p53 ? acc : 0.0);
+            acc = 0.0;
             d_w[r] = w[q];
             d_ps[r] = ps;
             ++r;
@@ -225,90 +262,69 @@ struct WhPos {
     const double *u_str;
 };
 
-// The rare paths below run as ONE rolled copy instead of eight inlined ones.  Registers cannot be indexed -- and a chain
-// of selects on the loop counter is turned into an indexed scratch access by the optimiser, which moves the whole array
-// to scratch memory for the hot path too -- so the arrays are ROTATED: every trip works on element 0 and shifts.
-template <class T>
-FK_HD T wh_rotate(T (&a)[WH_ITEMS], T last)
+// what the one-fma boundary estimate needs from the segment an element lies in
+template <bool STRATIFIED>
+struct WhSegPos {
+    double C0, Nu, K;                     // cs = (C0 + Et) 2^e;  N cs - u = fma(Et, Nu, K),  Nu = N 2^e,  K = C0 Nu - u
+    int e;
+};
+template <bool STRATIFIED>
+FK_HD WhSegPos<STRATIFIED> wh_seg_pos(int r, const int *seg_e, const double *seg_c, const WhPos<STRATIFIED> &px)
 {
-    const T first = a[0];
-    FK_UNROLL for (int r = 0; r + 1 < WH_ITEMS; ++r) a[r] = a[r + 1];
-    a[WH_ITEMS - 1] = last;
-    return first;
+    WhSegPos<STRATIFIED> s;
+    s.e = seg_e[r];
+    const double c = seg_c[r];
+    const bool claim = s.e != WH_NONE;
+    // a segment of zeros claims no binade: its elements all have cs = c, the estimate is the constant N c - u
+    s.C0 = claim ? scale2(c, -s.e) : c;
+    s.Nu = claim ? scale2(px.Nd, s.e) : 0.0;
+    s.K = fma(s.C0, claim ? s.Nu : px.Nd, STRATIFIED ? 0.0 : -px.u_sys);
+    return s;
 }
 
-// step 4 for one thread: the slot boundaries n(cs_j) of its elements (elements >= len: the carry-out, i.e. no slots)
+// step 4 for one thread: the slot boundaries n(cs_j) of its elements.  ONE loop for every thread:
+//   * a clean element of a segment that claims binade e has cs_j = (C0 + Et_j) 2^e exactly, C0 = c_start / 2^e and
+//     Et_j the increment prefix since the segment's start, so N cs_j - u = fma(Et_j, N 2^e, C0 N 2^e - u): one fma gives
+//     the estimate whose ceiling is n_j whenever it is not within eps of an integer (n_boundary_fast's argument: two
+//     roundings of 2^-22 slots each, the same budget; round 2's quick_boundaries); the rest -- about one weight in
+//     10^5 -- takes the exact tests on cs_j;
+//   * a dirty element (a few per vector) takes its cumulative sum from the chain and starts the next segment.
+// The two rare cases are branches inside the loop: a wave runs them only at the positions where one of its lanes needs
+// them.  (The first cut ran a general per-element form for every wave that held one dirty element: the slowest wave
+// sets the pace of a phase that ends in a barrier, 9.8k of 40k clocks per filter.)  Padding elements (>= len) are zero
+// weights: clean, no slots -- they repeat the boundary of the element before them.
 template <bool STRATIFIED>
-FK_HD void wh_boundaries(const WhThread &t, int j0, int len, int dbase, wh_u64 pbase, const int *seg_e, const double *seg_c,
-                         const wh_u64 *seg_ps0, const double *d_cs, double carry_out, const WhPos<STRATIFIED> &px,
-                         int (&nb)[WH_ITEMS])
+FK_HD void wh_boundaries(const WhThread &t, int dbase, wh_u64 pbase, const int *seg_e, const double *seg_c,
+                         const wh_u64 *seg_ps0, const double *d_cs, const WhPos<STRATIFIED> &px, int (&nb)[WH_ITEMS])
 {
-    const int e0 = seg_e[dbase];
-    if (t.uniform && e0 != WH_NONE) {
-        // all eight elements lie in segment `dbase`, which claims binade e0: cs_j = (C0 + Et_j) 2^e0 exactly with
-        // C0 = c_start / 2^e0 and Et_j the increment prefix since the segment's start, so N cs_j - u = fma(Et_j, N 2^e0,
-        // C0 N 2^e0 - u): ONE fma per weight gives the estimate whose ceiling is n_j whenever it is not within eps of
-        // an integer (n_boundary_fast's argument: two roundings of 2^-22 slots each, the same budget); the rare rest
-        // takes the exact tests on cs_j.  (Round 2's quick_boundaries, per thread instead of per chunk.)
-        const double C0 = scale2(seg_c[dbase], -e0), Nu = scale2(px.Nd, e0);
-        const double K = fma(C0, Nu, STRATIFIED ? 0.0 : -px.u_sys);
-        const double E0 = wh_to_f64(pbase - seg_ps0[dbase]);
-        double Et = E0;
-        unsigned unsure = 0;
-        FK_UNROLL for (int q = 0; q < WH_ITEMS; ++q) {
+    int r = dbase;
+    WhSegPos<STRATIFIED> sp = wh_seg_pos<STRATIFIED>(r, seg_e, seg_c, px);
+    double Et = wh_to_f64(pbase - seg_ps0[r]);
+    FK_UNROLL for (int q = 0; q < WH_ITEMS; ++q) {
+        int n;
+        if (t.dirty & (1u << q)) {                                         // rare
+            n = n_boundary_fast<STRATIFIED>(d_cs[r], px.Np, px.Nd, px.halfNd, px.u_sys, px.u_str);
+            ++r;
+            sp = wh_seg_pos<STRATIFIED>(r, seg_e, seg_c, px);
+            Et = 0.0;                                                      // the next segment starts behind this element
+        } else {
             Et += t.inc[q];                                                // exact: C0 + Et < 2^53 (the chain checked it)
-            const double est = fma(Et, Nu, K);
+            const double est = fma(Et, sp.Nu, sp.K);
             const double fl = floor(est), fr = est - fl;
             bool sure = fr > N_BOUNDARY_EPS && fr < 1.0 - N_BOUNDARY_EPS && est < px.Nd;
-            int n = (int)fl + 1;
+            n = (int)fl + 1;
             if (STRATIFIED) {
-                const double uf = px.u_str[est < px.Nd ? (int)fl : 0];     // est >= 0 here
+                const double uf = px.u_str[(est < px.Nd && est >= 0.0) ? (int)fl : 0];
                 const double gap = uf - fr;
-                sure = sure && (gap > N_BOUNDARY_EPS || gap < -N_BOUNDARY_EPS);
+                sure = sure && est >= 0.0 && (gap > N_BOUNDARY_EPS || gap < -N_BOUNDARY_EPS);
                 n = (int)fl + (gap > 0.0 ? 0 : 1);
             }
-            unsure |= sure ? 0u : (1u << q);
-            nb[q] = n;
-        }
-        if (unsure) {                                                      // about one weight in 10^5: the exact tests
-            double incr[WH_ITEMS];
-            FK_UNROLL for (int q = 0; q < WH_ITEMS; ++q) incr[q] = t.inc[q];
-            double Eq = E0;
-            _Pragma("nounroll") for (int q = 0; q < WH_ITEMS; ++q) {
-                Eq += wh_rotate(incr, 0.0);
-                int n = nb[0];
-                if (unsure & 1u) n = n_boundary<STRATIFIED>(scale2(C0 + Eq, e0), px.Np, px.Nd, px.halfNd, px.u_sys, px.u_str);
-                unsure >>= 1;
-                wh_rotate(nb, n);
+            if (!sure) {                                                   // rare
+                const double cs = sp.e != WH_NONE ? scale2(sp.C0 + Et, sp.e) : sp.C0;
+                n = n_boundary<STRATIFIED>(cs, px.Np, px.Nd, px.halfNd, px.u_sys, px.u_str);
             }
         }
-        return;
-    }
-    // the general form, one rolled copy: a thread that holds a dirty element or padding, or whose segment claims nothing
-    int r = dbase;
-    wh_u64 ps = pbase;
-    double incr[WH_ITEMS];
-    FK_UNROLL for (int q = 0; q < WH_ITEMS; ++q) {
-        incr[q] = t.inc[q];
-        nb[q] = 0;
-    }
-    unsigned claims = t.claims, dirty = t.dirty;
-    _Pragma("nounroll") for (int q = 0; q < WH_ITEMS; ++q) {
-        const double inc0 = wh_rotate(incr, 0.0);
-        if (claims & 1u) ps += wh_to_u64(inc0);
-        double c;
-        if (dirty & 1u) {
-            c = d_cs[r];
-            ++r;
-        } else {
-            // (C0 + dPS) 2^e = c_start + dPS 2^e: exact for the same reason as in the chain
-            const int e = seg_e[r];
-            c = e == WH_NONE ? seg_c[r] : seg_c[r] + scale2(wh_to_f64(ps - seg_ps0[r]), e);
-        }
-        claims >>= 1;
-        dirty >>= 1;
-        if (j0 + q >= len) c = carry_out;                                  // padding: the vector's last boundary, no slots
-        wh_rotate(nb, n_boundary_fast<STRATIFIED>(c, px.Np, px.Nd, px.halfNd, px.u_sys, px.u_str));
+        nb[q] = n;
     }
 }
 

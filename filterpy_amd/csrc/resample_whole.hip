@@ -36,6 +36,19 @@ struct WholeArgs {
     int32_t *idx, *status;
 };
 
+// Build-time instrumentation (tools/op_phase.py --whole builds a separate library with -DFK_OP_CLOCKS; the shipped library
+// has none of it): thread 0 of every workgroup adds the shader-clock ticks between the barriers to fk_wh_phase[].
+#ifdef FK_OP_CLOCKS
+__device__ unsigned long long fk_wh_phase[16];
+#define WH_CLOCK_START() long long t_prev = clock64()
+#define WH_CLOCK(slot) do { if (threadIdx.x == 0) { const long long t_now = clock64(); atomicAdd(&fk_wh_phase[slot], (unsigned long long)(t_now - t_prev)); t_prev = t_now; } } while (0)
+#define WH_COUNT(slot, n) do { if (threadIdx.x == 0) atomicAdd(&fk_wh_phase[slot], (unsigned long long)(n)); } while (0)
+#else
+#define WH_CLOCK_START() do { } while (0)
+#define WH_CLOCK(slot) do { } while (0)
+#define WH_COUNT(slot, n) do { } while (0)
+#endif
+
 template <int NT>
 struct WholeShared {
     static constexpr int NW = NT / 64, CAP = NT * WH_ITEMS;
@@ -74,6 +87,7 @@ resample_whole_kernel(const WholeArgs a)
     const double *u_str = STRATIFIED ? a.u + (long)f * Np : nullptr;
     const double Nd = (double)Np, halfNd = 0.5 * Nd;
     const int j0 = tid * WH_ITEMS;
+    WH_CLOCK_START();
 
     // ---- weights: eight consecutive ones per thread, straight from HBM into registers (padding: +0.0) ----
     double w[WH_ITEMS];
@@ -104,6 +118,7 @@ resample_whole_kernel(const WholeArgs a)
     const double winc = wave_incl_sum(run);
     if (lane == 63) sh.wtot[wave] = winc;
     const int any_neg = __syncthreads_or(mn < 0.0 ? 1 : 0);                                   // (1)
+    WH_CLOCK(0);                                                           // weights landed, sums
     double before = __shfl_up(winc, 1, 64);
     if (lane == 0) before = 0.0;
     double S = 0.0;
@@ -120,7 +135,7 @@ resample_whole_kernel(const WholeArgs a)
     u64 pbase = 0, ptotal = 0;
     if (!literal) {
         // ---- clean / dirty, increments; their prefix sums over the workgroup --------------------------------
-        wh_classify(w, before, run, j0, Np, th);
+        wh_classify(w, before, j0, Np, th);
         const int dincl = wave_incl_sum_i32(th.ndirty);
         const u64 pincl = wave_incl_sum_u64(th.psum);
         if (lane == 63) {
@@ -128,6 +143,7 @@ resample_whole_kernel(const WholeArgs a)
             sh.ptot[wave] = pincl;
         }
         __syncthreads();                                                                      // (2)
+        WH_CLOCK(1);                                                       // classification + scans
         dbase = dincl - th.ndirty;
         pbase = pincl - th.psum;
         FK_UNROLL for (int wv = 0; wv < NW; ++wv) {
@@ -145,10 +161,13 @@ resample_whole_kernel(const WholeArgs a)
     if (!literal) {
         wh_lists(w, th, dbase, pbase, sh.seg_e, sh.d_w, sh.d_ps);
         __syncthreads();                                                                      // (3)
-        if (wh_claims_bad(th, dbase, sh.seg_e)) sh.fail = 1;
-        // ---- the chain over the segments (wave 0; lane l holds segment b0 + l and dirty element b0 + l): what does
-        // not depend on the running sum is prepared by the lanes in parallel, the serial part is two dependent fp64
-        // adds per segment (fk_resample_whole.hpp, wh_chain_segment) --------------------------------------------------
+        WH_CLOCK(2);                                                       // lists
+        if (th.overflow || wh_claims_bad(th, dbase, sh.seg_e)) sh.fail = 1;
+        // ---- the chain over the segments (wave 0; lane l holds segment b0 + l and dirty element b0 + l).  The serial
+        // part is kept to what IS serial -- two dependent fp64 adds per segment, their operands fetched from the owning
+        // lane -- because a lone wave issues one instruction every 4-8 clocks: everything else (the segment's increment
+        // sum as a double, the check that the running sum enters and leaves the segment in the claimed binade, the
+        // running sum behind the dirty element) is done by the lanes in parallel before and after it -------------------
         if (wave == 0) {
             double c = 0.0;
             int fail = 0;
@@ -161,32 +180,29 @@ resample_whole_kernel(const WholeArgs a)
                 sg.ps0 = 0;
                 if (me <= D) sg = wh_segment(me, D, ptotal, sh.seg_e, sh.d_ps);
                 const double my_w = me < D ? sh.d_w[me < WH_DMAX ? me : 0] : 0.0;
-                fail |= sg.bad ? 1 : 0;
-                double r_c = 0.0, r_dcs = 0.0;
+                double r_c = 0.0;
                 const int cnt = D + 1 - b0 < 64 ? D + 1 - b0 : 64;
-                for (int r = 0; r < cnt; ++r) {                            // uniform
+                for (int r = 0; r < cnt; ++r) {                            // uniform, serial
                     const double add = lane_bcast(sg.add, r);
-                    const double wr = lane_bcast(my_w, r);
-                    const int xf = __builtin_amdgcn_readlane(sg.xf, r);
+                    const double wr = lane_bcast(my_w, r);                 // (+0.0 behind the last segment: c + 0 = c)
                     if (lane == r) r_c = c;
-                    bool fl = false;
-                    c = wh_chain_segment(c, add, xf, fl);
-                    fail |= fl ? 1 : 0;
-                    if (b0 + r < D) {
-                        c = c + wr;                                        // the real IEEE add of the dirty element
-                        if (lane == r) r_dcs = c;
-                    }
+                    c = (c + add) + wr;        // exact add of the segment's increments, real IEEE add of the dirty element
                 }
                 if (me <= D) {
+                    bool fl = sg.bad;
+                    const double after = wh_chain_segment(r_c, sg.add, sg.xf, fl);     // the same add, now with its checks
+                    fail |= fl ? 1 : 0;
                     sh.seg_c[me] = r_c;
                     sh.seg_ps0[me] = sg.ps0;
-                    if (me < D) sh.d_cs[me] = r_dcs;
+                    if (me < D) sh.d_cs[me] = after + my_w;
                 }
             }
             if (__builtin_amdgcn_ballot_w64(fail != 0) != 0 && lane == 0) sh.fail = 1;
             if (lane == 0) sh.carry_out = c;
         }
         __syncthreads();                                                                      // (4)
+        WH_CLOCK(3);                                                       // claims check + chain
+        WH_COUNT(10, D);
         literal = sh.fail != 0;                                            // uniform
     }
     if (literal) {
@@ -207,10 +223,11 @@ resample_whole_kernel(const WholeArgs a)
         px.halfNd = halfNd;
         px.u_sys = u_sys;
         px.u_str = u_str;
-        wh_boundaries<STRATIFIED>(th, j0, Np, dbase, pbase, sh.seg_e, sh.seg_c, sh.seg_ps0, sh.d_cs, sh.carry_out, px, nb);
+        wh_boundaries<STRATIFIED>(th, dbase, pbase, sh.seg_e, sh.seg_c, sh.seg_ps0, sh.d_cs, px, nb);
     }
     sh.nlast[tid] = nb[WH_ITEMS - 1];
     __syncthreads();                                                                          // (5)
+    WH_CLOCK(4);                                                           // boundaries
     int nprev = tid == 0 ? 0 : sh.nlast[tid - 1];
     const int u_hi = __builtin_amdgcn_readfirstlane(sh.nlast[NT - 1]);     // = n(carry-out): slots [0, u_hi) get an index
     // window position p = slot + sft: with sft = (address of slot 0 in ints) mod 4 a thread's two quads are 16-byte
@@ -226,6 +243,7 @@ resample_whole_kernel(const WholeArgs a)
         }
     }
     __syncthreads();                                                                          // (6)
+    WH_CLOCK(5);                                                           // heads
     int x[WH_ITEMS];
     FK_UNROLL for (int g = 0; g < WH_ITEMS / 4; ++g) {
         const i32x4 t = *reinterpret_cast<const i32x4 *>(&sh.win[j0 + 4 * g]);
@@ -238,6 +256,7 @@ resample_whole_kernel(const WholeArgs a)
     const int wincl = wave_incl_max(x[WH_ITEMS - 1]);
     if (lane == 63) sh.wmax[wave] = wincl;
     __syncthreads();                                                                          // (7)
+    WH_CLOCK(6);                                                           // window read + scan
     int pre = __shfl_up(wincl, 1, 64);
     if (lane == 0) pre = -1;
     FK_UNROLL for (int wv = 0; wv < NW; ++wv) {
@@ -260,6 +279,8 @@ resample_whole_kernel(const WholeArgs a)
         }
     }
     if (tid == 0 && a.status) a.status[f] = u_hi < Np ? ST_OVERRUN : 0;
+    WH_CLOCK(7);                                                           // stores issued
+    WH_COUNT(11, 1);
 }
 
 // Np <= 8192: one workgroup of 256 / 512 / 1024 threads per filter (8 weights per thread)
@@ -301,3 +322,14 @@ int whole_launch(bool stratified, int64_t Fn, int64_t Np, const double *w, const
 }
 
 }  // namespace fk
+
+#ifdef FK_OP_CLOCKS
+extern "C" int fk_debug_wh_phases(unsigned long long *out)      // only in the instrumented build (tools/op_phase.py --whole)
+{
+    unsigned long long host[16];
+    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(fk::fk_wh_phase), sizeof(host)) != hipSuccess) return FK_ERR_LAUNCH;
+    for (int q = 0; q < 16; ++q) out[q] = host[q];
+    memset(host, 0, sizeof(host));
+    return hipMemcpyToSymbol(HIP_SYMBOL(fk::fk_wh_phase), host, sizeof(host)) == hipSuccess ? FK_OK : FK_ERR_LAUNCH;
+}
+#endif

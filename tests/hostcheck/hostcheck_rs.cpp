@@ -85,9 +85,10 @@ static int whole_resample(int NT, int Np, const double *wts, const double *u, do
     for (int t = 0; t < NT; ++t) {
         double w8[WH_ITEMS];
         for (int q = 0; q < WH_ITEMS; ++q) w8[q] = w[t * WH_ITEMS + q];
-        wh_classify(w8, before[t], tsum[t], t * WH_ITEMS, Np, th[t]);
+        wh_classify(w8, before[t], t * WH_ITEMS, Np, th[t]);
         dbase[t] = D;
         pbase[t] = ptotal;
+        if (th[t].overflow) { info[0] = -1; info[1] = 1; return 0; }
         D += th[t].ndirty;
         ptotal += th[t].psum;
         info[3] += th[t].uniform ? 1 : 0;
@@ -121,8 +122,7 @@ static int whole_resample(int NT, int Np, const double *wts, const double *u, do
         int n8[WH_ITEMS];
         for (int q = 0; q < WH_ITEMS; ++q) w8[q] = w[t * WH_ITEMS + q];
         wh_cumsums(th[t], t * WH_ITEMS, Np, dbase[t], pbase[t], seg_e.data(), seg_c.data(), seg_ps0.data(), d_cs.data(), carry_out, cs);
-        wh_boundaries<STRATIFIED>(th[t], t * WH_ITEMS, Np, dbase[t], pbase[t], seg_e.data(), seg_c.data(), seg_ps0.data(),
-                                  d_cs.data(), carry_out, px, n8);
+        wh_boundaries<STRATIFIED>(th[t], dbase[t], pbase[t], seg_e.data(), seg_c.data(), seg_ps0.data(), d_cs.data(), px, n8);
         for (int q = 0; q < WH_ITEMS; ++q) {
             const int j = t * WH_ITEMS + q;
             if (j < Np) cs_out[j] = cs[q];

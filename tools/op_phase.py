@@ -23,7 +23,7 @@ def build(extra, tag):
     os.makedirs(os.path.join(CSRC, "exp_build"), exist_ok=True)
     cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
            "-fno-gpu-rdc", "-DFK_OP_CLOCKS"] + extra + ["-o", LIB % tag, os.path.join(CSRC, "resample_onepass.hip"),
-           os.path.join(CSRC, "resample_kernels.hip"), "-x", "hip", os.path.join(CSRC, "fk_host.cpp")]
+           os.path.join(CSRC, "resample_kernels.hip"), os.path.join(CSRC, "resample_whole.hip"), "-x", "hip", os.path.join(CSRC, "fk_host.cpp")]
     subprocess.check_call(cmd, cwd=CSRC)
     print("built", LIB % tag)
 
@@ -74,10 +74,50 @@ def run(shapes, iters, strat, tag):
                           "dirty_per_general_chunk": round(v[0] / max(v[8], 1), 2)}), flush=True)
 
 
+WH_PHASES = ["weights+sums", "classify+scans", "lists", "check+chain", "boundaries", "heads", "window scan", "stores"]
+
+
+def run_whole(shapes, iters, strat, tag):
+    """resample_whole_kernel (Np <= 8192): ticks between its seven barriers, thread 0 of every workgroup"""
+    import torch
+    lib = ctypes.CDLL(LIB % tag)
+    dev = torch.device("cuda")
+    for shape in shapes.split(","):
+        Fn, Np = (int(v) for v in shape.split("x"))
+        g = torch.Generator(device=dev)
+        g.manual_seed(1)
+        w = torch.rand((Fn, Np), generator=g, device=dev, dtype=torch.float64)
+        w /= w.sum(dim=1, keepdim=True)
+        u = torch.rand((Fn, Np) if strat else (Fn,), generator=g, device=dev, dtype=torch.float64)
+        idx = torch.empty((Fn, Np), dtype=torch.int32, device=dev)
+        p = ctypes.c_void_p
+        fn = lib.fk_resample_stratified_f64 if strat else lib.fk_resample_systematic_f64
+
+        def go():
+            rc = fn(ctypes.c_int64(Fn), ctypes.c_int64(Np), p(w.data_ptr()), p(u.data_ptr()), p(idx.data_ptr()), p(0), p(0),
+                    ctypes.c_size_t(0), p(0))
+            assert rc == 0, rc
+        out = (ctypes.c_ulonglong * 16)()
+        go()
+        torch.cuda.synchronize()
+        lib.fk_debug_wh_phases(out)          # clear
+        for _ in range(iters):
+            go()
+        torch.cuda.synchronize()
+        assert lib.fk_debug_wh_phases(out) == 0
+        v = [int(x) for x in out]
+        nwg = float(v[11]) or 1.0
+        print(json.dumps({"tag": tag, "kernel": "resample_whole_kernel", "shape": shape, "stratified": strat,
+                          "ticks_per_workgroup": {k: round(t / nwg, 1) for k, t in zip(WH_PHASES, v[:8])},
+                          "total_ticks_per_workgroup": round(sum(v[:8]) / nwg, 1), "dirty_per_vector": round(v[10] / nwg, 2),
+                          "workgroups": int(nwg)}), flush=True)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--build", action="store_true")
     ap.add_argument("--run", action="store_true")
+    ap.add_argument("--whole", action="store_true", help="with --run: the phases of resample_whole_kernel (shapes with Np <= 8192)")
     ap.add_argument("--shapes", default="125x8000000,1000x8000,8x8000000")
     ap.add_argument("--iters", type=int, default=3)
     ap.add_argument("--stratified", type=int, default=0)
@@ -86,7 +126,9 @@ if __name__ == "__main__":
     a = ap.parse_args()
     if a.build:
         build(["-D" + d for d in a.define], a.tag)
-    if a.run:
+    if a.run and a.whole:
+        run_whole(a.shapes, a.iters, a.stratified, a.tag)
+    elif a.run:
         run(a.shapes, a.iters, a.stratified, a.tag)
     if not (a.build or a.run):
         ap.print_help()
