@@ -44,16 +44,32 @@ constexpr double WH_SANE_LO = 0x1p-900, WH_SANE_HI = 0x1p900;
 
 typedef unsigned long long wh_u64;
 
-// integer-valued double in [0, 2^64) <-> wh_u64, exactly, without the library's range handling: two 32-bit halves
-FK_HD wh_u64 wh_to_u64(double v)
+// The arithmetic below avoids the quarter-rate fp64 instructions of gfx950 (v_ldexp_f64, v_floor_f64, v_cvt_*: 16
+// clocks per wave against 4 for an add / mul / fma) -- a first cut built on them spent 9k of its 32k clocks per filter
+// classifying --: scalings are multiplications by a power of two assembled from its exponent field, roundings and
+// integer conversions are additions of 2^52 (every integer involved is below 2^52: see wh_classify / wh_segment).
+constexpr double WH_M52 = 0x1p52;
+FK_HD double wh_pow2(int k)                            // 2^k, -1022 <= k <= 1023
 {
-    const double hi = floor(v * 0x1p-32);
-    const double lo = v - hi * 0x1p32;                 // exact: [0, 2^32)
-    return ((wh_u64)(unsigned)hi << 32) | (wh_u64)(unsigned)lo;
+    return bits_to_double((wh_u64)(unsigned)(k + 1023) << 52);
 }
-FK_HD double wh_to_f64(wh_u64 v)                       // exact for v < 2^53
+FK_HD wh_u64 wh_to_u64(double v)                       // integer-valued v in [0, 2^52)
 {
-    return (double)(unsigned)(v >> 32) * 0x1p32 + (double)(unsigned)v;
+    return double_to_bits(v + WH_M52) & 0x000fffffffffffffull;
+}
+FK_HD double wh_to_f64(wh_u64 v)                       // v < 2^52
+{
+    return bits_to_double(v | 0x4330000000000000ull) - WH_M52;
+}
+// the increment of weight w where the running sum has ulp 2^e (s = 2^-e): r = w / ulp rounded to the nearest integer
+// (= floor(w / ulp + 1/2) of fk_exact_scan.hpp's fast_inc away from ties).  ok = no exact half-ulp tie and r < 2^52 (a
+// valid increment always is: C >= 2^52 and C + inc < 2^53; above 2^52 the rounding trick returns garbage >= 2^52).
+FK_HD bool wh_increment(double w, double s, double &r)
+{
+    const double t = w * s;                            // exact (or a gradual underflow far below 1/2)
+    r = (t + WH_M52) - WH_M52;                         // nearest integer (ties to even), exact for t < 2^52
+    const double d = t - r;                            // exact: |d| <= 1/2
+    return fabs(d) != 0.5 && r < WH_M52;
 }
 
 struct WhThread {
@@ -70,12 +86,10 @@ struct WhThread {
 FK_HD void wh_classify_element(double w, double lo, double hi, bool in, int q, WhThread &t)
 {
     const bool known = lo > WH_SANE_LO && hi < WH_SANE_HI && ulp_exp(lo) == ulp_exp(hi);
-    const int e = ulp_exp(lo);
-    const double x = scale2(w, -e) + 0.5;
-    const double i = floor(x);
+    const int e = known ? ulp_exp(lo) : 0;
+    double i;
+    const bool ok = wh_increment(w, wh_pow2(-e), i) && known;
     const bool zero = w == 0.0;
-    // no half-ulp tie, and an increment below 2^52 (a valid one always is: C >= 2^52 and C + inc < 2^53)
-    const bool ok = known && i != x && i < 0x1p52;
     const bool claim = in && !zero && ok;
     if (claim) t.claims |= 1u << q;
     if (in && !zero && !ok) t.dirty |= 1u << q;
@@ -92,11 +106,11 @@ FK_HD bool wh_classify_half(const double (&w)[WH_ITEMS], double before, double h
     if (one) {
         // the running sum stays in ONE binade across the four adds: the bounds of every element lie inside [tlo, thi]
         const int e = ulp_exp(tlo);
+        const double sc = wh_pow2(-e);
         FK_UNROLL for (int q = Q0; q < Q0 + 4; ++q) {
-            const double x = scale2(w[q], -e) + 0.5;
-            const double i = floor(x);
+            double i;
+            const bool ok = wh_increment(w[q], sc, i);
             const bool zero = w[q] == 0.0;
-            const bool ok = i != x && i < 0x1p52;
             const bool in = j0 + q < len;
             const bool claim = in && !zero && ok;
             if (claim) t.claims |= 1u << q;
@@ -127,9 +141,9 @@ FK_HD void wh_classify(const double (&w)[WH_ITEMS], double before, int j0, int l
     const bool one0 = wh_classify_half<0>(w, before, h0, j0, len, t);
     const bool one1 = wh_classify_half<4>(w, before + h0, h1, j0, len, t);
     t.uniform = one0 && one1 && t.eq[0] == t.eq[4] && t.dirty == 0;
-    // the thread's increment sum (wrapping 64-bit), segment by segment: the increments of ONE segment are integers
-    // below 2^52 whose double sum is exact below 2^53 -- and a sum that is not stays >= 2^53 after rounding (monotone),
-    // which no valid segment holds: `overflow` fails the round.  Segments end at the thread's dirty elements; the
+    // the thread's increment sum (wrapping 64-bit), segment by segment: a valid segment starts at C >= 2^52 and ends
+    // below 2^53, so its increments add up to less than 2^52 -- exactly, as doubles; a sum that reaches 2^52 stays there
+    // after rounding (monotone): `overflow` fails the round.  Segments end at the thread's dirty elements; the
     // increments of different segments (other binades) do not add up to anything bounded and meet as integers.
     t.overflow = false;
     t.psum = 0;
@@ -139,15 +153,15 @@ FK_HD void wh_classify(const double (&w)[WH_ITEMS], double before, int j0, int l
     } else {
         FK_UNROLL for (int q = 0; q < WH_ITEMS; ++q) {
             if (t.dirty & (1u << q)) {
-                t.overflow = t.overflow || !(acc < 0x1p53);
-                t.psum += wh_to_u64(acc < 0x1p53 ? acc : 0.0);
+                t.overflow = t.overflow || !(acc < WH_M52);
+                t.psum += wh_to_u64(acc < WH_M52 ? acc : 0.0);
                 acc = 0.0;
             }
             acc += t.inc[q];
         }
     }
-    t.overflow = t.overflow || !(acc < 0x1p53);
-    t.psum += wh_to_u64(acc < 0x1p53 ? acc : 0.0);
+    t.overflow = t.overflow || !(acc < WH_M52);
+    t.psum += wh_to_u64(acc < WH_M52 ? acc : 0.0);
 #if defined(__HIP_DEVICE_COMPILE__)
     t.ndirty = __builtin_popcount(t.dirty);
 #else
@@ -174,7 +188,7 @@ FK_HD void wh_lists(const double (&w)[WH_ITEMS], const WhThread &t, int dbase, w
             acc += t.inc[q];
         }
         if (t.dirty & (1u << q)) {
-            ps += wh_to_u64(acc < 0x1p53 ? acc : 0.0);
+            ps += wh_to_u64(acc < WH_M52 ? acc : 0.0);
             acc = 0.0;
             d_w[r] = w[q];
             d_ps[r] = ps;
@@ -209,11 +223,11 @@ FK_HD WhSeg wh_segment(int r, int D, wh_u64 ptotal, const int *seg_e, const wh_u
     const wh_u64 end = r < D ? d_ps[r] : ptotal;
     const wh_u64 start = r >= 1 ? d_ps[r - 1] : 0;
     const int e = seg_e[r];
-    const wh_u64 I = end - start;                                          // (wrapping; < 2^52 for a segment that passes)
+    const wh_u64 I = end - start;                                          // (wrapping; < 2^52 for a valid segment)
     const bool claim = e != WH_NONE;
     WhSeg s;
-    s.bad = (claim && !(I < (1ull << 53))) || (!claim && I != 0);
-    s.add = claim ? scale2(wh_to_f64(I), e) : 0.0;
+    s.bad = (claim && !(I < (1ull << 52))) || (!claim && I != 0);
+    s.add = (claim && !s.bad) ? wh_to_f64(I) * wh_pow2(e) : 0.0;
     s.xf = claim ? e + 1075 : -1;
     s.ps0 = start;
     return s;
@@ -276,8 +290,8 @@ FK_HD WhSegPos<STRATIFIED> wh_seg_pos(int r, const int *seg_e, const double *seg
     const double c = seg_c[r];
     const bool claim = s.e != WH_NONE;
     // a segment of zeros claims no binade: its elements all have cs = c, the estimate is the constant N c - u
-    s.C0 = claim ? scale2(c, -s.e) : c;
-    s.Nu = claim ? scale2(px.Nd, s.e) : 0.0;
+    s.C0 = claim ? c * wh_pow2(-s.e) : c;
+    s.Nu = claim ? px.Nd * wh_pow2(s.e) : 0.0;
     s.K = fma(s.C0, claim ? s.Nu : px.Nd, STRATIFIED ? 0.0 : -px.u_sys);
     return s;
 }
@@ -310,14 +324,20 @@ FK_HD void wh_boundaries(const WhThread &t, int dbase, wh_u64 pbase, const int *
         } else {
             Et += t.inc[q];                                                // exact: C0 + Et < 2^53 (the chain checked it)
             const double est = fma(Et, sp.Nu, sp.K);
-            const double fl = floor(est), fr = est - fl;
-            bool sure = fr > N_BOUNDARY_EPS && fr < 1.0 - N_BOUNDARY_EPS && est < px.Nd;
-            n = (int)fl + 1;
+            // floor(est) + 1 without v_floor / v_cvt: a = est + 1.5 2^52 holds the nearest integer of est in its low
+            // mantissa bits (two's complement: est > -1 here), d = est - nearest is exact
+            const double a = est + 0x1.8p52;
+            const double d = est - (a - 0x1.8p52);
+            const int ri = (int)(unsigned)double_to_bits(a);
+            bool sure = fabs(d) > N_BOUNDARY_EPS && est < px.Nd;           // est within eps of an integer: the exact tests
+            n = ri + (d < 0.0 ? 0 : 1);
             if (STRATIFIED) {
-                const double uf = px.u_str[(est < px.Nd && est >= 0.0) ? (int)fl : 0];
+                const int fl = ri - (d < 0.0 ? 1 : 0);
+                const double fr = d < 0.0 ? d + 1.0 : d;                   // est - floor(est), exact
+                const double uf = px.u_str[(est < px.Nd && est >= 0.0) ? fl : 0];
                 const double gap = uf - fr;
                 sure = sure && est >= 0.0 && (gap > N_BOUNDARY_EPS || gap < -N_BOUNDARY_EPS);
-                n = (int)fl + (gap > 0.0 ? 0 : 1);
+                n = fl + (gap > 0.0 ? 0 : 1);
             }
             if (!sure) {                                                   // rare
                 const double cs = sp.e != WH_NONE ? scale2(sp.C0 + Et, sp.e) : sp.C0;
@@ -326,6 +346,59 @@ FK_HD void wh_boundaries(const WhThread &t, int dbase, wh_u64 pbase, const int *
         }
         nb[q] = n;
     }
+}
+
+// ---- step 0: the boundaries from the PLAIN prefix sums alone -------------------------------------------------------------
+// n(c) = #{ i : pos_i < c } is a step function of c, and the slot boundary of weight j only asks on which side of the
+// positions cs_j lies.  The plain prefix sum a_j (any summation order) and numpy's sequential cs_j are both within
+// gamma_n = n 2^-53 of the real sum of the same non-negative terms, so |a_j - cs_j| <= 2^-39 a_j for n <= 8192: in
+// slots, N a_j 2^-39 <= 2^-26 for a normalised vector.  Unless the estimate N a_j - u sits within `band` of an integer
+// -- band = 2^-36 N a_j + 2^-30: eight times that bound plus every rounding of the estimate and of the positions
+// themselves (fl(fl(u + i) / N): 2^-40 slots for N <= 2^15) -- its ceiling IS n(cs_j): no exact cumulative sum is needed.
+// For 8000 normalised weights one vector in ~500 holds an element inside the band; such a vector (and only such a
+// vector) runs the exact round above.  Returns the mask of elements inside the band.
+//   Stratified (pos_i = fl(fl(u_i + i) / N)): with f = floor(N c), slot f - 1 is below c, slot f + 1 is not, slot f is
+// iff u_f < frac(N c); an estimate within the band of an integer k leaves f = k - 1 or k open, but n = k either way
+// unless u_{k-1} or u_k is itself within the band of 1 or 0 -- a normalised vector ends exactly there (N c ~ N).
+template <bool STRATIFIED>
+FK_HD unsigned wh_approx_boundaries(const double (&w)[WH_ITEMS], double before, const WhPos<STRATIFIED> &px, int (&nb)[WH_ITEMS])
+{
+    unsigned unsure = 0;
+    double a = before;
+    FK_UNROLL for (int q = 0; q < WH_ITEMS; ++q) {
+        a += w[q];                                                         // plain inclusive prefix
+        const double pe = px.Nd * a;                                       // N a_j >= 0
+        const double est = STRATIFIED ? pe : pe - px.u_sys;
+        const double band = fma(pe, 0x1p-36, 0x1p-30);
+        const bool past = !(est < px.Nd);                                  // every position is below a_j: n = Np
+        // nearest integer k of est without v_floor / v_cvt (-1 < est < Nd < 2^31 where it is used)
+        const double m = est + 0x1.8p52;
+        const double d = est - (m - 0x1.8p52);                             // exact, |d| <= 1/2
+        const int k = (int)(unsigned)double_to_bits(m);
+        const bool clear = fabs(d) > band;                                 // est is not within the band of an integer
+        bool sure = clear;
+        int n = k + (d < 0.0 ? 0 : 1);                                     // systematic: the ceiling of est
+        if (STRATIFIED) {
+            const int fl = k - (d < 0.0 ? 1 : 0);
+            const double fr = d < 0.0 ? d + 1.0 : d;
+            const double uf = px.u_str[past ? 0 : fl];
+            const double gap = uf - fr;
+            sure = clear && (gap > band || gap < -band);
+            n = fl + (gap > 0.0 ? 0 : 1);
+            if (!clear && !past) {                                         // rare: est ~ k
+                const double u_lo = k >= 1 ? px.u_str[k - 1] : 0.0, u_hi = k < px.Np ? px.u_str[k] : 1.0;
+                sure = u_lo < 1.0 - 2.0 * band && u_hi > 2.0 * band;
+                n = k;
+            }
+        }
+        if (past) {
+            n = px.Np;
+            sure = true;
+        }
+        unsure |= sure ? 0u : (1u << q);
+        nb[q] = n;
+    }
+    return unsure;
 }
 
 // the cumulative sums themselves (tests only: the kernel goes straight to the boundaries)

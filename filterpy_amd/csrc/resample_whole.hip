@@ -31,7 +31,7 @@
 namespace fk {
 
 struct WholeArgs {
-    int Np;
+    int Np, force_exact;
     const double *w, *u;
     int32_t *idx, *status;
 };
@@ -129,10 +129,30 @@ resample_whole_kernel(const WholeArgs a)
     }
     bool literal = any_neg || !(S < 0x1p1000);                             // negative, NaN, Inf or absurdly large: uniform
 
+    WhPos<STRATIFIED> px;
+    px.Np = Np;
+    px.Nd = Nd;
+    px.halfNd = halfNd;
+    px.u_sys = u_sys;
+    px.u_str = u_str;
+    // ---- step 0: the slot boundaries from the plain prefix sums (fk_resample_whole.hpp, wh_approx_boundaries): exact unless
+    // an estimate lies within the error band of an integer -- one vector of 8000 weights in ~500 --, and only then does the
+    // workgroup run the exact round below.  FK_WHOLE_EXACT=1 (a.force_exact) runs it for every vector (tests, A/B timing).
+    int nb[WH_ITEMS];
+    bool exact = true;
+    if (!literal) {
+        const unsigned unsure = wh_approx_boundaries<STRATIFIED>(w, before, px, nb);
+        sh.nlast[tid] = nb[WH_ITEMS - 1];
+        exact = __syncthreads_or((unsure != 0 || a.force_exact) ? 1 : 0) != 0;                // (A) (also publishes nlast)
+        WH_CLOCK(8);                                                       // plain-prefix boundaries
+        WH_COUNT(12, exact ? 1 : 0);
+    }
+
     int D = 0;
     WhThread th;
     int dbase = 0;
     u64 pbase = 0, ptotal = 0;
+    if (exact) {
     if (!literal) {
         // ---- clean / dirty, increments; their prefix sums over the workgroup --------------------------------
         wh_classify(w, before, j0, Np, th);
@@ -215,19 +235,11 @@ resample_whole_kernel(const WholeArgs a)
     }
 
     // ---- cumulative sums -> slot boundaries: weight j owns the slots [n_{j-1}, n_j), n_j = n(cs_j) ------------------
-    int nb[WH_ITEMS];
-    {
-        WhPos<STRATIFIED> px;
-        px.Np = Np;
-        px.Nd = Nd;
-        px.halfNd = halfNd;
-        px.u_sys = u_sys;
-        px.u_str = u_str;
-        wh_boundaries<STRATIFIED>(th, dbase, pbase, sh.seg_e, sh.seg_c, sh.seg_ps0, sh.d_cs, px, nb);
-    }
-    sh.nlast[tid] = nb[WH_ITEMS - 1];
+    wh_boundaries<STRATIFIED>(th, dbase, pbase, sh.seg_e, sh.seg_c, sh.seg_ps0, sh.d_cs, px, nb);
+    sh.nlast[tid] = nb[WH_ITEMS - 1];       // (everybody read step 0's values? nobody has: they are read behind the next barrier)
     __syncthreads();                                                                          // (5)
     WH_CLOCK(4);                                                           // boundaries
+    }   // exact
     int nprev = tid == 0 ? 0 : sh.nlast[tid - 1];
     const int u_hi = __builtin_amdgcn_readfirstlane(sh.nlast[NT - 1]);     // = n(carry-out): slots [0, u_hi) get an index
     // window position p = slot + sft: with sft = (address of slot 0 in ints) mod 4 a thread's two quads are 16-byte
@@ -292,6 +304,8 @@ int whole_launch(bool stratified, int64_t Fn, int64_t Np, const double *w, const
     if (Fn > 0x7fffffffL || !whole_supported(Np)) return FK_ERR_UNSUPPORTED;
     WholeArgs a;
     a.Np = (int)Np;
+    const char *fe = getenv("FK_WHOLE_EXACT");
+    a.force_exact = (fe && fe[0] == '1') ? 1 : 0;
     a.w = w;
     a.u = u;
     a.idx = idx;

@@ -46,9 +46,9 @@ int hc_pos_ge(double a, double c, double Nd) { return fk::pos_ge(a, c, Nd, 0.5 *
 // the per-thread pieces are the kernel's own functions, fk_resample_whole.hpp; the chain runs in its serial form and the
 // emission is a plain fill): cumulative sums, slot boundaries, indices.  info[0] = dirty elements, info[1] = 1 when the
 // round declined (the kernel then runs the reference's loop literally), info[2] = last boundary (slots filled),
-// info[3] = threads on the one-fma boundary path.
+// info[3] = uniform threads, info[4] = 1 when the plain prefix sums alone answered.
 template <bool STRATIFIED>
-static int whole_resample(int NT, int Np, const double *wts, const double *u, double *cs_out, int *idx_out, int *info)
+static int whole_resample(int NT, int Np, const double *wts, const double *u, double *cs_out, int *idx_out, int *info, int mode)
 {
     using namespace fk;
     if (Np > NT * WH_ITEMS) return -1;
@@ -75,6 +75,38 @@ static int whole_resample(int NT, int Np, const double *wts, const double *u, do
         double b = lane_excl[t];
         for (int wv = 0; wv < t / 64; ++wv) b += wtot[wv];
         before[t] = b;
+    }
+    WhPos<STRATIFIED> px;
+    px.Np = Np;
+    px.Nd = (double)Np;
+    px.halfNd = 0.5 * px.Nd;
+    px.u_sys = STRATIFIED ? 0.0 : u[0];
+    px.u_str = STRATIFIED ? u : nullptr;
+    std::vector<int> nb((size_t)NT * WH_ITEMS);
+    // step 0: boundaries from the plain prefix sums; mode 1 = stop here when no element is inside the band (the kernel's
+    // common path: cs_out is not produced), mode 0 = always run the exact round
+    info[4] = 0;
+    if (mode == 1) {
+        unsigned any = 0;
+        for (int t = 0; t < NT; ++t) {
+            double w8[WH_ITEMS];
+            int n8[WH_ITEMS];
+            for (int q = 0; q < WH_ITEMS; ++q) w8[q] = w[t * WH_ITEMS + q];
+            any |= wh_approx_boundaries<STRATIFIED>(w8, before[t], px, n8);
+            for (int q = 0; q < WH_ITEMS; ++q) nb[t * WH_ITEMS + q] = n8[q];
+        }
+        if (!any) {
+            info[0] = info[1] = info[3] = 0;
+            info[4] = 1;
+            int prev = 0;
+            for (int j = 0; j < NT * WH_ITEMS; ++j) {
+                for (int i = prev; i < nb[j] && i < Np; ++i) idx_out[i] = j;
+                if (nb[j] > prev) prev = nb[j];
+            }
+            for (int i = prev; i < Np; ++i) idx_out[i] = Np - 1;
+            info[2] = prev;
+            return 0;
+        }
     }
     std::vector<WhThread> th(NT);
     std::vector<int> dbase(NT);
@@ -110,13 +142,6 @@ static int whole_resample(int NT, int Np, const double *wts, const double *u, do
     double carry_out = 0.0;
     const bool ok = wh_chain_serial(D, ptotal, seg_e.data(), d_ps.data(), d_w.data(), seg_c.data(), seg_ps0.data(), d_cs.data(), &carry_out);
     if (bad || !ok) { info[1] = 1; return 0; }
-    WhPos<STRATIFIED> px;
-    px.Np = Np;
-    px.Nd = (double)Np;
-    px.halfNd = 0.5 * px.Nd;
-    px.u_sys = STRATIFIED ? 0.0 : u[0];
-    px.u_str = STRATIFIED ? u : nullptr;
-    std::vector<int> nb((size_t)NT * WH_ITEMS);
     for (int t = 0; t < NT; ++t) {
         double w8[WH_ITEMS], cs[WH_ITEMS];
         int n8[WH_ITEMS];
@@ -140,7 +165,10 @@ static int whole_resample(int NT, int Np, const double *wts, const double *u, do
     return 0;
 }
 
-extern "C" int hc_whole_resample(int NT, int Np, const double *wts, int stratified, const double *u, double *cs_out, int *idx_out, int *info)
+// mode 0: the exact round; mode 1: the kernel's order -- plain-prefix boundaries first, the exact round only for a vector with
+// an element inside the band (info[4] = 1: answered by the plain prefix sums alone)
+extern "C" int hc_whole_resample(int NT, int Np, const double *wts, int stratified, const double *u, double *cs_out, int *idx_out, int *info,
+                                 int mode)
 {
-    return stratified ? whole_resample<true>(NT, Np, wts, u, cs_out, idx_out, info) : whole_resample<false>(NT, Np, wts, u, cs_out, idx_out, info);
+    return stratified ? whole_resample<true>(NT, Np, wts, u, cs_out, idx_out, info, mode) : whole_resample<false>(NT, Np, wts, u, cs_out, idx_out, info, mode);
 }

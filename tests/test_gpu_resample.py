@@ -287,20 +287,59 @@ def test_local_kernel_every_route(Np, monkeypatch):
     _check_against_merge_loop(5, Np, kinds, range(5), monkeypatch, force=False)
 
 
+@pytest.mark.parametrize("exact", ["0", "1"])
 @pytest.mark.parametrize("eu", ["4", "8"])
 @pytest.mark.parametrize("Np", [1, 2, 3, 7, 100, 2047, 2048, 2049, 4095, 4096, 4097, 8000, 8189, 8190, 8191, 8192])
-def test_whole_vector_kernel_every_route(Np, eu, monkeypatch):
+def test_whole_vector_kernel_every_route(Np, eu, exact, monkeypatch):
     """resample_whole_kernel (round 3; the default up to 8192 weights: one workgroup takes the whole vector in one
     round): every weight family -- plus vectors the round declines (exact half-ulp ties by the hundred, running sums
     below 2^-900) and must hand to the literal loop --, every filter of a 5-filter call (odd Np: every filter at another
     16-byte phase, so the shifted window, the unshifted 4-byte-store fallback at Np > 8189 and the scalar weight loads
     all run), systematic and stratified, both register budgets of the 1024-thread instantiation, against the
-    reference's merge loop (C restatement)."""
+    reference's merge loop (C restatement).  exact = "0": the kernel as dispatched -- boundaries from the plain prefix
+    sums, the exact round only for a vector with an estimate inside the error band; "1" (FK_WHOLE_EXACT): the exact
+    round for every vector."""
     if eu == "8" and Np <= 4096:
         pytest.skip("one instantiation below 4097 weights")
     monkeypatch.setenv("FK_WHOLE_EU", eu)
+    monkeypatch.setenv("FK_WHOLE_EXACT", exact)
     kinds = [k for k in _FAMILIES + ("dyadic", "tiny") if not (k in ("negative", "nan") and Np < 8)]
     _check_against_merge_loop(5, Np, kinds, range(5), monkeypatch, force=False)
+
+
+def test_whole_vector_kernel_positions_on_cumulative_sums(monkeypatch):
+    """u chosen so that a position lands on / next to a cumulative sum (0 ... 2^-20 slots on either side): the estimates
+    inside the error band send their vector to the exact round, the others are decided by the plain prefix sums -- both
+    must give the merge loop's indices (the same construction runs on the host emulation, test_hostcheck_resample_math.py)"""
+    import torch
+    from filterpy_amd import _engine as E
+    from oracle import resample_oracle as ro
+    rs = np.random.RandomState(2024)
+    for Np in (8000, 8192, 4096, 1000):
+        Fn = 66
+        w = rs.rand(Fn, Np) ** 1.5
+        w /= w.sum(axis=1, keepdims=True)
+        deltas = [0.0] + [s * 2.0 ** -k for k in (48, 40, 33, 26, 20) for s in (1, -1)]
+        u = np.empty(Fn)
+        us = rs.rand(Fn, Np)
+        for f in range(Fn):
+            cs = np.cumsum(w[f])
+            j = rs.randint(Np // 4, Np - 1)
+            t = Np * cs[j]
+            i = int(np.floor(t))
+            v = (t - i) + deltas[f % len(deltas)]
+            u[f] = v if 0.0 <= v < 1.0 else 0.5
+            us[f, i] = u[f]
+        for strat, uu in ((0, u), (1, us)):
+            dw, du = E.dev(w), E.dev(uu)
+            idx = torch.full((Fn, Np), -7, dtype=torch.int32, device=dw.device)
+            st = torch.zeros(Fn, dtype=torch.int32, device=dw.device)
+            (E.resample_stratified if strat else E.resample_systematic)(Fn, Np, dw, du, idx, st)
+            got = idx.cpu().numpy()
+            for f in range(Fn):
+                ref, over = (ro.stratified_c if strat else ro.systematic_c)(w[f], uu[f])
+                ok = ref < Np
+                assert np.array_equal(got[f][ok], ref[ok]), (Np, strat, f)
 
 
 def test_whole_vector_kernel_many_filters(monkeypatch):

@@ -75,14 +75,14 @@ def test_stratified_boundaries_equal_the_division(lib, Np):
 
 
 # ---- resample_whole_kernel's arithmetic (filterpy_amd/csrc/fk_resample_whole.hpp), emulated thread by thread ----------
-def _whole(lib, NT, w, strat, u):
+def _whole(lib, NT, w, strat, u, mode=0):
     Np = len(w)
     w = np.ascontiguousarray(w, dtype=np.float64)
     u = np.ascontiguousarray(np.atleast_1d(u), dtype=np.float64)
-    cs, idx, info = np.full(Np, np.nan), np.full(Np, -7, dtype=np.int32), np.zeros(4, dtype=np.int32)
+    cs, idx, info = np.full(Np, np.nan), np.full(Np, -7, dtype=np.int32), np.zeros(5, dtype=np.int32)
     vp = ctypes.c_void_p
     rc = lib.hc_whole_resample(ctypes.c_int(NT), ctypes.c_int(Np), w.ctypes.data_as(vp), ctypes.c_int(int(strat)),
-                               u.ctypes.data_as(vp), cs.ctypes.data_as(vp), idx.ctypes.data_as(vp), info.ctypes.data_as(vp))
+                               u.ctypes.data_as(vp), cs.ctypes.data_as(vp), idx.ctypes.data_as(vp), info.ctypes.data_as(vp), ctypes.c_int(mode))
     assert rc == 0
     return cs, idx, info
 
@@ -192,3 +192,101 @@ def test_whole_vector_round_never_declines_ordinary_weights(lib):
         w /= w.sum()
         info = _whole(lib, NT, w, 0, 0.5)[2]
         assert not info[1], (k, Np, info)
+
+
+@pytest.mark.parametrize("Np", [1, 2, 7, 100, 2047, 2048, 4096, 8000, 8189, 8192])
+def test_plain_prefix_boundaries_equal_the_merge_loop(lib, Np):
+    """step 0 of resample_whole_kernel (wh_approx_boundaries): the slot boundaries from the PLAIN prefix sums, taken
+    whenever no estimate lies within the error band of an integer -- the indices must equal the reference's merge loop on
+    every weight family, systematic and stratified, and nearly every ordinary vector must be answered this way"""
+    from oracle import resample_oracle as ro
+    NT = 256 if Np <= 2048 else (512 if Np <= 4096 else 1024)
+    direct = total = 0
+    for kind in ("uniform", "heavy_tail", "zeros", "leading_zeros", "one_heavy", "ties", "sum_half", "unnormalised", "dyadic", "tiny"):
+        for seed in range(4):
+            rs = np.random.RandomState(7000 * Np + seed)
+            w = _whole_family(kind, Np, rs)
+            if not np.all(np.isfinite(w)):
+                continue
+            for strat in (0, 1):
+                u = rs.rand(Np) if strat else (rs.rand() if seed else 0.0)
+                cs, idx, info = _whole(lib, NT, w, strat, u, mode=1)
+                if info[1]:
+                    continue                                  # declined by the exact round: the literal loop answers
+                ref, over = (ro.stratified_c if strat else ro.systematic_c)(w, u)
+                ok = ref < Np
+                assert np.array_equal(idx[ok], ref[ok]), (kind, Np, seed, strat, int(info[4]))
+                assert (info[2] < Np) == (over > 0)
+                if kind in ("uniform", "heavy_tail", "sum_half", "unnormalised", "one_heavy") and seed:
+                    total += 1
+                    direct += int(info[4])
+    assert direct >= 0.9 * total, (direct, total)
+
+
+def test_plain_prefix_boundaries_on_many_vectors(lib):
+    """6000 ordinary vectors (4.4e7 weights): every one equal to the merge loop, and the share that needs the exact round
+    stays below 1 % (the kernel's cost rests on it)"""
+    from oracle import resample_oracle as ro
+    rs = np.random.RandomState(99)
+    exact_needed = 0
+    K = 6000
+    for k in range(K):
+        Np = (8000, 8192, 5000, 3000, 1000)[k % 5]
+        NT = 256 if Np <= 2048 else (512 if Np <= 4096 else 1024)
+        w = rs.rand(Np) ** (1 + k % 3)
+        w /= w.sum()
+        strat = k % 2
+        u = rs.rand(Np) if strat else rs.rand()
+        cs, idx, info = _whole(lib, NT, w, strat, u, mode=1)
+        assert not info[1]
+        exact_needed += 0 if info[4] else 1
+        ref, over = (ro.stratified_c if strat else ro.systematic_c)(w, u)
+        ok = ref < Np
+        assert np.array_equal(idx[ok], ref[ok]), (k, Np, strat, int(info[4]))
+    assert exact_needed < 0.01 * K, exact_needed
+
+
+def test_plain_prefix_boundaries_adversarial_positions(lib):
+    """the uniform u is CHOSEN so that a position lands on / next to a cumulative sum (distances 0, 2^-48 ... 2^-20 slots on
+    either side): whatever the plain-prefix pass decides by itself, and whatever it hands to the exact round, the indices
+    equal the merge loop's"""
+    from oracle import resample_oracle as ro
+    rs = np.random.RandomState(2024)
+    checked = direct = 0
+    for k in range(400):
+        Np = (8000, 8192, 4096, 1000)[k % 4]
+        NT = 256 if Np <= 2048 else (512 if Np <= 4096 else 1024)
+        w = rs.rand(Np) ** (1 + k % 2)
+        w /= w.sum()
+        cs = np.cumsum(w)
+        j = rs.randint(Np // 4, Np - 1)
+        t = Np * cs[j]
+        i = int(np.floor(t))
+        for delta in (0.0, 2.0 ** -48, -2.0 ** -48, 2.0 ** -40, -2.0 ** -40, 2.0 ** -33, -2.0 ** -33, 2.0 ** -26, -2.0 ** -26,
+                      2.0 ** -20, -2.0 ** -20):
+            u = (t - i) + delta                       # N cs_j - u = i - delta: position i sits delta slots from cs_j
+            if not (0.0 <= u < 1.0):
+                continue
+            c, idx, info = _whole(lib, NT, w, 0, u, mode=1)
+            assert not info[1]
+            ref, over = ro.systematic_c(w, u)
+            ok = ref < Np
+            assert np.array_equal(idx[ok], ref[ok]), (k, Np, j, delta, int(info[4]))
+            checked += 1
+            direct += int(info[4])
+        # stratified: the uniform of slot f = floor(N cs_j) placed on / next to frac(N cs_j)
+        us = rs.rand(Np)
+        for delta in (0.0, 2.0 ** -45, -2.0 ** -45, 2.0 ** -30, -2.0 ** -30, 2.0 ** -22, -2.0 ** -22):
+            us2 = us.copy()
+            v = (t - i) + delta
+            if not (0.0 <= v < 1.0):
+                continue
+            us2[i] = v
+            c, idx, info = _whole(lib, NT, w, 1, us2, mode=1)
+            assert not info[1]
+            ref, over = ro.stratified_c(w, us2)
+            ok = ref < Np
+            assert np.array_equal(idx[ok], ref[ok]), (k, Np, j, delta, int(info[4]))
+            checked += 1
+            direct += int(info[4])
+    assert checked > 5000 and 0 < direct < checked           # both outcomes occur: inside the band -> exact round, outside -> direct

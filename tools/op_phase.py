@@ -74,7 +74,7 @@ def run(shapes, iters, strat, tag):
                           "dirty_per_general_chunk": round(v[0] / max(v[8], 1), 2)}), flush=True)
 
 
-WH_PHASES = ["weights+sums", "classify+scans", "lists", "check+chain", "boundaries", "heads", "window scan", "stores"]
+WH_PHASES = ["weights+sums", "classify+scans", "lists", "check+chain", "boundaries", "heads", "window scan", "stores", "plain-prefix boundaries"]
 
 
 def run_whole(shapes, iters, strat, tag):
@@ -108,8 +108,9 @@ def run_whole(shapes, iters, strat, tag):
         v = [int(x) for x in out]
         nwg = float(v[11]) or 1.0
         print(json.dumps({"tag": tag, "kernel": "resample_whole_kernel", "shape": shape, "stratified": strat,
-                          "ticks_per_workgroup": {k: round(t / nwg, 1) for k, t in zip(WH_PHASES, v[:8])},
-                          "total_ticks_per_workgroup": round(sum(v[:8]) / nwg, 1), "dirty_per_vector": round(v[10] / nwg, 2),
+                          "ticks_per_workgroup": {k: round(t / nwg, 1) for k, t in zip(WH_PHASES, v[:9])},
+                          "total_ticks_per_workgroup": round(sum(v[:9]) / nwg, 1), "exact_rounds": int(v[12]),
+                          "dirty_per_exact_round": round(v[10] / max(v[12], 1), 2),
                           "workgroups": int(nwg)}), flush=True)
 
 
