@@ -65,6 +65,8 @@ struct OpDesc {
                     //          3 = carry-out only in `raw`)
     u64 raw;        // bits of the exact carry-out
     u64 raw_chk;    // ~raw: the pair is valid when raw_chk == ~raw
+    u64 exact2;     // speculation (round 3): state 1 = increment sum of the chunk at a SECOND ulp exponent (same packing)
+    u64 pad;
 };
 
 struct OpHead {
@@ -233,6 +235,75 @@ __device__ double lookback_exact(const OpDesc *d, int k, bool clean, int eu, int
             if (spin_fail(spins2, abort_word)) { ok = false; return 0.0; }
         }
     }
+}
+
+// ---- speculation (round 3) ---------------------------------------------------------------------------------------------------
+// Round 2's chunk walked a chain of dependent global round trips: chunk sum -> stage 1 (approximate carry-in: WHICH binade)
+// -> increments in that binade -> stage 2 (exact carry-in).  A published pair (ulp exponent e, increment sum I) is a
+// CONDITIONAL truth -- "if my chunk lies entirely in the binade with ulp 2^e, its adds raise the running sum by I ulps" -- and
+// publishing it needs no knowledge of the carry-in at all.  So a chunk GUESSES its binade from its own sum (the k chunks
+// before it weigh about k times as much), publishes the sums for the guess g and for g + 1 the moment its weights have
+// landed, and looks back ONCE: increment sums of the predecessors down to the nearest published exact carry-out.  If that
+// carry-out lies in binade g (or g + 1), every chunk in between published a sum for it, and carry-out + sums + the chunk's
+// own sum stays inside the binade, then -- running sums are monotone -- every one of those chunks lies entirely in that
+// binade, the conditional truths all apply, and the exact carry-in is an integer sum: verified with exact arithmetic, no
+// approximation involved.  Anything else (a guess that missed, a crossing, a tie, the start of a vector, garbage) is a
+// miss: the chunk takes round 2's two stages unchanged.  Wave 0 only.  which = 0 / 1: hit at g / g + 1, -1: miss.
+#ifndef FK_OP_SPEC_POLLS
+#define FK_OP_SPEC_POLLS 24
+#endif
+__device__ double lookback_spec(const OpDesc *d, int k, int g, double I0, double I1, bool v0, bool v1, int lane, int &which)
+{
+    which = -1;
+    double acc0 = 0.0, acc1 = 0.0;
+    bool ok0 = v0, ok1 = v1;
+    const int g9 = g & 511, h9 = (g + 1) & 511;
+    unsigned polls = 0;
+    for (int j = k - 1; j >= 0; j -= 64) {
+        const int jj = j - lane;
+        u64 e1, e2, rw, term;
+        for (;;) {
+            e1 = jj >= 0 ? ld_agent(&d[jj].exact) : (u64)3;               // before the vector: a carry-out nobody can use
+            e2 = jj >= 0 ? ld_agent(&d[jj].exact2) : (u64)0;
+            rw = jj >= 0 ? ld_agent(&d[jj].raw) : (u64)0;
+            term = __ballot((e1 & ST_MASK) >= 2);
+            const u64 unpub = __ballot((e1 & ST_MASK) == 0 && (e2 & ST_MASK) == 0);
+            const u64 below = term ? (term & (0 - term)) - 1 : ~(u64)0;   // lanes nearer than the nearest carry-out
+            if ((unpub & below) == 0) break;
+            if (++polls > FK_OP_SPEC_POLLS) return 0.0;                   // somebody is not speculating: do not wait here
+            __builtin_amdgcn_s_sleep(FK_OP_SLEEP);
+        }
+        const int L = term ? __builtin_ctzll(term) : 64;
+        const bool mine = lane < L;
+        const bool a0 = ((e1 & ST_MASK) == 1 && exact_eu9(e1) == g9), b0 = ((e2 & ST_MASK) == 1 && exact_eu9(e2) == g9);
+        const bool a1 = ((e1 & ST_MASK) == 1 && exact_eu9(e1) == h9), b1 = ((e2 & ST_MASK) == 1 && exact_eu9(e2) == h9);
+        const double m0 = a0 ? exact_C(e1) : (b0 ? exact_C(e2) : 0.0), m1 = a1 ? exact_C(e1) : (b1 ? exact_C(e2) : 0.0);
+        ok0 = ok0 && __ballot(mine && !(a0 || b0)) == 0;
+        ok1 = ok1 && __ballot(mine && !(a1 || b1)) == 0;
+        if (!ok0 && !ok1) return 0.0;
+        acc0 += lane_bcast(wave_incl_sum(mine ? m0 : 0.0), 63);            // integers: exact below 2^53 (checked at the end)
+        acc1 += lane_bcast(wave_incl_sum(mine ? m1 : 0.0), 63);
+        if (!term) continue;
+        // the carry-out: state 2 = (C, eu mod 512) in the word, the double itself in `raw` -- taken only if the two agree
+        // (they are separate stores: a stale `raw` shows as a mismatch), and the exponent comes from the double
+        const u64 tw = lane_bcast_u64(e1, L), tr = lane_bcast_u64(rw, L);
+        if ((tw & ST_MASK) != 2 || j - L < 0) return 0.0;
+        const double c = bits_to_double(tr);
+        if (!(c > OP_SANE_LO && c < OP_SANE_HI)) return 0.0;
+        const int ec = ulp_exp(c);
+        const double Ct = scale2(c, -ec);
+        if (Ct != exact_C(tw) || (ec & 511) != exact_eu9(tw)) return 0.0;
+        if (ok0 && ec == g && acc0 < 0x1p53 && Ct + acc0 + I0 < 0x1p53) {
+            which = 0;
+            return scale2(Ct + acc0, g);
+        }
+        if (ok1 && ec == g + 1 && acc1 < 0x1p53 && Ct + acc1 + I1 < 0x1p53) {
+            which = 1;
+            return scale2(Ct + acc1, g + 1);
+        }
+        return 0.0;
+    }
+    return 0.0;
 }
 
 // publish the exact carry-out of a chunk (one lane)
@@ -593,11 +664,13 @@ __device__ __forceinline__ void init_window(int *win, int tid)
     FK_UNROLL for (int g = 0; g < 3; ++g) *reinterpret_cast<i32x4 *>(&win[12 * tid + 4 * g]) = i32x4{-1, -1, -1, -1};
 }
 
-// TICKET = false (FK_OP_STATIC=1, experiment): chunk (f, k) is a function of blockIdx alone -- chunk-major over the filters --
-// instead of an atomic ticket.  A chunk only waits for chunks with a smaller blockIdx; that is deadlock-free as long as the
-// dispatcher starts workgroups in blockIdx order per XCD (it does, but nothing guarantees it: the bounded spins + abort word
-// stay, and the default keeps the tickets).
-template <bool STRATIFIED, bool TICKET = true>
+// TICKET = false (the default since round 3): chunk (f, k) is a function of blockIdx alone -- chunk-major over the filters --
+// instead of an atomic ticket.  A chunk only waits for chunks with a smaller blockIdx.  Forward progress: every hardware
+// dispatcher (one per XCD) starts its share of the grid in increasing blockIdx order, so the unfinished workgroup with the
+// SMALLEST index is always resident (anything resident on its dispatcher was started before it, i.e. has a smaller index
+// and would be the smallest) -- and it waits for nobody.  The order of dispatch is how the hardware walks a 1-D grid, not
+// an architectural promise: the bounded spins + abort word (status ST_INTERNAL) stay, FK_OP_STATIC=0 brings the tickets back.
+template <bool STRATIFIED, bool TICKET = true, bool SPEC = false>
 __global__ void __launch_bounds__(OP_THREADS, FK_OP_WAVES)
 resample_onepass_kernel(const OpArgs a)
 {
@@ -688,6 +761,105 @@ resample_onepass_kernel(const OpArgs a)
     if (any_bad) S = __builtin_nan("");
     OP_CLOCK(1);                                                           // weights landed
 
+    // ---- speculation (lookback_spec above): publish the increment sums for a guessed binade and the next one, look back once ----
+    double E[OP_ITEMS];
+    double excl = 0.0, I = 0.0;
+    int eu = 0;
+    bool hit = false;
+    if constexpr (SPEC) {
+        int g = 0;
+        bool guess = false;
+        if (k > 0 && !any_bad && S > 0.0) {                                // uniform
+            // the k chunks before this one weigh about k times as much: the running sum enters near k S and leaves near
+            // (k + 1) S; the lower end picks g, the next binade is the second candidate
+            const double glo = (double)k * S * 0.96, ghi = ((double)k + 1.0) * S * 1.04;
+            guess = glo > OP_SANE_LO && ghi < OP_SANE_HI;
+            g = ulp_exp(glo);
+        }
+        if (guess) {                                                       // uniform
+            bool tie0 = false, tie1 = false;
+            double run0 = 0.0, run1 = 0.0;
+            FK_UNROLL for (int q = 0; q < OP_ITEMS; ++q) {
+                const double t0 = scale2(w8[q], -g);
+                const double x0 = t0 + 0.5, x1 = t0 * 0.5 + 0.5;           // (w / 2^(g+1) = t0 / 2: exact)
+                const double i0 = floor(x0), i1 = floor(x1);
+                tie0 = tie0 || (i0 == x0);
+                tie1 = tie1 || (i1 == x1);
+                run0 += i0;
+                run1 += i1;
+                E[q] = run0;
+            }
+            const double winc0 = wave_incl_sum(run0);
+            const double tot1 = lane_bcast(wave_incl_sum(run1), 63);
+            const int tf = (__ballot(tie0) != 0 ? 1 : 0) | (__ballot(tie1) != 0 ? 2 : 0);
+            if (lane == 63) sh.wsum[wave] = winc0;
+            if (lane == 0) {
+                sh.seg.wtot[wave] = tot1;
+                sh.wmax[wave] = tf;
+            }
+            __syncthreads();                                                                  // (S1)
+            excl = winc0 - run0;
+            double I0 = 0.0, I1 = 0.0;
+            int ties = 0;
+            FK_UNROLL for (int wv = 0; wv < OP_THREADS / 64; ++wv) {
+                if (wv < wave) excl += sh.wsum[wv];
+                I0 += sh.wsum[wv];
+                I1 += sh.seg.wtot[wv];
+                ties |= sh.wmax[wv];
+            }
+            const bool v0 = !(ties & 1) && I0 < 0x1p53 && I0 > 0.0, v1 = !(ties & 2) && I1 < 0x1p53 && I1 > 0.0;
+            if (wave == 0) {
+                if (lane == 0) {
+                    st_agent(&d[k].approx, pack_approx(S, 1));
+                    if (v0) st_agent(&d[k].exact, pack_exact(1, g, I0));
+                    if (v1) st_agent(&d[k].exact2, pack_exact(1, g + 1, I1));
+                }
+                int which = -1;
+                double c_in = 0.0;
+                if (v0 || v1) c_in = lookback_spec(d, k, g, I0, I1, v0, v1, lane, which);
+                int out_lo = 0;
+                if (which >= 0) {
+                    const int e = g + which;
+                    const double Cout = scale2(c_in, -e) + (which ? I1 : I0);                  // < 2^53: lookback_spec checked it
+                    if (lane == 0) {
+                        publish_carry(&d[k], scale2(Cout, e));
+                        st_agent(&d[k].approx, pack_approx(c_in + S, 2));  // what a successor on the two-stage path looks for
+                    }
+                    out_lo = n_boundary_fast<STRATIFIED>(c_in, (int)Np, Nd, halfNd, u_sys, u_str);
+                }
+                if (lane == 0) {
+                    sh.bc_d[1] = c_in;
+                    sh.bc_i[3] = which >= 0 ? 1 : 0;
+                    sh.bc_i[4] = out_lo;
+                    sh.bc_i[5] = which;
+                }
+            }
+            __syncthreads();                                                                  // (S2)
+            const int which = __builtin_amdgcn_readfirstlane(sh.bc_i[5]);
+            hit = which >= 0;
+            if (hit) {                                                     // uniform
+                eu = g + which;
+                I = which ? I1 : I0;
+                if (which == 1) {                                          // the thread's inclusive sums at the other ulp
+                    double run = 0.0;
+                    FK_UNROLL for (int q = 0; q < OP_ITEMS; ++q) {
+                        run += floor(scale2(w8[q], -eu) + 0.5);
+                        E[q] = run;
+                    }
+                    const double winc = wave_incl_sum(run);
+                    __syncthreads();                                       // (everybody has read wsum above)
+                    if (lane == 63) sh.wsum[wave] = winc;
+                    __syncthreads();                                                          // (S3)
+                    excl = winc - run;
+                    FK_UNROLL for (int wv = 0; wv < OP_THREADS / 64; ++wv)
+                        if (wv < wave) excl += sh.wsum[wv];
+                }
+            }
+            OP_CLOCK(2);                                                   // (speculation: counted as stage 1)
+        }
+    }
+    bool at_start = false;
+    if (!hit) {
     // ---- stage 1: approximate carry-in --------------------------------------------------------------------
     if (wave == 0) {
         double A = 0.0;
@@ -719,9 +891,8 @@ resample_onepass_kernel(const OpArgs a)
     }
     // A == 0 means EXACTLY: every weight before this chunk is +0.0 (they are all >= 0), so the carry-in is 0 and
     // needs no stage 2; with S == 0 as well the chunk is empty-handed: carry-out 0, no slots
-    const bool at_start = (k == 0) || (A == 0.0);
+    at_start = (k == 0) || (A == 0.0);
     bool clean = false;
-    int eu = 0;
     {
         const double lo = A * (1.0 - a.delta), hi = (A + S) * (1.0 + a.delta);
         if (lo > OP_SANE_LO && hi < OP_SANE_HI && ulp_exp(lo) == ulp_exp(hi)) {
@@ -732,8 +903,8 @@ resample_onepass_kernel(const OpArgs a)
     // increments in the promised binade (fk_exact_scan.hpp, fast_inc): inc = floor(w / ulp + 1/2) unless the
     // remainder is exactly half an ulp -- such a chunk, and one whose sums reach 2^53 (which is also where t + 1/2
     // stops being exact, and then the test fires by itself), leaves this path.  E[q] = inclusive sums of the thread.
-    double E[OP_ITEMS];
-    double excl = 0.0, I = 0.0;
+    excl = 0.0;
+    I = 0.0;
     bool fast = false;
     if (clean) {                                                           // uniform
         bool tie = false;
@@ -789,6 +960,7 @@ resample_onepass_kernel(const OpArgs a)
         }
     }
     __syncthreads();                                                                          // (D)
+    }   // !hit
     const double c_in = sh.bc_d[1];
     const int quick = __builtin_amdgcn_readfirstlane(sh.bc_i[3]);
     const int u_lo = __builtin_amdgcn_readfirstlane(sh.bc_i[4]);
@@ -1428,17 +1600,26 @@ int onepass_launch(bool stratified, int64_t Fn, int64_t Np, const double *w, con
     a.delta = (8.0 * (double)(Np + 4096) + 16.0 * (double)nch) * 0x1p-53;
     if (hipMemsetAsync(ws, 0, need, s) != hipSuccess) return FK_ERR_LAUNCH;
     if (status && hipMemsetAsync(status, 0, (size_t)Fn * sizeof(int32_t), s) != hipSuccess) return FK_ERR_LAUNCH;
+    // chunk assignment: static (blockIdx -> chunk, chunk-major over the filters) unless FK_OP_STATIC=0 asks for the atomic
+    // tickets of round 2.  125 x 8e6: 4.43 -> 3.47 ms (profiles/r03/onepass_static_vs_ticket.jsonl): the ticket was a
+    // dependent global round trip in front of the weight loads.
     const char *sv = getenv("FK_OP_STATIC");
-    const bool stat = sv && sv[0] == '1';
-    if (stratified) {
-        if (stat) hipLaunchKernelGGL((resample_onepass_kernel<true, false>), dim3((unsigned)total), dim3(OP_THREADS), 0, s, a);
-        else hipLaunchKernelGGL((resample_onepass_kernel<true>), dim3((unsigned)total), dim3(OP_THREADS), 0, s, a);
-        hipLaunchKernelGGL((resample_literal_kernel<true>), dim3((unsigned)Fn), dim3(64), 0, s, a);
-    } else {
-        if (stat) hipLaunchKernelGGL((resample_onepass_kernel<false, false>), dim3((unsigned)total), dim3(OP_THREADS), 0, s, a);
-        else hipLaunchKernelGGL((resample_onepass_kernel<false>), dim3((unsigned)total), dim3(OP_THREADS), 0, s, a);
-        hipLaunchKernelGGL((resample_literal_kernel<false>), dim3((unsigned)Fn), dim3(64), 0, s, a);
-    }
+    const bool stat = !(sv && sv[0] == '0');
+    // speculation (lookback_spec): on unless FK_OP_SPEC=0 (A/B timing; the tests run both)
+    const char *pv = getenv("FK_OP_SPEC");
+    const bool spec = !(pv && pv[0] == '0');
+    const dim3 grid((unsigned)total), block(OP_THREADS);
+#define GO(STRAT)                                                                                                     \
+    do {                                                                                                              \
+        if (stat && spec) hipLaunchKernelGGL((resample_onepass_kernel<STRAT, false, true>), grid, block, 0, s, a);    \
+        else if (stat) hipLaunchKernelGGL((resample_onepass_kernel<STRAT, false, false>), grid, block, 0, s, a);      \
+        else if (spec) hipLaunchKernelGGL((resample_onepass_kernel<STRAT, true, true>), grid, block, 0, s, a);        \
+        else hipLaunchKernelGGL((resample_onepass_kernel<STRAT, true, false>), grid, block, 0, s, a);                 \
+        hipLaunchKernelGGL((resample_literal_kernel<STRAT>), dim3((unsigned)Fn), dim3(64), 0, s, a);                  \
+    } while (0)
+    if (stratified) GO(true);
+    else GO(false);
+#undef GO
     return check_launch("resample_onepass_kernel");
 }
 

@@ -69,8 +69,7 @@ struct WholeShared {
     int lit_status;
 };
 
-// EU = waves per SIMD the register allocation must allow: a 1024-thread workgroup is four waves per SIMD, so EU = 8 (at
-// most 64 VGPRs) lets a CU hold two filters at once, EU = 4 one
+// EU = waves per SIMD the register allocation must allow (a 1024-thread workgroup is four waves per SIMD)
 template <bool STRATIFIED, int NT, int EU>
 __global__ void __launch_bounds__(NT, EU)
 resample_whole_kernel(const WholeArgs a)
@@ -316,20 +315,10 @@ int whole_launch(bool stratified, int64_t Fn, int64_t Np, const double *w, const
         if (stratified) hipLaunchKernelGGL((resample_whole_kernel<true, NTV, EUV>), grid, dim3(NTV), 0, s, a);   \
         else hipLaunchKernelGGL((resample_whole_kernel<false, NTV, EUV>), grid, dim3(NTV), 0, s, a);             \
     } while (0)
-    // FK_WHOLE_EU=4|8 picks the 1024-thread instantiation (A/B timing); default: two filters per CU once there are more
-    // filters than CUs
-    static int n_cu = 0;
-    if (!n_cu) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-                   ? prop.multiProcessorCount : 256;
-    }
-    const char *ev = getenv("FK_WHOLE_EU");
-    const bool two = ev ? atoi(ev) == 8 : Fn > n_cu;
+    // (an instantiation budgeted for two 1024-thread workgroups per CU -- 64 VGPRs -- was measured and dropped: it spills,
+    // 36 against 32 us at 1000 x 8000, 11.8 against 8.1 us at 125 x 8000; profiles/r03/resample_whole_variants.txt)
     if (Np <= 256 * WH_ITEMS) GO(256, 4);
     else if (Np <= 512 * WH_ITEMS) GO(512, 4);
-    else if (two) GO(1024, 8);
     else GO(1024, 4);
 #undef GO
     return check_launch("resample_whole_kernel");

@@ -235,6 +235,14 @@ def _family(kind, Fn, Np, rs):
     return np.ascontiguousarray(w)
 
 
+def _onepass_mode(monkeypatch, mode):
+    """spec: FK_OP_SPEC / FK_OP_STATIC defaults; two-stage: FK_OP_SPEC=0; tickets: FK_OP_SPEC=0 FK_OP_STATIC=0 (round 2)"""
+    if mode != "spec":
+        monkeypatch.setenv("FK_OP_SPEC", "0")
+    if mode == "tickets":
+        monkeypatch.setenv("FK_OP_STATIC", "0")
+
+
 def _check_against_merge_loop(Fn, Np, kinds, filters, monkeypatch, force):
     import torch
     from filterpy_amd import _engine as E
@@ -258,17 +266,29 @@ def _check_against_merge_loop(Fn, Np, kinds, filters, monkeypatch, force):
                 assert bool(sth[f] & 4) == (over > 0) and not (sth[f] & 8), (Np, kind, strat, f, int(sth[f]))
 
 
+@pytest.mark.parametrize("mode", ["spec", "two-stage", "tickets"])
 @pytest.mark.parametrize("Np", [1, 2, 100, 2049, 65536])
-def test_onepass_every_route_small(Np, monkeypatch):
+def test_onepass_every_route_small(Np, mode, monkeypatch):
     """FK_RESAMPLE_PATH=onepass forces short vectors through the one-pass kernel: every weight family, every filter,
     against the reference's merge loop (C restatement), systematic and stratified."""
     kinds = [k for k in _FAMILIES if not (k in ("negative", "nan") and Np < 8)]
+    _onepass_mode(monkeypatch, mode)
     _check_against_merge_loop(5, Np, kinds, range(5), monkeypatch, force=True)
 
 
-def test_onepass_every_route_long(monkeypatch):
-    """default dispatch on a long ragged vector (not a multiple of the chunk, odd address alignment per filter)"""
-    _check_against_merge_loop(6, 1000003, _FAMILIES, (0, 3, 5), monkeypatch, force=False)
+@pytest.mark.parametrize("mode", ["spec", "two-stage", "tickets"])
+def test_onepass_every_route_long(mode, monkeypatch):
+    """default dispatch on a long ragged vector (not a multiple of the chunk, odd address alignment per filter), in the three
+    protocols of the one-pass kernel: speculation + static chunk assignment (round 3's default), round 2's two stages on
+    static assignment, and round 2's atomic tickets"""
+    _onepass_mode(monkeypatch, mode)
+    _check_against_merge_loop(6, 1000003, _FAMILIES + ("dyadic", "tiny"), (0, 3, 5), monkeypatch, force=False)
+
+
+def test_onepass_many_filters_of_a_hundred_thousand(monkeypatch):
+    """1000 x 100 000: more concurrent chains than workgroup slots; speculation on ordinary and on skewed weights (whose
+    guesses mostly miss and fall back to the two stages)"""
+    _check_against_merge_loop(1000, 100000, ("uniform", "heavy_tail", "zeros"), (0, 1, 499, 998, 999), monkeypatch, force=False)
 
 
 def test_short_vectors_with_garbage_weights_follow_the_reference_loop(monkeypatch):
@@ -288,20 +308,16 @@ def test_local_kernel_every_route(Np, monkeypatch):
 
 
 @pytest.mark.parametrize("exact", ["0", "1"])
-@pytest.mark.parametrize("eu", ["4", "8"])
 @pytest.mark.parametrize("Np", [1, 2, 3, 7, 100, 2047, 2048, 2049, 4095, 4096, 4097, 8000, 8189, 8190, 8191, 8192])
-def test_whole_vector_kernel_every_route(Np, eu, exact, monkeypatch):
+def test_whole_vector_kernel_every_route(Np, exact, monkeypatch):
     """resample_whole_kernel (round 3; the default up to 8192 weights: one workgroup takes the whole vector in one
     round): every weight family -- plus vectors the round declines (exact half-ulp ties by the hundred, running sums
     below 2^-900) and must hand to the literal loop --, every filter of a 5-filter call (odd Np: every filter at another
     16-byte phase, so the shifted window, the unshifted 4-byte-store fallback at Np > 8189 and the scalar weight loads
-    all run), systematic and stratified, both register budgets of the 1024-thread instantiation, against the
+    all run), systematic and stratified, against the
     reference's merge loop (C restatement).  exact = "0": the kernel as dispatched -- boundaries from the plain prefix
     sums, the exact round only for a vector with an estimate inside the error band; "1" (FK_WHOLE_EXACT): the exact
     round for every vector."""
-    if eu == "8" and Np <= 4096:
-        pytest.skip("one instantiation below 4097 weights")
-    monkeypatch.setenv("FK_WHOLE_EU", eu)
     monkeypatch.setenv("FK_WHOLE_EXACT", exact)
     kinds = [k for k in _FAMILIES + ("dyadic", "tiny") if not (k in ("negative", "nan") and Np < 8)]
     _check_against_merge_loop(5, Np, kinds, range(5), monkeypatch, force=False)

@@ -6,7 +6,7 @@ O=$R/gpurun_out/${1:-r03e}
 mkdir -p $O
 export TMPDIR=/tmp
 cd $R
-timeout 600 python -m pytest tests/test_gpu_resample.py -m gpu -q -x -p no:cacheprovider -k "whole or goldens or bank_of or garbage" > $O/pytest_resample.log 2>&1; echo "pytest rc=$?"; tail -3 $O/pytest_resample.log
+timeout 600 python -m pytest tests/test_gpu_resample.py -m gpu -q -x -p no:cacheprovider -k "whole or goldens or bank_of or garbage or local_kernel" > $O/pytest_resample.log 2>&1; echo "pytest rc=$?"; tail -3 $O/pytest_resample.log
 python tools/op_phase.py --run --whole --shapes 125x8000,1000x8000,125x4000,1000x2000 --iters 5 > $O/whole_phase_clocks.jsonl 2>&1; cat $O/whole_phase_clocks.jsonl
 python tools/op_phase.py --run --whole --stratified 1 --shapes 125x8000,1000x8000 --iters 5 >> $O/whole_phase_clocks.jsonl 2>&1; tail -2 $O/whole_phase_clocks.jsonl
 SH="--shapes 125x8000,1000x8000,125x4000,1000x2000,4000x8000,250x8000,500x8000 --iters 20"
