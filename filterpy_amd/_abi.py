@@ -60,6 +60,7 @@ SIGNATURES = {
     "fk_ut_sigma_points_f64": (ctypes.c_int, [c_i32, c_i64, c_i32, c_f64, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "fk_ut_transform_f64": (ctypes.c_int, [c_i32, c_i32, c_i64, c_i32] + [c_vp] * 7),
     "fk_ut_cross_variance_f64": (ctypes.c_int, [c_i32, c_i32, c_i32, c_i64, c_i32] + [c_vp] * 7),
+    "fk_ut_linear_map_f64": (ctypes.c_int, [c_i32, c_i32, c_i32, c_i64, c_i32] + [c_vp] * 4),
     "fk_ukf_correct_f64": (ctypes.c_int, [c_i32, c_i32, c_i64, c_i32] + [c_vp] * 9),
     "fk_ukf_linear_batch_f64": (ctypes.c_int, [ctypes.POINTER(fk_ukf_desc)] + [c_vp] * 14),
     "fk_ukf_linear_rts_f64": (ctypes.c_int, [ctypes.POINTER(fk_ukf_desc)] + [c_vp] * 11),

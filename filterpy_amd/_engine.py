@@ -150,6 +150,12 @@ def ut_cross_variance(n, m, k, N, layout, x, z, sigmas_f, sigmas_h, Wc, Pxz):
     _abi.check(rc, "fk_ut_cross_variance_f64")
 
 
+def ut_linear_map(n_in, n_out, k, N, layout, M, sig_in, sig_out):
+    """fk_ut_linear_map_f64: out[i] = M in[i] for every sigma point of every track (a linear fx / hx given as a matrix)"""
+    rc = _abi.lib().fk_ut_linear_map_f64(n_in, n_out, k, N, LAYOUTS[layout], _ptr(M), _ptr(sig_in), _ptr(sig_out), _stream())
+    _abi.check(rc, "fk_ut_linear_map_f64")
+
+
 def ukf_correct(n, m, N, layout, Pxz, zp, S, z, x, P, K=None, status=None):
     rc = _abi.lib().fk_ukf_correct_f64(n, m, N, LAYOUTS[layout], _ptr(Pxz), _ptr(zp), _ptr(S), _ptr(z), _ptr(x),
                                        _ptr(P), _ptr(K), _ptr(status), _stream())
@@ -158,12 +164,12 @@ def ukf_correct(n, m, N, layout, Pxz, zp, S, z, x, P, K=None, status=None):
 
 def ukf_linear_supported(n, m):
     """sizes fk_ukf_linear_batch_f64 is compiled for (csrc/ukf_kernels.hip)"""
-    return 1 <= n <= 6 and 1 <= m <= 3
+    return (1 <= n <= 6 and 1 <= m <= 3) or (7 <= n <= 9 and 1 <= m <= 4)
 
 
 def ukf_linear_rts_supported(n):
     """sizes fk_ukf_linear_rts_f64 is compiled for"""
-    return 1 <= n <= 6
+    return 1 <= n <= 9
 
 
 def ukf_linear_batch(n, m, N, T, layout, scale, F, H, Q, R, Wm, Wc, z, x, P, *, mask=None,

@@ -215,4 +215,50 @@ int rts_chunked_call(const Args &a, int n, long slots, One &&one, hipStream_t s)
     return ml_join(ms, forked, s, rc);
 }
 
+// The fused linear UKF (ukf_kernels.hip, UkfArgs): only on request -- FK_UKF_CHUNKS="G,H" --, same hand-over through x / P.
+template <class Args, class One>
+int ukf_chunked_call(const Args &a, int n, int m, One &&one, hipStream_t s)
+{
+    int G = 1, H = 1;
+    const char *cv = getenv("FK_UKF_CHUNKS");
+    if (!cv || sscanf(cv, "%d,%d", &G, &H) != 2) return one(a, s);
+    if (G > MlStreams::MAXG) G = MlStreams::MAXG;
+    if (H > 64) H = 64;
+    if (H > a.T) H = (int)a.T;
+    if (G < 1 || H < 1 || (G == 1 && H == 1) || a.cnt < 256L * G) return one(a, s);
+    MlStreams *msp = ml_streams();
+    if (!msp) return one(a, s);
+    MlStreams &ms = *msp;
+    std::lock_guard<std::mutex> lock(ms.mu);
+    if (hipEventRecord(ms.fork, s) != hipSuccess) return one(a, s);
+    const long blocks = (a.cnt + 255) / 256, per = (blocks + G - 1) / G * 256, nn = (long)n * n;
+    int rc = 0;
+    bool forked[MlStreams::MAXG] = {};
+    for (int g = 0; g < G && rc == 0; ++g) {
+        const long g0 = a.i0 + (long)g * per;
+        const long gcnt = (g0 + per <= a.i0 + a.cnt) ? per : (a.i0 + a.cnt - g0);
+        if (gcnt <= 0) break;
+        hipStream_t sg = g == 0 ? s : ms.st[g];
+        if (g > 0) {
+            if (hipStreamWaitEvent(sg, ms.fork, 0) != hipSuccess) { rc = -1; break; }
+            forked[g] = true;
+        }
+        for (int h = 0; h <= H && rc == 0; ++h) {
+            long t0, t1;
+            if (!chunk_window(a.T, G, H, g, h, t0, t1)) continue;
+            Args b = a;
+            b.i0 = g0;
+            b.cnt = gcnt;
+            b.T = t1 - t0;
+            b.status_or = t0 > 0 ? 1 : a.status_or;
+            b.z = a.z + t0 * a.N * m;
+            b.mask = ml_off(a.mask, t0 * a.N);
+            b.means = ml_off(a.means, t0 * a.N * n);
+            b.covs = ml_off(a.covs, t0 * a.N * nn);
+            rc = one(b, sg);
+        }
+    }
+    return ml_join(ms, forked, s, rc);
+}
+
 }  // namespace fk

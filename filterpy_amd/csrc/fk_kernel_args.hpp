@@ -47,6 +47,8 @@ struct UkfArgs {
     long N, T;
     int n, m;
     double scale;
+    long i0, cnt;        // the launch covers tracks [i0, i0 + cnt) of the N (a piece of a chunked call, fk_chunks.hpp)
+    int status_or;       // 1: OR the status into what an earlier time chunk left
 };
 
 struct ImmArgs {

@@ -9,6 +9,7 @@
 #include <type_traits>
 
 #include "../../include/filterhip.h"
+#include "fk_chunks.hpp"
 #include "fk_device.hpp"
 #include "fk_kernel_args.hpp"
 #include "fk_math_sym.hpp"
@@ -54,7 +55,7 @@ struct ScalarFHModel {
 };
 
 template <int NX, int NZ, int LAYOUT, bool SCALAR_FH>
-__global__ void __launch_bounds__(BLOCK, (NX <= 2 ? 4 : 2))
+__global__ void __launch_bounds__(BLOCK, (NX <= 2 ? 4 : NX <= 6 ? 2 : 1))
 ukf_linear_kernel_v2(const UkfArgs a, const double *__restrict__ pF, const double *__restrict__ pH,
                   const double *__restrict__ pQ, const double *__restrict__ pR,
                   const double *__restrict__ pWm, const double *__restrict__ pWc,
@@ -65,9 +66,9 @@ ukf_linear_kernel_v2(const UkfArgs a, const double *__restrict__ pF, const doubl
     using SharedModel = LdsModel<NX, NZ>;
     __shared__ double s_model[SharedModel::SIZE + 2 * KS];
     const long N = a.N;
-    const long blk0 = (long)blockIdx.x * BLOCK;
+    const long blk0 = a.i0 + (long)blockIdx.x * BLOCK;
     const Lane ln{blk0, threadIdx.x, N};
-    const bool live = blk0 + ln.tid < N;
+    const bool live = blk0 + ln.tid < a.i0 + a.cnt;
     const Lane lr{blk0, live ? ln.tid : 0u, N};
     const int n = a.n, m = a.m;
     const int ks = 2 * n + 1;
@@ -144,7 +145,7 @@ ukf_linear_kernel_v2(const UkfArgs a, const double *__restrict__ pF, const doubl
         store_rec<NX, NX, LAYOUT, false>(Pf, a.P, ln, n, n);
         if (a.status) {
             if (!all_finite<NX>(x) || !all_finite<PL>(P)) st |= ST_NONFINITE;
-            a.status[ln.blk0 + ln.tid] = st;
+            a.status[ln.blk0 + ln.tid] = a.status_or ? (a.status[ln.blk0 + ln.tid] | st) : st;
         }
     }
 }
@@ -160,9 +161,9 @@ ukf_linear_kernel(const UkfArgs a, const double *__restrict__ pF, const double *
     using SharedModel = LdsModel<NX, NZ>;
     __shared__ double s_model[SharedModel::SIZE + 2 * KS];
     const long N = a.N;
-    const long blk0 = (long)blockIdx.x * BLOCK;
+    const long blk0 = a.i0 + (long)blockIdx.x * BLOCK;
     const Lane ln{blk0, threadIdx.x, N};
-    const bool live = blk0 + ln.tid < N;
+    const bool live = blk0 + ln.tid < a.i0 + a.cnt;
     const Lane lr{blk0, live ? ln.tid : 0u, N};
     const int n = a.n, m = a.m;
     const int ks = 2 * n + 1;
@@ -369,7 +370,7 @@ ukf_linear_kernel(const UkfArgs a, const double *__restrict__ pF, const double *
         store_rec<NX, NX, LAYOUT, false>(Pf, a.P, ln, n, n);
         if (a.status) {
             if (!all_finite<NX>(x) || !all_finite<PL>(P)) st |= ST_NONFINITE;
-            a.status[ln.blk0 + ln.tid] = st;
+            a.status[ln.blk0 + ln.tid] = a.status_or ? (a.status[ln.blk0 + ln.tid] | st) : st;
         }
     }
 }
@@ -506,42 +507,60 @@ int fk_ukf_linear_batch_f64(const fk_ukf_desc *d, const double *F, const double 
                             int32_t *status, void *stream)
 {
     if (!d) return fail(FK_ERR_BAD_ARG, "desc is NULL");
-    if (d->n < 1 || d->n > 6 || d->m < 1 || d->m > 3) return fail(FK_ERR_UNSUPPORTED, "fused linear UKF: dim_x 1..6, dim_z 1..3");
+    if (d->n < 1 || d->n > 9 || d->m < 1 || d->m > 4 || (d->n <= 6 && d->m > 3))
+        return fail(FK_ERR_UNSUPPORTED, "fused linear UKF: dim_x 1..6 with dim_z 1..3, dim_x 7..9 with dim_z 1..4");
     if (d->N < 0 || d->T < 0 || !F || !H || !Q || !R || !Wm || !Wc || !z || !x || !P)
         return fail(FK_ERR_BAD_ARG, "fused linear UKF: bad argument");
     if ((double)d->N * d->n * d->n * 8.0 >= 4294967296.0) return fail(FK_ERR_UNSUPPORTED, "fused linear UKF: record block >= 4 GiB, split the batch");
     if (d->N == 0 || d->T == 0) return FK_OK;
-    UkfArgs a{};
-    a.F = F; a.H = H; a.Q = Q; a.R = R; a.Wm = Wm; a.Wc = Wc; a.z = z; a.mask = mask;
-    a.x = x; a.P = P; a.means = means; a.covs = covs; a.status = status;
-    a.N = d->N; a.T = d->T; a.n = d->n; a.m = d->m; a.scale = d->scale;
-    const dim3 grid((unsigned)((a.N + BLOCK - 1) / BLOCK)), block(BLOCK);
-    hipStream_t s = (hipStream_t)stream;
-#define GO(NXV, NZV)                                                                                    \
-    if (d->layout == FK_LAYOUT_SOA)                                                                     \
-        hipLaunchKernelGGL((ukf_linear_kernel<NXV, NZV, LAYOUT_SOA>), grid, block, 0, s, a, F, H, Q, R, \
-                           Wm, Wc, z, mask);                                                            \
-    else                                                                                                \
-        hipLaunchKernelGGL((ukf_linear_kernel<NXV, NZV, LAYOUT_AOS>), grid, block, 0, s, a, F, H, Q, R, \
-                           Wm, Wc, z, mask)
-    // the register-lean organisation wins where the straightforward one runs at one wave per SIMD ((6,3): 3.08 ->
-    // 2.68 ms SOA, 4.22 -> 2.90 ms AOS at 1e5 x 100; profiles/r02/exp_ukf2.log) and loses below it
-    if (d->n <= 2 && d->m <= 2) { GO(2, 2); }
-    else if (d->n <= 4 && d->m <= 2) { GO(4, 2); }
-    else {
-        // exact (6,3): F and H as scalar operands (FK_UKF_LDS_MODEL=1 keeps them in LDS, for A/B timing and the parity tests)
-        static const bool lds_model = getenv("FK_UKF_LDS_MODEL") && getenv("FK_UKF_LDS_MODEL")[0] == '1';
-        const bool scalar = d->n == 6 && d->m == 3 && !lds_model;
-        if (d->layout == FK_LAYOUT_SOA) {
-            if (scalar) hipLaunchKernelGGL((ukf_linear_kernel_v2<6, 3, LAYOUT_SOA, true>), grid, block, 0, s, a, F, H, Q, R, Wm, Wc, z, mask);
-            else hipLaunchKernelGGL((ukf_linear_kernel_v2<6, 3, LAYOUT_SOA, false>), grid, block, 0, s, a, F, H, Q, R, Wm, Wc, z, mask);
+    UkfArgs a0{};
+    a0.F = F; a0.H = H; a0.Q = Q; a0.R = R; a0.Wm = Wm; a0.Wc = Wc; a0.z = z; a0.mask = mask;
+    a0.x = x; a0.P = P; a0.means = means; a0.covs = covs; a0.status = status;
+    a0.N = d->N; a0.T = d->T; a0.n = d->n; a0.m = d->m; a0.scale = d->scale;
+    a0.i0 = 0; a0.cnt = d->N; a0.status_or = 0;
+    const int layout = d->layout;
+    // exact (6,3): F and H as scalar operands (FK_UKF_LDS_MODEL=1 keeps them in LDS, for A/B timing and the parity tests)
+    static const bool lds_model = getenv("FK_UKF_LDS_MODEL") && getenv("FK_UKF_LDS_MODEL")[0] == '1';
+    // one piece: tracks [a.i0, a.i0 + a.cnt), a.T steps from the pointers in a
+    auto one = [&](const UkfArgs &a, hipStream_t s) -> int {
+        const dim3 grid((unsigned)((a.cnt + BLOCK - 1) / BLOCK)), block(BLOCK);
+#define GO(KERNEL, ...)                                                                                          \
+    do {                                                                                                         \
+        if (layout == FK_LAYOUT_SOA)                                                                             \
+            hipLaunchKernelGGL((KERNEL<__VA_ARGS__, LAYOUT_SOA>), grid, block, 0, s, a, F, H, Q, R, Wm, Wc, a.z, a.mask); \
+        else                                                                                                     \
+            hipLaunchKernelGGL((KERNEL<__VA_ARGS__, LAYOUT_AOS>), grid, block, 0, s, a, F, H, Q, R, Wm, Wc, a.z, a.mask); \
+    } while (0)
+#define GO2(NXV, NZV, SC)                                                                                        \
+    do {                                                                                                         \
+        if (layout == FK_LAYOUT_SOA)                                                                             \
+            hipLaunchKernelGGL((ukf_linear_kernel_v2<NXV, NZV, LAYOUT_SOA, SC>), grid, block, 0, s, a, F, H, Q, R, Wm, Wc, a.z, a.mask); \
+        else                                                                                                     \
+            hipLaunchKernelGGL((ukf_linear_kernel_v2<NXV, NZV, LAYOUT_AOS, SC>), grid, block, 0, s, a, F, H, Q, R, Wm, Wc, a.z, a.mask); \
+    } while (0)
+        // the register-lean organisation wins where the straightforward one runs at one wave per SIMD ((6,3): 3.08 ->
+        // 2.68 ms SOA, 4.22 -> 2.90 ms AOS at 1e5 x 100; profiles/r02/exp_ukf2.log) and loses below it
+        if (a.n <= 2 && a.m <= 2) GO(ukf_linear_kernel, 2, 2);
+        else if (a.n <= 4 && a.m <= 2) GO(ukf_linear_kernel, 4, 2);
+        else if (a.n <= 6 && a.m <= 3) {
+            if (a.n == 6 && a.m == 3 && !lds_model) GO2(6, 3, true);
+            else GO2(6, 3, false);
+        } else if (a.n <= 8) {                                             // round 3: dim_x 7..9 fused, one lane per track
+            if (a.n == 8 && a.m == 4) GO2(8, 4, true);
+            else GO2(8, 4, false);
         } else {
-            if (scalar) hipLaunchKernelGGL((ukf_linear_kernel_v2<6, 3, LAYOUT_AOS, true>), grid, block, 0, s, a, F, H, Q, R, Wm, Wc, z, mask);
-            else hipLaunchKernelGGL((ukf_linear_kernel_v2<6, 3, LAYOUT_AOS, false>), grid, block, 0, s, a, F, H, Q, R, Wm, Wc, z, mask);
+            if (a.m == 3) GO2(9, 3, true);
+            else GO2(9, 4, false);
         }
-    }
 #undef GO
-    return check_launch("ukf_linear_kernel");
+#undef GO2
+        return check_launch("ukf_linear_kernel");
+    };
+    // tail filling (fk_chunks.hpp): FK_UKF_CHUNKS="G,H" cuts the call into G track groups x H time chunks on G streams, the
+    // state handed from chunk to chunk through x / P in place (bit-identical results).  Default: one launch -- at
+    // BASELINE configs[3] (1563 waves for 2048 wave slots) there is no last round to fill, and the forced decompositions
+    // measured no faster (profiles/r03/ukf_chunking.jsonl).
+    return ukf_chunked_call(a0, a0.n, a0.m, one, (hipStream_t)stream);
 }
 
 int fk_ukf_linear_rts_f64(const fk_ukf_desc *d, const double *F, const double *Q, const double *Wm, const double *Wc,
@@ -549,7 +568,7 @@ int fk_ukf_linear_rts_f64(const fk_ukf_desc *d, const double *F, const double *Q
                           void *stream)
 {
     if (!d) return fail(FK_ERR_BAD_ARG, "desc is NULL");
-    if (d->n < 1 || d->n > 6) return fail(FK_ERR_UNSUPPORTED, "fused linear UKF smoother: dim_x 1..6");
+    if (d->n < 1 || d->n > 9) return fail(FK_ERR_UNSUPPORTED, "fused linear UKF smoother: dim_x 1..9");
     if (d->N < 0 || d->T < 0 || !F || !Q || !Wm || !Wc || !Xs || !Ps || !xs || !Ps_out)
         return fail(FK_ERR_BAD_ARG, "fused linear UKF smoother: bad argument");
     if ((double)d->N * d->n * d->n * 8.0 >= 4294967296.0) return fail(FK_ERR_UNSUPPORTED, "fused linear UKF smoother: record block >= 4 GiB, split the batch");
@@ -568,7 +587,9 @@ int fk_ukf_linear_rts_f64(const fk_ukf_desc *d, const double *F, const double *Q
     if (d->n <= 2) GO(2, false);
     else if (d->n <= 4) GO(4, false);
     else if (d->n == 6) GO(6, true);
-    else GO(6, false);
+    else if (d->n <= 6) GO(6, false);
+    else if (d->n <= 8) GO(8, false);                                      // round 3: dim_x 7..9
+    else GO(9, false);
 #undef GO
     return check_launch("ukf_linear_rts_kernel");
 }

@@ -180,6 +180,36 @@ cross_kernel(int n, int m, int k, long N, const double *__restrict__ px, const d
     }
 }
 
+// ------------------------------------------------------------ linear map --
+// A linear fx / hx handed over as a matrix (UnscentedKalmanFilter(fx=F, hx=H)), applied to every sigma point of every
+// track where the fused kernels do not reach (dim_x > 9, per-epoch Rs / dts, hooks): out[i] = M in[i], the products
+// accumulated over the columns in order (what numpy.dot of a matrix and a vector does in the reference's lambda,
+// UKF.py:521-522 / :462-466).  One track per lane, M in LDS.  (Round 2 called torch.matmul -- rocBLAS -- here.)
+template <int NX, int LAYOUT>
+__global__ void __launch_bounds__(BLOCK)
+linear_map_kernel(int n_in, int n_out, int k, long N, const double *__restrict__ pM, const double *__restrict__ in,
+                  double *__restrict__ out)
+{
+    __shared__ double sM[16 * 16];
+    for (int q = threadIdx.x; q < n_out * n_in; q += BLOCK) sM[q] = pM[q];
+    __syncthreads();
+    const long blk0 = (long)blockIdx.x * BLOCK;
+    const Lane ln{blk0, threadIdx.x, N};
+    if (blk0 + ln.tid >= N) return;
+    const RecView<LAYOUT> iv(in, ln, k * n_in), ov(out, ln, k * n_out);
+    for (int i = 0; i < k; ++i) {
+        double x[NX];
+        FK_UNROLL for (int c = 0; c < NX; ++c) x[c] = c < n_in ? iv.load(i * n_in + c) : 0.0;
+        for (int r = 0; r < n_out; ++r) {
+            const double *row = sM + r * n_in;
+            double acc = row[0] * x[0];
+            FK_UNROLL for (int c = 1; c < NX; ++c)
+                if (c < n_in) acc = fma(row[c], x[c], acc);
+            ov.store(i * n_out + r, acc);
+        }
+    }
+}
+
 // ------------------------------------------------------------- UKF correct --
 // The tail of UnscentedKalmanFilter.update (UKF.py:470-481) for arbitrary hx:
 //   K = Pxz S^-1 ; x += K (z - zp) ; P -= K (S K')
@@ -335,6 +365,28 @@ int fk_ut_cross_variance_f64(int32_t n, int32_t m, int32_t k, int64_t N, int32_t
     FK_BY_NX(n, CALL);
 #undef CALL
     return check_launch("cross_kernel");
+}
+
+int fk_ut_linear_map_f64(int32_t n_in, int32_t n_out, int32_t k, int64_t N, int32_t layout, const double *M,
+                         const double *in, double *out, void *stream)
+{
+    if (n_in < 1 || n_in > 16 || n_out < 1 || n_out > 16 || k < 1) return fail(FK_ERR_UNSUPPORTED, "linear map: dims must be 1..16");
+    if (N < 0 || !M || !in || !out) return fail(FK_ERR_BAD_ARG, "linear map: bad argument");
+    if ((double)N * k * (n_in > n_out ? n_in : n_out) * 8.0 >= 4294967296.0) return fail(FK_ERR_UNSUPPORTED, "linear map: record block >= 4 GiB, split the batch");
+    if (N == 0) return FK_OK;
+    const dim3 grid((unsigned)((N + BLOCK - 1) / BLOCK)), block(BLOCK);
+#define CALL(NXV)                                                                                                \
+    if (layout == FK_LAYOUT_SOA)                                                                                 \
+        hipLaunchKernelGGL((linear_map_kernel<NXV, LAYOUT_SOA>), grid, block, 0, (hipStream_t)stream, n_in, n_out, k, \
+                           (long)N, M, in, out);                                                                 \
+    else                                                                                                         \
+        hipLaunchKernelGGL((linear_map_kernel<NXV, LAYOUT_AOS>), grid, block, 0, (hipStream_t)stream, n_in, n_out, k, \
+                           (long)N, M, in, out)
+    if (n_in <= 4) { CALL(4); }
+    else if (n_in <= 8) { CALL(8); }
+    else { CALL(16); }
+#undef CALL
+    return check_launch("linear_map_kernel");
 }
 
 int fk_ukf_correct_f64(int32_t n, int32_t m, int64_t N, int32_t layout, const double *Pxz, const double *zp,

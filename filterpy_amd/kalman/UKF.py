@@ -119,8 +119,14 @@ class UnscentedKalmanFilter(object):
                 or getattr(pf, "_sqrt", None) is not None or getattr(pf, "_subtract", None) is not None)
 
     @property
+    def _linear(self):
+        """fx and hx were handed over as matrices"""
+        return (not callable(self.fx)) and (not callable(self.hx))
+
+    @property
     def _resident(self):
-        return self._devcall or self._hooked or self._ut_fn is not None
+        # (a matrix model has no host callable to run between the kernels: its steps stay on the device too)
+        return self._devcall or self._hooked or self._ut_fn is not None or not callable(self.fx) or not callable(self.hx)
 
     def _with_ut(self, UT):
         """context: a caller-supplied UT function (UKF.py:395-396, :447-448, :712-713) for the duration of one call"""
@@ -165,9 +171,12 @@ class UnscentedKalmanFilter(object):
 
     def _user(self, fn, sig, *args, **kw):
         """fx / hx on a (N, k, d) device tensor, in the mode's calling convention"""
-        import torch
-        if not callable(fn):                                   # a matrix: linear model
-            return torch.matmul(sig, E.dev(np.asarray(fn, dtype=np.float64)).T)
+        if not callable(fn):                                   # a matrix: linear model, one kernel (fk_ut_linear_map_f64)
+            M = np.asarray(fn, dtype=np.float64)
+            N, k, d_in = sig.shape
+            out = E.alloc_records((), N, k * M.shape[0], self._layout)
+            E.ut_linear_map(d_in, M.shape[0], k, N, self._layout, E.dev(M), self._to_rec(sig, k, d_in), out)
+            return self._rec_view(out, k, M.shape[0])
         if self._mode == "torch":
             return fn(sig, *args, **kw)
         return self._tt(self._apply(fn, sig.cpu().numpy(), *args, **kw), sig)
@@ -547,8 +556,10 @@ class UnscentedKalmanFilter(object):
         import torch
         from .unscented_transform import unscented_transform
         n, m = self._dim_x, self._dim_z
+        fused = (self._linear and Rs is None and dts is None and saver is None and UT is None and not self._devcall
+                 and not self._hooked and E.ukf_linear_supported(n, m) and not isinstance(zs, torch.Tensor))
         with self._with_ut(UT):
-            if self._resident and saver is None:
+            if self._resident and saver is None and not fused:
                 return self._dev_batch_filter(zs, Rs, dts, device_outputs)
         try:
             z0 = zs[0]
@@ -562,11 +573,7 @@ class UnscentedKalmanFilter(object):
                 raise TypeError('each element in zs must be a 1D array of length {}'.format(m))
         T = len(zs)
         N = self._N or 1
-        linear = (not callable(self.fx)) and (not callable(self.hx))
-        if linear and saver is None and not E.ukf_linear_supported(n, m):
-            # a linear model outside the fused kernels' sizes: the split path, resident in HBM for the whole call
-            return self._dev_batch_filter(zs, Rs, dts, device_outputs)
-        if linear and Rs is None and dts is None and saver is None:
+        if fused:
             lay = self._layout
             zarr = np.zeros((T, N, m))
             mask = np.ones((T, N), dtype=np.uint8)
@@ -661,12 +668,12 @@ class UnscentedKalmanFilter(object):
         from .unscented_transform import unscented_transform
         if len(Xs) != len(Ps):
             raise ValueError('Xs and Ps must have the same length')
+        fused = (not callable(self.fx) and dts is None and UT is None and not self._devcall and not self._hooked
+                 and E.ukf_linear_rts_supported(self._dim_x) and not isinstance(Xs, torch.Tensor))
         with self._with_ut(UT):
-            if self._resident or isinstance(Xs, torch.Tensor):
+            if (self._resident or isinstance(Xs, torch.Tensor)) and not fused:
                 return self._dev_rts_smoother(Xs, Ps, dts, device_outputs)
-        if not callable(self.fx) and not E.ukf_linear_rts_supported(self._dim_x):
-            return self._dev_rts_smoother(Xs, Ps, dts, device_outputs)
-        if not callable(self.fx) and dts is None:
+        if fused:
             # linear fx given as a matrix: the whole backward loop is ONE fused launch (fk_ukf_linear_rts_f64)
             n, N, lay = self._dim_x, self._N or 1, self._layout
             Xa = np.asarray(Xs, dtype=np.float64)

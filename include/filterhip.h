@@ -205,6 +205,13 @@ int fk_ut_cross_variance_f64(int32_t n, int32_t m, int32_t k, int64_t N, int32_t
                              const double *sigmas_f, const double *sigmas_h,
                              const double *Wc, double *Pxz, void *stream);
 
+/* A linear process / measurement model given as a matrix -- UnscentedKalmanFilter(fx=F, hx=H) -- applied to the sigma
+ * points where the fused kernels do not reach: what the reference's lambda `F @ s` does once per point (filterpy/kalman/
+ * UKF.py:521-522, :462-466), for every point of every track in one launch.
+ *   M [n_out*n_in] shared (device); in [N][k*n_in] records -> out [N][k*n_out] records.  Dims 1..16. */
+int fk_ut_linear_map_f64(int32_t n_in, int32_t n_out, int32_t k, int64_t N, int32_t layout, const double *M,
+                         const double *in, double *out, void *stream);
+
 /* The correction at the end of UnscentedKalmanFilter.update (filterpy/kalman/UKF.py:470-481) for
  * arbitrary measurement functions:  K = Pxz S^-1 (Cholesky solve) ; x += K (z - zp) ; P -= K (S K').
  *   Pxz [N][n*m], zp [N][m], S [N][m*m], z [N][m] ; x [N][n], P [N][n*n] updated in place ;

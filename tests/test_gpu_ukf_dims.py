@@ -218,3 +218,66 @@ def test_linear_bank_of_different_tracks_vs_oracle(n, m, layout):
             rxs, rps, rKs = ukf_oracle.ukf_rts_smoother(rmu, rcov, lambda x, dt: F @ x, 1.0, Q, alpha, beta, kappa)
             assert rel_err_rows(xs[:, trk], rxs) < TOL and rel_err_rows(ps[:, trk], rps) < TOL, (N, trk)
             assert rel_err_rows(Ks[:-1, trk], rKs[:-1]) < TOL, (N, trk)
+
+
+@pytest.mark.parametrize("layout", ["soa", "aos"])
+def test_linear_map_kernel_vs_numpy(layout):
+    """fk_ut_linear_map_f64 (a linear fx / hx given as a matrix, where the fused kernels do not reach): out[i] = M in[i] for
+    every sigma point of every track, all dims 1..16, ragged banks -- against numpy's matrix product of the same arrays"""
+    import torch
+    from filterpy_amd import _engine as E
+    rs = np.random.RandomState(11)
+    for n_in, n_out in ((1, 1), (2, 1), (4, 2), (6, 3), (7, 7), (9, 4), (12, 12), (16, 8), (16, 16), (3, 16)):
+        k = 2 * n_in + 1
+        M = rs.randn(n_out, n_in)
+        for N in SIZES:
+            sig = rs.randn(N, k, n_in)
+            out = E.alloc_records((), N, k * n_out, layout)
+            out.fill_(float("nan"))
+            E.ut_linear_map(n_in, n_out, k, N, layout, E.dev(M), E.to_records(sig, layout, 0), out)
+            torch.cuda.synchronize()
+            got = E.from_records(out, layout, 0, (k, n_out))
+            ref = sig @ M.T
+            assert rel_err_rows(got.reshape(N * k, n_out), ref.reshape(N * k, n_out)) < 1e-13, (n_in, n_out, N)
+
+
+@pytest.mark.parametrize("layout", ["soa", "aos"])
+@pytest.mark.parametrize("n,m", [(6, 3), (8, 4), (9, 3)])
+def test_fused_ukf_chunked_call_is_bit_identical(n, m, layout, monkeypatch):
+    """FK_UKF_CHUNKS="G,H" cuts fk_ukf_linear_batch_f64 into track groups x time chunks on helper streams (fk_chunks.hpp,
+    ukf_chunked_call), the state handed over through x / P in place: outputs, final state and status must be bit-identical
+    to the single launch, incl. a ragged bank, a missing measurement and a track that turns non-positive-definite"""
+    import torch
+    from filterpy_amd import _engine as E
+    rs = np.random.RandomState(5 * n + m)
+    N, T = 1000 + 37, 23
+    alpha, beta, kappa = 0.5, 2.0, 3.0 - n
+    from oracle import ukf_oracle
+    Wm, Wc = ukf_oracle.merwe_weights(n, alpha, beta, kappa)
+    lam = alpha ** 2 * (n + kappa) - n
+    F = np.eye(n) + 0.1 * rs.randn(n, n)
+    F /= max(1.0, 1.05 * np.max(np.abs(np.linalg.eigvals(F))))
+    H, Q, R = rs.randn(m, n), spd(rs, n, 0.05), spd(rs, m, 0.5)
+    x0, P0 = rs.randn(N, n), spd(rs, n, 2.0, (N,))
+    P0[77] = -np.eye(n)                                   # not positive definite: status bit, garbage that must not differ
+    zs = rs.randn(T, N, m)
+    mask = np.ones((T, N), dtype=np.uint8)
+    mask[5] = 0
+    res = {}
+    for tag, env in (("one", None), ("3x4", "3,4"), ("2x7", "2,7"), ("4x23", "4,23")):
+        if env:
+            monkeypatch.setenv("FK_UKF_CHUNKS", env)
+        else:
+            monkeypatch.delenv("FK_UKF_CHUNKS", raising=False)
+        dx, dP = E.to_records(x0, layout, 0), E.to_records(P0, layout, 0)
+        means, covs = E.alloc_records((T,), N, n, layout), E.alloc_records((T,), N, n * n, layout)
+        st = torch.zeros(N, dtype=torch.int32, device=dx.device)
+        E.ukf_linear_batch(n, m, N, T, layout, lam + n, E.dev(F), E.dev(H), E.dev(Q), E.dev(R), E.dev(Wm), E.dev(Wc),
+                           E.to_records(zs, layout, 1), dx, dP, mask=torch.as_tensor(mask, device=dx.device), means=means,
+                           covs=covs, status=st)
+        torch.cuda.synchronize()
+        res[tag] = [t.cpu().numpy().copy() for t in (means, covs, dx, dP, st)]
+    assert res["one"][4][77] != 0 and not res["one"][4][:77].any()
+    for tag in ("3x4", "2x7", "4x23"):
+        for a, b in zip(res["one"], res[tag]):
+            assert np.array_equal(a, b, equal_nan=True), tag
