@@ -248,6 +248,73 @@ def gpu_clocks():
         return {"error": repr(e)}
 
 
+def clocks_under_load(step, seconds=1.0):
+    """sclk / power of THIS GPU sampled from sysfs WHILE the benchmark kernel runs back to back (two
+    boxes with identical idle clock readings differ by 15-25 % on the headline kernel -- idle readings cannot show a
+    box that holds a lower clock under this kernel's load).  Not part of the timed region."""
+    import glob
+    import re
+    import subprocess
+    import threading
+    import torch
+    out = {}
+    try:
+        bdf = None
+        st = subprocess.run(["amd-smi", "static", "-g", "0"], capture_output=True, text=True, timeout=30).stdout
+        mm = re.search(r"BDF:\s*(\S+)", st)
+        if mm:
+            bdf = mm.group(1).lower()
+        cards = [d for d in glob.glob("/sys/class/drm/card*/device") if bdf and os.path.realpath(d).lower().endswith(bdf)]
+        if not cards:
+            return {"error": f"no sysfs card for BDF {bdf}"}
+        dev = cards[0]
+        hw = (glob.glob(os.path.join(dev, "hwmon", "hwmon*")) or [None])[0]
+        samples = {"sclk_mhz": [], "power_w": [], "busy": []}
+        stop = threading.Event()
+
+        def read(path):
+            try:
+                with open(path) as fh:
+                    return fh.read()
+            except OSError:
+                return ""
+
+        def sampler():
+            while not stop.is_set():
+                cur = re.search(r"(\d+)Mhz \*", read(os.path.join(dev, "pp_dpm_sclk")))
+                if cur:
+                    samples["sclk_mhz"].append(int(cur.group(1)))
+                if hw:
+                    pw = read(os.path.join(hw, "power1_average")) or read(os.path.join(hw, "power1_input"))
+                    if pw.strip().isdigit():
+                        samples["power_w"].append(int(pw) / 1e6)
+                b = read(os.path.join(dev, "gpu_busy_percent")).strip()
+                if b.isdigit():
+                    samples["busy"].append(int(b))
+                time.sleep(0.004)
+        th = threading.Thread(target=sampler, daemon=True)
+        torch.cuda.synchronize()
+        th.start()
+        t0 = time.perf_counter()
+        n = 0
+        while time.perf_counter() - t0 < seconds:
+            for _ in range(8):
+                step()
+            torch.cuda.synchronize()
+            n += 8
+        stop.set()
+        th.join(timeout=2)
+        out["launches"] = n
+        out["ms_per_launch_in_burst"] = 1e3 * (time.perf_counter() - t0) / max(1, n)
+        for k, v in samples.items():
+            if v:
+                vs = sorted(v)
+                out[k] = {"min": vs[0], "median": vs[len(vs) // 2], "max": vs[-1], "n": len(vs)}
+    except Exception as e:                     # the measurement does not depend on it
+        out["error"] = repr(e)
+    return out
+
+
 def selftest_cpu(args):
     """--selftest-cpu: the N-rank control flow of this file (env -> process group -> contiguous shards -> per-step
     all-gather of the summary state -> barrier + max-over-ranks timing -> ONE JSON line on rank 0) on the gloo
@@ -421,7 +488,7 @@ def main():
                          "kernel": "fk::kf_fast_kernel<4,2," + layout + ",nomask,outs> (variant " + os.environ.get("FK_FAST_VARIANT", "0") + ")", "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_launch": alg_bytes},
             "parity_max_rel_vs_oracle": worst, "parity_tracks": int(len(sample)),
-            "gpu_clocks": gpu_clocks(), "hbm_probes": hbm_probes(device),
+            "gpu_clocks": gpu_clocks(), "hbm_probes": hbm_probes(device), "under_load": clocks_under_load(step),
         }
         if args.force_dist:
             out["dist_forced"] = f"{world}-rank {dist.get_backend()} group: init_process_group(device_id), all_gather_into_tensor, barrier, all_reduce(MAX) executed"

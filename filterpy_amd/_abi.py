@@ -72,6 +72,8 @@ SIGNATURES = {
     "fk_resample_systematic_f64": (ctypes.c_int, [c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "fk_resample_stratified_f64": (ctypes.c_int, [c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "fk_resample_multinomial_f64": (ctypes.c_int, [c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "fk_resample_residual_fill_f64": (ctypes.c_int, [c_i64, c_i64] + [c_vp] * 6),
+    "fk_resample_residual_draw_f64": (ctypes.c_int, [c_i64, c_i64] + [c_vp] * 6),
     "fk_resample_gather_mean_f64": (ctypes.c_int, [c_i64, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp]),
     "fk_cumsum_exact_f64": (ctypes.c_int, [c_i64, c_i64, c_vp, c_vp, c_i32, c_vp]),
     "fk_resample_workspace_bytes": (c_sz, [c_i64, c_i64]),

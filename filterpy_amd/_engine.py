@@ -250,6 +250,16 @@ def resample_multinomial(Fn, Np, Nu, w, u, idx):
     _abi.check(rc, "fk_resample_multinomial_f64")
 
 
+def resample_residual_fill(Fn, Np, w, idx, k, cs, status):
+    rc = _abi.lib().fk_resample_residual_fill_f64(Fn, Np, _ptr(w), _ptr(idx), _ptr(k), _ptr(cs), _ptr(status), _stream())
+    _abi.check(rc, "fk_resample_residual_fill_f64")
+
+
+def resample_residual_draw(Fn, Np, cs, k, uoff, u, idx):
+    rc = _abi.lib().fk_resample_residual_draw_f64(Fn, Np, _ptr(cs), _ptr(k), _ptr(uoff), _ptr(u), _ptr(idx), _stream())
+    _abi.check(rc, "fk_resample_residual_draw_f64")
+
+
 def resample_gather_mean(Fn, Np, d, particles, idx, mean):
     """fk_resample_gather_mean_f64: mean[f] = particles[f][idx[f]].mean(axis=0) without the resampled copy."""
     rc = _abi.lib().fk_resample_gather_mean_f64(Fn, Np, d, _ptr(particles), _ptr(idx), _ptr(mean), _stream())

@@ -35,8 +35,8 @@ extern "C" int fk_imm_batch_ex_f64(const fk_imm_desc *d, const double *F, const 
                                        int32_t *status, void *stream)
 {
     if (!d) return fail(FK_ERR_BAD_ARG, "desc is NULL");
-    if (d->n < 1 || d->n > 6 || d->m < 1 || d->m > 3 || d->n_models < 2 || d->n_models > 3)
-        return fail(FK_ERR_UNSUPPORTED, "IMM: dim_x 1..6, dim_z 1..3, 2..3 models");
+    if (d->n < 1 || d->n > 9 || d->m < 1 || d->m > 4 || d->n_models < 2 || d->n_models > 8)
+        return fail(FK_ERR_UNSUPPORTED, "IMM: dim_x 1..9, dim_z 1..4, 2..8 models");
     if (d->layout != FK_LAYOUT_AOS && d->layout != FK_LAYOUT_SOA) return fail(FK_ERR_BAD_ARG, "IMM: bad layout");
     if (d->phase < FK_IMM_STEP || d->phase > FK_IMM_UPDATE) return fail(FK_ERR_BAD_ARG, "IMM: bad phase");
     const bool needs_z = (d->phase == FK_IMM_STEP && d->T > 0) || d->phase == FK_IMM_UPDATE;
@@ -65,15 +65,29 @@ extern "C" int fk_imm_batch_ex_f64(const fk_imm_desc *d, const double *F, const 
     if (d->phase != FK_IMM_STEP || a.mmae) mask = -1;   // the general kernel also carries the MMAE arithmetic
     if (zmask || ll0 || nu > 0) mask = -1;               // ... the missing-measurement bookkeeping and the control input
     hipStream_t s = (hipStream_t)stream;
-    const int cls = (d->n <= 2 && d->m <= 1) ? 0 : (d->n <= 4 && d->m <= 2) ? 1 : 2;
-    if (d->n_models == 2) {
-        if (cls == 0) launch_imm_2_1_2(a, d->layout, mask, s);
-        else if (cls == 1) launch_imm_4_2_2(a, d->layout, mask, s);
-        else launch_imm_6_3_2(a, d->layout, mask, s);
+    // register-resident instantiations for the small banks (2 / 3 filters, dim_x <= 6, dim_z <= 3); everything else -- up to
+    // eight filters, dim_x <= 9, dim_z <= 4 -- on the rolled (9, 4) class of its bank size (fk_dims_imm.def)
+    if (d->n <= 6 && d->m <= 3 && d->n_models <= 3) {
+        const int cls = (d->n <= 2 && d->m <= 1) ? 0 : (d->n <= 4 && d->m <= 2) ? 1 : 2;
+        if (d->n_models == 2) {
+            if (cls == 0) launch_imm_2_1_2(a, d->layout, mask, s);
+            else if (cls == 1) launch_imm_4_2_2(a, d->layout, mask, s);
+            else launch_imm_6_3_2(a, d->layout, mask, s);
+        } else {
+            if (cls == 0) launch_imm_2_1_3(a, d->layout, mask, s);
+            else if (cls == 1) launch_imm_4_2_3(a, d->layout, mask, s);
+            else launch_imm_6_3_3(a, d->layout, mask, s);
+        }
     } else {
-        if (cls == 0) launch_imm_2_1_3(a, d->layout, mask, s);
-        else if (cls == 1) launch_imm_4_2_3(a, d->layout, mask, s);
-        else launch_imm_6_3_3(a, d->layout, mask, s);
+        switch (d->n_models) {
+        case 2: launch_imm_9_4_2(a, d->layout, mask, s); break;
+        case 3: launch_imm_9_4_3(a, d->layout, mask, s); break;
+        case 4: launch_imm_9_4_4(a, d->layout, mask, s); break;
+        case 5: launch_imm_9_4_5(a, d->layout, mask, s); break;
+        case 6: launch_imm_9_4_6(a, d->layout, mask, s); break;
+        case 7: launch_imm_9_4_7(a, d->layout, mask, s); break;
+        default: launch_imm_9_4_8(a, d->layout, mask, s); break;
+        }
     }
     return check_launch("imm_kernel");
 }

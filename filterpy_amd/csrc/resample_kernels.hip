@@ -395,6 +395,123 @@ searchsorted_left_kernel(long Np, long Nu, const double *__restrict__ cs, const 
     idx[f * Nu + i] = lo;
 }
 
+// ---- residual_resample (filterpy/monte_carlo/resampling.py:27-76) ---------------------------------------------------------
+// Part 1, one workgroup per filter:
+//   num_copies = floor(N w)  (:61);  indexes[k++] = i, num_copies[i] times, i ascending  (:63-66) -- an exclusive integer scan
+//   of the copy counts gives every weight the start of its run;  residual = w - num_copies  (:70 -- not N w - num_copies:
+//   restated literally, so every weight that earned a copy has a NEGATIVE residual);  residual /= sum(residual)  (:71: the
+//   Python builtin, i.e. 0 + r_0 + r_1 + ... strictly left to right);  cumulative_sum = cumsum(residual); [-1] = 1.  (:72-74).
+// The two add chains are walked by ONE thread over tiles staged in LDS: with negative terms the running sum wanders through
+// binades in both directions and fk_exact_scan.hpp's monoid (non-negative terms) does not apply -- 2 x Np dependent adds,
+// ~70 us for 8000 particles, every filter on its own workgroup.  k > Np (the reference's fill loop then raises IndexError)
+// sets ST_OVERRUN and leaves the rest undone.
+// Part 2: indexes[k:N] = searchsorted(cumulative_sum, random(N - k))  (:75-76), one thread per draw.
+__global__ void __launch_bounds__(RS_THREADS)
+residual_fill_kernel(long Np, const double *__restrict__ w, int32_t *__restrict__ idx, long *__restrict__ kout,
+                     double *__restrict__ cs, int32_t *__restrict__ status)
+{
+    __shared__ double tile[RS_TILE];
+    __shared__ long wtot[RS_THREADS / 64];
+    __shared__ double bc;
+    const long f = blockIdx.x;
+    const double *wf = w + f * Np;
+    int32_t *of = idx + f * Np;
+    double *cf = cs + f * Np;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const double dN = (double)Np;
+    long carry = 0;                                                        // copies before the tile
+    for (long base = 0; base < Np; base += RS_TILE) {                      // uniform
+        const int len = (int)((Np - base) < RS_TILE ? (Np - base) : RS_TILE);
+        long cnt[RS_ITEMS], run = 0;
+        FK_UNROLL for (int q = 0; q < RS_ITEMS; ++q) {                     // thread t owns RS_ITEMS consecutive weights
+            const int j = tid * RS_ITEMS + q;
+            const double wj = j < len ? wf[base + j] : 0.0;
+            const double c = floor(dN * wj);                               // (np.floor(N * w)).astype(int): one rounding, then floor
+            const long ci = (c >= 0.0 && c < 0x1p40) ? (long)c : 0;        // (negative / NaN / absurd: no copies, garbage anyway)
+            cnt[q] = ci;
+            run += ci;
+            if (j < len) cf[base + j] = wj - c;                            // the residual, for the two passes below
+        }
+        long incl = run;
+        FK_UNROLL for (int d = 1; d < 64; d <<= 1) {
+            const long up = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += up;
+        }
+        if (lane == 63) wtot[wave] = incl;
+        __syncthreads();
+        long off = carry + incl - run, total = 0;
+        FK_UNROLL for (int wv = 0; wv < RS_THREADS / 64; ++wv) {
+            if (wv < wave) off += wtot[wv];
+            total += wtot[wv];
+        }
+        FK_UNROLL for (int q = 0; q < RS_ITEMS; ++q) {
+            const int j = tid * RS_ITEMS + q;
+            for (long c = 0; c < cnt[q]; ++c)
+                if (off + c < Np) of[off + c] = (int32_t)(base + j);
+            off += cnt[q];
+        }
+        carry += total;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        kout[f] = carry;
+        if (status) status[f] = carry > Np ? ST_OVERRUN : 0;
+    }
+    if (carry > Np) return;                                                // uniform: IndexError in the reference
+    __threadfence_block();
+    __syncthreads();
+    // sum(residual): the builtin's chain 0 + r_0 + r_1 + ...
+    double total = 0.0;
+    for (int pass = 0; pass < 2; ++pass) {                                 // 0: the sum; 1: the cumulative sums of r / sum
+        double c = 0.0;
+        for (long base = 0; base < Np; base += RS_TILE) {
+            const int len = (int)((Np - base) < RS_TILE ? (Np - base) : RS_TILE);
+            for (int j = tid; j < len; j += RS_THREADS) tile[j] = pass ? cf[base + j] / total : cf[base + j];   // (:71: one division each)
+            __syncthreads();
+            if (tid == 0) {
+                for (int j = 0; j < len; j += 8) {                         // eight independent LDS reads, then the add chain
+                    double v[8];
+                    FK_UNROLL for (int e = 0; e < 8; ++e) v[e] = j + e < len ? tile[j + e] : 0.0;
+                    FK_UNROLL for (int e = 0; e < 8; ++e) {
+                        if (j + e < len) {
+                            c = c + v[e];
+                            v[e] = c;
+                        }
+                    }
+                    if (pass) { FK_UNROLL for (int e = 0; e < 8; ++e) if (j + e < len) tile[j + e] = v[e]; }
+                }
+                bc = c;
+            }
+            __syncthreads();
+            if (pass)
+                for (int j = tid; j < len; j += RS_THREADS) cf[base + j] = tile[j];
+            c = bc;
+            __syncthreads();
+        }
+        if (pass == 0) total = c;
+    }
+    if (tid == 0) cf[Np - 1] = 1.0;                                        // :74
+}
+
+__global__ void __launch_bounds__(RS_THREADS)
+residual_draw_kernel(long Np, const double *__restrict__ cs, const long *__restrict__ k, const long *__restrict__ uoff,
+                     const double *__restrict__ u, int32_t *__restrict__ idx)
+{
+    const long f = blockIdx.y;
+    const long kf = k[f];
+    const long i = (long)blockIdx.x * RS_THREADS + threadIdx.x;
+    if (kf > Np || i >= Np - kf) return;
+    const double *cf = cs + f * Np;
+    const double v = u[uoff[f] + i];
+    long lo = 0, hi = Np;
+    while (lo < hi) {                                                      // numpy.searchsorted, side 'left'
+        const long mid = (lo + hi) >> 1;
+        if (cf[mid] < v) lo = mid + 1;
+        else hi = mid;
+    }
+    idx[f * Np + kf + i] = (int32_t)lo;
+}
+
 // vectors of at least RS_PAR_MIN weights take the one-pass path (resample_onepass.hip): many workgroups per filter
 constexpr long RS_PAR_MIN = 16L * RS_TILE;
 
@@ -538,6 +655,30 @@ int fk_resample_multinomial_f64(int64_t Fn, int64_t Np, int64_t Nu, const double
     const dim3 grid((unsigned)((Nu + RS_THREADS - 1) / RS_THREADS), (unsigned)Fn), block(RS_THREADS);
     hipLaunchKernelGGL(searchsorted_left_kernel, grid, block, 0, (hipStream_t)stream, (long)Np, (long)Nu, cs, u, idx);
     return check_launch("searchsorted_left_kernel");
+}
+
+int fk_resample_residual_fill_f64(int64_t Fn, int64_t Np, const double *w, int32_t *idx, int64_t *k, double *cs,
+                                  int32_t *status, void *stream)
+{
+    if (Fn < 0 || Np < 0) return fail(FK_ERR_BAD_ARG, "residual: negative size");
+    if (Np >= 2147483647LL || Fn > 0x7fffffffL) return fail(FK_ERR_UNSUPPORTED, "residual: Np must fit int32");
+    if (Fn == 0 || Np == 0) return FK_OK;
+    if (!w || !idx || !k || !cs) return fail(FK_ERR_BAD_ARG, "residual: w, idx, k, cs must not be NULL");
+    hipLaunchKernelGGL(residual_fill_kernel, dim3((unsigned)Fn), dim3(RS_THREADS), 0, (hipStream_t)stream, (long)Np, w, idx,
+                       (long *)k, cs, status);
+    return check_launch("residual_fill_kernel");
+}
+
+int fk_resample_residual_draw_f64(int64_t Fn, int64_t Np, const double *cs, const int64_t *k, const int64_t *uoff,
+                                  const double *u, int32_t *idx, void *stream)
+{
+    if (Fn < 0 || Np < 0) return fail(FK_ERR_BAD_ARG, "residual: negative size");
+    if (Fn == 0 || Np == 0) return FK_OK;
+    if (Fn > 65535) return fail(FK_ERR_UNSUPPORTED, "residual draw: at most 65535 filters per call");
+    if (!cs || !k || !uoff || !u || !idx) return fail(FK_ERR_BAD_ARG, "residual: NULL argument");
+    const dim3 grid((unsigned)((Np + RS_THREADS - 1) / RS_THREADS), (unsigned)Fn), block(RS_THREADS);
+    hipLaunchKernelGGL(residual_draw_kernel, grid, block, 0, (hipStream_t)stream, (long)Np, cs, (const long *)k, (const long *)uoff, u, idx);
+    return check_launch("residual_draw_kernel");
 }
 
 int fk_resample_gather_mean_f64(int64_t Fn, int64_t Np, int32_t d, const double *particles, const int32_t *idx,

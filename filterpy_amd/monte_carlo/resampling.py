@@ -82,29 +82,24 @@ def multinomial_resample(weights):
 
 
 def residual_resample(weights):
-    """resampling.py:27-76, restated literally on the device: floor(N w) deterministic copies,
-    then a multinomial draw on `weights - num_copies` normalised by its sequential sum."""
+    """resampling.py:27-76 on the device, for one filter or a bank: floor(N w) deterministic copies
+    (fk_resample_residual_fill_f64), then a multinomial draw on `weights - num_copies` normalised by its sequential sum
+    (fk_resample_residual_draw_f64).  The host only draws the uniforms -- random(N - k) per filter, in filter order: how
+    many the reference takes from numpy.random depends on the weights."""
     import torch
     w, batched = _prep(weights)
-    if batched:
-        return np.stack([residual_resample(wi) for wi in w])
-    wd = w[0]
-    N = wd.numel()
-    num_copies = torch.floor(N * wd)                              # :61
-    counts = num_copies.to(torch.int64)
-    k = int(counts.sum())
-    if k > N:        # the reference's fill loop writes indexes[k] past the end (resampling.py:63-66)
-        raise IndexError(f"index {N} is out of bounds for axis 0 with size {N}")
-    idx = torch.zeros(N, dtype=torch.int32, device=wd.device)
-    if k:
-        idx[:k] = torch.repeat_interleave(torch.arange(N, device=wd.device, dtype=torch.int32), counts)[:N]
-    residual = (wd - num_copies).contiguous()                     # :70 (not N*w - copies)
-    cs = torch.empty_like(residual)
-    E.cumsum_exact(1, N, residual, cs)                            # builtin sum() == last sequential partial sum
-    residual = (residual / cs[-1]).contiguous()                   # :71
-    if N - k > 0:
-        u = E.dev(random(N - k))
-        tail = torch.empty(N - k, dtype=torch.int64, device=wd.device)
-        E.resample_multinomial(1, N, N - k, residual, u, tail)    # cumsum, cs[-1]=1., searchsorted  (:72-76)
-        idx[k:] = tail.to(torch.int32)
-    return idx.cpu().numpy()
+    Fn, Np = w.shape
+    idx = torch.zeros((Fn, Np), dtype=torch.int32, device=w.device)
+    k = torch.zeros(Fn, dtype=torch.int64, device=w.device)
+    cs = torch.empty((Fn, Np), dtype=torch.float64, device=w.device)
+    st = torch.zeros(Fn, dtype=torch.int32, device=w.device)
+    E.resample_residual_fill(Fn, Np, w, idx, k, cs, st)
+    kh = k.cpu().numpy()
+    if (kh > Np).any():   # the reference's fill loop writes indexes[k] past the end (resampling.py:63-66)
+        raise IndexError(f"index {Np} is out of bounds for axis 0 with size {Np}")
+    draws = [random(int(Np - kf)) for kf in kh]
+    if sum(len(d) for d in draws):
+        uoff = np.concatenate([[0], np.cumsum([len(d) for d in draws])[:-1]]).astype(np.int64)
+        E.resample_residual_draw(Fn, Np, cs, k, torch.as_tensor(uoff, device=w.device), E.dev(np.concatenate(draws)), idx)
+    out = idx.cpu().numpy()
+    return out if batched else out[0]

@@ -309,7 +309,7 @@ int fk_ukf_rts_correct_f64(int32_t n, int64_t N, int32_t layout,
 
 typedef struct fk_imm_desc {
     int32_t n, m;         /* dim_x (1..6), dim_z (1..3): the same for every filter of the bank */
-    int32_t n_models;     /* filters per track: 2 or 3 */
+    int32_t n_models;     /* filters per track: 2 .. 8 (dim_x 1..9, dim_z 1..4) */
     int32_t layout;
     int64_t N, T;
     int32_t phase;        /* FK_IMM_STEP: T x {predict; update}; FK_IMM_PREDICT / FK_IMM_UPDATE: that half once */
@@ -399,6 +399,19 @@ int fk_resample_stratified_f64(int64_t Fn, int64_t Np, const double *w, const do
  * reference returns). */
 int fk_resample_multinomial_f64(int64_t Fn, int64_t Np, int64_t Nu, const double *w, const double *u,
                                 int64_t *idx, void *ws, size_t ws_bytes, void *stream);
+
+/* residual_resample (resampling.py:27-76) for Fn filters, in two launches around the host's draw of the uniforms (how many
+ * the reference consumes from numpy.random depends on the weights: random(N - k)).
+ *   fill: num_copies = floor(Np w) (:61); the deterministic copies idx[f][0 .. k_f) (:63-66); k_f -> k [Fn] (int64);
+ *         cs [Fn][Np] (caller's buffer) <- cumsum((w - num_copies) / sum(w - num_copies)) with cs[-1] = 1 (:70-74; the sum
+ *         is the Python builtin's left-to-right chain); status[f] = FK_STATUS_OVERRUN when k_f > Np (the reference's
+ *         IndexError), nothing else is written for that filter.
+ *   draw: idx[f][k_f + i] = searchsorted(cs_f, u[uoff[f] + i]) for i < Np - k_f (:75-76); u holds every filter's
+ *         Np - k_f uniforms back to back, uoff [Fn] (int64) their offsets.   idx is int32 like the reference's. */
+int fk_resample_residual_fill_f64(int64_t Fn, int64_t Np, const double *w, int32_t *idx, int64_t *k, double *cs,
+                                  int32_t *status, void *stream);
+int fk_resample_residual_draw_f64(int64_t Fn, int64_t Np, const double *cs, const int64_t *k, const int64_t *uoff,
+                                  const double *u, int32_t *idx, void *stream);
 
 size_t fk_resample_workspace_bytes(int64_t Fn, int64_t Np);     /* systematic / stratified */
 size_t fk_multinomial_workspace_bytes(int64_t Fn, int64_t Np);  /* multinomial: Fn*Np doubles */

@@ -167,7 +167,87 @@ def test_imm_rejects_what_the_kernel_cannot_do():
         IMMEstimator(fs[:1], [1.0], np.eye(1))
     imm = IMMEstimator(fs, [0.5, 0.5], np.array([[0.9, 0.1], [0.1, 0.9]]))
     with pytest.raises(NotImplementedError):
-        IMMEstimator([KalmanFilter(dim_x=2, dim_z=1) for _ in range(4)], [1, 1, 1, 1], np.full((4, 4), 0.25))
+        IMMEstimator([KalmanFilter(dim_x=2, dim_z=1) for _ in range(9)], [1] * 9, np.full((9, 9), 1 / 9))
+    with pytest.raises(NotImplementedError):
+        IMMEstimator([KalmanFilter(dim_x=10, dim_z=1) for _ in range(2)], [.5, .5], np.full((2, 2), .5))
+
+
+# ---- round 3: banks of up to eight filters, dim_x <= 9, dim_z <= 4 (the rolled (9, 4) class of every bank size) ----------
+def _big(kind):
+    g = golden("imm_big")
+    return [tuple(int(v) for v in c) for c in g[kind + "_cases"]]
+
+
+@pytest.mark.parametrize("layout", ["soa", "aos"])
+@pytest.mark.parametrize("n,m,nm", _big("imm"))
+def test_big_imm_banks_vs_live_reference(n, m, nm, layout):
+    """IMMEstimator on banks the round-2 kernel refused: every track of a ragged bank runs the live reference's sequence"""
+    from gpu_util import tile_tracks
+    g = golden("imm_big")
+    p = f"imm_n{n}m{m}k{nm}_"
+    N = 130
+    r = run_imm(tile_tracks(g[p + "xs0"], N), tile_tracks(g[p + "Ps0"], N), tile_tracks(g[p + "mu0"], N), g[p + "M"],
+                tile_tracks(g[p + "zs"], N, axis=1), g[p + "Fs"], g[p + "Qs"], g[p + "Hs"], g[p + "Rs"], layout)
+    for trk in (0, 63, 64, N - 1):
+        assert rel_err_rows(r["x_out"][:, trk], g[p + "x"]) < TOL and rel_err_rows(r["P_out"][:, trk], g[p + "P"]) < TOL
+        assert rel_err_rows(r["x_prior_out"][:, trk], g[p + "xp"]) < TOL
+        assert rel_err_rows(r["P_prior_out"][:, trk], g[p + "Pp"]) < TOL
+        assert np.allclose(r["mu_out"][:, trk], g[p + "mu"], rtol=1e-10, atol=1e-14)
+        assert np.allclose(r["likelihood_out"][:, trk], g[p + "L"], rtol=1e-10, atol=1e-300)
+        assert rel_err_rows(r["xs"][trk], g[p + "xs_final"]) < TOL and rel_err_rows(r["Ps"][trk], g[p + "Ps_final"]) < TOL
+
+
+@pytest.mark.parametrize("layout", ["soa", "aos"])
+@pytest.mark.parametrize("n,m,nm", [(9, 3, 4), (5, 4, 8), (3, 1, 6)])
+def test_big_imm_seeded_bank_vs_oracle(n, m, nm, layout):
+    """independent tracks (own states, measurements, mode probabilities) on the big banks, against the oracle"""
+    from oracle import imm_oracle
+    rs = np.random.RandomState(177 + n + nm)
+    N, T = 200, 10
+    Fs = np.array([stable_F(rs, n) for _ in range(nm)])
+    Qs = np.array([spd(rs, n, 0.05 * (j + 1)) for j in range(nm)])
+    Hs = np.array([rs.randn(m, n)] * nm)
+    Rs = np.array([spd(rs, m, 0.5) for _ in range(nm)])
+    M = rs.rand(nm, nm) + 2 * np.eye(nm)
+    M /= M.sum(axis=1, keepdims=True)
+    xs0 = rs.randn(N, nm, n)
+    Ps0 = np.array([[spd(rs, n, 2.0) for _ in range(nm)] for _ in range(N)])
+    mu0 = rs.rand(N, nm) + 0.1
+    mu0 /= mu0.sum(axis=1, keepdims=True)
+    zs = rs.randn(T, N, m) * 2
+    r = run_imm(xs0, Ps0, mu0, M, zs, Fs, Qs, Hs, Rs, layout)
+    for trk in (0, 1, 63, 64, N - 1):
+        x, P, mu, xp, Pp, L = imm_oracle.imm_batch(xs0[trk], Ps0[trk], mu0[trk], M, zs[:, trk], Fs, Qs, Hs, Rs)
+        assert rel_err_rows(r["x_out"][:, trk], x) < TOL and rel_err_rows(r["P_out"][:, trk], P) < TOL
+        assert rel_err_rows(r["x_prior_out"][:, trk], xp) < TOL and rel_err_rows(r["P_prior_out"][:, trk], Pp) < TOL
+        assert np.allclose(r["mu_out"][:, trk], mu, rtol=1e-10, atol=1e-14)
+        assert np.allclose(r["likelihood_out"][:, trk], L, rtol=1e-10, atol=1e-300)
+
+
+def test_big_imm_and_mmae_classes_drop_in():
+    """the reference's own usage on the big banks: predict(); update(z) call by call, then batch_filter for the rest"""
+    from filterpy_amd.kalman import IMMEstimator, MMAEFilterBank
+    g = golden("imm_big")
+    for n, m, nm in _big("imm")[:3]:
+        p = f"imm_n{n}m{m}k{nm}_"
+        imm = IMMEstimator(_make_filters(g, p, n, m, nm, False), g[p + "mu0"].copy(), g[p + "M"])
+        for t in range(6):
+            imm.predict()
+            assert rel_err_rows(imm.x[None], g[p + "xp"][t][None]) < TOL and rel_err_rows(imm.P[None], g[p + "Pp"][t][None]) < TOL
+            imm.update(g[p + "zs"][t])
+            assert rel_err_rows(imm.x[None], g[p + "x"][t][None]) < TOL and rel_err_rows(imm.P[None], g[p + "P"][t][None]) < TOL
+            assert np.allclose(imm.mu, g[p + "mu"][t], rtol=1e-10, atol=1e-14)
+    for n, m, nm in _big("mmae"):
+        q = f"mmae_n{n}m{m}k{nm}_"
+        gg = {k: g[k] for k in g.files if k.startswith(q)}
+        bank = MMAEFilterBank(_make_filters(gg, q, n, m, nm, False), g[q + "p0"].copy(), dim_x=n)
+        for t in range(6):
+            bank.predict()
+            bank.update(g[q + "zs"][t])
+            assert rel_err_rows(bank.x[None], g[q + "x"][t][None]) < TOL and rel_err_rows(bank.P[None], g[q + "P"][t][None]) < TOL
+            assert np.allclose(bank.p, g[q + "p"][t], rtol=1e-10, atol=1e-14)
+        xs, Ps, ps = bank.batch_filter(g[q + "zs"][6:])
+        assert rel_err_rows(xs.reshape(-1, n), g[q + "x"][6:]) < TOL and rel_err_rows(Ps, g[q + "P"][6:]) < TOL
 
 
 # ------------------------------------------------------------------------------- MMAE ----

@@ -105,6 +105,33 @@ def test_bank_of_filters_vs_oracle():
         assert over == 0 and np.array_equal(got[f], ref), f
 
 
+def test_residual_resample_bank_and_edges():
+    """residual_resample on the device (fk_resample_residual_fill_f64 + _draw_f64; resampling.py:27-76): a bank draws
+    random(N - k_f) per filter in filter order, so it equals the filters resampled one by one under the same seed -- and
+    both equal the oracle's restatement of the reference's loops; weights that earn more than N copies raise IndexError"""
+    import filterpy_amd.monte_carlo as mc
+    from oracle import resample_oracle as ro
+    rs = np.random.RandomState(404)
+    for Np in (1, 7, 100, 2049, 8000):
+        Fn = 6
+        w = rs.rand(Fn, Np) ** rs.choice([1, 3], size=(Fn, 1))
+        w /= w.sum(axis=1, keepdims=True)
+        w[1] = np.full(Np, 1.0 / Np)                              # every weight earns exactly one copy: k = N, no draw
+        if Np > 4:
+            w[2, : Np // 2] = 0.0                                  # zero weights
+            w[2] /= w[2].sum()
+        np.random.seed(1234 + Np)
+        bank = mc.residual_resample(w)
+        np.random.seed(1234 + Np)
+        single = np.stack([mc.residual_resample(w[f]) for f in range(Fn)])
+        np.random.seed(1234 + Np)
+        ref = np.stack([ro.residual_seeded(w[f]) for f in range(Fn)])
+        assert bank.dtype == np.int32 and bank.shape == (Fn, Np)
+        assert np.array_equal(bank, single) and np.array_equal(bank, ref), Np
+    with pytest.raises(IndexError):
+        mc.residual_resample(np.array([0.9, 0.9, 0.9]))            # floor(3 * .9) = 2 copies each: 6 > 3
+
+
 def test_exact_cumsum_kernel_bitwise():
     import torch
     from filterpy_amd import _engine as E

@@ -68,3 +68,21 @@ def test_control_input_vs_live_reference(kind):
                                              g[p + "Rs"], Bs=g[p + "Bs"], us=g[p + "us"])[:3]
         assert np.allclose(x, g[q + "x"], rtol=1e-11, atol=1e-12) and np.allclose(P, g[q + "P"], rtol=1e-11, atol=1e-12)
         assert np.allclose(mu, g[q + "mu"], rtol=1e-11, atol=1e-13)
+
+
+def test_big_banks_vs_live_reference():
+    """banks of up to eight filters, dim_x up to 9, dim_z up to 4 (tests/golden/make_imm_big_golden.py)"""
+    g = golden("imm_big")
+    for n, m, nm in g["imm_cases"]:
+        p = f"imm_n{n}m{m}k{nm}_"
+        x, P, mu, xp, Pp, L = imm_oracle.imm_batch(g[p + "xs0"], g[p + "Ps0"], g[p + "mu0"], g[p + "M"], g[p + "zs"],
+                                                   g[p + "Fs"], g[p + "Qs"], g[p + "Hs"], g[p + "Rs"])
+        assert rel_err_rows(x, g[p + "x"]) < 1e-12 and rel_err_rows(P, g[p + "P"]) < 1e-12
+        assert rel_err_rows(xp, g[p + "xp"]) < 1e-12 and rel_err_rows(Pp, g[p + "Pp"]) < 1e-12
+        assert np.allclose(mu, g[p + "mu"], rtol=1e-11, atol=1e-15) and np.allclose(L, g[p + "L"], rtol=1e-11, atol=1e-300)
+    for n, m, nm in g["mmae_cases"]:
+        p = f"mmae_n{n}m{m}k{nm}_"
+        x, P, pr, L = imm_oracle.mmae_batch(g[p + "xs0"], g[p + "Ps0"], g[p + "p0"], g[p + "zs"],
+                                            g[p + "Fs"], g[p + "Qs"], g[p + "Hs"], g[p + "Rs"])
+        assert rel_err_rows(x, g[p + "x"]) < 1e-12 and rel_err_rows(P, g[p + "P"]) < 1e-12
+        assert np.allclose(pr, g[p + "p"], rtol=1e-11, atol=1e-15) and np.allclose(L, g[p + "L"], rtol=1e-11, atol=1e-300)
