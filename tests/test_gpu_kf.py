@@ -430,7 +430,8 @@ def test_multilane_variants_small_shapes(N, T):
 
 
 @pytest.mark.parametrize("layout", ["soa", "aos"])
-@pytest.mark.parametrize("n,m", [(10, 1), (10, 4), (11, 2), (12, 3), (13, 1), (13, 4), (14, 2), (15, 3), (16, 1), (16, 4)])
+@pytest.mark.parametrize("n,m", [(10, 1), (10, 4), (11, 2), (12, 3), (13, 1), (13, 4), (14, 2), (15, 3), (16, 1), (16, 4),
+                                 (10, 5), (11, 8), (12, 6), (13, 7), (14, 5), (15, 6), (16, 8)])
 def test_four_lane_kernel_dims_10_to_16_vs_oracle(n, m, layout, monkeypatch):
     """kf_mlg.hip (four lanes per track; the rows past n-1 of lane 3 clamped to row n-1, entering the quad's H P sum
     with coefficient 0): every track its own state and measurements, N not a multiple of the 64 tracks of a workgroup,
@@ -584,7 +585,7 @@ def test_four_lane_smoother_small_shapes(N, T):
 
 
 @pytest.mark.parametrize("layout", ["soa", "aos"])
-@pytest.mark.parametrize("n,m", [(10, 2), (13, 4), (16, 3)])
+@pytest.mark.parametrize("n,m", [(10, 2), (13, 4), (16, 3), (12, 6), (16, 8)])
 def test_four_lane_kernel_variants_vs_oracle(n, m, layout):
     """kf_mlg.hip's VAR instantiations (per-step model lists incl. B, control input, update_first, mask: every
     combination) at dims above 9 -- calls that ran on the padded one-lane kernel before."""
