@@ -169,7 +169,7 @@ def test_chunk_plan_windows_tile_the_time_axis(monkeypatch):
 
 
 def test_design_table_is_the_committed_evidence():
-    """DESIGN.md section 5's per-kernel table is generated from profiles/r02/configs_all.jsonl (tools/make_design_table.py):
+    """DESIGN.md section 5's per-kernel table and section 4's byte table are generated from profiles/r03 (tools/make_design_table.py):
     the document cannot drift from the measurement files"""
     import subprocess
     import sys
