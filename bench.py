@@ -420,7 +420,7 @@ def main():
     gathered = torch.empty((world,) + tuple(x.shape), dtype=torch.float64, device=device) if exchange else None
     desc = dict(n=n, m=m, nu=0, model_mode=0, N=N, T=T, layout=E.LAYOUTS[layout], update_first=0, alpha_sq=1.0)
 
-    def step(ev=None):
+    def step(ev=None, with_exchange=True):
         x.copy_(x0)
         P.copy_(P0)
         if ev:
@@ -429,7 +429,7 @@ def main():
                           covs_p=covs_p, status=status)
         if ev:
             ev[1].record()
-        if exchange:
+        if exchange and with_exchange:
             parallel.allgather_summary(x, gathered)        # summary state over RCCL/xGMI
 
     barrier = parallel.barrier
@@ -488,7 +488,7 @@ def main():
                          "kernel": "fk::kf_fast_kernel<4,2," + layout + ",nomask,outs> (variant " + os.environ.get("FK_FAST_VARIANT", "0") + ")", "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_launch": alg_bytes},
             "parity_max_rel_vs_oracle": worst, "parity_tracks": int(len(sample)),
-            "gpu_clocks": gpu_clocks(), "hbm_probes": hbm_probes(device), "under_load": clocks_under_load(step),
+            "gpu_clocks": gpu_clocks(), "hbm_probes": hbm_probes(device), "under_load": clocks_under_load(lambda: step(None, False)),   # rank 0 alone: no collective in the burst
         }
         if args.force_dist:
             out["dist_forced"] = f"{world}-rank {dist.get_backend()} group: init_process_group(device_id), all_gather_into_tensor, barrier, all_reduce(MAX) executed"
