@@ -243,6 +243,35 @@ __device__ __forceinline__ void wave_store_aos(const double (&v)[LEN], const dou
     wave_lds_fence();
 }
 
+// The mirror image: wave-cooperative LOAD of one LEN-double record per lane from an AOS block -- memory order into the
+// tile (two consecutive doubles per lane per pass: buffer_load_dwordx4, 1 KiB contiguous per instruction; rows past the
+// block's last track read as 0 through the descriptor's range check), then every lane reads its own row.  A lane-strided
+// read of a 78-double record touches 64 different lines per instruction and thrashes the 16 KiB vector L1.
+template <int LEN>
+__device__ __forceinline__ void wave_load_aos(double (&v)[LEN], const double *slab, unsigned wave_row0, double *tile,
+                                              unsigned lane, unsigned last_row)
+{
+    static_assert(LEN % 2 == 0, "pairs of doubles");
+    constexpr int LENP = LEN | 1;
+    const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(slab), 0,
+                                                        (int)((last_row + 1u) * (unsigned)LEN * 8u), 0x00020000);
+    constexpr int PASSES = LEN / 2;
+    u32x4 w[PASSES];
+    FK_UNROLL for (int it = 0; it < PASSES; ++it) {
+        const unsigned q = it * 128u + lane * 2u;
+        w[it] = __builtin_amdgcn_raw_buffer_load_b128(rs, (wave_row0 * LEN + q) * 8u, 0, 0);
+    }
+    FK_UNROLL for (int it = 0; it < PASSES; ++it) {
+        const unsigned q = it * 128u + lane * 2u;
+        const unsigned row = q / LEN, col = q % LEN;
+        tile[row * LENP + col] = __builtin_bit_cast(double, u32x2{w[it].x, w[it].y});
+        tile[row * LENP + col + 1] = __builtin_bit_cast(double, u32x2{w[it].z, w[it].w});
+    }
+    wave_lds_fence();
+    FK_UNROLL for (int e = 0; e < LEN; ++e) v[e] = tile[lane * LENP + e];
+    wave_lds_fence();
+}
+
 // ---- host side ------------------------------------------------------------
 void set_last_error(const char *msg);
 int check_launch(const char *what);   // hipGetLastError -> FK_ERR_LAUNCH + message

@@ -9,6 +9,8 @@
 // (the fused linear-model filter lives in ukf_kernels.hip)
 // Algorithmic bytes: sigma points 8(n + n^2 + (2n+1)n), UT 8((2n+1)n + n + n^2) per track;
 // fused step 8(m + n + n^2) per track-step.
+#include <stdlib.h>
+
 #include "../../include/filterhip.h"
 #include "fk_device.hpp"
 #include "fk_kernel_args.hpp"
@@ -109,6 +111,88 @@ ut_reg_kernel(long N, const double *__restrict__ sig, const double *__restrict__
             pv.store(a * NX + b2, v);
             if (b2 != a) pv.store(b2 * NX + a, noise ? U[t] + noise[b2 * NX + a] : U[t]);
         }
+}
+
+// ---- NumPy order, exact dims 2 / 4 / 6: one WAVE per workgroup, records through a wave-private LDS tile -------------------
+// In NumPy order (AOS) a track's record is contiguous -- 78 doubles of sigma points at n = 6 -- and a lane-per-record access
+// touches 64 different cache lines per instruction: the round-2 kernels measured 0.32-0.43 of HBM there against 0.6-0.86
+// in the element-major layout.  Here the sigma points (and x, P) move like kf_fast's outputs: 1 KiB contiguous per
+// instruction between HBM and a tile, row-per-lane between the tile and the registers (wave_load_aos / wave_store_aos,
+// fk_device.hpp).  The tile is 64 x (LEN | 1) doubles -- 40 KiB at n = 6 --, hence one wave per workgroup.
+constexpr int UT_WAVE = 64;
+template <int NX>
+__global__ void __launch_bounds__(UT_WAVE)
+sigma_coop_kernel(long N, double scale, const double *__restrict__ px, const double *__restrict__ pP, double *sig,
+                  int32_t *status)
+{
+    constexpr int K = 2 * NX + 1, LEN = K * NX;
+    __shared__ double tile[UT_WAVE * (LEN | 1)];
+    const long blk0 = (long)blockIdx.x * UT_WAVE;
+    const unsigned lane = threadIdx.x;
+    const long left = N - blk0;
+    const unsigned last_row = (unsigned)(left < UT_WAVE ? left : UT_WAVE) - 1u;
+    double x[NX], P[NX * NX], L[NX * NX];
+    if constexpr (NX >= 2) {
+        wave_load_aos<NX>(x, px + blk0 * NX, 0u, tile, lane, last_row);
+        wave_load_aos<NX * NX>(P, pP + blk0 * NX * NX, 0u, tile, lane, last_row);
+    }
+    if (lane > last_row) {                                                 // rows past the end read as zeros: keep the Cholesky sane
+        FK_UNROLL for (int e = 0; e < NX * NX; ++e) P[e] = (e / NX == e % NX) ? 1.0 : 0.0;
+    }
+    const bool pd = chol_lower<NX>(P, scale, L);
+    double s[LEN];
+    FK_UNROLL for (int c = 0; c < NX; ++c) s[c] = x[c];
+    FK_UNROLL for (int k = 0; k < NX; ++k)
+        FK_UNROLL for (int c = 0; c < NX; ++c) {
+            // np.subtract(x, -U[k]) and np.subtract(x, U[k])  (sigma_points.py:174-175); U[k][c] = L[c][k]
+            s[(k + 1) * NX + c] = x[c] - (-L[c * NX + k]);
+            s[(NX + k + 1) * NX + c] = x[c] - L[c * NX + k];
+        }
+    wave_store_aos<LEN>(s, sig + blk0 * LEN, 0u, tile, lane, last_row);
+    if (status && lane <= last_row) status[blk0 + lane] = pd ? 0 : ST_NOT_PD;
+}
+
+template <int NX>
+__global__ void __launch_bounds__(UT_WAVE)
+ut_coop_kernel(long N, const double *__restrict__ sig, const double *__restrict__ Wm, const double *__restrict__ Wc,
+               const double *__restrict__ noise, double *xo, double *Po)
+{
+    constexpr int K = 2 * NX + 1, LEN = K * NX;
+    __shared__ double tile[UT_WAVE * (LEN | 1)];
+    const long blk0 = (long)blockIdx.x * UT_WAVE;
+    const unsigned lane = threadIdx.x;
+    const long left = N - blk0;
+    const unsigned last_row = (unsigned)(left < UT_WAVE ? left : UT_WAVE) - 1u;
+    double s[LEN];
+    wave_load_aos<LEN>(s, sig + blk0 * LEN, 0u, tile, lane, last_row);
+    // the arithmetic of ut_reg_kernel: x = Wm . sigmas; P = sum_i y_i (Wc_i y_i)' (+ noise), points in index order
+    double x[NX];
+    FK_UNROLL for (int c = 0; c < NX; ++c) {
+        double acc = Wm[0] * s[c];
+        FK_UNROLL for (int i = 1; i < K; ++i) acc = fma(Wm[i], s[i * NX + c], acc);
+        x[c] = acc;
+    }
+    FK_UNROLL for (int i = 0; i < K; ++i)
+        FK_UNROLL for (int c = 0; c < NX; ++c) s[i * NX + c] -= x[c];
+    double U[NX * (NX + 1) / 2];
+    FK_UNROLL for (int i = 0; i < K; ++i) {
+        double wy[NX];
+        FK_UNROLL for (int c = 0; c < NX; ++c) wy[c] = Wc[i] * s[i * NX + c];
+        int t = 0;
+        FK_UNROLL for (int a = 0; a < NX; ++a)
+            FK_UNROLL for (int b2 = a; b2 < NX; ++b2, ++t)
+                U[t] = (i == 0) ? s[a] * wy[b2] : fma(s[i * NX + a], wy[b2], U[t]);
+        FK_STAGE();
+    }
+    double Pf[NX * NX];
+    int t = 0;
+    FK_UNROLL for (int a = 0; a < NX; ++a)
+        FK_UNROLL for (int b2 = a; b2 < NX; ++b2, ++t) {
+            Pf[a * NX + b2] = noise ? U[t] + noise[a * NX + b2] : U[t];
+            if (b2 != a) Pf[b2 * NX + a] = noise ? U[t] + noise[b2 * NX + a] : U[t];
+        }
+    wave_store_aos<NX>(x, xo + blk0 * NX, 0u, tile, lane, last_row);
+    wave_store_aos<NX * NX>(Pf, Po + blk0 * NX * NX, 0u, tile, lane, last_row);
 }
 
 // ------------------------------------------------------ unscented transform --
@@ -294,6 +378,15 @@ int fk_ut_sigma_points_f64(int32_t n, int64_t N, int32_t layout, double scale, c
     if ((double)N * (2 * n + 1) * n * 8.0 >= 4294967296.0) return fail(FK_ERR_UNSUPPORTED, "sigma points: record block >= 4 GiB, split the batch");
     if (N == 0) return FK_OK;
     const dim3 grid((unsigned)((N + BLOCK - 1) / BLOCK)), block(BLOCK);
+    // NumPy order at the exact dims 2 / 4 / 6: the wave-cooperative kernel (FK_UT_COOP=0: the per-lane 16-byte pairs of round 2)
+    static const bool coop = !(getenv("FK_UT_COOP") && getenv("FK_UT_COOP")[0] == '0');
+    if (coop && layout == FK_LAYOUT_AOS && (n == 2 || n == 4 || n == 6)) {
+        const dim3 g1((unsigned)((N + UT_WAVE - 1) / UT_WAVE)), b1(UT_WAVE);
+        if (n == 2) hipLaunchKernelGGL((sigma_coop_kernel<2>), g1, b1, 0, (hipStream_t)stream, (long)N, scale, x, P, sigmas, status);
+        else if (n == 4) hipLaunchKernelGGL((sigma_coop_kernel<4>), g1, b1, 0, (hipStream_t)stream, (long)N, scale, x, P, sigmas, status);
+        else hipLaunchKernelGGL((sigma_coop_kernel<6>), g1, b1, 0, (hipStream_t)stream, (long)N, scale, x, P, sigmas, status);
+        return check_launch("sigma_coop_kernel");
+    }
 #define CALL(NXV)                                                                                      \
     if (layout == FK_LAYOUT_SOA)                                                                       \
         hipLaunchKernelGGL((sigma_kernel<NXV, LAYOUT_SOA>), grid, block, 0, (hipStream_t)stream, n, N, \
@@ -318,6 +411,14 @@ int fk_ut_transform_f64(int32_t n, int32_t k, int64_t N, int32_t layout, const d
     if ((double)N * k * n * 8.0 >= 4294967296.0) return fail(FK_ERR_UNSUPPORTED, "unscented transform: record block >= 4 GiB, split the batch");
     if (N == 0) return FK_OK;
     const dim3 grid((unsigned)((N + BLOCK - 1) / BLOCK)), block(BLOCK);
+    static const bool coop = !(getenv("FK_UT_COOP") && getenv("FK_UT_COOP")[0] == '0');
+    if (coop && layout == FK_LAYOUT_AOS && k == 2 * n + 1 && (n == 2 || n == 4 || n == 6)) {
+        const dim3 g1((unsigned)((N + UT_WAVE - 1) / UT_WAVE)), b1(UT_WAVE);
+        if (n == 2) hipLaunchKernelGGL((ut_coop_kernel<2>), g1, b1, 0, (hipStream_t)stream, (long)N, sigmas, Wm, Wc, noise_cov, x_out, P_out);
+        else if (n == 4) hipLaunchKernelGGL((ut_coop_kernel<4>), g1, b1, 0, (hipStream_t)stream, (long)N, sigmas, Wm, Wc, noise_cov, x_out, P_out);
+        else hipLaunchKernelGGL((ut_coop_kernel<6>), g1, b1, 0, (hipStream_t)stream, (long)N, sigmas, Wm, Wc, noise_cov, x_out, P_out);
+        return check_launch("ut_coop_kernel");
+    }
     if (k == 2 * n + 1 && (n == 2 || n == 4 || n == 6)) {
 #define REG(NXV)                                                                                          \
     if (layout == FK_LAYOUT_SOA)                                                                          \
