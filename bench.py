@@ -237,10 +237,13 @@ def gpu_clocks():
         try:                                   # WHICH physical GPU this is: the boxes of the pool are not equally fast
             import re
             st = subprocess.run(["amd-smi", "static", "-g", "0"], capture_output=True, text=True, timeout=30).stdout
-            for key in ("ASIC_SERIAL", "OAM_ID", "VERSION"):
+            for key in ("ASIC_SERIAL", "OAM_ID", "VERSION", "MODEL_NUMBER", "FRU_ID", "VENDOR"):   # (VENDOR: the first is the GPU's, see vram_vendor)
                 mm = re.search(r"^\s*" + key + r":\s*(\S+)", st, re.M)
                 if mm:
                     keep[key.lower()] = mm.group(1)
+            mm = re.search(r"VRAM:\s*\n\s*TYPE:\s*(\S+)\s*\n\s*VENDOR:\s*(\S+)", st)
+            if mm:
+                keep["vram"] = mm.group(1) + " " + mm.group(2)
         except Exception:
             pass
         return keep or None
