@@ -415,10 +415,17 @@ def main():
     dF, dQ, dH, dR = (E.dev(M, device) for M in (F, Q, H, R))
     x0, P0, z = c2_inputs_device(N, T, layout, seed=1234 + rank, device=device)
     x, P = x0.clone(), P0.clone()
-    means = E.alloc_records((T,), N, n, layout, device)
-    covs = E.alloc_records((T,), N, n * n, layout, device)
-    means_p = E.alloc_records((T,), N, n, layout, device)
-    covs_p = E.alloc_records((T,), N, n * n, layout, device)
+    # measurement knob (tools/gpu_scripts/slow_box_probe.sh): FK_BENCH_PAD_MB=k puts k MiB of unused allocation between
+    # the output arrays -- it moves their relative placement in HBM and nothing else
+    pad_mb = int(os.environ.get("FK_BENCH_PAD_MB", "0"))
+    pads = []
+
+    def records(width):
+        if pad_mb:
+            pads.append(torch.empty(pad_mb << 20, dtype=torch.uint8, device=device))
+        return E.alloc_records((T,), N, width, layout, device)
+
+    means, covs, means_p, covs_p = records(n), records(n * n), records(n), records(n * n)
     status = torch.zeros(N, dtype=torch.int32, device=device)
     gathered = torch.empty((world,) + tuple(x.shape), dtype=torch.float64, device=device) if exchange else None
     desc = dict(n=n, m=m, nu=0, model_mode=0, N=N, T=T, layout=E.LAYOUTS[layout], update_first=0, alpha_sq=1.0)

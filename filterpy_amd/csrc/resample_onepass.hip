@@ -252,6 +252,9 @@ __device__ double lookback_exact(const OpDesc *d, int k, bool clean, int eu, int
 #ifndef FK_OP_SPEC_POLLS
 #define FK_OP_SPEC_POLLS 24
 #endif
+#ifndef FK_OP_GUESS_LO
+#define FK_OP_GUESS_LO 0.96    // the guess g is the binade of this fraction of k times the chunk's own sum
+#endif
 __device__ double lookback_spec(const OpDesc *d, int k, int g, double I0, double I1, bool v0, bool v1, int lane, int &which)
 {
     which = -1;
@@ -772,7 +775,7 @@ resample_onepass_kernel(const OpArgs a)
         if (k > 0 && !any_bad && S > 0.0) {                                // uniform
             // the k chunks before this one weigh about k times as much: the running sum enters near k S and leaves near
             // (k + 1) S; the lower end picks g, the next binade is the second candidate
-            const double glo = (double)k * S * 0.96, ghi = ((double)k + 1.0) * S * 1.04;
+            const double glo = (double)k * S * FK_OP_GUESS_LO, ghi = ((double)k + 1.0) * S * 1.04;
             guess = glo > OP_SANE_LO && ghi < OP_SANE_HI;
             g = ulp_exp(glo);
         }

@@ -33,7 +33,7 @@ def build(specs):
         cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
                "-fno-gpu-rdc", "-I" + CSRC] + [d for d in defs.split(",") if d] + \
               ["-o", os.path.join(OUT, f"librsv_{name}.so"), src, os.path.join(CSRC, "resample_kernels.hip"),
-               "-x", "hip", os.path.join(CSRC, "fk_host.cpp")]
+               os.path.join(CSRC, "resample_whole.hip"), "-x", "hip", os.path.join(CSRC, "fk_host.cpp")]
         procs.append((name, subprocess.Popen(cmd, cwd=CSRC)))
     for name, p in procs:
         assert p.wait() == 0, name

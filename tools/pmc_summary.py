@@ -1,24 +1,33 @@
 #!/usr/bin/env python3
-"""Summarise rocprofv3 --pmc counter CSVs: per-kernel average of each counter per dispatch."""
+"""Mean of every counter of rocprofv3 --pmc passes, per kernel: python tools/pmc_summary.py <dir> [<dir> ...] [--kernel substr]
+One JSON line per (kernel, counter) group -- small enough to commit next to the bench line of the same box."""
 import csv
 import glob
+import json
 import os
 import sys
 from collections import defaultdict
 
-ALL = "--all" in sys.argv
-for d in [a for a in sys.argv[1:] if a != "--all"]:
-    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
-        acc = defaultdict(lambda: defaultdict(list))
-        with open(f) as fh:
-            for row in csv.DictReader(fh):
-                k = row.get("Kernel_Name", "?")
-                acc[k][row.get("Counter_Name", "?")].append(float(row.get("Counter_Value", "nan")))
-        print("==", f)
-        for k, cs in acc.items():
-            if not ALL and "kf_" not in k:
-                continue
-            if "fk::" not in k and "kf_" not in k:
-                continue
-            for c, vals in cs.items():
-                print(f"{k[:90]:90s} {c:12s} n={len(vals):4d} mean={sum(vals)/len(vals):.6g}")
+
+def main():
+    dirs = [a for a in sys.argv[1:] if not a.startswith("--")]
+    want = sys.argv[sys.argv.index("--kernel") + 1] if "--kernel" in sys.argv else "kf_fast"
+    acc = defaultdict(list)
+    for d in dirs:
+        for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+            for row in csv.DictReader(open(f)):
+                k = row.get("Kernel_Name", "")
+                if want in k:
+                    acc[(k.split("(")[0][:60], row["Counter_Name"])].append(float(row["Counter_Value"]))
+    by_kernel = defaultdict(dict)
+    for (k, c), v in acc.items():
+        by_kernel[k][c] = {"mean": sum(v) / len(v), "launches": len(v)}
+    for k, cs in by_kernel.items():
+        print(json.dumps({"kernel": k, "counters": {c: round(x["mean"], 1) for c, x in sorted(cs.items())},
+                          "launches": max(x["launches"] for x in cs.values())}))
+    if not by_kernel:
+        print(json.dumps({"error": "no counter rows for " + want, "dirs": dirs}))
+
+
+if __name__ == "__main__":
+    main()
