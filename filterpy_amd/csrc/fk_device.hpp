@@ -251,15 +251,27 @@ template <int LEN>
 __device__ __forceinline__ void wave_load_aos(double (&v)[LEN], const double *slab, unsigned wave_row0, double *tile,
                                               unsigned lane, unsigned last_row)
 {
-    static_assert(LEN % 2 == 0, "pairs of doubles");
     constexpr int LENP = LEN | 1;
     const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(slab), 0,
                                                         (int)((last_row + 1u) * (unsigned)LEN * 8u), 0x00020000);
-    constexpr int PASSES = LEN / 2;
-    u32x4 w[PASSES];
-    FK_UNROLL for (int it = 0; it < PASSES; ++it) {
-        const unsigned q = it * 128u + lane * 2u;
-        w[it] = __builtin_amdgcn_raw_buffer_load_b128(rs, (wave_row0 * LEN + q) * 8u, 0, 0);
+    if constexpr (LEN % 2 != 0) {
+        // odd records: 8-byte units (512 B contiguous per instruction)
+        u32x2 w1[LEN];
+        FK_UNROLL for (int it = 0; it < LEN; ++it)
+            w1[it] = __builtin_amdgcn_raw_buffer_load_b64(rs, (wave_row0 * LEN + it * 64u + lane) * 8u, 0, 0);
+        FK_UNROLL for (int it = 0; it < LEN; ++it) {
+            const unsigned q = it * 64u + lane;
+            tile[(q / LEN) * LENP + q % LEN] = __builtin_bit_cast(double, w1[it]);
+        }
+        wave_lds_fence();
+        FK_UNROLL for (int e = 0; e < LEN; ++e) v[e] = tile[lane * LENP + e];
+        wave_lds_fence();
+    } else {
+        constexpr int PASSES = LEN / 2;
+        u32x4 w[PASSES];
+        FK_UNROLL for (int it = 0; it < PASSES; ++it) {
+            const unsigned q = it * 128u + lane * 2u;
+            w[it] = __builtin_amdgcn_raw_buffer_load_b128(rs, (wave_row0 * LEN + q) * 8u, 0, 0);
     }
     FK_UNROLL for (int it = 0; it < PASSES; ++it) {
         const unsigned q = it * 128u + lane * 2u;
@@ -270,6 +282,7 @@ __device__ __forceinline__ void wave_load_aos(double (&v)[LEN], const double *sl
     wave_lds_fence();
     FK_UNROLL for (int e = 0; e < LEN; ++e) v[e] = tile[lane * LENP + e];
     wave_lds_fence();
+    }
 }
 
 // ---- host side ------------------------------------------------------------

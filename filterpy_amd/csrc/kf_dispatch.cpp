@@ -178,17 +178,20 @@ static int run_kf(const fk_kf_desc *d, KfArgs &a, void *stream)
     // input, all four outputs stored or none (every model mode at dim_x <= 6, shared constant model above).
     const bool all_out = a.means && a.covs && a.means_p && a.covs_p;
     const bool no_out = !a.means && !a.covs && !a.means_p && !a.covs_p;
-    if (a.do_predict && a.do_update &&
-        (all_out || no_out) && !a.y_out && !a.K_out && !a.S_out && !a.SI_out && !a.ll_out && !a.maha_out &&
-        !a.rj_diag && !getenv("FK_NO_FAST")) {
+    // ... and, round 3, the same call with the update's by-products as per-step histories (batch_filter_ex): kf_fast's
+    // extras instantiations (shared constant model, all four outputs); the multi-lane kernels do not carry them
+    const bool want_ex = a.y_out || a.K_out || a.S_out || a.SI_out || a.ll_out || a.maha_out;
+    const bool fast_ex = want_ex && a.extras_per_step && all_out && d->model_mode == FK_MODEL_SHARED && d->nu == 0 &&
+                         !d->update_first && !getenv("FK_NO_FAST_EX");
+    if (a.do_predict && a.do_update && (all_out || no_out) && (!want_ex || fast_ex) && !a.rj_diag && !getenv("FK_NO_FAST")) {
         const char *g9 = getenv("FK_ML9");          // "g": dim_x = 9 on the four-lane kernels (A/B against kf_ml / rts_ml)
-        if (d->n == 9 && d->m == 3 && !getenv("FK_NO_ML") && !(g9 && g9[0] == 'g')) {
+        if (!want_ex && d->n == 9 && d->m == 3 && !getenv("FK_NO_ML") && !(g9 && g9[0] == 'g')) {
             const int rc = launch_kf_ml_9_3(a, d->layout, all_out, d->model_mode, (hipStream_t)stream);
             if (rc <= 0) return rc;        // 1 = not a call the multi-lane kernel serves
         }
         // (dim_x = 7, 8 were tried on the four-lane kernel too: 0.30 against kf_fast's 0.50 -- two rows per lane leave
         // the replicated S / x work dominant; profiles/r02/dims_7_8_ml_vs_fast.txt)
-        if ((d->n >= 10 || (g9 && g9[0] == 'g')) && !getenv("FK_NO_MLG")) {
+        if (!want_ex && (d->n >= 10 || (g9 && g9[0] == 'g')) && !getenv("FK_NO_MLG")) {
             for (const FastEntry &g : mlg_table) {
                 if (g.nx != d->n || g.nz != d->m) continue;
                 const int rc = g.fn(a, d->layout, all_out, d->model_mode, (hipStream_t)stream);
@@ -199,7 +202,7 @@ static int run_kf(const fk_kf_desc *d, KfArgs &a, void *stream)
             const char *ev = getenv("FK_FAST_XCD");
             a.xcd_swizzle = ev ? atoi(ev) : 0;
             int rc;
-            if (d->n >= 7 && all_out && d->model_mode == FK_MODEL_SHARED && d->nu == 0 && !d->update_first) {
+            if (d->n >= 7 && all_out && !want_ex && d->model_mode == FK_MODEL_SHARED && d->nu == 0 && !d->update_first) {
                 // the one-wave-per-SIMD instantiations (dim_x 7..9) are bound by arithmetic, not HBM: tail filling
                 // (fk_chunks.hpp) where the last round of waves would be mostly idle -- e.g. 2e5 tracks = 3125 waves
                 // of 64 on 1024 slots

@@ -70,8 +70,11 @@ __device__ __forceinline__ void cov_full(const double (&P)[PLEN], double (&M)[NX
 // step ahead by the first SIZE threads).
 // UF: update_first (kalman_filter.py:966-978): every step is update(z) -> store posterior -> predict -> store prior
 // CTRL: control input x = F x + B u (kalman_filter.py:472-475) with one shared B (dim_u <= 4); u[t] travels with z[t]
-template <int NX, int NZ, int LAYOUT, bool HAS_MASK, bool OUTS, bool SYM, int MMODE, bool UF, bool CTRL>
-__global__ void __launch_bounds__(BLOCK, fast_min_waves(NX, LAYOUT) > 1 && (MMODE == 1 || MMODE == 2) ? fast_min_waves(NX, LAYOUT) - 1 : fast_min_waves(NX, LAYOUT))
+// EX: the update's by-products as per-step histories (fk_kf_batch_filter_ex_f64: y, K, S, SI, log-likelihood, mahalanobis;
+// KalmanFilter.batch_filter with a Saver, kalman_filter.py:533-563 and the lazy properties :1180-1225) stored by this kernel
+// instead of the generic one -- shared constant model, predict -> update, all four outputs.
+template <int NX, int NZ, int LAYOUT, bool HAS_MASK, bool OUTS, bool SYM, int MMODE, bool UF, bool CTRL, bool EX = false>
+__global__ void __launch_bounds__(BLOCK, fast_min_waves(NX, LAYOUT) > 1 && (MMODE == 1 || MMODE == 2 || EX) ? fast_min_waves(NX, LAYOUT) - 1 : fast_min_waves(NX, LAYOUT))
 kf_fast_kernel(const KfArgs a, const double *__restrict__ pF, const double *__restrict__ pQ,
                const double *__restrict__ pH, const double *__restrict__ pR,
                const double *__restrict__ pz, const uint8_t *__restrict__ pmask)
@@ -184,6 +187,14 @@ kf_fast_kernel(const KfArgs a, const double *__restrict__ pF, const double *__re
     if (ZDEPTH == 2) { FK_UNROLL for (int i = 0; i < ZW; ++i) asm volatile("" ::"v"(zb[1][i])); }
 
     int st = 0;
+    // EX with a mask: a missing measurement stores y = 0 and the LAST K / S / SI / log det S (kalman_filter.py:515-520
+    // leaves those attributes alone)
+    constexpr bool CARRY = EX && HAS_MASK;
+    double cK[CARRY ? NX * NZ : 1], cS[CARRY ? NZ * NZ : 1], cSI[CARRY ? NZ * NZ : 1], c_logdet = 0.0;
+    if constexpr (CARRY) {
+        FK_UNROLL for (int i = 0; i < NX * NZ; ++i) cK[i] = 0.0;
+        FK_UNROLL for (int i = 0; i < NZ * NZ; ++i) { cS[i] = 0.0; cSI[i] = 0.0; }
+    }
     // one time step: consumes (zu, hu), requests the measurement of step t + ZDEPTH into (zl, hl)
     auto step = [&](long t, const double (&zu)[ZW], bool hu, double (&zl)[ZW], bool &hl) {
         load_z(t + ZDEPTH, zl, hl);
@@ -222,6 +233,8 @@ kf_fast_kernel(const KfArgs a, const double *__restrict__ pF, const double *__re
             }
         };
         auto do_update = [&]() {
+            // EX: what this step's extras records will hold
+            double eK[EX ? NX * NZ : 1], ey[EX ? NZ : 1], eS[EX ? NZ * NZ : 1], eSI[EX ? NZ * NZ : 1], e_ll = 0.0, e_maha = 0.0;
             if (hu) {
                 double zq[NZ];
                 FK_UNROLL for (int c = 0; c < NZ; ++c) zq[c] = zu[c];
@@ -233,6 +246,58 @@ kf_fast_kernel(const KfArgs a, const double *__restrict__ pF, const double *__re
                     if constexpr (SYM) st |= kf_update_sym<NX, NZ>(x, P, zq, sm, K, y, S, Lf, dinv);
                     else st |= kf_update<NX, NZ>(x, P, zq, sm, K, y, S, Lf, dinv);
                 }
+                if constexpr (EX) {
+                    // S^-1, log det S and y' S^-1 y from the factorisation, exactly as kf_kernel does (kf_kernels.hip)
+                    double SI[NZ * NZ];
+                    inv_from_ldlt<NZ>(Lf, dinv, SI);
+                    double logdet = 0.0, q = 0.0;
+                    if constexpr (NZ == 1) {
+                        logdet = log(S[0]);
+                        q = y[0] * y[0] * dinv[0];
+                    } else {
+                        double w[NZ];
+                        FK_UNROLL for (int i = 0; i < NZ; ++i) {
+                            double acc = y[i];
+                            FK_UNROLL for (int k2 = 0; k2 < NZ; ++k2)
+                                if (k2 < i) acc = fma(-Lf[i * NZ + k2], w[k2], acc);
+                            w[i] = acc;
+                            logdet += log(1.0 / dinv[i]);
+                            q = fma(acc * acc, dinv[i], q);
+                        }
+                    }
+                    FK_UNROLL for (int i = 0; i < NX * NZ; ++i) eK[i] = K[i];
+                    FK_UNROLL for (int i = 0; i < NZ; ++i) ey[i] = y[i];
+                    FK_UNROLL for (int i = 0; i < NZ * NZ; ++i) { eS[i] = S[i]; eSI[i] = SI[i]; }
+                    e_ll = -0.5 * (NZ * 1.8378770664093453 + logdet + q);
+                    e_maha = sqrt(q);
+                    if constexpr (CARRY) {
+                        FK_UNROLL for (int i = 0; i < NX * NZ; ++i) cK[i] = K[i];
+                        FK_UNROLL for (int i = 0; i < NZ * NZ; ++i) { cS[i] = S[i]; cSI[i] = SI[i]; }
+                        c_logdet = logdet;
+                    }
+                }
+            } else if constexpr (CARRY) {
+                FK_UNROLL for (int i = 0; i < NX * NZ; ++i) eK[i] = cK[i];
+                FK_UNROLL for (int i = 0; i < NZ; ++i) ey[i] = 0.0;
+                FK_UNROLL for (int i = 0; i < NZ * NZ; ++i) { eS[i] = cS[i]; eSI[i] = cSI[i]; }
+                e_ll = -0.5 * (NZ * 1.8378770664093453 + c_logdet);
+                e_maha = 0.0;
+            }
+            if constexpr (EX) {
+                // uniform branches on the pointers: a caller asks for any subset
+                if constexpr (!COOP) {
+                    if (a.y_out) store_rec<NZ, 1, LAYOUT, true>(ey, a.y_out + t * N * NZ, ln, NZ, 1);
+                    if (a.K_out) store_rec<NX, NZ, LAYOUT, true>(eK, a.K_out + t * N * NX * NZ, ln, NX, NZ);
+                    if (a.S_out) store_rec<NZ, NZ, LAYOUT, true>(eS, a.S_out + t * N * NZ * NZ, ln, NZ, NZ);
+                    if (a.SI_out) store_rec<NZ, NZ, LAYOUT, true>(eSI, a.SI_out + t * N * NZ * NZ, ln, NZ, NZ);
+                } else {
+                    if (a.y_out) wave_store_aos<NZ>(ey, a.y_out + (t * N + blk0) * NZ, wave * 64u, tile, lane, last_row);
+                    if (a.K_out) wave_store_aos<NX * NZ>(eK, a.K_out + (t * N + blk0) * NX * NZ, wave * 64u, tile, lane, last_row);
+                    if (a.S_out) wave_store_aos<NZ * NZ>(eS, a.S_out + (t * N + blk0) * NZ * NZ, wave * 64u, tile, lane, last_row);
+                    if (a.SI_out) wave_store_aos<NZ * NZ>(eSI, a.SI_out + (t * N + blk0) * NZ * NZ, wave * 64u, tile, lane, last_row);
+                }
+                if (a.ll_out) a.ll_out[t * N + blk0 + ln.tid] = e_ll;          // tail lanes rewrite the last track's value
+                if (a.maha_out) a.maha_out[t * N + blk0 + ln.tid] = e_maha;
             }
             cov_full<NX, SYM, PLEN>(P, Pf);
             if (!OUTS) {
@@ -308,13 +373,34 @@ using namespace FK_CAT(fastv_, FK_NX, FK_NZ, FK_VARIANT);
 // mode (only variant 0 at dim_x <= 6 compiles the per-track / per-step modes): the caller then falls
 // back to the generic kernel.
 #define FK_FAST_ALL_MODES (FK_VARIANT == 0 && FK_NX <= 6)
+// the extras instantiations are compiled once per (dim_x, dim_z): in variant 0 where it exists, else in the lean variant
+#define FK_FAST_EX (FK_VARIANT == 0 || !((FK_NX == 4 && FK_NZ == 2) || (FK_NX == 6 && FK_NZ == 3)))
 int FK_CAT(launch_kf_fast_, FK_NX, FK_NZ, FK_VARIANT)(const KfArgs &a, int layout, bool outs, int mmode, hipStream_t stream)
 {
+    const dim3 grid((unsigned)((a.cnt + BLOCK - 1) / BLOCK)), block(BLOCK);
+    if (a.y_out || a.K_out || a.S_out || a.SI_out || a.ll_out || a.maha_out) {
+#if FK_FAST_EX
+        if (mmode != 0 || !outs || a.update_first || a.nu > 0 || !a.extras_per_step) return 1;
+#define FK_GOEX(LAY, MSK)                                                                                                \
+    hipLaunchKernelGGL((kf_fast_kernel<FK_NX, FK_NZ, LAY, MSK, true, (FK_FAST_SYM != 0), 0, false, false, true>), grid, block, 0, \
+                       stream, a, a.F, a.Q, a.H, a.R, a.z, a.mask)
+        if (layout == LAYOUT_SOA) {
+            if (a.mask) FK_GOEX(LAYOUT_SOA, true);
+            else FK_GOEX(LAYOUT_SOA, false);
+        } else {
+            if (a.mask) FK_GOEX(LAYOUT_AOS, true);
+            else FK_GOEX(LAYOUT_AOS, false);
+        }
+#undef FK_GOEX
+        return check_launch("kf_fast_kernel (extras)");
+#else
+        return 1;
+#endif
+    }
     if (mmode != 0 && !FK_FAST_ALL_MODES) return 1;
     if (!outs && FK_VARIANT != 0) return 1;
     if (a.update_first && !(FK_FAST_ALL_MODES && mmode == 0)) return 1;   // update_first: shared model, variant 0, dim_x <= 6
     if (a.nu > 0 && !(FK_FAST_ALL_MODES && mmode == 0 && !a.update_first && a.nu <= 4)) return 1;   // control input: same, dim_u <= 4
-    const dim3 grid((unsigned)((a.cnt + BLOCK - 1) / BLOCK)), block(BLOCK);
 #define FK_GO(LAY, MSK, OUT, MM)                                                                          \
     hipLaunchKernelGGL((kf_fast_kernel<FK_NX, FK_NZ, LAY, MSK, OUT, (FK_FAST_SYM != 0), MM, false, false>), grid, block, 0, \
                        stream, a, a.F, a.Q, a.H, a.R, a.z, a.mask)

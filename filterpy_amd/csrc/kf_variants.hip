@@ -33,7 +33,12 @@ __global__ void __launch_bounds__(BLOCK)
 steady_kernel(const SteadyArgs a)
 {
     constexpr int NU = 4;
+    // COOP (round 3; NumPy order, exact dims): the x / z / y records move between HBM and the registers through a
+    // wave-private LDS tile, memory order on the HBM side (wave_load_aos / wave_store_aos: 0.5-1 KiB contiguous per
+    // instruction) -- a lane-per-record 16-byte access touches 64 lines per instruction (measured 0.34 of HBM at (9,3))
+    constexpr bool COOP = LAYOUT == LAYOUT_AOS && EXACT;
     __shared__ double sF[NX * NX], sH[NZ * NX], sK[NX * NZ], sB[NX * NU];
+    __shared__ double s_tile[COOP ? (BLOCK / 64) * 64 * (NX | 1) : 1];
     const int n = a.n, m = a.m, nu = a.nu;
     const long N = a.N;
     lds_fill<NX, NX>(sF, a.F, n, n, 1.0, threadIdx.x);
@@ -41,10 +46,18 @@ steady_kernel(const SteadyArgs a)
     lds_fill<NX, NZ>(sK, a.k_per_track ? nullptr : a.K, n, m, 0.0, threadIdx.x);
     lds_fill<NX, NU>(sB, a.B, n, nu, 0.0, threadIdx.x);
     __syncthreads();
-    const Lane ln{(long)blockIdx.x * BLOCK, threadIdx.x, N};
-    if (ln.blk0 + ln.tid >= N) return;
+    const long blk0 = (long)blockIdx.x * BLOCK;
+    const long left = N - blk0;                                            // >= 1
+    const unsigned last_row = (unsigned)(left < BLOCK ? left : BLOCK) - 1u;
+    if (!COOP && threadIdx.x > last_row) return;
+    // COOP: every lane of a wave takes part in the moves; lanes past the last track compute on zeros (the buffer
+    // descriptors end at the last track: their loads return 0, their stores are dropped)
+    const Lane ln{blk0, COOP ? min(threadIdx.x, last_row) : threadIdx.x, N};
+    const unsigned lane = threadIdx.x & 63u, wrow = (threadIdx.x >> 6) * 64u;
+    double *tile = s_tile + (COOP ? (threadIdx.x >> 6) * 64 * (NX | 1) : 0);
     double x[NX], K[NX * NZ];
-    load_rec<NX, 1, LAYOUT, EXACT>(x, a.x, ln, n, 1, 0.0);
+    if constexpr (COOP) wave_load_aos<NX>(x, a.x + blk0 * NX, wrow, tile, lane, last_row);
+    else load_rec<NX, 1, LAYOUT, EXACT>(x, a.x, ln, n, 1, 0.0);
     if (a.k_per_track) {
         load_rec<NX, NZ, LAYOUT, false>(K, a.K, ln, n, m, 0.0);
     } else {
@@ -69,11 +82,15 @@ steady_kernel(const SteadyArgs a)
                 FK_UNROLL for (int i = 0; i < NX; ++i) xn[i] += Bu[i];
             }
             FK_UNROLL for (int i = 0; i < NX; ++i) x[i] = xn[i];
-            if (a.means_p) store_rec<NX, 1, LAYOUT, EXACT>(x, a.means_p + t * N * n, ln, n, 1);
+            if (a.means_p) {
+                if constexpr (COOP) wave_store_aos<NX>(x, a.means_p + (t * N + blk0) * NX, wrow, tile, lane, last_row);
+                else store_rec<NX, 1, LAYOUT, EXACT>(x, a.means_p + t * N * n, ln, n, 1);
+            }
         }
         if (a.z) {      // update_steadystate: y = z - H x ; x += K y
             double z[NZ], y[NZ];
-            load_rec<NZ, 1, LAYOUT, EXACT>(z, a.z + t * N * m, ln, m, 1, 0.0);
+            if constexpr (COOP) wave_load_aos<NZ>(z, a.z + (t * N + blk0) * NZ, wrow, tile, lane, last_row);
+            else load_rec<NZ, 1, LAYOUT, EXACT>(z, a.z + t * N * m, ln, m, 1, 0.0);
             const bool has_z = !a.mask || a.mask[t * N + ln.blk0 + ln.tid];
             FK_UNROLL for (int r = 0; r < NZ; ++r) {
                 double acc = sH[r * NX] * x[0];
@@ -87,11 +104,18 @@ steady_kernel(const SteadyArgs a)
                     x[i] += acc;
                 }
             }
-            if (a.y_out) store_rec<NZ, 1, LAYOUT, EXACT>(y, a.y_out + t * N * m, ln, m, 1);
-            if (a.means) store_rec<NX, 1, LAYOUT, EXACT>(x, a.means + t * N * n, ln, n, 1);
+            if constexpr (COOP) {
+                if (a.y_out) wave_store_aos<NZ>(y, a.y_out + (t * N + blk0) * NZ, wrow, tile, lane, last_row);
+                if (a.means) wave_store_aos<NX>(x, a.means + (t * N + blk0) * NX, wrow, tile, lane, last_row);
+            } else {
+                if (a.y_out) store_rec<NZ, 1, LAYOUT, EXACT>(y, a.y_out + t * N * m, ln, m, 1);
+                if (a.means) store_rec<NX, 1, LAYOUT, EXACT>(x, a.means + t * N * n, ln, n, 1);
+            }
         }
     }
-    store_rec<NX, 1, LAYOUT, EXACT>(x, a.x, ln, n, 1);
+    // (in place: a wave reads and writes its own 64 rows only)
+    if constexpr (COOP) wave_store_aos<NX>(x, a.x + blk0 * NX, wrow, tile, lane, last_row);
+    else store_rec<NX, 1, LAYOUT, EXACT>(x, a.x, ln, n, 1);
 }
 
 // update_correlated (kalman_filter.py:727-748), in the reference's association order:

@@ -40,8 +40,11 @@
 
 namespace fk {
 
+#ifndef FK_OP_ITEMS
+#define FK_OP_ITEMS 8          // weights per thread (A/B builds: tools/exp_rs_variants.py)
+#endif
 constexpr int OP_THREADS = 256;
-constexpr int OP_ITEMS = 8;
+constexpr int OP_ITEMS = FK_OP_ITEMS;
 constexpr int OP_TILE = OP_THREADS * OP_ITEMS;             // 2048 weights per chunk
 constexpr int OP_WIN = 12 * OP_THREADS;                     // 3072 output slots per window, 12 consecutive per thread
 constexpr int OP_REGIONS = 32;                             // ticket heads, each in a cache line of its own: ONE word takes
@@ -129,7 +132,7 @@ struct OpShared {
     SegShared seg;
     __device__ __forceinline__ int *win() { return reinterpret_cast<int *>(tile); }
 };
-static_assert(sizeof(OpShared) <= 24576, "six workgroups per CU need <= 24 KiB of LDS each (the kernel runs five)");
+static_assert(sizeof(OpShared) <= 24576 * OP_ITEMS / 8, "six workgroups per CU need <= 24 KiB of LDS each (the kernel runs five)");
 
 // ---- hand-off words --------------------------------------------------------------------------------------
 __device__ __forceinline__ u64 pack_approx(double v, u64 state) { return (double_to_bits(v) & ~ST_MASK) | state; }

@@ -776,3 +776,80 @@ def test_every_batch_filter_argument_at_once_vs_live_reference(n, m, nu, layout)
             for trk in (0, 63, 64, N - 1):
                 assert rel_err_rows(got[k][:, trk].reshape(T, -1), g[q + key].reshape(T, -1)) < TOL, (uf, key, trk)
         assert rel_err_rows(got[4][:1], g[q + "xfinal"][None]) < TOL and rel_err_rows(got[5][:1].reshape(1, -1), g[q + "Pfinal"].reshape(1, -1)) < TOL
+
+
+def _run_ex(x0, P0, zs, F, Q, H, R, layout, mask=None, keys=("y", "K", "S", "SI", "log_likelihood", "mahalanobis")):
+    """fk_kf_batch_filter_ex_f64 on host arrays -> (the four outputs, {extras histories})"""
+    import torch
+    from filterpy_amd import _engine as E
+    T, N, m = zs.shape
+    n = x0.shape[1]
+    dx, dP, dz = E.to_records(x0, layout, 0), E.to_records(P0, layout, 0), E.to_records(zs, layout, 1)
+    dmask = None if mask is None else torch.as_tensor(np.ascontiguousarray(mask, dtype=np.uint8), device=dx.device)
+    outs = [E.alloc_records((T,), N, w, layout).fill_(float("nan")) for w in (n, n * n, n, n * n)]
+    shapes = dict(y=(m,), K=(n, m), S=(m, m), SI=(m, m))
+    ex = {k: (E.alloc_records((T,), N, int(np.prod(shapes[k])), layout) if k in shapes
+              else torch.empty((T, N), dtype=torch.float64, device=dx.device)).fill_(float("nan")) for k in keys}
+    st = torch.zeros(N, dtype=torch.int32, device=dx.device)
+    E.kf_batch_filter_ex(dict(n=n, m=m, nu=0, model_mode=0, N=N, T=T, layout=E.LAYOUTS[layout], update_first=0, alpha_sq=1.0),
+                         E.dev(F), E.dev(Q), E.dev(H), E.dev(R), dz, dx, dP, ex, mask=dmask,
+                         means=outs[0], covs=outs[1], means_p=outs[2], covs_p=outs[3], status=st)
+    torch.cuda.synchronize()
+    assert not st.any()
+    res = [E.from_records(outs[0], layout, 1, (n,)), E.from_records(outs[1], layout, 1, (n, n)),
+           E.from_records(outs[2], layout, 1, (n,)), E.from_records(outs[3], layout, 1, (n, n))]
+    hist = {k: (E.from_records(v, layout, 1, shapes[k]) if k in shapes else v.cpu().numpy()) for k, v in ex.items()}
+    return res, hist
+
+
+@pytest.mark.parametrize("layout", ["soa", "aos"])
+@pytest.mark.parametrize("n,m", [(n, m) for n in range(1, 10) for m in range(1, min(n, 4) + 1)])
+def test_saver_histories_from_the_specialised_kernel(n, m, layout, monkeypatch):
+    """y / K / S / SI / log-likelihood / mahalanobis histories (fk_kf_batch_filter_ex_f64; kalman_filter.py:533-563, :1203-1240)
+    are stored by kf_fast's extras instantiations: against the oracle on sample tracks, against the generic kernel
+    (FK_NO_FAST_EX=1) on every track, with a mask (missing measurement: y = 0, K / S / SI keep their last values),
+    with a subset of the histories, and with the four regular outputs unchanged."""
+    rs = np.random.RandomState(100 * n + m)
+    N, T = 333, 12
+    A = rs.randn(N, n, n)
+    x0, P0 = rs.randn(N, n), 3.0 * (A @ A.transpose(0, 2, 1) / n + 0.5 * np.eye(n))
+    zs = rs.randn(T, N, m) * 2
+    F = np.eye(n) + 0.05 * rs.randn(n, n)
+    F /= max(1.0, 1.05 * np.max(np.abs(np.linalg.eigvals(F))))
+    B = rs.randn(n, n)
+    Q = 0.1 * (B @ B.T / n + 0.5 * np.eye(n))
+    H = rs.randn(m, n)
+    C = rs.randn(m, m)
+    R = 0.5 * (C @ C.T / m + 0.5 * np.eye(m))
+    mask = rs.rand(T, N) > 0.25
+    mask[0] = True                                   # (before the first measurement S = 0: compared in test_gpu_api)
+    sample = [0, 63, 64, 255, 256, N - 1]
+    for kw in ({}, {"mask": mask}):
+        outs, hist = _run_ex(x0, P0, zs, F, Q, H, R, layout, **kw)
+        with monkeypatch.context() as mp:
+            mp.setenv("FK_NO_FAST_EX", "1")
+            outs_g, hist_g = _run_ex(x0, P0, zs, F, Q, H, R, layout, **kw)
+        for a, b in zip(outs, outs_g):
+            assert rel_err_rows(_per_track(a), _per_track(b)) < TOL
+        for k in hist:
+            assert np.isfinite(hist[k]).all(), k
+            assert np.allclose(hist[k], hist_g[k], rtol=1e-10, atol=1e-11), (k, kw.keys())
+        for i in sample:
+            x, P = x0[i].copy(), P0[i].copy()
+            last = None
+            for t in range(T):
+                x, P = kf_oracle.kf_predict(x, P, F, Q)
+                if "mask" in kw and not mask[t, i]:
+                    y, (K, S, SI) = np.zeros(m), last
+                    ll, mh = kf_oracle.log_likelihood(y, S), 0.0
+                else:
+                    x, P, y, K, S, SI = kf_oracle.kf_update(x, P, zs[t, i], R, H)
+                    last = (K, S, SI)
+                    ll, mh = kf_oracle.log_likelihood(y, S), kf_oracle.mahalanobis(y, SI)
+                for key, ref in (("y", y), ("K", K), ("S", S), ("SI", SI)):
+                    assert np.allclose(hist[key][t, i], ref, rtol=1e-10, atol=1e-11), (key, t, i)
+                assert abs(hist["log_likelihood"][t, i] - ll) <= 1e-10 * max(1.0, abs(ll)), (t, i)
+                assert abs(hist["mahalanobis"][t, i] - mh) <= 1e-10 * max(1.0, mh), (t, i)
+    # a subset: only the likelihood history
+    _, h1 = _run_ex(x0, P0, zs, F, Q, H, R, layout, keys=("log_likelihood",))
+    assert np.array_equal(h1["log_likelihood"], _run_ex(x0, P0, zs, F, Q, H, R, layout)[1]["log_likelihood"])

@@ -199,6 +199,47 @@ def config_generic(layout, N, T):
         emit(f"KF (4,2) {name} N={N} {layout}", N * T, "track-steps", ms, 8 * (m + 2 * n + 2 * n * n) + extra)
 
 
+def config_extras(layout, n, m, N, T):
+    """fk_kf_batch_filter_ex_f64 with all six histories (a Saver's y / K / S / SI / log-likelihood /
+    mahalanobis): kf_fast's extras instantiation against the generic kernel (FK_NO_FAST_EX=1), same buffers."""
+    import torch
+    from filterpy_amd import _engine as E
+    rs = np.random.RandomState(5)
+    dev = torch.device("cuda")
+    F = np.eye(n) + 0.02 * rs.randn(n, n)
+    A = rs.randn(n, n)
+    Q = 0.1 * (A @ A.T / n + 0.5 * np.eye(n))
+    H = rs.randn(m, n)
+    R = 0.5 * np.eye(m)
+    g = torch.Generator(device=dev)
+    g.manual_seed(3)
+    z = E.alloc_records((T,), N, m, layout)
+    z.copy_(torch.randn(z.shape, generator=g, device=dev, dtype=torch.float64))
+    x0 = E.alloc_records((), N, n, layout).zero_()
+    P0 = E.to_records(np.tile(10.0 * np.eye(n), (N, 1, 1)), layout, 0)
+    x, P = x0.clone(), P0.clone()
+    outs = [E.alloc_records((T,), N, w, layout) for w in (n, n * n, n, n * n)]
+    ex = {k: E.alloc_records((T,), N, w, layout) for k, w in (("y", m), ("K", n * m), ("S", m * m), ("SI", m * m))}
+    ex["log_likelihood"] = torch.empty((T, N), dtype=torch.float64, device=dev)
+    ex["mahalanobis"] = torch.empty((T, N), dtype=torch.float64, device=dev)
+    st = torch.zeros(N, dtype=torch.int32, device=dev)
+    desc = dict(n=n, m=m, nu=0, model_mode=0, N=N, T=T, layout=E.LAYOUTS[layout], update_first=0, alpha_sq=1.0)
+    mods = [E.dev(M) for M in (F, Q, H, R)]
+
+    def run():
+        x.copy_(x0)
+        P.copy_(P0)
+        E.kf_batch_filter_ex(desc, *mods, z, x, P, ex, means=outs[0], covs=outs[1], means_p=outs[2], covs_p=outs[3], status=st)
+    nbytes = 8 * (m + 2 * n + 2 * n * n + m + n * m + 2 * m * m + 2)
+    for env, name in ((None, "kf_fast extras"), ("1", "generic kernel")):
+        if env:
+            os.environ["FK_NO_FAST_EX"] = env
+        ms = timeit(run, warm=1, reps=3)
+        os.environ.pop("FK_NO_FAST_EX", None)
+        assert not st.any()
+        emit(f"KF ({n},{m}) batch_filter + six Saver histories, {name}, N={N} {layout}", N * T, "track-steps", ms, nbytes)
+
+
 def config_imm(layout, n, m, nm, N, T):
     """N banks of nm filters, T x {IMM predict; update} in one launch.
     Algorithmic bytes per bank-step: z in, combined x, P and mu out."""
@@ -384,6 +425,10 @@ if __name__ == "__main__":
                     os.environ["FK_NO_MLG"] = "1"
                     config_kf(lay, n, m, N // 8, a.T)
                     del os.environ["FK_NO_MLG"]
+        if "e" in a.configs:      # Saver histories from the specialised kernel
+            config_extras(lay, 4, 2, 500_000, a.T)
+            config_extras(lay, 6, 3, 200_000, a.T)
+            config_extras(lay, 9, 3, 100_000, a.T)
         if "6" in a.configs:
             config_kf(lay, 6, 3, 300_000, a.T)
             config_kf(lay, 4, 2, 500_000, a.T)
