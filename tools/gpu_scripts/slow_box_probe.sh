@@ -22,9 +22,10 @@ cat $O/slow_knobs.jsonl
 timeout 200 python tools/bench_configs.py --configs 7 --layouts aos 2>/dev/null | grep "^{" | cut -c1-200 > $O/slow_configs7.jsonl; cat $O/slow_configs7.jsonl
 cd /tmp
 timeout 200 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM_WR SQ_INST_CYCLES_VMEM GRBM_GUI_ACTIVE --output-format csv -d $O/slow_sq -- python $R/bench.py --steps 10 --warmup 3 --no-cpu > /dev/null 2> $O/slow_sq.err
-timeout 200 rocprofv3 --pmc TCP_PENDING_STALL_CYCLES TCP_TCC_WRITE_REQ TCP_UTCL1_TRANSLATION_MISS TCP_UTCL1_REQUEST TCC_EA0_WRREQ_STALL TCC_EA0_WRREQ TCC_BUSY TCC_REQ --output-format csv -d $O/slow_tc -- python $R/bench.py --steps 10 --warmup 3 --no-cpu > /dev/null 2> $O/slow_tc.err
+timeout 200 rocprofv3 --pmc TCP_PENDING_STALL_CYCLES TCP_TCC_WRITE_REQ TCP_UTCL1_TRANSLATION_MISS TCP_UTCL1_REQUEST --output-format csv -d $O/slow_tc -- python $R/bench.py --steps 10 --warmup 3 --no-cpu > /dev/null 2> $O/slow_tc.err
+timeout 200 rocprofv3 --pmc TCC_EA0_WRREQ_STALL TCC_EA0_WRREQ TCC_BUSY TCC_REQ --output-format csv -d $O/slow_tcc -- python $R/bench.py --steps 10 --warmup 3 --no-cpu > /dev/null 2> $O/slow_tcc.err
 cd $R
-python tools/pmc_summary.py $O/slow_sq $O/slow_tc > $O/slow_pmc_summary.txt 2>&1; cat $O/slow_pmc_summary.txt | cut -c1-900; tail -3 $O/slow_tc.err
+python tools/pmc_summary.py $O/slow_sq $O/slow_tc $O/slow_tcc > $O/slow_pmc_summary.txt 2>&1; cat $O/slow_pmc_summary.txt | cut -c1-900; tail -2 $O/slow_tc.err $O/slow_tcc.err
 find $O -name "*counter_collection.csv" -size +1M -delete
 if python -c "import sys; sys.exit(0 if float('$MS') > 5.9 else 1)"; then
   echo "SLOW BOX: probing"
