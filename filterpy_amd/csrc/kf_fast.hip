@@ -233,12 +233,18 @@ kf_fast_kernel(const KfArgs a, const double *__restrict__ pF, const double *__re
             }
         };
         auto do_update = [&]() {
-            // EX: what this step's extras records will hold
-            double eK[EX ? NX * NZ : 1], ey[EX ? NZ : 1], eS[EX ? NZ * NZ : 1], eSI[EX ? NZ * NZ : 1], e_ll = 0.0, e_maha = 0.0;
+            // EX: the update's by-products leave the branch below in registers; the histories are formed from them in
+            // straight-line code with per-lane selects (a lane without a measurement keeps y = 0 and the LAST K / S / SI /
+            // log det S): the stores that follow are wave-cooperative, nothing between here and them may diverge
+            double K[NX * NZ], y[NZ], S[NZ * NZ], Lf[NZ * NZ], dinv[NZ];
+            if constexpr (EX && HAS_MASK) {
+                FK_UNROLL for (int i = 0; i < NX * NZ; ++i) K[i] = 0.0;
+                FK_UNROLL for (int i = 0; i < NZ * NZ; ++i) { S[i] = 0.0; Lf[i] = 0.0; }
+                FK_UNROLL for (int i = 0; i < NZ; ++i) { y[i] = 0.0; dinv[i] = 1.0; }
+            }
             if (hu) {
                 double zq[NZ];
                 FK_UNROLL for (int c = 0; c < NZ; ++c) zq[c] = zu[c];
-                double K[NX * NZ], y[NZ], S[NZ * NZ], Lf[NZ * NZ], dinv[NZ];
                 if constexpr (MMODE == 1 || MMODE == 2) {
                     if constexpr (SYM) st |= kf_update_sym<NX, NZ>(x, P, zq, tm, K, y, S, Lf, dinv);
                     else st |= kf_update<NX, NZ>(x, P, zq, tm, K, y, S, Lf, dinv);
@@ -246,54 +252,52 @@ kf_fast_kernel(const KfArgs a, const double *__restrict__ pF, const double *__re
                     if constexpr (SYM) st |= kf_update_sym<NX, NZ>(x, P, zq, sm, K, y, S, Lf, dinv);
                     else st |= kf_update<NX, NZ>(x, P, zq, sm, K, y, S, Lf, dinv);
                 }
-                if constexpr (EX) {
-                    // S^-1, log det S and y' S^-1 y from the factorisation, exactly as kf_kernel does (kf_kernels.hip)
-                    double SI[NZ * NZ];
-                    inv_from_ldlt<NZ>(Lf, dinv, SI);
-                    double logdet = 0.0, q = 0.0;
-                    if constexpr (NZ == 1) {
-                        logdet = log(S[0]);
-                        q = y[0] * y[0] * dinv[0];
-                    } else {
-                        double w[NZ];
-                        FK_UNROLL for (int i = 0; i < NZ; ++i) {
-                            double acc = y[i];
-                            FK_UNROLL for (int k2 = 0; k2 < NZ; ++k2)
-                                if (k2 < i) acc = fma(-Lf[i * NZ + k2], w[k2], acc);
-                            w[i] = acc;
-                            logdet += log(1.0 / dinv[i]);
-                            q = fma(acc * acc, dinv[i], q);
-                        }
-                    }
-                    FK_UNROLL for (int i = 0; i < NX * NZ; ++i) eK[i] = K[i];
-                    FK_UNROLL for (int i = 0; i < NZ; ++i) ey[i] = y[i];
-                    FK_UNROLL for (int i = 0; i < NZ * NZ; ++i) { eS[i] = S[i]; eSI[i] = SI[i]; }
-                    e_ll = -0.5 * (NZ * 1.8378770664093453 + logdet + q);
-                    e_maha = sqrt(q);
-                    if constexpr (CARRY) {
-                        FK_UNROLL for (int i = 0; i < NX * NZ; ++i) cK[i] = K[i];
-                        FK_UNROLL for (int i = 0; i < NZ * NZ; ++i) { cS[i] = S[i]; cSI[i] = SI[i]; }
-                        c_logdet = logdet;
+            }
+            double eSI[EX ? NZ * NZ : 1], e_ll = 0.0, e_maha = 0.0;
+            if constexpr (EX) {
+                // S^-1, log det S and y' S^-1 y from the factorisation, exactly as kf_kernel does (kf_kernels.hip)
+                inv_from_ldlt<NZ>(Lf, dinv, eSI);
+                double logdet = 0.0, q = 0.0;
+                if constexpr (NZ == 1) {
+                    logdet = log(S[0]);                                 // (a lane without a measurement: selected away below)
+                    q = y[0] * y[0] * dinv[0];
+                } else {
+                    double w[NZ];
+                    FK_UNROLL for (int i = 0; i < NZ; ++i) {
+                        double acc = y[i];
+                        FK_UNROLL for (int k2 = 0; k2 < NZ; ++k2)
+                            if (k2 < i) acc = fma(-Lf[i * NZ + k2], w[k2], acc);
+                        w[i] = acc;
+                        logdet += log(1.0 / dinv[i]);
+                        q = fma(acc * acc, dinv[i], q);
                     }
                 }
-            } else if constexpr (CARRY) {
-                FK_UNROLL for (int i = 0; i < NX * NZ; ++i) eK[i] = cK[i];
-                FK_UNROLL for (int i = 0; i < NZ; ++i) ey[i] = 0.0;
-                FK_UNROLL for (int i = 0; i < NZ * NZ; ++i) { eS[i] = cS[i]; eSI[i] = cSI[i]; }
-                e_ll = -0.5 * (NZ * 1.8378770664093453 + c_logdet);
-                e_maha = 0.0;
+                if constexpr (CARRY) {
+                    FK_UNROLL for (int i = 0; i < NX * NZ; ++i) { cK[i] = hu ? K[i] : cK[i]; K[i] = cK[i]; }
+                    FK_UNROLL for (int i = 0; i < NZ * NZ; ++i) {
+                        cS[i] = hu ? S[i] : cS[i];
+                        cSI[i] = hu ? eSI[i] : cSI[i];
+                        S[i] = cS[i];
+                        eSI[i] = cSI[i];
+                    }
+                    c_logdet = hu ? logdet : c_logdet;
+                    logdet = c_logdet;
+                    q = hu ? q : 0.0;
+                }
+                e_ll = -0.5 * (NZ * 1.8378770664093453 + logdet + q);
+                e_maha = sqrt(q);
             }
             if constexpr (EX) {
                 // uniform branches on the pointers: a caller asks for any subset
                 if constexpr (!COOP) {
-                    if (a.y_out) store_rec<NZ, 1, LAYOUT, true>(ey, a.y_out + t * N * NZ, ln, NZ, 1);
-                    if (a.K_out) store_rec<NX, NZ, LAYOUT, true>(eK, a.K_out + t * N * NX * NZ, ln, NX, NZ);
-                    if (a.S_out) store_rec<NZ, NZ, LAYOUT, true>(eS, a.S_out + t * N * NZ * NZ, ln, NZ, NZ);
+                    if (a.y_out) store_rec<NZ, 1, LAYOUT, true>(y, a.y_out + t * N * NZ, ln, NZ, 1);
+                    if (a.K_out) store_rec<NX, NZ, LAYOUT, true>(K, a.K_out + t * N * NX * NZ, ln, NX, NZ);
+                    if (a.S_out) store_rec<NZ, NZ, LAYOUT, true>(S, a.S_out + t * N * NZ * NZ, ln, NZ, NZ);
                     if (a.SI_out) store_rec<NZ, NZ, LAYOUT, true>(eSI, a.SI_out + t * N * NZ * NZ, ln, NZ, NZ);
                 } else {
-                    if (a.y_out) wave_store_aos<NZ>(ey, a.y_out + (t * N + blk0) * NZ, wave * 64u, tile, lane, last_row);
-                    if (a.K_out) wave_store_aos<NX * NZ>(eK, a.K_out + (t * N + blk0) * NX * NZ, wave * 64u, tile, lane, last_row);
-                    if (a.S_out) wave_store_aos<NZ * NZ>(eS, a.S_out + (t * N + blk0) * NZ * NZ, wave * 64u, tile, lane, last_row);
+                    if (a.y_out) wave_store_aos<NZ>(y, a.y_out + (t * N + blk0) * NZ, wave * 64u, tile, lane, last_row);
+                    if (a.K_out) wave_store_aos<NX * NZ>(K, a.K_out + (t * N + blk0) * NX * NZ, wave * 64u, tile, lane, last_row);
+                    if (a.S_out) wave_store_aos<NZ * NZ>(S, a.S_out + (t * N + blk0) * NZ * NZ, wave * 64u, tile, lane, last_row);
                     if (a.SI_out) wave_store_aos<NZ * NZ>(eSI, a.SI_out + (t * N + blk0) * NZ * NZ, wave * 64u, tile, lane, last_row);
                 }
                 if (a.ll_out) a.ll_out[t * N + blk0 + ln.tid] = e_ll;          // tail lanes rewrite the last track's value
