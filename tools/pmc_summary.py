@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""Mean of every counter of rocprofv3 --pmc passes, per kernel: python tools/pmc_summary.py <dir> [<dir> ...] [--kernel substr]
-One JSON line per (kernel, counter) group -- small enough to commit next to the bench line of the same box."""
+"""Mean of every counter of rocprofv3 --pmc passes, per kernel:
+    python tools/pmc_summary.py <dir> [<dir> ...] [--kernel substr | --all]
+One JSON line per kernel with the mean of each counter over its launches -- small enough to commit next to the bench line of
+the same box.  Default: the headline kernel (kf_fast); --all: every kernel of the library (fk::)."""
 import csv
 import glob
 import json
@@ -10,8 +12,8 @@ from collections import defaultdict
 
 
 def main():
-    dirs = [a for a in sys.argv[1:] if not a.startswith("--")]
-    want = sys.argv[sys.argv.index("--kernel") + 1] if "--kernel" in sys.argv else "kf_fast"
+    dirs = [a for i, a in enumerate(sys.argv[1:], 1) if not a.startswith("--") and sys.argv[i - 1] != "--kernel"]
+    want = sys.argv[sys.argv.index("--kernel") + 1] if "--kernel" in sys.argv else ("fk::" if "--all" in sys.argv else "kf_fast")
     acc = defaultdict(list)
     for d in dirs:
         for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
