@@ -243,6 +243,34 @@ __device__ __forceinline__ void wave_store_aos(const double (&v)[LEN], const dou
     wave_lds_fence();
 }
 
+// wave_store_aos for the inside of a time loop, even LEN: the tile is FLAT (row stride LEN doubles, i.e. laid out exactly
+// like the wave's slab of the array), so the copy-out needs no row / column arithmetic at all -- one lane-dependent LDS
+// address and one lane-dependent byte offset for the whole record, pass `it` adds the constant it * 1024 to both.  The
+// padded tile of wave_store_aos costs a division per pass where LEN does not divide 128; hoisted out of a time loop
+// those are two VGPRs of addressing per pass (36 at LEN = 36 -- the fused UKF spilled).  Price: the row-per-lane tile
+// writes are bank-conflicted (row stride 2 LEN dwords); at one record per time step that is noise.
+template <int LEN>
+__device__ __forceinline__ void wave_store_aos_flat(const double (&v)[LEN], const double *slab, unsigned wave_row0,
+                                                    double *tile, unsigned lane, unsigned last_row)
+{
+    static_assert(LEN % 2 == 0, "16-byte units");
+    const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(slab), 0,
+                                                        (int)((last_row + 1u) * (unsigned)LEN * 8u), 0x00020000);
+    wave_lds_fence();
+    FK_UNROLL for (int e = 0; e < LEN; ++e) tile[lane * LEN + e] = v[e];
+    wave_lds_fence();
+    const double *tb = tile + lane * 2u;
+    const unsigned gb = (wave_row0 * LEN + lane * 2u) * 8u;
+    FK_UNROLL for (int it = 0; it < LEN / 2; ++it) {
+        const u32x4 w = *reinterpret_cast<const u32x4 *>(tb + it * 128);
+        __builtin_amdgcn_raw_buffer_store_b128(w, rs, gb + (unsigned)(it * 1024), 0, 0);
+        // (a >8-byte store whose offset ends up in an SGPR is not covered by the compiler's hazard recogniser on
+        //  gfx950: see store_data_hazard in fk_ml.hpp)
+        asm volatile("s_nop 1" ::"v"(w.x), "v"(w.y), "v"(w.z), "v"(w.w) : "memory");
+    }
+    wave_lds_fence();
+}
+
 // The mirror image: wave-cooperative LOAD of one LEN-double record per lane from an AOS block -- memory order into the
 // tile (two consecutive doubles per lane per pass: buffer_load_dwordx4, 1 KiB contiguous per instruction; rows past the
 // block's last track read as 0 through the descriptor's range check), then every lane reads its own row.  A lane-strided

@@ -213,6 +213,269 @@ FK_HD int ukf_linear_step_v2(double (&x)[NX], double (&P)[NX * (NX + 1) / 2], co
     return st;
 }
 
+// sqrt(d) and 1 / sqrt(d) together; 1 / d.  On the device: v_rsq_f64 / v_rcp_f64 seeds (~2^-26) refined by one
+// Goldschmidt step and one residual correction (11 / 5 instructions; the compiler's correctly-rounded sqrt followed by
+// a correctly-rounded division is ~28, with range scaling the pivots of a covariance factor do not need).  The results
+// are within an ulp or two of the rounded ones -- far inside the 1e-10 bar, and the factor feeds sums that the
+// reference evaluates in BLAS order anyway.  A non-positive or non-finite pivot yields NaN / inf like sqrt would; the
+// caller's pivot test reports it (ST_NOT_PD).  On the host (tests/hostcheck): the plain operations.
+FK_HD void sqrt_rsqrt(double d, double &s, double &inv)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const double y = __builtin_amdgcn_rsq(d);
+    double g = d * y, h = 0.5 * y;
+    const double r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    const double e = fma(-g, g, d);
+    g = fma(e, h, g);
+    const double r2 = fma(-h, g, 0.5);
+    h = fma(h, r2, h);
+    s = g;
+    inv = h + h;
+#else
+    s = sqrt(d);
+    inv = 1.0 / s;
+#endif
+}
+
+FK_HD double rcp_refined(double d)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    double r = __builtin_amdgcn_rcp(d);
+    double e = fma(-d, r, 1.0);
+    r = fma(r, e, r);
+    e = fma(-d, r, 1.0);
+    return fma(r, e, r);
+#else
+    return 1.0 / d;
+#endif
+}
+
+// chol_packed (fk_math_sym.hpp) with the pivot's root and reciprocal from sqrt_rsqrt
+template <int NX>
+FK_HD bool chol_packed_rs(const double (&P)[NX * (NX + 1) / 2], double scale, double (&L)[NX * (NX + 1) / 2])
+{
+    bool pd = true;
+    FK_UNROLL for (int j = 0; j < NX; ++j) {
+        double d = scale * P[sym_idx<NX>(j, j)];
+        FK_UNROLL for (int k = 0; k < NX; ++k)
+            if (k < j) d = fma(-L[sym_idx<NX>(j, k)], L[sym_idx<NX>(j, k)], d);
+        pd = pd && (d > 0.0);
+        double ljj, inv;
+        sqrt_rsqrt(d, ljj, inv);
+        L[sym_idx<NX>(j, j)] = ljj;
+        FK_UNROLL for (int i = 0; i < NX; ++i)
+            if (i > j) {
+                double t = scale * P[sym_idx<NX>(j, i)];
+                FK_UNROLL for (int k = 0; k < NX; ++k)
+                    if (k < j) t = fma(-L[sym_idx<NX>(i, k)], L[sym_idx<NX>(j, k)], t);
+                L[sym_idx<NX>(i, j)] = t * inv;
+            }
+    }
+    return pd;
+}
+
+// ldlt2 (fk_math.hpp) with the pivots' reciprocals from rcp_refined
+template <int M>
+FK_HD bool ldlt2_rs(double (&A)[M * M], double (&d)[M], double (&dinv)[M])
+{
+    bool pd = true;
+    FK_UNROLL for (int j = 0; j < M; ++j) {
+        double dj = A[j * M + j];
+        FK_UNROLL for (int k = 0; k < j; ++k) {
+            const double l = A[j * M + k];
+            dj = fma(-l * l, d[k], dj);
+        }
+        pd = pd && (dj > 0.0);
+        d[j] = dj;
+        const double di = rcp_refined(dj);
+        dinv[j] = di;
+        FK_UNROLL for (int i = j + 1; i < M; ++i) {
+            double s = A[i * M + j];
+            FK_UNROLL for (int k = 0; k < j; ++k)
+                s = fma(-(A[i * M + k] * d[k]), A[j * M + k], s);
+            A[i * M + j] = s * di;
+        }
+    }
+    return pd;
+}
+
+// "V3" of the step (round 3): the same sums over the same 2n+1 points in the same index order, but the images of the
+// points are formed from the image of the FACTOR instead of point by point.  With fx(x) = F x the sigma-point matrix
+// [x, x + l_k, x - l_k] (sigma_points.py:167-175) maps to [F x, F x + F l_k, F x - F l_k]: one pass over the rows of F
+// produces F x and F L (column k of L has n - k non-zeros: n (n+1)/2 * n FMAs instead of (2n+1) n^2 per sweep, and V2
+// made two sweeps), and every point's image is then ONE add per component in each of the two unscented-transform
+// sweeps (mean, covariance -- unscented_transform.py:105-124 sums over all 2n+1 images, and so does this).  The same for
+// hx(x) = H x, and the cross variance (UKF.py:483-497) takes the points' offsets sigma_i - x = +-l_k from the factor
+// directly: the reference's (x + l) - x differs from l by one rounding of x, and the entries of l_k above the
+// diagonal are exact zeros in both, so those terms are skipped, not approximated.
+// Numerically each image differs from fl(F fl(x + l_k)) by a rounding of |F x| -- the same size as the reference's own
+// rounding of that dot product, amplified by the same Merwe weights -- so the parity bar is the package's 1e-10 (held
+// on the host against the oracle by tests/test_hostcheck_ukf_v2.py, on the GPU against the live-reference goldens).
+// (6,3): ~2000 VALU instructions per step against V2's 3780.
+template <int NX, int NZ, class Fresh, class Sweep = NoSweep>
+FK_HD int ukf_linear_step_v3(double (&x)[NX], double (&P)[NX * (NX + 1) / 2], const double (&z)[NZ], bool has_z,
+                             double scale, Fresh &&fresh, Sweep &&sweep = Sweep{})
+{
+    constexpr int PL = NX * (NX + 1) / 2;
+    int st = 0;
+    // ---------------- predict (UKF.py:400-411)
+    {
+        double Fx[NX], FL[NX][NX];
+        {
+            double L[PL];
+            if (!chol_packed_rs<NX>(P, scale, L)) st |= ST_NOT_PD;
+            // one pass over the rows of F: F x and F L (FL[r][k] = sum_{c >= k} F[r][c] L[c][k])
+            sweep();
+            const auto mv = fresh();
+            FK_UNROLL for (int r = 0; r < NX; ++r) {
+                double f[NX];
+                mv.sm.rowF(r, f);
+                Fx[r] = dot<NX>(f, x);
+                FK_UNROLL for (int k = 0; k < NX; ++k) {
+                    double acc = f[k] * L[sym_idx<NX>(k, k)];
+                    FK_UNROLL for (int c = 0; c < NX; ++c)
+                        if (c > k) acc = fma(f[c], L[sym_idx<NX>(c, k)], acc);
+                    FL[r][k] = acc;
+                }
+                FK_STAGE();
+            }
+        }
+        // sweep 1: x- = sum_i Wm_i sf_i, points in index order 0, +k (k = 0..n-1), -k
+        {
+            const auto mv = fresh();
+            const double *sWm = mv.Wm;
+            FK_UNROLL for (int r = 0; r < NX; ++r) x[r] = sWm[0] * Fx[r];
+            FK_UNROLL for (int k = 0; k < NX; ++k)
+                FK_UNROLL for (int r = 0; r < NX; ++r) x[r] = fma(sWm[1 + k], Fx[r] + FL[r][k], x[r]);
+            FK_UNROLL for (int k = 0; k < NX; ++k)
+                FK_UNROLL for (int r = 0; r < NX; ++r) x[r] = fma(sWm[1 + NX + k], Fx[r] - FL[r][k], x[r]);
+            FK_STAGE();
+        }
+        // sweep 2: P- = sum_i Wc_i y_i y_i' + Q, y_i = sf_i - x-   (upper triangle); the images are re-formed (one add)
+        // from copies the optimiser cannot relate to sweep 1's, or it would hold all (2n+1) n of them
+        FK_UNROLL for (int r = 0; r < NX; ++r) FK_OPAQUE(Fx[r]);
+        {
+            const auto mv = fresh();
+            const double *sWc = mv.Wc;
+            FK_UNROLL for (int i = 0; i < 2 * NX + 1; ++i) {
+                double y[NX], wy[NX];
+                FK_UNROLL for (int r = 0; r < NX; ++r) {
+                    const double v = (i == 0) ? Fx[r] : (i <= NX) ? Fx[r] + FL[r][(i - 1) % NX] : Fx[r] - FL[r][(i - 1) % NX];
+                    y[r] = v - x[r];
+                }
+                FK_UNROLL for (int r = 0; r < NX; ++r) wy[r] = sWc[i] * y[r];
+                FK_UNROLL for (int a2 = 0; a2 < NX; ++a2)
+                    FK_UNROLL for (int b = 0; b < NX; ++b)
+                        if (b >= a2)
+                            P[sym_idx<NX>(a2, b)] = (i == 0) ? y[a2] * wy[b] : fma(y[a2], wy[b], P[sym_idx<NX>(a2, b)]);
+                FK_STAGE();
+            }
+            FK_UNROLL for (int r = 0; r < NX; ++r) {
+                double q[NX];
+                mv.sm.rowQ(r, q);
+                FK_UNROLL for (int b = 0; b < NX; ++b)
+                    if (b >= r) P[sym_idx<NX>(r, b)] += q[b];
+            }
+        }
+    }
+    // ---------------- update (UKF.py:462-481), sigma points regenerated from the prior (:407)
+    if (has_z) {
+        double L[PL];
+        if (!chol_packed_rs<NX>(P, scale, L)) st |= ST_NOT_PD;
+        double Hx[NZ], HL[NZ][NX];
+        sweep();
+        {
+            const auto mv = fresh();
+            FK_UNROLL for (int r = 0; r < NZ; ++r) {
+                double h[NX];
+                mv.sm.rowH(r, h);
+                Hx[r] = dot<NX>(h, x);
+                FK_UNROLL for (int k = 0; k < NX; ++k) {
+                    double acc = h[k] * L[sym_idx<NX>(k, k)];
+                    FK_UNROLL for (int c = 0; c < NX; ++c)
+                        if (c > k) acc = fma(h[c], L[sym_idx<NX>(c, k)], acc);
+                    HL[r][k] = acc;
+                }
+            }
+            FK_STAGE();
+        }
+        // sweep 1: zp = sum_i Wm_i sh_i
+        double zp[NZ];
+        {
+            const auto mv = fresh();
+            const double *sWm = mv.Wm;
+            FK_UNROLL for (int r = 0; r < NZ; ++r) zp[r] = sWm[0] * Hx[r];
+            FK_UNROLL for (int k = 0; k < NX; ++k)
+                FK_UNROLL for (int r = 0; r < NZ; ++r) zp[r] = fma(sWm[1 + k], Hx[r] + HL[r][k], zp[r]);
+            FK_UNROLL for (int k = 0; k < NX; ++k)
+                FK_UNROLL for (int r = 0; r < NZ; ++r) zp[r] = fma(sWm[1 + NX + k], Hx[r] - HL[r][k], zp[r]);
+        }
+        // sweep 2: S = sum Wc_i d_i d_i' + R,  Pxz = sum Wc_i (sf_i - x) d_i',  d_i = sh_i - zp ; sf_0 - x = 0, sf_i - x = +-l_k
+        double S[NZ * NZ], K[NX * NZ];
+        FK_UNROLL for (int r = 0; r < NZ; ++r) FK_OPAQUE(Hx[r]);
+        {
+            const auto mv = fresh();
+            const double *sWc = mv.Wc;
+            FK_UNROLL for (int i = 0; i < 2 * NX + 1; ++i) {
+                double d[NZ], wd[NZ];
+                FK_UNROLL for (int r = 0; r < NZ; ++r) {
+                    const double v = (i == 0) ? Hx[r] : (i <= NX) ? Hx[r] + HL[r][(i - 1) % NX] : Hx[r] - HL[r][(i - 1) % NX];
+                    d[r] = v - zp[r];
+                }
+                FK_UNROLL for (int r = 0; r < NZ; ++r) wd[r] = sWc[i] * d[r];
+                FK_UNROLL for (int r = 0; r < NZ; ++r)
+                    FK_UNROLL for (int c = 0; c < NZ; ++c)
+                        S[r * NZ + c] = (i == 0) ? d[r] * wd[c] : fma(d[r], wd[c], S[r * NZ + c]);
+                if (i >= 1) {
+                    const int k = (i - 1) % NX;
+                    FK_UNROLL for (int r = 0; r < NX; ++r) {
+                        if (r < k) continue;                                   // l_k is zero above the diagonal
+                        const double lv = (i <= NX) ? L[sym_idx<NX>(r, k)] : -L[sym_idx<NX>(r, k)];
+                        FK_UNROLL for (int c = 0; c < NZ; ++c)
+                            K[r * NZ + c] = (i == 1) ? lv * wd[c] : fma(lv, wd[c], K[r * NZ + c]);
+                    }
+                }
+                FK_STAGE();
+            }
+            FK_UNROLL for (int r = 0; r < NZ; ++r) {
+                double rr[NZ];
+                mv.sm.rowR(r, rr);
+                FK_UNROLL for (int c = 0; c < NZ; ++c) S[r * NZ + c] += rr[c];
+            }
+        }
+        // K = Pxz S^-1
+        double Lf[NZ * NZ], dd[NZ], dinv[NZ];
+        FK_UNROLL for (int e = 0; e < NZ * NZ; ++e) Lf[e] = S[e];
+        if (!ldlt2_rs<NZ>(Lf, dd, dinv)) st |= ST_NOT_PD;
+        solve_rows_ldlt<NX, NZ>(Lf, dinv, K);
+        // x += K (z - zp)
+        FK_UNROLL for (int r = 0; r < NX; ++r) {
+            double acc = K[r * NZ] * (z[0] - zp[0]);
+            FK_UNROLL for (int c = 1; c < NZ; ++c) acc = fma(K[r * NZ + c], z[c] - zp[c], acc);
+            x[r] += acc;
+        }
+        // P -= K (S K'), upper triangle
+        FK_UNROLL for (int c2 = 0; c2 < NX; ++c2) {
+            double sk[NZ];                 // column c2 of S K'
+            FK_UNROLL for (int q = 0; q < NZ; ++q) {
+                double acc = S[q * NZ] * K[c2 * NZ];
+                FK_UNROLL for (int w = 1; w < NZ; ++w) acc = fma(S[q * NZ + w], K[c2 * NZ + w], acc);
+                sk[q] = acc;
+            }
+            FK_UNROLL for (int r = 0; r < NX; ++r)
+                if (r <= c2) {
+                    double acc = K[r * NZ] * sk[0];
+                    FK_UNROLL for (int q = 1; q < NZ; ++q) acc = fma(K[r * NZ + q], sk[q], acc);
+                    P[sym_idx<NX>(r, c2)] -= acc;
+                }
+            FK_STAGE();
+        }
+    }
+    return st;
+}
+
 // One backward step of UnscentedKalmanFilter.rts_smoother with fx(x, dt) = F x (UKF.py:714-737), fused:
 //   sigmas = sigma_points(xs[k], ps[k]) ; sigmas_f = F sigmas ; (xb, Pb) = UT(sigmas_f, Wm, Wc, Q)
 //   Pxb = sum_i Wc_i (sigmas_i - Xs[k]) (sigmas_f_i - xb)' ; K = Pxb inv(Pb)
@@ -300,6 +563,97 @@ FK_HD int ukf_linear_rts_gain(double (&x)[NX], const double (&P)[NX * (NX + 1) /
     }
     {
         const auto mv = fresh();
+        FK_UNROLL for (int r = 0; r < NX; ++r) {
+            double q[NX];
+            mv.sm.rowQ(r, q);
+            FK_UNROLL for (int b = 0; b < NX; ++b)
+                if (b >= r) Pb[sym_idx<NX>(r, b)] += q[b];
+        }
+    }
+    // K = Pxb inv(Pb)
+    {
+        double Lp[PL], d[NX], dinv[NX];
+        FK_UNROLL for (int e = 0; e < PL; ++e) Lp[e] = Pb[e];
+        if (!ldlt_packed<NX>(Lp, d, dinv)) st |= ST_NOT_PD;
+        FK_UNROLL for (int r = 0; r < NX; ++r) {
+            double row[NX];
+            FK_UNROLL for (int c = 0; c < NX; ++c) row[c] = K[r * NX + c];
+            solve_row_packed<NX>(Lp, dinv, row);
+            FK_UNROLL for (int c = 0; c < NX; ++c) K[r * NX + c] = row[c];
+        }
+    }
+    FK_STAGE();
+    return st;
+}
+
+// The factor-image organisation (see ukf_linear_step_v3) of ukf_linear_rts_gain: one pass over the rows of F gives F x and
+// F L, every point's image is one add per component in each sweep, and the offsets sigma_i - x = +-l_k of the cross
+// variance come from the factor (zero above the diagonal: those terms are skipped).
+template <int NX, class Fresh, class Sweep = NoSweep>
+FK_HD int ukf_linear_rts_gain_v3(double (&x)[NX], const double (&P)[NX * (NX + 1) / 2], double scale, double (&xb)[NX],
+                                 double (&Pb)[NX * (NX + 1) / 2], double (&K)[NX * NX], Fresh &&fresh,
+                                 Sweep &&sweep = Sweep{})
+{
+    constexpr int PL = NX * (NX + 1) / 2;
+    int st = 0;
+    double L[PL];
+    if (!chol_packed_rs<NX>(P, scale, L)) st |= ST_NOT_PD;
+    double Fx[NX], FL[NX][NX];
+    sweep();
+    {
+        const auto mv = fresh();
+        FK_UNROLL for (int r = 0; r < NX; ++r) {
+            double f[NX];
+            mv.sm.rowF(r, f);
+            Fx[r] = dot<NX>(f, x);
+            FK_UNROLL for (int k = 0; k < NX; ++k) {
+                double acc = f[k] * L[sym_idx<NX>(k, k)];
+                FK_UNROLL for (int c = 0; c < NX; ++c)
+                    if (c > k) acc = fma(f[c], L[sym_idx<NX>(c, k)], acc);
+                FL[r][k] = acc;
+            }
+            FK_STAGE();
+        }
+    }
+    // sweep 1: xb = sum_i Wm_i sf_i
+    {
+        const auto mv = fresh();
+        const double *sWm = mv.Wm;
+        FK_UNROLL for (int r = 0; r < NX; ++r) xb[r] = sWm[0] * Fx[r];
+        FK_UNROLL for (int k = 0; k < NX; ++k)
+            FK_UNROLL for (int r = 0; r < NX; ++r) xb[r] = fma(sWm[1 + k], Fx[r] + FL[r][k], xb[r]);
+        FK_UNROLL for (int k = 0; k < NX; ++k)
+            FK_UNROLL for (int r = 0; r < NX; ++r) xb[r] = fma(sWm[1 + NX + k], Fx[r] - FL[r][k], xb[r]);
+        FK_STAGE();
+    }
+    // sweep 2: Pb = sum Wc_i y_i y_i' (+ Q), Pxb = sum Wc_i (sigma_i - x) y_i', y_i = sf_i - xb
+    FK_UNROLL for (int r = 0; r < NX; ++r) FK_OPAQUE(Fx[r]);
+    {
+        const auto mv = fresh();
+        const double *sWc = mv.Wc;
+        FK_UNROLL for (int i = 0; i < 2 * NX + 1; ++i) {
+            double y[NX], wy[NX];
+            FK_UNROLL for (int r = 0; r < NX; ++r) {
+                const double v = (i == 0) ? Fx[r] : (i <= NX) ? Fx[r] + FL[r][(i - 1) % NX] : Fx[r] - FL[r][(i - 1) % NX];
+                y[r] = v - xb[r];
+            }
+            FK_UNROLL for (int r = 0; r < NX; ++r) wy[r] = sWc[i] * y[r];
+            FK_UNROLL for (int a2 = 0; a2 < NX; ++a2)
+                FK_UNROLL for (int b = 0; b < NX; ++b)
+                    if (b >= a2)
+                        Pb[sym_idx<NX>(a2, b)] = (i == 0) ? y[a2] * wy[b] : fma(y[a2], wy[b], Pb[sym_idx<NX>(a2, b)]);
+            if (i >= 1) {
+                const int k = (i - 1) % NX;
+                FK_UNROLL for (int r = 0; r < NX; ++r) {
+                    if (r < k) continue;                                       // l_k is zero above the diagonal
+                    const double lv = (i <= NX) ? L[sym_idx<NX>(r, k)] : -L[sym_idx<NX>(r, k)];
+                    // row r receives its first term from point 1 (k = 0): every row r >= 0 is below or on column 0's diagonal
+                    FK_UNROLL for (int c = 0; c < NX; ++c)
+                        K[r * NX + c] = (i == 1) ? lv * wy[c] : fma(lv, wy[c], K[r * NX + c]);
+                }
+            }
+            FK_STAGE();
+        }
         FK_UNROLL for (int r = 0; r < NX; ++r) {
             double q[NX];
             mv.sm.rowQ(r, q);

@@ -54,7 +54,7 @@ struct ScalarFHModel {
     __device__ __forceinline__ void rowR(int i, double (&r)[NZ]) const { LdsModel<NX, NZ>{s}.rowR(i, r); }
 };
 
-template <int NX, int NZ, int LAYOUT, bool SCALAR_FH>
+template <int NX, int NZ, int LAYOUT, bool SCALAR_FH, int VER = 3>
 __global__ void __launch_bounds__(BLOCK, (NX <= 2 ? 4 : NX <= 6 ? 2 : 1))
 ukf_linear_kernel_v2(const UkfArgs a, const double *__restrict__ pF, const double *__restrict__ pH,
                   const double *__restrict__ pQ, const double *__restrict__ pR,
@@ -65,6 +65,13 @@ ukf_linear_kernel_v2(const UkfArgs a, const double *__restrict__ pF, const doubl
     constexpr int PL = NX * (NX + 1) / 2;
     using SharedModel = LdsModel<NX, NZ>;
     __shared__ double s_model[SharedModel::SIZE + 2 * KS];
+    // NumPy order at the exact dims: the per-step outputs leave through a wave-private LDS tile, 1 KiB contiguous per store
+    // instruction (wave_store_aos, fk_device.hpp) -- a lane-per-record store touches 64 lines per instruction, and at V3's
+    // instruction count the 42 stores of a (6,3) step would make the address path, not the VALU, the bound.  (dim_x 9: the
+    // tile of an 81-double record does not fit next to four waves.)
+    constexpr bool COOP = LAYOUT == LAYOUT_AOS && NX <= 8 && NX % 2 == 0 && VER == 3;
+    constexpr int TILE = 64 * NX * NX;                       // flat: wave_store_aos_flat
+    __shared__ double s_tile[COOP ? (BLOCK / 64) * TILE : 1];
     const long N = a.N;
     const long blk0 = a.i0 + (long)blockIdx.x * BLOCK;
     const Lane ln{blk0, threadIdx.x, N};
@@ -72,6 +79,11 @@ ukf_linear_kernel_v2(const UkfArgs a, const double *__restrict__ pF, const doubl
     const Lane lr{blk0, live ? ln.tid : 0u, N};
     const int n = a.n, m = a.m;
     const int ks = 2 * n + 1;
+    const bool coop = COOP && n == NX;
+    double *tile = s_tile + (COOP ? (threadIdx.x >> 6) * TILE : 0);
+    const unsigned lane = threadIdx.x & 63u, wave_row0 = (threadIdx.x >> 6) * 64u;
+    const long left = a.i0 + a.cnt - blk0;
+    const unsigned last_row = (unsigned)(left < BLOCK ? left : BLOCK) - 1u;
 
     lds_fill<NX, NX>(s_model + SharedModel::OFF_F, pF, n, n, 1.0, threadIdx.x);
     lds_fill<NX, NX>(s_model + SharedModel::OFF_Q, pQ, n, n, 1.0, threadIdx.x);   // padded block of P stays I
@@ -126,8 +138,19 @@ ukf_linear_kernel_v2(const UkfArgs a, const double *__restrict__ pF, const doubl
         if (pmask) has_z = pmask[t * N + lr.blk0 + lr.tid] != 0;
         load_rec<NZ, 1, LAYOUT, false>(z, pz + t * N * m, lr, m, 1, 0.0);
 
-        st |= ukf_linear_step_v2<NX, NZ>(x, P, z, has_z, a.scale, fresh, sweep);
-        if (live) {
+        if constexpr (VER == 3) st |= ukf_linear_step_v3<NX, NZ>(x, P, z, has_z, a.scale, fresh, sweep);
+        else st |= ukf_linear_step_v2<NX, NZ>(x, P, z, has_z, a.scale, fresh, sweep);
+        if (COOP && coop) {
+            if constexpr (COOP) {
+                if (a.means) wave_store_aos_flat<NX>(x, a.means + t * N * NX + blk0 * NX, wave_row0, tile, lane, last_row);
+                if (a.covs) {
+                    double Pf[NX * NX];
+                    FK_UNROLL for (int i = 0; i < NX; ++i)
+                        FK_UNROLL for (int j = 0; j < NX; ++j) Pf[i * NX + j] = P[sym_idx<NX>(i, j)];
+                    wave_store_aos_flat<NX * NX>(Pf, a.covs + t * N * (NX * NX) + blk0 * (NX * NX), wave_row0, tile, lane, last_row);
+                }
+            }
+        } else if (live) {
             if (a.means) store_rec<NX, 1, LAYOUT, false>(x, a.means + t * N * n, ln, n, 1);
             if (a.covs) {
                 double Pf[NX * NX];
@@ -391,7 +414,7 @@ struct UkfRtsArgs {
 
 // (at dim_x = 6 the gain's second sweep accumulates Pb and the full n x n Pxb side by side next to L, x and xb: ~115
 // live doubles -- one wave per SIMD there; two spilled 90-220 registers)
-template <int NX, int LAYOUT, bool SCALAR_F>
+template <int NX, int LAYOUT, bool SCALAR_F, int VER = 3>
 __global__ void __launch_bounds__(BLOCK, (NX <= 2 ? 4 : NX <= 4 ? 2 : 1))
 ukf_linear_rts_kernel(const UkfRtsArgs a, const double *__restrict__ pF, const double *__restrict__ pQ,
                       const double *__restrict__ pWm, const double *__restrict__ pWc)
@@ -473,7 +496,8 @@ ukf_linear_rts_kernel(const UkfRtsArgs a, const double *__restrict__ pF, const d
         load_state(t, x, P);
         {
             double xb[NX], Pb[PL];
-            st |= ukf_linear_rts_gain<NX>(x, P, a.scale, xb, Pb, K, fresh, sweep);
+            if constexpr (VER == 3) st |= ukf_linear_rts_gain_v3<NX>(x, P, a.scale, xb, Pb, K, fresh, sweep);
+            else st |= ukf_linear_rts_gain<NX>(x, P, a.scale, xb, Pb, K, fresh, sweep);
             ukf_linear_rts_correct<NX>(x, P, xn, Pn, xb, Pb, K);
             FK_UNROLL for (int c = 0; c < NX; ++c) xn[c] = x[c];
             FK_UNROLL for (int e = 0; e < PL; ++e) Pn[e] = P[e];
@@ -519,8 +543,14 @@ int fk_ukf_linear_batch_f64(const fk_ukf_desc *d, const double *F, const double 
     a0.N = d->N; a0.T = d->T; a0.n = d->n; a0.m = d->m; a0.scale = d->scale;
     a0.i0 = 0; a0.cnt = d->N; a0.status_or = 0;
     const int layout = d->layout;
-    // exact (6,3): F and H as scalar operands (FK_UKF_LDS_MODEL=1 keeps them in LDS, for A/B timing and the parity tests)
-    static const bool lds_model = getenv("FK_UKF_LDS_MODEL") && getenv("FK_UKF_LDS_MODEL")[0] == '1';
+    // Round 3: every class runs the factor-image step (fk_ukf.hpp, ukf_linear_step_v3) with the model in LDS -- it reads each
+    // row of F and H once per step, so the scalar-operand form that V2's 4 x (2n+1) row sweeps needed no longer pays
+    // (its SGPR spills cost more than the 83 broadcast reads).  A/B switches, exact (6,3) only unless noted:
+    //   FK_UKF_SCALAR=1  F and H as scalar operands (also (8,4), (9,3));  FK_UKF_V2=1  round 2's point-by-point step;
+    //   FK_UKF_V1=1  the straightforward kernel at dim_x <= 4.
+    static const bool scalar_fh = getenv("FK_UKF_SCALAR") && getenv("FK_UKF_SCALAR")[0] == '1';
+    static const bool step_v2 = getenv("FK_UKF_V2") && getenv("FK_UKF_V2")[0] == '1';
+    static const bool kern_v1 = getenv("FK_UKF_V1") && getenv("FK_UKF_V1")[0] == '1';
     // one piece: tracks [a.i0, a.i0 + a.cnt), a.T steps from the pointers in a
     auto one = [&](const UkfArgs &a, hipStream_t s) -> int {
         const dim3 grid((unsigned)((a.cnt + BLOCK - 1) / BLOCK)), block(BLOCK);
@@ -531,26 +561,30 @@ int fk_ukf_linear_batch_f64(const fk_ukf_desc *d, const double *F, const double 
         else                                                                                                     \
             hipLaunchKernelGGL((KERNEL<__VA_ARGS__, LAYOUT_AOS>), grid, block, 0, s, a, F, H, Q, R, Wm, Wc, a.z, a.mask); \
     } while (0)
-#define GO2(NXV, NZV, SC)                                                                                        \
+#define GO2(NXV, NZV, SC, VER)                                                                                   \
     do {                                                                                                         \
         if (layout == FK_LAYOUT_SOA)                                                                             \
-            hipLaunchKernelGGL((ukf_linear_kernel_v2<NXV, NZV, LAYOUT_SOA, SC>), grid, block, 0, s, a, F, H, Q, R, Wm, Wc, a.z, a.mask); \
+            hipLaunchKernelGGL((ukf_linear_kernel_v2<NXV, NZV, LAYOUT_SOA, SC, VER>), grid, block, 0, s, a, F, H, Q, R, Wm, Wc, a.z, a.mask); \
         else                                                                                                     \
-            hipLaunchKernelGGL((ukf_linear_kernel_v2<NXV, NZV, LAYOUT_AOS, SC>), grid, block, 0, s, a, F, H, Q, R, Wm, Wc, a.z, a.mask); \
+            hipLaunchKernelGGL((ukf_linear_kernel_v2<NXV, NZV, LAYOUT_AOS, SC, VER>), grid, block, 0, s, a, F, H, Q, R, Wm, Wc, a.z, a.mask); \
     } while (0)
-        // the register-lean organisation wins where the straightforward one runs at one wave per SIMD ((6,3): 3.08 ->
-        // 2.68 ms SOA, 4.22 -> 2.90 ms AOS at 1e5 x 100; profiles/r02/exp_ukf2.log) and loses below it
-        if (a.n <= 2 && a.m <= 2) GO(ukf_linear_kernel, 2, 2);
-        else if (a.n <= 4 && a.m <= 2) GO(ukf_linear_kernel, 4, 2);
-        else if (a.n <= 6 && a.m <= 3) {
-            if (a.n == 6 && a.m == 3 && !lds_model) GO2(6, 3, true);
-            else GO2(6, 3, false);
+        if (a.n <= 2 && a.m <= 2) {
+            if (kern_v1) GO(ukf_linear_kernel, 2, 2);
+            else GO2(2, 2, false, 3);
+        } else if (a.n <= 4 && a.m <= 2) {
+            if (kern_v1) GO(ukf_linear_kernel, 4, 2);
+            else GO2(4, 2, false, 3);
+        } else if (a.n <= 6 && a.m <= 3) {
+            if (a.n == 6 && a.m == 3 && step_v2) GO2(6, 3, true, 2);
+            else if (a.n == 6 && a.m == 3 && scalar_fh) GO2(6, 3, true, 3);
+            else GO2(6, 3, false, 3);
         } else if (a.n <= 8) {                                             // round 3: dim_x 7..9 fused, one lane per track
-            if (a.n == 8 && a.m == 4) GO2(8, 4, true);
-            else GO2(8, 4, false);
+            if (a.n == 8 && a.m == 4 && scalar_fh) GO2(8, 4, true, 3);
+            else GO2(8, 4, false, 3);
         } else {
-            if (a.m == 3) GO2(9, 3, true);
-            else GO2(9, 4, false);
+            if (a.m == 3 && scalar_fh) GO2(9, 3, true, 3);
+            else if (a.m <= 3) GO2(9, 3, false, 3);
+            else GO2(9, 4, false, 3);
         }
 #undef GO
 #undef GO2
@@ -579,17 +613,20 @@ int fk_ukf_linear_rts_f64(const fk_ukf_desc *d, const double *F, const double *Q
     const dim3 grid((unsigned)((a.N + BLOCK - 1) / BLOCK)), block(BLOCK);
     hipStream_t s = (hipStream_t)stream;
     const bool soa = d->layout == FK_LAYOUT_SOA;
-#define GO(NXV, SC)                                                                                              \
+#define GO(NXV, SC, VER)                                                                                         \
     do {                                                                                                         \
-        if (soa) hipLaunchKernelGGL((ukf_linear_rts_kernel<NXV, LAYOUT_SOA, SC>), grid, block, 0, s, a, F, Q, Wm, Wc); \
-        else hipLaunchKernelGGL((ukf_linear_rts_kernel<NXV, LAYOUT_AOS, SC>), grid, block, 0, s, a, F, Q, Wm, Wc);     \
+        if (soa) hipLaunchKernelGGL((ukf_linear_rts_kernel<NXV, LAYOUT_SOA, SC, VER>), grid, block, 0, s, a, F, Q, Wm, Wc); \
+        else hipLaunchKernelGGL((ukf_linear_rts_kernel<NXV, LAYOUT_AOS, SC, VER>), grid, block, 0, s, a, F, Q, Wm, Wc);     \
     } while (0)
-    if (d->n <= 2) GO(2, false);
-    else if (d->n <= 4) GO(4, false);
-    else if (d->n == 6) GO(6, true);
-    else if (d->n <= 6) GO(6, false);
-    else if (d->n <= 8) GO(8, false);                                      // round 3: dim_x 7..9
-    else GO(9, false);
+    // every class runs the factor-image gain (fk_ukf.hpp, ukf_linear_rts_gain_v3); FK_UKF_V2=1: round 2's point-by-point
+    // gain with F as scalar operands, exact dim_x = 6 only (A/B)
+    static const bool gain_v2 = getenv("FK_UKF_V2") && getenv("FK_UKF_V2")[0] == '1';
+    if (d->n <= 2) GO(2, false, 3);
+    else if (d->n <= 4) GO(4, false, 3);
+    else if (d->n == 6 && gain_v2) GO(6, true, 2);
+    else if (d->n <= 6) GO(6, false, 3);
+    else if (d->n <= 8) GO(8, false, 3);                                   // round 3: dim_x 7..9
+    else GO(9, false, 3);
 #undef GO
     return check_launch("ukf_linear_rts_kernel");
 }

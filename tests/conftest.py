@@ -18,9 +18,14 @@ def pytest_configure(config):
 
 
 def _build(cmd, target, sources):
-    if os.path.exists(target) and all(os.path.getmtime(target) >= os.path.getmtime(s) for s in sources):
-        return
-    subprocess.check_call(cmd)
+    # under pytest-xdist every worker runs this fixture: one builds, the others wait on the lock and find it fresh
+    import fcntl
+    os.makedirs(os.path.dirname(target), exist_ok=True)
+    with open(target + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if os.path.exists(target) and all(os.path.getmtime(target) >= os.path.getmtime(s) for s in sources):
+            return
+        subprocess.check_call(cmd)
 
 
 @pytest.fixture(scope="session", autouse=True)

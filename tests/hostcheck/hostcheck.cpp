@@ -517,7 +517,7 @@ extern "C" int hc_imm_batch(int n, int m, int nm, long T, const double *F, const
 #include "../../filterpy_amd/csrc/fk_ukf.hpp"
 
 namespace {
-template <int NX, int NZ>
+template <int NX, int NZ, int VER = 2>
 int ukf_v2_batch(long T, const double *F, const double *H, const double *Q, const double *R, const double *Wm,
                  const double *Wc, double scale, const double *zs, const unsigned char *mask, double *x0,
                  double *P0, double *means, double *covs)
@@ -547,7 +547,8 @@ int ukf_v2_batch(long T, const double *F, const double *H, const double *Q, cons
     for (long t = 0; t < T; ++t) {
         double z[NZ];
         for (int r = 0; r < NZ; ++r) z[r] = zs[t * NZ + r];
-        st |= fk::ukf_linear_step_v2<NX, NZ>(x, P, z, mask ? mask[t] != 0 : true, scale, fresh);
+        if (VER == 3) st |= fk::ukf_linear_step_v3<NX, NZ>(x, P, z, mask ? mask[t] != 0 : true, scale, fresh);
+        else st |= fk::ukf_linear_step_v2<NX, NZ>(x, P, z, mask ? mask[t] != 0 : true, scale, fresh);
         for (int i = 0; i < NX; ++i) {
             means[t * NX + i] = x[i];
             for (int j = 0; j < NX; ++j) covs[(t * NX + i) * NX + j] = P[fk::sym_idx<NX>(i, j)];
@@ -563,7 +564,7 @@ int ukf_v2_batch(long T, const double *F, const double *H, const double *Q, cons
 
 namespace {
 // the fused linear-model UKF smoother's step (fk_ukf.hpp: ukf_linear_rts_gain / _correct) over a whole backward pass
-template <int NX>
+template <int NX, int VER = 2>
 int ukf_rts_batch(long T, const double *F, const double *Q, const double *Wm, const double *Wc, double scale,
                   const double *Xs, const double *Ps, double *xs, double *ps, double *Ks)
 {
@@ -602,7 +603,8 @@ int ukf_rts_batch(long T, const double *F, const double *Q, const double *Wm, co
     for (long t = T - 2; t >= 0; --t) {
         double x[NX], P[PL], K[NX * NX], xb[NX], Pb[PL];
         load(t, x, P);
-        st |= fk::ukf_linear_rts_gain<NX>(x, P, scale, xb, Pb, K, fresh);
+        if (VER == 3) st |= fk::ukf_linear_rts_gain_v3<NX>(x, P, scale, xb, Pb, K, fresh);
+        else st |= fk::ukf_linear_rts_gain<NX>(x, P, scale, xb, Pb, K, fresh);
         fk::ukf_linear_rts_correct<NX>(x, P, xn, Pn, xb, Pb, K);
         store(t, x, P);
         for (int e = 0; e < NX * NX; ++e) Ks[t * NX * NX + e] = K[e];
@@ -629,5 +631,25 @@ extern "C" int hc_ukf_linear_v2(int n, int m, long T, const double *F, const dou
     if (n == 2 && m == 2) return ukf_v2_batch<2, 2>(T, F, H, Q, R, Wm, Wc, scale, zs, mask, x0, P0, means, covs);
     if (n == 4 && m == 2) return ukf_v2_batch<4, 2>(T, F, H, Q, R, Wm, Wc, scale, zs, mask, x0, P0, means, covs);
     if (n == 6 && m == 3) return ukf_v2_batch<6, 3>(T, F, H, Q, R, Wm, Wc, scale, zs, mask, x0, P0, means, covs);
+    return -1;
+}
+
+// the factor-image organisation of the step (fk_ukf.hpp, ukf_linear_step_v3: what the kernels run since round 3)
+extern "C" int hc_ukf_linear_v3(int n, int m, long T, const double *F, const double *H, const double *Q, const double *R,
+                                const double *Wm, const double *Wc, double scale, const double *zs,
+                                const unsigned char *mask, double *x0, double *P0, double *means, double *covs)
+{
+#define GO(NXV, NZV) if (n == NXV && m == NZV) return ukf_v2_batch<NXV, NZV, 3>(T, F, H, Q, R, Wm, Wc, scale, zs, mask, x0, P0, means, covs)
+    GO(2, 2); GO(4, 2); GO(6, 3); GO(8, 4); GO(9, 3); GO(9, 4); GO(3, 1); GO(5, 2); GO(7, 3);
+#undef GO
+    return -1;
+}
+
+extern "C" int hc_ukf_linear_rts_v3(int n, long T, const double *F, const double *Q, const double *Wm, const double *Wc,
+                                    double scale, const double *Xs, const double *Ps, double *xs, double *ps, double *Ks)
+{
+#define GO(NXV) if (n == NXV) return ukf_rts_batch<NXV, 3>(T, F, Q, Wm, Wc, scale, Xs, Ps, xs, ps, Ks)
+    GO(2); GO(3); GO(4); GO(5); GO(6); GO(7); GO(8); GO(9);
+#undef GO
     return -1;
 }

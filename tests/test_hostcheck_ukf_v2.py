@@ -14,7 +14,7 @@ sys.path.insert(0, ROOT)
 from oracle import ukf_oracle  # noqa: E402
 
 
-def _v2(n, m, F, H, Q, R, Wm, Wc, scale, zs, mask, x0, P0):
+def _v2(n, m, F, H, Q, R, Wm, Wc, scale, zs, mask, x0, P0, entry="hc_ukf_linear_v2"):
     lib = ctypes.CDLL(os.path.join(ROOT, "tests", "hostcheck", "libhostcheck.so"))
     T = zs.shape[0]
     c = lambda a: np.ascontiguousarray(a, dtype=np.float64)  # noqa: E731
@@ -23,15 +23,19 @@ def _v2(n, m, F, H, Q, R, Wm, Wc, scale, zs, mask, x0, P0):
     means, covs = np.empty((T, n)), np.empty((T, n, n))
     mk = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
     p = lambda a: None if a is None else a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
-    st = lib.hc_ukf_linear_v2(ctypes.c_int(n), ctypes.c_int(m), ctypes.c_long(T), p(F), p(H), p(Q), p(R), p(Wm), p(Wc),
+    st = getattr(lib, entry)(ctypes.c_int(n), ctypes.c_int(m), ctypes.c_long(T), p(F), p(H), p(Q), p(R), p(Wm), p(Wc),
                               ctypes.c_double(scale), p(zs), p(mk), p(x), p(P), p(means), p(covs))
     assert st == 0, st
     return means, covs, x, P
 
 
-@pytest.mark.parametrize("n,m", [(2, 2), (4, 2), (6, 3)])
+@pytest.mark.parametrize("n,m,entry", [(2, 2, "hc_ukf_linear_v2"), (4, 2, "hc_ukf_linear_v2"), (6, 3, "hc_ukf_linear_v2")] +
+                         [(n, m, "hc_ukf_linear_v3") for n, m in
+                          [(2, 2), (3, 1), (4, 2), (5, 2), (6, 3), (7, 3), (8, 4), (9, 3), (9, 4)]])
 @pytest.mark.parametrize("abk", [(.1, 2., None), (1e-3, 2., 0.), (1., 2., .1)])
-def test_ukf_v2_step_matches_the_oracle(n, m, abk):
+def test_ukf_v2_step_matches_the_oracle(n, m, entry, abk):
+    """ukf_linear_step_v2 (round 2, point by point) and ukf_linear_step_v3 (round 3, images formed from the image of the
+    factor -- what the kernels run) on the host against the oracle's UKF.batch_filter (UKF.py:364-491, 634-712)."""
     alpha, beta, kappa = abk
     kappa = 3. - n if kappa is None else kappa
     r = np.random.default_rng(n * 10 + m)
@@ -49,7 +53,7 @@ def test_ukf_v2_step_matches_the_oracle(n, m, abk):
     Wm, Wc = ukf_oracle.merwe_weights(n, alpha, beta, kappa)
     mu_ref, cov_ref = ukf_oracle.ukf_batch_filter(x0, P0, list(zs), lambda s, d: F @ s, lambda s: H @ s, 0.1, Q, R,
                                                   alpha, beta, kappa)
-    mu, cov, xf, Pf = _v2(n, m, F, H, Q, R, Wm, Wc, lam + n, zs, None, x0, P0)
+    mu, cov, xf, Pf = _v2(n, m, F, H, Q, R, Wm, Wc, lam + n, zs, None, x0, P0, entry)
     rel = lambda a, b: np.max(np.abs(a - b)) / np.max(np.abs(b))  # noqa: E731
     # Merwe's cancelling weights (Wm0 ~ -1e6 at alpha = 1e-3) amplify rounding: the package's UKF bar is 1e-9
     tol = 1e-9 if alpha > 1e-2 else 1e-6
@@ -58,7 +62,8 @@ def test_ukf_v2_step_matches_the_oracle(n, m, abk):
     assert np.allclose(cov, np.swapaxes(cov, 1, 2))
 
 
-def test_ukf_v2_missing_measurements_skip_the_update():
+@pytest.mark.parametrize("entry", ["hc_ukf_linear_v2", "hc_ukf_linear_v3"])
+def test_ukf_v2_missing_measurements_skip_the_update(entry):
     n, m, T = 4, 2, 12
     r = np.random.default_rng(5)
     F = np.eye(n) + 0.05 * np.triu(r.standard_normal((n, n)), 1)
@@ -73,27 +78,28 @@ def test_ukf_v2_missing_measurements_skip_the_update():
     zl = [z if k else None for z, k in zip(zs, mask)]
     mu_ref, cov_ref = ukf_oracle.ukf_batch_filter(x0, P0, zl, lambda s, d: F @ s, lambda s: H @ s, 0.1, Q, R,
                                                   alpha, beta, kappa)
-    mu, cov, _, _ = _v2(n, m, F, H, Q, R, Wm, Wc, lam + n, zs, mask, x0, P0)
+    mu, cov, _, _ = _v2(n, m, F, H, Q, R, Wm, Wc, lam + n, zs, mask, x0, P0, entry)
     assert np.max(np.abs(mu - mu_ref)) / np.max(np.abs(mu_ref)) < 1e-9
     assert np.max(np.abs(cov - cov_ref)) / np.max(np.abs(cov_ref)) < 1e-9
 
 
-def _rts(n, F, Q, Wm, Wc, scale, Xs, Ps):
+def _rts(n, F, Q, Wm, Wc, scale, Xs, Ps, entry="hc_ukf_linear_rts"):
     lib = ctypes.CDLL(os.path.join(ROOT, "tests", "hostcheck", "libhostcheck.so"))
     T = Xs.shape[0]
     c = lambda a: np.ascontiguousarray(a, dtype=np.float64)  # noqa: E731
     F, Q, Wm, Wc, Xs, Ps = map(c, (F, Q, Wm, Wc, Xs, Ps))
     xs, ps, Ks = np.empty((T, n)), np.empty((T, n, n)), np.empty((T, n, n))
     p = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
-    st = lib.hc_ukf_linear_rts(ctypes.c_int(n), ctypes.c_long(T), p(F), p(Q), p(Wm), p(Wc), ctypes.c_double(scale),
+    st = getattr(lib, entry)(ctypes.c_int(n), ctypes.c_long(T), p(F), p(Q), p(Wm), p(Wc), ctypes.c_double(scale),
                                p(Xs), p(Ps), p(xs), p(ps), p(Ks))
     assert st == 0, st
     return xs, ps, Ks
 
 
-@pytest.mark.parametrize("n,m", [(2, 2), (4, 2), (6, 3)])
+@pytest.mark.parametrize("n,m,entry", [(2, 2, "hc_ukf_linear_rts"), (4, 2, "hc_ukf_linear_rts"), (6, 3, "hc_ukf_linear_rts")] +
+                         [(n, 2, "hc_ukf_linear_rts_v3") for n in range(2, 10)])
 @pytest.mark.parametrize("abk", [(.1, 2., None), (1., 2., .1)])
-def test_fused_ukf_smoother_step_matches_the_oracle(n, m, abk):
+def test_fused_ukf_smoother_step_matches_the_oracle(n, m, entry, abk):
     """fk_ukf.hpp ukf_linear_rts_gain / _correct (the arithmetic of fk_ukf_linear_rts_f64) on the host against the
     oracle's UKF.rts_smoother (UKF.py:714-739; oracle pinned to the live reference by tests/test_oracle_ukf.py)."""
     alpha, beta, kappa = abk
@@ -111,7 +117,7 @@ def test_fused_ukf_smoother_step_matches_the_oracle(n, m, abk):
     Wm, Wc = ukf_oracle.merwe_weights(n, alpha, beta, kappa)
     mu, cov = ukf_oracle.ukf_batch_filter(x0, P0, list(zs), lambda s, d: F @ s, lambda s: H @ s, 0.1, Q, R, alpha, beta, kappa)
     xr, Pr, Kr = ukf_oracle.ukf_rts_smoother(mu, cov, lambda s, d: F @ s, 0.1, Q, alpha, beta, kappa)
-    xs, ps, Ks = _rts(n, F, Q, Wm, Wc, lam + n, mu, cov)
+    xs, ps, Ks = _rts(n, F, Q, Wm, Wc, lam + n, mu, cov, entry)
     rel = lambda a, b: float(np.max(np.max(np.abs(a - b).reshape(len(a), -1), axis=1) / np.max(np.abs(b).reshape(len(b), -1), axis=1)))  # noqa: E731
     assert rel(xs, xr) < 1e-10 and rel(ps, Pr) < 1e-10 and rel(Ks[:-1], Kr[:-1]) < 1e-10
     assert np.array_equal(xs[-1], mu[-1]) and np.array_equal(ps[-1], cov[-1]) and not Ks[-1].any()
