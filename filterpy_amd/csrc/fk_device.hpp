@@ -313,6 +313,31 @@ __device__ __forceinline__ void wave_load_aos(double (&v)[LEN], const double *sl
     }
 }
 
+// wave_load_aos split in two for a fetch that is issued one time step ahead (even LEN, flat tile like wave_store_aos_flat):
+// issue() puts the wave's slab of the array in flight, memory order, 1 KiB per instruction, into LEN / 2 16-byte register
+// quads; row() -- a step later -- passes them through the tile and returns the lane's own record.  Rows past the block's
+// last track read as zeros (the descriptor's range check).
+template <int LEN>
+struct WaveAosFetch {
+    static_assert(LEN % 2 == 0, "16-byte units");
+    u32x4 w[LEN / 2];
+    __device__ __forceinline__ void issue(const double *slab, unsigned wave_row0, unsigned lane, unsigned last_row)
+    {
+        const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(slab), 0,
+                                                            (int)((last_row + 1u) * (unsigned)LEN * 8u), 0x00020000);
+        const unsigned gb = (wave_row0 * LEN + lane * 2u) * 8u;
+        FK_UNROLL for (int it = 0; it < LEN / 2; ++it) w[it] = __builtin_amdgcn_raw_buffer_load_b128(rs, gb + (unsigned)(it * 1024), 0, 0);
+    }
+    // the fetched quads -> tile (flat); afterwards tile[lane * LEN + e] is element e of the lane's record.  The caller
+    // fences (wave_lds_fence) after its reads, before the tile is written again.
+    __device__ __forceinline__ void to_tile(double *tile, unsigned lane)
+    {
+        wave_lds_fence();
+        FK_UNROLL for (int it = 0; it < LEN / 2; ++it) *reinterpret_cast<u32x4 *>(tile + lane * 2u + it * 128) = w[it];
+        wave_lds_fence();
+    }
+};
+
 // ---- host side ------------------------------------------------------------
 void set_last_error(const char *msg);
 int check_launch(const char *what);   // hipGetLastError -> FK_ERR_LAUNCH + message

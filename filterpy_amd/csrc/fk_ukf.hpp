@@ -1,10 +1,12 @@
-// fk_ukf.hpp -- one predict + update step of the fused linear-model UKF, register-lean organisation ("V2" of
-// ukf_kernels.hip, see there).  __host__ __device__: the kernel runs it per lane, tests/hostcheck runs the very
+// fk_ukf.hpp -- one predict + update step of the fused linear-model UKF and one backward step of its smoother (the arithmetic
+// of ukf_kernels.hip, see there).  __host__ __device__: the kernel runs it per lane, tests/hostcheck runs the very
 // same code on the host against the oracle.
 //
 //   fresh() returns a view {sm, Wm, Wc} of the shared model (rowF / rowQ / rowH / rowR policy) and the padded
 //   sigma-point weights; the kernel hands out a new, optimiser-opaque view on every call so that the broadcast
 //   LDS reads of the 2n+1 unrolled points are not hoisted and held, the host hands out the same plain arrays.
+//   fresh(v) additionally orders the view behind the arithmetic that produced v (the opaque point takes v as an input):
+//   a chain of views that depend on nothing but each other is emitted -- reads and all -- in front of the arithmetic.
 #pragma once
 
 #include "fk_math.hpp"
@@ -17,201 +19,6 @@
 #endif
 
 namespace fk {
-
-struct NoSweep {
-    FK_HD void operator()() const {}
-};
-
-//   sweep() is called at the head of each of the four passes over the sigma points: a model policy that keeps F / H
-//   in scalar registers for the length of one pass re-derives its (optimiser-opaque) base there, so that the rows
-//   are re-fetched per pass instead of being hoisted out of the time loop and held.
-template <int NX, int NZ, class Fresh, class Sweep = NoSweep>
-FK_HD int ukf_linear_step_v2(double (&x)[NX], double (&P)[NX * (NX + 1) / 2], const double (&z)[NZ], bool has_z,
-                             double scale, Fresh &&fresh, Sweep &&sweep = Sweep{})
-{
-    constexpr int KS = 2 * NX + 1;
-    constexpr int PL = NX * (NX + 1) / 2;
-    int st = 0;
-    const auto mv0 = fresh();
-    const auto &sm = mv0.sm;
-    // ---------------- predict (UKF.py:400-411)
-    double L[PL];
-    if (!chol_packed<NX>(P, scale, L)) st |= ST_NOT_PD;
-    // sweep 1: x- = sum_i Wm_i F sigma_i, one output component (row of F) at a time, points in
-    // index order 0, x + L[:,k] (k = 0..n-1), x - L[:,k]
-    double xm[NX];
-    sweep();
-    FK_UNROLL for (int i = 0; i < KS; ++i) {
-        const auto mv = fresh();
-        const auto &sm = mv.sm;
-        const double *sWm = mv.Wm, *sWc = mv.Wc;
-        (void)sWm; (void)sWc;
-        FK_UNROLL for (int r = 0; r < NX; ++r) {
-            double f[NX];
-            sm.rowF(r, f);
-            double v;
-            if (i == 0) {
-                v = dot<NX>(f, x);
-            } else if (i <= NX) {
-                v = f[0] * (x[0] - (-lcol<NX>(L, 0, i - 1)));
-                FK_UNROLL for (int c = 1; c < NX; ++c) v = fma(f[c], x[c] - (-lcol<NX>(L, c, i - 1)), v);
-            } else {
-                v = f[0] * (x[0] - lcol<NX>(L, 0, i - 1 - NX));
-                FK_UNROLL for (int c = 1; c < NX; ++c) v = fma(f[c], x[c] - lcol<NX>(L, c, i - 1 - NX), v);
-            }
-            xm[r] = (i == 0) ? sWm[0] * v : fma(sWm[i], v, xm[r]);
-        }
-        FK_STAGE();
-    }
-    // sweep 2: P- = sum_i Wc_i y_i y_i' + Q, y_i = F sigma_i - x-   (upper triangle).
-    // The points are recomputed from copies the optimiser cannot relate to sweep 1 (otherwise it
-    // common-subexpression-eliminates the recomputation by keeping all (2n+1) n values alive).
-    double Pn[PL];
-    FK_UNROLL for (int c = 0; c < NX; ++c) FK_OPAQUE(x[c]);
-    FK_UNROLL for (int e = 0; e < PL; ++e) FK_OPAQUE(L[e]);
-    sweep();
-    FK_UNROLL for (int i = 0; i < KS; ++i) {
-        const auto mv = fresh();
-        const auto &sm = mv.sm;
-        const double *sWm = mv.Wm, *sWc = mv.Wc;
-        (void)sWm; (void)sWc;
-        double y[NX], wy[NX];
-        FK_UNROLL for (int r = 0; r < NX; ++r) {
-            double f[NX];
-            sm.rowF(r, f);
-            double v;
-            if (i == 0) {
-                v = dot<NX>(f, x);
-            } else if (i <= NX) {
-                v = f[0] * (x[0] - (-lcol<NX>(L, 0, i - 1)));
-                FK_UNROLL for (int c = 1; c < NX; ++c) v = fma(f[c], x[c] - (-lcol<NX>(L, c, i - 1)), v);
-            } else {
-                v = f[0] * (x[0] - lcol<NX>(L, 0, i - 1 - NX));
-                FK_UNROLL for (int c = 1; c < NX; ++c) v = fma(f[c], x[c] - lcol<NX>(L, c, i - 1 - NX), v);
-            }
-            y[r] = v - xm[r];
-        }
-        FK_UNROLL for (int r = 0; r < NX; ++r) wy[r] = sWc[i] * y[r];
-        FK_UNROLL for (int a2 = 0; a2 < NX; ++a2)
-            FK_UNROLL for (int b = 0; b < NX; ++b)
-                if (b >= a2)
-                    Pn[sym_idx<NX>(a2, b)] = (i == 0) ? y[a2] * wy[b] : fma(y[a2], wy[b], Pn[sym_idx<NX>(a2, b)]);
-        FK_STAGE();
-    }
-    FK_UNROLL for (int r = 0; r < NX; ++r) {
-        double q[NX];
-        sm.rowQ(r, q);
-        FK_UNROLL for (int b = 0; b < NX; ++b)
-            if (b >= r) P[sym_idx<NX>(r, b)] = Pn[sym_idx<NX>(r, b)] + q[b];
-        x[r] = xm[r];
-    }
-
-    // ---------------- update (UKF.py:462-481), sigma points regenerated from the prior (:407)
-    if (has_z) {
-        if (!chol_packed<NX>(P, scale, L)) st |= ST_NOT_PD;
-        // sweep 1: zp = sum_i Wm_i H sigma_i, point by point (index order 0, +k, -k)
-        double zp[NZ];
-        sweep();
-        FK_UNROLL for (int i = 0; i < KS; ++i) {
-            const auto mv = fresh();
-            const auto &sm = mv.sm;
-            const double *sWm = mv.Wm, *sWc = mv.Wc;
-            (void)sWm; (void)sWc;
-            FK_UNROLL for (int r = 0; r < NZ; ++r) {
-                double h[NX];
-                sm.rowH(r, h);
-                double v;
-                if (i == 0) {
-                    v = dot<NX>(h, x);
-                } else if (i <= NX) {
-                    v = h[0] * (x[0] - (-lcol<NX>(L, 0, i - 1)));
-                    FK_UNROLL for (int c = 1; c < NX; ++c) v = fma(h[c], x[c] - (-lcol<NX>(L, c, i - 1)), v);
-                } else {
-                    v = h[0] * (x[0] - lcol<NX>(L, 0, i - 1 - NX));
-                    FK_UNROLL for (int c = 1; c < NX; ++c) v = fma(h[c], x[c] - lcol<NX>(L, c, i - 1 - NX), v);
-                }
-                zp[r] = (i == 0) ? sWm[0] * v : fma(sWm[i], v, zp[r]);
-            }
-            FK_STAGE();
-        }
-        // sweep 2: S = sum Wc_i d_i d_i' + R,  Pxz = sum Wc_i (sf_i - x) d_i',  d_i = H sigma_i - zp
-        double S[NZ * NZ], K[NX * NZ];
-        FK_UNROLL for (int c = 0; c < NX; ++c) FK_OPAQUE(x[c]);
-        FK_UNROLL for (int e = 0; e < PL; ++e) FK_OPAQUE(L[e]);
-        sweep();
-        FK_UNROLL for (int i = 0; i < KS; ++i) {
-            const auto mv = fresh();
-            const auto &sm = mv.sm;
-            const double *sWm = mv.Wm, *sWc = mv.Wc;
-            (void)sWm; (void)sWc;
-            double d[NZ], wd[NZ];
-            FK_UNROLL for (int r = 0; r < NZ; ++r) {
-                double h[NX];
-                sm.rowH(r, h);
-                double v;
-                if (i == 0) {
-                    v = dot<NX>(h, x);
-                } else if (i <= NX) {
-                    v = h[0] * (x[0] - (-lcol<NX>(L, 0, i - 1)));
-                    FK_UNROLL for (int c = 1; c < NX; ++c) v = fma(h[c], x[c] - (-lcol<NX>(L, c, i - 1)), v);
-                } else {
-                    v = h[0] * (x[0] - lcol<NX>(L, 0, i - 1 - NX));
-                    FK_UNROLL for (int c = 1; c < NX; ++c) v = fma(h[c], x[c] - lcol<NX>(L, c, i - 1 - NX), v);
-                }
-                d[r] = v - zp[r];
-            }
-            FK_UNROLL for (int r = 0; r < NZ; ++r) wd[r] = sWc[i] * d[r];
-            FK_UNROLL for (int r = 0; r < NZ; ++r)
-                FK_UNROLL for (int c = 0; c < NZ; ++c)
-                    S[r * NZ + c] = (i == 0) ? d[r] * wd[c] : fma(d[r], wd[c], S[r * NZ + c]);
-            FK_UNROLL for (int r = 0; r < NX; ++r) {
-                double dx;
-                if (i == 0) dx = x[r] - x[r];
-                else if (i <= NX) dx = (x[r] - (-lcol<NX>(L, r, i - 1))) - x[r];
-                else dx = (x[r] - lcol<NX>(L, r, i - 1 - NX)) - x[r];
-                FK_UNROLL for (int c = 0; c < NZ; ++c) {
-                    const double term = sWc[i] * (dx * d[c]);
-                    K[r * NZ + c] = (i == 0) ? term : K[r * NZ + c] + term;
-                }
-            }
-            FK_STAGE();
-        }
-        FK_UNROLL for (int r = 0; r < NZ; ++r) {
-            double rr[NZ];
-            sm.rowR(r, rr);
-            FK_UNROLL for (int c = 0; c < NZ; ++c) S[r * NZ + c] += rr[c];
-        }
-        // K = Pxz S^-1
-        double Lf[NZ * NZ], d[NZ], dinv[NZ];
-        FK_UNROLL for (int e = 0; e < NZ * NZ; ++e) Lf[e] = S[e];
-        if (!ldlt2<NZ>(Lf, d, dinv)) st |= ST_NOT_PD;
-        solve_rows_ldlt<NX, NZ>(Lf, dinv, K);
-        // x += K (z - zp)
-        FK_UNROLL for (int r = 0; r < NX; ++r) {
-            double acc = K[r * NZ] * (z[0] - zp[0]);
-            FK_UNROLL for (int c = 1; c < NZ; ++c) acc = fma(K[r * NZ + c], z[c] - zp[c], acc);
-            x[r] += acc;
-        }
-        // P -= K (S K'), upper triangle
-        FK_UNROLL for (int c2 = 0; c2 < NX; ++c2) {
-            double sk[NZ];                 // column c2 of S K'
-            FK_UNROLL for (int q = 0; q < NZ; ++q) {
-                double acc = S[q * NZ] * K[c2 * NZ];
-                FK_UNROLL for (int w = 1; w < NZ; ++w) acc = fma(S[q * NZ + w], K[c2 * NZ + w], acc);
-                sk[q] = acc;
-            }
-            FK_UNROLL for (int q = 0; q < NZ; ++q) FK_OPAQUE(sk[q]);
-            FK_UNROLL for (int r = 0; r < NX; ++r)
-                if (r <= c2) {
-                    double acc = K[r * NZ] * sk[0];
-                    FK_UNROLL for (int q = 1; q < NZ; ++q) acc = fma(K[r * NZ + q], sk[q], acc);
-                    P[sym_idx<NX>(r, c2)] -= acc;
-                }
-            FK_STAGE();
-        }
-    }
-    return st;
-}
 
 // sqrt(d) and 1 / sqrt(d) together; 1 / d.  On the device: v_rsq_f64 / v_rcp_f64 seeds (~2^-26) refined by one
 // Goldschmidt step and one residual correction (11 / 5 instructions; the compiler's correctly-rounded sqrt followed by
@@ -301,8 +108,9 @@ FK_HD bool ldlt2_rs(double (&A)[M * M], double (&d)[M], double (&dinv)[M])
     return pd;
 }
 
-// "V3" of the step (round 3): the same sums over the same 2n+1 points in the same index order, but the images of the
-// points are formed from the image of the FACTOR instead of point by point.  With fx(x) = F x the sigma-point matrix
+// One predict + update step (UKF.py:400-411, 462-481).  "V3" (round 3; round 2's V2 pushed every sigma point through F and
+// H one by one, twice): the same sums over the same 2n+1 points in the same index order, but the images of the points are
+// formed from the image of the FACTOR instead of point by point.  With fx(x) = F x the sigma-point matrix
 // [x, x + l_k, x - l_k] (sigma_points.py:167-175) maps to [F x, F x + F l_k, F x - F l_k]: one pass over the rows of F
 // produces F x and F L (column k of L has n - k non-zeros: n (n+1)/2 * n FMAs instead of (2n+1) n^2 per sweep, and V2
 // made two sweeps), and every point's image is then ONE add per component in each of the two unscented-transform
@@ -312,11 +120,13 @@ FK_HD bool ldlt2_rs(double (&A)[M * M], double (&d)[M], double (&dinv)[M])
 // diagonal are exact zeros in both, so those terms are skipped, not approximated.
 // Numerically each image differs from fl(F fl(x + l_k)) by a rounding of |F x| -- the same size as the reference's own
 // rounding of that dot product, amplified by the same Merwe weights -- so the parity bar is the package's 1e-10 (held
-// on the host against the oracle by tests/test_hostcheck_ukf_v2.py, on the GPU against the live-reference goldens).
+// on the host against the oracle by tests/test_hostcheck_ukf.py, on the GPU against the live-reference goldens).
 // (6,3): ~2000 VALU instructions per step against V2's 3780.
-template <int NX, int NZ, class Fresh, class Sweep = NoSweep>
-FK_HD int ukf_linear_step_v3(double (&x)[NX], double (&P)[NX * (NX + 1) / 2], const double (&z)[NZ], bool has_z,
-                             double scale, Fresh &&fresh, Sweep &&sweep = Sweep{})
+// load_z(z) delivers the step's measurement; it is called at the head of the update half -- the kernel issues the loads
+// there (behind the predict half: no registers held across it, and the update's own arithmetic hides the latency).
+template <int NX, int NZ, class LoadZ, class Fresh>
+FK_HD int ukf_linear_step_v3(double (&x)[NX], double (&P)[NX * (NX + 1) / 2], LoadZ &&load_z, bool has_z,
+                             double scale, Fresh &&fresh)
 {
     constexpr int PL = NX * (NX + 1) / 2;
     int st = 0;
@@ -327,7 +137,6 @@ FK_HD int ukf_linear_step_v3(double (&x)[NX], double (&P)[NX * (NX + 1) / 2], co
             double L[PL];
             if (!chol_packed_rs<NX>(P, scale, L)) st |= ST_NOT_PD;
             // one pass over the rows of F: F x and F L (FL[r][k] = sum_{c >= k} F[r][c] L[c][k])
-            sweep();
             const auto mv = fresh();
             FK_UNROLL for (int r = 0; r < NX; ++r) {
                 double f[NX];
@@ -357,21 +166,23 @@ FK_HD int ukf_linear_step_v3(double (&x)[NX], double (&P)[NX * (NX + 1) / 2], co
         // from copies the optimiser cannot relate to sweep 1's, or it would hold all (2n+1) n of them
         FK_UNROLL for (int r = 0; r < NX; ++r) FK_OPAQUE(Fx[r]);
         {
-            const auto mv = fresh();
-            const double *sWc = mv.Wc;
             FK_UNROLL for (int i = 0; i < 2 * NX + 1; ++i) {
+                // a fresh view per point, ordered behind the previous point's arithmetic: read here, not hoisted and held
+                const double wc = fresh(i ? P[PL - 1] : x[NX - 1]).Wc[i];
                 double y[NX], wy[NX];
                 FK_UNROLL for (int r = 0; r < NX; ++r) {
                     const double v = (i == 0) ? Fx[r] : (i <= NX) ? Fx[r] + FL[r][(i - 1) % NX] : Fx[r] - FL[r][(i - 1) % NX];
                     y[r] = v - x[r];
                 }
-                FK_UNROLL for (int r = 0; r < NX; ++r) wy[r] = sWc[i] * y[r];
+                FK_UNROLL for (int r = 0; r < NX; ++r) wy[r] = wc * y[r];
                 FK_UNROLL for (int a2 = 0; a2 < NX; ++a2)
                     FK_UNROLL for (int b = 0; b < NX; ++b)
                         if (b >= a2)
                             P[sym_idx<NX>(a2, b)] = (i == 0) ? y[a2] * wy[b] : fma(y[a2], wy[b], P[sym_idx<NX>(a2, b)]);
                 FK_STAGE();
             }
+            FK_UNROLL for (int e = 0; e < PL; ++e) FK_OPAQUE(P[e]);     // every sum complete before the rows of Q are read
+            const auto mv = fresh(P[PL - 1]);
             FK_UNROLL for (int r = 0; r < NX; ++r) {
                 double q[NX];
                 mv.sm.rowQ(r, q);
@@ -382,10 +193,11 @@ FK_HD int ukf_linear_step_v3(double (&x)[NX], double (&P)[NX * (NX + 1) / 2], co
     }
     // ---------------- update (UKF.py:462-481), sigma points regenerated from the prior (:407)
     if (has_z) {
+        double z[NZ];
+        load_z(z);
         double L[PL];
         if (!chol_packed_rs<NX>(P, scale, L)) st |= ST_NOT_PD;
         double Hx[NZ], HL[NZ][NX];
-        sweep();
         {
             const auto mv = fresh();
             FK_UNROLL for (int r = 0; r < NZ; ++r) {
@@ -416,15 +228,14 @@ FK_HD int ukf_linear_step_v3(double (&x)[NX], double (&P)[NX * (NX + 1) / 2], co
         double S[NZ * NZ], K[NX * NZ];
         FK_UNROLL for (int r = 0; r < NZ; ++r) FK_OPAQUE(Hx[r]);
         {
-            const auto mv = fresh();
-            const double *sWc = mv.Wc;
             FK_UNROLL for (int i = 0; i < 2 * NX + 1; ++i) {
+                const double wc = fresh(i ? S[NZ * NZ - 1] : zp[NZ - 1]).Wc[i];
                 double d[NZ], wd[NZ];
                 FK_UNROLL for (int r = 0; r < NZ; ++r) {
                     const double v = (i == 0) ? Hx[r] : (i <= NX) ? Hx[r] + HL[r][(i - 1) % NX] : Hx[r] - HL[r][(i - 1) % NX];
                     d[r] = v - zp[r];
                 }
-                FK_UNROLL for (int r = 0; r < NZ; ++r) wd[r] = sWc[i] * d[r];
+                FK_UNROLL for (int r = 0; r < NZ; ++r) wd[r] = wc * d[r];
                 FK_UNROLL for (int r = 0; r < NZ; ++r)
                     FK_UNROLL for (int c = 0; c < NZ; ++c)
                         S[r * NZ + c] = (i == 0) ? d[r] * wd[c] : fma(d[r], wd[c], S[r * NZ + c]);
@@ -439,6 +250,9 @@ FK_HD int ukf_linear_step_v3(double (&x)[NX], double (&P)[NX * (NX + 1) / 2], co
                 }
                 FK_STAGE();
             }
+            FK_UNROLL for (int e = 0; e < NZ * NZ; ++e) FK_OPAQUE(S[e]);
+            FK_UNROLL for (int e = 0; e < NX * NZ; ++e) FK_OPAQUE(K[e]);
+            const auto mv = fresh(S[NZ * NZ - 1]);
             FK_UNROLL for (int r = 0; r < NZ; ++r) {
                 double rr[NZ];
                 mv.sm.rowR(r, rr);
@@ -482,124 +296,22 @@ FK_HD int ukf_linear_step_v3(double (&x)[NX], double (&P)[NX * (NX + 1) / 2], co
 //   xs[k] += K (xs[k+1] - xb) ; ps[k] += K (ps[k+1] - Pb) K'
 // x / P (packed upper triangle): the filter output of step k in (xs[k] = Xs[k] until this step touches it), the
 // smoothed step k out; xn / Pn: the smoothed step k+1.  K: full n x n gain out.  The sums run over the sigma points
-// in the reference's index order, the sigma points and their images are regenerated point by point exactly like
-// ukf_linear_step_v2's sweeps.  inv(Pb) is applied by an L D L' solve (like every other gain here).
+// in the reference's index order.  inv(Pb) is applied by an L D L' solve (like every other gain here).
 // Two halves, so that the caller may keep xn / Pn out of the registers during the first:
-//   ukf_linear_rts_gain    (x, P) -> xb, Pb (packed), K            (the two sweeps and the solve)
+//   ukf_linear_rts_gain_v3 (x, P) -> xb, Pb (packed), K            (the two sweeps and the solve)
 //   ukf_linear_rts_correct x, P updated in place from xn, Pn, xb, Pb, K   (Pb is destroyed)
-template <int NX, class Fresh, class Sweep = NoSweep>
-FK_HD int ukf_linear_rts_gain(double (&x)[NX], const double (&P)[NX * (NX + 1) / 2], double scale, double (&xb)[NX],
-                              double (&Pb)[NX * (NX + 1) / 2], double (&K)[NX * NX], Fresh &&fresh,
-                              Sweep &&sweep = Sweep{})
-{
-    constexpr int KS = 2 * NX + 1;
-    constexpr int PL = NX * (NX + 1) / 2;
-    int st = 0;
-    double L[PL];
-    if (!chol_packed<NX>(P, scale, L)) st |= ST_NOT_PD;
-    // sweep 1: xb = sum_i Wm_i F sigma_i
-    sweep();
-    FK_UNROLL for (int i = 0; i < KS; ++i) {
-        const auto mv = fresh();
-        const auto &sm = mv.sm;
-        const double *sWm = mv.Wm;
-        FK_UNROLL for (int r = 0; r < NX; ++r) {
-            double f[NX];
-            sm.rowF(r, f);
-            double v;
-            if (i == 0) {
-                v = dot<NX>(f, x);
-            } else if (i <= NX) {
-                v = f[0] * (x[0] - (-lcol<NX>(L, 0, i - 1)));
-                FK_UNROLL for (int c = 1; c < NX; ++c) v = fma(f[c], x[c] - (-lcol<NX>(L, c, i - 1)), v);
-            } else {
-                v = f[0] * (x[0] - lcol<NX>(L, 0, i - 1 - NX));
-                FK_UNROLL for (int c = 1; c < NX; ++c) v = fma(f[c], x[c] - lcol<NX>(L, c, i - 1 - NX), v);
-            }
-            xb[r] = (i == 0) ? sWm[0] * v : fma(sWm[i], v, xb[r]);
-        }
-        FK_STAGE();
-    }
-    // sweep 2: Pb = sum Wc_i y_i y_i' (+ Q), Pxb = sum Wc_i z_i y_i', y_i = F sigma_i - xb, z_i = sigma_i - x
-    FK_UNROLL for (int c = 0; c < NX; ++c) FK_OPAQUE(x[c]);
-    FK_UNROLL for (int e = 0; e < PL; ++e) FK_OPAQUE(L[e]);
-    sweep();
-    FK_UNROLL for (int i = 0; i < KS; ++i) {
-        const auto mv = fresh();
-        const auto &sm = mv.sm;
-        const double *sWc = mv.Wc;
-        double y[NX], wy[NX];
-        FK_UNROLL for (int r = 0; r < NX; ++r) {
-            double f[NX];
-            sm.rowF(r, f);
-            double v;
-            if (i == 0) {
-                v = dot<NX>(f, x);
-            } else if (i <= NX) {
-                v = f[0] * (x[0] - (-lcol<NX>(L, 0, i - 1)));
-                FK_UNROLL for (int c = 1; c < NX; ++c) v = fma(f[c], x[c] - (-lcol<NX>(L, c, i - 1)), v);
-            } else {
-                v = f[0] * (x[0] - lcol<NX>(L, 0, i - 1 - NX));
-                FK_UNROLL for (int c = 1; c < NX; ++c) v = fma(f[c], x[c] - lcol<NX>(L, c, i - 1 - NX), v);
-            }
-            y[r] = v - xb[r];
-        }
-        FK_UNROLL for (int r = 0; r < NX; ++r) wy[r] = sWc[i] * y[r];
-        FK_UNROLL for (int a2 = 0; a2 < NX; ++a2)
-            FK_UNROLL for (int b = 0; b < NX; ++b)
-                if (b >= a2)
-                    Pb[sym_idx<NX>(a2, b)] = (i == 0) ? y[a2] * wy[b] : fma(y[a2], wy[b], Pb[sym_idx<NX>(a2, b)]);
-        FK_UNROLL for (int r = 0; r < NX; ++r) {
-            double z;
-            if (i == 0) z = x[r] - x[r];
-            else if (i <= NX) z = (x[r] - (-lcol<NX>(L, r, i - 1))) - x[r];
-            else z = (x[r] - lcol<NX>(L, r, i - 1 - NX)) - x[r];
-            FK_UNROLL for (int c = 0; c < NX; ++c) {
-                const double term = sWc[i] * (z * y[c]);
-                K[r * NX + c] = (i == 0) ? term : K[r * NX + c] + term;
-            }
-        }
-        FK_STAGE();
-    }
-    {
-        const auto mv = fresh();
-        FK_UNROLL for (int r = 0; r < NX; ++r) {
-            double q[NX];
-            mv.sm.rowQ(r, q);
-            FK_UNROLL for (int b = 0; b < NX; ++b)
-                if (b >= r) Pb[sym_idx<NX>(r, b)] += q[b];
-        }
-    }
-    // K = Pxb inv(Pb)
-    {
-        double Lp[PL], d[NX], dinv[NX];
-        FK_UNROLL for (int e = 0; e < PL; ++e) Lp[e] = Pb[e];
-        if (!ldlt_packed<NX>(Lp, d, dinv)) st |= ST_NOT_PD;
-        FK_UNROLL for (int r = 0; r < NX; ++r) {
-            double row[NX];
-            FK_UNROLL for (int c = 0; c < NX; ++c) row[c] = K[r * NX + c];
-            solve_row_packed<NX>(Lp, dinv, row);
-            FK_UNROLL for (int c = 0; c < NX; ++c) K[r * NX + c] = row[c];
-        }
-    }
-    FK_STAGE();
-    return st;
-}
-
-// The factor-image organisation (see ukf_linear_step_v3) of ukf_linear_rts_gain: one pass over the rows of F gives F x and
+// The gain in the factor-image organisation (see ukf_linear_step_v3): one pass over the rows of F gives F x and
 // F L, every point's image is one add per component in each sweep, and the offsets sigma_i - x = +-l_k of the cross
 // variance come from the factor (zero above the diagonal: those terms are skipped).
-template <int NX, class Fresh, class Sweep = NoSweep>
+template <int NX, class Fresh>
 FK_HD int ukf_linear_rts_gain_v3(double (&x)[NX], const double (&P)[NX * (NX + 1) / 2], double scale, double (&xb)[NX],
-                                 double (&Pb)[NX * (NX + 1) / 2], double (&K)[NX * NX], Fresh &&fresh,
-                                 Sweep &&sweep = Sweep{})
+                                 double (&Pb)[NX * (NX + 1) / 2], double (&K)[NX * NX], Fresh &&fresh)
 {
     constexpr int PL = NX * (NX + 1) / 2;
     int st = 0;
     double L[PL];
     if (!chol_packed_rs<NX>(P, scale, L)) st |= ST_NOT_PD;
     double Fx[NX], FL[NX][NX];
-    sweep();
     {
         const auto mv = fresh();
         FK_UNROLL for (int r = 0; r < NX; ++r) {
@@ -629,15 +341,14 @@ FK_HD int ukf_linear_rts_gain_v3(double (&x)[NX], const double (&P)[NX * (NX + 1
     // sweep 2: Pb = sum Wc_i y_i y_i' (+ Q), Pxb = sum Wc_i (sigma_i - x) y_i', y_i = sf_i - xb
     FK_UNROLL for (int r = 0; r < NX; ++r) FK_OPAQUE(Fx[r]);
     {
-        const auto mv = fresh();
-        const double *sWc = mv.Wc;
         FK_UNROLL for (int i = 0; i < 2 * NX + 1; ++i) {
+            const double wc = fresh(i ? Pb[PL - 1] : xb[NX - 1]).Wc[i];   // a fresh view per point, behind the previous point
             double y[NX], wy[NX];
             FK_UNROLL for (int r = 0; r < NX; ++r) {
                 const double v = (i == 0) ? Fx[r] : (i <= NX) ? Fx[r] + FL[r][(i - 1) % NX] : Fx[r] - FL[r][(i - 1) % NX];
                 y[r] = v - xb[r];
             }
-            FK_UNROLL for (int r = 0; r < NX; ++r) wy[r] = sWc[i] * y[r];
+            FK_UNROLL for (int r = 0; r < NX; ++r) wy[r] = wc * y[r];
             FK_UNROLL for (int a2 = 0; a2 < NX; ++a2)
                 FK_UNROLL for (int b = 0; b < NX; ++b)
                     if (b >= a2)
@@ -654,6 +365,8 @@ FK_HD int ukf_linear_rts_gain_v3(double (&x)[NX], const double (&P)[NX * (NX + 1
             }
             FK_STAGE();
         }
+        FK_UNROLL for (int e = 0; e < PL; ++e) FK_OPAQUE(Pb[e]);
+        const auto mv = fresh(Pb[PL - 1]);
         FK_UNROLL for (int r = 0; r < NX; ++r) {
             double q[NX];
             mv.sm.rowQ(r, q);

@@ -3,10 +3,18 @@
 //   fk_ukf_linear_batch_f64 <- UnscentedKalmanFilter.batch_filter (filterpy/kalman/UKF.py:524-632) with
 //                              fx(x, dt) = F x, hx(x) = H x: the whole predict (UKF.py:400-411) / update
 //                              (:462-481) loop stays in registers over the time steps.
-// (Split from ut_kernels.hip so the two translation units compile in parallel.)
+//   fk_ukf_linear_rts_f64   <- UnscentedKalmanFilter.rts_smoother (UKF.py:634-739), likewise.
+// FK_UKF_PART: the Makefile compiles this file four times (parallel build) -- 1: forward kernels dim_x <= 6 + the forward
+// entry point, 2: forward dim_x 7..9, 3: smoother dim_x <= 6 + the smoother's entry point, 4: smoother dim_x 7..9.
 #include <stdlib.h>
 
-#include <type_traits>
+#ifndef FK_UKF_PART
+#define FK_UKF_PART 0
+#endif
+#define FK_UKF_HAS(p) (FK_UKF_PART == 0 || FK_UKF_PART == (p))
+// (parts 91 / 92: the forward / smoother kernel templates alone, for one-off instantiations by the tools)
+#define FK_UKF_FWD (FK_UKF_HAS(1) || FK_UKF_HAS(2) || FK_UKF_PART == 91)
+#define FK_UKF_RTS (FK_UKF_HAS(3) || FK_UKF_HAS(4) || FK_UKF_PART == 92)
 
 #include "../../include/filterhip.h"
 #include "fk_chunks.hpp"
@@ -17,6 +25,16 @@
 
 namespace fk {
 
+struct UkfRtsArgs {
+    const double *Xs, *Ps;
+    double *xs, *ps, *Ks;
+    int32_t *status;
+    long N, T;
+    int n;
+    double scale;
+};
+
+#if FK_UKF_FWD
 // --------------------------------------------------- fused linear-model UKF --
 // Per step (UKF.py:400-411, 462-481) with fx(x) = F x, hx(x) = H x:
 //   L  = chol(scale P);  sigma_i = x, x +- L[:,k]          (sigma_points.py:167-175)
@@ -24,39 +42,29 @@ namespace fk {
 //   L  = chol(scale P);  sf_i = sigma_i(x,P)  (regenerated, UKF.py:407)
 //   sh_i = H sf_i ; (zp,S) = UT(sh, Wm, Wc, R) ; Pxz = sum Wc_i (sf_i-x)(sh_i-zp)'
 //   K = Pxz S^-1 ; x += K (z-zp) ; P -= K (S K')
-// The covariance and both Cholesky factors are packed triangles, and the propagated sigma points are
-// never all materialised: the predict makes two sweeps over the 2n+1 points (mean, then covariance),
-// regenerating each point x +- L[:,k] and pushing it through F on the fly -- ~70 live doubles at
-// n = 6 instead of ~260 (the first version spilled 196 registers at one wave per SIMD).
-// Two organisations of the kernel.  ukf_linear_kernel is the straightforward one; ukf_linear_kernel_v2 is the same
-// arithmetic -- every sum accumulates over the sigma points in the same index order -- reorganised for registers
-// (step arithmetic in fk_ukf.hpp, held against the oracle on the host; on the GPU it agrees with the first to 2e-13
-// and with the oracle to 1e-13, profiles/r02/exp_ukf2.log):
-//   * the mean sweeps run point by point like the covariance sweeps (row by row, the compiler kept all
-//     (2n+1) n sigma-point values alive across the rows);
-//   * the measurement update is two sweeps (zp, then S and Pxz) instead of holding all H sigma_i;
-//   * every unrolled point re-reads its model rows through an LDS offset the optimiser cannot see through
-//     (otherwise the broadcast reads of all points are hoisted and held);
-//   => (6,3): 223 (SOA) / 256 (AOS) VGPRs, no scratch, two waves per SIMD, against 512 VGPRs + 44 spilled
-//      registers at one wave per SIMD.
-//   * SCALAR_FH (exact dims only): the rows of F and H do not come from LDS at all but from the kernel's uniform
-//     pointers through the scalar cache into SGPRs, fetched once per pass over the sigma points and used as the
-//     scalar operand of the FMAs.  A broadcast ds_read still delivers 64 x 16 bytes through the CU's one 128 B/clk
-//     LDS port: 716 ds_read2_b64 per step and wave x 8 waves per CU was 46k LDS clocks per step against 30k VALU
-//     clocks per SIMD -- the kernel was LDS-bound, not VALU-bound.
-template <int NX, int NZ>
-struct ScalarFHModel {
-    const double *s;          // LDS model: Q, R (read once per step)
-    const double *gF, *gH;    // uniform global pointers
-    __device__ __forceinline__ void rowF(int i, double (&r)[NX]) const { FK_UNROLL for (int j = 0; j < NX; ++j) r[j] = gF[i * NX + j]; }
-    __device__ __forceinline__ void rowH(int i, double (&r)[NX]) const { FK_UNROLL for (int j = 0; j < NX; ++j) r[j] = gH[i * NX + j]; }
-    __device__ __forceinline__ void rowQ(int i, double (&r)[NX]) const { LdsModel<NX, NZ>{s}.rowQ(i, r); }
-    __device__ __forceinline__ void rowR(int i, double (&r)[NZ]) const { LdsModel<NX, NZ>{s}.rowR(i, r); }
-};
-
-template <int NX, int NZ, int LAYOUT, bool SCALAR_FH, int VER = 3>
+// The arithmetic of a step is ukf_linear_step_v3 (fk_ukf.hpp, held against the oracle on the host by
+// tests/test_hostcheck_ukf.py): packed triangles, the images of the sigma points formed from the image of the factor.
+// Round 2's point-by-point step and the scalar-operand model are gone (A/B of the last lease that had them:
+// profiles/r03/ukf_v3_ab.jsonl -- (6,3) 1.92 -> 1.27 ms SOA, 2.45 -> 1.33 ms NumPy order).
+//
+// The kernel around it, round 3 (the same rules as kf_fast / kf_ml):
+//   * EXACT instantiations (n == NX, m == NZ) have no run-time element guards, so a step's stores are straight-line
+//     code and the compiler can COUNT them in its s_waitcnt; the padded instantiations serve every smaller size.
+//   * z[t] is requested at the HEAD OF THE UPDATE HALF of step t (behind the predict half: no registers are held across
+//     it) and consumed at its end; the mask byte of step t+1 is requested at the top of step t (clamped index, no
+//     branch) and landed at the end of its arithmetic, in front of step t's stores.  vmcnt retires in order,
+//     so waiting for a load also waits for every store issued before it -- here the stores of step t-1, which have had
+//     a predict half to drain.  Before, the loop header was `load z; s_waitcnt vmcnt(0)`: every step paid an HBM round
+//     trip plus the drain of its predecessor's 42 stores with nothing to overlap.
+//   * the prologue loads (x0, P0, z[0]) are landed before the loop: left pending, the loop header's wait (which must
+//     cover the path from the prologue too) is a vmcnt(0) in every iteration.
+//   * no store in the loop is predicated: the lanes past the bank's last track duplicate the block's last track
+//     (same values to the same addresses); the wave-cooperative NumPy-order stores drop rows past the last track by
+//     the descriptor's range check.  The in-place store of the final state IS predicated and sits behind a workgroup
+//     barrier (a duplicate must have consumed x0 / P0 before its owner overwrites them).
+template <int NX, int NZ, int LAYOUT, bool EXACT>
 __global__ void __launch_bounds__(BLOCK, (NX <= 2 ? 4 : NX <= 6 ? 2 : 1))
-ukf_linear_kernel_v2(const UkfArgs a, const double *__restrict__ pF, const double *__restrict__ pH,
+ukf_linear_kernel(const UkfArgs a, const double *__restrict__ pF, const double *__restrict__ pH,
                   const double *__restrict__ pQ, const double *__restrict__ pR,
                   const double *__restrict__ pWm, const double *__restrict__ pWc,
                   const double *__restrict__ pz, const uint8_t *__restrict__ pmask)
@@ -66,24 +74,21 @@ ukf_linear_kernel_v2(const UkfArgs a, const double *__restrict__ pF, const doubl
     using SharedModel = LdsModel<NX, NZ>;
     __shared__ double s_model[SharedModel::SIZE + 2 * KS];
     // NumPy order at the exact dims: the per-step outputs leave through a wave-private LDS tile, 1 KiB contiguous per store
-    // instruction (wave_store_aos, fk_device.hpp) -- a lane-per-record store touches 64 lines per instruction, and at V3's
-    // instruction count the 42 stores of a (6,3) step would make the address path, not the VALU, the bound.  (dim_x 9: the
-    // tile of an 81-double record does not fit next to four waves.)
-    constexpr bool COOP = LAYOUT == LAYOUT_AOS && NX <= 8 && NX % 2 == 0 && VER == 3;
-    constexpr int TILE = 64 * NX * NX;                       // flat: wave_store_aos_flat
+    // instruction (wave_store_aos_flat, fk_device.hpp) -- a lane-per-record store touches 64 lines per instruction.
+    // (dim_x 9: the tile of an 81-double record does not fit next to four waves.)
+    constexpr bool COOP = EXACT && LAYOUT == LAYOUT_AOS && NX <= 8 && NX % 2 == 0;
+    constexpr int TILE = 64 * NX * NX;
     __shared__ double s_tile[COOP ? (BLOCK / 64) * TILE : 1];
     const long N = a.N;
     const long blk0 = a.i0 + (long)blockIdx.x * BLOCK;
-    const Lane ln{blk0, threadIdx.x, N};
-    const bool live = blk0 + ln.tid < a.i0 + a.cnt;
-    const Lane lr{blk0, live ? ln.tid : 0u, N};
-    const int n = a.n, m = a.m;
-    const int ks = 2 * n + 1;
-    const bool coop = COOP && n == NX;
-    double *tile = s_tile + (COOP ? (threadIdx.x >> 6) * TILE : 0);
-    const unsigned lane = threadIdx.x & 63u, wave_row0 = (threadIdx.x >> 6) * 64u;
     const long left = a.i0 + a.cnt - blk0;
     const unsigned last_row = (unsigned)(left < BLOCK ? left : BLOCK) - 1u;
+    const bool live = threadIdx.x <= last_row;
+    const Lane ln{blk0, live ? threadIdx.x : last_row, N};      // lanes past the last track duplicate it
+    const int n = EXACT ? NX : a.n, m = EXACT ? NZ : a.m;
+    const int ks = 2 * n + 1;
+    double *tile = s_tile + (COOP ? (threadIdx.x >> 6) * TILE : 0);
+    const unsigned lane = threadIdx.x & 63u, wave_row0 = (threadIdx.x >> 6) * 64u;
 
     lds_fill<NX, NX>(s_model + SharedModel::OFF_F, pF, n, n, 1.0, threadIdx.x);
     lds_fill<NX, NX>(s_model + SharedModel::OFF_Q, pQ, n, n, 1.0, threadIdx.x);   // padded block of P stays I
@@ -91,7 +96,7 @@ ukf_linear_kernel_v2(const UkfArgs a, const double *__restrict__ pF, const doubl
     lds_fill<NZ, NZ>(s_model + SharedModel::OFF_R, pR, m, m, 1.0, threadIdx.x);
     // weights, re-indexed from the runtime point set (0, 1..n, n+1..2n) to the padded one
     // (0, 1..NX, NX+1..2NX); padded points get weight 0
-    for (unsigned q = ln.tid; q < (unsigned)(2 * KS); q += BLOCK) {
+    for (unsigned q = threadIdx.x; q < (unsigned)(2 * KS); q += BLOCK) {
         const int which = q / KS, i = q % KS;
         int src = -1;
         if (i == 0) src = 0;
@@ -104,293 +109,76 @@ ukf_linear_kernel_v2(const UkfArgs a, const double *__restrict__ pF, const doubl
     // a view of the LDS model the optimiser cannot relate to the previous one: keeps it from hoisting the
     // broadcast row reads of all 2n+1 unrolled points to the top (they are cheap to repeat, dear to hold)
     // (an offset is made opaque, not the pointer: that keeps the LDS address space)
-    using StepModel = std::conditional_t<SCALAR_FH, ScalarFHModel<NX, NZ>, SharedModel>;
-    struct View { StepModel sm; const double *Wm, *Wc; };
-    int goff = 0;                                           // wave-uniform, re-made opaque at the head of every pass
-    auto sweep = [&]() {
-        if constexpr (SCALAR_FH) {
-            int t;
-            asm volatile("s_mov_b32 %0, 0" : "=s"(t));
-            goff = t;
-        }
-    };
-    auto fresh = [&]() {
+    struct View { SharedModel sm; const double *Wm, *Wc; };
+    auto fresh = [&](double after = 0.0) {
         int off = 0;
-        asm volatile("" : "+v"(off));
+        asm volatile("" : "+v"(off) : "v"(after));
         const double *mb = s_model + off;
-        if constexpr (SCALAR_FH) return View{StepModel{mb, pF + goff, pH + goff}, mb + SharedModel::SIZE, mb + SharedModel::SIZE + KS};
-        else return View{StepModel{mb}, mb + SharedModel::SIZE, mb + SharedModel::SIZE + KS};
+        return View{SharedModel{mb}, mb + SharedModel::SIZE, mb + SharedModel::SIZE + KS};
     };
 
     double x[NX], P[PL];
-    load_rec<NX, 1, LAYOUT, false>(x, a.x, lr, n, 1, 0.0);
+    load_rec<NX, 1, LAYOUT, EXACT>(x, a.x, ln, n, 1, 0.0);
     {
-        const RecView<LAYOUT> pv(a.P, lr, n * n);
+        const RecView<LAYOUT> pv(a.P, ln, n * n);
         FK_UNROLL for (int i = 0; i < NX; ++i)
             FK_UNROLL for (int j = 0; j < NX; ++j)
-                if (j >= i) P[sym_idx<NX>(i, j)] = (i < n && j < n) ? pv.load(i * n + j) : (i == j ? 1.0 : 0.0);
+                if (j >= i) P[sym_idx<NX>(i, j)] = (EXACT || (i < n && j < n)) ? pv.load(i * n + j) : (i == j ? 1.0 : 0.0);
     }
+    // without a mask the byte comes from a valid dummy address (the measurements) and is selected away: no branch.  Read
+    // through a descriptor (uniform base advanced per step + the lane's 32-bit offset): a per-lane 64-bit pointer that
+    // advances by N per step is a loop-carried VGPR pair the allocator spills, and its reload at the loop's end is a
+    // vmcnt(0) behind the step's stores.
+    const uint8_t *mk0 = (pmask ? pmask : reinterpret_cast<const uint8_t *>(pz)) + blk0;
+    unsigned hc = __builtin_amdgcn_raw_buffer_load_b8(make_rsrc(mk0), ln.tid, 0, 0);
+    // landed here (see above)
+    FK_UNROLL for (int c = 0; c < NX; ++c) asm volatile("" ::"v"(x[c]));
+    FK_UNROLL for (int e = 0; e < PL; ++e) asm volatile("" ::"v"(P[e]));
+    asm volatile("" ::"v"(hc));
     int st = 0;
 
-    for (long t = 0; t < a.T; ++t) {
-        double z[NZ];
-        bool has_z = true;
-        if (pmask) has_z = pmask[t * N + lr.blk0 + lr.tid] != 0;
-        load_rec<NZ, 1, LAYOUT, false>(z, pz + t * N * m, lr, m, 1, 0.0);
+    _Pragma("nounroll") for (long t = 0; t < a.T; ++t) {
+        const bool has_z = pmask ? hc != 0u : true;
+        // step t+1's mask byte: requested now, landed after this step's arithmetic IN FRONT of its stores (a wait placed
+        // behind them would be a vmcnt(0) that drains them: their number depends on which outputs were asked for)
+        unsigned hn;
+        {
+            long tn = t + 1 < a.T ? t + 1 : t;
+            asm volatile("" : "+s"(tn));      // opaque: keeps the compiler from re-deriving this load one iteration later
+            hn = __builtin_amdgcn_raw_buffer_load_b8(make_rsrc(mk0 + tn * N), ln.tid, 0, 0);
+        }
+        auto load_z = [&](double (&z)[NZ]) { load_rec<NZ, 1, LAYOUT, EXACT>(z, pz + t * N * m, ln, m, 1, 0.0); };
 
-        if constexpr (VER == 3) st |= ukf_linear_step_v3<NX, NZ>(x, P, z, has_z, a.scale, fresh, sweep);
-        else st |= ukf_linear_step_v2<NX, NZ>(x, P, z, has_z, a.scale, fresh, sweep);
-        if (COOP && coop) {
-            if constexpr (COOP) {
-                if (a.means) wave_store_aos_flat<NX>(x, a.means + t * N * NX + blk0 * NX, wave_row0, tile, lane, last_row);
-                if (a.covs) {
-                    double Pf[NX * NX];
-                    FK_UNROLL for (int i = 0; i < NX; ++i)
-                        FK_UNROLL for (int j = 0; j < NX; ++j) Pf[i * NX + j] = P[sym_idx<NX>(i, j)];
-                    wave_store_aos_flat<NX * NX>(Pf, a.covs + t * N * (NX * NX) + blk0 * (NX * NX), wave_row0, tile, lane, last_row);
-                }
-            }
-        } else if (live) {
-            if (a.means) store_rec<NX, 1, LAYOUT, false>(x, a.means + t * N * n, ln, n, 1);
+        st |= ukf_linear_step_v3<NX, NZ>(x, P, load_z, has_z, a.scale, fresh);
+        FK_STAGE();
+        asm volatile("" : "+v"(hn));
+        hc = hn;
+        FK_STAGE();
+        if constexpr (COOP) {
+            if (a.means) wave_store_aos_flat<NX>(x, a.means + t * N * NX + blk0 * NX, wave_row0, tile, lane, last_row);
             if (a.covs) {
                 double Pf[NX * NX];
                 FK_UNROLL for (int i = 0; i < NX; ++i)
                     FK_UNROLL for (int j = 0; j < NX; ++j) Pf[i * NX + j] = P[sym_idx<NX>(i, j)];
-                store_rec<NX, NX, LAYOUT, false>(Pf, a.covs + t * N * n * n, ln, n, n);
+                wave_store_aos_flat<NX * NX>(Pf, a.covs + t * N * (NX * NX) + blk0 * (NX * NX), wave_row0, tile, lane, last_row);
+            }
+        } else {
+            if (a.means) store_rec<NX, 1, LAYOUT, EXACT>(x, a.means + t * N * n, ln, n, 1);
+            if (a.covs) {
+                double Pf[NX * NX];
+                FK_UNROLL for (int i = 0; i < NX; ++i)
+                    FK_UNROLL for (int j = 0; j < NX; ++j) Pf[i * NX + j] = P[sym_idx<NX>(i, j)];
+                store_rec<NX, NX, LAYOUT, EXACT>(Pf, a.covs + t * N * n * n, ln, n, n);
             }
         }
-    }
-    if (live) {
-        store_rec<NX, 1, LAYOUT, false>(x, a.x, ln, n, 1);
-        double Pf[NX * NX];
-        FK_UNROLL for (int i = 0; i < NX; ++i)
-            FK_UNROLL for (int j = 0; j < NX; ++j) Pf[i * NX + j] = P[sym_idx<NX>(i, j)];
-        store_rec<NX, NX, LAYOUT, false>(Pf, a.P, ln, n, n);
-        if (a.status) {
-            if (!all_finite<NX>(x) || !all_finite<PL>(P)) st |= ST_NONFINITE;
-            a.status[ln.blk0 + ln.tid] = a.status_or ? (a.status[ln.blk0 + ln.tid] | st) : st;
-        }
-    }
-}
-template <int NX, int NZ, int LAYOUT>
-__global__ void __launch_bounds__(BLOCK, (NX <= 2 ? 4 : NX <= 4 ? 2 : 1))
-ukf_linear_kernel(const UkfArgs a, const double *__restrict__ pF, const double *__restrict__ pH,
-                  const double *__restrict__ pQ, const double *__restrict__ pR,
-                  const double *__restrict__ pWm, const double *__restrict__ pWc,
-                  const double *__restrict__ pz, const uint8_t *__restrict__ pmask)
-{
-    constexpr int KS = 2 * NX + 1;
-    constexpr int PL = NX * (NX + 1) / 2;
-    using SharedModel = LdsModel<NX, NZ>;
-    __shared__ double s_model[SharedModel::SIZE + 2 * KS];
-    const long N = a.N;
-    const long blk0 = a.i0 + (long)blockIdx.x * BLOCK;
-    const Lane ln{blk0, threadIdx.x, N};
-    const bool live = blk0 + ln.tid < a.i0 + a.cnt;
-    const Lane lr{blk0, live ? ln.tid : 0u, N};
-    const int n = a.n, m = a.m;
-    const int ks = 2 * n + 1;
-
-    lds_fill<NX, NX>(s_model + SharedModel::OFF_F, pF, n, n, 1.0, threadIdx.x);
-    lds_fill<NX, NX>(s_model + SharedModel::OFF_Q, pQ, n, n, 1.0, threadIdx.x);   // padded block of P stays I
-    lds_fill<NZ, NX>(s_model + SharedModel::OFF_H, pH, m, n, 0.0, threadIdx.x);
-    lds_fill<NZ, NZ>(s_model + SharedModel::OFF_R, pR, m, m, 1.0, threadIdx.x);
-    // weights, re-indexed from the runtime point set (0, 1..n, n+1..2n) to the padded one
-    // (0, 1..NX, NX+1..2NX); padded points get weight 0
-    for (unsigned q = ln.tid; q < (unsigned)(2 * KS); q += BLOCK) {
-        const int which = q / KS, i = q % KS;
-        int src = -1;
-        if (i == 0) src = 0;
-        else if (i <= NX) { if (i <= n) src = i; }
-        else { if (i - NX <= n) src = n + (i - NX); }
-        const double *W = which ? pWc : pWm;
-        s_model[SharedModel::SIZE + q] = (src >= 0 && src < ks) ? W[src] : 0.0;
     }
     __syncthreads();
-    const SharedModel sm{s_model};
-    const double *sWm = s_model + SharedModel::SIZE, *sWc = sWm + KS;
-
-    double x[NX], P[PL];
-    load_rec<NX, 1, LAYOUT, false>(x, a.x, lr, n, 1, 0.0);
-    {
-        const RecView<LAYOUT> pv(a.P, lr, n * n);
-        FK_UNROLL for (int i = 0; i < NX; ++i)
-            FK_UNROLL for (int j = 0; j < NX; ++j)
-                if (j >= i) P[sym_idx<NX>(i, j)] = (i < n && j < n) ? pv.load(i * n + j) : (i == j ? 1.0 : 0.0);
-    }
-    int st = 0;
-
-    for (long t = 0; t < a.T; ++t) {
-        double z[NZ];
-        bool has_z = true;
-        if (pmask) has_z = pmask[t * N + lr.blk0 + lr.tid] != 0;
-        load_rec<NZ, 1, LAYOUT, false>(z, pz + t * N * m, lr, m, 1, 0.0);
-
-        // ---------------- predict (UKF.py:400-411)
-        double L[PL];
-        if (!chol_packed<NX>(P, a.scale, L)) st |= ST_NOT_PD;
-        // sweep 1: x- = sum_i Wm_i F sigma_i, one output component (row of F) at a time, points in
-        // index order 0, x + L[:,k] (k = 0..n-1), x - L[:,k]
-        double xm[NX];
-        FK_UNROLL for (int r = 0; r < NX; ++r) {
-            double f[NX];
-            sm.rowF(r, f);
-            double acc = sWm[0] * dot<NX>(f, x);
-            FK_UNROLL for (int k = 0; k < NX; ++k) {
-                double v = f[0] * (x[0] - (-lcol<NX>(L, 0, k)));
-                FK_UNROLL for (int c = 1; c < NX; ++c) v = fma(f[c], x[c] - (-lcol<NX>(L, c, k)), v);
-                acc = fma(sWm[1 + k], v, acc);
-            }
-            FK_UNROLL for (int k = 0; k < NX; ++k) {
-                double v = f[0] * (x[0] - lcol<NX>(L, 0, k));
-                FK_UNROLL for (int c = 1; c < NX; ++c) v = fma(f[c], x[c] - lcol<NX>(L, c, k), v);
-                acc = fma(sWm[1 + NX + k], v, acc);
-            }
-            xm[r] = acc;
-            FK_STAGE();
-        }
-        // sweep 2: P- = sum_i Wc_i y_i y_i' + Q, y_i = F sigma_i - x-   (upper triangle).
-        // The points are recomputed from copies the optimiser cannot relate to sweep 1 (otherwise it
-        // common-subexpression-eliminates the recomputation by keeping all (2n+1) n values alive).
-        double Pn[PL];
-        FK_UNROLL for (int c = 0; c < NX; ++c) asm volatile("" : "+v"(x[c]));
-        FK_UNROLL for (int e = 0; e < PL; ++e) asm volatile("" : "+v"(L[e]));
-        FK_UNROLL for (int i = 0; i < KS; ++i) {
-            double y[NX], wy[NX];
-            FK_UNROLL for (int r = 0; r < NX; ++r) {
-                double f[NX];
-                sm.rowF(r, f);
-                double v;
-                if (i == 0) {
-                    v = dot<NX>(f, x);
-                } else if (i <= NX) {
-                    v = f[0] * (x[0] - (-lcol<NX>(L, 0, i - 1)));
-                    FK_UNROLL for (int c = 1; c < NX; ++c) v = fma(f[c], x[c] - (-lcol<NX>(L, c, i - 1)), v);
-                } else {
-                    v = f[0] * (x[0] - lcol<NX>(L, 0, i - 1 - NX));
-                    FK_UNROLL for (int c = 1; c < NX; ++c) v = fma(f[c], x[c] - lcol<NX>(L, c, i - 1 - NX), v);
-                }
-                y[r] = v - xm[r];
-            }
-            FK_UNROLL for (int r = 0; r < NX; ++r) wy[r] = sWc[i] * y[r];
-            FK_UNROLL for (int a2 = 0; a2 < NX; ++a2)
-                FK_UNROLL for (int b = 0; b < NX; ++b)
-                    if (b >= a2)
-                        Pn[sym_idx<NX>(a2, b)] = (i == 0) ? y[a2] * wy[b] : fma(y[a2], wy[b], Pn[sym_idx<NX>(a2, b)]);
-            FK_STAGE();
-        }
-        FK_UNROLL for (int r = 0; r < NX; ++r) {
-            double q[NX];
-            sm.rowQ(r, q);
-            FK_UNROLL for (int b = 0; b < NX; ++b)
-                if (b >= r) P[sym_idx<NX>(r, b)] = Pn[sym_idx<NX>(r, b)] + q[b];
-            x[r] = xm[r];
-        }
-
-        // ---------------- update (UKF.py:462-481), sigma points regenerated from the prior (:407)
-        if (has_z) {
-            if (!chol_packed<NX>(P, a.scale, L)) st |= ST_NOT_PD;
-            double h0[NZ], hp[NZ * NX], hm[NZ * NX];
-            FK_UNROLL for (int r = 0; r < NZ; ++r) {
-                double h[NX];
-                sm.rowH(r, h);
-                h0[r] = dot<NX>(h, x);
-                FK_UNROLL for (int k = 0; k < NX; ++k) {
-                    double vp = h[0] * (x[0] - (-lcol<NX>(L, 0, k))), vm = h[0] * (x[0] - lcol<NX>(L, 0, k));
-                    FK_UNROLL for (int c = 1; c < NX; ++c) {
-                        vp = fma(h[c], x[c] - (-lcol<NX>(L, c, k)), vp);
-                        vm = fma(h[c], x[c] - lcol<NX>(L, c, k), vm);
-                    }
-                    hp[r * NX + k] = vp;
-                    hm[r * NX + k] = vm;
-                }
-                FK_STAGE();
-            }
-            double zp[NZ];
-            FK_UNROLL for (int r = 0; r < NZ; ++r) {
-                double acc = sWm[0] * h0[r];
-                FK_UNROLL for (int k = 0; k < NX; ++k) acc = fma(sWm[1 + k], hp[r * NX + k], acc);
-                FK_UNROLL for (int k = 0; k < NX; ++k) acc = fma(sWm[1 + NX + k], hm[r * NX + k], acc);
-                zp[r] = acc;
-            }
-            FK_UNROLL for (int r = 0; r < NZ; ++r) {
-                h0[r] -= zp[r];
-                FK_UNROLL for (int k = 0; k < NX; ++k) {
-                    hp[r * NX + k] -= zp[r];
-                    hm[r * NX + k] -= zp[r];
-                }
-            }
-            double S[NZ * NZ];
-            FK_UNROLL for (int r = 0; r < NZ; ++r) {
-                double rr[NZ];
-                sm.rowR(r, rr);
-                FK_UNROLL for (int c = 0; c < NZ; ++c) {
-                    double acc = h0[r] * (sWc[0] * h0[c]);
-                    FK_UNROLL for (int k = 0; k < NX; ++k) acc = fma(hp[r * NX + k], sWc[1 + k] * hp[c * NX + k], acc);
-                    FK_UNROLL for (int k = 0; k < NX; ++k) acc = fma(hm[r * NX + k], sWc[1 + NX + k] * hm[c * NX + k], acc);
-                    S[r * NZ + c] = acc + rr[c];
-                }
-            }
-            // Pxz = sum Wc_i (sf_i - x)(sh_i - zp)' ; sf_0 - x = 0, sf_{k+1} - x = (x + l_k) - x
-            double K[NX * NZ];
-            FK_UNROLL for (int r = 0; r < NX; ++r) {
-                FK_UNROLL for (int c = 0; c < NZ; ++c) {
-                    double acc = sWc[0] * (((x[r]) - x[r]) * h0[c]);
-                    FK_UNROLL for (int k = 0; k < NX; ++k) {
-                        const double dp = (x[r] - (-lcol<NX>(L, r, k))) - x[r];
-                        acc += sWc[1 + k] * (dp * hp[c * NX + k]);
-                    }
-                    FK_UNROLL for (int k = 0; k < NX; ++k) {
-                        const double dm = (x[r] - lcol<NX>(L, r, k)) - x[r];
-                        acc += sWc[1 + NX + k] * (dm * hm[c * NX + k]);
-                    }
-                    K[r * NZ + c] = acc;
-                }
-                FK_STAGE();
-            }
-            // K = Pxz S^-1
-            double Lf[NZ * NZ], d[NZ], dinv[NZ];
-            FK_UNROLL for (int e = 0; e < NZ * NZ; ++e) Lf[e] = S[e];
-            if (!ldlt2<NZ>(Lf, d, dinv)) st |= ST_NOT_PD;
-            solve_rows_ldlt<NX, NZ>(Lf, dinv, K);
-            // x += K (z - zp)
-            FK_UNROLL for (int r = 0; r < NX; ++r) {
-                double acc = K[r * NZ] * (z[0] - zp[0]);
-                FK_UNROLL for (int c = 1; c < NZ; ++c) acc = fma(K[r * NZ + c], z[c] - zp[c], acc);
-                x[r] += acc;
-            }
-            // P -= K (S K'), upper triangle
-            FK_UNROLL for (int c2 = 0; c2 < NX; ++c2) {
-                double sk[NZ];                 // column c2 of S K'
-                FK_UNROLL for (int q = 0; q < NZ; ++q) {
-                    double acc = S[q * NZ] * K[c2 * NZ];
-                    FK_UNROLL for (int w = 1; w < NZ; ++w) acc = fma(S[q * NZ + w], K[c2 * NZ + w], acc);
-                    sk[q] = acc;
-                }
-                FK_UNROLL for (int r = 0; r < NX; ++r)
-                    if (r <= c2) {
-                        double acc = K[r * NZ] * sk[0];
-                        FK_UNROLL for (int q = 1; q < NZ; ++q) acc = fma(K[r * NZ + q], sk[q], acc);
-                        P[sym_idx<NX>(r, c2)] -= acc;
-                    }
-            }
-        }
-        if (live) {
-            if (a.means) store_rec<NX, 1, LAYOUT, false>(x, a.means + t * N * n, ln, n, 1);
-            if (a.covs) {
-                double Pf[NX * NX];
-                FK_UNROLL for (int i = 0; i < NX; ++i)
-                    FK_UNROLL for (int j = 0; j < NX; ++j) Pf[i * NX + j] = P[sym_idx<NX>(i, j)];
-                store_rec<NX, NX, LAYOUT, false>(Pf, a.covs + t * N * n * n, ln, n, n);
-            }
-        }
-    }
     if (live) {
-        store_rec<NX, 1, LAYOUT, false>(x, a.x, ln, n, 1);
+        store_rec<NX, 1, LAYOUT, EXACT>(x, a.x, ln, n, 1);
         double Pf[NX * NX];
         FK_UNROLL for (int i = 0; i < NX; ++i)
             FK_UNROLL for (int j = 0; j < NX; ++j) Pf[i * NX + j] = P[sym_idx<NX>(i, j)];
-        store_rec<NX, NX, LAYOUT, false>(Pf, a.P, ln, n, n);
+        store_rec<NX, NX, LAYOUT, EXACT>(Pf, a.P, ln, n, n);
         if (a.status) {
             if (!all_finite<NX>(x) || !all_finite<PL>(P)) st |= ST_NONFINITE;
             a.status[ln.blk0 + ln.tid] = a.status_or ? (a.status[ln.blk0 + ln.tid] | st) : st;
@@ -398,41 +186,93 @@ ukf_linear_kernel(const UkfArgs a, const double *__restrict__ pF, const double *
     }
 }
 
+#endif
+
+// launchers of the instantiations this part holds (declared in every part)
+int ukf_fwd_launch_small(const UkfArgs &a, int layout, bool exact, hipStream_t s);    // classes (2,2), (4,2), (6,3)
+int ukf_fwd_launch_big(const UkfArgs &a, int layout, bool exact, hipStream_t s);      // classes (8,4), (9,3), (9,4)
+int ukf_rts_launch_small(const UkfRtsArgs &a, const double *F, const double *Q, const double *Wm, const double *Wc, int layout, bool exact, hipStream_t s);   // 2, 4, 6
+int ukf_rts_launch_big(const UkfRtsArgs &a, const double *F, const double *Q, const double *Wm, const double *Wc, int layout, bool exact, hipStream_t s);     // 8, 9
+
+#if FK_UKF_FWD
+#define FK_UKF_GO(NXV, NZV)                                                                                      \
+    do {                                                                                                         \
+        const dim3 grid((unsigned)((a.cnt + BLOCK - 1) / BLOCK)), block(BLOCK);                                  \
+        const bool ex = exact && a.n == NXV && a.m == NZV;                                                       \
+        if (layout == FK_LAYOUT_SOA) {                                                                           \
+            if (ex) hipLaunchKernelGGL((ukf_linear_kernel<NXV, NZV, LAYOUT_SOA, true>), grid, block, 0, s, a, a.F, a.H, a.Q, a.R, a.Wm, a.Wc, a.z, a.mask); \
+            else hipLaunchKernelGGL((ukf_linear_kernel<NXV, NZV, LAYOUT_SOA, false>), grid, block, 0, s, a, a.F, a.H, a.Q, a.R, a.Wm, a.Wc, a.z, a.mask);  \
+        } else {                                                                                                 \
+            if (ex) hipLaunchKernelGGL((ukf_linear_kernel<NXV, NZV, LAYOUT_AOS, true>), grid, block, 0, s, a, a.F, a.H, a.Q, a.R, a.Wm, a.Wc, a.z, a.mask); \
+            else hipLaunchKernelGGL((ukf_linear_kernel<NXV, NZV, LAYOUT_AOS, false>), grid, block, 0, s, a, a.F, a.H, a.Q, a.R, a.Wm, a.Wc, a.z, a.mask);  \
+        }                                                                                                        \
+    } while (0)
+#if FK_UKF_HAS(1)
+int ukf_fwd_launch_small(const UkfArgs &a, int layout, bool exact, hipStream_t s)
+{
+    if (a.n <= 2 && a.m <= 2) FK_UKF_GO(2, 2);
+    else if (a.n <= 4 && a.m <= 2) FK_UKF_GO(4, 2);
+    else FK_UKF_GO(6, 3);
+    return check_launch("ukf_linear_kernel");
+}
+#endif
+#if FK_UKF_HAS(2)
+int ukf_fwd_launch_big(const UkfArgs &a, int layout, bool exact, hipStream_t s)
+{
+    if (a.n <= 8) FK_UKF_GO(8, 4);
+    else if (a.m <= 3) FK_UKF_GO(9, 3);
+    else FK_UKF_GO(9, 4);
+    return check_launch("ukf_linear_kernel");
+}
+#endif
+#undef FK_UKF_GO
+#endif
+
+#if FK_UKF_RTS
 // ------------------------------------------------ fused linear-model UKF smoother --
 //   fk_ukf_linear_rts_f64 <- UnscentedKalmanFilter.rts_smoother (filterpy/kalman/UKF.py:634-739) with fx(x, dt) = F x:
 // the whole backward loop in one launch, one track per lane, the smoothed step k+1 carried in registers
 // (fk_ukf.hpp, ukf_linear_rts_step).  Reads Xs[k], Ps[k]; writes xs[k], ps[k], Ks[k]: 8 (2n + 3n^2) bytes per
 // track-step (1008 at n = 6).  Before: four kernel launches and nine host<->device copies per step.
-struct UkfRtsArgs {
-    const double *Xs, *Ps;
-    double *xs, *ps, *Ks;
-    int32_t *status;
-    long N, T;
-    int n;
-    double scale;
-};
 
-// (at dim_x = 6 the gain's second sweep accumulates Pb and the full n x n Pxb side by side next to L, x and xb: ~115
-// live doubles -- one wave per SIMD there; two spilled 90-220 registers)
-template <int NX, int LAYOUT, bool SCALAR_F, int VER = 3>
+// One wave per SIMD from dim_x = 5 (the gain's second sweep accumulates Pb and the full n x n Pxb side by side next to L, F L,
+// x and xb).  Round 3, the kernel around the step (the forward kernel's rules):
+//   * EXACT instantiations: straight-line loads and stores;
+//   * the filtered state of step k is still requested at the top of step k (an HBM round trip behind the previous step's
+//     stores, exposed at one wave per SIMD): a request one step ahead needs 27 doubles (84 registers of raw quads on the
+//     cooperative path) that stay untouched for a whole step, and at 256 + 200 registers the allocator moves exactly those
+//     to AGPRs or scratch the moment they are loaded -- which is a wait for the load (tried; an LDS-DMA fetch that
+//     holds no register is the open item);
+//   * NumPy order (COOP: exact, even dim_x <= 8): records move between registers and HBM through a wave-private LDS tile,
+//     1 KiB contiguous per instruction, in both directions (a lane-per-record access of a 36-double record touches 64
+//     lines per instruction: the n = 6 backward pass took 5.6 ms in NumPy order against 2.0 ms element-major);
+//   * lanes past the last track duplicate it (or, on the cooperative path, compute on zeros that the descriptors never
+//     store); no store is predicated.
+template <int NX, int LAYOUT, bool EXACT>
 __global__ void __launch_bounds__(BLOCK, (NX <= 2 ? 4 : NX <= 4 ? 2 : 1))
 ukf_linear_rts_kernel(const UkfRtsArgs a, const double *__restrict__ pF, const double *__restrict__ pQ,
                       const double *__restrict__ pWm, const double *__restrict__ pWc)
 {
     constexpr int KS = 2 * NX + 1;
     constexpr int PL = NX * (NX + 1) / 2;
+    constexpr int NN = NX * NX;
+    constexpr bool COOP = EXACT && LAYOUT == LAYOUT_AOS && NX % 2 == 0 && NX <= 8;
     using SharedModel = LdsModel<NX, 1>;
     __shared__ double s_model[SharedModel::SIZE + 2 * KS];
+    __shared__ double s_tile[COOP ? (BLOCK / 64) * 64 * NN : 1];
     const long N = a.N;
     const long blk0 = (long)blockIdx.x * BLOCK;
-    const Lane ln{blk0, threadIdx.x, N};
-    const bool live = blk0 + ln.tid < N;
-    const Lane lr{blk0, live ? ln.tid : 0u, N};
-    const int n = a.n;
+    const long left = N - blk0;
+    const unsigned last_row = (unsigned)(left < BLOCK ? left : BLOCK) - 1u;
+    const bool live = threadIdx.x <= last_row;
+    const Lane ln{blk0, live ? threadIdx.x : last_row, N};
+    const int n = EXACT ? NX : a.n;
     const int ks = 2 * n + 1;
+    double *tile = s_tile + (COOP ? (threadIdx.x >> 6) * 64 * NN : 0);
+    const unsigned lane = threadIdx.x & 63u, wave_row0 = (threadIdx.x >> 6) * 64u;
     lds_fill<NX, NX>(s_model + SharedModel::OFF_F, pF, n, n, 1.0, threadIdx.x);
     lds_fill<NX, NX>(s_model + SharedModel::OFF_Q, pQ, n, n, 1.0, threadIdx.x);
-    for (unsigned q = ln.tid; q < (unsigned)(2 * KS); q += BLOCK) {           // weights re-indexed to the padded point set
+    for (unsigned q = threadIdx.x; q < (unsigned)(2 * KS); q += BLOCK) {      // weights re-indexed to the padded point set
         const int which = q / KS, i = q % KS;
         int src = -1;
         if (i == 0) src = 0;
@@ -442,70 +282,110 @@ ukf_linear_rts_kernel(const UkfRtsArgs a, const double *__restrict__ pF, const d
         s_model[SharedModel::SIZE + q] = (src >= 0 && src < ks) ? W[src] : 0.0;
     }
     __syncthreads();
-    using StepModel = std::conditional_t<SCALAR_F, ScalarFHModel<NX, 1>, SharedModel>;
-    struct View { StepModel sm; const double *Wm, *Wc; };
-    int goff = 0;
-    auto sweep = [&]() {
-        if constexpr (SCALAR_F) {
-            int t;
-            asm volatile("s_mov_b32 %0, 0" : "=s"(t));
-            goff = t;
+    struct View { SharedModel sm; const double *Wm, *Wc; };
+    auto fresh = [&](double after = 0.0) {
+        int off = 0;
+        asm volatile("" : "+v"(off) : "v"(after));
+        const double *mb = s_model + off;
+        return View{SharedModel{mb}, mb + SharedModel::SIZE, mb + SharedModel::SIZE + KS};
+    };
+    // the filtered state of step t in flight / landed.  Element-major (and the padded classes): the lane's own registers;
+    // cooperative: the wave's slab as register quads, then through the tile.
+    struct Fetch {
+        double x[COOP ? 1 : NX], P[COOP ? 1 : PL];
+        WaveAosFetch<COOP ? NX : 2> fx;
+        WaveAosFetch<COOP ? NN : 2> fP;
+    };
+    auto issue = [&](long t, Fetch &f) {
+        if constexpr (COOP) {
+            f.fx.issue(a.Xs + t * N * NX + blk0 * NX, wave_row0, lane, last_row);
+            f.fP.issue(a.Ps + t * N * NN + blk0 * NN, wave_row0, lane, last_row);
+        } else {
+            load_rec<NX, 1, LAYOUT, EXACT>(f.x, a.Xs + t * N * n, ln, n, 1, 0.0);
+            const RecView<LAYOUT> pv(a.Ps + t * N * n * n, ln, n * n);
+            FK_UNROLL for (int i = 0; i < NX; ++i)
+                FK_UNROLL for (int j = 0; j < NX; ++j)
+                    if (j >= i) f.P[sym_idx<NX>(i, j)] = (EXACT || (i < n && j < n)) ? pv.load(i * n + j) : (i == j ? 1.0 : 0.0);
         }
     };
-    auto fresh = [&]() {
-        int off = 0;
-        asm volatile("" : "+v"(off));
-        const double *mb = s_model + off;
-        if constexpr (SCALAR_F) return View{StepModel{mb, pF + goff, pF + goff}, mb + SharedModel::SIZE, mb + SharedModel::SIZE + KS};
-        else return View{StepModel{mb}, mb + SharedModel::SIZE, mb + SharedModel::SIZE + KS};
+    auto land = [&](Fetch &f, double (&x)[NX], double (&P)[PL]) {
+        if constexpr (COOP) {
+            f.fx.to_tile(tile, lane);
+            FK_UNROLL for (int c = 0; c < NX; ++c) x[c] = tile[lane * NX + c];
+            f.fP.to_tile(tile, lane);
+            FK_UNROLL for (int i = 0; i < NX; ++i)
+                FK_UNROLL for (int j = 0; j < NX; ++j)
+                    if (j >= i) P[sym_idx<NX>(i, j)] = tile[lane * NN + i * NX + j];
+            wave_lds_fence();
+        } else {
+            FK_UNROLL for (int c = 0; c < NX; ++c) { asm volatile("" : "+v"(f.x[c])); x[c] = f.x[c]; }
+            FK_UNROLL for (int e = 0; e < PL; ++e) { asm volatile("" : "+v"(f.P[e])); P[e] = f.P[e]; }
+        }
     };
-    auto load_state = [&](long t, double (&x)[NX], double (&P)[PL]) {
-        load_rec<NX, 1, LAYOUT, false>(x, a.Xs + t * N * n, lr, n, 1, 0.0);
-        const RecView<LAYOUT> pv(a.Ps + t * N * n * n, lr, n * n);
-        FK_UNROLL for (int i = 0; i < NX; ++i)
-            FK_UNROLL for (int j = 0; j < NX; ++j)
-                if (j >= i) P[sym_idx<NX>(i, j)] = (i < n && j < n) ? pv.load(i * n + j) : (i == j ? 1.0 : 0.0);
+    auto store_x = [&](long t, const double (&x)[NX]) {
+        if constexpr (COOP) wave_store_aos_flat<NX>(x, a.xs + t * N * NX + blk0 * NX, wave_row0, tile, lane, last_row);
+        else store_rec<NX, 1, LAYOUT, EXACT>(x, a.xs + t * N * n, ln, n, 1);
     };
-    auto store_state = [&](long t, const double (&x)[NX], const double (&P)[PL]) {
-        store_rec<NX, 1, LAYOUT, false>(x, a.xs + t * N * n, ln, n, 1);
-        double Pf[NX * NX];
-        FK_UNROLL for (int i = 0; i < NX; ++i)
-            FK_UNROLL for (int j = 0; j < NX; ++j) Pf[i * NX + j] = P[sym_idx<NX>(i, j)];
-        store_rec<NX, NX, LAYOUT, false>(Pf, a.ps + t * N * n * n, ln, n, n);
+    auto store_full = [&](double *arr, long t, const double (&M)[NN]) {
+        if constexpr (COOP) wave_store_aos_flat<NN>(M, arr + t * N * NN + blk0 * NN, wave_row0, tile, lane, last_row);
+        else store_rec<NX, NX, LAYOUT, EXACT>(M, arr + t * N * n * n, ln, n, n);
     };
 
+    // the last step is the filter's own output, copied as it is (both triangles: xs, ps = Xs.copy(), Ps.copy())
     double xn[NX], Pn[PL];
-    load_state(a.T - 1, xn, Pn);
-    if (live) {
-        // the last step is the filter's own output, copied as it is (both triangles: xs, ps = Xs.copy(), Ps.copy())
-        store_rec<NX, 1, LAYOUT, false>(xn, a.xs + (a.T - 1) * N * n, ln, n, 1);
-        {
-            double Pf[NX * NX];
-            load_rec<NX, NX, LAYOUT, false>(Pf, a.Ps + (a.T - 1) * N * n * n, lr, n, n, 0.0);
-            store_rec<NX, NX, LAYOUT, false>(Pf, a.ps + (a.T - 1) * N * n * n, ln, n, n);
+    {
+        double Pf[NN];
+        if constexpr (COOP) {
+            WaveAosFetch<NX> fx;
+            WaveAosFetch<NN> fP;
+            fx.issue(a.Xs + (a.T - 1) * N * NX + blk0 * NX, wave_row0, lane, last_row);
+            fP.issue(a.Ps + (a.T - 1) * N * NN + blk0 * NN, wave_row0, lane, last_row);
+            fx.to_tile(tile, lane);
+            FK_UNROLL for (int c = 0; c < NX; ++c) xn[c] = tile[lane * NX + c];
+            fP.to_tile(tile, lane);
+            FK_UNROLL for (int e = 0; e < NN; ++e) Pf[e] = tile[lane * NN + e];
+            wave_lds_fence();
+        } else {
+            load_rec<NX, 1, LAYOUT, EXACT>(xn, a.Xs + (a.T - 1) * N * n, ln, n, 1, 0.0);
+            load_rec<NX, NX, LAYOUT, EXACT>(Pf, a.Ps + (a.T - 1) * N * n * n, ln, n, n, 1.0);
         }
+        FK_UNROLL for (int i = 0; i < NX; ++i)
+            FK_UNROLL for (int j = 0; j < NX; ++j)
+                if (j >= i) Pn[sym_idx<NX>(i, j)] = Pf[i * NX + j];
+        store_x(a.T - 1, xn);
+        store_full(a.ps, a.T - 1, Pf);
         if (a.Ks) {
-            double Z[NX * NX];
-            FK_UNROLL for (int e = 0; e < NX * NX; ++e) Z[e] = 0.0;
-            store_rec<NX, NX, LAYOUT, false>(Z, a.Ks + (a.T - 1) * N * n * n, ln, n, n);
+            double Z[NN];
+            FK_UNROLL for (int e = 0; e < NN; ++e) Z[e] = 0.0;
+            store_full(a.Ks, a.T - 1, Z);
         }
     }
     int st = 0;
-    for (long t = a.T - 2; t >= 0; --t) {
-        double x[NX], P[PL], K[NX * NX];
-        load_state(t, x, P);
+    // landed: nothing of the prologue is pending at the loop header
+    FK_UNROLL for (int c = 0; c < NX; ++c) asm volatile("" ::"v"(xn[c]));
+    FK_UNROLL for (int e = 0; e < PL; ++e) asm volatile("" ::"v"(Pn[e]));
+    _Pragma("nounroll") for (long t = a.T - 2; t >= 0; --t) {
+        double x[NX], P[PL], K[NN];
+        {
+            Fetch f;
+            issue(t, f);
+            land(f, x, P);
+        }
         {
             double xb[NX], Pb[PL];
-            if constexpr (VER == 3) st |= ukf_linear_rts_gain_v3<NX>(x, P, a.scale, xb, Pb, K, fresh, sweep);
-            else st |= ukf_linear_rts_gain<NX>(x, P, a.scale, xb, Pb, K, fresh, sweep);
+            st |= ukf_linear_rts_gain_v3<NX>(x, P, a.scale, xb, Pb, K, fresh);
             ukf_linear_rts_correct<NX>(x, P, xn, Pn, xb, Pb, K);
             FK_UNROLL for (int c = 0; c < NX; ++c) xn[c] = x[c];
             FK_UNROLL for (int e = 0; e < PL; ++e) Pn[e] = P[e];
         }
-        if (live) {
-            store_state(t, x, P);
-            if (a.Ks) store_rec<NX, NX, LAYOUT, false>(K, a.Ks + t * N * n * n, ln, n, n);
+        store_x(t, x);
+        {
+            double Pf[NN];
+            FK_UNROLL for (int i = 0; i < NX; ++i)
+                FK_UNROLL for (int j = 0; j < NX; ++j) Pf[i * NX + j] = P[sym_idx<NX>(i, j)];
+            store_full(a.ps, t, Pf);
         }
+        if (a.Ks) store_full(a.Ks, t, K);
     }
     if (live && a.status) {
         if (!all_finite<NX>(xn) || !all_finite<PL>(Pn)) st |= ST_NONFINITE;
@@ -513,10 +393,50 @@ ukf_linear_rts_kernel(const UkfRtsArgs a, const double *__restrict__ pF, const d
     }
 }
 
+
+#define FK_UKF_GO(NXV)                                                                                           \
+    do {                                                                                                         \
+        const dim3 grid((unsigned)((a.N + BLOCK - 1) / BLOCK)), block(BLOCK);                                    \
+        const bool ex = exact && a.n == NXV;                                                                     \
+        if (layout == FK_LAYOUT_SOA) {                                                                           \
+            if (ex) hipLaunchKernelGGL((ukf_linear_rts_kernel<NXV, LAYOUT_SOA, true>), grid, block, 0, s, a, F, Q, Wm, Wc);  \
+            else hipLaunchKernelGGL((ukf_linear_rts_kernel<NXV, LAYOUT_SOA, false>), grid, block, 0, s, a, F, Q, Wm, Wc);   \
+        } else {                                                                                                 \
+            if (ex) hipLaunchKernelGGL((ukf_linear_rts_kernel<NXV, LAYOUT_AOS, true>), grid, block, 0, s, a, F, Q, Wm, Wc);  \
+            else hipLaunchKernelGGL((ukf_linear_rts_kernel<NXV, LAYOUT_AOS, false>), grid, block, 0, s, a, F, Q, Wm, Wc);   \
+        }                                                                                                        \
+    } while (0)
+#if FK_UKF_HAS(3)
+int ukf_rts_launch_small(const UkfRtsArgs &a, const double *F, const double *Q, const double *Wm, const double *Wc, int layout, bool exact, hipStream_t s)
+{
+    if (a.n <= 2) FK_UKF_GO(2);
+    else if (a.n <= 4) FK_UKF_GO(4);
+    else FK_UKF_GO(6);
+    return check_launch("ukf_linear_rts_kernel");
+}
+#endif
+#if FK_UKF_HAS(4)
+int ukf_rts_launch_big(const UkfRtsArgs &a, const double *F, const double *Q, const double *Wm, const double *Wc, int layout, bool exact, hipStream_t s)
+{
+    if (a.n <= 8) FK_UKF_GO(8);
+    else FK_UKF_GO(9);
+    return check_launch("ukf_linear_rts_kernel");
+}
+#endif
+#undef FK_UKF_GO
+
+#endif
 static int fail(int code, const char *msg)
 {
     set_last_error(msg);
     return code;
+}
+
+// FK_UKF_PADDED=1: the padded instantiations also at the exact dims (A/B, and the parity tests of the padded path)
+static bool ukf_exact()
+{
+    static const bool padded = getenv("FK_UKF_PADDED") && getenv("FK_UKF_PADDED")[0] == '1';
+    return !padded;
 }
 
 }  // namespace fk
@@ -525,6 +445,7 @@ using namespace fk;
 
 extern "C" {
 
+#if FK_UKF_HAS(1)
 int fk_ukf_linear_batch_f64(const fk_ukf_desc *d, const double *F, const double *H, const double *Q,
                             const double *R, const double *Wm, const double *Wc, const double *z,
                             const uint8_t *mask, double *x, double *P, double *means, double *covs,
@@ -543,52 +464,11 @@ int fk_ukf_linear_batch_f64(const fk_ukf_desc *d, const double *F, const double 
     a0.N = d->N; a0.T = d->T; a0.n = d->n; a0.m = d->m; a0.scale = d->scale;
     a0.i0 = 0; a0.cnt = d->N; a0.status_or = 0;
     const int layout = d->layout;
-    // Round 3: every class runs the factor-image step (fk_ukf.hpp, ukf_linear_step_v3) with the model in LDS -- it reads each
-    // row of F and H once per step, so the scalar-operand form that V2's 4 x (2n+1) row sweeps needed no longer pays
-    // (its SGPR spills cost more than the 83 broadcast reads).  A/B switches, exact (6,3) only unless noted:
-    //   FK_UKF_SCALAR=1  F and H as scalar operands (also (8,4), (9,3));  FK_UKF_V2=1  round 2's point-by-point step;
-    //   FK_UKF_V1=1  the straightforward kernel at dim_x <= 4.
-    static const bool scalar_fh = getenv("FK_UKF_SCALAR") && getenv("FK_UKF_SCALAR")[0] == '1';
-    static const bool step_v2 = getenv("FK_UKF_V2") && getenv("FK_UKF_V2")[0] == '1';
-    static const bool kern_v1 = getenv("FK_UKF_V1") && getenv("FK_UKF_V1")[0] == '1';
-    // one piece: tracks [a.i0, a.i0 + a.cnt), a.T steps from the pointers in a
+    const bool exact = ukf_exact();
+    // one piece: tracks [a.i0, a.i0 + a.cnt), a.T steps from the pointers in a.  Classes (2,2), (4,2), (6,3), (8,4), (9,3),
+    // (9,4): the exact instantiation where the dims are the class's own, the padded one otherwise.
     auto one = [&](const UkfArgs &a, hipStream_t s) -> int {
-        const dim3 grid((unsigned)((a.cnt + BLOCK - 1) / BLOCK)), block(BLOCK);
-#define GO(KERNEL, ...)                                                                                          \
-    do {                                                                                                         \
-        if (layout == FK_LAYOUT_SOA)                                                                             \
-            hipLaunchKernelGGL((KERNEL<__VA_ARGS__, LAYOUT_SOA>), grid, block, 0, s, a, F, H, Q, R, Wm, Wc, a.z, a.mask); \
-        else                                                                                                     \
-            hipLaunchKernelGGL((KERNEL<__VA_ARGS__, LAYOUT_AOS>), grid, block, 0, s, a, F, H, Q, R, Wm, Wc, a.z, a.mask); \
-    } while (0)
-#define GO2(NXV, NZV, SC, VER)                                                                                   \
-    do {                                                                                                         \
-        if (layout == FK_LAYOUT_SOA)                                                                             \
-            hipLaunchKernelGGL((ukf_linear_kernel_v2<NXV, NZV, LAYOUT_SOA, SC, VER>), grid, block, 0, s, a, F, H, Q, R, Wm, Wc, a.z, a.mask); \
-        else                                                                                                     \
-            hipLaunchKernelGGL((ukf_linear_kernel_v2<NXV, NZV, LAYOUT_AOS, SC, VER>), grid, block, 0, s, a, F, H, Q, R, Wm, Wc, a.z, a.mask); \
-    } while (0)
-        if (a.n <= 2 && a.m <= 2) {
-            if (kern_v1) GO(ukf_linear_kernel, 2, 2);
-            else GO2(2, 2, false, 3);
-        } else if (a.n <= 4 && a.m <= 2) {
-            if (kern_v1) GO(ukf_linear_kernel, 4, 2);
-            else GO2(4, 2, false, 3);
-        } else if (a.n <= 6 && a.m <= 3) {
-            if (a.n == 6 && a.m == 3 && step_v2) GO2(6, 3, true, 2);
-            else if (a.n == 6 && a.m == 3 && scalar_fh) GO2(6, 3, true, 3);
-            else GO2(6, 3, false, 3);
-        } else if (a.n <= 8) {                                             // round 3: dim_x 7..9 fused, one lane per track
-            if (a.n == 8 && a.m == 4 && scalar_fh) GO2(8, 4, true, 3);
-            else GO2(8, 4, false, 3);
-        } else {
-            if (a.m == 3 && scalar_fh) GO2(9, 3, true, 3);
-            else if (a.m <= 3) GO2(9, 3, false, 3);
-            else GO2(9, 4, false, 3);
-        }
-#undef GO
-#undef GO2
-        return check_launch("ukf_linear_kernel");
+        return (a.n <= 6 && a.m <= 3) ? ukf_fwd_launch_small(a, layout, exact, s) : ukf_fwd_launch_big(a, layout, exact, s);
     };
     // tail filling (fk_chunks.hpp): FK_UKF_CHUNKS="G,H" cuts the call into G track groups x H time chunks on G streams, the
     // state handed from chunk to chunk through x / P in place (bit-identical results).  Default: one launch -- at
@@ -596,7 +476,9 @@ int fk_ukf_linear_batch_f64(const fk_ukf_desc *d, const double *F, const double 
     // measured no faster (profiles/r03/ukf_chunking.jsonl).
     return ukf_chunked_call(a0, a0.n, a0.m, one, (hipStream_t)stream);
 }
+#endif
 
+#if FK_UKF_HAS(3)
 int fk_ukf_linear_rts_f64(const fk_ukf_desc *d, const double *F, const double *Q, const double *Wm, const double *Wc,
                           const double *Xs, const double *Ps, double *xs, double *Ps_out, double *K, int32_t *status,
                           void *stream)
@@ -610,25 +492,10 @@ int fk_ukf_linear_rts_f64(const fk_ukf_desc *d, const double *F, const double *Q
     UkfRtsArgs a{};
     a.Xs = Xs; a.Ps = Ps; a.xs = xs; a.ps = Ps_out; a.Ks = K; a.status = status;
     a.N = d->N; a.T = d->T; a.n = d->n; a.scale = d->scale;
-    const dim3 grid((unsigned)((a.N + BLOCK - 1) / BLOCK)), block(BLOCK);
     hipStream_t s = (hipStream_t)stream;
-    const bool soa = d->layout == FK_LAYOUT_SOA;
-#define GO(NXV, SC, VER)                                                                                         \
-    do {                                                                                                         \
-        if (soa) hipLaunchKernelGGL((ukf_linear_rts_kernel<NXV, LAYOUT_SOA, SC, VER>), grid, block, 0, s, a, F, Q, Wm, Wc); \
-        else hipLaunchKernelGGL((ukf_linear_rts_kernel<NXV, LAYOUT_AOS, SC, VER>), grid, block, 0, s, a, F, Q, Wm, Wc);     \
-    } while (0)
-    // every class runs the factor-image gain (fk_ukf.hpp, ukf_linear_rts_gain_v3); FK_UKF_V2=1: round 2's point-by-point
-    // gain with F as scalar operands, exact dim_x = 6 only (A/B)
-    static const bool gain_v2 = getenv("FK_UKF_V2") && getenv("FK_UKF_V2")[0] == '1';
-    if (d->n <= 2) GO(2, false, 3);
-    else if (d->n <= 4) GO(4, false, 3);
-    else if (d->n == 6 && gain_v2) GO(6, true, 2);
-    else if (d->n <= 6) GO(6, false, 3);
-    else if (d->n <= 8) GO(8, false, 3);                                   // round 3: dim_x 7..9
-    else GO(9, false, 3);
-#undef GO
-    return check_launch("ukf_linear_rts_kernel");
+    return d->n <= 6 ? ukf_rts_launch_small(a, F, Q, Wm, Wc, d->layout, ukf_exact(), s)
+                     : ukf_rts_launch_big(a, F, Q, Wm, Wc, d->layout, ukf_exact(), s);
 }
+#endif
 
 }  // extern "C"

@@ -511,14 +511,13 @@ extern "C" int hc_imm_batch(int n, int m, int nm, long T, const double *F, const
 
 
 // ---------------------------------------------------------------------------------------------------------
-// The register-lean organisation of the fused linear UKF step (filterpy_amd/csrc/fk_ukf.hpp, "V2" of
-// ukf_kernels.hip) on the host: T x { predict; update } for one track with exact dims, so that its arithmetic
+// The fused linear UKF step (filterpy_amd/csrc/fk_ukf.hpp, the arithmetic of ukf_kernels.hip) on the host: T x { predict; update } for one track with exact dims, so that its arithmetic
 // can be held against the oracle without a GPU.
 #include "../../filterpy_amd/csrc/fk_ukf.hpp"
 
 namespace {
-template <int NX, int NZ, int VER = 2>
-int ukf_v2_batch(long T, const double *F, const double *H, const double *Q, const double *R, const double *Wm,
+template <int NX, int NZ>
+int ukf_v3_batch(long T, const double *F, const double *H, const double *Q, const double *R, const double *Wm,
                  const double *Wc, double scale, const double *zs, const unsigned char *mask, double *x0,
                  double *P0, double *means, double *covs)
 {
@@ -537,7 +536,7 @@ int ukf_v2_batch(long T, const double *F, const double *H, const double *Q, cons
     std::copy(Wc, Wc + KS, wc);
     v.Wm = wm;
     v.Wc = wc;
-    auto fresh = [&]() -> const View & { return v; };
+    auto fresh = [&](double = 0.0) -> const View & { return v; };
     double x[NX], P[PL];
     for (int i = 0; i < NX; ++i) {
         x[i] = x0[i];
@@ -545,10 +544,10 @@ int ukf_v2_batch(long T, const double *F, const double *H, const double *Q, cons
     }
     int st = 0;
     for (long t = 0; t < T; ++t) {
-        double z[NZ];
-        for (int r = 0; r < NZ; ++r) z[r] = zs[t * NZ + r];
-        if (VER == 3) st |= fk::ukf_linear_step_v3<NX, NZ>(x, P, z, mask ? mask[t] != 0 : true, scale, fresh);
-        else st |= fk::ukf_linear_step_v2<NX, NZ>(x, P, z, mask ? mask[t] != 0 : true, scale, fresh);
+        auto load_z = [&](double (&z)[NZ]) {
+            for (int r = 0; r < NZ; ++r) z[r] = zs[t * NZ + r];
+        };
+        st |= fk::ukf_linear_step_v3<NX, NZ>(x, P, load_z, mask ? mask[t] != 0 : true, scale, fresh);
         for (int i = 0; i < NX; ++i) {
             means[t * NX + i] = x[i];
             for (int j = 0; j < NX; ++j) covs[(t * NX + i) * NX + j] = P[fk::sym_idx<NX>(i, j)];
@@ -563,8 +562,8 @@ int ukf_v2_batch(long T, const double *F, const double *H, const double *Q, cons
 }  // namespace
 
 namespace {
-// the fused linear-model UKF smoother's step (fk_ukf.hpp: ukf_linear_rts_gain / _correct) over a whole backward pass
-template <int NX, int VER = 2>
+// the fused linear-model UKF smoother's step (fk_ukf.hpp: ukf_linear_rts_gain_v3 / _correct) over a whole backward pass
+template <int NX>
 int ukf_rts_batch(long T, const double *F, const double *Q, const double *Wm, const double *Wc, double scale,
                   const double *Xs, const double *Ps, double *xs, double *ps, double *Ks)
 {
@@ -581,7 +580,7 @@ int ukf_rts_batch(long T, const double *F, const double *Q, const double *Wm, co
     std::copy(Wc, Wc + KS, wc);
     v.Wm = wm;
     v.Wc = wc;
-    auto fresh = [&]() -> const View & { return v; };
+    auto fresh = [&](double = 0.0) -> const View & { return v; };
     auto load = [&](long t, double (&x)[NX], double (&P)[PL]) {
         for (int i = 0; i < NX; ++i) {
             x[i] = Xs[t * NX + i];
@@ -603,8 +602,7 @@ int ukf_rts_batch(long T, const double *F, const double *Q, const double *Wm, co
     for (long t = T - 2; t >= 0; --t) {
         double x[NX], P[PL], K[NX * NX], xb[NX], Pb[PL];
         load(t, x, P);
-        if (VER == 3) st |= fk::ukf_linear_rts_gain_v3<NX>(x, P, scale, xb, Pb, K, fresh);
-        else st |= fk::ukf_linear_rts_gain<NX>(x, P, scale, xb, Pb, K, fresh);
+        st |= fk::ukf_linear_rts_gain_v3<NX>(x, P, scale, xb, Pb, K, fresh);
         fk::ukf_linear_rts_correct<NX>(x, P, xn, Pn, xb, Pb, K);
         store(t, x, P);
         for (int e = 0; e < NX * NX; ++e) Ks[t * NX * NX + e] = K[e];
@@ -615,31 +613,12 @@ int ukf_rts_batch(long T, const double *F, const double *Q, const double *Wm, co
 }
 }  // namespace
 
-extern "C" int hc_ukf_linear_rts(int n, long T, const double *F, const double *Q, const double *Wm, const double *Wc,
-                                 double scale, const double *Xs, const double *Ps, double *xs, double *ps, double *Ks)
-{
-    if (n == 2) return ukf_rts_batch<2>(T, F, Q, Wm, Wc, scale, Xs, Ps, xs, ps, Ks);
-    if (n == 4) return ukf_rts_batch<4>(T, F, Q, Wm, Wc, scale, Xs, Ps, xs, ps, Ks);
-    if (n == 6) return ukf_rts_batch<6>(T, F, Q, Wm, Wc, scale, Xs, Ps, xs, ps, Ks);
-    return -1;
-}
-
-extern "C" int hc_ukf_linear_v2(int n, int m, long T, const double *F, const double *H, const double *Q, const double *R,
-                                const double *Wm, const double *Wc, double scale, const double *zs,
-                                const unsigned char *mask, double *x0, double *P0, double *means, double *covs)
-{
-    if (n == 2 && m == 2) return ukf_v2_batch<2, 2>(T, F, H, Q, R, Wm, Wc, scale, zs, mask, x0, P0, means, covs);
-    if (n == 4 && m == 2) return ukf_v2_batch<4, 2>(T, F, H, Q, R, Wm, Wc, scale, zs, mask, x0, P0, means, covs);
-    if (n == 6 && m == 3) return ukf_v2_batch<6, 3>(T, F, H, Q, R, Wm, Wc, scale, zs, mask, x0, P0, means, covs);
-    return -1;
-}
-
 // the factor-image organisation of the step (fk_ukf.hpp, ukf_linear_step_v3: what the kernels run since round 3)
 extern "C" int hc_ukf_linear_v3(int n, int m, long T, const double *F, const double *H, const double *Q, const double *R,
                                 const double *Wm, const double *Wc, double scale, const double *zs,
                                 const unsigned char *mask, double *x0, double *P0, double *means, double *covs)
 {
-#define GO(NXV, NZV) if (n == NXV && m == NZV) return ukf_v2_batch<NXV, NZV, 3>(T, F, H, Q, R, Wm, Wc, scale, zs, mask, x0, P0, means, covs)
+#define GO(NXV, NZV) if (n == NXV && m == NZV) return ukf_v3_batch<NXV, NZV>(T, F, H, Q, R, Wm, Wc, scale, zs, mask, x0, P0, means, covs)
     GO(2, 2); GO(4, 2); GO(6, 3); GO(8, 4); GO(9, 3); GO(9, 4); GO(3, 1); GO(5, 2); GO(7, 3);
 #undef GO
     return -1;
@@ -648,7 +627,7 @@ extern "C" int hc_ukf_linear_v3(int n, int m, long T, const double *F, const dou
 extern "C" int hc_ukf_linear_rts_v3(int n, long T, const double *F, const double *Q, const double *Wm, const double *Wc,
                                     double scale, const double *Xs, const double *Ps, double *xs, double *ps, double *Ks)
 {
-#define GO(NXV) if (n == NXV) return ukf_rts_batch<NXV, 3>(T, F, Q, Wm, Wc, scale, Xs, Ps, xs, ps, Ks)
+#define GO(NXV) if (n == NXV) return ukf_rts_batch<NXV>(T, F, Q, Wm, Wc, scale, Xs, Ps, xs, ps, Ks)
     GO(2); GO(3); GO(4); GO(5); GO(6); GO(7); GO(8); GO(9);
 #undef GO
     return -1;

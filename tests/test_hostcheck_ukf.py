@@ -1,5 +1,5 @@
-"""The register-lean organisation of the fused linear UKF step (filterpy_amd/csrc/fk_ukf.hpp; the -DFK_UKF_V2 build
-of ukf_kernels.hip, not the default yet) compiled for the host and held against the oracle's UKF
+"""The arithmetic of the fused linear UKF kernels (filterpy_amd/csrc/fk_ukf.hpp: ukf_linear_step_v3, ukf_linear_rts_gain_v3 /
+_correct -- the very functions ukf_kernels.hip runs per lane) compiled for the host and held against the oracle's UKF
 (oracle/ukf_oracle.py, pinned to the reference by tests/test_oracle_ukf.py) with fx = F x, hx = H x."""
 import ctypes
 import os
@@ -14,7 +14,7 @@ sys.path.insert(0, ROOT)
 from oracle import ukf_oracle  # noqa: E402
 
 
-def _v2(n, m, F, H, Q, R, Wm, Wc, scale, zs, mask, x0, P0, entry="hc_ukf_linear_v2"):
+def _v3(n, m, F, H, Q, R, Wm, Wc, scale, zs, mask, x0, P0, entry="hc_ukf_linear_v3"):
     lib = ctypes.CDLL(os.path.join(ROOT, "tests", "hostcheck", "libhostcheck.so"))
     T = zs.shape[0]
     c = lambda a: np.ascontiguousarray(a, dtype=np.float64)  # noqa: E731
@@ -29,13 +29,12 @@ def _v2(n, m, F, H, Q, R, Wm, Wc, scale, zs, mask, x0, P0, entry="hc_ukf_linear_
     return means, covs, x, P
 
 
-@pytest.mark.parametrize("n,m,entry", [(2, 2, "hc_ukf_linear_v2"), (4, 2, "hc_ukf_linear_v2"), (6, 3, "hc_ukf_linear_v2")] +
-                         [(n, m, "hc_ukf_linear_v3") for n, m in
-                          [(2, 2), (3, 1), (4, 2), (5, 2), (6, 3), (7, 3), (8, 4), (9, 3), (9, 4)]])
+@pytest.mark.parametrize("n,m,entry", [(n, m, "hc_ukf_linear_v3") for n, m in
+                                       [(2, 2), (3, 1), (4, 2), (5, 2), (6, 3), (7, 3), (8, 4), (9, 3), (9, 4)]])
 @pytest.mark.parametrize("abk", [(.1, 2., None), (1e-3, 2., 0.), (1., 2., .1)])
-def test_ukf_v2_step_matches_the_oracle(n, m, entry, abk):
-    """ukf_linear_step_v2 (round 2, point by point) and ukf_linear_step_v3 (round 3, images formed from the image of the
-    factor -- what the kernels run) on the host against the oracle's UKF.batch_filter (UKF.py:364-491, 634-712)."""
+def test_ukf_step_matches_the_oracle(n, m, entry, abk):
+    """ukf_linear_step_v3 (images of the sigma points formed from the image of the factor) on the host against the oracle's
+    UKF.batch_filter (UKF.py:364-491, 524-632)."""
     alpha, beta, kappa = abk
     kappa = 3. - n if kappa is None else kappa
     r = np.random.default_rng(n * 10 + m)
@@ -53,7 +52,7 @@ def test_ukf_v2_step_matches_the_oracle(n, m, entry, abk):
     Wm, Wc = ukf_oracle.merwe_weights(n, alpha, beta, kappa)
     mu_ref, cov_ref = ukf_oracle.ukf_batch_filter(x0, P0, list(zs), lambda s, d: F @ s, lambda s: H @ s, 0.1, Q, R,
                                                   alpha, beta, kappa)
-    mu, cov, xf, Pf = _v2(n, m, F, H, Q, R, Wm, Wc, lam + n, zs, None, x0, P0, entry)
+    mu, cov, xf, Pf = _v3(n, m, F, H, Q, R, Wm, Wc, lam + n, zs, None, x0, P0, entry)
     rel = lambda a, b: np.max(np.abs(a - b)) / np.max(np.abs(b))  # noqa: E731
     # Merwe's cancelling weights (Wm0 ~ -1e6 at alpha = 1e-3) amplify rounding: the package's UKF bar is 1e-9
     tol = 1e-9 if alpha > 1e-2 else 1e-6
@@ -62,8 +61,8 @@ def test_ukf_v2_step_matches_the_oracle(n, m, entry, abk):
     assert np.allclose(cov, np.swapaxes(cov, 1, 2))
 
 
-@pytest.mark.parametrize("entry", ["hc_ukf_linear_v2", "hc_ukf_linear_v3"])
-def test_ukf_v2_missing_measurements_skip_the_update(entry):
+@pytest.mark.parametrize("entry", ["hc_ukf_linear_v3"])
+def test_ukf_missing_measurements_skip_the_update(entry):
     n, m, T = 4, 2, 12
     r = np.random.default_rng(5)
     F = np.eye(n) + 0.05 * np.triu(r.standard_normal((n, n)), 1)
@@ -78,12 +77,12 @@ def test_ukf_v2_missing_measurements_skip_the_update(entry):
     zl = [z if k else None for z, k in zip(zs, mask)]
     mu_ref, cov_ref = ukf_oracle.ukf_batch_filter(x0, P0, zl, lambda s, d: F @ s, lambda s: H @ s, 0.1, Q, R,
                                                   alpha, beta, kappa)
-    mu, cov, _, _ = _v2(n, m, F, H, Q, R, Wm, Wc, lam + n, zs, mask, x0, P0, entry)
+    mu, cov, _, _ = _v3(n, m, F, H, Q, R, Wm, Wc, lam + n, zs, mask, x0, P0, entry)
     assert np.max(np.abs(mu - mu_ref)) / np.max(np.abs(mu_ref)) < 1e-9
     assert np.max(np.abs(cov - cov_ref)) / np.max(np.abs(cov_ref)) < 1e-9
 
 
-def _rts(n, F, Q, Wm, Wc, scale, Xs, Ps, entry="hc_ukf_linear_rts"):
+def _rts(n, F, Q, Wm, Wc, scale, Xs, Ps, entry="hc_ukf_linear_rts_v3"):
     lib = ctypes.CDLL(os.path.join(ROOT, "tests", "hostcheck", "libhostcheck.so"))
     T = Xs.shape[0]
     c = lambda a: np.ascontiguousarray(a, dtype=np.float64)  # noqa: E731
@@ -96,11 +95,10 @@ def _rts(n, F, Q, Wm, Wc, scale, Xs, Ps, entry="hc_ukf_linear_rts"):
     return xs, ps, Ks
 
 
-@pytest.mark.parametrize("n,m,entry", [(2, 2, "hc_ukf_linear_rts"), (4, 2, "hc_ukf_linear_rts"), (6, 3, "hc_ukf_linear_rts")] +
-                         [(n, 2, "hc_ukf_linear_rts_v3") for n in range(2, 10)])
+@pytest.mark.parametrize("n,m,entry", [(n, 2, "hc_ukf_linear_rts_v3") for n in range(2, 10)])
 @pytest.mark.parametrize("abk", [(.1, 2., None), (1., 2., .1)])
 def test_fused_ukf_smoother_step_matches_the_oracle(n, m, entry, abk):
-    """fk_ukf.hpp ukf_linear_rts_gain / _correct (the arithmetic of fk_ukf_linear_rts_f64) on the host against the
+    """fk_ukf.hpp ukf_linear_rts_gain_v3 / _correct (the arithmetic of fk_ukf_linear_rts_f64) on the host against the
     oracle's UKF.rts_smoother (UKF.py:714-739; oracle pinned to the live reference by tests/test_oracle_ukf.py)."""
     alpha, beta, kappa = abk
     kappa = 3. - n if kappa is None else kappa

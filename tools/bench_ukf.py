@@ -3,7 +3,7 @@
 `fk_ukf_linear_rts_f64` (UKF.py:634-739, the whole backward pass) at several (dim_x, dim_z), both layouts.
 
 One JSON line per (kernel, dims, layout): time, track-steps/s, fraction of 8 TB/s on algorithmic bytes, parity against the
-oracle on one track.  The launchers read their A/B switches (FK_UKF_V2, FK_UKF_SCALAR, FK_UKF_V1) once per process, so an
+oracle on one track.  The launchers read their A/B switch (FK_UKF_PADDED) once per process, so an
 A/B comparison is two invocations of this script in one lease; the line carries the switches it ran under.
 
     python tools/bench_ukf.py --dims 6x3,4x2,8x4 --N 100000 --T 100
@@ -55,7 +55,7 @@ def run(n, m, N, T, layout, dense):
     means, covs = E.alloc_records((T,), N, n, layout), E.alloc_records((T,), N, n * n, layout)
     st = torch.zeros(N, dtype=torch.int32, device=dev)
     dd = [E.dev(M) for M in (F, H, Q, R, Wm, Wc)]
-    sw = {k: os.environ[k] for k in ("FK_UKF_V2", "FK_UKF_SCALAR", "FK_UKF_V1", "FK_UKF_CHUNKS") if k in os.environ}
+    sw = {k: os.environ[k] for k in ("FK_UKF_PADDED", "FK_UKF_CHUNKS") if k in os.environ}
 
     def fwd():
         x.copy_(x0)
