@@ -338,6 +338,32 @@ struct WaveAosFetch {
     }
 };
 
+// LDS-DMA (buffer_load_dwordx4 ... lds): 16 bytes per lane from global memory straight into LDS at (M0 base) + lane * 16 --
+// no VGPR holds the data, so a fetch can stay in flight for a whole time step of a kernel that has no register to spare.
+// hipcc does not count these (inline asm): the caller waits with its own s_waitcnt vmcnt before reading the LDS image, and
+// with lgkmcnt(0) before re-targeting a region it has just read.  M0 is written in the statement that uses it and restored.
+using dma_rsrc_t = __attribute__((ext_vector_type(4))) int;
+__device__ __forceinline__ dma_rsrc_t make_dma_rsrc(const void *p, unsigned bytes)
+{
+    const unsigned long long b = reinterpret_cast<unsigned long long>(p);
+    dma_rsrc_t r = {(int)(unsigned)b, (int)((unsigned)(b >> 32) & 0xffffu), (int)bytes, 0x00020000};
+    r.x = __builtin_amdgcn_readfirstlane(r.x);
+    r.y = __builtin_amdgcn_readfirstlane(r.y);
+    r.z = __builtin_amdgcn_readfirstlane(r.z);
+    return r;
+}
+__device__ __forceinline__ unsigned lds_address(const double *p)      // wave-uniform LDS byte address
+{
+    return __builtin_amdgcn_readfirstlane((unsigned)reinterpret_cast<unsigned long long>(
+        (const __attribute__((address_space(3))) double *)p));
+}
+__device__ __forceinline__ void lds_dma16(dma_rsrc_t rs, unsigned voff, unsigned soff, unsigned lds_addr)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(rs), "s"(soff), "s"(lds_addr) : "memory");
+}
+
 // ---- host side ------------------------------------------------------------
 void set_last_error(const char *msg);
 int check_launch(const char *what);   // hipGetLastError -> FK_ERR_LAUNCH + message

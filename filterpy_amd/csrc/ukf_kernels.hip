@@ -235,6 +235,17 @@ int ukf_fwd_launch_big(const UkfArgs &a, int layout, bool exact, hipStream_t s)
 // (fk_ukf.hpp, ukf_linear_rts_step).  Reads Xs[k], Ps[k]; writes xs[k], ps[k], Ks[k]: 8 (2n + 3n^2) bytes per
 // track-step (1008 at n = 6).  Before: four kernel launches and nine host<->device copies per step.
 
+template <int NX>
+struct UpperTriangle {
+    int flat[NX * (NX + 1) / 2];
+    constexpr UpperTriangle() : flat{}
+    {
+        int k = 0;
+        for (int i = 0; i < NX; ++i)
+            for (int j = i; j < NX; ++j) flat[k++] = i * NX + j;
+    }
+};
+
 // One wave per SIMD from dim_x = 5 (the gain's second sweep accumulates Pb and the full n x n Pxb side by side next to L, F L,
 // x and xb).  Round 3, the kernel around the step (the forward kernel's rules):
 //   * EXACT instantiations: straight-line loads and stores;
@@ -248,7 +259,7 @@ int ukf_fwd_launch_big(const UkfArgs &a, int layout, bool exact, hipStream_t s)
 //     lines per instruction: the n = 6 backward pass took 5.6 ms in NumPy order against 2.0 ms element-major);
 //   * lanes past the last track duplicate it (or, on the cooperative path, compute on zeros that the descriptors never
 //     store); no store is predicated.
-template <int NX, int LAYOUT, bool EXACT>
+template <int NX, int LAYOUT, bool EXACT, bool DMA = false>
 __global__ void __launch_bounds__(BLOCK, (NX <= 2 ? 4 : NX <= 4 ? 2 : 1))
 ukf_linear_rts_kernel(const UkfRtsArgs a, const double *__restrict__ pF, const double *__restrict__ pQ,
                       const double *__restrict__ pWm, const double *__restrict__ pWc)
@@ -257,9 +268,16 @@ ukf_linear_rts_kernel(const UkfRtsArgs a, const double *__restrict__ pF, const d
     constexpr int PL = NX * (NX + 1) / 2;
     constexpr int NN = NX * NX;
     constexpr bool COOP = EXACT && LAYOUT == LAYOUT_AOS && NX % 2 == 0 && NX <= 8;
+    static_assert(!DMA || (EXACT && NX % 2 == 0 && NX <= 6), "LDS-DMA fetch: exact classes 2, 4, 6");
+    // DMA: the filtered state of step k-1 travels HBM -> LDS while step k computes (lds_dma16, fk_device.hpp).  Its LDS image:
+    // NumPy order -- the wave's slab of Ps in memory order in the cooperative tile (which the store path reuses afterwards),
+    // the slab of Xs next to it; element-major -- [pair of elements][64 tracks], the upper triangle of P only.
+    constexpr int DPAIRS = (PL + 1) / 2;                                       // element-major: pairs of P's upper triangle
+    constexpr int DBUF = !DMA ? 1 : COOP ? 64 * NX : 64 * (NX + 2 * DPAIRS);   // doubles per wave next to the tile
     using SharedModel = LdsModel<NX, 1>;
     __shared__ double s_model[SharedModel::SIZE + 2 * KS];
     __shared__ double s_tile[COOP ? (BLOCK / 64) * 64 * NN : 1];
+    __shared__ double s_dma[(BLOCK / 64) * DBUF];
     const long N = a.N;
     const long blk0 = (long)blockIdx.x * BLOCK;
     const long left = N - blk0;
@@ -269,6 +287,7 @@ ukf_linear_rts_kernel(const UkfRtsArgs a, const double *__restrict__ pF, const d
     const int n = EXACT ? NX : a.n;
     const int ks = 2 * n + 1;
     double *tile = s_tile + (COOP ? (threadIdx.x >> 6) * 64 * NN : 0);
+    double *dbuf = s_dma + (threadIdx.x >> 6) * DBUF;
     const unsigned lane = threadIdx.x & 63u, wave_row0 = (threadIdx.x >> 6) * 64u;
     lds_fill<NX, NX>(s_model + SharedModel::OFF_F, pF, n, n, 1.0, threadIdx.x);
     lds_fill<NX, NX>(s_model + SharedModel::OFF_Q, pQ, n, n, 1.0, threadIdx.x);
@@ -331,6 +350,53 @@ ukf_linear_rts_kernel(const UkfRtsArgs a, const double *__restrict__ pF, const d
         else store_rec<NX, NX, LAYOUT, EXACT>(M, arr + t * N * n * n, ln, n, n);
     };
 
+    // ---- LDS-DMA fetch of the filtered state of step t (DMA instantiations)
+    auto dma_issue = [&](long t) {
+        if constexpr (DMA) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // every read of the regions about to be overwritten is done
+            if constexpr (COOP) {
+                const dma_rsrc_t rx = make_dma_rsrc(a.Xs + t * N * NX + blk0 * NX, (last_row + 1u) * (unsigned)NX * 8u);
+                const dma_rsrc_t rp = make_dma_rsrc(a.Ps + t * N * NN + blk0 * NN, (last_row + 1u) * (unsigned)NN * 8u);
+                const unsigned lx = lds_address(dbuf), lp = lds_address(tile);
+                FK_UNROLL for (int it = 0; it < NX / 2; ++it)
+                    lds_dma16(rx, (wave_row0 * NX + lane * 2u) * 8u, (unsigned)(it * 1024), lx + (unsigned)(it * 1024));
+                FK_UNROLL for (int it = 0; it < NN / 2; ++it)
+                    lds_dma16(rp, (wave_row0 * NN + lane * 2u) * 8u, (unsigned)(it * 1024), lp + (unsigned)(it * 1024));
+            } else {
+                // lanes 0..31 fetch tracks (2l, 2l+1) of the pair's first element, lanes 32..63 of its second: 1 KiB per
+                // instruction, lane-linear in LDS = [first element: 64 tracks][second element: 64 tracks]
+                const unsigned n8 = (unsigned)N * 8u;
+                const dma_rsrc_t rx = make_dma_rsrc(a.Xs + t * N * NX, (unsigned)NX * n8);
+                const dma_rsrc_t rp = make_dma_rsrc(a.Ps + t * N * NN, (unsigned)NN * n8);
+                const unsigned lb = lds_address(dbuf);
+                const unsigned vlo = ((unsigned)blk0 + wave_row0 + (lane & 31u) * 2u) * 8u, hi = lane >> 5;
+                FK_UNROLL for (int p = 0; p < NX / 2; ++p)
+                    lds_dma16(rx, vlo + hi * n8, (unsigned)(2 * p) * n8, lb + (unsigned)(p * 1024));
+                FK_UNROLL for (int p = 0; p < DPAIRS; ++p) {
+                    constexpr UpperTriangle<NX> TRI{};          // k-th element of the upper triangle as a flat index i * NX + j
+                    const int e1 = TRI.flat[2 * p], e2 = TRI.flat[2 * p + 1 < PL ? 2 * p + 1 : 2 * p];
+                    lds_dma16(rp, vlo + hi * ((unsigned)(e2 - e1) * n8), (unsigned)e1 * n8, lb + (unsigned)((NX / 2 + p) * 1024));
+                }
+            }
+        }
+    };
+    // waits for the fetch and takes the lane's record out of the LDS image (the tile is free for the store path afterwards)
+    auto dma_take = [&](double (&x)[NX], double (&P)[PL]) {
+        if constexpr (DMA) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if constexpr (COOP) {
+                FK_UNROLL for (int c = 0; c < NX; ++c) x[c] = dbuf[lane * NX + c];
+                FK_UNROLL for (int i = 0; i < NX; ++i)
+                    FK_UNROLL for (int j = 0; j < NX; ++j)
+                        if (j >= i) P[sym_idx<NX>(i, j)] = tile[lane * NN + i * NX + j];
+            } else {
+                FK_UNROLL for (int c = 0; c < NX; ++c) x[c] = dbuf[(c >> 1) * 128 + (c & 1) * 64 + lane];
+                FK_UNROLL for (int k = 0; k < PL; ++k) P[k] = dbuf[(NX / 2 + (k >> 1)) * 128 + (k & 1) * 64 + lane];
+            }
+            wave_lds_fence();
+        }
+    };
+
     // the last step is the filter's own output, copied as it is (both triangles: xs, ps = Xs.copy(), Ps.copy())
     double xn[NX], Pn[PL];
     {
@@ -361,12 +427,28 @@ ukf_linear_rts_kernel(const UkfRtsArgs a, const double *__restrict__ pF, const d
         }
     }
     int st = 0;
+    double xc[DMA ? NX : 1], Pc[DMA ? PL : 1];
+    if constexpr (DMA) {
+        if (a.T >= 2) {
+            dma_issue(a.T - 2);
+            double xq[NX], Pq[PL];
+            dma_take(xq, Pq);
+            FK_UNROLL for (int c = 0; c < NX; ++c) xc[c] = xq[c];
+            FK_UNROLL for (int e = 0; e < PL; ++e) Pc[e] = Pq[e];
+        }
+    }
     // landed: nothing of the prologue is pending at the loop header
     FK_UNROLL for (int c = 0; c < NX; ++c) asm volatile("" ::"v"(xn[c]));
     FK_UNROLL for (int e = 0; e < PL; ++e) asm volatile("" ::"v"(Pn[e]));
     _Pragma("nounroll") for (long t = a.T - 2; t >= 0; --t) {
         double x[NX], P[PL], K[NN];
-        {
+        if constexpr (DMA) {
+            FK_UNROLL for (int c = 0; c < NX; ++c) x[c] = xc[c];
+            FK_UNROLL for (int e = 0; e < PL; ++e) P[e] = Pc[e];
+            long tp = t > 0 ? t - 1 : 0;
+            asm volatile("" : "+s"(tp));
+            dma_issue(tp);                                  // in flight during this step's arithmetic, no register held
+        } else {
             Fetch f;
             issue(t, f);
             land(f, x, P);
@@ -377,6 +459,13 @@ ukf_linear_rts_kernel(const UkfRtsArgs a, const double *__restrict__ pF, const d
             ukf_linear_rts_correct<NX>(x, P, xn, Pn, xb, Pb, K);
             FK_UNROLL for (int c = 0; c < NX; ++c) xn[c] = x[c];
             FK_UNROLL for (int e = 0; e < PL; ++e) Pn[e] = P[e];
+        }
+        if constexpr (DMA) {
+            // in front of this step's stores: nothing else of this wave is in flight, so the wait is for the fetch alone
+            double xq[NX], Pq[PL];
+            dma_take(xq, Pq);
+            FK_UNROLL for (int c = 0; c < NX; ++c) xc[c] = xq[c];
+            FK_UNROLL for (int e = 0; e < PL; ++e) Pc[e] = Pq[e];
         }
         store_x(t, x);
         {
@@ -394,32 +483,37 @@ ukf_linear_rts_kernel(const UkfRtsArgs a, const double *__restrict__ pF, const d
 }
 
 
-#define FK_UKF_GO(NXV)                                                                                           \
+#define FK_UKF_GO(NXV, DMAV)                                                                                     \
     do {                                                                                                         \
         const dim3 grid((unsigned)((a.N + BLOCK - 1) / BLOCK)), block(BLOCK);                                    \
         const bool ex = exact && a.n == NXV;                                                                     \
         if (layout == FK_LAYOUT_SOA) {                                                                           \
-            if (ex) hipLaunchKernelGGL((ukf_linear_rts_kernel<NXV, LAYOUT_SOA, true>), grid, block, 0, s, a, F, Q, Wm, Wc);  \
+            if (ex && DMAV && dma) hipLaunchKernelGGL((ukf_linear_rts_kernel<NXV, LAYOUT_SOA, true, DMAV>), grid, block, 0, s, a, F, Q, Wm, Wc); \
+            else if (ex) hipLaunchKernelGGL((ukf_linear_rts_kernel<NXV, LAYOUT_SOA, true>), grid, block, 0, s, a, F, Q, Wm, Wc);  \
             else hipLaunchKernelGGL((ukf_linear_rts_kernel<NXV, LAYOUT_SOA, false>), grid, block, 0, s, a, F, Q, Wm, Wc);   \
         } else {                                                                                                 \
-            if (ex) hipLaunchKernelGGL((ukf_linear_rts_kernel<NXV, LAYOUT_AOS, true>), grid, block, 0, s, a, F, Q, Wm, Wc);  \
+            if (ex && DMAV && dma) hipLaunchKernelGGL((ukf_linear_rts_kernel<NXV, LAYOUT_AOS, true, DMAV>), grid, block, 0, s, a, F, Q, Wm, Wc); \
+            else if (ex) hipLaunchKernelGGL((ukf_linear_rts_kernel<NXV, LAYOUT_AOS, true>), grid, block, 0, s, a, F, Q, Wm, Wc);  \
             else hipLaunchKernelGGL((ukf_linear_rts_kernel<NXV, LAYOUT_AOS, false>), grid, block, 0, s, a, F, Q, Wm, Wc);   \
         }                                                                                                        \
     } while (0)
 #if FK_UKF_HAS(3)
 int ukf_rts_launch_small(const UkfRtsArgs &a, const double *F, const double *Q, const double *Wm, const double *Wc, int layout, bool exact, hipStream_t s)
 {
-    if (a.n <= 2) FK_UKF_GO(2);
-    else if (a.n <= 4) FK_UKF_GO(4);
-    else FK_UKF_GO(6);
+    // FK_UKF_DMA=0: the exact classes without the LDS-DMA fetch of the next state (A/B)
+    static const bool dma = !(getenv("FK_UKF_DMA") && getenv("FK_UKF_DMA")[0] == '0');
+    if (a.n <= 2) FK_UKF_GO(2, true);
+    else if (a.n <= 4) FK_UKF_GO(4, true);
+    else FK_UKF_GO(6, true);
     return check_launch("ukf_linear_rts_kernel");
 }
 #endif
 #if FK_UKF_HAS(4)
 int ukf_rts_launch_big(const UkfRtsArgs &a, const double *F, const double *Q, const double *Wm, const double *Wc, int layout, bool exact, hipStream_t s)
 {
-    if (a.n <= 8) FK_UKF_GO(8);
-    else FK_UKF_GO(9);
+    const bool dma = false;
+    if (a.n <= 8) FK_UKF_GO(8, false);
+    else FK_UKF_GO(9, false);
     return check_launch("ukf_linear_rts_kernel");
 }
 #endif
