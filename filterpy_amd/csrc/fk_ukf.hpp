@@ -164,16 +164,17 @@ FK_HD int ukf_linear_step_v3(double (&x)[NX], double (&P)[NX * (NX + 1) / 2], Lo
         }
         // sweep 2: P- = sum_i Wc_i y_i y_i' + Q, y_i = sf_i - x-   (upper triangle); the images are re-formed (one add)
         // from copies the optimiser cannot relate to sweep 1's, or it would hold all (2n+1) n of them
+        // y_i = (F x - x-) +- F l_k: the offset of the centre point is formed once and the offsets of the others are one add
+        // each (the reference rounds F(x + l_k) to an ulp of |F x| before it subtracts the mean; this keeps the digits of F l_k)
+        FK_UNROLL for (int r = 0; r < NX; ++r) Fx[r] -= x[r];
         FK_UNROLL for (int r = 0; r < NX; ++r) FK_OPAQUE(Fx[r]);
         {
             FK_UNROLL for (int i = 0; i < 2 * NX + 1; ++i) {
                 // a fresh view per point, ordered behind the previous point's arithmetic: read here, not hoisted and held
                 const double wc = fresh(i ? P[PL - 1] : x[NX - 1]).Wc[i];
                 double y[NX], wy[NX];
-                FK_UNROLL for (int r = 0; r < NX; ++r) {
-                    const double v = (i == 0) ? Fx[r] : (i <= NX) ? Fx[r] + FL[r][(i - 1) % NX] : Fx[r] - FL[r][(i - 1) % NX];
-                    y[r] = v - x[r];
-                }
+                FK_UNROLL for (int r = 0; r < NX; ++r)
+                    y[r] = (i == 0) ? Fx[r] : (i <= NX) ? Fx[r] + FL[r][(i - 1) % NX] : Fx[r] - FL[r][(i - 1) % NX];
                 FK_UNROLL for (int r = 0; r < NX; ++r) wy[r] = wc * y[r];
                 FK_UNROLL for (int a2 = 0; a2 < NX; ++a2)
                     FK_UNROLL for (int b = 0; b < NX; ++b)
@@ -226,19 +227,19 @@ FK_HD int ukf_linear_step_v3(double (&x)[NX], double (&P)[NX * (NX + 1) / 2], Lo
         }
         // sweep 2: S = sum Wc_i d_i d_i' + R,  Pxz = sum Wc_i (sf_i - x) d_i',  d_i = sh_i - zp ; sf_0 - x = 0, sf_i - x = +-l_k
         double S[NZ * NZ], K[NX * NZ];
+        FK_UNROLL for (int r = 0; r < NZ; ++r) Hx[r] -= zp[r];                 // d_i = (H x - zp) +- H l_k, as above
         FK_UNROLL for (int r = 0; r < NZ; ++r) FK_OPAQUE(Hx[r]);
         {
             FK_UNROLL for (int i = 0; i < 2 * NX + 1; ++i) {
                 const double wc = fresh(i ? S[NZ * NZ - 1] : zp[NZ - 1]).Wc[i];
                 double d[NZ], wd[NZ];
-                FK_UNROLL for (int r = 0; r < NZ; ++r) {
-                    const double v = (i == 0) ? Hx[r] : (i <= NX) ? Hx[r] + HL[r][(i - 1) % NX] : Hx[r] - HL[r][(i - 1) % NX];
-                    d[r] = v - zp[r];
-                }
+                FK_UNROLL for (int r = 0; r < NZ; ++r)
+                    d[r] = (i == 0) ? Hx[r] : (i <= NX) ? Hx[r] + HL[r][(i - 1) % NX] : Hx[r] - HL[r][(i - 1) % NX];
                 FK_UNROLL for (int r = 0; r < NZ; ++r) wd[r] = wc * d[r];
+                // upper triangle; the lower one is its mirror image (the reference's w * outer(d, d) is symmetric bit for bit)
                 FK_UNROLL for (int r = 0; r < NZ; ++r)
                     FK_UNROLL for (int c = 0; c < NZ; ++c)
-                        S[r * NZ + c] = (i == 0) ? d[r] * wd[c] : fma(d[r], wd[c], S[r * NZ + c]);
+                        if (c >= r) S[r * NZ + c] = (i == 0) ? d[r] * wd[c] : fma(d[r], wd[c], S[r * NZ + c]);
                 if (i >= 1) {
                     const int k = (i - 1) % NX;
                     FK_UNROLL for (int r = 0; r < NX; ++r) {
@@ -250,6 +251,9 @@ FK_HD int ukf_linear_step_v3(double (&x)[NX], double (&P)[NX * (NX + 1) / 2], Lo
                 }
                 FK_STAGE();
             }
+            FK_UNROLL for (int r = 0; r < NZ; ++r)
+                FK_UNROLL for (int c = 0; c < NZ; ++c)
+                    if (c < r) S[r * NZ + c] = S[c * NZ + r];
             FK_UNROLL for (int e = 0; e < NZ * NZ; ++e) FK_OPAQUE(S[e]);
             FK_UNROLL for (int e = 0; e < NX * NZ; ++e) FK_OPAQUE(K[e]);
             const auto mv = fresh(S[NZ * NZ - 1]);
@@ -339,15 +343,14 @@ FK_HD int ukf_linear_rts_gain_v3(double (&x)[NX], const double (&P)[NX * (NX + 1
         FK_STAGE();
     }
     // sweep 2: Pb = sum Wc_i y_i y_i' (+ Q), Pxb = sum Wc_i (sigma_i - x) y_i', y_i = sf_i - xb
+    FK_UNROLL for (int r = 0; r < NX; ++r) Fx[r] -= xb[r];                     // y_i = (F x - xb) +- F l_k
     FK_UNROLL for (int r = 0; r < NX; ++r) FK_OPAQUE(Fx[r]);
     {
         FK_UNROLL for (int i = 0; i < 2 * NX + 1; ++i) {
             const double wc = fresh(i ? Pb[PL - 1] : xb[NX - 1]).Wc[i];   // a fresh view per point, behind the previous point
             double y[NX], wy[NX];
-            FK_UNROLL for (int r = 0; r < NX; ++r) {
-                const double v = (i == 0) ? Fx[r] : (i <= NX) ? Fx[r] + FL[r][(i - 1) % NX] : Fx[r] - FL[r][(i - 1) % NX];
-                y[r] = v - xb[r];
-            }
+            FK_UNROLL for (int r = 0; r < NX; ++r)
+                y[r] = (i == 0) ? Fx[r] : (i <= NX) ? Fx[r] + FL[r][(i - 1) % NX] : Fx[r] - FL[r][(i - 1) % NX];
             FK_UNROLL for (int r = 0; r < NX; ++r) wy[r] = wc * y[r];
             FK_UNROLL for (int a2 = 0; a2 < NX; ++a2)
                 FK_UNROLL for (int b = 0; b < NX; ++b)
