@@ -20,25 +20,22 @@
 
 namespace fk {
 
-// sqrt(d) and 1 / sqrt(d) together; 1 / d.  On the device: v_rsq_f64 / v_rcp_f64 seeds (~2^-26) refined by one
-// Goldschmidt step and one residual correction (11 / 5 instructions; the compiler's correctly-rounded sqrt followed by
-// a correctly-rounded division is ~28, with range scaling the pivots of a covariance factor do not need).  The results
-// are within an ulp or two of the rounded ones -- far inside the 1e-10 bar, and the factor feeds sums that the
-// reference evaluates in BLAS order anyway.  A non-positive or non-finite pivot yields NaN / inf like sqrt would; the
-// caller's pivot test reports it (ST_NOT_PD).  On the host (tests/hostcheck): the plain operations.
+// sqrt(d) and 1 / sqrt(d) together; 1 / d.  On the device: the v_rsq_f64 / v_rcp_f64 seeds (2^-24 relative, measured:
+// tools/experiments/rsq_seed_accuracy.hip, profiles/r03/rsq_seed_accuracy.jsonl) refined by ONE Goldschmidt / Newton step:
+// 4e-15 / 2e-15 relative, 7 / 3 instructions (the compiler's correctly-rounded sqrt followed by a correctly-rounded division
+// is ~28, with range scaling the pivots of a covariance factor do not need; a second step reaches 1e-16 and costs four more
+// instructions on the critical path of every column).  The factor feeds covariance sums without cancellation and a mean in
+// which the +l_k and -l_k terms cancel to first order, so its error arrives unamplified: far inside the 1e-10 bar.  A
+// non-positive or non-finite pivot yields NaN / inf like sqrt would; the caller's pivot test reports it (ST_NOT_PD).  On the
+// host (tests/hostcheck): the plain operations.
 FK_HD void sqrt_rsqrt(double d, double &s, double &inv)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
     const double y = __builtin_amdgcn_rsq(d);
     double g = d * y, h = 0.5 * y;
     const double r = fma(-h, g, 0.5);
-    g = fma(g, r, g);
+    s = fma(g, r, g);
     h = fma(h, r, h);
-    const double e = fma(-g, g, d);
-    g = fma(e, h, g);
-    const double r2 = fma(-h, g, 0.5);
-    h = fma(h, r2, h);
-    s = g;
     inv = h + h;
 #else
     s = sqrt(d);
@@ -49,10 +46,8 @@ FK_HD void sqrt_rsqrt(double d, double &s, double &inv)
 FK_HD double rcp_refined(double d)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    double r = __builtin_amdgcn_rcp(d);
-    double e = fma(-d, r, 1.0);
-    r = fma(r, e, r);
-    e = fma(-d, r, 1.0);
+    const double r = __builtin_amdgcn_rcp(d);
+    const double e = fma(-d, r, 1.0);
     return fma(r, e, r);
 #else
     return 1.0 / d;
@@ -78,6 +73,33 @@ FK_HD bool chol_packed_rs(const double (&P)[NX * (NX + 1) / 2], double scale, do
                 FK_UNROLL for (int k = 0; k < NX; ++k)
                     if (k < j) t = fma(-L[sym_idx<NX>(i, k)], L[sym_idx<NX>(j, k)], t);
                 L[sym_idx<NX>(i, j)] = t * inv;
+            }
+    }
+    return pd;
+}
+
+// ldlt_packed (fk_math_sym.hpp) with the pivots' reciprocals from rcp_refined
+template <int N>
+FK_HD bool ldlt_packed_rs(double (&A)[N * (N + 1) / 2], double (&d)[N], double (&dinv)[N])
+{
+    bool pd = true;
+    FK_UNROLL for (int j = 0; j < N; ++j) {
+        double dj = A[sym_idx<N>(j, j)];
+        FK_UNROLL for (int k = 0; k < N; ++k)
+            if (k < j) {
+                const double l = A[sym_idx<N>(j, k)];
+                dj = fma(-l * l, d[k], dj);
+            }
+        pd = pd && (dj > 0.0);
+        d[j] = dj;
+        const double di = rcp_refined(dj);
+        dinv[j] = di;
+        FK_UNROLL for (int i = 0; i < N; ++i)
+            if (i > j) {
+                double t = A[sym_idx<N>(i, j)];
+                FK_UNROLL for (int k = 0; k < N; ++k)
+                    if (k < j) t = fma(-(A[sym_idx<N>(i, k)] * d[k]), A[sym_idx<N>(j, k)], t);
+                A[sym_idx<N>(i, j)] = t * di;
             }
     }
     return pd;
@@ -381,7 +403,7 @@ FK_HD int ukf_linear_rts_gain_v3(double (&x)[NX], const double (&P)[NX * (NX + 1
     {
         double Lp[PL], d[NX], dinv[NX];
         FK_UNROLL for (int e = 0; e < PL; ++e) Lp[e] = Pb[e];
-        if (!ldlt_packed<NX>(Lp, d, dinv)) st |= ST_NOT_PD;
+        if (!ldlt_packed_rs<NX>(Lp, d, dinv)) st |= ST_NOT_PD;
         FK_UNROLL for (int r = 0; r < NX; ++r) {
             double row[NX];
             FK_UNROLL for (int c = 0; c < NX; ++c) row[c] = K[r * NX + c];

@@ -278,6 +278,13 @@ ukf_linear_rts_kernel(const UkfRtsArgs a, const double *__restrict__ pF, const d
     __shared__ double s_model[SharedModel::SIZE + 2 * KS];
     __shared__ double s_tile[COOP ? (BLOCK / 64) * 64 * NN : 1];
     __shared__ double s_dma[(BLOCK / 64) * DBUF];
+    // PARK (dim_x >= 7, wherever the LDS holds it): the smoothed state of step k+1 waits in LDS ([element][lane], wave-private)
+    // between its birth at the end of step k+1 and its one use in step k's correction -- these classes spill, and 44 / 54
+    // doubles less to carry is 0.5 KB less scratch per lane.  (At dim_x <= 6, where the state rides in AGPRs, parking it
+    // removes 190 of 2530 VALU instructions per step and is NOT faster: 1.83 against 1.81 ms -- measured, not kept.)
+    constexpr bool PARK = NX >= 7 && ((COOP ? (BLOCK / 64) * 64 * NN : 1) + (BLOCK / 64) * DBUF + (BLOCK / 64) * 64 * (NX + PL)) * 8 + 4096 <= 160 * 1024;
+    __shared__ double s_park[PARK ? (BLOCK / 64) * 64 * (NX + PL) : 1];
+    double *park = s_park + (PARK ? (threadIdx.x >> 6) * 64 * (NX + PL) + (threadIdx.x & 63u) : 0);
     const long N = a.N;
     const long blk0 = (long)blockIdx.x * BLOCK;
     const long left = N - blk0;
@@ -440,6 +447,10 @@ ukf_linear_rts_kernel(const UkfRtsArgs a, const double *__restrict__ pF, const d
     // landed: nothing of the prologue is pending at the loop header
     FK_UNROLL for (int c = 0; c < NX; ++c) asm volatile("" ::"v"(xn[c]));
     FK_UNROLL for (int e = 0; e < PL; ++e) asm volatile("" ::"v"(Pn[e]));
+    if constexpr (PARK) {
+        FK_UNROLL for (int c = 0; c < NX; ++c) park[c * 64] = xn[c];
+        FK_UNROLL for (int e = 0; e < PL; ++e) park[(NX + e) * 64] = Pn[e];
+    }
     _Pragma("nounroll") for (long t = a.T - 2; t >= 0; --t) {
         double x[NX], P[PL], K[NN];
         if constexpr (DMA) {
@@ -456,9 +467,18 @@ ukf_linear_rts_kernel(const UkfRtsArgs a, const double *__restrict__ pF, const d
         {
             double xb[NX], Pb[PL];
             st |= ukf_linear_rts_gain_v3<NX>(x, P, a.scale, xb, Pb, K, fresh);
-            ukf_linear_rts_correct<NX>(x, P, xn, Pn, xb, Pb, K);
-            FK_UNROLL for (int c = 0; c < NX; ++c) xn[c] = x[c];
-            FK_UNROLL for (int e = 0; e < PL; ++e) Pn[e] = P[e];
+            if constexpr (PARK) {
+                double xq[NX], Pq[PL];
+                FK_UNROLL for (int c = 0; c < NX; ++c) xq[c] = park[c * 64];
+                FK_UNROLL for (int e = 0; e < PL; ++e) Pq[e] = park[(NX + e) * 64];
+                ukf_linear_rts_correct<NX>(x, P, xq, Pq, xb, Pb, K);
+                FK_UNROLL for (int c = 0; c < NX; ++c) park[c * 64] = x[c];
+                FK_UNROLL for (int e = 0; e < PL; ++e) park[(NX + e) * 64] = P[e];
+            } else {
+                ukf_linear_rts_correct<NX>(x, P, xn, Pn, xb, Pb, K);
+                FK_UNROLL for (int c = 0; c < NX; ++c) xn[c] = x[c];
+                FK_UNROLL for (int e = 0; e < PL; ++e) Pn[e] = P[e];
+            }
         }
         if constexpr (DMA) {
             // in front of this step's stores: nothing else of this wave is in flight, so the wait is for the fetch alone
@@ -475,6 +495,10 @@ ukf_linear_rts_kernel(const UkfRtsArgs a, const double *__restrict__ pF, const d
             store_full(a.ps, t, Pf);
         }
         if (a.Ks) store_full(a.Ks, t, K);
+    }
+    if constexpr (PARK) {
+        FK_UNROLL for (int c = 0; c < NX; ++c) xn[c] = park[c * 64];
+        FK_UNROLL for (int e = 0; e < PL; ++e) Pn[e] = park[(NX + e) * 64];
     }
     if (live && a.status) {
         if (!all_finite<NX>(xn) || !all_finite<PL>(Pn)) st |= ST_NONFINITE;
