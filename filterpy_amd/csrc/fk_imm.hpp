@@ -78,7 +78,13 @@ FK_HD void imm_predict(double (&xs)[NM][NX], double (&Ps)[NM][NX * (NX + 1) / 2]
     // held twice (same operations and order per element as the reference's loop over filters).
     double w[NM][NM], mx[NM][NX], y[NM][NM][NX];
     FK_UNROLL for (int j = 0; j < NM; ++j) {
-        FK_UNROLL for (int i = 0; i < NM; ++i) w[i][j] = (M[i * NM + j] * mu[i]) / cbar[j];
+        // one reciprocal per column, not NM divisions (a subnormal cbar is scaled first, like the sum in imm_update)
+        const bool tiny = cbar[j] < 0x1p-500;
+        const double rc = fk_rcp(tiny ? cbar[j] * 0x1p600 : cbar[j]);
+        FK_UNROLL for (int i = 0; i < NM; ++i) {
+            const double num = M[i * NM + j] * mu[i];
+            w[i][j] = (tiny ? num * 0x1p600 : num) * rc;
+        }
         FK_UNROLL for (int r = 0; r < NX; ++r) {
             double acc = 0.0;
             FK_UNROLL for (int i = 0; i < NM; ++i) acc = fma(xs[i][r], w[i][j], acc);
@@ -121,23 +127,32 @@ FK_HD int imm_update(double (&xs)[NM][NX], double (&Ps)[NM][NX * (NX + 1) / 2], 
     const double log2pi_m = m * 1.8378770664093453;
     FK_UNROLL for (int j = 0; j < NM; ++j) {
         double K[NX * NZ], y[NZ], S[NZ * NZ], Lf[NZ * NZ], dinv[NZ];
-        st |= kf_update_sym<NX, NZ>(xs[j], Ps[j], z, mods[j], K, y, S, Lf, dinv);
+        st |= kf_update_sym<NX, NZ, true>(xs[j], Ps[j], z, mods[j], K, y, S, Lf, dinv);
         double logdet = 0.0, q = 0.0;
         if constexpr (NZ == 1) {
             logdet = log(S[0]);
             q = y[0] * y[0] * dinv[0];
         } else {
-            double w[NZ];
+            // ln |S| = -ln prod_i (1 / d_i): ONE logarithm of the product of the reciprocal pivots the factorisation already
+            // holds, instead of a division and a logarithm per pivot (a double-precision log is ~80 VALU instructions, a
+            // division ~25: at (4,2) x 2 filters those were 440 of the bank-step's 1480).  The product is carried as
+            // mantissa x 2^exponent (frexp: two instructions per pivot), so it cannot leave the range, and there is no
+            // branch -- a fall-back path inside the time loop splits its one basic block and the allocator spills 0.5 KB.
+            double w[NZ], pm = 1.0;
+            int pe = 0;
             FK_UNROLL for (int i = 0; i < NZ; ++i) {
                 double acc = y[i];
                 FK_UNROLL for (int k2 = 0; k2 < NZ; ++k2)
                     if (k2 < i) acc = fma(-Lf[i * NZ + k2], w[k2], acc);
                 w[i] = acc;
                 if (i < m) {
-                    logdet += log(1.0 / dinv[i]);
+                    int e;
+                    pm *= frexp(dinv[i], &e);
+                    pe += e;
                     q = fma(acc * acc, dinv[i], q);
                 }
             }
+            logdet = -fma((double)pe, 0.6931471805599453, log(pm));
         }
         double lj = exp(-0.5 * (log2pi_m + logdet + q));
         if (lj == 0.0) lj = 2.2250738585072014e-308;
@@ -147,7 +162,13 @@ FK_HD int imm_update(double (&xs)[NM][NX], double (&Ps)[NM][NX * (NX + 1) / 2], 
     }
     double sum = 0.0;
     FK_UNROLL for (int j = 0; j < NM; ++j) { mu[j] = cbar[j] * L[j]; sum += mu[j]; }
-    FK_UNROLL for (int j = 0; j < NM; ++j) mu[j] /= sum;
+    // mu /= sum as a multiplication by the reciprocal (fk_rcp).  Every likelihood floored at DBL_MIN makes the sum subnormal,
+    // whose reciprocal overflows: such a bank is scaled by 2^600 first (exact), by selects -- no branch in the time loop.
+    {
+        const bool tiny = sum < 0x1p-500;
+        const double rsum = fk_rcp(tiny ? sum * 0x1p600 : sum);
+        FK_UNROLL for (int j = 0; j < NM; ++j) mu[j] = (tiny ? mu[j] * 0x1p600 : mu[j]) * rsum;
+    }
     return st;
 }
 

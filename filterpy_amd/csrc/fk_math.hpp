@@ -49,6 +49,23 @@ namespace fk {
 
 enum : int { ST_NOT_PD = 1, ST_NONFINITE = 2, ST_OVERRUN = 4, ST_INTERNAL = 8 };
 
+// 1 / d for the arithmetic-bound kernels: the v_rcp_f64 seed (2^-24, tools/experiments/rsq_seed_accuracy.hip) and two Newton
+// steps -- 1.1e-16 relative, five instructions; the compiler's IEEE division is ~25 with its scaling and fix-up.  No range
+// scaling: the callers divide by sums of probabilities and pivots of covariances, nowhere near the ends of the exponent range
+// (a zero or non-finite divisor yields inf / NaN like the division would).  On the host: the plain division.
+FK_HD double fk_rcp(double d)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    double r = __builtin_amdgcn_rcp(d);
+    double e = fma(-d, r, 1.0);
+    r = fma(r, e, r);
+    e = fma(-d, r, 1.0);
+    return fma(r, e, r);
+#else
+    return 1.0 / d;
+#endif
+}
+
 // C[R x C] = A[R x K] * B[K x C]
 template <int R, int K, int C>
 FK_HD void matmul(const double (&A)[R * K], const double (&B)[K * C], double (&Cm)[R * C])
@@ -89,7 +106,9 @@ FK_HD void matvec(const double (&A)[R * K], const double (&v)[K], double (&out)[
 // lower triangle is read.  On return the strict lower triangle holds L (unit
 // diagonal implied), d[j] = D[j], dinv[j] = 1/D[j].  Returns true iff every
 // pivot is > 0, i.e. the matrix is SPD.
-template <int M>
+// FAST: the pivots' reciprocals from fk_rcp (1e-16, five instructions) instead of the IEEE division (~25) -- for the
+// arithmetic-bound callers (IMM); the memory-bound ones keep the division.
+template <int M, bool FAST = false>
 FK_HD bool ldlt2(double (&A)[M * M], double (&d)[M], double (&dinv)[M])
 {
     bool pd = true;
@@ -101,7 +120,7 @@ FK_HD bool ldlt2(double (&A)[M * M], double (&d)[M], double (&dinv)[M])
         }
         pd = pd && (dj > 0.0);
         d[j] = dj;
-        const double di = 1.0 / dj;
+        const double di = FAST ? fk_rcp(dj) : 1.0 / dj;
         dinv[j] = di;
         FK_UNROLL for (int i = j + 1; i < M; ++i) {
             double s = A[i * M + j];

@@ -65,7 +65,7 @@ FK_HD void kf_predict_sym(double (&x)[NX], double (&U)[NX * (NX + 1) / 2], const
 }
 
 // Returns status bits.  K, y, S (full m x m) and the factorisation are outputs like kf_update.
-template <int NX, int NZ, class Model>
+template <int NX, int NZ, bool FAST_RCP = false, class Model>
 FK_HD int kf_update_sym(double (&x)[NX], double (&U)[NX * (NX + 1) / 2], const double (&z)[NZ], const Model &M,
                         double (&K)[NX * NZ], double (&y)[NZ], double (&S)[NZ * NZ],
                         double (&Lf)[NZ * NZ], double (&dinv)[NZ], bool rj_diag = false)
@@ -96,7 +96,7 @@ FK_HD int kf_update_sym(double (&x)[NX], double (&U)[NX * (NX + 1) / 2], const d
     FK_STAGE();
     FK_UNROLL for (int i = 0; i < NX * NZ; ++i) K[i] = PHT[i];
     if constexpr (NZ == 1) {
-        const double si = 1.0 / S[0];
+        const double si = FAST_RCP ? fk_rcp(S[0]) : 1.0 / S[0];
         if (!(S[0] != 0.0)) st |= ST_NOT_PD;
         dinv[0] = si;
         Lf[0] = S[0];
@@ -104,7 +104,7 @@ FK_HD int kf_update_sym(double (&x)[NX], double (&U)[NX * (NX + 1) / 2], const d
     } else {
         double d[NZ];
         FK_UNROLL for (int i = 0; i < NZ * NZ; ++i) Lf[i] = S[i];
-        if (!ldlt2<NZ>(Lf, d, dinv)) st |= ST_NOT_PD;
+        if (!ldlt2<NZ, FAST_RCP>(Lf, d, dinv)) st |= ST_NOT_PD;
         solve_rows_ldlt<NX, NZ>(Lf, dinv, K);
     }
     FK_STAGE();
