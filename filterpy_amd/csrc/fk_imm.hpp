@@ -133,26 +133,18 @@ FK_HD int imm_update(double (&xs)[NM][NX], double (&Ps)[NM][NX * (NX + 1) / 2], 
             logdet = log(S[0]);
             q = y[0] * y[0] * dinv[0];
         } else {
-            // ln |S| = -ln prod_i (1 / d_i): ONE logarithm of the product of the reciprocal pivots the factorisation already
-            // holds, instead of a division and a logarithm per pivot (a double-precision log is ~80 VALU instructions, a
-            // division ~25: at (4,2) x 2 filters those were 440 of the bank-step's 1480).  The product is carried as
-            // mantissa x 2^exponent (frexp: two instructions per pivot), so it cannot leave the range, and there is no
-            // branch -- a fall-back path inside the time loop splits its one basic block and the allocator spills 0.5 KB.
-            double w[NZ], pm = 1.0;
-            int pe = 0;
+            // ln |S| by ONE logarithm (logdet_from_dinv, fk_math.hpp): at (4,2) x 2 filters the division and logarithm per
+            // pivot were 440 of the bank-step's 1480 VALU instructions.  No branch: a fall-back path inside the time loop
+            // splits its one basic block and the allocator spills 0.5 KB.
+            double w[NZ];
             FK_UNROLL for (int i = 0; i < NZ; ++i) {
                 double acc = y[i];
                 FK_UNROLL for (int k2 = 0; k2 < NZ; ++k2)
                     if (k2 < i) acc = fma(-Lf[i * NZ + k2], w[k2], acc);
                 w[i] = acc;
-                if (i < m) {
-                    int e;
-                    pm *= frexp(dinv[i], &e);
-                    pe += e;
-                    q = fma(acc * acc, dinv[i], q);
-                }
+                if (i < m) q = fma(acc * acc, dinv[i], q);
             }
-            logdet = -fma((double)pe, 0.6931471805599453, log(pm));
+            logdet = logdet_from_dinv<NZ>(dinv, m);
         }
         double lj = exp(-0.5 * (log2pi_m + logdet + q));
         if (lj == 0.0) lj = 2.2250738585072014e-308;

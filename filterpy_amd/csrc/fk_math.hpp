@@ -49,6 +49,24 @@ namespace fk {
 
 enum : int { ST_NOT_PD = 1, ST_NONFINITE = 2, ST_OVERRUN = 4, ST_INTERNAL = 8 };
 
+// ln |S| from the reciprocal pivots of its L D L' factorisation: -ln prod_i (1 / d_i), ONE logarithm instead of a division and a
+// logarithm per pivot (a double-precision log is ~80 VALU instructions).  The product is carried as mantissa x 2^exponent
+// (frexp: two instructions per pivot), so it cannot leave the exponent range and needs no fall-back branch.  m: the run-time
+// number of pivots that count (padded instantiations).
+template <int NZ>
+FK_HD double logdet_from_dinv(const double (&dinv)[NZ], int m)
+{
+    double pm = 1.0;
+    int pe = 0;
+    FK_UNROLL for (int i = 0; i < NZ; ++i)
+        if (i < m) {
+            int e;
+            pm *= frexp(dinv[i], &e);
+            pe += e;
+        }
+    return -fma((double)pe, 0.6931471805599453, log(pm));
+}
+
 // 1 / d for the arithmetic-bound kernels: the v_rcp_f64 seed (2^-24, tools/experiments/rsq_seed_accuracy.hip) and two Newton
 // steps -- 1.1e-16 relative, five instructions; the compiler's IEEE division is ~25 with its scaling and fix-up.  No range
 // scaling: the callers divide by sums of probabilities and pivots of covariances, nowhere near the ends of the exponent range

@@ -268,9 +268,9 @@ kf_fast_kernel(const KfArgs a, const double *__restrict__ pF, const double *__re
                         FK_UNROLL for (int k2 = 0; k2 < NZ; ++k2)
                             if (k2 < i) acc = fma(-Lf[i * NZ + k2], w[k2], acc);
                         w[i] = acc;
-                        logdet += log(1.0 / dinv[i]);
                         q = fma(acc * acc, dinv[i], q);
                     }
+                    logdet = logdet_from_dinv<NZ>(dinv, NZ);            // one logarithm, not a division and a logarithm per pivot
                 }
                 if constexpr (CARRY) {
                     FK_UNROLL for (int i = 0; i < NX * NZ; ++i) { cK[i] = hu ? K[i] : cK[i]; K[i] = cK[i]; }

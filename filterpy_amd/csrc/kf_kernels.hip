@@ -144,11 +144,9 @@ kf_kernel(const KfArgs a,
                                 FK_UNROLL for (int k2 = 0; k2 < NZ; ++k2)
                                     if (k2 < i) acc = fma(-Lf[i * NZ + k2], w[k2], acc);
                                 w[i] = acc;
-                                if (EXACT || i < m) {
-                                    logdet += log(1.0 / dinv[i]);
-                                    q = fma(acc * acc, dinv[i], q);
-                                }
+                                if (EXACT || i < m) q = fma(acc * acc, dinv[i], q);
                             }
+                            logdet = logdet_from_dinv<NZ>(dinv, EXACT ? NZ : m);
                         }
                         FK_UNROLL for (int i = 0; i < NX * NZ; ++i) cK[i] = K[i];
                         FK_UNROLL for (int i = 0; i < NZ * NZ; ++i) { cS[i] = S[i]; cSI[i] = SI[i]; }

@@ -26,6 +26,7 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/rs_stats 
 timeout 1500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_cfg -- python $R/tools/bench_configs.py --configs 3456789abe --layouts soa,aos > $O/prof_cfg.log 2>&1; echo "cfg rc=$?"
 cd $R
 grep -E "^\{" $O/prof_cfg.log > $O/configs_all.jsonl; wc -l $O/configs_all.jsonl
+timeout 300 python tools/bench_ukf.py --dims 6x3,4x2,2x2,8x4,9x3,9x4 > $O/ukf_kernels.jsonl 2> $O/ukf_kernels.err; timeout 200 python tools/bench_ukf.py --dims 6x3 --N 1000000 --T 20 >> $O/ukf_kernels.jsonl 2>> $O/ukf_kernels.err; wc -l $O/ukf_kernels.jsonl
 for sh in "1000 8000" "125 8000" "125 8000000"; do set -- $sh; timeout 300 python tools/bench_c5.py --filters $1 --particles $2 > $O/bench_c5_$1x$2.json 2>/dev/null; cut -c1-400 $O/bench_c5_$1x$2.json; done
 timeout 300 python bench.py --steps 10 --warmup 3 --force-dist --no-cpu > $O/bench_force_dist.json 2> $O/bench_force_dist.err; echo "force-dist rc=$?"; grep -E "RCCL|rccl" $O/bench_force_dist.err | head -3
 timeout 300 python tools/bench_c5.py --filters 125 --particles 8000 --force-dist > $O/bench_c5_force_dist.json 2> $O/bench_c5_force_dist.err; echo "c5 force-dist rc=$?"
