@@ -348,13 +348,16 @@ ukf_linear_rts_kernel(const UkfRtsArgs a, const double *__restrict__ pF, const d
             FK_UNROLL for (int e = 0; e < PL; ++e) { asm volatile("" : "+v"(f.P[e])); P[e] = f.P[e]; }
         }
     };
+    // (DMA, element-major: a lane past the last track takes whatever the fetch left in its LDS slot -- not a copy of the last
+    //  track like the register fetch gives it -- so its stores, which would land on the last track, are predicated; hipcc
+    //  counts no vector-memory operation in that loop, so the branch costs no wait)
     auto store_x = [&](long t, const double (&x)[NX]) {
         if constexpr (COOP) wave_store_aos_flat<NX>(x, a.xs + t * N * NX + blk0 * NX, wave_row0, tile, lane, last_row);
-        else store_rec<NX, 1, LAYOUT, EXACT>(x, a.xs + t * N * n, ln, n, 1);
+        else if (!DMA || live) store_rec<NX, 1, LAYOUT, EXACT>(x, a.xs + t * N * n, ln, n, 1);
     };
     auto store_full = [&](double *arr, long t, const double (&M)[NN]) {
         if constexpr (COOP) wave_store_aos_flat<NN>(M, arr + t * N * NN + blk0 * NN, wave_row0, tile, lane, last_row);
-        else store_rec<NX, NX, LAYOUT, EXACT>(M, arr + t * N * n * n, ln, n, n);
+        else if (!DMA || live) store_rec<NX, NX, LAYOUT, EXACT>(M, arr + t * N * n * n, ln, n, n);
     };
 
     // ---- LDS-DMA fetch of the filtered state of step t (DMA instantiations)
@@ -524,8 +527,13 @@ ukf_linear_rts_kernel(const UkfRtsArgs a, const double *__restrict__ pF, const d
 #if FK_UKF_HAS(3)
 int ukf_rts_launch_small(const UkfRtsArgs &a, const double *F, const double *Q, const double *Wm, const double *Wc, int layout, bool exact, hipStream_t s)
 {
-    // FK_UKF_DMA=0: the exact classes without the LDS-DMA fetch of the next state (A/B)
-    static const bool dma = !(getenv("FK_UKF_DMA") && getenv("FK_UKF_DMA")[0] == '0');
+    // FK_UKF_DMA=0: the exact classes without the LDS-DMA fetch of the next state (A/B).  The fetch moves 16-byte units: it
+    // needs 16-byte aligned arrays and, element-major, an even track count -- with an odd one every element row starts 8
+    // bytes off and the last unit of the last row straddles the end of the array (the range check drops it whole, and the last
+    // track's last element with it).  Other calls take the same kernel with the register fetch.
+    static const bool dma_on = !(getenv("FK_UKF_DMA") && getenv("FK_UKF_DMA")[0] == '0');
+    const bool dma = dma_on && reinterpret_cast<uintptr_t>(a.Xs) % 16 == 0 && reinterpret_cast<uintptr_t>(a.Ps) % 16 == 0 &&
+                     (layout != FK_LAYOUT_SOA || a.N % 2 == 0);
     if (a.n <= 2) FK_UKF_GO(2, true);
     else if (a.n <= 4) FK_UKF_GO(4, true);
     else FK_UKF_GO(6, true);

@@ -106,3 +106,40 @@ def test_fused_linear_ukf_goldens(layout):
         for trk in (0, 64, N - 1):
             assert rel_err_rows(mu[:, trk], g[p + "mu"]) < ukf_tol(ci, "mu"), (ci, trk)
             assert rel_err_rows(cov[:, trk], g[p + "cov"]) < ukf_tol(ci, "cov"), (ci, trk)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("layout", ["soa", "aos"])
+@pytest.mark.parametrize("nb", [1, 2, 3, 63, 64, 65, 130, 257, 513])
+def test_fused_linear_ukf_smoother_goldens_every_bank_size(layout, nb):
+    """fk_ukf_linear_rts_f64 (UKF.py:634-739) on the reference's own filter output, banks of every shape of tail: one track,
+    odd and even counts, one short of / one past a wave and a workgroup.  First, last and a middle track of every bank
+    against the live-reference golden -- the LDS-DMA fetch of the exact classes reads 16-byte units, and an odd track
+    count makes the last unit of the last element row straddle the end of the array (found by
+    test_gpu_variants.py::test_ukf_rts_smoother_goldens on a single filter: such banks take the register fetch)."""
+    import torch
+    from filterpy_amd import _engine as E
+    from gpu_util import tile_tracks
+    g = golden("ukf_merwe")
+    for ci, n, m, alpha, beta, kappa in _cases():
+        if not E.ukf_linear_rts_supported(n):
+            continue
+        p = f"c{ci}_"
+        lam = alpha ** 2 * (n + kappa) - n
+        mu, cov = g[p + "mu"], g[p + "cov"]
+        T = mu.shape[0]
+        Xs = E.to_records(tile_tracks(mu, nb, 1), layout, 1)
+        Ps = E.to_records(tile_tracks(cov, nb, 1), layout, 1)
+        xs, ps = E.alloc_records((T,), nb, n, layout), E.alloc_records((T,), nb, n * n, layout)
+        Ks = E.alloc_records((T,), nb, n * n, layout)
+        st = torch.zeros(nb, dtype=torch.int32, device=Xs.device)
+        E.ukf_linear_rts(n, nb, T, layout, lam + n, E.dev(g[p + "F"]), E.dev(g[p + "Q"]), E.dev(g[p + "Wm"]),
+                         E.dev(g[p + "Wc"]), Xs, Ps, xs, ps, K=Ks, status=st)
+        torch.cuda.synchronize()
+        assert not st.any(), (ci, nb)
+        hx, hP = E.from_records(xs, layout, 1, (n,)), E.from_records(ps, layout, 1, (n, n))
+        hK = E.from_records(Ks, layout, 1, (n, n))
+        for trk in sorted({0, nb // 2, nb - 1}):
+            assert rel_err_rows(hx[:, trk], g[p + "rts_x"]) < ukf_tol(ci, "rts_x"), (ci, nb, trk)
+            assert rel_err_rows(hP[:, trk], g[p + "rts_P"]) < ukf_tol(ci, "rts_P"), (ci, nb, trk)
+            assert rel_err_rows(hK[:-1, trk], g[p + "rts_K"][:-1]) < ukf_tol(ci, "rts_K"), (ci, nb, trk)

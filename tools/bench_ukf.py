@@ -63,7 +63,7 @@ def run(n, m, N, T, layout, dense):
         E.ukf_linear_batch(n, m, N, T, layout, lam + n, *dd, z, x, P, means=means, covs=covs, status=st)
     ms = timeit(fwd)
     assert not st.any()
-    trk = 7
+    trk = N - 1                    # the bank's last track: the one a tail-handling mistake would hit
     zs_h = (z[:, trk] if layout == "aos" else z[:, :, trk]).cpu().numpy()
     x0h = (x0[trk] if layout == "aos" else x0[:, trk]).cpu().numpy()
     mu_ref, cov_ref = ukf_oracle.ukf_batch_filter(x0h, 10 * np.eye(n), list(zs_h), lambda s, d: F @ s, lambda s: H @ s,
