@@ -44,10 +44,11 @@ constexpr double WH_SANE_LO = 0x1p-900, WH_SANE_HI = 0x1p900;
 
 typedef unsigned long long wh_u64;
 
-// The arithmetic below avoids the quarter-rate fp64 instructions of gfx950 (v_ldexp_f64, v_floor_f64, v_cvt_*: 16
-// clocks per wave against 4 for an add / mul / fma) -- a first cut built on them spent 9k of its 32k clocks per filter
-// classifying --: scalings are multiplications by a power of two assembled from its exponent field, roundings and
-// integer conversions are additions of 2^52 (every integer involved is below 2^52: see wh_classify / wh_segment).
+// The arithmetic below avoids v_ldexp_f64 / v_floor_f64 / v_cvt_* sequences: scalings are multiplications by a power of two
+// assembled from its exponent field, roundings and integer conversions are additions of 2^52 (every integer involved is below
+// 2^52: see wh_classify / wh_segment) -- one instruction where floor + convert are two.  (The first cut built on them spent 9k
+// of its 32k clocks per filter classifying; they were taken for quarter-rate instructions then.  Measured since:
+// tools/experiments/valu_latency.hip -- on gfx950 they issue at the full rate; only v_rcp / v_rsq_f64 are quarter rate.)
 constexpr double WH_M52 = 0x1p52;
 FK_HD double wh_pow2(int k)                            // 2^k, -1022 <= k <= 1023
 {

@@ -992,7 +992,7 @@ resample_onepass_kernel(const OpArgs a)
         FK_UNROLL for (int q = 0; q < OP_ITEMS; ++q) {
             const double Et = excl + E[q];                                 // exact
             const double e = __builtin_fma(Et, Nu, K);
-            // floor(e) + 1 without the quarter-rate v_floor_f64 / v_cvt_i32_f64: m = e + 1.5 2^52 holds the nearest integer
+            // floor(e) + 1 without a v_floor_f64 / v_cvt_i32_f64 pair: m = e + 1.5 2^52 holds the nearest integer
             // of e in its low mantissa bits (two's complement; -1 < e < Nd < 2^31 where the result is used), dd = e - nearest
             const double m = e + 0x1.8p52;
             const double dd = e - (m - 0x1.8p52);                          // exact, |dd| <= 1/2

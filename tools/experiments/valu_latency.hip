@@ -32,6 +32,15 @@ __global__ void __launch_bounds__(256) chain_kernel(double *out, long long *clk,
                     else if (OP == 3) asm volatile("v_rsq_f64 %0, %0" : "+v"(v[c]));
                     else if (OP == 4) asm volatile("v_rcp_f64 %0, %0" : "+v"(v[c]));
                     else if (OP == 5) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(reinterpret_cast<float &>(v[c])) : "v"((float)b), "v"((float)a));
+                    else if (OP == 6) asm volatile("v_floor_f64 %0, %0" : "+v"(v[c]));
+                    else if (OP == 7) asm volatile("v_ldexp_f64 %0, %0, %1" : "+v"(v[c]) : "v"(0));
+                    else if (OP == 8) asm volatile("v_trunc_f64 %0, %0" : "+v"(v[c]));
+                    else if (OP == 9) asm volatile("v_fract_f64 %0, %0" : "+v"(v[c]));
+                    else if (OP == 10) asm volatile("v_cvt_u32_f64 %0, %1" : "=v"(reinterpret_cast<unsigned &>(v[c])) : "v"(v[c]));          // f64 -> u32 (result reused as bits)
+                    else if (OP == 11) asm volatile("v_cvt_f64_u32 %0, %1" : "=v"(v[c]) : "v"(reinterpret_cast<unsigned &>(v[c])));
+                    else if (OP == 12) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(reinterpret_cast<unsigned &>(v[c])) : "v"(3u));
+                    else if (OP == 13) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(v[c]) : "v"(3u), "v"(5u) : "vcc");
+                    else if (OP == 14) asm volatile("v_rndne_f64 %0, %0" : "+v"(v[c]));
                 }
             }
         }
@@ -97,6 +106,15 @@ int main()
         run<4, 4>("v_rcp_f64", w);
         run<1, 5>("v_fma_f32", w);
         run<4, 5>("v_fma_f32", w);
+        run<4, 6>("v_floor_f64", w);
+        run<4, 7>("v_ldexp_f64", w);
+        run<4, 8>("v_trunc_f64", w);
+        run<4, 9>("v_fract_f64", w);
+        run<4, 10>("v_cvt_u32_f64", w);
+        run<4, 11>("v_cvt_f64_u32", w);
+        run<4, 12>("v_mul_lo_u32", w);
+        run<4, 13>("v_mad_u64_u32", w);
+        run<4, 14>("v_rndne_f64", w);
     }
     return 0;
 }
