@@ -12,7 +12,7 @@
 #define FK_UKF_PART 0
 #endif
 #define FK_UKF_HAS(p) (FK_UKF_PART == 0 || FK_UKF_PART == (p))
-// (parts 91 / 92: the forward / smoother kernel templates alone, for one-off instantiations by the tools)
+// (parts 91 / 92: the forward / smoother kernel templates alone, for one-off instantiations: tools/ukf_one_kernel.py)
 #define FK_UKF_FWD (FK_UKF_HAS(1) || FK_UKF_HAS(2) || FK_UKF_PART == 91)
 #define FK_UKF_RTS (FK_UKF_HAS(3) || FK_UKF_HAS(4) || FK_UKF_PART == 92)
 
