@@ -5,13 +5,21 @@
 
 namespace fk {
 
+// FK_QUAD_SWIZZLE (build-time A/B): the broadcast through ds_swizzle_b32 (quad-permute mode: the LDS crossbar, no memory
+// access) instead of v_mov_b32 DPP -- two instructions per double either way, but on the LDS pipe: the multi-lane kernels are
+// bound by VALU issue and a fifth of their VALU instructions are these moves.
 template <int SRC>
 __device__ __forceinline__ double quad_bcast(double v)
 {
     constexpr int ctrl = SRC * 0x55;   // quad_perm:[SRC,SRC,SRC,SRC]
     int lo = __double2loint(v), hi = __double2hiint(v);
+#if defined(FK_QUAD_SWIZZLE)
+    lo = __builtin_amdgcn_ds_swizzle(lo, 0x8000 | ctrl);
+    hi = __builtin_amdgcn_ds_swizzle(hi, 0x8000 | ctrl);
+#else
     lo = __builtin_amdgcn_mov_dpp(lo, ctrl, 0xf, 0xf, true);
     hi = __builtin_amdgcn_mov_dpp(hi, ctrl, 0xf, 0xf, true);
+#endif
     return __hiloint2double(hi, lo);
 }
 

@@ -17,6 +17,9 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+if os.environ.get("FK_BENCH_LIB"):      # A/B of a variant build (csrc/exp_build/*.so) in one lease: this tool only, not the package
+    from filterpy_amd import _abi as _abi_for_variant
+    _abi_for_variant.LIB_PATH = os.path.abspath(os.environ["FK_BENCH_LIB"])
 PEAK = 8000.0
 
 
