@@ -125,17 +125,16 @@ FK_HD int imm_update(double (&xs)[NM][NX], double (&Ps)[NM][NX * (NX + 1) / 2], 
     // S_j -- what a later update(None) turns into that filter's likelihood (kalman_filter.py:511-520, :1203-1226)
     int st = 0;
     const double log2pi_m = m * 1.8378770664093453;
+    // (2 pi)^(-m/2), m = 0..4
+    const double cm = m == 1 ? 0.3989422804014327 : m == 2 ? 0.15915494309189535 : m == 3 ? 0.06349363593424097
+                    : m == 4 ? 0.025330295910584444 : 1.0;
     FK_UNROLL for (int j = 0; j < NM; ++j) {
         double K[NX * NZ], y[NZ], S[NZ * NZ], Lf[NZ * NZ], dinv[NZ];
         st |= kf_update_sym<NX, NZ, true>(xs[j], Ps[j], z, mods[j], K, y, S, Lf, dinv);
-        double logdet = 0.0, q = 0.0;
+        double q = 0.0;
         if constexpr (NZ == 1) {
-            logdet = log(S[0]);
             q = y[0] * y[0] * dinv[0];
         } else {
-            // ln |S| by ONE logarithm (logdet_from_dinv, fk_math.hpp): at (4,2) x 2 filters the division and logarithm per
-            // pivot were 440 of the bank-step's 1480 VALU instructions.  No branch: a fall-back path inside the time loop
-            // splits its one basic block and the allocator spills 0.5 KB.
             double w[NZ];
             FK_UNROLL for (int i = 0; i < NZ; ++i) {
                 double acc = y[i];
@@ -144,12 +143,17 @@ FK_HD int imm_update(double (&xs)[NM][NX], double (&Ps)[NM][NX * (NX + 1) / 2], 
                 w[i] = acc;
                 if (i < m) q = fma(acc * acc, dinv[i], q);
             }
-            logdet = logdet_from_dinv<NZ>(dinv, m);
         }
-        double lj = exp(-0.5 * (log2pi_m + logdet + q));
+        // The density exp(-(m ln 2 pi + ln |S| + q) / 2) as (2 pi)^(-m/2) |S|^(-1/2) exp(-q / 2): |S|^(-1/2) is the root of the
+        // product of the reciprocal pivots the factorisation already holds (rsqrt_det_from_dinv: ~15 instructions), where the
+        // literal form took a division and a double-precision logarithm PER PIVOT (~105 VALU instructions each: 440 of the
+        // 1480 of a (4,2) x 2 bank-step).  No branch anywhere: a fall-back path inside the time loop splits its one basic
+        // block and the allocator spills 0.5 KB.  ln |S| itself is only needed for ll0 (the masked instantiations): one
+        // logarithm of the same product (logdet_from_dinv).
+        double lj = (cm * rsqrt_det_from_dinv<NZ>(dinv, m)) * exp(-0.5 * q);
         if (lj == 0.0) lj = 2.2250738585072014e-308;
         L[j] = lj;
-        if (ll0) ll0[j] = -0.5 * (log2pi_m + logdet);
+        if (ll0) ll0[j] = -0.5 * (log2pi_m + logdet_from_dinv<NZ>(dinv, m));
         FK_STAGE();
     }
     double sum = 0.0;

@@ -67,6 +67,37 @@ FK_HD double logdet_from_dinv(const double (&dinv)[NZ], int m)
     return -fma((double)pe, 0.6931471805599453, log(pm));
 }
 
+// sqrt(prod_i 1 / d_i) = |S|^(-1/2) from the reciprocal pivots: the normalising factor of a Gaussian density WITHOUT a logarithm
+// (mantissa x 2^exponent like logdet_from_dinv; the root of the mantissa -- in [2^-NZ, 2) after evening out the exponent --
+// from the v_rsq_f64 seed, one Goldschmidt step and a residual correction: 1e-16, tools/experiments/rsq_seed_accuracy.hip;
+// on the host the plain sqrt).
+template <int NZ>
+FK_HD double rsqrt_det_from_dinv(const double (&dinv)[NZ], int m)
+{
+    double pm = 1.0;
+    int pe = 0;
+    FK_UNROLL for (int i = 0; i < NZ; ++i)
+        if (i < m) {
+            int e;
+            pm *= frexp(dinv[i], &e);
+            pe += e;
+        }
+    const int odd = pe & 1;
+    pm = odd ? pm + pm : pm;
+    pe -= odd;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const double y = __builtin_amdgcn_rsq(pm);
+    double g = pm * y, h = 0.5 * y;
+    const double r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    g = fma(fma(-g, g, pm), h, g);
+#else
+    const double g = sqrt(pm);
+#endif
+    return ldexp(g, pe / 2);
+}
+
 // 1 / d for the arithmetic-bound kernels: the v_rcp_f64 seed (2^-24, tools/experiments/rsq_seed_accuracy.hip) and two Newton
 // steps -- 1.1e-16 relative, five instructions; the compiler's IEEE division is ~25 with its scaling and fix-up.  No range
 // scaling: the callers divide by sums of probabilities and pivots of covariances, nowhere near the ends of the exponent range
