@@ -215,6 +215,63 @@ int rts_chunked_call(const Args &a, int n, long slots, One &&one, hipStream_t s)
     return ml_join(ms, forked, s, rc);
 }
 
+// The fused linear UKF smoother (ukf_kernels.hip, UkfRtsArgs): backward windows like rts_chunked_call.  Default policy: where
+// the waves of the call are more than one round and the last round is less than 60 % full (one wave per SIMD makes that
+// BASELINE configs[3]: 1563 waves on 1024 slots); FK_UKF_RTS_CHUNKS="G,H" forces a decomposition ("1,1": one launch).
+template <class Args, class One>
+int ukf_rts_chunked_call(const Args &a, int n, long slots, One &&one, hipStream_t s)
+{
+    int G = 1, H = 1;
+    const long steps = a.T - 1, waves = (a.cnt + 63) / 64;        // backward steps T-2 .. 0
+    if (const char *cv = getenv("FK_UKF_RTS_CHUNKS")) {
+        if (sscanf(cv, "%d,%d", &G, &H) != 2) G = H = 1;
+    } else if (waves > slots && steps >= 16) {
+        const long rem = waves % slots;
+        if (rem != 0 && rem * 10 < slots * 6) { G = FK_ML_CHUNK_G; H = FK_ML_CHUNK_H; }
+    }
+    if (G > MlStreams::MAXG) G = MlStreams::MAXG;
+    if (H > 64) H = 64;
+    if (H > steps) H = (int)steps;
+    if (G < 1 || H < 1 || (G == 1 && H == 1) || a.cnt < 256L * G) return one(a, s);
+    MlStreams *msp = ml_streams();
+    if (!msp) return one(a, s);
+    MlStreams &ms = *msp;
+    std::lock_guard<std::mutex> lock(ms.mu);
+    if (hipEventRecord(ms.fork, s) != hipSuccess) return one(a, s);
+    const long blocks = (a.cnt + 255) / 256, per = (blocks + G - 1) / G * 256, nn = (long)n * n;
+    int rc = 0;
+    bool forked[MlStreams::MAXG] = {};
+    for (int g = 0; g < G && rc == 0; ++g) {
+        const long g0 = a.i0 + (long)g * per;
+        const long gcnt = (g0 + per <= a.i0 + a.cnt) ? per : (a.i0 + a.cnt - g0);
+        if (gcnt <= 0) break;
+        hipStream_t sg = g == 0 ? s : ms.st[g];
+        if (g > 0) {
+            if (hipStreamWaitEvent(sg, ms.fork, 0) != hipSuccess) { rc = -1; break; }
+            forked[g] = true;
+        }
+        bool first = true;
+        for (int h = H; h >= 0 && rc == 0; --h) {                 // windows of backward steps [k0, k1), last first
+            long k0, k1;
+            if (!chunk_window(steps, G, H, g, h, k0, k1)) continue;
+            Args b = a;
+            b.i0 = g0;
+            b.cnt = gcnt;
+            b.T = k1 - k0 + 1;                                     // steps k0 .. k1 of the arrays; k1 is the window's "T-1"
+            b.cont = first ? a.cont : 1;
+            b.status_or = first ? a.status_or : 1;
+            b.Xs = a.Xs + k0 * a.N * n;
+            b.Ps = a.Ps + k0 * a.N * nn;
+            b.xs = a.xs + k0 * a.N * n;
+            b.ps = a.ps + k0 * a.N * nn;
+            b.Ks = ml_off(a.Ks, k0 * a.N * nn);
+            rc = one(b, sg);
+            first = false;
+        }
+    }
+    return ml_join(ms, forked, s, rc);
+}
+
 // The fused linear UKF (ukf_kernels.hip, UkfArgs): only on request -- FK_UKF_CHUNKS="G,H" --, same hand-over through x / P.
 template <class Args, class One>
 int ukf_chunked_call(const Args &a, int n, int m, One &&one, hipStream_t s)

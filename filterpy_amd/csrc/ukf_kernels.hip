@@ -32,6 +32,9 @@ struct UkfRtsArgs {
     long N, T;
     int n;
     double scale;
+    long i0, cnt;        // the launch covers tracks [i0, i0 + cnt) of the N (a piece of a chunked call, fk_chunks.hpp)
+    int cont;            // 1: the window's top step was smoothed by the piece before it -- read it from xs / ps, do not copy
+    int status_or;       // 1: OR the status into what an earlier piece left
 };
 
 #if FK_UKF_FWD
@@ -286,8 +289,8 @@ ukf_linear_rts_kernel(const UkfRtsArgs a, const double *__restrict__ pF, const d
     __shared__ double s_park[PARK ? (BLOCK / 64) * 64 * (NX + PL) : 1];
     double *park = s_park + (PARK ? (threadIdx.x >> 6) * 64 * (NX + PL) + (threadIdx.x & 63u) : 0);
     const long N = a.N;
-    const long blk0 = (long)blockIdx.x * BLOCK;
-    const long left = N - blk0;
+    const long blk0 = a.i0 + (long)blockIdx.x * BLOCK;
+    const long left = a.i0 + a.cnt - blk0;
     const unsigned last_row = (unsigned)(left < BLOCK ? left : BLOCK) - 1u;
     const bool live = threadIdx.x <= last_row;
     const Lane ln{blk0, live ? threadIdx.x : last_row, N};
@@ -407,33 +410,38 @@ ukf_linear_rts_kernel(const UkfRtsArgs a, const double *__restrict__ pF, const d
         }
     };
 
-    // the last step is the filter's own output, copied as it is (both triangles: xs, ps = Xs.copy(), Ps.copy())
+    // the last step is the filter's own output, copied as it is (both triangles: xs, ps = Xs.copy(), Ps.copy()) -- unless this
+    // launch continues a chunked call (a.cont): then the window's top step was smoothed by the piece before it and is read
+    // back from xs / ps, not rewritten
     double xn[NX], Pn[PL];
     {
+        const double *srcx = a.cont ? a.xs : a.Xs, *srcP = a.cont ? a.ps : a.Ps;
         double Pf[NN];
         if constexpr (COOP) {
             WaveAosFetch<NX> fx;
             WaveAosFetch<NN> fP;
-            fx.issue(a.Xs + (a.T - 1) * N * NX + blk0 * NX, wave_row0, lane, last_row);
-            fP.issue(a.Ps + (a.T - 1) * N * NN + blk0 * NN, wave_row0, lane, last_row);
+            fx.issue(srcx + (a.T - 1) * N * NX + blk0 * NX, wave_row0, lane, last_row);
+            fP.issue(srcP + (a.T - 1) * N * NN + blk0 * NN, wave_row0, lane, last_row);
             fx.to_tile(tile, lane);
             FK_UNROLL for (int c = 0; c < NX; ++c) xn[c] = tile[lane * NX + c];
             fP.to_tile(tile, lane);
             FK_UNROLL for (int e = 0; e < NN; ++e) Pf[e] = tile[lane * NN + e];
             wave_lds_fence();
         } else {
-            load_rec<NX, 1, LAYOUT, EXACT>(xn, a.Xs + (a.T - 1) * N * n, ln, n, 1, 0.0);
-            load_rec<NX, NX, LAYOUT, EXACT>(Pf, a.Ps + (a.T - 1) * N * n * n, ln, n, n, 1.0);
+            load_rec<NX, 1, LAYOUT, EXACT>(xn, srcx + (a.T - 1) * N * n, ln, n, 1, 0.0);
+            load_rec<NX, NX, LAYOUT, EXACT>(Pf, srcP + (a.T - 1) * N * n * n, ln, n, n, 1.0);
         }
         FK_UNROLL for (int i = 0; i < NX; ++i)
             FK_UNROLL for (int j = 0; j < NX; ++j)
                 if (j >= i) Pn[sym_idx<NX>(i, j)] = Pf[i * NX + j];
-        store_x(a.T - 1, xn);
-        store_full(a.ps, a.T - 1, Pf);
-        if (a.Ks) {
-            double Z[NN];
-            FK_UNROLL for (int e = 0; e < NN; ++e) Z[e] = 0.0;
-            store_full(a.Ks, a.T - 1, Z);
+        if (!a.cont) {
+            store_x(a.T - 1, xn);
+            store_full(a.ps, a.T - 1, Pf);
+            if (a.Ks) {
+                double Z[NN];
+                FK_UNROLL for (int e = 0; e < NN; ++e) Z[e] = 0.0;
+                store_full(a.Ks, a.T - 1, Z);
+            }
         }
     }
     int st = 0;
@@ -505,14 +513,14 @@ ukf_linear_rts_kernel(const UkfRtsArgs a, const double *__restrict__ pF, const d
     }
     if (live && a.status) {
         if (!all_finite<NX>(xn) || !all_finite<PL>(Pn)) st |= ST_NONFINITE;
-        a.status[ln.blk0 + ln.tid] = st;
+        a.status[ln.blk0 + ln.tid] = a.status_or ? (a.status[ln.blk0 + ln.tid] | st) : st;
     }
 }
 
 
 #define FK_UKF_GO(NXV, DMAV)                                                                                     \
     do {                                                                                                         \
-        const dim3 grid((unsigned)((a.N + BLOCK - 1) / BLOCK)), block(BLOCK);                                    \
+        const dim3 grid((unsigned)((a.cnt + BLOCK - 1) / BLOCK)), block(BLOCK);                                  \
         const bool ex = exact && a.n == NXV;                                                                     \
         if (layout == FK_LAYOUT_SOA) {                                                                           \
             if (ex && DMAV && dma) hipLaunchKernelGGL((ukf_linear_rts_kernel<NXV, LAYOUT_SOA, true, DMAV>), grid, block, 0, s, a, F, Q, Wm, Wc); \
@@ -615,12 +623,21 @@ int fk_ukf_linear_rts_f64(const fk_ukf_desc *d, const double *F, const double *Q
         return fail(FK_ERR_BAD_ARG, "fused linear UKF smoother: bad argument");
     if ((double)d->N * d->n * d->n * 8.0 >= 4294967296.0) return fail(FK_ERR_UNSUPPORTED, "fused linear UKF smoother: record block >= 4 GiB, split the batch");
     if (d->N == 0 || d->T == 0) return FK_OK;
-    UkfRtsArgs a{};
-    a.Xs = Xs; a.Ps = Ps; a.xs = xs; a.ps = Ps_out; a.Ks = K; a.status = status;
-    a.N = d->N; a.T = d->T; a.n = d->n; a.scale = d->scale;
-    hipStream_t s = (hipStream_t)stream;
-    return d->n <= 6 ? ukf_rts_launch_small(a, F, Q, Wm, Wc, d->layout, ukf_exact(), s)
-                     : ukf_rts_launch_big(a, F, Q, Wm, Wc, d->layout, ukf_exact(), s);
+    UkfRtsArgs a0{};
+    a0.Xs = Xs; a0.Ps = Ps; a0.xs = xs; a0.ps = Ps_out; a0.Ks = K; a0.status = status;
+    a0.N = d->N; a0.T = d->T; a0.n = d->n; a0.scale = d->scale;
+    a0.i0 = 0; a0.cnt = d->N; a0.cont = 0; a0.status_or = 0;
+    const int layout = d->layout;
+    const bool exact = ukf_exact();
+    auto one = [&](const UkfRtsArgs &a, hipStream_t s) -> int {
+        return a.n <= 6 ? ukf_rts_launch_small(a, F, Q, Wm, Wc, layout, exact, s) : ukf_rts_launch_big(a, F, Q, Wm, Wc, layout, exact, s);
+    };
+    // Tail filling (fk_chunks.hpp): the classes of dim_x >= 5 run one wave per SIMD, so BASELINE configs[3]'s 1563 waves are
+    // two rounds for 1.53 rounds of work; cut into track groups x backward time windows on helper streams the pieces of
+    // different groups fill each other's tails (bit-identical results: a window's top step is read back from the smoothed
+    // outputs).  FK_UKF_RTS_CHUNKS="G,H" forces a decomposition ("1,1": one launch).
+    const long slots = 1024L * (d->n <= 2 ? 4 : d->n <= 4 ? 2 : 1);
+    return ukf_rts_chunked_call(a0, a0.n, slots, one, (hipStream_t)stream);
 }
 #endif
 

@@ -281,3 +281,45 @@ def test_fused_ukf_chunked_call_is_bit_identical(n, m, layout, monkeypatch):
     for tag in ("3x4", "2x7", "4x23"):
         for a, b in zip(res["one"], res[tag]):
             assert np.array_equal(a, b, equal_nan=True), tag
+
+
+@pytest.mark.parametrize("layout", ["soa", "aos"])
+@pytest.mark.parametrize("n,N", [(6, 1037), (6, 1038), (4, 1038), (8, 515), (9, 514)])
+def test_fused_ukf_smoother_chunked_call_is_bit_identical(n, N, layout, monkeypatch):
+    """FK_UKF_RTS_CHUNKS="G,H" cuts fk_ukf_linear_rts_f64 into track groups x backward time windows on helper streams
+    (fk_chunks.hpp, ukf_rts_chunked_call); a window's top step is read back from the smoothed outputs of the piece before it:
+    xs, ps, Ks and the status must be bit-identical to the single launch -- odd and even banks (register fetch / LDS-DMA
+    fetch), a ragged last workgroup, a track whose covariance is not positive definite"""
+    import torch
+    from filterpy_amd import _engine as E
+    from oracle import ukf_oracle
+    rs = np.random.RandomState(7 * n + N % 5)
+    T = 23
+    alpha, beta, kappa = 0.5, 2.0, 3.0 - n
+    Wm, Wc = ukf_oracle.merwe_weights(n, alpha, beta, kappa)
+    lam = alpha ** 2 * (n + kappa) - n
+    F = np.eye(n) + 0.1 * rs.randn(n, n)
+    F /= max(1.0, 1.05 * np.max(np.abs(np.linalg.eigvals(F))))
+    Q = spd(rs, n, 0.05)
+    mu, cov = rs.randn(T, N, n), spd(rs, n, 2.0, (T, N))
+    cov[:, 77] = -np.eye(n)                                # not positive definite: status bit, garbage that must not differ
+    res = {}
+    for tag, env in (("one", "1,1"), ("3x4", "3,4"), ("2x7", "2,7"), ("4x22", "4,22"), ("default", None)):
+        if env:
+            monkeypatch.setenv("FK_UKF_RTS_CHUNKS", env)
+        else:
+            monkeypatch.delenv("FK_UKF_RTS_CHUNKS", raising=False)
+        Xs, Ps = E.to_records(mu, layout, 1), E.to_records(cov, layout, 1)
+        xs, ps = E.alloc_records((T,), N, n, layout), E.alloc_records((T,), N, n * n, layout)
+        Ks = E.alloc_records((T,), N, n * n, layout)
+        for t in (xs, ps, Ks):
+            t.fill_(float("nan"))
+        st = torch.zeros(N, dtype=torch.int32, device=Xs.device)
+        E.ukf_linear_rts(n, N, T, layout, lam + n, E.dev(F), E.dev(Q), E.dev(Wm), E.dev(Wc), Xs, Ps, xs, ps, K=Ks, status=st)
+        torch.cuda.synchronize()
+        res[tag] = [t.cpu().numpy().copy() for t in (xs, ps, Ks, st)]
+    assert res["one"][3][77] != 0 and not res["one"][3][:77].any()
+    assert not np.isnan(res["one"][0][:, :77] if layout == "aos" else res["one"][0][..., :77]).any()
+    for tag in ("3x4", "2x7", "4x22", "default"):
+        for a, b in zip(res["one"], res[tag]):
+            assert np.array_equal(a, b, equal_nan=True), tag

@@ -55,7 +55,7 @@ def run(n, m, N, T, layout, dense):
     means, covs = E.alloc_records((T,), N, n, layout), E.alloc_records((T,), N, n * n, layout)
     st = torch.zeros(N, dtype=torch.int32, device=dev)
     dd = [E.dev(M) for M in (F, H, Q, R, Wm, Wc)]
-    sw = {k: os.environ[k] for k in ("FK_UKF_PADDED", "FK_UKF_DMA", "FK_UKF_CHUNKS") if k in os.environ}
+    sw = {k: os.environ[k] for k in ("FK_UKF_PADDED", "FK_UKF_DMA", "FK_UKF_CHUNKS", "FK_UKF_RTS_CHUNKS") if k in os.environ}
 
     def fwd():
         x.copy_(x0)
