@@ -247,10 +247,13 @@ int fk_ukf_linear_batch_f64(const fk_ukf_desc *desc,
 /* UnscentedKalmanFilter.rts_smoother (filterpy/kalman/UKF.py:634-739) with LINEAR fx(x, dt) = F x, fused per track:
  * the whole backward loop in one launch (per step: sigma points of (xs[k], ps[k]) -> F sigma -> unscented transform
  * + Q -> cross variance around Xs[k] / xb -> K = Pxb inv(Pb) -> xs[k] += K (xs[k+1] - xb), ps[k] += K (ps[k+1] - Pb) K').
- * desc: n (1..6), N, T, layout, scale = lambda + n (m is ignored).
+ * desc: n (1..9), N, T, layout, scale = lambda + n (m is ignored).
  *   F [n*n], Q [n*n] (the filter's Q: the reference never reads its Qs argument, UKF.py:717-722), Wm, Wc [2n+1];
- *   Xs [T][N][n], Ps [T][N][n*n]: the filter output; xs, Ps_out likewise: the smoothed output; K [T][N][n*n] or NULL
- *   (K of the last step is zero, like the reference's); status [N] or NULL. */
+ *   Xs [T][N][n], Ps [T][N][n*n]: the filter output; xs, Ps_out likewise: the smoothed output (distinct arrays); K
+ *   [T][N][n*n] or NULL (K of the last step is zero, like the reference's); status [N] or NULL.
+ * Asynchronous on `stream` and ordered like one kernel on it; at dim_x >= 5 a call whose last round of waves would be
+ * mostly idle fans out over up to three helper streams like fk_kf_batch_filter_f64 (bit-identical; FK_UKF_RTS_CHUNKS=1,1
+ * turns it off; INTEGRATION.md, "Streams"). */
 int fk_ukf_linear_rts_f64(const fk_ukf_desc *desc, const double *F, const double *Q, const double *Wm, const double *Wc,
                           const double *Xs, const double *Ps, double *xs, double *Ps_out, double *K, int32_t *status,
                           void *stream);
