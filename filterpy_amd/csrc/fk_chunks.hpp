@@ -216,7 +216,7 @@ int rts_chunked_call(const Args &a, int n, long slots, One &&one, hipStream_t s)
 }
 
 // The fused linear UKF smoother (ukf_kernels.hip, UkfRtsArgs): backward windows like rts_chunked_call.  Default policy: where
-// the waves of the call are more than one round and the last round is less than 60 % full (one wave per SIMD makes that
+// the waves of the call are more than one round, at most three, and the last round is less than 60 % full (one wave per SIMD makes that
 // BASELINE configs[3]: 1563 waves on 1024 slots); FK_UKF_RTS_CHUNKS="G,H" forces a decomposition ("1,1": one launch).
 template <class Args, class One>
 int ukf_rts_chunked_call(const Args &a, int n, long slots, One &&one, hipStream_t s)
@@ -225,7 +225,9 @@ int ukf_rts_chunked_call(const Args &a, int n, long slots, One &&one, hipStream_
     const long steps = a.T - 1, waves = (a.cnt + 63) / 64;        // backward steps T-2 .. 0
     if (const char *cv = getenv("FK_UKF_RTS_CHUNKS")) {
         if (sscanf(cv, "%d,%d", &G, &H) != 2) G = H = 1;
-    } else if (waves > slots && steps >= 16) {
+    } else if (waves > slots && waves <= 3 * slots && steps >= 16) {
+        // (only for a handful of rounds: at 15 rounds the partial last one is 2 % of the call and the pieces' overheads are
+        //  not -- 1e6 tracks x 20 steps measured 3.06 ms in one launch, 3.63 ms cut up)
         const long rem = waves % slots;
         if (rem != 0 && rem * 10 < slots * 6) { G = FK_ML_CHUNK_G; H = FK_ML_CHUNK_H; }
     }
