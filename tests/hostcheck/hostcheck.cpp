@@ -632,3 +632,13 @@ extern "C" int hc_ukf_linear_rts_v3(int n, long T, const double *F, const double
 #undef GO
     return -1;
 }
+
+// ln |S| and |S|^(-1/2) from the reciprocal pivots (fk_math.hpp: logdet_from_dinv, rsqrt_det_from_dinv -- the mantissa /
+// exponent bookkeeping is the same code on the host; only the root's refinement differs)
+extern "C" void hc_det_from_dinv(int m, const double *dinv, double *logdet, double *rsqrt_det)
+{
+    double d[4] = {1.0, 1.0, 1.0, 1.0};
+    for (int i = 0; i < m && i < 4; ++i) d[i] = dinv[i];
+    *logdet = fk::logdet_from_dinv<4>(d, m);
+    *rsqrt_det = fk::rsqrt_det_from_dinv<4>(d, m);
+}

@@ -152,3 +152,31 @@ def test_rts_packed_symmetric_vs_golden(n, m):
     assert st == 0
     for got, key in ((xs, "rts_x"), (Pso, "rts_P"), (K, "rts_K"), (Pp, "rts_Pp")):
         assert rel_err_rows(got, g[p + key]) < 1e-9, key
+
+
+def test_det_from_reciprocal_pivots_over_the_whole_exponent_range():
+    """logdet_from_dinv / rsqrt_det_from_dinv (fk_math.hpp; the IMM likelihood and the Saver's log-likelihood): one logarithm /
+    no logarithm of the PRODUCT of the reciprocal pivots, carried as mantissa x 2^exponent -- against sums of logarithms in
+    extended precision, for pivots from 1e-300 to 1e300 whose plain product would leave the range, odd and even exponent sums."""
+    import ctypes
+    from conftest import ROOT
+    lib = ctypes.CDLL(os.path.join(ROOT, "tests", "hostcheck", "libhostcheck.so"))
+    rs = np.random.RandomState(11)
+    worst_l = worst_r = 0.0
+    for trial in range(4000):
+        m = 1 + trial % 4
+        lo, hi = [(-300, 300), (-5, 5), (-300, -200), (200, 300)][(trial // 4) % 4]
+        dinv = 10.0 ** rs.uniform(lo, hi, size=m)
+        ld, rd = ctypes.c_double(), ctypes.c_double()
+        lib.hc_det_from_dinv(ctypes.c_int(m), dinv.ctypes.data_as(ctypes.c_void_p), ctypes.byref(ld), ctypes.byref(rd))
+        ref_ld = -float(np.sum(np.log(dinv.astype(np.longdouble))))                 # ln |S| = -sum ln (1 / d_i)
+        assert abs(ld.value - ref_ld) <= 4e-16 * max(1.0, abs(ref_ld)) + 1e-15, (dinv, ld.value, ref_ld)
+        ref_r = np.exp(np.longdouble(-0.5) * np.longdouble(ref_ld))
+        if 1e-300 < ref_r < 1e300:
+            worst_r = max(worst_r, abs(float(rd.value / ref_r) - 1.0))
+        elif ref_r <= 1e-300:                                                        # down to the subnormals: to an ulp of those
+            assert abs(rd.value - float(ref_r)) <= max(1e-13 * float(ref_r), 1e-323), (dinv, rd.value, ref_r)
+        else:
+            assert np.isinf(rd.value) or abs(float(rd.value / ref_r) - 1.0) < 1e-12, (dinv, rd.value, ref_r)
+        worst_l = max(worst_l, abs(ld.value - ref_ld) / max(1.0, abs(ref_ld)))
+    assert worst_r < 1e-13, worst_r
