@@ -101,6 +101,40 @@ def test_imm_seeded_bank_vs_oracle(n, m, nm, layout):
     assert np.abs(r["P_out"] - np.swapaxes(r["P_out"], -1, -2)).max() == 0.0
 
 
+@pytest.mark.parametrize("layout", ["soa", "aos"])
+@pytest.mark.parametrize("n,m,nm", [(4, 2, 2), (2, 1, 3), (6, 3, 2)])
+def test_imm_extreme_likelihoods_vs_oracle(n, m, nm, layout):
+    """The ends of the likelihood's range: measurements hundreds of sigmas away (every likelihood underflows and is floored at
+    DBL_MIN, kalman_filter.py:1213-1226 -- the normalising sum is SUBNORMAL and its reciprocal would overflow), measurement
+    noise of 1e-150 and 1e+150 (|S| beyond what a plain product of pivots can hold), next to ordinary tracks.  The kernel forms
+    the density from the reciprocal pivots without a logarithm and normalises by a reciprocal (fk_imm.hpp)."""
+    from oracle import imm_oracle
+    rs = np.random.RandomState(5 + n + nm)
+    N, T = 260, 6
+    Fs = np.array([stable_F(rs, n) for _ in range(nm)])
+    Qs = np.array([spd(rs, n, 0.05 * (j + 1)) for j in range(nm)])
+    Hs = np.array([rs.randn(m, n)] * nm)
+    M = rs.rand(nm, nm) + 2 * np.eye(nm)
+    M /= M.sum(axis=1, keepdims=True)
+    xs0 = rs.randn(N, nm, n)
+    Ps0 = np.array([[spd(rs, n, 2.0) for _ in range(nm)] for _ in range(N)])
+    mu0 = rs.rand(N, nm) + 0.1
+    mu0 /= mu0.sum(axis=1, keepdims=True)
+    for scale_R, far in ((1.0, True), (1e-150, False), (1e150, False)):
+        Rs = np.array([spd(rs, m, 0.5) * scale_R for _ in range(nm)])
+        zs = rs.randn(T, N, m) * 2
+        if far:
+            zs[:, 1::2] += 1e4                              # every other track: hopeless measurements
+        r = run_imm(xs0, Ps0, mu0, M, zs, Fs, Qs, Hs, Rs, layout)
+        for trk in (0, 1, 2, 255, 256, N - 1):
+            x, P, mu, xp, Pp, L = imm_oracle.imm_batch(xs0[trk], Ps0[trk], mu0[trk], M, zs[:, trk], Fs, Qs, Hs, Rs)
+            assert np.all(np.isfinite(r["mu_out"][:, trk])) and np.all(np.isfinite(r["likelihood_out"][:, trk])), (scale_R, trk)
+            assert np.allclose(r["mu_out"][:, trk], mu, rtol=1e-9, atol=1e-14), (scale_R, trk)
+            assert np.allclose(r["likelihood_out"][:, trk], L, rtol=1e-9, atol=1e-307), (scale_R, trk)
+            assert rel_err_rows(r["x_out"][:, trk], x) < 1e-8, (scale_R, trk)
+        assert np.abs(r["mu_out"].sum(axis=-1) - 1).max() < 1e-13
+
+
 def _make_filters(g, p, n, m, nm, column):
     from filterpy_amd.kalman import KalmanFilter
     fs = []
