@@ -143,3 +143,43 @@ def test_fused_linear_ukf_smoother_goldens_every_bank_size(layout, nb):
             assert rel_err_rows(hx[:, trk], g[p + "rts_x"]) < ukf_tol(ci, "rts_x"), (ci, nb, trk)
             assert rel_err_rows(hP[:, trk], g[p + "rts_P"]) < ukf_tol(ci, "rts_P"), (ci, nb, trk)
             assert rel_err_rows(hK[:-1, trk], g[p + "rts_K"][:-1]) < ukf_tol(ci, "rts_K"), (ci, nb, trk)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("layout", ["soa", "aos"])
+def test_fused_linear_ukf_smoother_on_arrays_that_are_only_8_byte_aligned(layout):
+    """The LDS-DMA fetch of fk_ukf_linear_rts_f64 moves 16-byte units; arrays that start 8 bytes into an allocation (a view of a
+    larger tensor) must take the register fetch and give the same bits."""
+    import torch
+    from filterpy_amd import _engine as E
+    from gpu_util import tile_tracks
+    g = golden("ukf_merwe")
+    ci, n, m, alpha, beta, kappa = [c for c in _cases() if c[1] == 6][0]
+    p = f"c{ci}_"
+    lam = alpha ** 2 * (n + kappa) - n
+    nb = 130
+    mu, cov = g[p + "mu"], g[p + "cov"]
+    T = mu.shape[0]
+    Xs0 = E.to_records(tile_tracks(mu, nb, 1), layout, 1)
+    Ps0 = E.to_records(tile_tracks(cov, nb, 1), layout, 1)
+    res = []
+    for shift in (0, 1):
+        def place(t):
+            buf = torch.empty(t.numel() + 2, dtype=t.dtype, device=t.device)
+            v = buf[shift:shift + t.numel()].view(t.shape)
+            v.copy_(t)
+            assert v.data_ptr() % 16 == 8 * shift
+            return v
+        Xs, Ps = place(Xs0), place(Ps0)
+        xs, ps = E.alloc_records((T,), nb, n, layout), E.alloc_records((T,), nb, n * n, layout)
+        Ks = E.alloc_records((T,), nb, n * n, layout)
+        st = torch.zeros(nb, dtype=torch.int32, device=Xs.device)
+        E.ukf_linear_rts(n, nb, T, layout, lam + n, E.dev(g[p + "F"]), E.dev(g[p + "Q"]), E.dev(g[p + "Wm"]),
+                         E.dev(g[p + "Wc"]), Xs, Ps, xs, ps, K=Ks, status=st)
+        torch.cuda.synchronize()
+        assert not st.any()
+        res.append([t.cpu().numpy().copy() for t in (xs, ps, Ks)])
+    for a, b in zip(*res):
+        assert np.array_equal(a, b)
+    hx = E.from_records(torch.as_tensor(res[1][0]), layout, 1, (n,))
+    assert rel_err_rows(hx[:, nb - 1], g[p + "rts_x"]) < ukf_tol(ci, "rts_x")
