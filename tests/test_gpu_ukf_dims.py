@@ -284,7 +284,7 @@ def test_fused_ukf_chunked_call_is_bit_identical(n, m, layout, monkeypatch):
 
 
 @pytest.mark.parametrize("layout", ["soa", "aos"])
-@pytest.mark.parametrize("n,N", [(6, 1037), (6, 1038), (4, 1038), (8, 515), (9, 514)])
+@pytest.mark.parametrize("n,N", [(6, 1037), (6, 1038), (4, 1038), (8, 515), (9, 514), (7, 515), (5, 1038), (3, 1037)])
 def test_fused_ukf_smoother_chunked_call_is_bit_identical(n, N, layout, monkeypatch):
     """FK_UKF_RTS_CHUNKS="G,H" cuts fk_ukf_linear_rts_f64 into track groups x backward time windows on helper streams
     (fk_chunks.hpp, ukf_rts_chunked_call); a window's top step is read back from the smoothed outputs of the piece before it:
