@@ -1,7 +1,7 @@
 #!/bin/bash
 # Copies what the closing lease (tools/gpu_scripts/r03_final.sh -> gpurun_out/r03fin) produced into profiles/r03 under the names
 # DESIGN.md and profiles/README.md cite, reduces the PMC passes into profiles/pmc_traffic.json and regenerates DESIGN's tables.
-#   bash tools/import_closing_evidence.sh [gpurun_out/r03fin] [profiles/r03]
+#   bash tools/import_closing_evidence.sh [gpurun_out/r03fin] [profiles/r03]   (regenerates all three generated blocks of DESIGN.md)
 set -e
 S=${1:-gpurun_out/r03fin}
 D=${2:-profiles/r03}
