@@ -215,6 +215,66 @@ int rts_chunked_call(const Args &a, int n, long slots, One &&one, hipStream_t s)
     return ml_join(ms, forked, s, rc);
 }
 
+// The IMM / MMAE banks (imm_kernels.hip, ImmArgs; whole steps only): forward time chunks like kf_chunked_call, the state handed
+// from chunk to chunk through xs / Ps / mu (and ll0) in place.  Default policy: where the waves of the call are one to four
+// rounds and the last round is less than 60 % full (the one-wave-per-SIMD classes lose up to a quarter to it: 2e5 banks of
+// (6,3) x 2 took 4.25 ms where 196 608 -- three full rounds -- took 3.28); FK_IMM_CHUNKS="G,H" forces a decomposition ("1,1":
+// one launch).
+template <class Args, class One>
+int imm_chunked_call(const Args &a, int n, int m, int nm, long slots, One &&one, hipStream_t s)
+{
+    int G = 1, H = 1;
+    const long waves = (a.cnt + 63) / 64;
+    if (const char *cv = getenv("FK_IMM_CHUNKS")) {
+        if (sscanf(cv, "%d,%d", &G, &H) != 2) G = H = 1;
+    } else if (waves > slots && waves <= 4 * slots && a.T >= 16) {
+        const long rem = waves % slots;
+        if (rem != 0 && rem * 10 < slots * 6) { G = FK_ML_CHUNK_G; H = FK_ML_CHUNK_H; }
+    }
+    if (G > MlStreams::MAXG) G = MlStreams::MAXG;
+    if (H > 64) H = 64;
+    if (H > a.T) H = (int)a.T;
+    if (G < 1 || H < 1 || (G == 1 && H == 1) || a.cnt < 256L * G) return one(a, s);
+    MlStreams *msp = ml_streams();
+    if (!msp) return one(a, s);
+    MlStreams &ms = *msp;
+    std::lock_guard<std::mutex> lock(ms.mu);
+    if (hipEventRecord(ms.fork, s) != hipSuccess) return one(a, s);
+    const long blocks = (a.cnt + 255) / 256, per = (blocks + G - 1) / G * 256, nn = (long)n * n;
+    int rc = 0;
+    bool forked[MlStreams::MAXG] = {};
+    for (int g = 0; g < G && rc == 0; ++g) {
+        const long g0 = a.i0 + (long)g * per;
+        const long gcnt = (g0 + per <= a.i0 + a.cnt) ? per : (a.i0 + a.cnt - g0);
+        if (gcnt <= 0) break;
+        hipStream_t sg = g == 0 ? s : ms.st[g];
+        if (g > 0) {
+            if (hipStreamWaitEvent(sg, ms.fork, 0) != hipSuccess) { rc = -1; break; }
+            forked[g] = true;
+        }
+        for (int h = 0; h <= H && rc == 0; ++h) {
+            long t0, t1;
+            if (!chunk_window(a.T, G, H, g, h, t0, t1)) continue;
+            Args b = a;
+            b.i0 = g0;
+            b.cnt = gcnt;
+            b.T = t1 - t0;
+            b.status_or = t0 > 0 ? 1 : a.status_or;
+            b.z = a.z + t0 * a.N * m;
+            b.mask = ml_off(a.mask, t0 * a.N);
+            if (a.nu > 0) b.u = ml_off(a.u, t0 * a.N * a.nu);
+            b.x_out = ml_off(a.x_out, t0 * a.N * n);
+            b.P_out = ml_off(a.P_out, t0 * a.N * nn);
+            b.mu_out = ml_off(a.mu_out, t0 * a.N * nm);
+            b.xp_out = ml_off(a.xp_out, t0 * a.N * n);
+            b.Pp_out = ml_off(a.Pp_out, t0 * a.N * nn);
+            b.L_out = ml_off(a.L_out, t0 * a.N * nm);
+            rc = one(b, sg);
+        }
+    }
+    return ml_join(ms, forked, s, rc);
+}
+
 // The fused linear UKF smoother (ukf_kernels.hip, UkfRtsArgs): backward windows like rts_chunked_call.  Default policy: where
 // the waves of the call are more than one round, at most three, and the last round is less than 60 % full (one wave per SIMD makes that
 // BASELINE configs[3]: 1563 waves on 1024 slots); FK_UKF_RTS_CHUNKS="G,H" forces a decomposition ("1,1": one launch).

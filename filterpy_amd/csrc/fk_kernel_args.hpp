@@ -64,6 +64,8 @@ struct ImmArgs {
     int n, m;
     int phase;
     int mmae;
+    long i0, cnt;            // the launch covers banks [i0, i0 + cnt) of the N (a piece of a chunked call, fk_chunks.hpp)
+    int status_or;           // 1: OR the status into what an earlier time chunk left
 };
 
 }  // namespace fk

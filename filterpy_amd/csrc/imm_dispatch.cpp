@@ -2,6 +2,7 @@
 // the (dim_x, dim_z, n_models) instantiation of imm_kernels.hip.
 #include <hip/hip_runtime.h>
 
+#include "fk_chunks.hpp"
 #include "fk_device.hpp"
 #include "fk_kernel_args.hpp"
 #include "../../include/filterhip.h"
@@ -64,30 +65,41 @@ extern "C" int fk_imm_batch_ex_f64(const fk_imm_desc *d, const double *F, const 
     if (mask != 0 && mask != 1 && mask != 7) mask = -1;
     if (d->phase != FK_IMM_STEP || a.mmae) mask = -1;   // the general kernel also carries the MMAE arithmetic
     if (zmask || ll0 || nu > 0) mask = -1;               // ... the missing-measurement bookkeeping and the control input
-    hipStream_t s = (hipStream_t)stream;
+    a.i0 = 0; a.cnt = d->N; a.status_or = 0;
+    const int layout = d->layout, n_models = d->n_models;
     // register-resident instantiations for the small banks (2 / 3 filters, dim_x <= 6, dim_z <= 3); everything else -- up to
     // eight filters, dim_x <= 9, dim_z <= 4 -- on the rolled (9, 4) class of its bank size (fk_dims_imm.def)
-    if (d->n <= 6 && d->m <= 3 && d->n_models <= 3) {
-        const int cls = (d->n <= 2 && d->m <= 1) ? 0 : (d->n <= 4 && d->m <= 2) ? 1 : 2;
-        if (d->n_models == 2) {
-            if (cls == 0) launch_imm_2_1_2(a, d->layout, mask, s);
-            else if (cls == 1) launch_imm_4_2_2(a, d->layout, mask, s);
-            else launch_imm_6_3_2(a, d->layout, mask, s);
+    const bool small = d->n <= 6 && d->m <= 3 && n_models <= 3;
+    const int cls = (d->n <= 2 && d->m <= 1) ? 0 : (d->n <= 4 && d->m <= 2) ? 1 : 2;
+    auto one = [&](const ImmArgs &b, hipStream_t s) -> int {
+        if (small) {
+            if (n_models == 2) {
+                if (cls == 0) launch_imm_2_1_2(b, layout, mask, s);
+                else if (cls == 1) launch_imm_4_2_2(b, layout, mask, s);
+                else launch_imm_6_3_2(b, layout, mask, s);
+            } else {
+                if (cls == 0) launch_imm_2_1_3(b, layout, mask, s);
+                else if (cls == 1) launch_imm_4_2_3(b, layout, mask, s);
+                else launch_imm_6_3_3(b, layout, mask, s);
+            }
         } else {
-            if (cls == 0) launch_imm_2_1_3(a, d->layout, mask, s);
-            else if (cls == 1) launch_imm_4_2_3(a, d->layout, mask, s);
-            else launch_imm_6_3_3(a, d->layout, mask, s);
+            switch (n_models) {
+            case 2: launch_imm_9_4_2(b, layout, mask, s); break;
+            case 3: launch_imm_9_4_3(b, layout, mask, s); break;
+            case 4: launch_imm_9_4_4(b, layout, mask, s); break;
+            case 5: launch_imm_9_4_5(b, layout, mask, s); break;
+            case 6: launch_imm_9_4_6(b, layout, mask, s); break;
+            case 7: launch_imm_9_4_7(b, layout, mask, s); break;
+            default: launch_imm_9_4_8(b, layout, mask, s); break;
+            }
         }
-    } else {
-        switch (d->n_models) {
-        case 2: launch_imm_9_4_2(a, d->layout, mask, s); break;
-        case 3: launch_imm_9_4_3(a, d->layout, mask, s); break;
-        case 4: launch_imm_9_4_4(a, d->layout, mask, s); break;
-        case 5: launch_imm_9_4_5(a, d->layout, mask, s); break;
-        case 6: launch_imm_9_4_6(a, d->layout, mask, s); break;
-        case 7: launch_imm_9_4_7(a, d->layout, mask, s); break;
-        default: launch_imm_9_4_8(a, d->layout, mask, s); break;
-        }
-    }
-    return check_launch("imm_kernel");
+        return check_launch("imm_kernel");
+    };
+    hipStream_t s = (hipStream_t)stream;
+    if (d->phase != FK_IMM_STEP || a.T < 2) return one(a, s);
+    // tail filling (fk_chunks.hpp, imm_chunked_call): wave slots of the instantiation the call runs on -- the compiled output
+    // sets of the small banks at their FK_IMM_WAVES per SIMD (fk_dims_imm.def), everything else at one
+    static const int small_waves[3][2] = {{4, 3}, {2, 2}, {1, 1}};            // [class][n_models - 2]
+    const long slots = 1024L * ((small && mask >= 0) ? small_waves[cls][n_models - 2] : 1);
+    return imm_chunked_call(a, d->n, d->m, n_models, slots, one, s);
 }

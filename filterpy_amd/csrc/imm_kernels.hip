@@ -50,8 +50,8 @@ imm_kernel(const ImmArgs a)
     __syncthreads();
     const double *sM = smem + NM * LM::SIZE;
 
-    Lane ln{(long)blockIdx.x * BLOCK, threadIdx.x, N};
-    const bool live = ln.blk0 + ln.tid < N;
+    Lane ln{a.i0 + (long)blockIdx.x * BLOCK, threadIdx.x, N};
+    const bool live = ln.blk0 + ln.tid < a.i0 + a.cnt;
     if (!live) return;
 
     constexpr int PL = NX * (NX + 1) / 2;
@@ -175,7 +175,10 @@ imm_kernel(const ImmArgs a)
             const RecView<LAYOUT> vl(a.ll0, ln, NM);
             FK_UNROLL for (int j = 0; j < NM; ++j) vl.store(j, ll0[j]);
         }
-        if (a.status) a.status[ln.blk0 + ln.tid] = st | (fin ? 0 : ST_NONFINITE);
+        if (a.status) {
+            const int sv = st | (fin ? 0 : ST_NONFINITE);
+            a.status[ln.blk0 + ln.tid] = a.status_or ? (a.status[ln.blk0 + ln.tid] | sv) : sv;
+        }
     }
 }
 
@@ -187,7 +190,7 @@ template <int LAYOUT>
 static void launch_layout(const ImmArgs &a, int mask, hipStream_t s)
 {
     constexpr int NX = FK_NX, NZ = FK_NZ, NM = FK_NM;
-    const dim3 grid((unsigned)((a.N + BLOCK - 1) / BLOCK)), block(BLOCK);
+    const dim3 grid((unsigned)((a.cnt + BLOCK - 1) / BLOCK)), block(BLOCK);
     const bool exact = a.n == NX && a.m == NZ;
     if (exact && mask == 0) hipLaunchKernelGGL((imm_kernel<NX, NZ, NM, LAYOUT, true, 0>), grid, block, 0, s, a);
     else if (exact && mask == 1) hipLaunchKernelGGL((imm_kernel<NX, NZ, NM, LAYOUT, true, 1>), grid, block, 0, s, a);

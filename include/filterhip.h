@@ -338,6 +338,9 @@ enum { FK_IMM_FLAG_MMAE = 1 };
  * phase FK_IMM_PREDICT runs IMMEstimator.predict() once (mixing + every filter's predict; writes
  * xs, Ps and the prior outputs [N][..]), FK_IMM_UPDATE runs IMMEstimator.update(z) once (z [N][m];
  * writes xs, Ps, mu and x_out/P_out/mu_out/likelihood_out [N][..]); T is ignored for both.
+ * Asynchronous on `stream` and ordered like one kernel on it; a whole-step call whose last round of waves would be mostly
+ * idle fans out over up to three helper streams like fk_kf_batch_filter_f64 (bit-identical; FK_IMM_CHUNKS=1,1 turns it
+ * off; INTEGRATION.md, "Streams").
  *
  * flags & FK_IMM_FLAG_MMAE: filterpy.kalman.MMAEFilterBank (filterpy/kalman/mmae.py:140-212) on the
  * same records: no mixing (every filter predicts from its own state, mmae.py:153-154; M is unused and
