@@ -15,9 +15,11 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfilterhip.so")
 
 FK_OK = 0
+FK_ERR_BAD_ARG, FK_ERR_UNSUPPORTED, FK_ERR_LAUNCH, FK_ERR_WORKSPACE = -1, -2, -3, -4
 FK_LAYOUT_AOS, FK_LAYOUT_SOA = 0, 1
 FK_MODEL_SHARED, FK_MODEL_PER_TRACK, FK_MODEL_PER_TRACK_STEP, FK_MODEL_PER_STEP = 0, 1, 2, 3
-FK_STATUS_NOT_PD, FK_STATUS_NONFINITE, FK_STATUS_OVERRUN, FK_STATUS_INTERNAL = 1, 2, 4, 8
+FK_STATUS_NOT_PD, FK_STATUS_NONFINITE, FK_STATUS_OVERRUN, FK_STATUS_INTERNAL, FK_STATUS_BAD_WEIGHTS = 1, 2, 4, 8, 16
+FK_UKF_FLAG_PAIR_WEIGHTS = 1
 
 c_i32, c_i64, c_f64, c_vp, c_sz = ctypes.c_int32, ctypes.c_int64, ctypes.c_double, ctypes.c_void_p, ctypes.c_size_t
 
@@ -29,6 +31,7 @@ class fk_kf_desc(ctypes.Structure):
 
 
 FK_KF_FLAG_R_JOSEPH_DIAG = 1
+FK_KF_FLAG_COV_INTERLEAVED = 2
 
 
 class fk_kf_extras(ctypes.Structure):
@@ -37,7 +40,7 @@ class fk_kf_extras(ctypes.Structure):
 
 class fk_ukf_desc(ctypes.Structure):
     _fields_ = [("n", c_i32), ("m", c_i32), ("N", c_i64), ("T", c_i64), ("layout", c_i32),
-                ("reserved", c_i32), ("scale", c_f64)]
+                ("flags", c_i32), ("scale", c_f64)]
 
 
 class fk_imm_desc(ctypes.Structure):
@@ -46,7 +49,11 @@ class fk_imm_desc(ctypes.Structure):
 
 
 class FilterHipError(RuntimeError):
-    pass
+    """code: the FK_ERR_* value the library returned (None: raised by the Python layer)"""
+
+    def __init__(self, msg, code=None):
+        super().__init__(msg)
+        self.code = code
 
 
 # every symbol include/filterhip.h declares, with its signature
@@ -106,4 +113,4 @@ def lib():
 def check(rc, what):
     if rc != FK_OK:
         msg = lib().fk_last_error().decode(errors="replace")
-        raise FilterHipError(f"{what} failed with code {rc}: {msg}")
+        raise FilterHipError(f"{what} failed with code {rc}: {msg}", code=rc)

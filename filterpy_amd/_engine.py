@@ -74,6 +74,21 @@ def alloc_records(lead_shape, N, E, layout, device=None):
     return torch.empty(shape, dtype=torch.float64, device=device)
 
 
+def alloc_cov_pair(T, N, n, layout, device=None):
+    """Both covariance histories of a batch_filter call in ONE array (FK_KF_FLAG_COV_INTERLEAVED, include/filterhip.h):
+    returns (cov2, covs, covs_p) with covs / covs_p strided views -- NumPy order cov2[T][N][2][n*n], element-major
+    cov2[T][2][n*n][N].  A step's posterior and prior covariance then leave as one contiguous write front; two separate
+    arrays are two fronts, and those interfere when the driver backed both with the same class of physical memory
+    (docs/PLACEMENT.md: 5.2 .. 6.9 ms for the same launch)."""
+    device = device or require_gpu()
+    nn = n * n
+    if layout == "aos":
+        cov2 = torch.empty((T, N, 2, nn), dtype=torch.float64, device=device)
+        return cov2, cov2[:, :, 0], cov2[:, :, 1]
+    cov2 = torch.empty((T, 2, nn, N), dtype=torch.float64, device=device)
+    return cov2, cov2[:, 0], cov2[:, 1]
+
+
 def raise_on_status(status, what):
     """Map per-track status bits to the exception the reference would raise."""
     if status is None:
@@ -83,6 +98,8 @@ def raise_on_status(status, what):
         return
     first = int(bad[0])
     bits = int(status[first])
+    if bits & _abi.FK_STATUS_BAD_WEIGHTS:
+        raise ValueError(f"{what}: FK_UKF_FLAG_PAIR_WEIGHTS given, but the weights of a +- pair of sigma points differ")
     if bits & _abi.FK_STATUS_NOT_PD:
         raise np.linalg.LinAlgError(
             f"{what}: matrix not positive definite / singular for {bad.numel()} track(s), first = {first}")
@@ -172,18 +189,36 @@ def ukf_linear_rts_supported(n):
     return 1 <= n <= 9
 
 
+def pair_weights(Wm, Wc, n):
+    """True where the sigma-point weights are equal within every +- pair (Wm[1+k] == Wm[1+n+k], likewise Wc): what
+    MerweScaledSigmaPoints and JulierSigmaPoints produce (sigma_points.py:180-192, :358-372).  The fused kernels then form the
+    unscented-transform sums over the n pairs (FK_UKF_FLAG_PAIR_WEIGHTS, include/filterhip.h); any other weight set keeps the
+    reference's index-order sums.  Wm / Wc: NumPy arrays or device tensors (those are downloaded: 2 (2n+1) doubles)."""
+    a = Wm.detach().cpu().numpy() if isinstance(Wm, torch.Tensor) else np.asarray(Wm)
+    b = Wc.detach().cpu().numpy() if isinstance(Wc, torch.Tensor) else np.asarray(Wc)
+    return (a.shape == (2 * n + 1,) and b.shape == (2 * n + 1,) and bool(np.array_equal(a[1:n + 1], a[n + 1:]))
+            and bool(np.array_equal(b[1:n + 1], b[n + 1:])))
+
+
+def _ukf_flags(Wm, Wc, n, paired):
+    if paired is None:
+        paired = pair_weights(Wm, Wc, n)
+    return _abi.FK_UKF_FLAG_PAIR_WEIGHTS if paired else 0
+
+
 def ukf_linear_batch(n, m, N, T, layout, scale, F, H, Q, R, Wm, Wc, z, x, P, *, mask=None,
-                     means=None, covs=None, status=None):
-    d = fk_ukf_desc(n=n, m=m, N=N, T=T, layout=LAYOUTS[layout], reserved=0, scale=float(scale))
+                     means=None, covs=None, status=None, paired=None):
+    """fk_ukf_linear_batch_f64.  paired: None = look at the weights (pair_weights), True / False = the caller knows."""
+    d = fk_ukf_desc(n=n, m=m, N=N, T=T, layout=LAYOUTS[layout], flags=_ukf_flags(Wm, Wc, n, paired), scale=float(scale))
     rc = _abi.lib().fk_ukf_linear_batch_f64(d, _ptr(F), _ptr(H), _ptr(Q), _ptr(R), _ptr(Wm), _ptr(Wc),
                                             _ptr(z), _ptr(mask), _ptr(x), _ptr(P), _ptr(means), _ptr(covs),
                                             _ptr(status), _stream())
     _abi.check(rc, "fk_ukf_linear_batch_f64")
 
 
-def ukf_linear_rts(n, N, T, layout, scale, F, Q, Wm, Wc, Xs, Ps, xs, Ps_out, K=None, status=None):
+def ukf_linear_rts(n, N, T, layout, scale, F, Q, Wm, Wc, Xs, Ps, xs, Ps_out, K=None, status=None, paired=None):
     """fk_ukf_linear_rts_f64: the UKF smoother's whole backward pass for a linear fx, one launch."""
-    d = fk_ukf_desc(n=n, m=1, N=N, T=T, layout=LAYOUTS[layout], reserved=0, scale=float(scale))
+    d = fk_ukf_desc(n=n, m=1, N=N, T=T, layout=LAYOUTS[layout], flags=_ukf_flags(Wm, Wc, n, paired), scale=float(scale))
     rc = _abi.lib().fk_ukf_linear_rts_f64(d, _ptr(F), _ptr(Q), _ptr(Wm), _ptr(Wc), _ptr(Xs), _ptr(Ps), _ptr(xs),
                                           _ptr(Ps_out), _ptr(K), _ptr(status), _stream())
     _abi.check(rc, "fk_ukf_linear_rts_f64")

@@ -151,8 +151,8 @@ int kf_chunked_call(const Args &a, int n, int m, long slots, One &&one, hipStrea
             b.mask = ml_off(a.mask, t0 * a.N);
             b.means = ml_off(a.means, t0 * a.N * n);
             b.means_p = ml_off(a.means_p, t0 * a.N * n);
-            b.covs = ml_off(a.covs, t0 * a.N * nn);
-            b.covs_p = ml_off(a.covs_p, t0 * a.N * nn);
+            b.covs = ml_off(a.covs, t0 * a.cov_step);              // (cov_step = N n^2, or 2 N n^2: FK_KF_FLAG_COV_INTERLEAVED)
+            b.covs_p = ml_off(a.covs_p, t0 * a.cov_step);
             if (a.model_t) {                                   // one model per step, shared by the bank (VAR instantiations)
                 b.F = a.F + t0 * nn;
                 b.Q = a.Q + t0 * nn;
@@ -235,6 +235,10 @@ int imm_chunked_call(const Args &a, int n, int m, int nm, long slots, One &&one,
     if (H > 64) H = 64;
     if (H > a.T) H = (int)a.T;
     if (G < 1 || H < 1 || (G == 1 && H == 1) || a.cnt < 256L * G) return one(a, s);
+    // A masked call carries, per filter, the log-density of a zero residual under the LAST S (what update(None) leaves,
+    // kalman_filter.py:515-520 + IMM.py:176-177) from step to step: in registers inside one launch, through ll0 between
+    // launches.  Without ll0 a later time chunk would restart them at -inf: such a call is one launch.
+    if (a.mask && !a.ll0) return one(a, s);
     MlStreams *msp = ml_streams();
     if (!msp) return one(a, s);
     MlStreams &ms = *msp;

@@ -243,6 +243,53 @@ __device__ __forceinline__ void wave_store_aos(const double (&v)[LEN], const dou
     wave_lds_fence();
 }
 
+// wave_store_aos with a run-time record pitch (doubles between the records of consecutive tracks, >= LEN): the wave's 64
+// records are LEN-double islands `pitch` apart (FK_KF_FLAG_COV_INTERLEAVED: the other half of each period is the partner
+// array's record).  pitch == LEN is wave_store_aos.  Every store instruction still writes whole records' worth of
+// contiguous 16-byte units (LEN = 16: eight 128-byte records per instruction, each a full line).
+template <int LEN>
+__device__ __forceinline__ void wave_store_aos_pitch(const double (&v)[LEN], const double *slab, unsigned wave_row0,
+                                                     double *tile, unsigned lane, unsigned last_row, unsigned pitch)
+{
+    constexpr int LENP = LEN | 1;
+    const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(slab), 0,
+                                                        (int)((last_row * pitch + (unsigned)LEN) * 8u), 0x00020000);
+    FK_UNROLL for (int e = 0; e < LEN; ++e) tile[lane * LENP + e] = v[e];
+    wave_lds_fence();
+    if constexpr (LEN % 2 == 0 && 128 % LEN == 0) {
+        constexpr int PASSES = LEN / 2;          // 64*LEN doubles, 128 per pass
+        constexpr int RPP = 128 / LEN;           // rows per pass
+        const unsigned r0 = (lane * 2u) / LEN, col = (lane * 2u) % LEN;
+        const double *tb = tile + r0 * LENP + col;
+        const unsigned gb = ((wave_row0 + r0) * pitch + col) * 8u;
+        const unsigned pass = (unsigned)RPP * pitch * 8u;                  // uniform
+        FK_UNROLL for (int it = 0; it < PASSES; ++it) {
+            const double a = tb[it * RPP * LENP], b = tb[it * RPP * LENP + 1];
+            const u32x2 ua = __builtin_bit_cast(u32x2, a), ub = __builtin_bit_cast(u32x2, b);
+            const u32x4 w = {ua.x, ua.y, ub.x, ub.y};
+            __builtin_amdgcn_raw_buffer_store_b128(w, rs, gb + (unsigned)it * pass, 0, 0);
+        }
+    } else if constexpr (LEN % 2 == 0) {
+        constexpr int PASSES = LEN / 2;
+        FK_UNROLL for (int it = 0; it < PASSES; ++it) {
+            const unsigned q = it * 128u + lane * 2u;
+            const unsigned row = q / LEN, col = q % LEN;
+            const double a = tile[row * LENP + col], b = tile[row * LENP + col + 1];
+            const u32x2 ua = __builtin_bit_cast(u32x2, a), ub = __builtin_bit_cast(u32x2, b);
+            const u32x4 w = {ua.x, ua.y, ub.x, ub.y};
+            __builtin_amdgcn_raw_buffer_store_b128(w, rs, ((wave_row0 + row) * pitch + col) * 8u, 0, 0);
+        }
+    } else {
+        FK_UNROLL for (int it = 0; it < LEN; ++it) {
+            const unsigned q = it * 64u + lane;
+            const unsigned row = q / LEN, col = q % LEN;
+            const double a = tile[row * LENP + col];
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, a), rs, ((wave_row0 + row) * pitch + col) * 8u, 0, 0);
+        }
+    }
+    wave_lds_fence();
+}
+
 // wave_store_aos for the inside of a time loop, even LEN: the tile is FLAT (row stride LEN doubles, i.e. laid out exactly
 // like the wave's slab of the array), so the copy-out needs no row / column arithmetic at all -- one lane-dependent LDS
 // address and one lane-dependent byte offset for the whole record, pass `it` adds the constant it * 1024 to both.  The

@@ -22,6 +22,11 @@ struct KfArgs {
     int rj_diag;        // FK_KF_FLAG_R_JOSEPH_DIAG: K R K' uses only R's diagonal (generic kernel only)
     int status_or;      // kf_ml: OR the status bits into status[] instead of storing them (later time chunks of one call)
     double alpha_sq;
+    // FK_KF_FLAG_COV_INTERLEAVED (kf_fast only): covs / covs_p are the two halves of ONE array, so that a step writes one
+    // contiguous region.  cov_step: doubles between the slabs of consecutive steps (N n^2, or 2 N n^2 interleaved);
+    // cov_pitch: doubles between the records of consecutive tracks in NumPy order (n^2, or 2 n^2 interleaved).
+    long cov_step;
+    int cov_pitch;
 };
 
 struct RtsArgs {

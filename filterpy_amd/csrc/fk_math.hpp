@@ -47,7 +47,7 @@
 
 namespace fk {
 
-enum : int { ST_NOT_PD = 1, ST_NONFINITE = 2, ST_OVERRUN = 4, ST_INTERNAL = 8 };
+enum : int { ST_NOT_PD = 1, ST_NONFINITE = 2, ST_OVERRUN = 4, ST_INTERNAL = 8, ST_BAD_WEIGHTS = 16 };
 
 // ln |S| from the reciprocal pivots of its L D L' factorisation: -ln prod_i (1 / d_i), ONE logarithm instead of a division and a
 // logarithm per pivot (a double-precision log is ~80 VALU instructions).  The product is carried as mantissa x 2^exponent

@@ -316,6 +316,205 @@ FK_HD int ukf_linear_step_v3(double (&x)[NX], double (&P)[NX * (NX + 1) / 2], Lo
     return st;
 }
 
+// The pair table of the "V4" steps below: for sigma-point weights that are equal within every +- pair
+// (Wm[1+k] == Wm[1+n+k], Wc[1+k] == Wc[1+n+k] -- true of MerweScaledSigmaPoints and JulierSigmaPoints,
+// sigma_points.py:180-192, :358-372) the sums of unscented_transform.py:104-126 and UKF.py:483-497 over the 2n+1 points
+// regroup over the n pairs:  Wp = [ sum_i Wm_i , sum_i Wc_i , Wc[1+k] + Wc[1+n+k] (k = 0..NX-1) ]  (sums in index order;
+// padded pairs carry 0).  make_pair_table fills it from the PADDED weight arrays (index 0, 1..NX, NX+1..2NX).
+template <int NX>
+FK_HD void make_pair_table(const double *Wm, const double *Wc, double *Wp)
+{
+    double sm = Wm[0], sc = Wc[0];
+    for (int i = 1; i < 2 * NX + 1; ++i) {
+        sm += Wm[i];
+        sc += Wc[i];
+    }
+    Wp[0] = sm;
+    Wp[1] = sc;
+    for (int k = 0; k < NX; ++k) Wp[2 + k] = Wc[1 + k] + Wc[1 + NX + k];
+}
+
+template <int NX>
+FK_HD bool pair_weights_symmetric(const double *Wm, const double *Wc)
+{
+    bool ok = true;
+    for (int k = 0; k < NX; ++k) ok = ok && (Wm[1 + k] == Wm[1 + NX + k]) && (Wc[1 + k] == Wc[1 + NX + k]);
+    return ok;
+}
+
+// One predict + update step, "V4" (round 4): ukf_linear_step_v3 with the sums regrouped over the +- PAIRS of sigma points.
+// The factor of scale * P, its image F L, the image of the centre point and every weighted sum of
+// unscented_transform.py:104-126 / UKF.py:483-497 are still formed -- what changes is the ASSOCIATION of the sums.  With the
+// images  sf_0 = F x,  sf_{+-k} = F x +- f_k  (f_k = F l_k, column k of F L)  and weights equal within a pair:
+//     mean        sum_i Wm_i sf_i            = (sum_i Wm_i) F x                        [ + sum_k (Wm+ - Wm-) f_k = 0 ]
+//     offsets     y_0 = F x - mean,  y_{+-k} = y_0 +- f_k
+//     covariance  sum_i Wc_i y_i y_i'        = (sum_i Wc_i) y_0 y_0' + sum_k (Wc+ + Wc-) f_k f_k'
+//                                                                              [ + sum_k (Wc+ - Wc-) (y_0 f_k' + f_k y_0') = 0 ]
+//     cross       sum_i Wc_i (s_i - x) d_i'  = sum_k (Wc+ + Wc-) l_k h_k'   (s_{+-k} - x = +-l_k, d_{+-k} = d_0 +- h_k, h_k = H l_k)
+// i.e. n + 1 rank-one terms per covariance instead of 2n + 1 and a mean without its 2n cancelling additions.  Against the
+// reference's index-order sums this is a re-association (the reference's own result moves by as much when ITS sum is
+// re-ordered: tests/golden/make_conditioning.py measures that spread); it is NOT the linear filter's F P F' + Q -- the step
+// still factors scale * P twice, regenerates the points of the prior for the update (UKF.py:407) and applies the weights.
+// (6,3): ~1200 VALU instructions per step against V3's 1801.  Callers assert the symmetry (FK_UKF_FLAG_PAIR_WEIGHTS); the
+// index-order step remains for every other weight set and as the A/B switch (FK_UKF_PAIRED=0).
+// fresh() views carry Wp (make_pair_table) next to Wm / Wc.
+template <int NX, int NZ, class LoadZ, class Fresh>
+FK_HD int ukf_linear_step_v4(double (&x)[NX], double (&P)[NX * (NX + 1) / 2], LoadZ &&load_z, bool has_z,
+                             double scale, Fresh &&fresh)
+{
+    constexpr int PL = NX * (NX + 1) / 2;
+    int st = 0;
+    // ---------------- predict (UKF.py:400-411)
+    {
+        double Fx[NX], FL[NX][NX];
+        {
+            double L[PL];
+            if (!chol_packed_rs<NX>(P, scale, L)) st |= ST_NOT_PD;
+            const auto mv = fresh();
+            FK_UNROLL for (int r = 0; r < NX; ++r) {
+                double f[NX];
+                mv.sm.rowF(r, f);
+                Fx[r] = dot<NX>(f, x);
+                FK_UNROLL for (int k = 0; k < NX; ++k) {
+                    double acc = f[k] * L[sym_idx<NX>(k, k)];
+                    FK_UNROLL for (int c = 0; c < NX; ++c)
+                        if (c > k) acc = fma(f[c], L[sym_idx<NX>(c, k)], acc);
+                    FL[r][k] = acc;
+                }
+                FK_STAGE();
+            }
+        }
+        // mean and the centre point's offset
+        {
+            const auto mv = fresh();
+            const double wms = mv.Wp[0], wcs = mv.Wp[1];
+            double wy[NX];
+            FK_UNROLL for (int r = 0; r < NX; ++r) {
+                x[r] = wms * Fx[r];
+                Fx[r] -= x[r];                                             // y_0
+            }
+            FK_UNROLL for (int r = 0; r < NX; ++r) wy[r] = wcs * Fx[r];
+            FK_UNROLL for (int a2 = 0; a2 < NX; ++a2)
+                FK_UNROLL for (int b = 0; b < NX; ++b)
+                    if (b >= a2) P[sym_idx<NX>(a2, b)] = Fx[a2] * wy[b];
+            FK_STAGE();
+        }
+        // the pairs
+        FK_UNROLL for (int k = 0; k < NX; ++k) {
+            const double wp = fresh(P[PL - 1]).Wp[2 + k];
+            double wf[NX];
+            FK_UNROLL for (int r = 0; r < NX; ++r) wf[r] = wp * FL[r][k];
+            FK_UNROLL for (int a2 = 0; a2 < NX; ++a2)
+                FK_UNROLL for (int b = 0; b < NX; ++b)
+                    if (b >= a2) P[sym_idx<NX>(a2, b)] = fma(FL[a2][k], wf[b], P[sym_idx<NX>(a2, b)]);
+            FK_STAGE();
+        }
+        {
+            FK_UNROLL for (int e = 0; e < PL; ++e) FK_OPAQUE(P[e]);     // every sum complete before the rows of Q are read
+            const auto mv = fresh(P[PL - 1]);
+            FK_UNROLL for (int r = 0; r < NX; ++r) {
+                double q[NX];
+                mv.sm.rowQ(r, q);
+                FK_UNROLL for (int b = 0; b < NX; ++b)
+                    if (b >= r) P[sym_idx<NX>(r, b)] += q[b];
+            }
+        }
+    }
+    // ---------------- update (UKF.py:462-481), sigma points regenerated from the prior (:407)
+    if (has_z) {
+        double z[NZ];
+        load_z(z);
+        double L[PL];
+        if (!chol_packed_rs<NX>(P, scale, L)) st |= ST_NOT_PD;
+        double Hx[NZ], HL[NZ][NX];
+        {
+            const auto mv = fresh();
+            FK_UNROLL for (int r = 0; r < NZ; ++r) {
+                double h[NX];
+                mv.sm.rowH(r, h);
+                Hx[r] = dot<NX>(h, x);
+                FK_UNROLL for (int k = 0; k < NX; ++k) {
+                    double acc = h[k] * L[sym_idx<NX>(k, k)];
+                    FK_UNROLL for (int c = 0; c < NX; ++c)
+                        if (c > k) acc = fma(h[c], L[sym_idx<NX>(c, k)], acc);
+                    HL[r][k] = acc;
+                }
+            }
+            FK_STAGE();
+        }
+        double zp[NZ], S[NZ * NZ], K[NX * NZ];
+        {
+            const auto mv = fresh();
+            const double wms = mv.Wp[0], wcs = mv.Wp[1];
+            double wd[NZ];
+            FK_UNROLL for (int r = 0; r < NZ; ++r) {
+                zp[r] = wms * Hx[r];
+                Hx[r] -= zp[r];                                            // d_0
+            }
+            FK_UNROLL for (int r = 0; r < NZ; ++r) wd[r] = wcs * Hx[r];
+            FK_UNROLL for (int r = 0; r < NZ; ++r)
+                FK_UNROLL for (int c = 0; c < NZ; ++c)
+                    if (c >= r) S[r * NZ + c] = Hx[r] * wd[c];
+        }
+        FK_UNROLL for (int k = 0; k < NX; ++k) {
+            const double wp = fresh(S[NZ * NZ - 1]).Wp[2 + k];
+            double wh[NZ];
+            FK_UNROLL for (int r = 0; r < NZ; ++r) wh[r] = wp * HL[r][k];
+            FK_UNROLL for (int r = 0; r < NZ; ++r)
+                FK_UNROLL for (int c = 0; c < NZ; ++c)
+                    if (c >= r) S[r * NZ + c] = fma(HL[r][k], wh[c], S[r * NZ + c]);
+            FK_UNROLL for (int r = 0; r < NX; ++r) {
+                if (r < k) continue;                                       // l_k is zero above the diagonal
+                FK_UNROLL for (int c = 0; c < NZ; ++c)
+                    K[r * NZ + c] = (k == 0) ? L[sym_idx<NX>(r, k)] * wh[c] : fma(L[sym_idx<NX>(r, k)], wh[c], K[r * NZ + c]);
+            }
+            FK_STAGE();
+        }
+        {
+            FK_UNROLL for (int r = 0; r < NZ; ++r)
+                FK_UNROLL for (int c = 0; c < NZ; ++c)
+                    if (c < r) S[r * NZ + c] = S[c * NZ + r];
+            FK_UNROLL for (int e = 0; e < NZ * NZ; ++e) FK_OPAQUE(S[e]);
+            FK_UNROLL for (int e = 0; e < NX * NZ; ++e) FK_OPAQUE(K[e]);
+            const auto mv = fresh(S[NZ * NZ - 1]);
+            FK_UNROLL for (int r = 0; r < NZ; ++r) {
+                double rr[NZ];
+                mv.sm.rowR(r, rr);
+                FK_UNROLL for (int c = 0; c < NZ; ++c) S[r * NZ + c] += rr[c];
+            }
+        }
+        // K = Pxz S^-1
+        double Lf[NZ * NZ], dd[NZ], dinv[NZ];
+        FK_UNROLL for (int e = 0; e < NZ * NZ; ++e) Lf[e] = S[e];
+        if (!ldlt2_rs<NZ>(Lf, dd, dinv)) st |= ST_NOT_PD;
+        solve_rows_ldlt<NX, NZ>(Lf, dinv, K);
+        // x += K (z - zp)
+        FK_UNROLL for (int c = 0; c < NZ; ++c) z[c] -= zp[c];
+        FK_UNROLL for (int r = 0; r < NX; ++r) {
+            double acc = K[r * NZ] * z[0];
+            FK_UNROLL for (int c = 1; c < NZ; ++c) acc = fma(K[r * NZ + c], z[c], acc);
+            x[r] += acc;
+        }
+        // P -= K (S K'), upper triangle
+        FK_UNROLL for (int c2 = 0; c2 < NX; ++c2) {
+            double sk[NZ];                 // column c2 of S K'
+            FK_UNROLL for (int q = 0; q < NZ; ++q) {
+                double acc = S[q * NZ] * K[c2 * NZ];
+                FK_UNROLL for (int w = 1; w < NZ; ++w) acc = fma(S[q * NZ + w], K[c2 * NZ + w], acc);
+                sk[q] = acc;
+            }
+            FK_UNROLL for (int r = 0; r < NX; ++r)
+                if (r <= c2) {
+                    double acc = K[r * NZ] * sk[0];
+                    FK_UNROLL for (int q = 1; q < NZ; ++q) acc = fma(K[r * NZ + q], sk[q], acc);
+                    P[sym_idx<NX>(r, c2)] -= acc;
+                }
+            FK_STAGE();
+        }
+    }
+    return st;
+}
+
 // One backward step of UnscentedKalmanFilter.rts_smoother with fx(x, dt) = F x (UKF.py:714-737), fused:
 //   sigmas = sigma_points(xs[k], ps[k]) ; sigmas_f = F sigmas ; (xb, Pb) = UT(sigmas_f, Wm, Wc, Q)
 //   Pxb = sum_i Wc_i (sigmas_i - Xs[k]) (sigmas_f_i - xb)' ; K = Pxb inv(Pb)
@@ -390,6 +589,86 @@ FK_HD int ukf_linear_rts_gain_v3(double (&x)[NX], const double (&P)[NX * (NX + 1
             }
             FK_STAGE();
         }
+        FK_UNROLL for (int e = 0; e < PL; ++e) FK_OPAQUE(Pb[e]);
+        const auto mv = fresh(Pb[PL - 1]);
+        FK_UNROLL for (int r = 0; r < NX; ++r) {
+            double q[NX];
+            mv.sm.rowQ(r, q);
+            FK_UNROLL for (int b = 0; b < NX; ++b)
+                if (b >= r) Pb[sym_idx<NX>(r, b)] += q[b];
+        }
+    }
+    // K = Pxb inv(Pb)
+    {
+        double Lp[PL], d[NX], dinv[NX];
+        FK_UNROLL for (int e = 0; e < PL; ++e) Lp[e] = Pb[e];
+        if (!ldlt_packed_rs<NX>(Lp, d, dinv)) st |= ST_NOT_PD;
+        FK_UNROLL for (int r = 0; r < NX; ++r) {
+            double row[NX];
+            FK_UNROLL for (int c = 0; c < NX; ++c) row[c] = K[r * NX + c];
+            solve_row_packed<NX>(Lp, dinv, row);
+            FK_UNROLL for (int c = 0; c < NX; ++c) K[r * NX + c] = row[c];
+        }
+    }
+    FK_STAGE();
+    return st;
+}
+
+// ukf_linear_rts_gain_v3 with the sums regrouped over the +- pairs (see ukf_linear_step_v4; weights equal within a pair):
+//   xb = (sum Wm) F x ;  Pb = (sum Wc) y_0 y_0' + sum_k (Wc+ + Wc-) f_k f_k' + Q ;  Pxb = sum_k (Wc+ + Wc-) l_k f_k'
+template <int NX, class Fresh>
+FK_HD int ukf_linear_rts_gain_v4(double (&x)[NX], const double (&P)[NX * (NX + 1) / 2], double scale, double (&xb)[NX],
+                                 double (&Pb)[NX * (NX + 1) / 2], double (&K)[NX * NX], Fresh &&fresh)
+{
+    constexpr int PL = NX * (NX + 1) / 2;
+    int st = 0;
+    double L[PL];
+    if (!chol_packed_rs<NX>(P, scale, L)) st |= ST_NOT_PD;
+    double Fx[NX], FL[NX][NX];
+    {
+        const auto mv = fresh();
+        FK_UNROLL for (int r = 0; r < NX; ++r) {
+            double f[NX];
+            mv.sm.rowF(r, f);
+            Fx[r] = dot<NX>(f, x);
+            FK_UNROLL for (int k = 0; k < NX; ++k) {
+                double acc = f[k] * L[sym_idx<NX>(k, k)];
+                FK_UNROLL for (int c = 0; c < NX; ++c)
+                    if (c > k) acc = fma(f[c], L[sym_idx<NX>(c, k)], acc);
+                FL[r][k] = acc;
+            }
+            FK_STAGE();
+        }
+    }
+    {
+        const auto mv = fresh();
+        const double wms = mv.Wp[0], wcs = mv.Wp[1];
+        double wy[NX];
+        FK_UNROLL for (int r = 0; r < NX; ++r) {
+            xb[r] = wms * Fx[r];
+            Fx[r] -= xb[r];                                                // y_0
+        }
+        FK_UNROLL for (int r = 0; r < NX; ++r) wy[r] = wcs * Fx[r];
+        FK_UNROLL for (int a2 = 0; a2 < NX; ++a2)
+            FK_UNROLL for (int b = 0; b < NX; ++b)
+                if (b >= a2) Pb[sym_idx<NX>(a2, b)] = Fx[a2] * wy[b];
+        FK_STAGE();
+    }
+    FK_UNROLL for (int k = 0; k < NX; ++k) {
+        const double wp = fresh(Pb[PL - 1]).Wp[2 + k];
+        double wf[NX];
+        FK_UNROLL for (int r = 0; r < NX; ++r) wf[r] = wp * FL[r][k];
+        FK_UNROLL for (int a2 = 0; a2 < NX; ++a2)
+            FK_UNROLL for (int b = 0; b < NX; ++b)
+                if (b >= a2) Pb[sym_idx<NX>(a2, b)] = fma(FL[a2][k], wf[b], Pb[sym_idx<NX>(a2, b)]);
+        FK_UNROLL for (int r = 0; r < NX; ++r) {
+            if (r < k) continue;                                           // l_k is zero above the diagonal
+            FK_UNROLL for (int c = 0; c < NX; ++c)
+                K[r * NX + c] = (k == 0) ? L[sym_idx<NX>(r, k)] * wf[c] : fma(L[sym_idx<NX>(r, k)], wf[c], K[r * NX + c]);
+        }
+        FK_STAGE();
+    }
+    {
         FK_UNROLL for (int e = 0; e < PL; ++e) FK_OPAQUE(Pb[e]);
         const auto mv = fresh(Pb[PL - 1]);
         FK_UNROLL for (int r = 0; r < NX; ++r) {

@@ -150,7 +150,7 @@ static int check_desc(const fk_kf_desc *d)
     if (d->N < 0 || d->T < 0) return fail(FK_ERR_BAD_ARG, "N and T must be >= 0");
     if (d->layout != FK_LAYOUT_AOS && d->layout != FK_LAYOUT_SOA) return fail(FK_ERR_BAD_ARG, "bad layout");
     if (d->model_mode < 0 || d->model_mode > 3) return fail(FK_ERR_BAD_ARG, "bad model_mode");
-    if (d->flags & ~FK_KF_FLAG_R_JOSEPH_DIAG) return fail(FK_ERR_BAD_ARG, "unknown desc flag");
+    if (d->flags & ~(FK_KF_FLAG_R_JOSEPH_DIAG | FK_KF_FLAG_COV_INTERLEAVED)) return fail(FK_ERR_BAD_ARG, "unknown desc flag");
     // one step's record block is addressed with 32-bit byte offsets (fk_device.hpp)
     const long E = (long)d->n * (d->n > d->m ? d->n : d->m);
     if ((double)d->N * (double)E * 8.0 >= 4294967296.0)
@@ -174,6 +174,20 @@ static int run_kf(const fk_kf_desc *d, KfArgs &a, void *stream)
     const bool uniform = (d->model_mode == FK_MODEL_SHARED || d->model_mode == FK_MODEL_PER_STEP);
     a.i0 = 0;
     a.cnt = d->N;
+    const long nn = (long)d->n * d->n;
+    a.cov_step = d->N * nn;
+    a.cov_pitch = (int)nn;
+    const bool inter = (d->flags & FK_KF_FLAG_COV_INTERLEAVED) != 0;
+    if (inter) {
+        if (!a.means || !a.covs || !a.means_p || !a.covs_p || !a.do_predict || !a.do_update)
+            return fail(FK_ERR_BAD_ARG, "FK_KF_FLAG_COV_INTERLEAVED: batch_filter with all four outputs");
+        const long half = d->layout == FK_LAYOUT_AOS ? nn : nn * d->N;
+        if (a.covs_p != a.covs + half) return fail(FK_ERR_BAD_ARG, "FK_KF_FLAG_COV_INTERLEAVED: covs_p must be covs + n*n (AOS) / covs + n*n*N (SOA)");
+        if ((double)d->N * (double)nn * 16.0 >= 4294967296.0)
+            return fail(FK_ERR_UNSUPPORTED, "FK_KF_FLAG_COV_INTERLEAVED: 2 * N * dim_x^2 * 8 bytes must stay below 4 GiB");
+        a.cov_step = 2 * d->N * nn;
+        if (d->layout == FK_LAYOUT_AOS) a.cov_pitch = (int)(2 * nn);
+    }
     // Specialised kernel (kf_fast.hip) for the common batch_filter call: predict->update, no control
     // input, all four outputs stored or none (every model mode at dim_x <= 6, shared constant model above).
     const bool all_out = a.means && a.covs && a.means_p && a.covs_p;
@@ -186,12 +200,14 @@ static int run_kf(const fk_kf_desc *d, KfArgs &a, void *stream)
     if (a.do_predict && a.do_update && (all_out || no_out) && (!want_ex || fast_ex) && !a.rj_diag && !getenv("FK_NO_FAST")) {
         const char *g9 = getenv("FK_ML9");          // "g": dim_x = 9 on the four-lane kernels (A/B against kf_ml / rts_ml)
         if (!want_ex && d->n == 9 && d->m == 3 && !getenv("FK_NO_ML") && !(g9 && g9[0] == 'g')) {
+            if (inter) return fail(FK_ERR_UNSUPPORTED, "FK_KF_FLAG_COV_INTERLEAVED: (9,3) runs on the three-lane kernel, which takes two arrays");
             const int rc = launch_kf_ml_9_3(a, d->layout, all_out, d->model_mode, (hipStream_t)stream);
             if (rc <= 0) return rc;        // 1 = not a call the multi-lane kernel serves
         }
         // (dim_x = 7, 8 were tried on the four-lane kernel too: 0.30 against kf_fast's 0.50 -- two rows per lane leave
         // the replicated S / x work dominant; profiles/r02/dims_7_8_ml_vs_fast.txt)
         if (!want_ex && (d->n >= 10 || (g9 && g9[0] == 'g')) && !getenv("FK_NO_MLG")) {
+            if (inter) return fail(FK_ERR_UNSUPPORTED, "FK_KF_FLAG_COV_INTERLEAVED: dim_x >= 10 runs on the four-lane kernels, which take two arrays");
             for (const FastEntry &g : mlg_table) {
                 if (g.nx != d->n || g.nz != d->m) continue;
                 const int rc = g.fn(a, d->layout, all_out, d->model_mode, (hipStream_t)stream);
@@ -216,6 +232,7 @@ static int run_kf(const fk_kf_desc *d, KfArgs &a, void *stream)
             if (rc <= 0) return rc;        // 1 = this instantiation does not carry the model mode
         }
     }
+    if (inter) return fail(FK_ERR_UNSUPPORTED, "FK_KF_FLAG_COV_INTERLEAVED: not a call the specialised kernel serves");
     return e->fn(a, d->layout, uniform, (hipStream_t)stream);
 }
 

@@ -226,10 +226,10 @@ kf_fast_kernel(const KfArgs a, const double *__restrict__ pF, const double *__re
             if (!OUTS) {
             } else if (!COOP) {
                 store_rec<NX, 1, LAYOUT, true>(x, a.means_p + t * N * NX, ln, NX, 1);
-                store_rec<NX, NX, LAYOUT, true>(Pf, a.covs_p + t * N * NX * NX, ln, NX, NX);
+                store_rec<NX, NX, LAYOUT, true>(Pf, a.covs_p + t * a.cov_step, ln, NX, NX);
             } else {
                 wave_store_aos<NX>(x, a.means_p + (t * N + blk0) * NX, wave * 64u, tile, lane, last_row);
-                wave_store_aos<NX * NX>(Pf, a.covs_p + (t * N + blk0) * NX * NX, wave * 64u, tile, lane, last_row);
+                wave_store_aos_pitch<NX * NX>(Pf, a.covs_p + t * a.cov_step + blk0 * a.cov_pitch, wave * 64u, tile, lane, last_row, (unsigned)a.cov_pitch);
             }
         };
         auto do_update = [&]() {
@@ -307,10 +307,10 @@ kf_fast_kernel(const KfArgs a, const double *__restrict__ pF, const double *__re
             if (!OUTS) {
             } else if (!COOP) {
                 store_rec<NX, 1, LAYOUT, true>(x, a.means + t * N * NX, ln, NX, 1);
-                store_rec<NX, NX, LAYOUT, true>(Pf, a.covs + t * N * NX * NX, ln, NX, NX);
+                store_rec<NX, NX, LAYOUT, true>(Pf, a.covs + t * a.cov_step, ln, NX, NX);
             } else {
                 wave_store_aos<NX>(x, a.means + (t * N + blk0) * NX, wave * 64u, tile, lane, last_row);
-                wave_store_aos<NX * NX>(Pf, a.covs + (t * N + blk0) * NX * NX, wave * 64u, tile, lane, last_row);
+                wave_store_aos_pitch<NX * NX>(Pf, a.covs + t * a.cov_step + blk0 * a.cov_pitch, wave * 64u, tile, lane, last_row, (unsigned)a.cov_pitch);
             }
         };
         if constexpr (UF) {
@@ -382,6 +382,9 @@ using namespace FK_CAT(fastv_, FK_NX, FK_NZ, FK_VARIANT);
 int FK_CAT(launch_kf_fast_, FK_NX, FK_NZ, FK_VARIANT)(const KfArgs &a, int layout, bool outs, int mmode, hipStream_t stream)
 {
     const dim3 grid((unsigned)((a.cnt + BLOCK - 1) / BLOCK)), block(BLOCK);
+    // FK_KF_FLAG_COV_INTERLEAVED in NumPy order needs the wave-cooperative store path (the record pitch is its argument)
+    constexpr bool coop_aos = FK_NX * FK_NX <= 36 || (FK_NX <= 8 && fast_min_waves(FK_NX, LAYOUT_AOS) == 1);
+    if (layout == LAYOUT_AOS && a.cov_pitch != FK_NX * FK_NX && !coop_aos) return 1;
     if (a.y_out || a.K_out || a.S_out || a.SI_out || a.ll_out || a.maha_out) {
 #if FK_FAST_EX
         if (mmode != 0 || !outs || a.update_first || a.nu > 0 || !a.extras_per_step) return 1;

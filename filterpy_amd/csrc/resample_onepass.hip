@@ -659,6 +659,7 @@ struct OpArgs {
     OpDesc *desc;
     int *bad;           // [Fn]: filter holds a weight the fast path does not take -> resample_literal_kernel
     double delta;       // relative error bound of the stage-1 prefix
+    const unsigned *only_if;   // resample_local_kernel as the one-pass kernel's repair pass: run only if this word is non-zero
 };
 
 #ifndef FK_OP_WAVES
@@ -1317,6 +1318,8 @@ __global__ void __launch_bounds__(OP_THREADS, WAVES)
 resample_local_kernel(const OpArgs a)
 {
     __shared__ OpShared sh;
+    // the repair pass of onepass_launch: nothing to do unless a hand-off of the one-pass kernel timed out (uniform exit)
+    if (a.only_if && __hip_atomic_load(a.only_if, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;
     const long Np = a.Np, nch = a.nch;
     const int f = blockIdx.x;
     const double *wf = a.w + (long)f * Np;
@@ -1603,7 +1606,7 @@ int onepass_launch(bool stratified, int64_t Fn, int64_t Np, const double *w, con
     const unsigned long total = (unsigned long)Fn * (unsigned long)nch;
     if (total >= 0x7fffffffUL || Fn > 0x7fffffffL / 2) return FK_ERR_UNSUPPORTED;
     char *p = (char *)ws;
-    OpArgs a;
+    OpArgs a = {};
     a.Np = (long)Np;
     a.nch = nch;
     a.Fn = (int)Fn;
@@ -1634,7 +1637,22 @@ int onepass_launch(bool stratified, int64_t Fn, int64_t Np, const double *w, con
         else if (spec) hipLaunchKernelGGL((resample_onepass_kernel<STRAT, true, true>), grid, block, 0, s, a);        \
         else hipLaunchKernelGGL((resample_onepass_kernel<STRAT, true, false>), grid, block, 0, s, a);                 \
         hipLaunchKernelGGL((resample_literal_kernel<STRAT>), dim3((unsigned)Fn), dim3(64), 0, s, a);                  \
+        hipLaunchKernelGGL((resample_local_kernel<STRAT, 3>), dim3((unsigned)Fn), block, 0, s, r);                    \
     } while (0)
+    // The repair pass (round 4).  The hand-offs between chunks are bounded spins; one that times out sets the abort word and
+    // FK_STATUS_INTERNAL instead of hanging.  With tickets that cannot happen (a chunk only waits for chunks taken earlier);
+    // with the static assignment it rests on the order in which the hardware starts the workgroups of a 1-D grid, which is
+    // an observation, not a promise (CU masking, a co-tenant, a priority queue).  Instead of reporting the failure, the
+    // call repairs itself: resample_local_kernel -- one workgroup per filter, chunks in sequence, no workgroup ever waits
+    // for another -- runs behind the one-pass kernel and exits at once unless the abort word is set; then it recomputes
+    // every filter of the call (indices and status, bit-identical to the one-pass result by the same exact arithmetic).
+    // FK_OP_FORCE_ABORT=1 (tests) presets the abort word, so that every chunk that has to wait gives up.
+    OpArgs r = a;
+    r.only_if = &a.ctl->abort;
+    if (const char *fv = getenv("FK_OP_FORCE_ABORT"); fv && fv[0] == '1') {
+        static const unsigned one = 1u;
+        if (hipMemcpyAsync(&a.ctl->abort, &one, sizeof(one), hipMemcpyHostToDevice, s) != hipSuccess) return FK_ERR_LAUNCH;
+    }
     if (stratified) GO(true);
     else GO(false);
 #undef GO

@@ -4,8 +4,9 @@
 //                              fx(x, dt) = F x, hx(x) = H x: the whole predict (UKF.py:400-411) / update
 //                              (:462-481) loop stays in registers over the time steps.
 //   fk_ukf_linear_rts_f64   <- UnscentedKalmanFilter.rts_smoother (UKF.py:634-739), likewise.
-// FK_UKF_PART: the Makefile compiles this file four times (parallel build) -- 1: forward kernels dim_x <= 6 + the forward
-// entry point, 2: forward dim_x 7..9, 3: smoother dim_x <= 6 + the smoother's entry point, 4: smoother dim_x 7..9.
+// FK_UKF_PART: the Makefile compiles this file eight times (parallel build) -- 1: forward kernels dim_x <= 6 + the forward
+// entry point, 2: forward dim_x 7..9, 3: smoother dim_x <= 6 + the smoother's entry point, 4: smoother dim_x 7..9; 5..8: the
+// same four sets of kernels with the sums regrouped over the +- pairs of sigma points (PAIRED, fk_ukf.hpp: the V4 steps).
 #include <stdlib.h>
 
 #ifndef FK_UKF_PART
@@ -13,8 +14,8 @@
 #endif
 #define FK_UKF_HAS(p) (FK_UKF_PART == 0 || FK_UKF_PART == (p))
 // (parts 91 / 92: the forward / smoother kernel templates alone, for one-off instantiations: tools/ukf_one_kernel.py)
-#define FK_UKF_FWD (FK_UKF_HAS(1) || FK_UKF_HAS(2) || FK_UKF_PART == 91)
-#define FK_UKF_RTS (FK_UKF_HAS(3) || FK_UKF_HAS(4) || FK_UKF_PART == 92)
+#define FK_UKF_FWD (FK_UKF_HAS(1) || FK_UKF_HAS(2) || FK_UKF_HAS(5) || FK_UKF_HAS(6) || FK_UKF_PART == 91)
+#define FK_UKF_RTS (FK_UKF_HAS(3) || FK_UKF_HAS(4) || FK_UKF_HAS(7) || FK_UKF_HAS(8) || FK_UKF_PART == 92)
 
 #include "../../include/filterhip.h"
 #include "fk_chunks.hpp"
@@ -65,7 +66,10 @@ struct UkfRtsArgs {
 //     (same values to the same addresses); the wave-cooperative NumPy-order stores drop rows past the last track by
 //     the descriptor's range check.  The in-place store of the final state IS predicated and sits behind a workgroup
 //     barrier (a duplicate must have consumed x0 / P0 before its owner overwrites them).
-template <int NX, int NZ, int LAYOUT, bool EXACT>
+//   * PAIRED (round 4): the step is ukf_linear_step_v4 -- the sums regrouped over the +- pairs of sigma points, for weights
+//     equal within every pair (the caller's FK_UKF_FLAG_PAIR_WEIGHTS; the prologue checks it and reports
+//     FK_STATUS_BAD_WEIGHTS on every track otherwise).  The pair table sits behind the weights in LDS.
+template <int NX, int NZ, int LAYOUT, bool EXACT, bool PAIRED>
 __global__ void __launch_bounds__(BLOCK, (NX <= 2 ? 4 : NX <= 6 ? 2 : 1))
 ukf_linear_kernel(const UkfArgs a, const double *__restrict__ pF, const double *__restrict__ pH,
                   const double *__restrict__ pQ, const double *__restrict__ pR,
@@ -75,7 +79,7 @@ ukf_linear_kernel(const UkfArgs a, const double *__restrict__ pF, const double *
     constexpr int KS = 2 * NX + 1;
     constexpr int PL = NX * (NX + 1) / 2;
     using SharedModel = LdsModel<NX, NZ>;
-    __shared__ double s_model[SharedModel::SIZE + 2 * KS];
+    __shared__ double s_model[SharedModel::SIZE + 2 * KS + 2 + NX];
     // NumPy order at the exact dims: the per-step outputs leave through a wave-private LDS tile, 1 KiB contiguous per store
     // instruction (wave_store_aos_flat, fk_device.hpp) -- a lane-per-record store touches 64 lines per instruction.
     // (dim_x 9: the tile of an 81-double record does not fit next to four waves.)
@@ -109,15 +113,21 @@ ukf_linear_kernel(const UkfArgs a, const double *__restrict__ pF, const double *
         s_model[SharedModel::SIZE + q] = (src >= 0 && src < ks) ? W[src] : 0.0;
     }
     __syncthreads();
+    int st = 0;
+    if constexpr (PAIRED) {
+        if (threadIdx.x == 0) make_pair_table<NX>(s_model + SharedModel::SIZE, s_model + SharedModel::SIZE + KS, s_model + SharedModel::SIZE + 2 * KS);
+        if (!pair_weights_symmetric<NX>(s_model + SharedModel::SIZE, s_model + SharedModel::SIZE + KS)) st |= ST_BAD_WEIGHTS;
+        __syncthreads();
+    }
     // a view of the LDS model the optimiser cannot relate to the previous one: keeps it from hoisting the
     // broadcast row reads of all 2n+1 unrolled points to the top (they are cheap to repeat, dear to hold)
     // (an offset is made opaque, not the pointer: that keeps the LDS address space)
-    struct View { SharedModel sm; const double *Wm, *Wc; };
+    struct View { SharedModel sm; const double *Wm, *Wc, *Wp; };
     auto fresh = [&](double after = 0.0) {
         int off = 0;
         asm volatile("" : "+v"(off) : "v"(after));
         const double *mb = s_model + off;
-        return View{SharedModel{mb}, mb + SharedModel::SIZE, mb + SharedModel::SIZE + KS};
+        return View{SharedModel{mb}, mb + SharedModel::SIZE, mb + SharedModel::SIZE + KS, mb + SharedModel::SIZE + 2 * KS};
     };
 
     double x[NX], P[PL];
@@ -138,7 +148,6 @@ ukf_linear_kernel(const UkfArgs a, const double *__restrict__ pF, const double *
     FK_UNROLL for (int c = 0; c < NX; ++c) asm volatile("" ::"v"(x[c]));
     FK_UNROLL for (int e = 0; e < PL; ++e) asm volatile("" ::"v"(P[e]));
     asm volatile("" ::"v"(hc));
-    int st = 0;
 
     _Pragma("nounroll") for (long t = 0; t < a.T; ++t) {
         const bool has_z = pmask ? hc != 0u : true;
@@ -152,7 +161,8 @@ ukf_linear_kernel(const UkfArgs a, const double *__restrict__ pF, const double *
         }
         auto load_z = [&](double (&z)[NZ]) { load_rec<NZ, 1, LAYOUT, EXACT>(z, pz + t * N * m, ln, m, 1, 0.0); };
 
-        st |= ukf_linear_step_v3<NX, NZ>(x, P, load_z, has_z, a.scale, fresh);
+        if constexpr (PAIRED) st |= ukf_linear_step_v4<NX, NZ>(x, P, load_z, has_z, a.scale, fresh);
+        else st |= ukf_linear_step_v3<NX, NZ>(x, P, load_z, has_z, a.scale, fresh);
         FK_STAGE();
         asm volatile("" : "+v"(hn));
         hc = hn;
@@ -196,6 +206,11 @@ int ukf_fwd_launch_small(const UkfArgs &a, int layout, bool exact, hipStream_t s
 int ukf_fwd_launch_big(const UkfArgs &a, int layout, bool exact, hipStream_t s);      // classes (8,4), (9,3), (9,4)
 int ukf_rts_launch_small(const UkfRtsArgs &a, const double *F, const double *Q, const double *Wm, const double *Wc, int layout, bool exact, hipStream_t s);   // 2, 4, 6
 int ukf_rts_launch_big(const UkfRtsArgs &a, const double *F, const double *Q, const double *Wm, const double *Wc, int layout, bool exact, hipStream_t s);     // 8, 9
+// ... and of their PAIRED twins (parts 5..8)
+int ukf_fwd_launch_small_paired(const UkfArgs &a, int layout, bool exact, hipStream_t s);
+int ukf_fwd_launch_big_paired(const UkfArgs &a, int layout, bool exact, hipStream_t s);
+int ukf_rts_launch_small_paired(const UkfRtsArgs &a, const double *F, const double *Q, const double *Wm, const double *Wc, int layout, bool exact, hipStream_t s);
+int ukf_rts_launch_big_paired(const UkfRtsArgs &a, const double *F, const double *Q, const double *Wm, const double *Wc, int layout, bool exact, hipStream_t s);
 
 #if FK_UKF_FWD
 #define FK_UKF_GO(NXV, NZV)                                                                                      \
@@ -203,30 +218,40 @@ int ukf_rts_launch_big(const UkfRtsArgs &a, const double *F, const double *Q, co
         const dim3 grid((unsigned)((a.cnt + BLOCK - 1) / BLOCK)), block(BLOCK);                                  \
         const bool ex = exact && a.n == NXV && a.m == NZV;                                                       \
         if (layout == FK_LAYOUT_SOA) {                                                                           \
-            if (ex) hipLaunchKernelGGL((ukf_linear_kernel<NXV, NZV, LAYOUT_SOA, true>), grid, block, 0, s, a, a.F, a.H, a.Q, a.R, a.Wm, a.Wc, a.z, a.mask); \
-            else hipLaunchKernelGGL((ukf_linear_kernel<NXV, NZV, LAYOUT_SOA, false>), grid, block, 0, s, a, a.F, a.H, a.Q, a.R, a.Wm, a.Wc, a.z, a.mask);  \
+            if (ex) hipLaunchKernelGGL((ukf_linear_kernel<NXV, NZV, LAYOUT_SOA, true, PV>), grid, block, 0, s, a, a.F, a.H, a.Q, a.R, a.Wm, a.Wc, a.z, a.mask); \
+            else hipLaunchKernelGGL((ukf_linear_kernel<NXV, NZV, LAYOUT_SOA, false, PV>), grid, block, 0, s, a, a.F, a.H, a.Q, a.R, a.Wm, a.Wc, a.z, a.mask);  \
         } else {                                                                                                 \
-            if (ex) hipLaunchKernelGGL((ukf_linear_kernel<NXV, NZV, LAYOUT_AOS, true>), grid, block, 0, s, a, a.F, a.H, a.Q, a.R, a.Wm, a.Wc, a.z, a.mask); \
-            else hipLaunchKernelGGL((ukf_linear_kernel<NXV, NZV, LAYOUT_AOS, false>), grid, block, 0, s, a, a.F, a.H, a.Q, a.R, a.Wm, a.Wc, a.z, a.mask);  \
+            if (ex) hipLaunchKernelGGL((ukf_linear_kernel<NXV, NZV, LAYOUT_AOS, true, PV>), grid, block, 0, s, a, a.F, a.H, a.Q, a.R, a.Wm, a.Wc, a.z, a.mask); \
+            else hipLaunchKernelGGL((ukf_linear_kernel<NXV, NZV, LAYOUT_AOS, false, PV>), grid, block, 0, s, a, a.F, a.H, a.Q, a.R, a.Wm, a.Wc, a.z, a.mask);  \
         }                                                                                                        \
     } while (0)
-#if FK_UKF_HAS(1)
-int ukf_fwd_launch_small(const UkfArgs &a, int layout, bool exact, hipStream_t s)
+template <bool PV>
+static int ukf_fwd_small_t(const UkfArgs &a, int layout, bool exact, hipStream_t s)
 {
     if (a.n <= 2 && a.m <= 2) FK_UKF_GO(2, 2);
     else if (a.n <= 4 && a.m <= 2) FK_UKF_GO(4, 2);
     else FK_UKF_GO(6, 3);
     return check_launch("ukf_linear_kernel");
 }
-#endif
-#if FK_UKF_HAS(2)
-int ukf_fwd_launch_big(const UkfArgs &a, int layout, bool exact, hipStream_t s)
+template <bool PV>
+static int ukf_fwd_big_t(const UkfArgs &a, int layout, bool exact, hipStream_t s)
 {
     if (a.n <= 8) FK_UKF_GO(8, 4);
     else if (a.m <= 3) FK_UKF_GO(9, 3);
     else FK_UKF_GO(9, 4);
     return check_launch("ukf_linear_kernel");
 }
+#if FK_UKF_HAS(1)
+int ukf_fwd_launch_small(const UkfArgs &a, int layout, bool exact, hipStream_t s) { return ukf_fwd_small_t<false>(a, layout, exact, s); }
+#endif
+#if FK_UKF_HAS(2)
+int ukf_fwd_launch_big(const UkfArgs &a, int layout, bool exact, hipStream_t s) { return ukf_fwd_big_t<false>(a, layout, exact, s); }
+#endif
+#if FK_UKF_HAS(5)
+int ukf_fwd_launch_small_paired(const UkfArgs &a, int layout, bool exact, hipStream_t s) { return ukf_fwd_small_t<true>(a, layout, exact, s); }
+#endif
+#if FK_UKF_HAS(6)
+int ukf_fwd_launch_big_paired(const UkfArgs &a, int layout, bool exact, hipStream_t s) { return ukf_fwd_big_t<true>(a, layout, exact, s); }
 #endif
 #undef FK_UKF_GO
 #endif
@@ -262,7 +287,8 @@ struct UpperTriangle {
 //     lines per instruction: the n = 6 backward pass took 5.6 ms in NumPy order against 2.0 ms element-major);
 //   * lanes past the last track duplicate it (or, on the cooperative path, compute on zeros that the descriptors never
 //     store); no store is predicated.
-template <int NX, int LAYOUT, bool EXACT, bool DMA = false>
+//   * PAIRED (round 4): the gain is ukf_linear_rts_gain_v4 (sums regrouped over the +- pairs; see the forward kernel).
+template <int NX, int LAYOUT, bool EXACT, bool PAIRED, bool DMA = false>
 __global__ void __launch_bounds__(BLOCK, (NX <= 2 ? 4 : NX <= 4 ? 2 : 1))
 ukf_linear_rts_kernel(const UkfRtsArgs a, const double *__restrict__ pF, const double *__restrict__ pQ,
                       const double *__restrict__ pWm, const double *__restrict__ pWc)
@@ -278,7 +304,7 @@ ukf_linear_rts_kernel(const UkfRtsArgs a, const double *__restrict__ pF, const d
     constexpr int DPAIRS = (PL + 1) / 2;                                       // element-major: pairs of P's upper triangle
     constexpr int DBUF = !DMA ? 1 : COOP ? 64 * NX : 64 * (NX + 2 * DPAIRS);   // doubles per wave next to the tile
     using SharedModel = LdsModel<NX, 1>;
-    __shared__ double s_model[SharedModel::SIZE + 2 * KS];
+    __shared__ double s_model[SharedModel::SIZE + 2 * KS + 2 + NX];
     __shared__ double s_tile[COOP ? (BLOCK / 64) * 64 * NN : 1];
     __shared__ double s_dma[(BLOCK / 64) * DBUF];
     // PARK (dim_x >= 7, wherever the LDS holds it): the smoothed state of step k+1 waits in LDS ([element][lane], wave-private)
@@ -311,12 +337,18 @@ ukf_linear_rts_kernel(const UkfRtsArgs a, const double *__restrict__ pF, const d
         s_model[SharedModel::SIZE + q] = (src >= 0 && src < ks) ? W[src] : 0.0;
     }
     __syncthreads();
-    struct View { SharedModel sm; const double *Wm, *Wc; };
+    int st = 0;
+    if constexpr (PAIRED) {
+        if (threadIdx.x == 0) make_pair_table<NX>(s_model + SharedModel::SIZE, s_model + SharedModel::SIZE + KS, s_model + SharedModel::SIZE + 2 * KS);
+        if (!pair_weights_symmetric<NX>(s_model + SharedModel::SIZE, s_model + SharedModel::SIZE + KS)) st |= ST_BAD_WEIGHTS;
+        __syncthreads();
+    }
+    struct View { SharedModel sm; const double *Wm, *Wc, *Wp; };
     auto fresh = [&](double after = 0.0) {
         int off = 0;
         asm volatile("" : "+v"(off) : "v"(after));
         const double *mb = s_model + off;
-        return View{SharedModel{mb}, mb + SharedModel::SIZE, mb + SharedModel::SIZE + KS};
+        return View{SharedModel{mb}, mb + SharedModel::SIZE, mb + SharedModel::SIZE + KS, mb + SharedModel::SIZE + 2 * KS};
     };
     // the filtered state of step t in flight / landed.  Element-major (and the padded classes): the lane's own registers;
     // cooperative: the wave's slab as register quads, then through the tile.
@@ -444,7 +476,6 @@ ukf_linear_rts_kernel(const UkfRtsArgs a, const double *__restrict__ pF, const d
             }
         }
     }
-    int st = 0;
     double xc[DMA ? NX : 1], Pc[DMA ? PL : 1];
     if constexpr (DMA) {
         if (a.T >= 2) {
@@ -477,7 +508,8 @@ ukf_linear_rts_kernel(const UkfRtsArgs a, const double *__restrict__ pF, const d
         }
         {
             double xb[NX], Pb[PL];
-            st |= ukf_linear_rts_gain_v3<NX>(x, P, a.scale, xb, Pb, K, fresh);
+            if constexpr (PAIRED) st |= ukf_linear_rts_gain_v4<NX>(x, P, a.scale, xb, Pb, K, fresh);
+            else st |= ukf_linear_rts_gain_v3<NX>(x, P, a.scale, xb, Pb, K, fresh);
             if constexpr (PARK) {
                 double xq[NX], Pq[PL];
                 FK_UNROLL for (int c = 0; c < NX; ++c) xq[c] = park[c * 64];
@@ -523,17 +555,17 @@ ukf_linear_rts_kernel(const UkfRtsArgs a, const double *__restrict__ pF, const d
         const dim3 grid((unsigned)((a.cnt + BLOCK - 1) / BLOCK)), block(BLOCK);                                  \
         const bool ex = exact && a.n == NXV;                                                                     \
         if (layout == FK_LAYOUT_SOA) {                                                                           \
-            if (ex && DMAV && dma) hipLaunchKernelGGL((ukf_linear_rts_kernel<NXV, LAYOUT_SOA, true, DMAV>), grid, block, 0, s, a, F, Q, Wm, Wc); \
-            else if (ex) hipLaunchKernelGGL((ukf_linear_rts_kernel<NXV, LAYOUT_SOA, true>), grid, block, 0, s, a, F, Q, Wm, Wc);  \
-            else hipLaunchKernelGGL((ukf_linear_rts_kernel<NXV, LAYOUT_SOA, false>), grid, block, 0, s, a, F, Q, Wm, Wc);   \
+            if (ex && DMAV && dma) hipLaunchKernelGGL((ukf_linear_rts_kernel<NXV, LAYOUT_SOA, true, PV, DMAV>), grid, block, 0, s, a, F, Q, Wm, Wc); \
+            else if (ex) hipLaunchKernelGGL((ukf_linear_rts_kernel<NXV, LAYOUT_SOA, true, PV>), grid, block, 0, s, a, F, Q, Wm, Wc);  \
+            else hipLaunchKernelGGL((ukf_linear_rts_kernel<NXV, LAYOUT_SOA, false, PV>), grid, block, 0, s, a, F, Q, Wm, Wc);   \
         } else {                                                                                                 \
-            if (ex && DMAV && dma) hipLaunchKernelGGL((ukf_linear_rts_kernel<NXV, LAYOUT_AOS, true, DMAV>), grid, block, 0, s, a, F, Q, Wm, Wc); \
-            else if (ex) hipLaunchKernelGGL((ukf_linear_rts_kernel<NXV, LAYOUT_AOS, true>), grid, block, 0, s, a, F, Q, Wm, Wc);  \
-            else hipLaunchKernelGGL((ukf_linear_rts_kernel<NXV, LAYOUT_AOS, false>), grid, block, 0, s, a, F, Q, Wm, Wc);   \
+            if (ex && DMAV && dma) hipLaunchKernelGGL((ukf_linear_rts_kernel<NXV, LAYOUT_AOS, true, PV, DMAV>), grid, block, 0, s, a, F, Q, Wm, Wc); \
+            else if (ex) hipLaunchKernelGGL((ukf_linear_rts_kernel<NXV, LAYOUT_AOS, true, PV>), grid, block, 0, s, a, F, Q, Wm, Wc);  \
+            else hipLaunchKernelGGL((ukf_linear_rts_kernel<NXV, LAYOUT_AOS, false, PV>), grid, block, 0, s, a, F, Q, Wm, Wc);   \
         }                                                                                                        \
     } while (0)
-#if FK_UKF_HAS(3)
-int ukf_rts_launch_small(const UkfRtsArgs &a, const double *F, const double *Q, const double *Wm, const double *Wc, int layout, bool exact, hipStream_t s)
+template <bool PV>
+static int ukf_rts_small_t(const UkfRtsArgs &a, const double *F, const double *Q, const double *Wm, const double *Wc, int layout, bool exact, hipStream_t s)
 {
     // FK_UKF_DMA=0: the exact classes without the LDS-DMA fetch of the next state (A/B).  The fetch moves 16-byte units: it
     // needs 16-byte aligned arrays and, element-major, an even track count -- with an odd one every element row starts 8
@@ -547,15 +579,25 @@ int ukf_rts_launch_small(const UkfRtsArgs &a, const double *F, const double *Q, 
     else FK_UKF_GO(6, true);
     return check_launch("ukf_linear_rts_kernel");
 }
-#endif
-#if FK_UKF_HAS(4)
-int ukf_rts_launch_big(const UkfRtsArgs &a, const double *F, const double *Q, const double *Wm, const double *Wc, int layout, bool exact, hipStream_t s)
+template <bool PV>
+static int ukf_rts_big_t(const UkfRtsArgs &a, const double *F, const double *Q, const double *Wm, const double *Wc, int layout, bool exact, hipStream_t s)
 {
     const bool dma = false;
     if (a.n <= 8) FK_UKF_GO(8, false);
     else FK_UKF_GO(9, false);
     return check_launch("ukf_linear_rts_kernel");
 }
+#if FK_UKF_HAS(3)
+int ukf_rts_launch_small(const UkfRtsArgs &a, const double *F, const double *Q, const double *Wm, const double *Wc, int layout, bool exact, hipStream_t s) { return ukf_rts_small_t<false>(a, F, Q, Wm, Wc, layout, exact, s); }
+#endif
+#if FK_UKF_HAS(4)
+int ukf_rts_launch_big(const UkfRtsArgs &a, const double *F, const double *Q, const double *Wm, const double *Wc, int layout, bool exact, hipStream_t s) { return ukf_rts_big_t<false>(a, F, Q, Wm, Wc, layout, exact, s); }
+#endif
+#if FK_UKF_HAS(7)
+int ukf_rts_launch_small_paired(const UkfRtsArgs &a, const double *F, const double *Q, const double *Wm, const double *Wc, int layout, bool exact, hipStream_t s) { return ukf_rts_small_t<true>(a, F, Q, Wm, Wc, layout, exact, s); }
+#endif
+#if FK_UKF_HAS(8)
+int ukf_rts_launch_big_paired(const UkfRtsArgs &a, const double *F, const double *Q, const double *Wm, const double *Wc, int layout, bool exact, hipStream_t s) { return ukf_rts_big_t<true>(a, F, Q, Wm, Wc, layout, exact, s); }
 #endif
 #undef FK_UKF_GO
 
@@ -571,6 +613,14 @@ static bool ukf_exact()
 {
     static const bool padded = getenv("FK_UKF_PADDED") && getenv("FK_UKF_PADDED")[0] == '1';
     return !padded;
+}
+
+// The pair-regrouped kernels run when the caller asserts weights equal within every +- pair (FK_UKF_FLAG_PAIR_WEIGHTS);
+// FK_UKF_PAIRED=0 keeps the index-order sums for every call (A/B, and the parity tests of that path).
+static bool ukf_paired(const fk_ukf_desc *d)
+{
+    static const bool off = getenv("FK_UKF_PAIRED") && getenv("FK_UKF_PAIRED")[0] == '0';
+    return !off && (d->flags & FK_UKF_FLAG_PAIR_WEIGHTS) != 0;
 }
 
 }  // namespace fk
@@ -598,10 +648,11 @@ int fk_ukf_linear_batch_f64(const fk_ukf_desc *d, const double *F, const double 
     a0.N = d->N; a0.T = d->T; a0.n = d->n; a0.m = d->m; a0.scale = d->scale;
     a0.i0 = 0; a0.cnt = d->N; a0.status_or = 0;
     const int layout = d->layout;
-    const bool exact = ukf_exact();
+    const bool exact = ukf_exact(), paired = ukf_paired(d);
     // one piece: tracks [a.i0, a.i0 + a.cnt), a.T steps from the pointers in a.  Classes (2,2), (4,2), (6,3), (8,4), (9,3),
     // (9,4): the exact instantiation where the dims are the class's own, the padded one otherwise.
     auto one = [&](const UkfArgs &a, hipStream_t s) -> int {
+        if (paired) return (a.n <= 6 && a.m <= 3) ? ukf_fwd_launch_small_paired(a, layout, exact, s) : ukf_fwd_launch_big_paired(a, layout, exact, s);
         return (a.n <= 6 && a.m <= 3) ? ukf_fwd_launch_small(a, layout, exact, s) : ukf_fwd_launch_big(a, layout, exact, s);
     };
     // tail filling (fk_chunks.hpp): FK_UKF_CHUNKS="G,H" cuts the call into G track groups x H time chunks on G streams, the
@@ -628,8 +679,9 @@ int fk_ukf_linear_rts_f64(const fk_ukf_desc *d, const double *F, const double *Q
     a0.N = d->N; a0.T = d->T; a0.n = d->n; a0.scale = d->scale;
     a0.i0 = 0; a0.cnt = d->N; a0.cont = 0; a0.status_or = 0;
     const int layout = d->layout;
-    const bool exact = ukf_exact();
+    const bool exact = ukf_exact(), paired = ukf_paired(d);
     auto one = [&](const UkfRtsArgs &a, hipStream_t s) -> int {
+        if (paired) return a.n <= 6 ? ukf_rts_launch_small_paired(a, F, Q, Wm, Wc, layout, exact, s) : ukf_rts_launch_big_paired(a, F, Q, Wm, Wc, layout, exact, s);
         return a.n <= 6 ? ukf_rts_launch_small(a, F, Q, Wm, Wc, layout, exact, s) : ukf_rts_launch_big(a, F, Q, Wm, Wc, layout, exact, s);
     };
     // Tail filling (fk_chunks.hpp): the classes of dim_x >= 5 run one wave per SIMD, so BASELINE configs[3]'s 1563 waves are

@@ -589,7 +589,8 @@ class UnscentedKalmanFilter(object):
             E.ukf_linear_batch(n, m, N, T, lay, self.points_fn.scale, E.dev(self.fx), E.dev(self.hx),
                                E.dev(np.broadcast_to(self.Q, (n, n)).copy()), E.dev(np.broadcast_to(self.R, (m, m)).copy()),
                                E.dev(np.asarray(self.Wm, dtype=np.float64)), E.dev(np.asarray(self.Wc, dtype=np.float64)),
-                               E.to_records(zarr, lay, 1), dx, dP, mask=dm, means=means, covs=covs, status=st)
+                               E.to_records(zarr, lay, 1), dx, dP, mask=dm, means=means, covs=covs, status=st,
+                               paired=E.pair_weights(self.Wm, self.Wc, n))
             E.raise_on_status(st, "UnscentedKalmanFilter.batch_filter")
             self.x = self._unb(E.from_records(dx, lay, 0, (n,)))
             self.P = self._unb(E.from_records(dP, lay, 0, (n, n)))
@@ -685,7 +686,7 @@ class UnscentedKalmanFilter(object):
             E.ukf_linear_rts(n, N, T, lay, self.points_fn.scale, E.dev(np.asarray(self.fx, dtype=np.float64)),
                              E.dev(np.broadcast_to(np.asarray(self.Q, dtype=np.float64), (n, n)).copy()),
                              E.dev(np.asarray(self.Wm, dtype=np.float64)), E.dev(np.asarray(self.Wc, dtype=np.float64)),
-                             dX, dP, oxs, ops, oK, st)
+                             dX, dP, oxs, ops, oK, st, paired=E.pair_weights(self.Wm, self.Wc, n))
             E.raise_on_status(st, "UnscentedKalmanFilter.rts_smoother")
             xs, ps, Ks = E.from_records(oxs, lay, 1, (n,)), E.from_records(ops, lay, 1, (n, n)), E.from_records(oK, lay, 1, (n, n))
             if self._N is None:

@@ -25,6 +25,7 @@ import numpy as np
 
 from ..common.helpers import reshape_z, logpdf
 from .. import _engine as E
+from .. import _abi
 from .._abi import FK_MODEL_SHARED, FK_MODEL_PER_TRACK, FK_MODEL_PER_STEP, FK_KF_FLAG_R_JOSEPH_DIAG
 
 __all__ = ["KalmanFilter", "KalmanFilterBank", "predict", "update", "batch_filter", "rts_smoother",
@@ -65,7 +66,7 @@ class _Core:
     @staticmethod
     def batch(n, m, N, T, x0, P0, z, mask, F, Q, H, R, mode, B=None, us=None, nu=0,
               alpha_sq=1.0, update_first=False, layout="soa", want_outputs=True, device_outputs=False,
-              extras=()):
+              extras=(), cov_interleave=True):
         """All inputs are host arrays shaped for `mode`:
         x0 (N,n) P0 (N,n,n) z (T,N,m) mask (T,N) or None;
         models: SHARED (a,b) | PER_TRACK (N,a,b) | PER_STEP (T,a,b) | PER_TRACK_STEP (T,N,a,b).
@@ -87,11 +88,21 @@ class _Core:
         du = None if us is None else E.to_records(us, layout, 1)
         st = torch.zeros(N, dtype=torch.int32, device=dx.device)
         outs = [None] * 4
-        if want_outputs:
-            outs = [E.alloc_records((T,), N, n, layout), E.alloc_records((T,), N, n * n, layout),
-                    E.alloc_records((T,), N, n, layout), E.alloc_records((T,), N, n * n, layout)]
         desc = dict(n=n, m=m, nu=nu, model_mode=mode, N=N, T=T, layout=E.LAYOUTS[layout],
                     update_first=int(bool(update_first)), alpha_sq=float(alpha_sq))
+        # Device-resident outputs: the two covariance histories (76 % of the bytes at dim_x = 4) live in ONE array, posterior
+        # and prior record of a track side by side (FK_KF_FLAG_COV_INTERLEAVED): one write front instead of two that may
+        # interfere (docs/PLACEMENT.md).  The caller gets strided views.  Where the specialised kernel does not serve the
+        # call (FK_ERR_UNSUPPORTED) two plain arrays are used.
+        inter = bool(want_outputs and device_outputs and not extras and cov_interleave and n <= 9
+                     and 2 * N * n * n * 8 < 2 ** 32)
+        if want_outputs:
+            if inter:
+                _, cpost, cprior = E.alloc_cov_pair(T, N, n, layout)
+                outs = [E.alloc_records((T,), N, n, layout), cpost, E.alloc_records((T,), N, n, layout), cprior]
+            else:
+                outs = [E.alloc_records((T,), N, n, layout), E.alloc_records((T,), N, n * n, layout),
+                        E.alloc_records((T,), N, n, layout), E.alloc_records((T,), N, n * n, layout)]
         ex = {}
         if extras:
             # per-step histories of the update's by-products
@@ -104,8 +115,16 @@ class _Core:
             E.kf_batch_filter_ex(desc, model(F), model(Q), model(H), model(R), dz, dx, dP, ex, B=model(B), u=du,
                                  mask=dmask, means=outs[0], covs=outs[1], means_p=outs[2], covs_p=outs[3], status=st)
         else:
-            E.kf_batch_filter(desc, model(F), model(Q), model(H), model(R), dz, dx, dP, B=model(B), u=du, mask=dmask,
-                              means=outs[0], covs=outs[1], means_p=outs[2], covs_p=outs[3], status=st)
+            args = (model(F), model(Q), model(H), model(R), dz, dx, dP)
+            kw = dict(B=model(B), u=du, mask=dmask, status=st)
+            try:
+                E.kf_batch_filter(dict(desc, flags=_abi.FK_KF_FLAG_COV_INTERLEAVED) if inter else desc, *args,
+                                  means=outs[0], covs=outs[1], means_p=outs[2], covs_p=outs[3], **kw)
+            except _abi.FilterHipError as exc:
+                if not (inter and exc.code == _abi.FK_ERR_UNSUPPORTED):
+                    raise
+                outs[1], outs[3] = E.alloc_records((T,), N, n * n, layout), E.alloc_records((T,), N, n * n, layout)
+                E.kf_batch_filter(desc, *args, means=outs[0], covs=outs[1], means_p=outs[2], covs_p=outs[3], **kw)
         E.raise_on_status(st, "batch_filter")
         if device_outputs:
             return outs + [dx, dP] + ([ex] if extras else [])
@@ -810,8 +829,12 @@ class KalmanFilterBank(object):
         self.x, self.P, self.y, self.K, self.S, self.SI = _Core.update(
             self.dim_x, self.dim_z, self.n_tracks, x, P, z, mods["H"], mods["R"], mode, mask=mask, layout=self.layout)
 
-    def batch_filter(self, zs, mask=None, update_first=False, store=True, device_outputs=False, extras=()):
+    def batch_filter(self, zs, mask=None, update_first=False, store=True, device_outputs=False, extras=(),
+                     cov_interleave=True):
         """zs (T, N, dim_z) NumPy array or a device tensor already in self.layout.
+        device_outputs=True: the four histories come back as device tensors in self.layout; the two covariance histories
+        are then strided VIEWS of one array in which a track's posterior and prior record sit side by side (one write
+        front: docs/PLACEMENT.md) -- `.contiguous()` gives a dense copy, cov_interleave=False two dense arrays.
         extras: any of 'y', 'K', 'S', 'SI', 'log_likelihood', 'mahalanobis' -> also returns a dict of the
         per-step histories (T, N, ...) as a fifth element (what filterpy.common.Saver would record)."""
         import torch
@@ -831,7 +854,8 @@ class KalmanFilterBank(object):
                 z = np.where(np.asarray(mask, dtype=bool)[..., None], z, 0.0)
         out = _Core.batch(self.dim_x, self.dim_z, self.n_tracks, T, x, P, z, mask, mods["F"], mods["Q"],
                           mods["H"], mods["R"], mode, alpha_sq=self._alpha_sq, update_first=update_first,
-                          layout=self.layout, want_outputs=store, device_outputs=device_outputs, extras=tuple(extras))
+                          layout=self.layout, want_outputs=store, device_outputs=device_outputs, extras=tuple(extras),
+                          cov_interleave=cov_interleave)
         if device_outputs:
             self.x = E.from_records(out[4], self.layout, 0, (self.dim_x,))
             self.P = E.from_records(out[5], self.layout, 0, (self.dim_x, self.dim_x))

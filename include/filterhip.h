@@ -69,6 +69,8 @@ enum {
     FK_STATUS_NONFINITE = 2,   /* NaN/Inf in the track's state after the call */
     FK_STATUS_OVERRUN = 4,     /* resample: a position >= cumsum[-1] (reference: IndexError,
                                   resampling.py:109,145); the index is clamped to Np-1 */
+    FK_STATUS_BAD_WEIGHTS = 16,/* fused UKF: FK_UKF_FLAG_PAIR_WEIGHTS was given but the weights of a +- pair of sigma points differ;
+                                  the call's outputs are not meaningful */
     FK_STATUS_INTERNAL = 8     /* resample: an in-launch hand-off timed out (never expected; the indices of this
                                   filter are not valid) */
 };
@@ -94,6 +96,17 @@ typedef struct fk_kf_desc {
  * every element of S, `dot(dot(K, R), K.T)` is r K K'): pass R = r * ones(m, m) and set this flag -- the innovation
  * covariance uses R as given, the Joseph term K R K' only its diagonal. */
 #define FK_KF_FLAG_R_JOSEPH_DIAG 1
+
+/* fk_kf_batch_filter_f64 with all four outputs: `covs` and `covs_p` are the two halves of ONE array,
+ *     FK_LAYOUT_AOS:  cov2[T][N][2][n*n]   covs = cov2, covs_p = cov2 + n*n        (record pitch 2 n*n)
+ *     FK_LAYOUT_SOA:  cov2[T][2][n*n][N]   covs = cov2, covs_p = cov2 + n*n*N      (step stride 2 n*n*N)
+ * so that the posterior and the prior covariance of a step leave as ONE contiguous write front.  Why: on MI355X two large
+ * arrays written side by side at full rate run 2-25 % slower when the driver happened to back both with the same class of
+ * physical memory, which user space cannot control (docs/PLACEMENT.md); one front has no partner to interfere with.  The
+ * two histories are then strided views of cov2 (what KalmanFilterBank.batch_filter(device_outputs=True) returns).  The
+ * pointers must stand in exactly that relation (FK_ERR_BAD_ARG otherwise); calls the specialised kernel does not serve
+ * (dim_x >= 10, per-step extras, final-state-only) return FK_ERR_UNSUPPORTED -- use two arrays there. */
+#define FK_KF_FLAG_COV_INTERLEAVED 2
 
 /* KalmanFilter.batch_filter (filterpy/kalman/kalman_filter.py:826-993; module twin :1664-1788)
  * for N independent filters: T x { predict (:472-478) ; update (:533-556, Joseph form) },
@@ -222,11 +235,23 @@ int fk_ukf_correct_f64(int32_t n, int32_t m, int64_t N, int32_t layout,
                        const double *Pxz, const double *zp, const double *S, const double *z,
                        double *x, double *P, double *K, int32_t *status, void *stream);
 
+/* fk_ukf_desc.flags */
+enum {
+    FK_UKF_FLAG_PAIR_WEIGHTS = 1   /* the caller asserts Wm[1+k] == Wm[1+n+k] and Wc[1+k] == Wc[1+n+k] for k = 0..n-1 (true of
+                                      MerweScaledSigmaPoints and JulierSigmaPoints, sigma_points.py:180-192, :358-372): the sums
+                                      of unscented_transform.py:104-126 and UKF.py:483-497 are then formed over the n +- PAIRS of
+                                      sigma points (a re-association of the reference's index-order sums: every factor, image and
+                                      weighted sum is still formed, with n + 1 instead of 2n + 1 rank-one terms per covariance).
+                                      Without the flag -- and for every other weight set -- the sums run in the reference's index
+                                      order.  Environment FK_UKF_PAIRED=0 ignores the flag (A/B).  A violated assertion is
+                                      reported as FK_STATUS_BAD_WEIGHTS on every track. */
+};
+
 typedef struct fk_ukf_desc {
-    int32_t n, m;         /* dim_x (1..6), dim_z (1..3) */
+    int32_t n, m;         /* dim_x, dim_z */
     int64_t N, T;
     int32_t layout;
-    int32_t reserved;
+    int32_t flags;        /* FK_UKF_FLAG_* (0: index-order sums) */
     double  scale;        /* lambda + n */
 } fk_ukf_desc;
 

@@ -516,7 +516,7 @@ extern "C" int hc_imm_batch(int n, int m, int nm, long T, const double *F, const
 #include "../../filterpy_amd/csrc/fk_ukf.hpp"
 
 namespace {
-template <int NX, int NZ>
+template <int NX, int NZ, bool V4 = false>
 int ukf_v3_batch(long T, const double *F, const double *H, const double *Q, const double *R, const double *Wm,
                  const double *Wc, double scale, const double *zs, const unsigned char *mask, double *x0,
                  double *P0, double *means, double *covs)
@@ -524,18 +524,21 @@ int ukf_v3_batch(long T, const double *F, const double *H, const double *Q, cons
     constexpr int PL = NX * (NX + 1) / 2, KS = 2 * NX + 1;
     struct View {
         fk::RegModel<NX, NZ> sm;
-        const double *Wm, *Wc;
+        const double *Wm, *Wc, *Wp;
     };
     View v;
     std::copy(F, F + NX * NX, v.sm.F);
     std::copy(Q, Q + NX * NX, v.sm.Q);
     std::copy(H, H + NZ * NX, v.sm.H);
     std::copy(R, R + NZ * NZ, v.sm.R);
-    double wm[KS], wc[KS];
+    double wm[KS], wc[KS], wp[2 + NX];
     std::copy(Wm, Wm + KS, wm);
     std::copy(Wc, Wc + KS, wc);
+    fk::make_pair_table<NX>(wm, wc, wp);
+    if (V4 && !fk::pair_weights_symmetric<NX>(wm, wc)) return -2;
     v.Wm = wm;
     v.Wc = wc;
+    v.Wp = wp;
     auto fresh = [&](double = 0.0) -> const View & { return v; };
     double x[NX], P[PL];
     for (int i = 0; i < NX; ++i) {
@@ -547,7 +550,8 @@ int ukf_v3_batch(long T, const double *F, const double *H, const double *Q, cons
         auto load_z = [&](double (&z)[NZ]) {
             for (int r = 0; r < NZ; ++r) z[r] = zs[t * NZ + r];
         };
-        st |= fk::ukf_linear_step_v3<NX, NZ>(x, P, load_z, mask ? mask[t] != 0 : true, scale, fresh);
+        if (V4) st |= fk::ukf_linear_step_v4<NX, NZ>(x, P, load_z, mask ? mask[t] != 0 : true, scale, fresh);
+        else st |= fk::ukf_linear_step_v3<NX, NZ>(x, P, load_z, mask ? mask[t] != 0 : true, scale, fresh);
         for (int i = 0; i < NX; ++i) {
             means[t * NX + i] = x[i];
             for (int j = 0; j < NX; ++j) covs[(t * NX + i) * NX + j] = P[fk::sym_idx<NX>(i, j)];
@@ -563,23 +567,26 @@ int ukf_v3_batch(long T, const double *F, const double *H, const double *Q, cons
 
 namespace {
 // the fused linear-model UKF smoother's step (fk_ukf.hpp: ukf_linear_rts_gain_v3 / _correct) over a whole backward pass
-template <int NX>
+template <int NX, bool V4 = false>
 int ukf_rts_batch(long T, const double *F, const double *Q, const double *Wm, const double *Wc, double scale,
                   const double *Xs, const double *Ps, double *xs, double *ps, double *Ks)
 {
     constexpr int PL = NX * (NX + 1) / 2, KS = 2 * NX + 1;
     struct View {
         fk::RegModel<NX, 1> sm;
-        const double *Wm, *Wc;
+        const double *Wm, *Wc, *Wp;
     };
     View v;
     std::copy(F, F + NX * NX, v.sm.F);
     std::copy(Q, Q + NX * NX, v.sm.Q);
-    double wm[KS], wc[KS];
+    double wm[KS], wc[KS], wp[2 + NX];
     std::copy(Wm, Wm + KS, wm);
     std::copy(Wc, Wc + KS, wc);
+    fk::make_pair_table<NX>(wm, wc, wp);
+    if (V4 && !fk::pair_weights_symmetric<NX>(wm, wc)) return -2;
     v.Wm = wm;
     v.Wc = wc;
+    v.Wp = wp;
     auto fresh = [&](double = 0.0) -> const View & { return v; };
     auto load = [&](long t, double (&x)[NX], double (&P)[PL]) {
         for (int i = 0; i < NX; ++i) {
@@ -602,7 +609,8 @@ int ukf_rts_batch(long T, const double *F, const double *Q, const double *Wm, co
     for (long t = T - 2; t >= 0; --t) {
         double x[NX], P[PL], K[NX * NX], xb[NX], Pb[PL];
         load(t, x, P);
-        st |= fk::ukf_linear_rts_gain_v3<NX>(x, P, scale, xb, Pb, K, fresh);
+        if (V4) st |= fk::ukf_linear_rts_gain_v4<NX>(x, P, scale, xb, Pb, K, fresh);
+        else st |= fk::ukf_linear_rts_gain_v3<NX>(x, P, scale, xb, Pb, K, fresh);
         fk::ukf_linear_rts_correct<NX>(x, P, xn, Pn, xb, Pb, K);
         store(t, x, P);
         for (int e = 0; e < NX * NX; ++e) Ks[t * NX * NX + e] = K[e];
@@ -628,6 +636,27 @@ extern "C" int hc_ukf_linear_rts_v3(int n, long T, const double *F, const double
                                     double scale, const double *Xs, const double *Ps, double *xs, double *ps, double *Ks)
 {
 #define GO(NXV) if (n == NXV) return ukf_rts_batch<NXV>(T, F, Q, Wm, Wc, scale, Xs, Ps, xs, ps, Ks)
+    GO(2); GO(3); GO(4); GO(5); GO(6); GO(7); GO(8); GO(9);
+#undef GO
+    return -1;
+}
+
+// the pair-regrouped steps (fk_ukf.hpp, ukf_linear_step_v4 / ukf_linear_rts_gain_v4: what the kernels run since round 4 for
+// weights equal within every +- pair)
+extern "C" int hc_ukf_linear_v4(int n, int m, long T, const double *F, const double *H, const double *Q, const double *R,
+                                const double *Wm, const double *Wc, double scale, const double *zs,
+                                const unsigned char *mask, double *x0, double *P0, double *means, double *covs)
+{
+#define GO(NXV, NZV) if (n == NXV && m == NZV) return ukf_v3_batch<NXV, NZV, true>(T, F, H, Q, R, Wm, Wc, scale, zs, mask, x0, P0, means, covs)
+    GO(2, 2); GO(4, 2); GO(6, 3); GO(8, 4); GO(9, 3); GO(9, 4); GO(3, 1); GO(5, 2); GO(7, 3);
+#undef GO
+    return -1;
+}
+
+extern "C" int hc_ukf_linear_rts_v4(int n, long T, const double *F, const double *Q, const double *Wm, const double *Wc,
+                                    double scale, const double *Xs, const double *Ps, double *xs, double *ps, double *Ks)
+{
+#define GO(NXV) if (n == NXV) return ukf_rts_batch<NXV, true>(T, F, Q, Wm, Wc, scale, Xs, Ps, xs, ps, Ks)
     GO(2); GO(3); GO(4); GO(5); GO(6); GO(7); GO(8); GO(9);
 #undef GO
     return -1;

@@ -21,8 +21,9 @@ def stable_F(rs, n):
     return F / max(1.0, 1.05 * np.max(np.abs(np.linalg.eigvals(F))))
 
 
-def run_imm(xs0, Ps0, mu0, M, zs, Fs, Qs, Hs, Rs, layout, phase=0, priors=True):
-    """xs0 (N,nm,n), Ps0 (N,nm,n,n), mu0 (N,nm), zs (T,N,m) -> dict of host arrays."""
+def run_imm(xs0, Ps0, mu0, M, zs, Fs, Qs, Hs, Rs, layout, phase=0, priors=True, zmask=None, ll0=None):
+    """xs0 (N,nm,n), Ps0 (N,nm,n,n), mu0 (N,nm), zs (T,N,m) -> dict of host arrays.  zmask (T,N) uint8: 0 = update(None);
+    ll0 (N,nm): the filters' zero-residual log-densities in (the final ones come back as res["ll0"])."""
     import torch
     from filterpy_amd import _engine as E
     N, nm, n = xs0.shape
@@ -38,12 +39,16 @@ def run_imm(xs0, Ps0, mu0, M, zs, Fs, Qs, Hs, Rs, layout, phase=0, priors=True):
     for o in out.values():
         o.fill_(float("nan"))
     st = torch.zeros(N, dtype=torch.int32, device=dxs.device)
+    dmask = None if zmask is None else torch.as_tensor(np.ascontiguousarray(zmask, dtype=np.uint8), device=dxs.device)
+    dll0 = None if ll0 is None else E.to_records(ll0, layout, 0)
     E.imm_batch(n, m, nm, N, T, layout, E.dev(Fs), E.dev(Qs), E.dev(Hs), E.dev(Rs), E.dev(M), dz, dxs, dPs, dmu,
-                status=st, phase=phase, **out)
+                status=st, phase=phase, zmask=dmask, ll0=dll0, **out)
     torch.cuda.synchronize()
     assert not st.any()
     shapes = dict(x_out=(n,), P_out=(n, n), mu_out=(nm,), likelihood_out=(nm,), x_prior_out=(n,), P_prior_out=(n, n))
     res = {k: E.from_records(v, layout, 1, shapes[k]) for k, v in out.items()}
+    if dll0 is not None:
+        res["ll0"] = E.from_records(dll0, layout, 0, (nm,))
     res["xs"] = E.from_records(dxs, layout, 0, (nm, n))
     res["Ps"] = E.from_records(dPs, layout, 0, (nm, n, n))
     res["mu"] = E.from_records(dmu, layout, 0, (nm,))
@@ -169,6 +174,41 @@ def test_imm_chunked_call_is_bit_identical(n, m, nm, N, layout, monkeypatch):
         res[tag] = run_imm(xs0, Ps0, mu0, M, zs, Fs, Qs, Hs, Rs, layout)
     assert np.all(np.isfinite(res["one"]["x_out"]))
     for tag in ("3x4", "2x7", "4x23", "default"):
+        for k in res["one"]:
+            assert np.array_equal(res["one"][k], res[tag][k], equal_nan=True), (tag, k)
+
+
+@pytest.mark.parametrize("layout", ["soa", "aos"])
+@pytest.mark.parametrize("with_ll0", [False, True])
+@pytest.mark.parametrize("n,m,nm,N", [(4, 2, 2, 1037), (9, 3, 4, 515)])
+def test_imm_chunked_call_with_missing_measurements_is_bit_identical(n, m, nm, N, with_ll0, layout, monkeypatch):
+    """with a measurement mask the per-filter log-density of a zero residual under the last S is carried from step to
+    step -- in registers inside one launch, through ll0 between the pieces of a chunked call.  A masked call WITHOUT ll0 cannot
+    hand it over and must therefore stay one launch; with ll0 every decomposition is bit-identical.  Missing measurements sit
+    right behind every chunk boundary of the decompositions tried."""
+    rs = np.random.RandomState(5 * n + nm)
+    T = 24
+    Fs = np.array([stable_F(rs, n) for _ in range(nm)])
+    Qs = np.array([spd(rs, n, 0.05 * (j + 1)) for j in range(nm)])
+    Hs = np.array([rs.randn(m, n)] * nm)
+    Rs = np.array([spd(rs, m, 0.5) for _ in range(nm)])
+    M = rs.rand(nm, nm) + 2 * np.eye(nm)
+    M /= M.sum(axis=1, keepdims=True)
+    xs0 = rs.randn(N, nm, n)
+    Ps0 = np.array([[spd(rs, n, 2.0) for _ in range(nm)] for _ in range(N)])
+    mu0 = rs.rand(N, nm) + 0.1
+    mu0 /= mu0.sum(axis=1, keepdims=True)
+    zs = rs.randn(T, N, m) * 2
+    zmask = (rs.rand(T, N) > 0.3).astype(np.uint8)
+    zmask[0] = 1
+    zmask[[3, 4, 6, 7, 12, 13, 18, 19], ::2] = 0          # first steps of the time chunks of 3x4 / 2x7 (with their stagger)
+    ll0 = np.full((N, nm), -np.inf) if with_ll0 else None
+    res = {}
+    for tag, env in (("one", "1,1"), ("3x4", "3,4"), ("2x7", "2,7"), ("4x24", "4,24")):
+        monkeypatch.setenv("FK_IMM_CHUNKS", env)
+        res[tag] = run_imm(xs0, Ps0, mu0, M, zs, Fs, Qs, Hs, Rs, layout, zmask=zmask, ll0=None if ll0 is None else ll0.copy())
+    assert np.all(np.isfinite(res["one"]["x_out"]))
+    for tag in ("3x4", "2x7", "4x24"):
         for k in res["one"]:
             assert np.array_equal(res["one"][k], res[tag][k], equal_nan=True), (tag, k)
 

@@ -853,3 +853,103 @@ def test_saver_histories_from_the_specialised_kernel(n, m, layout, monkeypatch):
     # a subset: only the likelihood history
     _, h1 = _run_ex(x0, P0, zs, F, Q, H, R, layout, keys=("log_likelihood",))
     assert np.array_equal(h1["log_likelihood"], _run_ex(x0, P0, zs, F, Q, H, R, layout)[1]["log_likelihood"])
+
+
+@pytest.mark.parametrize("layout", ["soa", "aos"])
+@pytest.mark.parametrize("n,m", [(1, 1), (2, 1), (3, 2), (4, 2), (5, 3), (6, 3), (7, 2), (8, 4), (9, 4), (9, 3)])
+def test_interleaved_covariance_histories_equal_two_arrays_bit_for_bit(n, m, layout):
+    """FK_KF_FLAG_COV_INTERLEAVED (the kernel-side cure of the placement lottery): both covariance histories
+    in ONE array -- a track's posterior and prior record side by side in NumPy order, the two slabs of a step adjacent in
+    element-major order -- so that a step writes one front.  Nothing but addresses changes: every output of the interleaved
+    call equals the two-array call bit for bit -- ragged last workgroup, missing measurements, update_first, control input,
+    per-track models (the kf_fast instantiations that exist at the size; a call the specialised kernel does not serve
+    is FK_ERR_UNSUPPORTED and checked as such)."""
+    from filterpy_amd._abi import FilterHipError, FK_ERR_UNSUPPORTED, FK_MODEL_PER_TRACK
+    from gpu_util import run_kf_batch
+    rs = np.random.RandomState(31 * n + m)
+    N, T = 333, 9
+    F = np.eye(n) + 0.05 * np.triu(rs.randn(n, n), 1)
+    Q = 0.02 * np.eye(n)
+    H = rs.randn(m, n)
+    R = 0.5 * np.eye(m)
+    x0, P0 = rs.randn(N, n), np.tile(4.0 * np.eye(n), (N, 1, 1))
+    zs = rs.randn(T, N, m)
+    mask = (rs.rand(T, N) > 0.2).astype(np.uint8)
+    served = 0
+    for kw in (dict(), dict(mask=mask), dict(update_first=True), dict(B=rs.randn(n, 2), us=rs.randn(T, N, 2)),
+               dict(mode=FK_MODEL_PER_TRACK)):
+        args = [F, Q, H, R]
+        if kw.get("mode") == FK_MODEL_PER_TRACK:
+            args = [np.tile(M, (N, 1, 1)) for M in args]
+        ref = run_kf_batch(x0, P0, zs, *args, layout=layout, **kw)
+        try:
+            got = run_kf_batch(x0, P0, zs, *args, layout=layout, interleave=True, **kw)
+        except FilterHipError as exc:
+            assert exc.code == FK_ERR_UNSUPPORTED, (kw.keys(), exc)
+            continue
+        served += 1
+        for a, b in zip(ref, got):
+            assert np.array_equal(a, b, equal_nan=True), (n, m, layout, list(kw))
+    if n <= 6 or (layout == "soa" and (n, m) != (9, 3)):
+        assert served >= 2, served           # at least the plain and the masked call run on the specialised kernel
+
+
+def test_interleaved_flag_checks_its_arguments():
+    """the two pointers must be the halves of one array; final-state-only calls have nothing to interleave"""
+    import torch
+    from filterpy_amd import _engine as E
+    from filterpy_amd._abi import FilterHipError, FK_ERR_BAD_ARG, FK_ERR_UNSUPPORTED
+    n, m, N, T = 4, 2, 100, 3
+    d = dict(n=n, m=m, nu=0, model_mode=0, N=N, T=T, layout=E.LAYOUTS["aos"], update_first=0, alpha_sq=1.0, flags=2)
+    F, Q, H, R = E.dev(np.eye(n)), E.dev(np.eye(n)), E.dev(np.eye(m, n)), E.dev(np.eye(m))
+    z, x, P = E.dev(np.zeros((T, N, m))), E.dev(np.zeros((N, n))), E.dev(np.tile(np.eye(n), (N, 1, 1)))
+    mu, mup = E.alloc_records((T,), N, n, "aos"), E.alloc_records((T,), N, n, "aos")
+    c, cp = E.alloc_records((T,), N, n * n, "aos"), E.alloc_records((T,), N, n * n, "aos")
+    with pytest.raises(FilterHipError) as ei:
+        E.kf_batch_filter(d, F, Q, H, R, z, x, P, means=mu, covs=c, means_p=mup, covs_p=cp)
+    assert ei.value.code == FK_ERR_BAD_ARG
+    with pytest.raises(FilterHipError) as ei:
+        E.kf_batch_filter(d, F, Q, H, R, z, x, P)
+    assert ei.value.code == FK_ERR_BAD_ARG
+    d16 = dict(d, n=12, m=2)
+    F, Q, H, R = E.dev(np.eye(12)), E.dev(np.eye(12)), E.dev(np.eye(2, 12)), E.dev(np.eye(2))
+    z, x, P = E.dev(np.zeros((T, N, 2))), E.dev(np.zeros((N, 12))), E.dev(np.tile(np.eye(12), (N, 1, 1)))
+    mu, mup = E.alloc_records((T,), N, 12, "aos"), E.alloc_records((T,), N, 12, "aos")
+    _, c, cp = E.alloc_cov_pair(T, N, 12, "aos")
+    with pytest.raises(FilterHipError) as ei:
+        E.kf_batch_filter(d16, F, Q, H, R, z, x, P, means=mu, covs=c, means_p=mup, covs_p=cp)
+    assert ei.value.code == FK_ERR_UNSUPPORTED
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("layout", ["soa", "aos"])
+@pytest.mark.parametrize("n,m", [(4, 2), (9, 3), (12, 3)])
+def test_bank_device_outputs_are_views_of_one_array_and_equal_the_host_outputs(n, m, layout):
+    """KalmanFilterBank.batch_filter(device_outputs=True): the covariance histories are strided views of ONE allocation where
+    the one-lane specialised kernel is the kernel of the call, two plain arrays otherwise ((9,3), dim_x 12: the several-lanes-
+    per-track kernels), and in every case equal the host outputs of the same call bit for bit."""
+    from filterpy_amd import _engine as E
+    from filterpy_amd.kalman import KalmanFilterBank
+    rs = np.random.RandomState(n + m)
+    N, T = 200, 7
+    zs = rs.randn(T, N, m)
+
+    def bank():
+        b = KalmanFilterBank(n, m, N, layout=layout)
+        b.F = np.eye(n) + 0.05 * np.triu(np.ones((n, n)), 1)
+        b.Q, b.R = 0.02 * np.eye(n), 0.5 * np.eye(m)
+        b.H = np.eye(m, n)
+        b.x, b.P = np.zeros((N, n)), np.tile(3.0 * np.eye(n), (N, 1, 1))
+        return b
+    host = bank().batch_filter(zs)
+    b = bank()
+    dev = b.batch_filter(zs, device_outputs=True)
+    one_array = dev[1].untyped_storage().data_ptr() == dev[3].untyped_storage().data_ptr()
+    assert one_array == (n <= 8), (n, layout, one_array)
+    shapes = [(n,), (n, n), (n,), (n, n)]
+    for h, d, shp in zip(host, dev, shapes):
+        assert np.array_equal(h, E.from_records(d, layout, 1, shp))
+    two = bank().batch_filter(zs, device_outputs=True, cov_interleave=False)
+    assert two[1].is_contiguous() and two[1].untyped_storage().data_ptr() != two[3].untyped_storage().data_ptr()
+    for a, c in zip(dev, two):
+        assert np.array_equal(a.cpu().numpy(), c.cpu().numpy())

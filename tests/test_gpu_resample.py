@@ -312,6 +312,19 @@ def test_onepass_every_route_long(mode, monkeypatch):
     _check_against_merge_loop(6, 1000003, _FAMILIES + ("dyadic", "tiny"), (0, 3, 5), monkeypatch, force=False)
 
 
+@pytest.mark.parametrize("mode", ["spec", "tickets"])
+def test_onepass_repairs_itself_when_a_hand_off_times_out(mode, monkeypatch):
+    """a bounded spin of the one-pass kernel that times out sets the abort word (FK_STATUS_INTERNAL).  The
+    call must not report that, it must repair it: the repair pass (resample_local_kernel behind the one-pass kernel, one
+    workgroup per filter, no workgroup waits for another) recomputes every filter.  FK_OP_FORCE_ABORT=1 presets the abort
+    word, so every chunk that has to wait for a predecessor gives up: the indices must still be the merge loop's, bit for
+    bit, and the status must not carry FK_STATUS_INTERNAL (it does carry the IndexError bit of the sum_half family)."""
+    _onepass_mode(monkeypatch, mode)
+    monkeypatch.setenv("FK_OP_FORCE_ABORT", "1")
+    _check_against_merge_loop(6, 200003, _FAMILIES + ("dyadic", "tiny"), range(6), monkeypatch, force=False)
+    _check_against_merge_loop(3, 40000, ("uniform", "heavy_tail", "sum_half"), range(3), monkeypatch, force=False)
+
+
 def test_onepass_many_filters_of_a_hundred_thousand(monkeypatch):
     """1000 x 100 000: more concurrent chains than workgroup slots; speculation on ordinary and on skewed weights (whose
     guesses mostly miss and fall back to the two stages)"""

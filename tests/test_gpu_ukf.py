@@ -79,9 +79,12 @@ def test_cross_variance_vs_oracle(layout):
         assert rel_err_rows(got[trk][None], ref[None]) < 1e-12
 
 
+@pytest.mark.parametrize("paired", [True, False])
 @pytest.mark.parametrize("layout", ["soa", "aos"])
-def test_fused_linear_ukf_goldens(layout):
-    """UnscentedKalmanFilter.batch_filter with fx = F x, hx = H x (UKF.py:524-632)."""
+def test_fused_linear_ukf_goldens(layout, paired):
+    """UnscentedKalmanFilter.batch_filter with fx = F x, hx = H x (UKF.py:524-632).  paired: the sums regrouped over the +-
+    pairs of sigma points (FK_UKF_FLAG_PAIR_WEIGHTS; what the Python API asks for with Merwe's / Julier's weights) and the
+    reference's index-order sums -- both held to the live-reference golden at the same bar."""
     import torch
     from filterpy_amd import _engine as E
     from gpu_util import tile_tracks
@@ -97,9 +100,10 @@ def test_fused_linear_ukf_goldens(layout):
         st = torch.zeros(N, dtype=torch.int32, device=dx.device)
         E.ukf_linear_batch(n, m, N, T, layout, lam + n, E.dev(g[p + "F"]), E.dev(g[p + "H"]), E.dev(g[p + "Q"]),
                            E.dev(g[p + "R"]), E.dev(g[p + "Wm"]), E.dev(g[p + "Wc"]), dz, dx, dP,
-                           means=means, covs=covs, status=st)
+                           means=means, covs=covs, status=st, paired=paired)
         torch.cuda.synchronize()
         assert not st.any(), ci
+        assert E.pair_weights(g[p + "Wm"], g[p + "Wc"], n)
         mu, cov = E.from_records(means, layout, 1, (n,)), E.from_records(covs, layout, 1, (n, n))
         # 1e-10 everywhere except where the reference's OWN result moves more than that under one-ulp input
         # perturbations (alpha = 1e-3, Wm0 ~ -1e6: mu 2.3e-9 in the reference; tests/golden/ukf_conditioning.json)
@@ -108,10 +112,68 @@ def test_fused_linear_ukf_goldens(layout):
             assert rel_err_rows(cov[:, trk], g[p + "cov"]) < ukf_tol(ci, "cov"), (ci, trk)
 
 
+@pytest.mark.parametrize("layout", ["soa", "aos"])
+def test_pair_weights_flag_is_checked_and_other_weights_keep_the_index_order(layout):
+    """FK_UKF_FLAG_PAIR_WEIGHTS is the caller's assertion that the weights are equal within every +- pair; the kernels check it
+    (FK_STATUS_BAD_WEIGHTS -> ValueError).  A weight set that is NOT symmetric (legal for unscented_transform.py:104-126: any
+    Wm / Wc) is detected by _engine.pair_weights, runs the index-order sums and matches the oracle's transform chain."""
+    import torch
+    from filterpy_amd import _engine as E
+    from gpu_util import tile_tracks
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import ukf_oracle
+    g = golden("ukf_merwe")
+    ci, n, m, alpha, beta, kappa = [c for c in _cases() if c[1] == 4][-1]
+    p = f"c{ci}_"
+    lam = alpha ** 2 * (n + kappa) - n
+    Wm, Wc = g[p + "Wm"].copy(), g[p + "Wc"].copy()
+    Wm[2] *= 1.25
+    Wm[n + 2] -= Wm[2] - g[p + "Wm"][2]            # still sums to the same total
+    Wc[1] *= 0.5
+    assert not E.pair_weights(Wm, Wc, n)
+    zs = g[p + "zs"][:6]
+    T = zs.shape[0]
+    nb = 70
+
+    def run(paired, with_smoother=False):
+        dx, dP = E.to_records(tile_tracks(g[p + "x0"], nb), layout, 0), E.to_records(tile_tracks(g[p + "P0"], nb), layout, 0)
+        dz = E.to_records(tile_tracks(zs, nb, 1), layout, 1)
+        means, covs = E.alloc_records((T,), nb, n, layout), E.alloc_records((T,), nb, n * n, layout)
+        st = torch.zeros(nb, dtype=torch.int32, device=dx.device)
+        E.ukf_linear_batch(n, m, nb, T, layout, lam + n, E.dev(g[p + "F"]), E.dev(g[p + "H"]), E.dev(g[p + "Q"]),
+                           E.dev(g[p + "R"]), E.dev(Wm), E.dev(Wc), dz, dx, dP, means=means, covs=covs, status=st, paired=paired)
+        torch.cuda.synchronize()
+        if with_smoother:
+            xs, ps = E.alloc_records((T,), nb, n, layout), E.alloc_records((T,), nb, n * n, layout)
+            st2 = torch.zeros(nb, dtype=torch.int32, device=dx.device)
+            E.ukf_linear_rts(n, nb, T, layout, lam + n, E.dev(g[p + "F"]), E.dev(g[p + "Q"]), E.dev(Wm), E.dev(Wc), means, covs,
+                             xs, ps, status=st2, paired=paired)
+            torch.cuda.synchronize()
+            return st, st2
+        return st, E.from_records(means, layout, 1, (n,)), E.from_records(covs, layout, 1, (n, n))
+
+    st, st2 = run(True, with_smoother=True)
+    assert (st.cpu().numpy() & 16).all() and (st2.cpu().numpy() & 16).all()
+    with pytest.raises(ValueError):
+        E.raise_on_status(st, "fused UKF")
+    st, mu, cov = run(None)
+    assert not st.any()
+    # the oracle's predict / update (UKF.py:400-411, 462-481) with these weights
+    F, H, Q, R = g[p + "F"], g[p + "H"], g[p + "Q"], g[p + "R"]
+    x, P = g[p + "x0"].copy(), g[p + "P0"].copy()
+    for t in range(T):
+        x, P, sf = ukf_oracle.ukf_predict(x, P, lambda s_, d_: F @ s_, 0.1, Q, Wm, Wc, alpha, kappa)
+        x, P, _, _, _ = ukf_oracle.ukf_update(x, P, sf, zs[t], lambda s_: H @ s_, R, Wm, Wc)
+        for trk in (0, nb - 1):
+            assert rel_err_rows(mu[t, trk][None], x[None]) < TOL and rel_err_rows(cov[t, trk][None], P[None]) < TOL, t
+
+
 @pytest.mark.gpu
+@pytest.mark.parametrize("paired", [True, False])
 @pytest.mark.parametrize("layout", ["soa", "aos"])
 @pytest.mark.parametrize("nb", [1, 2, 3, 63, 64, 65, 130, 257, 513])
-def test_fused_linear_ukf_smoother_goldens_every_bank_size(layout, nb):
+def test_fused_linear_ukf_smoother_goldens_every_bank_size(layout, nb, paired):
     """fk_ukf_linear_rts_f64 (UKF.py:634-739) on the reference's own filter output, banks of every shape of tail: one track,
     odd and even counts, one short of / one past a wave and a workgroup.  First, last and a middle track of every bank
     against the live-reference golden -- the LDS-DMA fetch of the exact classes reads 16-byte units, and an odd track
@@ -134,7 +196,7 @@ def test_fused_linear_ukf_smoother_goldens_every_bank_size(layout, nb):
         Ks = E.alloc_records((T,), nb, n * n, layout)
         st = torch.zeros(nb, dtype=torch.int32, device=Xs.device)
         E.ukf_linear_rts(n, nb, T, layout, lam + n, E.dev(g[p + "F"]), E.dev(g[p + "Q"]), E.dev(g[p + "Wm"]),
-                         E.dev(g[p + "Wc"]), Xs, Ps, xs, ps, K=Ks, status=st)
+                         E.dev(g[p + "Wc"]), Xs, Ps, xs, ps, K=Ks, status=st, paired=paired)
         torch.cuda.synchronize()
         assert not st.any(), (ci, nb)
         hx, hP = E.from_records(xs, layout, 1, (n,)), E.from_records(ps, layout, 1, (n, n))

@@ -29,7 +29,7 @@ def _v3(n, m, F, H, Q, R, Wm, Wc, scale, zs, mask, x0, P0, entry="hc_ukf_linear_
     return means, covs, x, P
 
 
-@pytest.mark.parametrize("n,m,entry", [(n, m, "hc_ukf_linear_v3") for n, m in
+@pytest.mark.parametrize("n,m,entry", [(n, m, e) for e in ("hc_ukf_linear_v3", "hc_ukf_linear_v4") for n, m in
                                        [(2, 2), (3, 1), (4, 2), (5, 2), (6, 3), (7, 3), (8, 4), (9, 3), (9, 4)]])
 @pytest.mark.parametrize("abk", [(.1, 2., None), (1e-3, 2., 0.), (1., 2., .1)])
 def test_ukf_step_matches_the_oracle(n, m, entry, abk):
@@ -61,7 +61,7 @@ def test_ukf_step_matches_the_oracle(n, m, entry, abk):
     assert np.allclose(cov, np.swapaxes(cov, 1, 2))
 
 
-@pytest.mark.parametrize("entry", ["hc_ukf_linear_v3"])
+@pytest.mark.parametrize("entry", ["hc_ukf_linear_v3", "hc_ukf_linear_v4"])
 def test_ukf_missing_measurements_skip_the_update(entry):
     n, m, T = 4, 2, 12
     r = np.random.default_rng(5)
@@ -95,7 +95,7 @@ def _rts(n, F, Q, Wm, Wc, scale, Xs, Ps, entry="hc_ukf_linear_rts_v3"):
     return xs, ps, Ks
 
 
-@pytest.mark.parametrize("n,m,entry", [(n, 2, "hc_ukf_linear_rts_v3") for n in range(2, 10)])
+@pytest.mark.parametrize("n,m,entry", [(n, 2, e) for e in ("hc_ukf_linear_rts_v3", "hc_ukf_linear_rts_v4") for n in range(2, 10)])
 @pytest.mark.parametrize("abk", [(.1, 2., None), (1., 2., .1)])
 def test_fused_ukf_smoother_step_matches_the_oracle(n, m, entry, abk):
     """fk_ukf.hpp ukf_linear_rts_gain_v3 / _correct (the arithmetic of fk_ukf_linear_rts_f64) on the host against the

@@ -58,6 +58,62 @@ def test_two_rank_gloo_allgather():
     assert all(r[3] for r in res) and all(abs(r[4] - 2.0) < 1e-12 for r in res)
 
 
+def _overlap_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    parallel.init_from_env(backend="gloo")
+    N, n, steps = 4096, 4, 7
+    local = [torch.empty(N, n, dtype=torch.float64) for _ in range(2)]
+    ex = parallel.SummaryExchange(like=local[0], depth=2)
+    want = lambda k, r: (torch.arange(N * n, dtype=torch.float64).reshape(N, n) + r * N * n) * 0.25 + 100.0 * k  # noqa: E731
+    ok, in_flight = True, 0
+    for k in range(steps):
+        slot = k % 2
+        ex.acquire(slot)                       # the collective of step k - 2 is done with local[slot]
+        local[slot].copy_(want(k, rank))       # "kernel" of step k
+        ex.post(local[slot], slot)             # returns at once; step k + 1 overwrites the OTHER buffer meanwhile
+        if k >= 1:
+            prev = (k - 1) % 2
+            w = ex._work[prev]
+            in_flight += int(w is not None and not w.is_completed())
+            g = ex.wait(prev)                  # step k - 1: complete and in rank order although step k has been written
+            ok = ok and g.shape == (world, N, n) and all(torch.equal(g[r], want(k - 1, r)) for r in range(world))
+    g = ex.wait((steps - 1) % 2)
+    ok = ok and all(torch.equal(g[r], want(steps - 1, r)) for r in range(world))
+    ex.drain()
+    parallel.barrier()
+    q.put((rank, bool(ok), in_flight))
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_overlapped_exchange_is_rank_ordered_and_complete():
+    """the per-step all-gather runs beside the next step (parallel.SummaryExchange: double-buffered local
+    state and gathered state; on the GPU a side stream + events, here gloo's async work handles).  While step k's buffer is
+    being written the gathered state of step k - 1 must come out complete and in rank order, for every step."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_overlap_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(r[1] for r in res), res
+
+
+def test_single_process_exchange_is_a_copy():
+    local = [torch.full((5, 3), float(k)) for k in range(2)]
+    ex = parallel.SummaryExchange(like=local[0], depth=2)
+    for k in range(4):
+        ex.acquire(k % 2)
+        local[k % 2].fill_(10.0 + k)
+        ex.post(local[k % 2], k % 2)
+    assert ex.world == 1 and torch.equal(ex.wait(1)[0], torch.full((5, 3), 13.0)) and torch.equal(ex.wait(0)[0], torch.full((5, 3), 12.0))
+    assert ex.gather_ms() is None
+
+
 def test_single_process_needs_no_group():
     t = torch.ones(3, 2)
     assert parallel.allgather_summary(t).shape == (1, 3, 2)

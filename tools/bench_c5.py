@@ -63,38 +63,63 @@ def main():
     particles = torch.randn((Fn, Np, d), generator=g, device=dev, dtype=torch.float64)
     idx = torch.empty((Fn, Np), dtype=torch.int32, device=dev)
     st = torch.zeros(Fn, dtype=torch.int32, device=dev)
-    means = torch.empty((Fn, d), dtype=torch.float64, device=dev)
-    gathered = torch.empty((world, Fn, d), dtype=torch.float64, device=dev)
+    # the posterior means are all-gathered beside the next step (parallel.SummaryExchange: side stream, two mean buffers and
+    # two gathered buffers); the resampler of step k + 1 never waits for the collective of step k
+    mbuf = [torch.empty((Fn, d), dtype=torch.float64, device=dev) for _ in range(2)]
+    ex = parallel.SummaryExchange(like=mbuf[0], depth=2)
 
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(a.steps)]
 
-    def step(e=None):
+    def step(k, e=None):
+        slot = k % 2
+        ex.acquire(slot)
         if e:
             e[0].record()
         E.resample_systematic(Fn, Np, w, u, idx, st)
         if e:
             e[1].record()
         # posterior mean of the resampled set: gather + mean fused (fk_resample_gather_mean_f64)
-        E.resample_gather_mean(Fn, Np, d, particles, idx, means)
+        E.resample_gather_mean(Fn, Np, d, particles, idx, mbuf[slot])
         if e:
             e[2].record()
-        parallel.allgather_summary(means, gathered)
+        ex.post(mbuf[slot], slot, timed=e is not None)
 
-    for _ in range(a.warmup):
-        step()
+    for k in range(a.warmup):
+        step(k)
+    ex.drain()
     parallel.barrier()
     t0 = time.perf_counter()
     for k in range(a.steps):
-        step(ev[k])
+        step(k, ev[k])
+    ex.drain()
     parallel.barrier()
     elapsed = parallel.max_over_ranks(time.perf_counter() - t0, dev)
     assert not st.any()
-    # parity: first filter of this rank against the oracle, bit-exact
-    ref = ro.systematic_np(w[0].cpu().numpy(), float(u[0]))
-    exact = bool(np.array_equal(idx[0].cpu().numpy(), ref))
-    assert exact, "resample indices differ from the oracle"
-    m_ref = particles[0].index_select(0, idx[0].long()).mean(dim=0)
-    assert torch.allclose(means[0], m_ref, rtol=1e-11, atol=1e-13), "posterior mean differs from the gathered mean"
+    last = (a.steps - 1) % 2
+    means, gathered = mbuf[last], ex.gathered[last]
+    # parity (not timed), bit-exact: the first, a middle and the last filter of this rank against the reference's merge loop
+    # (C restatement, oracle/resample_oracle.c), and EVERY filter of the rank against the independent tile-by-tile kernel of
+    # round 1 (FK_RESAMPLE_SERIAL=1: no inter-workgroup protocol at all), every index compared on the GPU -- at 125 x 8e6 the
+    # one-pass kernel has 488 k chunks in flight, which is where its hand-off protocol matters
+    import hashlib
+    checked = sorted({0, Fn // 2, Fn - 1})
+    for f in checked:
+        ref, over = ro.systematic_c(w[f].cpu().numpy(), float(u[f]))
+        assert over == 0 and np.array_equal(idx[f].cpu().numpy(), ref), f"resample indices of filter {f} differ from the oracle"
+    exact = True
+    os.environ["FK_RESAMPLE_SERIAL"] = "1"
+    idx2 = torch.full_like(idx, -1)
+    E.resample_systematic(Fn, Np, w, u, idx2, st)
+    torch.cuda.synchronize()
+    del os.environ["FK_RESAMPLE_SERIAL"]
+    assert not st.any()
+    differ = (idx != idx2).any(dim=1).nonzero().flatten().tolist()          # every index of every filter, compared on the GPU
+    assert not differ, f"filters {differ[:8]} differ between the dispatched kernel and the serial kernel"
+    sha = {f: hashlib.sha256(idx[f].cpu().numpy().tobytes()).hexdigest()[:16] for f in checked}
+    del idx2
+    for f in checked:
+        m_ref = particles[f].index_select(0, idx[f].long()).mean(dim=0)
+        assert torch.allclose(means[f], m_ref, rtol=1e-11, atol=1e-13), "posterior mean differs from the gathered mean"
     if rank == 0:
         rs_ms = float(np.median([e[0].elapsed_time(e[1]) for e in ev]))
         gm_ms = float(np.median([e[1].elapsed_time(e[2]) for e in ev]))
@@ -106,6 +131,9 @@ def main():
                                    f"all-gather of ({per * world}, {d}) posterior means per step"},
             "resample_kernel_ms": rs_ms, "gather_mean_kernel_ms": gm_ms,
             "resample_GBs_algorithmic": 12.0 * per * Np / (rs_ms * 1e-3) / 1e9, "bit_exact_vs_oracle": exact,
+            "parity": f"filters {checked} vs the merge loop (oracle, C); all {Fn} filters, every index, vs the serial kernel",
+            "index_sha256_16": sha,
+            "allgather_ms": ex.gather_ms(), "exchange": "overlapped with the next step (side stream, double-buffered)",
             "collectives": (f"{world}-rank {torch.distributed.get_backend()} group" if parallel.collectives_active() else "none (single process)"),
             "gather_ok": bool(torch.equal(gathered[rank], means))}), flush=True)
     parallel.shutdown()

@@ -55,12 +55,13 @@ def run(n, m, N, T, layout, dense):
     means, covs = E.alloc_records((T,), N, n, layout), E.alloc_records((T,), N, n * n, layout)
     st = torch.zeros(N, dtype=torch.int32, device=dev)
     dd = [E.dev(M) for M in (F, H, Q, R, Wm, Wc)]
-    sw = {k: os.environ[k] for k in ("FK_UKF_PADDED", "FK_UKF_DMA", "FK_UKF_CHUNKS", "FK_UKF_RTS_CHUNKS") if k in os.environ}
+    sw = {k: os.environ[k] for k in ("FK_UKF_PADDED", "FK_UKF_DMA", "FK_UKF_CHUNKS", "FK_UKF_RTS_CHUNKS", "FK_UKF_PAIRED") if k in os.environ}
+    paired = E.pair_weights(Wm, Wc, n)      # looked at once, outside the timed calls (Merwe's weights: True)
 
     def fwd():
         x.copy_(x0)
         P.copy_(P0)
-        E.ukf_linear_batch(n, m, N, T, layout, lam + n, *dd, z, x, P, means=means, covs=covs, status=st)
+        E.ukf_linear_batch(n, m, N, T, layout, lam + n, *dd, z, x, P, means=means, covs=covs, status=st, paired=paired)
     ms = timeit(fwd)
     assert not st.any()
     trk = N - 1                    # the bank's last track: the one a tail-handling mistake would hit
@@ -81,7 +82,7 @@ def run(n, m, N, T, layout, dense):
     xs, Ps = E.alloc_records((T,), N, n, layout), E.alloc_records((T,), N, n * n, layout)
     Ks = E.alloc_records((T,), N, n * n, layout)
     ms = timeit(lambda: E.ukf_linear_rts(n, N, T, layout, lam + n, dd[0], dd[2], dd[4], dd[5], means, covs, xs, Ps, K=Ks,
-                                         status=st))
+                                         status=st, paired=paired))
     assert not st.any()
     xr, Pr, Kr = ukf_oracle.ukf_rts_smoother(mu_ref, cov_ref, lambda s, d: F @ s, 0.1, Q, alpha, beta, kappa)
     got_x = E.from_records(xs, layout, 1, (n,))[:, trk]

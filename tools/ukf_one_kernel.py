@@ -2,8 +2,8 @@
 """Compile ONE instantiation of the fused UKF kernels (two seconds instead of the two minutes of the whole unit) and print what
 the compiler made of it: registers, scratch, LDS, and the instruction mix of the time loop.
 
-    python tools/ukf_one_kernel.py fwd 6 3 soa            # ukf_linear_kernel<6, 3, LAYOUT_SOA, true>
-    python tools/ukf_one_kernel.py rts 6 aos --dma        # ukf_linear_rts_kernel<6, LAYOUT_AOS, true, true>
+    python tools/ukf_one_kernel.py fwd 6 3 soa            # ukf_linear_kernel<6, 3, LAYOUT_SOA, true, true>
+    python tools/ukf_one_kernel.py rts 6 aos --dma        # ukf_linear_rts_kernel<6, LAYOUT_AOS, true, true, true>
     python tools/ukf_one_kernel.py fwd 9 4 aos --padded   # the padded instantiation of the class
 
 Uses csrc/ukf_kernels.hip's parts 91 / 92 (the kernel templates alone).  The listing stays in /tmp for a closer look."""
@@ -22,17 +22,19 @@ def main():
     ap.add_argument("dims", nargs="+", help="fwd: NX NZ layout; rts: NX layout")
     ap.add_argument("--padded", action="store_true")
     ap.add_argument("--dma", action="store_true")
+    ap.add_argument("--index-order", action="store_true", help="the index-order sums (PAIRED = false)")
     a = ap.parse_args()
     lay = {"soa": "fk::LAYOUT_SOA", "aos": "fk::LAYOUT_AOS"}[a.dims[-1]]
     exact = "false" if a.padded else "true"
+    paired = "false" if a.index_order else "true"
     if a.kind == "fwd":
         nx, nz = int(a.dims[0]), int(a.dims[1])
-        inst = (f"template __global__ void fk::ukf_linear_kernel<{nx}, {nz}, {lay}, {exact}>(const fk::UkfArgs, const double *, "
+        inst = (f"template __global__ void fk::ukf_linear_kernel<{nx}, {nz}, {lay}, {exact}, {paired}>(const fk::UkfArgs, const double *, "
                 "const double *, const double *, const double *, const double *, const double *, const double *, const uint8_t *);")
         part = 91
     else:
         nx = int(a.dims[0])
-        inst = (f"template __global__ void fk::ukf_linear_rts_kernel<{nx}, {lay}, {exact}, {'true' if a.dma else 'false'}>("
+        inst = (f"template __global__ void fk::ukf_linear_rts_kernel<{nx}, {lay}, {exact}, {paired}, {'true' if a.dma else 'false'}>("
                 "const fk::UkfRtsArgs, const double *, const double *, const double *, const double *);")
         part = 92
     src = f"/tmp/ukf_one_{os.getpid()}.hip"
