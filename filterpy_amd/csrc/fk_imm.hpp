@@ -150,7 +150,12 @@ FK_HD int imm_update(double (&xs)[NM][NX], double (&Ps)[NM][NX * (NX + 1) / 2], 
         // 1480 of a (4,2) x 2 bank-step).  No branch anywhere: a fall-back path inside the time loop splits its one basic
         // block and the allocator spills 0.5 KB.  ln |S| itself is only needed for ll0 (the masked instantiations): one
         // logarithm of the same product (logdet_from_dinv).
-        double lj = (cm * rsqrt_det_from_dinv<NZ>(dinv, m)) * exp(-0.5 * q);
+        // (the root's binary exponent rides inside the one exponential: the two factors would under- / overflow apart --
+        //  exp(-q/2) is 0 beyond q ~ 1490 even where a tiny |S| brings the density back into range, and inf * 0 is NaN:
+        //  ADVICE r3; same VALU count, no branch)
+        int e2;
+        const double g = rsqrt_det_parts<NZ>(dinv, m, e2);
+        double lj = (cm * g) * exp(fma((double)e2, 0.6931471805599453, -0.5 * q));
         if (lj == 0.0) lj = 2.2250738585072014e-308;
         L[j] = lj;
         if (ll0) ll0[j] = -0.5 * (log2pi_m + logdet_from_dinv<NZ>(dinv, m));

@@ -71,8 +71,10 @@ FK_HD double logdet_from_dinv(const double (&dinv)[NZ], int m)
 // (mantissa x 2^exponent like logdet_from_dinv; the root of the mantissa -- in [2^-NZ, 2) after evening out the exponent --
 // from the v_rsq_f64 seed, one Goldschmidt step and a residual correction: 1e-16, tools/experiments/rsq_seed_accuracy.hip;
 // on the host the plain sqrt).
+// (rsqrt_det_parts: the root as mantissa g in [1/2, 2) and binary exponent e2, |S|^(-1/2) = g * 2^e2 -- a caller that
+//  multiplies by exp(.) folds e2 into that exponent and never leaves the range; rsqrt_det_from_dinv: the product itself)
 template <int NZ>
-FK_HD double rsqrt_det_from_dinv(const double (&dinv)[NZ], int m)
+FK_HD double rsqrt_det_parts(const double (&dinv)[NZ], int m, int &e2)
 {
     double pm = 1.0;
     int pe = 0;
@@ -85,6 +87,7 @@ FK_HD double rsqrt_det_from_dinv(const double (&dinv)[NZ], int m)
     const int odd = pe & 1;
     pm = odd ? pm + pm : pm;
     pe -= odd;
+    e2 = pe / 2;
 #if defined(__HIP_DEVICE_COMPILE__)
     const double y = __builtin_amdgcn_rsq(pm);
     double g = pm * y, h = 0.5 * y;
@@ -95,7 +98,15 @@ FK_HD double rsqrt_det_from_dinv(const double (&dinv)[NZ], int m)
 #else
     const double g = sqrt(pm);
 #endif
-    return ldexp(g, pe / 2);
+    return g;
+}
+
+template <int NZ>
+FK_HD double rsqrt_det_from_dinv(const double (&dinv)[NZ], int m)
+{
+    int e2;
+    const double g = rsqrt_det_parts<NZ>(dinv, m, e2);
+    return ldexp(g, e2);
 }
 
 // 1 / d for the arithmetic-bound kernels: the v_rcp_f64 seed (2^-24, tools/experiments/rsq_seed_accuracy.hip) and two Newton

@@ -358,6 +358,12 @@ FK_HD bool pair_weights_symmetric(const double *Wm, const double *Wc)
 // (6,3): ~1200 VALU instructions per step against V3's 1801.  Callers assert the symmetry (FK_UKF_FLAG_PAIR_WEIGHTS); the
 // index-order step remains for every other weight set and as the A/B switch (FK_UKF_PAIRED=0).
 // fresh() views carry Wp (make_pair_table) next to Wm / Wc.
+// Operand traffic (round 4): the shared model and the pair table sit in LDS, and a wave that asks for a row, waits, uses it
+// and asks for the next pays an LDS round trip per row -- 79 waits per step, about as long as the step's arithmetic on a SIMD
+// that holds one or two waves.  Here every operand of a half-step is REQUESTED AT ITS HEAD, in front of the factorisation
+// (which needs none of them): rows of F and the pair table before the predict's Cholesky, the rows of Q once the rows of F
+// are spent, rows of H / R and z before the update's Cholesky.  The round trips then run under ~130 instructions of
+// arithmetic each instead of under nothing; the price is registers (F: 2 n^2) that the factorisation leaves free anyway.
 template <int NX, int NZ, class LoadZ, class Fresh>
 FK_HD int ukf_linear_step_v4(double (&x)[NX], double (&P)[NX * (NX + 1) / 2], LoadZ &&load_z, bool has_z,
                              double scale, Fresh &&fresh)
@@ -366,28 +372,45 @@ FK_HD int ukf_linear_step_v4(double (&x)[NX], double (&P)[NX * (NX + 1) / 2], Lo
     int st = 0;
     // ---------------- predict (UKF.py:400-411)
     {
+        double Fm[NX][NX], wt[2 + NX];
+        {
+            const auto mv = fresh();
+            FK_UNROLL for (int r = 0; r < NX; ++r) mv.sm.rowF(r, Fm[r]);
+            FK_UNROLL for (int k = 0; k < 2 + NX; ++k) wt[k] = mv.Wp[k];
+        }
+        FK_STAGE();
         double Fx[NX], FL[NX][NX];
         {
             double L[PL];
             if (!chol_packed_rs<NX>(P, scale, L)) st |= ST_NOT_PD;
-            const auto mv = fresh();
+            FK_STAGE();
+            // one pass over the rows of F: F x and F L (FL[r][k] = sum_{c >= k} F[r][c] L[c][k])
             FK_UNROLL for (int r = 0; r < NX; ++r) {
-                double f[NX];
-                mv.sm.rowF(r, f);
-                Fx[r] = dot<NX>(f, x);
+                Fx[r] = dot<NX>(Fm[r], x);
                 FK_UNROLL for (int k = 0; k < NX; ++k) {
-                    double acc = f[k] * L[sym_idx<NX>(k, k)];
+                    double acc = Fm[r][k] * L[sym_idx<NX>(k, k)];
                     FK_UNROLL for (int c = 0; c < NX; ++c)
-                        if (c > k) acc = fma(f[c], L[sym_idx<NX>(c, k)], acc);
+                        if (c > k) acc = fma(Fm[r][c], L[sym_idx<NX>(c, k)], acc);
                     FL[r][k] = acc;
                 }
                 FK_STAGE();
             }
         }
+        // the rows of Q (upper triangle), requested now -- the registers of F are free -- and used after the last pair
+        double Qm[PL];
+        {
+            const auto mv = fresh(FL[NX - 1][NX - 1]);
+            FK_UNROLL for (int r = 0; r < NX; ++r) {
+                double q[NX];
+                mv.sm.rowQ(r, q);
+                FK_UNROLL for (int b = 0; b < NX; ++b)
+                    if (b >= r) Qm[sym_idx<NX>(r, b)] = q[b];
+            }
+        }
+        FK_STAGE();
         // mean and the centre point's offset
         {
-            const auto mv = fresh();
-            const double wms = mv.Wp[0], wcs = mv.Wp[1];
+            const double wms = wt[0], wcs = wt[1];
             double wy[NX];
             FK_UNROLL for (int r = 0; r < NX; ++r) {
                 x[r] = wms * Fx[r];
@@ -401,7 +424,7 @@ FK_HD int ukf_linear_step_v4(double (&x)[NX], double (&P)[NX * (NX + 1) / 2], Lo
         }
         // the pairs
         FK_UNROLL for (int k = 0; k < NX; ++k) {
-            const double wp = fresh(P[PL - 1]).Wp[2 + k];
+            const double wp = wt[2 + k];
             double wf[NX];
             FK_UNROLL for (int r = 0; r < NX; ++r) wf[r] = wp * FL[r][k];
             FK_UNROLL for (int a2 = 0; a2 < NX; ++a2)
@@ -409,43 +432,41 @@ FK_HD int ukf_linear_step_v4(double (&x)[NX], double (&P)[NX * (NX + 1) / 2], Lo
                     if (b >= a2) P[sym_idx<NX>(a2, b)] = fma(FL[a2][k], wf[b], P[sym_idx<NX>(a2, b)]);
             FK_STAGE();
         }
-        {
-            FK_UNROLL for (int e = 0; e < PL; ++e) FK_OPAQUE(P[e]);     // every sum complete before the rows of Q are read
-            const auto mv = fresh(P[PL - 1]);
-            FK_UNROLL for (int r = 0; r < NX; ++r) {
-                double q[NX];
-                mv.sm.rowQ(r, q);
-                FK_UNROLL for (int b = 0; b < NX; ++b)
-                    if (b >= r) P[sym_idx<NX>(r, b)] += q[b];
-            }
-        }
+        FK_UNROLL for (int e = 0; e < PL; ++e) P[e] += Qm[e];               // + Q last, like the reference
     }
     // ---------------- update (UKF.py:462-481), sigma points regenerated from the prior (:407)
     if (has_z) {
         double z[NZ];
         load_z(z);
+        double Hm[NZ][NX], Rm[NZ * NZ], wt[2 + NX];
+        {
+            const auto mv = fresh(P[PL - 1]);
+            FK_UNROLL for (int r = 0; r < NZ; ++r) mv.sm.rowH(r, Hm[r]);
+            FK_UNROLL for (int r = 0; r < NZ; ++r) {
+                double rr[NZ];
+                mv.sm.rowR(r, rr);
+                FK_UNROLL for (int c = 0; c < NZ; ++c) Rm[r * NZ + c] = rr[c];
+            }
+            FK_UNROLL for (int k = 0; k < 2 + NX; ++k) wt[k] = mv.Wp[k];
+        }
+        FK_STAGE();
         double L[PL];
         if (!chol_packed_rs<NX>(P, scale, L)) st |= ST_NOT_PD;
+        FK_STAGE();
         double Hx[NZ], HL[NZ][NX];
-        {
-            const auto mv = fresh();
-            FK_UNROLL for (int r = 0; r < NZ; ++r) {
-                double h[NX];
-                mv.sm.rowH(r, h);
-                Hx[r] = dot<NX>(h, x);
-                FK_UNROLL for (int k = 0; k < NX; ++k) {
-                    double acc = h[k] * L[sym_idx<NX>(k, k)];
-                    FK_UNROLL for (int c = 0; c < NX; ++c)
-                        if (c > k) acc = fma(h[c], L[sym_idx<NX>(c, k)], acc);
-                    HL[r][k] = acc;
-                }
+        FK_UNROLL for (int r = 0; r < NZ; ++r) {
+            Hx[r] = dot<NX>(Hm[r], x);
+            FK_UNROLL for (int k = 0; k < NX; ++k) {
+                double acc = Hm[r][k] * L[sym_idx<NX>(k, k)];
+                FK_UNROLL for (int c = 0; c < NX; ++c)
+                    if (c > k) acc = fma(Hm[r][c], L[sym_idx<NX>(c, k)], acc);
+                HL[r][k] = acc;
             }
-            FK_STAGE();
         }
+        FK_STAGE();
         double zp[NZ], S[NZ * NZ], K[NX * NZ];
         {
-            const auto mv = fresh();
-            const double wms = mv.Wp[0], wcs = mv.Wp[1];
+            const double wms = wt[0], wcs = wt[1];
             double wd[NZ];
             FK_UNROLL for (int r = 0; r < NZ; ++r) {
                 zp[r] = wms * Hx[r];
@@ -457,7 +478,7 @@ FK_HD int ukf_linear_step_v4(double (&x)[NX], double (&P)[NX * (NX + 1) / 2], Lo
                     if (c >= r) S[r * NZ + c] = Hx[r] * wd[c];
         }
         FK_UNROLL for (int k = 0; k < NX; ++k) {
-            const double wp = fresh(S[NZ * NZ - 1]).Wp[2 + k];
+            const double wp = wt[2 + k];
             double wh[NZ];
             FK_UNROLL for (int r = 0; r < NZ; ++r) wh[r] = wp * HL[r][k];
             FK_UNROLL for (int r = 0; r < NZ; ++r)
@@ -470,19 +491,10 @@ FK_HD int ukf_linear_step_v4(double (&x)[NX], double (&P)[NX * (NX + 1) / 2], Lo
             }
             FK_STAGE();
         }
-        {
-            FK_UNROLL for (int r = 0; r < NZ; ++r)
-                FK_UNROLL for (int c = 0; c < NZ; ++c)
-                    if (c < r) S[r * NZ + c] = S[c * NZ + r];
-            FK_UNROLL for (int e = 0; e < NZ * NZ; ++e) FK_OPAQUE(S[e]);
-            FK_UNROLL for (int e = 0; e < NX * NZ; ++e) FK_OPAQUE(K[e]);
-            const auto mv = fresh(S[NZ * NZ - 1]);
-            FK_UNROLL for (int r = 0; r < NZ; ++r) {
-                double rr[NZ];
-                mv.sm.rowR(r, rr);
-                FK_UNROLL for (int c = 0; c < NZ; ++c) S[r * NZ + c] += rr[c];
-            }
-        }
+        FK_UNROLL for (int r = 0; r < NZ; ++r)
+            FK_UNROLL for (int c = 0; c < NZ; ++c)
+                if (c < r) S[r * NZ + c] = S[c * NZ + r];
+        FK_UNROLL for (int e = 0; e < NZ * NZ; ++e) S[e] += Rm[e];          // + R last
         // K = Pxz S^-1
         double Lf[NZ * NZ], dd[NZ], dinv[NZ];
         FK_UNROLL for (int e = 0; e < NZ * NZ; ++e) Lf[e] = S[e];
@@ -622,27 +634,41 @@ FK_HD int ukf_linear_rts_gain_v4(double (&x)[NX], const double (&P)[NX * (NX + 1
 {
     constexpr int PL = NX * (NX + 1) / 2;
     int st = 0;
+    // operands requested at the head, in front of the factorisation (see ukf_linear_step_v4)
+    double Fm[NX][NX], wt[2 + NX];
+    {
+        const auto mv = fresh();
+        FK_UNROLL for (int r = 0; r < NX; ++r) mv.sm.rowF(r, Fm[r]);
+        FK_UNROLL for (int k = 0; k < 2 + NX; ++k) wt[k] = mv.Wp[k];
+    }
+    FK_STAGE();
     double L[PL];
     if (!chol_packed_rs<NX>(P, scale, L)) st |= ST_NOT_PD;
+    FK_STAGE();
     double Fx[NX], FL[NX][NX];
+    FK_UNROLL for (int r = 0; r < NX; ++r) {
+        Fx[r] = dot<NX>(Fm[r], x);
+        FK_UNROLL for (int k = 0; k < NX; ++k) {
+            double acc = Fm[r][k] * L[sym_idx<NX>(k, k)];
+            FK_UNROLL for (int c = 0; c < NX; ++c)
+                if (c > k) acc = fma(Fm[r][c], L[sym_idx<NX>(c, k)], acc);
+            FL[r][k] = acc;
+        }
+        FK_STAGE();
+    }
+    double Qm[PL];
     {
-        const auto mv = fresh();
+        const auto mv = fresh(FL[NX - 1][NX - 1]);
         FK_UNROLL for (int r = 0; r < NX; ++r) {
-            double f[NX];
-            mv.sm.rowF(r, f);
-            Fx[r] = dot<NX>(f, x);
-            FK_UNROLL for (int k = 0; k < NX; ++k) {
-                double acc = f[k] * L[sym_idx<NX>(k, k)];
-                FK_UNROLL for (int c = 0; c < NX; ++c)
-                    if (c > k) acc = fma(f[c], L[sym_idx<NX>(c, k)], acc);
-                FL[r][k] = acc;
-            }
-            FK_STAGE();
+            double q[NX];
+            mv.sm.rowQ(r, q);
+            FK_UNROLL for (int b = 0; b < NX; ++b)
+                if (b >= r) Qm[sym_idx<NX>(r, b)] = q[b];
         }
     }
+    FK_STAGE();
     {
-        const auto mv = fresh();
-        const double wms = mv.Wp[0], wcs = mv.Wp[1];
+        const double wms = wt[0], wcs = wt[1];
         double wy[NX];
         FK_UNROLL for (int r = 0; r < NX; ++r) {
             xb[r] = wms * Fx[r];
@@ -655,7 +681,7 @@ FK_HD int ukf_linear_rts_gain_v4(double (&x)[NX], const double (&P)[NX * (NX + 1
         FK_STAGE();
     }
     FK_UNROLL for (int k = 0; k < NX; ++k) {
-        const double wp = fresh(Pb[PL - 1]).Wp[2 + k];
+        const double wp = wt[2 + k];
         double wf[NX];
         FK_UNROLL for (int r = 0; r < NX; ++r) wf[r] = wp * FL[r][k];
         FK_UNROLL for (int a2 = 0; a2 < NX; ++a2)
@@ -668,16 +694,7 @@ FK_HD int ukf_linear_rts_gain_v4(double (&x)[NX], const double (&P)[NX * (NX + 1
         }
         FK_STAGE();
     }
-    {
-        FK_UNROLL for (int e = 0; e < PL; ++e) FK_OPAQUE(Pb[e]);
-        const auto mv = fresh(Pb[PL - 1]);
-        FK_UNROLL for (int r = 0; r < NX; ++r) {
-            double q[NX];
-            mv.sm.rowQ(r, q);
-            FK_UNROLL for (int b = 0; b < NX; ++b)
-                if (b >= r) Pb[sym_idx<NX>(r, b)] += q[b];
-        }
-    }
+    FK_UNROLL for (int e = 0; e < PL; ++e) Pb[e] += Qm[e];                  // + Q last
     // K = Pxb inv(Pb)
     {
         double Lp[PL], d[NX], dinv[NX];

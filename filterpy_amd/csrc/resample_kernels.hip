@@ -427,7 +427,11 @@ residual_fill_kernel(long Np, const double *__restrict__ w, int32_t *__restrict_
             const int j = tid * RS_ITEMS + q;
             const double wj = j < len ? wf[base + j] : 0.0;
             const double c = floor(dN * wj);                               // (np.floor(N * w)).astype(int): one rounding, then floor
-            const long ci = (c >= 0.0 && c < 0x1p40) ? (long)c : 0;        // (negative / NaN / absurd: no copies, garbage anyway)
+            // negative / NaN: no copies (the reference's range(negative) is empty).  More copies than slots: the reference's
+            // fill loop raises IndexError at slot Np -- saturate at Np + 1, so that the total exceeds Np and ST_OVERRUN is
+            // reported, whatever the size of N w (un-normalised weights: N w ~ 1e9 used to spin here for minutes, and counts
+            // of 2^40 and more were dropped silently: ADVICE r3)
+            const long ci = !(c >= 0.0) ? 0 : (c > dN ? Np + 1 : (long)c);
             cnt[q] = ci;
             run += ci;
             if (j < len) cf[base + j] = wj - c;                            // the residual, for the two passes below
@@ -446,8 +450,9 @@ residual_fill_kernel(long Np, const double *__restrict__ w, int32_t *__restrict_
         }
         FK_UNROLL for (int q = 0; q < RS_ITEMS; ++q) {
             const int j = tid * RS_ITEMS + q;
-            for (long c = 0; c < cnt[q]; ++c)
-                if (off + c < Np) of[off + c] = (int32_t)(base + j);
+            const long room = off < Np ? Np - off : 0;                     // copies that still land inside the vector
+            const long todo = cnt[q] < room ? cnt[q] : room;
+            for (long c = 0; c < todo; ++c) of[off + c] = (int32_t)(base + j);
             off += cnt[q];
         }
         carry += total;
@@ -495,9 +500,9 @@ residual_fill_kernel(long Np, const double *__restrict__ w, int32_t *__restrict_
 
 __global__ void __launch_bounds__(RS_THREADS)
 residual_draw_kernel(long Np, const double *__restrict__ cs, const long *__restrict__ k, const long *__restrict__ uoff,
-                     const double *__restrict__ u, int32_t *__restrict__ idx)
+                     const double *__restrict__ u, int32_t *__restrict__ idx, long f0)
 {
-    const long f = blockIdx.y;
+    const long f = f0 + blockIdx.y;
     const long kf = k[f];
     const long i = (long)blockIdx.x * RS_THREADS + threadIdx.x;
     if (kf > Np || i >= Np - kf) return;
@@ -524,10 +529,10 @@ constexpr int GM_CHUNK = 16384;
 template <int D>
 __global__ void __launch_bounds__(RS_THREADS)
 gather_mean_kernel(long Np, const double *__restrict__ particles, const int32_t *__restrict__ idx, double *__restrict__ mean,
-                   int d)
+                   int d, long f0)
 {
     __shared__ double red[RS_THREADS / 64][D];
-    const long f = blockIdx.y;
+    const long f = f0 + blockIdx.y;
     const long i0 = (long)blockIdx.x * GM_CHUNK;
     const long i1 = (i0 + GM_CHUNK < Np) ? i0 + GM_CHUNK : Np;
     const double *pf = particles + f * Np * d;
@@ -549,6 +554,60 @@ gather_mean_kernel(long Np, const double *__restrict__ particles, const int32_t 
         double t = 0.0;
         for (int w = 0; w < RS_THREADS / 64; ++w) t += red[w][threadIdx.x];
         atomicAdd(&mean[f * d + threadIdx.x], t / (double)Np);
+    }
+}
+
+// The same for 32-byte records (d = 4, 16-byte aligned: BASELINE configs[4]'s harness), round 4.  The indices a resampler
+// returns are non-decreasing, so a workgroup's slice of them points into ONE short contiguous range of particles and the
+// gather is a stream -- what the first kernel lacked was memory-level parallelism: one dependent (index -> record) pair in
+// flight per lane and four 8-byte loads per record (8.0 ms for 36 GB at 125 x 8e6 = 0.56 of HBM).  Here every lane has GM_U
+// independent index loads in flight, then 2 GM_U independent 16-byte record loads; a wave's 64 lanes take 64 consecutive
+// indices per load, i.e. (with duplicates) one or two KiB of consecutive records.
+constexpr int GM_U = 8;
+constexpr int GM_CHUNK4 = RS_THREADS * GM_U * 8;
+__global__ void __launch_bounds__(RS_THREADS)
+gather_mean4_kernel(long Np, const double *__restrict__ particles, const int32_t *__restrict__ idx, double *__restrict__ mean, long f0)
+{
+    using f64x2 = __attribute__((ext_vector_type(2))) double;
+    __shared__ double red[RS_THREADS / 64][4];
+    const long f = f0 + blockIdx.y;
+    const long i0 = (long)blockIdx.x * GM_CHUNK4;
+    const long i1 = (i0 + GM_CHUNK4 < Np) ? i0 + GM_CHUNK4 : Np;
+    const f64x2 *pf = reinterpret_cast<const f64x2 *>(particles + f * Np * 4);
+    const int32_t *xf = idx + f * Np;
+    f64x2 a0 = {0.0, 0.0}, a1 = {0.0, 0.0}, b0 = {0.0, 0.0}, b1 = {0.0, 0.0};      // two accumulator pairs: shorter add chains
+    long i = i0 + threadIdx.x;
+    for (; i + (long)(GM_U - 1) * RS_THREADS < i1; i += (long)GM_U * RS_THREADS) {
+        int j[GM_U];
+        FK_UNROLL for (int q = 0; q < GM_U; ++q) j[q] = __builtin_nontemporal_load(xf + i + (long)q * RS_THREADS);
+        f64x2 lo[GM_U], hi[GM_U];
+        FK_UNROLL for (int q = 0; q < GM_U; ++q) {
+            lo[q] = pf[2L * j[q]];
+            hi[q] = pf[2L * j[q] + 1];
+        }
+        FK_UNROLL for (int q = 0; q < GM_U; q += 2) {
+            a0 += lo[q];
+            a1 += hi[q];
+            b0 += lo[q + 1];
+            b1 += hi[q + 1];
+        }
+    }
+    for (; i < i1; i += RS_THREADS) {
+        const long j = xf[i];
+        a0 += pf[2 * j];
+        a1 += pf[2 * j + 1];
+    }
+    double acc[4] = {a0.x + b0.x, a0.y + b0.y, a1.x + b1.x, a1.y + b1.y};
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    FK_UNROLL for (int k = 0; k < 4; ++k) {
+        FK_UNROLL for (int s = 32; s > 0; s >>= 1) acc[k] += __shfl_down(acc[k], s, 64);
+        if (lane == 0) red[wave][k] = acc[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 4u) {
+        double t = 0.0;
+        for (int w = 0; w < RS_THREADS / 64; ++w) t += red[w][threadIdx.x];
+        atomicAdd(&mean[f * 4 + threadIdx.x], t / (double)Np);
     }
 }
 
@@ -674,10 +733,12 @@ int fk_resample_residual_draw_f64(int64_t Fn, int64_t Np, const double *cs, cons
 {
     if (Fn < 0 || Np < 0) return fail(FK_ERR_BAD_ARG, "residual: negative size");
     if (Fn == 0 || Np == 0) return FK_OK;
-    if (Fn > 65535) return fail(FK_ERR_UNSUPPORTED, "residual draw: at most 65535 filters per call");
     if (!cs || !k || !uoff || !u || !idx) return fail(FK_ERR_BAD_ARG, "residual: NULL argument");
-    const dim3 grid((unsigned)((Np + RS_THREADS - 1) / RS_THREADS), (unsigned)Fn), block(RS_THREADS);
-    hipLaunchKernelGGL(residual_draw_kernel, grid, block, 0, (hipStream_t)stream, (long)Np, cs, (const long *)k, (const long *)uoff, u, idx);
+    for (long f0 = 0; f0 < Fn; f0 += 65535) {                              // grid.y holds 65535 filters: larger banks in slices
+        const long fc = Fn - f0 < 65535 ? Fn - f0 : 65535;
+        const dim3 grid((unsigned)((Np + RS_THREADS - 1) / RS_THREADS), (unsigned)fc), block(RS_THREADS);
+        hipLaunchKernelGGL(residual_draw_kernel, grid, block, 0, (hipStream_t)stream, (long)Np, cs, (const long *)k, (const long *)uoff, u, idx, f0);
+    }
     return check_launch("residual_draw_kernel");
 }
 
@@ -687,13 +748,24 @@ int fk_resample_gather_mean_f64(int64_t Fn, int64_t Np, int32_t d, const double 
     if (Fn < 0 || Np < 0 || d < 1 || d > 8) return fail(FK_ERR_BAD_ARG, "gather_mean: Fn, Np >= 0 and 1 <= d <= 8");
     if (Fn == 0) return FK_OK;
     if (!mean || (Np > 0 && (!particles || !idx))) return fail(FK_ERR_BAD_ARG, "gather_mean: NULL argument");
-    if (Fn > 65535) return fail(FK_ERR_UNSUPPORTED, "gather_mean: at most 65535 filters per call");
     hipStream_t s = (hipStream_t)stream;
     if (hipMemsetAsync(mean, 0, (size_t)Fn * d * sizeof(double), s) != hipSuccess) return fail(FK_ERR_LAUNCH, "gather_mean: memset failed");
     if (Np == 0) return FK_OK;
-    const dim3 grid((unsigned)((Np + GM_CHUNK - 1) / GM_CHUNK), (unsigned)Fn), block(RS_THREADS);
-    if (d <= 4) hipLaunchKernelGGL((gather_mean_kernel<4>), grid, block, 0, s, (long)Np, particles, idx, mean, (int)d);
-    else hipLaunchKernelGGL((gather_mean_kernel<8>), grid, block, 0, s, (long)Np, particles, idx, mean, (int)d);
+    // FK_GATHER_MEAN_WIDE=0: the first kernel also for 32-byte records (A/B)
+    const char *wv = getenv("FK_GATHER_MEAN_WIDE");
+    const bool wide = d == 4 && reinterpret_cast<uintptr_t>(particles) % 16 == 0 && !(wv && wv[0] == '0');
+    for (long f0 = 0; f0 < Fn; f0 += 65535) {                              // grid.y holds 65535 filters: larger banks in slices
+        const long fc = Fn - f0 < 65535 ? Fn - f0 : 65535;
+        const dim3 block(RS_THREADS);
+        if (wide) {
+            const dim3 grid((unsigned)((Np + GM_CHUNK4 - 1) / GM_CHUNK4), (unsigned)fc);
+            hipLaunchKernelGGL(gather_mean4_kernel, grid, block, 0, s, (long)Np, particles, idx, mean, f0);
+            continue;
+        }
+        const dim3 grid((unsigned)((Np + GM_CHUNK - 1) / GM_CHUNK), (unsigned)fc);
+        if (d <= 4) hipLaunchKernelGGL((gather_mean_kernel<4>), grid, block, 0, s, (long)Np, particles, idx, mean, (int)d, f0);
+        else hipLaunchKernelGGL((gather_mean_kernel<8>), grid, block, 0, s, (long)Np, particles, idx, mean, (int)d, f0);
+    }
     return check_launch("gather_mean_kernel");
 }
 

@@ -592,9 +592,20 @@ class UnscentedKalmanFilter(object):
                                E.to_records(zarr, lay, 1), dx, dP, mask=dm, means=means, covs=covs, status=st,
                                paired=E.pair_weights(self.Wm, self.Wc, n))
             E.raise_on_status(st, "UnscentedKalmanFilter.batch_filter")
-            self.x = self._unb(E.from_records(dx, lay, 0, (n,)))
-            self.P = self._unb(E.from_records(dP, lay, 0, (n, n)))
+            x_end = self._unb(E.from_records(dx, lay, 0, (n,)))
+            P_end = self._unb(E.from_records(dP, lay, 0, (n, n)))
             mu, cov = E.from_records(means, lay, 1, (n,)), E.from_records(covs, lay, 1, (n, n))
+            # The reference's loop leaves the LAST epoch's by-products on the filter (UKF.py:623-632: x_prior / P_prior, sigmas_f,
+            # sigmas_h, K, S, SI, y, z, x_post / P_post, the lazy likelihoods reset); the fused launch keeps them in registers.
+            # One replay of that epoch through predict() / update() from the state before it puts them there;
+            # x / P themselves stay the fused launch's, so that means[-1] is self.x bit for bit like in the reference.
+            if T >= 1:
+                if T >= 2:
+                    self.x, self.P = self._unb(np.array(mu[T - 2])), self._unb(np.array(cov[T - 2]))
+                self.predict()
+                self.update(zs[T - 1])
+            self.x, self.P = x_end, P_end
+            self.x_post, self.P_post = np.copy(self.x), np.copy(self.P)
             return (mu, cov) if self._N is not None else (mu[:, 0], cov[:, 0])
         Rs = [self.R] * T if Rs is None else Rs
         dts = [self._dt] * T if dts is None else dts

@@ -194,6 +194,49 @@ def test_ukf_general_callables_vs_reference():
         assert rel_err_rows(mu2, g[p + "mu"]) < tmu and rel_err_rows(cov2, g[p + "cov"]) < tcov
 
 
+@pytest.mark.parametrize("last_missing", [False, True])
+def test_ukf_fused_batch_filter_leaves_the_last_epochs_attributes(last_missing):
+    """the reference's batch_filter is a loop of predict() / update() (UKF.py:623-632), so afterwards the filter
+    carries the LAST epoch's x_prior / P_prior, sigmas_f, sigmas_h, K, S, SI, y, z, x_post / P_post and reset likelihood
+    caches.  The fused launch (matrix fx / hx) must leave the same: compared with the same filter stepped one call at a
+    time through the callable path, single filter and bank; means[-1] is self.x bit for bit."""
+    from filterpy_amd.kalman import UnscentedKalmanFilter, MerweScaledSigmaPoints
+    g = golden("ukf_merwe")
+    ci = [i for i, c in enumerate(g["cases"]) if int(c[0]) == 6][0]
+    n, m, alpha, beta, kappa = (int(g["cases"][ci][0]), int(g["cases"][ci][1])) + tuple(float(v) for v in g["cases"][ci][2:5])
+    p = f"c{ci}_"
+    F, H = g[p + "F"], g[p + "H"]
+    zs = list(g[p + "zs"][:6])
+    if last_missing:
+        zs[-1] = None
+    for N in (None, 70):
+        def make(fx, hx):
+            u = UnscentedKalmanFilter(n, m, dt=1.0, hx=hx, fx=fx, points=MerweScaledSigmaPoints(n, alpha, beta, kappa),
+                                      **({} if N is None else {"n_tracks": N}))
+            tile = (lambda a: a.copy()) if N is None else (lambda a: np.tile(a, (N,) + (1,) * a.ndim))
+            u.x, u.P, u.Q, u.R = tile(g[p + "x0"]), tile(g[p + "P0"]), g[p + "Q"].copy(), g[p + "R"].copy()
+            return u
+        zz = zs if N is None else [None if z is None else np.tile(z, (N, 1)) for z in zs]
+        a = make(F, H)
+        mu, cov = a.batch_filter(zz)
+        b = make(lambda x, dt: x @ F.T, lambda x: x @ H.T) if N is not None else make(lambda x, dt: F @ x, lambda x: H @ x)
+        for z in zz:
+            b.predict()
+            b.update(z)
+        assert np.array_equal(np.asarray(a.x), mu[-1]) and np.array_equal(np.asarray(a.P), cov[-1])
+        assert np.array_equal(a.x_post, a.x) and np.array_equal(a.P_post, a.P)
+        for attr in ("x", "P", "x_prior", "P_prior", "sigmas_f", "x_post", "P_post") + (() if last_missing else ("sigmas_h", "K", "S", "SI", "y")):
+            va, vb = np.asarray(getattr(a, attr), dtype=float), np.asarray(getattr(b, attr), dtype=float)
+            assert va.shape == vb.shape, (attr, va.shape, vb.shape)
+            assert rel_err_rows(va.reshape(1, -1), vb.reshape(1, -1)) < 1e-10, (attr, N)
+        if last_missing:
+            assert np.array_equal(a.z, b.z)
+        else:
+            assert np.allclose(np.asarray(a.z, dtype=float), np.asarray(b.z, dtype=float))
+            if N is None:
+                assert a.log_likelihood == pytest.approx(b.log_likelihood, rel=1e-9)
+
+
 def test_unscented_transform_and_sigma_points_api():
     from filterpy_amd.kalman import MerweScaledSigmaPoints, unscented_transform
     g = golden("ukf_merwe")
