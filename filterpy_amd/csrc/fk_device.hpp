@@ -53,6 +53,15 @@ struct RecView {
     rsrc_t rs;
     unsigned voff;        // per-lane byte offset
     unsigned estride;     // SOA: N*8 (bytes between consecutive elements), uniform
+    // present = false: a descriptor of ZERO records -- every access through it is out of range, i.e. loads return 0 and stores
+    // are dropped by the hardware, but they are still ISSUED: an optional output costs no branch around its stores, the
+    // number of stores of a time step is a constant and the compiler can count them in its s_waitcnt (a load requested in
+    // front of them is then waited for with vmcnt(#stores) instead of vmcnt(0))
+    __device__ __forceinline__ RecView(const double *blk, const Lane &ln, int E, bool present)
+        : RecView(blk, ln, E)
+    {
+        if (!present) rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(blk), 0, 0, 0x00020000);
+    }
     __device__ __forceinline__ RecView(const double *blk, const Lane &ln, int E)
     {
         if (LAYOUT == LAYOUT_AOS) {
@@ -125,10 +134,10 @@ __device__ __forceinline__ void load_rec(double (&M)[ROWS * COLS], const double 
 
 template <int ROWS, int COLS, int LAYOUT, bool EXACT>
 __device__ __forceinline__ void store_rec(const double (&M)[ROWS * COLS], double *__restrict__ blk,
-                                          const Lane &ln, int r, int c)
+                                          const Lane &ln, int r, int c, bool present = true)
 {
     const int E = EXACT ? ROWS * COLS : r * c;
-    const RecView<LAYOUT> v(blk, ln, E);
+    const RecView<LAYOUT> v(blk, ln, E, present);
     if constexpr (EXACT && LAYOUT == LAYOUT_AOS && ROWS * COLS >= 2) {
         FK_UNROLL for (int e = 0; e + 1 < ROWS * COLS; e += 2) v.store2(e, M[e], M[e + 1]);
         if ((ROWS * COLS) % 2) v.store(ROWS * COLS - 1, M[ROWS * COLS - 1]);
@@ -298,11 +307,12 @@ __device__ __forceinline__ void wave_store_aos_pitch(const double (&v)[LEN], con
 // writes are bank-conflicted (row stride 2 LEN dwords); at one record per time step that is noise.
 template <int LEN>
 __device__ __forceinline__ void wave_store_aos_flat(const double (&v)[LEN], const double *slab, unsigned wave_row0,
-                                                    double *tile, unsigned lane, unsigned last_row)
+                                                    double *tile, unsigned lane, unsigned last_row, bool present = true)
 {
     static_assert(LEN % 2 == 0, "16-byte units");
+    // (present = false: zero records -- the stores are issued and dropped, see RecView)
     const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(slab), 0,
-                                                        (int)((last_row + 1u) * (unsigned)LEN * 8u), 0x00020000);
+                                                        present ? (int)((last_row + 1u) * (unsigned)LEN * 8u) : 0, 0x00020000);
     wave_lds_fence();
     FK_UNROLL for (int e = 0; e < LEN; ++e) tile[lane * LEN + e] = v[e];
     wave_lds_fence();

@@ -73,7 +73,11 @@ __device__ __forceinline__ void cov_full(const double (&P)[PLEN], double (&M)[NX
 // EX: the update's by-products as per-step histories (fk_kf_batch_filter_ex_f64: y, K, S, SI, log-likelihood, mahalanobis;
 // KalmanFilter.batch_filter with a Saver, kalman_filter.py:533-563 and the lazy properties :1180-1225) stored by this kernel
 // instead of the generic one -- shared constant model, predict -> update, all four outputs.
-template <int NX, int NZ, int LAYOUT, bool HAS_MASK, bool OUTS, bool SYM, int MMODE, bool UF, bool CTRL, bool EX = false>
+// IL (round 4; NumPy order, dim_x <= 4, FK_KF_FLAG_COV_INTERLEAVED): the prior covariance of a step waits in registers for the
+// posterior and the two leave TOGETHER as one 2 n^2-double record per track -- 1 KiB contiguous per store instruction, one
+// write front for both histories (written apart, as two n^2 islands per track at different moments of the step, the
+// interleaved array is slower than two arrays: profiles/r04/placement).
+template <int NX, int NZ, int LAYOUT, bool HAS_MASK, bool OUTS, bool SYM, int MMODE, bool UF, bool CTRL, bool EX = false, bool IL = false>
 __global__ void __launch_bounds__(BLOCK, fast_min_waves(NX, LAYOUT) > 1 && (MMODE == 1 || MMODE == 2 || EX) ? fast_min_waves(NX, LAYOUT) - 1 : fast_min_waves(NX, LAYOUT))
 kf_fast_kernel(const KfArgs a, const double *__restrict__ pF, const double *__restrict__ pQ,
                const double *__restrict__ pH, const double *__restrict__ pR,
@@ -84,7 +88,8 @@ kf_fast_kernel(const KfArgs a, const double *__restrict__ pF, const double *__re
     // dim_x <= 8 for the one-wave-per-SIMD instantiations (4 tiles of 64 x 65 doubles = 133 KB);
     // dim_x = 9 falls back to per-lane 16-byte stores (the three-lane kernel takes the common call)
     constexpr bool COOP = (LAYOUT == LAYOUT_AOS) && (NX * NX <= 36 || (NX <= 8 && fast_min_waves(NX, LAYOUT) == 1));
-    constexpr int TILE = COOP ? 64 * ((NX * NX) | 1) : 0;   // doubles per wave
+    static_assert(!IL || (COOP && OUTS && !UF && !EX && NX * NX <= 16), "IL: the plain predict -> update call in NumPy order, dim_x <= 4");
+    constexpr int TILE = COOP ? 64 * ((IL ? 2 * NX * NX : NX * NX) | 1) : 0;   // doubles per wave
     constexpr int MSIZE = SharedModel::SIZE * (MMODE == 3 ? 2 : 1);   // per-step models: double buffer
     __shared__ double s_mem[MSIZE + (BLOCK / 64) * TILE + 1];
     constexpr int NUC = 4;                                   // padded dim_u
@@ -206,6 +211,7 @@ kf_fast_kernel(const KfArgs a, const double *__restrict__ pF, const double *__re
         const double mpub = mnext;
         if constexpr (MMODE == 3) mnext = shared_elem(t + 2 < T ? t + 2 : T - 1);
         double Pf[NX * NX];
+        double Pprior[IL ? NX * NX : 1];
         auto do_predict = [&]() {
             if constexpr (MMODE == 1 || MMODE == 2) {
                 if constexpr (SYM) kf_predict_sym<NX>(x, P, tm, a.alpha_sq);
@@ -227,6 +233,9 @@ kf_fast_kernel(const KfArgs a, const double *__restrict__ pF, const double *__re
             } else if (!COOP) {
                 store_rec<NX, 1, LAYOUT, true>(x, a.means_p + t * N * NX, ln, NX, 1);
                 store_rec<NX, NX, LAYOUT, true>(Pf, a.covs_p + t * a.cov_step, ln, NX, NX);
+            } else if constexpr (IL) {
+                wave_store_aos<NX>(x, a.means_p + (t * N + blk0) * NX, wave * 64u, tile, lane, last_row);
+                FK_UNROLL for (int e = 0; e < NX * NX; ++e) Pprior[e] = Pf[e];        // leaves with the posterior
             } else {
                 wave_store_aos<NX>(x, a.means_p + (t * N + blk0) * NX, wave * 64u, tile, lane, last_row);
                 wave_store_aos_pitch<NX * NX>(Pf, a.covs_p + t * a.cov_step + blk0 * a.cov_pitch, wave * 64u, tile, lane, last_row, (unsigned)a.cov_pitch);
@@ -308,6 +317,11 @@ kf_fast_kernel(const KfArgs a, const double *__restrict__ pF, const double *__re
             } else if (!COOP) {
                 store_rec<NX, 1, LAYOUT, true>(x, a.means + t * N * NX, ln, NX, 1);
                 store_rec<NX, NX, LAYOUT, true>(Pf, a.covs + t * a.cov_step, ln, NX, NX);
+            } else if constexpr (IL) {
+                wave_store_aos<NX>(x, a.means + (t * N + blk0) * NX, wave * 64u, tile, lane, last_row);
+                double rec[2 * NX * NX];                                            // [posterior | prior]: cov2[t][track][2][n*n]
+                FK_UNROLL for (int e = 0; e < NX * NX; ++e) { rec[e] = Pf[e]; rec[NX * NX + e] = Pprior[e]; }
+                wave_store_aos<2 * NX * NX>(rec, a.covs + t * a.cov_step + blk0 * (2 * NX * NX), wave * 64u, tile, lane, last_row);
             } else {
                 wave_store_aos<NX>(x, a.means + (t * N + blk0) * NX, wave * 64u, tile, lane, last_row);
                 wave_store_aos_pitch<NX * NX>(Pf, a.covs + t * a.cov_step + blk0 * a.cov_pitch, wave * 64u, tile, lane, last_row, (unsigned)a.cov_pitch);
@@ -408,6 +422,14 @@ int FK_CAT(launch_kf_fast_, FK_NX, FK_NZ, FK_VARIANT)(const KfArgs &a, int layou
     if (!outs && FK_VARIANT != 0) return 1;
     if (a.update_first && !(FK_FAST_ALL_MODES && mmode == 0)) return 1;   // update_first: shared model, variant 0, dim_x <= 6
     if (a.nu > 0 && !(FK_FAST_ALL_MODES && mmode == 0 && !a.update_first && a.nu <= 4)) return 1;   // control input: same, dim_u <= 4
+    // FK_KF_FLAG_COV_INTERLEAVED, NumPy order, dim_x <= 4, the plain call on a shared model: prior and posterior leave together
+#if FK_NX * FK_NX <= 16 && FK_VARIANT == 0
+    if (layout == LAYOUT_AOS && a.cov_pitch == 2 * FK_NX * FK_NX && outs && mmode == 0 && !a.update_first && a.nu == 0 && !getenv("FK_FAST_NO_IL")) {
+        if (a.mask) hipLaunchKernelGGL((kf_fast_kernel<FK_NX, FK_NZ, LAYOUT_AOS, true, true, (FK_FAST_SYM != 0), 0, false, false, false, true>), grid, block, 0, stream, a, a.F, a.Q, a.H, a.R, a.z, a.mask);
+        else hipLaunchKernelGGL((kf_fast_kernel<FK_NX, FK_NZ, LAYOUT_AOS, false, true, (FK_FAST_SYM != 0), 0, false, false, false, true>), grid, block, 0, stream, a, a.F, a.Q, a.H, a.R, a.z, a.mask);
+        return check_launch("kf_fast_kernel (interleaved)");
+    }
+#endif
 #define FK_GO(LAY, MSK, OUT, MM)                                                                          \
     hipLaunchKernelGGL((kf_fast_kernel<FK_NX, FK_NZ, LAY, MSK, OUT, (FK_FAST_SYM != 0), MM, false, false>), grid, block, 0, \
                        stream, a, a.F, a.Q, a.H, a.R, a.z, a.mask)

@@ -144,45 +144,49 @@ ukf_linear_kernel(const UkfArgs a, const double *__restrict__ pF, const double *
     // vmcnt(0) behind the step's stores.
     const uint8_t *mk0 = (pmask ? pmask : reinterpret_cast<const uint8_t *>(pz)) + blk0;
     unsigned hc = __builtin_amdgcn_raw_buffer_load_b8(make_rsrc(mk0), ln.tid, 0, 0);
+    // z is carried from step to step: z[t+1] is requested at the end of step t IN FRONT of that step's stores (round 4).
+    // vmcnt retires in order: requested at the head of the update half (round 3), the load queued behind the 42 stores of
+    // the step before, and 1563 waves storing 21 KB each at the same moment take 5-7 us to drain -- the waves waited there
+    // for 41 % of their residency (profiles/r04/ukf_sq_counters.jsonl).  In front of the stores it is waited for with a
+    // counted vmcnt(#stores) a whole predict half later; the stores drain under the next step's arithmetic.  For the count
+    // to be a constant the stores of a step are unconditional: an output that was not asked for gets a descriptor of zero
+    // records (issued and dropped, RecView).
+    double zc[NZ];
+    load_rec<NZ, 1, LAYOUT, EXACT>(zc, pz, ln, m, 1, 0.0);
     // landed here (see above)
     FK_UNROLL for (int c = 0; c < NX; ++c) asm volatile("" ::"v"(x[c]));
     FK_UNROLL for (int e = 0; e < PL; ++e) asm volatile("" ::"v"(P[e]));
+    FK_UNROLL for (int c = 0; c < NZ; ++c) asm volatile("" ::"v"(zc[c]));
     asm volatile("" ::"v"(hc));
+    const bool st_m = a.means != nullptr, st_c = a.covs != nullptr;
 
     _Pragma("nounroll") for (long t = 0; t < a.T; ++t) {
         const bool has_z = pmask ? hc != 0u : true;
-        // step t+1's mask byte: requested now, landed after this step's arithmetic IN FRONT of its stores (a wait placed
-        // behind them would be a vmcnt(0) that drains them: their number depends on which outputs were asked for)
-        unsigned hn;
-        {
-            long tn = t + 1 < a.T ? t + 1 : t;
-            asm volatile("" : "+s"(tn));      // opaque: keeps the compiler from re-deriving this load one iteration later
-            hn = __builtin_amdgcn_raw_buffer_load_b8(make_rsrc(mk0 + tn * N), ln.tid, 0, 0);
-        }
-        auto load_z = [&](double (&z)[NZ]) { load_rec<NZ, 1, LAYOUT, EXACT>(z, pz + t * N * m, ln, m, 1, 0.0); };
+        auto load_z = [&](double (&z)[NZ]) { FK_UNROLL for (int c = 0; c < NZ; ++c) z[c] = zc[c]; };
 
         if constexpr (PAIRED) st |= ukf_linear_step_v4<NX, NZ>(x, P, load_z, has_z, a.scale, fresh);
         else st |= ukf_linear_step_v3<NX, NZ>(x, P, load_z, has_z, a.scale, fresh);
         FK_STAGE();
-        asm volatile("" : "+v"(hn));
-        hc = hn;
+        // step t+1's measurement and mask byte (clamped index, no branch), in front of this step's stores
+        {
+            long tn = t + 1 < a.T ? t + 1 : t;
+            asm volatile("" : "+s"(tn));      // opaque: keeps the compiler from re-deriving these loads one iteration later
+            hc = __builtin_amdgcn_raw_buffer_load_b8(make_rsrc(mk0 + tn * N), ln.tid, 0, 0);
+            load_rec<NZ, 1, LAYOUT, EXACT>(zc, pz + tn * N * m, ln, m, 1, 0.0);
+        }
         FK_STAGE();
         if constexpr (COOP) {
-            if (a.means) wave_store_aos_flat<NX>(x, a.means + t * N * NX + blk0 * NX, wave_row0, tile, lane, last_row);
-            if (a.covs) {
-                double Pf[NX * NX];
-                FK_UNROLL for (int i = 0; i < NX; ++i)
-                    FK_UNROLL for (int j = 0; j < NX; ++j) Pf[i * NX + j] = P[sym_idx<NX>(i, j)];
-                wave_store_aos_flat<NX * NX>(Pf, a.covs + t * N * (NX * NX) + blk0 * (NX * NX), wave_row0, tile, lane, last_row);
-            }
+            wave_store_aos_flat<NX>(x, a.means + t * N * NX + blk0 * NX, wave_row0, tile, lane, last_row, st_m);
+            double Pf[NX * NX];
+            FK_UNROLL for (int i = 0; i < NX; ++i)
+                FK_UNROLL for (int j = 0; j < NX; ++j) Pf[i * NX + j] = P[sym_idx<NX>(i, j)];
+            wave_store_aos_flat<NX * NX>(Pf, a.covs + t * N * (NX * NX) + blk0 * (NX * NX), wave_row0, tile, lane, last_row, st_c);
         } else {
-            if (a.means) store_rec<NX, 1, LAYOUT, EXACT>(x, a.means + t * N * n, ln, n, 1);
-            if (a.covs) {
-                double Pf[NX * NX];
-                FK_UNROLL for (int i = 0; i < NX; ++i)
-                    FK_UNROLL for (int j = 0; j < NX; ++j) Pf[i * NX + j] = P[sym_idx<NX>(i, j)];
-                store_rec<NX, NX, LAYOUT, EXACT>(Pf, a.covs + t * N * n * n, ln, n, n);
-            }
+            store_rec<NX, 1, LAYOUT, EXACT>(x, a.means + t * N * n, ln, n, 1, st_m);
+            double Pf[NX * NX];
+            FK_UNROLL for (int i = 0; i < NX; ++i)
+                FK_UNROLL for (int j = 0; j < NX; ++j) Pf[i * NX + j] = P[sym_idx<NX>(i, j)];
+            store_rec<NX, NX, LAYOUT, EXACT>(Pf, a.covs + t * N * n * n, ln, n, n, st_c);
         }
     }
     __syncthreads();
