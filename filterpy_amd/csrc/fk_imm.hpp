@@ -125,9 +125,10 @@ FK_HD int imm_update(double (&xs)[NM][NX], double (&Ps)[NM][NX * (NX + 1) / 2], 
     // S_j -- what a later update(None) turns into that filter's likelihood (kalman_filter.py:511-520, :1203-1226)
     int st = 0;
     const double log2pi_m = m * 1.8378770664093453;
-    // (2 pi)^(-m/2), m = 0..4
+    // (2 pi)^(-m/2), m = 1..8
     const double cm = m == 1 ? 0.3989422804014327 : m == 2 ? 0.15915494309189535 : m == 3 ? 0.06349363593424097
-                    : m == 4 ? 0.025330295910584444 : 1.0;
+                    : m == 4 ? 0.025330295910584444 : m == 5 ? 0.010105326013811644 : m == 6 ? 0.004031441804149937
+                    : m == 7 ? 0.0016083125866532416 : m == 8 ? 0.000641623890917771 : 1.0;
     FK_UNROLL for (int j = 0; j < NM; ++j) {
         double K[NX * NZ], y[NZ], S[NZ * NZ], Lf[NZ * NZ], dinv[NZ];
         st |= kf_update_sym<NX, NZ, true>(xs[j], Ps[j], z, mods[j], K, y, S, Lf, dinv);

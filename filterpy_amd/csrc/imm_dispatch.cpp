@@ -36,8 +36,8 @@ extern "C" int fk_imm_batch_ex_f64(const fk_imm_desc *d, const double *F, const 
                                        int32_t *status, void *stream)
 {
     if (!d) return fail(FK_ERR_BAD_ARG, "desc is NULL");
-    if (d->n < 1 || d->n > 9 || d->m < 1 || d->m > 4 || d->n_models < 2 || d->n_models > 8)
-        return fail(FK_ERR_UNSUPPORTED, "IMM: dim_x 1..9, dim_z 1..4, 2..8 models");
+    if (d->n < 1 || d->n > 16 || d->m < 1 || d->m > 8 || d->n_models < 2 || d->n_models > 8)
+        return fail(FK_ERR_UNSUPPORTED, "IMM: dim_x 1..16, dim_z 1..8, 2..8 models");
     if (d->layout != FK_LAYOUT_AOS && d->layout != FK_LAYOUT_SOA) return fail(FK_ERR_BAD_ARG, "IMM: bad layout");
     if (d->phase < FK_IMM_STEP || d->phase > FK_IMM_UPDATE) return fail(FK_ERR_BAD_ARG, "IMM: bad phase");
     const bool needs_z = (d->phase == FK_IMM_STEP && d->T > 0) || d->phase == FK_IMM_UPDATE;
@@ -68,7 +68,7 @@ extern "C" int fk_imm_batch_ex_f64(const fk_imm_desc *d, const double *F, const 
     a.i0 = 0; a.cnt = d->N; a.status_or = 0;
     const int layout = d->layout, n_models = d->n_models;
     // register-resident instantiations for the small banks (2 / 3 filters, dim_x <= 6, dim_z <= 3); everything else -- up to
-    // eight filters, dim_x <= 9, dim_z <= 4 -- on the rolled (9, 4) class of its bank size (fk_dims_imm.def)
+    // eight filters, dim_x <= 16, dim_z <= 8 -- on the rolled (9, 4) / (16, 8) class of its bank size (fk_dims_imm.def)
     const bool small = d->n <= 6 && d->m <= 3 && n_models <= 3;
     const int cls = (d->n <= 2 && d->m <= 1) ? 0 : (d->n <= 4 && d->m <= 2) ? 1 : 2;
     auto one = [&](const ImmArgs &b, hipStream_t s) -> int {
@@ -81,6 +81,16 @@ extern "C" int fk_imm_batch_ex_f64(const fk_imm_desc *d, const double *F, const 
                 if (cls == 0) launch_imm_2_1_3(b, layout, mask, s);
                 else if (cls == 1) launch_imm_4_2_3(b, layout, mask, s);
                 else launch_imm_6_3_3(b, layout, mask, s);
+            }
+        } else if (b.n > 9 || b.m > 4) {                  // the rolled class (16, 8), round 4
+            switch (n_models) {
+            case 2: launch_imm_16_8_2(b, layout, mask, s); break;
+            case 3: launch_imm_16_8_3(b, layout, mask, s); break;
+            case 4: launch_imm_16_8_4(b, layout, mask, s); break;
+            case 5: launch_imm_16_8_5(b, layout, mask, s); break;
+            case 6: launch_imm_16_8_6(b, layout, mask, s); break;
+            case 7: launch_imm_16_8_7(b, layout, mask, s); break;
+            default: launch_imm_16_8_8(b, layout, mask, s); break;
             }
         } else {
             switch (n_models) {

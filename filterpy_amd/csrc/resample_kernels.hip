@@ -560,11 +560,11 @@ gather_mean_kernel(long Np, const double *__restrict__ particles, const int32_t 
 // The same for 32-byte records (d = 4, 16-byte aligned: BASELINE configs[4]'s harness), round 4.  The indices a resampler
 // returns are non-decreasing, so a workgroup's slice of them points into ONE short contiguous range of particles and the
 // gather is a stream -- what the first kernel lacked was memory-level parallelism: one dependent (index -> record) pair in
-// flight per lane and four 8-byte loads per record (8.0 ms for 36 GB at 125 x 8e6 = 0.56 of HBM).  Here every lane has GM_U
+// flight per lane and four 8-byte loads per record (8.0 ms for 36 GB at 125 x 8e6 = 0.56 of HBM; this one: 5.8 ms = 0.78).  Here every lane has GM_U
 // independent index loads in flight, then 2 GM_U independent 16-byte record loads; a wave's 64 lanes take 64 consecutive
 // indices per load, i.e. (with duplicates) one or two KiB of consecutive records.
-constexpr int GM_U = 8;
-constexpr int GM_CHUNK4 = RS_THREADS * GM_U * 8;
+constexpr int GM_CHUNK4 = 16384;
+template <int GM_U>
 __global__ void __launch_bounds__(RS_THREADS)
 gather_mean4_kernel(long Np, const double *__restrict__ particles, const int32_t *__restrict__ idx, double *__restrict__ mean, long f0)
 {
@@ -759,7 +759,11 @@ int fk_resample_gather_mean_f64(int64_t Fn, int64_t Np, int32_t d, const double 
         const dim3 block(RS_THREADS);
         if (wide) {
             const dim3 grid((unsigned)((Np + GM_CHUNK4 - 1) / GM_CHUNK4), (unsigned)fc);
-            hipLaunchKernelGGL(gather_mean4_kernel, grid, block, 0, s, (long)Np, particles, idx, mean, f0);
+            // sixteen independent index / record pairs per lane in flight (FK_GATHER_MEAN_U=8: eight -- 5.95 against 5.79 ms at
+            // 125 x 8e6, profiles/r04/gather_mean.txt)
+            const char *uv = getenv("FK_GATHER_MEAN_U");
+            if (uv && atoi(uv) == 8) hipLaunchKernelGGL((gather_mean4_kernel<8>), grid, block, 0, s, (long)Np, particles, idx, mean, f0);
+            else hipLaunchKernelGGL((gather_mean4_kernel<16>), grid, block, 0, s, (long)Np, particles, idx, mean, f0);
             continue;
         }
         const dim3 grid((unsigned)((Np + GM_CHUNK - 1) / GM_CHUNK), (unsigned)fc);

@@ -82,8 +82,8 @@ class IMMEstimator(object):
             raise ValueError("per-track filter states must be shaped (n_tracks, dim_x)")
         self._m = np.atleast_2d(np.asarray(filters[0].H, dtype=np.float64)).shape[0]
         n, m = self._n, self._m
-        if n > 9 or m > 4:
-            raise NotImplementedError("the IMM kernel is built for dim_x <= 9 and dim_z <= 4")
+        if n > 16 or m > 8:
+            raise NotImplementedError("the IMM kernel is built for dim_x <= 16 and dim_z <= 8")
 
         # log-density of a zero residual under each filter's last real update's S (-inf before any: with S = 0 the
         # reference's density is 0, floored at float_info.min) -- what update(None) turns into the filter's likelihood;

@@ -62,11 +62,12 @@ def _seq(v, n):
 
 class _Core:
     """Shared device plumbing for one bank of N filters (N = 1 for KalmanFilter)."""
+    last_placement = None     # how the last batch() call with device outputs placed its covariance histories
 
     @staticmethod
     def batch(n, m, N, T, x0, P0, z, mask, F, Q, H, R, mode, B=None, us=None, nu=0,
               alpha_sq=1.0, update_first=False, layout="soa", want_outputs=True, device_outputs=False,
-              extras=(), cov_interleave=True):
+              extras=(), cov_interleave=True, placement=None):
         """All inputs are host arrays shaped for `mode`:
         x0 (N,n) P0 (N,n,n) z (T,N,m) mask (T,N) or None;
         models: SHARED (a,b) | PER_TRACK (N,a,b) | PER_STEP (T,a,b) | PER_TRACK_STEP (T,N,a,b).
@@ -95,8 +96,34 @@ class _Core:
         # interfere (docs/PLACEMENT.md).  The caller gets strided views.  Where the specialised kernel does not serve the
         # call (FK_ERR_UNSUPPORTED) two plain arrays are used.
         inter = bool(want_outputs and device_outputs and not extras and cov_interleave and n <= 9
-                     and 2 * N * n * n * 8 < 2 ** 32)
-        if want_outputs:
+                     and 2 * N * n * n * 8 < 2 ** 32 and placement != "probe")
+        _Core.last_placement = {"method": "interleave" if inter else "none"}
+        if want_outputs and device_outputs and not extras and placement == "probe" and T * N * n * n * 8 >= (256 << 20):
+            # two dense arrays, placed in HBM by measuring this very launch on several candidate buffers (placement.py:
+            # placed_pair; the pair is remembered per shape, the losers are freed).  Worth ~7 % over the interleaved array
+            # at BASELINE configs[1] (5.2 against 5.6 ms), costs about a second once per shape.
+            from .. import placement as _pl
+            dx0, dP0 = dx.clone(), dP.clone()
+            shp = (T, N, n * n) if layout == "aos" else (T, n * n, N)
+            as_rec = lambda b: b.view(torch.float64).view(shp)          # noqa: E731
+            mu, mup = E.alloc_records((T,), N, n, layout), E.alloc_records((T,), N, n, layout)
+
+            def run_ms(a, b):
+                dx.copy_(dx0)
+                dP.copy_(dP0)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                E.kf_batch_filter(desc, model(F), model(Q), model(H), model(R), dz, dx, dP, B=model(B), u=du, mask=dmask,
+                                  means=mu, covs=as_rec(a), means_p=mup, covs_p=as_rec(b), status=st)
+                e1.record()
+                torch.cuda.synchronize()
+                return e0.elapsed_time(e1)
+            pa, pb, _Core.last_placement = _pl.placed_pair(T * N * n * n * 8, run_ms, dx.device)
+            dx.copy_(dx0)
+            dP.copy_(dP0)
+            st.zero_()
+            outs = [mu, as_rec(pa), mup, as_rec(pb)]
+        elif want_outputs:
             if inter:
                 _, cpost, cprior = E.alloc_cov_pair(T, N, n, layout)
                 outs = [E.alloc_records((T,), N, n, layout), cpost, E.alloc_records((T,), N, n, layout), cprior]
@@ -830,11 +857,14 @@ class KalmanFilterBank(object):
             self.dim_x, self.dim_z, self.n_tracks, x, P, z, mods["H"], mods["R"], mode, mask=mask, layout=self.layout)
 
     def batch_filter(self, zs, mask=None, update_first=False, store=True, device_outputs=False, extras=(),
-                     cov_interleave=True):
+                     cov_interleave=True, placement=None):
         """zs (T, N, dim_z) NumPy array or a device tensor already in self.layout.
         device_outputs=True: the four histories come back as device tensors in self.layout; the two covariance histories
         are then strided VIEWS of one array in which a track's posterior and prior record sit side by side (one write
         front: docs/PLACEMENT.md) -- `.contiguous()` gives a dense copy, cov_interleave=False two dense arrays.
+        placement="probe" (device outputs of 256 MiB and more): two dense arrays placed in HBM by timing this very launch
+        on candidate buffers (filterpy_amd/placement.py: about a second once per shape, the pair is remembered and reused while
+        no earlier result is alive; `self.placement_info` says what happened) -- the fastest arrangement measured.
         extras: any of 'y', 'K', 'S', 'SI', 'log_likelihood', 'mahalanobis' -> also returns a dict of the
         per-step histories (T, N, ...) as a fifth element (what filterpy.common.Saver would record)."""
         import torch
@@ -855,7 +885,8 @@ class KalmanFilterBank(object):
         out = _Core.batch(self.dim_x, self.dim_z, self.n_tracks, T, x, P, z, mask, mods["F"], mods["Q"],
                           mods["H"], mods["R"], mode, alpha_sq=self._alpha_sq, update_first=update_first,
                           layout=self.layout, want_outputs=store, device_outputs=device_outputs, extras=tuple(extras),
-                          cov_interleave=cov_interleave)
+                          cov_interleave=cov_interleave, placement=placement)
+        self.placement_info = _Core.last_placement
         if device_outputs:
             self.x = E.from_records(out[4], self.layout, 0, (self.dim_x,))
             self.P = E.from_records(out[5], self.layout, 0, (self.dim_x, self.dim_x))

@@ -56,3 +56,66 @@ def place_pair(nbytes, run_ms, device, arena_bytes=None, step=16 << 30, reserve=
             "worst_ms": round(vals[-1], 4),
             "grid_ms": {f"{a >> 30},{b >> 30}": round(v, 3) for (a, b), v in grid.items()}}
     return view(oa), view(ob), info
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# The product-side form (round 4): no arena.  `placed_pair` allocates up to `max_chunks` SEPARATE buffers of the history's size,
+# times the caller's own kernel on every pair of them, keeps the fastest pair and FREES the rest -- steady-state memory is the
+# two histories and nothing else -- and remembers the pair per (device, size): a later call of the same shape gets the same
+# two buffers back without a probe, provided nothing derived from them is still alive (storage use count), else two plain
+# buffers.  KalmanFilterBank.batch_filter(device_outputs=True, placement="probe") and bench.py --placement probe both come
+# through here.
+_PAIRS = {}
+
+
+def _use_count(t):
+    return torch._C._storage_Use_Count(t.untyped_storage()._cdata)
+
+
+def placed_pair(nbytes, run_ms, device, max_chunks=11, reserve=24 << 30, reps=2):
+    """Two uint8 tensors of `nbytes` for the two concurrently written history arrays of a kernel, chosen by measurement.
+
+    run_ms(a, b): the caller's kernel with its two big outputs in the byte tensors a, b -> milliseconds.  Returns (a, b, info);
+    info["method"]: "probe" (just measured), "cached" (the pair of an earlier call, free again), "plain allocation (...)"."""
+    dev = torch.device(device)
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), int(nbytes))
+    ent = _PAIRS.get(key)
+    if ent is not None:
+        a, b, base, info = ent
+        if _use_count(a) == base[0] and _use_count(b) == base[1]:
+            return a, b, dict(info, method="cached")
+        return (torch.empty(nbytes, dtype=torch.uint8, device=dev), torch.empty(nbytes, dtype=torch.uint8, device=dev),
+                {"method": "plain allocation (the placed pair of this shape is still in use)"})
+    free, _ = torch.cuda.mem_get_info(dev)
+    k = int(min(max_chunks, max(0, free - reserve) // max(1, nbytes)))
+    if k < 3:
+        return (torch.empty(nbytes, dtype=torch.uint8, device=dev), torch.empty(nbytes, dtype=torch.uint8, device=dev),
+                {"method": "plain allocation (no room to probe)", "free_GiB": free >> 30})
+    chunks = [torch.empty(nbytes, dtype=torch.uint8, device=dev) for _ in range(k)]
+
+    def timed(i, j):
+        best = None
+        for r in range(reps + 1):
+            ms = run_ms(chunks[i], chunks[j])
+            if r and (best is None or ms < best):
+                best = ms
+        return best
+
+    grid = {(i, j): timed(i, j) for i in range(k) for j in range(i + 1, k)}
+    (i, j), best = min(grid.items(), key=lambda kv: kv[1])
+    vals = sorted(grid.values())
+    a, b = chunks[i], chunks[j]
+    del chunks
+    torch.cuda.empty_cache()                                # the other k - 2 buffers go back to the driver
+    info = {"method": "probe", "buffers_tried": k, "pairs": len(grid), "chosen": [i, j], "chosen_ms": round(best, 4),
+            "median_ms": round(vals[len(vals) // 2], 4), "worst_ms": round(vals[-1], 4), "first_pair_ms": round(grid[(0, 1)], 4),
+            "grid_ms": {f"{p},{q}": round(v, 3) for (p, q), v in grid.items()}}
+    _PAIRS[key] = (a, b, (_use_count(a), _use_count(b)), info)
+    return a, b, info
+
+
+def forget_placed_pairs():
+    """drop the remembered pairs (their memory is freed once the caller's own references are gone)"""
+    _PAIRS.clear()
+    if torch.cuda.is_available():
+        torch.cuda.empty_cache()

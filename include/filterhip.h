@@ -290,7 +290,7 @@ int fk_ukf_linear_rts_f64(const fk_ukf_desc *desc, const double *F, const double
 /* KalmanFilter.predict_steadystate (filterpy/kalman/kalman_filter.py:563-593) and
  * update_steadystate (:595-668) for N tracks: only x moves, the gain K is fixed.
  * T x { x = F x (+ B u) ; means_p[t] = x ; y = z - H x ; x += K y ; means[t] = x }.
- *   desc: n (1..9), m (1..4), nu (0..4), N, T, layout; model_mode FK_MODEL_SHARED: K [n*m] shared,
+ *   desc: n (1..16), m (1..8), nu (0..4), N, T, layout; model_mode FK_MODEL_SHARED: K [n*m] shared,
  *   FK_MODEL_PER_TRACK: K [N][n*m] records (every track its own converged gain).
  *   F [n*n], H [m*n], B [n*nu]: shared.  F == NULL: no predict (update_steadystate alone);
  *   z == NULL: no update (predict_steadystate alone).  u [T][N][nu], z [T][N][m], mask [T][N] or NULL
@@ -306,7 +306,7 @@ int fk_kf_steadystate_f64(const fk_kf_desc *desc,
 /* KalmanFilter.update_correlated (kalman_filter.py:670-752): process and measurement noise correlated
  * through M (dim_x x dim_z):  y = z - H x ; S = H P H' + H M + M' H' + R ; K = (P H' + M) S^-1 ;
  * x += K y ; P -= K (H P + M').   One update of N tracks.
- *   desc: n (1..9), m (1..4), N, layout; model_mode FK_MODEL_SHARED: M [n*m] shared,
+ *   desc: n (1..16), m (1..8), N, layout; model_mode FK_MODEL_SHARED: M [n*m] shared,
  *   FK_MODEL_PER_TRACK: M [N][n*m].  H [m*n], R [m*m]: shared.  z [N][m], mask [N] or NULL.
  *   x [N][n], P [N][n*n] in/out; y [N][m], K [N][n*m], S, SI [N][m*m]: optional outputs; status [N] or NULL. */
 int fk_kf_update_correlated_f64(const fk_kf_desc *desc,
@@ -336,8 +336,8 @@ int fk_ukf_rts_correct_f64(int32_t n, int64_t N, int32_t layout,
 /* ------------------------------------------------------------------ */
 
 typedef struct fk_imm_desc {
-    int32_t n, m;         /* dim_x (1..6), dim_z (1..3): the same for every filter of the bank */
-    int32_t n_models;     /* filters per track: 2 .. 8 (dim_x 1..9, dim_z 1..4) */
+    int32_t n, m;         /* dim_x (1..16), dim_z (1..8): the same for every filter of the bank */
+    int32_t n_models;     /* filters per track: 2 .. 8 */
     int32_t layout;
     int64_t N, T;
     int32_t phase;        /* FK_IMM_STEP: T x {predict; update}; FK_IMM_PREDICT / FK_IMM_UPDATE: that half once */

@@ -953,3 +953,47 @@ def test_bank_device_outputs_are_views_of_one_array_and_equal_the_host_outputs(n
     assert two[1].is_contiguous() and two[1].untyped_storage().data_ptr() != two[3].untyped_storage().data_ptr()
     for a, c in zip(dev, two):
         assert np.array_equal(a.cpu().numpy(), c.cpu().numpy())
+
+
+def test_bank_placement_probe_places_by_measurement_and_remembers_the_pair():
+    """KalmanFilterBank.batch_filter(device_outputs=True, placement="probe") (filterpy_amd/placement.py: placed_pair): the two
+    covariance histories are two dense arrays chosen by timing this very launch on candidate buffers; the pair is remembered
+    per shape and handed out again only when nothing derived from it is alive.  Results equal the default call bit for bit."""
+    import gc
+    import torch
+    from filterpy_amd import placement
+    from filterpy_amd.kalman import KalmanFilterBank
+    placement.forget_placed_pairs()
+    n, m, N, T = 4, 2, 200_000, 12                       # 307 MB per covariance history
+    rs = np.random.RandomState(3)
+    zs = torch.as_tensor(rs.randn(T, N, m), device="cuda")
+
+    def bank():
+        b = KalmanFilterBank(n, m, N, layout="aos")
+        b.F = np.eye(n) + 0.05 * np.triu(np.ones((n, n)), 1)
+        b.Q, b.R, b.H = 0.02 * np.eye(n), 0.5 * np.eye(m), np.eye(m, n)
+        b.x, b.P = np.zeros((N, n)), np.tile(3.0 * np.eye(n), (N, 1, 1))
+        return b
+    ref = [t.clone() for t in bank().batch_filter(zs, device_outputs=True)]
+    b1 = bank()
+    out1 = b1.batch_filter(zs, device_outputs=True, placement="probe")
+    assert b1.placement_info["method"] == "probe" and b1.placement_info["pairs"] >= 3, b1.placement_info
+    assert out1[1].is_contiguous() and out1[3].is_contiguous()
+    for a, c in zip(ref, out1):
+        assert torch.equal(a, c)
+    b2 = bank()
+    out2 = b2.batch_filter(zs, device_outputs=True, placement="probe")      # out1 still alive: the pair is taken
+    assert b2.placement_info["method"].startswith("plain allocation"), b2.placement_info
+    assert out2[1].data_ptr() != out1[1].data_ptr()
+    for a, c in zip(ref, out2):
+        assert torch.equal(a, c)
+    p1 = out1[1].data_ptr()
+    del out1, out2
+    gc.collect()
+    b3 = bank()
+    out3 = b3.batch_filter(zs, device_outputs=True, placement="probe")
+    assert b3.placement_info["method"] == "cached" and out3[1].data_ptr() == p1, b3.placement_info
+    for a, c in zip(ref, out3):
+        assert torch.equal(a, c)
+    del out3
+    placement.forget_placed_pairs()

