@@ -175,17 +175,19 @@ int rts_chunked_call(const Args &a, int n, long slots, One &&one, hipStream_t s)
 {
     int G, H;
     const long steps = a.T - 1;                                   // backward steps T-2 .. 0
-    if (!ml_chunk_policy((a.N + 15) / 16, steps, G, H, slots) || a.N < 64L * G) return one(a, s);
+    // (the call may itself be a track window of a larger bank: cnt != 0 -- kf_dispatch.cpp; N stays the array stride)
+    const long w0 = a.cnt ? a.i0 : 0, wn = a.cnt ? a.cnt : a.N;
+    if (!ml_chunk_policy((wn + 15) / 16, steps, G, H, slots) || wn < 64L * G) return one(a, s);
     MlStreams *msp = ml_streams();
     if (!msp) return one(a, s);
     MlStreams &ms = *msp;
     std::lock_guard<std::mutex> lock(ms.mu);
     if (hipEventRecord(ms.fork, s) != hipSuccess) return one(a, s);
-    const long blocks = (a.N + 63) / 64, per = (blocks + G - 1) / G * 64, nn = (long)n * n;
+    const long blocks = (wn + 63) / 64, per = (blocks + G - 1) / G * 64, nn = (long)n * n;
     int rc = 0;
     bool forked[MlStreams::MAXG] = {};
     for (int g = 0; g < G && rc == 0; ++g) {
-        const long g0 = (long)g * per, gcnt = (g0 + per <= a.N) ? per : (a.N - g0);
+        const long g0 = w0 + (long)g * per, gcnt = (g0 + per <= w0 + wn) ? per : (w0 + wn - g0);
         if (gcnt <= 0) break;
         hipStream_t sg = g == 0 ? s : ms.st[g];
         if (g > 0) {

@@ -65,10 +65,11 @@ rts_kernel(const RtsArgs a, const double *__restrict__ pF, const double *__restr
     const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
 
     const long N = a.N, T = a.T;
+    const long cnt = a.cnt ? a.cnt : N;        // a track window of a larger bank (kf_dispatch.cpp: N stays the array stride)
     const long blk0 = (long)blockIdx.x * BLOCK;
-    const unsigned last_row = (unsigned)(N - blk0 < BLOCK ? N - blk0 : BLOCK) - 1u;
+    const unsigned last_row = (unsigned)(cnt - blk0 < BLOCK ? cnt - blk0 : BLOCK) - 1u;
     const Lane ln{blk0, COOP ? min(threadIdx.x, last_row) : threadIdx.x, N};
-    const bool live = COOP || blk0 + ln.tid < N;
+    const bool live = COOP || blk0 + ln.tid < cnt;
     const Lane lr{blk0, live ? ln.tid : 0u, N};
     // one record array of the step: x-like (LEN = NX) or covariance-like (LEN = NX * NX)
     auto put_x = [&](const double (&v)[NX], double *dst, long k) {
@@ -159,7 +160,7 @@ rts_kernel(const RtsArgs a, const double *__restrict__ pF, const double *__restr
 template <int NX, bool EXACT>
 static int launch(const RtsArgs &a, int layout, bool uniform, hipStream_t stream)
 {
-    const dim3 grid((unsigned)((a.N + BLOCK - 1) / BLOCK)), block(BLOCK);
+    const dim3 grid((unsigned)(((a.cnt ? a.cnt : a.N) + BLOCK - 1) / BLOCK)), block(BLOCK);
 #define FK_GO(LAY, UNI) \
     hipLaunchKernelGGL((rts_kernel<NX, EXACT, LAY, UNI>), grid, block, 0, stream, a, a.F, a.Q, a.Xs, a.Ps)
     if (layout == LAYOUT_SOA) {

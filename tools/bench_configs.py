@@ -446,5 +446,12 @@ if __name__ == "__main__":
             config_imm(lay, 4, 2, 3, 300_000, a.T)
             config_imm(lay, 6, 3, 2, 200_000, a.T)
             config_imm(lay, 2, 1, 2, 1_000_000, a.T)
+        if "r" in a.configs:      # the rolled IMM classes (banks in scratch memory): (9,4) x {2, 4, 8}, (16,8) x 2 -- VERDICT r3 next 8
+            config_imm(lay, 9, 4, 2, 100_000, 20)
+            config_imm(lay, 9, 3, 4, 100_000, 20)
+            config_imm(lay, 9, 4, 8, 50_000, 20)
+            config_imm(lay, 16, 8, 2, 50_000, 20)
+        if "s" in a.configs:      # steady-state / IMM above (9,4) (round 4's padded classes)
+            config_steady(lay, 16, 8, 500_000, a.T)
     if "5" in a.configs:
         config5()
