@@ -81,11 +81,25 @@ imm_kernel(const ImmArgs a)
         FK_UNROLL for (int j = 0; j < NM; ++j) ll0[j] = vl.load(j);
     }
 
+    // z is carried from step to step (round 4): z[t+1] is requested at the TOP of step t, in front of that step's stores.
+    // vmcnt retires in order: a load issued at the top of step t+1 queues behind every store of step t and the wave sits
+    // there until they have drained -- once per step (the fused UKF lost 40 % of its wave time to exactly this wait).
+    // Requested a step ahead, it is waited for with vmcnt(#stores of the step) in the instantiations whose outputs are
+    // compile-time (the general kernel's stores are conditional: its wait stays conservative).
+    double zc[NZ];
+    {
+        const RecView<LAYOUT> vz(a.z, ln, m);
+        FK_UNROLL for (int r = 0; r < NZ; ++r) zc[r] = (r < m) ? vz.load(r) : 0.0;
+        FK_UNROLL for (int r = 0; r < NZ; ++r) asm volatile("" ::"v"(zc[r]));       // landed before the loop
+    }
     for (long t = 0; t < a.T; ++t) {
         double z[NZ];
+        FK_UNROLL for (int r = 0; r < NZ; ++r) z[r] = zc[r];
         {
-            const RecView<LAYOUT> vz(a.z + t * N * m, ln, m);
-            FK_UNROLL for (int r = 0; r < NZ; ++r) z[r] = (r < m) ? vz.load(r) : 0.0;
+            long tn = t + 1 < a.T ? t + 1 : t;
+            asm volatile("" : "+s"(tn));      // opaque: keeps the compiler from re-deriving this load one iteration later
+            const RecView<LAYOUT> vz(a.z + tn * N * m, ln, m);
+            FK_UNROLL for (int r = 0; r < NZ; ++r) zc[r] = (r < m) ? vz.load(r) : 0.0;
         }
         constexpr bool GENERAL = !(EXACT && OUTS >= 0);     // only the general kernel carries MMAE
         const bool mmae = GENERAL && a.mmae;

@@ -168,6 +168,10 @@ static long kf_window_tracks(const fk_kf_desc *d)
 {
     const long E = (long)d->n * (d->n > d->m ? d->n : d->m);
     long w = (long)(4294967295.0 / ((double)E * 8.0));
+    if (const char *wv = getenv("FK_KF_WINDOW")) {              // tests: force the windowing on a small bank
+        const long f = atol(wv);
+        if (f > 0 && f < w) w = f;
+    }
     w = w / 256 * 256;
     return w < 256 ? 256 : w;
 }
