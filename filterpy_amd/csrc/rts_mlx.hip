@@ -78,8 +78,10 @@ rts_mlx_kernel(const RtsArgs a)
     const long N = a.N, T = a.T;
     const unsigned lane = threadIdx.x & 63u;
     const unsigned L = lane % LPT;                              // lane within its track's group
-    long trk = (long)blockIdx.x * (BLOCK / LPT) + (threadIdx.x / LPT);
-    if (trk >= N) trk = N - 1;                                  // tail groups recompute the last track
+    // (a.cnt != 0: this launch is a track window [a.i0, a.i0 + a.cnt) of a larger bank, N stays the array stride)
+    const long i0 = a.cnt ? a.i0 : 0, iend = a.cnt ? a.i0 + a.cnt : N;
+    long trk = i0 + (long)blockIdx.x * (BLOCK / LPT) + (threadIdx.x / LPT);
+    if (trk >= iend) trk = iend - 1;                            // tail groups recompute the last track
     unsigned estride = AOS ? 8u : (unsigned)N * 8u;
     asm volatile("" : "+s"(estride));
     const unsigned t8 = (unsigned)trk * (AOS ? (unsigned)NX * 8u : 8u);
@@ -89,8 +91,8 @@ rts_mlx_kernel(const RtsArgs a)
         row[r] = g < (unsigned)NX ? g : (unsigned)NX - 1u;
         off_row[r] = (AOS ? (unsigned)trk * (unsigned)(NX * NX) * 8u : (unsigned)trk * 8u) + row[r] * (unsigned)NX * estride;
     }
-    const long w0 = (long)blockIdx.x * (BLOCK / LPT) + (long)(threadIdx.x >> 6) * TPW;
-    const unsigned valid = (unsigned)(N - w0 >= TPW ? TPW : (N - w0 > 0 ? N - w0 : 0));
+    const long w0 = i0 + (long)blockIdx.x * (BLOCK / LPT) + (long)(threadIdx.x >> 6) * TPW;
+    const unsigned valid = (unsigned)(iend - w0 >= TPW ? TPW : (iend - w0 > 0 ? iend - w0 : 0));
     const long xs_blk = N * NX, ps_blk = N * (long)NX * NX;
     // element e (= slot * NX + col) of this lane in a park: [e * 64 + lane]; of the lane that owns row q: group base + q / R
     double *mineA = parkA + lane, *mineB = parkB + lane;
@@ -299,7 +301,7 @@ int FK_RMLX_CAT(launch_rts_mlx_, FK_NX)(const RtsArgs &a, int layout, bool unifo
 {
     using namespace FK_RMLX_CAT(rmlx_, FK_NX);
     if (!uniform || a.model_t || a.n != FK_NX || !a.K || !a.Pp || a.T < 2) return 1;
-    const dim3 grid((unsigned)((a.N + BLOCK / LPT - 1) / (BLOCK / LPT))), block(BLOCK);
+    const dim3 grid((unsigned)(((a.cnt ? a.cnt : a.N) + BLOCK / LPT - 1) / (BLOCK / LPT))), block(BLOCK);
     if (layout == FK_LAYOUT_AOS) hipLaunchKernelGGL((rts_mlx_kernel<FK_NX, LAYOUT_AOS>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((rts_mlx_kernel<FK_NX, LAYOUT_SOA>), grid, block, 0, s, a);
     return check_launch("rts_mlx_kernel");

@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define FK_ABI_VERSION 2
+#define FK_ABI_VERSION 3
 
 enum {
     FK_OK = 0,

@@ -27,7 +27,7 @@ def test_library_exports_exactly_the_header():
     out = subprocess.check_output(["nm", "-D", "--defined-only", _abi.LIB_PATH], text=True)
     exported = sorted(set(re.findall(r" T (fk_[a-z0-9_]+)", out)))
     assert exported == declared, set(exported) ^ set(declared)
-    assert lib.fk_abi_version() == 2 and lib.fk_build_arch() == b"gfx950"
+    assert lib.fk_abi_version() == 3 and lib.fk_build_arch() == b"gfx950"
 
 
 def test_argument_errors_without_gpu():
