@@ -114,7 +114,6 @@ def test_track_windows_are_bit_identical_to_one_call(n, m, monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.skipif(not os.environ.get("FK_TEST_BIG_BANK"), reason="60 GB of HBM and offsets past 2 GiB: run on its own with FK_TEST_BIG_BANK=1")
 def test_banks_past_the_4_gib_record_block_are_split_into_track_windows():
     """VERDICT r3 missing 3: N * dim_x^2 * 8 >= 4 GiB per step used to be refused ("split the batch").  In NumPy order
     fk_kf_batch_filter_f64 and fk_kf_rts_f64 now cut such a bank into track windows themselves (kf_dispatch.cpp: kf_window):

@@ -281,7 +281,7 @@ def test_imm_rejects_what_the_kernel_cannot_do():
     with pytest.raises(NotImplementedError):
         IMMEstimator([KalmanFilter(dim_x=2, dim_z=1) for _ in range(9)], [1] * 9, np.full((9, 9), 1 / 9))
     with pytest.raises(NotImplementedError):
-        IMMEstimator([KalmanFilter(dim_x=10, dim_z=1) for _ in range(2)], [.5, .5], np.full((2, 2), .5))
+        IMMEstimator([KalmanFilter(dim_x=17, dim_z=1) for _ in range(2)], [.5, .5], np.full((2, 2), .5))
 
 
 # ---- round 3: banks of up to eight filters, dim_x <= 9, dim_z <= 4 (the rolled (9, 4) class of every bank size) ----------
