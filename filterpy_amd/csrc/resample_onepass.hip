@@ -258,13 +258,6 @@ __device__ double lookback_exact(const OpDesc *d, int k, bool clean, int eu, int
 #ifndef FK_OP_GUESS_LO
 #define FK_OP_GUESS_LO 0.96    // the guess g is the binade of this fraction of k times the chunk's own sum
 #endif
-// W (round 4): hand-off words of W windows of 64 predecessors are requested TOGETHER and consumed window by window.  With one
-// window per iteration the walk back to the nearest carry-out is a chain of dependent L2 round trips, one per 64 chunks; with
-// many filters that never shows (a carry-out is always near), but ONE long vector is resolved binade segment by binade segment
-// -- ~12 segments of up to ~1900 chunks for 8e6 weights, each waiting for the carry-out of the segment before it -- and the
-// last chunk of a segment walks all of it: 271 us for 1 x 8e6 where the chunks' own work is ~30 us (profiles/r04/c5/
-// onepass_phase_clocks.jsonl: 157 k of 203 k clocks per workgroup in this wait).  W = 4 for calls with few filters.
-template <int W>
 __device__ double lookback_spec(const OpDesc *d, int k, int g, double I0, double I1, bool v0, bool v1, int lane, int &which)
 {
     which = -1;
@@ -272,60 +265,49 @@ __device__ double lookback_spec(const OpDesc *d, int k, int g, double I0, double
     bool ok0 = v0, ok1 = v1;
     const int g9 = g & 511, h9 = (g + 1) & 511;
     unsigned polls = 0;
-    for (int jb = k - 1; jb >= 0; jb -= 64 * W) {
-        u64 we1[W], we2[W], wrw[W];
-        FK_UNROLL for (int s = 0; s < W; ++s) {
-            const int jj = jb - 64 * s - lane;
-            we1[s] = jj >= 0 ? ld_agent(&d[jj].exact) : (u64)3;           // before the vector: a carry-out nobody can use
-            we2[s] = jj >= 0 ? ld_agent(&d[jj].exact2) : (u64)0;
-            wrw[s] = jj >= 0 ? ld_agent(&d[jj].raw) : (u64)0;
+    for (int j = k - 1; j >= 0; j -= 64) {
+        const int jj = j - lane;
+        u64 e1, e2, rw, term;
+        for (;;) {
+            e1 = jj >= 0 ? ld_agent(&d[jj].exact) : (u64)3;               // before the vector: a carry-out nobody can use
+            e2 = jj >= 0 ? ld_agent(&d[jj].exact2) : (u64)0;
+            rw = jj >= 0 ? ld_agent(&d[jj].raw) : (u64)0;
+            term = __ballot((e1 & ST_MASK) >= 2);
+            const u64 unpub = __ballot((e1 & ST_MASK) == 0 && (e2 & ST_MASK) == 0);
+            const u64 below = term ? (term & (0 - term)) - 1 : ~(u64)0;   // lanes nearer than the nearest carry-out
+            if ((unpub & below) == 0) break;
+            if (++polls > FK_OP_SPEC_POLLS) return 0.0;                   // somebody is not speculating: do not wait here
+            __builtin_amdgcn_s_sleep(FK_OP_SLEEP);
         }
-        FK_UNROLL for (int s = 0; s < W; ++s) {
-            const int j = jb - 64 * s;
-            if (j < 0) return 0.0;                                         // (uniform) walked past the start without a carry-out
-            const int jj = j - lane;
-            u64 e1 = we1[s], e2 = we2[s], rw = wrw[s], term;
-            for (;;) {
-                term = __ballot((e1 & ST_MASK) >= 2);
-                const u64 unpub = __ballot((e1 & ST_MASK) == 0 && (e2 & ST_MASK) == 0);
-                const u64 below = term ? (term & (0 - term)) - 1 : ~(u64)0;   // lanes nearer than the nearest carry-out
-                if ((unpub & below) == 0) break;
-                if (++polls > FK_OP_SPEC_POLLS) return 0.0;                   // somebody is not speculating: do not wait here
-                __builtin_amdgcn_s_sleep(FK_OP_SLEEP);
-                e1 = jj >= 0 ? ld_agent(&d[jj].exact) : (u64)3;
-                e2 = jj >= 0 ? ld_agent(&d[jj].exact2) : (u64)0;
-                rw = jj >= 0 ? ld_agent(&d[jj].raw) : (u64)0;
-            }
-            const int L = term ? __builtin_ctzll(term) : 64;
-            const bool mine = lane < L;
-            const bool a0 = ((e1 & ST_MASK) == 1 && exact_eu9(e1) == g9), b0 = ((e2 & ST_MASK) == 1 && exact_eu9(e2) == g9);
-            const bool a1 = ((e1 & ST_MASK) == 1 && exact_eu9(e1) == h9), b1 = ((e2 & ST_MASK) == 1 && exact_eu9(e2) == h9);
-            const double m0 = a0 ? exact_C(e1) : (b0 ? exact_C(e2) : 0.0), m1 = a1 ? exact_C(e1) : (b1 ? exact_C(e2) : 0.0);
-            ok0 = ok0 && __ballot(mine && !(a0 || b0)) == 0;
-            ok1 = ok1 && __ballot(mine && !(a1 || b1)) == 0;
-            if (!ok0 && !ok1) return 0.0;
-            acc0 += lane_bcast(wave_incl_sum(mine ? m0 : 0.0), 63);        // integers: exact below 2^53 (checked at the end)
-            acc1 += lane_bcast(wave_incl_sum(mine ? m1 : 0.0), 63);
-            if (!term) continue;
-            // the carry-out: state 2 = (C, eu mod 512) in the word, the double itself in `raw` -- taken only if the two agree
-            // (they are separate stores: a stale `raw` shows as a mismatch), and the exponent comes from the double
-            const u64 tw = lane_bcast_u64(e1, L), tr = lane_bcast_u64(rw, L);
-            if ((tw & ST_MASK) != 2 || j - L < 0) return 0.0;
-            const double c = bits_to_double(tr);
-            if (!(c > OP_SANE_LO && c < OP_SANE_HI)) return 0.0;
-            const int ec = ulp_exp(c);
-            const double Ct = scale2(c, -ec);
-            if (Ct != exact_C(tw) || (ec & 511) != exact_eu9(tw)) return 0.0;
-            if (ok0 && ec == g && acc0 < 0x1p53 && Ct + acc0 + I0 < 0x1p53) {
-                which = 0;
-                return scale2(Ct + acc0, g);
-            }
-            if (ok1 && ec == g + 1 && acc1 < 0x1p53 && Ct + acc1 + I1 < 0x1p53) {
-                which = 1;
-                return scale2(Ct + acc1, g + 1);
-            }
-            return 0.0;
+        const int L = term ? __builtin_ctzll(term) : 64;
+        const bool mine = lane < L;
+        const bool a0 = ((e1 & ST_MASK) == 1 && exact_eu9(e1) == g9), b0 = ((e2 & ST_MASK) == 1 && exact_eu9(e2) == g9);
+        const bool a1 = ((e1 & ST_MASK) == 1 && exact_eu9(e1) == h9), b1 = ((e2 & ST_MASK) == 1 && exact_eu9(e2) == h9);
+        const double m0 = a0 ? exact_C(e1) : (b0 ? exact_C(e2) : 0.0), m1 = a1 ? exact_C(e1) : (b1 ? exact_C(e2) : 0.0);
+        ok0 = ok0 && __ballot(mine && !(a0 || b0)) == 0;
+        ok1 = ok1 && __ballot(mine && !(a1 || b1)) == 0;
+        if (!ok0 && !ok1) return 0.0;
+        acc0 += lane_bcast(wave_incl_sum(mine ? m0 : 0.0), 63);            // integers: exact below 2^53 (checked at the end)
+        acc1 += lane_bcast(wave_incl_sum(mine ? m1 : 0.0), 63);
+        if (!term) continue;
+        // the carry-out: state 2 = (C, eu mod 512) in the word, the double itself in `raw` -- taken only if the two agree
+        // (they are separate stores: a stale `raw` shows as a mismatch), and the exponent comes from the double
+        const u64 tw = lane_bcast_u64(e1, L), tr = lane_bcast_u64(rw, L);
+        if ((tw & ST_MASK) != 2 || j - L < 0) return 0.0;
+        const double c = bits_to_double(tr);
+        if (!(c > OP_SANE_LO && c < OP_SANE_HI)) return 0.0;
+        const int ec = ulp_exp(c);
+        const double Ct = scale2(c, -ec);
+        if (Ct != exact_C(tw) || (ec & 511) != exact_eu9(tw)) return 0.0;
+        if (ok0 && ec == g && acc0 < 0x1p53 && Ct + acc0 + I0 < 0x1p53) {
+            which = 0;
+            return scale2(Ct + acc0, g);
         }
+        if (ok1 && ec == g + 1 && acc1 < 0x1p53 && Ct + acc1 + I1 < 0x1p53) {
+            which = 1;
+            return scale2(Ct + acc1, g + 1);
+        }
+        return 0.0;
     }
     return 0.0;
 }
@@ -695,9 +677,8 @@ __device__ __forceinline__ void init_window(int *win, int tid)
 // SMALLEST index is always resident (anything resident on its dispatcher was started before it, i.e. has a smaller index
 // and would be the smallest) -- and it waits for nobody.  The order of dispatch is how the hardware walks a 1-D grid, not
 // an architectural promise: the bounded spins + abort word (status ST_INTERNAL) stay, FK_OP_STATIC=0 brings the tickets back.
-// DEEP (few filters): lookback_spec<4>, one workgroup per CU fewer (its twelve words in flight spill at 96 registers)
-template <bool STRATIFIED, bool TICKET = true, bool SPEC = false, bool DEEP = false>
-__global__ void __launch_bounds__(OP_THREADS, DEEP ? FK_OP_WAVES - 1 : FK_OP_WAVES)
+template <bool STRATIFIED, bool TICKET = true, bool SPEC = false>
+__global__ void __launch_bounds__(OP_THREADS, FK_OP_WAVES)
 resample_onepass_kernel(const OpArgs a)
 {
     __shared__ OpShared sh;
@@ -844,7 +825,7 @@ resample_onepass_kernel(const OpArgs a)
                 }
                 int which = -1;
                 double c_in = 0.0;
-                if (v0 || v1) c_in = lookback_spec<DEEP ? 4 : 1>(d, k, g, I0, I1, v0, v1, lane, which);
+                if (v0 || v1) c_in = lookback_spec(d, k, g, I0, I1, v0, v1, lane, which);
                 int out_lo = 0;
                 if (which >= 0) {
                     const int e = g + which;
@@ -1648,15 +1629,10 @@ int onepass_launch(bool stratified, int64_t Fn, int64_t Np, const double *w, con
     // speculation (lookback_spec): on unless FK_OP_SPEC=0 (A/B timing; the tests run both)
     const char *pv = getenv("FK_OP_SPEC");
     const bool spec = !(pv && pv[0] == '0');
-    // few filters: the walk back through a binade segment is the critical path -- four windows of hand-off words per round
-    // trip (lookback_spec<4>; FK_OP_DEEP=0 / 1 forces it off / on)
-    const char *dv = getenv("FK_OP_DEEP");
-    const bool deep = dv ? dv[0] == '1' : Fn <= 32;
     const dim3 grid((unsigned)total), block(OP_THREADS);
 #define GO(STRAT)                                                                                                     \
     do {                                                                                                              \
-        if (stat && spec && deep) hipLaunchKernelGGL((resample_onepass_kernel<STRAT, false, true, true>), grid, block, 0, s, a); \
-        else if (stat && spec) hipLaunchKernelGGL((resample_onepass_kernel<STRAT, false, true>), grid, block, 0, s, a); \
+        if (stat && spec) hipLaunchKernelGGL((resample_onepass_kernel<STRAT, false, true>), grid, block, 0, s, a);    \
         else if (stat) hipLaunchKernelGGL((resample_onepass_kernel<STRAT, false, false>), grid, block, 0, s, a);      \
         else if (spec) hipLaunchKernelGGL((resample_onepass_kernel<STRAT, true, true>), grid, block, 0, s, a);        \
         else hipLaunchKernelGGL((resample_onepass_kernel<STRAT, true, false>), grid, block, 0, s, a);                 \

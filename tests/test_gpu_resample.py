@@ -263,11 +263,7 @@ def _family(kind, Fn, Np, rs):
 
 
 def _onepass_mode(monkeypatch, mode):
-    """spec: FK_OP_SPEC / FK_OP_STATIC defaults (few filters: four look-back windows per round trip, FK_OP_DEEP); spec-shallow:
-    FK_OP_DEEP=0 (one window, what calls with many filters run); two-stage: FK_OP_SPEC=0; tickets: FK_OP_SPEC=0 FK_OP_STATIC=0"""
-    if mode == "spec-shallow":
-        monkeypatch.setenv("FK_OP_DEEP", "0")
-        return
+    """spec: FK_OP_SPEC / FK_OP_STATIC defaults; two-stage: FK_OP_SPEC=0; tickets: FK_OP_SPEC=0 FK_OP_STATIC=0 (round 2)"""
     if mode != "spec":
         monkeypatch.setenv("FK_OP_SPEC", "0")
     if mode == "tickets":
@@ -297,7 +293,7 @@ def _check_against_merge_loop(Fn, Np, kinds, filters, monkeypatch, force):
                 assert bool(sth[f] & 4) == (over > 0) and not (sth[f] & 8), (Np, kind, strat, f, int(sth[f]))
 
 
-@pytest.mark.parametrize("mode", ["spec", "spec-shallow", "two-stage", "tickets"])
+@pytest.mark.parametrize("mode", ["spec", "two-stage", "tickets"])
 @pytest.mark.parametrize("Np", [1, 2, 100, 2049, 65536])
 def test_onepass_every_route_small(Np, mode, monkeypatch):
     """FK_RESAMPLE_PATH=onepass forces short vectors through the one-pass kernel: every weight family, every filter,
@@ -307,7 +303,7 @@ def test_onepass_every_route_small(Np, mode, monkeypatch):
     _check_against_merge_loop(5, Np, kinds, range(5), monkeypatch, force=True)
 
 
-@pytest.mark.parametrize("mode", ["spec", "spec-shallow", "two-stage", "tickets"])
+@pytest.mark.parametrize("mode", ["spec", "two-stage", "tickets"])
 def test_onepass_every_route_long(mode, monkeypatch):
     """default dispatch on a long ragged vector (not a multiple of the chunk, odd address alignment per filter), in the three
     protocols of the one-pass kernel: speculation + static chunk assignment (round 3's default), round 2's two stages on
@@ -330,12 +326,10 @@ def test_onepass_repairs_itself_when_a_hand_off_times_out(mode, monkeypatch):
 
 
 def test_onepass_one_long_vector_walks_binade_segments(monkeypatch):
-    """ONE filter of 3e6 weights: the chunks of every binade segment wait for the carry-out of the segment before it and walk
-    back through all of their own -- the case the four-window look-back (FK_OP_DEEP) exists for; both depths, bit for bit"""
-    for deep in ("1", "0"):
-        monkeypatch.setenv("FK_OP_DEEP", deep)
-        _check_against_merge_loop(1, 3000017, ("uniform", "heavy_tail", "zeros"), (0,), monkeypatch, force=False)
-        _check_against_merge_loop(40, 70001, ("uniform",), (0, 17, 39), monkeypatch, force=True)
+    """ONE filter of 3e6 weights: the chunks of every binade segment wait for the carry-out of the segment before it (the
+    serial part of a call with few filters: ~12 binade crossings, each resolved by the general scan of its chunk)"""
+    _check_against_merge_loop(1, 3000017, ("uniform", "heavy_tail", "zeros"), (0,), monkeypatch, force=False)
+    _check_against_merge_loop(40, 70001, ("uniform",), (0, 17, 39), monkeypatch, force=True)
 
 
 def test_onepass_many_filters_of_a_hundred_thousand(monkeypatch):

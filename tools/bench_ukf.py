@@ -32,6 +32,9 @@ def model(n, m, dt=0.1):
     return F, H, 0.01 * np.eye(n), 0.5 * np.eye(m)
 
 
+NO_OUTPUTS = False      # --no-outputs: the per-step histories are not stored (zero-record descriptors: stores issued and dropped)
+
+
 def run(n, m, N, T, layout, dense):
     import torch
     from filterpy_amd import _engine as E
@@ -61,8 +64,12 @@ def run(n, m, N, T, layout, dense):
     def fwd():
         x.copy_(x0)
         P.copy_(P0)
-        E.ukf_linear_batch(n, m, N, T, layout, lam + n, *dd, z, x, P, means=means, covs=covs, status=st, paired=paired)
+        E.ukf_linear_batch(n, m, N, T, layout, lam + n, *dd, z, x, P, means=None if NO_OUTPUTS else means,
+                           covs=None if NO_OUTPUTS else covs, status=st, paired=paired)
     ms = timeit(fwd)
+    if NO_OUTPUTS:
+        print(json.dumps(dict(kernel=f"fused linear UKF ({n},{m}) {layout} WITHOUT per-step outputs", N=N, T=T, ms=ms)), flush=True)
+        return
     assert not st.any()
     trk = N - 1                    # the bank's last track: the one a tail-handling mistake would hit
     zs_h = (z[:, trk] if layout == "aos" else z[:, :, trk]).cpu().numpy()
@@ -102,7 +109,9 @@ if __name__ == "__main__":
     ap.add_argument("--N", type=int, default=100_000)
     ap.add_argument("--T", type=int, default=100)
     ap.add_argument("--dense", action="store_true", help="dense F and H instead of the constant-velocity pattern")
+    ap.add_argument("--no-outputs", action="store_true", help="forward kernel only, per-step histories not stored (how much of the step is the store path?)")
     a = ap.parse_args()
+    NO_OUTPUTS = a.no_outputs
     for d in a.dims.split(","):
         n, m = (int(v) for v in d.split("x"))
         for lay in a.layouts.split(","):
