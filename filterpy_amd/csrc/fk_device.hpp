@@ -328,6 +328,32 @@ __device__ __forceinline__ void wave_store_aos_flat(const double (&v)[LEN], cons
     wave_lds_fence();
 }
 
+// Element-major ([element][track]) output of one LEN-double record per lane as 16-BYTE stores (round 4).  A lane-per-track
+// 8-byte store writes 512 contiguous bytes of ONE element row per instruction; here an instruction writes two rows: lanes 0..31
+// store tracks (2l, 2l+1) of row 2p, lanes 32..63 of row 2p+1 -- the same bytes in half as many vector-memory operations
+// (a wave may have 63 in flight: a step of the fused UKF issues 42 + 4 of them, two steps' worth does not fit, and the stores of
+// step t are what step t+1's issue then waits for).  The exchange goes through a wave-private LDS tile [LEN][64].
+// Full waves only (no clipping), 16-byte aligned rows: `rows` = the array's first row at this wave's first track, N even.
+template <int LEN>
+__device__ __forceinline__ void wave_store_soa_pairs(const double (&v)[LEN], double *rows, unsigned n8 /* N * 8 */,
+                                                     double *tile, unsigned lane, bool present = true)
+{
+    static_assert(LEN % 2 == 0, "pairs of element rows");
+    const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(rows, 0, present ? -1 : 0, 0x00020000);
+    wave_lds_fence();
+    FK_UNROLL for (int e = 0; e < LEN; ++e) tile[e * 64 + lane] = v[e];
+    wave_lds_fence();
+    const unsigned half = lane >> 5, l2 = (lane & 31u) * 2u;
+    const double *tb = tile + half * 64u + l2;
+    const unsigned voff = l2 * 8u + half * n8;
+    FK_UNROLL for (int p = 0; p < LEN / 2; ++p) {
+        const u32x4 w = *reinterpret_cast<const u32x4 *>(tb + p * 128);
+        __builtin_amdgcn_raw_buffer_store_b128(w, rs, voff, (unsigned)(2 * p) * n8, 0);
+        asm volatile("s_nop 1" ::"v"(w.x), "v"(w.y), "v"(w.z), "v"(w.w) : "memory");    // (store-data hazard: see wave_store_aos_flat)
+    }
+    wave_lds_fence();
+}
+
 // The mirror image: wave-cooperative LOAD of one LEN-double record per lane from an AOS block -- memory order into the
 // tile (two consecutive doubles per lane per pass: buffer_load_dwordx4, 1 KiB contiguous per instruction; rows past the
 // block's last track read as 0 through the descriptor's range check), then every lane reads its own row.  A lane-strided

@@ -54,6 +54,7 @@ struct UkfArgs {
     double scale;
     long i0, cnt;        // the launch covers tracks [i0, i0 + cnt) of the N (a piece of a chunked call, fk_chunks.hpp)
     int status_or;       // 1: OR the status into what an earlier time chunk left
+    int soa_pairs;       // element-major outputs as 16-byte stores of two element rows (wave_store_soa_pairs) where a wave allows it
 };
 
 struct ImmArgs {

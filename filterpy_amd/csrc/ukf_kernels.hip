@@ -69,7 +69,11 @@ struct UkfRtsArgs {
 //   * PAIRED (round 4): the step is ukf_linear_step_v4 -- the sums regrouped over the +- pairs of sigma points, for weights
 //     equal within every pair (the caller's FK_UKF_FLAG_PAIR_WEIGHTS; the prologue checks it and reports
 //     FK_STATUS_BAD_WEIGHTS on every track otherwise).  The pair table sits behind the weights in LDS.
-template <int NX, int NZ, int LAYOUT, bool EXACT, bool PAIRED>
+//   * SP (round 4; element-major, exact even dims up to 6): the per-step outputs leave as 16-byte stores of two element rows
+//     each (wave_store_soa_pairs: 21 instead of 42 vector-memory operations per step at (6,3)).  Compile-time, not a branch:
+//     two store sequences of different lengths behind a run-time test make the compiler's s_waitcnt for z a vmcnt(0).
+//     Full workgroups only -- the launcher hands the last partial workgroup to the plain instantiation.
+template <int NX, int NZ, int LAYOUT, bool EXACT, bool PAIRED, bool SP = false>
 __global__ void __launch_bounds__(BLOCK, (NX <= 2 ? 4 : NX <= 6 ? 2 : 1))
 ukf_linear_kernel(const UkfArgs a, const double *__restrict__ pF, const double *__restrict__ pH,
                   const double *__restrict__ pQ, const double *__restrict__ pR,
@@ -84,8 +88,13 @@ ukf_linear_kernel(const UkfArgs a, const double *__restrict__ pF, const double *
     // instruction (wave_store_aos_flat, fk_device.hpp) -- a lane-per-record store touches 64 lines per instruction.
     // (dim_x 9: the tile of an 81-double record does not fit next to four waves.)
     constexpr bool COOP = EXACT && LAYOUT == LAYOUT_AOS && NX <= 8 && NX % 2 == 0;
+    // element-major at the exact even dims up to 6: the per-step outputs leave as 16-byte stores of two element rows each
+    // (wave_store_soa_pairs: 21 instead of 42 vector-memory operations per step at (6,3)) where the wave is full and the rows
+    // are 16-byte aligned; other waves take the 8-byte stores
+    constexpr bool PAIRS = SP;
+    static_assert(!SP || (EXACT && LAYOUT == LAYOUT_SOA && NX <= 6 && NX % 2 == 0), "SP: element-major, exact even dims up to 6");
     constexpr int TILE = 64 * NX * NX;
-    __shared__ double s_tile[COOP ? (BLOCK / 64) * TILE : 1];
+    __shared__ double s_tile[(COOP || PAIRS) ? (BLOCK / 64) * TILE : 1];
     const long N = a.N;
     const long blk0 = a.i0 + (long)blockIdx.x * BLOCK;
     const long left = a.i0 + a.cnt - blk0;
@@ -94,7 +103,7 @@ ukf_linear_kernel(const UkfArgs a, const double *__restrict__ pF, const double *
     const Lane ln{blk0, live ? threadIdx.x : last_row, N};      // lanes past the last track duplicate it
     const int n = EXACT ? NX : a.n, m = EXACT ? NZ : a.m;
     const int ks = 2 * n + 1;
-    double *tile = s_tile + (COOP ? (threadIdx.x >> 6) * TILE : 0);
+    double *tile = s_tile + ((COOP || PAIRS) ? (threadIdx.x >> 6) * TILE : 0);
     const unsigned lane = threadIdx.x & 63u, wave_row0 = (threadIdx.x >> 6) * 64u;
 
     lds_fill<NX, NX>(s_model + SharedModel::OFF_F, pF, n, n, 1.0, threadIdx.x);
@@ -182,11 +191,17 @@ ukf_linear_kernel(const UkfArgs a, const double *__restrict__ pF, const double *
                 FK_UNROLL for (int j = 0; j < NX; ++j) Pf[i * NX + j] = P[sym_idx<NX>(i, j)];
             wave_store_aos_flat<NX * NX>(Pf, a.covs + t * N * (NX * NX) + blk0 * (NX * NX), wave_row0, tile, lane, last_row, st_c);
         } else {
-            store_rec<NX, 1, LAYOUT, EXACT>(x, a.means + t * N * n, ln, n, 1, st_m);
             double Pf[NX * NX];
             FK_UNROLL for (int i = 0; i < NX; ++i)
                 FK_UNROLL for (int j = 0; j < NX; ++j) Pf[i * NX + j] = P[sym_idx<NX>(i, j)];
-            store_rec<NX, NX, LAYOUT, EXACT>(Pf, a.covs + t * N * n * n, ln, n, n, st_c);
+            if constexpr (PAIRS) {
+                const long w0 = blk0 + wave_row0;
+                wave_store_soa_pairs<NX>(x, a.means + t * N * NX + w0, (unsigned)N * 8u, tile, lane, st_m);
+                wave_store_soa_pairs<NX * NX>(Pf, a.covs + t * N * (NX * NX) + w0, (unsigned)N * 8u, tile, lane, st_c);
+            } else {
+                store_rec<NX, 1, LAYOUT, EXACT>(x, a.means + t * N * n, ln, n, 1, st_m);
+                store_rec<NX, NX, LAYOUT, EXACT>(Pf, a.covs + t * N * n * n, ln, n, n, st_c);
+            }
         }
     }
     __syncthreads();
@@ -222,13 +237,39 @@ int ukf_rts_launch_big_paired(const UkfRtsArgs &a, const double *F, const double
         const dim3 grid((unsigned)((a.cnt + BLOCK - 1) / BLOCK)), block(BLOCK);                                  \
         const bool ex = exact && a.n == NXV && a.m == NZV;                                                       \
         if (layout == FK_LAYOUT_SOA) {                                                                           \
-            if (ex) hipLaunchKernelGGL((ukf_linear_kernel<NXV, NZV, LAYOUT_SOA, true, PV>), grid, block, 0, s, a, a.F, a.H, a.Q, a.R, a.Wm, a.Wc, a.z, a.mask); \
+            if (ex && ukf_sp_ok<NXV>(a)) ukf_launch_sp<NXV, NZV, PV>(a, s);                                         \
+            else if (ex) hipLaunchKernelGGL((ukf_linear_kernel<NXV, NZV, LAYOUT_SOA, true, PV>), grid, block, 0, s, a, a.F, a.H, a.Q, a.R, a.Wm, a.Wc, a.z, a.mask); \
             else hipLaunchKernelGGL((ukf_linear_kernel<NXV, NZV, LAYOUT_SOA, false, PV>), grid, block, 0, s, a, a.F, a.H, a.Q, a.R, a.Wm, a.Wc, a.z, a.mask);  \
         } else {                                                                                                 \
             if (ex) hipLaunchKernelGGL((ukf_linear_kernel<NXV, NZV, LAYOUT_AOS, true, PV>), grid, block, 0, s, a, a.F, a.H, a.Q, a.R, a.Wm, a.Wc, a.z, a.mask); \
             else hipLaunchKernelGGL((ukf_linear_kernel<NXV, NZV, LAYOUT_AOS, false, PV>), grid, block, 0, s, a, a.F, a.H, a.Q, a.R, a.Wm, a.Wc, a.z, a.mask);  \
         }                                                                                                        \
     } while (0)
+// SP instantiations: even dims up to 6, element-major, N even, 16-byte aligned histories (or none); full workgroups on the SP
+// kernel, the last partial one on the plain kernel (a second launch over tracks [i0 + full, i0 + cnt))
+template <int NXV>
+static bool ukf_sp_ok(const UkfArgs &a)
+{
+    if constexpr (NXV > 6 || NXV % 2 != 0) return false;
+    return a.soa_pairs && (a.N & 1) == 0 && a.cnt >= BLOCK &&
+           ((reinterpret_cast<uintptr_t>(a.means) | reinterpret_cast<uintptr_t>(a.covs)) & 15u) == 0;
+}
+template <int NXV, int NZV, bool PV>
+static void ukf_launch_sp(const UkfArgs &a, hipStream_t s)
+{
+    if constexpr (NXV <= 6 && NXV % 2 == 0) {
+        const long full = a.cnt / BLOCK * BLOCK;
+        UkfArgs b = a;
+        b.cnt = full;
+        hipLaunchKernelGGL((ukf_linear_kernel<NXV, NZV, LAYOUT_SOA, true, PV, true>), dim3((unsigned)(full / BLOCK)), dim3(BLOCK), 0, s, b, a.F, a.H, a.Q, a.R, a.Wm, a.Wc, a.z, a.mask);
+        if (full < a.cnt) {
+            b.i0 = a.i0 + full;
+            b.cnt = a.cnt - full;
+            hipLaunchKernelGGL((ukf_linear_kernel<NXV, NZV, LAYOUT_SOA, true, PV>), dim3(1), dim3(BLOCK), 0, s, b, a.F, a.H, a.Q, a.R, a.Wm, a.Wc, a.z, a.mask);
+        }
+    }
+}
+
 template <bool PV>
 static int ukf_fwd_small_t(const UkfArgs &a, int layout, bool exact, hipStream_t s)
 {
@@ -651,6 +692,10 @@ int fk_ukf_linear_batch_f64(const fk_ukf_desc *d, const double *F, const double 
     a0.x = x; a0.P = P; a0.means = means; a0.covs = covs; a0.status = status;
     a0.N = d->N; a0.T = d->T; a0.n = d->n; a0.m = d->m; a0.scale = d->scale;
     a0.i0 = 0; a0.cnt = d->N; a0.status_or = 0;
+    {   // FK_UKF_SOA_PAIRS=0: the element-major outputs as 8-byte stores everywhere (A/B)
+        const char *pv = getenv("FK_UKF_SOA_PAIRS");
+        a0.soa_pairs = !(pv && pv[0] == '0');
+    }
     const int layout = d->layout;
     const bool exact = ukf_exact(), paired = ukf_paired(d);
     // one piece: tracks [a.i0, a.i0 + a.cnt), a.T steps from the pointers in a.  Classes (2,2), (4,2), (6,3), (8,4), (9,3),

@@ -245,3 +245,47 @@ def test_fused_linear_ukf_smoother_on_arrays_that_are_only_8_byte_aligned(layout
         assert np.array_equal(a, b)
     hx = E.from_records(torch.as_tensor(res[1][0]), layout, 1, (n,))
     assert rel_err_rows(hx[:, nb - 1], g[p + "rts_x"]) < ukf_tol(ci, "rts_x")
+
+
+@pytest.mark.parametrize("mask", [False, True])
+@pytest.mark.parametrize("n,m", [(2, 2), (4, 2), (6, 3)])
+def test_element_major_pair_stores_are_bit_identical(n, m, mask, monkeypatch):
+    """Round 4: in the element-major layout the fused UKF's per-step outputs leave as 16-byte stores of two element rows each
+    (wave_store_soa_pairs, the SP instantiations; full workgroups -- the last partial one runs the plain kernel in a second
+    launch).  Only the store instructions differ: every output equals the 8-byte-store kernel (FK_UKF_SOA_PAIRS=0) bit for bit,
+    bank sizes with and without a partial workgroup, odd banks (which take the plain kernel), missing measurements."""
+    import torch
+    from filterpy_amd import _engine as E
+    from oracle import ukf_oracle
+    rs = np.random.RandomState(11 * n + m)
+    T = 7
+    alpha, beta, kappa = .1, 2., 3. - n
+    lam = alpha ** 2 * (n + kappa) - n
+    Wm, Wc = ukf_oracle.merwe_weights(n, alpha, beta, kappa)
+    F = np.eye(n) + 0.05 * np.triu(rs.randn(n, n), 1)
+    H = np.eye(m, n) + 0.1 * rs.randn(m, n)
+    Q, R = 0.01 * np.eye(n), 0.5 * np.eye(m)
+    for N in (256, 778, 1024 + 130, 511):
+        x0, P0 = rs.randn(N, n), np.tile(5.0 * np.eye(n), (N, 1, 1))
+        zs = rs.randn(T, N, m)
+        mk = (rs.rand(T, N) > 0.25).astype(np.uint8) if mask else None
+        res = {}
+        for tag, env in (("pairs", None), ("plain", "0")):
+            if env is None:
+                monkeypatch.delenv("FK_UKF_SOA_PAIRS", raising=False)
+            else:
+                monkeypatch.setenv("FK_UKF_SOA_PAIRS", env)
+            dx, dP = E.to_records(x0, "soa", 0), E.to_records(P0, "soa", 0)
+            means, covs = E.alloc_records((T,), N, n, "soa"), E.alloc_records((T,), N, n * n, "soa")
+            means.fill_(float("nan"))
+            covs.fill_(float("nan"))
+            st = torch.zeros(N, dtype=torch.int32, device=dx.device)
+            E.ukf_linear_batch(n, m, N, T, "soa", lam + n, E.dev(F), E.dev(H), E.dev(Q), E.dev(R), E.dev(Wm), E.dev(Wc),
+                               E.to_records(zs, "soa", 1), dx, dP, mask=None if mk is None else torch.as_tensor(mk, device=dx.device),
+                               means=means, covs=covs, status=st, paired=True)
+            torch.cuda.synchronize()
+            assert not st.any()
+            res[tag] = [t.cpu().numpy() for t in (means, covs, dx, dP)]
+        for a, b in zip(res["pairs"], res["plain"]):
+            assert np.array_equal(a, b), (n, m, N, mask)
+        assert np.all(np.isfinite(res["pairs"][0])) and np.all(np.isfinite(res["pairs"][1]))

@@ -23,13 +23,14 @@ def main():
     ap.add_argument("--padded", action="store_true")
     ap.add_argument("--dma", action="store_true")
     ap.add_argument("--index-order", action="store_true", help="the index-order sums (PAIRED = false)")
+    ap.add_argument("--sp", action="store_true", help="fwd, element-major: 16-byte stores of two element rows (SP = true)")
     a = ap.parse_args()
     lay = {"soa": "fk::LAYOUT_SOA", "aos": "fk::LAYOUT_AOS"}[a.dims[-1]]
     exact = "false" if a.padded else "true"
     paired = "false" if a.index_order else "true"
     if a.kind == "fwd":
         nx, nz = int(a.dims[0]), int(a.dims[1])
-        inst = (f"template __global__ void fk::ukf_linear_kernel<{nx}, {nz}, {lay}, {exact}, {paired}>(const fk::UkfArgs, const double *, "
+        inst = (f"template __global__ void fk::ukf_linear_kernel<{nx}, {nz}, {lay}, {exact}, {paired}, {'true' if a.sp else 'false'}>(const fk::UkfArgs, const double *, "
                 "const double *, const double *, const double *, const double *, const double *, const double *, const uint8_t *);")
         part = 91
     else:
