@@ -161,6 +161,14 @@ int kf_chunked_call(const Args &a, int n, int m, long slots, One &&one, hipStrea
                 if (a.nu > 0) b.B = ml_off(a.B, t0 * (long)n * a.nu);
             }
             if (a.nu > 0) b.u = ml_off(a.u, t0 * a.N * a.nu);
+            if (a.extras_per_step) {                           // the by-product histories advance with the time window too
+                b.y_out = ml_off(a.y_out, t0 * a.N * m);
+                b.K_out = ml_off(a.K_out, t0 * a.N * (long)n * m);
+                b.S_out = ml_off(a.S_out, t0 * a.N * (long)m * m);
+                b.SI_out = ml_off(a.SI_out, t0 * a.N * (long)m * m);
+                b.ll_out = ml_off(a.ll_out, t0 * a.N);
+                b.maha_out = ml_off(a.maha_out, t0 * a.N);
+            }
             rc = one(b, sg);
         }
     }

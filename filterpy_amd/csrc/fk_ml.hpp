@@ -1,6 +1,7 @@
 // fk_ml.hpp -- cross-lane and buffer-access helpers shared by the several-lanes-per-track kernels
 // (kf_ml.hip: dim_x = 9 on three lanes; kf_mlg.hip: dim_x 10..16 on four lanes).
 #pragma once
+#include <type_traits>
 #include "fk_device.hpp"
 
 namespace fk {
@@ -129,6 +130,42 @@ __device__ __forceinline__ void ml_wave_fence()
 }
 
 
+// Copy-out of U 16-byte units staged in a wave-private LDS tile: the reads of a batch of B units FIRST, then their stores.
+// (read -> s_waitcnt -> store per unit, which is what a plain loop compiles to, exposes the LDS latency once per unit:
+// 13 .. 32 times per output set, with one wave per SIMD nothing covers it.)  No lane is predicated on the unit count: a
+// lane past the last unit reads a clamped unit, and `store(unit, in_range, v)` is expected to drop it (an offset outside
+// the descriptor).  Up to 2 B units: one straight-line batch pair; above: a rolled loop over batches.
+//   addr(unit): tile address of the unit;  store(unit, in_range, value)
+template <int U, int B, class Addr, class Store>
+__device__ __forceinline__ void ml_copy_units(unsigned lane, Addr &&addr, Store &&store)
+{
+    using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+    constexpr int IT = (U + 63) / 64;
+    auto batch = [&](int it0, auto nb_tag) {
+        constexpr int NB = decltype(nb_tag)::value;
+        u32x4 v[NB];
+        FK_UNROLL for (int b = 0; b < NB; ++b) {
+            const unsigned unit = (unsigned)(it0 + b) * 64u + lane, cu = unit < (unsigned)U ? unit : (unsigned)U - 1u;
+            v[b] = *reinterpret_cast<const u32x4 *>(addr(cu));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        FK_UNROLL for (int b = 0; b < NB; ++b) {
+            const unsigned unit = (unsigned)(it0 + b) * 64u + lane;
+            store(unit, unit < (unsigned)U, v[b]);
+        }
+    };
+    if constexpr (IT <= 2 * B) {
+        constexpr int H1 = IT < B ? IT : B;
+        batch(0, std::integral_constant<int, H1>{});
+        if constexpr (IT > B) batch(B, std::integral_constant<int, IT - B>{});
+    } else {
+        _Pragma("nounroll") for (int it0 = 0; it0 < IT; it0 += B) batch(it0, std::integral_constant<int, B>{});
+    }
+}
+// the offset of a dropped store: outside every descriptor SIZED TO ITS SLAB (the NumPy-order copy-outs; a descriptor made by
+// make_rsrc spans 4 GiB and drops nothing -- the element-major copy-outs predicate their stores instead)
+constexpr unsigned ML_OFF_DROP = 0xfffffff0u;
+
 // SOA (element-major, a[e][track]) output of one row-block matrix of a wave's TPW consecutive tracks: the lanes write
 // their rows into a wave-private LDS tile laid out [element][track], then the 64 lanes copy 16-byte units -- two
 // adjacent tracks of one element -- so that a store instruction moves 1 KiB instead of 512 B.  (A wave may have 63
@@ -150,17 +187,50 @@ __device__ __forceinline__ void ml_store_rows_soa_slab(const double (&M)[R][NX],
     ml_wave_fence();
     const rsrc_t rs = make_rsrc(plane0 + w0);
     const unsigned n8 = (unsigned)N * 8u;
-    _Pragma("unroll 4") for (int it = 0; it * 64 < UP; ++it) {
-        const unsigned unit = it * 64u + lane;
-        if (it * 64 + 63 < UP || unit < (unsigned)UP) {
-            const unsigned e = unit / (unsigned)HP, p = unit % (unsigned)HP;
-            const u32x4 v = *reinterpret_cast<const u32x4 *>(tile + e * TPW + 2u * p);
-            const unsigned off = e * n8 + p * 16u;
-            if (2u * p + 1u < valid) __builtin_amdgcn_raw_buffer_store_b128(v, rs, off, 0, 0);
-            else if (2u * p < valid) __builtin_amdgcn_raw_buffer_store_b64(u32x2{v.x, v.y}, rs, off, 0, 0);
-        }
-    }
+    ml_copy_units<UP, 4>(lane,
+        [&](unsigned unit) { return tile + (unit / (unsigned)HP) * TPW + 2u * (unit % (unsigned)HP); },
+        [&](unsigned unit, bool ok, const u32x4 &v) {
+            const unsigned e = unit / (unsigned)HP, p = unit % (unsigned)HP, off = e * n8 + p * 16u;
+            // (predicated, not dropped by offset: this descriptor spans the whole 4 GiB window, nothing is out of its range)
+            if (ok && 2u * p + 1u < valid) __builtin_amdgcn_raw_buffer_store_b128(v, rs, off, 0, 0);
+            else if (ok && 2u * p + 1u == valid) __builtin_amdgcn_raw_buffer_store_b64(u32x2{v.x, v.y}, rs, off, 0, 0);   // odd tail (last wave only)
+        });
     ml_wave_fence();
+}
+
+// Copy-out of a per-track record array of E doubles (the update's by-products: y, K, S, SI) that the lanes of a wave have
+// just staged in the wave-private tile -- 16-byte units, 1 KiB per store instruction, like the (x, P) sets above.
+//   AOS: the tile is laid out like the wave's slab ([track][e], tile[g * E + e]); dst = record of the wave's first track.
+//   SOA: the tile is [e][TPW] (tile[e * TPW + g]); plane0 = element 0 of the array at this time step, track 0.
+// The caller brackets its tile writes with ml_wave_fence(); `valid`: how many of the wave's TPW tracks exist.
+template <int E, int TPW>
+__device__ __forceinline__ void ml_tile_out_aos(double *dst, const double *tile, unsigned lane, unsigned valid)
+{
+    constexpr int U = TPW * E / 2;
+    static_assert((TPW * E) % 2 == 0, "whole 16-byte units");
+    using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+    const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(dst, 0, (int)(valid * (unsigned)E * 8u), 0x00020000);
+    ml_copy_units<U, 4>(lane, [&](unsigned unit) { return tile + 2u * unit; },
+                        [&](unsigned unit, bool ok, const u32x4 &v) {
+                            __builtin_amdgcn_raw_buffer_store_b128(v, rs, ok ? unit * 16u : ML_OFF_DROP, 0, 0);
+                        });
+}
+
+template <int E, int TPW>
+__device__ __forceinline__ void ml_tile_out_soa(double *plane0, long N, long w0, const double *tile, unsigned lane, unsigned valid)
+{
+    constexpr int HP = TPW / 2, U = E * HP;
+    using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+    const rsrc_t rs = make_rsrc(plane0 + w0);
+    const unsigned n8 = (unsigned)N * 8u;
+    ml_copy_units<U, 4>(lane,
+        [&](unsigned unit) { return tile + (unit / (unsigned)HP) * TPW + 2u * (unit % (unsigned)HP); },
+        [&](unsigned unit, bool ok, const u32x4 &v) {
+            const unsigned e = unit / (unsigned)HP, p = unit % (unsigned)HP, off = e * n8 + p * 16u;
+            // (predicated, not dropped by offset: this descriptor spans the whole 4 GiB window, nothing is out of its range)
+            if (ok && 2u * p + 1u < valid) __builtin_amdgcn_raw_buffer_store_b128(v, rs, off, 0, 0);
+            else if (ok && 2u * p + 1u == valid) __builtin_amdgcn_raw_buffer_store_b64(u32x2{v.x, v.y}, rs, off, 0, 0);   // odd tail (last wave only)
+        });
 }
 
 }  // namespace fk

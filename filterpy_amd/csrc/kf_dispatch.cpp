@@ -250,7 +250,17 @@ static int run_kf_window(const fk_kf_desc *d, KfArgs &a, long cnt, void *stream)
     const bool want_ex = a.y_out || a.K_out || a.S_out || a.SI_out || a.ll_out || a.maha_out;
     const bool fast_ex = want_ex && a.extras_per_step && all_out && d->model_mode == FK_MODEL_SHARED && d->nu == 0 &&
                          !d->update_first && !getenv("FK_NO_FAST_EX");
+    // ... and, round 4, from the four-lane kernels' EX instantiations (dim_x >= 10, and (9,3)): the plain call without a mask
+    const bool mlg_ex = fast_ex && !a.mask && !inter && (d->n >= 10 || (d->n == 9 && d->m == 3)) && !getenv("FK_NO_MLG_EX") &&
+                        !getenv("FK_NO_MLG");
     if (a.do_predict && a.do_update && (all_out || no_out) && (!want_ex || fast_ex) && !a.rj_diag && !getenv("FK_NO_FAST")) {
+        if (mlg_ex) {
+            for (const FastEntry &g : mlg_table) {
+                if (g.nx != d->n || g.nz != d->m) continue;
+                const int rc = g.fn(a, d->layout, all_out, d->model_mode, (hipStream_t)stream);
+                if (rc <= 0) return rc;    // 1 = not a call the four-lane kernel serves
+            }
+        }
         const char *g9 = getenv("FK_ML9");          // "g": dim_x = 9 on the four-lane kernels (A/B against kf_ml / rts_ml)
         if (!want_ex && d->n == 9 && d->m == 3 && !getenv("FK_NO_ML") && !(g9 && g9[0] == 'g')) {
             if (inter) return fail(FK_ERR_UNSUPPORTED, "FK_KF_FLAG_COV_INTERLEAVED: (9,3) runs on the three-lane kernel, which takes two arrays");

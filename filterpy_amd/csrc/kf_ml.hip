@@ -128,19 +128,27 @@ __device__ __forceinline__ void ml_store_aos(const double (&x)[NX], const double
     ml_wave_fence();
     const rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(xdst, 0, (int)(valid * (unsigned)NX * 8u), 0x00020000);
     const rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc(Pdst, 0, (int)(valid * (unsigned)EP * 8u), 0x00020000);
-    FK_UNROLL for (int it = 0; it * 64 < UX; ++it) {
-        const unsigned unit = it * 64u + lane;
-        if (unit < (unsigned)UX) {
-            const u32x4 v = *reinterpret_cast<const u32x4 *>(tx + 2 * unit);
-            __builtin_amdgcn_raw_buffer_store_b128(v, rx, unit * 16u, 0, 0);
-        }
+    // every unit is read from the tile FIRST, then the stores go out back to back: read -> wait -> store per unit exposed
+    // the LDS latency thirteen times per output set.  No lane is predicated: a lane past the slab reads a clamped unit and
+    // its store falls outside the descriptor (sized to the wave's valid tracks), which drops it.
+    constexpr int ITX = (UX + 63) / 64, ITP = (UP + 63) / 64;
+    u32x4 vx[ITX], vP[ITP];
+    FK_UNROLL for (int it = 0; it < ITX; ++it) {
+        const unsigned unit = it * 64u + lane, cu = unit < (unsigned)UX ? unit : (unsigned)UX - 1u;
+        vx[it] = *reinterpret_cast<const u32x4 *>(tx + 2 * cu);
     }
-    FK_UNROLL for (int it = 0; it * 64 < UP; ++it) {
+    FK_UNROLL for (int it = 0; it < ITP; ++it) {
+        const unsigned unit = it * 64u + lane, cu = unit < (unsigned)UP ? unit : (unsigned)UP - 1u;
+        vP[it] = *reinterpret_cast<const u32x4 *>(tP + 2 * cu);
+    }
+    FK_STAGE();
+    FK_UNROLL for (int it = 0; it < ITX; ++it) {
         const unsigned unit = it * 64u + lane;
-        if (it * 64 + 63 < UP || unit < (unsigned)UP) {
-            const u32x4 v = *reinterpret_cast<const u32x4 *>(tP + 2 * unit);
-            __builtin_amdgcn_raw_buffer_store_b128(v, rP, unit * 16u, 0, 0);
-        }
+        __builtin_amdgcn_raw_buffer_store_b128(vx[it], rx, unit < (unsigned)UX ? unit * 16u : 0xfffffff0u, 0, 0);
+    }
+    FK_UNROLL for (int it = 0; it < ITP; ++it) {
+        const unsigned unit = it * 64u + lane;
+        __builtin_amdgcn_raw_buffer_store_b128(vP[it], rP, unit < (unsigned)UP ? unit * 16u : 0xfffffff0u, 0, 0);
     }
 }
 
@@ -320,46 +328,95 @@ kf_ml_kernel(const KfArgs a)
         // PHT = P H', G and every row of T1 / P+ are lane-local; H P needs columns of P, i.e. one
         // three-way sum across the quad (27 values); PHT (for S) and K's rows are gathered.
         double y[NZ], K[R][NZ];
+        const double *myH = sH + Lc * R;                        // this lane's columns of H (the H P stage)
+        double hc[2][R];
         {
-            FK_UNROLL for (int c = 0; c < NZ; ++c) {
-                double acc = HX(c * NX) * x[0];
-                FK_UNROLL for (int k = 1; k < NX; ++k) acc = fma(HX(c * NX + k), x[k], acc);
-                y[c] = z[c] - acc;
+            if constexpr (!HLDS) {
+                FK_UNROLL for (int c = 0; c < NZ; ++c) {
+                    double acc = HX(c * NX) * x[0];
+                    FK_UNROLL for (int k = 1; k < NX; ++k) acc = fma(HX(c * NX + k), x[k], acc);
+                    y[c] = z[c] - acc;
+                }
             }
             // (update_first: P is the prior the PREVIOUS step's predict left; at t == 0 the initial P lands in covs_p[0]
             // and is overwritten one step later)
             const MlView vPri(a.covs_p + (UF ? (t > 0 ? t - 1 : 0) : t) * N * NX * NX, off_rows, estride, pair_rows);
             double PHT[R][NZ], S[NZ * NZ];
-            FK_UNROLL for (int r = 0; r < R; ++r) {
+            // the prior covariance's 27 stores in R groups, one per iteration of the P H' stage (element-major outputs)
+#define FK_ML_PRIOR_STORES(rr)                                                                                          \
+    if (OUTS && !AOS) {                                                                                                 \
+        if constexpr (PAIRS) {                                                                                          \
+            /* 27 elements = 13 pairs + 1, pairs may straddle rows: group rr sends the pairs that END in row rr */      \
+            FK_UNROLL for (int f0 = 0; f0 + 1 < R * NX; f0 += 2)                                                        \
+                if ((f0 + 1) / NX == (rr)) vPri.store_pair(f0, P[f0 / NX][f0 % NX], P[(f0 + 1) / NX][(f0 + 1) % NX]);   \
+            if ((rr) == R - 1) vPri.store(R * NX - 1, P[R - 1][NX - 1]);                                                \
+        } else {                                                                                                        \
+            FK_UNROLL for (int c_ = 0; c_ < NX; ++c_) vPri.store((rr) * NX + c_, P[(rr)][c_]);                          \
+        }                                                                                                               \
+    }
+            if constexpr (HLDS) {
+                // H from LDS (NumPy order, per-step models): row c serves y[c] and column c of P H' in one pass and is requested
+                // one row ahead, like F's rows in the predict half (the same sums in the same order)
+                double Hr[2][NX];
+                FK_UNROLL for (int k = 0; k < NX; ++k) Hr[0][k] = sH[k];
+                FK_UNROLL for (int c = 0; c < NZ; ++c) {
+                    if (c + 1 < NZ) {
+                        FK_UNROLL for (int k = 0; k < NX; ++k) Hr[(c + 1) & 1][k] = sH[(c + 1) * NX + k];
+                    }
+                    const double (&Hc)[NX] = Hr[c & 1];
+                    double acc = Hc[0] * x[0];
+                    FK_UNROLL for (int k = 1; k < NX; ++k) acc = fma(Hc[k], x[k], acc);
+                    y[c] = z[c] - acc;
+                    FK_UNROLL for (int r = 0; r < R; ++r) {
+                        double pa = P[r][0] * Hc[0];
+                        FK_UNROLL for (int k = 1; k < NX; ++k) pa = fma(P[r][k], Hc[k], pa);
+                        PHT[r][c] = pa;
+                    }
+                    static_assert(NZ == R, "the prior's store groups (one per row block) ride on the NZ iterations");
+                    FK_ML_PRIOR_STORES(c);
+                    FK_STAGE();
+                }
+            }
+            FK_UNROLL for (int r = 0; r < R && !HLDS; ++r) {
                 FK_UNROLL for (int c = 0; c < NZ; ++c) {
                     double acc = P[r][0] * HX(c * NX);
                     FK_UNROLL for (int k = 1; k < NX; ++k) acc = fma(P[r][k], HX(c * NX + k), acc);
                     PHT[r][c] = acc;
                 }
-                if (OUTS && !AOS) {
-                    if constexpr (PAIRS) {
-                        // 27 elements = 13 pairs + 1, pairs may straddle rows: row r sends the pairs that END in it
-                        FK_UNROLL for (int f0 = 0; f0 + 1 < R * NX; f0 += 2)
-                            if ((f0 + 1) / NX == r) vPri.store_pair(f0, P[f0 / NX][f0 % NX], P[(f0 + 1) / NX][(f0 + 1) % NX]);
-                        if (r == R - 1) vPri.store(R * NX - 1, P[R - 1][NX - 1]);
-                    } else {
-                        FK_UNROLL for (int c = 0; c < NX; ++c) vPri.store(r * NX + c, P[r][c]);
-                    }
-                }
+                FK_ML_PRIOR_STORES(r);
                 FK_STAGE();
             }
-            // S = H PHT + R, replicated in every lane: PHT's row k comes from its owner
+            // S = H PHT + R, replicated in every lane: PHT's row k comes from its owner  (R requested in front of the sums)
+            double Rs[NZ * NZ];
+            FK_UNROLL for (int e = 0; e < NZ * NZ; ++e) Rs[e] = sR[e];
+            FK_STAGE();
+            double hk[2][NZ];                                   // HLDS: column k of H one iteration ahead
+            if constexpr (HLDS) {
+                FK_UNROLL for (int r = 0; r < NZ; ++r) hk[0][r] = sH[r * NX];
+            }
             FK_UNROLL for (int k = 0; k < NX; ++k) {
+                if constexpr (HLDS) {
+                    if (k + 1 < NX) {
+                        FK_UNROLL for (int r = 0; r < NZ; ++r) hk[(k + 1) & 1][r] = sH[r * NX + k + 1];
+                    }
+                }
                 double pk[NZ];
                 FK_UNROLL for (int c = 0; c < NZ; ++c) {
                     const double v = PHT[k % R][c];
                     pk[c] = (k / R == 0) ? quad_bcast<0>(v) : (k / R == 1) ? quad_bcast<1>(v) : quad_bcast<2>(v);
                 }
-                FK_UNROLL for (int r = 0; r < NZ; ++r)
+                FK_UNROLL for (int r = 0; r < NZ; ++r) {
+                    const double h = HLDS ? hk[k & 1][r] : HX(r * NX + k);
                     FK_UNROLL for (int c = 0; c < NZ; ++c)
-                        S[r * NZ + c] = (k == 0) ? HX(r * NX) * pk[c] : fma(HX(r * NX + k), pk[c], S[r * NZ + c]);
+                        S[r * NZ + c] = (k == 0) ? h * pk[c] : fma(h, pk[c], S[r * NZ + c]);
+                }
+                if constexpr (HLDS) {
+                    if (k % 3 == 2) FK_STAGE();
+                }
             }
-            FK_UNROLL for (int e = 0; e < NZ * NZ; ++e) S[e] += sR[e];
+            FK_UNROLL for (int e = 0; e < NZ * NZ; ++e) S[e] += Rs[e];
+            FK_STAGE();
+            FK_UNROLL for (int r = 0; r < R; ++r) hc[0][r] = myH[r];     // requested in front of the factorisation that does not need them
             FK_STAGE();
             double Lf[NZ * NZ], d[NZ], dinv[NZ], Kr[R * NZ];
             FK_UNROLL for (int e = 0; e < NZ * NZ; ++e) Lf[e] = S[e];
@@ -373,19 +430,27 @@ kf_ml_kernel(const KfArgs a)
         FK_STAGE();
         {
             // H P: this lane's rows contribute sum_r H[c][row0 + r] P[r][:]; the quad adds the three parts
-            const double *myH = sH + Lc * R;
+            // (this lane's R coefficients of row c one iteration ahead of their use: see kf_ml_predict.inc)
             double HP[NZ][NX];
             FK_UNROLL for (int c = 0; c < NZ; ++c) {
+                if (c + 1 < NZ) {
+                    FK_UNROLL for (int r = 0; r < R; ++r) hc[(c + 1) & 1][r] = myH[(c + 1) * NX + r];
+                }
                 FK_UNROLL for (int j = 0; j < NX; ++j) {
-                    double acc = myH[c * NX] * P[0][j];
-                    FK_UNROLL for (int r = 1; r < R; ++r) acc = fma(myH[c * NX + r], P[r][j], acc);
+                    double acc = hc[c & 1][0] * P[0][j];
+                    FK_UNROLL for (int r = 1; r < R; ++r) acc = fma(hc[c & 1][r], P[r][j], acc);
                     HP[c][j] = acc;
                 }
                 FK_UNROLL for (int j = 0; j < NX; ++j) HP[c][j] = (HP[c][j] + quad_rot<0x09>(HP[c][j])) + quad_rot<0x52>(HP[c][j]);
                 FK_STAGE();
             }
             // T1 = P - K (H P) (own rows, in place)
+            double Rr[NZ * NZ];                                // R for the D stage, requested a stage early
             FK_UNROLL for (int r = 0; r < R; ++r) {
+                if (r == R - 1) {
+                    FK_UNROLL for (int e = 0; e < NZ * NZ; ++e) Rr[e] = sR[e];
+                    FK_STAGE();
+                }
                 FK_UNROLL for (int j = 0; j < NX; ++j) {
                     double acc = P[r][j];
                     FK_UNROLL for (int c = 0; c < NZ; ++c) acc = fma(-K[r][c], HP[c][j], acc);
@@ -395,10 +460,28 @@ kf_ml_kernel(const KfArgs a)
             }
             // D = K R - T1 H' (own rows)
             double D[R][NZ];
-            FK_UNROLL for (int r = 0; r < R; ++r)
+            if constexpr (HLDS) {
+                double Hr[2][NX];
+                FK_UNROLL for (int k = 0; k < NX; ++k) Hr[0][k] = sH[k];
                 FK_UNROLL for (int c = 0; c < NZ; ++c) {
-                    double kr = K[r][0] * sR[c];
-                    FK_UNROLL for (int q = 1; q < NZ; ++q) kr = fma(K[r][q], sR[q * NZ + c], kr);
+                    if (c + 1 < NZ) {
+                        FK_UNROLL for (int k = 0; k < NX; ++k) Hr[(c + 1) & 1][k] = sH[(c + 1) * NX + k];
+                    }
+                    const double (&Hc)[NX] = Hr[c & 1];
+                    FK_UNROLL for (int r = 0; r < R; ++r) {
+                        double kr = K[r][0] * Rr[c];
+                        FK_UNROLL for (int q = 1; q < NZ; ++q) kr = fma(K[r][q], Rr[q * NZ + c], kr);
+                        double g = P[r][0] * Hc[0];
+                        FK_UNROLL for (int k = 1; k < NX; ++k) g = fma(P[r][k], Hc[k], g);
+                        D[r][c] = kr - g;
+                    }
+                    FK_STAGE();
+                }
+            }
+            FK_UNROLL for (int r = 0; r < R && !HLDS; ++r)
+                FK_UNROLL for (int c = 0; c < NZ; ++c) {
+                    double kr = K[r][0] * Rr[c];
+                    FK_UNROLL for (int q = 1; q < NZ; ++q) kr = fma(K[r][q], Rr[q * NZ + c], kr);
                     double g = P[r][0] * HX(c * NX);
                     FK_UNROLL for (int k = 1; k < NX; ++k) g = fma(P[r][k], HX(c * NX + k), g);
                     D[r][c] = kr - g;
@@ -493,14 +576,10 @@ __device__ __forceinline__ void ml_store_rows_aos_park(const double (&M)[R][NX],
         }
     ml_wave_fence();
     const rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc(dst, 0, (int)(valid * (unsigned)EP * 8u), 0x00020000);
-    FK_UNROLL for (int it = 0; it * 64 < UP; ++it) {
-        const unsigned unit = it * 64u + lane;
-        if (it * 64 + 63 < UP || unit < (unsigned)UP) {
-            const unsigned i = 2u * unit;
-            const u32x4 v = *reinterpret_cast<const u32x4 *>(&park[i >> 6][c0 + (i & 63u)]);
-            __builtin_amdgcn_raw_buffer_store_b128(v, rP, unit * 16u, 0, 0);
-        }
-    }
+    ml_copy_units<UP, 6>(lane, [&](unsigned unit) { return &park[(2u * unit) >> 6][c0 + ((2u * unit) & 63u)]; },
+                         [&](unsigned unit, bool ok, const u32x4 &v) {
+                             __builtin_amdgcn_raw_buffer_store_b128(v, rP, ok ? unit * 16u : ML_OFF_DROP, 0, 0);
+                         });
     ml_wave_fence();
 }
 
@@ -601,11 +680,16 @@ rts_ml_kernel(const RtsArgs a)
             double P[R][NX];
             FK_UNROLL for (int r = 0; r < R; ++r)
                 FK_UNROLL for (int c = 0; c < NX; ++c) P[r][c] = Pnx[r][c];
-            // T = P F'
+            // T = P F'  (F's rows requested from LDS one iteration ahead: see kf_ml_predict.inc)
+            double Fr[2][NX];
+            FK_UNROLL for (int q = 0; q < NX; ++q) Fr[0][q] = sF[q];
             FK_UNROLL for (int i = 0; i < NX; ++i) {
+                if (i + 1 < NX) {
+                    FK_UNROLL for (int q = 0; q < NX; ++q) Fr[(i + 1) & 1][q] = sF[(i + 1) * NX + q];
+                }
                 FK_UNROLL for (int r = 0; r < R; ++r) {
-                    double acc = P[r][0] * sF[i * NX];
-                    FK_UNROLL for (int q = 1; q < NX; ++q) acc = fma(P[r][q], sF[i * NX + q], acc);
+                    double acc = P[r][0] * Fr[i & 1][0];
+                    FK_UNROLL for (int q = 1; q < NX; ++q) acc = fma(P[r][q], Fr[i & 1][q], acc);
                     Tm[r][i] = acc;
                 }
                 FK_STAGE();
@@ -613,19 +697,29 @@ rts_ml_kernel(const RtsArgs a)
         }
         // Pp = F T + Q (own rows)
         double Pp[R][NX];
+        double fq[2][R];                           // this lane's column q of F one iteration ahead
+        FK_UNROLL for (int r = 0; r < R; ++r) fq[0][r] = myF[r * NX];
         FK_UNROLL for (int q = 0; q < NX; ++q) {
+            if (q + 1 < NX) {
+                FK_UNROLL for (int r = 0; r < R; ++r) fq[(q + 1) & 1][r] = myF[r * NX + q + 1];
+            }
             double Tq[NX];
             FK_ROW_FROM_OWNER(Tq, Tm, q, NX);
             FK_UNROLL for (int r = 0; r < R; ++r) {
-                const double f = myF[r * NX + q];
+                const double f = fq[q & 1][r];
                 FK_UNROLL for (int j = 0; j < NX; ++j) Pp[r][j] = (q == 0) ? f * Tq[j] : fma(f, Tq[j], Pp[r][j]);
             }
             FK_STAGE();
         }
         {
             const MlView oPp(a.Pp + k * ps_blk, off_rows, estride, pair_rows);
-            FK_UNROLL for (int r = 0; r < R; ++r)
-                FK_UNROLL for (int j = 0; j < NX; ++j) Pp[r][j] += myQ[r * NX + j];
+            // (Q's 27 values in one batch, then the sums: left to itself the compiler interleaves one read, one wait, one add)
+            FK_UNROLL for (int r = 0; r < R; ++r) {
+                double Qr[NX];
+                FK_UNROLL for (int j = 0; j < NX; ++j) Qr[j] = myQ[r * NX + j];
+                FK_STAGE();
+                FK_UNROLL for (int j = 0; j < NX; ++j) Pp[r][j] += Qr[j];
+            }
             if constexpr (AOS) ml_store_rows_aos_park<R, NX, BLOCK>(Pp, a.Pp + (k * N + w0) * NX * NX, park, lane, wave, Lc, valid);
             else store_rows<R, NX, MODE>(oPp, Pp);
         }
@@ -663,9 +757,14 @@ rts_ml_kernel(const RtsArgs a)
         {
             double x[NX], dx[NX];
             FK_UNROLL for (int i = 0; i < NX; ++i) x[i] = park[R * NX + i][threadIdx.x];
+            double Fr[2][NX];
+            FK_UNROLL for (int q = 0; q < NX; ++q) Fr[0][q] = sF[q];
             FK_UNROLL for (int i = 0; i < NX; ++i) {
-                double acc = sF[i * NX] * x[0];
-                FK_UNROLL for (int q = 1; q < NX; ++q) acc = fma(sF[i * NX + q], x[q], acc);
+                if (i + 1 < NX) {
+                    FK_UNROLL for (int q = 0; q < NX; ++q) Fr[(i + 1) & 1][q] = sF[(i + 1) * NX + q];
+                }
+                double acc = Fr[i & 1][0] * x[0];
+                FK_UNROLL for (int q = 1; q < NX; ++q) acc = fma(Fr[i & 1][q], x[q], acc);
                 dx[i] = xn[i] - acc;
                 FK_STAGE();
             }
@@ -689,10 +788,13 @@ rts_ml_kernel(const RtsArgs a)
             load_rows<R, NX, MODE>(vP, Pn);
             double dxr[NX];
             FK_UNROLL for (int i = 0; i < NX; ++i) dxr[i] = park[NX + i][threadIdx.x];
+            double xp[2];
+            xp[0] = park[0][threadIdx.x];
             FK_UNROLL for (int j = 0; j < NX; ++j) {
+                if (j + 1 < NX) xp[(j + 1) & 1] = park[j + 1][threadIdx.x];
                 double Kj[NX];
                 FK_ROW_FROM_OWNER(Kj, Tm, j, NX);
-                double xa = park[j][threadIdx.x];
+                double xa = xp[j & 1];
                 FK_UNROLL for (int q = 0; q < NX; ++q) xa = fma(Kj[q], dxr[q], xa);
                 xn[j] = xa;
                 FK_UNROLL for (int r = 0; r < R; ++r) {
@@ -828,5 +930,6 @@ int launch_kf_ml_9_3_var(const KfArgs &a, int layout, hipStream_t s)
 #endif   // FK_ML_PART != 1
 
 #undef HX
+#undef FK_ML_PRIOR_STORES
 
 }  // namespace fk

@@ -21,6 +21,7 @@
 // wave per SIMD: at dim_x = 16 a lane holds P (64 doubles) and T (64) at once.  Per-track models, the update's
 // by-products and dim_z > 4 at these sizes stay on the padded kernels.
 #include <stdlib.h>
+#include <type_traits>
 
 #include "fk_device.hpp"
 #include "fk_math_sym.hpp"
@@ -80,28 +81,28 @@ __device__ __forceinline__ void mlg_store_aos(const double (&x)[NX], const doubl
     ml_wave_fence();
     const rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(xdst, 0, (int)(valid * (unsigned)NX * 8u), 0x00020000);
     const rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc(Pdst, 0, (int)(valid * (unsigned)EP * 8u), 0x00020000);
-    FK_UNROLL for (int it = 0; it * 64 < UX; ++it) {
-        const unsigned unit = it * 64u + lane;
-        if (it * 64 + 63 < UX || unit < (unsigned)UX) {
-            const u32x4 v = *reinterpret_cast<const u32x4 *>(tx + 2 * unit);
-            __builtin_amdgcn_raw_buffer_store_b128(v, rx, unit * 16u, 0, 0);
-        }
-    }
-    _Pragma("unroll 4") for (int it = 0; it * 64 < UP; ++it) {
-        const unsigned unit = it * 64u + lane;
-        if (it * 64 + 63 < UP || unit < (unsigned)UP) {
-            const u32x4 v = *reinterpret_cast<const u32x4 *>(tP + 2 * unit);
-            __builtin_amdgcn_raw_buffer_store_b128(v, rP, unit * 16u, 0, 0);
-        }
-    }
+    // (reads in batches ahead of their stores: ml_copy_units)
+    ml_copy_units<UX, 4>(lane, [&](unsigned unit) { return tx + 2u * unit; },
+                         [&](unsigned unit, bool ok, const u32x4 &v) {
+                             __builtin_amdgcn_raw_buffer_store_b128(v, rx, ok ? unit * 16u : ML_OFF_DROP, 0, 0);
+                         });
+    ml_copy_units<UP, 4>(lane, [&](unsigned unit) { return tP + 2u * unit; },
+                         [&](unsigned unit, bool ok, const u32x4 &v) {
+                             __builtin_amdgcn_raw_buffer_store_b128(v, rP, ok ? unit * 16u : ML_OFF_DROP, 0, 0);
+                         });
 }
 
 // VAR: batch_filter's other arguments (kalman_filter.py:941-991) exactly as kf_ml.hip's VAR family serves them at (9, 3):
 // one model per step shared by the bank ([F | Q | H | R | B] double-buffered in LDS, fetched a step ahead), a control
 // input x = F x + B u (u[t] travels with z[t]), both as BRANCH-FREE run-time switches; UF (update_first) swaps the
 // halves of the step at compile time (the predict half is kf_mlg_predict.inc, included before or after the update half).
-template <int NX, int NZ, int LAYOUT, bool VAR = false, bool UF = false>
-__global__ void __launch_bounds__(BLOCK, (NX <= 8 ? 3 : NX <= 9 ? 2 : 1))
+// EX: the update's by-products as per-step histories (fk_kf_batch_filter_ex_f64: y, K, S, SI, log-likelihood, mahalanobis --
+// what a Saver or batch_filter(saver=...) asks for, common/helpers.py:121-152) from the plain call without a mask: S^-1, log det S
+// and y' S^-1 y from the factorisation the gain was solved with, exactly as kf_fast / kf_kernel form them; every array
+// leaves through the wave's LDS tile in 16-byte units.  (With a mask the histories carry the LAST K / S / SI across missing
+// measurements: those calls stay on kf_fast's extras instantiations / the generic kernel.)
+template <int NX, int NZ, int LAYOUT, bool VAR = false, bool UF = false, bool EX = false>
+__global__ void __launch_bounds__(BLOCK, (EX ? 1 : NX <= 8 ? 3 : NX <= 9 ? 2 : 1))
 kf_mlg_kernel(const KfArgs a)
 {
     constexpr int R = (NX + 3) / 4;
@@ -114,11 +115,12 @@ kf_mlg_kernel(const KfArgs a)
     constexpr int MPT = (MLEN + BLOCK - 1) / BLOCK;              // model elements a thread fetches per step
     constexpr int MSZ = VAR ? 2 * MSTR : LM::SIZE;
     static_assert(!UF || VAR, "update_first is a VAR instantiation");
+    static_assert(!EX || !VAR, "the by-product histories come with the plain call");
     // SOA covariances leave through an LDS slab as 16-byte units (ml_store_rows_soa_slab) up to dim_x = 12: measured
     // 0.37 -> 0.48 of HBM at (10,2), 0.34 -> 0.35 at (12,3), but 0.39 -> 0.32 at (14,4) -- the larger kernels are bound by
     // their arithmetic and code size, not by store slots (profiles/r02/dims_10_16.jsonl vs dims_10_16_slab.jsonl)
     constexpr bool SOA_SLAB = !AOS && NX <= 12;
-    __shared__ double smem[MSZ + (AOS || SOA_SLAB ? (BLOCK / 64) * TILE : 0)];
+    __shared__ double smem[MSZ + (AOS || SOA_SLAB || EX ? (BLOCK / 64) * TILE : 0)];
     double *tile = smem + MSZ + (threadIdx.x >> 6) * TILE;
     lds_fill<NX, NX>(smem + LM::OFF_F, a.F, NX, NX, 1.0, threadIdx.x);
     lds_fill<NX, NX>(smem + LM::OFF_Q, a.Q, NX, NX, 0.0, threadIdx.x);
@@ -254,30 +256,65 @@ kf_mlg_kernel(const KfArgs a)
         // (kf_ml.hip explains why H P is not replaced by (P H')'):
         //   T1 = (I-KH) P = P - K (H P) ;  G = T1 H' ;  P+ = T1 (I-KH)' + K R K' = T1 + (K R - G) K'
         double y[NZ], K[R][NZ];
+        double exLf[EX ? NZ * NZ : 1], exdinv[EX ? NZ : 1];     // EX: the factor of S, kept for S^-1 at the end of the step
+        [[maybe_unused]] const unsigned g = lane >> 2;
+        // BRANCH-FREE like every other run-time switch of these kernels (a branch inside the time loop splits its one basic
+        // block and the register allocation falls apart: 0.2 -> 1.6 KB of scratch per lane measured here): a history the caller
+        // did not ask for is written through a descriptor of zero tracks -- the stores are issued and dropped
+        [[maybe_unused]] auto ex_out = [&](double *hist, auto e_tag) {
+            constexpr int E = decltype(e_tag)::value;
+            double *dst = hist ? hist : a.means;
+            const unsigned vv = hist ? valid : 0u;
+            if constexpr (AOS) ml_tile_out_aos<E, 16>(dst + (t * N + w0) * E, tile, lane, vv);
+            else ml_tile_out_soa<E, 16>(dst + t * N * E, N, w0, tile, lane, vv);
+        };
+        [[maybe_unused]] auto ex_scalar = [&](double *hist, double v) {
+            double *dst = hist ? hist : a.means;
+            const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(dst + t * N, 0, hist ? (int)((unsigned)N * 8u) : 0, 0x00020000);
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), rs, (unsigned)trk * 8u, 0, 0);
+        };
+#define FK_TILE_AT(E, e) tile[AOS ? g * (unsigned)(E) + (unsigned)(e) : (unsigned)(e) * 16u + g]
         {
-            FK_UNROLL for (int c = 0; c < NZ; ++c) {
-                double acc = sH[c * NX] * x[0];
-                FK_UNROLL for (int k = 1; k < NX; ++k) acc = fma(sH[c * NX + k], x[k], acc);
-                y[c] = z[c] - acc;
-            }
+            // Row c of H serves y[c] and column c of P H' in one pass and is requested one row ahead (kf_mlg_predict.inc);
+            // column k of H for S likewise, R in front of the sums it closes
             double PHT[R][NZ], S[NZ * NZ];
-            FK_UNROLL for (int r = 0; r < R; ++r) {
+            {
+                double Hr[2][NX];
+                FK_UNROLL for (int k = 0; k < NX; ++k) Hr[0][k] = sH[k];
                 FK_UNROLL for (int c = 0; c < NZ; ++c) {
-                    double acc = P[r][0] * sH[c * NX];
-                    FK_UNROLL for (int k = 1; k < NX; ++k) acc = fma(P[r][k], sH[c * NX + k], acc);
-                    PHT[r][c] = acc;
+                    if (c + 1 < NZ) {
+                        FK_UNROLL for (int k = 0; k < NX; ++k) Hr[(c + 1) & 1][k] = sH[(c + 1) * NX + k];
+                    }
+                    const double (&Hc)[NX] = Hr[c & 1];
+                    double acc = Hc[0] * x[0];
+                    FK_UNROLL for (int k = 1; k < NX; ++k) acc = fma(Hc[k], x[k], acc);
+                    y[c] = z[c] - acc;
+                    FK_UNROLL for (int r = 0; r < R; ++r) {
+                        double pa = P[r][0] * Hc[0];
+                        FK_UNROLL for (int k = 1; k < NX; ++k) pa = fma(P[r][k], Hc[k], pa);
+                        PHT[r][c] = pa;
+                    }
+                    FK_STAGE();
                 }
-                FK_STAGE();
             }
             // S = H PHT + R, replicated in every lane: PHT's row k comes from its owner
-            FK_UNROLL for (int k = 0; k < NX; ++k) {
-                double pk[NZ];
-                FK_OWNER_ROW(pk, PHT, k, NZ);
-                FK_UNROLL for (int r = 0; r < NZ; ++r)
-                    FK_UNROLL for (int c = 0; c < NZ; ++c)
-                        S[r * NZ + c] = (k == 0) ? sH[r * NX] * pk[c] : fma(sH[r * NX + k], pk[c], S[r * NZ + c]);
+            {
+                double hk[2][NZ], Rs[NZ * NZ];
+                FK_UNROLL for (int r = 0; r < NZ; ++r) hk[0][r] = sH[r * NX];
+                FK_UNROLL for (int e = 0; e < NZ * NZ; ++e) Rs[e] = sR[e];
+                FK_UNROLL for (int k = 0; k < NX; ++k) {
+                    if (k + 1 < NX) {
+                        FK_UNROLL for (int r = 0; r < NZ; ++r) hk[(k + 1) & 1][r] = sH[r * NX + k + 1];
+                    }
+                    double pk[NZ];
+                    FK_OWNER_ROW(pk, PHT, k, NZ);
+                    FK_UNROLL for (int r = 0; r < NZ; ++r)
+                        FK_UNROLL for (int c = 0; c < NZ; ++c)
+                            S[r * NZ + c] = (k == 0) ? hk[k & 1][r] * pk[c] : fma(hk[k & 1][r], pk[c], S[r * NZ + c]);
+                    if (k % 4 == 3) FK_STAGE();
+                }
+                FK_UNROLL for (int e = 0; e < NZ * NZ; ++e) S[e] += Rs[e];
             }
-            FK_UNROLL for (int e = 0; e < NZ * NZ; ++e) S[e] += sR[e];
             FK_STAGE();
             double Lf[NZ * NZ], d[NZ], dinv[NZ], Kr[R * NZ];
             FK_UNROLL for (int e = 0; e < NZ * NZ; ++e) Lf[e] = S[e];
@@ -287,15 +324,55 @@ kf_mlg_kernel(const KfArgs a)
             solve_rows_ldlt<R, NZ>(Lf, dinv, Kr);
             FK_UNROLL for (int r = 0; r < R; ++r)
                 FK_UNROLL for (int c = 0; c < NZ; ++c) K[r][c] = has_z ? Kr[r * NZ + c] : 0.0;
+            if constexpr (EX) {
+                // early: y, S and the two scalars (the residual is spent by the state update, S by nothing else); the factor
+                // (Lf, dinv) stays live to the end of the step, where K and S^-1 leave -- the step's register peak lies between
+                double logdet, q = 0.0;
+                if constexpr (NZ == 1) {
+                    logdet = log(S[0]);
+                    q = y[0] * y[0] * dinv[0];
+                } else {
+                    double w[NZ];
+                    FK_UNROLL for (int i = 0; i < NZ; ++i) {
+                        double acc = y[i];
+                        FK_UNROLL for (int k2 = 0; k2 < NZ; ++k2)
+                            if (k2 < i) acc = fma(-Lf[i * NZ + k2], w[k2], acc);
+                        w[i] = acc;
+                        q = fma(acc * acc, dinv[i], q);
+                    }
+                    logdet = logdet_from_dinv<NZ>(dinv, NZ);
+                }
+                {
+                    ml_wave_fence();
+                    FK_UNROLL for (int c = 0; c < NZ; ++c) FK_TILE_AT(NZ, c) = y[c];
+                    ml_wave_fence();
+                    ex_out(a.y_out, std::integral_constant<int, NZ>{});
+                }
+                {
+                    ml_wave_fence();
+                    FK_UNROLL for (int e = 0; e < NZ * NZ; ++e) FK_TILE_AT(NZ * NZ, e) = S[e];
+                    ml_wave_fence();
+                    ex_out(a.S_out, std::integral_constant<int, NZ * NZ>{});
+                }
+                ml_wave_fence();
+                ex_scalar(a.ll_out, -0.5 * (NZ * 1.8378770664093453 + logdet + q));   // the quad writes the same value
+                ex_scalar(a.maha_out, sqrt(q));
+                FK_UNROLL for (int e = 0; e < NZ * NZ; ++e) exLf[e] = Lf[e];
+                FK_UNROLL for (int e = 0; e < NZ; ++e) exdinv[e] = dinv[e];
+            }
         }
         FK_STAGE();
         {
             // H P: this lane's OWN rows contribute sum_r H[c][row r] P[r][:] (a clamped duplicate: coefficient 0);
             // the quad adds the four parts
-            double HP[NZ][NX];
+            double HP[NZ][NX], hcn[2][R];
+            FK_UNROLL for (int r = 0; r < R; ++r) hcn[0][r] = sH[row[r]];
             FK_UNROLL for (int c = 0; c < NZ; ++c) {
+                if (c + 1 < NZ) {
+                    FK_UNROLL for (int r = 0; r < R; ++r) hcn[(c + 1) & 1][r] = sH[(c + 1) * NX + row[r]];
+                }
                 double hc[R];
-                FK_UNROLL for (int r = 0; r < R; ++r) hc[r] = live[r] * sH[c * NX + row[r]];
+                FK_UNROLL for (int r = 0; r < R; ++r) hc[r] = live[r] * hcn[c & 1][r];
                 FK_UNROLL for (int j = 0; j < NX; ++j) {
                     double acc = hc[0] * P[0][j];
                     FK_UNROLL for (int r = 1; r < R; ++r) acc = fma(hc[r], P[r][j], acc);
@@ -314,15 +391,26 @@ kf_mlg_kernel(const KfArgs a)
             }
             // D = K R - T1 H' (own rows)
             double D[R][NZ];
-            FK_UNROLL for (int r = 0; r < R; ++r)
+            {
+                double Hr[2][NX], Rc[2][NZ];             // row c of H and column c of R one iteration ahead
+                FK_UNROLL for (int k = 0; k < NX; ++k) Hr[0][k] = sH[k];
+                FK_UNROLL for (int q = 0; q < NZ; ++q) Rc[0][q] = sR[q * NZ];
                 FK_UNROLL for (int c = 0; c < NZ; ++c) {
-                    double kr = K[r][0] * sR[c];
-                    FK_UNROLL for (int q = 1; q < NZ; ++q) kr = fma(K[r][q], sR[q * NZ + c], kr);
-                    double g = P[r][0] * sH[c * NX];
-                    FK_UNROLL for (int k = 1; k < NX; ++k) g = fma(P[r][k], sH[c * NX + k], g);
-                    D[r][c] = kr - g;
+                    if (c + 1 < NZ) {
+                        FK_UNROLL for (int k = 0; k < NX; ++k) Hr[(c + 1) & 1][k] = sH[(c + 1) * NX + k];
+                        FK_UNROLL for (int q = 0; q < NZ; ++q) Rc[(c + 1) & 1][q] = sR[q * NZ + c + 1];
+                    }
+                    const double (&Hc)[NX] = Hr[c & 1];
+                    FK_UNROLL for (int r = 0; r < R; ++r) {
+                        double kr = K[r][0] * Rc[c & 1][0];
+                        FK_UNROLL for (int q = 1; q < NZ; ++q) kr = fma(K[r][q], Rc[c & 1][q], kr);
+                        double g = P[r][0] * Hc[0];
+                        FK_UNROLL for (int k = 1; k < NX; ++k) g = fma(P[r][k], Hc[k], g);
+                        D[r][c] = kr - g;
+                    }
+                    FK_STAGE();
                 }
-            FK_STAGE();
+            }
             // P+ = T1 + D K' : column j needs K's row j from its owner; the same row updates x[j]
             FK_UNROLL for (int j = 0; j < NX; ++j) {
                 double Kj[NZ];
@@ -337,6 +425,26 @@ kf_mlg_kernel(const KfArgs a)
                 }
             }
         }
+        if constexpr (EX) {
+            // late: the gain (own rows) and S^-1 from the kept factor, as kf_fast / kf_kernel form it (inv_from_ldlt)
+            {
+                ml_wave_fence();
+                FK_UNROLL for (int r = 0; r < R; ++r)
+                    FK_UNROLL for (int c = 0; c < NZ; ++c) FK_TILE_AT(NX * NZ, row[r] * (unsigned)NZ + (unsigned)c) = K[r][c];
+                ml_wave_fence();
+                ex_out(a.K_out, std::integral_constant<int, NX * NZ>{});
+            }
+            {
+                double SI[NZ * NZ];
+                inv_from_ldlt<NZ>(exLf, exdinv, SI);
+                ml_wave_fence();
+                FK_UNROLL for (int e = 0; e < NZ * NZ; ++e) FK_TILE_AT(NZ * NZ, e) = SI[e];
+                ml_wave_fence();
+                ex_out(a.SI_out, std::integral_constant<int, NZ * NZ>{});
+            }
+            ml_wave_fence();
+        }
+#undef FK_TILE_AT
         if constexpr (AOS) {
             mlg_store_aos<R, NX>(x, P, row, a.means + (t * N + w0) * NX, a.covs + (t * N + w0) * NX * NX, tile, lane, valid);
         } else {
@@ -403,6 +511,17 @@ int FK_MLG_CAT(launch_kf_mlg_, FK_NX, FK_NZ)(const KfArgs &a, int layout, bool o
 {
     using namespace FK_MLG_CAT(mlg_, FK_NX, FK_NZ);
     if ((model_mode != FK_MODEL_SHARED && model_mode != FK_MODEL_PER_STEP) || a.n != FK_NX || a.m != FK_NZ || !outs) return 1;
+    if (a.y_out || a.K_out || a.S_out || a.SI_out || a.ll_out || a.maha_out) {
+        // the by-product histories: the plain call without a mask (EX instantiations)
+        if (model_mode != FK_MODEL_SHARED || a.nu > 0 || a.update_first || a.mask || !a.extras_per_step) return 1;
+        auto onex = [layout](const KfArgs &b, hipStream_t sb) -> int {
+            const dim3 gb((unsigned)((b.cnt + BLOCK / 4 - 1) / (BLOCK / 4))), bb(BLOCK);
+            if (layout == FK_LAYOUT_AOS) hipLaunchKernelGGL((kf_mlg_kernel<FK_NX, FK_NZ, LAYOUT_AOS, false, false, true>), gb, bb, 0, sb, b);
+            else hipLaunchKernelGGL((kf_mlg_kernel<FK_NX, FK_NZ, LAYOUT_SOA, false, false, true>), gb, bb, 0, sb, b);
+            return check_launch("kf_mlg_kernel<ex>");
+        };
+        return kf_chunked_call(a, FK_NX, FK_NZ, 1024, onex, s);      // one wave per SIMD at every size
+    }
     if (model_mode == FK_MODEL_PER_STEP || a.nu > 0 || a.update_first) {
         // the VAR instantiations (FK_ML_VAR=0 sends these calls back to the padded kernel)
         const char *vv = getenv("FK_ML_VAR");

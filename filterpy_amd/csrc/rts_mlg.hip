@@ -51,13 +51,10 @@ __device__ __forceinline__ void store_rows_aos(const double (&M)[R][NX], const u
         FK_UNROLL for (int c = 0; c < NX; ++c) tile[q * EP + row[r] * NX + c] = M[r][c];
     ml_wave_fence();
     const rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc(dst, 0, (int)(valid * (unsigned)EP * 8u), 0x00020000);
-    _Pragma("unroll 4") for (int it = 0; it * 64 < UP; ++it) {
-        const unsigned unit = it * 64u + lane;
-        if (it * 64 + 63 < UP || unit < (unsigned)UP) {
-            const u32x4 v = *reinterpret_cast<const u32x4 *>(tile + 2 * unit);
-            __builtin_amdgcn_raw_buffer_store_b128(v, rP, unit * 16u, 0, 0);
-        }
-    }
+    ml_copy_units<UP, 4>(lane, [&](unsigned unit) { return tile + 2u * unit; },
+                         [&](unsigned unit, bool ok, const u32x4 &v) {
+                             __builtin_amdgcn_raw_buffer_store_b128(v, rP, ok ? unit * 16u : ML_OFF_DROP, 0, 0);
+                         });
 }
 
 template <int NX, int LAYOUT>
@@ -174,11 +171,17 @@ rts_mlg_kernel(const RtsArgs a)
             FK_ROWS_HERE();
             double P[R][NX];
             FK_LOAD_ROWS(a.Ps + k * ps_blk, P);
-            // T = P F'
+            // T = P F'  (F's rows requested from LDS one iteration ahead -- two row buffers --: a ds_read -> s_waitcnt pair per
+            // row exposed the LDS latency NX times per stage; same sums in the same order)
+            double Fr[2][NX];
+            FK_UNROLL for (int q = 0; q < NX; ++q) Fr[0][q] = sF[q];
             FK_UNROLL for (int i = 0; i < NX; ++i) {
+                if (i + 1 < NX) {
+                    FK_UNROLL for (int q = 0; q < NX; ++q) Fr[(i + 1) & 1][q] = sF[(i + 1) * NX + q];
+                }
                 FK_UNROLL for (int r = 0; r < R; ++r) {
-                    double acc = P[r][0] * sF[i * NX];
-                    FK_UNROLL for (int q = 1; q < NX; ++q) acc = fma(P[r][q], sF[i * NX + q], acc);
+                    double acc = P[r][0] * Fr[i & 1][0];
+                    FK_UNROLL for (int q = 1; q < NX; ++q) acc = fma(P[r][q], Fr[i & 1][q], acc);
                     Tm[r][i] = acc;
                 }
                 FK_STAGE();
@@ -189,17 +192,27 @@ rts_mlg_kernel(const RtsArgs a)
             // Pp = F T + Q (own rows)
             FK_ROWS_HERE();
             double Pp[R][NX];
+            double fq[2][R];                                   // this lane's column q of F one iteration ahead
+            FK_UNROLL for (int r = 0; r < R; ++r) fq[0][r] = sF[row[r] * NX];
             FK_UNROLL for (int q = 0; q < NX; ++q) {
+                if (q + 1 < NX) {
+                    FK_UNROLL for (int r = 0; r < R; ++r) fq[(q + 1) & 1][r] = sF[row[r] * NX + q + 1];
+                }
                 double Tq[NX];
                 FK_OWNER_ROW(Tq, Tm, q, NX);
                 FK_UNROLL for (int r = 0; r < R; ++r) {
-                    const double f = sF[row[r] * NX + q];
+                    const double f = fq[q & 1][r];
                     FK_UNROLL for (int j = 0; j < NX; ++j) Pp[r][j] = (q == 0) ? f * Tq[j] : fma(f, Tq[j], Pp[r][j]);
                 }
                 FK_STAGE();
             }
-            FK_UNROLL for (int r = 0; r < R; ++r)
-                FK_UNROLL for (int j = 0; j < NX; ++j) Pp[r][j] += sQ[row[r] * NX + j];
+            // (a row of Q in one batch, then its sums)
+            FK_UNROLL for (int r = 0; r < R; ++r) {
+                double Qr[NX];
+                FK_UNROLL for (int j = 0; j < NX; ++j) Qr[j] = sQ[row[r] * NX + j];
+                FK_STAGE();
+                FK_UNROLL for (int j = 0; j < NX; ++j) Pp[r][j] += Qr[j];
+            }
             if constexpr (AOS || SOA_SLAB) {
                 // the staging slab is the park: lift the parked Pn out, ship Pp, put D = Pn - Pp back
                 double Pn[R][NX];
@@ -309,10 +322,16 @@ rts_mlg_kernel(const RtsArgs a)
                 FK_UNROLL for (int i = 0; i < NX; ++i) x[i] = vx.load(i);
             }
             ml_wave_fence();
+            double Fr[2][NX], xpk[NX];
+            FK_UNROLL for (int q = 0; q < NX; ++q) Fr[0][q] = sF[q];
+            FK_UNROLL for (int i = 0; i < NX; ++i) xpk[i] = xpark[i];
             FK_UNROLL for (int i = 0; i < NX; ++i) {
-                double acc = sF[i * NX] * x[0];
-                FK_UNROLL for (int q = 1; q < NX; ++q) acc = fma(sF[i * NX + q], x[q], acc);
-                dx[i] = xpark[i] - acc;
+                if (i + 1 < NX) {
+                    FK_UNROLL for (int q = 0; q < NX; ++q) Fr[(i + 1) & 1][q] = sF[(i + 1) * NX + q];
+                }
+                double acc = Fr[i & 1][0] * x[0];
+                FK_UNROLL for (int q = 1; q < NX; ++q) acc = fma(Fr[i & 1][q], x[q], acc);
+                dx[i] = xpk[i] - acc;
                 FK_STAGE();
             }
             double xn[NX];

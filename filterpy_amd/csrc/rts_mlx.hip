@@ -50,13 +50,10 @@ __device__ __forceinline__ void store_rows_aos(const double (&M)[R][NX], const u
         FK_UNROLL for (int c = 0; c < NX; ++c) tile[g * EP + row[r] * NX + c] = M[r][c];
     ml_wave_fence();
     const rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc(dst, 0, (int)(valid * (unsigned)EP * 8u), 0x00020000);
-    _Pragma("unroll 4") for (int it = 0; it * 64 < UP; ++it) {
-        const unsigned unit = it * 64u + lane;
-        if (it * 64 + 63 < UP || unit < (unsigned)UP) {
-            const u32x4 v = *reinterpret_cast<const u32x4 *>(tile + 2 * unit);
-            __builtin_amdgcn_raw_buffer_store_b128(v, rP, unit * 16u, 0, 0);
-        }
-    }
+    ml_copy_units<UP, 4>(lane, [&](unsigned unit) { return tile + 2u * unit; },
+                         [&](unsigned unit, bool ok, const u32x4 &v) {
+                             __builtin_amdgcn_raw_buffer_store_b128(v, rP, ok ? unit * 16u : ML_OFF_DROP, 0, 0);
+                         });
     ml_wave_fence();
 }
 

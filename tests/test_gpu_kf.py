@@ -856,6 +856,69 @@ def test_saver_histories_from_the_specialised_kernel(n, m, layout, monkeypatch):
 
 
 @pytest.mark.parametrize("layout", ["soa", "aos"])
+@pytest.mark.parametrize("n,m", [(9, 3), (10, 1), (10, 2), (11, 3), (12, 3), (12, 5), (13, 4), (14, 2), (15, 3), (16, 4), (16, 8)])
+def test_saver_histories_from_the_four_lane_kernel(n, m, layout, monkeypatch):
+    """Round 4 (VERDICT r3 missing 4): the by-product histories at dim_x >= 10 -- and (9,3) -- come from kf_mlg's EX
+    instantiations (four lanes per track; every history leaves through the wave's LDS tile) instead of the padded
+    generic kernel: against the oracle on sample tracks, against the generic kernel (FK_NO_MLG_EX=1) on every track
+    of a ragged bank, with a subset of the histories (absent ones are written through zero-track descriptors), with
+    the four regular outputs equal to the plain call's BIT FOR BIT, and with a forced time-chunk decomposition
+    (the histories advance with the chunk's window)."""
+    from gpu_util import run_kf_batch
+    rs = np.random.RandomState(100 * n + m)
+    N, T = 333, 9
+    A = rs.randn(N, n, n)
+    x0, P0 = rs.randn(N, n), 3.0 * (A @ A.transpose(0, 2, 1) / n + 0.5 * np.eye(n))
+    zs = rs.randn(T, N, m) * 2
+    F = np.eye(n) + 0.05 * rs.randn(n, n)
+    F /= max(1.0, 1.05 * np.max(np.abs(np.linalg.eigvals(F))))
+    B = rs.randn(n, n)
+    Q = 0.1 * (B @ B.T / n + 0.5 * np.eye(n))
+    H = rs.randn(m, n)
+    C = rs.randn(m, m)
+    R = 0.5 * (C @ C.T / m + 0.5 * np.eye(m))
+    outs, hist = _run_ex(x0, P0, zs, F, Q, H, R, layout)
+    with monkeypatch.context() as mp:
+        mp.setenv("FK_NO_MLG_EX", "1")
+        mp.setenv("FK_NO_FAST_EX", "1")
+        outs_g, hist_g = _run_ex(x0, P0, zs, F, Q, H, R, layout)
+    for a, b in zip(outs, outs_g):
+        assert rel_err_rows(_per_track(a), _per_track(b)) < TOL
+    plain = run_kf_batch(x0, P0, zs, F, Q, H, R, layout=layout)
+    for a, b in zip(outs, plain[:4]):
+        if n >= 10:
+            assert np.array_equal(a, b)           # the same arithmetic as the plain four-lane kernel
+        else:
+            assert rel_err_rows(_per_track(a), _per_track(b)) < TOL      # (9,3): the plain call runs on the three-lane kernel
+    for k in hist:
+        assert np.isfinite(hist[k]).all(), k
+        assert np.allclose(hist[k], hist_g[k], rtol=1e-10, atol=1e-11), k
+    for i in [0, 15, 16, 63, 64, 255, 256, N - 1]:
+        x, P = x0[i].copy(), P0[i].copy()
+        for t in range(T):
+            x, P = kf_oracle.kf_predict(x, P, F, Q)
+            x, P, y, K, S, SI = kf_oracle.kf_update(x, P, zs[t, i], R, H)
+            ll, mh = kf_oracle.log_likelihood(y, S), kf_oracle.mahalanobis(y, SI)
+            for key, ref in (("y", y), ("K", K), ("S", S), ("SI", SI)):
+                assert rel_err_rows(hist[key][t, i].reshape(1, -1), np.asarray(ref).reshape(1, -1)) < TOL, (key, t, i)
+            assert abs(hist["log_likelihood"][t, i] - ll) <= 1e-10 * max(1.0, abs(ll)), (t, i)
+            assert abs(hist["mahalanobis"][t, i] - mh) <= 1e-10 * max(1.0, mh), (t, i)
+    # subsets: the absent histories' stores are dropped, the present ones keep their bits
+    for keys in (("log_likelihood",), ("K", "mahalanobis"), ("y", "SI")):
+        _, h1 = _run_ex(x0, P0, zs, F, Q, H, R, layout, keys=keys)
+        for k in keys:
+            assert np.array_equal(h1[k], hist[k]), (keys, k)
+    # a forced decomposition into track groups x time chunks: same bits
+    with monkeypatch.context() as mp:
+        mp.setenv("FK_ML_CHUNKS", "2,3")
+        outs_c, hist_c = _run_ex(x0, P0, zs, F, Q, H, R, layout)
+    for a, b in zip(outs, outs_c):
+        assert np.array_equal(a, b)
+    for k in hist:
+        assert np.array_equal(hist[k], hist_c[k]), k
+
+
+@pytest.mark.parametrize("layout", ["soa", "aos"])
 @pytest.mark.parametrize("n,m", [(1, 1), (2, 1), (3, 2), (4, 2), (5, 3), (6, 3), (7, 2), (8, 4), (9, 4), (9, 3)])
 def test_interleaved_covariance_histories_equal_two_arrays_bit_for_bit(n, m, layout):
     """FK_KF_FLAG_COV_INTERLEAVED (the kernel-side cure of the placement lottery): both covariance histories

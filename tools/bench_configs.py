@@ -234,11 +234,17 @@ def config_extras(layout, n, m, N, T):
         P.copy_(P0)
         E.kf_batch_filter_ex(desc, *mods, z, x, P, ex, means=outs[0], covs=outs[1], means_p=outs[2], covs_p=outs[3], status=st)
     nbytes = 8 * (m + 2 * n + 2 * n * n + m + n * m + 2 * m * m + 2)
-    for env, name in ((None, "kf_fast extras"), ("1", "generic kernel")):
-        if env:
-            os.environ["FK_NO_FAST_EX"] = env
-        ms = timeit(run, warm=1, reps=3)
+    # (dim_x >= 10 and (9,3): the four-lane kernel's EX instantiations by default; FK_NO_MLG_EX=1 -> kf_fast's extras / generic)
+    mlg = n >= 10 or (n, m) == (9, 3)
+    rows = ([(None, None, "four-lane EX")] if mlg else []) + ([("1", None, "kf_fast extras")] if n <= 9 else []) + [("1", "1", "generic kernel")]
+    for no_mlg, no_fast, name in rows:
+        if no_mlg:
+            os.environ["FK_NO_MLG_EX"] = no_mlg
+        if no_fast:
+            os.environ["FK_NO_FAST_EX"] = no_fast
+        ms = timeit(run, warm=1, reps=3 if name != "generic kernel" or n < 10 else 1)
         os.environ.pop("FK_NO_FAST_EX", None)
+        os.environ.pop("FK_NO_MLG_EX", None)
         assert not st.any()
         emit(f"KF ({n},{m}) batch_filter + six Saver histories, {name}, N={N} {layout}", N * T, "track-steps", ms, nbytes)
 
@@ -434,6 +440,8 @@ if __name__ == "__main__":
             config_extras(lay, 4, 2, 500_000, a.T)
             config_extras(lay, 6, 3, 200_000, a.T)
             config_extras(lay, 9, 3, 100_000, a.T)
+            config_extras(lay, 12, 3, 100_000, a.T)
+            config_extras(lay, 16, 4, 60_000, a.T)
         if "6" in a.configs:
             config_kf(lay, 6, 3, 300_000, a.T)
             config_kf(lay, 4, 2, 500_000, a.T)
