@@ -47,6 +47,17 @@ __device__ __forceinline__ rsrc_t make_rsrc(const void *p)
 
 using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
 
+// The wave's index in its workgroup as a SCALAR.  threadIdx.x >> 6 is the same in every lane of a wave, but the compiler
+// does not know it: everything derived from it (the wave's first track, the base address and the size of the slab it
+// writes) sits in VGPRs, a buffer descriptor built from those is "divergent", and every access through it is wrapped in
+// a waterfall loop (4 v_readfirstlane + 2 v_cmp + s_and_saveexec + a branch per store: 26 of them per step in the
+// NumPy-order three-lane kernel, each splitting the time loop's basic block).  One v_readfirstlane here makes the whole
+// chain scalar (round 4; found in the ISA of the LDS-exchange build).
+__device__ __forceinline__ unsigned wave_index()
+{
+    return (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+}
+
 // Per-lane view of one record block `blk` ([N][E] AOS / [E][N] SOA) for the lane's workgroup.
 template <int LAYOUT>
 struct RecView {

@@ -4,6 +4,13 @@
 #include <type_traits>
 #include "fk_device.hpp"
 
+// element-major covariances of the four-lane kernels leave through the LDS slab (ml_store_rows_soa_slab) up to this dim_x;
+// above it: 8-byte stores per lane.  (Round 2 measured the slab as a loss above 12 -- with a copy-out that cost a division,
+// two address computations, two exec regions and a waterfall loop per unit; round 4's ml_slab_out_soa has none of those.)
+#ifndef FK_SOA_SLAB_MAX
+#define FK_SOA_SLAB_MAX 16
+#endif
+
 namespace fk {
 
 // FK_QUAD_SWIZZLE (build-time A/B): the broadcast through ds_swizzle_b32 (quad-permute mode: the LDS crossbar, no memory
@@ -166,6 +173,68 @@ __device__ __forceinline__ void ml_copy_units(unsigned lane, Addr &&addr, Store 
 // make_rsrc spans 4 GiB and drops nothing -- the element-major copy-outs predicate their stores instead)
 constexpr unsigned ML_OFF_DROP = 0xfffffff0u;
 
+// Element-major copy-out of a wave's staged block: tile[e * TPW + g] (element e of the wave's track g), E elements, TPW tracks
+// (HP = TPW / 2 track pairs).  Read as 16-byte units the tile is LINEAR (unit u = element u / HP, pair u % HP sits at byte 16 u),
+// and in memory unit u lands at (u / HP) * n8 + (u % HP) * 16 from the wave's first track of element 0: with u = 64 it + lane
+// that is one per-lane offset (lane / HP) * n8 + (lane % HP) * 16 plus a wave-uniform (64 / HP) it n8, and whether a lane's track pair exists
+// (2 p + 1 < valid; == valid: its first track only) does not depend on `it` at all -- ONE predicate per copy-out, hoisted
+// around each batch of stores, instead of a division, two address computations and two exec regions per unit (the unit
+// addresses of a plain loop were held in ~20 VGPRs across the time loop or spilled and reloaded behind a vmcnt(0)).
+// NOBRANCH: no exec region at all -- the descriptor ends 32 bytes short of 4 GiB (the host refuses banks whose step block
+// reaches that far), a lane without a track pair stores to ML_OFF_DROP, beyond it, and the odd tail's 8-byte store is issued
+// by every lane with the same select.  Twice the store instructions (half of them dropped by the range check), but straight-
+// line code: the by-product histories of the EX instantiations, where four more predicated regions per step cost 1.5 KB of
+// scratch per lane at dim_x 16.
+template <int E, int TPW = 16, int B = 4, bool NOBRANCH = false>
+__device__ __forceinline__ void ml_slab_out_soa(const double *tile, const double *first, unsigned n8, unsigned lane, unsigned valid)
+{
+    using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+    constexpr int HP = TPW / 2, EPI = 64 / HP;                    // track pairs per element; elements per store instruction
+    static_assert(TPW % 2 == 0 && 64 % HP == 0, "whole elements per store instruction");
+    constexpr int U = E * HP, IT = (U + 63) / 64;
+    const rsrc_t rs = NOBRANCH ? __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(first), 0, (int)0xffffffe0u, 0x00020000) : make_rsrc(first);
+    const unsigned p = lane % (unsigned)HP, voff = (lane / (unsigned)HP) * n8 + p * 16u;
+    const bool full = 2u * p + 1u < valid, half = 2u * p + 1u == valid;
+    auto batch = [&](int it0, auto nb_tag) {
+        constexpr int NB = decltype(nb_tag)::value;
+        u32x4 v[NB];
+        FK_UNROLL for (int b = 0; b < NB; ++b) {
+            const unsigned unit = (unsigned)(it0 + b) * 64u + lane, cu = unit < (unsigned)U ? unit : (unsigned)U - 1u;
+            v[b] = *reinterpret_cast<const u32x4 *>(tile + 2u * cu);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (NOBRANCH) {
+            FK_UNROLL for (int b = 0; b < NB; ++b) {
+                const unsigned unit = (unsigned)(it0 + b) * 64u + lane, off = voff + (unsigned)(it0 + b) * (unsigned)EPI * n8;
+                const bool ok = U % 64 == 0 || unit < (unsigned)U;
+                __builtin_amdgcn_raw_buffer_store_b128(v[b], rs, ok && full ? off : ML_OFF_DROP, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(u32x2{v[b].x, v[b].y}, rs, ok && half ? off : ML_OFF_DROP, 0, 0);
+            }
+        } else if (full) {
+            FK_UNROLL for (int b = 0; b < NB; ++b) {
+                const unsigned unit = (unsigned)(it0 + b) * 64u + lane;
+                if (U % 64 == 0 || unit < (unsigned)U)
+                    __builtin_amdgcn_raw_buffer_store_b128(v[b], rs, voff + (unsigned)(it0 + b) * (unsigned)EPI * n8, 0, 0);
+            }
+        } else if (half) {                                         // an odd tail: the last wave of a launch only
+            FK_UNROLL for (int b = 0; b < NB; ++b) {
+                const unsigned unit = (unsigned)(it0 + b) * 64u + lane;
+                if (U % 64 == 0 || unit < (unsigned)U)
+                    __builtin_amdgcn_raw_buffer_store_b64(u32x2{v[b].x, v[b].y}, rs, voff + (unsigned)(it0 + b) * (unsigned)EPI * n8, 0, 0);
+            }
+        }
+    };
+    if constexpr (IT <= 2 * B) {
+        constexpr int H1 = IT < B ? IT : B;
+        batch(0, std::integral_constant<int, H1>{});
+        if constexpr (IT > B) batch(B, std::integral_constant<int, IT - B>{});
+    } else {
+        constexpr int ITF = IT / B * B;
+        _Pragma("nounroll") for (int it0 = 0; it0 < ITF; it0 += B) batch(it0, std::integral_constant<int, B>{});
+        if constexpr (IT > ITF) batch(ITF, std::integral_constant<int, IT - ITF>{});
+    }
+}
+
 // SOA (element-major, a[e][track]) output of one row-block matrix of a wave's TPW consecutive tracks: the lanes write
 // their rows into a wave-private LDS tile laid out [element][track], then the 64 lanes copy 16-byte units -- two
 // adjacent tracks of one element -- so that a store instruction moves 1 KiB instead of 512 B.  (A wave may have 63
@@ -179,22 +248,12 @@ template <int R, int NX, int TPW>
 __device__ __forceinline__ void ml_store_rows_soa_slab(const double (&M)[R][NX], const unsigned (&row)[R], double *plane0, long N,
                                                        long w0, double *tile, unsigned lane, unsigned g, unsigned valid)
 {
-    constexpr int EP = NX * NX, HP = TPW / 2, UP = EP * HP;          // 16-byte units per element plane / per matrix
-    using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+    constexpr int EP = NX * NX;
     ml_wave_fence();
     FK_UNROLL for (int r = 0; r < R; ++r)
         FK_UNROLL for (int c = 0; c < NX; ++c) tile[(row[r] * NX + c) * TPW + g] = M[r][c];
     ml_wave_fence();
-    const rsrc_t rs = make_rsrc(plane0 + w0);
-    const unsigned n8 = (unsigned)N * 8u;
-    ml_copy_units<UP, 4>(lane,
-        [&](unsigned unit) { return tile + (unit / (unsigned)HP) * TPW + 2u * (unit % (unsigned)HP); },
-        [&](unsigned unit, bool ok, const u32x4 &v) {
-            const unsigned e = unit / (unsigned)HP, p = unit % (unsigned)HP, off = e * n8 + p * 16u;
-            // (predicated, not dropped by offset: this descriptor spans the whole 4 GiB window, nothing is out of its range)
-            if (ok && 2u * p + 1u < valid) __builtin_amdgcn_raw_buffer_store_b128(v, rs, off, 0, 0);
-            else if (ok && 2u * p + 1u == valid) __builtin_amdgcn_raw_buffer_store_b64(u32x2{v.x, v.y}, rs, off, 0, 0);   // odd tail (last wave only)
-        });
+    ml_slab_out_soa<EP, TPW>(tile, plane0 + w0, (unsigned)N * 8u, lane, valid);
     ml_wave_fence();
 }
 
@@ -219,18 +278,7 @@ __device__ __forceinline__ void ml_tile_out_aos(double *dst, const double *tile,
 template <int E, int TPW>
 __device__ __forceinline__ void ml_tile_out_soa(double *plane0, long N, long w0, const double *tile, unsigned lane, unsigned valid)
 {
-    constexpr int HP = TPW / 2, U = E * HP;
-    using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
-    const rsrc_t rs = make_rsrc(plane0 + w0);
-    const unsigned n8 = (unsigned)N * 8u;
-    ml_copy_units<U, 4>(lane,
-        [&](unsigned unit) { return tile + (unit / (unsigned)HP) * TPW + 2u * (unit % (unsigned)HP); },
-        [&](unsigned unit, bool ok, const u32x4 &v) {
-            const unsigned e = unit / (unsigned)HP, p = unit % (unsigned)HP, off = e * n8 + p * 16u;
-            // (predicated, not dropped by offset: this descriptor spans the whole 4 GiB window, nothing is out of its range)
-            if (ok && 2u * p + 1u < valid) __builtin_amdgcn_raw_buffer_store_b128(v, rs, off, 0, 0);
-            else if (ok && 2u * p + 1u == valid) __builtin_amdgcn_raw_buffer_store_b64(u32x2{v.x, v.y}, rs, off, 0, 0);   // odd tail (last wave only)
-        });
+    ml_slab_out_soa<E, TPW, 4, true>(tile, plane0 + w0, (unsigned)N * 8u, lane, valid);
 }
 
 }  // namespace fk

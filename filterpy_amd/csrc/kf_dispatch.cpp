@@ -155,7 +155,8 @@ static int check_desc(const fk_kf_desc *d)
     // larger bank into track windows themselves (kf_windows below); element-major: element e of a step sits e * N * 8 bytes
     // into it whatever the window, so there the caller has to split the bank
     const long E = (long)d->n * (d->n > d->m ? d->n : d->m);
-    if (d->layout == FK_LAYOUT_SOA && (double)d->N * (double)E * 8.0 >= 4294967296.0)
+    // (32 bytes short of it: the by-product histories' copy-out drops stores by an offset just below 4 GiB, fk_ml.hpp)
+    if (d->layout == FK_LAYOUT_SOA && (double)d->N * (double)E * 8.0 >= 4294967296.0 - 32.0)
         return fail(FK_ERR_UNSUPPORTED, "element-major layout: N * dim^2 * 8 bytes must stay below 4 GiB (use FK_LAYOUT_AOS, which is split automatically, or split the bank)");
     return FK_OK;
 }

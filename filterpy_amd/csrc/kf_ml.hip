@@ -128,33 +128,44 @@ __device__ __forceinline__ void ml_store_aos(const double (&x)[NX], const double
     ml_wave_fence();
     const rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(xdst, 0, (int)(valid * (unsigned)NX * 8u), 0x00020000);
     const rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc(Pdst, 0, (int)(valid * (unsigned)EP * 8u), 0x00020000);
-    // every unit is read from the tile FIRST, then the stores go out back to back: read -> wait -> store per unit exposed
-    // the LDS latency thirteen times per output set.  No lane is predicated: a lane past the slab reads a clamped unit and
-    // its store falls outside the descriptor (sized to the wave's valid tracks), which drops it.
-    constexpr int ITX = (UX + 63) / 64, ITP = (UP + 63) / 64;
-    u32x4 vx[ITX], vP[ITP];
-    FK_UNROLL for (int it = 0; it < ITX; ++it) {
-        const unsigned unit = it * 64u + lane, cu = unit < (unsigned)UX ? unit : (unsigned)UX - 1u;
-        vx[it] = *reinterpret_cast<const u32x4 *>(tx + 2 * cu);
-    }
-    FK_UNROLL for (int it = 0; it < ITP; ++it) {
-        const unsigned unit = it * 64u + lane, cu = unit < (unsigned)UP ? unit : (unsigned)UP - 1u;
-        vP[it] = *reinterpret_cast<const u32x4 *>(tP + 2 * cu);
-    }
-    FK_STAGE();
-    FK_UNROLL for (int it = 0; it < ITX; ++it) {
-        const unsigned unit = it * 64u + lane;
-        __builtin_amdgcn_raw_buffer_store_b128(vx[it], rx, unit < (unsigned)UX ? unit * 16u : 0xfffffff0u, 0, 0);
-    }
-    FK_UNROLL for (int it = 0; it < ITP; ++it) {
-        const unsigned unit = it * 64u + lane;
-        __builtin_amdgcn_raw_buffer_store_b128(vP[it], rP, unit < (unsigned)UP ? unit * 16u : 0xfffffff0u, 0, 0);
-    }
+    // units are read from the tile in batches AHEAD of their stores (ml_copy_units: read -> wait -> store per unit exposed the
+    // LDS latency thirteen times per output set); no lane is predicated: a lane past the slab reads a clamped unit and its
+    // store falls outside the descriptor (sized to the wave's valid tracks), which drops it
+    ml_copy_units<UX, 6>(lane, [&](unsigned unit) { return tx + 2u * unit; },
+                         [&](unsigned unit, bool ok, const u32x4 &v) {
+                             __builtin_amdgcn_raw_buffer_store_b128(v, rx, ok ? unit * 16u : ML_OFF_DROP, 0, 0);
+                         });
+    ml_copy_units<UP, 6>(lane, [&](unsigned unit) { return tP + 2u * unit; },
+                         [&](unsigned unit, bool ok, const u32x4 &v) {
+                             __builtin_amdgcn_raw_buffer_store_b128(v, rP, ok ? unit * 16u : ML_OFF_DROP, 0, 0);
+                         });
+}
+
+// element-major twin: the tile is [element][16 tracks] (x's NX planes, then P's NX*NX), copied out by ml_slab_out_soa;
+// xfirst / Pfirst: element 0 of the wave's first track at this time step
+template <int R, int NX>
+__device__ __forceinline__ void ml_store_soa_slab(const double (&x)[NX], const double (&P)[R][NX], double *xfirst, double *Pfirst,
+                                                  unsigned n8, double *tile, unsigned lane, unsigned Lc, unsigned valid)
+{
+    const unsigned q = lane >> 2;
+    double *tx = tile, *tP = tile + 16 * NX;
+    ml_wave_fence();
+    FK_UNROLL for (int k = 0; k < NX; ++k) tx[k * 16 + q] = x[k];                          // the quad writes the same value
+    FK_UNROLL for (int r = 0; r < R; ++r)
+        FK_UNROLL for (int c = 0; c < NX; ++c) tP[(Lc * (R * NX) + r * NX + c) * 16 + q] = P[r][c];
+    ml_wave_fence();
+    ml_slab_out_soa<NX, 16, 6>(tx, xfirst, n8, lane, valid);
+    ml_slab_out_soa<NX * NX, 16, 6>(tP, Pfirst, n8, lane, valid);
 }
 
 // VAR: per-step shared models (a.model_t), control input (a.nu > 0), mask by pointer -- all wave-uniform run-time
 // switches of ONE extra instantiation family; UF (update_first) reorders the step and is compile-time.
-template <int R, int NZ, bool OUTS, int WAVES, bool PAIRS, bool MASK, int LAYOUT, bool VAR = false, bool UF = false>
+// SLAB (element-major outputs, round 4): an output set leaves like the NumPy-order one -- staged in a wave-private LDS tile,
+// laid out [element][16 tracks], and copied out as 16-byte units of two adjacent tracks (ml_slab_out_soa: 8 elements x 128
+// contiguous bytes per store instruction) at the two points of the step where a set is complete -- instead of the PAIRS
+// scheme's DPP half-exchange per pair (136 v_mov_dpp + the store-data hazard nops per step, in a kernel bound by VALU
+// issue).  Any N (an odd tail's last track leaves as 8 bytes).  FK_ML_SLAB=0 selects the PAIRS / 8-byte instantiations.
+template <int R, int NZ, bool OUTS, int WAVES, bool PAIRS, bool MASK, int LAYOUT, bool VAR = false, bool UF = false, bool SLAB = false>
 __global__ void __launch_bounds__(BLOCK, WAVES)
 kf_ml_kernel(const KfArgs a)
 {
@@ -168,7 +179,8 @@ kf_ml_kernel(const KfArgs a)
     constexpr int MSZ = VAR ? 2 * MSTR : LM::SIZE;               // VAR: two model buffers (this step's, the next one's)
     static_assert(!VAR || MLEN <= BLOCK, "one thread per model element");
     static_assert(!UF || VAR, "update_first is a VAR instantiation");
-    __shared__ double smem[MSZ + (AOS && OUTS ? (BLOCK / 64) * TILE : 0)];
+    static_assert(!SLAB || (!AOS && !PAIRS && !VAR && OUTS), "SLAB: the plain element-major call with outputs");
+    __shared__ double smem[MSZ + ((AOS || SLAB) && OUTS ? (BLOCK / 64) * TILE : 0)];
     double *tile = smem + MSZ + (threadIdx.x >> 6) * TILE;
     const double *sB = smem + LM::SIZE;
     lds_fill<NX, NX>(smem + LM::OFF_F, a.F, NX, NX, 1.0, threadIdx.x);
@@ -223,7 +235,7 @@ kf_ml_kernel(const KfArgs a)
     const unsigned pair_rows = odd ? off_rows - 8u + estride : off_rows;
     const unsigned pair_x = odd ? t8 - 8u + estride : t8;
     // AOS output slabs: first track of this wave and how many of its 16 tracks exist
-    const long w0 = a.i0 + (long)blockIdx.x * (BLOCK / 4) + (long)(threadIdx.x >> 6) * 16;
+    const long w0 = a.i0 + (long)blockIdx.x * (BLOCK / 4) + (long)wave_index() * 16;        // scalar: see wave_index()
     const unsigned valid = (unsigned)(iend - w0 >= 16 ? 16 : (iend - w0 > 0 ? iend - w0 : 0));
     const unsigned lane = threadIdx.x & 63u;
     const double *myF = sF + Lc * (R * NX);                     // this lane's rows of F and Q
@@ -239,7 +251,7 @@ kf_ml_kernel(const KfArgs a)
     // per step (measured: 2 % faster than LDS reads, no occupancy change)
     // (not in the AOS instantiation: its LDS staging needs the registers, H is read from LDS there)
     // (nor in the VAR instantiations: H may change every step)
-    constexpr bool HLDS = AOS || VAR;
+    constexpr bool HLDS = AOS || VAR || !OUTS || SLAB;     // (the final-state-only instantiation: H from LDS too -- its registers go to the prefetched operands)
     double Hreg[HLDS ? 1 : NZ * NX];
     if constexpr (!HLDS) {
         FK_UNROLL for (int e = 0; e < NZ * NX; ++e) Hreg[e] = sH[e];
@@ -344,7 +356,7 @@ kf_ml_kernel(const KfArgs a)
             double PHT[R][NZ], S[NZ * NZ];
             // the prior covariance's 27 stores in R groups, one per iteration of the P H' stage (element-major outputs)
 #define FK_ML_PRIOR_STORES(rr)                                                                                          \
-    if (OUTS && !AOS) {                                                                                                 \
+    if (OUTS && !AOS && !SLAB) {                                                                                        \
         if constexpr (PAIRS) {                                                                                          \
             /* 27 elements = 13 pairs + 1, pairs may straddle rows: group rr sends the pairs that END in row rr */      \
             FK_UNROLL for (int f0 = 0; f0 + 1 < R * NX; f0 += 2)                                                        \
@@ -504,12 +516,14 @@ kf_ml_kernel(const KfArgs a)
                 }
             }
         }
-        if (OUTS && !AOS) {
+        if (OUTS && !AOS && !SLAB) {
             const MlView vx(a.means + t * N * NX, t8, estride, pair_x);
             store_x<NX, PAIRS ? 1 : 0>(vx, x);
         }
         if constexpr (OUTS && AOS)
             ml_store_aos<R, NX>(x, P, a.means + (t * N + w0) * NX, a.covs + (t * N + w0) * NX * NX, tile, lane, Lc, valid);
+        if constexpr (OUTS && SLAB)
+            ml_store_soa_slab<R, NX>(x, P, a.means + t * N * NX + w0, a.covs + t * N * NX * NX + w0, (unsigned)N * 8u, tile, lane, Lc, valid);
         }      // update half
         if constexpr (UF) {
 #include "kf_ml_predict.inc"
@@ -529,7 +543,7 @@ kf_ml_kernel(const KfArgs a)
             myQ = sQ + Lc * (R * NX);
         }
     }
-    if (OUTS && !AOS && a.T > 0) {      // the last step's posterior (update_first: prior) covariance -- the others were stored one step late
+    if (OUTS && !AOS && !SLAB && a.T > 0) {      // the last step's posterior (update_first: prior) covariance -- the others were stored one step late
         const MlView vP((UF ? a.covs_p : a.covs) + (a.T - 1) * N * NX * NX, off_rows, estride);
         FK_UNROLL for (int r = 0; r < R; ++r)
             FK_UNROLL for (int c = 0; c < NX; ++c) vP.store(r * NX + c, P[r][c]);
@@ -576,7 +590,7 @@ __device__ __forceinline__ void ml_store_rows_aos_park(const double (&M)[R][NX],
         }
     ml_wave_fence();
     const rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc(dst, 0, (int)(valid * (unsigned)EP * 8u), 0x00020000);
-    ml_copy_units<UP, 6>(lane, [&](unsigned unit) { return &park[(2u * unit) >> 6][c0 + ((2u * unit) & 63u)]; },
+    ml_copy_units<UP, 4>(lane, [&](unsigned unit) { return &park[(2u * unit) >> 6][c0 + ((2u * unit) & 63u)]; },
                          [&](unsigned unit, bool ok, const u32x4 &v) {
                              __builtin_amdgcn_raw_buffer_store_b128(v, rP, ok ? unit * 16u : ML_OFF_DROP, 0, 0);
                          });
@@ -629,7 +643,7 @@ rts_ml_kernel(const RtsArgs a)
     const double *myF = sF + Lc * (R * NX), *myQ = sQ + Lc * (R * NX);
     // AOS: covariance-like outputs leave through the parking buffer as 1 KiB stores (first track of this
     // wave, how many of its 16 tracks exist)
-    const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const unsigned lane = threadIdx.x & 63u, wave = wave_index();
     const long w0 = i0 + (long)blockIdx.x * (BLOCK / 4) + (long)wave * 16;
     const unsigned valid = (unsigned)(iend - w0 >= 16 ? 16 : (iend - w0 > 0 ? iend - w0 : 0));
     const long xs_blk = N * NX, ps_blk = N * (long)NX * NX;
@@ -877,8 +891,13 @@ static int launch_kf_ml_one(const KfArgs &a, int layout, bool outs, hipStream_t 
     // 16-byte pair stores (SOA) need the track count even (a pair never straddles a plane); FK_ML_PAIRS=0 turns them off
     const char *pv = getenv("FK_ML_PAIRS");
     const bool pairs = (a.N % 2 == 0) && (a.cnt % 2 == 0) && a.cnt >= 2 && !(pv && atoi(pv) == 0);
+    // FK_ML_SLAB=0: element-major outputs as DPP pair stores / 8-byte stores (rounds 2-3) instead of the LDS slab
+    const char *sv = getenv("FK_ML_SLAB");
+    const bool slab = !(sv && atoi(sv) == 0);
 #define GO(M, LAY)                                                                                                          \
-    if (outs && pairs && LAY == LAYOUT_SOA)                                                                                 \
+    if (outs && slab && LAY == LAYOUT_SOA)                                                                                  \
+        hipLaunchKernelGGL((kf_ml_kernel<3, 3, true, FK_ML_WAVES, false, M, LAYOUT_SOA, false, false, true>), grid, block, 0, s, a); \
+    else if (outs && pairs && LAY == LAYOUT_SOA)                                                                            \
         hipLaunchKernelGGL((kf_ml_kernel<3, 3, true, FK_ML_WAVES, true, M, LAYOUT_SOA>), grid, block, 0, s, a);             \
     else if (outs) hipLaunchKernelGGL((kf_ml_kernel<3, 3, true, FK_ML_WAVES, false, M, LAY>), grid, block, 0, s, a);        \
     else hipLaunchKernelGGL((kf_ml_kernel<3, 3, false, FK_ML_WAVES, false, M, LAY>), grid, block, 0, s, a)

@@ -119,7 +119,7 @@ kf_mlg_kernel(const KfArgs a)
     // SOA covariances leave through an LDS slab as 16-byte units (ml_store_rows_soa_slab) up to dim_x = 12: measured
     // 0.37 -> 0.48 of HBM at (10,2), 0.34 -> 0.35 at (12,3), but 0.39 -> 0.32 at (14,4) -- the larger kernels are bound by
     // their arithmetic and code size, not by store slots (profiles/r02/dims_10_16.jsonl vs dims_10_16_slab.jsonl)
-    constexpr bool SOA_SLAB = !AOS && NX <= 12;
+    constexpr bool SOA_SLAB = !AOS && NX <= FK_SOA_SLAB_MAX;
     __shared__ double smem[MSZ + (AOS || SOA_SLAB || EX ? (BLOCK / 64) * TILE : 0)];
     double *tile = smem + MSZ + (threadIdx.x >> 6) * TILE;
     lds_fill<NX, NX>(smem + LM::OFF_F, a.F, NX, NX, 1.0, threadIdx.x);
@@ -172,7 +172,7 @@ kf_mlg_kernel(const KfArgs a)
     unsigned off_row[R];                                                                      // element row[r] * NX of a covariance record
     FK_UNROLL for (int r = 0; r < R; ++r)
         off_row[r] = (AOS ? (unsigned)trk * (unsigned)(NX * NX) * 8u : (unsigned)trk * 8u) + row[r] * (unsigned)NX * estride;
-    const long w0 = a.i0 + (long)blockIdx.x * (BLOCK / 4) + (long)(threadIdx.x >> 6) * 16;
+    const long w0 = a.i0 + (long)blockIdx.x * (BLOCK / 4) + (long)wave_index() * 16;        // scalar: see wave_index()
     const unsigned valid = (unsigned)(iend - w0 >= 16 ? 16 : (iend - w0 > 0 ? iend - w0 : 0));
     const unsigned lane = threadIdx.x & 63u;
     const uint8_t *mask_or_dummy = a.mask ? a.mask : reinterpret_cast<const uint8_t *>(a.z);

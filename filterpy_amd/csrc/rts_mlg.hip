@@ -63,7 +63,7 @@ rts_mlg_kernel(const RtsArgs a)
 {
     constexpr int R = (NX + 3) / 4;
     constexpr bool AOS = LAYOUT == LAYOUT_AOS;
-    constexpr bool SOA_SLAB = !AOS && NX <= 12;      // SOA row blocks through the slab too (16-byte units): n = 10: 0.36 -> 0.45 of HBM, n = 14: 0.32 -> 0.30
+    constexpr bool SOA_SLAB = !AOS && NX <= FK_SOA_SLAB_MAX;      // SOA row blocks through the slab too (16-byte units): n = 10: 0.36 -> 0.45 of HBM, n = 14: 0.32 -> 0.30
     // One wave-private LDS region, used in turn as the AOS staging slab (16 x NX*NX doubles) and as the PARK of a
     // row block ([element][lane], conflict-free, R*NX x 64 doubles): the smoothed P of step k+1 waits there between
     // iterations and D = Pn - Pp across the factorisation.
@@ -102,7 +102,7 @@ rts_mlg_kernel(const RtsArgs a)
         }                                                                                                  \
     }
     const unsigned lane = threadIdx.x & 63u;
-    const long w0 = i0 + (long)blockIdx.x * (BLOCK / 4) + (long)(threadIdx.x >> 6) * 16;
+    const long w0 = i0 + (long)blockIdx.x * (BLOCK / 4) + (long)wave_index() * 16;          // scalar: see wave_index()
     const unsigned valid = (unsigned)(iend - w0 >= 16 ? 16 : (iend - w0 > 0 ? iend - w0 : 0));
     const long xs_blk = N * NX, ps_blk = N * (long)NX * NX;
     double *park = tile + lane;                                // element e of this lane: park[e * 64]

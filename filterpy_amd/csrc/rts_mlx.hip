@@ -88,7 +88,7 @@ rts_mlx_kernel(const RtsArgs a)
         row[r] = g < (unsigned)NX ? g : (unsigned)NX - 1u;
         off_row[r] = (AOS ? (unsigned)trk * (unsigned)(NX * NX) * 8u : (unsigned)trk * 8u) + row[r] * (unsigned)NX * estride;
     }
-    const long w0 = i0 + (long)blockIdx.x * (BLOCK / LPT) + (long)(threadIdx.x >> 6) * TPW;
+    const long w0 = i0 + (long)blockIdx.x * (BLOCK / LPT) + (long)wave_index() * TPW;      // scalar: see wave_index()
     const unsigned valid = (unsigned)(iend - w0 >= TPW ? TPW : (iend - w0 > 0 ? iend - w0 : 0));
     const long xs_blk = N * NX, ps_blk = N * (long)NX * NX;
     // element e (= slot * NX + col) of this lane in a park: [e * 64 + lane]; of the lane that owns row q: group base + q / R

@@ -856,6 +856,41 @@ def test_saver_histories_from_the_specialised_kernel(n, m, layout, monkeypatch):
 
 
 @pytest.mark.parametrize("layout", ["soa", "aos"])
+@pytest.mark.parametrize("N", [1000, 777, 64, 3])
+def test_three_lane_slab_outputs_equal_the_pair_store_build_bit_for_bit(N, layout, monkeypatch):
+    """Round 4: kf_ml's element-major outputs leave through a wave-private LDS slab (SLAB instantiations: 16-byte units of two
+    adjacent tracks, one predicate per copy-out) instead of DPP pair stores / 8-byte stores; in NumPy order the slab
+    descriptors are scalar now (wave_index(): no waterfall loop around each store).  Only addresses and store shapes change:
+    every output, the final state and the status equal the round-3 store paths' (FK_ML_SLAB=0) bit for bit -- even and odd
+    banks, ragged last wave (an odd tail's last track leaves as 8 bytes), with and without a mask."""
+    from gpu_util import run_kf_batch
+    rs = np.random.RandomState(7 + N)
+    n, m, T = 9, 3, 13
+    A = rs.randn(N, n, n)
+    x0, P0 = rs.randn(N, n), 3.0 * (A @ A.transpose(0, 2, 1) / n + 0.5 * np.eye(n))
+    zs = rs.randn(T, N, m) * 2
+    F = np.eye(n) + 0.05 * rs.randn(n, n)
+    B = rs.randn(n, n)
+    Q = 0.1 * (B @ B.T / n + 0.5 * np.eye(n))
+    H = rs.randn(m, n)
+    C = rs.randn(m, m)
+    R = 0.5 * (C @ C.T / m + 0.5 * np.eye(m))
+    mask = (rs.rand(T, N) > 0.3).astype(np.uint8)
+    for kw in (dict(), dict(mask=mask)):
+        got = run_kf_batch(x0, P0, zs, F, Q, H, R, layout=layout, **kw)
+        with monkeypatch.context() as mp:
+            mp.setenv("FK_ML_SLAB", "0")
+            ref = run_kf_batch(x0, P0, zs, F, Q, H, R, layout=layout, **kw)
+        for a, b in zip(got, ref):
+            assert np.array_equal(a, b), (N, layout, list(kw))
+        # ... and both against the oracle on sample tracks
+        for i in sorted({0, N // 2, N - 1}):
+            o = kf_oracle.kf_batch_filter_tracks(x0[[i]], P0[[i]], zs[:, [i]], F, Q, H, R, tracks=range(1),
+                                                 **({"mask": mask[:, [i]]} if kw else {}))
+            assert rel_err_rows(got[0][:, i], o[0][:, 0]) < TOL and rel_err_rows(got[1][:, i].reshape(T, -1), o[1][:, 0].reshape(T, -1)) < TOL
+
+
+@pytest.mark.parametrize("layout", ["soa", "aos"])
 @pytest.mark.parametrize("n,m", [(9, 3), (10, 1), (10, 2), (11, 3), (12, 3), (12, 5), (13, 4), (14, 2), (15, 3), (16, 4), (16, 8)])
 def test_saver_histories_from_the_four_lane_kernel(n, m, layout, monkeypatch):
     """Round 4 (VERDICT r3 missing 4): the by-product histories at dim_x >= 10 -- and (9,3) -- come from kf_mlg's EX
