@@ -39,14 +39,6 @@ struct Lane {
 
 using rsrc_t = __amdgpu_buffer_rsrc_t;
 
-__device__ __forceinline__ rsrc_t make_rsrc(const void *p)
-{
-    // raw buffer (stride 0), no clipping: tail lanes exit before touching memory
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), /*stride*/ 0, /*num_records*/ -1, 0x00020000);
-}
-
-using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
-
 // The wave's index in its workgroup as a SCALAR.  threadIdx.x >> 6 is the same in every lane of a wave, but the compiler
 // does not know it: everything derived from it (the wave's first track, the base address and the size of the slab it
 // writes) sits in VGPRs, a buffer descriptor built from those is "divergent", and every access through it is wrapped in
@@ -57,6 +49,28 @@ __device__ __forceinline__ unsigned wave_index()
 {
     return (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
 }
+
+// ... and for a pointer / a count that IS the same in every lane but reaches a descriptor through registers the compiler
+// treats as divergent: three v_readfirstlane per descriptor instead of a waterfall loop per access
+template <class T>
+__device__ __forceinline__ T *uniform_ptr(T *p)
+{
+    const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+    return reinterpret_cast<T *>(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ int uniform_int(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+__device__ __forceinline__ rsrc_t make_rsrc(const void *p)
+{
+    // raw buffer (stride 0), no clipping: tail lanes exit before touching memory.  The base is wave-uniform by construction
+    // at every call site; uniform_ptr makes the compiler know it (where it already does, the two v_readfirstlane fold away)
+    return __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(const_cast<void *>(p)), /*stride*/ 0, /*num_records*/ -1, 0x00020000);
+}
+
+using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
+
 
 // Per-lane view of one record block `blk` ([N][E] AOS / [E][N] SOA) for the lane's workgroup.
 template <int LAYOUT>
@@ -347,20 +361,24 @@ __device__ __forceinline__ void wave_store_aos_flat(const double (&v)[LEN], cons
 // Full waves only (no clipping), 16-byte aligned rows: `rows` = the array's first row at this wave's first track, N even.
 template <int LEN>
 __device__ __forceinline__ void wave_store_soa_pairs(const double (&v)[LEN], double *rows, unsigned n8 /* N * 8 */,
-                                                     double *tile, unsigned lane, bool present = true)
+                                                     double *tile, unsigned lane, bool present = true, unsigned valid = 64u)
 {
     static_assert(LEN % 2 == 0, "pairs of element rows");
-    const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(rows, 0, present ? -1 : 0, 0x00020000);
+    // `valid` (even): how many of the wave's 64 tracks exist.  A lane whose track pair does not exist stores to an offset
+    // just below 4 GiB, outside the descriptor (32 bytes short of it; the host keeps every step block below that): no exec
+    // region, and the last partial workgroup of a bank runs in the same launch as the full ones.  The whole offset sits in
+    // the VGPR (no soffset: a dropped offset plus a scalar offset would wrap around into range).
+    const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(rows), 0, uniform_int(present ? (int)0xffffffe0u : 0), 0x00020000);
     wave_lds_fence();
     FK_UNROLL for (int e = 0; e < LEN; ++e) tile[e * 64 + lane] = v[e];
     wave_lds_fence();
     const unsigned half = lane >> 5, l2 = (lane & 31u) * 2u;
     const double *tb = tile + half * 64u + l2;
     const unsigned voff = l2 * 8u + half * n8;
+    const bool ok = l2 + 1u < valid;
     FK_UNROLL for (int p = 0; p < LEN / 2; ++p) {
         const u32x4 w = *reinterpret_cast<const u32x4 *>(tb + p * 128);
-        __builtin_amdgcn_raw_buffer_store_b128(w, rs, voff, (unsigned)(2 * p) * n8, 0);
-        asm volatile("s_nop 1" ::"v"(w.x), "v"(w.y), "v"(w.z), "v"(w.w) : "memory");    // (store-data hazard: see wave_store_aos_flat)
+        __builtin_amdgcn_raw_buffer_store_b128(w, rs, ok ? voff + (unsigned)(2 * p) * n8 : 0xfffffff0u, 0, 0);
     }
     wave_lds_fence();
 }

@@ -287,7 +287,7 @@ kf_ml_kernel(const KfArgs a)
             hn = a.mask ? hb : 1u;
             const MlView vu(u_or_dummy, tu8, estride);
             FK_UNROLL for (int c = 0; c < NUC; ++c) {
-                const double v = vu.load((unsigned)c < nu ? c : (int)nu_idx);   // clamped element index: no branch
+                const double v = vu.load(uniform_int((unsigned)c < nu ? c : (int)nu_idx));   // clamped element index: no branch
                 un[c] = nu ? v : 0.0;
             }
             FK_UNROLL for (int c = 0; c < NUC; ++c) asm volatile("" ::"v"(un[c]));
@@ -313,7 +313,7 @@ kf_ml_kernel(const KfArgs a)
                 hn = a.mask ? hb : 1u;
                 const MlView vu(u_or_dummy + tn * N * (long)nu, tu8, estride);
                 FK_UNROLL for (int c = 0; c < NUC; ++c) {
-                    const double v = vu.load((unsigned)c < nu ? c : (int)nu_idx);
+                    const double v = vu.load(uniform_int((unsigned)c < nu ? c : (int)nu_idx));
                     un[c] = nu ? v : 0.0;
                 }
             } else if constexpr (MASK) hn = a.mask[tn * N + trk];

@@ -195,9 +195,12 @@ ukf_linear_kernel(const UkfArgs a, const double *__restrict__ pF, const double *
             FK_UNROLL for (int i = 0; i < NX; ++i)
                 FK_UNROLL for (int j = 0; j < NX; ++j) Pf[i * NX + j] = P[sym_idx<NX>(i, j)];
             if constexpr (PAIRS) {
-                const long w0 = blk0 + wave_row0;
-                wave_store_soa_pairs<NX>(x, a.means + t * N * NX + w0, (unsigned)N * 8u, tile, lane, st_m);
-                wave_store_soa_pairs<NX * NX>(Pf, a.covs + t * N * (NX * NX) + w0, (unsigned)N * 8u, tile, lane, st_c);
+                // (w0 scalar: wave_index() -- no waterfall loop around the pair stores; a wave of the last workgroup may hold
+                //  fewer than 64 tracks, or none: its missing pairs are dropped by offset, see wave_store_soa_pairs)
+                const long w0 = blk0 + (long)wave_index() * 64, leftw = a.i0 + a.cnt - w0;
+                const unsigned validw = leftw >= 64 ? 64u : (leftw > 0 ? (unsigned)leftw : 0u);
+                wave_store_soa_pairs<NX>(x, a.means + t * N * NX + w0, (unsigned)N * 8u, tile, lane, st_m, validw);
+                wave_store_soa_pairs<NX * NX>(Pf, a.covs + t * N * (NX * NX) + w0, (unsigned)N * 8u, tile, lane, st_c, validw);
             } else {
                 store_rec<NX, 1, LAYOUT, EXACT>(x, a.means + t * N * n, ln, n, 1, st_m);
                 store_rec<NX, NX, LAYOUT, EXACT>(Pf, a.covs + t * N * n * n, ln, n, n, st_c);
@@ -245,28 +248,23 @@ int ukf_rts_launch_big_paired(const UkfRtsArgs &a, const double *F, const double
             else hipLaunchKernelGGL((ukf_linear_kernel<NXV, NZV, LAYOUT_AOS, false, PV>), grid, block, 0, s, a, a.F, a.H, a.Q, a.R, a.Wm, a.Wc, a.z, a.mask);  \
         }                                                                                                        \
     } while (0)
-// SP instantiations: even dims up to 6, element-major, N even, 16-byte aligned histories (or none); full workgroups on the SP
-// kernel, the last partial one on the plain kernel (a second launch over tracks [i0 + full, i0 + cnt))
+// SP instantiations: even dims up to 6, element-major, N and the piece's track count even, 16-byte aligned histories (or none)
 template <int NXV>
 static bool ukf_sp_ok(const UkfArgs &a)
 {
     if constexpr (NXV > 6 || NXV % 2 != 0) return false;
-    return a.soa_pairs && (a.N & 1) == 0 && a.cnt >= BLOCK &&
+    return a.soa_pairs && (a.N & 1) == 0 && (a.cnt & 1) == 0 && (a.i0 & 63) == 0 &&
            ((reinterpret_cast<uintptr_t>(a.means) | reinterpret_cast<uintptr_t>(a.covs)) & 15u) == 0;
 }
 template <int NXV, int NZV, bool PV>
 static void ukf_launch_sp(const UkfArgs &a, hipStream_t s)
 {
     if constexpr (NXV <= 6 && NXV % 2 == 0) {
-        const long full = a.cnt / BLOCK * BLOCK;
-        UkfArgs b = a;
-        b.cnt = full;
-        hipLaunchKernelGGL((ukf_linear_kernel<NXV, NZV, LAYOUT_SOA, true, PV, true>), dim3((unsigned)(full / BLOCK)), dim3(BLOCK), 0, s, b, a.F, a.H, a.Q, a.R, a.Wm, a.Wc, a.z, a.mask);
-        if (full < a.cnt) {
-            b.i0 = a.i0 + full;
-            b.cnt = a.cnt - full;
-            hipLaunchKernelGGL((ukf_linear_kernel<NXV, NZV, LAYOUT_SOA, true, PV>), dim3(1), dim3(BLOCK), 0, s, b, a.F, a.H, a.Q, a.R, a.Wm, a.Wc, a.z, a.mask);
-        }
+        // every workgroup on the SP kernel, the last partial one included (its missing track pairs are dropped by offset).
+        // (Round 4 first launched the partial workgroup on the plain kernel behind the full ones: a lone workgroup stepping
+        //  through T epochs is latency-bound -- 277 us behind the 780 us of configs[3]'s 390 full workgroups, also from a
+        //  helper stream: 1.00-1.08 ms end to end where the 8-byte stores took 0.87.)
+        hipLaunchKernelGGL((ukf_linear_kernel<NXV, NZV, LAYOUT_SOA, true, PV, true>), dim3((unsigned)((a.cnt + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s, a, a.F, a.H, a.Q, a.R, a.Wm, a.Wc, a.z, a.mask);
     }
 }
 
@@ -685,7 +683,7 @@ int fk_ukf_linear_batch_f64(const fk_ukf_desc *d, const double *F, const double 
         return fail(FK_ERR_UNSUPPORTED, "fused linear UKF: dim_x 1..6 with dim_z 1..3, dim_x 7..9 with dim_z 1..4");
     if (d->N < 0 || d->T < 0 || !F || !H || !Q || !R || !Wm || !Wc || !z || !x || !P)
         return fail(FK_ERR_BAD_ARG, "fused linear UKF: bad argument");
-    if ((double)d->N * d->n * d->n * 8.0 >= 4294967296.0) return fail(FK_ERR_UNSUPPORTED, "fused linear UKF: record block >= 4 GiB, split the batch");
+    if ((double)d->N * d->n * d->n * 8.0 >= 4294967296.0 - 32.0) return fail(FK_ERR_UNSUPPORTED, "fused linear UKF: record block >= 4 GiB, split the batch");
     if (d->N == 0 || d->T == 0) return FK_OK;
     UkfArgs a0{};
     a0.F = F; a0.H = H; a0.Q = Q; a0.R = R; a0.Wm = Wm; a0.Wc = Wc; a0.z = z; a0.mask = mask;

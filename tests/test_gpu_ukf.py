@@ -251,8 +251,8 @@ def test_fused_linear_ukf_smoother_on_arrays_that_are_only_8_byte_aligned(layout
 @pytest.mark.parametrize("n,m", [(2, 2), (4, 2), (6, 3)])
 def test_element_major_pair_stores_are_bit_identical(n, m, mask, monkeypatch):
     """Round 4: in the element-major layout the fused UKF's per-step outputs leave as 16-byte stores of two element rows each
-    (wave_store_soa_pairs, the SP instantiations; full workgroups -- the last partial one runs the plain kernel in a second
-    launch).  Only the store instructions differ: every output equals the 8-byte-store kernel (FK_UKF_SOA_PAIRS=0) bit for bit,
+    (wave_store_soa_pairs, the SP instantiations; the last partial workgroup runs in the same launch, its missing track pairs
+    dropped by an out-of-range offset).  Only the store instructions differ: every output equals the 8-byte-store kernel (FK_UKF_SOA_PAIRS=0) bit for bit,
     bank sizes with and without a partial workgroup, odd banks (which take the plain kernel), missing measurements."""
     import torch
     from filterpy_amd import _engine as E
