@@ -183,6 +183,7 @@ template <int NX, int NZ>
 struct LdsModel {
     static constexpr int OFF_F = 0, OFF_Q = NX * NX, OFF_H = 2 * NX * NX, OFF_R = 2 * NX * NX + NZ * NX;
     static constexpr int SIZE = OFF_R + NZ * NZ;
+    static constexpr bool IN_LDS = true;          // fk_math_sym.hpp: model_cached
     const double *s;
     template <int LEN>
     __device__ __forceinline__ void row(int off, double (&r)[LEN]) const
@@ -473,6 +474,14 @@ __device__ __forceinline__ void lds_dma16(dma_rsrc_t rs, unsigned voff, unsigned
 {
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(rs), "s"(soff), "s"(lds_addr) : "memory");
+}
+
+// the 4-byte form (dword alignment is all it asks of the global address): lane l's dword lands at (M0 base) + 4 l
+__device__ __forceinline__ void lds_dma4(dma_rsrc_t rs, unsigned voff, unsigned soff, unsigned lds_addr)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(voff), "s"(rs), "s"(soff), "s"(lds_addr) : "memory");
 }
 

@@ -15,6 +15,7 @@
 // implicitly; rounding differences vs the factored form are O(eps |P|), the same size as the
 // reference's own.
 #pragma once
+#include <type_traits>
 
 #include "fk_math.hpp"
 
@@ -30,14 +31,51 @@ FK_HD constexpr int sym_idx(int i, int j)
 template <int NX>
 constexpr int SYM_LEN = NX * (NX + 1) / 2;
 
+// A model staged in LDS (LdsModel: IN_LDS) hands out one row per call, and the arithmetic below consumes a row right after
+// asking for it: every request exposes the full LDS latency.  With several waves per SIMD another wave covers it; the
+// instantiations of dim_x >= 7 run ONE wave per SIMD and nothing does -- at (8,4) 240 of the step's 311 LDS waits sat directly
+// behind their reads, about as many clocks as the step's 2500 VALU instructions (round 4, ISA of kf_fast 8_4).  There the
+// whole block a half-step needs (F, then Q; H and R) is read into registers in ONE batch at its head -- the register file of a
+// lone wave has the room (F at dim_x 9: 162 of 512 VGPRs) -- and the arithmetic runs on the copy.  Same values into the same
+// operations: bit-identical results.
+#ifndef FK_MODEL_CACHE_MIN_NX
+#define FK_MODEL_CACHE_MIN_NX 7
+#endif
+#ifndef FK_MODEL_CACHE_UPDATE
+#define FK_MODEL_CACHE_UPDATE 1
+#endif
+#ifndef FK_MODEL_CACHE_R
+#define FK_MODEL_CACHE_R 1
+#endif
+template <class M, class = void>
+struct model_in_lds { static constexpr bool value = false; };
+template <class M>
+struct model_in_lds<M, std::void_t<decltype(M::IN_LDS)>> { static constexpr bool value = M::IN_LDS; };
+// (not in the rolled builds -- FK_ROLLED: loops kept as loops, arrays in scratch memory --, where a copy indexed by a loop
+//  variable would be one more scratch array)
+#if defined(FK_ROLLED) && FK_ROLLED
+constexpr bool model_cache_build = false;
+#else
+constexpr bool model_cache_build = true;
+#endif
+template <class M, int NX>
+constexpr bool model_cached = model_cache_build && model_in_lds<M>::value && NX >= FK_MODEL_CACHE_MIN_NX;
+
 template <int NX, class Model>
 FK_HD void kf_predict_sym(double (&x)[NX], double (&U)[NX * (NX + 1) / 2], const Model &M, double alpha_sq)
 {
+    constexpr bool PF = model_cached<Model, NX>;
     double xn[NX];
     double Un[NX * (NX + 1) / 2];
+    double Fc[PF ? NX : 1][NX];
+    if constexpr (PF) {
+        FK_UNROLL for (int i = 0; i < NX; ++i) M.rowF(i, Fc[i]);
+        FK_STAGE();
+    }
     FK_UNROLL for (int i = 0; i < NX; ++i) {
         double f[NX];
-        M.rowF(i, f);
+        if constexpr (PF) { FK_UNROLL for (int k = 0; k < NX; ++k) f[k] = Fc[PF ? i : 0][k]; }
+        else M.rowF(i, f);
         xn[i] = dot<NX>(f, x);
         // row i of F P
         double fp[NX];
@@ -50,31 +88,53 @@ FK_HD void kf_predict_sym(double (&x)[NX], double (&U)[NX * (NX + 1) / 2], const
         Un[sym_idx<NX>(i, i)] = dot<NX>(fp, f);
         FK_UNROLL for (int j = i + 1; j < NX; ++j) {
             double g[NX];
-            M.rowF(j, g);
+            if constexpr (PF) { FK_UNROLL for (int k = 0; k < NX; ++k) g[k] = Fc[PF ? j : 0][k]; }
+            else M.rowF(j, g);
             Un[sym_idx<NX>(i, j)] = dot<NX>(fp, g);
         }
         FK_STAGE();
     }
     FK_UNROLL for (int i = 0; i < NX; ++i) x[i] = xn[i];
-    FK_UNROLL for (int i = 0; i < NX; ++i) {
-        double q[NX];
-        M.rowQ(i, q);
-        FK_UNROLL for (int j = i; j < NX; ++j) U[sym_idx<NX>(i, j)] = fma(alpha_sq, Un[sym_idx<NX>(i, j)], q[j]);
+    if constexpr (PF) {
+        double Qc[NX][NX];                       // (F's copy is dead: Q takes its registers)
+        FK_UNROLL for (int i = 0; i < NX; ++i) M.rowQ(i, Qc[i]);
+        FK_STAGE();
+        FK_UNROLL for (int i = 0; i < NX; ++i)
+            FK_UNROLL for (int j = i; j < NX; ++j) U[sym_idx<NX>(i, j)] = fma(alpha_sq, Un[sym_idx<NX>(i, j)], Qc[i][j]);
+    } else {
+        FK_UNROLL for (int i = 0; i < NX; ++i) {
+            double q[NX];
+            M.rowQ(i, q);
+            FK_UNROLL for (int j = i; j < NX; ++j) U[sym_idx<NX>(i, j)] = fma(alpha_sq, Un[sym_idx<NX>(i, j)], q[j]);
+        }
     }
     FK_STAGE();
 }
 
 // Returns status bits.  K, y, S (full m x m) and the factorisation are outputs like kf_update.
-template <int NX, int NZ, bool FAST_RCP = false, class Model>
+// UPD_CACHE: a caller whose own register peak sits in the update half switches the H / R copy off (model_cached)
+template <int NX, int NZ, bool FAST_RCP = false, bool UPD_CACHE = true, class Model>
 FK_HD int kf_update_sym(double (&x)[NX], double (&U)[NX * (NX + 1) / 2], const double (&z)[NZ], const Model &M,
                         double (&K)[NX * NZ], double (&y)[NZ], double (&S)[NZ * NZ],
                         double (&Lf)[NZ * NZ], double (&dinv)[NZ], bool rj_diag = false)
 {
     int st = 0;
+    constexpr bool PF = model_cached<Model, NX> && UPD_CACHE && FK_MODEL_CACHE_UPDATE;
+    constexpr bool PFR = PF && FK_MODEL_CACHE_R;
+    double Hc[PF ? NZ : 1][NX], Rc[PFR ? NZ : 1][NZ];
+    if constexpr (PF) {
+        FK_UNROLL for (int r = 0; r < NZ; ++r) {
+            M.rowH(r, Hc[r]);
+            if constexpr (PFR) M.rowR(r, Rc[PFR ? r : 0]);
+        }
+        FK_STAGE();
+    }
+#define FK_ROWH(r, h) do { if constexpr (PF) { FK_UNROLL for (int k_ = 0; k_ < NX; ++k_) h[k_] = Hc[PF ? (r) : 0][k_]; } else M.rowH((r), h); } while (0)
+#define FK_ROWR(r, rr) do { if constexpr (PFR) { FK_UNROLL for (int k_ = 0; k_ < NZ; ++k_) rr[k_] = Rc[PFR ? (r) : 0][k_]; } else M.rowR((r), rr); } while (0)
     double PHT[NX * NZ];
     FK_UNROLL for (int r = 0; r < NZ; ++r) {
         double h[NX];
-        M.rowH(r, h);
+        FK_ROWH(r, h);
         y[r] = z[r] - dot<NX>(h, x);
         FK_UNROLL for (int i = 0; i < NX; ++i) {
             double acc = U[sym_idx<NX>(i, 0)] * h[0];
@@ -85,8 +145,8 @@ FK_HD int kf_update_sym(double (&x)[NX], double (&U)[NX * (NX + 1) / 2], const d
     FK_STAGE();
     FK_UNROLL for (int r = 0; r < NZ; ++r) {
         double h[NX], rr[NZ];
-        M.rowH(r, h);
-        M.rowR(r, rr);
+        FK_ROWH(r, h);
+        FK_ROWR(r, rr);
         FK_UNROLL for (int c = 0; c < NZ; ++c) {
             double acc = h[0] * PHT[c];
             FK_UNROLL for (int k = 1; k < NX; ++k) acc = fma(h[k], PHT[k * NZ + c], acc);
@@ -128,13 +188,13 @@ FK_HD int kf_update_sym(double (&x)[NX], double (&U)[NX * (NX + 1) / 2], const d
         FK_UNROLL for (int c = 0; c < NZ; ++c) D[c] = 0.0;
         FK_UNROLL for (int r = 0; r < NZ; ++r) {
             double rr[NZ];
-            M.rowR(r, rr);
+            FK_ROWR(r, rr);
             FK_UNROLL for (int c = 0; c < NZ; ++c) rr[c] = (rj_diag && c != r) ? 0.0 : rr[c];   // fk_math.hpp, kf_update
             FK_UNROLL for (int c = 0; c < NZ; ++c) D[c] = (r == 0) ? K[i * NZ] * rr[c] : fma(K[i * NZ + r], rr[c], D[c]);
         }
         FK_UNROLL for (int r = 0; r < NZ; ++r) {
             double h[NX];
-            M.rowH(r, h);
+            FK_ROWH(r, h);
             D[r] -= dot<NX>(t1, h);
         }
         FK_UNROLL for (int j = i; j < NX; ++j) {
@@ -145,6 +205,8 @@ FK_HD int kf_update_sym(double (&x)[NX], double (&U)[NX * (NX + 1) / 2], const d
         FK_STAGE();
     }
     FK_UNROLL for (int e = 0; e < NX * (NX + 1) / 2; ++e) U[e] = Un[e];
+#undef FK_ROWH
+#undef FK_ROWR
     return st;
 }
 
@@ -212,6 +274,7 @@ FK_HD int rts_step_sym(double (&x)[NX], double (&U)[NX * (NX + 1) / 2], const do
     int st = 0;
     double dx[NX];
     // K0 = P F' = (F P)' : row i of F P is column i of K0
+    // (no model_cached copy here: the one-lane smoother of dim_x 7, 8 already spills, and the copy only adds to it)
     FK_UNROLL for (int i = 0; i < NX; ++i) {
         double f[NX];
         M.rowF(i, f);

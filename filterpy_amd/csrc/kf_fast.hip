@@ -29,6 +29,10 @@
 #define FK_FAST_SYM 0
 #endif
 // FK_FAST_ZDEPTH: steps of measurement prefetch (0 = default: 2 for AOS with small records, else 1)
+// FK_FAST_ZDMA=0 (build time): the one-wave-per-SIMD instantiations prefetch their measurements into registers again (A/B)
+#ifndef FK_FAST_ZDMA
+#define FK_FAST_ZDMA 1
+#endif
 #ifndef FK_FAST_ZDEPTH
 #define FK_FAST_ZDEPTH 0
 #endif
@@ -95,6 +99,16 @@ kf_fast_kernel(const KfArgs a, const double *__restrict__ pF, const double *__re
     constexpr int NUC = 4;                                   // padded dim_u
     constexpr int ZW = NZ + (CTRL ? NUC : 0);                // a measurement buffer carries [z | u]
     __shared__ double s_B[CTRL ? NX * NUC : 1];
+    // ZDMA (dim_x >= 7: one wave per SIMD, the plain and extras calls without a mask or a control input): the measurement of
+    // step t + 1 travels HBM -> LDS by LDS-DMA while step t computes.  These instantiations have no VGPR to spare: a register
+    // prefetch was "spilled" to an AGPR the moment it was issued, i.e. waited for on the spot with vmcnt(0) -- dim_z pipeline
+    // drains per step behind the previous step's 144 stores (round 4, ISA of kf_fast 8_4).  A wave's 64 measurements of one
+    // step are 2 dim_z dword-DMA instructions (256 B each, dword alignment suffices) into one of two images of 512 dim_z
+    // bytes; the image of step t is read at the top of step t behind s_waitcnt vmcnt(63) -- the DMA is older than the >= 72
+    // stores step t - 1 issued after it (vmcnt retires in order) -- or vmcnt(0) where a step has no stores to drain.
+    constexpr bool ZDMA = NX > 6 && !CTRL && !HAS_MASK && FK_FAST_ZDMA;
+    constexpr int ZIMG = 64 * NZ;                             // doubles per image
+    __shared__ double s_z[ZDMA ? (BLOCK / 64) * 2 * ZIMG : 1];
     if constexpr (CTRL) lds_fill<NX, NUC>(s_B, a.B, NX, a.nu, 0.0, threadIdx.x);   // synchronised with the model fill below
 
     const long N = a.N, T = a.T;
@@ -114,6 +128,27 @@ kf_fast_kernel(const KfArgs a, const double *__restrict__ pF, const double *__re
     const Lane lr = ln;
     const unsigned lane = tid & 63u, wave = tid >> 6;
     double *tile = s_mem + MSIZE + wave * TILE;
+    // ZDMA: the 64-track slab this wave fetches (a wave past the bank's last track duplicates that track: it fetches the slab
+    // the track lives in), its LDS images, this lane's track inside the slab
+    const unsigned zw0 = ZDMA ? min(wave_index() * 64u, last_row & ~63u) : 0u;
+    [[maybe_unused]] const unsigned zlt = ln.tid - zw0;
+    [[maybe_unused]] const unsigned zlds = ZDMA ? lds_address(s_z + wave_index() * (2 * ZIMG)) : 0u;
+    [[maybe_unused]] auto dma_z = [&](long tt, unsigned buf) {
+        const long tq = tt < T ? tt : T - 1;
+        const dma_rsrc_t rz = make_dma_rsrc(pz + tq * N * NZ, (unsigned)N * (unsigned)NZ * 8u);
+        const unsigned img = zlds + buf * (unsigned)(ZIMG * 8);
+        if constexpr (LAYOUT == LAYOUT_AOS) {
+            // the slab is 64 * NZ doubles in one piece
+            const unsigned g0 = ((unsigned)blk0 + zw0) * (unsigned)NZ * 8u;
+            FK_UNROLL for (int h = 0; h < 2 * NZ; ++h) lds_dma4(rz, g0 + (unsigned)h * 256u + lane * 4u, 0u, img + (unsigned)h * 256u);
+        } else {
+            // element c of the slab: 512 contiguous bytes
+            const unsigned g0 = ((unsigned)blk0 + zw0) * 8u;
+            FK_UNROLL for (int c = 0; c < NZ; ++c)
+                FK_UNROLL for (int h = 0; h < 2; ++h)
+                    lds_dma4(rz, g0 + (unsigned)h * 256u + lane * 4u, (unsigned)c * (unsigned)N * 8u, img + (unsigned)(c * 512 + h * 256));
+        }
+    };
 
     RegModel<NX, NZ> tm;                       // per-track models (MMODE 1, 2)
     constexpr long FSZ = NX * NX, HSZ = NZ * NX, RSZ = NZ * NZ;
@@ -171,7 +206,11 @@ kf_fast_kernel(const KfArgs a, const double *__restrict__ pF, const double *__re
     double zb[3][ZW];
     bool hb[3] = {true, true, true};
     auto load_z = [&](long tt, double (&zd)[ZW], bool &hd) {
-        const long tq = tt < T ? tt : T - 1;          // clamp: always issue the same number of loads
+        long tq = tt < T ? tt : T - 1;                // clamp: always issue the same number of loads
+        // the rolled loop of dim_x >= 7 (below): opaque, or the compiler re-derives this load one iteration LATER -- right in
+        // front of its use, each element followed by its own s_waitcnt vmcnt(0): no prefetch at all and four pipeline drains
+        // per step (round 4, ISA of kf_fast 8_4; kf_ml.hip does the same for the same reason)
+        if constexpr (NX > 6) asm volatile("" : "+s"(tq));
         {
             const RecView<LAYOUT> zv(pz + tq * N * NZ, lr, NZ);
             FK_UNROLL for (int c = 0; c < NZ; ++c) zd[c] = zv.load(c);
@@ -182,7 +221,12 @@ kf_fast_kernel(const KfArgs a, const double *__restrict__ pF, const double *__re
         }
         if (HAS_MASK) hd = pmask[tq * N + lr.blk0 + lr.tid] != 0;
     };
-    load_z(0, zb[0], hb[0]);
+    if constexpr (ZDMA) {
+        dma_z(0, 0u);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+        load_z(0, zb[0], hb[0]);
+    }
     if (ZDEPTH == 2) load_z(1, zb[1], hb[1]);
     // Land every prologue load before the loop: a load still pending at the loop header would
     // make the compiler wait vmcnt(0) inside the loop on every iteration (draining the stores).
@@ -202,7 +246,17 @@ kf_fast_kernel(const KfArgs a, const double *__restrict__ pF, const double *__re
     }
     // one time step: consumes (zu, hu), requests the measurement of step t + ZDEPTH into (zl, hl)
     auto step = [&](long t, const double (&zu)[ZW], bool hu, double (&zl)[ZW], bool &hl) {
-        load_z(t + ZDEPTH, zl, hl);
+        double zdm[ZDMA ? NZ : 1];
+        if constexpr (ZDMA) {
+            // this step's image (requested a step ago), then the request for the next one into the other image
+            if constexpr (OUTS) asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const double *img = s_z + wave * (2 * ZIMG) + (unsigned)(t & 1) * ZIMG;
+            FK_UNROLL for (int c = 0; c < NZ; ++c) zdm[c] = (LAYOUT == LAYOUT_AOS) ? img[zlt * NZ + c] : img[c * 64 + zlt];
+            dma_z(t + 1, (unsigned)((t + 1) & 1));          // (the other image: nothing in flight reads or writes it)
+        } else {
+            load_z(t + ZDEPTH, zl, hl);
+        }
         if constexpr (MMODE == 2) {
             if (t > 0) load_track_model(t);            // this step's per-track model
         }
@@ -241,6 +295,9 @@ kf_fast_kernel(const KfArgs a, const double *__restrict__ pF, const double *__re
                 wave_store_aos_pitch<NX * NX>(Pf, a.covs_p + t * a.cov_step + blk0 * a.cov_pitch, wave * 64u, tile, lane, last_row, (unsigned)a.cov_pitch);
             }
         };
+        // (the NumPy-order plain kernel at dim_x 8 has its register peak in the update half -- the full covariance staged for the
+        //  slab store sits next to it --: the H / R copy of model_cached spilled 184 B there and is switched off)
+        constexpr bool UPDC = NX <= 8 && !(COOP && !EX && NX == 8);      // (dim_x 9: no room for it at all)
         auto do_update = [&]() {
             // EX: the update's by-products leave the branch below in registers; the histories are formed from them in
             // straight-line code with per-lane selects (a lane without a measurement keeps y = 0 and the LAST K / S / SI /
@@ -253,12 +310,12 @@ kf_fast_kernel(const KfArgs a, const double *__restrict__ pF, const double *__re
             }
             if (hu) {
                 double zq[NZ];
-                FK_UNROLL for (int c = 0; c < NZ; ++c) zq[c] = zu[c];
+                FK_UNROLL for (int c = 0; c < NZ; ++c) zq[c] = ZDMA ? zdm[ZDMA ? c : 0] : zu[c];
                 if constexpr (MMODE == 1 || MMODE == 2) {
                     if constexpr (SYM) st |= kf_update_sym<NX, NZ>(x, P, zq, tm, K, y, S, Lf, dinv);
                     else st |= kf_update<NX, NZ>(x, P, zq, tm, K, y, S, Lf, dinv);
                 } else {
-                    if constexpr (SYM) st |= kf_update_sym<NX, NZ>(x, P, zq, sm, K, y, S, Lf, dinv);
+                    if constexpr (SYM) st |= kf_update_sym<NX, NZ, false, UPDC>(x, P, zq, sm, K, y, S, Lf, dinv);
                     else st |= kf_update<NX, NZ>(x, P, zq, sm, K, y, S, Lf, dinv);
                 }
             }
@@ -357,8 +414,10 @@ kf_fast_kernel(const KfArgs a, const double *__restrict__ pF, const double *__re
         static_assert(NX <= 6 || ZDEPTH == 1, "the rolled loop implements ZDEPTH == 1");
         for (long t = 0; t < T; ++t) {
             step(t, zb[0], hb[0], zb[1], hb[1]);
-            FK_UNROLL for (int i = 0; i < ZW; ++i) zb[0][i] = zb[1][i];
-            hb[0] = hb[1];
+            if constexpr (!ZDMA) {
+                FK_UNROLL for (int i = 0; i < ZW; ++i) zb[0][i] = zb[1][i];
+                hb[0] = hb[1];
+            }
         }
     }
 
