@@ -485,6 +485,45 @@ __device__ __forceinline__ void lds_dma4(dma_rsrc_t rs, unsigned voff, unsigned 
                  : "=&s"(keep) : "v"(voff), "s"(rs), "s"(soff), "s"(lds_addr) : "memory");
 }
 
+// One NZ-double record per lane (a measurement), fetched a time step ahead by LDS-DMA: for kernels that run one wave per
+// SIMD with no VGPR to spare -- a register prefetch there is parked in an AGPR the moment it is issued, i.e. waited for on the
+// spot with vmcnt(0), behind every store of the previous step.  Lane l requests the two dwords of each of its OWN record's
+// elements (2 NZ dword-DMA instructions per step; dword alignment is all they need; a lane that left the kernel or duplicates
+// another track needs no special case); they land in planes [element][dword half][lane] of one of two images per wave.
+// The caller waits (hipcc does not count these loads) with s_waitcnt vmcnt(k), k = min(63, vector-memory operations it has
+// issued since the request) -- vmcnt retires in order -- before read().
+template <int NZ, int LAYOUT>
+struct LaneRecordDma {
+    static constexpr int IMG_DOUBLES = NZ * 64;                  // per image
+    unsigned lds, voff, soff_e;                                  // wave's LDS byte address; lane's byte offset; element stride (SOA) in bytes
+    const unsigned *img0;
+    unsigned lane;
+    // s_wave: this wave's 2 * IMG_DOUBLES doubles of LDS; rec: the lane's record index inside a step's block; N: records per block
+    __device__ __forceinline__ void init(const double *s_wave, unsigned rec, unsigned N, unsigned lane_)
+    {
+        lds = lds_address(s_wave);
+        img0 = reinterpret_cast<const unsigned *>(s_wave);
+        lane = lane_;
+        voff = LAYOUT == LAYOUT_AOS ? rec * (unsigned)NZ * 8u : rec * 8u;
+        soff_e = LAYOUT == LAYOUT_AOS ? 0u : N * 8u;
+    }
+    // block: the step's [N][NZ] (AOS) / [NZ][N] (SOA) array; bytes: its size (the descriptor's range)
+    __device__ __forceinline__ void request(const double *block, unsigned bytes, unsigned buf) const
+    {
+        const dma_rsrc_t rs = make_dma_rsrc(block, bytes);
+        FK_UNROLL for (int c = 0; c < NZ; ++c)
+            FK_UNROLL for (int h = 0; h < 2; ++h)
+                lds_dma4(rs, voff + (LAYOUT == LAYOUT_AOS ? (unsigned)(c * 8) : 0u) + (unsigned)(h * 4), (unsigned)c * soff_e,
+                         lds + buf * (unsigned)(IMG_DOUBLES * 8) + (unsigned)((c * 2 + h) * 256));
+    }
+    __device__ __forceinline__ void read(unsigned buf, double (&z)[NZ]) const
+    {
+        const unsigned *img = img0 + buf * (unsigned)(IMG_DOUBLES * 2);
+        FK_UNROLL for (int c = 0; c < NZ; ++c)
+            z[c] = __hiloint2double((int)img[(c * 2 + 1) * 64 + lane], (int)img[(c * 2) * 64 + lane]);
+    }
+};
+
 // ---- host side ------------------------------------------------------------
 void set_last_error(const char *msg);
 int check_launch(const char *what);   // hipGetLastError -> FK_ERR_LAUNCH + message

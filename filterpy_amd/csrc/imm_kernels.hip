@@ -86,16 +86,44 @@ imm_kernel(const ImmArgs a)
     // there until they have drained -- once per step (the fused UKF lost 40 % of its wave time to exactly this wait).
     // Requested a step ahead, it is waited for with vmcnt(#stores of the step) in the instantiations whose outputs are
     // compile-time (the general kernel's stores are conditional: its wait stays conservative).
+    // ... which is what the ISA of the compiled-output instantiations did NOT show: the carried registers were waited for with
+    // vmcnt(2) / (1) / (0) at the END of every step, behind all of its stores (88 at (6,3) x 2).  Those instantiations now
+    // fetch the measurement by LDS-DMA (LaneRecordDma, fk_device.hpp): requested at the top of step t into one of two LDS
+    // images, read at the top of step t + 1 behind s_waitcnt vmcnt(k), k = the step's store instructions (at most 63) --
+    // hipcc does not see these loads, so the wait is exactly what the in-order counter needs and no more.
+    constexpr bool ZDMA = EXACT && OUTS >= 0;
+    // store instructions of one step (a lower bound: NumPy-order records leave as 16-byte pairs)
+    constexpr int ST_REC = LAYOUT == LAYOUT_AOS ? NX / 2 + NX * NX / 2 : NX + NX * NX;
+    constexpr int ST_STEP = ((OUTS & 1) ? ST_REC + NM : 0) + ((OUTS & 2) ? ST_REC : 0) + ((OUTS & 4) ? NM : 0);
+    constexpr int ZWAIT = ST_STEP < 63 ? ST_STEP : 63;
+    __shared__ double s_z[ZDMA ? (BLOCK / 64) * 2 * LaneRecordDma<NZ, LAYOUT>::IMG_DOUBLES : 1];
+    LaneRecordDma<NZ, LAYOUT> zdma;
     double zc[NZ];
-    {
+    if constexpr (ZDMA) {
+        // (the bank's state lands HERE, visibly to the compiler: left pending across the loop header, every first use inside
+        //  the loop gets a counted wait that also has to hold on the back edge -- i.e. drains the step's stores)
+        FK_UNROLL for (int j = 0; j < NM; ++j) {
+            asm volatile("" ::"v"(mu[j]));
+            FK_UNROLL for (int r = 0; r < NX; ++r) asm volatile("" ::"v"(xs[j][r]));
+            FK_UNROLL for (int e = 0; e < PL; ++e) asm volatile("" ::"v"(Ps[j][e]));
+        }
+        zdma.init(s_z + wave_index() * (2 * LaneRecordDma<NZ, LAYOUT>::IMG_DOUBLES), (unsigned)(ln.blk0 + ln.tid), (unsigned)N, threadIdx.x & 63u);
+        zdma.request(a.z, (unsigned)N * (unsigned)NZ * 8u, 0u);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
         const RecView<LAYOUT> vz(a.z, ln, m);
         FK_UNROLL for (int r = 0; r < NZ; ++r) zc[r] = (r < m) ? vz.load(r) : 0.0;
         FK_UNROLL for (int r = 0; r < NZ; ++r) asm volatile("" ::"v"(zc[r]));       // landed before the loop
     }
     for (long t = 0; t < a.T; ++t) {
         double z[NZ];
-        FK_UNROLL for (int r = 0; r < NZ; ++r) z[r] = zc[r];
-        {
+        if constexpr (ZDMA) {
+            if (t > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ZWAIT) : "memory");
+            zdma.read((unsigned)(t & 1), z);
+            const long tn = t + 1 < a.T ? t + 1 : t;
+            zdma.request(a.z + tn * N * NZ, (unsigned)N * (unsigned)NZ * 8u, (unsigned)((t + 1) & 1));
+        } else {
+            FK_UNROLL for (int r = 0; r < NZ; ++r) z[r] = zc[r];
             long tn = t + 1 < a.T ? t + 1 : t;
             asm volatile("" : "+s"(tn));      // opaque: keeps the compiler from re-deriving this load one iteration later
             const RecView<LAYOUT> vz(a.z + tn * N * m, ln, m);

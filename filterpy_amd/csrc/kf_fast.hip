@@ -102,10 +102,10 @@ kf_fast_kernel(const KfArgs a, const double *__restrict__ pF, const double *__re
     // ZDMA (dim_x >= 7: one wave per SIMD, the plain and extras calls without a mask or a control input): the measurement of
     // step t + 1 travels HBM -> LDS by LDS-DMA while step t computes.  These instantiations have no VGPR to spare: a register
     // prefetch was "spilled" to an AGPR the moment it was issued, i.e. waited for on the spot with vmcnt(0) -- dim_z pipeline
-    // drains per step behind the previous step's 144 stores (round 4, ISA of kf_fast 8_4).  A wave's 64 measurements of one
-    // step are 2 dim_z dword-DMA instructions (256 B each, dword alignment suffices) into one of two images of 512 dim_z
-    // bytes; the image of step t is read at the top of step t behind s_waitcnt vmcnt(63) -- the DMA is older than the >= 72
-    // stores step t - 1 issued after it (vmcnt retires in order) -- or vmcnt(0) where a step has no stores to drain.
+    // drains per step behind the previous step's 144 stores (round 4, ISA of kf_fast 8_4).  LaneRecordDma (fk_device.hpp): 2 dim_z
+    // dword-DMA instructions per step into one of two images; the image of step t is read at the top of step t behind
+    // s_waitcnt vmcnt(63) -- the DMA is older than the >= 72 stores step t - 1 issued after it (vmcnt retires in order) -- or
+    // vmcnt(0) where a step has no stores to drain.
     constexpr bool ZDMA = NX > 6 && !CTRL && !HAS_MASK && FK_FAST_ZDMA;
     constexpr int ZIMG = 64 * NZ;                             // doubles per image
     __shared__ double s_z[ZDMA ? (BLOCK / 64) * 2 * ZIMG : 1];
@@ -128,26 +128,12 @@ kf_fast_kernel(const KfArgs a, const double *__restrict__ pF, const double *__re
     const Lane lr = ln;
     const unsigned lane = tid & 63u, wave = tid >> 6;
     double *tile = s_mem + MSIZE + wave * TILE;
-    // ZDMA: the 64-track slab this wave fetches (a wave past the bank's last track duplicates that track: it fetches the slab
-    // the track lives in), its LDS images, this lane's track inside the slab
-    const unsigned zw0 = ZDMA ? min(wave_index() * 64u, last_row & ~63u) : 0u;
-    [[maybe_unused]] const unsigned zlt = ln.tid - zw0;
-    [[maybe_unused]] const unsigned zlds = ZDMA ? lds_address(s_z + wave_index() * (2 * ZIMG)) : 0u;
+    // ZDMA: every lane fetches its own (clamped) track's measurement (LaneRecordDma, fk_device.hpp)
+    LaneRecordDma<NZ, LAYOUT> zdma;
+    if constexpr (ZDMA) zdma.init(s_z + wave_index() * (2 * ZIMG), (unsigned)blk0 + ln.tid, (unsigned)N, lane);
     [[maybe_unused]] auto dma_z = [&](long tt, unsigned buf) {
         const long tq = tt < T ? tt : T - 1;
-        const dma_rsrc_t rz = make_dma_rsrc(pz + tq * N * NZ, (unsigned)N * (unsigned)NZ * 8u);
-        const unsigned img = zlds + buf * (unsigned)(ZIMG * 8);
-        if constexpr (LAYOUT == LAYOUT_AOS) {
-            // the slab is 64 * NZ doubles in one piece
-            const unsigned g0 = ((unsigned)blk0 + zw0) * (unsigned)NZ * 8u;
-            FK_UNROLL for (int h = 0; h < 2 * NZ; ++h) lds_dma4(rz, g0 + (unsigned)h * 256u + lane * 4u, 0u, img + (unsigned)h * 256u);
-        } else {
-            // element c of the slab: 512 contiguous bytes
-            const unsigned g0 = ((unsigned)blk0 + zw0) * 8u;
-            FK_UNROLL for (int c = 0; c < NZ; ++c)
-                FK_UNROLL for (int h = 0; h < 2; ++h)
-                    lds_dma4(rz, g0 + (unsigned)h * 256u + lane * 4u, (unsigned)c * (unsigned)N * 8u, img + (unsigned)(c * 512 + h * 256));
-        }
+        zdma.request(pz + tq * N * NZ, (unsigned)N * (unsigned)NZ * 8u, buf);
     };
 
     RegModel<NX, NZ> tm;                       // per-track models (MMODE 1, 2)
@@ -251,8 +237,7 @@ kf_fast_kernel(const KfArgs a, const double *__restrict__ pF, const double *__re
             // this step's image (requested a step ago), then the request for the next one into the other image
             if constexpr (OUTS) asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const double *img = s_z + wave * (2 * ZIMG) + (unsigned)(t & 1) * ZIMG;
-            FK_UNROLL for (int c = 0; c < NZ; ++c) zdm[c] = (LAYOUT == LAYOUT_AOS) ? img[zlt * NZ + c] : img[c * 64 + zlt];
+            zdma.read((unsigned)(t & 1), zdm);
             dma_z(t + 1, (unsigned)((t + 1) & 1));          // (the other image: nothing in flight reads or writes it)
         } else {
             load_z(t + ZDEPTH, zl, hl);
