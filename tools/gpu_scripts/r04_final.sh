@@ -7,7 +7,7 @@
 ulimit -c 0
 set -x
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r04fin
+O=$R/gpurun_out/r04fin2
 mkdir -p $O
 export TMPDIR=/tmp
 cd $R
