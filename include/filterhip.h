@@ -151,7 +151,11 @@ typedef struct fk_kf_extras {
     double *log_likelihood, *mahalanobis;
 } fk_kf_extras;
 
-/* fk_kf_batch_filter_f64 plus the histories above (ex may be NULL). */
+/* fk_kf_batch_filter_f64 plus the histories above (ex may be NULL).  Which kernel serves the call (all are tested against
+ * the same oracle): the plain call (shared constant model, predict -> update, all four outputs) runs on the specialised kernels'
+ * extras instantiations -- one lane per track at dim_x <= 9, four lanes per track at dim_x 10..16 and (9,3) (the latter without
+ * a mask) --; every other combination (per-track / per-step models, control input, update_first, a subset of the outputs)
+ * on the generic kernel. */
 int fk_kf_batch_filter_ex_f64(const fk_kf_desc *desc,
                               const double *F, const double *Q, const double *H, const double *R,
                               const double *B, const double *u,
