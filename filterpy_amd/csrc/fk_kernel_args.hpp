@@ -27,6 +27,11 @@ struct KfArgs {
     // cov_pitch: doubles between the records of consecutive tracks in NumPy order (n^2, or 2 n^2 interleaved).
     long cov_step;
     int cov_pitch;
+    // kf_ml PERS instantiations (persistent grid: one ticket per (time chunk, workgroup of tracks), kf_ml.hip): ctl[0] the
+    // ticket counter, ctl[1 + g] how many time chunks of track group g are complete; G groups x H chunks
+    int *pers_ctl;
+    int pers_G, pers_H;
+    double *pers_ws;    // [n + n*n][N] element-major: the state between the chunks of a group (coalesced in both layouts)
 };
 
 struct RtsArgs {

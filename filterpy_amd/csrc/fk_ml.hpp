@@ -69,13 +69,17 @@ struct MlView {
         // gets hoisted out of the time loop (60 SGPRs) and the scalar file spills into VGPRs
         asm volatile("" : "+s"(estride));
     }
+    // AUX: the instruction's cache-policy bits (gfx950: 16 = sc1, agent scope -- the access is coherent across the XCDs' L2s
+    // by itself; the persistent grid hands a track's state from one workgroup to another this way, without L2 write-backs)
+    template <int AUX = 0>
     __device__ __forceinline__ double load(int e) const
     {
-        return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, voff, (unsigned)e * estride, 0));
+        return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, voff, (unsigned)e * estride, AUX));
     }
+    template <int AUX = 0>
     __device__ __forceinline__ void store(int e, double x) const
     {
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, x), rs, voff, (unsigned)e * estride, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, x), rs, voff, (unsigned)e * estride, AUX);
     }
     // Two elements per lane as ONE 16-byte store.  In the element-major layout the 16 bytes next to a
     // lane's value belong to the next track, i.e. to the next quad: even quads write element e of tracks

@@ -165,10 +165,23 @@ __device__ __forceinline__ void ml_store_soa_slab(const double (&x)[NX], const d
 // contiguous bytes per store instruction) at the two points of the step where a set is complete -- instead of the PAIRS
 // scheme's DPP half-exchange per pair (136 v_mov_dpp + the store-data hazard nops per step, in a kernel bound by VALU
 // issue).  Any N (an odd tail's last track leaves as 8 bytes).  FK_ML_SLAB=0 selects the PAIRS / 8-byte instantiations.
-template <int R, int NZ, bool OUTS, int WAVES, bool PAIRS, bool MASK, int LAYOUT, bool VAR = false, bool UF = false, bool SLAB = false>
+// PERS (round 4): a persistent grid instead of one workgroup per 64 tracks for all T steps.  Every wave runs the same T steps, so
+// W waves on S wave slots cost ceil(W / S) rounds: configs[2]'s 6250 waves on 2048 slots pay for a fourth round that is 5 %
+// full (measured: 2 / 3 / 4 whole rounds 2.18 / 3.04 / 4.03 ms, N = 1e5 3.40 ms).  The multi-stream tail filling of
+// fk_chunks.hpp returns 1-4 % of that -- every piece is a kernel with its own launch gap and its own tail.  Here the call is
+// cut into G = ceil(N / 64) track groups x H time chunks and 512 resident workgroups draw TICKETS, chunk-major (all groups'
+// chunk h before any chunk h + 1): a workgroup that finishes early simply takes the next ticket.  Chunk h of a group needs
+// chunk h - 1 of the same group: its ticket is at least G >= 512 draws older, i.e. held by a workgroup that is running or
+// done -- no deadlock whatever is resident; the state travels through an element-major hand-over block of the call's scratch
+// allocation, written and read with agent-scope (sc1) accesses -- coherent across the XCDs' L2s without write-backs; NumPy-order
+// x / P in place would make them 8-byte accesses to 64 different lines per instruction -- and announced by a completion word.  Same arithmetic per track: results are bit-identical to the single launch.
+template <int R, int NZ, bool OUTS, int WAVES, bool PAIRS, bool MASK, int LAYOUT, bool VAR = false, bool UF = false, bool SLAB = false, bool PERS = false>
 __global__ void __launch_bounds__(BLOCK, WAVES)
-kf_ml_kernel(const KfArgs a)
+kf_ml_kernel(const KfArgs a_in)
 {
+    static_assert(!PERS || (OUTS && !VAR && !PAIRS && (LAYOUT == LAYOUT_AOS || SLAB)), "PERS: the plain call with outputs that leave in their own step");
+    constexpr int HAUX = PERS ? 16 : 0;      // cache policy of the state hand-over: sc1 = agent scope (MlView::load / store)
+    KfArgs a = a_in;
     constexpr int NX = 3 * R;
     using LM = LdsModel<NX, NZ>;
     constexpr bool AOS = LAYOUT == LAYOUT_AOS;
@@ -214,13 +227,46 @@ kf_ml_kernel(const KfArgs a)
     __syncthreads();
     const double *sF = smem + LM::OFF_F, *sQ = smem + LM::OFF_Q, *sH = smem + LM::OFF_H, *sR = smem + LM::OFF_R;
 
+    [[maybe_unused]] int pers_g = 0, pers_h = 0;
+    __shared__ int s_task;
+    for (;;) {                                                   // PERS: one trip per ticket; otherwise exactly one trip
+    unsigned bid = blockIdx.x;
+    if constexpr (PERS) {
+        __syncthreads();                                         // the previous ticket's LDS traffic is over, s_task is free
+        if (threadIdx.x == 0) s_task = atomicAdd(a_in.pers_ctl, 1);
+        __syncthreads();
+        const int task = __builtin_amdgcn_readfirstlane(s_task);
+        const int G = a_in.pers_G, H = a_in.pers_H;
+        if (task >= G * H) break;
+        pers_h = task / G;
+        pers_g = task - pers_h * G;
+        bid = (unsigned)pers_g;
+        const long t0 = a_in.T * pers_h / H, t1 = a_in.T * (pers_h + 1) / H, NN = a_in.N;
+        a = a_in;
+        a.T = t1 - t0;
+        a.z = a_in.z + t0 * NN * NZ;
+        a.mask = a_in.mask ? a_in.mask + t0 * NN : nullptr;
+        a.means = a_in.means + t0 * NN * (3 * R);
+        a.means_p = a_in.means_p + t0 * NN * (3 * R);
+        a.covs = a_in.covs + t0 * NN * (9 * R * R);
+        a.covs_p = a_in.covs_p + t0 * NN * (9 * R * R);
+        a.status_or = t0 > 0 ? 1 : a_in.status_or;
+        if (pers_h > 0) {
+            // (the state is then read with agent-scope loads: no acquire fence, i.e. no L2 invalidation, is needed)
+            if (threadIdx.x == 0) {
+                while (__hip_atomic_load(&a_in.pers_ctl[1 + pers_g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < pers_h) __builtin_amdgcn_s_sleep(8);
+            }
+            __syncthreads();
+        }
+    }
+
     const long N = a.N;
     const unsigned L = threadIdx.x & 3u;
     const unsigned Lc = L < 3u ? L : 2u;                       // lane 3 mirrors lane 2
     // this launch handles tracks [i0, iend) of the bank (N stays the array stride): the whole bank, or one track group
     // of a chunked call (launch_kf_ml_9_3: groups start on multiples of 64 tracks)
     const long iend = a.i0 + a.cnt;
-    long trk = a.i0 + (long)blockIdx.x * (BLOCK / 4) + (threadIdx.x >> 2);
+    long trk = a.i0 + (long)bid * (BLOCK / 4) + (threadIdx.x >> 2);
     const unsigned odd = (threadIdx.x >> 2) & 1u;              // odd quad of its pair (workgroups start on even tracks)
     const bool owner = trk < iend;                             // tail quads only duplicate: they never write the final state
     if (trk >= iend) trk = PAIRS ? iend - 2 + odd : iend - 1;  // tail quads recompute the last track (pair)
@@ -235,7 +281,7 @@ kf_ml_kernel(const KfArgs a)
     const unsigned pair_rows = odd ? off_rows - 8u + estride : off_rows;
     const unsigned pair_x = odd ? t8 - 8u + estride : t8;
     // AOS output slabs: first track of this wave and how many of its 16 tracks exist
-    const long w0 = a.i0 + (long)blockIdx.x * (BLOCK / 4) + (long)wave_index() * 16;        // scalar: see wave_index()
+    const long w0 = a.i0 + (long)bid * (BLOCK / 4) + (long)wave_index() * 16;               // scalar: see wave_index()
     const unsigned valid = (unsigned)(iend - w0 >= 16 ? 16 : (iend - w0 > 0 ? iend - w0 : 0));
     const unsigned lane = threadIdx.x & 63u;
     const double *myF = sF + Lc * (R * NX);                     // this lane's rows of F and Q
@@ -259,10 +305,20 @@ kf_ml_kernel(const KfArgs a)
 #define HX(e) (HLDS ? sH[(e)] : Hreg[HLDS ? 0 : (e)])
     double P[R][NX], x[NX];
     {
-        const MlView vP(a.P, off_rows, estride), vx(a.x, t8, estride);
-        FK_UNROLL for (int r = 0; r < R; ++r)
-            FK_UNROLL for (int c = 0; c < NX; ++c) P[r][c] = vP.load(r * NX + c);
-        FK_UNROLL for (int k = 0; k < NX; ++k) x[k] = vx.load(k);
+        if (PERS && pers_h > 0) {
+            // a later chunk of the group: the state the previous chunk left in the hand-over block (element-major whatever the
+            // layout: 512 contiguous bytes per wave instruction; agent-scope loads)
+            const unsigned n8 = (unsigned)N * 8u;
+            const MlView wx(a_in.pers_ws, (unsigned)trk * 8u, n8), wP(a_in.pers_ws + (long)NX * N, (unsigned)trk * 8u + Lc * (unsigned)(R * NX) * n8, n8);
+            FK_UNROLL for (int r = 0; r < R; ++r)
+                FK_UNROLL for (int c = 0; c < NX; ++c) P[r][c] = wP.template load<HAUX>(r * NX + c);
+            FK_UNROLL for (int k = 0; k < NX; ++k) x[k] = wx.template load<HAUX>(k);
+        } else {
+            const MlView vP(a.P, off_rows, estride), vx(a.x, t8, estride);
+            FK_UNROLL for (int r = 0; r < R; ++r)
+                FK_UNROLL for (int c = 0; c < NX; ++c) P[r][c] = vP.load(r * NX + c);
+            FK_UNROLL for (int k = 0; k < NX; ++k) x[k] = vx.load(k);
+        }
         // land the prologue loads here: left pending, the loop header's s_waitcnt (which must cover this
         // path too) makes every iteration wait for the previous step's stores
         FK_UNROLL for (int r = 0; r < R; ++r)
@@ -554,21 +610,45 @@ kf_ml_kernel(const KfArgs a)
     // consumed its initial state once it arrives here (one barrier per launch, outside the time loop)
     __syncthreads();
     if (owner) {
-        const MlView vx(a.x, t8, estride), vP(a.P, off_rows, estride);
         bool fin = all_finite<NX>(x);
-        FK_UNROLL for (int k = 0; k < NX; ++k) vx.store(k, x[k]);
-        FK_UNROLL for (int r = 0; r < R; ++r) {
-            FK_UNROLL for (int c = 0; c < NX; ++c) {
-                vP.store(r * NX + c, P[r][c]);
-                fin = fin && (fabs(P[r][c]) <= 1.79769313486231570815e+308);
-            }
+        FK_UNROLL for (int r = 0; r < R; ++r)
+            FK_UNROLL for (int c = 0; c < NX; ++c) fin = fin && (fabs(P[r][c]) <= 1.79769313486231570815e+308);
+        if (PERS && pers_h + 1 < a_in.pers_H) {
+            // not the group's last chunk: the state goes to the hand-over block (agent-scope stores), x / P stay untouched
+            const unsigned n8 = (unsigned)N * 8u;
+            const MlView wx(a_in.pers_ws, (unsigned)trk * 8u, n8), wP(a_in.pers_ws + (long)NX * N, (unsigned)trk * 8u + Lc * (unsigned)(R * NX) * n8, n8);
+            FK_UNROLL for (int k = 0; k < NX; ++k) wx.template store<HAUX>(k, x[k]);
+            FK_UNROLL for (int r = 0; r < R; ++r)
+                FK_UNROLL for (int c = 0; c < NX; ++c) wP.template store<HAUX>(r * NX + c, P[r][c]);
+        } else {
+            const MlView vx(a.x, t8, estride), vP(a.P, off_rows, estride);
+            FK_UNROLL for (int k = 0; k < NX; ++k) vx.store(k, x[k]);
+            FK_UNROLL for (int r = 0; r < R; ++r)
+                FK_UNROLL for (int c = 0; c < NX; ++c) vP.store(r * NX + c, P[r][c]);
         }
         if (a.status) {
             int s = st | (fin ? 0 : ST_NONFINITE);
             s |= __builtin_amdgcn_mov_dpp(s, 0x55 * 1, 0xf, 0xf, true) | __builtin_amdgcn_mov_dpp(s, 0x55 * 2, 0xf, 0xf, true);
-            if (L == 0) a.status[trk] = a.status_or ? (a.status[trk] | s) : s;
+            if constexpr (PERS) {
+                if (L == 0) {
+                    const int old = a.status_or ? __hip_atomic_load(&a.status[trk], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+                    __hip_atomic_store(&a.status[trk], old | s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            } else {
+                if (L == 0) a.status[trk] = a.status_or ? (a.status[trk] | s) : s;
+            }
         }
     }
+    if constexpr (PERS) {
+        // this chunk's final state (and status) is in place -- written with agent-scope stores, which are coherent across the
+        // XCDs by themselves (a release FENCE here writes back the whole L2 the kernel is streaming 14 GB of outputs through:
+        // measured 0.55 ms per chunk) -- and complete once the barrier's vmcnt(0) has passed: publish the chunk
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(&a_in.pers_ctl[1 + pers_g], pers_h + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        break;
+    }
+    }      // tickets
 }
 
 #if FK_ML_PART != 2
@@ -869,6 +949,7 @@ int launch_rts_ml_9(const RtsArgs &a, int layout, bool uniform, hipStream_t s)
 int launch_kf_ml_9_3_var(const KfArgs &a, int layout, hipStream_t s);
 static int launch_kf_ml_one(const KfArgs &a, int layout, bool outs, hipStream_t s);
 static int launch_kf_ml_chunked(const KfArgs &a, int layout, bool outs, hipStream_t s);
+static int launch_kf_ml_persistent(const KfArgs &a, int layout, bool outs, hipStream_t s);
 
 // returns 1 when this call is not one the multi-lane kernel serves
 int launch_kf_ml_9_3(const KfArgs &a, int layout, bool outs, int model_mode, hipStream_t s)
@@ -881,7 +962,56 @@ int launch_kf_ml_9_3(const KfArgs &a, int layout, bool outs, int model_mode, hip
         if (!outs || a.nu > 4 || (vv && atoi(vv) == 0)) return 1;
         return kf_chunked_call(a, 9, 3, 2048, [layout](const KfArgs &b, hipStream_t sb) { return launch_kf_ml_9_3_var(b, layout, sb); }, s);
     }
+    {
+        const int rc = launch_kf_ml_persistent(a, layout, outs, s);
+        if (rc <= 0) return rc;                                // 1 = not a call the persistent grid takes
+    }
     return launch_kf_ml_chunked(a, layout, outs, s);
+}
+
+// The persistent grid (PERS instantiations): where the bank is more workgroups than the chip holds at once and long enough
+// to cut -- G = ceil(cnt / 64) track groups x H time chunks of >= 16 steps, 2 workgroups per CU drawing tickets.  The
+// ticket counter and the G completion words live in a stream-ordered scratch allocation of this call (hipMallocAsync: no
+// state shared between concurrent calls; capturable).  FK_ML_PERSIST=0: off (the multi-stream tail filling below).
+static int launch_kf_ml_persistent(const KfArgs &a, int layout, bool outs, hipStream_t s)
+{
+    const char *pv = getenv("FK_ML_PERSIST");
+    if (pv && atoi(pv) == 0) return 1;
+    const char *sv = getenv("FK_ML_SLAB");
+    const bool slab = !(sv && atoi(sv) == 0);
+    if (!outs || (layout != FK_LAYOUT_AOS && !slab)) return 1;
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+                   ? prop.multiProcessorCount : 256;
+    }
+    const long G = (a.cnt + BLOCK / 4 - 1) / (BLOCK / 4), slots = 2L * n_cu;
+    // chunks: more of them shorten the tail (ceil(G H / slots) rounds of T / H steps) but each costs a state reload and a
+    // pipeline start -- three measured best at configs[2] (3.10 ms; 4: 3.15, 6: 3.22, 10: 3.29; one launch 3.39)
+    long H = a.T >= 48 ? 3 : a.T / 16;
+    if (const char *hv = getenv("FK_ML_PERSIST_H")) H = atol(hv);
+    if (G <= slots || H < 2 || G > (1L << 24)) return 1;
+    int *ctl = nullptr;
+    const size_t cbytes = ((size_t)(1 + G) * sizeof(int) + 255) & ~(size_t)255, wbytes = (size_t)90 * (size_t)a.N * sizeof(double);
+    if (hipMallocAsync((void **)&ctl, cbytes + wbytes, s) != hipSuccess || !ctl) { (void)hipGetLastError(); return 1; }
+    if (hipMemsetAsync(ctl, 0, cbytes, s) != hipSuccess) { (void)hipFreeAsync(ctl, s); (void)hipGetLastError(); return 1; }
+    KfArgs b = a;
+    b.pers_ctl = ctl;
+    b.pers_ws = reinterpret_cast<double *>(reinterpret_cast<char *>(ctl) + cbytes);
+    b.pers_G = (int)G;
+    b.pers_H = (int)H;
+    const dim3 grid((unsigned)slots), block(BLOCK);
+#define GOP(M)                                                                                                              \
+    if (layout == FK_LAYOUT_AOS)                                                                                            \
+        hipLaunchKernelGGL((kf_ml_kernel<3, 3, true, FK_ML_WAVES, false, M, LAYOUT_AOS, false, false, false, true>), grid, block, 0, s, b); \
+    else hipLaunchKernelGGL((kf_ml_kernel<3, 3, true, FK_ML_WAVES, false, M, LAYOUT_SOA, false, false, true, true>), grid, block, 0, s, b)
+    if (a.mask) { GOP(true); } else { GOP(false); }
+#undef GOP
+    const int rc = check_launch("kf_ml_kernel<pers>");
+    (void)hipFreeAsync(ctl, s);
+    return rc;
 }
 
 // one launch over tracks [a.i0, a.i0 + a.cnt), a.T steps from the pointers in `a`

@@ -855,6 +855,60 @@ def test_saver_histories_from_the_specialised_kernel(n, m, layout, monkeypatch):
     assert np.array_equal(h1["log_likelihood"], _run_ex(x0, P0, zs, F, Q, H, R, layout)[1]["log_likelihood"])
 
 
+@pytest.mark.parametrize("masked", [False, True])
+@pytest.mark.parametrize("layout", ["soa", "aos"])
+def test_three_lane_persistent_grid_is_bit_identical(layout, masked, monkeypatch):
+    """Round 4: banks of more workgroups than the chip holds at once run on a PERSISTENT grid -- 512 workgroups draw tickets,
+    one per (time chunk, group of 64 tracks), chunk-major; a chunk waits for its group's previous chunk through a completion
+    word and picks the state up from x / P in place (kf_ml.hip, PERS).  Same arithmetic per track: every output, the final
+    state and the status equal the single launch's (FK_ML_PERSIST=0, FK_ML_CHUNKS=1,1) bit for bit -- a ragged bank of
+    33 003 tracks (516 groups, the last one partial), 70 steps in 4 chunks, with and without missing measurements, a
+    non-positive-definite track -- and a forced decomposition into 7 chunks as well."""
+    import torch
+    from filterpy_amd import _engine as E
+    n, m, N, T = 9, 3, 33_003, 70
+    dev = torch.device("cuda")
+    g = torch.Generator(device=dev)
+    g.manual_seed(11)
+    rs = np.random.RandomState(3)
+    F = np.eye(n) + 0.05 * np.triu(rs.randn(n, n), 1)
+    A = rs.randn(n, n)
+    Q = 0.05 * (A @ A.T / n + 0.5 * np.eye(n))
+    H = rs.randn(m, n)
+    R = 0.5 * np.eye(m)
+    z = E.alloc_records((T,), N, m, layout)
+    z.copy_(torch.randn(z.shape, generator=g, device=dev, dtype=torch.float64))
+    x0 = E.alloc_records((), N, n, layout)
+    x0.copy_(torch.randn(x0.shape, generator=g, device=dev, dtype=torch.float64))
+    P0h = np.tile(4.0 * np.eye(n), (N, 1, 1))
+    P0h[N // 2] = -np.eye(n)                                  # one track that is not positive definite: its status bit must survive the chunks
+    P0 = E.to_records(P0h, layout, 0)
+    mask = (torch.rand((T, N), generator=g, device=dev) > 0.2).to(torch.uint8) if masked else None
+    desc = dict(n=n, m=m, nu=0, model_mode=0, N=N, T=T, layout=E.LAYOUTS[layout], update_first=0, alpha_sq=1.0)
+    mods = [E.dev(M) for M in (F, Q, H, R)]
+
+    def run():
+        x, P = x0.clone(), P0.clone()
+        outs = [E.alloc_records((T,), N, w, layout).fill_(float("nan")) for w in (n, n * n, n, n * n)]
+        st = torch.zeros(N, dtype=torch.int32, device=dev)
+        E.kf_batch_filter(desc, *mods, z, x, P, mask=mask, means=outs[0], covs=outs[1], means_p=outs[2], covs_p=outs[3], status=st)
+        torch.cuda.synchronize()
+        return outs + [x, P, st]
+
+    with monkeypatch.context() as mp:
+        mp.setenv("FK_ML_PERSIST", "0")
+        mp.setenv("FK_ML_CHUNKS", "1,1")
+        ref = run()
+    assert int(ref[6][N // 2]) != 0 and int((ref[6] != 0).sum()) == 1
+    for env in ({}, {"FK_ML_PERSIST_H": "7"}):
+        with monkeypatch.context() as mp:
+            for k, v in env.items():
+                mp.setenv(k, v)
+            got = run()
+        for i, (a, b) in enumerate(zip(got, ref)):
+            assert torch.equal(a.view(torch.int64) if a.dtype == torch.float64 else a, b.view(torch.int64) if b.dtype == torch.float64 else b), (layout, masked, env, i)
+
+
 @pytest.mark.parametrize("layout", ["soa", "aos"])
 @pytest.mark.parametrize("N", [1000, 777, 64, 3])
 def test_three_lane_slab_outputs_equal_the_pair_store_build_bit_for_bit(N, layout, monkeypatch):
