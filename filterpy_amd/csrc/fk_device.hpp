@@ -498,6 +498,7 @@ struct LaneRecordDma {
     unsigned lds, voff, soff_e;                                  // wave's LDS byte address; lane's byte offset; element stride (SOA) in bytes
     const unsigned *img0;
     unsigned lane;
+    unsigned stride_doubles = IMG_DOUBLES;                       // doubles between the two images (a caller may keep more per image)
     // s_wave: this wave's 2 * IMG_DOUBLES doubles of LDS; rec: the lane's record index inside a step's block; N: records per block
     __device__ __forceinline__ void init(const double *s_wave, unsigned rec, unsigned N, unsigned lane_)
     {
@@ -514,11 +515,11 @@ struct LaneRecordDma {
         FK_UNROLL for (int c = 0; c < NZ; ++c)
             FK_UNROLL for (int h = 0; h < 2; ++h)
                 lds_dma4(rs, voff + (LAYOUT == LAYOUT_AOS ? (unsigned)(c * 8) : 0u) + (unsigned)(h * 4), (unsigned)c * soff_e,
-                         lds + buf * (unsigned)(IMG_DOUBLES * 8) + (unsigned)((c * 2 + h) * 256));
+                         lds + buf * (stride_doubles * 8u) + (unsigned)((c * 2 + h) * 256));
     }
     __device__ __forceinline__ void read(unsigned buf, double (&z)[NZ]) const
     {
-        const unsigned *img = img0 + buf * (unsigned)(IMG_DOUBLES * 2);
+        const unsigned *img = img0 + buf * (stride_doubles * 2u);
         FK_UNROLL for (int c = 0; c < NZ; ++c)
             z[c] = __hiloint2double((int)img[(c * 2 + 1) * 64 + lane], (int)img[(c * 2) * 64 + lane]);
     }

@@ -33,6 +33,11 @@
 #ifndef FK_NX
 #error "compile with -DFK_NX=<dim_x> -DFK_NZ=<dim_z>"
 #endif
+// FK_MLG_ZDMA (build time): 0 = measurement and mask prefetched into registers again (A/B), 1 = LDS-DMA in the element-major
+// kernels (measured +2..3 % at (10,2), (14,4), (16,4)), 2 = in the NumPy-order kernels too (measured -2..3 % at (12,3), (16,4))
+#ifndef FK_MLG_ZDMA
+#define FK_MLG_ZDMA 1
+#endif
 
 #define FK_MLG_CAT_(a, b, c) a##b##_##c
 #define FK_MLG_CAT(a, b, c) FK_MLG_CAT_(a, b, c)
@@ -194,10 +199,43 @@ kf_mlg_kernel(const KfArgs a)
         FK_UNROLL for (int k = 0; k < NX; ++k) asm volatile("" ::"v"(x[k]));
     }
     int st = 0;
+    // ZDMA (the plain call and its EX twin): the measurement and the mask byte of step t + 1 travel HBM -> LDS by LDS-DMA while
+    // step t computes (LaneRecordDma, fk_device.hpp; the byte as the aligned dword around it).  As register prefetches they
+    // were waited for at the end of the step with vmcnt(12 .. 24): a partial drain of the step's stores, with one wave per SIMD
+    // and nothing to cover it.  Read behind s_waitcnt vmcnt(k), k = the store instructions of a step (a lower bound, <= 63).
+    constexpr int ZIMGD = LaneRecordDma<NZ, LAYOUT>::IMG_DOUBLES + 32;        // + 64 dwords: the mask bytes' dwords
+    // (where the images fit next to the staging tiles: at dim_x 16 with dim_z >= 5 they do not)
+    constexpr long LDS_OTHER = (long)(MSZ + (AOS || SOA_SLAB || EX ? (BLOCK / 64) * TILE : 0)) * 8 + 64;
+    constexpr bool ZDMA = !VAR && (AOS ? FK_MLG_ZDMA >= 2 : FK_MLG_ZDMA >= 1) && LDS_OTHER + (long)(BLOCK / 64) * 2 * ZIMGD * 8 <= 160 * 1024;
+    constexpr int ZST = AOS ? 2 * ((16 * NX / 2 + 63) / 64 + (16 * NX * NX / 2 + 63) / 64)
+                            : (SOA_SLAB ? 2 * (NX + (NX * NX * 8 + 63) / 64) : 2 * (NX + R * NX));
+    constexpr int ZWAIT = ZST < 63 ? ZST : 63;
+    __shared__ double s_zd[ZDMA ? (BLOCK / 64) * 2 * ZIMGD : 1];
+    LaneRecordDma<NZ, LAYOUT> zdma;
+    [[maybe_unused]] auto zreq = [&](long tt, unsigned buf) {
+        zdma.request(a.z + tt * N * NZ, (unsigned)N * (unsigned)NZ * 8u, buf);
+        // the mask byte of (tt, trk): the aligned dword around it (base and its misalignment are wave-uniform)
+        const unsigned long long mb = reinterpret_cast<unsigned long long>(mask_or_dummy) + (unsigned long long)(tt * N);
+        const unsigned delta = (unsigned)(mb & 3ull);
+        const dma_rsrc_t rm = make_dma_rsrc(reinterpret_cast<const void *>(mb & ~3ull), (unsigned)N + 8u);
+        lds_dma4(rm, ((unsigned)trk + delta) & ~3u, 0u, zdma.lds + buf * (unsigned)(ZIMGD * 8) + (unsigned)(LaneRecordDma<NZ, LAYOUT>::IMG_DOUBLES * 8));
+    };
+    [[maybe_unused]] auto zread = [&](long tt, unsigned buf, double (&zd)[NZ]) -> unsigned {
+        zdma.read(buf, zd);                                    // (its images are ZIMGD apart: see init below)
+        const unsigned long long mb = reinterpret_cast<unsigned long long>(mask_or_dummy) + (unsigned long long)(tt * N);
+        const unsigned sh = (((unsigned)trk + (unsigned)(mb & 3ull)) & 3u) * 8u;
+        const unsigned dw = zdma.img0[buf * (unsigned)(ZIMGD * 2) + (unsigned)(LaneRecordDma<NZ, LAYOUT>::IMG_DOUBLES * 2) + (threadIdx.x & 63u)];
+        return (dw >> sh) & 0xffu;
+    };
     double zn[NZ];
     double un[VAR ? NUC : 1];
     unsigned hn = 1u;
-    {
+    if constexpr (ZDMA) {
+        zdma.init(s_zd + wave_index() * (2 * ZIMGD), (unsigned)trk, (unsigned)N, threadIdx.x & 63u);
+        zdma.stride_doubles = ZIMGD;
+        zreq(0, 0u);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
         const MlView vz(a.z, tz8, estride);
         FK_UNROLL for (int c = 0; c < NZ; ++c) zn[c] = vz.load(c);
         const unsigned hb = mask_or_dummy[trk];
@@ -216,12 +254,18 @@ kf_mlg_kernel(const KfArgs a)
     _Pragma("nounroll") for (long t = 0; t < a.T; ++t) {
         double z[NZ];
         double u[VAR ? NUC : 1];
+        if constexpr (ZDMA) {
+            if (t > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ZWAIT) : "memory");
+            const unsigned hb = zread(t, (unsigned)(t & 1), zn);
+            hn = a.mask ? hb : 1u;
+            zreq(t + 1 < a.T ? t + 1 : t, (unsigned)((t + 1) & 1));
+        }
         const bool has_z = hn != 0u;
         FK_UNROLL for (int c = 0; c < NZ; ++c) z[c] = has_z ? zn[c] : 0.0;
         if constexpr (VAR) {
             FK_UNROLL for (int c = 0; c < NUC; ++c) u[c] = un[c];
         }
-        {
+        if constexpr (!ZDMA) {
             long tn = t + 1 < a.T ? t + 1 : t;
             asm volatile("" : "+s"(tn));
             const MlView vz(a.z + tn * N * NZ, tz8, estride);
