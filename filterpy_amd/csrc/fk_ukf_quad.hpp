@@ -1,0 +1,234 @@
+// fk_ukf_quad.hpp -- one predict + update step of the fused linear-model UKF with FOUR LANES PER TRACK (dim_x 10..16): the
+// arithmetic of ukf_mlg.hip.  __host__ __device__ like fk_ukf.hpp: the kernel runs it with the quad exchanges as DPP moves,
+// tests/hostcheck runs the very same code on the host with the four lanes of a quad as four fibers (tests/test_hostcheck_ukf.py).
+//
+// The step is ukf_linear_step_v4 (fk_ukf.hpp: UKF.py:400-411, 462-481 with fx = F x, hx = H x, sums regrouped over the +- pairs of
+// sigma points; every sum below keeps v4's order of terms), distributed:
+//   * lane q of the quad holds rows q, q + 4, q + 8, ... of P (CYCLIC, not kf_mlg's blocks: column j of the Cholesky factor only
+//     touches rows below j, and with cyclic rows every lane has its share of them down to the last columns); a slot past row
+//     n-1 duplicates row n-1 (same inputs, same instructions: same values, so nothing is predicated); x is replicated;
+//   * the factor of scale * P column by column: the pivot and row j of the factor (final once column j-1 is done) are BROADCAST
+//     from their owner, each lane eliminates its own rows -- and the same broadcast row is all the images need:
+//         predict   F L (own rows) and F x (own rows) accumulate a row of L at a time:  FL[a][k] += F[a][j] L[j][k]
+//         update    H L (replicated, dim_z rows) likewise; the cross variance takes the lane's OWN rows of L
+//   * P- = (sum Wc) y0 y0' + sum_k wp_k f_k f_k' + Q: column k of F L is gathered (pre-multiplied by its pair weight by the
+//     owners), each lane accumulates its own rows;
+//   * S, its L D L' and z - zp are replicated; the gain's rows are solved by their owners and gathered one at a time for
+//     x += K (z - zp) and P -= K (S K').
+// The only exchange is "the value lane o of my quad holds" (quad.bcast<o>(v)); there is no cross-lane sum.  A row of P computed
+// by one lane and its mirror image computed by another agree to a rounding (f_a (w f_b) against f_b (w f_a)), not bit for
+// bit; the factorisation reads a row's own elements.
+// A missing measurement runs the update half on z = 0 with the gain, S and the residual selected to zero (no branch).
+#pragma once
+
+#include "fk_ukf.hpp"
+
+namespace fk {
+
+struct UkfQuadModel {
+    const double *F, *Q, *H, *R, *Wp;       // row-major [n][n], [n][n], [m][n], [m][m]; the pair table (make_pair_table)
+};
+
+// the value lane o of the quad holds (o is a constant wherever this is used, once the loops are unrolled)
+template <class Quad>
+FK_HD double quad_from(Quad &quad, double v, int o)
+{
+    if (o == 0) return quad.template bcast<0>(v);
+    if (o == 1) return quad.template bcast<1>(v);
+    if (o == 2) return quad.template bcast<2>(v);
+    return quad.template bcast<3>(v);
+}
+
+// Lower factor of scale * P, rows distributed cyclically (g[r]: the row slot r holds -- q + 4 r, clamped to NX - 1).
+// Lw[r][k], k <= 4 r + 3: the lane's rows (zero above the diagonal; entries past 4 r + 3 are never written nor read).
+// row_done(j, lrow, ljj): called once row j is final -- lrow[0..j-1] and the pivot's root, replicated in the quad.
+template <int NX, class Quad, class RowDone>
+FK_HD bool quad_chol_rows(const double (&P)[(NX + 3) / 4][NX], const unsigned (&g)[(NX + 3) / 4], double scale,
+                          double (&Lw)[(NX + 3) / 4][NX], Quad &quad, RowDone &&row_done)
+{
+    constexpr int R = (NX + 3) / 4;
+    bool pd = true;
+    FK_UNROLL for (int j = 0; j < NX; ++j) {
+        const int sj = j / 4, oj = j % 4;
+        // the pivot: every lane forms it for its row of slot sj, the owner's counts
+        double dl = scale * P[sj][j];
+        FK_UNROLL for (int k = 0; k < NX; ++k)
+            if (k < j) dl = fma(-Lw[sj][k], Lw[sj][k], dl);
+        const double d = quad_from(quad, dl, oj);
+        pd = pd && (d > 0.0);
+        double ljj, inv;
+        sqrt_rsqrt(d, ljj, inv);
+        double lrow[NX];
+        FK_UNROLL for (int k = 0; k < NX; ++k)
+            if (k < j) lrow[k] = quad_from(quad, Lw[sj][k], oj);
+        FK_UNROLL for (int r = 0; r < R; ++r) {
+            if (4 * r + 3 < j) continue;                      // the slot's rows all lie above row j
+            double t = scale * P[r][j];
+            FK_UNROLL for (int k = 0; k < NX; ++k)
+                if (k < j) t = fma(-Lw[r][k], lrow[k], t);
+            t *= inv;
+            if (4 * r > j) Lw[r][j] = t;                      // all of them below it
+            else Lw[r][j] = g[r] > (unsigned)j ? t : (g[r] == (unsigned)j ? ljj : 0.0);
+        }
+        row_done(j, lrow, ljj);
+        FK_STAGE();
+    }
+    return pd;
+}
+
+template <int NX, int NZ, class Quad>
+FK_HD int ukf_quad_step_v4(double (&x)[NX], double (&P)[(NX + 3) / 4][NX], const unsigned (&g)[(NX + 3) / 4],
+                           const double (&zin)[NZ], bool has_z, double scale, const UkfQuadModel &mv, Quad &quad)
+{
+    constexpr int R = (NX + 3) / 4;
+    int st = 0;
+    // ---------------- predict (UKF.py:400-411)
+    {
+        double FL[R][NX], Fxo[R];
+        {
+            double Lw[R][NX], fc[R];                          // fc: column j of F at the lane's rows, requested a column ahead
+            FK_UNROLL for (int r = 0; r < R; ++r) fc[r] = mv.F[g[r] * NX];
+            const bool pd = quad_chol_rows<NX>(P, g, scale, Lw, quad, [&](int j, const double (&lrow)[NX], double ljj) {
+                double f[R];
+                FK_UNROLL for (int r = 0; r < R; ++r) f[r] = fc[r];
+                if (j + 1 < NX) {
+                    FK_UNROLL for (int r = 0; r < R; ++r) fc[r] = mv.F[g[r] * NX + j + 1];
+                }
+                FK_UNROLL for (int r = 0; r < R; ++r) {
+                    Fxo[r] = (j == 0) ? f[r] * x[0] : fma(f[r], x[j], Fxo[r]);
+                    FK_UNROLL for (int k = 0; k < NX; ++k)
+                        if (k < j) FL[r][k] = fma(f[r], lrow[k], FL[r][k]);
+                    FL[r][j] = f[r] * ljj;
+                }
+            });
+            if (!pd) st |= ST_NOT_PD;
+        }
+        const double wms = mv.Wp[0], wcs = mv.Wp[1];
+        // mean (replicated) and the centre point's offset
+        {
+            double wy[NX];
+            FK_UNROLL for (int b = 0; b < NX; ++b) {
+                const double fx = quad_from(quad, Fxo[b / 4], b % 4);
+                x[b] = wms * fx;
+                wy[b] = wcs * (fx - x[b]);
+            }
+            FK_UNROLL for (int r = 0; r < R; ++r) {
+                const double xa = wms * Fxo[r];
+                const double ya = Fxo[r] - xa;
+                FK_UNROLL for (int b = 0; b < NX; ++b) P[r][b] = ya * wy[b];
+            }
+            FK_STAGE();
+        }
+        // the pairs: column k of F L, weighted by its owners, gathered
+        double Qr[R][NX];
+        FK_UNROLL for (int k = 0; k < NX; ++k) {
+            const double wp = mv.Wp[2 + k];
+            double wfo[R], wf[NX];
+            FK_UNROLL for (int r = 0; r < R; ++r) wfo[r] = wp * FL[r][k];
+            FK_UNROLL for (int b = 0; b < NX; ++b) wf[b] = quad_from(quad, wfo[b / 4], b % 4);
+            if (k == NX - 1) {
+                FK_UNROLL for (int r = 0; r < R; ++r)
+                    FK_UNROLL for (int b = 0; b < NX; ++b) Qr[r][b] = mv.Q[g[r] * NX + b];
+            }
+            FK_UNROLL for (int r = 0; r < R; ++r)
+                FK_UNROLL for (int b = 0; b < NX; ++b) P[r][b] = fma(FL[r][k], wf[b], P[r][b]);
+            FK_STAGE();
+        }
+        FK_UNROLL for (int r = 0; r < R; ++r)
+            FK_UNROLL for (int b = 0; b < NX; ++b) P[r][b] += Qr[r][b];       // + Q last, like the reference
+    }
+    // ---------------- update (UKF.py:462-481), sigma points regenerated from the prior (:407)
+    {
+        double Lw[R][NX], HL[NZ][NX];
+        {
+            double hc[NZ];
+            FK_UNROLL for (int c = 0; c < NZ; ++c) hc[c] = mv.H[c * NX];
+            const bool pd = quad_chol_rows<NX>(P, g, scale, Lw, quad, [&](int j, const double (&lrow)[NX], double ljj) {
+                double h[NZ];
+                FK_UNROLL for (int c = 0; c < NZ; ++c) h[c] = hc[c];
+                if (j + 1 < NX) {
+                    FK_UNROLL for (int c = 0; c < NZ; ++c) hc[c] = mv.H[c * NX + j + 1];
+                }
+                FK_UNROLL for (int c = 0; c < NZ; ++c) {
+                    FK_UNROLL for (int k = 0; k < NX; ++k)
+                        if (k < j) HL[c][k] = fma(h[c], lrow[k], HL[c][k]);
+                    HL[c][j] = h[c] * ljj;
+                }
+            });
+            if (!pd && has_z) st |= ST_NOT_PD;
+        }
+        double zp[NZ], S[NZ * NZ], Ko[R * NZ], Rm[NZ * NZ];
+        FK_UNROLL for (int e = 0; e < NZ * NZ; ++e) Rm[e] = mv.R[e];
+        const double wms = mv.Wp[0], wcs = mv.Wp[1];
+        {
+            double d0[NZ], wd[NZ];
+            FK_UNROLL for (int c = 0; c < NZ; ++c) {
+                double acc = mv.H[c * NX] * x[0];
+                FK_UNROLL for (int k = 1; k < NX; ++k) acc = fma(mv.H[c * NX + k], x[k], acc);
+                zp[c] = wms * acc;
+                d0[c] = acc - zp[c];
+            }
+            FK_UNROLL for (int c = 0; c < NZ; ++c) wd[c] = wcs * d0[c];
+            FK_UNROLL for (int r = 0; r < NZ; ++r)
+                FK_UNROLL for (int c = 0; c < NZ; ++c)
+                    if (c >= r) S[r * NZ + c] = d0[r] * wd[c];
+        }
+        FK_STAGE();
+        FK_UNROLL for (int k = 0; k < NX; ++k) {
+            const double wp = mv.Wp[2 + k];
+            double wh[NZ];
+            FK_UNROLL for (int c = 0; c < NZ; ++c) wh[c] = wp * HL[c][k];
+            FK_UNROLL for (int r = 0; r < NZ; ++r)
+                FK_UNROLL for (int c = 0; c < NZ; ++c)
+                    if (c >= r) S[r * NZ + c] = fma(HL[r][k], wh[c], S[r * NZ + c]);
+            // the cross variance's own rows: l_k is zero above the diagonal (slots whose rows all lie above row k: skipped;
+            // a row above it inside a slot: its element of L is a stored zero)
+            FK_UNROLL for (int r = 0; r < R; ++r) {
+                if (4 * r + 3 < k) continue;
+                FK_UNROLL for (int c = 0; c < NZ; ++c)
+                    Ko[r * NZ + c] = (k == 0) ? Lw[r][0] * wh[c] : fma(Lw[r][k], wh[c], Ko[r * NZ + c]);
+            }
+            if (k % 4 == 3) FK_STAGE();
+        }
+        FK_UNROLL for (int r = 0; r < NZ; ++r)
+            FK_UNROLL for (int c = 0; c < NZ; ++c)
+                if (c < r) S[r * NZ + c] = S[c * NZ + r];
+        FK_UNROLL for (int e = 0; e < NZ * NZ; ++e) S[e] += Rm[e];              // + R last
+        // K = Pxz S^-1 (own rows)
+        {
+            double Lf[NZ * NZ], dd[NZ], dinv[NZ];
+            FK_UNROLL for (int e = 0; e < NZ * NZ; ++e) Lf[e] = S[e];
+            if (!ldlt2_rs<NZ>(Lf, dd, dinv) && has_z) st |= ST_NOT_PD;
+            solve_rows_ldlt<R, NZ>(Lf, dinv, Ko);
+        }
+        double zc[NZ];
+        FK_UNROLL for (int e = 0; e < R * NZ; ++e) Ko[e] = has_z ? Ko[e] : 0.0;
+        FK_UNROLL for (int e = 0; e < NZ * NZ; ++e) S[e] = has_z ? S[e] : 0.0;
+        FK_UNROLL for (int c = 0; c < NZ; ++c) zc[c] = has_z ? zin[c] - zp[c] : 0.0;
+        FK_STAGE();
+        // x += K (z - zp) ; P -= K (S K') : row b of K from its owner serves x[b] and column b of P
+        FK_UNROLL for (int b = 0; b < NX; ++b) {
+            double Kb[NZ], sk[NZ];
+            FK_UNROLL for (int c = 0; c < NZ; ++c) Kb[c] = quad_from(quad, Ko[(b / 4) * NZ + c], b % 4);
+            {
+                double acc = Kb[0] * zc[0];
+                FK_UNROLL for (int c = 1; c < NZ; ++c) acc = fma(Kb[c], zc[c], acc);
+                x[b] += acc;
+            }
+            FK_UNROLL for (int qq = 0; qq < NZ; ++qq) {
+                double acc = S[qq * NZ] * Kb[0];
+                FK_UNROLL for (int w = 1; w < NZ; ++w) acc = fma(S[qq * NZ + w], Kb[w], acc);
+                sk[qq] = acc;
+            }
+            FK_UNROLL for (int r = 0; r < R; ++r) {
+                double acc = Ko[r * NZ] * sk[0];
+                FK_UNROLL for (int qq = 1; qq < NZ; ++qq) acc = fma(Ko[r * NZ + qq], sk[qq], acc);
+                P[r][b] -= acc;
+            }
+            if (b % 4 == 3) FK_STAGE();
+        }
+    }
+    return st;
+}
+
+}  // namespace fk

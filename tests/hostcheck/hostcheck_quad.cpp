@@ -1,0 +1,149 @@
+// hostcheck_quad.cpp -- TEST-ONLY harness: the four-lanes-per-track UKF step (filterpy_amd/csrc/fk_ukf_quad.hpp, the arithmetic
+// ukf_mlg.hip runs with DPP quad exchanges) compiled for the HOST, the four lanes of a quad running as four fibers in lockstep:
+// an exchange stores the lane's value, hands control round the quad and reads the owner's slot.  Never loaded by filterpy_amd/.
+#include <stdint.h>
+#include <string.h>
+#include <ucontext.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "../../filterpy_amd/csrc/fk_ukf_quad.hpp"
+
+namespace {
+
+struct FiberQuad {
+    ucontext_t main_ctx, ctx[4];
+    std::vector<char> stack[4];
+    double slot[2][4];
+    long exchanges[4] = {0, 0, 0, 0};
+    void (*body)(void *, int) = nullptr;
+    void *arg = nullptr;
+};
+thread_local FiberQuad *g_fq = nullptr;
+
+void fiber_entry(int lane) { g_fq->body(g_fq->arg, lane); }
+
+// lane `lane` of the quad: bcast<O>(v) = the value lane O passed to ITS call of the same exchange
+struct HostQuad {
+    FiberQuad *fq;
+    int lane;
+    unsigned calls = 0;
+    template <int O>
+    double bcast(double v)
+    {
+        const unsigned p = calls++ & 1u;
+        fq->slot[p][lane] = v;
+        fq->exchanges[lane]++;
+        swapcontext(&fq->ctx[lane], &fq->ctx[(lane + 1) & 3]);      // round the quad; back here once all four have stored
+        return fq->slot[p][O];
+    }
+};
+
+void run_quad(void (*body)(void *, int), void *arg)
+{
+    FiberQuad fq;
+    fq.body = body;
+    fq.arg = arg;
+    g_fq = &fq;
+    for (int l = 0; l < 4; ++l) {
+        fq.stack[l].resize(1 << 20);
+        getcontext(&fq.ctx[l]);
+        fq.ctx[l].uc_stack.ss_sp = fq.stack[l].data();
+        fq.ctx[l].uc_stack.ss_size = fq.stack[l].size();
+        fq.ctx[l].uc_link = l < 3 ? &fq.ctx[l + 1] : &fq.main_ctx;   // a lane that returns hands over to the next one
+        makecontext(&fq.ctx[l], (void (*)())fiber_entry, 1, l);
+    }
+    swapcontext(&fq.main_ctx, &fq.ctx[0]);
+    g_fq = nullptr;
+}
+
+template <int NX, int NZ>
+struct QuadJob {
+    long T;
+    const double *F, *H, *Q, *R, *Wp, *zs;
+    const unsigned char *mask;
+    double scale;
+    double *x0, *P0, *means, *covs;
+    int st[4];
+};
+
+template <int NX, int NZ>
+void quad_lane(void *vp, int lane)
+{
+    constexpr int R = (NX + 3) / 4;
+    auto &job = *static_cast<QuadJob<NX, NZ> *>(vp);
+    HostQuad quad{g_fq, lane};
+    unsigned g[R];
+    double x[NX], P[R][NX];
+    for (int r = 0; r < R; ++r) {
+        const unsigned row = 4u * (unsigned)r + (unsigned)lane;
+        g[r] = row < (unsigned)NX ? row : (unsigned)NX - 1u;
+        for (int c = 0; c < NX; ++c) P[r][c] = job.P0[g[r] * NX + c];
+    }
+    for (int i = 0; i < NX; ++i) x[i] = job.x0[i];
+    const fk::UkfQuadModel mv{job.F, job.Q, job.H, job.R, job.Wp};
+    int st = 0;
+    for (long t = 0; t < job.T; ++t) {
+        const bool has_z = job.mask ? job.mask[t] != 0 : true;
+        double z[NZ];
+        for (int c = 0; c < NZ; ++c) z[c] = has_z ? job.zs[t * NZ + c] : 0.0;
+        st |= fk::ukf_quad_step_v4<NX, NZ>(x, P, g, z, has_z, job.scale, mv, quad);
+        // every lane writes what it holds: x (replicated) must agree, rows of P go where their slot says
+        for (int i = 0; i < NX; ++i) {
+            if (lane == 0) job.means[t * NX + i] = x[i];
+            else if (memcmp(&job.means[t * NX + i], &x[i], 8) != 0) st |= 1 << 20;        // replicated values differ between lanes
+        }
+        for (int r = 0; r < R; ++r) {
+            const bool dup = 4u * (unsigned)r + (unsigned)lane >= (unsigned)NX;
+            for (int c = 0; c < NX; ++c) {
+                double &dst = job.covs[(t * NX + g[r]) * NX + c];
+                if (!dup) dst = P[r][c];
+            }
+        }
+    }
+    // duplicates (slots past row n-1) must hold row n-1's values bit for bit: checked against what its owner wrote last
+    for (int r = 0; r < R; ++r)
+        if (4u * (unsigned)r + (unsigned)lane >= (unsigned)NX && job.T > 0 && ((NX - 1) % 4) < lane) {
+            for (int c = 0; c < NX; ++c)
+                if (memcmp(&job.covs[((job.T - 1) * NX + (NX - 1)) * NX + c], &P[r][c], 8) != 0) st |= 1 << 21;
+        }
+    if (lane == 0)
+        for (int i = 0; i < NX; ++i) job.x0[i] = x[i];
+    for (int r = 0; r < R; ++r)
+        if (4u * (unsigned)r + (unsigned)lane < (unsigned)NX)
+            for (int c = 0; c < NX; ++c) job.P0[g[r] * NX + c] = P[r][c];
+    job.st[lane] = st;
+}
+
+template <int NX, int NZ>
+int ukf_quad_batch(long T, const double *F, const double *H, const double *Q, const double *R, const double *Wm,
+                   const double *Wc, double scale, const double *zs, const unsigned char *mask, double *x0, double *P0,
+                   double *means, double *covs)
+{
+    constexpr int KS = 2 * NX + 1;
+    double wm[KS], wc[KS], wp[2 + NX];
+    std::copy(Wm, Wm + KS, wm);
+    std::copy(Wc, Wc + KS, wc);
+    fk::make_pair_table<NX>(wm, wc, wp);
+    if (!fk::pair_weights_symmetric<NX>(wm, wc)) return -2;
+    QuadJob<NX, NZ> job{T, F, H, Q, R, wp, zs, mask, scale, x0, P0, means, covs, {0, 0, 0, 0}};
+    run_quad(&quad_lane<NX, NZ>, &job);
+    if (job.st[0] != job.st[1] || job.st[0] != job.st[2] || job.st[0] != job.st[3]) return 1 << 22;   // the status is replicated
+    return job.st[0];
+}
+
+}  // namespace
+
+extern "C" int hc_ukf_quad_v4(int n, int m, long T, const double *F, const double *H, const double *Q, const double *R,
+                              const double *Wm, const double *Wc, double scale, const double *zs,
+                              const unsigned char *mask, double *x0, double *P0, double *means, double *covs)
+{
+#define GO(NXV, NZV) if (n == NXV && m == NZV) return ukf_quad_batch<NXV, NZV>(T, F, H, Q, R, Wm, Wc, scale, zs, mask, x0, P0, means, covs)
+#define GOM(NXV) GO(NXV, 1); GO(NXV, 2); GO(NXV, 3); GO(NXV, 4)
+    GO(3, 1); GO(4, 2); GO(5, 2); GO(7, 3); GO(8, 4); GO(9, 3);
+    GOM(10); GOM(11); GOM(12); GOM(13); GOM(14); GOM(15); GOM(16);
+#undef GOM
+#undef GO
+    return -1;
+}
