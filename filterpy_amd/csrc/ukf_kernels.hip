@@ -645,6 +645,32 @@ int ukf_rts_launch_big_paired(const UkfRtsArgs &a, const double *F, const double
 #undef FK_UKF_GO
 
 #endif
+// ukf_mlg.hip, one object per dim_x
+#define FK_UMLG_DECL(NXV) int launch_ukf_mlg_##NXV(const UkfArgs &, int, hipStream_t);
+FK_UMLG_DECL(10) FK_UMLG_DECL(11) FK_UMLG_DECL(12) FK_UMLG_DECL(13) FK_UMLG_DECL(14) FK_UMLG_DECL(15) FK_UMLG_DECL(16)
+#undef FK_UMLG_DECL
+#if FK_UKF_HAS(1)
+static int ukf_mlg_launch(const UkfArgs &a, int layout, hipStream_t s)
+{
+    int rc = 1;
+    switch (a.n) {
+        case 10: rc = launch_ukf_mlg_10(a, layout, s); break;
+        case 11: rc = launch_ukf_mlg_11(a, layout, s); break;
+        case 12: rc = launch_ukf_mlg_12(a, layout, s); break;
+        case 13: rc = launch_ukf_mlg_13(a, layout, s); break;
+        case 14: rc = launch_ukf_mlg_14(a, layout, s); break;
+        case 15: rc = launch_ukf_mlg_15(a, layout, s); break;
+        case 16: rc = launch_ukf_mlg_16(a, layout, s); break;
+        default: break;
+    }
+    if (rc == 1) {
+        set_last_error("fused linear UKF: no four-lane instantiation for these dims");
+        return FK_ERR_UNSUPPORTED;
+    }
+    return rc;
+}
+#endif
+
 static int fail(int code, const char *msg)
 {
     set_last_error(msg);
@@ -679,8 +705,15 @@ int fk_ukf_linear_batch_f64(const fk_ukf_desc *d, const double *F, const double 
                             int32_t *status, void *stream)
 {
     if (!d) return fail(FK_ERR_BAD_ARG, "desc is NULL");
-    if (d->n < 1 || d->n > 9 || d->m < 1 || d->m > 4 || (d->n <= 6 && d->m > 3))
-        return fail(FK_ERR_UNSUPPORTED, "fused linear UKF: dim_x 1..6 with dim_z 1..3, dim_x 7..9 with dim_z 1..4");
+    // dim_x 10..16 (dim_z 1..4): four lanes per track (ukf_mlg.hip), the pair-regrouped sums only -- and only with FK_UKF_MLG=1
+    // until the kernel has been through a GPU parity run (round 4 ended without one; tests/test_gpu_ukf_mlg.py)
+    const bool quad = d->n >= 10 && d->n <= 16 && d->m >= 1 && d->m <= 4;
+    if (quad) {
+        static const bool on = getenv("FK_UKF_MLG") && getenv("FK_UKF_MLG")[0] == '1';
+        if (!on || !(d->flags & FK_UKF_FLAG_PAIR_WEIGHTS))
+            return fail(FK_ERR_UNSUPPORTED, "fused linear UKF at dim_x 10..16: FK_UKF_MLG=1 and weights equal within every +- pair (FK_UKF_FLAG_PAIR_WEIGHTS)");
+    } else if (d->n < 1 || d->n > 9 || d->m < 1 || d->m > 4 || (d->n <= 6 && d->m > 3))
+        return fail(FK_ERR_UNSUPPORTED, "fused linear UKF: dim_x 1..6 with dim_z 1..3, dim_x 7..9 with dim_z 1..4, dim_x 10..16 with dim_z 1..4");
     if (d->N < 0 || d->T < 0 || !F || !H || !Q || !R || !Wm || !Wc || !z || !x || !P)
         return fail(FK_ERR_BAD_ARG, "fused linear UKF: bad argument");
     if ((double)d->N * d->n * d->n * 8.0 >= 4294967296.0 - 32.0) return fail(FK_ERR_UNSUPPORTED, "fused linear UKF: record block >= 4 GiB, split the batch");
@@ -699,6 +732,7 @@ int fk_ukf_linear_batch_f64(const fk_ukf_desc *d, const double *F, const double 
     // one piece: tracks [a.i0, a.i0 + a.cnt), a.T steps from the pointers in a.  Classes (2,2), (4,2), (6,3), (8,4), (9,3),
     // (9,4): the exact instantiation where the dims are the class's own, the padded one otherwise.
     auto one = [&](const UkfArgs &a, hipStream_t s) -> int {
+        if (quad) return ukf_mlg_launch(a, layout, s);
         if (paired) return (a.n <= 6 && a.m <= 3) ? ukf_fwd_launch_small_paired(a, layout, exact, s) : ukf_fwd_launch_big_paired(a, layout, exact, s);
         return (a.n <= 6 && a.m <= 3) ? ukf_fwd_launch_small(a, layout, exact, s) : ukf_fwd_launch_big(a, layout, exact, s);
     };

@@ -1,0 +1,196 @@
+// ukf_mlg.hip -- the fused linear-model UKF (UnscentedKalmanFilter.batch_filter, filterpy/kalman/UKF.py:524-632, with
+// fx(x, dt) = F x and hx(x) = H x) for dim_x = 10..16, dim_z = 1..4 with FOUR LANES PER TRACK (gfx950).
+//
+// One lane per track ends at dim_x = 9 (ukf_kernels.hip); above it the step ran as five launches per epoch on resident blocks.
+// Here a quad of lanes owns a track for the whole time loop, like kf_mlg.hip, but with the rows of P dealt out CYCLICALLY (lane q
+// holds rows q, q + 4, ...; a slot past row n-1 duplicates row n-1): the step is two Cholesky factorisations, and cyclic rows
+// keep all four lanes busy down to their last columns.  The arithmetic is ukf_quad_step_v4 (fk_ukf_quad.hpp: ukf_linear_step_v4
+// distributed, every sum in v4's order; held against the oracle on the host with the lanes as fibers,
+// tests/test_hostcheck_ukf_quad.py); the exchanges are quad-permute DPP moves.
+//
+// Pair-regrouped sums only (the caller's FK_UKF_FLAG_PAIR_WEIGHTS, verified in the prologue: FK_STATUS_BAD_WEIGHTS
+// otherwise); exact dims; optional mask (branch-free: fk_ukf_quad.hpp); both layouts, the per-step outputs through the wave's
+// LDS tile as 16-byte units (fk_ml.hpp).  One wave per SIMD.  One object per dim_x (-DFK_NX), dim_z = 1..4 inside.
+#include <stdlib.h>
+#include <type_traits>
+
+#include "fk_device.hpp"
+#include "fk_kernel_args.hpp"
+#include "fk_ml.hpp"
+#include "fk_chunks.hpp"
+#include "fk_ukf_quad.hpp"
+#include "../../include/filterhip.h"
+
+#ifndef FK_NX
+#error "compile with -DFK_NX=<dim_x>"
+#endif
+
+#define FK_UMLG_CAT_(a, b) a##b
+#define FK_UMLG_CAT(a, b) FK_UMLG_CAT_(a, b)
+
+namespace fk {
+namespace FK_UMLG_CAT(ukf_mlg_, FK_NX) {
+
+struct QuadDpp {
+    template <int O>
+    __device__ __forceinline__ double bcast(double v) const { return quad_bcast<O>(v); }
+};
+
+template <int NX, int NZ, int LAYOUT>
+__global__ void __launch_bounds__(BLOCK, 1)
+ukf_mlg_kernel(const UkfArgs a)
+{
+    constexpr int R = (NX + 3) / 4, KS = 2 * NX + 1;
+    using LM = LdsModel<NX, NZ>;
+    constexpr bool AOS = LAYOUT == LAYOUT_AOS;
+    constexpr int EP = NX * NX;
+    constexpr int TILE = 16 * EP;                                // one output set of a wave's 16 tracks (x reuses its head)
+    constexpr int MSZ = LM::SIZE + 2 * KS + 2 + NX;              // [F | Q | H | R | Wm | Wc | pair table]
+    __shared__ double smem[MSZ + (BLOCK / 64) * TILE];
+    double *tile = smem + MSZ + (threadIdx.x >> 6) * TILE;
+    lds_fill<NX, NX>(smem + LM::OFF_F, a.F, NX, NX, 1.0, threadIdx.x);
+    lds_fill<NX, NX>(smem + LM::OFF_Q, a.Q, NX, NX, 0.0, threadIdx.x);
+    lds_fill<NZ, NX>(smem + LM::OFF_H, a.H, NZ, NX, 0.0, threadIdx.x);
+    lds_fill<NZ, NZ>(smem + LM::OFF_R, a.R, NZ, NZ, 1.0, threadIdx.x);
+    for (unsigned q = threadIdx.x; q < (unsigned)(2 * KS); q += BLOCK) smem[LM::SIZE + q] = (q < (unsigned)KS ? a.Wm[q] : a.Wc[q - KS]);
+    __syncthreads();
+    int st = 0;
+    if (threadIdx.x == 0) make_pair_table<NX>(smem + LM::SIZE, smem + LM::SIZE + KS, smem + LM::SIZE + 2 * KS);
+    if (!pair_weights_symmetric<NX>(smem + LM::SIZE, smem + LM::SIZE + KS)) st |= ST_BAD_WEIGHTS;
+    __syncthreads();
+    const UkfQuadModel mv{smem + LM::OFF_F, smem + LM::OFF_Q, smem + LM::OFF_H, smem + LM::OFF_R, smem + LM::SIZE + 2 * KS};
+
+    const long N = a.N;
+    const unsigned L = threadIdx.x & 3u;
+    const long iend = a.i0 + a.cnt;
+    long trk = a.i0 + (long)blockIdx.x * (BLOCK / 4) + (threadIdx.x >> 2);
+    const bool owner = trk < iend;                               // tail quads duplicate the last track; they never write the final state
+    if (trk >= iend) trk = iend - 1;
+    unsigned row[R];                                             // slot r holds row L + 4 r (clamped: see the header)
+    FK_UNROLL for (int r = 0; r < R; ++r) {
+        const unsigned g = L + 4u * (unsigned)r;
+        row[r] = g < (unsigned)NX ? g : (unsigned)NX - 1u;
+    }
+    unsigned estride = AOS ? 8u : (unsigned)N * 8u;
+    asm volatile("" : "+s"(estride));
+    const unsigned t8 = (unsigned)trk * (AOS ? (unsigned)NX * 8u : 8u);
+    const unsigned tz8 = (unsigned)trk * (AOS ? (unsigned)NZ * 8u : 8u);
+    unsigned off_row[R];
+    FK_UNROLL for (int r = 0; r < R; ++r)
+        off_row[r] = (AOS ? (unsigned)trk * (unsigned)EP * 8u : (unsigned)trk * 8u) + row[r] * (unsigned)NX * estride;
+    const long w0 = a.i0 + (long)blockIdx.x * (BLOCK / 4) + (long)wave_index() * 16;      // scalar: wave_index()
+    const unsigned valid = (unsigned)(iend - w0 >= 16 ? 16 : (iend - w0 > 0 ? iend - w0 : 0));
+    const unsigned lane = threadIdx.x & 63u, g16 = lane >> 2;
+    const uint8_t *mask_or_dummy = a.mask ? a.mask : reinterpret_cast<const uint8_t *>(a.z);
+
+    double P[R][NX], x[NX];
+    {
+        const MlView vx(a.x, t8, estride);
+        FK_UNROLL for (int r = 0; r < R; ++r) {
+            const MlView vP(a.P, off_row[r], estride);
+            FK_UNROLL for (int c = 0; c < NX; ++c) P[r][c] = vP.load(c);
+        }
+        FK_UNROLL for (int k = 0; k < NX; ++k) x[k] = vx.load(k);
+        FK_UNROLL for (int r = 0; r < R; ++r)
+            FK_UNROLL for (int c = 0; c < NX; ++c) asm volatile("" ::"v"(P[r][c]));       // landed before the loop
+        FK_UNROLL for (int k = 0; k < NX; ++k) asm volatile("" ::"v"(x[k]));
+    }
+    // z[t+1] and its mask byte are requested at the top of step t and consumed at the top of step t+1 (clamped index, no branch)
+    double zn[NZ];
+    unsigned hn;
+    {
+        const MlView vz(a.z, tz8, estride);
+        FK_UNROLL for (int c = 0; c < NZ; ++c) zn[c] = vz.load(c);
+        const unsigned hb = mask_or_dummy[trk];
+        hn = a.mask ? hb : 1u;
+        FK_UNROLL for (int c = 0; c < NZ; ++c) asm volatile("" ::"v"(zn[c]));
+        asm volatile("" ::"v"(hn));
+    }
+    QuadDpp quad;
+    const bool st_m = a.means != nullptr, st_c = a.covs != nullptr;
+    _Pragma("nounroll") for (long t = 0; t < a.T; ++t) {
+        const bool has_z = hn != 0u;
+        double z[NZ];
+        FK_UNROLL for (int c = 0; c < NZ; ++c) z[c] = has_z ? zn[c] : 0.0;
+        {
+            long tn = t + 1 < a.T ? t + 1 : t;
+            asm volatile("" : "+s"(tn));
+            const MlView vz(a.z + tn * N * NZ, tz8, estride);
+            FK_UNROLL for (int c = 0; c < NZ; ++c) zn[c] = vz.load(c);
+            const unsigned hb = mask_or_dummy[tn * N + trk];
+            hn = a.mask ? hb : 1u;
+        }
+        st |= ukf_quad_step_v4<NX, NZ>(x, P, row, z, has_z, a.scale, mv, quad);
+        FK_STAGE();
+        // the step's outputs through the wave's tile, 16-byte units (an output that was not asked for: a descriptor of zero
+        // tracks -- issued and dropped, no branch in the loop)
+        {
+            double *md = st_m ? a.means : a.x, *cd = st_c ? a.covs : a.P;
+            const unsigned vm = st_m ? valid : 0u, vc = st_c ? valid : 0u;
+            if constexpr (AOS) {
+                ml_wave_fence();
+                FK_UNROLL for (int k = 0; k < NX; ++k) tile[g16 * NX + k] = x[k];          // the quad writes the same value
+                ml_wave_fence();
+                ml_tile_out_aos<NX, 16>(md + (t * N + w0) * NX, tile, lane, vm);
+                ml_wave_fence();
+                FK_UNROLL for (int r = 0; r < R; ++r)
+                    FK_UNROLL for (int c = 0; c < NX; ++c) tile[g16 * EP + row[r] * NX + c] = P[r][c];
+                ml_wave_fence();
+                ml_tile_out_aos<EP, 16>(cd + (t * N + w0) * EP, tile, lane, vc);
+                ml_wave_fence();
+            } else {
+                ml_wave_fence();
+                FK_UNROLL for (int k = 0; k < NX; ++k) tile[k * 16 + g16] = x[k];
+                ml_wave_fence();
+                ml_tile_out_soa<NX, 16>(md + t * N * NX, N, w0, tile, lane, vm);
+                ml_wave_fence();
+                FK_UNROLL for (int r = 0; r < R; ++r)
+                    FK_UNROLL for (int c = 0; c < NX; ++c) tile[(row[r] * NX + c) * 16 + g16] = P[r][c];
+                ml_wave_fence();
+                ml_tile_out_soa<EP, 16>(cd + t * N * EP, N, w0, tile, lane, vc);
+                ml_wave_fence();
+            }
+        }
+    }
+    // the final state goes back in place: only a track's own quad writes it, and only once every wave of the workgroup has
+    // consumed its initial state (a duplicating tail quad reads the last track's)
+    __syncthreads();
+    if (owner) {
+        const MlView vx(a.x, t8, estride);
+        bool fin = all_finite<NX>(x);
+        FK_UNROLL for (int k = 0; k < NX; ++k) vx.store(k, x[k]);
+        FK_UNROLL for (int r = 0; r < R; ++r) {
+            const MlView vP(a.P, off_row[r], estride);
+            FK_UNROLL for (int c = 0; c < NX; ++c) {
+                vP.store(c, P[r][c]);
+                fin = fin && (fabs(P[r][c]) <= 1.79769313486231570815e+308);
+            }
+        }
+        if (a.status) {
+            int s = st | (fin ? 0 : ST_NONFINITE);
+            s |= __builtin_amdgcn_mov_dpp(s, 0xB1, 0xf, 0xf, true);
+            s |= __builtin_amdgcn_mov_dpp(s, 0x4E, 0xf, 0xf, true);
+            if (L == 0) a.status[trk] = a.status_or ? (a.status[trk] | s) : s;
+        }
+    }
+}
+
+}  // namespace (instantiation)
+
+// returns 1 when this call is not one the four-lane kernel serves
+int FK_UMLG_CAT(launch_ukf_mlg_, FK_NX)(const UkfArgs &a, int layout, hipStream_t s)
+{
+    using namespace FK_UMLG_CAT(ukf_mlg_, FK_NX);
+    if (a.n != FK_NX || a.m < 1 || a.m > 4) return 1;
+    const dim3 grid((unsigned)((a.cnt + BLOCK / 4 - 1) / (BLOCK / 4))), block(BLOCK);
+#define GO(NZV)                                                                                                         \
+    if (a.m == NZV) {                                                                                                   \
+        if (layout == FK_LAYOUT_AOS) hipLaunchKernelGGL((ukf_mlg_kernel<FK_NX, NZV, LAYOUT_AOS>), grid, block, 0, s, a); \
+        else hipLaunchKernelGGL((ukf_mlg_kernel<FK_NX, NZV, LAYOUT_SOA>), grid, block, 0, s, a);                         \
+    }
+    GO(1) GO(2) GO(3) GO(4)
+#undef GO
+    return check_launch("ukf_mlg_kernel");
+}
+
+}  // namespace fk

@@ -557,7 +557,8 @@ class UnscentedKalmanFilter(object):
         from .unscented_transform import unscented_transform
         n, m = self._dim_x, self._dim_z
         fused = (self._linear and Rs is None and dts is None and saver is None and UT is None and not self._devcall
-                 and not self._hooked and E.ukf_linear_supported(n, m) and not isinstance(zs, torch.Tensor))
+                 and not self._hooked and not isinstance(zs, torch.Tensor)
+                 and E.ukf_linear_supported(n, m, n >= 10 and E.pair_weights(self.Wm, self.Wc, n)))
         with self._with_ut(UT):
             if self._resident and saver is None and not fused:
                 return self._dev_batch_filter(zs, Rs, dts, device_outputs)

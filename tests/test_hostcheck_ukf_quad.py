@@ -53,7 +53,7 @@ def _model(n, m, seed):
 
 rel = lambda a, b: np.max(np.abs(a - b)) / np.max(np.abs(b))  # noqa: E731
 
-DIMS = [(3, 1), (4, 2), (5, 2), (7, 3), (8, 4), (9, 3)] + [(n, m) for n in range(10, 17) for m in (1, 2, 3, 4)]
+DIMS = [(4, 2), (5, 2), (7, 3), (8, 4), (9, 3)] + [(n, m) for n in range(10, 17) for m in (1, 2, 3, 4)]
 
 
 @pytest.mark.parametrize("n,m", DIMS)
@@ -80,7 +80,7 @@ def test_quad_step_matches_the_oracle(quad_lib, n, m, abk):
     assert rel(cov, np.swapaxes(cov, 1, 2)) < (1e-13 if alpha > 1e-2 else 1e-8)
 
 
-@pytest.mark.parametrize("n,m", [(3, 1), (4, 2), (5, 2), (7, 3), (8, 4), (9, 3)])
+@pytest.mark.parametrize("n,m", [(4, 2), (5, 2), (7, 3), (8, 4), (9, 3)])
 def test_quad_step_agrees_with_the_one_lane_step_it_distributes(quad_lib, n, m):
     """Same sums in the same order (fk_ukf.hpp, ukf_linear_step_v4); the differences: a row's own elements feed the factor
     instead of the upper triangle's, and the mirrored elements of P are computed twice."""
