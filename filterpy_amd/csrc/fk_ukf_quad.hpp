@@ -122,22 +122,28 @@ FK_HD int ukf_quad_step_v4(double (&x)[NX], double (&P)[(NX + 3) / 4][NX], const
             FK_STAGE();
         }
         // the pairs: column k of F L, weighted by its owners, gathered
-        double Qr[R][NX];
         FK_UNROLL for (int k = 0; k < NX; ++k) {
             const double wp = mv.Wp[2 + k];
             double wfo[R], wf[NX];
             FK_UNROLL for (int r = 0; r < R; ++r) wfo[r] = wp * FL[r][k];
             FK_UNROLL for (int b = 0; b < NX; ++b) wf[b] = quad_from(quad, wfo[b / 4], b % 4);
-            if (k == NX - 1) {
-                FK_UNROLL for (int r = 0; r < R; ++r)
-                    FK_UNROLL for (int b = 0; b < NX; ++b) Qr[r][b] = mv.Q[g[r] * NX + b];
-            }
             FK_UNROLL for (int r = 0; r < R; ++r)
                 FK_UNROLL for (int b = 0; b < NX; ++b) P[r][b] = fma(FL[r][k], wf[b], P[r][b]);
             FK_STAGE();
         }
-        FK_UNROLL for (int r = 0; r < R; ++r)
-            FK_UNROLL for (int b = 0; b < NX; ++b) P[r][b] += Qr[r][b];       // + Q last, like the reference
+        // + Q last, like the reference: the lane's rows of Q, each requested while the one before it is added (all of them at
+        // once are R * NX more registers at the point where P-, F L and x are all live)
+        {
+            double Qr[2][NX];
+            FK_UNROLL for (int b = 0; b < NX; ++b) Qr[0][b] = mv.Q[g[0] * NX + b];
+            FK_UNROLL for (int r = 0; r < R; ++r) {
+                if (r + 1 < R) {
+                    FK_UNROLL for (int b = 0; b < NX; ++b) Qr[(r + 1) & 1][b] = mv.Q[g[r + 1] * NX + b];
+                }
+                FK_UNROLL for (int b = 0; b < NX; ++b) P[r][b] += Qr[r & 1][b];
+                FK_STAGE();
+            }
+        }
     }
     // ---------------- update (UKF.py:462-481), sigma points regenerated from the prior (:407)
     {
