@@ -42,7 +42,7 @@ FK_HD double quad_from(Quad &quad, double v, int o)
 
 // Lower factor of scale * P, rows distributed cyclically (g[r]: the row slot r holds -- q + 4 r, clamped to NX - 1).
 // Lw[r][k], k <= 4 r + 3: the lane's rows (zero above the diagonal; entries past 4 r + 3 are never written nor read).
-// row_done(j, lrow, ljj): called once row j is final -- lrow[0..j-1] and the pivot's root, replicated in the quad.
+// row_done(j, lrow, ljj, inv): called once row j is final -- lrow[0..j-1], the pivot's root and its reciprocal, replicated in the quad.
 template <int NX, class Quad, class RowDone>
 FK_HD bool quad_chol_rows(const double (&P)[(NX + 3) / 4][NX], const unsigned (&g)[(NX + 3) / 4], double scale,
                           double (&Lw)[(NX + 3) / 4][NX], Quad &quad, RowDone &&row_done)
@@ -71,7 +71,7 @@ FK_HD bool quad_chol_rows(const double (&P)[(NX + 3) / 4][NX], const unsigned (&
             if (4 * r > j) Lw[r][j] = t;                      // all of them below it
             else Lw[r][j] = g[r] > (unsigned)j ? t : (g[r] == (unsigned)j ? ljj : 0.0);
         }
-        row_done(j, lrow, ljj);
+        row_done(j, lrow, ljj, inv);
         FK_STAGE();
     }
     return pd;
@@ -90,7 +90,7 @@ FK_HD int ukf_quad_step_v4(double (&x)[NX], double (&P)[(NX + 3) / 4][NX], const
         {
             double Lw[R][NX], fc[R];                          // fc: column j of F at the lane's rows, requested a column ahead
             FK_UNROLL for (int r = 0; r < R; ++r) fc[r] = mv.F[g[r] * NX];
-            const bool pd = quad_chol_rows<NX>(P, g, scale, Lw, quad, [&](int j, const double (&lrow)[NX], double ljj) {
+            const bool pd = quad_chol_rows<NX>(P, g, scale, Lw, quad, [&](int j, const double (&lrow)[NX], double ljj, double) {
                 double f[R];
                 FK_UNROLL for (int r = 0; r < R; ++r) f[r] = fc[r];
                 if (j + 1 < NX) {
@@ -152,7 +152,7 @@ FK_HD int ukf_quad_step_v4(double (&x)[NX], double (&P)[(NX + 3) / 4][NX], const
         const unsigned hrow = g[0] < (unsigned)NZ ? g[0] : (unsigned)NZ - 1u;      // g[0] = q (NX >= 4) or its clamp
         {
             double hc = mv.H[hrow * NX];
-            const bool pd = quad_chol_rows<NX>(P, g, scale, Lw, quad, [&](int j, const double (&lrow)[NX], double ljj) {
+            const bool pd = quad_chol_rows<NX>(P, g, scale, Lw, quad, [&](int j, const double (&lrow)[NX], double ljj, double) {
                 const double h = hc;
                 if (j + 1 < NX) hc = mv.H[hrow * NX + j + 1];
                 FK_UNROLL for (int k = 0; k < NX; ++k)
@@ -232,6 +232,179 @@ FK_HD int ukf_quad_step_v4(double (&x)[NX], double (&P)[(NX + 3) / 4][NX], const
             }
             if (b % 4 == 3) FK_STAGE();
         }
+    }
+    return st;
+}
+
+// One backward step of UnscentedKalmanFilter.rts_smoother with fx(x, dt) = F x (UKF.py:714-737) on four lanes per track:
+// ukf_linear_rts_gain_v4 + ukf_linear_rts_correct (fk_ukf.hpp) distributed like the filter step above, every sum in their order:
+//   sweep      the factor of scale * Ps[k] column by column; F L and F x (own rows) from its broadcast rows
+//   Pxb, Pb    two passes over the gathered, weighted columns of F L (one pass would hold both accumulators next to F L and
+//              the factor: 232 doubles at dim_x 16): Pxb = sum_k wp_k l_k f_k' with the lane's own rows of L, then
+//              Pb = (sum Wc) y0 y0' + sum_k wp_k f_k f_k' + Q
+//   K          K = Pxb Pb^-1 with Pb = Lb Lb' (a Cholesky factor here, where v4 takes L D L': the same solve to a rounding):
+//              the FORWARD substitution w Lb' = Pxb[a] rides on the rows of Lb the factorisation broadcasts anyway, the
+//              backward one K[a] Lb = w gathers Lb's columns from their owners
+//   correct    x += K (xn - xb) (own rows, gathered);  T1 = K (Pn - Pb): the rows of D = Pn - Pb are formed by their owners a
+//              slot at a time and broadcast;  P += T1 K': K's rows gathered.  Full rows (v4: the upper triangle), so a row of
+//              the result and its mirror image agree to a rounding.
+// What the step keeps OUT of the registers: the smoothed covariance of step k+1 (next_row(r, out): the caller's copy of the
+// lane's row of slot r -- the kernel's output tile still holds it) and the full rows of Ps[k] (own_row(r, out): requested
+// again for the correction; the sweep only needs P[r][c], c <= 4 r + 3).
+// x: Xs[k] in, xs[k] out (replicated);  P: rows of Ps[k] in (lower part), of ps[k] out;  xn: xs[k+1];  K: the lane's rows of
+// the gain out.
+template <int NX, class Quad, class NextRow, class OwnRow>
+FK_HD int ukf_quad_rts_step_v4(double (&x)[NX], double (&P)[(NX + 3) / 4][NX], const unsigned (&g)[(NX + 3) / 4],
+                               const double (&xn)[NX], double scale, const UkfQuadModel &mv, Quad &quad,
+                               double (&K)[(NX + 3) / 4][NX], NextRow &&next_row, OwnRow &&own_row)
+{
+    constexpr int R = (NX + 3) / 4;
+    static_assert(NX >= 4, "dim_x >= 4 (every lane of the quad holds a row)");
+    int st = 0;
+    double Pb[R][NX], xb[NX];
+    {
+        double FL[R][NX], Fxo[R];
+        {
+            double Lw[R][NX];
+            {
+                double fc[R];
+                FK_UNROLL for (int r = 0; r < R; ++r) fc[r] = mv.F[g[r] * NX];
+                const bool pd = quad_chol_rows<NX>(P, g, scale, Lw, quad, [&](int j, const double (&lrow)[NX], double ljj, double) {
+                    double f[R];
+                    FK_UNROLL for (int r = 0; r < R; ++r) f[r] = fc[r];
+                    if (j + 1 < NX) {
+                        FK_UNROLL for (int r = 0; r < R; ++r) fc[r] = mv.F[g[r] * NX + j + 1];
+                    }
+                    FK_UNROLL for (int r = 0; r < R; ++r) {
+                        Fxo[r] = (j == 0) ? f[r] * x[0] : fma(f[r], x[j], Fxo[r]);
+                        FK_UNROLL for (int k = 0; k < NX; ++k)
+                            if (k < j) FL[r][k] = fma(f[r], lrow[k], FL[r][k]);
+                        FL[r][j] = f[r] * ljj;
+                    }
+                });
+                if (!pd) st |= ST_NOT_PD;
+            }
+            // Pxb = sum_k wp_k l_k f_k' (own rows of L; l_k is zero above the diagonal) -> K
+            FK_UNROLL for (int k = 0; k < NX; ++k) {
+                const double wp = mv.Wp[2 + k];
+                double wfo[R], wf[NX];
+                FK_UNROLL for (int r = 0; r < R; ++r) wfo[r] = wp * FL[r][k];
+                FK_UNROLL for (int b = 0; b < NX; ++b) wf[b] = quad_from(quad, wfo[b / 4], b % 4);
+                FK_UNROLL for (int r = 0; r < R; ++r) {
+                    if (4 * r + 3 < k) continue;
+                    FK_UNROLL for (int b = 0; b < NX; ++b) K[r][b] = (k == 0) ? Lw[r][0] * wf[b] : fma(Lw[r][k], wf[b], K[r][b]);
+                }
+                FK_STAGE();
+            }
+        }
+        // xb (replicated), the centre point's offset, Pb
+        const double wms = mv.Wp[0], wcs = mv.Wp[1];
+        {
+            double wy[NX];
+            FK_UNROLL for (int b = 0; b < NX; ++b) {
+                const double fx = quad_from(quad, Fxo[b / 4], b % 4);
+                xb[b] = wms * fx;
+                wy[b] = wcs * (fx - xb[b]);
+            }
+            FK_UNROLL for (int r = 0; r < R; ++r) {
+                const double xa = wms * Fxo[r];
+                const double ya = Fxo[r] - xa;
+                FK_UNROLL for (int b = 0; b < NX; ++b) Pb[r][b] = ya * wy[b];
+            }
+            FK_STAGE();
+        }
+        FK_UNROLL for (int k = 0; k < NX; ++k) {
+            const double wp = mv.Wp[2 + k];
+            double wfo[R], wf[NX];
+            FK_UNROLL for (int r = 0; r < R; ++r) wfo[r] = wp * FL[r][k];
+            FK_UNROLL for (int b = 0; b < NX; ++b) wf[b] = quad_from(quad, wfo[b / 4], b % 4);
+            FK_UNROLL for (int r = 0; r < R; ++r)
+                FK_UNROLL for (int b = 0; b < NX; ++b) Pb[r][b] = fma(FL[r][k], wf[b], Pb[r][b]);
+            FK_STAGE();
+        }
+        {
+            double Qr[2][NX];
+            FK_UNROLL for (int b = 0; b < NX; ++b) Qr[0][b] = mv.Q[g[0] * NX + b];
+            FK_UNROLL for (int r = 0; r < R; ++r) {
+                if (r + 1 < R) {
+                    FK_UNROLL for (int b = 0; b < NX; ++b) Qr[(r + 1) & 1][b] = mv.Q[g[r + 1] * NX + b];
+                }
+                FK_UNROLL for (int b = 0; b < NX; ++b) Pb[r][b] += Qr[r & 1][b];
+                FK_STAGE();
+            }
+        }
+    }
+    // ---------------- K = Pxb Pb^-1
+    {
+        double Lb[R][NX], invd[NX];
+        const bool pd = quad_chol_rows<NX>(Pb, g, 1.0, Lb, quad, [&](int j, const double (&lrow)[NX], double, double inv) {
+            invd[j] = inv;
+            // forward substitution, column j of every own row: w[j] = (Pxb[a][j] - sum_{k<j} w[k] Lb[j][k]) / Lb[j][j]
+            FK_UNROLL for (int r = 0; r < R; ++r) {
+                double acc = K[r][j];
+                FK_UNROLL for (int k = 0; k < NX; ++k)
+                    if (k < j) acc = fma(-K[r][k], lrow[k], acc);
+                K[r][j] = acc * inv;
+            }
+        });
+        if (!pd) st |= ST_NOT_PD;
+        // backward substitution: K[a][i] = (w[i] - sum_{k>i} K[a][k] Lb[k][i]) / Lb[i][i]
+        FK_UNROLL for (int i = NX - 1; i >= 0; --i) {
+            double col[NX];
+            FK_UNROLL for (int k = 0; k < NX; ++k)
+                if (k > i) col[k] = quad_from(quad, Lb[k / 4][i], k % 4);
+            FK_UNROLL for (int r = 0; r < R; ++r) {
+                double acc = K[r][i];
+                FK_UNROLL for (int k = NX - 1; k >= 0; --k)
+                    if (k > i) acc = fma(-K[r][k], col[k], acc);
+                K[r][i] = acc * invd[i];
+            }
+            if (i % 4 == 0) FK_STAGE();
+        }
+    }
+    // ---------------- correct: x += K (xn - xb)
+    {
+        double dx[NX], xo[R];
+        FK_UNROLL for (int c = 0; c < NX; ++c) dx[c] = xn[c] - xb[c];
+        FK_UNROLL for (int r = 0; r < R; ++r) {
+            double acc = K[r][0] * dx[0];
+            FK_UNROLL for (int c = 1; c < NX; ++c) acc = fma(K[r][c], dx[c], acc);
+            xo[r] = acc;
+        }
+        FK_UNROLL for (int b = 0; b < NX; ++b) x[b] += quad_from(quad, xo[b / 4], b % 4);
+    }
+    FK_STAGE();
+    // T1 = K D, D = Pn - Pb: the rows of D a slot at a time from their owners
+    double T1[R][NX];
+    {
+        double Pn[2][NX];
+        next_row(0, Pn[0]);
+        FK_UNROLL for (int s = 0; s < R; ++s) {
+            if (s + 1 < R) next_row(s + 1, Pn[(s + 1) & 1]);
+            double Ds[NX];
+            FK_UNROLL for (int c = 0; c < NX; ++c) Ds[c] = Pn[s & 1][c] - Pb[s][c];
+            FK_UNROLL for (int q = 0; q < 4; ++q) {
+                const int b = 4 * s + q;
+                if (b >= NX) continue;
+                double Db[NX];
+                FK_UNROLL for (int c = 0; c < NX; ++c) Db[c] = quad_from(quad, Ds[c], q);
+                FK_UNROLL for (int r = 0; r < R; ++r)
+                    FK_UNROLL for (int c = 0; c < NX; ++c) T1[r][c] = (b == 0) ? K[r][0] * Db[c] : fma(K[r][b], Db[c], T1[r][c]);
+            }
+            FK_STAGE();
+        }
+    }
+    // P += T1 K': row j of K from its owner
+    FK_UNROLL for (int r = 0; r < R; ++r) own_row(r, P[r]);
+    FK_UNROLL for (int j = 0; j < NX; ++j) {
+        double Kj[NX];
+        FK_UNROLL for (int c = 0; c < NX; ++c) Kj[c] = quad_from(quad, K[j / 4][c], j % 4);
+        FK_UNROLL for (int r = 0; r < R; ++r) {
+            double acc = T1[r][0] * Kj[0];
+            FK_UNROLL for (int c = 1; c < NX; ++c) acc = fma(T1[r][c], Kj[c], acc);
+            P[r][j] += acc;
+        }
+        if (j % 4 == 3) FK_STAGE();
     }
     return st;
 }

@@ -147,3 +147,97 @@ extern "C" int hc_ukf_quad_v4(int n, int m, long T, const double *F, const doubl
 #undef GO
     return -1;
 }
+
+// ---- the smoother's backward pass (ukf_quad_rts_step_v4) over one track
+namespace {
+
+template <int NX>
+struct RtsJob {
+    long T;
+    const double *F, *Q, *Wp, *Xs, *Ps;
+    double scale;
+    double *xs, *ps, *Ks;
+    int st[4];
+};
+
+template <int NX>
+void quad_rts_lane(void *vp, int lane)
+{
+    constexpr int R = (NX + 3) / 4;
+    auto &job = *static_cast<RtsJob<NX> *>(vp);
+    HostQuad quad{g_fq, lane};
+    unsigned g[R];
+    bool dup[R];
+    for (int r = 0; r < R; ++r) {
+        const unsigned row = 4u * (unsigned)r + (unsigned)lane;
+        dup[r] = row >= (unsigned)NX;
+        g[r] = dup[r] ? (unsigned)NX - 1u : row;
+    }
+    const long T = job.T;
+    const fk::UkfQuadModel mv{job.F, job.Q, nullptr, nullptr, job.Wp};
+    // the last step is the filter's own output (xs, ps = Xs.copy(), Ps.copy(); K[T-1] = 0)
+    double xn[NX], Pn[R][NX];
+    for (int i = 0; i < NX; ++i) xn[i] = job.Xs[(T - 1) * NX + i];
+    for (int r = 0; r < R; ++r)
+        for (int c = 0; c < NX; ++c) Pn[r][c] = job.Ps[((T - 1) * NX + g[r]) * NX + c];
+    if (lane == 0)
+        for (int i = 0; i < NX; ++i) job.xs[(T - 1) * NX + i] = xn[i];
+    for (int r = 0; r < R; ++r)
+        if (!dup[r])
+            for (int c = 0; c < NX; ++c) {
+                job.ps[((T - 1) * NX + g[r]) * NX + c] = Pn[r][c];
+                job.Ks[((T - 1) * NX + g[r]) * NX + c] = 0.0;
+            }
+    int st = 0;
+    for (long t = T - 2; t >= 0; --t) {
+        double x[NX], P[R][NX], K[R][NX];
+        for (int i = 0; i < NX; ++i) x[i] = job.Xs[t * NX + i];
+        for (int r = 0; r < R; ++r)
+            for (int c = 0; c < NX; ++c) P[r][c] = c <= 4 * r + 3 ? job.Ps[(t * NX + g[r]) * NX + c] : -1e300;   // only the lower part is handed over
+        st |= fk::ukf_quad_rts_step_v4<NX>(x, P, g, xn, job.scale, mv, quad, K,
+                                           [&](int r, double (&out)[NX]) { for (int c = 0; c < NX; ++c) out[c] = Pn[r][c]; },
+                                           [&](int r, double (&out)[NX]) { for (int c = 0; c < NX; ++c) out[c] = job.Ps[(t * NX + g[r]) * NX + c]; });
+        for (int i = 0; i < NX; ++i) {
+            if (lane == 0) job.xs[t * NX + i] = x[i];
+            else if (memcmp(&job.xs[t * NX + i], &x[i], 8) != 0) st |= 1 << 20;
+            xn[i] = x[i];
+        }
+        for (int r = 0; r < R; ++r)
+            for (int c = 0; c < NX; ++c) {
+                if (!dup[r]) {
+                    job.ps[(t * NX + g[r]) * NX + c] = P[r][c];
+                    job.Ks[(t * NX + g[r]) * NX + c] = K[r][c];
+                } else if (memcmp(&job.ps[(t * NX + g[r]) * NX + c], &P[r][c], 8) != 0 || memcmp(&job.Ks[(t * NX + g[r]) * NX + c], &K[r][c], 8) != 0)
+                    st |= 1 << 21;                                   // a duplicate differs from the row it duplicates
+                Pn[r][c] = P[r][c];
+            }
+    }
+    job.st[lane] = st;
+}
+
+template <int NX>
+int ukf_quad_rts_batch(long T, const double *F, const double *Q, const double *Wm, const double *Wc, double scale,
+                       const double *Xs, const double *Ps, double *xs, double *ps, double *Ks)
+{
+    constexpr int KS = 2 * NX + 1;
+    double wm[KS], wc[KS], wp[2 + NX];
+    std::copy(Wm, Wm + KS, wm);
+    std::copy(Wc, Wc + KS, wc);
+    fk::make_pair_table<NX>(wm, wc, wp);
+    if (!fk::pair_weights_symmetric<NX>(wm, wc)) return -2;
+    RtsJob<NX> job{T, F, Q, wp, Xs, Ps, scale, xs, ps, Ks, {0, 0, 0, 0}};
+    run_quad(&quad_rts_lane<NX>, &job);
+    if (job.st[0] != job.st[1] || job.st[0] != job.st[2] || job.st[0] != job.st[3]) return 1 << 22;
+    return job.st[0];
+}
+
+}  // namespace
+
+extern "C" int hc_ukf_quad_rts_v4(int n, long T, const double *F, const double *Q, const double *Wm, const double *Wc,
+                                  double scale, const double *Xs, const double *Ps, double *xs, double *ps, double *Ks)
+{
+#define GO(NXV) if (n == NXV) return ukf_quad_rts_batch<NXV>(T, F, Q, Wm, Wc, scale, Xs, Ps, xs, ps, Ks)
+    GO(4); GO(5); GO(7); GO(8); GO(9); GO(10); GO(11); GO(12); GO(13); GO(14); GO(15); GO(16);
+#undef GO
+    return -1;
+}

@@ -137,3 +137,52 @@ def test_quad_step_julier_weights(quad_lib):
     assert np.allclose(Wm, W) and np.allclose(Wc, W)
     mu, cov, _, _ = _run(quad_lib, "hc_ukf_quad_v4", n, m, F, H, Q, R, W, W, n + kappa, zs, None, x0, P0)
     assert rel(mu, mu_ref) < 1e-9 and rel(cov, cov_ref) < 1e-9
+
+
+def _rts(lib, entry, n, F, Q, Wm, Wc, scale, Xs, Ps):
+    T = Xs.shape[0]
+    c = lambda a: np.ascontiguousarray(a, dtype=np.float64)  # noqa: E731
+    F, Q, Wm, Wc, Xs, Ps = map(c, (F, Q, Wm, Wc, Xs, Ps))
+    xs, ps, Ks = np.full((T, n), np.nan), np.full((T, n, n), np.nan), np.full((T, n, n), np.nan)
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+    st = getattr(lib, entry)(ctypes.c_int(n), ctypes.c_long(T), p(F), p(Q), p(Wm), p(Wc), ctypes.c_double(scale),
+                              p(Xs), p(Ps), p(xs), p(ps), p(Ks))
+    assert st == 0, st
+    return xs, ps, Ks
+
+
+relrows = lambda a, b: float(np.max(np.max(np.abs(a - b).reshape(len(a), -1), axis=1) / np.max(np.abs(b).reshape(len(b), -1), axis=1)))  # noqa: E731
+
+
+@pytest.mark.parametrize("n", [4, 5, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16])
+@pytest.mark.parametrize("abk", [(.1, 2., None), (1., 2., .1)])
+def test_quad_smoother_step_matches_the_oracle(quad_lib, n, abk):
+    """UKF.rts_smoother (UKF.py:714-739) through the oracle against the distributed backward step (ukf_quad_rts_step_v4: the
+    gain's forward substitution fused into the factorisation of Pb, the rows of Pn - Pb and of K broadcast by their owners)."""
+    alpha, beta, kappa = abk
+    kappa = 3. - n if kappa is None else kappa
+    m = 2
+    r, F, H, Q, R, x0, P0 = _model(n, m, n * 10 + 3)
+    T = 20
+    zs = r.standard_normal((T, m))
+    Wm, Wc = ukf_oracle.merwe_weights(n, alpha, beta, kappa)
+    mu, cov = ukf_oracle.ukf_batch_filter(x0, P0, list(zs), lambda s, d: F @ s, lambda s: H @ s, 0.1, Q, R, alpha, beta, kappa)
+    xr, Pr, Kr = ukf_oracle.ukf_rts_smoother(mu, cov, lambda s, d: F @ s, 0.1, Q, alpha, beta, kappa)
+    xs, ps, Ks = _rts(quad_lib, "hc_ukf_quad_rts_v4", n, F, Q, Wm, Wc, alpha ** 2 * (n + kappa), mu, cov)
+    assert relrows(xs, xr) < 1e-10 and relrows(ps, Pr) < 1e-10 and relrows(Ks[:-1], Kr[:-1]) < 1e-10
+    assert np.array_equal(xs[-1], mu[-1]) and np.array_equal(ps[-1], cov[-1]) and not Ks[-1].any()
+    assert relrows(ps, np.swapaxes(ps, 1, 2)) < 1e-13
+
+
+@pytest.mark.parametrize("n", [4, 5, 7, 8, 9])
+def test_quad_smoother_step_agrees_with_the_one_lane_step(quad_lib, n):
+    one = ctypes.CDLL(os.path.join(HC, "libhostcheck.so"))
+    r, F, H, Q, R, x0, P0 = _model(n, 2, 50 + n)
+    zs = r.standard_normal((25, 2))
+    alpha, beta, kappa = .3, 2., 3. - n
+    Wm, Wc = ukf_oracle.merwe_weights(n, alpha, beta, kappa)
+    mu, cov = ukf_oracle.ukf_batch_filter(x0, P0, list(zs), lambda s, d: F @ s, lambda s: H @ s, 0.1, Q, R, alpha, beta, kappa)
+    a = _rts(quad_lib, "hc_ukf_quad_rts_v4", n, F, Q, Wm, Wc, alpha ** 2 * (n + kappa), mu, cov)
+    b = _rts(one, "hc_ukf_linear_rts_v4", n, F, Q, Wm, Wc, alpha ** 2 * (n + kappa), mu, cov)
+    for u, v in zip(a, b):
+        assert relrows(u[:-1], v[:-1]) < 1e-12
