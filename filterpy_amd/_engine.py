@@ -189,8 +189,10 @@ def ukf_linear_supported(n, m, paired=False):
     return (1 <= n <= 6 and 1 <= m <= 3) or (7 <= n <= 9 and 1 <= m <= 4)
 
 
-def ukf_linear_rts_supported(n):
-    """sizes fk_ukf_linear_rts_f64 is compiled for"""
+def ukf_linear_rts_supported(n, paired=False):
+    """sizes fk_ukf_linear_rts_f64 is compiled for (dim_x 10..16: like ukf_linear_supported)"""
+    if 10 <= n <= 16:
+        return bool(paired) and os.environ.get("FK_UKF_MLG", "0")[:1] == "1"
     return 1 <= n <= 9
 
 

@@ -62,6 +62,19 @@ struct UkfArgs {
     int soa_pairs;       // element-major outputs as 16-byte stores of two element rows (wave_store_soa_pairs) where a wave allows it
 };
 
+// the fused linear UKF smoothers (ukf_kernels.hip, ukf_mlg.hip)
+struct UkfRtsArgs {
+    const double *Xs, *Ps;
+    double *xs, *ps, *Ks;
+    int32_t *status;
+    long N, T;
+    int n;
+    double scale;
+    long i0, cnt;        // the launch covers tracks [i0, i0 + cnt) of the N (a piece of a chunked call, fk_chunks.hpp)
+    int cont;            // 1: the window's top step was smoothed by the piece before it -- read it from xs / ps, do not copy
+    int status_or;       // 1: OR the status into what an earlier piece left
+};
+
 struct ImmArgs {
     const double *F, *Q, *H, *R, *Mt, *z;
     double *xs, *Ps, *mu;

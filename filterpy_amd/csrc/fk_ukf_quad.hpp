@@ -251,12 +251,13 @@ FK_HD int ukf_quad_step_v4(double (&x)[NX], double (&P)[(NX + 3) / 4][NX], const
 // What the step keeps OUT of the registers: the smoothed covariance of step k+1 (next_row(r, out): the caller's copy of the
 // lane's row of slot r -- the kernel's output tile still holds it) and the full rows of Ps[k] (own_row(r, out): requested
 // again for the correction; the sweep only needs P[r][c], c <= 4 r + 3).
-// x: Xs[k] in, xs[k] out (replicated);  P: rows of Ps[k] in (lower part), of ps[k] out;  xn: xs[k+1];  K: the lane's rows of
-// the gain out.
-template <int NX, class Quad, class NextRow, class OwnRow>
+// Likewise the two means: the sweep spends x[j] at column j, so the correction asks for Xs[k] again (own_x) and for xs[k+1]
+// (next_x) instead of carrying 2 n doubles through the passes.
+// x: Xs[k] in, xs[k] out (replicated);  P: rows of Ps[k] in (lower part), of ps[k] out;  K: the lane's rows of the gain out.
+template <int NX, class Quad, class NextX, class NextRow, class OwnX, class OwnRow>
 FK_HD int ukf_quad_rts_step_v4(double (&x)[NX], double (&P)[(NX + 3) / 4][NX], const unsigned (&g)[(NX + 3) / 4],
-                               const double (&xn)[NX], double scale, const UkfQuadModel &mv, Quad &quad,
-                               double (&K)[(NX + 3) / 4][NX], NextRow &&next_row, OwnRow &&own_row)
+                               double scale, const UkfQuadModel &mv, Quad &quad, double (&K)[(NX + 3) / 4][NX],
+                               NextX &&next_x, NextRow &&next_row, OwnX &&own_x, OwnRow &&own_row)
 {
     constexpr int R = (NX + 3) / 4;
     static_assert(NX >= 4, "dim_x >= 4 (every lane of the quad holds a row)");
@@ -365,12 +366,14 @@ FK_HD int ukf_quad_rts_step_v4(double (&x)[NX], double (&P)[(NX + 3) / 4][NX], c
     // ---------------- correct: x += K (xn - xb)
     {
         double dx[NX], xo[R];
-        FK_UNROLL for (int c = 0; c < NX; ++c) dx[c] = xn[c] - xb[c];
+        next_x(dx);
+        FK_UNROLL for (int c = 0; c < NX; ++c) dx[c] -= xb[c];
         FK_UNROLL for (int r = 0; r < R; ++r) {
             double acc = K[r][0] * dx[0];
             FK_UNROLL for (int c = 1; c < NX; ++c) acc = fma(K[r][c], dx[c], acc);
             xo[r] = acc;
         }
+        own_x(x);
         FK_UNROLL for (int b = 0; b < NX; ++b) x[b] += quad_from(quad, xo[b / 4], b % 4);
     }
     FK_STAGE();

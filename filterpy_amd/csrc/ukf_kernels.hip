@@ -26,17 +26,6 @@
 
 namespace fk {
 
-struct UkfRtsArgs {
-    const double *Xs, *Ps;
-    double *xs, *ps, *Ks;
-    int32_t *status;
-    long N, T;
-    int n;
-    double scale;
-    long i0, cnt;        // the launch covers tracks [i0, i0 + cnt) of the N (a piece of a chunked call, fk_chunks.hpp)
-    int cont;            // 1: the window's top step was smoothed by the piece before it -- read it from xs / ps, do not copy
-    int status_or;       // 1: OR the status into what an earlier piece left
-};
 
 #if FK_UKF_FWD
 // --------------------------------------------------- fused linear-model UKF --
@@ -646,7 +635,9 @@ int ukf_rts_launch_big_paired(const UkfRtsArgs &a, const double *F, const double
 
 #endif
 // ukf_mlg.hip, one object per dim_x
-#define FK_UMLG_DECL(NXV) int launch_ukf_mlg_##NXV(const UkfArgs &, int, hipStream_t);
+#define FK_UMLG_DECL(NXV)                                         \
+    int launch_ukf_mlg_##NXV(const UkfArgs &, int, hipStream_t); \
+    int launch_ukf_mlg_rts_##NXV(const UkfRtsArgs &, const double *, const double *, const double *, const double *, int, hipStream_t);
 FK_UMLG_DECL(10) FK_UMLG_DECL(11) FK_UMLG_DECL(12) FK_UMLG_DECL(13) FK_UMLG_DECL(14) FK_UMLG_DECL(15) FK_UMLG_DECL(16)
 #undef FK_UMLG_DECL
 #if FK_UKF_HAS(1)
@@ -665,6 +656,28 @@ static int ukf_mlg_launch(const UkfArgs &a, int layout, hipStream_t s)
     }
     if (rc == 1) {
         set_last_error("fused linear UKF: no four-lane instantiation for these dims");
+        return FK_ERR_UNSUPPORTED;
+    }
+    return rc;
+}
+#endif
+
+#if FK_UKF_HAS(3)
+static int ukf_mlg_rts_launch(const UkfRtsArgs &a, const double *F, const double *Q, const double *Wm, const double *Wc, int layout, hipStream_t s)
+{
+    int rc = 1;
+    switch (a.n) {
+        case 10: rc = launch_ukf_mlg_rts_10(a, F, Q, Wm, Wc, layout, s); break;
+        case 11: rc = launch_ukf_mlg_rts_11(a, F, Q, Wm, Wc, layout, s); break;
+        case 12: rc = launch_ukf_mlg_rts_12(a, F, Q, Wm, Wc, layout, s); break;
+        case 13: rc = launch_ukf_mlg_rts_13(a, F, Q, Wm, Wc, layout, s); break;
+        case 14: rc = launch_ukf_mlg_rts_14(a, F, Q, Wm, Wc, layout, s); break;
+        case 15: rc = launch_ukf_mlg_rts_15(a, F, Q, Wm, Wc, layout, s); break;
+        case 16: rc = launch_ukf_mlg_rts_16(a, F, Q, Wm, Wc, layout, s); break;
+        default: break;
+    }
+    if (rc == 1) {
+        set_last_error("fused linear UKF smoother: no four-lane instantiation for this dim_x");
         return FK_ERR_UNSUPPORTED;
     }
     return rc;
@@ -750,7 +763,14 @@ int fk_ukf_linear_rts_f64(const fk_ukf_desc *d, const double *F, const double *Q
                           void *stream)
 {
     if (!d) return fail(FK_ERR_BAD_ARG, "desc is NULL");
-    if (d->n < 1 || d->n > 9) return fail(FK_ERR_UNSUPPORTED, "fused linear UKF smoother: dim_x 1..9");
+    // dim_x 10..16: four lanes per track (ukf_mlg.hip), pair-regrouped sums only, opt-in like the filter (fk_ukf_linear_batch_f64)
+    const bool quad = d->n >= 10 && d->n <= 16;
+    if (quad) {
+        static const bool on = getenv("FK_UKF_MLG") && getenv("FK_UKF_MLG")[0] == '1';
+        if (!on || !(d->flags & FK_UKF_FLAG_PAIR_WEIGHTS))
+            return fail(FK_ERR_UNSUPPORTED, "fused linear UKF smoother at dim_x 10..16: FK_UKF_MLG=1 and weights equal within every +- pair (FK_UKF_FLAG_PAIR_WEIGHTS)");
+        if ((double)d->N * d->n * d->n * 8.0 >= 4294967296.0 - 32.0) return fail(FK_ERR_UNSUPPORTED, "fused linear UKF smoother: record block >= 4 GiB, split the batch");
+    } else if (d->n < 1 || d->n > 9) return fail(FK_ERR_UNSUPPORTED, "fused linear UKF smoother: dim_x 1..9, 10..16");
     if (d->N < 0 || d->T < 0 || !F || !Q || !Wm || !Wc || !Xs || !Ps || !xs || !Ps_out)
         return fail(FK_ERR_BAD_ARG, "fused linear UKF smoother: bad argument");
     if ((double)d->N * d->n * d->n * 8.0 >= 4294967296.0) return fail(FK_ERR_UNSUPPORTED, "fused linear UKF smoother: record block >= 4 GiB, split the batch");
@@ -760,6 +780,7 @@ int fk_ukf_linear_rts_f64(const fk_ukf_desc *d, const double *F, const double *Q
     a0.N = d->N; a0.T = d->T; a0.n = d->n; a0.scale = d->scale;
     a0.i0 = 0; a0.cnt = d->N; a0.cont = 0; a0.status_or = 0;
     const int layout = d->layout;
+    if (quad) return d->T >= 1 ? ukf_mlg_rts_launch(a0, F, Q, Wm, Wc, layout, (hipStream_t)stream) : FK_OK;
     const bool exact = ukf_exact(), paired = ukf_paired(d);
     auto one = [&](const UkfRtsArgs &a, hipStream_t s) -> int {
         if (paired) return a.n <= 6 ? ukf_rts_launch_small_paired(a, F, Q, Wm, Wc, layout, exact, s) : ukf_rts_launch_big_paired(a, F, Q, Wm, Wc, layout, exact, s);

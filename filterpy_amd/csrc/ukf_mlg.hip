@@ -175,6 +175,151 @@ ukf_mlg_kernel(const UkfArgs a)
     }
 }
 
+// The smoother (UnscentedKalmanFilter.rts_smoother, UKF.py:634-739, with fx(x, dt) = F x) on the same four lanes per track:
+// ukf_quad_rts_step_v4 per backward step.  What a step needs of its neighbours stays out of the registers:
+//   * the smoothed covariance of step k+1 is still in the wave's output tile, where step k+1 staged it for its copy-out (the
+//     LAST copy-out of a step, so that nothing overwrites it): the lanes read their rows back from there;
+//   * the full rows of Ps[k] are requested a second time for the correction (the factorisation takes the lower part only);
+//   * the smoothed mean of step k+1 is replicated in the quad (dim_x registers).
+// Reads Xs[k], Ps[k] (the latter 1.6 times); writes xs[k], ps[k], Ks[k]: 8 (2 n + 3 n^2) algorithmic bytes per track-step.
+// In-place calls (xs == Xs, Ps_out == Ps) are fine: a step's reads of step k are consumed before its copy-outs are issued.
+template <int NX, int LAYOUT>
+__global__ void __launch_bounds__(BLOCK, 1)
+ukf_mlg_rts_kernel(const UkfRtsArgs a, const double *__restrict__ pF, const double *__restrict__ pQ,
+                   const double *__restrict__ pWm, const double *__restrict__ pWc)
+{
+    constexpr int R = (NX + 3) / 4, KS = 2 * NX + 1;
+    constexpr bool AOS = LAYOUT == LAYOUT_AOS;
+    constexpr int EP = NX * NX;
+    constexpr int TILE = 16 * EP, XT = 2 * 16 * NX;              // per wave: one covariance-sized output set; xs[k+1] as staged + Xs[k] parked
+    constexpr int OFF_F = 0, OFF_Q = EP, OFF_W = 2 * EP;         // [F | Q | Wm | Wc | pair table]
+    constexpr int MSZ = OFF_W + 2 * KS + 2 + NX;
+    __shared__ double smem[MSZ + (BLOCK / 64) * (TILE + XT)];
+    double *tile = smem + MSZ + (threadIdx.x >> 6) * (TILE + XT), *xt = tile + TILE;
+    lds_fill<NX, NX>(smem + OFF_F, pF, NX, NX, 1.0, threadIdx.x);
+    lds_fill<NX, NX>(smem + OFF_Q, pQ, NX, NX, 0.0, threadIdx.x);
+    for (unsigned q = threadIdx.x; q < (unsigned)(2 * KS); q += BLOCK) smem[OFF_W + q] = (q < (unsigned)KS ? pWm[q] : pWc[q - KS]);
+    __syncthreads();
+    int st = 0;
+    if (threadIdx.x == 0) make_pair_table<NX>(smem + OFF_W, smem + OFF_W + KS, smem + OFF_W + 2 * KS);
+    if (!pair_weights_symmetric<NX>(smem + OFF_W, smem + OFF_W + KS)) st |= ST_BAD_WEIGHTS;
+    __syncthreads();
+    const UkfQuadModel mv{smem + OFF_F, smem + OFF_Q, nullptr, nullptr, smem + OFF_W + 2 * KS};
+
+    const long N = a.N;
+    const unsigned L = threadIdx.x & 3u;
+    const long iend = a.i0 + a.cnt;
+    long trk = a.i0 + (long)blockIdx.x * (BLOCK / 4) + (threadIdx.x >> 2);
+    const bool owner = trk < iend;
+    if (trk >= iend) trk = iend - 1;
+    unsigned row[R];
+    FK_UNROLL for (int r = 0; r < R; ++r) {
+        const unsigned g = L + 4u * (unsigned)r;
+        row[r] = g < (unsigned)NX ? g : (unsigned)NX - 1u;
+    }
+    unsigned estride = AOS ? 8u : (unsigned)N * 8u;
+    asm volatile("" : "+s"(estride));
+    const unsigned t8 = (unsigned)trk * (AOS ? (unsigned)NX * 8u : 8u);
+    unsigned off_row[R];
+    FK_UNROLL for (int r = 0; r < R; ++r)
+        off_row[r] = (AOS ? (unsigned)trk * (unsigned)EP * 8u : (unsigned)trk * 8u) + row[r] * (unsigned)NX * estride;
+    const long w0 = a.i0 + (long)blockIdx.x * (BLOCK / 4) + (long)wave_index() * 16;
+    const unsigned valid = (unsigned)(iend - w0 >= 16 ? 16 : (iend - w0 > 0 ? iend - w0 : 0));
+    const unsigned lane = threadIdx.x & 63u, g16 = lane >> 2;
+    // element e of the wave's track g16 in the staging tile (laid out like the wave's slab of the output array)
+    auto tile_at = [&](unsigned e) -> double & { return tile[AOS ? g16 * (unsigned)EP + e : e * 16u + g16]; };
+    auto xt_at = [&](unsigned e) -> double & { return xt[AOS ? g16 * (unsigned)NX + e : e * 16u + g16]; };
+    double *xpark = xt + 16 * NX + g16;                          // Xs[k] of the step, [element][track]
+    // copy-outs of the staged sets (a set that was not asked for, or must not be rewritten: zero tracks -- issued and dropped)
+    auto out_cov = [&](double *arr, long t, unsigned vv) {
+        double *dst = arr ? arr : a.ps;
+        const unsigned v = arr ? vv : 0u;
+        ml_wave_fence();
+        if constexpr (AOS) ml_tile_out_aos<EP, 16>(dst + (t * N + w0) * EP, tile, lane, v);
+        else ml_tile_out_soa<EP, 16>(dst + t * N * EP, N, w0, tile, lane, v);
+        ml_wave_fence();
+    };
+    auto out_mean = [&](long t, unsigned vv) {
+        ml_wave_fence();
+        if constexpr (AOS) ml_tile_out_aos<NX, 16>(a.xs + (t * N + w0) * NX, xt, lane, vv);
+        else ml_tile_out_soa<NX, 16>(a.xs + t * N * NX, N, w0, xt, lane, vv);
+        ml_wave_fence();
+    };
+    QuadDpp quad;
+
+    // the last step is the filter's own output (xs, ps = Xs.copy(), Ps.copy(); K[T-1] = 0) -- unless this launch continues a
+    // chunked call (a.cont): then the window's top step was smoothed by the piece before it and is read back, not rewritten
+    {
+        double xn[NX];
+        const double *srcx = a.cont ? a.xs : a.Xs, *srcP = a.cont ? a.ps : a.Ps;
+        const unsigned vtop = a.cont ? 0u : valid;
+        const MlView vx(srcx + (a.T - 1) * N * NX, t8, estride);
+        double Pt[R][NX];
+        FK_UNROLL for (int r = 0; r < R; ++r) {
+            const MlView vP(srcP + (a.T - 1) * N * EP, off_row[r], estride);
+            FK_UNROLL for (int c = 0; c < NX; ++c) Pt[r][c] = vP.load(c);
+        }
+        FK_UNROLL for (int k = 0; k < NX; ++k) xn[k] = vx.load(k);
+        ml_wave_fence();
+        FK_UNROLL for (int r = 0; r < R; ++r)
+            FK_UNROLL for (int c = 0; c < NX; ++c) tile_at(row[r] * (unsigned)NX + (unsigned)c) = 0.0;
+        out_cov(a.Ks, a.T - 1, vtop);
+        FK_UNROLL for (int k = 0; k < NX; ++k) xt_at((unsigned)k) = xn[k];
+        out_mean(a.T - 1, vtop);
+        FK_UNROLL for (int r = 0; r < R; ++r)
+            FK_UNROLL for (int c = 0; c < NX; ++c) tile_at(row[r] * (unsigned)NX + (unsigned)c) = Pt[r][c];
+        out_cov(a.ps, a.T - 1, vtop);                          // ... and stays in the tile for step T-2
+    }
+    _Pragma("nounroll") for (long t = a.T - 2; t >= 0; --t) {
+        double x[NX], P[R][NX], K[R][NX];
+        {
+            const MlView vx(a.Xs + t * N * NX, t8, estride);
+            FK_UNROLL for (int r = 0; r < R; ++r) {
+                const MlView vP(a.Ps + t * N * EP, off_row[r], estride);
+                FK_UNROLL for (int c = 0; c < NX; ++c)
+                    if (c <= 4 * r + 3) P[r][c] = vP.load(c);
+            }
+            FK_UNROLL for (int k = 0; k < NX; ++k) x[k] = vx.load(k);
+            FK_UNROLL for (int k = 0; k < NX; ++k) xpark[k * 16] = x[k];
+        }
+        st |= ukf_quad_rts_step_v4<NX>(x, P, row, a.scale, mv, quad, K,
+            [&](double (&out)[NX]) {                            // xs[k+1]: still staged in xt
+                FK_UNROLL for (int c = 0; c < NX; ++c) out[c] = xt_at((unsigned)c);
+            },
+            [&](int r, double (&out)[NX]) {
+                FK_UNROLL for (int c = 0; c < NX; ++c) out[c] = tile_at(row[r] * (unsigned)NX + (unsigned)c);
+            },
+            [&](double (&out)[NX]) {
+                FK_UNROLL for (int c = 0; c < NX; ++c) out[c] = xpark[c * 16];
+            },
+            [&](int r, double (&out)[NX]) {
+                const MlView vP(a.Ps + t * N * EP, off_row[r], estride);
+                FK_UNROLL for (int c = 0; c < NX; ++c) out[c] = vP.load(c);
+            });
+        FK_STAGE();
+        ml_wave_fence();
+        FK_UNROLL for (int k = 0; k < NX; ++k) xt_at((unsigned)k) = x[k];
+        out_mean(t, valid);
+        FK_UNROLL for (int r = 0; r < R; ++r)
+            FK_UNROLL for (int c = 0; c < NX; ++c) tile_at(row[r] * (unsigned)NX + (unsigned)c) = K[r][c];
+        out_cov(a.Ks, t, valid);
+        FK_UNROLL for (int r = 0; r < R; ++r)
+            FK_UNROLL for (int c = 0; c < NX; ++c) tile_at(row[r] * (unsigned)NX + (unsigned)c) = P[r][c];
+        out_cov(a.ps, t, valid);                               // last: the tile keeps ps[t] for step t-1
+    }
+    if (owner && a.status) {
+        // the last smoothed state is what the wave's staging areas hold: finite?
+        bool fin = true;
+        FK_UNROLL for (int k = 0; k < NX; ++k) fin = fin && (fabs(xt_at((unsigned)k)) <= 1.79769313486231570815e+308);
+        FK_UNROLL for (int r = 0; r < R; ++r)
+            FK_UNROLL for (int c = 0; c < NX; ++c) fin = fin && (fabs(tile_at(row[r] * (unsigned)NX + (unsigned)c)) <= 1.79769313486231570815e+308);
+        int s = st | (fin ? 0 : ST_NONFINITE);
+        s |= __builtin_amdgcn_mov_dpp(s, 0xB1, 0xf, 0xf, true);
+        s |= __builtin_amdgcn_mov_dpp(s, 0x4E, 0xf, 0xf, true);
+        if (L == 0) a.status[trk] = a.status_or ? (a.status[trk] | s) : s;
+    }
+}
+
 }  // namespace (instantiation)
 
 // returns 1 when this call is not one the four-lane kernel serves
@@ -191,6 +336,18 @@ int FK_UMLG_CAT(launch_ukf_mlg_, FK_NX)(const UkfArgs &a, int layout, hipStream_
     GO(1) GO(2) GO(3) GO(4)
 #undef GO
     return check_launch("ukf_mlg_kernel");
+}
+
+// the smoother's launch (fk_ukf_linear_rts_f64 at dim_x 10..16); returns 1 when this file does not serve the call
+int FK_UMLG_CAT(launch_ukf_mlg_rts_, FK_NX)(const UkfRtsArgs &a, const double *F, const double *Q, const double *Wm, const double *Wc,
+                                            int layout, hipStream_t s)
+{
+    using namespace FK_UMLG_CAT(ukf_mlg_, FK_NX);
+    if (a.n != FK_NX) return 1;
+    const dim3 grid((unsigned)((a.cnt + BLOCK / 4 - 1) / (BLOCK / 4))), block(BLOCK);
+    if (layout == FK_LAYOUT_AOS) hipLaunchKernelGGL((ukf_mlg_rts_kernel<FK_NX, LAYOUT_AOS>), grid, block, 0, s, a, F, Q, Wm, Wc);
+    else hipLaunchKernelGGL((ukf_mlg_rts_kernel<FK_NX, LAYOUT_SOA>), grid, block, 0, s, a, F, Q, Wm, Wc);
+    return check_launch("ukf_mlg_rts_kernel");
 }
 
 }  // namespace fk

@@ -682,7 +682,8 @@ class UnscentedKalmanFilter(object):
         if len(Xs) != len(Ps):
             raise ValueError('Xs and Ps must have the same length')
         fused = (not callable(self.fx) and dts is None and UT is None and not self._devcall and not self._hooked
-                 and E.ukf_linear_rts_supported(self._dim_x) and not isinstance(Xs, torch.Tensor))
+                 and not isinstance(Xs, torch.Tensor)
+                 and E.ukf_linear_rts_supported(self._dim_x, self._dim_x >= 10 and E.pair_weights(self.Wm, self.Wc, self._dim_x)))
         with self._with_ut(UT):
             if (self._resident or isinstance(Xs, torch.Tensor)) and not fused:
                 return self._dev_rts_smoother(Xs, Ps, dts, device_outputs)

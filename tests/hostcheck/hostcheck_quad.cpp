@@ -194,8 +194,10 @@ void quad_rts_lane(void *vp, int lane)
         for (int i = 0; i < NX; ++i) x[i] = job.Xs[t * NX + i];
         for (int r = 0; r < R; ++r)
             for (int c = 0; c < NX; ++c) P[r][c] = c <= 4 * r + 3 ? job.Ps[(t * NX + g[r]) * NX + c] : -1e300;   // only the lower part is handed over
-        st |= fk::ukf_quad_rts_step_v4<NX>(x, P, g, xn, job.scale, mv, quad, K,
+        st |= fk::ukf_quad_rts_step_v4<NX>(x, P, g, job.scale, mv, quad, K,
+                                           [&](double (&out)[NX]) { for (int c = 0; c < NX; ++c) out[c] = xn[c]; },
                                            [&](int r, double (&out)[NX]) { for (int c = 0; c < NX; ++c) out[c] = Pn[r][c]; },
+                                           [&](double (&out)[NX]) { for (int c = 0; c < NX; ++c) out[c] = job.Xs[t * NX + c]; },
                                            [&](int r, double (&out)[NX]) { for (int c = 0; c < NX; ++c) out[c] = job.Ps[(t * NX + g[r]) * NX + c]; });
         for (int i = 0; i < NX; ++i) {
             if (lane == 0) job.xs[t * NX + i] = x[i];

@@ -155,3 +155,86 @@ def test_python_api_routes_matrix_models_here(layout):
         assert np.array_equal(ukf.x, mu[-1]) and np.array_equal(ukf.P, cov[-1])
         done += 1
     assert done >= 1
+
+
+# ------------------------------------------------------------------------------------------------ the smoother
+def _smooth(n, N, T, layout, seed, in_place=False, with_K=True):
+    """fk_ukf_linear_rts_f64 at dim_x 10..16 on the oracle's filter output of N different tracks"""
+    import torch
+    from filterpy_amd import _engine as E
+    from oracle import ukf_oracle
+    rs = np.random.RandomState(seed)
+    m, alpha, beta, kappa = 2, .5, 2.0, 3.0 - n
+    F = np.eye(n) + 0.1 * rs.randn(n, n)
+    F /= max(1.0, 1.05 * np.max(np.abs(np.linalg.eigvals(F))))
+    H, Q, R = rs.randn(m, n), spd(rs, n, 0.05), spd(rs, m, 0.5)
+    Wm, Wc = ukf_oracle.merwe_weights(n, alpha, beta, kappa)
+    mus, covs = np.empty((T, N, n)), np.empty((T, N, n, n))
+    # a few distinct filter histories, dealt out over the bank (the oracle's loop is slow), each scaled per track
+    base = []
+    for b in range(min(N, 5)):
+        base.append(ukf_oracle.ukf_batch_filter(rs.randn(n), spd(rs, n, 2.0), list(rs.randn(T, m)), lambda x, dt: F @ x,
+                                                lambda x: H @ x, 1.0, Q, R, alpha, beta, kappa))
+    pick = rs.randint(0, len(base), size=N)
+    for i in range(N):
+        mus[:, i], covs[:, i] = base[pick[i]][0], base[pick[i]][1]
+    dX, dP = E.to_records(mus, layout, 1), E.to_records(covs, layout, 1)
+    oxs = dX if in_place else E.alloc_records((T,), N, n, layout)
+    ops = dP if in_place else E.alloc_records((T,), N, n * n, layout)
+    oK = E.alloc_records((T,), N, n * n, layout) if with_K else None
+    st = torch.full((N,), -1, dtype=torch.int32, device=dX.device)
+    E.ukf_linear_rts(n, N, T, layout, alpha ** 2 * (n + kappa), E.dev(F), E.dev(Q), E.dev(Wm), E.dev(Wc), dX, dP, oxs, ops, oK, st, paired=True)
+    assert not st.cpu().numpy().any()
+    xs, ps = E.from_records(oxs, layout, 1, (n,)), E.from_records(ops, layout, 1, (n, n))
+    Ks = E.from_records(oK, layout, 1, (n, n)) if with_K else None
+    refs = [ukf_oracle.ukf_rts_smoother(b[0], b[1], lambda x, dt: F @ x, 1.0, Q, alpha, beta, kappa) for b in base]
+    return xs, ps, Ks, pick, refs, mus, covs
+
+
+@pytest.mark.parametrize("layout", ["soa", "aos"])
+@pytest.mark.parametrize("n", range(10, 17))
+def test_smoother_every_dim_vs_oracle(n, layout):
+    """UKF.rts_smoother (UKF.py:634-739) at every dim_x of the file, a bank that ends inside a wave: EVERY track against the
+    oracle's backward pass of its history at 1e-10; the last step is the filter's own output, its gain zero."""
+    N, T = 150, 8
+    xs, ps, Ks, pick, refs, mus, covs = _smooth(n, N, T, layout, 40 + n)
+    for trk in range(N):
+        rx, rP, rK = refs[pick[trk]]
+        assert rel_err_rows(xs[:, trk], rx) < TOL and rel_err_rows(ps[:, trk], rP) < TOL, trk
+        assert rel_err_rows(Ks[:-1, trk], rK[:-1]) < TOL, trk
+    assert np.array_equal(xs[-1], mus[-1]) and np.array_equal(ps[-1], covs[-1]) and not Ks[-1].any()
+
+
+@pytest.mark.parametrize("layout", ["soa", "aos"])
+@pytest.mark.parametrize("N", [1, 2, 15, 17, 65, 1000])
+def test_smoother_bank_sizes_in_place_and_without_gain(N, layout):
+    """ragged banks; xs / Ps_out aliasing the inputs (a step's reads are consumed before its copy-outs); K == NULL"""
+    n, T = 14, 6
+    a = _smooth(n, N, T, layout, 3 + N)
+    b = _smooth(n, N, T, layout, 3 + N, in_place=True, with_K=False)
+    for trk in sorted({0, N // 2, N - 1}):
+        rx, rP, rK = a[4][a[3][trk]]
+        assert rel_err_rows(a[0][:, trk], rx) < TOL and rel_err_rows(a[1][:, trk], rP) < TOL, (N, trk)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+@pytest.mark.parametrize("layout", ["soa", "aos"])
+def test_python_api_smoother_routes_here(layout):
+    from filterpy_amd.kalman import UnscentedKalmanFilter, MerweScaledSigmaPoints
+    g = golden("ukf_dims")
+    done = 0
+    for ci, c in enumerate(g["cases"]):
+        n, m, alpha, beta, kappa = int(c[0]), int(c[1]), float(c[2]), float(c[3]), float(c[4])
+        if n < 10:
+            continue
+        p, N = f"c{ci}_", 21
+        ukf = UnscentedKalmanFilter(n, m, dt=1.0, hx=g[p + "H"], fx=g[p + "F"], points=MerweScaledSigmaPoints(n, alpha, beta, kappa),
+                                    n_tracks=N, layout=layout)
+        ukf.Q = g[p + "Q"].copy()
+        Xs, Ps = np.tile(g[p + "mu"][:, None], (1, N, 1)), np.tile(g[p + "cov"][:, None], (1, N, 1, 1))
+        xs, ps, Ks = ukf.rts_smoother(Xs, Ps)
+        for trk in (0, 16, N - 1):
+            assert rel_err_rows(xs[:, trk], g[p + "rts_x"]) < TOL and rel_err_rows(ps[:, trk], g[p + "rts_P"]) < TOL, (n, trk)
+            assert rel_err_rows(Ks[:-1, trk], g[p + "rts_K"][:-1]) < TOL, (n, trk)
+        done += 1
+    assert done >= 5
