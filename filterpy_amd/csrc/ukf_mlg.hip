@@ -182,7 +182,6 @@ ukf_mlg_kernel(const UkfArgs a)
 //   * the full rows of Ps[k] are requested a second time for the correction (the factorisation takes the lower part only);
 //   * the smoothed mean of step k+1 is replicated in the quad (dim_x registers).
 // Reads Xs[k], Ps[k] (the latter 1.6 times); writes xs[k], ps[k], Ks[k]: 8 (2 n + 3 n^2) algorithmic bytes per track-step.
-// In-place calls (xs == Xs, Ps_out == Ps) are fine: a step's reads of step k are consumed before its copy-outs are issued.
 template <int NX, int LAYOUT>
 __global__ void __launch_bounds__(BLOCK, 1)
 ukf_mlg_rts_kernel(const UkfRtsArgs a, const double *__restrict__ pF, const double *__restrict__ pQ,

@@ -279,7 +279,8 @@ int fk_ukf_linear_batch_f64(const fk_ukf_desc *desc,
 /* UnscentedKalmanFilter.rts_smoother (filterpy/kalman/UKF.py:634-739) with LINEAR fx(x, dt) = F x, fused per track:
  * the whole backward loop in one launch (per step: sigma points of (xs[k], ps[k]) -> F sigma -> unscented transform
  * + Q -> cross variance around Xs[k] / xb -> K = Pxb inv(Pb) -> xs[k] += K (xs[k+1] - xb), ps[k] += K (ps[k+1] - Pb) K').
- * desc: n (1..9), N, T, layout, scale = lambda + n (m is ignored).
+ * desc: n (1..9; 10..16 on four lanes per track for FK_UKF_FLAG_PAIR_WEIGHTS callers, opt-in with FK_UKF_MLG=1 like
+ *   fk_ukf_linear_batch_f64), N, T, layout, scale = lambda + n (m is ignored).
  *   F [n*n], Q [n*n] (the filter's Q: the reference never reads its Qs argument, UKF.py:717-722), Wm, Wc [2n+1];
  *   Xs [T][N][n], Ps [T][N][n*n]: the filter output; xs, Ps_out likewise: the smoothed output (distinct arrays); K
  *   [T][N][n*n] or NULL (K of the last step is zero, like the reference's); status [N] or NULL.
