@@ -58,7 +58,7 @@ def run(n, m, N, T, layout, dense):
     means, covs = E.alloc_records((T,), N, n, layout), E.alloc_records((T,), N, n * n, layout)
     st = torch.zeros(N, dtype=torch.int32, device=dev)
     dd = [E.dev(M) for M in (F, H, Q, R, Wm, Wc)]
-    sw = {k: os.environ[k] for k in ("FK_UKF_PADDED", "FK_UKF_DMA", "FK_UKF_CHUNKS", "FK_UKF_RTS_CHUNKS", "FK_UKF_PAIRED") if k in os.environ}
+    sw = {k: os.environ[k] for k in ("FK_UKF_PADDED", "FK_UKF_DMA", "FK_UKF_CHUNKS", "FK_UKF_RTS_CHUNKS", "FK_UKF_PAIRED", "FK_UKF_MLG") if k in os.environ}
     paired = E.pair_weights(Wm, Wc, n)      # looked at once, outside the timed calls (Merwe's weights: True)
 
     def fwd():
@@ -84,7 +84,7 @@ def run(n, m, N, T, layout, dense):
     print(json.dumps(dict(kernel=f"fused linear UKF ({n},{m}) {layout}", N=N, T=T, dense_model=dense, ms=ms,
                           track_steps_per_s=N * T / (ms * 1e-3), alg_bytes_per_unit=b, frac_of_8TBs=gbs / PEAK,
                           parity_max_rel=par, switches=sw)), flush=True)
-    if not E.ukf_linear_rts_supported(n):
+    if not E.ukf_linear_rts_supported(n, paired):
         return
     xs, Ps = E.alloc_records((T,), N, n, layout), E.alloc_records((T,), N, n * n, layout)
     Ks = E.alloc_records((T,), N, n * n, layout)

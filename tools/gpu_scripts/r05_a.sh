@@ -1,0 +1,23 @@
+#!/bin/bash
+# Round 5, first lease: the four-lane UKF filter and smoother (csrc/ukf_mlg.hip, dims 10..16) have been checked on the host only
+# (tests/test_hostcheck_ukf_quad.py).  Their GPU parity tests, then -- if green -- the whole UKF suite with the kernels switched
+# on, then their first timings next to the split path's.
+ulimit -c 0
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/r05a
+mkdir -p $O
+cd $R
+export FK_UKF_MLG=1
+timeout 600 python -m pytest tests/test_gpu_ukf_mlg.py -m gpu -q -x -p no:cacheprovider > $O/ukf_mlg_tests.log 2>&1
+tail -15 $O/ukf_mlg_tests.log | cut -c1-220
+if grep -q " passed" $O/ukf_mlg_tests.log && ! grep -q "failed" $O/ukf_mlg_tests.log; then
+    timeout 600 python -m pytest tests -m gpu -q -k "ukf or UKF" -p no:cacheprovider 2>&1 | tail -4 | cut -c1-220
+    cd /tmp
+    for d in 10x2 12x3 14x4 16x4; do
+        timeout 200 python $R/tools/bench_ukf.py --dims $d --N 50000 --T 50 --dense 2>$O/bench_$d.err | tee -a $O/ukf_mlg_bench.jsonl | python -c "
+import sys,json
+for l in sys.stdin:
+    d=json.loads(l); print(d['kernel'][:48], 'ms=%.3f'%d['ms'], 'frac=%.3f'%d.get('frac_of_8TBs',0), d.get('parity_max_rel'))
+"
+    done
+fi
