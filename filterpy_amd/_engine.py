@@ -184,7 +184,7 @@ def ukf_correct(n, m, N, layout, Pxz, zp, S, z, x, P, K=None, status=None):
 def ukf_linear_supported(n, m, paired=False):
     """sizes fk_ukf_linear_batch_f64 is compiled for (csrc/ukf_kernels.hip; dim_x 10..16: csrc/ukf_mlg.hip -- four lanes per
     track, for weights equal within every +- pair, and behind FK_UKF_MLG=1 until it has been through a GPU parity run)"""
-    if 10 <= n <= 16 and 1 <= m <= 4:
+    if 10 <= n <= 16 and 1 <= m <= 8:
         return bool(paired) and os.environ.get("FK_UKF_MLG", "0")[:1] == "1"
     return (1 <= n <= 6 and 1 <= m <= 3) or (7 <= n <= 9 and 1 <= m <= 4)
 

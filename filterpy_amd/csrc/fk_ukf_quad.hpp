@@ -10,8 +10,8 @@
 //   * the factor of scale * P column by column: the pivot and row j of the factor (final once column j-1 is done) are BROADCAST
 //     from their owner, each lane eliminates its own rows -- and the same broadcast row is all the images need:
 //         predict   F L (own rows) and F x (own rows) accumulate a row of L at a time:  FL[a][k] += F[a][j] L[j][k]
-//         update    H L likewise, row c on lane c (dim_z <= 4), its columns gathered for S; the cross variance takes the
-//                   lane's OWN rows of L
+//         update    H L likewise, its rows dealt out like P's (dim_z <= 8), its columns gathered for S; the cross variance
+//                   takes the lane's OWN rows of L
 //   * P- = (sum Wc) y0 y0' + sum_k wp_k f_k f_k' + Q: column k of F L is gathered (pre-multiplied by its pair weight by the
 //     owners), each lane accumulates its own rows;
 //   * S, its L D L' and z - zp are replicated; the gain's rows are solved by their owners and gathered one at a time for
@@ -82,7 +82,7 @@ FK_HD int ukf_quad_step_v4(double (&x)[NX], double (&P)[(NX + 3) / 4][NX], const
                            const double (&zin)[NZ], bool has_z, double scale, const UkfQuadModel &mv, Quad &quad)
 {
     constexpr int R = (NX + 3) / 4;
-    static_assert(NX >= 4 && NZ >= 1 && NZ <= 4, "dim_x >= 4 (every lane of the quad holds a row), dim_z <= 4 (a row of H L per lane)");
+    static_assert(NX >= 4 && NZ >= 1 && NZ <= 8, "dim_x >= 4 (every lane of the quad holds a row), dim_z <= 8 (two rows of H L per lane)");
     int st = 0;
     // ---------------- predict (UKF.py:400-411)
     {
@@ -147,17 +147,28 @@ FK_HD int ukf_quad_step_v4(double (&x)[NX], double (&P)[(NX + 3) / 4][NX], const
     }
     // ---------------- update (UKF.py:462-481), sigma points regenerated from the prior (:407)
     {
-        // H L, one row per lane: lane q accumulates row min(q, dim_z - 1) (dim_z <= 4; a lane past the last row duplicates it)
-        double Lw[R][NX], HLo[NX];
-        const unsigned hrow = g[0] < (unsigned)NZ ? g[0] : (unsigned)NZ - 1u;      // g[0] = q (NX >= 4) or its clamp
+        // H L, its rows dealt out like P's: lane q accumulates rows q and q + 4 (dim_z <= 8; a slot past the last row duplicates it)
+        constexpr int RZ = (NZ + 3) / 4;
+        double Lw[R][NX], HLo[RZ][NX];
+        unsigned hrow[RZ];
+        FK_UNROLL for (int rz = 0; rz < RZ; ++rz) {
+            const unsigned hr = g[0] + 4u * (unsigned)rz;                            // g[0] = q (NX >= 4)
+            hrow[rz] = hr < (unsigned)NZ ? hr : (unsigned)NZ - 1u;
+        }
         {
-            double hc = mv.H[hrow * NX];
+            double hc[RZ];
+            FK_UNROLL for (int rz = 0; rz < RZ; ++rz) hc[rz] = mv.H[hrow[rz] * NX];
             const bool pd = quad_chol_rows<NX>(P, g, scale, Lw, quad, [&](int j, const double (&lrow)[NX], double ljj, double) {
-                const double h = hc;
-                if (j + 1 < NX) hc = mv.H[hrow * NX + j + 1];
-                FK_UNROLL for (int k = 0; k < NX; ++k)
-                    if (k < j) HLo[k] = fma(h, lrow[k], HLo[k]);
-                HLo[j] = h * ljj;
+                double h[RZ];
+                FK_UNROLL for (int rz = 0; rz < RZ; ++rz) h[rz] = hc[rz];
+                if (j + 1 < NX) {
+                    FK_UNROLL for (int rz = 0; rz < RZ; ++rz) hc[rz] = mv.H[hrow[rz] * NX + j + 1];
+                }
+                FK_UNROLL for (int rz = 0; rz < RZ; ++rz) {
+                    FK_UNROLL for (int k = 0; k < NX; ++k)
+                        if (k < j) HLo[rz][k] = fma(h[rz], lrow[k], HLo[rz][k]);
+                    HLo[rz][j] = h[rz] * ljj;
+                }
             });
             if (!pd && has_z) st |= ST_NOT_PD;
         }
@@ -181,7 +192,7 @@ FK_HD int ukf_quad_step_v4(double (&x)[NX], double (&P)[(NX + 3) / 4][NX], const
         FK_UNROLL for (int k = 0; k < NX; ++k) {
             const double wp = mv.Wp[2 + k];
             double hl[NZ], wh[NZ];                             // column k of H L, gathered from the lanes that hold its rows
-            FK_UNROLL for (int c = 0; c < NZ; ++c) hl[c] = quad_from(quad, HLo[k], c);
+            FK_UNROLL for (int c = 0; c < NZ; ++c) hl[c] = quad_from(quad, HLo[c / 4][k], c % 4);
             FK_UNROLL for (int c = 0; c < NZ; ++c) wh[c] = wp * hl[c];
             FK_UNROLL for (int r = 0; r < NZ; ++r)
                 FK_UNROLL for (int c = 0; c < NZ; ++c)

@@ -718,15 +718,15 @@ int fk_ukf_linear_batch_f64(const fk_ukf_desc *d, const double *F, const double 
                             int32_t *status, void *stream)
 {
     if (!d) return fail(FK_ERR_BAD_ARG, "desc is NULL");
-    // dim_x 10..16 (dim_z 1..4): four lanes per track (ukf_mlg.hip), the pair-regrouped sums only -- and only with FK_UKF_MLG=1
+    // dim_x 10..16 (dim_z 1..8): four lanes per track (ukf_mlg.hip), the pair-regrouped sums only -- and only with FK_UKF_MLG=1
     // until the kernel has been through a GPU parity run (round 4 ended without one; tests/test_gpu_ukf_mlg.py)
-    const bool quad = d->n >= 10 && d->n <= 16 && d->m >= 1 && d->m <= 4;
+    const bool quad = d->n >= 10 && d->n <= 16 && d->m >= 1 && d->m <= 8;
     if (quad) {
         static const bool on = getenv("FK_UKF_MLG") && getenv("FK_UKF_MLG")[0] == '1';
         if (!on || !(d->flags & FK_UKF_FLAG_PAIR_WEIGHTS))
             return fail(FK_ERR_UNSUPPORTED, "fused linear UKF at dim_x 10..16: FK_UKF_MLG=1 and weights equal within every +- pair (FK_UKF_FLAG_PAIR_WEIGHTS)");
     } else if (d->n < 1 || d->n > 9 || d->m < 1 || d->m > 4 || (d->n <= 6 && d->m > 3))
-        return fail(FK_ERR_UNSUPPORTED, "fused linear UKF: dim_x 1..6 with dim_z 1..3, dim_x 7..9 with dim_z 1..4, dim_x 10..16 with dim_z 1..4");
+        return fail(FK_ERR_UNSUPPORTED, "fused linear UKF: dim_x 1..6 with dim_z 1..3, dim_x 7..9 with dim_z 1..4, dim_x 10..16 with dim_z 1..8");
     if (d->N < 0 || d->T < 0 || !F || !H || !Q || !R || !Wm || !Wc || !z || !x || !P)
         return fail(FK_ERR_BAD_ARG, "fused linear UKF: bad argument");
     if ((double)d->N * d->n * d->n * 8.0 >= 4294967296.0 - 32.0) return fail(FK_ERR_UNSUPPORTED, "fused linear UKF: record block >= 4 GiB, split the batch");

@@ -1,5 +1,5 @@
 // ukf_mlg.hip -- the fused linear-model UKF (UnscentedKalmanFilter.batch_filter, filterpy/kalman/UKF.py:524-632, with
-// fx(x, dt) = F x and hx(x) = H x) for dim_x = 10..16, dim_z = 1..4 with FOUR LANES PER TRACK (gfx950).
+// fx(x, dt) = F x and hx(x) = H x) for dim_x = 10..16, dim_z = 1..8 with FOUR LANES PER TRACK (gfx950).
 //
 // One lane per track ends at dim_x = 9 (ukf_kernels.hip); above it the step ran as five launches per epoch on resident blocks.
 // Here a quad of lanes owns a track for the whole time loop, like kf_mlg.hip, but with the rows of P dealt out CYCLICALLY (lane q
@@ -10,7 +10,7 @@
 //
 // Pair-regrouped sums only (the caller's FK_UKF_FLAG_PAIR_WEIGHTS, verified in the prologue: FK_STATUS_BAD_WEIGHTS
 // otherwise); exact dims; optional mask (branch-free: fk_ukf_quad.hpp); both layouts, the per-step outputs through the wave's
-// LDS tile as 16-byte units (fk_ml.hpp).  One wave per SIMD.  One object per dim_x (-DFK_NX), dim_z = 1..4 inside.
+// LDS tile as 16-byte units (fk_ml.hpp).  One wave per SIMD.  One object per dim_x (-DFK_NX), dim_z = 1..8 inside.
 #include <stdlib.h>
 #include <type_traits>
 
@@ -325,14 +325,14 @@ ukf_mlg_rts_kernel(const UkfRtsArgs a, const double *__restrict__ pF, const doub
 int FK_UMLG_CAT(launch_ukf_mlg_, FK_NX)(const UkfArgs &a, int layout, hipStream_t s)
 {
     using namespace FK_UMLG_CAT(ukf_mlg_, FK_NX);
-    if (a.n != FK_NX || a.m < 1 || a.m > 4) return 1;
+    if (a.n != FK_NX || a.m < 1 || a.m > 8) return 1;
     const dim3 grid((unsigned)((a.cnt + BLOCK / 4 - 1) / (BLOCK / 4))), block(BLOCK);
 #define GO(NZV)                                                                                                         \
     if (a.m == NZV) {                                                                                                   \
         if (layout == FK_LAYOUT_AOS) hipLaunchKernelGGL((ukf_mlg_kernel<FK_NX, NZV, LAYOUT_AOS>), grid, block, 0, s, a); \
         else hipLaunchKernelGGL((ukf_mlg_kernel<FK_NX, NZV, LAYOUT_SOA>), grid, block, 0, s, a);                         \
     }
-    GO(1) GO(2) GO(3) GO(4)
+    GO(1) GO(2) GO(3) GO(4) GO(5) GO(6) GO(7) GO(8)
 #undef GO
     return check_launch("ukf_mlg_kernel");
 }

@@ -267,7 +267,7 @@ typedef struct fk_ukf_desc {
  *   z [T][N][m], mask [T][N] or NULL; x [N][n], P [N][n*n] in/out;
  *   means [T][N][n], covs [T][N][n*n] posterior per step (NULL = not stored).
  * Sizes: dim_x 1..6 with dim_z 1..3, dim_x 7..9 with dim_z 1..4 (one track per lane, ukf_kernels.hip); dim_x 10..16 with
- * dim_z 1..4 on four lanes per track (ukf_mlg.hip) for FK_UKF_FLAG_PAIR_WEIGHTS callers -- while that kernel has had no GPU
+ * dim_z 1..8 on four lanes per track (ukf_mlg.hip) for FK_UKF_FLAG_PAIR_WEIGHTS callers -- while that kernel has had no GPU
  * parity run only with FK_UKF_MLG=1 in the environment; FK_ERR_UNSUPPORTED otherwise (the building blocks serve every size). */
 int fk_ukf_linear_batch_f64(const fk_ukf_desc *desc,
                             const double *F, const double *H, const double *Q, const double *R,

@@ -1,5 +1,5 @@
 """-m gpu, and only with FK_UKF_MLG=1 in the environment: the fused linear UKF on four lanes per track (csrc/ukf_mlg.hip, dim_x
-10..16, dim_z 1..4) through the C ABI against the oracle's per-filter loop (UKF.py:364-491, 524-632) and the live-reference
+10..16, dim_z 1..8) through the C ABI against the oracle's per-filter loop (UKF.py:364-491, 524-632) and the live-reference
 goldens.  The kernel's arithmetic (csrc/fk_ukf_quad.hpp) is held against the oracle on the host by
 tests/test_hostcheck_ukf_quad.py; round 4 ended before the kernel itself had a GPU run, so the library keeps these sizes on the
 split path unless FK_UKF_MLG=1 -- run this file (and the rest of the UKF suite) with it first thing in the next round."""
@@ -54,7 +54,7 @@ def _bank(n, m, N, T, layout, seed, mask_every=0, alpha=.5):
 
 
 @pytest.mark.parametrize("layout", ["soa", "aos"])
-@pytest.mark.parametrize("n,m", [(n, m) for n in range(10, 17) for m in (1, 2, 3, 4)])
+@pytest.mark.parametrize("n,m", [(n, m) for n in range(10, 17) for m in range(1, 9)])
 def test_every_instantiation_vs_oracle(n, m, layout):
     """every (dim_x, dim_z) the file instantiates, both layouts: a bank that ends inside a wave (a quad-duplicated tail), a few
     missing measurements; each checked track against the oracle's loop at 1e-10."""
@@ -140,7 +140,7 @@ def test_python_api_routes_matrix_models_here(layout):
     done = 0
     for ci, c in enumerate(g["cases"]):
         n, m, alpha, beta, kappa = int(c[0]), int(c[1]), float(c[2]), float(c[3]), float(c[4])
-        if n < 10 or m > 4:
+        if n < 10:
             continue
         p, N = f"c{ci}_", 37
         ukf = UnscentedKalmanFilter(n, m, dt=1.0, hx=g[p + "H"], fx=g[p + "F"], points=MerweScaledSigmaPoints(n, alpha, beta, kappa),
@@ -154,7 +154,7 @@ def test_python_api_routes_matrix_models_here(layout):
             assert rel_err_rows(mu[:, trk], g[p + "mu"]) < tol and rel_err_rows(cov[:, trk], g[p + "cov"]) < tol, (n, m, trk)
         assert np.array_equal(ukf.x, mu[-1]) and np.array_equal(ukf.P, cov[-1])
         done += 1
-    assert done >= 1
+    assert done >= 7
 
 
 # ------------------------------------------------------------------------------------------------ the smoother

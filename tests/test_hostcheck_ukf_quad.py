@@ -53,7 +53,7 @@ def _model(n, m, seed):
 
 rel = lambda a, b: np.max(np.abs(a - b)) / np.max(np.abs(b))  # noqa: E731
 
-DIMS = [(4, 2), (5, 2), (7, 3), (8, 4), (9, 3)] + [(n, m) for n in range(10, 17) for m in (1, 2, 3, 4)]
+DIMS = [(4, 2), (5, 2), (7, 3), (8, 4), (9, 3)] + [(n, m) for n in range(10, 17) for m in range(1, 9)]
 
 
 @pytest.mark.parametrize("n,m", DIMS)
@@ -95,7 +95,7 @@ def test_quad_step_agrees_with_the_one_lane_step_it_distributes(quad_lib, n, m):
     assert rel(a[0], b[0]) < 1e-13 and rel(a[1], b[1]) < 1e-13
 
 
-@pytest.mark.parametrize("n,m", [(10, 2), (13, 3), (16, 4)])
+@pytest.mark.parametrize("n,m", [(10, 2), (13, 3), (16, 4), (12, 5), (15, 8)])
 def test_quad_step_missing_measurements_skip_the_update(quad_lib, n, m):
     """update(None) (UKF.py:462-466): the step runs its update half on z = 0 with the gain selected to zero -- x and P must come
     out as the prior, bit for bit what the next predict sees in the reference's flow."""
