@@ -206,20 +206,26 @@ FK_HD int ukf_quad_step_v4(double (&x)[NX], double (&P)[(NX + 3) / 4][NX], const
             }
             if (k % 4 == 3) FK_STAGE();
         }
+        // S stays an UPPER triangle (its mirror image is the same bits: the reference's w * outer(d, d) is symmetric bit for
+        // bit, and so is R as far as anybody reads it); the factorisation reads a lower one: its transpose.  At dim_z 8 the
+        // full S next to a full copy for the factor was 56 doubles more at the point where P-, K and x are live.
         FK_UNROLL for (int r = 0; r < NZ; ++r)
             FK_UNROLL for (int c = 0; c < NZ; ++c)
-                if (c < r) S[r * NZ + c] = S[c * NZ + r];
-        FK_UNROLL for (int e = 0; e < NZ * NZ; ++e) S[e] += Rm[e];              // + R last
+                if (c >= r) S[r * NZ + c] += Rm[r * NZ + c];                    // + R last
         // K = Pxz S^-1 (own rows)
         {
             double Lf[NZ * NZ], dd[NZ], dinv[NZ];
-            FK_UNROLL for (int e = 0; e < NZ * NZ; ++e) Lf[e] = S[e];
+            FK_UNROLL for (int r = 0; r < NZ; ++r)
+                FK_UNROLL for (int c = 0; c < NZ; ++c)
+                    if (c <= r) Lf[r * NZ + c] = S[c * NZ + r];
             if (!ldlt2_rs<NZ>(Lf, dd, dinv) && has_z) st |= ST_NOT_PD;
             solve_rows_ldlt<R, NZ>(Lf, dinv, Ko);
         }
         double zc[NZ];
         FK_UNROLL for (int e = 0; e < R * NZ; ++e) Ko[e] = has_z ? Ko[e] : 0.0;
-        FK_UNROLL for (int e = 0; e < NZ * NZ; ++e) S[e] = has_z ? S[e] : 0.0;
+        FK_UNROLL for (int r = 0; r < NZ; ++r)
+            FK_UNROLL for (int c = 0; c < NZ; ++c)
+                if (c >= r) S[r * NZ + c] = has_z ? S[r * NZ + c] : 0.0;
         FK_UNROLL for (int c = 0; c < NZ; ++c) zc[c] = has_z ? zin[c] - zp[c] : 0.0;
         FK_STAGE();
         // x += K (z - zp) ; P -= K (S K') : row b of K from its owner serves x[b] and column b of P
@@ -232,8 +238,8 @@ FK_HD int ukf_quad_step_v4(double (&x)[NX], double (&P)[(NX + 3) / 4][NX], const
                 x[b] += acc;
             }
             FK_UNROLL for (int qq = 0; qq < NZ; ++qq) {
-                double acc = S[qq * NZ] * Kb[0];
-                FK_UNROLL for (int w = 1; w < NZ; ++w) acc = fma(S[qq * NZ + w], Kb[w], acc);
+                double acc = S[0 * NZ + qq] * Kb[0];                             // S[qq][0] = S[0][qq]
+                FK_UNROLL for (int w = 1; w < NZ; ++w) acc = fma(w >= qq ? S[qq * NZ + w] : S[w * NZ + qq], Kb[w], acc);
                 sk[qq] = acc;
             }
             FK_UNROLL for (int r = 0; r < R; ++r) {

@@ -327,8 +327,12 @@ int FK_UMLG_CAT(launch_ukf_mlg_, FK_NX)(const UkfArgs &a, int layout, hipStream_
     using namespace FK_UMLG_CAT(ukf_mlg_, FK_NX);
     if (a.n != FK_NX || a.m < 1 || a.m > 8) return 1;
     const dim3 grid((unsigned)((a.cnt + BLOCK / 4 - 1) / (BLOCK / 4))), block(BLOCK);
+// (FK_UMLG_ONLY_NZ=<dim_z>: a one-off build with that filter instantiation alone, for looking at its code)
+#ifndef FK_UMLG_ONLY_NZ
+#define FK_UMLG_ONLY_NZ 0
+#endif
 #define GO(NZV)                                                                                                         \
-    if (a.m == NZV) {                                                                                                   \
+    if constexpr (FK_UMLG_ONLY_NZ == 0 || FK_UMLG_ONLY_NZ == NZV) if (a.m == NZV) {                                                                                                   \
         if (layout == FK_LAYOUT_AOS) hipLaunchKernelGGL((ukf_mlg_kernel<FK_NX, NZV, LAYOUT_AOS>), grid, block, 0, s, a); \
         else hipLaunchKernelGGL((ukf_mlg_kernel<FK_NX, NZV, LAYOUT_SOA>), grid, block, 0, s, a);                         \
     }
