@@ -77,9 +77,11 @@ FK_HD bool quad_chol_rows(const double (&P)[(NX + 3) / 4][NX], const unsigned (&
     return pd;
 }
 
-template <int NX, int NZ, class Quad>
+// zin / has_z_fn(): the step's measurement and whether there is one -- both are first looked at in the UPDATE half (has_z_fn is
+// called there), so a kernel that carries them as loads in flight waits for them a predict half after it asked.
+template <int NX, int NZ, class Quad, class HasZ>
 FK_HD int ukf_quad_step_v4(double (&x)[NX], double (&P)[(NX + 3) / 4][NX], const unsigned (&g)[(NX + 3) / 4],
-                           const double (&zin)[NZ], bool has_z, double scale, const UkfQuadModel &mv, Quad &quad)
+                           const double (&zin)[NZ], HasZ &&has_z_fn, double scale, const UkfQuadModel &mv, Quad &quad)
 {
     constexpr int R = (NX + 3) / 4;
     static_assert(NX >= 4 && NZ >= 1 && NZ <= 8, "dim_x >= 4 (every lane of the quad holds a row), dim_z <= 8 (two rows of H L per lane)");
@@ -151,6 +153,7 @@ FK_HD int ukf_quad_step_v4(double (&x)[NX], double (&P)[(NX + 3) / 4][NX], const
         constexpr int RZ = (NZ + 3) / 4;
         double Lw[R][NX], HLo[RZ][NX];
         unsigned hrow[RZ];
+        bool upd_pd;
         FK_UNROLL for (int rz = 0; rz < RZ; ++rz) {
             const unsigned hr = g[0] + 4u * (unsigned)rz;                            // g[0] = q (NX >= 4)
             hrow[rz] = hr < (unsigned)NZ ? hr : (unsigned)NZ - 1u;
@@ -170,8 +173,10 @@ FK_HD int ukf_quad_step_v4(double (&x)[NX], double (&P)[(NX + 3) / 4][NX], const
                     HLo[rz][j] = h[rz] * ljj;
                 }
             });
-            if (!pd && has_z) st |= ST_NOT_PD;
+            upd_pd = pd;
         }
+        const bool has_z = has_z_fn();
+        if (!upd_pd && has_z) st |= ST_NOT_PD;
         double zp[NZ], S[NZ * NZ], Ko[R * NZ], Rm[NZ * NZ];
         FK_UNROLL for (int e = 0; e < NZ * NZ; ++e) Rm[e] = mv.R[e];
         const double wms = mv.Wp[0], wcs = mv.Wp[1];

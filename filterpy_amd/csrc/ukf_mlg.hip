@@ -95,7 +95,11 @@ ukf_mlg_kernel(const UkfArgs a)
             FK_UNROLL for (int c = 0; c < NX; ++c) asm volatile("" ::"v"(P[r][c]));       // landed before the loop
         FK_UNROLL for (int k = 0; k < NX; ++k) asm volatile("" ::"v"(x[k]));
     }
-    // z[t+1] and its mask byte are requested at the top of step t and consumed at the top of step t+1 (clamped index, no branch)
+    // z[t+1] and its mask byte are requested at the top of step t and consumed at the top of step t+1 (clamped index, no branch).
+    // (The wait for them sits at the end of the loop, behind the step's stores -- vmcnt retires in order, so it is also a wait
+    //  for all but the last few of those.  Requesting them in front of the stores and reading them in the update half, as
+    //  ukf_kernels.hip does, measured +116 registers here at (12,3) and tipped (14,4) / (16,4) into scratch, whose reloads are
+    //  vmcnt(0) waits of their own; LDS-DMA, which holds no register, is the open item -- 18 KB of images fit at dim_x 16.)
     double zn[NZ];
     unsigned hn;
     {
@@ -120,7 +124,7 @@ ukf_mlg_kernel(const UkfArgs a)
             const unsigned hb = mask_or_dummy[tn * N + trk];
             hn = a.mask ? hb : 1u;
         }
-        st |= ukf_quad_step_v4<NX, NZ>(x, P, row, z, has_z, a.scale, mv, quad);
+        st |= ukf_quad_step_v4<NX, NZ>(x, P, row, z, [&] { return has_z; }, a.scale, mv, quad);
         FK_STAGE();
         // the step's outputs through the wave's tile, 16-byte units (an output that was not asked for: a descriptor of zero
         // tracks -- issued and dropped, no branch in the loop)

@@ -88,7 +88,7 @@ void quad_lane(void *vp, int lane)
         const bool has_z = job.mask ? job.mask[t] != 0 : true;
         double z[NZ];
         for (int c = 0; c < NZ; ++c) z[c] = has_z ? job.zs[t * NZ + c] : 0.0;
-        st |= fk::ukf_quad_step_v4<NX, NZ>(x, P, g, z, has_z, job.scale, mv, quad);
+        st |= fk::ukf_quad_step_v4<NX, NZ>(x, P, g, z, [&] { return has_z; }, job.scale, mv, quad);
         // every lane writes what it holds: x (replicated) must agree, rows of P go where their slot says
         for (int i = 0; i < NX; ++i) {
             if (lane == 0) job.means[t * NX + i] = x[i];
