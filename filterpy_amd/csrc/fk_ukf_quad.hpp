@@ -276,10 +276,16 @@ FK_HD int ukf_quad_step_v4(double (&x)[NX], double (&P)[(NX + 3) / 4][NX], const
 // Likewise the two means: the sweep spends x[j] at column j, so the correction asks for Xs[k] again (own_x) and for xs[k+1]
 // (next_x) instead of carrying 2 n doubles through the passes.
 // x: Xs[k] in, xs[k] out (replicated);  P: rows of Ps[k] in (lower part), of ps[k] out;  K: the lane's rows of the gain out.
-template <int NX, class Quad, class NextX, class NextRow, class OwnX, class OwnRow>
+// io: where the step's neighbours and its parked intermediates live --
+//   io.next_x(out), io.next_row(r, out)   xs[k+1] (replicated) and the lane's row of slot r of ps[k+1]
+//   io.own_x(out),  io.own_row(r, out)    Xs[k] and the lane's full row of slot r of Ps[k], again
+//   Io::PARK (dim_x >= 13 in the kernel): a covariance-sized parking lot per track.  Pxb waits there through the Pb pass
+//   (park_k / unpark_k), then Pb's full rows until the correction reads them back a slot at a time (park_pb / pb_row): without
+//   it the second pass holds F L, Pb and Pxb -- 192 doubles -- and the step spills 2.4 KB per lane at dim_x 16, every reload a
+//   vmcnt(0).  (The kernel's lot is its output tile, so with PARK the smoothed covariance of step k+1 comes from memory.)
+template <int NX, class Quad, class Io>
 FK_HD int ukf_quad_rts_step_v4(double (&x)[NX], double (&P)[(NX + 3) / 4][NX], const unsigned (&g)[(NX + 3) / 4],
-                               double scale, const UkfQuadModel &mv, Quad &quad, double (&K)[(NX + 3) / 4][NX],
-                               NextX &&next_x, NextRow &&next_row, OwnX &&own_x, OwnRow &&own_row)
+                               double scale, const UkfQuadModel &mv, Quad &quad, double (&K)[(NX + 3) / 4][NX], Io &io)
 {
     constexpr int R = (NX + 3) / 4;
     static_assert(NX >= 4, "dim_x >= 4 (every lane of the quad holds a row)");
@@ -320,6 +326,7 @@ FK_HD int ukf_quad_rts_step_v4(double (&x)[NX], double (&P)[(NX + 3) / 4][NX], c
                 FK_STAGE();
             }
         }
+        if constexpr (Io::PARK) io.park_k(K);
         // xb (replicated), the centre point's offset, Pb
         const double wms = mv.Wp[0], wcs = mv.Wp[1];
         {
@@ -357,6 +364,10 @@ FK_HD int ukf_quad_rts_step_v4(double (&x)[NX], double (&P)[(NX + 3) / 4][NX], c
             }
         }
     }
+    if constexpr (Io::PARK) {
+        io.unpark_k(K);
+        io.park_pb(Pb);
+    }
     // ---------------- K = Pxb Pb^-1
     {
         double Lb[R][NX], invd[NX];
@@ -388,26 +399,30 @@ FK_HD int ukf_quad_rts_step_v4(double (&x)[NX], double (&P)[(NX + 3) / 4][NX], c
     // ---------------- correct: x += K (xn - xb)
     {
         double dx[NX], xo[R];
-        next_x(dx);
+        io.next_x(dx);
         FK_UNROLL for (int c = 0; c < NX; ++c) dx[c] -= xb[c];
         FK_UNROLL for (int r = 0; r < R; ++r) {
             double acc = K[r][0] * dx[0];
             FK_UNROLL for (int c = 1; c < NX; ++c) acc = fma(K[r][c], dx[c], acc);
             xo[r] = acc;
         }
-        own_x(x);
+        io.own_x(x);
         FK_UNROLL for (int b = 0; b < NX; ++b) x[b] += quad_from(quad, xo[b / 4], b % 4);
     }
     FK_STAGE();
     // T1 = K D, D = Pn - Pb: the rows of D a slot at a time from their owners
     double T1[R][NX];
     {
-        double Pn[2][NX];
-        next_row(0, Pn[0]);
+        double Pn[2][NX], Pq[Io::PARK ? 2 : 1][NX];
+        io.next_row(0, Pn[0]);
+        if constexpr (Io::PARK) io.pb_row(0, Pq[0]);
         FK_UNROLL for (int s = 0; s < R; ++s) {
-            if (s + 1 < R) next_row(s + 1, Pn[(s + 1) & 1]);
+            if (s + 1 < R) {
+                io.next_row(s + 1, Pn[(s + 1) & 1]);
+                if constexpr (Io::PARK) io.pb_row(s + 1, Pq[(s + 1) & 1]);
+            }
             double Ds[NX];
-            FK_UNROLL for (int c = 0; c < NX; ++c) Ds[c] = Pn[s & 1][c] - Pb[s][c];
+            FK_UNROLL for (int c = 0; c < NX; ++c) Ds[c] = Pn[s & 1][c] - (Io::PARK ? Pq[Io::PARK ? (s & 1) : 0][c] : Pb[s][c]);
             FK_UNROLL for (int q = 0; q < 4; ++q) {
                 const int b = 4 * s + q;
                 if (b >= NX) continue;
@@ -420,7 +435,7 @@ FK_HD int ukf_quad_rts_step_v4(double (&x)[NX], double (&P)[(NX + 3) / 4][NX], c
         }
     }
     // P += T1 K': row j of K from its owner
-    FK_UNROLL for (int r = 0; r < R; ++r) own_row(r, P[r]);
+    FK_UNROLL for (int r = 0; r < R; ++r) io.own_row(r, P[r]);
     FK_UNROLL for (int j = 0; j < NX; ++j) {
         double Kj[NX];
         FK_UNROLL for (int c = 0; c < NX; ++c) Kj[c] = quad_from(quad, K[j / 4][c], j % 4);

@@ -179,10 +179,76 @@ ukf_mlg_kernel(const UkfArgs a)
     }
 }
 
+// FK_UMLG_RTS_PARK (build time): 1 = the smoother parks Pxb / Pb in its output tile where the step would spill otherwise (dim_x >= 13),
+// 0 = nowhere, 2 = at every dim_x (A/B)
+#ifndef FK_UMLG_RTS_PARK
+#define FK_UMLG_RTS_PARK 1
+#endif
+
+// what ukf_quad_rts_step_v4 asks its caller for (fk_ukf_quad.hpp): the neighbours of the step and, with PARK, a parking lot
+template <int NX, int LAYOUT, bool PARKV>
+struct RtsIo {
+    static constexpr bool PARK = PARKV;
+    static constexpr int R = (NX + 3) / 4, EP = NX * NX;
+    static constexpr bool AOS = LAYOUT == LAYOUT_AOS;
+    const double *Ps_t, *ps_next;            // Ps[t] and ps[t+1]: element 0 of the step's block
+    unsigned estride;
+    const unsigned (&row)[R];
+    const unsigned (&off_row)[R];
+    double *tile, *xt, *xpark;
+    unsigned g16;
+    __device__ __forceinline__ double &tile_at(unsigned e) const { return tile[AOS ? g16 * (unsigned)EP + e : e * 16u + g16]; }
+    __device__ __forceinline__ double &lot_at(unsigned e) const { return tile[e * 16u + g16]; }      // the lot: [element][track], whatever the layout
+    __device__ __forceinline__ void next_x(double (&out)[NX]) const       // xs[k+1]: still staged in xt
+    {
+        FK_UNROLL for (int c = 0; c < NX; ++c) out[c] = xt[AOS ? g16 * (unsigned)NX + (unsigned)c : (unsigned)c * 16u + g16];
+    }
+    __device__ __forceinline__ void next_row(int r, double (&out)[NX]) const
+    {
+        if constexpr (PARK) {
+            // from memory: this wave's own copy-out of the step before (other lanes' stores: complete once vmcnt reaches 0;
+            // the loads at agent scope, past the vector L1)
+            if (r == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const MlView vP(ps_next, off_row[r], estride);
+            FK_UNROLL for (int c = 0; c < NX; ++c) out[c] = vP.template load<16>(c);
+        } else {
+            FK_UNROLL for (int c = 0; c < NX; ++c) out[c] = tile_at(row[r] * (unsigned)NX + (unsigned)c);
+        }
+    }
+    __device__ __forceinline__ void own_x(double (&out)[NX]) const
+    {
+        FK_UNROLL for (int c = 0; c < NX; ++c) out[c] = xpark[c * 16];
+    }
+    __device__ __forceinline__ void own_row(int r, double (&out)[NX]) const
+    {
+        const MlView vP(Ps_t, off_row[r], estride);
+        FK_UNROLL for (int c = 0; c < NX; ++c) out[c] = vP.load(c);
+    }
+    // the lot: every lane reads back exactly the addresses it wrote (a duplicated slot: its original's, with the same values)
+    __device__ __forceinline__ void park_k(const double (&K)[R][NX]) const
+    {
+        FK_UNROLL for (int r = 0; r < R; ++r)
+            FK_UNROLL for (int c = 0; c < NX; ++c) lot_at(row[r] * (unsigned)NX + (unsigned)c) = K[r][c];
+    }
+    __device__ __forceinline__ void unpark_k(double (&K)[R][NX]) const
+    {
+        FK_UNROLL for (int r = 0; r < R; ++r)
+            FK_UNROLL for (int c = 0; c < NX; ++c) K[r][c] = lot_at(row[r] * (unsigned)NX + (unsigned)c);
+    }
+    __device__ __forceinline__ void park_pb(const double (&Pb)[R][NX]) const { park_k(Pb); }
+    __device__ __forceinline__ void pb_row(int r, double (&out)[NX]) const
+    {
+        FK_UNROLL for (int c = 0; c < NX; ++c) out[c] = lot_at(row[r] * (unsigned)NX + (unsigned)c);
+    }
+};
+
 // The smoother (UnscentedKalmanFilter.rts_smoother, UKF.py:634-739, with fx(x, dt) = F x) on the same four lanes per track:
 // ukf_quad_rts_step_v4 per backward step.  What a step needs of its neighbours stays out of the registers:
 //   * the smoothed covariance of step k+1 is still in the wave's output tile, where step k+1 staged it for its copy-out (the
-//     LAST copy-out of a step, so that nothing overwrites it): the lanes read their rows back from there;
+//     LAST copy-out of a step, so that nothing overwrites it): the lanes read their rows back from there -- up to dim_x 12.
+//     From 13 on (R = 4 row slots) the step would spill 1.5-2.7 KB per lane, every reload a vmcnt(0): there the tile is the
+//     step's parking lot instead (RtsIo::PARK) and the covariance of step k+1 is read back from memory, behind the wave's own
+//     stores of the step before;
 //   * the full rows of Ps[k] are requested a second time for the correction (the factorisation takes the lower part only);
 //   * the smoothed mean of step k+1 is replicated in the quad (dim_x registers).
 // Reads Xs[k], Ps[k] (the latter 1.6 times); writes xs[k], ps[k], Ks[k]: 8 (2 n + 3 n^2) algorithmic bytes per track-step.
@@ -193,6 +259,7 @@ ukf_mlg_rts_kernel(const UkfRtsArgs a, const double *__restrict__ pF, const doub
 {
     constexpr int R = (NX + 3) / 4, KS = 2 * NX + 1;
     constexpr bool AOS = LAYOUT == LAYOUT_AOS;
+    constexpr bool PARKV = FK_UMLG_RTS_PARK >= 2 || (FK_UMLG_RTS_PARK == 1 && NX >= 13);
     constexpr int EP = NX * NX;
     constexpr int TILE = 16 * EP, XT = 2 * 16 * NX;              // per wave: one covariance-sized output set; xs[k+1] as staged + Xs[k] parked
     constexpr int OFF_F = 0, OFF_Q = EP, OFF_W = 2 * EP;         // [F | Q | Wm | Wc | pair table]
@@ -285,20 +352,8 @@ ukf_mlg_rts_kernel(const UkfRtsArgs a, const double *__restrict__ pF, const doub
             FK_UNROLL for (int k = 0; k < NX; ++k) x[k] = vx.load(k);
             FK_UNROLL for (int k = 0; k < NX; ++k) xpark[k * 16] = x[k];
         }
-        st |= ukf_quad_rts_step_v4<NX>(x, P, row, a.scale, mv, quad, K,
-            [&](double (&out)[NX]) {                            // xs[k+1]: still staged in xt
-                FK_UNROLL for (int c = 0; c < NX; ++c) out[c] = xt_at((unsigned)c);
-            },
-            [&](int r, double (&out)[NX]) {
-                FK_UNROLL for (int c = 0; c < NX; ++c) out[c] = tile_at(row[r] * (unsigned)NX + (unsigned)c);
-            },
-            [&](double (&out)[NX]) {
-                FK_UNROLL for (int c = 0; c < NX; ++c) out[c] = xpark[c * 16];
-            },
-            [&](int r, double (&out)[NX]) {
-                const MlView vP(a.Ps + t * N * EP, off_row[r], estride);
-                FK_UNROLL for (int c = 0; c < NX; ++c) out[c] = vP.load(c);
-            });
+        RtsIo<NX, LAYOUT, PARKV> io{a.Ps + t * N * EP, a.ps + (t + 1) * N * EP, estride, row, off_row, tile, xt, xpark, g16};
+        st |= ukf_quad_rts_step_v4<NX>(x, P, row, a.scale, mv, quad, K, io);
         FK_STAGE();
         ml_wave_fence();
         FK_UNROLL for (int k = 0; k < NX; ++k) xt_at((unsigned)k) = x[k];

@@ -160,7 +160,27 @@ struct RtsJob {
     int st[4];
 };
 
-template <int NX>
+template <int NX, bool PARKV>
+struct HostRtsIo {
+    static constexpr int R = (NX + 3) / 4;
+    static constexpr bool PARK = PARKV;
+    const RtsJob<NX> &job;
+    const unsigned (&g)[R];
+    const double (&xn)[NX];
+    const double (&Pn)[R][NX];
+    long t;
+    double lot[R][NX];                                   // the track's parking lot, this lane's rows
+    void next_x(double (&out)[NX]) { for (int c = 0; c < NX; ++c) out[c] = xn[c]; }
+    void next_row(int r, double (&out)[NX]) { for (int c = 0; c < NX; ++c) out[c] = Pn[r][c]; }
+    void own_x(double (&out)[NX]) { for (int c = 0; c < NX; ++c) out[c] = job.Xs[t * NX + c]; }
+    void own_row(int r, double (&out)[NX]) { for (int c = 0; c < NX; ++c) out[c] = job.Ps[(t * NX + g[r]) * NX + c]; }
+    void park_k(double (&Kv)[R][NX]) { for (int r = 0; r < R; ++r) for (int c = 0; c < NX; ++c) { lot[r][c] = Kv[r][c]; Kv[r][c] = -7e300; } }
+    void unpark_k(double (&Kv)[R][NX]) { for (int r = 0; r < R; ++r) for (int c = 0; c < NX; ++c) Kv[r][c] = lot[r][c]; }
+    void park_pb(const double (&Pbv)[R][NX]) { for (int r = 0; r < R; ++r) for (int c = 0; c < NX; ++c) lot[r][c] = Pbv[r][c]; }
+    void pb_row(int r, double (&out)[NX]) { for (int c = 0; c < NX; ++c) out[c] = lot[r][c]; }
+};
+
+template <int NX, bool PARKV>
 void quad_rts_lane(void *vp, int lane)
 {
     constexpr int R = (NX + 3) / 4;
@@ -194,11 +214,8 @@ void quad_rts_lane(void *vp, int lane)
         for (int i = 0; i < NX; ++i) x[i] = job.Xs[t * NX + i];
         for (int r = 0; r < R; ++r)
             for (int c = 0; c < NX; ++c) P[r][c] = c <= 4 * r + 3 ? job.Ps[(t * NX + g[r]) * NX + c] : -1e300;   // only the lower part is handed over
-        st |= fk::ukf_quad_rts_step_v4<NX>(x, P, g, job.scale, mv, quad, K,
-                                           [&](double (&out)[NX]) { for (int c = 0; c < NX; ++c) out[c] = xn[c]; },
-                                           [&](int r, double (&out)[NX]) { for (int c = 0; c < NX; ++c) out[c] = Pn[r][c]; },
-                                           [&](double (&out)[NX]) { for (int c = 0; c < NX; ++c) out[c] = job.Xs[t * NX + c]; },
-                                           [&](int r, double (&out)[NX]) { for (int c = 0; c < NX; ++c) out[c] = job.Ps[(t * NX + g[r]) * NX + c]; });
+        HostRtsIo<NX, PARKV> io{job, g, xn, Pn, t, {}};
+        st |= fk::ukf_quad_rts_step_v4<NX>(x, P, g, job.scale, mv, quad, K, io);
         for (int i = 0; i < NX; ++i) {
             if (lane == 0) job.xs[t * NX + i] = x[i];
             else if (memcmp(&job.xs[t * NX + i], &x[i], 8) != 0) st |= 1 << 20;
@@ -217,7 +234,7 @@ void quad_rts_lane(void *vp, int lane)
     job.st[lane] = st;
 }
 
-template <int NX>
+template <int NX, bool PARKV>
 int ukf_quad_rts_batch(long T, const double *F, const double *Q, const double *Wm, const double *Wc, double scale,
                        const double *Xs, const double *Ps, double *xs, double *ps, double *Ks)
 {
@@ -228,7 +245,7 @@ int ukf_quad_rts_batch(long T, const double *F, const double *Q, const double *W
     fk::make_pair_table<NX>(wm, wc, wp);
     if (!fk::pair_weights_symmetric<NX>(wm, wc)) return -2;
     RtsJob<NX> job{T, F, Q, wp, Xs, Ps, scale, xs, ps, Ks, {0, 0, 0, 0}};
-    run_quad(&quad_rts_lane<NX>, &job);
+    run_quad(&quad_rts_lane<NX, PARKV>, &job);
     if (job.st[0] != job.st[1] || job.st[0] != job.st[2] || job.st[0] != job.st[3]) return 1 << 22;
     return job.st[0];
 }
@@ -238,7 +255,17 @@ int ukf_quad_rts_batch(long T, const double *F, const double *Q, const double *W
 extern "C" int hc_ukf_quad_rts_v4(int n, long T, const double *F, const double *Q, const double *Wm, const double *Wc,
                                   double scale, const double *Xs, const double *Ps, double *xs, double *ps, double *Ks)
 {
-#define GO(NXV) if (n == NXV) return ukf_quad_rts_batch<NXV>(T, F, Q, Wm, Wc, scale, Xs, Ps, xs, ps, Ks)
+#define GO(NXV) if (n == NXV) return ukf_quad_rts_batch<NXV, false>(T, F, Q, Wm, Wc, scale, Xs, Ps, xs, ps, Ks)
+    GO(4); GO(5); GO(7); GO(8); GO(9); GO(10); GO(11); GO(12); GO(13); GO(14); GO(15); GO(16);
+#undef GO
+    return -1;
+}
+
+// ... with the parking lot (Io::PARK: Pxb parked through the Pb pass, Pb's rows read back for the correction)
+extern "C" int hc_ukf_quad_rts_park_v4(int n, long T, const double *F, const double *Q, const double *Wm, const double *Wc,
+                                       double scale, const double *Xs, const double *Ps, double *xs, double *ps, double *Ks)
+{
+#define GO(NXV) if (n == NXV) return ukf_quad_rts_batch<NXV, true>(T, F, Q, Wm, Wc, scale, Xs, Ps, xs, ps, Ks)
     GO(4); GO(5); GO(7); GO(8); GO(9); GO(10); GO(11); GO(12); GO(13); GO(14); GO(15); GO(16);
 #undef GO
     return -1;

@@ -154,9 +154,10 @@ def _rts(lib, entry, n, F, Q, Wm, Wc, scale, Xs, Ps):
 relrows = lambda a, b: float(np.max(np.max(np.abs(a - b).reshape(len(a), -1), axis=1) / np.max(np.abs(b).reshape(len(b), -1), axis=1)))  # noqa: E731
 
 
+@pytest.mark.parametrize("entry", ["hc_ukf_quad_rts_v4", "hc_ukf_quad_rts_park_v4"])
 @pytest.mark.parametrize("n", [4, 5, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16])
 @pytest.mark.parametrize("abk", [(.1, 2., None), (1., 2., .1)])
-def test_quad_smoother_step_matches_the_oracle(quad_lib, n, abk):
+def test_quad_smoother_step_matches_the_oracle(quad_lib, n, abk, entry):
     """UKF.rts_smoother (UKF.py:714-739) through the oracle against the distributed backward step (ukf_quad_rts_step_v4: the
     gain's forward substitution fused into the factorisation of Pb, the rows of Pn - Pb and of K broadcast by their owners)."""
     alpha, beta, kappa = abk
@@ -168,7 +169,10 @@ def test_quad_smoother_step_matches_the_oracle(quad_lib, n, abk):
     Wm, Wc = ukf_oracle.merwe_weights(n, alpha, beta, kappa)
     mu, cov = ukf_oracle.ukf_batch_filter(x0, P0, list(zs), lambda s, d: F @ s, lambda s: H @ s, 0.1, Q, R, alpha, beta, kappa)
     xr, Pr, Kr = ukf_oracle.ukf_rts_smoother(mu, cov, lambda s, d: F @ s, 0.1, Q, alpha, beta, kappa)
-    xs, ps, Ks = _rts(quad_lib, "hc_ukf_quad_rts_v4", n, F, Q, Wm, Wc, alpha ** 2 * (n + kappa), mu, cov)
+    xs, ps, Ks = _rts(quad_lib, entry, n, F, Q, Wm, Wc, alpha ** 2 * (n + kappa), mu, cov)
+    if entry.endswith("park_v4"):                              # parking moves values, not bits
+        plain = _rts(quad_lib, "hc_ukf_quad_rts_v4", n, F, Q, Wm, Wc, alpha ** 2 * (n + kappa), mu, cov)
+        assert all(np.array_equal(u, v) for u, v in zip((xs, ps, Ks), plain))
     assert relrows(xs, xr) < 1e-10 and relrows(ps, Pr) < 1e-10 and relrows(Ks[:-1], Kr[:-1]) < 1e-10
     assert np.array_equal(xs[-1], mu[-1]) and np.array_equal(ps[-1], cov[-1]) and not Ks[-1].any()
     assert relrows(ps, np.swapaxes(ps, 1, 2)) < 1e-13
