@@ -25,6 +25,11 @@
 #error "compile with -DFK_NX=<dim_x>"
 #endif
 
+// FK_UMLG_ZDMA=0 (build time): the filter's measurement and mask byte as register loads again (A/B)
+#ifndef FK_UMLG_ZDMA
+#define FK_UMLG_ZDMA 1
+#endif
+
 #define FK_UMLG_CAT_(a, b) a##b
 #define FK_UMLG_CAT(a, b) FK_UMLG_CAT_(a, b)
 
@@ -95,14 +100,42 @@ ukf_mlg_kernel(const UkfArgs a)
             FK_UNROLL for (int c = 0; c < NX; ++c) asm volatile("" ::"v"(P[r][c]));       // landed before the loop
         FK_UNROLL for (int k = 0; k < NX; ++k) asm volatile("" ::"v"(x[k]));
     }
-    // z[t+1] and its mask byte are requested at the top of step t and consumed at the top of step t+1 (clamped index, no branch).
-    // (The wait for them sits at the end of the loop, behind the step's stores -- vmcnt retires in order, so it is also a wait
-    //  for all but the last few of those.  Requesting them in front of the stores and reading them in the update half, as
-    //  ukf_kernels.hip does, measured +116 registers here at (12,3) and tipped (14,4) / (16,4) into scratch, whose reloads are
-    //  vmcnt(0) waits of their own; LDS-DMA, which holds no register, is the open item -- 18 KB of images fit at dim_x 16.)
+    // z[t+1] and its mask byte travel HBM -> LDS by LDS-DMA while step t computes (ZDMA; LaneRecordDma, fk_device.hpp -- the very
+    // scheme of kf_mlg.hip: requested at the top of step t, read at the top of step t+1 behind s_waitcnt vmcnt(k), k = the store
+    // instructions a step issues (a lower bound, <= 63): vmcnt retires in order, so that wait covers the request and everything
+    // older, and none of the step's own stores).  As register loads they are waited for at the end of the loop behind the step's
+    // stores -- all but the last few of 35 KB per wave, one wave per SIMD, nothing to cover it; requested in front of the stores
+    // and read in the update half (ukf_kernels.hip's way) they cost 116 registers at (12,3) and tipped (14,4) / (16,4) into
+    // scratch.  Where the two images per wave do not fit next to the tiles (dim_x 16 with dim_z >= 6): the register loads.
+    constexpr int ZIMGD = LaneRecordDma<NZ, LAYOUT>::IMG_DOUBLES + 32;        // + 64 dwords: the mask bytes' dwords
+    constexpr bool ZDMA = FK_UMLG_ZDMA && (long)(MSZ + (BLOCK / 64) * TILE) * 8 + 64 + (long)(BLOCK / 64) * 2 * ZIMGD * 8 <= 160 * 1024;
+    constexpr int ZST = AOS ? (8 * NX + 63) / 64 + (8 * EP + 63) / 64 : 2 * ((8 * NX + 63) / 64 + (8 * EP + 63) / 64);
+    constexpr int ZWAIT = ZST < 63 ? ZST : 63;
+    __shared__ double s_zd[ZDMA ? (BLOCK / 64) * 2 * ZIMGD : 1];
+    LaneRecordDma<NZ, LAYOUT> zdma;
+    [[maybe_unused]] auto zreq = [&](long tt, unsigned buf) {
+        zdma.request(a.z + tt * N * NZ, (unsigned)N * (unsigned)NZ * 8u, buf);
+        // the mask byte of (tt, trk): the aligned dword around it (base and its misalignment are wave-uniform)
+        const unsigned long long mb = reinterpret_cast<unsigned long long>(mask_or_dummy) + (unsigned long long)(tt * N);
+        const unsigned delta = (unsigned)(mb & 3ull);
+        const dma_rsrc_t rm = make_dma_rsrc(reinterpret_cast<const void *>(mb & ~3ull), (unsigned)N + 8u);
+        lds_dma4(rm, ((unsigned)trk + delta) & ~3u, 0u, zdma.lds + buf * (unsigned)(ZIMGD * 8) + (unsigned)(LaneRecordDma<NZ, LAYOUT>::IMG_DOUBLES * 8));
+    };
+    [[maybe_unused]] auto zread = [&](long tt, unsigned buf, double (&zd)[NZ]) -> unsigned {
+        zdma.read(buf, zd);
+        const unsigned long long mb = reinterpret_cast<unsigned long long>(mask_or_dummy) + (unsigned long long)(tt * N);
+        const unsigned sh = (((unsigned)trk + (unsigned)(mb & 3ull)) & 3u) * 8u;
+        const unsigned dw = zdma.img0[buf * (unsigned)(ZIMGD * 2) + (unsigned)(LaneRecordDma<NZ, LAYOUT>::IMG_DOUBLES * 2) + (threadIdx.x & 63u)];
+        return (dw >> sh) & 0xffu;
+    };
     double zn[NZ];
-    unsigned hn;
-    {
+    unsigned hn = 1u;
+    if constexpr (ZDMA) {
+        zdma.init(s_zd + wave_index() * (2 * ZIMGD), (unsigned)trk, (unsigned)N, threadIdx.x & 63u);
+        zdma.stride_doubles = ZIMGD;
+        zreq(0, 0u);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
         const MlView vz(a.z, tz8, estride);
         FK_UNROLL for (int c = 0; c < NZ; ++c) zn[c] = vz.load(c);
         const unsigned hb = mask_or_dummy[trk];
@@ -113,10 +146,16 @@ ukf_mlg_kernel(const UkfArgs a)
     QuadDpp quad;
     const bool st_m = a.means != nullptr, st_c = a.covs != nullptr;
     _Pragma("nounroll") for (long t = 0; t < a.T; ++t) {
+        if constexpr (ZDMA) {
+            if (t > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ZWAIT) : "memory");
+            const unsigned hb = zread(t, (unsigned)(t & 1), zn);
+            hn = a.mask ? hb : 1u;
+            zreq(t + 1 < a.T ? t + 1 : t, (unsigned)((t + 1) & 1));
+        }
         const bool has_z = hn != 0u;
         double z[NZ];
         FK_UNROLL for (int c = 0; c < NZ; ++c) z[c] = has_z ? zn[c] : 0.0;
-        {
+        if constexpr (!ZDMA) {
             long tn = t + 1 < a.T ? t + 1 : t;
             asm volatile("" : "+s"(tn));
             const MlView vz(a.z + tn * N * NZ, tz8, estride);
