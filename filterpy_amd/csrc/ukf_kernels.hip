@@ -638,13 +638,16 @@ int ukf_rts_launch_big_paired(const UkfRtsArgs &a, const double *F, const double
 #define FK_UMLG_DECL(NXV)                                         \
     int launch_ukf_mlg_##NXV(const UkfArgs &, int, hipStream_t); \
     int launch_ukf_mlg_rts_##NXV(const UkfRtsArgs &, const double *, const double *, const double *, const double *, int, hipStream_t);
-FK_UMLG_DECL(10) FK_UMLG_DECL(11) FK_UMLG_DECL(12) FK_UMLG_DECL(13) FK_UMLG_DECL(14) FK_UMLG_DECL(15) FK_UMLG_DECL(16)
+FK_UMLG_DECL(7) FK_UMLG_DECL(8) FK_UMLG_DECL(9) FK_UMLG_DECL(10) FK_UMLG_DECL(11) FK_UMLG_DECL(12) FK_UMLG_DECL(13) FK_UMLG_DECL(14) FK_UMLG_DECL(15) FK_UMLG_DECL(16)
 #undef FK_UMLG_DECL
 #if FK_UKF_HAS(1)
 static int ukf_mlg_launch(const UkfArgs &a, int layout, hipStream_t s)
 {
     int rc = 1;
     switch (a.n) {
+        case 7: rc = launch_ukf_mlg_7(a, layout, s); break;
+        case 8: rc = launch_ukf_mlg_8(a, layout, s); break;
+        case 9: rc = launch_ukf_mlg_9(a, layout, s); break;
         case 10: rc = launch_ukf_mlg_10(a, layout, s); break;
         case 11: rc = launch_ukf_mlg_11(a, layout, s); break;
         case 12: rc = launch_ukf_mlg_12(a, layout, s); break;
@@ -667,6 +670,9 @@ static int ukf_mlg_rts_launch(const UkfRtsArgs &a, const double *F, const double
 {
     int rc = 1;
     switch (a.n) {
+        case 7: rc = launch_ukf_mlg_rts_7(a, F, Q, Wm, Wc, layout, s); break;
+        case 8: rc = launch_ukf_mlg_rts_8(a, F, Q, Wm, Wc, layout, s); break;
+        case 9: rc = launch_ukf_mlg_rts_9(a, F, Q, Wm, Wc, layout, s); break;
         case 10: rc = launch_ukf_mlg_rts_10(a, F, Q, Wm, Wc, layout, s); break;
         case 11: rc = launch_ukf_mlg_rts_11(a, F, Q, Wm, Wc, layout, s); break;
         case 12: rc = launch_ukf_mlg_rts_12(a, F, Q, Wm, Wc, layout, s); break;
@@ -683,6 +689,20 @@ static int ukf_mlg_rts_launch(const UkfRtsArgs &a, const double *F, const double
     return rc;
 }
 #endif
+
+// FK_UKF_MLG=1: the four-lane kernels serve dim_x 10..16; FK_UKF_MLG_MIN_NX=7 | 8 | 9 additionally hands them the pair-weight
+// calls of the one-lane classes from that dim_x on (A/B: those classes run one wave per SIMD with scratch)
+static int ukf_mlg_min_nx()
+{
+    static const int v = [] {
+        const char *on = getenv("FK_UKF_MLG");
+        if (!on || on[0] != '1') return 99;
+        const char *mn = getenv("FK_UKF_MLG_MIN_NX");
+        const int m = mn ? atoi(mn) : 10;
+        return m >= 7 && m <= 10 ? m : 10;
+    }();
+    return v;
+}
 
 static int fail(int code, const char *msg)
 {
@@ -720,10 +740,10 @@ int fk_ukf_linear_batch_f64(const fk_ukf_desc *d, const double *F, const double 
     if (!d) return fail(FK_ERR_BAD_ARG, "desc is NULL");
     // dim_x 10..16 (dim_z 1..8): four lanes per track (ukf_mlg.hip), the pair-regrouped sums only -- and only with FK_UKF_MLG=1
     // until the kernel has been through a GPU parity run (round 4 ended without one; tests/test_gpu_ukf_mlg.py)
-    const bool quad = d->n >= 10 && d->n <= 16 && d->m >= 1 && d->m <= 8;
-    if (quad) {
-        static const bool on = getenv("FK_UKF_MLG") && getenv("FK_UKF_MLG")[0] == '1';
-        if (!on || !(d->flags & FK_UKF_FLAG_PAIR_WEIGHTS))
+    const bool big = d->n >= 10 && d->n <= 16 && d->m >= 1 && d->m <= 8;
+    const bool quad = big || (d->n >= ukf_mlg_min_nx() && d->n <= 9 && d->m >= 1 && d->m <= 4 && (d->flags & FK_UKF_FLAG_PAIR_WEIGHTS) && ukf_paired(d));
+    if (big) {
+        if (ukf_mlg_min_nx() > 10 || !(d->flags & FK_UKF_FLAG_PAIR_WEIGHTS))
             return fail(FK_ERR_UNSUPPORTED, "fused linear UKF at dim_x 10..16: FK_UKF_MLG=1 and weights equal within every +- pair (FK_UKF_FLAG_PAIR_WEIGHTS)");
     } else if (d->n < 1 || d->n > 9 || d->m < 1 || d->m > 4 || (d->n <= 6 && d->m > 3))
         return fail(FK_ERR_UNSUPPORTED, "fused linear UKF: dim_x 1..6 with dim_z 1..3, dim_x 7..9 with dim_z 1..4, dim_x 10..16 with dim_z 1..8");
@@ -764,13 +784,13 @@ int fk_ukf_linear_rts_f64(const fk_ukf_desc *d, const double *F, const double *Q
 {
     if (!d) return fail(FK_ERR_BAD_ARG, "desc is NULL");
     // dim_x 10..16: four lanes per track (ukf_mlg.hip), pair-regrouped sums only, opt-in like the filter (fk_ukf_linear_batch_f64)
-    const bool quad = d->n >= 10 && d->n <= 16;
-    if (quad) {
-        static const bool on = getenv("FK_UKF_MLG") && getenv("FK_UKF_MLG")[0] == '1';
-        if (!on || !(d->flags & FK_UKF_FLAG_PAIR_WEIGHTS))
+    const bool big = d->n >= 10 && d->n <= 16;
+    const bool quad = big || (d->n >= ukf_mlg_min_nx() && d->n <= 9 && (d->flags & FK_UKF_FLAG_PAIR_WEIGHTS) && ukf_paired(d));
+    if (big) {
+        if (ukf_mlg_min_nx() > 10 || !(d->flags & FK_UKF_FLAG_PAIR_WEIGHTS))
             return fail(FK_ERR_UNSUPPORTED, "fused linear UKF smoother at dim_x 10..16: FK_UKF_MLG=1 and weights equal within every +- pair (FK_UKF_FLAG_PAIR_WEIGHTS)");
-        if ((double)d->N * d->n * d->n * 8.0 >= 4294967296.0 - 32.0) return fail(FK_ERR_UNSUPPORTED, "fused linear UKF smoother: record block >= 4 GiB, split the batch");
     } else if (d->n < 1 || d->n > 9) return fail(FK_ERR_UNSUPPORTED, "fused linear UKF smoother: dim_x 1..9, 10..16");
+    if (quad && (double)d->N * d->n * d->n * 8.0 >= 4294967296.0 - 32.0) return fail(FK_ERR_UNSUPPORTED, "fused linear UKF smoother: record block >= 4 GiB, split the batch");
     if (d->N < 0 || d->T < 0 || !F || !Q || !Wm || !Wc || !Xs || !Ps || !xs || !Ps_out)
         return fail(FK_ERR_BAD_ARG, "fused linear UKF smoother: bad argument");
     if ((double)d->N * d->n * d->n * 8.0 >= 4294967296.0) return fail(FK_ERR_UNSUPPORTED, "fused linear UKF smoother: record block >= 4 GiB, split the batch");

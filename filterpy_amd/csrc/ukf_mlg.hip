@@ -42,7 +42,7 @@ struct QuadDpp {
 };
 
 template <int NX, int NZ, int LAYOUT>
-__global__ void __launch_bounds__(BLOCK, 1)
+__global__ void __launch_bounds__(BLOCK, (NX <= 8 ? 2 : 1))
 ukf_mlg_kernel(const UkfArgs a)
 {
     constexpr int R = (NX + 3) / 4, KS = 2 * NX + 1;
@@ -292,7 +292,7 @@ struct RtsIo {
 //   * the smoothed mean of step k+1 is replicated in the quad (dim_x registers).
 // Reads Xs[k], Ps[k] (the latter 1.6 times); writes xs[k], ps[k], Ks[k]: 8 (2 n + 3 n^2) algorithmic bytes per track-step.
 template <int NX, int LAYOUT>
-__global__ void __launch_bounds__(BLOCK, 1)
+__global__ void __launch_bounds__(BLOCK, (NX <= 8 ? 2 : 1))
 ukf_mlg_rts_kernel(const UkfRtsArgs a, const double *__restrict__ pF, const double *__restrict__ pQ,
                    const double *__restrict__ pWm, const double *__restrict__ pWc)
 {

@@ -238,3 +238,33 @@ def test_python_api_smoother_routes_here(layout):
             assert rel_err_rows(Ks[:-1, trk], g[p + "rts_K"][:-1]) < TOL, (n, trk)
         done += 1
     assert done >= 5
+
+
+# ------------------------------------------------------------------- dim_x 7..9 on the four-lane kernels (A/B switch)
+small = pytest.mark.skipif(os.environ.get("FK_UKF_MLG_MIN_NX", "10") != "7",
+                           reason="FK_UKF_MLG_MIN_NX=7 hands the one-lane classes' pair-weight calls at dim_x 7..9 to the four-lane kernels")
+
+
+@small
+@pytest.mark.parametrize("layout", ["soa", "aos"])
+@pytest.mark.parametrize("n,m", [(7, 1), (7, 3), (8, 2), (8, 4), (9, 3), (9, 4)])
+def test_small_dims_filter_vs_oracle(n, m, layout):
+    N, T = 200, 7
+    mu, cov, xe, Pe, st, ref = _bank(n, m, N, T, layout, 100 * n + m, mask_every=9)
+    assert not st.any()
+    for trk in (0, 15, 16, 63, 64, 191, 192, N - 1):
+        rmu, rcov = ref(trk)
+        assert rel_err_rows(mu[:, trk], rmu) < TOL and rel_err_rows(cov[:, trk], rcov) < TOL, trk
+    assert np.array_equal(xe, mu[-1]) and np.array_equal(Pe, cov[-1])
+
+
+@small
+@pytest.mark.parametrize("layout", ["soa", "aos"])
+@pytest.mark.parametrize("n", [7, 8, 9])
+def test_small_dims_smoother_vs_oracle(n, layout):
+    N, T = 200, 8
+    xs, ps, Ks, pick, refs, mus, covs = _smooth(n, N, T, layout, 40 + n)
+    for trk in range(N):
+        rx, rP, rK = refs[pick[trk]]
+        assert rel_err_rows(xs[:, trk], rx) < TOL and rel_err_rows(ps[:, trk], rP) < TOL, trk
+        assert rel_err_rows(Ks[:-1, trk], rK[:-1]) < TOL, trk

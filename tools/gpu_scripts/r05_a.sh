@@ -20,4 +20,19 @@ for l in sys.stdin:
     d=json.loads(l); print(d['kernel'][:48], 'ms=%.3f'%d['ms'], 'frac=%.3f'%d.get('frac_of_8TBs',0), d.get('parity_max_rel'))
 "
     done
+    # the one-lane classes at dim_x 8 / 9 (one wave per SIMD, scratch) against the four-lane kernels on the same calls
+    FK_UKF_MLG_MIN_NX=7 timeout 300 python -m pytest $R/tests/test_gpu_ukf_mlg.py -m gpu -q -x -k "small_dims" -p no:cacheprovider 2>&1 | tail -2 | cut -c1-200
+    for d in 8x4 9x3; do
+        for mn in 10 7; do
+            FK_UKF_MLG_MIN_NX=$mn timeout 200 python $R/tools/bench_ukf.py --dims $d --N 100000 --T 100 2>>$O/bench_small.err | python -c "
+import sys,json
+for l in sys.stdin:
+    d=json.loads(l); d['min_nx']=$mn; print(json.dumps(d))
+" | tee -a $O/ukf_small_ab.jsonl | python -c "
+import sys,json
+for l in sys.stdin:
+    d=json.loads(l); print('min_nx', d['min_nx'], d['kernel'][:48], 'ms=%.3f'%d['ms'], 'frac=%.3f'%d.get('frac_of_8TBs',0), d.get('parity_max_rel'))
+"
+        done
+    done
 fi
