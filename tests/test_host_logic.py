@@ -4,6 +4,7 @@ imports the oracle and fails loudly without a GPU."""
 import os
 import re
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -176,3 +177,34 @@ def test_design_table_is_the_committed_evidence():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "make_design_table.py"), "--check"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_fused_ukf_size_routing_without_gpu():
+    """fk_ukf_linear_batch_f64 / fk_ukf_linear_rts_f64 decide which sizes they serve before anything is launched: the
+    one-lane classes as before; dim_x 10..16 (the four-lane kernels, csrc/ukf_mlg.hip) only with FK_UKF_MLG=1 in the
+    environment AND the pair-weight flag -- the switch is read once per process, so each setting gets its own interpreter."""
+    code = r'''
+import ctypes, sys
+from filterpy_amd import _abi
+lib = _abi.lib()
+one = ctypes.c_void_p(8)
+def fwd(n, m, flags, N=0):
+    d = _abi.fk_ukf_desc(n=n, m=m, N=N, T=1, layout=0, flags=flags, scale=1.0)
+    return lib.fk_ukf_linear_batch_f64(ctypes.byref(d), one, one, one, one, one, one, one, None, one, one, None, None, None, None)
+def rts(n, flags, N=0):
+    d = _abi.fk_ukf_desc(n=n, m=1, N=N, T=1, layout=0, flags=flags, scale=1.0)
+    return lib.fk_ukf_linear_rts_f64(ctypes.byref(d), one, one, one, one, one, one, one, one, None, None, None)
+PAIR = 1
+out = [fwd(6, 3, 0), fwd(6, 4, 0), fwd(9, 4, PAIR), fwd(9, 5, PAIR), fwd(12, 3, PAIR), fwd(12, 3, 0), fwd(16, 8, PAIR), fwd(16, 9, PAIR), fwd(17, 2, PAIR),
+       rts(9, PAIR), rts(12, PAIR), rts(12, 0), rts(17, PAIR)]
+print(" ".join(str(v) for v in out))
+'''
+    def run(env):
+        e = {k: v for k, v in os.environ.items() if not k.startswith("FK_UKF_MLG")}
+        e.update(env)
+        return [int(v) for v in subprocess.check_output([sys.executable, "-c", code], text=True, cwd=ROOT, env=e).split()]
+    OK, UNS = 0, -2
+    #                  6x3  6x4  9x4  9x5  12x3p 12x3 16x8p 16x9 17x2 | r9  r12p r12  r17
+    assert run({}) == [OK, UNS, OK, UNS, UNS, UNS, UNS, UNS, UNS, OK, UNS, UNS, UNS]
+    assert run({"FK_UKF_MLG": "1"}) == [OK, UNS, OK, UNS, OK, UNS, OK, UNS, UNS, OK, OK, UNS, UNS]
+    assert run({"FK_UKF_MLG": "1", "FK_UKF_MLG_MIN_NX": "7"}) == [OK, UNS, OK, UNS, OK, UNS, OK, UNS, UNS, OK, OK, UNS, UNS]
