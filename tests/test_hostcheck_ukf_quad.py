@@ -190,3 +190,29 @@ def test_quad_smoother_step_agrees_with_the_one_lane_step(quad_lib, n):
     b = _rts(one, "hc_ukf_linear_rts_v4", n, F, Q, Wm, Wc, alpha ** 2 * (n + kappa), mu, cov)
     for u, v in zip(a, b):
         assert relrows(u[:-1], v[:-1]) < 1e-12
+
+
+def test_quad_step_is_as_accurate_as_the_one_lane_step_on_ill_conditioned_covariances(quad_lib):
+    """Covariances of condition 1e3 .. 1e7, states of size 1e-2 .. 1e3: the error against the oracle is the problem's own
+    sensitivity (cond x eps), and the distributed step's must be the one-lane step's -- same sums, same order -- not worse."""
+    one = ctypes.CDLL(os.path.join(HC, "libhostcheck.so"))
+    worst = 0.0
+    for seed in range(25):
+        r = np.random.default_rng(1000 + seed)
+        n, m = [(7, 3), (8, 4), (9, 3), (5, 2), (4, 2)][seed % 5]
+        U, _ = np.linalg.qr(r.standard_normal((n, n)))
+        P0 = (U * np.geomspace(1, 10.0 ** r.uniform(3, 7), n)) @ U.T
+        P0 = (P0 + P0.T) / 2
+        F = np.eye(n) + 0.2 * r.standard_normal((n, n))
+        F /= max(1, 1.1 * np.max(np.abs(np.linalg.eigvals(F))))
+        H, A, B = r.standard_normal((m, n)), r.standard_normal((n, n)), r.standard_normal((m, m))
+        Q, R = 1e-3 * (A @ A.T / n + 0.1 * np.eye(n)), 0.3 * (B @ B.T / m + 0.2 * np.eye(m))
+        x0, zs = r.standard_normal(n) * 10 ** r.uniform(-2, 3), r.standard_normal((15, m)) * 10
+        alpha, kappa = float(r.choice([1.0, 0.5, 0.1, 0.3])), float(r.choice([0.0, 1.0]))
+        Wm, Wc = ukf_oracle.merwe_weights(n, alpha, 2.0, kappa)
+        mu, cov = ukf_oracle.ukf_batch_filter(x0, P0, list(zs), lambda s, d: F @ s, lambda s: H @ s, 0.1, Q, R, alpha, 2.0, kappa)
+        a = _run(quad_lib, "hc_ukf_quad_v4", n, m, F, H, Q, R, Wm, Wc, alpha ** 2 * (n + kappa), zs, None, x0, P0)
+        b = _run(one, "hc_ukf_linear_v4", n, m, F, H, Q, R, Wm, Wc, alpha ** 2 * (n + kappa), zs, None, x0, P0)
+        eq, eo = max(rel(a[0], mu), rel(a[1], cov)), max(rel(b[0], mu), rel(b[1], cov))
+        worst = max(worst, eq / max(eo, 1e-13))
+    assert worst < 5.0, worst
