@@ -28,6 +28,17 @@ def _ptr(t):
     return None if t is None else t.data_ptr()
 
 
+def _mask_ptr(t, keep):
+    """A [T][N] byte mask as the C ABI reads it: row stride N.  A strided view (NumPy's zs_mask[:, idx] hands out column-major
+    memory, and torch.as_tensor keeps its strides) is copied; `keep` holds the copy for the duration of the call."""
+    if t is None:
+        return None
+    if not t.is_contiguous():
+        t = t.contiguous()
+    keep.append(t)
+    return t.data_ptr()
+
+
 def _stream():
     return torch.cuda.current_stream().cuda_stream
 
@@ -112,9 +123,10 @@ def raise_on_status(status, what):
 def kf_batch_filter(desc_kw, F, Q, H, R, z, x, P, *, B=None, u=None, mask=None,
                     means=None, covs=None, means_p=None, covs_p=None, status=None):
     """fk_kf_batch_filter_f64.  desc_kw: n, m, nu, model_mode, N, T, layout, update_first, alpha_sq."""
+    _keep = []
     d = fk_kf_desc(**desc_kw)
     rc = _abi.lib().fk_kf_batch_filter_f64(d, _ptr(F), _ptr(Q), _ptr(H), _ptr(R), _ptr(B), _ptr(u),
-                                           _ptr(z), _ptr(mask), _ptr(x), _ptr(P), _ptr(means), _ptr(covs),
+                                           _ptr(z), _mask_ptr(mask, _keep), _ptr(x), _ptr(P), _ptr(means), _ptr(covs),
                                            _ptr(means_p), _ptr(covs_p), _ptr(status), _stream())
     _abi.check(rc, "fk_kf_batch_filter_f64")
 
@@ -122,10 +134,11 @@ def kf_batch_filter(desc_kw, F, Q, H, R, z, x, P, *, B=None, u=None, mask=None,
 def kf_batch_filter_ex(desc_kw, F, Q, H, R, z, x, P, extras, *, B=None, u=None, mask=None,
                        means=None, covs=None, means_p=None, covs_p=None, status=None):
     """fk_kf_batch_filter_ex_f64: `extras` maps y/K/S/SI/log_likelihood/mahalanobis -> device tensor."""
+    _keep = []
     d = fk_kf_desc(**desc_kw)
     ex = _abi.fk_kf_extras(**{k: _ptr(extras.get(k)) for k in ("y", "K", "S", "SI", "log_likelihood", "mahalanobis")})
     rc = _abi.lib().fk_kf_batch_filter_ex_f64(d, _ptr(F), _ptr(Q), _ptr(H), _ptr(R), _ptr(B), _ptr(u), _ptr(z),
-                                              _ptr(mask), _ptr(x), _ptr(P), _ptr(means), _ptr(covs), _ptr(means_p),
+                                              _mask_ptr(mask, _keep), _ptr(x), _ptr(P), _ptr(means), _ptr(covs), _ptr(means_p),
                                               _ptr(covs_p), ex, _ptr(status), _stream())
     _abi.check(rc, "fk_kf_batch_filter_ex_f64")
 
@@ -138,8 +151,9 @@ def kf_predict(desc_kw, F, Q, x, P, *, B=None, u=None, status=None):
 
 
 def kf_update(desc_kw, H, R, z, x, P, *, mask=None, y=None, K=None, S=None, SI=None, status=None):
+    _keep = []
     d = fk_kf_desc(**desc_kw)
-    rc = _abi.lib().fk_kf_update_f64(d, _ptr(H), _ptr(R), _ptr(z), _ptr(mask), _ptr(x), _ptr(P),
+    rc = _abi.lib().fk_kf_update_f64(d, _ptr(H), _ptr(R), _ptr(z), _mask_ptr(mask, _keep), _ptr(x), _ptr(P),
                                      _ptr(y), _ptr(K), _ptr(S), _ptr(SI), _ptr(status), _stream())
     _abi.check(rc, "fk_kf_update_f64")
 
@@ -216,9 +230,10 @@ def _ukf_flags(Wm, Wc, n, paired):
 def ukf_linear_batch(n, m, N, T, layout, scale, F, H, Q, R, Wm, Wc, z, x, P, *, mask=None,
                      means=None, covs=None, status=None, paired=None):
     """fk_ukf_linear_batch_f64.  paired: None = look at the weights (pair_weights), True / False = the caller knows."""
+    _keep = []
     d = fk_ukf_desc(n=n, m=m, N=N, T=T, layout=LAYOUTS[layout], flags=_ukf_flags(Wm, Wc, n, paired), scale=float(scale))
     rc = _abi.lib().fk_ukf_linear_batch_f64(d, _ptr(F), _ptr(H), _ptr(Q), _ptr(R), _ptr(Wm), _ptr(Wc),
-                                            _ptr(z), _ptr(mask), _ptr(x), _ptr(P), _ptr(means), _ptr(covs),
+                                            _ptr(z), _mask_ptr(mask, _keep), _ptr(x), _ptr(P), _ptr(means), _ptr(covs),
                                             _ptr(status), _stream())
     _abi.check(rc, "fk_ukf_linear_batch_f64")
 
@@ -233,15 +248,17 @@ def ukf_linear_rts(n, N, T, layout, scale, F, Q, Wm, Wc, Xs, Ps, xs, Ps_out, K=N
 
 def kf_steadystate(desc_kw, F, H, K, z, x, *, B=None, u=None, mask=None, means=None, means_p=None, y=None):
     """fk_kf_steadystate_f64 (F None: update only; z None: predict only)."""
+    _keep = []
     d = fk_kf_desc(**desc_kw)
-    rc = _abi.lib().fk_kf_steadystate_f64(d, _ptr(F), _ptr(H), _ptr(K), _ptr(B), _ptr(u), _ptr(z), _ptr(mask),
+    rc = _abi.lib().fk_kf_steadystate_f64(d, _ptr(F), _ptr(H), _ptr(K), _ptr(B), _ptr(u), _ptr(z), _mask_ptr(mask, _keep),
                                           _ptr(x), _ptr(means), _ptr(means_p), _ptr(y), _stream())
     _abi.check(rc, "fk_kf_steadystate_f64")
 
 
 def kf_update_correlated(desc_kw, H, R, M, z, x, P, *, mask=None, y=None, K=None, S=None, SI=None, status=None):
+    _keep = []
     d = fk_kf_desc(**desc_kw)
-    rc = _abi.lib().fk_kf_update_correlated_f64(d, _ptr(H), _ptr(R), _ptr(M), _ptr(z), _ptr(mask), _ptr(x), _ptr(P),
+    rc = _abi.lib().fk_kf_update_correlated_f64(d, _ptr(H), _ptr(R), _ptr(M), _ptr(z), _mask_ptr(mask, _keep), _ptr(x), _ptr(P),
                                                 _ptr(y), _ptr(K), _ptr(S), _ptr(SI), _ptr(status), _stream())
     _abi.check(rc, "fk_kf_update_correlated_f64")
 
@@ -256,8 +273,9 @@ def imm_batch(n, m, n_models, N, T, layout, F, Q, H, R, M, z, xs, Ps, mu, *, x_o
               mu_out=None, x_prior_out=None, P_prior_out=None, likelihood_out=None, status=None, phase=0, mmae=False,
               zmask=None, ll0=None, nu=0, B=None, u=None):
     """fk_imm_batch_ex_f64: T x { IMMEstimator.predict(); IMMEstimator.update(z or None) } for N banks."""
+    _keep = []
     d = _abi.fk_imm_desc(n=n, m=m, n_models=n_models, layout=LAYOUTS[layout], N=N, T=T, phase=phase, flags=1 if mmae else 0)
-    rc = _abi.lib().fk_imm_batch_ex_f64(d, _ptr(F), _ptr(Q), _ptr(H), _ptr(R), _ptr(M), _ptr(z), _ptr(zmask), _ptr(ll0),
+    rc = _abi.lib().fk_imm_batch_ex_f64(d, _ptr(F), _ptr(Q), _ptr(H), _ptr(R), _ptr(M), _ptr(z), _mask_ptr(zmask, _keep), _ptr(ll0),
                                             int(nu), _ptr(B), _ptr(u),
                                             _ptr(xs), _ptr(Ps), _ptr(mu), _ptr(x_out), _ptr(P_out), _ptr(mu_out),
                                             _ptr(x_prior_out), _ptr(P_prior_out), _ptr(likelihood_out), _ptr(status), _stream())
