@@ -1,7 +1,7 @@
 """-m gpu, and only with FK_UKF_MLG=1 in the environment: the fused linear UKF on four lanes per track (csrc/ukf_mlg.hip, dim_x
 10..16, dim_z 1..8) through the C ABI against the oracle's per-filter loop (UKF.py:364-491, 524-632) and the live-reference
 goldens.  The kernel's arithmetic (csrc/fk_ukf_quad.hpp) is held against the oracle on the host by
-tests/test_hostcheck_ukf_quad.py; round 4 ended before the kernel itself had a GPU run, so the library keeps these sizes on the
+tests/test_hostcheck_ukf_quad.py; round 4's last GPU seconds went to a probe of it (profiles/r04/lease_q: passes), not to this file, so the library keeps these sizes on the
 split path unless FK_UKF_MLG=1 -- run this file (and the rest of the UKF suite) with it first thing in the next round."""
 import os
 
