@@ -30,45 +30,53 @@ struct UkfQuadModel {
     const double *F, *Q, *H, *R, *Wp;       // row-major [n][n], [n][n], [m][n], [m][m]; the pair table (make_pair_table)
 };
 
-// the value lane o of the quad holds (o is a constant wherever this is used, once the loops are unrolled)
-template <class Quad>
+// the value lane o of the track's lane group holds (o is a constant wherever this is used, once the loops are unrolled);
+// LN: lanes per track -- 4 (a quad: DPP) or 8 (the smoother at dim_x >= 13: half the unrolled arithmetic per lane)
+template <int LN = 4, class Quad>
 FK_HD double quad_from(Quad &quad, double v, int o)
 {
     if (o == 0) return quad.template bcast<0>(v);
     if (o == 1) return quad.template bcast<1>(v);
     if (o == 2) return quad.template bcast<2>(v);
-    return quad.template bcast<3>(v);
+    if constexpr (LN == 4) return quad.template bcast<3>(v);
+    else {
+        if (o == 3) return quad.template bcast<3>(v);
+        if (o == 4) return quad.template bcast<4>(v);
+        if (o == 5) return quad.template bcast<5>(v);
+        if (o == 6) return quad.template bcast<6>(v);
+        return quad.template bcast<7>(v);
+    }
 }
 
-// Lower factor of scale * P, rows distributed cyclically (g[r]: the row slot r holds -- q + 4 r, clamped to NX - 1).
-// Lw[r][k], k <= 4 r + 3: the lane's rows (zero above the diagonal; entries past 4 r + 3 are never written nor read).
+// Lower factor of scale * P, rows distributed cyclically (g[r]: the row slot r holds -- q + LN r, clamped to NX - 1).
+// Lw[r][k], k <= LN r + LN - 1: the lane's rows (zero above the diagonal; entries past that are never written nor read).
 // row_done(j, lrow, ljj, inv): called once row j is final -- lrow[0..j-1], the pivot's root and its reciprocal, replicated in the quad.
-template <int NX, class Quad, class RowDone>
-FK_HD bool quad_chol_rows(const double (&P)[(NX + 3) / 4][NX], const unsigned (&g)[(NX + 3) / 4], double scale,
-                          double (&Lw)[(NX + 3) / 4][NX], Quad &quad, RowDone &&row_done)
+template <int NX, int LN = 4, class Quad, class RowDone>
+FK_HD bool quad_chol_rows(const double (&P)[(NX + LN - 1) / LN][NX], const unsigned (&g)[(NX + LN - 1) / LN], double scale,
+                          double (&Lw)[(NX + LN - 1) / LN][NX], Quad &quad, RowDone &&row_done)
 {
-    constexpr int R = (NX + 3) / 4;
+    constexpr int R = (NX + LN - 1) / LN;
     bool pd = true;
     FK_UNROLL for (int j = 0; j < NX; ++j) {
-        const int sj = j / 4, oj = j % 4;
+        const int sj = j / LN, oj = j % LN;
         // the pivot: every lane forms it for its row of slot sj, the owner's counts
         double dl = scale * P[sj][j];
         FK_UNROLL for (int k = 0; k < NX; ++k)
             if (k < j) dl = fma(-Lw[sj][k], Lw[sj][k], dl);
-        const double d = quad_from(quad, dl, oj);
+        const double d = quad_from<LN>(quad, dl, oj);
         pd = pd && (d > 0.0);
         double ljj, inv;
         sqrt_rsqrt(d, ljj, inv);
         double lrow[NX];
         FK_UNROLL for (int k = 0; k < NX; ++k)
-            if (k < j) lrow[k] = quad_from(quad, Lw[sj][k], oj);
+            if (k < j) lrow[k] = quad_from<LN>(quad, Lw[sj][k], oj);
         FK_UNROLL for (int r = 0; r < R; ++r) {
-            if (4 * r + 3 < j) continue;                      // the slot's rows all lie above row j
+            if (LN * r + LN - 1 < j) continue;                      // the slot's rows all lie above row j
             double t = scale * P[r][j];
             FK_UNROLL for (int k = 0; k < NX; ++k)
                 if (k < j) t = fma(-Lw[r][k], lrow[k], t);
             t *= inv;
-            if (4 * r > j) Lw[r][j] = t;                      // all of them below it
+            if (LN * r > j) Lw[r][j] = t;                      // all of them below it
             else Lw[r][j] = g[r] > (unsigned)j ? t : (g[r] == (unsigned)j ? ljj : 0.0);
         }
         row_done(j, lrow, ljj, inv);
@@ -283,22 +291,39 @@ FK_HD int ukf_quad_step_v4(double (&x)[NX], double (&P)[(NX + 3) / 4][NX], const
 //   (park_k / unpark_k), then Pb's full rows until the correction reads them back a slot at a time (park_pb / pb_row): without
 //   it the second pass holds F L, Pb and Pxb -- 192 doubles -- and the step spills 2.4 KB per lane at dim_x 16, every reload a
 //   vmcnt(0).  (The kernel's lot is its output tile, so with PARK the smoothed covariance of step k+1 comes from memory.)
-template <int NX, class Quad, class Io>
-FK_HD int ukf_quad_rts_step_v4(double (&x)[NX], double (&P)[(NX + 3) / 4][NX], const unsigned (&g)[(NX + 3) / 4],
-                               double scale, const UkfQuadModel &mv, Quad &quad, double (&K)[(NX + 3) / 4][NX], Io &io)
+template <int NX, int LN = 4, class Quad, class Io>
+FK_HD int ukf_quad_rts_step_v4(double (&x)[NX], double (&P)[(NX + LN - 1) / LN][NX], const unsigned (&g)[(NX + LN - 1) / LN],
+                               double scale, const UkfQuadModel &mv, Quad &quad, double (&K)[(NX + LN - 1) / LN][NX], Io &io)
 {
-    constexpr int R = (NX + 3) / 4;
-    static_assert(NX >= 4, "dim_x >= 4 (every lane of the quad holds a row)");
+    constexpr int R = (NX + LN - 1) / LN;
+    static_assert((LN == 4 || LN == 8) && NX >= LN, "four or eight lanes per track, every one of them holding a row");
     int st = 0;
     double Pb[R][NX], xb[NX];
+    constexpr bool FUSE = LN == 8 && !Io::PARK;
     {
         double FL[R][NX], Fxo[R];
+        // xb (replicated), the centre point's offset, Pb's first term -- once the sweep has F x
+        auto init_pb = [&] {
+            const double wms = mv.Wp[0], wcs = mv.Wp[1];
+            double wy[NX];
+            FK_UNROLL for (int b = 0; b < NX; ++b) {
+                const double fx = quad_from<LN>(quad, Fxo[b / LN], b % LN);
+                xb[b] = wms * fx;
+                wy[b] = wcs * (fx - xb[b]);
+            }
+            FK_UNROLL for (int r = 0; r < R; ++r) {
+                const double xa = wms * Fxo[r];
+                const double ya = Fxo[r] - xa;
+                FK_UNROLL for (int b = 0; b < NX; ++b) Pb[r][b] = ya * wy[b];
+            }
+            FK_STAGE();
+        };
         {
             double Lw[R][NX];
             {
                 double fc[R];
                 FK_UNROLL for (int r = 0; r < R; ++r) fc[r] = mv.F[g[r] * NX];
-                const bool pd = quad_chol_rows<NX>(P, g, scale, Lw, quad, [&](int j, const double (&lrow)[NX], double ljj, double) {
+                const bool pd = quad_chol_rows<NX, LN>(P, g, scale, Lw, quad, [&](int j, const double (&lrow)[NX], double ljj, double) {
                     double f[R];
                     FK_UNROLL for (int r = 0; r < R; ++r) f[r] = fc[r];
                     if (j + 1 < NX) {
@@ -313,44 +338,37 @@ FK_HD int ukf_quad_rts_step_v4(double (&x)[NX], double (&P)[(NX + 3) / 4][NX], c
                 });
                 if (!pd) st |= ST_NOT_PD;
             }
-            // Pxb = sum_k wp_k l_k f_k' (own rows of L; l_k is zero above the diagonal) -> K
+            // Pxb = sum_k wp_k l_k f_k' (own rows of L; l_k is zero above the diagonal) -> K;  with eight lanes per track (two
+            // row slots: every accumulator fits) Pb takes its rank-one terms from the same gathered columns in the same pass
+            if constexpr (FUSE) init_pb();
             FK_UNROLL for (int k = 0; k < NX; ++k) {
                 const double wp = mv.Wp[2 + k];
                 double wfo[R], wf[NX];
                 FK_UNROLL for (int r = 0; r < R; ++r) wfo[r] = wp * FL[r][k];
-                FK_UNROLL for (int b = 0; b < NX; ++b) wf[b] = quad_from(quad, wfo[b / 4], b % 4);
+                FK_UNROLL for (int b = 0; b < NX; ++b) wf[b] = quad_from<LN>(quad, wfo[b / LN], b % LN);
                 FK_UNROLL for (int r = 0; r < R; ++r) {
-                    if (4 * r + 3 < k) continue;
+                    if (LN * r + LN - 1 < k) continue;
                     FK_UNROLL for (int b = 0; b < NX; ++b) K[r][b] = (k == 0) ? Lw[r][0] * wf[b] : fma(Lw[r][k], wf[b], K[r][b]);
+                }
+                if constexpr (FUSE) {
+                    FK_UNROLL for (int r = 0; r < R; ++r)
+                        FK_UNROLL for (int b = 0; b < NX; ++b) Pb[r][b] = fma(FL[r][k], wf[b], Pb[r][b]);
                 }
                 FK_STAGE();
             }
         }
         if constexpr (Io::PARK) io.park_k(K);
-        // xb (replicated), the centre point's offset, Pb
-        const double wms = mv.Wp[0], wcs = mv.Wp[1];
-        {
-            double wy[NX];
-            FK_UNROLL for (int b = 0; b < NX; ++b) {
-                const double fx = quad_from(quad, Fxo[b / 4], b % 4);
-                xb[b] = wms * fx;
-                wy[b] = wcs * (fx - xb[b]);
+        if constexpr (!FUSE) {
+            init_pb();
+            FK_UNROLL for (int k = 0; k < NX; ++k) {
+                const double wp = mv.Wp[2 + k];
+                double wfo[R], wf[NX];
+                FK_UNROLL for (int r = 0; r < R; ++r) wfo[r] = wp * FL[r][k];
+                FK_UNROLL for (int b = 0; b < NX; ++b) wf[b] = quad_from<LN>(quad, wfo[b / LN], b % LN);
+                FK_UNROLL for (int r = 0; r < R; ++r)
+                    FK_UNROLL for (int b = 0; b < NX; ++b) Pb[r][b] = fma(FL[r][k], wf[b], Pb[r][b]);
+                FK_STAGE();
             }
-            FK_UNROLL for (int r = 0; r < R; ++r) {
-                const double xa = wms * Fxo[r];
-                const double ya = Fxo[r] - xa;
-                FK_UNROLL for (int b = 0; b < NX; ++b) Pb[r][b] = ya * wy[b];
-            }
-            FK_STAGE();
-        }
-        FK_UNROLL for (int k = 0; k < NX; ++k) {
-            const double wp = mv.Wp[2 + k];
-            double wfo[R], wf[NX];
-            FK_UNROLL for (int r = 0; r < R; ++r) wfo[r] = wp * FL[r][k];
-            FK_UNROLL for (int b = 0; b < NX; ++b) wf[b] = quad_from(quad, wfo[b / 4], b % 4);
-            FK_UNROLL for (int r = 0; r < R; ++r)
-                FK_UNROLL for (int b = 0; b < NX; ++b) Pb[r][b] = fma(FL[r][k], wf[b], Pb[r][b]);
-            FK_STAGE();
         }
         {
             double Qr[2][NX];
@@ -371,7 +389,7 @@ FK_HD int ukf_quad_rts_step_v4(double (&x)[NX], double (&P)[(NX + 3) / 4][NX], c
     // ---------------- K = Pxb Pb^-1
     {
         double Lb[R][NX], invd[NX];
-        const bool pd = quad_chol_rows<NX>(Pb, g, 1.0, Lb, quad, [&](int j, const double (&lrow)[NX], double, double inv) {
+        const bool pd = quad_chol_rows<NX, LN>(Pb, g, 1.0, Lb, quad, [&](int j, const double (&lrow)[NX], double, double inv) {
             invd[j] = inv;
             // forward substitution, column j of every own row: w[j] = (Pxb[a][j] - sum_{k<j} w[k] Lb[j][k]) / Lb[j][j]
             FK_UNROLL for (int r = 0; r < R; ++r) {
@@ -386,7 +404,7 @@ FK_HD int ukf_quad_rts_step_v4(double (&x)[NX], double (&P)[(NX + 3) / 4][NX], c
         FK_UNROLL for (int i = NX - 1; i >= 0; --i) {
             double col[NX];
             FK_UNROLL for (int k = 0; k < NX; ++k)
-                if (k > i) col[k] = quad_from(quad, Lb[k / 4][i], k % 4);
+                if (k > i) col[k] = quad_from<LN>(quad, Lb[k / LN][i], k % LN);
             FK_UNROLL for (int r = 0; r < R; ++r) {
                 double acc = K[r][i];
                 FK_UNROLL for (int k = NX - 1; k >= 0; --k)
@@ -407,7 +425,7 @@ FK_HD int ukf_quad_rts_step_v4(double (&x)[NX], double (&P)[(NX + 3) / 4][NX], c
             xo[r] = acc;
         }
         io.own_x(x);
-        FK_UNROLL for (int b = 0; b < NX; ++b) x[b] += quad_from(quad, xo[b / 4], b % 4);
+        FK_UNROLL for (int b = 0; b < NX; ++b) x[b] += quad_from<LN>(quad, xo[b / LN], b % LN);
     }
     FK_STAGE();
     // T1 = K D, D = Pn - Pb: the rows of D a slot at a time from their owners
@@ -423,11 +441,11 @@ FK_HD int ukf_quad_rts_step_v4(double (&x)[NX], double (&P)[(NX + 3) / 4][NX], c
             }
             double Ds[NX];
             FK_UNROLL for (int c = 0; c < NX; ++c) Ds[c] = Pn[s & 1][c] - (Io::PARK ? Pq[Io::PARK ? (s & 1) : 0][c] : Pb[s][c]);
-            FK_UNROLL for (int q = 0; q < 4; ++q) {
-                const int b = 4 * s + q;
+            FK_UNROLL for (int q = 0; q < LN; ++q) {
+                const int b = LN * s + q;
                 if (b >= NX) continue;
                 double Db[NX];
-                FK_UNROLL for (int c = 0; c < NX; ++c) Db[c] = quad_from(quad, Ds[c], q);
+                FK_UNROLL for (int c = 0; c < NX; ++c) Db[c] = quad_from<LN>(quad, Ds[c], q);
                 FK_UNROLL for (int r = 0; r < R; ++r)
                     FK_UNROLL for (int c = 0; c < NX; ++c) T1[r][c] = (b == 0) ? K[r][0] * Db[c] : fma(K[r][b], Db[c], T1[r][c]);
             }
@@ -438,7 +456,7 @@ FK_HD int ukf_quad_rts_step_v4(double (&x)[NX], double (&P)[(NX + 3) / 4][NX], c
     FK_UNROLL for (int r = 0; r < R; ++r) io.own_row(r, P[r]);
     FK_UNROLL for (int j = 0; j < NX; ++j) {
         double Kj[NX];
-        FK_UNROLL for (int c = 0; c < NX; ++c) Kj[c] = quad_from(quad, K[j / 4][c], j % 4);
+        FK_UNROLL for (int c = 0; c < NX; ++c) Kj[c] = quad_from<LN>(quad, K[j / LN][c], j % LN);
         FK_UNROLL for (int r = 0; r < R; ++r) {
             double acc = T1[r][0] * Kj[0];
             FK_UNROLL for (int c = 1; c < NX; ++c) acc = fma(T1[r][c], Kj[c], acc);

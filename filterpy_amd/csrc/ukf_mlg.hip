@@ -41,6 +41,20 @@ struct QuadDpp {
     __device__ __forceinline__ double bcast(double v) const { return quad_bcast<O>(v); }
 };
 
+// eight lanes per track: DPP cannot leave a quad; ds_swizzle's bit mode can -- within every group of 32 lanes the source
+// lane is ((lane & and_mask) | or_mask) ^ xor_mask: and 0x18 keeps the group of eight, or O picks its lane O.  The LDS crossbar,
+// no memory access; two per double like the DPP moves, on the LDS pipe.
+struct OctSwizzle {
+    template <int O>
+    __device__ __forceinline__ double bcast(double v) const
+    {
+        static_assert(O >= 0 && O < 8, "eight lanes per track");
+        constexpr int pat = 0x18 | (O << 5);
+        const int lo = __builtin_amdgcn_ds_swizzle(__double2loint(v), pat), hi = __builtin_amdgcn_ds_swizzle(__double2hiint(v), pat);
+        return __hiloint2double(hi, lo);
+    }
+};
+
 template <int NX, int NZ, int LAYOUT>
 __global__ void __launch_bounds__(BLOCK, (NX <= 8 ? 2 : 1))
 ukf_mlg_kernel(const UkfArgs a)
@@ -225,22 +239,22 @@ ukf_mlg_kernel(const UkfArgs a)
 #endif
 
 // what ukf_quad_rts_step_v4 asks its caller for (fk_ukf_quad.hpp): the neighbours of the step and, with PARK, a parking lot
-template <int NX, int LAYOUT, bool PARKV>
+template <int NX, int LAYOUT, bool PARKV, int LN = 4>
 struct RtsIo {
     static constexpr bool PARK = PARKV;
-    static constexpr int R = (NX + 3) / 4, EP = NX * NX;
+    static constexpr int R = (NX + LN - 1) / LN, EP = NX * NX, TPW = 64 / LN;     // TPW: tracks per wave
     static constexpr bool AOS = LAYOUT == LAYOUT_AOS;
     const double *Ps_t, *ps_next;            // Ps[t] and ps[t+1]: element 0 of the step's block
     unsigned estride;
     const unsigned (&row)[R];
     const unsigned (&off_row)[R];
     double *tile, *xt, *xpark;
-    unsigned g16;
-    __device__ __forceinline__ double &tile_at(unsigned e) const { return tile[AOS ? g16 * (unsigned)EP + e : e * 16u + g16]; }
-    __device__ __forceinline__ double &lot_at(unsigned e) const { return tile[e * 16u + g16]; }      // the lot: [element][track], whatever the layout
+    unsigned g16;                            // the track's index inside the wave
+    __device__ __forceinline__ double &tile_at(unsigned e) const { return tile[AOS ? g16 * (unsigned)EP + e : e * (unsigned)TPW + g16]; }
+    __device__ __forceinline__ double &lot_at(unsigned e) const { return tile[e * (unsigned)TPW + g16]; }      // the lot: [element][track], whatever the layout
     __device__ __forceinline__ void next_x(double (&out)[NX]) const       // xs[k+1]: still staged in xt
     {
-        FK_UNROLL for (int c = 0; c < NX; ++c) out[c] = xt[AOS ? g16 * (unsigned)NX + (unsigned)c : (unsigned)c * 16u + g16];
+        FK_UNROLL for (int c = 0; c < NX; ++c) out[c] = xt[AOS ? g16 * (unsigned)NX + (unsigned)c : (unsigned)c * (unsigned)TPW + g16];
     }
     __device__ __forceinline__ void next_row(int r, double (&out)[NX]) const
     {
@@ -256,7 +270,7 @@ struct RtsIo {
     }
     __device__ __forceinline__ void own_x(double (&out)[NX]) const
     {
-        FK_UNROLL for (int c = 0; c < NX; ++c) out[c] = xpark[c * 16];
+        FK_UNROLL for (int c = 0; c < NX; ++c) out[c] = xpark[c * TPW];
     }
     __device__ __forceinline__ void own_row(int r, double (&out)[NX]) const
     {
@@ -291,16 +305,17 @@ struct RtsIo {
 //   * the full rows of Ps[k] are requested a second time for the correction (the factorisation takes the lower part only);
 //   * the smoothed mean of step k+1 is replicated in the quad (dim_x registers).
 // Reads Xs[k], Ps[k] (the latter 1.6 times); writes xs[k], ps[k], Ks[k]: 8 (2 n + 3 n^2) algorithmic bytes per track-step.
-template <int NX, int LAYOUT>
+template <int NX, int LAYOUT, int LN = 4>
 __global__ void __launch_bounds__(BLOCK, (NX <= 8 ? 2 : 1))
 ukf_mlg_rts_kernel(const UkfRtsArgs a, const double *__restrict__ pF, const double *__restrict__ pQ,
                    const double *__restrict__ pWm, const double *__restrict__ pWc)
 {
-    constexpr int R = (NX + 3) / 4, KS = 2 * NX + 1;
+    constexpr int R = (NX + LN - 1) / LN, KS = 2 * NX + 1, TPW = 64 / LN;      // LN lanes per track, TPW tracks per wave
+    static_assert(LN == 4 || LN == 8, "four or eight lanes per track");
     constexpr bool AOS = LAYOUT == LAYOUT_AOS;
-    constexpr bool PARKV = FK_UMLG_RTS_PARK >= 2 || (FK_UMLG_RTS_PARK == 1 && NX >= 13);
+    constexpr bool PARKV = LN == 4 && (FK_UMLG_RTS_PARK >= 2 || (FK_UMLG_RTS_PARK == 1 && NX >= 13));
     constexpr int EP = NX * NX;
-    constexpr int TILE = 16 * EP, XT = 2 * 16 * NX;              // per wave: one covariance-sized output set; xs[k+1] as staged + Xs[k] parked
+    constexpr int TILE = TPW * EP, XT = 2 * TPW * NX;              // per wave: one covariance-sized output set; xs[k+1] as staged + Xs[k] parked
     constexpr int OFF_F = 0, OFF_Q = EP, OFF_W = 2 * EP;         // [F | Q | Wm | Wc | pair table]
     constexpr int MSZ = OFF_W + 2 * KS + 2 + NX;
     __shared__ double smem[MSZ + (BLOCK / 64) * (TILE + XT)];
@@ -316,14 +331,14 @@ ukf_mlg_rts_kernel(const UkfRtsArgs a, const double *__restrict__ pF, const doub
     const UkfQuadModel mv{smem + OFF_F, smem + OFF_Q, nullptr, nullptr, smem + OFF_W + 2 * KS};
 
     const long N = a.N;
-    const unsigned L = threadIdx.x & 3u;
+    const unsigned L = threadIdx.x & (unsigned)(LN - 1);
     const long iend = a.i0 + a.cnt;
-    long trk = a.i0 + (long)blockIdx.x * (BLOCK / 4) + (threadIdx.x >> 2);
+    long trk = a.i0 + (long)blockIdx.x * (BLOCK / LN) + (threadIdx.x / (unsigned)LN);
     const bool owner = trk < iend;
     if (trk >= iend) trk = iend - 1;
     unsigned row[R];
     FK_UNROLL for (int r = 0; r < R; ++r) {
-        const unsigned g = L + 4u * (unsigned)r;
+        const unsigned g = L + (unsigned)LN * (unsigned)r;
         row[r] = g < (unsigned)NX ? g : (unsigned)NX - 1u;
     }
     unsigned estride = AOS ? 8u : (unsigned)N * 8u;
@@ -332,29 +347,29 @@ ukf_mlg_rts_kernel(const UkfRtsArgs a, const double *__restrict__ pF, const doub
     unsigned off_row[R];
     FK_UNROLL for (int r = 0; r < R; ++r)
         off_row[r] = (AOS ? (unsigned)trk * (unsigned)EP * 8u : (unsigned)trk * 8u) + row[r] * (unsigned)NX * estride;
-    const long w0 = a.i0 + (long)blockIdx.x * (BLOCK / 4) + (long)wave_index() * 16;
-    const unsigned valid = (unsigned)(iend - w0 >= 16 ? 16 : (iend - w0 > 0 ? iend - w0 : 0));
-    const unsigned lane = threadIdx.x & 63u, g16 = lane >> 2;
+    const long w0 = a.i0 + (long)blockIdx.x * (BLOCK / LN) + (long)wave_index() * TPW;
+    const unsigned valid = (unsigned)(iend - w0 >= TPW ? TPW : (iend - w0 > 0 ? iend - w0 : 0));
+    const unsigned lane = threadIdx.x & 63u, g16 = lane / (unsigned)LN;       // g16: the track's index inside the wave
     // element e of the wave's track g16 in the staging tile (laid out like the wave's slab of the output array)
-    auto tile_at = [&](unsigned e) -> double & { return tile[AOS ? g16 * (unsigned)EP + e : e * 16u + g16]; };
-    auto xt_at = [&](unsigned e) -> double & { return xt[AOS ? g16 * (unsigned)NX + e : e * 16u + g16]; };
-    double *xpark = xt + 16 * NX + g16;                          // Xs[k] of the step, [element][track]
+    auto tile_at = [&](unsigned e) -> double & { return tile[AOS ? g16 * (unsigned)EP + e : e * (unsigned)TPW + g16]; };
+    auto xt_at = [&](unsigned e) -> double & { return xt[AOS ? g16 * (unsigned)NX + e : e * (unsigned)TPW + g16]; };
+    double *xpark = xt + TPW * NX + g16;                          // Xs[k] of the step, [element][track]
     // copy-outs of the staged sets (a set that was not asked for, or must not be rewritten: zero tracks -- issued and dropped)
     auto out_cov = [&](double *arr, long t, unsigned vv) {
         double *dst = arr ? arr : a.ps;
         const unsigned v = arr ? vv : 0u;
         ml_wave_fence();
-        if constexpr (AOS) ml_tile_out_aos<EP, 16>(dst + (t * N + w0) * EP, tile, lane, v);
-        else ml_tile_out_soa<EP, 16>(dst + t * N * EP, N, w0, tile, lane, v);
+        if constexpr (AOS) ml_tile_out_aos<EP, TPW>(dst + (t * N + w0) * EP, tile, lane, v);
+        else ml_tile_out_soa<EP, TPW>(dst + t * N * EP, N, w0, tile, lane, v);
         ml_wave_fence();
     };
     auto out_mean = [&](long t, unsigned vv) {
         ml_wave_fence();
-        if constexpr (AOS) ml_tile_out_aos<NX, 16>(a.xs + (t * N + w0) * NX, xt, lane, vv);
-        else ml_tile_out_soa<NX, 16>(a.xs + t * N * NX, N, w0, xt, lane, vv);
+        if constexpr (AOS) ml_tile_out_aos<NX, TPW>(a.xs + (t * N + w0) * NX, xt, lane, vv);
+        else ml_tile_out_soa<NX, TPW>(a.xs + t * N * NX, N, w0, xt, lane, vv);
         ml_wave_fence();
     };
-    QuadDpp quad;
+    std::conditional_t<LN == 4, QuadDpp, OctSwizzle> quad;
 
     // the last step is the filter's own output (xs, ps = Xs.copy(), Ps.copy(); K[T-1] = 0) -- unless this launch continues a
     // chunked call (a.cont): then the window's top step was smoothed by the piece before it and is read back, not rewritten
@@ -386,13 +401,13 @@ ukf_mlg_rts_kernel(const UkfRtsArgs a, const double *__restrict__ pF, const doub
             FK_UNROLL for (int r = 0; r < R; ++r) {
                 const MlView vP(a.Ps + t * N * EP, off_row[r], estride);
                 FK_UNROLL for (int c = 0; c < NX; ++c)
-                    if (c <= 4 * r + 3) P[r][c] = vP.load(c);
+                    if (c <= LN * r + LN - 1) P[r][c] = vP.load(c);
             }
             FK_UNROLL for (int k = 0; k < NX; ++k) x[k] = vx.load(k);
-            FK_UNROLL for (int k = 0; k < NX; ++k) xpark[k * 16] = x[k];
+            FK_UNROLL for (int k = 0; k < NX; ++k) xpark[k * TPW] = x[k];
         }
-        RtsIo<NX, LAYOUT, PARKV> io{a.Ps + t * N * EP, a.ps + (t + 1) * N * EP, estride, row, off_row, tile, xt, xpark, g16};
-        st |= ukf_quad_rts_step_v4<NX>(x, P, row, a.scale, mv, quad, K, io);
+        RtsIo<NX, LAYOUT, PARKV, LN> io{a.Ps + t * N * EP, a.ps + (t + 1) * N * EP, estride, row, off_row, tile, xt, xpark, g16};
+        st |= ukf_quad_rts_step_v4<NX, LN>(x, P, row, a.scale, mv, quad, K, io);
         FK_STAGE();
         ml_wave_fence();
         FK_UNROLL for (int k = 0; k < NX; ++k) xt_at((unsigned)k) = x[k];
@@ -413,6 +428,7 @@ ukf_mlg_rts_kernel(const UkfRtsArgs a, const double *__restrict__ pF, const doub
         int s = st | (fin ? 0 : ST_NONFINITE);
         s |= __builtin_amdgcn_mov_dpp(s, 0xB1, 0xf, 0xf, true);
         s |= __builtin_amdgcn_mov_dpp(s, 0x4E, 0xf, 0xf, true);
+        if constexpr (LN == 8) s |= __builtin_amdgcn_mov_dpp(s, 0x104, 0xf, 0xf, true);      // row_shl:4 : lanes 0..3 of the group see lanes 4..7
         if (L == 0) a.status[trk] = a.status_or ? (a.status[trk] | s) : s;
     }
 }
@@ -445,6 +461,18 @@ int FK_UMLG_CAT(launch_ukf_mlg_rts_, FK_NX)(const UkfRtsArgs &a, const double *F
 {
     using namespace FK_UMLG_CAT(ukf_mlg_, FK_NX);
     if (a.n != FK_NX) return 1;
+    // lanes per track: four; eight from dim_x 13, where the four-lane step is 65-105 KB of code for a 64 KB instruction cache
+    // (profiles/r04/lease_q: 85 us per wave-step at dim_x 16).  FK_UKF_MLG_RTS_LANES=4 | 8 forces one (8: dim_x >= 9 only).
+    static const int forced = [] { const char *v = getenv("FK_UKF_MLG_RTS_LANES"); return v ? atoi(v) : 0; }();
+    [[maybe_unused]] const bool oct = FK_NX >= 9 && (forced == 8 || (forced != 4 && FK_NX >= 13));
+#if FK_NX >= 9
+    if (oct) {
+        const dim3 grid((unsigned)((a.cnt + BLOCK / 8 - 1) / (BLOCK / 8))), block(BLOCK);
+        if (layout == FK_LAYOUT_AOS) hipLaunchKernelGGL((ukf_mlg_rts_kernel<FK_NX, LAYOUT_AOS, 8>), grid, block, 0, s, a, F, Q, Wm, Wc);
+        else hipLaunchKernelGGL((ukf_mlg_rts_kernel<FK_NX, LAYOUT_SOA, 8>), grid, block, 0, s, a, F, Q, Wm, Wc);
+        return check_launch("ukf_mlg_rts_kernel<8 lanes>");
+    }
+#endif
     const dim3 grid((unsigned)((a.cnt + BLOCK / 4 - 1) / (BLOCK / 4))), block(BLOCK);
     if (layout == FK_LAYOUT_AOS) hipLaunchKernelGGL((ukf_mlg_rts_kernel<FK_NX, LAYOUT_AOS>), grid, block, 0, s, a, F, Q, Wm, Wc);
     else hipLaunchKernelGGL((ukf_mlg_rts_kernel<FK_NX, LAYOUT_SOA>), grid, block, 0, s, a, F, Q, Wm, Wc);

@@ -13,10 +13,11 @@
 namespace {
 
 struct FiberQuad {
-    ucontext_t main_ctx, ctx[4];
-    std::vector<char> stack[4];
-    double slot[2][4];
-    long exchanges[4] = {0, 0, 0, 0};
+    int lanes = 4;                               // lanes per track: 4 (a quad) or 8
+    ucontext_t main_ctx, ctx[8];
+    std::vector<char> stack[8];
+    double slot[2][8];
+    long exchanges[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     void (*body)(void *, int) = nullptr;
     void *arg = nullptr;
 };
@@ -35,23 +36,24 @@ struct HostQuad {
         const unsigned p = calls++ & 1u;
         fq->slot[p][lane] = v;
         fq->exchanges[lane]++;
-        swapcontext(&fq->ctx[lane], &fq->ctx[(lane + 1) & 3]);      // round the quad; back here once all four have stored
+        swapcontext(&fq->ctx[lane], &fq->ctx[(lane + 1) % fq->lanes]);   // round the group; back here once every lane has stored
         return fq->slot[p][O];
     }
 };
 
-void run_quad(void (*body)(void *, int), void *arg)
+void run_quad(void (*body)(void *, int), void *arg, int lanes = 4)
 {
     FiberQuad fq;
+    fq.lanes = lanes;
     fq.body = body;
     fq.arg = arg;
     g_fq = &fq;
-    for (int l = 0; l < 4; ++l) {
+    for (int l = 0; l < lanes; ++l) {
         fq.stack[l].resize(1 << 20);
         getcontext(&fq.ctx[l]);
         fq.ctx[l].uc_stack.ss_sp = fq.stack[l].data();
         fq.ctx[l].uc_stack.ss_size = fq.stack[l].size();
-        fq.ctx[l].uc_link = l < 3 ? &fq.ctx[l + 1] : &fq.main_ctx;   // a lane that returns hands over to the next one
+        fq.ctx[l].uc_link = l < lanes - 1 ? &fq.ctx[l + 1] : &fq.main_ctx;   // a lane that returns hands over to the next one
         makecontext(&fq.ctx[l], (void (*)())fiber_entry, 1, l);
     }
     swapcontext(&fq.main_ctx, &fq.ctx[0]);
@@ -157,12 +159,12 @@ struct RtsJob {
     const double *F, *Q, *Wp, *Xs, *Ps;
     double scale;
     double *xs, *ps, *Ks;
-    int st[4];
+    int st[8];
 };
 
-template <int NX, bool PARKV>
+template <int NX, bool PARKV, int LN = 4>
 struct HostRtsIo {
-    static constexpr int R = (NX + 3) / 4;
+    static constexpr int R = (NX + LN - 1) / LN;
     static constexpr bool PARK = PARKV;
     const RtsJob<NX> &job;
     const unsigned (&g)[R];
@@ -180,16 +182,16 @@ struct HostRtsIo {
     void pb_row(int r, double (&out)[NX]) { for (int c = 0; c < NX; ++c) out[c] = lot[r][c]; }
 };
 
-template <int NX, bool PARKV>
+template <int NX, bool PARKV, int LN = 4>
 void quad_rts_lane(void *vp, int lane)
 {
-    constexpr int R = (NX + 3) / 4;
+    constexpr int R = (NX + LN - 1) / LN;
     auto &job = *static_cast<RtsJob<NX> *>(vp);
     HostQuad quad{g_fq, lane};
     unsigned g[R];
     bool dup[R];
     for (int r = 0; r < R; ++r) {
-        const unsigned row = 4u * (unsigned)r + (unsigned)lane;
+        const unsigned row = (unsigned)LN * (unsigned)r + (unsigned)lane;
         dup[r] = row >= (unsigned)NX;
         g[r] = dup[r] ? (unsigned)NX - 1u : row;
     }
@@ -213,9 +215,9 @@ void quad_rts_lane(void *vp, int lane)
         double x[NX], P[R][NX], K[R][NX];
         for (int i = 0; i < NX; ++i) x[i] = job.Xs[t * NX + i];
         for (int r = 0; r < R; ++r)
-            for (int c = 0; c < NX; ++c) P[r][c] = c <= 4 * r + 3 ? job.Ps[(t * NX + g[r]) * NX + c] : -1e300;   // only the lower part is handed over
-        HostRtsIo<NX, PARKV> io{job, g, xn, Pn, t, {}};
-        st |= fk::ukf_quad_rts_step_v4<NX>(x, P, g, job.scale, mv, quad, K, io);
+            for (int c = 0; c < NX; ++c) P[r][c] = c <= LN * r + LN - 1 ? job.Ps[(t * NX + g[r]) * NX + c] : -1e300;   // only the lower part is handed over
+        HostRtsIo<NX, PARKV, LN> io{job, g, xn, Pn, t, {}};
+        st |= fk::ukf_quad_rts_step_v4<NX, LN>(x, P, g, job.scale, mv, quad, K, io);
         for (int i = 0; i < NX; ++i) {
             if (lane == 0) job.xs[t * NX + i] = x[i];
             else if (memcmp(&job.xs[t * NX + i], &x[i], 8) != 0) st |= 1 << 20;
@@ -234,7 +236,7 @@ void quad_rts_lane(void *vp, int lane)
     job.st[lane] = st;
 }
 
-template <int NX, bool PARKV>
+template <int NX, bool PARKV, int LN = 4>
 int ukf_quad_rts_batch(long T, const double *F, const double *Q, const double *Wm, const double *Wc, double scale,
                        const double *Xs, const double *Ps, double *xs, double *ps, double *Ks)
 {
@@ -244,9 +246,10 @@ int ukf_quad_rts_batch(long T, const double *F, const double *Q, const double *W
     std::copy(Wc, Wc + KS, wc);
     fk::make_pair_table<NX>(wm, wc, wp);
     if (!fk::pair_weights_symmetric<NX>(wm, wc)) return -2;
-    RtsJob<NX> job{T, F, Q, wp, Xs, Ps, scale, xs, ps, Ks, {0, 0, 0, 0}};
-    run_quad(&quad_rts_lane<NX, PARKV>, &job);
-    if (job.st[0] != job.st[1] || job.st[0] != job.st[2] || job.st[0] != job.st[3]) return 1 << 22;
+    RtsJob<NX> job{T, F, Q, wp, Xs, Ps, scale, xs, ps, Ks, {0, 0, 0, 0, 0, 0, 0, 0}};
+    run_quad(&quad_rts_lane<NX, PARKV, LN>, &job, LN);
+    for (int l = 1; l < LN; ++l)
+        if (job.st[l] != job.st[0]) return 1 << 22;
     return job.st[0];
 }
 
@@ -267,6 +270,16 @@ extern "C" int hc_ukf_quad_rts_park_v4(int n, long T, const double *F, const dou
 {
 #define GO(NXV) if (n == NXV) return ukf_quad_rts_batch<NXV, true>(T, F, Q, Wm, Wc, scale, Xs, Ps, xs, ps, Ks)
     GO(4); GO(5); GO(7); GO(8); GO(9); GO(10); GO(11); GO(12); GO(13); GO(14); GO(15); GO(16);
+#undef GO
+    return -1;
+}
+
+// ... on EIGHT lanes per track (LN = 8: what the smoother at dim_x >= 13 is headed for; dim_x >= 8)
+extern "C" int hc_ukf_oct_rts_v4(int n, long T, const double *F, const double *Q, const double *Wm, const double *Wc,
+                                 double scale, const double *Xs, const double *Ps, double *xs, double *ps, double *Ks)
+{
+#define GO(NXV) if (n == NXV) return ukf_quad_rts_batch<NXV, false, 8>(T, F, Q, Wm, Wc, scale, Xs, Ps, xs, ps, Ks)
+    GO(8); GO(9); GO(10); GO(11); GO(12); GO(13); GO(14); GO(15); GO(16);
 #undef GO
     return -1;
 }

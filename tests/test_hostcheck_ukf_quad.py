@@ -216,3 +216,22 @@ def test_quad_step_is_as_accurate_as_the_one_lane_step_on_ill_conditioned_covari
         eq, eo = max(rel(a[0], mu), rel(a[1], cov)), max(rel(b[0], mu), rel(b[1], cov))
         worst = max(worst, eq / max(eo, 1e-13))
     assert worst < 5.0, worst
+
+
+@pytest.mark.parametrize("n", [8, 9, 10, 11, 12, 13, 14, 15, 16])
+def test_oct_smoother_step_matches_the_oracle_and_the_quad(quad_lib, n):
+    """The same backward step on EIGHT lanes per track (two row slots per lane at dim_x 16; the exchange is still "the value lane
+    o of my group holds"): against the oracle at 1e-10, and against the four-lane run -- same sums in the same order, only the
+    ownership of the rows differs, so the two agree to the last bits of a few sums that rows computed by different lanes enter."""
+    alpha, beta, kappa = .3, 2., 3. - n
+    r, F, H, Q, R, x0, P0 = _model(n, 2, n * 7 + 1)
+    zs = r.standard_normal((18, 2))
+    Wm, Wc = ukf_oracle.merwe_weights(n, alpha, beta, kappa)
+    mu, cov = ukf_oracle.ukf_batch_filter(x0, P0, list(zs), lambda s, d: F @ s, lambda s: H @ s, 0.1, Q, R, alpha, beta, kappa)
+    xr, Pr, Kr = ukf_oracle.ukf_rts_smoother(mu, cov, lambda s, d: F @ s, 0.1, Q, alpha, beta, kappa)
+    a = _rts(quad_lib, "hc_ukf_oct_rts_v4", n, F, Q, Wm, Wc, alpha ** 2 * (n + kappa), mu, cov)
+    b = _rts(quad_lib, "hc_ukf_quad_rts_v4", n, F, Q, Wm, Wc, alpha ** 2 * (n + kappa), mu, cov)
+    assert relrows(a[0], xr) < 1e-10 and relrows(a[1], Pr) < 1e-10 and relrows(a[2][:-1], Kr[:-1]) < 1e-10
+    for u, v in zip(a, b):
+        assert relrows(u[:-1], v[:-1]) < 1e-12
+    assert np.array_equal(a[0][-1], mu[-1]) and np.array_equal(a[1][-1], cov[-1]) and not a[2][-1].any()

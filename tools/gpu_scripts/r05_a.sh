@@ -20,6 +20,18 @@ for l in sys.stdin:
     d=json.loads(l); print(d['kernel'][:48], 'ms=%.3f'%d['ms'], 'frac=%.3f'%d.get('frac_of_8TBs',0), d.get('parity_max_rel'))
 "
     done
+    # the smoother at dim_x 13..16: eight lanes per track (the default there: 42-64 KB of code) against four (72-105 KB)
+    for ln in 8 4; do
+        FK_UKF_MLG_RTS_LANES=$ln timeout 200 python $R/tools/bench_ukf.py --dims 14x4,16x4 --N 50000 --T 50 --dense 2>>$O/bench_lanes.err | grep smoother | python -c "
+import sys,json
+for l in sys.stdin:
+    d=json.loads(l); d['rts_lanes']=$ln; print(json.dumps(d))
+" | tee -a $O/ukf_rts_lanes_ab.jsonl | python -c "
+import sys,json
+for l in sys.stdin:
+    d=json.loads(l); print('lanes', d['rts_lanes'], d['kernel'][:48], 'ms=%.3f'%d['ms'], 'frac=%.3f'%d.get('frac_of_8TBs',0), d.get('parity_max_rel'))
+"
+    done
     # the one-lane classes at dim_x 8 / 9 (one wave per SIMD, scratch) against the four-lane kernels on the same calls
     FK_UKF_MLG_MIN_NX=7 timeout 300 python -m pytest $R/tests/test_gpu_ukf_mlg.py -m gpu -q -x -k "small_dims" -p no:cacheprovider 2>&1 | tail -2 | cut -c1-200
     for d in 8x4 9x3; do
