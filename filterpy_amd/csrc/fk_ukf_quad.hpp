@@ -87,12 +87,12 @@ FK_HD bool quad_chol_rows(const double (&P)[(NX + LN - 1) / LN][NX], const unsig
 
 // zin / has_z_fn(): the step's measurement and whether there is one -- both are first looked at in the UPDATE half (has_z_fn is
 // called there), so a kernel that carries them as loads in flight waits for them a predict half after it asked.
-template <int NX, int NZ, class Quad, class HasZ>
-FK_HD int ukf_quad_step_v4(double (&x)[NX], double (&P)[(NX + 3) / 4][NX], const unsigned (&g)[(NX + 3) / 4],
+template <int NX, int NZ, int LN = 4, class Quad, class HasZ>
+FK_HD int ukf_quad_step_v4(double (&x)[NX], double (&P)[(NX + LN - 1) / LN][NX], const unsigned (&g)[(NX + LN - 1) / LN],
                            const double (&zin)[NZ], HasZ &&has_z_fn, double scale, const UkfQuadModel &mv, Quad &quad)
 {
-    constexpr int R = (NX + 3) / 4;
-    static_assert(NX >= 4 && NZ >= 1 && NZ <= 8, "dim_x >= 4 (every lane of the quad holds a row), dim_z <= 8 (two rows of H L per lane)");
+    constexpr int R = (NX + LN - 1) / LN;
+    static_assert((LN == 4 || LN == 8) && NX >= LN && NZ >= 1 && NZ <= 8, "four or eight lanes per track, every one holding a row; dim_z <= 8 (at most two rows of H L per lane)");
     int st = 0;
     // ---------------- predict (UKF.py:400-411)
     {
@@ -100,7 +100,7 @@ FK_HD int ukf_quad_step_v4(double (&x)[NX], double (&P)[(NX + 3) / 4][NX], const
         {
             double Lw[R][NX], fc[R];                          // fc: column j of F at the lane's rows, requested a column ahead
             FK_UNROLL for (int r = 0; r < R; ++r) fc[r] = mv.F[g[r] * NX];
-            const bool pd = quad_chol_rows<NX>(P, g, scale, Lw, quad, [&](int j, const double (&lrow)[NX], double ljj, double) {
+            const bool pd = quad_chol_rows<NX, LN>(P, g, scale, Lw, quad, [&](int j, const double (&lrow)[NX], double ljj, double) {
                 double f[R];
                 FK_UNROLL for (int r = 0; r < R; ++r) f[r] = fc[r];
                 if (j + 1 < NX) {
@@ -120,7 +120,7 @@ FK_HD int ukf_quad_step_v4(double (&x)[NX], double (&P)[(NX + 3) / 4][NX], const
         {
             double wy[NX];
             FK_UNROLL for (int b = 0; b < NX; ++b) {
-                const double fx = quad_from(quad, Fxo[b / 4], b % 4);
+                const double fx = quad_from<LN>(quad, Fxo[b / LN], b % LN);
                 x[b] = wms * fx;
                 wy[b] = wcs * (fx - x[b]);
             }
@@ -136,7 +136,7 @@ FK_HD int ukf_quad_step_v4(double (&x)[NX], double (&P)[(NX + 3) / 4][NX], const
             const double wp = mv.Wp[2 + k];
             double wfo[R], wf[NX];
             FK_UNROLL for (int r = 0; r < R; ++r) wfo[r] = wp * FL[r][k];
-            FK_UNROLL for (int b = 0; b < NX; ++b) wf[b] = quad_from(quad, wfo[b / 4], b % 4);
+            FK_UNROLL for (int b = 0; b < NX; ++b) wf[b] = quad_from<LN>(quad, wfo[b / LN], b % LN);
             FK_UNROLL for (int r = 0; r < R; ++r)
                 FK_UNROLL for (int b = 0; b < NX; ++b) P[r][b] = fma(FL[r][k], wf[b], P[r][b]);
             FK_STAGE();
@@ -158,18 +158,18 @@ FK_HD int ukf_quad_step_v4(double (&x)[NX], double (&P)[(NX + 3) / 4][NX], const
     // ---------------- update (UKF.py:462-481), sigma points regenerated from the prior (:407)
     {
         // H L, its rows dealt out like P's: lane q accumulates rows q and q + 4 (dim_z <= 8; a slot past the last row duplicates it)
-        constexpr int RZ = (NZ + 3) / 4;
+        constexpr int RZ = (NZ + LN - 1) / LN;
         double Lw[R][NX], HLo[RZ][NX];
         unsigned hrow[RZ];
         bool upd_pd;
         FK_UNROLL for (int rz = 0; rz < RZ; ++rz) {
-            const unsigned hr = g[0] + 4u * (unsigned)rz;                            // g[0] = q (NX >= 4)
+            const unsigned hr = g[0] + (unsigned)LN * (unsigned)rz;                  // g[0] = q (NX >= LN)
             hrow[rz] = hr < (unsigned)NZ ? hr : (unsigned)NZ - 1u;
         }
         {
             double hc[RZ];
             FK_UNROLL for (int rz = 0; rz < RZ; ++rz) hc[rz] = mv.H[hrow[rz] * NX];
-            const bool pd = quad_chol_rows<NX>(P, g, scale, Lw, quad, [&](int j, const double (&lrow)[NX], double ljj, double) {
+            const bool pd = quad_chol_rows<NX, LN>(P, g, scale, Lw, quad, [&](int j, const double (&lrow)[NX], double ljj, double) {
                 double h[RZ];
                 FK_UNROLL for (int rz = 0; rz < RZ; ++rz) h[rz] = hc[rz];
                 if (j + 1 < NX) {
@@ -205,7 +205,7 @@ FK_HD int ukf_quad_step_v4(double (&x)[NX], double (&P)[(NX + 3) / 4][NX], const
         FK_UNROLL for (int k = 0; k < NX; ++k) {
             const double wp = mv.Wp[2 + k];
             double hl[NZ], wh[NZ];                             // column k of H L, gathered from the lanes that hold its rows
-            FK_UNROLL for (int c = 0; c < NZ; ++c) hl[c] = quad_from(quad, HLo[c / 4][k], c % 4);
+            FK_UNROLL for (int c = 0; c < NZ; ++c) hl[c] = quad_from<LN>(quad, HLo[c / LN][k], c % LN);
             FK_UNROLL for (int c = 0; c < NZ; ++c) wh[c] = wp * hl[c];
             FK_UNROLL for (int r = 0; r < NZ; ++r)
                 FK_UNROLL for (int c = 0; c < NZ; ++c)
@@ -213,7 +213,7 @@ FK_HD int ukf_quad_step_v4(double (&x)[NX], double (&P)[(NX + 3) / 4][NX], const
             // the cross variance's own rows: l_k is zero above the diagonal (slots whose rows all lie above row k: skipped;
             // a row above it inside a slot: its element of L is a stored zero)
             FK_UNROLL for (int r = 0; r < R; ++r) {
-                if (4 * r + 3 < k) continue;
+                if (LN * r + LN - 1 < k) continue;
                 FK_UNROLL for (int c = 0; c < NZ; ++c)
                     Ko[r * NZ + c] = (k == 0) ? Lw[r][0] * wh[c] : fma(Lw[r][k], wh[c], Ko[r * NZ + c]);
             }
@@ -244,7 +244,7 @@ FK_HD int ukf_quad_step_v4(double (&x)[NX], double (&P)[(NX + 3) / 4][NX], const
         // x += K (z - zp) ; P -= K (S K') : row b of K from its owner serves x[b] and column b of P
         FK_UNROLL for (int b = 0; b < NX; ++b) {
             double Kb[NZ], sk[NZ];
-            FK_UNROLL for (int c = 0; c < NZ; ++c) Kb[c] = quad_from(quad, Ko[(b / 4) * NZ + c], b % 4);
+            FK_UNROLL for (int c = 0; c < NZ; ++c) Kb[c] = quad_from<LN>(quad, Ko[(b / LN) * NZ + c], b % LN);
             {
                 double acc = Kb[0] * zc[0];
                 FK_UNROLL for (int c = 1; c < NZ; ++c) acc = fma(Kb[c], zc[c], acc);

@@ -42,8 +42,8 @@ struct QuadDpp {
 };
 
 // eight lanes per track: DPP cannot leave a quad; ds_swizzle's bit mode can -- within every group of 32 lanes the source
-// lane is ((lane & and_mask) | or_mask) ^ xor_mask: and 0x18 keeps the group of eight, or O picks its lane O.  The LDS crossbar,
-// no memory access; two per double like the DPP moves, on the LDS pipe.
+// lane is ((lane & and_mask) | or_mask) ^ xor_mask: and 0x18 keeps the group of eight, or O picks its lane O (the assembler
+// prints these as swizzle(BROADCAST,8,O)).  The LDS crossbar, no memory access; two per double like the DPP moves, on the LDS pipe.
 struct OctSwizzle {
     template <int O>
     __device__ __forceinline__ double bcast(double v) const
@@ -55,15 +55,16 @@ struct OctSwizzle {
     }
 };
 
-template <int NX, int NZ, int LAYOUT>
+template <int NX, int NZ, int LAYOUT, int LN = 4>
 __global__ void __launch_bounds__(BLOCK, (NX <= 8 ? 2 : 1))
 ukf_mlg_kernel(const UkfArgs a)
 {
-    constexpr int R = (NX + 3) / 4, KS = 2 * NX + 1;
+    constexpr int R = (NX + LN - 1) / LN, KS = 2 * NX + 1, TPW = 64 / LN;      // LN lanes per track, TPW tracks per wave
+    static_assert(LN == 4 || LN == 8, "four or eight lanes per track");
     using LM = LdsModel<NX, NZ>;
     constexpr bool AOS = LAYOUT == LAYOUT_AOS;
     constexpr int EP = NX * NX;
-    constexpr int TILE = 16 * EP;                                // one output set of a wave's 16 tracks (x reuses its head)
+    constexpr int TILE = TPW * EP;                               // one output set of a wave's tracks (x reuses its head)
     constexpr int MSZ = LM::SIZE + 2 * KS + 2 + NX;              // [F | Q | H | R | Wm | Wc | pair table]
     __shared__ double smem[MSZ + (BLOCK / 64) * TILE];
     double *tile = smem + MSZ + (threadIdx.x >> 6) * TILE;
@@ -80,14 +81,14 @@ ukf_mlg_kernel(const UkfArgs a)
     const UkfQuadModel mv{smem + LM::OFF_F, smem + LM::OFF_Q, smem + LM::OFF_H, smem + LM::OFF_R, smem + LM::SIZE + 2 * KS};
 
     const long N = a.N;
-    const unsigned L = threadIdx.x & 3u;
+    const unsigned L = threadIdx.x & (unsigned)(LN - 1);
     const long iend = a.i0 + a.cnt;
-    long trk = a.i0 + (long)blockIdx.x * (BLOCK / 4) + (threadIdx.x >> 2);
+    long trk = a.i0 + (long)blockIdx.x * (BLOCK / LN) + (threadIdx.x / (unsigned)LN);
     const bool owner = trk < iend;                               // tail quads duplicate the last track; they never write the final state
     if (trk >= iend) trk = iend - 1;
     unsigned row[R];                                             // slot r holds row L + 4 r (clamped: see the header)
     FK_UNROLL for (int r = 0; r < R; ++r) {
-        const unsigned g = L + 4u * (unsigned)r;
+        const unsigned g = L + (unsigned)LN * (unsigned)r;
         row[r] = g < (unsigned)NX ? g : (unsigned)NX - 1u;
     }
     unsigned estride = AOS ? 8u : (unsigned)N * 8u;
@@ -97,9 +98,9 @@ ukf_mlg_kernel(const UkfArgs a)
     unsigned off_row[R];
     FK_UNROLL for (int r = 0; r < R; ++r)
         off_row[r] = (AOS ? (unsigned)trk * (unsigned)EP * 8u : (unsigned)trk * 8u) + row[r] * (unsigned)NX * estride;
-    const long w0 = a.i0 + (long)blockIdx.x * (BLOCK / 4) + (long)wave_index() * 16;      // scalar: wave_index()
-    const unsigned valid = (unsigned)(iend - w0 >= 16 ? 16 : (iend - w0 > 0 ? iend - w0 : 0));
-    const unsigned lane = threadIdx.x & 63u, g16 = lane >> 2;
+    const long w0 = a.i0 + (long)blockIdx.x * (BLOCK / LN) + (long)wave_index() * TPW;    // scalar: wave_index()
+    const unsigned valid = (unsigned)(iend - w0 >= TPW ? TPW : (iend - w0 > 0 ? iend - w0 : 0));
+    const unsigned lane = threadIdx.x & 63u, g16 = lane / (unsigned)LN;       // g16: the track's index inside the wave
     const uint8_t *mask_or_dummy = a.mask ? a.mask : reinterpret_cast<const uint8_t *>(a.z);
 
     double P[R][NX], x[NX];
@@ -123,7 +124,7 @@ ukf_mlg_kernel(const UkfArgs a)
     // scratch.  Where the two images per wave do not fit next to the tiles (dim_x 16 with dim_z >= 6): the register loads.
     constexpr int ZIMGD = LaneRecordDma<NZ, LAYOUT>::IMG_DOUBLES + 32;        // + 64 dwords: the mask bytes' dwords
     constexpr bool ZDMA = FK_UMLG_ZDMA && (long)(MSZ + (BLOCK / 64) * TILE) * 8 + 64 + (long)(BLOCK / 64) * 2 * ZIMGD * 8 <= 160 * 1024;
-    constexpr int ZST = AOS ? (8 * NX + 63) / 64 + (8 * EP + 63) / 64 : 2 * ((8 * NX + 63) / 64 + (8 * EP + 63) / 64);
+    constexpr int ZST = AOS ? (TPW / 2 * NX + 63) / 64 + (TPW / 2 * EP + 63) / 64 : 2 * ((TPW / 2 * NX + 63) / 64 + (TPW / 2 * EP + 63) / 64);
     constexpr int ZWAIT = ZST < 63 ? ZST : 63;
     __shared__ double s_zd[ZDMA ? (BLOCK / 64) * 2 * ZIMGD : 1];
     LaneRecordDma<NZ, LAYOUT> zdma;
@@ -157,7 +158,7 @@ ukf_mlg_kernel(const UkfArgs a)
         FK_UNROLL for (int c = 0; c < NZ; ++c) asm volatile("" ::"v"(zn[c]));
         asm volatile("" ::"v"(hn));
     }
-    QuadDpp quad;
+    std::conditional_t<LN == 4, QuadDpp, OctSwizzle> quad;
     const bool st_m = a.means != nullptr, st_c = a.covs != nullptr;
     _Pragma("nounroll") for (long t = 0; t < a.T; ++t) {
         if constexpr (ZDMA) {
@@ -177,7 +178,7 @@ ukf_mlg_kernel(const UkfArgs a)
             const unsigned hb = mask_or_dummy[tn * N + trk];
             hn = a.mask ? hb : 1u;
         }
-        st |= ukf_quad_step_v4<NX, NZ>(x, P, row, z, [&] { return has_z; }, a.scale, mv, quad);
+        st |= ukf_quad_step_v4<NX, NZ, LN>(x, P, row, z, [&] { return has_z; }, a.scale, mv, quad);
         FK_STAGE();
         // the step's outputs through the wave's tile, 16-byte units (an output that was not asked for: a descriptor of zero
         // tracks -- issued and dropped, no branch in the loop)
@@ -188,23 +189,23 @@ ukf_mlg_kernel(const UkfArgs a)
                 ml_wave_fence();
                 FK_UNROLL for (int k = 0; k < NX; ++k) tile[g16 * NX + k] = x[k];          // the quad writes the same value
                 ml_wave_fence();
-                ml_tile_out_aos<NX, 16>(md + (t * N + w0) * NX, tile, lane, vm);
+                ml_tile_out_aos<NX, TPW>(md + (t * N + w0) * NX, tile, lane, vm);
                 ml_wave_fence();
                 FK_UNROLL for (int r = 0; r < R; ++r)
                     FK_UNROLL for (int c = 0; c < NX; ++c) tile[g16 * EP + row[r] * NX + c] = P[r][c];
                 ml_wave_fence();
-                ml_tile_out_aos<EP, 16>(cd + (t * N + w0) * EP, tile, lane, vc);
+                ml_tile_out_aos<EP, TPW>(cd + (t * N + w0) * EP, tile, lane, vc);
                 ml_wave_fence();
             } else {
                 ml_wave_fence();
-                FK_UNROLL for (int k = 0; k < NX; ++k) tile[k * 16 + g16] = x[k];
+                FK_UNROLL for (int k = 0; k < NX; ++k) tile[k * TPW + g16] = x[k];
                 ml_wave_fence();
-                ml_tile_out_soa<NX, 16>(md + t * N * NX, N, w0, tile, lane, vm);
+                ml_tile_out_soa<NX, TPW>(md + t * N * NX, N, w0, tile, lane, vm);
                 ml_wave_fence();
                 FK_UNROLL for (int r = 0; r < R; ++r)
-                    FK_UNROLL for (int c = 0; c < NX; ++c) tile[(row[r] * NX + c) * 16 + g16] = P[r][c];
+                    FK_UNROLL for (int c = 0; c < NX; ++c) tile[(row[r] * NX + c) * TPW + g16] = P[r][c];
                 ml_wave_fence();
-                ml_tile_out_soa<EP, 16>(cd + t * N * EP, N, w0, tile, lane, vc);
+                ml_tile_out_soa<EP, TPW>(cd + t * N * EP, N, w0, tile, lane, vc);
                 ml_wave_fence();
             }
         }
@@ -227,6 +228,7 @@ ukf_mlg_kernel(const UkfArgs a)
             int s = st | (fin ? 0 : ST_NONFINITE);
             s |= __builtin_amdgcn_mov_dpp(s, 0xB1, 0xf, 0xf, true);
             s |= __builtin_amdgcn_mov_dpp(s, 0x4E, 0xf, 0xf, true);
+            if constexpr (LN == 8) s |= __builtin_amdgcn_mov_dpp(s, 0x104, 0xf, 0xf, true);  // row_shl:4 : lanes 0..3 of the group see lanes 4..7
             if (L == 0) a.status[trk] = a.status_or ? (a.status[trk] | s) : s;
         }
     }
@@ -440,13 +442,22 @@ int FK_UMLG_CAT(launch_ukf_mlg_, FK_NX)(const UkfArgs &a, int layout, hipStream_
 {
     using namespace FK_UMLG_CAT(ukf_mlg_, FK_NX);
     if (a.n != FK_NX || a.m < 1 || a.m > 8) return 1;
-    const dim3 grid((unsigned)((a.cnt + BLOCK / 4 - 1) / (BLOCK / 4))), block(BLOCK);
+    // lanes per track: four; eight where four would spill kilobytes (dim_z >= 5 from dim_x 13: S, its factor and two rows of H L
+    // per lane on top of the rows of P- and L).  FK_UKF_MLG_LANES=4 | 8 forces one (8: dim_x >= 9, dim_z as compiled below).
+    static const int forced = [] { const char *v = getenv("FK_UKF_MLG_LANES"); return v ? atoi(v) : 0; }();
+    [[maybe_unused]] const bool oct = FK_NX >= 9 && (forced == 8 || (forced != 4 && FK_NX >= 13 && a.m >= 5));
+    const dim3 grid((unsigned)((a.cnt + BLOCK / 4 - 1) / (BLOCK / 4))), grid8((unsigned)((a.cnt + BLOCK / 8 - 1) / (BLOCK / 8))), block(BLOCK);
 // (FK_UMLG_ONLY_NZ=<dim_z>: a one-off build with that filter instantiation alone, for looking at its code)
 #ifndef FK_UMLG_ONLY_NZ
 #define FK_UMLG_ONLY_NZ 0
 #endif
 #define GO(NZV)                                                                                                         \
-    if constexpr (FK_UMLG_ONLY_NZ == 0 || FK_UMLG_ONLY_NZ == NZV) if (a.m == NZV) {                                                                                                   \
+    if constexpr (FK_UMLG_ONLY_NZ == 0 || FK_UMLG_ONLY_NZ == NZV) if (a.m == NZV) {                                      \
+        if constexpr (FK_NX >= 9) if (oct) {                                                                            \
+            if (layout == FK_LAYOUT_AOS) hipLaunchKernelGGL((ukf_mlg_kernel<FK_NX, NZV, LAYOUT_AOS, (FK_NX >= 9 ? 8 : 4)>), grid8, block, 0, s, a); \
+            else hipLaunchKernelGGL((ukf_mlg_kernel<FK_NX, NZV, LAYOUT_SOA, (FK_NX >= 9 ? 8 : 4)>), grid8, block, 0, s, a); \
+            return check_launch("ukf_mlg_kernel<8 lanes>");                                                             \
+        }                                                                                                               \
         if (layout == FK_LAYOUT_AOS) hipLaunchKernelGGL((ukf_mlg_kernel<FK_NX, NZV, LAYOUT_AOS>), grid, block, 0, s, a); \
         else hipLaunchKernelGGL((ukf_mlg_kernel<FK_NX, NZV, LAYOUT_SOA>), grid, block, 0, s, a);                         \
     }

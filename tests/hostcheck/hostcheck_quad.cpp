@@ -67,19 +67,19 @@ struct QuadJob {
     const unsigned char *mask;
     double scale;
     double *x0, *P0, *means, *covs;
-    int st[4];
+    int st[8];
 };
 
-template <int NX, int NZ>
+template <int NX, int NZ, int LN = 4>
 void quad_lane(void *vp, int lane)
 {
-    constexpr int R = (NX + 3) / 4;
+    constexpr int R = (NX + LN - 1) / LN;
     auto &job = *static_cast<QuadJob<NX, NZ> *>(vp);
     HostQuad quad{g_fq, lane};
     unsigned g[R];
     double x[NX], P[R][NX];
     for (int r = 0; r < R; ++r) {
-        const unsigned row = 4u * (unsigned)r + (unsigned)lane;
+        const unsigned row = (unsigned)LN * (unsigned)r + (unsigned)lane;
         g[r] = row < (unsigned)NX ? row : (unsigned)NX - 1u;
         for (int c = 0; c < NX; ++c) P[r][c] = job.P0[g[r] * NX + c];
     }
@@ -90,14 +90,14 @@ void quad_lane(void *vp, int lane)
         const bool has_z = job.mask ? job.mask[t] != 0 : true;
         double z[NZ];
         for (int c = 0; c < NZ; ++c) z[c] = has_z ? job.zs[t * NZ + c] : 0.0;
-        st |= fk::ukf_quad_step_v4<NX, NZ>(x, P, g, z, [&] { return has_z; }, job.scale, mv, quad);
+        st |= fk::ukf_quad_step_v4<NX, NZ, LN>(x, P, g, z, [&] { return has_z; }, job.scale, mv, quad);
         // every lane writes what it holds: x (replicated) must agree, rows of P go where their slot says
         for (int i = 0; i < NX; ++i) {
             if (lane == 0) job.means[t * NX + i] = x[i];
             else if (memcmp(&job.means[t * NX + i], &x[i], 8) != 0) st |= 1 << 20;        // replicated values differ between lanes
         }
         for (int r = 0; r < R; ++r) {
-            const bool dup = 4u * (unsigned)r + (unsigned)lane >= (unsigned)NX;
+            const bool dup = (unsigned)LN * (unsigned)r + (unsigned)lane >= (unsigned)NX;
             for (int c = 0; c < NX; ++c) {
                 double &dst = job.covs[(t * NX + g[r]) * NX + c];
                 if (!dup) dst = P[r][c];
@@ -106,19 +106,19 @@ void quad_lane(void *vp, int lane)
     }
     // duplicates (slots past row n-1) must hold row n-1's values bit for bit: checked against what its owner wrote last
     for (int r = 0; r < R; ++r)
-        if (4u * (unsigned)r + (unsigned)lane >= (unsigned)NX && job.T > 0 && ((NX - 1) % 4) < lane) {
+        if ((unsigned)LN * (unsigned)r + (unsigned)lane >= (unsigned)NX && job.T > 0 && ((NX - 1) % LN) < lane) {
             for (int c = 0; c < NX; ++c)
                 if (memcmp(&job.covs[((job.T - 1) * NX + (NX - 1)) * NX + c], &P[r][c], 8) != 0) st |= 1 << 21;
         }
     if (lane == 0)
         for (int i = 0; i < NX; ++i) job.x0[i] = x[i];
     for (int r = 0; r < R; ++r)
-        if (4u * (unsigned)r + (unsigned)lane < (unsigned)NX)
+        if ((unsigned)LN * (unsigned)r + (unsigned)lane < (unsigned)NX)
             for (int c = 0; c < NX; ++c) job.P0[g[r] * NX + c] = P[r][c];
     job.st[lane] = st;
 }
 
-template <int NX, int NZ>
+template <int NX, int NZ, int LN = 4>
 int ukf_quad_batch(long T, const double *F, const double *H, const double *Q, const double *R, const double *Wm,
                    const double *Wc, double scale, const double *zs, const unsigned char *mask, double *x0, double *P0,
                    double *means, double *covs)
@@ -129,9 +129,10 @@ int ukf_quad_batch(long T, const double *F, const double *H, const double *Q, co
     std::copy(Wc, Wc + KS, wc);
     fk::make_pair_table<NX>(wm, wc, wp);
     if (!fk::pair_weights_symmetric<NX>(wm, wc)) return -2;
-    QuadJob<NX, NZ> job{T, F, H, Q, R, wp, zs, mask, scale, x0, P0, means, covs, {0, 0, 0, 0}};
-    run_quad(&quad_lane<NX, NZ>, &job);
-    if (job.st[0] != job.st[1] || job.st[0] != job.st[2] || job.st[0] != job.st[3]) return 1 << 22;   // the status is replicated
+    QuadJob<NX, NZ> job{T, F, H, Q, R, wp, zs, mask, scale, x0, P0, means, covs, {0, 0, 0, 0, 0, 0, 0, 0}};
+    run_quad(&quad_lane<NX, NZ, LN>, &job, LN);
+    for (int l = 1; l < LN; ++l)
+        if (job.st[l] != job.st[0]) return 1 << 22;                                              // the status is replicated
     return job.st[0];
 }
 
@@ -280,6 +281,19 @@ extern "C" int hc_ukf_oct_rts_v4(int n, long T, const double *F, const double *Q
 {
 #define GO(NXV) if (n == NXV) return ukf_quad_rts_batch<NXV, false, 8>(T, F, Q, Wm, Wc, scale, Xs, Ps, xs, ps, Ks)
     GO(8); GO(9); GO(10); GO(11); GO(12); GO(13); GO(14); GO(15); GO(16);
+#undef GO
+    return -1;
+}
+
+// the filter step on eight lanes per track (where dim_z >= 5 at dim_x >= 13 is headed: one row of H L per lane)
+extern "C" int hc_ukf_oct_v4(int n, int m, long T, const double *F, const double *H, const double *Q, const double *R,
+                             const double *Wm, const double *Wc, double scale, const double *zs,
+                             const unsigned char *mask, double *x0, double *P0, double *means, double *covs)
+{
+#define GO(NXV, NZV) if (n == NXV && m == NZV) return ukf_quad_batch<NXV, NZV, 8>(T, F, H, Q, R, Wm, Wc, scale, zs, mask, x0, P0, means, covs)
+#define GOM(NXV) GO(NXV, 1); GO(NXV, 3); GO(NXV, 4); GO(NXV, 5); GO(NXV, 6); GO(NXV, 7); GO(NXV, 8)
+    GO(8, 4); GO(9, 3); GOM(10); GOM(13); GOM(14); GOM(15); GOM(16);
+#undef GOM
 #undef GO
     return -1;
 }

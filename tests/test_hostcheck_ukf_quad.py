@@ -235,3 +235,23 @@ def test_oct_smoother_step_matches_the_oracle_and_the_quad(quad_lib, n):
     for u, v in zip(a, b):
         assert relrows(u[:-1], v[:-1]) < 1e-12
     assert np.array_equal(a[0][-1], mu[-1]) and np.array_equal(a[1][-1], cov[-1]) and not a[2][-1].any()
+
+
+@pytest.mark.parametrize("n,m", [(8, 4), (9, 3)] + [(n, m) for n in (10, 13, 14, 15, 16) for m in (1, 3, 4, 5, 6, 7, 8)])
+def test_oct_filter_step_matches_the_oracle_and_the_quad(quad_lib, n, m):
+    """The filter step on eight lanes per track against the oracle (1e-9, the package's UKF bar on this model) and against
+    the four-lane run (same sums, same order; rows owned by other lanes)."""
+    alpha, beta, kappa = .4, 2., 3. - n
+    r, F, H, Q, R, x0, P0 = _model(n, m, n * 13 + m)
+    T = 14
+    zs = r.standard_normal((T, m))
+    mask = np.ones(T, dtype=np.uint8)
+    mask[5] = mask[6] = 0
+    Wm, Wc = ukf_oracle.merwe_weights(n, alpha, beta, kappa)
+    zl = [z if k else None for z, k in zip(zs, mask)]
+    mu_ref, cov_ref = ukf_oracle.ukf_batch_filter(x0, P0, zl, lambda s, d: F @ s, lambda s: H @ s, 0.1, Q, R, alpha, beta, kappa)
+    a = _run(quad_lib, "hc_ukf_oct_v4", n, m, F, H, Q, R, Wm, Wc, alpha ** 2 * (n + kappa), zs, mask, x0, P0)
+    b = _run(quad_lib, "hc_ukf_quad_v4", n, m, F, H, Q, R, Wm, Wc, alpha ** 2 * (n + kappa), zs, mask, x0, P0)
+    assert rel(a[0], mu_ref) < 1e-9 and rel(a[1], cov_ref) < 1e-9
+    assert rel(a[0], b[0]) < 1e-12 and rel(a[1], b[1]) < 1e-12
+    assert np.array_equal(a[2], a[0][-1]) and np.array_equal(a[3], a[1][-1])
