@@ -185,8 +185,7 @@ FK_HD int ukf_quad_step_v4(double (&x)[NX], double (&P)[(NX + LN - 1) / LN][NX],
         }
         const bool has_z = has_z_fn();
         if (!upd_pd && has_z) st |= ST_NOT_PD;
-        double zp[NZ], S[NZ * NZ], Ko[R * NZ], Rm[NZ * NZ];
-        FK_UNROLL for (int e = 0; e < NZ * NZ; ++e) Rm[e] = mv.R[e];
+        double zp[NZ], S[NZ * NZ], Ko[R * NZ];
         const double wms = mv.Wp[0], wcs = mv.Wp[1];
         {
             double d0[NZ], wd[NZ];
@@ -222,9 +221,11 @@ FK_HD int ukf_quad_step_v4(double (&x)[NX], double (&P)[(NX + LN - 1) / LN][NX],
         // S stays an UPPER triangle (its mirror image is the same bits: the reference's w * outer(d, d) is symmetric bit for
         // bit, and so is R as far as anybody reads it); the factorisation reads a lower one: its transpose.  At dim_z 8 the
         // full S next to a full copy for the factor was 56 doubles more at the point where P-, K and x are live.
+        // (R is requested here, not at the head of the half: its upper triangle is dim_z (dim_z + 1) / 2 more doubles to hold
+        //  through the sweep and the pairs -- 36 at dim_z 8 -- for one LDS round trip saved)
         FK_UNROLL for (int r = 0; r < NZ; ++r)
             FK_UNROLL for (int c = 0; c < NZ; ++c)
-                if (c >= r) S[r * NZ + c] += Rm[r * NZ + c];                    // + R last
+                if (c >= r) S[r * NZ + c] += mv.R[r * NZ + c];                  // + R last
         // K = Pxz S^-1 (own rows)
         {
             double Lf[NZ * NZ], dd[NZ], dinv[NZ];
