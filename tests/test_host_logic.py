@@ -208,3 +208,25 @@ print(" ".join(str(v) for v in out))
     assert run({}) == [OK, UNS, OK, UNS, UNS, UNS, UNS, UNS, UNS, OK, UNS, UNS, UNS]
     assert run({"FK_UKF_MLG": "1"}) == [OK, UNS, OK, UNS, OK, UNS, OK, UNS, UNS, OK, OK, UNS, UNS]
     assert run({"FK_UKF_MLG": "1", "FK_UKF_MLG_MIN_NX": "7"}) == [OK, UNS, OK, UNS, OK, UNS, OK, UNS, UNS, OK, OK, UNS, UNS]
+
+
+def test_a_strided_mask_is_copied_before_its_pointer_is_handed_to_the_c_abi():
+    """The C ABI reads a [T][N] byte mask with row stride N.  NumPy's mask[:, idx] is column-major memory and
+    torch.as_tensor keeps the strides: _engine._mask_ptr copies such a view (found by a GPU probe that fed a kernel a transposed
+    mask, profiles/r04/lease_q) and leaves a contiguous one alone."""
+    import ctypes
+    import torch
+    from filterpy_amd import _engine as E
+    base = np.arange(12, dtype=np.uint8).reshape(4, 3)
+    view = base[:, np.array([2, 0, 1, 1, 0])]                   # shape (4, 5), strides (1, 4)
+    assert not view.flags.c_contiguous
+    t = torch.as_tensor(view)
+    assert not t.is_contiguous()
+    keep = []
+    p = E._mask_ptr(t, keep)
+    assert len(keep) == 1 and keep[0].is_contiguous() and p == keep[0].data_ptr() != t.data_ptr()
+    got = np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(ctypes.c_uint8)), shape=(20,))
+    assert np.array_equal(got, np.ascontiguousarray(view).ravel())
+    c = torch.as_tensor(np.ascontiguousarray(view))
+    keep = []
+    assert E._mask_ptr(c, keep) == c.data_ptr() and E._mask_ptr(None, keep) is None
