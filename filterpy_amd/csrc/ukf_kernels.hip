@@ -690,13 +690,18 @@ static int ukf_mlg_rts_launch(const UkfRtsArgs &a, const double *F, const double
 }
 #endif
 
+// FK_UKF_MLG_DEFAULT: what an unset FK_UKF_MLG means.  0 until tests/test_gpu_ukf_mlg.py has run on a GPU; the one place to flip
+// on the C side (the Python side: _engine._UKF_MLG_DEFAULT).
+#ifndef FK_UKF_MLG_DEFAULT
+#define FK_UKF_MLG_DEFAULT 0
+#endif
 // FK_UKF_MLG=1: the four-lane kernels serve dim_x 10..16; FK_UKF_MLG_MIN_NX=7 | 8 | 9 additionally hands them the pair-weight
 // calls of the one-lane classes from that dim_x on (A/B: those classes run one wave per SIMD with scratch)
 static int ukf_mlg_min_nx()
 {
     static const int v = [] {
         const char *on = getenv("FK_UKF_MLG");
-        if (!on || on[0] != '1') return 99;
+        if (!(on ? on[0] == '1' : FK_UKF_MLG_DEFAULT != 0)) return 99;
         const char *mn = getenv("FK_UKF_MLG_MIN_NX");
         const int m = mn ? atoi(mn) : 10;
         return m >= 7 && m <= 10 ? m : 10;

@@ -10,8 +10,13 @@ import pytest
 
 from conftest import golden, rel_err_rows
 
+def _enabled():
+    from filterpy_amd import _engine as E
+    return E.ukf_mlg_enabled()
+
+
 pytestmark = [pytest.mark.gpu,
-              pytest.mark.skipif(os.environ.get("FK_UKF_MLG", "0")[:1] != "1", reason="the four-lane UKF is opt-in: FK_UKF_MLG=1")]
+              pytest.mark.skipif(not _enabled(), reason="the four-lane UKF is opt-in: FK_UKF_MLG=1")]
 TOL = 1e-10
 
 
