@@ -185,83 +185,173 @@ FK_HD int ukf_quad_step_v4(double (&x)[NX], double (&P)[(NX + LN - 1) / LN][NX],
         }
         const bool has_z = has_z_fn();
         if (!upd_pd && has_z) st |= ST_NOT_PD;
-        double zp[NZ], S[NZ * NZ], Ko[R * NZ];
-        const double wms = mv.Wp[0], wcs = mv.Wp[1];
-        {
-            double d0[NZ], wd[NZ];
-            FK_UNROLL for (int c = 0; c < NZ; ++c) {
-                double acc = mv.H[c * NX] * x[0];
-                FK_UNROLL for (int k = 1; k < NX; ++k) acc = fma(mv.H[c * NX + k], x[k], acc);
-                zp[c] = wms * acc;
-                d0[c] = acc - zp[c];
-            }
-            FK_UNROLL for (int c = 0; c < NZ; ++c) wd[c] = wcs * d0[c];
-            FK_UNROLL for (int r = 0; r < NZ; ++r)
-                FK_UNROLL for (int c = 0; c < NZ; ++c)
-                    if (c >= r) S[r * NZ + c] = d0[r] * wd[c];
-        }
-        FK_STAGE();
-        FK_UNROLL for (int k = 0; k < NX; ++k) {
-            const double wp = mv.Wp[2 + k];
-            double hl[NZ], wh[NZ];                             // column k of H L, gathered from the lanes that hold its rows
-            FK_UNROLL for (int c = 0; c < NZ; ++c) hl[c] = quad_from<LN>(quad, HLo[c / LN][k], c % LN);
-            FK_UNROLL for (int c = 0; c < NZ; ++c) wh[c] = wp * hl[c];
-            FK_UNROLL for (int r = 0; r < NZ; ++r)
-                FK_UNROLL for (int c = 0; c < NZ; ++c)
-                    if (c >= r) S[r * NZ + c] = fma(hl[r], wh[c], S[r * NZ + c]);
-            // the cross variance's own rows: l_k is zero above the diagonal (slots whose rows all lie above row k: skipped;
-            // a row above it inside a slot: its element of L is a stored zero)
-            FK_UNROLL for (int r = 0; r < R; ++r) {
-                if (LN * r + LN - 1 < k) continue;
-                FK_UNROLL for (int c = 0; c < NZ; ++c)
-                    Ko[r * NZ + c] = (k == 0) ? Lw[r][0] * wh[c] : fma(Lw[r][k], wh[c], Ko[r * NZ + c]);
-            }
-            if (k % 4 == 3) FK_STAGE();
-        }
-        // S stays an UPPER triangle (its mirror image is the same bits: the reference's w * outer(d, d) is symmetric bit for
-        // bit, and so is R as far as anybody reads it); the factorisation reads a lower one: its transpose.  At dim_z 8 the
-        // full S next to a full copy for the factor was 56 doubles more at the point where P-, K and x are live.
-        // (R is requested here, not at the head of the half: its upper triangle is dim_z (dim_z + 1) / 2 more doubles to hold
-        //  through the sweep and the pairs -- 36 at dim_z 8 -- for one LDS round trip saved)
-        FK_UNROLL for (int r = 0; r < NZ; ++r)
-            FK_UNROLL for (int c = 0; c < NZ; ++c)
-                if (c >= r) S[r * NZ + c] += mv.R[r * NZ + c];                  // + R last
-        // K = Pxz S^-1 (own rows)
-        {
-            double Lf[NZ * NZ], dd[NZ], dinv[NZ];
-            FK_UNROLL for (int r = 0; r < NZ; ++r)
-                FK_UNROLL for (int c = 0; c < NZ; ++c)
-                    if (c <= r) Lf[r * NZ + c] = S[c * NZ + r];
-            if (!ldlt2_rs<NZ>(Lf, dd, dinv) && has_z) st |= ST_NOT_PD;
-            solve_rows_ldlt<R, NZ>(Lf, dinv, Ko);
-        }
-        double zc[NZ];
-        FK_UNROLL for (int e = 0; e < R * NZ; ++e) Ko[e] = has_z ? Ko[e] : 0.0;
-        FK_UNROLL for (int r = 0; r < NZ; ++r)
-            FK_UNROLL for (int c = 0; c < NZ; ++c)
-                if (c >= r) S[r * NZ + c] = has_z ? S[r * NZ + c] : 0.0;
-        FK_UNROLL for (int c = 0; c < NZ; ++c) zc[c] = has_z ? zin[c] - zp[c] : 0.0;
-        FK_STAGE();
-        // x += K (z - zp) ; P -= K (S K') : row b of K from its owner serves x[b] and column b of P
-        FK_UNROLL for (int b = 0; b < NX; ++b) {
-            double Kb[NZ], sk[NZ];
-            FK_UNROLL for (int c = 0; c < NZ; ++c) Kb[c] = quad_from<LN>(quad, Ko[(b / LN) * NZ + c], b % LN);
+        if constexpr (NZ >= 5) {
+            // dim_z 5..8: the dim_z x dim_z block DISTRIBUTED as well (replicated it is S, its factor and their temporaries: 80
+            // doubles at dim_z 8 on top of the rows of P-, L and H L -- 2.3-3.7 KB of scratch per lane at dim_x 16).  Lane q holds
+            // the rows of S that it holds of H L; S = Ls Ls' is factored like P (quad_chol_rows over dim_z rows), the forward
+            // substitution W = Pxz Ls^-T rides on the broadcast rows, and with it
+            //     P -= K S K'  =  P - W W'        (K = W Ls^-1, so K S K' = W Ls^-1 Ls Ls' Ls^-T W')
+            // needs neither S again nor the products S K'; K = W Ls^-1 (column gathers) follows for x += K (z - zp).
+            double So[RZ][NZ], Ko[R * NZ], zp[NZ];
+            const double wms = mv.Wp[0], wcs = mv.Wp[1];
             {
-                double acc = Kb[0] * zc[0];
-                FK_UNROLL for (int c = 1; c < NZ; ++c) acc = fma(Kb[c], zc[c], acc);
-                x[b] += acc;
+                double wd[NZ];
+                FK_UNROLL for (int c = 0; c < NZ; ++c) {
+                    double acc = mv.H[c * NX] * x[0];
+                    FK_UNROLL for (int k = 1; k < NX; ++k) acc = fma(mv.H[c * NX + k], x[k], acc);
+                    zp[c] = wms * acc;
+                    wd[c] = wcs * (acc - zp[c]);
+                }
+                FK_UNROLL for (int rz = 0; rz < RZ; ++rz) {                              // the lane's own rows: the same arithmetic
+                    double acc = mv.H[hrow[rz] * NX] * x[0];
+                    FK_UNROLL for (int k = 1; k < NX; ++k) acc = fma(mv.H[hrow[rz] * NX + k], x[k], acc);
+                    const double d0o = acc - wms * acc;
+                    FK_UNROLL for (int c = 0; c < NZ; ++c) So[rz][c] = d0o * wd[c];
+                }
             }
-            FK_UNROLL for (int qq = 0; qq < NZ; ++qq) {
-                double acc = S[0 * NZ + qq] * Kb[0];                             // S[qq][0] = S[0][qq]
-                FK_UNROLL for (int w = 1; w < NZ; ++w) acc = fma(w >= qq ? S[qq * NZ + w] : S[w * NZ + qq], Kb[w], acc);
-                sk[qq] = acc;
+            FK_STAGE();
+            FK_UNROLL for (int k = 0; k < NX; ++k) {
+                const double wp = mv.Wp[2 + k];
+                double wh[NZ];
+                FK_UNROLL for (int c = 0; c < NZ; ++c) wh[c] = wp * quad_from<LN>(quad, HLo[c / LN][k], c % LN);
+                FK_UNROLL for (int rz = 0; rz < RZ; ++rz)
+                    FK_UNROLL for (int c = 0; c < NZ; ++c) So[rz][c] = fma(HLo[rz][k], wh[c], So[rz][c]);
+                FK_UNROLL for (int r = 0; r < R; ++r) {
+                    if (LN * r + LN - 1 < k) continue;
+                    FK_UNROLL for (int c = 0; c < NZ; ++c)
+                        Ko[r * NZ + c] = (k == 0) ? Lw[r][0] * wh[c] : fma(Lw[r][k], wh[c], Ko[r * NZ + c]);
+                }
+                if (k % 4 == 3) FK_STAGE();
             }
-            FK_UNROLL for (int r = 0; r < R; ++r) {
-                double acc = Ko[r * NZ] * sk[0];
-                FK_UNROLL for (int qq = 1; qq < NZ; ++qq) acc = fma(Ko[r * NZ + qq], sk[qq], acc);
-                P[r][b] -= acc;
+            FK_UNROLL for (int rz = 0; rz < RZ; ++rz)
+                FK_UNROLL for (int c = 0; c < NZ; ++c) So[rz][c] += mv.R[hrow[rz] * NZ + c];   // + R last
+            double Ls[RZ][NZ], invz[NZ];
+            {
+                const bool pd = quad_chol_rows<NZ, LN>(So, hrow, 1.0, Ls, quad, [&](int j, const double (&lrow)[NZ], double, double inv) {
+                    invz[j] = inv;
+                    FK_UNROLL for (int r = 0; r < R; ++r) {                              // W[a][j] = (Pxz[a][j] - sum_{k<j} W[a][k] Ls[j][k]) / Ls[j][j]
+                        double acc = Ko[r * NZ + j];
+                        FK_UNROLL for (int k = 0; k < NZ; ++k)
+                            if (k < j) acc = fma(-Ko[r * NZ + k], lrow[k], acc);
+                        Ko[r * NZ + j] = acc * inv;
+                    }
+                });
+                if (!pd && has_z) st |= ST_NOT_PD;
             }
-            if (b % 4 == 3) FK_STAGE();
+            FK_UNROLL for (int e = 0; e < R * NZ; ++e) Ko[e] = has_z ? Ko[e] : 0.0;
+            // P -= W W': row b of W from its owner
+            FK_UNROLL for (int b = 0; b < NX; ++b) {
+                double Wb[NZ];
+                FK_UNROLL for (int c = 0; c < NZ; ++c) Wb[c] = quad_from<LN>(quad, Ko[(b / LN) * NZ + c], b % LN);
+                FK_UNROLL for (int r = 0; r < R; ++r) {
+                    double acc = Ko[r * NZ] * Wb[0];
+                    FK_UNROLL for (int qq = 1; qq < NZ; ++qq) acc = fma(Ko[r * NZ + qq], Wb[qq], acc);
+                    P[r][b] -= acc;
+                }
+                if (b % 4 == 3) FK_STAGE();
+            }
+            // K = W Ls^-1 in place: K[a][i] = (W[a][i] - sum_{k>i} K[a][k] Ls[k][i]) / Ls[i][i]
+            FK_UNROLL for (int i = NZ - 1; i >= 0; --i) {
+                double col[NZ];
+                FK_UNROLL for (int k = 0; k < NZ; ++k)
+                    if (k > i) col[k] = quad_from<LN>(quad, Ls[k / LN][i], k % LN);
+                FK_UNROLL for (int r = 0; r < R; ++r) {
+                    double acc = Ko[r * NZ + i];
+                    FK_UNROLL for (int k = NZ - 1; k >= 0; --k)
+                        if (k > i) acc = fma(-Ko[r * NZ + k], col[k], acc);
+                    Ko[r * NZ + i] = acc * invz[i];
+                }
+            }
+            // x += K (z - zp): own rows, gathered
+            {
+                double zc[NZ], xo[R];
+                FK_UNROLL for (int c = 0; c < NZ; ++c) zc[c] = has_z ? zin[c] - zp[c] : 0.0;
+                FK_UNROLL for (int r = 0; r < R; ++r) {
+                    double acc = Ko[r * NZ] * zc[0];
+                    FK_UNROLL for (int c = 1; c < NZ; ++c) acc = fma(Ko[r * NZ + c], zc[c], acc);
+                    xo[r] = acc;
+                }
+                FK_UNROLL for (int b = 0; b < NX; ++b) x[b] += quad_from<LN>(quad, xo[b / LN], b % LN);
+            }
+        } else {
+            double zp[NZ], S[NZ * NZ], Ko[R * NZ];
+            const double wms = mv.Wp[0], wcs = mv.Wp[1];
+            {
+                double d0[NZ], wd[NZ];
+                FK_UNROLL for (int c = 0; c < NZ; ++c) {
+                    double acc = mv.H[c * NX] * x[0];
+                    FK_UNROLL for (int k = 1; k < NX; ++k) acc = fma(mv.H[c * NX + k], x[k], acc);
+                    zp[c] = wms * acc;
+                    d0[c] = acc - zp[c];
+                }
+                FK_UNROLL for (int c = 0; c < NZ; ++c) wd[c] = wcs * d0[c];
+                FK_UNROLL for (int r = 0; r < NZ; ++r)
+                    FK_UNROLL for (int c = 0; c < NZ; ++c)
+                        if (c >= r) S[r * NZ + c] = d0[r] * wd[c];
+            }
+            FK_STAGE();
+            FK_UNROLL for (int k = 0; k < NX; ++k) {
+                const double wp = mv.Wp[2 + k];
+                double hl[NZ], wh[NZ];                             // column k of H L, gathered from the lanes that hold its rows
+                FK_UNROLL for (int c = 0; c < NZ; ++c) hl[c] = quad_from<LN>(quad, HLo[c / LN][k], c % LN);
+                FK_UNROLL for (int c = 0; c < NZ; ++c) wh[c] = wp * hl[c];
+                FK_UNROLL for (int r = 0; r < NZ; ++r)
+                    FK_UNROLL for (int c = 0; c < NZ; ++c)
+                        if (c >= r) S[r * NZ + c] = fma(hl[r], wh[c], S[r * NZ + c]);
+                // the cross variance's own rows: l_k is zero above the diagonal (slots whose rows all lie above row k: skipped;
+                // a row above it inside a slot: its element of L is a stored zero)
+                FK_UNROLL for (int r = 0; r < R; ++r) {
+                    if (LN * r + LN - 1 < k) continue;
+                    FK_UNROLL for (int c = 0; c < NZ; ++c)
+                        Ko[r * NZ + c] = (k == 0) ? Lw[r][0] * wh[c] : fma(Lw[r][k], wh[c], Ko[r * NZ + c]);
+                }
+                if (k % 4 == 3) FK_STAGE();
+            }
+            // S stays an UPPER triangle (its mirror image is the same bits: the reference's w * outer(d, d) is symmetric bit for
+            // bit, and so is R as far as anybody reads it); the factorisation reads a lower one: its transpose.  At dim_z 8 the
+            // full S next to a full copy for the factor was 56 doubles more at the point where P-, K and x are live.
+            // (R is requested here, not at the head of the half: its upper triangle is dim_z (dim_z + 1) / 2 more doubles to hold
+            //  through the sweep and the pairs -- 36 at dim_z 8 -- for one LDS round trip saved)
+            FK_UNROLL for (int r = 0; r < NZ; ++r)
+                FK_UNROLL for (int c = 0; c < NZ; ++c)
+                    if (c >= r) S[r * NZ + c] += mv.R[r * NZ + c];                  // + R last
+            // K = Pxz S^-1 (own rows)
+            {
+                double Lf[NZ * NZ], dd[NZ], dinv[NZ];
+                FK_UNROLL for (int r = 0; r < NZ; ++r)
+                    FK_UNROLL for (int c = 0; c < NZ; ++c)
+                        if (c <= r) Lf[r * NZ + c] = S[c * NZ + r];
+                if (!ldlt2_rs<NZ>(Lf, dd, dinv) && has_z) st |= ST_NOT_PD;
+                solve_rows_ldlt<R, NZ>(Lf, dinv, Ko);
+            }
+            double zc[NZ];
+            FK_UNROLL for (int e = 0; e < R * NZ; ++e) Ko[e] = has_z ? Ko[e] : 0.0;
+            FK_UNROLL for (int r = 0; r < NZ; ++r)
+                FK_UNROLL for (int c = 0; c < NZ; ++c)
+                    if (c >= r) S[r * NZ + c] = has_z ? S[r * NZ + c] : 0.0;
+            FK_UNROLL for (int c = 0; c < NZ; ++c) zc[c] = has_z ? zin[c] - zp[c] : 0.0;
+            FK_STAGE();
+            // x += K (z - zp) ; P -= K (S K') : row b of K from its owner serves x[b] and column b of P
+            FK_UNROLL for (int b = 0; b < NX; ++b) {
+                double Kb[NZ], sk[NZ];
+                FK_UNROLL for (int c = 0; c < NZ; ++c) Kb[c] = quad_from<LN>(quad, Ko[(b / LN) * NZ + c], b % LN);
+                {
+                    double acc = Kb[0] * zc[0];
+                    FK_UNROLL for (int c = 1; c < NZ; ++c) acc = fma(Kb[c], zc[c], acc);
+                    x[b] += acc;
+                }
+                FK_UNROLL for (int qq = 0; qq < NZ; ++qq) {
+                    double acc = S[0 * NZ + qq] * Kb[0];                             // S[qq][0] = S[0][qq]
+                    FK_UNROLL for (int w = 1; w < NZ; ++w) acc = fma(w >= qq ? S[qq * NZ + w] : S[w * NZ + qq], Kb[w], acc);
+                    sk[qq] = acc;
+                }
+                FK_UNROLL for (int r = 0; r < R; ++r) {
+                    double acc = Ko[r * NZ] * sk[0];
+                    FK_UNROLL for (int qq = 1; qq < NZ; ++qq) acc = fma(Ko[r * NZ + qq], sk[qq], acc);
+                    P[r][b] -= acc;
+                }
+                if (b % 4 == 3) FK_STAGE();
+            }
         }
     }
     return st;
