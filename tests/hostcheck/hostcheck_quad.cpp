@@ -144,7 +144,7 @@ extern "C" int hc_ukf_quad_v4(int n, int m, long T, const double *F, const doubl
 {
 #define GO(NXV, NZV) if (n == NXV && m == NZV) return ukf_quad_batch<NXV, NZV>(T, F, H, Q, R, Wm, Wc, scale, zs, mask, x0, P0, means, covs)
 #define GOM(NXV) GO(NXV, 1); GO(NXV, 2); GO(NXV, 3); GO(NXV, 4); GO(NXV, 5); GO(NXV, 6); GO(NXV, 7); GO(NXV, 8)
-    GO(4, 2); GO(5, 2); GO(7, 3); GO(8, 4); GO(9, 3);
+    GO(4, 2); GO(5, 2); GO(7, 1); GO(7, 3); GO(8, 2); GO(8, 4); GO(9, 3); GO(9, 4);
     GOM(10); GOM(11); GOM(12); GOM(13); GOM(14); GOM(15); GOM(16);
 #undef GOM
 #undef GO

@@ -119,3 +119,12 @@ def test_dry_smoother_bank_sizes(gpu_tests):
     for N in (1, 17):
         gpu_tests.test_smoother_bank_sizes_and_without_gain(N, "soa")
         gpu_tests.test_smoother_bank_sizes_and_without_gain(N, "aos")
+
+
+@pytest.mark.parametrize("n,m", [(7, 1), (8, 4), (9, 3), (9, 4)])
+def test_dry_small_dims(gpu_tests, n, m):
+    """(the FK_UKF_MLG_MIN_NX=7 A/B: dim_x 7..9 on the four-lane kernels)"""
+    gpu_tests.test_small_dims_filter_vs_oracle(n, m, "soa")
+    gpu_tests.test_small_dims_filter_vs_oracle(n, m, "aos")
+    if m == 4 or n == 7:
+        gpu_tests.test_small_dims_smoother_vs_oracle(n, "aos")
