@@ -1,6 +1,6 @@
 #!/bin/bash
-# Round 5, first lease: the four-lane UKF filter and smoother (csrc/ukf_mlg.hip, dims 10..16) have been checked on the host only
-# (tests/test_hostcheck_ukf_quad.py).  Their GPU parity tests, then -- if green -- the whole UKF suite with the kernels switched
+# Round 5, first lease: the several-lane UKF filter and smoother (csrc/ukf_mlg.hip, dims 10..16) have been checked on the host
+# (tests/test_hostcheck_ukf_quad.py, tests/test_cpu_dryrun_ukf_mlg.py) and probed on a GPU for 3 seconds (profiles/r04/lease_q).  Their GPU parity tests, then -- if green -- the whole UKF suite with the kernels switched
 # on, then their first timings next to the split path's.
 ulimit -c 0
 R=$GRAFT_REPO_ROOT
@@ -8,7 +8,7 @@ O=$R/gpurun_out/r05a
 mkdir -p $O
 cd $R
 export FK_UKF_MLG=1
-timeout 600 python -m pytest tests/test_gpu_ukf_mlg.py -m gpu -q -x -p no:cacheprovider > $O/ukf_mlg_tests.log 2>&1
+timeout 600 python -m pytest tests/test_gpu_ukf_mlg.py -m gpu -q -p no:cacheprovider > $O/ukf_mlg_tests.log 2>&1
 tail -15 $O/ukf_mlg_tests.log | cut -c1-220
 if grep -q " passed" $O/ukf_mlg_tests.log && ! grep -q "failed" $O/ukf_mlg_tests.log; then
     timeout 600 python -m pytest tests -m gpu -q -k "ukf or UKF" -p no:cacheprovider 2>&1 | tail -4 | cut -c1-220
