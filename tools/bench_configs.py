@@ -327,6 +327,57 @@ def config_steady(layout, n, m, N, T):
     emit(f"steady-state KF ({n},{m}) N={N} {layout}", N * T, "track-steps", ms, 8 * (m + 2 * n), parity_max_rel=par)
 
 
+def config_ukf(layout, n, m, N, T):
+    """The fused linear UKF (filter + smoother) at any size the library fuses -- dim_x 10..16 once the several-lane kernels
+    are on (csrc/ukf_mlg.hip; FK_UKF_MLG) -- on a dense model, last track against the oracle."""
+    import torch
+    from filterpy_amd import _engine as E
+    from oracle import ukf_oracle
+    alpha, beta, kappa = .5, 2., 3. - n
+    Wm, Wc = ukf_oracle.merwe_weights(n, alpha, beta, kappa)
+    if not E.ukf_linear_supported(n, m, E.pair_weights(Wm, Wc, n)):
+        return
+    rs = np.random.RandomState(n * 10 + m)
+    F = np.eye(n) + 0.05 * rs.randn(n, n)
+    F /= max(1.0, 1.05 * np.max(np.abs(np.linalg.eigvals(F))))
+    H, Q, R = rs.randn(m, n), 0.01 * np.eye(n), 0.5 * np.eye(m)
+    sc = alpha ** 2 * (n + kappa)
+    dev = torch.device("cuda")
+    g = torch.Generator(device=dev)
+    g.manual_seed(4)
+    z = torch.randn((T, N, m) if layout == "aos" else (T, m, N), generator=g, device=dev, dtype=torch.float64)
+    x0 = torch.randn((N, n) if layout == "aos" else (n, N), generator=g, device=dev, dtype=torch.float64)
+    P0 = (5.0 * torch.eye(n, dtype=torch.float64, device=dev)).reshape(1, n * n).repeat(N, 1)
+    P0 = P0.contiguous() if layout == "aos" else P0.T.contiguous()
+    x, P = x0.clone(), P0.clone()
+    means, covs = E.alloc_records((T,), N, n, layout), E.alloc_records((T,), N, n * n, layout)
+    st = torch.zeros(N, dtype=torch.int32, device=dev)
+    dd = [E.dev(M) for M in (F, H, Q, R, Wm, Wc)]
+
+    def fwd():
+        x.copy_(x0)
+        P.copy_(P0)
+        E.ukf_linear_batch(n, m, N, T, layout, sc, *dd, z, x, P, means=means, covs=covs, status=st, paired=True)
+    ms = timeit(fwd)
+    assert not st.any()
+    trk = N - 1
+    zs_h = (z[:, trk] if layout == "aos" else z[:, :, trk]).cpu().numpy()
+    x0h = (x0[trk] if layout == "aos" else x0[:, trk]).cpu().numpy()
+    mu_ref, cov_ref = ukf_oracle.ukf_batch_filter(x0h, 5 * np.eye(n), list(zs_h), lambda s, d: F @ s, lambda s: H @ s, 1.0, Q, R, alpha, beta, kappa)
+    mu, cov = E.from_records(means, layout, 1, (n,))[:, trk], E.from_records(covs, layout, 1, (n, n))[:, trk]
+    par = max(rel(mu, mu_ref), rel(cov.reshape(T, -1), cov_ref.reshape(T, -1)))
+    emit(f"fused linear UKF ({n},{m}) N={N} {layout}", N * T, "track-steps", ms, 8 * (m + n + n * n), parity_max_rel=par)
+    if not E.ukf_linear_rts_supported(n, True):
+        return
+    xs, ps, Ks = E.alloc_records((T,), N, n, layout), E.alloc_records((T,), N, n * n, layout), E.alloc_records((T,), N, n * n, layout)
+    ms = timeit(lambda: E.ukf_linear_rts(n, N, T, layout, sc, dd[0], dd[2], dd[4], dd[5], means, covs, xs, ps, K=Ks, status=st, paired=True))
+    assert not st.any()
+    xr, Pr, Kr = ukf_oracle.ukf_rts_smoother(mu_ref, cov_ref, lambda s, d: F @ s, 1.0, Q, alpha, beta, kappa)
+    gx, gp = E.from_records(xs, layout, 1, (n,))[:, trk], E.from_records(ps, layout, 1, (n, n))[:, trk]
+    par = max(rel(gx, xr), rel(gp.reshape(T, -1), Pr.reshape(T, -1)))
+    emit(f"fused linear UKF smoother n={n} N={N} {layout}", N * T, "track-steps", ms, 8 * (2 * n + 3 * n * n), parity_max_rel=par)
+
+
 def config4(layout, N, T):
     import torch
     from filterpy_amd import _engine as E
@@ -459,6 +510,9 @@ if __name__ == "__main__":
             config_imm(lay, 9, 3, 4, 100_000, 20)
             config_imm(lay, 9, 4, 8, 50_000, 20)
             config_imm(lay, 16, 8, 2, 50_000, 20)
+        if "u" in a.configs:      # the fused linear UKF above dim_x 9 (several lanes per track; rows appear once FK_UKF_MLG is on)
+            for (n, m, N) in ((10, 2, 100_000), (12, 3, 100_000), (14, 4, 80_000), (16, 4, 60_000), (16, 8, 60_000)):
+                config_ukf(lay, n, m, N, 50)
         if "s" in a.configs:      # steady-state / IMM above (9,4) (round 4's padded classes)
             config_steady(lay, 16, 8, 500_000, a.T)
     if "5" in a.configs:
