@@ -1,10 +1,11 @@
-// fk_ukf_quad.hpp -- one predict + update step of the fused linear-model UKF with FOUR LANES PER TRACK (dim_x 10..16): the
-// arithmetic of ukf_mlg.hip.  __host__ __device__ like fk_ukf.hpp: the kernel runs it with the quad exchanges as DPP moves,
-// tests/hostcheck runs the very same code on the host with the four lanes of a quad as four fibers (tests/test_hostcheck_ukf.py).
+// fk_ukf_quad.hpp -- one predict + update step of the fused linear-model UKF, and one backward step of its smoother, with SEVERAL
+// LANES PER TRACK (LN = 4: a quad, DPP exchanges; LN = 8: ds_swizzle) -- the arithmetic of ukf_mlg.hip (dim_x 10..16).
+// __host__ __device__ like fk_ukf.hpp: the kernels run it with the exchanges as cross-lane moves, tests/hostcheck runs the very same
+// code on the host with the lanes of a track as fibers in lockstep (tests/test_hostcheck_ukf_quad.py).
 //
-// The step is ukf_linear_step_v4 (fk_ukf.hpp: UKF.py:400-411, 462-481 with fx = F x, hx = H x, sums regrouped over the +- pairs of
-// sigma points; every sum below keeps v4's order of terms), distributed:
-//   * lane q of the quad holds rows q, q + 4, q + 8, ... of P (CYCLIC, not kf_mlg's blocks: column j of the Cholesky factor only
+// The filter step is ukf_linear_step_v4 (fk_ukf.hpp: UKF.py:400-411, 462-481 with fx = F x, hx = H x, sums regrouped over the +- pairs
+// of sigma points; every sum below keeps v4's order of terms), distributed:
+//   * lane q of the group holds rows q, q + LN, q + 2 LN, ... of P (CYCLIC, not kf_mlg's blocks: column j of the Cholesky factor only
 //     touches rows below j, and with cyclic rows every lane has its share of them down to the last columns); a slot past row
 //     n-1 duplicates row n-1 (same inputs, same instructions: same values, so nothing is predicated); x is replicated;
 //   * the factor of scale * P column by column: the pivot and row j of the factor (final once column j-1 is done) are BROADCAST
@@ -14,9 +15,9 @@
 //                   takes the lane's OWN rows of L
 //   * P- = (sum Wc) y0 y0' + sum_k wp_k f_k f_k' + Q: column k of F L is gathered (pre-multiplied by its pair weight by the
 //     owners), each lane accumulates its own rows;
-//   * S, its L D L' and z - zp are replicated; the gain's rows are solved by their owners and gathered one at a time for
-//     x += K (z - zp) and P -= K (S K').
-// The only exchange is "the value lane o of my quad holds" (quad.bcast<o>(v)); there is no cross-lane sum.  A row of P computed
+//   * dim_z <= 4: S, its L D L' and z - zp are replicated; the gain's rows are solved by their owners and gathered one at a time
+//     for x += K (z - zp) and P -= K (S K').  dim_z >= 5: S is distributed and factored like P, P -= W W' (see there).
+// The only exchange is "the value lane o of my group holds" (quad.bcast<o>(v)); there is no cross-lane sum.  A row of P computed
 // by one lane and its mirror image computed by another agree to a rounding (f_a (w f_b) against f_b (w f_a)), not bit for
 // bit; the factorisation reads a row's own elements.
 // A missing measurement runs the update half on z = 0 with the gain, S and the residual selected to zero (no branch).

@@ -1,5 +1,6 @@
 // ukf_mlg.hip -- the fused linear-model UKF (UnscentedKalmanFilter.batch_filter, filterpy/kalman/UKF.py:524-632, with
-// fx(x, dt) = F x and hx(x) = H x) for dim_x = 10..16, dim_z = 1..8 with FOUR LANES PER TRACK (gfx950).
+// fx(x, dt) = F x and hx(x) = H x) and its smoother (:634-739) for dim_x = 10..16, dim_z = 1..8 with FOUR -- where code size or
+// registers ask for it, EIGHT -- LANES PER TRACK (gfx950).
 //
 // One lane per track ends at dim_x = 9 (ukf_kernels.hip); above it the step ran as five launches per epoch on resident blocks.
 // Here a quad of lanes owns a track for the whole time loop, like kf_mlg.hip, but with the rows of P dealt out CYCLICALLY (lane q
