@@ -520,6 +520,10 @@ FK_HD int ukf_quad_rts_step_v4(double (&x)[NX], double (&P)[(NX + LN - 1) / LN][
         FK_UNROLL for (int b = 0; b < NX; ++b) x[b] += quad_from<LN>(quad, xo[b / LN], b % LN);
     }
     FK_STAGE();
+    // (eight lanes: the full rows of Ps[k] are requested HERE, a phase ahead of their use -- two row slots per lane leave the room)
+    if constexpr (LN == 8) {
+        FK_UNROLL for (int r = 0; r < R; ++r) io.own_row(r, P[r]);
+    }
     // T1 = K D, D = Pn - Pb: the rows of D a slot at a time from their owners
     double T1[R][NX];
     {
@@ -545,7 +549,9 @@ FK_HD int ukf_quad_rts_step_v4(double (&x)[NX], double (&P)[(NX + LN - 1) / LN][
         }
     }
     // P += T1 K': row j of K from its owner
-    FK_UNROLL for (int r = 0; r < R; ++r) io.own_row(r, P[r]);
+    if constexpr (LN != 8) {
+        FK_UNROLL for (int r = 0; r < R; ++r) io.own_row(r, P[r]);
+    }
     FK_UNROLL for (int j = 0; j < NX; ++j) {
         double Kj[NX];
         FK_UNROLL for (int c = 0; c < NX; ++c) Kj[c] = quad_from<LN>(quad, K[j / LN][c], j % LN);
