@@ -2,6 +2,9 @@
 """Static facts of the built gfx950 kernels, no GPU needed: code size (the instruction cache holds 64 KB), registers, scratch,
 LDS, waterfall loops (a buffer op whose descriptor the compiler could not prove uniform) and exec-masked regions inside the time
 loop that contain a cross-lane operation (DPP / ds_swizzle / ds_bpermute under a divergent branch would read disabled lanes).
+A heuristic over the disassembly in LAYOUT order (a region = s_*_saveexec up to the next scalar write of exec): good for spotting,
+not a proof -- a block the compiler placed out of line (the odd-tail branch of a copy-out, say) makes the linear scan span code
+that is not under that mask; look at what it flags.
 
     python tools/isa_lint.py filterpy_amd/csrc/build/ukf_mlg_16.o [...]        # objects built by csrc/Makefile
 """
@@ -73,7 +76,7 @@ def lint_asm(elf):
         for i, l in enumerate(lines):
             if "saveexec" in l:
                 depth_start = i
-            elif depth_start is not None and re.search(r"s_or_b64 exec, exec|s_mov_b64 exec", l):
+            elif depth_start is not None and re.search(r"\bs_\w+\s+exec\b", l):           # any scalar write of exec closes the region
                 if any(("dpp" in p or "ds_swizzle" in p or "ds_bpermute" in p) for p in lines[depth_start:i]):
                     if span[0] <= depth_start <= span[1]:
                         bad_in += 1
