@@ -15,18 +15,16 @@ from conftest import ROOT, _build
 HC = os.path.join(ROOT, "tests", "hostcheck")
 
 
-@pytest.fixture(scope="module")
-def gpu_tests(monkeypatch_module):
+def _host_lib():
     so, src = os.path.join(HC, "libhostcheck_quad.so"), os.path.join(HC, "hostcheck_quad.cpp")
     deps = [src] + [os.path.join(ROOT, "filterpy_amd", "csrc", h) for h in ("fk_ukf_quad.hpp", "fk_ukf.hpp", "fk_math.hpp", "fk_math_sym.hpp")]
     _build(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=on", "-w", "-o", so, src], so, deps)
-    lib = ctypes.CDLL(so)
+    return ctypes.CDLL(so)
+
+
+def _install_fused(mp, lib):
+    """the two fused C-ABI calls of the several-lane UKF, served by the host model of the kernels"""
     from filterpy_amd import _engine as E
-    mp = monkeypatch_module
-    mp.setenv("FK_UKF_MLG", "1")
-    mp.setattr(E, "require_gpu", lambda: torch.device("cpu"))
-    real_dev = E.dev
-    mp.setattr(E, "dev", lambda a, device=None: real_dev(a, device).clone())      # (an upload copies; torch.from_numpy on the CPU aliases)
     p = lambda a: None if a is None else a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
     c = lambda a: np.ascontiguousarray(a, dtype=np.float64)  # noqa: E731
 
@@ -81,6 +79,18 @@ def gpu_tests(monkeypatch_module):
 
     mp.setattr(E, "ukf_linear_batch", fake_batch)
     mp.setattr(E, "ukf_linear_rts", fake_rts)
+
+
+@pytest.fixture(scope="module")
+def gpu_tests(monkeypatch_module):
+    lib = _host_lib()
+    from filterpy_amd import _engine as E
+    mp = monkeypatch_module
+    mp.setenv("FK_UKF_MLG", "1")
+    mp.setattr(E, "require_gpu", lambda: torch.device("cpu"))
+    real_dev = E.dev
+    mp.setattr(E, "dev", lambda a, device=None: real_dev(a, device).clone())      # (an upload copies; torch.from_numpy on the CPU aliases)
+    _install_fused(mp, lib)
     import test_gpu_ukf_mlg
     return importlib.reload(test_gpu_ukf_mlg)
 
@@ -128,3 +138,24 @@ def test_dry_small_dims(gpu_tests, n, m):
     gpu_tests.test_small_dims_filter_vs_oracle(n, m, "aos")
     if m == 4 or n == 7:
         gpu_tests.test_small_dims_smoother_vs_oracle(n, "aos")
+
+
+@pytest.mark.parametrize("layout", ["soa", "aos"])
+def test_dry_python_api(monkeypatch, layout):
+    """UnscentedKalmanFilter.batch_filter / rts_smoother with matrix models at dim_x >= 10 and the switch on: the class's routing,
+    marshalling and last-epoch replay around the fused calls (the building blocks served by tests/fake_ut_engine.py's stand-ins),
+    against the live-reference goldens."""
+    import fake_ut_engine
+    monkeypatch.setenv("FK_UKF_MLG", "1")
+    fake_ut_engine.install(monkeypatch)
+    _install_fused(monkeypatch, _host_lib())
+    from filterpy_amd import _engine as E
+
+    def fake_linear_map(n_in, n_out, k, N, lay, M, sig_in, sig_out):      # out[i] = M in[i] for every sigma point of every track
+        a = fake_ut_engine._get(sig_in, lay, (k, n_in))
+        fake_ut_engine._put(sig_out, lay, a @ M.numpy().T)
+    monkeypatch.setattr(E, "ut_linear_map", fake_linear_map)
+    import test_gpu_ukf_mlg
+    mod = importlib.reload(test_gpu_ukf_mlg)
+    mod.test_python_api_routes_matrix_models_here(layout)
+    mod.test_python_api_smoother_routes_here(layout)
