@@ -263,14 +263,15 @@ FK_HD int ukf_quad_step_v4(double (&x)[NX], double (&P)[(NX + LN - 1) / LN][NX],
                     Ko[r * NZ + i] = acc * invz[i];
                 }
             }
-            // x += K (z - zp): own rows, gathered
+            // x += K (z - zp): own rows, gathered  (selected to zero again: a factor with a NaN in it -- S not positive definite --
+            // turns the zero rows of a missing measurement into NaN in the substitution, and 0 * NaN would reach x)
             {
                 double zc[NZ], xo[R];
                 FK_UNROLL for (int c = 0; c < NZ; ++c) zc[c] = has_z ? zin[c] - zp[c] : 0.0;
                 FK_UNROLL for (int r = 0; r < R; ++r) {
                     double acc = Ko[r * NZ] * zc[0];
                     FK_UNROLL for (int c = 1; c < NZ; ++c) acc = fma(Ko[r * NZ + c], zc[c], acc);
-                    xo[r] = acc;
+                    xo[r] = has_z ? acc : 0.0;
                 }
                 FK_UNROLL for (int b = 0; b < NX; ++b) x[b] += quad_from<LN>(quad, xo[b / LN], b % LN);
             }
