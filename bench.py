@@ -384,13 +384,14 @@ def main():
     ap.add_argument("--layout", default=os.environ.get("FK_BENCH_LAYOUT", "aos"), choices=["soa", "aos"],
                     help="record layout of z and the outputs: aos = NumPy C order [T][N][n][n] (default), soa = [T][n*n][N]")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--placement", default=os.environ.get("FK_BENCH_PLACEMENT", "probe"), choices=["interleave", "probe", "none"],
+    ap.add_argument("--placement", default=os.environ.get("FK_BENCH_PLACEMENT", "interleave"), choices=["interleave", "probe", "none"],
                     help="how the two covariance histories (76 %% of the bytes) are allocated -- every mode is a mode of the product "
-                         "API KalmanFilterBank.batch_filter(device_outputs=True, ...).  probe (default): placement='probe', two arrays "
-                         "placed in HBM by timing this launch on candidate buffers (filterpy_amd/placement.py: placed_pair; ~1 s once "
-                         "per shape, the losing buffers are freed); interleave: the API's default, both histories in ONE array, a "
-                         "track's posterior and prior record side by side (FK_KF_FLAG_COV_INTERLEAVED); none: cov_interleave=False, two "
-                         "plain arrays.  The line reports the launch time of all three on this box.")
+                         "API KalmanFilterBank.batch_filter(device_outputs=True, ...).  interleave (default, and the API's default: what "
+                         "a caller gets without reading docs/PLACEMENT.md): both histories in ONE array, a track's posterior and prior "
+                         "record side by side (FK_KF_FLAG_COV_INTERLEAVED); probe: placement='probe', two arrays placed in HBM by timing "
+                         "this launch on candidate buffers (filterpy_amd/placement.py: placed_pair; ~1 s once per shape, up to 11 "
+                         "buffers allocated while probing, the losers freed); none: cov_interleave=False, two plain arrays.  The line "
+                         "reports the launch time of all three on this box (`placement`), the timed loop runs the one named here.")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="total budget of the CPU baseline's process-count sweep")
     ap.add_argument("--cpu-procs", type=int, default=0, help="cap the CPU baseline's process count (0 = every host core)")
     ap.add_argument("--force-dist", action="store_true",
@@ -502,6 +503,11 @@ def main():
                 info = {"method": "plain allocation (probe failed)", "error": repr(exc)[:200]}
             covs, covs_p = as_records(a_), as_records(b_)
             placement_info["probe"] = info
+            if world > 1:                            # every rank probes its own GPU: a rank that fell back shows in the line
+                outcomes = [None] * world
+                dist.all_gather_object(outcomes, {"rank": rank, "method": info.get("method"), "chosen_ms": info.get("chosen_ms"),
+                                                  "error": info.get("error")})
+                placement_info["per_rank"] = outcomes
 
     def step(k=0, ev=None, with_exchange=True):
         slot = k % 2 if (ex and with_exchange) else 0
@@ -574,6 +580,10 @@ def main():
             "config": {"workload": f"BASELINE configs[1]: {N} independent dim_x=4 dim_z=2 tracks x {T} steps per GPU, "
                                    "fp64, shared F/H/Q/R, KalmanFilter.batch_filter (all 4 outputs stored)",
                        "tracks_per_gpu": N, "T": T, "layout": layout,
+                       "placement": {"interleave": "interleave = KalmanFilterBank.batch_filter(device_outputs=True) as called without "
+                                                   "further arguments (one array for both covariance histories)",
+                                     "probe": "probe = KalmanFilterBank.batch_filter(device_outputs=True, placement='probe')",
+                                     "none": "none = KalmanFilterBank.batch_filter(device_outputs=True, cov_interleave=False)"}[args.placement],
                        "parallelism": f"tracks sharded over {world} GPU(s)" + (", RCCL all-gather of final x per step" if world > 1 else "")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
@@ -588,6 +598,23 @@ def main():
                                "double-buffered x / gathered" % (x.numel() * 8 // 1000000))
         if args.force_dist:
             out["dist_forced"] = f"{world}-rank {dist.get_backend()} group: init_process_group(device_id), all_gather_into_tensor, barrier, all_reduce(MAX) executed"
+        if world == 1 and args.placement != "probe" and not os.environ.get("FK_BENCH_SKIP_PROBE"):
+            # the third arrangement (two arrays placed by measurement), timed AFTER the measurement, for the record only
+            try:
+                del covs, covs_p, got
+                if args.placement == "interleave":
+                    del cov2, c_il, cp_il
+                torch.cuda.empty_cache()
+                desc["flags"] = 0
+                from filterpy_amd import placement
+                as_records = lambda b: b.view(torch.float64).view(shape)          # noqa: E731
+                a_, b_, info = placement.placed_pair(csize, lambda a, b: one_launch_ms(as_records(a), as_records(b)), device)
+                out["placement"]["probe_ms"] = round(float(np.median([one_launch_ms(as_records(a_), as_records(b_)) for _ in range(3)])), 4)
+                out["placement"]["probe"] = {k: info.get(k) for k in ("method", "buffers_tried", "pairs", "chosen_ms", "median_ms", "worst_ms", "error") if k in info}
+                del a_, b_
+                torch.cuda.empty_cache()
+            except Exception as exc:
+                out["placement"]["probe_error"] = repr(exc)[:200]
         if world == 1 and not args.no_cpu:
             # the CPU baseline filters the same measurements: the first 64 x 256 tracks of the timed z buffer
             kc = min(N, CPU_TRACKS_PER_PROC * 256)

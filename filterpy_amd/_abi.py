@@ -71,6 +71,7 @@ SIGNATURES = {
     "fk_ukf_correct_f64": (ctypes.c_int, [c_i32, c_i32, c_i64, c_i32] + [c_vp] * 9),
     "fk_ukf_linear_batch_f64": (ctypes.c_int, [ctypes.POINTER(fk_ukf_desc)] + [c_vp] * 14),
     "fk_ukf_linear_rts_f64": (ctypes.c_int, [ctypes.POINTER(fk_ukf_desc)] + [c_vp] * 11),
+    "fk_ukf_linear_supported": (ctypes.c_int, [ctypes.c_int32] * 4),
     "fk_kf_steadystate_f64": (ctypes.c_int, [ctypes.POINTER(fk_kf_desc)] + [c_vp] * 12),
     "fk_kf_update_correlated_f64": (ctypes.c_int, [ctypes.POINTER(fk_kf_desc)] + [c_vp] * 13),
     "fk_ukf_rts_correct_f64": (ctypes.c_int, [c_i32, c_i64, c_i32] + [c_vp] * 10),

@@ -195,28 +195,16 @@ def ukf_correct(n, m, N, layout, Pxz, zp, S, z, x, P, K=None, status=None):
     _abi.check(rc, "fk_ukf_correct_f64")
 
 
-_UKF_MLG_DEFAULT = False      # what an unset FK_UKF_MLG means (the C side: FK_UKF_MLG_DEFAULT in csrc/ukf_kernels.hip)
-
-
-def ukf_mlg_enabled():
-    """the several-lanes-per-track UKF kernels (csrc/ukf_mlg.hip) serve dim_x 10..16: FK_UKF_MLG=1 / 0, or the default"""
-    v = os.environ.get("FK_UKF_MLG")
-    return (v[:1] == "1") if v else _UKF_MLG_DEFAULT
-
-
 def ukf_linear_supported(n, m, paired=False):
-    """sizes fk_ukf_linear_batch_f64 is compiled for (csrc/ukf_kernels.hip; dim_x 10..16: csrc/ukf_mlg.hip -- four lanes per
-    track, for weights equal within every +- pair, and behind FK_UKF_MLG=1 until it has been through a GPU parity run)"""
-    if 10 <= n <= 16 and 1 <= m <= 8:
-        return bool(paired) and ukf_mlg_enabled()
-    return (1 <= n <= 6 and 1 <= m <= 3) or (7 <= n <= 9 and 1 <= m <= 4)
+    """will fk_ukf_linear_batch_f64 take this size?  The LIBRARY answers (fk_ukf_linear_supported: csrc/ukf_kernels.hip, dim_x <= 9
+    one track per lane; 10..16: csrc/ukf_mlg.hip, several lanes per track, for weights equal within every +- pair), so the host
+    and the library cannot disagree about the library's A/B switches"""
+    return bool(_abi.lib().fk_ukf_linear_supported(int(n), int(m), _abi.FK_UKF_FLAG_PAIR_WEIGHTS if paired else 0, 0))
 
 
 def ukf_linear_rts_supported(n, paired=False):
-    """sizes fk_ukf_linear_rts_f64 is compiled for (dim_x 10..16: like ukf_linear_supported)"""
-    if 10 <= n <= 16:
-        return bool(paired) and ukf_mlg_enabled()
-    return 1 <= n <= 9
+    """will fk_ukf_linear_rts_f64 take this dim_x?  (asked of the library like ukf_linear_supported)"""
+    return bool(_abi.lib().fk_ukf_linear_supported(int(n), 1, _abi.FK_UKF_FLAG_PAIR_WEIGHTS if paired else 0, 1))
 
 
 def pair_weights(Wm, Wc, n):

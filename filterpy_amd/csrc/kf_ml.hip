@@ -642,7 +642,11 @@ kf_ml_kernel(const KfArgs a_in)
     if constexpr (PERS) {
         // this chunk's final state (and status) is in place -- written with agent-scope stores, which are coherent across the
         // XCDs by themselves (a release FENCE here writes back the whole L2 the kernel is streaming 14 GB of outputs through:
-        // measured 0.55 ms per chunk) -- and complete once the barrier's vmcnt(0) has passed: publish the chunk
+        // measured 0.55 ms per chunk).  They are COMPLETE only once this wave's vmcnt has drained: a workgroup barrier does not
+        // wait for VMEM on gfx950 (the compiler emits `s_waitcnt vmcnt(63)` -- nothing -- in front of s_barrier; ADVICE r4: with
+        // status == NULL no other wait stood between the hand-over stores and the flag), so every wave drains explicitly --
+        // inline asm, invisible to the pass that drops "redundant" waits -- then the barrier, then the chunk is published
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (threadIdx.x == 0) __hip_atomic_store(&a_in.pers_ctl[1 + pers_g], pers_h + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {

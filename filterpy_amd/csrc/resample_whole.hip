@@ -31,7 +31,7 @@
 namespace fk {
 
 struct WholeArgs {
-    int Np, force_exact;
+    int Np, force_exact, Fn;
     const double *w, *u;
     int32_t *idx, *status;
 };
@@ -77,33 +77,72 @@ resample_whole_kernel(const WholeArgs a)
     using Sh = WholeShared<NT>;
     constexpr int NW = Sh::NW, CAP = Sh::CAP;
     __shared__ Sh sh;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int Np = a.Np;
-    const int f = blockIdx.x;
-    const double *wf = a.w + (long)f * Np;
-    int32_t *of = a.idx + (long)f * Np;
-    const double u_sys = STRATIFIED ? 0.0 : a.u[f];
-    const double *u_str = STRATIFIED ? a.u + (long)f * Np : nullptr;
     const double Nd = (double)Np, halfNd = 0.5 * Nd;
-    const int j0 = tid * WH_ITEMS;
     WH_CLOCK_START();
 
     // ---- weights: eight consecutive ones per thread, straight from HBM into registers (padding: +0.0) ----
-    double w[WH_ITEMS];
-    if ((((uintptr_t)wf) & 15) == 0 && j0 + WH_ITEMS <= Np) {
-        const double *src = wf + j0;
-        FK_UNROLL for (int q = 0; q < WH_ITEMS; q += 2) {
-            const f64x2 t = *reinterpret_cast<const f64x2 *>(src + q);
-            w[q] = t.x;
-            w[q + 1] = t.y;
+    auto fetch = [&](int f, int j0, double (&dst)[WH_ITEMS]) {
+        const double *wf = a.w + (long)f * Np;
+        if ((((uintptr_t)wf) & 15) == 0 && j0 + WH_ITEMS <= Np) {
+            const double *src = wf + j0;
+            FK_UNROLL for (int q = 0; q < WH_ITEMS; q += 2) {
+                const f64x2 t = *reinterpret_cast<const f64x2 *>(src + q);
+                dst[q] = t.x;
+                dst[q + 1] = t.y;
+            }
+        } else {
+            FK_UNROLL for (int q = 0; q < WH_ITEMS; ++q) {
+                const int j = j0 + q;
+                const double t = wf[j < Np ? j : 0];                       // Np >= 1: always a valid address
+                dst[q] = j < Np ? t : 0.0;
+            }
         }
-    } else {
-        FK_UNROLL for (int q = 0; q < WH_ITEMS; ++q) {
-            const int j = j0 + q;
-            const double t = wf[j < Np ? j : 0];                           // Np >= 1: always a valid address
-            w[q] = j < Np ? t : 0.0;
-        }
+    };
+    // Round 5: the grid is PERSISTENT -- a workgroup takes the filters blockIdx.x, + gridDim.x, ... (whole_launch: one grid's
+    // worth of resident workgroups) and fetches the NEXT filter's weights into a second register set before it starts on the
+    // current one: of a filter's 12.7k clocks 4.2k were the HBM latency of its weights with nothing else resident on the CU to
+    // cover them (one 1024-thread workgroup per CU; profiles/r03/resample_whole_phase_clocks.jsonl), and every later round of a
+    // 1000-filter call paid them again.  The prefetched set (and the next filter's u) is landed just before the index stores,
+    // i.e. behind ~8k clocks of work, and NO other global load sits in the common path in between: vmcnt retires in order, so
+    // a wait for any younger load would wait for the prefetch too.  The exact round (one vector in ~500) needs the registers:
+    // the prefetched set is dead across it and simply fetched again behind it (from L2 by then) -- no spill in either path.
+    double w[WH_ITEMS], wn[WH_ITEMS];
+    FK_UNROLL for (int q = 0; q < WH_ITEMS; ++q) w[q] = wn[q] = 0.0;
+    int f = blockIdx.x;
+    double u_sys = 0.0, u_next = 0.0;
+    if (f < a.Fn) {
+        fetch(f, (int)threadIdx.x * WH_ITEMS, w);
+        if (!STRATIFIED) u_sys = a.u[f];
     }
+    // (landed before the loop is entered: with loads pending on ONE of the two ways into the loop head, the wait in front of the
+    //  first use of w becomes a vmcnt(0) on both -- and in every later trip it would wait for the prefetch issued just above it)
+    FK_UNROLL for (int q = 0; q < WH_ITEMS; ++q) asm volatile("" ::"v"(w[q]));
+    asm volatile("" ::"v"(u_sys));
+    for (; f < a.Fn; f += gridDim.x) {
+    // the thread's coordinates are re-derived in every trip from an opaque copy of threadIdx.x: as loop invariants the two
+    // dozen addresses and masks derived from them were hoisted, kept live across the whole body and SPILLED (104 bytes of
+    // scratch, reloaded behind a vmcnt(0) in front of two of the barriers); re-deriving them is a handful of VALU instructions
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63, wave = tid >> 6, j0 = tid * WH_ITEMS;
+    const double *wf = a.w + (long)f * Np;
+    int32_t *of = a.idx + (long)f * Np;
+    const double *u_str = STRATIFIED ? a.u + (long)f * Np : nullptr;
+    const int f_next = f + (int)gridDim.x;
+    const bool has_next = f_next < a.Fn;                                   // uniform
+    auto prefetch = [&]() {
+        if (has_next) {
+            fetch(f_next, j0, wn);
+            if (!STRATIFIED) u_next = a.u[f_next];
+        } else {                             // (a definition on every path: the set is DEAD across the exact round, not carried)
+            FK_UNROLL for (int q = 0; q < WH_ITEMS; ++q) wn[q] = 0.0;
+            u_next = 0.0;
+        }
+    };
+    // systematic: in flight from here until the end of this trip.  Stratified: its boundaries GATHER u[f][.] (a wait for those
+    // loads would be a wait for the prefetch issued before them), so there the prefetch starts behind the boundaries
+    if (!STRATIFIED) prefetch();
     // the slot window and the segment claims are reset while the loads are in flight
     FK_UNROLL for (int g = 0; g < WH_ITEMS / 4; ++g) *reinterpret_cast<i32x4 *>(&sh.win[j0 + 4 * g]) = i32x4{-1, -1, -1, -1};
     for (int r = tid; r <= WH_DMAX; r += NT) sh.seg_e[r] = WH_NONE;
@@ -230,7 +269,11 @@ resample_whole_kernel(const WholeArgs a)
             const int st = literal_merge<STRATIFIED>(wf, STRATIFIED ? u_str : a.u + f, (long)Np, of);
             if (a.status) a.status[f] = st;
         }
-        return;
+        __syncthreads();                     // nobody still reads this filter's shared state when the next one resets it
+        if (STRATIFIED) prefetch();
+        FK_UNROLL for (int q = 0; q < WH_ITEMS; ++q) w[q] = wn[q];
+        u_sys = u_next;
+        continue;
     }
 
     // ---- cumulative sums -> slot boundaries: weight j owns the slots [n_{j-1}, n_j), n_j = n(cs_j) ------------------
@@ -239,6 +282,7 @@ resample_whole_kernel(const WholeArgs a)
     __syncthreads();                                                                          // (5)
     WH_CLOCK(4);                                                           // boundaries
     }   // exact
+    if (STRATIFIED) prefetch();
     int nprev = tid == 0 ? 0 : sh.nlast[tid - 1];
     const int u_hi = __builtin_amdgcn_readfirstlane(sh.nlast[NT - 1]);     // = n(carry-out): slots [0, u_hi) get an index
     // window position p = slot + sft: with sft = (address of slot 0 in ints) mod 4 a thread's two quads are 16-byte
@@ -275,6 +319,8 @@ resample_whole_kernel(const WholeArgs a)
         if (wv < wave) pre = pre > t ? pre : t;
     }
     const int last = Np - 1;
+    FK_UNROLL for (int q = 0; q < WH_ITEMS; ++q) asm volatile("" ::"v"(wn[q]));   // the next filter's weights land HERE
+    asm volatile("" ::"v"(u_next));
     FK_UNROLL for (int g = 0; g < WH_ITEMS / 4; ++g) {
         int v[4];
         FK_UNROLL for (int e = 0; e < 4; ++e) {
@@ -292,6 +338,9 @@ resample_whole_kernel(const WholeArgs a)
     if (tid == 0 && a.status) a.status[f] = u_hi < Np ? ST_OVERRUN : 0;
     WH_CLOCK(7);                                                           // stores issued
     WH_COUNT(11, 1);
+    FK_UNROLL for (int q = 0; q < WH_ITEMS; ++q) w[q] = wn[q];
+    u_sys = u_next;
+    }   // filters of this workgroup
 }
 
 // Np <= 8192: one workgroup of 256 / 512 / 1024 threads per filter (8 weights per thread)
@@ -309,7 +358,20 @@ int whole_launch(bool stratified, int64_t Fn, int64_t Np, const double *w, const
     a.u = u;
     a.idx = idx;
     a.status = status;
-    const dim3 grid((unsigned)Fn);
+    a.Fn = (int)Fn;
+    // one grid's worth of resident workgroups (16 waves per CU at <= 128 VGPRs: one 1024-, two 512-, four 256-thread workgroups),
+    // each walking its filters f, f + grid, ...  FK_WHOLE_GRID=<workgroups> forces a grid (0: one workgroup per filter as before)
+    static const int cus = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        return n;
+    }();
+    const char *gv = getenv("FK_WHOLE_GRID");                              // (per call, like FK_WHOLE_EXACT: the tests flip it)
+    const long forced = gv ? atol(gv) : -1L;
+    const int per_cu = Np <= 256 * WH_ITEMS ? 4 : Np <= 512 * WH_ITEMS ? 2 : 1;
+    long G = forced > 0 ? forced : forced == 0 ? Fn : (long)cus * per_cu;
+    if (G > Fn) G = Fn;
+    const dim3 grid((unsigned)G);
 #define GO(NTV, EUV)                                                                                             \
     do {                                                                                                         \
         if (stratified) hipLaunchKernelGGL((resample_whole_kernel<true, NTV, EUV>), grid, dim3(NTV), 0, s, a);   \

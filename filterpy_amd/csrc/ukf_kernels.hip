@@ -690,24 +690,31 @@ static int ukf_mlg_rts_launch(const UkfRtsArgs &a, const double *F, const double
 }
 #endif
 
-// FK_UKF_MLG_DEFAULT: what an unset FK_UKF_MLG means.  0 until tests/test_gpu_ukf_mlg.py has run on a GPU; the one place to flip
-// on the C side (the Python side: _engine._UKF_MLG_DEFAULT).
-#ifndef FK_UKF_MLG_DEFAULT
-#define FK_UKF_MLG_DEFAULT 0
-#endif
-// FK_UKF_MLG=1: the four-lane kernels serve dim_x 10..16; FK_UKF_MLG_MIN_NX=7 | 8 | 9 additionally hands them the pair-weight
-// calls of the one-lane classes from that dim_x on (A/B: those classes run one wave per SIMD with scratch)
-static int ukf_mlg_min_nx()
+// Which calls the several-lanes-per-track kernels (ukf_mlg.hip) serve, decided by measurement (profiles/r05/ukf_mlg/):
+//   filter:   dim_x 10..16 (no one-lane kernel exists there); at 7..9 the one-lane classes are faster (8: 1.9 vs 2.8 ms, 9: 2.2
+//             vs 4.4 ms at N = 1e5, T = 100) and keep the call;
+//   smoother: dim_x 10..16, and 7..9 too for pair-weight callers (8: 5.1 / 8.2 -> 4.4 / 4.1 ms, 9: 10.3 / 13.8 -> 7.8 / 7.4 ms
+//             element-major / NumPy order): the one-lane smoother classes run one wave per SIMD with 0.4-1.3 KB of scratch.
+// A/B knobs, read once per process: FK_UKF_MLG=0 takes the several-lane kernels out altogether (dim_x >= 10 then answers
+// FK_ERR_UNSUPPORTED and the host takes the building blocks); FK_UKF_MLG_MIN_NX / FK_UKF_MLG_RTS_MIN_NX = 7..10 move the
+// filter's / the smoother's lower bound.
+struct UkfMlgRoute { int fwd_min, rts_min; };
+static UkfMlgRoute ukf_mlg_route()
 {
-    static const int v = [] {
+    static const UkfMlgRoute v = [] {
         const char *on = getenv("FK_UKF_MLG");
-        if (!(on ? on[0] == '1' : FK_UKF_MLG_DEFAULT != 0)) return 99;
-        const char *mn = getenv("FK_UKF_MLG_MIN_NX");
-        const int m = mn ? atoi(mn) : 10;
-        return m >= 7 && m <= 10 ? m : 10;
+        if (on && on[0] == '0') return UkfMlgRoute{99, 99};
+        auto knob = [](const char *name, int dflt) {
+            const char *mn = getenv(name);
+            const int m = mn ? atoi(mn) : dflt;
+            return m >= 7 && m <= 10 ? m : dflt;
+        };
+        return UkfMlgRoute{knob("FK_UKF_MLG_MIN_NX", 10), knob("FK_UKF_MLG_RTS_MIN_NX", 7)};
     }();
     return v;
 }
+static int ukf_mlg_min_nx() { return ukf_mlg_route().fwd_min; }
+static int ukf_mlg_rts_min_nx() { return ukf_mlg_route().rts_min; }
 
 static int fail(int code, const char *msg)
 {
@@ -737,19 +744,31 @@ using namespace fk;
 extern "C" {
 
 #if FK_UKF_HAS(1)
+int fk_ukf_linear_supported(int32_t n, int32_t m, int32_t flags, int32_t smoother)
+{
+    const bool pairw = (flags & FK_UKF_FLAG_PAIR_WEIGHTS) != 0;
+    if (smoother) {
+        if (n >= 10 && n <= 16) return pairw && ukf_mlg_rts_min_nx() <= 10;
+        return n >= 1 && n <= 9;
+    }
+    if (n >= 10 && n <= 16) return m >= 1 && m <= 8 && pairw && ukf_mlg_min_nx() <= 10;
+    return (n >= 1 && n <= 6 && m >= 1 && m <= 3) || (n >= 7 && n <= 9 && m >= 1 && m <= 4);
+}
+#endif
+
+#if FK_UKF_HAS(1)
 int fk_ukf_linear_batch_f64(const fk_ukf_desc *d, const double *F, const double *H, const double *Q,
                             const double *R, const double *Wm, const double *Wc, const double *z,
                             const uint8_t *mask, double *x, double *P, double *means, double *covs,
                             int32_t *status, void *stream)
 {
     if (!d) return fail(FK_ERR_BAD_ARG, "desc is NULL");
-    // dim_x 10..16 (dim_z 1..8): four lanes per track (ukf_mlg.hip), the pair-regrouped sums only -- and only with FK_UKF_MLG=1
-    // until the kernel has been through a GPU parity run (round 4 ended without one; tests/test_gpu_ukf_mlg.py)
+    // dim_x 10..16 (dim_z 1..8): four / eight lanes per track (ukf_mlg.hip), the pair-regrouped sums only
     const bool big = d->n >= 10 && d->n <= 16 && d->m >= 1 && d->m <= 8;
     const bool quad = big || (d->n >= ukf_mlg_min_nx() && d->n <= 9 && d->m >= 1 && d->m <= 4 && (d->flags & FK_UKF_FLAG_PAIR_WEIGHTS) && ukf_paired(d));
     if (big) {
         if (ukf_mlg_min_nx() > 10 || !(d->flags & FK_UKF_FLAG_PAIR_WEIGHTS))
-            return fail(FK_ERR_UNSUPPORTED, "fused linear UKF at dim_x 10..16: FK_UKF_MLG=1 and weights equal within every +- pair (FK_UKF_FLAG_PAIR_WEIGHTS)");
+            return fail(FK_ERR_UNSUPPORTED, "fused linear UKF at dim_x 10..16: needs weights equal within every +- pair (FK_UKF_FLAG_PAIR_WEIGHTS; and FK_UKF_MLG != 0)");
     } else if (d->n < 1 || d->n > 9 || d->m < 1 || d->m > 4 || (d->n <= 6 && d->m > 3))
         return fail(FK_ERR_UNSUPPORTED, "fused linear UKF: dim_x 1..6 with dim_z 1..3, dim_x 7..9 with dim_z 1..4, dim_x 10..16 with dim_z 1..8");
     if (d->N < 0 || d->T < 0 || !F || !H || !Q || !R || !Wm || !Wc || !z || !x || !P)
@@ -788,12 +807,12 @@ int fk_ukf_linear_rts_f64(const fk_ukf_desc *d, const double *F, const double *Q
                           void *stream)
 {
     if (!d) return fail(FK_ERR_BAD_ARG, "desc is NULL");
-    // dim_x 10..16: four lanes per track (ukf_mlg.hip), pair-regrouped sums only, opt-in like the filter (fk_ukf_linear_batch_f64)
+    // dim_x 10..16 -- and 7..9 for pair-weight callers (ukf_mlg_route) --: four / eight lanes per track (ukf_mlg.hip), pair-regrouped sums only
     const bool big = d->n >= 10 && d->n <= 16;
-    const bool quad = big || (d->n >= ukf_mlg_min_nx() && d->n <= 9 && (d->flags & FK_UKF_FLAG_PAIR_WEIGHTS) && ukf_paired(d));
+    const bool quad = big || (d->n >= ukf_mlg_rts_min_nx() && d->n <= 9 && (d->flags & FK_UKF_FLAG_PAIR_WEIGHTS) && ukf_paired(d));
     if (big) {
-        if (ukf_mlg_min_nx() > 10 || !(d->flags & FK_UKF_FLAG_PAIR_WEIGHTS))
-            return fail(FK_ERR_UNSUPPORTED, "fused linear UKF smoother at dim_x 10..16: FK_UKF_MLG=1 and weights equal within every +- pair (FK_UKF_FLAG_PAIR_WEIGHTS)");
+        if (ukf_mlg_rts_min_nx() > 10 || !(d->flags & FK_UKF_FLAG_PAIR_WEIGHTS))
+            return fail(FK_ERR_UNSUPPORTED, "fused linear UKF smoother at dim_x 10..16: needs weights equal within every +- pair (FK_UKF_FLAG_PAIR_WEIGHTS; and FK_UKF_MLG != 0)");
     } else if (d->n < 1 || d->n > 9) return fail(FK_ERR_UNSUPPORTED, "fused linear UKF smoother: dim_x 1..9, 10..16");
     if (quad && (double)d->N * d->n * d->n * 8.0 >= 4294967296.0 - 32.0) return fail(FK_ERR_UNSUPPORTED, "fused linear UKF smoother: record block >= 4 GiB, split the batch");
     if (d->N < 0 || d->T < 0 || !F || !Q || !Wm || !Wc || !Xs || !Ps || !xs || !Ps_out)

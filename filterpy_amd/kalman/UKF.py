@@ -583,6 +583,7 @@ class UnscentedKalmanFilter(object):
                     mask[i] = 0
                 else:
                     zarr[i] = np.asarray(zi, dtype=np.float64).reshape(N, m)
+            x_init, P_init = np.array(self.x, dtype=np.float64), np.array(self.P, dtype=np.float64)
             dx, dP = E.to_records(self._b(self.x, (n,)), lay, 0), E.to_records(self._b(self.P, (n, n)), lay, 0)
             means, covs = E.alloc_records((T,), N, n, lay), E.alloc_records((T,), N, n * n, lay)
             st = torch.zeros(N, dtype=torch.int32, device=dx.device)
@@ -597,14 +598,19 @@ class UnscentedKalmanFilter(object):
             P_end = self._unb(E.from_records(dP, lay, 0, (n, n)))
             mu, cov = E.from_records(means, lay, 1, (n,)), E.from_records(covs, lay, 1, (n, n))
             # The reference's loop leaves the LAST epoch's by-products on the filter (UKF.py:623-632: x_prior / P_prior, sigmas_f,
-            # sigmas_h, K, S, SI, y, z, x_post / P_post, the lazy likelihoods reset); the fused launch keeps them in registers.
-            # One replay of that epoch through predict() / update() from the state before it puts them there;
-            # x / P themselves stay the fused launch's, so that means[-1] is self.x bit for bit like in the reference.
+            # z, x_post / P_post, the lazy likelihoods reset) and -- update(None) returns early, UKF.py:443-447 -- the K, S, SI,
+            # y, sigmas_h of the last epoch that HAD a measurement; the fused launch keeps all of them in registers.  Those
+            # epochs (one, or two when the call ends on missing measurements: ADVICE r4) are replayed through predict() /
+            # update() from the state before them; x / P themselves stay the fused launch's, so that means[-1] is self.x bit
+            # for bit like in the reference.
             if T >= 1:
-                if T >= 2:
-                    self.x, self.P = self._unb(np.array(mu[T - 2])), self._unb(np.array(cov[T - 2]))
-                self.predict()
-                self.update(zs[T - 1])
+                def before(t):
+                    return (x_init, P_init) if t == 0 else (self._unb(np.array(mu[t - 1])), self._unb(np.array(cov[t - 1])))
+                seen = [t for t in range(T) if zs[t] is not None]
+                for t in ([seen[-1]] if seen and seen[-1] != T - 1 else []) + [T - 1]:
+                    self.x, self.P = before(t)
+                    self.predict()
+                    self.update(zs[t])
             self.x, self.P = x_end, P_end
             self.x_post, self.P_post = np.copy(self.x), np.copy(self.P)
             return (mu, cov) if self._N is not None else (mu[:, 0], cov[:, 0])

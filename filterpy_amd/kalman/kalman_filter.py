@@ -62,17 +62,17 @@ def _seq(v, n):
 
 class _Core:
     """Shared device plumbing for one bank of N filters (N = 1 for KalmanFilter)."""
-    last_placement = None     # how the last batch() call with device outputs placed its covariance histories
 
     @staticmethod
     def batch(n, m, N, T, x0, P0, z, mask, F, Q, H, R, mode, B=None, us=None, nu=0,
               alpha_sq=1.0, update_first=False, layout="soa", want_outputs=True, device_outputs=False,
-              extras=(), cov_interleave=True, placement=None):
+              extras=(), cov_interleave=True, placement=None, placement_out=None):
         """All inputs are host arrays shaped for `mode`:
         x0 (N,n) P0 (N,n,n) z (T,N,m) mask (T,N) or None;
         models: SHARED (a,b) | PER_TRACK (N,a,b) | PER_STEP (T,a,b) | PER_TRACK_STEP (T,N,a,b).
         Returns (means, covs, means_p, covs_p, x_final, P_final) as host arrays (T,N,...)
-        or device tensors in `layout` when device_outputs."""
+        or device tensors in `layout` when device_outputs.  placement_out: a dict of the CALLER's that receives how the covariance
+        histories were placed (per call: no state shared between banks or threads)."""
         import torch
         E.require_gpu()
 
@@ -95,9 +95,14 @@ class _Core:
         # and prior record of a track side by side (FK_KF_FLAG_COV_INTERLEAVED): one write front instead of two that may
         # interfere (docs/PLACEMENT.md).  The caller gets strided views.  Where the specialised kernel does not serve the
         # call (FK_ERR_UNSUPPORTED) two plain arrays are used.
-        inter = bool(want_outputs and device_outputs and not extras and cov_interleave and n <= 9
+        # Asked for only where the library takes it (kf_dispatch.cpp, run_kf_window): the specialised kernel's calls -- dim_x <= 9
+        # except (9,3), which runs on the three-lane kernel; predict -> update without a control input; any model mode up to
+        # dim_x 6, the shared constant model above.  (The except branch below stays as the safety net for the library's A/B
+        # switches; it reports what it did.)
+        inter = bool(want_outputs and device_outputs and not extras and cov_interleave and n <= 9 and (n, m) != (9, 3)
+                     and m <= min(n, 4) and nu == 0 and not update_first and (mode == FK_MODEL_SHARED or n <= 6)
                      and 2 * N * n * n * 8 < 2 ** 32 and placement != "probe")
-        _Core.last_placement = {"method": "interleave" if inter else "none"}
+        pinfo = {"method": "interleave" if inter else "none"}
         if want_outputs and device_outputs and not extras and placement == "probe" and T * N * n * n * 8 >= (256 << 20):
             # two dense arrays, placed in HBM by measuring this very launch on several candidate buffers (placement.py:
             # placed_pair; the pair is remembered per shape, the losers are freed).  Worth ~7 % over the interleaved array
@@ -118,7 +123,7 @@ class _Core:
                 e1.record()
                 torch.cuda.synchronize()
                 return e0.elapsed_time(e1)
-            pa, pb, _Core.last_placement = _pl.placed_pair(T * N * n * n * 8, run_ms, dx.device)
+            pa, pb, pinfo = _pl.placed_pair(T * N * n * n * 8, run_ms, dx.device)
             dx.copy_(dx0)
             dP.copy_(dP0)
             st.zero_()
@@ -151,7 +156,11 @@ class _Core:
                 if not (inter and exc.code == _abi.FK_ERR_UNSUPPORTED):
                     raise
                 outs[1], outs[3] = E.alloc_records((T,), N, n * n, layout), E.alloc_records((T,), N, n * n, layout)
+                pinfo = {"method": "none", "note": "interleaved histories declined by the library: " + str(exc)[:160]}
                 E.kf_batch_filter(desc, *args, means=outs[0], covs=outs[1], means_p=outs[2], covs_p=outs[3], **kw)
+        if placement_out is not None:
+            placement_out.clear()
+            placement_out.update(pinfo)
         E.raise_on_status(st, "batch_filter")
         if device_outputs:
             return outs + [dx, dP] + ([ex] if extras else [])
@@ -882,11 +891,12 @@ class KalmanFilterBank(object):
                 mask = ~nanrow
             if mask is not None:
                 z = np.where(np.asarray(mask, dtype=bool)[..., None], z, 0.0)
+        pinfo = {}
         out = _Core.batch(self.dim_x, self.dim_z, self.n_tracks, T, x, P, z, mask, mods["F"], mods["Q"],
                           mods["H"], mods["R"], mode, alpha_sq=self._alpha_sq, update_first=update_first,
                           layout=self.layout, want_outputs=store, device_outputs=device_outputs, extras=tuple(extras),
-                          cov_interleave=cov_interleave, placement=placement)
-        self.placement_info = _Core.last_placement
+                          cov_interleave=cov_interleave, placement=placement, placement_out=pinfo)
+        self.placement_info = pinfo
         if device_outputs:
             self.x = E.from_records(out[4], self.layout, 0, (self.dim_x,))
             self.P = E.from_records(out[5], self.layout, 0, (self.dim_x, self.dim_x))

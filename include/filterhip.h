@@ -267,8 +267,8 @@ typedef struct fk_ukf_desc {
  *   z [T][N][m], mask [T][N] or NULL; x [N][n], P [N][n*n] in/out;
  *   means [T][N][n], covs [T][N][n*n] posterior per step (NULL = not stored).
  * Sizes: dim_x 1..6 with dim_z 1..3, dim_x 7..9 with dim_z 1..4 (one track per lane, ukf_kernels.hip); dim_x 10..16 with
- * dim_z 1..8 on four lanes per track (ukf_mlg.hip) for FK_UKF_FLAG_PAIR_WEIGHTS callers -- while that kernel has had no GPU
- * parity run only with FK_UKF_MLG=1 in the environment; FK_ERR_UNSUPPORTED otherwise (the building blocks serve every size). */
+ * dim_z 1..8 on four / eight lanes per track (ukf_mlg.hip) for FK_UKF_FLAG_PAIR_WEIGHTS callers; FK_ERR_UNSUPPORTED
+ * otherwise (the building blocks serve every size) -- fk_ukf_linear_supported answers without a launch. */
 int fk_ukf_linear_batch_f64(const fk_ukf_desc *desc,
                             const double *F, const double *H, const double *Q, const double *R,
                             const double *Wm, const double *Wc,
@@ -279,8 +279,8 @@ int fk_ukf_linear_batch_f64(const fk_ukf_desc *desc,
 /* UnscentedKalmanFilter.rts_smoother (filterpy/kalman/UKF.py:634-739) with LINEAR fx(x, dt) = F x, fused per track:
  * the whole backward loop in one launch (per step: sigma points of (xs[k], ps[k]) -> F sigma -> unscented transform
  * + Q -> cross variance around Xs[k] / xb -> K = Pxb inv(Pb) -> xs[k] += K (xs[k+1] - xb), ps[k] += K (ps[k+1] - Pb) K').
- * desc: n (1..9; 10..16 on four lanes per track for FK_UKF_FLAG_PAIR_WEIGHTS callers, opt-in with FK_UKF_MLG=1 like
- *   fk_ukf_linear_batch_f64), N, T, layout, scale = lambda + n (m is ignored).
+ * desc: n (1..9; 10..16 on four / eight lanes per track for FK_UKF_FLAG_PAIR_WEIGHTS callers, like
+ *   fk_ukf_linear_batch_f64; pair-weight callers get those kernels from dim_x 7 on), N, T, layout, scale = lambda + n (m is ignored).
  *   F [n*n], Q [n*n] (the filter's Q: the reference never reads its Qs argument, UKF.py:717-722), Wm, Wc [2n+1];
  *   Xs [T][N][n], Ps [T][N][n*n]: the filter output; xs, Ps_out likewise: the smoothed output (distinct arrays); K
  *   [T][N][n*n] or NULL (K of the last step is zero, like the reference's); status [N] or NULL.
@@ -290,6 +290,12 @@ int fk_ukf_linear_batch_f64(const fk_ukf_desc *desc,
 int fk_ukf_linear_rts_f64(const fk_ukf_desc *desc, const double *F, const double *Q, const double *Wm, const double *Wc,
                           const double *Xs, const double *Ps, double *xs, double *Ps_out, double *K, int32_t *status,
                           void *stream);
+
+/* Will fk_ukf_linear_batch_f64 (smoother = 0) / fk_ukf_linear_rts_f64 (smoother != 0; m ignored) take this size with these
+ * fk_ukf_desc.flags?  1 / 0; no launch, no device needed.  The host side of UnscentedKalmanFilter.batch_filter / rts_smoother
+ * (filterpy/kalman/UKF.py:524-739) asks before choosing between the fused launch and the per-step building blocks, so that the
+ * two sides cannot disagree about the library's A/B switches (FK_UKF_MLG, read once per process by the library). */
+int fk_ukf_linear_supported(int32_t n, int32_t m, int32_t flags, int32_t smoother);
 
 /* ------------------------------------------------------------------ */
 /* API variants of the linear filter               */

@@ -86,7 +86,6 @@ def gpu_tests(monkeypatch_module):
     lib = _host_lib()
     from filterpy_amd import _engine as E
     mp = monkeypatch_module
-    mp.setenv("FK_UKF_MLG", "1")
     mp.setattr(E, "require_gpu", lambda: torch.device("cpu"))
     real_dev = E.dev
     mp.setattr(E, "dev", lambda a, device=None: real_dev(a, device).clone())      # (an upload copies; torch.from_numpy on the CPU aliases)
@@ -134,8 +133,8 @@ def test_dry_smoother_bank_sizes(gpu_tests):
 @pytest.mark.parametrize("n,m", [(7, 1), (8, 4), (9, 3), (9, 4)])
 def test_dry_small_dims(gpu_tests, n, m):
     """(the FK_UKF_MLG_MIN_NX=7 A/B: dim_x 7..9 on the four-lane kernels)"""
-    gpu_tests.test_small_dims_filter_vs_oracle(n, m, "soa")
-    gpu_tests.test_small_dims_filter_vs_oracle(n, m, "aos")
+    gpu_tests._small_dims_filter_vs_oracle(n, m, "soa")
+    gpu_tests._small_dims_filter_vs_oracle(n, m, "aos")
     if m == 4 or n == 7:
         gpu_tests.test_small_dims_smoother_vs_oracle(n, "aos")
 
@@ -146,7 +145,6 @@ def test_dry_python_api(monkeypatch, layout):
     marshalling and last-epoch replay around the fused calls (the building blocks served by tests/fake_ut_engine.py's stand-ins),
     against the live-reference goldens."""
     import fake_ut_engine
-    monkeypatch.setenv("FK_UKF_MLG", "1")
     fake_ut_engine.install(monkeypatch)
     _install_fused(monkeypatch, _host_lib())
     from filterpy_amd import _engine as E

@@ -194,12 +194,14 @@ def test_ukf_general_callables_vs_reference():
         assert rel_err_rows(mu2, g[p + "mu"]) < tmu and rel_err_rows(cov2, g[p + "cov"]) < tcov
 
 
-@pytest.mark.parametrize("last_missing", [False, True])
+@pytest.mark.parametrize("last_missing", [0, 1, 2, 6])
 def test_ukf_fused_batch_filter_leaves_the_last_epochs_attributes(last_missing):
     """the reference's batch_filter is a loop of predict() / update() (UKF.py:623-632), so afterwards the filter
     carries the LAST epoch's x_prior / P_prior, sigmas_f, sigmas_h, K, S, SI, y, z, x_post / P_post and reset likelihood
     caches.  The fused launch (matrix fx / hx) must leave the same: compared with the same filter stepped one call at a
-    time through the callable path, single filter and bank; means[-1] is self.x bit for bit."""
+    time through the callable path, single filter and bank; means[-1] is self.x bit for bit.  last_missing = k: the call
+    ends on k missing measurements -- update(None) returns early (UKF.py:443-447), so K / S / SI / y / sigmas_h are those of
+    the last epoch that HAD a measurement (k = 6: none had one, the constructor's values stay)."""
     from filterpy_amd.kalman import UnscentedKalmanFilter, MerweScaledSigmaPoints
     g = golden("ukf_merwe")
     ci = [i for i, c in enumerate(g["cases"]) if int(c[0]) == 6][0]
@@ -207,8 +209,8 @@ def test_ukf_fused_batch_filter_leaves_the_last_epochs_attributes(last_missing):
     p = f"c{ci}_"
     F, H = g[p + "F"], g[p + "H"]
     zs = list(g[p + "zs"][:6])
-    if last_missing:
-        zs[-1] = None
+    for k in range(last_missing):
+        zs[-1 - k] = None
     for N in (None, 70):
         def make(fx, hx):
             u = UnscentedKalmanFilter(n, m, dt=1.0, hx=hx, fx=fx, points=MerweScaledSigmaPoints(n, alpha, beta, kappa),
@@ -225,7 +227,7 @@ def test_ukf_fused_batch_filter_leaves_the_last_epochs_attributes(last_missing):
             b.update(z)
         assert np.array_equal(np.asarray(a.x), mu[-1]) and np.array_equal(np.asarray(a.P), cov[-1])
         assert np.array_equal(a.x_post, a.x) and np.array_equal(a.P_post, a.P)
-        for attr in ("x", "P", "x_prior", "P_prior", "sigmas_f", "x_post", "P_post") + (() if last_missing else ("sigmas_h", "K", "S", "SI", "y")):
+        for attr in ("x", "P", "x_prior", "P_prior", "sigmas_f", "x_post", "P_post", "sigmas_h", "K", "S", "SI", "y"):
             va, vb = np.asarray(getattr(a, attr), dtype=float), np.asarray(getattr(b, attr), dtype=float)
             assert va.shape == vb.shape, (attr, va.shape, vb.shape)
             assert rel_err_rows(va.reshape(1, -1), vb.reshape(1, -1)) < 1e-10, (attr, N)

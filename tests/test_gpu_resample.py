@@ -370,6 +370,21 @@ def test_whole_vector_kernel_every_route(Np, exact, monkeypatch):
     _check_against_merge_loop(5, Np, kinds, range(5), monkeypatch, force=False)
 
 
+@pytest.mark.parametrize("grid", ["0", "1", "2", "3"])
+@pytest.mark.parametrize("Np", [7, 2049, 4097, 8000, 8191])
+def test_whole_vector_kernel_persistent_grid(Np, grid, monkeypatch):
+    """Round 5: resample_whole_kernel's grid is persistent -- a workgroup walks the filters b, b + grid, ... and fetches the next
+    filter's weights (and u) into a second register set while it works on the current one.  FK_WHOLE_GRID forces the grid:
+    1 / 2 / 3 workgroups for 7 filters (every workgroup makes several trips; a trip that ends in the literal loop or runs the
+    exact round hands the prefetched set on like any other), 0 = one workgroup per filter.  Every family, every filter, against
+    the reference's merge loop; odd Np: every filter at another 16-byte phase (scalar weight loads in the prefetch)."""
+    monkeypatch.setenv("FK_WHOLE_GRID", grid)
+    kinds = [k for k in _FAMILIES + ("dyadic", "tiny") if not (k in ("negative", "nan") and Np < 8)]
+    _check_against_merge_loop(7, Np, kinds, range(7), monkeypatch, force=False)
+    monkeypatch.setenv("FK_WHOLE_EXACT", "1")
+    _check_against_merge_loop(7, Np, ("uniform", "negative", "zeros"), range(7), monkeypatch, force=False)
+
+
 def test_whole_vector_kernel_positions_on_cumulative_sums(monkeypatch):
     """u chosen so that a position lands on / next to a cumulative sum (0 ... 2^-20 slots on either side): the estimates
     inside the error band send their vector to the exact round, the others are decided by the plain prefix sums -- both
@@ -408,8 +423,10 @@ def test_whole_vector_kernel_positions_on_cumulative_sums(monkeypatch):
 def test_whole_vector_kernel_many_filters(monkeypatch):
     """the C5 shape: 1000 x 8000 and 125 x 8000 in one launch each (more workgroups than CUs; two filters per CU),
     sampled filters bit-exact"""
-    _check_against_merge_loop(1000, 8000, ("uniform", "heavy_tail"), (0, 1, 255, 256, 511, 767, 768, 999), monkeypatch, force=False)
+    _check_against_merge_loop(1000, 8000, ("uniform",), range(1000), monkeypatch, force=False)       # (persistent grid: every filter)
+    _check_against_merge_loop(1000, 8000, ("heavy_tail", "negative"), (0, 1, 255, 256, 511, 767, 768, 999), monkeypatch, force=False)
     _check_against_merge_loop(125, 8000, ("uniform", "zeros"), (0, 1, 63, 124), monkeypatch, force=False)
+    _check_against_merge_loop(3000, 2000, ("uniform",), range(0, 3000, 7), monkeypatch, force=False)   # 256-thread workgroups, four per CU
 
 
 def test_local_kernel_on_a_long_vector_and_many_filters(monkeypatch):

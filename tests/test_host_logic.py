@@ -181,8 +181,9 @@ def test_design_table_is_the_committed_evidence():
 
 def test_fused_ukf_size_routing_without_gpu():
     """fk_ukf_linear_batch_f64 / fk_ukf_linear_rts_f64 decide which sizes they serve before anything is launched: the
-    one-lane classes as before; dim_x 10..16 (the four-lane kernels, csrc/ukf_mlg.hip) only with FK_UKF_MLG=1 in the
-    environment AND the pair-weight flag -- the switch is read once per process, so each setting gets its own interpreter."""
+    one-lane classes as before; dim_x 10..16 (the several-lane kernels, csrc/ukf_mlg.hip) with the pair-weight flag -- unless
+    FK_UKF_MLG=0 takes them out (A/B; read once per process, so each setting gets its own interpreter).  fk_ukf_linear_supported
+    must give the same answers without being handed a descriptor: the host side asks it before choosing a path."""
     code = r'''
 import ctypes, sys
 from filterpy_amd import _abi
@@ -197,6 +198,10 @@ def rts(n, flags, N=0):
 PAIR = 1
 out = [fwd(6, 3, 0), fwd(6, 4, 0), fwd(9, 4, PAIR), fwd(9, 5, PAIR), fwd(12, 3, PAIR), fwd(12, 3, 0), fwd(16, 8, PAIR), fwd(16, 9, PAIR), fwd(17, 2, PAIR),
        rts(9, PAIR), rts(12, PAIR), rts(12, 0), rts(17, PAIR)]
+q = lib.fk_ukf_linear_supported
+ask = [q(6, 3, 0, 0), q(6, 4, 0, 0), q(9, 4, PAIR, 0), q(9, 5, PAIR, 0), q(12, 3, PAIR, 0), q(12, 3, 0, 0), q(16, 8, PAIR, 0), q(16, 9, PAIR, 0), q(17, 2, PAIR, 0),
+       q(9, 1, PAIR, 1), q(12, 1, PAIR, 1), q(12, 1, 0, 1), q(17, 1, PAIR, 1)]
+assert [0 if v else -2 for v in ask] == out, (ask, out)
 print(" ".join(str(v) for v in out))
 '''
     def run(env):
@@ -205,9 +210,9 @@ print(" ".join(str(v) for v in out))
         return [int(v) for v in subprocess.check_output([sys.executable, "-c", code], text=True, cwd=ROOT, env=e).split()]
     OK, UNS = 0, -2
     #                  6x3  6x4  9x4  9x5  12x3p 12x3 16x8p 16x9 17x2 | r9  r12p r12  r17
-    assert run({}) == [OK, UNS, OK, UNS, UNS, UNS, UNS, UNS, UNS, OK, UNS, UNS, UNS]
-    assert run({"FK_UKF_MLG": "1"}) == [OK, UNS, OK, UNS, OK, UNS, OK, UNS, UNS, OK, OK, UNS, UNS]
-    assert run({"FK_UKF_MLG": "1", "FK_UKF_MLG_MIN_NX": "7"}) == [OK, UNS, OK, UNS, OK, UNS, OK, UNS, UNS, OK, OK, UNS, UNS]
+    assert run({"FK_UKF_MLG": "0"}) == [OK, UNS, OK, UNS, UNS, UNS, UNS, UNS, UNS, OK, UNS, UNS, UNS]
+    assert run({}) == [OK, UNS, OK, UNS, OK, UNS, OK, UNS, UNS, OK, OK, UNS, UNS]
+    assert run({"FK_UKF_MLG_MIN_NX": "7", "FK_UKF_MLG_RTS_MIN_NX": "10"}) == [OK, UNS, OK, UNS, OK, UNS, OK, UNS, UNS, OK, OK, UNS, UNS]
 
 
 def test_a_strided_mask_is_copied_before_its_pointer_is_handed_to_the_c_abi():
