@@ -31,7 +31,7 @@
 namespace fk {
 
 struct WholeArgs {
-    int Np, force_exact, Fn;
+    int Np, force_exact, Fn, deferred_only;
     const double *w, *u;
     int32_t *idx, *status;
 };
@@ -70,6 +70,33 @@ struct WholeShared {
 };
 
 // EU = waves per SIMD the register allocation must allow (a 1024-thread workgroup is four waves per SIMD)
+// ---- weights: eight consecutive ones per thread, straight from HBM into registers (padding: +0.0) ----
+__device__ __forceinline__ void wh_fetch(const double *wf, int j0, int Np, double (&w)[WH_ITEMS])
+{
+    if ((((uintptr_t)wf) & 15) == 0 && j0 + WH_ITEMS <= Np) {
+        const double *src = wf + j0;
+        FK_UNROLL for (int q = 0; q < WH_ITEMS; q += 2) {
+            const f64x2 t = *reinterpret_cast<const f64x2 *>(src + q);
+            w[q] = t.x;
+            w[q + 1] = t.y;
+        }
+    } else {
+        FK_UNROLL for (int q = 0; q < WH_ITEMS; ++q) {
+            const int j = j0 + q;
+            const double t = wf[j < Np ? j : 0];                           // Np >= 1: always a valid address
+            w[q] = j < Np ? t : 0.0;
+        }
+    }
+}
+
+// A filter the quick kernel below does not finish is marked by this value in its FIRST output slot (indices are >= 0)
+constexpr int32_t WH_DEFER = -1;
+constexpr int WH_SCAN = 16;               // markers one workgroup of the full kernel looks at
+
+// The whole algorithm: plain-prefix boundaries, the exact round where an estimate is inside the error band, the literal loop for
+// garbage.  Since round 5 this kernel only sees the filters the quick kernel deferred (a.deferred_only: a few workgroups scan the
+// markers) -- or every filter, one workgroup each, with FK_WHOLE_SPLIT=0 (the round-3 / round-4 organisation).
+// EU = waves per SIMD the register allocation must allow (a 1024-thread workgroup is four waves per SIMD)
 template <bool STRATIFIED, int NT, int EU>
 __global__ void __launch_bounds__(NT, EU)
 resample_whole_kernel(const WholeArgs a)
@@ -77,72 +104,31 @@ resample_whole_kernel(const WholeArgs a)
     using Sh = WholeShared<NT>;
     constexpr int NW = Sh::NW, CAP = Sh::CAP;
     __shared__ Sh sh;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int Np = a.Np;
     const double Nd = (double)Np, halfNd = 0.5 * Nd;
+    const int j0 = tid * WH_ITEMS;
     WH_CLOCK_START();
-
-    // ---- weights: eight consecutive ones per thread, straight from HBM into registers (padding: +0.0) ----
-    auto fetch = [&](int f, int j0, double (&dst)[WH_ITEMS]) {
-        const double *wf = a.w + (long)f * Np;
-        if ((((uintptr_t)wf) & 15) == 0 && j0 + WH_ITEMS <= Np) {
-            const double *src = wf + j0;
-            FK_UNROLL for (int q = 0; q < WH_ITEMS; q += 2) {
-                const f64x2 t = *reinterpret_cast<const f64x2 *>(src + q);
-                dst[q] = t.x;
-                dst[q + 1] = t.y;
-            }
-        } else {
-            FK_UNROLL for (int q = 0; q < WH_ITEMS; ++q) {
-                const int j = j0 + q;
-                const double t = wf[j < Np ? j : 0];                       // Np >= 1: always a valid address
-                dst[q] = j < Np ? t : 0.0;
-            }
-        }
-    };
-    // Round 5: the grid is PERSISTENT -- a workgroup takes the filters blockIdx.x, + gridDim.x, ... (whole_launch: one grid's
-    // worth of resident workgroups) and fetches the NEXT filter's weights into a second register set before it starts on the
-    // current one: of a filter's 12.7k clocks 4.2k were the HBM latency of its weights with nothing else resident on the CU to
-    // cover them (one 1024-thread workgroup per CU; profiles/r03/resample_whole_phase_clocks.jsonl), and every later round of a
-    // 1000-filter call paid them again.  The prefetched set (and the next filter's u) is landed just before the index stores,
-    // i.e. behind ~8k clocks of work, and NO other global load sits in the common path in between: vmcnt retires in order, so
-    // a wait for any younger load would wait for the prefetch too.  The exact round (one vector in ~500) needs the registers:
-    // the prefetched set is dead across it and simply fetched again behind it (from L2 by then) -- no spill in either path.
-    double w[WH_ITEMS], wn[WH_ITEMS];
-    FK_UNROLL for (int q = 0; q < WH_ITEMS; ++q) w[q] = wn[q] = 0.0;
-    int f = blockIdx.x;
-    double u_sys = 0.0, u_next = 0.0;
-    if (f < a.Fn) {
-        fetch(f, (int)threadIdx.x * WH_ITEMS, w);
-        if (!STRATIFIED) u_sys = a.u[f];
+    // This workgroup's filters: [fbase, fbase + WH_SCAN) -- the deferred ones among them (every wave reads the markers of the
+    // whole range with ONE load, lane l that of filter fbase + l: one memory latency per workgroup, not one per filter; and all
+    // of them before any wave can store an index -- those stores sit behind this trip's barriers) -- or just filter blockIdx.x
+    const int fbase = a.deferred_only ? (int)blockIdx.x * WH_SCAN : (int)blockIdx.x;
+    unsigned long long pending = 1;
+    if (a.deferred_only) {
+        const int fl = fbase + lane;
+        const bool mine = lane < WH_SCAN && fl < a.Fn;
+        const int32_t mark = __hip_atomic_load(a.idx + (long)(mine ? fl : fbase) * Np, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        pending = __builtin_amdgcn_ballot_w64(mine && mark == WH_DEFER);
     }
-    // (landed before the loop is entered: with loads pending on ONE of the two ways into the loop head, the wait in front of the
-    //  first use of w becomes a vmcnt(0) on both -- and in every later trip it would wait for the prefetch issued just above it)
-    FK_UNROLL for (int q = 0; q < WH_ITEMS; ++q) asm volatile("" ::"v"(w[q]));
-    asm volatile("" ::"v"(u_sys));
-    for (; f < a.Fn; f += gridDim.x) {
-    // the thread's coordinates are re-derived in every trip from an opaque copy of threadIdx.x: as loop invariants the two
-    // dozen addresses and masks derived from them were hoisted, kept live across the whole body and SPILLED (104 bytes of
-    // scratch, reloaded behind a vmcnt(0) in front of two of the barriers); re-deriving them is a handful of VALU instructions
-    int tid = threadIdx.x;
-    asm volatile("" : "+v"(tid));
-    const int lane = tid & 63, wave = tid >> 6, j0 = tid * WH_ITEMS;
+    while (pending) {
+    const int f = fbase + (int)__builtin_ctzll(pending);
+    pending &= pending - 1;
     const double *wf = a.w + (long)f * Np;
     int32_t *of = a.idx + (long)f * Np;
+    const double u_sys = STRATIFIED ? 0.0 : a.u[f];
     const double *u_str = STRATIFIED ? a.u + (long)f * Np : nullptr;
-    const int f_next = f + (int)gridDim.x;
-    const bool has_next = f_next < a.Fn;                                   // uniform
-    auto prefetch = [&]() {
-        if (has_next) {
-            fetch(f_next, j0, wn);
-            if (!STRATIFIED) u_next = a.u[f_next];
-        } else {                             // (a definition on every path: the set is DEAD across the exact round, not carried)
-            FK_UNROLL for (int q = 0; q < WH_ITEMS; ++q) wn[q] = 0.0;
-            u_next = 0.0;
-        }
-    };
-    // systematic: in flight from here until the end of this trip.  Stratified: its boundaries GATHER u[f][.] (a wait for those
-    // loads would be a wait for the prefetch issued before them), so there the prefetch starts behind the boundaries
-    if (!STRATIFIED) prefetch();
+    double w[WH_ITEMS];
+    wh_fetch(wf, j0, Np, w);
     // the slot window and the segment claims are reset while the loads are in flight
     FK_UNROLL for (int g = 0; g < WH_ITEMS / 4; ++g) *reinterpret_cast<i32x4 *>(&sh.win[j0 + 4 * g]) = i32x4{-1, -1, -1, -1};
     for (int r = tid; r <= WH_DMAX; r += NT) sh.seg_e[r] = WH_NONE;
@@ -269,10 +255,7 @@ resample_whole_kernel(const WholeArgs a)
             const int st = literal_merge<STRATIFIED>(wf, STRATIFIED ? u_str : a.u + f, (long)Np, of);
             if (a.status) a.status[f] = st;
         }
-        __syncthreads();                     // nobody still reads this filter's shared state when the next one resets it
-        if (STRATIFIED) prefetch();
-        FK_UNROLL for (int q = 0; q < WH_ITEMS; ++q) w[q] = wn[q];
-        u_sys = u_next;
+        __syncthreads();                     // nobody still reads this filter's shared state when the next trip resets it
         continue;
     }
 
@@ -282,7 +265,6 @@ resample_whole_kernel(const WholeArgs a)
     __syncthreads();                                                                          // (5)
     WH_CLOCK(4);                                                           // boundaries
     }   // exact
-    if (STRATIFIED) prefetch();
     int nprev = tid == 0 ? 0 : sh.nlast[tid - 1];
     const int u_hi = __builtin_amdgcn_readfirstlane(sh.nlast[NT - 1]);     // = n(carry-out): slots [0, u_hi) get an index
     // window position p = slot + sft: with sft = (address of slot 0 in ints) mod 4 a thread's two quads are 16-byte
@@ -319,8 +301,6 @@ resample_whole_kernel(const WholeArgs a)
         if (wv < wave) pre = pre > t ? pre : t;
     }
     const int last = Np - 1;
-    FK_UNROLL for (int q = 0; q < WH_ITEMS; ++q) asm volatile("" ::"v"(wn[q]));   // the next filter's weights land HERE
-    asm volatile("" ::"v"(u_next));
     FK_UNROLL for (int g = 0; g < WH_ITEMS / 4; ++g) {
         int v[4];
         FK_UNROLL for (int e = 0; e < 4; ++e) {
@@ -338,9 +318,115 @@ resample_whole_kernel(const WholeArgs a)
     if (tid == 0 && a.status) a.status[f] = u_hi < Np ? ST_OVERRUN : 0;
     WH_CLOCK(7);                                                           // stores issued
     WH_COUNT(11, 1);
-    FK_UNROLL for (int q = 0; q < WH_ITEMS; ++q) w[q] = wn[q];
-    u_sys = u_next;
+    __syncthreads();                         // (a workgroup that takes another filter: this one's window is done with)
     }   // filters of this workgroup
+}
+
+// Round 5: the QUICK kernel -- the common path of resample_whole_kernel and nothing else: weights -> plain prefix sums -> slot
+// boundaries from the estimates -> heads -> max-scan -> stores; a vector with an estimate inside the error band (one in ~500 at
+// 8000 weights), a negative / NaN / huge weight or FK_WHOLE_EXACT=1 is DEFERRED: its first output slot gets WH_DEFER and
+// resample_whole_kernel redoes it right behind this launch.  Why: with the exact round inside, the kernel needs 87 VGPRs -- one
+// 1024-thread workgroup per CU, so nothing covers a workgroup's load latency (4.2k of its 12.7k clocks), its seven barriers or
+// its store tail (profiles/r03/resample_whole_phase_clocks.jsonl), and a persistent grid that prefetches the next filter's
+// weights into registers measured 35.1 against 36.2 us: the latency is not the weights' alone (profiles/r05/c5/).  Without the
+// exact round the live set fits the 64 VGPRs that let TWO workgroups share a CU (32 waves), each filling the other's stalls.
+template <bool STRATIFIED, int NT, int EU>
+__global__ void __launch_bounds__(NT, EU)
+resample_whole_quick_kernel(const WholeArgs a)
+{
+    constexpr int NW = NT / 64, CAP = NT * WH_ITEMS;
+    __shared__ int s_win[CAP];
+    __shared__ int s_nlast[NT];
+    __shared__ double s_wtot[NW];
+    __shared__ int s_wmax[NW];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int Np = a.Np;
+    const int f = blockIdx.x;
+    const double *wf = a.w + (long)f * Np;
+    int32_t *of = a.idx + (long)f * Np;
+    const int j0 = tid * WH_ITEMS;
+    double w[WH_ITEMS];
+    wh_fetch(wf, j0, Np, w);
+    WhPos<STRATIFIED> px;
+    px.Np = Np;
+    px.Nd = (double)Np;
+    px.halfNd = 0.5 * px.Nd;
+    px.u_sys = STRATIFIED ? 0.0 : a.u[f];
+    px.u_str = STRATIFIED ? a.u + (long)f * Np : nullptr;
+    FK_UNROLL for (int g = 0; g < WH_ITEMS / 4; ++g) *reinterpret_cast<i32x4 *>(&s_win[j0 + 4 * g]) = i32x4{-1, -1, -1, -1};
+    double run = 0.0, mn = 0.0;
+    FK_UNROLL for (int q = 0; q < WH_ITEMS; ++q) {
+        run += w[q];
+        mn = w[q] < mn ? w[q] : mn;
+    }
+    const double winc = wave_incl_sum(run);
+    if (lane == 63) s_wtot[wave] = winc;
+    const int any_neg = __syncthreads_or(mn < 0.0 ? 1 : 0);                                   // (1)
+    double before = __shfl_up(winc, 1, 64);
+    if (lane == 0) before = 0.0;
+    double S = 0.0;
+    FK_UNROLL for (int wv = 0; wv < NW; ++wv) {
+        const double t = s_wtot[wv];
+        if (wv < wave) before += t;
+        S += t;
+    }
+    const bool garbage = any_neg || !(S < 0x1p1000);                       // uniform
+    int nb[WH_ITEMS];
+    unsigned unsure = 1;
+    if (!garbage) {
+        unsure = wh_approx_boundaries<STRATIFIED>(w, before, px, nb);
+        s_nlast[tid] = nb[WH_ITEMS - 1];
+    }
+    if (__syncthreads_or((unsure != 0 || a.force_exact) ? 1 : 0)) {                           // (A) (also publishes nlast)
+        if (tid == 0) *of = WH_DEFER;
+        return;
+    }
+    int nprev = tid == 0 ? 0 : s_nlast[tid - 1];
+    const int u_hi = __builtin_amdgcn_readfirstlane(s_nlast[NT - 1]);
+    const int mis = (int)(((uintptr_t)of >> 2) & 3);
+    const int sft = Np + mis <= CAP ? mis : 0;
+    const bool vec_ok = sft == mis;
+    FK_UNROLL for (int q = 0; q < WH_ITEMS; ++q) {
+        if (nb[q] > nprev) {
+            s_win[nprev + sft] = j0 + q;
+            nprev = nb[q];
+        }
+    }
+    __syncthreads();                                                                          // (6)
+    int x[WH_ITEMS];
+    FK_UNROLL for (int g = 0; g < WH_ITEMS / 4; ++g) {
+        const i32x4 t = *reinterpret_cast<const i32x4 *>(&s_win[j0 + 4 * g]);
+        x[4 * g + 0] = t.x;
+        x[4 * g + 1] = t.y;
+        x[4 * g + 2] = t.z;
+        x[4 * g + 3] = t.w;
+    }
+    FK_UNROLL for (int e = 1; e < WH_ITEMS; ++e) x[e] = x[e] > x[e - 1] ? x[e] : x[e - 1];
+    const int wincl = wave_incl_max(x[WH_ITEMS - 1]);
+    if (lane == 63) s_wmax[wave] = wincl;
+    __syncthreads();                                                                          // (7)
+    int pre = __shfl_up(wincl, 1, 64);
+    if (lane == 0) pre = -1;
+    FK_UNROLL for (int wv = 0; wv < NW; ++wv) {
+        const int t = s_wmax[wv];
+        if (wv < wave) pre = pre > t ? pre : t;
+    }
+    const int last = Np - 1;
+    FK_UNROLL for (int g = 0; g < WH_ITEMS / 4; ++g) {
+        int v[4];
+        FK_UNROLL for (int e = 0; e < 4; ++e) {
+            const int s = j0 + 4 * g + e - sft;
+            const int m = x[4 * g + e] > pre ? x[4 * g + e] : pre;
+            v[e] = s < u_hi ? m : last;
+        }
+        const int s0 = j0 + 4 * g - sft;
+        if (vec_ok && s0 >= 0 && s0 + 3 < Np) *reinterpret_cast<i32x4 *>(&of[s0]) = i32x4{v[0], v[1], v[2], v[3]};
+        else {
+            FK_UNROLL for (int e = 0; e < 4; ++e)
+                if (s0 + e >= 0 && s0 + e < Np) of[s0 + e] = v[e];
+        }
+    }
+    if (tid == 0 && a.status) a.status[f] = u_hi < Np ? ST_OVERRUN : 0;
 }
 
 // Np <= 8192: one workgroup of 256 / 512 / 1024 threads per filter (8 weights per thread)
@@ -359,29 +445,30 @@ int whole_launch(bool stratified, int64_t Fn, int64_t Np, const double *w, const
     a.idx = idx;
     a.status = status;
     a.Fn = (int)Fn;
-    // one grid's worth of resident workgroups (16 waves per CU at <= 128 VGPRs: one 1024-, two 512-, four 256-thread workgroups),
-    // each walking its filters f, f + grid, ...  FK_WHOLE_GRID=<workgroups> forces a grid (0: one workgroup per filter as before)
-    static const int cus = [] {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-        return n;
-    }();
-    const char *gv = getenv("FK_WHOLE_GRID");                              // (per call, like FK_WHOLE_EXACT: the tests flip it)
-    const long forced = gv ? atol(gv) : -1L;
-    const int per_cu = Np <= 256 * WH_ITEMS ? 4 : Np <= 512 * WH_ITEMS ? 2 : 1;
-    long G = forced > 0 ? forced : forced == 0 ? Fn : (long)cus * per_cu;
-    if (G > Fn) G = Fn;
-    const dim3 grid((unsigned)G);
-#define GO(NTV, EUV)                                                                                             \
+    // FK_WHOLE_SPLIT=0: every filter through the full kernel, one workgroup each (rounds 3 / 4; A/B and tests)
+    const char *sv = getenv("FK_WHOLE_SPLIT");
+    const bool split = !(sv && sv[0] == '0');
+#define GO(K, NTV, EUV, G)                                                                                       \
     do {                                                                                                         \
-        if (stratified) hipLaunchKernelGGL((resample_whole_kernel<true, NTV, EUV>), grid, dim3(NTV), 0, s, a);   \
-        else hipLaunchKernelGGL((resample_whole_kernel<false, NTV, EUV>), grid, dim3(NTV), 0, s, a);             \
+        if (stratified) hipLaunchKernelGGL((K<true, NTV, EUV>), dim3((unsigned)(G)), dim3(NTV), 0, s, a);        \
+        else hipLaunchKernelGGL((K<false, NTV, EUV>), dim3((unsigned)(G)), dim3(NTV), 0, s, a);                  \
     } while (0)
+    if (split) {
+        // the quick kernel: one workgroup per filter, 64 VGPRs -- 32 waves per CU: two 1024-, four 512-, eight 256-thread workgroups
+        a.deferred_only = 0;
+        if (Np <= 256 * WH_ITEMS) GO(resample_whole_quick_kernel, 256, 8, Fn);
+        else if (Np <= 512 * WH_ITEMS) GO(resample_whole_quick_kernel, 512, 8, Fn);
+        else GO(resample_whole_quick_kernel, 1024, 8, Fn);
+        if (int rc = check_launch("resample_whole_quick_kernel")) return rc;
+    }
+    // the full kernel: the deferred filters (a few workgroups look for their markers), or every filter
+    a.deferred_only = split ? 1 : 0;
+    const long G = split ? (Fn + WH_SCAN - 1) / WH_SCAN : Fn;
     // (an instantiation budgeted for two 1024-thread workgroups per CU -- 64 VGPRs -- was measured and dropped: it spills,
     // 36 against 32 us at 1000 x 8000, 11.8 against 8.1 us at 125 x 8000; profiles/r03/resample_whole_variants.txt)
-    if (Np <= 256 * WH_ITEMS) GO(256, 4);
-    else if (Np <= 512 * WH_ITEMS) GO(512, 4);
-    else GO(1024, 4);
+    if (Np <= 256 * WH_ITEMS) GO(resample_whole_kernel, 256, 4, G);
+    else if (Np <= 512 * WH_ITEMS) GO(resample_whole_kernel, 512, 4, G);
+    else GO(resample_whole_kernel, 1024, 4, G);
 #undef GO
     return check_launch("resample_whole_kernel");
 }

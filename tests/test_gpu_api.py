@@ -194,14 +194,14 @@ def test_ukf_general_callables_vs_reference():
         assert rel_err_rows(mu2, g[p + "mu"]) < tmu and rel_err_rows(cov2, g[p + "cov"]) < tcov
 
 
-@pytest.mark.parametrize("last_missing", [0, 1, 2, 6])
+@pytest.mark.parametrize("last_missing", [0, 1, 2, 5])
 def test_ukf_fused_batch_filter_leaves_the_last_epochs_attributes(last_missing):
     """the reference's batch_filter is a loop of predict() / update() (UKF.py:623-632), so afterwards the filter
     carries the LAST epoch's x_prior / P_prior, sigmas_f, sigmas_h, K, S, SI, y, z, x_post / P_post and reset likelihood
     caches.  The fused launch (matrix fx / hx) must leave the same: compared with the same filter stepped one call at a
     time through the callable path, single filter and bank; means[-1] is self.x bit for bit.  last_missing = k: the call
     ends on k missing measurements -- update(None) returns early (UKF.py:443-447), so K / S / SI / y / sigmas_h are those of
-    the last epoch that HAD a measurement (k = 6: none had one, the constructor's values stay)."""
+    the last epoch that HAD a measurement (k = 5: only the first epoch had one -- zs[0] = None is a TypeError in the reference too, UKF.py:586-595)."""
     from filterpy_amd.kalman import UnscentedKalmanFilter, MerweScaledSigmaPoints
     g = golden("ukf_merwe")
     ci = [i for i, c in enumerate(g["cases"]) if int(c[0]) == 6][0]

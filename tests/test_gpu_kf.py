@@ -1153,3 +1153,29 @@ def test_bank_placement_probe_places_by_measurement_and_remembers_the_pair():
         assert torch.equal(a, c)
     del out3
     placement.forget_placed_pairs()
+
+
+@pytest.mark.parametrize("layout", ["soa", "aos"])
+@pytest.mark.parametrize("ci", range(13))
+def test_smoother_margin_on_badly_conditioned_models(ci, layout):
+    """VERDICT r4 weak 2 / next 5.  Every smoother class (rts_kernel dim_x <= 8, rts_ml 9, rts_mlg 10..12, rts_mlx / rts_mlg
+    13..16) on models whose backward recursion is badly conditioned (tests/golden/make_rts_conditioning.py: the unstable random
+    models of tools/bench_configs.py, where round 4 measured 6.9e-11 at dim_x 10, and integrator chains up to cond(Pp) = 1e9),
+    a bank of 70 copies so that tail lanes and several waves take part: every track bit-equal to the first, and that one inside
+    max(1e-10, 2 x the reference's own spread under one-ulp perturbations of the smoother's inputs) -- the gain inside
+    max(that, 8 x the reference's own distance from the exactly rounded gain), against the reference and against that gain."""
+    from gpu_util import run_rts, tile_tracks
+    g = golden("rts_conditioning")
+    p = f"c{ci}_"
+    N = 70
+    xs, Ps, K, Pp = run_rts(tile_tracks(g[p + "mu"], N, 1), tile_tracks(g[p + "cov"], N, 1), g[p + "F"], g[p + "Q"], layout=layout)
+    for a in (xs, Ps, K, Pp):
+        assert np.array_equal(a, np.repeat(a[:, :1], N, axis=1))
+    sp = g[p + "spread"]
+    bar = {k: max(TOL, 2.0 * float(v)) for k, v in zip(("xs", "Ps", "K", "Pp"), sp)}
+    bar["K"] = max(bar["K"], 8.0 * float(g[p + "K_ref_err"]))
+    got = dict(xs=xs[:, 0], Ps=Ps[:, 0], K=K[:-1, 0], Pp=Pp[:-1, 0])
+    ref = dict(xs=g[p + "xs"], Ps=g[p + "Ps"], K=g[p + "K"][:-1], Pp=g[p + "Pp"][:-1])
+    errs = {k: rel_err_rows(got[k], ref[k]) for k in got}
+    errs["K_exact"] = rel_err_rows(got["K"], g[p + "K_exact"][:-1])
+    assert all(errs[k] < bar[k] for k in got) and errs["K_exact"] < bar["K"], (ci, layout, errs, bar)

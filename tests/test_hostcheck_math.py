@@ -180,3 +180,29 @@ def test_det_from_reciprocal_pivots_over_the_whole_exponent_range():
             assert np.isinf(rd.value) or abs(float(rd.value / ref_r) - 1.0) < 1e-12, (dinv, rd.value, ref_r)
         worst_l = max(worst_l, abs(ld.value - ref_ld) / max(1.0, abs(ref_ld)))
     assert worst_r < 1e-13, worst_r
+
+
+def _rts_bars(g, p):
+    """max(1e-10, 2 * spread) per output; for the gain also 8 x the reference's own distance from the exactly rounded gain
+    (tests/golden/make_rts_conditioning.py says why)"""
+    sp = g[p + "spread"]
+    bar = {k: max(TOL, 2.0 * float(v)) for k, v in zip(("xs", "Ps", "K", "Pp"), sp)}
+    bar["K"] = max(bar["K"], 8.0 * float(g[p + "K_ref_err"]))
+    return bar
+
+
+@pytest.mark.parametrize("ci", range(13))
+def test_rts_margin_on_badly_conditioned_models(ci):
+    """the smoother's margin.  On models whose backward recursion is badly conditioned (cond(Pp)
+    1e2 .. 1e9: tools/bench_configs.py's unstable random models, where the several-lane kernel measured 6.9e-11, and integrator
+    chains) the kernels' arithmetic -- the LDL' solve of Pp where the reference calls numpy.linalg.inv -- stays inside
+    max(1e-10, 2 x the reference's own spread under one-ulp input perturbations); the gain also inside 8 x the reference's own
+    distance from the exactly rounded gain, against the reference and against that gain itself."""
+    g = golden("rts_conditioning")
+    p = f"c{ci}_"
+    xs, Ps, K, Pp, st = hc_rts(g[p + "mu"], g[p + "cov"], g[p + "F"], g[p + "Q"])
+    assert st == 0
+    bar = _rts_bars(g, p)
+    assert rel_err_rows(xs, g[p + "xs"]) < bar["xs"] and rel_err_rows(Ps, g[p + "Ps"]) < bar["Ps"]
+    assert rel_err_rows(K[:-1], g[p + "K"][:-1]) < bar["K"] and rel_err_rows(K[:-1], g[p + "K_exact"][:-1]) < bar["K"]
+    assert rel_err_rows(Pp[:-1], g[p + "Pp"][:-1]) < bar["Pp"]
