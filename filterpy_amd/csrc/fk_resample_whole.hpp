@@ -351,13 +351,17 @@ FK_HD void wh_boundaries(const WhThread &t, int dbase, wh_u64 pbase, const int *
 
 // ---- step 0: the boundaries from the PLAIN prefix sums alone -------------------------------------------------------------
 // n(c) = #{ i : pos_i < c } is a step function of c, and the slot boundary of weight j only asks on which side of the
-// positions cs_j lies.  The plain prefix sum a_j (any summation order) and numpy's sequential cs_j are both within
-// gamma_n = n 2^-53 of the real sum of the same non-negative terms, so |a_j - cs_j| <= 2^-39 a_j for n <= 8192: in
-// slots, N a_j 2^-39 <= 2^-26 for a normalised vector.  Unless the estimate N a_j - u sits within `band` of an integer
-// -- band = 2^-36 N a_j + 2^-30: eight times that bound plus every rounding of the estimate and of the positions
-// themselves (fl(fl(u + i) / N): 2^-40 slots for N <= 2^15) -- its ceiling IS n(cs_j): no exact cumulative sum is needed.
-// For 8000 normalised weights one vector in ~500 holds an element inside the band; such a vector (and only such a
-// vector) runs the exact round above.  Returns the mask of elements inside the band.
+// positions cs_j lies.  numpy's sequential cs_j is within j 2^-53 <= 2^-40 (n <= 8192) of the real sum s_j of the same
+// non-negative terms; the plain prefix sum a_j formed here is within D 2^-53 of it, D = the DEPTH of its adds -- 8 inside a
+// thread, 6 in the wave scan, 1 + 15 over the waves, 8 to the element: D <= 38 on the GPU, <= 96 in the host emulation (its
+// wave scan is serial) --, i.e. within 2^-46.  So |N a_j - N cs_j| <= (2^-40 + 2^-46) N a_j; the estimate's own two roundings
+// add 2^-52 N a_j, the positions' (fl(fl(u + i) / N), N <= 8192) 2^-39 slots.  Unless N a_j - u sits within
+//     band = 1.5 * 2^-40 N a_j + 2^-36
+// of an integer -- 1.45 times the relative terms, 8 times the absolute one -- its ceiling IS n(cs_j): no exact cumulative sum
+// is needed.  (Rounds 3 / 4 used 2^-36 N a_j + 2^-30, pricing a_j at n roundings like cs_j: one vector of 8000 normalised
+// weights in ~500 had an element inside that band; with this one it is one in ~5000 -- which is what lets the quick kernel of
+// round 5 finish nearly every CALL by itself.)  Such a vector (and only such a vector) runs the exact round above.  Returns
+// the mask of elements inside the band.
 //   Stratified (pos_i = fl(fl(u_i + i) / N)): with f = floor(N c), slot f - 1 is below c, slot f + 1 is not, slot f is
 // iff u_f < frac(N c); an estimate within the band of an integer k leaves f = k - 1 or k open, but n = k either way
 // unless u_{k-1} or u_k is itself within the band of 1 or 0 -- a normalised vector ends exactly there (N c ~ N).
@@ -370,7 +374,7 @@ FK_HD unsigned wh_approx_boundaries(const double (&w)[WH_ITEMS], double before, 
         a += w[q];                                                         // plain inclusive prefix
         const double pe = px.Nd * a;                                       // N a_j >= 0
         const double est = STRATIFIED ? pe : pe - px.u_sys;
-        const double band = fma(pe, 0x1p-36, 0x1p-30);
+        const double band = fma(pe, 0x1.8p-40, 0x1p-36);
         const bool past = !(est < px.Nd);                                  // every position is below a_j: n = Np
         // nearest integer k of est without v_floor / v_cvt (-1 < est < Nd < 2^31 where it is used)
         const double m = est + 0x1.8p52;

@@ -31,7 +31,7 @@
 namespace fk {
 
 struct WholeArgs {
-    int Np, force_exact, Fn, deferred_only;
+    int Np, force_exact;
     const double *w, *u;
     int32_t *idx, *status;
 };
@@ -89,40 +89,24 @@ __device__ __forceinline__ void wh_fetch(const double *wf, int j0, int Np, doubl
     }
 }
 
-// A filter the quick kernel below does not finish is marked by this value in its FIRST output slot (indices are >= 0)
-constexpr int32_t WH_DEFER = -1;
-constexpr int WH_SCAN = 16;               // markers one workgroup of the full kernel looks at
-
-// The whole algorithm: plain-prefix boundaries, the exact round where an estimate is inside the error band, the literal loop for
-// garbage.  Since round 5 this kernel only sees the filters the quick kernel deferred (a.deferred_only: a few workgroups scan the
-// markers) -- or every filter, one workgroup each, with FK_WHOLE_SPLIT=0 (the round-3 / round-4 organisation).
-// EU = waves per SIMD the register allocation must allow (a 1024-thread workgroup is four waves per SIMD)
-template <bool STRATIFIED, int NT, int EU>
-__global__ void __launch_bounds__(NT, EU)
-resample_whole_kernel(const WholeArgs a)
+// The whole algorithm on ONE filter: plain-prefix boundaries, the exact round where an estimate is inside the error band, the
+// literal loop for garbage.  Rounds 3 / 4 ran it as the kernel (resample_whole_kernel below: FK_WHOLE_QUICK=0); since round 5 it
+// is the rare tail of resample_whole_quick_kernel.
+// one filter, start to finish, by the whole workgroup (every barrier inside is reached by all of its threads)
+template <bool STRATIFIED, int NT>
+__device__ __forceinline__ void wh_full_one(const WholeArgs &a, const int f_in, WholeShared<NT> &sh)
 {
     using Sh = WholeShared<NT>;
     constexpr int NW = Sh::NW, CAP = Sh::CAP;
-    __shared__ Sh sh;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int Np = a.Np;
+    // (opaque copies: as the quick kernel's tail this code must share NO value with the common path in front of it -- a shared
+    //  one would be live across the whole tail and be spilled by the path that cannot afford it)
+    int tid = threadIdx.x, Np = a.Np, f = f_in;
+    asm volatile("" : "+v"(tid));
+    asm volatile("" : "+s"(Np), "+s"(f));
+    const int lane = tid & 63, wave = tid >> 6;
     const double Nd = (double)Np, halfNd = 0.5 * Nd;
     const int j0 = tid * WH_ITEMS;
     WH_CLOCK_START();
-    // This workgroup's filters: [fbase, fbase + WH_SCAN) -- the deferred ones among them (every wave reads the markers of the
-    // whole range with ONE load, lane l that of filter fbase + l: one memory latency per workgroup, not one per filter; and all
-    // of them before any wave can store an index -- those stores sit behind this trip's barriers) -- or just filter blockIdx.x
-    const int fbase = a.deferred_only ? (int)blockIdx.x * WH_SCAN : (int)blockIdx.x;
-    unsigned long long pending = 1;
-    if (a.deferred_only) {
-        const int fl = fbase + lane;
-        const bool mine = lane < WH_SCAN && fl < a.Fn;
-        const int32_t mark = __hip_atomic_load(a.idx + (long)(mine ? fl : fbase) * Np, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        pending = __builtin_amdgcn_ballot_w64(mine && mark == WH_DEFER);
-    }
-    while (pending) {
-    const int f = fbase + (int)__builtin_ctzll(pending);
-    pending &= pending - 1;
     const double *wf = a.w + (long)f * Np;
     int32_t *of = a.idx + (long)f * Np;
     const double u_sys = STRATIFIED ? 0.0 : a.u[f];
@@ -256,7 +240,7 @@ resample_whole_kernel(const WholeArgs a)
             if (a.status) a.status[f] = st;
         }
         __syncthreads();                     // nobody still reads this filter's shared state when the next trip resets it
-        continue;
+        return;
     }
 
     // ---- cumulative sums -> slot boundaries: weight j owns the slots [n_{j-1}, n_j), n_j = n(cs_j) ------------------
@@ -319,26 +303,38 @@ resample_whole_kernel(const WholeArgs a)
     WH_CLOCK(7);                                                           // stores issued
     WH_COUNT(11, 1);
     __syncthreads();                         // (a workgroup that takes another filter: this one's window is done with)
-    }   // filters of this workgroup
 }
 
-// Round 5: the QUICK kernel -- the common path of resample_whole_kernel and nothing else: weights -> plain prefix sums -> slot
-// boundaries from the estimates -> heads -> max-scan -> stores; a vector with an estimate inside the error band (one in ~500 at
-// 8000 weights), a negative / NaN / huge weight or FK_WHOLE_EXACT=1 is DEFERRED: its first output slot gets WH_DEFER and
-// resample_whole_kernel redoes it right behind this launch.  Why: with the exact round inside, the kernel needs 87 VGPRs -- one
-// 1024-thread workgroup per CU, so nothing covers a workgroup's load latency (4.2k of its 12.7k clocks), its seven barriers or
-// its store tail (profiles/r03/resample_whole_phase_clocks.jsonl), and a persistent grid that prefetches the next filter's
-// weights into registers measured 35.1 against 36.2 us: the latency is not the weights' alone (profiles/r05/c5/).  Without the
-// exact round the live set fits the 64 VGPRs that let TWO workgroups share a CU (32 waves), each filling the other's stalls.
+template <bool STRATIFIED, int NT, int EU>
+__global__ void __launch_bounds__(NT, EU)
+resample_whole_kernel(const WholeArgs a)
+{
+    __shared__ WholeShared<NT> sh;
+    wh_full_one<STRATIFIED, NT>(a, (int)blockIdx.x, sh);
+}
+
+// Round 5: the QUICK kernel.  With the exact round inside its one code path the kernel above needs 87 VGPRs: ONE 1024-thread
+// workgroup per CU, so nothing covers a workgroup's load latency (4.2k of its 12.7k clocks), its seven barriers or its store tail
+// (profiles/r03/resample_whole_phase_clocks.jsonl) -- and a persistent grid that prefetched the next filter's weights into
+// registers measured 35.1 against 36.2 us at 1000 x 8000: the latency is not the weights' alone (profiles/r05/c5/).  Here the
+// common path -- weights -> plain prefix sums -> slot boundaries from the estimates -> heads -> max-scan -> stores -- is
+// straight-line code that fits the 64 VGPRs at which TWO 1024-thread workgroups share a CU (32 waves), each filling the other's
+// stalls: 25.0 against 36.3 us on the same GPU.  A vector with an estimate inside the error band (one in ~5000 at 8000 weights
+// since the band is priced at the prefix sums' real depth, fk_resample_whole.hpp), a negative / NaN / huge weight, or
+// FK_WHOLE_EXACT=1 leaves through wh_full_one, inlined behind the common path's `return` and marked unlikely: the register
+// allocator spills there (128-190 bytes per lane) and nowhere in the common path (checked in the ISA: no scratch instruction in
+// front of the first s_endpgm; tests/test_host_logic.py holds that).  First tried as two launches (quick kernel + the full kernel
+// on marked filters): the second launch cost 4.8 us + the boundary even with nothing to do, 19 us with one deferred filter.
 template <bool STRATIFIED, int NT, int EU>
 __global__ void __launch_bounds__(NT, EU)
 resample_whole_quick_kernel(const WholeArgs a)
 {
     constexpr int NW = NT / 64, CAP = NT * WH_ITEMS;
-    __shared__ int s_win[CAP];
-    __shared__ int s_nlast[NT];
-    __shared__ double s_wtot[NW];
-    __shared__ int s_wmax[NW];
+    __shared__ WholeShared<NT> sh;
+    int (&s_win)[CAP] = sh.win;
+    int (&s_nlast)[NT] = sh.nlast;
+    double (&s_wtot)[NW] = sh.wtot;
+    int (&s_wmax)[NW] = sh.wmax;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int Np = a.Np;
     const int f = blockIdx.x;
@@ -377,10 +373,7 @@ resample_whole_quick_kernel(const WholeArgs a)
         unsure = wh_approx_boundaries<STRATIFIED>(w, before, px, nb);
         s_nlast[tid] = nb[WH_ITEMS - 1];
     }
-    if (__syncthreads_or((unsure != 0 || a.force_exact) ? 1 : 0)) {                           // (A) (also publishes nlast)
-        if (tid == 0) *of = WH_DEFER;
-        return;
-    }
+    if (__builtin_expect(!__syncthreads_or((unsure != 0 || a.force_exact) ? 1 : 0), 1)) {     // (A) (also publishes nlast)
     int nprev = tid == 0 ? 0 : s_nlast[tid - 1];
     const int u_hi = __builtin_amdgcn_readfirstlane(s_nlast[NT - 1]);
     const int mis = (int)(((uintptr_t)of >> 2) & 3);
@@ -427,6 +420,12 @@ resample_whole_quick_kernel(const WholeArgs a)
         }
     }
     if (tid == 0 && a.status) a.status[f] = u_hi < Np ? ST_OVERRUN : 0;
+    return;
+    }
+    // ---- the rare way out: the whole algorithm on this filter, from its weights (inline, at the END of the kernel: nothing of
+    // the common path is live across it, so what it spills under the 64-VGPR budget it spills inside itself) ----
+    __syncthreads();                         // (every thread has read what step 0 left in the shared arrays)
+    wh_full_one<STRATIFIED, NT>(a, f, sh);
 }
 
 // Np <= 8192: one workgroup of 256 / 512 / 1024 threads per filter (8 weights per thread)
@@ -444,31 +443,25 @@ int whole_launch(bool stratified, int64_t Fn, int64_t Np, const double *w, const
     a.u = u;
     a.idx = idx;
     a.status = status;
-    a.Fn = (int)Fn;
-    // FK_WHOLE_SPLIT=0: every filter through the full kernel, one workgroup each (rounds 3 / 4; A/B and tests)
-    const char *sv = getenv("FK_WHOLE_SPLIT");
-    const bool split = !(sv && sv[0] == '0');
-#define GO(K, NTV, EUV, G)                                                                                       \
+    // FK_WHOLE_QUICK=0: the round-3 / round-4 kernel (one code path, one workgroup of <= 128 VGPRs per filter): A/B and tests
+    const char *qv = getenv("FK_WHOLE_QUICK");
+    const bool quick = !(qv && qv[0] == '0');
+#define GO(K, NTV, EUV)                                                                                          \
     do {                                                                                                         \
-        if (stratified) hipLaunchKernelGGL((K<true, NTV, EUV>), dim3((unsigned)(G)), dim3(NTV), 0, s, a);        \
-        else hipLaunchKernelGGL((K<false, NTV, EUV>), dim3((unsigned)(G)), dim3(NTV), 0, s, a);                  \
+        if (stratified) hipLaunchKernelGGL((K<true, NTV, EUV>), dim3((unsigned)Fn), dim3(NTV), 0, s, a);         \
+        else hipLaunchKernelGGL((K<false, NTV, EUV>), dim3((unsigned)Fn), dim3(NTV), 0, s, a);                   \
     } while (0)
-    if (split) {
-        // the quick kernel: one workgroup per filter, 64 VGPRs -- 32 waves per CU: two 1024-, four 512-, eight 256-thread workgroups
-        a.deferred_only = 0;
-        if (Np <= 256 * WH_ITEMS) GO(resample_whole_quick_kernel, 256, 8, Fn);
-        else if (Np <= 512 * WH_ITEMS) GO(resample_whole_quick_kernel, 512, 8, Fn);
-        else GO(resample_whole_quick_kernel, 1024, 8, Fn);
-        if (int rc = check_launch("resample_whole_quick_kernel")) return rc;
+    if (quick) {
+        // 64 VGPRs in the common path -- 32 waves per CU: two 1024-, four 512-thread workgroups (256 threads: with the tail
+        // 97 VGPRs, five workgroups -- 20 waves -- per CU)
+        if (Np <= 256 * WH_ITEMS) GO(resample_whole_quick_kernel, 256, 5);
+        else if (Np <= 512 * WH_ITEMS) GO(resample_whole_quick_kernel, 512, 8);
+        else GO(resample_whole_quick_kernel, 1024, 8);
+    } else {
+        if (Np <= 256 * WH_ITEMS) GO(resample_whole_kernel, 256, 4);
+        else if (Np <= 512 * WH_ITEMS) GO(resample_whole_kernel, 512, 4);
+        else GO(resample_whole_kernel, 1024, 4);
     }
-    // the full kernel: the deferred filters (a few workgroups look for their markers), or every filter
-    a.deferred_only = split ? 1 : 0;
-    const long G = split ? (Fn + WH_SCAN - 1) / WH_SCAN : Fn;
-    // (an instantiation budgeted for two 1024-thread workgroups per CU -- 64 VGPRs -- was measured and dropped: it spills,
-    // 36 against 32 us at 1000 x 8000, 11.8 against 8.1 us at 125 x 8000; profiles/r03/resample_whole_variants.txt)
-    if (Np <= 256 * WH_ITEMS) GO(resample_whole_kernel, 256, 4, G);
-    else if (Np <= 512 * WH_ITEMS) GO(resample_whole_kernel, 512, 4, G);
-    else GO(resample_whole_kernel, 1024, 4, G);
 #undef GO
     return check_launch("resample_whole_kernel");
 }

@@ -370,18 +370,17 @@ def test_whole_vector_kernel_every_route(Np, exact, monkeypatch):
     _check_against_merge_loop(5, Np, kinds, range(5), monkeypatch, force=False)
 
 
-@pytest.mark.parametrize("split", ["1", "0"])
+@pytest.mark.parametrize("quick", ["1", "0"])
 @pytest.mark.parametrize("Np", [7, 2049, 4097, 8000, 8191])
-def test_whole_vector_kernel_quick_and_deferred(Np, split, monkeypatch):
-    """Round 5: short vectors take TWO launches -- resample_whole_quick_kernel (the common path only, 64 VGPRs: two 1024-thread
-    workgroups per CU) finishes every vector whose boundary estimates are clear of the error band and marks the others (garbage
-    weights, an estimate inside the band, FK_WHOLE_EXACT=1) in their first output slot; resample_whole_kernel, a few workgroups
-    each reading 16 markers with one load, redoes exactly those.  37 filters (three scanning workgroups, the last one partial),
-    finished and deferred ones mixed within a call (the `negative` / `nan` families: first and last filter garbage; `dyadic` /
-    `tiny`: every filter declined down to the literal loop), every filter against the reference's merge loop, systematic and
-    stratified; odd Np: every filter at another 16-byte phase.  split = "0" (FK_WHOLE_SPLIT): every filter through the full
-    kernel, one workgroup each, as in rounds 3 / 4."""
-    monkeypatch.setenv("FK_WHOLE_SPLIT", split)
+def test_whole_vector_kernel_quick_path_and_its_tail(Np, quick, monkeypatch):
+    """Round 5: short vectors run resample_whole_quick_kernel -- the common path alone within 64 VGPRs (two 1024-thread
+    workgroups per CU), the whole algorithm (exact round, literal loop) as an unlikely tail behind it for a vector whose
+    boundary estimates touch the error band, for garbage weights and for FK_WHOLE_EXACT=1.  37 filters, finished-by-the-common-
+    path and tail ones mixed within a call (the `negative` / `nan` families: first and last filter garbage; `dyadic` / `tiny`:
+    every filter declined down to the literal loop), every filter against the reference's merge loop, systematic and
+    stratified; odd Np: every filter at another 16-byte phase.  quick = "0" (FK_WHOLE_QUICK): the one-code-path kernel of
+    rounds 3 / 4."""
+    monkeypatch.setenv("FK_WHOLE_QUICK", quick)
     kinds = [k for k in _FAMILIES + ("dyadic", "tiny") if not (k in ("negative", "nan") and Np < 8)]
     _check_against_merge_loop(37, Np, kinds, range(37), monkeypatch, force=False)
     monkeypatch.setenv("FK_WHOLE_EXACT", "1")
@@ -426,7 +425,7 @@ def test_whole_vector_kernel_positions_on_cumulative_sums(monkeypatch):
 def test_whole_vector_kernel_many_filters(monkeypatch):
     """the C5 shape: 1000 x 8000 and 125 x 8000 in one launch each (more workgroups than CUs; two filters per CU),
     sampled filters bit-exact"""
-    _check_against_merge_loop(1000, 8000, ("uniform",), range(1000), monkeypatch, force=False)       # (every filter: ~2 of them deferred)
+    _check_against_merge_loop(1000, 8000, ("uniform",), range(1000), monkeypatch, force=False)       # (every filter)
     _check_against_merge_loop(1000, 8000, ("heavy_tail", "negative"), (0, 1, 255, 256, 511, 767, 768, 999), monkeypatch, force=False)
     _check_against_merge_loop(125, 8000, ("uniform", "zeros"), (0, 1, 63, 124), monkeypatch, force=False)
     _check_against_merge_loop(3000, 2000, ("uniform",), range(0, 3000, 7), monkeypatch, force=False)   # 256-thread workgroups, eight per CU

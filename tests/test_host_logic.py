@@ -235,3 +235,71 @@ def test_a_strided_mask_is_copied_before_its_pointer_is_handed_to_the_c_abi():
     c = torch.as_tensor(np.ascontiguousarray(view))
     keep = []
     assert E._mask_ptr(c, keep) == c.data_ptr() and E._mask_ptr(None, keep) is None
+
+
+def test_quick_resampler_spills_only_in_its_unlikely_tail():
+    """resample_whole_quick_kernel (csrc/resample_whole.hip) is worth its name only while the COMMON path stays inside the 64
+    VGPRs that let two 1024-thread workgroups share a CU, with no scratch access: the whole algorithm hangs behind the common
+    path's `return` as an unlikely tail and may spill all it wants.  Read from the built object: 64 VGPRs at 1024 / 512 threads,
+    and no scratch_ instruction in front of the kernel's first s_endpgm (= the end of the common path)."""
+    import re
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import isa_lint
+    obj = os.path.join(ROOT, "filterpy_amd", "csrc", "build", "resample_whole.o")
+    if not os.path.exists(obj):
+        pytest.skip("library not built")
+    with tempfile.TemporaryDirectory() as tmp:
+        elf = isa_lint.device_elf(obj, tmp)
+        info = isa_lint.kernels(elf)
+        dis = subprocess.check_output([f"{isa_lint.LLVM}/llvm-objdump", "-d", "--no-show-raw-insn", elf], text=True)
+    quick = {k: v for k, v in info.items() if "resample_whole_quick_kernel" in k}
+    assert len(quick) == 6, sorted(info)
+    for name, v in quick.items():
+        if "Li1024E" in name or "Li512E" in name:
+            assert v["vgpr"] <= 64, (name, v)
+        body = dis.split("<" + name + ">:")[1]
+        first_exit = body.index("s_endpgm")
+        assert "scratch_" not in body[:first_exit], name
+        assert len(re.findall(r"s_barrier", body[:first_exit])) >= 4, name        # (1), (A), (6), (7): the common path is all there
+
+
+def test_pmc_evidence_still_describes_the_built_kernel():
+    """bench.py's `roofline.traffic` is read from COMMITTED rocprofv3 --pmc passes (profiles/pmc_traffic.json), not measured in
+    the run: this test ties that evidence to the library as built -- the kernel the counters were collected
+    on must still exist under that name, with the workgroup size, LDS block, scratch size and register count the counter rows
+    recorded.  A kernel change that could move the traffic fails here until the PMC passes are re-run."""
+    import csv
+    import json
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import isa_lint
+    rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    checked = 0
+    for layout in ("aos", "soa"):
+        for key in ("fetch_csv", "write_csv"):
+            path = rec.get(layout, {}).get(key)
+            if not path:
+                continue
+            rows = [r for r in csv.DictReader(open(os.path.join(ROOT, path))) if "kf_fast_kernel" in r["Kernel_Name"]]
+            assert rows, path
+            r = rows[-1]
+            m = re.match(r"void fk::(fastv_\d+_\d+_v\d+)::kf_fast_kernel<([^>]*)>", r["Kernel_Name"])
+            assert m, r["Kernel_Name"]
+            targs = ",".join({"false": "0", "true": "1"}.get(t.strip(), t.strip()) for t in m.group(2).split(","))
+            nx, nz = targs.split(",")[:2]
+            objs = [f for f in os.listdir(os.path.join(ROOT, "filterpy_amd", "csrc", "build")) if f.startswith(f"inst_fast_{nx}_{nz}_{m.group(1)[-1]}_") and f.endswith(".o")]
+            assert objs, (nx, nz)
+            with tempfile.TemporaryDirectory() as tmp:
+                info = isa_lint.kernels(isa_lint.device_elf(os.path.join(ROOT, "filterpy_amd", "csrc", "build", objs[0]), tmp))
+            kinds = "iiibbbibbbb"                   # NX, NZ, LAYOUT, HAS_MASK, OUTS, SYM, MMODE, UF, CTRL, EX, IL (kf_fast.hip)
+            want = "kf_fast_kernelI" + "".join(f"L{k}{t}E" for k, t in zip(kinds, targs.split(","))) + "E"
+            hit = [v for k, v in info.items() if want in k and m.group(1) in k]
+            assert len(hit) == 1, (want, [k for k in info if "kf_fast" in k][:4])
+            v = hit[0]
+            assert int(r["Workgroup_Size"]) == 256
+            assert int(r["Scratch_Size"]) == v["scratch"], (r["Scratch_Size"], v)
+            assert int(r["LDS_Block_Size"]) == -(-v["lds"] // 512) * 512, (r["LDS_Block_Size"], v)
+            assert int(r["VGPR_Count"]) * 2 == -(-v["vgpr"] // 8) * 8, (r["VGPR_Count"], v)        # (rocprofv3 reports half of the unified file)
+            checked += 1
+    assert checked >= 2

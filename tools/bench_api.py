@@ -1,0 +1,101 @@
+#!/usr/bin/env python3
+"""What the drop-in call costs END TO END ("report H2D / D2H separately"; VERDICT r4 missing 4):
+KalmanFilterBank.batch_filter with host arrays in and host arrays out -- upload of z / x0 / P0, the launch, download of the four
+histories -- each timed apart with the same engine calls the class makes, next to the wall time of the class call itself and of
+the same call with device_outputs=True (histories stay in HBM).  BASELINE configs[1] ((4,2), T = 100) and configs[2] ((9,3)).
+
+    python tools/bench_api.py [--N 1000000,100000] [--layout aos]
+One JSON line per (config, N).  The histories are 2 * 8 * (n + n^2) bytes per track-step: 32 GB at configs[1]'s 1e6 tracks -- the
+full size runs only where the host has the memory for them (else the largest power-of-ten fraction that fits)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def host_free_bytes():
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable"):
+                return int(line.split()[1]) * 1024
+    except OSError:
+        pass
+    return 0
+
+
+def run(n, m, N, T, layout):
+    import torch
+    from filterpy_amd import _engine as E
+    from filterpy_amd.kalman import KalmanFilterBank
+    from bench import c2_model
+    if (n, m) == (4, 2):
+        F, Q, H, R = c2_model()
+    else:
+        rs = np.random.RandomState(93)
+        F = np.eye(n) + np.diag(np.full(n - 3, 0.1), 3)
+        Q, H, R = 0.01 * np.eye(n), np.eye(m, n), 0.5 * np.eye(m)
+    rs = np.random.RandomState(5)
+    zs = rs.standard_normal((T, N, m))
+    x0, P0 = np.zeros((N, n)), np.tile(100.0 * np.eye(n), (N, 1, 1))
+    sync = torch.cuda.synchronize
+    out_bytes = 2 * 8 * (n + n * n) * N * T
+    rec = {"config": f"({n},{m}) N={N} T={T} {layout}", "input_bytes": zs.nbytes + x0.nbytes + P0.nbytes, "history_bytes": out_bytes}
+
+    def timed(fn):
+        sync()
+        t0 = time.perf_counter()
+        r = fn()
+        sync()
+        return r, time.perf_counter() - t0
+
+    # the pieces, with the calls _Core.batch makes (kalman_filter.py)
+    (dz, dx, dP), rec["h2d_s"] = timed(lambda: (E.to_records(zs, layout, 1), E.to_records(x0, layout, 0), E.to_records(P0, layout, 0)))
+    outs = [E.alloc_records((T,), N, n, layout), E.alloc_records((T,), N, n * n, layout),
+            E.alloc_records((T,), N, n, layout), E.alloc_records((T,), N, n * n, layout)]
+    st = torch.zeros(N, dtype=torch.int32, device=dx.device)
+    desc = dict(n=n, m=m, nu=0, model_mode=0, N=N, T=T, layout=E.LAYOUTS[layout], update_first=0, alpha_sq=1.0)
+    mods = [E.dev(M) for M in (F, Q, H, R)]
+    launch = lambda: E.kf_batch_filter(desc, *mods, dz, dx, dP, means=outs[0], covs=outs[1], means_p=outs[2], covs_p=outs[3], status=st)  # noqa: E731
+    timed(launch)
+    _, rec["kernel_s"] = timed(launch)
+    host, rec["d2h_s"] = timed(lambda: [E.from_records(outs[0], layout, 1, (n,)), E.from_records(outs[1], layout, 1, (n, n)),
+                                        E.from_records(outs[2], layout, 1, (n,)), E.from_records(outs[3], layout, 1, (n, n))])
+    rec["h2d_GBs"] = rec["input_bytes"] / rec["h2d_s"] / 1e9
+    rec["d2h_GBs"] = out_bytes / rec["d2h_s"] / 1e9
+    del host, outs, dz, dx, dP
+    torch.cuda.empty_cache()
+
+    def bank():
+        b = KalmanFilterBank(n, m, N, layout=layout)
+        b.x, b.P, b.F, b.Q, b.H, b.R = x0.copy(), P0.copy(), F, Q, H, R
+        return b
+    b = bank()
+    _, rec["api_host_outputs_s"] = timed(lambda: b.batch_filter(zs))
+    b = bank()
+    res, rec["api_device_outputs_s"] = timed(lambda: b.batch_filter(zs, device_outputs=True))
+    rec["placement"] = getattr(b, "placement_info", None)
+    rec["sum_of_pieces_s"] = rec["h2d_s"] + rec["kernel_s"] + rec["d2h_s"]
+    rec["kernel_share_of_host_output_call"] = rec["kernel_s"] / rec["api_host_outputs_s"]
+    print(json.dumps(rec), flush=True)
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--N", default="1000000,100000")
+    ap.add_argument("--layout", default="aos")
+    ap.add_argument("--T", type=int, default=100)
+    a = ap.parse_args()
+    free = host_free_bytes()
+    for (n, m) in ((4, 2), (9, 3)):
+        for N in (int(v) for v in a.N.split(",")):
+            need = 3 * 2 * 8 * (n + n * n) * N * a.T           # the histories on the host twice (pieces, then the API call) + slack
+            while need > 0.6 * free and N > 1000:
+                N //= 10
+                need //= 10
+            run(n, m, N, a.T, a.layout)
