@@ -164,14 +164,15 @@ def cpu_baseline(zs_host, budget_s=12.0, max_procs=None):
             "sweep": sweep, "host_cpus": avail, "cgroup_cpu_max": quota}
 
 
-def pmc_traffic(layout):
+def pmc_traffic(layout, placement="none"):
     """HBM bytes per launch of the dominant kernel from the COMMITTED rocprofv3 PMC summary of this same command
     (profiles/pmc_traffic.json: FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE, separate --pmc passes, reduced by
     tools/pmc_summary.py).  Counters cannot be read from inside an unprofiled run, so this is not a live measurement:
     the line says where the number comes from (`traffic_source`).  (None, None) if no summary is committed."""
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
-            rec = json.load(fh)[layout]
+            allrec = json.load(fh)
+            rec = allrec.get(f"{layout}_{placement}") or allrec[layout]
         return rec["hbm_bytes_per_launch"], ("committed rocprofv3 --pmc passes of this command (not collected in this run): "
                                              + rec.get("source", "profiles/pmc_traffic.json"))
     except (OSError, KeyError, ValueError):
@@ -384,13 +385,14 @@ def main():
     ap.add_argument("--layout", default=os.environ.get("FK_BENCH_LAYOUT", "aos"), choices=["soa", "aos"],
                     help="record layout of z and the outputs: aos = NumPy C order [T][N][n][n] (default), soa = [T][n*n][N]")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--placement", default=os.environ.get("FK_BENCH_PLACEMENT", "interleave"), choices=["interleave", "probe", "none"],
+    ap.add_argument("--placement", default=os.environ.get("FK_BENCH_PLACEMENT", "interleave"), choices=["interleave", "quad", "probe", "none"],
                     help="how the two covariance histories (76 %% of the bytes) are allocated -- every mode is a mode of the product "
                          "API KalmanFilterBank.batch_filter(device_outputs=True, ...).  interleave (default, and the API's default: what "
                          "a caller gets without reading docs/PLACEMENT.md): both histories in ONE array, a track's posterior and prior "
                          "record side by side (FK_KF_FLAG_COV_INTERLEAVED); probe: placement='probe', two arrays placed in HBM by timing "
                          "this launch on candidate buffers (filterpy_amd/placement.py: placed_pair; ~1 s once per shape, up to 11 "
-                         "buffers allocated while probing, the losers freed); none: cov_interleave=False, two plain arrays.  The line "
+                         "buffers allocated while probing, the losers freed); none: cov_interleave=False, two plain arrays; quad: "
+                         "out_interleave=True, ALL FOUR histories views of one array (FK_KF_FLAG_OUT_INTERLEAVED).  The line "
                          "reports the launch time of all three on this box (`placement`), the timed loop runs the one named here.")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="total budget of the CPU baseline's process-count sweep")
     ap.add_argument("--cpu-procs", type=int, default=0, help="cap the CPU baseline's process count (0 = every host core)")
@@ -461,12 +463,13 @@ def main():
     # track's posterior and prior record side by side, written together (one front: 5.5-5.75 ms on every allocation, where
     # two plain arrays range over 5.3-6.7); placement="probe" places two arrays by timing the launch on candidate buffers
     # (5.2 ms).  All of it outside the timed region; the arithmetic and every stored value are the same.
-    def one_launch_ms(cv, cvp):
+    def one_launch_ms(cv, cvp, mu=None, mup=None):
         x.copy_(x0)
         P.copy_(P0)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        E.kf_batch_filter(desc, dF, dQ, dH, dR, z, x, P, means=means, covs=cv, means_p=means_p, covs_p=cvp, status=status)
+        E.kf_batch_filter(desc, dF, dQ, dH, dR, z, x, P, means=means if mu is None else mu, covs=cv,
+                          means_p=means_p if mup is None else mup, covs_p=cvp, status=status)
         e1.record()
         torch.cuda.synchronize()
         return e0.elapsed_time(e1)
@@ -475,9 +478,11 @@ def main():
     # the timed loop then runs the one --placement names.
     placement_info = {"method": {"none": "two plain arrays", "interleave": "one array for both covariance histories "
                                  "(FK_KF_FLAG_COV_INTERLEAVED; KalmanFilterBank.batch_filter(device_outputs=True))",
+                                 "quad": "one array for all four histories (FK_KF_FLAG_OUT_INTERLEAVED; "
+                                         "KalmanFilterBank.batch_filter(device_outputs=True, out_interleave=True))",
                                  "probe": "two arrays placed by measurement (filterpy_amd.placement.placed_pair; "
                                           "KalmanFilterBank.batch_filter(device_outputs=True, placement='probe'))"}[args.placement]}
-    med3 = lambda cv, cvp: (one_launch_ms(cv, cvp), float(np.median([one_launch_ms(cv, cvp) for _ in range(3)])))[1]  # noqa: E731
+    med3 = lambda *b: (one_launch_ms(*b), float(np.median([one_launch_ms(*b) for _ in range(3)])))[1]  # noqa: E731
     placement_info["two_arrays_ms"] = round(med3(covs, covs_p), 4)
     shape, csize = tuple(covs.shape), covs.numel() * 8
     if args.placement != "none":
@@ -486,7 +491,20 @@ def main():
         cov2, c_il, cp_il = E.alloc_cov_pair(T, N, n, layout, device)
         desc["flags"] = _abi.FK_KF_FLAG_COV_INTERLEAVED
         placement_info["interleave_ms"] = round(med3(c_il, cp_il), 4)
-        if args.placement == "interleave":
+        if layout == "aos" and (args.placement == "quad" or not os.environ.get("FK_BENCH_SKIP_QUAD")):
+            del cov2, c_il, cp_il
+            torch.cuda.empty_cache()
+            out4, q_mu, q_c, q_mup, q_cp = E.alloc_out_quad(T, N, n, device)
+            desc["flags"] = _abi.FK_KF_FLAG_OUT_INTERLEAVED
+            placement_info["quad_ms"] = round(med3(q_c, q_cp, q_mu, q_mup), 4)
+            if args.placement != "quad":
+                del out4, q_mu, q_c, q_mup, q_cp
+                torch.cuda.empty_cache()
+                cov2, c_il, cp_il = E.alloc_cov_pair(T, N, n, layout, device)
+                desc["flags"] = _abi.FK_KF_FLAG_COV_INTERLEAVED
+        if args.placement == "quad":
+            means, covs, means_p, covs_p = q_mu, q_c, q_mup, q_cp
+        elif args.placement == "interleave":
             covs, covs_p = c_il, cp_il
         else:
             del cov2, c_il, cp_il
@@ -568,7 +586,7 @@ def main():
         last = (args.steps - 1) % 2
         assert torch.equal(ex.gathered[last][rank], xbuf[last]), "all-gather returned something else than this rank's final state"
     if rank == 0:
-        traffic, traffic_source = pmc_traffic(layout)
+        traffic, traffic_source = pmc_traffic(layout, args.placement)
         units = float(N) * T * world * args.steps
         alg_bytes = 8.0 * (m + 2 * n + 2 * n * n) * N * T + 2 * 8.0 * (n + n * n) * N   # per launch
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
@@ -582,12 +600,13 @@ def main():
                        "tracks_per_gpu": N, "T": T, "layout": layout,
                        "placement": {"interleave": "interleave = KalmanFilterBank.batch_filter(device_outputs=True) as called without "
                                                    "further arguments (one array for both covariance histories)",
+                                     "quad": "quad = KalmanFilterBank.batch_filter(device_outputs=True, out_interleave=True)",
                                      "probe": "probe = KalmanFilterBank.batch_filter(device_outputs=True, placement='probe')",
                                      "none": "none = KalmanFilterBank.batch_filter(device_outputs=True, cov_interleave=False)"}[args.placement],
                        "parallelism": f"tracks sharded over {world} GPU(s)" + (", RCCL all-gather of final x per step" if world > 1 else "")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
-                         "kernel": "fk::kf_fast_kernel<4,2," + layout + ",nomask,outs> (variant " + os.environ.get("FK_FAST_VARIANT", "0") + ")", "kernel_ms": kernel_ms,
+                         "kernel": "fk::kf_fast_kernel<4,2," + layout + ",nomask,outs" + {"interleave": ",IL=1", "quad": ",IL=2"}.get(args.placement, "") + "> (variant " + os.environ.get("FK_FAST_VARIANT", "0") + ")", "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_launch": alg_bytes},
             "parity_max_rel_vs_oracle": worst, "parity_tracks": int(len(sample)), "placement": placement_info,
             "gpu_clocks": gpu_clocks(), "hbm_probes": hbm_probes(device), "under_load": clocks_under_load(lambda: step(0, None, False)),   # rank 0 alone: no collective in the burst
@@ -604,6 +623,9 @@ def main():
                 del covs, covs_p, got
                 if args.placement == "interleave":
                     del cov2, c_il, cp_il
+                if args.placement == "quad":
+                    del out4, q_mu, q_c, q_mup, q_cp
+                    means, means_p = records(n), records(n)
                 torch.cuda.empty_cache()
                 desc["flags"] = 0
                 from filterpy_amd import placement

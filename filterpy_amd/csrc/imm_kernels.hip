@@ -228,23 +228,46 @@ imm_kernel(const ImmArgs a)
 
 using namespace fk;
 
-template <int LAYOUT>
-static void launch_layout(const ImmArgs &a, int mask, hipStream_t s)
+// One object per (layout, compiled output set): FK_IMM_PART = 4 * layout + set (set 0..2: the exact dims with OUTS bits 0 / 1 /
+// 7, set 3: the padded any-dims kernel) -- the unrolled (9,4) x 4 instantiation alone compiled for six of the library's 8.5
+// minutes as one object; its eight kernels now build side by side.  Part 0 also holds the launcher.
+#ifndef FK_IMM_PART
+#error "compile with -DFK_IMM_PART=0..7"
+#endif
+#define FK_CAT5_(a, b, c, d, e) a##b##_##c##_##d##_p##e
+#define FK_CAT5(a, b, c, d, e) FK_CAT5_(a, b, c, d, e)
+#define FK_CAT_(a, b, c, d) a##b##_##c##_##d
+#define FK_CAT(a, b, c, d) FK_CAT_(a, b, c, d)
+
+void FK_CAT5(launch_imm_, FK_NX, FK_NZ, FK_NM, FK_IMM_PART)(const ImmArgs &a, hipStream_t s)
 {
     constexpr int NX = FK_NX, NZ = FK_NZ, NM = FK_NM;
+    constexpr int LAYOUT = (FK_IMM_PART / 4) ? LAYOUT_AOS : LAYOUT_SOA;
+    constexpr int SET = FK_IMM_PART % 4;
     const dim3 grid((unsigned)((a.cnt + BLOCK - 1) / BLOCK)), block(BLOCK);
-    const bool exact = a.n == NX && a.m == NZ;
-    if (exact && mask == 0) hipLaunchKernelGGL((imm_kernel<NX, NZ, NM, LAYOUT, true, 0>), grid, block, 0, s, a);
-    else if (exact && mask == 1) hipLaunchKernelGGL((imm_kernel<NX, NZ, NM, LAYOUT, true, 1>), grid, block, 0, s, a);
-    else if (exact && mask == 7) hipLaunchKernelGGL((imm_kernel<NX, NZ, NM, LAYOUT, true, 7>), grid, block, 0, s, a);
+    if constexpr (SET == 0) hipLaunchKernelGGL((imm_kernel<NX, NZ, NM, LAYOUT, true, 0>), grid, block, 0, s, a);
+    else if constexpr (SET == 1) hipLaunchKernelGGL((imm_kernel<NX, NZ, NM, LAYOUT, true, 1>), grid, block, 0, s, a);
+    else if constexpr (SET == 2) hipLaunchKernelGGL((imm_kernel<NX, NZ, NM, LAYOUT, true, 7>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((imm_kernel<NX, NZ, NM, LAYOUT, false, -1>), grid, block, 0, s, a);
 }
 
-#define FK_CAT_(a, b, c, d) a##b##_##c##_##d
-#define FK_CAT(a, b, c, d) FK_CAT_(a, b, c, d)
+#if FK_IMM_PART == 0
+#define FK_IMM_DECL(k) void FK_CAT5(launch_imm_, FK_NX, FK_NZ, FK_NM, k)(const ImmArgs &, hipStream_t);
+FK_IMM_DECL(1) FK_IMM_DECL(2) FK_IMM_DECL(3) FK_IMM_DECL(4) FK_IMM_DECL(5) FK_IMM_DECL(6) FK_IMM_DECL(7)
 // launch_imm_<NX>_<NZ>_<NM>: mask = OUTS bits when the outputs form one of the compiled sets, else -1
 void FK_CAT(launch_imm_, FK_NX, FK_NZ, FK_NM)(const ImmArgs &a, int layout, int mask, hipStream_t s)
 {
-    if (layout == FK_LAYOUT_SOA) launch_layout<LAYOUT_SOA>(a, mask, s);
-    else launch_layout<LAYOUT_AOS>(a, mask, s);
+    const bool exact = a.n == FK_NX && a.m == FK_NZ;
+    const int set = (exact && mask == 0) ? 0 : (exact && mask == 1) ? 1 : (exact && mask == 7) ? 2 : 3;
+    switch ((layout == FK_LAYOUT_SOA ? 0 : 4) + set) {
+        case 0: FK_CAT5(launch_imm_, FK_NX, FK_NZ, FK_NM, 0)(a, s); break;
+        case 1: FK_CAT5(launch_imm_, FK_NX, FK_NZ, FK_NM, 1)(a, s); break;
+        case 2: FK_CAT5(launch_imm_, FK_NX, FK_NZ, FK_NM, 2)(a, s); break;
+        case 3: FK_CAT5(launch_imm_, FK_NX, FK_NZ, FK_NM, 3)(a, s); break;
+        case 4: FK_CAT5(launch_imm_, FK_NX, FK_NZ, FK_NM, 4)(a, s); break;
+        case 5: FK_CAT5(launch_imm_, FK_NX, FK_NZ, FK_NM, 5)(a, s); break;
+        case 6: FK_CAT5(launch_imm_, FK_NX, FK_NZ, FK_NM, 6)(a, s); break;
+        default: FK_CAT5(launch_imm_, FK_NX, FK_NZ, FK_NM, 7)(a, s); break;
+    }
 }
+#endif
