@@ -385,14 +385,13 @@ def main():
     ap.add_argument("--layout", default=os.environ.get("FK_BENCH_LAYOUT", "aos"), choices=["soa", "aos"],
                     help="record layout of z and the outputs: aos = NumPy C order [T][N][n][n] (default), soa = [T][n*n][N]")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--placement", default=os.environ.get("FK_BENCH_PLACEMENT", "interleave"), choices=["interleave", "quad", "probe", "none"],
+    ap.add_argument("--placement", default=os.environ.get("FK_BENCH_PLACEMENT", "interleave"), choices=["interleave", "probe", "none"],
                     help="how the two covariance histories (76 %% of the bytes) are allocated -- every mode is a mode of the product "
                          "API KalmanFilterBank.batch_filter(device_outputs=True, ...).  interleave (default, and the API's default: what "
                          "a caller gets without reading docs/PLACEMENT.md): both histories in ONE array, a track's posterior and prior "
                          "record side by side (FK_KF_FLAG_COV_INTERLEAVED); probe: placement='probe', two arrays placed in HBM by timing "
                          "this launch on candidate buffers (filterpy_amd/placement.py: placed_pair; ~1 s once per shape, up to 11 "
-                         "buffers allocated while probing, the losers freed); none: cov_interleave=False, two plain arrays; quad: "
-                         "out_interleave=True, ALL FOUR histories views of one array (FK_KF_FLAG_OUT_INTERLEAVED).  The line "
+                         "buffers allocated while probing, the losers freed); none: cov_interleave=False, two plain arrays.  The line "
                          "reports the launch time of all three on this box (`placement`), the timed loop runs the one named here.")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="total budget of the CPU baseline's process-count sweep")
     ap.add_argument("--cpu-procs", type=int, default=0, help="cap the CPU baseline's process count (0 = every host core)")
@@ -463,13 +462,12 @@ def main():
     # track's posterior and prior record side by side, written together (one front: 5.5-5.75 ms on every allocation, where
     # two plain arrays range over 5.3-6.7); placement="probe" places two arrays by timing the launch on candidate buffers
     # (5.2 ms).  All of it outside the timed region; the arithmetic and every stored value are the same.
-    def one_launch_ms(cv, cvp, mu=None, mup=None):
+    def one_launch_ms(cv, cvp):
         x.copy_(x0)
         P.copy_(P0)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        E.kf_batch_filter(desc, dF, dQ, dH, dR, z, x, P, means=means if mu is None else mu, covs=cv,
-                          means_p=means_p if mup is None else mup, covs_p=cvp, status=status)
+        E.kf_batch_filter(desc, dF, dQ, dH, dR, z, x, P, means=means, covs=cv, means_p=means_p, covs_p=cvp, status=status)
         e1.record()
         torch.cuda.synchronize()
         return e0.elapsed_time(e1)
@@ -478,8 +476,6 @@ def main():
     # the timed loop then runs the one --placement names.
     placement_info = {"method": {"none": "two plain arrays", "interleave": "one array for both covariance histories "
                                  "(FK_KF_FLAG_COV_INTERLEAVED; KalmanFilterBank.batch_filter(device_outputs=True))",
-                                 "quad": "one array for all four histories (FK_KF_FLAG_OUT_INTERLEAVED; "
-                                         "KalmanFilterBank.batch_filter(device_outputs=True, out_interleave=True))",
                                  "probe": "two arrays placed by measurement (filterpy_amd.placement.placed_pair; "
                                           "KalmanFilterBank.batch_filter(device_outputs=True, placement='probe'))"}[args.placement]}
     med3 = lambda *b: (one_launch_ms(*b), float(np.median([one_launch_ms(*b) for _ in range(3)])))[1]  # noqa: E731
@@ -491,20 +487,7 @@ def main():
         cov2, c_il, cp_il = E.alloc_cov_pair(T, N, n, layout, device)
         desc["flags"] = _abi.FK_KF_FLAG_COV_INTERLEAVED
         placement_info["interleave_ms"] = round(med3(c_il, cp_il), 4)
-        if layout == "aos" and (args.placement == "quad" or not os.environ.get("FK_BENCH_SKIP_QUAD")):
-            del cov2, c_il, cp_il
-            torch.cuda.empty_cache()
-            out4, q_mu, q_c, q_mup, q_cp = E.alloc_out_quad(T, N, n, device)
-            desc["flags"] = _abi.FK_KF_FLAG_OUT_INTERLEAVED
-            placement_info["quad_ms"] = round(med3(q_c, q_cp, q_mu, q_mup), 4)
-            if args.placement != "quad":
-                del out4, q_mu, q_c, q_mup, q_cp
-                torch.cuda.empty_cache()
-                cov2, c_il, cp_il = E.alloc_cov_pair(T, N, n, layout, device)
-                desc["flags"] = _abi.FK_KF_FLAG_COV_INTERLEAVED
-        if args.placement == "quad":
-            means, covs, means_p, covs_p = q_mu, q_c, q_mup, q_cp
-        elif args.placement == "interleave":
+        if args.placement == "interleave":
             covs, covs_p = c_il, cp_il
         else:
             del cov2, c_il, cp_il
@@ -600,13 +583,12 @@ def main():
                        "tracks_per_gpu": N, "T": T, "layout": layout,
                        "placement": {"interleave": "interleave = KalmanFilterBank.batch_filter(device_outputs=True) as called without "
                                                    "further arguments (one array for both covariance histories)",
-                                     "quad": "quad = KalmanFilterBank.batch_filter(device_outputs=True, out_interleave=True)",
                                      "probe": "probe = KalmanFilterBank.batch_filter(device_outputs=True, placement='probe')",
                                      "none": "none = KalmanFilterBank.batch_filter(device_outputs=True, cov_interleave=False)"}[args.placement],
                        "parallelism": f"tracks sharded over {world} GPU(s)" + (", RCCL all-gather of final x per step" if world > 1 else "")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
-                         "kernel": "fk::kf_fast_kernel<4,2," + layout + ",nomask,outs" + {"interleave": ",IL=1", "quad": ",IL=2"}.get(args.placement, "") + "> (variant " + os.environ.get("FK_FAST_VARIANT", "0") + ")", "kernel_ms": kernel_ms,
+                         "kernel": "fk::kf_fast_kernel<4,2," + layout + ",nomask,outs" + {"interleave": ",IL"}.get(args.placement, "") + "> (variant " + os.environ.get("FK_FAST_VARIANT", "0") + ")", "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_launch": alg_bytes},
             "parity_max_rel_vs_oracle": worst, "parity_tracks": int(len(sample)), "placement": placement_info,
             "gpu_clocks": gpu_clocks(), "hbm_probes": hbm_probes(device), "under_load": clocks_under_load(lambda: step(0, None, False)),   # rank 0 alone: no collective in the burst
@@ -623,9 +605,6 @@ def main():
                 del covs, covs_p, got
                 if args.placement == "interleave":
                     del cov2, c_il, cp_il
-                if args.placement == "quad":
-                    del out4, q_mu, q_c, q_mup, q_cp
-                    means, means_p = records(n), records(n)
                 torch.cuda.empty_cache()
                 desc["flags"] = 0
                 from filterpy_amd import placement

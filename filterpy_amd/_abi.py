@@ -32,7 +32,6 @@ class fk_kf_desc(ctypes.Structure):
 
 FK_KF_FLAG_R_JOSEPH_DIAG = 1
 FK_KF_FLAG_COV_INTERLEAVED = 2
-FK_KF_FLAG_OUT_INTERLEAVED = 4
 
 
 class fk_kf_extras(ctypes.Structure):

@@ -102,15 +102,6 @@ def alloc_cov_pair(T, N, n, layout, device=None):
     return cov2, cov2[:, 0], cov2[:, 1]
 
 
-def alloc_out_quad(T, N, n, device=None):
-    """All four histories of a batch_filter call in ONE array (FK_KF_FLAG_OUT_INTERLEAVED, include/filterhip.h; NumPy order,
-    dim_x <= 4): returns (out4, means, covs, means_p, covs_p), the four being strided views of out4[T][N][x | x- | P | P-]."""
-    device = device or require_gpu()
-    nn = n * n
-    out4 = torch.empty((T, N, 2 * n + 2 * nn), dtype=torch.float64, device=device)
-    return out4, out4[:, :, :n], out4[:, :, 2 * n:2 * n + nn], out4[:, :, n:2 * n], out4[:, :, 2 * n + nn:]
-
-
 def raise_on_status(status, what):
     """Map per-track status bits to the exception the reference would raise."""
     if status is None:

@@ -27,10 +27,6 @@ struct KfArgs {
     // cov_pitch: doubles between the records of consecutive tracks in NumPy order (n^2, or 2 n^2 interleaved).
     long cov_step;
     int cov_pitch;
-    // FK_KF_FLAG_OUT_INTERLEAVED (kf_fast, NumPy order, dim_x <= 4): all four histories are views of ONE array
-    // out4[T][N][x | x- | P | P-] (record of 2 n + 2 n^2 doubles): means = out4, means_p = out4 + n, covs = out4 + 2 n,
-    // covs_p = out4 + 2 n + n^2.  out_il: 0 four arrays, 1 FK_KF_FLAG_COV_INTERLEAVED, 2 this.
-    int out_il;
     // kf_ml PERS instantiations (persistent grid: one ticket per (time chunk, workgroup of tracks), kf_ml.hip): ctl[0] the
     // ticket counter, ctl[1 + g] how many time chunks of track group g are complete; G groups x H chunks
     int *pers_ctl;

@@ -150,8 +150,7 @@ static int check_desc(const fk_kf_desc *d)
     if (d->N < 0 || d->T < 0) return fail(FK_ERR_BAD_ARG, "N and T must be >= 0");
     if (d->layout != FK_LAYOUT_AOS && d->layout != FK_LAYOUT_SOA) return fail(FK_ERR_BAD_ARG, "bad layout");
     if (d->model_mode < 0 || d->model_mode > 3) return fail(FK_ERR_BAD_ARG, "bad model_mode");
-    if (d->flags & ~(FK_KF_FLAG_R_JOSEPH_DIAG | FK_KF_FLAG_COV_INTERLEAVED | FK_KF_FLAG_OUT_INTERLEAVED)) return fail(FK_ERR_BAD_ARG, "unknown desc flag");
-    if ((d->flags & FK_KF_FLAG_COV_INTERLEAVED) && (d->flags & FK_KF_FLAG_OUT_INTERLEAVED)) return fail(FK_ERR_BAD_ARG, "FK_KF_FLAG_COV_INTERLEAVED and FK_KF_FLAG_OUT_INTERLEAVED exclude each other");
+    if (d->flags & ~(FK_KF_FLAG_R_JOSEPH_DIAG | FK_KF_FLAG_COV_INTERLEAVED)) return fail(FK_ERR_BAD_ARG, "unknown desc flag");
     // one step's record block is addressed with 32-bit byte offsets (fk_device.hpp).  NumPy order: the entry points cut a
     // larger bank into track windows themselves (kf_windows below); element-major: element e of a step sits e * N * 8 bytes
     // into it whatever the window, so there the caller has to split the bank
@@ -192,9 +191,8 @@ static KfArgs kf_window(const fk_kf_desc *d, const KfArgs &a, long i0)
     b.u = adv(a.u, i0 * nu); b.z = adv(a.z, i0 * m); b.mask = adv(a.mask, i0);
     b.x = adv(a.x, i0 * n); b.P = adv(a.P, i0 * n * n);
     b.means = adv(a.means, i0 * n); b.means_p = adv(a.means_p, i0 * n);
-    const long pitch = (d->flags & FK_KF_FLAG_OUT_INTERLEAVED) ? 2 * n + 2 * n * n : (d->flags & FK_KF_FLAG_COV_INTERLEAVED) ? 2 * n * n : n * n;
+    const long pitch = (d->flags & FK_KF_FLAG_COV_INTERLEAVED) ? 2 * n * n : n * n;
     b.covs = adv(a.covs, i0 * pitch); b.covs_p = adv(a.covs_p, i0 * pitch);
-    if (d->flags & FK_KF_FLAG_OUT_INTERLEAVED) { b.means = adv(a.means, i0 * pitch); b.means_p = adv(a.means_p, i0 * pitch); }
     b.y_out = adv(a.y_out, i0 * m); b.K_out = adv(a.K_out, i0 * n * m); b.S_out = adv(a.S_out, i0 * m * m);
     b.SI_out = adv(a.SI_out, i0 * m * m); b.ll_out = adv(a.ll_out, i0); b.maha_out = adv(a.maha_out, i0);
     b.status = adv(a.status, i0);
@@ -233,23 +231,8 @@ static int run_kf_window(const fk_kf_desc *d, KfArgs &a, long cnt, void *stream)
     const long nn = (long)d->n * d->n;
     a.cov_step = d->N * nn;
     a.cov_pitch = (int)nn;
-    a.out_il = 0;
-    const bool quad = (d->flags & FK_KF_FLAG_OUT_INTERLEAVED) != 0;
-    if (quad) {
-        if (!a.means || !a.covs || !a.means_p || !a.covs_p || !a.do_predict || !a.do_update)
-            return fail(FK_ERR_BAD_ARG, "FK_KF_FLAG_OUT_INTERLEAVED: batch_filter with all four outputs");
-        if (d->layout != FK_LAYOUT_AOS) return fail(FK_ERR_UNSUPPORTED, "FK_KF_FLAG_OUT_INTERLEAVED: NumPy order (FK_LAYOUT_AOS) only");
-        if (a.means_p != a.means + d->n || a.covs != a.means + 2 * d->n || a.covs_p != a.covs + nn)
-            return fail(FK_ERR_BAD_ARG, "FK_KF_FLAG_OUT_INTERLEAVED: means_p = means + n, covs = means + 2 n, covs_p = covs + n*n");
-        if ((double)cnt * (double)(2 * d->n + 2 * nn) * 8.0 >= 4294967296.0)
-            return fail(FK_ERR_UNSUPPORTED, "FK_KF_FLAG_OUT_INTERLEAVED: N * (2 n + 2 n^2) * 8 bytes must stay below 4 GiB");
-        a.out_il = 2;
-        a.cov_step = d->N * (2 * d->n + 2 * nn);
-        a.cov_pitch = (int)(2 * d->n + 2 * nn);
-    }
-    const bool inter = (d->flags & FK_KF_FLAG_COV_INTERLEAVED) != 0 || quad;
-    if (inter && !quad) {
-        a.out_il = 1;
+    const bool inter = (d->flags & FK_KF_FLAG_COV_INTERLEAVED) != 0;
+    if (inter) {
         if (!a.means || !a.covs || !a.means_p || !a.covs_p || !a.do_predict || !a.do_update)
             return fail(FK_ERR_BAD_ARG, "FK_KF_FLAG_COV_INTERLEAVED: batch_filter with all four outputs");
         const long half = d->layout == FK_LAYOUT_AOS ? nn : nn * d->N;

@@ -77,14 +77,11 @@ __device__ __forceinline__ void cov_full(const double (&P)[PLEN], double (&M)[NX
 // EX: the update's by-products as per-step histories (fk_kf_batch_filter_ex_f64: y, K, S, SI, log-likelihood, mahalanobis;
 // KalmanFilter.batch_filter with a Saver, kalman_filter.py:533-563 and the lazy properties :1180-1225) stored by this kernel
 // instead of the generic one -- shared constant model, predict -> update, all four outputs.
-// IL = 1 (round 4; NumPy order, dim_x <= 4, FK_KF_FLAG_COV_INTERLEAVED): the prior covariance of a step waits in registers for
-// the posterior and the two leave TOGETHER as one 2 n^2-double record per track -- 1 KiB contiguous per store instruction, one
+// IL (round 4; NumPy order, dim_x <= 4, FK_KF_FLAG_COV_INTERLEAVED): the prior covariance of a step waits in registers for the
+// posterior and the two leave TOGETHER as one 2 n^2-double record per track -- 1 KiB contiguous per store instruction, one
 // write front for both histories (written apart, as two n^2 islands per track at different moments of the step, the
 // interleaved array is slower than two arrays: profiles/r04/placement).
-// IL = 2 (round 5; FK_KF_FLAG_OUT_INTERLEAVED): ALL FOUR histories in one array out4[T][N][x | x- | P | P-] -- the prior state
-// waits too, and a step's whole output of a track (2 n + 2 n^2 doubles: 320 bytes at dim_x 4) leaves at ONE moment into ONE
-// write front: the [x | x-] part and the [P | P-] part as two store groups back to back into the same lines (they meet in L2).
-template <int NX, int NZ, int LAYOUT, bool HAS_MASK, bool OUTS, bool SYM, int MMODE, bool UF, bool CTRL, bool EX = false, int IL = 0>
+template <int NX, int NZ, int LAYOUT, bool HAS_MASK, bool OUTS, bool SYM, int MMODE, bool UF, bool CTRL, bool EX = false, bool IL = false>
 __global__ void __launch_bounds__(BLOCK, fast_min_waves(NX, LAYOUT) > 1 && (MMODE == 1 || MMODE == 2 || EX) ? fast_min_waves(NX, LAYOUT) - 1 : fast_min_waves(NX, LAYOUT))
 kf_fast_kernel(const KfArgs a, const double *__restrict__ pF, const double *__restrict__ pQ,
                const double *__restrict__ pH, const double *__restrict__ pR,
@@ -253,7 +250,7 @@ kf_fast_kernel(const KfArgs a, const double *__restrict__ pF, const double *__re
         const double mpub = mnext;
         if constexpr (MMODE == 3) mnext = shared_elem(t + 2 < T ? t + 2 : T - 1);
         double Pf[NX * NX];
-        double Pprior[IL ? NX * NX : 1], xprior[IL == 2 ? NX : 1];
+        double Pprior[IL ? NX * NX : 1];
         auto do_predict = [&]() {
             if constexpr (MMODE == 1 || MMODE == 2) {
                 if constexpr (SYM) kf_predict_sym<NX>(x, P, tm, a.alpha_sq);
@@ -275,9 +272,8 @@ kf_fast_kernel(const KfArgs a, const double *__restrict__ pF, const double *__re
             } else if (!COOP) {
                 store_rec<NX, 1, LAYOUT, true>(x, a.means_p + t * N * NX, ln, NX, 1);
                 store_rec<NX, NX, LAYOUT, true>(Pf, a.covs_p + t * a.cov_step, ln, NX, NX);
-            } else if constexpr (IL != 0) {
-                if constexpr (IL == 2) { FK_UNROLL for (int e = 0; e < NX; ++e) xprior[e] = x[e]; }
-                else wave_store_aos<NX>(x, a.means_p + (t * N + blk0) * NX, wave * 64u, tile, lane, last_row);
+            } else if constexpr (IL) {
+                wave_store_aos<NX>(x, a.means_p + (t * N + blk0) * NX, wave * 64u, tile, lane, last_row);
                 FK_UNROLL for (int e = 0; e < NX * NX; ++e) Pprior[e] = Pf[e];        // leaves with the posterior
             } else {
                 wave_store_aos<NX>(x, a.means_p + (t * N + blk0) * NX, wave * 64u, tile, lane, last_row);
@@ -363,19 +359,11 @@ kf_fast_kernel(const KfArgs a, const double *__restrict__ pF, const double *__re
             } else if (!COOP) {
                 store_rec<NX, 1, LAYOUT, true>(x, a.means + t * N * NX, ln, NX, 1);
                 store_rec<NX, NX, LAYOUT, true>(Pf, a.covs + t * a.cov_step, ln, NX, NX);
-            } else if constexpr (IL != 0) {
+            } else if constexpr (IL) {
+                wave_store_aos<NX>(x, a.means + (t * N + blk0) * NX, wave * 64u, tile, lane, last_row);
                 double rec[2 * NX * NX];                                            // [posterior | prior]: cov2[t][track][2][n*n]
                 FK_UNROLL for (int e = 0; e < NX * NX; ++e) { rec[e] = Pf[e]; rec[NX * NX + e] = Pprior[e]; }
-                if constexpr (IL == 2) {
-                    constexpr unsigned PITCH = 2 * NX + 2 * NX * NX;                // out4[t][track][x | x- | P | P-]
-                    double rx[2 * NX];
-                    FK_UNROLL for (int e = 0; e < NX; ++e) { rx[e] = x[e]; rx[NX + e] = xprior[e]; }
-                    wave_store_aos_pitch<2 * NX>(rx, a.means + (t * N + blk0) * PITCH, wave * 64u, tile, lane, last_row, PITCH);
-                    wave_store_aos_pitch<2 * NX * NX>(rec, a.covs + (t * N + blk0) * PITCH, wave * 64u, tile, lane, last_row, PITCH);
-                } else {
-                    wave_store_aos<NX>(x, a.means + (t * N + blk0) * NX, wave * 64u, tile, lane, last_row);
-                    wave_store_aos<2 * NX * NX>(rec, a.covs + t * a.cov_step + blk0 * (2 * NX * NX), wave * 64u, tile, lane, last_row);
-                }
+                wave_store_aos<2 * NX * NX>(rec, a.covs + t * a.cov_step + blk0 * (2 * NX * NX), wave * 64u, tile, lane, last_row);
             } else {
                 wave_store_aos<NX>(x, a.means + (t * N + blk0) * NX, wave * 64u, tile, lane, last_row);
                 wave_store_aos_pitch<NX * NX>(Pf, a.covs + t * a.cov_step + blk0 * a.cov_pitch, wave * 64u, tile, lane, last_row, (unsigned)a.cov_pitch);
@@ -455,12 +443,6 @@ int FK_CAT(launch_kf_fast_, FK_NX, FK_NZ, FK_VARIANT)(const KfArgs &a, int layou
     // FK_KF_FLAG_COV_INTERLEAVED in NumPy order needs the wave-cooperative store path (the record pitch is its argument)
     constexpr bool coop_aos = FK_NX * FK_NX <= 36 || (FK_NX <= 8 && fast_min_waves(FK_NX, LAYOUT_AOS) == 1);
     if (layout == LAYOUT_AOS && a.cov_pitch != FK_NX * FK_NX && !coop_aos) return 1;
-    // FK_KF_FLAG_OUT_INTERLEAVED: only the IL = 2 instantiations below write the four-in-one record
-    {
-        constexpr bool have_il2 = FK_NX * FK_NX <= 16 && FK_VARIANT == 0;
-        const bool extras = a.y_out || a.K_out || a.S_out || a.SI_out || a.ll_out || a.maha_out;
-        if (a.out_il == 2 && !(have_il2 && layout == LAYOUT_AOS && outs && mmode == 0 && !a.update_first && a.nu == 0 && !extras)) return 1;
-    }
     if (a.y_out || a.K_out || a.S_out || a.SI_out || a.ll_out || a.maha_out) {
 #if FK_FAST_EX
         if (mmode != 0 || !outs || a.update_first || a.nu > 0 || !a.extras_per_step) return 1;
@@ -486,16 +468,10 @@ int FK_CAT(launch_kf_fast_, FK_NX, FK_NZ, FK_VARIANT)(const KfArgs &a, int layou
     if (a.nu > 0 && !(FK_FAST_ALL_MODES && mmode == 0 && !a.update_first && a.nu <= 4)) return 1;   // control input: same, dim_u <= 4
     // FK_KF_FLAG_COV_INTERLEAVED, NumPy order, dim_x <= 4, the plain call on a shared model: prior and posterior leave together
 #if FK_NX * FK_NX <= 16 && FK_VARIANT == 0
-    if (layout == LAYOUT_AOS && a.out_il == 1 && outs && mmode == 0 && !a.update_first && a.nu == 0 && !getenv("FK_FAST_NO_IL")) {
-        if (a.mask) hipLaunchKernelGGL((kf_fast_kernel<FK_NX, FK_NZ, LAYOUT_AOS, true, true, (FK_FAST_SYM != 0), 0, false, false, false, 1>), grid, block, 0, stream, a, a.F, a.Q, a.H, a.R, a.z, a.mask);
-        else hipLaunchKernelGGL((kf_fast_kernel<FK_NX, FK_NZ, LAYOUT_AOS, false, true, (FK_FAST_SYM != 0), 0, false, false, false, 1>), grid, block, 0, stream, a, a.F, a.Q, a.H, a.R, a.z, a.mask);
+    if (layout == LAYOUT_AOS && a.cov_pitch == 2 * FK_NX * FK_NX && outs && mmode == 0 && !a.update_first && a.nu == 0 && !getenv("FK_FAST_NO_IL")) {
+        if (a.mask) hipLaunchKernelGGL((kf_fast_kernel<FK_NX, FK_NZ, LAYOUT_AOS, true, true, (FK_FAST_SYM != 0), 0, false, false, false, true>), grid, block, 0, stream, a, a.F, a.Q, a.H, a.R, a.z, a.mask);
+        else hipLaunchKernelGGL((kf_fast_kernel<FK_NX, FK_NZ, LAYOUT_AOS, false, true, (FK_FAST_SYM != 0), 0, false, false, false, true>), grid, block, 0, stream, a, a.F, a.Q, a.H, a.R, a.z, a.mask);
         return check_launch("kf_fast_kernel (interleaved)");
-    }
-    // FK_KF_FLAG_OUT_INTERLEAVED: all four histories in one array (cov_pitch = the record of 2 n + 2 n^2 doubles)
-    if (layout == LAYOUT_AOS && a.out_il == 2 && outs && mmode == 0 && !a.update_first && a.nu == 0) {
-        if (a.mask) hipLaunchKernelGGL((kf_fast_kernel<FK_NX, FK_NZ, LAYOUT_AOS, true, true, (FK_FAST_SYM != 0), 0, false, false, false, 2>), grid, block, 0, stream, a, a.F, a.Q, a.H, a.R, a.z, a.mask);
-        else hipLaunchKernelGGL((kf_fast_kernel<FK_NX, FK_NZ, LAYOUT_AOS, false, true, (FK_FAST_SYM != 0), 0, false, false, false, 2>), grid, block, 0, stream, a, a.F, a.Q, a.H, a.R, a.z, a.mask);
-        return check_launch("kf_fast_kernel (all outputs interleaved)");
     }
 #endif
 #define FK_GO(LAY, MSK, OUT, MM)                                                                          \

@@ -60,18 +60,13 @@ def _seq(v, n):
     return list(v)
 
 
-# KalmanFilterBank.batch_filter(device_outputs=True) at (1,1), (2,1), (4,2) in NumPy order: all four histories as views of one
-# array (True) or the covariance pair in one array and the means in two (False) -- whichever measured faster (profiles/r05/)
-_OUT_INTERLEAVE_DEFAULT = False
-
-
 class _Core:
     """Shared device plumbing for one bank of N filters (N = 1 for KalmanFilter)."""
 
     @staticmethod
     def batch(n, m, N, T, x0, P0, z, mask, F, Q, H, R, mode, B=None, us=None, nu=0,
               alpha_sq=1.0, update_first=False, layout="soa", want_outputs=True, device_outputs=False,
-              extras=(), cov_interleave=True, placement=None, placement_out=None, out_interleave=None):
+              extras=(), cov_interleave=True, placement=None, placement_out=None):
         """All inputs are host arrays shaped for `mode`:
         x0 (N,n) P0 (N,n,n) z (T,N,m) mask (T,N) or None;
         models: SHARED (a,b) | PER_TRACK (N,a,b) | PER_STEP (T,a,b) | PER_TRACK_STEP (T,N,a,b).
@@ -107,12 +102,7 @@ class _Core:
         inter = bool(want_outputs and device_outputs and not extras and cov_interleave and n <= 9 and (n, m) != (9, 3)
                      and m <= min(n, 4) and nu == 0 and not update_first and (mode == FK_MODEL_SHARED or n <= 6)
                      and 2 * N * n * n * 8 < 2 ** 32 and placement != "probe")
-        # Round 5: ALL FOUR histories in one array (FK_KF_FLAG_OUT_INTERLEAVED; NumPy order, the specialised kernel's full
-        # instantiations (1,1), (2,1), (4,2), shared model): a step's whole output of a track leaves as one record.
-        # out_interleave: True / False, or None = where it applies (_OUT_INTERLEAVE_DEFAULT).
-        quad = bool(inter and layout == "aos" and (n, m) in ((1, 1), (2, 1), (4, 2)) and mode == FK_MODEL_SHARED)
-        quad = quad and (N * (2 * n + 2 * n * n) * 8 < 2 ** 32) and (_OUT_INTERLEAVE_DEFAULT if out_interleave is None else bool(out_interleave))
-        pinfo = {"method": "quad" if quad else "interleave" if inter else "none"}
+        pinfo = {"method": "interleave" if inter else "none"}
         if want_outputs and device_outputs and not extras and placement == "probe" and T * N * n * n * 8 >= (256 << 20):
             # two dense arrays, placed in HBM by measuring this very launch on several candidate buffers (placement.py:
             # placed_pair; the pair is remembered per shape, the losers are freed).  Worth ~7 % over the interleaved array
@@ -139,9 +129,7 @@ class _Core:
             st.zero_()
             outs = [mu, as_rec(pa), mup, as_rec(pb)]
         elif want_outputs:
-            if quad:
-                outs = list(E.alloc_out_quad(T, N, n)[1:])
-            elif inter:
+            if inter:
                 _, cpost, cprior = E.alloc_cov_pair(T, N, n, layout)
                 outs = [E.alloc_records((T,), N, n, layout), cpost, E.alloc_records((T,), N, n, layout), cprior]
             else:
@@ -162,14 +150,11 @@ class _Core:
             args = (model(F), model(Q), model(H), model(R), dz, dx, dP)
             kw = dict(B=model(B), u=du, mask=dmask, status=st)
             try:
-                fl = _abi.FK_KF_FLAG_OUT_INTERLEAVED if quad else _abi.FK_KF_FLAG_COV_INTERLEAVED
-                E.kf_batch_filter(dict(desc, flags=fl) if inter else desc, *args,
+                E.kf_batch_filter(dict(desc, flags=_abi.FK_KF_FLAG_COV_INTERLEAVED) if inter else desc, *args,
                                   means=outs[0], covs=outs[1], means_p=outs[2], covs_p=outs[3], **kw)
             except _abi.FilterHipError as exc:
                 if not (inter and exc.code == _abi.FK_ERR_UNSUPPORTED):
                     raise
-                if quad:
-                    outs[0], outs[2] = E.alloc_records((T,), N, n, layout), E.alloc_records((T,), N, n, layout)
                 outs[1], outs[3] = E.alloc_records((T,), N, n * n, layout), E.alloc_records((T,), N, n * n, layout)
                 pinfo = {"method": "none", "note": "interleaved histories declined by the library: " + str(exc)[:160]}
                 E.kf_batch_filter(desc, *args, means=outs[0], covs=outs[1], means_p=outs[2], covs_p=outs[3], **kw)
@@ -881,7 +866,7 @@ class KalmanFilterBank(object):
             self.dim_x, self.dim_z, self.n_tracks, x, P, z, mods["H"], mods["R"], mode, mask=mask, layout=self.layout)
 
     def batch_filter(self, zs, mask=None, update_first=False, store=True, device_outputs=False, extras=(),
-                     cov_interleave=True, placement=None, out_interleave=None):
+                     cov_interleave=True, placement=None):
         """zs (T, N, dim_z) NumPy array or a device tensor already in self.layout.
         device_outputs=True: the four histories come back as device tensors in self.layout; the two covariance histories
         are then strided VIEWS of one array in which a track's posterior and prior record sit side by side (one write
@@ -910,7 +895,7 @@ class KalmanFilterBank(object):
         out = _Core.batch(self.dim_x, self.dim_z, self.n_tracks, T, x, P, z, mask, mods["F"], mods["Q"],
                           mods["H"], mods["R"], mode, alpha_sq=self._alpha_sq, update_first=update_first,
                           layout=self.layout, want_outputs=store, device_outputs=device_outputs, extras=tuple(extras),
-                          cov_interleave=cov_interleave, placement=placement, placement_out=pinfo, out_interleave=out_interleave)
+                          cov_interleave=cov_interleave, placement=placement, placement_out=pinfo)
         self.placement_info = pinfo
         if device_outputs:
             self.x = E.from_records(out[4], self.layout, 0, (self.dim_x,))

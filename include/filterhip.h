@@ -108,15 +108,6 @@ typedef struct fk_kf_desc {
  * (dim_x >= 10, per-step extras, final-state-only) return FK_ERR_UNSUPPORTED -- use two arrays there. */
 #define FK_KF_FLAG_COV_INTERLEAVED 2
 
-/* fk_kf_batch_filter_f64 with all four outputs, FK_LAYOUT_AOS, dim_x <= 4 ((1,1), (2,1), (4,2): the specialised kernel's full
- * instantiations), shared constant model, predict -> update: ALL FOUR histories are views of ONE array
- *     out4[T][N][ x (n) | x_prior (n) | P (n*n) | P_prior (n*n) ]        (record pitch 2 n + 2 n*n doubles: 320 bytes at dim_x 4)
- *     means = out4, means_p = out4 + n, covs = out4 + 2 n, covs_p = out4 + 2 n + n*n
- * -- a step's whole output of a track leaves at one moment into one write front (FK_KF_FLAG_COV_INTERLEAVED still has three:
- * the covariance pair and the two mean histories).  Pointers in exactly that relation (FK_ERR_BAD_ARG otherwise); any other
- * call: FK_ERR_UNSUPPORTED.  Excludes FK_KF_FLAG_COV_INTERLEAVED. */
-#define FK_KF_FLAG_OUT_INTERLEAVED 4
-
 /* KalmanFilter.batch_filter (filterpy/kalman/kalman_filter.py:826-993; module twin :1664-1788)
  * for N independent filters: T x { predict (:472-478) ; update (:533-556, Joseph form) },
  * state kept in registers across the whole time loop.

@@ -19,7 +19,7 @@ def model_to_dev(M, mode, layout):
 
 
 def run_kf_batch(x0, P0, zs, F, Q, H, R, *, layout="soa", mode=FK_MODEL_SHARED, mask=None, B=None, us=None,
-                 alpha_sq=1.0, update_first=False, outputs=True, check_status=True, interleave=False, quad=False):
+                 alpha_sq=1.0, update_first=False, outputs=True, check_status=True, interleave=False):
     """x0 (N,n), P0 (N,n,n), zs (T,N,m) host arrays; returns host arrays
     (means (T,N,n), covs (T,N,n,n), means_p, covs_p, x_final (N,n), P_final (N,n,n), status (N,))."""
     T, N, m = zs.shape
@@ -38,12 +38,10 @@ def run_kf_batch(x0, P0, zs, F, Q, H, R, *, layout="soa", mode=FK_MODEL_SHARED, 
                 E.alloc_records((T,), N, n, layout), E.alloc_records((T,), N, n * n, layout)]
         if interleave:          # both covariance histories in one array (FK_KF_FLAG_COV_INTERLEAVED)
             _, outs[1], outs[3] = E.alloc_cov_pair(T, N, n, layout)
-        if quad:                # all four histories in one array (FK_KF_FLAG_OUT_INTERLEAVED)
-            _, outs[0], outs[1], outs[2], outs[3] = E.alloc_out_quad(T, N, n)
         for o in outs:
             o.fill_(float("nan"))
     E.kf_batch_filter(dict(n=n, m=m, nu=nu, model_mode=mode, N=N, T=T, layout=E.LAYOUTS[layout],
-                           update_first=int(update_first), alpha_sq=alpha_sq, flags=4 if quad else (2 if interleave else 0)),
+                           update_first=int(update_first), alpha_sq=alpha_sq, flags=2 if interleave else 0),
                       dF, dQ, dH, dR, dz, dx, dP, B=dB, u=du, mask=dmask,
                       means=outs[0], covs=outs[1], means_p=outs[2], covs_p=outs[3], status=st)
     torch.cuda.synchronize()

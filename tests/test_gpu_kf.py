@@ -1050,35 +1050,6 @@ def test_interleaved_covariance_histories_equal_two_arrays_bit_for_bit(n, m, lay
         assert served >= 2, served           # at least the plain and the masked call run on the specialised kernel
 
 
-@pytest.mark.parametrize("n,m", [(1, 1), (2, 1), (4, 2), (3, 2), (6, 3)])
-def test_all_four_histories_in_one_array_equal_four_arrays_bit_for_bit(n, m):
-    """FK_KF_FLAG_OUT_INTERLEAVED (round 5): all four histories are views of ONE array out4[T][N][x | x- | P | P-] in NumPy
-    order, written by the specialised kernel's IL = 2 instantiations ((1,1), (2,1), (4,2)) as one record per track and step.
-    Nothing but addresses changes: every output equals the four-array call bit for bit -- ragged last workgroup, missing
-    measurements; sizes and calls without such an instantiation answer FK_ERR_UNSUPPORTED and touch nothing."""
-    from filterpy_amd._abi import FilterHipError, FK_ERR_UNSUPPORTED
-    from gpu_util import run_kf_batch
-    rs = np.random.RandomState(77 * n + m)
-    N, T = 333, 9
-    F = np.eye(n) + 0.05 * np.triu(rs.randn(n, n), 1)
-    Q, H, R = 0.02 * np.eye(n), rs.randn(m, n), 0.5 * np.eye(m)
-    x0, P0 = rs.randn(N, n), np.tile(4.0 * np.eye(n), (N, 1, 1))
-    zs = rs.randn(T, N, m)
-    mask = (rs.rand(T, N) > 0.2).astype(np.uint8)
-    for kw in (dict(), dict(mask=mask), dict(update_first=True)):
-        ref = run_kf_batch(x0, P0, zs, F, Q, H, R, layout="aos", **kw)
-        try:
-            got = run_kf_batch(x0, P0, zs, F, Q, H, R, layout="aos", quad=True, **kw)
-        except FilterHipError as exc:
-            assert exc.code == FK_ERR_UNSUPPORTED and ((n, m) not in ((1, 1), (2, 1), (4, 2)) or "update_first" in kw), (n, m, list(kw), exc)
-            continue
-        assert (n, m) in ((1, 1), (2, 1), (4, 2)) and "update_first" not in kw
-        for a, b in zip(ref, got):
-            assert np.array_equal(a, b, equal_nan=True), (n, m, list(kw))
-    with pytest.raises(FilterHipError):
-        run_kf_batch(x0, P0, zs, F, Q, H, R, layout="soa", quad=True)
-
-
 def test_interleaved_flag_checks_its_arguments():
     """the two pointers must be the halves of one array; final-state-only calls have nothing to interleave"""
     import torch

@@ -278,7 +278,7 @@ def test_pmc_evidence_still_describes_the_built_kernel():
     if not os.path.isdir(os.path.join(ROOT, "filterpy_amd", "csrc", "build")):
         pytest.skip("library not built here (the objects do not travel with the .so)")
     checked = 0
-    for layout in ("aos", "soa", "aos_interleave", "aos_quad"):
+    for layout in ("aos", "soa", "aos_interleave"):
         for key in ("fetch_csv", "write_csv"):
             path = rec.get(layout, {}).get(key)
             if not path:
@@ -294,7 +294,7 @@ def test_pmc_evidence_still_describes_the_built_kernel():
             assert objs, (nx, nz)
             with tempfile.TemporaryDirectory() as tmp:
                 info = isa_lint.kernels(isa_lint.device_elf(os.path.join(ROOT, "filterpy_amd", "csrc", "build", objs[0]), tmp))
-            kinds = "iiibbbibbbi"                   # NX, NZ, LAYOUT, HAS_MASK, OUTS, SYM, MMODE, UF, CTRL, EX, IL (int since round 5: kf_fast.hip)
+            kinds = "iiibbbibbbb"                   # NX, NZ, LAYOUT, HAS_MASK, OUTS, SYM, MMODE, UF, CTRL, EX, IL (kf_fast.hip)
             want = "kf_fast_kernelI" + "".join(f"L{k}{t}E" for k, t in zip(kinds, targs.split(","))) + "E"
             hit = [v for k, v in info.items() if want in k and m.group(1) in k]
             assert len(hit) == 1, (want, [k for k in info if "kf_fast" in k][:4])
