@@ -92,9 +92,13 @@ imm_kernel(const ImmArgs a)
     // images, read at the top of step t + 1 behind s_waitcnt vmcnt(k), k = the step's store instructions (at most 63) --
     // hipcc does not see these loads, so the wait is exactly what the in-order counter needs and no more.
     constexpr bool ZDMA = EXACT && OUTS >= 0;
-    // store instructions of one step (a lower bound: NumPy-order records leave as 16-byte pairs)
+    // store instructions of one step -- a LOWER bound (the wait must never name more operations than a step issues behind the
+    // request): NumPy-order records leave as 16-byte pairs, and the NM mode probabilities / likelihoods of a NumPy-order bank
+    // are adjacent 8-byte stores the compiler is free to merge into pairs too (at (2,1) x 3 the count was exact,
+    // margin zero).  tests/test_host_logic.py reads K and the stores behind the request off every built instantiation.
     constexpr int ST_REC = LAYOUT == LAYOUT_AOS ? NX / 2 + NX * NX / 2 : NX + NX * NX;
-    constexpr int ST_STEP = ((OUTS & 1) ? ST_REC + NM : 0) + ((OUTS & 2) ? ST_REC : 0) + ((OUTS & 4) ? NM : 0);
+    constexpr int ST_NM = LAYOUT == LAYOUT_AOS ? (NM + 1) / 2 : NM;
+    constexpr int ST_STEP = ((OUTS & 1) ? ST_REC + ST_NM : 0) + ((OUTS & 2) ? ST_REC : 0) + ((OUTS & 4) ? ST_NM : 0);
     constexpr int ZWAIT = ST_STEP < 63 ? ST_STEP : 63;
     __shared__ double s_z[ZDMA ? (BLOCK / 64) * 2 * LaneRecordDma<NZ, LAYOUT>::IMG_DOUBLES : 1];
     LaneRecordDma<NZ, LAYOUT> zdma;

@@ -305,3 +305,33 @@ def test_pmc_evidence_still_describes_the_built_kernel():
             assert int(r["VGPR_Count"]) * 2 == -(-v["vgpr"] // 8) * 8, (r["VGPR_Count"], v)        # (rocprofv3 reports half of the unified file)
             checked += 1
     assert checked >= 2
+
+
+def test_counted_waits_behind_lds_dma_requests_have_their_stores():
+    """the kernels that fetch the next measurement by LDS-DMA wait for it with a hand-counted `s_waitcnt vmcnt(K)`
+    (K = the store instructions a step issues behind the request, written in the source as a lower bound).  The compiler never
+    sees the DMA, so nothing but this test ties K to what it actually emitted: in every built instantiation with such a loop
+    (IMM banks, kf_fast at dim_x >= 7; the several-lane filters' time loops hold rolled copy-out loops, which a static count
+    cannot price) the vector-memory instructions behind the request must number at least K -- fewer, and the wait returns with
+    the DMA in flight and the step reads a stale image."""
+    import glob
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import isa_lint
+    build = os.path.join(ROOT, "filterpy_amd", "csrc", "build")
+    if not os.path.isdir(build):
+        pytest.skip("library not built here (the objects do not travel with the .so)")
+    objs = sorted(set(glob.glob(os.path.join(build, "inst_imm_2_1_*_p[1256].o")) + glob.glob(os.path.join(build, "inst_imm_4_2_*_p[1256].o"))
+                      + glob.glob(os.path.join(build, "inst_imm_6_3_*_p[1256].o")) + glob.glob(os.path.join(build, "inst_imm_9_4_[234]_*_p[1256].o"))
+                      + glob.glob(os.path.join(build, "inst_fast_[789]_*.o")) + glob.glob(os.path.join(build, "inst_mlg_1[06]_*.o"))
+                      + glob.glob(os.path.join(build, "ukf_mlg_1[06].o"))))
+    assert len(objs) > 40, len(objs)
+    seen = 0
+    with tempfile.TemporaryDirectory() as tmp:
+        for o in objs:
+            for name, (K, younger, checkable) in isa_lint.dma_wait_margins(isa_lint.device_elf(o, tmp)).items():
+                if not checkable:        # (stores inside rolled copy-out loops: a static count sees them once, not per trip)
+                    continue
+                assert younger >= K, (os.path.basename(o), isa_lint.short(name), K, younger)
+                seen += 1
+    assert seen >= 30, seen

@@ -95,6 +95,67 @@ def lint_asm(elf):
     return res
 
 
+def dma_wait_margins(elf):
+    """LDS-DMA prefetches (`buffer_load_dword ... lds`) in a time loop are waited for by a hand-counted `s_waitcnt vmcnt(K)` at
+    the top of the NEXT trip: K must not exceed the vector-memory instructions a trip issues BEHIND the request (vmcnt retires in
+    order: with fewer than K younger operations the wait returns while the DMA is still in flight and the kernel reads a stale
+    image -- ADVICE r4: the count is a lower bound written in the source, the compiler may merge adjacent stores).
+    Returns {kernel: (K, younger, checkable)} for every kernel with such a loop: K = the largest explicit vmcnt(>= 1) that sits
+    between the loop head and the first DMA request of the loop, younger = VMEM instructions from behind the loop's LAST DMA
+    request to the loop's end plus from its head to that wait, counted in layout order -- which is program order only where the
+    time loop holds no inner loop (checkable; IMM banks, kf_fast): the several-lane kernels copy their tiles out in rolled loops
+    whose stores this static count sees once, not once per trip."""
+    dis = subprocess.check_output([f"{LLVM}/llvm-objdump", "-d", "--no-show-raw-insn", elf], text=True)
+    out, cur, lines = {}, None, []
+
+    def flush():
+        if cur is None:
+            return
+        addr = []
+        for l in lines:
+            m = re.search(r"//\s*([0-9A-Fa-f]+):", l)
+            addr.append(int(m.group(1), 16) if m else None)
+        known = [(a, i) for i, a in enumerate(addr) if a is not None]
+        if not known:
+            return
+        base = known[0][0]
+        vmem = lambda l: re.match(r"\s*(buffer|global|flat|scratch)_(load|store|atomic)", l) is not None      # noqa: E731
+        for i, l in enumerate(lines):
+            m = re.search(r"s_cbranch_(scc[01]|vccn?z|execn?z)\s.*<\S+?\+0x([0-9a-f]+)>", l)
+            if not (m and addr[i] is not None):
+                continue
+            tgt = base + int(m.group(2), 16)
+            if tgt >= addr[i]:
+                continue
+            j = next((k for a, k in known if a >= tgt), i)
+            body = lines[j:i + 1]
+            dma = [k for k, b in enumerate(body) if re.match(r"\s*buffer_load_\w+ .*\blds\b", b)]
+            if not dma:
+                continue
+            waits = [(k, int(mm.group(1))) for k, b in enumerate(body[:dma[0]]) for mm in [re.search(r"s_waitcnt vmcnt\((\d+)\)", b)] if mm and int(mm.group(1)) >= 1]
+            if not waits:
+                continue
+            wk, K = max(waits, key=lambda t: t[1])
+            younger = sum(1 for b in body[dma[-1] + 1:] if vmem(b)) + sum(1 for b in body[:wk] if vmem(b))
+            inner = False
+            for k, b in enumerate(body[:-1]):
+                mm = re.search(r"s_cbranch_\w+\s.*<\S+?\+0x([0-9a-f]+)>", b)
+                if mm and addr[j + k] is not None and base + int(mm.group(1), 16) < addr[j + k]:
+                    inner = True
+            prev = out.get(cur)
+            if prev is None or K - younger > prev[0] - prev[1]:
+                out[cur] = (K, younger, not inner)
+    for l in dis.splitlines():
+        m = re.match(r"^[0-9a-f]+ <(\S+)>:", l)
+        if m:
+            flush()
+            cur, lines = m.group(1), []
+        elif cur is not None:
+            lines.append(l)
+    flush()
+    return out
+
+
 def short(name):
     m = re.search(r"\d+(ukf_mlg_rts_kernel|ukf_mlg_kernel|[a-z_0-9]+_kernel)I(.*?)EEv", name)
     return (m.group(1) + "<" + re.sub(r"L[ib](\d+)E", r"\1,", m.group(2)).rstrip(",") + ">") if m else name[:60]
