@@ -385,14 +385,17 @@ def main():
     ap.add_argument("--layout", default=os.environ.get("FK_BENCH_LAYOUT", "aos"), choices=["soa", "aos"],
                     help="record layout of z and the outputs: aos = NumPy C order [T][N][n][n] (default), soa = [T][n*n][N]")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--placement", default=os.environ.get("FK_BENCH_PLACEMENT", "interleave"), choices=["interleave", "probe", "none"],
+    ap.add_argument("--placement", default=os.environ.get("FK_BENCH_PLACEMENT", "auto"), choices=["auto", "interleave", "probe", "none"],
                     help="how the two covariance histories (76 %% of the bytes) are allocated -- every mode is a mode of the product "
-                         "API KalmanFilterBank.batch_filter(device_outputs=True, ...).  interleave (default, and the API's default: what "
-                         "a caller gets without reading docs/PLACEMENT.md): both histories in ONE array, a track's posterior and prior "
-                         "record side by side (FK_KF_FLAG_COV_INTERLEAVED); probe: placement='probe', two arrays placed in HBM by timing "
-                         "this launch on candidate buffers (filterpy_amd/placement.py: placed_pair; ~1 s once per shape, up to 11 "
-                         "buffers allocated while probing, the losers freed); none: cov_interleave=False, two plain arrays.  The line "
-                         "reports the launch time of all three on this box (`placement`), the timed loop runs the one named here.")
+                         "API KalmanFilterBank.batch_filter(device_outputs=True, ...).  auto (default) = the API called without "
+                         "further arguments: what a caller gets without reading docs/PLACEMENT.md -- at this size (dim_x <= 4, "
+                         "histories of 256 MiB and more) two arrays placed in HBM by timing this launch on candidate buffers "
+                         "(filterpy_amd/placement.py: placed_pair; ~1 s once per shape, up to 11 buffers allocated while probing, the "
+                         "losers freed), the interleaved array where that cannot run; interleave: placement='interleave', both "
+                         "histories in ONE array, a track's posterior and prior record side by side (FK_KF_FLAG_COV_INTERLEAVED); "
+                         "probe: placement='probe' (like auto, falling back to two plain arrays); none: cov_interleave=False, two "
+                         "plain arrays.  The line reports the launch time of all three arrangements on this box (`placement`), the "
+                         "timed loop runs the one named here.")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="total budget of the CPU baseline's process-count sweep")
     ap.add_argument("--cpu-procs", type=int, default=0, help="cap the CPU baseline's process count (0 = every host core)")
     ap.add_argument("--force-dist", action="store_true",
@@ -475,9 +478,11 @@ def main():
     # All three arrangements are timed on this box (3 launches each, outside the timed region) and reported in the line;
     # the timed loop then runs the one --placement names.
     placement_info = {"method": {"none": "two plain arrays", "interleave": "one array for both covariance histories "
-                                 "(FK_KF_FLAG_COV_INTERLEAVED; KalmanFilterBank.batch_filter(device_outputs=True))",
+                                 "(FK_KF_FLAG_COV_INTERLEAVED; KalmanFilterBank.batch_filter(device_outputs=True, placement='interleave'))",
                                  "probe": "two arrays placed by measurement (filterpy_amd.placement.placed_pair; "
-                                          "KalmanFilterBank.batch_filter(device_outputs=True, placement='probe'))"}[args.placement]}
+                                          "KalmanFilterBank.batch_filter(device_outputs=True, placement='probe'))",
+                                 "auto": "the API's default at this size: two arrays placed by measurement "
+                                         "(filterpy_amd.placement.placed_pair; KalmanFilterBank.batch_filter(device_outputs=True))"}[args.placement]}
     med3 = lambda *b: (one_launch_ms(*b), float(np.median([one_launch_ms(*b) for _ in range(3)])))[1]  # noqa: E731
     placement_info["two_arrays_ms"] = round(med3(covs, covs_p), 4)
     shape, csize = tuple(covs.shape), covs.numel() * 8
@@ -496,13 +501,19 @@ def main():
             from filterpy_amd import placement
             as_records = lambda b: b.view(torch.float64).view(shape)          # noqa: E731
             try:
-                a_, b_, info = placement.placed_pair(csize, lambda a, b: one_launch_ms(as_records(a), as_records(b)), device)
+                a_, b_, info = placement.placed_pair(csize, lambda a, b: one_launch_ms(as_records(a), as_records(b)), device,
+                                                     or_none=args.placement == "auto")
             except Exception as exc:                 # (e.g. another tenant holds most of the memory): plain allocation
                 torch.cuda.empty_cache()
-                a_ = torch.empty(csize, dtype=torch.uint8, device=device)
-                b_ = torch.empty(csize, dtype=torch.uint8, device=device)
+                a_ = None if args.placement == "auto" else torch.empty(csize, dtype=torch.uint8, device=device)
+                b_ = None if args.placement == "auto" else torch.empty(csize, dtype=torch.uint8, device=device)
                 info = {"method": "plain allocation (probe failed)", "error": repr(exc)[:200]}
-            covs, covs_p = as_records(a_), as_records(b_)
+            if a_ is None:                           # auto, like the API: the interleaved array where the probe cannot run
+                cov2, covs, covs_p = E.alloc_cov_pair(T, N, n, layout, device)
+                desc["flags"] = _abi.FK_KF_FLAG_COV_INTERLEAVED
+                info = dict(info, fell_back_to="interleave")
+            else:
+                covs, covs_p = as_records(a_), as_records(b_)
             placement_info["probe"] = info
             if world > 1:                            # every rank probes its own GPU: a rank that fell back shows in the line
                 outcomes = [None] * world
@@ -569,7 +580,7 @@ def main():
         last = (args.steps - 1) % 2
         assert torch.equal(ex.gathered[last][rank], xbuf[last]), "all-gather returned something else than this rank's final state"
     if rank == 0:
-        traffic, traffic_source = pmc_traffic(layout, args.placement)
+        traffic, traffic_source = pmc_traffic(layout, "interleave" if desc.get("flags") else "none")
         units = float(N) * T * world * args.steps
         alg_bytes = 8.0 * (m + 2 * n + 2 * n * n) * N * T + 2 * 8.0 * (n + n * n) * N   # per launch
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
@@ -581,14 +592,16 @@ def main():
             "config": {"workload": f"BASELINE configs[1]: {N} independent dim_x=4 dim_z=2 tracks x {T} steps per GPU, "
                                    "fp64, shared F/H/Q/R, KalmanFilter.batch_filter (all 4 outputs stored)",
                        "tracks_per_gpu": N, "T": T, "layout": layout,
-                       "placement": {"interleave": "interleave = KalmanFilterBank.batch_filter(device_outputs=True) as called without "
-                                                   "further arguments (one array for both covariance histories)",
+                       "placement": {"auto": "auto = KalmanFilterBank.batch_filter(device_outputs=True) as called without further "
+                                             "arguments: at this size two covariance arrays placed in HBM by measurement",
+                                     "interleave": "interleave = KalmanFilterBank.batch_filter(device_outputs=True, placement='interleave') "
+                                                   "(one array for both covariance histories)",
                                      "probe": "probe = KalmanFilterBank.batch_filter(device_outputs=True, placement='probe')",
                                      "none": "none = KalmanFilterBank.batch_filter(device_outputs=True, cov_interleave=False)"}[args.placement],
                        "parallelism": f"tracks sharded over {world} GPU(s)" + (", RCCL all-gather of final x per step" if world > 1 else "")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
-                         "kernel": "fk::kf_fast_kernel<4,2," + layout + ",nomask,outs" + {"interleave": ",IL"}.get(args.placement, "") + "> (variant " + os.environ.get("FK_FAST_VARIANT", "0") + ")", "kernel_ms": kernel_ms,
+                         "kernel": "fk::kf_fast_kernel<4,2," + layout + ",nomask,outs" + (",IL" if desc.get("flags") else "") + "> (variant " + os.environ.get("FK_FAST_VARIANT", "0") + ")", "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_launch": alg_bytes},
             "parity_max_rel_vs_oracle": worst, "parity_tracks": int(len(sample)), "placement": placement_info,
             "gpu_clocks": gpu_clocks(), "hbm_probes": hbm_probes(device), "under_load": clocks_under_load(lambda: step(0, None, False)),   # rank 0 alone: no collective in the burst
@@ -599,7 +612,7 @@ def main():
                                "double-buffered x / gathered" % (x.numel() * 8 // 1000000))
         if args.force_dist:
             out["dist_forced"] = f"{world}-rank {dist.get_backend()} group: init_process_group(device_id), all_gather_into_tensor, barrier, all_reduce(MAX) executed"
-        if world == 1 and args.placement != "probe" and not os.environ.get("FK_BENCH_SKIP_PROBE"):
+        if world == 1 and args.placement in ("interleave", "none") and not os.environ.get("FK_BENCH_SKIP_PROBE"):
             # the third arrangement (two arrays placed by measurement), timed AFTER the measurement, for the record only
             try:
                 del covs, covs_p, got

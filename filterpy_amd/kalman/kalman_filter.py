@@ -102,8 +102,14 @@ class _Core:
         inter = bool(want_outputs and device_outputs and not extras and cov_interleave and n <= 9 and (n, m) != (9, 3)
                      and m <= min(n, 4) and nu == 0 and not update_first and (mode == FK_MODEL_SHARED or n <= 6)
                      and 2 * N * n * n * 8 < 2 ** 32 and placement != "probe")
+        # placement=None (round 5, the default): where the launch is HBM-bound and its two big streams are most of its bytes --
+        # the one-lane specialised kernel at dim_x <= 4 -- and the histories are large (256 MiB each and more), place them by
+        # measurement ("probe": 5.24-5.41 ms at BASELINE configs[1] on every box of rounds 4 / 5, where the interleaved array
+        # ran 5.49-5.87 and two plain arrays 5.33-6.73); the interleaved array everywhere else, and where the probe cannot run
+        # (no room for three candidates, the remembered pair of this shape still alive in the caller's hands).
+        auto_probe = bool(placement is None and inter and n * n <= 16 and T * N * n * n * 8 >= (256 << 20))
         pinfo = {"method": "interleave" if inter else "none"}
-        if want_outputs and device_outputs and not extras and placement == "probe" and T * N * n * n * 8 >= (256 << 20):
+        if want_outputs and device_outputs and not extras and (placement == "probe" or auto_probe) and T * N * n * n * 8 >= (256 << 20):
             # two dense arrays, placed in HBM by measuring this very launch on several candidate buffers (placement.py:
             # placed_pair; the pair is remembered per shape, the losers are freed).  Worth ~7 % over the interleaved array
             # at BASELINE configs[1] (5.2 against 5.6 ms), costs about a second once per shape.
@@ -123,11 +129,18 @@ class _Core:
                 e1.record()
                 torch.cuda.synchronize()
                 return e0.elapsed_time(e1)
-            pa, pb, pinfo = _pl.placed_pair(T * N * n * n * 8, run_ms, dx.device)
+            pa, pb, pinfo = _pl.placed_pair(T * N * n * n * 8, run_ms, dx.device, or_none=auto_probe)
             dx.copy_(dx0)
             dP.copy_(dP0)
             st.zero_()
-            outs = [mu, as_rec(pa), mup, as_rec(pb)]
+            if pa is not None:
+                outs = [mu, as_rec(pa), mup, as_rec(pb)]
+                inter = False
+            else:                            # (auto only) the interleaved array after all
+                note = pinfo["method"]
+                _, cpost, cprior = E.alloc_cov_pair(T, N, n, layout)
+                outs = [mu, cpost, mup, cprior]
+                pinfo = {"method": "interleave", "note": note}
         elif want_outputs:
             if inter:
                 _, cpost, cprior = E.alloc_cov_pair(T, N, n, layout)
@@ -873,7 +886,9 @@ class KalmanFilterBank(object):
         front: docs/PLACEMENT.md) -- `.contiguous()` gives a dense copy, cov_interleave=False two dense arrays.
         placement="probe" (device outputs of 256 MiB and more): two dense arrays placed in HBM by timing this very launch
         on candidate buffers (filterpy_amd/placement.py: about a second once per shape, the pair is remembered and reused while
-        no earlier result is alive; `self.placement_info` says what happened) -- the fastest arrangement measured.
+        no earlier result is alive; `self.placement_info` says what happened) -- the fastest arrangement measured, and what
+        placement=None (the default) does by itself at dim_x <= 4 for histories of that size; placement="interleave" keeps the
+        one-array form there too (no probe, no transient candidate buffers).
         extras: any of 'y', 'K', 'S', 'SI', 'log_likelihood', 'mahalanobis' -> also returns a dict of the
         per-step histories (T, N, ...) as a fifth element (what filterpy.common.Saver would record)."""
         import torch

@@ -72,11 +72,13 @@ def _use_count(t):
     return torch._C._storage_Use_Count(t.untyped_storage()._cdata)
 
 
-def placed_pair(nbytes, run_ms, device, max_chunks=11, reserve=24 << 30, reps=2):
+def placed_pair(nbytes, run_ms, device, max_chunks=11, reserve=24 << 30, reps=2, or_none=False):
     """Two uint8 tensors of `nbytes` for the two concurrently written history arrays of a kernel, chosen by measurement.
 
     run_ms(a, b): the caller's kernel with its two big outputs in the byte tensors a, b -> milliseconds.  Returns (a, b, info);
-    info["method"]: "probe" (just measured), "cached" (the pair of an earlier call, free again), "plain allocation (...)"."""
+    info["method"]: "probe" (just measured), "cached" (the pair of an earlier call, free again), "plain allocation (...)".
+    or_none=True: where the probe cannot run (no room for three candidates, the remembered pair still in use) return
+    (None, None, info) instead of two plain buffers -- the caller has something better than the lottery to fall back on."""
     dev = torch.device(device)
     key = (dev.index if dev.index is not None else torch.cuda.current_device(), int(nbytes))
     ent = _PAIRS.get(key)
@@ -84,10 +86,14 @@ def placed_pair(nbytes, run_ms, device, max_chunks=11, reserve=24 << 30, reps=2)
         a, b, base, info = ent
         if _use_count(a) == base[0] and _use_count(b) == base[1]:
             return a, b, dict(info, method="cached")
+        if or_none:
+            return None, None, {"method": "not placed (the placed pair of this shape is still in use)"}
         return (torch.empty(nbytes, dtype=torch.uint8, device=dev), torch.empty(nbytes, dtype=torch.uint8, device=dev),
                 {"method": "plain allocation (the placed pair of this shape is still in use)"})
     free, _ = torch.cuda.mem_get_info(dev)
     k = int(min(max_chunks, max(0, free - reserve) // max(1, nbytes)))
+    if k < 3 and or_none:
+        return None, None, {"method": "not placed (no room to probe)", "free_GiB": free >> 30}
     if k < 3:
         return (torch.empty(nbytes, dtype=torch.uint8, device=dev), torch.empty(nbytes, dtype=torch.uint8, device=dev),
                 {"method": "plain allocation (no room to probe)", "free_GiB": free >> 30})
