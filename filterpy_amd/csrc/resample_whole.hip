@@ -356,8 +356,12 @@ resample_whole_quick_kernel(const WholeArgs a)
         mn = w[q] < mn ? w[q] : mn;
     }
     const double winc = wave_incl_sum(run);
-    if (lane == 63) s_wtot[wave] = winc;
-    const int any_neg = __syncthreads_or(mn < 0.0 ? 1 : 0);                                   // (1)
+    // (one s_barrier here and one at (A) instead of the three a __syncthreads_or costs: a wave that holds a negative weight
+    //  publishes NaN as its total -- the sum then fails the sanity test like any other garbage --, and (A)'s verdict travels in
+    //  one flag word per wave)
+    const bool wave_neg = __builtin_amdgcn_ballot_w64(mn < 0.0) != 0;
+    if (lane == 63) s_wtot[wave] = wave_neg ? __builtin_nan("") : winc;
+    __syncthreads();                                                                          // (1)
     double before = __shfl_up(winc, 1, 64);
     if (lane == 0) before = 0.0;
     double S = 0.0;
@@ -366,14 +370,21 @@ resample_whole_quick_kernel(const WholeArgs a)
         if (wv < wave) before += t;
         S += t;
     }
-    const bool garbage = any_neg || !(S < 0x1p1000);                       // uniform
+    const bool garbage = !(S < 0x1p1000);                                  // uniform: negative, NaN, Inf or absurdly large
     int nb[WH_ITEMS];
     unsigned unsure = 1;
     if (!garbage) {
         unsure = wh_approx_boundaries<STRATIFIED>(w, before, px, nb);
         s_nlast[tid] = nb[WH_ITEMS - 1];
     }
-    if (__builtin_expect(!__syncthreads_or((unsure != 0 || a.force_exact) ? 1 : 0), 1)) {     // (A) (also publishes nlast)
+    {
+        const bool wave_unsure = __builtin_amdgcn_ballot_w64(unsure != 0 || a.force_exact != 0) != 0;
+        if (lane == 0) sh.dtot[wave] = wave_unsure ? 1 : 0;
+    }
+    __syncthreads();                                                                          // (A) (also publishes nlast)
+    int tail = 0;
+    FK_UNROLL for (int wv = 0; wv < NW; ++wv) tail |= sh.dtot[wv];
+    if (__builtin_expect(tail == 0, 1)) {
     int nprev = tid == 0 ? 0 : s_nlast[tid - 1];
     const int u_hi = __builtin_amdgcn_readfirstlane(s_nlast[NT - 1]);
     const int mis = (int)(((uintptr_t)of >> 2) & 3);

@@ -1157,7 +1157,7 @@ def test_bank_placement_probe_places_by_measurement_and_remembers_the_pair():
         assert torch.equal(a, c)
     # the default: the same measurement, unasked; a second default call while the first one's arrays are alive gets the
     # interleaved array (strided views of one allocation), not the lottery of two plain ones
-    del out3
+    del out3, a, c                           # (the loop variables above still name two of its tensors)
     gc.collect()
     b4 = bank()
     out4 = b4.batch_filter(zs, device_outputs=True)
@@ -1168,7 +1168,7 @@ def test_bank_placement_probe_places_by_measurement_and_remembers_the_pair():
     assert out5[1].untyped_storage().data_ptr() == out5[3].untyped_storage().data_ptr()
     for a, c, e in zip(ref, out4, out5):
         assert torch.equal(a, c) and torch.equal(a, e)
-    del out4, out5
+    del out4, out5, a, c, e
     gc.collect()
     placement.forget_placed_pairs()
     b6 = bank()
