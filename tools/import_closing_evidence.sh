@@ -9,24 +9,34 @@ mkdir -p $D/c5
 cp $S/bench_default.json $S/bench_placement_probe.json $S/bench_placement_none.json $S/bench_under_rocprof_stats.json \
    $S/bench_under_rocprof_pmc_fetch.json $S/bench_under_rocprof_pmc_write.json $S/configs_all.jsonl $S/configs_all_kernel_durations.txt \
    $S/configs_all_kernel_stats.csv $S/resample_shapes.jsonl $S/kernel_durations.txt $S/kernel_durations_bench_last20.txt \
-   $S/bench_kernel_trace_fk.csv $S/pytest_gpu_full.log $S/box_state.txt $S/smoke.log $S/pmc_headline.json \
+   $S/bench_kernel_trace_fk.csv $S/pytest_gpu_full.log $S/box_state.txt $S/smoke.log \
    $S/ukf_kernels.jsonl $S/ukf_kernels_index_order.jsonl $S/ukf_kernel_durations.txt $S/ukf_kernel_durations_index_order.txt $D/
-cp $S/prof_fetch_fk.csv $D/kf_c2_aos_il_pmc_fetch.csv
-cp $S/prof_write_fk.csv $D/kf_c2_aos_il_pmc_write.csv
+cp $S/prof_fetch_fk.csv $D/kf_c2_aos_pmc_fetch.csv
+cp $S/prof_write_fk.csv $D/kf_c2_aos_pmc_write.csv
 cp $S/kernel_durations_round4_resampler.txt $S/bench_api.jsonl $S/c_abi_multi_gpu.log $D/ 2>/dev/null || true
 cp $S/bench_c5_1000x8000.json $S/bench_c5_125x8000.json $S/bench_c5_125x8000000.json $S/bench_c5_force_dist_1rank_nccl.json $D/c5/
 cp $S/bench_force_dist_1rank_nccl.json $D/bench_force_dist_1rank_nccl.json
-python - "$S" <<'PY'
-import json, sys
+python - "$D" <<'PY'
+# HBM traffic per launch of the kernel the DEFAULT placement runs (two placed arrays: the plain kf_fast instantiation) from the
+# two separate PMC passes of `python bench.py --steps 20 --warmup 5 --no-cpu` (rows of every fk:: kernel are in the CSVs; the
+# interleaved instantiation's entry, aos_interleave, comes from the lease that ran it as the timed kernel: profiles/r05/kf_c2_aos_il_*)
+import csv, json, sys
+d = sys.argv[1]
+plain = "kf_fast_kernel<4, 2, 0, false, true, false, 0, false, false, false, false>"
+def mean(path, counter):
+    v = [float(r["Counter_Value"]) for r in csv.DictReader(open(path)) if r["Counter_Name"] == counter and plain in r["Kernel_Name"]]
+    return sum(v) / len(v), len(v)
+f, nf = mean(d + "/kf_c2_aos_pmc_fetch.csv", "FETCH_SIZE")
+w, nw = mean(d + "/kf_c2_aos_pmc_write.csv", "WRITE_SIZE")
 p = "profiles/pmc_traffic.json"
 t = json.load(open(p))
-h = json.load(open(sys.argv[1] + "/pmc_headline.json"))
-t["aos_interleave"] = dict(FETCH_SIZE_KiB=h["FETCH_SIZE_KiB"], WRITE_SIZE_KiB=h["WRITE_SIZE_KiB"], hbm_bytes_per_launch=h["hbm_bytes_per_launch"], round="r05",
-                           fetch_csv="profiles/r05/kf_c2_aos_il_pmc_fetch.csv", write_csv="profiles/r05/kf_c2_aos_il_pmc_write.csv",
-                           source="profiles/r05/kf_c2_aos_il_pmc_fetch.csv + kf_c2_aos_il_pmc_write.csv (mean of %d / %d launches of the IL kernel under `python bench.py --steps 20 --warmup 5 --no-cpu`, the default placement; FETCH_SIZE doubled per the gfx950 correction; tools/pmc_reduce.py)" % tuple(h["launches"]))
+t["aos"] = dict(FETCH_SIZE_KiB=f, WRITE_SIZE_KiB=w, hbm_bytes_per_launch=int(round((2 * f + w) * 1024)), round="r05",
+                fetch_csv=d + "/kf_c2_aos_pmc_fetch.csv", write_csv=d + "/kf_c2_aos_pmc_write.csv",
+                source="%s/kf_c2_aos_pmc_fetch.csv + kf_c2_aos_pmc_write.csv (mean of %d / %d launches of the plain kf_fast<4,2,aos> kernel -- the one the default placement runs -- under `python bench.py --steps 20 --warmup 5 --no-cpu`, FETCH_SIZE doubled per the gfx950 correction)" % (d, nf, nw))
 json.dump(t, open(p, "w"), indent=2)
 open(p, "a").write("\n")
-print("pmc:", t["aos_interleave"]["hbm_bytes_per_launch"], "bytes per launch")
+json.dump(dict(kernel=plain, FETCH_SIZE_KiB=f, WRITE_SIZE_KiB=w, launches=[nf, nw], hbm_bytes_per_launch=t["aos"]["hbm_bytes_per_launch"]), open(d + "/pmc_headline.json", "w"))
+print("pmc:", t["aos"]["hbm_bytes_per_launch"], "bytes per launch")
 PY
 python tools/make_design_table.py $D --write
 tail -1 $D/pytest_gpu_full.log
