@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--dma", action="store_true")
     ap.add_argument("--index-order", action="store_true", help="the index-order sums (PAIRED = false)")
     ap.add_argument("--sp", action="store_true", help="fwd, element-major: 16-byte stores of two element rows (SP = true)")
+    ap.add_argument("--mllvm", action="append", default=[], help="extra -mllvm option (repeatable), e.g. --mllvm=-amdgpu-sched-strategy=max-ilp")
     a = ap.parse_args()
     lay = {"soa": "fk::LAYOUT_SOA", "aos": "fk::LAYOUT_AOS"}[a.dims[-1]]
     exact = "false" if a.padded else "true"
@@ -44,6 +45,8 @@ def main():
         fh.write(f'#define FK_UKF_PART {part}\n#include "{os.path.join(CSRC, "ukf_kernels.hip")}"\n{inst}\n')
     cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fno-gpu-rdc", "-Wno-pass-failed", "-S",
            "--cuda-device-only", "-Rpass-analysis=kernel-resource-usage", src, "-o", asm]
+    for opt in a.mllvm:
+        cmd += ["-mllvm", opt]
     out = subprocess.run(cmd, capture_output=True, text=True)
     for line in out.stderr.splitlines():
         if "error" in line:
