@@ -243,6 +243,18 @@ using namespace fk;
 #define FK_CAT_(a, b, c, d) a##b##_##c##_##d
 #define FK_CAT(a, b, c, d) FK_CAT_(a, b, c, d)
 
+#if defined(FK_IMM_GENERAL_ONLY) && (FK_IMM_PART % 4) != 3
+// Classes built UNROLLED beyond (9,4) x 4 -- (9,4) x 5..8, (16,8) x 2: static scratch offsets instead of dynamically indexed
+// scratch arrays, 7-9 x faster (profiles/r05/imm/), at 4-9 minutes of compile per kernel -- carry only the general kernel (any
+// dims of the class, any output set: parts 3 and 7); the compiled-output-set parts forward to it.
+void FK_CAT5(launch_imm_, FK_NX, FK_NZ, FK_NM, 3)(const ImmArgs &, hipStream_t);
+void FK_CAT5(launch_imm_, FK_NX, FK_NZ, FK_NM, 7)(const ImmArgs &, hipStream_t);
+void FK_CAT5(launch_imm_, FK_NX, FK_NZ, FK_NM, FK_IMM_PART)(const ImmArgs &a, hipStream_t s)
+{
+    if (FK_IMM_PART / 4) FK_CAT5(launch_imm_, FK_NX, FK_NZ, FK_NM, 7)(a, s);
+    else FK_CAT5(launch_imm_, FK_NX, FK_NZ, FK_NM, 3)(a, s);
+}
+#else
 void FK_CAT5(launch_imm_, FK_NX, FK_NZ, FK_NM, FK_IMM_PART)(const ImmArgs &a, hipStream_t s)
 {
     constexpr int NX = FK_NX, NZ = FK_NZ, NM = FK_NM;
@@ -254,6 +266,7 @@ void FK_CAT5(launch_imm_, FK_NX, FK_NZ, FK_NM, FK_IMM_PART)(const ImmArgs &a, hi
     else if constexpr (SET == 2) hipLaunchKernelGGL((imm_kernel<NX, NZ, NM, LAYOUT, true, 7>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((imm_kernel<NX, NZ, NM, LAYOUT, false, -1>), grid, block, 0, s, a);
 }
+#endif
 
 #if FK_IMM_PART == 0
 #define FK_IMM_DECL(k) void FK_CAT5(launch_imm_, FK_NX, FK_NZ, FK_NM, k)(const ImmArgs &, hipStream_t);

@@ -508,6 +508,7 @@ if __name__ == "__main__":
         if "r" in a.configs:      # the rolled IMM classes (banks in scratch memory): (9,4) x {2, 4, 8}, (16,8) x 2 -- VERDICT r3 next 8
             config_imm(lay, 9, 4, 2, 100_000, 20)
             config_imm(lay, 9, 3, 4, 100_000, 20)
+            config_imm(lay, 9, 4, 5, 50_000, 20)
             config_imm(lay, 9, 4, 8, 50_000, 20)
             config_imm(lay, 16, 8, 2, 50_000, 20)
         if "u" in a.configs:      # the fused linear UKF above dim_x 9 (several lanes per track; rows appear once FK_UKF_MLG is on)
