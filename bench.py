@@ -516,10 +516,15 @@ def main():
                 covs, covs_p = as_records(a_), as_records(b_)
             placement_info["probe"] = info
             if world > 1:                            # every rank probes its own GPU: a rank that fell back shows in the line
-                outcomes = [None] * world
-                dist.all_gather_object(outcomes, {"rank": rank, "method": info.get("method"), "chosen_ms": info.get("chosen_ms"),
-                                                  "error": info.get("error")})
-                placement_info["per_rank"] = outcomes
+                try:                                 # (a float pair per rank through the same collective the timing uses)
+                    mine = torch.tensor([float(info.get("chosen_ms") or -1.0), 1.0 if info.get("method") in ("probe", "cached") else 0.0],
+                                        dtype=torch.float64, device=device)
+                    allr = torch.empty((world, 2), dtype=torch.float64, device=device)
+                    dist.all_gather_into_tensor(allr, mine)
+                    placement_info["per_rank"] = [{"rank": r, "chosen_ms": round(float(allr[r, 0]), 4), "placed": bool(allr[r, 1] > 0)}
+                                                  for r in range(world)]
+                except Exception as exc:             # the measurement does not depend on it
+                    placement_info["per_rank_error"] = repr(exc)[:200]
 
     def step(k=0, ev=None, with_exchange=True):
         slot = k % 2 if (ex and with_exchange) else 0
