@@ -69,7 +69,6 @@ struct WholeShared {
     int lit_status;
 };
 
-// EU = waves per SIMD the register allocation must allow (a 1024-thread workgroup is four waves per SIMD)
 // ---- weights: eight consecutive ones per thread, straight from HBM into registers (padding: +0.0) ----
 __device__ __forceinline__ void wh_fetch(const double *wf, int j0, int Np, double (&w)[WH_ITEMS])
 {
@@ -91,8 +90,8 @@ __device__ __forceinline__ void wh_fetch(const double *wf, int j0, int Np, doubl
 
 // The whole algorithm on ONE filter: plain-prefix boundaries, the exact round where an estimate is inside the error band, the
 // literal loop for garbage.  Rounds 3 / 4 ran it as the kernel (resample_whole_kernel below: FK_WHOLE_QUICK=0); since round 5 it
-// is the rare tail of resample_whole_quick_kernel.
-// one filter, start to finish, by the whole workgroup (every barrier inside is reached by all of its threads)
+// is the rare tail of resample_whole_quick_kernel.  One filter, start to finish, by the whole workgroup (every barrier inside is
+// reached by all of its threads).
 template <bool STRATIFIED, int NT>
 __device__ __forceinline__ void wh_full_one(const WholeArgs &a, const int f_in, WholeShared<NT> &sh)
 {
@@ -305,6 +304,7 @@ __device__ __forceinline__ void wh_full_one(const WholeArgs &a, const int f_in, 
     __syncthreads();                         // (a workgroup that takes another filter: this one's window is done with)
 }
 
+// EU = waves per SIMD the register allocation must allow (a 1024-thread workgroup is four waves per SIMD)
 template <bool STRATIFIED, int NT, int EU>
 __global__ void __launch_bounds__(NT, EU)
 resample_whole_kernel(const WholeArgs a)
@@ -319,7 +319,8 @@ resample_whole_kernel(const WholeArgs a)
 // registers measured 35.1 against 36.2 us at 1000 x 8000: the latency is not the weights' alone (profiles/r05/c5/).  Here the
 // common path -- weights -> plain prefix sums -> slot boundaries from the estimates -> heads -> max-scan -> stores -- is
 // straight-line code that fits the 64 VGPRs at which TWO 1024-thread workgroups share a CU (32 waves), each filling the other's
-// stalls: 25.0 against 36.3 us on the same GPU.  A vector with an estimate inside the error band (one in ~5000 at 8000 weights
+// stalls: 25.0 against 36.3 us on the same GPU, 24.1-24.9 us once its two __syncthreads_or (three s_barrier each) were single
+// barriers.  A vector with an estimate inside the error band (one in ~5000 at 8000 weights
 // since the band is priced at the prefix sums' real depth, fk_resample_whole.hpp), a negative / NaN / huge weight, or
 // FK_WHOLE_EXACT=1 leaves through wh_full_one, inlined behind the common path's `return` and marked unlikely: the register
 // allocator spills there (128-190 bytes per lane) and nowhere in the common path (checked in the ISA: no scratch instruction in
