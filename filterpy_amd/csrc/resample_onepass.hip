@@ -252,6 +252,9 @@ __device__ double lookback_exact(const OpDesc *d, int k, bool clean, int eu, int
 // binade, the conditional truths all apply, and the exact carry-in is an integer sum: verified with exact arithmetic, no
 // approximation involved.  Anything else (a guess that missed, a crossing, a tie, the start of a vector, garbage) is a
 // miss: the chunk takes round 2's two stages unchanged.  Wave 0 only.  which = 0 / 1: hit at g / g + 1, -1: miss.
+#ifndef FK_OP_SPEC_SINGLE
+#define FK_OP_SPEC_SINGLE 1     // 0: always speculate on two binades (rounds 3 / 4; A/B build)
+#endif
 #ifndef FK_OP_SPEC_POLLS
 #define FK_OP_SPEC_POLLS 24
 #endif
@@ -784,23 +787,39 @@ resample_onepass_kernel(const OpArgs a)
             g = ulp_exp(glo);
         }
         if (guess) {                                                       // uniform
-            bool tie0 = false, tie1 = false;
+            // Round 5 (the lever DESIGN section 9 carried since round 3): where the whole guess interval lies inside ONE binade
+            // -- two chunks in three once k is past a few dozen: away from power-of-two carries -- the second candidate g + 1
+            // cannot be the binade of this chunk's adds, so its increments, their tie test and their wave scan are not formed and
+            // nothing is published at g + 1 (a successor that would have needed this chunk's sum there falls back to the
+            // two-stage path like after any other miss; every shortcut is re-verified against the exact carry either way).
+            const bool single = FK_OP_SPEC_SINGLE && __builtin_amdgcn_readfirstlane((int)(ulp_exp(((double)k + 1.0) * S * 1.04) == g)) != 0;   // uniform
+            bool tie0 = false, tie1 = single;
             double run0 = 0.0, run1 = 0.0;
-            FK_UNROLL for (int q = 0; q < OP_ITEMS; ++q) {
-                const double t0 = scale2(w8[q], -g);
-                const double x0 = t0 + 0.5, x1 = t0 * 0.5 + 0.5;           // (w / 2^(g+1) = t0 / 2: exact)
-                const double i0 = floor(x0), i1 = floor(x1);
-                tie0 = tie0 || (i0 == x0);
-                tie1 = tie1 || (i1 == x1);
-                run0 += i0;
-                run1 += i1;
-                E[q] = run0;
+            if (single) {
+                FK_UNROLL for (int q = 0; q < OP_ITEMS; ++q) {
+                    const double x0 = scale2(w8[q], -g) + 0.5;
+                    const double i0 = floor(x0);
+                    tie0 = tie0 || (i0 == x0);
+                    run0 += i0;
+                    E[q] = run0;
+                }
+            } else {
+                FK_UNROLL for (int q = 0; q < OP_ITEMS; ++q) {
+                    const double t0 = scale2(w8[q], -g);
+                    const double x0 = t0 + 0.5, x1 = t0 * 0.5 + 0.5;       // (w / 2^(g+1) = t0 / 2: exact)
+                    const double i0 = floor(x0), i1 = floor(x1);
+                    tie0 = tie0 || (i0 == x0);
+                    tie1 = tie1 || (i1 == x1);
+                    run0 += i0;
+                    run1 += i1;
+                    E[q] = run0;
+                }
             }
             // (the same loop on multiplications by 2^-g and 2^52-rounding instead of v_ldexp / v_floor was measured: four more
             // VGPRs, 32 B of scratch, 3.36 -> 3.71 ms at 125 x 8e6 -- a spill in this kernel is a vmcnt(0) behind its stores)
             const double winc0 = wave_incl_sum(run0);
-            const double tot1 = lane_bcast(wave_incl_sum(run1), 63);
-            const int tf = (__ballot(tie0) != 0 ? 1 : 0) | (__ballot(tie1) != 0 ? 2 : 0);
+            const double tot1 = single ? 0.0 : lane_bcast(wave_incl_sum(run1), 63);
+            const int tf = (__ballot(tie0) != 0 ? 1 : 0) | ((single || __ballot(tie1) != 0) ? 2 : 0);
             if (lane == 63) sh.wsum[wave] = winc0;
             if (lane == 0) {
                 sh.seg.wtot[wave] = tot1;
