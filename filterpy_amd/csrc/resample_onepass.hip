@@ -54,7 +54,10 @@ constexpr int OP_SERIAL_RUN = 256;                         // elements per seque
 constexpr int OP_MAX_TIES = 8;                             // more half-ulp ties than this in a chunk: sequential
 constexpr unsigned OP_SPIN_LIMIT = 1u << 22;
 #ifndef FK_OP_LOOKBACK
-#define FK_OP_LOOKBACK 64      // predecessors polled per look-back step (lanes of wave 0 that load a hand-off word)
+#define FK_OP_LOOKBACK 16      // predecessors polled per look-back step (lanes of wave 0 that load a hand-off word).  64 until
+                               // round 5; A/B/A in one lease (profiles/r05/c5/onepass_lookback_window.txt): 125 x 8e6 3221 / 3209 /
+                               // 3202 / 3228 us at 64 / 32 / 16 / 64, 8 x 8e6 733 / 721 / 712 / 730, 1 x 8e6 267.8 / 263.0 / 262.8 /
+                               // 267.8 -- the "look-back over-fetch" is worth 0.7-2.7 %
 #endif
 #ifndef FK_OP_SLEEP
 #define FK_OP_SLEEP 2          // s_sleep argument between two polls
