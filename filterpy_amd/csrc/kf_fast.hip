@@ -205,7 +205,12 @@ kf_fast_kernel(const KfArgs a, const double *__restrict__ pF, const double *__re
             const RecView<LAYOUT> uv(a.u + tq * N * a.nu, lr, a.nu);
             FK_UNROLL for (int c = 0; c < NUC; ++c) zd[NZ + c] = uv.load(c < a.nu ? c : a.nu - 1);   // clamped: no branch
         }
-        if (HAS_MASK) hd = pmask[tq * N + lr.blk0 + lr.tid] != 0;
+        if constexpr (HAS_MASK && EX) {
+            // (the extras twins also serve calls WITHOUT a mask -- see the launcher: pmask == NULL reads a valid dummy byte of z
+            //  and selects "present"; no branch in the time loop)
+            const uint8_t *pm = pmask ? pmask : reinterpret_cast<const uint8_t *>(pz);
+            hd = (pm[tq * N + lr.blk0 + lr.tid] != 0) | (pmask == nullptr);
+        } else if (HAS_MASK) hd = pmask[tq * N + lr.blk0 + lr.tid] != 0;
     };
     if constexpr (ZDMA) {
         dma_z(0, 0u);
@@ -449,11 +454,21 @@ int FK_CAT(launch_kf_fast_, FK_NX, FK_NZ, FK_VARIANT)(const KfArgs &a, int layou
 #define FK_GOEX(LAY, MSK)                                                                                                \
     hipLaunchKernelGGL((kf_fast_kernel<FK_NX, FK_NZ, LAY, MSK, true, (FK_FAST_SYM != 0), 0, false, false, true>), grid, block, 0, \
                        stream, a, a.F, a.Q, a.H, a.R, a.z, a.mask)
+        // Round 5: a call WITHOUT a mask runs on the masked twin where the no-mask instantiation is the worse kernel.  Without the
+        // `if (hu)` branches its three unrolled steps are one basic block, and at some shapes the scheduler interleaves them past the
+        // register file: (6,3) 512 VGPRs + 568 / 168 B of scratch against 414 / 328 and none.  Measured A/B/A/B over every shape
+        // whose twins differ statically (profiles/r05/extras/, ms NumPy order / element-major, N x 100 steps):
+        //   (6,3) 8.53 -> 4.85 / 5.85 -> 4.61    (5,4) 15.2 -> 5.96 / 11.2 -> 5.88    (6,4) 16.9 -> 5.77 / 14.4 -> 5.31
+        //   (9,4) 18.7 -> 11.4 / 11.9 -> 7.58;   within 2 % at (4,2) (4,3) (4,4) (5,2) (5,3) (6,2) (7,3); the masked twin is the
+        //   slower one at (8,4) (x 2) and (9,3) (x 1.14): the rule is per instantiation.  FK_FAST_EX_MASKED=0 / 1 forces either.
+        constexpr bool prefer_masked = (FK_NX == 5 && FK_NZ == 4) || (FK_NX == 6 && FK_NZ >= 3) || (FK_NX == 9 && FK_NZ == 4);
+        static const int ex_masked = [] { const char *v = getenv("FK_FAST_EX_MASKED"); return v ? (v[0] == '1' ? 1 : 0) : -1; }();
+        const bool msk = a.mask != nullptr || (ex_masked < 0 ? prefer_masked : ex_masked == 1);
         if (layout == LAYOUT_SOA) {
-            if (a.mask) FK_GOEX(LAYOUT_SOA, true);
+            if (msk) FK_GOEX(LAYOUT_SOA, true);
             else FK_GOEX(LAYOUT_SOA, false);
         } else {
-            if (a.mask) FK_GOEX(LAYOUT_AOS, true);
+            if (msk) FK_GOEX(LAYOUT_AOS, true);
             else FK_GOEX(LAYOUT_AOS, false);
         }
 #undef FK_GOEX

@@ -487,12 +487,18 @@ if __name__ == "__main__":
                     os.environ["FK_NO_MLG"] = "1"
                     config_kf(lay, n, m, N // 8, a.T)
                     del os.environ["FK_NO_MLG"]
-        if "e" in a.configs:      # Saver histories from the specialised kernel
-            config_extras(lay, 4, 2, 500_000, a.T)
-            config_extras(lay, 6, 3, 200_000, a.T)
-            config_extras(lay, 9, 3, 100_000, a.T)
-            config_extras(lay, 12, 3, 100_000, a.T)
-            config_extras(lay, 16, 4, 60_000, a.T)
+        if "e" in a.configs:      # Saver histories from the specialised kernel (EXTRAS_DIMS="5x3,6x4": other instantiations)
+            dims = os.environ.get("EXTRAS_DIMS")
+            if dims:
+                for nm in dims.split(","):
+                    n, m = (int(v) for v in nm.split("x"))
+                    config_extras(lay, n, m, max(20_000, 7_200_000 // (n * n)) // 1000 * 1000, a.T)
+            else:
+                config_extras(lay, 4, 2, 500_000, a.T)
+                config_extras(lay, 6, 3, 200_000, a.T)
+                config_extras(lay, 9, 3, 100_000, a.T)
+                config_extras(lay, 12, 3, 100_000, a.T)
+                config_extras(lay, 16, 4, 60_000, a.T)
         if "6" in a.configs:
             config_kf(lay, 6, 3, 300_000, a.T)
             config_kf(lay, 4, 2, 500_000, a.T)
