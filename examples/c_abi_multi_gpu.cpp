@@ -71,7 +71,10 @@ int main(int argc, char **argv)
     std::vector<int> devs(ndev);
     std::vector<ncclComm_t> comms(ndev);
     for (int d = 0; d < ndev; ++d) devs[d] = d;
+    // (progress on stderr: a communicator setup that never returns -- seen once on a one-GPU box -- is then told apart from a launch that hangs)
+    fprintf(stderr, "[c_abi_multi_gpu] %d device(s), library ok; ncclCommInitAll ...\n", ndev); fflush(stderr);
     NCCL_OK(ncclCommInitAll(comms.data(), ndev, devs.data()));
+    fprintf(stderr, "[c_abi_multi_gpu] communicators ready\n"); fflush(stderr);
 
     struct Dev { hipStream_t s; double *F, *Q, *H, *R, *z, *x, *P, *mu, *cov, *mup, *covp, *xall; int32_t *st; };
     std::vector<Dev> D(ndev);

@@ -252,7 +252,7 @@ static int run_kf_window(const fk_kf_desc *d, KfArgs &a, long cnt, void *stream)
     const bool fast_ex = want_ex && a.extras_per_step && all_out && d->model_mode == FK_MODEL_SHARED && d->nu == 0 &&
                          !d->update_first && !getenv("FK_NO_FAST_EX");
     // ... and, round 4, from the four-lane kernels' EX instantiations (dim_x >= 10, and (9,3)): the plain call without a mask
-    const bool mlg_ex = fast_ex && !a.mask && !inter && (d->n >= 10 || (d->n == 9 && d->m == 3)) && !getenv("FK_NO_MLG_EX") &&
+    const bool mlg_ex = fast_ex && !a.mask && !inter && d->n >= 9 && !getenv("FK_NO_MLG_EX") &&
                         !getenv("FK_NO_MLG");
     if (a.do_predict && a.do_update && (all_out || no_out) && (!want_ex || fast_ex) && !a.rj_diag && !getenv("FK_NO_FAST")) {
         if (mlg_ex) {
@@ -270,8 +270,10 @@ static int run_kf_window(const fk_kf_desc *d, KfArgs &a, long cnt, void *stream)
         }
         // (dim_x = 7, 8 were tried on the four-lane kernel too: 0.30 against kf_fast's 0.50 -- two rows per lane leave
         // the replicated S / x work dominant; profiles/r02/dims_7_8_ml_vs_fast.txt)
-        if (!want_ex && (d->n >= 10 || (g9 && g9[0] == 'g')) && !getenv("FK_NO_MLG")) {
-            if (inter) return fail(FK_ERR_UNSUPPORTED, "FK_KF_FLAG_COV_INTERLEAVED: dim_x >= 10 runs on the four-lane kernels, which take two arrays");
+        // round 5: (9,1), (9,2), (9,4) too -- the one-lane kernel holds 9 x 9 at 0.18-0.26 of HBM (profiles/r05/dims/); FK_ML9=m keeps it
+        const bool nine_g = d->n == 9 && (d->m != 3 ? !(g9 && g9[0] == 'm') : (g9 && g9[0] == 'g'));
+        if (!want_ex && (d->n >= 10 || nine_g) && !getenv("FK_NO_MLG")) {
+            if (inter) return fail(FK_ERR_UNSUPPORTED, "FK_KF_FLAG_COV_INTERLEAVED: dim_x >= 9 runs on the several-lane kernels, which take two arrays");
             for (const FastEntry &g : mlg_table) {
                 if (g.nx != d->n || g.nz != d->m) continue;
                 const int rc = g.fn(a, d->layout, all_out, d->model_mode, (hipStream_t)stream);

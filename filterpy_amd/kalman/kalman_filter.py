@@ -95,11 +95,11 @@ class _Core:
         # and prior record of a track side by side (FK_KF_FLAG_COV_INTERLEAVED): one write front instead of two that may
         # interfere (docs/PLACEMENT.md).  The caller gets strided views.  Where the specialised kernel does not serve the
         # call (FK_ERR_UNSUPPORTED) two plain arrays are used.
-        # Asked for only where the library takes it (kf_dispatch.cpp, run_kf_window): the specialised kernel's calls -- dim_x <= 9
-        # except (9,3), which runs on the three-lane kernel; predict -> update without a control input; any model mode up to
+        # Asked for only where the library takes it (kf_dispatch.cpp, run_kf_window): the one-lane specialised kernel's calls -- dim_x
+        # <= 8 (dim_x 9 runs on the three- / four-lane kernels); predict -> update without a control input; any model mode up to
         # dim_x 6, the shared constant model above.  (The except branch below stays as the safety net for the library's A/B
         # switches; it reports what it did.)
-        inter = bool(want_outputs and device_outputs and not extras and cov_interleave and n <= 9 and (n, m) != (9, 3)
+        inter = bool(want_outputs and device_outputs and not extras and cov_interleave and n <= 8
                      and m <= min(n, 4) and nu == 0 and not update_first and (mode == FK_MODEL_SHARED or n <= 6)
                      and 2 * N * n * n * 8 < 2 ** 32 and placement != "probe")
         # placement=None (round 5, the default): where the launch is HBM-bound and its two big streams are most of its bytes --

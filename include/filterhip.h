@@ -105,7 +105,7 @@ typedef struct fk_kf_desc {
  * physical memory, which user space cannot control (docs/PLACEMENT.md); one front has no partner to interfere with.  The
  * two histories are then strided views of cov2 (what KalmanFilterBank.batch_filter(device_outputs=True) returns).  The
  * pointers must stand in exactly that relation (FK_ERR_BAD_ARG otherwise); calls the specialised kernel does not serve
- * (dim_x >= 10, per-step extras, final-state-only) return FK_ERR_UNSUPPORTED -- use two arrays there. */
+ * (dim_x >= 9, per-step extras, final-state-only) return FK_ERR_UNSUPPORTED -- use two arrays there. */
 #define FK_KF_FLAG_COV_INTERLEAVED 2
 
 /* KalmanFilter.batch_filter (filterpy/kalman/kalman_filter.py:826-993; module twin :1664-1788)
@@ -153,8 +153,8 @@ typedef struct fk_kf_extras {
 
 /* fk_kf_batch_filter_f64 plus the histories above (ex may be NULL).  Which kernel serves the call (all are tested against
  * the same oracle): the plain call (shared constant model, predict -> update, all four outputs) runs on the specialised kernels'
- * extras instantiations -- one lane per track at dim_x <= 9, four lanes per track at dim_x 10..16 and (9,3) (the latter without
- * a mask) --; every other combination (per-track / per-step models, control input, update_first, a subset of the outputs)
+ * extras instantiations -- one lane per track at dim_x <= 8 (and at dim_x 9 with a mask), four lanes per track at dim_x 9..16
+ * without a mask --; every other combination (per-track / per-step models, control input, update_first, a subset of the outputs)
  * on the generic kernel. */
 int fk_kf_batch_filter_ex_f64(const fk_kf_desc *desc,
                               const double *F, const double *Q, const double *H, const double *R,

@@ -1046,7 +1046,7 @@ def test_interleaved_covariance_histories_equal_two_arrays_bit_for_bit(n, m, lay
         served += 1
         for a, b in zip(ref, got):
             assert np.array_equal(a, b, equal_nan=True), (n, m, layout, list(kw))
-    if n <= 6 or (layout == "soa" and (n, m) != (9, 3)):
+    if n <= 6 or (layout == "soa" and n <= 8):       # (dim_x 9 runs on the three- / four-lane kernels: two arrays only)
         assert served >= 2, served           # at least the plain and the masked call run on the specialised kernel
 
 

@@ -144,6 +144,8 @@ def config_kf(layout, n, m, N, T):
     cov = E.from_records(outs[1], layout, 1, (n, n))[:, sample]
     par = rel(cov.reshape(-1, n * n), ref[1].reshape(-1, n * n))
     emit(f"KF batch_filter ({n},{m}) N={N} {layout}", N * T, "track-steps", ms, 8 * (m + 2 * n + 2 * n * n), parity_max_rel=par)
+    if os.environ.get("KF_NO_RTS"):      # sweeps of the forward kernels only
+        return
     so = [E.alloc_records((T,), N, n, layout)] + [E.alloc_records((T,), N, n * n, layout) for _ in range(3)]
     ms = timeit(lambda: E.kf_rts(desc, dF, dQ, outs[0], outs[1], so[0], so[1], so[2], so[3], convention=0, status=st))
     assert not st.any()
@@ -234,8 +236,8 @@ def config_extras(layout, n, m, N, T):
         P.copy_(P0)
         E.kf_batch_filter_ex(desc, *mods, z, x, P, ex, means=outs[0], covs=outs[1], means_p=outs[2], covs_p=outs[3], status=st)
     nbytes = 8 * (m + 2 * n + 2 * n * n + m + n * m + 2 * m * m + 2)
-    # (dim_x >= 10 and (9,3): the four-lane kernel's EX instantiations by default; FK_NO_MLG_EX=1 -> kf_fast's extras / generic)
-    mlg = n >= 10 or (n, m) == (9, 3)
+    # (dim_x >= 9: the four-lane kernel's EX instantiations by default; FK_NO_MLG_EX=1 -> kf_fast's extras / generic)
+    mlg = n >= 9
     rows = ([(None, None, "four-lane EX")] if mlg else []) + ([("1", None, "kf_fast extras")] if n <= 9 else []) + [("1", "1", "generic kernel")]
     for no_mlg, no_fast, name in rows:
         if no_mlg:
@@ -467,6 +469,9 @@ if __name__ == "__main__":
     ap.add_argument("--N", type=int, default=100_000)
     ap.add_argument("--T", type=int, default=100)
     a = ap.parse_args()
+    if os.environ.get("FK_LIB"):      # an experimental build of the library (A/B of compile-time choices in one lease); tools only
+        from filterpy_amd import _abi
+        _abi.LIB_PATH = os.path.abspath(os.environ["FK_LIB"])
     for lay in a.layouts.split(","):
         if "3" in a.configs:
             config3(lay, a.N, a.T)
@@ -474,7 +479,11 @@ if __name__ == "__main__":
             config4(lay, a.N, a.T)
         if "7" in a.configs:
             config_generic(lay, 200_000, a.T)
-        if "a" in a.configs:      # dims served by the lean specialised instantiations
+        if "a" in a.configs and os.environ.get("KF_DIMS"):      # KF_DIMS="3x2,3x3": any instantiation, ~7.2e6 / dim_x^2 tracks
+            for nm in os.environ["KF_DIMS"].split(","):
+                n, m = (int(v) for v in nm.split("x"))
+                config_kf(lay, n, m, max(20_000, 18_000_000 // (n * n)) // 1000 * 1000, a.T)
+        elif "a" in a.configs:      # dims served by the lean specialised instantiations
             config_kf(lay, 3, 1, 2_000_000, a.T)
             config_kf(lay, 5, 2, 500_000, a.T)
             config_kf(lay, 6, 2, 400_000, a.T)
