@@ -335,3 +335,35 @@ def test_counted_waits_behind_lds_dma_requests_have_their_stores():
                 assert younger >= K, (os.path.basename(o), isa_lint.short(name), K, younger)
                 seen += 1
     assert seen >= 30, seen
+
+
+def test_no_specialised_instantiation_spills_under_a_launch_bound_of_its_own_making():
+    """Round 5 (docs/KERNEL_NOTES.md, "Every one-lane shape measured"): the element-major (3,2) / (3,3) kernels ran at 0.34 / 0.15 of
+    HBM because `FK_FAST_INST`'s occupancy target left them 80 VGPRs and the rest went to scratch -- unnoticed for three rounds,
+    since neither shape was benchmarked.  What made them visible is one line of tools/isa_lint.py, so that line is a test: no
+    kernel of the one-lane specialised family (kf_fast.hip) whose register budget is a launch bound of OURS (fewer than the
+    256 VGPRs of two waves per SIMD) may carry more than a few words of scratch in the call shape the tables serve -- plain or
+    masked, all four outputs, shared model.  (At 256 / 512 VGPRs scratch is the kernel's size, not the bound's: (6,3), (9,x) --
+    listed in docs/KERNEL_NOTES.md, not asserted here.)"""
+    import glob
+    import re
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import isa_lint
+    objs = sorted(glob.glob(os.path.join(ROOT, "filterpy_amd", "csrc", "build", "inst_fast_*.o")))
+    if not objs:
+        pytest.skip("library not built")
+    seen, bad = 0, []
+    with tempfile.TemporaryDirectory() as tmp:
+        for obj in objs:
+            for name, v in isa_lint.kernels(isa_lint.device_elf(obj, tmp)).items():
+                m = re.search(r"kf_fast_kernel<([\d,]+)>", isa_lint.short(name))
+                if not m:
+                    continue
+                t = [int(x) for x in m.group(1).split(",")]      # NX, NZ, LAYOUT, HAS_MASK, OUTS, SYM, MMODE, UF, CTRL, EX, IL
+                if t[4] == 1 and t[6] == 0 and t[7] == 0 and t[8] == 0 and t[9] == 0:
+                    seen += 1
+                    if v["vgpr"] < 256 and v["scratch"] > 64:
+                        bad.append((tuple(t), v["vgpr"], v["scratch"]))
+    assert seen >= 120, seen                                      # 30 shapes x 2 record orders x {plain, masked} (+ the IL twins)
+    assert not bad, bad
