@@ -24,6 +24,11 @@
 #error "compile with -DFK_NX=<dim_x>"
 #endif
 
+// occupancy bound at dim_x 8: three waves per SIMD leave the NumPy-order kernel 168 VGPRs + 204 B of scratch, two waves 234 and none --
+// measured the same (14.45 vs 14.48-14.56 ms at N = 2.81e5 x 100, A/B/A/B in one lease, profiles/r05/dims/rmlg8_waves_ab.jsonl): kept at 3
+#ifndef FK_RMLG8_WAVES
+#define FK_RMLG8_WAVES 3
+#endif
 #define FK_RMLG_CAT_(a, b) a##b
 #define FK_RMLG_CAT(a, b) FK_RMLG_CAT_(a, b)
 
@@ -58,7 +63,7 @@ __device__ __forceinline__ void store_rows_aos(const double (&M)[R][NX], const u
 }
 
 template <int NX, int LAYOUT>
-__global__ void __launch_bounds__(BLOCK, (NX <= 8 ? 3 : NX <= 9 ? 2 : 1))
+__global__ void __launch_bounds__(BLOCK, (NX <= 8 ? FK_RMLG8_WAVES : NX <= 9 ? 2 : 1))
 rts_mlg_kernel(const RtsArgs a)
 {
     constexpr int R = (NX + 3) / 4;
