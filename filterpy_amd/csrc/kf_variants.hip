@@ -28,8 +28,13 @@ struct SteadyArgs {
 // F (NX x NX), H (NZ x NX) and the shared K (NX x NZ) sit in LDS; a per-track K in registers.
 // EXACT (n == NX, m == NZ): the x / z / y records move without per-element guards -- in NumPy order (AOS) as 16-byte
 // pairs, half as many memory operations (steady-state AOS measured 0.24-0.38 of HBM with the guarded 8-byte accesses).
-template <int NX, int NZ, int LAYOUT, bool EXACT>
-__global__ void __launch_bounds__(BLOCK)
+#ifndef FK_STEADY_KLDS_WAVES
+#define FK_STEADY_KLDS_WAVES 3
+#endif
+// KREG = false (round 5, the padded classes (12,8) / (16,8) with a shared gain): K is read from LDS where it is used instead of
+// being held in 2 NX NZ registers per lane -- with unrolled loops that is the difference between ~120 and ~380 VGPRs.
+template <int NX, int NZ, int LAYOUT, bool EXACT, bool KREG = true, int WAVES = (KREG ? 1 : FK_STEADY_KLDS_WAVES)>
+__global__ void __launch_bounds__(BLOCK, WAVES)
 steady_kernel(const SteadyArgs a)
 {
     constexpr int NU = 4;
@@ -55,13 +60,15 @@ steady_kernel(const SteadyArgs a)
     const Lane ln{blk0, COOP ? min(threadIdx.x, last_row) : threadIdx.x, N};
     const unsigned lane = threadIdx.x & 63u, wrow = (threadIdx.x >> 6) * 64u;
     double *tile = s_tile + (COOP ? (threadIdx.x >> 6) * 64 * (NX | 1) : 0);
-    double x[NX], K[NX * NZ];
+    double x[NX], K[KREG ? NX * NZ : 1];
     if constexpr (COOP) wave_load_aos<NX>(x, a.x + blk0 * NX, wrow, tile, lane, last_row);
     else load_rec<NX, 1, LAYOUT, EXACT>(x, a.x, ln, n, 1, 0.0);
-    if (a.k_per_track) {
-        load_rec<NX, NZ, LAYOUT, false>(K, a.K, ln, n, m, 0.0);
-    } else {
-        FK_UNROLL for (int e = 0; e < NX * NZ; ++e) K[e] = sK[e];
+    if constexpr (KREG) {
+        if (a.k_per_track) {
+            load_rec<NX, NZ, LAYOUT, false>(K, a.K, ln, n, m, 0.0);
+        } else {
+            FK_UNROLL for (int e = 0; e < NX * NZ; ++e) K[e] = sK[e];
+        }
     }
     for (long t = 0; t < a.T; ++t) {
         if (a.F) {      // predict_steadystate: x = F x (+ B u)
@@ -99,8 +106,8 @@ steady_kernel(const SteadyArgs a)
             }
             if (has_z) {
                 FK_UNROLL for (int i = 0; i < NX; ++i) {
-                    double acc = K[i * NZ] * y[0];
-                    FK_UNROLL for (int k = 1; k < NZ; ++k) acc = fma(K[i * NZ + k], y[k], acc);
+                    double acc = (KREG ? K[KREG ? i * NZ : 0] : sK[i * NZ]) * y[0];
+                    FK_UNROLL for (int k = 1; k < NZ; ++k) acc = fma(KREG ? K[KREG ? i * NZ + k : 0] : sK[i * NZ + k], y[k], acc);
                     x[i] += acc;
                 }
             }
@@ -365,7 +372,30 @@ int fk_kf_steadystate_f64(const fk_kf_desc *d, const double *F, const double *H,
     a.n = d->n; a.m = d->m; a.nu = d->nu; a.k_per_track = d->model_mode == FK_MODEL_PER_TRACK && K != nullptr;
     const dim3 grid((unsigned)((a.N + BLOCK - 1) / BLOCK)), block(BLOCK);
     hipStream_t s = (hipStream_t)stream;
-    if (d->n > 9 || d->m > 4) return steady_big_launch(a, d->layout, s);          // padded classes (12,8), (16,8): rolled unit
+    if (d->n > 9 || d->m > 4) {
+        // the padded classes (12,8), (16,8).  Round 4 ran them in the rolled unit (x and K in scratch: 0.12 / 0.08 of HBM at (16,8));
+        // round 5: unrolled here -- only x moves, 512 multiply-adds per step at (16,8) -- with a shared gain read from LDS (KREG =
+        // false), a per-track gain in registers.  FK_STEADY_ROLLED=1 keeps the rolled unit (A/B).
+        static const bool rolled = [] { const char *v = getenv("FK_STEADY_ROLLED"); return v && v[0] == '1'; }();
+        if (rolled) return steady_big_launch(a, d->layout, s);
+#define CALLB(NXV)                                                                                                           \
+        if (d->n == NXV && d->m == 8 && !a.k_per_track) {       /* the class's own shape: unguarded records, NumPy order through the LDS tiles */ \
+            if (d->layout == FK_LAYOUT_SOA) hipLaunchKernelGGL((steady_kernel<NXV, 8, LAYOUT_SOA, true, false>), grid, block, 0, s, a); \
+            else hipLaunchKernelGGL((steady_kernel<NXV, 8, LAYOUT_AOS, true, false>), grid, block, 0, s, a);                            \
+        } else if (a.k_per_track) {                                                                                                     \
+            if (d->layout == FK_LAYOUT_SOA) hipLaunchKernelGGL((steady_kernel<NXV, 8, LAYOUT_SOA, false, true>), grid, block, 0, s, a); \
+            else hipLaunchKernelGGL((steady_kernel<NXV, 8, LAYOUT_AOS, false, true>), grid, block, 0, s, a);                            \
+        } else if (d->layout == FK_LAYOUT_SOA) hipLaunchKernelGGL((steady_kernel<NXV, 8, LAYOUT_SOA, false, false>), grid, block, 0, s, a); \
+        else if (aos_waves == 3) hipLaunchKernelGGL((steady_kernel<NXV, 8, LAYOUT_AOS, false, false, 3>), grid, block, 0, s, a);          \
+        else hipLaunchKernelGGL((steady_kernel<NXV, 8, LAYOUT_AOS, false, false, 1>), grid, block, 0, s, a)
+        // (the guarded NumPy-order records of the padded class are what costs registers: 512 VGPRs + 724 B of scratch at one wave per
+        // SIMD, 168 + 2260 B at three; FK_STEADY_AOS_WAVES=1 / 3 picks, A/B in profiles/r05/dims/steady_big.jsonl)
+        static const int aos_waves = [] { const char *v = getenv("FK_STEADY_AOS_WAVES"); return v && v[0] == '3' ? 3 : 1; }();
+        if (d->n <= 12) { CALLB(12); }
+        else { CALLB(16); }
+#undef CALLB
+        return check_launch("steady_kernel");
+    }
 #define CALL(NXV, NZV)                                                                                      \
     if (d->n == NXV && d->m == NZV) {                                                                                    \
         if (d->layout == FK_LAYOUT_SOA) hipLaunchKernelGGL((steady_kernel<NXV, NZV, LAYOUT_SOA, true>), grid, block, 0, s, a); \

@@ -529,6 +529,10 @@ if __name__ == "__main__":
         if "u" in a.configs:      # the fused linear UKF above dim_x 9 (several lanes per track; rows appear once FK_UKF_MLG is on)
             for (n, m, N) in ((10, 2, 100_000), (12, 3, 100_000), (14, 4, 80_000), (16, 4, 60_000), (16, 8, 60_000)):
                 config_ukf(lay, n, m, N, 50)
+        if "S" in a.configs:      # STEADY_DIMS="16x8,14x6": the steady-state filter at any shape, 8e6 / dim_x tracks
+            for nm in os.environ.get("STEADY_DIMS", "16x8").split(","):
+                n, m = (int(v) for v in nm.split("x"))
+                config_steady(lay, n, m, 8_000_000 // n // 1000 * 1000, a.T)
         if "s" in a.configs:      # steady-state / IMM above (9,4) (round 4's padded classes)
             config_steady(lay, 16, 8, 500_000, a.T)
     if "5" in a.configs:
