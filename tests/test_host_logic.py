@@ -367,3 +367,31 @@ def test_no_specialised_instantiation_spills_under_a_launch_bound_of_its_own_mak
                         bad.append((tuple(t), v["vgpr"], v["scratch"]))
     assert seen >= 120, seen                                      # 30 shapes x 2 record orders x {plain, masked} (+ the IL twins)
     assert not bad, bad
+
+
+def test_two_stage_build_lists_are_consistent():
+    """csrc/Makefile links the library twice in a cold build: stage 1 from every object except the slow unrolled IMM classes, with
+    rolled stand-ins (build/quick/) in their place -- a complete library half-way through --, stage 2 as shipped.  The lists
+    the two link lines are made of: every slow object has exactly one stand-in of the same name, no object is linked twice, and
+    the two link lines differ in nothing else."""
+    import subprocess
+    csrc = os.path.join(ROOT, "filterpy_amd", "csrc")
+    db = subprocess.run(["make", "-C", csrc, "-pnq"], capture_output=True, text=True).stdout
+
+    def var(name):
+        for line in db.splitlines():
+            if line.startswith(name + " := ") or line.startswith(name + " = "):
+                return line.split("=", 1)[1].split()
+        raise AssertionError(name + " not in the Makefile's database")
+    base, slow, quick, objs = var("BASE_OBJS"), var("SLOW_OBJS"), var("QUICK_OBJS"), var("OBJS")
+    assert len(set(objs)) == len(objs) and set(objs) == set(base) | set(slow) and not set(base) & set(slow)
+    assert sorted(q.replace("build/quick/", "build/") for q in quick) == sorted(slow) and len(slow) % 8 == 0
+    # the slow classes are exactly the ones built with the general kernel only (all eight parts of each)
+    classes = sorted({o.rsplit("_p", 1)[0] for o in slow})
+    assert all(sum(o.startswith(c + "_p") for o in slow) == 8 for c in classes)
+    # where the shipped library and the stage stamp both exist, the library is stage 2's (stage 1 dates its own before the stamp)
+    lib, stamp = os.path.join(ROOT, "filterpy_amd", "libfilterhip.so"), os.path.join(csrc, "build", "stage1.stamp")
+    if os.path.exists(lib) and os.path.exists(stamp) and os.path.getmtime(lib) < os.path.getmtime(stamp):
+        import warnings
+        warnings.warn("filterpy_amd/libfilterhip.so is a STAGE 1 library (rolled stand-ins for the slow IMM classes): the build "
+                      "was cut short; `make -C filterpy_amd/csrc -j` finishes it")
