@@ -67,15 +67,17 @@ def main():
     if args.only:
         gens = [g for g in gens if g in set(args.only.split(","))]
     env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1", MPLBACKEND="Agg", FILTERPY_REFERENCE=args.reference,
-               OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1")
+               OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1",
+               PYTHONPATH=args.reference + (os.pathsep + os.environ["PYTHONPATH"] if os.environ.get("PYTHONPATH") else ""))
     rows, failed = [], False
     with tempfile.TemporaryDirectory(prefix="fk_goldens_") as tmp:
         tdir = os.path.join(tmp, "tests")
         os.makedirs(os.path.join(tdir, "golden"))
         for p in glob.glob(os.path.join(ROOT, "tests", "*.py")):          # helper modules the generators import (ukf_hook_model, ...)
             shutil.copy(p, tdir)
-        for p in glob.glob(os.path.join(GOLD, "*.py")):
-            shutil.copy(p, os.path.join(tdir, "golden"))
+        for p in glob.glob(os.path.join(GOLD, "*")):                      # the generators, and the committed fixtures some of them
+            if os.path.isfile(p):                                         # read as INPUT (make_conditioning.py: ukf_merwe.npz)
+                shutil.copy(p, os.path.join(tdir, "golden"))
         for g in gens:
             before = {f: os.path.getmtime(os.path.join(tdir, "golden", f)) for f in os.listdir(os.path.join(tdir, "golden"))}
             t0 = time.time()
