@@ -1,0 +1,395 @@
+"""The drop-in surface against the LIVE reference, on the CPU: filterpy_amd.kalman.KalmanFilter / KalmanFilterBank and the module
+functions driven through seeded random call sequences side by side with filterpy's own objects, with the kernels replaced by
+CPU stand-ins that read their operands exactly as include/filterhip.h lays them out (tests/fake_kf_engine.py; arithmetic: the
+oracle).  What is under test is everything ABOVE the C ABI -- names, argument meaning, accepted shapes, scalar / list / column
+forms, attribute side effects after every call, return shapes, exceptions -- i.e. SURVEY section 8(b)'s Python boundary.
+Runs where the reference checkout exists (the build container); the same comparisons through the real kernels, on the frozen
+cases, are tests/test_gpu_api.py."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import fake_kf_engine
+
+REF = os.environ.get("FILTERPY_REFERENCE", "/root/reference")
+pytestmark = [pytest.mark.filterwarnings("ignore::DeprecationWarning"), pytest.mark.filterwarnings("ignore::RuntimeWarning")]
+ATTRS = ("x", "P", "x_prior", "P_prior", "x_post", "P_post", "K", "y", "S", "SI", "z")
+
+
+@pytest.fixture(scope="module")
+def ref():
+    if not os.path.isdir(os.path.join(REF, "filterpy")):
+        pytest.skip("no reference checkout here")
+    os.environ.setdefault("MPLBACKEND", "Agg")
+    before = set(sys.modules)
+    sys.path.insert(0, REF)
+    old_flag, sys.dont_write_bytecode = sys.dont_write_bytecode, True
+    try:
+        import filterpy.kalman as K
+        import filterpy.kalman.kalman_filter as KM
+        import filterpy.common as C
+        yield type("Ref", (), dict(K=K, KM=KM, C=C))
+    finally:
+        sys.dont_write_bytecode = old_flag
+        sys.path.remove(REF)
+        for name in set(sys.modules) - before:
+            if name == "filterpy" or name.startswith("filterpy."):
+                del sys.modules[name]
+
+
+def spd(rs, k, scale=1.0):
+    a = rs.randn(k, k)
+    return scale * (a @ a.T / k + 0.5 * np.eye(k))
+
+
+def stable_F(rs, n):
+    a = rs.randn(n, n)
+    return 0.95 * a / max(1.0, np.max(np.abs(np.linalg.eigvals(a))))
+
+
+def same(a, b, what, tol=1e-11):
+    """same kind of object, same shape, same values (None entries -- the z of a skipped update -- compared as such)"""
+    if a is None or b is None:
+        assert a is None and b is None, what
+        return
+    a_, b_ = np.asarray(a), np.asarray(b)
+    assert a_.shape == b_.shape, (what, a_.shape, b_.shape)
+    if a_.dtype == object or b_.dtype == object:
+        assert all((p is None) == (q is None) and (p is None or abs(float(p) - float(q)) <= tol * max(1.0, abs(float(q))))
+                   for p, q in zip(a_.ravel(), b_.ravel())), what
+        return
+    a_, b_ = a_.astype(float), b_.astype(float)
+    scale = max(1.0, float(np.max(np.abs(b_)))) if b_.size else 1.0
+    assert np.all(np.isfinite(a_) == np.isfinite(b_)), what
+    assert float(np.max(np.abs(np.nan_to_num(a_ - b_)))) <= tol * scale if a_.size else True, (what, a_, b_)
+
+
+def both(mine, theirs, fn, what):
+    """run fn on both objects: same exception type or same result"""
+    res, exc = [], []
+    for obj in (theirs, mine):
+        try:
+            res.append(fn(obj))
+            exc.append(None)
+        except (ValueError, IndexError, TypeError, AssertionError, np.linalg.LinAlgError) as e:
+            res.append(None)
+            exc.append(type(e))
+    assert (exc[0] is None) == (exc[1] is None), (what, exc)
+    if exc[0] is not None:
+        # the reference's checks are asserts / whatever NumPy raises first; ours are ValueErrors: both must REFUSE
+        return None, None, True
+    return res[1], res[0], False
+
+
+def compare_state(mine, theirs, what):
+    for k in ATTRS:
+        same(getattr(mine, k), getattr(theirs, k), (what, k))
+    for k in ("log_likelihood", "likelihood", "mahalanobis"):      # (lazily evaluated: scipy refuses an S that is not PSD, in both)
+        a, b, refused = both(mine, theirs, lambda kf: getattr(kf, k), (what, k))
+        if not refused:
+            same(a, b, (what, k), tol=1e-9)
+
+
+def make_pair(ref, kfm, rs, n, m, nu, column):
+    pair = []
+    x0 = rs.randn(n, 1) if column else rs.randn(n)
+    P0, F, Q, H, R = spd(rs, n, 3.0), stable_F(rs, n), spd(rs, n, 0.05), rs.randn(m, n), spd(rs, m, 0.5)
+    B = rs.randn(n, nu) if nu else None
+    Mx = 0.05 * rs.randn(n, m)
+    for cls in (ref.K.KalmanFilter, kfm.KalmanFilter):
+        kf = cls(dim_x=n, dim_z=m, dim_u=nu)
+        kf.x, kf.P, kf.F, kf.Q, kf.H, kf.R, kf.M = x0.copy(), P0.copy(), F.copy(), Q.copy(), H.copy(), R.copy(), Mx.copy()
+        if nu:
+            kf.B = B.copy()
+        pair.append(kf)
+    return pair[1], pair[0]
+
+
+def z_forms(rs, m, column):
+    """a measurement in one of the forms callers use (kalman_filter.py:527-529, helpers.py:324-342)"""
+    z = rs.randn(m)
+    forms = [z, z.reshape(m, 1), list(z)]
+    if m == 1:
+        forms += [float(z[0]), [float(z[0])]]
+    if not column:
+        forms.append(z.reshape(1, m) if m > 1 else z)
+    return forms[rs.randint(len(forms))]
+
+
+OPS = ("predict", "predict_args", "update", "update_args", "update_none", "batch", "batch_lists", "batch_update_first", "rts",
+       "get_prediction", "get_update", "residual_of", "measurement_of_state", "steadystate", "correlated", "sequential", "alpha",
+       "log_likelihood_of", "bad_z")
+
+
+@pytest.mark.parametrize("seed", range(120))
+def test_random_call_sequences(ref, monkeypatch, seed):
+    import filterpy_amd.kalman.kalman_filter as kfm
+    fake_kf_engine.install(monkeypatch)
+    rs = np.random.RandomState(4000 + seed)
+    n = int(rs.choice([1, 2, 3, 4, 6, 9, 12, 16]))
+    m = int(rs.randint(1, min(n, 8) + 1))
+    nu = int(rs.choice([0, 0, 1, 2]))
+    column = bool(rs.randint(2))
+    mine, theirs = make_pair(ref, kfm, rs, n, m, nu, column)
+    compare_state(mine, theirs, "fresh")
+    for step in range(14):
+        op = OPS[rs.randint(len(OPS))]
+        what = (seed, step, op, n, m, nu, column)
+        if op == "predict":
+            u = rs.randn(nu) if (nu and rs.randint(2)) else None
+            _, _, refused = both(mine, theirs, lambda kf: kf.predict(u=None if u is None else (u.reshape(nu, 1) if column else u)), what)
+        elif op == "predict_args":
+            Fo, Qo = stable_F(rs, n), [None, 0.03, spd(rs, n, 0.02)][rs.randint(3)]
+            _, _, refused = both(mine, theirs, lambda kf: kf.predict(F=Fo, Q=Qo), what)
+        elif op == "update":
+            z = z_forms(rs, m, column)
+            _, _, refused = both(mine, theirs, lambda kf: kf.update(z), what)
+        elif op == "update_args":
+            z = rs.randn(m, 1) if column else rs.randn(m)
+            Ro, Ho = [None, 0.7, spd(rs, m)][rs.randint(3)], [None, rs.randn(m, n)][rs.randint(2)]
+            _, _, refused = both(mine, theirs, lambda kf: kf.update(z, R=Ro, H=Ho), what)
+        elif op == "update_none":
+            _, _, refused = both(mine, theirs, lambda kf: kf.update(None), what)
+        elif op in ("batch", "batch_lists", "batch_update_first"):
+            T = int(rs.randint(1, 7))
+            zs = [rs.randn(m, 1) if column else rs.randn(m) for _ in range(T)]
+            # (with B set the reference needs `us` too: its default u = 0 makes dot(B, u) an (n, dim_u) block of zeros that
+            #  broadcasts a 1-D state to (n, n) -- kalman_filter.py:934-935, :472)
+            kw = dict(us=[rs.randn(nu, 1) if column else rs.randn(nu) for _ in range(T)]) if nu else {}
+            if op == "batch_lists":
+                kw = dict(Fs=[stable_F(rs, n) for _ in range(T)], Qs=[spd(rs, n, 0.03) for _ in range(T)],
+                          Hs=[rs.randn(m, n) for _ in range(T)], Rs=[spd(rs, m, 0.4) for _ in range(T)])
+                if nu:
+                    kw.update(Bs=[rs.randn(n, nu) for _ in range(T)], us=[rs.randn(nu, 1) if column else rs.randn(nu) for _ in range(T)])
+            if op == "batch_update_first":
+                kw["update_first"] = True
+            a, b, refused = both(mine, theirs, lambda kf: kf.batch_filter(list(zs), **kw), what)
+            if not refused:
+                for g, w, key in zip(a, b, ("means", "covs", "means_p", "covs_p")):
+                    same(g, w, (what, key))
+        elif op == "rts":
+            T = int(rs.randint(2, 6))
+            zs = [rs.randn(m, 1) if column else rs.randn(m) for _ in range(T)]
+            kw = dict(us=[rs.randn(nu, 1) if column else rs.randn(nu) for _ in range(T)]) if nu else {}
+            a, b, refused = both(mine, theirs, lambda kf: kf.rts_smoother(*kf.batch_filter(list(zs), **kw)[:2]), what)
+            if not refused:
+                for g, w, key in zip(a, b, ("x", "P", "K", "Pp")):
+                    same(g, w, (what, key), tol=1e-9)
+        elif op == "get_prediction":
+            a, b, refused = both(mine, theirs, lambda kf: kf.get_prediction(), what)
+            if not refused:
+                same(a[0], b[0], (what, "x"))
+                same(a[1], b[1], (what, "P"))
+        elif op == "get_update":
+            z = rs.randn(m, 1) if column else rs.randn(m)
+            a, b, refused = both(mine, theirs, lambda kf: kf.get_update(z), what)
+            if not refused:
+                same(a[0], b[0], (what, "x"))
+                same(a[1], b[1], (what, "P"))
+        elif op == "residual_of":
+            z = rs.randn(m, 1) if column else rs.randn(m)
+            a, b, refused = both(mine, theirs, lambda kf: kf.residual_of(z), what)
+            if not refused:
+                same(a, b, what)
+        elif op == "measurement_of_state":
+            xx = rs.randn(n, 1) if column else rs.randn(n)
+            a, b, refused = both(mine, theirs, lambda kf: kf.measurement_of_state(xx), what)
+            if not refused:
+                same(a, b, what)
+        elif op == "steadystate":
+            z = rs.randn(m, 1) if column else rs.randn(m)
+            # (with B set the default u = 0 broadcasts the reference's state to (n, dim_u), kalman_filter.py:589: u is passed)
+            u = (rs.randn(nu, 1) if column else rs.randn(nu)) if nu else 0
+
+            def run(kf):
+                kf.predict_steadystate(u=u)
+                kf.update_steadystate(z)
+            _, _, refused = both(mine, theirs, run, what)
+        elif op == "correlated":
+            z = rs.randn(m, 1) if column else rs.randn(m)
+            _, _, refused = both(mine, theirs, lambda kf: kf.update_correlated(z), what)
+        elif op == "sequential":
+            if not column:               # the reference's update_sequential needs a column state (kalman_filter.py:802-811)
+                continue
+            start = int(rs.randint(m))
+            length = int(rs.randint(1, m - start + 1))
+            z_i = rs.randn(length)
+            _, _, refused = both(mine, theirs, lambda kf: kf.update_sequential(start, z_i if length > 1 else float(z_i[0])), what)
+        elif op == "alpha":
+            a = float(1.0 + 0.05 * rs.rand())
+
+            def seta(kf):
+                kf.alpha = a
+            both(mine, theirs, seta, what)
+            same(mine.alpha, theirs.alpha, what)
+            refused = False
+        elif op == "log_likelihood_of":
+            z = rs.randn(m, 1) if column else rs.randn(m)
+            a, b, refused = both(mine, theirs, lambda kf: kf.log_likelihood_of(z), what)
+            if not refused:
+                same(a, b, what, tol=1e-9)
+        else:   # bad_z: one element too many -- both must refuse and stay as they were
+            z = rs.randn(m + 1)
+            _, _, refused = both(mine, theirs, lambda kf: kf.update(z), what)
+            if not refused:              # (m + 1 values that the reference happens to take: then so must we, identically)
+                pass
+        if not refused:
+            compare_state(mine, theirs, what)
+        else:
+            # a refused call may leave the reference half-updated (it checks late); restart both from a common state
+            mine, theirs = make_pair(ref, kfm, rs, n, m, nu, column)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_scalar_attributes_missing_measurements_and_saver(ref, monkeypatch, seed):
+    """the quirks of the reference's attribute handling -- a scalar R / Q ATTRIBUTE is taken raw by predict() / update()
+    (kalman_filter.py:478, :540, :556) but becomes eye * value through batch_filter's kwargs (:944-947, :467-468, :524-525) --,
+    batch_filter with None measurements (object array, column state) and with a Saver attached (helpers.py:121-152)"""
+    import filterpy_amd.kalman.kalman_filter as kfm
+    from filterpy_amd.common import Saver
+    fake_kf_engine.install(monkeypatch)
+    rs = np.random.RandomState(9000 + seed)
+    n = int(rs.choice([1, 2, 4, 6, 9]))
+    m = int(rs.randint(1, min(n, 4) + 1))
+    mine, theirs = make_pair(ref, kfm, rs, n, m, 0, True)
+    r, q = float(0.5 + rs.rand()), float(0.01 + 0.1 * rs.rand())
+    for kf in (mine, theirs):
+        kf.R, kf.Q = r, q
+    what = (seed, n, m)
+    both(mine, theirs, lambda kf: kf.predict(), what)
+    compare_state(mine, theirs, (what, "predict, scalar Q attribute"))
+    z = rs.randn(m, 1)
+    _, _, refused = both(mine, theirs, lambda kf: kf.update(z), what)
+    if not refused:
+        compare_state(mine, theirs, (what, "update, scalar R attribute"))
+    T = 9
+    zs = np.empty(T, dtype=object)
+    for t in range(T):
+        zs[t] = None if t in (2, 3, T - 1) else rs.randn(m, 1)
+    savers = []
+
+    def run(kf):
+        s = (Saver if kf is mine else ref.C.Saver)(kf)
+        savers.append(s)
+        return kf.batch_filter(zs, saver=s, update_first=bool(seed % 2))
+    a, b, refused = both(mine, theirs, run, what)
+    assert not refused
+    for g, w, key in zip(a, b, ("means", "covs", "means_p", "covs_p")):
+        same(g, w, (what, key))
+    compare_state(mine, theirs, (what, "after batch_filter"))
+    s_theirs, s_mine = savers
+    for key in ("x", "P", "x_prior", "P_prior", "x_post", "P_post", "K", "y", "S", "SI", "z"):
+        assert len(s_mine[key]) == len(s_theirs[key]) == T
+        for t in range(T):
+            same(s_mine[key][t], s_theirs[key][t], (what, "saver", key, t))
+    for key in ("log_likelihood", "mahalanobis"):
+        same(np.array(s_mine[key], dtype=float), np.array(s_theirs[key], dtype=float), (what, "saver", key), tol=1e-9)
+
+
+@pytest.mark.parametrize("seed", range(30))
+def test_module_functions(ref, monkeypatch, seed):
+    """the stateless twins (kalman_filter.py:1401-1508, :1571-1621, :1664-1788, :1792-1858, :1511-1568, :1624-1660) incl. the
+    univariate scalar forms"""
+    import filterpy_amd.kalman.kalman_filter as kfm
+    fake_kf_engine.install(monkeypatch)
+    rs = np.random.RandomState(12000 + seed)
+    n = int(rs.choice([1, 2, 3, 6, 9, 14]))
+    m = int(rs.randint(1, min(n, 8) + 1))
+    what = (seed, n, m)
+    x, P = rs.randn(n), spd(rs, n, 2.0)
+    F, Q, H, R = stable_F(rs, n), spd(rs, n, 0.05), rs.randn(m, n), spd(rs, m, 0.5)
+    z = rs.randn(m)
+    for alpha in (1.0, 1.02):
+        a, b = kfm.predict(x, P, F, Q, alpha=alpha), ref.KM.predict(x, P, F, Q, alpha=alpha)
+        same(a[0], b[0], (what, "predict x"))
+        same(a[1], b[1], (what, "predict P"))
+    a, b = kfm.update(x, P, z, R, H, return_all=True), ref.KM.update(x, P, z, R, H, return_all=True)
+    for g, w, key in zip(a, b, ("x", "P", "y", "K", "S", "log_likelihood")):
+        same(g, w, (what, "update", key), tol=1e-9)
+    a, b = kfm.update(x, P, z, R, H), ref.KM.update(x, P, z, R, H)
+    same(a[0], b[0], (what, "update x"))
+    same(a[1], b[1], (what, "update P"))
+    if n == 1:          # the univariate forms: python scalars in, scalars out (kalman_filter.py:1440-1470, :1604-1606)
+        a, b = kfm.predict(1.5, 2.0, 0.9, 0.1), ref.KM.predict(1.5, 2.0, 0.9, 0.1)
+        same(a[0], b[0], (what, "scalar predict x"))
+        same(a[1], b[1], (what, "scalar predict P"))
+        # (update: NumPy scalars -- the reference reads x.ndim, a python float has none, kalman_filter.py:1474)
+        a, b = kfm.update(np.float64(1.5), 2.0, 1.1, 0.5), ref.KM.update(np.float64(1.5), 2.0, 1.1, 0.5)
+        same(a[0], b[0], (what, "scalar update x"))
+        same(a[1], b[1], (what, "scalar update P"))
+    T = 6
+    zs = [rs.randn(m) for _ in range(T)]
+    Fs, Qs = [stable_F(rs, n) for _ in range(T)], [spd(rs, n, 0.04) for _ in range(T)]
+    Hs, Rs = [rs.randn(m, n) for _ in range(T)], [spd(rs, m, 0.4) for _ in range(T)]
+    for uf in (False, True):
+        a = kfm.batch_filter(x, P, zs, Fs, Qs, Hs, Rs, update_first=uf)
+        b = ref.KM.batch_filter(x, P, zs, Fs, Qs, Hs, Rs, update_first=uf)
+        for g, w, key in zip(a, b, ("means", "covs", "means_p", "covs_p")):
+            same(g, w, (what, "batch_filter", uf, key))
+    a, b = kfm.rts_smoother(a[0], a[1], Fs, Qs), ref.KM.rts_smoother(b[0], b[1], Fs, Qs)
+    for g, w, key in zip(a, b, ("x", "P", "K", "Pp")):
+        same(g, w, (what, "rts_smoother", key), tol=1e-9)
+    K = rs.randn(n, m) * 0.1
+    same(kfm.update_steadystate(x, z, K, H), ref.KM.update_steadystate(x, z, K, H), (what, "update_steadystate"))
+    same(kfm.predict_steadystate(x, F), ref.KM.predict_steadystate(x, F), (what, "predict_steadystate"))
+
+
+@pytest.mark.parametrize("layout", ["soa", "aos"])
+@pytest.mark.parametrize("seed", range(10))
+def test_bank_equals_n_reference_filters(ref, monkeypatch, seed, layout):
+    """KalmanFilterBank (shared or per-track models, both record layouts, NaN rows / masks as missing measurements) against N
+    reference filters stepped one by one: the marshalling of banks into records, model modes and masks"""
+    import filterpy_amd.kalman.kalman_filter as kfm
+    fake_kf_engine.install(monkeypatch)
+    rs = np.random.RandomState(15000 + seed)
+    n = int(rs.choice([2, 3, 4, 6, 9, 11]))
+    m = int(rs.randint(1, min(n, 5) + 1))
+    N, T = int(rs.randint(1, 6)), 7
+    per_track = bool(seed % 2)
+    what = (seed, layout, n, m, N, per_track)
+    x0, P0 = rs.randn(N, n), np.array([spd(rs, n, 2.0) for _ in range(N)])
+    if per_track:
+        F, Q = np.array([stable_F(rs, n) for _ in range(N)]), np.array([spd(rs, n, 0.05) for _ in range(N)])
+        H, R = rs.randn(N, m, n), np.array([spd(rs, m, 0.5) for _ in range(N)])
+    else:
+        F, Q, H, R = stable_F(rs, n), spd(rs, n, 0.05), rs.randn(m, n), spd(rs, m, 0.5)
+    bank = kfm.KalmanFilterBank(n, m, N, layout=layout)
+    bank.x, bank.P, bank.F, bank.Q, bank.H, bank.R = x0.copy(), P0.copy(), F, Q, H, R
+    bank.alpha = 1.01
+    zs = rs.randn(T, N, m)
+    zs[2, 0] = np.nan                                              # a missing measurement for one track
+    if N > 1:
+        zs[4, N - 1] = np.nan
+    got = bank.batch_filter(zs.copy(), update_first=bool(seed % 3 == 0))
+    kfs = []
+    for i in range(N):
+        kf = ref.K.KalmanFilter(dim_x=n, dim_z=m)
+        kf.x, kf.P = x0[i].copy(), P0[i].copy()
+        kf.F, kf.Q, kf.H, kf.R = (F[i], Q[i], H[i], R[i]) if per_track else (F, Q, H, R)
+        kf.alpha = 1.01
+        zl = np.empty(T, dtype=object)
+        for t in range(T):
+            zl[t] = None if np.isnan(zs[t, i]).all() else zs[t, i]
+        want = kf.batch_filter(zl, update_first=bool(seed % 3 == 0))
+        for g, w, key in zip(got, want, ("means", "covs", "means_p", "covs_p")):
+            same(np.asarray(g)[:, i], w, (what, i, key))
+        same(bank.x[i], kf.x, (what, i, "x"))
+        same(bank.P[i], kf.P, (what, i, "P"))
+        kfs.append(kf)
+    # single steps on the bank
+    bank.predict()
+    z1 = rs.randn(N, m)
+    bank.update(z1)
+    for i, kf in enumerate(kfs):
+        kf.predict()
+        kf.update(z1[i])
+        for key in ("x", "P", "y", "K", "S", "SI"):
+            same(np.asarray(getattr(bank, key))[i], getattr(kf, key), (what, i, "step", key))
+    # smoother of the bank's own histories (class convention)
+    xs, Ps, Ks, Pps = bank.rts_smoother(np.asarray(got[0]), np.asarray(got[1]))
+    for i, kf in enumerate(kfs):
+        w = kf.rts_smoother(np.asarray(got[0])[:, i], np.asarray(got[1])[:, i])
+        for g, ww, key in zip((xs, Ps, Ks, Pps), w, ("x", "P", "K", "Pp")):
+            same(np.asarray(g)[:, i], ww, (what, i, "rts", key), tol=1e-9)
