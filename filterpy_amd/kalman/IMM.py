@@ -14,9 +14,11 @@ P (N, n, n), mu (N, n_models), z (N, m); ``batch_filter(zs)`` (no reference coun
 reference has no batch method on IMMEstimator) runs T x {predict; update} in ONE launch and returns
 the per-step estimates.
 
-Restrictions (the kernel keeps a whole bank in one lane's registers): linear ``KalmanFilter``-like
-filters of the same dim_x <= 6 and dim_z <= 3, 2 or 3 filters, no control input, every
-measurement present.
+Reach (one lane owns a track's whole bank): linear ``KalmanFilter``-like filters of the same dim_x <= 16 and
+dim_z <= 8, 2 to 8 filters, ``predict(u)`` with every filter's own B (dim_u <= 4), ``update(None)`` (IMM.py:171-186 as the
+reference runs it on top of kalman_filter.py:511-520: the filters keep x and P, each likelihood is the density of a zero
+residual under that filter's last S).  Register-resident classes: (2,1), (4,2), (6,3) x {2, 3}; (9,4) x 2..8 and (16,8) x 2
+unrolled with spills; (16,8) x 3..8 rolled.
 """
 import numpy as np
 import torch

@@ -252,3 +252,101 @@ def install(monkeypatch):
                      ("kf_steadystate", kf_steadystate)):
         monkeypatch.setattr(E, name, fn)
     return calls
+
+
+def install_imm(monkeypatch):
+    """fk_imm_batch_ex_f64's stand-in (include/filterhip.h: phases, FK_IMM_FLAG_MMAE, zmask, the ll0 record, control input):
+    IMM.py:160-249 / mmae.py:140-212 step by step on the bank records, with the oracle's pieces"""
+    import sys
+    from filterpy_amd import _engine as E
+    from oracle import imm_oracle
+    if getattr(E.require_gpu, "__name__", "") != "<lambda>":       # (install() not called yet: the transfers must copy here too)
+        monkeypatch.setattr(E, "require_gpu", lambda: CPU)
+        real_dev, real_from = E.dev, E.from_records
+        monkeypatch.setattr(E, "dev", lambda a, device=None: real_dev(a, device).clone())
+        monkeypatch.setattr(E, "from_records", lambda t, layout, lead, rec_shape: real_from(t.clone(), layout, lead, rec_shape))
+
+    def imm_batch(n, m, nm, N, T, layout, F, Q, H, R, M, z, xs, Ps, mu, *, x_out=None, P_out=None, mu_out=None, x_prior_out=None,
+                  P_prior_out=None, likelihood_out=None, status=None, phase=0, mmae=False, zmask=None, ll0=None, nu=0, B=None,
+                  u=None):
+        L = layout
+        Fm, Qm = F.detach().numpy().reshape(nm, n, n), Q.detach().numpy().reshape(nm, n, n)
+        Hm, Rm = H.detach().numpy().reshape(nm, m, n), R.detach().numpy().reshape(nm, m, m)
+        Mm = None if M is None else M.detach().numpy().reshape(nm, nm)
+        Bm = None if (B is None or not nu) else B.detach().numpy().reshape(nm, n, nu)
+        steps = T if phase == 0 else 1
+        zs = None if z is None else get(z, L, 1, (m,))
+        us = None if (u is None or not nu) else get(u, L, 1, (nu,))
+        mk = None if zmask is None else zmask.detach().numpy().reshape(steps, N)
+        X, PP, MU = get(xs, L, 0, (nm, n)), get(Ps, L, 0, (nm, n, n)), get(mu, L, 0, (nm,))
+        LL = None if ll0 is None else get(ll0, L, 0, (nm,))
+        o = dict(x=np.zeros((steps, N, n)), P=np.zeros((steps, N, n, n)), mu=np.zeros((steps, N, nm)), xp=np.zeros((steps, N, n)),
+                 Pp=np.zeros((steps, N, n, n)), L=np.zeros((steps, N, nm)))
+        for i in range(N):
+            x, P, p = [X[i, j].copy() for j in range(nm)], [PP[i, j].copy() for j in range(nm)], MU[i].copy()
+            l0 = np.full(nm, -np.inf) if LL is None else LL[i].copy()
+            for t in range(steps):
+                if phase in (0, 1):
+                    if mmae:
+                        src_x, src_P = x, P
+                    else:
+                        _, omega = imm_oracle.mixing(p, Mm)
+                        src_x, src_P = [], []
+                        for j in range(nm):
+                            xm = np.zeros(n)
+                            for xi, wi in zip(x, omega[:, j]):
+                                xm += xi * wi
+                            Pm = np.zeros((n, n))
+                            for xi, Pi, wi in zip(x, P, omega[:, j]):
+                                yy = xi - xm
+                                Pm += wi * (np.outer(yy, yy) + Pi)
+                            src_x.append(xm)
+                            src_P.append(Pm)
+                    for j in range(nm):
+                        x[j], P[j] = kf_oracle.kf_predict(src_x[j], src_P[j], Fm[j], Qm[j], None if Bm is None else Bm[j],
+                                                          None if us is None else us[t, i])
+                    if not mmae:
+                        o["xp"][t, i], o["Pp"][t, i] = imm_oracle.state_estimate(x, P, p)
+                if phase in (0, 2):
+                    present = mk is None or bool(mk[t, i])
+                    Lk = np.zeros(nm)
+                    for j in range(nm):
+                        if present:
+                            x[j], P[j], y, K, S, SI = kf_oracle.kf_update(x[j], P[j], zs[t, i], Rm[j], Hm[j])
+                            ll = kf_oracle.log_likelihood(y, S)
+                            l0[j] = kf_oracle.log_likelihood(np.zeros(m), S)
+                        else:
+                            ll = l0[j]
+                        Lk[j] = np.exp(ll)
+                        if Lk[j] == 0:
+                            Lk[j] = sys.float_info.min
+                    if mmae:
+                        p = p * Lk
+                        p = p / sum(p)
+                        xe = np.zeros(n)
+                        for xj, pj in zip(x, p):
+                            xe += np.dot(xj, pj)
+                        Pe = np.zeros((n, n))
+                        for xk, xj, Pj, pj in zip(xe, x, P, p):      # mmae.py:205-207: zips the COMPONENTS of x with the filters
+                            yy = xj - xk
+                            Pe += pj * (np.outer(yy, yy) + Pj)
+                    else:
+                        cbar, _ = imm_oracle.mixing(p, Mm)
+                        p = cbar * Lk
+                        p = p / np.sum(p)
+                        xe, Pe = imm_oracle.state_estimate(x, P, p)
+                    o["x"][t, i], o["P"][t, i], o["mu"][t, i], o["L"][t, i] = xe, Pe, p, Lk
+            for j in range(nm):
+                X[i, j], PP[i, j] = x[j], P[j]
+            MU[i] = p
+            if LL is not None:
+                LL[i] = l0
+        put(xs, L, 0, X)
+        put(Ps, L, 0, PP)
+        put(mu, L, 0, MU)
+        if ll0 is not None:
+            put(ll0, L, 0, LL)
+        for rec, key in ((x_out, "x"), (P_out, "P"), (mu_out, "mu"), (x_prior_out, "xp"), (P_prior_out, "Pp"), (likelihood_out, "L")):
+            put(rec, L, 1, o[key])
+
+    monkeypatch.setattr(E, "imm_batch", imm_batch)

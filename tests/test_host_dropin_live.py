@@ -393,3 +393,88 @@ def test_bank_equals_n_reference_filters(ref, monkeypatch, seed, layout):
         w = kf.rts_smoother(np.asarray(got[0])[:, i], np.asarray(got[1])[:, i])
         for g, ww, key in zip((xs, Ps, Ks, Pps), w, ("x", "P", "K", "Pp")):
             same(np.asarray(g)[:, i], ww, (what, i, "rts", key), tol=1e-9)
+
+
+@pytest.mark.parametrize("layout", ["soa", "aos"])
+@pytest.mark.parametrize("seed", range(16))
+def test_imm_and_mmae_call_by_call(ref, monkeypatch, seed, layout):
+    """IMMEstimator (IMM.py:124-249) and MMAEFilterBank (mmae.py:99-212) call by call -- predict(), predict(u), update(z),
+    update(None) -- with every attribute compared after every call, the filters' own x / P included; then the one-launch
+    batch_filter of this package against the same calls made one by one on the reference"""
+    import filterpy_amd.kalman as amd
+    import filterpy_amd.kalman.kalman_filter as kfm
+    fake_kf_engine.install(monkeypatch)
+    fake_kf_engine.install_imm(monkeypatch)
+    rs = np.random.RandomState(20000 + seed)
+    n = int(rs.choice([2, 4, 6, 9, 12]))
+    m = int(rs.randint(1, min(n, 6) + 1))
+    nm = int(rs.randint(2, 7))
+    nu = int(rs.choice([0, 0, 2]))
+    column = bool(seed % 2)
+    what = (seed, layout, n, m, nm, nu, column)
+    Fs, Qs = [stable_F(rs, n) for _ in range(nm)], [spd(rs, n, 0.05) for _ in range(nm)]
+    Hs, Rs = [rs.randn(m, n) for _ in range(nm)], [spd(rs, m, 0.5) for _ in range(nm)]
+    Bs = [rs.randn(n, nu) for _ in range(nm)] if nu else None
+    xs0 = [rs.randn(n, 1) if column else rs.randn(n) for _ in range(nm)]
+    Ps0 = [spd(rs, n, 2.0) for _ in range(nm)]
+    mu0 = rs.rand(nm) + 0.1
+    Mt = rs.rand(nm, nm) + 0.2
+    Mt /= Mt.sum(axis=1, keepdims=True)
+
+    def bank(cls):
+        out = []
+        for j in range(nm):
+            f = cls(dim_x=n, dim_z=m, dim_u=nu)
+            f.x, f.P, f.F, f.Q, f.H, f.R = xs0[j].copy(), Ps0[j].copy(), Fs[j], Qs[j], Hs[j], Rs[j]
+            if nu:
+                f.B = Bs[j]
+            out.append(f)
+        return out
+
+    def check(a, b, names, tag):
+        for k in names:
+            same(getattr(a, k), getattr(b, k), (what, tag, k), tol=1e-10)
+        for j, (fa, fb) in enumerate(zip(a.filters, b.filters)):
+            same(fa.x, fb.x, (what, tag, "filter x", j), tol=1e-10)
+            same(fa.P, fb.P, (what, tag, "filter P", j), tol=1e-10)
+    imm_names = ("x", "P", "x_prior", "P_prior", "x_post", "P_post", "mu", "cbar", "omega", "likelihood")
+    mine, theirs = amd.IMMEstimator(bank(kfm.KalmanFilter), mu0.copy(), Mt.copy(), layout=layout), \
+        ref.K.IMMEstimator(bank(ref.K.KalmanFilter), mu0.copy(), Mt.copy())
+    check(mine, theirs, imm_names, "fresh")
+    calls = []
+    for step in range(8):
+        u = (rs.randn(nu, 1) if column else rs.randn(nu)) if (nu and rs.randint(2)) else None
+        z = None if (step in (0, 5) and seed % 3 == 0) or step == 3 else (rs.randn(m, 1) if column else rs.randn(m))
+        calls.append((u, z))
+        for o in (mine, theirs):
+            o.predict(u) if u is not None else o.predict()
+        check(mine, theirs, imm_names, ("predict", step))
+        for o in (mine, theirs):
+            o.update(z)
+        check(mine, theirs, imm_names, ("update", step))
+    # the same sequence in ONE launch (no reference counterpart) must reach the same object state and histories
+    if not nu:
+        one = amd.IMMEstimator(bank(kfm.KalmanFilter), mu0.copy(), Mt.copy(), layout=layout)
+        zl = np.empty(len(calls), dtype=object)
+        for t, (_, z) in enumerate(calls):
+            zl[t] = z
+        xs, Ps, mus = one.batch_filter(zl)
+        check(one, theirs, imm_names, "batch_filter")
+        same(xs[-1], theirs.x, (what, "batch x"), tol=1e-10)
+        same(mus[-1], theirs.mu, (what, "batch mu"), tol=1e-10)
+    # MMAE
+    mm_names = ("x", "P", "x_prior", "P_prior", "x_post", "P_post", "p", "z")
+    mine, theirs = amd.MMAEFilterBank(bank(kfm.KalmanFilter), mu0.copy(), dim_x=n, layout=layout), \
+        ref.K.MMAEFilterBank(bank(ref.K.KalmanFilter), mu0.copy(), dim_x=n)
+    check(mine, theirs, mm_names, "mmae fresh")
+    for step in range(6):
+        z = None if step == 2 else (rs.randn(m, 1) if column else rs.randn(m))
+        # (with B set the reference's default u = 0 broadcasts every filter's state to (n, dim_u), mmae.py:140-154: u is passed)
+        u = (rs.randn(nu, 1) if column else rs.randn(nu)) if nu else 0
+        for o in (mine, theirs):
+            o.predict(u)
+        check(mine, theirs, mm_names, ("mmae predict", step))
+        Ro = [None, 0.8][step % 2]
+        for o in (mine, theirs):
+            o.update(z, R=Ro)
+        check(mine, theirs, mm_names, ("mmae update", step))
