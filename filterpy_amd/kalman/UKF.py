@@ -90,6 +90,8 @@ class UnscentedKalmanFilter(object):
         self.S = np.zeros((dim_z, dim_z))
         self.SI = np.zeros((dim_z, dim_z))
         self.inv = np.linalg.inv
+        # copies of x, P "after update()" exist from construction on (UKF.py:360-362)
+        self.x_post, self.P_post = np.copy(self.x), np.copy(self.P)
 
     # ---------------------------------------------------------------- helpers --
     def _b(self, a, tail):

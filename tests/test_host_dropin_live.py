@@ -478,3 +478,95 @@ def test_imm_and_mmae_call_by_call(ref, monkeypatch, seed, layout):
         for o in (mine, theirs):
             o.update(z, R=Ro)
         check(mine, theirs, mm_names, ("mmae update", step))
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_unscented_filter_call_by_call(ref, monkeypatch, seed):
+    """UnscentedKalmanFilter with NONLINEAR Python callables (UKF.py:284-739) call by call against the live reference: predict(),
+    update(z), update(None), per-call R, then batch_filter with a missing measurement and rts_smoother -- every attribute after
+    every call.  The unscented kernels are replaced by tests/fake_ut_engine.py (arithmetic: the oracle's)."""
+    import fake_ut_engine
+    import filterpy_amd.kalman as amd
+    from filterpy_amd import _engine as E
+    fake_ut_engine.install(monkeypatch)
+    real_dev, real_from = E.dev, E.from_records                    # host <-> device transfers copy (see fake_kf_engine.install)
+    monkeypatch.setattr(E, "dev", lambda a, device=None: real_dev(a, device).clone())
+    monkeypatch.setattr(E, "from_records", lambda t, layout, lead, rec_shape: real_from(t.clone(), layout, lead, rec_shape))
+    rs = np.random.RandomState(30000 + seed)
+    n = int(rs.choice([1, 2, 3, 5, 8, 11]))
+    m = int(rs.randint(1, min(n, 4) + 1))
+    dt = 0.1
+    A, C = np.eye(n) + 0.1 * stable_F(rs, n), rs.randn(m, n)
+    what = (seed, n, m)
+
+    def fx(x, dt_):
+        return A @ x + 0.05 * dt_ * np.sin(x)
+
+    def hx(x):
+        return C @ x + 0.1 * np.tanh(x[:m])
+    julier = bool(seed % 4 == 3)
+    Q, R = spd(rs, n, 0.02), spd(rs, m, 0.3)
+    x0, P0 = rs.randn(n), spd(rs, n, 1.5)
+    pair = []
+    for K in (ref.K, amd):
+        pts = K.JulierSigmaPoints(n, 1.0) if julier else K.MerweScaledSigmaPoints(n, 0.5, 2.0, 3.0 - n)
+        f = K.UnscentedKalmanFilter(dim_x=n, dim_z=m, dt=dt, hx=hx, fx=fx, points=pts)
+        f.x, f.P, f.Q, f.R = x0.copy(), P0.copy(), Q.copy(), R.copy()
+        pair.append(f)
+    theirs, mine = pair
+    names = ("x", "P", "x_prior", "P_prior", "x_post", "P_post", "K", "y", "S", "SI", "sigmas_f", "sigmas_h", "z")
+
+    def check(tag):
+        for k in names:
+            same(getattr(mine, k), getattr(theirs, k), (what, tag, k), tol=1e-10)
+    check("fresh")
+    for step in range(6):
+        for f in pair:
+            f.predict()
+        check(("predict", step))
+        z = None if step == 2 else rs.randn(m)
+        Ro = spd(rs, m, 0.2) if step == 4 else None
+        for f in pair:
+            f.update(z, R=Ro)
+        check(("update", step))
+        if z is not None:
+            for k in ("log_likelihood", "likelihood", "mahalanobis"):
+                same(getattr(mine, k), getattr(theirs, k), (what, step, k), tol=1e-8)
+    T = 7
+    zs = np.empty(T, dtype=object)
+    for t in range(T):
+        zs[t] = None if t == 3 else rs.randn(m)
+    outs = [f.batch_filter(zs) for f in pair]
+    same(outs[1][0], outs[0][0], (what, "batch means"), tol=1e-10)
+    same(outs[1][1], outs[0][1], (what, "batch covs"), tol=1e-10)
+    check("after batch_filter")
+    sm = [f.rts_smoother(outs[0][0], outs[0][1]) for f in pair]
+    for g, w, key in zip(sm[1], sm[0], ("x", "P", "K")):
+        same(g, w, (what, "rts", key), tol=1e-9)
+
+
+def test_every_instance_attribute_of_the_reference_objects_exists_here(ref):
+    """freshly constructed objects: whatever attribute the reference's instance carries (Saver reads them all, callers poke at
+    them), ours carries too -- found the one gap of round 5: UnscentedKalmanFilter.x_post / P_post exist from construction on
+    (UKF.py:360-362)"""
+    import filterpy_amd.kalman as amd
+    import filterpy_amd.common as amdc
+
+    def build(K):
+        pts, jul = K.MerweScaledSigmaPoints(3, .5, 2., 0.), K.JulierSigmaPoints(3, 1.)
+        ukf = K.UnscentedKalmanFilter(3, 2, .1, lambda x: x[:2], lambda x, dt: x, pts)
+        kfs = [K.KalmanFilter(2, 1) for _ in range(2)]
+        imm = K.IMMEstimator(kfs, [.5, .5], np.array([[.9, .1], [.1, .9]]))
+        mm = K.MMAEFilterBank([K.KalmanFilter(2, 1) for _ in range(2)], [.5, .5], dim_x=2)
+        return dict(merwe=pts, julier=jul, ukf=ukf, kf=kfs[0], imm=imm, mmae=mm)
+    theirs, mine = build(ref.K), build(amd)
+    for k in theirs:
+        missing = sorted(a for a in set(vars(theirs[k])) - set(vars(mine[k])) if not a.startswith("__"))
+        assert not missing, (k, missing)
+        for a, v in vars(theirs[k]).items():          # same kind of value where it is data
+            if isinstance(v, np.ndarray) and v.dtype != object:
+                same(getattr(mine[k], a), v, (k, a))
+    s_t, s_m = ref.C.Saver(theirs["kf"]), amdc.Saver(mine["kf"])
+    s_t.save()
+    s_m.save()
+    assert sorted(s_t.keys) == sorted(s_m.keys)
