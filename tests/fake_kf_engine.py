@@ -350,3 +350,47 @@ def install_imm(monkeypatch):
             put(rec, L, 1, o[key])
 
     monkeypatch.setattr(E, "imm_batch", imm_batch)
+
+
+def install_resample(monkeypatch):
+    """stand-ins for the resampling entry points (include/filterhip.h: one u per filter / N per filter, int32 / int64 indices,
+    FK_STATUS_OVERRUN where the reference's merge loop would run off the end, the residual fill / draw pair): the oracle's loops"""
+    from filterpy_amd import _engine as E
+    from oracle import resample_oracle as ro
+    OVERRUN = 4
+    monkeypatch.setattr(E, "require_gpu", lambda: CPU)
+
+    def merge(name, Fn, Np, w, u, idx, status):
+        wh, uh = w.detach().numpy().reshape(Fn, Np), u.detach().numpy()
+        for f in range(Fn):
+            got, over = (ro.systematic_c(wh[f], float(uh.reshape(-1)[f])) if name == "sys" else ro.stratified_c(wh[f], uh.reshape(Fn, Np)[f]))
+            idx[f] = torch.as_tensor(np.minimum(got, Np - 1))
+            if over and status is not None:
+                status[f] |= OVERRUN
+
+    def resample_multinomial(Fn, Np, Nu, w, u, idx):
+        wh, uh = w.detach().numpy().reshape(Fn, Np), u.detach().numpy().reshape(Fn, Nu)
+        for f in range(Fn):
+            idx[f] = torch.as_tensor(ro.multinomial(wh[f], uh[f]).astype(np.int64))
+
+    def resample_residual_fill(Fn, Np, w, idx, k, cs, status):
+        wh = w.detach().numpy().reshape(Fn, Np)
+        for f in range(Fn):
+            copies, kk, c = ro.residual_parts(wh[f])
+            fill = np.repeat(np.arange(Np), np.maximum(copies, 0))[:Np]
+            idx[f, :len(fill)] = torch.as_tensor(fill.astype(np.int32))
+            k[f] = int(kk)
+            cs[f] = torch.as_tensor(c)
+
+    def resample_residual_draw(Fn, Np, cs, k, uoff, u, idx):
+        ch, kh, uh, off = cs.detach().numpy(), k.detach().numpy(), u.detach().numpy(), uoff.detach().numpy()
+        for f in range(Fn):
+            cnt = Np - int(kh[f])
+            if cnt > 0:
+                idx[f, int(kh[f]):] = torch.as_tensor(np.searchsorted(ch[f], uh[off[f]:off[f] + cnt]).astype(np.int32))
+
+    monkeypatch.setattr(E, "resample_systematic", lambda Fn, Np, w, u, idx, status=None: merge("sys", Fn, Np, w, u, idx, status))
+    monkeypatch.setattr(E, "resample_stratified", lambda Fn, Np, w, u, idx, status=None: merge("str", Fn, Np, w, u, idx, status))
+    monkeypatch.setattr(E, "resample_multinomial", resample_multinomial)
+    monkeypatch.setattr(E, "resample_residual_fill", resample_residual_fill)
+    monkeypatch.setattr(E, "resample_residual_draw", resample_residual_draw)

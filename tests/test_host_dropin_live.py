@@ -570,3 +570,46 @@ def test_every_instance_attribute_of_the_reference_objects_exists_here(ref):
     s_t.save()
     s_m.save()
     assert sorted(s_t.keys) == sorted(s_m.keys)
+
+
+@pytest.mark.parametrize("N", [1, 3, 10, 257, 5000])
+@pytest.mark.parametrize("form", ["array", "list", "unnormalised_low", "bank"])
+def test_resampling_functions(ref, monkeypatch, N, form):
+    """filterpy.monte_carlo's four functions (resampling.py:27-176) through this package's wrappers: identical indices, dtype and
+    shape, the process-global NumPy stream left at the same position (the NEXT random number agrees), IndexError where the
+    reference's merge loop runs off the end (weights that sum to less than the last position)"""
+    import filterpy.monte_carlo as rmc
+    import filterpy_amd.monte_carlo as amc
+    fake_kf_engine.install_resample(monkeypatch)
+    rs = np.random.RandomState(40000 + N)
+    w = rs.rand(N)
+    w /= w.sum()
+    if form == "unnormalised_low":
+        w = w * 0.5                                   # positions beyond cumsum[-1]: the reference raises IndexError
+    arg = list(w) if form == "list" else w
+    for name in ("systematic_resample", "stratified_resample", "multinomial_resample", "residual_resample"):
+        if form == "bank":
+            # (F, N) weights: no reference counterpart -- one reference call per filter, in filter order, on the same stream
+            W = np.stack([w, w[::-1].copy(), np.roll(w, 1)])
+            np.random.seed(77)
+            want = np.stack([getattr(rmc, name)(W[f].copy()) for f in range(3)])
+            nxt_want = np.random.random()
+            np.random.seed(77)
+            got = getattr(amc, name)(W.copy())
+            nxt_got = np.random.random()
+            assert got.shape == want.shape and got.dtype == want.dtype and np.array_equal(got, want), name
+            assert nxt_got == nxt_want, name
+            continue
+        res = []
+        for mod in (rmc, amc):
+            np.random.seed(1234)
+            try:
+                out = getattr(mod, name)(arg if not isinstance(arg, np.ndarray) else arg.copy())
+                res.append(("ok", out, np.random.random()))
+            except IndexError:
+                res.append(("IndexError", None, None))
+        assert res[0][0] == res[1][0], (name, form, N, res[0][0], res[1][0])
+        if res[0][0] == "ok":
+            a, b = np.asarray(res[1][1]), np.asarray(res[0][1])
+            assert a.dtype == b.dtype and a.shape == b.shape and np.array_equal(a, b), (name, form, N)
+            assert res[0][2] == res[1][2], (name, "stream position")
