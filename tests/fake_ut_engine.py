@@ -99,7 +99,74 @@ def install(monkeypatch):
         if K is not None:
             _put(K, layout, Ks)
 
+    def ut_linear_map(n_in, n_out, k, N, layout, M, sig_in, sig_out):
+        calls.append("linear_map")
+        s = _get(sig_in, layout, (k, n_in))
+        _put(sig_out, layout, s @ M.numpy().reshape(n_out, n_in).T)
+
+    def ukf_linear_batch(n, m, N, T, layout, scale, F, H, Q, R, Wm, Wc, z, x, P, *, mask=None, means=None, covs=None, status=None,
+                         paired=None):
+        """fk_ukf_linear_batch_f64: T x { UKF.predict ; UKF.update } (UKF.py:364-491) with fx = F x, hx = H x, any weight set"""
+        calls.append("fused_batch")
+        Fh, Hh, Qh, Rh, wm, wc = F.numpy().reshape(n, n), H.numpy().reshape(m, n), Q.numpy().reshape(n, n), R.numpy().reshape(m, m), Wm.numpy(), Wc.numpy()
+        zs = z.numpy().reshape(T, N, m) if layout == "aos" else np.swapaxes(z.numpy().reshape(T, m, N), 1, 2)
+        mk = None if mask is None else mask.numpy().reshape(T, N)
+        xs, Ps = _get(x, layout, (n,)), _get(P, layout, (n, n))
+        mu, cov = np.zeros((T, N, n)), np.zeros((T, N, n, n))
+
+        def sig(xx, PP):
+            U = cholesky(scale * PP)
+            return np.vstack([xx, xx + U, xx - U])
+        for i in range(N):
+            xi, Pi = xs[i].copy(), Ps[i].copy()
+            for t in range(T):
+                xi, Pi = uo.unscented_transform(sig(xi, Pi) @ Fh.T, wm, wc, Qh)
+                sf = sig(xi, Pi)
+                if mk is None or mk[t, i]:
+                    sh = sf @ Hh.T
+                    zp, S = uo.unscented_transform(sh, wm, wc, Rh)
+                    Pxz = uo.cross_variance(xi, zp, sf, sh, wc)
+                    K = Pxz @ np.linalg.inv(S)
+                    xi = xi + K @ (zs[t, i] - zp)
+                    Pi = Pi - K @ (S @ K.T)
+                mu[t, i], cov[t, i] = xi, Pi
+            xs[i], Ps[i] = xi, Pi
+        _put(x, layout, xs)
+        _put(P, layout, Ps)
+        for rec, arr in ((means, mu), (covs, cov)):
+            if rec is not None:
+                a = arr.reshape(T, N, -1)
+                rec.copy_(torch.as_tensor(np.ascontiguousarray(a if layout == "aos" else np.swapaxes(a, 1, 2))).reshape(rec.shape))
+
+    def ukf_linear_rts(n, N, T, layout, scale, F, Q, Wm, Wc, Xs, Ps, xs, Ps_out, K=None, status=None, paired=None):
+        """fk_ukf_linear_rts_f64: UKF.rts_smoother (UKF.py:714-739) with fx = F x"""
+        calls.append("fused_rts")
+        Fh, Qh, wm, wc = F.numpy().reshape(n, n), Q.numpy().reshape(n, n), Wm.numpy(), Wc.numpy()
+        unrec = lambda t, d: (t.numpy().reshape(T, N, d) if layout == "aos" else np.swapaxes(t.numpy().reshape(T, d, N), 1, 2))  # noqa: E731
+        X, Pm = unrec(Xs, n).copy(), unrec(Ps, n * n).reshape(T, N, n, n).copy()
+        ox, oP, oK = X.copy(), Pm.copy(), np.zeros((T, N, n, n))
+        for i in range(N):
+            for k in reversed(range(T - 1)):
+                U = cholesky(scale * oP[k, i])
+                s = np.vstack([ox[k, i], ox[k, i] + U, ox[k, i] - U])
+                sf = s @ Fh.T
+                xb, Pb = uo.unscented_transform(sf, wm, wc, Qh)
+                Pxb = 0
+                for j in range(2 * n + 1):
+                    Pxb = Pxb + wc[j] * np.outer(s[j] - X[k, i], sf[j] - xb)
+                Kk = Pxb @ np.linalg.inv(Pb)
+                ox[k, i] = ox[k, i] + Kk @ (ox[k + 1, i] - xb)
+                oP[k, i] = oP[k, i] + (Kk @ (oP[k + 1, i] - Pb)) @ Kk.T
+                oK[k, i] = Kk
+        for rec, arr in ((xs, ox), (Ps_out, oP), (K, oK)):
+            if rec is not None:
+                a = arr.reshape(T, N, -1)
+                rec.copy_(torch.as_tensor(np.ascontiguousarray(a if layout == "aos" else np.swapaxes(a, 1, 2))).reshape(rec.shape))
+
+    monkeypatch.setattr(E, "ukf_linear_supported", lambda n, m, paired=False: True)
+    monkeypatch.setattr(E, "ukf_linear_rts_supported", lambda n, paired=False: True)
     for name, fn in dict(ut_sigma_points=ut_sigma_points, ut_transform=ut_transform, ut_cross_variance=ut_cross_variance,
-                         ukf_correct=ukf_correct, ukf_rts_correct=ukf_rts_correct).items():
+                         ukf_correct=ukf_correct, ukf_rts_correct=ukf_rts_correct, ut_linear_map=ut_linear_map,
+                         ukf_linear_batch=ukf_linear_batch, ukf_linear_rts=ukf_linear_rts).items():
         monkeypatch.setattr(E, name, fn)
     return calls

@@ -613,3 +613,47 @@ def test_resampling_functions(ref, monkeypatch, N, form):
             a, b = np.asarray(res[1][1]), np.asarray(res[0][1])
             assert a.dtype == b.dtype and a.shape == b.shape and np.array_equal(a, b), (name, form, N)
             assert res[0][2] == res[1][2], (name, "stream position")
+
+
+@pytest.mark.parametrize("ends_on_missing", [0, 1, 2])
+@pytest.mark.parametrize("seed", range(8))
+def test_unscented_filter_with_matrix_models_fused_path(ref, monkeypatch, seed, ends_on_missing):
+    """UnscentedKalmanFilter(fx=F, hx=H) -- matrices instead of callables: this package's one-launch batch_filter / rts_smoother --
+    against the reference's per-epoch loop with the equivalent lambdas: histories, and every attribute the loop leaves behind
+    (K, S, SI, y, sigmas_h belong to the last epoch that HAD a measurement, x_prior / sigmas_f / z to the last epoch:
+    UKF.py:440-447, :623-632), for runs that end on 0, 1 or 2 missing measurements"""
+    import fake_ut_engine
+    import filterpy_amd.kalman as amd
+    from filterpy_amd import _engine as E
+    calls = fake_ut_engine.install(monkeypatch)
+    real_dev, real_from = E.dev, E.from_records
+    monkeypatch.setattr(E, "dev", lambda a, device=None: real_dev(a, device).clone())
+    monkeypatch.setattr(E, "from_records", lambda t, layout, lead, rec_shape: real_from(t.clone(), layout, lead, rec_shape))
+    rs = np.random.RandomState(50000 + seed)
+    n = int(rs.choice([2, 4, 6, 9, 12, 16]))
+    m = int(rs.randint(1, min(n, 8) + 1))
+    F, H = np.eye(n) + 0.1 * stable_F(rs, n), rs.randn(m, n)
+    Q, R = spd(rs, n, 0.02), spd(rs, m, 0.3)
+    x0, P0 = rs.randn(n), spd(rs, n, 1.5)
+    what = (seed, n, m, ends_on_missing)
+    julier = bool(seed % 3 == 2)
+    pts_r = ref.K.JulierSigmaPoints(n, 0.8) if julier else ref.K.MerweScaledSigmaPoints(n, 0.4, 2.0, 3.0 - n)
+    pts_m = amd.JulierSigmaPoints(n, 0.8) if julier else amd.MerweScaledSigmaPoints(n, 0.4, 2.0, 3.0 - n)
+    theirs = ref.K.UnscentedKalmanFilter(dim_x=n, dim_z=m, dt=1.0, hx=lambda x: H @ x, fx=lambda x, dt: F @ x, points=pts_r)
+    mine = amd.UnscentedKalmanFilter(dim_x=n, dim_z=m, dt=1.0, hx=H, fx=F, points=pts_m)
+    for f in (theirs, mine):
+        f.x, f.P, f.Q, f.R = x0.copy(), P0.copy(), Q.copy(), R.copy()
+    T = 8
+    zs = np.empty(T, dtype=object)
+    for t in range(T):
+        zs[t] = None if (t == 2 or t >= T - ends_on_missing) else rs.randn(m)
+    a, b = mine.batch_filter(zs), theirs.batch_filter(zs)
+    assert "fused_batch" in calls
+    same(a[0], b[0], (what, "means"), tol=1e-10)
+    same(a[1], b[1], (what, "covs"), tol=1e-10)
+    for k in ("x", "P", "x_prior", "P_prior", "x_post", "P_post", "K", "y", "S", "SI", "sigmas_f", "sigmas_h", "z"):
+        same(getattr(mine, k), getattr(theirs, k), (what, k), tol=1e-10)
+    sa, sb = mine.rts_smoother(b[0], b[1]), theirs.rts_smoother(b[0], b[1])
+    assert "fused_rts" in calls
+    for g, w, key in zip(sa, sb, ("x", "P", "K")):
+        same(g, w, (what, "rts", key), tol=1e-9)
