@@ -395,3 +395,45 @@ def test_two_stage_build_lists_are_consistent():
         import warnings
         warnings.warn("filterpy_amd/libfilterhip.so is a STAGE 1 library (rolled stand-ins for the slow IMM classes): the build "
                       "was cut short; `make -C filterpy_amd/csrc -j` finishes it")
+
+
+def test_every_entry_point_refuses_null_and_nonsense_without_touching_a_device():
+    """All 31 symbols of include/filterhip.h, every pointer NULL and every size 0 / -1 / 1 / 33 in turn: each call returns
+    FK_OK (nothing to do), FK_ERR_BAD_ARG or FK_ERR_UNSUPPORTED -- none dereferences a NULL pointer, none needs a GPU to say
+    no.  One child process for all 100-odd calls (a crash would take the test runner with it)."""
+    import subprocess
+    import sys
+    code = r'''
+import ctypes, sys
+sys.path.insert(0, %r)
+from filterpy_amd import _abi
+lib = _abi.lib()
+bad = []
+for name in _abi.SIGNATURES:
+    if name in ("fk_abi_version", "fk_build_arch", "fk_last_error"):
+        continue
+    fn = getattr(lib, name)
+    for v in (0, -1, 1, 33):
+        keep, args = [], []
+        for t in fn.argtypes:
+            if t is ctypes.c_void_p:
+                args.append(None)
+            elif t is ctypes.c_double:
+                args.append(1.0)
+            elif t in (ctypes.c_int32, ctypes.c_int64, ctypes.c_size_t):
+                args.append(v)
+            else:
+                st = t._type_()
+                for f, ft in st._fields_:
+                    setattr(st, f, 1.0 if ft is ctypes.c_double else v)
+                keep.append(st)
+                args.append(ctypes.byref(st))
+        r = fn(*args)
+        sized = name.endswith("workspace_bytes") or name in ("fk_ukf_linear_supported", "fk_chunk_plan")
+        if not sized and r not in (0, -1, -2):
+            bad.append((name, v, r))
+print("CALLS_DONE", bad)
+''' % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.returncode, r.stderr[-400:])
+    assert "CALLS_DONE []" in r.stdout, r.stdout[-400:]
