@@ -437,3 +437,21 @@ print("CALLS_DONE", bad)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, (r.returncode, r.stderr[-400:])
     assert "CALLS_DONE []" in r.stdout, r.stdout[-400:]
+
+
+def test_header_is_plain_c_and_a_c_program_links_against_the_library(tmp_path):
+    """include/filterhip.h is the boundary a non-Python host binds: it compiles as strict C99 and as C++11 without
+    a warning, and a plain C program links against libfilterhip.so and calls into it (no HIP header, no GPU needed for that)."""
+    import subprocess
+    src = tmp_path / "host.c"
+    src.write_text('#include "filterhip.h"\n#include <string.h>\n'
+                   'int main(void) { fk_kf_desc d; memset(&d, 0, sizeof d);\n'
+                   '  if (fk_abi_version() != 3 || strcmp(fk_build_arch(), "gfx950")) return 1;\n'
+                   '  return fk_kf_batch_filter_f64(&d, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0) == -1 ? 0 : 2; }\n')
+    inc, libdir = os.path.join(ROOT, "include"), os.path.join(ROOT, "filterpy_amd")
+    for cc, std, lang in (("gcc", "-std=c99", "c"), ("g++", "-std=c++11", "c++")):
+        subprocess.check_call([cc, std, "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", inc, "-x", lang, "-c", str(src),
+                               "-o", str(tmp_path / ("host_" + lang.replace("+", "x") + ".o"))])
+    exe = tmp_path / "host"
+    subprocess.check_call(["gcc", str(tmp_path / "host_c.o"), "-L", libdir, "-lfilterhip", "-Wl,-rpath," + libdir, "-o", str(exe)])
+    assert subprocess.run([str(exe)], timeout=120).returncode == 0
