@@ -1,6 +1,8 @@
 """world_size-2 gloo test (CPU) of the multi-GPU path: contiguous track sharding with no
 data-path collective + all-gather of the summary state + max-over-ranks timing."""
 import os
+
+import pytest
 import socket
 
 import numpy as np
@@ -146,13 +148,16 @@ def test_bench_self_spawns_one_rank_per_gpu():
     assert line["n_gpus"] == 2 and line["gather_ok"] is True and line["steps"] == 3 and line["data"] == "selftest-stub"
 
 
-def test_bench_under_the_drivers_torchrun_command():
-    """the driver's own launch line: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N"""
-    r = _run_bench("-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                   "--master-port", str(_free_port()), "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1",
-                   "--selftest-cpu")
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_bench_under_the_drivers_torchrun_command(world):
+    """the driver's own launch line: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --
+    at every N of its scaling run (1 is the plain call)"""
+    r = _run_bench("-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+                   "--master-port", str(_free_port()), "bench.py", "--gpus", str(world), "--steps", "3", "--warmup", "1",
+                   "--selftest-cpu", timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
-    assert _json_line(r.stdout)["n_gpus"] == 2
+    line = _json_line(r.stdout)
+    assert line["n_gpus"] == world and line["gather_ok"] is True and line["collectives"] is True
 
 
 def test_bench_refuses_more_ranks_than_gpus():
