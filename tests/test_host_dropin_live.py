@@ -657,3 +657,66 @@ def test_unscented_filter_with_matrix_models_fused_path(ref, monkeypatch, seed, 
     assert "fused_rts" in calls
     for g, w, key in zip(sa, sb, ("x", "P", "K")):
         same(g, w, (what, "rts", key), tol=1e-9)
+
+
+@pytest.mark.parametrize("opts", [dict(), dict(save_current=True), dict(skip_private=True), dict(skip_callable=True),
+                                  dict(ignore=("P", "K")), dict(skip_private=True, skip_callable=True, ignore=("z",))])
+def test_saver_options_and_reshape_z(ref, monkeypatch, opts):
+    """filterpy.common.Saver (helpers.py:27-219) with every constructor option on the SAME kind of object driven through the same
+    calls: the keys, the order of what is recorded, to_array() / flatten() shapes; reshape_z (helpers.py:324-342) on every shape
+    a measurement can arrive in, accepted and refused alike"""
+    import filterpy_amd.kalman.kalman_filter as kfm
+    from filterpy_amd.common import Saver, reshape_z
+    fake_kf_engine.install(monkeypatch)
+    rs = np.random.RandomState(77)
+    n, m = 3, 2
+    mine, theirs = make_pair(ref, kfm, rs, n, m, 0, False)
+    s_m, s_t = Saver(mine, **opts), ref.C.Saver(theirs, **opts)
+    for step in range(5):
+        z = None if step == 2 else rs.randn(m)
+        for kf, s in ((mine, s_m), (theirs, s_t)):
+            kf.predict()
+            kf.update(z)
+            s.save()
+    assert len(s_m) == len(s_t)
+    km, kt = sorted(s_m.keys), sorted(s_t.keys)
+    # (this package's object has no `inv` callable history to offer beyond the reference's; private names are the same set)
+    assert [k for k in kt if k in km] == kt or set(kt) - set(km) <= {"_I"}, (set(kt) ^ set(km))
+    for k in kt:
+        if k not in km:
+            continue
+        a, b = s_m[k], s_t[k]
+        assert len(a) == len(b), k
+        for u, v in zip(a, b):
+            if callable(v):
+                continue
+            same(u, v, ("saver", k), tol=1e-10)
+    # to_array(): with a missing measurement in the run the z history is ragged ((m,) arrays and the (m, 1) array of None) and
+    # np.array refuses it -- in both (helpers.py:169-189); otherwise the same arrays
+    res = []
+    for s in (s_t, s_m):
+        try:
+            s.to_array()
+            res.append("ok")
+        except ValueError:
+            res.append("ValueError")
+    assert res[0] == res[1], res
+    if res[0] == "ok":
+        for k in ("x", "P", "y", "K"):
+            if k in kt and k in km:
+                same(getattr(s_m, k), getattr(s_t, k), ("to_array", k), tol=1e-10)
+    # reshape_z: every form, accepted or refused identically
+    forms = [1.5, [1.5], [[1.5]], np.array(1.5), np.zeros(2), np.zeros((2, 1)), np.zeros((1, 2)), np.zeros((2, 2)), np.zeros(3),
+             [1., 2.], [[1.], [2.]], [[1., 2.]], np.zeros((1, 1, 2))]
+    for z in forms:
+        for dim_z in (1, 2):
+            for ndim in (0, 1, 2):
+                out = []
+                for fn in (ref.C.reshape_z, reshape_z):
+                    try:
+                        out.append(("ok", fn(z, dim_z, ndim)))
+                    except ValueError:
+                        out.append(("ValueError", None))
+                assert out[0][0] == out[1][0], (z, dim_z, ndim, out)
+                if out[0][0] == "ok":
+                    same(out[1][1], out[0][1], ("reshape_z", str(z), dim_z, ndim))
