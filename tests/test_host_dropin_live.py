@@ -720,3 +720,35 @@ def test_saver_options_and_reshape_z(ref, monkeypatch, opts):
                 assert out[0][0] == out[1][0], (z, dim_z, ndim, out)
                 if out[0][0] == "ok":
                     same(out[1][1], out[0][1], ("reshape_z", str(z), dim_z, ndim))
+
+
+@pytest.mark.parametrize("n", [1, 2, 5, 9, 16])
+def test_sigma_point_classes_and_unscented_transform_standalone(ref, monkeypatch, n):
+    """MerweScaledSigmaPoints / JulierSigmaPoints (sigma_points.py:99-192, :211-372) used on their own -- weights, num_sigmas,
+    sigma_points() with array / scalar x and P, the size check's ValueError -- and the unscented_transform function
+    (unscented_transform.py:22-128) with and without noise, a mean function and a residual function"""
+    import fake_ut_engine
+    import filterpy_amd.kalman as amd
+    fake_ut_engine.install(monkeypatch)
+    rs = np.random.RandomState(60000 + n)
+    x, P = rs.randn(n), spd(rs, n, 2.0)
+    for make in (lambda K: K.MerweScaledSigmaPoints(n, 0.3, 2.0, 3.0 - n), lambda K: K.MerweScaledSigmaPoints(n, 1.0, 0.0, 1.0),
+                 lambda K: K.JulierSigmaPoints(n, 0.7)):
+        pr, pm = make(ref.K), make(amd)
+        assert pm.num_sigmas() == pr.num_sigmas() == 2 * n + 1
+        assert np.array_equal(pm.Wm, pr.Wm) and np.array_equal(pm.Wc, pr.Wc)
+        same(pm.sigma_points(x, P), pr.sigma_points(x, P), ("sigma_points", n), tol=1e-12)
+        if n == 1:                                            # scalar x and P are promoted (sigma_points.py:159-165)
+            same(pm.sigma_points(0.7, 2.0), pr.sigma_points(0.7, 2.0), ("scalar forms", n), tol=1e-12)
+        else:                                                 # a scalar P means P * I
+            same(pm.sigma_points(x, 2.0), pr.sigma_points(x, 2.0), ("scalar P", n), tol=1e-12)
+        for p in (pr, pm):                                    # wrong size: ValueError in both (sigma_points.py:153-155)
+            with pytest.raises(ValueError):
+                p.sigma_points(np.zeros(n + 1), np.eye(n + 1))
+        s = pr.sigma_points(x, P)
+        Q = spd(rs, n, 0.1)
+        for kw in (dict(), dict(noise_cov=Q), dict(noise_cov=Q, mean_fn=lambda sig, w: np.dot(w, sig)),
+                   dict(residual_fn=lambda a, b: a - b)):
+            a, b = amd.unscented_transform(s, pm.Wm, pm.Wc, **kw), ref.K.unscented_transform(s, pr.Wm, pr.Wc, **kw)
+            same(a[0], b[0], ("unscented_transform x", n, sorted(kw)), tol=1e-12)
+            same(a[1], b[1], ("unscented_transform P", n, sorted(kw)), tol=1e-12)
