@@ -5,7 +5,6 @@ Record layouts (see include/filterhip.h): 'aos' = NumPy C order [..][N][E], 'soa
 lane-coalesced [..][E][N].  Every function here takes/returns torch CUDA tensors of dtype
 float64 already in the requested layout; `to_records`/`from_records` convert NumPy arrays.
 """
-import os
 
 import numpy as np
 import torch

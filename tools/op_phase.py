@@ -10,7 +10,6 @@ import ctypes
 import json
 import os
 import subprocess
-import sys
 
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 CSRC = os.path.join(ROOT, "filterpy_amd", "csrc")
