@@ -603,7 +603,7 @@ static int ukf_rts_small_t(const UkfRtsArgs &a, const double *F, const double *Q
     // needs 16-byte aligned arrays and, element-major, an even track count -- with an odd one every element row starts 8
     // bytes off and the last unit of the last row straddles the end of the array (the range check drops it whole, and the last
     // track's last element with it).  Other calls take the same kernel with the register fetch.
-    static const bool dma_on = !(getenv("FK_UKF_DMA") && getenv("FK_UKF_DMA")[0] == '0');
+    static const bool dma_on = [] { const char *v = getenv("FK_UKF_DMA"); return !(v && v[0] == '0'); }();
     const bool dma = dma_on && reinterpret_cast<uintptr_t>(a.Xs) % 16 == 0 && reinterpret_cast<uintptr_t>(a.Ps) % 16 == 0 &&
                      (layout != FK_LAYOUT_SOA || a.N % 2 == 0);
     if (a.n <= 2) FK_UKF_GO(2, true);
@@ -725,7 +725,7 @@ static int fail(int code, const char *msg)
 // FK_UKF_PADDED=1: the padded instantiations also at the exact dims (A/B, and the parity tests of the padded path)
 static bool ukf_exact()
 {
-    static const bool padded = getenv("FK_UKF_PADDED") && getenv("FK_UKF_PADDED")[0] == '1';
+    static const bool padded = [] { const char *v = getenv("FK_UKF_PADDED"); return v && v[0] == '1'; }();
     return !padded;
 }
 
@@ -733,7 +733,7 @@ static bool ukf_exact()
 // FK_UKF_PAIRED=0 keeps the index-order sums for every call (A/B, and the parity tests of that path).
 static bool ukf_paired(const fk_ukf_desc *d)
 {
-    static const bool off = getenv("FK_UKF_PAIRED") && getenv("FK_UKF_PAIRED")[0] == '0';
+    static const bool off = [] { const char *v = getenv("FK_UKF_PAIRED"); return v && v[0] == '0'; }();
     return !off && (d->flags & FK_UKF_FLAG_PAIR_WEIGHTS) != 0;
 }
 

@@ -379,7 +379,7 @@ int fk_ut_sigma_points_f64(int32_t n, int64_t N, int32_t layout, double scale, c
     if (N == 0) return FK_OK;
     const dim3 grid((unsigned)((N + BLOCK - 1) / BLOCK)), block(BLOCK);
     // NumPy order at the exact dims 2 / 4 / 6: the wave-cooperative kernel (FK_UT_COOP=0: the per-lane 16-byte pairs of round 2)
-    static const bool coop = !(getenv("FK_UT_COOP") && getenv("FK_UT_COOP")[0] == '0');
+    static const bool coop = [] { const char *v = getenv("FK_UT_COOP"); return !(v && v[0] == '0'); }();
     if (coop && layout == FK_LAYOUT_AOS && (n == 2 || n == 4 || n == 6)) {
         const dim3 g1((unsigned)((N + UT_WAVE - 1) / UT_WAVE)), b1(UT_WAVE);
         if (n == 2) hipLaunchKernelGGL((sigma_coop_kernel<2>), g1, b1, 0, (hipStream_t)stream, (long)N, scale, x, P, sigmas, status);
@@ -411,7 +411,7 @@ int fk_ut_transform_f64(int32_t n, int32_t k, int64_t N, int32_t layout, const d
     if ((double)N * k * n * 8.0 >= 4294967296.0) return fail(FK_ERR_UNSUPPORTED, "unscented transform: record block >= 4 GiB, split the batch");
     if (N == 0) return FK_OK;
     const dim3 grid((unsigned)((N + BLOCK - 1) / BLOCK)), block(BLOCK);
-    static const bool coop = !(getenv("FK_UT_COOP") && getenv("FK_UT_COOP")[0] == '0');
+    static const bool coop = [] { const char *v = getenv("FK_UT_COOP"); return !(v && v[0] == '0'); }();
     if (coop && layout == FK_LAYOUT_AOS && k == 2 * n + 1 && (n == 2 || n == 4 || n == 6)) {
         const dim3 g1((unsigned)((N + UT_WAVE - 1) / UT_WAVE)), b1(UT_WAVE);
         if (n == 2) hipLaunchKernelGGL((ut_coop_kernel<2>), g1, b1, 0, (hipStream_t)stream, (long)N, sigmas, Wm, Wc, noise_cov, x_out, P_out);
