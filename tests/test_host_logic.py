@@ -455,3 +455,59 @@ def test_header_is_plain_c_and_a_c_program_links_against_the_library(tmp_path):
     exe = tmp_path / "host"
     subprocess.check_call(["gcc", str(tmp_path / "host_c.o"), "-L", libdir, "-lfilterhip", "-Wl,-rpath," + libdir, "-o", str(exe)])
     assert subprocess.run([str(exe)], timeout=120).returncode == 0
+
+
+def test_ctypes_signatures_match_the_header_parameter_by_parameter():
+    """filterpy_amd/_abi.py binds by hand: every prototype of include/filterhip.h is parsed and compared with the ctypes
+    signature -- parameter count, and the kind of every parameter (pointer / int32 / int64 / size_t / double / which struct) and of
+    the return value -- and the three structs field by field (name, type, order).  A transposed or mistyped argument in a
+    binding would hand the kernels garbage without any error."""
+    import ctypes
+    from filterpy_amd import _abi
+    src = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "filterhip.h")).read(), flags=re.S)
+    kinds = {"int32_t": ctypes.c_int32, "int64_t": ctypes.c_int64, "size_t": ctypes.c_size_t, "double": ctypes.c_double,
+             "int": ctypes.c_int}
+    structs = {"fk_kf_desc": _abi.fk_kf_desc, "fk_ukf_desc": _abi.fk_ukf_desc, "fk_imm_desc": _abi.fk_imm_desc,
+               "fk_kf_extras": _abi.fk_kf_extras}
+    same_size = lambda a, b: ctypes.sizeof(a) == ctypes.sizeof(b)  # noqa: E731
+
+    def kind(decl):
+        decl = decl.replace("const", " ").strip()
+        if decl == "void":
+            return None
+        if "*" in decl:
+            base = decl.split("*")[0].split()[0]
+            return ctypes.POINTER(structs[base]) if base in structs else ctypes.c_void_p
+        return kinds[decl.split()[0]]
+    protos = re.findall(r"^\s*(int|size_t|const char \*)\s*(fk_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", src, flags=re.M | re.S)
+    assert len(protos) == len(_abi.SIGNATURES), (len(protos), len(_abi.SIGNATURES))
+    for ret, name, params in protos:
+        restype, argtypes = _abi.SIGNATURES[name]
+        want = [kind(p) for p in params.replace("\n", " ").split(",")]
+        want = [w for w in want if w is not None]
+        assert len(want) == len(argtypes), (name, len(want), len(argtypes))
+        for i, (w, a) in enumerate(zip(want, argtypes)):
+            if w is ctypes.c_void_p or (isinstance(w, type) and issubclass(w, ctypes._Pointer)):
+                ok = (a is ctypes.c_void_p) if w is ctypes.c_void_p else (a is w or a is ctypes.c_void_p and False)
+                assert ok, (name, i, w, a)
+            else:
+                assert same_size(w, a) and (w is ctypes.c_double) == (a is ctypes.c_double), (name, i, w, a)
+        if ret == "const char *":
+            assert restype is ctypes.c_char_p, name
+        else:
+            assert same_size(kinds[ret], restype), (name, ret, restype)
+    for sname, cls in structs.items():
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (sname, sname), src, flags=re.S).group(1)
+        fields = []
+        for stmt in body.split(";"):
+            stmt = stmt.strip()
+            if not stmt:
+                continue
+            typ = stmt.split()[0]
+            for nm in stmt[len(typ):].split(","):
+                nm = nm.strip()
+                fields.append((nm.lstrip("*").strip(), ctypes.c_void_p if nm.startswith("*") else kinds[typ]))
+        got = [(f, t) for f, t in cls._fields_]
+        assert [f for f, _ in fields] == [f for f, _ in got], (sname, fields, got)
+        for (f, w), (_, a) in zip(fields, got):
+            assert same_size(w, a) and (w is ctypes.c_double) == (a is ctypes.c_double), (sname, f, w, a)
