@@ -511,3 +511,94 @@ def test_ctypes_signatures_match_the_header_parameter_by_parameter():
         assert [f for f, _ in fields] == [f for f, _ in got], (sname, fields, got)
         for (f, w), (_, a) in zip(fields, got):
             assert same_size(w, a) and (w is ctypes.c_double) == (a is ctypes.c_double), (sname, f, w, a)
+
+
+def test_engine_wrappers_hand_every_operand_to_the_parameter_of_its_name(monkeypatch):
+    """filterpy_amd/_engine.py is the one place where Python operands become positional C arguments.  Every wrapper is called with
+    a distinct tensor per operand and a recording stand-in for the library; each recorded pointer must sit at the position of the
+    header parameter that carries the operand's NAME (five documented aliases), each descriptor field must hold the wrapper's
+    value of that name.  (The GPU suite proves the same by results; this one says which operand went astray, on the CPU.)"""
+    import ctypes
+    import inspect
+    import torch
+    from filterpy_amd import _abi, _engine as E
+    src = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "filterhip.h")).read(), flags=re.S)
+    protos = {n: [p.strip().split()[-1].lstrip("*") for p in ps.replace("\n", " ").split(",")]
+              for _, n, ps in re.findall(r"^\s*(int|size_t|const char \*)\s*(fk_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", src, flags=re.M | re.S)}
+    alias = {"noise": "noise_cov", "sig_in": "in", "sig_out": "out", "convention": "index_convention", "y": "y_out"}
+    calls = []
+
+    class Lib:
+        def __getattr__(self, name):
+            def fn(*a):
+                calls.append((name, a))
+                return 64 if name.endswith("workspace_bytes") else (1 if name == "fk_ukf_linear_supported" else 0)
+            return fn
+    monkeypatch.setattr(_abi, "lib", lambda: Lib())
+    monkeypatch.setattr(E, "_stream", lambda: 4321)
+    ints = dict(n=3, m=2, k=7, N=5, T=4, Fn=6, Np=8, Nu=9, d=4, n_in=3, n_out=2, n_models=2, nu=1, phase=2, scale=1.5)
+    desc_kw = dict(n=3, m=2, nu=1, model_mode=3, N=5, T=4, layout=1, update_first=1, alpha_sq=1.25, flags=2)
+    wrappers = {"kf_batch_filter": "fk_kf_batch_filter_f64", "kf_batch_filter_ex": "fk_kf_batch_filter_ex_f64",
+                "kf_predict": "fk_kf_predict_f64", "kf_update": "fk_kf_update_f64", "kf_rts": "fk_kf_rts_f64",
+                "ut_sigma_points": "fk_ut_sigma_points_f64", "ut_transform": "fk_ut_transform_f64",
+                "ut_cross_variance": "fk_ut_cross_variance_f64", "ut_linear_map": "fk_ut_linear_map_f64",
+                "ukf_correct": "fk_ukf_correct_f64", "ukf_linear_batch": "fk_ukf_linear_batch_f64",
+                "ukf_linear_rts": "fk_ukf_linear_rts_f64", "kf_steadystate": "fk_kf_steadystate_f64",
+                "kf_update_correlated": "fk_kf_update_correlated_f64", "ukf_rts_correct": "fk_ukf_rts_correct_f64",
+                "imm_batch": "fk_imm_batch_ex_f64", "resample_systematic": "fk_resample_systematic_f64",
+                "resample_stratified": "fk_resample_stratified_f64", "resample_multinomial": "fk_resample_multinomial_f64",
+                "resample_residual_fill": "fk_resample_residual_fill_f64", "resample_residual_draw": "fk_resample_residual_draw_f64",
+                "resample_gather_mean": "fk_resample_gather_mean_f64", "cumsum_exact": "fk_cumsum_exact_f64"}
+    checked = 0
+    for wname, cname in wrappers.items():
+        fn = getattr(E, wname)
+        kw, tensors = {}, {}
+        for p in inspect.signature(fn).parameters:
+            if p == "desc_kw":
+                kw[p] = dict(desc_kw)
+            elif p == "extras":
+                kw[p] = {k: torch.zeros(3, dtype=torch.float64) for k in ("y", "K", "S", "SI", "log_likelihood", "mahalanobis")}
+            elif p == "layout":
+                kw[p] = "soa"
+            elif p in ints and not (p == "k" and wname.startswith("resample_residual")):       # (there k is the count array)
+                kw[p] = ints[p]
+            elif p in ("mmae", "force_last_one"):
+                kw[p] = True
+            elif p == "paired":
+                kw[p] = True
+            elif p in ("convention",):
+                kw[p] = 1
+            else:
+                tensors[p] = kw[p] = torch.zeros(3, dtype=torch.uint8 if p in ("mask", "zmask") else torch.float64)
+        calls.clear()
+        fn(**kw)
+        rec = [a for nm, a in calls if nm == cname]
+        assert len(rec) == 1, (wname, [nm for nm, _ in calls])
+        args, cparams = rec[0], protos[cname]
+        assert len(args) == len(cparams), (wname, len(args), len(cparams))
+        for pname, t in tensors.items():
+            c = pname if pname in cparams else alias.get(pname, pname)
+            assert c in cparams, (wname, pname, cparams)
+            assert args[cparams.index(c)] == t.data_ptr(), (wname, pname, "went to", [cparams[i] for i, a in enumerate(args) if a == t.data_ptr()])
+            checked += 1
+        assert args[cparams.index("stream")] == 4321, wname
+        for c, a in zip(cparams, args):
+            if c in ints and c in kw and not isinstance(kw[c], torch.Tensor) and not isinstance(a, ctypes.Structure):
+                assert a == kw[c], (wname, c, a)
+            if c == "index_convention":
+                assert a == 1, wname
+        if "desc" in cparams:
+            d = args[cparams.index("desc")]
+            want = kw.get("desc_kw") or dict(n=3, m=2, N=5, T=4, layout=E.LAYOUTS["soa"], scale=1.5, n_models=2, phase=2)
+            for f, _ in d._fields_:
+                if f in want and not (wname == "ukf_linear_rts" and f == "m"):       # (the smoother has no dim_z: m = 1)
+                    assert getattr(d, f) == want[f], (wname, "desc." + f, getattr(d, f), want[f])
+            if wname == "imm_batch":
+                assert d.flags == 1
+            if wname.startswith("ukf_linear"):
+                assert d.flags == _abi.FK_UKF_FLAG_PAIR_WEIGHTS
+        if "extras" in cparams:
+            ex = args[cparams.index("extras")]
+            for k, t in kw["extras"].items():
+                assert getattr(ex, k) == t.data_ptr(), (wname, "extras." + k)
+    assert checked > 150
