@@ -130,6 +130,8 @@ def test_random_call_sequences(ref, monkeypatch, seed):
     rs = np.random.RandomState(4000 + seed)
     n = int(rs.choice([1, 2, 3, 4, 6, 9, 12, 16]))
     m = int(rs.randint(1, min(n, 8) + 1))
+    if seed % 7 == 6:
+        m = min(8, n + int(rs.randint(1, 3)))              # more measurements than states (dim_z <= dim_x is not required)
     nu = int(rs.choice([0, 0, 1, 2]))
     column = bool(rs.randint(2))
     mine, theirs = make_pair(ref, kfm, rs, n, m, nu, column)
@@ -159,8 +161,11 @@ def test_random_call_sequences(ref, monkeypatch, seed):
             #  broadcasts a 1-D state to (n, n) -- kalman_filter.py:934-935, :472)
             kw = dict(us=[rs.randn(nu, 1) if column else rs.randn(nu) for _ in range(T)]) if nu else {}
             if op == "batch_lists":
-                kw = dict(Fs=[stable_F(rs, n) for _ in range(T)], Qs=[spd(rs, n, 0.03) for _ in range(T)],
-                          Hs=[rs.randn(m, n) for _ in range(T)], Rs=[spd(rs, m, 0.4) for _ in range(T)])
+                # (per-epoch lists may hold scalars: a scalar Q / R kwarg is eye * value, kalman_filter.py:467-468, :524-525)
+                kw = dict(Fs=[stable_F(rs, n) for _ in range(T)],
+                          Qs=[spd(rs, n, 0.03) if rs.randint(3) else float(0.01 + 0.05 * rs.rand()) for _ in range(T)],
+                          Hs=[rs.randn(m, n) for _ in range(T)],
+                          Rs=[spd(rs, m, 0.4) if rs.randint(3) else float(0.3 + rs.rand()) for _ in range(T)])
                 if nu:
                     kw.update(Bs=[rs.randn(n, nu) for _ in range(T)], us=[rs.randn(nu, 1) if column else rs.randn(nu) for _ in range(T)])
             if op == "batch_update_first":
@@ -173,7 +178,10 @@ def test_random_call_sequences(ref, monkeypatch, seed):
             T = int(rs.randint(2, 6))
             zs = [rs.randn(m, 1) if column else rs.randn(m) for _ in range(T)]
             kw = dict(us=[rs.randn(nu, 1) if column else rs.randn(nu) for _ in range(T)]) if nu else {}
-            a, b, refused = both(mine, theirs, lambda kf: kf.rts_smoother(*kf.batch_filter(list(zs), **kw)[:2]), what)
+            skw = {}
+            if rs.randint(2):                     # per-epoch models for the smoother too (class convention: Fs[k+1], Qs[k+1])
+                skw = dict(Fs=[stable_F(rs, n) for _ in range(T)], Qs=[spd(rs, n, 0.03) for _ in range(T)])
+            a, b, refused = both(mine, theirs, lambda kf: kf.rts_smoother(*kf.batch_filter(list(zs), **kw)[:2], **skw), what)
             if not refused:
                 for g, w, key in zip(a, b, ("x", "P", "K", "Pp")):
                     same(g, w, (what, key), tol=1e-9)
