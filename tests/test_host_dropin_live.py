@@ -760,3 +760,85 @@ def test_sigma_point_classes_and_unscented_transform_standalone(ref, monkeypatch
             a, b = amd.unscented_transform(s, pm.Wm, pm.Wc, **kw), ref.K.unscented_transform(s, pr.Wm, pr.Wc, **kw)
             same(a[0], b[0], ("unscented_transform x", n, sorted(kw)), tol=1e-12)
             same(a[1], b[1], ("unscented_transform P", n, sorted(kw)), tol=1e-12)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_unscented_filter_optional_arguments(ref, monkeypatch, seed):
+    """the optional arguments of the UKF's methods (UKF.py:364-632): predict(dt=, fx=, **fx_args), update(z, R=, hx=, **hx_args),
+    a caller-supplied UT, compute_process_sigmas, cross_variance, batch_filter(zs, Rs=, dts=, saver=) and rts_smoother(dts=)"""
+    import fake_ut_engine
+    import filterpy_amd.kalman as amd
+    from filterpy_amd import _engine as E
+    from filterpy_amd.common import Saver
+    fake_ut_engine.install(monkeypatch)
+    real_dev, real_from = E.dev, E.from_records
+    monkeypatch.setattr(E, "dev", lambda a, device=None: real_dev(a, device).clone())
+    monkeypatch.setattr(E, "from_records", lambda t, layout, lead, rec_shape: real_from(t.clone(), layout, lead, rec_shape))
+    rs = np.random.RandomState(70000 + seed)
+    n = int(rs.choice([2, 3, 5, 8]))
+    m = int(rs.randint(1, min(n, 3) + 1))
+    A, C = np.eye(n) + 0.1 * stable_F(rs, n), rs.randn(m, n)
+    what = (seed, n, m)
+
+    def fx(x, dt, gain=1.0):
+        return A @ x * gain + 0.01 * dt * np.cos(x)
+
+    def fx2(x, dt, gain=1.0):
+        return A.T @ x * gain
+
+    def hx(x, bias=0.0):
+        return C @ x + bias
+
+    def hx2(x, bias=0.0):
+        return 2.0 * (C @ x) + bias
+    Q, R = spd(rs, n, 0.02), spd(rs, m, 0.3)
+    x0, P0 = rs.randn(n), spd(rs, n, 1.5)
+    pair = []
+    for K in (ref.K, amd):
+        f = K.UnscentedKalmanFilter(dim_x=n, dim_z=m, dt=0.1, hx=hx, fx=fx, points=K.MerweScaledSigmaPoints(n, 0.5, 2.0, 3.0 - n))
+        f.x, f.P, f.Q, f.R = x0.copy(), P0.copy(), Q.copy(), R.copy()
+        pair.append(f)
+    theirs, mine = pair
+    names = ("x", "P", "x_prior", "P_prior", "x_post", "P_post", "K", "y", "S", "SI", "sigmas_f", "sigmas_h", "z")
+
+    def check(tag):
+        for k in names:
+            same(getattr(mine, k), getattr(theirs, k), (what, tag, k), tol=1e-10)
+
+    def each(fn):
+        return [fn(f, K) for f, K in zip(pair, (ref.K, amd))]
+    each(lambda f, K: f.predict(dt=0.25))
+    check("predict(dt)")
+    each(lambda f, K: f.predict(fx=fx2, gain=0.9))
+    check("predict(fx, **fx_args)")
+    z = rs.randn(m)
+    each(lambda f, K: f.update(z, R=spd(np.random.RandomState(5), m, 0.2), hx=hx2, bias=0.3))
+    check("update(R, hx, **hx_args)")
+    each(lambda f, K: f.predict(UT=K.unscented_transform))
+    each(lambda f, K: f.update(rs.randn(m) * 0 + 0.1, UT=K.unscented_transform))
+    check("caller-supplied UT")
+    each(lambda f, K: f.compute_process_sigmas(0.2))
+    same(mine.sigmas_f, theirs.sigmas_f, (what, "compute_process_sigmas"), tol=1e-10)
+    each(lambda f, K: f.compute_process_sigmas(0.1))
+    a, b = [f.cross_variance(f.x, hx(f.x), f.sigmas_f, np.array([hx(s) for s in f.sigmas_f])) for f in (mine, theirs)]
+    same(a, b, (what, "cross_variance"), tol=1e-10)
+    T = 5
+    zs = [rs.randn(m) for _ in range(T)]
+    Rs, dts = [spd(rs, m, 0.3) for _ in range(T)], [0.05 * (t + 1) for t in range(T)]
+    savers = []
+
+    def run(f, K):
+        s = (ref.C.Saver if f is theirs else Saver)(f)
+        savers.append(s)
+        return f.batch_filter(zs, Rs=Rs, dts=dts, saver=s)
+    outs = each(run)
+    same(outs[1][0], outs[0][0], (what, "batch means"), tol=1e-10)
+    same(outs[1][1], outs[0][1], (what, "batch covs"), tol=1e-10)
+    check("after batch_filter(Rs, dts, saver)")
+    assert len(savers[0]) == len(savers[1]) == T
+    for k in ("x", "P", "K", "y", "S"):
+        for t in range(T):
+            same(savers[1][k][t], savers[0][k][t], (what, "saver", k, t), tol=1e-10)
+    sm = each(lambda f, K: f.rts_smoother(outs[0][0], outs[0][1], dts=dts))
+    for g, w, key in zip(sm[1], sm[0], ("x", "P", "K")):
+        same(g, w, (what, "rts(dts)", key), tol=1e-9)
