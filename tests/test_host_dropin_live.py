@@ -842,3 +842,62 @@ def test_unscented_filter_optional_arguments(ref, monkeypatch, seed):
     sm = each(lambda f, K: f.rts_smoother(outs[0][0], outs[0][1], dts=dts))
     for g, w, key in zip(sm[1], sm[0], ("x", "P", "K")):
         same(g, w, (what, "rts(dts)", key), tol=1e-9)
+
+
+@pytest.mark.parametrize("mode", ["loop", "vectorized", "torch"])
+@pytest.mark.parametrize("layout", ["soa", "aos"])
+@pytest.mark.parametrize("seed", range(4))
+def test_unscented_bank_equals_n_reference_filters(ref, monkeypatch, seed, layout, mode):
+    """UnscentedKalmanFilter(n_tracks=N): a bank in the three calling conventions of its callables -- once per sigma point like the
+    reference, once per call on NumPy arrays (vectorized=True), once per call on tensors with everything resident
+    (device_callables=True; CPU tensors here) -- against N reference filters run one by one: batch_filter with a missing
+    measurement, the attributes afterwards, rts_smoother"""
+    import torch
+    import fake_ut_engine
+    import filterpy_amd.kalman as amd
+    from filterpy_amd import _engine as E
+    fake_ut_engine.install(monkeypatch)
+    real_dev, real_from = E.dev, E.from_records
+    monkeypatch.setattr(E, "dev", lambda a, device=None: real_dev(a, device).clone())
+    monkeypatch.setattr(E, "from_records", lambda t, layout, lead, rec_shape: real_from(t.clone(), layout, lead, rec_shape))
+    rs = np.random.RandomState(80000 + seed)
+    n = int(rs.choice([2, 3, 6]))
+    m = int(rs.randint(1, min(n, 3) + 1))
+    N, T = int(rs.randint(1, 5)), 6
+    A, C = np.eye(n) + 0.1 * stable_F(rs, n), rs.randn(m, n)
+    what = (seed, layout, mode, n, m, N)
+
+    def fx(x, dt):                        # works on (n,), (N, k, n) arrays and tensors alike
+        lib = torch if isinstance(x, torch.Tensor) else np
+        Am = torch.as_tensor(A) if lib is torch else A
+        return x @ Am.T + 0.05 * dt * lib.sin(x)
+
+    def hx(x):
+        lib = torch if isinstance(x, torch.Tensor) else np
+        Cm = torch.as_tensor(C) if lib is torch else C
+        return x @ Cm.T + 0.1 * lib.tanh(x[..., :m])
+    Q, R = spd(rs, n, 0.02), spd(rs, m, 0.3)
+    x0, P0 = rs.randn(N, n), np.array([spd(rs, n, 1.5) for _ in range(N)])
+    zs = rs.randn(T, N, m)
+    kw = dict(vectorized=True) if mode == "vectorized" else (dict(device_callables=True) if mode == "torch" else {})
+    bank = amd.UnscentedKalmanFilter(dim_x=n, dim_z=m, dt=0.1, hx=hx, fx=fx, points=amd.MerweScaledSigmaPoints(n, 0.5, 2.0, 3.0 - n),
+                                     n_tracks=N, layout=layout, **kw)
+    bank.x, bank.P, bank.Q, bank.R = x0.copy(), P0.copy(), Q.copy(), R.copy()
+    zl = [zs[t] if t != 2 else None for t in range(T)]
+    mu, cov = bank.batch_filter(zl)
+    mu, cov = np.asarray(mu), np.asarray(cov)
+    xs, Ps, Ks = bank.rts_smoother(mu, cov)
+    for i in range(N):
+        f = ref.K.UnscentedKalmanFilter(dim_x=n, dim_z=m, dt=0.1, hx=hx, fx=fx, points=ref.K.MerweScaledSigmaPoints(n, 0.5, 2.0, 3.0 - n))
+        f.x, f.P, f.Q, f.R = x0[i].copy(), P0[i].copy(), Q.copy(), R.copy()
+        zr = np.empty(T, dtype=object)
+        for t in range(T):
+            zr[t] = None if t == 2 else zs[t, i]
+        wmu, wcov = f.batch_filter(zr)
+        same(mu[:, i], wmu, (what, i, "means"), tol=1e-10)
+        same(cov[:, i], wcov, (what, i, "covs"), tol=1e-10)
+        same(np.asarray(bank.x)[i], f.x, (what, i, "x"), tol=1e-10)
+        same(np.asarray(bank.P)[i], f.P, (what, i, "P"), tol=1e-10)
+        w = f.rts_smoother(wmu, wcov)
+        for g, ww, key in zip((xs, Ps, Ks), w, ("x", "P", "K")):
+            same(np.asarray(g)[:, i], ww, (what, i, "rts", key), tol=1e-9)
