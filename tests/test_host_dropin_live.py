@@ -901,3 +901,69 @@ def test_unscented_bank_equals_n_reference_filters(ref, monkeypatch, seed, layou
         w = f.rts_smoother(wmu, wcov)
         for g, ww, key in zip((xs, Ps, Ks), w, ("x", "P", "K")):
             same(np.asarray(g)[:, i], ww, (what, i, "rts", key), tol=1e-9)
+
+
+@pytest.mark.parametrize("layout", ["soa", "aos"])
+@pytest.mark.parametrize("seed", range(6))
+def test_imm_bank_equals_n_reference_estimators(ref, monkeypatch, seed, layout):
+    """IMMEstimator(..., n_tracks=N) / MMAEFilterBank(..., n_tracks=N): N independent banks that share the models, states shaped
+    (N, dim_x), measurements (N, dim_z) -- call by call and in one batch_filter launch against N reference estimators"""
+    import filterpy_amd.kalman as amd
+    import filterpy_amd.kalman.kalman_filter as kfm
+    fake_kf_engine.install(monkeypatch)
+    fake_kf_engine.install_imm(monkeypatch)
+    rs = np.random.RandomState(90000 + seed)
+    n = int(rs.choice([2, 4, 6, 9]))
+    m = int(rs.randint(1, min(n, 4) + 1))
+    nm, N, T = int(rs.randint(2, 5)), int(rs.randint(1, 5)), 6
+    what = (seed, layout, n, m, nm, N)
+    Fs, Qs = [stable_F(rs, n) for _ in range(nm)], [spd(rs, n, 0.05) for _ in range(nm)]
+    Hs, Rs = [rs.randn(m, n) for _ in range(nm)], [spd(rs, m, 0.5) for _ in range(nm)]
+    xs0 = [rs.randn(N, n) for _ in range(nm)]
+    Ps0 = [np.array([spd(rs, n, 2.0) for _ in range(N)]) for _ in range(nm)]
+    mu0 = rs.rand(nm) + 0.1
+    Mt = rs.rand(nm, nm) + 0.2
+    Mt /= Mt.sum(axis=1, keepdims=True)
+    zs = rs.randn(T, N, m)
+
+    def my_bank():
+        out = []
+        for j in range(nm):
+            f = kfm.KalmanFilter(dim_x=n, dim_z=m)
+            f.x, f.P, f.F, f.Q, f.H, f.R = xs0[j].copy(), Ps0[j].copy(), Fs[j], Qs[j], Hs[j], Rs[j]
+            out.append(f)
+        return out
+
+    def ref_bank(i):
+        out = []
+        for j in range(nm):
+            f = ref.K.KalmanFilter(dim_x=n, dim_z=m)
+            f.x, f.P, f.F, f.Q, f.H, f.R = xs0[j][i].copy(), Ps0[j][i].copy(), Fs[j], Qs[j], Hs[j], Rs[j]
+            out.append(f)
+        return out
+    mine = amd.IMMEstimator(my_bank(), mu0.copy(), Mt.copy(), n_tracks=N, layout=layout)
+    theirs = [ref.K.IMMEstimator(ref_bank(i), mu0.copy(), Mt.copy()) for i in range(N)]
+    for t in range(T):
+        mine.predict()
+        mine.update(zs[t])
+        for i, o in enumerate(theirs):
+            o.predict()
+            o.update(zs[t, i])
+            for k in ("x", "P", "mu", "likelihood", "x_prior", "P_prior"):
+                same(np.asarray(getattr(mine, k))[i], getattr(o, k), (what, t, i, k), tol=1e-10)
+    one = amd.IMMEstimator(my_bank(), mu0.copy(), Mt.copy(), n_tracks=N, layout=layout)
+    bx, bP, bmu = one.batch_filter(zs)
+    for i, o in enumerate(theirs):
+        same(np.asarray(bx)[-1, i], o.x, (what, "batch x", i), tol=1e-10)
+        same(np.asarray(bP)[-1, i], o.P, (what, "batch P", i), tol=1e-10)
+        same(np.asarray(bmu)[-1, i], o.mu, (what, "batch mu", i), tol=1e-10)
+    mm = amd.MMAEFilterBank(my_bank(), mu0.copy(), dim_x=n, n_tracks=N, layout=layout)
+    mm_t = [ref.K.MMAEFilterBank(ref_bank(i), mu0.copy(), dim_x=n) for i in range(N)]
+    for t in range(4):
+        mm.predict()
+        mm.update(zs[t])
+        for i, o in enumerate(mm_t):
+            o.predict()
+            o.update(zs[t, i])
+            for k in ("x", "P", "p"):
+                same(np.asarray(getattr(mm, k))[i], getattr(o, k), (what, "mmae", t, i, k), tol=1e-10)
