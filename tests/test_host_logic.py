@@ -602,3 +602,37 @@ def test_engine_wrappers_hand_every_operand_to_the_parameter_of_its_name(monkeyp
             for k, t in kw["extras"].items():
                 assert getattr(ex, k) == t.data_ptr(), (wname, "extras." + k)
     assert checked > 150
+
+
+def test_committed_bench_line_keeps_the_drivers_contract():
+    """profiles/r05/bench_default.json is a line bench.py printed on an MI355X: it carries every key the driver's contract names
+    (metric / value / unit / n_gpus / steps / warmup / ms_per_step / higher_is_better / scaling / vs_baseline / dtype / data /
+    config.workload, the roofline object and the cpu_baseline object), its numbers are consistent with one another (value =
+    units / time, roofline.achieved = algorithmic bytes / kernel time, frac = achieved / peak, kernel time <= step time), the
+    metric is BASELINE.json's, and the source of bench.py still prints each of those keys."""
+    import json
+    with open(os.path.join(ROOT, "profiles", "r05", "bench_default.json")) as fh:
+        d = json.load(fh)
+    with open(os.path.join(ROOT, "BASELINE.json")) as fh:
+        base = json.load(fh)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f64"
+    assert d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    assert "track-steps" in d["metric"] and "track-steps" in json.dumps(base)
+    r, c = d["roofline"], d["cpu_baseline"]
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(r) and r["bound"] == "hbm" and r["unit"] == "GB/s"
+    assert set(("value", "unit", "cores", "kind", "sample")) <= set(c) and c["kind"] in ("port", "reference")
+    N, T = d["config"]["tracks_per_gpu"], d["config"]["T"]
+    assert abs(d["value"] - N * T * d["n_gpus"] / (d["ms_per_step"] * 1e-3)) <= 1e-9 * d["value"]
+    alg = 8.0 * (2 + 2 * 4 + 2 * 16) * N * T + 2 * 8.0 * (4 + 16) * N               # 336 B per track-step + 320 B per track once
+    assert abs(r["algorithmic_bytes_per_launch"] - alg) < 1.0
+    assert abs(r["achieved"] - alg / (r["kernel_ms"] * 1e-3) / 1e9) <= 1e-9 * r["achieved"]
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["peak"] == 8000.0 and 0.5 < r["frac"] < 1.0
+    assert r["kernel_ms"] <= d["ms_per_step"] and (r["traffic"] is None or 0.95 * alg < r["traffic"] < 1.1 * alg)
+    assert d["parity_max_rel_vs_oracle"] < 1e-10 and c["value"] > 0 and c["cores"] >= 1
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    for k in ('"metric"', '"value"', '"unit"', '"n_gpus"', '"ms_per_step"', '"higher_is_better"', '"scaling"', '"vs_baseline"',
+              '"dtype"', '"data"', '"config"', '"roofline"', '"cpu_baseline"', '"traffic"', '"frac"', '"kind"', '"sample"', '"cores"'):
+        assert k in src, k
