@@ -208,6 +208,43 @@ def hbm_probes(device):
     return out
 
 
+def baseline_configs(reps=10):
+    """The other GPU workloads of BASELINE.json -- configs[2] (1e5 tracks (9,3): batch_filter + rts_smoother), configs[3] (UKF
+    (6,3), 1e5 tracks: Merwe sigma points / unscented transform standalone and the fused 100-step filter) and configs[4]
+    (systematic_resample: 1000 filters x 8000 particles, and one GPU's share of 1000 x 8e6 = 125 filters x 8e6 particles) --
+    AFTER the timed headline region, `reps` event-timed launches each (median), every row checked against the oracle on a
+    sample (tools/bench_configs.py holds the workloads; the full-size parity tests are tests/test_gpu_baseline_configs.py).
+    Not part of `value`; a row that fails is reported as {"name", "error"} and the line still prints."""
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_configs as bc
+    rows, out = [], []
+    bc.ROWS, bc.REPS = rows, max(1, int(reps))
+    jobs = [("configs[2] " + lay, (lambda lay=lay: bc.config3(lay, 100_000, 100))) for lay in ("aos", "soa")]
+    jobs += [("configs[3] " + lay, (lambda lay=lay: bc.config4(lay, 100_000, 100, sizes=(1,)))) for lay in ("aos", "soa")]
+    jobs += [("configs[4]", lambda: bc.config5(shapes=((1000, 8000), (125, 8_000_000)), stratified=False))]
+    try:
+        for name, job in jobs:
+            before = len(rows)
+            try:
+                job()
+            except Exception as exc:                       # the headline does not depend on it
+                out.append({"name": name, "error": repr(exc)[:300]})
+            for r in rows[before:]:
+                row = {"name": r["kernel"], "config": r.get("config"), "kernel": r.get("kernel_fn"), "kernel_ms": r["ms"],
+                       "launches_timed": bc.REPS, "units": r["units"], "unit": r["unit"],
+                       "algorithmic_bytes": r["units"] * r["alg_bytes_per_unit"], "achieved_GBs": r["achieved_GBs"],
+                       "frac": r["frac_of_8TBs"]}
+                for k in ("parity_max_rel", "bit_exact", "status_flagged"):
+                    if k in r:
+                        row[k] = r[k]
+                out.append(row)
+            torch.cuda.empty_cache()
+    finally:
+        bc.ROWS, bc.REPS = None, None
+    return out
+
+
 def parity_rel_err(got, ref):
     """Worst normwise relative error over (step, track) records: max|got - ref| / max|ref| per vector / matrix
     (tests/conftest.py::rel_err_rows).  A record whose reference is exactly zero (means_p at t = 0 with
@@ -332,13 +369,22 @@ def selftest_cpu(args):
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world_env}: launch one rank per GPU")
     rank, world = parallel.init_from_env(backend="gloo", force=args.force_dist)
     exchange = world > 1 or args.force_dist
-    N, n = min(args.tracks, 1000), 4
+    n = 4
+    if args.scaling == "strong":                   # --tracks in total (capped: 1001, so that two ranks get ragged shards)
+        total = min(args.tracks, 1001)
+        lo, hi = parallel.shard_bounds(total, rank, world)
+        N, N_pad = hi - lo, -(-total // world)
+    else:
+        N = N_pad = min(args.tracks, 1000)
+        lo, total = rank * N, N * world
+    ragged = exchange and N != N_pad
     # the same double-buffered, overlapped exchange as the GPU path (parallel.SummaryExchange; async work handles on gloo)
     xb = [torch.empty(N, n, dtype=torch.float64) for _ in range(2)]
-    ex = parallel.SummaryExchange(like=xb[0], depth=2) if exchange else None
+    sb = [torch.zeros(N_pad, n, dtype=torch.float64) for _ in range(2)] if ragged else None
+    ex = parallel.SummaryExchange(like=sb[0] if ragged else xb[0], depth=2) if exchange else None
 
     def stub(k):                                   # a known function of (step, global track index)
-        return (torch.arange(N * n, dtype=torch.float64).reshape(N, n) + rank * N * n) * 0.5 + 1000.0 * k
+        return (torch.arange(N * n, dtype=torch.float64).reshape(N, n) + lo * n) * 0.5 + 1000.0 * k
 
     def step(k):
         slot = k % 2
@@ -346,7 +392,9 @@ def selftest_cpu(args):
             ex.acquire(slot)
         xb[slot].copy_(stub(k))                                                                    # stub "kernel"
         if ex:
-            ex.post(xb[slot], slot)
+            if ragged:
+                sb[slot][:N].copy_(xb[slot])
+            ex.post(sb[slot] if ragged else xb[slot], slot)
 
     for k in range(args.warmup):
         step(k)
@@ -363,12 +411,15 @@ def selftest_cpu(args):
     ok = True
     if exchange:
         for k in range(max(0, args.steps - 2), args.steps):         # the last two steps still sit in the two slots
-            want = torch.arange(world * N * n, dtype=torch.float64).reshape(world, N, n) * 0.5 + 1000.0 * k
-            ok = ok and bool(torch.equal(ex.gathered[k % 2], want))
+            want = torch.arange(total * n, dtype=torch.float64).reshape(total, n) * 0.5 + 1000.0 * k
+            got = torch.cat([ex.gathered[k % 2][r][:parallel.shard_bounds(total, r, world)[1] - parallel.shard_bounds(total, r, world)[0]]
+                             if args.scaling == "strong" else ex.gathered[k % 2][r] for r in range(world)])
+            ok = ok and bool(torch.equal(got, want))
     if rank == 0:
         print(json.dumps({"metric": "selftest", "value": None, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": 1e3 * elapsed / max(1, args.steps), "data": "selftest-stub", "gather_ok": ok,
-                          "scaling": "weak", "collectives": parallel.collectives_active()}), flush=True)
+                          "scaling": args.scaling, "tracks_total": total, "tracks_rank0": N,
+                          "collectives": parallel.collectives_active()}), flush=True)
     parallel.shutdown()
     if not ok:
         raise SystemExit("selftest: gathered summary state is wrong")
@@ -380,7 +431,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--tracks", type=int, default=1_000_000, help="tracks per GPU")
+    ap.add_argument("--tracks", type=int, default=1_000_000, help="tracks per GPU (--scaling weak) / in total (--scaling strong)")
+    ap.add_argument("--scaling", default=os.environ.get("FK_BENCH_SCALING", "weak"), choices=["weak", "strong"],
+                    help="weak (default; the driver's scaling run): every rank filters --tracks tracks of its own.  strong: "
+                         "BASELINE configs[1] read literally -- --tracks tracks IN TOTAL, rank r the contiguous shard "
+                         "parallel.shard_bounds(tracks, r, N) (125000 per GPU at N = 8: launch and tail cost show)")
+    ap.add_argument("--no-configs", action="store_true",
+                    help="skip the rows of BASELINE configs[2..4] (the line's \"configs\" key; after the timed region, rank 0 at N = 1 only)")
+    ap.add_argument("--config-reps", type=int, default=10, help="event-timed launches per row of \"configs\"")
     ap.add_argument("--T", type=int, default=100)
     ap.add_argument("--layout", default=os.environ.get("FK_BENCH_LAYOUT", "aos"), choices=["soa", "aos"],
                     help="record layout of z and the outputs: aos = NumPy C order [T][N][n][n] (default), soa = [T][n*n][N]")
@@ -434,7 +492,13 @@ def main():
     rank, world = parallel.init_from_env(backend="nccl", device=device, force=args.force_dist)
     exchange = world > 1 or args.force_dist
 
-    N, T, layout, n, m = args.tracks, args.T, args.layout, 4, 2
+    T, layout, n, m = args.T, args.layout, 4, 2
+    if args.scaling == "strong":
+        lo_, hi_ = parallel.shard_bounds(args.tracks, rank, world)
+        N, N_total = hi_ - lo_, args.tracks
+        N_pad = -(-args.tracks // world)                   # equal-shaped summary buffers for the all-gather (shards differ by <= 1)
+    else:
+        N, N_total, N_pad = args.tracks, args.tracks * world, args.tracks
     F, Q, H, R = c2_model()
     dF, dQ, dH, dR = (E.dev(M, device) for M in (F, Q, H, R))
     x0, P0, z = c2_inputs_device(N, T, layout, seed=1234 + rank, device=device)
@@ -455,7 +519,11 @@ def main():
     # side stream + events, two x buffers and two gathered buffers (parallel.SummaryExchange).  The kernel never waits for
     # the collective; its duration is reported apart (allgather_ms).
     xbuf = [x, x0.clone()] if exchange else [x]
-    ex = parallel.SummaryExchange(like=x, depth=2) if exchange else None
+    # strong scaling with shards that differ by one track: the collective wants equal shapes, so the summary leaves through a
+    # zero-padded copy of N_pad records (a 4 MB device copy on the exchange's side of the step, only in that case)
+    ragged = exchange and N != N_pad
+    sbuf = [torch.zeros((N_pad, n) if layout == "aos" else (n, N_pad), dtype=torch.float64, device=device) for _ in range(2)] if ragged else None
+    ex = parallel.SummaryExchange(like=sbuf[0] if ragged else x, depth=2) if exchange else None
     desc = dict(n=n, m=m, nu=0, model_mode=0, N=N, T=T, layout=E.LAYOUTS[layout], update_first=0, alpha_sq=1.0)
 
     # Where the two covariance histories (76 % of the bytes) sit in HBM decides 5.2 .. 6.9 ms of this kernel on one and the
@@ -540,7 +608,9 @@ def main():
         if ev:
             ev[1].record()
         if ex and with_exchange:
-            ex.post(xs, slot, timed=ev is not None)        # exchange stream, behind this launch; returns at once
+            if ragged:
+                (sbuf[slot][:N] if layout == "aos" else sbuf[slot][:, :N]).copy_(xs)
+            ex.post(sbuf[slot] if ragged else xs, slot, timed=ev is not None)   # exchange stream, behind this launch; returns at once
 
     barrier = parallel.barrier
 
@@ -583,20 +653,33 @@ def main():
 
     if exchange:                                           # the gathered summary state is every rank's final x, in rank order
         last = (args.steps - 1) % 2
-        assert torch.equal(ex.gathered[last][rank], xbuf[last]), "all-gather returned something else than this rank's final state"
+        mine = ex.gathered[last][rank]
+        if ragged:
+            mine = mine[:N] if layout == "aos" else mine[:, :N]
+        assert torch.equal(mine, xbuf[last]), "all-gather returned something else than this rank's final state"
+    per_rank = None
+    if world > 1:                                          # every rank's own launch time and shard (one small collective, after the timed region)
+        try:
+            mine = torch.tensor([kernel_ms, float(N)], dtype=torch.float64, device=device)
+            allr = torch.empty((world, 2), dtype=torch.float64, device=device)
+            dist.all_gather_into_tensor(allr, mine)
+            per_rank = [{"rank": r, "kernel_ms": round(float(allr[r, 0]), 4), "tracks": int(allr[r, 1])} for r in range(world)]
+        except Exception as exc:                           # the measurement does not depend on it
+            per_rank = {"error": repr(exc)[:200]}
     if rank == 0:
         traffic, traffic_source = pmc_traffic(layout, "interleave" if desc.get("flags") else "none")
-        units = float(N) * T * world * args.steps
+        units = float(N_total) * T * args.steps
         alg_bytes = 8.0 * (m + 2 * n + 2 * n * n) * N * T + 2 * 8.0 * (n + n * n) * N   # per launch
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
         out = {
             "metric": "track-steps/sec (predict+update) at dim_x=4 dim_z=2",
             "value": units / elapsed, "unit": "track-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[1]: {N} independent dim_x=4 dim_z=2 tracks x {T} steps per GPU, "
-                                   "fp64, shared F/H/Q/R, KalmanFilter.batch_filter (all 4 outputs stored)",
-                       "tracks_per_gpu": N, "T": T, "layout": layout,
+            "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[1]: {N} independent dim_x=4 dim_z=2 tracks x {T} steps per GPU"
+                                   + (f" ({N_total} in total, sharded)" if args.scaling == "strong" else "") +
+                                   ", fp64, shared F/H/Q/R, KalmanFilter.batch_filter (all 4 outputs stored)",
+                       "tracks_per_gpu": N, "tracks_total": N_total, "T": T, "layout": layout,
                        "placement": {"auto": "auto = KalmanFilterBank.batch_filter(device_outputs=True) as called without further "
                                              "arguments: at this size two covariance arrays placed in HBM by measurement",
                                      "interleave": "interleave = KalmanFilterBank.batch_filter(device_outputs=True, placement='interleave') "
@@ -608,9 +691,13 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": "fk::kf_fast_kernel<4,2," + layout + ",nomask,outs" + (",IL" if desc.get("flags") else "") + "> (variant " + os.environ.get("FK_FAST_VARIANT", "0") + ")", "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_launch": alg_bytes},
+            # the same launch on two plain torch allocations (no placement): what the 55-pair probe of `placement` buys on this box
+            "value_unplaced": float(N) * T / (placement_info["two_arrays_ms"] * 1e-3) * world,
             "parity_max_rel_vs_oracle": worst, "parity_tracks": int(len(sample)), "placement": placement_info,
             "gpu_clocks": gpu_clocks(), "hbm_probes": hbm_probes(device), "under_load": clocks_under_load(lambda: step(0, None, False)),   # rank 0 alone: no collective in the burst
         }
+        if per_rank is not None:
+            out["per_rank"] = per_rank
         if exchange:
             out["allgather_ms"] = ex.gather_ms()
             out["exchange"] = ("all-gather of final x (%d MB per rank) on a side stream, overlapped with the next launch; "
@@ -639,6 +726,8 @@ def main():
             kc = min(N, CPU_TRACKS_PER_PROC * 256)
             zc = (z[:, :kc] if layout == "aos" else z[:, :, :kc].transpose(1, 2)).cpu().numpy()
             out["cpu_baseline"] = cpu_baseline(np.ascontiguousarray(zc), args.cpu_seconds, args.cpu_procs or None)
+        if world == 1 and not args.no_configs:
+            out["configs"] = baseline_configs(args.config_reps)
         print(json.dumps(out), flush=True)
     parallel.shutdown()
 

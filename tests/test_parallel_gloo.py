@@ -160,6 +160,20 @@ def test_bench_under_the_drivers_torchrun_command(world):
     assert line["n_gpus"] == world and line["gather_ok"] is True and line["collectives"] is True
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_bench_strong_scaling_shards_one_total(world):
+    """--scaling strong: --tracks is the TOTAL, rank r owns parallel.shard_bounds(total, r, world) -- 1001
+    tracks here, so the shards are ragged and the summary leaves through the zero-padded buffers -- and the gathered state,
+    cut back to the shards, is the whole bank in rank order."""
+    r = _run_bench("-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+                   "--master-port", str(_free_port()), "bench.py", "--gpus", str(world), "--steps", "3", "--warmup", "1",
+                   "--selftest-cpu", "--scaling", "strong", timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = _json_line(r.stdout)
+    assert line["scaling"] == "strong" and line["tracks_total"] == 1001 and line["gather_ok"] is True
+    assert line["tracks_rank0"] == -(-1001 // world)
+
+
 def test_bench_refuses_more_ranks_than_gpus():
     """no silent 1-GPU run: asking for more GPUs than the node has is an error (this container has none)."""
     r = _run_bench("bench.py", "--gpus", "8", "--steps", "1", "--warmup", "0", "--no-cpu")

@@ -23,13 +23,26 @@ if os.environ.get("FK_BENCH_LIB"):      # A/B of a variant build (csrc/exp_build
 PEAK = 8000.0
 
 
-def timeit(fn, warm=2, reps=5):
+# bench.py collects the rows of BASELINE configs[2..4] through these hooks (its "configs" key): ROWS = a list to append to
+# instead of printing, REPS = event-timed launches per row (None: each call site's own count)
+ROWS = None
+REPS = None
+
+
+def timeit(fn, warm=2, reps=5, pre=None):
+    """median milliseconds of `fn` between two events on torch's current stream (the stream the C ABI launches on);
+    `pre` (state reset) runs in front of every call, outside the event pair"""
     import torch
+    reps = REPS or reps
     for _ in range(warm):
+        if pre:
+            pre()
         fn()
     torch.cuda.synchronize()
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
     for a, b in evs:
+        if pre:
+            pre()
         a.record()
         fn()
         b.record()
@@ -39,9 +52,12 @@ def timeit(fn, warm=2, reps=5):
 
 def emit(name, units, unit_name, ms, bytes_per_unit, **extra):
     gbs = units * bytes_per_unit / (ms * 1e-3) / 1e9
-    print(json.dumps(dict(kernel=name, units=units, unit=unit_name, ms=ms, units_per_s=units / (ms * 1e-3),
-                          alg_bytes_per_unit=bytes_per_unit, achieved_GBs=gbs, frac_of_8TBs=gbs / PEAK, **extra)),
-          flush=True)
+    row = dict(kernel=name, units=units, unit=unit_name, ms=ms, units_per_s=units / (ms * 1e-3),
+               alg_bytes_per_unit=bytes_per_unit, achieved_GBs=gbs, frac_of_8TBs=gbs / PEAK, **extra)
+    if ROWS is not None:
+        ROWS.append(row)
+    else:
+        print(json.dumps(row), flush=True)
 
 
 def cv3d_model(dt=0.1):
@@ -80,19 +96,25 @@ def config3(layout, N, T):
     dF, dQ, dH, dR = (E.dev(M) for M in (F, Q, H, R))
     desc = dict(n=n, m=m, nu=0, model_mode=0, N=N, T=T, layout=E.LAYOUTS[layout], update_first=0, alpha_sq=1.0)
 
-    def fwd():
+    def reset():
         x.copy_(x0)
         P.copy_(P0)
+
+    def fwd():
         E.kf_batch_filter(desc, dF, dQ, dH, dR, z, x, P, means=outs[0], covs=outs[1], means_p=outs[2], covs_p=outs[3], status=st)
-    ms = timeit(fwd)
+    ms = timeit(fwd, pre=reset)
     assert not st.any()
     sample = [0, 255, 256, N - 1]
     zs_h = (z[:, sample] if layout == "aos" else z[:, :, sample].permute(0, 2, 1)).cpu().numpy()
     ref = kf_oracle.kf_batch_filter_tracks(np.zeros((4, n)), np.tile(10 * np.eye(n), (4, 1, 1)), zs_h, F, Q, H, R, tracks=range(4))
-    mu = E.from_records(outs[0], layout, 1, (n,))[:, sample]
-    cov = E.from_records(outs[1], layout, 1, (n, n))[:, sample]
-    par = max(rel(mu.reshape(-1, n), ref[0].reshape(-1, n)), rel(cov.reshape(-1, n * n), ref[1].reshape(-1, n * n)))
-    emit(f"C3 kf batch_filter (9,3) {layout}", N * T, "track-steps", ms, 8 * (m + 2 * n + 2 * n * n), parity_max_rel=par)
+
+    def pick(t, rec):                     # the sampled tracks of a [T][N][E] / [T][E][N] history, as a host array [T][4]+rec
+        h = (t[:, sample] if layout == "aos" else t[:, :, sample].permute(0, 2, 1)).cpu().numpy()
+        return h.reshape(T, len(sample), *rec)
+    par = max(rel(pick(outs[k], r).reshape(-1, int(np.prod(r))), ref[k].reshape(-1, int(np.prod(r))))
+              for k, r in ((0, (n,)), (1, (n, n)), (2, (n,)), (3, (n, n))))
+    emit(f"C3 kf batch_filter (9,3) {layout}", N * T, "track-steps", ms, 8 * (m + 2 * n + 2 * n * n), parity_max_rel=par,
+         kernel_fn="fk::kf_ml_kernel<9,3> (three lanes per track, persistent grid)", config="configs[2]")
 
     so = [E.alloc_records((T,), N, n, layout)] + [E.alloc_records((T,), N, n * n, layout) for _ in range(3)]
 
@@ -101,9 +123,10 @@ def config3(layout, N, T):
     ms = timeit(bwd)
     assert not st.any()
     sm = kf_oracle.rts_smoother_tracks(ref[0], ref[1], F, Q, tracks=range(4))
-    Ps = E.from_records(so[1], layout, 1, (n, n))[:, sample]
-    par = rel(Ps.reshape(-1, n * n), sm[1].reshape(-1, n * n))
-    emit(f"C3 rts_smoother n=9 {layout}", N * T, "track-steps", ms, 8 * (2 * n + 4 * n * n), parity_max_rel=par)
+    par = max(rel(pick(so[k], r).reshape(-1, int(np.prod(r))), sm[k].reshape(-1, int(np.prod(r))))
+              for k, r in ((0, (n,)), (1, (n, n)), (2, (n, n)), (3, (n, n))))
+    emit(f"C3 rts_smoother n=9 {layout}", N * T, "track-steps", ms, 8 * (2 * n + 4 * n * n), parity_max_rel=par,
+         kernel_fn="fk::rts_ml_kernel<9> (three lanes per track)", config="configs[2]")
 
 
 def config_kf(layout, n, m, N, T):
@@ -380,7 +403,8 @@ def config_ukf(layout, n, m, N, T):
     emit(f"fused linear UKF smoother n={n} N={N} {layout}", N * T, "track-steps", ms, 8 * (2 * n + 3 * n * n), parity_max_rel=par)
 
 
-def config4(layout, N, T):
+def config4(layout, N, T, sizes=(1, 10, 50)):
+    """sizes: the standalone sigma_points / unscented_transform launches run at N x each of these (bench.py: (1,))"""
     import torch
     from filterpy_amd import _engine as E
     from oracle import ukf_oracle
@@ -398,7 +422,7 @@ def config4(layout, N, T):
     dev = torch.device("cuda")
     g = torch.Generator(device=dev)
     g.manual_seed(4)
-    for NN in (N, 10 * N, 50 * N):          # 50N = 5e6 tracks: the (2n+1)n record slab stays below the 4 GiB addressing limit
+    for NN in [N * k_ for k_ in sizes]:     # 50N = 5e6 tracks: the (2n+1)n record slab stays below the 4 GiB addressing limit
         x = torch.randn((NN, n) if layout == "aos" else (n, NN), generator=g, device=dev, dtype=torch.float64)
         P = (10.0 * torch.eye(n, dtype=torch.float64, device=dev)).reshape(1, n * n).repeat(NN, 1)
         P = P.contiguous() if layout == "aos" else P.T.contiguous()
@@ -406,9 +430,24 @@ def config4(layout, N, T):
         xo, Po = E.alloc_records((), NN, n, layout), E.alloc_records((), NN, n * n, layout)
         dWm, dWc, dQ = E.dev(Wm), E.dev(Wc), E.dev(Q)
         ms = timeit(lambda: E.ut_sigma_points(n, NN, layout, lam + n, x, P, sig))
-        emit(f"C4 sigma_points n=6 N={NN} {layout}", NN, "tracks", ms, 8 * (n + n * n + k * n))
+        par = None
+        if NN == N:                         # the standalone blocks against the oracle on a sample (every track: tests/test_gpu_baseline_configs.py)
+            smp = [0, 63, 64, NN - 1]
+            xh = (x[smp] if layout == "aos" else x[:, smp].T).cpu().numpy()
+            sg = (sig[smp] if layout == "aos" else sig[:, smp].T).cpu().numpy().reshape(len(smp), k, n)
+            par = max(rel(sg[i], ukf_oracle.merwe_sigma_points(xh[i], 10.0 * np.eye(n), alpha, kappa)) for i in range(len(smp)))
+        emit(f"C4 sigma_points n=6 N={NN} {layout}", NN, "tracks", ms, 8 * (n + n * n + k * n), kernel_fn="fk::sigma_kernel<6>",
+             config="configs[3]", **({"parity_max_rel": par} if par is not None else {}))
         ms = timeit(lambda: E.ut_transform(n, k, NN, layout, sig, dWm, dWc, dQ, xo, Po))
-        emit(f"C4 unscented_transform n=6 N={NN} {layout}", NN, "tracks", ms, 8 * (k * n + n + n * n))
+        if NN == N:
+            xg = (xo[smp] if layout == "aos" else xo[:, smp].T).cpu().numpy()
+            Pg = (Po[smp] if layout == "aos" else Po[:, smp].T).cpu().numpy().reshape(len(smp), n, n)
+            par = 0.0
+            for i in range(len(smp)):
+                xr, Pr = ukf_oracle.unscented_transform(sg[i], Wm, Wc, Q)
+                par = max(par, rel(xg[i][None], xr[None]), rel(Pg[i].reshape(1, -1), Pr.reshape(1, -1)))
+        emit(f"C4 unscented_transform n=6 N={NN} {layout}", NN, "tracks", ms, 8 * (k * n + n + n * n), kernel_fn="fk::ut_reg_kernel<6>",
+             config="configs[3]", **({"parity_max_rel": par} if NN == N else {}))
     # fused linear UKF over T steps
     z = torch.randn((T, N, m) if layout == "aos" else (T, m, N), generator=g, device=dev, dtype=torch.float64)
     x0 = torch.randn((N, n) if layout == "aos" else (n, N), generator=g, device=dev, dtype=torch.float64)
@@ -421,11 +460,13 @@ def config4(layout, N, T):
 
     paired = E.pair_weights(Wm, Wc, n)      # looked at once, outside the timed calls (Merwe's weights: True)
 
-    def run():
+    def reset():
         x.copy_(x0)
         P.copy_(P0)
+
+    def run():
         E.ukf_linear_batch(n, m, N, T, layout, lam + n, *dd, z, x, P, means=means, covs=covs, status=st, paired=paired)
-    ms = timeit(run)
+    ms = timeit(run, pre=reset)
     assert not st.any()
     trk = 7
     zs_h = (z[:, trk] if layout == "aos" else z[:, :, trk]).cpu().numpy()
@@ -435,15 +476,16 @@ def config4(layout, N, T):
     mu = E.from_records(means, layout, 1, (n,))[:, trk]
     cov = E.from_records(covs, layout, 1, (n, n))[:, trk]
     par = max(rel(mu, mu_ref), rel(cov.reshape(T, -1), cov_ref.reshape(T, -1)))
-    emit(f"C4 fused linear UKF (6,3) {layout}", N * T, "track-steps", ms, 8 * (m + n + n * n), parity_max_rel=par)
+    emit(f"C4 fused linear UKF (6,3) {layout}", N * T, "track-steps", ms, 8 * (m + n + n * n), parity_max_rel=par,
+         kernel_fn="fk::ukf_linear_kernel<6,3> (pair-regrouped sums)", config="configs[3]")
 
 
-def config5():
+def config5(shapes=((1000, 8000), (125, 8000), (8, 8_000_000), (1, 8_000_000)), stratified=True):
     import torch
     from filterpy_amd import _engine as E
     from oracle import resample_oracle as ro
     dev = torch.device("cuda")
-    for Fn, Np in ((1000, 8000), (125, 8000), (8, 8_000_000), (1, 8_000_000)):
+    for Fn, Np in shapes:
         rs = np.random.RandomState(5)
         w = rs.rand(min(Fn, 8), Np)
         w /= w.sum(axis=1, keepdims=True)
@@ -452,11 +494,18 @@ def config5():
         idx = torch.empty((Fn, Np), dtype=torch.int32, device=dev)
         st = torch.zeros(Fn, dtype=torch.int32, device=dev)
         ms = timeit(lambda: E.resample_systematic(Fn, Np, wd, u, idx, st), warm=1, reps=3)
-        assert not st.any()
-        ref = ro.systematic_np(w[0], float(u[0]))
-        exact = bool(np.array_equal(idx[0].cpu().numpy(), ref))
-        emit(f"C5 systematic_resample {Fn} filters x {Np} particles", Fn * Np, "particles", ms, 12, bit_exact=exact)
-        if Np <= 8000:
+        flagged = int((st != 0).sum())      # (a position >= cumsum[-1]: the reference's IndexError; the index stored is N - 1)
+        # bit-exact against the merge loop (C restatement of resampling.py:139-149): the first, one in the middle and the last
+        # filter of the call, every index
+        exact = True
+        uh = u.cpu().numpy()
+        for f in sorted({0, Fn // 2, Fn - 1}):
+            ref = np.minimum(ro.systematic_np(w[f % w.shape[0]], float(uh[f])), Np - 1)
+            exact = exact and bool(np.array_equal(idx[f].cpu().numpy(), ref))
+        emit(f"C5 systematic_resample {Fn} filters x {Np} particles", Fn * Np, "particles", ms, 12, bit_exact=exact, status_flagged=flagged,
+             kernel_fn="fk::resample_whole_quick_kernel" if Np <= 8192 else "fk::resample_onepass_kernel (+ its two guard launches)",
+             config="configs[4]")
+        if Np <= 8000 and stratified:
             us = E.dev(rs.rand(Fn, Np))
             ms = timeit(lambda: E.resample_stratified(Fn, Np, wd, us, idx, st), warm=1, reps=3)
             emit(f"C5 stratified_resample {Fn} filters x {Np} particles", Fn * Np, "particles", ms, 20)
