@@ -448,7 +448,7 @@ def main():
                          "API KalmanFilterBank.batch_filter(device_outputs=True, ...).  auto (default) = the API called without "
                          "further arguments: what a caller gets without reading docs/PLACEMENT.md -- at this size (dim_x <= 4, "
                          "histories of 256 MiB and more) two arrays placed in HBM by timing this launch on candidate buffers "
-                         "(filterpy_amd/placement.py: placed_pair; ~1 s once per shape, up to 11 buffers allocated while probing, the "
+                         "(filterpy_amd/placement.py: placed_pair; once per shape, candidates one at a time -- at most 11 / half of the free memory --, stopping at the first fast pair; the "
                          "losers freed), the interleaved array where that cannot run; interleave: placement='interleave', both "
                          "histories in ONE array, a track's posterior and prior record side by side (FK_KF_FLAG_COV_INTERLEAVED); "
                          "probe: placement='probe' (like auto, falling back to two plain arrays); none: cov_interleave=False, two "
@@ -576,6 +576,7 @@ def main():
                 a_ = None if args.placement == "auto" else torch.empty(csize, dtype=torch.uint8, device=device)
                 b_ = None if args.placement == "auto" else torch.empty(csize, dtype=torch.uint8, device=device)
                 info = {"method": "plain allocation (probe failed)", "error": repr(exc)[:200]}
+            torch.cuda.empty_cache()                 # (the probe's losers sit in torch's cache: this process has other uses for the memory)
             if a_ is None:                           # auto, like the API: the interleaved array where the probe cannot run
                 cov2, covs, covs_p = E.alloc_cov_pair(T, N, n, layout, device)
                 desc["flags"] = _abi.FK_KF_FLAG_COV_INTERLEAVED

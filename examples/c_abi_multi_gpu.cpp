@@ -63,7 +63,7 @@ int main(int argc, char **argv)
     int ndev = 0;
     HIP_OK(hipGetDeviceCount(&ndev));
     if (ndev < 1) { fprintf(stderr, "no GPU\n"); return 1; }
-    if (fk_abi_version() < 3 || strcmp(fk_build_arch(), "gfx950") != 0) { fprintf(stderr, "unexpected library\n"); return 1; }
+    if (fk_abi_version() != FK_ABI_VERSION || strcmp(fk_build_arch(), "gfx950") != 0) { fprintf(stderr, "unexpected library\n"); return 1; }
     const double F[16] = {1, 1, 0, 0, 0, 1, 0, 0, 0, 0, 1, 1, 0, 0, 0, 1};
     const double Hm[8] = {1, 0, 0, 0, 0, 0, 1, 0};
     const double Q[16] = {.0025, .005, 0, 0, .005, .01, 0, 0, 0, 0, .0025, .005, 0, 0, .005, .01};

@@ -32,6 +32,10 @@ class fk_kf_desc(ctypes.Structure):
 
 FK_KF_FLAG_R_JOSEPH_DIAG = 1
 FK_KF_FLAG_COV_INTERLEAVED = 2
+# a caller-supplied inverse (KalmanFilter.inv / rts_smoother(inv=...)): fk_kf_update_f64 / fk_kf_rts_f64 cut at the callable
+FK_KF_FLAG_S_ONLY, FK_KF_FLAG_SI_GIVEN, FK_KF_FLAG_PP_ONLY, FK_KF_FLAG_PPINV_GIVEN = 4, 8, 16, 32
+
+FK_ABI_VERSION = 4          # include/filterhip.h: the library must report exactly this
 
 
 class fk_kf_extras(ctypes.Structure):
@@ -104,8 +108,20 @@ def lib():
                 f"{LIB_PATH} not found: build it with `make -C filterpy_amd/csrc` "
                 "(or __graft_entry__.build()). filterpy_amd has no CPU fallback.")
         handle = ctypes.CDLL(LIB_PATH)
+        # the version FIRST: a stale library (an older checkout's build) must say "rebuild", not die on a missing symbol
+        try:
+            handle.fk_abi_version.restype, handle.fk_abi_version.argtypes = ctypes.c_int, []
+            have = handle.fk_abi_version()
+        except AttributeError:
+            have = None
+        if have != FK_ABI_VERSION:
+            raise FilterHipError(f"{LIB_PATH} reports ABI version {have}, this package binds version {FK_ABI_VERSION} "
+                                 "(include/filterhip.h): rebuild the library (`make -C filterpy_amd/csrc` or __graft_entry__.build())")
         for name, (res, args) in SIGNATURES.items():
-            fn = getattr(handle, name)     # AttributeError if the library lacks a declared symbol
+            try:
+                fn = getattr(handle, name)
+            except AttributeError:
+                raise FilterHipError(f"{LIB_PATH} lacks {name}, which include/filterhip.h declares: rebuild the library") from None
             fn.restype, fn.argtypes = res, args
         _lib = handle
     return _lib

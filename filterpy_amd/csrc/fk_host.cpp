@@ -1,6 +1,7 @@
 // fk_host.cpp -- host-side plumbing of libfilterhip: error capture and ABI utilities.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/filterhip.h"
@@ -25,6 +26,25 @@ int check_launch(const char *what)
     snprintf(buf, sizeof(buf), "%s: %s", what, hipGetErrorString(e));
     set_last_error(buf);
     return FK_ERR_LAUNCH;
+}
+
+// Where the several-lane fused UKF (ukf_mlg.hip) takes over from the one-lane kernels (ukf_kernels.hip: FK_UKF_MLG=0 turns it off,
+// FK_UKF_MLG_MIN_NX / FK_UKF_MLG_RTS_MIN_NX = 7..10 move the filter's / the smoother's lower bound).  Read ONCE per process, here:
+// every part of ukf_kernels.hip and fk_ukf_linear_supported share this snapshot.
+struct UkfMlgRoute { int fwd_min, rts_min; };
+UkfMlgRoute ukf_mlg_route()
+{
+    static const UkfMlgRoute v = [] {
+        const char *on = getenv("FK_UKF_MLG");
+        if (on && on[0] == '0') return UkfMlgRoute{99, 99};
+        auto knob = [](const char *name, int dflt) {
+            const char *mn = getenv(name);
+            const int m = mn ? atoi(mn) : dflt;
+            return m >= 7 && m <= 10 ? m : dflt;
+        };
+        return UkfMlgRoute{knob("FK_UKF_MLG_MIN_NX", 10), knob("FK_UKF_MLG_RTS_MIN_NX", 7)};
+    }();
+    return v;
 }
 
 }  // namespace fk

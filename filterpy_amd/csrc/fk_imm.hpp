@@ -91,6 +91,22 @@ FK_HD void imm_predict(double (&xs)[NM][NX], double (&Ps)[NM][NX * (NX + 1) / 2]
             mx[j][r] = acc;
         }
     }
+#if defined(FK_ROLLED) && FK_ROLLED
+    // rolled builds (the bank in scratch memory): the spreads are formed where they are used -- the same subtraction, one
+    // instruction instead of a scratch read, and no NM x NM x NX array (32 KB per lane for a bank of sixteen (16, 8) filters)
+    (void)y;
+    FK_UNROLL for (int r = 0; r < NX; ++r) {
+        FK_UNROLL for (int c = r; c < NX; ++c) {
+            double acc[NM];
+            FK_UNROLL for (int j = 0; j < NM; ++j) {
+                acc[j] = 0.0;
+                FK_UNROLL for (int i = 0; i < NM; ++i)
+                    acc[j] = fma(w[i][j], fma(xs[i][r] - mx[j][r], xs[i][c] - mx[j][c], Ps[i][sym_idx<NX>(r, c)]), acc[j]);
+            }
+            FK_UNROLL for (int j = 0; j < NM; ++j) Ps[j][sym_idx<NX>(r, c)] = acc[j];
+        }
+    }
+#else
     FK_UNROLL for (int j = 0; j < NM; ++j)
         FK_UNROLL for (int i = 0; i < NM; ++i)
             FK_UNROLL for (int r = 0; r < NX; ++r) y[i][j][r] = xs[i][r] - mx[j][r];
@@ -107,6 +123,7 @@ FK_HD void imm_predict(double (&xs)[NM][NX], double (&Ps)[NM][NX * (NX + 1) / 2]
         }
         FK_STAGE();
     }
+#endif
     FK_UNROLL for (int j = 0; j < NM; ++j) {
         FK_UNROLL for (int r = 0; r < NX; ++r) xs[j][r] = mx[j][r];
         kf_predict_sym<NX>(xs[j], Ps[j], mods[j], 1.0);

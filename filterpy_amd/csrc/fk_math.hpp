@@ -378,6 +378,93 @@ FK_HD int kf_update(double (&x)[NX], double (&P)[NX * NX], const double (&z)[NZ]
     return st;
 }
 
+// ---- a caller-supplied inverse (KalmanFilter.inv = numpy.linalg.pinv, kalman_filter.py:363,434,541) ----------------------
+// The reference calls whatever `self.inv` names on S; a drop-in cannot run a Python callable inside a kernel, so update() is cut
+// at that call: kf_innovation forms y and S (:533-540), the host applies the callable, kf_update_given_si takes its result --
+// K = PHT SI (:545), x += K y (:549), the Joseph form (:555-556) in kf_update's operation order.  No factorisation, no status.
+template <int NX, int NZ, class Model>
+FK_HD void kf_innovation(const double (&x)[NX], const double (&P)[NX * NX], const double (&z)[NZ], const Model &M,
+                         double (&PHT)[NX * NZ], double (&y)[NZ], double (&S)[NZ * NZ])
+{
+    FK_UNROLL for (int r = 0; r < NZ; ++r) {
+        double h[NX];
+        M.rowH(r, h);
+        y[r] = z[r] - dot<NX>(h, x);
+        FK_UNROLL for (int i = 0; i < NX; ++i) {
+            double acc = P[i * NX] * h[0];
+            FK_UNROLL for (int k = 1; k < NX; ++k) acc = fma(P[i * NX + k], h[k], acc);
+            PHT[i * NZ + r] = acc;
+        }
+        FK_STAGE();
+    }
+    FK_UNROLL for (int r = 0; r < NZ; ++r) {
+        double h[NX], rr[NZ];
+        M.rowH(r, h);
+        M.rowR(r, rr);
+        FK_UNROLL for (int c = 0; c < NZ; ++c) {
+            double acc = h[0] * PHT[c];
+            FK_UNROLL for (int k = 1; k < NX; ++k) acc = fma(h[k], PHT[k * NZ + c], acc);
+            S[r * NZ + c] = acc + rr[c];
+        }
+        FK_STAGE();
+    }
+}
+
+template <int NX, int NZ, class Model>
+FK_HD void kf_update_given_si(double (&x)[NX], double (&P)[NX * NX], const double (&z)[NZ], const Model &M,
+                              const double (&SI)[NZ * NZ], double (&K)[NX * NZ], double (&y)[NZ], double (&S)[NZ * NZ],
+                              bool rj_diag = false)
+{
+    double PHT[NX * NZ];
+    kf_innovation<NX, NZ>(x, P, z, M, PHT, y, S);
+    FK_UNROLL for (int i = 0; i < NX; ++i) {
+        FK_UNROLL for (int c = 0; c < NZ; ++c) {
+            double acc = PHT[i * NZ] * SI[c];
+            FK_UNROLL for (int k = 1; k < NZ; ++k) acc = fma(PHT[i * NZ + k], SI[k * NZ + c], acc);
+            K[i * NZ + c] = acc;
+        }
+    }
+    FK_STAGE();
+    FK_UNROLL for (int i = 0; i < NX; ++i) {
+        double acc = x[i];
+        FK_UNROLL for (int k = 0; k < NZ; ++k) acc = fma(K[i * NZ + k], y[k], acc);
+        x[i] = acc;
+    }
+    double IKH[NX * NX];
+    FK_UNROLL for (int i = 0; i < NX; ++i)
+        FK_UNROLL for (int j = 0; j < NX; ++j) IKH[i * NX + j] = (i == j) ? 1.0 : 0.0;
+    FK_UNROLL for (int r = 0; r < NZ; ++r) {
+        double h[NX];
+        M.rowH(r, h);
+        FK_UNROLL for (int i = 0; i < NX; ++i)
+            FK_UNROLL for (int j = 0; j < NX; ++j) IKH[i * NX + j] = fma(-K[i * NZ + r], h[j], IKH[i * NX + j]);
+        FK_STAGE();
+    }
+    double T1[NX * NX];
+    matmul<NX, NX, NX>(IKH, P, T1);
+    FK_STAGE();
+    double KR[NX * NZ];
+    FK_UNROLL for (int i = 0; i < NX * NZ; ++i) KR[i] = 0.0;
+    FK_UNROLL for (int r = 0; r < NZ; ++r) {
+        double rr[NZ];
+        M.rowR(r, rr);
+        FK_UNROLL for (int c = 0; c < NZ; ++c) rr[c] = (rj_diag && c != r) ? 0.0 : rr[c];
+        FK_UNROLL for (int i = 0; i < NX; ++i)
+            FK_UNROLL for (int c = 0; c < NZ; ++c)
+                KR[i * NZ + c] = (r == 0) ? K[i * NZ] * rr[c] : fma(K[i * NZ + r], rr[c], KR[i * NZ + c]);
+    }
+    FK_STAGE();
+    FK_UNROLL for (int i = 0; i < NX; ++i) {
+        FK_UNROLL for (int j = 0; j < NX; ++j) {
+            double acc = T1[i * NX] * IKH[j * NX];
+            FK_UNROLL for (int k = 1; k < NX; ++k) acc = fma(T1[i * NX + k], IKH[j * NX + k], acc);
+            FK_UNROLL for (int k = 0; k < NZ; ++k) acc = fma(KR[i * NZ + k], K[j * NZ + k], acc);
+            P[i * NX + j] = acc;
+        }
+        FK_STAGE();
+    }
+}
+
 // S^-1 from the factorisation produced inside kf_update (only for the optional SI output).
 template <int NZ>
 FK_HD void inv_from_ldlt(const double (&Lf)[NZ * NZ], const double (&dinv)[NZ], double (&SI)[NZ * NZ])
@@ -466,6 +553,90 @@ FK_HD int rts_step(double (&x)[NX], double (&P)[NX * NX], const double (&xn)[NX]
         }
     }
     return st;
+}
+
+// rts_smoother(inv=...) (kalman_filter.py:995, 1069): the backward recursion cut at the callable like update() above.  Pp[k] =
+// F P[k] F' + Q depends on the FILTERED covariance only, so one pass stores every Pp (rts_pp_only), the host inverts them, and
+// the sweep takes the inverses (rts_step_given: K = (P F') PpInv, then :1071-1072 in rts_step's order).
+template <int NX, class Model>
+FK_HD void rts_pp_only(const double (&P)[NX * NX], const Model &M, double (&Pp)[NX * NX])
+{
+    double FP[NX * NX];
+    FK_UNROLL for (int i = 0; i < NX; ++i) {
+        double f[NX];
+        M.rowF(i, f);
+        FK_UNROLL for (int j = 0; j < NX; ++j) {
+            double acc = f[0] * P[j];
+            FK_UNROLL for (int k = 1; k < NX; ++k) acc = fma(f[k], P[k * NX + j], acc);
+            FP[i * NX + j] = acc;
+        }
+        FK_STAGE();
+    }
+    FK_UNROLL for (int j = 0; j < NX; ++j) {
+        double f[NX];
+        M.rowF(j, f);
+        FK_UNROLL for (int i = 0; i < NX; ++i) {
+            double acc = FP[i * NX] * f[0];
+            FK_UNROLL for (int k = 1; k < NX; ++k) acc = fma(FP[i * NX + k], f[k], acc);
+            Pp[i * NX + j] = acc;
+        }
+        FK_STAGE();
+    }
+    FK_UNROLL for (int i = 0; i < NX; ++i) {
+        double q[NX];
+        M.rowQ(i, q);
+        FK_UNROLL for (int j = 0; j < NX; ++j) Pp[i * NX + j] += q[j];
+    }
+}
+
+// K: in = the caller's inv(Pp[k]), out = the gain
+template <int NX, class Model>
+FK_HD void rts_step_given(double (&x)[NX], double (&P)[NX * NX], const double (&xn)[NX], const double (&Pn)[NX * NX],
+                          const Model &M, double (&K)[NX * NX], double (&Pp)[NX * NX])
+{
+    rts_pp_only<NX>(P, M, Pp);
+    double Fx[NX], PFt[NX * NX];
+    FK_UNROLL for (int i = 0; i < NX; ++i) {
+        double f[NX];
+        M.rowF(i, f);
+        Fx[i] = dot<NX>(f, x);
+        FK_UNROLL for (int r = 0; r < NX; ++r) {
+            double acc = P[r * NX] * f[0];
+            FK_UNROLL for (int k = 1; k < NX; ++k) acc = fma(P[r * NX + k], f[k], acc);
+            PFt[r * NX + i] = acc;
+        }
+        FK_STAGE();
+    }
+    double G[NX * NX];
+    FK_UNROLL for (int i = 0; i < NX; ++i)
+        FK_UNROLL for (int j = 0; j < NX; ++j) {
+            double acc = PFt[i * NX] * K[j];
+            FK_UNROLL for (int k = 1; k < NX; ++k) acc = fma(PFt[i * NX + k], K[k * NX + j], acc);
+            G[i * NX + j] = acc;
+        }
+    FK_UNROLL for (int i = 0; i < NX * NX; ++i) K[i] = G[i];
+    FK_STAGE();
+    FK_UNROLL for (int i = 0; i < NX; ++i) {
+        double acc = x[i];
+        FK_UNROLL for (int k = 0; k < NX; ++k) acc = fma(K[i * NX + k], xn[k] - Fx[k], acc);
+        x[i] = acc;
+    }
+    double KD[NX * NX];
+    FK_UNROLL for (int i = 0; i < NX; ++i) {
+        FK_UNROLL for (int j = 0; j < NX; ++j) {
+            double acc = K[i * NX] * (Pn[j] - Pp[j]);
+            FK_UNROLL for (int k = 1; k < NX; ++k) acc = fma(K[i * NX + k], Pn[k * NX + j] - Pp[k * NX + j], acc);
+            KD[i * NX + j] = acc;
+        }
+    }
+    FK_STAGE();
+    FK_UNROLL for (int i = 0; i < NX; ++i) {
+        FK_UNROLL for (int j = 0; j < NX; ++j) {
+            double acc = P[i * NX + j];
+            FK_UNROLL for (int k = 0; k < NX; ++k) acc = fma(KD[i * NX + k], K[j * NX + k], acc);
+            P[i * NX + j] = acc;
+        }
+    }
 }
 
 // ------------------------------------------------------------ sigma / UT --

@@ -36,8 +36,8 @@ extern "C" int fk_imm_batch_ex_f64(const fk_imm_desc *d, const double *F, const 
                                        int32_t *status, void *stream)
 {
     if (!d) return fail(FK_ERR_BAD_ARG, "desc is NULL");
-    if (d->n < 1 || d->n > 16 || d->m < 1 || d->m > 8 || d->n_models < 2 || d->n_models > 8)
-        return fail(FK_ERR_UNSUPPORTED, "IMM: dim_x 1..16, dim_z 1..8, 2..8 models");
+    if (d->n < 1 || d->n > 16 || d->m < 1 || d->m > 8 || d->n_models < 2 || d->n_models > 16)
+        return fail(FK_ERR_UNSUPPORTED, "IMM: dim_x 1..16, dim_z 1..8, 2..16 models");
     if (d->layout != FK_LAYOUT_AOS && d->layout != FK_LAYOUT_SOA) return fail(FK_ERR_BAD_ARG, "IMM: bad layout");
     if (d->phase < FK_IMM_STEP || d->phase > FK_IMM_UPDATE) return fail(FK_ERR_BAD_ARG, "IMM: bad phase");
     const bool needs_z = (d->phase == FK_IMM_STEP && d->T > 0) || d->phase == FK_IMM_UPDATE;
@@ -81,6 +81,17 @@ extern "C" int fk_imm_batch_ex_f64(const fk_imm_desc *d, const double *F, const 
                 if (cls == 0) launch_imm_2_1_3(b, layout, mask, s);
                 else if (cls == 1) launch_imm_4_2_3(b, layout, mask, s);
                 else launch_imm_6_3_3(b, layout, mask, s);
+            }
+        } else if (n_models > 8) {                        // banks of 9..16 filters: the rolled general kernel, every size
+            switch (n_models) {
+            case 9: launch_imm_16_8_9(b, layout, mask, s); break;
+            case 10: launch_imm_16_8_10(b, layout, mask, s); break;
+            case 11: launch_imm_16_8_11(b, layout, mask, s); break;
+            case 12: launch_imm_16_8_12(b, layout, mask, s); break;
+            case 13: launch_imm_16_8_13(b, layout, mask, s); break;
+            case 14: launch_imm_16_8_14(b, layout, mask, s); break;
+            case 15: launch_imm_16_8_15(b, layout, mask, s); break;
+            default: launch_imm_16_8_16(b, layout, mask, s); break;
             }
         } else if (b.n > 9 || b.m > 4) {                  // the rolled class (16, 8), round 4
             switch (n_models) {

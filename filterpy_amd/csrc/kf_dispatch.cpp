@@ -33,6 +33,8 @@ namespace fk {
 #undef FK_MLG_INST
 #undef FK_RMLG_INST
 
+int launch_kf_given(const KfArgs &, int, bool, int, hipStream_t);     // kf_given_inv.hip: update() / rts_smoother() around a
+int launch_rts_given(const RtsArgs &, int, bool, int, hipStream_t);   // caller-supplied inverse
 int launch_kf_ml_9_3(const KfArgs &, int, bool, int, hipStream_t);   // kf_ml.hip: three lanes per track
 int launch_rts_ml_9(const RtsArgs &, int, bool, hipStream_t);
 
@@ -150,7 +152,9 @@ static int check_desc(const fk_kf_desc *d)
     if (d->N < 0 || d->T < 0) return fail(FK_ERR_BAD_ARG, "N and T must be >= 0");
     if (d->layout != FK_LAYOUT_AOS && d->layout != FK_LAYOUT_SOA) return fail(FK_ERR_BAD_ARG, "bad layout");
     if (d->model_mode < 0 || d->model_mode > 3) return fail(FK_ERR_BAD_ARG, "bad model_mode");
-    if (d->flags & ~(FK_KF_FLAG_R_JOSEPH_DIAG | FK_KF_FLAG_COV_INTERLEAVED)) return fail(FK_ERR_BAD_ARG, "unknown desc flag");
+    if (d->flags & ~(FK_KF_FLAG_R_JOSEPH_DIAG | FK_KF_FLAG_COV_INTERLEAVED | FK_KF_FLAG_S_ONLY | FK_KF_FLAG_SI_GIVEN |
+                     FK_KF_FLAG_PP_ONLY | FK_KF_FLAG_PPINV_GIVEN))
+        return fail(FK_ERR_BAD_ARG, "unknown desc flag");
     // one step's record block is addressed with 32-bit byte offsets (fk_device.hpp).  NumPy order: the entry points cut a
     // larger bank into track windows themselves (kf_windows below); element-major: element e of a step sits e * N * 8 bytes
     // into it whatever the window, so there the caller has to split the bank
@@ -384,6 +388,18 @@ int fk_kf_update_f64(const fk_kf_desc *desc, const double *H, const double *R, c
     a.do_update = 1;
     fk_kf_desc d = *desc;
     d.nu = 0;
+    if (const int gm = desc->flags & (FK_KF_FLAG_S_ONLY | FK_KF_FLAG_SI_GIVEN)) {
+        // update() around a caller-supplied inverse (kf_given_inv.hip): one padded instantiation for every size
+        if (gm == (FK_KF_FLAG_S_ONLY | FK_KF_FLAG_SI_GIVEN)) return fail(FK_ERR_BAD_ARG, "FK_KF_FLAG_S_ONLY and FK_KF_FLAG_SI_GIVEN exclude each other");
+        if (gm == FK_KF_FLAG_S_ONLY && (!y || !S)) return fail(FK_ERR_BAD_ARG, "FK_KF_FLAG_S_ONLY: y and S must not be NULL");
+        if (gm == FK_KF_FLAG_SI_GIVEN && !SI) return fail(FK_ERR_BAD_ARG, "FK_KF_FLAG_SI_GIVEN: SI (the input) must not be NULL");
+        if (desc->n > 16 || desc->m > 8) return fail(FK_ERR_UNSUPPORTED, "dim_x/dim_z outside the compiled range (dim_x <= 16, dim_z <= 8)");
+        if (desc->N > kf_window_tracks(desc)) return fail(FK_ERR_UNSUPPORTED, "caller-supplied inverse: N * dim^2 * 8 bytes must stay below 4 GiB (split the bank)");
+        a.N = desc->N; a.n = desc->n; a.m = desc->m; a.i0 = 0; a.cnt = desc->N;
+        a.rj_diag = (desc->flags & FK_KF_FLAG_R_JOSEPH_DIAG) ? 1 : 0;
+        const bool uniform = (desc->model_mode == FK_MODEL_SHARED || desc->model_mode == FK_MODEL_PER_STEP);
+        return launch_kf_given(a, desc->layout, uniform, gm == FK_KF_FLAG_S_ONLY ? 1 : 2, (hipStream_t)stream);
+    }
     return run_kf(&d, a, stream);
 }
 
@@ -405,6 +421,15 @@ int fk_kf_rts_f64(const fk_kf_desc *desc, const double *F, const double *Q, cons
     a0.model_t = (desc->model_mode == FK_MODEL_PER_TRACK_STEP || desc->model_mode == FK_MODEL_PER_STEP) ? 1 : 0;
     a0.conv_off = index_convention == 0 ? 1 : 0;
     const bool uniform = (desc->model_mode == FK_MODEL_SHARED || desc->model_mode == FK_MODEL_PER_STEP);
+    if (const int gm = desc->flags & (FK_KF_FLAG_PP_ONLY | FK_KF_FLAG_PPINV_GIVEN)) {
+        // rts_smoother(inv=...) around a caller-supplied inverse (kf_given_inv.hip)
+        if (gm == (FK_KF_FLAG_PP_ONLY | FK_KF_FLAG_PPINV_GIVEN)) return fail(FK_ERR_BAD_ARG, "FK_KF_FLAG_PP_ONLY and FK_KF_FLAG_PPINV_GIVEN exclude each other");
+        if (gm == FK_KF_FLAG_PP_ONLY && !Pp) return fail(FK_ERR_BAD_ARG, "FK_KF_FLAG_PP_ONLY: Pp must not be NULL");
+        if (gm == FK_KF_FLAG_PPINV_GIVEN && !K) return fail(FK_ERR_BAD_ARG, "FK_KF_FLAG_PPINV_GIVEN: K (inverses in, gains out) must not be NULL");
+        if (desc->N > kf_window_tracks(desc)) return fail(FK_ERR_UNSUPPORTED, "caller-supplied inverse: N * dim^2 * 8 bytes must stay below 4 GiB (split the bank)");
+        a0.i0 = 0; a0.cnt = desc->N;
+        return launch_rts_given(a0, desc->layout, uniform, gm == FK_KF_FLAG_PP_ONLY ? 1 : 2, (hipStream_t)stream);
+    }
     // NumPy order: a bank whose per-step record block reaches 4 GiB is smoothed in track windows (see kf_window above)
     const long w = kf_window_tracks(desc);
     if (desc->layout == FK_LAYOUT_AOS && desc->N > w) {

@@ -1167,6 +1167,315 @@ resample_onepass_kernel(const OpArgs a)
     }
 }
 
+#include "resample_onepass2.inc"
+
+// ---- the chunk as round 3's kernel resolves it when the speculation does not apply: stage 1 -> stage 2 -> boundaries (quick /
+// zeros / general scan) -> emission -> end of the vector.  A verbatim copy of resample_onepass_kernel's body from "stage 1" on
+// (that kernel stays as it is: FK_OP_V2=0 is the A/B), out of line: resample_onepass2_kernel calls it for the chunks its fast
+// path declines -- a miss of the guess, a tie, the start of a vector, the last chunk, garbage -- so that those never cost the
+// fast path a register.  The eight weights are read again (L2); everything else is recomputed from them.
+template <bool STRATIFIED>
+__device__ OP2_SLOW_INLINE void op_chunk_slow(OpShared &sh, const double *a_w, const double *a_u, int32_t *a_idx, int32_t *a_status,
+                                                        OpCtl *a_ctl, OpDesc *a_desc, int *a_bad, const double a_delta, const long a_Np,
+                                                        const long a_nch, const int f, const int k, const double S_in, const int any_bad_in)
+{
+    // (the arguments one by one: an OpArgs by value would travel through scratch memory, written at the top of the CALLER)
+    OpArgs a = {};
+    a.w = a_w; a.u = a_u; a.idx = a_idx; a.status = a_status; a.ctl = a_ctl; a.desc = a_desc; a.bad = a_bad;
+    a.delta = a_delta; a.Np = a_Np; a.nch = a_nch;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long Np = a.Np, nch = a.nch;
+    int *win = sh.win();
+    const double *wf = a.w + (long)f * Np;
+    int32_t *of = a.idx + (long)f * Np;
+    const double u_sys = STRATIFIED ? 0.0 : a.u[f];
+    const double *u_str = STRATIFIED ? a.u + (long)f * Np : nullptr;
+    const double Nd = (double)Np, halfNd = 0.5 * Nd;
+    OpDesc *d = a.desc + (long)f * nch;
+    unsigned *abort_word = &a.ctl->abort;
+    const long base = (long)k * OP_TILE;
+    const int len = (int)((Np - base) < OP_TILE ? (Np - base) : OP_TILE);
+    double w8[OP_ITEMS];
+    FK_UNROLL for (int q = 0; q < OP_ITEMS; ++q) {
+        const int j = tid * OP_ITEMS + q;
+        const double t = wf[base + (j < len ? j : 0)];
+        w8[q] = j < len ? t : 0.0;
+    }
+    const bool any_bad = any_bad_in != 0;
+    const double S = any_bad ? __builtin_nan("") : S_in;
+    double E[OP_ITEMS];
+    double excl = 0.0, I = 0.0;
+    int eu = 0;
+    const bool hit = false;
+    __syncthreads();                                                       // everybody has left the fast path's LDS slots
+    init_window(win, tid);
+    bool at_start = false;
+    if (!hit) {
+    // ---- stage 1: approximate carry-in --------------------------------------------------------------------
+    if (wave == 0) {
+        double A = 0.0;
+        if (k > 0) {
+            if (lane == 0) st_agent(&d[k].approx, pack_approx(S, 1));
+            A = lookback_approx(d, k, lane, abort_word);
+        }
+        if (lane == 0) {
+            st_agent(&d[k].approx, pack_approx(A + S, 2));
+            sh.bc_d[0] = A;
+        }
+    }
+    __syncthreads();                                                                          // (B)
+    const double A = sh.bc_d[0];
+
+    // ---- what stage 1 tells this chunk --------------------------------------------------------------------
+    const bool poison = !(A >= 0.0 && S >= 0.0 && A + S < 0x1p1000);
+    if (poison) {                                                          // uniform
+        // a weight this path does not take (negative, NaN, huge) here or upstream: the whole filter is redone by
+        // resample_literal_kernel; successors only need to learn that quickly
+        if (tid == 0) {
+            publish_carry(&d[k], __builtin_nan(""));
+            if (any_bad) __hip_atomic_store(&a.bad[f], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (a.status && __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                atomicOr(&a.status[f], ST_INTERNAL);
+        }
+        return;
+    }
+    // A == 0 means EXACTLY: every weight before this chunk is +0.0 (they are all >= 0), so the carry-in is 0 and
+    // needs no stage 2; with S == 0 as well the chunk is empty-handed: carry-out 0, no slots
+    at_start = (k == 0) || (A == 0.0);
+    bool clean = false;
+    {
+        const double lo = A * (1.0 - a.delta), hi = (A + S) * (1.0 + a.delta);
+        if (lo > OP_SANE_LO && hi < OP_SANE_HI && ulp_exp(lo) == ulp_exp(hi)) {
+            clean = true;
+            eu = ulp_exp(lo);
+        }
+    }
+    // increments in the promised binade (fk_exact_scan.hpp, fast_inc): inc = floor(w / ulp + 1/2) unless the
+    // remainder is exactly half an ulp -- such a chunk, and one whose sums reach 2^53 (which is also where t + 1/2
+    // stops being exact, and then the test fires by itself), leaves this path.  E[q] = inclusive sums of the thread.
+    excl = 0.0;
+    I = 0.0;
+    bool fast = false;
+    if (clean) {                                                           // uniform
+        bool tie = false;
+        double run = 0.0;
+        FK_UNROLL for (int q = 0; q < OP_ITEMS; ++q) {
+            const double x = scale2(w8[q], -eu) + 0.5;
+            const double i = floor(x);
+            tie = tie || (i == x);
+            run += i;
+            E[q] = run;
+        }
+        const double winc = wave_incl_sum(run);
+        if (lane == 63) sh.wsum[wave] = winc;
+        const int any_tie = __syncthreads_or(tie ? 1 : 0);                                    // (C)
+        excl = winc - run;                                                 // exact: everything is an integer < 2^53 ...
+        FK_UNROLL for (int wv = 0; wv < OP_THREADS / 64; ++wv) {
+            if (wv < wave) excl += sh.wsum[wv];
+            I += sh.wsum[wv];
+        }
+        fast = !any_tie && I < 0x1p53;                                     // ... or this says so
+    } else {
+        FK_UNROLL for (int q = 0; q < OP_ITEMS; ++q) E[q] = 0.0;
+    }
+
+    // ---- stage 2: exact carry-in ---------------------------------------------------------------------------
+    if (wave == 0) {
+        double c_in = 0.0;
+        bool ok = true;
+        if (!at_start) {
+            if (fast && lane == 0) st_agent(&d[k].exact, pack_exact(1, eu, I));
+            c_in = lookback_exact(d, k, fast, eu, lane, abort_word, ok);
+        }
+        // carry-out of a chunk that stayed inside its binade: known right now, successors need not wait for the scan
+        int quick = 0;
+        if (ok && fast && c_in > OP_SANE_LO && c_in < OP_SANE_HI && ulp_exp(c_in) == eu) {
+            const double Cout = scale2(c_in, -eu) + I;
+            if (Cout < 0x1p53) {
+                quick = 1;
+                if (lane == 0) publish_carry(&d[k], scale2(Cout, eu));
+            }
+        }
+        if (ok && at_start && S == 0.0) {
+            quick = 2;                                                     // still nothing but zeros
+            if (lane == 0) publish_carry(&d[k], 0.0);
+        }
+        // first slot of this chunk: everything below n(carry-in) belongs to earlier chunks
+        const int out_lo = at_start ? 0 : n_boundary_fast<STRATIFIED>(c_in, (int)Np, Nd, halfNd, u_sys, u_str);
+        if (lane == 0) {
+            sh.bc_d[1] = c_in;
+            sh.bc_i[3] = ok ? quick : -1;
+            sh.bc_i[4] = out_lo;
+        }
+    }
+    __syncthreads();                                                                          // (D)
+    }   // !hit
+    const double c_in = sh.bc_d[1];
+    const int quick = __builtin_amdgcn_readfirstlane(sh.bc_i[3]);
+    const int u_lo = __builtin_amdgcn_readfirstlane(sh.bc_i[4]);
+    if (quick < 0) {                                                       // abort: a predecessor never published
+        if (tid == 0 && a.status) atomicOr(&a.status[f], ST_INTERNAL);
+        return;
+    }
+
+    // ---- slot boundaries: weight j owns the slots [n_{j-1}, n_j), n_j = n(cs_j)  (fk_resample_math.hpp) -----------
+    int nb[OP_ITEMS];
+    bool win_ready = true;
+    if (quick == 1) {                                                      // uniform
+        // cs_j = (C0 + E_j) ulp exactly, so N cs_j - u = fma(E_j, N ulp, C0 N ulp - u): ONE fma per weight gives the
+        // estimate whose ceiling is n_j whenever it is not within eps of an integer (n_boundary_fast's argument:
+        // here two roundings of 2^-22 slots each, the same budget); the rare rest takes the exact tests on cs_j.
+        const double ulp = scale2(1.0, eu), C0 = scale2(c_in, -eu), Nu = scale2(Nd, eu);
+        const double K = __builtin_fma(C0, Nu, STRATIFIED ? 0.0 : -u_sys);
+        unsigned unsure = 0;
+        FK_UNROLL for (int q = 0; q < OP_ITEMS; ++q) {
+            const double Et = excl + E[q];                                 // exact
+            const double e = __builtin_fma(Et, Nu, K);
+            // floor(e) + 1 without a v_floor_f64 / v_cvt_i32_f64 pair: m = e + 1.5 2^52 holds the nearest integer
+            // of e in its low mantissa bits (two's complement; -1 < e < Nd < 2^31 where the result is used), dd = e - nearest
+            const double m = e + 0x1.8p52;
+            const double dd = e - (m - 0x1.8p52);                          // exact, |dd| <= 1/2
+            const int ri = (int)(unsigned)double_to_bits(m);
+            bool sure = fabs(dd) > N_BOUNDARY_EPS && e < Nd;               // (= fr in (eps, 1 - eps))
+            int n = ri + (dd < 0.0 ? 0 : 1);
+            if (STRATIFIED) {
+                const int fl = ri - (dd < 0.0 ? 1 : 0);
+                const double fr = dd < 0.0 ? dd + 1.0 : dd;                // e - floor(e), exact
+                const double uf = u_str[e < Nd ? fl : 0];                  // e >= 0 here
+                const double gap = uf - fr;
+                sure = sure && (gap > N_BOUNDARY_EPS || gap < -N_BOUNDARY_EPS);
+                n = fl + (gap > 0.0 ? 0 : 1);
+            }
+            unsure |= sure ? 0u : (1u << q);
+            nb[q] = n;
+        }
+        if (unsure) {                                                      // about one weight in 10^5: the exact tests
+            // ONE inlined copy in a rolled loop; E[q] / nb[q] are picked and put back with selects (registers
+            // cannot be indexed)
+            _Pragma("nounroll") for (int q = 0; q < OP_ITEMS; ++q) {
+                if (!(unsure & (1u << q))) continue;
+                double Eq = E[0];
+                FK_UNROLL for (int r = 1; r < OP_ITEMS; ++r) Eq = (q == r) ? E[r] : Eq;
+                const int n = n_boundary<STRATIFIED>((C0 + (excl + Eq)) * ulp, (int)Np, Nd, halfNd, u_sys, u_str);
+                FK_UNROLL for (int r = 0; r < OP_ITEMS; ++r) nb[r] = (q == r) ? n : nb[r];
+            }
+        }
+#ifdef FK_OP_CLOCKS
+        FK_UNROLL for (int q = 0; q < OP_ITEMS; ++q) {
+            if (g_dbg_cs && tid * OP_ITEMS + q < len) {
+                g_dbg_cs[(long)f * Np + base + tid * OP_ITEMS + q] = (C0 + (excl + E[q])) * ulp;
+                g_dbg_n[(long)f * Np + base + tid * OP_ITEMS + q] = nb[q];
+            }
+        }
+#endif
+    } else if (quick == 2) {
+        FK_UNROLL for (int q = 0; q < OP_ITEMS; ++q) nb[q] = 0;
+    } else {
+        // general scan: the weights once more (L2), now into the padded LDS tile the scan works in
+        FK_UNROLL for (int q = 0; q < OP_ITEMS; ++q) {
+            const int j = tid * OP_ITEMS + q;
+            sh.tile[pad8(j)] = j < len ? wf[base + j] : 0.0;
+        }
+        __syncthreads();
+        const double c_out = general_cumsum(sh, len, c_in);
+        if (tid == 0) publish_carry(&d[k], c_out);
+        // (each thread reads back only its own slots, behind general_cumsum's final barrier; n_j goes into the low
+        // half of cs_j's slot so that this loop stays rolled)
+        int *nslot = reinterpret_cast<int *>(&sh.tile[pad8(tid * OP_ITEMS)]);
+        _Pragma("nounroll") for (int q = 0; q < OP_ITEMS; ++q) {
+            const int j = tid * OP_ITEMS + q;
+            const double c = j < len ? sh.tile[pad8(j)] : c_out;
+            const int n = n_boundary_fast<STRATIFIED>(c, (int)Np, Nd, halfNd, u_sys, u_str);
+            nslot[2 * q] = n;
+#ifdef FK_OP_CLOCKS
+            if (g_dbg_cs && j < len) {
+                g_dbg_cs[(long)f * Np + base + j] = c;
+                g_dbg_n[(long)f * Np + base + j] = n;
+            }
+#endif
+        }
+        FK_UNROLL for (int q = 0; q < OP_ITEMS; ++q) nb[q] = nslot[2 * q];
+        win_ready = false;                                                 // the tile overwrote the window
+    }
+    sh.nlast[tid] = nb[OP_ITEMS - 1];
+    __syncthreads();                                                                          // (E)
+    int nprev = tid == 0 ? u_lo : sh.nlast[tid - 1];
+    const int u_hi = __builtin_amdgcn_readfirstlane(sh.nlast[OP_THREADS - 1]);
+    // heads: the slot where each non-empty run starts (boundaries are non-decreasing for valid input)
+    int head[OP_ITEMS];
+    FK_UNROLL for (int q = 0; q < OP_ITEMS; ++q) {
+        head[q] = nb[q] > nprev ? nprev : -1;
+        nprev = nb[q] > nprev ? nb[q] : nprev;
+    }
+
+    // ---- emission: windows of OP_WIN slots; heads -> inclusive max-scan -> coalesced 16-byte stores --------------
+    // (slot numbers fit an int: Np < 2^31; everything about a window is wave-uniform and lives in SGPRs)
+    const int mis = (int)(((uintptr_t)of >> 2) & 3);
+    int seed = -1;
+    for (int wb = u_lo - ((mis + u_lo) & 3); u_hi > u_lo && wb < u_hi; wb += OP_WIN) {        // uniform
+        if (!win_ready) {
+            __syncthreads();                                               // everybody is done with the tile / the last window
+            init_window(win, tid);
+            __syncthreads();
+        }
+        win_ready = false;
+        int have = 0;
+        FK_UNROLL for (int q = 0; q < OP_ITEMS; ++q) {
+            const unsigned h = (unsigned)(head[q] - wb);                   // a head below wb wraps to a huge number
+            if (head[q] >= 0 && h < (unsigned)OP_WIN) {
+                win[h] = (int)base + tid * OP_ITEMS + q;
+                have = 1;
+            }
+        }
+        const int any_head = __syncthreads_or(have);                                          // (G)
+        const int lim = u_hi - wb;                                         // slots [max(first, 0), lim) are ours
+        const int first = u_lo - wb;
+        int32_t *ow = of + wb;                                             // uniform; 16-byte aligned
+        const int s0 = 12 * tid;
+        int x[12];
+        if (any_head) {                                                    // uniform
+            FK_UNROLL for (int g = 0; g < 3; ++g) {
+                const i32x4 t = *reinterpret_cast<const i32x4 *>(&win[s0 + 4 * g]);
+                x[4 * g + 0] = t.x;
+                x[4 * g + 1] = t.y;
+                x[4 * g + 2] = t.z;
+                x[4 * g + 3] = t.w;
+            }
+            FK_UNROLL for (int e = 1; e < 12; ++e) x[e] = x[e] > x[e - 1] ? x[e] : x[e - 1];
+            const int wincl = wave_incl_max(x[11]);
+            if (lane == 63) sh.wmax[wave] = wincl;
+            __syncthreads();
+            const int up = __shfl_up(wincl, 1, 64);
+            int pre = (lane == 0 || up < seed) ? seed : up;               // everything before this thread, this wave
+            FK_UNROLL for (int wv = 0; wv < OP_THREADS / 64; ++wv) {
+                const int t = sh.wmax[wv];
+                if (wv < wave) pre = pre > t ? pre : t;
+                seed = seed > t ? seed : t;                                // every thread: running max after this window
+            }
+            FK_UNROLL for (int e = 0; e < 12; ++e) x[e] = x[e] > pre ? x[e] : pre;
+        } else {
+            // the whole window lies inside one run (a weight owning more than OP_WIN slots): constant fill
+            FK_UNROLL for (int e = 0; e < 12; ++e) x[e] = seed;
+        }
+        if (s0 < lim) {
+            FK_UNROLL for (int g = 0; g < 3; ++g) {
+                const int sg = s0 + 4 * g;
+                if (sg >= first && sg + 3 < lim) *reinterpret_cast<i32x4 *>(&ow[sg]) = i32x4{x[4 * g], x[4 * g + 1], x[4 * g + 2], x[4 * g + 3]};
+                else {
+                    FK_UNROLL for (int e = 0; e < 4; ++e)
+                        if (sg + e >= first && sg + e < lim) ow[sg + e] = x[4 * g + e];
+                }
+            }
+        }
+    }
+
+    // ---- end of the vector: positions >= cumsum[-1] (the reference raises IndexError, resampling.py:109,145) --
+    if (k == nch - 1) {
+        for (long i = (long)u_hi + tid; i < Np; i += OP_THREADS) of[i] = (int32_t)(Np - 1);
+        if (tid == 0 && a.status && u_hi < (int)Np) atomicOr(&a.status[f], ST_OVERRUN);
+    }
+}
+
 // ---- short vectors: one workgroup per filter, its chunks in sequence, the carry in a register ------------------------
 // (Np < RS_PAR_MIN.  No tickets, no look-back, no workspace: the exact carry-in of a chunk is the carry-out of the one
 // before, so its binade is KNOWN and most chunks take the integer-increment path straight away; the chunks that cross
@@ -1674,6 +1983,27 @@ int onepass_launch(bool stratified, int64_t Fn, int64_t Np, const double *w, con
     if (const char *fv = getenv("FK_OP_FORCE_ABORT"); fv && fv[0] == '1') {
         static const unsigned one = 1u;
         if (hipMemcpyAsync(&a.ctl->abort, &one, sizeof(one), hipMemcpyHostToDevice, s) != hipSuccess) return FK_ERR_LAUNCH;
+    }
+    // Round 6: systematic calls on the static assignment with speculation run resample_onepass2_kernel (resample_onepass2.inc:
+    // the same protocol, the common chunk in fewer instructions and barriers); FK_OP_V2=0 keeps round 3's kernel (A/B, tests).
+    // pred_back: how far back a chunk looks for a PUBLISHED inclusive prefix to predict its binade from -- a chunk of the same
+    // vector that finished before this one started: 1.25 rounds of resident workgroups back, at least 16 chunks.
+    const char *v2 = getenv("FK_OP_V2");
+    if (!stratified && stat && spec && !(v2 && v2[0] == '0')) {
+        static int n_cu = 0;
+        if (!n_cu) {
+            int dev = 0;
+            hipDeviceProp_t prop;
+            n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+                       ? prop.multiProcessorCount : 256;
+        }
+        long back = (5L * FK_OP2_WAVES * n_cu / 4 + Fn - 1) / Fn + 2;      // (FK_OP2_WAVES workgroups per CU resident)
+        if (back < 16) back = 16;
+        if (const char *pb = getenv("FK_OP_PRED_BACK")) back = atol(pb);   // (0: never predict)
+        hipLaunchKernelGGL(resample_onepass2_kernel, grid, block, 0, s, a, (int)(back > 0x3fffffff ? 0x3fffffff : back));
+        hipLaunchKernelGGL((resample_literal_kernel<false>), dim3((unsigned)Fn), dim3(64), 0, s, a);
+        hipLaunchKernelGGL((resample_local_kernel<false, 3>), dim3((unsigned)Fn), block, 0, s, r);
+        return check_launch("resample_onepass2_kernel");
     }
     if (stratified) GO(true);
     else GO(false);

@@ -698,21 +698,11 @@ static int ukf_mlg_rts_launch(const UkfRtsArgs &a, const double *F, const double
 // A/B knobs, read once per process: FK_UKF_MLG=0 takes the several-lane kernels out altogether (dim_x >= 10 then answers
 // FK_ERR_UNSUPPORTED and the host takes the building blocks); FK_UKF_MLG_MIN_NX / FK_UKF_MLG_RTS_MIN_NX = 7..10 move the
 // filter's / the smoother's lower bound.
+// (ONE snapshot of the environment for the whole library -- fk_host.cpp: this file is compiled as eight objects, and a copy per
+// object, each initialised at its own first call, let fk_ukf_linear_supported and the launchers disagree when a knob changed in
+// between)
 struct UkfMlgRoute { int fwd_min, rts_min; };
-static UkfMlgRoute ukf_mlg_route()
-{
-    static const UkfMlgRoute v = [] {
-        const char *on = getenv("FK_UKF_MLG");
-        if (on && on[0] == '0') return UkfMlgRoute{99, 99};
-        auto knob = [](const char *name, int dflt) {
-            const char *mn = getenv(name);
-            const int m = mn ? atoi(mn) : dflt;
-            return m >= 7 && m <= 10 ? m : dflt;
-        };
-        return UkfMlgRoute{knob("FK_UKF_MLG_MIN_NX", 10), knob("FK_UKF_MLG_RTS_MIN_NX", 7)};
-    }();
-    return v;
-}
+UkfMlgRoute ukf_mlg_route();
 static int ukf_mlg_min_nx() { return ukf_mlg_route().fwd_min; }
 static int ukf_mlg_rts_min_nx() { return ukf_mlg_route().rts_min; }
 

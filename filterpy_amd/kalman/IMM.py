@@ -15,7 +15,7 @@ reference has no batch method on IMMEstimator) runs T x {predict; update} in ONE
 the per-step estimates.
 
 Reach (one lane owns a track's whole bank): linear ``KalmanFilter``-like filters of the same dim_x <= 16 and
-dim_z <= 8, 2 to 8 filters, ``predict(u)`` with every filter's own B (dim_u <= 4), ``update(None)`` (IMM.py:171-186 as the
+dim_z <= 8, 2 to 16 filters (9 to 16: the rolled general kernel, bank in scratch memory), ``predict(u)`` with every filter's own B (dim_u <= 4), ``update(None)`` (IMM.py:171-186 as the
 reference runs it on top of kalman_filter.py:511-520: the filters keep x and P, each likelihood is the density of a zero
 residual under that filter's last S).  Register-resident classes: (2,1), (4,2), (6,3) x {2, 3}; (9,4) x 2..8 and (16,8) x 2
 unrolled with spills; (16,8) x 3..8 rolled.
@@ -72,8 +72,11 @@ class IMMEstimator(object):
         self.filters = filters
         self.N = len(filters)
         self.M = None
-        if self.N > 8:
-            raise NotImplementedError("the IMM kernel is built for banks of 2 to 8 filters")
+        if self.N > 16:
+            raise NotImplementedError("the IMM kernel is built for banks of 2 to 16 filters (filterpy_amd/csrc/fk_dims_imm.def)")
+        if any(getattr(f, "inv", np.linalg.inv) is not np.linalg.inv for f in filters):
+            # (KalmanFilter.update honours a non-default `inv`; the bank kernels apply S^-1 themselves -- loud, not ignored)
+            raise NotImplementedError("a filter of the bank has a non-default `inv`: the IMM / MMAE kernels apply S^-1 in-lane")
         self._nt = n_tracks
         self._layout = layout
         nt = n_tracks or 1

@@ -111,8 +111,9 @@ class _Core:
         pinfo = {"method": "interleave" if inter else "none"}
         if want_outputs and device_outputs and not extras and (placement == "probe" or auto_probe) and T * N * n * n * 8 >= (256 << 20):
             # two dense arrays, placed in HBM by measuring this very launch on several candidate buffers (placement.py:
-            # placed_pair; the pair is remembered per shape, the losers are freed).  Worth ~7 % over the interleaved array
-            # at BASELINE configs[1] (5.2 against 5.6 ms), costs about a second once per shape.
+            # placed_pair; the pair is remembered per shape -- a two-entry LRU per device --, the losers go back to torch's
+            # caching allocator).  Worth ~7 % over the interleaved array at BASELINE configs[1] (5.2 against 5.6 ms), costs a
+            # few to ~100 launches once per shape (the probe stops as soon as a fast pair shows).
             from .. import placement as _pl
             dx0, dP0 = dx.clone(), dP.clone()
             shp = (T, N, n * n) if layout == "aos" else (T, n * n, N)
@@ -189,7 +190,9 @@ class _Core:
         return res
 
     @staticmethod
-    def rts(n, N, T, Xs, Ps, F, Q, mode, convention, layout="soa"):
+    def rts(n, N, T, Xs, Ps, F, Q, mode, convention, layout="soa", inv=None):
+        """inv: a caller-supplied inverse (rts_smoother(inv=...), kalman_filter.py:995, 1069) -- two launches with the callable
+        applied on the host in between (include/filterhip.h: FK_KF_FLAG_PP_ONLY / FK_KF_FLAG_PPINV_GIVEN)."""
         import torch
         E.require_gpu()
 
@@ -201,9 +204,21 @@ class _Core:
         dX, dPs = E.to_records(Xs, layout, 1), E.to_records(Ps, layout, 1)
         o = [E.alloc_records((T,), N, n, layout)] + [E.alloc_records((T,), N, n * n, layout) for _ in range(3)]
         st = torch.zeros(N, dtype=torch.int32, device=dX.device)
-        E.kf_rts(dict(n=n, m=1, nu=0, model_mode=mode, N=N, T=T, layout=E.LAYOUTS[layout], update_first=0,
-                      alpha_sq=1.0), model(F), model(Q), dX, dPs, o[0], o[1], o[2], o[3],
-                 convention=convention, status=st)
+        desc = dict(n=n, m=1, nu=0, model_mode=mode, N=N, T=T, layout=E.LAYOUTS[layout], update_first=0, alpha_sq=1.0)
+        if inv is not None:
+            dF, dQ = model(F), model(Q)
+            E.kf_rts(dict(desc, flags=_abi.FK_KF_FLAG_PP_ONLY), dF, dQ, dX, dPs, o[0], o[1], o[2], o[3],
+                     convention=convention, status=st)
+            Pp = E.from_records(o[3], layout, 1, (n, n))
+            PpI = np.zeros((T, N, n, n))
+            for k in range(T - 1):                        # the reference's own call, one matrix at a time (:1069)
+                for i in range(N):
+                    PpI[k, i] = np.asarray(inv(Pp[k, i]), dtype=np.float64).reshape(n, n)
+            o[2] = E.to_records(PpI, layout, 1)          # inverses in, gains out
+            E.kf_rts(dict(desc, flags=_abi.FK_KF_FLAG_PPINV_GIVEN), dF, dQ, dX, dPs, o[0], o[1], o[2], o[3],
+                     convention=convention, status=st)
+        else:
+            E.kf_rts(desc, model(F), model(Q), dX, dPs, o[0], o[1], o[2], o[3], convention=convention, status=st)
         E.raise_on_status(st, "rts_smoother")
         return (E.from_records(o[0], layout, 1, (n,)), E.from_records(o[1], layout, 1, (n, n)),
                 E.from_records(o[2], layout, 1, (n, n)), E.from_records(o[3], layout, 1, (n, n)))
@@ -228,7 +243,10 @@ class _Core:
         return E.from_records(dx, layout, 0, (n,)), E.from_records(dP, layout, 0, (n, n))
 
     @staticmethod
-    def update(n, m, N, x, P, z, H, R, mode, mask=None, layout="soa", flags=0):
+    def update(n, m, N, x, P, z, H, R, mode, mask=None, layout="soa", flags=0, inv=None):
+        """inv: a caller-supplied inverse (KalmanFilter.inv, kalman_filter.py:363, 434, 541) -- y and S from one launch, the
+        callable on the host, the correction from a second launch that takes its result (include/filterhip.h:
+        FK_KF_FLAG_S_ONLY / FK_KF_FLAG_SI_GIVEN)."""
         import torch
         E.require_gpu()
 
@@ -242,9 +260,21 @@ class _Core:
         for t in (y, K, S, SI):
             t.zero_()
         st = torch.zeros(N, dtype=torch.int32, device=dx.device)
-        E.kf_update(dict(n=n, m=m, nu=0, model_mode=mode, N=N, T=1, layout=E.LAYOUTS[layout], update_first=0,
-                         alpha_sq=1.0, flags=flags), model(H), model(R), dz, dx, dP, mask=dmask, y=y, K=K, S=S, SI=SI,
-                    status=st)
+        desc = dict(n=n, m=m, nu=0, model_mode=mode, N=N, T=1, layout=E.LAYOUTS[layout], update_first=0, alpha_sq=1.0, flags=flags)
+        if inv is not None:
+            dH, dR = model(H), model(R)
+            E.kf_update(dict(desc, flags=flags | _abi.FK_KF_FLAG_S_ONLY), dH, dR, dz, dx, dP, mask=dmask, y=y, K=K, S=S, SI=SI,
+                        status=st)
+            Sh = E.from_records(S, layout, 0, (m, m))
+            SIh = np.zeros((N, m, m))
+            for i in range(N):
+                if mask is None or np.ravel(mask)[i]:
+                    SIh[i] = np.asarray(inv(Sh[i]), dtype=np.float64).reshape(m, m)
+            SI = E.to_records(SIh, layout, 0)
+            E.kf_update(dict(desc, flags=flags | _abi.FK_KF_FLAG_SI_GIVEN), dH, dR, dz, dx, dP, mask=dmask, y=y, K=K, S=S, SI=SI,
+                        status=st)
+        else:
+            E.kf_update(desc, model(H), model(R), dz, dx, dP, mask=dmask, y=y, K=K, S=S, SI=SI, status=st)
         E.raise_on_status(st, "update")
         return (E.from_records(dx, layout, 0, (n,)), E.from_records(dP, layout, 0, (n, n)),
                 E.from_records(y, layout, 0, (m,)), E.from_records(K, layout, 0, (n, m)),
@@ -328,8 +358,14 @@ class KalmanFilter(object):
         self._log_likelihood = log(sys.float_info.min)
         self._likelihood = sys.float_info.min
         self._mahalanobis = None
-        # kept for attribute compatibility; S^-1 is applied by the kernel's Cholesky solve
+        # numpy.linalg.inv (the default): S^-1 is applied by the kernel's in-lane LDL' solve.  Anything else (the reference's
+        # documented `kf.inv = np.linalg.pinv`, kalman_filter.py:363) is HONOURED: update() / batch_filter() then run the
+        # step around the callable (_custom_inv below)
         self.inv = np.linalg.inv
+
+    def _custom_inv(self):
+        """the callable update() must apply to S, or None for numpy.linalg.inv (then the fused kernels' own solve runs)"""
+        return None if self.inv is np.linalg.inv else self.inv
 
     # -- attribute normalisation ------------------------------------------------
     def _xP(self):
@@ -418,7 +454,7 @@ class KalmanFilter(object):
             zz = np.broadcast_to(zraw, hx_shape)
         x, P = self._xP()
         xn, Pn, y, K, S, SI = _Core.update(n, m, 1, x, P, np.ascontiguousarray(zz).reshape(1, m), _mat(H, m, n, "H"),
-                                           Rm, FK_MODEL_SHARED, flags=rflags)
+                                           Rm, FK_MODEL_SHARED, flags=rflags, inv=self._custom_inv())
         self._set_x(xn[0])
         self.P = Pn[0]
         self.y = y[0].reshape(m, 1) if x_ndim == 2 else y[0]
@@ -488,6 +524,9 @@ class KalmanFilter(object):
 
     def update_correlated(self, z, R=None, H=None):
         """kalman_filter.py:670-752: update with process and measurement noise correlated through self.M."""
+        if self._custom_inv() is not None:
+            raise NotImplementedError("update_correlated applies S^-1 inside the kernel; a non-default `inv` is honoured by "
+                                      "update(), batch_filter() and rts_smoother(inv=...) only")
         self._log_likelihood = None
         self._likelihood = None
         self._mahalanobis = None
@@ -556,6 +595,8 @@ class KalmanFilter(object):
         the filter's own x, P end at the final state, like the reference."""
         n, m = self.dim_x, self.dim_z
         T = len(zs)
+        if self._custom_inv() is not None:
+            return self._batch_filter_epochwise(zs, Fs, Qs, Hs, Rs, Bs, us, update_first, saver)
         Fs, Qs, Hs, Rs, Bs = (_seq(v, T) for v in (Fs, Qs, Hs, Rs, Bs))
         want_hist = saver is not None
         x_ndim = np.ndim(self.x)
@@ -647,6 +688,36 @@ class KalmanFilter(object):
                 self.x_post, self.P_post = np.copy(self.x), self.P.copy()
         return (mu, cov, mup, covp)
 
+    def _batch_filter_epochwise(self, zs, Fs, Qs, Hs, Rs, Bs, us, update_first, saver):
+        """batch_filter with a non-default `inv`: the reference's own per-epoch loop (kalman_filter.py:940-991) over this
+        object's predict() / update(), every step on the GPU around the caller's callable -- one filter's escape hatch for a
+        singular S, not the throughput path (that is the fused launch above)."""
+        T = np.size(zs, 0)
+        seq = lambda v, default: [default] * T if v is None else v          # noqa: E731
+        Fs, Qs, Hs, Rs = seq(Fs, self.F), seq(Qs, self.Q), seq(Hs, self.H), seq(Rs, self.R)
+        Bs = seq(Bs, self.B)
+        us_ = [None] * T if us is None else us          # (without `us` the fused path ignores B too: see batch_filter)
+        n = self.dim_x
+        if np.ndim(self.x) == 1:
+            means, means_p = np.zeros((T, n)), np.zeros((T, n))
+        else:
+            means, means_p = np.zeros((T, n, 1)), np.zeros((T, n, 1))
+        covariances, covariances_p = np.zeros((T, n, n)), np.zeros((T, n, n))
+        for i, (z, F, Q, H, R, B, u) in enumerate(zip(zs, Fs, Qs, Hs, Rs, Bs, us_)):
+            if update_first:
+                self.update(z, R=R, H=H)
+                means[i, :], covariances[i, :, :] = self.x, self.P
+                self.predict(u=u, B=B, F=F, Q=Q)
+                means_p[i, :], covariances_p[i, :, :] = self.x, self.P
+            else:
+                self.predict(u=u, B=B, F=F, Q=Q)
+                means_p[i, :], covariances_p[i, :, :] = self.x, self.P
+                self.update(z, R=R, H=H)
+                means[i, :], covariances[i, :, :] = self.x, self.P
+            if saver is not None:
+                saver.save()
+        return (means, covariances, means_p, covariances_p)
+
     def _replay_for_saver(self, saver, zs, present, mu, cov, mup, covp, hist, update_first):
         """saver.save() reads the filter's attributes after every epoch (kalman_filter.py:990-991,
         filterpy/common/helpers.py:121-152).  The whole run was ONE kernel launch that also stored the
@@ -673,11 +744,13 @@ class KalmanFilter(object):
     # -- rts_smoother -----------------------------------------------------------
     def rts_smoother(self, Xs, Ps, Fs=None, Qs=None, inv=None):
         """kalman_filter.py:995-1074 (class method: F[k+1], Q[k+1]).  Returns (x, P, K, Pp).
-        `inv` is accepted for signature compatibility; Pp^-1 is applied by a Cholesky solve."""
+        inv=None / numpy.linalg.inv: Pp^-1 is applied by the kernel's in-lane LDL' solve (one launch).  Any other callable
+        (the reference's documented use: numpy.linalg.pinv) is applied to every Pp[k] on the host between two launches."""
         if len(Xs) != len(Ps):
             raise ValueError('length of Xs and Ps must be the same')
         return _rts(np.asarray(Xs, dtype=np.float64), np.asarray(Ps, dtype=np.float64),
-                    Fs if Fs is not None else self.F, Qs if Qs is not None else self.Q, convention=0)
+                    Fs if Fs is not None else self.F, Qs if Qs is not None else self.Q, convention=0,
+                    inv=None if (inv is None or inv is np.linalg.inv) else inv)
 
     # -- small helpers the reference exposes -------------------------------------
     def residual_of(self, z):
@@ -776,7 +849,7 @@ class KalmanFilter(object):
                           ("dim_x", "dim_z", "dim_u", "x", "P", "F", "Q", "R", "H", "K", "y", "S", "alpha")])
 
 
-def _rts(Xs, Ps, Fs, Qs, convention):
+def _rts(Xs, Ps, Fs, Qs, convention, inv=None):
     T = Xs.shape[0]
     n = Xs.shape[1]
     Xr = Xs.reshape(T, 1, n)
@@ -794,7 +867,7 @@ def _rts(Xs, Ps, Fs, Qs, convention):
         Fm, Qm, mode = _mat(Fs, n, n, "F"), _mat(Qs, n, n, "Q", scalar="full"), FK_MODEL_SHARED
     if T == 0:
         return Xs.copy(), Ps.copy(), np.zeros((0, n, n)), Ps.copy()
-    x, P, K, Pp = _Core.rts(n, 1, T, Xr, Pr, Fm, Qm, mode, convention)
+    x, P, K, Pp = _Core.rts(n, 1, T, Xr, Pr, Fm, Qm, mode, convention, inv=inv)
     return x[:, 0].reshape(Xs.shape), P[:, 0], K[:, 0], Pp[:, 0]
 
 
@@ -885,10 +958,14 @@ class KalmanFilterBank(object):
         are then strided VIEWS of one array in which a track's posterior and prior record sit side by side (one write
         front: docs/PLACEMENT.md) -- `.contiguous()` gives a dense copy, cov_interleave=False two dense arrays.
         placement="probe" (device outputs of 256 MiB and more): two dense arrays placed in HBM by timing this very launch
-        on candidate buffers (filterpy_amd/placement.py: about a second once per shape, the pair is remembered and reused while
-        no earlier result is alive; `self.placement_info` says what happened) -- the fastest arrangement measured, and what
-        placement=None (the default) does by itself at dim_x <= 4 for histories of that size; placement="interleave" keeps the
-        one-array form there too (no probe, no transient candidate buffers).
+        on candidate buffers (filterpy_amd/placement.py: candidates arrive one at a time, at most 11 and at most half of the
+        free memory, and the probe stops as soon as a fast pair shows -- a few to ~100 launches once per shape; the pair is
+        remembered -- the last two shapes per device -- and reused while no earlier result is alive; `self.placement_info`
+        says what happened) -- the fastest arrangement measured, and what placement=None (the default) does by itself at
+        dim_x <= 4 for histories of that size; placement="interleave" keeps the one-array form there too (no probe, no
+        transient candidate buffers).  The probe's losing candidates stay in torch's caching allocator (reused by later
+        allocations of this process); `filterpy_amd.placement.forget_placed_pairs()` drops the remembered pairs and hands
+        every cached block back to the driver.  The outcome is this process's draw: nothing is kept across processes.
         extras: any of 'y', 'K', 'S', 'SI', 'log_likelihood', 'mahalanobis' -> also returns a dict of the
         per-step histories (T, N, ...) as a fifth element (what filterpy.common.Saver would record)."""
         import torch

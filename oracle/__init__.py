@@ -7,7 +7,7 @@ be *timed* as the CPU baseline.  It is never the product:
 
   * only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s
     ``cpu_baseline`` leg may import anything from here;
-  * nothing under ``filterpy_amd/`` imports it (tests/test_no_oracle_in_product.py
+  * nothing under ``filterpy_amd/`` imports it (tests/test_host_logic.py::test_product_never_imports_oracle
     enforces that).
 
 Parity pin: every function here is checked against outputs of the live

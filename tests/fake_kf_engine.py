@@ -188,6 +188,34 @@ def install(monkeypatch):
         calls.append("update")
         n, m, mode, N, L = desc["n"], desc["m"], desc["model_mode"], desc["N"], lay(desc)
         fH, fR = model(H, mode, L, (m, n), 1, N), model(R, mode, L, (m, m), 1, N)
+        given = desc.get("flags", 0) & (4 | 8)           # FK_KF_FLAG_S_ONLY / FK_KF_FLAG_SI_GIVEN (a caller-supplied inverse)
+        if given:
+            zs, xs, Ps = get(z, L, 0, (m,)), get(x, L, 0, (n,)), get(P, L, 0, (n, n))
+            mk = None if mask is None else mask.detach().numpy().reshape(N)
+            yo, So = get(y, L, 0, (m,)), get(S, L, 0, (m, m))
+            Ko = get(K, L, 0, (n, m)) if K is not None else np.zeros((N, n, m))
+            SIs = get(SI, L, 0, (m, m)) if SI is not None else None
+            rj = bool(desc.get("flags", 0) & FLAG_R_JOSEPH_DIAG)
+            for i in range(N):
+                if mk is not None and not mk[i]:
+                    continue
+                Hm, Rm = fH(0, i), fR(0, i)
+                yo[i] = zs[i] - Hm @ xs[i]
+                PHT = Ps[i] @ Hm.T
+                So[i] = Hm @ PHT + Rm
+                if given == 8:
+                    Ko[i] = PHT @ SIs[i]
+                    xs[i] = xs[i] + Ko[i] @ yo[i]
+                    I_KH = np.eye(n) - Ko[i] @ Hm
+                    Ps[i] = (I_KH @ Ps[i]) @ I_KH.T + (Ko[i] @ (np.diag(np.diag(Rm)) if rj else Rm)) @ Ko[i].T
+            put(y, L, 0, yo)
+            put(S, L, 0, So)
+            if given == 8:
+                put(x, L, 0, xs)
+                put(P, L, 0, Ps)
+                if K is not None:
+                    put(K, L, 0, Ko)
+            return
         _one_update(lambda i, xi, Pi, zi, rj: _update(xi, Pi, zi, fR(0, i), fH(0, i), rj), desc, H, R, z, x, P, mask, y, K, S, SI,
                     status)
 
@@ -205,6 +233,27 @@ def install(monkeypatch):
         fF, fQ = model(F, mode, L, (n, n), T, N), model(Q, mode, L, (n, n), T, N)
         X, Pm = get(Xs, L, 1, (n,)), get(Ps, L, 1, (n, n))
         o = [np.zeros((T, N, n))] + [np.zeros((T, N, n, n)) for _ in range(3)]
+        given = desc.get("flags", 0) & (16 | 32)         # FK_KF_FLAG_PP_ONLY / FK_KF_FLAG_PPINV_GIVEN
+        if given:
+            off = 0 if convention else 1
+            Kio = get(K, L, 1, (n, n))
+            o[0][:], o[1][:] = X, Pm
+            for i in range(N):
+                o[3][T - 1, i] = Pm[T - 1, i]
+                for k in range(T - 2, -1, -1):
+                    Fk, Qk = fF(k + off, i), fQ(k + off, i)
+                    o[3][k, i] = Fk @ Pm[k, i] @ Fk.T + Qk
+                    if given == 32:
+                        Kk = Pm[k, i] @ Fk.T @ Kio[k, i]
+                        o[2][k, i] = Kk
+                        o[0][k, i] = X[k, i] + Kk @ (o[0][k + 1, i] - Fk @ X[k, i])
+                        o[1][k, i] = Pm[k, i] + Kk @ (o[1][k + 1, i] - o[3][k, i]) @ Kk.T
+            if given == 16:
+                put(Pp, L, 1, o[3])
+            else:
+                for rec, arr in zip((xs, Ps_out, K, Pp), o):
+                    put(rec, L, 1, arr)
+            return
         for i in range(N):
             try:
                 r = kf_oracle.rts_smoother(X[:, i], Pm[:, i], [fF(t, i) for t in range(T)], [fQ(t, i) for t in range(T)],

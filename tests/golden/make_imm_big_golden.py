@@ -19,6 +19,7 @@ OUT = os.path.dirname(os.path.abspath(__file__))
 IMM_CASES = [(9, 3, 4), (4, 2, 8), (7, 4, 5), (6, 3, 6), (9, 4, 2), (2, 1, 7), (8, 2, 3)]
 MMAE_CASES = [(9, 3, 4), (4, 2, 8), (7, 4, 3)]
 T = 20
+OUT_NAME = "imm_big.npz"          # (make_imm_banks16_golden.py runs this file's main() with its own cases and name)
 
 
 def spd(rs, n, scale=1.0):
@@ -91,8 +92,8 @@ def main():
                   q + "xs0": np.array(xs0), q + "Ps0": np.array(Ps0), q + "p0": p0, q + "zs": zs,
                   q + "x": np.array(X), q + "P": np.array(P), q + "p": np.array(PR), q + "L": np.array(L),
                   q + "xs_final": np.array([f.x for f in filters]), q + "Ps_final": np.array([f.P for f in filters])})
-    np.savez_compressed(os.path.join(OUT, "imm_big.npz"), **d)
-    print("wrote imm_big.npz:", len(d), "arrays")
+    np.savez_compressed(os.path.join(OUT, OUT_NAME), **d)
+    print("wrote " + OUT_NAME + ":", len(d), "arrays")
 
 
 if __name__ == "__main__":

@@ -279,23 +279,31 @@ def test_imm_rejects_what_the_kernel_cannot_do():
         IMMEstimator(fs[:1], [1.0], np.eye(1))
     imm = IMMEstimator(fs, [0.5, 0.5], np.array([[0.9, 0.1], [0.1, 0.9]]))
     with pytest.raises(NotImplementedError):
-        IMMEstimator([KalmanFilter(dim_x=2, dim_z=1) for _ in range(9)], [1] * 9, np.full((9, 9), 1 / 9))
+        IMMEstimator([KalmanFilter(dim_x=2, dim_z=1) for _ in range(17)], [1] * 17, np.full((17, 17), 1 / 17))
+    odd = [KalmanFilter(dim_x=2, dim_z=1) for _ in range(2)]
+    odd[1].inv = np.linalg.pinv              # honoured by KalmanFilter.update, refused -- loudly -- by the bank kernels
+    with pytest.raises(NotImplementedError):
+        IMMEstimator(odd, [.5, .5], np.full((2, 2), .5))
     with pytest.raises(NotImplementedError):
         IMMEstimator([KalmanFilter(dim_x=17, dim_z=1) for _ in range(2)], [.5, .5], np.full((2, 2), .5))
 
 
 # ---- round 3: banks of up to eight filters, dim_x <= 9, dim_z <= 4 (the rolled (9, 4) class of every bank size) ----------
-def _big(kind):
-    g = golden("imm_big")
+def _big(kind, name="imm_big"):
+    g = golden(name)
     return [tuple(int(v) for v in c) for c in g[kind + "_cases"]]
 
 
+def _big_file(nm):
+    return "imm_banks16" if nm > 8 else "imm_big"          # (round 6: banks of nine to sixteen filters, make_imm_banks16_golden.py)
+
+
 @pytest.mark.parametrize("layout", ["soa", "aos"])
-@pytest.mark.parametrize("n,m,nm", _big("imm"))
+@pytest.mark.parametrize("n,m,nm", _big("imm") + _big("imm", "imm_banks16"))
 def test_big_imm_banks_vs_live_reference(n, m, nm, layout):
     """IMMEstimator on banks the round-2 kernel refused: every track of a ragged bank runs the live reference's sequence"""
     from gpu_util import tile_tracks
-    g = golden("imm_big")
+    g = golden(_big_file(nm))
     p = f"imm_n{n}m{m}k{nm}_"
     N = 130
     r = run_imm(tile_tracks(g[p + "xs0"], N), tile_tracks(g[p + "Ps0"], N), tile_tracks(g[p + "mu0"], N), g[p + "M"],
@@ -339,8 +347,8 @@ def test_big_imm_seeded_bank_vs_oracle(n, m, nm, layout):
 def test_big_imm_and_mmae_classes_drop_in():
     """the reference's own usage on the big banks: predict(); update(z) call by call, then batch_filter for the rest"""
     from filterpy_amd.kalman import IMMEstimator, MMAEFilterBank
-    g = golden("imm_big")
-    for n, m, nm in _big("imm")[:3]:
+    for n, m, nm in _big("imm")[:3] + _big("imm", "imm_banks16")[:3]:
+        g = golden(_big_file(nm))
         p = f"imm_n{n}m{m}k{nm}_"
         imm = IMMEstimator(_make_filters(g, p, n, m, nm, False), g[p + "mu0"].copy(), g[p + "M"])
         for t in range(6):
@@ -349,7 +357,8 @@ def test_big_imm_and_mmae_classes_drop_in():
             imm.update(g[p + "zs"][t])
             assert rel_err_rows(imm.x[None], g[p + "x"][t][None]) < TOL and rel_err_rows(imm.P[None], g[p + "P"][t][None]) < TOL
             assert np.allclose(imm.mu, g[p + "mu"][t], rtol=1e-10, atol=1e-14)
-    for n, m, nm in _big("mmae"):
+    for n, m, nm in _big("mmae") + _big("mmae", "imm_banks16"):
+        g = golden(_big_file(nm))
         q = f"mmae_n{n}m{m}k{nm}_"
         gg = {k: g[k] for k in g.files if k.startswith(q)}
         bank = MMAEFilterBank(_make_filters(gg, q, n, m, nm, False), g[q + "p0"].copy(), dim_x=n)

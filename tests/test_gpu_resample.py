@@ -263,7 +263,18 @@ def _family(kind, Fn, Np, rs):
 
 
 def _onepass_mode(monkeypatch, mode):
-    """spec: FK_OP_SPEC / FK_OP_STATIC defaults; two-stage: FK_OP_SPEC=0; tickets: FK_OP_SPEC=0 FK_OP_STATIC=0 (round 2)"""
+    """spec: the defaults (round 6: systematic calls on resample_onepass2_kernel, its binade predictions on); round3: FK_OP_V2=0,
+    round 3's kernel with speculation; nopredict: round 6's kernel without the predictions (every chunk in round 3's order);
+    two-stage: FK_OP_SPEC=0; tickets: FK_OP_SPEC=0 FK_OP_STATIC=0 (round 2)"""
+    if mode == "round3":
+        monkeypatch.setenv("FK_OP_V2", "0")
+        return
+    if mode == "nopredict":
+        monkeypatch.setenv("FK_OP_PRED_BACK", "0")
+        return
+    if mode == "predict-near":                 # predictions from a chunk that is usually NOT finished yet, and from the nearest one
+        monkeypatch.setenv("FK_OP_PRED_BACK", "1")
+        return
     if mode != "spec":
         monkeypatch.setenv("FK_OP_SPEC", "0")
     if mode == "tickets":
@@ -293,7 +304,7 @@ def _check_against_merge_loop(Fn, Np, kinds, filters, monkeypatch, force):
                 assert bool(sth[f] & 4) == (over > 0) and not (sth[f] & 8), (Np, kind, strat, f, int(sth[f]))
 
 
-@pytest.mark.parametrize("mode", ["spec", "two-stage", "tickets"])
+@pytest.mark.parametrize("mode", ["spec", "round3", "nopredict", "predict-near", "two-stage", "tickets"])
 @pytest.mark.parametrize("Np", [1, 2, 100, 2049, 65536])
 def test_onepass_every_route_small(Np, mode, monkeypatch):
     """FK_RESAMPLE_PATH=onepass forces short vectors through the one-pass kernel: every weight family, every filter,
@@ -303,7 +314,7 @@ def test_onepass_every_route_small(Np, mode, monkeypatch):
     _check_against_merge_loop(5, Np, kinds, range(5), monkeypatch, force=True)
 
 
-@pytest.mark.parametrize("mode", ["spec", "two-stage", "tickets"])
+@pytest.mark.parametrize("mode", ["spec", "round3", "nopredict", "predict-near", "two-stage", "tickets"])
 def test_onepass_every_route_long(mode, monkeypatch):
     """default dispatch on a long ragged vector (not a multiple of the chunk, odd address alignment per filter), in the three
     protocols of the one-pass kernel: speculation + static chunk assignment (round 3's default), round 2's two stages on
@@ -312,7 +323,7 @@ def test_onepass_every_route_long(mode, monkeypatch):
     _check_against_merge_loop(6, 1000003, _FAMILIES + ("dyadic", "tiny"), (0, 3, 5), monkeypatch, force=False)
 
 
-@pytest.mark.parametrize("mode", ["spec", "tickets"])
+@pytest.mark.parametrize("mode", ["spec", "round3", "tickets"])
 def test_onepass_repairs_itself_when_a_hand_off_times_out(mode, monkeypatch):
     """a bounded spin of the one-pass kernel that times out sets the abort word (FK_STATUS_INTERNAL).  The
     call must not report that, it must repair it: the repair pass (resample_local_kernel behind the one-pass kernel, one
@@ -325,16 +336,20 @@ def test_onepass_repairs_itself_when_a_hand_off_times_out(mode, monkeypatch):
     _check_against_merge_loop(3, 40000, ("uniform", "heavy_tail", "sum_half"), range(3), monkeypatch, force=False)
 
 
-def test_onepass_one_long_vector_walks_binade_segments(monkeypatch):
+@pytest.mark.parametrize("mode", ["spec", "round3", "predict-near"])
+def test_onepass_one_long_vector_walks_binade_segments(mode, monkeypatch):
     """ONE filter of 3e6 weights: the chunks of every binade segment wait for the carry-out of the segment before it (the
     serial part of a call with few filters: ~12 binade crossings, each resolved by the general scan of its chunk)"""
+    _onepass_mode(monkeypatch, mode)
     _check_against_merge_loop(1, 3000017, ("uniform", "heavy_tail", "zeros"), (0,), monkeypatch, force=False)
     _check_against_merge_loop(40, 70001, ("uniform",), (0, 17, 39), monkeypatch, force=True)
 
 
-def test_onepass_many_filters_of_a_hundred_thousand(monkeypatch):
+@pytest.mark.parametrize("mode", ["spec", "round3"])
+def test_onepass_many_filters_of_a_hundred_thousand(mode, monkeypatch):
     """1000 x 100 000: more concurrent chains than workgroup slots; speculation on ordinary and on skewed weights (whose
     guesses mostly miss and fall back to the two stages)"""
+    _onepass_mode(monkeypatch, mode)
     _check_against_merge_loop(1000, 100000, ("uniform", "heavy_tail", "zeros"), (0, 1, 499, 998, 999), monkeypatch, force=False)
 
 

@@ -56,7 +56,7 @@ def test_batch_filter_fills_the_package_saver(monkeypatch, n, m):
     assert s.x.shape == g[p + "x"].shape and s.P.shape == g[p + "P"].shape
 
 
-def _fake_update(n, m, N, x, P, z, H, R, mode, mask=None, layout="soa", flags=0):
+def _fake_update(n, m, N, x, P, z, H, R, mode, mask=None, layout="soa", flags=0, inv=None):
     assert N == 1 and mode == kfm.FK_MODEL_SHARED and mask is None
     xn, Pn, y, K, S, SI = kf_oracle.kf_update(x[0], P[0], np.asarray(z).reshape(m), R, H)
     return xn[None], Pn[None], y[None], K[None], S[None], SI[None]

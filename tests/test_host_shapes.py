@@ -19,7 +19,7 @@ from make_shapes_golden import run  # noqa: E402
 import filterpy_amd.kalman.kalman_filter as kfm  # noqa: E402
 
 
-def _fake_update(n, m, N, x, P, z, H, R, mode, mask=None, layout="soa", flags=0):
+def _fake_update(n, m, N, x, P, z, H, R, mode, mask=None, layout="soa", flags=0, inv=None):
     assert N == 1 and x.shape == (1, n) and P.shape == (1, n, n) and z.shape == (1, m)
     assert H.shape == (m, n) and R.shape == (m, m)
     y = z[0] - H @ x[0]

@@ -70,9 +70,11 @@ def test_control_input_vs_live_reference(kind):
         assert np.allclose(mu, g[q + "mu"], rtol=1e-11, atol=1e-13)
 
 
-def test_big_banks_vs_live_reference():
-    """banks of up to eight filters, dim_x up to 9, dim_z up to 4 (tests/golden/make_imm_big_golden.py)"""
-    g = golden("imm_big")
+@pytest.mark.parametrize("name", ["imm_big", "imm_banks16"])
+def test_big_banks_vs_live_reference(name):
+    """banks of up to eight filters, dim_x up to 9, dim_z up to 4 (tests/golden/make_imm_big_golden.py); nine to sixteen filters,
+    dim_x up to 16, dim_z up to 8 (make_imm_banks16_golden.py)"""
+    g = golden(name)
     for n, m, nm in g["imm_cases"]:
         p = f"imm_n{n}m{m}k{nm}_"
         x, P, mu, xp, Pp, L = imm_oracle.imm_batch(g[p + "xs0"], g[p + "Ps0"], g[p + "mu0"], g[p + "M"], g[p + "zs"],

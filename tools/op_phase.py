@@ -70,7 +70,8 @@ def run(shapes, iters, strat, tag):
                           "counts_per_call": {n: v[s] / iters for s, n in COUNTS.items()},
                           "segmented_scan_ticks_per_general_chunk": {n: round(v[s] / max(v[8], 1), 1) for s, n in
                                                                      ((12, "classify+scans"), (13, "lists"), (14, "check+chain"), (15, "sums"))},
-                          "dirty_per_general_chunk": round(v[0] / max(v[8], 1), 2)}), flush=True)
+                          "dirty_per_general_chunk": round(v[0] / max(v[8], 1), 2),
+                          "v2": os.environ.get("FK_OP_V2", "1") != "0", "predicted_chunks_per_call": v[12] / iters}), flush=True)
 
 
 WH_PHASES = ["weights+sums", "classify+scans", "lists", "check+chain", "boundaries", "heads", "window scan", "stores", "plain-prefix boundaries"]
