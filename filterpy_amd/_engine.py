@@ -10,6 +10,7 @@ import numpy as np
 import torch
 
 from . import _abi
+from . import _transfer
 from ._abi import (FK_LAYOUT_AOS, FK_LAYOUT_SOA, FK_MODEL_SHARED, FK_MODEL_PER_TRACK,
                    FK_MODEL_PER_TRACK_STEP, FK_MODEL_PER_STEP, fk_kf_desc, fk_ukf_desc)  # noqa: F401
 
@@ -48,6 +49,8 @@ def dev(a, device=None):
     if isinstance(a, torch.Tensor):
         return a.to(device=device, dtype=torch.float64).contiguous()
     h = np.ascontiguousarray(a, dtype=np.float64)
+    if h.nbytes >= _transfer.MIN_BYTES:
+        return _transfer.to_device(h, device)          # (large inputs: pinned, pipelined -- _transfer.py)
     if not h.flags.writeable:          # e.g. a broadcast view: torch refuses to wrap read-only memory silently
         h = h.copy()
     return torch.as_tensor(h, device=device)
@@ -71,7 +74,7 @@ def to_records(a, layout, lead):
 def from_records(t, layout, lead, rec_shape):
     """Device tensor in `layout` -> host NumPy array lead + (N,) + rec_shape (zero-copy view of
     the downloaded buffer for 'soa': a transposed view, as the API docs describe)."""
-    h = t.cpu().numpy()
+    h = _transfer.to_host([t])[0]        # (large histories: pinned, pipelined, several host threads -- _transfer.py)
     rec = int(np.prod(rec_shape)) if rec_shape else 1                      # (explicit sizes: -1 is ambiguous for empty banks)
     if layout == "aos":
         return h.reshape(*h.shape[:lead + 1], *rec_shape) if rec_shape else h

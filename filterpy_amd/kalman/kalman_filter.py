@@ -978,9 +978,13 @@ class KalmanFilterBank(object):
             z = np.asarray(zs, dtype=np.float64)
             T = z.shape[0]
             z = z.reshape(T, self.n_tracks, self.dim_z)
-            nanrow = np.isnan(z).all(axis=2)
-            if mask is None and nanrow.any():
-                mask = ~nanrow
+            # NaN rows = missing measurements.  (One reduction first: a sum is NaN whenever any element is -- 0.08 s for the
+            # 1.6 GB of BASELINE configs[1] where isnan().all(axis=2) and its 200 MB temporary take 0.5 s; only a bank that
+            # holds a NaN, or an inf - inf, pays for the row test.)
+            if mask is None and z.size and np.isnan(np.sum(z)):
+                nanrow = np.isnan(z).all(axis=2)
+                if nanrow.any():
+                    mask = ~nanrow
             if mask is not None:
                 z = np.where(np.asarray(mask, dtype=bool)[..., None], z, 0.0)
         pinfo = {}

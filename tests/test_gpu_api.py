@@ -407,3 +407,43 @@ def test_c_abi_from_a_cpp_host_with_rccl_for_the_exchange():
             pytest.skip("ncclCommInitAll did not return within 120 s on this box (before the first call into libfilterhip.so)")
         raise AssertionError("examples/c_abi_multi_gpu hung after the communicators were up:\n" + err)
     assert r.returncode == 0 and "c_abi_multi_gpu ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_pipelined_download_is_bit_identical_and_the_bank_returns_it(monkeypatch):
+    """filterpy_amd/_transfer.py: histories of 32 MiB and more leave the device through pinned staging buffers and several host
+    threads.  Bit for bit what `tensor.cpu()` returns -- ragged sizes (not a multiple of the 64 MiB slab),
+    a non-contiguous view, several tensors in one call, int32 -- and KalmanFilterBank.batch_filter's host arrays are the same
+    with the pipeline on and off (FK_D2H_PIPE=0), in both layouts."""
+    import torch
+    from filterpy_amd import _transfer
+    from filterpy_amd.kalman import KalmanFilterBank
+    g = torch.Generator(device="cuda")
+    g.manual_seed(5)
+    a = torch.randn((37, 70001, 5), generator=g, device="cuda", dtype=torch.float64)          # 103.6 MB, ragged
+    b = torch.randint(-2 ** 31, 2 ** 31 - 1, (9_000_001,), generator=g, device="cuda", dtype=torch.int64).to(torch.int32)
+    c = a[:, ::2, 1:4]                                                                          # strided view
+    got = _transfer.to_host([a, b, c, torch.zeros((0, 3), device="cuda", dtype=torch.float64)])
+    for t, h in zip((a, b, c), got):
+        ref = t.cpu().numpy()
+        assert h.dtype == ref.dtype and h.shape == ref.shape and np.array_equal(h, ref)
+        assert np.array_equal(h.view(np.uint8).reshape(-1), np.ascontiguousarray(ref).view(np.uint8).reshape(-1))
+    assert got[3].shape == (0, 3)
+    # ... and the way up: a large host array through the same staging buffers, bit for bit
+    h = np.random.RandomState(3).standard_normal((41, 70001, 3))           # 68.9 MB, ragged
+    up = _transfer.to_device(h, torch.device("cuda"))
+    assert up.shape == h.shape and up.dtype == torch.float64 and np.array_equal(up.cpu().numpy(), h)
+    n, m, N, T = 4, 2, 60_000, 50                        # 96 MB per covariance history
+    rs = np.random.RandomState(8)
+    zs = rs.randn(T, N, m)
+    for layout in ("aos", "soa"):
+        res = []
+        for pipe in ("1", "0"):
+            monkeypatch.setenv("FK_D2H_PIPE", pipe)
+            bank = KalmanFilterBank(n, m, N, layout=layout)
+            bank.F = np.eye(n) + 0.05 * np.triu(np.ones((n, n)), 1)
+            bank.Q, bank.R, bank.H = 0.02 * np.eye(n), 0.5 * np.eye(m), np.eye(m, n)
+            bank.P = np.tile(3.0 * np.eye(n), (N, 1, 1))
+            res.append(bank.batch_filter(zs) + (bank.x, bank.P))
+        for u, v in zip(*res):
+            assert u.shape == v.shape and np.array_equal(u, v)
+    _transfer.release()

@@ -11,6 +11,10 @@ import torch  # noqa: E402
 
 from filterpy_amd import _engine as E  # noqa: E402
 
+if os.environ.get("FK_LIB"):      # an experimental build of the library (A/B of compile-time choices in one lease); tools only
+    from filterpy_amd import _abi
+    _abi.LIB_PATH = os.path.abspath(os.environ["FK_LIB"])
+
 
 def main():
     ap = argparse.ArgumentParser()

@@ -71,7 +71,9 @@ def run(shapes, iters, strat, tag):
                           "segmented_scan_ticks_per_general_chunk": {n: round(v[s] / max(v[8], 1), 1) for s, n in
                                                                      ((12, "classify+scans"), (13, "lists"), (14, "check+chain"), (15, "sums"))},
                           "dirty_per_general_chunk": round(v[0] / max(v[8], 1), 2),
-                          "v2": os.environ.get("FK_OP_V2", "1") != "0", "predicted_chunks_per_call": v[12] / iters}), flush=True)
+                          "v2": os.environ.get("FK_OP_V2", "1") != "0", "predicted_chunks_per_call": v[12] / iters,
+                          "v2_slow_chunks_per_call": {"no valid guess": v[13] / iters, "look-back missed": v[14] / iters, "end of positions": v[15] / iters},
+                          "env": {k: os.environ[k] for k in ("FK_OP_V2", "FK_OP_PRED_BACK", "FK_OP_POLLS") if k in os.environ}}), flush=True)
 
 
 WH_PHASES = ["weights+sums", "classify+scans", "lists", "check+chain", "boundaries", "heads", "window scan", "stores", "plain-prefix boundaries"]
