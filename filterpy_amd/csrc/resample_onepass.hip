@@ -1175,7 +1175,7 @@ resample_onepass_kernel(const OpArgs a)
 // (that kernel stays as it is: FK_OP_V2=0 is the A/B), out of line: resample_onepass2_kernel calls it for the chunks its fast
 // path declines -- a miss of the guess, a tie, the start of a vector, the last chunk, garbage -- so that those never cost the
 // fast path a register.  The eight weights are read again (L2); everything else is recomputed from them.
-template <bool STRATIFIED>
+template <bool STRATIFIED, int BUDGET>
 __device__ OP2_SLOW_INLINE void op_chunk_slow(OpShared &sh, const double *a_w, const double *a_u, int32_t *a_idx, int32_t *a_status,
                                                         OpCtl *a_ctl, OpDesc *a_desc, int *a_bad, const double a_delta, const long a_Np,
                                                         const long a_nch, const int f, const int k, const double S_in, const int any_bad_in)
@@ -1998,15 +1998,11 @@ int onepass_launch(bool stratified, int64_t Fn, int64_t Np, const double *w, con
             n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
                        ? prop.multiProcessorCount : 256;
         }
-        long back = (5L * FK_OP2_WAVES * n_cu / 4 + Fn - 1) / Fn + 2;      // (FK_OP2_WAVES workgroups per CU resident)
+        long back = (5L * 7 * n_cu / 4 + Fn - 1) / Fn + 2;                 // (up to seven workgroups per CU resident)
         if (back < 16) back = 16;
         if (const char *pb = getenv("FK_OP_PRED_BACK")) back = atol(pb);   // (0: never predict)
         int polls = 48;                                                    // look-back polls before a chunk gives its guess up
         if (const char *pv2 = getenv("FK_OP_POLLS")) polls = atoi(pv2);
-        // persistent grid (FK_OP_PERSIST=0: one workgroup per chunk): as many workgroups as the device holds at once -- asked of the
-        // runtime, once -- each walking chunks c, c + G, ...; every one of them must be resident (a chunk waits for chunks that
-        // other workgroups own), which is what the occupancy query promises for a device that runs nothing else; the bounded
-        // spins and the repair pass cover the case that it does
         // workgroups per CU (FK_OP_WAVES = 5 / 6 / 7): the kernel is latency-bound -- every chunk is a chain of load -> sums ->
         // publish -> look back -> boundaries -> emission --, so what a CU retires per microsecond is how many such chains it
         // interleaves
@@ -2014,34 +2010,12 @@ int onepass_launch(bool stratified, int64_t Fn, int64_t Np, const double *w, con
         if (const char *wv = getenv("FK_OP_WAVES")) waves = atoi(wv);
         if (waves < 5) waves = 5;
         if (waves > 7) waves = 7;
-        static int resident[8] = {};
-        if (!resident[waves]) {
-            int per_cu = 0;
-            const hipError_t e = waves == 5 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, resample_onepass2_kernel<true, 5>, OP_THREADS, 0)
-                               : waves == 6 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, resample_onepass2_kernel<true, 6>, OP_THREADS, 0)
-                                            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, resample_onepass2_kernel<true, 7>, OP_THREADS, 0);
-            resident[waves] = (e == hipSuccess && per_cu >= 1 ? per_cu : 1) * n_cu;
-            if (getenv("FK_OP_DEBUG")) fprintf(stderr, "onepass2: waves %d -> %d workgroups per CU resident (occupancy query), %d CUs\n", waves, per_cu, n_cu);
-        }
-        // persistent grid (FK_OP_PERSIST=1; off by default: measured slower, see resample_onepass2.inc): as many workgroups as the
-        // device holds at once, each walking chunks c, c + G, ...; every one of them must be resident (a chunk waits for chunks
-        // that other workgroups own), which is what the occupancy query promises for a device that runs nothing else; the
-        // bounded spins and the repair pass cover the case that it does
-        const char *pe = getenv("FK_OP_PERSIST");
-        const bool persist = pe && pe[0] == '1' && total > (unsigned long)resident[waves];
         const int pb = (int)(back > 0x3fffffff ? 0x3fffffff : back);
-        // (FK_OP_LDS_PAD: bytes of dynamic LDS nobody uses -- lowers the workgroups a CU holds; occupancy experiments only)
+        // (FK_OP_LDS_PAD: bytes of dynamic LDS nobody uses -- lowers the workgroups a CU holds; occupancy experiments only:
+        //  profiles/r06/onepass_occupancy.txt, time = 1.62 + 7.97 / (workgroups per CU) ms at 125 x 8e6)
         const unsigned lds_pad = getenv("FK_OP_LDS_PAD") ? (unsigned)atol(getenv("FK_OP_LDS_PAD")) : 0u;
-#define GO2(P, W) hipLaunchKernelGGL((resample_onepass2_kernel<P, W>), dim3((unsigned)G), block, lds_pad, s, a, pb, polls)
-        long G = (long)total;
-        if (persist) {
-            G = resident[waves];
-            if (const char *gv = getenv("FK_OP_GRID")) { const long gq = atol(gv); if (gq > 0 && gq < G) G = gq; }
-            if (Fn < G) G -= G % Fn;                                       // a workgroup stays with one vector (its u, its descriptors)
-            if (waves == 5) GO2(true, 5); else if (waves == 6) GO2(true, 6); else GO2(true, 7);
-        } else {
-            if (waves == 5) GO2(false, 5); else if (waves == 6) GO2(false, 6); else GO2(false, 7);
-        }
+#define GO2(W) hipLaunchKernelGGL((resample_onepass2_kernel<W>), grid, block, lds_pad, s, a, pb, polls)
+        if (waves == 5) GO2(5); else if (waves == 6) GO2(6); else GO2(7);
 #undef GO2
         hipLaunchKernelGGL((resample_literal_kernel<false>), dim3((unsigned)Fn), dim3(64), 0, s, a);
         hipLaunchKernelGGL((resample_local_kernel<false, 3>), dim3((unsigned)Fn), block, 0, s, r);

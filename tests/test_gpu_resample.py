@@ -272,10 +272,6 @@ def _onepass_mode(monkeypatch, mode):
     if mode in ("waves5", "waves6", "waves7"):     # the instantiation budgeted for that many workgroups per CU (FK_OP_WAVES)
         monkeypatch.setenv("FK_OP_WAVES", mode[-1])
         return
-    if mode == "persist":                          # a resident grid walking the chunks, the next chunk's weights requested ahead
-        monkeypatch.setenv("FK_OP_PERSIST", "1")
-        monkeypatch.setenv("FK_OP_GRID", "37")     # (few workgroups: every one walks many chunks of several vectors)
-        return
     if mode == "nopredict":
         monkeypatch.setenv("FK_OP_PRED_BACK", "0")
         return
@@ -311,7 +307,7 @@ def _check_against_merge_loop(Fn, Np, kinds, filters, monkeypatch, force):
                 assert bool(sth[f] & 4) == (over > 0) and not (sth[f] & 8), (Np, kind, strat, f, int(sth[f]))
 
 
-@pytest.mark.parametrize("mode", ["spec", "round3", "nopredict", "predict-near", "waves5", "waves6", "waves7", "persist", "two-stage", "tickets"])
+@pytest.mark.parametrize("mode", ["spec", "round3", "nopredict", "predict-near", "waves5", "waves6", "waves7", "two-stage", "tickets"])
 @pytest.mark.parametrize("Np", [1, 2, 100, 2049, 65536])
 def test_onepass_every_route_small(Np, mode, monkeypatch):
     """FK_RESAMPLE_PATH=onepass forces short vectors through the one-pass kernel: every weight family, every filter,
@@ -321,7 +317,7 @@ def test_onepass_every_route_small(Np, mode, monkeypatch):
     _check_against_merge_loop(5, Np, kinds, range(5), monkeypatch, force=True)
 
 
-@pytest.mark.parametrize("mode", ["spec", "round3", "nopredict", "predict-near", "waves5", "waves6", "waves7", "persist", "two-stage", "tickets"])
+@pytest.mark.parametrize("mode", ["spec", "round3", "nopredict", "predict-near", "waves5", "waves6", "waves7", "two-stage", "tickets"])
 def test_onepass_every_route_long(mode, monkeypatch):
     """default dispatch on a long ragged vector (not a multiple of the chunk, odd address alignment per filter), in the three
     protocols of the one-pass kernel: speculation + static chunk assignment (round 3's default), round 2's two stages on
@@ -343,7 +339,7 @@ def test_onepass_repairs_itself_when_a_hand_off_times_out(mode, monkeypatch):
     _check_against_merge_loop(3, 40000, ("uniform", "heavy_tail", "sum_half"), range(3), monkeypatch, force=False)
 
 
-@pytest.mark.parametrize("mode", ["spec", "round3", "predict-near", "waves7", "persist"])
+@pytest.mark.parametrize("mode", ["spec", "round3", "predict-near", "waves7"])
 def test_onepass_one_long_vector_walks_binade_segments(mode, monkeypatch):
     """ONE filter of 3e6 weights: the chunks of every binade segment wait for the carry-out of the segment before it (the
     serial part of a call with few filters: ~12 binade crossings, each resolved by the general scan of its chunk)"""
