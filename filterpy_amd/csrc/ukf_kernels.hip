@@ -62,13 +62,26 @@ namespace fk {
 //     each (wave_store_soa_pairs: 21 instead of 42 vector-memory operations per step at (6,3)).  Compile-time, not a branch:
 //     two store sequences of different lengths behind a run-time test make the compiler's s_waitcnt for z a vmcnt(0).
 //     Full workgroups only -- the launcher hands the last partial workgroup to the plain instantiation.
-template <int NX, int NZ, int LAYOUT, bool EXACT, bool PAIRED, bool SP = false>
+//   * PERS (round 6): a persistent grid drawing TICKETS, like kf_ml's (kf_ml.hip).  Every wave runs the same T steps, and BASELINE
+//     configs[3] is 391 workgroups for 512 slots (two per CU): 135 CUs carry two workgroups for the whole call, 121 carry one
+//     and idle half their issue slots -- the launch takes what a two-workgroup CU takes (round 5: VALU executing 32 % of wave
+//     residency, 49 % waiting for issue).  Here the call is cut into G = ceil(N / 256) track groups x H time chunks and 2 x CUs
+//     resident workgroups draw tickets chunk-major; chunk h of a group waits for chunk h - 1 (a ticket at least G draws older:
+//     held by a workgroup that runs or is done) through a completion word and picks the state up from an element-major
+//     hand-over block ([NX + NX (NX + 1) / 2][N], agent-scope accesses: no fence, no L2 write-back).  Same arithmetic per
+//     track: bit-identical to the single launch (tests/test_gpu_ukf.py).
+template <int NX, int NZ, int LAYOUT, bool EXACT, bool PAIRED, bool SP = false, bool PERS = false>
 __global__ void __launch_bounds__(BLOCK, (NX <= 2 ? 4 : NX <= 6 ? 2 : 1))
-ukf_linear_kernel(const UkfArgs a, const double *__restrict__ pF, const double *__restrict__ pH,
+ukf_linear_kernel(const UkfArgs a_in, const double *__restrict__ pF, const double *__restrict__ pH,
                   const double *__restrict__ pQ, const double *__restrict__ pR,
                   const double *__restrict__ pWm, const double *__restrict__ pWc,
-                  const double *__restrict__ pz, const uint8_t *__restrict__ pmask)
+                  const double *__restrict__ pz_in, const uint8_t *__restrict__ pmask_in,
+                  int *pers_ctl = nullptr, double *pers_ws = nullptr, const int pers_G = 1, const int pers_H = 1)
 {
+    static_assert(!PERS || EXACT, "PERS: the exact instantiations");
+    UkfArgs a = a_in;
+    const double *pz = pz_in;
+    const uint8_t *pmask = pmask_in;
     constexpr int KS = 2 * NX + 1;
     constexpr int PL = NX * (NX + 1) / 2;
     using SharedModel = LdsModel<NX, NZ>;
@@ -84,13 +97,8 @@ ukf_linear_kernel(const UkfArgs a, const double *__restrict__ pF, const double *
     static_assert(!SP || (EXACT && LAYOUT == LAYOUT_SOA && NX <= 6 && NX % 2 == 0), "SP: element-major, exact even dims up to 6");
     constexpr int TILE = 64 * NX * NX;
     __shared__ double s_tile[(COOP || PAIRS) ? (BLOCK / 64) * TILE : 1];
-    const long N = a.N;
-    const long blk0 = a.i0 + (long)blockIdx.x * BLOCK;
-    const long left = a.i0 + a.cnt - blk0;
-    const unsigned last_row = (unsigned)(left < BLOCK ? left : BLOCK) - 1u;
-    const bool live = threadIdx.x <= last_row;
-    const Lane ln{blk0, live ? threadIdx.x : last_row, N};      // lanes past the last track duplicate it
-    const int n = EXACT ? NX : a.n, m = EXACT ? NZ : a.m;
+    const long N = a_in.N;
+    const int n = EXACT ? NX : a_in.n, m = EXACT ? NZ : a_in.m;
     const int ks = 2 * n + 1;
     double *tile = s_tile + ((COOP || PAIRS) ? (threadIdx.x >> 6) * TILE : 0);
     const unsigned lane = threadIdx.x & 63u, wave_row0 = (threadIdx.x >> 6) * 64u;
@@ -128,13 +136,56 @@ ukf_linear_kernel(const UkfArgs a, const double *__restrict__ pF, const double *
         return View{SharedModel{mb}, mb + SharedModel::SIZE, mb + SharedModel::SIZE + KS, mb + SharedModel::SIZE + 2 * KS};
     };
 
+    [[maybe_unused]] int pers_g = 0, pers_h = 0;
+    __shared__ int s_task;
+    const int st_prologue = st;
+    for (;;) {                                                   // PERS: one trip per ticket; otherwise exactly one trip
+    unsigned bid = blockIdx.x;
+    if constexpr (PERS) {
+        __syncthreads();                                         // the previous ticket's LDS traffic is over, s_task is free
+        if (threadIdx.x == 0) s_task = atomicAdd(pers_ctl, 1);
+        __syncthreads();
+        const int task = __builtin_amdgcn_readfirstlane(s_task);
+        if (task >= pers_G * pers_H) break;
+        pers_h = task / pers_G;
+        pers_g = task - pers_h * pers_G;
+        bid = (unsigned)pers_g;
+        const long t0 = a_in.T * pers_h / pers_H, t1 = a_in.T * (pers_h + 1) / pers_H;
+        a = a_in;
+        a.T = t1 - t0;
+        pz = pz_in + t0 * N * m;
+        pmask = pmask_in ? pmask_in + t0 * N : nullptr;
+        a.means = a_in.means ? a_in.means + t0 * N * NX : nullptr;
+        a.covs = a_in.covs ? a_in.covs + t0 * N * (NX * NX) : nullptr;
+        a.status_or = t0 > 0 ? 1 : a_in.status_or;
+        st = st_prologue;
+        if (pers_h > 0) {
+            if (threadIdx.x == 0) {
+                while (__hip_atomic_load(&pers_ctl[1 + pers_g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < pers_h) __builtin_amdgcn_s_sleep(8);
+            }
+            __syncthreads();
+        }
+    }
+    const long blk0 = a.i0 + (long)bid * BLOCK;
+    const long left = a.i0 + a.cnt - blk0;
+    const unsigned last_row = (unsigned)(left < BLOCK ? left : BLOCK) - 1u;
+    const bool live = threadIdx.x <= last_row;
+    const Lane ln{blk0, live ? threadIdx.x : last_row, N};      // lanes past the last track duplicate it
     double x[NX], P[PL];
+    if (PERS && pers_h > 0) {
+        // a later chunk of the group: the state the previous chunk left in the hand-over block (element-major: 512 contiguous
+        // bytes per wave instruction; agent-scope loads -- coherent across the XCDs' L2s without a fence)
+        const double *hx = pers_ws + (blk0 + ln.tid);
+        FK_UNROLL for (int c = 0; c < NX; ++c) x[c] = __hip_atomic_load(hx + (long)c * N, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        FK_UNROLL for (int e = 0; e < PL; ++e) P[e] = __hip_atomic_load(hx + (long)(NX + e) * N, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
     load_rec<NX, 1, LAYOUT, EXACT>(x, a.x, ln, n, 1, 0.0);
     {
         const RecView<LAYOUT> pv(a.P, ln, n * n);
         FK_UNROLL for (int i = 0; i < NX; ++i)
             FK_UNROLL for (int j = 0; j < NX; ++j)
                 if (j >= i) P[sym_idx<NX>(i, j)] = (EXACT || (i < n && j < n)) ? pv.load(i * n + j) : (i == j ? 1.0 : 0.0);
+    }
     }
     // without a mask the byte comes from a valid dummy address (the measurements) and is selected away: no branch.  Read
     // through a descriptor (uniform base advanced per step + the lane's 32-bit offset): a per-lane 64-bit pointer that
@@ -198,16 +249,38 @@ ukf_linear_kernel(const UkfArgs a, const double *__restrict__ pF, const double *
     }
     __syncthreads();
     if (live) {
+        if (PERS && pers_h + 1 < pers_H) {
+            // not the group's last chunk: the state goes to the hand-over block (agent-scope stores), x / P stay untouched
+            double *hx = pers_ws + (blk0 + ln.tid);
+            FK_UNROLL for (int c = 0; c < NX; ++c) __hip_atomic_store(hx + (long)c * N, x[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            FK_UNROLL for (int e = 0; e < PL; ++e) __hip_atomic_store(hx + (long)(NX + e) * N, P[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
         store_rec<NX, 1, LAYOUT, EXACT>(x, a.x, ln, n, 1);
         double Pf[NX * NX];
         FK_UNROLL for (int i = 0; i < NX; ++i)
             FK_UNROLL for (int j = 0; j < NX; ++j) Pf[i * NX + j] = P[sym_idx<NX>(i, j)];
         store_rec<NX, NX, LAYOUT, EXACT>(Pf, a.P, ln, n, n);
+        }
         if (a.status) {
             if (!all_finite<NX>(x) || !all_finite<PL>(P)) st |= ST_NONFINITE;
-            a.status[ln.blk0 + ln.tid] = a.status_or ? (a.status[ln.blk0 + ln.tid] | st) : st;
+            if constexpr (PERS) {
+                const int old = a.status_or ? __hip_atomic_load(&a.status[ln.blk0 + ln.tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+                __hip_atomic_store(&a.status[ln.blk0 + ln.tid], old | st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                a.status[ln.blk0 + ln.tid] = a.status_or ? (a.status[ln.blk0 + ln.tid] | st) : st;
+            }
         }
     }
+    if constexpr (PERS) {
+        // the chunk's state (and status) is in place once every wave's vmcnt has drained -- a workgroup barrier does not wait
+        // for VMEM (kf_ml.hip) --, then the barrier, then the chunk is published
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(&pers_ctl[1 + pers_g], pers_h + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        break;
+    }
+    }      // tickets
 }
 
 #endif
@@ -257,9 +330,68 @@ static void ukf_launch_sp(const UkfArgs &a, hipStream_t s)
     }
 }
 
+// The persistent grid (PERS instantiation; the exact (6, 3) class with pair weights: BASELINE configs[3]): a whole-bank call of
+// more workgroups than CUs and at least 32 steps is cut into G track groups x H time chunks, 2 x CUs resident workgroups draw
+// tickets.  H: the count in [4, T / 6] whose last round of tickets is fullest (ceil(G H / slots) rounds of T / H steps), the
+// larger chunk on a draw.  The ticket counter, the completion words and the hand-over block live in a stream-ordered scratch
+// allocation of this call (hipMallocAsync: no state shared between concurrent calls).  FK_UKF_PERSIST=0: off;
+// FK_UKF_PERSIST_H: the chunk count.  Returns 1 where the call is not one it takes.
+template <bool PV>
+static int ukf_fwd_persistent_6_3(const UkfArgs &a, int layout, hipStream_t s)
+{
+    if constexpr (!PV) return 1;
+    else {
+    // OFF unless FK_UKF_PERSIST=1.  Measured (profiles/r06/ukf_persist.txt, 1e5 x 100, same lease): one launch 0.81-0.85 ms, tickets
+    // with H = 5 / 8 / 10 / 13 chunks 0.87 / 0.91 / 0.94 / 0.96 -- every chunk costs ~10 us (ticket, completion word, state reload,
+    // drain) and the balance buys NOTHING: a CU that carries one workgroup takes as long as one that carries two.  The launch is
+    // bound by the length of ONE wave's dependent instruction chain (100 steps x 1193 instructions at ~6.9 ns each), not by issue
+    // slots: what would help is a shorter chain per step, not a better spread of the waves.
+    const char *pv = getenv("FK_UKF_PERSIST");
+    if (!(pv && atoi(pv) == 1)) return 1;
+    if (a.i0 != 0 || a.cnt != a.N || a.T < 32) return 1;
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+                   ? prop.multiProcessorCount : 256;
+    }
+    const long G = (a.cnt + BLOCK - 1) / BLOCK, slots = 2L * n_cu;
+    if (G <= n_cu || G > (1L << 24)) return 1;
+    long H = 0;
+    double best = 0.0;
+    for (long h = 4; h <= a.T / 6; ++h) {
+        const double rounds = (double)(G * h) / (double)slots, fill = rounds / (double)((G * h + slots - 1) / slots);
+        if (fill > best + 0.02) { best = fill; H = h; }
+    }
+    if (const char *hv = getenv("FK_UKF_PERSIST_H")) H = atol(hv);
+    if (H < 2 || H > a.T) return 1;
+    const bool sp = layout == FK_LAYOUT_SOA && ukf_sp_ok<6>(a);
+    int *ctl = nullptr;
+    const size_t cbytes = ((size_t)(1 + G) * sizeof(int) + 255) & ~(size_t)255, wbytes = (size_t)(6 + 21) * (size_t)a.N * sizeof(double);
+    if (hipMallocAsync((void **)&ctl, cbytes + wbytes, s) != hipSuccess || !ctl) { (void)hipGetLastError(); return 1; }
+    if (hipMemsetAsync(ctl, 0, cbytes, s) != hipSuccess) { (void)hipFreeAsync(ctl, s); (void)hipGetLastError(); return 1; }
+    double *ws = reinterpret_cast<double *>(reinterpret_cast<char *>(ctl) + cbytes);
+    const dim3 grid((unsigned)(G * H < slots ? G * H : slots)), block(BLOCK);
+    if (layout == FK_LAYOUT_SOA) {
+        if (sp) hipLaunchKernelGGL((ukf_linear_kernel<6, 3, LAYOUT_SOA, true, true, true, true>), grid, block, 0, s, a, a.F, a.H, a.Q, a.R, a.Wm, a.Wc, a.z, a.mask, ctl, ws, (int)G, (int)H);
+        else hipLaunchKernelGGL((ukf_linear_kernel<6, 3, LAYOUT_SOA, true, true, false, true>), grid, block, 0, s, a, a.F, a.H, a.Q, a.R, a.Wm, a.Wc, a.z, a.mask, ctl, ws, (int)G, (int)H);
+    } else {
+        hipLaunchKernelGGL((ukf_linear_kernel<6, 3, LAYOUT_AOS, true, true, false, true>), grid, block, 0, s, a, a.F, a.H, a.Q, a.R, a.Wm, a.Wc, a.z, a.mask, ctl, ws, (int)G, (int)H);
+    }
+    const int rc = check_launch("ukf_linear_kernel<pers>");
+    (void)hipFreeAsync(ctl, s);
+    return rc;
+    }
+}
+
 template <bool PV>
 static int ukf_fwd_small_t(const UkfArgs &a, int layout, bool exact, hipStream_t s)
 {
+    if (PV && exact && a.n == 6 && a.m == 3) {
+        const int rc = ukf_fwd_persistent_6_3<PV>(a, layout, s);
+        if (rc <= 0) return rc;                                // 1 = not a call the persistent grid takes
+    }
     if (a.n <= 2 && a.m <= 2) FK_UKF_GO(2, 2);
     else if (a.n <= 4 && a.m <= 2) FK_UKF_GO(4, 2);
     else FK_UKF_GO(6, 3);

@@ -289,3 +289,52 @@ def test_element_major_pair_stores_are_bit_identical(n, m, mask, monkeypatch):
         for a, b in zip(res["pairs"], res["plain"]):
             assert np.array_equal(a, b), (n, m, N, mask)
         assert np.all(np.isfinite(res["pairs"][0])) and np.all(np.isfinite(res["pairs"][1]))
+
+
+@pytest.mark.parametrize("mask", [False, True])
+@pytest.mark.parametrize("layout", ["soa", "aos"])
+def test_persistent_grid_of_the_fused_ukf_is_bit_identical(layout, mask, monkeypatch):
+    """Round 6 (FK_UKF_PERSIST=1; measured slower than the single launch and therefore off by default -- the finding is in
+    csrc/ukf_kernels.hip): a whole-bank (6,3) call with pair weights, more workgroups than CUs and at least 32 steps on a persistent
+    grid drawing tickets -- track groups x time chunks, the state handed from chunk to chunk through an element-major block
+    (csrc/ukf_kernels.hip, PERS).  Same arithmetic per track: every output, the final state and the status equal the single
+    launch's (FK_UKF_PERSIST=0) bit for bit -- ragged bank (a partial last workgroup; odd bank: the 8-byte stores), forced
+    chunk counts incl. one that does not divide T, missing measurements, a non-SPD track whose status bit must survive."""
+    import torch
+    from filterpy_amd import _engine as E, _abi
+    from oracle import ukf_oracle
+    n, m, T = 6, 3, 41
+    rs = np.random.RandomState(77)
+    alpha, beta, kappa = .1, 2., 3. - n
+    lam = alpha ** 2 * (n + kappa) - n
+    Wm, Wc = ukf_oracle.merwe_weights(n, alpha, beta, kappa)
+    F = np.eye(n) + 0.05 * np.triu(rs.randn(n, n), 1)
+    H = np.eye(m, n) + 0.1 * rs.randn(m, n)
+    Q, R = 0.01 * np.eye(n), 0.5 * np.eye(m)
+    for N in (70_000, 66_001):
+        x0, P0 = rs.randn(N, n), np.tile(5.0 * np.eye(n), (N, 1, 1))
+        P0[N // 3] = -np.eye(n)                      # not positive definite: FK_STATUS_NOT_PD on that track, every variant
+        zs = rs.randn(T, N, m)
+        mk = (rs.rand(T, N) > 0.25).astype(np.uint8) if mask else None
+        res = {}
+        for tag, env in (("single", {"FK_UKF_PERSIST": "0"}), ("tickets", {"FK_UKF_PERSIST": "1"}), ("h7", {"FK_UKF_PERSIST": "1", "FK_UKF_PERSIST_H": "7"}),
+                         ("h2", {"FK_UKF_PERSIST": "1", "FK_UKF_PERSIST_H": "2"})):
+            for k in ("FK_UKF_PERSIST", "FK_UKF_PERSIST_H"):
+                monkeypatch.delenv(k, raising=False)
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            dx, dP = E.to_records(x0, layout, 0), E.to_records(P0, layout, 0)
+            means, covs = E.alloc_records((T,), N, n, layout), E.alloc_records((T,), N, n * n, layout)
+            means.fill_(float("nan"))
+            covs.fill_(float("nan"))
+            st = torch.zeros(N, dtype=torch.int32, device=dx.device)
+            E.ukf_linear_batch(n, m, N, T, layout, lam + n, E.dev(F), E.dev(H), E.dev(Q), E.dev(R), E.dev(Wm), E.dev(Wc),
+                               E.to_records(zs, layout, 1), dx, dP, mask=None if mk is None else torch.as_tensor(mk, device=dx.device),
+                               means=means, covs=covs, status=st, paired=True)
+            torch.cuda.synchronize()
+            res[tag] = [t.cpu().numpy() for t in (means, covs, dx, dP, st)]
+        sth = res["single"][4]
+        assert sth[N // 3] & _abi.FK_STATUS_NOT_PD and np.count_nonzero(sth) == 1
+        for tag in ("tickets", "h7", "h2"):
+            for a, b in zip(res["single"], res[tag]):
+                assert np.array_equal(a, b, equal_nan=True), (layout, mask, N, tag)
