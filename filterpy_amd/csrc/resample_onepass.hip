@@ -1378,7 +1378,12 @@ __device__ OP2_SLOW_INLINE void op_chunk_slow(OpShared &sh, const double *a_w, c
             sh.tile[pad8(j)] = j < len ? wf[base + j] : 0.0;
         }
         __syncthreads();
-        const double c_out = general_cumsum(sh, len, c_in);
+        // (round 6: the one-round scan first -- binades predicted for all elements at once, then verified; round 3 went straight
+        //  to general_cumsum, one block scan and four barriers per binade the running sum passes through: ~45 k clocks for the
+        //  first chunk of a vector, ~20 k for a crossing.  Those chunks are 0.5 % of a 125 x 8e6 call and the whole serial
+        //  chain of a call with few long vectors: every binade segment waits for the crossing chunk at its head)
+        double c_out = 0.0;
+        if (!segmented_cumsum(sh, len, c_in, &c_out)) c_out = general_cumsum(sh, len, c_in);
         if (tid == 0) publish_carry(&d[k], c_out);
         // (each thread reads back only its own slots, behind general_cumsum's final barrier; n_j goes into the low
         // half of cs_j's slot so that this loop stays rolled)
