@@ -158,16 +158,16 @@ __device__ __forceinline__ bool spin_fail(unsigned &spins, unsigned *abort_word)
 
 // stage 1, wave 0 only: approximate running sum entering chunk k (k >= 1) = sum of the predecessors' chunk sums
 // down to the nearest published inclusive prefix.  NaN = poison (a bad weight upstream) or abort.
-__device__ double lookback_approx(const OpDesc *d, int k, int lane, unsigned *abort_word)
+__device__ double lookback_approx(const OpDesc *d, int k, int lane, unsigned *abort_word, const int lbw = OP_LB)
 {
     double A = 0.0;
     unsigned spins = 0;
-    for (int j = k - 1;; j -= OP_LB) {
+    for (int j = k - 1;; j -= lbw) {
         const int jj = j - lane;
         u64 word, incl;
         for (;;) {
             // before the vector: inclusive prefix 0; lanes beyond the window: a chunk sum of 0 (never waited for)
-            word = lane >= OP_LB ? (u64)1 : (jj >= 0 ? ld_agent(&d[jj].approx) : (u64)2);
+            word = lane >= lbw ? (u64)1 : (jj >= 0 ? ld_agent(&d[jj].approx) : (u64)2);
             incl = __ballot((word & ST_MASK) == 2);
             const u64 empty = __ballot((word & ST_MASK) == 0);
             const u64 need = incl ? ((incl & (0 - incl)) << 1) - 1 : ~(u64)0;   // lanes up to the nearest inclusive one
@@ -195,22 +195,22 @@ __device__ double read_raw(const OpDesc *d, int jj, unsigned *abort_word)
 // stage 2, wave 0 only: EXACT running sum entering chunk k (k >= 1).  A chunk that knows its binade (`clean`,
 // ulp exponent eu) may add up the increment sums of predecessors in the same binade down to the nearest
 // published carry-out; anything else waits for the carry-out of chunk k-1.  `ok` = false on abort.
-__device__ double lookback_exact(const OpDesc *d, int k, bool clean, int eu, int lane, unsigned *abort_word, bool &ok)
+__device__ double lookback_exact(const OpDesc *d, int k, bool clean, int eu, int lane, unsigned *abort_word, bool &ok, const int lbw = OP_LB)
 {
     ok = true;
     double acc = 0.0;            // integer sum of increments, in units of 2^eu
     unsigned spins = 0;
     const int my9 = eu & 511;
-    for (int j = k - 1;; j -= OP_LB) {
+    for (int j = k - 1;; j -= lbw) {
         const int jj = j - lane;
         u64 word, term;
         for (;;) {
             // before the vector: carry-out 0 (state 3: value in `raw`, handled below without a load); lanes beyond
             // the window: an increment sum of 0
-            word = lane >= OP_LB ? (u64)1 : (jj >= 0 ? ld_agent(&d[jj].exact) : (u64)3);
+            word = lane >= lbw ? (u64)1 : (jj >= 0 ? ld_agent(&d[jj].exact) : (u64)3);
             const u64 st = word & ST_MASK;
             const bool is_term = st >= 2;
-            const bool compat = (clean || lane >= OP_LB) && st == 1 && (exact_eu9(word) == my9 || (word >> 11) == 0);
+            const bool compat = (clean || lane >= lbw) && st == 1 && (exact_eu9(word) == my9 || (word >> 11) == 0);
             term = __ballot(is_term);
             const u64 blocked = __ballot(!(is_term || compat));
             const u64 below = term ? (term & (0 - term)) - 1 : ~(u64)0;   // lanes nearer than the nearest carry-out
@@ -458,18 +458,30 @@ __device__ double general_cumsum(OpShared &sh, int len, double carry)
 // Declining (returns false; the tile still holds the weights) hands the chunk to general_cumsum.
 // In: weights in sh.tile (padded; slots >= len hold +0.0, no negative / NaN weight), exact carry-in.
 // Out: cumulative sums in sh.tile, *c_out = carry-out.
-__device__ __forceinline__ bool segmented_cumsum(OpShared &sh, int len, double carry, double *c_out)
+// The scan comes in three pieces so that a chunk of the one-pass kernel can do everything that does not need the EXACT carry-in
+// before that carry arrives (op_chunk_slow): seg_prepare (steps 1-2 and the lists of step 3; its bounds only need the carry
+// to a relative `slack`, e.g. the approximate carry-in of stage 1 -- the classification is a prediction, step 3 verifies it),
+// seg_chain (step 3's walk, wave 0: the only part behind the carry -- a few dependent adds), seg_finish (step 4).
+struct SegRegs {
+    int eq[OP_ITEMS];
+    unsigned dirty, claims;
+    int dbase, D;
+    u64 pbase, ptotal;
+};
+
+// SYNC_CLAIMS: one more barrier at the end, behind which sg.fail holds every thread's verdict on the claims (the caller's wave 0
+// decides on it alone, before the next barrier).  Returns false (uniform) if the chunk holds too many dirty elements.
+template <bool SYNC_CLAIMS>
+__device__ __forceinline__ bool seg_prepare(OpShared &sh, int len, double carry, double slack, SegRegs &R)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     SegShared &sg = sh.seg;
-    // bound on the relative distance between the plain prefix sums and the sequential fp64 sums: both are within
-    // (OP_TILE + 1) rounding errors of the real sum of non-negative terms, 2 * 2049 * 2^-53 < 2^-41; 2^-38 is safe
-    constexpr double DELTA = 0x1p-38;
     if (tid <= SEG_DMAX) sg.seg_e[tid] = SEG_NONE;
     if (tid == 0) sg.fail = 0;
     // (registers: the weights and one exponent per element are kept; the increments are recomputed from them at each
     // of their three uses -- two instructions -- instead of being held)
     double w[OP_ITEMS];
+    int (&eq)[OP_ITEMS] = R.eq;
     double run = 0.0;
     FK_UNROLL for (int q = 0; q < OP_ITEMS; ++q) {
         w[q] = sh.tile[pad8(tid * OP_ITEMS + q)];
@@ -487,18 +499,14 @@ __device__ __forceinline__ bool segmented_cumsum(OpShared &sh, int len, double c
         if (wv < wave) excl += sg.wtot[wv];
     // classification + increments
     unsigned dirty = 0, claims = 0;       // bit q: element q is dirty / claims a binade (clean and non-zero)
-    int eq[OP_ITEMS];
     int dl = 0;
     u64 psum = 0;
     double prev = carry + excl, arun = 0.0;
-    auto inc_of = [&](int q) -> u64 {     // increment of a claiming element in its claimed binade
-        return (u64)floor(scale2(w[q], -eq[q]) + 0.5);
-    };
     FK_UNROLL for (int q = 0; q < OP_ITEMS; ++q) {
         const int j = tid * OP_ITEMS + q;
         arun += w[q];
         const double cur = carry + (excl + arun);
-        const double lo = prev * (1.0 - DELTA), hi = cur * (1.0 + DELTA);
+        const double lo = prev * (1.0 - slack), hi = cur * (1.0 + slack);
         const bool known = lo > OP_SANE_LO && hi < OP_SANE_HI && ulp_exp(lo) == ulp_exp(hi);
         const int e = ulp_exp(lo);
         const double x = scale2(w[q], -e) + 0.5;
@@ -533,6 +541,12 @@ __device__ __forceinline__ bool segmented_cumsum(OpShared &sh, int len, double c
         D += sg.dtot[wv];
         ptotal += sg.ptot[wv];
     }
+    R.dirty = dirty;
+    R.claims = claims;
+    R.dbase = dbase;
+    R.D = D;
+    R.pbase = pbase;
+    R.ptotal = ptotal;
     if (D > SEG_DMAX) return false;                                        // uniform
     // the dirty list and the segments' claims (all claimants of a segment write the same value -- checked below)
     {
@@ -541,7 +555,7 @@ __device__ __forceinline__ bool segmented_cumsum(OpShared &sh, int len, double c
         FK_UNROLL for (int q = 0; q < OP_ITEMS; ++q) {
             if (claims & (1u << q)) {
                 sg.seg_e[r] = eq[q];
-                ps += inc_of(q);
+                ps += (u64)floor(scale2(w[q], -eq[q]) + 0.5);
             }
             if (dirty & (1u << q)) {
                 sg.d_pos[r] = tid * OP_ITEMS + q;
@@ -563,74 +577,102 @@ __device__ __forceinline__ bool segmented_cumsum(OpShared &sh, int len, double c
         }
         if (bad) sg.fail = 1;
     }
-    // ---- the chain over the segments (wave 0; lane r holds segment r and dirty element r) -------------------------
-    // Everything that does not depend on the running sum is prepared by the lanes in parallel -- the segment's whole
-    // increment sum as a double in units of ONE (I 2^e: exact, a power-of-two scaling) and the exponent field its
-    // running sum must show -- so that the serial part is two dependent fp64 adds per segment:
-    //   c + I 2^e  is exact when C0 + I < 2^53 (the sum is representable), and when it is not the rounded result is
-    //   >= 2^(e+53), the next binade (rounding is monotone, the bound is representable): the exponent field of the
-    //   result tells; the exponent field of c before the add is the claim itself.
-    if (wave == 0) {
-        const u64 my_end = lane < D ? sg.d_ps[lane < SEG_DMAX ? lane : 0] : ptotal;
-        const u64 my_start = (lane >= 1 && lane <= D) ? sg.d_ps[lane - 1] : 0;
-        const int my_e = lane <= D ? sg.seg_e[lane] : SEG_NONE;
-        const double my_w = lane < D ? sg.d_w[lane < SEG_DMAX ? lane : 0] : 0.0;
-        const u64 I = my_end - my_start;                                   // (wrapping; < 2^53 for a segment that passes)
-        const bool claim = my_e != SEG_NONE;
-        int fail = (lane <= D && ((claim && !(I < (1ull << 53))) || (!claim && I != 0))) ? 1 : 0;
-        const double my_add = claim ? scale2((double)I, my_e) : 0.0;      // I 2^e
-        const int my_xf = claim ? my_e + 1075 : -1;                        // biased exponent of a sum with ulp 2^e (-1: any)
-        double c = carry, r_c = 0.0, r_dcs = 0.0;
-        for (int r = 0; r <= D; ++r) {                                     // uniform
-            const double add = lane_bcast(my_add, r);
-            const double wr = lane_bcast(my_w, r);
-            const int xf = __builtin_amdgcn_readlane(my_xf, r);
-            const int x0 = (int)((double_to_bits(c) >> 52) & 0x7ffu);
-            if (lane == r) r_c = c;
-            c = c + add;                                                   // exact, or out of the binade (see above)
-            const int x1 = (int)((double_to_bits(c) >> 52) & 0x7ffu);
-            fail |= (xf >= 0 && (x0 != xf || x1 != xf || xf <= 1075 - 900 || xf >= 1075 + 900 - 52)) ? 1 : 0;
-            if (r < D) {
-                c = c + wr;                                                // the real IEEE add of the dirty element
-                if (lane == r) r_dcs = c;
-            }
+    if (SYNC_CLAIMS) __syncthreads();                                                         // (3b)
+    return true;
+}
+
+// ---- the chain over the segments (wave 0; lane r holds segment r and dirty element r) -------------------------
+// Everything that does not depend on the running sum is prepared by the lanes in parallel -- the segment's whole
+// increment sum as a double in units of ONE (I 2^e: exact, a power-of-two scaling) and the exponent field its
+// running sum must show -- so that the serial part is two dependent fp64 adds per segment:
+//   c + I 2^e  is exact when C0 + I < 2^53 (the sum is representable), and when it is not the rounded result is
+//   >= 2^(e+53), the next binade (rounding is monotone, the bound is representable): the exponent field of the
+//   result tells; the exponent field of c before the add is the claim itself.
+// Returns the carry-out; failed (wave-uniform) = the walk contradicts a claim (the caller declines the scan).
+__device__ __forceinline__ double seg_chain(OpShared &sh, double carry, int D, u64 ptotal, int lane, bool &failed)
+{
+    SegShared &sg = sh.seg;
+    const u64 my_end = lane < D ? sg.d_ps[lane < SEG_DMAX ? lane : 0] : ptotal;
+    const u64 my_start = (lane >= 1 && lane <= D) ? sg.d_ps[lane - 1] : 0;
+    const int my_e = lane <= D ? sg.seg_e[lane] : SEG_NONE;
+    const double my_w = lane < D ? sg.d_w[lane < SEG_DMAX ? lane : 0] : 0.0;
+    const u64 I = my_end - my_start;                                   // (wrapping; < 2^53 for a segment that passes)
+    const bool claim = my_e != SEG_NONE;
+    int fail = (lane <= D && ((claim && !(I < (1ull << 53))) || (!claim && I != 0))) ? 1 : 0;
+    const double my_add = claim ? scale2((double)I, my_e) : 0.0;      // I 2^e
+    const int my_xf = claim ? my_e + 1075 : -1;                        // biased exponent of a sum with ulp 2^e (-1: any)
+    double c = carry, r_c = 0.0, r_dcs = 0.0;
+    for (int r = 0; r <= D; ++r) {                                     // uniform
+        const double add = lane_bcast(my_add, r);
+        const double wr = lane_bcast(my_w, r);
+        const int xf = __builtin_amdgcn_readlane(my_xf, r);
+        const int x0 = (int)((double_to_bits(c) >> 52) & 0x7ffu);
+        if (lane == r) r_c = c;
+        c = c + add;                                                   // exact, or out of the binade (see above)
+        const int x1 = (int)((double_to_bits(c) >> 52) & 0x7ffu);
+        fail |= (xf >= 0 && (x0 != xf || x1 != xf || xf <= 1075 - 900 || xf >= 1075 + 900 - 52)) ? 1 : 0;
+        if (r < D) {
+            c = c + wr;                                                // the real IEEE add of the dirty element
+            if (lane == r) r_dcs = c;
         }
-        if (lane <= D) {
-            sg.seg_c[lane] = r_c;
-            sg.seg_ps0[lane] = my_start;
-            if (lane < D) sg.d_cs[lane] = r_dcs;
-        }
-        if (__builtin_amdgcn_ballot_w64(fail != 0) != 0 && lane == 0) sg.fail = 1;
-        if (lane == 0) sg.carry_out = c;
     }
-    __syncthreads();                                                                          // (4)
-#ifdef FK_OP_CLOCKS
-    if (tid == 0) sg.dbg_t[3] = clock64();
-#endif
-    if (sg.fail) return false;                                             // uniform; the tile is untouched
-    {
-        int r = dbase;
-        u64 ps = pbase;
-        FK_UNROLL for (int q = 0; q < OP_ITEMS; ++q) {
-            const int j = tid * OP_ITEMS + q;
-            if (claims & (1u << q)) ps += inc_of(q);
-            double cs;
-            if (dirty & (1u << q)) {
-                cs = sg.d_cs[r];
-                ++r;
-            } else {
-                // (C0 + dPS) 2^e = c_start + dPS 2^e: exact for the same reason as in the chain
-                const int e = sg.seg_e[r];
-                cs = e == SEG_NONE ? sg.seg_c[r] : sg.seg_c[r] + scale2((double)(ps - sg.seg_ps0[r]), e);
-            }
-            if (j < len) sh.tile[pad8(j)] = cs;
+    if (lane <= D) {
+        sg.seg_c[lane] = r_c;
+        sg.seg_ps0[lane] = my_start;
+        if (lane < D) sg.d_cs[lane] = r_dcs;
+    }
+    failed = __builtin_amdgcn_ballot_w64(fail != 0) != 0;
+    if (failed && lane == 0) sg.fail = 1;
+    if (lane == 0) sg.carry_out = c;
+    return c;
+}
+
+// step 4 (behind a barrier that follows seg_chain; sg.fail == 0): the cumulative sums into the tile, one more barrier
+__device__ __forceinline__ void seg_finish(OpShared &sh, int len, const SegRegs &R)
+{
+    const int tid = threadIdx.x;
+    SegShared &sg = sh.seg;
+    int r = R.dbase;
+    u64 ps = R.pbase;
+    FK_UNROLL for (int q = 0; q < OP_ITEMS; ++q) {
+        const int j = tid * OP_ITEMS + q;
+        // (the weight once more from the thread's own tile slot, overwritten below: not kept in registers across the wait for the carry)
+        if (R.claims & (1u << q)) ps += (u64)floor(scale2(sh.tile[pad8(j)], -R.eq[q]) + 0.5);
+        double cs;
+        if (R.dirty & (1u << q)) {
+            cs = sg.d_cs[r];
+            ++r;
+        } else {
+            // (C0 + dPS) 2^e = c_start + dPS 2^e: exact for the same reason as in the chain
+            const int e = sg.seg_e[r];
+            cs = e == SEG_NONE ? sg.seg_c[r] : sg.seg_c[r] + scale2((double)(ps - sg.seg_ps0[r]), e);
         }
+        if (j < len) sh.tile[pad8(j)] = cs;
     }
     __syncthreads();                                                                          // (5)
 #ifdef FK_OP_CLOCKS
     if (tid == 0) sg.dbg_t[4] = clock64();
 #endif
-    *c_out = sg.carry_out;
+}
+
+__device__ __forceinline__ bool segmented_cumsum(OpShared &sh, int len, double carry, double *c_out)
+{
+    // bound on the relative distance between the plain prefix sums and the sequential fp64 sums: both are within
+    // (OP_TILE + 1) rounding errors of the real sum of non-negative terms, 2 * 2049 * 2^-53 < 2^-41; 2^-38 is safe
+    constexpr double DELTA = 0x1p-38;
+    SegRegs R;
+    if (!seg_prepare<false>(sh, len, carry, DELTA, R)) return false;       // uniform
+    if (threadIdx.x < 64) {
+        bool failed;
+        seg_chain(sh, carry, R.D, R.ptotal, (int)threadIdx.x, failed);
+    }
+    __syncthreads();                                                                          // (4)
+#ifdef FK_OP_CLOCKS
+    if (threadIdx.x == 0) sh.seg.dbg_t[3] = clock64();
+#endif
+    if (sh.seg.fail) return false;                                         // uniform; the tile is untouched
+    seg_finish(sh, len, R);
+    *c_out = sh.seg.carry_out;
     return true;
 }
 
@@ -642,6 +684,9 @@ constexpr int OP_PHASE_SLOTS = 16, OP_PHASE_BUCKETS = 1024;
 __device__ unsigned long long fk_op_phase[OP_PHASE_SLOTS][OP_PHASE_BUCKETS];
 __device__ double *g_dbg_cs;     // [Fn][Np] dump of the cumulative sums / boundaries the kernel worked with (or null)
 __device__ int *g_dbg_n;
+__device__ unsigned long long *g_dbg_tl;   // [Fn * nch][16] wall-clock stamps (100 MHz) of a chunk's way through the kernel (or null)
+#define OP_STAMP(slot) do { if (threadIdx.x == 0 && g_dbg_tl) g_dbg_tl[((long)f * nch + k) * 16 + (slot)] = wall_clock64(); } while (0)
+#define OP_NOTE(slot, v) do { if (threadIdx.x == 0 && g_dbg_tl) g_dbg_tl[((long)f * nch + k) * 16 + (slot)] = (unsigned long long)(v); } while (0)
 // (accumulators live in LDS, touched by thread 0 only: sixteen 64-bit counters in registers would spill)
 #define OP_CLOCK_START() __shared__ long long t_acc[OP_PHASE_SLOTS]; long long t_prev = clock64(); \
     if (threadIdx.x == 0) for (int q_ = 0; q_ < OP_PHASE_SLOTS; ++q_) t_acc[q_] = 0
@@ -654,6 +699,8 @@ __device__ int *g_dbg_n;
 #define OP_CLOCK(slot) do { } while (0)
 #define OP_COUNT(slot, n) do { } while (0)
 #define OP_CLOCK_FLUSH() do { } while (0)
+#define OP_STAMP(slot) do { } while (0)
+#define OP_NOTE(slot, v) do { } while (0)
 #endif
 
 // ---- the kernel -------------------------------------------------------------------------------------------
@@ -1178,7 +1225,8 @@ resample_onepass_kernel(const OpArgs a)
 template <bool STRATIFIED, int BUDGET>
 __device__ OP2_SLOW_INLINE void op_chunk_slow(OpShared &sh, const double *a_w, const double *a_u, int32_t *a_idx, int32_t *a_status,
                                                         OpCtl *a_ctl, OpDesc *a_desc, int *a_bad, const double a_delta, const long a_Np,
-                                                        const long a_nch, const int f, const int k, const double S_in, const int any_bad_in)
+                                                        const long a_nch, const int f, const int k, const double S_in, const int any_bad_in,
+                                                        const int lb_mode)
 {
     // (the arguments one by one: an OpArgs by value would travel through scratch memory, written at the top of the CALLER)
     OpArgs a = {};
@@ -1202,6 +1250,9 @@ __device__ OP2_SLOW_INLINE void op_chunk_slow(OpShared &sh, const double *a_w, c
         const double t = wf[base + (j < len ? j : 0)];
         w8[q] = j < len ? t : 0.0;
     }
+    // (lb_mode & 8: 64 predecessors per look-back step instead of 16 -- calls with few long vectors walk hundreds of chunks back.
+    //  Measured with and without, and with s_setprio 3 on this path: 1 x 8e6 108 / 110 / 111 us, nothing -- profiles/r06/onepass/r06o)
+    const int lbw = (lb_mode & 8) ? 64 : OP_LB;
     const bool any_bad = any_bad_in != 0;
     const double S = any_bad ? __builtin_nan("") : S_in;
     double E[OP_ITEMS];
@@ -1209,15 +1260,18 @@ __device__ OP2_SLOW_INLINE void op_chunk_slow(OpShared &sh, const double *a_w, c
     int eu = 0;
     const bool hit = false;
     __syncthreads();                                                       // everybody has left the fast path's LDS slots
+    OP_STAMP(5);
     init_window(win, tid);
     bool at_start = false;
+    SegRegs R;
+    bool prepared = false, scan_tried = false;
     if (!hit) {
     // ---- stage 1: approximate carry-in --------------------------------------------------------------------
     if (wave == 0) {
         double A = 0.0;
         if (k > 0) {
             if (lane == 0) st_agent(&d[k].approx, pack_approx(S, 1));
-            A = lookback_approx(d, k, lane, abort_word);
+            A = lookback_approx(d, k, lane, abort_word, lbw);
         }
         if (lane == 0) {
             st_agent(&d[k].approx, pack_approx(A + S, 2));
@@ -1225,6 +1279,7 @@ __device__ OP2_SLOW_INLINE void op_chunk_slow(OpShared &sh, const double *a_w, c
         }
     }
     __syncthreads();                                                                          // (B)
+    OP_STAMP(6);
     const double A = sh.bc_d[0];
 
     // ---- what stage 1 tells this chunk --------------------------------------------------------------------
@@ -1280,13 +1335,41 @@ __device__ OP2_SLOW_INLINE void op_chunk_slow(OpShared &sh, const double *a_w, c
         FK_UNROLL for (int q = 0; q < OP_ITEMS; ++q) E[q] = 0.0;
     }
 
+    // ---- a chunk that needs the general scan prepares it NOW (lb_mode & 4): the weights into the tile, seg_prepare on the
+    // APPROXIMATE carry-in of stage 1 (relative error <= a.delta; exactly 0 at the start of a vector) -- all of this before the
+    // exact carry-in has arrived, while the chunks below are still being resolved.  What is left behind the carry is
+    // seg_chain, a few dependent adds by wave 0, and the carry-out goes out at once: with few long vectors every crossing of
+    // a binade and every tie-holder sits on the one chain all later chunks wait for, and it used to hold that chain for a
+    // reload of its weights, five barriers and the whole scan -- 7 us per crossing, 19 crossings in a row at 1 x 2e6
+    // (tools/op_timeline.py; profiles/r06/onepass/timeline_before.txt).
+    if (!fast && (lb_mode & 4) && !(at_start && S == 0.0)) {               // uniform
+        FK_UNROLL for (int q = 0; q < OP_ITEMS; ++q) sh.tile[pad8(tid * OP_ITEMS + q)] = w8[q];   // (0.0 behind len)
+        __syncthreads();
+        scan_tried = true;
+        prepared = seg_prepare<true>(sh, len, at_start ? 0.0 : A, (at_start ? 0.0 : a.delta) + 0x1p-38, R);
+    }
     // ---- stage 2: exact carry-in ---------------------------------------------------------------------------
+    OP_STAMP(7);
     if (wave == 0) {
         double c_in = 0.0;
         bool ok = true;
         if (!at_start) {
             if (fast && lane == 0) st_agent(&d[k].exact, pack_exact(1, eu, I));
-            c_in = lookback_exact(d, k, fast, eu, lane, abort_word, ok);
+            // (lb_mode & 2: a chunk that does NOT stay inside one binade -- a crossing -- still knows the binade of its carry-in from
+            //  stage 1, and may add up the predecessors' increment sums in THAT binade down to the nearest carry-out like anybody
+            //  else (the argument of lookback_exact is about the chunks in between, not about this one) instead of waiting for
+            //  chunk k-1 to see that carry, add the same sums and publish: one global round trip less per binade on the chain
+            //  every chunk of the binade above waits for)
+            bool lb_ok = fast;
+            int lb_eu = eu;
+            if (!fast && (lb_mode & 2)) {
+                const double lo = A * (1.0 - a.delta), hi = A * (1.0 + a.delta);
+                if (lo > OP_SANE_LO && hi < OP_SANE_HI && ulp_exp(lo) == ulp_exp(hi)) {
+                    lb_ok = true;
+                    lb_eu = ulp_exp(lo);
+                }
+            }
+            c_in = lookback_exact(d, k, lb_ok, lb_eu, lane, abort_word, ok, lbw);
         }
         // carry-out of a chunk that stayed inside its binade: known right now, successors need not wait for the scan
         int quick = 0;
@@ -1301,6 +1384,12 @@ __device__ OP2_SLOW_INLINE void op_chunk_slow(OpShared &sh, const double *a_w, c
             quick = 2;                                                     // still nothing but zeros
             if (lane == 0) publish_carry(&d[k], 0.0);
         }
+        if (ok && prepared && sh.seg.fail == 0) {                          // (behind seg_prepare's last barrier: every thread's verdict)
+            bool failed;
+            const double c_out = seg_chain(sh, c_in, R.D, R.ptotal, lane, failed);
+            if (!failed && lane == 0) publish_carry(&d[k], c_out);
+            OP_STAMP(14);
+        }
         // first slot of this chunk: everything below n(carry-in) belongs to earlier chunks
         const int out_lo = at_start ? 0 : n_boundary_fast<STRATIFIED>(c_in, (int)Np, Nd, halfNd, u_sys, u_str);
         if (lane == 0) {
@@ -1310,6 +1399,7 @@ __device__ OP2_SLOW_INLINE void op_chunk_slow(OpShared &sh, const double *a_w, c
         }
     }
     __syncthreads();                                                                          // (D)
+    OP_STAMP(8);
     }   // !hit
     const double c_in = sh.bc_d[1];
     const int quick = __builtin_amdgcn_readfirstlane(sh.bc_i[3]);
@@ -1372,19 +1462,25 @@ __device__ OP2_SLOW_INLINE void op_chunk_slow(OpShared &sh, const double *a_w, c
     } else if (quick == 2) {
         FK_UNROLL for (int q = 0; q < OP_ITEMS; ++q) nb[q] = 0;
     } else {
-        // general scan: the weights once more (L2), now into the padded LDS tile the scan works in
-        FK_UNROLL for (int q = 0; q < OP_ITEMS; ++q) {
-            const int j = tid * OP_ITEMS + q;
-            sh.tile[pad8(j)] = j < len ? wf[base + j] : 0.0;
-        }
-        __syncthreads();
-        // (round 6: the one-round scan first -- binades predicted for all elements at once, then verified; round 3 went straight
-        //  to general_cumsum, one block scan and four barriers per binade the running sum passes through: ~45 k clocks for the
-        //  first chunk of a vector, ~20 k for a crossing.  Those chunks are 0.5 % of a 125 x 8e6 call and the whole serial
-        //  chain of a call with few long vectors: every binade segment waits for the crossing chunk at its head)
         double c_out = 0.0;
-        if (!segmented_cumsum(sh, len, c_in, &c_out)) c_out = general_cumsum(sh, len, c_in);
-        if (tid == 0) publish_carry(&d[k], c_out);
+        if (prepared && sh.seg.fail == 0) {                                // uniform (behind barrier (D))
+            seg_finish(sh, len, R);
+            c_out = sh.seg.carry_out;                                      // (published by wave 0 the moment it was known)
+        } else {
+            // general scan: the weights into the padded LDS tile the scan works in (a prepared scan that declined left them there)
+            if (!prepared) {
+                __syncthreads();
+                FK_UNROLL for (int q = 0; q < OP_ITEMS; ++q) sh.tile[pad8(tid * OP_ITEMS + q)] = w8[q];
+            }
+            __syncthreads();
+            // (round 6: the one-round scan first -- binades predicted for all elements at once, then verified; round 3 went straight
+            //  to general_cumsum, one block scan and four barriers per binade the running sum passes through: ~45 k clocks for the
+            //  first chunk of a vector, ~20 k for a crossing)
+            if (scan_tried || !segmented_cumsum(sh, len, c_in, &c_out)) c_out = general_cumsum(sh, len, c_in);
+            if (tid == 0) publish_carry(&d[k], c_out);
+        }
+        OP_STAMP(9);
+        OP_NOTE(15, (prepared ? 1 : 0) | (sh.seg.fail ? 2 : 0) | ((unsigned)R.D << 8));
         // (each thread reads back only its own slots, behind general_cumsum's final barrier; n_j goes into the low
         // half of cs_j's slot so that this loop stays rolled)
         int *nslot = reinterpret_cast<int *>(&sh.tile[pad8(tid * OP_ITEMS)]);
@@ -1475,6 +1571,8 @@ __device__ OP2_SLOW_INLINE void op_chunk_slow(OpShared &sh, const double *a_w, c
         }
     }
 
+    OP_STAMP(10);
+    OP_NOTE(11, 100 + quick);
     // ---- end of the vector: positions >= cumsum[-1] (the reference raises IndexError, resampling.py:109,145) --
     if (k == nch - 1) {
         for (long i = (long)u_hi + tid; i < Np; i += OP_THREADS) of[i] = (int32_t)(Np - 1);
@@ -1861,6 +1959,10 @@ extern "C" int fk_debug_set_dump(double *cs, int *n)
     if (hipMemcpyToSymbol(HIP_SYMBOL(fk::g_dbg_cs), &cs, sizeof(cs)) != hipSuccess) return -1;
     return hipMemcpyToSymbol(HIP_SYMBOL(fk::g_dbg_n), &n, sizeof(n)) == hipSuccess ? 0 : -1;
 }
+extern "C" int fk_debug_set_timeline(unsigned long long *tl)
+{
+    return hipMemcpyToSymbol(HIP_SYMBOL(fk::g_dbg_tl), &tl, sizeof(tl)) == hipSuccess ? 0 : -1;
+}
 extern "C" int fk_debug_op_phases(unsigned long long *out)     // only in the instrumented build (tools/op_phase.py)
 {
     using namespace fk;
@@ -2019,7 +2121,18 @@ int onepass_launch(bool stratified, int64_t Fn, int64_t Np, const double *w, con
         // (FK_OP_LDS_PAD: bytes of dynamic LDS nobody uses -- lowers the workgroups a CU holds; occupancy experiments only:
         //  profiles/r06/onepass_occupancy.txt, time = 1.62 + 7.97 / (workgroups per CU) ms at 125 x 8e6)
         const unsigned lds_pad = getenv("FK_OP_LDS_PAD") ? (unsigned)atol(getenv("FK_OP_LDS_PAD")) : 0u;
-#define GO2(W) hipLaunchKernelGGL((resample_onepass2_kernel<W>), grid, block, lds_pad, s, a, pb, polls)
+        // FK_OP_LB: bit 0 -- a look-back waits for predecessors that published at another binade (they become carry-outs) instead of
+        // missing; bit 1 -- a crossing chunk adds up the increment sums of the binade it enters from (op_chunk_slow); bit 2 -- the general scan
+        // of a chunk is prepared on the approximate carry-in, the carry-out published a few adds behind the exact one.  The polls
+        // are then bounded by the spin limit of the slow path, not by FK_OP_POLLS.
+        // bit 2 costs a chunk that takes the general scan ~5 us of its own time (the scan in two pieces holds more across the wait)
+        // and takes ~6 us per crossing off the chain behind it: on where many chunks of a vector are in flight at once (the chain
+        // is what the call waits for), off where the chunks of a vector come one or two at a time -- 1000 x 1e5: 0.41 ms without,
+        // 0.46 with; 32 x 1e6: 0.28 / 0.25; 1 x 8e6: 0.174 / 0.108 (profiles/r06/onepass/r06o/rs_ab.txt)
+        int lb_mode = 3 | (Fn <= 128 ? 4 : 0);
+        if (const char *lbv = getenv("FK_OP_LB")) lb_mode = atoi(lbv);
+        if ((lb_mode & 1) && !getenv("FK_OP_POLLS")) polls = 1 << 16;
+#define GO2(W) hipLaunchKernelGGL((resample_onepass2_kernel<W>), grid, block, lds_pad, s, a, pb, polls, lb_mode)
         if (waves == 5) GO2(5); else if (waves == 6) GO2(6); else GO2(7);
 #undef GO2
         hipLaunchKernelGGL((resample_literal_kernel<false>), dim3((unsigned)Fn), dim3(64), 0, s, a);

@@ -272,6 +272,9 @@ def _onepass_mode(monkeypatch, mode):
     if mode in ("waves5", "waves6", "waves7"):     # the instantiation budgeted for that many workgroups per CU (FK_OP_WAVES)
         monkeypatch.setenv("FK_OP_WAVES", mode[-1])
         return
+    if mode in ("lb0", "lb3", "lb7"):          # FK_OP_LB: how look-backs wait and when the general scan of a chunk is prepared (the
+        monkeypatch.setenv("FK_OP_LB", mode[2:])   # launcher picks 3 or 7 by the number of filters; 0 = before round 6's last leases)
+        return
     if mode == "nopredict":
         monkeypatch.setenv("FK_OP_PRED_BACK", "0")
         return
@@ -307,7 +310,7 @@ def _check_against_merge_loop(Fn, Np, kinds, filters, monkeypatch, force):
                 assert bool(sth[f] & 4) == (over > 0) and not (sth[f] & 8), (Np, kind, strat, f, int(sth[f]))
 
 
-@pytest.mark.parametrize("mode", ["spec", "round3", "nopredict", "predict-near", "waves5", "waves6", "waves7", "two-stage", "tickets"])
+@pytest.mark.parametrize("mode", ["spec", "round3", "nopredict", "predict-near", "waves5", "waves6", "waves7", "lb0", "lb3", "lb7", "two-stage", "tickets"])
 @pytest.mark.parametrize("Np", [1, 2, 100, 2049, 65536])
 def test_onepass_every_route_small(Np, mode, monkeypatch):
     """FK_RESAMPLE_PATH=onepass forces short vectors through the one-pass kernel: every weight family, every filter,
@@ -317,7 +320,7 @@ def test_onepass_every_route_small(Np, mode, monkeypatch):
     _check_against_merge_loop(5, Np, kinds, range(5), monkeypatch, force=True)
 
 
-@pytest.mark.parametrize("mode", ["spec", "round3", "nopredict", "predict-near", "waves5", "waves6", "waves7", "two-stage", "tickets"])
+@pytest.mark.parametrize("mode", ["spec", "round3", "nopredict", "predict-near", "waves5", "waves6", "waves7", "lb0", "lb3", "lb7", "two-stage", "tickets"])
 def test_onepass_every_route_long(mode, monkeypatch):
     """default dispatch on a long ragged vector (not a multiple of the chunk, odd address alignment per filter), in the three
     protocols of the one-pass kernel: speculation + static chunk assignment (round 3's default), round 2's two stages on

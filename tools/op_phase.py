@@ -73,7 +73,7 @@ def run(shapes, iters, strat, tag):
                           "dirty_per_general_chunk": round(v[0] / max(v[8], 1), 2),
                           "v2": os.environ.get("FK_OP_V2", "1") != "0", "predicted_chunks_per_call": v[12] / iters,
                           "v2_slow_chunks_per_call": {"no valid guess": v[13] / iters, "look-back missed": v[14] / iters, "end of positions": v[15] / iters},
-                          "env": {k: os.environ[k] for k in ("FK_OP_V2", "FK_OP_PRED_BACK", "FK_OP_POLLS", "FK_OP_WAVES") if k in os.environ}}), flush=True)
+                          "env": {k: os.environ[k] for k in ("FK_OP_V2", "FK_OP_PRED_BACK", "FK_OP_POLLS", "FK_OP_WAVES", "FK_OP_LB") if k in os.environ}}), flush=True)
 
 
 WH_PHASES = ["weights+sums", "classify+scans", "lists", "check+chain", "boundaries", "heads", "window scan", "stores", "plain-prefix boundaries"]
