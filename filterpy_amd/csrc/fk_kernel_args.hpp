@@ -47,6 +47,11 @@ struct RtsArgs {
     // from there and leave it alone; status_or: OR the status bits into status[]
     long i0, cnt;
     int cont, status_or;
+    // the persistent grid of rts_ml_kernel (PERS instantiations; same scheme as KfArgs'): ticket counter + one completion word per
+    // track group, the smoothed state between the time chunks of a group [n + n*n][N] element-major
+    int *pers_ctl;
+    int pers_G, pers_H;
+    double *pers_ws;
 };
 
 struct UkfArgs {

@@ -695,26 +695,67 @@ __device__ __forceinline__ void ml_store_rows_aos_park(const double (&M)[R][NX],
 // every lane on a gathered packed copy (45 doubles) and each lane back-substitutes its own three
 // rows of K.  The filtered P is read twice (second time from L2) instead of being held across the
 // factorisation.  Shared constant F, Q; SOA; K and Pp outputs both present.
-template <int R, int WAVES, int MODE>
+// PERS (round 6): the forward kernel's persistent grid (see kf_ml_kernel) for the smoother -- G track groups x H time chunks drawn
+// as tickets by 2 workgroups per CU, chunk-major from the END of the time axis (a chunk needs the smoothed state of the first step
+// of the chunk after it in time: the ticket of that one is at least G draws older).  The state travels through the element-major
+// hand-over block with agent-scope accesses and is announced by the group's completion word; the window of a later-drawn chunk
+// overlaps its predecessor's by the one step it starts from (the `cont` convention of the chunked calls), whose outputs it leaves
+// alone.  Same arithmetic per track: bit-identical to the single launch.
+template <int R, int WAVES, int MODE, bool PERS = false>
 __global__ void __launch_bounds__(BLOCK, WAVES)
-rts_ml_kernel(const RtsArgs a)
+rts_ml_kernel(const RtsArgs a_in)
 {
+    constexpr int HAUX = PERS ? 16 : 0;      // sc1 = agent scope (MlView::load / store)
     constexpr int NX = 3 * R, PL = NX * (NX + 1) / 2;
     __shared__ double smem[2 * NX * NX];
     // x and xn - F x are parked here ([element][lane]: conflict-free) across the E = K D stage: spilled
     // to scratch instead, their reloads would be vector-memory operations that retire in order behind
     // the step's stores (s_waitcnt vmcnt(0)); LDS traffic has its own counter.
     __shared__ double park[R * NX + NX][BLOCK];   // rows 0..26: D = Pn - Pp across the factorisation (the register peak), then x | dx; rows 27..35: x from the top of the step
-    lds_fill<NX, NX>(smem, a.F, NX, NX, 1.0, threadIdx.x);
-    lds_fill<NX, NX>(smem + NX * NX, a.Q, NX, NX, 0.0, threadIdx.x);
+    lds_fill<NX, NX>(smem, a_in.F, NX, NX, 1.0, threadIdx.x);
+    lds_fill<NX, NX>(smem + NX * NX, a_in.Q, NX, NX, 0.0, threadIdx.x);
     __syncthreads();
     const double *sF = smem, *sQ = smem + NX * NX;
 
+    RtsArgs a = a_in;
+    [[maybe_unused]] int pers_g = 0, pers_c = 0;
+    __shared__ int s_task;
+    for (;;) {                                                   // PERS: one trip per ticket; otherwise exactly one trip
+    unsigned bid = blockIdx.x;
+    if constexpr (PERS) {
+        __syncthreads();                                         // the previous ticket's LDS traffic is over, s_task is free
+        if (threadIdx.x == 0) s_task = atomicAdd(a_in.pers_ctl, 1);
+        __syncthreads();
+        const int task = __builtin_amdgcn_readfirstlane(s_task);
+        const int G = a_in.pers_G, H = a_in.pers_H;
+        if (task >= G * H) break;
+        pers_c = task / G;                                       // chunk number counted from the END of the time axis
+        pers_g = task - pers_c * G;
+        bid = (unsigned)pers_g;
+        const long hh = H - 1 - pers_c;
+        const long t0 = a_in.T * hh / H, t1 = a_in.T * (hh + 1) / H, NN = a_in.N;
+        a = a_in;
+        a.cont = pers_c > 0 ? 1 : 0;
+        a.T = t1 - t0 + (pers_c > 0 ? 1 : 0);                    // (+ the step the chunk starts from, smoothed by the chunk before it)
+        a.Xs = a_in.Xs + t0 * NN * NX;
+        a.xs = a_in.xs + t0 * NN * NX;
+        a.Ps = a_in.Ps + t0 * NN * (NX * NX);
+        a.Ps_out = a_in.Ps_out + t0 * NN * (NX * NX);
+        a.K = a_in.K + t0 * NN * (NX * NX);
+        a.Pp = a_in.Pp + t0 * NN * (NX * NX);
+        a.status_or = pers_c > 0 ? 1 : a_in.status_or;
+        if (pers_c > 0) {
+            if (threadIdx.x == 0) {
+                while (__hip_atomic_load(&a_in.pers_ctl[1 + pers_g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < pers_c) __builtin_amdgcn_s_sleep(8);
+            }
+            __syncthreads();
+        }
+    }
     const long N = a.N, T = a.T;
     const unsigned L = threadIdx.x & 3u;
     const unsigned Lc = L < 3u ? L : 2u;
     const long i0 = a.cnt ? a.i0 : 0, iend = a.cnt ? a.i0 + a.cnt : N;     // this launch's track group (chunked calls)
-    long trk = i0 + (long)blockIdx.x * (BLOCK / 4) + (threadIdx.x >> 2);
+    long trk = i0 + (long)bid * (BLOCK / 4) + (threadIdx.x >> 2);
     const unsigned odd = (threadIdx.x >> 2) & 1u;
     if (trk >= iend) trk = MODE == 1 ? iend - 2 + odd : iend - 1;
     // SOA: element e of a track at track*8 + e*N*8 ; AOS (MODE 2): track*E*8 + e*8
@@ -728,13 +769,20 @@ rts_ml_kernel(const RtsArgs a)
     // AOS: covariance-like outputs leave through the parking buffer as 1 KiB stores (first track of this
     // wave, how many of its 16 tracks exist)
     const unsigned lane = threadIdx.x & 63u, wave = wave_index();
-    const long w0 = i0 + (long)blockIdx.x * (BLOCK / 4) + (long)wave * 16;
+    const long w0 = i0 + (long)bid * (BLOCK / 4) + (long)wave * 16;
     const unsigned valid = (unsigned)(iend - w0 >= 16 ? 16 : (iend - w0 > 0 ? iend - w0 : 0));
     const long xs_blk = N * NX, ps_blk = N * (long)NX * NX;
 
     // k = T-1: smoothed == filtered; K = 0; Pp = Ps   (kalman_filter.py:1063-1065)
     double xn[NX], Pn[R][NX];
-    if (a.cont) {
+    if (PERS && a.cont) {
+        // a later ticket of the group: the smoothed state of step T-1 of this window, from the hand-over block
+        const unsigned n8 = (unsigned)N * 8u;
+        const MlView wx(a_in.pers_ws, (unsigned)trk * 8u, n8), wP(a_in.pers_ws + (long)NX * N, (unsigned)trk * 8u + Lc * (unsigned)(R * NX) * n8, n8);
+        FK_UNROLL for (int k = 0; k < NX; ++k) xn[k] = wx.template load<HAUX>(k);
+        FK_UNROLL for (int r = 0; r < R; ++r)
+            FK_UNROLL for (int c = 0; c < NX; ++c) Pn[r][c] = wP.template load<HAUX>(r * NX + c);
+    } else if (a.cont) {
         // a later chunk of the call: step T-1 of this window was smoothed by the chunk that ran before (after it in time)
         const MlView vx(a.xs + (T - 1) * xs_blk, t8, estride), vP(a.Ps_out + (T - 1) * ps_blk, off_rows, estride);
         FK_UNROLL for (int k = 0; k < NX; ++k) xn[k] = vx.load(k);
@@ -924,8 +972,32 @@ rts_ml_kernel(const RtsArgs a)
             FK_UNROLL for (int c = 0; c < NX; ++c) fin = fin && (fabs(Pn[r][c]) <= 1.79769313486231570815e+308);
         int s = st | (fin ? 0 : ST_NONFINITE);
         s |= __builtin_amdgcn_mov_dpp(s, 0x55 * 1, 0xf, 0xf, true) | __builtin_amdgcn_mov_dpp(s, 0x55 * 2, 0xf, 0xf, true);
-        if (L == 0) a.status[trk] = a.status_or ? (a.status[trk] | s) : s;
+        if constexpr (PERS) {
+            if (L == 0) {
+                const int old = a.status_or ? __hip_atomic_load(&a.status[trk], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+                __hip_atomic_store(&a.status[trk], old | s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        } else {
+            if (L == 0) a.status[trk] = a.status_or ? (a.status[trk] | s) : s;
+        }
     }
+    if constexpr (PERS) {
+        if (pers_c + 1 < a_in.pers_H) {
+            // not the group's last ticket: the smoothed state of this window's first step goes to the hand-over block
+            const unsigned n8 = (unsigned)N * 8u;
+            const MlView wx(a_in.pers_ws, (unsigned)trk * 8u, n8), wP(a_in.pers_ws + (long)NX * N, (unsigned)trk * 8u + Lc * (unsigned)(R * NX) * n8, n8);
+            FK_UNROLL for (int k = 0; k < NX; ++k) wx.template store<HAUX>(k, xn[k]);
+            FK_UNROLL for (int r = 0; r < R; ++r)
+                FK_UNROLL for (int c = 0; c < NX; ++c) wP.template store<HAUX>(r * NX + c, Pn[r][c]);
+        }
+        // (complete only once every wave's vmcnt has drained: see kf_ml_kernel)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(&a_in.pers_ctl[1 + pers_g], pers_c + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        break;
+    }
+    }      // tickets
 }
 
 static int launch_rts_ml_one(const RtsArgs &a, int layout, hipStream_t s)
@@ -942,11 +1014,57 @@ static int launch_rts_ml_one(const RtsArgs &a, int layout, hipStream_t s)
 
 static int launch_rts_ml_chunked(const RtsArgs &a, int layout, hipStream_t s);
 
+// The smoother on the persistent grid (rts_ml_kernel<..., PERS>): same conditions, same scratch allocation scheme and the same
+// chunk count as launch_kf_ml_persistent below.  OFF unless FK_RTS_PERSIST=1: measured at configs[2] (1e5 tracks x 100 steps,
+// one lease, A/B/A/B): single launch 5.51 / 5.51 ms, tickets 5.51 / 5.61 (H = 3), 5.54 (2), 5.43 (4) -- nothing, where the forward
+// kernel gained 3-7 % (profiles/r06/c3_rts_persist.txt).  The smoother's fourth round of workgroups is as empty as the forward
+// kernel's, but its step is twice as long on the memory side (2736 against 1464 bytes per track-step): the three full rounds
+// already keep the memory system as busy as this kernel can.  Kept for the bit-identity test and the next idea.  FK_RTS_PERSIST_H: chunks.
+static int launch_rts_ml_persistent(const RtsArgs &a, int layout, hipStream_t s)
+{
+    const char *pv = getenv("FK_RTS_PERSIST");
+    if (!pv || atoi(pv) == 0) return 1;
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+                   ? prop.multiProcessorCount : 256;
+    }
+    const long cnt = a.cnt ? a.cnt : a.N;
+    const long G = (cnt + BLOCK / 4 - 1) / (BLOCK / 4), slots = 2L * n_cu;
+    long H = a.T >= 48 ? 3 : a.T / 16;
+    if (const char *hv = getenv("FK_RTS_PERSIST_H")) H = atol(hv);
+    if (G <= slots || H < 2 || a.T / H < 2 || G > (1L << 24)) return 1;
+    int *ctl = nullptr;
+    const size_t cbytes = ((size_t)(1 + G) * sizeof(int) + 255) & ~(size_t)255, wbytes = (size_t)90 * (size_t)a.N * sizeof(double);
+    if (hipMallocAsync((void **)&ctl, cbytes + wbytes, s) != hipSuccess || !ctl) { (void)hipGetLastError(); return 1; }
+    if (hipMemsetAsync(ctl, 0, cbytes, s) != hipSuccess) { (void)hipFreeAsync(ctl, s); (void)hipGetLastError(); return 1; }
+    RtsArgs b = a;
+    b.pers_ctl = ctl;
+    b.pers_ws = reinterpret_cast<double *>(reinterpret_cast<char *>(ctl) + cbytes);
+    b.pers_G = (int)G;
+    b.pers_H = (int)H;
+    const dim3 grid((unsigned)slots), block(BLOCK);
+    const char *pp = getenv("FK_ML_PAIRS");
+    const bool pairs = (a.N % 2 == 0) && (cnt % 2 == 0) && cnt >= 2 && !(pp && atoi(pp) == 0);
+    if (layout == FK_LAYOUT_AOS) hipLaunchKernelGGL((rts_ml_kernel<3, FK_ML_WAVES, 2, true>), grid, block, 0, s, b);
+    else if (pairs) hipLaunchKernelGGL((rts_ml_kernel<3, FK_ML_WAVES, 1, true>), grid, block, 0, s, b);
+    else hipLaunchKernelGGL((rts_ml_kernel<3, FK_ML_WAVES, 0, true>), grid, block, 0, s, b);
+    const int rc = check_launch("rts_ml_kernel<pers>");
+    (void)hipFreeAsync(ctl, s);
+    return rc;
+}
+
 // returns 1 when this call is not one the multi-lane smoother serves
 int launch_rts_ml_9(const RtsArgs &a, int layout, bool uniform, hipStream_t s)
 {
     if (!uniform || a.model_t || a.n != 9 || !a.K || !a.Pp || a.T < 2) return 1;
     if (layout == FK_LAYOUT_AOS && (double)a.N * 81.0 * 8.0 >= 4294967296.0) return 1;
+    {
+        const int rc = launch_rts_ml_persistent(a, layout, s);
+        if (rc <= 0) return rc;                                // 1 = not a call the persistent grid takes
+    }
     return launch_rts_ml_chunked(a, layout, s);
 }
 

@@ -105,7 +105,10 @@ __device__ __forceinline__ int pad8(int j) { return j + (j >> 3); }   // one spa
 // scratch of segmented_cumsum (below): the elements of a chunk that cannot be taken as integer increments (`dirty`:
 // a binade crossing, the first weight of a vector, a half-ulp tie, an ambiguous prediction) cut it into SEGMENTS of
 // clean elements
-constexpr int SEG_DMAX = 64;              // dirty elements a chunk may hold before the scan declines
+#ifndef FK_SEG_DMAX
+#define FK_SEG_DMAX 64
+#endif
+constexpr int SEG_DMAX = FK_SEG_DMAX;              // dirty elements a chunk may hold before the scan declines
 constexpr int SEG_NONE = 0x7fffffff;      // a segment without a non-zero clean element claims no binade
 struct SegShared {
     double wtot[OP_THREADS / 64];         // per-wave partial sums (approximate prefix)

@@ -913,6 +913,67 @@ def test_three_lane_persistent_grid_is_bit_identical(layout, masked, with_status
             assert torch.equal(a.view(torch.int64) if a.dtype == torch.float64 else a, b.view(torch.int64) if b.dtype == torch.float64 else b), (layout, masked, env, i)
 
 
+@pytest.mark.parametrize("with_status", [True, False])
+@pytest.mark.parametrize("layout,N", [("soa", 33_003), ("soa", 33_002), ("aos", 33_003)])
+def test_three_lane_smoother_persistent_grid_is_bit_identical(layout, N, with_status, monkeypatch):
+    """Round 6: the (9) smoother on the forward kernel's persistent grid (FK_RTS_PERSIST=1; rts_ml_kernel PERS: tickets = (time chunk counted from
+    the end, group of 64 tracks), the smoothed state of a chunk's first step handed to the chunk before it in time through the
+    element-major block, agent-scope).  Same arithmetic per track: xs, Ps, K, Pp and the status equal the single launch's
+    (FK_RTS_PERSIST=0, FK_ML_CHUNKS=1,1) bit for bit -- an odd bank (8-byte stores), an even one (16-byte pair stores), NumPy
+    order through FK_ML9=m (by default that layout runs on the four-lane kernel), 70 steps in 3 chunks and forced into 7 and
+    2, one track whose predicted covariance is not positive definite (its status bit must survive the chunks)."""
+    import torch
+    from filterpy_amd import _engine as E
+    n, T = 9, 70
+    dev = torch.device("cuda")
+    g = torch.Generator(device=dev)
+    g.manual_seed(23)
+    rs = np.random.RandomState(5)
+    F = np.eye(n) + 0.05 * np.triu(rs.randn(n, n), 1)
+    A = rs.randn(n, n)
+    Q = 0.05 * (A @ A.T / n + 0.5 * np.eye(n))
+    Xs = E.alloc_records((T,), N, n, layout)
+    Xs.copy_(torch.randn(Xs.shape, generator=g, device=dev, dtype=torch.float64))
+    # filtered covariances: a random SPD matrix per (step, track) built on the device (B B' / n + I), symmetric bit for bit
+    B = torch.randn((T, N, n, n), generator=g, device=dev, dtype=torch.float64)
+    Pd = B @ B.transpose(-1, -2) / n + torch.eye(n, device=dev, dtype=torch.float64)
+    Pd = 0.5 * (Pd + Pd.transpose(-1, -2))
+    Pd[T // 2, N // 2] = -torch.eye(n, device=dev, dtype=torch.float64) * 50.0   # Pp = F P F' + Q not positive definite at one step of one track
+    Ps = E.alloc_records((T,), N, n * n, layout)
+    if layout == "aos":
+        Ps.copy_(Pd.reshape(Ps.shape))
+    else:
+        Ps.copy_(Pd.reshape(T, N, n * n).permute(0, 2, 1).reshape(Ps.shape))
+    del B, Pd
+    desc = dict(n=n, m=3, nu=0, model_mode=0, N=N, T=T, layout=E.LAYOUTS[layout], update_first=0, alpha_sq=1.0)
+    dF, dQ = E.dev(F), E.dev(Q)
+    if layout == "aos":
+        monkeypatch.setenv("FK_ML9", "m")
+
+    def run():
+        outs = [E.alloc_records((T,), N, w, layout).fill_(float("nan")) for w in (n, n * n, n * n, n * n)]
+        st = torch.zeros(N, dtype=torch.int32, device=dev)
+        E.kf_rts(desc, dF, dQ, Xs, Ps, outs[0], outs[1], outs[2], outs[3], convention=1, status=st if with_status else None)
+        torch.cuda.synchronize()
+        return outs + [st]
+
+    with monkeypatch.context() as mp:
+        mp.setenv("FK_RTS_PERSIST", "0")
+        mp.setenv("FK_ML_CHUNKS", "1,1")
+        ref = run()
+    if with_status:
+        assert int(ref[4][N // 2]) != 0 and int((ref[4] != 0).sum()) == 1
+    assert not bool(torch.isnan(ref[0]).any())
+    for env in ({}, {"FK_RTS_PERSIST_H": "7"}, {"FK_RTS_PERSIST_H": "2"}):
+        with monkeypatch.context() as mp:
+            mp.setenv("FK_RTS_PERSIST", "1")                   # (off by default: measured no faster than the single launch)
+            for k, v in env.items():
+                mp.setenv(k, v)
+            got = run()
+        for i, (a, b) in enumerate(zip(got, ref)):
+            assert torch.equal(a.view(torch.int64) if a.dtype == torch.float64 else a, b.view(torch.int64) if b.dtype == torch.float64 else b), (layout, N, env, i)
+
+
 @pytest.mark.parametrize("layout", ["soa", "aos"])
 @pytest.mark.parametrize("N", [1000, 777, 64, 3])
 def test_three_lane_slab_outputs_equal_the_pair_store_build_bit_for_bit(N, layout, monkeypatch):
