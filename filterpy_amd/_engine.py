@@ -71,10 +71,21 @@ def to_records(a, layout, lead):
     return t.transpose(-1, -2).contiguous()
 
 
+def download_into(pairs):
+    """[(device tensor, NumPy array of the same shape and dtype, both contiguous)]: the tensors' bytes into the arrays, through the
+    pinned pipeline where that pays (kalman_filter.py: the streamed host outputs of batch_filter)"""
+    _transfer.into_host(pairs)
+
+
 def from_records(t, layout, lead, rec_shape):
     """Device tensor in `layout` -> host NumPy array lead + (N,) + rec_shape (zero-copy view of
     the downloaded buffer for 'soa': a transposed view, as the API docs describe)."""
     h = _transfer.to_host([t])[0]        # (large histories: pinned, pipelined, several host threads -- _transfer.py)
+    return host_records(h, layout, lead, rec_shape)
+
+
+def host_records(h, layout, lead, rec_shape):
+    """the downloaded buffer (device order) as the array the API returns: see from_records"""
     rec = int(np.prod(rec_shape)) if rec_shape else 1                      # (explicit sizes: -1 is ambiguous for empty banks)
     if layout == "aos":
         return h.reshape(*h.shape[:lead + 1], *rec_shape) if rec_shape else h

@@ -146,6 +146,22 @@ def to_host(tensors):
     return out
 
 
+def into_host(pairs):
+    """[(device tensor, NumPy array)] of equal shape / dtype, both contiguous: the tensor's bytes into the array (the caller owns
+    it: a slice of a larger result).  Small or CPU tensors: a plain copy."""
+    big, dev = [], None
+    piped = sum(t.numel() * t.element_size() for t, _ in pairs if t.is_cuda) >= MIN_BYTES and os.environ.get("FK_D2H_PIPE", "1") != "0"
+    for t, h in pairs:
+        assert tuple(t.shape) == tuple(h.shape) and t.is_contiguous() and h.flags.c_contiguous, (t.shape, h.shape)
+        if not t.is_cuda or not piped or t.numel() == 0:
+            np.copyto(h, t.cpu().numpy())
+            continue
+        big.append((t.view(-1).view(torch.uint8), h.reshape(-1).view(np.uint8)))
+        dev = t.device
+    if big:
+        _pipe(dev).download(big)
+
+
 def release():
     """free the staging buffers and stop the workers (they come back on the next large download)"""
     with _pipes_lock:

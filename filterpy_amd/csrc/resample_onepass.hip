@@ -125,6 +125,7 @@ struct SegShared {
     int fail;
 #ifdef FK_OP_CLOCKS
     long long dbg_t[5];                   // thread 0's clock after each barrier of segmented_cumsum (tools/op_phase.py)
+    long long dbg_in;
     int dbg_D;
 #endif
 };
@@ -479,6 +480,9 @@ __device__ __forceinline__ bool seg_prepare(OpShared &sh, int len, double carry,
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     SegShared &sg = sh.seg;
+#ifdef FK_OP_CLOCKS
+    const long long t_in = clock64();
+#endif
     if (tid <= SEG_DMAX) sg.seg_e[tid] = SEG_NONE;
     if (tid == 0) sg.fail = 0;
     // (registers: the weights and one exponent per element are kept; the increments are recomputed from them at each
@@ -494,7 +498,7 @@ __device__ __forceinline__ bool seg_prepare(OpShared &sh, int len, double carry,
     if (lane == 63) sg.wtot[wave] = winc;
     __syncthreads();                                                                          // (1)
 #ifdef FK_OP_CLOCKS
-    if (tid == 0) sg.dbg_t[0] = clock64();
+    if (tid == 0) { sg.dbg_t[0] = clock64(); sg.dbg_in = t_in; }
 #endif
     double excl = __shfl_up(winc, 1, 64);
     if (lane == 0) excl = 0.0;
@@ -581,6 +585,9 @@ __device__ __forceinline__ bool seg_prepare(OpShared &sh, int len, double carry,
         if (bad) sg.fail = 1;
     }
     if (SYNC_CLAIMS) __syncthreads();                                                         // (3b)
+#ifdef FK_OP_CLOCKS
+    if (tid == 0) sg.dbg_t[3] = clock64();
+#endif
     return true;
 }
 
@@ -717,6 +724,7 @@ struct OpArgs {
     int *bad;           // [Fn]: filter holds a weight the fast path does not take -> resample_literal_kernel
     double delta;       // relative error bound of the stage-1 prefix
     const unsigned *only_if;   // resample_local_kernel as the one-pass kernel's repair pass: run only if this word is non-zero
+    int literal_first;         // ... and, in the same launch, in front of it: the filters the one-pass kernel declined (bad[f]) redone literally
 };
 
 #ifndef FK_OP_WAVES
@@ -1350,6 +1358,13 @@ __device__ OP2_SLOW_INLINE void op_chunk_slow(OpShared &sh, const double *a_w, c
         __syncthreads();
         scan_tried = true;
         prepared = seg_prepare<true>(sh, len, at_start ? 0.0 : A, (at_start ? 0.0 : a.delta) + 0x1p-38, R);
+#ifdef FK_OP_CLOCKS
+        {   // (tools/op_timeline.py: core clocks / 16 between the barriers of seg_prepare, 16 bits each)
+            const SegShared &sg = sh.seg;
+            auto d16 = [](long long d) -> unsigned long long { d >>= 4; return (unsigned long long)(d < 0 ? 0 : (d > 65535 ? 65535 : d)); };
+            OP_NOTE(2, d16(sg.dbg_t[0] - sg.dbg_in) | (d16(sg.dbg_t[1] - sg.dbg_t[0]) << 16) | (d16(sg.dbg_t[2] - sg.dbg_t[1]) << 32) | (d16(sg.dbg_t[3] - sg.dbg_t[2]) << 48));
+        }
+#endif
     }
     // ---- stage 2: exact carry-in ---------------------------------------------------------------------------
     OP_STAMP(7);
@@ -1748,6 +1763,8 @@ __device__ __forceinline__ void load_chunk(double (&w8)[OP_ITEMS], const double 
 // without a spill and are the faster ones while the chip is not full (125 x 8000: 39 vs 46 us); four per CU spill ~30
 // registers but hold 1024 filters at once -- one round instead of two for BASELINE configs[4]'s 1000 x 8000 (68 vs
 // 80 us; profiles/r02/resample_local_variants.log).  The launcher picks by the filter count.
+template <bool STRATIFIED>
+__device__ void literal_filter(const OpArgs &a, const int f);
 #ifndef FK_LOCAL_PREFETCH
 #define FK_LOCAL_PREFETCH 0    // 1: the next chunk's weights are requested before the current chunk is worked on (measured: no gain)
 #endif
@@ -1756,7 +1773,13 @@ __global__ void __launch_bounds__(OP_THREADS, WAVES)
 resample_local_kernel(const OpArgs a)
 {
     __shared__ OpShared sh;
-    // the repair pass of onepass_launch: nothing to do unless a hand-off of the one-pass kernel timed out (uniform exit)
+    // behind the one-pass kernel, ONE launch for both follow-ups (round 6; two launches before: ~5 us of a call whose kernel takes
+    // 100): first the filter the one-pass kernel declined, redone literally by one thread (what resample_literal_kernel does) ...
+    if (a.literal_first && a.bad[blockIdx.x]) {                            // uniform
+        if (threadIdx.x == 0) literal_filter<STRATIFIED>(a, (int)blockIdx.x);
+        __syncthreads();
+    }
+    // ... then the repair pass of onepass_launch: nothing to do unless a hand-off of the one-pass kernel timed out (uniform exit)
     if (a.only_if && __hip_atomic_load(a.only_if, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;
     const long Np = a.Np, nch = a.nch;
     const int f = blockIdx.x;
@@ -1894,24 +1917,9 @@ resample_local_kernel(const OpArgs a)
 // i += 1 : j += 1   (resampling.py:106-112 / 142-149; j == N is the IndexError).  One thread: such input is
 // garbage, but the answer is still the reference's.
 template <bool STRATIFIED>
-__global__ void __launch_bounds__(64)
-resample_literal_kernel(const OpArgs a)
+__device__ void literal_filter(const OpArgs &a, const int f)              // ONE thread
 {
-    const int f = blockIdx.x;
     const long Np = a.Np;
-    if (a.bad) {
-        if (!a.bad[f]) return;
-    } else {
-        // no verdict from the one-pass kernel (short vectors take resample_kernel): look for a weight that path is
-        // not defined on -- negative, NaN, Inf or absurdly large
-        int bad = 0;
-        for (long j = threadIdx.x; j < Np; j += 64) {
-            const double v = a.w[(long)f * Np + j];
-            bad |= !(v >= 0.0 && v < 0x1p1000);
-        }
-        if (!__syncthreads_or(bad)) return;
-    }
-    if (threadIdx.x != 0) return;
     const double *wf = a.w + (long)f * Np;
     int32_t *of = a.idx + (long)f * Np;
     const double Nd = (double)Np;
@@ -1935,6 +1943,28 @@ resample_literal_kernel(const OpArgs a)
         st = ST_OVERRUN;
     }
     if (a.status) a.status[f] = st;
+}
+
+template <bool STRATIFIED>
+__global__ void __launch_bounds__(64)
+resample_literal_kernel(const OpArgs a)
+{
+    const int f = blockIdx.x;
+    const long Np = a.Np;
+    if (a.bad) {
+        if (!a.bad[f]) return;
+    } else {
+        // no verdict from the one-pass kernel (short vectors take resample_kernel): look for a weight that path is
+        // not defined on -- negative, NaN, Inf or absurdly large
+        int bad = 0;
+        for (long j = threadIdx.x; j < Np; j += 64) {
+            const double v = a.w[(long)f * Np + j];
+            bad |= !(v >= 0.0 && v < 0x1p1000);
+        }
+        if (!__syncthreads_or(bad)) return;
+    }
+    if (threadIdx.x != 0) return;
+    literal_filter<STRATIFIED>(a, f);
 }
 
 #ifdef FK_OP_CLOCKS
@@ -2032,6 +2062,14 @@ int local_launch(bool stratified, int64_t Fn, int64_t Np, const double *w, const
     return check_launch("resample_local_kernel");
 }
 
+__global__ void __launch_bounds__(256) op_clear_kernel(u32x4 *ws, size_t n16, int32_t *status, long Fn)
+{
+    const size_t stride = (size_t)gridDim.x * 256u;
+    for (size_t i = (size_t)blockIdx.x * 256u + threadIdx.x; i < n16; i += stride) ws[i] = u32x4{0u, 0u, 0u, 0u};
+    if (status)
+        for (size_t i = (size_t)blockIdx.x * 256u + threadIdx.x; i < (size_t)Fn; i += stride) status[i] = 0;
+}
+
 size_t onepass_workspace_bytes(int64_t Fn, int64_t Np)
 {
     if (Fn <= 0 || Np <= 0) return 0;
@@ -2044,7 +2082,7 @@ int onepass_launch(bool stratified, int64_t Fn, int64_t Np, const double *w, con
 {
     const long nch = (long)((Np + OP_TILE - 1) / OP_TILE);
     const size_t need = onepass_workspace_bytes(Fn, Np);
-    if (!ws || ws_bytes < need) return FK_ERR_WORKSPACE;
+    if (!ws || ws_bytes < need || (reinterpret_cast<uintptr_t>(ws) & 15u)) return FK_ERR_WORKSPACE;
     const unsigned long total = (unsigned long)Fn * (unsigned long)nch;
     if (total >= 0x7fffffffUL || Fn > 0x7fffffffL / 2) return FK_ERR_UNSUPPORTED;
     char *p = (char *)ws;
@@ -2061,8 +2099,13 @@ int onepass_launch(bool stratified, int64_t Fn, int64_t Np, const double *w, con
     a.desc = (OpDesc *)(p + op_align(sizeof(OpCtl)));
     a.bad = (int *)(p + op_align(sizeof(OpCtl)) + op_align((size_t)Fn * nch * sizeof(OpDesc)));
     a.delta = (8.0 * (double)(Np + 4096) + 16.0 * (double)nch) * 0x1p-53;
-    if (hipMemsetAsync(ws, 0, need, s) != hipSuccess) return FK_ERR_LAUNCH;
-    if (status && hipMemsetAsync(status, 0, (size_t)Fn * sizeof(int32_t), s) != hipSuccess) return FK_ERR_LAUNCH;
+    // the hand-off words and the status cleared in ONE launch (two memsets before: a launch each, ~3 us of a 100 us call)
+    {
+        const size_t n16 = need / 16;                                      // (need is a multiple of 256)
+        const size_t blocks = (n16 + 1023) / 1024;
+        hipLaunchKernelGGL(op_clear_kernel, dim3((unsigned)(blocks < 4096 ? (blocks ? blocks : 1) : 4096)), dim3(256), 0, s,
+                           reinterpret_cast<u32x4 *>(ws), n16, status, (long)Fn);
+    }
     // chunk assignment: static (blockIdx -> chunk, chunk-major over the filters) unless FK_OP_STATIC=0 asks for the atomic
     // tickets of round 2.  125 x 8e6: 4.43 -> 3.47 ms (profiles/r03/onepass_static_vs_ticket.jsonl): the ticket was a
     // dependent global round trip in front of the weight loads.
@@ -2078,7 +2121,6 @@ int onepass_launch(bool stratified, int64_t Fn, int64_t Np, const double *w, con
         else if (stat) hipLaunchKernelGGL((resample_onepass_kernel<STRAT, false, false>), grid, block, 0, s, a);      \
         else if (spec) hipLaunchKernelGGL((resample_onepass_kernel<STRAT, true, true>), grid, block, 0, s, a);        \
         else hipLaunchKernelGGL((resample_onepass_kernel<STRAT, true, false>), grid, block, 0, s, a);                 \
-        hipLaunchKernelGGL((resample_literal_kernel<STRAT>), dim3((unsigned)Fn), dim3(64), 0, s, a);                  \
         hipLaunchKernelGGL((resample_local_kernel<STRAT, 3>), dim3((unsigned)Fn), block, 0, s, r);                    \
     } while (0)
     // The repair pass (round 4).  The hand-offs between chunks are bounded spins; one that times out sets the abort word and
@@ -2091,6 +2133,7 @@ int onepass_launch(bool stratified, int64_t Fn, int64_t Np, const double *w, con
     // FK_OP_FORCE_ABORT=1 (tests) presets the abort word, so that every chunk that has to wait gives up.
     OpArgs r = a;
     r.only_if = &a.ctl->abort;
+    r.literal_first = 1;
     if (const char *fv = getenv("FK_OP_FORCE_ABORT"); fv && fv[0] == '1') {
         static const unsigned one = 1u;
         if (hipMemcpyAsync(&a.ctl->abort, &one, sizeof(one), hipMemcpyHostToDevice, s) != hipSuccess) return FK_ERR_LAUNCH;
@@ -2138,7 +2181,6 @@ int onepass_launch(bool stratified, int64_t Fn, int64_t Np, const double *w, con
 #define GO2(W) hipLaunchKernelGGL((resample_onepass2_kernel<W>), grid, block, lds_pad, s, a, pb, polls, lb_mode)
         if (waves == 5) GO2(5); else if (waves == 6) GO2(6); else GO2(7);
 #undef GO2
-        hipLaunchKernelGGL((resample_literal_kernel<false>), dim3((unsigned)Fn), dim3(64), 0, s, a);
         hipLaunchKernelGGL((resample_local_kernel<false, 3>), dim3((unsigned)Fn), block, 0, s, r);
         return check_launch("resample_onepass2_kernel");
     }

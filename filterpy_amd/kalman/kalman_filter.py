@@ -17,6 +17,7 @@ S^-1 is applied by an in-lane LDL' (Cholesky) solve, so S must be symmetric posi
 definite (the reference's numpy.linalg.inv also accepts indefinite S); a failed
 factorisation raises numpy.linalg.LinAlgError like a singular S does in the reference.
 """
+import os
 import sys
 from copy import deepcopy
 from math import exp, log, sqrt
@@ -91,6 +92,40 @@ class _Core:
         outs = [None] * 4
         desc = dict(n=n, m=m, nu=nu, model_mode=mode, N=N, T=T, layout=E.LAYOUTS[layout],
                     update_first=int(bool(update_first)), alpha_sq=float(alpha_sq))
+        # Host outputs of several GiB are STREAMED (round 6): the call is cut into time chunks of ~2 GiB of histories, each
+        # launched into the same four device buffers and downloaded through the pinned pipeline straight into its rows of the
+        # result arrays (every array of the path is time-major: a chunk is one contiguous block on both sides).  The histories
+        # never exist in HBM as a whole -- no 144 GB allocation in front of a (9,3) x 1e6 call (that alone was ~1 s of 3.9), and
+        # a host-output call is no longer limited by what fits next to its inputs on the device.  Same kernels, same arithmetic
+        # per step: bit-identical to the single launch (a GPU test); the launches are ~1 % of the call.  FK_STREAM_OUTPUTS=0: off.
+        # (FK_STREAM_MIN_BYTES / FK_STREAM_CHUNK_BYTES: the thresholds, for the tests)
+        step_bytes = 2 * 8 * (n + n * n) * N
+        if (want_outputs and not device_outputs and not extras and T >= 2 and N > 0
+                and step_bytes * T >= int(os.environ.get("FK_STREAM_MIN_BYTES", 4 << 30))
+                and os.environ.get("FK_STREAM_OUTPUTS", "1") != "0"):
+            Tc = max(1, min(T, int(os.environ.get("FK_STREAM_CHUNK_BYTES", 2 << 30)) // step_bytes))
+            shp = (lambda e: (T, N, e)) if layout == "aos" else (lambda e: (T, e, N))
+            host = [np.empty(shp(e)) for e in (n, n * n, n, n * n)]
+            bufs = [E.alloc_records((Tc,), N, e, layout) for e in (n, n * n, n, n * n)]
+            per_t = mode not in (FK_MODEL_SHARED, FK_MODEL_PER_TRACK)
+            mods = [model(Mx) for Mx in (F, Q, H, R, B)]
+            st_all = torch.zeros_like(st)
+            for t0 in range(0, T, Tc):
+                t1 = min(T, t0 + Tc)
+                cut = lambda v: None if v is None else v[t0:t1]              # noqa: E731
+                mm = [cut(v) if per_t else v for v in mods]
+                o = [b[:t1 - t0] for b in bufs]
+                E.kf_batch_filter(dict(desc, T=t1 - t0), mm[0], mm[1], mm[2], mm[3], dz[t0:t1], dx, dP, B=mm[4], u=cut(du),
+                                  mask=cut(dmask), means=o[0], covs=o[1], means_p=o[2], covs_p=o[3], status=st)
+                st_all |= st
+                E.download_into([(o[k], host[k][t0:t1]) for k in range(4)])
+            if placement_out is not None:
+                placement_out.clear()
+                placement_out.update({"method": "none", "note": "host outputs streamed in %d time chunks" % ((T + Tc - 1) // Tc)})
+            E.raise_on_status(st_all, "batch_filter")
+            res = [E.host_records(host[0], layout, 1, (n,)), E.host_records(host[1], layout, 1, (n, n)),
+                   E.host_records(host[2], layout, 1, (n,)), E.host_records(host[3], layout, 1, (n, n))]
+            return res + [E.from_records(dx, layout, 0, (n,)), E.from_records(dP, layout, 0, (n, n))]
         # Device-resident outputs: the two covariance histories (76 % of the bytes at dim_x = 4) live in ONE array, posterior
         # and prior record of a track side by side (FK_KF_FLAG_COV_INTERLEAVED): one write front instead of two that may
         # interfere (docs/PLACEMENT.md).  The caller gets strided views.  Where the specialised kernel does not serve the

@@ -446,7 +446,8 @@ int fk_imm_batch_f64(const fk_imm_desc *desc,
  *   idx [Fn][Np] int32 (np.zeros(N,'i'), resampling.py:141);  status [Fn] or NULL.
  *   ws / ws_bytes : scratch from fk_resample_workspace_bytes(Fn, Np); with it, weight vectors of
  *                   >= 32768 particles are processed chunk-parallel (many workgroups per filter);
- *                   NULL / too small = one workgroup per filter. */
+ *                   NULL / too small = one workgroup per filter.  16-byte aligned (FK_ERR_WORKSPACE otherwise;
+ *                   any device allocation is). */
 int fk_resample_systematic_f64(int64_t Fn, int64_t Np, const double *w, const double *u,
                                int32_t *idx, int32_t *status,
                                void *ws, size_t ws_bytes, void *stream);

@@ -2,7 +2,7 @@
 tests/ and compares array by array, bit for bit.  Where the reference checkout exists (the build container) every generator but
 the 30-second one runs in the default CPU suite (11 generators, 11 fixtures, ~12 s); FK_VERIFY_ALL_GOLDENS=1 adds
 make_goldens.py (the ten largest fixtures; `python tools/verify_goldens.py` by hand does the same:
-profiles/r05/goldens_verified.json).  Elsewhere: skipped."""
+profiles/r06/goldens_verified.json).  Elsewhere: skipped."""
 import glob
 import os
 import subprocess

@@ -447,3 +447,52 @@ def test_pipelined_download_is_bit_identical_and_the_bank_returns_it(monkeypatch
         for u, v in zip(*res):
             assert u.shape == v.shape and np.array_equal(u, v)
     _transfer.release()
+
+
+@pytest.mark.parametrize("layout", ["aos", "soa"])
+def test_streamed_host_outputs_are_bit_identical(layout, monkeypatch):
+    """Round 6: host outputs of several GiB are produced in time chunks -- each launched into the same device buffers and
+    downloaded into its rows of the result (kalman_filter.py, _Core.batch) -- so the histories never exist in HBM as a whole.
+    Same kernels, same arithmetic per step: every history, the final state and the raised status equal the single launch's
+    (FK_STREAM_OUTPUTS=0) bit for bit; forced here at 80 MB with 7- and 1-step chunks (a ragged last chunk), through the pinned
+    pipeline and below its threshold, with missing measurements, for (4,2) and (9,3), and through KalmanFilter with per-epoch
+    models and a control input."""
+    from filterpy_amd.kalman import KalmanFilter, KalmanFilterBank
+    rs = np.random.RandomState(17)
+    for (n, m, N, T) in ((4, 2, 5000, 50), (9, 3, 1111, 50)):
+        zs = rs.randn(T, N, m)
+        mask = (rs.rand(T, N) > 0.15).astype(np.uint8)
+        step = 2 * 8 * (n + n * n) * N
+        res = []
+        for env in ({"FK_STREAM_OUTPUTS": "0"}, {"FK_STREAM_MIN_BYTES": "1", "FK_STREAM_CHUNK_BYTES": str(7 * step)},
+                    {"FK_STREAM_MIN_BYTES": "1", "FK_STREAM_CHUNK_BYTES": "1"}):
+            with monkeypatch.context() as mp:
+                for k, v in env.items():
+                    mp.setenv(k, v)
+                bank = KalmanFilterBank(n, m, N, layout=layout)
+                bank.F = np.eye(n) + 0.05 * np.triu(np.ones((n, n)), 1)
+                bank.Q, bank.R, bank.H = 0.02 * np.eye(n), 0.5 * np.eye(m), np.eye(m, n)
+                bank.x = rs.__class__(3).randn(N, n)
+                bank.P = np.tile(3.0 * np.eye(n), (N, 1, 1))
+                res.append(bank.batch_filter(zs, mask=mask, update_first=bool(n == 9)) + (bank.x, bank.P))
+        for other in res[1:]:
+            for u, v in zip(res[0], other):
+                assert u.shape == v.shape and np.array_equal(u, v), (layout, n)
+    # one filter, per-epoch models and a control input (PER_STEP slices), the reference's call surface
+    n, m, T = 4, 2, 40
+    Fs = [np.eye(n) + 0.01 * (t + 1) * np.triu(np.ones((n, n)), 1) for t in range(T)]
+    Qs = [0.01 * (1 + t % 3) * np.eye(n) for t in range(T)]
+    Bs = [0.1 * (t + 1) * np.ones((n, 1)) for t in range(T)]
+    us = [np.array([0.5 * t]) for t in range(T)]
+    zl = [None if t in (3, 17) else rs.randn(m, 1) for t in range(T)]
+    out = []
+    for env in ({"FK_STREAM_OUTPUTS": "0"}, {"FK_STREAM_MIN_BYTES": "1", "FK_STREAM_CHUNK_BYTES": str(3 * 2 * 8 * (n + n * n))}):
+        with monkeypatch.context() as mp:
+            for k, v in env.items():
+                mp.setenv(k, v)
+            kf = KalmanFilter(n, m, dim_u=1)
+            kf.H, kf.R, kf.P = np.eye(m, n), 0.3 * np.eye(m), 2.0 * np.eye(n)
+            out.append(kf.batch_filter(zl, Fs=Fs, Qs=Qs, Bs=Bs, us=us) + (kf.x, kf.P))
+    for u, v in zip(*out):
+        assert np.array_equal(u, v)
+

@@ -608,13 +608,13 @@ def test_engine_wrappers_hand_every_operand_to_the_parameter_of_its_name(monkeyp
 
 
 def test_committed_bench_line_keeps_the_drivers_contract():
-    """profiles/r05/bench_default.json is a line bench.py printed on an MI355X: it carries every key the driver's contract names
+    """profiles/r06/bench_default.json is a line bench.py printed on an MI355X: it carries every key the driver's contract names
     (metric / value / unit / n_gpus / steps / warmup / ms_per_step / higher_is_better / scaling / vs_baseline / dtype / data /
     config.workload, the roofline object and the cpu_baseline object), its numbers are consistent with one another (value =
     units / time, roofline.achieved = algorithmic bytes / kernel time, frac = achieved / peak, kernel time <= step time), the
     metric is BASELINE.json's, and the source of bench.py still prints each of those keys."""
     import json
-    with open(os.path.join(ROOT, "profiles", "r05", "bench_default.json")) as fh:
+    with open(os.path.join(ROOT, "profiles", "r06", "bench_default.json")) as fh:
         d = json.load(fh)
     with open(os.path.join(ROOT, "BASELINE.json")) as fh:
         base = json.load(fh)
@@ -635,6 +635,17 @@ def test_committed_bench_line_keeps_the_drivers_contract():
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["peak"] == 8000.0 and 0.5 < r["frac"] < 1.0
     assert r["kernel_ms"] <= d["ms_per_step"] and (r["traffic"] is None or 0.95 * alg < r["traffic"] < 1.1 * alg)
     assert d["parity_max_rel_vs_oracle"] < 1e-10 and c["value"] > 0 and c["cores"] >= 1
+    # round 6: BASELINE configs[2], [3], [4] ride in the same line -- every row consistent with itself
+    rows = d["configs"]
+    names = " | ".join(r_["name"] for r_ in rows)
+    for want in ("C3 kf batch_filter (9,3)", "C3 rts_smoother", "C4 fused linear UKF (6,3)", "1000 filters x 8000", "125 filters x 8000000"):
+        assert want in names, want
+    for r_ in rows:
+        assert set(("name", "kernel", "kernel_ms", "algorithmic_bytes", "frac", "launches_timed")) <= set(r_), r_
+        assert r_["launches_timed"] >= 10 and 0.0 < r_["frac"] < 1.0
+        assert abs(r_["frac"] - r_["algorithmic_bytes"] / (r_["kernel_ms"] * 1e-3) / 8e12) <= 1e-6
+        assert r_.get("bit_exact") is True or r_["parity_max_rel"] < 1e-10, r_
+    assert d["value_unplaced"] > 0
     src = open(os.path.join(ROOT, "bench.py")).read()
     for k in ('"metric"', '"value"', '"unit"', '"n_gpus"', '"ms_per_step"', '"higher_is_better"', '"scaling"', '"vs_baseline"',
               '"dtype"', '"data"', '"config"', '"roofline"', '"cpu_baseline"', '"traffic"', '"frac"', '"kind"', '"sample"', '"cores"'):

@@ -77,6 +77,10 @@ def show(tl, Fn=1, brief=False):
         print("general chunks %d: entry->approx %.1f, ->prepared %.1f, ->exact %.1f, ->scan done %.1f, ->done %.1f us (means); declined %d, not prepared %d" % (
             int(gen.sum()), np.mean(d[:, 6] - d[:, 5]) / 100, np.mean(d[:, 7] - d[:, 6]) / 100, np.mean(d[:, 8] - d[:, 7]) / 100,
             np.mean(d[:, 9] - d[:, 8]) / 100, np.mean(d[:, 10] - d[:, 9]) / 100, int(((d[:, 15] >> 1) & 1).sum()), int(((d[:, 15] & 1) == 0).sum())))
+        pk = d[:, 2].astype(np.uint64)
+        if pk.any():
+            parts = [((pk >> np.uint64(16 * i)) & np.uint64(0xffff)).astype(np.float64) * 16 for i in range(4)]
+            print("  seg_prepare, core clocks (thread 0, means): to barrier 1 %.0f, to 2 %.0f, to 3 %.0f, to the end %.0f" % tuple(np.mean(x[pk > 0]) for x in parts))
     q1 = slow & (tl[:, 11] == 101)
     if q1.any():
         d = tl[q1]
