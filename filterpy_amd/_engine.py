@@ -71,10 +71,11 @@ def to_records(a, layout, lead):
     return t.transpose(-1, -2).contiguous()
 
 
-def download_into(pairs):
+def download_into(pairs, wait=True):
     """[(device tensor, NumPy array of the same shape and dtype, both contiguous)]: the tensors' bytes into the arrays, through the
-    pinned pipeline where that pays (kalman_filter.py: the streamed host outputs of batch_filter)"""
-    _transfer.into_host(pairs)
+    pinned pipeline where that pays (kalman_filter.py: the streamed host outputs of batch_filter).  wait=False: returns futures the
+    caller must .result() before it touches the tensors or the arrays again."""
+    return _transfer.into_host(pairs, wait)
 
 
 def from_records(t, layout, lead, rec_shape):

@@ -60,8 +60,10 @@ class _Pipe:
         finally:
             self._give(i)
 
-    def download(self, pairs):
-        """pairs: [(flat uint8 device tensor, flat uint8 NumPy destination)], equal lengths"""
+    def download(self, pairs, wait=True):
+        """pairs: [(flat uint8 device tensor, flat uint8 NumPy destination)], equal lengths.  wait=False: returns the slabs' futures
+        once all of them are submitted (the caller keeps source and destination alive and calls .result() on each before it
+        touches either) -- the next download's slabs then queue right behind these, the pipeline never drains in between."""
         with self.lock:
             self.stream.wait_stream(torch.cuda.current_stream(self.device))    # behind the kernel that wrote them
             futs = []
@@ -75,8 +77,11 @@ class _Pipe:
                         ev = torch.cuda.Event()
                         ev.record(self.stream)
                     futs.append(self.pool.submit(self._drain, i, ev, dst[a:a + n], n))
-            for f in futs:
-                f.result()                                      # (re-raises a worker's exception)
+        if not wait:
+            return futs
+        for f in futs:
+            f.result()                                          # (re-raises a worker's exception)
+        return []
 
 
 def _upload(self, src, dst):
@@ -146,9 +151,10 @@ def to_host(tensors):
     return out
 
 
-def into_host(pairs):
+def into_host(pairs, wait=True):
     """[(device tensor, NumPy array)] of equal shape / dtype, both contiguous: the tensor's bytes into the array (the caller owns
-    it: a slice of a larger result).  Small or CPU tensors: a plain copy."""
+    it: a slice of a larger result).  Small or CPU tensors: a plain copy.  wait=False: futures to call .result() on (see
+    _Pipe.download)."""
     big, dev = [], None
     piped = sum(t.numel() * t.element_size() for t, _ in pairs if t.is_cuda) >= MIN_BYTES and os.environ.get("FK_D2H_PIPE", "1") != "0"
     for t, h in pairs:
@@ -159,7 +165,8 @@ def into_host(pairs):
         big.append((t.view(-1).view(torch.uint8), h.reshape(-1).view(np.uint8)))
         dev = t.device
     if big:
-        _pipe(dev).download(big)
+        return _pipe(dev).download(big, wait)
+    return []
 
 
 def release():

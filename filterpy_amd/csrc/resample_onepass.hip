@@ -1255,6 +1255,8 @@ __device__ OP2_SLOW_INLINE void op_chunk_slow(OpShared &sh, const double *a_w, c
     unsigned *abort_word = &a.ctl->abort;
     const long base = (long)k * OP_TILE;
     const int len = (int)((Np - base) < OP_TILE ? (Np - base) : OP_TILE);
+    // (the weights once more, from L2.  Handing the caller's registers over -- the path is inlined -- was tried: the allocator then
+    //  spills in the FAST path's emission loop, 62 -> 90 spilled registers; the second trip costs a slow chunk ~2 us)
     double w8[OP_ITEMS];
     FK_UNROLL for (int q = 0; q < OP_ITEMS; ++q) {
         const int j = tid * OP_ITEMS + q;

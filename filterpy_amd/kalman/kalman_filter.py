@@ -106,19 +106,27 @@ class _Core:
             Tc = max(1, min(T, int(os.environ.get("FK_STREAM_CHUNK_BYTES", 2 << 30)) // step_bytes))
             shp = (lambda e: (T, N, e)) if layout == "aos" else (lambda e: (T, e, N))
             host = [np.empty(shp(e)) for e in (n, n * n, n, n * n)]
-            bufs = [E.alloc_records((Tc,), N, e, layout) for e in (n, n * n, n, n * n)]
+            # two sets of device buffers: chunk c + 1 is launched into the other set while chunk c is on its way out, and its slabs
+            # queue right behind chunk c's (the pipeline never drains between chunks); a set is reused once its download is done
+            bufs = [[E.alloc_records((Tc,), N, e, layout) for e in (n, n * n, n, n * n)] for _ in range(2)]
+            pending = [[], []]
             per_t = mode not in (FK_MODEL_SHARED, FK_MODEL_PER_TRACK)
             mods = [model(Mx) for Mx in (F, Q, H, R, B)]
             st_all = torch.zeros_like(st)
-            for t0 in range(0, T, Tc):
+            for c, t0 in enumerate(range(0, T, Tc)):
                 t1 = min(T, t0 + Tc)
                 cut = lambda v: None if v is None else v[t0:t1]              # noqa: E731
                 mm = [cut(v) if per_t else v for v in mods]
-                o = [b[:t1 - t0] for b in bufs]
+                for f in pending[c & 1]:
+                    f.result()
+                o = [b[:t1 - t0] for b in bufs[c & 1]]
                 E.kf_batch_filter(dict(desc, T=t1 - t0), mm[0], mm[1], mm[2], mm[3], dz[t0:t1], dx, dP, B=mm[4], u=cut(du),
                                   mask=cut(dmask), means=o[0], covs=o[1], means_p=o[2], covs_p=o[3], status=st)
                 st_all |= st
-                E.download_into([(o[k], host[k][t0:t1]) for k in range(4)])
+                pending[c & 1] = E.download_into([(o[k], host[k][t0:t1]) for k in range(4)], wait=False) or []
+            for fs in pending:
+                for f in fs:
+                    f.result()
             if placement_out is not None:
                 placement_out.clear()
                 placement_out.update({"method": "none", "note": "host outputs streamed in %d time chunks" % ((T + Tc - 1) // Tc)})
