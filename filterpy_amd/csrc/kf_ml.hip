@@ -460,26 +460,37 @@ kf_ml_kernel(const KfArgs a_in)
             FK_STAGE();
             double hk[2][NZ];                                   // HLDS: column k of H one iteration ahead
             if constexpr (HLDS) {
-                FK_UNROLL for (int r = 0; r < NZ; ++r) hk[0][r] = sH[r * NX];
-            }
-            FK_UNROLL for (int k = 0; k < NX; ++k) {
-                if constexpr (HLDS) {
-                    if (k + 1 < NX) {
-                        FK_UNROLL for (int r = 0; r < NZ; ++r) hk[(k + 1) & 1][r] = sH[r * NX + k + 1];
+                // Round 6: lane Lc forms ROW Lc of S (NZ == R: one row per lane of the quad's three) -- the same nine products
+                // in the same order as before, 27 fused multiply-adds instead of 81 -- and the rows are gathered afterwards
+                static_assert(NZ == R, "one row of S per lane");
+                const double *hrow = sH + Lc * NX;
+                hk[0][0] = hrow[0];
+                double Srow[NZ];
+                FK_UNROLL for (int k = 0; k < NX; ++k) {
+                    if (k + 1 < NX) hk[(k + 1) & 1][0] = hrow[k + 1];
+                    double pk[NZ];
+                    FK_UNROLL for (int c = 0; c < NZ; ++c) {
+                        const double v = PHT[k % R][c];
+                        pk[c] = (k / R == 0) ? quad_bcast<0>(v) : (k / R == 1) ? quad_bcast<1>(v) : quad_bcast<2>(v);
                     }
+                    const double h = hk[k & 1][0];
+                    FK_UNROLL for (int c = 0; c < NZ; ++c) Srow[c] = (k == 0) ? h * pk[c] : fma(h, pk[c], Srow[c]);
+                    if (k % 3 == 2) FK_STAGE();
                 }
+                FK_UNROLL for (int r = 0; r < NZ; ++r)
+                    FK_UNROLL for (int c = 0; c < NZ; ++c)
+                        S[r * NZ + c] = (r == 0) ? quad_bcast<0>(Srow[c]) : (r == 1) ? quad_bcast<1>(Srow[c]) : quad_bcast<2>(Srow[c]);
+            }
+            FK_UNROLL for (int k = 0; k < NX && !HLDS; ++k) {
                 double pk[NZ];
                 FK_UNROLL for (int c = 0; c < NZ; ++c) {
                     const double v = PHT[k % R][c];
                     pk[c] = (k / R == 0) ? quad_bcast<0>(v) : (k / R == 1) ? quad_bcast<1>(v) : quad_bcast<2>(v);
                 }
                 FK_UNROLL for (int r = 0; r < NZ; ++r) {
-                    const double h = HLDS ? hk[k & 1][r] : HX(r * NX + k);
+                    const double h = HX(r * NX + k);
                     FK_UNROLL for (int c = 0; c < NZ; ++c)
                         S[r * NZ + c] = (k == 0) ? h * pk[c] : fma(h, pk[c], S[r * NZ + c]);
-                }
-                if constexpr (HLDS) {
-                    if (k % 3 == 2) FK_STAGE();
                 }
             }
             FK_UNROLL for (int e = 0; e < NZ * NZ; ++e) S[e] += Rs[e];
