@@ -1,6 +1,7 @@
 // imm_dispatch.cpp -- C ABI entry of the batched IMM estimator: argument checks and the choice of
 // the (dim_x, dim_z, n_models) instantiation of imm_kernels.hip.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 
 #include "fk_chunks.hpp"
 #include "fk_device.hpp"
@@ -12,6 +13,21 @@ using namespace fk;
 #define FK_IMM_INST(NX, NZ, NM, W) void launch_imm_##NX##_##NZ##_##NM(const ImmArgs &, int, int, hipStream_t);
 #include "fk_dims_imm.def"
 #undef FK_IMM_INST
+// imm_lanes.hip: one lane per filter of a bank (round 6) -- the class (9, 4), every bank size 2..16
+#define FK_IL_DECL(NX, NZ)                                                              \
+    int launch_imm_lanes_##NX##_##NZ##_g2(const ImmArgs &, int, int, hipStream_t);         \
+    int launch_imm_lanes_##NX##_##NZ##_g4(const ImmArgs &, int, int, hipStream_t);         \
+    int launch_imm_lanes_##NX##_##NZ##_g8(const ImmArgs &, int, int, hipStream_t);         \
+    int launch_imm_lanes_##NX##_##NZ##_g16(const ImmArgs &, int, int, hipStream_t);        \
+    static int launch_imm_lanes_##NX##_##NZ(const ImmArgs &a, int nm, int layout, hipStream_t s)                       \
+    {                                                                                                                  \
+        return nm <= 2 ? launch_imm_lanes_##NX##_##NZ##_g2(a, nm, layout, s) : nm <= 4 ? launch_imm_lanes_##NX##_##NZ##_g4(a, nm, layout, s) \
+             : nm <= 8 ? launch_imm_lanes_##NX##_##NZ##_g8(a, nm, layout, s) : launch_imm_lanes_##NX##_##NZ##_g16(a, nm, layout, s);         \
+    }
+FK_IL_DECL(4, 2)
+FK_IL_DECL(6, 3)
+FK_IL_DECL(9, 4)
+#undef FK_IL_DECL
 
 static int fail(int code, const char *msg)
 {
@@ -71,7 +87,19 @@ extern "C" int fk_imm_batch_ex_f64(const fk_imm_desc *d, const double *F, const 
     // eight filters, dim_x <= 16, dim_z <= 8 -- on the rolled (9, 4) / (16, 8) class of its bank size (fk_dims_imm.def)
     const bool small = d->n <= 6 && d->m <= 3 && n_models <= 3;
     const int cls = (d->n <= 2 && d->m <= 1) ? 0 : (d->n <= 4 && d->m <= 2) ? 1 : 2;
+    // One lane per FILTER (imm_lanes.hip) for the plain multi-step call of every bank the register-resident small classes do
+    // not hold, dim_x <= 9 / dim_z <= 4: 2..16 filters.  FK_IMM_LANES=0: the one-lane-per-bank kernels as before (A/B);
+    // =2: the small classes too.
+    static const int lanes_mode = [] { const char *v = getenv("FK_IMM_LANES"); return v ? atoi(v) : 1; }();
+    const bool lanes = lanes_mode > 0 && (lanes_mode > 1 || !small) && d->n <= 9 && d->m <= 4 && d->phase == FK_IMM_STEP && !a.mmae &&
+                       !zmask && !ll0 && nu == 0;
     auto one = [&](const ImmArgs &b, hipStream_t s) -> int {
+        if (lanes) {
+            // the smallest class that holds the filters: (4, 2), (6, 3), (9, 4)
+            const int rc = (b.n <= 4 && b.m <= 2) ? launch_imm_lanes_4_2(b, n_models, layout, s)
+                         : (b.n <= 6 && b.m <= 3) ? launch_imm_lanes_6_3(b, n_models, layout, s) : launch_imm_lanes_9_4(b, n_models, layout, s);
+            if (rc == 0) return check_launch("imm_lanes_kernel");
+        }
         if (small) {
             if (n_models == 2) {
                 if (cls == 0) launch_imm_2_1_2(b, layout, mask, s);
@@ -121,6 +149,8 @@ extern "C" int fk_imm_batch_ex_f64(const fk_imm_desc *d, const double *F, const 
     // tail filling (fk_chunks.hpp, imm_chunked_call): wave slots of the instantiation the call runs on -- the compiled output
     // sets of the small banks at their FK_IMM_WAVES per SIMD (fk_dims_imm.def), everything else at one
     static const int small_waves[3][2] = {{4, 3}, {2, 2}, {1, 1}};            // [class][n_models - 2]
-    const long slots = 1024L * ((small && mask >= 0) ? small_waves[cls][n_models - 2] : 1);
+    // (the lanes kernel: a wave holds 64 / G banks, G = the bank size rounded up to a power of two)
+    const int lanes_g = n_models <= 2 ? 2 : n_models <= 4 ? 4 : n_models <= 8 ? 8 : 16;
+    const long slots = lanes ? 1024L / lanes_g : 1024L * ((small && mask >= 0) ? small_waves[cls][n_models - 2] : 1);
     return imm_chunked_call(a, d->n, d->m, n_models, slots, one, s);
 }

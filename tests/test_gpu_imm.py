@@ -622,3 +622,112 @@ def test_imm_banks_above_9_4_vs_oracle(n, m, nm, layout):
         imm.update(zs[t, 0])
         assert rel_err_rows(imm.x[None], x[t][None]) < TOL and rel_err_rows(imm.P[None], P[t][None]) < TOL
         assert np.allclose(imm.mu, mu[t], rtol=1e-9, atol=1e-14)
+
+
+# ---- round 6: one lane per filter (csrc/imm_lanes.hip): every class x every group width, ragged banks, output subsets
+LANES_CASES = [(4, 2, 4), (3, 2, 7), (4, 1, 12), (6, 3, 4), (5, 3, 6), (6, 2, 16), (9, 4, 2), (7, 2, 3), (9, 4, 8), (8, 3, 5), (9, 2, 13), (7, 4, 16)]
+
+
+def _lanes_bank(n, m, nm, N, T, seed):
+    rs = np.random.RandomState(seed)
+    Fs = np.array([stable_F(rs, n) for _ in range(nm)])
+    Qs = np.array([spd(rs, n, 0.05 * (j % 5 + 1)) for j in range(nm)])
+    Hs = np.array([rs.randn(m, n) for _ in range(nm)])
+    Rs = np.array([spd(rs, m, 0.5) for _ in range(nm)])
+    M = rs.rand(nm, nm) + 2 * np.eye(nm)
+    M /= M.sum(axis=1, keepdims=True)
+    xs0 = rs.randn(N, nm, n)
+    Ps0 = np.array([[spd(rs, n, 2.0) for _ in range(nm)] for _ in range(N)])
+    mu0 = rs.rand(N, nm) + 0.1
+    mu0 /= mu0.sum(axis=1, keepdims=True)
+    zs = rs.randn(T, N, m) * 2
+    return xs0, Ps0, mu0, M, zs, Fs, Qs, Hs, Rs
+
+
+@pytest.mark.parametrize("layout", ["soa", "aos"])
+@pytest.mark.parametrize("n,m,nm", LANES_CASES)
+def test_imm_lanes_kernel_vs_oracle(n, m, nm, layout):
+    """banks the one-lane-per-filter kernel serves (IMM.py:160-249), N not a multiple of the banks of a wave or a block, every
+    bank checked at its ends: per-step estimate, prior, mode probabilities, likelihoods and the bank's final state"""
+    from oracle import imm_oracle
+    N, T = 203, 7
+    b = _lanes_bank(n, m, nm, N, T, 500 + 10 * n + nm)
+    xs0, Ps0, mu0, M, zs, Fs, Qs, Hs, Rs = b
+    r = run_imm(*b, layout)
+    assert np.isfinite(r["x_out"]).all() and np.isfinite(r["P_out"]).all() and np.isfinite(r["mu_out"]).all()
+    for trk in (0, 1, 3, 4, 7, 8, 15, 16, 31, 32, 63, 64, 127, 128, 200, 201, N - 1):
+        x, P, mu, xp, Pp, L = imm_oracle.imm_batch(xs0[trk], Ps0[trk], mu0[trk], M, zs[:, trk], Fs, Qs, Hs, Rs)
+        assert rel_err_rows(r["x_out"][:, trk], x) < TOL and rel_err_rows(r["P_out"][:, trk], P) < TOL
+        assert rel_err_rows(r["x_prior_out"][:, trk], xp) < TOL and rel_err_rows(r["P_prior_out"][:, trk], Pp) < TOL
+        assert np.allclose(r["mu_out"][:, trk], mu, rtol=1e-10, atol=1e-14)
+        assert np.allclose(r["likelihood_out"][:, trk], L, rtol=1e-10, atol=1e-300)
+        assert np.allclose(r["mu"][trk], mu[-1], rtol=1e-10, atol=1e-14)
+    # the bank's final state: a second call that continues from it equals one call over both halves
+    r2 = run_imm(r["xs"], r["Ps"], r["mu"], M, zs[:3], Fs, Qs, Hs, Rs, layout)
+    for trk in (0, 100, N - 1):
+        x, P, mu, _, _, _ = imm_oracle.imm_batch(xs0[trk], Ps0[trk], mu0[trk], M, np.concatenate([zs[:, trk], zs[:3, trk]]), Fs, Qs, Hs, Rs)
+        assert rel_err_rows(r2["x_out"][:, trk], x[T:]) < TOL and rel_err_rows(r2["P_out"][:, trk], P[T:]) < TOL
+
+
+@pytest.mark.parametrize("layout", ["soa", "aos"])
+@pytest.mark.parametrize("outs", [("x_out",), ("P_out", "mu_out"), ("x_prior_out", "P_prior_out"), ("likelihood_out",), ()])
+def test_imm_lanes_kernel_output_subsets(outs, layout):
+    """any subset of the per-step outputs (the pointers are tested at run time): what is asked for equals the all-outputs call
+    bit for bit, and so does the final state of the bank"""
+    import torch
+    from filterpy_amd import _engine as E
+    n, m, nm, N, T = 8, 3, 6, 77, 5
+    b = _lanes_bank(n, m, nm, N, T, 77)
+    xs0, Ps0, mu0, M, zs, Fs, Qs, Hs, Rs = b
+    full = run_imm(*b, layout)
+    dxs = E.to_records(xs0.reshape(N, nm * n), layout, 0)
+    dPs = E.to_records(Ps0.reshape(N, nm * n * n), layout, 0)
+    dmu = E.to_records(mu0, layout, 0)
+    dz = E.to_records(zs, layout, 1)
+    sizes = dict(x_out=n, P_out=n * n, mu_out=nm, likelihood_out=nm, x_prior_out=n, P_prior_out=n * n)
+    shapes = dict(x_out=(n,), P_out=(n, n), mu_out=(nm,), likelihood_out=(nm,), x_prior_out=(n,), P_prior_out=(n, n))
+    out = {k: E.alloc_records((T,), N, sizes[k], layout) for k in outs}
+    st = torch.zeros(N, dtype=torch.int32, device=dxs.device)
+    E.imm_batch(n, m, nm, N, T, layout, E.dev(Fs), E.dev(Qs), E.dev(Hs), E.dev(Rs), E.dev(M), dz, dxs, dPs, dmu, status=st, **out)
+    torch.cuda.synchronize()
+    assert not st.any()
+    for k, v in out.items():
+        assert np.array_equal(E.from_records(v, layout, 1, shapes[k]), full[k]), k
+    assert np.array_equal(E.from_records(dxs, layout, 0, (nm, n)), full["xs"])
+    assert np.array_equal(E.from_records(dPs, layout, 0, (nm, n, n)), full["Ps"])
+    assert np.array_equal(E.from_records(dmu, layout, 0, (nm,)), full["mu"])
+
+
+def test_imm_lanes_kernel_against_the_one_lane_per_bank_kernels():
+    """FK_IMM_LANES=0 (read once per process: two subprocesses) runs the same banks on imm_kernels.hip: every record of both
+    within 1e-11 of each other (normwise per bank and step)"""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, "tests")
+import test_gpu_imm as t
+res = {}
+for (n, m, nm) in [(9, 4, 8), (6, 3, 5), (4, 2, 4)]:
+    b = t._lanes_bank(n, m, nm, 150, 6, 9 + nm)
+    for layout in ("soa", "aos"):
+        r = t.run_imm(*b, layout)
+        for k in ("x_out", "P_out", "mu_out", "likelihood_out", "x_prior_out", "P_prior_out", "xs", "Ps", "mu"):
+            res[f"{n}_{m}_{nm}_{layout}_{k}"] = r[k]
+np.savez(sys.argv[1], **res)
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    got = {}
+    with tempfile.TemporaryDirectory() as td:
+        for mode in ("0", "1"):
+            f = os.path.join(td, f"m{mode}.npz")
+            env = dict(os.environ, FK_IMM_LANES=mode, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+            subprocess.run([sys.executable, "-c", code, f], check=True, cwd=root, env=env, timeout=600)
+            got[mode] = dict(np.load(f))
+    assert got["0"].keys() == got["1"].keys() and len(got["0"]) == 54
+    for k in got["0"]:
+        a, b = got["0"][k], got["1"][k]
+        w = a.shape[-1] * (a.shape[-2] if k.endswith(("P_out", "Ps")) else 1)
+        assert rel_err_rows(a.reshape(-1, w), b.reshape(-1, w)) < 1e-11, k

@@ -575,6 +575,10 @@ if __name__ == "__main__":
             config_imm(lay, 9, 4, 5, 50_000, 20)
             config_imm(lay, 9, 4, 8, 50_000, 20)
             config_imm(lay, 16, 8, 2, 50_000, 20)
+            # round 6: banks the one-lane-per-filter kernel took over from the padded (9,4) class (csrc/imm_lanes.hip)
+            config_imm(lay, 4, 2, 4, 200_000, 20)
+            config_imm(lay, 6, 3, 4, 100_000, 20)
+            config_imm(lay, 9, 4, 16, 25_000, 20)
         if "u" in a.configs:      # the fused linear UKF above dim_x 9 (several lanes per track; rows appear once FK_UKF_MLG is on)
             for (n, m, N) in ((10, 2, 100_000), (12, 3, 100_000), (14, 4, 80_000), (16, 4, 60_000), (16, 8, 60_000)):
                 config_ukf(lay, n, m, N, 50)
