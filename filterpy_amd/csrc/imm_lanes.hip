@@ -29,6 +29,18 @@
 #include "fk_ml.hpp"
 #include "../../include/filterhip.h"
 
+// FK_IL_STREAM_PREDICT / FK_IL_STREAM_UPDATE = 1 (build time): lanes_predict / lanes_update below -- the model's rows streamed from LDS,
+// the results parked in the exchange image -- instead of kf_predict_sym / kf_update_sym with their register copy of the model.
+// MEASURED SLOWER (profiles/r06/imm_lanes/streamed_vs_register_copy*.txt: (9,4) x 8 4.02 ms both streamed, 3.84 / 3.74 one of them,
+// 3.55 neither): with one wave per SIMD the 1500 LDS operations of a streamed step are latency nobody hides, while the copy's
+// v_accvgpr_read are issue slots the lone wave has to spare.  Kept as the A/B.
+#ifndef FK_IL_STREAM_PREDICT
+#define FK_IL_STREAM_PREDICT 0
+#endif
+#ifndef FK_IL_STREAM_UPDATE
+#define FK_IL_STREAM_UPDATE 0
+#endif
+
 namespace fk {
 
 // offset (in doubles) of element e of record `rec` in an [N][nelem] (NumPy order) or [nelem][N] (element-major) block: 32 bits
@@ -380,7 +392,7 @@ imm_lanes_kernel(const ImmArgs a, const int NM, const int aos)
                 zc[r] = (r < m) ? zv : 0.0;
             }
         }
-        if constexpr (PH == 1 && NX >= 7) {
+        if constexpr (PH == 1 && NX >= 7 && FK_IL_STREAM_PREDICT) {
             ml_wave_fence();
             lanes_predict<NX>(x, P, mod, wP + lane);
             ml_wave_fence();
@@ -394,7 +406,7 @@ imm_lanes_kernel(const ImmArgs a, const int NM, const int aos)
         double lj;
         {
             double y[NZ], Lf[NZ * NZ], dinv[NZ];
-            if constexpr (PH == 1 && NX >= 7) {
+            if constexpr (PH == 1 && NX >= 7 && FK_IL_STREAM_UPDATE) {
                 ml_wave_fence();
                 st |= lanes_update<NX, NZ>(x, P, z, mod, wP + lane, y, Lf, dinv);
                 ml_wave_fence();

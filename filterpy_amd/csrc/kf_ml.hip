@@ -914,15 +914,26 @@ rts_ml_kernel(const RtsArgs a_in)
         {
             double x[NX], dx[NX];
             FK_UNROLL for (int i = 0; i < NX; ++i) x[i] = park[R * NX + i][threadIdx.x];
-            double Fr[2][NX];
-            FK_UNROLL for (int q = 0; q < NX; ++q) Fr[0][q] = sF[q];
-            FK_UNROLL for (int i = 0; i < NX; ++i) {
-                if (i + 1 < NX) {
-                    FK_UNROLL for (int q = 0; q < NX; ++q) Fr[(i + 1) & 1][q] = sF[(i + 1) * NX + q];
+            // Round 6: F x by rows of the quad -- lane Lc forms rows 3 Lc .. 3 Lc + 2 from its own rows of F (the same products in
+            // the same order as the nine rows every lane used to form: 27 fused multiply-adds instead of 81), gathered afterwards
+            {
+                double fxo[R];
+                double Fo[2][NX];
+                FK_UNROLL for (int q = 0; q < NX; ++q) Fo[0][q] = myF[q];
+                FK_UNROLL for (int r = 0; r < R; ++r) {
+                    if (r + 1 < R) {
+                        FK_UNROLL for (int q = 0; q < NX; ++q) Fo[(r + 1) & 1][q] = myF[(r + 1) * NX + q];
+                    }
+                    double acc = Fo[r & 1][0] * x[0];
+                    FK_UNROLL for (int q = 1; q < NX; ++q) acc = fma(Fo[r & 1][q], x[q], acc);
+                    fxo[r] = acc;
                 }
-                double acc = Fr[i & 1][0] * x[0];
-                FK_UNROLL for (int q = 1; q < NX; ++q) acc = fma(Fr[i & 1][q], x[q], acc);
-                dx[i] = xn[i] - acc;
+                FK_STAGE();
+                FK_UNROLL for (int i = 0; i < NX; ++i) {
+                    const double v = fxo[i % R];
+                    const double fx = (i / R == 0) ? quad_bcast<0>(v) : (i / R == 1) ? quad_bcast<1>(v) : quad_bcast<2>(v);
+                    dx[i] = xn[i] - fx;
+                }
                 FK_STAGE();
             }
             FK_UNROLL for (int i = 0; i < NX; ++i) {
@@ -945,15 +956,22 @@ rts_ml_kernel(const RtsArgs a_in)
             load_rows<R, NX, MODE>(vP, Pn);
             double dxr[NX];
             FK_UNROLL for (int i = 0; i < NX; ++i) dxr[i] = park[NX + i][threadIdx.x];
-            double xp[2];
-            xp[0] = park[0][threadIdx.x];
+            // Round 6: x + K dx by rows of the quad too: this lane's rows of K are its own registers (Tm), the sums the ones every lane
+            // used to form for all nine rows; gathered from their owners below
+            double xao[R];
+            FK_UNROLL for (int r = 0; r < R; ++r) {
+                double xa = park[Lc * R + r][threadIdx.x];
+                FK_UNROLL for (int q = 0; q < NX; ++q) xa = fma(Tm[r][q], dxr[q], xa);
+                xao[r] = xa;
+            }
+            FK_STAGE();
             FK_UNROLL for (int j = 0; j < NX; ++j) {
-                if (j + 1 < NX) xp[(j + 1) & 1] = park[j + 1][threadIdx.x];
                 double Kj[NX];
                 FK_ROW_FROM_OWNER(Kj, Tm, j, NX);
-                double xa = xp[j & 1];
-                FK_UNROLL for (int q = 0; q < NX; ++q) xa = fma(Kj[q], dxr[q], xa);
-                xn[j] = xa;
+                {
+                    const double v = xao[j % R];
+                    xn[j] = (j / R == 0) ? quad_bcast<0>(v) : (j / R == 1) ? quad_bcast<1>(v) : quad_bcast<2>(v);
+                }
                 FK_UNROLL for (int r = 0; r < R; ++r) {
                     double acc = Pn[r][j];
                     FK_UNROLL for (int q = 0; q < NX; ++q) acc = fma(E[r][q], Kj[q], acc);
