@@ -14,20 +14,32 @@ using namespace fk;
 #include "fk_dims_imm.def"
 #undef FK_IMM_INST
 // imm_lanes.hip: one lane per filter of a bank (round 6) -- the class (9, 4), every bank size 2..16
-#define FK_IL_DECL(NX, NZ)                                                              \
-    int launch_imm_lanes_##NX##_##NZ##_g2(const ImmArgs &, int, int, hipStream_t);         \
-    int launch_imm_lanes_##NX##_##NZ##_g4(const ImmArgs &, int, int, hipStream_t);         \
-    int launch_imm_lanes_##NX##_##NZ##_g8(const ImmArgs &, int, int, hipStream_t);         \
-    int launch_imm_lanes_##NX##_##NZ##_g16(const ImmArgs &, int, int, hipStream_t);        \
+#define FK_IL_DECL1(NX, NZ, X)                                                                                         \
+    int launch_imm_lanes_##NX##_##NZ##_g2_x##X(const ImmArgs &, int, int, hipStream_t);                                 \
+    int launch_imm_lanes_##NX##_##NZ##_g4_x##X(const ImmArgs &, int, int, hipStream_t);                                 \
+    int launch_imm_lanes_##NX##_##NZ##_g8_x##X(const ImmArgs &, int, int, hipStream_t);                                 \
+    int launch_imm_lanes_##NX##_##NZ##_g16_x##X(const ImmArgs &, int, int, hipStream_t);                                \
+    static int launch_imm_lanes_##NX##_##NZ##_x##X(const ImmArgs &a, int nm, int layout, hipStream_t s)                 \
+    {                                                                                                                  \
+        return nm <= 2 ? launch_imm_lanes_##NX##_##NZ##_g2_x##X(a, nm, layout, s)                                      \
+             : nm <= 4 ? launch_imm_lanes_##NX##_##NZ##_g4_x##X(a, nm, layout, s)                                      \
+             : nm <= 8 ? launch_imm_lanes_##NX##_##NZ##_g8_x##X(a, nm, layout, s)                                      \
+                       : launch_imm_lanes_##NX##_##NZ##_g16_x##X(a, nm, layout, s);                                    \
+    }
+// (x0: the plain call; x1: the instantiation that also carries MMAE, missing measurements and the control input)
+#define FK_IL_DECL(NX, NZ)                                                                                             \
+    FK_IL_DECL1(NX, NZ, 0)                                                                                             \
+    FK_IL_DECL1(NX, NZ, 1)                                                                                             \
     static int launch_imm_lanes_##NX##_##NZ(const ImmArgs &a, int nm, int layout, hipStream_t s)                       \
     {                                                                                                                  \
-        return nm <= 2 ? launch_imm_lanes_##NX##_##NZ##_g2(a, nm, layout, s) : nm <= 4 ? launch_imm_lanes_##NX##_##NZ##_g4(a, nm, layout, s) \
-             : nm <= 8 ? launch_imm_lanes_##NX##_##NZ##_g8(a, nm, layout, s) : launch_imm_lanes_##NX##_##NZ##_g16(a, nm, layout, s);         \
+        const bool ext = a.mmae || a.mask || a.ll0 || a.nu > 0;                                                        \
+        return ext ? launch_imm_lanes_##NX##_##NZ##_x1(a, nm, layout, s) : launch_imm_lanes_##NX##_##NZ##_x0(a, nm, layout, s); \
     }
 FK_IL_DECL(4, 2)
 FK_IL_DECL(6, 3)
 FK_IL_DECL(9, 4)
 #undef FK_IL_DECL
+#undef FK_IL_DECL1
 
 static int fail(int code, const char *msg)
 {
@@ -87,12 +99,11 @@ extern "C" int fk_imm_batch_ex_f64(const fk_imm_desc *d, const double *F, const 
     // eight filters, dim_x <= 16, dim_z <= 8 -- on the rolled (9, 4) / (16, 8) class of its bank size (fk_dims_imm.def)
     const bool small = d->n <= 6 && d->m <= 3 && n_models <= 3;
     const int cls = (d->n <= 2 && d->m <= 1) ? 0 : (d->n <= 4 && d->m <= 2) ? 1 : 2;
-    // One lane per FILTER (imm_lanes.hip) for the plain multi-step call of every bank the register-resident small classes do
+    // One lane per FILTER (imm_lanes.hip) for the multi-step call (IMM or MMAE, missing measurements and control input included) of every bank the register-resident small classes do
     // not hold, dim_x <= 9 / dim_z <= 4: 2..16 filters.  FK_IMM_LANES=0: the one-lane-per-bank kernels as before (A/B);
     // =2: the small classes too.
     static const int lanes_mode = [] { const char *v = getenv("FK_IMM_LANES"); return v ? atoi(v) : 1; }();
-    const bool lanes = lanes_mode > 0 && (lanes_mode > 1 || !small) && d->n <= 9 && d->m <= 4 && d->phase == FK_IMM_STEP && !a.mmae &&
-                       !zmask && !ll0 && nu == 0;
+    const bool lanes = lanes_mode > 0 && (lanes_mode > 1 || !small) && d->n <= 9 && d->m <= 4 && d->phase == FK_IMM_STEP;
     auto one = [&](const ImmArgs &b, hipStream_t s) -> int {
         if (lanes) {
             // the smallest class that holds the filters: (4, 2), (6, 3), (9, 4)

@@ -18,9 +18,9 @@
 // (9,4) track costs the one-lane kernels -- for eight banks at once.
 //
 // n_models is a run-time value (2 .. G, idle lanes of a group duplicate the last filter and store nothing): four kernels per
-// class.  Exact arithmetic per element as in fk_imm.hpp (same operations, same order); parity against the oracle in
-// tests/test_gpu_imm.py.  Not served here (imm_kernels.hip keeps them): MMAE, missing measurements, control input, the
-// single-phase calls.
+// class and kind (plain; extended: MMAE, missing measurements, control input).  Exact arithmetic per element as in fk_imm.hpp (same
+// operations, same order); parity against the oracle in tests/test_gpu_imm.py.  Not served here (imm_kernels.hip keeps them): the
+// single-phase calls (one step: launch-bound either way), the register-resident small banks, and the (16, 8) class.
 #include <type_traits>
 
 #include "fk_device.hpp"
@@ -189,7 +189,7 @@ struct LanesCtx {
 // run-time flag every element of P carried a copy through the join of the two paths -- it kept the kernel's P in scratch memory.)
 template <bool MIX, int NX, int G, int CH, int PH>
 __device__ __forceinline__ void lanes_exchange(const LanesCtx &c, double (&x)[NX], double (&P)[NX * (NX + 1) / 2], const double mu,
-                                               double &cbar, const bool est, double *x_dst, double *P_dst)
+                                               double &cbar, const bool est, double *x_dst, double *P_dst, const bool mmae = false)
 {
     constexpr bool mix = MIX;
     constexpr int PL = NX * (NX + 1) / 2, GPW = 64 / G;
@@ -256,9 +256,20 @@ __device__ __forceinline__ void lanes_exchange(const LanesCtx &c, double (&x)[NX
                     const int rcw = s_rc[lo + qc], r = rcw & 255, c = rcw >> 8;
                     const double hr = wH[r * GPW + grp], hc = wH[c * GPW + grp];
                     double acc = 0.0;
-                    for (int i = 0; i < NM; ++i) {
-                        const double ya = wX[r * 64 + g0 + i] - hr, yb = wX[c * 64 + g0 + i] - hc;
-                        acc = fma(wMu[g0 + i], fma(ya, yb, wP[qc * 64 + g0 + i]), acc);
+                    if (mmae) {
+                        // MMAEFilterBank's covariance (mmae.py:191-207) zips the COMPONENTS of x with the filters: filter k is centred on
+                        // the scalar x[k], and only the first min(dim_x, n_models) filters contribute (fk_imm.hpp, mmae_estimate)
+                        const int kmax = NM < n ? NM : n;
+                        for (int i = 0; i < kmax; ++i) {
+                            const double hk = wH[i * GPW + grp];
+                            const double ya = wX[r * 64 + g0 + i] - hk, yb = wX[c * 64 + g0 + i] - hk;
+                            acc = fma(wMu[g0 + i], fma(ya, yb, wP[qc * 64 + g0 + i]), acc);
+                        }
+                    } else {
+                        for (int i = 0; i < NM; ++i) {
+                            const double ya = wX[r * 64 + g0 + i] - hr, yb = wX[c * 64 + g0 + i] - hc;
+                            acc = fma(wMu[g0 + i], fma(ya, yb, wP[qc * 64 + g0 + i]), acc);
+                        }
                     }
                     if (lo + q < hi && c < n && live) {
                         P_dst[oP.at(bank, r * n + c)] = acc;
@@ -287,7 +298,11 @@ __device__ __forceinline__ void lanes_exchange(const LanesCtx &c, double (&x)[NX
 }
 
 // (waves per SIMD the register budget is held to: left to itself the compiler spreads a (4,2) filter over 280 registers)
-template <int NX, int NZ, int G>
+// EXT: the instantiation that also carries MMAE (mmae.py:140-207: no mixing, p *= likelihood, its own estimate), missing measurements
+// (update(None): the filters keep x, P; the likelihood is the density of a zero residual under the S of the filter's last real update,
+// IMM.py:171-179 + kalman_filter.py:511-520) and the control input (x = F x + B u, kalman_filter.py:472-475) -- as run-time choices, kept
+// out of the plain kernel's register allocation.
+template <int NX, int NZ, int G, bool EXT>
 __global__ void __launch_bounds__(BLOCK, (NX <= 4 ? 2 : 1))
 imm_lanes_kernel(const ImmArgs a, const int NM, const int aos)
 {
@@ -313,7 +328,7 @@ imm_lanes_kernel(const ImmArgs a, const int NM, const int aos)
         lds_fill<NZ, NZ>(s + LM::OFF_R, a.R + (long)j * m * m, m, m, 1.0, threadIdx.x);
     }
     double *sM = smem + G * LM::SIZE;
-    if ((int)threadIdx.x < NM * NM) sM[threadIdx.x] = a.Mt[threadIdx.x];
+    if ((int)threadIdx.x < NM * NM) sM[threadIdx.x] = a.Mt ? a.Mt[threadIdx.x] : 0.0;
     for (int p = threadIdx.x; p < PL; p += BLOCK) {
         int r = 0, base = 0;
         while (base + (NX - r) <= p) { base += NX - r; ++r; }
@@ -364,6 +379,12 @@ imm_lanes_kernel(const ImmArgs a, const int NM, const int aos)
                     : m == 4 ? 0.025330295910584444 : m == 5 ? 0.010105326013811644 : m == 6 ? 0.004031441804149937
                     : m == 7 ? 0.0016083125866532416 : m == 8 ? 0.000641623890917771 : 1.0;
     const bool want_post = a.x_out || a.P_out, want_prior = a.xp_out || a.Pp_out;
+    const bool mmae = EXT && a.mmae;
+    // missing measurements: the log-density of a zero residual under this filter's last S (before any update S = 0: the density
+    // evaluates to 0 and is floored at DBL_MIN, kalman_filter.py:1221-1225)
+    [[maybe_unused]] double ll0v = -__builtin_inf();
+    if (EXT && a.ll0) ll0v = a.ll0[rec_map(aos, N, NM).at(bank, (int)jm)];
+    [[maybe_unused]] const double log2pi_m = m * 1.8378770664093453;
 
     double zc[NZ];
     FK_UNROLL for (int r = 0; r < NZ; ++r) {
@@ -372,8 +393,15 @@ imm_lanes_kernel(const ImmArgs a, const int NM, const int aos)
     }
     for (long t = 0; t < a.T; ++t) {
         // posterior estimate of step t-1 and mixing for step t from one publication
-        lanes_exchange<true, NX, G, CH, PH>(ctx, x, P, mu, cbar, t > 0 && want_post, a.x_out ? a.x_out + (t - 1) * N * n : nullptr,
-                                            a.P_out ? a.P_out + (t - 1) * N * nn : nullptr);
+        if (mmae) {
+            cbar = mu;                                          // p_i *= likelihood_i (mmae.py:186-187): no mixing
+            if (t > 0 && want_post)
+                lanes_exchange<false, NX, G, CH, PH>(ctx, x, P, mu, cbar, true, a.x_out ? a.x_out + (t - 1) * N * n : nullptr,
+                                                     a.P_out ? a.P_out + (t - 1) * N * nn : nullptr, true);
+        } else {
+            lanes_exchange<true, NX, G, CH, PH>(ctx, x, P, mu, cbar, t > 0 && want_post, a.x_out ? a.x_out + (t - 1) * N * n : nullptr,
+                                                a.P_out ? a.P_out + (t - 1) * N * nn : nullptr);
+        }
         // (the model block's offset is made opaque once per step: F, Q, H, R are the same every step, and hoisted out of the time
         //  loop they would sit in 88 .. 400 registers across it)
         {
@@ -399,12 +427,33 @@ imm_lanes_kernel(const ImmArgs a, const int NM, const int aos)
         } else {
             kf_predict_sym<NX>(x, P, mod, 1.0);
         }
+        if (EXT && a.nu > 0) {
+            // every filter's predict(u): x = F x + B u, B u formed on its own like dot(B, u)
+            const double *ut = a.u + t * N * a.nu;
+            const RecMap ou = rec_map(aos, N, a.nu);
+            double uu[4];
+            FK_UNROLL for (int c = 0; c < 4; ++c) uu[c] = c < a.nu ? ut[ou.at(bank, c)] : 0.0;
+            FK_UNROLL for (int r = 0; r < NX; ++r) {
+                if (r < n) {
+                    const double *Br = a.B + ((int)jm * n + r) * a.nu;
+                    double bu = Br[0] * uu[0];
+                    FK_UNROLL for (int c = 1; c < 4; ++c)
+                        if (c < a.nu) bu = fma(Br[c], uu[c], bu);
+                    x[r] += bu;
+                }
+            }
+        }
         if (want_prior)
             lanes_exchange<false, NX, G, CH, PH>(ctx, x, P, mu, cbar, true, a.xp_out ? a.xp_out + t * N * n : nullptr,
                                                  a.Pp_out ? a.Pp_out + t * N * nn : nullptr);
         // this lane's filter: update, likelihood floored at DBL_MIN (kalman_filter.py:1213-1226; fk_imm.hpp, imm_update)
         double lj;
-        {
+        bool has_z = true;
+        if (EXT && a.mask) has_z = a.mask[t * N + bank] != 0;
+        if (!has_z) {
+            lj = exp(ll0v);
+            if (lj == 0.0) lj = 2.2250738585072014e-308;
+        } else {
             double y[NZ], Lf[NZ * NZ], dinv[NZ];
             if constexpr (PH == 1 && NX >= 7 && FK_IL_STREAM_UPDATE) {
                 ml_wave_fence();
@@ -431,6 +480,7 @@ imm_lanes_kernel(const ImmArgs a, const int NM, const int aos)
             const double g = rsqrt_det_parts<NZ>(dinv, m, e2);
             lj = (cm * g) * exp(fma((double)e2, 0.6931471805599453, -0.5 * q));
             if (lj == 0.0) lj = 2.2250738585072014e-308;
+            if constexpr (EXT) ll0v = -0.5 * (log2pi_m + logdet_from_dinv<NZ>(dinv, m));
         }
         // mu_j = cbar_j L_j / sum (IMM.py:181-183): the sum over the group in filter order
         {
@@ -451,12 +501,13 @@ imm_lanes_kernel(const ImmArgs a, const int NM, const int aos)
     }
     if (want_post && a.T > 0)      // the last step's posterior estimate
         lanes_exchange<false, NX, G, CH, PH>(ctx, x, P, mu, cbar, true, a.x_out ? a.x_out + (a.T - 1) * N * n : nullptr,
-                                             a.P_out ? a.P_out + (a.T - 1) * N * nn : nullptr);
+                                             a.P_out ? a.P_out + (a.T - 1) * N * nn : nullptr, mmae);
     {
         const RecMap mx = rec_map(aos, N, NM * n), mP = rec_map(aos, N, NM * n * n), mm = rec_map(aos, N, NM);
         bool fin = all_finite<NX>(x) && all_finite<PL>(P) && (fabs(mu) <= 1.79769313486231570815e+308);
         if (writer) {
             a.mu[mm.at(bank, (int)j)] = mu;
+            if (EXT && a.ll0) a.ll0[mm.at(bank, (int)j)] = ll0v;
             FK_UNROLL for (int r = 0; r < NX; ++r) {
                 if (r < n) a.xs[mx.at(bank, (int)j * n + r)] = x[r];
                 FK_UNROLL for (int c = 0; c < NX; ++c)
@@ -480,21 +531,21 @@ imm_lanes_kernel(const ImmArgs a, const int NM, const int aos)
 
 using namespace fk;
 
-#if !defined(FK_NX) || !defined(FK_NZ) || !defined(FK_IL_G)
-#error "compile with -DFK_NX= -DFK_NZ= (the class: every dim_x <= FK_NX, dim_z <= FK_NZ) -DFK_IL_G=2|4|8|16 (lanes per bank)"
+#if !defined(FK_NX) || !defined(FK_NZ) || !defined(FK_IL_G) || !defined(FK_IL_EXT)
+#error "compile with -DFK_NX= -DFK_NZ= (the class: every dim_x <= FK_NX, dim_z <= FK_NZ) -DFK_IL_G=2|4|8|16 (lanes per bank) -DFK_IL_EXT=0|1"
 #endif
-#define FK_IL_CAT_(a, b, c, d) a##b##_##c##_g##d
-#define FK_IL_CAT(a, b, c, d) FK_IL_CAT_(a, b, c, d)
+#define FK_IL_CAT_(a, b, c, d, e) a##b##_##c##_g##d##_x##e
+#define FK_IL_CAT(a, b, c, d, e) FK_IL_CAT_(a, b, c, d, e)
 
-// launch_imm_lanes_<NX>_<NZ>_g<G>: banks of G/2 + 1 .. G filters of the class (one object per G: the (16, 8) kernels take minutes
-// to compile); returns 1 when the call is not one this file serves
-int FK_IL_CAT(launch_imm_lanes_, FK_NX, FK_NZ, FK_IL_G)(const ImmArgs &a, int n_models, int layout, hipStream_t s)
+// launch_imm_lanes_<NX>_<NZ>_g<G>_x<EXT>: banks of G/2 + 1 .. G filters of the class (one object per G and kind); x1 also serves MMAE,
+// missing measurements and the control input; returns 1 when the call is not one this file serves
+int FK_IL_CAT(launch_imm_lanes_, FK_NX, FK_NZ, FK_IL_G, FK_IL_EXT)(const ImmArgs &a, int n_models, int layout, hipStream_t s)
 {
-    if (a.n > FK_NX || a.m > FK_NZ || n_models < 2 || n_models > FK_IL_G) return 1;
-    if (a.mmae || a.mask || a.ll0 || a.nu > 0 || a.phase != FK_IMM_STEP) return 1;
+    if (a.n > FK_NX || a.m > FK_NZ || n_models < 2 || n_models > FK_IL_G || a.phase != FK_IMM_STEP) return 1;
+    if (!FK_IL_EXT && (a.mmae || a.mask || a.ll0 || a.nu > 0)) return 1;
     const int aos = layout == FK_LAYOUT_AOS ? 1 : 0;
     const long per_block = (BLOCK / 64) * (64 / FK_IL_G);
     const dim3 grid((unsigned)((a.cnt + per_block - 1) / per_block)), block(BLOCK);
-    hipLaunchKernelGGL((imm_lanes_kernel<FK_NX, FK_NZ, FK_IL_G>), grid, block, 0, s, a, n_models, aos);
+    hipLaunchKernelGGL((imm_lanes_kernel<FK_NX, FK_NZ, FK_IL_G, (FK_IL_EXT != 0)>), grid, block, 0, s, a, n_models, aos);
     return 0;
 }

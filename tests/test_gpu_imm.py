@@ -731,3 +731,60 @@ np.savez(sys.argv[1], **res)
         a, b = got["0"][k], got["1"][k]
         w = a.shape[-1] * (a.shape[-2] if k.endswith(("P_out", "Ps")) else 1)
         assert rel_err_rows(a.reshape(-1, w), b.reshape(-1, w)) < 1e-11, k
+
+
+@pytest.mark.parametrize("layout", ["soa", "aos"])
+@pytest.mark.parametrize("kind", ["imm", "mmae"])
+@pytest.mark.parametrize("n,m,nm,nu", [(9, 4, 8, 2), (6, 3, 5, 1), (4, 2, 4, 3), (7, 2, 12, 0), (8, 3, 3, 4)])
+def test_imm_lanes_kernel_missing_measurements_control_mmae_vs_oracle(n, m, nm, nu, kind, layout):
+    """the extended instantiation of the one-lane-per-filter kernel: every bank its own pattern of missing measurements
+    (update(None): IMM.py:171-179 + kalman_filter.py:511-520), a control input per bank and step with every filter's own B
+    (kalman_filter.py:472-475), IMM and MMAE (mmae.py:140-207) -- one launch, against the oracle bank by bank; the zero-residual
+    log-densities carried over a second call (ll0)"""
+    import torch
+    from filterpy_amd import _engine as E
+    from oracle import imm_oracle
+    N, T = 45, 9
+    xs0, Ps0, mu0, M, zs, Fs, Qs, Hs, Rs = _lanes_bank(n, m, nm, N, T, 900 + n + nm)
+    rs = np.random.RandomState(5 + n)
+    mask = (rs.rand(T, N) > 0.3).astype(np.uint8)
+    mask[0, ::3] = 0                                              # some banks start with update(None): S = 0, density floored
+    Bs = rs.randn(nm, n, nu) if nu else None
+    us = rs.randn(T, N, nu) if nu else None
+    mmae = kind == "mmae"
+
+    def call(xs_, Ps_, mu_, zs_, mask_, us_, ll0_):
+        Tn = len(zs_)
+        dxs = E.to_records(xs_.reshape(N, nm * n), layout, 0)
+        dPs = E.to_records(Ps_.reshape(N, nm * n * n), layout, 0)
+        dmu = E.to_records(mu_, layout, 0)
+        out = dict(x_out=E.alloc_records((Tn,), N, n, layout), P_out=E.alloc_records((Tn,), N, n * n, layout),
+                   mu_out=E.alloc_records((Tn,), N, nm, layout), likelihood_out=E.alloc_records((Tn,), N, nm, layout))
+        st = torch.zeros(N, dtype=torch.int32, device=dxs.device)
+        dll0 = E.to_records(ll0_, layout, 0)
+        kw = dict(nu=nu, B=E.dev(Bs), u=E.to_records(us_, layout, 1)) if nu else {}
+        E.imm_batch(n, m, nm, N, Tn, layout, E.dev(Fs), E.dev(Qs), E.dev(Hs), E.dev(Rs), None if mmae else E.dev(M),
+                    E.to_records(zs_, layout, 1), dxs, dPs, dmu, status=st, mmae=mmae,
+                    zmask=torch.as_tensor(np.ascontiguousarray(mask_), device=dxs.device), ll0=dll0, **kw, **out)
+        torch.cuda.synchronize()
+        assert not st.any()
+        shapes = dict(x_out=(n,), P_out=(n, n), mu_out=(nm,), likelihood_out=(nm,))
+        r = {k: E.from_records(v, layout, 1, shapes[k]) for k, v in out.items()}
+        r.update(xs=E.from_records(dxs, layout, 0, (nm, n)), Ps=E.from_records(dPs, layout, 0, (nm, n, n)),
+                 mu=E.from_records(dmu, layout, 0, (nm,)), ll0=E.from_records(dll0, layout, 0, (nm,)))
+        return r
+
+    T1 = 5
+    r1 = call(xs0, Ps0, mu0, zs[:T1], mask[:T1], None if us is None else us[:T1], np.full((N, nm), -np.inf))
+    r2 = call(r1["xs"], r1["Ps"], r1["mu"], zs[T1:], mask[T1:], None if us is None else us[T1:], r1["ll0"])
+    for trk in (0, 1, 2, 3, 7, 8, 31, 32, N - 1):
+        zl = [zs[t, trk] if mask[t, trk] else None for t in range(T)]
+        ul = None if us is None else us[:, trk]
+        if mmae:
+            x, P, mu, L = imm_oracle.mmae_batch(xs0[trk], Ps0[trk], mu0[trk], zl, Fs, Qs, Hs, Rs, Bs, ul)
+        else:
+            x, P, mu, _, _, L = imm_oracle.imm_batch(xs0[trk], Ps0[trk], mu0[trk], M, zl, Fs, Qs, Hs, Rs, Bs, ul)
+        for r, sl in ((r1, slice(0, T1)), (r2, slice(T1, T))):
+            assert rel_err_rows(r["x_out"][:, trk], x[sl]) < TOL and rel_err_rows(r["P_out"][:, trk], P[sl]) < TOL
+            assert np.allclose(r["mu_out"][:, trk], mu[sl], rtol=1e-9, atol=1e-14)
+            assert np.allclose(r["likelihood_out"][:, trk], L[sl], rtol=1e-9, atol=1e-300)
