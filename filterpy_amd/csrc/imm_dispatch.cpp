@@ -32,7 +32,7 @@ using namespace fk;
     FK_IL_DECL1(NX, NZ, 1)                                                                                             \
     static int launch_imm_lanes_##NX##_##NZ(const ImmArgs &a, int nm, int layout, hipStream_t s)                       \
     {                                                                                                                  \
-        const bool ext = a.mmae || a.mask || a.ll0 || a.nu > 0;                                                        \
+        const bool ext = a.mmae || a.mask || a.ll0 || a.nu > 0 || a.phase != FK_IMM_STEP;                              \
         return ext ? launch_imm_lanes_##NX##_##NZ##_x1(a, nm, layout, s) : launch_imm_lanes_##NX##_##NZ##_x0(a, nm, layout, s); \
     }
 FK_IL_DECL(4, 2)
@@ -99,11 +99,11 @@ extern "C" int fk_imm_batch_ex_f64(const fk_imm_desc *d, const double *F, const 
     // eight filters, dim_x <= 16, dim_z <= 8 -- on the rolled (9, 4) / (16, 8) class of its bank size (fk_dims_imm.def)
     const bool small = d->n <= 6 && d->m <= 3 && n_models <= 3;
     const int cls = (d->n <= 2 && d->m <= 1) ? 0 : (d->n <= 4 && d->m <= 2) ? 1 : 2;
-    // One lane per FILTER (imm_lanes.hip) for the multi-step call (IMM or MMAE, missing measurements and control input included) of every bank the register-resident small classes do
+    // One lane per FILTER (imm_lanes.hip) for every call (IMM or MMAE, missing measurements, control input and the single-phase calls included) of every bank the register-resident small classes do
     // not hold, dim_x <= 9 / dim_z <= 4: 2..16 filters.  FK_IMM_LANES=0: the one-lane-per-bank kernels as before (A/B);
     // =2: the small classes too.
     static const int lanes_mode = [] { const char *v = getenv("FK_IMM_LANES"); return v ? atoi(v) : 1; }();
-    const bool lanes = lanes_mode > 0 && (lanes_mode > 1 || !small) && d->n <= 9 && d->m <= 4 && d->phase == FK_IMM_STEP;
+    const bool lanes = lanes_mode > 0 && (lanes_mode > 1 || !small) && d->n <= 9 && d->m <= 4;
     auto one = [&](const ImmArgs &b, hipStream_t s) -> int {
         if (lanes) {
             // the smallest class that holds the filters: (4, 2), (6, 3), (9, 4)

@@ -18,9 +18,9 @@
 // (9,4) track costs the one-lane kernels -- for eight banks at once.
 //
 // n_models is a run-time value (2 .. G, idle lanes of a group duplicate the last filter and store nothing): four kernels per
-// class and kind (plain; extended: MMAE, missing measurements, control input).  Exact arithmetic per element as in fk_imm.hpp (same
-// operations, same order); parity against the oracle in tests/test_gpu_imm.py.  Not served here (imm_kernels.hip keeps them): the
-// single-phase calls (one step: launch-bound either way), the register-resident small banks, and the (16, 8) class.
+// class and kind (plain; extended: MMAE, missing measurements, control input, the single-phase calls).  Exact arithmetic per
+// element as in fk_imm.hpp (same operations, same order); parity against the oracle in tests/test_gpu_imm.py.  Not served here (imm_kernels.hip keeps them): the
+// register-resident small banks and the (16, 8) class.
 #include <type_traits>
 
 #include "fk_device.hpp"
@@ -393,22 +393,6 @@ imm_lanes_kernel(const ImmArgs a, const int NM, const int aos)
     }
     for (long t = 0; t < a.T; ++t) {
         // posterior estimate of step t-1 and mixing for step t from one publication
-        if (mmae) {
-            cbar = mu;                                          // p_i *= likelihood_i (mmae.py:186-187): no mixing
-            if (t > 0 && want_post)
-                lanes_exchange<false, NX, G, CH, PH>(ctx, x, P, mu, cbar, true, a.x_out ? a.x_out + (t - 1) * N * n : nullptr,
-                                                     a.P_out ? a.P_out + (t - 1) * N * nn : nullptr, true);
-        } else {
-            lanes_exchange<true, NX, G, CH, PH>(ctx, x, P, mu, cbar, t > 0 && want_post, a.x_out ? a.x_out + (t - 1) * N * n : nullptr,
-                                                a.P_out ? a.P_out + (t - 1) * N * nn : nullptr);
-        }
-        // (the model block's offset is made opaque once per step: F, Q, H, R are the same every step, and hoisted out of the time
-        //  loop they would sit in 88 .. 400 registers across it)
-        {
-            unsigned moff = jm * (unsigned)LM::SIZE;
-            asm volatile("" : "+v"(moff));
-            mod.s = smem + moff;
-        }
         double z[NZ];
         FK_UNROLL for (int r = 0; r < NZ; ++r) z[r] = zc[r];
         {
@@ -420,6 +404,37 @@ imm_lanes_kernel(const ImmArgs a, const int NM, const int aos)
                 zc[r] = (r < m) ? zv : 0.0;
             }
         }
+        // (the single-phase calls of the class API, EXT only: FK_IMM_UPDATE skips mixing and predict -- cbar = mu . M from the mode
+        //  probabilities as they stand, IMM.py:244 --, FK_IMM_PREDICT leaves before the update; T = 1)
+        const int phase = EXT ? a.phase : (int)FK_IMM_STEP;
+        if (phase == FK_IMM_UPDATE) {
+            if (mmae) {
+                cbar = mu;
+            } else {
+                ml_wave_fence();
+                wMu[lane] = mu;
+                ml_wave_fence();
+                double acc = 0.0;
+                for (int i = 0; i < NM; ++i) acc = fma(wMu[g0 + i], sM[i * NM + (int)jm], acc);
+                cbar = acc;
+            }
+        } else {
+        if (mmae) {
+                cbar = mu;                                          // p_i *= likelihood_i (mmae.py:186-187): no mixing
+                if (t > 0 && want_post)
+                    lanes_exchange<false, NX, G, CH, PH>(ctx, x, P, mu, cbar, true, a.x_out ? a.x_out + (t - 1) * N * n : nullptr,
+                                                         a.P_out ? a.P_out + (t - 1) * N * nn : nullptr, true);
+            } else {
+                lanes_exchange<true, NX, G, CH, PH>(ctx, x, P, mu, cbar, t > 0 && want_post, a.x_out ? a.x_out + (t - 1) * N * n : nullptr,
+                                                    a.P_out ? a.P_out + (t - 1) * N * nn : nullptr);
+            }
+            // (the model block's offset is made opaque once per step: F, Q, H, R are the same every step, and hoisted out of the time
+            //  loop they would sit in 88 .. 400 registers across it)
+            {
+                unsigned moff = jm * (unsigned)LM::SIZE;
+                asm volatile("" : "+v"(moff));
+                mod.s = smem + moff;
+            }
         if constexpr (PH == 1 && NX >= 7 && FK_IL_STREAM_PREDICT) {
             ml_wave_fence();
             lanes_predict<NX>(x, P, mod, wP + lane);
@@ -446,6 +461,8 @@ imm_lanes_kernel(const ImmArgs a, const int NM, const int aos)
         if (want_prior)
             lanes_exchange<false, NX, G, CH, PH>(ctx, x, P, mu, cbar, true, a.xp_out ? a.xp_out + t * N * n : nullptr,
                                                  a.Pp_out ? a.Pp_out + t * N * nn : nullptr);
+        }      // phase != FK_IMM_UPDATE
+        if (phase == FK_IMM_PREDICT) break;
         // this lane's filter: update, likelihood floored at DBL_MIN (kalman_filter.py:1213-1226; fk_imm.hpp, imm_update)
         double lj;
         bool has_z = true;
@@ -499,7 +516,7 @@ imm_lanes_kernel(const ImmArgs a, const int NM, const int aos)
             if (a.L_out) (a.L_out + t * N * NM)[oM.at(bank, (int)j)] = lj;
         }
     }
-    if (want_post && a.T > 0)      // the last step's posterior estimate
+    if (want_post && a.T > 0 && !(EXT && a.phase == FK_IMM_PREDICT))      // the last step's posterior estimate
         lanes_exchange<false, NX, G, CH, PH>(ctx, x, P, mu, cbar, true, a.x_out ? a.x_out + (a.T - 1) * N * n : nullptr,
                                              a.P_out ? a.P_out + (a.T - 1) * N * nn : nullptr, mmae);
     {
@@ -541,8 +558,8 @@ using namespace fk;
 // missing measurements and the control input; returns 1 when the call is not one this file serves
 int FK_IL_CAT(launch_imm_lanes_, FK_NX, FK_NZ, FK_IL_G, FK_IL_EXT)(const ImmArgs &a, int n_models, int layout, hipStream_t s)
 {
-    if (a.n > FK_NX || a.m > FK_NZ || n_models < 2 || n_models > FK_IL_G || a.phase != FK_IMM_STEP) return 1;
-    if (!FK_IL_EXT && (a.mmae || a.mask || a.ll0 || a.nu > 0)) return 1;
+    if (a.n > FK_NX || a.m > FK_NZ || n_models < 2 || n_models > FK_IL_G) return 1;
+    if (!FK_IL_EXT && (a.mmae || a.mask || a.ll0 || a.nu > 0 || a.phase != FK_IMM_STEP)) return 1;
     const int aos = layout == FK_LAYOUT_AOS ? 1 : 0;
     const long per_block = (BLOCK / 64) * (64 / FK_IL_G);
     const dim3 grid((unsigned)((a.cnt + per_block - 1) / per_block)), block(BLOCK);

@@ -1,9 +1,9 @@
 #!/bin/bash
-# Round 6, lease zf: the extended one-lane-per-filter IMM kernel (MMAE, missing measurements, control input): the IMM suite
+# Round 6, lease zg: the extended one-lane-per-filter IMM kernel (MMAE, missing measurements, control input): the IMM suite
 ulimit -c 0
 set -x
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r06zf
+O=$R/gpurun_out/r06zg
 mkdir -p $O
 export TMPDIR=/tmp
 cd $R
