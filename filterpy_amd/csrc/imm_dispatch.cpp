@@ -38,6 +38,7 @@ using namespace fk;
 FK_IL_DECL(4, 2)
 FK_IL_DECL(6, 3)
 FK_IL_DECL(9, 4)
+FK_IL_DECL(16, 8)
 #undef FK_IL_DECL
 #undef FK_IL_DECL1
 
@@ -103,12 +104,14 @@ extern "C" int fk_imm_batch_ex_f64(const fk_imm_desc *d, const double *F, const 
     // not hold, dim_x <= 9 / dim_z <= 4: 2..16 filters.  FK_IMM_LANES=0: the one-lane-per-bank kernels as before (A/B);
     // =2: the small classes too.
     static const int lanes_mode = [] { const char *v = getenv("FK_IMM_LANES"); return v ? atoi(v) : 1; }();
-    const bool lanes = lanes_mode > 0 && (lanes_mode > 1 || !small) && d->n <= 9 && d->m <= 4;
+    static const int lanes16 = [] { const char *v = getenv("FK_IMM_LANES16"); return v ? atoi(v) : 1; }();
+    const bool lanes = lanes_mode > 0 && (lanes_mode > 1 || !small) && ((d->n <= 9 && d->m <= 4) || lanes16);
     auto one = [&](const ImmArgs &b, hipStream_t s) -> int {
         if (lanes) {
             // the smallest class that holds the filters: (4, 2), (6, 3), (9, 4)
             const int rc = (b.n <= 4 && b.m <= 2) ? launch_imm_lanes_4_2(b, n_models, layout, s)
-                         : (b.n <= 6 && b.m <= 3) ? launch_imm_lanes_6_3(b, n_models, layout, s) : launch_imm_lanes_9_4(b, n_models, layout, s);
+                         : (b.n <= 6 && b.m <= 3) ? launch_imm_lanes_6_3(b, n_models, layout, s)
+                         : (b.n <= 9 && b.m <= 4) ? launch_imm_lanes_9_4(b, n_models, layout, s) : launch_imm_lanes_16_8(b, n_models, layout, s);
             if (rc == 0) return check_launch("imm_lanes_kernel");
         }
         if (small) {

@@ -1,0 +1,19 @@
+#!/bin/bash
+# Round 6, lease zi: the (16,8) class on the one-lane-per-filter kernel (first try: scratch-resident), IMM suite + the IMM rows of bench_configs
+ulimit -c 0
+set -x
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/r06zi
+mkdir -p $O
+export TMPDIR=/tmp
+cd $R
+timeout 1500 python -m pytest tests/test_gpu_imm.py -m gpu -q -p no:cacheprovider > $O/pytest_imm.log 2>&1; echo "pytest imm rc=$?"; tail -25 $O/pytest_imm.log
+for v in 1 0; do
+FK_IMM_LANES16=$v timeout 600 python tools/bench_configs.py --configs r --layouts soa,aos 2>/dev/null | python -c "
+import sys, json
+for l in sys.stdin:
+    if l.startswith('{'):
+        d = json.loads(l)
+        if '16,8' in d['kernel']: print('lanes16=$v', d['kernel'], round(d['ms'], 3))
+"
+done
