@@ -38,9 +38,33 @@ using namespace fk;
 FK_IL_DECL(4, 2)
 FK_IL_DECL(6, 3)
 FK_IL_DECL(9, 4)
-FK_IL_DECL(16, 8)
 #undef FK_IL_DECL
 #undef FK_IL_DECL1
+// imm_quad.hip: four lanes per filter -- the classes (12, 4) and (16, 8), every bank size 2..16
+#define FK_IQ_DECL1(NX, NZ, X)                                                                                         \
+    int launch_imm_quad_##NX##_##NZ##_g2_x##X(const ImmArgs &, int, int, hipStream_t);                                  \
+    int launch_imm_quad_##NX##_##NZ##_g4_x##X(const ImmArgs &, int, int, hipStream_t);                                  \
+    int launch_imm_quad_##NX##_##NZ##_g8_x##X(const ImmArgs &, int, int, hipStream_t);                                  \
+    int launch_imm_quad_##NX##_##NZ##_g16_x##X(const ImmArgs &, int, int, hipStream_t);                                 \
+    static int launch_imm_quad_##NX##_##NZ##_x##X(const ImmArgs &a, int nm, int layout, hipStream_t s)                  \
+    {                                                                                                                  \
+        return nm <= 2 ? launch_imm_quad_##NX##_##NZ##_g2_x##X(a, nm, layout, s)                                       \
+             : nm <= 4 ? launch_imm_quad_##NX##_##NZ##_g4_x##X(a, nm, layout, s)                                       \
+             : nm <= 8 ? launch_imm_quad_##NX##_##NZ##_g8_x##X(a, nm, layout, s)                                       \
+                       : launch_imm_quad_##NX##_##NZ##_g16_x##X(a, nm, layout, s);                                     \
+    }
+#define FK_IQ_DECL(NX, NZ)                                                                                             \
+    FK_IQ_DECL1(NX, NZ, 0)                                                                                             \
+    FK_IQ_DECL1(NX, NZ, 1)                                                                                             \
+    static int launch_imm_quad_##NX##_##NZ(const ImmArgs &a, int nm, int layout, hipStream_t s)                        \
+    {                                                                                                                  \
+        const bool ext = a.mmae || a.mask || a.ll0 || a.nu > 0 || a.phase != FK_IMM_STEP;                              \
+        return ext ? launch_imm_quad_##NX##_##NZ##_x1(a, nm, layout, s) : launch_imm_quad_##NX##_##NZ##_x0(a, nm, layout, s); \
+    }
+FK_IQ_DECL(12, 4)
+FK_IQ_DECL(16, 8)
+#undef FK_IQ_DECL
+#undef FK_IQ_DECL1
 
 static int fail(int code, const char *msg)
 {
@@ -104,15 +128,21 @@ extern "C" int fk_imm_batch_ex_f64(const fk_imm_desc *d, const double *F, const 
     // not hold, dim_x <= 9 / dim_z <= 4: 2..16 filters.  FK_IMM_LANES=0: the one-lane-per-bank kernels as before (A/B);
     // =2: the small classes too.
     static const int lanes_mode = [] { const char *v = getenv("FK_IMM_LANES"); return v ? atoi(v) : 1; }();
-    static const int lanes16 = [] { const char *v = getenv("FK_IMM_LANES16"); return v ? atoi(v) : 1; }();
-    const bool lanes = lanes_mode > 0 && (lanes_mode > 1 || !small) && ((d->n <= 9 && d->m <= 4) || lanes16);
+    // Above that -- dim_x 10..16 / dim_z 5..8 -- FOUR lanes per filter (imm_quad.hip), classes (12, 4) and (16, 8); FK_IMM_QUAD=0: the
+    // rolled general kernel as before (A/B).
+    static const int quad_mode = [] { const char *v = getenv("FK_IMM_QUAD"); return v ? atoi(v) : 1; }();
+    const bool quad = quad_mode > 0 && !(d->n <= 9 && d->m <= 4);
+    const bool lanes = lanes_mode > 0 && (lanes_mode > 1 || !small) && d->n <= 9 && d->m <= 4;
     auto one = [&](const ImmArgs &b, hipStream_t s) -> int {
         if (lanes) {
             // the smallest class that holds the filters: (4, 2), (6, 3), (9, 4)
             const int rc = (b.n <= 4 && b.m <= 2) ? launch_imm_lanes_4_2(b, n_models, layout, s)
-                         : (b.n <= 6 && b.m <= 3) ? launch_imm_lanes_6_3(b, n_models, layout, s)
-                         : (b.n <= 9 && b.m <= 4) ? launch_imm_lanes_9_4(b, n_models, layout, s) : launch_imm_lanes_16_8(b, n_models, layout, s);
+                         : (b.n <= 6 && b.m <= 3) ? launch_imm_lanes_6_3(b, n_models, layout, s) : launch_imm_lanes_9_4(b, n_models, layout, s);
             if (rc == 0) return check_launch("imm_lanes_kernel");
+        }
+        if (quad) {
+            const int rc = (b.n <= 12 && b.m <= 4) ? launch_imm_quad_12_4(b, n_models, layout, s) : launch_imm_quad_16_8(b, n_models, layout, s);
+            if (rc == 0) return check_launch("imm_quad_kernel");
         }
         if (small) {
             if (n_models == 2) {
@@ -165,6 +195,6 @@ extern "C" int fk_imm_batch_ex_f64(const fk_imm_desc *d, const double *F, const 
     static const int small_waves[3][2] = {{4, 3}, {2, 2}, {1, 1}};            // [class][n_models - 2]
     // (the lanes kernel: a wave holds 64 / G banks, G = the bank size rounded up to a power of two)
     const int lanes_g = n_models <= 2 ? 2 : n_models <= 4 ? 4 : n_models <= 8 ? 8 : 16;
-    const long slots = lanes ? 1024L / lanes_g : 1024L * ((small && mask >= 0) ? small_waves[cls][n_models - 2] : 1);
+    const long slots = quad ? 256L / lanes_g : lanes ? 1024L / lanes_g : 1024L * ((small && mask >= 0) ? small_waves[cls][n_models - 2] : 1);
     return imm_chunked_call(a, d->n, d->m, n_models, slots, one, s);
 }
