@@ -626,6 +626,8 @@ def test_imm_banks_above_9_4_vs_oracle(n, m, nm, layout):
 
 # ---- round 6: one lane per filter (csrc/imm_lanes.hip): every class x every group width, ragged banks, output subsets
 LANES_CASES = [(4, 2, 4), (3, 2, 7), (4, 1, 12), (6, 3, 4), (5, 3, 6), (6, 2, 16), (9, 4, 2), (7, 2, 3), (9, 4, 8), (8, 3, 5), (9, 2, 13), (7, 4, 16)]
+# ---- four lanes per filter (csrc/imm_quad.hip): the classes (12, 4) and (16, 8), every group width, padded and exact dims
+QUAD_CASES = [(10, 3, 2), (12, 4, 4), (11, 2, 7), (12, 3, 16), (16, 8, 2), (13, 5, 3), (14, 6, 8), (15, 7, 12), (16, 4, 16), (9, 5, 2)]
 
 
 def _lanes_bank(n, m, nm, N, T, seed):
@@ -645,9 +647,9 @@ def _lanes_bank(n, m, nm, N, T, seed):
 
 
 @pytest.mark.parametrize("layout", ["soa", "aos"])
-@pytest.mark.parametrize("n,m,nm", LANES_CASES)
+@pytest.mark.parametrize("n,m,nm", LANES_CASES + QUAD_CASES)
 def test_imm_lanes_kernel_vs_oracle(n, m, nm, layout):
-    """banks the one-lane-per-filter kernel serves (IMM.py:160-249), N not a multiple of the banks of a wave or a block, every
+    """banks the one-lane-per-filter kernel (and, above (9,4), the four-lanes-per-filter kernel) serves (IMM.py:160-249), N not a multiple of the banks of a wave or a block, every
     bank checked at its ends: per-step estimate, prior, mode probabilities, likelihoods and the bank's final state"""
     from oracle import imm_oracle
     N, T = 203, 7
@@ -670,13 +672,14 @@ def test_imm_lanes_kernel_vs_oracle(n, m, nm, layout):
 
 
 @pytest.mark.parametrize("layout", ["soa", "aos"])
+@pytest.mark.parametrize("dims", [(8, 3, 6), (14, 6, 5)])
 @pytest.mark.parametrize("outs", [("x_out",), ("P_out", "mu_out"), ("x_prior_out", "P_prior_out"), ("likelihood_out",), ()])
-def test_imm_lanes_kernel_output_subsets(outs, layout):
+def test_imm_lanes_kernel_output_subsets(outs, layout, dims):
     """any subset of the per-step outputs (the pointers are tested at run time): what is asked for equals the all-outputs call
     bit for bit, and so does the final state of the bank"""
     import torch
     from filterpy_amd import _engine as E
-    n, m, nm, N, T = 8, 3, 6, 77, 5
+    (n, m, nm), N, T = dims, 77, 5
     b = _lanes_bank(n, m, nm, N, T, 77)
     xs0, Ps0, mu0, M, zs, Fs, Qs, Hs, Rs = b
     full = run_imm(*b, layout)
@@ -699,8 +702,8 @@ def test_imm_lanes_kernel_output_subsets(outs, layout):
 
 
 def test_imm_lanes_kernel_against_the_one_lane_per_bank_kernels():
-    """FK_IMM_LANES=0 (read once per process: two subprocesses) runs the same banks on imm_kernels.hip: every record of both
-    within 1e-11 of each other (normwise per bank and step)"""
+    """FK_IMM_LANES=0 / FK_IMM_QUAD=0 (read once per process: two subprocesses) runs the same banks on imm_kernels.hip: every record
+    of both within 1e-11 of each other (normwise per bank and step)"""
     import os
     import subprocess
     import sys
@@ -710,7 +713,7 @@ import sys, numpy as np
 sys.path.insert(0, "tests")
 import test_gpu_imm as t
 res = {}
-for (n, m, nm) in [(9, 4, 8), (6, 3, 5), (4, 2, 4)]:
+for (n, m, nm) in [(9, 4, 8), (6, 3, 5), (4, 2, 4), (12, 5, 3), (16, 8, 2)]:
     b = t._lanes_bank(n, m, nm, 150, 6, 9 + nm)
     for layout in ("soa", "aos"):
         r = t.run_imm(*b, layout)
@@ -723,10 +726,10 @@ np.savez(sys.argv[1], **res)
     with tempfile.TemporaryDirectory() as td:
         for mode in ("0", "1"):
             f = os.path.join(td, f"m{mode}.npz")
-            env = dict(os.environ, FK_IMM_LANES=mode, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+            env = dict(os.environ, FK_IMM_LANES=mode, FK_IMM_QUAD=mode, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
             subprocess.run([sys.executable, "-c", code, f], check=True, cwd=root, env=env, timeout=600)
             got[mode] = dict(np.load(f))
-    assert got["0"].keys() == got["1"].keys() and len(got["0"]) == 54
+    assert got["0"].keys() == got["1"].keys() and len(got["0"]) == 90
     for k in got["0"]:
         a, b = got["0"][k], got["1"][k]
         w = a.shape[-1] * (a.shape[-2] if k.endswith(("P_out", "Ps")) else 1)
@@ -735,7 +738,8 @@ np.savez(sys.argv[1], **res)
 
 @pytest.mark.parametrize("layout", ["soa", "aos"])
 @pytest.mark.parametrize("kind", ["imm", "mmae"])
-@pytest.mark.parametrize("n,m,nm,nu", [(9, 4, 8, 2), (6, 3, 5, 1), (4, 2, 4, 3), (7, 2, 12, 0), (8, 3, 3, 4)])
+@pytest.mark.parametrize("n,m,nm,nu", [(9, 4, 8, 2), (6, 3, 5, 1), (4, 2, 4, 3), (7, 2, 12, 0), (8, 3, 3, 4),
+                                       (12, 4, 3, 2), (16, 8, 2, 1), (13, 5, 9, 0), (10, 6, 6, 4)])
 def test_imm_lanes_kernel_missing_measurements_control_mmae_vs_oracle(n, m, nm, nu, kind, layout):
     """the extended instantiation of the one-lane-per-filter kernel: every bank its own pattern of missing measurements
     (update(None): IMM.py:171-179 + kalman_filter.py:511-520), a control input per bank and step with every filter's own B
