@@ -120,19 +120,15 @@ extern "C" int fk_imm_batch_ex_f64(const fk_imm_desc *d, const double *F, const 
     if (zmask || ll0 || nu > 0) mask = -1;               // ... the missing-measurement bookkeeping and the control input
     a.i0 = 0; a.cnt = d->N; a.status_or = 0;
     const int layout = d->layout, n_models = d->n_models;
-    // register-resident instantiations for the small banks (2 / 3 filters, dim_x <= 6, dim_z <= 3); everything else -- up to
-    // eight filters, dim_x <= 16, dim_z <= 8 -- on the rolled (9, 4) / (16, 8) class of its bank size (fk_dims_imm.def)
+    // register-resident instantiations for the small banks (2 / 3 filters, dim_x <= 6, dim_z <= 3: imm_kernels.hip, fk_dims_imm.def)
     const bool small = d->n <= 6 && d->m <= 3 && n_models <= 3;
     const int cls = (d->n <= 2 && d->m <= 1) ? 0 : (d->n <= 4 && d->m <= 2) ? 1 : 2;
-    // One lane per FILTER (imm_lanes.hip) for every call (IMM or MMAE, missing measurements, control input and the single-phase calls included) of every bank the register-resident small classes do
-    // not hold, dim_x <= 9 / dim_z <= 4: 2..16 filters.  FK_IMM_LANES=0: the one-lane-per-bank kernels as before (A/B);
-    // =2: the small classes too.
+    // Every other bank, 2..16 filters, IMM or MMAE, missing measurements, control input and the single-phase calls included: one lane per
+    // FILTER up to dim_x 9 / dim_z 4 (imm_lanes.hip: classes (4,2), (6,3), (9,4)), FOUR lanes per filter above (imm_quad.hip: classes
+    // (12,4), (16,8)).  FK_IMM_LANES=2: the small banks on imm_lanes.hip too (the A/B of tests/test_gpu_imm.py).
     static const int lanes_mode = [] { const char *v = getenv("FK_IMM_LANES"); return v ? atoi(v) : 1; }();
-    // Above that -- dim_x 10..16 / dim_z 5..8 -- FOUR lanes per filter (imm_quad.hip), classes (12, 4) and (16, 8); FK_IMM_QUAD=0: the
-    // rolled general kernel as before (A/B).
-    static const int quad_mode = [] { const char *v = getenv("FK_IMM_QUAD"); return v ? atoi(v) : 1; }();
-    const bool quad = quad_mode > 0 && !(d->n <= 9 && d->m <= 4);
-    const bool lanes = lanes_mode > 0 && (lanes_mode > 1 || !small) && d->n <= 9 && d->m <= 4;
+    const bool quad = !(d->n <= 9 && d->m <= 4);
+    const bool lanes = (lanes_mode > 1 || !small) && !quad;
     auto one = [&](const ImmArgs &b, hipStream_t s) -> int {
         if (lanes) {
             // the smallest class that holds the filters: (4, 2), (6, 3), (9, 4)
@@ -154,37 +150,8 @@ extern "C" int fk_imm_batch_ex_f64(const fk_imm_desc *d, const double *F, const 
                 else if (cls == 1) launch_imm_4_2_3(b, layout, mask, s);
                 else launch_imm_6_3_3(b, layout, mask, s);
             }
-        } else if (n_models > 8) {                        // banks of 9..16 filters: the rolled general kernel, every size
-            switch (n_models) {
-            case 9: launch_imm_16_8_9(b, layout, mask, s); break;
-            case 10: launch_imm_16_8_10(b, layout, mask, s); break;
-            case 11: launch_imm_16_8_11(b, layout, mask, s); break;
-            case 12: launch_imm_16_8_12(b, layout, mask, s); break;
-            case 13: launch_imm_16_8_13(b, layout, mask, s); break;
-            case 14: launch_imm_16_8_14(b, layout, mask, s); break;
-            case 15: launch_imm_16_8_15(b, layout, mask, s); break;
-            default: launch_imm_16_8_16(b, layout, mask, s); break;
-            }
-        } else if (b.n > 9 || b.m > 4) {                  // the rolled class (16, 8), round 4
-            switch (n_models) {
-            case 2: launch_imm_16_8_2(b, layout, mask, s); break;
-            case 3: launch_imm_16_8_3(b, layout, mask, s); break;
-            case 4: launch_imm_16_8_4(b, layout, mask, s); break;
-            case 5: launch_imm_16_8_5(b, layout, mask, s); break;
-            case 6: launch_imm_16_8_6(b, layout, mask, s); break;
-            case 7: launch_imm_16_8_7(b, layout, mask, s); break;
-            default: launch_imm_16_8_8(b, layout, mask, s); break;
-            }
         } else {
-            switch (n_models) {
-            case 2: launch_imm_9_4_2(b, layout, mask, s); break;
-            case 3: launch_imm_9_4_3(b, layout, mask, s); break;
-            case 4: launch_imm_9_4_4(b, layout, mask, s); break;
-            case 5: launch_imm_9_4_5(b, layout, mask, s); break;
-            case 6: launch_imm_9_4_6(b, layout, mask, s); break;
-            case 7: launch_imm_9_4_7(b, layout, mask, s); break;
-            default: launch_imm_9_4_8(b, layout, mask, s); break;
-            }
+            return fail(FK_ERR_UNSUPPORTED, "IMM: no kernel holds this bank");      // (not reached: the three families cover dim_x <= 16, dim_z <= 8, 2..16 filters)
         }
         return check_launch("imm_kernel");
     };

@@ -585,7 +585,7 @@ def test_control_input(kind, layout):
 @pytest.mark.parametrize("n,m,nm", [(10, 3, 2), (12, 5, 3), (16, 8, 2), (11, 2, 8), (9, 6, 4)])
 def test_imm_banks_above_9_4_vs_oracle(n, m, nm, layout):
     """VERDICT r3 missing 3: IMMEstimator takes filters of any size (IMM.py:14-120); the kernels stopped at dim_x 9 / dim_z 4.
-    The rolled class (16, 8) (fk_dims_imm.def) against the oracle: independent tracks, a ragged last workgroup, all outputs,
+    The classes (12, 4) / (16, 8) (csrc/imm_quad.hip; rounds 4-6: a rolled one-lane-per-bank class) against the oracle: independent tracks, a ragged last workgroup, all outputs,
     and the class API on the same bank."""
     from filterpy_amd.kalman import IMMEstimator, KalmanFilter
     from oracle import imm_oracle
@@ -702,8 +702,11 @@ def test_imm_lanes_kernel_output_subsets(outs, layout, dims):
 
 
 def test_imm_lanes_kernel_against_the_one_lane_per_bank_kernels():
-    """FK_IMM_LANES=0 / FK_IMM_QUAD=0 (read once per process: two subprocesses) runs the same banks on imm_kernels.hip: every record
-    of both within 1e-11 of each other (normwise per bank and step)"""
+    """The small banks (2 / 3 filters, dim_x <= 6, dim_z <= 3) run on the register-resident one-lane-per-BANK kernels of
+    imm_kernels.hip by default and on imm_lanes.hip with FK_IMM_LANES=2 (read once per process: two subprocesses): two
+    independent implementations of IMM.py:160-249, every record of both within 1e-11 of each other (normwise per bank and step).
+    (Rounds 3-6 also built one-lane-per-bank kernels for the classes (9,4) and (16,8); they were compared with imm_lanes.hip /
+    imm_quad.hip here -- profiles/r06/imm_lanes/ -- before they were removed from the build.)"""
     import os
     import subprocess
     import sys
@@ -713,7 +716,7 @@ import sys, numpy as np
 sys.path.insert(0, "tests")
 import test_gpu_imm as t
 res = {}
-for (n, m, nm) in [(9, 4, 8), (6, 3, 5), (4, 2, 4), (12, 5, 3), (16, 8, 2)]:
+for (n, m, nm) in [(6, 3, 3), (4, 2, 2), (2, 1, 3), (5, 2, 2)]:
     b = t._lanes_bank(n, m, nm, 150, 6, 9 + nm)
     for layout in ("soa", "aos"):
         r = t.run_imm(*b, layout)
@@ -724,14 +727,14 @@ np.savez(sys.argv[1], **res)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     got = {}
     with tempfile.TemporaryDirectory() as td:
-        for mode in ("0", "1"):
+        for mode in ("1", "2"):
             f = os.path.join(td, f"m{mode}.npz")
-            env = dict(os.environ, FK_IMM_LANES=mode, FK_IMM_QUAD=mode, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+            env = dict(os.environ, FK_IMM_LANES=mode, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
             subprocess.run([sys.executable, "-c", code, f], check=True, cwd=root, env=env, timeout=600)
             got[mode] = dict(np.load(f))
-    assert got["0"].keys() == got["1"].keys() and len(got["0"]) == 90
-    for k in got["0"]:
-        a, b = got["0"][k], got["1"][k]
+    assert got["1"].keys() == got["2"].keys() and len(got["1"]) == 72
+    for k in got["1"]:
+        a, b = got["1"][k], got["2"][k]
         w = a.shape[-1] * (a.shape[-2] if k.endswith(("P_out", "Ps")) else 1)
         assert rel_err_rows(a.reshape(-1, w), b.reshape(-1, w)) < 1e-11, k
 
