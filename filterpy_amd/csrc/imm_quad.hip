@@ -41,6 +41,38 @@ __device__ __forceinline__ RecMap rec_map(bool aos, long N, int nelem)
     return aos ? RecMap{(unsigned)nelem, 1u} : RecMap{1u, (unsigned)N};
 }
 
+// A filter's model block in LDS with PADDED pitches.  The lanes of a wave read it through per-lane addresses -- the quads of a wave
+// belong to different filters, and the lane's own rows of F, Q, H, R start at sub * R rows --: with LdsModel's dense layout (row pitch
+// NX, 704 doubles per (16,8) block) the blocks of two filters and the row groups of the four sub indices all start on the SAME LDS
+// bank, an eight-way conflict on every per-lane read.  Row pitch NX + 2 (R's: NZ + 2) spreads the sub indices over the banks (16,8):
+// 0 / 16 / 32 / 48, (12,4): 0 / 20 / 40 / 60), a block size = 2 (mod 32) doubles shifts every filter by 4 banks.
+template <int NX, int NZ>
+struct QuadModel {
+    static constexpr int PX = NX + 2, PZ = NZ + 2;
+    static constexpr int OFF_F = 0, OFF_Q = NX * PX, OFF_H = 2 * NX * PX, OFF_R = 2 * NX * PX + NZ * PX;
+    static constexpr int SIZE0 = OFF_R + NZ * PZ, SIZE = SIZE0 + ((2 - SIZE0 % 32) + 32) % 32;
+    const double *s;
+    template <int LEN>
+    __device__ __forceinline__ void row(int off, double (&r)[LEN]) const
+    {
+        FK_UNROLL for (int j = 0; j < LEN; ++j) r[j] = s[off + j];
+    }
+    __device__ __forceinline__ void rowF(int i, double (&r)[NX]) const { row<NX>(OFF_F + i * PX, r); }
+    __device__ __forceinline__ void rowQ(int i, double (&r)[NX]) const { row<NX>(OFF_Q + i * PX, r); }
+    __device__ __forceinline__ void rowH(int i, double (&r)[NX]) const { row<NX>(OFF_H + i * PX, r); }
+    __device__ __forceinline__ void rowR(int i, double (&r)[NZ]) const { row<NZ>(OFF_R + i * PZ, r); }
+};
+
+// cooperative fill of one padded ROWS x COLS matrix (row pitch PITCH) from an r x c matrix in global memory; caller synchronises
+template <int ROWS, int COLS, int PITCH>
+__device__ __forceinline__ void quad_fill(double *dst, const double *__restrict__ src, int r, int c, double diag_pad, unsigned tid)
+{
+    for (unsigned k = tid; k < (unsigned)(ROWS * COLS); k += BLOCK) {
+        const int a = (int)k / COLS, b = (int)k % COLS;
+        dst[a * PITCH + b] = (a < r && b < c) ? src[a * c + b] : ((a == b) ? diag_pad : 0.0);
+    }
+}
+
 // the value lane (k / R) of the quad holds (k: a compile-time constant after unrolling)
 #define FK_Q_OWNER(k, R, v)                                                                                            \
     (((k) / (R)) == 0 ? quad_bcast<0>(v) : ((k) / (R)) == 1 ? quad_bcast<1>(v) : ((k) / (R)) == 2 ? quad_bcast<2>(v) : quad_bcast<3>(v))
@@ -80,11 +112,11 @@ __device__ __forceinline__ void quad_predict(double (&x)[NX], double (&P)[NX / 4
     constexpr int R = NX / 4;
     {
         const LM M = quad_fresh(M0);
-        const double *fo = M.s + LM::OFF_F + sub * (unsigned)(R * NX);      // the lane's own rows of F
+        const double *fo = M.s + LM::OFF_F + sub * (unsigned)(R * LM::PX);      // the lane's own rows of F
         double xo[R];
         FK_UNROLL for (int r = 0; r < R; ++r) {
-            double acc = fo[r * NX] * x[0];
-            FK_UNROLL for (int k = 1; k < NX; ++k) acc = fma(fo[r * NX + k], x[k], acc);
+            double acc = fo[r * LM::PX] * x[0];
+            FK_UNROLL for (int k = 1; k < NX; ++k) acc = fma(fo[r * LM::PX + k], x[k], acc);
             xo[r] = acc;
         }
         FK_UNROLL for (int k = 0; k < NX; ++k) x[k] = FK_Q_OWNER(k, R, xo[k % R]);
@@ -92,12 +124,17 @@ __device__ __forceinline__ void quad_predict(double (&x)[NX], double (&P)[NX / 4
     double FP[R][NX];
     {
     const LM M = quad_fresh(M0);
-    const double *fo = M.s + LM::OFF_F + sub * (unsigned)(R * NX);
+    const double *fo = M.s + LM::OFF_F + sub * (unsigned)(R * LM::PX);
+    // (every LDS read of the step's loops is requested one iteration AHEAD of its use -- two buffers --: a lone wave per SIMD has nothing
+    //  else to cover a ds_read -> s_waitcnt pair with; kf_mlg_predict.inc)
+    double fc[2][R];
+    FK_UNROLL for (int r = 0; r < R; ++r) fc[0][r] = fo[r * LM::PX];
     FK_UNROLL for (int l = 0; l < NX; ++l) {
+        if (l + 1 < NX) { FK_UNROLL for (int r = 0; r < R; ++r) fc[(l + 1) & 1][r] = fo[r * LM::PX + l + 1]; }
         double prow[NX];
         FK_UNROLL for (int c = 0; c < NX; ++c) prow[c] = FK_Q_OWNER(l, R, P[l % R][c]);
         FK_UNROLL for (int r = 0; r < R; ++r) {
-            const double f = fo[r * NX + l];
+            const double f = fc[l & 1][r];
             FK_UNROLL for (int c = 0; c < NX; ++c) FP[r][c] = (l == 0) ? f * prow[c] : fma(f, prow[c], FP[r][c]);
         }
         FK_STAGE();
@@ -105,12 +142,17 @@ __device__ __forceinline__ void quad_predict(double (&x)[NX], double (&P)[NX / 4
     }
     FK_STAGE();
     const LM M = quad_fresh(M0);
-    const double *qo = M.s + LM::OFF_Q + sub * (unsigned)(R * NX);
+    const double *qo = M.s + LM::OFF_Q + sub * (unsigned)(R * LM::PX);
+    double fr[2][NX], qc[2][R];
+    M.rowF(0, fr[0]);
+    FK_UNROLL for (int r = 0; r < R; ++r) qc[0][r] = qo[r * LM::PX];
     FK_UNROLL for (int j = 0; j < NX; ++j) {
-        double f[NX];
-        M.rowF(j, f);
-        FK_UNROLL for (int r = 0; r < R; ++r) P[r][j] = dot<NX>(FP[r], f) + qo[r * NX + j];
-        if (j % 2 == 1) FK_STAGE();
+        if (j + 1 < NX) {
+            M.rowF(j + 1, fr[(j + 1) & 1]);
+            FK_UNROLL for (int r = 0; r < R; ++r) qc[(j + 1) & 1][r] = qo[r * LM::PX + j + 1];
+        }
+        FK_UNROLL for (int r = 0; r < R; ++r) P[r][j] = dot<NX>(FP[r], fr[j & 1]) + qc[j & 1][r];
+        FK_STAGE();
     }
     FK_UNROLL for (int r = 0; r < R; ++r)
         FK_UNROLL for (int c = 0; c < NX; ++c) asm volatile("" : "+v"(P[r][c]));
@@ -132,34 +174,49 @@ __device__ __forceinline__ int quad_update(double (&x)[NX], double (&P)[NX / 4][
     }
     double PHT[R][NZ];
     M = quad_fresh(M0);
-    FK_UNROLL for (int c = 0; c < NZ; ++c) {
-        double h[NX];
-        M.rowH(c, h);
-        FK_UNROLL for (int r = 0; r < R; ++r) {
-            double acc = P[r][0] * h[0];
-            FK_UNROLL for (int k = 1; k < NX; ++k) acc = fma(P[r][k], h[k], acc);
-            PHT[r][c] = acc;
+    {
+        double hr[2][NX];
+        M.rowH(0, hr[0]);
+        FK_UNROLL for (int c = 0; c < NZ; ++c) {
+            if (c + 1 < NZ) M.rowH(c + 1, hr[(c + 1) & 1]);
+            const double (&h)[NX] = hr[c & 1];
+            FK_UNROLL for (int r = 0; r < R; ++r) {
+                double acc = P[r][0] * h[0];
+                FK_UNROLL for (int k = 1; k < NX; ++k) acc = fma(P[r][k], h[k], acc);
+                PHT[r][c] = acc;
+            }
+            FK_STAGE();
         }
-        FK_STAGE();
     }
     FK_STAGE();
     {
         // S = H (P H') + R: lane `sub` forms rows sub ZR .. sub ZR + ZR - 1
         double So[ZR][NZ];
         M = quad_fresh(M0);
-        const double *ho = M.s + LM::OFF_H + sub * (unsigned)(ZR * NX);
+        const double *ho = M.s + LM::OFF_H + sub * (unsigned)(ZR * LM::PX);
+        const double *ro = M.s + LM::OFF_R + sub * (unsigned)(ZR * LM::PZ);
+        double hs[2][ZR][4], rq[ZR][NZ];
+        FK_UNROLL for (int q = 0; q < ZR; ++q)
+            FK_UNROLL for (int kk = 0; kk < 4; ++kk) hs[0][q][kk] = ho[q * LM::PX + kk];
         FK_UNROLL for (int k = 0; k < NX; ++k) {
+            if (k % 4 == 0 && k + 4 < NX) {
+                FK_UNROLL for (int q = 0; q < ZR; ++q)
+                    FK_UNROLL for (int kk = 0; kk < 4; ++kk) hs[(k / 4 + 1) & 1][q][kk] = ho[q * LM::PX + k + 4 + kk];
+            }
+            if (k == NX - 4) {
+                FK_UNROLL for (int q = 0; q < ZR; ++q)
+                    FK_UNROLL for (int c = 0; c < NZ; ++c) rq[q][c] = ro[q * LM::PZ + c];
+            }
             double prow[NZ];
             FK_UNROLL for (int c = 0; c < NZ; ++c) prow[c] = FK_Q_OWNER(k, R, PHT[k % R][c]);
             FK_UNROLL for (int q = 0; q < ZR; ++q) {
-                const double h = ho[q * NX + k];
+                const double h = hs[(k / 4) & 1][q][k % 4];
                 FK_UNROLL for (int c = 0; c < NZ; ++c) So[q][c] = (k == 0) ? h * prow[c] : fma(h, prow[c], So[q][c]);
             }
             if (k % 4 == 3) FK_STAGE();
         }
-        const double *ro = M.s + LM::OFF_R + sub * (unsigned)(ZR * NZ);
         FK_UNROLL for (int q = 0; q < ZR; ++q)
-            FK_UNROLL for (int c = 0; c < NZ; ++c) So[q][c] += ro[q * NZ + c];
+            FK_UNROLL for (int c = 0; c < NZ; ++c) So[q][c] += rq[q][c];
         FK_UNROLL for (int a = 0; a < NZ; ++a)
             FK_UNROLL for (int c = 0; c < NZ; ++c) Lf[a * NZ + c] = (c <= a) ? FK_Q_OWNER(a, ZR, So[a % ZR][c]) : 0.0;
     }
@@ -207,11 +264,14 @@ __device__ __forceinline__ int quad_update(double (&x)[NX], double (&P)[NX / 4][
         FK_UNROLL for (int r = 0; r < R; ++r)
             FK_UNROLL for (int c = 0; c < NZ; ++c) D[r][c] = (a == 0) ? K[r * NZ] * rr[c] : fma(K[r * NZ + a], rr[c], D[r][c]);
     }
-    FK_UNROLL for (int c = 0; c < NZ; ++c) {
-        double h[NX];
-        M.rowH(c, h);
-        FK_UNROLL for (int r = 0; r < R; ++r) D[r][c] -= dot<NX>(P[r], h);
-        FK_STAGE();
+    {
+        double hr[2][NX];
+        M.rowH(0, hr[0]);
+        FK_UNROLL for (int c = 0; c < NZ; ++c) {
+            if (c + 1 < NZ) M.rowH(c + 1, hr[(c + 1) & 1]);
+            FK_UNROLL for (int r = 0; r < R; ++r) D[r][c] -= dot<NX>(P[r], hr[c & 1]);
+            FK_STAGE();
+        }
     }
     FK_STAGE();
     // P+ = T1 + D K'
@@ -307,7 +367,9 @@ __device__ __forceinline__ void quad_exchange(const QuadCtx &c, double (&x)[NX],
         if (est && P_dst) {
             // rows sub R .. of the estimate's P by the lanes with this sub index: their elements of the piece dealt out over the G
             // quads of the bank
-            _Pragma("nounroll") for (int k = 0; k < (CH + G - 1) / G; ++k) {
+            // (four elements per trip: their LDS reads in one batch -- as a loop of one it is a chain of dependent round trips, 2.3 of
+            //  the 7.9 ms of a (16,8) x 2 launch that asks for P)
+            _Pragma("unroll 4") for (int k = 0; k < (CH + G - 1) / G; ++k) {
                 const int q = (int)fj + G * k;
                 const int qc = lo + q < hi ? q : hi - lo - 1;
                 const int e = lo + qc, r = (int)sub * R + e / NX, cc = e % NX;
@@ -320,6 +382,14 @@ __device__ __forceinline__ void quad_exchange(const QuadCtx &c, double (&x)[NX],
                         const double hk = wH[i * GPW + grp];
                         const double ya = wX[r * 64 + s0 + 4 * i] - hk, yb = wX[cc * 64 + s0 + 4 * i] - hk;
                         acc = fma(wMu[s0 + 4 * i], fma(ya, yb, wP[qc * 64 + s0 + 4 * i]), acc);
+                    }
+                } else if constexpr (G <= 4) {
+                    // (small banks: the filters' terms unrolled under a predicate, their LDS reads in one batch)
+                    FK_UNROLL for (int i = 0; i < G; ++i) {
+                        const int ic = i < NM ? i : 0;
+                        const double ya = wX[r * 64 + s0 + 4 * ic] - hr, yb = wX[cc * 64 + s0 + 4 * ic] - hc;
+                        const double t = fma(wMu[s0 + 4 * ic], fma(ya, yb, wP[qc * 64 + s0 + 4 * ic]), acc);
+                        acc = i < NM ? t : acc;
                     }
                 } else {
                     for (int i = 0; i < NM; ++i) {
@@ -357,7 +427,7 @@ template <int NX, int NZ, int G, bool EXT>
 __global__ void __launch_bounds__(BLOCK, 1)
 imm_quad_kernel(const ImmArgs a, const int NM, const int aos)
 {
-    using LM = LdsModel<NX, NZ>;
+    using LM = QuadModel<NX, NZ>;
     static_assert(NX % 4 == 0 && NZ % 4 == 0 && 4 * G <= 64, "four lanes per filter, whole rows per lane");
     constexpr int R = NX / 4, PE = R * NX, WAVES = BLOCK / 64, LPB = 4 * G, GPW = 64 / LPB;      // GPW: banks per wave
     // The lane's rows of P are exchanged in PH pieces of at most CH elements (as many as fit beside the G model blocks in 160 KB)
@@ -372,10 +442,10 @@ imm_quad_kernel(const ImmArgs a, const int NM, const int aos)
     const long N = a.N;
     for (int j = 0; j < NM; ++j) {
         double *s = smem + j * LM::SIZE;
-        lds_fill<NX, NX>(s + LM::OFF_F, a.F + (long)j * n * n, n, n, 1.0, threadIdx.x);
-        lds_fill<NX, NX>(s + LM::OFF_Q, a.Q + (long)j * n * n, n, n, 0.0, threadIdx.x);
-        lds_fill<NZ, NX>(s + LM::OFF_H, a.H + (long)j * m * n, m, n, 0.0, threadIdx.x);
-        lds_fill<NZ, NZ>(s + LM::OFF_R, a.R + (long)j * m * m, m, m, 1.0, threadIdx.x);
+        quad_fill<NX, NX, LM::PX>(s + LM::OFF_F, a.F + (long)j * n * n, n, n, 1.0, threadIdx.x);
+        quad_fill<NX, NX, LM::PX>(s + LM::OFF_Q, a.Q + (long)j * n * n, n, n, 0.0, threadIdx.x);
+        quad_fill<NZ, NX, LM::PX>(s + LM::OFF_H, a.H + (long)j * m * n, m, n, 0.0, threadIdx.x);
+        quad_fill<NZ, NZ, LM::PZ>(s + LM::OFF_R, a.R + (long)j * m * m, m, m, 1.0, threadIdx.x);
     }
     double *sM = smem + G * LM::SIZE;
     if ((int)threadIdx.x < NM * NM) sM[threadIdx.x] = a.Mt ? a.Mt[threadIdx.x] : 0.0;
