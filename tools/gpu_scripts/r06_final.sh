@@ -55,6 +55,12 @@ FK_UKF_PAIRED=0 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv
 timeout 200 python $R/tools/bench_ukf.py --dims 6x3 --N 1000000 --T 20 >> $O/ukf_kernels.jsonl 2>> $O/ukf_stats.err
 cd $R
 grep -E "^\{" $O/prof_cfg.log > $O/configs_all.jsonl; wc -l $O/configs_all.jsonl
+# HBM traffic of the C3 / C4 kernels (configs[2], [3]): two separate PMC passes of the same command, every fk:: kernel by name
+cd /tmp
+for c in FETCH_SIZE WRITE_SIZE; do timeout 600 rocprofv3 --pmc $c --output-format csv -d $O/cfg_pmc_$c -- python $R/tools/bench_configs.py --configs 34 --layouts soa,aos > /dev/null 2> $O/cfg_pmc_$c.err; done
+cd $R
+python tools/pmc_configs.py $O/cfg_pmc_FETCH_SIZE $O/cfg_pmc_WRITE_SIZE "--expect=kf_ml_kernel<9, 3=14784000000" "--expect=rts_ml_kernel<9=27360000000" "--expect=ukf_linear_kernel<6, 3=3600000000" > $O/configs_traffic.jsonl 2> $O/configs_traffic.err; cut -c1-260 $O/configs_traffic.jsonl
+python tools/bench_imm_outputs.py --dims 16x8x2 > $O/imm_outputs.jsonl 2>/dev/null; python tools/bench_imm_outputs.py --dims 9x4x8 >> $O/imm_outputs.jsonl 2>/dev/null
 for sh in "1000 8000" "125 8000" "125 8000000"; do set -- $sh; timeout 400 python tools/bench_c5.py --filters $1 --particles $2 > $O/bench_c5_$1x$2.json 2>/dev/null; cut -c1-300 $O/bench_c5_$1x$2.json; done
 timeout 300 python bench.py --steps 10 --warmup 3 --scaling strong --no-cpu --no-configs > $O/bench_strong_1rank.json 2> $O/bench_strong.err; echo "strong rc=$?"
 timeout 300 python bench.py --steps 10 --warmup 3 --force-dist --no-cpu --no-configs > $O/bench_force_dist_1rank_nccl.json 2> $O/bench_force_dist.err; echo "force-dist rc=$?"; grep -iE "rccl|nccl version" $O/bench_force_dist.err | head -2

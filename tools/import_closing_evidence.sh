@@ -11,6 +11,7 @@ cp $S/bench_default.json $S/bench_placement_probe.json $S/bench_placement_none.j
    $S/configs_all_kernel_stats.csv $S/resample_shapes.jsonl $S/kernel_durations.txt $S/kernel_durations_bench_last20.txt \
    $S/bench_kernel_trace_fk.csv $S/pytest_gpu_full.log $S/box_state.txt $S/smoke.log \
    $S/ukf_kernels.jsonl $S/ukf_kernels_index_order.jsonl $S/ukf_kernel_durations.txt $S/ukf_kernel_durations_index_order.txt $D/
+cp $S/configs_traffic.jsonl $S/imm_outputs.jsonl $D/ 2>/dev/null || true
 cp $S/prof_fetch_fk.csv $D/kf_c2_aos_pmc_fetch.csv
 cp $S/prof_write_fk.csv $D/kf_c2_aos_pmc_write.csv
 cp $S/kernel_durations_round3_onepass.txt $S/resample_under_stats_round3_onepass.jsonl $S/onepass_pmc.json $S/onepass_phase_clocks.jsonl $S/bench_strong_1rank.json $S/bench_api.jsonl $S/c_abi_multi_gpu.log $D/ 2>/dev/null || true
