@@ -63,6 +63,15 @@ FK_IL_DECL(9, 4)
     }
 FK_IQ_DECL(12, 4)
 FK_IQ_DECL(16, 8)
+// the same unit built with EIGHT lanes per filter (FK_IQ_LPF=8): the class (16, 8), banks of two filters -- where it is the faster one
+// (x, P, mu out: 7.2 -> 6.4 ms per 1e6 bank-steps; banks of four: the same, of eight: slower; docs/KERNEL_NOTES.md)
+int launch_imm_oct_16_8_g2_x0(const ImmArgs &, int, int, hipStream_t);
+int launch_imm_oct_16_8_g2_x1(const ImmArgs &, int, int, hipStream_t);
+static int launch_imm_oct_16_8(const ImmArgs &a, int nm, int layout, hipStream_t s)
+{
+    const bool ext = a.mmae || a.mask || a.ll0 || a.nu > 0 || a.phase != FK_IMM_STEP;
+    return ext ? launch_imm_oct_16_8_g2_x1(a, nm, layout, s) : launch_imm_oct_16_8_g2_x0(a, nm, layout, s);
+}
 #undef FK_IQ_DECL
 #undef FK_IQ_DECL1
 
@@ -137,7 +146,10 @@ extern "C" int fk_imm_batch_ex_f64(const fk_imm_desc *d, const double *F, const 
             if (rc == 0) return check_launch("imm_lanes_kernel");
         }
         if (quad) {
-            const int rc = (b.n <= 12 && b.m <= 4) ? launch_imm_quad_12_4(b, n_models, layout, s) : launch_imm_quad_16_8(b, n_models, layout, s);
+            // (the class (16, 8) with two filters: eight lanes per filter; FK_IMM_OCT=0: four, the A/B)
+            static const int oct_mode = [] { const char *v = getenv("FK_IMM_OCT"); return v ? atoi(v) : 1; }();
+            const int rc = (b.n <= 12 && b.m <= 4) ? launch_imm_quad_12_4(b, n_models, layout, s)
+                         : (oct_mode > 0 && n_models <= 2) ? launch_imm_oct_16_8(b, n_models, layout, s) : launch_imm_quad_16_8(b, n_models, layout, s);
             if (rc == 0) return check_launch("imm_quad_kernel");
         }
         if (small) {

@@ -5,7 +5,7 @@
 // imm_lanes.hip gives every FILTER of a bank a lane (x and the packed P in registers); a 16 x 16 packed P is 272 registers, more
 // than a lane addresses directly, and that kernel's (16,8) build lived in 9 KB of scratch memory per lane with 320-660 KB of code
 // (40.8 ms for 5e6 bank-steps of (16,8) x 2; the one-lane-per-BANK rolled kernel before it: 247 ms).  Here a QUAD of lanes owns a
-// filter the way kf_mlg.hip's quad owns a track: lane `sub` holds rows sub R .. sub R + R - 1 of the FULL P (R = NX / 4: 64 doubles at
+// filter the way kf_mlg.hip's quad owns a track: lane `sub` holds rows sub R .. sub R + R - 1 of the FULL P (R = NX / LPF: 64 doubles at
 // dim_x 16), x is replicated in the quad, rows travel by quad-permute DPP moves, the filter's F, Q, H, R come from LDS through a
 // per-lane base address.  A group of 4 G adjacent lanes (G = 2, 4, 8, 16 filters) owns a bank; a wave works on 16 / G banks.
 //
@@ -28,7 +28,20 @@
 #include "fk_ml.hpp"
 #include "../../include/filterhip.h"
 
+#ifndef FK_IQ_LPF
+#define FK_IQ_LPF 4          // lanes per filter: 4 (a quad) or 8 (a pair of quads: the second build of this file, imm_oct_*.o)
+#endif
+#define FK_IQ_NS_(l) iq##l
+#define FK_IQ_NS(l) FK_IQ_NS_(l)
+
 namespace fk {
+namespace FK_IQ_NS(FK_IQ_LPF) {
+
+#ifndef FK_IQ_OCC2
+#define FK_IQ_OCC2 0
+#endif
+constexpr int LPF = FK_IQ_LPF;
+static_assert(LPF == 4 || LPF == 8, "four or eight lanes per filter");
 
 // offset (in doubles) of element e of record `rec` in an [N][nelem] (NumPy order) or [nelem][N] (element-major) block (32 bits:
 // the entry point refuses record blocks of 4 GiB and more)
@@ -73,22 +86,46 @@ __device__ __forceinline__ void quad_fill(double *dst, const double *__restrict_
     }
 }
 
-// the value lane (k / R) of the quad holds (k: a compile-time constant after unrolling)
+// The value lane OWNER of the filter's group holds, in every lane of the group.  Four lanes: one quad-permute DPP move per half.  Eight
+// lanes (a pair of quads, inside a DPP row of 16): every quad broadcasts ITS lane OWNER % 4, then the quad that does not hold the
+// owner takes the other quad's value -- row_shr:4 into the odd quads (bank mask 0xA) or row_shl:4 into the even ones (0x5).
+template <int OWNER>
+__device__ __forceinline__ double grp_bcast(double v)
+{
+    static_assert(OWNER >= 0 && OWNER < LPF, "a lane of the group");
+    if constexpr (LPF == 4) {
+        return quad_bcast<OWNER>(v);
+    } else {
+        constexpr int q = OWNER & 3, h = OWNER >> 2;
+        int lo = __double2loint(v), hi = __double2hiint(v);
+        lo = __builtin_amdgcn_mov_dpp(lo, q * 0x55, 0xf, 0xf, true);
+        hi = __builtin_amdgcn_mov_dpp(hi, q * 0x55, 0xf, 0xf, true);
+        constexpr int ctrl = h == 0 ? 0x114 : 0x104, banks = h == 0 ? 0xA : 0x5;
+        lo = __builtin_amdgcn_update_dpp(lo, lo, ctrl, 0xf, banks, false);
+        hi = __builtin_amdgcn_update_dpp(hi, hi, ctrl, 0xf, banks, false);
+        return __hiloint2double(hi, lo);
+    }
+}
+// (k: a compile-time constant after unrolling; owner = lane k / R of the group)
+#define FK_Q_OWN_(o, v) grp_bcast<((o) < LPF ? (o) : 0)>(v)
 #define FK_Q_OWNER(k, R, v)                                                                                            \
-    (((k) / (R)) == 0 ? quad_bcast<0>(v) : ((k) / (R)) == 1 ? quad_bcast<1>(v) : ((k) / (R)) == 2 ? quad_bcast<2>(v) : quad_bcast<3>(v))
+    (((k) / (R)) == 0 ? FK_Q_OWN_(0, v) : ((k) / (R)) == 1 ? FK_Q_OWN_(1, v) : ((k) / (R)) == 2 ? FK_Q_OWN_(2, v) : ((k) / (R)) == 3 ? FK_Q_OWN_(3, v) \
+     : ((k) / (R)) == 4 ? FK_Q_OWN_(4, v) : ((k) / (R)) == 5 ? FK_Q_OWN_(5, v) : ((k) / (R)) == 6 ? FK_Q_OWN_(6, v) : FK_Q_OWN_(7, v))
 
 // element sub R + r of a replicated vector
 template <int NX>
 __device__ __forceinline__ double quad_pick(const double (&x)[NX], unsigned sub, int r)
 {
-    constexpr int R = NX / 4;
-    // (the four candidates as VALUES before the selection: as a selection between loads the optimiser made it one load through a
+    constexpr int R = NX / LPF;
+    // (the candidates as VALUES before the selection: as a selection between loads the optimiser made it one load through a
     //  selected address, and the replicated vector an array in scratch memory)
-    double v0 = x[r], v1 = x[R + r], v2 = x[2 * R + r], v3 = x[3 * R + r];
-    asm volatile("" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3));
-    double v = sub == 1u ? v1 : v0;
-    v = sub == 2u ? v2 : v;
-    v = sub == 3u ? v3 : v;
+    double c[LPF];
+    FK_UNROLL for (int s = 0; s < LPF; ++s) {
+        c[s] = x[s * R + r];
+        asm volatile("" : "+v"(c[s]));
+    }
+    double v = c[0];
+    FK_UNROLL for (int s = 1; s < LPF; ++s) v = sub == (unsigned)s ? c[s] : v;
     return v;
 }
 
@@ -107,9 +144,9 @@ __device__ __forceinline__ LM quad_fresh(const LM &M)
 
 // x = F x ; P = (F P) F' + Q  (kalman_filter.py:472-478), the lane's rows of P
 template <int NX, class LM>
-__device__ __forceinline__ void quad_predict(double (&x)[NX], double (&P)[NX / 4][NX], const LM &M0, unsigned sub)
+__device__ __forceinline__ void quad_predict(double (&x)[NX], double (&P)[NX / LPF][NX], const LM &M0, unsigned sub)
 {
-    constexpr int R = NX / 4;
+    constexpr int R = NX / LPF;
     {
         const LM M = quad_fresh(M0);
         const double *fo = M.s + LM::OFF_F + sub * (unsigned)(R * LM::PX);      // the lane's own rows of F
@@ -161,10 +198,10 @@ __device__ __forceinline__ void quad_predict(double (&x)[NX], double (&P)[NX / 4
 
 // The update of the lane's filter; y, Lf (L D L' of S: strict lower part), dinv replicated in the quad for the caller's likelihood.
 template <int NX, int NZ, class LM>
-__device__ __forceinline__ int quad_update(double (&x)[NX], double (&P)[NX / 4][NX], const double (&z)[NZ], const LM &M0, unsigned sub,
+__device__ __forceinline__ int quad_update(double (&x)[NX], double (&P)[NX / LPF][NX], const double (&z)[NZ], const LM &M0, unsigned sub,
                                            double (&y)[NZ], double (&Lf)[NZ * NZ], double (&dinv)[NZ])
 {
-    constexpr int R = NX / 4, ZR = NZ / 4;
+    constexpr int R = NX / LPF, ZR = NZ / LPF;
     int st = 0;
     LM M = quad_fresh(M0);
     FK_UNROLL for (int r = 0; r < NZ; ++r) {
@@ -307,10 +344,10 @@ struct QuadCtx {
 // (IMM.py:200-219, :224-237, :239-249; MMAE's estimate: mmae.py:191-207).  A function template taking x and P by reference
 // (docs/KERNEL_NOTES.md: as a generic lambda the kernel's P stayed in scratch memory).
 template <bool MIX, int NX, int G, int CH, int PH>
-__device__ __forceinline__ void quad_exchange(const QuadCtx &c, double (&x)[NX], double (&P)[NX / 4][NX], const double mu, double &cbar,
+__device__ __forceinline__ void quad_exchange(const QuadCtx &c, double (&x)[NX], double (&P)[NX / LPF][NX], const double mu, double &cbar,
                                               const bool est, double *x_dst, double *P_dst, const bool mmae = false)
 {
-    constexpr int R = NX / 4, PE = R * NX, LPB = 4 * G, GPW = 64 / LPB;
+    constexpr int R = NX / LPF, PE = R * NX, LPB = LPF * G, GPW = 64 / LPB;
     double *const wX = c.wX, *const wP = c.wP, *const wH = c.wH, *const wMu = c.wMu;
     const double *const sM = c.sM;
     const unsigned lane = c.lane, grp = c.grp, bl = c.bl, sub = c.sub, jm = c.jm, bank = c.bank;
@@ -326,7 +363,7 @@ __device__ __forceinline__ void quad_exchange(const QuadCtx &c, double (&x)[NX],
     bool tiny = false;
     if constexpr (MIX) {
         double acc = 0.0;                                  // cbar_j = sum_i mu_i M[i][j]  (IMM.py:244)
-        for (int i = 0; i < NM; ++i) acc = fma(wMu[s0 + 4 * i], sM[i * NM + (int)jm], acc);
+        for (int i = 0; i < NM; ++i) acc = fma(wMu[s0 + LPF * i], sM[i * NM + (int)jm], acc);
         cbar = acc;
         tiny = cbar < 0x1p-500;
         rc = fk_rcp(tiny ? cbar * 0x1p600 : cbar);
@@ -335,11 +372,11 @@ __device__ __forceinline__ void quad_exchange(const QuadCtx &c, double (&x)[NX],
         double xh[NX], xm[NX];
         FK_UNROLL for (int r = 0; r < NX; ++r) xh[r] = xm[r] = 0.0;
         for (int i = 0; i < NM; ++i) {
-            const double mi = wMu[s0 + 4 * i];
+            const double mi = wMu[s0 + LPF * i];
             const double num = sM[i * NM + (int)jm] * mi;
             const double w = (tiny ? num * 0x1p600 : num) * rc;
             FK_UNROLL for (int r = 0; r < NX; ++r) {
-                const double xi = wX[r * 64 + s0 + 4 * i];
+                const double xi = wX[r * 64 + s0 + LPF * i];
                 xh[r] = fma(xi, mi, xh[r]);
                 xm[r] = fma(xi, w, xm[r]);
             }
@@ -357,7 +394,7 @@ __device__ __forceinline__ void quad_exchange(const QuadCtx &c, double (&x)[NX],
         if constexpr (MIX) { FK_UNROLL for (int r = 0; r < NX; ++r) x[r] = xm[r]; }       // (the old x stays published in wX)
     }
     if (!MIX && !(est && P_dst)) return;
-    const unsigned fj = bl >> 2;
+    const unsigned fj = bl / (unsigned)LPF;
     FK_UNROLL for (int ph = 0; ph < PH; ++ph) {
         const int lo = ph * CH, hi = (lo + CH < PE) ? lo + CH : PE;
         ml_wave_fence();
@@ -380,21 +417,21 @@ __device__ __forceinline__ void quad_exchange(const QuadCtx &c, double (&x)[NX],
                     const int kmax = NM < n ? NM : n;
                     for (int i = 0; i < kmax; ++i) {
                         const double hk = wH[i * GPW + grp];
-                        const double ya = wX[r * 64 + s0 + 4 * i] - hk, yb = wX[cc * 64 + s0 + 4 * i] - hk;
-                        acc = fma(wMu[s0 + 4 * i], fma(ya, yb, wP[qc * 64 + s0 + 4 * i]), acc);
+                        const double ya = wX[r * 64 + s0 + LPF * i] - hk, yb = wX[cc * 64 + s0 + LPF * i] - hk;
+                        acc = fma(wMu[s0 + LPF * i], fma(ya, yb, wP[qc * 64 + s0 + LPF * i]), acc);
                     }
                 } else if constexpr (G <= 4) {
                     // (small banks: the filters' terms unrolled under a predicate, their LDS reads in one batch)
                     FK_UNROLL for (int i = 0; i < G; ++i) {
                         const int ic = i < NM ? i : 0;
-                        const double ya = wX[r * 64 + s0 + 4 * ic] - hr, yb = wX[cc * 64 + s0 + 4 * ic] - hc;
-                        const double t = fma(wMu[s0 + 4 * ic], fma(ya, yb, wP[qc * 64 + s0 + 4 * ic]), acc);
+                        const double ya = wX[r * 64 + s0 + LPF * ic] - hr, yb = wX[cc * 64 + s0 + LPF * ic] - hc;
+                        const double t = fma(wMu[s0 + LPF * ic], fma(ya, yb, wP[qc * 64 + s0 + LPF * ic]), acc);
                         acc = i < NM ? t : acc;
                     }
                 } else {
                     for (int i = 0; i < NM; ++i) {
-                        const double ya = wX[r * 64 + s0 + 4 * i] - hr, yb = wX[cc * 64 + s0 + 4 * i] - hc;
-                        acc = fma(wMu[s0 + 4 * i], fma(ya, yb, wP[qc * 64 + s0 + 4 * i]), acc);
+                        const double ya = wX[r * 64 + s0 + LPF * i] - hr, yb = wX[cc * 64 + s0 + LPF * i] - hc;
+                        acc = fma(wMu[s0 + LPF * i], fma(ya, yb, wP[qc * 64 + s0 + LPF * i]), acc);
                     }
                 }
                 if (lo + q < hi && r < n && cc < n && live) P_dst[oP.at(bank, r * n + cc)] = acc;
@@ -408,30 +445,36 @@ __device__ __forceinline__ void quad_exchange(const QuadCtx &c, double (&x)[NX],
             double xo[R];
             FK_UNROLL for (int r = 0; r < R; ++r) xo[r] = quad_pick<NX>(x, sub, r);
             for (int i = 0; i < NM; ++i) {
-                const double num = sM[i * NM + (int)jm] * wMu[s0 + 4 * i];
+                const double num = sM[i * NM + (int)jm] * wMu[s0 + LPF * i];
                 const double w = (tiny ? num * 0x1p600 : num) * rc;
                 double d[NX], dr[R];
-                FK_UNROLL for (int r = 0; r < NX; ++r) d[r] = wX[r * 64 + s0 + 4 * i] - x[r];
-                FK_UNROLL for (int r = 0; r < R; ++r) dr[r] = wX[(sub * R + r) * 64 + s0 + 4 * i] - xo[r];
+                FK_UNROLL for (int r = 0; r < NX; ++r) d[r] = wX[r * 64 + s0 + LPF * i] - x[r];
+                FK_UNROLL for (int r = 0; r < R; ++r) dr[r] = wX[(sub * R + r) * 64 + s0 + LPF * i] - xo[r];
                 FK_UNROLL for (int r = 0; r < R; ++r)
                     FK_UNROLL for (int cc = 0; cc < NX; ++cc) {
                         const int e = r * NX + cc;
-                        if (e >= lo && e < hi) P[r][cc] = fma(w, fma(dr[r], d[cc], wP[(e - lo) * 64 + s0 + 4 * i]), P[r][cc]);
+                        if (e >= lo && e < hi) P[r][cc] = fma(w, fma(dr[r], d[cc], wP[(e - lo) * 64 + s0 + LPF * i]), P[r][cc]);
                     }
             }
         }
     }
 }
 
+// (FK_IQ_OCC2=1, build time: eight lanes per filter, banks of up to four, TWO waves per SIMD -- 256 registers, 80 KB of LDS per workgroup.
+//  MEASURED SLOWER, (16,8) x 2 without outputs 5.4 -> 9.6 ms: the step does not fit 256 registers (1.2 KB of spills per lane) and the
+//  exchange goes in three pieces.  profiles/r06/imm_quad/oct_*.txt)
+template <int G>
+constexpr int IQ_WAVES = (LPF == 8 && G <= 4 && FK_IQ_OCC2) ? 2 : 1;
+
 template <int NX, int NZ, int G, bool EXT>
-__global__ void __launch_bounds__(BLOCK, 1)
+__global__ void __launch_bounds__(BLOCK, IQ_WAVES<G>)
 imm_quad_kernel(const ImmArgs a, const int NM, const int aos)
 {
     using LM = QuadModel<NX, NZ>;
-    static_assert(NX % 4 == 0 && NZ % 4 == 0 && 4 * G <= 64, "four lanes per filter, whole rows per lane");
-    constexpr int R = NX / 4, PE = R * NX, WAVES = BLOCK / 64, LPB = 4 * G, GPW = 64 / LPB;      // GPW: banks per wave
+    static_assert(NX % LPF == 0 && NZ % LPF == 0 && LPF * G <= 64, "LPF lanes per filter, whole rows per lane");
+    constexpr int R = NX / LPF, PE = R * NX, WAVES = BLOCK / 64, LPB = LPF * G, GPW = 64 / LPB;      // GPW: banks per wave
     // The lane's rows of P are exchanged in PH pieces of at most CH elements (as many as fit beside the G model blocks in 160 KB)
-    constexpr int LDS_DOUBLES = 160 * 1024 / 8 - 64;
+    constexpr int LDS_DOUBLES = 160 * 1024 / IQ_WAVES<G> / 8 - 64;
     constexpr int FIXED = NX * 64 + NX * GPW + 64 + 64;                            // X | xhat | mu | scratch
     constexpr int ROOM = (LDS_DOUBLES - G * LM::SIZE - G * G) / WAVES - FIXED;
     static_assert(ROOM >= 64 * 8, "no room for the exchange image");
@@ -452,7 +495,7 @@ imm_quad_kernel(const ImmArgs a, const int NM, const int aos)
     __syncthreads();
 
     const unsigned lane = threadIdx.x & 63u, wave = wave_index();
-    const unsigned g0 = lane & ~(unsigned)(LPB - 1), grp = lane / (unsigned)LPB, bl = lane - g0, sub = lane & 3u, j = bl >> 2;
+    const unsigned g0 = lane & ~(unsigned)(LPB - 1), grp = lane / (unsigned)LPB, bl = lane - g0, sub = lane & (unsigned)(LPF - 1), j = bl / (unsigned)LPF;
     const unsigned s0 = g0 + sub;
     const bool active = (int)j < NM;
     const unsigned jm = active ? j : (unsigned)(NM - 1);
@@ -531,7 +574,7 @@ imm_quad_kernel(const ImmArgs a, const int NM, const int aos)
                 wMu[lane] = mu;
                 ml_wave_fence();
                 double acc = 0.0;
-                for (int i = 0; i < NM; ++i) acc = fma(wMu[s0 + 4 * i], sM[i * NM + (int)jm], acc);
+                for (int i = 0; i < NM; ++i) acc = fma(wMu[s0 + LPF * i], sM[i * NM + (int)jm], acc);
                 cbar = acc;
             }
         } else {
@@ -607,7 +650,7 @@ imm_quad_kernel(const ImmArgs a, const int NM, const int aos)
             wS[lane] = mj;
             ml_wave_fence();
             double sum = 0.0;
-            for (int i = 0; i < NM; ++i) sum += wS[s0 + 4 * i];
+            for (int i = 0; i < NM; ++i) sum += wS[s0 + LPF * i];
             const bool tny = sum < 0x1p-500;
             const double rsum = fk_rcp(tny ? sum * 0x1p600 : sum);
             mu = (tny ? mj * 0x1p600 : mj) * rsum;
@@ -644,15 +687,17 @@ imm_quad_kernel(const ImmArgs a, const int NM, const int aos)
             wI[lane] = st | (fin ? 0 : ST_NONFINITE);
             ml_wave_fence();
             int sv = 0;
-            for (int i = 0; i < 4 * NM; ++i) sv |= wI[g0 + i];
+            for (int i = 0; i < LPF * NM; ++i) sv |= wI[g0 + i];
             if (live && bl == 0u) a.status[bank] = a.status_or ? (a.status[bank] | sv) : sv;
         }
     }
 }
 
+}  // namespace iq<LPF>
 }  // namespace fk
 
 using namespace fk;
+using namespace fk::FK_IQ_NS(FK_IQ_LPF);
 
 #if !defined(FK_NX) || !defined(FK_NZ) || !defined(FK_IL_G) || !defined(FK_IL_EXT)
 #error "compile with -DFK_NX= -DFK_NZ= (the class: every dim_x <= FK_NX, dim_z <= FK_NZ; both multiples of 4) -DFK_IL_G=2|4|8|16 (filters per bank) -DFK_IL_EXT=0|1"
@@ -662,12 +707,17 @@ using namespace fk;
 
 // launch_imm_quad_<NX>_<NZ>_g<G>_x<EXT>: banks of G/2 + 1 .. G filters of the class (one object per G and kind); x1 also serves MMAE,
 // missing measurements, the control input and the single-phase calls; returns 1 when the call is not one this file serves
-int FK_IQ_CAT(launch_imm_quad_, FK_NX, FK_NZ, FK_IL_G, FK_IL_EXT)(const ImmArgs &a, int n_models, int layout, hipStream_t s)
+#if FK_IQ_LPF == 8
+#define FK_IQ_LAUNCH launch_imm_oct_
+#else
+#define FK_IQ_LAUNCH launch_imm_quad_
+#endif
+int FK_IQ_CAT(FK_IQ_LAUNCH, FK_NX, FK_NZ, FK_IL_G, FK_IL_EXT)(const ImmArgs &a, int n_models, int layout, hipStream_t s)
 {
     if (a.n > FK_NX || a.m > FK_NZ || n_models < 2 || n_models > FK_IL_G) return 1;
     if (!FK_IL_EXT && (a.mmae || a.mask || a.ll0 || a.nu > 0 || a.phase != FK_IMM_STEP)) return 1;
     const int aos = layout == FK_LAYOUT_AOS ? 1 : 0;
-    const long per_block = (BLOCK / 64) * (64 / (4 * FK_IL_G));
+    const long per_block = (BLOCK / 64) * (64 / (FK_IQ_LPF * FK_IL_G));
     const dim3 grid((unsigned)((a.cnt + per_block - 1) / per_block)), block(BLOCK);
     hipLaunchKernelGGL((imm_quad_kernel<FK_NX, FK_NZ, FK_IL_G, (FK_IL_EXT != 0)>), grid, block, 0, s, a, n_models, aos);
     return 0;

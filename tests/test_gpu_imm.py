@@ -627,7 +627,7 @@ def test_imm_banks_above_9_4_vs_oracle(n, m, nm, layout):
 # ---- round 6: one lane per filter (csrc/imm_lanes.hip): every class x every group width, ragged banks, output subsets
 LANES_CASES = [(4, 2, 4), (3, 2, 7), (4, 1, 12), (6, 3, 4), (5, 3, 6), (6, 2, 16), (9, 4, 2), (7, 2, 3), (9, 4, 8), (8, 3, 5), (9, 2, 13), (7, 4, 16)]
 # ---- four lanes per filter (csrc/imm_quad.hip): the classes (12, 4) and (16, 8), every group width, padded and exact dims
-QUAD_CASES = [(10, 3, 2), (12, 4, 4), (11, 2, 7), (12, 3, 16), (16, 8, 2), (13, 5, 3), (14, 6, 8), (15, 7, 12), (16, 4, 16), (9, 5, 2)]
+QUAD_CASES = [(10, 3, 2), (12, 4, 4), (11, 2, 7), (12, 3, 16), (16, 8, 2), (13, 5, 3), (14, 6, 8), (15, 7, 12), (16, 4, 16), (9, 5, 2), (14, 8, 2)]
 
 
 def _lanes_bank(n, m, nm, N, T, seed):
@@ -737,6 +737,44 @@ np.savez(sys.argv[1], **res)
         a, b = got["1"][k], got["2"][k]
         w = a.shape[-1] * (a.shape[-2] if k.endswith(("P_out", "Ps")) else 1)
         assert rel_err_rows(a.reshape(-1, w), b.reshape(-1, w)) < 1e-11, k
+
+
+def test_imm_eight_lanes_per_filter_against_four():
+    """Banks of two filters of the class (16,8) run on imm_quad.hip built with EIGHT lanes per filter (imm_oct_*); FK_IMM_OCT=0 (read once per
+    process: two subprocesses) runs them on the four-lane build: same arithmetic, another distribution of it -- every record of both
+    within 1e-11 of each other (normwise per bank and step)"""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, "tests")
+import test_gpu_imm as t
+res = {}
+for (n, m, nm) in [(16, 8, 2), (13, 5, 2), (10, 7, 2)]:
+    b = t._lanes_bank(n, m, nm, 150, 6, 19 + n)
+    for layout in ("soa", "aos"):
+        r = t.run_imm(*b, layout)
+        for k in ("x_out", "P_out", "mu_out", "likelihood_out", "x_prior_out", "P_prior_out", "xs", "Ps", "mu"):
+            res[f"{n}_{m}_{nm}_{layout}_{k}"] = r[k]
+np.savez(sys.argv[1], **res)
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    got = {}
+    with tempfile.TemporaryDirectory() as td:
+        for mode in ("0", "1"):
+            f = os.path.join(td, f"m{mode}.npz")
+            env = dict(os.environ, FK_IMM_OCT=mode, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+            subprocess.run([sys.executable, "-c", code, f], check=True, cwd=root, env=env, timeout=600)
+            got[mode] = dict(np.load(f))
+    assert got["0"].keys() == got["1"].keys() and len(got["0"]) == 54
+    differs = False
+    for k in got["0"]:
+        a, b = got["0"][k], got["1"][k]
+        w = a.shape[-1] * (a.shape[-2] if k.endswith(("P_out", "Ps")) else 1)
+        assert rel_err_rows(a.reshape(-1, w), b.reshape(-1, w)) < 1e-11, k
+        differs = differs or not np.array_equal(a, b)
 
 
 @pytest.mark.parametrize("layout", ["soa", "aos"])
