@@ -56,6 +56,34 @@ struct OctSwizzle {
     }
 };
 
+// The same broadcast on the VALU (round 6, imm_quad.hip's): every quad broadcasts ITS lane O % 4 by quad-permute, then the quad of the pair that
+// does not hold lane O takes the other quad's value -- row_shr:4 into the odd quads (bank mask 0xA) or row_shl:4 into the even ones
+// (0x5); a group of eight lies inside a DPP row of 16.  Four VALU moves per double instead of two LDS-pipe operations: the eight-lane
+// kernels kept the LDS pipe of a CU busy in 80 % of the cycles (four waves x 20 %, profiles/r06/ukf_mlg_counters/) with the VALU at 35 %.
+// FK_UMLG_OCT_DPP=0 (build time): ds_swizzle again (A/B; the same bits either way).
+#ifndef FK_UMLG_OCT_DPP
+#define FK_UMLG_OCT_DPP 1
+#endif
+struct OctDpp {
+    template <int O>
+    __device__ __forceinline__ double bcast(double v) const
+    {
+        static_assert(O >= 0 && O < 8, "eight lanes per track");
+        constexpr int q = O & 3, ctrl = (O >> 2) == 0 ? 0x114 : 0x104, banks = (O >> 2) == 0 ? 0xA : 0x5;
+        int lo = __double2loint(v), hi = __double2hiint(v);
+        lo = __builtin_amdgcn_mov_dpp(lo, q * 0x55, 0xf, 0xf, true);
+        hi = __builtin_amdgcn_mov_dpp(hi, q * 0x55, 0xf, 0xf, true);
+        lo = __builtin_amdgcn_update_dpp(lo, lo, ctrl, 0xf, banks, false);
+        hi = __builtin_amdgcn_update_dpp(hi, hi, ctrl, 0xf, banks, false);
+        return __hiloint2double(hi, lo);
+    }
+};
+#if FK_UMLG_OCT_DPP
+using OctBcast = OctDpp;
+#else
+using OctBcast = OctSwizzle;
+#endif
+
 template <int NX, int NZ, int LAYOUT, int LN = 4>
 __global__ void __launch_bounds__(BLOCK, (NX <= 8 ? 2 : 1))
 ukf_mlg_kernel(const UkfArgs a)
@@ -159,7 +187,7 @@ ukf_mlg_kernel(const UkfArgs a)
         FK_UNROLL for (int c = 0; c < NZ; ++c) asm volatile("" ::"v"(zn[c]));
         asm volatile("" ::"v"(hn));
     }
-    std::conditional_t<LN == 4, QuadDpp, OctSwizzle> quad;
+    std::conditional_t<LN == 4, QuadDpp, OctBcast> quad;
     const bool st_m = a.means != nullptr, st_c = a.covs != nullptr;
     _Pragma("nounroll") for (long t = 0; t < a.T; ++t) {
         if constexpr (ZDMA) {
@@ -372,7 +400,7 @@ ukf_mlg_rts_kernel(const UkfRtsArgs a, const double *__restrict__ pF, const doub
         else ml_tile_out_soa<NX, TPW>(a.xs + t * N * NX, N, w0, xt, lane, vv);
         ml_wave_fence();
     };
-    std::conditional_t<LN == 4, QuadDpp, OctSwizzle> quad;
+    std::conditional_t<LN == 4, QuadDpp, OctBcast> quad;
 
     // the last step is the filter's own output (xs, ps = Xs.copy(), Ps.copy(); K[T-1] = 0) -- unless this launch continues a
     // chunked call (a.cont): then the window's top step was smoothed by the piece before it and is read back, not rewritten
